@@ -1,0 +1,230 @@
+"""Deterministic synthetic inputs for the hot path.
+
+* `frame_stream`  -- 640x480 8-bit mono stream, seed 0x5EED: a 1280x960 base texture (3 octaves of
+  value noise + 2400 random axis-aligned / rotated rectangles) viewed through a smoothly moving
+  homography (<= 8 px/frame), so consecutive frames are matchable and every pyramid level holds
+  far more than its quota of FAST corners.
+* `ba_problem`    -- bundle-adjustment problem, seed 0xBA5E: cameras on a closed loop looking inward,
+  landmarks in a shell, k observations each, pixel noise + gross outliers, perturbed initial state.
+
+Only numpy; no reference code involved (the reference ships no synthetic generator: its inputs are
+rosbags / Webots, src/webots_sim/worlds/webots.yaml for the 640x480 pinhole intrinsics).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_FRAMES = 0x5EED
+SEED_BA = 0xBA5E
+# src/webots_sim/worlds/webots.yaml:23-34 (pinhole, zero distortion)
+FX = FY = 149.0
+CX, CY = 320.0, 240.0
+WIDTH, HEIGHT = 640, 480
+
+
+def _value_noise(rng: np.random.Generator, h: int, w: int, cell: int) -> np.ndarray:
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rng.random((gh, gw))
+    ys = np.arange(h) / cell
+    xs = np.arange(w) / cell
+    y0 = ys.astype(np.int64)
+    x0 = xs.astype(np.int64)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def base_texture(seed: int = SEED_FRAMES, h: int = 960, w: int = 1280, nrect: int = 2400) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    tex = 0.5 * _value_noise(rng, h, w, 64) + 0.3 * _value_noise(rng, h, w, 16) + 0.2 * _value_noise(rng, h, w, 4)
+    tex = 40.0 + 150.0 * tex
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(nrect):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        hw, hh = rng.uniform(3, 40), rng.uniform(3, 40)
+        ang = rng.uniform(0, np.pi) if rng.random() < 0.5 else 0.0
+        val = rng.uniform(0, 255)
+        r = int(np.ceil(np.hypot(hw, hh))) + 1
+        x0, x1 = max(int(cx) - r, 0), min(int(cx) + r + 1, w)
+        y0, y1 = max(int(cy) - r, 0), min(int(cy) + r + 1, h)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        dx = xx[y0:y1, x0:x1] - cx
+        dy = yy[y0:y1, x0:x1] - cy
+        u = dx * np.cos(ang) + dy * np.sin(ang)
+        v = -dx * np.sin(ang) + dy * np.cos(ang)
+        m = (np.abs(u) <= hw) & (np.abs(v) <= hh)
+        tex[y0:y1, x0:x1][m] = val
+    return np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+
+
+def _warp(tex: np.ndarray, H: np.ndarray, h: int, w: int) -> np.ndarray:
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = H[2, 0] * xs + H[2, 1] * ys + H[2, 2]
+    sx = (H[0, 0] * xs + H[0, 1] * ys + H[0, 2]) / d
+    sy = (H[1, 0] * xs + H[1, 1] * ys + H[1, 2]) / d
+    sx = np.clip(sx, 0, tex.shape[1] - 1.001)
+    sy = np.clip(sy, 0, tex.shape[0] - 1.001)
+    x0 = sx.astype(np.int64)
+    y0 = sy.astype(np.int64)
+    fx = sx - x0
+    fy = sy - y0
+    t = tex.astype(np.float64)
+    v = (t[y0, x0] * (1 - fx) + t[y0, x0 + 1] * fx) * (1 - fy) + (t[y0 + 1, x0] * (1 - fx) + t[y0 + 1, x0 + 1] * fx) * fy
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def frame_homography(t: int) -> np.ndarray:
+    """Camera path over the base texture: slow pan + roll + zoom + slight perspective, <= 8 px/frame."""
+    a = 0.004 * t
+    s = 1.0 + 0.15 * np.sin(0.011 * t)
+    c, si = np.cos(a) * s, np.sin(a) * s
+    tx = 320.0 + 250.0 * np.sin(0.013 * t) + 1.5 * t * 0.3
+    ty = 240.0 + 180.0 * np.sin(0.009 * t + 1.0)
+    # rotate/scale about the frame centre, then translate into the texture
+    T0 = np.array([[1, 0, -WIDTH / 2], [0, 1, -HEIGHT / 2], [0, 0, 1.0]])
+    R = np.array([[c, -si, 0], [si, c, 0], [0, 0, 1.0]])
+    T1 = np.array([[1, 0, tx + WIDTH / 2], [0, 1, ty + HEIGHT / 2], [0, 0, 1.0]])
+    P = np.array([[1, 0, 0], [0, 1, 0], [2e-5 * np.sin(0.02 * t), 1e-5 * np.cos(0.017 * t), 1.0]])
+    return T1 @ R @ P @ T0
+
+
+def frame_stream(n: int = 256, seed: int = SEED_FRAMES, h: int = HEIGHT, w: int = WIDTH, start: int = 0) -> np.ndarray:
+    """Returns uint8 [n, h, w]."""
+    tex = base_texture(seed)
+    return np.stack([_warp(tex, frame_homography(start + t), h, w) for t in range(n)])
+
+
+def small_image(seed: int, h: int, w: int) -> np.ndarray:
+    """Small textured test image (value noise + rectangles), any size >= 40x40."""
+    rng = np.random.default_rng(seed)
+    tex = base_texture(seed, h=max(h, 64), w=max(w, 64), nrect=max(8, (h * w) // 3000))
+    img = tex[:h, :w].copy()
+    # sprinkle salt so FAST has work on tiny images too
+    m = rng.random((h, w)) < 0.01
+    img[m] = rng.integers(0, 256, size=int(m.sum()), dtype=np.uint8)
+    return img
+
+
+# ------------------------------------------------------------------------------------------- BA
+def _rot_from_axis_angle(w: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def _quat_from_rot(R: np.ndarray) -> np.ndarray:
+    """(x, y, z, w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = SEED_BA, noise_px: float = 1.0,
+               outlier_frac: float = 0.05, radius: float = 50.0):
+    """Synthetic global-BA problem.  Returns a dict of numpy arrays:
+
+    poses  [P,7] f64  (tx,ty,tz, qx,qy,qz,qw) world->camera (Tcw), perturbed initial estimate
+    poses_gt [P,7], fixed [P] u8 (KF 0 fixed), points [L,3] f64 perturbed, points_gt [L,3],
+    edge_pose [E] i32, edge_point [E] i32, obs [E,2] f64, inv_sigma2 [E] f64, intrinsics (fx,fy,cx,cy).
+    Every landmark is observed by k_obs consecutive keyframes that see it in-frame.
+    """
+    rng = np.random.default_rng(seed)
+    ang = 2 * np.pi * np.arange(n_kf) / n_kf
+    centres = np.stack([radius * np.cos(ang), radius * np.sin(ang), np.zeros(n_kf)], axis=1)
+    Rcw = np.zeros((n_kf, 3, 3))
+    tcw = np.zeros((n_kf, 3))
+    for i in range(n_kf):
+        # camera z axis points to the loop centre (inward), y axis = world -z (down), x = y cross z
+        z = -centres[i] / np.linalg.norm(centres[i])
+        y = np.array([0.0, 0.0, -1.0])
+        x = np.cross(y, z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        Rwc = np.stack([x, y, z], axis=1)
+        Rcw[i] = Rwc.T
+        tcw[i] = -Rwc.T @ centres[i]
+    pts = np.zeros((n_pts, 3))
+    edge_pose, edge_point, obs = [], [], []
+    l = 0
+    tries = 0
+    while l < n_pts:
+        tries += 1
+        if tries > 200 * n_pts:
+            raise RuntimeError("could not place landmarks")
+        # shell of points 8..18 m in front of a random anchor keyframe
+        a = int(rng.integers(0, n_kf))
+        depth = rng.uniform(8.0, 18.0)
+        u = rng.uniform(60, WIDTH - 60)
+        v = rng.uniform(60, HEIGHT - 60)
+        pc = np.array([(u - CX) / FX * depth, (v - CY) / FY * depth, depth])
+        pw = Rcw[a].T @ (pc - tcw[a])
+        first = a - k_obs // 2
+        kfs = [(first + j) % n_kf for j in range(k_obs)]
+        uv = []
+        ok = True
+        for kf in kfs:
+            q = Rcw[kf] @ pw + tcw[kf]
+            if q[2] <= 0.5:
+                ok = False
+                break
+            uu, vv = FX * q[0] / q[2] + CX, FY * q[1] / q[2] + CY
+            if not (0 <= uu < WIDTH and 0 <= vv < HEIGHT):
+                ok = False
+                break
+            uv.append((uu, vv))
+        if not ok or len(set(kfs)) != k_obs:
+            continue
+        pts[l] = pw
+        for kf, o in zip(kfs, uv):
+            edge_pose.append(kf)
+            edge_point.append(l)
+            obs.append(o)
+        l += 1
+    edge_pose = np.asarray(edge_pose, np.int32)
+    edge_point = np.asarray(edge_point, np.int32)
+    obs = np.asarray(obs, np.float64)
+    E = len(edge_pose)
+    obs += rng.normal(0, noise_px, size=obs.shape)
+    out = rng.random(E) < outlier_frac
+    obs[out] += rng.choice([-1.0, 1.0], size=(int(out.sum()), 2)) * 50.0
+    octave = rng.integers(0, 8, size=E)
+    inv_sigma2 = (1.2 ** (-2.0 * octave)).astype(np.float64)
+    poses_gt = np.zeros((n_kf, 7))
+    poses = np.zeros((n_kf, 7))
+    for i in range(n_kf):
+        poses_gt[i, :3] = tcw[i]
+        poses_gt[i, 3:] = _quat_from_rot(Rcw[i])
+        if i == 0:
+            poses[i] = poses_gt[i]
+            continue
+        dR = _rot_from_axis_angle(rng.normal(0, np.deg2rad(0.5) / np.sqrt(3), 3))
+        Rn = dR @ Rcw[i]
+        tn = dR @ tcw[i] + rng.normal(0, 0.02 / np.sqrt(3), 3)
+        poses[i, :3] = tn
+        poses[i, 3:] = _quat_from_rot(Rn)
+    points = pts + rng.normal(0, 0.05 / np.sqrt(3), pts.shape)
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[0] = 1
+    return dict(poses=poses, poses_gt=poses_gt, fixed=fixed, points=points, points_gt=pts, edge_pose=edge_pose,
+                edge_point=edge_point, obs=obs, inv_sigma2=inv_sigma2, intrinsics=np.array([FX, FY, CX, CY]))

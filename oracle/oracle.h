@@ -1,0 +1,102 @@
+/*
+ * oracle/oracle.h -- C interface of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so.  The product
+ * (dvm_slam_amd/csrc -> libdvmslam_hip.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference (proroklab/DVM-SLAM, ORB-SLAM3 fork) cannot be built in this
+ * image (needs OpenCV>=4.2, Eigen3, Boost, ROS 2, Pangolin -- none present, no network) and holds
+ * no test / golden vector for this path.  The pixel arithmetic lives in
+ * un-vendored OpenCV (cv::resize, cv::GaussianBlur, cv::FAST, cv::fastAtan2, cvRound), restated
+ * here from the published OpenCV 4.x algorithms; everything else follows
+ * the reference file:line cited at each function.  The oracle is pinned only against independent
+ * brute-force numpy restatements (tests/test_oracle_*.py) and the committed tests/golden vectors.
+ */
+#ifndef DVM_ORACLE_H
+#define DVM_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout-identical to cv::KeyPoint (7 x 4 B) */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct {
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels, ini_th_fast, min_th_fast;
+} orc_orb_params;
+
+typedef struct orc_orb orc_orb; /* opaque */
+
+/* ---- ORB extractor (reference ORBextractor.cc) ---- */
+orc_orb* orc_orb_create(const orc_orb_params* p);
+void orc_orb_destroy(orc_orb* h);
+/* constructor tables, ORBextractor.cc:282-339.  Arrays sized nlevels (umax: 16). */
+void orc_orb_tables(const orc_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* nfeat_per_level, int32_t* umax16);
+/* operator(), ORBextractor.cc:876-955.  Returns number of keypoints written (<= cap), or -1 for an
+ * empty image; *mono_index receives the reference's return value. */
+int orc_orb_extract(orc_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
+                    orc_keypoint* kps, uint8_t* desc, int cap, int* mono_index);
+/* intermediates of the last extract (for stage-wise parity tests) */
+int orc_orb_level_dims(const orc_orb* h, int level, int* rows, int* cols);
+/* copies the level image WITHOUT border, tightly packed cols bytes per row */
+int orc_orb_get_level(const orc_orb* h, int level, uint8_t* out);
+/* copies the level image WITH its 19-px REFLECT_101 border, (cols+38) bytes per row */
+int orc_orb_get_level_bordered(const orc_orb* h, int level, uint8_t* out);
+int orc_orb_get_blurred(const orc_orb* h, int level, uint8_t* out);
+/* per-level FAST candidates (vToDistributeKeys, border-relative coords) in reference order */
+int orc_orb_get_candidates(const orc_orb* h, int level, int32_t* xs, int32_t* ys, int32_t* scores, int cap);
+/* per-level keypoints after octree + orientation, level coordinates (before scaling) */
+int orc_orb_get_level_keypoints(const orc_orb* h, int level, orc_keypoint* kps, int cap);
+
+/* ---- stand-alone primitives (OpenCV restatements) ---- */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
+                          int dstride);
+void orc_gaussian_blur7_s2_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+void orc_gaussian_kernel7_s2_q8(int32_t k[7]);
+/* cv::FAST(roi, kps, threshold, nonmaxSuppression=true), TYPE_9_16.  Returns count. */
+int orc_fast9_16(const uint8_t* roi, int w, int h, int stride, int threshold, int32_t* xs, int32_t* ys,
+                 int32_t* scores, int cap);
+float orc_fast_atan2(float y, float x);
+int orc_cv_round(float v);
+/* (float)cos / (float)sin of (angle_deg * (float)(pi/180)) -- shared-spec implementation, DESIGN.md */
+void orc_sincos_deg(float angle_deg, float* c, float* s);
+float orc_ic_angle(const uint8_t* img, int stride, int cx, int cy);
+void orc_brief_descriptor(const uint8_t* blurred, int stride, int cx, int cy, float angle_deg, uint8_t out[32]);
+/* DistributeOctTree, ORBextractor.cc:419-610.  Returns number of selected keypoints. */
+int orc_distribute_octree(const int32_t* xs, const int32_t* ys, const int32_t* scores, int n, int minX, int maxX,
+                          int minY, int maxY, int N, int32_t* out_idx, int cap);
+
+/* ---- matching (reference ORBmatcher.cc / Frame.cc) ---- */
+/* ORBmatcher::DescriptorDistance, ORBmatcher.cc:1900-1914 */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void orc_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
+
+/* Frame grid: Frame.cc:443-444,481-506,773-782 (PosInGrid) and :712-770 (GetFeaturesInArea) */
+typedef struct orc_grid orc_grid;
+orc_grid* orc_grid_create(const orc_keypoint* kps, int n, float minX, float maxX, float minY, float maxY);
+void orc_grid_destroy(orc_grid* g);
+int orc_grid_features_in_area(const orc_grid* g, float x, float y, float r, int minLevel, int maxLevel,
+                              int32_t* out, int cap);
+
+/* Windowed best / second-best search: the inner loop shared by ORBmatcher::SearchByProjection
+ * (ORBmatcher.cc:70-115 and :1604-1639).  For query q (descriptor qdesc[q], predicted position
+ * (qx,qy), radius qr, octave window [qmin,qmax]) scan GetFeaturesInArea candidates in reference
+ * order, skipping train indices with skip[idx]!=0, strict '<' updates.  Outputs best idx (-1 if
+ * none), best dist (256), second-best dist (256), levels of both (-1). */
+void orc_match_window(const orc_grid* g, const uint8_t* tdesc, const uint8_t* skip, const uint8_t* qdesc,
+                      const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                      const int32_t* qmax, int nq, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                      int32_t* best_level, int32_t* second_level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,240 @@
+"""ctypes binding of oracle/liboracle.so.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by the product package (dvm_slam_amd).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib(path: str | None = None):
+    global _LIB
+    if _LIB is None or path is not None:
+        L = C.CDLL(path or build())
+        vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+        L.orc_orb_create.restype = vp
+        L.orc_orb_create.argtypes = [C.POINTER(OrbParams)]
+        L.orc_orb_destroy.argtypes = [vp]
+        L.orc_orb_tables.argtypes = [vp] * 7
+        L.orc_orb_extract.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+        L.orc_orb_level_dims.argtypes = [vp, i32, vp, vp]
+        for n in ("orc_orb_get_level", "orc_orb_get_level_bordered", "orc_orb_get_blurred"):
+            getattr(L, n).argtypes = [vp, i32, vp]
+        L.orc_orb_get_candidates.argtypes = [vp, i32, vp, vp, vp, i32]
+        L.orc_orb_get_level_keypoints.argtypes = [vp, i32, vp, i32]
+        L.orc_resize_linear_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32]
+        L.orc_gaussian_blur7_s2_u8.argtypes = [vp, i32, i32, i32, vp, i32]
+        L.orc_gaussian_kernel7_s2_q8.argtypes = [vp]
+        L.orc_fast9_16.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32]
+        L.orc_fast_atan2.restype = f32
+        L.orc_fast_atan2.argtypes = [f32, f32]
+        L.orc_cv_round.argtypes = [f32]
+        L.orc_sincos_deg.argtypes = [f32, vp, vp]
+        L.orc_ic_angle.restype = f32
+        L.orc_ic_angle.argtypes = [vp, i32, i32, i32]
+        L.orc_brief_descriptor.argtypes = [vp, i32, i32, i32, f32, vp]
+        L.orc_distribute_octree.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32]
+        L.orc_descriptor_distance.argtypes = [vp, vp]
+        L.orc_hamming_matrix.argtypes = [vp, i32, vp, i32, vp]
+        L.orc_grid_create.restype = vp
+        L.orc_grid_create.argtypes = [vp, i32, f32, f32, f32, f32]
+        L.orc_grid_destroy.argtypes = [vp]
+        L.orc_grid_features_in_area.argtypes = [vp, f32, f32, f32, i32, i32, vp, i32]
+        L.orc_match_window.argtypes = [vp] * 9 + [i32] + [vp] * 5
+        if path is not None:
+            return L
+        _LIB = L
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbOracle:
+    """CPU oracle of ORB_SLAM3::ORBextractor (reference ORBextractor.cc)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, libpath=None):
+        self.L = lib(libpath) if libpath else lib()
+        self.params = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.h = self.L.orc_orb_create(C.byref(self.params))
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_orb_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.orc_orb_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, nfeat=nf, umax=um)
+
+    def extract(self, img: np.ndarray, lap=(0, 1000), cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = cap or (self.nfeatures * 2 + 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        mono = C.c_int(0)
+        n = self.L.orc_orb_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1],
+                                   _p(kps), _p(desc), cap, C.byref(mono))
+        if n < 0:
+            return n, None, None, mono.value
+        return n, kps[:n].copy(), desc[:n].copy(), mono.value
+
+    def level_dims(self, level):
+        r, c = C.c_int(0), C.c_int(0)
+        self.L.orc_orb_level_dims(self.h, level, C.byref(r), C.byref(c))
+        return r.value, c.value
+
+    def level(self, level, bordered=False):
+        r, c = self.level_dims(level)
+        if bordered:
+            out = np.zeros((r + 38, c + 38), np.uint8)
+            self.L.orc_orb_get_level_bordered(self.h, level, _p(out))
+        else:
+            out = np.zeros((r, c), np.uint8)
+            self.L.orc_orb_get_level(self.h, level, _p(out))
+        return out
+
+    def blurred(self, level):
+        r, c = self.level_dims(level)
+        out = np.zeros((r, c), np.uint8)
+        rc = self.L.orc_orb_get_blurred(self.h, level, _p(out))
+        return out if rc == 0 else None
+
+    def candidates(self, level, cap=200000):
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = self.L.orc_orb_get_candidates(self.h, level, _p(xs), _p(ys), _p(sc), cap)
+        return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+    def level_keypoints(self, level, cap=20000):
+        k = np.zeros(cap, KP_DTYPE)
+        n = self.L.orc_orb_get_level_keypoints(self.h, level, _p(k), cap)
+        return k[:n].copy()
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7_s2_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def gaussian_kernel7():
+    k = np.zeros(7, np.int32)
+    lib().orc_gaussian_kernel7_s2_q8(_p(k))
+    return k
+
+
+def fast9_16(roi: np.ndarray, threshold: int):
+    roi = np.ascontiguousarray(roi, np.uint8)
+    cap = roi.size
+    xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().orc_fast9_16(_p(roi), roi.shape[1], roi.shape[0], roi.strides[0], threshold, _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def sincos_deg(a):
+    c, s = C.c_float(0), C.c_float(0)
+    lib().orc_sincos_deg(float(a), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def ic_angle(img: np.ndarray, cx: int, cy: int) -> float:
+    img = np.ascontiguousarray(img, np.uint8)
+    return float(lib().orc_ic_angle(_p(img), img.strides[0], cx, cy))
+
+
+def brief_descriptor(blurred: np.ndarray, cx: int, cy: int, angle_deg: float) -> np.ndarray:
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().orc_brief_descriptor(_p(blurred), blurred.strides[0], cx, cy, float(angle_deg), _p(out))
+    return out
+
+
+def distribute_octree(xs, ys, scores, minX, maxX, minY, maxY, N):
+    xs, ys, scores = (np.ascontiguousarray(a, np.int32) for a in (xs, ys, scores))
+    cap = len(xs) + 8
+    out = np.zeros(cap, np.int32)
+    n = lib().orc_distribute_octree(_p(xs), _p(ys), _p(scores), len(xs), minX, maxX, minY, maxY, N, _p(out), cap)
+    return out[:n].copy()
+
+
+def hamming_matrix(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    A = np.ascontiguousarray(A, np.uint8)
+    B = np.ascontiguousarray(B, np.uint8)
+    D = np.zeros((len(A), len(B)), np.uint16)
+    lib().orc_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(D))
+    return D
+
+
+class Grid:
+    """Frame's 64x48 feature grid (reference Frame.cc:443-506, 712-782)."""
+
+    def __init__(self, kps: np.ndarray, minX=0.0, maxX=640.0, minY=0.0, maxY=480.0):
+        self.L = lib()
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.g = self.L.orc_grid_create(_p(self.kps), len(self.kps), minX, maxX, minY, maxY)
+
+    def __del__(self):
+        if getattr(self, "g", None):
+            self.L.orc_grid_destroy(self.g)
+            self.g = None
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(len(self.kps) + 1, np.int32)
+        n = self.L.orc_grid_features_in_area(self.g, x, y, r, min_level, max_level, _p(out), len(out))
+        return out[:n].copy()
+
+    def match_window(self, tdesc, qdesc, qx, qy, qr, qmin, qmax, skip=None):
+        nq = len(qdesc)
+        tdesc = np.ascontiguousarray(tdesc, np.uint8)
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        outs = [np.zeros(nq, np.int32) for _ in range(5)]
+        sk = _p(np.ascontiguousarray(skip, np.uint8)) if skip is not None else None
+        self.L.orc_match_window(self.g, _p(tdesc), sk, _p(qdesc), _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), nq,
+                                *[_p(o) for o in outs])
+        return dict(best_idx=outs[0], best_dist=outs[1], second_dist=outs[2], best_level=outs[3],
+                    second_level=outs[4])
