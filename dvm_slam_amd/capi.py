@@ -1,0 +1,279 @@
+"""ctypes binding of libdvmslam_hip.so (include/dvmslam_hip.h).
+
+This is the only way Python (tests, bench.py, smoke) reaches the product: through the C ABI a
+reference maintainer would bind.  There is NO CPU fallback: if the shared library is missing the
+import raises, and on a box without a gfx950 device every compute entry point returns
+DVM_ERR_NO_DEVICE (raised here as DvmError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdvmslam_hip.so")
+
+DVM_OK = 0
+ERRORS = {-1: "DVM_ERR_INVALID", -2: "DVM_ERR_EMPTY", -3: "DVM_ERR_CAPACITY", -4: "DVM_ERR_HIP",
+          -5: "DVM_ERR_NO_DEVICE", -6: "DVM_ERR_STATE"}
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+MATCH_DTYPE = np.dtype([("best_idx", "<i4"), ("best_dist", "<i4"), ("second_dist", "<i4"),
+                        ("best_level", "<i2"), ("second_level", "<i2")])
+
+
+class DvmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+_LIB = None
+
+
+def lib():
+    """Loads the HIP library; raises if it has not been built (no silent fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); dvm_slam_amd has no CPU implementation")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.dvm_last_error.restype = C.c_char_p
+    L.dvm_version.restype = C.c_char_p
+    L.dvm_device_count.restype = i32
+    L.dvm_orb_create.argtypes = [C.POINTER(OrbParams), i32, i32, C.POINTER(vp)]
+    L.dvm_orb_destroy.argtypes = [vp]
+    L.dvm_orb_destroy.restype = None
+    L.dvm_orb_tables.argtypes = [vp] * 6
+    L.dvm_orb_extract.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    L.dvm_orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32]
+    L.dvm_orb_extract_batch_host.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32]
+    L.dvm_orb_sync.argtypes = [vp]
+    L.dvm_orb_result_device.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.dvm_orb_scale_factors_device.argtypes = [vp]
+    L.dvm_orb_scale_factors_device.restype = vp
+    L.dvm_orb_download.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+    L.dvm_orb_pyramid.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    L.dvm_orb_debug_level.argtypes = [vp, i32, i32, i32, vp]
+    L.dvm_orb_debug_blurred.argtypes = [vp, i32, i32, vp]
+    L.dvm_orb_debug_candidates.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
+    L.dvm_orb_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.dvm_orb_profiling.argtypes = [vp, i32]
+    L.dvm_orb_profile_get.argtypes = [vp, C.c_char_p, vp, vp]
+    L.dvm_orb_profile_reset.argtypes = [vp]
+    L.dvm_orb_stream.argtypes = [vp]
+    L.dvm_orb_stream.restype = vp
+    L.dvm_hamming_matrix.argtypes = [vp, i32, vp, i32, vp, i32, vp]
+    L.dvm_frame_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.dvm_frame_destroy.argtypes = [vp]
+    L.dvm_frame_destroy.restype = None
+    L.dvm_frame_build.argtypes = [vp, i32, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp]
+    L.dvm_frame_build_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, f32, f32, f32, f32, vp]
+    L.dvm_match_window.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
+    L.dvm_match_frames_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, f32, vp, i32, vp, i64,
+                                         vp, vp]
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != DVM_OK:
+        raise DvmError(rc, lib().dvm_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(lib().dvm_device_count())
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+class OrbExtractor:
+    """Mirror of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:47-91) over the C ABI."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, device=0, max_batch=1):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.params = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.nlevels, self.nfeatures, self.max_batch = nlevels, nfeatures, max_batch
+        check(self.L.dvm_orb_create(C.byref(self.params), device, max_batch, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.dvm_orb_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        check(self.L.dvm_orb_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(nf)))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, nfeat=nf)
+
+    @property
+    def cap(self):
+        return self.nfeatures + 5 * self.nlevels + 8
+
+    def extract(self, img: np.ndarray, lap=(0, 1000)):
+        """operator(): returns (n, keypoints, descriptors, monoIndex); n == -1 for an empty image."""
+        if img is None or img.size == 0:
+            rc = self.L.dvm_orb_extract(self.h, None, 0, 0, 0, lap[0], lap[1], None, None, 0, None, None)
+            assert rc == -2, rc
+            return -1, None, None, -1
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            img = np.ascontiguousarray(img, np.uint8)  # row-strided views (stride > cols) pass through as they are
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        check(self.L.dvm_orb_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1],
+                                     _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono)))
+        return n.value, kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def extract_batch_host(self, imgs: np.ndarray, lap=(0, 1000)):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        b, r, c = imgs.shape
+        check(self.L.dvm_orb_extract_batch_host(self.h, _p(imgs), b, r, c, imgs.strides[1], imgs.strides[0], lap[0], lap[1]))
+
+    def extract_batch_device(self, d_ptr: int, batch, rows, cols, stride=None, frame_stride=None, lap=(0, 1000)):
+        stride = stride or cols
+        frame_stride = frame_stride or rows * stride
+        check(self.L.dvm_orb_extract_batch_device(self.h, C.c_void_p(d_ptr), batch, rows, cols, stride, frame_stride,
+                                                  lap[0], lap[1]))
+
+    def sync(self):
+        check(self.L.dvm_orb_sync(self.h))
+
+    def download(self, frame=0):
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n, mono = C.c_int(0), C.c_int(0)
+        check(self.L.dvm_orb_download(self.h, frame, _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono)))
+        return n.value, kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def result_device(self, frame=0):
+        k, d, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap = C.c_int(0)
+        check(self.L.dvm_orb_result_device(self.h, frame, C.byref(k), C.byref(d), C.byref(n), C.byref(cap)))
+        return k.value, d.value, n.value, cap.value
+
+    def scale_factors_device(self):
+        return self.L.dvm_orb_scale_factors_device(self.h)
+
+    def pyramid(self, frame, level):
+        ptr = C.c_void_p()
+        r, c, s = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self.L.dvm_orb_pyramid(self.h, frame, level, C.byref(ptr), C.byref(r), C.byref(c), C.byref(s)))
+        return ptr.value, r.value, c.value, s.value
+
+    def debug_level(self, frame, level, bordered=False):
+        _, r, c, _ = self.pyramid(frame, level)
+        out = np.zeros((r + 38, c + 38) if bordered else (r, c), np.uint8)
+        check(self.L.dvm_orb_debug_level(self.h, frame, level, int(bordered), _p(out)))
+        return out
+
+    def debug_blurred(self, frame, level):
+        _, r, c, _ = self.pyramid(frame, level)
+        out = np.zeros((r, c), np.uint8)
+        check(self.L.dvm_orb_debug_blurred(self.h, frame, level, _p(out)))
+        return out
+
+    def debug_candidates(self, frame, level, cap=300000):
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int(0)
+        check(self.L.dvm_orb_debug_candidates(self.h, frame, level, _p(xs), _p(ys), _p(sc), cap, C.byref(n)))
+        return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
+
+    def debug_level_keypoints(self, frame, level, cap=20000):
+        k = np.zeros(cap, KP_DTYPE)
+        n = C.c_int(0)
+        check(self.L.dvm_orb_debug_level_keypoints(self.h, frame, level, _p(k), cap, C.byref(n)))
+        return k[:n.value].copy()
+
+    def profiling(self, on=True):
+        check(self.L.dvm_orb_profiling(self.h, int(on)))
+
+    def profile_reset(self):
+        check(self.L.dvm_orb_profile_reset(self.h))
+
+    def profile_get(self, name):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        rc = self.L.dvm_orb_profile_get(self.h, name.encode(), C.byref(ms), C.byref(cnt))
+        return (ms.value, cnt.value) if rc == 0 else (0.0, 0)
+
+    def stream(self):
+        return self.L.dvm_orb_stream(self.h)
+
+
+def hamming_matrix(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """All-pairs ORBmatcher::DescriptorDistance (host arrays in, host matrix out)."""
+    A = np.ascontiguousarray(A, np.uint8).reshape(-1, 32)
+    B = np.ascontiguousarray(B, np.uint8).reshape(-1, 32)
+    D = np.zeros((len(A), len(B)), np.uint16)
+    check(lib().dvm_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(D), 0, None))
+    return D
+
+
+class FrameGrid:
+    """Frame's feature grid + windowed search (reference Frame.cc:443-506,712-782; ORBmatcher.cc:70-115)."""
+
+    def __init__(self, capacity=2048, slots=1, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.capacity, self.slots = capacity, slots
+        check(self.L.dvm_frame_create(device, capacity, slots, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.dvm_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def build(self, kps: np.ndarray, desc: np.ndarray, bounds=(0.0, 640.0, 0.0, 480.0), slot=0):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        check(self.L.dvm_frame_build(self.h, slot, _p(kps), _p(desc), len(kps), None, *bounds, 0, None))
+
+    def build_batch_device(self, first_slot, count, d_kps, kps_stride, d_desc, desc_stride, d_n, bounds, stream=None):
+        check(self.L.dvm_frame_build_batch(self.h, first_slot, count, C.c_void_p(d_kps), kps_stride, C.c_void_p(d_desc),
+                                           desc_stride, C.c_void_p(d_n), *bounds, C.c_void_p(stream or 0)))
+
+    def match_window(self, qdesc, qx, qy, qr, qmin, qmax, skip=None, slot=0):
+        qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        nq = len(qdesc)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        out = np.zeros(nq, MATCH_DTYPE)
+        sk = None
+        if skip is not None:
+            sk = np.zeros(self.capacity, np.uint8)
+            sk[:len(skip)] = skip
+        check(self.L.dvm_match_window(self.h, slot, _p(sk), _p(qdesc), _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), nq,
+                                      None, _p(out), 0, None))
+        return out
+
+    def match_frames_batch(self, first_slot, count, d_kps, kps_stride, d_desc, desc_stride, d_n, carry, cap, th,
+                           d_scale, nlevels, d_out, out_stride, d_nq_out=None, stream=None):
+        ck, cd, cn = carry if carry else (0, 0, 0)
+        check(self.L.dvm_match_frames_batch(self.h, first_slot, count, C.c_void_p(d_kps), kps_stride, C.c_void_p(d_desc),
+                                            desc_stride, C.c_void_p(d_n), C.c_void_p(ck), C.c_void_p(cd), C.c_void_p(cn),
+                                            cap, th, C.c_void_p(d_scale), nlevels, C.c_void_p(d_out), out_stride,
+                                            C.c_void_p(d_nq_out or 0), C.c_void_p(stream or 0)))

@@ -1,0 +1,419 @@
+// dvm_slam_amd/csrc/capi.cpp -- extern "C" boundary of libdvmslam_hip.so (include/dvmslam_hip.h).
+// Thin: argument checks, handle lifetime, host<->device staging.  No compute happens on the host
+// here; if no HIP device is visible every entry point that needs one fails with DVM_ERR_NO_DEVICE.
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dvmslam_hip.h"
+#include "match_kernels.h"
+#include "orb_pipeline.h"
+
+namespace dvm {
+const char* last_error_cstr();
+}
+using namespace dvm;
+
+struct dvm_orb {
+  OrbPipeline* p;
+  float* d_scale = nullptr;
+};
+
+struct dvm_frame {
+  int device, cap, slots;
+  FrameView view{};
+  // scratch for the host-pointer convenience paths
+  void* d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+static int need_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible (libdvmslam_hip has no CPU path)");
+    return DVM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device index out of range");
+    return DVM_ERR_INVALID;
+  }
+  return hip_check(hipSetDevice(device), "hipSetDevice");
+}
+
+extern "C" {
+
+const char* dvm_last_error(void) { return last_error_cstr(); }
+const char* dvm_version(void) { return "dvmslam-hip 0.1 (gfx950)"; }
+int dvm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------ ORB
+int dvm_orb_create(const dvm_orb_params* p, int device, int max_batch, dvm_orb** out) {
+  if (!p || !out || p->nlevels < 1 || p->nlevels > kMaxLevels || p->nfeatures < 0 || !(p->scale_factor > 1.0f)) {
+    set_error("dvm_orb_create: bad parameters");
+    return DVM_ERR_INVALID;
+  }
+  *out = nullptr;
+  OrbPipeline* pipe = new (std::nothrow) OrbPipeline(*p, device, max_batch);
+  if (!pipe) return DVM_ERR_INVALID;
+  int rc = pipe->init();
+  if (rc != DVM_OK) {
+    delete pipe;
+    return rc;
+  }
+  dvm_orb* h = new dvm_orb{pipe};
+  if (hipMalloc(&h->d_scale, sizeof(float) * kMaxLevels) == hipSuccess)
+    hipMemcpy(h->d_scale, pipe->scale.data(), sizeof(float) * p->nlevels, hipMemcpyHostToDevice);
+  *out = h;
+  return DVM_OK;
+}
+void dvm_orb_destroy(dvm_orb* h) {
+  if (!h) return;
+  if (h->d_scale) hipFree(h->d_scale);
+  delete h->p;
+  delete h;
+}
+int dvm_orb_tables(const dvm_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* nfeat) {
+  if (!h) return DVM_ERR_INVALID;
+  const OrbPipeline& P = *h->p;
+  for (int i = 0; i < P.params.nlevels; i++) {
+    if (scale) scale[i] = P.scale[i];
+    if (inv_scale) inv_scale[i] = P.inv_scale[i];
+    if (sigma2) sigma2[i] = P.sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = P.inv_sigma2[i];
+    if (nfeat) nfeat[i] = P.nfeat[i];
+  }
+  return DVM_OK;
+}
+int dvm_orb_extract(dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
+                    dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index) {
+  if (!h) return DVM_ERR_INVALID;
+  if (n) *n = 0;
+  if (mono_index) *mono_index = -1;
+  int rc = h->p->extract_host(img, 1, rows, cols, stride, (int64_t)rows * stride, lap0, lap1);
+  if (rc != DVM_OK) return rc;
+  return h->p->download(0, kps, desc, cap, n, mono_index);
+}
+int dvm_orb_extract_batch_device(dvm_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int stride,
+                                 int64_t frame_stride, int lap0, int lap1) {
+  if (!h) return DVM_ERR_INVALID;
+  return h->p->extract_device(d_imgs, batch, rows, cols, stride, frame_stride, lap0, lap1);
+}
+int dvm_orb_extract_batch_host(dvm_orb* h, const uint8_t* imgs, int batch, int rows, int cols, int stride,
+                               int64_t frame_stride, int lap0, int lap1) {
+  if (!h) return DVM_ERR_INVALID;
+  return h->p->extract_host(imgs, batch, rows, cols, stride, frame_stride, lap0, lap1);
+}
+int dvm_orb_sync(dvm_orb* h) { return h ? h->p->sync() : DVM_ERR_INVALID; }
+int dvm_orb_result_device(dvm_orb* h, int frame, const dvm_keypoint** d_kps, const uint8_t** d_desc,
+                          const int32_t** d_n, int* capacity) {
+  if (!h || !h->p->configured || frame < 0 || frame >= h->p->max_batch) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  if (d_kps) *d_kps = reinterpret_cast<const dvm_keypoint*>(P.d_kps + (size_t)frame * P.PD.kp_cap);
+  if (d_desc) *d_desc = P.d_desc + (size_t)frame * P.PD.kp_cap * 32;
+  if (d_n) *d_n = P.d_n + frame;
+  if (capacity) *capacity = P.PD.kp_cap;
+  return DVM_OK;
+}
+const float* dvm_orb_scale_factors_device(dvm_orb* h) { return h ? h->d_scale : nullptr; }
+int dvm_orb_download(dvm_orb* h, int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index) {
+  if (!h) return DVM_ERR_INVALID;
+  return h->p->download(frame, kps, desc, cap, n, mono_index);
+}
+int dvm_orb_pyramid(dvm_orb* h, int frame, int level, const uint8_t** d_ptr, int* rows, int* cols, int* stride) {
+  if (!h || !h->p->configured) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  if (level < 0 || level >= P.PD.nlevels || frame < 0 || frame >= P.max_batch) return DVM_ERR_INVALID;
+  const LevelDesc& L = P.PD.lv[level];
+  if (d_ptr) *d_ptr = P.d_pyr + (size_t)frame * P.PD.pyr_frame_bytes + L.pyr_off + (size_t)kEdge * L.stride + kEdge;
+  if (rows) *rows = L.h;
+  if (cols) *cols = L.w;
+  if (stride) *stride = L.stride;
+  return DVM_OK;
+}
+
+int dvm_orb_debug_level(dvm_orb* h, int frame, int level, int bordered, uint8_t* out) {
+  if (!h || !h->p->configured || !out) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  if (level < 0 || level >= P.PD.nlevels || frame < 0 || frame >= P.last_batch) return DVM_ERR_INVALID;
+  int rc = P.sync();
+  if (rc != DVM_OK) return rc;
+  const LevelDesc& L = P.PD.lv[level];
+  const uint8_t* base = P.d_pyr + (size_t)frame * P.PD.pyr_frame_bytes + L.pyr_off;
+  if (bordered)
+    return hip_check(hipMemcpy2D(out, L.w + 2 * kEdge, base, L.stride, L.w + 2 * kEdge, L.h + 2 * kEdge, hipMemcpyDeviceToHost), "memcpy2d");
+  return hip_check(hipMemcpy2D(out, L.w, base + (size_t)kEdge * L.stride + kEdge, L.stride, L.w, L.h, hipMemcpyDeviceToHost), "memcpy2d");
+}
+int dvm_orb_debug_blurred(dvm_orb* h, int frame, int level, uint8_t* out) {
+  if (!h || !h->p->configured || !out) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  if (level < 0 || level >= P.PD.nlevels || frame < 0 || frame >= P.last_batch) return DVM_ERR_INVALID;
+  int rc = P.sync();
+  if (rc != DVM_OK) return rc;
+  const LevelDesc& L = P.PD.lv[level];
+  return hip_check(hipMemcpy2D(out, L.w, P.d_blur + (size_t)frame * P.PD.blur_frame_bytes + L.blur_off, L.blur_stride, L.w, L.h,
+                               hipMemcpyDeviceToHost), "memcpy2d");
+}
+int dvm_orb_debug_candidates(dvm_orb* h, int frame, int level, int32_t* xs, int32_t* ys, int32_t* scores, int cap, int* n) {
+  if (!h || !h->p->configured) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  if (level < 0 || level >= P.PD.nlevels || frame < 0 || frame >= P.last_batch) return DVM_ERR_INVALID;
+  int rc = P.sync();
+  if (rc != DVM_OK) return rc;
+  int32_t ls[kMaxLevels + 1];
+  rc = hip_check(hipMemcpy(ls, P.d_lvl_start + (size_t)frame * (kMaxLevels + 1), sizeof(ls), hipMemcpyDeviceToHost), "memcpy");
+  if (rc != DVM_OK) return rc;
+  const int cnt = ls[level + 1] - ls[level];
+  if (n) *n = cnt;
+  if (cnt > cap) return DVM_ERR_CAPACITY;
+  std::vector<uint32_t> tmp(cnt > 0 ? cnt : 1);
+  if (cnt > 0) {
+    rc = hip_check(hipMemcpy(tmp.data(), P.d_dense + (size_t)frame * P.PD.cand_frame_slots + ls[level], (size_t)cnt * 4, hipMemcpyDeviceToHost), "memcpy");
+    if (rc != DVM_OK) return rc;
+  }
+  for (int i = 0; i < cnt; i++) {
+    int x, y, s;
+    unpack_cand(tmp[i], x, y, s);
+    xs[i] = x; ys[i] = y; scores[i] = s;
+  }
+  return DVM_OK;
+}
+int dvm_orb_debug_level_keypoints(dvm_orb* h, int frame, int level, dvm_keypoint* kps, int cap, int* n) {
+  if (!h || !h->p->configured) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  if (level < 0 || level >= P.PD.nlevels || frame < 0 || frame >= P.last_batch) return DVM_ERR_INVALID;
+  int rc = P.sync();
+  if (rc != DVM_OK) return rc;
+  const int L = P.PD.nlevels;
+  std::vector<int32_t> nsel(L), nk(1);
+  rc = hip_check(hipMemcpy(nsel.data(), P.d_nsel + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost), "memcpy");
+  if (rc != DVM_OK) return rc;
+  int start = 0;
+  for (int l = 0; l < level; l++) start += nsel[l];
+  const int cnt = nsel[level];
+  if (n) *n = cnt;
+  if (cnt > cap) return DVM_ERR_CAPACITY;
+  if (cnt == 0) return DVM_OK;
+  // keypoints g = start..start+cnt-1 in (level, octree) order live at aux[g].out_pos; undo the scaling
+  std::vector<KpAux> aux(cnt);
+  rc = hip_check(hipMemcpy(aux.data(), P.d_aux + (size_t)frame * P.PD.kp_cap + start, (size_t)cnt * sizeof(KpAux), hipMemcpyDeviceToHost), "memcpy");
+  if (rc != DVM_OK) return rc;
+  std::vector<dvm_keypoint> all(P.PD.kp_cap);
+  rc = hip_check(hipMemcpy(all.data(), P.d_kps + (size_t)frame * P.PD.kp_cap, (size_t)P.PD.kp_cap * sizeof(dvm_keypoint), hipMemcpyDeviceToHost), "memcpy");
+  if (rc != DVM_OK) return rc;
+  for (int i = 0; i < cnt; i++) {
+    dvm_keypoint k = all[aux[i].out_pos];
+    k.x = (float)aux[i].cx;
+    k.y = (float)aux[i].cy;
+    kps[i] = k;
+  }
+  return DVM_OK;
+}
+
+int dvm_orb_profiling(dvm_orb* h, int enable) {
+  if (!h) return DVM_ERR_INVALID;
+  h->p->prof.enabled = enable != 0;
+  return DVM_OK;
+}
+int dvm_orb_profile_get(dvm_orb* h, const char* name, double* total_ms, int64_t* launches) {
+  if (!h || !name) return DVM_ERR_INVALID;
+  if (total_ms) *total_ms = 0;
+  if (launches) *launches = 0;
+  return h->p->prof.get(name, total_ms, launches) ? DVM_OK : DVM_ERR_STATE;
+}
+int dvm_orb_profile_reset(dvm_orb* h) {
+  if (!h) return DVM_ERR_INVALID;
+  h->p->prof.reset();
+  return DVM_OK;
+}
+void* dvm_orb_stream(dvm_orb* h) { return h ? (void*)h->p->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------- matching
+int dvm_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D, int on_device, void* stream) {
+  if (nA < 0 || nB < 0 || (nA && !A) || (nB && !B)) return DVM_ERR_INVALID;
+  if (nA == 0 || nB == 0) return DVM_OK;
+  if (!D) return DVM_ERR_INVALID;
+  int rc = need_device(0);
+  if (on_device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DVM_ERR_NO_DEVICE;
+    launch_hamming_matrix((hipStream_t)stream, A, nA, B, nB, D);
+    return hip_check(hipGetLastError(), "hamming launch");
+  }
+  if (rc != DVM_OK) return rc;
+  uint8_t *dA = nullptr, *dB = nullptr;
+  uint16_t* dD = nullptr;
+  rc = hip_check(hipMalloc(&dA, (size_t)nA * 32), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&dB, (size_t)nB * 32), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&dD, (size_t)nA * nB * 2), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(dA, A, (size_t)nA * 32, hipMemcpyHostToDevice), "memcpy");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(dB, B, (size_t)nB * 32, hipMemcpyHostToDevice), "memcpy");
+  if (rc == DVM_OK) {
+    launch_hamming_matrix(nullptr, dA, nA, dB, nB, dD);
+    rc = hip_check(hipGetLastError(), "hamming launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(D, dD, (size_t)nA * nB * 2, hipMemcpyDeviceToHost), "memcpy");
+  if (dA) hipFree(dA);
+  if (dB) hipFree(dB);
+  if (dD) hipFree(dD);
+  return rc;
+}
+
+int dvm_frame_create(int device, int capacity, int slots, dvm_frame** out) {
+  if (!out || capacity < 1 || capacity > kFrameCap || slots < 1) {
+    set_error("dvm_frame_create: capacity must be 1..8192, slots >= 1");
+    return DVM_ERR_INVALID;
+  }
+  *out = nullptr;
+  int rc = need_device(device);
+  if (rc != DVM_OK) return rc;
+  dvm_frame* f = new dvm_frame{};
+  f->device = device; f->cap = capacity; f->slots = slots;
+  FrameView& V = f->view;
+  V.cap = capacity;
+  const size_t S = (size_t)slots;
+  rc = hip_check(hipMalloc(&V.skp, S * capacity * sizeof(float4)), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.sidx, S * capacity * 4), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.sdesc, S * capacity * 32), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.cellx_start, S * 80 * 4), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.n_sorted, S * 4), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.n_total, S * 4), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(V.cellx_start, 0, S * 80 * 4), "memset");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(V.n_sorted, 0, S * 4), "memset");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(V.n_total, 0, S * 4), "memset");
+  if (rc != DVM_OK) {
+    dvm_frame_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return DVM_OK;
+}
+void dvm_frame_destroy(dvm_frame* f) {
+  if (!f) return;
+  FrameView& V = f->view;
+  if (V.skp) hipFree(V.skp);
+  if (V.sidx) hipFree(V.sidx);
+  if (V.sdesc) hipFree(V.sdesc);
+  if (V.cellx_start) hipFree(V.cellx_start);
+  if (V.n_sorted) hipFree(V.n_sorted);
+  if (V.n_total) hipFree(V.n_total);
+  if (f->d_scratch) hipFree(f->d_scratch);
+  delete f;
+}
+static int frame_bounds(dvm_frame* f, float minX, float maxX, float minY, float maxY) {
+  if (!(maxX > minX) || !(maxY > minY)) {
+    set_error("frame bounds empty");
+    return DVM_ERR_INVALID;
+  }
+  FrameView& V = f->view;
+  V.minX = minX; V.minY = minY;
+  V.wInv = static_cast<float>(64) / static_cast<float>(maxX - minX);  // Frame.cc:443-444
+  V.hInv = static_cast<float>(48) / static_cast<float>(maxY - minY);
+  return DVM_OK;
+}
+static int frame_scratch(dvm_frame* f, size_t bytes) {
+  if (bytes <= f->scratch_bytes) return DVM_OK;
+  if (f->d_scratch) hipFree(f->d_scratch);
+  f->d_scratch = nullptr; f->scratch_bytes = 0;
+  int rc = hip_check(hipMalloc(&f->d_scratch, bytes), "hipMalloc");
+  if (rc == DVM_OK) f->scratch_bytes = bytes;
+  return rc;
+}
+int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, const int32_t* d_n,
+                    float minX, float maxX, float minY, float maxY, int on_device, void* stream) {
+  if (!f || slot < 0 || slot >= f->slots || n < 0 || n > f->cap || (n && (!kps || !desc))) return DVM_ERR_INVALID;
+  int rc = frame_bounds(f, minX, maxX, minY, maxY);
+  if (rc != DVM_OK) return rc;
+  rc = hip_check(hipSetDevice(f->device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  if (on_device) {
+    launch_frame_build((hipStream_t)stream, reinterpret_cast<const dvm_keypoint_pod*>(kps), 0, desc, 0, n, d_n, f->view, slot, 1);
+    return hip_check(hipGetLastError(), "frame_build launch");
+  }
+  const size_t kb = (size_t)std::max(n, 1) * sizeof(dvm_keypoint), db = (size_t)std::max(n, 1) * 32;
+  rc = frame_scratch(f, kb + db);
+  if (rc != DVM_OK) return rc;
+  uint8_t* base = static_cast<uint8_t*>(f->d_scratch);
+  if (n) {
+    rc = hip_check(hipMemcpy(base, kps, (size_t)n * sizeof(dvm_keypoint), hipMemcpyHostToDevice), "memcpy");
+    if (rc == DVM_OK) rc = hip_check(hipMemcpy(base + kb, desc, (size_t)n * 32, hipMemcpyHostToDevice), "memcpy");
+    if (rc != DVM_OK) return rc;
+  }
+  launch_frame_build(nullptr, reinterpret_cast<const dvm_keypoint_pod*>(base), 0, base + kb, 0, n, nullptr, f->view, slot, 1);
+  rc = hip_check(hipGetLastError(), "frame_build launch");
+  if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "sync");
+  return rc;
+}
+int dvm_frame_build_batch(dvm_frame* f, int first_slot, int count, const dvm_keypoint* d_kps, int64_t kps_stride,
+                          const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n, float minX, float maxX,
+                          float minY, float maxY, void* stream) {
+  if (!f || first_slot < 0 || count < 1 || first_slot + count > f->slots || !d_kps || !d_desc || !d_n) return DVM_ERR_INVALID;
+  int rc = frame_bounds(f, minX, maxX, minY, maxY);
+  if (rc != DVM_OK) return rc;
+  launch_frame_build((hipStream_t)stream, reinterpret_cast<const dvm_keypoint_pod*>(d_kps), kps_stride, d_desc, desc_stride, 0,
+                     d_n, f->view, first_slot, count);
+  return hip_check(hipGetLastError(), "frame_build launch");
+}
+
+int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                     const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
+                     const int32_t* d_nq, dvm_match* out, int on_device, void* stream) {
+  if (!train || slot < 0 || slot >= train->slots || nq < 0) return DVM_ERR_INVALID;
+  if (nq == 0) return DVM_OK;
+  if (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !out) return DVM_ERR_INVALID;
+  int rc = hip_check(hipSetDevice(train->device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  if (on_device) {
+    launch_match_window((hipStream_t)stream, train->view, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, d_nq, nq,
+                        reinterpret_cast<dvm_match_pod*>(out));
+    return hip_check(hipGetLastError(), "match launch");
+  }
+  // host convenience path: stage queries, run, copy back
+  const size_t qb = (size_t)nq;
+  const size_t off_desc = 0, off_x = off_desc + qb * 32, off_y = off_x + qb * 4, off_r = off_y + qb * 4,
+               off_min = off_r + qb * 4, off_max = off_min + qb * 4, off_out = off_max + qb * 4,
+               off_skip = off_out + qb * sizeof(dvm_match), total = off_skip + (size_t)train->cap;
+  uint8_t* d = nullptr;
+  rc = hip_check(hipMalloc(&d, total), "hipMalloc");
+  if (rc != DVM_OK) return rc;
+  auto up = [&](size_t off, const void* src, size_t bytes) {
+    if (rc == DVM_OK) rc = hip_check(hipMemcpy(d + off, src, bytes, hipMemcpyHostToDevice), "memcpy");
+  };
+  up(off_desc, qdesc, qb * 32); up(off_x, qx, qb * 4); up(off_y, qy, qb * 4); up(off_r, qr, qb * 4);
+  up(off_min, qmin, qb * 4); up(off_max, qmax, qb * 4);
+  if (skip) up(off_skip, skip, (size_t)train->cap);
+  if (rc == DVM_OK) {
+    launch_match_window(nullptr, train->view, slot, skip ? d + off_skip : nullptr, d + off_desc,
+                        reinterpret_cast<float*>(d + off_x), reinterpret_cast<float*>(d + off_y),
+                        reinterpret_cast<float*>(d + off_r), reinterpret_cast<int32_t*>(d + off_min),
+                        reinterpret_cast<int32_t*>(d + off_max), nq, nullptr, nq, reinterpret_cast<dvm_match_pod*>(d + off_out));
+    rc = hip_check(hipGetLastError(), "match launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, d + off_out, qb * sizeof(dvm_match), hipMemcpyDeviceToHost), "memcpy");
+  hipFree(d);
+  return rc;
+}
+
+int dvm_match_frames_batch(const dvm_frame* train, int first_slot, int count, const dvm_keypoint* d_kps,
+                           int64_t kps_stride, const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n,
+                           const dvm_keypoint* d_carry_kps, const uint8_t* d_carry_desc, const int32_t* d_carry_n,
+                           int cap, float th, const float* d_scale_factors, int nlevels, dvm_match* d_out,
+                           int64_t out_stride, int32_t* d_nq_out, void* stream) {
+  if (!train || first_slot < 0 || count < 1 || first_slot + count > train->slots || cap < 1 || !d_out || !d_scale_factors)
+    return DVM_ERR_INVALID;
+  if (count > 1 && (!d_kps || !d_desc || !d_n)) return DVM_ERR_INVALID;
+  PairQueries pq{};
+  pq.kps = reinterpret_cast<const dvm_keypoint_pod*>(d_kps);
+  pq.desc = d_desc; pq.n = d_n; pq.kps_stride = kps_stride; pq.desc_stride = desc_stride;
+  pq.carry_kps = reinterpret_cast<const dvm_keypoint_pod*>(d_carry_kps);
+  pq.carry_desc = d_carry_desc; pq.carry_n = d_carry_n; pq.n_out = d_nq_out; pq.cap = cap;
+  launch_match_frames((hipStream_t)stream, train->view, first_slot, count, pq, th, d_scale_factors, nlevels,
+                      reinterpret_cast<dvm_match_pod*>(d_out), out_stride);
+  return hip_check(hipGetLastError(), "match_frames launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// dvm_slam_amd/csrc/match_kernels.h -- launchers of the matching kernels (match_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_kernels.h"
+
+namespace dvm {
+
+constexpr int kFrameCap = 8192;  // keypoints per frame slot (13-bit index inside the sort key)
+
+struct dvm_match_pod {  // == dvm_match
+  int32_t best_idx, best_dist, second_dist;
+  int16_t best_level, second_level;
+};
+
+// Device view of a set of frame slots, each `cap` keypoints, sorted in GetFeaturesInArea order.
+struct FrameView {
+  float4* skp;           // (x, y, octave bits, cell bits) per sorted position
+  int32_t* sidx;         // original keypoint index
+  uint8_t* sdesc;        // 32 B descriptors, sorted
+  int32_t* cellx_start;  // [65] first sorted position with grid column >= c
+  int32_t* n_sorted;     // keypoints inside the grid
+  int32_t* n_total;      // keypoints given
+  int32_t cap;
+  float minX, minY, wInv, hInv;
+  __host__ __device__ FrameView slot(int s) const {
+    FrameView v = *this;
+    v.skp += (int64_t)s * cap;
+    v.sidx += (int64_t)s * cap;
+    v.sdesc += (int64_t)s * cap * 32;
+    v.cellx_start += (int64_t)s * 80;
+    v.n_sorted += s;
+    v.n_total += s;
+    return v;
+  }
+};
+
+// Query source of the frame-to-frame search: pair i matches the keypoints of frame i-1 (arrays with
+// a per-frame stride) -- or of the carry frame for pair 0 -- against train slot first_slot + i.
+struct PairQueries {
+  const dvm_keypoint_pod* kps;
+  const uint8_t* desc;
+  const int32_t* n;
+  int64_t kps_stride, desc_stride;
+  const dvm_keypoint_pod* carry_kps;
+  const uint8_t* carry_desc;
+  const int32_t* carry_n;
+  int32_t* n_out;  // [count] number of queries of each pair (may be null)
+  int32_t cap;
+};
+
+void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_stride, const uint8_t* desc,
+                        int64_t desc_stride, int n, const int32_t* d_n, const FrameView& F, int first_slot, int count);
+void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc,
+                         const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
+                         int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out);
+void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
+                         const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride);
+void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
+
+}  // namespace dvm

@@ -1,0 +1,234 @@
+// dvm_slam_amd/csrc/match_kernels.hip -- gfx950 kernels of the matching path.
+//
+//   ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1900-1914) -> popcount over 8 dwords
+//   Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:481-506,773-782)  -> k_frame_build
+//   Frame::GetFeaturesInArea (src/Frame.cc:712-770) + the best / second-best loops of
+//   ORBmatcher::SearchByProjection (src/ORBmatcher.cc:70-115,1604-1639)      -> k_match_window
+//
+// Layout: a frame's keypoints are stored SORTED by (grid column ix, grid row iy, keypoint index) --
+// exactly the order in which GetFeaturesInArea enumerates candidates -- so "first candidate wins a
+// tie" becomes "smallest sorted position wins", an associative rule a wavefront can reduce.
+#include <hip/hip_runtime.h>
+
+#include "match_kernels.h"
+
+namespace dvm {
+
+constexpr int kGridCols = 64, kGridRows = 48;  // Frame.h:44-45
+constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
+
+// One workgroup (1024 threads) per frame slot.  Bitonic sort of (cell << 13 | idx) keys in LDS, then
+// gather.  Slot s = first_slot + blockIdx.x reads keypoints kps + blockIdx.x*kps_stride.
+__global__ void __launch_bounds__(1024) k_frame_build(const dvm_keypoint_pod* __restrict__ kps_base, int64_t kps_stride,
+                                                      const uint8_t* __restrict__ desc_base, int64_t desc_stride,
+                                                      int n_host, const int32_t* __restrict__ d_n, FrameView FB,
+                                                      int first_slot) {
+  __shared__ uint32_t keys[kFrameCap];
+  const int tid = threadIdx.x;
+  const FrameView F = FB.slot(first_slot + blockIdx.x);
+  const dvm_keypoint_pod* kps = kps_base + (int64_t)blockIdx.x * kps_stride;
+  const uint8_t* desc = desc_base + (int64_t)blockIdx.x * desc_stride;
+  int n = d_n ? d_n[blockIdx.x] : n_host;
+  n = min(max(n, 0), F.cap);
+  int P = 64;
+  while (P < n) P <<= 1;
+  for (int i = tid; i < P; i += 1024) {
+    uint32_t key = kInvalidKey;
+    if (i < n) {
+      const dvm_keypoint_pod kp = kps[i];
+      // PosInGrid: round() = half away from zero; keypoints outside the grid are not indexed
+      int px = (int)roundf((kp.x - F.minX) * F.wInv);
+      int py = (int)roundf((kp.y - F.minY) * F.hInv);
+      if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) key = ((uint32_t)(px * kGridRows + py) << 13) | (uint32_t)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 1024) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          uint32_t a = keys[i], b = keys[ixj];
+          bool up = ((i & k) == 0);
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // number of indexed keypoints = first invalid key (binary search by thread 0 is fine: log2(8192))
+  __shared__ int s_m;
+  if (tid == 0) {
+    int lo = 0, hi = P;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (keys[mid] == kInvalidKey) hi = mid; else lo = mid + 1;
+    }
+    s_m = lo;
+    *F.n_sorted = lo;
+    *F.n_total = n;
+  }
+  __syncthreads();
+  const int m = s_m;
+  if (tid <= kGridCols) {  // cellx_start[c] = first sorted position whose column >= c
+    uint32_t want = (uint32_t)(tid * kGridRows) << 13;
+    int lo = 0, hi = m;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    F.cellx_start[tid] = lo;
+  }
+  for (int p = tid; p < m; p += 1024) {
+    const uint32_t key = keys[p];
+    const int i = (int)(key & 0x1FFFu);
+    const dvm_keypoint_pod kp = kps[i];
+    F.skp[p] = make_float4(kp.x, kp.y, __int_as_float(kp.octave), __int_as_float((int)(key >> 13)));
+    F.sidx[p] = i;
+    const uint4* s = reinterpret_cast<const uint4*>(desc + (size_t)i * 32);
+    uint4* d = reinterpret_cast<uint4*>(F.sdesc + (size_t)p * 32);
+    d[0] = s[0];
+    d[1] = s[1];
+  }
+}
+
+__device__ __forceinline__ void top2_insert(uint32_t& k1, uint32_t& k2, uint32_t k) {
+  if (k < k1) { k2 = k1; k1 = k; }
+  else if (k < k2) k2 = k;
+}
+
+// One wave per query.  QUERIES_FROM_KPS: queries are keypoints of another frame (frame-to-frame
+// search, window th*scale[octave], octaves [o-1,o+1]); otherwise explicit query arrays.
+template <bool QUERIES_FROM_KPS>
+__global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_slot, const uint8_t* __restrict__ skip,
+                                                      const uint8_t* __restrict__ qdesc, const float* __restrict__ qx,
+                                                      const float* __restrict__ qy, const float* __restrict__ qr,
+                                                      const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax,
+                                                      int nq_host, const int32_t* __restrict__ d_nq, PairQueries PQ,
+                                                      float th, const float* __restrict__ scale_factors, int nlevels,
+                                                      dvm_match_pod* __restrict__ out, int64_t out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const FrameView F = FB.slot(first_slot + pair);
+  const dvm_keypoint_pod* qkps = nullptr;
+  int nq;
+  if (QUERIES_FROM_KPS) {
+    // pair 0 takes its queries from the carry frame (previous batch), pair i>0 from frame i-1
+    if (pair == 0) {
+      if (!PQ.carry_kps) { if (q == 0 && lane == 0 && PQ.n_out) PQ.n_out[0] = 0; return; }
+      qkps = PQ.carry_kps; qdesc = PQ.carry_desc; nq = *PQ.carry_n;
+    } else {
+      qkps = PQ.kps + (int64_t)(pair - 1) * PQ.kps_stride;
+      qdesc = PQ.desc + (int64_t)(pair - 1) * PQ.desc_stride;
+      nq = PQ.n[pair - 1];
+    }
+    nq = min(nq, PQ.cap);
+    if (q == 0 && lane == 0 && PQ.n_out) PQ.n_out[pair] = nq;
+    out += (int64_t)pair * out_stride;
+  } else {
+    nq = d_nq ? *d_nq : nq_host;
+  }
+  if (q >= nq) return;
+  float x, y, r;
+  int minLevel, maxLevel;
+  if (QUERIES_FROM_KPS) {
+    const dvm_keypoint_pod kp = qkps[q];
+    x = kp.x; y = kp.y;
+    const int o = min(max(kp.octave, 0), nlevels - 1);
+    r = th * scale_factors[o];
+    minLevel = kp.octave - 1;
+    maxLevel = kp.octave + 1;
+  } else {
+    x = qx[q]; y = qy[q]; r = qr[q];
+    minLevel = qmin[q]; maxLevel = qmax[q];
+  }
+  uint32_t k1 = (256u << 16) | 0xFFFFu, k2 = k1;
+  // GetFeaturesInArea cell rectangle (with the reference's early-outs)
+  const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+  const int nMaxCellX = min(kGridCols - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+  const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+  const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+  const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
+  if (!empty && nMinCellX <= nMaxCellX) {
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(qdesc + (size_t)q * 32);
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = qd[i];
+    const int beg = F.cellx_start[nMinCellX], end = F.cellx_start[nMaxCellX + 1];
+    for (int p = beg + lane; p < end; p += 64) {
+      const float4 kp = F.skp[p];
+      const int oct = __float_as_int(kp.z);
+      const int cell = __float_as_int(kp.w);
+      const int iy = cell % kGridRows;
+      if (iy < nMinCellY || iy > nMaxCellY) continue;
+      if (checkLevels) {
+        if (oct < minLevel) continue;
+        if (maxLevel >= 0 && oct > maxLevel) continue;
+      }
+      const float dx = kp.x - x, dy = kp.y - y;
+      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+      if (skip && skip[F.sidx[p]]) continue;
+      const uint4* td = reinterpret_cast<const uint4*>(F.sdesc + (size_t)p * 32);
+      const uint4 a = td[0], b = td[1];
+      int d = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
+              __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
+      top2_insert(k1, k2, ((uint32_t)d << 16) | (uint32_t)p);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t o1 = __shfl_xor(k1, off), o2 = __shfl_xor(k2, off);
+    uint32_t n1 = min(k1, o1);
+    uint32_t n2 = min(max(k1, o1), min(k2, o2));
+    k1 = n1; k2 = n2;
+  }
+  if (lane == 0) {
+    dvm_match_pod m;
+    const int p1 = (int)(k1 & 0xFFFFu), p2 = (int)(k2 & 0xFFFFu);
+    m.best_dist = (int)(k1 >> 16);
+    m.second_dist = (int)(k2 >> 16);
+    m.best_idx = (m.best_dist < 256) ? F.sidx[p1] : -1;
+    m.best_level = (m.best_dist < 256) ? (int16_t)__float_as_int(F.skp[p1].z) : (int16_t)-1;
+    m.second_level = (m.second_dist < 256) ? (int16_t)__float_as_int(F.skp[p2].z) : (int16_t)-1;
+    out[q] = m;
+  }
+}
+
+// D[i][j] = Hamming(A[i], B[j]); one thread per pair, 64 columns x 4 rows per workgroup.
+__global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t* __restrict__ A, int nA,
+                                                        const uint8_t* __restrict__ B, int nB, uint16_t* __restrict__ D) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= nA || j >= nB) return;
+  const uint4* a = reinterpret_cast<const uint4*>(A + (size_t)i * 32);
+  const uint4* b = reinterpret_cast<const uint4*>(B + (size_t)j * 32);
+  const uint4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+  int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+  D[(size_t)i * nB + j] = (uint16_t)d;
+}
+
+void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_stride, const uint8_t* desc,
+                        int64_t desc_stride, int n, const int32_t* d_n, const FrameView& F, int first_slot, int count) {
+  hipLaunchKernelGGL(k_frame_build, dim3(count), dim3(1024), 0, s, kps, kps_stride, desc, desc_stride, n, d_n, F, first_slot);
+}
+void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc,
+                         const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
+                         int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out) {
+  PairQueries pq{};
+  hipLaunchKernelGGL(k_match_window<false>, dim3((grid_q + 3) / 4, 1), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr,
+                     qmin, qmax, nq, d_nq, pq, 0.f, nullptr, 0, out, 0);
+}
+void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
+                         const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {
+  hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 3) / 4, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride);
+}
+void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D) {
+  hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 63) / 64, (nA + 3) / 4), dim3(256), 0, s, A, nA, B, nB, D);
+}
+
+}  // namespace dvm

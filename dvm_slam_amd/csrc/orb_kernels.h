@@ -1,0 +1,31 @@
+// dvm_slam_amd/csrc/orb_kernels.h -- launchers of the ORB front-end kernels (orb_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_device.h"
+
+namespace dvm {
+
+// same layout as dvm_keypoint / cv::KeyPoint
+struct dvm_keypoint_pod {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+};
+
+void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gauss7);
+void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
+                       uint8_t* d_pyr, const PipelineDesc& PD, int batch);
+void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int level, const int32_t* d_tabs, int batch);
+void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
+                 int32_t* d_cell_count, int batch);
+void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
+                    const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch);
+void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
+                     int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch);
+void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
+                 const int32_t* d_nsel, int batch);
+void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
+                        const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch);
+
+}  // namespace dvm

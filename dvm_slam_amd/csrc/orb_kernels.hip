@@ -1,0 +1,546 @@
+// dvm_slam_amd/csrc/orb_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ORB front end.
+//
+// Stage map (reference file:line -> kernel), see DESIGN.md for layouts and rooflines:
+//   ORBextractor.cc:957-976  ComputePyramid              -> k_pyr_level0, k_pyr_resize
+//   ORBextractor.cc:634-692  per-cell cv::FAST x2 + NMS  -> k_fast_cells, k_compact_cands
+//   ORBextractor.cc:876-955  operator() output placement -> k_assemble
+//   ORBextractor.cc:919-920  GaussianBlur 7x7 sigma 2    -> k_blur7
+//   ORBextractor.cc:75-99    IC_Angle                    -> k_orient_desc (phase 1)
+//   ORBextractor.cc:102-143  computeOrbDescriptor        -> k_orient_desc (phase 2)
+// All integer results are bit-exact by construction; the few float ops (fastAtan2, rotation of the
+// BRIEF pattern, keypoint scaling) are compiled with FP contraction OFF so every operation is one
+// IEEE rounding, the same sequence the CPU oracle performs.
+#include <hip/hip_runtime.h>
+
+#include "orb_device.h"
+#include "orb_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace dvm {
+
+__constant__ int c_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+// FAST-16 Bresenham circle, OpenCV order (dx,dy)
+__constant__ int8_t c_circle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                       {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+// orientation disc: for pixel p of the 749-px disc, (u,v) offsets; filled by the host at init
+__constant__ int8_t c_disc_u[768];
+__constant__ int8_t c_disc_v[768];
+__constant__ int c_gauss7[7];
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------ K1
+// Level 0: copy the input image into the bordered level-0 buffer and fill the 19-px REFLECT_101
+// frame.  One thread per 4 destination bytes (aligned dword store).
+__global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ src, int rows, int cols, int sstride,
+                                                    int64_t frame_stride, uint8_t* __restrict__ pyr,
+                                                    int pyr_frame_bytes, LevelDesc L) {
+  const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int Y = blockIdx.y;
+  const int f = blockIdx.z;
+  const int bw = L.w + 2 * kEdge;
+  if (X4 >= bw) return;
+  const uint8_t* S = src + (int64_t)f * frame_stride + (int64_t)reflect101(Y - kEdge, rows) * sstride;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int X = X4 + k;
+    if (X < bw) v |= (uint32_t)S[reflect101(X - kEdge, cols)] << (8 * k);
+  }
+  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)Y * L.stride;
+  *reinterpret_cast<uint32_t*>(D + X4) = v;
+}
+
+// Level l>0: cv::resize(level l-1 -> l, INTER_LINEAR) 8-bit fixed point (coefficient tables built on
+// the host: xofs/xalpha/yofs/ybeta, 11-bit weights) fused with copyMakeBorder(REFLECT_101): a border
+// pixel recomputes the interior pixel it mirrors.  One thread per 4 destination bytes.
+__global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
+                                                    LevelDesc L, const int32_t* __restrict__ tabs) {
+  const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int Y = blockIdx.y;
+  const int f = blockIdx.z;
+  const int bw = L.w + 2 * kEdge;
+  if (X4 >= bw) return;
+  const int32_t* xofs = tabs + L.tab_off;
+  const int32_t* xal = xofs + L.w;   // (a0 | a1 << 16)
+  const int32_t* yofs = xal + L.w;
+  const int32_t* ybe = yofs + L.h;   // (b0 | b1 << 16)
+  const int dy = reflect101(Y - kEdge, L.h);
+  const uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;
+  const uint8_t* S = base + P.pyr_off + (int64_t)kEdge * P.stride + kEdge;  // pixel (0,0) of level l-1
+  int sy = yofs[dy];
+  int sy0 = min(max(sy, 0), P.h - 1), sy1 = min(max(sy + 1, 0), P.h - 1);
+  const uint8_t* S0 = S + (int64_t)sy0 * P.stride;
+  const uint8_t* S1 = S + (int64_t)sy1 * P.stride;
+  const int bb = ybe[dy];
+  const int b0 = (int16_t)(bb & 0xFFFF), b1 = (int16_t)(bb >> 16);
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int X = X4 + k;
+    if (X >= bw) break;
+    int dx = reflect101(X - kEdge, L.w);
+    int sx = xofs[dx];
+    int aa = xal[dx];
+    int a0 = (int16_t)(aa & 0xFFFF), a1 = (int16_t)(aa >> 16);
+    // S[sx+1] is always addressable (level l-1 carries its border); its weight is 0 at the clamp
+    int h0 = S0[sx] * a0 + S0[sx + 1] * a1;
+    int h1 = S1[sx] * a0 + S1[sx + 1] * a1;
+    int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    r = min(max(r, 0), 255);
+    v |= (uint32_t)r << (8 * k);
+  }
+  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)Y * L.stride;
+  *reinterpret_cast<uint32_t*>(D + X4) = v;
+}
+
+// ------------------------------------------------------------------------------------------ K2
+// FAST-9/16 strength max(A,B) of one pixel: A = max over the 16 nine-pixel arcs of min(v - p),
+// B = the same for (p - v).  Sliding-window min/max of width 9 over the circular 16-vector by
+// doubling (2,4,8,+1): 4 x 16 min + 4 x 16 max.
+__device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int pitch) {
+  const int v = t[0];
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - (int)t[c_circle[k][0] + c_circle[k][1] * pitch];
+  int lo2[16], hi2[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo2[k] = min(d[k], d[(k + 1) & 15]);
+    hi2[k] = max(d[k], d[(k + 1) & 15]);
+  }
+  int lo4[16], hi4[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+    hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+  }
+  int A = -256, Bn = 256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+    int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+    A = max(A, lo9);
+    Bn = min(Bn, hi9);
+  }
+  return max(A, -Bn);
+}
+
+// One workgroup per (cell, frame).  Reproduces, for the cell's ROI,
+//   FAST(roi, kps, iniThFAST, true); if (kps.empty()) FAST(roi, kps, minThFAST, true);
+// using the identity (DESIGN.md "FAST as a score map"): with S(p) = max(A,B)-1 where max(A,B) > tlow
+// (0 elsewhere and outside the 3-px ROI frame), cv::FAST(t) with NMS returns exactly
+// { p : S(p) >= t and S(p) > S(q) for the 8 neighbours q }, in row-major order, response S(p).
+// Output: candidates in the cell's slot range, row-major, packed (x-16, y-16, score).
+__global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
+                                                    const CellDesc* __restrict__ cells, PipelineDesc PD,
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count) {
+  __shared__ uint8_t tile[kMaxCellDim * kMaxCellDim];
+  __shared__ uint8_t score[(kMaxCellDim - 4) * (kMaxCellDim - 4)];
+  __shared__ int s_cnt_ini;
+  __shared__ int s_wave_tot[40][4];
+
+  const int f = blockIdx.y;
+  const CellDesc c = cells[blockIdx.x];
+  const LevelDesc& L = PD.lv[c.level];
+  const int tid = threadIdx.x;
+  const int rw = c.rw, rh = c.rh;
+  const int ew = rw - 6, eh = rh - 6;  // evaluated area (FAST skips a 3-px frame of the ROI)
+  const int sp = ew + 2;               // score pitch (1-px zero ring)
+  int32_t* my_count = cell_count + (int64_t)f * PD.ncells + blockIdx.x;
+  if (ew <= 0 || eh <= 0) {
+    if (tid == 0) *my_count = 0;
+    return;
+  }
+  const uint8_t* img = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + c.y0) * L.stride + kEdge + c.x0;
+  for (int i = tid; i < rw * rh; i += 256) {
+    int y = i / rw, x = i - y * rw;
+    tile[y * rw + x] = img[(int64_t)y * L.stride + x];
+  }
+  for (int i = tid; i < sp * (eh + 2); i += 256) score[i] = 0;
+  if (tid == 0) s_cnt_ini = 0;
+  __syncthreads();
+
+  const int tlow = min(PD.ini_th, PD.min_th);
+  const int npx = ew * eh;
+  for (int i = tid; i < npx; i += 256) {
+    int ey = i / ew, ex = i - ey * ew;
+    int m = fast_strength(&tile[(ey + 3) * rw + ex + 3], rw);
+    if (m > tlow) score[(ey + 1) * sp + ex + 1] = (uint8_t)(m - 1);
+  }
+  __syncthreads();
+
+  // local strict maxima; bit0 = passes iniTh, bit1 = passes minTh
+  const int rounds = (npx + 255) / 256;
+  uint32_t flags_lo = 0, flags_hi = 0;  // 2 bits per round, up to 32 rounds (npx <= 8192)
+  int cnt_ini = 0;
+  for (int r = 0; r < rounds; r++) {
+    int i = r * 256 + tid;
+    int fl = 0;
+    if (i < npx) {
+      int ey = i / ew, ex = i - ey * ew;
+      const uint8_t* s = &score[(ey + 1) * sp + ex + 1];
+      int sv = s[0];
+      if (sv > 0) {
+        int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
+                     max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
+        if (sv > mx) fl = (sv >= PD.ini_th ? 1 : 0) | (sv >= PD.min_th ? 2 : 0);
+      }
+    }
+    cnt_ini += fl & 1;
+    if (r < 16) flags_lo |= (uint32_t)fl << (2 * r);
+    else flags_hi |= (uint32_t)fl << (2 * (r - 16));
+  }
+  if (cnt_ini) atomicAdd(&s_cnt_ini, cnt_ini);
+  __syncthreads();
+  const int bit = (s_cnt_ini > 0) ? 1 : 2;  // first call non-empty -> keep it, else the retry's result
+
+  // ordered compaction: element index i = r*256 + tid must come out in increasing i
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int r = 0; r < rounds; r++) {
+    int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
+    unsigned long long m = __ballot((fl & bit) != 0);
+    if (lane == 0) s_wave_tot[r][wave] = __popcll(m);
+  }
+  __syncthreads();
+  int base = 0;
+  uint32_t* out = cand + (int64_t)f * PD.cand_frame_slots + c.cand_base;
+  for (int r = 0; r < rounds; r++) {
+    int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
+    bool keep = (fl & bit) != 0;
+    unsigned long long m = __ballot(keep);
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
+    int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && pos < c.cand_cap) {
+      int i = r * 256 + tid;
+      int ey = i / ew, ex = i - ey * ew;
+      // border-relative level coordinates: (roi origin + 3 + e) - 16
+      out[pos] = pack_cand(c.x0 + 3 + ex - (kEdge - 3), c.y0 + 3 + ey - (kEdge - 3), score[(ey + 1) * sp + ex + 1]);
+    }
+    base += s_wave_tot[r][0] + s_wave_tot[r][1] + s_wave_tot[r][2] + s_wave_tot[r][3];
+  }
+  if (tid == 0) *my_count = min(base, c.cand_cap);
+}
+
+// Concatenate the per-cell lists of one frame in cell-table order (level-major, then the
+// reference's cell loop order) -> per-level vToDistributeKeys, densely packed per frame.
+// grid (batch); dense[f][lvl_start[f][l] + i], lvl_start[f][0..nlevels] (last = total).
+__global__ void __launch_bounds__(256) k_compact_cands(const uint32_t* __restrict__ cand,
+                                                       const int32_t* __restrict__ cell_count,
+                                                       const CellDesc* __restrict__ cells, PipelineDesc PD,
+                                                       uint32_t* __restrict__ dense, int32_t* __restrict__ lvl_start) {
+  __shared__ int s_scan[256];
+  __shared__ int s_carry;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  const uint32_t* src = cand + (int64_t)f * PD.cand_frame_slots;
+  uint32_t* dst = dense + (int64_t)f * PD.cand_frame_slots;
+  for (int c0 = 0; c0 < PD.ncells; c0 += 256) {
+    int ci = c0 + tid;
+    int n = (ci < PD.ncells) ? cell_count[(int64_t)f * PD.ncells + ci] : 0;
+    s_scan[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+      int v = (tid >= off) ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    int start = s_carry + s_scan[tid] - n;
+    if (ci < PD.ncells) {
+      const CellDesc c = cells[ci];
+      if (ci == PD.lv[c.level].cell_first) lvl_start[f * (kMaxLevels + 1) + c.level] = start;
+      const uint32_t* s = src + c.cand_base;
+      for (int k = 0; k < n; k++) dst[start + k] = s[k];
+    }
+    __syncthreads();
+    if (tid == 255) s_carry += s_scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int32_t* ls = lvl_start + f * (kMaxLevels + 1);
+    ls[PD.nlevels] = s_carry;
+    for (int l = PD.nlevels - 1; l >= 0; l--)  // levels without any cell own an empty range
+      if (PD.lv[l].cell_count == 0) ls[l] = ls[l + 1];
+  }
+}
+
+// ------------------------------------------------------------------------------------ assemble
+// operator() output placement (reference ORBextractor.cc:898-951).  One workgroup per frame.
+// Walks the selected keypoints in (level, octree-list) order g = 0..N-1, scales pt by
+// mvScaleFactor[level] (level>0), and places keypoints inside the lapping area from the back
+// (stereoIndex--) and the others from the front (monoIndex++).
+__global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel,
+                                                  PipelineDesc PD, int lap0, int lap1, dvm_keypoint_pod* __restrict__ kps,
+                                                  KpAux* __restrict__ aux, int32_t* __restrict__ n_out,
+                                                  int32_t* __restrict__ mono_out) {
+  __shared__ int s_lvl_start[kMaxLevels + 1];
+  __shared__ int s_scan[256];
+  __shared__ int s_carry;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < PD.nlevels; l++) {
+      s_lvl_start[l] = acc;
+      acc += min(nsel[f * PD.nlevels + l], PD.lv[l].sel_cap);
+    }
+    s_lvl_start[PD.nlevels] = min(acc, PD.kp_cap);
+    s_carry = 0;
+  }
+  __syncthreads();
+  const int N = s_lvl_start[PD.nlevels];
+  const uint32_t* S = sel + (int64_t)f * PD.sel_frame_slots;
+  dvm_keypoint_pod* K = kps + (int64_t)f * PD.kp_cap;
+  KpAux* A = aux + (int64_t)f * PD.kp_cap;
+  for (int g0 = 0; g0 < N; g0 += 256) {
+    int g = g0 + tid;
+    int lvl = 0, inlap = 0;
+    float px = 0, py = 0, resp = 0;
+    int cx = 0, cy = 0;
+    if (g < N) {
+      while (g >= s_lvl_start[lvl + 1]) lvl++;
+      int x, y, s;
+      unpack_cand(S[PD.lv[lvl].sel_off + (g - s_lvl_start[lvl])], x, y, s);
+      cx = x + (kEdge - 3);
+      cy = y + (kEdge - 3);
+      px = (float)cx;
+      py = (float)cy;
+      if (lvl != 0) {
+        px = px * PD.lv[lvl].scale;
+        py = py * PD.lv[lvl].scale;
+      }
+      resp = (float)s;
+      inlap = (px >= (float)lap0 && px <= (float)lap1) ? 1 : 0;
+    }
+    s_scan[tid] = inlap;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      int v = (tid >= off) ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    if (g < N) {
+      int lap_before = s_carry + s_scan[tid] - inlap;  // lapping keypoints among g' < g
+      int pos = inlap ? (N - 1 - lap_before) : (g - lap_before);
+      dvm_keypoint_pod kp;
+      kp.x = px; kp.y = py;
+      kp.size = (float)PD.lv[lvl].patch_size;
+      kp.angle = -1.f;
+      kp.response = resp;
+      kp.octave = lvl;
+      kp.class_id = -1;
+      K[pos] = kp;
+      KpAux a;
+      a.level = (int16_t)lvl; a.pad = 0; a.cx = (int16_t)cx; a.cy = (int16_t)cy; a.out_pos = pos;
+      A[g] = a;
+    }
+    __syncthreads();
+    if (tid == 255) s_carry += s_scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    n_out[f] = N;
+    mono_out[f] = N - s_carry;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K5
+// GaussianBlur(7x7, sigma=2, BORDER_REFLECT_101) in OpenCV's 8-bit fixed-point form:
+// out = (sum_j sum_i k[j] k[i] src + 32768) >> 16 with the 8.8 kernel [18,34,48,56,48,34,18].
+// The pyramid's 19-px REFLECT_101 frame already holds the mirrored pixels, so the tile loader just
+// reads the bordered buffer.  Tile = 64 x 32 outputs, LDS: raw (38 x 70) u8 + hpass (38 x 64) u16.
+constexpr int kBlurTW = 64, kBlurTH = 32;
+__global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
+                                               uint8_t* __restrict__ blur, int blur_frame_bytes,
+                                               const TileDesc* __restrict__ tiles, PipelineDesc PD,
+                                               const int32_t* __restrict__ nsel) {
+  __shared__ uint8_t raw[(kBlurTH + 6) * (kBlurTW + 8)];
+  __shared__ uint16_t hp[(kBlurTH + 6) * kBlurTW];
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const TileDesc t = tiles[blockIdx.x];
+  if (nsel[f * PD.nlevels + t.level] == 0) return;  // reference skips levels without keypoints (:915-916)
+  const LevelDesc& L = PD.lv[t.level];
+  const uint8_t* src = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + t.y0 - 3) * L.stride +
+                       (kEdge + t.x0 - 3);
+  const int tw = min(kBlurTW, L.w - t.x0), th = min(kBlurTH, L.h - t.y0);
+  const int RW = kBlurTW + 8;
+  for (int i = tid; i < (th + 6) * (tw + 6); i += 256) {
+    int y = i / (tw + 6), x = i - y * (tw + 6);
+    raw[y * RW + x] = src[(int64_t)y * L.stride + x];
+  }
+  __syncthreads();
+  for (int i = tid; i < (th + 6) * tw; i += 256) {
+    int y = i / tw, x = i - y * tw;
+    const uint8_t* r = &raw[y * RW + x];
+    int acc = c_gauss7[0] * (r[0] + r[6]) + c_gauss7[1] * (r[1] + r[5]) + c_gauss7[2] * (r[2] + r[4]) + c_gauss7[3] * r[3];
+    hp[y * kBlurTW + x] = (uint16_t)acc;
+  }
+  __syncthreads();
+  uint8_t* dst = blur + (int64_t)f * blur_frame_bytes + L.blur_off + (int64_t)t.y0 * L.blur_stride + t.x0;
+  for (int i = tid; i < th * tw; i += 256) {
+    int y = i / tw, x = i - y * tw;
+    const uint16_t* c = &hp[y * kBlurTW + x];
+    uint32_t acc = (uint32_t)c_gauss7[0] * (c[0] + c[6 * kBlurTW]) + (uint32_t)c_gauss7[1] * (c[kBlurTW] + c[5 * kBlurTW]) +
+                   (uint32_t)c_gauss7[2] * (c[2 * kBlurTW] + c[4 * kBlurTW]) + (uint32_t)c_gauss7[3] * c[3 * kBlurTW];
+    dst[(int64_t)y * L.blur_stride + x] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+  }
+}
+
+// -------------------------------------------------------------------------------------- K4 + K6
+// cv::fastAtan2 scalar path (degrees), no FMA.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  const float eps = (float)2.2204460492503131e-16;
+  float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// (float)cos / (float)sin of angle_deg * (float)(pi/180): DESIGN.md "sincos spec" (double Cody-Waite
+// reduction by pi/2 + fdlibm kernel polynomials, Horner with separate mul/add).
+__device__ __forceinline__ void sincos_deg(float angle_deg, float& cs, float& sn) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float angf = angle_deg * factorPI;
+  double x = (double)angf;
+  double kd = rint(x * 0.63661977236758134308);
+  int k = (int)kd;
+  double r = (x - kd * 1.57079632679489655800e+00) - kd * 6.12323399573676603587e-17;
+  double z = r * r;
+  double ps = -1.66666666666666324348e-01 +
+              z * (8.33333333332248946124e-03 +
+                   z * (-1.98412698298579493134e-04 +
+                        z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  double pc = 4.16666666666666019037e-02 +
+              z * (-1.38888888888741095749e-03 +
+                   z * (2.48015872894767294178e-05 +
+                        z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  double s = r + r * (z * ps);
+  double c = (1.0 - 0.5 * z) + (z * z) * pc;
+  double co, si;
+  switch (k & 3) {
+    case 0: co = c; si = s; break;
+    case 1: co = -s; si = c; break;
+    case 2: co = -c; si = -s; break;
+    default: co = s; si = -c; break;
+  }
+  cs = (float)co;
+  sn = (float)si;
+}
+
+// One wave per keypoint (4 keypoints per workgroup).  Phase 1: intensity-centroid moments over the
+// 749-px disc of the UN-blurred level (int32, exact, order-free), fastAtan2.  Phase 2: 256 BRIEF
+// tests on the blurred level, pair p = 64*i + lane, packed by 4 wave ballots (bit p%8 of byte p/8).
+__global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
+                                                     const uint8_t* __restrict__ blur, int blur_frame_bytes,
+                                                     PipelineDesc PD, const KpAux* __restrict__ aux,
+                                                     const int32_t* __restrict__ n_kp, dvm_keypoint_pod* __restrict__ kps,
+                                                     uint8_t* __restrict__ desc) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_kp[f]) return;
+  const KpAux a = aux[(int64_t)f * PD.kp_cap + g];
+  const LevelDesc& L = PD.lv[a.level];
+  const uint8_t* c0 = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + a.cy) * L.stride + kEdge + a.cx;
+  int m10 = 0, m01 = 0;
+  for (int p = lane; p < kDiscPixels; p += 64) {
+    int u = c_disc_u[p], v = c_disc_v[p];
+    int val = c0[v * L.stride + u];
+    m10 += u * val;
+    m01 += v * val;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m10 += __shfl_xor(m10, off);
+    m01 += __shfl_xor(m01, off);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  float ca, sb;
+  sincos_deg(angle, ca, sb);
+  const uint8_t* c1 = blur + (int64_t)f * blur_frame_bytes + L.blur_off + (int64_t)a.cy * L.blur_stride + a.cx;
+  const int st = L.blur_stride;
+  unsigned long long words[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int* pt = &c_pattern[(64 * i + lane) * 4];
+    float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    int t0 = c1[__float2int_rn(x0 * sb + y0 * ca) * st + __float2int_rn(x0 * ca - y0 * sb)];
+    int t1 = c1[__float2int_rn(x1 * sb + y1 * ca) * st + __float2int_rn(x1 * ca - y1 * sb)];
+    words[i] = __ballot(t0 < t1);
+  }
+  if (lane == 0) {
+    kps[(int64_t)f * PD.kp_cap + a.out_pos].angle = angle;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((int64_t)f * PD.kp_cap + a.out_pos) * 32);
+    d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------- launchers
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gauss7) {
+  hipMemcpyToSymbol(HIP_SYMBOL(c_disc_u), disc_u, kDiscPixels);
+  hipMemcpyToSymbol(HIP_SYMBOL(c_disc_v), disc_v, kDiscPixels);
+  hipMemcpyToSymbol(HIP_SYMBOL(c_gauss7), gauss7, 7 * sizeof(int));
+}
+
+void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
+                       uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
+  const LevelDesc& L = PD.lv[0];
+  dim3 grid(cdiv(cdiv(L.w + 2 * kEdge, 4), 256), L.h + 2 * kEdge, batch);
+  hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_src, rows, cols, sstride, frame_stride, d_pyr,
+                     PD.pyr_frame_bytes, L);
+}
+void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int level, const int32_t* d_tabs, int batch) {
+  const LevelDesc& L = PD.lv[level];
+  dim3 grid(cdiv(cdiv(L.w + 2 * kEdge, 4), 256), L.h + 2 * kEdge, batch);
+  hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, PD.lv[level - 1], L, d_tabs);
+}
+void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
+                 int32_t* d_cell_count, int batch) {
+  hipLaunchKernelGGL(k_fast_cells, dim3(PD.ncells, batch), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_cells, PD,
+                     d_cand, d_cell_count);
+}
+void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
+                    const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch) {
+  hipLaunchKernelGGL(k_compact_cands, dim3(batch), dim3(256), 0, s, d_cand, d_cell_count, d_cells, PD, d_dense,
+                     d_lvl_start);
+}
+void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
+                     int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch) {
+  hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(256), 0, s, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono);
+}
+void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
+                 const int32_t* d_nsel, int batch) {
+  hipLaunchKernelGGL(k_blur7, dim3(PD.ntiles, batch), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_blur,
+                     PD.blur_frame_bytes, d_tiles, PD, d_nsel);
+}
+void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
+                        const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch) {
+  hipLaunchKernelGGL(k_orient_desc, dim3(cdiv(PD.kp_cap, 4), batch), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_blur,
+                     PD.blur_frame_bytes, PD, d_aux, d_n, d_kps, d_desc);
+}
+
+}  // namespace dvm

@@ -1,0 +1,567 @@
+// dvm_slam_amd/csrc/orb_pipeline.cpp -- host orchestration of the ORB extractor on one MI355X.
+//
+// Mirrors ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:47-91, src/ORBextractor.cc):
+//   constructor tables      ORBextractor.cc:282-339 -> OrbPipeline::OrbPipeline
+//   ComputePyramid          :957-976                -> launch_pyr_level0 / launch_pyr_resize
+//   ComputeKeyPointsOctTree :612-715                -> launch_fast + launch_compact + octree_select
+//   operator()              :876-955                -> extract_device (stage order, output placement)
+// Everything that touches pixels runs in HIP kernels (orb_kernels.hip).  DistributeOctTree is
+// sequential list surgery over <= ~10^4 candidates per level and stays on the host in this round
+// (SURVEY.md section 2.2 row K3); it is the only host compute on the path.
+#include "orb_pipeline.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace dvm {
+
+// ------------------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* last_error_cstr() { return g_err.c_str(); }
+int hip_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return DVM_OK;
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return DVM_ERR_HIP;
+}
+
+// ----------------------------------------------------------------------------------- profiler
+hipEvent_t Profiler::get_event() {
+  if (!pool_.empty()) {
+    hipEvent_t e = pool_.back();
+    pool_.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+void Profiler::begin(hipStream_t s, const char* name) {
+  if (!enabled) return;
+  Pending p{name, get_event(), get_event()};
+  hipEventRecord(p.a, s);
+  pending_.push_back(p);
+}
+void Profiler::end(hipStream_t s) {
+  if (!enabled || pending_.empty()) return;
+  hipEventRecord(pending_.back().b, s);
+}
+void Profiler::resolve() {
+  for (auto& p : pending_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto& t = totals_[p.name];
+      t.first += ms;
+      t.second += 1;
+    }
+    pool_.push_back(p.a);
+    pool_.push_back(p.b);
+  }
+  pending_.clear();
+}
+void Profiler::reset() {
+  resolve();
+  totals_.clear();
+}
+bool Profiler::get(const std::string& name, double* ms, int64_t* launches) {
+  auto it = totals_.find(name);
+  if (it == totals_.end()) return false;
+  if (ms) *ms = it->second.first;
+  if (launches) *launches = it->second.second;
+  return true;
+}
+Profiler::~Profiler() {
+  resolve();
+  for (auto e : pool_) hipEventDestroy(e);
+}
+
+// ------------------------------------------------------------------------------- host octree
+// DistributeOctTree, reference ORBextractor.cc:419-610, restated without std::list.
+// Invariant used: after a round that splits the node sequence P = (p1..pm) (in processing order),
+//   new list = reverse(children(p1) ++ ... ++ children(pm)) ++ (old list without P)
+// because every child is push_front'ed (n1..n4 order) and the parent erased in place.  Phase 1
+// processes all splittable nodes in list order; phase 2 processes them in the order given by
+// std::sort(compareNodes) walked from the back, stopping as soon as the list reaches N nodes.
+namespace {
+struct ONode {
+  int x0, y0, x1, y1;
+  std::vector<int> keys;  // indices into the candidate array, parent's order preserved
+};
+struct OCtx {
+  const uint32_t* cand;
+  std::vector<ONode> nodes;
+  void split(int id, int child_ids[4], int& nchild) {
+    const int x0 = nodes[id].x0, y0 = nodes[id].y0, x1 = nodes[id].x1, y1 = nodes[id].y1;
+    const int hx = (int)std::ceil(static_cast<float>(x1 - x0) / 2);
+    const int hy = (int)std::ceil(static_cast<float>(y1 - y0) / 2);
+    const int xm = x0 + hx, ym = y0 + hy;
+    ONode ch[4];
+    ch[0] = ONode{x0, y0, xm, ym, {}};
+    ch[1] = ONode{xm, y0, x1, ym, {}};
+    ch[2] = ONode{x0, ym, xm, y1, {}};
+    ch[3] = ONode{xm, ym, x1, y1, {}};
+    for (int k : nodes[id].keys) {
+      int x, y, s;
+      unpack_cand(cand[k], x, y, s);
+      const int q = ((float)x < (float)xm ? 0 : 1) + ((float)y < (float)ym ? 0 : 2);
+      ch[q].keys.push_back(k);
+    }
+    nchild = 0;
+    for (int q = 0; q < 4; q++) {
+      if (ch[q].keys.empty()) continue;
+      child_ids[nchild++] = (int)nodes.size();
+      nodes.push_back(std::move(ch[q]));
+    }
+  }
+};
+}  // namespace
+
+void octree_select(const uint32_t* cand, int n, int minX, int maxX, int minY, int maxY, int N, std::vector<uint32_t>& out) {
+  out.clear();
+  if (n <= 0) return;
+  OCtx cx;
+  cx.cand = cand;
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  if (nIni <= 0) return;  // aspect < 0.5: the reference indexes an empty vector here (undefined)
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+  for (int i = 0; i < nIni; i++)
+    cx.nodes.push_back(ONode{(int)(hX * static_cast<float>(i)), 0, (int)(hX * static_cast<float>(i + 1)), maxY - minY, {}});
+  for (int i = 0; i < n; i++) {
+    int x, y, s;
+    unpack_cand(cand[i], x, y, s);
+    cx.nodes[(int)((float)x / hX)].keys.push_back(i);
+  }
+  std::vector<int> list;  // node ids in std::list order
+  for (int i = 0; i < nIni; i++)
+    if (!cx.nodes[i].keys.empty()) list.push_back(i);
+
+  typedef std::pair<int, int> SizeId;  // (#keys, node id)
+  auto less = [&](const SizeId& a, const SizeId& b) {
+    if (a.first != b.first) return a.first < b.first;
+    return cx.nodes[a.second].x0 < cx.nodes[b.second].x0;
+  };
+  std::vector<int> fresh, rest;
+  std::vector<char> gone;
+  std::vector<SizeId> expandable;
+  // splits `proc` (processing order), stops early once the list would hold >= stopN nodes
+  auto round = [&](const std::vector<int>& proc, int stopN) {
+    fresh.clear();
+    expandable.clear();
+    gone.assign(cx.nodes.size() + 4 * proc.size() + 4, 0);
+    int size = (int)list.size();
+    for (int id : proc) {
+      int ch[4], nc;
+      cx.split(id, ch, nc);
+      for (int k = 0; k < nc; k++) {
+        fresh.push_back(ch[k]);
+        if (cx.nodes[ch[k]].keys.size() > 1) expandable.push_back(SizeId((int)cx.nodes[ch[k]].keys.size(), ch[k]));
+      }
+      gone[id] = 1;
+      size += nc - 1;
+      if (stopN >= 0 && size >= stopN) break;
+    }
+    rest.clear();
+    for (int id : list)
+      if (!gone[id]) rest.push_back(id);
+    list.assign(fresh.rbegin(), fresh.rend());
+    list.insert(list.end(), rest.begin(), rest.end());
+  };
+
+  bool finish = false;
+  std::vector<int> proc;
+  while (!finish) {
+    const int prev = (int)list.size();
+    proc.clear();
+    for (int id : list)
+      if (cx.nodes[id].keys.size() > 1) proc.push_back(id);
+    round(proc, -1);
+    const int nToExpand = (int)expandable.size();
+    if ((int)list.size() >= N || (int)list.size() == prev) {
+      finish = true;
+    } else if ((int)list.size() + nToExpand * 3 > N) {
+      while (!finish) {
+        const int prev2 = (int)list.size();
+        std::vector<SizeId> order = expandable;
+        std::sort(order.begin(), order.end(), less);
+        proc.clear();
+        for (int j = (int)order.size() - 1; j >= 0; j--) proc.push_back(order[j].second);
+        round(proc, N);
+        if ((int)list.size() >= N || (int)list.size() == prev2) finish = true;
+      }
+    }
+  }
+  out.reserve(list.size());
+  for (int id : list) {
+    const std::vector<int>& keys = cx.nodes[id].keys;
+    int best = keys[0];
+    int bs = (int)(cand[best] >> 24);
+    for (size_t k = 1; k < keys.size(); k++) {
+      int s = (int)(cand[keys[k]] >> 24);
+      if (s > bs) { bs = s; best = keys[k]; }
+    }
+    out.push_back(cand[best]);
+  }
+}
+
+// -------------------------------------------------------------------------------- OrbPipeline
+static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+OrbPipeline::OrbPipeline(const dvm_orb_params& p, int dev, int mb) : params(p), device(dev), max_batch(std::max(1, mb)) {
+  const int L = params.nlevels;
+  const double sf = (double)params.scale_factor;  // the reference stores scaleFactor as double (ORBextractor.h:84)
+  scale.assign(L, 1.f); inv_scale.assign(L, 1.f); sigma2.assign(L, 1.f); inv_sigma2.assign(L, 1.f); nfeat.assign(L, 0);
+  for (int i = 1; i < L; i++) {
+    scale[i] = (float)(scale[i - 1] * sf);
+    sigma2[i] = scale[i] * scale[i];
+  }
+  for (int i = 0; i < L; i++) {
+    inv_scale[i] = 1.0f / scale[i];
+    inv_sigma2[i] = 1.0f / sigma2[i];
+  }
+  const float factor = (float)(1.0f / sf);
+  float per_scale = params.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+  int sum = 0;
+  for (int l = 0; l < L - 1; l++) {
+    nfeat[l] = cv_round_f(per_scale);
+    sum += nfeat[l];
+    per_scale *= factor;
+  }
+  nfeat[L - 1] = std::max(params.nfeatures - sum, 0);
+  // umax, :320-338
+  const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+  const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+  std::fill(umax, umax + 16, 0);
+  for (int v = 0; v <= vmax; ++v) umax[v] = (int)std::nearbyint(std::sqrt((double)kHalfPatch * kHalfPatch - v * v));
+  for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+    while (umax[v0] == umax[v0 + 1]) ++v0;
+    umax[v] = v0;
+    ++v0;
+  }
+}
+
+OrbPipeline::~OrbPipeline() {
+  if (stream) hipStreamSynchronize(stream);
+  free_all();
+  if (d_stage) hipFree(d_stage);
+  if (h_stage) hipHostFree(h_stage);
+  if (stream) hipStreamDestroy(stream);
+}
+
+int OrbPipeline::init() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible (libdvmslam_hip has no CPU path)");
+    return DVM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("device index out of range");
+    return DVM_ERR_INVALID;
+  }
+  DVM_HIP(hipSetDevice(device));
+  DVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  // orientation disc offsets (any order: the moments are exact integer sums)
+  int8_t du[kDiscPixels], dv[kDiscPixels];
+  int n = 0;
+  for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+    const int d = umax[std::abs(v)];
+    for (int u = -d; u <= d; u++) { du[n] = (int8_t)u; dv[n] = (int8_t)v; n++; }
+  }
+  if (n != kDiscPixels) { set_error("disc size mismatch"); return DVM_ERR_STATE; }
+  // 8.8 fixed-point Gaussian kernel, ksize 7, sigma 2 (OpenCV getGaussianKernelFixedPoint_ED)
+  int g7[7];
+  {
+    double k[7], s = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3.0; k[i] = std::exp(-0.5 / 4.0 * x * x); s += k[i]; }
+    double err = 0; long long acc = 0;
+    for (int i = 0; i < 3; i++) {
+      double adj = k[i] * (1.0 / s) * 256.0 + err;
+      long long v = (long long)std::nearbyint(adj);
+      err = adj - (double)v;
+      g7[i] = g7[6 - i] = (int)v;
+      acc += v;
+    }
+    g7[3] = (int)(256 - 2 * acc);
+  }
+  upload_constants(du, dv, g7);
+  DVM_HIP(hipGetLastError());
+  DVM_HIP(hipDeviceSynchronize());
+  return DVM_OK;
+}
+
+void OrbPipeline::free_all() {
+  void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_start, d_sel, d_nsel,
+                   d_kps, d_desc, d_aux, d_n, d_mono};
+  for (void* p : dptrs) if (p) hipFree(p);
+  void* hptrs[] = {h_lvl_start, h_dense, h_sel, h_nsel, h_n, h_mono};
+  for (void* p : hptrs) if (p) hipHostFree(p);
+  d_pyr = d_blur = d_desc = nullptr; d_tabs = nullptr; d_cells = nullptr; d_tiles = nullptr;
+  d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_start = d_nsel = d_n = d_mono = nullptr;
+  d_kps = nullptr; d_aux = nullptr;
+  h_lvl_start = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
+  configured = false;  // (the host-image staging buffers d_stage/h_stage live until the destructor)
+}
+
+// cv::resize INTER_LINEAR coefficient tables for one axis (OpenCV resize.cpp, 11-bit weights)
+static void resize_axis_tables(int ssize, int dsize, bool clamp_like_x, std::vector<int32_t>& ofs, std::vector<int32_t>& wts) {
+  const double inv_scale = (double)dsize / ssize;
+  const double sc = 1. / inv_scale;
+  ofs.resize(dsize);
+  wts.resize(dsize);
+  for (int d = 0; d < dsize; d++) {
+    float f = (float)((d + 0.5) * sc - 0.5);
+    int s = (int)std::floor(f);
+    f -= s;
+    if (clamp_like_x) {  // x axis: offsets are clamped and the fraction zeroed at the borders
+      if (s < 0) { f = 0; s = 0; }
+      if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+    }
+    auto sat = [](float v) { int i = (int)std::nearbyintf(v); return std::min(std::max(i, -32768), 32767); };
+    const int w0 = sat((1.f - f) * 2048), w1 = sat(f * 2048);
+    ofs[d] = s;
+    wts[d] = (int32_t)((uint32_t)(uint16_t)(int16_t)w0 | ((uint32_t)(uint16_t)(int16_t)w1 << 16));
+  }
+}
+
+int OrbPipeline::configure(int rows, int cols) {
+  if (configured && PD.rows == rows && PD.cols == cols) return DVM_OK;
+  if (stream) hipStreamSynchronize(stream);
+  free_all();
+  const int L = params.nlevels;
+  if (L < 1 || L > kMaxLevels) { set_error("nlevels out of range"); return DVM_ERR_INVALID; }
+  if (cols + 2 * kEdge > 4095 || rows + 2 * kEdge > 4095) { set_error("image larger than 4057 px unsupported"); return DVM_ERR_INVALID; }
+  std::memset(&PD, 0, sizeof(PD));
+  PD.nlevels = L; PD.rows = rows; PD.cols = cols;
+  PD.ini_th = std::min(std::max(params.ini_th_fast, 0), 255);
+  PD.min_th = std::min(std::max(params.min_th_fast, 0), 255);
+  cells.clear(); tiles.clear();
+  std::vector<int32_t> tabs;
+  int pyr_off = 0, blur_off = 0, cand_off = 0, sel_off = 0;
+  for (int l = 0; l < L; l++) {
+    LevelDesc& D = PD.lv[l];
+    D.w = cv_round_f((float)cols * inv_scale[l]);   // ORBextractor.cc:959-960
+    D.h = cv_round_f((float)rows * inv_scale[l]);
+    if (D.w < 1 || D.h < 1) { set_error("pyramid level collapses to zero size"); return DVM_ERR_INVALID; }
+    D.stride = align_up(D.w + 2 * kEdge, 64);
+    D.pyr_off = pyr_off;
+    pyr_off += align_up(D.stride * (D.h + 2 * kEdge), 256);
+    D.blur_stride = align_up(D.w, 64);
+    D.blur_off = blur_off;
+    blur_off += align_up(D.blur_stride * D.h, 256);
+    D.scale = scale[l];
+    D.patch_size = (int)(31 * scale[l]);  // :700
+    D.quota = nfeat[l];
+    D.sel_off = sel_off;
+    D.sel_cap = std::max(nfeat[l], 1) + 4;
+    sel_off += D.sel_cap;
+    if (l > 0) {
+      std::vector<int32_t> xo, xa, yo, yb;
+      resize_axis_tables(PD.lv[l - 1].w, D.w, true, xo, xa);
+      resize_axis_tables(PD.lv[l - 1].h, D.h, false, yo, yb);
+      D.tab_off = (int)tabs.size();
+      tabs.insert(tabs.end(), xo.begin(), xo.end());
+      tabs.insert(tabs.end(), xa.begin(), xa.end());
+      tabs.insert(tabs.end(), yo.begin(), yo.end());
+      tabs.insert(tabs.end(), yb.begin(), yb.end());
+    }
+    // FAST cells, ORBextractor.cc:617-650
+    D.cell_first = (int)cells.size();
+    D.cand_off = cand_off;
+    const int minBX = kEdge - 3, minBY = minBX, maxBX = D.w - kEdge + 3, maxBY = D.h - kEdge + 3;
+    const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+    const float W = 35;
+    const int nCols = (int)(width / W), nRows = (int)(height / W);
+    if (nCols > 0 && nRows > 0) {
+      const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBY - 3) continue;
+        if (maxY > maxBY) maxY = (float)maxBY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = (float)(minBX + j * wCell);
+          float maxX = iniX + wCell + 6;
+          if (iniX >= maxBX - 6) continue;
+          if (maxX > maxBX) maxX = (float)maxBX;
+          CellDesc c{};
+          c.level = (int16_t)l;
+          c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
+          c.rw = (int16_t)((int)maxX - (int)iniX); c.rh = (int16_t)((int)maxY - (int)iniY);
+          if (c.rw > kMaxCellDim || c.rh > kMaxCellDim) { set_error("FAST cell larger than supported"); return DVM_ERR_INVALID; }
+          const int ew = std::max(c.rw - 6, 0), eh = std::max(c.rh - 6, 0);
+          c.cand_cap = ((ew + 1) / 2) * ((eh + 1) / 2);  // strict local maxima cannot be 8-adjacent
+          c.cand_base = cand_off;
+          cand_off += c.cand_cap;
+          cells.push_back(c);
+        }
+      }
+    }
+    D.cell_count = (int)cells.size() - D.cell_first;
+    D.cand_cap = cand_off - D.cand_off;
+    for (int y = 0; y < D.h; y += 32)
+      for (int x = 0; x < D.w; x += 64) tiles.push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
+  }
+  PD.ncells = (int)cells.size();
+  PD.ntiles = (int)tiles.size();
+  PD.pyr_frame_bytes = pyr_off;
+  PD.blur_frame_bytes = blur_off;
+  PD.cand_frame_slots = std::max(cand_off, 1);
+  PD.sel_frame_slots = sel_off;
+  PD.kp_cap = sel_off;
+  const size_t B = (size_t)max_batch;
+  DVM_HIP(hipMalloc(&d_pyr, B * PD.pyr_frame_bytes));
+  DVM_HIP(hipMalloc(&d_blur, B * PD.blur_frame_bytes));
+  DVM_HIP(hipMalloc(&d_tabs, std::max<size_t>(tabs.size(), 1) * 4));
+  DVM_HIP(hipMalloc(&d_cells, std::max<size_t>(cells.size(), 1) * sizeof(CellDesc)));
+  DVM_HIP(hipMalloc(&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc)));
+  DVM_HIP(hipMalloc(&d_cand, B * PD.cand_frame_slots * 4));
+  DVM_HIP(hipMalloc(&d_dense, B * PD.cand_frame_slots * 4));
+  DVM_HIP(hipMalloc(&d_cell_count, B * std::max(PD.ncells, 1) * 4));
+  DVM_HIP(hipMalloc(&d_lvl_start, B * (kMaxLevels + 1) * 4));
+  DVM_HIP(hipMalloc(&d_sel, B * PD.sel_frame_slots * 4));
+  DVM_HIP(hipMalloc(&d_nsel, B * L * 4));
+  DVM_HIP(hipMalloc(&d_kps, B * PD.kp_cap * sizeof(dvm_keypoint_pod)));
+  DVM_HIP(hipMalloc(&d_desc, B * PD.kp_cap * 32));
+  DVM_HIP(hipMalloc(&d_aux, B * PD.kp_cap * sizeof(KpAux)));
+  DVM_HIP(hipMalloc(&d_n, B * 4));
+  DVM_HIP(hipMalloc(&d_mono, B * 4));
+  DVM_HIP(hipHostMalloc(&h_lvl_start, B * (kMaxLevels + 1) * 4));
+  DVM_HIP(hipHostMalloc(&h_dense, B * PD.cand_frame_slots * 4));
+  DVM_HIP(hipHostMalloc(&h_sel, B * PD.sel_frame_slots * 4));
+  DVM_HIP(hipHostMalloc(&h_nsel, B * L * 4));
+  DVM_HIP(hipHostMalloc(&h_n, B * 4));
+  DVM_HIP(hipHostMalloc(&h_mono, B * 4));
+  if (!tabs.empty()) DVM_HIP(hipMemcpy(d_tabs, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice));
+  if (!cells.empty()) DVM_HIP(hipMemcpy(d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+  if (!tiles.empty()) DVM_HIP(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  // the blurred images are read up to 18 px around a keypoint only; clear once so debug dumps are defined
+  DVM_HIP(hipMemset(d_blur, 0, B * PD.blur_frame_bytes));
+  DVM_HIP(hipMemset(d_pyr, 0, B * PD.pyr_frame_bytes));
+  // the handle's stream is non-blocking: null-stream memsets/copies above must land before it runs
+  DVM_HIP(hipDeviceSynchronize());
+  configured = true;
+  return DVM_OK;
+}
+
+int OrbPipeline::extract_host(const uint8_t* imgs, int batch, int rows, int cols, int stride, int64_t frame_stride,
+                              int lap0, int lap1) {
+  if (!imgs || rows <= 0 || cols <= 0) return DVM_ERR_EMPTY;
+  if (batch < 1 || batch > max_batch || stride < cols) { set_error("bad batch/stride"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(device));
+  const size_t need = (size_t)batch * rows * cols;
+  if (need > stage_bytes) {
+    if (stream) hipStreamSynchronize(stream);
+    if (d_stage) hipFree(d_stage);
+    if (h_stage) hipHostFree(h_stage);
+    d_stage = nullptr; h_stage = nullptr;
+    DVM_HIP(hipMalloc(&d_stage, need));
+    DVM_HIP(hipHostMalloc(&h_stage, need));
+    stage_bytes = need;
+  }
+  DVM_HIP(hipStreamSynchronize(stream));  // staging buffer reuse
+  for (int f = 0; f < batch; f++)
+    for (int y = 0; y < rows; y++)
+      std::memcpy(h_stage + ((size_t)f * rows + y) * cols, imgs + (size_t)f * frame_stride + (size_t)y * stride, cols);
+  DVM_HIP(hipMemcpyAsync(d_stage, h_stage, need, hipMemcpyHostToDevice, stream));
+  return extract_device(d_stage, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
+}
+
+int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int cols, int stride, int64_t frame_stride,
+                                int lap0, int lap1) {
+  if (!d_imgs || rows <= 0 || cols <= 0) return DVM_ERR_EMPTY;
+  if (batch < 1 || batch > max_batch || stride < cols) { set_error("bad batch/stride"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(device));
+  int rc = configure(rows, cols);
+  if (rc != DVM_OK) return rc;
+  const int L = PD.nlevels;
+  last_batch = batch;
+
+  prof.begin(stream, "pyramid");
+  launch_pyr_level0(stream, d_imgs, rows, cols, stride, frame_stride, d_pyr, PD, batch);
+  for (int l = 1; l < L; l++) launch_pyr_resize(stream, d_pyr, PD, l, d_tabs, batch);
+  prof.end(stream);
+  prof.begin(stream, "fast");
+  launch_fast(stream, d_pyr, d_cells, PD, d_cand, d_cell_count, batch);
+  prof.end(stream);
+  prof.begin(stream, "compact");
+  launch_compact(stream, d_cand, d_cell_count, d_cells, PD, d_dense, d_lvl_start, batch);
+  prof.end(stream);
+
+  // ---- DistributeOctTree on the host (K3): counts, then each frame's dense candidate prefix
+  DVM_HIP(hipMemcpyAsync(h_lvl_start, d_lvl_start, (size_t)batch * (kMaxLevels + 1) * 4, hipMemcpyDeviceToHost, stream));
+  DVM_HIP(hipStreamSynchronize(stream));
+  for (int f = 0; f < batch; f++) {
+    const int total = h_lvl_start[f * (kMaxLevels + 1) + L];
+    if (total > 0)
+      DVM_HIP(hipMemcpyAsync(h_dense + (size_t)f * PD.cand_frame_slots, d_dense + (size_t)f * PD.cand_frame_slots,
+                             (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+  }
+  DVM_HIP(hipStreamSynchronize(stream));
+  {
+    const int jobs = batch * L;
+    const int nthreads = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), std::min(jobs / 4, 16)));
+    auto work = [&](int t) {
+      std::vector<uint32_t> out;
+      for (int j = t; j < jobs; j += nthreads) {
+        const int f = j / L, l = j % L;
+        const int32_t* ls = h_lvl_start + f * (kMaxLevels + 1);
+        const LevelDesc& D = PD.lv[l];
+        octree_select(h_dense + (size_t)f * PD.cand_frame_slots + ls[l], ls[l + 1] - ls[l], kEdge - 3, D.w - kEdge + 3,
+                      kEdge - 3, D.h - kEdge + 3, D.quota, out);
+        const int n = std::min<int>((int)out.size(), D.sel_cap);
+        h_nsel[f * L + l] = n;
+        std::memcpy(h_sel + (size_t)f * PD.sel_frame_slots + D.sel_off, out.data(), (size_t)n * 4);
+      }
+    };
+    if (nthreads == 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+      for (auto& t : th) t.join();
+    }
+  }
+  DVM_HIP(hipMemcpyAsync(d_nsel, h_nsel, (size_t)batch * L * 4, hipMemcpyHostToDevice, stream));
+  DVM_HIP(hipMemcpyAsync(d_sel, h_sel, (size_t)batch * PD.sel_frame_slots * 4, hipMemcpyHostToDevice, stream));
+
+  prof.begin(stream, "assemble");
+  launch_assemble(stream, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono, batch);
+  prof.end(stream);
+  prof.begin(stream, "blur");
+  launch_blur(stream, d_pyr, d_blur, d_tiles, PD, d_nsel, batch);
+  prof.end(stream);
+  prof.begin(stream, "orient_desc");
+  launch_orient_desc(stream, d_pyr, d_blur, PD, d_aux, d_n, d_kps, d_desc, batch);
+  prof.end(stream);
+  DVM_HIP(hipGetLastError());
+  return DVM_OK;
+}
+
+int OrbPipeline::sync() {
+  DVM_HIP(hipSetDevice(device));
+  DVM_HIP(hipStreamSynchronize(stream));
+  prof.resolve();
+  return DVM_OK;
+}
+
+int OrbPipeline::download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono) {
+  if (!configured || frame < 0 || frame >= last_batch) { set_error("no results for that frame"); return DVM_ERR_STATE; }
+  DVM_HIP(hipSetDevice(device));
+  DVM_HIP(hipMemcpyAsync(h_n, d_n, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
+  DVM_HIP(hipMemcpyAsync(h_mono, d_mono, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
+  int rc = sync();
+  if (rc != DVM_OK) return rc;
+  const int N = h_n[frame];
+  if (n) *n = N;
+  if (mono) *mono = h_mono[frame];
+  if (N > cap) { set_error("keypoint buffer too small"); return DVM_ERR_CAPACITY; }
+  if (N > 0) {
+    if (kps) DVM_HIP(hipMemcpy(kps, d_kps + (size_t)frame * PD.kp_cap, (size_t)N * sizeof(dvm_keypoint), hipMemcpyDeviceToHost));
+    if (desc) DVM_HIP(hipMemcpy(desc, d_desc + (size_t)frame * PD.kp_cap * 32, (size_t)N * 32, hipMemcpyDeviceToHost));
+  }
+  return DVM_OK;
+}
+
+}  // namespace dvm

@@ -1,0 +1,104 @@
+// dvm_slam_amd/csrc/orb_pipeline.h -- host side of the ORB extractor (handle behind dvm_orb_*).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dvmslam_hip.h"
+#include "orb_device.h"
+#include "orb_kernels.h"
+
+namespace dvm {
+
+void set_error(const std::string& msg);
+int hip_check(hipError_t e, const char* what);
+#define DVM_HIP(call)                                  \
+  do {                                                 \
+    int _rc = ::dvm::hip_check((call), #call);         \
+    if (_rc != DVM_OK) return _rc;                     \
+  } while (0)
+
+// HIP-event stopwatch: one (start, stop) pair per timed launch group on the owning stream.
+class Profiler {
+ public:
+  bool enabled = false;
+  void begin(hipStream_t s, const char* name);
+  void end(hipStream_t s);
+  void resolve();  // after a stream sync: fold finished pairs into the totals
+  void reset();
+  bool get(const std::string& name, double* ms, int64_t* launches);
+  ~Profiler();
+
+ private:
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> pending_;
+  std::vector<hipEvent_t> pool_;
+  std::map<std::string, std::pair<double, int64_t>> totals_;
+  hipEvent_t get_event();
+};
+
+// DistributeOctTree (reference ORBextractor.cc:419-610) on the host: array formulation, see .cpp
+void octree_select(const uint32_t* cand, int n, int minX, int maxX, int minY, int maxY, int N, std::vector<uint32_t>& out);
+
+class OrbPipeline {
+ public:
+  OrbPipeline(const dvm_orb_params& p, int device, int max_batch);
+  ~OrbPipeline();
+  int init();  // device + stream + constants
+  int extract_device(const uint8_t* d_imgs, int batch, int rows, int cols, int stride, int64_t frame_stride, int lap0,
+                     int lap1);
+  int extract_host(const uint8_t* imgs, int batch, int rows, int cols, int stride, int64_t frame_stride, int lap0,
+                   int lap1);
+  int sync();
+  int download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono);
+
+  dvm_orb_params params;
+  int device, max_batch;
+  hipStream_t stream = nullptr;
+  Profiler prof;
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> nfeat;
+  int umax[16];
+
+  PipelineDesc PD{};
+  std::vector<CellDesc> cells;
+  std::vector<TileDesc> tiles;
+  int last_batch = 0;
+  bool configured = false;
+
+  // device memory
+  uint8_t* d_pyr = nullptr;
+  uint8_t* d_blur = nullptr;
+  int32_t* d_tabs = nullptr;
+  CellDesc* d_cells = nullptr;
+  TileDesc* d_tiles = nullptr;
+  uint32_t* d_cand = nullptr;        // cell-slotted
+  uint32_t* d_dense = nullptr;       // per-frame dense, level-major
+  int32_t* d_cell_count = nullptr;
+  int32_t* d_lvl_start = nullptr;    // [batch][kMaxLevels+1]
+  uint32_t* d_sel = nullptr;         // [batch][sel_frame_slots]
+  int32_t* d_nsel = nullptr;         // [batch][nlevels]
+  dvm_keypoint_pod* d_kps = nullptr; // [batch][kp_cap]
+  uint8_t* d_desc = nullptr;         // [batch][kp_cap][32]
+  KpAux* d_aux = nullptr;
+  int32_t* d_n = nullptr;            // [batch]
+  int32_t* d_mono = nullptr;
+  uint8_t* d_stage = nullptr;        // staging for host images
+  size_t stage_bytes = 0;
+  // pinned host mirrors
+  int32_t* h_lvl_start = nullptr;
+  uint32_t* h_dense = nullptr;
+  uint32_t* h_sel = nullptr;
+  int32_t* h_nsel = nullptr;
+  int32_t* h_n = nullptr;
+  int32_t* h_mono = nullptr;
+  uint8_t* h_stage = nullptr;
+
+ private:
+  int configure(int rows, int cols);
+  void free_all();
+};
+
+}  // namespace dvm

@@ -1,0 +1,169 @@
+/*
+ * include/dvmslam_hip.h -- C ABI of libdvmslam_hip.so: the MI355X (gfx950) implementation of the
+ * per-agent visual-SLAM hot path of proroklab/DVM-SLAM (ORB front end, Hamming matching, bundle
+ * adjustment).  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Reference interface replaced (all under /root/reference/src/slam_system/orb_slam3/):
+ *   dvm_orb_*      <- class ORBextractor            include/ORBextractor.h:47-91, src/ORBextractor.cc:282-976
+ *   dvm_frame_*    <- Frame grid members            include/Frame.h:44-45,221-251, src/Frame.cc:443-506,712-782
+ *   dvm_hamming_*  <- ORBmatcher::DescriptorDistance include/ORBmatcher.h:44, src/ORBmatcher.cc:1900-1914
+ *   dvm_match_*    <- inner loops of ORBmatcher::SearchByProjection / SearchForInitialization
+ *                                                    src/ORBmatcher.cc:44-205,605-707,1553-1748
+ *   dvm_ba_*       <- Optimizer::{BundleAdjustment,LocalBundleAdjustment} + g2o BlockSolver_6_3/LM
+ *                                                    src/Optimizer.cc:55-356,1030-1387
+ *   dvm_pose_optimize <- Optimizer::PoseOptimization src/Optimizer.cc:744-1028
+ * The reference has no FFI: these classes live inside static libORB_SLAM3.a.  INTEGRATION.md shows
+ * the C++ shim classes (same names / signatures) a maintainer links instead.
+ *
+ * Conventions: every function returns DVM_OK (0) or a negative dvm_status; nothing throws across
+ * the boundary.  A handle owns one HIP stream and all of its device memory; handles are not
+ * thread-safe (one per calling thread, like the reference's ORBextractor instance per Tracking).
+ * Pointers named d_* are DEVICE pointers (HBM), all others are host pointers.
+ */
+#ifndef DVMSLAM_HIP_H
+#define DVMSLAM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DVM_OK = 0,
+  DVM_ERR_INVALID = -1,    /* bad argument */
+  DVM_ERR_EMPTY = -2,      /* empty image: the reference's operator() returns -1 (ORBextractor.cc:879-880) */
+  DVM_ERR_CAPACITY = -3,   /* caller buffer too small */
+  DVM_ERR_HIP = -4,        /* HIP runtime error (see dvm_last_error) */
+  DVM_ERR_NO_DEVICE = -5,  /* no gfx950 device visible: the library never falls back to a CPU path */
+  DVM_ERR_STATE = -6       /* call sequence error */
+} dvm_status;
+
+const char* dvm_last_error(void);
+const char* dvm_version(void);
+/* number of visible HIP devices (0 when none); never fails */
+int dvm_device_count(void);
+
+/* layout-identical to cv::KeyPoint (7 x 4 B): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} dvm_keypoint;
+
+/* ------------------------------------------------------------------------------ ORB extractor */
+/* ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) */
+typedef struct {
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels, ini_th_fast, min_th_fast;
+} dvm_orb_params;
+
+typedef struct dvm_orb dvm_orb;
+
+/* max_batch: frames processed per launch set (>=1).  Device buffers are sized lazily for the first
+ * image size seen and re-sized when it changes. */
+int dvm_orb_create(const dvm_orb_params* p, int device, int max_batch, dvm_orb** out);
+void dvm_orb_destroy(dvm_orb* h);
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares and
+ * mnFeaturesPerLevel; arrays of nlevels entries, any may be NULL */
+int dvm_orb_tables(const dvm_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                   int32_t* nfeat_per_level);
+
+/* operator()(image, mask, keypoints, descriptors, vLappingArea): one host image in, host results
+ * out (synchronous).  *n = number of keypoints, *mono_index = the reference's return value.
+ * desc receives n x 32 bytes.  Returns DVM_ERR_EMPTY for a null / zero-sized image. */
+int dvm_orb_extract(dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
+                    dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+
+/* Batched, device-resident form: `batch` frames of rows x cols at d_imgs + f*frame_stride (bytes),
+ * row pitch `stride`.  Asynchronous on the handle's stream; results stay in HBM until fetched. */
+int dvm_orb_extract_batch_device(dvm_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int stride,
+                                 int64_t frame_stride, int lap0, int lap1);
+/* Same, from host memory (one pinned staging copy + H2D on the handle's stream). */
+int dvm_orb_extract_batch_host(dvm_orb* h, const uint8_t* imgs, int batch, int rows, int cols, int stride,
+                               int64_t frame_stride, int lap0, int lap1);
+/* blocks until the handle's stream is idle */
+int dvm_orb_sync(dvm_orb* h);
+/* device views of frame f's results (valid until the next extract on this handle).  kps are in
+ * the reference's output order; d_n points at the int32 keypoint count of the frame. */
+int dvm_orb_result_device(dvm_orb* h, int frame, const dvm_keypoint** d_kps, const uint8_t** d_desc,
+                          const int32_t** d_n, int* capacity);
+/* device array of mvScaleFactor (nlevels floats) */
+const float* dvm_orb_scale_factors_device(dvm_orb* h);
+/* synchronises, then copies frame f's results to the host */
+int dvm_orb_download(dvm_orb* h, int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+/* mvImagePyramid[level] of frame f: device pointer to pixel (0,0) of the level; the 19-px
+ * REFLECT_101 border is addressable at negative offsets exactly like the reference's ROI Mats */
+int dvm_orb_pyramid(dvm_orb* h, int frame, int level, const uint8_t** d_ptr, int* rows, int* cols, int* stride);
+
+/* stage-wise intermediates of frame f (parity tests; each synchronises) */
+int dvm_orb_debug_level(dvm_orb* h, int frame, int level, int bordered, uint8_t* out /* tight rows */);
+int dvm_orb_debug_blurred(dvm_orb* h, int frame, int level, uint8_t* out);
+int dvm_orb_debug_candidates(dvm_orb* h, int frame, int level, int32_t* xs, int32_t* ys, int32_t* scores,
+                             int cap, int* n);
+int dvm_orb_debug_level_keypoints(dvm_orb* h, int frame, int level, dvm_keypoint* kps, int cap, int* n);
+
+/* per-kernel HIP-event timing on the handle's stream.  names: "pyramid","fast","octree",
+ * "assemble","blur","orient_desc","grid_sort","match" ...  Returns accumulated milliseconds and launch count since
+ * the last reset. */
+int dvm_orb_profiling(dvm_orb* h, int enable);
+int dvm_orb_profile_get(dvm_orb* h, const char* name, double* total_ms, int64_t* launches);
+int dvm_orb_profile_reset(dvm_orb* h);
+/* the handle's hipStream_t (so callers can order their own work / events against it) */
+void* dvm_orb_stream(dvm_orb* h);
+
+/* ----------------------------------------------------------------------------------- matching */
+/* DescriptorDistance for all pairs: D[i*nB+j] = popcount(A[i]^B[j]) over 256 bits (uint16).
+ * on_device != 0: A, B, D are device pointers and the call is asynchronous on `stream`
+ * (hipStream_t, may be NULL for the default stream); otherwise host pointers, synchronous. */
+int dvm_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D, int on_device, void* stream);
+
+/* Frame feature grid (FRAME_GRID_COLS=64 x FRAME_GRID_ROWS=48) + windowed best/second-best search.
+ * A dvm_frame holds `slots` frames' undistorted keypoints + descriptors in HBM, each ordered the
+ * way Frame::GetFeaturesInArea enumerates them, so ties resolve exactly like the reference's loops.
+ * capacity <= 8192 keypoints per slot. */
+typedef struct dvm_frame dvm_frame;
+int dvm_frame_create(int device, int capacity, int slots, dvm_frame** out);
+void dvm_frame_destroy(dvm_frame* f);
+/* (Re)build slot `slot` from n keypoints + descriptors; on_device selects pointer kind; d_n (device
+ * int32*, may be NULL, only with on_device) overrides n with a device-side count.  Bounds are
+ * Frame::mnMinX/mnMaxX/mnMinY/mnMaxY (0,cols,0,rows when undistorted) and apply to all slots.
+ * Asynchronous on `stream` when on_device (host pointers: synchronous). */
+int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, const int32_t* d_n,
+                    float minX, float maxX, float minY, float maxY, int on_device, void* stream);
+/* Build slots [first_slot, first_slot+count) from device arrays d_kps + i*kps_stride (elements),
+ * d_desc + i*desc_stride (bytes), counts d_n[i] -- the layout dvm_orb_result_device exposes. */
+int dvm_frame_build_batch(dvm_frame* f, int first_slot, int count, const dvm_keypoint* d_kps, int64_t kps_stride,
+                          const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n, float minX, float maxX,
+                          float minY, float maxY, void* stream);
+
+typedef struct {
+  int32_t best_idx;     /* index into the slot's ORIGINAL keypoint order, -1 if no candidate */
+  int32_t best_dist;    /* 256 if none */
+  int32_t second_dist;  /* 256 if none */
+  int16_t best_level, second_level; /* octaves of best / second best, -1 if none */
+} dvm_match;
+
+/* For each query q: scan Frame::GetFeaturesInArea(qx,qy,qr,qmin,qmax) of train slot `slot`
+ * (skipping indices with skip[idx]!=0, skip may be NULL) and return best / second best by
+ * DescriptorDistance with the reference's strict-'<' first-wins tie rule.  Query arrays: qdesc
+ * nq x 32 B, qx/qy/qr float, qmin/qmax int32 (-1 = unbounded, as in the reference).  d_nq (device
+ * int32*, may be NULL) overrides nq.  All pointers are device pointers when on_device != 0
+ * (asynchronous on `stream`), else host pointers (synchronous). */
+int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                     const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
+                     const int32_t* d_nq, dvm_match* out, int on_device, void* stream);
+
+/* TrackWithMotionModel-style frame-to-frame search over a batch (ORBmatcher.cc:1596-1611, mono):
+ * pair i (0 <= i < count) searches train slot first_slot+i for every keypoint of frame i-1 of the
+ * device arrays (d_kps + (i-1)*kps_stride, ...); pair 0 takes its queries from the carry frame
+ * (d_carry_*, may be NULL: pair 0 then yields 0 matches).  Window th*scale[octave], octaves
+ * [o-1,o+1].  d_out + i*out_stride receives `cap` dvm_match per pair, d_nq_out[i] the query count. */
+int dvm_match_frames_batch(const dvm_frame* train, int first_slot, int count, const dvm_keypoint* d_kps,
+                           int64_t kps_stride, const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n,
+                           const dvm_keypoint* d_carry_kps, const uint8_t* d_carry_desc, const int32_t* d_carry_n,
+                           int cap, float th, const float* d_scale_factors, int nlevels, dvm_match* d_out,
+                           int64_t out_stride, int32_t* d_nq_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
