@@ -47,6 +47,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); dvm_slam_amd has no CPU implementation")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname as
+    # /opt/rocm's).  Whichever is loaded first serves both; loading torch AFTER us would pull a second
+    # runtime in and neither would see the GPU.  So when torch is importable, import it first.
+    if os.environ.get("DVM_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.dvm_last_error.restype = C.c_char_p

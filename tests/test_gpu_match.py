@@ -1,0 +1,142 @@
+"""GPU parity: Hamming / grid-window matching kernels (through the C ABI) vs the CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (37, 1001), (1000, 1000), (3, 2048)])
+def test_hamming_matrix(capi, oracle, na, nb):
+    rng = np.random.default_rng(na * 7 + nb)
+    A = rng.integers(0, 256, (na, 32), dtype=np.uint8)
+    B = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+    B[: min(na, nb)] = A[: min(na, nb)]  # exact zeros on the diagonal
+    D = capi.hamming_matrix(A, B)
+    assert np.array_equal(D, oracle.hamming_matrix(A, B))
+    assert D[0, 0] == 0
+    # identity: popcount(a^b) via numpy unpackbits
+    ref = np.unpackbits(A[:, None, :] ^ B[None, : min(nb, 64), :], axis=2).sum(axis=2)
+    assert np.array_equal(D[:, : min(nb, 64)], ref)
+
+
+def test_hamming_empty(capi):
+    D = capi.hamming_matrix(np.zeros((0, 32), np.uint8), np.zeros((5, 32), np.uint8))
+    assert D.shape == (0, 5)
+
+
+def _check_matches(g, o):
+    for k in ("best_idx", "best_dist", "second_dist", "best_level", "second_level"):
+        assert np.array_equal(g[k].astype(np.int64), o[k].astype(np.int64)), k
+
+
+def test_match_window_vs_oracle(capi, oracle, frames):
+    orc = oracle.OrbOracle()
+    _, k0, d0, _ = orc.extract(frames[0])
+    _, k1, d1, _ = orc.extract(frames[1])
+    grid_g = capi.FrameGrid(capacity=2048)
+    grid_g.build(k1, d1)
+    grid_o = oracle.Grid(k1)
+    scale = orc.tables()["scale"]
+    # TrackWithMotionModel-style queries (ORBmatcher.cc:1596-1611): th=15, octaves [o-1, o+1]
+    qx, qy = k0["x"], k0["y"]
+    qr = (np.float32(15) * scale[k0["octave"]]).astype(np.float32)
+    qmin, qmax = k0["octave"] - 1, k0["octave"] + 1
+    _check_matches(grid_g.match_window(d0, qx, qy, qr, qmin, qmax), grid_o.match_window(d1, d0, qx, qy, qr, qmin, qmax))
+    # SearchByProjection(F, mappoints)-style: levels [l-1, l], radius 2.5/4 * scale
+    qr2 = (np.float32(4.0) * scale[k0["octave"]]).astype(np.float32)
+    _check_matches(grid_g.match_window(d0, qx, qy, qr2, k0["octave"] - 1, k0["octave"]),
+                   grid_o.match_window(d1, d0, qx, qy, qr2, k0["octave"] - 1, k0["octave"]))
+    # random windows incl. out-of-image centres, huge / tiny radii, unbounded levels, a skip mask
+    rng = np.random.default_rng(3)
+    nq = 700
+    qd = d0[rng.integers(0, len(d0), nq)]
+    qx = rng.uniform(-80, 720, nq).astype(np.float32)
+    qy = rng.uniform(-80, 560, nq).astype(np.float32)
+    qr = rng.choice([0.5, 3, 15, 50, 100, 1000], nq).astype(np.float32)
+    qmin = rng.integers(-1, 8, nq).astype(np.int32)
+    qmax = rng.integers(-1, 8, nq).astype(np.int32)
+    skip = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+    _check_matches(grid_g.match_window(qd, qx, qy, qr, qmin, qmax, skip=skip),
+                   grid_o.match_window(d1, qd, qx, qy, qr, qmin, qmax, skip=skip))
+    grid_g.close()
+
+
+def test_match_window_ties(capi, oracle):
+    """Many identical descriptors: the winner must be the FIRST candidate in GetFeaturesInArea order."""
+    rng = np.random.default_rng(11)
+    n = 1500
+    kps = np.zeros(n, oracle.KP_DTYPE)
+    kps["x"] = rng.uniform(0, 640, n).astype(np.float32)
+    kps["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    base = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+    desc = base[rng.integers(0, 4, n)]            # only 4 distinct descriptors -> ties everywhere
+    grid_g = capi.FrameGrid(capacity=2048)
+    grid_g.build(kps, desc)
+    grid_o = oracle.Grid(kps)
+    nq = 500
+    qd = base[rng.integers(0, 4, nq)]
+    qx = rng.uniform(0, 640, nq).astype(np.float32)
+    qy = rng.uniform(0, 480, nq).astype(np.float32)
+    qr = rng.choice([20, 60, 200], nq).astype(np.float32)
+    neg = np.full(nq, -1, np.int32)
+    _check_matches(grid_g.match_window(qd, qx, qy, qr, neg, neg), grid_o.match_window(desc, qd, qx, qy, qr, neg, neg))
+    grid_g.close()
+
+
+def test_grid_edge_cases(capi, oracle):
+    # empty frame, single keypoint, keypoints outside the grid (dropped by PosInGrid), ragged n
+    for n in (0, 1, 63, 65, 1025):
+        rng = np.random.default_rng(n)
+        kps = np.zeros(n, oracle.KP_DTYPE)
+        kps["x"] = rng.uniform(-5, 645, n).astype(np.float32)  # some round to column 64 -> not indexed
+        kps["y"] = rng.uniform(-5, 485, n).astype(np.float32)
+        kps["octave"] = rng.integers(0, 8, n)
+        desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        g = capi.FrameGrid(capacity=2048)
+        g.build(kps, desc)
+        o = oracle.Grid(kps)
+        nq = 64
+        qd = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        qx = rng.uniform(0, 640, nq).astype(np.float32)
+        qy = rng.uniform(0, 480, nq).astype(np.float32)
+        qr = np.full(nq, 700, np.float32)
+        neg = np.full(nq, -1, np.int32)
+        _check_matches(g.match_window(qd, qx, qy, qr, neg, neg), o.match_window(desc, qd, qx, qy, qr, neg, neg))
+        g.close()
+
+
+def test_match_frames_batch(capi, oracle, frames):
+    """extract(batch) -> grid build (batch) -> frame-to-frame search, all device resident."""
+    import torch
+    B = len(frames)
+    e = capi.OrbExtractor(max_batch=B)
+    e.extract_batch_host(frames)
+    k_ptr, d_ptr, n_ptr, cap = e.result_device(0)
+    grid = capi.FrameGrid(capacity=2048, slots=B)
+    st = e.stream()
+    grid.build_batch_device(0, B, k_ptr, cap, d_ptr, cap * 32, n_ptr, (0.0, 640.0, 0.0, 480.0), stream=st)
+    out = torch.zeros((B, cap, 4), dtype=torch.int32, device="cuda")
+    nq = torch.zeros(B, dtype=torch.int32, device="cuda")
+    grid.match_frames_batch(0, B, k_ptr, cap, d_ptr, cap * 32, n_ptr, None, cap, 15.0, e.scale_factors_device(), 8,
+                            out.data_ptr(), cap, nq.data_ptr(), stream=st)
+    e.sync()
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().view(capi.MATCH_DTYPE).reshape(B, cap)
+    nqh = nq.cpu().numpy()
+    orc = oracle.OrbOracle()
+    scale = orc.tables()["scale"]
+    ext = [orc.extract(f) for f in frames]
+    assert nqh[0] == 0
+    for i in range(1, B):
+        _, kq, dq, _ = ext[i - 1]
+        _, kt, dt, _ = ext[i]
+        assert nqh[i] == len(kq)
+        go = oracle.Grid(kt)
+        ref = go.match_window(dt, dq, kq["x"], kq["y"], (np.float32(15) * scale[kq["octave"]]).astype(np.float32),
+                              kq["octave"] - 1, kq["octave"] + 1)
+        _check_matches(res[i][: len(kq)], ref)
+        # the synthetic stream moves <= 8 px/frame: most keypoints must find a good match
+        assert (ref["best_dist"] <= 50).mean() > 0.5
+    grid.close()
+    e.close()
