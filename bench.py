@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the DVM-SLAM hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+A "step" = one batch of `--batch` synthetic 640x480 frames through the whole front end on one GPU:
+ORB extract (8-level pyramid, per-cell FAST, octree, orientation, blur, rBRIEF, 1000 features) +
+frame-to-frame windowed Hamming matching against the previous frame (M3 rule, th=15).  Inputs are
+resident in HBM before the timed region.  One agent (= one frame stream) per GPU, no data-path
+collective: `value` = frames processed by all ranks / max-over-ranks wall time ("weak" scaling).
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      -- dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration
+  cpu_baseline  -- the CPU oracle (port of the reference path) timed single-threaded on this host
+  ba            -- bundle-adjustment iterations/s (second half of BASELINE.json's metric) when built
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# compulsory stage traffic per 640x480 frame (pyramid materialised)
+BYTES_PER_FRAME_TOTAL = 4_421_474
+BYTES_PER_FRAME_FAST = 950_532  # the FAST stage reads every pyramid pixel once
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step (per GPU)")
+    ap.add_argument("--stream-frames", type=int, default=128, help="distinct synthetic frames resident in HBM")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 = skip)")
+    ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--ba-iters", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(frames: np.ndarray, budget_s: float):
+    """Oracle (CPU port of the reference path), single thread: extract + windowed match per frame."""
+    from oracle import pyoracle as po
+    libpath = None
+    try:  # -march=native copy for this host (the committed build is portable)
+        out = "/tmp/liboracle_native.so"
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", f"OUT={out}", "ARCHFLAGS=-march=native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        libpath = out
+    except Exception:
+        libpath = None
+    orc = po.OrbOracle(libpath=libpath)
+    scale = orc.tables()["scale"]
+    prev = None
+    done = 0
+    t_total = 0.0
+    i = 0
+    while True:
+        f = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        n, k, d, _ = orc.extract(f)
+        if prev is not None:
+            g = po.Grid(k)
+            kq, dq = prev
+            g.match_window(d, dq, kq["x"], kq["y"], (np.float32(15) * scale[kq["octave"]]).astype(np.float32),
+                           kq["octave"] - 1, kq["octave"] + 1)
+        t_total += time.perf_counter() - t0
+        prev = (k, d)
+        done += 1
+        i += 1
+        if t_total >= budget_s or done >= 4096:
+            break
+    return {"value": done / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames of the same synthetic 640x480 stream, extract+match, oracle built "
+                      f"{'-O3 -march=native' if libpath else '-O3 portable'}, {os.cpu_count()} host cores present"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    from dvm_slam_amd import capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    B = a.batch
+    nstream = max(a.stream_frames, B)
+    nstream = (nstream + B - 1) // B * B
+    # every rank is its own agent: a different segment of the camera path
+    frames = synth.frame_stream(nstream, start=rank * nstream)
+    d_frames = torch.from_numpy(frames).cuda()
+    H, W = frames.shape[1:]
+
+    ext = capi.OrbExtractor(max_batch=B, device=local)
+    grid = capi.FrameGrid(capacity=2048, slots=B, device=local)
+    bounds = (0.0, float(W), 0.0, float(H))
+    st = ext.stream()
+
+    # one un-timed call sizes the device buffers
+    ext.extract_batch_device(d_frames.data_ptr(), B, H, W)
+    ext.sync()
+    k_ptr, d_ptr, n_ptr, cap = ext.result_device(0)
+    carry_k = torch.zeros((cap, 7), dtype=torch.int32, device="cuda")
+    carry_d = torch.zeros((cap, 32), dtype=torch.uint8, device="cuda")
+    carry_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    matches = torch.zeros((B, cap, 4), dtype=torch.int32, device="cuda")
+    nq = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_scale = ext.scale_factors_device()
+    nbatches = nstream // B
+
+    def step(i):
+        off = (i % nbatches) * B
+        ext.extract_batch_device(d_frames.data_ptr() + off * H * W, B, H, W)
+        grid.build_batch_device(0, B, k_ptr, cap, d_ptr, cap * 32, n_ptr, bounds, stream=st)
+        grid.match_frames_batch(0, B, k_ptr, cap, d_ptr, cap * 32, n_ptr,
+                                (carry_k.data_ptr(), carry_d.data_ptr(), carry_n.data_ptr()), cap, 15.0, d_scale, 8,
+                                matches.data_ptr(), cap, nq.data_ptr(), stream=st)
+        ext.copy_result(B - 1, carry_k.data_ptr(), carry_d.data_ptr(), carry_n.data_ptr())
+
+    def barrier():
+        ext.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    ext.sync()
+    ext.profiling(True)
+    ext.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ext.profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = {k: ext.profile_get(k) for k in ("pyramid", "fast", "compact", "assemble", "blur", "orient_desc")}
+    nmatched = int((matches[:, :, 1] <= 100).sum().item())  # TH_HIGH gate, sanity only
+
+    if rank == 0:
+        total_frames = world * a.steps * B
+        fast_ms, fast_n = prof["fast"]
+        roof = None
+        if fast_n:
+            per_launch_s = fast_ms / fast_n / 1e3
+            ach = BYTES_PER_FRAME_FAST * B / per_launch_s / 1e9
+            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "bytes_per_launch": BYTES_PER_FRAME_FAST * B, "avg_launch_ms": fast_ms / fast_n,
+                    "all_stage_bytes_per_frame": BYTES_PER_FRAME_TOTAL,
+                    "gpu_kernel_ms_per_step": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}}
+        out = {
+            "metric": "frames/sec ORB extract+match 640x480x8lvl", "value": total_frames / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "single agent tracking front end: 640x480 8-level ORB extract (1000 features) + "
+                                   "frame-to-frame windowed Hamming match, one agent per GPU",
+                       "frames_per_step_per_gpu": B, "nfeatures": 1000, "nlevels": 8, "scale_factor": 1.2,
+                       "ini_th_fast": 20, "min_th_fast": 7, "match": "SearchByProjection(Cur,Last) window th=15",
+                       "parallelism": f"agents{world}"},
+            "roofline": roof, "sanity_matches_le_TH_HIGH_last_step": nmatched,
+        }
+        if a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
+        if not a.no_ba:
+            try:
+                from dvm_slam_amd import ba_bench
+                out["ba"] = ba_bench.run(local, a.ba_iters)
+            except ImportError:
+                out["ba"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

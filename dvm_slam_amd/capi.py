@@ -69,6 +69,7 @@ def lib():
     L.dvm_orb_extract_batch_host.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, i32]
     L.dvm_orb_sync.argtypes = [vp]
     L.dvm_orb_result_device.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.dvm_orb_copy_result.argtypes = [vp, i32, vp, vp, vp]
     L.dvm_orb_scale_factors_device.argtypes = [vp]
     L.dvm_orb_scale_factors_device.restype = vp
     L.dvm_orb_download.argtypes = [vp, i32, vp, vp, i32, vp, vp]
@@ -181,6 +182,9 @@ class OrbExtractor:
         cap = C.c_int(0)
         check(self.L.dvm_orb_result_device(self.h, frame, C.byref(k), C.byref(d), C.byref(n), C.byref(cap)))
         return k.value, d.value, n.value, cap.value
+
+    def copy_result(self, frame, d_kps, d_desc, d_n):
+        check(self.L.dvm_orb_copy_result(self.h, frame, C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_n)))
 
     def scale_factors_device(self):
         return self.L.dvm_orb_scale_factors_device(self.h)

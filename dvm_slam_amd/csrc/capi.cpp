@@ -119,6 +119,15 @@ int dvm_orb_result_device(dvm_orb* h, int frame, const dvm_keypoint** d_kps, con
   if (capacity) *capacity = P.PD.kp_cap;
   return DVM_OK;
 }
+int dvm_orb_copy_result(dvm_orb* h, int frame, dvm_keypoint* d_kps_dst, uint8_t* d_desc_dst, int32_t* d_n_dst) {
+  if (!h || !h->p->configured || frame < 0 || frame >= h->p->max_batch || !d_kps_dst || !d_desc_dst || !d_n_dst) return DVM_ERR_STATE;
+  OrbPipeline& P = *h->p;
+  const size_t cap = (size_t)P.PD.kp_cap;
+  int rc = hip_check(hipMemcpyAsync(d_kps_dst, P.d_kps + (size_t)frame * cap, cap * sizeof(dvm_keypoint), hipMemcpyDeviceToDevice, P.stream), "copy kps");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpyAsync(d_desc_dst, P.d_desc + (size_t)frame * cap * 32, cap * 32, hipMemcpyDeviceToDevice, P.stream), "copy desc");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpyAsync(d_n_dst, P.d_n + frame, 4, hipMemcpyDeviceToDevice, P.stream), "copy n");
+  return rc;
+}
 const float* dvm_orb_scale_factors_device(dvm_orb* h) { return h ? h->d_scale : nullptr; }
 int dvm_orb_download(dvm_orb* h, int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index) {
   if (!h) return DVM_ERR_INVALID;

@@ -86,6 +86,10 @@ int dvm_orb_sync(dvm_orb* h);
  * the reference's output order; d_n points at the int32 keypoint count of the frame. */
 int dvm_orb_result_device(dvm_orb* h, int frame, const dvm_keypoint** d_kps, const uint8_t** d_desc,
                           const int32_t** d_n, int* capacity);
+/* asynchronous device-to-device copy (on the handle's stream) of frame f's keypoints, descriptors
+ * and count into caller-owned device buffers (capacity as reported by dvm_orb_result_device) --
+ * used to carry the last frame of a batch over to the next batch's frame-to-frame search */
+int dvm_orb_copy_result(dvm_orb* h, int frame, dvm_keypoint* d_kps_dst, uint8_t* d_desc_dst, int32_t* d_n_dst);
 /* device array of mvScaleFactor (nlevels floats) */
 const float* dvm_orb_scale_factors_device(dvm_orb* h);
 /* synchronises, then copies frame f's results to the host */
