@@ -36,6 +36,21 @@ class OrbParams(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+BA_EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", "<f8"), ("inv_sigma2", "<f8")])
+
+
+class BaCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("stop_reason", C.c_int32), ("pad", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("trials_per_iter", C.c_int32 * 64), ("chi2_per_iter", C.c_double * 64),
+                ("lambda_per_iter", C.c_double * 64), ("ms_structure", C.c_double), ("ms_optimize", C.c_double)]
+
+
 _LIB = None
 
 
@@ -92,6 +107,15 @@ def lib():
     L.dvm_match_window.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     L.dvm_match_frames_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, f32, vp, i32, vp, i64,
                                          vp, vp]
+    L.dvm_ba_create.argtypes = [i32, C.POINTER(vp)]
+    L.dvm_ba_destroy.argtypes = [vp]
+    L.dvm_ba_destroy.restype = None
+    L.dvm_ba_set_problem.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, C.POINTER(BaCamera)]
+    L.dvm_ba_optimize.argtypes = [vp, i32, vp, C.POINTER(BaStats)]
+    L.dvm_ba_get_result.argtypes = [vp, vp, vp]
+    L.dvm_ba_edge_chi2.argtypes = [vp, vp, vp]
+    L.dvm_ba_stream.argtypes = [vp]
+    L.dvm_ba_stream.restype = vp
     _LIB = L
     return L
 
@@ -289,3 +313,59 @@ class FrameGrid:
                                             desc_stride, C.c_void_p(d_n), C.c_void_p(ck), C.c_void_p(cd), C.c_void_p(cn),
                                             cap, th, C.c_void_p(d_scale), nlevels, C.c_void_p(d_out), out_stride,
                                             C.c_void_p(d_nq_out or 0), C.c_void_p(stream or 0)))
+
+
+def make_edges(edge_pose, edge_point, obs, inv_sigma2) -> np.ndarray:
+    e = np.zeros(len(edge_pose), BA_EDGE_DTYPE)
+    e["pose"], e["point"] = edge_pose, edge_point
+    e["u"], e["v"] = obs[:, 0], obs[:, 1]
+    e["inv_sigma2"] = inv_sigma2
+    return e
+
+
+class BundleAdjuster:
+    """Optimizer::BundleAdjustment / LocalBundleAdjustment numerics (reference Optimizer.cc:55-356,1030-1387)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        check(self.L.dvm_ba_create(device, C.byref(self.h)))
+        self.P = self.Lm = self.E = 0
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.dvm_ba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_problem(self, poses, fixed, points, edges, intrinsics, huber_delta):
+        poses = np.ascontiguousarray(poses, np.float64)
+        points = np.ascontiguousarray(points, np.float64)
+        fixed = np.ascontiguousarray(fixed, np.uint8)
+        edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+        cam = BaCamera(*[float(v) for v in intrinsics], float(huber_delta))
+        self.P, self.Lm, self.E = len(poses), len(points), len(edges)
+        check(self.L.dvm_ba_set_problem(self.h, _p(poses), _p(fixed), self.P, _p(points), self.Lm, _p(edges), self.E,
+                                        C.byref(cam)))
+
+    def optimize(self, iterations, stop_flag=None):
+        st = BaStats()
+        check(self.L.dvm_ba_optimize(self.h, iterations, _p(stop_flag) if stop_flag is not None else None, C.byref(st)))
+        n = min(st.iterations, 64)
+        return dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason,
+                    chi2_initial=st.chi2_initial, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
+                    trials=list(st.trials_per_iter[:n]), chi2=list(st.chi2_per_iter[:n]), lam=list(st.lambda_per_iter[:n]),
+                    ms_structure=st.ms_structure, ms_optimize=st.ms_optimize)
+
+    def result(self):
+        poses = np.zeros((self.P, 7), np.float64)
+        points = np.zeros((self.Lm, 3), np.float64)
+        check(self.L.dvm_ba_get_result(self.h, _p(poses), _p(points)))
+        return poses, points
+
+    def edge_chi2(self):
+        chi = np.zeros(self.E, np.float64)
+        dp = np.zeros(self.E, np.uint8)
+        check(self.L.dvm_ba_edge_chi2(self.h, _p(chi), _p(dp)))
+        return chi, dp

@@ -1,0 +1,50 @@
+// dvm_slam_amd/csrc/ba_kernels.h -- device view + launchers of the FP64 bundle-adjustment kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+namespace dvm {
+
+constexpr int kEdgeLinStride = 24;  // doubles per edge: A[6] B[12] w wr0 wr1 + pad
+
+// Structure-of-arrays problem state in HBM (DESIGN.md "BA layout").  Poses are (t, q_xyzw) doubles.
+struct BaView {
+  int32_t P, L, E, nfree, nblk, ldS;
+  double fx, fy, cx, cy, delta;
+  double* poses;            // [P][7]
+  double* points;           // [L][3]
+  const int32_t* pidx;      // [P] free index or -1
+  const int32_t* free_pose; // [nfree] pose index
+  const int32_t* e_pose;    // [E]
+  const int32_t* e_point;   // [E]
+  const double* e_obs;      // [E][2]
+  const double* e_info;     // [E]
+  double* e_chi2;           // [E] chi2 at the last evaluation (what g2o's e->chi2() reports)
+  double* e_lin;            // [E][kEdgeLinStride]
+  double* e_W;              // [E][18]  Hpl block (pose 6 x point 3)
+  const int32_t* pt_start;  // [L+1] CSR landmark -> edges (input order)
+  const int32_t* pt_edges;  // [E]
+  const int32_t* ps_start;  // [P+1] CSR camera -> edges
+  const int32_t* ps_edges;  // [E]
+  double *Hpp, *bp;         // [nfree][36], [nfree*6]
+  double *Hll, *bl;         // [L][9], [L][3]
+  double *Dinv, *db;        // [L][9], [L][3]
+  const int32_t *blk_i1, *blk_i2, *blk_start;  // non-zero lower blocks of the reduced camera matrix
+  const int32_t *pair_k1, *pair_k2;            // per block: (edge of i1, edge of i2) sharing a landmark
+  double* S;                // [ldS][ldS] dense lower triangle + augmented rhs row
+  double* Ldiag;            // [64*64] scratch for the factored diagonal block
+  double* ytmp;             // [6*nfree]
+  double* x;                // [6*nfree + 3*L]
+  double *partial, *partial2;
+};
+
+void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, double* d_scalars, int slot);
+void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot_maxdiag);
+void ba_launch_schur(hipStream_t s, const BaView& V, double lambda);
+void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail);
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, double lambda, double* d_scalars, int slot_scale);
+void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
+
+}  // namespace dvm

@@ -1,0 +1,633 @@
+// dvm_slam_amd/csrc/ba_kernels.hip -- FP64 bundle-adjustment kernels for gfx950.
+//
+// One Levenberg-Marquardt iteration of the reference's BA (g2o BlockSolver_6_3 + Levenberg,
+// reference Thirdparty/g2o/g2o/core/{block_solver.hpp,optimization_algorithm_levenberg.cpp},
+// src/Optimizer.cc:55-356,1030-1387, src/OptimizableTypes.cpp:136-155, src/CameraModels/Pinhole.cpp):
+//   K8  k_edge_eval            per-edge residual, Huber weight, 2x3 / 2x6 Jacobians, Hpl block
+//       k_point_accum          Hll (3x3), bl per landmark       (gather over the landmark's edges)
+//       k_pose_accum           Hpp (6x6), bp per camera         (one wave per camera, fixed-order reduce)
+//   K9  k_dinv, k_schur_blocks Dinv = (Hll+lambda I)^-1 ; Hschur block = Hpp - sum W Dinv W^T
+//       k_schur_rhs            bschur = bp - sum W Dinv bl  (stored as the augmented row of S)
+//   K10 k_chol_panel / k_chol_update   blocked dense Cholesky, trailing update on v_mfma_f64_16x16x4
+//       k_chol_backsolve       L^T x = y
+//   K11 k_point_backsub, k_update      xl = Dinv (bl - W^T xp); T <- exp(d) T, X <- X + d
+// All accumulations are gathers with a fixed order: results are run-to-run deterministic.
+#include <hip/hip_runtime.h>
+
+#include "ba_kernels.h"
+
+namespace dvm {
+
+// ------------------------------------------------------------------------------- small algebra
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void R_to_quat(const double* R, double* q) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+}
+__device__ __forceinline__ void quat_normalize(double* q) {
+  if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__device__ __forceinline__ void mat3_vec(const double* R, const double* v, double* o) {
+  o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+
+// Huber (robust_kernel_impl.cpp:68-81); delta <= 0 means "no robust kernel"
+__device__ __forceinline__ void robustify(double e, double delta, double& rho0, double& rho1) {
+  if (delta <= 0 || e <= delta * delta) { rho0 = e; rho1 = 1.; }
+  else { const double s = sqrt(e); rho0 = 2 * s * delta - delta * delta; rho1 = delta / s; }
+}
+
+// ------------------------------------------------------------------------------------------ K8
+// JAC=false: residual / chi2 only (computeActiveErrors + activeRobustChi2 terms).
+// JAC=true : additionally Jacobians A (2x3, point), B (2x6, pose), weights and Hpl block W (6x3).
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_edge_eval(BaView V) {
+  __shared__ double s_part[256];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  double rho0 = 0;
+  if (k < V.E) {
+    const int p = V.e_pose[k], l = V.e_point[k];
+    const double* T = V.poses + 7 * (size_t)p;
+    const double* X = V.points + 3 * (size_t)l;
+    double R[9], Xc[3];
+    quat_to_R(T + 3, R);
+    mat3_vec(R, X, Xc);
+    Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
+    const double x = Xc[0], y = Xc[1], z = Xc[2];
+    const double info = V.e_info[k];
+    const double e0 = V.e_obs[2 * (size_t)k] - (V.fx * x / z + V.cx);
+    const double e1 = V.e_obs[2 * (size_t)k + 1] - (V.fy * y / z + V.cy);
+    const double chi2 = e0 * info * e0 + e1 * info * e1;
+    V.e_chi2[k] = chi2;
+    double rho1;
+    robustify(chi2, V.delta, rho0, rho1);
+    if (JAC) {
+      const double J[6] = {-(V.fx / z), 0, V.fx * x / (z * z), 0, -(V.fy / z), V.fy * y / (z * z)};
+      double A[6], B[12];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[3 * r + c] = J[3 * r] * R[c] + J[3 * r + 1] * R[3 + c] + J[3 * r + 2] * R[6 + c];
+      const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
+      const double w = rho1 * info;
+      const double wr0 = -info * e0 * rho1, wr1 = -info * e1 * rho1;
+      double* out = V.e_lin + (size_t)k * kEdgeLinStride;
+#pragma unroll
+      for (int i = 0; i < 6; i++) out[i] = A[i];
+#pragma unroll
+      for (int i = 0; i < 12; i++) out[6 + i] = B[i];
+      out[18] = w; out[19] = wr0; out[20] = wr1;
+      double* W = V.e_W + (size_t)k * 18;
+      const bool pose_free = V.pidx[p] >= 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) W[3 * a + b] = pose_free ? w * (B[a] * A[b] + B[6 + a] * A[3 + b]) : 0.0;
+    }
+  }
+  // fixed-order block reduction of rho0 -> partial[blockIdx.x]
+  s_part[threadIdx.x] = rho0;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) V.partial[blockIdx.x] = s_part[0];
+}
+
+// Sum `n` partials in a fixed order into out[slot]; single workgroup.
+__global__ void __launch_bounds__(256) k_reduce_sum(const double* __restrict__ partial, int n, double* __restrict__ out, int slot) {
+  __shared__ double s[256];
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[slot] = s[0];
+}
+
+// Hll (3x3) and bl per landmark: thread per landmark, edges in input order.
+__global__ void __launch_bounds__(256) k_point_accum(BaView V) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= V.L) return;
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int i = V.pt_start[l]; i < V.pt_start[l + 1]; i++) {
+    const double* lin = V.e_lin + (size_t)V.pt_edges[i] * kEdgeLinStride;
+    const double w = lin[18], wr0 = lin[19], wr1 = lin[20];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      b[a] += lin[a] * wr0 + lin[3 + a] * wr1;
+#pragma unroll
+      for (int c = 0; c < 3; c++) H[3 * a + c] += w * (lin[a] * lin[c] + lin[3 + a] * lin[3 + c]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) V.Hll[9 * (size_t)l + i] = H[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) V.bl[3 * (size_t)l + i] = b[i];
+}
+
+// Hpp (6x6) and bp per free camera: one wave per camera, lanes stride over the camera's edges, then a
+// fixed-order xor-butterfly reduction (identical on every run).
+__global__ void __launch_bounds__(256) k_pose_accum(BaView V) {
+  const int lane = threadIdx.x & 63;
+  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (fi >= V.nfree) return;
+  const int p = V.free_pose[fi];
+  double H[21], b[6];
+#pragma unroll
+  for (int i = 0; i < 21; i++) H[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) b[i] = 0;
+  for (int i = V.ps_start[p] + lane; i < V.ps_start[p + 1]; i += 64) {
+    const double* lin = V.e_lin + (size_t)V.ps_edges[i] * kEdgeLinStride;
+    const double* B = lin + 6;
+    const double w = lin[18], wr0 = lin[19], wr1 = lin[20];
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      b[a] += B[a] * wr0 + B[6 + a] * wr1;
+#pragma unroll
+      for (int c = 0; c <= a; c++) H[t++] += w * (B[a] * B[c] + B[6 + a] * B[6 + c]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) H[i] += __shfl_xor(H[i], off);
+#pragma unroll
+    for (int i = 0; i < 6; i++) b[i] += __shfl_xor(b[i], off);
+  }
+  if (lane == 0) {
+    double* out = V.Hpp + 36 * (size_t)fi;
+    int t = 0;
+    for (int a = 0; a < 6; a++)
+      for (int c = 0; c <= a; c++) { out[6 * a + c] = H[t]; out[6 * c + a] = H[t]; t++; }
+    for (int a = 0; a < 6; a++) V.bp[6 * (size_t)fi + a] = b[a];
+  }
+}
+
+// max |diag| over Hpp and Hll -> out[slot] (computeLambdaInit); single workgroup.
+__global__ void __launch_bounds__(256) k_max_diag(BaView V, double* out, int slot) {
+  __shared__ double s[256];
+  double m = 0;
+  for (int i = threadIdx.x; i < V.nfree * 6; i += 256) m = fmax(m, fabs(V.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+  for (int i = threadIdx.x; i < V.L * 3; i += 256)
+    if (V.pt_start[i / 3 + 1] > V.pt_start[i / 3]) m = fmax(m, fabs(V.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+  s[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[slot] = s[0];
+}
+
+// ------------------------------------------------------------------------------------------ K9
+__global__ void __launch_bounds__(256) k_dinv(BaView V, double lambda) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= V.L) return;
+  if (V.pt_start[l + 1] == V.pt_start[l]) return;  // landmark without observation: not a vertex of the graph
+  const double* H = V.Hll + 9 * (size_t)l;
+  const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3], e = H[4] + lambda, f = H[5], g = H[6], h = H[7], i = H[8] + lambda;
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  const double id = 1.0 / det;
+  double* D = V.Dinv + 9 * (size_t)l;
+  D[0] = (e * i - f * h) * id; D[1] = (c * h - b * i) * id; D[2] = (b * f - c * e) * id;
+  D[3] = (f * g - d * i) * id; D[4] = (a * i - c * g) * id; D[5] = (c * d - a * f) * id;
+  D[6] = (d * h - e * g) * id; D[7] = (b * g - a * h) * id; D[8] = (a * e - b * d) * id;
+  const double* bl = V.bl + 3 * (size_t)l;
+  double* db = V.db + 3 * (size_t)l;
+  db[0] = D[0] * bl[0] + D[1] * bl[1] + D[2] * bl[2];
+  db[1] = D[3] * bl[0] + D[4] * bl[1] + D[5] * bl[2];
+  db[2] = D[6] * bl[0] + D[7] * bl[1] + D[8] * bl[2];
+}
+
+// One wave per non-zero lower block (i1 >= i2) of the reduced camera matrix:
+//   S[i1,i2] = Hpp[i1] (+lambda I) if i1 == i2  -  sum over co-observed landmarks of W1 Dinv W2^T
+// `pairs` lists (edge of pose i1, edge of pose i2) per block (symbolic structure built once on host).
+__global__ void __launch_bounds__(256) k_schur_blocks(BaView V, double lambda) {
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= V.nblk) return;
+  const int i1 = V.blk_i1[blk], i2 = V.blk_i2[blk];
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; i++) acc[i] = 0;
+  for (int t = V.blk_start[blk] + lane; t < V.blk_start[blk + 1]; t += 64) {
+    const int k1 = V.pair_k1[t], k2 = V.pair_k2[t];
+    const double* W1 = V.e_W + (size_t)k1 * 18;
+    const double* W2 = V.e_W + (size_t)k2 * 18;
+    const double* D = V.Dinv + 9 * (size_t)V.e_point[k1];
+    double WD[18];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) WD[3 * a + b] = W1[3 * a] * D[b] + W1[3 * a + 1] * D[3 + b] + W1[3 * a + 2] * D[6 + b];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[6 * a + b] += WD[3 * a] * W2[3 * b] + WD[3 * a + 1] * W2[3 * b + 1] + WD[3 * a + 2] * W2[3 * b + 2];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], off);
+  if (lane < 36) {
+    const int a = lane / 6, b = lane % 6;
+    double v = 0;
+#pragma unroll
+    for (int i = 0; i < 36; i++) if (i == lane) v = acc[i];
+    v = -v;
+    if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + lane] + (a == b ? lambda : 0.0);
+    V.S[(size_t)(6 * i1 + a) * V.ldS + 6 * i2 + b] = v;
+  }
+}
+
+// bschur[i] = bp[i] - sum_{edges k of camera i} W_k (Dinv bl)_{point(k)}  -> augmented row n of S.
+__global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
+  const int lane = threadIdx.x & 63;
+  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (fi >= V.nfree) return;
+  const int p = V.free_pose[fi];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = V.ps_start[p] + lane; i < V.ps_start[p + 1]; i += 64) {
+    const int k = V.ps_edges[i];
+    const double* W = V.e_W + (size_t)k * 18;
+    const double* db = V.db + 3 * (size_t)V.e_point[k];
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[a] += W[3 * a] * db[0] + W[3 * a + 1] * db[1] + W[3 * a + 2] * db[2];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[a] += __shfl_xor(acc[a], off);
+  if (lane == 0) {
+    const int n = 6 * V.nfree;
+    for (int a = 0; a < 6; a++) V.S[(size_t)n * V.ldS + 6 * fi + a] = V.bp[6 * (size_t)fi + a] - acc[a];
+    if (fi == 0) V.S[(size_t)n * V.ldS + n] = 1e200;  // augmented corner: keeps the last pivot positive
+  }
+}
+
+// ----------------------------------------------------------------------------------------- K10
+// Blocked right-looking Cholesky of the lower triangle of S (row-major, leading dim ldS), NB = 64,
+// over n1 = 6*nfree + 1 rows: the extra row carries bschur^T, so after the factorisation row n holds
+// y^T with L y = bschur (forward substitution for free).
+//
+// Panel step kb: every workgroup factors the 64x64 diagonal block in LDS (redundantly: same latency
+// as a separate launch, one launch fewer), then solves its own 64-row strip X L_kk^T = A_ik.
+constexpr int NB = 64;
+__global__ void __launch_bounds__(256) k_chol_panel(double* __restrict__ S, int ldS, int n1, int kb, int* __restrict__ fail,
+                                                    double* __restrict__ Ldiag) {
+  __shared__ double Lkk[NB][NB + 1];
+  __shared__ double strip[NB][NB + 1];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  const int k0 = kb * NB;
+  const int kw = min(NB, n1 - k0);  // columns of this panel
+  if (tid == 0) s_fail = 0;
+  for (int i = tid; i < NB * NB; i += 256) {
+    int r = i / NB, c = i % NB;
+    Lkk[r][c] = (r < kw && c <= r) ? S[(size_t)(k0 + r) * ldS + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  // unblocked Cholesky of Lkk (lower), column by column
+  for (int j = 0; j < kw; j++) {
+    if (tid == 0) {
+      double d = Lkk[j][j];
+      if (!(d > 0)) { s_fail = 1; d = 1.0; }
+      Lkk[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    const double djj = Lkk[j][j];
+    for (int r = j + 1 + tid; r < kw; r += 256) Lkk[r][j] /= djj;
+    __syncthreads();
+    // trailing update of the block: A[r][c] -= L[r][j] L[c][j], j < c <= r
+    const int m = kw - j - 1;
+    for (int i = tid; i < m * m; i += 256) {
+      int r = j + 1 + i / m, c = j + 1 + i % m;
+      if (c <= r) Lkk[r][c] -= Lkk[r][j] * Lkk[c][j];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    // The other workgroups are still reading the un-factored block from S: park the factor in Ldiag
+    // (k_chol_update's first workgroup moves it into S); with no strip below, write S directly.
+    for (int i = tid; i < NB * NB; i += 256) {
+      int r = i / NB, c = i % NB;
+      if (gridDim.x == 1) { if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Lkk[r][c]; }
+      else Ldiag[i] = Lkk[r][c];
+    }
+    if (tid == 0 && s_fail) *fail = 1;
+    return;
+  }
+  // strip rows [r0, r0+rw)
+  const int r0 = k0 + NB + (blockIdx.x - 1) * NB;
+  const int rw = min(NB, n1 - r0);
+  if (rw <= 0) return;
+  for (int i = tid; i < NB * NB; i += 256) {
+    int r = i / NB, c = i % NB;
+    strip[r][c] = (r < rw && c < kw) ? S[(size_t)(r0 + r) * ldS + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  // X L^T = A  ->  for column c: X[r][c] = (A[r][c] - sum_{t<c} X[r][t] L[c][t]) / L[c][c]; one thread per row
+  if (tid < rw) {
+    for (int c = 0; c < kw; c++) {
+      double s = strip[tid][c];
+      for (int t = 0; t < c; t++) s -= strip[tid][t] * Lkk[c][t];
+      strip[tid][c] = s / Lkk[c][c];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NB * NB; i += 256) {
+    int r = i / NB, c = i % NB;
+    if (r < rw && c < kw) S[(size_t)(r0 + r) * ldS + k0 + c] = strip[r][c];
+  }
+}
+
+// Trailing update A_ij -= A_ik A_jk^T for 64x64 tiles i >= j > kb.  blockIdx.x enumerates the lower
+// triangle of tiles.  4 waves, each owning a 32x32 quadrant = 2x2 MFMA tiles of
+// v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
+// C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg).
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1, int kb,
+                                                     const double* __restrict__ Ldiag) {
+  __shared__ double Ai[NB][NB + 1];
+  __shared__ double Aj[NB][NB + 1];
+  if (blockIdx.x == 0) {  // move the factored diagonal block of this step into S (nobody reads it here)
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+      int r = i / NB, c = i % NB;
+      if (kb * NB + r < n1 && c <= r) S[(size_t)(kb * NB + r) * ldS + kb * NB + c] = Ldiag[i];
+    }
+  }
+  // decode (ti, tj), ti >= tj, from the linear lower-triangle index
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+  while (ti * (ti + 1) / 2 > t) ti--;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int k0 = kb * NB;
+  const int i0 = k0 + NB + ti * NB, j0 = k0 + NB + tj * NB;
+  const int iw = min(NB, n1 - i0), jw = min(NB, n1 - j0);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NB * NB; i += 256) {
+    int r = i / NB, c = i % NB;
+    Ai[r][c] = (r < iw) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
+    Aj[r][c] = (r < jw) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
+  if (ti == tj && qj > qi) return;  // strictly upper quadrant of a diagonal tile
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = (double4_t){0, 0, 0, 0};
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+  for (int k = 0; k < NB; k += 4) {
+    double a0 = Ai[qi + lr][k + lk], a1 = Ai[qi + 16 + lr][k + lk];
+    double b0 = Aj[qj + lr][k + lk], b1 = Aj[qj + 16 + lr][k + lk];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = qi + 16 * a + (lane >> 4) + 4 * r, col = qj + 16 * b + (lane & 15);
+        if (row < iw && col < jw && (i0 + row) >= (j0 + col)) S[(size_t)(i0 + row) * ldS + j0 + col] -= acc[a][b][r];
+      }
+}
+
+// Backward substitution L^T x = y, y = row n of S (in place in `x`).  Step kb (descending): every
+// workgroup solves the kb-th 64-block x_k = L_kk^-T y_k redundantly; workgroup 0 stores it, workgroup
+// j+1 (j < kb) applies y_j -= L[kblock, jblock]^T x_k.
+__global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ S, int ldS, int n, int kb,
+                                                       double* __restrict__ y, double* __restrict__ x) {
+  __shared__ double xk[NB];
+  __shared__ double Lkk[NB][NB + 1];
+  const int tid = threadIdx.x;
+  const int k0 = kb * NB;
+  const int kw = min(NB, n - k0);
+  for (int i = tid; i < NB * NB; i += 64) {
+    int r = i / NB, c = i % NB;
+    Lkk[r][c] = (r < kw && c <= r) ? S[(size_t)(k0 + r) * ldS + k0 + c] : 0.0;
+  }
+  if (tid < NB) xk[tid] = (tid < kw) ? y[k0 + tid] : 0.0;  // y_k is final: only blocks j < kb are updated below
+  __syncthreads();
+  if (tid == 0) {
+    for (int c = kw - 1; c >= 0; c--) {
+      double s = xk[c];
+      for (int r = c + 1; r < kw; r++) s -= Lkk[r][c] * xk[r];
+      xk[c] = s / Lkk[c][c];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid < kw) x[k0 + tid] = xk[tid];
+    return;
+  }
+  const int j0 = (blockIdx.x - 1) * NB;  // j < kb
+  // y_j[c] -= sum_r L[k0+r][j0+c] * xk[r]
+  double s = 0;
+  for (int r = 0; r < kw; r++) s += S[(size_t)(k0 + r) * ldS + j0 + tid] * xk[r];
+  y[j0 + tid] -= s;
+}
+
+__global__ void __launch_bounds__(256) k_copy_rhs_row(const double* __restrict__ S, int ldS, int n, double* __restrict__ x) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = S[(size_t)n * ldS + i];
+}
+
+// ----------------------------------------------------------------------------------------- K11
+// xl = Dinv (bl - sum_k W_k^T xp[pose(k)])   (block_solver.hpp:459-483); thread per landmark.
+__global__ void __launch_bounds__(256) k_point_backsub(BaView V) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= V.L) return;
+  const int n = 6 * V.nfree;
+  double* xl = V.x + n + 3 * (size_t)l;
+  if (V.pt_start[l + 1] == V.pt_start[l]) { xl[0] = xl[1] = xl[2] = 0; return; }
+  double c[3] = {V.bl[3 * (size_t)l], V.bl[3 * (size_t)l + 1], V.bl[3 * (size_t)l + 2]};
+  for (int i = V.pt_start[l]; i < V.pt_start[l + 1]; i++) {
+    const int k = V.pt_edges[i];
+    const int fi = V.pidx[V.e_pose[k]];
+    if (fi < 0) continue;
+    const double* W = V.e_W + (size_t)k * 18;
+    const double* xp = V.x + 6 * (size_t)fi;
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+      for (int a = 0; a < 6; a++) c[b] -= W[3 * a + b] * xp[a];
+  }
+  const double* D = V.Dinv + 9 * (size_t)l;
+  xl[0] = D[0] * c[0] + D[1] * c[1] + D[2] * c[2];
+  xl[1] = D[3] * c[0] + D[4] * c[1] + D[5] * c[2];
+  xl[2] = D[6] * c[0] + D[7] * c[1] + D[8] * c[2];
+}
+
+// oplus: cameras T <- exp(dx) T (se3quat.h:212-240, types_six_dof_expmap.h:71-74), landmarks X += dx;
+// also the per-thread terms of computeScale = sum x (lambda x + b), reduced like k_edge_eval.
+__global__ void __launch_bounds__(256) k_update(BaView V, double lambda) {
+  __shared__ double s_part[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = 6 * V.nfree;
+  double sc = 0;
+  if (i < V.nfree) {
+    const int p = V.free_pose[i];
+    const double* u = V.x + 6 * (size_t)i;
+    const double* b = V.bp + 6 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 6; a++) sc += u[a] * (lambda * u[a] + b[a]);
+    double* T = V.poses + 7 * (size_t)p;
+    const double om0 = u[0], om1 = u[1], om2 = u[2];
+    const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+    const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+    double O2[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) O2[3 * r + c] = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
+    double R[9], Vm[9];
+    if (theta < 0.00001) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) { R[k] = ((k % 4 == 0) ? 1.0 : 0.0) + O[k] + O2[k]; Vm[k] = R[k]; }
+    } else {
+      const double a = sin(theta) / theta, bb = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const double I = (k % 4 == 0) ? 1.0 : 0.0;
+        R[k] = I + a * O[k] + bb * O2[k];
+        Vm[k] = I + bb * O[k] + c * O2[k];
+      }
+    }
+    double dq[4], dt[3], Rd[9], rt[3], nq[4];
+    R_to_quat(R, dq);
+    quat_normalize(dq);
+    mat3_vec(Vm, u + 3, dt);
+    quat_to_R(dq, Rd);
+    mat3_vec(Rd, T, rt);
+    const double* q = T + 3;
+    nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+    nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+    nq[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
+    nq[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
+    quat_normalize(nq);
+    T[0] = dt[0] + rt[0]; T[1] = dt[1] + rt[1]; T[2] = dt[2] + rt[2];
+    T[3] = nq[0]; T[4] = nq[1]; T[5] = nq[2]; T[6] = nq[3];
+  }
+  if (i < V.L && V.pt_start[i + 1] > V.pt_start[i]) {
+    const double* u = V.x + n + 3 * (size_t)i;
+    const double* b = V.bl + 3 * (size_t)i;
+    double* X = V.points + 3 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { sc += u[a] * (lambda * u[a] + b[a]); X[a] += u[a]; }
+  }
+  s_part[threadIdx.x] = sc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) V.partial2[blockIdx.x] = s_part[0];
+}
+
+// per-edge depth sign at the current state (EdgeSE3ProjectXYZ::isDepthPositive)
+__global__ void __launch_bounds__(256) k_edge_depth(BaView V, uint8_t* __restrict__ out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= V.E) return;
+  const double* T = V.poses + 7 * (size_t)V.e_pose[k];
+  const double* X = V.points + 3 * (size_t)V.e_point[k];
+  double R[9];
+  quat_to_R(T + 3, R);
+  const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + T[2];
+  out[k] = z > 0.0;
+}
+
+// ------------------------------------------------------------------------------------- launchers
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, double* d_scalars, int slot) {
+  const int nb = cdiv(V.E, 256);
+  if (jac) hipLaunchKernelGGL(k_edge_eval<true>, dim3(nb), dim3(256), 0, s, V);
+  else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, V.partial, nb, d_scalars, slot);
+}
+void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot_maxdiag) {
+  hipLaunchKernelGGL(k_point_accum, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
+  if (V.nfree > 0) hipLaunchKernelGGL(k_pose_accum, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
+  if (slot_maxdiag >= 0) hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, s, V, d_scalars, slot_maxdiag);
+}
+void ba_launch_schur(hipStream_t s, const BaView& V, double lambda) {
+  hipLaunchKernelGGL(k_dinv, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V, lambda);
+  if (V.nfree == 0) return;
+  hipMemsetAsync(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double), s);
+  hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V, lambda);
+  hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
+}
+void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
+  const int n = 6 * V.nfree, n1 = n + 1;
+  if (n == 0) return;
+  const int nkb = cdiv(n1, NB);
+  for (int kb = 0; kb < nkb; kb++) {
+    const int below = cdiv(std::max(n1 - (kb + 1) * NB, 0), NB);
+    hipLaunchKernelGGL(k_chol_panel, dim3(1 + below), dim3(256), 0, s, V.S, V.ldS, n1, kb, d_fail, V.Ldiag);
+    if (below > 0)
+      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.Ldiag);
+  }
+  hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(n, 256)), dim3(256), 0, s, V.S, V.ldS, n, V.ytmp);
+  const int nxb = cdiv(n, NB);
+  for (int kb = nxb - 1; kb >= 0; kb--)
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + kb), dim3(64), 0, s, V.S, V.ldS, n, kb, V.ytmp, V.x);
+}
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, double lambda, double* d_scalars, int slot_scale) {
+  hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
+  const int nb = cdiv(std::max(V.L, V.nfree), 256);
+  hipLaunchKernelGGL(k_update, dim3(nb), dim3(256), 0, s, V, lambda);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, V.partial2, nb, d_scalars, slot_scale);
+}
+void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out) {
+  hipLaunchKernelGGL(k_edge_depth, dim3(cdiv(V.E, 256)), dim3(256), 0, s, V, d_out);
+}
+
+}  // namespace dvm

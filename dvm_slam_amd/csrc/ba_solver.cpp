@@ -1,0 +1,296 @@
+// dvm_slam_amd/csrc/ba_solver.cpp -- host driver of the MI355X bundle adjustment (dvm_ba_* C ABI).
+//
+// Mirrors Optimizer::BundleAdjustment / LocalBundleAdjustment (reference src/Optimizer.cc:55-356,
+// 1030-1387) at the level of "build graph -> optimizer.optimize(n) -> read estimates / chi2 back",
+// with g2o's generic hyper-graph replaced by flat SoA arrays in HBM.  The Levenberg-Marquardt control
+// flow (reference Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:59-165 and
+// sparse_optimizer.cpp:349-412) runs here on the host, one scalar read-back per trial step; every
+// numerical step is a HIP kernel (ba_kernels.hip).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <vector>
+
+#include "../../include/dvmslam_hip.h"
+#include "ba_kernels.h"
+#include "orb_pipeline.h"  // set_error / hip_check / DVM_HIP
+
+using namespace dvm;
+
+struct dvm_ba {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  BaView V{};
+  std::vector<void*> allocs;
+  double* d_scalars = nullptr;   // [8]
+  int* d_fail = nullptr;
+  double* h_scalars = nullptr;   // pinned [8]
+  int* h_fail = nullptr;         // pinned
+  double *d_poses_bak = nullptr, *d_points_bak = nullptr;
+  uint8_t* d_depth = nullptr;
+  bool have_problem = false;
+  double ms_structure = 0;
+
+  template <typename T>
+  int dalloc(T** p, size_t n) {
+    void* q = nullptr;
+    int rc = hip_check(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc(ba)");
+    if (rc == DVM_OK) { allocs.push_back(q); *p = static_cast<T*>(q); }
+    return rc;
+  }
+  template <typename T>
+  int upload(const T** dst, const std::vector<T>& v) {
+    T* p = nullptr;
+    int rc = dalloc(&p, v.size());
+    if (rc == DVM_OK && !v.empty()) rc = hip_check(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "upload");
+    *dst = p;
+    return rc;
+  }
+  void free_problem() {
+    for (void* p : allocs) hipFree(p);
+    allocs.clear();
+    have_problem = false;
+  }
+};
+
+extern "C" {
+
+int dvm_ba_create(int device, dvm_ba** out) {
+  if (!out) return DVM_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { set_error("device index out of range"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(device));
+  dvm_ba* h = new dvm_ba;
+  h->device = device;
+  int rc = hip_check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "stream");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_scalars, 8 * sizeof(double)), "malloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_fail, sizeof(int)), "malloc");
+  if (rc == DVM_OK) rc = hip_check(hipHostMalloc(&h->h_scalars, 8 * sizeof(double)), "hostmalloc");
+  if (rc == DVM_OK) rc = hip_check(hipHostMalloc(&h->h_fail, sizeof(int)), "hostmalloc");
+  if (rc != DVM_OK) { delete h; return rc; }
+  *out = h;
+  return DVM_OK;
+}
+
+void dvm_ba_destroy(dvm_ba* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  h->free_problem();
+  if (h->d_scalars) hipFree(h->d_scalars);
+  if (h->d_fail) hipFree(h->d_fail);
+  if (h->h_scalars) hipHostFree(h->h_scalars);
+  if (h->h_fail) hipHostFree(h->h_fail);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// Graph construction ("buildStructure", block_solver.hpp:143-295): vertex ordering, CSR incidence
+// lists and the block pattern of the reduced camera matrix.  Done once per problem on the host.
+int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
+                       const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam) {
+  if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1) { set_error("dvm_ba_set_problem: bad arguments"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(h->device));
+  DVM_HIP(hipStreamSynchronize(h->stream));
+  h->free_problem();
+  const auto t0 = std::chrono::steady_clock::now();
+  BaView& V = h->V;
+  std::memset(&V, 0, sizeof(V));
+  V.P = P; V.L = L; V.E = E;
+  V.fx = cam->fx; V.fy = cam->fy; V.cx = cam->cx; V.cy = cam->cy; V.delta = cam->huber_delta;
+  std::vector<int32_t> e_pose(E), e_point(E);
+  std::vector<double> e_obs(2 * (size_t)E), e_info(E);
+  std::vector<int32_t> pt_cnt(L + 1, 0), ps_cnt(P + 1, 0);
+  for (int k = 0; k < E; k++) {
+    if (edges[k].pose < 0 || edges[k].pose >= P || edges[k].point < 0 || edges[k].point >= L) { set_error("edge index out of range"); return DVM_ERR_INVALID; }
+    e_pose[k] = edges[k].pose; e_point[k] = edges[k].point;
+    e_obs[2 * (size_t)k] = edges[k].u; e_obs[2 * (size_t)k + 1] = edges[k].v; e_info[k] = edges[k].inv_sigma2;
+    pt_cnt[e_point[k] + 1]++; ps_cnt[e_pose[k] + 1]++;
+  }
+  std::vector<int32_t> pt_start(L + 1, 0), ps_start(P + 1, 0);
+  for (int l = 0; l < L; l++) pt_start[l + 1] = pt_start[l] + pt_cnt[l + 1];
+  for (int p = 0; p < P; p++) ps_start[p + 1] = ps_start[p] + ps_cnt[p + 1];
+  std::vector<int32_t> pt_edges(E), ps_edges(E), pt_fill(pt_start.begin(), pt_start.end() - 1), ps_fill(ps_start.begin(), ps_start.end() - 1);
+  for (int k = 0; k < E; k++) { pt_edges[pt_fill[e_point[k]]++] = k; ps_edges[ps_fill[e_pose[k]]++] = k; }
+  // free cameras in index order (g2o sorts the active vertices by id, sparse_optimizer.cpp:161-185)
+  std::vector<int32_t> pidx(P, -1), free_pose;
+  for (int p = 0; p < P; p++)
+    if (!fixed[p] && ps_cnt[p + 1] > 0) { pidx[p] = (int32_t)free_pose.size(); free_pose.push_back(p); }
+  V.nfree = (int)free_pose.size();
+  // non-zero lower blocks (i1 >= i2) and their (edge, edge) pairs
+  std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> blocks;
+  for (int i = 0; i < V.nfree; i++) blocks[{i, i}];
+  for (int l = 0; l < L; l++)
+    for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
+      const int k1 = pt_edges[a], i1 = pidx[e_pose[k1]];
+      if (i1 < 0) continue;
+      for (int b = pt_start[l]; b < pt_start[l + 1]; b++) {
+        const int k2 = pt_edges[b], i2 = pidx[e_pose[k2]];
+        if (i2 < 0 || i2 > i1) continue;
+        blocks[{i1, i2}].push_back({k1, k2});
+      }
+    }
+  std::vector<int32_t> blk_i1, blk_i2, blk_start{0}, pair_k1, pair_k2;
+  for (auto& kv : blocks) {
+    blk_i1.push_back(kv.first.first); blk_i2.push_back(kv.first.second);
+    for (auto& pr : kv.second) { pair_k1.push_back(pr.first); pair_k2.push_back(pr.second); }
+    blk_start.push_back((int32_t)pair_k1.size());
+  }
+  V.nblk = (int)blk_i1.size();
+  const int n = 6 * V.nfree;
+  V.ldS = (n + 1 + 63) / 64 * 64;
+
+  int rc = DVM_OK;
+  auto ok = [&](int r) { if (rc == DVM_OK) rc = r; };
+  ok(h->dalloc(&V.poses, 7 * (size_t)P)); ok(h->dalloc(&V.points, 3 * (size_t)L));
+  ok(h->dalloc(&h->d_poses_bak, 7 * (size_t)P)); ok(h->dalloc(&h->d_points_bak, 3 * (size_t)L));
+  ok(h->upload(&V.pidx, pidx)); ok(h->upload(&V.free_pose, free_pose));
+  ok(h->upload(&V.e_pose, e_pose)); ok(h->upload(&V.e_point, e_point));
+  ok(h->upload(&V.e_obs, e_obs)); ok(h->upload(&V.e_info, e_info));
+  ok(h->upload(&V.pt_start, pt_start)); ok(h->upload(&V.pt_edges, pt_edges));
+  ok(h->upload(&V.ps_start, ps_start)); ok(h->upload(&V.ps_edges, ps_edges));
+  ok(h->upload(&V.blk_i1, blk_i1)); ok(h->upload(&V.blk_i2, blk_i2)); ok(h->upload(&V.blk_start, blk_start));
+  ok(h->upload(&V.pair_k1, pair_k1)); ok(h->upload(&V.pair_k2, pair_k2));
+  ok(h->dalloc(&V.e_chi2, (size_t)E)); ok(h->dalloc(&V.e_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&V.e_W, (size_t)E * 18));
+  ok(h->dalloc(&V.Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&V.bp, (size_t)n));
+  ok(h->dalloc(&V.Hll, 9 * (size_t)L)); ok(h->dalloc(&V.bl, 3 * (size_t)L));
+  ok(h->dalloc(&V.Dinv, 9 * (size_t)L)); ok(h->dalloc(&V.db, 3 * (size_t)L));
+  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Ldiag, (size_t)64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)n + 64));
+  ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
+  ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(std::max(L, V.nfree) + 255) / 256));
+  ok(h->dalloc(&h->d_depth, (size_t)E));
+  if (rc != DVM_OK) { h->free_problem(); return rc; }
+  // poses: normalise quaternions like SE3Quat's constructor (se3quat.h:261-266)
+  std::vector<double> pn(poses, poses + 7 * (size_t)P);
+  for (int p = 0; p < P; p++) {
+    double* q = &pn[7 * (size_t)p + 3];
+    if (q[3] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
+    const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= nn;
+  }
+  ok(hip_check(hipMemcpy(V.poses, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
+  ok(hip_check(hipMemcpy(V.points, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
+  ok(hip_check(hipMemset(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double)), "memset"));
+  ok(hip_check(hipMemset(V.e_chi2, 0, (size_t)E * sizeof(double)), "memset"));
+  ok(hip_check(hipDeviceSynchronize(), "sync"));
+  if (rc != DVM_OK) { h->free_problem(); return rc; }
+  h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  h->have_problem = true;
+  return DVM_OK;
+}
+
+static int read_scalars(dvm_ba* h) {
+  DVM_HIP(hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  DVM_HIP(hipMemcpyAsync(h->h_fail, h->d_fail, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  DVM_HIP(hipStreamSynchronize(h->stream));
+  return DVM_OK;
+}
+
+// optimizer.optimize(iterations) with OptimizationAlgorithmLevenberg.  stop_flag mirrors g2o's
+// setForceStopFlag(bool*): polled at the top of every iteration and after every trial.
+int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag, dvm_ba_stats* st) {
+  if (!h || !h->have_problem) { set_error("dvm_ba_optimize: no problem set"); return DVM_ERR_STATE; }
+  DVM_HIP(hipSetDevice(h->device));
+  BaView& V = h->V;
+  hipStream_t s = h->stream;
+  const int n = 6 * V.nfree;
+  if (st) { std::memset(st, 0, sizeof(*st)); st->ms_structure = h->ms_structure; }
+  const auto t0 = std::chrono::steady_clock::now();
+  enum { S_CHI = 0, S_TMPCHI = 1, S_SCALE = 2, S_MAXDIAG = 3 };
+  double lambda = -1, ni = 2;
+  int nBad = 0, it_done = 0, trials_total = 0, stop = 0;
+  double chi_last = 0;
+  auto terminate = [&]() { return stop_flag && *stop_flag; };
+  for (int it = 0; it < iterations && !terminate(); it++) {
+    // computeActiveErrors + activeRobustChi2 + buildSystem (one fused edge pass at the current state)
+    ba_launch_edge_eval(s, V, true, h->d_scalars, S_CHI);
+    ba_launch_accum(s, V, h->d_scalars, it == 0 ? S_MAXDIAG : -1);
+    int rc = read_scalars(h);
+    if (rc != DVM_OK) return rc;
+    double currentChi = h->h_scalars[S_CHI], tempChi = currentChi;
+    const double iniChi = currentChi;
+    if (it == 0) {
+      if (st) st->chi2_initial = currentChi;
+      lambda = 1e-5 * h->h_scalars[S_MAXDIAG];  // computeLambdaInit, _tau = 1e-5
+      ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      // push(): keep the state before the trial
+      DVM_HIP(hipMemcpyAsync(h->d_poses_bak, V.poses, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s));
+      DVM_HIP(hipMemcpyAsync(h->d_points_bak, V.points, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s));
+      DVM_HIP(hipMemsetAsync(h->d_fail, 0, sizeof(int), s));
+      ba_launch_schur(s, V, lambda);            // setLambda + Schur complement
+      ba_launch_cholesky_solve(s, V, h->d_fail);  // reduced camera system
+      ba_launch_backsub_update(s, V, lambda, h->d_scalars, S_SCALE);  // landmarks, oplus, computeScale terms
+      ba_launch_edge_eval(s, V, false, h->d_scalars, S_TMPCHI);
+      rc = read_scalars(h);
+      if (rc != DVM_OK) return rc;
+      const bool ok2 = (*h->h_fail == 0);
+      tempChi = ok2 ? h->h_scalars[S_TMPCHI] : std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = ok2 ? h->h_scalars[S_SCALE] : 0.0;
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        DVM_HIP(hipMemcpyAsync(V.poses, h->d_poses_bak, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s));  // pop()
+        DVM_HIP(hipMemcpyAsync(V.points, h->d_points_bak, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s));
+      }
+      qmax++;
+      trials_total++;
+    } while (rho < 0 && qmax < 10 && !terminate());
+    it_done++;
+    chi_last = currentChi;
+    if (st && it < 64) { st->trials_per_iter[it] = qmax; st->chi2_per_iter[it] = currentChi; st->lambda_per_iter[it] = lambda; }
+    if (qmax == 10 || rho == 0) { stop = 1; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { stop = 2; break; }
+  }
+  DVM_HIP(hipStreamSynchronize(s));
+  (void)n;
+  if (st) {
+    st->iterations = it_done; st->total_trials = trials_total; st->stop_reason = stop;
+    st->chi2_final = chi_last; st->lambda_final = lambda;
+    st->ms_optimize = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return DVM_OK;
+}
+
+int dvm_ba_get_result(dvm_ba* h, double* poses, double* points) {
+  if (!h || !h->have_problem) return DVM_ERR_STATE;
+  DVM_HIP(hipSetDevice(h->device));
+  DVM_HIP(hipStreamSynchronize(h->stream));
+  if (poses) DVM_HIP(hipMemcpy(poses, h->V.poses, 7 * (size_t)h->V.P * sizeof(double), hipMemcpyDeviceToHost));
+  if (points) DVM_HIP(hipMemcpy(points, h->V.points, 3 * (size_t)h->V.L * sizeof(double), hipMemcpyDeviceToHost));
+  return DVM_OK;
+}
+
+// e->chi2() of every edge as g2o reports it after optimize() (value at the last error evaluation)
+// and e->isDepthPositive() at the final estimates (Optimizer.cc:1317-1354, :297-312).
+int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive) {
+  if (!h || !h->have_problem) return DVM_ERR_STATE;
+  DVM_HIP(hipSetDevice(h->device));
+  if (depth_positive) ba_launch_edge_depth(h->stream, h->V, h->d_depth);
+  DVM_HIP(hipStreamSynchronize(h->stream));
+  if (chi2) DVM_HIP(hipMemcpy(chi2, h->V.e_chi2, (size_t)h->V.E * sizeof(double), hipMemcpyDeviceToHost));
+  if (depth_positive) DVM_HIP(hipMemcpy(depth_positive, h->d_depth, (size_t)h->V.E, hipMemcpyDeviceToHost));
+  return DVM_OK;
+}
+
+void* dvm_ba_stream(dvm_ba* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

@@ -167,6 +167,35 @@ int dvm_match_frames_batch(const dvm_frame* train, int first_slot, int count, co
                            int cap, float th, const float* d_scale_factors, int nlevels, dvm_match* d_out,
                            int64_t out_stride, int32_t* d_nq_out, void* stream);
 
+/* --------------------------------------------------------------------------- bundle adjustment */
+/* Optimizer::BundleAdjustment / LocalBundleAdjustment (Optimizer.cc:55-356,1030-1387): SE3 camera
+ * vertices (fixed or free), XYZ landmark vertices (all marginalised), one EdgeSE3ProjectXYZ per
+ * observation with information I*inv_sigma2 and an optional Huber kernel, solved by g2o's
+ * BlockSolver_6_3 + Levenberg recipe in FP64.  Cameras are (tx,ty,tz,qx,qy,qz,qw), world->camera. */
+typedef struct { int32_t pose, point; double u, v, inv_sigma2; } dvm_ba_edge;
+typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel (bRobust=false) */ } dvm_ba_camera;
+typedef struct {
+  int32_t iterations, total_trials, stop_reason, pad; /* stop: 0 iteration budget / stop flag, 1 LM terminate, 2 Mur-Artal criterion */
+  double chi2_initial, chi2_final, lambda_final;
+  int32_t trials_per_iter[64];
+  double chi2_per_iter[64], lambda_per_iter[64];
+  double ms_structure, ms_optimize;                   /* host wall time: graph build / optimize() */
+} dvm_ba_stats;
+typedef struct dvm_ba dvm_ba;
+int dvm_ba_create(int device, dvm_ba** out);
+void dvm_ba_destroy(dvm_ba* h);
+/* builds the graph (vertex order, incidence lists, reduced-camera block pattern) and uploads it */
+int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
+                       const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam);
+/* optimizer.optimize(iterations); stop_flag (may be NULL) is g2o's forceStopFlag: polled between
+ * iterations and trials, may be written by another thread (LocalMapping.cc:305,359) */
+int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
+int dvm_ba_get_result(dvm_ba* h, double* poses, double* points);
+/* per-edge chi2() as g2o reports it after optimize(), and isDepthPositive() (outlier tests of
+ * Optimizer.cc:1317-1354); either output may be NULL */
+int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive);
+void* dvm_ba_stream(dvm_ba* h);
+
 #ifdef __cplusplus
 }
 #endif

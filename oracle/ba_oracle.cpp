@@ -1,0 +1,578 @@
+// oracle/ba_oracle.cpp -- CPU restatement of the reference bundle-adjustment numerics (double).
+//
+// TEST INFRASTRUCTURE ONLY (see oracle/oracle.h).  PARITY UNPINNED: the reference's optimizer is
+// vendored g2o + un-vendored Eigen3 (absent here, so the reference cannot be compiled) and no
+// reference test holds a BA result.  This file restates the recipe; it is pinned against an
+// independent numpy/scipy Gauss-Newton/LM implementation in tests/test_oracle_ba.py.
+//
+// Reference files followed (under /root/reference/src/slam_system/orb_slam3/):
+//   src/Optimizer.cc:55-356      BundleAdjustment        (graph: SE3 vertices, XYZ vertices marginalised,
+//   src/Optimizer.cc:1030-1387   LocalBundleAdjustment    EdgeSE3ProjectXYZ, info = I*invSigma2, Huber)
+//   src/Optimizer.cc:744-1028    PoseOptimization        -> orc_pose_optimize
+//   src/OptimizableTypes.cpp:51-63,136-155 / include/OptimizableTypes.h:98-103   error + Jacobians
+//   src/CameraModels/Pinhole.cpp:38-44,69-79              project / projectJac
+//   Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:59-188          LM driver
+//   Thirdparty/g2o/g2o/core/block_solver.hpp:354-486,502-604                     buildSystem/Schur/solve
+//   Thirdparty/g2o/g2o/core/base_binary_edge.hpp:55-116, base_unary_edge.hpp     constructQuadraticForm
+//   Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:68-81                         Huber
+//   Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:61-110,349-427                  errors, chi2, optimize, update
+//   Thirdparty/g2o/g2o/types/se3quat.h:210-266, types_six_dof_expmap.h:71-74     SE3Quat exp/map/oplus
+// The reduced camera system is solved by an envelope (skyline) Cholesky in natural pose order: a
+// sparse direct solve like the reference's Eigen SimplicialLDLT (same solution up to round-off).
+#include "oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+struct Pose { double t[3]; double q[4]; };  // q = (x,y,z,w)
+
+void quat_to_R(const double q[4], double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+void R_to_quat(const double R[9], double q[4]) {  // Eigen's quaternion-from-matrix
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+}
+void quat_normalize(double q[4]) {  // SE3Quat::normalizeRotation, se3quat.h:261-266
+  if (q[3] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
+  double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+void quat_mul(const double a[4], const double b[4], double o[4]) {
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+void mat3_vec(const double R[9], const double v[3], double o[3]) {
+  for (int i = 0; i < 3; i++) o[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+// T <- exp(update) * T, update = (omega, upsilon); se3quat.h:212-240 and operator*
+void pose_oplus(Pose& T, const double u[6]) {
+  const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+  const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  double O2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+  double R[9], V[9];
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) R[i] = I[i] + O[i] + O2[i];
+    std::memcpy(V, R, sizeof(R));
+  } else {
+    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta),
+                 c = (theta - std::sin(theta)) / std::pow(theta, 3);
+    for (int i = 0; i < 9; i++) {
+      R[i] = I[i] + a * O[i] + b * O2[i];
+      V[i] = I[i] + b * O[i] + c * O2[i];
+    }
+  }
+  double dq[4], dt[3];
+  R_to_quat(R, dq);
+  quat_normalize(dq);
+  mat3_vec(V, up, dt);
+  // (dq,dt) * (q,t): r = dq*q ; t = dt + dq*t ; normalize
+  double Rd[9], rt[3], nq[4];
+  quat_to_R(dq, Rd);
+  mat3_vec(Rd, T.t, rt);
+  quat_mul(dq, T.q, nq);
+  for (int i = 0; i < 3; i++) T.t[i] = dt[i] + rt[i];
+  std::memcpy(T.q, nq, sizeof(nq));
+  quat_normalize(T.q);
+}
+
+struct Cam { double fx, fy, cx, cy, delta; };
+
+// error, chi2, Jacobians of one projection edge (OptimizableTypes.cpp:136-155, Pinhole.cpp:38-79)
+struct EdgeLin { double e[2]; double A[6]; double B[12]; double chi2; double Xc[3]; };
+void linearize(const Pose& T, const double X[3], const double obs[2], double info, const Cam& c, EdgeLin& L, bool jac) {
+  double R[9];
+  quat_to_R(T.q, R);
+  double Xc[3];
+  mat3_vec(R, X, Xc);
+  for (int i = 0; i < 3; i++) Xc[i] += T.t[i];
+  std::memcpy(L.Xc, Xc, sizeof(Xc));
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  L.e[0] = obs[0] - (c.fx * x / z + c.cx);
+  L.e[1] = obs[1] - (c.fy * y / z + c.cy);
+  L.chi2 = L.e[0] * info * L.e[0] + L.e[1] * info * L.e[1];
+  if (!jac) return;
+  // -projectJac
+  const double J[6] = {-(c.fx / z), 0, c.fx * x / (z * z), 0, -(c.fy / z), c.fy * y / (z * z)};
+  for (int r = 0; r < 2; r++)
+    for (int k = 0; k < 3; k++) L.A[3 * r + k] = J[3 * r] * R[k] + J[3 * r + 1] * R[3 + k] + J[3 * r + 2] * R[6 + k];
+  const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+  for (int r = 0; r < 2; r++)
+    for (int k = 0; k < 6; k++) L.B[6 * r + k] = J[3 * r] * S[k] + J[3 * r + 1] * S[6 + k] + J[3 * r + 2] * S[12 + k];
+}
+// RobustKernelHuber::robustify, robust_kernel_impl.cpp:68-81; delta <= 0 -> no kernel
+inline void robustify(double e, double delta, double& rho0, double& rho1) {
+  if (delta <= 0 || e <= delta * delta) { rho0 = e; rho1 = 1.; }
+  else { double s = std::sqrt(e); rho0 = 2 * s * delta - delta * delta; rho1 = delta / s; }
+}
+
+bool inv3(const double M[9], double Inv[9]) {
+  const double a = M[0], b = M[1], c = M[2], d = M[3], e = M[4], f = M[5], g = M[6], h = M[7], i = M[8];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  const double id = 1.0 / det;
+  Inv[0] = (e * i - f * h) * id; Inv[1] = (c * h - b * i) * id; Inv[2] = (b * f - c * e) * id;
+  Inv[3] = (f * g - d * i) * id; Inv[4] = (a * i - c * g) * id; Inv[5] = (c * d - a * f) * id;
+  Inv[6] = (d * h - e * g) * id; Inv[7] = (b * g - a * h) * id; Inv[8] = (a * e - b * d) * id;
+  return std::isfinite(id);
+}
+
+// Envelope (skyline) Cholesky of a symmetric matrix given by rows i -> columns [first[i], i].
+struct Skyline {
+  int n = 0;
+  std::vector<int> first;
+  std::vector<size_t> off;   // offset of row i's first stored entry
+  std::vector<double> a;
+  double& at(int i, int j) { return a[off[i] + (j - first[i])]; }
+  void setup(int n_, const std::vector<int>& f) {
+    n = n_; first = f; off.assign(n + 1, 0);
+    for (int i = 0; i < n; i++) off[i + 1] = off[i] + (size_t)(i - first[i] + 1);
+    a.assign(off[n], 0.0);
+  }
+  bool factor() {
+    for (int i = 0; i < n; i++) {
+      for (int j = first[i]; j <= i; j++) {
+        const int k0 = std::max(first[i], first[j]);
+        double s = at(i, j);
+        const double* ri = &a[off[i] + (k0 - first[i])];
+        const double* rj = &a[off[j] + (k0 - first[j])];
+        for (int k = 0; k < j - k0; k++) s -= ri[k] * rj[k];
+        if (j < i) at(i, j) = s / at(j, j);
+        else {
+          if (!(s > 0)) return false;
+          at(i, i) = std::sqrt(s);
+        }
+      }
+    }
+    return true;
+  }
+  void solve(double* x) {  // in place
+    for (int i = 0; i < n; i++) {
+      double s = x[i];
+      for (int j = first[i]; j < i; j++) s -= at(i, j) * x[j];
+      x[i] = s / at(i, i);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      x[i] /= at(i, i);
+      for (int j = first[i]; j < i; j++) x[j] -= at(i, j) * x[i];
+    }
+  }
+};
+
+struct BA {
+  int P, L, E;
+  std::vector<Pose> poses;
+  std::vector<uint8_t> fixed;
+  std::vector<double> pts;
+  std::vector<orc_ba_edge> edges;
+  Cam cam;
+  std::vector<int> pidx;  // pose -> free index or -1
+  int nfree = 0;
+  std::vector<uint8_t> pt_active;
+  std::vector<int> lidx;  // landmark -> active index
+  int nact = 0;
+  // linear system
+  std::vector<double> Hpp, bp, Hll, bl, W;  // W: per edge 6x3 (pose x point)
+  std::vector<double> x;                     // [6*nfree + 3*nact]
+  Skyline S;
+  std::vector<std::vector<int>> pt_edges;
+  std::vector<double> last_chi2;  // e->chi2() as g2o would report it: value at the LAST computeActiveErrors
+
+  double robust_chi2() {
+    double chi = 0;
+    EdgeLin Lz;
+    last_chi2.resize(E);
+    for (int k = 0; k < E; k++) {
+      const auto& e = edges[k];
+      const double obs[2] = {e.u, e.v};
+      linearize(poses[e.pose], &pts[3 * e.point], obs, e.inv_sigma2, cam, Lz, false);
+      last_chi2[k] = Lz.chi2;
+      double r0, r1;
+      robustify(Lz.chi2, cam.delta, r0, r1);
+      chi += r0;
+    }
+    return chi;
+  }
+  void build_system() {
+    std::fill(Hpp.begin(), Hpp.end(), 0.0); std::fill(bp.begin(), bp.end(), 0.0);
+    std::fill(Hll.begin(), Hll.end(), 0.0); std::fill(bl.begin(), bl.end(), 0.0);
+    EdgeLin Lz;
+    for (int k = 0; k < E; k++) {
+      const auto& e = edges[k];
+      const double obs[2] = {e.u, e.v};
+      linearize(poses[e.pose], &pts[3 * e.point], obs, e.inv_sigma2, cam, Lz, true);
+      double r0, r1;
+      robustify(Lz.chi2, cam.delta, r0, r1);
+      const double w = r1 * e.inv_sigma2;                         // weightedOmega = rho' * Omega
+      const double wr[2] = {-e.inv_sigma2 * Lz.e[0] * r1, -e.inv_sigma2 * Lz.e[1] * r1};  // omega_r * rho'
+      const int li = lidx[e.point], pi = pidx[e.pose];
+      double* hl = &Hll[9 * li];
+      for (int a = 0; a < 3; a++) {
+        bl[3 * li + a] += Lz.A[a] * wr[0] + Lz.A[3 + a] * wr[1];
+        for (int b = 0; b < 3; b++) hl[3 * a + b] += w * (Lz.A[a] * Lz.A[b] + Lz.A[3 + a] * Lz.A[3 + b]);
+      }
+      double* Wk = &W[18 * k];
+      if (pi >= 0) {
+        double* hp = &Hpp[36 * pi];
+        for (int a = 0; a < 6; a++) {
+          bp[6 * pi + a] += Lz.B[a] * wr[0] + Lz.B[6 + a] * wr[1];
+          for (int b = 0; b < 6; b++) hp[6 * a + b] += w * (Lz.B[a] * Lz.B[b] + Lz.B[6 + a] * Lz.B[6 + b]);
+          for (int b = 0; b < 3; b++) Wk[3 * a + b] = w * (Lz.B[a] * Lz.A[b] + Lz.B[6 + a] * Lz.A[3 + b]);
+        }
+      } else std::fill(Wk, Wk + 18, 0.0);
+    }
+  }
+  // Schur complement + solve + back-substitution with damping lambda; fills x.  block_solver.hpp:354-486
+  bool solve(double lambda) {
+    const int n = 6 * nfree;
+    std::fill(S.a.begin(), S.a.end(), 0.0);
+    std::vector<double> bs(bp.begin(), bp.begin() + n);
+    for (int i = 0; i < nfree; i++)
+      for (int a = 0; a < 6; a++)
+        for (int b = 0; b <= a; b++) S.at(6 * i + a, 6 * i + b) = Hpp[36 * i + 6 * a + b] + (a == b ? lambda : 0.0);
+    std::vector<double> Dinv((size_t)9 * nact);
+    for (int l = 0; l < L; l++) {
+      if (!pt_active[l]) continue;
+      const int li = lidx[l];
+      double D[9];
+      std::memcpy(D, &Hll[9 * li], sizeof(D));
+      D[0] += lambda; D[4] += lambda; D[8] += lambda;
+      double* Di = &Dinv[9 * li];
+      inv3(D, Di);
+      double db[3];
+      mat3_vec(Di, &bl[3 * li], db);
+      const std::vector<int>& ev = pt_edges[l];
+      for (int k1 : ev) {
+        const int i1 = pidx[edges[k1].pose];
+        if (i1 < 0) continue;
+        const double* W1 = &W[18 * k1];
+        double WD[18];
+        for (int a = 0; a < 6; a++)
+          for (int b = 0; b < 3; b++) WD[3 * a + b] = W1[3 * a] * Di[b] + W1[3 * a + 1] * Di[3 + b] + W1[3 * a + 2] * Di[6 + b];
+        for (int a = 0; a < 6; a++) bs[6 * i1 + a] -= W1[3 * a] * db[0] + W1[3 * a + 1] * db[1] + W1[3 * a + 2] * db[2];
+        for (int k2 : ev) {
+          const int i2 = pidx[edges[k2].pose];
+          if (i2 < 0 || i2 > i1) continue;  // lower triangle (i1 >= i2)
+          if (i2 == i1 && k2 != k1) continue;  // one edge per (pose, point) pair by construction
+          const double* W2 = &W[18 * k2];
+          for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) {
+              if (i1 == i2 && b > a) continue;
+              S.at(6 * i1 + a, 6 * i2 + b) -= WD[3 * a] * W2[3 * b] + WD[3 * a + 1] * W2[3 * b + 1] + WD[3 * a + 2] * W2[3 * b + 2];
+            }
+        }
+      }
+    }
+    if (!S.factor()) return false;
+    S.solve(bs.data());
+    std::copy(bs.begin(), bs.end(), x.begin());
+    // xl = Dinv (bl - W^T xp)
+    for (int l = 0; l < L; l++) {
+      if (!pt_active[l]) continue;
+      const int li = lidx[l];
+      double c[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
+      for (int k : pt_edges[l]) {
+        const int i = pidx[edges[k].pose];
+        if (i < 0) continue;
+        const double* Wk = &W[18 * k];
+        for (int b = 0; b < 3; b++)
+          for (int a = 0; a < 6; a++) c[b] -= Wk[3 * a + b] * x[6 * i + a];
+      }
+      mat3_vec(&Dinv[9 * li], c, &x[n + 3 * li]);
+    }
+    return true;
+  }
+  void apply_update() {
+    for (int p = 0; p < P; p++)
+      if (pidx[p] >= 0) pose_oplus(poses[p], &x[6 * pidx[p]]);
+    const int n = 6 * nfree;
+    for (int l = 0; l < L; l++)
+      if (pt_active[l]) for (int a = 0; a < 3; a++) pts[3 * l + a] += x[n + 3 * lidx[l] + a];
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
+                    const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2) {
+  BA ba;
+  ba.P = P; ba.L = L; ba.E = E;
+  ba.poses.resize(P);
+  for (int p = 0; p < P; p++) {
+    std::memcpy(ba.poses[p].t, poses + 7 * p, 3 * sizeof(double));
+    std::memcpy(ba.poses[p].q, poses + 7 * p + 3, 4 * sizeof(double));
+    quat_normalize(ba.poses[p].q);
+  }
+  ba.fixed.assign(fixed, fixed + P);
+  ba.pts.assign(points, points + 3 * (size_t)L);
+  ba.edges.assign(edges, edges + E);
+  ba.cam = Cam{cam->fx, cam->fy, cam->cx, cam->cy, cam->huber_delta};
+  ba.pidx.assign(P, -1);
+  std::vector<uint8_t> pose_used(P, 0);
+  ba.pt_active.assign(L, 0);
+  ba.pt_edges.assign(L, {});
+  for (int k = 0; k < E; k++) {
+    pose_used[edges[k].pose] = 1;
+    ba.pt_active[edges[k].point] = 1;
+    ba.pt_edges[edges[k].point].push_back(k);
+  }
+  for (int p = 0; p < P; p++)
+    if (!fixed[p] && pose_used[p]) ba.pidx[p] = ba.nfree++;
+  ba.lidx.assign(L, -1);
+  for (int l = 0; l < L; l++)
+    if (ba.pt_active[l]) ba.lidx[l] = ba.nact++;
+  const int n = 6 * ba.nfree;
+  ba.Hpp.assign((size_t)36 * ba.nfree, 0); ba.bp.assign((size_t)n, 0);
+  ba.Hll.assign((size_t)9 * ba.nact, 0); ba.bl.assign((size_t)3 * ba.nact, 0);
+  ba.W.assign((size_t)18 * E, 0);
+  ba.x.assign((size_t)n + 3 * ba.nact, 0);
+  // envelope of the reduced camera matrix: first co-observing free pose of every pose
+  std::vector<int> minblk(ba.nfree);
+  for (int i = 0; i < ba.nfree; i++) minblk[i] = i;
+  for (int l = 0; l < L; l++) {
+    int lo = 1 << 30;
+    for (int k : ba.pt_edges[l]) if (ba.pidx[edges[k].pose] >= 0) lo = std::min(lo, ba.pidx[edges[k].pose]);
+    for (int k : ba.pt_edges[l]) { int i = ba.pidx[edges[k].pose]; if (i >= 0) minblk[i] = std::min(minblk[i], lo); }
+  }
+  std::vector<int> first(n);
+  for (int i = 0; i < ba.nfree; i++) for (int a = 0; a < 6; a++) first[6 * i + a] = 6 * minblk[i];
+  ba.S.setup(n, first);
+
+  if (st) { std::memset(st, 0, sizeof(*st)); }
+  double lambda = -1, ni = 2;
+  int nBad = 0, it_done = 0, trials_total = 0, stop = 0;
+  double chi_last = 0;
+  for (int it = 0; it < iterations; it++) {
+    double currentChi = ba.robust_chi2();
+    double tempChi = currentChi;
+    const double iniChi = currentChi;
+    if (it == 0 && st) st->chi2_initial = currentChi;
+    ba.build_system();
+    if (it == 0) {  // computeLambdaInit: tau * max diagonal over all active vertices
+      double mx = 0;
+      for (int i = 0; i < ba.nfree; i++) for (int a = 0; a < 6; a++) mx = std::max(mx, std::fabs(ba.Hpp[36 * i + 7 * a]));
+      for (int i = 0; i < ba.nact; i++) for (int a = 0; a < 3; a++) mx = std::max(mx, std::fabs(ba.Hll[9 * i + 4 * a]));
+      lambda = 1e-5 * mx;
+      ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      std::vector<Pose> poses_bak = ba.poses;
+      std::vector<double> pts_bak = ba.pts;
+      const bool ok = ba.solve(lambda);
+      if (ok) ba.apply_update();
+      tempChi = ok ? ba.robust_chi2() : std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = 0;
+      if (ok) {
+        for (int j = 0; j < n; j++) scale += ba.x[j] * (lambda * ba.x[j] + ba.bp[j]);
+        for (int j = 0; j < 3 * ba.nact; j++) scale += ba.x[n + j] * (lambda * ba.x[n + j] + ba.bl[j]);
+      }
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        ba.poses = poses_bak;
+        ba.pts = pts_bak;
+      }
+      qmax++;
+      trials_total++;
+    } while (rho < 0 && qmax < 10);
+    it_done++;
+    chi_last = currentChi;
+    if (st && it < 64) { st->trials_per_iter[it] = qmax; st->chi2_per_iter[it] = currentChi; st->lambda_per_iter[it] = lambda; }
+    if (qmax == 10 || rho == 0) { stop = 1; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { stop = 2; break; }
+  }
+  for (int p = 0; p < P; p++) {
+    std::memcpy(poses + 7 * p, ba.poses[p].t, 3 * sizeof(double));
+    std::memcpy(poses + 7 * p + 3, ba.poses[p].q, 4 * sizeof(double));
+  }
+  std::memcpy(points, ba.pts.data(), sizeof(double) * 3 * (size_t)L);
+  if (edge_chi2 && (int)ba.last_chi2.size() == E) std::memcpy(edge_chi2, ba.last_chi2.data(), sizeof(double) * (size_t)E);
+  if (st) {
+    st->iterations = it_done; st->total_trials = trials_total; st->chi2_final = chi_last; st->lambda_final = lambda;
+    st->stop_reason = stop;
+  }
+  return it_done;
+}
+
+// per-edge raw chi2 and depth sign at the given state (Optimizer.cc:1317-1354 outlier tests)
+void orc_ba_edge_chi2(const double* poses, const double* points, const orc_ba_edge* edges, int E, const orc_ba_camera* cam,
+                      double* chi2, uint8_t* depth_positive) {
+  Cam c{cam->fx, cam->fy, cam->cx, cam->cy, cam->huber_delta};
+  EdgeLin Lz;
+  for (int k = 0; k < E; k++) {
+    Pose T;
+    std::memcpy(T.t, poses + 7 * edges[k].pose, 3 * sizeof(double));
+    std::memcpy(T.q, poses + 7 * edges[k].pose + 3, 4 * sizeof(double));
+    const double obs[2] = {edges[k].u, edges[k].v};
+    linearize(T, points + 3 * (size_t)edges[k].point, obs, edges[k].inv_sigma2, c, Lz, false);
+    chi2[k] = Lz.chi2;
+    if (depth_positive) depth_positive[k] = Lz.Xc[2] > 0;
+  }
+}
+
+// Optimizer::PoseOptimization (Optimizer.cc:744-1028), mono edges only.  pose: (t, q) double in/out
+// (the reference reads/writes a float Sophus pose; callers cast).  Xw [N][3] double, obs [N][2],
+// inv_sigma2 [N].  outlier[N] receives mvbOutlier.  Returns nInitialCorrespondences - nBad.
+int orc_pose_optimize(double* pose, const double* Xw, const double* obs, const double* inv_sigma2, int N,
+                      const orc_ba_camera* cam, uint8_t* outlier) {
+  if (N < 3) return 0;
+  const double delta = (double)(float)std::sqrt(5.991);  // const float deltaMono = sqrt(5.991)
+  const float chi2Mono = 5.991f;
+  Cam c{cam->fx, cam->fy, cam->cx, cam->cy, delta};
+  Pose T0;
+  std::memcpy(T0.t, pose, 3 * sizeof(double));
+  std::memcpy(T0.q, pose + 3, 4 * sizeof(double));
+  quat_normalize(T0.q);
+  std::vector<uint8_t> level(N, 0), robust(N, 1);
+  std::vector<double> last_chi2(N, 0.0);  // edge->chi2(): value at the last computeActiveErrors it took part in
+  std::fill(outlier, outlier + N, 0);
+  Pose T = T0;
+  int nBad = 0;
+  auto edge_err = [&](const Pose& P_, int i, EdgeLin& Lz, bool jac) {
+    // unary edge: same projection; B (2x6) is the pose Jacobian (OptimizableTypes.cpp:51-63)
+    linearize(P_, Xw + 3 * i, obs + 2 * i, inv_sigma2[i], c, Lz, jac);
+  };
+  for (int round = 0; round < 4; round++) {
+    T = T0;  // vSE3->setEstimate(pFrame->GetPose()) every round
+    auto chi_active = [&](const Pose& P_) {
+      double chi = 0;
+      EdgeLin Lz;
+      for (int i = 0; i < N; i++) {
+        if (level[i]) continue;
+        edge_err(P_, i, Lz, false);
+        last_chi2[i] = Lz.chi2;
+        double r0, r1;
+        robustify(Lz.chi2, robust[i] ? delta : 0.0, r0, r1);
+        chi += r0;
+      }
+      return chi;
+    };
+    double lambda = -1, ni = 2;
+    int nBadIt = 0;
+    int nactive = 0;
+    for (int i = 0; i < N; i++) nactive += !level[i];
+    for (int it = 0; it < 10 && nactive > 0; it++) {
+      double currentChi = chi_active(T), tempChi = currentChi;
+      const double iniChi = currentChi;
+      double H[36] = {0}, b[6] = {0};
+      EdgeLin Lz;
+      for (int i = 0; i < N; i++) {
+        if (level[i]) continue;
+        edge_err(T, i, Lz, true);
+        double r0, r1;
+        robustify(Lz.chi2, robust[i] ? delta : 0.0, r0, r1);
+        const double w = r1 * inv_sigma2[i];
+        const double wr[2] = {-inv_sigma2[i] * Lz.e[0] * r1, -inv_sigma2[i] * Lz.e[1] * r1};
+        for (int a = 0; a < 6; a++) {
+          b[a] += Lz.B[a] * wr[0] + Lz.B[6 + a] * wr[1];
+          for (int bb = 0; bb < 6; bb++) H[6 * a + bb] += w * (Lz.B[a] * Lz.B[bb] + Lz.B[6 + a] * Lz.B[6 + bb]);
+        }
+      }
+      if (it == 0) {
+        double mx = 0;
+        for (int a = 0; a < 6; a++) mx = std::max(mx, std::fabs(H[7 * a]));
+        lambda = 1e-5 * mx; ni = 2; nBadIt = 0;
+      }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        Pose bak = T;
+        // dense 6x6 Cholesky solve of (H + lambda I) x = b
+        double Lm[36], x[6];
+        bool ok = true;
+        for (int i = 0; i < 6 && ok; i++)
+          for (int j = 0; j <= i; j++) {
+            double s = H[6 * i + j] + (i == j ? lambda : 0.0);
+            for (int k = 0; k < j; k++) s -= Lm[6 * i + k] * Lm[6 * j + k];
+            if (i == j) { if (!(s > 0)) { ok = false; break; } Lm[6 * i + i] = std::sqrt(s); }
+            else Lm[6 * i + j] = s / Lm[6 * j + j];
+          }
+        if (ok) {
+          for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= Lm[6 * i + k] * x[k]; x[i] = s / Lm[6 * i + i]; }
+          for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= Lm[6 * k + i] * x[k]; x[i] = s / Lm[6 * i + i]; }
+          pose_oplus(T, x);
+        }
+        tempChi = ok ? chi_active(T) : std::numeric_limits<double>::max();
+        rho = currentChi - tempChi;
+        double scale = 0;
+        if (ok) for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow(2 * rho - 1, 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+        } else {
+          lambda *= ni; ni *= 2; T = bak;
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBadIt++; else nBadIt = 0;
+      if (nBadIt >= 3) break;
+    }
+    nBad = 0;
+    EdgeLin Lz;
+    for (int i = 0; i < N; i++) {
+      if (outlier[i]) { edge_err(T, i, Lz, false); last_chi2[i] = Lz.chi2; }  // :929-931 recompute for outliers only
+      const float chi2 = (float)last_chi2[i];
+      if (chi2 > chi2Mono) { outlier[i] = 1; level[i] = 1; nBad++; }
+      else { outlier[i] = 0; level[i] = 0; }
+      if (round == 2) robust[i] = 0;
+    }
+    if (N < 10) break;  // optimizer.edges().size() < 10
+  }
+  std::memcpy(pose, T.t, 3 * sizeof(double));
+  std::memcpy(pose + 3, T.q, 4 * sizeof(double));
+  return N - nBad;
+}
+
+}  // extern "C"

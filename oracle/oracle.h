@@ -96,6 +96,25 @@ void orc_match_window(const orc_grid* g, const uint8_t* tdesc, const uint8_t* sk
                       const int32_t* qmax, int nq, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
                       int32_t* best_level, int32_t* second_level);
 
+/* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
+typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
+typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;
+typedef struct {
+  int32_t iterations, total_trials, stop_reason, pad;  /* stop: 0 ran out of iterations, 1 LM terminate, 2 Mur-Artal criterion */
+  double chi2_initial, chi2_final, lambda_final;
+  int32_t trials_per_iter[64];
+  double chi2_per_iter[64], lambda_per_iter[64];
+} orc_ba_stats;
+/* poses [P][7] = (tx,ty,tz,qx,qy,qz,qw) world->camera, in/out; points [L][3] in/out.  Runs
+ * optimizer.optimize(iterations) of the reference's BA graph.  edge_chi2 (may be NULL) receives each
+ * edge's chi2() as g2o would report it after optimize().  Returns iterations performed. */
+int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
+                    const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2);
+void orc_ba_edge_chi2(const double* poses, const double* points, const orc_ba_edge* edges, int E,
+                      const orc_ba_camera* cam, double* chi2, uint8_t* depth_positive);
+int orc_pose_optimize(double* pose, const double* Xw, const double* obs, const double* inv_sigma2, int N,
+                      const orc_ba_camera* cam, uint8_t* outlier);
+
 #ifdef __cplusplus
 }
 #endif

@@ -238,3 +238,75 @@ class Grid:
                                 *[_p(o) for o in outs])
         return dict(best_idx=outs[0], best_dist=outs[1], second_dist=outs[2], best_level=outs[3],
                     second_level=outs[4])
+
+
+# ------------------------------------------------------------------------------------------- BA
+BA_EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f8"), ("v", "<f8"), ("inv_sigma2", "<f8")])
+
+
+class BaCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("stop_reason", C.c_int32), ("pad", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("trials_per_iter", C.c_int32 * 64), ("chi2_per_iter", C.c_double * 64),
+                ("lambda_per_iter", C.c_double * 64)]
+
+
+def make_edges(edge_pose, edge_point, obs, inv_sigma2) -> np.ndarray:
+    e = np.zeros(len(edge_pose), BA_EDGE_DTYPE)
+    e["pose"], e["point"] = edge_pose, edge_point
+    e["u"], e["v"] = obs[:, 0], obs[:, 1]
+    e["inv_sigma2"] = inv_sigma2
+    return e
+
+
+def ba_optimize(poses, fixed, points, edges, intrinsics, huber_delta, iterations, libpath=None):
+    """Returns (poses, points, stats dict, edge_chi2)."""
+    L = lib(libpath) if libpath else lib()
+    L.orc_ba_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                  C.POINTER(BaCamera), C.c_int32, C.POINTER(BaStats), C.c_void_p]
+    poses = np.array(poses, np.float64, copy=True, order="C")
+    points = np.array(points, np.float64, copy=True, order="C")
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam = BaCamera(*[float(v) for v in intrinsics], float(huber_delta))
+    st = BaStats()
+    chi = np.zeros(len(edges), np.float64)
+    it = L.orc_ba_optimize(_p(poses), _p(fixed), len(poses), _p(points), len(points), _p(edges), len(edges),
+                           C.byref(cam), iterations, C.byref(st), _p(chi))
+    n = st.iterations
+    stats = dict(iterations=it, total_trials=st.total_trials, stop_reason=st.stop_reason, chi2_initial=st.chi2_initial,
+                 chi2_final=st.chi2_final, lambda_final=st.lambda_final, trials=list(st.trials_per_iter[:n]),
+                 chi2=list(st.chi2_per_iter[:n]), lam=list(st.lambda_per_iter[:n]))
+    return poses, points, stats, chi
+
+
+def ba_edge_chi2(poses, points, edges, intrinsics):
+    L = lib()
+    L.orc_ba_edge_chi2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(BaCamera), C.c_void_p, C.c_void_p]
+    poses = np.ascontiguousarray(poses, np.float64)
+    points = np.ascontiguousarray(points, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam = BaCamera(*[float(v) for v in intrinsics], 0.0)
+    chi = np.zeros(len(edges), np.float64)
+    dp = np.zeros(len(edges), np.uint8)
+    L.orc_ba_edge_chi2(_p(poses), _p(points), _p(edges), len(edges), C.byref(cam), _p(chi), _p(dp))
+    return chi, dp
+
+
+def pose_optimize(pose, Xw, obs, inv_sigma2, intrinsics):
+    """Optimizer::PoseOptimization.  Returns (pose[7], outlier mask, n_inliers)."""
+    L = lib()
+    L.orc_pose_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(BaCamera), C.c_void_p]
+    pose = np.array(pose, np.float64, copy=True)
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    inv_sigma2 = np.ascontiguousarray(inv_sigma2, np.float64)
+    cam = BaCamera(*[float(v) for v in intrinsics], 0.0)
+    out = np.zeros(len(Xw), np.uint8)
+    n = L.orc_pose_optimize(_p(pose), _p(Xw), _p(obs), _p(inv_sigma2), len(Xw), C.byref(cam), _p(out))
+    return pose, out, n
