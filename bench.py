@@ -92,7 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from dvm_slam_amd import capi, synth
+    from dvm_slam_amd import capi, exchange, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
@@ -104,7 +104,7 @@ def main():
     nstream = max(a.stream_frames, B)
     nstream = (nstream + B - 1) // B * B
     # every rank is its own agent: a different segment of the camera path
-    frames = synth.frame_stream(nstream, start=rank * nstream)
+    frames = synth.frame_stream(nstream, start=exchange.agent_stream_segment(rank, nstream))
     d_frames = torch.from_numpy(frames).cuda()
     H, W = frames.shape[1:]
 
@@ -153,10 +153,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ext.profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = exchange.max_over_ranks(dt, device="cuda")
     prof = {k: ext.profile_get(k) for k in ("pyramid", "fast", "compact", "assemble", "blur", "orient_desc")}
     nmatched = int((matches[:, :, 1] <= 100).sum().item())  # TH_HIGH gate, sanity only
 

@@ -1,0 +1,69 @@
+// dvm_slam_amd/host/ORBextractor_shim.h -- drop-in for ORB_SLAM3::ORBextractor (reference
+// include/ORBextractor.h:47-91) over the dvmslam_hip C ABI.  Compile inside the reference tree in
+// place of src/ORBextractor.cc (it needs the reference's own OpenCV); nothing else in libORB_SLAM3
+// changes: Frame.cc:411,508-511 keeps calling (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors, vLapping).
+#pragma once
+#include <opencv2/core/core.hpp>
+#include <vector>
+
+#include "dvmslam_hip.h"
+
+namespace ORB_SLAM3 {
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+      : nlevels_(nlevels), scaleFactor_(scaleFactor) {
+    dvm_orb_params p{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
+    if (dvm_orb_create(&p, /*device=*/0, /*max_batch=*/1, &h_) != DVM_OK) throw std::runtime_error(dvm_last_error());
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    dvm_orb_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr);
+    mvImagePyramid.resize(nlevels);
+    cap_ = nfeatures + 5 * nlevels + 8;
+    kps_.resize(cap_);
+  }
+  ~ORBextractor() { dvm_orb_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+
+  // Mask is ignored, exactly as in the reference (ORBextractor.h:53-56).  Returns monoIndex, -1 if empty.
+  int operator()(cv::InputArray _image, cv::InputArray, std::vector<cv::KeyPoint>& _keypoints,
+                 cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    CV_Assert(image.type() == CV_8UC1);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(dvm_keypoint), "cv::KeyPoint layout");
+    cv::Mat desc(cap_, 32, CV_8U);
+    int n = 0, mono = 0;
+    int rc = dvm_orb_extract(h_, image.data, image.rows, image.cols, (int)image.step, vLappingArea[0], vLappingArea[1],
+                             kps_.data(), desc.data, cap_, &n, &mono);
+    if (rc != DVM_OK) throw std::runtime_error(dvm_last_error());
+    _keypoints.resize(n);
+    std::memcpy(static_cast<void*>(_keypoints.data()), kps_.data(), sizeof(dvm_keypoint) * n);
+    if (n == 0) _descriptors.release();
+    else desc.rowRange(0, n).copyTo(_descriptors);
+    // mvImagePyramid is only read by Frame::ComputeStereoMatches (stereo; Frame.cc:856,940-956): expose the
+    // device pyramid lazily through dvm_orb_pyramid() + hipMemcpy2D when a stereo caller needs it.
+    return mono;
+  }
+
+  int inline GetLevels() { return nlevels_; }
+  float inline GetScaleFactor() { return scaleFactor_; }
+  std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+  std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+  std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+  std::vector<cv::Mat> mvImagePyramid;
+
+ protected:
+  dvm_orb* h_ = nullptr;
+  int nlevels_, cap_;
+  float scaleFactor_;
+  std::vector<dvm_keypoint> kps_;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+}  // namespace ORB_SLAM3

@@ -1,0 +1,73 @@
+"""The C-ABI library loads and exports every symbol include/dvmslam_hip.h declares; without a GPU
+every compute entry point fails loudly (DVM_ERR_NO_DEVICE) -- there is no CPU fallback in the product."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "dvmslam_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dvm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.lib()
+    names = _declared()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (dvm_[a-z0-9_]+)", out))
+    assert set(names) <= exported
+    assert lib.dvm_version().decode().startswith("dvmslam-hip")
+
+
+def test_struct_layouts(capi):
+    assert capi.KP_DTYPE.itemsize == 28      # cv::KeyPoint
+    assert capi.MATCH_DTYPE.itemsize == 16
+    assert capi.BA_EDGE_DTYPE.itemsize == 32
+    assert ctypes.sizeof(capi.OrbParams) == 20
+
+
+def test_product_does_not_reference_oracle():
+    """Nothing under dvm_slam_amd/ may import, link or load anything under oracle/ (bench's cpu_baseline
+    helper in ba_bench.py is the sanctioned exception and only runs from bench.py / smoke)."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "dvm_slam_amd")):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                continue
+            txt = open(os.path.join(dp, f), errors="replace").read()
+            if f == "ba_bench.py":
+                continue
+            if re.search(r"(from|import)\s+oracle|liboracle|oracle/", txt) and f not in ("__init__.py",):
+                bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    deps = subprocess.run(["readelf", "-d", os.path.join(ROOT, "dvm_slam_amd", "lib", "libdvmslam_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in deps
+
+
+def test_fails_loudly_without_gpu(capi):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(capi.DvmError) as ei:
+        capi.OrbExtractor()
+    assert ei.value.code == -5
+    with pytest.raises(capi.DvmError):
+        capi.hamming_matrix(np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8))
+    with pytest.raises(capi.DvmError):
+        capi.BundleAdjuster()
+    with pytest.raises(capi.DvmError):
+        capi.FrameGrid()
+
+
+def test_graft_entry_symbols():
+    import __graft_entry__ as g
+    assert g.exported_symbols() == _declared()

@@ -1,0 +1,65 @@
+"""Pins the BA oracle (oracle/ba_oracle.cpp: Schur complement + sparse Cholesky + g2o's LM) against a plain
+numpy LM on the FULL normal equations (tests/ref_numpy.py) -- two independent derivations of the same optimum."""
+import numpy as np
+import pytest
+
+import ref_numpy as ref
+
+
+def _tiny_problem(seed, delta):
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=6, n_pts=40, k_obs=4, seed=seed, radius=20.0)
+    return pr
+
+
+@pytest.mark.parametrize("seed,delta", [(1, 0.0), (2, float(np.sqrt(5.991)))])
+def test_ba_oracle_matches_dense_lm(oracle, seed, delta):
+    pr = _tiny_problem(seed, delta)
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    poses, pts, st, chi = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, 8)
+    Rs = [ref.quat_to_R(p[3:]) for p in pr["poses"]]
+    ts = [p[:3].copy() for p in pr["poses"]]
+    Rn, tn, ptn, hist = ref.ba_lm_dense(Rs, ts, pr["fixed"], pr["points"], pr["edge_pose"], pr["edge_point"], pr["obs"],
+                                        pr["inv_sigma2"], pr["intrinsics"], delta, 8)
+    assert st["trials"] == [h[0] for h in hist]
+    assert np.allclose(st["chi2"], [h[1] for h in hist], rtol=1e-8)
+    assert np.allclose(st["lam"], [h[2] for h in hist], rtol=1e-6)
+    for p in range(len(Rs)):
+        assert np.allclose(ref.quat_to_R(poses[p, 3:]), Rn[p], atol=1e-8)
+        assert np.allclose(poses[p, :3], tn[p], atol=1e-8)
+    assert np.allclose(pts, ptn, atol=1e-8)
+    # chi2 report equals a fresh evaluation at the final state when the last trial was accepted
+    chi_now, depth = oracle.ba_edge_chi2(poses, pts, e, pr["intrinsics"])
+    assert np.allclose(chi, chi_now, rtol=1e-9) and depth.all()
+
+
+def test_ba_oracle_reduces_error_and_respects_gauge(oracle):
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=30, n_pts=800, seed=7, outlier_frac=0.0)
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    poses, pts, st, _ = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], np.sqrt(5.991), 10)
+    assert st["chi2_final"] < 0.5 * st["chi2_initial"]
+    assert np.array_equal(poses[0], pr["poses"][0])
+    assert np.allclose(np.linalg.norm(poses[:, 3:], axis=1), 1, atol=1e-12)
+
+
+def test_pose_optimization_oracle(oracle):
+    """Optimizer::PoseOptimization: recovers a perturbed pose and flags the planted gross outliers."""
+    from dvm_slam_amd import synth
+    rng = np.random.default_rng(0)
+    pr = synth.ba_problem(n_kf=4, n_pts=300, k_obs=4, seed=11, noise_px=0.5, outlier_frac=0.0, radius=20.0)
+    kf = 1
+    sel = pr["edge_pose"] == kf
+    Xw = pr["points_gt"][pr["edge_point"][sel]]
+    obs = pr["obs"][sel].copy()
+    bad = rng.random(len(obs)) < 0.1
+    obs[bad] += 40.0
+    pose0 = pr["poses"][kf]
+    pose, outl, nin = oracle.pose_optimize(pose0, Xw, obs, pr["inv_sigma2"][sel], pr["intrinsics"])
+    gt = pr["poses_gt"][kf]
+    assert np.abs(pose[:3] - gt[:3]).max() < 0.05 and np.abs(pose[:3] - gt[:3]).max() < np.abs(pose0[:3] - gt[:3]).max()
+    assert outl[bad].mean() > 0.9 and outl[~bad].mean() < 0.1
+    assert nin == len(obs) - int(outl.sum())
+    # fewer than 3 correspondences: returns 0 and leaves the pose alone (Optimizer.cc:904-905)
+    p2, _, n2 = oracle.pose_optimize(pose0, Xw[:2], obs[:2], pr["inv_sigma2"][sel][:2], pr["intrinsics"])
+    assert n2 == 0 and np.array_equal(p2, pose0)
