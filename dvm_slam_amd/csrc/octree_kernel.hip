@@ -1,0 +1,264 @@
+// dvm_slam_amd/csrc/octree_kernel.hip -- ORBextractor::DistributeOctTree on the device.
+//
+// Reference: src/ORBextractor.cc:419-610 (+ ExtractorNode::DivideNode :348-400, compareNodes :402-417).
+// One workgroup per (pyramid level, frame).  The std::list surgery is restated as array rounds
+// (DESIGN.md section 6): a round splits the node sequence P (processing order) and yields
+//     list' = reverse(children(p1) ++ ... ++ children(pm)) ++ (list \ P).
+//   phase 1: P = all nodes with > 1 key, in list order (the reference's full sweeps)
+//   phase 2: P = nodes created by the previous round with > 1 key, ordered by libstdc++'s
+//            std::sort(compareNodes) walked from the back, cut as soon as the list holds >= N nodes
+// Keys keep a node id; child sizes come from LDS atomics over all candidates (order-free counts).
+// The retained key per node is max response, first in vToDistributeKeys order on ties (:594-607),
+// i.e. atomicMax of (response << 20 | ~index).  std::sort's treatment of EQUAL (size, UL.x) keys is
+// reproduced by the step-exact emulation in introsort_emul.h (one lane).
+#include <hip/hip_runtime.h>
+
+#include "introsort_emul.h"
+#include "orb_device.h"
+#include "orb_kernels.h"
+
+namespace dvm {
+
+constexpr int kOctMaxNodes = 1536;
+struct ONodeRec {
+  int16_t x0, y0, x1, y1;
+  int32_t cnt;
+};
+
+// exclusive scan of data[0..m) in place, 256 threads, returns total through *total (shared)
+__device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, int* total) {
+  const int tid = threadIdx.x;
+  const int per = (m + 255) / 256;
+  const int b = tid * per, e = min(b + per, m);
+  int sum = 0;
+  for (int i = b; i < e; i++) sum += data[i];
+  s_tmp[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = (tid >= off) ? s_tmp[tid - off] : 0;
+    __syncthreads();
+    s_tmp[tid] += v;
+    __syncthreads();
+  }
+  int run = s_tmp[tid] - sum;
+  for (int i = b; i < e; i++) { int v = data[i]; data[i] = run; run += v; }
+  if (tid == 255) *total = s_tmp[255];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ dense, const int32_t* __restrict__ lvl_start,
+                                                PipelineDesc PD, int32_t* __restrict__ nid_scratch,
+                                                uint32_t* __restrict__ sel, int32_t* __restrict__ nsel,
+                                                int32_t* __restrict__ err_flag) {
+  __shared__ ONodeRec listA[kOctMaxNodes], listB[kOctMaxNodes];
+  __shared__ int cc[kOctMaxNodes][4];          // child key counts, later child new-index
+  __shared__ int a_scan[kOctMaxNodes];         // scan workspace 1 (keep index / flags)
+  __shared__ int b_scan[kOctMaxNodes];         // scan workspace 2 (children per processed node)
+  __shared__ int16_t proc[kOctMaxNodes];       // processing order: list indices
+  __shared__ int16_t prank[kOctMaxNodes];      // list index -> rank in processing order or -1
+  __shared__ uint32_t skey[kOctMaxNodes];      // sort keys
+  __shared__ uint16_t sval[kOctMaxNodes];      // sort payload / expandable set (creation order)
+  __shared__ int s_tmp[256];
+  __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
+
+  const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const LevelDesc& LV = PD.lv[level];
+  const int32_t* ls = lvl_start + f * (kMaxLevels + 1);
+  const int n = ls[level + 1] - ls[level];
+  const uint32_t* cand = dense + (int64_t)f * PD.cand_frame_slots + ls[level];
+  int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + ls[level];
+  uint32_t* out = sel + (int64_t)f * PD.sel_frame_slots + LV.sel_off;
+  int32_t* out_n = nsel + f * PD.nlevels + level;
+  const int N = LV.quota;
+  if (n <= 0) {
+    if (tid == 0) *out_n = 0;
+    return;
+  }
+  const int W = (LV.w - kEdge + 3) - (kEdge - 3), H = (LV.h - kEdge + 3) - (kEdge - 3);  // maxX-minX, maxY-minY
+  const int nIni = (int)roundf((float)W / (float)H);
+  if (nIni <= 0 || 4 * nIni > kOctMaxNodes || N + 8 > kOctMaxNodes) {
+    if (tid == 0) { *out_n = 0; atomicExch(err_flag, 1); }
+    return;
+  }
+  const float hX = (float)W / (float)nIni;
+  ONodeRec* L = listA;
+  ONodeRec* Lnew = listB;
+  // ---- roots (:424-458)
+  for (int i = tid; i < nIni; i += 256) {
+    ONodeRec r;
+    r.x0 = (int16_t)(int)(hX * (float)i);
+    r.x1 = (int16_t)(int)(hX * (float)(i + 1));
+    r.y0 = 0; r.y1 = (int16_t)H; r.cnt = 0;
+    Lnew[i] = r;
+    a_scan[i] = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    int x = (int)(cand[i] & 0xFFFu);
+    int r = (int)((float)x / hX);
+    nid[i] = r;
+    atomicAdd(&Lnew[r].cnt, 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < nIni; i += 256) a_scan[i] = Lnew[i].cnt > 0 ? 1 : 0;
+  __syncthreads();
+  block_scan_excl(a_scan, nIni, s_tmp, &s_total);
+  for (int i = tid; i < nIni; i += 256)
+    if (Lnew[i].cnt > 0) L[a_scan[i]] = Lnew[i];
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) nid[i] = a_scan[nid[i]];
+  if (tid == 0) { s_m = s_total; s_phase = 1; s_finish = 0; s_ne = 0; }
+  __syncthreads();
+
+  while (true) {
+    const int m = s_m;
+    const int phase = s_phase;
+    // ---- processing order
+    if (phase == 1) {
+      for (int j = tid; j < m; j += 256) a_scan[j] = L[j].cnt > 1 ? 1 : 0;
+      __syncthreads();
+      block_scan_excl(a_scan, m, s_tmp, &s_np);
+      for (int j = tid; j < m; j += 256)
+        if (L[j].cnt > 1) proc[a_scan[j]] = (int16_t)j;
+      __syncthreads();
+    } else {
+      const int ne = s_ne;
+      for (int k = tid; k < ne; k += 256) {
+        const int j = sval[k];
+        skey[k] = ((uint32_t)L[j].cnt << 12) | (uint32_t)(uint16_t)L[j].x0;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        KV kv{skey, sval};
+        kv_std_sort(kv, ne);
+      }
+      __syncthreads();
+      for (int t = tid; t < ne; t += 256) proc[t] = (int16_t)sval[ne - 1 - t];
+      if (tid == 0) s_np = ne;
+      __syncthreads();
+    }
+    int np = s_np;
+    // ---- child sizes of every node in the processing order
+    for (int t = tid; t < np; t += 256) { const int j = proc[t]; cc[j][0] = cc[j][1] = cc[j][2] = cc[j][3] = 0; }
+    for (int j = tid; j < m; j += 256) prank[j] = -1;
+    __syncthreads();
+    for (int t = tid; t < np; t += 256) prank[proc[t]] = (int16_t)t;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int j = nid[i];
+      if (prank[j] >= 0) {
+        const ONodeRec r = L[j];
+        const int xm = r.x0 + (r.x1 - r.x0 + 1) / 2, ym = r.y0 + (r.y1 - r.y0 + 1) / 2;  // ceil(float(d)/2)
+        const uint32_t c = cand[i];
+        const int x = (int)(c & 0xFFFu), y = (int)((c >> 12) & 0xFFFu);
+        const int q = (x < xm ? 0 : 1) + (y < ym ? 0 : 2);
+        atomicAdd(&cc[j][q], 1);
+      }
+    }
+    __syncthreads();
+    // ---- children per processed node (processing order); phase 2: cut where the list reaches N
+    for (int t = tid; t < np; t += 256) {
+      const int j = proc[t];
+      b_scan[t] = (cc[j][0] > 0) + (cc[j][1] > 0) + (cc[j][2] > 0) + (cc[j][3] > 0);
+    }
+    __syncthreads();
+    if (phase == 2) {
+      // inclusive gain scan: size after processing t = m + sum_{t'<=t} (nchild - 1)
+      for (int t = tid; t < np; t += 256) a_scan[t] = b_scan[t] - 1;
+      if (tid == 0) s_cut = np;
+      __syncthreads();
+      block_scan_excl(a_scan, np, s_tmp, &s_total);
+      for (int t = tid; t < np; t += 256)
+        if (m + a_scan[t] + (b_scan[t] - 1) >= N) atomicMin(&s_cut, t + 1);
+      __syncthreads();
+      np = s_cut;
+      for (int t = np + tid; t < s_np; t += 256) prank[proc[t]] = -1;  // not reached: stay in the list
+      __syncthreads();
+    }
+    block_scan_excl(b_scan, np, s_tmp, &s_total);
+    const int totalC = s_total;
+    for (int j = tid; j < m; j += 256) a_scan[j] = prank[j] < 0 ? 1 : 0;
+    __syncthreads();
+    block_scan_excl(a_scan, m, s_tmp, &s_keep);
+    const int newSize = totalC + s_keep;
+    if (newSize > kOctMaxNodes) {
+      if (tid == 0) { *out_n = 0; atomicExch(err_flag, 2); }
+      return;
+    }
+    // ---- build the new list
+    for (int j = tid; j < m; j += 256)
+      if (prank[j] < 0) { Lnew[totalC + a_scan[j]] = L[j]; a_scan[j] = totalC + a_scan[j]; }
+    for (int t = tid; t < np; t += 256) {
+      const int j = proc[t];
+      const ONodeRec r = L[j];
+      const int xm = r.x0 + (r.x1 - r.x0 + 1) / 2, ym = r.y0 + (r.y1 - r.y0 + 1) / 2;
+      int posC = b_scan[t];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = cc[j][q];
+        if (c > 0) {
+          ONodeRec ch;
+          ch.x0 = (q & 1) ? (int16_t)xm : r.x0;
+          ch.x1 = (q & 1) ? r.x1 : (int16_t)xm;
+          ch.y0 = (q & 2) ? (int16_t)ym : r.y0;
+          ch.y1 = (q & 2) ? r.y1 : (int16_t)ym;
+          ch.cnt = c;
+          const int ni = totalC - 1 - posC;
+          Lnew[ni] = ch;
+          cc[j][q] = ni;
+          posC++;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int j = nid[i];
+      if (prank[j] >= 0) {
+        const ONodeRec r = L[j];
+        const int xm = r.x0 + (r.x1 - r.x0 + 1) / 2, ym = r.y0 + (r.y1 - r.y0 + 1) / 2;
+        const uint32_t c = cand[i];
+        const int x = (int)(c & 0xFFFu), y = (int)((c >> 12) & 0xFFFu);
+        nid[i] = cc[j][(x < xm ? 0 : 1) + (y < ym ? 0 : 2)];
+      } else {
+        nid[i] = a_scan[j];
+      }
+    }
+    __syncthreads();
+    // ---- nodes created this round with > 1 key, in creation order (posC ascending = index descending)
+    for (int p = tid; p < totalC; p += 256) b_scan[p] = Lnew[totalC - 1 - p].cnt > 1 ? 1 : 0;
+    __syncthreads();
+    block_scan_excl(b_scan, totalC, s_tmp, &s_ne);
+    for (int p = tid; p < totalC; p += 256)
+      if (Lnew[totalC - 1 - p].cnt > 1) sval[b_scan[p]] = (uint16_t)(totalC - 1 - p);
+    __syncthreads();
+    if (tid == 0) {
+      const int nToExpand = s_ne;
+      if (newSize >= N || newSize == m) s_finish = 1;
+      else if (phase == 1 && newSize + nToExpand * 3 > N) s_phase = 2;
+      s_m = newSize;
+    }
+    ONodeRec* tsw = L; L = Lnew; Lnew = tsw;
+    __syncthreads();
+    if (s_finish) break;
+  }
+
+  // ---- keep the best key of every node (:594-607)
+  const int m = s_m;
+  for (int j = tid; j < m; j += 256) a_scan[j] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const uint32_t key = ((cand[i] >> 24) << 20) | (0xFFFFFu - (uint32_t)i);
+    atomicMax(reinterpret_cast<unsigned int*>(&a_scan[nid[i]]), key);
+  }
+  __syncthreads();
+  const int mo = min(m, LV.sel_cap);
+  for (int j = tid; j < mo; j += 256) out[j] = cand[0xFFFFFu - ((uint32_t)a_scan[j] & 0xFFFFFu)];
+  if (tid == 0) *out_n = mo;
+}
+
+void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_start, const PipelineDesc& PD,
+                   int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch) {
+  hipLaunchKernelGGL(k_octree, dim3(PD.nlevels, batch), dim3(256), 0, s, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel, d_err);
+}
+
+}  // namespace dvm

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -263,6 +264,7 @@ int OrbPipeline::init() {
   }
   DVM_HIP(hipSetDevice(device));
   DVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree = (e[0] == '1');  // debug / A-B switch only
   // orientation disc offsets (any order: the moments are exact integer sums)
   int8_t du[kDiscPixels], dv[kDiscPixels];
   int n = 0;
@@ -294,13 +296,13 @@ int OrbPipeline::init() {
 
 void OrbPipeline::free_all() {
   void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_start, d_sel, d_nsel,
-                   d_kps, d_desc, d_aux, d_n, d_mono};
+                   d_kps, d_desc, d_aux, d_n, d_mono, d_nid, d_err};
   for (void* p : dptrs) if (p) hipFree(p);
   void* hptrs[] = {h_lvl_start, h_dense, h_sel, h_nsel, h_n, h_mono};
   for (void* p : hptrs) if (p) hipHostFree(p);
   d_pyr = d_blur = d_desc = nullptr; d_tabs = nullptr; d_cells = nullptr; d_tiles = nullptr;
   d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_start = d_nsel = d_n = d_mono = nullptr;
-  d_kps = nullptr; d_aux = nullptr;
+  d_kps = nullptr; d_aux = nullptr; d_nid = nullptr; d_err = nullptr;
   h_lvl_start = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
   configured = false;  // (the host-image staging buffers d_stage/h_stage live until the destructor)
 }
@@ -428,6 +430,9 @@ int OrbPipeline::configure(int rows, int cols) {
   DVM_HIP(hipMalloc(&d_aux, B * PD.kp_cap * sizeof(KpAux)));
   DVM_HIP(hipMalloc(&d_n, B * 4));
   DVM_HIP(hipMalloc(&d_mono, B * 4));
+  DVM_HIP(hipMalloc(&d_nid, B * PD.cand_frame_slots * 4));
+  DVM_HIP(hipMalloc(&d_err, 4));
+  DVM_HIP(hipMemset(d_err, 0, 4));
   DVM_HIP(hipHostMalloc(&h_lvl_start, B * (kMaxLevels + 1) * 4));
   DVM_HIP(hipHostMalloc(&h_dense, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipHostMalloc(&h_sel, B * PD.sel_frame_slots * 4));
@@ -490,41 +495,47 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   launch_compact(stream, d_cand, d_cell_count, d_cells, PD, d_dense, d_lvl_start, batch);
   prof.end(stream);
 
+  if (!host_octree) {
+    prof.begin(stream, "octree");
+    launch_octree(stream, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel, d_err, batch);
+    prof.end(stream);
+  } else {
   // ---- DistributeOctTree on the host (K3): counts, then each frame's dense candidate prefix
-  DVM_HIP(hipMemcpyAsync(h_lvl_start, d_lvl_start, (size_t)batch * (kMaxLevels + 1) * 4, hipMemcpyDeviceToHost, stream));
-  DVM_HIP(hipStreamSynchronize(stream));
-  for (int f = 0; f < batch; f++) {
-    const int total = h_lvl_start[f * (kMaxLevels + 1) + L];
-    if (total > 0)
-      DVM_HIP(hipMemcpyAsync(h_dense + (size_t)f * PD.cand_frame_slots, d_dense + (size_t)f * PD.cand_frame_slots,
-                             (size_t)total * 4, hipMemcpyDeviceToHost, stream));
-  }
-  DVM_HIP(hipStreamSynchronize(stream));
-  {
-    const int jobs = batch * L;
-    const int nthreads = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), std::min(jobs / 4, 16)));
-    auto work = [&](int t) {
-      std::vector<uint32_t> out;
-      for (int j = t; j < jobs; j += nthreads) {
-        const int f = j / L, l = j % L;
-        const int32_t* ls = h_lvl_start + f * (kMaxLevels + 1);
-        const LevelDesc& D = PD.lv[l];
-        octree_select(h_dense + (size_t)f * PD.cand_frame_slots + ls[l], ls[l + 1] - ls[l], kEdge - 3, D.w - kEdge + 3,
-                      kEdge - 3, D.h - kEdge + 3, D.quota, out);
-        const int n = std::min<int>((int)out.size(), D.sel_cap);
-        h_nsel[f * L + l] = n;
-        std::memcpy(h_sel + (size_t)f * PD.sel_frame_slots + D.sel_off, out.data(), (size_t)n * 4);
-      }
-    };
-    if (nthreads == 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
-      for (auto& t : th) t.join();
+    DVM_HIP(hipMemcpyAsync(h_lvl_start, d_lvl_start, (size_t)batch * (kMaxLevels + 1) * 4, hipMemcpyDeviceToHost, stream));
+    DVM_HIP(hipStreamSynchronize(stream));
+    for (int f = 0; f < batch; f++) {
+      const int total = h_lvl_start[f * (kMaxLevels + 1) + L];
+      if (total > 0)
+        DVM_HIP(hipMemcpyAsync(h_dense + (size_t)f * PD.cand_frame_slots, d_dense + (size_t)f * PD.cand_frame_slots,
+                               (size_t)total * 4, hipMemcpyDeviceToHost, stream));
     }
+    DVM_HIP(hipStreamSynchronize(stream));
+    {
+      const int jobs = batch * L;
+      const int nthreads = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), std::min(jobs / 4, 16)));
+      auto work = [&](int t) {
+        std::vector<uint32_t> out;
+        for (int j = t; j < jobs; j += nthreads) {
+          const int f = j / L, l = j % L;
+          const int32_t* ls = h_lvl_start + f * (kMaxLevels + 1);
+          const LevelDesc& D = PD.lv[l];
+          octree_select(h_dense + (size_t)f * PD.cand_frame_slots + ls[l], ls[l + 1] - ls[l], kEdge - 3, D.w - kEdge + 3,
+                        kEdge - 3, D.h - kEdge + 3, D.quota, out);
+          const int n = std::min<int>((int)out.size(), D.sel_cap);
+          h_nsel[f * L + l] = n;
+          std::memcpy(h_sel + (size_t)f * PD.sel_frame_slots + D.sel_off, out.data(), (size_t)n * 4);
+        }
+      };
+      if (nthreads == 1) work(0);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+        for (auto& t : th) t.join();
+      }
+    }
+    DVM_HIP(hipMemcpyAsync(d_nsel, h_nsel, (size_t)batch * L * 4, hipMemcpyHostToDevice, stream));
+    DVM_HIP(hipMemcpyAsync(d_sel, h_sel, (size_t)batch * PD.sel_frame_slots * 4, hipMemcpyHostToDevice, stream));
   }
-  DVM_HIP(hipMemcpyAsync(d_nsel, h_nsel, (size_t)batch * L * 4, hipMemcpyHostToDevice, stream));
-  DVM_HIP(hipMemcpyAsync(d_sel, h_sel, (size_t)batch * PD.sel_frame_slots * 4, hipMemcpyHostToDevice, stream));
 
   prof.begin(stream, "assemble");
   launch_assemble(stream, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono, batch);
@@ -553,6 +564,9 @@ int OrbPipeline::download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, 
   DVM_HIP(hipMemcpyAsync(h_mono, d_mono, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
   int rc = sync();
   if (rc != DVM_OK) return rc;
+  int32_t oct_err = 0;
+  DVM_HIP(hipMemcpy(&oct_err, d_err, 4, hipMemcpyDeviceToHost));
+  if (oct_err) { set_error("device octree capacity exceeded (quota > 1528 nodes per level)"); return DVM_ERR_CAPACITY; }
   const int N = h_n[frame];
   if (n) *n = N;
   if (mono) *mono = h_mono[frame];

@@ -85,6 +85,9 @@ class OrbPipeline {
   KpAux* d_aux = nullptr;
   int32_t* d_n = nullptr;            // [batch]
   int32_t* d_mono = nullptr;
+  int32_t* d_nid = nullptr;          // [batch][cand_frame_slots] octree scratch: node id per candidate
+  int32_t* d_err = nullptr;          // device error flag (octree capacity)
+  bool host_octree = false;          // debug switch: run DistributeOctTree on the host instead of k_octree
   uint8_t* d_stage = nullptr;        // staging for host images
   size_t stage_bytes = 0;
   // pinned host mirrors
