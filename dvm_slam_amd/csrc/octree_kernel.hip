@@ -13,6 +13,8 @@
 // reproduced by the step-exact emulation in introsort_emul.h (one lane).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "introsort_emul.h"
 #include "orb_device.h"
 #include "orb_kernels.h"
@@ -25,39 +27,46 @@ struct ONodeRec {
   int32_t cnt;
 };
 
-// exclusive scan of data[0..m) in place, 256 threads, returns total through *total (shared)
+// exclusive scan of data[0..m) in place, 256 threads (4 waves): per-thread serial chunk, wave scan by
+// DPP-free shuffles, 4 wave totals through LDS.  *total (shared) receives the sum.  3 barriers.
 __device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, int* total) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (m + 255) / 256;
   const int b = tid * per, e = min(b + per, m);
   int sum = 0;
   for (int i = b; i < e; i++) sum += data[i];
-  s_tmp[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    int v = (tid >= off) ? s_tmp[tid - off] : 0;
-    __syncthreads();
-    s_tmp[tid] += v;
-    __syncthreads();
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
   }
-  int run = s_tmp[tid] - sum;
+  if (lane == 63) s_tmp[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; w++) base += s_tmp[w];
+  int run = base + incl - sum;
   for (int i = b; i < e; i++) { int v = data[i]; data[i] = run; run += v; }
-  if (tid == 255) *total = s_tmp[255];
+  if (tid == 255) *total = base + incl;
   __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ dense, const int32_t* __restrict__ lvl_start,
                                                 PipelineDesc PD, int32_t* __restrict__ nid_scratch,
                                                 uint32_t* __restrict__ sel, int32_t* __restrict__ nsel,
-                                                int32_t* __restrict__ err_flag) {
-  __shared__ ONodeRec listA[kOctMaxNodes], listB[kOctMaxNodes];
-  __shared__ int cc[kOctMaxNodes][4];          // child key counts, later child new-index
-  __shared__ int a_scan[kOctMaxNodes];         // scan workspace 1 (keep index / flags)
-  __shared__ int b_scan[kOctMaxNodes];         // scan workspace 2 (children per processed node)
-  __shared__ int16_t proc[kOctMaxNodes];       // processing order: list indices
-  __shared__ int16_t prank[kOctMaxNodes];      // list index -> rank in processing order or -1
-  __shared__ uint32_t skey[kOctMaxNodes];      // sort keys
-  __shared__ uint16_t sval[kOctMaxNodes];      // sort payload / expandable set (creation order)
+                                                int32_t* __restrict__ err_flag, int cap) {
+  // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64):
+  // 44 B per slot, so the BASELINE config (cap 256) keeps ~11 KB and 8 workgroups fit a CU
+  extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
+  ONodeRec* listA = reinterpret_cast<ONodeRec*>(oct_smem);
+  ONodeRec* listB = listA + cap;
+  int(*cc)[4] = reinterpret_cast<int(*)[4]>(listB + cap);   // child key counts, later child new-index
+  int* a_scan = reinterpret_cast<int*>(cc + cap);            // scan workspace 1 (keep index / flags)
+  int* b_scan = a_scan + cap;                                // scan workspace 2 (children per processed node)
+  uint32_t* skey = reinterpret_cast<uint32_t*>(b_scan + cap);  // sort keys
+  int16_t* proc = reinterpret_cast<int16_t*>(skey + cap);    // processing order: list indices
+  int16_t* prank = proc + cap;                               // list index -> rank in processing order or -1
+  uint16_t* sval = reinterpret_cast<uint16_t*>(prank + cap); // sort payload / expandable set (creation order)
   __shared__ int s_tmp[256];
   __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
 
@@ -76,7 +85,7 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
   }
   const int W = (LV.w - kEdge + 3) - (kEdge - 3), H = (LV.h - kEdge + 3) - (kEdge - 3);  // maxX-minX, maxY-minY
   const int nIni = (int)roundf((float)W / (float)H);
-  if (nIni <= 0 || 4 * nIni > kOctMaxNodes || N + 8 > kOctMaxNodes) {
+  if (nIni <= 0 || 4 * nIni > cap || N + 8 > cap) {
     if (tid == 0) { *out_n = 0; atomicExch(err_flag, 1); }
     return;
   }
@@ -181,7 +190,7 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
     __syncthreads();
     block_scan_excl(a_scan, m, s_tmp, &s_keep);
     const int newSize = totalC + s_keep;
-    if (newSize > kOctMaxNodes) {
+    if (newSize > cap) {
       if (tid == 0) { *out_n = 0; atomicExch(err_flag, 2); }
       return;
     }
@@ -258,7 +267,22 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
 
 void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_start, const PipelineDesc& PD,
                    int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch) {
-  hipLaunchKernelGGL(k_octree, dim3(PD.nlevels, batch), dim3(256), 0, s, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel, d_err);
+  int need = 64;
+  for (int l = 0; l < PD.nlevels; l++) {
+    const int W = PD.lv[l].w - 2 * (kEdge - 3), H = PD.lv[l].h - 2 * (kEdge - 3);
+    const int nIni = H > 0 ? (int)(W / (float)H + 0.5f) : 0;
+    need = std::max(need, std::max(PD.lv[l].quota + 8, 4 * nIni + 4));
+  }
+  int cap = std::min((need + 63) / 64 * 64, kOctMaxNodes);
+  static bool attr_set = false;
+  const size_t bytes = (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2);
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        kOctMaxNodes * (2 * (int)sizeof(ONodeRec) + 34));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_octree, dim3(PD.nlevels, batch), dim3(256), bytes, s, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel,
+                     d_err, cap);
 }
 
 }  // namespace dvm

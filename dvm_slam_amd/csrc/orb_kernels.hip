@@ -139,58 +139,144 @@ __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int 
 // (0 elsewhere and outside the 3-px ROI frame), cv::FAST(t) with NMS returns exactly
 // { p : S(p) >= t and S(p) > S(q) for the 8 neighbours q }, in row-major order, response S(p).
 // Output: candidates in the cell's slot range, row-major, packed (x-16, y-16, score).
+//
+// Structure (work shrinks at every step, wavefronts stay dense):
+//   1. ROI tile -> LDS with aligned dword loads; score map zeroed
+//   A. every pixel: compass pre-test (two ADJACENT ring positions of {0,4,8,12} both darker than
+//      v - tlow or both brighter than v + tlow -- necessary because any 9-arc of the 16-ring holds two
+//      adjacent compass pixels); survivors are appended IN ROW-MAJOR ORDER to an LDS list
+//   B. survivors only: full FAST strength -> score map + per-survivor score
+//   C. survivors with a score: 3x3 strict-maximum test, threshold bits, ordered compaction
+// LDS is dynamic and sized for the largest cell of the current image size (FastLds), so the BASELINE
+// config needs ~12 KB per workgroup and 8 workgroups (32 waves) stay resident per CU.
+struct FastLds {
+  int tile_pitch, tile_bytes, score_bytes, plist_bytes, pscore_bytes;
+  __host__ __device__ int total() const { return tile_bytes + score_bytes + plist_bytes + pscore_bytes; }
+};
+__host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
+  FastLds l;
+  l.tile_pitch = (max_rw + 3 + 3) & ~3;
+  l.tile_bytes = (l.tile_pitch * max_rh + 15) & ~15;
+  const int ew = max_rw - 6 > 0 ? max_rw - 6 : 1, eh = max_rh - 6 > 0 ? max_rh - 6 : 1;
+  l.score_bytes = ((((ew + 2 + 3) & ~3) * (eh + 2)) + 15) & ~15;
+  l.plist_bytes = (ew * eh * 2 + 15) & ~15;
+  l.pscore_bytes = (ew * eh + 15) & ~15;
+  return l;
+}
 __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                     const CellDesc* __restrict__ cells, PipelineDesc PD,
-                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count) {
-  __shared__ uint8_t tile[kMaxCellDim * kMaxCellDim];
-  __shared__ uint8_t score[(kMaxCellDim - 4) * (kMaxCellDim - 4)];
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
+                                                    int max_rw, int max_rh) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+  const FastLds lay = fast_lds_layout(max_rw, max_rh);
+  const int kTilePitch = lay.tile_pitch;
+  uint8_t* tile = fast_smem;
+  uint8_t* score = tile + lay.tile_bytes;
+  uint16_t* plist = reinterpret_cast<uint16_t*>(score + lay.score_bytes);
+  uint8_t* pscore = reinterpret_cast<uint8_t*>(plist) + lay.plist_bytes;
   __shared__ int s_cnt_ini;
-  __shared__ int s_wave_tot[40][4];
+  __shared__ int s_wave_tot[33][4];
 
   const int f = blockIdx.y;
   const CellDesc c = cells[blockIdx.x];
   const LevelDesc& L = PD.lv[c.level];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rw = c.rw, rh = c.rh;
   const int ew = rw - 6, eh = rh - 6;  // evaluated area (FAST skips a 3-px frame of the ROI)
-  const int sp = ew + 2;               // score pitch (1-px zero ring)
+  const int sp = (ew + 2 + 3) & ~3;    // score pitch (1-px zero ring), multiple of 4
   int32_t* my_count = cell_count + (int64_t)f * PD.ncells + blockIdx.x;
   if (ew <= 0 || eh <= 0) {
     if (tid == 0) *my_count = 0;
     return;
   }
-  const uint8_t* img = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + c.y0) * L.stride + kEdge + c.x0;
-  for (int i = tid; i < rw * rh; i += 256) {
-    int y = i / rw, x = i - y * rw;
-    tile[y * rw + x] = img[(int64_t)y * L.stride + x];
+  // ---- 1. tile load: aligned dwords covering each ROI row; LDS column = global column - (x_start & ~3)
+  const int64_t row0 = (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + c.y0) * L.stride;
+  const int xg = kEdge + c.x0;           // first ROI column inside the bordered row
+  const int sh = xg & 3;                 // tile[y][sh + x] holds ROI pixel (x, y)
+  const int dwr = (sh + rw + 3) >> 2;    // dwords per row
+  const uint32_t* g32 = reinterpret_cast<const uint32_t*>(pyr + row0 + (xg - sh));  // stride is a multiple of 64
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
+  {
+    int y = tid / dwr, x = tid - y * dwr;          // one division, then incremental
+    const int dy = 256 / dwr, dx = 256 - dy * dwr;
+    while (y < rh) {
+      t32[y * (kTilePitch / 4) + x] = g32[(int64_t)y * (L.stride >> 2) + x];
+      x += dx; y += dy;
+      if (x >= dwr) { x -= dwr; y++; }
+    }
   }
-  for (int i = tid; i < sp * (eh + 2); i += 256) score[i] = 0;
+  uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
+  for (int i = tid; i < (sp * (eh + 2)) >> 2; i += 256) s32[i] = 0;
   if (tid == 0) s_cnt_ini = 0;
   __syncthreads();
 
   const int tlow = min(PD.ini_th, PD.min_th);
   const int npx = ew * eh;
-  for (int i = tid; i < npx; i += 256) {
-    int ey = i / ew, ex = i - ey * ew;
-    int m = fast_strength(&tile[(ey + 3) * rw + ex + 3], rw);
-    if (m > tlow) score[(ey + 1) * sp + ex + 1] = (uint8_t)(m - 1);
+  const int roundsA = (npx + 255) >> 8;   // <= 32
+  const uint8_t* T = tile + sh;
+  // ---- A. compass pre-test over all pixels; (ey, ex) advance incrementally by 256 pixels
+  uint32_t passbits = 0;
+  {
+    int ey = tid / ew, ex = tid - ey * ew;
+    const int dy = 256 / ew, dx = 256 - dy * ew;
+    for (int r = 0; r < roundsA; r++) {
+      bool pass = false;
+      if (ey < eh) {
+        const uint8_t* t = &T[(ey + 3) * kTilePitch + ex + 3];
+        const int v = t[0];
+        const int dn = v - t[3 * kTilePitch], de = v - t[3], ds = v - t[-3 * kTilePitch], dw = v - t[-3];
+        const bool kn = dn > tlow, ke = de > tlow, ks = ds > tlow, kw = dw > tlow;       // darker
+        const bool bn = dn < -tlow, be = de < -tlow, bs = ds < -tlow, bw = dw < -tlow;   // brighter
+        pass = (kn & ke) | (ke & ks) | (ks & kw) | (kw & kn) | (bn & be) | (be & bs) | (bs & bw) | (bw & bn);
+      }
+      const unsigned long long mk = __ballot(pass);
+      if (lane == 0) s_wave_tot[r][wave] = __popcll(mk);
+      passbits |= (pass ? 1u : 0u) << r;
+      ex += dx; ey += dy;
+      if (ex >= ew) { ex -= ew; ey++; }
+    }
   }
   __syncthreads();
-
-  // local strict maxima; bit0 = passes iniTh, bit1 = passes minTh
-  const int rounds = (npx + 255) / 256;
-  uint32_t flags_lo = 0, flags_hi = 0;  // 2 bits per round, up to 32 rounds (npx <= 8192)
+  int npass = 0;
+  {
+    int ey = tid / ew, ex = tid - ey * ew;
+    const int dy = 256 / ew, dx = 256 - dy * ew;
+    for (int r = 0; r < roundsA; r++) {
+      const bool pass = (passbits >> r) & 1u;
+      const unsigned long long mk = __ballot(pass);
+      int before = 0;
+      for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
+      if (pass) plist[npass + before + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)((ey << 7) | ex);
+      npass += s_wave_tot[r][0] + s_wave_tot[r][1] + s_wave_tot[r][2] + s_wave_tot[r][3];
+      ex += dx; ey += dy;
+      if (ex >= ew) { ex -= ew; ey++; }
+    }
+  }
+  __syncthreads();
+  // ---- B. full strength for the survivors (list is row-major ordered)
+  for (int k = tid; k < npass; k += 256) {
+    const int pe = plist[k];
+    const int ey = pe >> 7, ex = pe & 127;
+    const int m = fast_strength(&T[(ey + 3) * kTilePitch + ex + 3], kTilePitch);
+    const int sc = m > tlow ? m - 1 : 0;
+    pscore[k] = (uint8_t)sc;
+    if (sc) score[(ey + 1) * sp + ex + 1] = (uint8_t)sc;
+  }
+  __syncthreads();
+  // ---- C. strict local maxima among the survivors; bit0 = passes iniTh, bit1 = passes minTh
+  const int rounds = (npass + 255) >> 8;
+  uint32_t flags_lo = 0, flags_hi = 0;  // 2 bits per round, up to 32 rounds
   int cnt_ini = 0;
   for (int r = 0; r < rounds; r++) {
-    int i = r * 256 + tid;
+    const int k = r * 256 + tid;
     int fl = 0;
-    if (i < npx) {
-      int ey = i / ew, ex = i - ey * ew;
-      const uint8_t* s = &score[(ey + 1) * sp + ex + 1];
-      int sv = s[0];
+    if (k < npass) {
+      const int sv = pscore[k];
       if (sv > 0) {
-        int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
-                     max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
+        const int pe = plist[k];
+        const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
+        const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
+                           max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
         if (sv > mx) fl = (sv >= PD.ini_th ? 1 : 0) | (sv >= PD.min_th ? 2 : 0);
       }
     }
@@ -202,28 +288,27 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   __syncthreads();
   const int bit = (s_cnt_ini > 0) ? 1 : 2;  // first call non-empty -> keep it, else the retry's result
 
-  // ordered compaction: element index i = r*256 + tid must come out in increasing i
-  const int lane = tid & 63, wave = tid >> 6;
+  // ordered compaction: survivor index k = r*256 + tid is row-major, so emit in increasing k
   for (int r = 0; r < rounds; r++) {
-    int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
-    unsigned long long m = __ballot((fl & bit) != 0);
+    const int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
+    const unsigned long long m = __ballot((fl & bit) != 0);
     if (lane == 0) s_wave_tot[r][wave] = __popcll(m);
   }
   __syncthreads();
   int base = 0;
   uint32_t* out = cand + (int64_t)f * PD.cand_frame_slots + c.cand_base;
   for (int r = 0; r < rounds; r++) {
-    int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
-    bool keep = (fl & bit) != 0;
-    unsigned long long m = __ballot(keep);
+    const int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
+    const bool keep = (fl & bit) != 0;
+    const unsigned long long m = __ballot(keep);
     int before = 0;
     for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
-    int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+    const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
     if (keep && pos < c.cand_cap) {
-      int i = r * 256 + tid;
-      int ey = i / ew, ex = i - ey * ew;
+      const int k = r * 256 + tid;
+      const int pe = plist[k];
       // border-relative level coordinates: (roi origin + 3 + e) - 16
-      out[pos] = pack_cand(c.x0 + 3 + ex - (kEdge - 3), c.y0 + 3 + ey - (kEdge - 3), score[(ey + 1) * sp + ex + 1]);
+      out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), pscore[k]);
     }
     base += s_wave_tot[r][0] + s_wave_tot[r][1] + s_wave_tot[r][2] + s_wave_tot[r][3];
   }
@@ -519,9 +604,16 @@ void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, in
   hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, PD.lv[level - 1], L, d_tabs);
 }
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
-                 int32_t* d_cell_count, int batch) {
-  hipLaunchKernelGGL(k_fast_cells, dim3(PD.ncells, batch), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_cells, PD,
-                     d_cand, d_cell_count);
+                 int32_t* d_cell_count, int batch, int max_rw, int max_rh) {
+  const FastLds lay = fast_lds_layout(max_rw, max_rh);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        fast_lds_layout(kMaxCellDim, kMaxCellDim).total());
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_fast_cells, dim3(PD.ncells, batch), dim3(256), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells,
+                     PD, d_cand, d_cell_count, max_rw, max_rh);
 }
 void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
                     const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch) {

@@ -406,6 +406,8 @@ int OrbPipeline::configure(int rows, int cols) {
     for (int y = 0; y < D.h; y += 32)
       for (int x = 0; x < D.w; x += 64) tiles.push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
   }
+  max_cell_rw = max_cell_rh = 8;
+  for (const CellDesc& c : cells) { max_cell_rw = std::max<int>(max_cell_rw, c.rw); max_cell_rh = std::max<int>(max_cell_rh, c.rh); }
   PD.ncells = (int)cells.size();
   PD.ntiles = (int)tiles.size();
   PD.pyr_frame_bytes = pyr_off;
@@ -489,7 +491,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   for (int l = 1; l < L; l++) launch_pyr_resize(stream, d_pyr, PD, l, d_tabs, batch);
   prof.end(stream);
   prof.begin(stream, "fast");
-  launch_fast(stream, d_pyr, d_cells, PD, d_cand, d_cell_count, batch);
+  launch_fast(stream, d_pyr, d_cells, PD, d_cand, d_cell_count, batch, max_cell_rw, max_cell_rh);
   prof.end(stream);
   prof.begin(stream, "compact");
   launch_compact(stream, d_cand, d_cell_count, d_cells, PD, d_dense, d_lvl_start, batch);

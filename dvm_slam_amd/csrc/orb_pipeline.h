@@ -66,6 +66,7 @@ class OrbPipeline {
   std::vector<CellDesc> cells;
   std::vector<TileDesc> tiles;
   int last_batch = 0;
+  int max_cell_rw = 8, max_cell_rh = 8;  // largest FAST cell ROI of the current image size
   bool configured = false;
 
   // device memory
