@@ -445,39 +445,66 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ s
 // The pyramid's 19-px REFLECT_101 frame already holds the mirrored pixels, so the tile loader just
 // reads the bordered buffer.  Tile = 64 x 32 outputs, LDS: raw (38 x 70) u8 + hpass (38 x 64) u16.
 constexpr int kBlurTW = 64, kBlurTH = 32;
+constexpr int kRawPitch = 72;   // bytes: 64 + 6 halo, rounded to dwords (tile rows are dword aligned: x0 % 64 == 0)
+constexpr int kHpPitch = 68;    // u16 elements (136 B): de-phases the 64-bit column reads of the v-pass
 __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                const TileDesc* __restrict__ tiles, PipelineDesc PD,
                                                const int32_t* __restrict__ nsel) {
-  __shared__ uint8_t raw[(kBlurTH + 6) * (kBlurTW + 8)];
-  __shared__ uint16_t hp[(kBlurTH + 6) * kBlurTW];
+  __shared__ __attribute__((aligned(16))) uint8_t raw[(kBlurTH + 6) * kRawPitch];
+  __shared__ __attribute__((aligned(16))) uint16_t hp[(kBlurTH + 6) * kHpPitch];
   const int f = blockIdx.y, tid = threadIdx.x;
   const TileDesc t = tiles[blockIdx.x];
   if (nsel[f * PD.nlevels + t.level] == 0) return;  // reference skips levels without keypoints (:915-916)
   const LevelDesc& L = PD.lv[t.level];
-  const uint8_t* src = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + t.y0 - 3) * L.stride +
-                       (kEdge + t.x0 - 3);
-  const int tw = min(kBlurTW, L.w - t.x0), th = min(kBlurTH, L.h - t.y0);
-  const int RW = kBlurTW + 8;
-  for (int i = tid; i < (th + 6) * (tw + 6); i += 256) {
-    int y = i / (tw + 6), x = i - y * (tw + 6);
-    raw[y * RW + x] = src[(int64_t)y * L.stride + x];
+  const int th = min(kBlurTH, L.h - t.y0);
+  // raw tile: rows y0-3 .. y0+th+2, bordered columns (16 + x0) .. +71 as 18 aligned dwords per row
+  const int colb = kEdge - 3 + t.x0;                       // multiple of 4
+  const int ndw = min(kRawPitch / 4, (L.stride - colb) >> 2);  // stay inside the bordered row
+  const uint32_t* g32 = reinterpret_cast<const uint32_t*>(pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off +
+                                                          (int64_t)(kEdge + t.y0 - 3) * L.stride + colb);
+  uint32_t* r32 = reinterpret_cast<uint32_t*>(raw);
+  for (int i = tid; i < (th + 6) * (kRawPitch / 4); i += 256) {
+    const int y = i / (kRawPitch / 4), x = i - y * (kRawPitch / 4);
+    r32[i] = (x < ndw) ? g32[(int64_t)y * (L.stride >> 2) + x] : 0u;
   }
   __syncthreads();
-  for (int i = tid; i < (th + 6) * tw; i += 256) {
-    int y = i / tw, x = i - y * tw;
-    const uint8_t* r = &raw[y * RW + x];
-    int acc = c_gauss7[0] * (r[0] + r[6]) + c_gauss7[1] * (r[1] + r[5]) + c_gauss7[2] * (r[2] + r[4]) + c_gauss7[3] * r[3];
-    hp[y * kBlurTW + x] = (uint16_t)acc;
+  const int g0 = c_gauss7[0], g1 = c_gauss7[1], g2 = c_gauss7[2], g3 = c_gauss7[3];
+  // h-pass: one item = 4 adjacent outputs of one row (10 source bytes), 8.8 fixed point
+  for (int i = tid; i < (th + 6) * 16; i += 256) {
+    const int y = i >> 4, g = i & 15;
+    const uint8_t* r = &raw[y * kRawPitch + 4 * g];
+    int p[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) p[k] = r[k];
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = g0 * (p[k] + p[k + 6]) + g1 * (p[k + 1] + p[k + 5]) + g2 * (p[k + 2] + p[k + 4]) + g3 * p[k + 3];
+    uint2 w;
+    w.x = o[0] | (o[1] << 16);
+    w.y = o[2] | (o[3] << 16);
+    *reinterpret_cast<uint2*>(&hp[y * kHpPitch + 4 * g]) = w;
   }
   __syncthreads();
+  // v-pass: one item = 4 adjacent columns of one output row, 16.16 accumulate, round to nearest
   uint8_t* dst = blur + (int64_t)f * blur_frame_bytes + L.blur_off + (int64_t)t.y0 * L.blur_stride + t.x0;
-  for (int i = tid; i < th * tw; i += 256) {
-    int y = i / tw, x = i - y * tw;
-    const uint16_t* c = &hp[y * kBlurTW + x];
-    uint32_t acc = (uint32_t)c_gauss7[0] * (c[0] + c[6 * kBlurTW]) + (uint32_t)c_gauss7[1] * (c[kBlurTW] + c[5 * kBlurTW]) +
-                   (uint32_t)c_gauss7[2] * (c[2 * kBlurTW] + c[4 * kBlurTW]) + (uint32_t)c_gauss7[3] * c[3 * kBlurTW];
-    dst[(int64_t)y * L.blur_stride + x] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+  for (int i = tid; i < th * 16; i += 256) {
+    const int y = i >> 4, g = i & 15;
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const uint2 w = *reinterpret_cast<const uint2*>(&hp[(y + j) * kHpPitch + 4 * g]);
+      const uint32_t k = (uint32_t)c_gauss7[j];
+      acc[0] += k * (w.x & 0xFFFFu);
+      acc[1] += k * (w.x >> 16);
+      acc[2] += k * (w.y & 0xFFFFu);
+      acc[3] += k * (w.y >> 16);
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out |= min((acc[k] + 32768u) >> 16, 255u) << (8 * k);
+    // the blurred image's pitch is a multiple of 64, so a full dword store never leaves the row
+    *reinterpret_cast<uint32_t*>(dst + (int64_t)y * L.blur_stride + 4 * g) = out;
   }
 }
 
