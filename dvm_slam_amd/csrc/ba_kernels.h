@@ -34,7 +34,7 @@ struct BaView {
   const int32_t *blk_i1, *blk_i2, *blk_start;  // non-zero lower blocks of the reduced camera matrix
   const int32_t *pair_k1, *pair_k2;            // per block: (edge of i1, edge of i2) sharing a landmark
   double* S;                // [ldS][ldS] dense lower triangle + augmented rhs row
-  double* Ldiag;            // [64*64] scratch for the factored diagonal block
+  double* Linv;             // [ldS/64][64*64] inverses of the factored diagonal blocks
   double* ytmp;             // [6*nfree]
   double* x;                // [6*nfree + 3*L]
   double *partial, *partial2;

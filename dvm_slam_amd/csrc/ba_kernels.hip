@@ -8,7 +8,7 @@
 //       k_pose_accum           Hpp (6x6), bp per camera         (one wave per camera, fixed-order reduce)
 //   K9  k_dinv, k_schur_blocks Dinv = (Hll+lambda I)^-1 ; Hschur block = Hpp - sum W Dinv W^T
 //       k_schur_rhs            bschur = bp - sum W Dinv bl  (stored as the augmented row of S)
-//   K10 k_chol_panel / k_chol_update   blocked dense Cholesky, trailing update on v_mfma_f64_16x16x4
+//   K10 k_chol_diag / k_chol_trsm / k_chol_update   blocked dense Cholesky on v_mfma_f64_16x16x4
 //       k_chol_backsolve       L^T x = y
 //   K11 k_point_backsub, k_update      xl = Dinv (bl - W^T xp); T <- exp(d) T, X <- X + d
 // All accumulations are gathers with a fixed order: results are run-to-run deterministic.
@@ -307,94 +307,132 @@ __global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
 // ----------------------------------------------------------------------------------------- K10
 // Blocked right-looking Cholesky of the lower triangle of S (row-major, leading dim ldS), NB = 64,
 // over n1 = 6*nfree + 1 rows: the extra row carries bschur^T, so after the factorisation row n holds
-// y^T with L y = bschur (forward substitution for free).
-//
-// Panel step kb: every workgroup factors the 64x64 diagonal block in LDS (redundantly: same latency
-// as a separate launch, one launch fewer), then solves its own 64-row strip X L_kk^T = A_ik.
+// y^T with L y = bschur (forward substitution for free).  Per step: k_chol_diag (one wave: block
+// Cholesky + its inverse), k_chol_trsm (strips as GEMM with the inverse), k_chol_update (MFMA).
 constexpr int NB = 64;
-__global__ void __launch_bounds__(256) k_chol_panel(double* __restrict__ S, int ldS, int n1, int kb, int* __restrict__ fail,
-                                                    double* __restrict__ Ldiag) {
-  __shared__ double Lkk[NB][NB + 1];
-  __shared__ double strip[NB][NB + 1];
-  __shared__ int s_fail;
+
+__device__ __forceinline__ double bcast_lane(double v, int src_lane) {  // src_lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Diagonal step kb, ONE wavefront, no barriers: lane r keeps row r of the 64x64 block in registers.
+//   1. left-looking Cholesky: column j of L from row j broadcast lane->scalar (v_readlane)
+//   2. Linv = L^-1 by forward substitution, lane c owning column c
+// L goes back into S (lower triangle), Linv (row-major, zero above the diagonal) into Linv_all[kb].
+// The column-by-column dependency chain of a dense Cholesky lives here; keeping it inside one wave
+// (instead of two workgroup barriers per column) is what makes the solve fast.
+__global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ S, int ldS, int n1, int kb, int* __restrict__ fail,
+                                                  double* __restrict__ Linv_all) {
+  const int lane = threadIdx.x;
+  const int k0 = kb * NB;
+  const int kw = min(NB, n1 - k0);
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; c++) {
+    double v = (lane == c) ? 1.0 : 0.0;  // rows / columns beyond the matrix: identity
+    if (lane < kw && c < kw && c <= lane) v = S[(size_t)(k0 + lane) * ldS + k0 + c];
+    a[c] = v;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    // four independent partial sums: the FMA latency chain is j/4 long instead of j
+    double s0 = a[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < j; k++) {
+      const double t = bcast_lane(a[k], j);
+      if ((k & 3) == 0) s0 = __builtin_fma(-a[k], t, s0);
+      else if ((k & 3) == 1) s1 = __builtin_fma(-a[k], t, s1);
+      else if ((k & 3) == 2) s2 = __builtin_fma(-a[k], t, s2);
+      else s3 = __builtin_fma(-a[k], t, s3);
+    }
+    const double s = (s0 + s1) + (s2 + s3);
+    const double d = bcast_lane(s, j);
+    if (!(d > 0.0)) bad = true;
+    const double sq = sqrt(d > 0.0 ? d : 1.0);
+    a[j] = (lane == j) ? sq : (lane > j ? s / sq : 0.0);
+  }
+  if (bad && lane == 0) *fail = 1;
+#pragma unroll
+  for (int c = 0; c < NB; c++)
+    if (lane < kw && c <= lane) S[(size_t)(k0 + lane) * ldS + k0 + c] = a[c];
+  // forward substitution: y = column `lane` of L^-1
+  double y[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int t = 0; t < i; t++) {
+      const double l = bcast_lane(a[t], i);
+      if ((t & 3) == 0) s0 = __builtin_fma(-l, y[t], s0);
+      else if ((t & 3) == 1) s1 = __builtin_fma(-l, y[t], s1);
+      else if ((t & 3) == 2) s2 = __builtin_fma(-l, y[t], s2);
+      else s3 = __builtin_fma(-l, y[t], s3);
+    }
+    y[i] = ((s0 + s1) + (s2 + s3)) / bcast_lane(a[i], i);
+  }
+  double* Li = Linv_all + (size_t)kb * NB * NB;
+#pragma unroll
+  for (int i = 0; i < NB; i++) Li[i * NB + lane] = (lane <= i) ? y[i] : 0.0;
+}
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// Panel solve of step kb: strip i (64 rows below the diagonal block) becomes X = A_ik * Linv_kk^T
+// (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM.
+__global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1, int kb,
+                                                   const double* __restrict__ Linv_all) {
+  __shared__ double Ai[NB][NB + 1];
+  __shared__ double Li[NB][NB + 1];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
-  const int kw = min(NB, n1 - k0);  // columns of this panel
-  if (tid == 0) s_fail = 0;
-  for (int i = tid; i < NB * NB; i += 256) {
-    int r = i / NB, c = i % NB;
-    Lkk[r][c] = (r < kw && c <= r) ? S[(size_t)(k0 + r) * ldS + k0 + c] : 0.0;
-  }
-  __syncthreads();
-  // unblocked Cholesky of Lkk (lower), column by column
-  for (int j = 0; j < kw; j++) {
-    if (tid == 0) {
-      double d = Lkk[j][j];
-      if (!(d > 0)) { s_fail = 1; d = 1.0; }
-      Lkk[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    const double djj = Lkk[j][j];
-    for (int r = j + 1 + tid; r < kw; r += 256) Lkk[r][j] /= djj;
-    __syncthreads();
-    // trailing update of the block: A[r][c] -= L[r][j] L[c][j], j < c <= r
-    const int m = kw - j - 1;
-    for (int i = tid; i < m * m; i += 256) {
-      int r = j + 1 + i / m, c = j + 1 + i % m;
-      if (c <= r) Lkk[r][c] -= Lkk[r][j] * Lkk[c][j];
-    }
-    __syncthreads();
-  }
-  if (blockIdx.x == 0) {
-    // The other workgroups are still reading the un-factored block from S: park the factor in Ldiag
-    // (k_chol_update's first workgroup moves it into S); with no strip below, write S directly.
-    for (int i = tid; i < NB * NB; i += 256) {
-      int r = i / NB, c = i % NB;
-      if (gridDim.x == 1) { if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Lkk[r][c]; }
-      else Ldiag[i] = Lkk[r][c];
-    }
-    if (tid == 0 && s_fail) *fail = 1;
-    return;
-  }
-  // strip rows [r0, r0+rw)
-  const int r0 = k0 + NB + (blockIdx.x - 1) * NB;
+  const int r0 = k0 + NB + blockIdx.x * NB;
   const int rw = min(NB, n1 - r0);
-  if (rw <= 0) return;
+  const double* Lk = Linv_all + (size_t)kb * NB * NB;
   for (int i = tid; i < NB * NB; i += 256) {
-    int r = i / NB, c = i % NB;
-    strip[r][c] = (r < rw && c < kw) ? S[(size_t)(r0 + r) * ldS + k0 + c] : 0.0;
+    const int r = i / NB, c = i % NB;
+    Ai[r][c] = (r < rw) ? S[(size_t)(r0 + r) * ldS + k0 + c] : 0.0;
+    Li[r][c] = Lk[i];
   }
   __syncthreads();
-  // X L^T = A  ->  for column c: X[r][c] = (A[r][c] - sum_{t<c} X[r][t] L[c][t]) / L[c][c]; one thread per row
-  if (tid < rw) {
-    for (int c = 0; c < kw; c++) {
-      double s = strip[tid][c];
-      for (int t = 0; t < c; t++) s -= strip[tid][t] * Lkk[c][t];
-      strip[tid][c] = s / Lkk[c][c];
-    }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; x++)
+#pragma unroll
+    for (int y = 0; y < 2; y++) acc[x][y] = (double4_t){0, 0, 0, 0};
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+  for (int k = 0; k < NB; k += 4) {
+    const double a0 = Ai[qi + lr][k + lk], a1 = Ai[qi + 16 + lr][k + lk];
+    const double b0 = Li[qj + lr][k + lk], b1 = Li[qj + 16 + lr][k + lk];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
   }
-  __syncthreads();
-  for (int i = tid; i < NB * NB; i += 256) {
-    int r = i / NB, c = i % NB;
-    if (r < rw && c < kw) S[(size_t)(r0 + r) * ldS + k0 + c] = strip[r][c];
-  }
+  const int kw = min(NB, n1 - k0);
+#pragma unroll
+  for (int x = 0; x < 2; x++)
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = qi + 16 * x + (lane >> 4) + 4 * r, col = qj + 16 * y + (lane & 15);
+        if (row < rw && col < kw) S[(size_t)(r0 + row) * ldS + k0 + col] = acc[x][y][r];
+      }
 }
 
 // Trailing update A_ij -= A_ik A_jk^T for 64x64 tiles i >= j > kb.  blockIdx.x enumerates the lower
 // triangle of tiles.  4 waves, each owning a 32x32 quadrant = 2x2 MFMA tiles of
 // v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
 // C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg).
-typedef double double4_t __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1, int kb,
-                                                     const double* __restrict__ Ldiag) {
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1, int kb) {
   __shared__ double Ai[NB][NB + 1];
   __shared__ double Aj[NB][NB + 1];
-  if (blockIdx.x == 0) {  // move the factored diagonal block of this step into S (nobody reads it here)
-    for (int i = threadIdx.x; i < NB * NB; i += 256) {
-      int r = i / NB, c = i % NB;
-      if (kb * NB + r < n1 && c <= r) S[(size_t)(kb * NB + r) * ldS + kb * NB + c] = Ldiag[i];
-    }
-  }
   // decode (ti, tj), ti >= tj, from the linear lower-triangle index
   const int t = blockIdx.x;
   int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
@@ -440,39 +478,43 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
       }
 }
 
-// Backward substitution L^T x = y, y = row n of S (in place in `x`).  Step kb (descending): every
-// workgroup solves the kb-th 64-block x_k = L_kk^-T y_k redundantly; workgroup 0 stores it, workgroup
-// j+1 (j < kb) applies y_j -= L[kblock, jblock]^T x_k.
-__global__ void __launch_bounds__(64) k_chol_backsolve(const double* __restrict__ S, int ldS, int n, int kb,
-                                                       double* __restrict__ y, double* __restrict__ x) {
+// Backward substitution L^T x = y, y = row n of S.  Step kb (descending): every workgroup forms
+// x_k = Linv_kk^T y_k (64 dot products, no dependency chain); workgroup 0 stores it, workgroup j+1
+// (j < kb) applies y_j -= L[kblock, jblock]^T x_k.
+__global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n, int kb,
+                                                        double* __restrict__ y, double* __restrict__ x,
+                                                        const double* __restrict__ Linv_all) {
+  __shared__ double yk[NB];
   __shared__ double xk[NB];
-  __shared__ double Lkk[NB][NB + 1];
-  const int tid = threadIdx.x;
+  __shared__ double part[4][NB];
+  const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
   const int k0 = kb * NB;
   const int kw = min(NB, n - k0);
-  for (int i = tid; i < NB * NB; i += 64) {
-    int r = i / NB, c = i % NB;
-    Lkk[r][c] = (r < kw && c <= r) ? S[(size_t)(k0 + r) * ldS + k0 + c] : 0.0;
-  }
-  if (tid < NB) xk[tid] = (tid < kw) ? y[k0 + tid] : 0.0;  // y_k is final: only blocks j < kb are updated below
+  if (tid < NB) yk[tid] = (tid < kw) ? y[k0 + tid] : 0.0;  // y_k is final: only blocks j < kb are updated below
   __syncthreads();
-  if (tid == 0) {
-    for (int c = kw - 1; c >= 0; c--) {
-      double s = xk[c];
-      for (int r = c + 1; r < kw; r++) s -= Lkk[r][c] * xk[r];
-      xk[c] = s / Lkk[c][c];
-    }
-  }
+  const double* Lk = Linv_all + (size_t)kb * NB * NB;
+  // (Linv^T y)[c] = sum_r Linv[r][c] y[r]  (Linv is zero above the diagonal); 4 row-quarters per column
+  double s = 0;
+#pragma unroll
+  for (int r = 0; r < 16; r++) s += Lk[(16 * q + r) * NB + c] * yk[16 * q + r];
+  part[q][c] = s;
+  __syncthreads();
+  if (tid < NB) xk[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
   __syncthreads();
   if (blockIdx.x == 0) {
     if (tid < kw) x[k0 + tid] = xk[tid];
     return;
   }
   const int j0 = (blockIdx.x - 1) * NB;  // j < kb
-  // y_j[c] -= sum_r L[k0+r][j0+c] * xk[r]
-  double s = 0;
-  for (int r = 0; r < kw; r++) s += S[(size_t)(k0 + r) * ldS + j0 + tid] * xk[r];
-  y[j0 + tid] -= s;
+  double u = 0;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int rr = 16 * q + r;
+    u += (rr < kw) ? S[(size_t)(k0 + rr) * ldS + j0 + c] * xk[rr] : 0.0;
+  }
+  part[q][c] = u;
+  __syncthreads();
+  if (tid < NB) y[j0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
 __global__ void __launch_bounds__(256) k_copy_rhs_row(const double* __restrict__ S, int ldS, int n, double* __restrict__ x) {
@@ -611,14 +653,16 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
   const int nkb = cdiv(n1, NB);
   for (int kb = 0; kb < nkb; kb++) {
     const int below = cdiv(std::max(n1 - (kb + 1) * NB, 0), NB);
-    hipLaunchKernelGGL(k_chol_panel, dim3(1 + below), dim3(256), 0, s, V.S, V.ldS, n1, kb, d_fail, V.Ldiag);
-    if (below > 0)
-      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.Ldiag);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, V.S, V.ldS, n1, kb, d_fail, V.Linv);
+    if (below > 0) {
+      hipLaunchKernelGGL(k_chol_trsm, dim3(below), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.Linv);
+      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, s, V.S, V.ldS, n1, kb);
+    }
   }
   hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(n, 256)), dim3(256), 0, s, V.S, V.ldS, n, V.ytmp);
   const int nxb = cdiv(n, NB);
   for (int kb = nxb - 1; kb >= 0; kb--)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + kb), dim3(64), 0, s, V.S, V.ldS, n, kb, V.ytmp, V.x);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + kb), dim3(256), 0, s, V.S, V.ldS, n, kb, V.ytmp, V.x, V.Linv);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, double lambda, double* d_scalars, int slot_scale) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);

@@ -160,7 +160,7 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(h->dalloc(&V.Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&V.bp, (size_t)n));
   ok(h->dalloc(&V.Hll, 9 * (size_t)L)); ok(h->dalloc(&V.bl, 3 * (size_t)L));
   ok(h->dalloc(&V.Dinv, 9 * (size_t)L)); ok(h->dalloc(&V.db, 3 * (size_t)L));
-  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Ldiag, (size_t)64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)n + 64));
+  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)n + 64));
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(std::max(L, V.nfree) + 255) / 256));
   ok(h->dalloc(&h->d_depth, (size_t)E));
