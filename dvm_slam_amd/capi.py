@@ -116,6 +116,7 @@ def lib():
     L.dvm_ba_edge_chi2.argtypes = [vp, vp, vp]
     L.dvm_ba_stream.argtypes = [vp]
     L.dvm_ba_stream.restype = vp
+    L.dvm_pose_optimize.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(BaCamera), vp, vp, vp]
     _LIB = L
     return L
 
@@ -369,3 +370,22 @@ class BundleAdjuster:
         dp = np.zeros(self.E, np.uint8)
         check(self.L.dvm_ba_edge_chi2(self.h, _p(chi), _p(dp)))
         return chi, dp
+
+
+def pose_optimize(poses, Xw, obs, inv_sigma2, n, intrinsics, device=0):
+    """Optimizer::PoseOptimization for a batch of frames.  poses [B,7]; Xw [B,S,3]; obs [B,S,2]; inv_sigma2 [B,S];
+    n [B].  Returns (poses [B,7], outlier [B,S] uint8, n_inliers [B])."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    B = len(poses)
+    Xw = np.ascontiguousarray(Xw, np.float64).reshape(B, -1, 3)
+    S = Xw.shape[1]
+    obs = np.ascontiguousarray(obs, np.float64).reshape(B, S, 2)
+    inv_sigma2 = np.ascontiguousarray(inv_sigma2, np.float64).reshape(B, S)
+    n = np.ascontiguousarray(n, np.int32).reshape(B)
+    cam = BaCamera(*[float(v) for v in intrinsics], 0.0)
+    out = np.zeros((B, 7), np.float64)
+    outl = np.zeros((B, S), np.uint8)
+    nin = np.zeros(B, np.int32)
+    check(lib().dvm_pose_optimize(device, _p(poses), _p(Xw), _p(obs), _p(inv_sigma2), _p(n), S, B, C.byref(cam), _p(out),
+                                  _p(outl), _p(nin)))
+    return out, outl, nin

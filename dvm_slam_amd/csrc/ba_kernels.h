@@ -38,13 +38,17 @@ struct BaView {
   double* ytmp;             // [6*nfree]
   double* x;                // [6*nfree + 3*L]
   double *partial, *partial2;
+  const double* lambda;     // device scalar: current LM damping (so the per-trial launch sequence is a replayable graph)
 };
 
 void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, double* d_scalars, int slot);
 void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot_maxdiag);
-void ba_launch_schur(hipStream_t s, const BaView& V, double lambda);
+void ba_launch_schur(hipStream_t s, const BaView& V);
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail);
-void ba_launch_backsub_update(hipStream_t s, const BaView& V, double lambda, double* d_scalars, int slot_scale);
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale);
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
+void ba_launch_pose_optimize(hipStream_t s, const double* pose_in, const double* Xw, const double* obs, const double* info,
+                             const int32_t* n_per_frame, int stride, int batch, double fx, double fy, double cx, double cy,
+                             double* pose_out, uint8_t* outlier, int32_t* n_inliers, double* chi_scratch);
 
 }  // namespace dvm

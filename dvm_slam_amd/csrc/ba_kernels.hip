@@ -59,6 +59,46 @@ __device__ __forceinline__ void mat3_vec(const double* R, const double* v, doubl
   o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
 }
 
+// T <- exp(u) * T, u = (omega, upsilon): SE3Quat::exp + operator* + normalizeRotation
+// (reference Thirdparty/g2o/g2o/types/se3quat.h:212-266, types_six_dof_expmap.h:71-74)
+__device__ __forceinline__ void se3_oplus(double* T, const double* u) {
+  const double om0 = u[0], om1 = u[1], om2 = u[2];
+  const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+  const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+  double O2[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) O2[3 * r + c] = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
+  double R[9], Vm[9];
+  if (theta < 0.00001) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { R[k] = ((k % 4 == 0) ? 1.0 : 0.0) + O[k] + O2[k]; Vm[k] = R[k]; }
+  } else {
+    const double a = sin(theta) / theta, bb = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const double I = (k % 4 == 0) ? 1.0 : 0.0;
+      R[k] = I + a * O[k] + bb * O2[k];
+      Vm[k] = I + bb * O[k] + c * O2[k];
+    }
+  }
+  double dq[4], dt[3], Rd[9], rt[3], nq[4];
+  R_to_quat(R, dq);
+  quat_normalize(dq);
+  mat3_vec(Vm, u + 3, dt);
+  quat_to_R(dq, Rd);
+  mat3_vec(Rd, T, rt);
+  const double* q = T + 3;
+  nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+  nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+  nq[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
+  nq[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
+  quat_normalize(nq);
+  T[0] = dt[0] + rt[0]; T[1] = dt[1] + rt[1]; T[2] = dt[2] + rt[2];
+  T[3] = nq[0]; T[4] = nq[1]; T[5] = nq[2]; T[6] = nq[3];
+}
+
 // Huber (robust_kernel_impl.cpp:68-81); delta <= 0 means "no robust kernel"
 __device__ __forceinline__ void robustify(double e, double delta, double& rho0, double& rho1) {
   if (delta <= 0 || e <= delta * delta) { rho0 = e; rho1 = 1.; }
@@ -219,7 +259,8 @@ __global__ void __launch_bounds__(256) k_max_diag(BaView V, double* out, int slo
 }
 
 // ------------------------------------------------------------------------------------------ K9
-__global__ void __launch_bounds__(256) k_dinv(BaView V, double lambda) {
+__global__ void __launch_bounds__(256) k_dinv(BaView V) {
+  const double lambda = *V.lambda;
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= V.L) return;
   if (V.pt_start[l + 1] == V.pt_start[l]) return;  // landmark without observation: not a vertex of the graph
@@ -241,7 +282,8 @@ __global__ void __launch_bounds__(256) k_dinv(BaView V, double lambda) {
 // One wave per non-zero lower block (i1 >= i2) of the reduced camera matrix:
 //   S[i1,i2] = Hpp[i1] (+lambda I) if i1 == i2  -  sum over co-observed landmarks of W1 Dinv W2^T
 // `pairs` lists (edge of pose i1, edge of pose i2) per block (symbolic structure built once on host).
-__global__ void __launch_bounds__(256) k_schur_blocks(BaView V, double lambda) {
+__global__ void __launch_bounds__(256) k_schur_blocks(BaView V) {
+  const double lambda = *V.lambda;
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= V.nblk) return;
@@ -550,7 +592,8 @@ __global__ void __launch_bounds__(256) k_point_backsub(BaView V) {
 
 // oplus: cameras T <- exp(dx) T (se3quat.h:212-240, types_six_dof_expmap.h:71-74), landmarks X += dx;
 // also the per-thread terms of computeScale = sum x (lambda x + b), reduced like k_edge_eval.
-__global__ void __launch_bounds__(256) k_update(BaView V, double lambda) {
+__global__ void __launch_bounds__(256) k_update(BaView V) {
+  const double lambda = *V.lambda;
   __shared__ double s_part[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = 6 * V.nfree;
@@ -561,42 +604,7 @@ __global__ void __launch_bounds__(256) k_update(BaView V, double lambda) {
     const double* b = V.bp + 6 * (size_t)i;
 #pragma unroll
     for (int a = 0; a < 6; a++) sc += u[a] * (lambda * u[a] + b[a]);
-    double* T = V.poses + 7 * (size_t)p;
-    const double om0 = u[0], om1 = u[1], om2 = u[2];
-    const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
-    const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
-    double O2[9];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) O2[3 * r + c] = O[3 * r] * O[c] + O[3 * r + 1] * O[3 + c] + O[3 * r + 2] * O[6 + c];
-    double R[9], Vm[9];
-    if (theta < 0.00001) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) { R[k] = ((k % 4 == 0) ? 1.0 : 0.0) + O[k] + O2[k]; Vm[k] = R[k]; }
-    } else {
-      const double a = sin(theta) / theta, bb = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
-#pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const double I = (k % 4 == 0) ? 1.0 : 0.0;
-        R[k] = I + a * O[k] + bb * O2[k];
-        Vm[k] = I + bb * O[k] + c * O2[k];
-      }
-    }
-    double dq[4], dt[3], Rd[9], rt[3], nq[4];
-    R_to_quat(R, dq);
-    quat_normalize(dq);
-    mat3_vec(Vm, u + 3, dt);
-    quat_to_R(dq, Rd);
-    mat3_vec(Rd, T, rt);
-    const double* q = T + 3;
-    nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
-    nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
-    nq[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
-    nq[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
-    quat_normalize(nq);
-    T[0] = dt[0] + rt[0]; T[1] = dt[1] + rt[1]; T[2] = dt[2] + rt[2];
-    T[3] = nq[0]; T[4] = nq[1]; T[5] = nq[2]; T[6] = nq[3];
+    se3_oplus(V.poses + 7 * (size_t)p, u);
   }
   if (i < V.L && V.pt_start[i + 1] > V.pt_start[i]) {
     const double* u = V.x + n + 3 * (size_t)i;
@@ -626,6 +634,231 @@ __global__ void __launch_bounds__(256) k_edge_depth(BaView V, uint8_t* __restric
   out[k] = z > 0.0;
 }
 
+// ---------------------------------------------------------------------------------------- B1
+// Optimizer::PoseOptimization (reference src/Optimizer.cc:744-1028, mono edges
+// EdgeSE3ProjectXYZOnlyPose, src/OptimizableTypes.cpp:51-63): one camera, N unary reprojection edges,
+// 4 rounds x optimize(10) of g2o's Levenberg with a dense 6x6 solve, re-classifying inliers after every
+// round (chi2 > 5.991 as float), Huber removed after round 2.  ONE workgroup runs the whole thing for
+// one frame -- about 40 LM iterations with no host round trip; frames are batched over the grid.
+struct PoseAccum { double v[28]; };  // 21 upper-H + 6 b + 1 chi
+__device__ __forceinline__ void pose_block_reduce(PoseAccum& a, double (*s_red)[28], double* out28) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int i = 0; i < 28; i++) a.v[i] += __shfl_xor(a.v[i], off);
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < 28; i++) s_red[wave][i] = a.v[i];
+  __syncthreads();
+  if (threadIdx.x < 28) out28[threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict__ pose_in, const double* __restrict__ Xw,
+                                                       const double* __restrict__ obs, const double* __restrict__ info,
+                                                       const int32_t* __restrict__ n_per_frame, int stride, double fx,
+                                                       double fy, double cx, double cy, double* __restrict__ pose_out,
+                                                       uint8_t* __restrict__ outlier, int32_t* __restrict__ n_inliers,
+                                                       double* __restrict__ chi_scratch) {
+  __shared__ double s_red[4][28];
+  __shared__ double s_sum[28];
+  __shared__ double s_T[7], s_Tbak[7], s_T0[7];
+  __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
+  __shared__ int s_ctl, s_qmax, s_nbad, s_nact;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int N = n_per_frame[f];
+  const double* X = Xw + (size_t)f * stride * 3;
+  const double* O = obs + (size_t)f * stride * 2;
+  const double* W = info + (size_t)f * stride;
+  uint8_t* outl = outlier + (size_t)f * stride;
+  double* last_chi = chi_scratch + (size_t)f * stride;  // e->chi2() as g2o reports it (last evaluation)
+  uint8_t* level = outl;  // level(1) == outlier flag in the reference's bookkeeping
+  const double delta = (double)sqrtf(5.991f);
+  const float chi2Mono = 5.991f;
+  if (tid < 7) {
+    double v = pose_in[7 * (size_t)f + tid];
+    s_T0[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) quat_normalize(&s_T0[3]);
+  for (int i = tid; i < N; i += 256) { outl[i] = 0; last_chi[i] = 0; }
+  __syncthreads();
+  if (N < 3) {  // nInitialCorrespondences < 3: return 0, pose untouched (Optimizer.cc:904-905)
+    if (tid < 7) pose_out[7 * (size_t)f + tid] = pose_in[7 * (size_t)f + tid];
+    if (tid == 0) n_inliers[f] = 0;
+    return;
+  }
+  // evaluates the active edges at pose T: chi (always), H/b (jac) ; updates last_chi
+  auto eval = [&](const double* T, bool jac, bool robust_on) {
+    PoseAccum a;
+#pragma unroll
+    for (int i = 0; i < 28; i++) a.v[i] = 0;
+    double R[9];
+    quat_to_R(T + 3, R);
+    for (int i = tid; i < N; i += 256) {
+      if (level[i]) continue;
+      double Xc[3];
+      mat3_vec(R, X + 3 * i, Xc);
+      Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
+      const double x = Xc[0], y = Xc[1], z = Xc[2], w0 = W[i];
+      const double e0 = O[2 * i] - (fx * x / z + cx), e1 = O[2 * i + 1] - (fy * y / z + cy);
+      const double chi2 = e0 * w0 * e0 + e1 * w0 * e1;
+      last_chi[i] = chi2;
+      double r0, r1;
+      robustify(chi2, robust_on ? delta : 0.0, r0, r1);
+      a.v[27] += r0;
+      if (jac) {
+        const double J[6] = {-(fx / z), 0, fx * x / (z * z), 0, -(fy / z), fy * y / (z * z)};
+        const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+        double B[12];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
+        const double w = r1 * w0, wr0 = -w0 * e0 * r1, wr1 = -w0 * e1 * r1;
+        int t = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+          a.v[21 + p] += B[p] * wr0 + B[6 + p] * wr1;
+#pragma unroll
+          for (int q = 0; q <= p; q++) a.v[t++] += w * (B[p] * B[q] + B[6 + p] * B[6 + q]);
+        }
+      }
+    }
+    pose_block_reduce(a, s_red, s_sum);
+  };
+
+  bool robust_on = true;
+  for (int round = 0; round < 4; round++) {
+    if (tid < 7) s_T[tid] = s_T0[tid];  // vSE3->setEstimate(pFrame->GetPose()) every round
+    if (tid == 0) { s_nact = 0; s_ctl = 0; s_nbad = 0; }
+    __syncthreads();
+    int my = 0;
+    for (int i = tid; i < N; i += 256) my += level[i] ? 0 : 1;
+    if (my) atomicAdd(&s_nact, my);
+    __syncthreads();
+    const int nact = s_nact;
+    for (int it = 0; it < 10 && nact > 0; it++) {
+      eval(s_T, true, robust_on);
+      if (tid == 0) {
+        s_cur = s_sum[27]; s_ini = s_sum[27];
+        if (it == 0) {
+          double mx = 0;
+          int t = 0;
+          for (int p = 0; p < 6; p++) for (int q = 0; q <= p; q++) { if (p == q) mx = fmax(mx, fabs(s_sum[t])); t++; }
+          s_lambda = 1e-5 * mx; s_ni = 2; s_nbad = 0;
+        }
+        s_qmax = 0;
+      }
+      __syncthreads();
+      double Hs[21], bs[6];
+      if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) Hs[i] = s_sum[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) bs[i] = s_sum[21 + i];
+      }
+      while (true) {
+        double xs[6];
+        bool ok = true;
+        if (tid == 0) {
+          for (int i = 0; i < 7; i++) s_Tbak[i] = s_T[i];
+          // dense 6x6 Cholesky of (H + lambda I), lower-packed Hs[p(p+1)/2 + q]
+          double Lm[21];
+          for (int i = 0; i < 6 && ok; i++)
+            for (int j = 0; j <= i; j++) {
+              double sacc = Hs[i * (i + 1) / 2 + j] + (i == j ? s_lambda : 0.0);
+              for (int k = 0; k < j; k++) sacc -= Lm[i * (i + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
+              if (i == j) { if (!(sacc > 0)) { ok = false; break; } Lm[i * (i + 1) / 2 + i] = sqrt(sacc); }
+              else Lm[i * (i + 1) / 2 + j] = sacc / Lm[j * (j + 1) / 2 + j];
+            }
+          if (ok) {
+            for (int i = 0; i < 6; i++) { double sacc = bs[i]; for (int k = 0; k < i; k++) sacc -= Lm[i * (i + 1) / 2 + k] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
+            for (int i = 5; i >= 0; i--) { double sacc = xs[i]; for (int k = i + 1; k < 6; k++) sacc -= Lm[k * (k + 1) / 2 + i] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
+            se3_oplus(s_T, xs);
+          }
+          s_ctl = ok ? 1 : 0;
+        }
+        __syncthreads();
+        const bool okb = s_ctl != 0;
+        if (okb) eval(s_T, false, robust_on);
+        if (tid == 0) {
+          const double tempChi = okb ? s_sum[27] : 1.7976931348623157e308;
+          double rho = s_cur - tempChi;
+          double scale = 0;
+          if (okb) for (int j = 0; j < 6; j++) scale += xs[j] * (s_lambda * xs[j] + bs[j]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && isfinite(tempChi)) {
+            double alpha = 1. - pow(2 * rho - 1, 3);
+            alpha = fmin(alpha, 2. / 3.);
+            s_lambda *= fmax(1. / 3., alpha);
+            s_ni = 2;
+            s_cur = tempChi;
+          } else {
+            s_lambda *= s_ni; s_ni *= 2;
+            for (int i = 0; i < 7; i++) s_T[i] = s_Tbak[i];
+          }
+          s_qmax++;
+          s_rho = rho;
+          s_ctl = (rho < 0 && s_qmax < 10) ? 1 : 0;  // continue the trial loop?
+        }
+        __syncthreads();
+        if (!s_ctl) break;
+        __syncthreads();
+      }
+      if (tid == 0) {
+        int stop = 0;
+        if (s_qmax == 10 || s_rho == 0) stop = 1;
+        else {
+          if ((s_ini - s_cur) * 1e3 < s_ini) s_nbad++; else s_nbad = 0;
+          if (s_nbad >= 3) stop = 1;
+        }
+        s_ctl = stop;
+      }
+      __syncthreads();
+      const int stop = s_ctl;
+      __syncthreads();
+      if (stop) break;
+    }
+    // classification (Optimizer.cc:923-948): outliers recompute their error, inliers report the last evaluation
+    {
+      double R[9];
+      quat_to_R(s_T + 3, R);
+      for (int i = tid; i < N; i += 256) {
+        if (outl[i]) {
+          double Xc[3];
+          mat3_vec(R, X + 3 * i, Xc);
+          Xc[0] += s_T[0]; Xc[1] += s_T[1]; Xc[2] += s_T[2];
+          const double e0 = O[2 * i] - (fx * Xc[0] / Xc[2] + cx), e1 = O[2 * i + 1] - (fy * Xc[1] / Xc[2] + cy);
+          last_chi[i] = e0 * W[i] * e0 + e1 * W[i] * e1;
+        }
+        const float chi2 = (float)last_chi[i];
+        outl[i] = chi2 > chi2Mono ? 1 : 0;
+      }
+    }
+    if (round == 2) robust_on = false;
+    __syncthreads();
+    if (N < 10) break;  // optimizer.edges().size() < 10
+  }
+  if (tid == 0) s_nact = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int i = tid; i < N; i += 256) bad += outl[i];
+  if (bad) atomicAdd(&s_nact, bad);
+  __syncthreads();
+  if (tid < 7) pose_out[7 * (size_t)f + tid] = s_T[tid];
+  if (tid == 0) n_inliers[f] = N - s_nact;
+}
+
+void ba_launch_pose_optimize(hipStream_t s, const double* pose_in, const double* Xw, const double* obs, const double* info,
+                             const int32_t* n_per_frame, int stride, int batch, double fx, double fy, double cx, double cy,
+                             double* pose_out, uint8_t* outlier, int32_t* n_inliers, double* chi_scratch) {
+  hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(256), 0, s, pose_in, Xw, obs, info, n_per_frame, stride, fx, fy, cx, cy,
+                     pose_out, outlier, n_inliers, chi_scratch);
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -640,11 +873,11 @@ void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot
   if (V.nfree > 0) hipLaunchKernelGGL(k_pose_accum, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
   if (slot_maxdiag >= 0) hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, s, V, d_scalars, slot_maxdiag);
 }
-void ba_launch_schur(hipStream_t s, const BaView& V, double lambda) {
-  hipLaunchKernelGGL(k_dinv, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V, lambda);
+void ba_launch_schur(hipStream_t s, const BaView& V) {
+  hipLaunchKernelGGL(k_dinv, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
   if (V.nfree == 0) return;
   hipMemsetAsync(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double), s);
-  hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V, lambda);
+  hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
 }
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
@@ -664,10 +897,10 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
   for (int kb = nxb - 1; kb >= 0; kb--)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + kb), dim3(256), 0, s, V.S, V.ldS, n, kb, V.ytmp, V.x, V.Linv);
 }
-void ba_launch_backsub_update(hipStream_t s, const BaView& V, double lambda, double* d_scalars, int slot_scale) {
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
   const int nb = cdiv(std::max(V.L, V.nfree), 256);
-  hipLaunchKernelGGL(k_update, dim3(nb), dim3(256), 0, s, V, lambda);
+  hipLaunchKernelGGL(k_update, dim3(nb), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, V.partial2, nb, d_scalars, slot_scale);
 }
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out) {

@@ -33,6 +33,7 @@ struct dvm_ba {
   uint8_t* d_depth = nullptr;
   bool have_problem = false;
   double ms_structure = 0;
+  hipGraphExec_t trial_graph = nullptr;  // one LM trial (push, Schur, Cholesky solve, update, chi2) as a hipGraph
 
   template <typename T>
   int dalloc(T** p, size_t n) {
@@ -50,6 +51,7 @@ struct dvm_ba {
     return rc;
   }
   void free_problem() {
+    if (trial_graph) { hipGraphExecDestroy(trial_graph); trial_graph = nullptr; }
     for (void* p : allocs) hipFree(p);
     allocs.clear();
     have_problem = false;
@@ -180,6 +182,7 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(hip_check(hipDeviceSynchronize(), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  V.lambda = h->d_scalars + 7;
   h->have_problem = true;
   return DVM_OK;
 }
@@ -222,14 +225,25 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     double rho = 0;
     int qmax = 0;
     do {
-      // push(): keep the state before the trial
-      DVM_HIP(hipMemcpyAsync(h->d_poses_bak, V.poses, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s));
-      DVM_HIP(hipMemcpyAsync(h->d_points_bak, V.points, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s));
-      DVM_HIP(hipMemsetAsync(h->d_fail, 0, sizeof(int), s));
-      ba_launch_schur(s, V, lambda);            // setLambda + Schur complement
-      ba_launch_cholesky_solve(s, V, h->d_fail);  // reduced camera system
-      ba_launch_backsub_update(s, V, lambda, h->d_scalars, S_SCALE);  // landmarks, oplus, computeScale terms
-      ba_launch_edge_eval(s, V, false, h->d_scalars, S_TMPCHI);
+      // one trial = push() + setLambda/Schur + reduced solve + landmarks/oplus + chi2: ~200 small
+      // launches, replayed as ONE hipGraph (the host would otherwise be the bottleneck)
+      h->h_scalars[7] = lambda;
+      DVM_HIP(hipMemcpyAsync(h->d_scalars + 7, h->h_scalars + 7, sizeof(double), hipMemcpyHostToDevice, s));
+      if (!h->trial_graph) {
+        hipGraph_t g = nullptr;
+        DVM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipMemcpyAsync(h->d_poses_bak, V.poses, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(h->d_points_bak, V.points, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s);
+        hipMemsetAsync(h->d_fail, 0, sizeof(int), s);
+        ba_launch_schur(s, V);
+        ba_launch_cholesky_solve(s, V, h->d_fail);
+        ba_launch_backsub_update(s, V, h->d_scalars, S_SCALE);
+        ba_launch_edge_eval(s, V, false, h->d_scalars, S_TMPCHI);
+        DVM_HIP(hipStreamEndCapture(s, &g));
+        DVM_HIP(hipGraphInstantiate(&h->trial_graph, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+      }
+      DVM_HIP(hipGraphLaunch(h->trial_graph, s));
       rc = read_scalars(h);
       if (rc != DVM_OK) return rc;
       const bool ok2 = (*h->h_fail == 0);
@@ -292,5 +306,41 @@ int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive) {
 }
 
 void* dvm_ba_stream(dvm_ba* h) { return h ? (void*)h->stream : nullptr; }
+
+int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const double* obs, const double* inv_sigma2,
+                      const int32_t* n, int stride, int batch, const dvm_ba_camera* cam, double* pose_out,
+                      uint8_t* outlier, int32_t* n_inliers) {
+  if (!pose_in || !Xw || !obs || !inv_sigma2 || !n || !cam || !pose_out || !outlier || !n_inliers || stride < 1 || batch < 1) {
+    set_error("dvm_pose_optimize: bad arguments");
+    return DVM_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) return DVM_ERR_INVALID;
+  for (int f = 0; f < batch; f++) if (n[f] < 0 || n[f] > stride) { set_error("n[f] out of range"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(device));
+  const size_t B = (size_t)batch, S = (size_t)stride;
+  const size_t b_pose = B * 7 * 8, b_x = B * S * 3 * 8, b_o = B * S * 2 * 8, b_w = B * S * 8, b_n = B * 4, b_out = B * S, b_chi = B * S * 8;
+  const size_t off_pose = 0, off_x = off_pose + b_pose, off_o = off_x + b_x, off_w = off_o + b_o, off_pout = off_w + b_w,
+               off_chi = off_pout + b_pose, off_n = off_chi + b_chi, off_nin = off_n + b_n, off_outl = off_nin + b_n,
+               total = off_outl + b_out;
+  uint8_t* d = nullptr;
+  DVM_HIP(hipMalloc(&d, total));
+  int rc = DVM_OK;
+  auto up = [&](size_t off, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(d + off, src, bytes, hipMemcpyHostToDevice), "upload"); };
+  up(off_pose, pose_in, b_pose); up(off_x, Xw, b_x); up(off_o, obs, b_o); up(off_w, inv_sigma2, b_w); up(off_n, n, b_n);
+  if (rc == DVM_OK) {
+    ba_launch_pose_optimize(nullptr, (const double*)(d + off_pose), (const double*)(d + off_x), (const double*)(d + off_o),
+                            (const double*)(d + off_w), (const int32_t*)(d + off_n), stride, batch, cam->fx, cam->fy, cam->cx,
+                            cam->cy, (double*)(d + off_pout), d + off_outl, (int32_t*)(d + off_nin), (double*)(d + off_chi));
+    rc = hip_check(hipGetLastError(), "pose_optimize launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "pose_optimize sync");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(pose_out, d + off_pout, b_pose, hipMemcpyDeviceToHost), "download");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(outlier, d + off_outl, b_out, hipMemcpyDeviceToHost), "download");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(n_inliers, d + off_nin, b_n, hipMemcpyDeviceToHost), "download");
+  hipFree(d);
+  return rc;
+}
 
 }  // extern "C"

@@ -196,6 +196,16 @@ int dvm_ba_get_result(dvm_ba* h, double* poses, double* points);
 int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive);
 void* dvm_ba_stream(dvm_ba* h);
 
+/* Optimizer::PoseOptimization (Optimizer.cc:744-1028, monocular edges): `batch` independent frames.
+ * Frame f: pose (tx,ty,tz,qx,qy,qz,qw) at pose_in + 7f; n[f] 2D-3D matches stored with a common
+ * `stride` (Xw [batch][stride][3], obs [batch][stride][2] = undistorted keypoint, inv_sigma2
+ * [batch][stride] = mvInvLevelSigma2[octave]).  Outputs: optimised pose, mvbOutlier flags, and the
+ * reference's return value nInitialCorrespondences - nBad.  Host pointers, synchronous; each frame is
+ * one workgroup running the 4 x optimize(10) Levenberg rounds entirely on the device. */
+int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const double* obs, const double* inv_sigma2,
+                      const int32_t* n, int stride, int batch, const dvm_ba_camera* cam, double* pose_out,
+                      uint8_t* outlier, int32_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif
