@@ -6,10 +6,15 @@
 // stable, so which of two equal nodes is split first -- and therefore which keypoints survive -- is
 // decided by the exact sequence of swaps of GCC's introsort (bits/stl_algo.h: __introsort_loop with
 // median-of-3 + unguarded partition, threshold 16, depth limit 2*lg(n) -> heapsort, then
-// __final_insertion_sort).  The device octree reproduces that sequence on (key, payload) pairs held
-// in LDS; tools/check_introsort.cpp verifies this header against the real std::sort on the host.
+// __final_insertion_sort).  The device octree reproduces that sequence on (key, payload) pairs;
+// tools/check_introsort.cpp verifies this header against the real std::sort on the host.
 //
-// key ordering: a < b  <=>  k[a] < k[b]  (caller packs (size, UL.x) lexicographically into 32 bits).
+// The algorithm is written once over an accessor `A` with
+//     uint32_t key(int i);  uint32_t val(int i);  void set(int i, uint32_t k, uint32_t v);
+// Two accessors exist: KV (plain arrays: host test, LDS fallback) and, in octree_kernel.hip, LaneKV
+// (elements live in the lanes of one wavefront and are addressed with v_readlane / v_writelane, so
+// the whole sort is scalar-unit control flow without any LDS round trip).
+// key ordering: a < b  <=>  key(a) < key(b)  (caller packs (size, UL.x) lexicographically in 32 bits).
 #pragma once
 #include <stdint.h>
 
@@ -24,44 +29,53 @@ namespace dvm {
 struct KV {
   uint32_t* k;
   uint16_t* v;
+  DVM_HD uint32_t key(int i) const { return k[i]; }
+  DVM_HD uint32_t val(int i) const { return v[i]; }
+  DVM_HD void set(int i, uint32_t kk, uint32_t vv) { k[i] = kk; v[i] = (uint16_t)vv; }
 };
 
-DVM_HD void kv_swap(KV a, int i, int j) {
-  uint32_t tk = a.k[i]; a.k[i] = a.k[j]; a.k[j] = tk;
-  uint16_t tv = a.v[i]; a.v[i] = a.v[j]; a.v[j] = tv;
+template <class A>
+DVM_HD void kv_move(A& a, int dst, int src) { a.set(dst, a.key(src), a.val(src)); }
+template <class A>
+DVM_HD void kv_swap(A& a, int i, int j) {
+  const uint32_t ki = a.key(i), vi = a.val(i), kj = a.key(j), vj = a.val(j);
+  a.set(i, kj, vj);
+  a.set(j, ki, vi);
 }
 
 // std::__adjust_heap + std::__push_heap (max-heap on '<')
-DVM_HD void kv_adjust_heap(KV a, int first, int hole, int len, uint32_t vk, uint16_t vv) {
+template <class A>
+DVM_HD void kv_adjust_heap(A& a, int first, int hole, int len, uint32_t vk, uint32_t vv) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (a.k[first + child] < a.k[first + child - 1]) child--;
-    a.k[first + hole] = a.k[first + child]; a.v[first + hole] = a.v[first + child];
+    if (a.key(first + child) < a.key(first + child - 1)) child--;
+    kv_move(a, first + hole, first + child);
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    a.k[first + hole] = a.k[first + child - 1]; a.v[first + hole] = a.v[first + child - 1];
+    kv_move(a, first + hole, first + child - 1);
     hole = child - 1;
   }
   int parent = (hole - 1) / 2;
-  while (hole > top && a.k[first + parent] < vk) {
-    a.k[first + hole] = a.k[first + parent]; a.v[first + hole] = a.v[first + parent];
+  while (hole > top && a.key(first + parent) < vk) {
+    kv_move(a, first + hole, first + parent);
     hole = parent;
     parent = (hole - 1) / 2;
   }
-  a.k[first + hole] = vk; a.v[first + hole] = vv;
+  a.set(first + hole, vk, vv);
 }
 
 // std::__partial_sort(first, last, last) = __heap_select (make_heap only) + __sort_heap
-DVM_HD void kv_heapsort(KV a, int first, int last) {
+template <class A>
+DVM_HD void kv_heapsort(A& a, int first, int last) {
   const int len = last - first;
   if (len >= 2) {
     int parent = (len - 2) / 2;
     while (true) {
-      kv_adjust_heap(a, first, parent, len, a.k[first + parent], a.v[first + parent]);
+      kv_adjust_heap(a, first, parent, len, a.key(first + parent), a.val(first + parent));
       if (parent == 0) break;
       parent--;
     }
@@ -70,45 +84,52 @@ DVM_HD void kv_heapsort(KV a, int first, int last) {
   while (l - first > 1) {
     --l;
     // __pop_heap(first, l, l): value = *l; *l = *first; adjust_heap(first, 0, l-first, value)
-    uint32_t vk = a.k[l]; uint16_t vv = a.v[l];
-    a.k[l] = a.k[first]; a.v[l] = a.v[first];
+    const uint32_t vk = a.key(l), vv = a.val(l);
+    kv_move(a, l, first);
     kv_adjust_heap(a, first, 0, l - first, vk, vv);
   }
 }
 
-DVM_HD void kv_unguarded_linear_insert(KV a, int last) {
-  uint32_t vk = a.k[last]; uint16_t vv = a.v[last];
+template <class A>
+DVM_HD void kv_unguarded_linear_insert(A& a, int last) {
+  const uint32_t vk = a.key(last), vv = a.val(last);
   int next = last - 1;
-  while (vk < a.k[next]) {
-    a.k[last] = a.k[next]; a.v[last] = a.v[next];
+  while (vk < a.key(next)) {
+    kv_move(a, last, next);
     last = next;
     --next;
   }
-  a.k[last] = vk; a.v[last] = vv;
+  a.set(last, vk, vv);
 }
 
-DVM_HD void kv_insertion_sort(KV a, int first, int last) {
+template <class A>
+DVM_HD void kv_insertion_sort(A& a, int first, int last) {
   if (first == last) return;
   for (int i = first + 1; i != last; ++i) {
-    if (a.k[i] < a.k[first]) {
-      uint32_t vk = a.k[i]; uint16_t vv = a.v[i];
-      for (int j = i; j > first; --j) { a.k[j] = a.k[j - 1]; a.v[j] = a.v[j - 1]; }  // move_backward
-      a.k[first] = vk; a.v[first] = vv;
+    if (a.key(i) < a.key(first)) {
+      const uint32_t vk = a.key(i), vv = a.val(i);
+      for (int j = i; j > first; --j) kv_move(a, j, j - 1);  // move_backward
+      a.set(first, vk, vv);
     } else {
       kv_unguarded_linear_insert(a, i);
     }
   }
 }
 
-// std::sort(first, last, comp) of libstdc++ on n elements starting at index 0.
-DVM_HD void kv_std_sort(KV a, int n) {
-  if (n <= 1) {
-    return;
-  }
+// Phase 1 of std::sort: __introsort_loop only (median-of-3 quicksort partitions until every
+// unsorted run is <= 16 long, heapsort below the depth limit).  This is the only part of std::sort
+// whose treatment of EQUAL keys is not "stable".  Phase 2, __final_insertion_sort, is a plain
+// insertion sort of the whole array, i.e. the unique STABLE ordering of phase 1's output -- which a
+// GPU computes in parallel as rank(i) = #{j : key[j] < key[i]} + #{j < i : key[j] == key[i]}.
+// `stk` = caller-provided scratch of 3*48 ints (on the GPU: LDS, so the explicit stack does not
+// land in scratch memory).
+template <class A, class StackPtr>
+DVM_HD void kv_introsort_loop(A& a, int n, StackPtr stk) {
+  if (n <= 1) return;
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) lg++;
   // explicit stack instead of the recursion on the right part (disjoint ranges: same result)
-  int sf[48], sl[48], sd[48];
+  StackPtr sf = stk, sl = stk + 48, sd = stk + 96;
   int sp = 0;
   sf[sp] = 0; sl[sp] = n; sd[sp] = 2 * lg; sp++;
   while (sp > 0) {
@@ -124,20 +145,21 @@ DVM_HD void kv_std_sort(KV a, int n) {
       const int mid = first + (last - first) / 2;
       {  // __move_median_to_first(first, first+1, mid, last-1)
         const int r = first, x = first + 1, y = mid, z = last - 1;
-        if (a.k[x] < a.k[y]) {
-          if (a.k[y] < a.k[z]) kv_swap(a, r, y);
-          else if (a.k[x] < a.k[z]) kv_swap(a, r, z);
+        const uint32_t kx = a.key(x), ky = a.key(y), kz = a.key(z);
+        if (kx < ky) {
+          if (ky < kz) kv_swap(a, r, y);
+          else if (kx < kz) kv_swap(a, r, z);
           else kv_swap(a, r, x);
-        } else if (a.k[x] < a.k[z]) kv_swap(a, r, x);
-        else if (a.k[y] < a.k[z]) kv_swap(a, r, z);
+        } else if (kx < kz) kv_swap(a, r, x);
+        else if (ky < kz) kv_swap(a, r, z);
         else kv_swap(a, r, y);
       }
       int lo = first + 1, hi = last;
-      const uint32_t pk = a.k[first];
+      const uint32_t pk = a.key(first);
       while (true) {
-        while (a.k[lo] < pk) ++lo;
+        while (a.key(lo) < pk) ++lo;
         --hi;
-        while (pk < a.k[hi]) --hi;
+        while (pk < a.key(hi)) --hi;
         if (!(lo < hi)) break;
         kv_swap(a, lo, hi);
         ++lo;
@@ -147,6 +169,14 @@ DVM_HD void kv_std_sort(KV a, int n) {
       last = cut;
     }
   }
+}
+
+// std::sort(first, last, comp) of libstdc++ on n elements starting at index 0 (fully serial form).
+template <class A>
+DVM_HD void kv_std_sort(A& a, int n) {
+  if (n <= 1) return;
+  int stk[144];
+  kv_introsort_loop(a, n, stk);
   // __final_insertion_sort
   if (n > 16) {
     kv_insertion_sort(a, 0, 16);

@@ -26,6 +26,19 @@ struct ONodeRec {
   int16_t x0, y0, x1, y1;
   int32_t cnt;
 };
+// LDS-typed accessor for introsort_emul.h: with plain (generic) pointers the serial sort compiles to
+// flat_load/flat_store, several times the latency of ds_read/ds_write -- and that latency IS the
+// critical path of this kernel.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) int lds_i32;
+struct KVLds {
+  lds_u32* k;
+  lds_u16* v;
+  __device__ __forceinline__ uint32_t key(int i) const { return k[i]; }
+  __device__ __forceinline__ uint32_t val(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, uint32_t kk, uint32_t vv) { k[i] = kk; v[i] = (uint16_t)vv; }
+};
 
 // exclusive scan of data[0..m) in place, 256 threads (4 waves): per-thread serial chunk, wave scan by
 // DPP-free shuffles, 4 wave totals through LDS.  *total (shared) receives the sum.  3 barriers.
@@ -68,6 +81,7 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
   int16_t* prank = proc + cap;                               // list index -> rank in processing order or -1
   uint16_t* sval = reinterpret_cast<uint16_t*>(prank + cap); // sort payload / expandable set (creation order)
   __shared__ int s_tmp[256];
+  __shared__ int s_stack[144];
   __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
 
   const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -137,12 +151,22 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
         skey[k] = ((uint32_t)L[j].cnt << 12) | (uint32_t)(uint16_t)L[j].x0;
       }
       __syncthreads();
+      // std::sort = serial __introsort_loop (the only part that is not a stable sort) on one lane,
+      // then __final_insertion_sort == stable ordering of that output, computed in parallel by rank
       if (tid == 0) {
-        KV kv{skey, sval};
-        kv_std_sort(kv, ne);
+        KVLds kv{(lds_u32*)skey, (lds_u16*)sval};
+        kv_introsort_loop(kv, ne, (lds_i32*)s_stack);
       }
       __syncthreads();
-      for (int t = tid; t < ne; t += 256) proc[t] = (int16_t)sval[ne - 1 - t];
+      for (int k = tid; k < ne; k += 256) {
+        const uint32_t kk = skey[k];
+        int rank = 0;
+        for (int j = 0; j < ne; j++) {
+          const uint32_t kj = skey[j];
+          rank += (kj < kk || (kj == kk && j < k)) ? 1 : 0;
+        }
+        proc[ne - 1 - rank] = (int16_t)sval[k];  // processed from the back of the sorted vector (:551)
+      }
       if (tid == 0) s_np = ne;
       __syncthreads();
     }

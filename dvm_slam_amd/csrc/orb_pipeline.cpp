@@ -249,6 +249,9 @@ OrbPipeline::~OrbPipeline() {
   free_all();
   if (d_stage) hipFree(d_stage);
   if (h_stage) hipHostFree(h_stage);
+  if (stream2) { hipStreamSynchronize(stream2); hipStreamDestroy(stream2); }
+  if (ev_fork) hipEventDestroy(ev_fork);
+  if (ev_join) hipEventDestroy(ev_join);
   if (stream) hipStreamDestroy(stream);
 }
 
@@ -264,6 +267,10 @@ int OrbPipeline::init() {
   }
   DVM_HIP(hipSetDevice(device));
   DVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  DVM_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  DVM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  DVM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  if (const char* e = getenv("DVM_SINGLE_STREAM")) dual_stream = !(e[0] == '1');
   if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree = (e[0] == '1');  // debug / A-B switch only
   // orientation disc offsets (any order: the moments are exact integer sums)
   int8_t du[kDiscPixels], dv[kDiscPixels];
@@ -486,68 +493,90 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   const int L = PD.nlevels;
   last_batch = batch;
 
-  prof.begin(stream, "pyramid");
-  launch_pyr_level0(stream, d_imgs, rows, cols, stride, frame_stride, d_pyr, PD, batch);
-  for (int l = 1; l < L; l++) launch_pyr_resize(stream, d_pyr, PD, l, d_tabs, batch);
-  prof.end(stream);
-  prof.begin(stream, "fast");
-  launch_fast(stream, d_pyr, d_cells, PD, d_cand, d_cell_count, batch, max_cell_rw, max_cell_rh);
-  prof.end(stream);
-  prof.begin(stream, "compact");
-  launch_compact(stream, d_cand, d_cell_count, d_cells, PD, d_dense, d_lvl_start, batch);
-  prof.end(stream);
+  // The batch is processed as two halves on two HIP streams: latency-bound stages of one half
+  // (7 dependent pyramid launches, the single-lane std::sort emulation inside k_octree) overlap with
+  // throughput-bound stages (FAST, blur) of the other.  `stream` stays the handle's ordering point.
+  auto run_half = [&](hipStream_t st, int f0, int nb) -> int {
+    prof.begin(st, "pyramid");
+    launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
+    for (int l = 1; l < L; l++) launch_pyr_resize(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, l, d_tabs, nb);
+    prof.end(st);
+    prof.begin(st, "fast");
+    launch_fast(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), d_cells, PD, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), nb, max_cell_rw, max_cell_rh);
+    prof.end(st);
+    prof.begin(st, "compact");
+    launch_compact(st, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), d_cells, PD, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
+    prof.end(st);
 
-  if (!host_octree) {
-    prof.begin(stream, "octree");
-    launch_octree(stream, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel, d_err, batch);
-    prof.end(stream);
-  } else {
-  // ---- DistributeOctTree on the host (K3): counts, then each frame's dense candidate prefix
-    DVM_HIP(hipMemcpyAsync(h_lvl_start, d_lvl_start, (size_t)batch * (kMaxLevels + 1) * 4, hipMemcpyDeviceToHost, stream));
-    DVM_HIP(hipStreamSynchronize(stream));
-    for (int f = 0; f < batch; f++) {
-      const int total = h_lvl_start[f * (kMaxLevels + 1) + L];
-      if (total > 0)
-        DVM_HIP(hipMemcpyAsync(h_dense + (size_t)f * PD.cand_frame_slots, d_dense + (size_t)f * PD.cand_frame_slots,
-                               (size_t)total * 4, hipMemcpyDeviceToHost, stream));
-    }
-    DVM_HIP(hipStreamSynchronize(stream));
-    {
-      const int jobs = batch * L;
-      const int nthreads = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), std::min(jobs / 4, 16)));
-      auto work = [&](int t) {
-        std::vector<uint32_t> out;
-        for (int j = t; j < jobs; j += nthreads) {
-          const int f = j / L, l = j % L;
-          const int32_t* ls = h_lvl_start + f * (kMaxLevels + 1);
-          const LevelDesc& D = PD.lv[l];
-          octree_select(h_dense + (size_t)f * PD.cand_frame_slots + ls[l], ls[l + 1] - ls[l], kEdge - 3, D.w - kEdge + 3,
-                        kEdge - 3, D.h - kEdge + 3, D.quota, out);
-          const int n = std::min<int>((int)out.size(), D.sel_cap);
-          h_nsel[f * L + l] = n;
-          std::memcpy(h_sel + (size_t)f * PD.sel_frame_slots + D.sel_off, out.data(), (size_t)n * 4);
-        }
-      };
-      if (nthreads == 1) work(0);
-      else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
-        for (auto& t : th) t.join();
+    if (!host_octree) {
+      prof.begin(st, "octree");
+      launch_octree(st, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), PD, (d_nid + (size_t)f0 * PD.cand_frame_slots), (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), d_err, nb);
+      prof.end(st);
+    } else {
+    // ---- DistributeOctTree on the host (K3): counts, then each frame's dense candidate prefix
+      DVM_HIP(hipMemcpyAsync(h_lvl_start, d_lvl_start, (size_t)batch * (kMaxLevels + 1) * 4, hipMemcpyDeviceToHost, st));
+      DVM_HIP(hipStreamSynchronize(st));
+      for (int f = 0; f < batch; f++) {
+        const int total = h_lvl_start[f * (kMaxLevels + 1) + L];
+        if (total > 0)
+          DVM_HIP(hipMemcpyAsync(h_dense + (size_t)f * PD.cand_frame_slots, d_dense + (size_t)f * PD.cand_frame_slots,
+                                 (size_t)total * 4, hipMemcpyDeviceToHost, st));
       }
+      DVM_HIP(hipStreamSynchronize(st));
+      {
+        const int jobs = batch * L;
+        const int nthreads = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), std::min(jobs / 4, 16)));
+        auto work = [&](int t) {
+          std::vector<uint32_t> out;
+          for (int j = t; j < jobs; j += nthreads) {
+            const int f = j / L, l = j % L;
+            const int32_t* ls = h_lvl_start + f * (kMaxLevels + 1);
+            const LevelDesc& D = PD.lv[l];
+            octree_select(h_dense + (size_t)f * PD.cand_frame_slots + ls[l], ls[l + 1] - ls[l], kEdge - 3, D.w - kEdge + 3,
+                          kEdge - 3, D.h - kEdge + 3, D.quota, out);
+            const int n = std::min<int>((int)out.size(), D.sel_cap);
+            h_nsel[f * L + l] = n;
+            std::memcpy(h_sel + (size_t)f * PD.sel_frame_slots + D.sel_off, out.data(), (size_t)n * 4);
+          }
+        };
+        if (nthreads == 1) work(0);
+        else {
+          std::vector<std::thread> th;
+          for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+          for (auto& t : th) t.join();
+        }
+      }
+      DVM_HIP(hipMemcpyAsync(d_nsel, h_nsel, (size_t)batch * L * 4, hipMemcpyHostToDevice, st));
+      DVM_HIP(hipMemcpyAsync(d_sel, h_sel, (size_t)batch * PD.sel_frame_slots * 4, hipMemcpyHostToDevice, st));
     }
-    DVM_HIP(hipMemcpyAsync(d_nsel, h_nsel, (size_t)batch * L * 4, hipMemcpyHostToDevice, stream));
-    DVM_HIP(hipMemcpyAsync(d_sel, h_sel, (size_t)batch * PD.sel_frame_slots * 4, hipMemcpyHostToDevice, stream));
-  }
 
-  prof.begin(stream, "assemble");
-  launch_assemble(stream, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono, batch);
-  prof.end(stream);
-  prof.begin(stream, "blur");
-  launch_blur(stream, d_pyr, d_blur, d_tiles, PD, d_nsel, batch);
-  prof.end(stream);
-  prof.begin(stream, "orient_desc");
-  launch_orient_desc(stream, d_pyr, d_blur, PD, d_aux, d_n, d_kps, d_desc, batch);
-  prof.end(stream);
+    prof.begin(st, "assemble");
+    launch_assemble(st, (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), PD, lap0, lap1, (d_kps + (size_t)f0 * PD.kp_cap), (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_mono + f0), nb);
+    prof.end(st);
+    prof.begin(st, "blur");
+    launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_nsel + (size_t)f0 * L), nb);
+    prof.end(st);
+    prof.begin(st, "orient_desc");
+    launch_orient_desc(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), PD, (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_kps + (size_t)f0 * PD.kp_cap), (d_desc + (size_t)f0 * PD.kp_cap * 32), nb);
+    prof.end(st);
+
+    return DVM_OK;
+  };
+  const bool dual = dual_stream && !host_octree && batch >= 2 && stream2 != nullptr;
+  if (!dual) {
+    rc = run_half(stream, 0, batch);
+    if (rc != DVM_OK) return rc;
+  } else {
+    const int h1 = batch / 2;
+    DVM_HIP(hipEventRecord(ev_fork, stream));
+    DVM_HIP(hipStreamWaitEvent(stream2, ev_fork, 0));
+    rc = run_half(stream, 0, h1);
+    if (rc != DVM_OK) return rc;
+    rc = run_half(stream2, h1, batch - h1);
+    if (rc != DVM_OK) return rc;
+    DVM_HIP(hipEventRecord(ev_join, stream2));
+    DVM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+  }
   DVM_HIP(hipGetLastError());
   return DVM_OK;
 }

@@ -57,6 +57,9 @@ class OrbPipeline {
   dvm_orb_params params;
   int device, max_batch;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second half of a batch (overlaps latency-bound stages)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool dual_stream = true;
   Profiler prof;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> nfeat;

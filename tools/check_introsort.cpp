@@ -30,10 +30,24 @@ static bool run_case(const std::vector<std::pair<int, int>>& in) {  // (size, x0
     v[i] = (uint16_t)i;
   }
   std::sort(ref.begin(), ref.end(), compareNodes);
+  std::vector<uint32_t> k2 = k;
+  std::vector<uint16_t> v2 = v;
   dvm::KV kv{k.data(), v.data()};
   dvm::kv_std_sort(kv, n);
   for (int i = 0; i < n; i++)
     if (ref[i].second->id != (int)v[i]) return false;
+  // split form used on the GPU: serial __introsort_loop, then the stable rank placement
+  dvm::KV kv2{k2.data(), v2.data()};
+  int stk[144];
+  dvm::kv_introsort_loop(kv2, n, stk);
+  std::vector<uint16_t> out(n);
+  for (int i = 0; i < n; i++) {
+    int rank = 0;
+    for (int j = 0; j < n; j++) rank += (k2[j] < k2[i]) || (k2[j] == k2[i] && j < i);
+    out[rank] = v2[i];
+  }
+  for (int i = 0; i < n; i++)
+    if (ref[i].second->id != (int)out[i]) return false;
   return true;
 }
 
