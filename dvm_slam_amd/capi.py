@@ -105,6 +105,7 @@ def lib():
     L.dvm_frame_build.argtypes = [vp, i32, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp]
     L.dvm_frame_build_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, f32, f32, f32, f32, vp]
     L.dvm_match_window.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
+    L.dvm_match_lists.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp]
     L.dvm_match_frames_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, f32, vp, i32, vp, i64,
                                          vp, vp]
     L.dvm_ba_create.argtypes = [i32, C.POINTER(vp)]
@@ -266,6 +267,17 @@ def hamming_matrix(A: np.ndarray, B: np.ndarray) -> np.ndarray:
     D = np.zeros((len(A), len(B)), np.uint16)
     check(lib().dvm_hamming_matrix(_p(A), len(A), _p(B), len(B), _p(D), 0, None))
     return D
+
+
+def match_lists(tdesc: np.ndarray, qdesc: np.ndarray, offsets: np.ndarray, cand: np.ndarray) -> np.ndarray:
+    """Best / second best of query q over train indices cand[offsets[q]:offsets[q+1]] (list order = tie order)."""
+    tdesc = np.ascontiguousarray(tdesc, np.uint8).reshape(-1, 32)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    cand = np.ascontiguousarray(cand, np.int32)
+    out = np.zeros(len(qdesc), MATCH_DTYPE)
+    check(lib().dvm_match_lists(_p(tdesc), len(tdesc), _p(qdesc), len(qdesc), _p(offsets), _p(cand), _p(out), 0, None))
+    return out
 
 
 class FrameGrid:

@@ -1,6 +1,7 @@
 // dvm_slam_amd/csrc/capi.cpp -- extern "C" boundary of libdvmslam_hip.so (include/dvmslam_hip.h).
 // Thin: argument checks, handle lifetime, host<->device staging.  No compute happens on the host
 // here; if no HIP device is visible every entry point that needs one fails with DVM_ERR_NO_DEVICE.
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -403,6 +404,37 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
     rc = hip_check(hipGetLastError(), "match launch");
   }
   if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, d + off_out, qb * sizeof(dvm_match), hipMemcpyDeviceToHost), "memcpy");
+  hipFree(d);
+  return rc;
+}
+
+int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, const int32_t* off, const int32_t* cand,
+                    dvm_match* out, int on_device, void* stream) {
+  if (nq < 0 || nt < 0) return DVM_ERR_INVALID;
+  if (nq == 0) return DVM_OK;
+  if (!tdesc || !qdesc || !off || !cand || !out) return DVM_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (on_device) {
+    launch_match_lists((hipStream_t)stream, tdesc, qdesc, off, cand, nq, reinterpret_cast<dvm_match_pod*>(out));
+    return hip_check(hipGetLastError(), "match_lists launch");
+  }
+  const int ncand = off[nq];
+  if (ncand < 0) return DVM_ERR_INVALID;
+  const size_t b_t = (size_t)std::max(nt, 1) * 32, b_q = (size_t)nq * 32, b_off = (size_t)(nq + 1) * 4, b_c = (size_t)std::max(ncand, 1) * 4,
+               b_out = (size_t)nq * sizeof(dvm_match);
+  const size_t o_t = 0, o_q = o_t + b_t, o_off = o_q + b_q, o_c = o_off + b_off, o_out = (o_c + b_c + 15) & ~(size_t)15, total = o_out + b_out;
+  uint8_t* d = nullptr;
+  int rc = hip_check(hipMalloc(&d, total), "hipMalloc");
+  if (rc != DVM_OK) return rc;
+  auto up = [&](size_t o, const void* src, size_t bytes) { if (rc == DVM_OK && bytes) rc = hip_check(hipMemcpy(d + o, src, bytes, hipMemcpyHostToDevice), "memcpy"); };
+  up(o_t, tdesc, (size_t)nt * 32); up(o_q, qdesc, b_q); up(o_off, off, b_off); up(o_c, cand, (size_t)ncand * 4);
+  if (rc == DVM_OK) {
+    launch_match_lists(nullptr, d + o_t, d + o_q, reinterpret_cast<int32_t*>(d + o_off), reinterpret_cast<int32_t*>(d + o_c), nq,
+                       reinterpret_cast<dvm_match_pod*>(d + o_out));
+    rc = hip_check(hipGetLastError(), "match_lists launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, d + o_out, b_out, hipMemcpyDeviceToHost), "memcpy");
   hipFree(d);
   return rc;
 }

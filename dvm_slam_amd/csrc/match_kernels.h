@@ -57,6 +57,8 @@ void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint
                          int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out);
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride);
+void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,
+                        int nq, dvm_match_pod* out);
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
 
 }  // namespace dvm

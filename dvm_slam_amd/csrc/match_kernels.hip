@@ -197,6 +197,50 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
   }
 }
 
+// Best / second-best over an EXPLICIT candidate list per query (CSR: cand[off[q] .. off[q+1]) in the
+// reference's scan order).  This is the inner loop of the vocabulary-node restricted searches --
+// ORBmatcher::SearchByBoW (reference src/ORBmatcher.cc:262-300,:760-800), SearchForTriangulation
+// (:905-960), SearchBySim3, Fuse -- whose candidate enumeration (DBoW2 FeatureVector walk, epipolar /
+// chi2 gates) stays with the caller.  Strict '<' first-wins ties == min over (dist << 20 | position).
+__global__ void __launch_bounds__(256) k_match_lists(const uint8_t* __restrict__ tdesc, const uint8_t* __restrict__ qdesc,
+                                                     const int32_t* __restrict__ off, const int32_t* __restrict__ cand,
+                                                     int nq, dvm_match_pod* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const uint32_t* qd = reinterpret_cast<const uint32_t*>(qdesc + (size_t)q * 32);
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = qd[i];
+  const int beg = off[q], end = off[q + 1];
+  unsigned long long k1 = (256ull << 32) | 0xFFFFFFFFull, k2 = k1;
+  for (int p = beg + lane; p < end; p += 64) {
+    const int idx = cand[p];
+    if (idx < 0) continue;  // caller-masked candidate
+    const uint4* td = reinterpret_cast<const uint4*>(tdesc + (size_t)idx * 32);
+    const uint4 a = td[0], b = td[1];
+    const int d = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
+                  __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
+    const unsigned long long k = ((unsigned long long)d << 32) | (unsigned)(p - beg);
+    if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+    const unsigned long long n1 = min(k1, o1), n2 = min(max(k1, o1), min(k2, o2));
+    k1 = n1; k2 = n2;
+  }
+  if (lane == 0) {
+    dvm_match_pod m;
+    m.best_dist = (int)(k1 >> 32);
+    m.second_dist = (int)(k2 >> 32);
+    m.best_idx = m.best_dist < 256 ? cand[beg + (int)(k1 & 0xFFFFFFFFu)] : -1;
+    m.best_level = -1;
+    m.second_level = -1;
+    out[q] = m;
+  }
+}
+
 // D[i][j] = Hamming(A[i], B[j]); one thread per pair, 64 columns x 4 rows per workgroup.
 __global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t* __restrict__ A, int nA,
                                                         const uint8_t* __restrict__ B, int nB, uint16_t* __restrict__ D) {
@@ -226,6 +270,10 @@ void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int 
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {
   hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 3) / 4, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride);
+}
+void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,
+                        int nq, dvm_match_pod* out) {
+  hipLaunchKernelGGL(k_match_lists, dim3((nq + 3) / 4), dim3(256), 0, s, tdesc, qdesc, off, cand, nq, out);
 }
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D) {
   hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 63) / 64, (nA + 3) / 4), dim3(256), 0, s, A, nA, B, nB, D);

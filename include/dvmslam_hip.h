@@ -156,6 +156,14 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
                      const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
                      const int32_t* d_nq, dvm_match* out, int on_device, void* stream);
 
+/* Best / second best over an explicit candidate list per query -- the inner loop of the
+ * vocabulary-node restricted searches (SearchByBoW ORBmatcher.cc:262-300,760-800; SearchForTriangulation
+ * :905-960; SearchBySim3; Fuse): query q scans train descriptors cand[off[q] .. off[q+1]) in that order
+ * (entries < 0 are skipped), strict-'<' first-wins.  best_idx is the train index, levels are -1.
+ * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
+int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, const int32_t* off, const int32_t* cand,
+                    dvm_match* out, int on_device, void* stream);
+
 /* TrackWithMotionModel-style frame-to-frame search over a batch (ORBmatcher.cc:1596-1611, mono):
  * pair i (0 <= i < count) searches train slot first_slot+i for every keypoint of frame i-1 of the
  * device arrays (d_kps + (i-1)*kps_stride, ...); pair 0 takes its queries from the carry frame

@@ -140,3 +140,30 @@ def test_match_frames_batch(capi, oracle, frames):
         assert (ref["best_dist"] <= 50).mean() > 0.5
     grid.close()
     e.close()
+
+
+def test_match_lists_bow_style(capi, oracle):
+    """SearchByBoW inner loop: per query an explicit candidate list (same vocabulary node), incl. empty lists,
+    masked (-1) entries, duplicates and heavy ties; reference semantics = sequential strict-'<' scan."""
+    rng = np.random.default_rng(21)
+    nt, nq = 900, 400
+    base = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    td = np.where(rng.random((nt, 1)) < 0.5, base[rng.integers(0, 6, nt)], rng.integers(0, 256, (nt, 32), dtype=np.uint8)).astype(np.uint8)
+    qd = np.where(rng.random((nq, 1)) < 0.5, base[rng.integers(0, 6, nq)], rng.integers(0, 256, (nq, 32), dtype=np.uint8)).astype(np.uint8)
+    lens = rng.choice([0, 1, 2, 5, 30, 200], nq)
+    off = np.zeros(nq + 1, np.int32)
+    off[1:] = np.cumsum(lens)
+    cand = rng.integers(0, nt, off[-1]).astype(np.int32)
+    cand[rng.random(len(cand)) < 0.1] = -1
+    got = capi.match_lists(td, qd, off, cand)
+    for q in range(nq):
+        best, second, bidx = 256, 256, -1
+        for idx in cand[off[q]:off[q + 1]]:
+            if idx < 0:
+                continue
+            d = int(np.unpackbits(td[idx] ^ qd[q]).sum())
+            if d < best:
+                second, best, bidx = best, d, int(idx)
+            elif d < second:
+                second = d
+        assert (got["best_idx"][q], got["best_dist"][q], got["second_dist"][q]) == (bidx, best, second), q
