@@ -164,8 +164,15 @@ def main():
         if fast_n:
             per_launch_s = fast_ms / fast_n / 1e3
             ach = BYTES_PER_FRAME_FAST * B / per_launch_s / 1e9
+            traffic = None
+            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same batch size only)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if pmc["batch"] == B:
+                    traffic = pmc["kernels"]["dvm::k_fast_cells"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "bytes_per_launch": BYTES_PER_FRAME_FAST * B, "avg_launch_ms": fast_ms / fast_n,
                     "all_stage_bytes_per_frame": BYTES_PER_FRAME_TOTAL,
                     "gpu_kernel_ms_per_step": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}}
