@@ -195,10 +195,12 @@ void resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* 
     }
     for (; dx < dw; dx++) out[dx] = S[xofs[dx]] * 2048;
   };
+  int have0 = -1, have1 = -1;  // source rows currently held in row0 / row1 (OpenCV keeps the same ring)
   for (int dy = 0; dy < dh; dy++) {
     int sy0 = clip(yofs[dy], 0, sh), sy1 = clip(yofs[dy] + 1, 0, sh);
-    hresize(sy0, row0);
-    hresize(sy1, row1);
+    if (have1 == sy0) { row0.swap(row1); std::swap(have0, have1); }
+    if (have0 != sy0) { hresize(sy0, row0); have0 = sy0; }
+    if (have1 != sy1) { if (sy1 == sy0) row1 = row0; else hresize(sy1, row1); have1 = sy1; }
     int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
     uint8_t* D = dst + (std::ptrdiff_t)dy * dstride;
     for (int x = 0; x < dw; x++) {
@@ -245,20 +247,30 @@ void gaussian_kernel7_q8(int32_t k[7]) {
 void gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
   int32_t k[7];
   gaussian_kernel7_q8(k);
-  std::vector<uint16_t> tmp((size_t)w * h);
-  for (int y = 0; y < h; y++) {
-    const uint8_t* S = src + (std::ptrdiff_t)y * sstride;
+  // REFLECT_101-padded copy (3 px), then plain separable loops: same arithmetic, no per-tap index math
+  const int pw = w + 6, ph = h + 6;
+  std::vector<uint8_t> pad((size_t)pw * ph);
+  for (int y = 0; y < ph; y++) {
+    const uint8_t* S = src + (std::ptrdiff_t)reflect101(y - 3, h) * sstride;
+    uint8_t* P = &pad[(size_t)y * pw];
+    for (int x = 0; x < pw; x++) P[x] = S[reflect101(x - 3, w)];
+  }
+  std::vector<uint16_t> tmp((size_t)w * ph);
+  for (int y = 0; y < ph; y++) {
+    const uint8_t* P = &pad[(size_t)y * pw];
+    uint16_t* T = &tmp[(size_t)y * w];
     for (int x = 0; x < w; x++) {
-      uint32_t acc = 0;
-      for (int i = 0; i < 7; i++) acc += (uint32_t)k[i] * S[reflect101(x + i - 3, w)];
-      tmp[(size_t)y * w + x] = (uint16_t)std::min(acc, 65535u);
+      uint32_t acc = (uint32_t)k[0] * (P[x] + P[x + 6]) + (uint32_t)k[1] * (P[x + 1] + P[x + 5]) +
+                     (uint32_t)k[2] * (P[x + 2] + P[x + 4]) + (uint32_t)k[3] * P[x + 3];
+      T[x] = (uint16_t)std::min(acc, 65535u);
     }
   }
   for (int y = 0; y < h; y++) {
     uint8_t* D = dst + (std::ptrdiff_t)y * dstride;
+    const uint16_t *r0 = &tmp[(size_t)y * w], *r1 = r0 + w, *r2 = r1 + w, *r3 = r2 + w, *r4 = r3 + w, *r5 = r4 + w, *r6 = r5 + w;
     for (int x = 0; x < w; x++) {
-      uint32_t acc = 0;
-      for (int j = 0; j < 7; j++) acc += (uint32_t)k[j] * tmp[(size_t)reflect101(y + j - 3, h) * w + x];
+      uint32_t acc = (uint32_t)k[0] * ((uint32_t)r0[x] + r6[x]) + (uint32_t)k[1] * ((uint32_t)r1[x] + r5[x]) +
+                     (uint32_t)k[2] * ((uint32_t)r2[x] + r4[x]) + (uint32_t)k[3] * r3[x];
       D[x] = (uint8_t)std::min((acc + 32768u) >> 16, 255u);
     }
   }
@@ -294,7 +306,15 @@ int fast9_16(const uint8_t* roi, int w, int h, int stride, int threshold, std::v
   std::vector<uint8_t> score((size_t)w * h, 0);
   for (int y = 3; y < h - 3; y++)
     for (int x = 3; x < w - 3; x++) {
-      int m = fast_strength(roi + (std::ptrdiff_t)y * stride + x, stride);
+      const uint8_t* p = roi + (std::ptrdiff_t)y * stride + x;
+      // quick reject as in OpenCV's FAST_t (opposing ring pixels 0/8 and 4/12): a 9-arc contains at least
+      // one pixel of every opposing pair, so both pairs need a pixel darker than v-t or both a brighter one
+      const int v = p[0], lo = v - threshold, hi = v + threshold;
+      const int n = p[3 * stride], s_ = p[-3 * stride], e = p[3], w_ = p[-3];
+      const bool dark = (n < lo || s_ < lo) && (e < lo || w_ < lo);
+      const bool bright = (n > hi || s_ > hi) && (e > hi || w_ > hi);
+      if (!dark && !bright) continue;
+      int m = fast_strength(p, stride);
       if (m > threshold) score[(size_t)y * w + x] = (uint8_t)(m - 1);
     }
   // note: a corner at threshold 0 with max(A,B)=1 has score 0 and can never pass the strict NMS,
