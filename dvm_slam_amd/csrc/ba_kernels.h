@@ -38,6 +38,11 @@ struct BaView {
   double* ytmp;             // [6*nfree]
   double* x;                // [6*nfree + 3*L]
   double *partial, *partial2;
+  // tile-level (64x64) structure of the Cholesky factor incl. fill, from a symbolic factorisation on the host:
+  const int32_t* strips;    // per step kb: tile rows i > kb with L(i,kb) != 0          (offsets h_strip_off)
+  const int32_t* tiles;     // per step kb: (i,j), i >= j > kb, L(i,kb) and L(j,kb) != 0 (offsets h_tile_off)
+  const int32_t* rowtiles;  // per tile row k: columns j < k with L(k,j) != 0           (offsets h_row_off)
+  const int32_t *h_strip_off, *h_tile_off, *h_row_off;  // HOST arrays [nkb+1]
   const double* lambda;     // device scalar: current LM damping (so the per-trial launch sequence is a replayable graph)
 };
 

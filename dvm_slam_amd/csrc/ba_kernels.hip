@@ -359,78 +359,144 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {  // src_l
   return __hiloint2double(hi, lo);
 }
 
-// Diagonal step kb, ONE wavefront, no barriers: lane r keeps row r of the 64x64 block in registers.
-//   1. left-looking Cholesky: column j of L from row j broadcast lane->scalar (v_readlane)
-//   2. Linv = L^-1 by forward substitution, lane c owning column c
-// L goes back into S (lower triangle), Linv (row-major, zero above the diagonal) into Linv_all[kb].
-// The column-by-column dependency chain of a dense Cholesky lives here; keeping it inside one wave
-// (instead of two workgroup barriers per column) is what makes the solve fast.
-__global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ S, int ldS, int n1, int kb, int* __restrict__ fail,
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
+
+// Diagonal step kb: Cholesky factor L of the 64x64 block AND its inverse, one workgroup (4 waves).
+// The block is processed as 4x4 sub-blocks of 16x16:
+//   A. wave 0: 16x16 Cholesky + inverse of the diagonal sub-block, row-per-lane in registers, column
+//      broadcasts by v_readlane -- the only strictly sequential part (4 x 16 columns instead of 64)
+//   B. panel sub-blocks below:   X_i = A_ib * Linv_bb^T            (v_mfma_f64_16x16x4_f64)
+//   C. trailing sub-blocks:      A_ij -= X_i * X_j^T               (v_mfma_f64_16x16x4_f64)
+// then Linv by block forward substitution, Linv_ij = -Linv_ii * sum_k L_ik Linv_kj, again on MFMA: the
+// C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly its B-operand
+// layout for k-step = reg, so the running sum feeds the next product without touching LDS.
+__global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, int kb, int* __restrict__ fail,
                                                   double* __restrict__ Linv_all) {
-  const int lane = threadIdx.x;
+  __shared__ double Bm[NB * LP];
+  __shared__ double Li[NB * LP];
+  __shared__ double Iv[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = kb * NB;
   const int kw = min(NB, n1 - k0);
-  double a[NB];
-#pragma unroll
-  for (int c = 0; c < NB; c++) {
-    double v = (lane == c) ? 1.0 : 0.0;  // rows / columns beyond the matrix: identity
-    if (lane < kw && c < kw && c <= lane) v = S[(size_t)(k0 + lane) * ldS + k0 + c];
-    a[c] = v;
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    double v = (r == c) ? 1.0 : 0.0;  // rows / columns beyond the matrix: identity
+    if (r < kw && c <= r) v = S[(size_t)(k0 + r) * ldS + k0 + c];
+    Bm[r * LP + c] = v;
+    Li[r * LP + c] = 0.0;
   }
-  bool bad = false;
+  __syncthreads();
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int b = 0; b < 4; b++) {
+    const int o = 16 * b;
+    if (wave == 0) {  // ---- A
+      double a[16];
 #pragma unroll
-  for (int j = 0; j < NB; j++) {
-    // four independent partial sums: the FMA latency chain is j/4 long instead of j
-    double s0 = a[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int c = 0; c < 16; c++) a[c] = (lane < 16 && c <= lane) ? Bm[(o + lane) * LP + o + c] : 0.0;
+      bool bad = false;
 #pragma unroll
-    for (int k = 0; k < j; k++) {
-      const double t = bcast_lane(a[k], j);
-      if ((k & 3) == 0) s0 = __builtin_fma(-a[k], t, s0);
-      else if ((k & 3) == 1) s1 = __builtin_fma(-a[k], t, s1);
-      else if ((k & 3) == 2) s2 = __builtin_fma(-a[k], t, s2);
-      else s3 = __builtin_fma(-a[k], t, s3);
+      for (int j = 0; j < 16; j++) {
+        double s0 = a[j], s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+          const double t = bcast_lane(a[k], j);
+          if (k & 1) s1 = __builtin_fma(-a[k], t, s1); else s0 = __builtin_fma(-a[k], t, s0);
+        }
+        const double s = s0 + s1;
+        const double d = bcast_lane(s, j);
+        if (!(d > 0.0)) bad = true;
+        const double sq = sqrt(d > 0.0 ? d : 1.0);
+        a[j] = (lane == j) ? sq : (lane > j ? s / sq : 0.0);
+      }
+      if (bad && lane == 0) *fail = 1;
+      double y[16];  // column `lane` of the 16x16 inverse
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < i; t++) {
+          const double l = bcast_lane(a[t], i);
+          if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
+        }
+        y[i] = (s0 + s1) / bcast_lane(a[i], i);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (c <= lane) ? a[c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const double v = (lane <= i) ? y[i] : 0.0;
+          Iv[b][i][lane] = v;
+          Li[(o + i) * LP + o + lane] = v;
+        }
+      }
     }
-    const double s = (s0 + s1) + (s2 + s3);
-    const double d = bcast_lane(s, j);
-    if (!(d > 0.0)) bad = true;
-    const double sq = sqrt(d > 0.0 ? d : 1.0);
-    a[j] = (lane == j) ? sq : (lane > j ? s / sq : 0.0);
-  }
-  if (bad && lane == 0) *fail = 1;
+    __syncthreads();
+    // ---- B: wave w owns sub-block row i = b + 1 + w
+    if (b + 1 + wave < 4) {
+      const int oi = 16 * (b + 1 + wave);
+      double4_t acc = {0, 0, 0, 0};
 #pragma unroll
-  for (int c = 0; c < NB; c++)
-    if (lane < kw && c <= lane) S[(size_t)(k0 + lane) * ldS + k0 + c] = a[c];
-  // forward substitution: y = column `lane` of L^-1
-  double y[NB];
+      for (int k = 0; k < 16; k += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + o + k + lq], Iv[b][lr][k + lq], acc, 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < NB; i++) {
-    double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-    for (int t = 0; t < i; t++) {
-      const double l = bcast_lane(a[t], i);
-      if ((t & 3) == 0) s0 = __builtin_fma(-l, y[t], s0);
-      else if ((t & 3) == 1) s1 = __builtin_fma(-l, y[t], s1);
-      else if ((t & 3) == 2) s2 = __builtin_fma(-l, y[t], s2);
-      else s3 = __builtin_fma(-l, y[t], s3);
+      for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + o + lr] = acc[r];
     }
-    y[i] = ((s0 + s1) + (s2 + s3)) / bcast_lane(a[i], i);
-  }
-  double* Li = Linv_all + (size_t)kb * NB * NB;
+    __syncthreads();
+    // ---- C: trailing sub-blocks (i >= j > b), round-robin over the waves
+    int pair = 0;
+    for (int i = b + 1; i < 4; i++)
+      for (int j = b + 1; j <= i; j++, pair++) {
+        if ((pair & 3) != wave) continue;
+        const int oi = 16 * i, oj = 16 * j;
+        double4_t acc = {0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < NB; i++) Li[i * NB + lane] = (lane <= i) ? y[i] : 0.0;
+        for (int k = 0; k < 16; k += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + o + k + lq], Bm[(oj + lr) * LP + o + k + lq], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
+      }
+    __syncthreads();
+  }
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Bm[r * LP + c];
+  }
+  // ---- Linv: wave j builds block column j top-down
+  if (wave < 3) {
+    const int j = wave;
+    for (int i = j + 1; i < 4; i++) {
+      double4_t t = {0, 0, 0, 0};
+      for (int k = j; k < i; k++) {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4)
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(16 * i + lr) * LP + 16 * k + kk + lq], Li[(16 * k + kk + lq) * LP + 16 * j + lr], t, 0, 0, 0);
+      }
+      double4_t r4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; st++) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[i][lr][4 * st + lq], t[st], r4, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) Li[(16 * i + lq + 4 * r) * LP + 16 * j + lr] = -r4[r];
+      __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes feed its next block row
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  double* Lo = Linv_all + (size_t)kb * NB * NB;
+  for (int i = tid; i < NB * NB; i += 256) Lo[i] = Li[(i >> 6) * LP + (i & 63)];
 }
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // Panel solve of step kb: strip i (64 rows below the diagonal block) becomes X = A_ik * Linv_kk^T
 // (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM.
 __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1, int kb,
-                                                   const double* __restrict__ Linv_all) {
+                                                   const double* __restrict__ Linv_all, const int32_t* __restrict__ strips) {
   __shared__ double Ai[NB][NB + 1];
   __shared__ double Li[NB][NB + 1];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
-  const int r0 = k0 + NB + blockIdx.x * NB;
+  const int r0 = strips[blockIdx.x] * NB;  // tile row of a structurally non-zero strip of this panel
   const int rw = min(NB, n1 - r0);
   const double* Lk = Linv_all + (size_t)kb * NB * NB;
   for (int i = tid; i < NB * NB; i += 256) {
@@ -472,17 +538,14 @@ __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int l
 // triangle of tiles.  4 waves, each owning a 32x32 quadrant = 2x2 MFMA tiles of
 // v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
 // C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg).
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1, int kb) {
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1, int kb,
+                                                     const int32_t* __restrict__ tiles) {
   __shared__ double Ai[NB][NB + 1];
   __shared__ double Aj[NB][NB + 1];
-  // decode (ti, tj), ti >= tj, from the linear lower-triangle index
-  const int t = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-  while (ti * (ti + 1) / 2 > t) ti--;
-  const int tj = t - ti * (ti + 1) / 2;
+  // (ti, tj), ti >= tj: a trailing tile whose two panel strips are both structurally non-zero
+  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
   const int k0 = kb * NB;
-  const int i0 = k0 + NB + ti * NB, j0 = k0 + NB + tj * NB;
+  const int i0 = ti * NB, j0 = tj * NB;
   const int iw = min(NB, n1 - i0), jw = min(NB, n1 - j0);
   const int tid = threadIdx.x;
   for (int i = tid; i < NB * NB; i += 256) {
@@ -525,7 +588,8 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
 // (j < kb) applies y_j -= L[kblock, jblock]^T x_k.
 __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n, int kb,
                                                         double* __restrict__ y, double* __restrict__ x,
-                                                        const double* __restrict__ Linv_all) {
+                                                        const double* __restrict__ Linv_all,
+                                                        const int32_t* __restrict__ rowtiles) {
   __shared__ double yk[NB];
   __shared__ double xk[NB];
   __shared__ double part[4][NB];
@@ -547,7 +611,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
     if (tid < kw) x[k0 + tid] = xk[tid];
     return;
   }
-  const int j0 = (blockIdx.x - 1) * NB;  // j < kb
+  const int j0 = rowtiles[blockIdx.x - 1] * NB;  // structurally non-zero tile (kb, j), j < kb
   double u = 0;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -886,16 +950,17 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
   const int nkb = cdiv(n1, NB);
   for (int kb = 0; kb < nkb; kb++) {
     const int below = cdiv(std::max(n1 - (kb + 1) * NB, 0), NB);
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, V.S, V.ldS, n1, kb, d_fail, V.Linv);
-    if (below > 0) {
-      hipLaunchKernelGGL(k_chol_trsm, dim3(below), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.Linv);
-      hipLaunchKernelGGL(k_chol_update, dim3(below * (below + 1) / 2), dim3(256), 0, s, V.S, V.ldS, n1, kb);
-    }
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, V.S, V.ldS, n1, kb, d_fail, V.Linv);
+    (void)below;
+    const int ns = V.h_strip_off[kb + 1] - V.h_strip_off[kb], nt = V.h_tile_off[kb + 1] - V.h_tile_off[kb];
+    if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(ns), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.Linv, V.strips + V.h_strip_off[kb]);
+    if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.tiles + 2 * (size_t)V.h_tile_off[kb]);
   }
   hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(n, 256)), dim3(256), 0, s, V.S, V.ldS, n, V.ytmp);
   const int nxb = cdiv(n, NB);
   for (int kb = nxb - 1; kb >= 0; kb--)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + kb), dim3(256), 0, s, V.S, V.ldS, n, kb, V.ytmp, V.x, V.Linv);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + V.h_row_off[kb + 1] - V.h_row_off[kb]), dim3(256), 0, s, V.S, V.ldS, n, kb,
+                       V.ytmp, V.x, V.Linv, V.rowtiles + V.h_row_off[kb]);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);

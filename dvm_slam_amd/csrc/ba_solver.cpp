@@ -33,6 +33,8 @@ struct dvm_ba {
   uint8_t* d_depth = nullptr;
   bool have_problem = false;
   double ms_structure = 0;
+  std::vector<int32_t> strip_off, tile_off, row_off;  // host copies of the per-step tile lists' offsets
+  double tile_fill = 1.0;                             // non-zero tiles / all lower tiles of the factor
   hipGraphExec_t trial_graph = nullptr;  // one LM trial (push, Schur, Cholesky solve, update, chi2) as a hipGraph
 
   template <typename T>
@@ -146,6 +148,36 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   V.nblk = (int)blk_i1.size();
   const int n = 6 * V.nfree;
   V.ldS = (n + 1 + 63) / 64 * 64;
+  // ---- symbolic tile-level Cholesky (64x64 tiles): which tiles of L are structurally non-zero.  SLAM
+  // reduced camera matrices are banded along the trajectory plus a few loop-closure blocks; skipping
+  // zero tiles keeps the dense-tile solver exact while doing only the work the structure requires.
+  const int nkb = V.ldS / 64;
+  std::vector<std::vector<char>> T(nkb, std::vector<char>(nkb, 0));
+  for (size_t b = 0; b < blk_i1.size(); b++) {
+    const int r0 = 6 * blk_i1[b], c0 = 6 * blk_i2[b];
+    for (int tr = r0 / 64; tr <= (r0 + 5) / 64; tr++)
+      for (int tc = c0 / 64; tc <= (c0 + 5) / 64; tc++)
+        if (tr >= tc) T[tr][tc] = 1; else T[tc][tr] = 1;
+  }
+  for (int k = 0; k < nkb; k++) { T[k][k] = 1; T[n / 64][k] = (k <= n / 64) ? 1 : T[n / 64][k]; }  // augmented rhs row is dense
+  std::vector<int32_t> strips, tiles, rowtiles;
+  h->strip_off.assign(1, 0); h->tile_off.assign(1, 0); h->row_off.assign(1, 0);
+  for (int k = 0; k < nkb; k++) {
+    std::vector<int> rows;
+    for (int i = k + 1; i < nkb; i++) if (T[i][k]) rows.push_back(i);
+    for (int i : rows) strips.push_back(i);
+    for (size_t a = 0; a < rows.size(); a++)
+      for (size_t b2 = 0; b2 <= a; b2++) { T[rows[a]][rows[b2]] = 1; tiles.push_back(rows[a]); tiles.push_back(rows[b2]); }
+    h->strip_off.push_back((int32_t)strips.size());
+    h->tile_off.push_back((int32_t)(tiles.size() / 2));
+  }
+  size_t nz = 0;
+  for (int k = 0; k < nkb; k++) {
+    for (int j = 0; j < k; j++) if (T[k][j]) rowtiles.push_back(j);
+    h->row_off.push_back((int32_t)rowtiles.size());
+    for (int j = 0; j <= k; j++) nz += T[k][j];
+  }
+  h->tile_fill = (double)nz / ((double)nkb * (nkb + 1) / 2);
 
   int rc = DVM_OK;
   auto ok = [&](int r) { if (rc == DVM_OK) rc = r; };
@@ -166,6 +198,8 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(std::max(L, V.nfree) + 255) / 256));
   ok(h->dalloc(&h->d_depth, (size_t)E));
+  ok(h->upload(&V.strips, strips)); ok(h->upload(&V.tiles, tiles)); ok(h->upload(&V.rowtiles, rowtiles));
+  V.h_strip_off = h->strip_off.data(); V.h_tile_off = h->tile_off.data(); V.h_row_off = h->row_off.data();
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   // poses: normalise quaternions like SE3Quat's constructor (se3quat.h:261-266)
   std::vector<double> pn(poses, poses + 7 * (size_t)P);
