@@ -17,6 +17,7 @@ void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gau
 void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
                        uint8_t* d_pyr, const PipelineDesc& PD, int batch);
 void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int level, const int32_t* d_tabs, int batch);
+void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch);
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh);
 void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,

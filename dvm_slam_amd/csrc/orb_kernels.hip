@@ -12,6 +12,8 @@
 // IEEE rounding, the same sequence the CPU oracle performs.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "orb_device.h"
 #include "orb_kernels.h"
 
@@ -37,68 +39,150 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 // ------------------------------------------------------------------------------------------ K1
-// Level 0: copy the input image into the bordered level-0 buffer and fill the 19-px REFLECT_101
-// frame.  One thread per 4 destination bytes (aligned dword store).
+// ComputePyramid (reference ORBextractor.cc:957-976) in three kinds of launches:
+//   k_pyr_level0   level 0 = the input image (interior only)
+//   k_pyr_resize   level l = cv::resize(level l-1, INTER_LINEAR), 8-bit fixed point, interior only;
+//                  a workgroup stages the source rectangle of its 256x16 destination tile in LDS with
+//                  aligned dword loads, then every destination pixel is 4 LDS byte reads
+//   k_pyr_borders  copyMakeBorder(REFLECT_101, 19 px) of ALL levels in one launch (the border of a level
+//                  depends only on that level's interior; no later stage of the mono path reads it except
+//                  the blur, which needs 3 px)
+// Destination dwords are aligned in BORDERED coordinates (the image starts at byte 19 of a row), so a
+// dword at a row end may mix interior and border bytes: those are stored byte-wise.
+constexpr int kRzTW = 256, kRzTH = 16;   // destination tile (bordered columns x interior rows)
+
+__device__ __forceinline__ void store_px4(uint8_t* D, int X4, int w, uint32_t v) {
+  const int d0 = X4 - kEdge;             // interior x of byte 0
+  if (d0 >= 0 && d0 + 3 < w) {
+    *reinterpret_cast<uint32_t*>(D + X4) = v;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (d0 + k >= 0 && d0 + k < w) D[X4 + k] = (uint8_t)(v >> (8 * k));
+  }
+}
+
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ src, int rows, int cols, int sstride,
                                                     int64_t frame_stride, uint8_t* __restrict__ pyr,
                                                     int pyr_frame_bytes, LevelDesc L) {
-  const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int Y = blockIdx.y;
+  const int X4 = 16 + (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y = blockIdx.y;
   const int f = blockIdx.z;
-  const int bw = L.w + 2 * kEdge;
-  if (X4 >= bw) return;
-  const uint8_t* S = src + (int64_t)f * frame_stride + (int64_t)reflect101(Y - kEdge, rows) * sstride;
+  if (X4 - kEdge >= cols) return;
+  const uint8_t* S = src + (int64_t)f * frame_stride + (int64_t)y * sstride;
   uint32_t v = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int X = X4 + k;
-    if (X < bw) v |= (uint32_t)S[reflect101(X - kEdge, cols)] << (8 * k);
+    const int x = X4 + k - kEdge;
+    if (x >= 0 && x < cols) v |= (uint32_t)S[x] << (8 * k);
   }
-  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)Y * L.stride;
-  *reinterpret_cast<uint32_t*>(D + X4) = v;
+  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + y) * L.stride;
+  store_px4(D, X4, cols, v);
 }
 
-// Level l>0: cv::resize(level l-1 -> l, INTER_LINEAR) 8-bit fixed point (coefficient tables built on
-// the host: xofs/xalpha/yofs/ybeta, 11-bit weights) fused with copyMakeBorder(REFLECT_101): a border
-// pixel recomputes the interior pixel it mirrors.  One thread per 4 destination bytes.
 __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
-                                                    LevelDesc L, const int32_t* __restrict__ tabs) {
-  const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int Y = blockIdx.y;
+                                                    LevelDesc L, const int32_t* __restrict__ tabs, int lds_pitch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rz_smem[];
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   const int f = blockIdx.z;
-  const int bw = L.w + 2 * kEdge;
-  if (X4 >= bw) return;
+  const int X0 = 16 + blockIdx.x * kRzTW;          // first bordered column of the tile (dword aligned)
+  const int y0 = blockIdx.y * kRzTH;               // first interior row
+  const int dxa = max(X0 - kEdge, 0), dxb = min(X0 + kRzTW - 1 - kEdge, L.w - 1);
+  if (dxa > dxb) return;
   const int32_t* xofs = tabs + L.tab_off;
   const int32_t* xal = xofs + L.w;   // (a0 | a1 << 16)
   const int32_t* yofs = xal + L.w;
   const int32_t* ybe = yofs + L.h;   // (b0 | b1 << 16)
-  const int dy = reflect101(Y - kEdge, L.h);
-  const uint8_t* base = pyr + (int64_t)f * pyr_frame_bytes;
-  const uint8_t* S = base + P.pyr_off + (int64_t)kEdge * P.stride + kEdge;  // pixel (0,0) of level l-1
-  int sy = yofs[dy];
-  int sy0 = min(max(sy, 0), P.h - 1), sy1 = min(max(sy + 1, 0), P.h - 1);
-  const uint8_t* S0 = S + (int64_t)sy0 * P.stride;
-  const uint8_t* S1 = S + (int64_t)sy1 * P.stride;
-  const int bb = ybe[dy];
-  const int b0 = (int16_t)(bb & 0xFFFF), b1 = (int16_t)(bb >> 16);
-  uint32_t v = 0;
+  const int yb = min(y0 + kRzTH - 1, L.h - 1);
+  const int sya = min(max(yofs[y0], 0), P.h - 1), syb = min(max(yofs[yb] + 1, 0), P.h - 1);
+  const int sxa = xofs[dxa], sxb = xofs[dxb] + 1;  // sx+1 may be the first border column of level l-1 (weight 0)
+  const int ga = (kEdge + sxa) & ~3;               // bordered source column of LDS column 0
+  const int ndw = ((kEdge + sxb - ga) >> 2) + 1;
+  const uint8_t* Sg = pyr + (int64_t)f * pyr_frame_bytes + P.pyr_off + (int64_t)(kEdge + sya) * P.stride + ga;
+  uint32_t* lds32 = reinterpret_cast<uint32_t*>(rz_smem);
+  const int nrow = syb - sya + 1;
+  for (int i = tid; i < nrow * ndw; i += 256) {
+    const int r = i / ndw, c = i - r * ndw;
+    lds32[r * (lds_pitch >> 2) + c] = reinterpret_cast<const uint32_t*>(Sg + (int64_t)r * P.stride)[c];
+  }
+  __syncthreads();
+  const int X4 = X0 + 4 * tx;
+  int sx[4], a0[4], a1[4];
+  bool any = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int X = X4 + k;
-    if (X >= bw) break;
-    int dx = reflect101(X - kEdge, L.w);
-    int sx = xofs[dx];
-    int aa = xal[dx];
-    int a0 = (int16_t)(aa & 0xFFFF), a1 = (int16_t)(aa >> 16);
-    // S[sx+1] is always addressable (level l-1 carries its border); its weight is 0 at the clamp
-    int h0 = S0[sx] * a0 + S0[sx + 1] * a1;
-    int h1 = S1[sx] * a0 + S1[sx + 1] * a1;
-    int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    r = min(max(r, 0), 255);
-    v |= (uint32_t)r << (8 * k);
+    const int dx = X4 + k - kEdge;
+    const bool ok = dx >= 0 && dx < L.w;
+    any |= ok;
+    const int dxc = min(max(dx, 0), L.w - 1);
+    sx[k] = kEdge + xofs[dxc] - ga;
+    const int aa = xal[dxc];
+    a0[k] = (int16_t)(aa & 0xFFFF); a1[k] = (int16_t)(aa >> 16);
   }
-  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)Y * L.stride;
-  *reinterpret_cast<uint32_t*>(D + X4) = v;
+  if (!any) return;
+#pragma unroll
+  for (int rr = 0; rr < kRzTH / 4; rr++) {
+    const int dy = y0 + ty + 4 * rr;
+    if (dy >= L.h) break;
+    const int sy = yofs[dy];
+    const int r0 = min(max(sy, 0), P.h - 1) - sya, r1 = min(max(sy + 1, 0), P.h - 1) - sya;
+    const int bb = ybe[dy];
+    const int b0 = (int16_t)(bb & 0xFFFF), b1 = (int16_t)(bb >> 16);
+    const uint8_t* S0 = rz_smem + r0 * lds_pitch;
+    const uint8_t* S1 = rz_smem + r1 * lds_pitch;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int h0 = S0[sx[k]] * a0[k] + S0[sx[k] + 1] * a1[k];
+      const int h1 = S1[sx[k]] * a0[k] + S1[sx[k] + 1] * a1[k];
+      int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      r = min(max(r, 0), 255);
+      v |= (uint32_t)r << (8 * k);
+    }
+    uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + dy) * L.stride;
+    store_px4(D, X4, L.w, v);
+  }
+}
+
+// REFLECT_101 frame of every level in ONE launch, touching border bytes only:
+//   blockIdx.y <  38*nlevels : one full bordered row of the top / bottom strip (19 + 19 rows per level)
+//   blockIdx.y >= 38*nlevels : 16 interior rows per workgroup, 16 threads per row: 5 dwords on the left
+//                              (bordered columns 0..19) and up to 6 on the right
+__global__ void __launch_bounds__(256) k_pyr_borders(uint8_t* __restrict__ pyr, PipelineDesc PD) {
+  const int f = blockIdx.z, tid = threadIdx.x;
+  const int nstrip = 2 * kEdge * PD.nlevels;
+  if ((int)blockIdx.y < nstrip) {
+    const LevelDesc& L = PD.lv[blockIdx.y / (2 * kEdge)];
+    const int r = blockIdx.y % (2 * kEdge);
+    const int row = r < kEdge ? r : L.h + r;          // bordered row: 0..18 or h+19..h+37
+    const int bw = L.w + 2 * kEdge;
+    const int X4 = (blockIdx.x * 256 + tid) * 4;
+    if (X4 >= bw) return;
+    uint8_t* base = pyr + (int64_t)f * PD.pyr_frame_bytes + L.pyr_off;
+    const uint8_t* S = base + (int64_t)(kEdge + reflect101(row - kEdge, L.h)) * L.stride + kEdge;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)S[reflect101(min(X4 + k, bw - 1) - kEdge, L.w)] << (8 * k);
+    *reinterpret_cast<uint32_t*>(base + (int64_t)row * L.stride + X4) = v;   // row pitch is a multiple of 64
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  int g = ((int)blockIdx.y - nstrip) * 16 + (tid >> 4), lvl = 0;
+  while (lvl < PD.nlevels && g >= PD.lv[lvl].h) { g -= PD.lv[lvl].h; lvl++; }
+  if (lvl >= PD.nlevels) return;
+  const LevelDesc& L = PD.lv[lvl];
+  const int j = tid & 15;
+  const int bw = L.w + 2 * kEdge;
+  const int X4 = j < 5 ? 4 * j : ((kEdge + L.w) & ~3) + 4 * (j - 5);
+  if (X4 >= bw) return;
+  uint8_t* D = pyr + (int64_t)f * PD.pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + g) * L.stride;
+  const uint8_t* S = D + kEdge;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int X = X4 + k, x = X - kEdge;
+    if (X >= bw || (x >= 0 && x < L.w)) continue;
+    D[X] = S[reflect101(x, L.w)];
+  }
 }
 
 // ------------------------------------------------------------------------------------------ K2
@@ -621,14 +705,25 @@ void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gau
 void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
                        uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
   const LevelDesc& L = PD.lv[0];
-  dim3 grid(cdiv(cdiv(L.w + 2 * kEdge, 4), 256), L.h + 2 * kEdge, batch);
+  dim3 grid(cdiv(cdiv(L.w + 3, 4), 256), L.h, batch);
   hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_src, rows, cols, sstride, frame_stride, d_pyr,
                      PD.pyr_frame_bytes, L);
 }
 void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int level, const int32_t* d_tabs, int batch) {
   const LevelDesc& L = PD.lv[level];
-  dim3 grid(cdiv(cdiv(L.w + 2 * kEdge, 4), 256), L.h + 2 * kEdge, batch);
-  hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, PD.lv[level - 1], L, d_tabs);
+  const LevelDesc& P = PD.lv[level - 1];
+  // LDS for the source rectangle of a 256 x 16 destination tile (scale = P/L, +margins)
+  const double sxs = (double)P.w / L.w, sys = (double)P.h / L.h;
+  const int pitch = (((int)(kRzTW * sxs) + 16) + 3) & ~3;
+  const int nrows = (int)(kRzTH * sys) + 4;
+  dim3 grid(cdiv(L.w + 3, kRzTW), cdiv(L.h, kRzTH), batch);
+  hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)pitch * nrows, s, d_pyr, PD.pyr_frame_bytes, P, L, d_tabs, pitch);
+}
+void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
+  int rows = 0, maxw = 0;
+  for (int l = 0; l < PD.nlevels; l++) { rows += PD.lv[l].h; maxw = std::max(maxw, PD.lv[l].w + 2 * kEdge); }
+  dim3 grid(cdiv(cdiv(maxw, 4), 256), 2 * kEdge * PD.nlevels + cdiv(rows, 16), batch);
+  hipLaunchKernelGGL(k_pyr_borders, grid, dim3(256), 0, s, d_pyr, PD);
 }
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh) {

@@ -270,7 +270,7 @@ int OrbPipeline::init() {
   DVM_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
   DVM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   DVM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  if (const char* e = getenv("DVM_SINGLE_STREAM")) dual_stream = !(e[0] == '1');
+  if (const char* e = getenv("DVM_DUAL_STREAM")) dual_stream = (e[0] == '1');  // two half-batches on two streams
   if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree = (e[0] == '1');  // debug / A-B switch only
   // orientation disc offsets (any order: the moments are exact integer sums)
   int8_t du[kDiscPixels], dv[kDiscPixels];
@@ -500,6 +500,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.begin(st, "pyramid");
     launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
     for (int l = 1; l < L; l++) launch_pyr_resize(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, l, d_tabs, nb);
+    launch_pyr_borders(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
     prof.end(st);
     prof.begin(st, "fast");
     launch_fast(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), d_cells, PD, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), nb, max_cell_rw, max_cell_rh);

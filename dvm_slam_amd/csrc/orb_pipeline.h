@@ -59,7 +59,7 @@ class OrbPipeline {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second half of a batch (overlaps latency-bound stages)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool dual_stream = true;
+  bool dual_stream = false;  // DVM_DUAL_STREAM=1: measured +4 % at batch 64, nil at batch 256
   Profiler prof;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> nfeat;
