@@ -37,10 +37,10 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s ach
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (per GPU)")
-    ap.add_argument("--stream-frames", type=int, default=128, help="distinct synthetic frames resident in HBM")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step (per GPU)")
+    ap.add_argument("--stream-frames", type=int, default=256, help="distinct synthetic frames resident in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--ba-iters", type=int, default=10)
@@ -163,17 +163,19 @@ def main():
         roof = None
         if fast_n:
             per_launch_s = fast_ms / fast_n / 1e3
-            ach = BYTES_PER_FRAME_FAST * B / per_launch_s / 1e9
+            frames_per_launch = a.steps * B / fast_n          # B, or B/2 with DVM_DUAL_STREAM=1
+            ach = BYTES_PER_FRAME_FAST * frames_per_launch / per_launch_s / 1e9
             traffic = None
             try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same batch size only)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if pmc["batch"] == B:
+                if pmc["batch"] == frames_per_launch:
                     traffic = pmc["kernels"]["dvm::k_fast_cells"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "bytes_per_launch": BYTES_PER_FRAME_FAST * B, "avg_launch_ms": fast_ms / fast_n,
+                    "bytes_per_launch": BYTES_PER_FRAME_FAST * frames_per_launch, "avg_launch_ms": fast_ms / fast_n,
+                    "frames_per_launch": frames_per_launch,
                     "all_stage_bytes_per_frame": BYTES_PER_FRAME_TOTAL,
                     "gpu_kernel_ms_per_step": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}}
         out = {

@@ -32,6 +32,20 @@ __constant__ int8_t c_disc_u[768];
 __constant__ int8_t c_disc_v[768];
 __constant__ int c_gauss7[7];
 
+// XCD-aware (block, frame) mapping for per-frame kernels launched as a 1-D grid of
+// blocks_per_frame * 8 * ceil(batch/8) workgroups.  The dispatcher places workgroup b on XCD b % 8
+// (observed, used for speed only): interleaving 8 frames keeps ALL workgroups of one frame on one XCD,
+// so the frame's pyramid / blurred levels (~2 MB) are served by that XCD's 4 MB L2 instead of being
+// fetched into all eight.  Returns false for the padding frames of a batch that is not a multiple of 8.
+__device__ __forceinline__ bool xcd_frame_map(int blocks_per_frame, int batch, int& blk, int& f) {
+  const int b = blockIdx.x;
+  const int i = b >> 3;
+  blk = i % blocks_per_frame;
+  f = (i / blocks_per_frame) * 8 + (b & 7);
+  return f < batch;
+}
+static inline int xcd_grid(int blocks_per_frame, int batch) { return blocks_per_frame * 8 * ((batch + 7) / 8); }
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   if (len == 1) return 0;
   while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
@@ -188,32 +202,46 @@ __global__ void __launch_bounds__(256) k_pyr_borders(uint8_t* __restrict__ pyr, 
 // ------------------------------------------------------------------------------------------ K2
 // FAST-9/16 strength max(A,B) of one pixel: A = max over the 16 nine-pixel arcs of min(v - p),
 // B = the same for (p - v).  Sliding-window min/max of width 9 over the circular 16-vector by
-// doubling (2,4,8,+1): 4 x 16 min + 4 x 16 max.
+// doubling (2,4,8,+1), on PACKED 16-bit lanes (v_pk_min_i16 / v_pk_max_i16: two ring positions per
+// instruction; differences are in [-255, 255]).
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2_t pk(int lo, int hi) {
+  const int w = (lo & 0xFFFF) | (hi << 16);
+  return __builtin_bit_cast(short2_t, w);
+}
 __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int pitch) {
   const int v = t[0];
-  int d[16];
+  int p[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - (int)t[c_circle[k][0] + c_circle[k][1] * pitch];
-  int lo2[16], hi2[16];
+  for (int k = 0; k < 16; k++) p[k] = (int)t[c_circle[k][0] + c_circle[k][1] * pitch];
+  const short2_t V = pk(v, v);
+  short2_t P[8], Q[8];   // P[j] = (d[2j], d[2j+1]),  Q[j] = (d[2j+1], d[2j+2])
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo2[k] = min(d[k], d[(k + 1) & 15]);
-    hi2[k] = max(d[k], d[(k + 1) & 15]);
+  for (int j = 0; j < 8; j++) {
+    P[j] = V - pk(p[2 * j], p[2 * j + 1]);
+    Q[j] = V - pk(p[2 * j + 1], p[(2 * j + 2) & 15]);
   }
-  int lo4[16], hi4[16];
+  short2_t lo[8], hi[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-    hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+  for (int j = 0; j < 8; j++) {  // windows of 2: (w2[2j], w2[2j+1])
+    lo[j] = __builtin_elementwise_min(P[j], Q[j]);
+    hi[j] = __builtin_elementwise_max(P[j], Q[j]);
   }
-  int A = -256, Bn = 256;
+  short2_t lo4[8], hi4[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-    int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-    A = max(A, lo9);
-    Bn = min(Bn, hi9);
+  for (int j = 0; j < 8; j++) {  // windows of 4
+    lo4[j] = __builtin_elementwise_min(lo[j], lo[(j + 1) & 7]);
+    hi4[j] = __builtin_elementwise_max(hi[j], hi[(j + 1) & 7]);
   }
+  short2_t A2 = pk(-256, -256), B2 = pk(256, 256);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {  // windows of 8, then the ninth element d[k+8]
+    const short2_t lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[j], lo4[(j + 2) & 7]), P[(j + 4) & 7]);
+    const short2_t hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[j], hi4[(j + 2) & 7]), P[(j + 4) & 7]);
+    A2 = __builtin_elementwise_max(A2, lo9);
+    B2 = __builtin_elementwise_min(B2, hi9);
+  }
+  const int A = max((int)A2.x, (int)A2.y), Bn = min((int)B2.x, (int)B2.y);
   return max(A, -Bn);
 }
 
@@ -250,7 +278,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
 __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                     const CellDesc* __restrict__ cells, PipelineDesc PD,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
-                                                    int max_rw, int max_rh) {
+                                                    int max_rw, int max_rh, int batch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
   const int kTilePitch = lay.tile_pitch;
@@ -261,14 +289,15 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   __shared__ int s_cnt_ini;
   __shared__ int s_wave_tot[33][4];
 
-  const int f = blockIdx.y;
-  const CellDesc c = cells[blockIdx.x];
+  int cell_id, f;
+  if (!xcd_frame_map(PD.ncells, batch, cell_id, f)) return;
+  const CellDesc c = cells[cell_id];
   const LevelDesc& L = PD.lv[c.level];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rw = c.rw, rh = c.rh;
   const int ew = rw - 6, eh = rh - 6;  // evaluated area (FAST skips a 3-px frame of the ROI)
   const int sp = (ew + 2 + 3) & ~3;    // score pitch (1-px zero ring), multiple of 4
-  int32_t* my_count = cell_count + (int64_t)f * PD.ncells + blockIdx.x;
+  int32_t* my_count = cell_count + (int64_t)f * PD.ncells + cell_id;
   if (ew <= 0 || eh <= 0) {
     if (tid == 0) *my_count = 0;
     return;
@@ -296,44 +325,72 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
 
   const int tlow = min(PD.ini_th, PD.min_th);
   const int npx = ew * eh;
-  const int roundsA = (npx + 255) >> 8;   // <= 32
   const uint8_t* T = tile + sh;
-  // ---- A. compass pre-test over all pixels; (ey, ex) advance incrementally by 256 pixels
-  uint32_t passbits = 0;
+  // ---- A. compass pre-test, 4 pixels per thread: one item = one LDS dword column c of one row, so the
+  // north / south / centre / west / east bytes of its 4 pixels come from 5 dword reads + 2 v_alignbyte.
+  // Items are walked row-major, survivors keep that order (ballot prefix per byte lane).
+  const int pitch4 = kTilePitch >> 2;
+  const int c0 = (sh + 3) >> 2, c1 = (sh + 3 + ew - 1) >> 2, ncol = c1 - c0 + 1;
+  const int nitems = eh * ncol;
+  const int roundsA = (nitems + 255) >> 8;   // <= 32 for the supported cell sizes
+  uint32_t passbits_lo = 0, passbits_hi = 0, passbits_x = 0, passbits_y = 0;  // 4 bits per round, 8 rounds per word
   {
-    int ey = tid / ew, ex = tid - ey * ew;
-    const int dy = 256 / ew, dx = 256 - dy * ew;
+    int ey = tid / ncol, cc = tid - ey * ncol;
+    const int dy = 256 / ncol, dc = 256 - dy * ncol;
     for (int r = 0; r < roundsA; r++) {
-      bool pass = false;
+      uint32_t pm = 0;
       if (ey < eh) {
-        const uint8_t* t = &T[(ey + 3) * kTilePitch + ex + 3];
-        const int v = t[0];
-        const int dn = v - t[3 * kTilePitch], de = v - t[3], ds = v - t[-3 * kTilePitch], dw = v - t[-3];
-        const bool kn = dn > tlow, ke = de > tlow, ks = ds > tlow, kw = dw > tlow;       // darker
-        const bool bn = dn < -tlow, be = de < -tlow, bs = ds < -tlow, bw = dw < -tlow;   // brighter
-        pass = (kn & ke) | (ke & ks) | (ks & kw) | (kw & kn) | (bn & be) | (be & bs) | (bs & bw) | (bw & bn);
+        const int c = c0 + cc;
+        const uint32_t* row = t32 + (ey + 3) * pitch4 + c;
+        const uint32_t Cd = row[0], Wd = row[-1], Ed = row[1], Nd = row[3 * pitch4], Sd = row[-3 * pitch4];
+        const uint32_t WB = __builtin_amdgcn_alignbyte(Cd, Wd, 1);  // pixel k's west neighbour (x-3) in byte k
+        const uint32_t EB = __builtin_amdgcn_alignbyte(Ed, Cd, 3);  // east neighbour (x+3)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int ex = 4 * c + k - sh - 3;
+          const int v = (Cd >> (8 * k)) & 255;
+          const int dn = v - (int)((Nd >> (8 * k)) & 255), ds = v - (int)((Sd >> (8 * k)) & 255);
+          const int de = v - (int)((EB >> (8 * k)) & 255), dw = v - (int)((WB >> (8 * k)) & 255);
+          const bool kn = dn > tlow, ke = de > tlow, ks = ds > tlow, kw = dw > tlow;       // darker
+          const bool bn = dn < -tlow, be = de < -tlow, bs = ds < -tlow, bw = dw < -tlow;   // brighter
+          const bool pass = ((kn & ke) | (ke & ks) | (ks & kw) | (kw & kn) | (bn & be) | (be & bs) | (bs & bw) | (bw & bn)) &&
+                            ex >= 0 && ex < ew;
+          pm |= (pass ? 1u : 0u) << k;
+        }
       }
-      const unsigned long long mk = __ballot(pass);
-      if (lane == 0) s_wave_tot[r][wave] = __popcll(mk);
-      passbits |= (pass ? 1u : 0u) << r;
-      ex += dx; ey += dy;
-      if (ex >= ew) { ex -= ew; ey++; }
+      int tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) tot += __popcll(__ballot((pm >> k) & 1u));
+      if (lane == 0) s_wave_tot[r][wave] = tot;
+      const uint32_t sh4 = (uint32_t)(r & 7) * 4;
+      if (r < 8) passbits_lo |= pm << sh4; else if (r < 16) passbits_hi |= pm << sh4;
+      else if (r < 24) passbits_x |= pm << sh4; else passbits_y |= pm << sh4;
+      cc += dc; ey += dy;
+      if (cc >= ncol) { cc -= ncol; ey++; }
     }
   }
   __syncthreads();
   int npass = 0;
   {
-    int ey = tid / ew, ex = tid - ey * ew;
-    const int dy = 256 / ew, dx = 256 - dy * ew;
+    int ey = tid / ncol, cc = tid - ey * ncol;
+    const int dy = 256 / ncol, dc = 256 - dy * ncol;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for (int r = 0; r < roundsA; r++) {
-      const bool pass = (passbits >> r) & 1u;
-      const unsigned long long mk = __ballot(pass);
+      const uint32_t word = r < 8 ? passbits_lo : (r < 16 ? passbits_hi : (r < 24 ? passbits_x : passbits_y));
+      const uint32_t pm = (word >> ((r & 7) * 4)) & 15u;
       int before = 0;
       for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
-      if (pass) plist[npass + before + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)((ey << 7) | ex);
+      unsigned long long bm[4];
+      int mine = 0;  // survivors of earlier lanes of this wave
+#pragma unroll
+      for (int k = 0; k < 4; k++) { bm[k] = __ballot((pm >> k) & 1u); mine += __popcll(bm[k] & lt); }
+      int pos = npass + before + mine;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if ((pm >> k) & 1u) plist[pos++] = (uint16_t)((ey << 7) | (4 * (c0 + cc) + k - sh - 3));
       npass += s_wave_tot[r][0] + s_wave_tot[r][1] + s_wave_tot[r][2] + s_wave_tot[r][3];
-      ex += dx; ey += dy;
-      if (ex >= ew) { ex -= ew; ey++; }
+      cc += dc; ey += dy;
+      if (cc >= ncol) { cc -= ncol; ey++; }
     }
   }
   __syncthreads();
@@ -534,11 +591,13 @@ constexpr int kHpPitch = 68;    // u16 elements (136 B): de-phases the 64-bit co
 __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                const TileDesc* __restrict__ tiles, PipelineDesc PD,
-                                               const int32_t* __restrict__ nsel) {
+                                               const int32_t* __restrict__ nsel, int batch) {
   __shared__ __attribute__((aligned(16))) uint8_t raw[(kBlurTH + 6) * kRawPitch];
   __shared__ __attribute__((aligned(16))) uint16_t hp[(kBlurTH + 6) * kHpPitch];
-  const int f = blockIdx.y, tid = threadIdx.x;
-  const TileDesc t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  int tile_id, f;
+  if (!xcd_frame_map(PD.ntiles, batch, tile_id, f)) return;
+  const TileDesc t = tiles[tile_id];
   if (nsel[f * PD.nlevels + t.level] == 0) return;  // reference skips levels without keypoints (:915-916)
   const LevelDesc& L = PD.lv[t.level];
   const int th = min(kBlurTH, L.h - t.y0);
@@ -652,10 +711,11 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
                                                      const uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                      PipelineDesc PD, const KpAux* __restrict__ aux,
                                                      const int32_t* __restrict__ n_kp, dvm_keypoint_pod* __restrict__ kps,
-                                                     uint8_t* __restrict__ desc) {
-  const int f = blockIdx.y;
+                                                     uint8_t* __restrict__ desc, int batch) {
+  int blk, f;
+  if (!xcd_frame_map((PD.kp_cap + 3) / 4, batch, blk, f)) return;
   const int lane = threadIdx.x & 63;
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int g = blk * 4 + (threadIdx.x >> 6);
   if (g >= n_kp[f]) return;
   const KpAux a = aux[(int64_t)f * PD.kp_cap + g];
   const LevelDesc& L = PD.lv[a.level];
@@ -734,8 +794,8 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
                         fast_lds_layout(kMaxCellDim, kMaxCellDim).total());
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_fast_cells, dim3(PD.ncells, batch), dim3(256), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells,
-                     PD, d_cand, d_cell_count, max_rw, max_rh);
+  hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(PD.ncells, batch)), dim3(256), lay.total(), s, d_pyr, PD.pyr_frame_bytes,
+                     d_cells, PD, d_cand, d_cell_count, max_rw, max_rh, batch);
 }
 void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
                     const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch) {
@@ -748,13 +808,13 @@ void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel
 }
 void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
                  const int32_t* d_nsel, int batch) {
-  hipLaunchKernelGGL(k_blur7, dim3(PD.ntiles, batch), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_blur,
-                     PD.blur_frame_bytes, d_tiles, PD, d_nsel);
+  hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(PD.ntiles, batch)), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_blur,
+                     PD.blur_frame_bytes, d_tiles, PD, d_nsel, batch);
 }
 void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
                         const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch) {
-  hipLaunchKernelGGL(k_orient_desc, dim3(cdiv(PD.kp_cap, 4), batch), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_blur,
-                     PD.blur_frame_bytes, PD, d_aux, d_n, d_kps, d_desc);
+  hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(cdiv(PD.kp_cap, 4), batch)), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes,
+                     d_blur, PD.blur_frame_bytes, PD, d_aux, d_n, d_kps, d_desc, batch);
 }
 
 }  // namespace dvm
