@@ -51,6 +51,15 @@ class BaStats(C.Structure):
                 ("lambda_per_iter", C.c_double * 64), ("ms_structure", C.c_double), ("ms_optimize", C.c_double)]
 
 
+class FrustumFrame(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("bf", C.c_float), ("log_scale_factor", C.c_float), ("n_levels", C.c_int32)]
+
+
+TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"),
+                        ("level", "<i4"), ("in_view", "<i4")])
+
 _LIB = None
 
 
@@ -105,6 +114,7 @@ def lib():
     L.dvm_frame_build.argtypes = [vp, i32, vp, vp, i32, vp, f32, f32, f32, f32, i32, vp]
     L.dvm_frame_build_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, f32, f32, f32, f32, vp]
     L.dvm_match_window.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
+    L.dvm_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), vp, vp, vp, vp, i32, f32, vp, i32, vp]
     L.dvm_match_lists.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp]
     L.dvm_match_frames_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, f32, vp, i32, vp, i64,
                                          vp, vp]
@@ -401,3 +411,13 @@ def pose_optimize(poses, Xw, obs, inv_sigma2, n, intrinsics, device=0):
     check(lib().dvm_pose_optimize(device, _p(poses), _p(Xw), _p(obs), _p(inv_sigma2), _p(n), S, B, C.byref(cam), _p(out),
                                   _p(outl), _p(nin)))
     return out, outl, nin
+
+
+def is_in_frustum(F: "FrustumFrame", P, normal, min_dist, max_dist, viewing_cos_limit=0.5):
+    """Frame::isInFrustum for an array of map points; returns a TRACK_DTYPE array."""
+    P = np.ascontiguousarray(P, np.float32); normal = np.ascontiguousarray(normal, np.float32)
+    min_dist = np.ascontiguousarray(min_dist, np.float32); max_dist = np.ascontiguousarray(max_dist, np.float32)
+    out = np.zeros(len(P), TRACK_DTYPE)
+    check(lib().dvm_is_in_frustum(C.byref(F), _p(P), _p(normal), _p(min_dist), _p(max_dist), len(P), float(viewing_cos_limit),
+                                  _p(out), 0, None))
+    return out

@@ -408,6 +408,34 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
   return rc;
 }
 
+int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const float* normal, const float* min_dist,
+                      const float* max_dist, int n, float viewing_cos_limit, dvm_track_point* out, int on_device, void* stream) {
+  static_assert(sizeof(dvm_frustum_frame) == sizeof(FrustumFrame) && sizeof(dvm_track_point) == sizeof(TrackPoint), "layout");
+  if (!frame || n < 0) return DVM_ERR_INVALID;
+  if (n == 0) return DVM_OK;
+  if (!P || !normal || !min_dist || !max_dist || !out) return DVM_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  FrustumFrame F;
+  std::memcpy(&F, frame, sizeof(F));
+  if (on_device) {
+    launch_is_in_frustum((hipStream_t)stream, F, P, normal, min_dist, max_dist, n, viewing_cos_limit, reinterpret_cast<TrackPoint*>(out));
+    return hip_check(hipGetLastError(), "is_in_frustum launch");
+  }
+  const size_t N = (size_t)n, total = N * (3 + 3 + 1 + 1) * 4 + N * sizeof(TrackPoint);
+  uint8_t* d = nullptr;
+  int rc = hip_check(hipMalloc(&d, total), "hipMalloc");
+  if (rc != DVM_OK) return rc;
+  float* dP = reinterpret_cast<float*>(d); float* dN = dP + 3 * N; float* dmin = dN + 3 * N; float* dmax = dmin + N;
+  TrackPoint* dout = reinterpret_cast<TrackPoint*>(dmax + N);
+  auto up = [&](void* dst, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "memcpy"); };
+  up(dP, P, N * 12); up(dN, normal, N * 12); up(dmin, min_dist, N * 4); up(dmax, max_dist, N * 4);
+  if (rc == DVM_OK) { launch_is_in_frustum(nullptr, F, dP, dN, dmin, dmax, n, viewing_cos_limit, dout); rc = hip_check(hipGetLastError(), "launch"); }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, dout, N * sizeof(TrackPoint), hipMemcpyDeviceToHost), "memcpy");
+  hipFree(d);
+  return rc;
+}
+
 int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, const int32_t* off, const int32_t* cand,
                     dvm_match* out, int on_device, void* stream) {
   if (nq < 0 || nt < 0) return DVM_ERR_INVALID;

@@ -50,6 +50,16 @@ struct PairQueries {
   int32_t cap;
 };
 
+struct FrustumFrame {  // == dvm_frustum_frame
+  float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, bf, log_scale_factor;
+  int32_t n_levels;
+};
+struct TrackPoint {  // == dvm_track_point
+  float proj_x, proj_y, proj_xr, depth, view_cos;
+  int32_t level, in_view;
+};
+void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
+                          const float* max_dist, int n, float cos_limit, TrackPoint* out);
 void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_stride, const uint8_t* desc,
                         int64_t desc_stride, int n, const int32_t* d_n, const FrameView& F, int first_slot, int count);
 void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc,

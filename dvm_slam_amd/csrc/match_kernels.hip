@@ -241,6 +241,42 @@ __global__ void __launch_bounds__(256) k_match_lists(const uint8_t* __restrict__
   }
 }
 
+// Frame::isInFrustum, mono branch (reference src/Frame.cc:575-636) + MapPoint::PredictScale
+// (src/MapPoint.cc:573-587): thread per map point, float arithmetic in the reference's order.
+__global__ void __launch_bounds__(256) k_is_in_frustum(FrustumFrame F, const float* __restrict__ P, const float* __restrict__ normal,
+                                                       const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                                       int n, float cos_limit, TrackPoint* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  TrackPoint o;
+  o.in_view = 0; o.proj_x = -1; o.proj_y = -1; o.proj_xr = 0; o.depth = 0; o.level = -1; o.view_cos = 0;
+  const float p0 = P[3 * i], p1 = P[3 * i + 1], p2 = P[3 * i + 2];
+  const float X = (F.Rcw[0] * p0 + F.Rcw[1] * p1 + F.Rcw[2] * p2) + F.tcw[0];
+  const float Y = (F.Rcw[3] * p0 + F.Rcw[4] * p1 + F.Rcw[5] * p2) + F.tcw[1];
+  const float Z = (F.Rcw[6] * p0 + F.Rcw[7] * p1 + F.Rcw[8] * p2) + F.tcw[2];
+  const float Pc_dist = sqrtf(X * X + Y * Y + Z * Z);
+  const float invz = 1.0f / Z;
+  bool ok = !(Z < 0.0f);
+  const float u = F.fx * X / Z + F.cx, v = F.fy * Y / Z + F.cy;
+  ok = ok && !(u < F.min_x || u > F.max_x) && !(v < F.min_y || v > F.max_y);
+  if (ok) {
+    o.proj_x = u; o.proj_y = v;
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    const float q0 = p0 - F.Ow[0], q1 = p1 - F.Ow[1], q2 = p2 - F.Ow[2];
+    const float dist = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    if (!(dist < minDistance || dist > maxDistance)) {
+      const float viewCos = (q0 * normal[3 * i] + q1 * normal[3 * i + 1] + q2 * normal[3 * i + 2]) / dist;
+      if (!(viewCos < cos_limit)) {
+        const float ratio = max_dist[i] / dist;
+        int nScale = (int)ceilf(logf(ratio) / F.log_scale_factor);
+        nScale = nScale < 0 ? 0 : (nScale >= F.n_levels ? F.n_levels - 1 : nScale);
+        o.in_view = 1; o.proj_xr = u - F.bf * invz; o.depth = Pc_dist; o.level = nScale; o.view_cos = viewCos;
+      }
+    }
+  }
+  out[i] = o;
+}
+
 // D[i][j] = Hamming(A[i], B[j]); one thread per pair, 64 columns x 4 rows per workgroup.
 __global__ void __launch_bounds__(256) k_hamming_matrix(const uint8_t* __restrict__ A, int nA,
                                                         const uint8_t* __restrict__ B, int nB, uint16_t* __restrict__ D) {
@@ -270,6 +306,10 @@ void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int 
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {
   hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 3) / 4, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride);
+}
+void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
+                          const float* max_dist, int n, float cos_limit, TrackPoint* out) {
+  hipLaunchKernelGGL(k_is_in_frustum, dim3((n + 255) / 256), dim3(256), 0, s, F, P, normal, min_dist, max_dist, n, cos_limit, out);
 }
 void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,
                         int nq, dvm_match_pod* out) {

@@ -156,6 +156,15 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
                      const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
                      const int32_t* d_nq, dvm_match* out, int on_device, void* stream);
 
+/* Frame::isInFrustum (Frame.cc:575-636, mono branch) for n map points at once: projection with the frame's
+ * Rcw/tcw (float), image bounds, distance inside [0.8*mfMinDistance, 1.2*mfMaxDistance], viewing cosine,
+ * MapPoint::PredictScale.  Outputs the mbTrackInView / mTrackProj* / mnTrackScaleLevel / mTrackViewCos fields the
+ * reference stores on the MapPoint.  Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
+typedef struct { float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, bf, log_scale_factor; int32_t n_levels; } dvm_frustum_frame;
+typedef struct { float proj_x, proj_y, proj_xr, depth, view_cos; int32_t level; int32_t in_view; } dvm_track_point;
+int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const float* normal, const float* min_dist,
+                      const float* max_dist, int n, float viewing_cos_limit, dvm_track_point* out, int on_device, void* stream);
+
 /* Best / second best over an explicit candidate list per query -- the inner loop of the
  * vocabulary-node restricted searches (SearchByBoW ORBmatcher.cc:262-300,760-800; SearchForTriangulation
  * :905-960; SearchBySim3; Fuse): query q scans train descriptors cand[off[q] .. off[q+1]) in that order

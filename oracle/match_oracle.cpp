@@ -131,4 +131,36 @@ void orc_match_window(const orc_grid* g, const uint8_t* tdesc, const uint8_t* sk
   }
 }
 
+// Frame::isInFrustum (mono branch, Frame.cc:575-636) + MapPoint::PredictScale (MapPoint.cc:573-587) +
+// Get{Min,Max}DistanceInvariance (0.8f*min, 1.2f*max, MapPoint.cc:545-553).  All float, like the reference.
+void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* normal, const float* min_dist,
+                       const float* max_dist, int n, float viewing_cos_limit, orc_track_point* out) {
+  for (int i = 0; i < n; i++) {
+    orc_track_point& o = out[i];
+    o.in_view = 0; o.proj_x = -1; o.proj_y = -1; o.proj_xr = 0; o.depth = 0; o.level = -1; o.view_cos = 0;
+    const float* p = P + 3 * i;
+    float Pc[3];
+    for (int r = 0; r < 3; r++) Pc[r] = (F->Rcw[3 * r] * p[0] + F->Rcw[3 * r + 1] * p[1] + F->Rcw[3 * r + 2] * p[2]) + F->tcw[r];
+    const float Pc_dist = std::sqrt(Pc[0] * Pc[0] + Pc[1] * Pc[1] + Pc[2] * Pc[2]);
+    const float PcZ = Pc[2];
+    const float invz = 1.0f / PcZ;
+    if (PcZ < 0.0f) continue;
+    const float u = F->fx * Pc[0] / Pc[2] + F->cx, v = F->fy * Pc[1] / Pc[2] + F->cy;
+    if (u < F->min_x || u > F->max_x) continue;
+    if (v < F->min_y || v > F->max_y) continue;
+    o.proj_x = u; o.proj_y = v;
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    const float PO[3] = {p[0] - F->Ow[0], p[1] - F->Ow[1], p[2] - F->Ow[2]};
+    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+    if (viewCos < viewing_cos_limit) continue;
+    const float ratio = max_dist[i] / dist;
+    int nScale = (int)std::ceil(std::log(ratio) / F->log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= F->n_levels) nScale = F->n_levels - 1;
+    o.in_view = 1; o.proj_xr = u - F->bf * invz; o.depth = Pc_dist; o.level = nScale; o.view_cos = viewCos;
+  }
+}
+
 }  // extern "C"

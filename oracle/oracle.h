@@ -96,6 +96,12 @@ void orc_match_window(const orc_grid* g, const uint8_t* tdesc, const uint8_t* sk
                       const int32_t* qmax, int nq, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
                       int32_t* best_level, int32_t* second_level);
 
+/* Frame::isInFrustum (Frame.cc:575-636), mono */
+typedef struct { float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, bf, log_scale_factor; int32_t n_levels; } orc_frustum_frame;
+typedef struct { float proj_x, proj_y, proj_xr, depth, view_cos; int32_t level; int32_t in_view; } orc_track_point;
+void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* normal, const float* min_dist,
+                       const float* max_dist, int n, float viewing_cos_limit, orc_track_point* out);
+
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;

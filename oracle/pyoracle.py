@@ -310,3 +310,36 @@ def pose_optimize(pose, Xw, obs, inv_sigma2, intrinsics):
     out = np.zeros(len(Xw), np.uint8)
     n = L.orc_pose_optimize(_p(pose), _p(Xw), _p(obs), _p(inv_sigma2), len(Xw), C.byref(cam), _p(out))
     return pose, out, n
+
+
+# ------------------------------------------------------------------------------------- frustum
+class FrustumFrame(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("bf", C.c_float), ("log_scale_factor", C.c_float), ("n_levels", C.c_int32)]
+
+
+TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"),
+                        ("level", "<i4"), ("in_view", "<i4")])
+
+
+def make_frustum_frame(Rcw, tcw, K, bounds=(0.0, 640.0, 0.0, 480.0), bf=0.0, scale_factor=1.2, n_levels=8, cls=FrustumFrame):
+    Rcw = np.asarray(Rcw, np.float32).reshape(3, 3)
+    tcw = np.asarray(tcw, np.float32)
+    Ow = (-(Rcw.T @ tcw)).astype(np.float32)
+    F = cls()
+    F.Rcw[:] = list(Rcw.reshape(-1)); F.tcw[:] = list(tcw); F.Ow[:] = list(Ow)
+    F.fx, F.fy, F.cx, F.cy = [float(np.float32(v)) for v in K]
+    F.min_x, F.max_x, F.min_y, F.max_y = [float(v) for v in bounds]
+    F.bf = float(bf); F.log_scale_factor = float(np.float32(np.log(np.float32(scale_factor)))); F.n_levels = n_levels
+    return F
+
+
+def is_in_frustum(F, P, normal, min_dist, max_dist, viewing_cos_limit=0.5):
+    L = lib()
+    L.orc_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+    P = np.ascontiguousarray(P, np.float32); normal = np.ascontiguousarray(normal, np.float32)
+    min_dist = np.ascontiguousarray(min_dist, np.float32); max_dist = np.ascontiguousarray(max_dist, np.float32)
+    out = np.zeros(len(P), TRACK_DTYPE)
+    L.orc_is_in_frustum(C.byref(F), _p(P), _p(normal), _p(min_dist), _p(max_dist), len(P), float(viewing_cos_limit), _p(out))
+    return out

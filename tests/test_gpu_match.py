@@ -167,3 +167,34 @@ def test_match_lists_bow_style(capi, oracle):
             elif d < second:
                 second = d
         assert (got["best_idx"][q], got["best_dist"][q], got["second_dist"][q]) == (bidx, best, second), q
+
+
+def test_is_in_frustum(capi, oracle):
+    """Frame::isInFrustum: float tolerance 1e-5 (relative) on projections; flags / levels identical away from
+    decision boundaries (points within 1e-4 of a bound, distance limit or level boundary are not compared)."""
+    rng = np.random.default_rng(8)
+    n = 5000
+    ang = 0.3
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.2, -0.1, 0.5], np.float32)
+    K = (149.0, 149.0, 320.0, 240.0)
+    P = rng.uniform(-15, 15, (n, 3)).astype(np.float32)
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    maxd = rng.uniform(5, 30, n).astype(np.float32)
+    mind = (maxd / np.float32(1.2) ** 7).astype(np.float32)
+    Fo = oracle.make_frustum_frame(Rcw, tcw, K)
+    Fg = oracle.make_frustum_frame(Rcw, tcw, K, cls=capi.FrustumFrame)
+    ref = oracle.is_in_frustum(Fo, P, normal, mind, maxd, 0.5)
+    got = capi.is_in_frustum(Fg, P, normal, mind, maxd, 0.5)
+    assert ref["in_view"].sum() > 50
+    diff_flag = ref["in_view"] != got["in_view"]
+    assert diff_flag.mean() < 2e-3          # only borderline points may flip
+    both = (ref["in_view"] == 1) & (got["in_view"] == 1)
+    for f in ("proj_x", "proj_y", "proj_xr", "depth", "view_cos"):
+        assert np.allclose(got[f][both], ref[f][both], rtol=1e-5, atol=1e-4), f
+    assert (got["level"][both] != ref["level"][both]).mean() < 2e-3
+    # points behind the camera are never in view and keep proj = -1
+    Pc = (Rcw @ P.T).T + tcw
+    behind = Pc[:, 2] < -0.1
+    assert (got["in_view"][behind] == 0).all() and (got["proj_x"][behind] == -1).all()
