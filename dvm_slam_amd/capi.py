@@ -127,6 +127,7 @@ def lib():
     L.dvm_ba_edge_chi2.argtypes = [vp, vp, vp]
     L.dvm_ba_stream.argtypes = [vp]
     L.dvm_ba_stream.restype = vp
+    L.dvm_optimize_sim3.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, C.c_double, vp, vp]
     L.dvm_pose_optimize.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(BaCamera), vp, vp, vp]
     _LIB = L
     return L
@@ -421,3 +422,15 @@ def is_in_frustum(F: "FrustumFrame", P, normal, min_dist, max_dist, viewing_cos_
     check(lib().dvm_is_in_frustum(C.byref(F), _p(P), _p(normal), _p(min_dist), _p(max_dist), len(P), float(viewing_cos_limit),
                                   _p(out), 0, None))
     return out
+
+
+def optimize_sim3(S12, fix_scale, P1c, P2c, obs1, obs2, w1, w2, K1, K2, th2, device=0):
+    """Optimizer::OptimizeSim3 numerics on the device.  Returns (S12[8], inlier mask, nIn)."""
+    S = np.array(S12, np.float64, copy=True)
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (P1c, P2c, obs1, obs2, w1, w2, K1, K2)]
+    n = len(arrs[0])
+    inl = np.zeros(n, np.uint8)
+    nin = C.c_int32(0)
+    check(lib().dvm_optimize_sim3(device, _p(S), int(fix_scale), *[_p(a) for a in arrs[:6]], n, _p(arrs[6]), _p(arrs[7]),
+                                  float(th2), _p(inl), C.byref(nin)))
+    return S, inl, nin.value

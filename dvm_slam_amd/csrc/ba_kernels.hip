@@ -923,6 +923,319 @@ void ba_launch_pose_optimize(hipStream_t s, const double* pose_in, const double*
                      pose_out, outlier, n_inliers, chi_scratch);
 }
 
+// ---------------------------------------------------------------------------------------- B9
+// Optimizer::OptimizeSim3 (reference src/Optimizer.cc:1960-2212): one 7-DoF g2o::Sim3 vertex, two
+// reprojection edges per correspondence (EdgeSim3ProjectXYZ, EdgeInverseSim3ProjectXYZ) whose Jacobians
+// g2o takes NUMERICALLY (central differences, delta 1e-9, base_binary_edge.hpp:131-205) because the
+// analytic linearizeOplus is commented out (include/OptimizableTypes.h:186,205); dense 7x7 Levenberg,
+// optimize(5), inlier test chi2 <= th2, robust kernel off, optimize(5 or 10), final inlier count.
+// One workgroup runs everything; the 14 perturbed Sim3 states (and inverses) are shared by all edges.
+struct Sim3d { double q[4]; double t[3]; double s; };
+__device__ void sim3_exp(const double* u, Sim3d& S) {  // g2o::Sim3(const Vector7d&), sim3.h:62-125
+  const double om0 = u[0], om1 = u[1], om2 = u[2], sigma = u[6];
+  const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+  const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+  double O2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+  S.s = exp(sigma);
+  const double eps = 0.00001;
+  double A, B, C, R[9];
+  if (fabs(sigma) < eps) {
+    C = 1;
+    if (theta < eps) { A = 0.5; B = 1. / 6.; for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + O[i] + O2[i]; }
+    else {
+      const double th2 = theta * theta;
+      A = (1 - cos(theta)) / th2; B = (theta - sin(theta)) / (th2 * theta);
+      for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + sin(theta) / theta * O[i] + (1 - cos(theta)) / (theta * theta) * O2[i];
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (theta < eps) {
+      const double s2 = sigma * sigma;
+      A = ((sigma - 1) * S.s + 1) / s2; B = ((0.5 * s2 - sigma + 1) * S.s) / (s2 * sigma);
+      for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + O[i] + O2[i];
+    } else {
+      for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + sin(theta) / theta * O[i] + (1 - cos(theta)) / (theta * theta) * O2[i];
+      const double a = S.s * sin(theta), b = S.s * cos(theta), th2 = theta * theta, s2 = sigma * sigma, c = th2 + s2;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / th2;
+    }
+  }
+  R_to_quat(R, S.q);
+  double W[9];
+  for (int i = 0; i < 9; i++) W[i] = A * O[i] + B * O2[i] + C * ((i % 4 == 0) ? 1.0 : 0.0);
+  mat3_vec(W, u + 3, S.t);
+}
+__device__ void sim3_mul(const Sim3d& a, const Sim3d& b, Sim3d& o) {
+  const double* p = a.q; const double* q = b.q;
+  o.q[3] = p[3] * q[3] - p[0] * q[0] - p[1] * q[1] - p[2] * q[2];
+  o.q[0] = p[3] * q[0] + p[0] * q[3] + p[1] * q[2] - p[2] * q[1];
+  o.q[1] = p[3] * q[1] + p[1] * q[3] + p[2] * q[0] - p[0] * q[2];
+  o.q[2] = p[3] * q[2] + p[2] * q[3] + p[0] * q[1] - p[1] * q[0];
+  double R[9], rt[3];
+  quat_to_R(a.q, R);
+  mat3_vec(R, b.t, rt);
+  for (int i = 0; i < 3; i++) o.t[i] = a.s * rt[i] + a.t[i];
+  o.s = a.s * b.s;
+}
+__device__ void sim3_inv(const Sim3d& a, Sim3d& o) {
+  o.q[0] = -a.q[0]; o.q[1] = -a.q[1]; o.q[2] = -a.q[2]; o.q[3] = a.q[3];
+  double R[9];
+  const double v[3] = {(-1. / a.s) * a.t[0], (-1. / a.s) * a.t[1], (-1. / a.s) * a.t[2]};
+  quat_to_R(o.q, R);
+  mat3_vec(R, v, o.t);
+  o.s = 1. / a.s;
+}
+struct Sim3M { double R[9]; double t[3]; double s; };  // map-ready form: x -> s R x + t
+__device__ __forceinline__ void sim3_to_map(const Sim3d& a, Sim3M& m) {
+  quat_to_R(a.q, m.R);
+  m.t[0] = a.t[0]; m.t[1] = a.t[1]; m.t[2] = a.t[2]; m.s = a.s;
+}
+__device__ __forceinline__ void sim3_proj(const Sim3M& m, const double* x, const double* K, double& u, double& v) {
+  double rx[3];
+  mat3_vec(m.R, x, rx);
+  const double X = m.s * rx[0] + m.t[0], Y = m.s * rx[1] + m.t[1], Z = m.s * rx[2] + m.t[2];
+  u = K[0] * X / Z + K[2];
+  v = K[1] * Y / Z + K[3];
+}
+
+__global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12io, int fix_scale, const double* __restrict__ P1c,
+                                                       const double* __restrict__ P2c, const double* __restrict__ obs1,
+                                                       const double* __restrict__ obs2, const double* __restrict__ w1,
+                                                       const double* __restrict__ w2, int N, const double* __restrict__ Kio,
+                                                       double th2, uint8_t* __restrict__ inlier, int32_t* __restrict__ nin_out,
+                                                       double* __restrict__ chi_scratch, uint8_t* __restrict__ flag_scratch) {
+  __shared__ double s_red[4][36];
+  __shared__ double s_sum[36];
+  __shared__ Sim3d s_S, s_bak;
+  __shared__ Sim3M s_M[30];   // [0] S, [1] S^-1, [2+2d] S+d, [3+2d] (S+d)^-1, [16+2d] S-d, [17+2d] (S-d)^-1
+  __shared__ double s_K[8];
+  __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
+  __shared__ int s_ctl, s_qmax, s_nbad, s_cnt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* chi12 = chi_scratch;
+  double* chi21 = chi_scratch + N;
+  uint8_t* alive = flag_scratch;
+  uint8_t* robust = flag_scratch + N;
+  if (tid < 8) s_K[tid] = Kio[tid];
+  if (tid == 0) {
+    for (int i = 0; i < 4; i++) s_S.q[i] = S12io[i];
+    for (int i = 0; i < 3; i++) s_S.t[i] = S12io[4 + i];
+    s_S.s = S12io[7];
+  }
+  for (int i = tid; i < N; i += 256) { alive[i] = 1; robust[i] = 1; inlier[i] = 0; chi12[i] = 0; chi21[i] = 0; }
+  __syncthreads();
+  const double deltaHuber = (double)sqrtf((float)th2);
+
+  // refreshes s_M[0..1] (jac=false) or all 30 maps (jac=true) from s_S
+  auto prepare = [&](bool jac) {
+    if (tid == 0) { sim3_to_map(s_S, s_M[0]); Sim3d Si; sim3_inv(s_S, Si); sim3_to_map(Si, s_M[1]); }
+    if (jac && tid >= 64 && tid < 78) {
+      const int k = tid - 64, d = k >> 1, sgn = k & 1;
+      double u[7] = {0, 0, 0, 0, 0, 0, 0};
+      u[d] = sgn ? -1e-9 : 1e-9;
+      if (fix_scale) u[6] = 0;
+      Sim3d E, Sx, Sxi;
+      sim3_exp(u, E);
+      sim3_mul(E, s_S, Sx);
+      sim3_inv(Sx, Sxi);
+      sim3_to_map(Sx, s_M[(sgn ? 16 : 2) + 2 * d]);
+      sim3_to_map(Sxi, s_M[(sgn ? 17 : 3) + 2 * d]);
+    }
+    __syncthreads();
+  };
+  auto eval = [&](bool jac) {
+    prepare(jac);
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+    for (int i = tid; i < N; i += 256) {
+      if (!alive[i]) continue;
+      const double* x1 = P1c + 3 * i; const double* x2 = P2c + 3 * i;
+      double u, v;
+      sim3_proj(s_M[0], x2, s_K, u, v);
+      const double a0 = obs1[2 * i] - u, a1 = obs1[2 * i + 1] - v;
+      sim3_proj(s_M[1], x1, s_K + 4, u, v);
+      const double b0 = obs2[2 * i] - u, b1 = obs2[2 * i + 1] - v;
+      const double c12 = w1[i] * (a0 * a0 + a1 * a1), c21 = w2[i] * (b0 * b0 + b1 * b1);
+      chi12[i] = c12; chi21[i] = c21;
+      const double dl = robust[i] ? deltaHuber : 0.0;
+      double r0a, r1a, r0b, r1b;
+      robustify(c12, dl, r0a, r1a);
+      robustify(c21, dl, r0b, r1b);
+      acc[35] += r0a;
+      acc[35] += r0b;
+      if (jac) {
+        double J12[14], J21[14];
+#pragma unroll
+        for (int d = 0; d < 7; d++) {
+          double up, vp, um, vm;
+          sim3_proj(s_M[2 + 2 * d], x2, s_K, up, vp); sim3_proj(s_M[16 + 2 * d], x2, s_K, um, vm);
+          // e(+d) - e(-d) = (obs - proj+) - (obs - proj-)
+          J12[d] = 5e8 * ((obs1[2 * i] - up) - (obs1[2 * i] - um)); J12[7 + d] = 5e8 * ((obs1[2 * i + 1] - vp) - (obs1[2 * i + 1] - vm));
+          sim3_proj(s_M[3 + 2 * d], x1, s_K + 4, up, vp); sim3_proj(s_M[17 + 2 * d], x1, s_K + 4, um, vm);
+          J21[d] = 5e8 * ((obs2[2 * i] - up) - (obs2[2 * i] - um)); J21[7 + d] = 5e8 * ((obs2[2 * i + 1] - vp) - (obs2[2 * i + 1] - vm));
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+          const double* J = pass ? J21 : J12;
+          const double e0 = pass ? b0 : a0, e1 = pass ? b1 : a1, w0 = pass ? w2[i] : w1[i], r1 = pass ? r1b : r1a;
+          const double w = r1 * w0, wr0 = -w0 * e0 * r1, wr1 = -w0 * e1 * r1;
+          int t = 0;
+#pragma unroll
+          for (int p = 0; p < 7; p++) {
+            acc[28 + p] += J[p] * wr0 + J[7 + p] * wr1;
+#pragma unroll
+            for (int q = 0; q <= p; q++) acc[t++] += w * (J[p] * J[q] + J[7 + p] * J[7 + q]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], off);
+    if (lane == 0)
+#pragma unroll
+      for (int i = 0; i < 36; i++) s_red[wave][i] = acc[i];
+    __syncthreads();
+    if (tid < 36) s_sum[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    __syncthreads();
+  };
+  auto optimize = [&](int iters) {
+    for (int it = 0; it < iters; it++) {
+      eval(true);
+      double Hs[28], bs[7], xs[7];
+      if (tid == 0) {
+        s_cur = s_sum[35]; s_ini = s_sum[35];
+        for (int i = 0; i < 28; i++) Hs[i] = s_sum[i];
+        for (int i = 0; i < 7; i++) bs[i] = s_sum[28 + i];
+        if (it == 0) {
+          double mx = 0;
+          for (int p = 0; p < 7; p++) mx = fmax(mx, fabs(Hs[p * (p + 1) / 2 + p]));
+          s_lambda = 1e-5 * mx; s_ni = 2; s_nbad = 0;
+        }
+        s_qmax = 0;
+      }
+      __syncthreads();
+      while (true) {
+        if (tid == 0) {
+          s_bak = s_S;
+          double Lm[28];
+          bool ok = true;
+          for (int i = 0; i < 7 && ok; i++)
+            for (int j = 0; j <= i; j++) {
+              double sacc = Hs[i * (i + 1) / 2 + j] + (i == j ? s_lambda : 0.0);
+              for (int k = 0; k < j; k++) sacc -= Lm[i * (i + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
+              if (i == j) { if (!(sacc > 0)) { ok = false; break; } Lm[i * (i + 1) / 2 + i] = sqrt(sacc); }
+              else Lm[i * (i + 1) / 2 + j] = sacc / Lm[j * (j + 1) / 2 + j];
+            }
+          if (ok) {
+            for (int i = 0; i < 7; i++) { double sacc = bs[i]; for (int k = 0; k < i; k++) sacc -= Lm[i * (i + 1) / 2 + k] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
+            for (int i = 6; i >= 0; i--) { double sacc = xs[i]; for (int k = i + 1; k < 7; k++) sacc -= Lm[k * (k + 1) / 2 + i] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
+            double u[7];
+            for (int i = 0; i < 7; i++) u[i] = xs[i];
+            if (fix_scale) u[6] = 0;
+            Sim3d E, Sn;
+            sim3_exp(u, E);
+            sim3_mul(E, s_S, Sn);
+            s_S = Sn;
+          }
+          s_ctl = ok ? 1 : 0;
+        }
+        __syncthreads();
+        const bool okb = s_ctl != 0;
+        if (okb) eval(false);
+        if (tid == 0) {
+          const double tempChi = okb ? s_sum[35] : 1.7976931348623157e308;
+          double rho = s_cur - tempChi;
+          double scale = 0;
+          if (okb) for (int j = 0; j < 7; j++) scale += xs[j] * (s_lambda * xs[j] + bs[j]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && isfinite(tempChi)) {
+            double alpha = 1. - pow(2 * rho - 1, 3);
+            alpha = fmin(alpha, 2. / 3.);
+            s_lambda *= fmax(1. / 3., alpha);
+            s_ni = 2;
+            s_cur = tempChi;
+          } else {
+            s_lambda *= s_ni; s_ni *= 2;
+            s_S = s_bak;
+          }
+          s_qmax++;
+          s_rho = rho;
+          s_ctl = (rho < 0 && s_qmax < 10) ? 1 : 0;
+        }
+        __syncthreads();
+        const int again = s_ctl;
+        __syncthreads();
+        if (!again) break;
+      }
+      if (tid == 0) {
+        int stop = 0;
+        if (s_qmax == 10 || s_rho == 0) stop = 1;
+        else {
+          if ((s_ini - s_cur) * 1e3 < s_ini) s_nbad++; else s_nbad = 0;
+          if (s_nbad >= 3) stop = 1;
+        }
+        s_ctl = stop;
+      }
+      __syncthreads();
+      const int stop = s_ctl;
+      __syncthreads();
+      if (stop) break;
+    }
+  };
+
+  optimize(5);
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int i = tid; i < N; i += 256) {
+    if (chi12[i] > th2 || chi21[i] > th2) { alive[i] = 0; bad++; } else robust[i] = 0;
+  }
+  if (bad) atomicAdd(&s_cnt, bad);
+  __syncthreads();
+  const int nBad = s_cnt;
+  __syncthreads();
+  if (N - nBad < 10) {
+    if (tid == 0) *nin_out = 0;
+    return;
+  }
+  optimize(nBad > 0 ? 10 : 5);
+  prepare(false);
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int in = 0;
+  for (int i = tid; i < N; i += 256) {
+    if (!alive[i]) continue;
+    double u, v;
+    sim3_proj(s_M[0], P2c + 3 * i, s_K, u, v);
+    const double a0 = obs1[2 * i] - u, a1 = obs1[2 * i + 1] - v;
+    sim3_proj(s_M[1], P1c + 3 * i, s_K + 4, u, v);
+    const double b0 = obs2[2 * i] - u, b1 = obs2[2 * i + 1] - v;
+    const double c12 = w1[i] * (a0 * a0 + a1 * a1), c21 = w2[i] * (b0 * b0 + b1 * b1);
+    if (!(c12 > th2 || c21 > th2)) { inlier[i] = 1; in++; }
+  }
+  if (in) atomicAdd(&s_cnt, in);
+  __syncthreads();
+  if (tid == 0) {
+    *nin_out = s_cnt;
+    for (int i = 0; i < 4; i++) S12io[i] = s_S.q[i];
+    for (int i = 0; i < 3; i++) S12io[4 + i] = s_S.t[i];
+    S12io[7] = s_S.s;
+  }
+}
+
+void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const double* P1c, const double* P2c,
+                             const double* obs1, const double* obs2, const double* w1, const double* w2, int N,
+                             const double* K, double th2, uint8_t* inlier, int32_t* nin, double* chi_scratch, uint8_t* flag_scratch) {
+  hipLaunchKernelGGL(k_optimize_sim3, dim3(1), dim3(256), 0, s, S12io, fix_scale, P1c, P2c, obs1, obs2, w1, w2, N, K, th2, inlier,
+                     nin, chi_scratch, flag_scratch);
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

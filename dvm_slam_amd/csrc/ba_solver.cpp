@@ -377,4 +377,45 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
   return rc;
 }
 
+int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c, const double* P2c, const double* obs1,
+                      const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
+                      double th2, uint8_t* inlier, int32_t* n_inliers) {
+  if (!S12 || !P1c || !P2c || !obs1 || !obs2 || !w1 || !w2 || !K1 || !K2 || !inlier || !n_inliers || N < 1) {
+    set_error("dvm_optimize_sim3: bad arguments");
+    return DVM_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) return DVM_ERR_INVALID;
+  DVM_HIP(hipSetDevice(device));
+  const size_t n = (size_t)N;
+  // doubles: S12[8] K[8] P1c[3n] P2c[3n] obs1[2n] obs2[2n] w1[n] w2[n] chi[2n]; then int32 nin; bytes inlier[n] flags[2n]
+  const size_t nd = 16 + 14 * n;
+  const size_t total = nd * 8 + 8 + 3 * n;
+  uint8_t* d = nullptr;
+  DVM_HIP(hipMalloc(&d, total));
+  double* dd = reinterpret_cast<double*>(d);
+  double *dS = dd, *dK = dd + 8, *dP1 = dd + 16, *dP2 = dP1 + 3 * n, *dO1 = dP2 + 3 * n, *dO2 = dO1 + 2 * n, *dW1 = dO2 + 2 * n,
+         *dW2 = dW1 + n, *dChi = dW2 + n;
+  int32_t* dNin = reinterpret_cast<int32_t*>(dd + nd);
+  uint8_t* dInl = reinterpret_cast<uint8_t*>(dNin) + 8;
+  uint8_t* dFlags = dInl + n;
+  int rc = DVM_OK;
+  auto up = [&](void* dst, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload"); };
+  double K[8];
+  std::memcpy(K, K1, 32); std::memcpy(K + 4, K2, 32);
+  up(dS, S12, 64); up(dK, K, 64); up(dP1, P1c, 24 * n); up(dP2, P2c, 24 * n); up(dO1, obs1, 16 * n); up(dO2, obs2, 16 * n);
+  up(dW1, w1, 8 * n); up(dW2, w2, 8 * n);
+  if (rc == DVM_OK) {
+    ba_launch_optimize_sim3(nullptr, dS, fix_scale, dP1, dP2, dO1, dO2, dW1, dW2, N, dK, th2, dInl, dNin, dChi, dFlags);
+    rc = hip_check(hipGetLastError(), "optimize_sim3 launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "optimize_sim3 sync");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(n_inliers, dNin, 4, hipMemcpyDeviceToHost), "download");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(inlier, dInl, n, hipMemcpyDeviceToHost), "download");
+  if (rc == DVM_OK && *n_inliers > 0) rc = hip_check(hipMemcpy(S12, dS, 64, hipMemcpyDeviceToHost), "download");
+  hipFree(d);
+  return rc;
+}
+
 }  // extern "C"

@@ -223,6 +223,17 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
                       const int32_t* n, int stride, int batch, const dvm_ba_camera* cam, double* pose_out,
                       uint8_t* outlier, int32_t* n_inliers);
 
+/* Optimizer::OptimizeSim3 (Optimizer.cc:1960-2212), numerics for N correspondences gathered by the caller:
+ * P1c / P2c = the matched map points in their own key frame's camera frame (R1w*P+t1w, R2w*P+t2w), obs1 / obs2 =
+ * undistorted keypoints in KF1 / KF2, w1 / w2 = mvInvLevelSigma2[octave], K1 / K2 = (fx,fy,cx,cy) of both pinhole
+ * cameras, th2 = chi-square gate (Huber delta = sqrt(th2)).  S12 (in/out) = (qx,qy,qz,qw, tx,ty,tz, s) = g2o::Sim3.
+ * Runs optimize(5) -> inlier test -> kernels off -> optimize(5|10) -> final test on the device (one workgroup).
+ * inlier[N] = 1 for surviving pairs; *n_inliers = the reference's return value (0 if < 10 pairs survive round 1).
+ * Host pointers, synchronous. */
+int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c, const double* P2c, const double* obs1,
+                      const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
+                      double th2, uint8_t* inlier, int32_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

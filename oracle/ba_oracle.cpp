@@ -575,4 +575,180 @@ int orc_pose_optimize(double* pose, const double* Xw, const double* obs, const d
   return N - nBad;
 }
 
+// ------------------------------------------------------------------------------------- Sim3
+// g2o::Sim3 (Thirdparty/g2o/g2o/types/sim3.h:47-230): exp, product, inverse, map.
+struct Sim3d { double q[4]; double t[3]; double s; };
+static void sim3_exp(const double u[7], Sim3d& S) {
+  const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]}, sigma = u[6];
+  const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  double O2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  S.s = std::exp(sigma);
+  const double eps = 0.00001;
+  double A, B, C, R[9];
+  if (std::fabs(sigma) < eps) {
+    C = 1;
+    if (theta < eps) { A = 0.5; B = 1. / 6.; for (int i = 0; i < 9; i++) R[i] = I[i] + O[i] + O2[i]; }
+    else {
+      const double th2 = theta * theta;
+      A = (1 - std::cos(theta)) / th2; B = (theta - std::sin(theta)) / (th2 * theta);
+      for (int i = 0; i < 9; i++) R[i] = I[i] + std::sin(theta) / theta * O[i] + (1 - std::cos(theta)) / (theta * theta) * O2[i];
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (theta < eps) {
+      const double s2 = sigma * sigma;
+      A = ((sigma - 1) * S.s + 1) / s2; B = ((0.5 * s2 - sigma + 1) * S.s) / (s2 * sigma);
+      for (int i = 0; i < 9; i++) R[i] = I[i] + O[i] + O2[i];
+    } else {
+      for (int i = 0; i < 9; i++) R[i] = I[i] + std::sin(theta) / theta * O[i] + (1 - std::cos(theta)) / (theta * theta) * O2[i];
+      const double a = S.s * std::sin(theta), b = S.s * std::cos(theta), th2 = theta * theta, s2 = sigma * sigma, c = th2 + s2;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / th2;
+    }
+  }
+  R_to_quat(R, S.q);
+  double W[9];
+  for (int i = 0; i < 9; i++) W[i] = A * O[i] + B * O2[i] + C * I[i];
+  mat3_vec(W, up, S.t);
+}
+static void sim3_mul(const Sim3d& a, const Sim3d& b, Sim3d& o) {
+  quat_mul(a.q, b.q, o.q);
+  double R[9], rt[3];
+  quat_to_R(a.q, R);
+  mat3_vec(R, b.t, rt);
+  for (int i = 0; i < 3; i++) o.t[i] = a.s * rt[i] + a.t[i];
+  o.s = a.s * b.s;
+}
+static void sim3_inv(const Sim3d& a, Sim3d& o) {
+  o.q[0] = -a.q[0]; o.q[1] = -a.q[1]; o.q[2] = -a.q[2]; o.q[3] = a.q[3];
+  double R[9], v[3] = {(-1. / a.s) * a.t[0], (-1. / a.s) * a.t[1], (-1. / a.s) * a.t[2]};
+  quat_to_R(o.q, R);
+  mat3_vec(R, v, o.t);
+  o.s = 1. / a.s;
+}
+static void sim3_map(const Sim3d& a, const double x[3], double o[3]) {
+  double R[9], rx[3];
+  quat_to_R(a.q, R);
+  mat3_vec(R, x, rx);
+  for (int i = 0; i < 3; i++) o[i] = a.s * rx[i] + a.t[i];
+}
+
+// Optimizer::OptimizeSim3 numerics (Optimizer.cc:1960-2212) for N correspondences already gathered by the
+// caller: P1c/P2c = map points in their own key frame's camera frame, obs1/obs2 = undistorted keypoints,
+// w1/w2 = mvInvLevelSigma2, pinhole intrinsics of both cameras.  S12 in/out = (qx,qy,qz,qw, tx,ty,tz, s).
+// Edges: e12 = obs1 - proj1(S12 * P2c), e21 = obs2 - proj2(S12^-1 * P1c); NUMERIC Jacobians (g2o
+// BaseBinaryEdge::linearizeOplus, delta 1e-9, base_binary_edge.hpp:131-205); dense 7x7 LM.
+// inlier[N] receives 1 for pairs that survive; returns nIn (0 when fewer than 10 pairs survive round 1).
+int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const double* P2c, const double* obs1,
+                      const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
+                      double th2, uint8_t* inlier) {
+  Sim3d S;
+  std::memcpy(S.q, S12io, 4 * sizeof(double)); std::memcpy(S.t, S12io + 4, 3 * sizeof(double)); S.s = S12io[7];
+  const double deltaHuber = (double)(float)std::sqrt((float)th2);  // const float deltaHuber = sqrt(th2)
+  std::vector<uint8_t> alive(N, 1), robust(N, 1);
+  std::vector<double> chi12(N, 0), chi21(N, 0);
+  auto proj = [](const double* K, const double X[3], double uv[2]) { uv[0] = K[0] * X[0] / X[2] + K[2]; uv[1] = K[1] * X[1] / X[2] + K[3]; };
+  auto errors = [&](const Sim3d& Sx, int i, double e12[2], double e21[2]) {
+    Sim3d Si; sim3_inv(Sx, Si);
+    double X[3], uv[2];
+    sim3_map(Sx, P2c + 3 * i, X); proj(K1, X, uv); e12[0] = obs1[2 * i] - uv[0]; e12[1] = obs1[2 * i + 1] - uv[1];
+    sim3_map(Si, P1c + 3 * i, X); proj(K2, X, uv); e21[0] = obs2[2 * i] - uv[0]; e21[1] = obs2[2 * i + 1] - uv[1];
+  };
+  auto chi_all = [&](const Sim3d& Sx) {
+    double chi = 0;
+    for (int i = 0; i < N; i++) {
+      if (!alive[i]) continue;
+      double a[2], b[2]; errors(Sx, i, a, b);
+      chi12[i] = w1[i] * (a[0] * a[0] + a[1] * a[1]); chi21[i] = w2[i] * (b[0] * b[0] + b[1] * b[1]);
+      double r0, r1;
+      robustify(chi12[i], robust[i] ? deltaHuber : 0.0, r0, r1); chi += r0;
+      robustify(chi21[i], robust[i] ? deltaHuber : 0.0, r0, r1); chi += r0;
+    }
+    return chi;
+  };
+  auto optimize = [&](int iters) {
+    double lambda = -1, ni = 2; int nBad = 0;
+    for (int it = 0; it < iters; it++) {
+      double currentChi = chi_all(S), tempChi = currentChi; const double iniChi = currentChi;
+      // perturbed estimates for the numeric Jacobian: Sim3(+-delta e_d) * S
+      Sim3d Sp[7], Sm[7];
+      for (int d = 0; d < 7; d++) {
+        double u[7] = {0, 0, 0, 0, 0, 0, 0};
+        u[d] = 1e-9; if (fix_scale) u[6] = 0; Sim3d E; sim3_exp(u, E); sim3_mul(E, S, Sp[d]);
+        u[d] = -1e-9; if (fix_scale) u[6] = 0; sim3_exp(u, E); sim3_mul(E, S, Sm[d]);
+      }
+      double H[49] = {0}, b[7] = {0};
+      for (int i = 0; i < N; i++) {
+        if (!alive[i]) continue;
+        double J12[14], J21[14];  // 2x7 row-major
+        for (int d = 0; d < 7; d++) {
+          double ap[2], bp[2], am[2], bm[2];
+          errors(Sp[d], i, ap, bp); errors(Sm[d], i, am, bm);
+          for (int r = 0; r < 2; r++) { J12[7 * r + d] = 5e8 * (ap[r] - am[r]); J21[7 * r + d] = 5e8 * (bp[r] - bm[r]); }
+        }
+        double e12[2], e21[2]; errors(S, i, e12, e21);
+        for (int pass = 0; pass < 2; pass++) {
+          const double* J = pass ? J21 : J12; const double* e = pass ? e21 : e12; const double w0 = pass ? w2[i] : w1[i];
+          const double chi2 = w0 * (e[0] * e[0] + e[1] * e[1]);
+          double r0, r1; robustify(chi2, robust[i] ? deltaHuber : 0.0, r0, r1);
+          const double w = r1 * w0, wr0 = -w0 * e[0] * r1, wr1 = -w0 * e[1] * r1;
+          for (int a = 0; a < 7; a++) {
+            b[a] += J[a] * wr0 + J[7 + a] * wr1;
+            for (int c = 0; c < 7; c++) H[7 * a + c] += w * (J[a] * J[c] + J[7 + a] * J[7 + c]);
+          }
+        }
+      }
+      if (it == 0) { double mx = 0; for (int a = 0; a < 7; a++) mx = std::max(mx, std::fabs(H[8 * a])); lambda = 1e-5 * mx; ni = 2; nBad = 0; }
+      double rho = 0; int qmax = 0;
+      do {
+        const Sim3d bak = S;
+        double Lm[49], x[7]; bool ok = true;
+        for (int i = 0; i < 7 && ok; i++)
+          for (int j = 0; j <= i; j++) {
+            double sacc = H[7 * i + j] + (i == j ? lambda : 0.0);
+            for (int k = 0; k < j; k++) sacc -= Lm[7 * i + k] * Lm[7 * j + k];
+            if (i == j) { if (!(sacc > 0)) { ok = false; break; } Lm[7 * i + i] = std::sqrt(sacc); } else Lm[7 * i + j] = sacc / Lm[7 * j + j];
+          }
+        if (ok) {
+          for (int i = 0; i < 7; i++) { double sacc = b[i]; for (int k = 0; k < i; k++) sacc -= Lm[7 * i + k] * x[k]; x[i] = sacc / Lm[7 * i + i]; }
+          for (int i = 6; i >= 0; i--) { double sacc = x[i]; for (int k = i + 1; k < 7; k++) sacc -= Lm[7 * k + i] * x[k]; x[i] = sacc / Lm[7 * i + i]; }
+          double u[7]; std::memcpy(u, x, sizeof(u)); if (fix_scale) u[6] = 0;
+          Sim3d E; sim3_exp(u, E); Sim3d Sn; sim3_mul(E, S, Sn); S = Sn;
+        }
+        tempChi = ok ? chi_all(S) : std::numeric_limits<double>::max();
+        rho = currentChi - tempChi;
+        double scale = 0; if (ok) for (int j = 0; j < 7; j++) scale += x[j] * (lambda * x[j] + b[j]);
+        scale += 1e-3; rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow(2 * rho - 1, 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
+        else { lambda *= ni; ni *= 2; S = bak; }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) break;
+    }
+  };
+  optimize(5);
+  int nBad = 0;
+  for (int i = 0; i < N; i++) {
+    if (chi12[i] > th2 || chi21[i] > th2) { alive[i] = 0; nBad++; } else robust[i] = 0;
+  }
+  for (int i = 0; i < N; i++) inlier[i] = 0;
+  if (N - nBad < 10) return 0;
+  optimize(nBad > 0 ? 10 : 5);
+  int nIn = 0;
+  for (int i = 0; i < N; i++) {
+    if (!alive[i]) continue;
+    double a[2], b[2]; errors(S, i, a, b);
+    const double c12 = w1[i] * (a[0] * a[0] + a[1] * a[1]), c21 = w2[i] * (b[0] * b[0] + b[1] * b[1]);
+    if (!(c12 > th2 || c21 > th2)) { inlier[i] = 1; nIn++; }
+  }
+  std::memcpy(S12io, S.q, 4 * sizeof(double)); std::memcpy(S12io + 4, S.t, 3 * sizeof(double)); S12io[7] = S.s;
+  return nIn;
+}
+
 }  // extern "C"

@@ -121,6 +121,11 @@ void orc_ba_edge_chi2(const double* poses, const double* points, const orc_ba_ed
 int orc_pose_optimize(double* pose, const double* Xw, const double* obs, const double* inv_sigma2, int N,
                       const orc_ba_camera* cam, uint8_t* outlier);
 
+/* Optimizer::OptimizeSim3 numerics (Optimizer.cc:1960-2212); S12 = (qx,qy,qz,qw,tx,ty,tz,s); K = (fx,fy,cx,cy) */
+int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const double* P2c, const double* obs1,
+                      const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
+                      double th2, uint8_t* inlier);
+
 #ifdef __cplusplus
 }
 #endif

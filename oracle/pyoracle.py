@@ -343,3 +343,15 @@ def is_in_frustum(F, P, normal, min_dist, max_dist, viewing_cos_limit=0.5):
     out = np.zeros(len(P), TRACK_DTYPE)
     L.orc_is_in_frustum(C.byref(F), _p(P), _p(normal), _p(min_dist), _p(max_dist), len(P), float(viewing_cos_limit), _p(out))
     return out
+
+
+def optimize_sim3(S12, fix_scale, P1c, P2c, obs1, obs2, w1, w2, K1, K2, th2):
+    """Optimizer::OptimizeSim3 numerics.  Returns (S12[8], inlier mask, nIn)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orc_optimize_sim3.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_double, vp]
+    S = np.array(S12, np.float64, copy=True)
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (P1c, P2c, obs1, obs2, w1, w2, K1, K2)]
+    inl = np.zeros(len(arrs[0]), np.uint8)
+    n = L.orc_optimize_sim3(_p(S), int(fix_scale), *[_p(a) for a in arrs[:6]], len(arrs[0]), _p(arrs[6]), _p(arrs[7]), float(th2), _p(inl))
+    return S, inl, n

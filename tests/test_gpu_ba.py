@@ -138,3 +138,48 @@ def test_pose_optimization_matches_oracle(capi, oracle):
     # degenerate: fewer than 3 matches -> 0 inliers, pose untouched
     pg, og, ng = capi.pose_optimize(poses[:1], Xw[:1], obs[:1], w[:1], np.array([2], np.int32), cases[0][4])
     assert ng[0] == 0 and np.array_equal(pg[0], poses[0])
+
+
+def _sim3_case(seed, N=150, out_frac=0.1, fix_scale=False):
+    rng = np.random.default_rng(seed)
+    ang = rng.uniform(-0.4, 0.4)
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * (Kx @ Kx)
+    t = rng.uniform(-0.5, 0.5, 3)
+    s = 1.0 if fix_scale else rng.uniform(0.7, 1.4)
+    P2 = np.c_[rng.uniform(-3, 3, N), rng.uniform(-2, 2, N), rng.uniform(4, 12, N)]
+    P1 = (s * (R @ P2.T)).T + t
+    K = np.array([149.0, 149.0, 320.0, 240.0])
+    proj = lambda P: np.c_[K[0] * P[:, 0] / P[:, 2] + K[2], K[1] * P[:, 1] / P[:, 2] + K[3]]
+    obs1 = proj(P1) + rng.normal(0, 0.6, (N, 2))
+    obs2 = proj(P2) + rng.normal(0, 0.6, (N, 2))
+    bad = rng.random(N) < out_frac
+    obs1[bad] += rng.choice([-1, 1], (int(bad.sum()), 2)) * 25.0
+    w1 = 1.2 ** (-2.0 * rng.integers(0, 8, N)); w2 = 1.2 ** (-2.0 * rng.integers(0, 8, N))
+    # initial guess: perturbed truth, quaternion from R
+    from dvm_slam_amd.synth import _quat_from_rot, _rot_from_axis_angle
+    R0 = _rot_from_axis_angle(rng.normal(0, 0.03, 3)) @ R
+    S0 = np.r_[_quat_from_rot(R0), t + rng.normal(0, 0.05, 3), s * (1.0 if fix_scale else 1.05)]
+    return S0, P1, P2, obs1, obs2, w1, w2, K
+
+
+@pytest.mark.parametrize("seed,N,out_frac,fix", [(1, 150, 0.1, False), (2, 60, 0.0, False), (3, 400, 0.2, True), (4, 25, 0.0, False)])
+def test_optimize_sim3_matches_oracle(capi, oracle, seed, N, out_frac, fix):
+    """Optimizer::OptimizeSim3 numerics (numeric Jacobians, 7-DoF LM): Sim3 within 1e-6, identical inlier mask."""
+    S0, P1, P2, o1, o2, w1, w2, K = _sim3_case(seed, N, out_frac, fix)
+    So, io, no = oracle.optimize_sim3(S0, fix, P1, P2, o1, o2, w1, w2, K, K, 10.0)
+    Sg, ig, ng = capi.optimize_sim3(S0, fix, P1, P2, o1, o2, w1, w2, K, K, 10.0)
+    assert ng == no and np.array_equal(ig, io)
+    assert np.abs(Sg - So).max() < 1e-6, np.abs(Sg - So).max()
+    assert no >= 0.7 * N * (1 - out_frac)
+    if fix:
+        assert abs(Sg[7] - S0[7]) < 1e-12
+
+
+def test_optimize_sim3_too_few_inliers(capi, oracle):
+    S0, P1, P2, o1, o2, w1, w2, K = _sim3_case(9, 12, 0.0, False)
+    o1 = o1 + 80.0  # every pair fails the chi2 gate after round 1 -> fewer than 10 survive -> returns 0
+    So, io, no = oracle.optimize_sim3(S0, False, P1, P2, o1, o2, w1, w2, K, K, 10.0)
+    Sg, ig, ng = capi.optimize_sim3(S0, False, P1, P2, o1, o2, w1, w2, K, K, 10.0)
+    assert no == 0 and ng == 0 and not ig.any() and np.array_equal(Sg, S0)

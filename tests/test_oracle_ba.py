@@ -63,3 +63,44 @@ def test_pose_optimization_oracle(oracle):
     # fewer than 3 correspondences: returns 0 and leaves the pose alone (Optimizer.cc:904-905)
     p2, _, n2 = oracle.pose_optimize(pose0, Xw[:2], obs[:2], pr["inv_sigma2"][sel][:2], pr["intrinsics"])
     assert n2 == 0 and np.array_equal(p2, pose0)
+
+
+def test_optimize_sim3_oracle_vs_scipy(oracle):
+    """OptimizeSim3 oracle: on an outlier-free problem its optimum coincides with scipy's least-squares optimum of
+    the same bidirectional reprojection cost (independent parametrisation: rotation vector, t, log s)."""
+    from scipy.optimize import least_squares
+    rng = np.random.default_rng(5)
+    N = 80
+    ang = 0.25
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    t = np.array([0.3, -0.2, 0.1]); s = 1.25
+    P2 = np.c_[rng.uniform(-3, 3, N), rng.uniform(-2, 2, N), rng.uniform(4, 12, N)]
+    P1 = (s * (R @ P2.T)).T + t
+    K = np.array([149.0, 149.0, 320.0, 240.0])
+    proj = lambda P: np.c_[K[0] * P[:, 0] / P[:, 2] + K[2], K[1] * P[:, 1] / P[:, 2] + K[3]]
+    obs1 = proj(P1) + rng.normal(0, 0.5, (N, 2)); obs2 = proj(P2) + rng.normal(0, 0.5, (N, 2))
+    w = np.ones(N)
+    S0 = np.r_[0, 0, np.sin(0.11), np.cos(0.11), t + 0.03, 1.2]
+    S, inl, n = oracle.optimize_sim3(S0, 0, P1, P2, obs1, obs2, w, w, K, K, 50.0)
+    assert n == N and inl.all()
+
+    def unpack(p):
+        th = np.linalg.norm(p[:3])
+        k = p[:3] / th if th > 0 else np.zeros(3)
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx), p[3:6], np.exp(p[6])
+
+    def res(p):
+        Rr, tt, ss = unpack(p)
+        a = obs1 - proj((ss * (Rr @ P2.T)).T + tt)
+        b = obs2 - proj(((Rr.T @ (P1 - tt).T) / ss).T)
+        return np.r_[a.ravel(), b.ravel()]
+
+    sol = least_squares(res, np.r_[0, 0, 0.22, t, np.log(1.2)], xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    Rr, tt, ss = unpack(sol.x)
+    import ref_numpy as ref
+    assert np.allclose(ref.quat_to_R(S[:4] / np.linalg.norm(S[:4])), Rr, atol=2e-5)
+    assert np.allclose(S[4:7], tt, atol=2e-4) and abs(S[7] - ss) < 2e-5
+    # fix_scale keeps s exactly
+    S2, _, n2 = oracle.optimize_sim3(np.r_[S0[:7], 1.0], 1, P1, P2, obs1, obs2, w, w, K, K, 1e9)
+    assert S2[7] == 1.0
