@@ -434,3 +434,44 @@ def optimize_sim3(S12, fix_scale, P1c, P2c, obs1, obs2, w1, w2, K1, K2, th2, dev
     check(lib().dvm_optimize_sim3(device, _p(S), int(fix_scale), *[_p(a) for a in arrs[:6]], n, _p(arrs[6]), _p(arrs[7]),
                                   float(th2), _p(inl), C.byref(nin)))
     return S, inl, nin.value
+
+
+# ---- host C++ mirror (dvm_slam_amd/host, libdvmslam_host.so): ORBmatcher on plain structs over the C ABI
+HOST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libdvmslam_host.so")
+MAP_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
+_HOST = None
+
+
+def host_lib():
+    global _HOST
+    if _HOST is None:
+        lib()  # HIP library (and torch's runtime) first
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} not built (make -C dvm_slam_amd/host)")
+        _HOST = C.CDLL(HOST_LIB_PATH)
+        vp = C.c_void_p
+        _HOST.dvmh_search_by_projection_frames.restype = C.c_int32
+        _HOST.dvmh_search_by_projection_frames.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32,
+                                                           C.c_int32, vp, vp, vp, vp, C.c_float, C.c_int32, vp]
+    return _HOST
+
+
+def search_by_projection_frames(kps_c, desc_c, mp_c, Rcw, tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
+                                check_ori=True, device=0):
+    """dvm_host::ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono=true) -- reference
+    ORBmatcher.cc:1553-1748.  Returns (nmatches, updated mvpMapPoints of the current frame, #host re-queries)."""
+    H = host_lib()
+    kps_c = np.ascontiguousarray(kps_c, KP_DTYPE); kps_l = np.ascontiguousarray(kps_l, KP_DTYPE)
+    desc_c = np.ascontiguousarray(desc_c, np.uint8)
+    mp = np.array(mp_c, np.int32, copy=True)
+    mp_l = np.ascontiguousarray(mp_l, np.int32)
+    outl = None if outlier_l is None else np.ascontiguousarray(outlier_l, np.uint8)
+    f = [np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, K, bounds, scale_factors)]
+    mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
+    req = C.c_int32(0)
+    n = H.dvmh_search_by_projection_frames(device, len(kps_c), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f],
+                                           len(f[4]), len(kps_l), _p(kps_l), _p(mp_l), None if outl is None else _p(outl),
+                                           _p(mps), float(th), int(check_ori), C.byref(req))
+    if n < 0:
+        check(n)
+    return n, mp, req.value

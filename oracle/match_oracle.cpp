@@ -11,6 +11,8 @@
 //   src/Frame.cc:773-782         PosInGrid (round, drop if out)   -> orc_grid ctor
 //   src/Frame.cc:712-770         GetFeaturesInArea                -> features_in_area()
 //   src/ORBmatcher.cc:70-115, :1604-1639  best / second-best loops -> orc_match_window()
+//   src/ORBmatcher.cc:1553-1748  SearchByProjection(CurrentFrame, LastFrame, th, bMono=true), whole function,
+//   src/ORBmatcher.cc:1862-1896  ComputeThreeMaxima              -> orc_search_by_projection_frames()
 #include "oracle.h"
 
 #include <algorithm>
@@ -161,6 +163,71 @@ void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* 
     if (nScale < 0) nScale = 0; else if (nScale >= F->n_levels) nScale = F->n_levels - 1;
     o.in_view = 1; o.proj_xr = u - F->bf * invz; o.depth = Pc_dist; o.level = nScale; o.view_cos = viewCos;
   }
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- ORBmatcher.cc:1553-1748,
+// monocular (bForward = bBackward = false, no right image, no Nleft).  Plain sequential restatement: the claim check
+// `CurrentFrame.mvpMapPoints[i2]->Observations() > 0` is evaluated against the state left by earlier iterations.
+int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* Rcw,
+                                    const float* tcw, const float* K, const float* bounds, const float* scale_factors,
+                                    int Nl, const orc_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
+                                    const orc_map_point* mps, float th, int check_ori) {
+  const int HISTO_LENGTH = 30, TH_HIGH = 100;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  orc_grid* g = orc_grid_create(kps_c, Nc, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> vIndices2;
+  for (int i = 0; i < Nl; i++) {
+    const int pMP = mp_l[i];
+    if (pMP < 0) continue;
+    if (outlier_l && outlier_l[i]) continue;
+    const float* X = mps[pMP].pos;
+    float x3Dc[3];
+    for (int r = 0; r < 3; r++) x3Dc[r] = (Rcw[3 * r] * X[0] + Rcw[3 * r + 1] * X[1] + Rcw[3 * r + 2] * X[2]) + tcw[r];
+    const float invzc = 1.0 / x3Dc[2];
+    if (invzc < 0) continue;
+    const float u = K[0] * x3Dc[0] / x3Dc[2] + K[2], v = K[1] * x3Dc[1] / x3Dc[2] + K[3];  // Pinhole::project
+    if (u < bounds[0] || u > bounds[1]) continue;
+    if (v < bounds[2] || v > bounds[3]) continue;
+    const int nLastOctave = kps_l[i].octave;
+    const float radius = th * scale_factors[nLastOctave];
+    features_in_area(g, u, v, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+    if (vIndices2.empty()) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (mp_c[i2] >= 0 && mps[mp_c[i2]].n_obs > 0) continue;
+      const int dist = descriptor_distance(mps[pMP].desc, desc_c + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      mp_c[bestIdx2] = pMP;
+      nmatches++;
+      if (check_ori) {
+        float rot = kps_l[i].angle - kps_c[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = (int)rotHist[i].size();
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0; j < rotHist[i].size(); j++) { mp_c[rotHist[i][j]] = -1; nmatches--; }
+  }
+  orc_grid_destroy(g);
+  return nmatches;
 }
 
 }  // extern "C"

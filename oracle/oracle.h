@@ -102,6 +102,14 @@ typedef struct { float proj_x, proj_y, proj_xr, depth, view_cos; int32_t level; 
 void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* normal, const float* min_dist,
                        const float* max_dist, int n, float viewing_cos_limit, orc_track_point* out);
 
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono=true), whole function (ORBmatcher.cc:1553-1748):
+   mp_c / mp_l hold map-point indices (-1 = NULL); mp_c is updated in place; returns nmatches. */
+typedef struct { float pos[3]; uint8_t desc[32]; int32_t n_obs; } orc_map_point;
+int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* Rcw,
+                                    const float* tcw, const float* K, const float* bounds, const float* scale_factors,
+                                    int Nl, const orc_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
+                                    const orc_map_point* mps, float th, int check_ori);
+
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;

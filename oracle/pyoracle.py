@@ -355,3 +355,26 @@ def optimize_sim3(S12, fix_scale, P1c, P2c, obs1, obs2, w1, w2, K1, K2, th2):
     inl = np.zeros(len(arrs[0]), np.uint8)
     n = L.orc_optimize_sim3(_p(S), int(fix_scale), *[_p(a) for a in arrs[:6]], len(arrs[0]), _p(arrs[6]), _p(arrs[7]), float(th2), _p(inl))
     return S, inl, n
+
+
+MAP_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
+
+
+def search_by_projection_frames(kps_c, desc_c, mp_c, Rcw, tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
+                                check_ori=True):
+    """Whole ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (mono).  Returns (nmatches, mp_c updated copy)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_by_projection_frames.restype = C.c_int32
+    L.orc_search_by_projection_frames.argtypes = [C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp,
+                                                  C.c_float, C.c_int32]
+    kps_c = np.ascontiguousarray(kps_c, KP_DTYPE); kps_l = np.ascontiguousarray(kps_l, KP_DTYPE)
+    desc_c = np.ascontiguousarray(desc_c, np.uint8)
+    mp = np.array(mp_c, np.int32, copy=True)
+    mp_l = np.ascontiguousarray(mp_l, np.int32)
+    outl = None if outlier_l is None else np.ascontiguousarray(outlier_l, np.uint8)
+    f = [np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, K, bounds, scale_factors)]
+    mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
+    n = L.orc_search_by_projection_frames(len(kps_c), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f], len(kps_l), _p(kps_l),
+                                          _p(mp_l), None if outl is None else _p(outl), _p(mps), float(th), int(check_ori))
+    return n, mp

@@ -1,0 +1,69 @@
+"""Synthetic two-frame tracking scene for the whole-function SearchByProjection(CurrentFrame, LastFrame) tests."""
+import numpy as np
+
+
+def make_scene(oracle, seed=0, n_last=1000, n_cur=1100, dup_frac=0.15, zero_obs_frac=0.1, flip_bits=20):
+    """LastFrame keypoints carry map points; CurrentFrame keypoints are noisy re-projections (plus clutter) so that
+    several queries compete for the same current keypoint (exercises the sequential claim rule)."""
+    rng = np.random.default_rng(seed)
+    K = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    bounds = np.array([0.0, 640.0, 0.0, 480.0], np.float32)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    # last frame at identity
+    kl = np.zeros(n_last, oracle.KP_DTYPE)
+    kl["x"] = rng.uniform(20, 620, n_last).astype(np.float32)
+    kl["y"] = rng.uniform(20, 460, n_last).astype(np.float32)
+    kl["octave"] = rng.integers(0, 8, n_last)
+    kl["angle"] = rng.uniform(0, 360, n_last).astype(np.float32)
+    z = rng.uniform(2, 12, n_last).astype(np.float32)
+    mps = np.zeros(n_last, oracle.MAP_POINT_DTYPE)
+    mps["pos"][:, 0] = (kl["x"] - K[2]) / K[0] * z
+    mps["pos"][:, 1] = (kl["y"] - K[3]) / K[1] * z
+    mps["pos"][:, 2] = z
+    mps["desc"] = rng.integers(0, 256, (n_last, 32), dtype=np.uint8)
+    mps["n_obs"] = np.where(rng.random(n_last) < zero_obs_frac, 0, rng.integers(1, 6, n_last))
+    # duplicates: a second map point at (almost) the same place with the same descriptor -> competes for one keypoint
+    ndup = int(dup_frac * n_last)
+    src = rng.choice(n_last, ndup, replace=False)
+    dst = rng.choice(np.setdiff1d(np.arange(n_last), src), ndup, replace=False)
+    mps["pos"][dst] = mps["pos"][src] + rng.normal(0, 1e-3, (ndup, 3)).astype(np.float32)
+    mps["desc"][dst] = mps["desc"][src]
+    kl["octave"][dst] = kl["octave"][src]
+    # a few behind the camera / far outside
+    mps["pos"][rng.choice(n_last, 20, replace=False), 2] *= -1
+    mp_l = np.arange(n_last, dtype=np.int32)
+    mp_l[rng.random(n_last) < 0.1] = -1
+    outl = (rng.random(n_last) < 0.05).astype(np.uint8)
+    # current pose: small motion
+    a = 0.01
+    Rcw = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    tcw = np.array([0.03, -0.02, 0.05], np.float32)
+    Xc = mps["pos"] @ Rcw.T + tcw
+    u = K[0] * Xc[:, 0] / Xc[:, 2] + K[2]
+    v = K[1] * Xc[:, 1] / Xc[:, 2] + K[3]
+    kc = np.zeros(n_cur, oracle.KP_DTYPE)
+    dc = rng.integers(0, 256, (n_cur, 32), dtype=np.uint8)
+    pick = rng.choice(n_last, min(n_last, n_cur - 100), replace=False)
+    m = len(pick)
+    kc["x"][:m] = (u[pick] + rng.normal(0, 2.0, m)).astype(np.float32)
+    kc["y"][:m] = (v[pick] + rng.normal(0, 2.0, m)).astype(np.float32)
+    kc["octave"][:m] = np.clip(kl["octave"][pick] + rng.integers(-1, 2, m), 0, 7)
+    # most matches share one rotation; a minority is rotated elsewhere -> removed by the histogram filter
+    rot = np.where(rng.random(m) < 0.8, 10.0, rng.uniform(0, 360, m))
+    kc["angle"][:m] = np.mod(kl["angle"][pick] - rot + 720.0, 360.0).astype(np.float32)
+    d = mps["desc"][pick].copy()
+    bits = np.unpackbits(d, axis=1)
+    for r in range(m):
+        bits[r, rng.choice(256, rng.integers(0, flip_bits + 1), replace=False)] ^= 1
+    dc[:m] = np.packbits(bits, axis=1)
+    kc["x"][m:] = rng.uniform(0, 640, n_cur - m).astype(np.float32)
+    kc["y"][m:] = rng.uniform(0, 480, n_cur - m).astype(np.float32)
+    kc["octave"][m:] = rng.integers(0, 8, n_cur - m)
+    kc["angle"][m:] = rng.uniform(0, 360, n_cur - m).astype(np.float32)
+    perm = rng.permutation(n_cur)
+    kc, dc = kc[perm], dc[perm]
+    mp_c = np.full(n_cur, -1, np.int32)
+    pre = rng.choice(n_cur, 40, replace=False)          # already-associated keypoints (some with 0 observations)
+    mp_c[pre] = rng.integers(0, n_last, 40)
+    return dict(kps_c=kc, desc_c=dc, mp_c=mp_c, Rcw=Rcw.reshape(-1), tcw=tcw, K=K, bounds=bounds, scale_factors=scale,
+                kps_l=kl, mp_l=mp_l, outlier_l=outl, mps=mps)

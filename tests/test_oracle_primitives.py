@@ -185,3 +185,45 @@ def test_extract_invariants(oracle, frames):
     n2, k2, d2, mono2 = o.extract(frames[0], lap=(0, 0))
     assert mono2 == n2 == n and np.array_equal(k2["octave"], k["octave"][::-1]) and np.array_equal(d2, d[::-1])
     assert o.extract(np.zeros((0, 0), np.uint8))[0] == -1
+
+
+def test_search_by_projection_frames_oracle_semantics(oracle):
+    """Whole-function SearchByProjection(Cur, Last) restatement: independent numpy re-derivation on a scene without
+    competing queries (where the sequential claim rule cannot matter) + the rotation-histogram filter."""
+    from matcher_scene import make_scene
+    po = oracle
+    sc = make_scene(po, 7, dup_frac=0.0, zero_obs_frac=0.0)
+    sc["mp_c"][:] = -1
+    n, mp = po.search_by_projection_frames(th=15.0, check_ori=False, **sc)
+    # brute force: for every valid last-frame map point, best current keypoint in the window, in order, with claims
+    kc, dc, kl, mps = sc["kps_c"], sc["desc_c"], sc["kps_l"], sc["mps"]
+    R = sc["Rcw"].reshape(3, 3); t = sc["tcw"]; K = sc["K"]
+    grid = po.Grid(kc)
+    ref = np.full(len(kc), -1, np.int32); cnt = 0
+    for i in range(len(kl)):
+        if sc["mp_l"][i] < 0 or sc["outlier_l"][i]:
+            continue
+        X = mps["pos"][i]
+        xc = [np.float32(np.float32(np.float32(R[r, 0] * X[0]) + np.float32(R[r, 1] * X[1])) + np.float32(R[r, 2] * X[2])) + t[r] for r in range(3)]
+        if xc[2] < 0:
+            continue
+        u = np.float32(np.float32(K[0] * xc[0]) / xc[2]) + K[2]; v = np.float32(np.float32(K[1] * xc[1]) / xc[2]) + K[3]
+        if not (0 <= u <= 640 and 0 <= v <= 480):
+            continue
+        o = int(kl["octave"][i])
+        cand = grid.features_in_area(u, v, np.float32(15.0) * sc["scale_factors"][o], o - 1, o + 1)
+        best, bi = 256, -1
+        for j in cand:
+            if ref[j] >= 0:
+                continue
+            dd = int(np.unpackbits(mps["desc"][i] ^ dc[j]).sum())
+            if dd < best:
+                best, bi = dd, j
+        if best <= 100:
+            ref[bi] = i; cnt += 1
+    assert n == cnt and np.array_equal(mp, ref)
+    # with the orientation check: ~20 % of true matches have a random rotation -> most of them are removed
+    n2, mp2 = po.search_by_projection_frames(th=15.0, check_ori=True, **sc)
+    assert 0.6 * n < n2 < n
+    kept = mp2 >= 0
+    assert np.array_equal(mp2[kept], mp[kept])
