@@ -200,49 +200,54 @@ __global__ void __launch_bounds__(256) k_pyr_borders(uint8_t* __restrict__ pyr, 
 }
 
 // ------------------------------------------------------------------------------------------ K2
-// FAST-9/16 strength max(A,B) of one pixel: A = max over the 16 nine-pixel arcs of min(v - p),
-// B = the same for (p - v).  Sliding-window min/max of width 9 over the circular 16-vector by
-// doubling (2,4,8,+1), on PACKED 16-bit lanes (v_pk_min_i16 / v_pk_max_i16: two ring positions per
-// instruction; differences are in [-255, 255]).
-typedef short short2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ short2_t pk(int lo, int hi) {
-  const int w = (lo & 0xFFFF) | (hi << 16);
-  return __builtin_bit_cast(short2_t, w);
+// FAST-9/16 strength max(A,B) of one pixel v with ring p[0..15]:
+//   A = max over the 16 nine-pixel arcs of min(v - p_i) = v - min_arcs max_i p_i
+//   B = max over arcs of min(p_i - v)                   = max_arcs min_i p_i - v
+// so the whole sliding-window network runs on the raw ring bytes: window-9 min and max over the circular
+// 16-vector by doubling (2,4,8,+1) on PACKED 16-bit lanes (v_pk_min_u16 / v_pk_max_u16: two ring
+// positions per instruction).  PITCH != 0: compile-time LDS pitch, ring offsets become ds_read immediates.
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ushort2_t pk(int lo, int hi) {
+  const uint32_t w = (uint32_t)lo | ((uint32_t)hi << 16);
+  return __builtin_bit_cast(ushort2_t, w);
 }
-__device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int pitch) {
+template <int PITCH>
+__device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int pitch_dyn) {
+  constexpr int cx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  constexpr int cy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+  const int pitch = PITCH ? PITCH : pitch_dyn;
   const int v = t[0];
   int p[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) p[k] = (int)t[c_circle[k][0] + c_circle[k][1] * pitch];
-  const short2_t V = pk(v, v);
-  short2_t P[8], Q[8];   // P[j] = (d[2j], d[2j+1]),  Q[j] = (d[2j+1], d[2j+2])
+  for (int k = 0; k < 16; k++) p[k] = (int)t[cx[k] + cy[k] * pitch];
+  ushort2_t P[8], Q[8];   // P[j] = (p[2j], p[2j+1]),  Q[j] = (p[2j+1], p[2j+2])
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    P[j] = V - pk(p[2 * j], p[2 * j + 1]);
-    Q[j] = V - pk(p[2 * j + 1], p[(2 * j + 2) & 15]);
+    P[j] = pk(p[2 * j], p[2 * j + 1]);
+    Q[j] = pk(p[2 * j + 1], p[(2 * j + 2) & 15]);
   }
-  short2_t lo[8], hi[8];
+  ushort2_t lo[8], hi[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {  // windows of 2: (w2[2j], w2[2j+1])
     lo[j] = __builtin_elementwise_min(P[j], Q[j]);
     hi[j] = __builtin_elementwise_max(P[j], Q[j]);
   }
-  short2_t lo4[8], hi4[8];
+  ushort2_t lo4[8], hi4[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {  // windows of 4
     lo4[j] = __builtin_elementwise_min(lo[j], lo[(j + 1) & 7]);
     hi4[j] = __builtin_elementwise_max(hi[j], hi[(j + 1) & 7]);
   }
-  short2_t A2 = pk(-256, -256), B2 = pk(256, 256);
+  ushort2_t maxmin = pk(0, 0), minmax = pk(255, 255);
 #pragma unroll
-  for (int j = 0; j < 8; j++) {  // windows of 8, then the ninth element d[k+8]
-    const short2_t lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[j], lo4[(j + 2) & 7]), P[(j + 4) & 7]);
-    const short2_t hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[j], hi4[(j + 2) & 7]), P[(j + 4) & 7]);
-    A2 = __builtin_elementwise_max(A2, lo9);
-    B2 = __builtin_elementwise_min(B2, hi9);
+  for (int j = 0; j < 8; j++) {  // windows of 8, then the ninth element p[k+8]
+    const ushort2_t lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[j], lo4[(j + 2) & 7]), P[(j + 4) & 7]);
+    const ushort2_t hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[j], hi4[(j + 2) & 7]), P[(j + 4) & 7]);
+    maxmin = __builtin_elementwise_max(maxmin, lo9);
+    minmax = __builtin_elementwise_min(minmax, hi9);
   }
-  const int A = max((int)A2.x, (int)A2.y), Bn = min((int)B2.x, (int)B2.y);
-  return max(A, -Bn);
+  const int A = v - min((int)minmax.x, (int)minmax.y), B = max((int)maxmin.x, (int)maxmin.y) - v;
+  return max(A, B);
 }
 
 // One workgroup per (cell, frame).  Reproduces, for the cell's ROI,
@@ -252,41 +257,54 @@ __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int 
 // { p : S(p) >= t and S(p) > S(q) for the 8 neighbours q }, in row-major order, response S(p).
 // Output: candidates in the cell's slot range, row-major, packed (x-16, y-16, score).
 //
-// Structure (work shrinks at every step, wavefronts stay dense):
+// Structure (work shrinks at every step, wavefronts stay dense; the kernel is VALU-issue bound, so every
+// step is written for instruction count):
 //   1. ROI tile -> LDS with aligned dword loads; score map zeroed
 //   A. every pixel: compass pre-test (two ADJACENT ring positions of {0,4,8,12} both darker than
 //      v - tlow or both brighter than v + tlow -- necessary because any 9-arc of the 16-ring holds two
-//      adjacent compass pixels); survivors are appended IN ROW-MAJOR ORDER to an LDS list
+//      adjacent compass pixels), 4 pixels per thread on packed 16-bit lanes.  Each wave owns a contiguous
+//      row-major quarter of the items and appends its survivors, in order, to its own list region;
+//      the four regions concatenated are the row-major survivor list (indexed virtually, never copied)
 //   B. survivors only: full FAST strength -> score map + per-survivor score
 //   C. survivors with a score: 3x3 strict-maximum test, threshold bits, ordered compaction
 // LDS is dynamic and sized for the largest cell of the current image size (FastLds), so the BASELINE
-// config needs ~12 KB per workgroup and 8 workgroups (32 waves) stay resident per CU.
+// config needs ~13 KB per workgroup and 8 workgroups (32 waves) stay resident per CU.
 struct FastLds {
   int tile_pitch, tile_bytes, score_bytes, plist_bytes, pscore_bytes;
   __host__ __device__ int total() const { return tile_bytes + score_bytes + plist_bytes + pscore_bytes; }
 };
+// compile-time pitches the kernel is instantiated for (0 = dynamic fallback)
+__host__ __device__ inline int fast_pick_pitch(int max_rw) {
+  const int need = (max_rw + 3 + 3) & ~3;
+  return need <= 56 ? 56 : (need <= 64 ? 64 : need);
+}
 __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
   FastLds l;
-  l.tile_pitch = (max_rw + 3 + 3) & ~3;
+  l.tile_pitch = fast_pick_pitch(max_rw);
   l.tile_bytes = (l.tile_pitch * max_rh + 15) & ~15;
   const int ew = max_rw - 6 > 0 ? max_rw - 6 : 1, eh = max_rh - 6 > 0 ? max_rh - 6 : 1;
   l.score_bytes = ((((ew + 2 + 3) & ~3) * (eh + 2)) + 15) & ~15;
-  l.plist_bytes = (ew * eh * 2 + 15) & ~15;
+  l.plist_bytes = (((ew + 9) * eh + 16) * 2 + 15) & ~15;   // 4 wave regions of ceil(items/4)*4 entries
   l.pscore_bytes = (ew * eh + 15) & ~15;
   return l;
 }
+// zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
+#define DVM_PERM2(a, b, i0, i1) __builtin_amdgcn_perm((a), (b), 0x0c000c00u | (uint32_t)(i0) | ((uint32_t)(i1) << 16))
+
+template <int PITCH>
 __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                     const CellDesc* __restrict__ cells, PipelineDesc PD,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
                                                     int max_rw, int max_rh, int batch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
-  const int kTilePitch = lay.tile_pitch;
+  const int kTilePitch = PITCH ? PITCH : lay.tile_pitch;
   uint8_t* tile = fast_smem;
   uint8_t* score = tile + lay.tile_bytes;
   uint16_t* plist = reinterpret_cast<uint16_t*>(score + lay.score_bytes);
   uint8_t* pscore = reinterpret_cast<uint8_t*>(plist) + lay.plist_bytes;
   __shared__ int s_cnt_ini;
+  __shared__ int s_tot[4];
   __shared__ int s_wave_tot[33][4];
 
   int cell_id, f;
@@ -309,11 +327,12 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   const int dwr = (sh + rw + 3) >> 2;    // dwords per row
   const uint32_t* g32 = reinterpret_cast<const uint32_t*>(pyr + row0 + (xg - sh));  // stride is a multiple of 64
   uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
+  const int pitch4 = kTilePitch >> 2;
   {
-    int y = tid / dwr, x = tid - y * dwr;          // one division, then incremental
+    int y = (int)(((float)tid + 0.5f) * (1.0f / (float)dwr)), x = tid - y * dwr;   // exact for these small ints
     const int dy = 256 / dwr, dx = 256 - dy * dwr;
     while (y < rh) {
-      t32[y * (kTilePitch / 4) + x] = g32[(int64_t)y * (L.stride >> 2) + x];
+      t32[y * pitch4 + x] = g32[(int64_t)y * (L.stride >> 2) + x];
       x += dx; y += dy;
       if (x >= dwr) { x -= dwr; y++; }
     }
@@ -324,81 +343,92 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   __syncthreads();
 
   const int tlow = min(PD.ini_th, PD.min_th);
-  const int npx = ew * eh;
   const uint8_t* T = tile + sh;
-  // ---- A. compass pre-test, 4 pixels per thread: one item = one LDS dword column c of one row, so the
-  // north / south / centre / west / east bytes of its 4 pixels come from 5 dword reads + 2 v_alignbyte.
-  // Items are walked row-major, survivors keep that order (ballot prefix per byte lane).
-  const int pitch4 = kTilePitch >> 2;
+  // ---- A. compass pre-test.  One item = one LDS dword column of one row = 4 pixels: north / south / centre
+  // dwords plus west / east dwords give all five bytes of each pixel; v_perm_b32 zero-extends byte pairs to
+  // packed u16, the test itself is 9 packed min/max per pixel pair:
+  //   darker  pair (i,j) of adjacent compass points:  v - max(p_i, p_j) > t
+  //   brighter:                                         min(p_i, p_j) - v > t
+  //   pass  <=>  max(v - min_pairs max, max_pairs min - v) > t
   const int c0 = (sh + 3) >> 2, c1 = (sh + 3 + ew - 1) >> 2, ncol = c1 - c0 + 1;
   const int nitems = eh * ncol;
-  const int roundsA = (nitems + 255) >> 8;   // <= 32 for the supported cell sizes
-  uint32_t passbits_lo = 0, passbits_hi = 0, passbits_x = 0, passbits_y = 0;  // 4 bits per round, 8 rounds per word
+  const int Q = (nitems + 3) >> 2;          // items per wave
+  const int roundsA = (Q + 63) >> 6;
+  const int it_end = min(nitems, (wave + 1) * Q);
+  uint16_t* mylist = plist + wave * Q * 4;
+  int wcount = 0;                           // wave-uniform running length of this wave's list
   {
-    int ey = tid / ncol, cc = tid - ey * ncol;
-    const int dy = 256 / ncol, dc = 256 - dy * ncol;
+    int it = wave * Q + lane;
+    int ey = (int)(((float)it + 0.5f) * (1.0f / (float)ncol)), cc = it - ey * ncol;
+    const int dy = 64 / ncol, dc = 64 - dy * ncol;
+    const ushort2_t T2 = pk(tlow, tlow);
     for (int r = 0; r < roundsA; r++) {
       uint32_t pm = 0;
-      if (ey < eh) {
+      int exb = 0;
+      if (it < it_end) {
         const int c = c0 + cc;
         const uint32_t* row = t32 + (ey + 3) * pitch4 + c;
         const uint32_t Cd = row[0], Wd = row[-1], Ed = row[1], Nd = row[3 * pitch4], Sd = row[-3 * pitch4];
-        const uint32_t WB = __builtin_amdgcn_alignbyte(Cd, Wd, 1);  // pixel k's west neighbour (x-3) in byte k
-        const uint32_t EB = __builtin_amdgcn_alignbyte(Ed, Cd, 3);  // east neighbour (x+3)
+        uint32_t q[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int ex = 4 * c + k - sh - 3;
-          const int v = (Cd >> (8 * k)) & 255;
-          const int dn = v - (int)((Nd >> (8 * k)) & 255), ds = v - (int)((Sd >> (8 * k)) & 255);
-          const int de = v - (int)((EB >> (8 * k)) & 255), dw = v - (int)((WB >> (8 * k)) & 255);
-          const bool kn = dn > tlow, ke = de > tlow, ks = ds > tlow, kw = dw > tlow;       // darker
-          const bool bn = dn < -tlow, be = de < -tlow, bs = ds < -tlow, bw = dw < -tlow;   // brighter
-          const bool pass = ((kn & ke) | (ke & ks) | (ks & kw) | (kw & kn) | (bn & be) | (be & bs) | (bs & bw) | (bw & bn)) &&
-                            ex >= 0 && ex < ew;
-          pm |= (pass ? 1u : 0u) << k;
+        for (int h = 0; h < 2; h++) {
+          const ushort2_t C = __builtin_bit_cast(ushort2_t, DVM_PERM2(0u, Cd, 2 * h, 2 * h + 1));
+          const ushort2_t N = __builtin_bit_cast(ushort2_t, DVM_PERM2(0u, Nd, 2 * h, 2 * h + 1));
+          const ushort2_t S = __builtin_bit_cast(ushort2_t, DVM_PERM2(0u, Sd, 2 * h, 2 * h + 1));
+          // west neighbour (x-3) of pixel k = byte k+1 of {Cd:Wd}; east (x+3) = byte k+3 of {Ed:Cd}
+          const ushort2_t W = __builtin_bit_cast(ushort2_t, DVM_PERM2(Cd, Wd, 2 * h + 1, 2 * h + 2));
+          const ushort2_t E = __builtin_bit_cast(ushort2_t, DVM_PERM2(Ed, Cd, 2 * h + 3, 2 * h + 4));
+          const ushort2_t mx = __builtin_elementwise_min(
+              __builtin_elementwise_min(__builtin_elementwise_max(N, E), __builtin_elementwise_max(E, S)),
+              __builtin_elementwise_min(__builtin_elementwise_max(S, W), __builtin_elementwise_max(W, N)));
+          const ushort2_t mn = __builtin_elementwise_max(
+              __builtin_elementwise_max(__builtin_elementwise_min(N, E), __builtin_elementwise_min(E, S)),
+              __builtin_elementwise_max(__builtin_elementwise_min(S, W), __builtin_elementwise_min(W, N)));
+          typedef short short2s __attribute__((ext_vector_type(2)));
+          const short2s dk = __builtin_bit_cast(short2s, C) - __builtin_bit_cast(short2s, mx);   // darker margin
+          const short2s br = __builtin_bit_cast(short2s, mn) - __builtin_bit_cast(short2s, C);   // brighter margin
+          const short2s m = __builtin_elementwise_max(dk, br);
+          q[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2s, T2) - m);  // sign bit of a half set <=> margin > t
         }
+        exb = 4 * c - sh - 3;                                   // evaluated x of byte 0 (may be < 0)
+        const int vlo = max(0, -exb), vhi = min(4, ew - exb);   // valid bytes [vlo, vhi)
+        const uint32_t vmask = (0xFu >> (4 - vhi)) & (0xFu << vlo);
+        pm = (((q[0] >> 15) & 1u) | ((q[0] >> 30) & 2u) | ((q[1] >> 13) & 4u) | ((q[1] >> 28) & 8u)) & vmask;
       }
-      int tot = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) tot += __popcll(__ballot((pm >> k) & 1u));
-      if (lane == 0) s_wave_tot[r][wave] = tot;
-      const uint32_t sh4 = (uint32_t)(r & 7) * 4;
-      if (r < 8) passbits_lo |= pm << sh4; else if (r < 16) passbits_hi |= pm << sh4;
-      else if (r < 24) passbits_x |= pm << sh4; else passbits_y |= pm << sh4;
-      cc += dc; ey += dy;
-      if (cc >= ncol) { cc -= ncol; ey++; }
-    }
-  }
-  __syncthreads();
-  int npass = 0;
-  {
-    int ey = tid / ncol, cc = tid - ey * ncol;
-    const int dy = 256 / ncol, dc = 256 - dy * ncol;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int r = 0; r < roundsA; r++) {
-      const uint32_t word = r < 8 ? passbits_lo : (r < 16 ? passbits_hi : (r < 24 ? passbits_x : passbits_y));
-      const uint32_t pm = (word >> ((r & 7) * 4)) & 15u;
-      int before = 0;
-      for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
       unsigned long long bm[4];
-      int mine = 0;  // survivors of earlier lanes of this wave
+      int mine = 0, tot = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) { bm[k] = __ballot((pm >> k) & 1u); mine += __popcll(bm[k] & lt); }
-      int pos = npass + before + mine;
+      for (int k = 0; k < 4; k++) {
+        bm[k] = __ballot((pm >> k) & 1u);
+        mine += __builtin_amdgcn_mbcnt_hi((uint32_t)(bm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[k], 0u));
+        tot += __popcll(bm[k]);
+      }
+      if (pm) {
+        int pos = wcount + mine;
+        const int e0 = (ey << 7) + exb;
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if ((pm >> k) & 1u) plist[pos++] = (uint16_t)((ey << 7) | (4 * (c0 + cc) + k - sh - 3));
-      npass += s_wave_tot[r][0] + s_wave_tot[r][1] + s_wave_tot[r][2] + s_wave_tot[r][3];
-      cc += dc; ey += dy;
+        for (int k = 0; k < 4; k++)
+          if ((pm >> k) & 1u) mylist[pos++] = (uint16_t)(e0 + k);
+      }
+      wcount += tot;
+      it += 64; cc += dc; ey += dy;
       if (cc >= ncol) { cc -= ncol; ey++; }
     }
   }
+  if (lane == 0) s_tot[wave] = wcount;
   __syncthreads();
-  // ---- B. full strength for the survivors (list is row-major ordered)
+  // virtual concatenation of the four wave lists = row-major survivor list
+  const int p1 = s_tot[0], p2 = p1 + s_tot[1], p3 = p2 + s_tot[2], npass = p3 + s_tot[3];
+  auto entry = [&](int k) -> int {
+    const int w = (k >= p1) + (k >= p2) + (k >= p3);
+    const int base = (k >= p3) ? p3 : ((k >= p2) ? p2 : ((k >= p1) ? p1 : 0));
+    return plist[w * Q * 4 + k - base];
+  };
+  // ---- B. full strength for the survivors
   for (int k = tid; k < npass; k += 256) {
-    const int pe = plist[k];
+    const int pe = entry(k);
     const int ey = pe >> 7, ex = pe & 127;
-    const int m = fast_strength(&T[(ey + 3) * kTilePitch + ex + 3], kTilePitch);
+    const int m = fast_strength<PITCH>(&T[(ey + 3) * kTilePitch + ex + 3], kTilePitch);
     const int sc = m > tlow ? m - 1 : 0;
     pscore[k] = (uint8_t)sc;
     if (sc) score[(ey + 1) * sp + ex + 1] = (uint8_t)sc;
@@ -414,7 +444,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
     if (k < npass) {
       const int sv = pscore[k];
       if (sv > 0) {
-        const int pe = plist[k];
+        const int pe = entry(k);
         const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
         const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
                            max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
@@ -447,7 +477,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
     const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
     if (keep && pos < c.cand_cap) {
       const int k = r * 256 + tid;
-      const int pe = plist[k];
+      const int pe = entry(k);
       // border-relative level coordinates: (roi origin + 3 + e) - 16
       out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), pscore[k]);
     }
@@ -790,12 +820,20 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        fast_lds_layout(kMaxCellDim, kMaxCellDim).total());
+    const int cap = fast_lds_layout(kMaxCellDim, kMaxCellDim).total();
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<56>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(PD.ncells, batch)), dim3(256), lay.total(), s, d_pyr, PD.pyr_frame_bytes,
-                     d_cells, PD, d_cand, d_cell_count, max_rw, max_rh, batch);
+  const dim3 grid(xcd_grid(PD.ncells, batch));
+#define DVM_FAST_LAUNCH(P)                                                                                         \
+  hipLaunchKernelGGL(k_fast_cells<P>, grid, dim3(256), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells, PD, d_cand, \
+                     d_cell_count, max_rw, max_rh, batch)
+  if (lay.tile_pitch == 56) DVM_FAST_LAUNCH(56);
+  else if (lay.tile_pitch == 64) DVM_FAST_LAUNCH(64);
+  else DVM_FAST_LAUNCH(0);
+#undef DVM_FAST_LAUNCH
 }
 void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
                     const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch) {
