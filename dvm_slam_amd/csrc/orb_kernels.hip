@@ -28,8 +28,9 @@ __constant__ int c_pattern[1024] = {
 __constant__ int8_t c_circle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
                                        {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
 // orientation disc: for pixel p of the 749-px disc, (u,v) offsets; filled by the host at init
-__constant__ int8_t c_disc_u[768];
-__constant__ int8_t c_disc_v[768];
+// orientation disc as dot4 weights: item (row v+15, dword c) of the 31 x 32-byte patch rows -> {WU, W1}: byte k of
+// WU = u+16 (u = 4c+k-15) inside the disc else 0, byte k of W1 = 1 inside else 0; filled by the host at init
+__device__ uint2 c_disc_w[256];
 __constant__ int c_gauss7[7];
 
 // XCD-aware (block, frame) mapping for per-frame kernels launched as a 1-D grid of
@@ -76,22 +77,47 @@ __device__ __forceinline__ void store_px4(uint8_t* D, int X4, int w, uint32_t v)
   }
 }
 
+// level 0: thread = 16 destination bytes [X, X+16) (X % 16 == 0 in bordered columns) of FOUR interior rows
+// (y, y+4, y+8, y+12: all loads are issued before the first store).  The source run starts at an arbitrary
+// byte address -> 5 aligned dwords + v_alignbyte, one dwordx4 store per row.  No edge branch: dword addresses
+// are clamped to the row, and the bytes that do not come from the row land in border columns, which
+// k_pyr_borders rewrites afterwards.
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ src, int rows, int cols, int sstride,
                                                     int64_t frame_stride, uint8_t* __restrict__ pyr,
                                                     int pyr_frame_bytes, LevelDesc L) {
-  const int X4 = 16 + (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int y = blockIdx.y;
+  const int X = 16 + (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
+  const int yb = blockIdx.y * 16 + (threadIdx.x >> 6);
   const int f = blockIdx.z;
-  if (X4 - kEdge >= cols) return;
-  const uint8_t* S = src + (int64_t)f * frame_stride + (int64_t)y * sstride;
-  uint32_t v = 0;
+  const int x0 = X - kEdge;
+  if (x0 >= cols) return;
+  const uint8_t* S = src + (int64_t)f * frame_stride;
+  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)kEdge * L.stride;
+  uint4 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int x = X4 + k - kEdge;
-    if (x >= 0 && x < cols) v |= (uint32_t)S[x] << (8 * k);
+  for (int i = 0; i < 4; i++) {
+    const int y = min(yb + 4 * i, rows - 1);
+    const uintptr_t r0 = reinterpret_cast<uintptr_t>(S + (int64_t)y * sstride);
+    const uintptr_t lo = r0 & ~(uintptr_t)3, hi = (r0 + cols - 1) & ~(uintptr_t)3;   // first / last dword of the row
+    const intptr_t a = (intptr_t)r0 + x0;
+    const uintptr_t q = (uintptr_t)(a & ~(intptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    uint32_t d[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      uintptr_t p = q + 4 * j;
+      p = p < lo ? lo : (p > hi ? hi : p);
+      d[j] = *reinterpret_cast<const uint32_t*>(p);
+    }
+    v[i].x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+    v[i].y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+    v[i].z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+    v[i].w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
   }
-  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + y) * L.stride;
-  store_px4(D, X4, cols, v);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int y = yb + 4 * i;
+    if (y < rows) *reinterpret_cast<uint4*>(D + (int64_t)y * L.stride + X) = v[i];
+  }
 }
 
 __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
@@ -158,44 +184,91 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   }
 }
 
-// REFLECT_101 frame of every level in ONE launch, touching border bytes only:
-//   blockIdx.y <  38*nlevels : one full bordered row of the top / bottom strip (19 + 19 rows per level)
-//   blockIdx.y >= 38*nlevels : 16 interior rows per workgroup, 16 threads per row: 5 dwords on the left
-//                              (bordered columns 0..19) and up to 6 on the right
-__global__ void __launch_bounds__(256) k_pyr_borders(uint8_t* __restrict__ pyr, PipelineDesc PD) {
+// REFLECT_101 frame of every level in ONE launch.  Per level, "bordered row" R in [0, h+38):
+//   interior rows (19 <= R < h+19): source row = the row itself, only the 19 + 19 side columns are written
+//   strip rows (top / bottom 19):   source row = the mirrored interior row; the whole row is written
+// Work items:  blockIdx.y <  strip_blocks : 4 strip rows per workgroup, thread = one FULLY INTERIOR 16-byte group
+//                                           (straight dwordx4 copy of the mirrored row)
+//              above                       : 128 bordered rows per workgroup, two threads per row:
+//   left  thread: D[X] = S[38 - X], X = 0..18 -> byte-reversed S[16..39] (5 v_perm); strip rows also copy S[20..31]
+//   right thread: D[X] = S[2w + 36 - X], X = w+19..w+37 -> per destination dword an aligned pair of source dwords,
+//                 v_alignbyte to the 4-byte run, byte reversal; the first dword keeps its interior bytes; strip rows
+//                 also copy the interior dwords after the last full 16-byte group
+// Sources are always INTERIOR pixels of a level, so nothing here depends on another border byte.
+__global__ void __launch_bounds__(256) k_pyr_borders(uint8_t* __restrict__ pyr, PipelineDesc PD, int strip_blocks) {
   const int f = blockIdx.z, tid = threadIdx.x;
-  const int nstrip = 2 * kEdge * PD.nlevels;
-  if ((int)blockIdx.y < nstrip) {
-    const LevelDesc& L = PD.lv[blockIdx.y / (2 * kEdge)];
-    const int r = blockIdx.y % (2 * kEdge);
+  if ((int)blockIdx.y < strip_blocks) {
+    const int sr = blockIdx.y * 4 + (tid >> 6);
+    if (sr >= 2 * kEdge * PD.nlevels) return;
+    const LevelDesc& L = PD.lv[sr / (2 * kEdge)];
+    const int r = sr % (2 * kEdge);
     const int row = r < kEdge ? r : L.h + r;          // bordered row: 0..18 or h+19..h+37
-    const int bw = L.w + 2 * kEdge;
-    const int X4 = (blockIdx.x * 256 + tid) * 4;
-    if (X4 >= bw) return;
+    const int X = 32 + (blockIdx.x * 64 + (tid & 63)) * 16;
+    if (X + 16 > L.w + kEdge) return;
     uint8_t* base = pyr + (int64_t)f * PD.pyr_frame_bytes + L.pyr_off;
-    const uint8_t* S = base + (int64_t)(kEdge + reflect101(row - kEdge, L.h)) * L.stride + kEdge;
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) v |= (uint32_t)S[reflect101(min(X4 + k, bw - 1) - kEdge, L.w)] << (8 * k);
-    *reinterpret_cast<uint32_t*>(base + (int64_t)row * L.stride + X4) = v;   // row pitch is a multiple of 64
+    const uint8_t* S = base + (int64_t)(kEdge + reflect101(row - kEdge, L.h)) * L.stride;
+    *reinterpret_cast<uint4*>(base + (int64_t)row * L.stride + X) = *reinterpret_cast<const uint4*>(S + X);
     return;
   }
   if (blockIdx.x != 0) return;
-  int g = ((int)blockIdx.y - nstrip) * 16 + (tid >> 4), lvl = 0;
-  while (lvl < PD.nlevels && g >= PD.lv[lvl].h) { g -= PD.lv[lvl].h; lvl++; }
+  int g = ((int)blockIdx.y - strip_blocks) * 128 + (tid >> 1), lvl = 0;
+  while (lvl < PD.nlevels && g >= PD.lv[lvl].h + 2 * kEdge) { g -= PD.lv[lvl].h + 2 * kEdge; lvl++; }
   if (lvl >= PD.nlevels) return;
   const LevelDesc& L = PD.lv[lvl];
-  const int j = tid & 15;
-  const int bw = L.w + 2 * kEdge;
-  const int X4 = j < 5 ? 4 * j : ((kEdge + L.w) & ~3) + 4 * (j - 5);
-  if (X4 >= bw) return;
-  uint8_t* D = pyr + (int64_t)f * PD.pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + g) * L.stride;
-  const uint8_t* S = D + kEdge;
+  const int w = L.w;
+  const bool strip = g < kEdge || g >= L.h + kEdge;
+  uint8_t* base = pyr + (int64_t)f * PD.pyr_frame_bytes + L.pyr_off;
+  uint8_t* D = base + (int64_t)g * L.stride;
+  const uint8_t* S = base + (int64_t)(kEdge + reflect101(g - kEdge, L.h)) * L.stride;   // == D for interior rows
+  uint32_t* D32 = reinterpret_cast<uint32_t*>(D);
+  const uint32_t* S32 = reinterpret_cast<const uint32_t*>(S);
+  if (w < 40) {   // tiny level: the mirror may bounce more than once -> generic byte path
+    if (tid & 1) return;
+    for (int X = 0; X < w + 2 * kEdge; X++)
+      if (strip || X < kEdge || X >= w + kEdge) D[X] = S[kEdge + reflect101(X - kEdge, w)];
+    return;
+  }
+  if ((tid & 1) == 0) {
+    uint32_t r[6];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int X = X4 + k, x = X - kEdge;
-    if (X >= bw || (x >= 0 && x < L.w)) continue;
-    D[X] = S[reflect101(x, L.w)];
+    for (int i = 0; i < 6; i++) r[i] = S32[4 + i];          // S[16..39]
+    uint32_t o[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) o[j] = __builtin_amdgcn_perm(r[5 - j], r[4 - j], 0x03040506u);
+    *reinterpret_cast<uint4*>(D) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (strip) *reinterpret_cast<uint4*>(D + 16) = make_uint4(o[4], r[1], r[2], r[3]);
+    else D32[4] = o[4];
+  } else {
+    const int t = 2 * w + 36;
+    const int Xd0 = (w + kEdge) & ~3, nd = ((w + 37) >> 2) - ((w + kEdge) >> 2) + 1;   // <= 6 dwords
+    const int keep = (w + kEdge) - Xd0;                                               // interior bytes of dword 0
+    uint32_t v[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int Xd = Xd0 + 4 * min(j, nd - 1);
+      const int s0 = t - Xd - 3;
+      const uint32_t A = S32[s0 >> 2], B = S32[(s0 >> 2) + 1];
+      v[j] = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(B, A, (uint32_t)(s0 & 3)), 0x00010203u);
+    }
+    if (keep) {
+      const uint32_t m = (1u << (8 * keep)) - 1u;
+      v[0] = (S32[Xd0 >> 2] & m) | (v[0] & ~m);
+    }
+    uint32_t c[3];
+    const int Xc = 32 + ((w + kEdge - 32) & ~15);   // end of the last full interior 16-byte group (w >= 40)
+    const int nc = (Xd0 - Xc) >> 2;                 // interior dwords a strip row still has to copy (0..3)
+    if (strip) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) c[j] = S32[(Xc >> 2) + min(j, max(nc - 1, 0))];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+      if (j < nd) D32[(Xd0 >> 2) + j] = v[j];
+    if (strip) {
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (j < nc) D32[(Xc >> 2) + j] = c[j];
+    }
   }
 }
 
@@ -737,43 +810,85 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float& cs, float& sn
 // One wave per keypoint (4 keypoints per workgroup).  Phase 1: intensity-centroid moments over the
 // 749-px disc of the UN-blurred level (int32, exact, order-free), fastAtan2.  Phase 2: 256 BRIEF
 // tests on the blurred level, pair p = 64*i + lane, packed by 4 wave ballots (bit p%8 of byte p/8).
+// wave64 integer sum: 4 DPP steps inside each row of 16 lanes, then 4 v_readlane + scalar adds (wave-uniform result)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+
+// One wave per keypoint.  The kernel used to be bound by the texture path (20 byte-gather instructions per wave, every
+// lane on its own cache line); now every memory instruction of a wave covers whole row segments:
+//   IC_Angle: the 31 x 31 patch is read as 31 rows x 8 UNALIGNED dwords (4 instructions); the moments are
+//             v_dot4_u32_u8 against the disc weights:  m10 = sum (u+16) I - 16 sum I,  m01 = sum v I  (exact integers)
+//   rBRIEF:   the 37 x 37 blurred patch (pattern radius 18.4) is staged in LDS as 37 rows x 10 dwords (6 instructions);
+//             the 512 rotated samples are LDS byte reads; 256 tests = 4 ballots of 64 lanes
+constexpr int kDescR = 18, kDescPitch = 40, kDescRows = 2 * kDescR + 1;
 __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                      const uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                      PipelineDesc PD, const KpAux* __restrict__ aux,
                                                      const int32_t* __restrict__ n_kp, dvm_keypoint_pod* __restrict__ kps,
                                                      uint8_t* __restrict__ desc, int batch) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescRows * kDescPitch];
   int blk, f;
   if (!xcd_frame_map((PD.kp_cap + 3) / 4, batch, blk, f)) return;
   const int lane = threadIdx.x & 63;
-  const int g = blk * 4 + (threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blk * 4 + wave;
   if (g >= n_kp[f]) return;
   const KpAux a = aux[(int64_t)f * PD.kp_cap + g];
   const LevelDesc& L = PD.lv[a.level];
+  // ---- blurred patch -> LDS (flat addressing of the blurred level, exactly what the byte gathers used to read;
+  // addresses are clamped to the level so the unused corner bytes of edge keypoints never leave the buffer)
+  const uint8_t* bl = blur + (int64_t)f * blur_frame_bytes + L.blur_off;
+  const int st = L.blur_stride;
+  const int bmax = st * L.h - 4;
+  uint8_t* P = s_patch[wave];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int item = lane + 64 * i;
+    const int r = (item * 205) >> 11, c = item - 10 * r;   // item / 10 for item < 1024
+    if (item < kDescRows * 10) {
+      const int off = min(max((a.cy - kDescR + r) * st + a.cx - kDescR + 4 * c, 0), bmax);
+      uint32_t v;
+      __builtin_memcpy(&v, bl + off, 4);
+      *reinterpret_cast<uint32_t*>(P + r * kDescPitch + 4 * c) = v;
+    }
+  }
+  // ---- IC_Angle
   const uint8_t* c0 = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + a.cy) * L.stride + kEdge + a.cx;
   int m10 = 0, m01 = 0;
-  for (int p = lane; p < kDiscPixels; p += 64) {
-    int u = c_disc_u[p], v = c_disc_v[p];
-    int val = c0[v * L.stride + u];
-    m10 += u * val;
-    m01 += v * val;
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    m10 += __shfl_xor(m10, off);
-    m01 += __shfl_xor(m01, off);
+  for (int i = 0; i < 4; i++) {
+    const int item = lane + 64 * i;            // rows 0..30 (item 248..255: weights are zero, row clamped)
+    const int r = min(item >> 3, 30), c = item & 7;
+    uint32_t v;
+    __builtin_memcpy(&v, c0 + (r - kHalfPatch) * L.stride + 4 * c - kHalfPatch, 4);
+    const uint2 w = c_disc_w[item];
+    const int s1 = (int)__builtin_amdgcn_udot4(v, w.y, 0u, false);
+    const int su = (int)__builtin_amdgcn_udot4(v, w.x, 0u, false);
+    m10 += su - 16 * s1;
+    m01 += (r - kHalfPatch) * s1;
   }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   float ca, sb;
   sincos_deg(angle, ca, sb);
-  const uint8_t* c1 = blur + (int64_t)f * blur_frame_bytes + L.blur_off + (int64_t)a.cy * L.blur_stride + a.cx;
-  const int st = L.blur_stride;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint8_t* c1 = P + kDescR * kDescPitch + kDescR;
   unsigned long long words[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int* pt = &c_pattern[(64 * i + lane) * 4];
     float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-    int t0 = c1[__float2int_rn(x0 * sb + y0 * ca) * st + __float2int_rn(x0 * ca - y0 * sb)];
-    int t1 = c1[__float2int_rn(x1 * sb + y1 * ca) * st + __float2int_rn(x1 * ca - y1 * sb)];
+    int t0 = c1[__float2int_rn(x0 * sb + y0 * ca) * kDescPitch + __float2int_rn(x0 * ca - y0 * sb)];
+    int t1 = c1[__float2int_rn(x1 * sb + y1 * ca) * kDescPitch + __float2int_rn(x1 * ca - y1 * sb)];
     words[i] = __ballot(t0 < t1);
   }
   if (lane == 0) {
@@ -787,15 +902,22 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gauss7) {
-  hipMemcpyToSymbol(HIP_SYMBOL(c_disc_u), disc_u, kDiscPixels);
-  hipMemcpyToSymbol(HIP_SYMBOL(c_disc_v), disc_v, kDiscPixels);
+  uint2 w[256];
+  for (int i = 0; i < 256; i++) w[i] = make_uint2(0u, 0u);
+  for (int p = 0; p < kDiscPixels; p++) {
+    const int u = disc_u[p], v = disc_v[p];
+    const int item = (v + kHalfPatch) * 8 + ((u + kHalfPatch) >> 2), k = (u + kHalfPatch) & 3;
+    w[item].x |= (uint32_t)(u + 16) << (8 * k);
+    w[item].y |= 1u << (8 * k);
+  }
+  hipMemcpyToSymbol(HIP_SYMBOL(c_disc_w), w, sizeof(w));
   hipMemcpyToSymbol(HIP_SYMBOL(c_gauss7), gauss7, 7 * sizeof(int));
 }
 
 void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
                        uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
   const LevelDesc& L = PD.lv[0];
-  dim3 grid(cdiv(cdiv(L.w + 3, 4), 256), L.h, batch);
+  dim3 grid(cdiv(cdiv(L.w + 3, 16), 64), cdiv(L.h, 16), batch);
   hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_src, rows, cols, sstride, frame_stride, d_pyr,
                      PD.pyr_frame_bytes, L);
 }
@@ -811,9 +933,10 @@ void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, in
 }
 void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
   int rows = 0, maxw = 0;
-  for (int l = 0; l < PD.nlevels; l++) { rows += PD.lv[l].h; maxw = std::max(maxw, PD.lv[l].w + 2 * kEdge); }
-  dim3 grid(cdiv(cdiv(maxw, 4), 256), 2 * kEdge * PD.nlevels + cdiv(rows, 16), batch);
-  hipLaunchKernelGGL(k_pyr_borders, grid, dim3(256), 0, s, d_pyr, PD);
+  for (int l = 0; l < PD.nlevels; l++) { rows += PD.lv[l].h + 2 * kEdge; maxw = std::max(maxw, PD.lv[l].w + 2 * kEdge); }
+  const int strip_blocks = cdiv(2 * kEdge * PD.nlevels, 4);
+  dim3 grid(std::max(1, cdiv(cdiv(maxw, 16), 64)), strip_blocks + cdiv(rows, 128), batch);
+  hipLaunchKernelGGL(k_pyr_borders, grid, dim3(256), 0, s, d_pyr, PD, strip_blocks);
 }
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh) {

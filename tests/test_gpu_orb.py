@@ -63,6 +63,8 @@ def test_end_to_end_sizes(capi, oracle, shape):
         assert (n_g, m_g) == (n_o, m_o), (shape, lap)
         _same_kps(k_g, k_o)
         assert np.array_equal(d_g, d_o)
+    for l in range(8):   # REFLECT_101 frame at every width alignment (vectorised border kernel)
+        assert np.array_equal(e.debug_level(0, l, bordered=True), orc.level(l, bordered=True)), (shape, l)
     e.close()
 
 
