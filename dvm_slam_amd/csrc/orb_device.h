@@ -5,6 +5,7 @@
 namespace dvm {
 
 constexpr int kEdge = 19;        // EDGE_THRESHOLD, reference ORBextractor.cc:72
+constexpr int kBlurTW = 64, kBlurTH = 64;  // k_blur7 output tile
 constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, :71
 constexpr int kMaxLevels = 16;
 constexpr int kMaxCellDim = 96;  // ROI side (wCell+6) upper bound: wCell < 70 for W=35 cells

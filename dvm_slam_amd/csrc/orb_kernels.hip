@@ -688,15 +688,24 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ s
 // out = (sum_j sum_i k[j] k[i] src + 32768) >> 16 with the 8.8 kernel [18,34,48,56,48,34,18].
 // The pyramid's 19-px REFLECT_101 frame already holds the mirrored pixels, so the tile loader just
 // reads the bordered buffer.  Tile = 64 x 32 outputs, LDS: raw (38 x 70) u8 + hpass (38 x 64) u16.
-constexpr int kBlurTW = 64, kBlurTH = 32;
 constexpr int kRawPitch = 72;   // bytes: 64 + 6 halo, rounded to dwords (tile rows are dword aligned: x0 % 64 == 0)
-constexpr int kHpPitch = 68;    // u16 elements (136 B): de-phases the 64-bit column reads of the v-pass
+constexpr int kHtPitch = 37;    // dwords per COLUMN of the transposed h-pass buffer: 35 row pairs, odd -> conflict-free
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
+// GaussianBlur 7x7 sigma 2, OpenCV's 8-bit fixed-point path: h-pass 8.8 (u16), v-pass 16.16 accumulate, +0.5, >> 16.
+// The kernel is VALU-bound, so both passes run on the dot-product units:
+//   h-pass: out(x) = v_dot4_u32_u8(bytes x-3..x, (g0,g1,g2,g3)) + v_dot4_u32_u8(bytes x+1..x+4, (g2,g1,g0,0));
+//           one item = 4 columns x 2 rows, written as (row, row+1) u16 pairs into a column-major LDS buffer
+//   v-pass: out(y) = sum of four v_dot2_u32_u16 over vertical pairs; one item = 4 columns x 4 rows, odd rows use
+//           pairs re-aligned with v_alignbyte; rounding constant rides in the accumulator operand
 __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                const TileDesc* __restrict__ tiles, PipelineDesc PD,
                                                const int32_t* __restrict__ nsel, int batch) {
   __shared__ __attribute__((aligned(16))) uint8_t raw[(kBlurTH + 6) * kRawPitch];
-  __shared__ __attribute__((aligned(16))) uint16_t hp[(kBlurTH + 6) * kHpPitch];
+  __shared__ __attribute__((aligned(16))) uint32_t hpt[kBlurTW * kHtPitch];
   const int tid = threadIdx.x;
   int tile_id, f;
   if (!xcd_frame_map(PD.ntiles, batch, tile_id, f)) return;
@@ -710,47 +719,66 @@ __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, 
   const uint32_t* g32 = reinterpret_cast<const uint32_t*>(pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off +
                                                           (int64_t)(kEdge + t.y0 - 3) * L.stride + colb);
   uint32_t* r32 = reinterpret_cast<uint32_t*>(raw);
-  for (int i = tid; i < (th + 6) * (kRawPitch / 4); i += 256) {
-    const int y = i / (kRawPitch / 4), x = i - y * (kRawPitch / 4);
-    r32[i] = (x < ndw) ? g32[(int64_t)y * (L.stride >> 2) + x] : 0u;
+  {
+    int y = tid / 18, x = tid - 18 * y;           // 256 = 14 * 18 + 4
+    while (y < th + 6) {
+      r32[y * 18 + x] = (x < ndw) ? g32[(int64_t)y * (L.stride >> 2) + x] : 0u;
+      x += 4; y += 14;
+      if (x >= 18) { x -= 18; y++; }
+    }
   }
   __syncthreads();
-  const int g0 = c_gauss7[0], g1 = c_gauss7[1], g2 = c_gauss7[2], g3 = c_gauss7[3];
-  // h-pass: one item = 4 adjacent outputs of one row (10 source bytes), 8.8 fixed point
-  for (int i = tid; i < (th + 6) * 16; i += 256) {
-    const int y = i >> 4, g = i & 15;
-    const uint8_t* r = &raw[y * kRawPitch + 4 * g];
-    int p[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) p[k] = r[k];
+  const uint32_t g0 = c_gauss7[0], g1 = c_gauss7[1], g2 = c_gauss7[2], g3 = c_gauss7[3];
+  const uint32_t GA = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), GB = g2 | (g1 << 8) | (g0 << 16);
+  // h-pass
+  const int npair = (th + 7) >> 1;
+  for (int i = tid; i < npair * 16; i += 256) {
+    const int yp = i >> 4, g = i & 15;
+    const uint32_t* ra = r32 + (2 * yp) * 18 + g;
+    const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = ra[18], b1 = ra[19], b2 = ra[20];
     uint32_t o[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = g0 * (p[k] + p[k + 6]) + g1 * (p[k + 1] + p[k + 5]) + g2 * (p[k + 2] + p[k + 4]) + g3 * p[k + 3];
-    uint2 w;
-    w.x = o[0] | (o[1] << 16);
-    w.y = o[2] | (o[3] << 16);
-    *reinterpret_cast<uint2*>(&hp[y * kHpPitch + 4 * g]) = w;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t wa0 = k ? __builtin_amdgcn_alignbyte(a1, a0, k) : a0, wa1 = k ? __builtin_amdgcn_alignbyte(a2, a1, k) : a1;
+      const uint32_t wb0 = k ? __builtin_amdgcn_alignbyte(b1, b0, k) : b0, wb1 = k ? __builtin_amdgcn_alignbyte(b2, b1, k) : b1;
+      const uint32_t ha = __builtin_amdgcn_udot4(wa1, GB, __builtin_amdgcn_udot4(wa0, GA, 0u, false), false);
+      const uint32_t hb = __builtin_amdgcn_udot4(wb1, GB, __builtin_amdgcn_udot4(wb0, GA, 0u, false), false);
+      o[k] = ha | (hb << 16);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) hpt[(4 * g + k) * kHtPitch + yp] = o[k];
   }
   __syncthreads();
-  // v-pass: one item = 4 adjacent columns of one output row, 16.16 accumulate, round to nearest
+  // v-pass
+  const uint32_t W01 = g0 | (g1 << 16), W23 = g2 | (g3 << 16), W21 = g2 | (g1 << 16), W0 = g0;
   uint8_t* dst = blur + (int64_t)f * blur_frame_bytes + L.blur_off + (int64_t)t.y0 * L.blur_stride + t.x0;
-  for (int i = tid; i < th * 16; i += 256) {
-    const int y = i >> 4, g = i & 15;
-    uint32_t acc[4] = {0, 0, 0, 0};
+  for (int i = tid; i < ((th + 3) >> 2) * 16; i += 256) {
+    const int gy = i >> 4, gx = i & 15;
+    uint32_t acc[4][4];   // [row][column]
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-      const uint2 w = *reinterpret_cast<const uint2*>(&hp[(y + j) * kHpPitch + 4 * g]);
-      const uint32_t k = (uint32_t)c_gauss7[j];
-      acc[0] += k * (w.x & 0xFFFFu);
-      acc[1] += k * (w.x >> 16);
-      acc[2] += k * (w.y & 0xFFFFu);
-      acc[3] += k * (w.y >> 16);
+    for (int c = 0; c < 4; c++) {
+      const uint32_t* col = hpt + (4 * gx + c) * kHtPitch + 2 * gy;
+      uint32_t P[6], Q[5];
+#pragma unroll
+      for (int j = 0; j < 6; j++) P[j] = col[j];
+#pragma unroll
+      for (int j = 0; j < 5; j++) Q[j] = __builtin_amdgcn_alignbyte(P[j + 1], P[j], 2);
+      acc[0][c] = udot2(P[3], W0, udot2(P[2], W21, udot2(P[1], W23, udot2(P[0], W01, 32768u))));
+      acc[1][c] = udot2(Q[3], W0, udot2(Q[2], W21, udot2(Q[1], W23, udot2(Q[0], W01, 32768u))));
+      acc[2][c] = udot2(P[4], W0, udot2(P[3], W21, udot2(P[2], W23, udot2(P[1], W01, 32768u))));
+      acc[3][c] = udot2(Q[4], W0, udot2(Q[3], W21, udot2(Q[2], W23, udot2(Q[1], W01, 32768u))));
     }
-    uint32_t out = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) out |= min((acc[k] + 32768u) >> 16, 255u) << (8 * k);
-    // the blurred image's pitch is a multiple of 64, so a full dword store never leaves the row
-    *reinterpret_cast<uint32_t*>(dst + (int64_t)y * L.blur_stride + 4 * g) = out;
+    for (int r = 0; r < 4; r++) {
+      const int y = 4 * gy + r;
+      if (y < th) {
+        // byte 2 of each accumulator = (acc >> 16) & 255 (the sum never reaches 256 << 16)
+        const uint32_t lo = __builtin_amdgcn_perm(acc[r][1], acc[r][0], 0x0c0c0602u);
+        const uint32_t hi = __builtin_amdgcn_perm(acc[r][3], acc[r][2], 0x06020c0cu);
+        // the blurred image's pitch is a multiple of 64, so a full dword store never leaves the row
+        *reinterpret_cast<uint32_t*>(dst + (int64_t)y * L.blur_stride + 4 * gx) = lo | hi;
+      }
+    }
   }
 }
 

@@ -410,8 +410,8 @@ int OrbPipeline::configure(int rows, int cols) {
     }
     D.cell_count = (int)cells.size() - D.cell_first;
     D.cand_cap = cand_off - D.cand_off;
-    for (int y = 0; y < D.h; y += 32)
-      for (int x = 0; x < D.w; x += 64) tiles.push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
+    for (int y = 0; y < D.h; y += kBlurTH)
+      for (int x = 0; x < D.w; x += kBlurTW) tiles.push_back(TileDesc{(int16_t)l, (int16_t)x, (int16_t)y, 0});
   }
   max_cell_rw = max_cell_rh = 8;
   for (const CellDesc& c : cells) { max_cell_rw = std::max<int>(max_cell_rw, c.rw); max_cell_rh = std::max<int>(max_cell_rh, c.rh); }
