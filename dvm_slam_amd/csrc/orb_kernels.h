@@ -27,7 +27,7 @@ void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
                      int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch);
 void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
-                 const int32_t* d_nsel, int batch);
+                 const int32_t* d_lvl_start, int batch);
 void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
                         const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch);
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "orb_device.h"
 #include "orb_kernels.h"
@@ -46,6 +47,12 @@ __device__ __forceinline__ bool xcd_frame_map(int blocks_per_frame, int batch, i
   return f < batch;
 }
 static inline int xcd_grid(int blocks_per_frame, int batch) { return blocks_per_frame * 8 * ((batch + 7) / 8); }
+
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+// v_dot2_u32_u16: a.lo * b.lo + a.hi * b.hi + c
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
 
 __device__ __forceinline__ int reflect101(int p, int len) {
   if (len == 1) return 0;
@@ -141,13 +148,19 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   const uint8_t* Sg = pyr + (int64_t)f * pyr_frame_bytes + P.pyr_off + (int64_t)(kEdge + sya) * P.stride + ga;
   uint32_t* lds32 = reinterpret_cast<uint32_t*>(rz_smem);
   const int nrow = syb - sya + 1;
-  for (int i = tid; i < nrow * ndw; i += 256) {
-    const int r = i / ndw, c = i - r * ndw;
-    lds32[r * (lds_pitch >> 2) + c] = reinterpret_cast<const uint32_t*>(Sg + (int64_t)r * P.stride)[c];
+  {
+    int r = (int)(((float)tid + 0.5f) * (1.0f / (float)ndw)), c = tid - r * ndw;   // exact for these small ints
+    const int dr = 256 / ndw, dc = 256 - dr * ndw;
+    while (r < nrow) {
+      lds32[r * (lds_pitch >> 2) + c] = reinterpret_cast<const uint32_t*>(Sg + (int64_t)r * P.stride)[c];
+      c += dc; r += dr;
+      if (c >= ndw) { c -= ndw; r++; }
+    }
   }
   __syncthreads();
   const int X4 = X0 + 4 * tx;
-  int sx[4], a0[4], a1[4];
+  int sx[4];
+  uint32_t al[4];   // (a0 | a1 << 16): the two 11-bit horizontal weights, ready for v_dot2_u32_u16
   bool any = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -156,8 +169,7 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
     any |= ok;
     const int dxc = min(max(dx, 0), L.w - 1);
     sx[k] = kEdge + xofs[dxc] - ga;
-    const int aa = xal[dxc];
-    a0[k] = (int16_t)(aa & 0xFFFF); a1[k] = (int16_t)(aa >> 16);
+    al[k] = (uint32_t)xal[dxc];
   }
   if (!any) return;
 #pragma unroll
@@ -166,18 +178,20 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
     if (dy >= L.h) break;
     const int sy = yofs[dy];
     const int r0 = min(max(sy, 0), P.h - 1) - sya, r1 = min(max(sy + 1, 0), P.h - 1) - sya;
-    const int bb = ybe[dy];
-    const int b0 = (int16_t)(bb & 0xFFFF), b1 = (int16_t)(bb >> 16);
+    const uint32_t bb = (uint32_t)ybe[dy];
+    const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
     const uint8_t* S0 = rz_smem + r0 * lds_pitch;
     const uint8_t* S1 = rz_smem + r1 * lds_pitch;
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int h0 = S0[sx[k]] * a0[k] + S0[sx[k] + 1] * a1[k];
-      const int h1 = S1[sx[k]] * a0[k] + S1[sx[k] + 1] * a1[k];
-      int r = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      r = min(max(r, 0), 255);
-      v |= (uint32_t)r << (8 * k);
+      // (unaligned LDS u16 reads are slow on gfx950 -- measured 2x on the whole pyramid -- so two byte reads per row)
+      const uint32_t s00 = S0[sx[k]], s01 = S0[sx[k] + 1], s10 = S1[sx[k]], s11 = S1[sx[k] + 1];
+      const uint32_t h0 = udot2(s00 | (s01 << 16), al[k], 0u);
+      const uint32_t h1 = udot2(s10 | (s11 << 16), al[k], 0u);
+      // ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2; a convex combination, never above 255
+      const uint32_t r = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
+      v |= r << (8 * k);
     }
     uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + dy) * L.stride;
     store_px4(D, X4, L.w, v);
@@ -364,8 +378,8 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
 // zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
 #define DVM_PERM2(a, b, i0, i1) __builtin_amdgcn_perm((a), (b), 0x0c000c00u | (uint32_t)(i0) | ((uint32_t)(i1) << 16))
 
-template <int PITCH>
-__global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
+template <int PITCH, int NW>
+__global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                     const CellDesc* __restrict__ cells, PipelineDesc PD,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
                                                     int max_rw, int max_rh, int batch) {
@@ -377,8 +391,9 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   uint16_t* plist = reinterpret_cast<uint16_t*>(score + lay.score_bytes);
   uint8_t* pscore = reinterpret_cast<uint8_t*>(plist) + lay.plist_bytes;
   __shared__ int s_cnt_ini;
-  __shared__ int s_tot[4];
-  __shared__ int s_wave_tot[33][4];
+  constexpr int NT = 64 * NW;   // NW = 2 for small cells: fewer half-empty rounds and half the per-wave fixed cost
+  __shared__ int s_tot[NW];
+  __shared__ int s_wave_tot[33][NW];
 
   int cell_id, f;
   if (!xcd_frame_map(PD.ncells, batch, cell_id, f)) return;
@@ -403,7 +418,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   const int pitch4 = kTilePitch >> 2;
   {
     int y = (int)(((float)tid + 0.5f) * (1.0f / (float)dwr)), x = tid - y * dwr;   // exact for these small ints
-    const int dy = 256 / dwr, dx = 256 - dy * dwr;
+    const int dy = NT / dwr, dx = NT - dy * dwr;
     while (y < rh) {
       t32[y * pitch4 + x] = g32[(int64_t)y * (L.stride >> 2) + x];
       x += dx; y += dy;
@@ -411,7 +426,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
     }
   }
   uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
-  for (int i = tid; i < (sp * (eh + 2)) >> 2; i += 256) s32[i] = 0;
+  for (int i = tid; i < (sp * (eh + 2)) >> 2; i += NT) s32[i] = 0;
   if (tid == 0) s_cnt_ini = 0;
   __syncthreads();
 
@@ -425,7 +440,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   //   pass  <=>  max(v - min_pairs max, max_pairs min - v) > t
   const int c0 = (sh + 3) >> 2, c1 = (sh + 3 + ew - 1) >> 2, ncol = c1 - c0 + 1;
   const int nitems = eh * ncol;
-  const int Q = (nitems + 3) >> 2;          // items per wave
+  const int Q = (nitems + NW - 1) / NW;     // items per wave
   const int roundsA = (Q + 63) >> 6;
   const int it_end = min(nitems, (wave + 1) * Q);
   uint16_t* mylist = plist + wave * Q * 4;
@@ -491,14 +506,17 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   if (lane == 0) s_tot[wave] = wcount;
   __syncthreads();
   // virtual concatenation of the four wave lists = row-major survivor list
-  const int p1 = s_tot[0], p2 = p1 + s_tot[1], p3 = p2 + s_tot[2], npass = p3 + s_tot[3];
+  const int p1 = s_tot[0], p2 = NW > 1 ? p1 + s_tot[NW > 1 ? 1 : 0] : p1, p3 = NW > 2 ? p2 + s_tot[NW > 2 ? 2 : 0] : p2;
+  const int npass = NW > 2 ? p3 + s_tot[NW > 2 ? 3 : 0] : p2;
   auto entry = [&](int k) -> int {
+    if (NW == 1) return plist[k];
+    if (NW == 2) return plist[(k >= p1) ? Q * 4 + k - p1 : k];
     const int w = (k >= p1) + (k >= p2) + (k >= p3);
     const int base = (k >= p3) ? p3 : ((k >= p2) ? p2 : ((k >= p1) ? p1 : 0));
     return plist[w * Q * 4 + k - base];
   };
   // ---- B. full strength for the survivors
-  for (int k = tid; k < npass; k += 256) {
+  for (int k = tid; k < npass; k += NT) {
     const int pe = entry(k);
     const int ey = pe >> 7, ex = pe & 127;
     const int m = fast_strength<PITCH>(&T[(ey + 3) * kTilePitch + ex + 3], kTilePitch);
@@ -508,11 +526,11 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   }
   __syncthreads();
   // ---- C. strict local maxima among the survivors; bit0 = passes iniTh, bit1 = passes minTh
-  const int rounds = (npass + 255) >> 8;
+  const int rounds = (npass + NT - 1) / NT;
   uint32_t flags_lo = 0, flags_hi = 0;  // 2 bits per round, up to 32 rounds
   int cnt_ini = 0;
   for (int r = 0; r < rounds; r++) {
-    const int k = r * 256 + tid;
+    const int k = r * NT + tid;
     int fl = 0;
     if (k < npass) {
       const int sv = pscore[k];
@@ -532,7 +550,7 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
   __syncthreads();
   const int bit = (s_cnt_ini > 0) ? 1 : 2;  // first call non-empty -> keep it, else the retry's result
 
-  // ordered compaction: survivor index k = r*256 + tid is row-major, so emit in increasing k
+  // ordered compaction: survivor index k = r*NT + tid is row-major, so emit in increasing k
   for (int r = 0; r < rounds; r++) {
     const int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
     const unsigned long long m = __ballot((fl & bit) != 0);
@@ -549,12 +567,13 @@ __global__ void __launch_bounds__(256) k_fast_cells(const uint8_t* __restrict__ 
     for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
     const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
     if (keep && pos < c.cand_cap) {
-      const int k = r * 256 + tid;
+      const int k = r * NT + tid;
       const int pe = entry(k);
       // border-relative level coordinates: (roi origin + 3 + e) - 16
       out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), pscore[k]);
     }
-    base += s_wave_tot[r][0] + s_wave_tot[r][1] + s_wave_tot[r][2] + s_wave_tot[r][3];
+#pragma unroll
+    for (int w = 0; w < NW; w++) base += s_wave_tot[r][w];
   }
   if (tid == 0) *my_count = min(base, c.cand_cap);
 }
@@ -690,10 +709,6 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ s
 // reads the bordered buffer.  Tile = 64 x 32 outputs, LDS: raw (38 x 70) u8 + hpass (38 x 64) u16.
 constexpr int kRawPitch = 72;   // bytes: 64 + 6 halo, rounded to dwords (tile rows are dword aligned: x0 % 64 == 0)
 constexpr int kHtPitch = 37;    // dwords per COLUMN of the transposed h-pass buffer: 35 row pairs, odd -> conflict-free
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
-}
 // GaussianBlur 7x7 sigma 2, OpenCV's 8-bit fixed-point path: h-pass 8.8 (u16), v-pass 16.16 accumulate, +0.5, >> 16.
 // The kernel is VALU-bound, so both passes run on the dot-product units:
 //   h-pass: out(x) = v_dot4_u32_u8(bytes x-3..x, (g0,g1,g2,g3)) + v_dot4_u32_u8(bytes x+1..x+4, (g2,g1,g0,0));
@@ -703,14 +718,17 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
 __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                const TileDesc* __restrict__ tiles, PipelineDesc PD,
-                                               const int32_t* __restrict__ nsel, int batch) {
+                                               const int32_t* __restrict__ lvl_start, int batch) {
   __shared__ __attribute__((aligned(16))) uint8_t raw[(kBlurTH + 6) * kRawPitch];
   __shared__ __attribute__((aligned(16))) uint32_t hpt[kBlurTW * kHtPitch];
   const int tid = threadIdx.x;
   int tile_id, f;
   if (!xcd_frame_map(PD.ntiles, batch, tile_id, f)) return;
   const TileDesc t = tiles[tile_id];
-  if (nsel[f * PD.nlevels + t.level] == 0) return;  // reference skips levels without keypoints (:915-916)
+  // the reference skips levels without keypoints (:915-916); a level has keypoints iff it has FAST candidates
+  // (the octree keeps >= 1 of n > 0), which is known before the octree runs -> the blur overlaps with it
+  const int32_t* ls = lvl_start + (int64_t)f * (kMaxLevels + 1) + t.level;
+  if (ls[1] == ls[0]) return;
   const LevelDesc& L = PD.lv[t.level];
   const int th = min(kBlurTH, L.h - t.y0);
   // raw tile: rows y0-3 .. y0+th+2, bordered columns (16 + x0) .. +71 as 18 aligned dwords per row
@@ -970,20 +988,25 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh) {
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
   static bool attr_set = false;
+  const int cap = fast_lds_layout(kMaxCellDim, kMaxCellDim).total();
+#define DVM_FAST_ATTR(P, W) \
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<P, W>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)
   if (!attr_set) {
-    const int cap = fast_lds_layout(kMaxCellDim, kMaxCellDim).total();
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<56>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    DVM_FAST_ATTR(56, 1); DVM_FAST_ATTR(56, 2); DVM_FAST_ATTR(64, 2); DVM_FAST_ATTR(56, 4); DVM_FAST_ATTR(64, 4); DVM_FAST_ATTR(0, 4);
     attr_set = true;
   }
+#undef DVM_FAST_ATTR
   const dim3 grid(xcd_grid(PD.ncells, batch));
-#define DVM_FAST_LAUNCH(P)                                                                                         \
-  hipLaunchKernelGGL(k_fast_cells<P>, grid, dim3(256), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells, PD, d_cand, \
-                     d_cell_count, max_rw, max_rh, batch)
-  if (lay.tile_pitch == 56) DVM_FAST_LAUNCH(56);
-  else if (lay.tile_pitch == 64) DVM_FAST_LAUNCH(64);
-  else DVM_FAST_LAUNCH(0);
+  // two waves per cell while 32 survivor rounds of 128 cover the largest cell, else four
+  const bool small = (max_rw - 6) * (max_rh - 6) <= 32 * 128;
+#define DVM_FAST_LAUNCH(P, W)                                                                                          \
+  hipLaunchKernelGGL((k_fast_cells<P, W>), grid, dim3(64 * W), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells, PD, \
+                     d_cand, d_cell_count, max_rw, max_rh, batch)
+  static const bool one_wave = getenv("DVM_FAST_NW1") != nullptr;
+  if (lay.tile_pitch == 56 && one_wave && (max_rw - 6) * (max_rh - 6) <= 32 * 64) DVM_FAST_LAUNCH(56, 1);
+  else if (lay.tile_pitch == 56) { if (small) DVM_FAST_LAUNCH(56, 2); else DVM_FAST_LAUNCH(56, 4); }
+  else if (lay.tile_pitch == 64) { if (small) DVM_FAST_LAUNCH(64, 2); else DVM_FAST_LAUNCH(64, 4); }
+  else DVM_FAST_LAUNCH(0, 4);
 #undef DVM_FAST_LAUNCH
 }
 void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
@@ -996,9 +1019,9 @@ void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel
   hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(256), 0, s, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono);
 }
 void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
-                 const int32_t* d_nsel, int batch) {
+                 const int32_t* d_lvl_start, int batch) {
   hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(PD.ntiles, batch)), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes, d_blur,
-                     PD.blur_frame_bytes, d_tiles, PD, d_nsel, batch);
+                     PD.blur_frame_bytes, d_tiles, PD, d_lvl_start, batch);
 }
 void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
                         const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch) {

@@ -270,7 +270,7 @@ int OrbPipeline::init() {
   DVM_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
   DVM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   DVM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  if (const char* e = getenv("DVM_DUAL_STREAM")) dual_stream = (e[0] == '1');  // two half-batches on two streams
+  if (const char* e = getenv("DVM_SERIAL")) overlap_blur = (e[0] != '1');      // debug / A-B switch only
   if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree = (e[0] == '1');  // debug / A-B switch only
   // orientation disc offsets (any order: the moments are exact integer sums)
   int8_t du[kDiscPixels], dv[kDiscPixels];
@@ -493,9 +493,9 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   const int L = PD.nlevels;
   last_batch = batch;
 
-  // The batch is processed as two halves on two HIP streams: latency-bound stages of one half
-  // (7 dependent pyramid launches, the single-lane std::sort emulation inside k_octree) overlap with
-  // throughput-bound stages (FAST, blur) of the other.  `stream` stays the handle's ordering point.
+  // One in-order pipeline on `stream`, except the blur: it depends only on the pyramid and on the per-level candidate
+  // counts, so it runs on `stream2` concurrently with the latency-bound k_octree (one workgroup per level whose
+  // critical path is a single-lane std::sort emulation) and joins before the descriptors.  DVM_SERIAL=1 disables it.
   auto run_half = [&](hipStream_t st, int f0, int nb) -> int {
     prof.begin(st, "pyramid");
     launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
@@ -509,6 +509,15 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     launch_compact(st, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), d_cells, PD, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
     prof.end(st);
 
+    const bool blur_forked = overlap_blur && !host_octree && stream2 != nullptr;
+    if (blur_forked) {
+      DVM_HIP(hipEventRecord(ev_fork, st));
+      DVM_HIP(hipStreamWaitEvent(stream2, ev_fork, 0));
+      prof.begin(stream2, "blur");
+      launch_blur(stream2, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
+      prof.end(stream2);
+      DVM_HIP(hipEventRecord(ev_join, stream2));
+    }
     if (!host_octree) {
       prof.begin(st, "octree");
       launch_octree(st, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), PD, (d_nid + (size_t)f0 * PD.cand_frame_slots), (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), d_err, nb);
@@ -554,30 +563,21 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.begin(st, "assemble");
     launch_assemble(st, (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), PD, lap0, lap1, (d_kps + (size_t)f0 * PD.kp_cap), (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_mono + f0), nb);
     prof.end(st);
-    prof.begin(st, "blur");
-    launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_nsel + (size_t)f0 * L), nb);
-    prof.end(st);
+    if (!blur_forked) {
+      prof.begin(st, "blur");
+      launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
+      prof.end(st);
+    } else {
+      DVM_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    }
     prof.begin(st, "orient_desc");
     launch_orient_desc(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), PD, (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_kps + (size_t)f0 * PD.kp_cap), (d_desc + (size_t)f0 * PD.kp_cap * 32), nb);
     prof.end(st);
 
     return DVM_OK;
   };
-  const bool dual = dual_stream && !host_octree && batch >= 2 && stream2 != nullptr;
-  if (!dual) {
-    rc = run_half(stream, 0, batch);
-    if (rc != DVM_OK) return rc;
-  } else {
-    const int h1 = batch / 2;
-    DVM_HIP(hipEventRecord(ev_fork, stream));
-    DVM_HIP(hipStreamWaitEvent(stream2, ev_fork, 0));
-    rc = run_half(stream, 0, h1);
-    if (rc != DVM_OK) return rc;
-    rc = run_half(stream2, h1, batch - h1);
-    if (rc != DVM_OK) return rc;
-    DVM_HIP(hipEventRecord(ev_join, stream2));
-    DVM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
-  }
+  rc = run_half(stream, 0, batch);
+  if (rc != DVM_OK) return rc;
   DVM_HIP(hipGetLastError());
   return DVM_OK;
 }

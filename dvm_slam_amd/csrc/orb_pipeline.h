@@ -57,9 +57,9 @@ class OrbPipeline {
   dvm_orb_params params;
   int device, max_batch;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // second half of a batch (overlaps latency-bound stages)
+  hipStream_t stream2 = nullptr;   // side stream: the blur runs here, concurrently with k_octree
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool dual_stream = false;  // DVM_DUAL_STREAM=1: measured +4 % at batch 64, nil at batch 256
+  bool overlap_blur = true;  // DVM_SERIAL=1 puts the blur back on `stream`
   Profiler prof;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> nfeat;
