@@ -84,58 +84,102 @@ __device__ __forceinline__ void store_px4(uint8_t* D, int X4, int w, uint32_t v)
   }
 }
 
-// level 0: thread = 16 destination bytes [X, X+16) (X % 16 == 0 in bordered columns) of FOUR interior rows
-// (y, y+4, y+8, y+12: all loads are issued before the first store).  The source run starts at an arbitrary
-// byte address -> 5 aligned dwords + v_alignbyte, one dwordx4 store per row.  No edge branch: dword addresses
-// are clamped to the row, and the bytes that do not come from the row land in border columns, which
-// k_pyr_borders rewrites afterwards.
+// 16 bytes of source row S starting at column x0 (any alignment, may start before / end after the row): 5 aligned
+// dwords clamped to the row + v_alignbyte.  Bytes outside [0, cols) are unspecified.
+__device__ __forceinline__ uint4 row_window16(const uint8_t* S, int cols, int x0) {
+  const uintptr_t r0 = reinterpret_cast<uintptr_t>(S);
+  const uintptr_t lo = r0 & ~(uintptr_t)3, hi = (r0 + cols - 1) & ~(uintptr_t)3;   // first / last dword of the row
+  const intptr_t a = (intptr_t)r0 + x0;
+  const uintptr_t q = (uintptr_t)(a & ~(intptr_t)3);
+  const uint32_t sh = (uint32_t)(a & 3);
+  uint32_t d[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    intptr_t p = (intptr_t)q + 4 * j;
+    p = p < (intptr_t)lo ? (intptr_t)lo : (p > (intptr_t)hi ? (intptr_t)hi : p);
+    d[j] = *reinterpret_cast<const uint32_t*>(p);
+  }
+  return make_uint4(__builtin_amdgcn_alignbyte(d[1], d[0], sh), __builtin_amdgcn_alignbyte(d[2], d[1], sh),
+                    __builtin_amdgcn_alignbyte(d[3], d[2], sh), __builtin_amdgcn_alignbyte(d[4], d[3], sh));
+}
+__device__ __forceinline__ uint32_t byte_mask_lt(int n) {   // bytes [0, n) set, n clamped to 0..4
+  return n <= 0 ? 0u : (n >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n)) - 1u));
+}
+// bordered rows that mirror interior row y (REFLECT_101, 19 px): at most one above and one below when h >= 20
+__device__ __forceinline__ void mirror_rows(int y, int h, int& top, int& bot) {
+  top = (y >= 1 && y <= kEdge) ? kEdge - y : -1;
+  bot = (y >= h - 1 - kEdge && y <= h - 2) ? 2 * h + kEdge - 2 - y : -1;
+}
+
+// level 0 WITH its REFLECT_101 frame: thread = 16 destination bytes [X, X+16) (X % 16 == 0, bordered columns
+// 0 .. w+37) of FOUR interior rows (y, y+4, y+8, y+12; all loads are issued before the first store).
+// Interior bytes come from the source run at x = X-19 (row_window16); a group that overlaps the left / right frame
+// also builds the byte-reversed run of the pixels it mirrors and merges the two per byte, so every cache line of
+// the bordered row is written once, in full.  Rows 1..19 and h-20..h-2 are stored a second time into the top /
+// bottom strip row that mirrors them.
 __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ src, int rows, int cols, int sstride,
                                                     int64_t frame_stride, uint8_t* __restrict__ pyr,
                                                     int pyr_frame_bytes, LevelDesc L) {
-  const int X = 16 + (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
+  const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
   const int yb = blockIdx.y * 16 + (threadIdx.x >> 6);
   const int f = blockIdx.z;
-  const int x0 = X - kEdge;
-  if (x0 >= cols) return;
+  if (X >= cols + 2 * kEdge) return;
   const uint8_t* S = src + (int64_t)f * frame_stride;
-  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)kEdge * L.stride;
+  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off;
+  const bool left = X < kEdge, right = X + 16 > cols + kEdge;
+  // mirrored run: left frame  x' = 19 - X - k  -> reversed window starting at 4 - X
+  //               right frame x' = 2w + 17 - X - k -> reversed window starting at 2w + 2 - X
+  const int xm = left ? 4 - X : 2 * cols + 2 - X;
+  const int kb = left ? kEdge - X : cols + kEdge - X;   // left: bytes k < kb mirrored; right: bytes k >= kb mirrored
   uint4 v[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int y = min(yb + 4 * i, rows - 1);
-    const uintptr_t r0 = reinterpret_cast<uintptr_t>(S + (int64_t)y * sstride);
-    const uintptr_t lo = r0 & ~(uintptr_t)3, hi = (r0 + cols - 1) & ~(uintptr_t)3;   // first / last dword of the row
-    const intptr_t a = (intptr_t)r0 + x0;
-    const uintptr_t q = (uintptr_t)(a & ~(intptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
-    uint32_t d[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      uintptr_t p = q + 4 * j;
-      p = p < lo ? lo : (p > hi ? hi : p);
-      d[j] = *reinterpret_cast<const uint32_t*>(p);
+    const uint8_t* Sr = S + (int64_t)y * sstride;
+    v[i] = row_window16(Sr, cols, X - kEdge);
+    if (left || right) {
+      const uint4 m = row_window16(Sr, cols, xm);
+      const uint32_t r0 = __builtin_amdgcn_perm(0u, m.w, 0x00010203u), r1 = __builtin_amdgcn_perm(0u, m.z, 0x00010203u);
+      const uint32_t r2 = __builtin_amdgcn_perm(0u, m.y, 0x00010203u), r3 = __builtin_amdgcn_perm(0u, m.x, 0x00010203u);
+      // mask = bytes that take the mirrored value
+      uint32_t k0 = byte_mask_lt(kb), k1 = byte_mask_lt(kb - 4), k2 = byte_mask_lt(kb - 8), k3 = byte_mask_lt(kb - 12);
+      if (!left) { k0 = ~k0; k1 = ~k1; k2 = ~k2; k3 = ~k3; }
+      v[i].x = (v[i].x & ~k0) | (r0 & k0);
+      v[i].y = (v[i].y & ~k1) | (r1 & k1);
+      v[i].z = (v[i].z & ~k2) | (r2 & k2);
+      v[i].w = (v[i].w & ~k3) | (r3 & k3);
     }
-    v[i].x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
-    v[i].y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-    v[i].z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
-    v[i].w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int y = yb + 4 * i;
-    if (y < rows) *reinterpret_cast<uint4*>(D + (int64_t)y * L.stride + X) = v[i];
+    if (y < rows) {
+      *reinterpret_cast<uint4*>(D + (int64_t)(kEdge + y) * L.stride + X) = v[i];
+      int top, bot;
+      mirror_rows(y, rows, top, bot);
+      if (top >= 0) *reinterpret_cast<uint4*>(D + (int64_t)top * L.stride + X) = v[i];
+      if (bot >= 0) *reinterpret_cast<uint4*>(D + (int64_t)bot * L.stride + X) = v[i];
+    }
   }
 }
 
+// level l = cv::resize(level l-1, INTER_LINEAR) WITH its REFLECT_101 frame.  A workgroup owns a 256 x 16 tile of
+// BORDERED columns x interior rows; a frame column computes the pixel it mirrors (its source lies in the same LDS
+// rectangle, at most 19 destination pixels further in), rows 1..19 / h-20..h-2 are stored twice (strip rows).
 __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
                                                     LevelDesc L, const int32_t* __restrict__ tabs, int lds_pitch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rz_smem[];
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   const int f = blockIdx.z;
-  const int X0 = 16 + blockIdx.x * kRzTW;          // first bordered column of the tile (dword aligned)
+  const int w = L.w, bw = L.w + 2 * kEdge;
+  const int X0 = blockIdx.x * kRzTW;               // first bordered column of the tile (dword aligned)
   const int y0 = blockIdx.y * kRzTH;               // first interior row
-  const int dxa = max(X0 - kEdge, 0), dxb = min(X0 + kRzTW - 1 - kEdge, L.w - 1);
-  if (dxa > dxb) return;
+  if (X0 >= bw) return;
+  // interior columns whose sources the tile needs: its own, plus the ones its frame columns mirror
+  const int lo = X0 - kEdge, hi = min(X0 + kRzTW - 1, bw - 1) - kEdge;
+  int dxa = max(lo, 0), dxb = min(hi, w - 1);
+  if (lo < 0) dxb = max(dxb, min(-lo, w - 1));
+  if (hi > w - 1) dxa = min(dxa, max(2 * (w - 1) - hi, 0));
   const int32_t* xofs = tabs + L.tab_off;
   const int32_t* xal = xofs + L.w;   // (a0 | a1 << 16)
   const int32_t* yofs = xal + L.w;
@@ -159,19 +203,18 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   }
   __syncthreads();
   const int X4 = X0 + 4 * tx;
+  if (X4 >= bw) return;
   int sx[4];
   uint32_t al[4];   // (a0 | a1 << 16): the two 11-bit horizontal weights, ready for v_dot2_u32_u16
-  bool any = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int dx = X4 + k - kEdge;
-    const bool ok = dx >= 0 && dx < L.w;
-    any |= ok;
-    const int dxc = min(max(dx, 0), L.w - 1);
+    const int x = X4 + k - kEdge;
+    const int xm = x < 0 ? -x : (x >= w ? 2 * (w - 1) - x : x);   // REFLECT_101 (one bounce: w >= 20)
+    const int dxc = min(max(min(max(xm, dxa), dxb), 0), w - 1);   // pad bytes beyond the frame: any in-tile column
     sx[k] = kEdge + xofs[dxc] - ga;
     al[k] = (uint32_t)xal[dxc];
   }
-  if (!any) return;
+  uint8_t* Dl = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off;
 #pragma unroll
   for (int rr = 0; rr < kRzTH / 4; rr++) {
     const int dy = y0 + ty + 4 * rr;
@@ -193,11 +236,17 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
       const uint32_t r = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
       v |= r << (8 * k);
     }
-    uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + dy) * L.stride;
-    store_px4(D, X4, L.w, v);
+    // row pitch is a multiple of 64 >= bw: a full dword store never leaves the row
+    *reinterpret_cast<uint32_t*>(Dl + (int64_t)(kEdge + dy) * L.stride + X4) = v;
+    int top, bot;
+    mirror_rows(dy, L.h, top, bot);
+    if (top >= 0) *reinterpret_cast<uint32_t*>(Dl + (int64_t)top * L.stride + X4) = v;
+    if (bot >= 0) *reinterpret_cast<uint32_t*>(Dl + (int64_t)bot * L.stride + X4) = v;
   }
 }
 
+// FALLBACK for tiny levels (w < 40 or h < 20, where the mirror bounces more than once): the level kernels above
+// already write the frame for every normal size, and this kernel is then not launched.
 // REFLECT_101 frame of every level in ONE launch.  Per level, "bordered row" R in [0, h+38):
 //   interior rows (19 <= R < h+19): source row = the row itself, only the 19 + 19 side columns are written
 //   strip rows (top / bottom 19):   source row = the mirrored interior row; the whole row is written
@@ -963,7 +1012,7 @@ void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gau
 void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
                        uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
   const LevelDesc& L = PD.lv[0];
-  dim3 grid(cdiv(cdiv(L.w + 3, 16), 64), cdiv(L.h, 16), batch);
+  dim3 grid(cdiv(cdiv(L.w + 2 * kEdge, 16), 64), cdiv(L.h, 16), batch);
   hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, d_src, rows, cols, sstride, frame_stride, d_pyr,
                      PD.pyr_frame_bytes, L);
 }
@@ -974,7 +1023,7 @@ void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, in
   const double sxs = (double)P.w / L.w, sys = (double)P.h / L.h;
   const int pitch = (((int)(kRzTW * sxs) + 16) + 3) & ~3;
   const int nrows = (int)(kRzTH * sys) + 4;
-  dim3 grid(cdiv(L.w + 3, kRzTW), cdiv(L.h, kRzTH), batch);
+  dim3 grid(cdiv(L.w + 2 * kEdge, kRzTW), cdiv(L.h, kRzTH), batch);
   hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)pitch * nrows, s, d_pyr, PD.pyr_frame_bytes, P, L, d_tabs, pitch);
 }
 void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch) {

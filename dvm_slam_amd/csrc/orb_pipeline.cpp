@@ -415,6 +415,8 @@ int OrbPipeline::configure(int rows, int cols) {
   }
   max_cell_rw = max_cell_rh = 8;
   for (const CellDesc& c : cells) { max_cell_rw = std::max<int>(max_cell_rw, c.rw); max_cell_rh = std::max<int>(max_cell_rh, c.rh); }
+  tiny_levels = false;
+  for (int l = 0; l < PD.nlevels; l++) tiny_levels |= (PD.lv[l].w < 40 || PD.lv[l].h < 20);
   PD.ncells = (int)cells.size();
   PD.ntiles = (int)tiles.size();
   PD.pyr_frame_bytes = pyr_off;
@@ -500,7 +502,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.begin(st, "pyramid");
     launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
     for (int l = 1; l < L; l++) launch_pyr_resize(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, l, d_tabs, nb);
-    launch_pyr_borders(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
+    if (tiny_levels) launch_pyr_borders(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);   // else: fused into the level kernels
     prof.end(st);
     prof.begin(st, "fast");
     launch_fast(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), d_cells, PD, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), nb, max_cell_rw, max_cell_rh);

@@ -70,6 +70,7 @@ class OrbPipeline {
   std::vector<TileDesc> tiles;
   int last_batch = 0;
   int max_cell_rw = 8, max_cell_rh = 8;  // largest FAST cell ROI of the current image size
+  bool tiny_levels = false;  // some level is too small for the fused single-bounce frame -> k_pyr_borders fixes it up
   bool configured = false;
 
   // device memory
