@@ -249,9 +249,13 @@ OrbPipeline::~OrbPipeline() {
   free_all();
   if (d_stage) hipFree(d_stage);
   if (h_stage) hipHostFree(h_stage);
-  if (stream2) { hipStreamSynchronize(stream2); hipStreamDestroy(stream2); }
-  if (ev_fork) hipEventDestroy(ev_fork);
-  if (ev_join) hipEventDestroy(ev_join);
+  for (hipStream_t st : {lane_main[1], lane_side[0], lane_side[1]})
+    if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (int c = 0; c < kMaxChunks; c++)
+    for (hipEvent_t e : {ev_compact[c], ev_fork[c], ev_join[c]})
+      if (e) hipEventDestroy(e);
+  if (ev_start) hipEventDestroy(ev_start);
+  if (ev_done) hipEventDestroy(ev_done);
   if (stream) hipStreamDestroy(stream);
 }
 
@@ -267,9 +271,18 @@ int OrbPipeline::init() {
   }
   DVM_HIP(hipSetDevice(device));
   DVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  DVM_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-  DVM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-  DVM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  lane_main[0] = stream;
+  DVM_HIP(hipStreamCreateWithFlags(&lane_main[1], hipStreamNonBlocking));
+  DVM_HIP(hipStreamCreateWithFlags(&lane_side[0], hipStreamNonBlocking));
+  DVM_HIP(hipStreamCreateWithFlags(&lane_side[1], hipStreamNonBlocking));
+  DVM_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+  DVM_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+  for (int c = 0; c < kMaxChunks; c++) {
+    DVM_HIP(hipEventCreateWithFlags(&ev_compact[c], hipEventDisableTiming));
+    DVM_HIP(hipEventCreateWithFlags(&ev_fork[c], hipEventDisableTiming));
+    DVM_HIP(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
+  }
+  if (const char* e = getenv("DVM_CHUNKS")) chunks = std::min(std::max(atoi(e), 1), (int)kMaxChunks);
   if (const char* e = getenv("DVM_SERIAL")) overlap_blur = (e[0] != '1');      // debug / A-B switch only
   if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree = (e[0] == '1');  // debug / A-B switch only
   // orientation disc offsets (any order: the moments are exact integer sums)
@@ -495,10 +508,11 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   const int L = PD.nlevels;
   last_batch = batch;
 
-  // One in-order pipeline on `stream`, except the blur: it depends only on the pyramid and on the per-level candidate
-  // counts, so it runs on `stream2` concurrently with the latency-bound k_octree (one workgroup per level whose
-  // critical path is a single-lane std::sort emulation) and joins before the descriptors.  DVM_SERIAL=1 disables it.
-  auto run_half = [&](hipStream_t st, int f0, int nb) -> int {
+  // Per chunk: one in-order chain, except the blur: it depends only on the pyramid and on the per-level candidate
+  // counts, so it runs on the lane's side stream concurrently with the latency-bound k_octree (one workgroup per
+  // level whose critical path is a single-lane std::sort emulation) and joins before the descriptors.
+  // DVM_SERIAL=1 keeps the blur on the main chain, DVM_CHUNKS=1 disables the chunk pipeline.
+  auto run_half = [&](hipStream_t st, hipStream_t side, int ck, int f0, int nb) -> int {
     prof.begin(st, "pyramid");
     launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
     for (int l = 1; l < L; l++) launch_pyr_resize(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, l, d_tabs, nb);
@@ -511,14 +525,15 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     launch_compact(st, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), d_cells, PD, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
     prof.end(st);
 
-    const bool blur_forked = overlap_blur && !host_octree && stream2 != nullptr;
+    DVM_HIP(hipEventRecord(ev_compact[ck], st));   // this chunk has left the throughput-bound stages
+    const bool blur_forked = overlap_blur && !host_octree && side != nullptr;
     if (blur_forked) {
-      DVM_HIP(hipEventRecord(ev_fork, st));
-      DVM_HIP(hipStreamWaitEvent(stream2, ev_fork, 0));
-      prof.begin(stream2, "blur");
-      launch_blur(stream2, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
-      prof.end(stream2);
-      DVM_HIP(hipEventRecord(ev_join, stream2));
+      DVM_HIP(hipEventRecord(ev_fork[ck], st));
+      DVM_HIP(hipStreamWaitEvent(side, ev_fork[ck], 0));
+      prof.begin(side, "blur");
+      launch_blur(side, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
+      prof.end(side);
+      DVM_HIP(hipEventRecord(ev_join[ck], side));
     }
     if (!host_octree) {
       prof.begin(st, "octree");
@@ -570,7 +585,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
       prof.end(st);
     } else {
-      DVM_HIP(hipStreamWaitEvent(st, ev_join, 0));
+      DVM_HIP(hipStreamWaitEvent(st, ev_join[ck], 0));
     }
     prof.begin(st, "orient_desc");
     launch_orient_desc(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), PD, (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_kps + (size_t)f0 * PD.kp_cap), (d_desc + (size_t)f0 * PD.kp_cap * 32), nb);
@@ -578,8 +593,25 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
 
     return DVM_OK;
   };
-  rc = run_half(stream, 0, batch);
-  if (rc != DVM_OK) return rc;
+  int nck = host_octree ? 1 : std::min(chunks, std::max(1, batch / 32));   // chunks of >= 32 frames
+  if (nck == 1) {
+    rc = run_half(stream, lane_side[0], 0, 0, batch);
+    if (rc != DVM_OK) return rc;
+  } else {
+    DVM_HIP(hipEventRecord(ev_start, stream));              // everything queued on `stream` so far precedes the batch
+    DVM_HIP(hipStreamWaitEvent(lane_main[1], ev_start, 0));
+    const int per = (batch + nck - 1) / nck;
+    for (int c = 0; c < nck; c++) {
+      const int f0 = c * per, nb = std::min(per, batch - f0);
+      if (nb <= 0) { nck = c; break; }
+      hipStream_t st = lane_main[c & 1];
+      if (c > 0) DVM_HIP(hipStreamWaitEvent(st, ev_compact[c - 1], 0));
+      rc = run_half(st, lane_side[c & 1], c, f0, nb);
+      if (rc != DVM_OK) return rc;
+    }
+    DVM_HIP(hipEventRecord(ev_done, lane_main[1]));         // `stream` stays the handle's ordering point
+    DVM_HIP(hipStreamWaitEvent(stream, ev_done, 0));
+  }
   DVM_HIP(hipGetLastError());
   return DVM_OK;
 }

@@ -81,6 +81,34 @@ def test_batch_equals_single(capi, oracle, frames):
     e.close()
 
 
+def test_chunked_pipeline_equals_single(capi, oracle, frames):
+    """DVM_CHUNKS=n cuts a batch into a two-lane chunk pipeline (orb_pipeline.cpp, off by default): every frame
+    must still be exact, twice in a row (buffer reuse across calls), including a ragged last chunk."""
+    import os
+    os.environ["DVM_CHUNKS"] = "3"
+    try:
+        _chunked(capi, oracle, frames)
+    finally:
+        del os.environ["DVM_CHUNKS"]
+
+
+def _chunked(capi, oracle, frames):
+    orc = oracle.OrbOracle()
+    ref = [orc.extract(f) for f in frames]
+    for B in (64, 97, 256):
+        batch = np.stack([frames[i % len(frames)] for i in range(B)])
+        e = capi.OrbExtractor(max_batch=B)
+        for rep in range(2):
+            e.extract_batch_host(batch)
+            for f in (0, 1, B // 2 - 1, B // 2, B // 2 + 1, B - 2, B - 1):
+                n_g, k_g, d_g, m_g = e.download(f)
+                n_o, k_o, d_o, m_o = ref[f % len(frames)]
+                assert (n_g, m_g) == (n_o, m_o), (B, f)
+                _same_kps(k_g, k_o)
+                assert np.array_equal(d_g, d_o)
+        e.close()
+
+
 def test_edge_cases(capi, oracle):
     e = capi.OrbExtractor(max_batch=1)
     orc = oracle.OrbOracle()
