@@ -98,7 +98,9 @@ __device__ __forceinline__ void top2_insert(uint32_t& k1, uint32_t& k2, uint32_t
   else if (k < k2) k2 = k;
 }
 
-// One wave per query.  QUERIES_FROM_KPS: queries are keypoints of another frame (frame-to-frame
+// Sixteen lanes (one DPP row) per query, four queries per wave: a window holds ~10 candidates out of the ~70 of its
+// grid columns, so a full wave per query left most lanes idle and paid a 6-step cross-lane reduction; a row reduces
+// its top-2 with four DPP steps and no LDS traffic.  QUERIES_FROM_KPS: queries are keypoints of another frame (frame-to-frame
 // search, window th*scale[octave], octaves [o-1,o+1]); otherwise explicit query arrays.
 template <bool QUERIES_FROM_KPS>
 __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_slot, const uint8_t* __restrict__ skip,
@@ -108,8 +110,8 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
                                                       int nq_host, const int32_t* __restrict__ d_nq, PairQueries PQ,
                                                       float th, const float* __restrict__ scale_factors, int nlevels,
                                                       dvm_match_pod* __restrict__ out, int64_t out_stride) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 15;               // lane within the query's row
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int pair = blockIdx.y;
   const FrameView F = FB.slot(first_slot + pair);
   const dvm_keypoint_pod* qkps = nullptr;
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
 #pragma unroll
     for (int i = 0; i < 8; i++) w[i] = qd[i];
     const int beg = F.cellx_start[nMinCellX], end = F.cellx_start[nMaxCellX + 1];
-    for (int p = beg + lane; p < end; p += 64) {
+    for (int p = beg + lane; p < end; p += 16) {
       const float4 kp = F.skp[p];
       const int oct = __float_as_int(kp.z);
       const int cell = __float_as_int(kp.w);
@@ -178,13 +180,19 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
       top2_insert(k1, k2, ((uint32_t)d << 16) | (uint32_t)p);
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t o1 = __shfl_xor(k1, off), o2 = __shfl_xor(k2, off);
-    uint32_t n1 = min(k1, o1);
-    uint32_t n2 = min(max(k1, o1), min(k2, o2));
-    k1 = n1; k2 = n2;
+  // top-2 of the row: xor-1, xor-2 inside quads, then half-row and row mirrors (the merged sets are disjoint)
+#define DVM_TOP2_STEP(CTRL)                                                              \
+  {                                                                                      \
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false); \
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false); \
+    const uint32_t n1 = min(k1, o1), n2 = min(max(k1, o1), min(k2, o2));                 \
+    k1 = n1; k2 = n2;                                                                    \
   }
+  DVM_TOP2_STEP(0xB1)    // quad_perm [1,0,3,2]
+  DVM_TOP2_STEP(0x4E)    // quad_perm [2,3,0,1]
+  DVM_TOP2_STEP(0x141)   // row_half_mirror
+  DVM_TOP2_STEP(0x140)   // row_mirror
+#undef DVM_TOP2_STEP
   if (lane == 0) {
     dvm_match_pod m;
     const int p1 = (int)(k1 & 0xFFFFu), p2 = (int)(k2 & 0xFFFFu);
@@ -299,12 +307,12 @@ void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint
                          const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
                          int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out) {
   PairQueries pq{};
-  hipLaunchKernelGGL(k_match_window<false>, dim3((grid_q + 3) / 4, 1), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr,
+  hipLaunchKernelGGL(k_match_window<false>, dim3((grid_q + 15) / 16, 1), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr,
                      qmin, qmax, nq, d_nq, pq, 0.f, nullptr, 0, out, 0);
 }
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {
-  hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 3) / 4, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
+  hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 15) / 16, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride);
 }
 void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
