@@ -8,6 +8,8 @@
 namespace dvm {
 
 constexpr int kEdgeLinStride = 24;  // doubles per edge: A[6] B[12] w wr0 wr1 + pad
+// first row of camera i (elimination order) in the tiled reduced system: 10 whole cameras per 64-row tile
+__host__ __device__ inline int ba_row(int i) { return (i / 10) * 64 + (i % 10) * 6; }
 
 // Structure-of-arrays problem state in HBM (DESIGN.md "BA layout").  Poses are (t, q_xyzw) doubles.
 struct BaView {
@@ -35,14 +37,23 @@ struct BaView {
   const int32_t *pair_k1, *pair_k2;            // per block: (edge of i1, edge of i2) sharing a landmark
   double* S;                // [ldS][ldS] dense lower triangle + augmented rhs row
   double* Linv;             // [ldS/64][64*64] inverses of the factored diagonal blocks
-  double* ytmp;             // [6*nfree]
+  double* ytmp;             // [n_pad]
   double* x;                // [6*nfree + 3*L]
   double *partial, *partial2;
-  // tile-level (64x64) structure of the Cholesky factor incl. fill, from a symbolic factorisation on the host:
-  const int32_t* strips;    // per step kb: tile rows i > kb with L(i,kb) != 0          (offsets h_strip_off)
-  const int32_t* tiles;     // per step kb: (i,j), i >= j > kb, L(i,kb) and L(j,kb) != 0 (offsets h_tile_off)
-  const int32_t* rowtiles;  // per tile row k: columns j < k with L(k,j) != 0           (offsets h_row_off)
-  const int32_t *h_strip_off, *h_tile_off, *h_row_off;  // HOST arrays [nkb+1]
+  // Reduced camera system in TILE space (ba_ordering.h): camera i (elimination order) owns rows
+  // ba_row(i) = (i / 10) * 64 + (i % 10) * 6; rows 60..63 of a tile are identity padding; n_pad = 64 * camera tiles;
+  // row n_pad carries bschur^T (augmented rhs), so ldS = n_pad + 64.
+  int32_t n_pad;
+  double* xrow;             // [n_pad] solution in row space (back substitution reads its ancestors here)
+  // level schedule of the tile Cholesky (columns of one elimination-tree height are independent):
+  const int32_t* cols;      // columns by level                                  (host offsets h_level_off)
+  const int32_t* strips;    // (row tile, column) pairs by level                 (h_strip_off)
+  const int32_t* targets;   // (ti, tj, c0, c1) trailing tiles by level          (h_tgt_off)
+  const int32_t* contrib;   // contributing columns of each target, ascending
+  const int32_t* colstrip_off;  // [ntiles+1] device
+  const int32_t* colstrips;     // per column: its strip rows
+  const int32_t *h_level_off, *h_strip_off, *h_tgt_off;  // HOST arrays [nlevels+1]
+  int32_t nlevels;
   const double* lambda;     // device scalar: current LM damping (so the per-trial launch sequence is a replayable graph)
 };
 

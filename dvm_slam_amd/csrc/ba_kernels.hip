@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) k_schur_blocks(BaView V) {
     for (int i = 0; i < 36; i++) if (i == lane) v = acc[i];
     v = -v;
     if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + lane] + (a == b ? lambda : 0.0);
-    V.S[(size_t)(6 * i1 + a) * V.ldS + 6 * i2 + b] = v;
+    V.S[(size_t)(ba_row(i1) + a) * V.ldS + ba_row(i2) + b] = v;
   }
 }
 
@@ -340,17 +340,26 @@ __global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
 #pragma unroll
     for (int a = 0; a < 6; a++) acc[a] += __shfl_xor(acc[a], off);
   if (lane == 0) {
-    const int n = 6 * V.nfree;
-    for (int a = 0; a < 6; a++) V.S[(size_t)n * V.ldS + 6 * fi + a] = V.bp[6 * (size_t)fi + a] - acc[a];
-    if (fi == 0) V.S[(size_t)n * V.ldS + n] = 1e200;  // augmented corner: keeps the last pivot positive
+    for (int a = 0; a < 6; a++) V.S[(size_t)V.n_pad * V.ldS + ba_row(fi) + a] = V.bp[6 * (size_t)fi + a] - acc[a];
+    if (fi == 0) V.S[(size_t)V.n_pad * V.ldS + V.n_pad] = 1e200;  // augmented corner: keeps the last pivot positive
   }
 }
 
+// identity on the padding rows of the tiled system (rows 60..63 of every tile, cameras beyond nfree in the last tile)
+__global__ void __launch_bounds__(256) k_pad_identity(BaView V) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= V.n_pad) return;
+  const int w = r & 63;
+  if (w >= 60 || (r >> 6) * 10 + w / 6 >= V.nfree) V.S[(size_t)r * V.ldS + r] = 1.0;
+}
+
 // ----------------------------------------------------------------------------------------- K10
-// Blocked right-looking Cholesky of the lower triangle of S (row-major, leading dim ldS), NB = 64,
-// over n1 = 6*nfree + 1 rows: the extra row carries bschur^T, so after the factorisation row n holds
-// y^T with L y = bschur (forward substitution for free).  Per step: k_chol_diag (one wave: block
-// Cholesky + its inverse), k_chol_trsm (strips as GEMM with the inverse), k_chol_update (MFMA).
+// Tile Cholesky of the lower triangle of S (row-major, leading dim ldS), NB = 64, over n1 = n_pad + 1 rows: the
+// extra row carries bschur^T, so after the factorisation row n_pad holds y^T with L y = bschur (forward
+// substitution for free).  The tile columns are processed LEVEL BY LEVEL of the elimination tree (ba_ordering.h):
+// per level one k_chol_diag launch (a workgroup per column: block Cholesky + its inverse), one k_chol_trsm launch
+// (all strips of the level as GEMMs with the inverses) and one k_chol_update launch (a workgroup per trailing tile,
+// summing its contributing columns in a fixed order: deterministic, no atomics).
 constexpr int NB = 64;
 
 __device__ __forceinline__ double bcast_lane(double v, int src_lane) {  // src_lane must be wave-uniform
@@ -371,8 +380,9 @@ constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
 // then Linv by block forward substitution, Linv_ij = -Linv_ii * sum_k L_ik Linv_kj, again on MFMA: the
 // C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly its B-operand
 // layout for k-step = reg, so the running sum feeds the next product without touching LDS.
-__global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, int kb, int* __restrict__ fail,
-                                                  double* __restrict__ Linv_all) {
+__global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, const int32_t* __restrict__ cols,
+                                                  int* __restrict__ fail, double* __restrict__ Linv_all) {
+  const int kb = cols[blockIdx.x];
   __shared__ double Bm[NB * LP];
   __shared__ double Li[NB * LP];
   __shared__ double Iv[4][16][17];
@@ -490,13 +500,14 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 
 // Panel solve of step kb: strip i (64 rows below the diagonal block) becomes X = A_ik * Linv_kk^T
 // (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM.
-__global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1, int kb,
+__global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1,
                                                    const double* __restrict__ Linv_all, const int32_t* __restrict__ strips) {
   __shared__ double Ai[NB][NB + 1];
   __shared__ double Li[NB][NB + 1];
   const int tid = threadIdx.x;
+  const int kb = strips[2 * blockIdx.x + 1];
   const int k0 = kb * NB;
-  const int r0 = strips[blockIdx.x] * NB;  // tile row of a structurally non-zero strip of this panel
+  const int r0 = strips[2 * blockIdx.x] * NB;  // tile row of a structurally non-zero strip of column kb
   const int rw = min(NB, n1 - r0);
   const double* Lk = Linv_all + (size_t)kb * NB * NB;
   for (int i = tid; i < NB * NB; i += 256) {
@@ -534,44 +545,49 @@ __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int l
       }
 }
 
-// Trailing update A_ij -= A_ik A_jk^T for 64x64 tiles i >= j > kb.  blockIdx.x enumerates the lower
-// triangle of tiles.  4 waves, each owning a 32x32 quadrant = 2x2 MFMA tiles of
-// v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
+// Trailing update A_ij -= sum_k A_ik A_jk^T for one 64x64 tile (ti >= tj) and the columns k of the current level
+// that reach it (contrib[c0..c1), ascending: fixed summation order).  4 waves, each owning a 32x32 quadrant = 2x2
+// MFMA tiles of v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
 // C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg).
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1, int kb,
-                                                     const int32_t* __restrict__ tiles) {
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1,
+                                                     const int32_t* __restrict__ targets, const int32_t* __restrict__ contrib) {
   __shared__ double Ai[NB][NB + 1];
   __shared__ double Aj[NB][NB + 1];
-  // (ti, tj), ti >= tj: a trailing tile whose two panel strips are both structurally non-zero
-  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
-  const int k0 = kb * NB;
+  const int ti = targets[4 * blockIdx.x], tj = targets[4 * blockIdx.x + 1];
+  const int c0 = targets[4 * blockIdx.x + 2], c1 = targets[4 * blockIdx.x + 3];
   const int i0 = ti * NB, j0 = tj * NB;
   const int iw = min(NB, n1 - i0), jw = min(NB, n1 - j0);
   const int tid = threadIdx.x;
-  for (int i = tid; i < NB * NB; i += 256) {
-    int r = i / NB, c = i % NB;
-    Ai[r][c] = (r < iw) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
-    Aj[r][c] = (r < jw) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
-  }
-  __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   const int qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
-  if (ti == tj && qj > qi) return;  // strictly upper quadrant of a diagonal tile
+  const bool idle = (ti == tj && qj > qi);  // strictly upper quadrant of a diagonal tile
   double4_t acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = (double4_t){0, 0, 0, 0};
   const int lr = lane & 15, lk = lane >> 4;
+  for (int c = c0; c < c1; c++) {
+    const int k0 = contrib[c] * NB;
+    if (c > c0) __syncthreads();
+    for (int i = tid; i < NB * NB; i += 256) {
+      int r = i / NB, cc = i % NB;
+      Ai[r][cc] = (r < iw) ? S[(size_t)(i0 + r) * ldS + k0 + cc] : 0.0;
+      Aj[r][cc] = (r < jw) ? S[(size_t)(j0 + r) * ldS + k0 + cc] : 0.0;
+    }
+    __syncthreads();
+    if (idle) continue;
 #pragma unroll 4
-  for (int k = 0; k < NB; k += 4) {
-    double a0 = Ai[qi + lr][k + lk], a1 = Ai[qi + 16 + lr][k + lk];
-    double b0 = Aj[qj + lr][k + lk], b1 = Aj[qj + 16 + lr][k + lk];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    for (int k = 0; k < NB; k += 4) {
+      double a0 = Ai[qi + lr][k + lk], a1 = Ai[qi + 16 + lr][k + lk];
+      double b0 = Aj[qj + lr][k + lk], b1 = Aj[qj + 16 + lr][k + lk];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
   }
+  if (idle) return;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -583,20 +599,40 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
       }
 }
 
-// Backward substitution L^T x = y, y = row n of S.  Step kb (descending): every workgroup forms
-// x_k = Linv_kk^T y_k (64 dot products, no dependency chain); workgroup 0 stores it, workgroup j+1
-// (j < kb) applies y_j -= L[kblock, jblock]^T x_k.
-__global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n, int kb,
-                                                        double* __restrict__ y, double* __restrict__ x,
+// Backward substitution L^T x = y (y = row n_pad of S) in PULL form, one workgroup per tile column of a level,
+// levels visited from the root down:  x_k = Linv_kk^T (y_k - sum_{i in struct(k)} L(i,k)^T x_i); the x_i belong to
+// ancestors of k and are final.  The result goes to row space (xrow, for the descendants) and, compacted to
+// 6 doubles per camera, to V.x for the update kernels.
+__global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n_pad, int nfree,
+                                                        const int32_t* __restrict__ cols, const double* __restrict__ y,
+                                                        double* __restrict__ xrow, double* __restrict__ x,
                                                         const double* __restrict__ Linv_all,
-                                                        const int32_t* __restrict__ rowtiles) {
+                                                        const int32_t* __restrict__ colstrip_off,
+                                                        const int32_t* __restrict__ colstrips) {
   __shared__ double yk[NB];
-  __shared__ double xk[NB];
+  __shared__ double xi[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+  const int kb = cols[blockIdx.x];
   const int k0 = kb * NB;
-  const int kw = min(NB, n - k0);
-  if (tid < NB) yk[tid] = (tid < kw) ? y[k0 + tid] : 0.0;  // y_k is final: only blocks j < kb are updated below
+  if (k0 >= n_pad) return;                       // the rhs tile itself
+  if (tid < NB) yk[tid] = y[k0 + tid];
+  for (int s = colstrip_off[kb]; s < colstrip_off[kb + 1]; s++) {
+    const int i0 = colstrips[s] * NB;
+    if (i0 >= n_pad) continue;                   // the rhs row is not an unknown
+    __syncthreads();
+    if (tid < NB) xi[tid] = xrow[i0 + tid];
+    __syncthreads();
+    double u = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int rr = 16 * q + r;
+      u += S[(size_t)(i0 + rr) * ldS + k0 + c] * xi[rr];
+    }
+    part[q][c] = u;
+    __syncthreads();
+    if (tid < NB) yk[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  }
   __syncthreads();
   const double* Lk = Linv_all + (size_t)kb * NB * NB;
   // (Linv^T y)[c] = sum_r Linv[r][c] y[r]  (Linv is zero above the diagonal); 4 row-quarters per column
@@ -605,22 +641,12 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   for (int r = 0; r < 16; r++) s += Lk[(16 * q + r) * NB + c] * yk[16 * q + r];
   part[q][c] = s;
   __syncthreads();
-  if (tid < NB) xk[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (tid < kw) x[k0 + tid] = xk[tid];
-    return;
+  if (tid < NB) {
+    const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    xrow[k0 + tid] = v;
+    const int cam = kb * 10 + tid / 6;
+    if (tid < 60 && cam < nfree) x[6 * (size_t)cam + tid % 6] = v;
   }
-  const int j0 = rowtiles[blockIdx.x - 1] * NB;  // structurally non-zero tile (kb, j), j < kb
-  double u = 0;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int rr = 16 * q + r;
-    u += (rr < kw) ? S[(size_t)(k0 + rr) * ldS + j0 + c] * xk[rr] : 0.0;
-  }
-  part[q][c] = u;
-  __syncthreads();
-  if (tid < NB) y[j0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
 __global__ void __launch_bounds__(256) k_copy_rhs_row(const double* __restrict__ S, int ldS, int n, double* __restrict__ x) {
@@ -1256,24 +1282,22 @@ void ba_launch_schur(hipStream_t s, const BaView& V) {
   hipMemsetAsync(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double), s);
   hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
+  hipLaunchKernelGGL(k_pad_identity, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V);
 }
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
-  const int n = 6 * V.nfree, n1 = n + 1;
-  if (n == 0) return;
-  const int nkb = cdiv(n1, NB);
-  for (int kb = 0; kb < nkb; kb++) {
-    const int below = cdiv(std::max(n1 - (kb + 1) * NB, 0), NB);
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, V.S, V.ldS, n1, kb, d_fail, V.Linv);
-    (void)below;
-    const int ns = V.h_strip_off[kb + 1] - V.h_strip_off[kb], nt = V.h_tile_off[kb + 1] - V.h_tile_off[kb];
-    if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(ns), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.Linv, V.strips + V.h_strip_off[kb]);
-    if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt), dim3(256), 0, s, V.S, V.ldS, n1, kb, V.tiles + 2 * (size_t)V.h_tile_off[kb]);
+  if (V.nfree == 0) return;
+  const int n1 = V.n_pad + 1;
+  for (int h = 0; h < V.nlevels; h++) {
+    const int nc = V.h_level_off[h + 1] - V.h_level_off[h], ns = V.h_strip_off[h + 1] - V.h_strip_off[h];
+    const int nt = V.h_tgt_off[h + 1] - V.h_tgt_off[h];
+    hipLaunchKernelGGL(k_chol_diag, dim3(nc), dim3(256), 0, s, V.S, V.ldS, n1, V.cols + V.h_level_off[h], d_fail, V.Linv);
+    if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
+    if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }
-  hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(n, 256)), dim3(256), 0, s, V.S, V.ldS, n, V.ytmp);
-  const int nxb = cdiv(n, NB);
-  for (int kb = nxb - 1; kb >= 0; kb--)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1 + V.h_row_off[kb + 1] - V.h_row_off[kb]), dim3(256), 0, s, V.S, V.ldS, n, kb,
-                       V.ytmp, V.x, V.Linv, V.rowtiles + V.h_row_off[kb]);
+  hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.ytmp);
+  for (int h = V.nlevels - 1; h >= 0; h--)
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(V.h_level_off[h + 1] - V.h_level_off[h]), dim3(256), 0, s, V.S, V.ldS, V.n_pad,
+                       V.nfree, V.cols + V.h_level_off[h], V.ytmp, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);

@@ -1,0 +1,201 @@
+// dvm_slam_amd/csrc/ba_ordering.cpp -- see ba_ordering.h.
+#include "ba_ordering.h"
+
+#include <algorithm>
+#include <functional>
+#include <queue>
+
+namespace dvm {
+
+namespace {
+using Graph = std::vector<std::vector<int>>;
+
+Graph clean(const Graph& g) {
+  Graph c(g.size());
+  for (size_t a = 0; a < g.size(); a++) {
+    c[a] = g[a];
+    std::sort(c[a].begin(), c[a].end());
+    c[a].erase(std::unique(c[a].begin(), c[a].end()), c[a].end());
+    c[a].erase(std::remove(c[a].begin(), c[a].end(), (int)a), c[a].end());
+  }
+  return c;
+}
+
+// BFS level structure of the sub-graph `in` (mask) from `root`; returns levels, fills order (level by level,
+// neighbours by increasing degree = Cuthill-McKee)
+std::vector<std::vector<int>> bfs_levels(const Graph& g, const std::vector<char>& in, int root, std::vector<char>& seen) {
+  std::vector<std::vector<int>> levels;
+  std::vector<int> cur{root};
+  seen[root] = 1;
+  while (!cur.empty()) {
+    levels.push_back(cur);
+    std::vector<int> next;
+    for (int v : cur) {
+      std::vector<int> nb;
+      for (int u : g[v]) if (in[u] && !seen[u]) { seen[u] = 1; nb.push_back(u); }
+      std::sort(nb.begin(), nb.end(), [&](int a, int b) { return g[a].size() != g[b].size() ? g[a].size() < g[b].size() : a < b; });
+      next.insert(next.end(), nb.begin(), nb.end());
+    }
+    cur.swap(next);
+  }
+  return levels;
+}
+
+// pseudo-peripheral node of the component of `start` (George-Liu: repeat BFS from a min-degree node of the last level)
+int pseudo_peripheral(const Graph& g, const std::vector<char>& in, int start) {
+  int root = start;
+  size_t depth = 0;
+  for (int it = 0; it < 8; it++) {
+    std::vector<char> seen(g.size(), 0);
+    auto lv = bfs_levels(g, in, root, seen);
+    if (lv.size() <= depth) break;
+    depth = lv.size();
+    int best = lv.back()[0];
+    for (int v : lv.back()) if (g[v].size() < g[best].size()) best = v;
+    if (best == root) break;
+    root = best;
+  }
+  return root;
+}
+
+// nested dissection of the sub-graph `nodes`: returns the elimination order (separators last)
+void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vector<int>& out) {
+  if (nodes.size() <= 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+  std::vector<char> in(g.size(), 0);
+  for (int v : nodes) in[v] = 1;
+  std::vector<char> done(g.size(), 0);
+  for (int s : nodes) {
+    if (done[s]) continue;
+    const int root = pseudo_peripheral(g, in, s);
+    std::vector<char> seen(g.size(), 0);
+    auto lv = bfs_levels(g, in, root, seen);
+    size_t cnt = 0;
+    for (auto& l : lv) { cnt += l.size(); for (int v : l) done[v] = 1; }
+    if (lv.size() < 3) {   // no interior level to cut at: a clique-like piece, eliminate as is
+      for (auto& l : lv) out.insert(out.end(), l.begin(), l.end());
+      continue;
+    }
+    // separator = the level that best balances the two sides
+    size_t acc = 0, mid = 1, best = cnt;
+    for (size_t i = 0; i + 1 < lv.size(); i++) {
+      if (i >= 1) {
+        const size_t a = acc, b = cnt - acc - lv[i].size();
+        const size_t unbalance = (a > b ? a - b : b - a) + lv[i].size();
+        if (unbalance < best) { best = unbalance; mid = i; }
+      }
+      acc += lv[i].size();
+    }
+    std::vector<int> A, B;
+    for (size_t i = 0; i < mid; i++) A.insert(A.end(), lv[i].begin(), lv[i].end());
+    for (size_t i = mid + 1; i < lv.size(); i++) B.insert(B.end(), lv[i].begin(), lv[i].end());
+    nested_dissection(g, A, out);
+    nested_dissection(g, B, out);
+    out.insert(out.end(), lv[mid].begin(), lv[mid].end());
+  }
+}
+}  // namespace
+
+std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in) {
+  const int n = (int)adj_in.size();
+  const Graph g = clean(adj_in);
+  // 1. band the camera graph: Cuthill-McKee per connected component
+  std::vector<int> cm;
+  {
+    std::vector<char> all(n, 1), placed(n, 0);
+    for (int s = 0; s < n; s++) {
+      if (placed[s]) continue;
+      const int root = pseudo_peripheral(g, all, s);
+      std::vector<char> seen(n, 0);
+      for (auto& l : bfs_levels(g, all, root, seen))
+        for (int v : l) { cm.push_back(v); placed[v] = 1; }
+    }
+  }
+  // 2. whole cameras per tile, tile graph
+  const int nt = (n + kCamsPerTile - 1) / kCamsPerTile;
+  std::vector<int> tile_of(n);
+  for (int i = 0; i < n; i++) tile_of[cm[i]] = i / kCamsPerTile;
+  Graph tg(nt);
+  for (int a = 0; a < n; a++)
+    for (int b : g[a]) if (tile_of[a] != tile_of[b]) tg[tile_of[a]].push_back(tile_of[b]);
+  tg = clean(tg);
+  // 3. nested dissection of the tiles
+  std::vector<int> all_tiles(nt), torder;
+  for (int t = 0; t < nt; t++) all_tiles[t] = t;
+  nested_dissection(tg, all_tiles, torder);
+  // 4. final camera order: tiles in elimination order, cameras inside a tile in banded order
+  std::vector<int> pos(n, -1);
+  int p = 0;
+  for (int t : torder)
+    for (int i = t * kCamsPerTile; i < std::min(n, (t + 1) * kCamsPerTile); i++) pos[cm[i]] = p++;
+  // a partially filled tile may only be the LAST one (row mapping i -> (i / 10) * 64 + (i % 10) * 6): if the short
+  // tile was moved forward by the dissection, shift it to the end of the order
+  if (n % kCamsPerTile != 0 && nt > 0 && torder.back() != nt - 1) {
+    std::vector<int> t2;
+    for (int t : torder) if (t != nt - 1) t2.push_back(t);
+    t2.push_back(nt - 1);
+    p = 0;
+    for (int t : t2)
+      for (int i = t * kCamsPerTile; i < std::min(n, (t + 1) * kCamsPerTile); i++) pos[cm[i]] = p++;
+  }
+  return pos;
+}
+
+BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
+  BaTileSchedule S;
+  const int nt = (int)T.size();
+  S.ntiles = nt;
+  for (int k = 0; k < nt; k++) { T[k][k] = 1; T[nt - 1][k] = 1; }
+  // symbolic factorisation in index order, per-column structure
+  std::vector<std::vector<int>> col(nt);
+  for (int k = 0; k < nt; k++) {
+    for (int i = k + 1; i < nt; i++) if (T[i][k]) col[k].push_back(i);
+    for (size_t a = 0; a < col[k].size(); a++)
+      for (size_t b = 0; b <= a; b++) T[col[k][a]][col[k][b]] = 1;
+  }
+  size_t nz = 0;
+  for (int i = 0; i < nt; i++) for (int j = 0; j <= i; j++) nz += T[i][j] ? 1 : 0;
+  S.fill = (double)nz / ((double)nt * (nt + 1) / 2);
+  // elimination tree heights: parent(k) = first row of column k
+  std::vector<int> height(nt, 0);
+  for (int k = 0; k < nt; k++)
+    if (!col[k].empty()) height[col[k][0]] = std::max(height[col[k][0]], height[k] + 1);
+  // (heights are final when visited in index order because parent(k) > k)
+  int nl = 0;
+  for (int k = 0; k < nt; k++) nl = std::max(nl, height[k] + 1);
+  S.nlevels = nl;
+  S.level_off.assign(1, 0); S.strip_off.assign(1, 0); S.tgt_off.assign(1, 0);
+  for (int h = 0; h < nl; h++) {
+    std::vector<std::vector<std::vector<int>>> upd(nt);   // upd[ti][tj] -> contributing columns (dense map is fine: nt is small)
+    std::vector<std::pair<int, int>> touched;
+    for (int k = 0; k < nt; k++) {
+      if (height[k] != h) continue;
+      S.cols.push_back(k);
+      for (int i : col[k]) { S.strips.push_back(i); S.strips.push_back(k); }
+      for (size_t a = 0; a < col[k].size(); a++)
+        for (size_t b = 0; b <= a; b++) {
+          const int ti = col[k][a], tj = col[k][b];
+          if (upd[ti].empty()) upd[ti].resize(nt);
+          if (upd[ti][tj].empty()) touched.push_back({ti, tj});
+          upd[ti][tj].push_back(k);
+        }
+    }
+    std::sort(touched.begin(), touched.end());
+    for (auto& t : touched) {
+      S.targets.push_back(t.first); S.targets.push_back(t.second);
+      S.targets.push_back((int32_t)S.contrib.size());
+      for (int k : upd[t.first][t.second]) S.contrib.push_back(k);
+      S.targets.push_back((int32_t)S.contrib.size());
+    }
+    S.level_off.push_back((int32_t)S.cols.size());
+    S.strip_off.push_back((int32_t)(S.strips.size() / 2));
+    S.tgt_off.push_back((int32_t)(S.targets.size() / 4));
+  }
+  S.colstrip_off.assign(1, 0);
+  for (int k = 0; k < nt; k++) {
+    for (int i : col[k]) S.colstrips.push_back(i);
+    S.colstrip_off.push_back((int32_t)S.colstrips.size());
+  }
+  return S;
+}
+
+}  // namespace dvm

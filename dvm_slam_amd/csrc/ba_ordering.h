@@ -1,0 +1,43 @@
+// dvm_slam_amd/csrc/ba_ordering.h -- host-side ordering + symbolic analysis of the reduced camera system.
+//
+// g2o hands the reduced camera matrix to a sparse Cholesky with a fill-reducing ordering
+// (reference Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:59, Eigen::SimplicialLDLT + AMD).  On the GPU the
+// matrix is factored as dense 64x64 tiles; what matters there is not fill alone but the LENGTH OF THE DEPENDENCY
+// CHAIN: a trajectory-ordered matrix is block-banded and its elimination tree is a path (one tile column after the
+// other, 47 dependent steps at 500 keyframes).  This module
+//   1. bands the camera graph (Cuthill-McKee), packs whole cameras into tiles (10 cameras = 60 of 64 rows),
+//   2. orders the TILES by nested dissection (BFS level-structure separators), which turns the path into a
+//      bushy elimination tree,
+//   3. runs the symbolic tile factorisation and groups the tile columns by elimination-tree height: all columns of
+//      one height are independent and are factored by ONE launch.
+// Pure host code, no HIP: unit-tested on the CPU (tests/test_host_logic.py via tools/check_ba_ordering.cpp).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace dvm {
+
+constexpr int kCamsPerTile = 10;   // 6 * 10 = 60 rows of a 64-row tile; rows 60..63 are identity padding
+
+// adj[a] = cameras sharing a landmark with camera a (any order, may contain duplicates / a itself).
+// Returns pos[a] = position of camera a in the elimination order (a permutation of 0..n-1).
+std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj);
+
+struct BaTileSchedule {
+  int ntiles = 0;                      // tiles of the factor, the last one holds the augmented rhs row
+  int nlevels = 0;
+  std::vector<int32_t> level_off;      // [nlevels+1] -> cols
+  std::vector<int32_t> cols;           // tile columns grouped by elimination-tree height (leaves first)
+  std::vector<int32_t> strip_off;      // [nlevels+1] -> strips (pairs)
+  std::vector<int32_t> strips;         // (row tile i, column k): L(i,k) != 0, i > k, k in the level
+  std::vector<int32_t> tgt_off;        // [nlevels+1] -> targets (quads)
+  std::vector<int32_t> targets;        // (ti, tj, c0, c1): trailing tile ti >= tj updated by contrib[c0..c1)
+  std::vector<int32_t> contrib;        // column k of each contribution, ascending within a target (deterministic sum)
+  std::vector<int32_t> colstrip_off;   // [ntiles+1] -> colstrips
+  std::vector<int32_t> colstrips;      // per column k: row tiles i > k with L(i,k) != 0 (back substitution)
+  double fill = 1.0;                   // non-zero tiles / all lower tiles
+};
+// T[i][j] (i >= j) = structurally non-zero tile of the matrix in elimination order; the last tile row (rhs) is dense.
+BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T);
+
+}  // namespace dvm

@@ -16,6 +16,7 @@
 
 #include "../../include/dvmslam_hip.h"
 #include "ba_kernels.h"
+#include "ba_ordering.h"
 #include "orb_pipeline.h"  // set_error / hip_check / DVM_HIP
 
 using namespace dvm;
@@ -33,7 +34,7 @@ struct dvm_ba {
   uint8_t* d_depth = nullptr;
   bool have_problem = false;
   double ms_structure = 0;
-  std::vector<int32_t> strip_off, tile_off, row_off;  // host copies of the per-step tile lists' offsets
+  BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
   double tile_fill = 1.0;                             // non-zero tiles / all lower tiles of the factor
   hipGraphExec_t trial_graph = nullptr;  // one LM trial (push, Schur, Cholesky solve, update, chi2) as a hipGraph
 
@@ -121,11 +122,26 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   for (int p = 0; p < P; p++) ps_start[p + 1] = ps_start[p] + ps_cnt[p + 1];
   std::vector<int32_t> pt_edges(E), ps_edges(E), pt_fill(pt_start.begin(), pt_start.end() - 1), ps_fill(ps_start.begin(), ps_start.end() - 1);
   for (int k = 0; k < E; k++) { pt_edges[pt_fill[e_point[k]]++] = k; ps_edges[ps_fill[e_pose[k]]++] = k; }
-  // free cameras in index order (g2o sorts the active vertices by id, sparse_optimizer.cpp:161-185)
-  std::vector<int32_t> pidx(P, -1), free_pose;
+  // Free cameras.  g2o orders them by vertex id (sparse_optimizer.cpp:161-185) and leaves the fill-reducing
+  // permutation to the sparse Cholesky; here the permutation is applied up front (ba_ordering.h): banding + nested
+  // dissection at tile granularity, so that the dense-tile factorisation has a short dependency chain.
+  std::vector<int32_t> nat_of(P, -1), nat_pose;
   for (int p = 0; p < P; p++)
-    if (!fixed[p] && ps_cnt[p + 1] > 0) { pidx[p] = (int32_t)free_pose.size(); free_pose.push_back(p); }
-  V.nfree = (int)free_pose.size();
+    if (!fixed[p] && ps_cnt[p + 1] > 0) { nat_of[p] = (int32_t)nat_pose.size(); nat_pose.push_back(p); }
+  V.nfree = (int)nat_pose.size();
+  std::vector<std::vector<int>> cam_adj(V.nfree);
+  for (int l = 0; l < L; l++)
+    for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
+      const int ca = nat_of[e_pose[pt_edges[a]]];
+      if (ca < 0) continue;
+      for (int b = pt_start[l]; b < a; b++) {
+        const int cb = nat_of[e_pose[pt_edges[b]]];
+        if (cb >= 0 && cb != ca) { cam_adj[ca].push_back(cb); cam_adj[cb].push_back(ca); }
+      }
+    }
+  const std::vector<int> cam_pos = ba_order_cameras(cam_adj);
+  std::vector<int32_t> pidx(P, -1), free_pose(V.nfree);
+  for (int a = 0; a < V.nfree; a++) { pidx[nat_pose[a]] = cam_pos[a]; free_pose[cam_pos[a]] = nat_pose[a]; }
   // non-zero lower blocks (i1 >= i2) and their (edge, edge) pairs
   std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> blocks;
   for (int i = 0; i < V.nfree; i++) blocks[{i, i}];
@@ -147,37 +163,22 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   }
   V.nblk = (int)blk_i1.size();
   const int n = 6 * V.nfree;
-  V.ldS = (n + 1 + 63) / 64 * 64;
-  // ---- symbolic tile-level Cholesky (64x64 tiles): which tiles of L are structurally non-zero.  SLAM
-  // reduced camera matrices are banded along the trajectory plus a few loop-closure blocks; skipping
-  // zero tiles keeps the dense-tile solver exact while doing only the work the structure requires.
-  const int nkb = V.ldS / 64;
+  // ---- tile space: 10 whole cameras per 64-row tile, one extra tile for the augmented rhs row
+  const int ncamt = (V.nfree + kCamsPerTile - 1) / kCamsPerTile, nkb = ncamt + 1;
+  V.n_pad = 64 * ncamt;
+  V.ldS = 64 * nkb;
+  // ---- symbolic tile Cholesky + level schedule.  SLAM reduced camera matrices are banded along the trajectory plus
+  // a few loop-closure blocks; skipping zero tiles keeps the dense-tile solver exact while doing only the work the
+  // structure requires, and the nested-dissection order makes most tile columns independent of each other.
   std::vector<std::vector<char>> T(nkb, std::vector<char>(nkb, 0));
   for (size_t b = 0; b < blk_i1.size(); b++) {
-    const int r0 = 6 * blk_i1[b], c0 = 6 * blk_i2[b];
-    for (int tr = r0 / 64; tr <= (r0 + 5) / 64; tr++)
-      for (int tc = c0 / 64; tc <= (c0 + 5) / 64; tc++)
-        if (tr >= tc) T[tr][tc] = 1; else T[tc][tr] = 1;
+    const int tr = blk_i1[b] / kCamsPerTile, tc = blk_i2[b] / kCamsPerTile;
+    T[std::max(tr, tc)][std::min(tr, tc)] = 1;
   }
-  for (int k = 0; k < nkb; k++) { T[k][k] = 1; T[n / 64][k] = (k <= n / 64) ? 1 : T[n / 64][k]; }  // augmented rhs row is dense
-  std::vector<int32_t> strips, tiles, rowtiles;
-  h->strip_off.assign(1, 0); h->tile_off.assign(1, 0); h->row_off.assign(1, 0);
-  for (int k = 0; k < nkb; k++) {
-    std::vector<int> rows;
-    for (int i = k + 1; i < nkb; i++) if (T[i][k]) rows.push_back(i);
-    for (int i : rows) strips.push_back(i);
-    for (size_t a = 0; a < rows.size(); a++)
-      for (size_t b2 = 0; b2 <= a; b2++) { T[rows[a]][rows[b2]] = 1; tiles.push_back(rows[a]); tiles.push_back(rows[b2]); }
-    h->strip_off.push_back((int32_t)strips.size());
-    h->tile_off.push_back((int32_t)(tiles.size() / 2));
-  }
-  size_t nz = 0;
-  for (int k = 0; k < nkb; k++) {
-    for (int j = 0; j < k; j++) if (T[k][j]) rowtiles.push_back(j);
-    h->row_off.push_back((int32_t)rowtiles.size());
-    for (int j = 0; j <= k; j++) nz += T[k][j];
-  }
-  h->tile_fill = (double)nz / ((double)nkb * (nkb + 1) / 2);
+  h->sched = ba_tile_schedule(T);
+  const BaTileSchedule& SC = h->sched;
+  h->tile_fill = SC.fill;
+  V.nlevels = SC.nlevels;
 
   int rc = DVM_OK;
   auto ok = [&](int r) { if (rc == DVM_OK) rc = r; };
@@ -194,12 +195,14 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(h->dalloc(&V.Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&V.bp, (size_t)n));
   ok(h->dalloc(&V.Hll, 9 * (size_t)L)); ok(h->dalloc(&V.bl, 3 * (size_t)L));
   ok(h->dalloc(&V.Dinv, 9 * (size_t)L)); ok(h->dalloc(&V.db, 3 * (size_t)L));
-  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)n + 64));
+  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)V.n_pad + 64));
+  ok(h->dalloc(&V.xrow, (size_t)V.n_pad + 64));
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(std::max(L, V.nfree) + 255) / 256));
   ok(h->dalloc(&h->d_depth, (size_t)E));
-  ok(h->upload(&V.strips, strips)); ok(h->upload(&V.tiles, tiles)); ok(h->upload(&V.rowtiles, rowtiles));
-  V.h_strip_off = h->strip_off.data(); V.h_tile_off = h->tile_off.data(); V.h_row_off = h->row_off.data();
+  ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
+  ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
+  V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   // poses: normalise quaternions like SE3Quat's constructor (se3quat.h:261-266)
   std::vector<double> pn(poses, poses + 7 * (size_t)P);

@@ -1,0 +1,59 @@
+// tools/check_ba_ordering.cpp -- CPU check of dvm_slam_amd/csrc/ba_ordering.cpp (run by tests/test_host_logic.py):
+// the camera order is a permutation, whole tiles stay together, the level schedule respects every dependency of
+// the tile Cholesky, and nested dissection shortens the dependency chain of a loop trajectory.
+//   g++ -O2 -std=c++17 tools/check_ba_ordering.cpp dvm_slam_amd/csrc/ba_ordering.cpp -o /tmp/check_ba_ordering
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#include "../dvm_slam_amd/csrc/ba_ordering.h"
+
+using namespace dvm;
+
+static int fail(const char* m) { std::printf("FAIL: %s\n", m); return 1; }
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? std::atoi(argv[1]) : 499, span = argc > 2 ? std::atoi(argv[2]) : 7;
+  const bool loop = argc > 3 ? std::atoi(argv[3]) != 0 : true;
+  std::vector<std::vector<int>> adj(n);
+  for (int a = 0; a < n; a++)
+    for (int d = 1; d <= span; d++) {
+      int b = a + d;
+      if (b >= n) { if (!loop) continue; b -= n; }
+      adj[a].push_back(b); adj[b].push_back(a);
+    }
+  const std::vector<int> pos = ba_order_cameras(adj);
+  std::set<int> seen(pos.begin(), pos.end());
+  if ((int)seen.size() != n || *seen.begin() != 0 || *seen.rbegin() != n - 1) return fail("not a permutation");
+  const int nt = (n + kCamsPerTile - 1) / kCamsPerTile + 1;   // + rhs tile
+  std::vector<std::vector<char>> T(nt, std::vector<char>(nt, 0));
+  for (int a = 0; a < n; a++)
+    for (int b : adj[a]) {
+      const int ta = pos[a] / kCamsPerTile, tb = pos[b] / kCamsPerTile;
+      T[std::max(ta, tb)][std::min(ta, tb)] = 1;
+    }
+  const BaTileSchedule S = ba_tile_schedule(T);
+  // replay: a column may be factored only after every update into it and into its strips has been applied
+  std::vector<int> level_of(nt, -1);
+  for (int h = 0; h < S.nlevels; h++)
+    for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) level_of[S.cols[c]] = h;
+  for (int k = 0; k < nt; k++) if (level_of[k] < 0) return fail("column missing from the schedule");
+  for (int h = 0; h < S.nlevels; h++) {
+    for (int s = S.strip_off[h]; s < S.strip_off[h + 1]; s++) {
+      const int i = S.strips[2 * s], k = S.strips[2 * s + 1];
+      if (level_of[k] != h || i <= k) return fail("strip in the wrong level");
+      if (level_of[i] <= h) return fail("a strip row is factored no later than its column");
+    }
+    for (int t = S.tgt_off[h]; t < S.tgt_off[h + 1]; t++) {
+      const int ti = S.targets[4 * t], tj = S.targets[4 * t + 1];
+      if (level_of[ti] <= h || level_of[tj] <= h) return fail("update target already factored");
+      for (int c = S.targets[4 * t + 2]; c < S.targets[4 * t + 3]; c++)
+        if (level_of[S.contrib[c]] != h) return fail("contribution from another level");
+    }
+  }
+  std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
+              S.targets.size() / 4);
+  if (loop && n >= 300 && S.nlevels > nt / 2) return fail("nested dissection did not shorten the dependency chain");
+  return 0;
+}
