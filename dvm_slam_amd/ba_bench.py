@@ -35,8 +35,9 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0):
                      "unit": "TFLOP/s", "frac": FLOPS_DENSE_CHOLESKY * st["total_trials"] / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                      "note": "dense-equivalent rate: n^3/3 FLOP of a dense n=2994 factorisation per trial over the WHOLE "
                              "iteration time (edge pass, Schur, solve, update); the solver itself skips structurally zero "
-                             "64x64 tiles (symbolic tile fill), so executed FLOPs are lower -- the solve is a latency chain of "
-                             "47 dependent steps, not MFMA-throughput bound (DESIGN.md section 3)"},
+                             "64x64 tiles (symbolic tile fill), so executed FLOPs are lower -- the solve is a dependency chain of "
+                             "elimination-tree levels (12 at this size after nested dissection; 47 tile columns before), "
+                             "each level = 3 launches, not MFMA-throughput bound (DESIGN.md section 3)"},
     }
     if cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(pr, delta, cpu_seconds)
