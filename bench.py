@@ -177,6 +177,8 @@ def main():
                     "bytes_per_launch": BYTES_PER_FRAME_FAST * frames_per_launch, "avg_launch_ms": fast_ms / fast_n,
                     "frames_per_launch": frames_per_launch,
                     "all_stage_bytes_per_frame": BYTES_PER_FRAME_TOTAL,
+                    "pipeline_achieved": BYTES_PER_FRAME_TOTAL * total_frames / world / dt / 1e9,   # whole step, GB/s per GPU
+                    "pipeline_frac": BYTES_PER_FRAME_TOTAL * total_frames / world / dt / 1e9 / HBM_PEAK_GBS,
                     "gpu_kernel_ms_per_step": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}}
         out = {
             "metric": "frames/sec ORB extract+match 640x480x8lvl", "value": total_frames / dt, "unit": "frames/s",
