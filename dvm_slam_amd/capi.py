@@ -475,3 +475,29 @@ def search_by_projection_frames(kps_c, desc_c, mp_c, Rcw, tcw, K, bounds, scale_
     if n < 0:
         check(n)
     return n, mp, req.value
+
+
+TRACKED_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                                ("in_view", "u1"), ("bad", "u1"), ("pad", "u1", (2,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
+
+
+def search_by_projection_points(kps, desc, mp, claimed_obs, bounds, scale_factors, pts, th, nnratio=0.8, far_points=False,
+                                th_far=0.0, device=0):
+    """dvm_host::ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) -- reference
+    ORBmatcher.cc:44-205.  Returns (nmatches, updated mvpMapPoints, #host re-queries)."""
+    H = host_lib()
+    vp = C.c_void_p
+    H.dvmh_search_by_projection_points.restype = C.c_int32
+    H.dvmh_search_by_projection_points.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32,
+                                                   C.c_float, C.c_float, C.c_int32, C.c_float, vp]
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    mpc = np.array(mp, np.int32, copy=True)
+    co = np.ascontiguousarray(claimed_obs, np.uint8)
+    b = np.ascontiguousarray(bounds, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    pts = np.ascontiguousarray(pts, TRACKED_POINT_DTYPE)
+    req = C.c_int32(0)
+    n = H.dvmh_search_by_projection_points(device, len(kps), _p(kps), _p(desc), _p(mpc), _p(co), _p(b), _p(sf), len(sf), _p(pts),
+                                           len(pts), float(th), float(nnratio), int(far_points), float(th_far), C.byref(req))
+    if n < 0:
+        check(n)
+    return n, mpc, req.value

@@ -113,15 +113,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   if (nq == 0) return 0;
 
   // ---- one batched device search against CurrentFrame's grid (claims known at entry are masked)
-  if (!grid_ || grid_cap_ < Cur.N) {
-    if (grid_) dvm_frame_destroy(grid_);
-    grid_ = nullptr;
-    grid_cap_ = std::max(2048, Cur.N);
-    int rc = dvm_frame_create(device_, grid_cap_, 1, &grid_);
-    if (rc != DVM_OK) return rc;
-  }
-  int rc = dvm_frame_build(grid_, 0, Cur.mvKeysUn, Cur.mDescriptors, Cur.N, nullptr, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY,
-                           Cur.mnMaxY, 0, nullptr);
+  int rc = ensure_grid(Cur);
   if (rc != DVM_OK) return rc;
   std::vector<uint8_t> claimed(grid_cap_, 0);
   for (int j = 0; j < Cur.N; j++)
@@ -175,6 +167,95 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   return nmatches;
 }
 
+int ORBmatcher::ensure_grid(const FrameView& F) {
+  if (!grid_ || grid_cap_ < F.N) {
+    if (grid_) dvm_frame_destroy(grid_);
+    grid_ = nullptr;
+    grid_cap_ = std::max(2048, F.N);
+    int rc = dvm_frame_create(device_, grid_cap_, 1, &grid_);
+    if (rc != DVM_OK) return rc;
+  }
+  return dvm_frame_build(grid_, 0, F.mvKeysUn, F.mDescriptors, F.N, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY, 0, nullptr);
+}
+
+int ORBmatcher::SearchByProjection(FrameView& F, const TrackedPointPOD* MPs, int nMP, const uint8_t* claimedObs, float th,
+                                   bool bFarPoints, float thFarPoints, int mp_index_base) {
+  int nmatches = 0;
+  last_requeried = 0;
+  const bool bFactor = th != 1.0;
+  // ---- queries: the loop header of :50-73
+  std::vector<int> qi;
+  std::vector<float> qx, qy, qr;
+  std::vector<int32_t> qmin, qmax;
+  std::vector<uint8_t> qdesc;
+  for (int i = 0; i < nMP; i++) {
+    const TrackedPointPOD& mp = MPs[i];
+    if (!mp.mbTrackInView) continue;
+    if (bFarPoints && mp.mTrackDepth > thFarPoints) continue;
+    if (mp.bad) continue;
+    const int nPredictedLevel = mp.mnTrackScaleLevel;
+    float r = RadiusByViewingCos(mp.mTrackViewCos);
+    if (bFactor) r *= th;
+    qi.push_back(i); qx.push_back(mp.mTrackProjX); qy.push_back(mp.mTrackProjY);
+    qr.push_back(r * F.mvScaleFactors[nPredictedLevel]);
+    qmin.push_back(nPredictedLevel - 1); qmax.push_back(nPredictedLevel);
+    qdesc.insert(qdesc.end(), mp.desc, mp.desc + 32);
+  }
+  const int nq = (int)qi.size();
+  if (nq == 0) return 0;
+  int rc = ensure_grid(F);
+  if (rc != DVM_OK) return rc;
+  std::vector<uint8_t> claimed(grid_cap_, 0);
+  for (int j = 0; j < F.N; j++)
+    if (F.mvpMapPoints[j] >= 0 && claimedObs && claimedObs[j]) claimed[j] = 1;
+  std::vector<dvm_match> res(nq);
+  rc = dvm_match_window(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
+                        nullptr, res.data(), 0, nullptr);
+  if (rc != DVM_OK) return rc;
+  // ---- sequential epilogue (:75-131).  A keypoint claimed earlier in THIS call (by a point with observations) is
+  // skipped by later queries and may have been their best OR second-best candidate, so a query whose window contains
+  // such a keypoint is recomputed on the host; all others keep the device result.
+  HostGrid hg;
+  bool hg_built = false;
+  std::vector<uint8_t> claimed_now = claimed;
+  std::vector<int> fresh;   // keypoints claimed during this call
+  std::vector<int> cand;
+  for (int q = 0; q < nq; q++) {
+    int bestDist = res[q].best_dist, bestDist2 = res[q].second_dist, bestLevel = res[q].best_level, bestLevel2 = res[q].second_level;
+    int bestIdx = res[q].best_idx;
+    bool touched = false;
+    for (int j : fresh) {
+      const dvm_keypoint& kp = F.mvKeysUn[j];
+      if (kp.octave < qmin[q] || kp.octave > qmax[q]) continue;
+      if (std::fabs(kp.x - qx[q]) < qr[q] && std::fabs(kp.y - qy[q]) < qr[q]) { touched = true; break; }
+    }
+    if (touched) {
+      if (!hg_built) { hg.build(F); hg_built = true; }
+      last_requeried++;
+      hg.query(qx[q], qy[q], qr[q], qmin[q], qmax[q], cand);
+      bestDist = 256; bestLevel = -1; bestDist2 = 256; bestLevel2 = -1; bestIdx = -1;
+      for (int idx : cand) {
+        if (claimed_now[idx]) continue;
+        const int dist = DescriptorDistance(&qdesc[32 * (size_t)q], F.mDescriptors + 32 * (size_t)idx);
+        if (dist < bestDist) {
+          bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F.mvKeysUn[idx].octave; bestIdx = idx;
+        } else if (dist < bestDist2) {
+          bestLevel2 = F.mvKeysUn[idx].octave; bestDist2 = dist;
+        }
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+        F.mvpMapPoints[bestIdx] = mp_index_base + qi[q];
+        if (MPs[qi[q]].n_obs > 0 && !claimed_now[bestIdx]) { claimed_now[bestIdx] = 1; fresh.push_back(bestIdx); }
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace dvm_host
 
 // ---- C entry point for the Python harness (tests only; a C++ caller uses the class directly)
@@ -193,6 +274,20 @@ extern "C" int dvmh_search_by_projection_frames(int device, int Nc, const dvm_ke
   L.N = Nl; L.mvKeysUn = kps_l; L.mDescriptors = nullptr; L.mvpMapPoints = const_cast<int32_t*>(mp_l); L.mvbOutlier = outlier_l;
   dvm_host::ORBmatcher m(0.9f, check_ori != 0, device);
   const int n = m.SearchByProjection(C, L, mps, th, true);
+  if (requeried) *requeried = m.last_requeried;
+  return n;
+}
+
+extern "C" int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp,
+                                                const uint8_t* claimed_obs, const float* bounds, const float* scale_factors,
+                                                int nlevels, const dvm_host::TrackedPointPOD* pts, int npts, float th,
+                                                float nnratio, int far_points, float th_far, int* requeried) {
+  dvm_host::FrameView F;
+  F.N = N; F.mvKeysUn = kps; F.mDescriptors = desc; F.mvpMapPoints = mp;
+  F.mnMinX = bounds[0]; F.mnMaxX = bounds[1]; F.mnMinY = bounds[2]; F.mnMaxY = bounds[3];
+  F.mvScaleFactors = scale_factors; F.nLevels = nlevels;
+  dvm_host::ORBmatcher m(nnratio, true, device);
+  const int n = m.SearchByProjection(F, pts, npts, claimed_obs, th, far_points != 0, th_far, 0);
   if (requeried) *requeried = m.last_requeried;
   return n;
 }

@@ -20,6 +20,16 @@ struct MapPointPOD {
   int32_t n_obs;       // MapPoint::Observations()
 };
 
+// A local map point as Tracking::SearchLocalPoints leaves it for the matcher: the mTrack* fields written by
+// Frame::isInFrustum (dvm_is_in_frustum fills the same values), isBad(), descriptor, Observations().
+struct TrackedPointPOD {
+  float mTrackProjX, mTrackProjY, mTrackDepth, mTrackViewCos;
+  int32_t mnTrackScaleLevel;
+  uint8_t mbTrackInView, bad, pad_[2];
+  uint8_t desc[32];
+  int32_t n_obs;
+};
+
 // The members of ORB_SLAM3::Frame the matcher touches (mono).
 struct FrameView {
   int N = 0;
@@ -50,6 +60,14 @@ class ORBmatcher {
   int SearchByProjection(FrameView& CurrentFrame, const FrameView& LastFrame, const MapPointPOD* mapPoints, float th,
                          bool bMono = true);
 
+  // int SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints,
+  //                        const float thFarPoints)   (ORBmatcher.cc:44-205, monocular: Nleft == -1, no right image).
+  // F.mvpMapPoints[idx] receives the INDEX of the matched point in vpMapPoints (offset by mp_index_base); entries
+  // already >= 0 refer to `claimedObs`: claimedObs[j] != 0 <=> F.mvpMapPoints[j]->Observations() > 0 at entry.
+  int SearchByProjection(FrameView& F, const TrackedPointPOD* vpMapPoints, int nMapPoints, const uint8_t* claimedObs, float th,
+                         bool bFarPoints, float thFarPoints, int mp_index_base = 0);
+  static float RadiusByViewingCos(float viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }   // :207-212
+
   int last_requeried = 0;  // queries re-issued on the host because an earlier match claimed their keypoint
 
  private:
@@ -59,6 +77,7 @@ class ORBmatcher {
   int device_;
   dvm_frame* grid_ = nullptr;
   int grid_cap_ = 0;
+  int ensure_grid(const FrameView& F);
 };
 
 }  // namespace dvm_host

@@ -13,6 +13,8 @@
 //   src/ORBmatcher.cc:70-115, :1604-1639  best / second-best loops -> orc_match_window()
 //   src/ORBmatcher.cc:1553-1748  SearchByProjection(CurrentFrame, LastFrame, th, bMono=true), whole function,
 //   src/ORBmatcher.cc:1862-1896  ComputeThreeMaxima              -> orc_search_by_projection_frames()
+//   src/ORBmatcher.cc:44-212     SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), mono branch,
+//                                RadiusByViewingCos              -> orc_search_by_projection_points()
 #include "oracle.h"
 
 #include <algorithm>
@@ -225,6 +227,52 @@ int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uin
     for (int i = 0; i < HISTO_LENGTH; i++)
       if (i != ind1 && i != ind2 && i != ind3)
         for (size_t j = 0; j < rotHist[i].size(); j++) { mp_c[rotHist[i][j]] = -1; nmatches--; }
+  }
+  orc_grid_destroy(g);
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, bFarPoints, thFarPoints) --
+// ORBmatcher.cc:44-205, monocular (F.Nleft == -1, mvuRight < 0).  mp[idx] = index of the matched point (-1 = NULL);
+// claimed_obs[idx] = (F.mvpMapPoints[idx]->Observations() > 0) for the entries that are set at entry.
+int orc_search_by_projection_points(int N, const orc_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
+                                    const float* bounds, const float* scale_factors, const orc_tracked_point* pts, int npts,
+                                    float th, float nnratio, int far_points, float th_far) {
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  orc_grid* g = orc_grid_create(kps, N, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<uint8_t> has_obs(N, 0);
+  for (int j = 0; j < N; j++) has_obs[j] = (mp[j] >= 0 && claimed_obs && claimed_obs[j]) ? 1 : 0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < npts; iMP++) {
+    const orc_tracked_point& pMP = pts[iMP];
+    if (!pMP.in_view) continue;
+    if (far_points && pMP.depth > th_far) continue;
+    if (pMP.bad) continue;
+    const int nPredictedLevel = pMP.level;
+    float r = pMP.view_cos > 0.998 ? 2.5 : 4.0;
+    if (bFactor) r *= th;
+    features_in_area(g, pMP.proj_x, pMP.proj_y, r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+    if (vIndices.empty()) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (mp[idx] >= 0 && has_obs[idx]) continue;
+      const int dist = descriptor_distance(pMP.desc, desc + 32 * (size_t)idx);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = kps[idx].octave; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+        mp[bestIdx] = iMP;
+        has_obs[bestIdx] = pMP.n_obs > 0 ? 1 : 0;
+        nmatches++;
+      }
+    }
   }
   orc_grid_destroy(g);
   return nmatches;

@@ -110,6 +110,12 @@ int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uin
                                     int Nl, const orc_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
                                     const orc_map_point* mps, float th, int check_ori);
 
+/* ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), mono (ORBmatcher.cc:44-205) */
+typedef struct { float proj_x, proj_y, depth, view_cos; int32_t level; uint8_t in_view, bad, pad_[2]; uint8_t desc[32]; int32_t n_obs; } orc_tracked_point;
+int orc_search_by_projection_points(int N, const orc_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
+                                    const float* bounds, const float* scale_factors, const orc_tracked_point* pts, int npts,
+                                    float th, float nnratio, int far_points, float th_far);
+
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;

@@ -378,3 +378,25 @@ def search_by_projection_frames(kps_c, desc_c, mp_c, Rcw, tcw, K, bounds, scale_
     n = L.orc_search_by_projection_frames(len(kps_c), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f], len(kps_l), _p(kps_l),
                                           _p(mp_l), None if outl is None else _p(outl), _p(mps), float(th), int(check_ori))
     return n, mp
+
+
+TRACKED_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                                ("in_view", "u1"), ("bad", "u1"), ("pad", "u1", (2,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
+
+
+def search_by_projection_points(kps, desc, mp, claimed_obs, bounds, scale_factors, pts, th, nnratio=0.8, far_points=False,
+                                th_far=0.0):
+    """Whole ORBmatcher::SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (mono).  Returns (nmatches, mp copy)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_by_projection_points.restype = C.c_int32
+    L.orc_search_by_projection_points.argtypes = [C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_float, C.c_float,
+                                                  C.c_int32, C.c_float]
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    mpc = np.array(mp, np.int32, copy=True)
+    co = np.ascontiguousarray(claimed_obs, np.uint8)
+    b = np.ascontiguousarray(bounds, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    pts = np.ascontiguousarray(pts, TRACKED_POINT_DTYPE)
+    n = L.orc_search_by_projection_points(len(kps), _p(kps), _p(desc), _p(mpc), _p(co), _p(b), _p(sf), _p(pts), len(pts),
+                                          float(th), float(nnratio), int(far_points), float(th_far))
+    return n, mpc

@@ -67,3 +67,28 @@ def make_scene(oracle, seed=0, n_last=1000, n_cur=1100, dup_frac=0.15, zero_obs_
     mp_c[pre] = rng.integers(0, n_last, 40)
     return dict(kps_c=kc, desc_c=dc, mp_c=mp_c, Rcw=Rcw.reshape(-1), tcw=tcw, K=K, bounds=bounds, scale_factors=scale,
                 kps_l=kl, mp_l=mp_l, outlier_l=outl, mps=mps)
+
+
+def make_local_map_scene(oracle, seed=0, **kw):
+    """TrackLocalMap-style input for SearchByProjection(F, vpMapPoints): tracked points (the mTrack* fields) built from
+    the two-frame scene; points compete for keypoints (duplicates), some are bad / out of view / far."""
+    sc = make_scene(oracle, seed, **kw)
+    rng = np.random.default_rng(seed + 100)
+    mps, K = sc["mps"], sc["K"]
+    R = sc["Rcw"].reshape(3, 3)
+    Xc = mps["pos"] @ R.T + sc["tcw"]
+    n = len(mps)
+    pts = np.zeros(n, oracle.TRACKED_POINT_DTYPE)
+    pts["proj_x"] = K[0] * Xc[:, 0] / Xc[:, 2] + K[2]
+    pts["proj_y"] = K[1] * Xc[:, 1] / Xc[:, 2] + K[3]
+    pts["depth"] = np.linalg.norm(Xc, axis=1)
+    pts["view_cos"] = np.where(rng.random(n) < 0.5, 0.9995, rng.uniform(0.5, 0.998, n)).astype(np.float32)
+    pts["level"] = np.clip(sc["kps_l"]["octave"] + rng.integers(0, 2, n), 0, 7)
+    inside = (Xc[:, 2] > 0) & (pts["proj_x"] >= 0) & (pts["proj_x"] < 640) & (pts["proj_y"] >= 0) & (pts["proj_y"] < 480)
+    pts["in_view"] = (inside & (rng.random(n) < 0.9)).astype(np.uint8)
+    pts["bad"] = (rng.random(n) < 0.03).astype(np.uint8)
+    pts["desc"] = mps["desc"]
+    pts["n_obs"] = mps["n_obs"]
+    claimed_obs = (rng.random(len(sc["kps_c"])) < 0.5).astype(np.uint8)
+    return dict(kps=sc["kps_c"], desc=sc["desc_c"], mp=sc["mp_c"], claimed_obs=claimed_obs, bounds=sc["bounds"],
+                scale_factors=sc["scale_factors"], pts=pts)

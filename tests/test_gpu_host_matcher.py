@@ -55,3 +55,17 @@ def test_search_by_projection_real_frames(capi, oracle, frames):
     n_g, mp_g, _ = capi.search_by_projection_frames(th=15.0, **args)
     assert n_g == n_o and np.array_equal(mp_g, mp_o)
     assert n_o > 200
+
+
+@pytest.mark.parametrize("seed,th,ratio,far", [(0, 1.0, 0.8, False), (1, 3.0, 0.8, False), (2, 5.0, 0.9, True), (3, 1.0, 0.6, True)])
+def test_search_by_projection_points(capi, oracle, seed, th, ratio, far):
+    """Whole SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints) (TrackLocalMap / relocalisation form)."""
+    from matcher_scene import make_local_map_scene
+    sc = make_local_map_scene(oracle, seed)
+    n_o, mp_o = oracle.search_by_projection_points(th=th, nnratio=ratio, far_points=far, th_far=9.0, **sc)
+    n_g, mp_g, req = capi.search_by_projection_points(th=th, nnratio=ratio, far_points=far, th_far=9.0, **sc)
+    assert n_g == n_o
+    assert np.array_equal(mp_g, mp_o)
+    assert n_o > 100
+    if seed == 1:
+        assert req > 0, "scene must exercise the claimed-keypoint re-query path"

@@ -227,3 +227,30 @@ def test_search_by_projection_frames_oracle_semantics(oracle):
     assert 0.6 * n < n2 < n
     kept = mp2 >= 0
     assert np.array_equal(mp2[kept], mp[kept])
+
+
+def test_search_by_projection_points_oracle_semantics(oracle):
+    """SearchByProjection(F, vpMapPoints): with no competing points the result must equal the per-point window search
+    (orc_match_window) followed by the reference's accept rule (TH_HIGH, same-level ratio test)."""
+    from matcher_scene import make_local_map_scene
+    sc = make_local_map_scene(oracle, 11, dup_frac=0.0)
+    sc["pts"]["n_obs"] = 0                       # nothing ever claims a keypoint -> order independent
+    sc["mp"][:] = -1
+    n, mp = oracle.search_by_projection_points(th=3.0, nnratio=0.8, **sc)
+    pts = sc["pts"]
+    sel = np.flatnonzero((pts["in_view"] == 1) & (pts["bad"] == 0))
+    r = np.where(pts["view_cos"][sel] > 0.998, np.float32(2.5), np.float32(4.0)) * np.float32(3.0)
+    qr = (r * sc["scale_factors"][pts["level"][sel]]).astype(np.float32)
+    g = oracle.Grid(sc["kps"])
+    m = g.match_window(sc["desc"], pts["desc"][sel], pts["proj_x"][sel], pts["proj_y"][sel], qr, pts["level"][sel] - 1, pts["level"][sel])
+    ref = np.full(len(sc["kps"]), -1, np.int32); cnt = 0
+    for k, i in enumerate(sel):
+        bd, sd = int(m["best_dist"][k]), int(m["second_dist"][k])
+        if bd > 100:
+            continue
+        same = m["best_level"][k] == m["second_level"][k]
+        if same and np.float32(bd) > np.float32(0.8) * np.float32(sd):
+            continue
+        ref[m["best_idx"][k]] = i; cnt += 1
+    assert n == cnt and np.array_equal(mp, ref)
+    assert n > 100
