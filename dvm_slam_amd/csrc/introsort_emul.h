@@ -171,6 +171,60 @@ DVM_HD void kv_introsort_loop(A& a, int n, StackPtr stk) {
   }
 }
 
+// The same __introsort_loop with __unguarded_partition in RANK form -- the formulation the device parallelises
+// (octree_kernel.hip: one wavefront, ballots instead of the two loops below).  With pivot P = a[first]:
+//   I[k] = k-th position in (first, last), ascending, whose key is >= P          (where the `lo` scan stops)
+//   J[k] = k-th position in [first, last), descending, whose key is <= P         (where the `hi` scan stops;
+//          `first` itself holds P and is the sentinel the unguarded scan relies on)
+// The serial loop swaps exactly the pairs (I[k], J[k]) for k < m, m = first k with !(I[k] < J[k]), because a swapped
+// element is never examined again (lo steps over it, hi steps under it); it returns cut = min(I[m], J[m-1]):
+// lo stops at the next untouched >= P position or at the last position it filled with one, whichever comes first.
+// I, J: scratch of n entries each.  tools/check_introsort.cpp checks this against std::sort as well.
+template <class A, class StackPtr, class IdxPtr>
+DVM_HD void kv_introsort_loop_ranked(A& a, int n, StackPtr stk, IdxPtr I, IdxPtr J) {
+  if (n <= 1) return;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) lg++;
+  StackPtr sf = stk, sl = stk + 48, sd = stk + 96;
+  int sp = 0;
+  sf[sp] = 0; sl[sp] = n; sd[sp] = 2 * lg; sp++;
+  while (sp > 0) {
+    --sp;
+    int first = sf[sp], last = sl[sp], depth = sd[sp];
+    while (last - first > 16) {
+      if (depth == 0) {
+        kv_heapsort(a, first, last);
+        break;
+      }
+      --depth;
+      const int mid = first + (last - first) / 2;
+      {  // __move_median_to_first(first, first+1, mid, last-1)
+        const int r = first, x = first + 1, y = mid, z = last - 1;
+        const uint32_t kx = a.key(x), ky = a.key(y), kz = a.key(z);
+        if (kx < ky) {
+          if (ky < kz) kv_swap(a, r, y);
+          else if (kx < kz) kv_swap(a, r, z);
+          else kv_swap(a, r, x);
+        } else if (kx < kz) kv_swap(a, r, x);
+        else if (ky < kz) kv_swap(a, r, z);
+        else kv_swap(a, r, y);
+      }
+      const uint32_t pk = a.key(first);
+      int nI = 0, nJ = 0;
+      for (int p = first + 1; p < last; p++) if (!(a.key(p) < pk)) I[nI++] = p;
+      for (int p = last - 1; p >= first; p--) if (!(pk < a.key(p))) J[nJ++] = p;
+      int m = 0;
+      while (m < nI && m < nJ && I[m] < J[m]) m++;
+      for (int k = 0; k < m; k++) kv_swap(a, I[k], J[k]);
+      int cut = 0x7fffffff;
+      if (m < nI) cut = I[m];
+      if (m > 0 && J[m - 1] < cut) cut = J[m - 1];
+      sf[sp] = cut; sl[sp] = last; sd[sp] = depth; sp++;
+      last = cut;
+    }
+  }
+}
+
 // std::sort(first, last, comp) of libstdc++ on n elements starting at index 0 (fully serial form).
 template <class A>
 DVM_HD void kv_std_sort(A& a, int n) {

@@ -10,7 +10,7 @@
 // Keys keep a node id; child sizes come from LDS atomics over all candidates (order-free counts).
 // The retained key per node is max response, first in vToDistributeKeys order on ties (:594-607),
 // i.e. atomicMax of (response << 20 | ~index).  std::sort's treatment of EQUAL (size, UL.x) keys is
-// reproduced by the step-exact emulation in introsort_emul.h (one lane).
+// reproduced by the step-exact emulation in introsort_emul.h (one wavefront, partition in rank form).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,6 +39,99 @@ struct KVLds {
   __device__ __forceinline__ uint32_t val(int i) const { return v[i]; }
   __device__ __forceinline__ void set(int i, uint32_t kk, uint32_t vv) { k[i] = kk; v[i] = (uint16_t)vv; }
 };
+
+__device__ __forceinline__ void wave_lds_sync() {   // order this wave's LDS traffic across lanes
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// libstdc++ __introsort_loop (introsort_emul.h, kv_introsort_loop_ranked) executed by ONE wavefront: the control flow
+// is wave-uniform, the median swap is a handful of broadcast reads, and __unguarded_partition runs in rank form --
+// ballots give every element its rank among the ">= pivot" positions (ascending) and the "<= pivot" positions
+// (descending), the k-th pair is swapped by lane k.  Same array as the serial loop after every step
+// (tools/check_introsort.cpp), ~10 dependent LDS operations per partition instead of ~5 per ELEMENT.
+// key/val: the array; I, J: scratch of n ints each; stk: 144 ints.  All in LDS.
+__device__ void wave_introsort_loop(lds_u32* key, lds_u16* val, int n, lds_i32* stk, lds_i32* I, lds_i32* J) {
+  const int lane = threadIdx.x & 63;
+  if (n <= 1) return;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) lg++;
+  lds_i32 *sf = stk, *sl = stk + 48, *sd = stk + 96;
+  int sp = 0;
+  sf[sp] = 0; sl[sp] = n; sd[sp] = 2 * lg; sp++;   // every lane writes the same value
+  wave_lds_sync();
+  while (sp > 0) {
+    --sp;
+    int first = sf[sp], last = sl[sp], depth = sd[sp];
+    while (last - first > 16) {
+      if (depth == 0) {
+        if (lane == 0) { KVLds kv{key, val}; kv_heapsort(kv, first, last); }
+        wave_lds_sync();
+        break;
+      }
+      --depth;
+      {  // __move_median_to_first(first, first+1, mid, last-1)
+        const int mid = first + (last - first) / 2;
+        const int x = first + 1, y = mid, z = last - 1;
+        const uint32_t kx = key[x], ky = key[y], kz = key[z];
+        int t;
+        if (kx < ky) t = (ky < kz) ? y : ((kx < kz) ? z : x);
+        else t = (kx < kz) ? x : ((ky < kz) ? z : y);
+        if (lane == 0) {
+          const uint32_t k0 = key[first], kt = key[t];
+          const uint16_t v0 = val[first], vt = val[t];
+          key[first] = kt; val[first] = vt; key[t] = k0; val[t] = v0;
+        }
+        wave_lds_sync();
+      }
+      const uint32_t pk = key[first];
+      int totalLE = 0;
+      for (int base = first; base < last; base += 64) {
+        const int p = base + lane;
+        const bool l = p < last && !(pk < key[p]);
+        totalLE += __popcll(__ballot(l));
+      }
+      int nI = 0, nL = 0;
+      for (int base = first; base < last; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < last;
+        const uint32_t k = valid ? key[p] : 0u;
+        const bool g = valid && p > first && !(k < pk), l = valid && !(pk < k);
+        const unsigned long long bg = __ballot(g), bl = __ballot(l);
+        if (g) I[nI + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bg, 0u))] = p;
+        if (l) J[totalLE - 1 - (nL + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u)))] = p;
+        nI += __popcll(bg); nL += __popcll(bl);
+      }
+      wave_lds_sync();
+      const int npair = min(nI, totalLE);
+      int m = 0;
+      for (int base = 0;; base += 64) {
+        const int k = base + lane;
+        const bool t = k < npair && I[k] < J[k];
+        const unsigned long long b = __ballot(t);
+        if (b == ~0ull) { m += 64; continue; }
+        m += __builtin_ctzll(~b);
+        break;
+      }
+      for (int base = 0; base < m; base += 64) {
+        const int k = base + lane;
+        if (k < m) {
+          const int i = I[k], j = J[k];
+          const uint32_t ki = key[i], kj = key[j];
+          const uint16_t vi = val[i], vj = val[j];
+          key[i] = kj; val[i] = vj; key[j] = ki; val[j] = vi;
+        }
+      }
+      int cut = 0x7fffffff;
+      if (m < nI) cut = I[m];
+      if (m > 0) cut = min(cut, (int)J[m - 1]);
+      wave_lds_sync();
+      sf[sp] = cut; sl[sp] = last; sd[sp] = depth; sp++;
+      wave_lds_sync();
+      last = cut;
+    }
+  }
+}
 
 // exclusive scan of data[0..m) in place, 256 threads (4 waves): per-thread serial chunk, wave scan by
 // DPP-free shuffles, 4 wave totals through LDS.  *total (shared) receives the sum.  3 barriers.
@@ -151,12 +244,9 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
         skey[k] = ((uint32_t)L[j].cnt << 12) | (uint32_t)(uint16_t)L[j].x0;
       }
       __syncthreads();
-      // std::sort = serial __introsort_loop (the only part that is not a stable sort) on one lane,
+      // std::sort = __introsort_loop (the only part that is not a stable sort) on one wavefront in rank form,
       // then __final_insertion_sort == stable ordering of that output, computed in parallel by rank
-      if (tid == 0) {
-        KVLds kv{(lds_u32*)skey, (lds_u16*)sval};
-        kv_introsort_loop(kv, ne, (lds_i32*)s_stack);
-      }
+      if (tid < 64) wave_introsort_loop((lds_u32*)skey, (lds_u16*)sval, ne, (lds_i32*)s_stack, (lds_i32*)a_scan, (lds_i32*)b_scan);
       __syncthreads();
       for (int k = tid; k < ne; k += 256) {
         const uint32_t kk = skey[k];

@@ -48,6 +48,15 @@ static bool run_case(const std::vector<std::pair<int, int>>& in) {  // (size, x0
   }
   for (int i = 0; i < n; i++)
     if (ref[i].second->id != (int)out[i]) return false;
+  // rank form of the partition (what the device runs with ballots): must leave the SAME array as the serial loop
+  std::vector<uint32_t> k3(n);
+  std::vector<uint16_t> v3(n);
+  for (int i = 0; i < n; i++) { k3[i] = ((uint32_t)in[i].first << 12) | (uint32_t)in[i].second; v3[i] = (uint16_t)i; }
+  dvm::KV kv3{k3.data(), v3.data()};
+  std::vector<int> I(n + 1), J(n + 1);
+  dvm::kv_introsort_loop_ranked(kv3, n, stk, I.data(), J.data());
+  for (int i = 0; i < n; i++)
+    if (k3[i] != k2[i] || v3[i] != v2[i]) return false;
   return true;
 }
 
