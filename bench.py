@@ -191,14 +191,17 @@ def main():
                        "parallelism": f"agents{world}"},
             "roofline": roof, "sanity_matches_le_TH_HIGH_last_step": nmatched,
         }
-        if a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
+        # BA leg first, while the GPU is still in its operating power state from the extract leg: the LM loop alone
+        # (host-synchronised, mostly single-workgroup kernels) does not lift an idle MI355X off its 584 MHz idle clock
+        # (measured: 315 it/s cold vs 1050 it/s hot); the CPU baseline below leaves the GPU idle for ~12 s.
         if not a.no_ba:
             try:
                 from dvm_slam_amd import ba_bench
-                out["ba"] = ba_bench.run(local, a.ba_iters)
+                out["ba"] = ba_bench.run(local, a.ba_iters, cpu_seconds=6.0 if a.cpu_seconds > 0 else 0.0)
             except ImportError:
                 out["ba"] = None
+        if a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -95,10 +95,59 @@ void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vecto
 }
 }  // namespace
 
+namespace {
+// camera sequence `seq` (a banded order) -> tiles of 10 consecutive cameras -> nested dissection of the tile graph
+// -> final position of every camera
+std::vector<int> order_from_sequence(const Graph& g, const std::vector<int>& seq) {
+  const int n = (int)seq.size();
+  const int nt = (n + kCamsPerTile - 1) / kCamsPerTile;
+  std::vector<int> tile_of(n);
+  for (int i = 0; i < n; i++) tile_of[seq[i]] = i / kCamsPerTile;
+  Graph tg(nt);
+  for (int a = 0; a < n; a++)
+    for (int b : g[a]) if (tile_of[a] != tile_of[b]) tg[tile_of[a]].push_back(tile_of[b]);
+  tg = clean(tg);
+  std::vector<int> all_tiles(nt), torder;
+  for (int t = 0; t < nt; t++) all_tiles[t] = t;
+  nested_dissection(tg, all_tiles, torder);
+  // a partially filled tile may only be the LAST one (row mapping i -> (i / 10) * 64 + (i % 10) * 6): if the short
+  // tile was moved forward by the dissection, shift it to the end of the order
+  if (n % kCamsPerTile != 0 && nt > 0 && torder.back() != nt - 1) {
+    std::vector<int> t2;
+    for (int t : torder) if (t != nt - 1) t2.push_back(t);
+    t2.push_back(nt - 1);
+    torder.swap(t2);
+  }
+  std::vector<int> pos(n, -1);
+  int p = 0;
+  for (int t : torder)
+    for (int i = t * kCamsPerTile; i < std::min(n, (t + 1) * kCamsPerTile); i++) pos[seq[i]] = p++;
+  return pos;
+}
+
+// dependency-chain length (and fill) of the tile Cholesky under camera order `pos`
+std::pair<int, double> evaluate(const Graph& g, const std::vector<int>& pos) {
+  const int n = (int)pos.size();
+  const int nt = (n + kCamsPerTile - 1) / kCamsPerTile + 1;
+  std::vector<std::vector<char>> T(nt, std::vector<char>(nt, 0));
+  for (int a = 0; a < n; a++)
+    for (int b : g[a]) {
+      const int ta = pos[a] / kCamsPerTile, tb = pos[b] / kCamsPerTile;
+      T[std::max(ta, tb)][std::min(ta, tb)] = 1;
+    }
+  const BaTileSchedule S = ba_tile_schedule(T);
+  return {S.nlevels, S.fill};
+}
+}  // namespace
+
 std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in) {
   const int n = (int)adj_in.size();
   const Graph g = clean(adj_in);
-  // 1. band the camera graph: Cuthill-McKee per connected component
+  // candidate 1: the given order (keyframe ids follow the trajectory: already banded, and a loop closure stays ONE
+  // wrap-around block instead of doubling the bandwidth as a breadth-first order of a ring does)
+  std::vector<int> natural(n);
+  for (int i = 0; i < n; i++) natural[i] = i;
+  // candidate 2: Cuthill-McKee per connected component (for inputs whose ids do not follow the co-visibility)
   std::vector<int> cm;
   {
     std::vector<char> all(n, 1), placed(n, 0);
@@ -110,34 +159,9 @@ std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in) {
         for (int v : l) { cm.push_back(v); placed[v] = 1; }
     }
   }
-  // 2. whole cameras per tile, tile graph
-  const int nt = (n + kCamsPerTile - 1) / kCamsPerTile;
-  std::vector<int> tile_of(n);
-  for (int i = 0; i < n; i++) tile_of[cm[i]] = i / kCamsPerTile;
-  Graph tg(nt);
-  for (int a = 0; a < n; a++)
-    for (int b : g[a]) if (tile_of[a] != tile_of[b]) tg[tile_of[a]].push_back(tile_of[b]);
-  tg = clean(tg);
-  // 3. nested dissection of the tiles
-  std::vector<int> all_tiles(nt), torder;
-  for (int t = 0; t < nt; t++) all_tiles[t] = t;
-  nested_dissection(tg, all_tiles, torder);
-  // 4. final camera order: tiles in elimination order, cameras inside a tile in banded order
-  std::vector<int> pos(n, -1);
-  int p = 0;
-  for (int t : torder)
-    for (int i = t * kCamsPerTile; i < std::min(n, (t + 1) * kCamsPerTile); i++) pos[cm[i]] = p++;
-  // a partially filled tile may only be the LAST one (row mapping i -> (i / 10) * 64 + (i % 10) * 6): if the short
-  // tile was moved forward by the dissection, shift it to the end of the order
-  if (n % kCamsPerTile != 0 && nt > 0 && torder.back() != nt - 1) {
-    std::vector<int> t2;
-    for (int t : torder) if (t != nt - 1) t2.push_back(t);
-    t2.push_back(nt - 1);
-    p = 0;
-    for (int t : t2)
-      for (int i = t * kCamsPerTile; i < std::min(n, (t + 1) * kCamsPerTile); i++) pos[cm[i]] = p++;
-  }
-  return pos;
+  const std::vector<int> p1 = order_from_sequence(g, natural), p2 = order_from_sequence(g, cm);
+  const auto e1 = evaluate(g, p1), e2 = evaluate(g, p2);
+  return (e1 < e2 || e1 == e2) ? p1 : p2;   // shortest dependency chain, then least fill
 }
 
 BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {

@@ -14,9 +14,19 @@ using namespace dvm;
 static int fail(const char* m) { std::printf("FAIL: %s\n", m); return 1; }
 
 int main(int argc, char** argv) {
-  const int n = argc > 1 ? std::atoi(argv[1]) : 499, span = argc > 2 ? std::atoi(argv[2]) : 7;
-  const bool loop = argc > 3 ? std::atoi(argv[3]) != 0 : true;
+  int n = argc > 1 ? std::atoi(argv[1]) : 499;
+  const int span = argc > 2 ? std::atoi(argv[2]) : 7;
+  bool loop = argc > 3 ? std::atoi(argv[3]) != 0 : true;
   std::vector<std::vector<int>> adj(n);
+  if (argc > 4) {   // adjacency from a file: "n" then pairs "a b" (used to inspect real problems)
+    FILE* f = std::fopen(argv[4], "r");
+    if (!f || std::fscanf(f, "%d", &n) != 1) return fail("cannot read adjacency file");
+    adj.assign(n, {});
+    int a, b;
+    while (std::fscanf(f, "%d %d", &a, &b) == 2) { adj[a].push_back(b); adj[b].push_back(a); }
+    std::fclose(f);
+    loop = false;
+  } else
   for (int a = 0; a < n; a++)
     for (int d = 1; d <= span; d++) {
       int b = a + d;
