@@ -501,3 +501,17 @@ def search_by_projection_points(kps, desc, mp, claimed_obs, bounds, scale_factor
     if n < 0:
         check(n)
     return n, mpc, req.value
+
+
+def distinctive_descriptors(desc, off):
+    """dvm_distinctive_descriptors: MapPoint::ComputeDistinctiveDescriptors for a batch of map points (CSR offsets).
+    Returns (best_idx, best_median)."""
+    L = lib()
+    L.dvm_distinctive_descriptors.restype = C.c_int32
+    L.dvm_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); off = np.ascontiguousarray(off, np.int32)
+    n = len(off) - 1
+    bi = np.zeros(max(n, 1), np.int32); bm = np.zeros(max(n, 1), np.int32)
+    dummy = np.zeros((1, 32), np.uint8)
+    check(L.dvm_distinctive_descriptors(_p(desc if len(desc) else dummy), _p(off), n, _p(bi), _p(bm), 0, None))
+    return bi[:n], bm[:n]

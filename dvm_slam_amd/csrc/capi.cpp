@@ -467,6 +467,37 @@ int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, 
   return rc;
 }
 
+int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median,
+                                int on_device, void* stream) {
+  if (n_points < 0) return DVM_ERR_INVALID;
+  if (n_points == 0) return DVM_OK;
+  if (!desc || !off || !best_idx || !best_median) return DVM_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (on_device) {
+    launch_distinctive((hipStream_t)stream, desc, off, n_points, best_idx, best_median);
+    return hip_check(hipGetLastError(), "distinctive launch");
+  }
+  const int total = off[n_points];
+  if (total < 0) return DVM_ERR_INVALID;
+  const size_t b_d = (size_t)std::max(total, 1) * 32, b_off = (size_t)(n_points + 1) * 4, b_o = (size_t)n_points * 4;
+  const size_t o_d = 0, o_off = o_d + b_d, o_i = o_off + ((b_off + 15) & ~(size_t)15), o_m = o_i + ((b_o + 15) & ~(size_t)15), tot = o_m + b_o;
+  uint8_t* d = nullptr;
+  int rc = hip_check(hipMalloc(&d, tot), "hipMalloc");
+  if (rc != DVM_OK) return rc;
+  if (total > 0) rc = hip_check(hipMemcpy(d + o_d, desc, (size_t)total * 32, hipMemcpyHostToDevice), "memcpy");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(d + o_off, off, b_off, hipMemcpyHostToDevice), "memcpy");
+  if (rc == DVM_OK) {
+    launch_distinctive(nullptr, d + o_d, reinterpret_cast<int32_t*>(d + o_off), n_points, reinterpret_cast<int32_t*>(d + o_i),
+                       reinterpret_cast<int32_t*>(d + o_m));
+    rc = hip_check(hipGetLastError(), "distinctive launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(best_idx, d + o_i, b_o, hipMemcpyDeviceToHost), "memcpy");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(best_median, d + o_m, b_o, hipMemcpyDeviceToHost), "memcpy");
+  hipFree(d);
+  return rc;
+}
+
 int dvm_match_frames_batch(const dvm_frame* train, int first_slot, int count, const dvm_keypoint* d_kps,
                            int64_t kps_stride, const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n,
                            const dvm_keypoint* d_carry_kps, const uint8_t* d_carry_desc, const int32_t* d_carry_n,

@@ -71,4 +71,5 @@ void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdes
                         int nq, dvm_match_pod* out);
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
 
+void launch_distinctive(hipStream_t s, const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
 }  // namespace dvm

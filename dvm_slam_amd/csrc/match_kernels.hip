@@ -327,4 +327,56 @@ void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_
   hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 63) / 64, (nA + 3) / 4), dim3(256), 0, s, A, nA, B, nB, D);
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:384-453), batched over map points: point p owns
+// the descriptors desc[off[p] .. off[p+1]) (its observations, in the reference's iteration order).  For every row i of
+// the N x N Hamming table the median is vDists[0.5 * (N - 1)] of the SORTED row (self distance 0 included); the
+// winner is the first i with the strictly smallest median.  One wavefront per map point: descriptors staged in LDS,
+// row i = one distance per lane (chunks of 64), the k-th order statistic by a 9-step binary search over the value
+// range [0, 256] with ballot counts -- no sort.  Points with more than kDistinctMaxN observations report -2.
+constexpr int kDistinctMaxN = 512;
+__global__ void __launch_bounds__(64) k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ off, int npts,
+                                                    int32_t* __restrict__ best_idx, int32_t* __restrict__ best_median) {
+  __shared__ uint32_t s_desc[kDistinctMaxN * 8];
+  __shared__ uint16_t s_row[kDistinctMaxN];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  if (p >= npts) return;
+  const int o0 = off[p], N = off[p + 1] - o0;
+  if (N <= 0) { if (lane == 0) { best_idx[p] = -1; best_median[p] = -1; } return; }
+  if (N > kDistinctMaxN) { if (lane == 0) { best_idx[p] = -2; best_median[p] = -2; } return; }
+  const uint32_t* g = reinterpret_cast<const uint32_t*>(desc + (size_t)o0 * 32);
+  for (int i = lane; i < N * 8; i += 64) s_desc[i] = g[i];
+  __syncthreads();
+  const int k = (N - 1) >> 1;                     // (size_t)(0.5 * (N - 1))
+  uint32_t best = 0xFFFFFFFFu;                    // median << 16 | i
+  for (int i = 0; i < N; i++) {
+    uint32_t di[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) di[w] = s_desc[i * 8 + w];
+    for (int j = lane; j < N; j += 64) {
+      int d = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) d += __popc(di[w] ^ s_desc[j * 8 + w]);
+      s_row[j] = (uint16_t)d;
+    }
+    __syncthreads();
+    // smallest v with #{j : d_j <= v} > k
+    int lo = 0, hi = 256;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+      for (int base = 0; base < N; base += 64) {
+        const int j = base + lane;
+        cnt += __popcll(__ballot(j < N && (int)s_row[j] <= mid));
+      }
+      if (cnt > k) hi = mid; else lo = mid + 1;
+    }
+    best = min(best, ((uint32_t)lo << 16) | (uint32_t)i);
+    __syncthreads();
+  }
+  if (lane == 0) { best_idx[p] = (int)(best & 0xFFFFu); best_median[p] = (int)(best >> 16); }
+}
+void launch_distinctive(hipStream_t s, const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median) {
+  if (npts > 0) hipLaunchKernelGGL(k_distinctive, dim3(npts), dim3(64), 0, s, desc, off, npts, best_idx, best_median);
+}
+
 }  // namespace dvm

@@ -12,6 +12,7 @@
  *   dvm_ba_*       <- Optimizer::{BundleAdjustment,LocalBundleAdjustment} + g2o BlockSolver_6_3/LM
  *                                                    src/Optimizer.cc:55-356,1030-1387
  *   dvm_pose_optimize <- Optimizer::PoseOptimization src/Optimizer.cc:744-1028
+ *   dvm_distinctive_descriptors <- MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:384-453
  * The reference has no FFI: these classes live inside static libORB_SLAM3.a.  INTEGRATION.md shows
  * the C++ shim classes (same names / signatures) a maintainer links instead.
  *
@@ -172,6 +173,15 @@ int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const floa
  * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
 int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, const int32_t* off, const int32_t* cand,
                     dvm_match* out, int on_device, void* stream);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:384-453), batched: map point p owns the descriptors
+ * desc[off[p] .. off[p+1]) (32 B each, its observations in the reference's iteration order); best_idx[p] = index
+ * inside that range of the descriptor with the least median Hamming distance to the others (median =
+ * sorted_row[0.5 * (N - 1)], first strictly smaller wins), best_median[p] = that median.  Empty range: -1;
+ * more than 512 observations: -2 (the caller keeps its CPU path for those).
+ * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
+int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median,
+                                int on_device, void* stream);
 
 /* TrackWithMotionModel-style frame-to-frame search over a batch (ORBmatcher.cc:1596-1611, mono):
  * pair i (0 <= i < count) searches train slot first_slot+i for every keypoint of frame i-1 of the

@@ -15,6 +15,7 @@
 //   src/ORBmatcher.cc:1862-1896  ComputeThreeMaxima              -> orc_search_by_projection_frames()
 //   src/ORBmatcher.cc:44-212     SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), mono branch,
 //                                RadiusByViewingCos              -> orc_search_by_projection_points()
+//   src/MapPoint.cc:384-453      MapPoint::ComputeDistinctiveDescriptors -> orc_distinctive_descriptors()
 #include "oracle.h"
 
 #include <algorithm>
@@ -276,6 +277,33 @@ int orc_search_by_projection_points(int N, const orc_keypoint* kps, const uint8_
   }
   orc_grid_destroy(g);
   return nmatches;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:420-447) for a batch of map points: the N x N table, every row
+// sorted with std::sort, median = vDists[0.5 * (N - 1)], first strictly smaller median wins.
+void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median) {
+  for (int p = 0; p < npts; p++) {
+    const int N = off[p + 1] - off[p];
+    if (N <= 0) { best_idx[p] = -1; best_median[p] = -1; continue; }
+    const uint8_t* D = desc + (size_t)off[p] * 32;
+    std::vector<float> Distances((size_t)N * N);
+    for (int i = 0; i < N; i++) {
+      Distances[(size_t)i * N + i] = 0;
+      for (int j = i + 1; j < N; j++) {
+        const int distij = descriptor_distance(D + 32 * i, D + 32 * j);
+        Distances[(size_t)i * N + j] = distij;
+        Distances[(size_t)j * N + i] = distij;
+      }
+    }
+    int BestMedian = 0x7fffffff, BestIdx = 0;
+    for (int i = 0; i < N; i++) {
+      std::vector<int> vDists(Distances.begin() + (size_t)i * N, Distances.begin() + (size_t)(i + 1) * N);
+      std::sort(vDists.begin(), vDists.end());
+      const int median = vDists[(size_t)(0.5 * (N - 1))];
+      if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    best_idx[p] = BestIdx; best_median[p] = BestMedian;
+  }
 }
 
 }  // extern "C"

@@ -116,6 +116,9 @@ int orc_search_by_projection_points(int N, const orc_keypoint* kps, const uint8_
                                     const float* bounds, const float* scale_factors, const orc_tracked_point* pts, int npts,
                                     float th, float nnratio, int far_points, float th_far);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
+void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
+
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;

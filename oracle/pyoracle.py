@@ -400,3 +400,16 @@ def search_by_projection_points(kps, desc, mp, claimed_obs, bounds, scale_factor
     n = L.orc_search_by_projection_points(len(kps), _p(kps), _p(desc), _p(mpc), _p(co), _p(b), _p(sf), _p(pts), len(pts),
                                           float(th), float(nnratio), int(far_points), float(th_far))
     return n, mpc
+
+
+def distinctive_descriptors(desc, off):
+    """MapPoint::ComputeDistinctiveDescriptors for a batch.  Returns (best_idx, best_median)."""
+    L = lib()
+    L.orc_distinctive_descriptors.restype = None
+    L.orc_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); off = np.ascontiguousarray(off, np.int32)
+    n = len(off) - 1
+    bi = np.zeros(max(n, 1), np.int32); bm = np.zeros(max(n, 1), np.int32)
+    if n > 0:
+        L.orc_distinctive_descriptors(_p(desc) if len(desc) else None, _p(off), n, _p(bi), _p(bm))
+    return bi[:n], bm[:n]

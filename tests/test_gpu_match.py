@@ -198,3 +198,25 @@ def test_is_in_frustum(capi, oracle):
     Pc = (Rcw @ P.T).T + tcw
     behind = Pc[:, 2] < -0.1
     assert (got["in_view"][behind] == 0).all() and (got["proj_x"][behind] == -1).all()
+
+
+def test_distinctive_descriptors(capi, oracle):
+    """dvm_distinctive_descriptors (MapPoint::ComputeDistinctiveDescriptors, batched) vs the oracle: ragged observation
+    counts 0..300, duplicate-heavy sets (median ties -> first index wins), one set above the 512 limit (-2)."""
+    rng = np.random.default_rng(33)
+    sizes = [1, 2, 3, 7, 0, 64, 65, 130, 300, 12, 600] + list(rng.integers(1, 40, 200))
+    descs, off = [], [0]
+    for n in sizes:
+        n = int(n)
+        base = rng.integers(0, 256, (max(n, 1), 32), dtype=np.uint8)
+        d = base[rng.integers(0, max(1, n // 3 + 1), n)] if n else base[:0]
+        flip = rng.random((n, 32)) < 0.04
+        d = np.where(flip, rng.integers(0, 256, (n, 32), dtype=np.uint8), d).astype(np.uint8)
+        descs.append(d); off.append(off[-1] + n)
+    desc = np.concatenate(descs)
+    bi_g, bm_g = capi.distinctive_descriptors(desc, off)
+    bi_o, bm_o = oracle.distinctive_descriptors(desc, off)
+    big = np.array(sizes) > 512
+    assert np.all(bi_g[big] == -2) and np.all(bm_g[big] == -2)
+    assert np.array_equal(bi_g[~big], bi_o[~big]) and np.array_equal(bm_g[~big], bm_o[~big])
+    assert capi.distinctive_descriptors(np.zeros((0, 32), np.uint8), [0])[0].shape == (0,)

@@ -254,3 +254,27 @@ def test_search_by_projection_points_oracle_semantics(oracle):
         ref[m["best_idx"][k]] = i; cnt += 1
     assert n == cnt and np.array_equal(mp, ref)
     assert n > 100
+
+
+def test_distinctive_descriptors_oracle_vs_numpy(oracle):
+    """ComputeDistinctiveDescriptors: numpy restatement (unpackbits distances, np.sort rows, floor((N-1)/2)-th entry,
+    first strict minimum) on ragged sets incl. N = 1, 2 and sets full of duplicates."""
+    rng = np.random.default_rng(21)
+    sizes = [1, 2, 3, 8, 15, 16, 40, 0, 65, 5]
+    descs, off = [], [0]
+    for n in sizes:
+        base = rng.integers(0, 256, (max(n, 1), 32), dtype=np.uint8)
+        d = base[rng.integers(0, max(1, n // 2 + 1), n)] if n else base[:0]   # many duplicates -> median ties
+        flip = rng.random((n, 32)) < 0.05
+        d = np.where(flip, rng.integers(0, 256, (n, 32), dtype=np.uint8), d).astype(np.uint8)
+        descs.append(d); off.append(off[-1] + n)
+    desc = np.concatenate(descs)
+    bi, bm = oracle.distinctive_descriptors(desc, off)
+    for p, n in enumerate(sizes):
+        if n == 0:
+            assert bi[p] == -1 and bm[p] == -1
+            continue
+        d = desc[off[p]:off[p + 1]]
+        D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(axis=2)
+        med = np.sort(D, axis=1)[:, (n - 1) // 2]
+        assert bm[p] == med.min() and bi[p] == int(np.argmin(med)), p
