@@ -515,3 +515,56 @@ def distinctive_descriptors(desc, off):
     dummy = np.zeros((1, 32), np.uint8)
     check(L.dvm_distinctive_descriptors(_p(desc if len(desc) else dummy), _p(off), n, _p(bi), _p(bm), 0, None))
     return bi[:n], bm[:n]
+
+
+class Vocabulary:
+    """dvm_vocab_*: DBoW2 vocabulary tree resident on the device, per-feature transform."""
+
+    def __init__(self, voc, device=0):
+        L = lib()
+        vp, i32 = C.c_void_p, C.c_int32
+        L.dvm_vocab_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(vp)]
+        L.dvm_vocab_destroy.argtypes = [vp]; L.dvm_vocab_destroy.restype = None
+        L.dvm_vocab_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, vp]
+        self.L, self.h = L, vp()
+        self.keep = [np.ascontiguousarray(voc[k]) for k in ("child_off", "children", "desc", "weight", "word_id")]
+        check(L.dvm_vocab_create(device, voc["n_nodes"], *[_p(a) for a in self.keep], voc["L"], C.byref(self.h)))
+
+    def transform(self, features, levelsup):
+        f = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+        n = len(f)
+        word = np.zeros(max(n, 1), np.int32); node = np.zeros(max(n, 1), np.int32); w = np.zeros(max(n, 1), np.float64)
+        check(self.L.dvm_vocab_transform(self.h, _p(f) if n else None, n, levelsup, _p(word), _p(node), _p(w), 0, None))
+        return word[:n], node[:n], w[:n]
+
+    def close(self):
+        if self.h:
+            self.L.dvm_vocab_destroy(self.h)
+            self.h = None
+
+
+def vocab_transform_host(voc, features, levelsup, device=0):
+    """dvm_host::ORBVocabulary::transform (host C++ mirror): returns dict(bow_ids, bow_vals, fv_nodes, fv_off, fv_feat)."""
+    H = host_lib()
+    vp, i32 = C.c_void_p, C.c_int32
+    H.dvmh_vocab_transform.restype = i32
+    H.dvmh_vocab_transform.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    f = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+    n = len(f)
+    bi = np.zeros(n + 1, np.int32); bv = np.zeros(n + 1, np.float64); fn = np.zeros(n + 1, np.int32)
+    fo = np.zeros(n + 2, np.int32); ff = np.zeros(n + 1, np.int32)
+    nb = C.c_int32(0); nf = C.c_int32(0)
+    check(H.dvmh_vocab_transform(device, voc["n_nodes"], _p(voc["child_off"]), _p(voc["children"]), _p(voc["desc"]),
+                                 _p(voc["weight"]), _p(voc["word_id"]), voc["L"], _p(f), n, levelsup, _p(bi), _p(bv),
+                                 C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf)))
+    return dict(bow_ids=bi[:nb.value], bow_vals=bv[:nb.value], fv_nodes=fn[:nf.value], fv_off=fo[:nf.value + 1],
+                fv_feat=ff[:fo[nf.value]])
+
+
+def bow_score_host(ids1, vals1, ids2, vals2):
+    H = host_lib()
+    H.dvmh_bow_score.restype = C.c_double
+    H.dvmh_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    a = np.ascontiguousarray(ids1, np.int32); b = np.ascontiguousarray(vals1, np.float64)
+    c = np.ascontiguousarray(ids2, np.int32); d = np.ascontiguousarray(vals2, np.float64)
+    return H.dvmh_bow_score(_p(a), _p(b), len(a), _p(c), _p(d), len(c))

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dvmslam_hip.h"
@@ -494,6 +495,84 @@ int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_p
   }
   if (rc == DVM_OK) rc = hip_check(hipMemcpy(best_idx, d + o_i, b_o, hipMemcpyDeviceToHost), "memcpy");
   if (rc == DVM_OK) rc = hip_check(hipMemcpy(best_median, d + o_m, b_o, hipMemcpyDeviceToHost), "memcpy");
+  hipFree(d);
+  return rc;
+}
+
+struct dvm_vocab {
+  int device = 0, n_nodes = 0, L = 0;
+  int32_t *child_off = nullptr, *children = nullptr, *word_id = nullptr;
+  uint8_t* desc = nullptr;
+  double* weight = nullptr;
+};
+
+void dvm_vocab_destroy(dvm_vocab* v) {
+  if (!v) return;
+  hipSetDevice(v->device);
+  for (void* p : {(void*)v->child_off, (void*)v->children, (void*)v->word_id, (void*)v->desc, (void*)v->weight})
+    if (p) hipFree(p);
+  delete v;
+}
+
+int dvm_vocab_create(int device, int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* desc,
+                     const double* weight, const int32_t* word_id, int L, dvm_vocab** out) {
+  if (!out) return DVM_ERR_INVALID;
+  *out = nullptr;
+  if (n_nodes < 1 || !child_off || !children || !desc || !weight || !word_id || L < 0) return DVM_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) return DVM_ERR_INVALID;
+  const int nch = child_off[n_nodes];
+  if (child_off[0] != 0 || nch < 0) { set_error("vocabulary: bad child_off"); return DVM_ERR_INVALID; }
+  for (int i = 0; i < n_nodes; i++) if (child_off[i + 1] < child_off[i]) { set_error("vocabulary: child_off not monotone"); return DVM_ERR_INVALID; }
+  for (int c = 0; c < nch; c++) if (children[c] <= 0 || children[c] >= n_nodes) { set_error("vocabulary: child id out of range"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(device));
+  dvm_vocab* v = new dvm_vocab;
+  v->device = device; v->n_nodes = n_nodes; v->L = L;
+  int rc = DVM_OK;
+  auto up = [&](auto** dst, const void* src, size_t bytes) {
+    if (rc != DVM_OK) return;
+    void* p = nullptr;
+    rc = hip_check(hipMalloc(&p, std::max<size_t>(bytes, 16)), "hipMalloc(vocab)");
+    if (rc == DVM_OK && bytes) rc = hip_check(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice), "memcpy(vocab)");
+    *dst = static_cast<std::remove_reference_t<decltype(**dst)>*>(p);
+  };
+  up(&v->child_off, child_off, (size_t)(n_nodes + 1) * 4);
+  up(&v->children, children, (size_t)nch * 4);
+  up(&v->desc, desc, (size_t)n_nodes * 32);
+  up(&v->weight, weight, (size_t)n_nodes * 8);
+  up(&v->word_id, word_id, (size_t)n_nodes * 4);
+  if (rc != DVM_OK) { dvm_vocab_destroy(v); return rc; }
+  *out = v;
+  return DVM_OK;
+}
+
+int dvm_vocab_transform(const dvm_vocab* v, const uint8_t* features, int n, int levelsup, int32_t* word_id, int32_t* node_id,
+                        double* weight, int on_device, void* stream) {
+  if (!v || n < 0) return DVM_ERR_INVALID;
+  if (n == 0) return DVM_OK;
+  if (!features || !word_id || !node_id || !weight) return DVM_ERR_INVALID;
+  DVM_HIP(hipSetDevice(v->device));
+  if (on_device) {
+    launch_vocab_transform((hipStream_t)stream, v->child_off, v->children, v->desc, v->weight, v->word_id, v->L, features, n, levelsup,
+                           word_id, node_id, weight);
+    return hip_check(hipGetLastError(), "vocab_transform launch");
+  }
+  const size_t b_f = (size_t)n * 32, b_i = ((size_t)n * 4 + 15) & ~(size_t)15, b_w = (size_t)n * 8;
+  uint8_t* d = nullptr;
+  int rc = hip_check(hipMalloc(&d, b_f + 2 * b_i + b_w), "hipMalloc");
+  if (rc != DVM_OK) return rc;
+  rc = hip_check(hipMemcpy(d, features, b_f, hipMemcpyHostToDevice), "memcpy");
+  int32_t* dw = reinterpret_cast<int32_t*>(d + b_f);
+  int32_t* dn = reinterpret_cast<int32_t*>(d + b_f + b_i);
+  double* dwt = reinterpret_cast<double*>(d + b_f + 2 * b_i);
+  if (rc == DVM_OK) {
+    launch_vocab_transform(nullptr, v->child_off, v->children, v->desc, v->weight, v->word_id, v->L, d, n, levelsup, dw, dn, dwt);
+    rc = hip_check(hipGetLastError(), "vocab_transform launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(word_id, dw, (size_t)n * 4, hipMemcpyDeviceToHost), "memcpy");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(node_id, dn, (size_t)n * 4, hipMemcpyDeviceToHost), "memcpy");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(weight, dwt, b_w, hipMemcpyDeviceToHost), "memcpy");
   hipFree(d);
   return rc;
 }

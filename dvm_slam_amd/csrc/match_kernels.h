@@ -72,4 +72,7 @@ void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdes
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
 
 void launch_distinctive(hipStream_t s, const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
+void launch_vocab_transform(hipStream_t s, const int32_t* child_off, const int32_t* children, const uint8_t* node_desc,
+                            const double* weight, const int32_t* word_id, int L, const uint8_t* feat, int n, int levelsup,
+                            int32_t* out_word, int32_t* out_node, double* out_weight);
 }  // namespace dvm

@@ -379,4 +379,60 @@ void launch_distinctive(hipStream_t s, const uint8_t* desc, const int32_t* off, 
   if (npts > 0) hipLaunchKernelGGL(k_distinctive, dim3(npts), dim3(64), 0, s, desc, off, npts, best_idx, best_median);
 }
 
+// DBoW2 TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (reference
+// Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1098-1138): walk the vocabulary tree from the root, at every node take
+// the child with the smallest FORB::distance (first child wins ties: strict '<' scan), remember the node reached at
+// level L - levelsup.  One DPP row (16 lanes) per feature: lane c scores child c (k = 10 in ORBvoc), the argmin of
+// (distance << 16 | child position) is four DPP steps.  Nodes: CSR children lists, 32-B descriptors, weight, word id.
+__global__ void __launch_bounds__(256) k_vocab_transform(const int32_t* __restrict__ child_off, const int32_t* __restrict__ children,
+                                                         const uint8_t* __restrict__ node_desc, const double* __restrict__ weight,
+                                                         const int32_t* __restrict__ word_id, int L, const uint8_t* __restrict__ feat,
+                                                         int n, int levelsup, int32_t* __restrict__ out_word,
+                                                         int32_t* __restrict__ out_node, double* __restrict__ out_weight) {
+  const int lane = threadIdx.x & 15;
+  const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (f >= n) return;
+  uint32_t w[8];
+  {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(feat + (size_t)f * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = q[i];
+  }
+  const int nid_level = L - levelsup;
+  int nid = nid_level <= 0 ? 0 : -1;   // the reference leaves *nid unset if the walk ends above nid_level
+  int cur = 0, level = 0;
+  int c0 = child_off[0], c1 = child_off[1];
+  while (c1 > c0) {
+    ++level;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int base = c0; base < c1; base += 16) {
+      const int c = base + lane;
+      uint32_t key = 0xFFFFFFFFu;
+      if (c < c1) {
+        const uint4* d = reinterpret_cast<const uint4*>(node_desc + (size_t)children[c] * 32);
+        const uint4 a = d[0], b = d[1];
+        const int dist = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
+                         __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
+        key = ((uint32_t)dist << 16) | (uint32_t)(c - c0);
+      }
+      best = min(best, key);
+    }
+    best = min(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0xB1, 0xF, 0xF, false));
+    best = min(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x4E, 0xF, 0xF, false));
+    best = min(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x141, 0xF, 0xF, false));
+    best = min(best, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best, 0x140, 0xF, 0xF, false));
+    cur = children[c0 + (int)(best & 0xFFFFu)];
+    if (level == nid_level) nid = cur;
+    c0 = child_off[cur]; c1 = child_off[cur + 1];
+  }
+  if (lane == 0) { out_word[f] = word_id[cur]; out_node[f] = nid; out_weight[f] = weight[cur]; }
+}
+void launch_vocab_transform(hipStream_t s, const int32_t* child_off, const int32_t* children, const uint8_t* node_desc,
+                            const double* weight, const int32_t* word_id, int L, const uint8_t* feat, int n, int levelsup,
+                            int32_t* out_word, int32_t* out_node, double* out_weight) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_vocab_transform, dim3((n + 15) / 16), dim3(256), 0, s, child_off, children, node_desc, weight, word_id, L,
+                       feat, n, levelsup, out_word, out_node, out_weight);
+}
+
 }  // namespace dvm

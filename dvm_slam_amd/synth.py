@@ -228,3 +228,34 @@ def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = 
     fixed[0] = 1
     return dict(poses=poses, poses_gt=poses_gt, fixed=fixed, points=points, points_gt=pts, edge_pose=edge_pose,
                 edge_point=edge_point, obs=obs, inv_sigma2=inv_sigma2, intrinsics=np.array([FX, FY, CX, CY]))
+
+
+def vocabulary(k: int = 10, L: int = 3, seed: int = 0x0B0C, ragged: bool = True, stop_frac: float = 0.02):
+    """Synthetic DBoW2 vocabulary tree (ORBvoc.txt is not shipped with the reference: .MISSING_LARGE_BLOBS).
+    Breadth-first node ids, root = 0, depth L, fan-out k (6..k when `ragged`), random 256-bit node descriptors,
+    idf-like leaf weights (a few exactly 0 = stopped words).  Returns CSR children lists like dvm_vocab_create."""
+    rng = np.random.default_rng(seed)
+    child_off, children, level = [0], [], [0]
+    frontier, n = [0], 1
+    off_of = {}
+    for d in range(L):
+        nxt = []
+        for node in frontier:
+            kk = int(rng.integers(max(2, k - 4), k + 1)) if ragged else k
+            off_of[node] = list(range(n, n + kk))
+            nxt.extend(off_of[node]); level.extend([d + 1] * kk); n += kk
+        frontier = nxt
+    for node in range(n):
+        ch = off_of.get(node, [])
+        children.extend(ch)
+        child_off.append(len(children))
+    level = np.array(level)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    word_id = np.full(n, -1, np.int32)
+    leaves = np.flatnonzero(level == L)
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
+    weight = np.zeros(n, np.float64)
+    weight[leaves] = np.log(rng.uniform(1.5, 400.0, len(leaves)))
+    weight[leaves[rng.random(len(leaves)) < stop_frac]] = 0.0
+    return dict(n_nodes=n, child_off=np.array(child_off, np.int32), children=np.array(children, np.int32), desc=desc,
+                weight=weight, word_id=word_id, L=L)

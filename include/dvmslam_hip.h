@@ -13,6 +13,7 @@
  *                                                    src/Optimizer.cc:55-356,1030-1387
  *   dvm_pose_optimize <- Optimizer::PoseOptimization src/Optimizer.cc:744-1028
  *   dvm_distinctive_descriptors <- MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:384-453
+ *   dvm_vocab_transform <- DBoW2::TemplatedVocabulary::transform Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1098-1138
  * The reference has no FFI: these classes live inside static libORB_SLAM3.a.  INTEGRATION.md shows
  * the C++ shim classes (same names / signatures) a maintainer links instead.
  *
@@ -182,6 +183,20 @@ int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, 
  * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
 int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median,
                                 int on_device, void* stream);
+
+/* DBoW2 vocabulary tree on the device + per-feature transform (reference Thirdparty/DBoW2/DBoW2/
+ * TemplatedVocabulary.h:1098-1138, FORB::distance FORB.cpp:80-97).  Nodes 0..n_nodes-1, node 0 = root;
+ * children[child_off[i] .. child_off[i+1]) in m_nodes[i].children order (empty = leaf); desc 32 B per node; weight and
+ * word_id as in m_nodes[i] (word_id < 0 for inner nodes); L = m_L.  dvm_vocab_transform fills, for feature f,
+ * word_id / weight of the leaf reached and node_id = the node on the path at level L - levelsup (0 if that level is
+ * <= 0; -1 where the reference leaves *nid unset because the leaf lies above that level).  The BowVector /
+ * FeatureVector bookkeeping on top of it is host code (dvm_slam_amd/host/orb_vocabulary.cpp). */
+typedef struct dvm_vocab dvm_vocab;
+int dvm_vocab_create(int device, int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* desc,
+                     const double* weight, const int32_t* word_id, int L, dvm_vocab** out);
+void dvm_vocab_destroy(dvm_vocab* v);
+int dvm_vocab_transform(const dvm_vocab* v, const uint8_t* features, int n, int levelsup, int32_t* word_id, int32_t* node_id,
+                        double* weight, int on_device, void* stream);
 
 /* TrackWithMotionModel-style frame-to-frame search over a batch (ORBmatcher.cc:1596-1611, mono):
  * pair i (0 <= i < count) searches train slot first_slot+i for every keypoint of frame i-1 of the

@@ -16,11 +16,14 @@
 //   src/ORBmatcher.cc:44-212     SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), mono branch,
 //                                RadiusByViewingCos              -> orc_search_by_projection_points()
 //   src/MapPoint.cc:384-453      MapPoint::ComputeDistinctiveDescriptors -> orc_distinctive_descriptors()
+//   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1025-1138 transform (TF_IDF, L1), BowVector.cpp:32-72,
+//   FeatureVector.cpp:27-38, ScoringObject.cpp:23-63 L1Scoring::score, FORB.cpp:80-97 -> orc_vocab_transform(), orc_bow_score()
 #include "oracle.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <vector>
 
 namespace {
@@ -304,6 +307,78 @@ void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int np
     }
     best_idx[p] = BestIdx; best_median[p] = BestMedian;
   }
+}
+
+// TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1098-1138)
+static void vocab_transform_one(const int32_t* child_off, const int32_t* children, const uint8_t* node_desc, const double* weight,
+                                const int32_t* word_id, int L, const uint8_t* feature, int levelsup, int32_t* wid, double* w,
+                                int32_t* nid) {
+  const int nid_level = L - levelsup;
+  *nid = (nid_level <= 0) ? 0 : -1;   // (the reference leaves it unset in the second case)
+  int final_id = 0, current_level = 0;
+  do {
+    ++current_level;
+    const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
+    final_id = children[c0];
+    double best_d = descriptor_distance(feature, node_desc + 32 * (size_t)final_id);
+    for (int c = c0 + 1; c < c1; c++) {
+      const int id = children[c];
+      const double d = descriptor_distance(feature, node_desc + 32 * (size_t)id);
+      if (d < best_d) { best_d = d; final_id = id; }
+    }
+    if (current_level == nid_level) *nid = final_id;
+  } while (child_off[final_id + 1] > child_off[final_id]);
+  *wid = word_id[final_id];
+  *w = weight[final_id];
+}
+
+// per-feature outputs + the whole transform(features, BowVector&, FeatureVector&, levelsup) with TF_IDF / L1_NORM,
+// flattened: bow (ids ascending, values), fv (node ids ascending, CSR feature lists)
+void orc_vocab_transform(int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* node_desc,
+                         const double* weight, const int32_t* word_id, int L, const uint8_t* features, int n, int levelsup,
+                         int32_t* out_word, int32_t* out_node, double* out_weight, int32_t* bow_ids, double* bow_vals,
+                         int32_t* n_bow, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int32_t* n_fv) {
+  (void)n_nodes;
+  std::map<unsigned, double> v;
+  std::map<unsigned, std::vector<unsigned>> fv;
+  for (int i = 0; i < n; i++) {
+    int32_t id, nid; double w;
+    vocab_transform_one(child_off, children, node_desc, weight, word_id, L, features + 32 * (size_t)i, levelsup, &id, &w, &nid);
+    out_word[i] = id; out_node[i] = nid; out_weight[i] = w;
+    if (w > 0) {
+      auto vit = v.lower_bound((unsigned)id);
+      if (vit != v.end() && !(v.key_comp()((unsigned)id, vit->first))) vit->second += w;
+      else v.insert(vit, std::make_pair((unsigned)id, w));
+      auto fit = fv.lower_bound((unsigned)nid);
+      if (fit != fv.end() && fit->first == (unsigned)nid) fit->second.push_back(i);
+      else { fit = fv.insert(fit, std::make_pair((unsigned)nid, std::vector<unsigned>())); fit->second.push_back(i); }
+    }
+  }
+  double norm = 0.0;
+  for (auto& e : v) norm += std::fabs(e.second);
+  if (norm > 0.0) for (auto& e : v) e.second /= norm;
+  int k = 0;
+  for (auto& e : v) { bow_ids[k] = (int32_t)e.first; bow_vals[k] = e.second; k++; }
+  *n_bow = k;
+  int m = 0, t = 0;
+  fv_off[0] = 0;
+  for (auto& e : fv) { fv_nodes[m] = (int32_t)e.first; for (unsigned f : e.second) fv_feat[t++] = (int32_t)f; fv_off[++m] = t; }
+  *n_fv = m;
+}
+
+double orc_bow_score(const int32_t* ids1, const double* vals1, int n1, const int32_t* ids2, const double* vals2, int n2) {
+  std::map<unsigned, double> v1, v2;
+  for (int i = 0; i < n1; i++) v1[(unsigned)ids1[i]] = vals1[i];
+  for (int i = 0; i < n2; i++) v2[(unsigned)ids2[i]] = vals2[i];
+  auto v1_it = v1.begin(), v2_it = v2.begin();
+  double score = 0;
+  while (v1_it != v1.end() && v2_it != v2.end()) {
+    const double vi = v1_it->second, wi = v2_it->second;
+    if (v1_it->first == v2_it->first) { score += std::fabs(vi - wi) - std::fabs(vi) - std::fabs(wi); ++v1_it; ++v2_it; }
+    else if (v1_it->first < v2_it->first) v1_it = v1.lower_bound(v2_it->first);
+    else v2_it = v2.lower_bound(v1_it->first);
+  }
+  return -score / 2.0;
 }
 
 }  // extern "C"

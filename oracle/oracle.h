@@ -119,6 +119,13 @@ int orc_search_by_projection_points(int N, const orc_keypoint* kps, const uint8_
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
 
+/* DBoW2 TemplatedVocabulary::transform (TF_IDF, L1_NORM) on a CSR vocabulary tree + L1Scoring::score */
+void orc_vocab_transform(int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* node_desc,
+                         const double* weight, const int32_t* word_id, int L, const uint8_t* features, int n, int levelsup,
+                         int32_t* out_word, int32_t* out_node, double* out_weight, int32_t* bow_ids, double* bow_vals,
+                         int32_t* n_bow, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int32_t* n_fv);
+double orc_bow_score(const int32_t* ids1, const double* vals1, int n1, const int32_t* ids2, const double* vals2, int n2);
+
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;

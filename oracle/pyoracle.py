@@ -413,3 +413,32 @@ def distinctive_descriptors(desc, off):
     if n > 0:
         L.orc_distinctive_descriptors(_p(desc) if len(desc) else None, _p(off), n, _p(bi), _p(bm))
     return bi[:n], bm[:n]
+
+
+def vocab_transform(voc, features, levelsup):
+    """DBoW2 transform (TF_IDF / L1) on a synthetic vocabulary.  Returns dict(word, node, weight, bow_ids, bow_vals,
+    fv_nodes, fv_off, fv_feat)."""
+    L = lib()
+    vp, i32 = C.c_void_p, C.c_int32
+    L.orc_vocab_transform.restype = None
+    L.orc_vocab_transform.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i32] + [vp] * 10
+    f = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+    n = len(f)
+    word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); w = np.zeros(n, np.float64)
+    bi = np.zeros(n + 1, np.int32); bv = np.zeros(n + 1, np.float64); fn = np.zeros(n + 1, np.int32)
+    fo = np.zeros(n + 2, np.int32); ff = np.zeros(n + 1, np.int32)
+    nb = np.zeros(1, np.int32); nf = np.zeros(1, np.int32)
+    L.orc_vocab_transform(voc["n_nodes"], _p(voc["child_off"]), _p(voc["children"]), _p(voc["desc"]), _p(voc["weight"]),
+                          _p(voc["word_id"]), voc["L"], _p(f), n, levelsup, _p(word), _p(node), _p(w), _p(bi), _p(bv), _p(nb),
+                          _p(fn), _p(fo), _p(ff), _p(nf))
+    return dict(word=word, node=node, weight=w, bow_ids=bi[:nb[0]], bow_vals=bv[:nb[0]], fv_nodes=fn[:nf[0]],
+                fv_off=fo[:nf[0] + 1], fv_feat=ff[:fo[nf[0]]])
+
+
+def bow_score(ids1, vals1, ids2, vals2):
+    L = lib()
+    L.orc_bow_score.restype = C.c_double
+    L.orc_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    a = np.ascontiguousarray(ids1, np.int32); b = np.ascontiguousarray(vals1, np.float64)
+    c = np.ascontiguousarray(ids2, np.int32); d = np.ascontiguousarray(vals2, np.float64)
+    return L.orc_bow_score(_p(a), _p(b), len(a), _p(c), _p(d), len(c))

@@ -220,3 +220,29 @@ def test_distinctive_descriptors(capi, oracle):
     assert np.all(bi_g[big] == -2) and np.all(bm_g[big] == -2)
     assert np.array_equal(bi_g[~big], bi_o[~big]) and np.array_equal(bm_g[~big], bm_o[~big])
     assert capi.distinctive_descriptors(np.zeros((0, 32), np.uint8), [0])[0].shape == (0,)
+
+
+@pytest.mark.parametrize("k,L", [(10, 3), (6, 4), (10, 1)])
+def test_vocab_transform(capi, oracle, k, L):
+    """dvm_vocab_transform (DBoW2 tree descent on the device) and the host mirror's BowVector / FeatureVector / score
+    vs the oracle restatement of TemplatedVocabulary::transform.  Word / node ids and weights identical, BoW values
+    bit-identical doubles."""
+    from dvm_slam_amd import synth
+    voc = synth.vocabulary(k=k, L=L, seed=k * 10 + L)
+    rng = np.random.default_rng(k + L)
+    feats = voc["desc"][rng.integers(1, voc["n_nodes"], 1500)].copy()
+    feats[rng.random(feats.shape) < 0.05] ^= 0x81
+    feats[:50] = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    v = capi.Vocabulary(voc)
+    for levelsup in (0, 2, 4, 7):
+        wg, ng, wtg = v.transform(feats, levelsup)
+        r = oracle.vocab_transform(voc, feats, levelsup)
+        assert np.array_equal(wg, r["word"]) and np.array_equal(ng, r["node"]) and np.array_equal(wtg, r["weight"])
+        h = capi.vocab_transform_host(voc, feats, levelsup)
+        for key in ("bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+            assert np.array_equal(h[key], r[key]), key
+    assert v.transform(np.zeros((0, 32), np.uint8), 4)[0].shape == (0,)
+    v.close()
+    a = capi.vocab_transform_host(voc, feats[:800], 4); b = capi.vocab_transform_host(voc, feats[600:], 4)
+    assert capi.bow_score_host(a["bow_ids"], a["bow_vals"], b["bow_ids"], b["bow_vals"]) == \
+        oracle.bow_score(a["bow_ids"], a["bow_vals"], b["bow_ids"], b["bow_vals"])

@@ -278,3 +278,44 @@ def test_distinctive_descriptors_oracle_vs_numpy(oracle):
         D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(axis=2)
         med = np.sort(D, axis=1)[:, (n - 1) // 2]
         assert bm[p] == med.min() and bi[p] == int(np.argmin(med)), p
+
+
+def test_vocab_transform_oracle_vs_numpy(oracle):
+    """DBoW2 transform restatement: greedy descent (first child wins ties), TF-IDF accumulation, L1 normalisation and
+    L1 score, against a literal numpy / dict re-derivation on a small ragged vocabulary."""
+    from dvm_slam_amd import synth
+    voc = synth.vocabulary(k=6, L=3, seed=5)
+    rng = np.random.default_rng(8)
+    feats = voc["desc"][rng.integers(1, voc["n_nodes"], 300)].copy()        # near-duplicates of node descriptors -> ties
+    feats[rng.random(feats.shape) < 0.03] ^= 0x10
+    for levelsup in (0, 1, 2, 3, 5):
+        r = oracle.vocab_transform(voc, feats, levelsup)
+        bow, fv = {}, {}
+        for i, f in enumerate(feats):
+            cur, lvl, nid = 0, 0, (0 if voc["L"] - levelsup <= 0 else -1)
+            while voc["child_off"][cur + 1] > voc["child_off"][cur]:
+                lvl += 1
+                ch = voc["children"][voc["child_off"][cur]:voc["child_off"][cur + 1]]
+                d = np.unpackbits(voc["desc"][ch] ^ f, axis=1).sum(axis=1)
+                cur = int(ch[int(np.argmin(d))])                                # argmin = first minimum
+                if lvl == voc["L"] - levelsup:
+                    nid = cur
+            assert r["word"][i] == voc["word_id"][cur] and r["node"][i] == nid and r["weight"][i] == voc["weight"][cur]
+            if voc["weight"][cur] > 0:
+                bow[int(voc["word_id"][cur])] = bow.get(int(voc["word_id"][cur]), 0.0) + voc["weight"][cur]
+                fv.setdefault(nid, []).append(i)
+        ids = sorted(bow)
+        norm = 0.0
+        for k in ids:
+            norm += abs(bow[k])
+        assert list(r["bow_ids"]) == ids
+        assert np.array_equal(r["bow_vals"], np.array([bow[k] / norm for k in ids]))
+        assert list(r["fv_nodes"]) == sorted(fv)
+        for m, nd in enumerate(sorted(fv)):
+            assert list(r["fv_feat"][r["fv_off"][m]:r["fv_off"][m + 1]]) == fv[nd]
+    a = oracle.vocab_transform(voc, feats[:150], 1); b = oracle.vocab_transform(voc, feats[100:], 1)
+    s = oracle.bow_score(a["bow_ids"], a["bow_vals"], b["bow_ids"], b["bow_vals"])
+    da = dict(zip(a["bow_ids"], a["bow_vals"])); db = dict(zip(b["bow_ids"], b["bow_vals"]))
+    ref = 1.0 - 0.5 * sum(abs(da.get(k, 0.0) - db.get(k, 0.0)) for k in set(da) | set(db))
+    assert 0.0 < s < 1.0 and abs(s - ref) < 1e-12
+    assert abs(oracle.bow_score(a["bow_ids"], a["bow_vals"], a["bow_ids"], a["bow_vals"]) - 1.0) < 1e-12
