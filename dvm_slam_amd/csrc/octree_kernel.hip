@@ -388,13 +388,11 @@ void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_
     need = std::max(need, std::max(PD.lv[l].quota + 8, 4 * nIni + 4));
   }
   int cap = std::min((need + 63) / 64 * 64, kOctMaxNodes);
-  static bool attr_set = false;
   const size_t bytes = (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2);
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        kOctMaxNodes * (2 * (int)sizeof(ONodeRec) + 34));
-    attr_set = true;
-  }
+  // beyond the default 48 KB of dynamic LDS the limit has to be raised on the CURRENT device (the attribute is per
+  // device and the library serves one handle per GPU), so no process-wide "done once" flag
+  if (bytes > 48 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   hipLaunchKernelGGL(k_octree, dim3(PD.nlevels, batch), dim3(256), bytes, s, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel,
                      d_err, cap);
 }
