@@ -19,7 +19,7 @@ void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, 
 void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int level, const int32_t* d_tabs, int batch);
 void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch);
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
-                 int32_t* d_cell_count, int batch, int max_rw, int max_rh);
+                 int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num);
 void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
                     const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch);
 void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_start, const PipelineDesc& PD,

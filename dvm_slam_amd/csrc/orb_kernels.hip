@@ -431,7 +431,7 @@ template <int PITCH, int NW>
 __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                     const CellDesc* __restrict__ cells, PipelineDesc PD,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
-                                                    int max_rw, int max_rh, int batch) {
+                                                    int max_rw, int max_rh, int batch, int cell_first, int cell_num) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
   const int kTilePitch = PITCH ? PITCH : lay.tile_pitch;
@@ -445,7 +445,8 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   __shared__ int s_wave_tot[33][NW];
 
   int cell_id, f;
-  if (!xcd_frame_map(PD.ncells, batch, cell_id, f)) return;
+  if (!xcd_frame_map(cell_num, batch, cell_id, f)) return;
+  cell_id += cell_first;                 // this launch covers cells [cell_first, cell_first + cell_num)
   const CellDesc c = cells[cell_id];
   const LevelDesc& L = PD.lv[c.level];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1034,9 +1035,10 @@ void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, i
   hipLaunchKernelGGL(k_pyr_borders, grid, dim3(256), 0, s, d_pyr, PD, strip_blocks);
 }
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
-                 int32_t* d_cell_count, int batch, int max_rw, int max_rh) {
+                 int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num) {
+  if (cell_num <= 0) return;
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
-  const dim3 grid(xcd_grid(PD.ncells, batch));
+  const dim3 grid(xcd_grid(cell_num, batch));
   // two waves per cell while 32 survivor rounds of 128 cover the largest cell, else four
   const bool small = (max_rw - 6) * (max_rh - 6) <= 32 * 128;
   // (beyond the default 48 KB of dynamic LDS the limit is raised on the current device: per device, so per launch)
@@ -1046,7 +1048,7 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<P, W>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                           lay.total());                                                                                    \
     hipLaunchKernelGGL((k_fast_cells<P, W>), grid, dim3(64 * W), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells, PD,   \
-                       d_cand, d_cell_count, max_rw, max_rh, batch);                                                       \
+                       d_cand, d_cell_count, max_rw, max_rh, batch, cell_first, cell_num);                                 \
   } while (0)
   // (one wave per cell was measured too: occupancy-bound, 0.76 ms vs 0.68 ms for two)
   if (lay.tile_pitch == 56) { if (small) DVM_FAST_LAUNCH(56, 2); else DVM_FAST_LAUNCH(56, 4); }

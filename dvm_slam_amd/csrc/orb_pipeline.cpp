@@ -42,18 +42,23 @@ hipEvent_t Profiler::get_event() {
 }
 void Profiler::begin(hipStream_t s, const char* name) {
   if (!enabled) return;
-  Pending p{name, get_event(), get_event()};
+  Pending p{name, get_event(), get_event(), s, false};
   hipEventRecord(p.a, s);
   pending_.push_back(p);
 }
-void Profiler::end(hipStream_t s) {
-  if (!enabled || pending_.empty()) return;
-  hipEventRecord(pending_.back().b, s);
+void Profiler::end(hipStream_t s) {   // closes the most recent open bracket of stream `s` (brackets of different streams nest)
+  if (!enabled) return;
+  for (auto it = pending_.rbegin(); it != pending_.rend(); ++it)
+    if (!it->closed && it->stream == s) {
+      hipEventRecord(it->b, s);
+      it->closed = true;
+      return;
+    }
 }
 void Profiler::resolve() {
   for (auto& p : pending_) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+    if (p.closed && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
       auto& t = totals_[p.name];
       t.first += ms;
       t.second += 1;
@@ -513,13 +518,19 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   // level whose critical path is a single-lane std::sort emulation) and joins before the descriptors.
   // DVM_SERIAL=1 keeps the blur on the main chain, DVM_CHUNKS=1 disables the chunk pipeline.
   auto run_half = [&](hipStream_t st, hipStream_t side, int ck, int f0, int nb) -> int {
+    uint8_t* pyr_f0 = d_pyr + (size_t)f0 * PD.pyr_frame_bytes;
+    uint32_t* cand_f0 = d_cand + (size_t)f0 * PD.cand_frame_slots;
+    int32_t* cnt_f0 = d_cell_count + (size_t)f0 * PD.ncells;
+    // (tried: FAST of level 0 forked onto the side stream right after k_pyr_level0 so that it overlaps the seven resize
+    // launches -- the resizes are VALU-bound too and slow down by as much as is gained: 1.740 -> 1.717 ms per step,
+    // at the price of two k_fast_cells launches per batch; not kept.  launch_fast still takes a cell range.)
     prof.begin(st, "pyramid");
-    launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);
-    for (int l = 1; l < L; l++) launch_pyr_resize(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, l, d_tabs, nb);
-    if (tiny_levels) launch_pyr_borders(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), PD, nb);   // else: fused into the level kernels
+    launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, pyr_f0, PD, nb);
+    for (int l = 1; l < L; l++) launch_pyr_resize(st, pyr_f0, PD, l, d_tabs, nb);
+    if (tiny_levels) launch_pyr_borders(st, pyr_f0, PD, nb);   // else: fused into the level kernels
     prof.end(st);
     prof.begin(st, "fast");
-    launch_fast(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), d_cells, PD, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), nb, max_cell_rw, max_cell_rh);
+    launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, 0, PD.ncells);
     prof.end(st);
     prof.begin(st, "compact");
     launch_compact(st, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), d_cells, PD, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);

@@ -32,7 +32,7 @@ class Profiler {
   ~Profiler();
 
  private:
-  struct Pending { std::string name; hipEvent_t a, b; };
+  struct Pending { std::string name; hipEvent_t a, b; hipStream_t stream; bool closed; };
   std::vector<Pending> pending_;
   std::vector<hipEvent_t> pool_;
   std::map<std::string, std::pair<double, int64_t>> totals_;
