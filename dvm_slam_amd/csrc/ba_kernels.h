@@ -66,6 +66,8 @@ void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
 void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const double* P1c, const double* P2c,
                              const double* obs1, const double* obs2, const double* w1, const double* w2, int N,
                              const double* K, double th2, uint8_t* inlier, int32_t* nin, double* chi_scratch, uint8_t* flag_scratch);
+void ba_launch_sim3_hypotheses(hipStream_t s, const float* P1c, const float* P2c, const float* e1, const float* e2, int N,
+                               const float* K, const int32_t* triples, int H, int fix_scale, float* T12, int32_t* nin, uint8_t* mask);
 void ba_launch_pose_optimize(hipStream_t s, const double* pose_in, const double* Xw, const double* obs, const double* info,
                              const int32_t* n_per_frame, int stride, int batch, double fx, double fy, double cx, double cy,
                              double* pose_out, uint8_t* outlier, int32_t* n_inliers, double* chi_scratch);

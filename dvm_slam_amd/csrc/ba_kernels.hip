@@ -1262,6 +1262,149 @@ void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const 
                      nin, chi_scratch, flag_scratch);
 }
 
+// ------------------------------------------------------------------------------------------ Sim3Solver
+// Sim3Solver::ComputeSim3 (Horn 1987 closed form, reference src/Sim3Solver.cc:294-385) + CheckInliers (:387-408) for
+// a batch of RANSAC hypotheses, one wavefront each: the 3-point solve is wave-uniform (every lane computes it, no
+// communication), the N correspondences are strided over the lanes, inliers counted by ballots.  The minimal sets are
+// input (the reference draws them with DUtils::Random).  float / double split as in the reference except the 4x4
+// eigen-decomposition: cyclic Jacobi in double ("Horn spec", same as the oracle) instead of Eigen::EigenSolver<float>.
+__device__ __forceinline__ void jacobi4_dev(double A[4][4], double V[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 16; sweep++) {
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+      }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_sim3_hypotheses(const float* __restrict__ P1c, const float* __restrict__ P2c,
+                                                        const float* __restrict__ max_err1, const float* __restrict__ max_err2,
+                                                        int N, const float* __restrict__ K, const int32_t* __restrict__ triples,
+                                                        int H, int fix_scale, float* __restrict__ T12,
+                                                        int32_t* __restrict__ n_inliers, uint8_t* __restrict__ mask) {
+  const int h = blockIdx.x, lane = threadIdx.x;
+  if (h >= H) return;
+  float P1[3][3], P2[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int idx = triples[3 * h + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { P1[r][c] = P1c[3 * idx + r]; P2[r][c] = P2c[3 * idx + r]; }
+  }
+  float O1[3], O2[3], Pr1[3][3], Pr2[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    O1[r] = ((P1[r][0] + P1[r][1]) + P1[r][2]) / 3.0f; O2[r] = ((P2[r][0] + P2[r][1]) + P2[r][2]) / 3.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { Pr1[r][c] = P1[r][c] - O1[r]; Pr2[r][c] = P2[r][c] - O2[r]; }
+  }
+  float M[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) M[r][c] = (Pr2[r][0] * Pr1[c][0] + Pr2[r][1] * Pr1[c][1]) + Pr2[r][2] * Pr1[c][2];
+  const float N11 = M[0][0] + M[1][1] + M[2][2], N12 = M[1][2] - M[2][1], N13 = M[2][0] - M[0][2], N14 = M[0][1] - M[1][0];
+  const float N22 = M[0][0] - M[1][1] - M[2][2], N23 = M[0][1] + M[1][0], N24 = M[2][0] + M[0][2];
+  const float N33 = -M[0][0] + M[1][1] - M[2][2], N34 = M[1][2] + M[2][1], N44 = -M[0][0] - M[1][1] + M[2][2];
+  double A[4][4] = {{N11, N12, N13, N14}, {N12, N22, N23, N24}, {N13, N23, N33, N34}, {N14, N24, N34, N44}}, V[4][4];
+  jacobi4_dev(A, V);
+  int mi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++) if (A[k][k] > A[mi][mi]) mi = k;
+  double q0 = V[0][0], vx = V[1][0], vy = V[2][0], vz = V[3][0];
+#pragma unroll
+  for (int k = 1; k < 4; k++) if (mi == k) { q0 = V[0][k]; vx = V[1][k]; vy = V[2][k]; vz = V[3][k]; }
+  const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+  const double ang = atan2(vn, q0);
+  float R[3][3];
+  {
+    double ax = 0, ay = 0, az = 0;
+    if (vn > 0) { ax = vx / vn; ay = vy / vn; az = vz / vn; }
+    const double w = cos(ang), sh = sin(ang), x = sh * ax, y = sh * ay, z = sh * az;
+    R[0][0] = (float)(1 - 2 * (y * y + z * z)); R[0][1] = (float)(2 * (x * y - z * w)); R[0][2] = (float)(2 * (x * z + y * w));
+    R[1][0] = (float)(2 * (x * y + z * w)); R[1][1] = (float)(1 - 2 * (x * x + z * z)); R[1][2] = (float)(2 * (y * z - x * w));
+    R[2][0] = (float)(2 * (x * z - y * w)); R[2][1] = (float)(2 * (y * z + x * w)); R[2][2] = (float)(1 - 2 * (x * x + y * y));
+  }
+  float P3[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) P3[r][c] = (R[r][0] * Pr2[0][c] + R[r][1] * Pr2[1][c]) + R[r][2] * Pr2[2][c];
+  float sc = 1.0f;
+  if (!fix_scale) {
+    float nom = 0, den = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) { nom += Pr1[r][c] * P3[r][c]; den += P3[r][c] * P3[r][c]; }
+    sc = (float)((double)nom / (double)den);
+  }
+  float t[3], sR[3][3], sRi[3][3], ti[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) t[r] = O1[r] - ((sc * R[r][0]) * O2[0] + (sc * R[r][1]) * O2[1] + (sc * R[r][2]) * O2[2]);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { sR[r][c] = sc * R[r][c]; sRi[r][c] = (float)((1.0 / sc) * R[c][r]); }
+#pragma unroll
+  for (int r = 0; r < 3; r++) ti[r] = (-sRi[r][0] * t[0] + -sRi[r][1] * t[1]) + -sRi[r][2] * t[2];
+  if (lane == 0) {
+    float* out = T12 + 13 * (size_t)h;
+    out[0] = sc;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) out[1 + 3 * r + c] = R[r][c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) out[10 + r] = t[r];
+  }
+  const float fx1 = K[0], fy1 = K[1], cx1 = K[2], cy1 = K[3], fx2 = K[4], fy2 = K[5], cx2 = K[6], cy2 = K[7];
+  int nin = 0;
+  for (int base = 0; base < N; base += 64) {
+    const int i = base + lane;
+    bool in = false;
+    if (i < N) {
+      const float X1[3] = {P1c[3 * i], P1c[3 * i + 1], P1c[3 * i + 2]}, X2[3] = {P2c[3 * i], P2c[3 * i + 1], P2c[3 * i + 2]};
+      float a[3], b[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        a[r] = ((sR[r][0] * X2[0] + sR[r][1] * X2[1]) + sR[r][2] * X2[2]) + t[r];
+        b[r] = ((sRi[r][0] * X1[0] + sRi[r][1] * X1[1]) + sRi[r][2] * X1[2]) + ti[r];
+      }
+      const float p1x = fx1 * X1[0] / X1[2] + cx1, p1y = fy1 * X1[1] / X1[2] + cy1;   // FromCameraToImage
+      const float p2x = fx2 * X2[0] / X2[2] + cx2, p2y = fy2 * X2[1] / X2[2] + cy2;
+      const float u1 = fx1 * a[0] / a[2] + cx1, v1 = fy1 * a[1] / a[2] + cy1;
+      const float u2 = fx2 * b[0] / b[2] + cx2, v2 = fy2 * b[1] / b[2] + cy2;
+      const float d1x = p1x - u1, d1y = p1y - v1, d2x = u2 - p2x, d2y = v2 - p2y;
+      const float err1 = d1x * d1x + d1y * d1y, err2 = d2x * d2x + d2y * d2y;
+      in = err1 < max_err1[i] && err2 < max_err2[i];
+      mask[(size_t)h * N + i] = in ? 1 : 0;
+    }
+    nin += __popcll(__ballot(in));
+  }
+  if (lane == 0) n_inliers[h] = nin;
+}
+
+void ba_launch_sim3_hypotheses(hipStream_t s, const float* P1c, const float* P2c, const float* e1, const float* e2, int N,
+                               const float* K, const int32_t* triples, int H, int fix_scale, float* T12, int32_t* nin, uint8_t* mask) {
+  if (H > 0) hipLaunchKernelGGL(k_sim3_hypotheses, dim3(H), dim3(64), 0, s, P1c, P2c, e1, e2, N, K, triples, H, fix_scale, T12, nin, mask);
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

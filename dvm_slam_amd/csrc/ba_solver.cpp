@@ -421,4 +421,42 @@ int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c,
   return rc;
 }
 
+int dvm_sim3_hypotheses(int device, const float* P1c, const float* P2c, const float* max_err1, const float* max_err2, int N,
+                        const float* K1, const float* K2, const int32_t* triples, int H, int fix_scale, float* T12,
+                        int32_t* n_inliers, uint8_t* inlier_mask) {
+  if (!P1c || !P2c || !max_err1 || !max_err2 || !K1 || !K2 || !triples || !T12 || !n_inliers || !inlier_mask || N < 3 || H < 1) {
+    set_error("dvm_sim3_hypotheses: bad arguments");
+    return DVM_ERR_INVALID;
+  }
+  for (int i = 0; i < 3 * H; i++) if (triples[i] < 0 || triples[i] >= N) { set_error("dvm_sim3_hypotheses: sample index out of range"); return DVM_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) return DVM_ERR_INVALID;
+  DVM_HIP(hipSetDevice(device));
+  const size_t n = (size_t)N, hh = (size_t)H;
+  // floats: P1c[3n] P2c[3n] e1[n] e2[n] K[8] T12[13h]; int32: triples[3h] nin[h]; bytes: mask[h*n]
+  const size_t nf = 8 * n + 8 + 13 * hh, ni = 4 * hh;
+  uint8_t* d = nullptr;
+  DVM_HIP(hipMalloc(&d, nf * 4 + ni * 4 + hh * n + 16));
+  float* df = reinterpret_cast<float*>(d);
+  float *dP1 = df, *dP2 = df + 3 * n, *dE1 = df + 6 * n, *dE2 = df + 7 * n, *dK = df + 8 * n, *dT = dK + 8;
+  int32_t* dTri = reinterpret_cast<int32_t*>(df + nf);
+  int32_t* dNin = dTri + 3 * hh;
+  uint8_t* dMask = reinterpret_cast<uint8_t*>(dNin + hh);
+  int rc = DVM_OK;
+  auto up = [&](void* dst, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload"); };
+  float K[8];
+  std::memcpy(K, K1, 16); std::memcpy(K + 4, K2, 16);
+  up(dP1, P1c, 12 * n); up(dP2, P2c, 12 * n); up(dE1, max_err1, 4 * n); up(dE2, max_err2, 4 * n); up(dK, K, 32); up(dTri, triples, 12 * hh);
+  if (rc == DVM_OK) {
+    ba_launch_sim3_hypotheses(nullptr, dP1, dP2, dE1, dE2, N, dK, dTri, H, fix_scale, dT, dNin, dMask);
+    rc = hip_check(hipGetLastError(), "sim3_hypotheses launch");
+  }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(T12, dT, 52 * hh, hipMemcpyDeviceToHost), "download");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(n_inliers, dNin, 4 * hh, hipMemcpyDeviceToHost), "download");
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(inlier_mask, dMask, hh * n, hipMemcpyDeviceToHost), "download");
+  hipFree(d);
+  return rc;
+}
+
 }  // extern "C"

@@ -12,6 +12,7 @@
  *   dvm_ba_*       <- Optimizer::{BundleAdjustment,LocalBundleAdjustment} + g2o BlockSolver_6_3/LM
  *                                                    src/Optimizer.cc:55-356,1030-1387
  *   dvm_pose_optimize <- Optimizer::PoseOptimization src/Optimizer.cc:744-1028
+ *   dvm_sim3_hypotheses <- Sim3Solver::ComputeSim3 + CheckInliers src/Sim3Solver.cc:294-408
  *   dvm_distinctive_descriptors <- MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:384-453
  *   dvm_vocab_transform <- DBoW2::TemplatedVocabulary::transform Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1098-1138
  * The reference has no FFI: these classes live inside static libORB_SLAM3.a.  INTEGRATION.md shows
@@ -258,6 +259,16 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
 int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c, const double* P2c, const double* obs1,
                       const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
                       double th2, uint8_t* inlier, int32_t* n_inliers);
+
+/* Sim3Solver::ComputeSim3 + CheckInliers (src/Sim3Solver.cc:294-408) for H RANSAC hypotheses in one launch.
+ * P1c / P2c: the N matched map points in the two keyframes' camera frames (mvX3Dc1 / mvX3Dc2, float[3N]);
+ * max_err1/2: mvnMaxError1/2 as the reference stores them, (float)(size_t)(9.210 * sigma2); K1 / K2: fx, fy, cx, cy;
+ * triples: the minimal sets (3 correspondence indices each; the reference draws them with DUtils::Random, :171-181).
+ * Outputs per hypothesis: T12[13] = {s12, R12 row-major, t12}, n_inliers, inlier_mask[N].  The sequential
+ * best-hypothesis rule of iterate() (:154-185) stays with the caller.  Host pointers, synchronous. */
+int dvm_sim3_hypotheses(int device, const float* P1c, const float* P2c, const float* max_err1, const float* max_err2, int N,
+                        const float* K1, const float* K2, const int32_t* triples, int H, int fix_scale, float* T12,
+                        int32_t* n_inliers, uint8_t* inlier_mask);
 
 #ifdef __cplusplus
 }

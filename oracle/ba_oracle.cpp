@@ -751,4 +751,102 @@ int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const dou
   return nIn;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sim3Solver (reference src/Sim3Solver.cc): ComputeSim3 (Horn 1987, :294-385) for a batch of RANSAC hypotheses, each
+// followed by CheckInliers (:387-408) with Project (:421-435) / Pinhole::project.  The minimal sets are INPUT
+// (`triples`: the reference draws them with DUtils::Random, :171-181).  Arithmetic types follow the reference: points,
+// centroids, M, N, R, s, t and the reprojection errors are float; only the eigen-decomposition differs in method:
+// the reference runs Eigen::EigenSolver<Matrix4f>; here (and on the device) the symmetric N is diagonalised in double
+// by cyclic Jacobi rotations ("Horn spec").  max_err* = (float)(size_t)(9.210 * sigma2) as the reference stores them.
+namespace {
+void jacobi4(double A[4][4], double V[4][4]) {
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 16; sweep++) {
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 4; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+        for (int k = 0; k < 4; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+        for (int k = 0; k < 4; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+      }
+  }
+}
+}  // namespace
+
+void orc_sim3_hypotheses(const float* P1c, const float* P2c, const float* max_err1, const float* max_err2, int N, const float* K1,
+                         const float* K2, const int32_t* triples, int H, int fix_scale, float* T12 /*[H][12]: s R(9) t(3)... see below*/,
+                         int32_t* n_inliers, uint8_t* inlier_mask /*[H][N]*/) {
+  std::vector<float> p1im1(2 * (size_t)N), p2im2(2 * (size_t)N);
+  for (int i = 0; i < N; i++) {   // FromCameraToImage (:437-446)
+    p1im1[2 * i] = K1[0] * P1c[3 * i] / P1c[3 * i + 2] + K1[2]; p1im1[2 * i + 1] = K1[1] * P1c[3 * i + 1] / P1c[3 * i + 2] + K1[3];
+    p2im2[2 * i] = K2[0] * P2c[3 * i] / P2c[3 * i + 2] + K2[2]; p2im2[2 * i + 1] = K2[1] * P2c[3 * i + 1] / P2c[3 * i + 2] + K2[3];
+  }
+  for (int h = 0; h < H; h++) {
+    float P1[3][3], P2[3][3];   // [row][col], column i = point i
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) { P1[r][c] = P1c[3 * triples[3 * h + c] + r]; P2[r][c] = P2c[3 * triples[3 * h + c] + r]; }
+    float O1[3], O2[3], Pr1[3][3], Pr2[3][3];
+    for (int r = 0; r < 3; r++) {
+      O1[r] = ((P1[r][0] + P1[r][1]) + P1[r][2]) / 3.0f; O2[r] = ((P2[r][0] + P2[r][1]) + P2[r][2]) / 3.0f;
+      for (int c = 0; c < 3; c++) { Pr1[r][c] = P1[r][c] - O1[r]; Pr2[r][c] = P2[r][c] - O2[r]; }
+    }
+    float M[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r][c] = (Pr2[r][0] * Pr1[c][0] + Pr2[r][1] * Pr1[c][1]) + Pr2[r][2] * Pr1[c][2];
+    const float N11 = M[0][0] + M[1][1] + M[2][2], N12 = M[1][2] - M[2][1], N13 = M[2][0] - M[0][2], N14 = M[0][1] - M[1][0];
+    const float N22 = M[0][0] - M[1][1] - M[2][2], N23 = M[0][1] + M[1][0], N24 = M[2][0] + M[0][2];
+    const float N33 = -M[0][0] + M[1][1] - M[2][2], N34 = M[1][2] + M[2][1], N44 = -M[0][0] - M[1][1] + M[2][2];
+    double A[4][4] = {{N11, N12, N13, N14}, {N12, N22, N23, N24}, {N13, N23, N33, N34}, {N14, N24, N34, N44}}, V[4][4];
+    jacobi4(A, V);
+    int mi = 0;
+    for (int k = 1; k < 4; k++) if (A[k][k] > A[mi][mi]) mi = k;
+    const double q0 = V[0][mi], vx = V[1][mi], vy = V[2][mi], vz = V[3][mi];
+    const double vn = std::sqrt(vx * vx + vy * vy + vz * vz);
+    const double ang = std::atan2(vn, q0);
+    float R[3][3];
+    {  // vec = 2*ang*vec/|vec|; R = SO3::exp(vec)  (Rodrigues via the unit quaternion (cos ang, sin ang * axis))
+      double ax = 0, ay = 0, az = 0;
+      if (vn > 0) { ax = vx / vn; ay = vy / vn; az = vz / vn; }
+      const double w = std::cos(ang), sh = std::sin(ang), x = sh * ax, y = sh * ay, z = sh * az;
+      R[0][0] = (float)(1 - 2 * (y * y + z * z)); R[0][1] = (float)(2 * (x * y - z * w)); R[0][2] = (float)(2 * (x * z + y * w));
+      R[1][0] = (float)(2 * (x * y + z * w)); R[1][1] = (float)(1 - 2 * (x * x + z * z)); R[1][2] = (float)(2 * (y * z - x * w));
+      R[2][0] = (float)(2 * (x * z - y * w)); R[2][1] = (float)(2 * (y * z + x * w)); R[2][2] = (float)(1 - 2 * (x * x + y * y));
+    }
+    float P3[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) P3[r][c] = (R[r][0] * Pr2[0][c] + R[r][1] * Pr2[1][c]) + R[r][2] * Pr2[2][c];
+    float sc = 1.0f;
+    if (!fix_scale) {
+      float nom = 0, den = 0;
+      for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) { nom += Pr1[r][c] * P3[r][c]; den += P3[r][c] * P3[r][c]; }   // column-major sum
+      sc = (float)((double)nom / (double)den);
+    }
+    float t[3];
+    for (int r = 0; r < 3; r++) t[r] = O1[r] - ((sc * R[r][0]) * O2[0] + (sc * R[r][1]) * O2[1] + (sc * R[r][2]) * O2[2]);
+    float sR[3][3], sRi[3][3], ti[3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR[r][c] = sc * R[r][c]; sRi[r][c] = (float)((1.0 / sc) * R[c][r]); }
+    for (int r = 0; r < 3; r++) ti[r] = (-sRi[r][0] * t[0] + -sRi[r][1] * t[1]) + -sRi[r][2] * t[2];
+    float* out = T12 + 13 * (size_t)h;
+    out[0] = sc;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out[1 + 3 * r + c] = R[r][c];
+    for (int r = 0; r < 3; r++) out[10 + r] = t[r];
+    int nin = 0;
+    for (int i = 0; i < N; i++) {   // CheckInliers
+      float a[3], b[3];
+      for (int r = 0; r < 3; r++) {
+        a[r] = ((sR[r][0] * P2c[3 * i] + sR[r][1] * P2c[3 * i + 1]) + sR[r][2] * P2c[3 * i + 2]) + t[r];      // X2 in camera 1
+        b[r] = ((sRi[r][0] * P1c[3 * i] + sRi[r][1] * P1c[3 * i + 1]) + sRi[r][2] * P1c[3 * i + 2]) + ti[r];   // X1 in camera 2
+      }
+      const float u1 = K1[0] * a[0] / a[2] + K1[2], v1 = K1[1] * a[1] / a[2] + K1[3];
+      const float u2 = K2[0] * b[0] / b[2] + K2[2], v2 = K2[1] * b[1] / b[2] + K2[3];
+      const float d1x = p1im1[2 * i] - u1, d1y = p1im1[2 * i + 1] - v1, d2x = u2 - p2im2[2 * i], d2y = v2 - p2im2[2 * i + 1];
+      const float err1 = d1x * d1x + d1y * d1y, err2 = d2x * d2x + d2y * d2y;
+      const bool in = err1 < max_err1[i] && err2 < max_err2[i];
+      inlier_mask[(size_t)h * N + i] = in ? 1 : 0;
+      nin += in ? 1 : 0;
+    }
+    n_inliers[h] = nin;
+  }
+}
+
 }  // extern "C"

@@ -150,6 +150,11 @@ int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const dou
                       const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
                       double th2, uint8_t* inlier);
 
+/* Sim3Solver::ComputeSim3 + CheckInliers (src/Sim3Solver.cc:294-408) for H given minimal sets; T12 = [s, R row-major (9), t (3)] */
+void orc_sim3_hypotheses(const float* P1c, const float* P2c, const float* max_err1, const float* max_err2, int N, const float* K1,
+                         const float* K2, const int32_t* triples, int H, int fix_scale, float* T12, int32_t* n_inliers,
+                         uint8_t* inlier_mask);
+
 #ifdef __cplusplus
 }
 #endif

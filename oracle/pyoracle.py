@@ -442,3 +442,17 @@ def bow_score(ids1, vals1, ids2, vals2):
     a = np.ascontiguousarray(ids1, np.int32); b = np.ascontiguousarray(vals1, np.float64)
     c = np.ascontiguousarray(ids2, np.int32); d = np.ascontiguousarray(vals2, np.float64)
     return L.orc_bow_score(_p(a), _p(b), len(a), _p(c), _p(d), len(c))
+
+
+def sim3_hypotheses(P1c, P2c, max_err1, max_err2, K1, K2, triples, fix_scale=False):
+    """Sim3Solver::ComputeSim3 + CheckInliers for given minimal sets.  Returns (T12[H,13], n_inliers[H], mask[H,N])."""
+    L = lib()
+    vp, i32 = C.c_void_p, C.c_int32
+    L.orc_sim3_hypotheses.restype = None
+    L.orc_sim3_hypotheses.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
+    a = [np.ascontiguousarray(x, np.float32) for x in (P1c, P2c, max_err1, max_err2, K1, K2)]
+    tr = np.ascontiguousarray(triples, np.int32).reshape(-1, 3)
+    N, H = len(a[0]), len(tr)
+    T = np.zeros((H, 13), np.float32); nin = np.zeros(H, np.int32); mask = np.zeros((H, N), np.uint8)
+    L.orc_sim3_hypotheses(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), N, _p(a[4]), _p(a[5]), _p(tr), H, int(fix_scale), _p(T), _p(nin), _p(mask))
+    return T, nin, mask

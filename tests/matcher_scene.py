@@ -92,3 +92,22 @@ def make_local_map_scene(oracle, seed=0, **kw):
     claimed_obs = (rng.random(len(sc["kps_c"])) < 0.5).astype(np.uint8)
     return dict(kps=sc["kps_c"], desc=sc["desc_c"], mp=sc["mp_c"], claimed_obs=claimed_obs, bounds=sc["bounds"],
                 scale_factors=sc["scale_factors"], pts=pts)
+
+
+def make_sim3_scene(seed=0, n=200, outlier_frac=0.3, scale=1.7, noise=0.002):
+    """Two keyframes seeing the same map points up to a similarity (s, R, t) + noise + gross outliers.
+    Returns P1c, P2c (float32 [n,3]), max errors, intrinsics and the ground truth."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    P2 = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 9, n)])
+    R = Rotation.from_rotvec(rng.normal(0, 0.25, 3)).as_matrix()
+    t = rng.normal(0, 0.3, 3)
+    P1 = scale * (P2 @ R.T) + t + rng.normal(0, noise, (n, 3))
+    bad = rng.random(n) < outlier_frac
+    P1[bad] += rng.normal(0, 1.0, (int(bad.sum()), 3))
+    P1[:, 2] = np.maximum(P1[:, 2], 0.5)
+    K = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    sigma2 = (1.2 ** (2 * rng.integers(0, 8, n))).astype(np.float32)
+    max_err = np.floor(9.210 * sigma2).astype(np.float32)      # vector<size_t> in the reference
+    return dict(P1c=P1.astype(np.float32), P2c=P2.astype(np.float32), max_err1=max_err, max_err2=max_err.copy(), K1=K, K2=K.copy()), \
+        dict(s=scale, R=R, t=t, bad=bad)

@@ -183,3 +183,22 @@ def test_optimize_sim3_too_few_inliers(capi, oracle):
     So, io, no = oracle.optimize_sim3(S0, False, P1, P2, o1, o2, w1, w2, K, K, 10.0)
     Sg, ig, ng = capi.optimize_sim3(S0, False, P1, P2, o1, o2, w1, w2, K, K, 10.0)
     assert no == 0 and ng == 0 and not ig.any() and np.array_equal(Sg, S0)
+
+
+def test_sim3_hypotheses(capi, oracle):
+    """dvm_sim3_hypotheses (Sim3Solver::ComputeSim3 + CheckInliers, 300 RANSAC hypotheses in one launch) vs the oracle:
+    same Horn spec on both sides -> s, R, t to 1e-5, inlier masks identical away from the decision threshold."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from matcher_scene import make_sim3_scene
+    for seed, fix in ((0, False), (1, True), (2, False)):
+        sc, gt = make_sim3_scene(seed, n=300 if seed else 67, scale=1.0 if fix else 1.7)
+        rng = np.random.default_rng(seed + 10)
+        tri = np.array([rng.choice(len(sc["P1c"]), 3, replace=False) for _ in range(300)], np.int32)
+        Tg, ng, mg = capi.sim3_hypotheses(triples=tri, fix_scale=fix, **sc)
+        To, no, mo = oracle.sim3_hypotheses(triples=tri, fix_scale=fix, **sc)
+        assert np.allclose(Tg, To, rtol=1e-5, atol=1e-5)
+        differ = (mg != mo).sum(axis=1)
+        assert differ.max() <= 2 and differ.sum() <= 10, differ.sum()     # only points sitting on the chi2 threshold
+        assert np.all(np.abs(ng - no) <= 2)
+        assert ng.max() > 0.5 * (~gt["bad"]).sum()                         # RANSAC finds the similarity

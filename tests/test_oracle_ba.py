@@ -104,3 +104,39 @@ def test_optimize_sim3_oracle_vs_scipy(oracle):
     # fix_scale keeps s exactly
     S2, _, n2 = oracle.optimize_sim3(np.r_[S0[:7], 1.0], 1, P1, P2, obs1, obs2, w, w, K, K, 1e9)
     assert S2[7] == 1.0
+
+
+def test_sim3_hypotheses_oracle_vs_closed_form(oracle):
+    """Sim3Solver::ComputeSim3 restatement (Horn, Jacobi eigen-solver) against scipy's Kabsch / Umeyama on the same three
+    points (noise-free triples must reproduce the exact similarity), and CheckInliers against a numpy re-projection."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from matcher_scene import make_sim3_scene
+    from scipy.spatial.transform import Rotation
+    sc, gt = make_sim3_scene(3, noise=0.0, outlier_frac=0.25)
+    rng = np.random.default_rng(4)
+    good = np.flatnonzero(~gt["bad"])
+    tri = np.array([rng.choice(good, 3, replace=False) for _ in range(50)] +
+                   [rng.choice(len(gt["bad"]), 3, replace=False) for _ in range(50)], np.int32)
+    T, nin, mask = oracle.sim3_hypotheses(triples=tri, **sc)
+    for h in range(50):   # exact triples: the similarity is recovered (float arithmetic -> 1e-4)
+        assert abs(T[h, 0] - gt["s"]) < 2e-3
+        assert np.allclose(T[h, 1:10].reshape(3, 3), gt["R"], atol=2e-3)
+        assert np.allclose(T[h, 10:13], gt["t"], atol=2e-2)
+        assert nin[h] >= 0.9 * len(good)
+    P1, P2, K = sc["P1c"].astype(np.float64), sc["P2c"].astype(np.float64), sc["K1"].astype(np.float64)
+    for h in range(100):  # Horn == Kabsch/Umeyama on the 3 points; inliers == numpy re-projection away from the threshold
+        a, b = P1[tri[h]], P2[tri[h]]
+        ca, cb = a.mean(0), b.mean(0)
+        rot, _ = Rotation.align_vectors(a - ca, b - cb)          # a ~ R b
+        Rr = rot.as_matrix()
+        assert np.allclose(T[h, 1:10].reshape(3, 3), Rr, atol=5e-3), h
+        s, R, t = float(T[h, 0]), T[h, 1:10].reshape(3, 3).astype(np.float64), T[h, 10:13].astype(np.float64)
+        X21 = s * (P2 @ R.T) + t
+        X12 = ((P1 - t) @ R) / s
+        pr = lambda X: np.column_stack([K[0] * X[:, 0] / X[:, 2] + K[2], K[1] * X[:, 1] / X[:, 2] + K[3]])
+        e1 = ((pr(P1) - pr(X21)) ** 2).sum(1); e2 = ((pr(X12) - pr(P2)) ** 2).sum(1)
+        ref = (e1 < sc["max_err1"]) & (e2 < sc["max_err2"])
+        clear = (np.abs(e1 - sc["max_err1"]) > 1e-2 * sc["max_err1"]) & (np.abs(e2 - sc["max_err2"]) > 1e-2 * sc["max_err2"])
+        assert np.array_equal(mask[h].astype(bool)[clear], ref[clear]), h
+        assert nin[h] == mask[h].sum()
