@@ -584,3 +584,31 @@ def sim3_hypotheses(P1c, P2c, max_err1, max_err2, K1, K2, triples, fix_scale=Fal
     check(L.dvm_sim3_hypotheses(device, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), N, _p(a[4]), _p(a[5]), _p(tr), H, int(fix_scale),
                                 _p(T), _p(nin), _p(mask)))
     return T, nin, mask
+
+
+PG_EDGE_DTYPE = np.dtype([("vi", "<i4"), ("vj", "<i4"), ("Sji", "<f8", (8,))])
+
+
+class PgStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("stop_reason", C.c_int32), ("levels", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double), ("tile_fill", C.c_double),
+                ("ms_structure", C.c_double), ("ms_optimize", C.c_double), ("chi2_per_iter", C.c_double * 32),
+                ("trials_per_iter", C.c_int32 * 32)]
+
+
+def pose_graph_optimize(S, fixed, edges_v, edges_meas, fix_scale=False, iterations=20, device=0):
+    """dvm_pose_graph_optimize (Optimizer::OptimizeEssentialGraph numerics).  Returns (S_opt[n,8], stats dict)."""
+    L = lib()
+    L.dvm_pose_graph_optimize.restype = C.c_int32
+    L.dvm_pose_graph_optimize.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(PgStats)]
+    So = np.array(S, np.float64, copy=True)
+    fx = np.ascontiguousarray(fixed, np.uint8)
+    e = np.zeros(len(edges_v), PG_EDGE_DTYPE)
+    ev = np.asarray(edges_v)
+    e["vi"] = ev[:, 0]; e["vj"] = ev[:, 1]; e["Sji"] = edges_meas
+    st = PgStats()
+    check(L.dvm_pose_graph_optimize(device, _p(So), _p(fx), len(So), _p(e), len(e), int(fix_scale), int(iterations), C.byref(st)))
+    d = {k: getattr(st, k) for k, _ in PgStats._fields_}
+    d["chi2_per_iter"] = np.array(st.chi2_per_iter[:]); d["trials_per_iter"] = np.array(st.trials_per_iter[:])
+    return So, d

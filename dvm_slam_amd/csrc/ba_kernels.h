@@ -44,6 +44,7 @@ struct BaView {
   // ba_row(i) = (i / 10) * 64 + (i % 10) * 6; rows 60..63 of a tile are identity padding; n_pad = 64 * camera tiles;
   // row n_pad carries bschur^T (augmented rhs), so ldS = n_pad + 64.
   int32_t n_pad;
+  int32_t per_tile, dof;    // unknown blocks per 64-row tile and their size: (10, 6) cameras, (9, 7) Sim3 vertices
   double* xrow;             // [n_pad] solution in row space (back substitution reads its ancestors here)
   // level schedule of the tile Cholesky (columns of one elimination-tree height are independent):
   const int32_t* cols;      // columns by level                                  (host offsets h_level_off)
@@ -56,6 +57,27 @@ struct BaView {
   int32_t nlevels;
   const double* lambda;     // device scalar: current LM damping (so the per-trial launch sequence is a replayable graph)
 };
+
+// Sim3 pose graph (Optimizer::OptimizeEssentialGraph numerics): vertex states + EdgeSim3 list + block structure.
+// The reduced system lives in a BaView used as a plain tile system (S, schedule, x): per_tile = 9, dof = 7.
+struct PgView {
+  int32_t n, E, nfree, fix_scale, nblk;
+  double* S;                 // [n][8] vertex estimates Siw (q_xyzw, t, s)
+  const int32_t* vidx;       // [n] position in the elimination order or -1 (fixed)
+  const int32_t* free_v;     // [nfree] vertex id
+  const int32_t* ev;         // [E][2] (vertex 0 = i, vertex 1 = j)
+  const double* emeas;       // [E][8] measurement Sji
+  double* e_err;             // [E][7]
+  double* e_J;               // [E][2][49] numeric Jacobians w.r.t. vertex i / vertex j, row-major [error row][dof]
+  const int32_t *blk_a, *blk_b, *blk_start;   // non-zero 7x7 blocks (pos a >= pos b) and their contribution lists
+  const int32_t* blk_contrib;                 // edge << 2 | side_a << 1 | side_b
+  const int32_t *v_start, *v_contrib;         // per free vertex: incident edges, edge << 1 | side
+  double* bp;                // [7 * nfree] gradient b (compact), for computeScale
+  double* partial;           // per-block partial sums
+};
+void pg_launch_edge_eval(hipStream_t s, const PgView& G, bool jac, double* d_scalars, int slot);
+void pg_launch_build(hipStream_t s, const PgView& G, const BaView& T);
+void pg_launch_update(hipStream_t s, const PgView& G, const BaView& T, double* d_scalars, int slot_scale);
 
 void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, double* d_scalars, int slot);
 void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot_maxdiag);

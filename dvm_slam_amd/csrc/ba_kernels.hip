@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(256) k_pad_identity(BaView V) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= V.n_pad) return;
   const int w = r & 63;
-  if (w >= 60 || (r >> 6) * 10 + w / 6 >= V.nfree) V.S[(size_t)r * V.ldS + r] = 1.0;
+  if (w >= V.per_tile * V.dof || (r >> 6) * V.per_tile + w / V.dof >= V.nfree) V.S[(size_t)r * V.ldS + r] = 1.0;
 }
 
 // ----------------------------------------------------------------------------------------- K10
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
 // levels visited from the root down:  x_k = Linv_kk^T (y_k - sum_{i in struct(k)} L(i,k)^T x_i); the x_i belong to
 // ancestors of k and are final.  The result goes to row space (xrow, for the descendants) and, compacted to
 // 6 doubles per camera, to V.x for the update kernels.
-__global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n_pad, int nfree,
+__global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n_pad, int nfree, int per_tile, int dof,
                                                         const int32_t* __restrict__ cols, const double* __restrict__ y,
                                                         double* __restrict__ xrow, double* __restrict__ x,
                                                         const double* __restrict__ Linv_all,
@@ -644,8 +644,8 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   if (tid < NB) {
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     xrow[k0 + tid] = v;
-    const int cam = kb * 10 + tid / 6;
-    if (tid < 60 && cam < nfree) x[6 * (size_t)cam + tid % 6] = v;
+    const int cam = kb * per_tile + tid / dof;
+    if (tid < per_tile * dof && cam < nfree) x[dof * (size_t)cam + tid % dof] = v;
   }
 }
 
@@ -1405,6 +1405,176 @@ void ba_launch_sim3_hypotheses(hipStream_t s, const float* P1c, const float* P2c
   if (H > 0) hipLaunchKernelGGL(k_sim3_hypotheses, dim3(H), dim3(64), 0, s, P1c, P2c, e1, e2, N, K, triples, H, fix_scale, T12, nin, mask);
 }
 
+// ---------------------------------------------------------------------------------- essential graph
+// Optimizer::OptimizeEssentialGraph numerics (reference src/Optimizer.cc:1389-1652): VertexSim3Expmap + EdgeSim3
+// (types_seven_dof_expmap.h:93-117), numeric Jacobians as g2o takes them (base_binary_edge.hpp:131-205).
+__device__ void sim3_log(const Sim3d& S, double* res) {   // g2o Sim3::log, sim3.h:128-197
+  const double sigma = log(S.s);
+  double R[9];
+  quat_to_R(S.q, R);
+  const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+  const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  double omega[3];
+  const double eps = 0.00001;
+  double A, B, C;
+  if (fabs(sigma) < eps) {
+    C = 1;
+    if (d > 1 - eps) { for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i]; A = 1. / 2.; B = 1. / 6.; }
+    else {
+      const double theta = acos(d), theta2 = theta * theta;
+      for (int i = 0; i < 3; i++) omega[i] = theta / (2 * sqrt(1 - d * d)) * dR[i];
+      A = (1 - cos(theta)) / theta2; B = (theta - sin(theta)) / (theta2 * theta);
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (d > 1 - eps) {
+      const double sigma2 = sigma * sigma;
+      for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i];
+      A = ((sigma - 1) * S.s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+    } else {
+      const double theta = acos(d);
+      for (int i = 0; i < 3; i++) omega[i] = theta / (2 * sqrt(1 - d * d)) * dR[i];
+      const double theta2 = theta * theta, a = S.s * sin(theta), b = S.s * cos(theta), c = theta2 + sigma * sigma;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+    }
+  }
+  const double O[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+  double W[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double o2 = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+      W[3 * i + j] = A * O[3 * i + j] + B * o2 + C * (i == j ? 1.0 : 0.0);
+    }
+  const double c00 = W[4] * W[8] - W[5] * W[7], c01 = W[5] * W[6] - W[3] * W[8], c02 = W[3] * W[7] - W[4] * W[6];
+  const double det = W[0] * c00 + W[1] * c01 + W[2] * c02;
+  const double inv[9] = {c00, W[2] * W[7] - W[1] * W[8], W[1] * W[5] - W[2] * W[4],
+                         c01, W[0] * W[8] - W[2] * W[6], W[2] * W[3] - W[0] * W[5],
+                         c02, W[1] * W[6] - W[0] * W[7], W[0] * W[4] - W[1] * W[3]};
+  for (int i = 0; i < 3; i++) res[i] = omega[i];
+  for (int i = 0; i < 3; i++) res[3 + i] = (inv[3 * i] * S.t[0] + inv[3 * i + 1] * S.t[1] + inv[3 * i + 2] * S.t[2]) / det;
+  res[6] = sigma;
+}
+__device__ __forceinline__ void sim3_load(const double* p, Sim3d& S) {
+  S.q[0] = p[0]; S.q[1] = p[1]; S.q[2] = p[2]; S.q[3] = p[3]; S.t[0] = p[4]; S.t[1] = p[5]; S.t[2] = p[6]; S.s = p[7];
+}
+__device__ void pg_edge_error(const Sim3d& C, const Sim3d& Si, const Sim3d& Sj, double* e) {   // log(C * v1 * v2^-1)
+  Sim3d Sji, t1, t2;
+  sim3_inv(Sj, Sji);
+  sim3_mul(C, Si, t1);
+  sim3_mul(t1, Sji, t2);
+  sim3_log(t2, e);
+}
+// thread per edge: error, chi2 partial; JAC: the two 7x7 numeric Jacobians (14 columns x 2 perturbed error evaluations)
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_pg_edge(PgView G) {
+  __shared__ double red[256];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  double chi = 0;
+  if (k < G.E) {
+    const int vi = G.ev[2 * k], vj = G.ev[2 * k + 1];
+    Sim3d C, Si, Sj;
+    sim3_load(G.emeas + 8 * (size_t)k, C); sim3_load(G.S + 8 * (size_t)vi, Si); sim3_load(G.S + 8 * (size_t)vj, Sj);
+    double e[7];
+    pg_edge_error(C, Si, Sj, e);
+    for (int a = 0; a < 7; a++) { G.e_err[7 * (size_t)k + a] = e[a]; chi += e[a] * e[a]; }
+    if (JAC) {
+      for (int side = 0; side < 2; side++) {
+        const int v = side ? vj : vi;
+        double* J = G.e_J + (size_t)k * 98 + 49 * side;
+        if (G.vidx[v] < 0) { for (int a = 0; a < 49; a++) J[a] = 0; continue; }
+        const Sim3d& X = side ? Sj : Si;
+        for (int d = 0; d < 7; d++) {
+          double e1[7], e2[7];
+          for (int sgn = 0; sgn < 2; sgn++) {
+            double u[7] = {0, 0, 0, 0, 0, 0, 0};
+            u[d] = sgn ? -1e-9 : 1e-9;
+            if (G.fix_scale) u[6] = 0;
+            Sim3d Ex, Xp;
+            sim3_exp(u, Ex);
+            sim3_mul(Ex, X, Xp);
+            pg_edge_error(C, side ? Si : Xp, side ? Xp : Sj, sgn ? e2 : e1);
+          }
+          for (int a = 0; a < 7; a++) J[7 * a + d] = (1.0 / (2 * 1e-9)) * (e1[a] - e2[a]);
+        }
+      }
+    }
+  }
+  red[threadIdx.x] = chi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) G.partial[blockIdx.x] = red[0];
+}
+// 64 threads per non-zero 7x7 block (a >= b): H_ab = sum over its contributions J_a^T J_b (+ lambda on the diagonal),
+// fixed order, written into the tile-space matrix
+__global__ void __launch_bounds__(256) k_pg_blocks(PgView G, BaView T) {
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), t = threadIdx.x & 63;
+  if (blk >= G.nblk || t >= 49) return;
+  const int r = t / 7, c = t % 7;
+  const int a = G.blk_a[blk], b = G.blk_b[blk];
+  double acc = 0;
+  for (int i = G.blk_start[blk]; i < G.blk_start[blk + 1]; i++) {
+    const int w = G.blk_contrib[i];
+    const double* Ja = G.e_J + (size_t)(w >> 2) * 98 + 49 * ((w >> 1) & 1);
+    const double* Jb = G.e_J + (size_t)(w >> 2) * 98 + 49 * (w & 1);
+    double h = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) h += Ja[7 * k + r] * Jb[7 * k + c];
+    acc += h;
+  }
+  if (a == b && r == c) acc += *T.lambda;
+  const int ra = (a / T.per_tile) * 64 + (a % T.per_tile) * T.dof, rb = (b / T.per_tile) * 64 + (b % T.per_tile) * T.dof;
+  T.S[(size_t)(ra + r) * T.ldS + rb + c] = acc;
+}
+// thread per free vertex: b_v = - sum J_v^T e  -> compact copy (computeScale) and the augmented rhs row
+__global__ void __launch_bounds__(256) k_pg_rhs(PgView G, BaView T) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= G.nfree) return;
+  double b[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = G.v_start[p]; i < G.v_start[p + 1]; i++) {
+    const int w = G.v_contrib[i];
+    const double* J = G.e_J + (size_t)(w >> 1) * 98 + 49 * (w & 1);
+    const double* e = G.e_err + 7 * (size_t)(w >> 1);
+    for (int r = 0; r < 7; r++) {
+      double g = 0;
+#pragma unroll
+      for (int a = 0; a < 7; a++) g += J[7 * a + r] * (-e[a]);
+      b[r] += g;
+    }
+  }
+  const int row = (p / T.per_tile) * 64 + (p % T.per_tile) * T.dof;
+  for (int r = 0; r < 7; r++) { G.bp[7 * (size_t)p + r] = b[r]; T.S[(size_t)T.n_pad * T.ldS + row + r] = b[r]; }
+  if (p == 0) T.S[(size_t)T.n_pad * T.ldS + T.n_pad] = 1e200;
+}
+// thread per free vertex: oplus (S <- Sim3(x) * S) and the computeScale partial sum x^T (lambda x + b)
+__global__ void __launch_bounds__(256) k_pg_update(PgView G, BaView T) {
+  __shared__ double red[256];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  double sc = 0;
+  if (p < G.nfree) {
+    const double lambda = *T.lambda;
+    double u[7];
+    for (int r = 0; r < 7; r++) { u[r] = T.x[7 * (size_t)p + r]; sc += u[r] * (lambda * u[r] + G.bp[7 * (size_t)p + r]); }
+    if (G.fix_scale) u[6] = 0;
+    double* Sp = G.S + 8 * (size_t)G.free_v[p];
+    Sim3d X, Ex, Xn;
+    sim3_load(Sp, X);
+    sim3_exp(u, Ex);
+    sim3_mul(Ex, X, Xn);
+    Sp[0] = Xn.q[0]; Sp[1] = Xn.q[1]; Sp[2] = Xn.q[2]; Sp[3] = Xn.q[3]; Sp[4] = Xn.t[0]; Sp[5] = Xn.t[1]; Sp[6] = Xn.t[2]; Sp[7] = Xn.s;
+  }
+  red[threadIdx.x] = sc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) G.partial[blockIdx.x] = red[0];
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -1440,7 +1610,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
   hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.ytmp);
   for (int h = V.nlevels - 1; h >= 0; h--)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(V.h_level_off[h + 1] - V.h_level_off[h]), dim3(256), 0, s, V.S, V.ldS, V.n_pad,
-                       V.nfree, V.cols + V.h_level_off[h], V.ytmp, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
+                       V.nfree, V.per_tile, V.dof, V.cols + V.h_level_off[h], V.ytmp, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
@@ -1450,6 +1620,24 @@ void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars,
 }
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out) {
   hipLaunchKernelGGL(k_edge_depth, dim3(cdiv(V.E, 256)), dim3(256), 0, s, V, d_out);
+}
+
+void pg_launch_edge_eval(hipStream_t s, const PgView& G, bool jac, double* d_scalars, int slot) {
+  const int nb = cdiv(G.E, 256);
+  if (jac) hipLaunchKernelGGL(k_pg_edge<true>, dim3(nb), dim3(256), 0, s, G);
+  else hipLaunchKernelGGL(k_pg_edge<false>, dim3(nb), dim3(256), 0, s, G);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, G.partial, nb, d_scalars, slot);
+}
+void pg_launch_build(hipStream_t s, const PgView& G, const BaView& T) {
+  hipMemsetAsync(T.S, 0, (size_t)T.ldS * T.ldS * sizeof(double), s);
+  hipLaunchKernelGGL(k_pg_blocks, dim3(cdiv(G.nblk, 4)), dim3(256), 0, s, G, T);
+  hipLaunchKernelGGL(k_pg_rhs, dim3(cdiv(G.nfree, 256)), dim3(256), 0, s, G, T);
+  hipLaunchKernelGGL(k_pad_identity, dim3(cdiv(T.n_pad, 256)), dim3(256), 0, s, T);
+}
+void pg_launch_update(hipStream_t s, const PgView& G, const BaView& T, double* d_scalars, int slot_scale) {
+  const int nb = cdiv(G.nfree, 256);
+  hipLaunchKernelGGL(k_pg_update, dim3(nb), dim3(256), 0, s, G, T);
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, G.partial, nb, d_scalars, slot_scale);
 }
 
 }  // namespace dvm

@@ -98,7 +98,7 @@ void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vecto
 namespace {
 // camera sequence `seq` (a banded order) -> tiles of 10 consecutive cameras -> nested dissection of the tile graph
 // -> final position of every camera
-std::vector<int> order_from_sequence(const Graph& g, const std::vector<int>& seq) {
+std::vector<int> order_from_sequence(const Graph& g, const std::vector<int>& seq, int kCamsPerTile) {
   const int n = (int)seq.size();
   const int nt = (n + kCamsPerTile - 1) / kCamsPerTile;
   std::vector<int> tile_of(n);
@@ -126,7 +126,7 @@ std::vector<int> order_from_sequence(const Graph& g, const std::vector<int>& seq
 }
 
 // dependency-chain length (and fill) of the tile Cholesky under camera order `pos`
-std::pair<int, double> evaluate(const Graph& g, const std::vector<int>& pos) {
+std::pair<int, double> evaluate(const Graph& g, const std::vector<int>& pos, int kCamsPerTile) {
   const int n = (int)pos.size();
   const int nt = (n + kCamsPerTile - 1) / kCamsPerTile + 1;
   std::vector<std::vector<char>> T(nt, std::vector<char>(nt, 0));
@@ -140,7 +140,7 @@ std::pair<int, double> evaluate(const Graph& g, const std::vector<int>& pos) {
 }
 }  // namespace
 
-std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in) {
+std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in, int per_tile) {
   const int n = (int)adj_in.size();
   const Graph g = clean(adj_in);
   // candidate 1: the given order (keyframe ids follow the trajectory: already banded, and a loop closure stays ONE
@@ -159,8 +159,8 @@ std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in) {
         for (int v : l) { cm.push_back(v); placed[v] = 1; }
     }
   }
-  const std::vector<int> p1 = order_from_sequence(g, natural), p2 = order_from_sequence(g, cm);
-  const auto e1 = evaluate(g, p1), e2 = evaluate(g, p2);
+  const std::vector<int> p1 = order_from_sequence(g, natural, per_tile), p2 = order_from_sequence(g, cm, per_tile);
+  const auto e1 = evaluate(g, p1, per_tile), e2 = evaluate(g, p2, per_tile);
   return (e1 < e2 || e1 == e2) ? p1 : p2;   // shortest dependency chain, then least fill
 }
 

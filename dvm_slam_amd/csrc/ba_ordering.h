@@ -17,11 +17,12 @@
 
 namespace dvm {
 
-constexpr int kCamsPerTile = 10;   // 6 * 10 = 60 rows of a 64-row tile; rows 60..63 are identity padding
+constexpr int kCamsPerTile = 10;   // BA: 6 * 10 = 60 rows of a 64-row tile; rows 60..63 are identity padding
+constexpr int kSim3PerTile = 9;    // pose graph: 7 * 9 = 63 rows
 
 // adj[a] = cameras sharing a landmark with camera a (any order, may contain duplicates / a itself).
 // Returns pos[a] = position of camera a in the elimination order (a permutation of 0..n-1).
-std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj);
+std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj, int per_tile = kCamsPerTile);
 
 struct BaTileSchedule {
   int ntiles = 0;                      // tiles of the factor, the last one holds the augmented rhs row

@@ -166,6 +166,7 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   // ---- tile space: 10 whole cameras per 64-row tile, one extra tile for the augmented rhs row
   const int ncamt = (V.nfree + kCamsPerTile - 1) / kCamsPerTile, nkb = ncamt + 1;
   V.n_pad = 64 * ncamt;
+  V.per_tile = kCamsPerTile; V.dof = 6;
   V.ldS = 64 * nkb;
   // ---- symbolic tile Cholesky + level schedule.  SLAM reduced camera matrices are banded along the trajectory plus
   // a few loop-closure blocks; skipping zero tiles keeps the dense-tile solver exact while doing only the work the

@@ -259,3 +259,64 @@ def vocabulary(k: int = 10, L: int = 3, seed: int = 0x0B0C, ragged: bool = True,
     weight[leaves[rng.random(len(leaves)) < stop_frac]] = 0.0
     return dict(n_nodes=n, child_off=np.array(child_off, np.int32), children=np.array(children, np.int32), desc=desc,
                 weight=weight, word_id=word_id, L=L)
+
+
+def _sim3_mul(a, b):
+    from scipy.spatial.transform import Rotation as Rot
+    ra, rb = Rot.from_quat(a[:4]), Rot.from_quat(b[:4])
+    q = (ra * rb).as_quat()
+    if q[3] < 0:
+        q = -q
+    return np.concatenate([q, a[7] * ra.apply(b[4:7]) + a[4:7], [a[7] * b[7]]])
+
+
+def _sim3_inv(a):
+    from scipy.spatial.transform import Rotation as Rot
+    ri = Rot.from_quat(a[:4]).inv()
+    q = ri.as_quat()
+    if q[3] < 0:
+        q = -q
+    return np.concatenate([q, ri.apply(-a[4:7] / a[7]), [1.0 / a[7]]])
+
+
+def pose_graph(n: int = 60, seed: int = 0xE55E, drift: float = 0.02, extra: int = 2, noise: float = 0.0):
+    """Essential-graph style Sim3 pose graph: keyframes on a loop; spanning-tree edges (i, i-1), `extra` covisibility edges
+    per keyframe, one loop-closure edge (n-1, 0).  Measurements Sji = Sjw * Swi come from the ground truth (optionally
+    noisy); the initial estimates carry an accumulated drift in rotation, translation and scale.  Vertex 0 is fixed.
+    Returns dict(S0 [n,8] (q_xyzw, t, s), S_gt, fixed, edges_v [E,2] (i, j), edges_meas [E,8])."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((n, 8))
+    for i in range(n):
+        a = 2 * np.pi * i / n
+        Rwc = Rot.from_euler("zyx", [a + np.pi / 2, 0.1 * np.sin(3 * a), 0.05 * np.cos(2 * a)])
+        twc = np.array([10 * np.cos(a), 10 * np.sin(a), 0.3 * np.sin(4 * a)])
+        Rcw = Rwc.inv()
+        q = Rcw.as_quat()
+        if q[3] < 0:
+            q = -q
+        gt[i] = np.concatenate([q, -Rcw.apply(twc), [1.0]])
+    S0 = gt.copy()
+    acc = np.array([0, 0, 0, 1, 0, 0, 0, 1.0])
+    for i in range(1, n):
+        d = np.concatenate([Rot.from_rotvec(rng.normal(0, drift, 3)).as_quat(), rng.normal(0, drift * 5, 3), [np.exp(rng.normal(0, drift))]])
+        acc = _sim3_mul(d, acc)
+        S0[i] = _sim3_mul(acc, gt[i])
+    ev, em = [], []
+
+    def add(i, j):
+        m = _sim3_mul(gt[j], _sim3_inv(gt[i]))
+        if noise > 0:
+            d = np.concatenate([Rot.from_rotvec(rng.normal(0, noise, 3)).as_quat(), rng.normal(0, noise, 3), [np.exp(rng.normal(0, noise))]])
+            m = _sim3_mul(d, m)
+        ev.append((i, j)); em.append(m)
+
+    for i in range(1, n):
+        add(i, i - 1)
+        for k in range(extra):
+            j = i - 2 - int(rng.integers(0, 4))
+            if j >= 0:
+                add(i, j)
+    add(n - 1, 0)
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    return dict(S0=S0, S_gt=gt, fixed=fixed, edges_v=np.array(ev, np.int32), edges_meas=np.array(em, np.float64))

@@ -12,6 +12,7 @@
  *   dvm_ba_*       <- Optimizer::{BundleAdjustment,LocalBundleAdjustment} + g2o BlockSolver_6_3/LM
  *                                                    src/Optimizer.cc:55-356,1030-1387
  *   dvm_pose_optimize <- Optimizer::PoseOptimization src/Optimizer.cc:744-1028
+ *   dvm_pose_graph_optimize <- Optimizer::OptimizeEssentialGraph src/Optimizer.cc:1389-1652 (g2o part)
  *   dvm_sim3_hypotheses <- Sim3Solver::ComputeSim3 + CheckInliers src/Sim3Solver.cc:294-408
  *   dvm_distinctive_descriptors <- MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:384-453
  *   dvm_vocab_transform <- DBoW2::TemplatedVocabulary::transform Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1098-1138
@@ -259,6 +260,21 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
 int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c, const double* P2c, const double* obs1,
                       const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
                       double th2, uint8_t* inlier, int32_t* n_inliers);
+
+/* Optimizer::OptimizeEssentialGraph numerics (src/Optimizer.cc:1389-1652): Sim3 pose graph of n vertices
+ * (S[n][8] = estimates Siw as (q_xyzw, t, s), in/out; fixed[v] != 0 keeps a vertex) and E EdgeSim3 (vertex 0 = vi,
+ * vertex 1 = vj, measurement Sji = Sjw * Swi, information = identity).  g2o's numeric Jacobians, Levenberg-Marquardt
+ * with lambda_init 1e-16, `iterations` = optimize(20) in the reference.  Which keyframes / edges enter the graph and the
+ * SE3 / map-point correction afterwards (:1601-1648) stay with the caller.  Host pointers, synchronous. */
+typedef struct { int32_t vi, vj; double Sji[8]; } dvm_pg_edge;
+typedef struct {
+  int32_t iterations, total_trials, stop_reason, levels;
+  double chi2_initial, chi2_final, lambda_final, tile_fill, ms_structure, ms_optimize;
+  double chi2_per_iter[32];   /* chi2 after each outer iteration (first 32) */
+  int32_t trials_per_iter[32];
+} dvm_pg_stats;
+int dvm_pose_graph_optimize(int device, double* S, const uint8_t* fixed, int n, const dvm_pg_edge* edges, int E,
+                            int fix_scale, int iterations, dvm_pg_stats* stats);
 
 /* Sim3Solver::ComputeSim3 + CheckInliers (src/Sim3Solver.cc:294-408) for H RANSAC hypotheses in one launch.
  * P1c / P2c: the N matched map points in the two keyframes' camera frames (mvX3Dc1 / mvX3Dc2, float[3N]);

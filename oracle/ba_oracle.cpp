@@ -752,6 +752,188 @@ int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const dou
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Optimizer::OptimizeEssentialGraph numerics (reference src/Optimizer.cc:1389-1652): a pose graph of VertexSim3Expmap
+// (estimate Siw, oplus: S <- Sim3(update) * S, scale frozen by _fix_scale) and EdgeSim3 (error = log(Sji * Siw * Sjw^-1),
+// information = identity, no robust kernel; Thirdparty/g2o/g2o/types/types_seven_dof_expmap.h:93-117) whose Jacobians
+// g2o takes numerically (base_binary_edge.hpp:131-205, central differences, delta = 1e-9), solved by
+// OptimizationAlgorithmLevenberg with setUserLambdaInit(1e-16) and optimize(20).  Graph assembly (which keyframes,
+// which spanning-tree / loop / covisibility edges, their measurements Sji) stays with the caller.
+// Sim3::log follows sim3.h:128-197; W.lu().solve(t) is restated as the adjugate inverse (3x3).
+static void sim3_log(const Sim3d& S, double res[7]) {
+  const double sigma = std::log(S.s);
+  double R[9];
+  quat_to_R(S.q, R);
+  const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+  const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};   // deltaR
+  double omega[3];
+  const double eps = 0.00001;
+  double A, B, C;
+  if (std::fabs(sigma) < eps) {
+    C = 1;
+    if (d > 1 - eps) { for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i]; A = 1. / 2.; B = 1. / 6.; }
+    else {
+      const double theta = std::acos(d), theta2 = theta * theta;
+      for (int i = 0; i < 3; i++) omega[i] = theta / (2 * std::sqrt(1 - d * d)) * dR[i];
+      A = (1 - std::cos(theta)) / theta2; B = (theta - std::sin(theta)) / (theta2 * theta);
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (d > 1 - eps) {
+      const double sigma2 = sigma * sigma;
+      for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i];
+      A = ((sigma - 1) * S.s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+    } else {
+      const double theta = std::acos(d);
+      for (int i = 0; i < 3; i++) omega[i] = theta / (2 * std::sqrt(1 - d * d)) * dR[i];
+      const double theta2 = theta * theta, a = S.s * std::sin(theta), b = S.s * std::cos(theta), c = theta2 + sigma * sigma;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+    }
+  }
+  const double O[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+  double W[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double o2 = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+      W[3 * i + j] = A * O[3 * i + j] + B * o2 + C * (i == j ? 1.0 : 0.0);
+    }
+  // upsilon = W^-1 t
+  const double c00 = W[4] * W[8] - W[5] * W[7], c01 = W[5] * W[6] - W[3] * W[8], c02 = W[3] * W[7] - W[4] * W[6];
+  const double det = W[0] * c00 + W[1] * c01 + W[2] * c02;
+  const double inv[9] = {c00, W[2] * W[7] - W[1] * W[8], W[1] * W[5] - W[2] * W[4],
+                         c01, W[0] * W[8] - W[2] * W[6], W[2] * W[3] - W[0] * W[5],
+                         c02, W[1] * W[6] - W[0] * W[7], W[0] * W[4] - W[1] * W[3]};
+  for (int i = 0; i < 3; i++) res[i] = omega[i];
+  for (int i = 0; i < 3; i++) res[3 + i] = (inv[3 * i] * S.t[0] + inv[3 * i + 1] * S.t[1] + inv[3 * i + 2] * S.t[2]) / det;
+  res[6] = sigma;
+}
+
+// EdgeSim3::computeError: log(C * v1 * v2^-1), v1 = vertex 0 (i), v2 = vertex 1 (j)
+static void pg_edge_error(const Sim3d& C, const Sim3d& Si, const Sim3d& Sj, double e[7]) {
+  Sim3d Sji, t1, t2;
+  sim3_inv(Sj, Sji);
+  sim3_mul(C, Si, t1);
+  sim3_mul(t1, Sji, t2);
+  sim3_log(t2, e);
+}
+
+// test hook: g2o::Sim3(update) and Sim3::log of it (pins sim3_exp / sim3_log against scipy's expm in tests/)
+void orc_sim3_exp_log(const double* u, double* S8, double* log7) {
+  Sim3d S;
+  sim3_exp(u, S);
+  std::memcpy(S8, S.q, 32); std::memcpy(S8 + 4, S.t, 24); S8[7] = S.s;
+  sim3_log(S, log7);
+}
+
+int orc_pose_graph_optimize(double* Sio, const uint8_t* fixed, int n, const int32_t* ev, const double* emeas, int E, int fix_scale,
+                            int iterations, double* stats /*[6 + 64]: iterations, trials, chi2_initial, chi2_final, lambda_final, stop, chi2_per_iter[32], trials_per_iter[32]*/) {
+  std::vector<Sim3d> S(n);
+  for (int v = 0; v < n; v++) { std::memcpy(S[v].q, Sio + 8 * v, 32); std::memcpy(S[v].t, Sio + 8 * v + 4, 24); S[v].s = Sio[8 * v + 7]; }
+  std::vector<Sim3d> C(E);
+  for (int k = 0; k < E; k++) { std::memcpy(C[k].q, emeas + 8 * k, 32); std::memcpy(C[k].t, emeas + 8 * k + 4, 24); C[k].s = emeas[8 * k + 7]; }
+  std::vector<int> idx(n, -1);
+  int m = 0;
+  for (int v = 0; v < n; v++) if (!fixed[v]) idx[v] = m++;
+  const int dim = 7 * m;
+  auto chi_all = [&]() { double chi = 0; for (int k = 0; k < E; k++) { double e[7]; pg_edge_error(C[k], S[ev[2 * k]], S[ev[2 * k + 1]], e); for (int a = 0; a < 7; a++) chi += e[a] * e[a]; } return chi; };
+  auto oplus = [&](Sim3d& X, const double* u) {
+    double uu[7]; for (int a = 0; a < 7; a++) uu[a] = u[a];
+    if (fix_scale) uu[6] = 0;
+    Sim3d Ex, Sn; sim3_exp(uu, Ex); sim3_mul(Ex, X, Sn); X = Sn;
+  };
+  double lambda = 1e-16, ni = 2;   // setUserLambdaInit(1e-16)
+  int nBad = 0, it_done = 0, trials = 0, stop = 0;
+  double chi_last = 0, chi_init = 0;
+  std::vector<double> H((size_t)dim * dim), Hl, b(dim), x(dim);
+  for (int it = 0; it < iterations; it++) {
+    double currentChi = chi_all(), tempChi = currentChi;
+    const double iniChi = currentChi;
+    if (it == 0) chi_init = currentChi;
+    std::fill(H.begin(), H.end(), 0.0); std::fill(b.begin(), b.end(), 0.0);
+    for (int k = 0; k < E; k++) {   // linearizeOplus (numeric) + constructQuadraticForm
+      const int vi = ev[2 * k], vj = ev[2 * k + 1];
+      double e[7], J[2][49];
+      pg_edge_error(C[k], S[vi], S[vj], e);
+      for (int side = 0; side < 2; side++) {
+        const int v = side ? vj : vi;
+        if (fixed[v]) continue;
+        for (int d = 0; d < 7; d++) {
+          double u[7] = {0, 0, 0, 0, 0, 0, 0}, e1[7], e2[7];
+          Sim3d bak = S[v];
+          u[d] = 1e-9; oplus(S[v], u); pg_edge_error(C[k], S[vi], S[vj], e1); S[v] = bak;
+          u[d] = -1e-9; oplus(S[v], u); pg_edge_error(C[k], S[vi], S[vj], e2); S[v] = bak;
+          for (int a = 0; a < 7; a++) J[side][7 * a + d] = (1.0 / (2 * 1e-9)) * (e1[a] - e2[a]);
+        }
+      }
+      for (int sa = 0; sa < 2; sa++) {
+        const int va = sa ? vj : vi;
+        if (fixed[va]) continue;
+        const int ia = 7 * idx[va];
+        for (int r = 0; r < 7; r++) { double g = 0; for (int a = 0; a < 7; a++) g += J[sa][7 * a + r] * (-e[a]); b[ia + r] += g; }
+        for (int sb = 0; sb < 2; sb++) {
+          const int vb = sb ? vj : vi;
+          if (fixed[vb]) continue;
+          const int ib = 7 * idx[vb];
+          for (int r = 0; r < 7; r++)
+            for (int c = 0; c < 7; c++) { double hsum = 0; for (int a = 0; a < 7; a++) hsum += J[sa][7 * a + r] * J[sb][7 * a + c]; H[(size_t)(ia + r) * dim + ib + c] += hsum; }
+        }
+      }
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      std::vector<Sim3d> bak = S;   // push()
+      Hl = H;
+      for (int r = 0; r < dim; r++) Hl[(size_t)r * dim + r] += lambda;
+      bool ok = true;   // dense Cholesky + solve
+      for (int j = 0; j < dim && ok; j++) {
+        double dj = Hl[(size_t)j * dim + j];
+        for (int k = 0; k < j; k++) dj -= Hl[(size_t)j * dim + k] * Hl[(size_t)j * dim + k];
+        if (!(dj > 0)) { ok = false; break; }
+        dj = std::sqrt(dj);
+        Hl[(size_t)j * dim + j] = dj;
+        for (int r = j + 1; r < dim; r++) {
+          double v = Hl[(size_t)r * dim + j];
+          for (int k = 0; k < j; k++) v -= Hl[(size_t)r * dim + k] * Hl[(size_t)j * dim + k];
+          Hl[(size_t)r * dim + j] = v / dj;
+        }
+      }
+      if (ok) {
+        for (int r = 0; r < dim; r++) { double v = b[r]; for (int k = 0; k < r; k++) v -= Hl[(size_t)r * dim + k] * x[k]; x[r] = v / Hl[(size_t)r * dim + r]; }
+        for (int r = dim - 1; r >= 0; r--) { double v = x[r]; for (int k = r + 1; k < dim; k++) v -= Hl[(size_t)k * dim + r] * x[k]; x[r] = v / Hl[(size_t)r * dim + r]; }
+        for (int v = 0; v < n; v++) if (!fixed[v]) oplus(S[v], &x[7 * idx[v]]);
+      }
+      tempChi = ok ? chi_all() : std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = 0;
+      if (ok) for (int r = 0; r < dim; r++) scale += x[r] * (lambda * x[r] + b[r]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni; ni *= 2;
+        S = bak;   // pop()
+      }
+      qmax++; trials++;
+    } while (rho < 0 && qmax < 10);
+    if (stats && it < 32) { stats[6 + it] = currentChi; stats[38 + it] = qmax; }
+    it_done++;
+    chi_last = currentChi;
+    if (qmax == 10 || rho == 0) { stop = 1; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { stop = 2; break; }
+  }
+  for (int v = 0; v < n; v++) { std::memcpy(Sio + 8 * v, S[v].q, 32); std::memcpy(Sio + 8 * v + 4, S[v].t, 24); Sio[8 * v + 7] = S[v].s; }
+  if (stats) { stats[0] = it_done; stats[1] = trials; stats[2] = chi_init; stats[3] = chi_last; stats[4] = lambda; stats[5] = stop; }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Sim3Solver (reference src/Sim3Solver.cc): ComputeSim3 (Horn 1987, :294-385) for a batch of RANSAC hypotheses, each
 // followed by CheckInliers (:387-408) with Project (:421-435) / Pinhole::project.  The minimal sets are INPUT
 // (`triples`: the reference draws them with DUtils::Random, :171-181).  Arithmetic types follow the reference: points,

@@ -150,6 +150,13 @@ int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const dou
                       const double* obs2, const double* w1, const double* w2, int N, const double* K1, const double* K2,
                       double th2, uint8_t* inlier);
 
+/* Optimizer::OptimizeEssentialGraph numerics (Optimizer.cc:1389-1652): Sim3 pose graph, EdgeSim3 with g2o's numeric
+   Jacobians, LM with lambda_init 1e-16.  S[n][8] = (q_xyzw, t, s) Siw in/out; ev[E][2] = (vertex 0 = i, vertex 1 = j);
+   emeas[E][8] = Sji; stats[70] = iterations, trials, chi2_initial, chi2_final, lambda_final, stop_reason, chi2_per_iter[32], trials_per_iter[32] */
+void orc_sim3_exp_log(const double* u, double* S8, double* log7);
+int orc_pose_graph_optimize(double* S, const uint8_t* fixed, int n, const int32_t* ev, const double* emeas, int E, int fix_scale,
+                            int iterations, double* stats);
+
 /* Sim3Solver::ComputeSim3 + CheckInliers (src/Sim3Solver.cc:294-408) for H given minimal sets; T12 = [s, R row-major (9), t (3)] */
 void orc_sim3_hypotheses(const float* P1c, const float* P2c, const float* max_err1, const float* max_err2, int N, const float* K1,
                          const float* K2, const int32_t* triples, int H, int fix_scale, float* T12, int32_t* n_inliers,

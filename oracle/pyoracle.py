@@ -456,3 +456,25 @@ def sim3_hypotheses(P1c, P2c, max_err1, max_err2, K1, K2, triples, fix_scale=Fal
     T = np.zeros((H, 13), np.float32); nin = np.zeros(H, np.int32); mask = np.zeros((H, N), np.uint8)
     L.orc_sim3_hypotheses(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), N, _p(a[4]), _p(a[5]), _p(tr), H, int(fix_scale), _p(T), _p(nin), _p(mask))
     return T, nin, mask
+
+
+def sim3_exp_log(u):
+    L = lib()
+    L.orc_sim3_exp_log.restype = None
+    L.orc_sim3_exp_log.argtypes = [C.c_void_p] * 3
+    u = np.ascontiguousarray(u, np.float64); S = np.zeros(8); lg = np.zeros(7)
+    L.orc_sim3_exp_log(_p(u), _p(S), _p(lg))
+    return S, lg
+
+
+def pose_graph_optimize(S, fixed, edges_v, edges_meas, fix_scale=False, iterations=20):
+    """OptimizeEssentialGraph numerics.  S[n,8] (q_xyzw,t,s); edges_v[E,2]; edges_meas[E,8].  Returns (S_opt, stats[6])."""
+    L = lib()
+    vp, i32 = C.c_void_p, C.c_int32
+    L.orc_pose_graph_optimize.restype = i32
+    L.orc_pose_graph_optimize.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    So = np.array(S, np.float64, copy=True)
+    fx = np.ascontiguousarray(fixed, np.uint8); ev = np.ascontiguousarray(edges_v, np.int32); em = np.ascontiguousarray(edges_meas, np.float64)
+    st = np.zeros(70)
+    L.orc_pose_graph_optimize(_p(So), _p(fx), len(So), _p(ev), _p(em), len(ev), int(fix_scale), int(iterations), _p(st))
+    return So, st

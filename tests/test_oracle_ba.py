@@ -140,3 +140,38 @@ def test_sim3_hypotheses_oracle_vs_closed_form(oracle):
         clear = (np.abs(e1 - sc["max_err1"]) > 1e-2 * sc["max_err1"]) & (np.abs(e2 - sc["max_err2"]) > 1e-2 * sc["max_err2"])
         assert np.array_equal(mask[h].astype(bool)[clear], ref[clear]), h
         assert nin[h] == mask[h].sum()
+
+
+def test_sim3_exp_log_vs_expm(oracle):
+    """g2o::Sim3(update) / Sim3::log restatement vs scipy.linalg.expm of the 4x4 generator [[sigma I + [w]x, v], [0, 0]]."""
+    from scipy.linalg import expm
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(0)
+    for k in range(200):
+        u = np.concatenate([rng.normal(0, 0.7, 3), rng.normal(0, 2.0, 3), [rng.normal(0, 0.3)]])
+        if k % 5 == 0: u[6] = 0.0                      # |sigma| < eps branch
+        if k % 7 == 0: u[:3] *= 1e-7                   # tiny rotation branch
+        S, lg = oracle.sim3_exp_log(u)
+        G = np.zeros((4, 4))
+        w = u[:3]
+        G[:3, :3] = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) + u[6] * np.eye(3)
+        G[:3, 3] = u[3:6]
+        M = expm(G)
+        sR = S[7] * Rot.from_quat(S[:4]).as_matrix()
+        assert np.allclose(sR, M[:3, :3], atol=1e-9) and np.allclose(S[4:7], M[:3, 3], atol=1e-9)
+        assert np.allclose(lg, u, atol=1e-7), (k, lg - u)
+
+
+def test_pose_graph_oracle_recovers_consistent_graph(oracle):
+    """Essential-graph LM restatement: measurements consistent with the ground truth, vertex 0 fixed -> chi2 -> 0 and the
+    estimates return to the ground truth; at the ground truth nothing moves; fix_scale keeps every scale."""
+    from dvm_slam_amd import synth
+    pg = synth.pose_graph(n=40)
+    S, st = oracle.pose_graph_optimize(pg["S0"], pg["fixed"], pg["edges_v"], pg["edges_meas"], iterations=20)
+    assert st[2] > 1.0 and st[3] < 1e-10 * st[2], st
+    assert np.allclose(S[:, 4:], pg["S_gt"][:, 4:], atol=1e-5)
+    assert np.allclose(np.abs((S[:, :4] * pg["S_gt"][:, :4]).sum(1)), 1.0, atol=1e-9)
+    S2, st2 = oracle.pose_graph_optimize(pg["S_gt"], pg["fixed"], pg["edges_v"], pg["edges_meas"], iterations=20)
+    assert st2[2] < 1e-20 and np.allclose(S2, pg["S_gt"], atol=1e-9)
+    S3, st3 = oracle.pose_graph_optimize(pg["S0"], pg["fixed"], pg["edges_v"], pg["edges_meas"], fix_scale=True, iterations=20)
+    assert np.allclose(S3[:, 7], pg["S0"][:, 7], atol=1e-12) and st3[3] < st3[2]
