@@ -11,9 +11,10 @@
 //
 // The algorithm is written once over an accessor `A` with
 //     uint32_t key(int i);  uint32_t val(int i);  void set(int i, uint32_t k, uint32_t v);
-// Two accessors exist: KV (plain arrays: host test, LDS fallback) and, in octree_kernel.hip, LaneKV
-// (elements live in the lanes of one wavefront and are addressed with v_readlane / v_writelane, so
-// the whole sort is scalar-unit control flow without any LDS round trip).
+// (KV: plain arrays, used by the host check; KVLds in octree_kernel.hip: LDS-typed pointers for the rare heapsort
+// branch).  Three forms of the partition phase: kv_introsort_loop (the serial text of libstdc++), 
+// kv_introsort_loop_ranked (the same result stated by ranks -- what can run in parallel), and the wave-parallel
+// implementation of the ranked form in octree_kernel.hip (wave_introsort_loop, ballots).
 // key ordering: a < b  <=>  key(a) < key(b)  (caller packs (size, UL.x) lexicographically in 32 bits).
 #pragma once
 #include <stdint.h>

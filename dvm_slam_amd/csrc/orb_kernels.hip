@@ -903,9 +903,6 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float& cs, float& sn
   sn = (float)si;
 }
 
-// One wave per keypoint (4 keypoints per workgroup).  Phase 1: intensity-centroid moments over the
-// 749-px disc of the UN-blurred level (int32, exact, order-free), fastAtan2.  Phase 2: 256 BRIEF
-// tests on the blurred level, pair p = 64*i + lane, packed by 4 wave ballots (bit p%8 of byte p/8).
 // wave64 integer sum: 4 DPP steps inside each row of 16 lanes, then 4 v_readlane + scalar adds (wave-uniform result)
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
@@ -916,7 +913,9 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
          __builtin_amdgcn_readlane(v, 48);
 }
 
-// One wave per keypoint.  The kernel used to be bound by the texture path (20 byte-gather instructions per wave, every
+// One wave per keypoint (4 keypoints per workgroup).  Phase 1: intensity-centroid moments over the 749-px disc of the
+// UN-blurred level (int32, exact, order-free), fastAtan2.  Phase 2: 256 BRIEF tests on the blurred level, pair
+// p = 64*i + lane, packed by 4 wave ballots (bit p%8 of byte p/8).  The kernel used to be bound by the texture path (20 byte-gather instructions per wave, every
 // lane on its own cache line); now every memory instruction of a wave covers whole row segments:
 //   IC_Angle: the 31 x 31 patch is read as 31 rows x 8 UNALIGNED dwords (4 instructions); the moments are
 //             v_dot4_u32_u8 against the disc weights:  m10 = sum (u+16) I - 16 sum I,  m01 = sum v I  (exact integers)
