@@ -412,7 +412,7 @@ struct FastLds {
 // compile-time pitches the kernel is instantiated for (0 = dynamic fallback)
 __host__ __device__ inline int fast_pick_pitch(int max_rw) {
   const int need = (max_rw + 3 + 3) & ~3;
-  return need <= 56 ? 56 : (need <= 64 ? 64 : need);
+  return need <= 64 ? 64 : need;   // 64: rows are 16-byte aligned in LDS -> the tile is loaded with dwordx4 / ds_write_b128
 }
 __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
   FastLds l;
@@ -466,7 +466,20 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   const uint32_t* g32 = reinterpret_cast<const uint32_t*>(pyr + row0 + (xg - sh));  // stride is a multiple of 64
   uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
   const int pitch4 = kTilePitch >> 2;
-  {
+  if (PITCH == 64) {
+    // 16 bytes per thread: an (unaligned) dwordx4 from the pyramid row, one ds_write_b128; a row is at most 4 such
+    // items and the last one may run past the ROI (never past the 64-byte LDS row; the pyramid buffer has slack)
+    const int q = (dwr + 3) >> 2;
+    int y = (int)(((float)tid + 0.5f) * (1.0f / (float)q)), x = tid - y * q;
+    const int dy = NT / q, dx = NT - dy * q;
+    while (y < rh) {
+      uint4 v;
+      __builtin_memcpy(&v, g32 + (int64_t)y * (L.stride >> 2) + 4 * x, 16);
+      *reinterpret_cast<uint4*>(t32 + y * 16 + 4 * x) = v;
+      x += dx; y += dy;
+      if (x >= q) { x -= q; y++; }
+    }
+  } else {
     int y = (int)(((float)tid + 0.5f) * (1.0f / (float)dwr)), x = tid - y * dwr;   // exact for these small ints
     const int dy = NT / dwr, dx = NT - dy * dwr;
     while (y < rh) {
@@ -1050,8 +1063,7 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
                        d_cand, d_cell_count, max_rw, max_rh, batch, cell_first, cell_num);                                 \
   } while (0)
   // (one wave per cell was measured too: occupancy-bound, 0.76 ms vs 0.68 ms for two)
-  if (lay.tile_pitch == 56) { if (small) DVM_FAST_LAUNCH(56, 2); else DVM_FAST_LAUNCH(56, 4); }
-  else if (lay.tile_pitch == 64) { if (small) DVM_FAST_LAUNCH(64, 2); else DVM_FAST_LAUNCH(64, 4); }
+  if (lay.tile_pitch == 64) { if (small) DVM_FAST_LAUNCH(64, 2); else DVM_FAST_LAUNCH(64, 4); }
   else DVM_FAST_LAUNCH(0, 4);
 #undef DVM_FAST_LAUNCH
 }

@@ -443,7 +443,7 @@ int OrbPipeline::configure(int rows, int cols) {
   PD.sel_frame_slots = sel_off;
   PD.kp_cap = sel_off;
   const size_t B = (size_t)max_batch;
-  DVM_HIP(hipMalloc(&d_pyr, B * PD.pyr_frame_bytes));
+  DVM_HIP(hipMalloc(&d_pyr, B * PD.pyr_frame_bytes + 256));   // + slack: 16-byte tile loads may run past the last ROI
   DVM_HIP(hipMalloc(&d_blur, B * PD.blur_frame_bytes));
   DVM_HIP(hipMalloc(&d_tabs, std::max<size_t>(tabs.size(), 1) * 4));
   DVM_HIP(hipMalloc(&d_cells, std::max<size_t>(cells.size(), 1) * sizeof(CellDesc)));
