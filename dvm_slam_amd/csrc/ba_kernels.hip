@@ -567,15 +567,27 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = (double4_t){0, 0, 0, 0};
   const int lr = lane & 15, lk = lane >> 4;
-  for (int c = c0; c < c1; c++) {
+  // software pipeline: the two strips of contributor c+1 travel global -> registers while contributor c is on the MFMAs
+  // thread t owns elements (row 4k + t / 64, column t % 64), k = 0..15: every load instruction covers 4 full rows
+  const int pr = tid >> 6, pc = tid & 63;
+  double ra[16], rb[16];
+  auto fetch = [&](int c) {
     const int k0 = contrib[c] * NB;
-    if (c > c0) __syncthreads();
-    for (int i = tid; i < NB * NB; i += 256) {
-      int r = i / NB, cc = i % NB;
-      Ai[r][cc] = (r < iw) ? S[(size_t)(i0 + r) * ldS + k0 + cc] : 0.0;
-      Aj[r][cc] = (r < jw) ? S[(size_t)(j0 + r) * ldS + k0 + cc] : 0.0;
+    const double* ga = S + (size_t)(i0 + pr) * ldS + k0 + pc;
+    const double* gb = S + (size_t)(j0 + pr) * ldS + k0 + pc;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      ra[k] = (4 * k + pr < iw) ? ga[(size_t)4 * k * ldS] : 0.0;
+      rb[k] = (4 * k + pr < jw) ? gb[(size_t)4 * k * ldS] : 0.0;
     }
+  };
+  fetch(c0);
+  for (int c = c0; c < c1; c++) {
+    if (c > c0) __syncthreads();          // the previous contributor's MFMAs have read Ai / Aj
+#pragma unroll
+    for (int k = 0; k < 16; k++) { Ai[4 * k + pr][pc] = ra[k]; Aj[4 * k + pr][pc] = rb[k]; }
     __syncthreads();
+    if (c + 1 < c1) fetch(c + 1);
     if (idle) continue;
 #pragma unroll 4
     for (int k = 0; k < NB; k += 4) {
