@@ -405,6 +405,7 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = (lane < 16 && c <= lane) ? Bm[(o + lane) * LP + o + c] : 0.0;
       bool bad = false;
+      double rinv[16];   // 1 / L_jj (wave-uniform): v_rsq_f64 + two Newton steps instead of a sqrt and 16 + 16 divisions
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         double s0 = a[j], s1 = 0.0;
@@ -416,8 +417,14 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
         const double s = s0 + s1;
         const double d = bcast_lane(s, j);
         if (!(d > 0.0)) bad = true;
-        const double sq = sqrt(d > 0.0 ? d : 1.0);
-        a[j] = (lane == j) ? sq : (lane > j ? s / sq : 0.0);
+        const double dd = d > 0.0 ? d : 1.0;
+        double y = __builtin_amdgcn_rsq(dd);
+        y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+        y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+        double sq = dd * y;
+        sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);   // sqrt(dd) to the last bit or one ulp
+        rinv[j] = y;
+        a[j] = (lane == j) ? sq : (lane > j ? s * y : 0.0);
       }
       if (bad && lane == 0) *fail = 1;
       double y[16];  // column `lane` of the 16x16 inverse
@@ -429,7 +436,7 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
           const double l = bcast_lane(a[t], i);
           if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
         }
-        y[i] = (s0 + s1) / bcast_lane(a[i], i);
+        y[i] = (s0 + s1) * rinv[i];
       }
       if (lane < 16) {
 #pragma unroll
