@@ -401,8 +401,8 @@ __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int 
 //      adjacent compass pixels), 4 pixels per thread on packed 16-bit lanes.  Each wave owns a contiguous
 //      row-major quarter of the items and appends its survivors, in order, to its own list region;
 //      the four regions concatenated are the row-major survivor list (indexed virtually, never copied)
-//   B. survivors only: full FAST strength -> score map + per-survivor score
-//   C. survivors with a score: 3x3 strict-maximum test, threshold bits, ordered compaction
+//   B. per wave, its own survivors: full FAST strength -> score map; corners (score > 0) compacted in place
+//   C. per wave, its own corners: 3x3 strict-maximum test, threshold bits, ordered compaction (one prefix over waves)
 // LDS is dynamic and sized for the largest cell of the current image size (FastLds), so the BASELINE
 // config needs ~13 KB per workgroup and 8 workgroups (32 waves) stay resident per CU.
 struct FastLds {
@@ -421,7 +421,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
   const int ew = max_rw - 6 > 0 ? max_rw - 6 : 1, eh = max_rh - 6 > 0 ? max_rh - 6 : 1;
   l.score_bytes = ((((ew + 2 + 3) & ~3) * (eh + 2)) + 15) & ~15;
   l.plist_bytes = (((ew + 9) * eh + 16) * 2 + 15) & ~15;   // 4 wave regions of ceil(items/4)*4 entries
-  l.pscore_bytes = (ew * eh + 15) & ~15;
+  l.pscore_bytes = (((ew + 9) * eh + 16) + 15) & ~15;      // corner scores, same offsets as the lists
   return l;
 }
 // zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
@@ -442,7 +442,6 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   __shared__ int s_cnt_ini;
   constexpr int NT = 64 * NW;   // NW = 2 for small cells: fewer half-empty rounds and half the per-wave fixed cost
   __shared__ int s_tot[NW];
-  __shared__ int s_wave_tot[33][NW];
 
   int cell_id, f;
   if (!xcd_frame_map(cell_num, batch, cell_id, f)) return;
@@ -566,44 +565,43 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
       if (cc >= ncol) { cc -= ncol; ey++; }
     }
   }
-  if (lane == 0) s_tot[wave] = wcount;
-  __syncthreads();
-  // virtual concatenation of the four wave lists = row-major survivor list
-  const int p1 = s_tot[0], p2 = NW > 1 ? p1 + s_tot[NW > 1 ? 1 : 0] : p1, p3 = NW > 2 ? p2 + s_tot[NW > 2 ? 2 : 0] : p2;
-  const int npass = NW > 2 ? p3 + s_tot[NW > 2 ? 3 : 0] : p2;
-  auto entry = [&](int k) -> int {
-    if (NW == 1) return plist[k];
-    if (NW == 2) return plist[(k >= p1) ? Q * 4 + k - p1 : k];
-    const int w = (k >= p1) + (k >= p2) + (k >= p3);
-    const int base = (k >= p3) ? p3 : ((k >= p2) ? p2 : ((k >= p1) ? p1 : 0));
-    return plist[w * Q * 4 + k - base];
-  };
-  // ---- B. full strength for the survivors
-  for (int k = tid; k < npass; k += NT) {
-    const int pe = entry(k);
-    const int ey = pe >> 7, ex = pe & 127;
-    const int m = fast_strength<PITCH>(&T[(ey + 3) * kTilePitch + ex + 3], kTilePitch);
-    const int sc = m > tlow ? m - 1 : 0;
-    pscore[k] = (uint8_t)sc;
-    if (sc) score[(ey + 1) * sp + ex + 1] = (uint8_t)sc;
+  // ---- B. per wave, no barrier: full strength of the wave's OWN survivors.  Corners (score > 0) are compacted in
+  // place at the head of the wave's list -- the write position never passes the read position -- with their scores
+  // at the same offsets of `pscore`; the four corner lists concatenated are still row-major.
+  uint8_t* myscore = pscore + wave * Q * 4;
+  int ncorner = 0;   // wave-uniform
+  for (int base = 0; base < wcount; base += 64) {
+    const int k = base + lane;
+    int pe = 0, sc = 0;
+    if (k < wcount) {
+      pe = mylist[k];
+      const int ey = pe >> 7, ex = pe & 127;
+      const int m = fast_strength<PITCH>(&T[(ey + 3) * kTilePitch + ex + 3], kTilePitch);
+      sc = m > tlow ? m - 1 : 0;
+      if (sc) score[(ey + 1) * sp + ex + 1] = (uint8_t)sc;
+    }
+    const unsigned long long bc = __ballot(sc > 0);
+    if (sc > 0) {
+      const int pos = ncorner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u));
+      mylist[pos] = (uint16_t)pe;
+      myscore[pos] = (uint8_t)sc;
+    }
+    ncorner += __popcll(bc);
   }
-  __syncthreads();
-  // ---- C. strict local maxima among the survivors; bit0 = passes iniTh, bit1 = passes minTh
-  const int rounds = (npass + NT - 1) / NT;
-  uint32_t flags_lo = 0, flags_hi = 0;  // 2 bits per round, up to 32 rounds
+  __syncthreads();   // the score map is complete
+  // ---- C. per wave: strict local maxima among its corners; bit0 = passes iniTh, bit1 = passes minTh
+  const int rounds = (ncorner + 63) >> 6;   // <= 32: a wave owns at most 2048 pixels
+  uint32_t flags_lo = 0, flags_hi = 0;      // 2 bits per round
   int cnt_ini = 0;
   for (int r = 0; r < rounds; r++) {
-    const int k = r * NT + tid;
+    const int k = r * 64 + lane;
     int fl = 0;
-    if (k < npass) {
-      const int sv = pscore[k];
-      if (sv > 0) {
-        const int pe = entry(k);
-        const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
-        const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
-                           max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
-        if (sv > mx) fl = (sv >= PD.ini_th ? 1 : 0) | (sv >= PD.min_th ? 2 : 0);
-      }
+    if (k < ncorner) {
+      const int sv = myscore[k], pe = mylist[k];
+      const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
+      const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
+                         max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
+      if (sv > mx) fl = (sv >= PD.ini_th ? 1 : 0) | (sv >= PD.min_th ? 2 : 0);
     }
     cnt_ini += fl & 1;
     if (r < 16) flags_lo |= (uint32_t)fl << (2 * r);
@@ -612,33 +610,32 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   if (cnt_ini) atomicAdd(&s_cnt_ini, cnt_ini);
   __syncthreads();
   const int bit = (s_cnt_ini > 0) ? 1 : 2;  // first call non-empty -> keep it, else the retry's result
-
-  // ordered compaction: survivor index k = r*NT + tid is row-major, so emit in increasing k
+  // ordered compaction: wave lists in wave order, inside a list in list order = row-major
+  int kept = 0;
   for (int r = 0; r < rounds; r++) {
     const int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
-    const unsigned long long m = __ballot((fl & bit) != 0);
-    if (lane == 0) s_wave_tot[r][wave] = __popcll(m);
+    kept += __popcll(__ballot((fl & bit) != 0));
   }
+  if (lane == 0) s_tot[wave] = kept;
   __syncthreads();
-  int base = 0;
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) { if (w < wave) base += s_tot[w]; total += s_tot[w]; }
   uint32_t* out = cand + (int64_t)f * PD.cand_frame_slots + c.cand_base;
   for (int r = 0; r < rounds; r++) {
     const int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
     const bool keep = (fl & bit) != 0;
     const unsigned long long m = __ballot(keep);
-    int before = 0;
-    for (int w = 0; w < wave; w++) before += s_wave_tot[r][w];
-    const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     if (keep && pos < c.cand_cap) {
-      const int k = r * NT + tid;
-      const int pe = entry(k);
+      const int k = r * 64 + lane;
+      const int pe = mylist[k];
       // border-relative level coordinates: (roi origin + 3 + e) - 16
-      out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), pscore[k]);
+      out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), myscore[k]);
     }
-#pragma unroll
-    for (int w = 0; w < NW; w++) base += s_wave_tot[r][w];
+    base += __popcll(m);
   }
-  if (tid == 0) *my_count = min(base, c.cand_cap);
+  if (tid == 0) *my_count = min(total, c.cand_cap);
 }
 
 // Concatenate the per-cell lists of one frame in cell-table order (level-major, then the
