@@ -427,11 +427,11 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
 // zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
 #define DVM_PERM2(a, b, i0, i1) __builtin_amdgcn_perm((a), (b), 0x0c000c00u | (uint32_t)(i0) | ((uint32_t)(i1) << 16))
 
+constexpr int kFastFramesPerWG = 4;   // a workgroup walks the same cell of 4 frames: amortises dispatch + prologue
 template <int PITCH, int NW>
-__global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
-                                                    const CellDesc* __restrict__ cells, PipelineDesc PD,
-                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
-                                                    int max_rw, int max_rh, int batch, int cell_first, int cell_num) {
+__device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int pyr_frame_bytes, const CellDesc& c,
+                                          const PipelineDesc& PD, uint32_t* __restrict__ cand,
+                                          int32_t* __restrict__ cell_count, int max_rw, int max_rh, int cell_id, int f) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
   const int kTilePitch = PITCH ? PITCH : lay.tile_pitch;
@@ -443,10 +443,6 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   constexpr int NT = 64 * NW;   // NW = 2 for small cells: fewer half-empty rounds and half the per-wave fixed cost
   __shared__ int s_tot[NW];
 
-  int cell_id, f;
-  if (!xcd_frame_map(cell_num, batch, cell_id, f)) return;
-  cell_id += cell_first;                 // this launch covers cells [cell_first, cell_first + cell_num)
-  const CellDesc c = cells[cell_id];
   const LevelDesc& L = PD.lv[c.level];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rw = c.rw, rh = c.rh;
@@ -636,6 +632,26 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
     base += __popcll(m);
   }
   if (tid == 0) *my_count = min(total, c.cand_cap);
+}
+
+// Launch geometry: 1-D grid of cell_num * 8 * ceil(batch / 32) workgroups; workgroup b handles cell
+// cell_first + (b >> 3) % cell_num of frames fbase + 8 j (j < 4), fbase = (b >> 3) / cell_num * 32 + (b & 7): the eight
+// frames of an XCD group stay on one XCD (see xcd_frame_map), and the cell descriptor is read once.
+template <int PITCH, int NW>
+__global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
+                                                    const CellDesc* __restrict__ cells, PipelineDesc PD,
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
+                                                    int max_rw, int max_rh, int batch, int cell_first, int cell_num) {
+  const int b = blockIdx.x, i = b >> 3;
+  const int cell_id = cell_first + i % cell_num;
+  const int fbase = (i / cell_num) * (8 * kFastFramesPerWG) + (b & 7);
+  const CellDesc c = cells[cell_id];
+  for (int j = 0; j < kFastFramesPerWG; j++) {
+    const int f = fbase + 8 * j;
+    if (f >= batch) break;
+    if (j) __syncthreads();   // the previous frame's LDS is dead
+    fast_cell<PITCH, NW>(pyr, pyr_frame_bytes, c, PD, cand, cell_count, max_rw, max_rh, cell_id, f);
+  }
 }
 
 // Concatenate the per-cell lists of one frame in cell-table order (level-major, then the
@@ -1047,7 +1063,7 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num) {
   if (cell_num <= 0) return;
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
-  const dim3 grid(xcd_grid(cell_num, batch));
+  const dim3 grid(cell_num * 8 * ((batch + 8 * kFastFramesPerWG - 1) / (8 * kFastFramesPerWG)));
   // two waves per cell while 32 survivor rounds of 128 cover the largest cell, else four
   const bool small = (max_rw - 6) * (max_rh - 6) <= 32 * 128;
   // (beyond the default 48 KB of dynamic LDS the limit is raised on the current device: per device, so per launch)
