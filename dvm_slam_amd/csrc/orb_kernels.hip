@@ -804,8 +804,10 @@ __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, 
   const TileDesc t = tiles[tile_id];
   // the reference skips levels without keypoints (:915-916); a level has keypoints iff it has FAST candidates
   // (the octree keeps >= 1 of n > 0), which is known before the octree runs -> the blur overlaps with it
-  const int32_t* ls = lvl_start + (int64_t)f * (kMaxLevels + 1) + t.level;
-  if (ls[1] == ls[0]) return;
+  if (lvl_start) {   // (null: blur every level -- lets the launch precede FAST; an empty level's blur is simply unused)
+    const int32_t* ls = lvl_start + (int64_t)f * (kMaxLevels + 1) + t.level;
+    if (ls[1] == ls[0]) return;
+  }
   const LevelDesc& L = PD.lv[t.level];
   const int th = min(kBlurTH, L.h - t.y0);
   // raw tile: rows y0-3 .. y0+th+2, bordered columns (16 + x0) .. +71 as 18 aligned dwords per row

@@ -278,8 +278,13 @@ int OrbPipeline::init() {
   DVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   lane_main[0] = stream;
   DVM_HIP(hipStreamCreateWithFlags(&lane_main[1], hipStreamNonBlocking));
-  DVM_HIP(hipStreamCreateWithFlags(&lane_side[0], hipStreamNonBlocking));
-  DVM_HIP(hipStreamCreateWithFlags(&lane_side[1], hipStreamNonBlocking));
+  {  // side streams at the LOWEST priority: their kernels (the blur) only fill what the main chain leaves idle
+    int least = 0, greatest = 0;
+    DVM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    DVM_HIP(hipStreamCreateWithPriority(&lane_side[0], hipStreamNonBlocking, least));
+    DVM_HIP(hipStreamCreateWithPriority(&lane_side[1], hipStreamNonBlocking, least));
+  }
+  if (const char* e = getenv("DVM_BLUR_EARLY")) blur_early = (e[0] == '1');
   DVM_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
   DVM_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
   for (int c = 0; c < kMaxChunks; c++) {
@@ -529,6 +534,15 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     for (int l = 1; l < L; l++) launch_pyr_resize(st, pyr_f0, PD, l, d_tabs, nb);
     if (tiny_levels) launch_pyr_borders(st, pyr_f0, PD, nb);   // else: fused into the level kernels
     prof.end(st);
+    const bool blur_forked = overlap_blur && !host_octree && side != nullptr;
+    if (blur_forked && blur_early) {   // blur needs the pyramid only: low-priority side stream, fills the idle slots of
+      DVM_HIP(hipEventRecord(ev_fork[ck], st));               // FAST's tail, the small scan kernels and the octree
+      DVM_HIP(hipStreamWaitEvent(side, ev_fork[ck], 0));
+      prof.begin(side, "blur");
+      launch_blur(side, pyr_f0, (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, nullptr, nb);
+      prof.end(side);
+      DVM_HIP(hipEventRecord(ev_join[ck], side));
+    }
     prof.begin(st, "fast");
     launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, 0, PD.ncells);
     prof.end(st);
@@ -537,8 +551,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.end(st);
 
     DVM_HIP(hipEventRecord(ev_compact[ck], st));   // this chunk has left the throughput-bound stages
-    const bool blur_forked = overlap_blur && !host_octree && side != nullptr;
-    if (blur_forked) {
+    if (blur_forked && !blur_early) {
       DVM_HIP(hipEventRecord(ev_fork[ck], st));
       DVM_HIP(hipStreamWaitEvent(side, ev_fork[ck], 0));
       prof.begin(side, "blur");

@@ -65,6 +65,7 @@ class OrbPipeline {
   hipEvent_t ev_start = nullptr, ev_compact[kMaxChunks] = {}, ev_fork[kMaxChunks] = {}, ev_join[kMaxChunks] = {}, ev_done = nullptr;
   int chunks = 1;            // DVM_CHUNKS=n; measured on MI355X at batch 256: 1 -> 1.82 ms, 2 -> 1.93 ms, 4 -> 2.11 ms per
                              // step (concurrent queues do not recover the k_octree idle time), so the default is off
+  bool blur_early = true;    // launch the blur right after the pyramid (all levels) instead of after the candidate counts
   bool overlap_blur = true;  // DVM_SERIAL=1 puts the blur back on `stream`
   Profiler prof;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
