@@ -189,8 +189,11 @@ class OrbExtractor:
         kps = np.zeros(self.cap, KP_DTYPE)
         desc = np.zeros((self.cap, 32), np.uint8)
         n, mono = C.c_int(0), C.c_int(0)
-        check(self.L.dvm_orb_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1],
-                                     _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono)))
+        rc = self.L.dvm_orb_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1],
+                                    _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono))
+        if rc == -3 and n.value > self.cap:   # DVM_ERR_CAPACITY: *n holds the size needed (small quotas on wide images)
+            return self.download(0, cap=n.value)
+        check(rc)
         return n.value, kps[:n.value].copy(), desc[:n.value].copy(), mono.value
 
     def extract_batch_host(self, imgs: np.ndarray, lap=(0, 1000)):
@@ -207,11 +210,15 @@ class OrbExtractor:
     def sync(self):
         check(self.L.dvm_orb_sync(self.h))
 
-    def download(self, frame=0):
-        kps = np.zeros(self.cap, KP_DTYPE)
-        desc = np.zeros((self.cap, 32), np.uint8)
+    def download(self, frame=0, cap=None):
+        cap = cap or self.cap
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
         n, mono = C.c_int(0), C.c_int(0)
-        check(self.L.dvm_orb_download(self.h, frame, _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono)))
+        rc = self.L.dvm_orb_download(self.h, frame, _p(kps), _p(desc), cap, C.byref(n), C.byref(mono))
+        if rc == -3 and n.value > cap:
+            return self.download(frame, cap=n.value)
+        check(rc)
         return n.value, kps[:n.value].copy(), desc[:n.value].copy(), mono.value
 
     def result_device(self, frame=0):

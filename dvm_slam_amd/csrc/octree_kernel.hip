@@ -379,15 +379,23 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
   if (tid == 0) *out_n = mo;
 }
 
+// root nodes of a level: nIni = round((maxX - minX) / (maxY - minY)) (ORBextractor.cc:423)
+int octree_root_nodes(const LevelDesc& L) {
+  const int W = L.w - 2 * (kEdge - 3), H = L.h - 2 * (kEdge - 3);
+  return H > 0 ? (int)roundf((float)W / (float)H) : 0;
+}
+// node slots k_octree needs for this pyramid (a level ends with up to max(quota + 2, 4 * nIni) nodes: the first
+// sweep splits every root unconditionally, later sweeps are guarded by the "size + 3 * nToExpand > N" test)
+int octree_required_nodes(const PipelineDesc& PD) {
+  int need = 64;
+  for (int l = 0; l < PD.nlevels; l++) need = std::max(need, std::max(PD.lv[l].quota + 8, 4 * octree_root_nodes(PD.lv[l]) + 4));
+  return (need + 63) / 64 * 64;
+}
+bool octree_fits_device(const PipelineDesc& PD) { return octree_required_nodes(PD) <= kOctMaxNodes; }
+
 void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_start, const PipelineDesc& PD,
                    int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch) {
-  int need = 64;
-  for (int l = 0; l < PD.nlevels; l++) {
-    const int W = PD.lv[l].w - 2 * (kEdge - 3), H = PD.lv[l].h - 2 * (kEdge - 3);
-    const int nIni = H > 0 ? (int)(W / (float)H + 0.5f) : 0;
-    need = std::max(need, std::max(PD.lv[l].quota + 8, 4 * nIni + 4));
-  }
-  int cap = std::min((need + 63) / 64 * 64, kOctMaxNodes);
+  int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
   const size_t bytes = (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2);
   // beyond the default 48 KB of dynamic LDS the limit has to be raised on the CURRENT device (the attribute is per
   // device and the library serves one handle per GPU), so no process-wide "done once" flag

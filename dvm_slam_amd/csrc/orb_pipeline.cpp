@@ -294,7 +294,8 @@ int OrbPipeline::init() {
   }
   if (const char* e = getenv("DVM_CHUNKS")) chunks = std::min(std::max(atoi(e), 1), (int)kMaxChunks);
   if (const char* e = getenv("DVM_SERIAL")) overlap_blur = (e[0] != '1');      // debug / A-B switch only
-  if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree = (e[0] == '1');  // debug / A-B switch only
+  if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree_forced = (e[0] == '1');  // debug / A-B switch only
+  host_octree = host_octree_forced;
   // orientation disc offsets (any order: the moments are exact integer sums)
   int8_t du[kDiscPixels], dv[kDiscPixels];
   int n = 0;
@@ -387,7 +388,9 @@ int OrbPipeline::configure(int rows, int cols) {
     D.patch_size = (int)(31 * scale[l]);  // :700
     D.quota = nfeat[l];
     D.sel_off = sel_off;
-    D.sel_cap = std::max(nfeat[l], 1) + 4;
+    // a level keeps up to max(quota + 2, 4 * nIni) keypoints: the first octree sweep splits every root node before the
+    // node count is compared with the quota (ORBextractor.cc:460-536), which matters for small quotas on wide images
+    D.sel_cap = std::max(std::max(nfeat[l], 1), 4 * std::max(octree_root_nodes(D), 0)) + 4;
     sel_off += D.sel_cap;
     if (l > 0) {
       std::vector<int32_t> xo, xa, yo, yb;
@@ -438,6 +441,15 @@ int OrbPipeline::configure(int rows, int cols) {
   }
   max_cell_rw = max_cell_rh = 8;
   for (const CellDesc& c : cells) { max_cell_rw = std::max<int>(max_cell_rw, c.rw); max_cell_rh = std::max<int>(max_cell_rh, c.rh); }
+  // DistributeOctTree starts from nIni = round((cols - 32) / (rows - 32)) root nodes per level (ORBextractor.cc:423);
+  // for a portrait level nIni = 0 and the reference divides by it: reject such sizes instead of guessing
+  for (int l = 0; l < PD.nlevels; l++)
+    if (PD.lv[l].w > 2 * (kEdge - 3) && PD.lv[l].h > 2 * (kEdge - 3) && octree_root_nodes(PD.lv[l]) < 1) {   // (levels without a FAST area have no candidates)
+      set_error("image too narrow for DistributeOctTree: round((cols-32)/(rows-32)) = 0 at some pyramid level");
+      return DVM_ERR_INVALID;
+    }
+  // quotas beyond the device octree's node capacity (e.g. 3000 features on 2 levels): same algorithm on the host
+  host_octree = host_octree_forced || !octree_fits_device(PD);
   tiny_levels = false;
   for (int l = 0; l < PD.nlevels; l++) tiny_levels |= (PD.lv[l].w < 40 || PD.lv[l].h < 20);
   PD.ncells = (int)cells.size();
@@ -656,7 +668,7 @@ int OrbPipeline::download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, 
   if (rc != DVM_OK) return rc;
   int32_t oct_err = 0;
   DVM_HIP(hipMemcpy(&oct_err, d_err, 4, hipMemcpyDeviceToHost));
-  if (oct_err) { set_error("device octree capacity exceeded (quota > 1528 nodes per level)"); return DVM_ERR_CAPACITY; }
+  if (oct_err) { set_error("device octree: node capacity exceeded (internal: configure() should have chosen the host path)"); return DVM_ERR_CAPACITY; }
   const int N = h_n[frame];
   if (n) *n = N;
   if (mono) *mono = h_mono[frame];

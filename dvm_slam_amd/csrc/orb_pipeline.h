@@ -99,7 +99,8 @@ class OrbPipeline {
   int32_t* d_mono = nullptr;
   int32_t* d_nid = nullptr;          // [batch][cand_frame_slots] octree scratch: node id per candidate
   int32_t* d_err = nullptr;          // device error flag (octree capacity)
-  bool host_octree = false;          // debug switch: run DistributeOctTree on the host instead of k_octree
+  bool host_octree = false;          // DistributeOctTree on the host instead of k_octree: forced (debug) or because a
+  bool host_octree_forced = false;   // level quota exceeds the device kernel's node capacity
   uint8_t* d_stage = nullptr;        // staging for host images
   size_t stage_bytes = 0;
   // pinned host mirrors

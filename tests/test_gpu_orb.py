@@ -156,3 +156,26 @@ def test_other_parameters(capi, oracle):
         _same_kps(k_g, k_o)
         assert np.array_equal(d_g, d_o)
         e.close()
+
+
+def test_soak_regressions(capi, oracle):
+    """Cases found by tools/soak_parity.py: (a) small quotas on wide images -- the first octree sweep splits all
+    nIni = round(W / H) root nodes before the node count is compared with the quota, so a level may keep up to 4 * nIni
+    keypoints (> quota + 2); (b) quotas beyond the device octree's node capacity run DistributeOctTree on the host;
+    (c) portrait sizes with nIni = 0 (the reference divides by zero) are rejected."""
+    from dvm_slam_amd import synth
+    for (h, w, nf, sf, nl, it, mt) in [(326, 895, 100, 1.3, 8, 31, 19), (200, 664, 100, 1.2, 8, 36, 3), (126, 1192, 100, 1.3, 4, 20, 20),
+                                       (410, 766, 3000, 1.3, 2, 33, 24), (480, 640, 3000, 1.3, 2, 19, 17)]:
+        img = synth.small_image(h + w, h, w)
+        e = capi.OrbExtractor(nf, sf, nl, it, mt, max_batch=1)
+        orc = oracle.OrbOracle(nf, sf, nl, it, mt)
+        n_o, k_o, d_o, m_o = orc.extract(img, cap=4 * nf + 256)
+        n_g, k_g, d_g, m_g = e.extract(img)
+        assert (n_g, m_g) == (n_o, m_o), (h, w, nf)
+        _same_kps(k_g, k_o)
+        assert np.array_equal(d_g, d_o)
+        e.close()
+    e = capi.OrbExtractor(max_batch=1)
+    with pytest.raises(capi.DvmError, match="too narrow"):
+        e.extract(synth.small_image(3, 900, 300))
+    e.close()
