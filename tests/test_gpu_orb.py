@@ -179,3 +179,24 @@ def test_soak_regressions(capi, oracle):
     with pytest.raises(capi.DvmError, match="too narrow"):
         e.extract(synth.small_image(3, 900, 300))
     e.close()
+
+
+def test_reconfigure_same_handle(capi, oracle):
+    """One handle, changing image sizes and batch sizes between calls (device buffers are re-planned per size)."""
+    from dvm_slam_amd import synth
+    e = capi.OrbExtractor(max_batch=4)
+    orc = oracle.OrbOracle()
+    for i, ((h, w), b) in enumerate([((480, 640), 1), ((240, 320), 3), ((376, 1241), 4), ((480, 640), 2), ((240, 320), 1)]):
+        imgs = np.stack([synth.small_image(100 * i + j, h, w) for j in range(b)])
+        if b == 1:
+            res = [e.extract(imgs[0])]
+        else:
+            e.extract_batch_host(imgs)
+            res = [e.download(f) for f in range(b)]
+        for f in range(b):
+            n_o, k_o, d_o, m_o = orc.extract(imgs[f])
+            n_g, k_g, d_g, m_g = res[f]
+            assert (n_g, m_g) == (n_o, m_o), (h, w, b, f)
+            _same_kps(k_g, k_o)
+            assert np.array_equal(d_g, d_o)
+    e.close()
