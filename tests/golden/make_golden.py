@@ -55,5 +55,48 @@ def main():
     print("ba", st["trials"], st["chi2"][-1])
 
 
+def more():
+    """Fixtures for the entry points added after the first set (second call so the first files stay byte-identical)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from matcher_scene import make_local_map_scene, make_scene, make_sim3_scene
+    # whole-function matchers
+    sc = make_scene(po, 0, n_last=300, n_cur=340)
+    n, mp = po.search_by_projection_frames(th=15.0, check_ori=True, **sc)
+    sl = make_local_map_scene(po, 1, n_last=300, n_cur=340)
+    n2, mp2 = po.search_by_projection_points(th=3.0, nnratio=0.8, far_points=True, th_far=9.0, **sl)
+    np.savez_compressed(os.path.join(HERE, "matcher_functions.npz"), frames_n=n, frames_mp=mp, points_n=n2, points_mp=mp2,
+                        **{"f_" + k: v for k, v in sc.items()}, **{"p_" + k: v for k, v in sl.items()})
+    print("matchers", n, n2)
+    # distinctive descriptors + vocabulary
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 5, 9, 16, 33, 70]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    desc = base[rng.integers(0, 40, off[-1])].copy()
+    desc[rng.random(desc.shape) < 0.05] ^= 0x24
+    bi, bm = po.distinctive_descriptors(desc, off)
+    voc = synth.vocabulary(k=6, L=3, seed=11)
+    feats = voc["desc"][rng.integers(1, voc["n_nodes"], 200)].copy()
+    feats[rng.random(feats.shape) < 0.04] ^= 0x81
+    r = po.vocab_transform(voc, feats, 2)
+    np.savez_compressed(os.path.join(HERE, "bow_distinctive.npz"), dd_desc=desc, dd_off=off, dd_best=bi, dd_median=bm, feats=feats,
+                        levelsup=2, **{"voc_" + k: np.asarray(v) for k, v in voc.items()}, **{"tr_" + k: v for k, v in r.items()})
+    print("distinctive", list(bi), "bow", len(r["bow_ids"]))
+    # Sim3Solver hypotheses + essential graph
+    s3, _ = make_sim3_scene(5, n=80)
+    tri = np.array([rng.choice(80, 3, replace=False) for _ in range(40)], np.int32)
+    T, nin, mask = po.sim3_hypotheses(triples=tri, **s3)
+    pg = synth.pose_graph(n=24, noise=0.002, seed=3)
+    S, st = po.pose_graph_optimize(pg["S0"], pg["fixed"], pg["edges_v"], pg["edges_meas"], iterations=20)
+    np.savez_compressed(os.path.join(HERE, "sim3_posegraph.npz"), triples=tri, T12=T, n_inliers=nin, mask=mask,
+                        **{"s3_" + k: v for k, v in s3.items()}, pg_S0=pg["S0"], pg_fixed=pg["fixed"], pg_ev=pg["edges_v"],
+                        pg_em=pg["edges_meas"], pg_S=S, pg_stats=st)
+    print("sim3", int(nin.max()), "pose graph chi2", st[2], "->", st[3])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "more":
+        more()
+    else:
+        main()
+        more()

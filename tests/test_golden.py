@@ -78,3 +78,59 @@ def test_hip_reproduces_ba_golden(capi):
     assert np.abs(p - z["poses"]).max() < 1e-6 and np.abs(pts - z["points"]).max() < 1e-6
     assert np.allclose(st["chi2"], z["chi2"], rtol=1e-9)
     ba.close()
+
+
+# ---- second set: whole-function matchers, ComputeDistinctiveDescriptors, DBoW2 transform, Sim3Solver, essential graph
+def _sub(z, prefix):
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def _voc(z):
+    v = _sub(z, "voc_")
+    return dict(n_nodes=int(v["n_nodes"]), child_off=v["child_off"], children=v["children"], desc=v["desc"], weight=v["weight"],
+                word_id=v["word_id"], L=int(v["L"]))
+
+
+def test_oracle_reproduces_second_set(oracle):
+    z = np.load(os.path.join(G, "matcher_functions.npz"))
+    n, mp = oracle.search_by_projection_frames(th=15.0, check_ori=True, **_sub(z, "f_"))
+    assert n == int(z["frames_n"]) and np.array_equal(mp, z["frames_mp"])
+    n, mp = oracle.search_by_projection_points(th=3.0, nnratio=0.8, far_points=True, th_far=9.0, **_sub(z, "p_"))
+    assert n == int(z["points_n"]) and np.array_equal(mp, z["points_mp"])
+    z = np.load(os.path.join(G, "bow_distinctive.npz"))
+    bi, bm = oracle.distinctive_descriptors(z["dd_desc"], z["dd_off"])
+    assert np.array_equal(bi, z["dd_best"]) and np.array_equal(bm, z["dd_median"])
+    r = oracle.vocab_transform(_voc(z), z["feats"], int(z["levelsup"]))
+    for k, v in r.items():
+        assert np.array_equal(v, z["tr_" + k]), k
+    z = np.load(os.path.join(G, "sim3_posegraph.npz"))
+    T, nin, mask = oracle.sim3_hypotheses(triples=z["triples"], **_sub(z, "s3_"))
+    assert np.array_equal(T, z["T12"]) and np.array_equal(nin, z["n_inliers"]) and np.array_equal(mask, z["mask"])
+    S, st = oracle.pose_graph_optimize(z["pg_S0"], z["pg_fixed"], z["pg_ev"], z["pg_em"], iterations=20)
+    assert np.allclose(S, z["pg_S"], atol=1e-12) and np.allclose(st[:6], z["pg_stats"][:6], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_second_set(capi):
+    z = np.load(os.path.join(G, "matcher_functions.npz"))
+    n, mp, _ = capi.search_by_projection_frames(th=15.0, check_ori=True, **_sub(z, "f_"))
+    assert n == int(z["frames_n"]) and np.array_equal(mp, z["frames_mp"])
+    n, mp, _ = capi.search_by_projection_points(th=3.0, nnratio=0.8, far_points=True, th_far=9.0, **_sub(z, "p_"))
+    assert n == int(z["points_n"]) and np.array_equal(mp, z["points_mp"])
+    z = np.load(os.path.join(G, "bow_distinctive.npz"))
+    bi, bm = capi.distinctive_descriptors(z["dd_desc"], z["dd_off"])
+    assert np.array_equal(bi, z["dd_best"]) and np.array_equal(bm, z["dd_median"])
+    voc = _voc(z)
+    v = capi.Vocabulary(voc)
+    w, nd, wt = v.transform(z["feats"], int(z["levelsup"]))
+    assert np.array_equal(w, z["tr_word"]) and np.array_equal(nd, z["tr_node"]) and np.array_equal(wt, z["tr_weight"])
+    v.close()
+    h = capi.vocab_transform_host(voc, z["feats"], int(z["levelsup"]))
+    for k in ("bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+        assert np.array_equal(h[k], z["tr_" + k]), k
+    z = np.load(os.path.join(G, "sim3_posegraph.npz"))
+    T, nin, mask = capi.sim3_hypotheses(triples=z["triples"], **_sub(z, "s3_"))
+    assert np.allclose(T, z["T12"], rtol=1e-5, atol=1e-5) and np.all(np.abs(nin - z["n_inliers"]) <= 1)
+    S, st = capi.pose_graph_optimize(z["pg_S0"], z["pg_fixed"], z["pg_ev"], z["pg_em"], iterations=20)
+    assert abs(st["chi2_per_iter"][0] - z["pg_stats"][6]) <= 5e-5 * z["pg_stats"][6]        # first LM step (see test_gpu_ba)
+    assert st["chi2_final"] <= 1.5 * z["pg_stats"][3] and z["pg_stats"][3] <= 1.5 * st["chi2_final"]
