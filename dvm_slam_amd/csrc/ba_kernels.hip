@@ -1622,12 +1622,15 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
   for (int h = 0; h < V.nlevels; h++) {
     const int nc = V.h_level_off[h + 1] - V.h_level_off[h], ns = V.h_strip_off[h + 1] - V.h_strip_off[h];
     const int nt = V.h_tgt_off[h + 1] - V.h_tgt_off[h];
+    // the root of the elimination tree is the tile of the augmented rhs row: its "factorisation" (one scalar) is never
+    // used -- row n_pad already holds y = L^-1 b once the last camera level is done -- so that level is not launched
+    if (h == V.nlevels - 1 && nc == 1 && ns == 0 && nt == 0) break;
     hipLaunchKernelGGL(k_chol_diag, dim3(nc), dim3(256), 0, s, V.S, V.ldS, n1, V.cols + V.h_level_off[h], d_fail, V.Linv);
     if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
     if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }
   hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.ytmp);
-  for (int h = V.nlevels - 1; h >= 0; h--)
+  for (int h = V.nlevels - 2; h >= 0; h--)   // (level nlevels - 1 is the rhs tile alone: not an unknown)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(V.h_level_off[h + 1] - V.h_level_off[h]), dim3(256), 0, s, V.S, V.ldS, V.n_pad,
                        V.nfree, V.per_tile, V.dof, V.cols + V.h_level_off[h], V.ytmp, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
 }
