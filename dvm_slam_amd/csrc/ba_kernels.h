@@ -51,6 +51,8 @@ struct BaView {
   const int32_t* strips;    // (row tile, column) pairs by level                 (h_strip_off)
   const int32_t* targets;   // (ti, tj, c0, c1) trailing tiles by level          (h_tgt_off)
   const int32_t* contrib;   // contributing columns of each target, ascending
+  const int32_t* nz_tiles;  // (i, j) pairs of the structurally non-zero tiles (n_nz of them): cleared before every trial
+  int32_t n_nz;
   const int32_t* colstrip_off;  // [ntiles+1] device
   const int32_t* colstrips;     // per column: its strip rows
   const int32_t *h_level_off, *h_strip_off, *h_tgt_off;  // HOST arrays [nlevels+1]

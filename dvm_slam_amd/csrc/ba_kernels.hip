@@ -345,6 +345,17 @@ __global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
   }
 }
 
+// clears the structurally non-zero tiles of S (a trial rebuilds them); everything else is never touched and stays zero
+// from the allocation-time memset: 197 of 1 326 tiles = 6 MB instead of 85 MB at 500 keyframes
+__global__ void __launch_bounds__(256) k_zero_tiles(double* __restrict__ S, int ldS, const int32_t* __restrict__ nz) {
+  const int ti = nz[2 * blockIdx.x], tj = nz[2 * blockIdx.x + 1];
+  double* base = S + (size_t)ti * 64 * ldS + tj * 64;
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int r = i >> 5, c2 = i & 31;
+    reinterpret_cast<double2*>(base + (size_t)r * ldS)[c2] = make_double2(0.0, 0.0);
+  }
+}
+
 // identity on the padding rows of the tiled system (rows 60..63 of every tile, cameras beyond nfree in the last tile)
 __global__ void __launch_bounds__(256) k_pad_identity(BaView V) {
   const int r = blockIdx.x * 256 + threadIdx.x;
@@ -1611,7 +1622,7 @@ void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot
 void ba_launch_schur(hipStream_t s, const BaView& V) {
   hipLaunchKernelGGL(k_dinv, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
   if (V.nfree == 0) return;
-  hipMemsetAsync(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double), s);
+  hipLaunchKernelGGL(k_zero_tiles, dim3(V.n_nz), dim3(256), 0, s, V.S, V.ldS, V.nz_tiles);
   hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_pad_identity, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V);
@@ -1651,7 +1662,7 @@ void pg_launch_edge_eval(hipStream_t s, const PgView& G, bool jac, double* d_sca
   hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, G.partial, nb, d_scalars, slot);
 }
 void pg_launch_build(hipStream_t s, const PgView& G, const BaView& T) {
-  hipMemsetAsync(T.S, 0, (size_t)T.ldS * T.ldS * sizeof(double), s);
+  hipLaunchKernelGGL(k_zero_tiles, dim3(T.n_nz), dim3(256), 0, s, T.S, T.ldS, T.nz_tiles);
   hipLaunchKernelGGL(k_pg_blocks, dim3(cdiv(G.nblk, 4)), dim3(256), 0, s, G, T);
   hipLaunchKernelGGL(k_pg_rhs, dim3(cdiv(G.nfree, 256)), dim3(256), 0, s, G, T);
   hipLaunchKernelGGL(k_pad_identity, dim3(cdiv(T.n_pad, 256)), dim3(256), 0, s, T);

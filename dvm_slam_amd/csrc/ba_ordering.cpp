@@ -177,7 +177,9 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
       for (size_t b = 0; b <= a; b++) T[col[k][a]][col[k][b]] = 1;
   }
   size_t nz = 0;
-  for (int i = 0; i < nt; i++) for (int j = 0; j <= i; j++) nz += T[i][j] ? 1 : 0;
+  for (int i = 0; i < nt; i++)
+    for (int j = 0; j <= i; j++)
+      if (T[i][j]) { nz++; S.nz_tiles.push_back(i); S.nz_tiles.push_back(j); }
   S.fill = (double)nz / ((double)nt * (nt + 1) / 2);
   // elimination tree heights: parent(k) = first row of column k
   std::vector<int> height(nt, 0);

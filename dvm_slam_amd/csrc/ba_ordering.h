@@ -36,6 +36,7 @@ struct BaTileSchedule {
   std::vector<int32_t> contrib;        // column k of each contribution, ascending within a target (deterministic sum)
   std::vector<int32_t> colstrip_off;   // [ntiles+1] -> colstrips
   std::vector<int32_t> colstrips;      // per column k: row tiles i > k with L(i,k) != 0 (back substitution)
+  std::vector<int32_t> nz_tiles;       // (i, j), i >= j: every structurally non-zero tile of the factor (what a trial must clear)
   double fill = 1.0;                   // non-zero tiles / all lower tiles
 };
 // T[i][j] (i >= j) = structurally non-zero tile of the matrix in elimination order; the last tile row (rhs) is dense.

@@ -201,6 +201,7 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(std::max(L, V.nfree) + 255) / 256));
   ok(h->dalloc(&h->d_depth, (size_t)E));
+  ok(h->upload(&V.nz_tiles, SC.nz_tiles)); V.n_nz = (int)(SC.nz_tiles.size() / 2);
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
@@ -216,6 +217,7 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(hip_check(hipMemcpy(V.poses, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
   ok(hip_check(hipMemcpy(V.points, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
   ok(hip_check(hipMemset(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double)), "memset"));
+  ok(hip_check(hipMemset(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double)), "memset"));   // once: trials clear only the non-zero tiles
   ok(hip_check(hipMemset(V.e_chi2, 0, (size_t)E * sizeof(double)), "memset"));
   ok(hip_check(hipDeviceSynchronize(), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }

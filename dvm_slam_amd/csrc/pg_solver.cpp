@@ -110,6 +110,7 @@ extern "C" int dvm_pose_graph_optimize(int device, double* S, const uint8_t* fix
   T.nfree = nfree; T.per_tile = kSim3PerTile; T.dof = 7; T.n_pad = 64 * ntv; T.ldS = 64 * nkb; T.nlevels = SC.nlevels;
   T.S = D.alloc<double>((size_t)T.ldS * T.ldS); T.Linv = D.alloc<double>((size_t)nkb * 64 * 64);
   T.ytmp = D.alloc<double>((size_t)T.n_pad + 64); T.xrow = D.alloc<double>((size_t)T.n_pad + 64); T.x = D.alloc<double>(7 * (size_t)nfree + 8);
+  T.nz_tiles = D.upload(SC.nz_tiles); T.n_nz = (int)(SC.nz_tiles.size() / 2);
   T.cols = D.upload(SC.cols); T.strips = D.upload(SC.strips); T.targets = D.upload(SC.targets); T.contrib = D.upload(SC.contrib);
   T.colstrip_off = D.upload(SC.colstrip_off); T.colstrips = D.upload(SC.colstrips);
   T.h_level_off = SC.level_off.data(); T.h_strip_off = SC.strip_off.data(); T.h_tgt_off = SC.tgt_off.data();
@@ -117,6 +118,7 @@ extern "C" int dvm_pose_graph_optimize(int device, double* S, const uint8_t* fix
   int* d_fail = D.alloc<int>(1);
   T.lambda = d_scalars + 7;
   if (D.rc != DVM_OK) return D.rc;
+  DVM_HIP(hipMemset(T.S, 0, (size_t)T.ldS * T.ldS * sizeof(double)));   // once: trials clear only the non-zero tiles
   // estimates: unit quaternions with w >= 0 like g2o::Sim3's constructor (sim3.h:56-60 normalises r)
   std::vector<double> Sn(S, S + 8 * (size_t)n);
   for (int v = 0; v < n; v++) {
