@@ -383,11 +383,12 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
 
 // Diagonal step kb: Cholesky factor L of the 64x64 block AND its inverse, one workgroup (4 waves).
-// The block is processed as 4x4 sub-blocks of 16x16:
-//   A. wave 0: 16x16 Cholesky + inverse of the diagonal sub-block, row-per-lane in registers, column
-//      broadcasts by v_readlane -- the only strictly sequential part (4 x 16 columns instead of 64)
-//   B. panel sub-blocks below:   X_i = A_ib * Linv_bb^T            (v_mfma_f64_16x16x4_f64)
-//   C. trailing sub-blocks:      A_ij -= X_i * X_j^T               (v_mfma_f64_16x16x4_f64)
+// The block is processed as four 16-column panels:
+//   A. wave 0: the panel (diagonal 16x16 sub-block and all rows below it) row-per-lane in registers, column
+//      broadcasts by v_readlane -- the only strictly sequential part (4 x 16 columns instead of 64); the rows below
+//      the diagonal are solved by the same instruction stream
+//   C. trailing sub-blocks:      A_ij -= X_i * X_j^T               (v_mfma_f64_16x16x4_f64, waves 0..2)
+//      while wave 3 inverts the diagonal sub-block (16x16, registers) for the L^-1 assembly
 // then Linv by block forward substitution, Linv_ij = -Linv_ii * sum_k L_ik Linv_kj, again on MFMA: the
 // C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly its B-operand
 // layout for k-step = reg, so the running sum feeds the next product without touching LDS.
@@ -409,14 +410,17 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   }
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
+  __shared__ double s_rinv[16];
   for (int b = 0; b < 4; b++) {
-    const int o = 16 * b;
-    if (wave == 0) {  // ---- A
+    const int o = 16 * b, nrows = NB - o;
+    if (wave == 0) {
+      // ---- A: the whole 16-column PANEL (diagonal sub-block + every row below it) in registers, lane = panel row.
+      // Column j: s_r = a_rj - sum_{k<j} a_rk L_jk with L_jk broadcast from lane j by v_readlane; the rows below the
+      // diagonal sub-block ride along in the same instructions, so no separate triangular solve is needed.
       double a[16];
 #pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = (lane < 16 && c <= lane) ? Bm[(o + lane) * LP + o + c] : 0.0;
+      for (int c = 0; c < 16; c++) a[c] = (lane < nrows && (lane >= 16 || c <= lane)) ? Bm[(o + lane) * LP + o + c] : 0.0;
       bool bad = false;
-      double rinv[16];   // 1 / L_jj (wave-uniform): v_rsq_f64 + two Newton steps instead of a sqrt and 16 + 16 divisions
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         double s0 = a[j], s1 = 0.0;
@@ -429,16 +433,27 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
         const double d = bcast_lane(s, j);
         if (!(d > 0.0)) bad = true;
         const double dd = d > 0.0 ? d : 1.0;
-        double y = __builtin_amdgcn_rsq(dd);
+        double y = __builtin_amdgcn_rsq(dd);     // 1 / L_jj: v_rsq_f64 + two Newton steps instead of sqrt and divisions
         y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
         y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
         double sq = dd * y;
         sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);   // sqrt(dd) to the last bit or one ulp
-        rinv[j] = y;
+        if (lane == 0) s_rinv[j] = y;
         a[j] = (lane == j) ? sq : (lane > j ? s * y : 0.0);
       }
       if (bad && lane == 0) *fail = 1;
-      double y[16];  // column `lane` of the 16x16 inverse
+      if (lane < nrows) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (lane >= 16 || c <= lane) ? a[c] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (wave == 3) {
+      // ---- inverse of the 16x16 diagonal sub-block (needed by the L^-1 assembly below, not by this loop): off the
+      // critical path, on the wave that has no trailing update to do
+      double a[16], y[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = (lane < 16 && c <= lane) ? Bm[(o + lane) * LP + o + c] : 0.0;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
@@ -447,11 +462,9 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
           const double l = bcast_lane(a[t], i);
           if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
         }
-        y[i] = (s0 + s1) * rinv[i];
+        y[i] = (s0 + s1) * s_rinv[i];
       }
       if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (c <= lane) ? a[c] : 0.0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const double v = (lane <= i) ? y[i] : 0.0;
@@ -459,32 +472,21 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
           Li[(o + i) * LP + o + lane] = v;
         }
       }
+    } else {
+      // ---- C: trailing sub-blocks (i >= j > b), round-robin over waves 0..2
+      int pair = 0;
+      for (int i = b + 1; i < 4; i++)
+        for (int j = b + 1; j <= i; j++, pair++) {
+          if (pair % 3 != wave) continue;
+          const int oi = 16 * i, oj = 16 * j;
+          double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 16; k += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + o + k + lq], Bm[(oj + lr) * LP + o + k + lq], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
+        }
     }
-    __syncthreads();
-    // ---- B: wave w owns sub-block row i = b + 1 + w
-    if (b + 1 + wave < 4) {
-      const int oi = 16 * (b + 1 + wave);
-      double4_t acc = {0, 0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < 16; k += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + o + k + lq], Iv[b][lr][k + lq], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + o + lr] = acc[r];
-    }
-    __syncthreads();
-    // ---- C: trailing sub-blocks (i >= j > b), round-robin over the waves
-    int pair = 0;
-    for (int i = b + 1; i < 4; i++)
-      for (int j = b + 1; j <= i; j++, pair++) {
-        if ((pair & 3) != wave) continue;
-        const int oi = 16 * i, oj = 16 * j;
-        double4_t acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; k += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + o + k + lq], Bm[(oj + lr) * LP + o + k + lq], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
-      }
     __syncthreads();
   }
   for (int i = tid; i < NB * NB; i += 256) {
