@@ -423,10 +423,12 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
+        // L_jk, k < j - 1: finished columns were published to LDS (all lanes read one address: a broadcast read, and the
+        // reads pipeline); only the column finished in the previous step comes by v_readlane, so no step waits on LDS
         double s0 = a[j], s1 = 0.0;
 #pragma unroll
         for (int k = 0; k < j; k++) {
-          const double t = bcast_lane(a[k], j);
+          const double t = (k == j - 1) ? bcast_lane(a[k], j) : Bm[(o + j) * LP + o + k];
           if (k & 1) s1 = __builtin_fma(-a[k], t, s1); else s0 = __builtin_fma(-a[k], t, s0);
         }
         const double s = s0 + s1;
@@ -440,26 +442,25 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
         sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);   // sqrt(dd) to the last bit or one ulp
         if (lane == 0) s_rinv[j] = y;
         a[j] = (lane == j) ? sq : (lane > j ? s * y : 0.0);
+        if (lane < nrows) Bm[(o + lane) * LP + o + j] = a[j];          // publish column j
       }
       if (bad && lane == 0) *fail = 1;
-      if (lane < nrows) {
+      if (lane < 16) {   // zero the strict upper part of the diagonal sub-block
 #pragma unroll
-        for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (lane >= 16 || c <= lane) ? a[c] : 0.0;
+        for (int c = 1; c < 16; c++) if (c > lane) Bm[(o + lane) * LP + o + c] = 0.0;
       }
     }
     __syncthreads();
     if (wave == 3) {
       // ---- inverse of the 16x16 diagonal sub-block (needed by the L^-1 assembly below, not by this loop): off the
       // critical path, on the wave that has no trailing update to do
-      double a[16], y[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = (lane < 16 && c <= lane) ? Bm[(o + lane) * LP + o + c] : 0.0;
+      double y[16];   // column `lane` of the inverse; L_it comes straight from LDS (uniform address = broadcast read)
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
         for (int t = 0; t < i; t++) {
-          const double l = bcast_lane(a[t], i);
+          const double l = Bm[(o + i) * LP + o + t];
           if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
         }
         y[i] = (s0 + s1) * s_rinv[i];
