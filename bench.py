@@ -154,7 +154,7 @@ def main():
     dt = time.perf_counter() - t0
     ext.profiling(False)
     dt = exchange.max_over_ranks(dt, device="cuda")
-    prof = {k: ext.profile_get(k) for k in ("pyramid", "fast", "compact", "octree", "assemble", "blur", "orient_desc")}
+    prof = {k: ext.profile_get(k) for k in ("pyramid", "fast", "octree", "assemble", "blur", "orient_desc")}
     nmatched = int((matches[:, :, 1] <= 100).sum().item())  # TH_HIGH gate, sanity only
 
     if rank == 0:

@@ -175,16 +175,25 @@ int dvm_orb_debug_candidates(dvm_orb* h, int frame, int level, int32_t* xs, int3
   if (level < 0 || level >= P.PD.nlevels || frame < 0 || frame >= P.last_batch) return DVM_ERR_INVALID;
   int rc = P.sync();
   if (rc != DVM_OK) return rc;
-  int32_t ls[kMaxLevels + 1];
-  rc = hip_check(hipMemcpy(ls, P.d_lvl_start + (size_t)frame * (kMaxLevels + 1), sizeof(ls), hipMemcpyDeviceToHost), "memcpy");
-  if (rc != DVM_OK) return rc;
-  const int cnt = ls[level + 1] - ls[level];
+  // vToDistributeKeys of the level = the per-cell lists of k_fast_cells in the reference's cell loop order
+  const LevelDesc& LD = P.PD.lv[level];
+  std::vector<int32_t> cc(std::max(LD.cell_count, 1));
+  if (LD.cell_count > 0) {
+    rc = hip_check(hipMemcpy(cc.data(), P.d_cell_count + (size_t)frame * P.PD.ncells + LD.cell_first, (size_t)LD.cell_count * 4, hipMemcpyDeviceToHost), "memcpy");
+    if (rc != DVM_OK) return rc;
+  }
+  int cnt = 0;
+  for (int c = 0; c < LD.cell_count; c++) cnt += cc[c];
   if (n) *n = cnt;
   if (cnt > cap) return DVM_ERR_CAPACITY;
   std::vector<uint32_t> tmp(cnt > 0 ? cnt : 1);
-  if (cnt > 0) {
-    rc = hip_check(hipMemcpy(tmp.data(), P.d_dense + (size_t)frame * P.PD.cand_frame_slots + ls[level], (size_t)cnt * 4, hipMemcpyDeviceToHost), "memcpy");
-    if (rc != DVM_OK) return rc;
+  for (int c = 0, o = 0; c < LD.cell_count; c++) {
+    if (cc[c] > 0) {
+      rc = hip_check(hipMemcpy(tmp.data() + o, P.d_cand + (size_t)frame * P.PD.cand_frame_slots + P.cells[LD.cell_first + c].cand_base,
+                               (size_t)cc[c] * 4, hipMemcpyDeviceToHost), "memcpy");
+      if (rc != DVM_OK) return rc;
+      o += cc[c];
+    }
   }
   for (int i = 0; i < cnt; i++) {
     int x, y, s;

@@ -157,10 +157,12 @@ __device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, in
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ dense, const int32_t* __restrict__ lvl_start,
-                                                PipelineDesc PD, int32_t* __restrict__ nid_scratch,
-                                                uint32_t* __restrict__ sel, int32_t* __restrict__ nsel,
-                                                int32_t* __restrict__ err_flag, int cap) {
+__global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
+                                                const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
+                                                int32_t* __restrict__ lvl_count, PipelineDesc PD,
+                                                int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
+                                                int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
+                                                int level_first) {
   // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64):
   // 44 B per slot, so the BASELINE config (cap 256) keeps ~11 KB and 8 workgroups fit a CU
   extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
@@ -177,12 +179,41 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ den
   __shared__ int s_stack[144];
   __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
 
-  const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int level = level_first + blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   const LevelDesc& LV = PD.lv[level];
-  const int32_t* ls = lvl_start + f * (kMaxLevels + 1);
-  const int n = ls[level + 1] - ls[level];
-  const uint32_t* cand = dense + (int64_t)f * PD.cand_frame_slots + ls[level];
-  int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + ls[level];
+  // ---- vToDistributeKeys of this level: the per-cell candidate lists (k_fast_cells) concatenated in the reference's
+  // cell loop order, into the level's own range of `dense` (this used to be a separate per-frame kernel; doing it here
+  // makes a level's octree depend on that level's FAST cells only)
+  uint32_t* cand_w = dense + (int64_t)f * PD.cand_frame_slots + LV.cand_off;
+  __shared__ int s_carry;
+  {
+    __shared__ int s_cnt[256];
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    const uint32_t* src = cand_slots + (int64_t)f * PD.cand_frame_slots;
+    for (int c0 = 0; c0 < LV.cell_count; c0 += 256) {
+      const int ci = LV.cell_first + c0 + tid;
+      const int cn = (c0 + tid < LV.cell_count) ? cell_count[(int64_t)f * PD.ncells + ci] : 0;
+      s_cnt[tid] = cn;
+      __syncthreads();
+      block_scan_excl(s_cnt, 256, s_tmp, &s_total);
+      const int start = s_carry + s_cnt[tid];
+      if (cn > 0) {
+        const uint32_t* sp = src + cells[ci].cand_base;
+        for (int k = 0; k < cn; k++) cand_w[start + k] = sp[k];
+      }
+      __syncthreads();
+      if (tid == 0) s_carry += s_total;
+      __syncthreads();
+    }
+    if (tid == 0) lvl_count[f * kMaxLevels + level] = s_carry;
+    __threadfence_block();   // the candidates written above are re-read below by other threads of this workgroup (the
+                             // level's range owns its cache lines: cand_off is 128-byte aligned, so no stale L1 line)
+    __syncthreads();
+  }
+  const int n = s_carry;
+  const uint32_t* cand = cand_w;
+  int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + LV.cand_off;
   uint32_t* out = sel + (int64_t)f * PD.sel_frame_slots + LV.sel_off;
   int32_t* out_n = nsel + f * PD.nlevels + level;
   const int N = LV.quota;
@@ -393,16 +424,18 @@ int octree_required_nodes(const PipelineDesc& PD) {
 }
 bool octree_fits_device(const PipelineDesc& PD) { return octree_required_nodes(PD) <= kOctMaxNodes; }
 
-void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_start, const PipelineDesc& PD,
-                   int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch) {
+void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
+                   int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err,
+                   int batch, int level_first, int level_num) {
+  if (level_num <= 0) return;
   int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
   const size_t bytes = (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2);
   // beyond the default 48 KB of dynamic LDS the limit has to be raised on the CURRENT device (the attribute is per
   // device and the library serves one handle per GPU), so no process-wide "done once" flag
   if (bytes > 48 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  hipLaunchKernelGGL(k_octree, dim3(PD.nlevels, batch), dim3(256), bytes, s, d_dense, d_lvl_start, PD, d_nid, d_sel, d_nsel,
-                     d_err, cap);
+  hipLaunchKernelGGL(k_octree, dim3(level_num, batch), dim3(256), bytes, s, d_cand, d_cell_count, d_cells, d_dense, d_lvl_count,
+                     PD, d_nid, d_sel, d_nsel, d_err, cap, level_first);
 }
 
 }  // namespace dvm

@@ -20,12 +20,11 @@ void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, in
 void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch);
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num);
-void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
-                    const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch);
 int octree_root_nodes(const LevelDesc& L);
 bool octree_fits_device(const PipelineDesc& PD);   // else: DistributeOctTree runs on the host for this configuration
-void launch_octree(hipStream_t s, const uint32_t* d_dense, const int32_t* d_lvl_start, const PipelineDesc& PD,
-                   int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch);
+void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
+                   int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err,
+                   int batch, int level_first, int level_num);
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
                      int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch);
 void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,

@@ -2,7 +2,7 @@
 //
 // Stage map (reference file:line -> kernel), see DESIGN.md for layouts and rooflines:
 //   ORBextractor.cc:957-976  ComputePyramid              -> k_pyr_level0, k_pyr_resize
-//   ORBextractor.cc:634-692  per-cell cv::FAST x2 + NMS  -> k_fast_cells, k_compact_cands
+//   ORBextractor.cc:634-692  per-cell cv::FAST x2 + NMS  -> k_fast_cells (lists concatenated per level by k_octree)
 //   ORBextractor.cc:876-955  operator() output placement -> k_assemble
 //   ORBextractor.cc:919-920  GaussianBlur 7x7 sigma 2    -> k_blur7
 //   ORBextractor.cc:75-99    IC_Angle                    -> k_orient_desc (phase 1)
@@ -657,50 +657,6 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   }
 }
 
-// Concatenate the per-cell lists of one frame in cell-table order (level-major, then the
-// reference's cell loop order) -> per-level vToDistributeKeys, densely packed per frame.
-// grid (batch); dense[f][lvl_start[f][l] + i], lvl_start[f][0..nlevels] (last = total).
-__global__ void __launch_bounds__(256) k_compact_cands(const uint32_t* __restrict__ cand,
-                                                       const int32_t* __restrict__ cell_count,
-                                                       const CellDesc* __restrict__ cells, PipelineDesc PD,
-                                                       uint32_t* __restrict__ dense, int32_t* __restrict__ lvl_start) {
-  __shared__ int s_scan[256];
-  __shared__ int s_carry;
-  const int f = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  const uint32_t* src = cand + (int64_t)f * PD.cand_frame_slots;
-  uint32_t* dst = dense + (int64_t)f * PD.cand_frame_slots;
-  for (int c0 = 0; c0 < PD.ncells; c0 += 256) {
-    int ci = c0 + tid;
-    int n = (ci < PD.ncells) ? cell_count[(int64_t)f * PD.ncells + ci] : 0;
-    s_scan[tid] = n;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
-      int v = (tid >= off) ? s_scan[tid - off] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
-    }
-    int start = s_carry + s_scan[tid] - n;
-    if (ci < PD.ncells) {
-      const CellDesc c = cells[ci];
-      if (ci == PD.lv[c.level].cell_first) lvl_start[f * (kMaxLevels + 1) + c.level] = start;
-      const uint32_t* s = src + c.cand_base;
-      for (int k = 0; k < n; k++) dst[start + k] = s[k];
-    }
-    __syncthreads();
-    if (tid == 255) s_carry += s_scan[255];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    int32_t* ls = lvl_start + f * (kMaxLevels + 1);
-    ls[PD.nlevels] = s_carry;
-    for (int l = PD.nlevels - 1; l >= 0; l--)  // levels without any cell own an empty range
-      if (PD.lv[l].cell_count == 0) ls[l] = ls[l + 1];
-  }
-}
-
 // ------------------------------------------------------------------------------------ assemble
 // operator() output placement (reference ORBextractor.cc:898-951).  One workgroup per frame.
 // Walks the selected keypoints in (level, octree-list) order g = 0..N-1, scales pt by
@@ -1085,11 +1041,6 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
   if (lay.tile_pitch == 64) { if (small) DVM_FAST_LAUNCH(64, 2); else DVM_FAST_LAUNCH(64, 4); }
   else DVM_FAST_LAUNCH(0, 4);
 #undef DVM_FAST_LAUNCH
-}
-void launch_compact(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells,
-                    const PipelineDesc& PD, uint32_t* d_dense, int32_t* d_lvl_start, int batch) {
-  hipLaunchKernelGGL(k_compact_cands, dim3(batch), dim3(256), 0, s, d_cand, d_cell_count, d_cells, PD, d_dense,
-                     d_lvl_start);
 }
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
                      int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch) {

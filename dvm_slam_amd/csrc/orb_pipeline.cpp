@@ -3,7 +3,7 @@
 // Mirrors ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:47-91, src/ORBextractor.cc):
 //   constructor tables      ORBextractor.cc:282-339 -> OrbPipeline::OrbPipeline
 //   ComputePyramid          :957-976                -> launch_pyr_level0 / launch_pyr_resize
-//   ComputeKeyPointsOctTree :612-715                -> launch_fast + launch_compact + octree_select
+//   ComputeKeyPointsOctTree :612-715                -> launch_fast + launch_octree (host fallback: octree_select)
 //   operator()              :876-955                -> extract_device (stage order, output placement)
 // Everything that touches pixels runs in HIP kernels (orb_kernels.hip).  DistributeOctTree is
 // sequential list surgery over <= ~10^4 candidates per level and stays on the host in this round
@@ -326,15 +326,15 @@ int OrbPipeline::init() {
 }
 
 void OrbPipeline::free_all() {
-  void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_start, d_sel, d_nsel,
+  void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_count, d_sel, d_nsel,
                    d_kps, d_desc, d_aux, d_n, d_mono, d_nid, d_err};
   for (void* p : dptrs) if (p) hipFree(p);
-  void* hptrs[] = {h_lvl_start, h_dense, h_sel, h_nsel, h_n, h_mono};
+  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono};
   for (void* p : hptrs) if (p) hipHostFree(p);
   d_pyr = d_blur = d_desc = nullptr; d_tabs = nullptr; d_cells = nullptr; d_tiles = nullptr;
-  d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_start = d_nsel = d_n = d_mono = nullptr;
+  d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_count = d_nsel = d_n = d_mono = nullptr;
   d_kps = nullptr; d_aux = nullptr; d_nid = nullptr; d_err = nullptr;
-  h_lvl_start = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
+  h_cell_count = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
   configured = false;  // (the host-image staging buffers d_stage/h_stage live until the destructor)
 }
 
@@ -404,6 +404,7 @@ int OrbPipeline::configure(int rows, int cols) {
     }
     // FAST cells, ORBextractor.cc:617-650
     D.cell_first = (int)cells.size();
+    cand_off = align_up(cand_off, 32);   // a level's range starts on its own 128-byte line (k_octree writes and re-reads it)
     D.cand_off = cand_off;
     const int minBX = kEdge - 3, minBY = minBX, maxBX = D.w - kEdge + 3, maxBY = D.h - kEdge + 3;
     const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
@@ -456,7 +457,7 @@ int OrbPipeline::configure(int rows, int cols) {
   PD.ntiles = (int)tiles.size();
   PD.pyr_frame_bytes = pyr_off;
   PD.blur_frame_bytes = blur_off;
-  PD.cand_frame_slots = std::max(cand_off, 1);
+  PD.cand_frame_slots = align_up(std::max(cand_off, 1), 32);
   PD.sel_frame_slots = sel_off;
   PD.kp_cap = sel_off;
   const size_t B = (size_t)max_batch;
@@ -468,7 +469,7 @@ int OrbPipeline::configure(int rows, int cols) {
   DVM_HIP(hipMalloc(&d_cand, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipMalloc(&d_dense, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipMalloc(&d_cell_count, B * std::max(PD.ncells, 1) * 4));
-  DVM_HIP(hipMalloc(&d_lvl_start, B * (kMaxLevels + 1) * 4));
+  DVM_HIP(hipMalloc(&d_lvl_count, B * kMaxLevels * 4));
   DVM_HIP(hipMalloc(&d_sel, B * PD.sel_frame_slots * 4));
   DVM_HIP(hipMalloc(&d_nsel, B * L * 4));
   DVM_HIP(hipMalloc(&d_kps, B * PD.kp_cap * sizeof(dvm_keypoint_pod)));
@@ -479,7 +480,7 @@ int OrbPipeline::configure(int rows, int cols) {
   DVM_HIP(hipMalloc(&d_nid, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipMalloc(&d_err, 4));
   DVM_HIP(hipMemset(d_err, 0, 4));
-  DVM_HIP(hipHostMalloc(&h_lvl_start, B * (kMaxLevels + 1) * 4));
+  DVM_HIP(hipHostMalloc(&h_cell_count, B * std::max(PD.ncells, 1) * 4));
   DVM_HIP(hipHostMalloc(&h_dense, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipHostMalloc(&h_sel, B * PD.sel_frame_slots * 4));
   DVM_HIP(hipHostMalloc(&h_nsel, B * L * 4));
@@ -558,33 +559,24 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.begin(st, "fast");
     launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, 0, PD.ncells);
     prof.end(st);
-    prof.begin(st, "compact");
-    launch_compact(st, (d_cand + (size_t)f0 * PD.cand_frame_slots), (d_cell_count + (size_t)f0 * PD.ncells), d_cells, PD, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
-    prof.end(st);
-
     DVM_HIP(hipEventRecord(ev_compact[ck], st));   // this chunk has left the throughput-bound stages
     if (blur_forked && !blur_early) {
       DVM_HIP(hipEventRecord(ev_fork[ck], st));
       DVM_HIP(hipStreamWaitEvent(side, ev_fork[ck], 0));
       prof.begin(side, "blur");
-      launch_blur(side, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
+      launch_blur(side, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, nullptr, nb);
       prof.end(side);
       DVM_HIP(hipEventRecord(ev_join[ck], side));
     }
     if (!host_octree) {
       prof.begin(st, "octree");
-      launch_octree(st, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), PD, (d_nid + (size_t)f0 * PD.cand_frame_slots), (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), d_err, nb);
+      launch_octree(st, cand_f0, cnt_f0, d_cells, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_count + (size_t)f0 * kMaxLevels), PD,
+                    (d_nid + (size_t)f0 * PD.cand_frame_slots), (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), d_err, nb, 0, L);
       prof.end(st);
     } else {
-    // ---- DistributeOctTree on the host (K3): counts, then each frame's dense candidate prefix
-      DVM_HIP(hipMemcpyAsync(h_lvl_start, d_lvl_start, (size_t)batch * (kMaxLevels + 1) * 4, hipMemcpyDeviceToHost, st));
-      DVM_HIP(hipStreamSynchronize(st));
-      for (int f = 0; f < batch; f++) {
-        const int total = h_lvl_start[f * (kMaxLevels + 1) + L];
-        if (total > 0)
-          DVM_HIP(hipMemcpyAsync(h_dense + (size_t)f * PD.cand_frame_slots, d_dense + (size_t)f * PD.cand_frame_slots,
-                                 (size_t)total * 4, hipMemcpyDeviceToHost, st));
-      }
+    // ---- DistributeOctTree on the host (K3): per-cell candidate lists -> vToDistributeKeys per level -> octree_select
+      DVM_HIP(hipMemcpyAsync(h_cell_count, d_cell_count, (size_t)batch * PD.ncells * 4, hipMemcpyDeviceToHost, st));
+      DVM_HIP(hipMemcpyAsync(h_dense, d_cand, (size_t)batch * PD.cand_frame_slots * 4, hipMemcpyDeviceToHost, st));
       DVM_HIP(hipStreamSynchronize(st));
       {
         const int jobs = batch * L;
@@ -593,10 +585,13 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
           std::vector<uint32_t> out;
           for (int j = t; j < jobs; j += nthreads) {
             const int f = j / L, l = j % L;
-            const int32_t* ls = h_lvl_start + f * (kMaxLevels + 1);
             const LevelDesc& D = PD.lv[l];
-            octree_select(h_dense + (size_t)f * PD.cand_frame_slots + ls[l], ls[l + 1] - ls[l], kEdge - 3, D.w - kEdge + 3,
-                          kEdge - 3, D.h - kEdge + 3, D.quota, out);
+            std::vector<uint32_t> keys;   // concatenation in the reference's cell loop order
+            for (int ci = D.cell_first; ci < D.cell_first + D.cell_count; ci++) {
+              const uint32_t* sp = h_dense + (size_t)f * PD.cand_frame_slots + cells[ci].cand_base;
+              keys.insert(keys.end(), sp, sp + h_cell_count[(size_t)f * PD.ncells + ci]);
+            }
+            octree_select(keys.data(), (int)keys.size(), kEdge - 3, D.w - kEdge + 3, kEdge - 3, D.h - kEdge + 3, D.quota, out);
             const int n = std::min<int>((int)out.size(), D.sel_cap);
             h_nsel[f * L + l] = n;
             std::memcpy(h_sel + (size_t)f * PD.sel_frame_slots + D.sel_off, out.data(), (size_t)n * 4);
@@ -618,7 +613,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.end(st);
     if (!blur_forked) {
       prof.begin(st, "blur");
-      launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, (d_lvl_start + (size_t)f0 * (kMaxLevels + 1)), nb);
+      launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, nullptr, nb);
       prof.end(st);
     } else {
       DVM_HIP(hipStreamWaitEvent(st, ev_join[ck], 0));

@@ -87,9 +87,9 @@ class OrbPipeline {
   CellDesc* d_cells = nullptr;
   TileDesc* d_tiles = nullptr;
   uint32_t* d_cand = nullptr;        // cell-slotted
-  uint32_t* d_dense = nullptr;       // per-frame dense, level-major
+  uint32_t* d_dense = nullptr;       // per-frame vToDistributeKeys, level l at its own cand_off (written by k_octree)
   int32_t* d_cell_count = nullptr;
-  int32_t* d_lvl_start = nullptr;    // [batch][kMaxLevels+1]
+  int32_t* d_lvl_count = nullptr;    // [batch][kMaxLevels] candidates per level (written by k_octree)
   uint32_t* d_sel = nullptr;         // [batch][sel_frame_slots]
   int32_t* d_nsel = nullptr;         // [batch][nlevels]
   dvm_keypoint_pod* d_kps = nullptr; // [batch][kp_cap]
@@ -104,7 +104,7 @@ class OrbPipeline {
   uint8_t* d_stage = nullptr;        // staging for host images
   size_t stage_bytes = 0;
   // pinned host mirrors
-  int32_t* h_lvl_start = nullptr;
+  int32_t* h_cell_count = nullptr;   // host octree fallback: per-cell counts
   uint32_t* h_dense = nullptr;
   uint32_t* h_sel = nullptr;
   int32_t* h_nsel = nullptr;
