@@ -619,3 +619,215 @@ def pose_graph_optimize(S, fixed, edges_v, edges_meas, fix_scale=False, iteratio
     d = {k: getattr(st, k) for k, _ in PgStats._fields_}
     d["chi2_per_iter"] = np.array(st.chi2_per_iter[:]); d["trials_per_iter"] = np.array(st.trials_per_iter[:])
     return So, d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the remaining whole ORBmatcher functions (host mirrors in dvm_slam_amd/host/orb_matcher.cpp over
+# dvm_hamming_matrix / dvm_match_lists / dvm_project_search / dvm_match_triangulation).  The view structs of
+# host/orb_matcher.h are mirrored as ctypes.Structure; numpy arrays referenced by a view are kept alive on the object.
+class _FeatureVectorView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("node", C.c_void_p), ("off", C.c_void_p), ("feat", C.c_void_p)]
+
+
+class _FrameView(C.Structure):
+    _fields_ = [("N", C.c_int32), ("mvKeysUn", C.c_void_p), ("mDescriptors", C.c_void_p), ("mvpMapPoints", C.c_void_p),
+                ("mvbOutlier", C.c_void_p), ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("mnMinX", C.c_float), ("mnMaxX", C.c_float), ("mnMinY", C.c_float),
+                ("mnMaxY", C.c_float), ("mvScaleFactors", C.c_void_p), ("nLevels", C.c_int32)]
+
+
+class _KeyFrameView(C.Structure):
+    _fields_ = [("N", C.c_int32), ("mvKeysUn", C.c_void_p), ("mDescriptors", C.c_void_p), ("mvpMapPoints", C.c_void_p),
+                ("mpBad", C.c_void_p), ("mFeatVec", _FeatureVectorView), ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3),
+                ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("mnMinX", C.c_float), ("mnMaxX", C.c_float), ("mnMinY", C.c_float), ("mnMaxY", C.c_float),
+                ("mvScaleFactors", C.c_void_p), ("mvLevelSigma2", C.c_void_p), ("mvInvLevelSigma2", C.c_void_p),
+                ("mfLogScaleFactor", C.c_float), ("nLevels", C.c_int32)]
+
+
+class _MapPointsView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("id", C.c_void_p), ("bad", C.c_void_p), ("pos", C.c_void_p), ("normal", C.c_void_p),
+                ("min_dist", C.c_void_p), ("max_dist", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class _Sim3View(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("s", C.c_float)]
+
+
+def _ptr(a):
+    return None if a is None or a.size == 0 else a.ctypes.data
+
+
+def _fv_view(fv, keep):
+    v = _FeatureVectorView()
+    if fv is not None:
+        arrs = [np.ascontiguousarray(fv[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat")]
+        keep.extend(arrs)
+        v.n, v.node, v.off, v.feat = len(arrs[0]), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2])
+    return v
+
+
+def frame_view(kps, desc, bounds, scale_factors, mp=None, K=(0, 0, 0, 0)):
+    """FrameView for the matcher mirrors; returns (struct, keepalive list)."""
+    keep = [np.ascontiguousarray(kps, KP_DTYPE), np.ascontiguousarray(desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)]
+    v = _FrameView()
+    v.N, v.mvKeysUn, v.mDescriptors, v.mvScaleFactors, v.nLevels = len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), len(keep[2])
+    if mp is not None:
+        keep.append(mp)
+        v.mvpMapPoints = _ptr(mp)
+    v.fx, v.fy, v.cx, v.cy = (float(x) for x in K)
+    v.mnMinX, v.mnMaxX, v.mnMinY, v.mnMaxY = (float(x) for x in bounds)
+    return v, keep
+
+
+def keyframe_view(kf):
+    """kf: dict(kps, desc, mp (int32, modified in place by Fuse), bad, fv, Rcw, tcw, Ow, K, bounds, scale_factors,
+    level_sigma2, inv_level_sigma2, log_scale_factor); missing optional keys are NULL.  Returns (struct, keepalive)."""
+    keep = [np.ascontiguousarray(kf["kps"], KP_DTYPE), np.ascontiguousarray(kf["desc"], np.uint8)]
+    v = _KeyFrameView()
+    v.N, v.mvKeysUn, v.mDescriptors = len(keep[0]), _ptr(keep[0]), _ptr(keep[1])
+    mp = kf.get("mp")
+    if mp is not None:
+        assert mp.dtype == np.int32 and mp.flags.c_contiguous
+        keep.append(mp); v.mvpMapPoints = _ptr(mp)
+    if kf.get("bad") is not None:
+        b = np.ascontiguousarray(kf["bad"], np.uint8); keep.append(b); v.mpBad = _ptr(b)
+    v.mFeatVec = _fv_view(kf.get("fv"), keep)
+    for name, key, n in (("Rcw", "Rcw", 9), ("tcw", "tcw", 3), ("Ow", "Ow", 3)):
+        if kf.get(key) is not None:
+            setattr(v, name, (C.c_float * n)(*np.asarray(kf[key], np.float32).reshape(-1)))
+    v.fx, v.fy, v.cx, v.cy = (float(x) for x in kf.get("K", (0, 0, 0, 0)))
+    v.mnMinX, v.mnMaxX, v.mnMinY, v.mnMaxY = (float(x) for x in kf["bounds"])
+    for name, key in (("mvScaleFactors", "scale_factors"), ("mvLevelSigma2", "level_sigma2"), ("mvInvLevelSigma2", "inv_level_sigma2")):
+        if kf.get(key) is not None:
+            a = np.ascontiguousarray(kf[key], np.float32); keep.append(a); setattr(v, name, _ptr(a)); v.nLevels = len(a)
+    v.mfLogScaleFactor = float(kf.get("log_scale_factor", 0.0))
+    return v, keep
+
+
+def map_points_view(pts):
+    """pts: dict(pos, normal, min_dist, max_dist, desc[, id, bad])."""
+    keep = [np.ascontiguousarray(pts[k], np.float32) for k in ("pos", "normal", "min_dist", "max_dist")]
+    keep.append(np.ascontiguousarray(pts["desc"], np.uint8))
+    v = _MapPointsView()
+    v.n = len(keep[2])
+    v.pos, v.normal, v.min_dist, v.max_dist, v.desc = (_ptr(a) for a in keep)
+    if pts.get("id") is not None:
+        a = np.ascontiguousarray(pts["id"], np.int32); keep.append(a); v.id = _ptr(a)
+    if pts.get("bad") is not None:
+        a = np.ascontiguousarray(pts["bad"], np.uint8); keep.append(a); v.bad = _ptr(a)
+    return v, keep
+
+
+def _sim3_view(R, t, s):
+    v = _Sim3View()
+    v.R = (C.c_float * 9)(*np.asarray(R, np.float32).reshape(-1)); v.t = (C.c_float * 3)(*np.asarray(t, np.float32)); v.s = float(s)
+    return v
+
+
+def _hcall(name, restype, *args):
+    fn = getattr(host_lib(), name)
+    fn.restype = restype
+    fn.argtypes = None
+    return fn(*args)
+
+
+def search_for_initialization(F1, F2, prev_matched, window=100, nnratio=0.9, check_ori=True, device=0):
+    """dvm_host::ORBmatcher::SearchForInitialization (ORBmatcher.cc:605-707).  F1 / F2 = frame_view() results.
+    Returns (nmatches, vnMatches12, vbPrevMatched updated)."""
+    pm = np.array(prev_matched, np.float32, copy=True).reshape(-1, 2)
+    m = np.zeros(max(F1[0].N, 1), np.int32)
+    n = _hcall("dvmh_search_for_initialization", C.c_int32, C.c_int32(device), C.byref(F1[0]), C.byref(F2[0]), C.c_void_p(pm.ctypes.data),
+               C.c_void_p(m.ctypes.data), C.c_int32(int(window)), C.c_float(nnratio), C.c_int32(int(check_ori)))
+    check(min(n, 0))
+    return n, m[:F1[0].N], pm
+
+
+def search_by_bow_kf_frame(KF, F, fv_f, nnratio=0.7, check_ori=True, device=0):
+    """SearchByBoW(KF, F, vpMapPointMatches) (:214-393).  Returns (nmatches, matches[F.N], #host re-queries)."""
+    keep = []
+    fv = _fv_view(fv_f, keep)
+    m = np.zeros(max(F[0].N, 1), np.int32); rq = C.c_int32(0)
+    n = _hcall("dvmh_search_by_bow_kf_frame", C.c_int32, C.c_int32(device), C.byref(KF[0]), C.byref(F[0]), C.byref(fv), C.c_float(nnratio),
+               C.c_int32(int(check_ori)), C.c_void_p(m.ctypes.data), C.byref(rq))
+    check(min(n, 0))
+    return n, m[:F[0].N], rq.value
+
+
+def search_by_bow_kf_kf(KF1, KF2, nnratio=0.8, check_ori=True, device=0):
+    """SearchByBoW(KF1, KF2, vpMatches12) (:709-834).  Returns (nmatches, matches12[KF1.N], #host re-queries)."""
+    m = np.zeros(max(KF1[0].N, 1), np.int32); rq = C.c_int32(0)
+    n = _hcall("dvmh_search_by_bow_kf_kf", C.c_int32, C.c_int32(device), C.byref(KF1[0]), C.byref(KF2[0]), C.c_float(nnratio),
+               C.c_int32(int(check_ori)), C.c_void_p(m.ctypes.data), C.byref(rq))
+    check(min(n, 0))
+    return n, m[:KF1[0].N], rq.value
+
+
+def triangulation_geometry(KF1, KF2):
+    R12 = np.zeros(9, np.float32); t12 = np.zeros(3, np.float32); ep = np.zeros(2, np.float32); F12 = np.zeros(9, np.float32)
+    _hcall("dvmh_triangulation_geometry", None, C.byref(KF1[0]), C.byref(KF2[0]), *(C.c_void_p(a.ctypes.data) for a in (R12, t12, ep, F12)))
+    return R12, t12, ep, F12
+
+
+def search_for_triangulation(KF1, KF2, coarse=False, check_ori=True, device=0):
+    """SearchForTriangulation (:836-1058, mono).  Returns (nmatches, pairs[nmatches, 2])."""
+    pairs = np.zeros((max(KF1[0].N, 1), 2), np.int32)
+    n = _hcall("dvmh_search_for_triangulation", C.c_int32, C.c_int32(device), C.byref(KF1[0]), C.byref(KF2[0]), C.c_int32(int(coarse)),
+               C.c_int32(int(check_ori)), C.c_void_p(pairs.ctypes.data))
+    check(min(n, 0))
+    return n, pairs[:n]
+
+
+def fuse(KF, P, in_kf, th, device=0):
+    """Fuse(KF, vpMapPoints, th) search part (:1060-1213).  Returns (count, vBestIdx)."""
+    bi = np.zeros(max(P[0].n, 1), np.int32)
+    ik = None if in_kf is None else np.ascontiguousarray(in_kf, np.uint8)
+    n = _hcall("dvmh_fuse", C.c_int32, C.c_int32(device), C.byref(KF[0]), C.byref(P[0]), None if ik is None else C.c_void_p(ik.ctypes.data),
+               C.c_float(th), C.c_void_p(bi.ctypes.data))
+    check(min(n, 0))
+    return n, bi[:P[0].n]
+
+
+def fuse_sim3(KF, R, t, s, P, th, device=0):
+    """Fuse(KF, Scw, vpPoints, th, vpReplacePoint) (:1236-1345); KF's mp array is updated in place.  Returns (nFused, replace)."""
+    S = _sim3_view(R, t, s)
+    rep = np.zeros(max(P[0].n, 1), np.int32)
+    n = _hcall("dvmh_fuse_sim3", C.c_int32, C.c_int32(device), C.byref(KF[0]), C.byref(S), C.byref(P[0]), C.c_float(th), C.c_void_p(rep.ctypes.data))
+    check(min(n, 0))
+    return n, rep[:P[0].n]
+
+
+def search_by_projection_sim3(KF, R, t, s, P, matched, th, ratio_hamming=1.0, device=0):
+    """SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) (:395-496).  Returns (nmatches, vpMatched, #re-queries)."""
+    S = _sim3_view(R, t, s)
+    m = np.array(matched, np.int32, copy=True); rq = C.c_int32(0)
+    n = _hcall("dvmh_search_by_projection_sim3", C.c_int32, C.c_int32(device), C.byref(KF[0]), C.byref(S), C.byref(P[0]),
+               C.c_void_p(m.ctypes.data), C.c_int32(int(th)), C.c_float(ratio_hamming), C.byref(rq))
+    check(min(n, 0))
+    return n, m, rq.value
+
+
+def project_search(grid, cam, pts, th, scale_factors, skip=None, gate_inv_sigma2=None, gate=5.99, valid=None):
+    """dvm_project_search on a FrameGrid slot 0.  cam: dict(Rcw, tcw, Ow, K, bounds, log_scale_factor).  Returns (matches, proj)."""
+    class _Cam(C.Structure):
+        _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("K", C.c_float * 4), ("b", C.c_float * 4),
+                    ("lsf", C.c_float), ("nl", C.c_int32)]
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    c = _Cam()
+    c.Rcw = (C.c_float * 9)(*np.asarray(cam["Rcw"], np.float32).reshape(-1)); c.tcw = (C.c_float * 3)(*np.asarray(cam["tcw"], np.float32))
+    c.Ow = (C.c_float * 3)(*np.asarray(cam["Ow"], np.float32)); c.K = (C.c_float * 4)(*np.asarray(cam["K"], np.float32))
+    c.b = (C.c_float * 4)(*np.asarray(cam["bounds"], np.float32)); c.lsf = float(cam["log_scale_factor"]); c.nl = len(sf)
+    P, keep = map_points_view(pts)
+    n = P.n
+    out = np.zeros(max(n, 1), MATCH_DTYPE); proj = np.zeros(max(n, 1), np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("level", "<i4")]))
+    sk = None
+    if skip is not None:
+        sk = np.zeros(grid.capacity, np.uint8); sk[:len(skip)] = skip
+    gi = None if gate_inv_sigma2 is None else np.ascontiguousarray(gate_inv_sigma2, np.float32)
+    va = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+    fn = lib().dvm_project_search
+    fn.restype = C.c_int32; fn.argtypes = None
+    vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+    check(fn(grid.h, C.c_int32(0), vp(sk), C.byref(c), C.c_void_p(P.pos), C.c_void_p(P.normal), C.c_void_p(P.min_dist), C.c_void_p(P.max_dist),
+             C.c_void_p(P.desc), vp(va), C.c_int32(n), C.c_float(th), vp(sf), vp(gi), C.c_double(gate), vp(out), vp(proj), C.c_int32(0), None))
+    return out[:n], proj[:n]

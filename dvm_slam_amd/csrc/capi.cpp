@@ -43,6 +43,37 @@ static int need_device(int device) {
   return hip_check(hipSetDevice(device), "hipSetDevice");
 }
 
+// Host-pointer convenience paths: one device allocation holding every staged input and output of a call.
+namespace {
+struct Stage {
+  struct Item { const void* src; void* dst; size_t bytes, off; };
+  std::vector<Item> items;
+  size_t total = 0;
+  uint8_t* d = nullptr;
+  int add(const void* src, void* dst, size_t bytes) {
+    items.push_back({src, dst, bytes, total});
+    total += (std::max<size_t>(bytes, 16) + 15) & ~(size_t)15;
+    return (int)items.size() - 1;
+  }
+  int in(const void* src, size_t bytes) { return add(src, nullptr, src ? bytes : 0); }
+  int out(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0); }
+  int upload() {
+    int rc = hip_check(hipMalloc(&d, std::max<size_t>(total, 16)), "hipMalloc");
+    for (const Item& it : items)
+      if (rc == DVM_OK && it.src && it.bytes) rc = hip_check(hipMemcpy(d + it.off, it.src, it.bytes, hipMemcpyHostToDevice), "memcpy");
+    return rc;
+  }
+  template <class T> T* ptr(int i) const { return items[i].bytes ? reinterpret_cast<T*>(d + items[i].off) : nullptr; }
+  int download() {
+    int rc = hip_check(hipDeviceSynchronize(), "sync");
+    for (const Item& it : items)
+      if (rc == DVM_OK && it.dst && it.bytes) rc = hip_check(hipMemcpy(it.dst, d + it.off, it.bytes, hipMemcpyDeviceToHost), "memcpy");
+    return rc;
+  }
+  ~Stage() { if (d) hipFree(d); }
+};
+}  // namespace
+
 extern "C" {
 
 const char* dvm_last_error(void) { return last_error_cstr(); }
@@ -475,6 +506,76 @@ int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, 
   if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, d + o_out, b_out, hipMemcpyDeviceToHost), "memcpy");
   hipFree(d);
   return rc;
+}
+
+int dvm_project_search(const dvm_frame* train, int slot, const uint8_t* skip, const dvm_kf_camera* cam, const float* P,
+                       const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc,
+                       const uint8_t* valid, int n, float th, const float* scale_factors, const float* gate_inv_sigma2,
+                       double gate, dvm_match* out, dvm_projection* proj, int on_device, void* stream) {
+  static_assert(sizeof(dvm_kf_camera) + 4 == sizeof(ProjectCam) && sizeof(dvm_projection) == sizeof(Projection), "layout");
+  if (!train || slot < 0 || slot >= train->slots || !cam || n < 0) return DVM_ERR_INVALID;
+  if (n == 0) return DVM_OK;
+  if (!P || !normal || !min_dist || !max_dist || !desc || !scale_factors || !out) return DVM_ERR_INVALID;
+  if (cam->n_levels < 1 || cam->n_levels > 32) return DVM_ERR_INVALID;
+  int rc = hip_check(hipSetDevice(train->device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  ProjectCam C;
+  std::memcpy(&C, cam, sizeof(dvm_kf_camera));
+  C.th = th;
+  if (on_device) {
+    launch_project_search((hipStream_t)stream, train->view, slot, skip, C, P, normal, min_dist, max_dist, desc, valid, n,
+                          scale_factors, gate_inv_sigma2, gate, reinterpret_cast<dvm_match_pod*>(out), reinterpret_cast<Projection*>(proj));
+    return hip_check(hipGetLastError(), "project_search launch");
+  }
+  Stage st;
+  const size_t N = (size_t)n, L = (size_t)cam->n_levels;
+  const int iP = st.in(P, N * 12), iN = st.in(normal, N * 12), imin = st.in(min_dist, N * 4), imax = st.in(max_dist, N * 4),
+            iD = st.in(desc, N * 32), iV = st.in(valid, N), iS = st.in(scale_factors, L * 4), iG = st.in(gate_inv_sigma2, L * 4),
+            iK = st.in(skip, (size_t)train->cap), oM = st.out(out, N * sizeof(dvm_match)), oP = st.out(proj, N * sizeof(dvm_projection));
+  rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_project_search(nullptr, train->view, slot, st.ptr<uint8_t>(iK), C, st.ptr<float>(iP), st.ptr<float>(iN), st.ptr<float>(imin),
+                        st.ptr<float>(imax), st.ptr<uint8_t>(iD), st.ptr<uint8_t>(iV), n, st.ptr<float>(iS), st.ptr<float>(iG), gate,
+                        st.ptr<dvm_match_pod>(oM), st.ptr<Projection>(oP));
+  rc = hip_check(hipGetLastError(), "project_search launch");
+  return rc == DVM_OK ? st.download() : rc;
+}
+
+int dvm_match_triangulation(const uint8_t* desc1, const dvm_keypoint* kps1, int n1, const int32_t* qidx, int nq,
+                            const uint8_t* desc2, const dvm_keypoint* kps2, int n2, const int32_t* off, const int32_t* cand,
+                            const float* F12, const float* ep, int coarse, const float* scale_factors2,
+                            const float* level_sigma2_2, int nlevels, int32_t* best_idx, int32_t* best_dist, int on_device,
+                            void* stream) {
+  if (nq < 0 || n1 < 0 || n2 < 0 || nlevels < 1) return DVM_ERR_INVALID;
+  if (nq == 0) return DVM_OK;
+  if (!desc1 || !kps1 || !qidx || !desc2 || !kps2 || !off || !cand || !F12 || !ep || !scale_factors2 || !level_sigma2_2 || !best_idx ||
+      !best_dist)
+    return DVM_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  TriGeom G;
+  std::memcpy(G.F12, F12, 36);
+  G.ep[0] = ep[0]; G.ep[1] = ep[1];
+  G.coarse = coarse != 0; G.th_low = 50;   // ORBmatcher::TH_LOW
+  if (on_device) {
+    launch_match_triangulation((hipStream_t)stream, desc1, reinterpret_cast<const dvm_keypoint_pod*>(kps1), qidx, nq, desc2,
+                               reinterpret_cast<const dvm_keypoint_pod*>(kps2), off, cand, G, scale_factors2, level_sigma2_2, best_idx, best_dist);
+    return hip_check(hipGetLastError(), "match_triangulation launch");
+  }
+  const int ncand = off[nq];
+  if (ncand < 0) return DVM_ERR_INVALID;
+  Stage st;
+  const int i1 = st.in(desc1, (size_t)n1 * 32), k1 = st.in(kps1, (size_t)n1 * sizeof(dvm_keypoint)), iq = st.in(qidx, (size_t)nq * 4),
+            i2 = st.in(desc2, (size_t)n2 * 32), k2 = st.in(kps2, (size_t)n2 * sizeof(dvm_keypoint)), io = st.in(off, (size_t)(nq + 1) * 4),
+            ic = st.in(cand, (size_t)ncand * 4), is = st.in(scale_factors2, (size_t)nlevels * 4), iv = st.in(level_sigma2_2, (size_t)nlevels * 4),
+            oi = st.out(best_idx, (size_t)nq * 4), od = st.out(best_dist, (size_t)nq * 4);
+  int rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_match_triangulation(nullptr, st.ptr<uint8_t>(i1), st.ptr<dvm_keypoint_pod>(k1), st.ptr<int32_t>(iq), nq, st.ptr<uint8_t>(i2),
+                             st.ptr<dvm_keypoint_pod>(k2), st.ptr<int32_t>(io), st.ptr<int32_t>(ic), G, st.ptr<float>(is), st.ptr<float>(iv),
+                             st.ptr<int32_t>(oi), st.ptr<int32_t>(od));
+  rc = hip_check(hipGetLastError(), "match_triangulation launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median,

@@ -58,6 +58,27 @@ struct TrackPoint {  // == dvm_track_point
   float proj_x, proj_y, proj_xr, depth, view_cos;
   int32_t level, in_view;
 };
+struct ProjectCam {  // == dvm_kf_camera (+ th)
+  float R[9], t[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
+  int32_t n_levels;
+  float th;
+};
+struct Projection {  // == dvm_projection
+  float u, v, radius;
+  int32_t level;
+};
+struct TriGeom {
+  float F12[9], ep[2];
+  int32_t coarse, th_low;
+};
+void launch_project_search(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const ProjectCam& C, const float* P,
+                           const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc,
+                           const uint8_t* valid, int n, const float* scale_factors, const float* gate_inv_sigma2, double gate,
+                           dvm_match_pod* out, Projection* proj);
+void launch_match_triangulation(hipStream_t s, const uint8_t* desc1, const dvm_keypoint_pod* kps1, const int32_t* qidx, int nq,
+                                const uint8_t* desc2, const dvm_keypoint_pod* kps2, const int32_t* off, const int32_t* cand,
+                                const TriGeom& G, const float* scale_factors2, const float* level_sigma2_2, int32_t* best_idx,
+                                int32_t* best_dist);
 void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
                           const float* max_dist, int n, float cos_limit, TrackPoint* out);
 void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_stride, const uint8_t* desc,

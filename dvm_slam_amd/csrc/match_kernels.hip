@@ -98,6 +98,68 @@ __device__ __forceinline__ void top2_insert(uint32_t& k1, uint32_t& k2, uint32_t
   else if (k < k2) k2 = k;
 }
 
+// GetFeaturesInArea(x, y, r, minLevel, maxLevel) of frame F scanned by one DPP row (16 lanes): best / second best
+// (dist << 16 | sorted position) after the row reduction, identical on all 16 lanes.  gate_inv_sigma2 != nullptr adds the
+// per-candidate reprojection gate of ORBmatcher::Fuse (ORBmatcher.cc:1187-1196): skip if (ex^2 + ey^2) * invSigma2[octave]
+// > gate (the comparison is made in double there: 5.99 is a double literal).
+__device__ __forceinline__ void window_top2(const FrameView& F, float x, float y, float r, int minLevel, int maxLevel,
+                                            const uint8_t* __restrict__ qdesc32, const uint8_t* __restrict__ skip,
+                                            const float* __restrict__ gate_inv_sigma2, double gate, int lane, uint32_t& k1_out,
+                                            uint32_t& k2_out) {
+  uint32_t k1 = (256u << 16) | 0xFFFFu, k2 = k1;
+  // GetFeaturesInArea cell rectangle (with the reference's early-outs)
+  const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+  const int nMaxCellX = min(kGridCols - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+  const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+  const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+  const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
+  if (!empty && nMinCellX <= nMaxCellX) {
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(qdesc32);
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = qd[i];
+    const int beg = F.cellx_start[nMinCellX], end = F.cellx_start[nMaxCellX + 1];
+    for (int p = beg + lane; p < end; p += 16) {
+      const float4 kp = F.skp[p];
+      const int oct = __float_as_int(kp.z);
+      const int cell = __float_as_int(kp.w);
+      const int iy = cell % kGridRows;
+      if (iy < nMinCellY || iy > nMaxCellY) continue;
+      if (checkLevels) {
+        if (oct < minLevel) continue;
+        if (maxLevel >= 0 && oct > maxLevel) continue;
+      }
+      const float dx = kp.x - x, dy = kp.y - y;
+      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+      if (skip && skip[F.sidx[p]]) continue;
+      if (gate_inv_sigma2) {
+        const float e2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        if ((double)__fmul_rn(e2, gate_inv_sigma2[oct]) > gate) continue;
+      }
+      const uint4* td = reinterpret_cast<const uint4*>(F.sdesc + (size_t)p * 32);
+      const uint4 a = td[0], b = td[1];
+      int d = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
+              __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
+      top2_insert(k1, k2, ((uint32_t)d << 16) | (uint32_t)p);
+    }
+  }
+  // top-2 of the row: xor-1, xor-2 inside quads, then half-row and row mirrors (the merged sets are disjoint)
+#define DVM_TOP2_STEP(CTRL)                                                              \
+  {                                                                                      \
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false); \
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false); \
+    const uint32_t n1 = min(k1, o1), n2 = min(max(k1, o1), min(k2, o2));                 \
+    k1 = n1; k2 = n2;                                                                    \
+  }
+  DVM_TOP2_STEP(0xB1)    // quad_perm [1,0,3,2]
+  DVM_TOP2_STEP(0x4E)    // quad_perm [2,3,0,1]
+  DVM_TOP2_STEP(0x141)   // row_half_mirror
+  DVM_TOP2_STEP(0x140)   // row_mirror
+#undef DVM_TOP2_STEP
+  k1_out = k1; k2_out = k2;
+}
+
 // Sixteen lanes (one DPP row) per query, four queries per wave: a window holds ~10 candidates out of the ~70 of its
 // grid columns, so a full wave per query left most lanes idle and paid a 6-step cross-lane reduction; a row reduces
 // its top-2 with four DPP steps and no LDS traffic.  QUERIES_FROM_KPS: queries are keypoints of another frame (frame-to-frame
@@ -146,53 +208,8 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
     x = qx[q]; y = qy[q]; r = qr[q];
     minLevel = qmin[q]; maxLevel = qmax[q];
   }
-  uint32_t k1 = (256u << 16) | 0xFFFFu, k2 = k1;
-  // GetFeaturesInArea cell rectangle (with the reference's early-outs)
-  const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
-  const int nMaxCellX = min(kGridCols - 1, (int)ceilf((x - F.minX + r) * F.wInv));
-  const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
-  const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - F.minY + r) * F.hInv));
-  const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
-  if (!empty && nMinCellX <= nMaxCellX) {
-    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
-    const uint32_t* qd = reinterpret_cast<const uint32_t*>(qdesc + (size_t)q * 32);
-    uint32_t w[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = qd[i];
-    const int beg = F.cellx_start[nMinCellX], end = F.cellx_start[nMaxCellX + 1];
-    for (int p = beg + lane; p < end; p += 16) {
-      const float4 kp = F.skp[p];
-      const int oct = __float_as_int(kp.z);
-      const int cell = __float_as_int(kp.w);
-      const int iy = cell % kGridRows;
-      if (iy < nMinCellY || iy > nMaxCellY) continue;
-      if (checkLevels) {
-        if (oct < minLevel) continue;
-        if (maxLevel >= 0 && oct > maxLevel) continue;
-      }
-      const float dx = kp.x - x, dy = kp.y - y;
-      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
-      if (skip && skip[F.sidx[p]]) continue;
-      const uint4* td = reinterpret_cast<const uint4*>(F.sdesc + (size_t)p * 32);
-      const uint4 a = td[0], b = td[1];
-      int d = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
-              __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
-      top2_insert(k1, k2, ((uint32_t)d << 16) | (uint32_t)p);
-    }
-  }
-  // top-2 of the row: xor-1, xor-2 inside quads, then half-row and row mirrors (the merged sets are disjoint)
-#define DVM_TOP2_STEP(CTRL)                                                              \
-  {                                                                                      \
-    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false); \
-    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false); \
-    const uint32_t n1 = min(k1, o1), n2 = min(max(k1, o1), min(k2, o2));                 \
-    k1 = n1; k2 = n2;                                                                    \
-  }
-  DVM_TOP2_STEP(0xB1)    // quad_perm [1,0,3,2]
-  DVM_TOP2_STEP(0x4E)    // quad_perm [2,3,0,1]
-  DVM_TOP2_STEP(0x141)   // row_half_mirror
-  DVM_TOP2_STEP(0x140)   // row_mirror
-#undef DVM_TOP2_STEP
+  uint32_t k1, k2;
+  window_top2(F, x, y, r, minLevel, maxLevel, qdesc + (size_t)q * 32, skip, nullptr, 0.0, lane, k1, k2);
   if (lane == 0) {
     dvm_match_pod m;
     const int p1 = (int)(k1 & 0xFFFFu), p2 = (int)(k2 & 0xFFFFu);
@@ -246,6 +263,123 @@ __global__ void __launch_bounds__(256) k_match_lists(const uint8_t* __restrict__
     m.best_level = -1;
     m.second_level = -1;
     out[q] = m;
+  }
+}
+
+// Projection of map points into a keyframe + windowed best-descriptor search: the common body of ORBmatcher::Fuse(KF, MPs)
+// (reference src/ORBmatcher.cc:1060-1234), Fuse(KF, Scw, ...) (:1236-1345), SearchByProjection(KF, Scw, ...) x2 (:395-603)
+// -- depth > 0, KeyFrame::IsInImage, distance inside the scale-invariance range, viewing angle < 60 deg
+// (PO.Pn >= 0.5 dist), MapPoint::PredictScale, radius = th * scaleFactor[level], candidates of octave [level-1, level],
+// optional per-candidate chi2 gate (Fuse).  One DPP row (16 lanes) per map point; every lane repeats the projection.
+__global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, const uint8_t* __restrict__ skip, ProjectCam C,
+                                                        const float* __restrict__ P, const float* __restrict__ normal,
+                                                        const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                                        const uint8_t* __restrict__ desc, const uint8_t* __restrict__ valid, int n,
+                                                        const float* __restrict__ scale_factors,
+                                                        const float* __restrict__ gate_inv_sigma2, double gate,
+                                                        dvm_match_pod* __restrict__ out, Projection* __restrict__ proj) {
+  const int lane = threadIdx.x & 15;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (i >= n) return;
+  const FrameView F = FB.slot(slot);
+  Projection pr;
+  pr.u = -1.f; pr.v = -1.f; pr.radius = 0.f; pr.level = -1;
+  bool ok = valid == nullptr || valid[i] != 0;
+  const float p0 = P[3 * i], p1 = P[3 * i + 1], p2 = P[3 * i + 2];
+  const float X = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(C.R[0], p0), __fmul_rn(C.R[1], p1)), __fmul_rn(C.R[2], p2)), C.t[0]);
+  const float Y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(C.R[3], p0), __fmul_rn(C.R[4], p1)), __fmul_rn(C.R[5], p2)), C.t[1]);
+  const float Z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(C.R[6], p0), __fmul_rn(C.R[7], p1)), __fmul_rn(C.R[8], p2)), C.t[2]);
+  ok = ok && !(Z < 0.0f);
+  const float u = __fadd_rn(__fdiv_rn(__fmul_rn(C.fx, X), Z), C.cx), v = __fadd_rn(__fdiv_rn(__fmul_rn(C.fy, Y), Z), C.cy);
+  ok = ok && (u >= C.min_x && u < C.max_x && v >= C.min_y && v < C.max_y);
+  if (ok) {
+    const float maxDistance = __fmul_rn(1.2f, max_dist[i]), minDistance = __fmul_rn(0.8f, min_dist[i]);
+    const float q0 = __fsub_rn(p0, C.Ow[0]), q1 = __fsub_rn(p1, C.Ow[1]), q2 = __fsub_rn(p2, C.Ow[2]);
+    const float dist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(q0, q0), __fmul_rn(q1, q1)), __fmul_rn(q2, q2)));
+    ok = !(dist < minDistance || dist > maxDistance);
+    if (ok) {
+      const float dot = __fadd_rn(__fadd_rn(__fmul_rn(q0, normal[3 * i]), __fmul_rn(q1, normal[3 * i + 1])), __fmul_rn(q2, normal[3 * i + 2]));
+      ok = !((double)dot < 0.5 * (double)dist);
+      if (ok) {
+        const float ratio = __fdiv_rn(max_dist[i], dist);
+        int nScale = (int)ceilf(__fdiv_rn(logf(ratio), C.log_scale_factor));
+        nScale = nScale < 0 ? 0 : (nScale >= C.n_levels ? C.n_levels - 1 : nScale);
+        pr.u = u; pr.v = v; pr.level = nScale; pr.radius = __fmul_rn(C.th, scale_factors[nScale]);
+      }
+    }
+  }
+  uint32_t k1 = (256u << 16) | 0xFFFFu, k2 = k1;
+  if (pr.level >= 0)   // uniform inside the row: all 16 lanes computed the same projection
+    window_top2(F, pr.u, pr.v, pr.radius, pr.level - 1, pr.level, desc + (size_t)i * 32, skip, gate_inv_sigma2, gate, lane, k1, k2);
+  if (lane == 0) {
+    dvm_match_pod m;
+    const int p1i = (int)(k1 & 0xFFFFu), p2i = (int)(k2 & 0xFFFFu);
+    m.best_dist = (int)(k1 >> 16);
+    m.second_dist = (int)(k2 >> 16);
+    m.best_idx = (m.best_dist < 256) ? F.sidx[p1i] : -1;
+    m.best_level = (m.best_dist < 256) ? (int16_t)__float_as_int(F.skp[p1i].z) : (int16_t)-1;
+    m.second_level = (m.second_dist < 256) ? (int16_t)__float_as_int(F.skp[p2i].z) : (int16_t)-1;
+    out[i] = m;
+    if (proj) proj[i] = pr;
+  }
+}
+
+// ORBmatcher::SearchForTriangulation inner loop (reference src/ORBmatcher.cc:905-998, monocular): query q = keypoint
+// qidx[q] of KF1 scans KF2 keypoints cand[off[q] .. off[q+1]) (its vocabulary node's features that are neither matched
+// nor carry a map point); a candidate is taken if dist <= TH_LOW, dist <= the best so far, it is not within
+// 100*scaleFactor[octave] (squared px) of the epipole, and (bCoarse or) Pinhole::epipolarConstrain holds
+// (CameraModels/Pinhole.cpp:104-127).  The reference never sets vbMatched2, so queries are independent; within a query the
+// sequential rule "<= replaces" is "minimum distance, LAST position wins a tie" = min over (dist << 16 | 0xFFFF - pos).
+__global__ void __launch_bounds__(256) k_match_triangulation(const uint8_t* __restrict__ desc1, const dvm_keypoint_pod* __restrict__ kps1,
+                                                             const int32_t* __restrict__ qidx, int nq,
+                                                             const uint8_t* __restrict__ desc2, const dvm_keypoint_pod* __restrict__ kps2,
+                                                             const int32_t* __restrict__ off, const int32_t* __restrict__ cand, TriGeom G,
+                                                             const float* __restrict__ scale_factors2,
+                                                             const float* __restrict__ level_sigma2_2, int32_t* __restrict__ best_idx,
+                                                             int32_t* __restrict__ best_dist) {
+  const int lane = threadIdx.x & 15;
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (q >= nq) return;
+  const int idx1 = qidx[q];
+  const uint32_t* qd = reinterpret_cast<const uint32_t*>(desc1 + (size_t)idx1 * 32);
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = qd[i];
+  const float x1 = kps1[idx1].x, y1 = kps1[idx1].y;
+  // epipolar line in the second image l = x1' F12 = [a b c]
+  const float a = __fadd_rn(__fadd_rn(__fmul_rn(x1, G.F12[0]), __fmul_rn(y1, G.F12[3])), G.F12[6]);
+  const float b = __fadd_rn(__fadd_rn(__fmul_rn(x1, G.F12[1]), __fmul_rn(y1, G.F12[4])), G.F12[7]);
+  const float c = __fadd_rn(__fadd_rn(__fmul_rn(x1, G.F12[2]), __fmul_rn(y1, G.F12[5])), G.F12[8]);
+  const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+  const int beg = off[q], end = off[q + 1];
+  uint32_t k = 0xFFFFFFFFu;
+  for (int p = beg + lane; p < end; p += 16) {
+    const int idx2 = cand[p];
+    if (idx2 < 0) continue;
+    const uint4* td = reinterpret_cast<const uint4*>(desc2 + (size_t)idx2 * 32);
+    const uint4 A = td[0], B = td[1];
+    const int d = __popc(A.x ^ w[0]) + __popc(A.y ^ w[1]) + __popc(A.z ^ w[2]) + __popc(A.w ^ w[3]) +
+                  __popc(B.x ^ w[4]) + __popc(B.y ^ w[5]) + __popc(B.z ^ w[6]) + __popc(B.w ^ w[7]);
+    if (d > G.th_low) continue;
+    const dvm_keypoint_pod kp2 = kps2[idx2];
+    const float distex = __fsub_rn(G.ep[0], kp2.x), distey = __fsub_rn(G.ep[1], kp2.y);
+    if (__fadd_rn(__fmul_rn(distex, distex), __fmul_rn(distey, distey)) < __fmul_rn(100.f, scale_factors2[kp2.octave])) continue;
+    if (!G.coarse) {
+      const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, kp2.x), __fmul_rn(b, kp2.y)), c);
+      if (den == 0.f) continue;
+      const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+      if (!((double)dsqr < 3.84 * (double)level_sigma2_2[kp2.octave])) continue;
+    }
+    k = min(k, ((uint32_t)d << 16) | (uint32_t)(0xFFFF - (p - beg)));
+  }
+  k = min(k, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k, 0xB1, 0xF, 0xF, false));
+  k = min(k, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k, 0x4E, 0xF, 0xF, false));
+  k = min(k, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k, 0x141, 0xF, 0xF, false));
+  k = min(k, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k, 0x140, 0xF, 0xF, false));
+  if (lane == 0) {
+    const bool hit = k != 0xFFFFFFFFu;
+    best_idx[q] = hit ? cand[beg + (0xFFFF - (int)(k & 0xFFFFu))] : -1;
+    best_dist[q] = hit ? (int)(k >> 16) : 256;
   }
 }
 
@@ -322,6 +456,20 @@ void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, 
 void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,
                         int nq, dvm_match_pod* out) {
   hipLaunchKernelGGL(k_match_lists, dim3((nq + 3) / 4), dim3(256), 0, s, tdesc, qdesc, off, cand, nq, out);
+}
+void launch_project_search(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const ProjectCam& C, const float* P,
+                           const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc,
+                           const uint8_t* valid, int n, const float* scale_factors, const float* gate_inv_sigma2, double gate,
+                           dvm_match_pod* out, Projection* proj) {
+  hipLaunchKernelGGL(k_project_search, dim3((n + 15) / 16), dim3(256), 0, s, F, slot, skip, C, P, normal, min_dist, max_dist, desc,
+                     valid, n, scale_factors, gate_inv_sigma2, gate, out, proj);
+}
+void launch_match_triangulation(hipStream_t s, const uint8_t* desc1, const dvm_keypoint_pod* kps1, const int32_t* qidx, int nq,
+                                const uint8_t* desc2, const dvm_keypoint_pod* kps2, const int32_t* off, const int32_t* cand,
+                                const TriGeom& G, const float* scale_factors2, const float* level_sigma2_2, int32_t* best_idx,
+                                int32_t* best_dist) {
+  hipLaunchKernelGGL(k_match_triangulation, dim3((nq + 15) / 16), dim3(256), 0, s, desc1, kps1, qidx, nq, desc2, kps2, off, cand, G,
+                     scale_factors2, level_sigma2_2, best_idx, best_dist);
 }
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D) {
   hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 63) / 64, (nA + 3) / 4), dim3(256), 0, s, A, nA, B, nB, D);

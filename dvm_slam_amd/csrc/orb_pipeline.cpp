@@ -259,6 +259,7 @@ OrbPipeline::~OrbPipeline() {
   for (int c = 0; c < kMaxChunks; c++)
     for (hipEvent_t e : {ev_compact[c], ev_fork[c], ev_join[c]})
       if (e) hipEventDestroy(e);
+  for (hipEvent_t e : ev_group) if (e) hipEventDestroy(e);
   if (ev_start) hipEventDestroy(ev_start);
   if (ev_done) hipEventDestroy(ev_done);
   if (stream) hipStreamDestroy(stream);
@@ -277,16 +278,21 @@ int OrbPipeline::init() {
   DVM_HIP(hipSetDevice(device));
   DVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   lane_main[0] = stream;
-  DVM_HIP(hipStreamCreateWithFlags(&lane_main[1], hipStreamNonBlocking));
   {  // side streams at the LOWEST priority: their kernels (the blur) only fill what the main chain leaves idle
     int least = 0, greatest = 0;
     DVM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     DVM_HIP(hipStreamCreateWithPriority(&lane_side[0], hipStreamNonBlocking, least));
     DVM_HIP(hipStreamCreateWithPriority(&lane_side[1], hipStreamNonBlocking, least));
+    // NOTE: four streams in total -- the runtime multiplexes streams onto 4 hardware queues per device, and a fifth
+    // stream made the main chain share a queue with the background blur (every stage ~2x slower when measured).
+    DVM_HIP(hipStreamCreateWithFlags(&lane_main[1], hipStreamNonBlocking));
+    (void)greatest;
   }
   if (const char* e = getenv("DVM_BLUR_EARLY")) blur_early = (e[0] == '1');
+  if (const char* e = getenv("DVM_GROUPS")) sscanf(e, "%d,%d", &group_split[0], &group_split[1]);
   DVM_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
   DVM_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+  for (int g = 0; g < 4; g++) DVM_HIP(hipEventCreateWithFlags(&ev_group[g], hipEventDisableTiming));
   for (int c = 0; c < kMaxChunks; c++) {
     DVM_HIP(hipEventCreateWithFlags(&ev_compact[c], hipEventDisableTiming));
     DVM_HIP(hipEventCreateWithFlags(&ev_fork[c], hipEventDisableTiming));
@@ -556,8 +562,34 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       prof.end(side);
       DVM_HIP(hipEventRecord(ev_join[ck], side));
     }
-    prof.begin(st, "fast");
-    launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, 0, PD.ncells);
+    // FAST and the octree, pipelined over level groups: a level's octree (a latency chain of small scans and one
+    // wavefront sort) needs that level's FAST cells only, so it runs on the auxiliary stream while the main stream is
+    // already on the FAST cells of the next group; only the last group's octree is left after FAST has finished.
+    //   main: FAST(G0) | FAST(G1) | FAST(G2) octree(G2) ... wait aux
+    //   aux :            octree(G0) | octree(G1)
+    hipStream_t aux = lane_main[st == lane_main[0] ? 1 : 0];
+    const bool grouped = overlap_blur && !host_octree && chunks == 1 && aux != nullptr && group_split[0] < L;
+    const int g_a = std::min(std::max(group_split[0], 0), L), g_b = std::min(std::max(group_split[1], g_a), L);
+    const int gl[4] = {0, grouped ? g_a : L, grouped ? g_b : L, L};   // level groups [gl[i], gl[i+1])
+    uint32_t* dense_f0 = d_dense + (size_t)f0 * PD.cand_frame_slots;
+    int32_t* lcnt_f0 = d_lvl_count + (size_t)f0 * kMaxLevels;
+    int32_t* nid_f0 = d_nid + (size_t)f0 * PD.cand_frame_slots;
+    uint32_t* sel_f0 = d_sel + (size_t)f0 * PD.sel_frame_slots;
+    int32_t* nsel_f0 = d_nsel + (size_t)f0 * L;
+    int oct_main_first = 0;   // levels below this one have their octree on the auxiliary stream
+    prof.begin(st, "fast");   // one bracket over the (up to three) k_fast_cells launches of the batch
+    for (int gi = 0; gi < 3; gi++) {
+      const int la = gl[gi], lb = gl[gi + 1];
+      if (la >= lb) continue;
+      const int c_first = PD.lv[la].cell_first, c_end = PD.lv[lb - 1].cell_first + PD.lv[lb - 1].cell_count;
+      launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, c_first, c_end - c_first);
+      if (grouped && lb < L) {
+        DVM_HIP(hipEventRecord(ev_group[gi], st));
+        DVM_HIP(hipStreamWaitEvent(aux, ev_group[gi], 0));
+        launch_octree(aux, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, lb - la);
+        oct_main_first = lb;
+      }
+    }
     prof.end(st);
     DVM_HIP(hipEventRecord(ev_compact[ck], st));   // this chunk has left the throughput-bound stages
     if (blur_forked && !blur_early) {
@@ -569,9 +601,13 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       DVM_HIP(hipEventRecord(ev_join[ck], side));
     }
     if (!host_octree) {
-      prof.begin(st, "octree");
-      launch_octree(st, cand_f0, cnt_f0, d_cells, (d_dense + (size_t)f0 * PD.cand_frame_slots), (d_lvl_count + (size_t)f0 * kMaxLevels), PD,
-                    (d_nid + (size_t)f0 * PD.cand_frame_slots), (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), d_err, nb, 0, L);
+      prof.begin(st, "octree");   // the part of the octree work that is NOT hidden behind FAST
+      const int la = oct_main_first;
+      launch_octree(st, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, L - la);
+      if (oct_main_first > 0) {
+        DVM_HIP(hipEventRecord(ev_group[3], aux));
+        DVM_HIP(hipStreamWaitEvent(st, ev_group[3], 0));
+      }
       prof.end(st);
     } else {
     // ---- DistributeOctTree on the host (K3): per-cell candidate lists -> vToDistributeKeys per level -> octree_select

@@ -62,6 +62,12 @@ class OrbPipeline {
   // throughput-bound stages (pyramid, FAST), so they overlap chunk c's latency-bound k_octree.
   static constexpr int kMaxChunks = 8;
   hipStream_t lane_main[2] = {nullptr, nullptr}, lane_side[2] = {nullptr, nullptr};
+  // Optional FAST / octree pipelining over level groups [0,a) [a,b) [b,L) (DVM_GROUPS=a,b): the octree of a group runs
+  // on lane_main[1] under the FAST cells of the next group.  Measured 1.56 vs 1.58 ms per 256-frame step (the octree is
+  // VALU work too, only its latency hides), so the default stays ONE k_fast_cells launch per batch -- which is also what
+  // the roofline line of bench.py and the rocprofv3 summary describe.
+  int group_split[2] = {kMaxLevels, kMaxLevels};
+  hipEvent_t ev_group[4] = {};   // FAST level group g done (0..2) / auxiliary-stream octrees done (3)
   hipEvent_t ev_start = nullptr, ev_compact[kMaxChunks] = {}, ev_fork[kMaxChunks] = {}, ev_join[kMaxChunks] = {}, ev_done = nullptr;
   int chunks = 1;            // DVM_CHUNKS=n; measured on MI355X at batch 256: 1 -> 1.82 ms, 2 -> 1.93 ms, 4 -> 2.11 ms per
                              // step (concurrent queues do not recover the k_octree idle time), so the default is off

@@ -2,6 +2,7 @@
 #include "orb_matcher.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 
@@ -15,12 +16,13 @@ struct HostGrid {
   std::vector<int> cell[kCols][kRows];
   float minX, minY, wInv, hInv;
   const dvm_keypoint* kps;
-  void build(const FrameView& F) {
-    kps = F.mvKeysUn;
-    minX = F.mnMinX; minY = F.mnMinY;
-    wInv = static_cast<float>(kCols) / static_cast<float>(F.mnMaxX - F.mnMinX);
-    hInv = static_cast<float>(kRows) / static_cast<float>(F.mnMaxY - F.mnMinY);
-    for (int i = 0; i < F.N; i++) {
+  void build(const FrameView& F) { build(F.mvKeysUn, F.N, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY); }
+  void build(const dvm_keypoint* k, int N, float mnMinX, float mnMaxX, float mnMinY, float mnMaxY) {
+    kps = k;
+    minX = mnMinX; minY = mnMinY;
+    wInv = static_cast<float>(kCols) / static_cast<float>(mnMaxX - mnMinX);
+    hInv = static_cast<float>(kRows) / static_cast<float>(mnMaxY - mnMinY);
+    for (int i = 0; i < N; i++) {
       const int px = (int)std::round((kps[i].x - minX) * wInv), py = (int)std::round((kps[i].y - minY) * hInv);
       if (px < 0 || px >= kCols || py < 0 || py >= kRows) continue;
       cell[px][py].push_back(i);
@@ -256,6 +258,418 @@ int ORBmatcher::SearchByProjection(FrameView& F, const TrackedPointPOD* MPs, int
   return nmatches;
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// the remaining whole functions of ORBmatcher.  Pattern: everything that is a descriptor
+// distance runs on the device in ONE batched call (Hamming table / candidate-list search / projection + window search /
+// triangulation search); the reference's sequential bookkeeping (claims, mutual best, rotation histogram) is replayed
+// on the host in the reference's order, and a query whose device result was computed with a candidate that an earlier
+// query claimed meanwhile is re-evaluated over its (short) candidate list.
+// --------------------------------------------------------------------------------------------------------------------
+namespace {
+int RotBin(float a1, float a2) {
+  const float factor = 1.0f / ORBmatcher::HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == ORBmatcher::HISTO_LENGTH) bin = 0;
+  return bin;
+}
+int LowerBound(const FeatureVectorView& fv, int from, int key) { return (int)(std::lower_bound(fv.node + from, fv.node + fv.n, key) - fv.node); }
+
+// Walk two FeatureVectors like the while loops of :232-364 / :735-818 / :890-1031 and call f(a, b) for every common node.
+template <class Fn>
+void ForEachCommonNode(const FeatureVectorView& A, const FeatureVectorView& B, Fn f) {
+  int a = 0, b = 0;
+  while (a < A.n && b < B.n) {
+    if (A.node[a] == B.node[b]) { f(a, b); a++; b++; }
+    else if (A.node[a] < B.node[b]) a = LowerBound(A, a, B.node[b]);
+    else b = LowerBound(B, b, A.node[a]);
+  }
+}
+}  // namespace
+
+int ORBmatcher::SearchForInitialization(const FrameView& F1, const FrameView& F2, float* vbPrevMatched, int32_t* vnMatches12,
+                                        int windowSize) {
+  int nmatches = 0;
+  for (int i = 0; i < F1.N; i++) vnMatches12[i] = -1;
+  // level-0 keypoints of both frames (level1 > 0 -> continue; GetFeaturesInArea(.., level1, level1) keeps octave 0 only)
+  std::vector<int> rows, col_of(F2.N, -1);
+  std::vector<uint8_t> d1, d2;
+  for (int i = 0; i < F1.N; i++)
+    if (F1.mvKeysUn[i].octave <= 0) { rows.push_back(i); d1.insert(d1.end(), F1.mDescriptors + 32 * (size_t)i, F1.mDescriptors + 32 * (size_t)i + 32); }
+  int ncol = 0;
+  for (int j = 0; j < F2.N; j++)
+    if (F2.mvKeysUn[j].octave == 0) { col_of[j] = ncol++; d2.insert(d2.end(), F2.mDescriptors + 32 * (size_t)j, F2.mDescriptors + 32 * (size_t)j + 32); }
+  if (rows.empty() || ncol == 0) return 0;
+  std::vector<uint16_t> D((size_t)rows.size() * ncol);
+  int rc = dvm_hamming_matrix(d1.data(), (int)rows.size(), d2.data(), ncol, D.data(), 0, nullptr);
+  if (rc != DVM_OK) return rc;
+
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (auto& h : rotHist) h.reserve(500);
+  std::vector<int> vMatchedDistance(F2.N, INT32_MAX), vnMatches21(F2.N, -1);
+  HostGrid hg;
+  hg.build(F2);
+  std::vector<int> vIndices2;
+  for (size_t r = 0; r < rows.size(); r++) {
+    const int i1 = rows[r];
+    const int level1 = F1.mvKeysUn[i1].octave;
+    hg.query(vbPrevMatched[2 * i1], vbPrevMatched[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+    if (vIndices2.empty()) continue;
+    const uint16_t* Drow = &D[r * (size_t)ncol];
+    int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      const int dist = Drow[col_of[i2]];
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * mfNNratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (mbCheckOrientation) rotHist[RotBin(F1.mvKeysUn[i1].angle, F2.mvKeysUn[bestIdx2].angle)].push_back(i1);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < F1.N; i1++)
+    if (vnMatches12[i1] >= 0) { vbPrevMatched[2 * i1] = F2.mvKeysUn[vnMatches12[i1]].x; vbPrevMatched[2 * i1 + 1] = F2.mvKeysUn[vnMatches12[i1]].y; }
+  return nmatches;
+}
+
+int ORBmatcher::SearchByBoW(const KeyFrameView& KF, const FrameView& F, const FeatureVectorView& Ffv, int32_t* vpMapPointMatches) {
+  for (int i = 0; i < F.N; i++) vpMapPointMatches[i] = -1;
+  last_requeried = 0;
+  // queries in walk order; the candidate list of a query is its node's feature list in F (CSR into Ffv.feat)
+  std::vector<int> qkf, qnodeF;
+  std::vector<int32_t> off(1, 0), cand;
+  std::vector<uint8_t> qdesc;
+  ForEachCommonNode(KF.mFeatVec, Ffv, [&](int a, int b) {
+    for (int k = KF.mFeatVec.off[a]; k < KF.mFeatVec.off[a + 1]; k++) {
+      const int realIdxKF = KF.mFeatVec.feat[k];
+      if (KF.mvpMapPoints[realIdxKF] < 0) continue;
+      if (KF.mpBad && KF.mpBad[realIdxKF]) continue;
+      qkf.push_back(realIdxKF); qnodeF.push_back(b);
+      qdesc.insert(qdesc.end(), KF.mDescriptors + 32 * (size_t)realIdxKF, KF.mDescriptors + 32 * (size_t)realIdxKF + 32);
+      cand.insert(cand.end(), Ffv.feat + Ffv.off[b], Ffv.feat + Ffv.off[b + 1]);
+      off.push_back((int32_t)cand.size());
+    }
+  });
+  const int nq = (int)qkf.size();
+  if (nq == 0) return 0;
+  std::vector<dvm_match> res(nq);
+  int rc = dvm_match_lists(F.mDescriptors, F.N, qdesc.data(), nq, off.data(), cand.data(), res.data(), 0, nullptr);
+  if (rc != DVM_OK) return rc;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (auto& h : rotHist) h.reserve(500);
+  for (int q = 0; q < nq; q++) {
+    int bestDist1 = res[q].best_dist, bestDist2 = res[q].second_dist, bestIdxF = res[q].best_idx;
+    bool touched = false;
+    for (int p = off[q]; p < off[q + 1] && !touched; p++) touched = vpMapPointMatches[cand[p]] >= 0;
+    if (touched) {   // a feature of this node was matched by an earlier query: it is skipped by this one (:265-266)
+      last_requeried++;
+      bestDist1 = 256; bestDist2 = 256; bestIdxF = -1;
+      for (int p = off[q]; p < off[q + 1]; p++) {
+        const int realIdxF = cand[p];
+        if (vpMapPointMatches[realIdxF] >= 0) continue;
+        const int dist = DescriptorDistance(&qdesc[32 * (size_t)q], F.mDescriptors + 32 * (size_t)realIdxF);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+    }
+    if (bestDist1 <= TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        vpMapPointMatches[bestIdxF] = KF.mvpMapPoints[qkf[q]];
+        if (mbCheckOrientation) rotHist[RotBin(KF.mvKeysUn[qkf[q]].angle, F.mvKeysUn[bestIdxF].angle)].push_back(bestIdxF);
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { vpMapPointMatches[idx] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+int ORBmatcher::SearchByBoW(const KeyFrameView& KF1, const KeyFrameView& KF2, int32_t* vpMatches12) {
+  for (int i = 0; i < KF1.N; i++) vpMatches12[i] = -1;
+  last_requeried = 0;
+  std::vector<int> q1;
+  std::vector<int32_t> off(1, 0), cand;
+  std::vector<uint8_t> qdesc;
+  ForEachCommonNode(KF1.mFeatVec, KF2.mFeatVec, [&](int a, int b) {
+    for (int k = KF1.mFeatVec.off[a]; k < KF1.mFeatVec.off[a + 1]; k++) {
+      const int idx1 = KF1.mFeatVec.feat[k];
+      if (KF1.mvpMapPoints[idx1] < 0) continue;
+      if (KF1.mpBad && KF1.mpBad[idx1]) continue;
+      q1.push_back(idx1);
+      qdesc.insert(qdesc.end(), KF1.mDescriptors + 32 * (size_t)idx1, KF1.mDescriptors + 32 * (size_t)idx1 + 32);
+      for (int k2 = KF2.mFeatVec.off[b]; k2 < KF2.mFeatVec.off[b + 1]; k2++) {
+        const int idx2 = KF2.mFeatVec.feat[k2];
+        if (KF2.mvpMapPoints[idx2] < 0) continue;            // !pMP2
+        if (KF2.mpBad && KF2.mpBad[idx2]) continue;           // pMP2->isBad()
+        cand.push_back(idx2);
+      }
+      off.push_back((int32_t)cand.size());
+    }
+  });
+  const int nq = (int)q1.size();
+  if (nq == 0) return 0;
+  std::vector<dvm_match> res(nq);
+  int rc = dvm_match_lists(KF2.mDescriptors, KF2.N, qdesc.data(), nq, off.data(), cand.data(), res.data(), 0, nullptr);
+  if (rc != DVM_OK) return rc;
+  int nmatches = 0;
+  std::vector<uint8_t> vbMatched2(KF2.N, 0);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (auto& h : rotHist) h.reserve(500);
+  for (int q = 0; q < nq; q++) {
+    int bestDist1 = res[q].best_dist, bestDist2 = res[q].second_dist, bestIdx2 = res[q].best_idx;
+    bool touched = false;
+    for (int p = off[q]; p < off[q + 1] && !touched; p++) touched = vbMatched2[cand[p]] != 0;
+    if (touched) {
+      last_requeried++;
+      bestDist1 = 256; bestDist2 = 256; bestIdx2 = -1;
+      for (int p = off[q]; p < off[q + 1]; p++) {
+        const int idx2 = cand[p];
+        if (vbMatched2[idx2]) continue;
+        const int dist = DescriptorDistance(&qdesc[32 * (size_t)q], KF2.mDescriptors + 32 * (size_t)idx2);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+    }
+    if (bestDist1 < TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        vpMatches12[q1[q]] = KF2.mvpMapPoints[bestIdx2];
+        vbMatched2[bestIdx2] = 1;
+        if (mbCheckOrientation) rotHist[RotBin(KF1.mvKeysUn[q1[q]].angle, KF2.mvKeysUn[bestIdx2].angle)].push_back(q1[q]);
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { vpMatches12[idx] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+void ORBmatcher::TriangulationGeometry(const KeyFrameView& KF1, const KeyFrameView& KF2, float* R12, float* t12, float* ep, float* F12) {
+  auto mul = [](const float* A, const float* B, float* C) {
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+  };
+  const float *R1w = KF1.Rcw, *t1w = KF1.tcw, *R2w = KF2.Rcw, *t2w = KF2.tcw;
+  float Cw[3], C2[3];   // Cw = KF1 camera centre; C2 = T2w * Cw; ep = pKF2->mpCamera->project(C2)
+  for (int r = 0; r < 3; r++) Cw[r] = -((R1w[r] * t1w[0] + R1w[3 + r] * t1w[1]) + R1w[6 + r] * t1w[2]);
+  for (int r = 0; r < 3; r++) C2[r] = ((R2w[3 * r] * Cw[0] + R2w[3 * r + 1] * Cw[1]) + R2w[3 * r + 2] * Cw[2]) + t2w[r];
+  ep[0] = KF2.fx * C2[0] / C2[2] + KF2.cx;
+  ep[1] = KF2.fy * C2[1] / C2[2] + KF2.cy;
+  float R2wT[9];   // T12 = T1w * Tw2
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) R2wT[3 * r + c] = R2w[3 * c + r];
+  mul(R1w, R2wT, R12);
+  for (int r = 0; r < 3; r++) t12[r] = t1w[r] - ((R12[3 * r] * t2w[0] + R12[3 * r + 1] * t2w[1]) + R12[3 * r + 2] * t2w[2]);
+  // F12 = K1^-T [t12]x R12 K2^-1 (Pinhole::epipolarConstrain), K^-1 in closed form
+  const float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
+  const float K1invT[9] = {1.f / KF1.fx, 0.f, 0.f, 0.f, 1.f / KF1.fy, 0.f, -KF1.cx / KF1.fx, -KF1.cy / KF1.fy, 1.f};
+  const float K2inv[9] = {1.f / KF2.fx, 0.f, -KF2.cx / KF2.fx, 0.f, 1.f / KF2.fy, -KF2.cy / KF2.fy, 0.f, 0.f, 1.f};
+  float A[9], B[9];
+  mul(K1invT, t12x, A);
+  mul(A, R12, B);
+  mul(B, K2inv, F12);
+}
+
+int ORBmatcher::SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameView& KF2, int32_t* vMatchedPairs, bool bOnlyStereo,
+                                       bool bCoarse) {
+  if (bOnlyStereo) return 0;   // monocular keyframes have no stereo keypoints (mvuRight < 0): every idx1 is skipped (:896-898)
+  float R12[9], t12[3], ep[2], F12[9];
+  TriangulationGeometry(KF1, KF2, R12, t12, ep, F12);
+  std::vector<int32_t> qidx, off(1, 0), cand;
+  ForEachCommonNode(KF1.mFeatVec, KF2.mFeatVec, [&](int a, int b) {
+    for (int k = KF1.mFeatVec.off[a]; k < KF1.mFeatVec.off[a + 1]; k++) {
+      const int idx1 = KF1.mFeatVec.feat[k];
+      if (KF1.mvpMapPoints[idx1] >= 0) continue;   // already a MapPoint
+      qidx.push_back(idx1);
+      for (int k2 = KF2.mFeatVec.off[b]; k2 < KF2.mFeatVec.off[b + 1]; k2++) {
+        const int idx2 = KF2.mFeatVec.feat[k2];
+        if (KF2.mvpMapPoints[idx2] >= 0) continue;
+        cand.push_back(idx2);
+      }
+      off.push_back((int32_t)cand.size());
+    }
+  });
+  const int nq = (int)qidx.size();
+  if (nq == 0) return 0;
+  std::vector<int32_t> bi(nq), bd(nq);
+  int rc = dvm_match_triangulation(KF1.mDescriptors, KF1.mvKeysUn, KF1.N, qidx.data(), nq, KF2.mDescriptors, KF2.mvKeysUn, KF2.N,
+                                   off.data(), cand.data(), F12, ep, bCoarse ? 1 : 0, KF2.mvScaleFactors, KF2.mvLevelSigma2, KF2.nLevels,
+                                   bi.data(), bd.data(), 0, nullptr);
+  if (rc != DVM_OK) return rc;
+  int nmatches = 0;
+  std::vector<int> vMatches12(KF1.N, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (auto& h : rotHist) h.reserve(500);
+  for (int q = 0; q < nq; q++) {
+    if (bi[q] < 0) continue;
+    vMatches12[qidx[q]] = bi[q];
+    nmatches++;
+    if (mbCheckOrientation) rotHist[RotBin(KF1.mvKeysUn[qidx[q]].angle, KF2.mvKeysUn[bi[q]].angle)].push_back(qidx[q]);
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { vMatches12[idx] = -1; nmatches--; }
+    }
+  }
+  int k = 0;
+  for (int i = 0; i < KF1.N; i++)
+    if (vMatches12[i] >= 0) { vMatchedPairs[2 * k] = i; vMatchedPairs[2 * k + 1] = vMatches12[i]; k++; }
+  return nmatches;
+}
+
+int ORBmatcher::ensure_grid(const KeyFrameView& KF) {
+  FrameView F;
+  F.N = KF.N; F.mvKeysUn = KF.mvKeysUn; F.mDescriptors = KF.mDescriptors;
+  F.mnMinX = KF.mnMinX; F.mnMaxX = KF.mnMaxX; F.mnMinY = KF.mnMinY; F.mnMaxY = KF.mnMaxY;
+  return ensure_grid(F);
+}
+
+int ORBmatcher::project_search(const KeyFrameView& KF, const float* Rcw, const float* tcw, const float* Ow, const MapPointsView& P,
+                               const uint8_t* valid, const uint8_t* skip, float th, bool gate, std::vector<dvm_match>& res,
+                               std::vector<dvm_projection>& proj) {
+  int rc = ensure_grid(KF);
+  if (rc != DVM_OK) return rc;
+  dvm_kf_camera cam;
+  std::memcpy(cam.Rcw, Rcw, 36); std::memcpy(cam.tcw, tcw, 12); std::memcpy(cam.Ow, Ow, 12);
+  cam.fx = KF.fx; cam.fy = KF.fy; cam.cx = KF.cx; cam.cy = KF.cy;
+  cam.min_x = KF.mnMinX; cam.max_x = KF.mnMaxX; cam.min_y = KF.mnMinY; cam.max_y = KF.mnMaxY;
+  cam.log_scale_factor = KF.mfLogScaleFactor; cam.n_levels = KF.nLevels;
+  res.resize(P.n); proj.resize(P.n);
+  std::vector<uint8_t> skip_cap;
+  if (skip) { skip_cap.assign(grid_cap_, 0); std::memcpy(skip_cap.data(), skip, KF.N); }
+  return dvm_project_search(grid_, 0, skip ? skip_cap.data() : nullptr, &cam, P.pos, P.normal, P.min_dist, P.max_dist, P.desc, valid, P.n,
+                            th, KF.mvScaleFactors, gate ? KF.mvInvLevelSigma2 : nullptr, 5.99, res.data(), proj.data(), 0, nullptr);
+}
+
+int ORBmatcher::Fuse(const KeyFrameView& KF, const MapPointsView& P, const uint8_t* inKF, float th, int32_t* vBestIdx) {
+  if (P.n == 0) return 0;
+  std::vector<uint8_t> valid(P.n, 1);
+  for (int i = 0; i < P.n; i++)
+    if ((P.id && P.id[i] < 0) || (P.bad && P.bad[i]) || (inKF && inKF[i])) valid[i] = 0;   // !pMP, isBad(), IsInKeyFrame(pKF)
+  std::vector<dvm_match> res;
+  std::vector<dvm_projection> proj;
+  int rc = project_search(KF, KF.Rcw, KF.tcw, KF.Ow, P, valid.data(), nullptr, th, true, res, proj);
+  if (rc != DVM_OK) return rc;
+  int nFused = 0;
+  for (int i = 0; i < P.n; i++) {
+    vBestIdx[i] = -1;
+    if (valid[i] && res[i].best_idx >= 0 && res[i].best_dist <= TH_LOW) { vBestIdx[i] = res[i].best_idx; nFused++; }
+  }
+  return nFused;
+}
+
+namespace {
+void DecomposeSim3(const Sim3View& S, float* tcw, float* Ow) {   // Tcw = SE3f(R, t / s); Ow = Tcw.inverse().translation()
+  for (int r = 0; r < 3; r++) tcw[r] = S.t[r] / S.s;
+  for (int r = 0; r < 3; r++) Ow[r] = -((S.R[r] * tcw[0] + S.R[3 + r] * tcw[1]) + S.R[6 + r] * tcw[2]);
+}
+}  // namespace
+
+int ORBmatcher::Fuse(KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& P, float th, int32_t* vpReplacePoint) {
+  if (P.n == 0) return 0;
+  float tcw[3], Ow[3];
+  DecomposeSim3(Scw, tcw, Ow);
+  std::vector<int32_t> already(KF.mvpMapPoints, KF.mvpMapPoints + KF.N);   // spAlreadyFound = pKF->GetMapPoints()
+  std::sort(already.begin(), already.end());
+  std::vector<uint8_t> valid(P.n, 1);
+  for (int i = 0; i < P.n; i++) {
+    vpReplacePoint[i] = -1;
+    if ((P.bad && P.bad[i]) || std::binary_search(already.begin(), already.end(), P.id[i])) valid[i] = 0;
+  }
+  std::vector<dvm_match> res;
+  std::vector<dvm_projection> proj;
+  int rc = project_search(KF, Scw.R, tcw, Ow, P, valid.data(), nullptr, th, false, res, proj);
+  if (rc != DVM_OK) return rc;
+  int nFused = 0;
+  std::vector<uint8_t> fresh(KF.N, 0);
+  for (int i = 0; i < P.n; i++) {
+    if (!valid[i] || res[i].best_idx < 0 || res[i].best_dist > TH_LOW) continue;
+    const int bestIdx = res[i].best_idx;
+    const int pMPinKF = KF.mvpMapPoints[bestIdx];
+    if (pMPinKF >= 0) {
+      if (fresh[bestIdx] || !(KF.mpBad && KF.mpBad[bestIdx])) vpReplacePoint[i] = pMPinKF;
+    } else {
+      KF.mvpMapPoints[bestIdx] = P.id[i];   // pMP->AddObservation(pKF, bestIdx); pKF->AddMapPoint(pMP, bestIdx)
+      fresh[bestIdx] = 1;
+    }
+    nFused++;
+  }
+  return nFused;
+}
+
+int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& P, int32_t* vpMatched, int th,
+                                   float ratioHamming) {
+  if (P.n == 0) return 0;
+  last_requeried = 0;
+  float tcw[3], Ow[3];
+  DecomposeSim3(Scw, tcw, Ow);
+  std::vector<int32_t> already(vpMatched, vpMatched + KF.N);   // spAlreadyFound (fixed at entry)
+  std::sort(already.begin(), already.end());
+  std::vector<uint8_t> valid(P.n, 1), skip(KF.N, 0);
+  for (int i = 0; i < P.n; i++)
+    if ((P.bad && P.bad[i]) || (P.id[i] >= 0 && std::binary_search(already.begin(), already.end(), P.id[i]))) valid[i] = 0;
+  for (int j = 0; j < KF.N; j++) skip[j] = vpMatched[j] >= 0;
+  std::vector<dvm_match> res;
+  std::vector<dvm_projection> proj;
+  int rc = project_search(KF, Scw.R, tcw, Ow, P, valid.data(), skip.data(), (float)th, false, res, proj);
+  if (rc != DVM_OK) return rc;
+  int nmatches = 0;
+  HostGrid hg;
+  bool hg_built = false;
+  std::vector<int> cand;
+  for (int i = 0; i < P.n; i++) {
+    if (!valid[i] || proj[i].level < 0) continue;
+    int bestIdx = res[i].best_idx, bestDist = res[i].best_dist;
+    if (bestIdx >= 0 && vpMatched[bestIdx] >= 0) {   // claimed by an earlier point of this call: search again without it
+      if (!hg_built) { hg.build(KF.mvKeysUn, KF.N, KF.mnMinX, KF.mnMaxX, KF.mnMinY, KF.mnMaxY); hg_built = true; }
+      last_requeried++;
+      hg.query(proj[i].u, proj[i].v, proj[i].radius, proj[i].level - 1, proj[i].level, cand);
+      bestDist = 256; bestIdx = -1;
+      for (int idx : cand) {
+        if (vpMatched[idx] >= 0) continue;
+        const int dist = DescriptorDistance(P.desc + 32 * (size_t)i, KF.mDescriptors + 32 * (size_t)idx);
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+      }
+    }
+    if (bestIdx >= 0 && bestDist <= TH_LOW * ratioHamming) { vpMatched[bestIdx] = P.id[i]; nmatches++; }
+  }
+  return nmatches;
+}
+
 }  // namespace dvm_host
 
 // ---- C entry point for the Python harness (tests only; a C++ caller uses the class directly)
@@ -290,4 +704,54 @@ extern "C" int dvmh_search_by_projection_points(int device, int N, const dvm_key
   const int n = m.SearchByProjection(F, pts, npts, claimed_obs, th, far_points != 0, th_far, 0);
   if (requeried) *requeried = m.last_requeried;
   return n;
+}
+
+// ---- C entry points for the M4-M7 mirrors (Python harness: the view structs are passed as ctypes.Structure)
+using dvm_host::FeatureVectorView;
+using dvm_host::FrameView;
+using dvm_host::KeyFrameView;
+using dvm_host::MapPointsView;
+using dvm_host::Sim3View;
+extern "C" {
+int dvmh_search_for_initialization(int device, const FrameView* F1, const FrameView* F2, float* prev_matched, int32_t* matches12,
+                                   int window, float nnratio, int check_ori) {
+  dvm_host::ORBmatcher m(nnratio, check_ori != 0, device);
+  return m.SearchForInitialization(*F1, *F2, prev_matched, matches12, window);
+}
+int dvmh_search_by_bow_kf_frame(int device, const KeyFrameView* KF, const FrameView* F, const FeatureVectorView* Ffv, float nnratio,
+                                int check_ori, int32_t* matches, int* requeried) {
+  dvm_host::ORBmatcher m(nnratio, check_ori != 0, device);
+  const int n = m.SearchByBoW(*KF, *F, *Ffv, matches);
+  if (requeried) *requeried = m.last_requeried;
+  return n;
+}
+int dvmh_search_by_bow_kf_kf(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, float nnratio, int check_ori,
+                             int32_t* matches12, int* requeried) {
+  dvm_host::ORBmatcher m(nnratio, check_ori != 0, device);
+  const int n = m.SearchByBoW(*KF1, *KF2, matches12);
+  if (requeried) *requeried = m.last_requeried;
+  return n;
+}
+void dvmh_triangulation_geometry(const KeyFrameView* KF1, const KeyFrameView* KF2, float* R12, float* t12, float* ep, float* F12) {
+  dvm_host::ORBmatcher::TriangulationGeometry(*KF1, *KF2, R12, t12, ep, F12);
+}
+int dvmh_search_for_triangulation(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, int coarse, int check_ori, int32_t* pairs) {
+  dvm_host::ORBmatcher m(0.6f, check_ori != 0, device);
+  return m.SearchForTriangulation(*KF1, *KF2, pairs, false, coarse != 0);
+}
+int dvmh_fuse(int device, const KeyFrameView* KF, const MapPointsView* P, const uint8_t* inKF, float th, int32_t* best_idx) {
+  dvm_host::ORBmatcher m(0.6f, true, device);
+  return m.Fuse(*KF, *P, inKF, th, best_idx);
+}
+int dvmh_fuse_sim3(int device, KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, float th, int32_t* replace) {
+  dvm_host::ORBmatcher m(0.6f, true, device);
+  return m.Fuse(*KF, *Scw, *P, th, replace);
+}
+int dvmh_search_by_projection_sim3(int device, const KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, int32_t* matched,
+                                   int th, float ratio_hamming, int* requeried) {
+  dvm_host::ORBmatcher m(0.6f, true, device);
+  const int n = m.SearchByProjection(*KF, *Scw, *P, matched, th, ratio_hamming);
+  if (requeried) *requeried = m.last_requeried;
+  return n;
+}
 }

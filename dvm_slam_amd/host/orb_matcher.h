@@ -44,6 +44,48 @@ struct FrameView {
   int nLevels = 8;
 };
 
+// DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened: node ids ascending, the features of node k are
+// feat[off[k] .. off[k+1]) in insertion order (dvm_host::ORBVocabulary::transform produces exactly this).
+struct FeatureVectorView {
+  int n = 0;
+  const int32_t* node = nullptr;
+  const int32_t* off = nullptr;
+  const int32_t* feat = nullptr;
+};
+
+// The members of ORB_SLAM3::KeyFrame the matcher touches (mono: NLeft == -1, no mpCamera2, mvuRight < 0).
+struct KeyFrameView {
+  int N = 0;
+  const dvm_keypoint* mvKeysUn = nullptr;
+  const uint8_t* mDescriptors = nullptr;
+  int32_t* mvpMapPoints = nullptr;       // GetMapPointMatches(): map point id per keypoint, -1 = NULL
+  const uint8_t* mpBad = nullptr;        // isBad() of that map point (may be null: none is bad)
+  FeatureVectorView mFeatVec;
+  float Rcw[9], tcw[3], Ow[3];           // GetPose() as rotation matrix + translation, GetCameraCenter()
+  float fx, fy, cx, cy;
+  float mnMinX, mnMaxX, mnMinY, mnMaxY;
+  const float* mvScaleFactors = nullptr;
+  const float* mvLevelSigma2 = nullptr;
+  const float* mvInvLevelSigma2 = nullptr;
+  float mfLogScaleFactor = 0.f;
+  int nLevels = 8;
+};
+
+// A list of map points as the projection searches read them (SoA): GetWorldPos, GetNormal, mfMinDistance / mfMaxDistance
+// (GetMin/MaxDistanceInvariance = 0.8 / 1.2 times these), GetDescriptor, isBad, and an id standing for the pointer.
+struct MapPointsView {
+  int n = 0;
+  const int32_t* id = nullptr;
+  const uint8_t* bad = nullptr;          // may be null
+  const float* pos = nullptr;            // 3n
+  const float* normal = nullptr;         // 3n
+  const float* min_dist = nullptr;
+  const float* max_dist = nullptr;
+  const uint8_t* desc = nullptr;         // 32n
+};
+
+struct Sim3View { float R[9], t[3], s; };   // Sophus::Sim3f: rotationMatrix(), translation(), scale()
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // ORBmatcher.cc:36-38
@@ -68,6 +110,41 @@ class ORBmatcher {
                          bool bFarPoints, float thFarPoints, int mp_index_base = 0);
   static float RadiusByViewingCos(float viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }   // :207-212
 
+  // int SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12,
+  //                             int windowSize)   (ORBmatcher.cc:605-707).  vbPrevMatched: 2 floats per F1 keypoint (in/out),
+  // vnMatches12: F1.N ints.  The level-0 x level-0 Hamming table comes from the device (dvm_hamming_matrix); the mutual-best
+  // bookkeeping (vMatchedDistance / vnMatches21) is sequential and stays on the host.
+  int SearchForInitialization(const FrameView& F1, const FrameView& F2, float* vbPrevMatched, int32_t* vnMatches12, int windowSize = 10);
+
+  // int SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)   (:214-393, mono).
+  // vpMapPointMatches: F.N map point ids (-1 = NULL).
+  int SearchByBoW(const KeyFrameView& KF, const FrameView& F, const FeatureVectorView& FfeatVec, int32_t* vpMapPointMatches);
+  // int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12)   (:709-834).  vpMatches12: KF1.N ids of
+  // KF2 map points.
+  int SearchByBoW(const KeyFrameView& KF1, const KeyFrameView& KF2, int32_t* vpMatches12);
+
+  // int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t,size_t>>& vMatchedPairs,
+  //                            const bool bOnlyStereo, const bool bCoarse)   (:836-1058, mono => bOnlyStereo finds nothing).
+  // vMatchedPairs: up to KF1.N (idx1, idx2) pairs ordered by idx1.  Whole search on the device (dvm_match_triangulation).
+  int SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameView& KF2, int32_t* vMatchedPairs, bool bOnlyStereo = false,
+                             bool bCoarse = false);
+  // the geometry it derives from the two poses (:841-862, Pinhole.cpp:106-110): R12, t12, epipole in image 2, F12
+  static void TriangulationGeometry(const KeyFrameView& KF1, const KeyFrameView& KF2, float* R12, float* t12, float* ep, float* F12);
+
+  // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th, const bool bRight = false)   (:1060-1234),
+  // search part: vBestIdx[i] = keypoint of pKF the i-th point would be fused into (bestDist <= TH_LOW), -1 otherwise; the
+  // return value counts them.  Points already in the keyframe (IsInKeyFrame) must be flagged in `inKF` (may be null).  The
+  // Replace / AddObservation step mutates the map graph and stays with the caller, who replays vBestIdx in order (skipping
+  // points that turned bad through an earlier Replace).
+  int Fuse(const KeyFrameView& KF, const MapPointsView& vpMapPoints, const uint8_t* inKF, float th, int32_t* vBestIdx);
+  // int Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint)
+  // (:1236-1345), whole function: KF.mvpMapPoints receives the added points, vpReplacePoint[i] the id to replace (-1 none).
+  int Fuse(KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& vpPoints, float th, int32_t* vpReplacePoint);
+  // int SearchByProjection(KeyFrame* pKF, Sophus::Sim3f& Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched,
+  //                        int th, float ratioHamming)   (:395-496), whole function.  vpMatched: KF.N ids (in/out).
+  int SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& vpPoints, int32_t* vpMatched, int th,
+                         float ratioHamming = 1.f);
+
   int last_requeried = 0;  // queries re-issued on the host because an earlier match claimed their keypoint
 
  private:
@@ -78,6 +155,10 @@ class ORBmatcher {
   dvm_frame* grid_ = nullptr;
   int grid_cap_ = 0;
   int ensure_grid(const FrameView& F);
+  int ensure_grid(const KeyFrameView& KF);
+  int project_search(const KeyFrameView& KF, const float* Rcw, const float* tcw, const float* Ow, const MapPointsView& P,
+                     const uint8_t* valid, const uint8_t* skip, float th, bool gate, std::vector<dvm_match>& res,
+                     std::vector<dvm_projection>& proj);
 };
 
 }  // namespace dvm_host

@@ -177,6 +177,35 @@ int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const floa
 int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, const int32_t* off, const int32_t* cand,
                     dvm_match* out, int on_device, void* stream);
 
+/* Projection of n map points into a keyframe + windowed best-descriptor search -- the common body of
+ * ORBmatcher::Fuse(KF, vpMapPoints, th) (ORBmatcher.cc:1060-1234, gate_inv_sigma2 = KF.mvInvLevelSigma2, gate = 5.99),
+ * Fuse(KF, Scw, ...) (:1236-1345), SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) x2 (:395-603)
+ * (gate_inv_sigma2 = NULL).  Per point (skipped when valid[i] == 0; valid may be NULL): p3Dc = Rcw*p + tcw (for the
+ * Sim3 variants Rcw = Scw.rotationMatrix(), tcw = Scw.translation()/Scw.scale()), depth >= 0, KeyFrame::IsInImage,
+ * dist in [0.8*min_dist, 1.2*max_dist], PO.Pn >= 0.5*dist, level = MapPoint::PredictScale, radius = th *
+ * scale_factors[level], candidates = KeyFrame::GetFeaturesInArea(u, v, radius) with octave in [level-1, level], minus
+ * skip[idx] != 0 (skip may be NULL; `cap` bytes of the train frame).  out[i] = best / second best (strict '<', first
+ * wins); proj[i] (may be NULL) = projection, radius and predicted level (-1: rejected before the search).
+ * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
+typedef struct { float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor; int32_t n_levels; } dvm_kf_camera;
+typedef struct { float u, v, radius; int32_t level; } dvm_projection;
+int dvm_project_search(const dvm_frame* train, int slot, const uint8_t* skip, const dvm_kf_camera* cam, const float* P,
+                       const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc,
+                       const uint8_t* valid, int n, float th, const float* scale_factors, const float* gate_inv_sigma2,
+                       double gate, dvm_match* out, dvm_projection* proj, int on_device, void* stream);
+
+/* ORBmatcher::SearchForTriangulation inner loop (ORBmatcher.cc:905-998, monocular): query q = keypoint qidx[q] of KF1
+ * scans the KF2 keypoints cand[off[q] .. off[q+1]) (entries < 0 skipped); a candidate is kept if dist <= 50, dist <= best
+ * so far, it is not within sqrt(100*scale_factors2[octave]) px of the epipole `ep`, and (coarse != 0 or)
+ * Pinhole::epipolarConstrain (CameraModels/Pinhole.cpp:104-127) holds with the fundamental matrix F12 (row-major 3x3,
+ * float) and level_sigma2_2[octave].  best_idx[q] = KF2 index (-1 none), best_dist[q] (256 none); a tie goes to the LAST
+ * candidate, as the reference's "dist > bestDist -> continue" does. */
+int dvm_match_triangulation(const uint8_t* desc1, const dvm_keypoint* kps1, int n1, const int32_t* qidx, int nq,
+                            const uint8_t* desc2, const dvm_keypoint* kps2, int n2, const int32_t* off, const int32_t* cand,
+                            const float* F12, const float* ep, int coarse, const float* scale_factors2,
+                            const float* level_sigma2_2, int nlevels, int32_t* best_idx, int32_t* best_dist, int on_device,
+                            void* stream);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:384-453), batched: map point p owns the descriptors
  * desc[off[p] .. off[p+1]) (32 B each, its observations in the reference's iteration order); best_idx[p] = index
  * inside that range of the descriptor with the least median Hamming distance to the others (median =

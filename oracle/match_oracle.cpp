@@ -15,6 +15,15 @@
 //   src/ORBmatcher.cc:1862-1896  ComputeThreeMaxima              -> orc_search_by_projection_frames()
 //   src/ORBmatcher.cc:44-212     SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), mono branch,
 //                                RadiusByViewingCos              -> orc_search_by_projection_points()
+//   src/ORBmatcher.cc:605-707    SearchForInitialization          -> orc_search_for_initialization()
+//   src/ORBmatcher.cc:214-393    SearchByBoW(KF, F, vpMapPointMatches), mono -> orc_search_by_bow_kf_frame()
+//   src/ORBmatcher.cc:709-834    SearchByBoW(KF1, KF2, vpMatches12)          -> orc_search_by_bow_kf_kf()
+//   src/ORBmatcher.cc:836-1058   SearchForTriangulation, mono; CameraModels/Pinhole.cpp:104-127 epipolarConstrain
+//                                                                  -> orc_search_for_triangulation()
+//   src/ORBmatcher.cc:1060-1234  Fuse(KF, vpMapPoints, th) search part (up to bestDist / bestIdx), :1236-1345 Fuse(KF, Scw, ...)
+//                                whole function, :395-496 SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming)
+//                                whole function; KeyFrame.cc:750-794 GetFeaturesInArea / IsInImage; MapPoint.cc:573-587
+//                                PredictScale              -> orc_project_search(), orc_fuse_sim3(), orc_search_by_projection_sim3()
 //   src/MapPoint.cc:384-453      MapPoint::ComputeDistinctiveDescriptors -> orc_distinctive_descriptors()
 //   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1025-1138 transform (TF_IDF, L1), BowVector.cpp:32-72,
 //   FeatureVector.cpp:27-38, ScoringObject.cpp:23-63 L1Scoring::score, FORB.cpp:80-97 -> orc_vocab_transform(), orc_bow_score()
@@ -379,6 +388,383 @@ double orc_bow_score(const int32_t* ids1, const double* vals1, int n1, const int
     else v2_it = v2.lower_bound(v1_it->first);
   }
   return -score / 2.0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Whole matcher functions of SURVEY.md 8(a) rows M4-M7 (monocular: Nleft == -1, no mpCamera2, mvuRight < 0).
+ * Map points are indices (-1 = NULL); "bad" flags stand for MapPoint::isBad().  FeatureVectors are CSR:
+ * node ids ascending (std::map order), features of node k = feat[off[k] .. off[k+1]).
+ * ------------------------------------------------------------------------------------------------------------------ */
+namespace {
+const int kHisto = 30, kThLow = 50;
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1862-1896
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+int rot_bin(float a1, float a2) {
+  const float factor = 1.0f / kHisto;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == kHisto) bin = 0;
+  return bin;
+}
+// std::map::lower_bound over the CSR node list
+int fv_lower_bound(const int32_t* nodes, int n, int from, int key) { return (int)(std::lower_bound(nodes + from, nodes + n, key) - nodes); }
+}  // namespace
+
+int orc_search_for_initialization(int N1, const orc_keypoint* kps1, const uint8_t* desc1, int N2, const orc_keypoint* kps2,
+                                  const uint8_t* desc2, const float* bounds, float* prev_matched, int32_t* matches12,
+                                  int windowSize, float nnratio, int check_ori) {
+  int nmatches = 0;
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  std::vector<int> rotHist[kHisto];
+  std::vector<int> vMatchedDistance(N2, INT32_MAX), vnMatches21(N2, -1);
+  orc_grid* g = orc_grid_create(kps2, N2, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> vIndices2;
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int level1 = kps1[i1].octave;
+    if (level1 > 0) continue;
+    features_in_area(g, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+    if (vIndices2.empty()) continue;
+    int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      const int dist = descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= kThLow) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        matches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) rotHist[rot_bin(kps1[i1].angle, kps2[bestIdx2].angle)].push_back(i1);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+    for (int i = 0; i < kHisto; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < N1; i1++)
+    if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[matches12[i1]].x; prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y; }
+  orc_grid_destroy(g);
+  return nmatches;
+}
+
+int orc_search_by_bow_kf_frame(const orc_keypoint* kps_kf, const uint8_t* desc_kf, const int32_t* mp_kf, const uint8_t* bad_kf,
+                               const int32_t* fv_nodes_kf, const int32_t* fv_off_kf, const int32_t* fv_feat_kf, int nn_kf, int N_f,
+                               const orc_keypoint* kps_f, const uint8_t* desc_f, const int32_t* fv_nodes_f, const int32_t* fv_off_f,
+                               const int32_t* fv_feat_f, int nn_f, float nnratio, int check_ori, int32_t* matches) {
+  for (int i = 0; i < N_f; i++) matches[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[kHisto];
+  int a = 0, b = 0;
+  while (a < nn_kf && b < nn_f) {
+    if (fv_nodes_kf[a] == fv_nodes_f[b]) {
+      for (int iKF = fv_off_kf[a]; iKF < fv_off_kf[a + 1]; iKF++) {
+        const int realIdxKF = fv_feat_kf[iKF];
+        const int pMP = mp_kf[realIdxKF];
+        if (pMP < 0) continue;
+        if (bad_kf && bad_kf[realIdxKF]) continue;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int iF = fv_off_f[b]; iF < fv_off_f[b + 1]; iF++) {
+          const int realIdxF = fv_feat_f[iF];
+          if (matches[realIdxF] >= 0) continue;
+          const int dist = descriptor_distance(desc_kf + 32 * (size_t)realIdxKF, desc_f + 32 * (size_t)realIdxF);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= kThLow) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches[bestIdxF] = pMP;
+            if (check_ori) rotHist[rot_bin(kps_kf[realIdxKF].angle, kps_f[bestIdxF].angle)].push_back(bestIdxF);
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv_nodes_kf[a] < fv_nodes_f[b]) {
+      a = fv_lower_bound(fv_nodes_kf, nn_kf, a, fv_nodes_f[b]);
+    } else {
+      b = fv_lower_bound(fv_nodes_f, nn_f, b, fv_nodes_kf[a]);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+    for (int i = 0; i < kHisto; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+int orc_search_by_bow_kf_kf(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const uint8_t* bad1,
+                            const int32_t* fv_nodes1, const int32_t* fv_off1, const int32_t* fv_feat1, int nn1, int N2,
+                            const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2,
+                            const int32_t* fv_nodes2, const int32_t* fv_off2, const int32_t* fv_feat2, int nn2, float nnratio,
+                            int check_ori, int32_t* matches12) {
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  std::vector<uint8_t> vbMatched2(N2, 0);
+  std::vector<int> rotHist[kHisto];
+  int nmatches = 0, a = 0, b = 0;
+  while (a < nn1 && b < nn2) {
+    if (fv_nodes1[a] == fv_nodes2[b]) {
+      for (int i1 = fv_off1[a]; i1 < fv_off1[a + 1]; i1++) {
+        const int idx1 = fv_feat1[i1];
+        if (mp1[idx1] < 0) continue;
+        if (bad1 && bad1[idx1]) continue;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int i2 = fv_off2[b]; i2 < fv_off2[b + 1]; i2++) {
+          const int idx2 = fv_feat2[i2];
+          if (vbMatched2[idx2] || mp2[idx2] < 0) continue;
+          if (bad2 && bad2[idx2]) continue;
+          const int dist = descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < kThLow) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches12[idx1] = mp2[bestIdx2];
+            vbMatched2[bestIdx2] = 1;
+            if (check_ori) rotHist[rot_bin(kps1[idx1].angle, kps2[bestIdx2].angle)].push_back(idx1);
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv_nodes1[a] < fv_nodes2[b]) {
+      a = fv_lower_bound(fv_nodes1, nn1, a, fv_nodes2[b]);
+    } else {
+      b = fv_lower_bound(fv_nodes2, nn2, b, fv_nodes1[a]);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+    for (int i = 0; i < kHisto; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// Geometry of SearchForTriangulation (ORBmatcher.cc:841-862) + Pinhole::epipolarConstrain's fundamental matrix
+// (Pinhole.cpp:106-110), float, products evaluated left to right with plain sum-of-products rows; K^-1 in closed form.
+// (The reference goes through Sophus quaternions and Eigen's 3x3 inverse: same values up to float rounding -- unpinned.)
+void orc_triangulation_geometry(const float* R1w, const float* t1w, const float* R2w, const float* t2w, const float* K1,
+                                const float* K2, float* R12, float* t12, float* ep, float* F12) {
+  auto mul = [](const float* A, const float* B, float* C) {
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+  };
+  // Cw = -R1w^T t1w (camera centre of KF1); C2 = R2w Cw + t2w; ep = project(C2)
+  float Cw[3], C2[3];
+  for (int r = 0; r < 3; r++) Cw[r] = -((R1w[r] * t1w[0] + R1w[3 + r] * t1w[1]) + R1w[6 + r] * t1w[2]);
+  for (int r = 0; r < 3; r++) C2[r] = ((R2w[3 * r] * Cw[0] + R2w[3 * r + 1] * Cw[1]) + R2w[3 * r + 2] * Cw[2]) + t2w[r];
+  ep[0] = K2[0] * C2[0] / C2[2] + K2[2];
+  ep[1] = K2[1] * C2[1] / C2[2] + K2[3];
+  // T12 = T1w * Tw2: R12 = R1w R2w^T, t12 = t1w - R12 t2w
+  float R2wT[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) R2wT[3 * r + c] = R2w[3 * c + r];
+  mul(R1w, R2wT, R12);
+  for (int r = 0; r < 3; r++) t12[r] = t1w[r] - ((R12[3 * r] * t2w[0] + R12[3 * r + 1] * t2w[1]) + R12[3 * r + 2] * t2w[2]);
+  const float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
+  const float K1invT[9] = {1.f / K1[0], 0.f, 0.f, 0.f, 1.f / K1[1], 0.f, -K1[2] / K1[0], -K1[3] / K1[1], 1.f};
+  const float K2inv[9] = {1.f / K2[0], 0.f, -K2[2] / K2[0], 0.f, 1.f / K2[1], -K2[3] / K2[1], 0.f, 0.f, 1.f};
+  float A[9], B[9];
+  mul(K1invT, t12x, A);
+  mul(A, R12, B);
+  mul(B, K2inv, F12);
+}
+
+int orc_search_for_triangulation(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const int32_t* fv_nodes1,
+                                 const int32_t* fv_off1, const int32_t* fv_feat1, int nn1, int N2, const orc_keypoint* kps2,
+                                 const uint8_t* desc2, const int32_t* mp2, const int32_t* fv_nodes2, const int32_t* fv_off2,
+                                 const int32_t* fv_feat2, int nn2, const float* F12, const float* ep, const float* scale_factors2,
+                                 const float* level_sigma2_2, int coarse, int check_ori, int32_t* pairs) {
+  int nmatches = 0;
+  std::vector<uint8_t> vbMatched2(N2, 0);   // never set by the reference either (:878, :913)
+  std::vector<int> vMatches12(N1, -1);
+  std::vector<int> rotHist[kHisto];
+  int a = 0, b = 0;
+  while (a < nn1 && b < nn2) {
+    if (fv_nodes1[a] == fv_nodes2[b]) {
+      for (int i1 = fv_off1[a]; i1 < fv_off1[a + 1]; i1++) {
+        const int idx1 = fv_feat1[i1];
+        if (mp1[idx1] >= 0) continue;
+        const orc_keypoint& kp1 = kps1[idx1];
+        int bestDist = kThLow, bestIdx2 = -1;
+        for (int i2 = fv_off2[b]; i2 < fv_off2[b + 1]; i2++) {
+          const int idx2 = fv_feat2[i2];
+          if (vbMatched2[idx2] || mp2[idx2] >= 0) continue;
+          const int dist = descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist > kThLow || dist > bestDist) continue;
+          const orc_keypoint& kp2 = kps2[idx2];
+          const float distex = ep[0] - kp2.x, distey = ep[1] - kp2.y;
+          if (distex * distex + distey * distey < 100 * scale_factors2[kp2.octave]) continue;
+          bool ok = coarse != 0;
+          if (!ok) {  // Pinhole::epipolarConstrain
+            const float la = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+            const float lb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+            const float lc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+            const float num = la * kp2.x + lb * kp2.y + lc;
+            const float den = la * la + lb * lb;
+            if (den == 0) ok = false;
+            else { const float dsqr = num * num / den; ok = dsqr < 3.84 * level_sigma2_2[kp2.octave]; }
+          }
+          if (ok) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (check_ori) rotHist[rot_bin(kp1.angle, kps2[bestIdx2].angle)].push_back(idx1);
+        }
+      }
+      a++; b++;
+    } else if (fv_nodes1[a] < fv_nodes2[b]) {
+      a = fv_lower_bound(fv_nodes1, nn1, a, fv_nodes2[b]);
+    } else {
+      b = fv_lower_bound(fv_nodes2, nn2, b, fv_nodes1[a]);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+    for (int i = 0; i < kHisto; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { vMatches12[idx] = -1; nmatches--; }
+    }
+  }
+  int k = 0;
+  for (int i = 0; i < N1; i++)
+    if (vMatches12[i] >= 0) { pairs[2 * k] = i; pairs[2 * k + 1] = vMatches12[i]; k++; }
+  return nmatches;
+}
+
+// Projection gates + window search shared by Fuse x2 and SearchByProjection(KF, Scw, ...) (see the file header).
+// best_idx / best_dist per point (-1 / 256: nothing found or rejected by a gate); proj = (u, v, radius, level) with
+// level -1 when a gate rejected the point.  skip[idx] != 0 removes a keyframe keypoint from every window.
+void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, const uint8_t* skip, const float* Rcw,
+                        const float* tcw, const float* Ow, const float* K, int n, const float* P, const float* normal,
+                        const float* min_dist, const float* max_dist, const uint8_t* pdesc, const uint8_t* valid, float th,
+                        const float* scale_factors, float log_scale_factor, int n_levels, const float* gate_inv_sigma2, double gate,
+                        int32_t* best_idx, int32_t* best_dist, float* proj) {
+  orc_grid* g = orc_grid_create(kps, N, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> vIndices;
+  for (int i = 0; i < n; i++) {
+    best_idx[i] = -1; best_dist[i] = 256;
+    float* pr = proj ? proj + 4 * i : nullptr;
+    if (pr) { pr[0] = -1.f; pr[1] = -1.f; pr[2] = 0.f; pr[3] = -1.f; }
+    if (valid && !valid[i]) continue;
+    const float* p = P + 3 * i;
+    float c[3];
+    for (int r = 0; r < 3; r++) c[r] = ((Rcw[3 * r] * p[0] + Rcw[3 * r + 1] * p[1]) + Rcw[3 * r + 2] * p[2]) + tcw[r];
+    if (c[2] < 0.0f) continue;
+    const float u = K[0] * c[0] / c[2] + K[2], v = K[1] * c[1] / c[2] + K[3];
+    if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) continue;   // KeyFrame::IsInImage
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    const float PO[3] = {p[0] - Ow[0], p[1] - Ow[1], p[2] - Ow[2]};
+    const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float dot = (PO[0] * normal[3 * i] + PO[1] * normal[3 * i + 1]) + PO[2] * normal[3 * i + 2];
+    if (dot < 0.5 * dist3D) continue;
+    const float ratio = max_dist[i] / dist3D;                                  // MapPoint::PredictScale
+    int nScale = (int)std::ceil(std::log(ratio) / log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+    const float radius = th * scale_factors[nScale];
+    if (pr) { pr[0] = u; pr[1] = v; pr[2] = radius; pr[3] = (float)nScale; }
+    features_in_area(g, u, v, radius, -1, -1, vIndices);                       // KeyFrame::GetFeaturesInArea: no level filter
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (skip && skip[idx]) continue;
+      const int kpLevel = kps[idx].octave;
+      if (kpLevel < nScale - 1 || kpLevel > nScale) continue;
+      if (gate_inv_sigma2) {
+        const float ex = u - kps[idx].x, ey = v - kps[idx].y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * gate_inv_sigma2[kpLevel] > gate) continue;
+      }
+      const int dist = descriptor_distance(pdesc + 32 * (size_t)i, desc + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    best_idx[i] = bestIdx; best_dist[i] = bestDist;
+  }
+  orc_grid_destroy(g);
+}
+
+// ORBmatcher::Fuse(KF, Scw, vpPoints, th, vpReplacePoint): kf_mp (in/out) = KF map point ids per keypoint, kf_mp_bad = their
+// isBad(); point i has id point_id[i]; replace[i] receives the id of the KF map point to be replaced (-1 none).
+int orc_fuse_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* kf_mp, const uint8_t* kf_mp_bad,
+                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                  const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist, const float* max_dist,
+                  const uint8_t* pdesc, float th, const float* scale_factors, float log_scale_factor, int n_levels, int32_t* replace) {
+  std::vector<uint8_t> valid(n, 1);
+  std::vector<int32_t> already(kf_mp, kf_mp + N);   // spAlreadyFound = pKF->GetMapPoints() at entry
+  std::sort(already.begin(), already.end());
+  for (int i = 0; i < n; i++) {
+    replace[i] = -1;
+    if ((point_bad && point_bad[i]) || std::binary_search(already.begin(), already.end(), point_id[i])) valid[i] = 0;
+  }
+  std::vector<int32_t> bi(n), bd(n);
+  orc_project_search(N, kps, desc, bounds, nullptr, Rcw, tcw, Ow, K, n, P, normal, min_dist, max_dist, pdesc, valid.data(), th,
+                     scale_factors, log_scale_factor, n_levels, nullptr, 0.0, bi.data(), bd.data(), nullptr);
+  int nFused = 0;
+  std::vector<uint8_t> fresh(N, 0);   // keypoints that received a point in this call (never bad)
+  for (int i = 0; i < n; i++) {
+    if (!valid[i] || bi[i] < 0 || bd[i] > kThLow) continue;
+    const int pMPinKF = kf_mp[bi[i]];
+    if (pMPinKF >= 0) {
+      if (fresh[bi[i]] || !(kf_mp_bad && kf_mp_bad[bi[i]])) replace[i] = pMPinKF;
+    } else {
+      kf_mp[bi[i]] = point_id[i];
+      fresh[bi[i]] = 1;
+    }
+    nFused++;
+  }
+  return nFused;
+}
+
+// ORBmatcher::SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) (:395-496): matched (in/out) = point id
+// per KF keypoint (-1 = NULL); a keypoint matched earlier (at entry or in this call) is skipped by later points.
+int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* matched,
+                                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                                  const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist,
+                                  const float* max_dist, const uint8_t* pdesc, int th, float ratioHamming, const float* scale_factors,
+                                  float log_scale_factor, int n_levels) {
+  std::vector<int32_t> already(matched, matched + N);
+  std::sort(already.begin(), already.end());
+  int nmatches = 0;
+  std::vector<uint8_t> skip(N), one(1, 1);
+  for (int i = 0; i < n; i++) {
+    if ((point_bad && point_bad[i]) || (point_id[i] >= 0 && std::binary_search(already.begin(), already.end(), point_id[i]))) continue;
+    for (int j = 0; j < N; j++) skip[j] = matched[j] >= 0;
+    int32_t bi, bd;
+    orc_project_search(N, kps, desc, bounds, skip.data(), Rcw, tcw, Ow, K, 1, P + 3 * i, normal + 3 * i, min_dist + i, max_dist + i,
+                       pdesc + 32 * (size_t)i, one.data(), (float)th, scale_factors, log_scale_factor, n_levels, nullptr, 0.0, &bi, &bd,
+                       nullptr);
+    if (bi >= 0 && bd <= kThLow * ratioHamming) { matched[bi] = point_id[i]; nmatches++; }
+  }
+  return nmatches;
 }
 
 }  // extern "C"

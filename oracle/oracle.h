@@ -116,6 +116,42 @@ int orc_search_by_projection_points(int N, const orc_keypoint* kps, const uint8_
                                     const float* bounds, const float* scale_factors, const orc_tracked_point* pts, int npts,
                                     float th, float nnratio, int far_points, float th_far);
 
+/* Whole matcher functions, SURVEY.md 8(a) M4-M7 (monocular).  Map points are indices (-1 = NULL), bad_* = isBad() of the
+   map point at that keypoint (may be NULL); FeatureVectors are CSR (node ids ascending). See match_oracle.cpp. */
+int orc_search_for_initialization(int N1, const orc_keypoint* kps1, const uint8_t* desc1, int N2, const orc_keypoint* kps2,
+                                  const uint8_t* desc2, const float* bounds, float* prev_matched, int32_t* matches12,
+                                  int windowSize, float nnratio, int check_ori);
+int orc_search_by_bow_kf_frame(const orc_keypoint* kps_kf, const uint8_t* desc_kf, const int32_t* mp_kf, const uint8_t* bad_kf,
+                               const int32_t* fv_nodes_kf, const int32_t* fv_off_kf, const int32_t* fv_feat_kf, int nn_kf, int N_f,
+                               const orc_keypoint* kps_f, const uint8_t* desc_f, const int32_t* fv_nodes_f, const int32_t* fv_off_f,
+                               const int32_t* fv_feat_f, int nn_f, float nnratio, int check_ori, int32_t* matches);
+int orc_search_by_bow_kf_kf(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const uint8_t* bad1,
+                            const int32_t* fv_nodes1, const int32_t* fv_off1, const int32_t* fv_feat1, int nn1, int N2,
+                            const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2,
+                            const int32_t* fv_nodes2, const int32_t* fv_off2, const int32_t* fv_feat2, int nn2, float nnratio,
+                            int check_ori, int32_t* matches12);
+void orc_triangulation_geometry(const float* R1w, const float* t1w, const float* R2w, const float* t2w, const float* K1,
+                                const float* K2, float* R12, float* t12, float* ep, float* F12);
+int orc_search_for_triangulation(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const int32_t* fv_nodes1,
+                                 const int32_t* fv_off1, const int32_t* fv_feat1, int nn1, int N2, const orc_keypoint* kps2,
+                                 const uint8_t* desc2, const int32_t* mp2, const int32_t* fv_nodes2, const int32_t* fv_off2,
+                                 const int32_t* fv_feat2, int nn2, const float* F12, const float* ep, const float* scale_factors2,
+                                 const float* level_sigma2_2, int coarse, int check_ori, int32_t* pairs);
+void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, const uint8_t* skip, const float* Rcw,
+                        const float* tcw, const float* Ow, const float* K, int n, const float* P, const float* normal,
+                        const float* min_dist, const float* max_dist, const uint8_t* pdesc, const uint8_t* valid, float th,
+                        const float* scale_factors, float log_scale_factor, int n_levels, const float* gate_inv_sigma2, double gate,
+                        int32_t* best_idx, int32_t* best_dist, float* proj);
+int orc_fuse_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* kf_mp, const uint8_t* kf_mp_bad,
+                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                  const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist, const float* max_dist,
+                  const uint8_t* pdesc, float th, const float* scale_factors, float log_scale_factor, int n_levels, int32_t* replace);
+int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* matched,
+                                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                                  const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist,
+                                  const float* max_dist, const uint8_t* pdesc, int th, float ratioHamming, const float* scale_factors,
+                                  float log_scale_factor, int n_levels);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
 

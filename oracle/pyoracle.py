@@ -402,6 +402,143 @@ def search_by_projection_points(kps, desc, mp, claimed_obs, bounds, scale_factor
     return n, mpc
 
 
+class F32(float):
+    """Marks a Python float as a C float argument for _call."""
+
+
+class F64(float):
+    """Marks a Python float as a C double argument for _call."""
+
+
+def _call(fn, restype, *args):
+    """ctypes call without an argtypes table: arrays -> pointers, int -> int32, F32 / F64 -> float / double."""
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif isinstance(a, np.ndarray):
+            conv.append(C.c_void_p(a.ctypes.data) if a.size else None)
+        elif isinstance(a, F32):
+            conv.append(C.c_float(a))
+        elif isinstance(a, F64):
+            conv.append(C.c_double(a))
+        elif isinstance(a, (int, np.integer, bool)):
+            conv.append(C.c_int32(int(a)))
+        else:
+            raise TypeError(type(a))
+    fn.restype = restype
+    fn.argtypes = None
+    return fn(*conv)
+
+
+def _kd(kps, desc):
+    return np.ascontiguousarray(kps, KP_DTYPE), np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+
+
+def _fv(fv):
+    """FeatureVector dict (fv_nodes, fv_off, fv_feat) -> 3 int32 arrays + node count."""
+    n, o, f = (np.ascontiguousarray(fv[k], np.int32) for k in ("fv_nodes", "fv_off", "fv_feat"))
+    return n, o, f, len(n)
+
+
+def _u8(x):
+    return None if x is None else np.ascontiguousarray(x, np.uint8)
+
+
+def _f32(x):
+    return None if x is None else np.ascontiguousarray(x, np.float32)
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_matched, window=100, nnratio=0.9, check_ori=True):
+    """ORBmatcher::SearchForInitialization.  Returns (nmatches, vnMatches12, vbPrevMatched updated)."""
+    k1, d1 = _kd(kps1, desc1); k2, d2 = _kd(kps2, desc2)
+    pm = np.array(prev_matched, np.float32, copy=True).reshape(-1, 2)
+    m = np.zeros(len(k1), np.int32)
+    n = _call(lib().orc_search_for_initialization, C.c_int32, len(k1), k1, d1, len(k2), k2, d2, _f32(bounds), pm, m, int(window),
+              F32(nnratio), int(check_ori))
+    return n, m, pm
+
+
+def search_by_bow_kf_frame(kps_kf, desc_kf, mp_kf, bad_kf, fv_kf, kps_f, desc_f, fv_f, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW(KF, F, vpMapPointMatches) (mono).  Returns (nmatches, matches[F.N] = map point id or -1)."""
+    kk, dk = _kd(kps_kf, desc_kf); kf, df = _kd(kps_f, desc_f)
+    a = _fv(fv_kf); b = _fv(fv_f)
+    m = np.zeros(len(kf), np.int32)
+    n = _call(lib().orc_search_by_bow_kf_frame, C.c_int32, kk, dk, np.ascontiguousarray(mp_kf, np.int32), _u8(bad_kf), a[0], a[1], a[2],
+              a[3], len(kf), kf, df, b[0], b[1], b[2], b[3], F32(nnratio), int(check_ori), m)
+    return n, m
+
+
+def search_by_bow_kf_kf(kps1, desc1, mp1, bad1, fv1, kps2, desc2, mp2, bad2, fv2, nnratio=0.8, check_ori=True):
+    """ORBmatcher::SearchByBoW(KF1, KF2, vpMatches12).  Returns (nmatches, matches12[N1] = KF2 map point id or -1)."""
+    k1, d1 = _kd(kps1, desc1); k2, d2 = _kd(kps2, desc2)
+    a = _fv(fv1); b = _fv(fv2)
+    m = np.zeros(len(k1), np.int32)
+    n = _call(lib().orc_search_by_bow_kf_kf, C.c_int32, len(k1), k1, d1, np.ascontiguousarray(mp1, np.int32), _u8(bad1), a[0], a[1], a[2],
+              a[3], len(k2), k2, d2, np.ascontiguousarray(mp2, np.int32), _u8(bad2), b[0], b[1], b[2], b[3], F32(nnratio),
+              int(check_ori), m)
+    return n, m
+
+
+def triangulation_geometry(R1w, t1w, R2w, t2w, K1, K2):
+    """R12, t12, epipole in image 2 and F12 (float32) as SearchForTriangulation / epipolarConstrain build them."""
+    R12 = np.zeros(9, np.float32); t12 = np.zeros(3, np.float32); ep = np.zeros(2, np.float32); F12 = np.zeros(9, np.float32)
+    _call(lib().orc_triangulation_geometry, None, _f32(R1w).reshape(-1), _f32(t1w), _f32(R2w).reshape(-1), _f32(t2w), _f32(K1), _f32(K2),
+          R12, t12, ep, F12)
+    return R12, t12, ep, F12
+
+
+def search_for_triangulation(kps1, desc1, mp1, fv1, kps2, desc2, mp2, fv2, F12, ep, scale_factors2, level_sigma2_2, coarse=False,
+                             check_ori=True):
+    """ORBmatcher::SearchForTriangulation (mono).  Returns (nmatches, pairs[nmatches, 2])."""
+    k1, d1 = _kd(kps1, desc1); k2, d2 = _kd(kps2, desc2)
+    a = _fv(fv1); b = _fv(fv2)
+    pairs = np.zeros((max(len(k1), 1), 2), np.int32)
+    n = _call(lib().orc_search_for_triangulation, C.c_int32, len(k1), k1, d1, np.ascontiguousarray(mp1, np.int32), a[0], a[1], a[2], a[3],
+              len(k2), k2, d2, np.ascontiguousarray(mp2, np.int32), b[0], b[1], b[2], b[3], _f32(F12), _f32(ep), _f32(scale_factors2),
+              _f32(level_sigma2_2), int(coarse), int(check_ori), pairs)
+    return n, pairs[:n]
+
+
+def project_search(kps, desc, bounds, skip, Rcw, tcw, Ow, K, pts, th, scale_factors, log_scale_factor, gate_inv_sigma2=None,
+                   gate=0.0):
+    """Projection gates + window search of Fuse / SearchByProjection(KF, Scw, ...).  pts: dict(pos, normal, min_dist, max_dist,
+    desc, valid).  Returns (best_idx, best_dist, proj[n, 4] = u, v, radius, level)."""
+    k, d = _kd(kps, desc)
+    n = len(pts["pos"])
+    bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32); pr = np.zeros((n, 4), np.float32)
+    sf = _f32(scale_factors)
+    _call(lib().orc_project_search, None, len(k), k, d, _f32(bounds), _u8(skip), _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow), _f32(K), n,
+          _f32(pts["pos"]), _f32(pts["normal"]), _f32(pts["min_dist"]), _f32(pts["max_dist"]), _u8(pts["desc"]), _u8(pts.get("valid")),
+          F32(th), sf, F32(log_scale_factor), len(sf), _f32(gate_inv_sigma2), F64(gate), bi, bd, pr)
+    return bi, bd, pr
+
+
+def fuse_sim3(kps, desc, bounds, kf_mp, kf_mp_bad, Rcw, tcw, Ow, K, pts, th, scale_factors, log_scale_factor):
+    """ORBmatcher::Fuse(KF, Scw, vpPoints, th, vpReplacePoint).  pts adds id, bad.  Returns (nFused, kf_mp updated, replace)."""
+    k, d = _kd(kps, desc)
+    n = len(pts["pos"])
+    mp = np.array(kf_mp, np.int32, copy=True); rep = np.zeros(n, np.int32)
+    sf = _f32(scale_factors)
+    nf = _call(lib().orc_fuse_sim3, C.c_int32, len(k), k, d, _f32(bounds), mp, _u8(kf_mp_bad), _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow),
+               _f32(K), n, np.ascontiguousarray(pts["id"], np.int32), _u8(pts.get("bad")), _f32(pts["pos"]), _f32(pts["normal"]),
+               _f32(pts["min_dist"]), _f32(pts["max_dist"]), _u8(pts["desc"]), F32(th), sf, F32(log_scale_factor), len(sf), rep)
+    return nf, mp, rep
+
+
+def search_by_projection_sim3(kps, desc, bounds, matched, Rcw, tcw, Ow, K, pts, th, ratio_hamming, scale_factors, log_scale_factor):
+    """ORBmatcher::SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming).  Returns (nmatches, vpMatched updated)."""
+    k, d = _kd(kps, desc)
+    n = len(pts["pos"])
+    m = np.array(matched, np.int32, copy=True)
+    sf = _f32(scale_factors)
+    nm = _call(lib().orc_search_by_projection_sim3, C.c_int32, len(k), k, d, _f32(bounds), m, _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow),
+               _f32(K), n, np.ascontiguousarray(pts["id"], np.int32), _u8(pts.get("bad")), _f32(pts["pos"]), _f32(pts["normal"]),
+               _f32(pts["min_dist"]), _f32(pts["max_dist"]), _u8(pts["desc"]), int(th), F32(ratio_hamming), sf, F32(log_scale_factor),
+               len(sf))
+    return nm, m
+
+
 def distinctive_descriptors(desc, off):
     """MapPoint::ComputeDistinctiveDescriptors for a batch.  Returns (best_idx, best_median)."""
     L = lib()

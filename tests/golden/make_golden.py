@@ -94,9 +94,51 @@ def more():
     print("sim3", int(nin.max()), "pose graph chi2", st[2], "->", st[3])
 
 
+def kf_functions():
+    """Third set: the remaining whole ORBmatcher functions on one small two-keyframe scene."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from matcher_scene import make_init_scene, make_kf_pair_scene
+    sc = make_kf_pair_scene(po, 21, n_pts=260, n_clutter=80, n_nodes=40, dup_frac=0.25)
+    a, b = sc["kf"]
+    pts = sc["pts"]
+    out = {}
+    for tag, kf in (("a", a), ("b", b)):
+        for k in ("kps", "desc", "mp", "bad", "Rcw", "tcw", "Ow"):
+            out[f"{tag}_{k}"] = kf[k]
+        for k, v in kf["fv"].items():
+            out[f"{tag}_{k}"] = v
+    for k in ("K", "bounds", "scale_factors", "level_sigma2", "inv_level_sigma2"):
+        out[k] = a[k]
+    out["log_scale_factor"] = np.float32(a["log_scale_factor"])
+    for k, v in pts.items():
+        out["pt_" + k] = v
+    n1, m1 = po.search_by_bow_kf_kf(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["mp"], b["bad"], b["fv"], 0.8, True)
+    n2, m2 = po.search_by_bow_kf_frame(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["fv"], 0.7, True)
+    geo = po.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    n3, pairs = po.search_for_triangulation(a["kps"], a["desc"], a["mp"], a["fv"], b["kps"], b["desc"], b["mp"], b["fv"], geo[3], geo[2],
+                                            b["scale_factors"], b["level_sigma2"], False, True)
+    bi, bd, pr = po.project_search(b["kps"], b["desc"], b["bounds"], None, b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 3.0, b["scale_factors"],
+                                   b["log_scale_factor"], b["inv_level_sigma2"], 5.99)
+    matched = np.where(np.random.default_rng(2).random(len(b["kps"])) < 0.3, b["mp"], -1).astype(np.int32)
+    n4, m4 = po.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], matched, b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 8, 1.0,
+                                          b["scale_factors"], b["log_scale_factor"])
+    n5, mp5, rep5 = po.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 4.0,
+                                 b["scale_factors"], b["log_scale_factor"])
+    si = make_init_scene(po, 22, n=400)
+    n6, m6, pm6 = po.search_for_initialization(si["k1"], si["d1"], si["k2"], si["d2"], si["bounds"], si["prev_matched"], 100, 0.9, True)
+    np.savez_compressed(os.path.join(HERE, "kf_matcher_functions.npz"), bowkk_n=n1, bowkk_m=m1, bowkf_n=n2, bowkf_m=m2, tri_F12=geo[3],
+                        tri_ep=geo[2], tri_n=n3, tri_pairs=pairs, ps_idx=bi, ps_dist=bd, ps_proj=pr, sim3_matched_in=matched, sim3_n=n4,
+                        sim3_m=m4, fuse_n=n5, fuse_mp=mp5, fuse_rep=rep5, init_n=n6, init_m=m6, init_pm=pm6,
+                        **{"i_" + k: v for k, v in si.items()}, **out)
+    print("kf functions", n1, n2, n3, int((bi >= 0).sum()), n4, n5, n6)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "more":
         more()
+    elif len(sys.argv) > 1 and sys.argv[1] == "kf":
+        kf_functions()
     else:
         main()
         more()
+        kf_functions()

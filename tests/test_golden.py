@@ -134,3 +134,70 @@ def test_hip_reproduces_second_set(capi):
     S, st = capi.pose_graph_optimize(z["pg_S0"], z["pg_fixed"], z["pg_ev"], z["pg_em"], iterations=20)
     assert abs(st["chi2_per_iter"][0] - z["pg_stats"][6]) <= 5e-5 * z["pg_stats"][6]        # first LM step (see test_gpu_ba)
     assert st["chi2_final"] <= 1.5 * z["pg_stats"][3] and z["pg_stats"][3] <= 1.5 * st["chi2_final"]
+
+
+def _kf_from_golden(z, tag):
+    kf = {k: z[f"{tag}_{k}"] for k in ("kps", "desc", "mp", "bad", "Rcw", "tcw", "Ow")}
+    kf["fv"] = {k: z[f"{tag}_{k}"] for k in ("fv_nodes", "fv_off", "fv_feat")}
+    for k in ("K", "bounds", "scale_factors", "level_sigma2", "inv_level_sigma2"):
+        kf[k] = z[k]
+    kf["log_scale_factor"] = float(z["log_scale_factor"])
+    return kf
+
+
+def test_oracle_reproduces_kf_matcher_functions(oracle):
+    z = np.load(os.path.join(G, "kf_matcher_functions.npz"))
+    a, b = _kf_from_golden(z, "a"), _kf_from_golden(z, "b")
+    pts = _sub(z, "pt_")
+    n, m = oracle.search_by_bow_kf_kf(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["mp"], b["bad"], b["fv"], 0.8, True)
+    assert n == int(z["bowkk_n"]) and np.array_equal(m, z["bowkk_m"])
+    n, m = oracle.search_by_bow_kf_frame(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["fv"], 0.7, True)
+    assert n == int(z["bowkf_n"]) and np.array_equal(m, z["bowkf_m"])
+    geo = oracle.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    assert np.array_equal(geo[3], z["tri_F12"]) and np.array_equal(geo[2], z["tri_ep"])
+    n, pairs = oracle.search_for_triangulation(a["kps"], a["desc"], a["mp"], a["fv"], b["kps"], b["desc"], b["mp"], b["fv"], geo[3], geo[2],
+                                               b["scale_factors"], b["level_sigma2"], False, True)
+    assert n == int(z["tri_n"]) and np.array_equal(pairs, z["tri_pairs"])
+    bi, bd, pr = oracle.project_search(b["kps"], b["desc"], b["bounds"], None, b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 3.0, b["scale_factors"],
+                                       b["log_scale_factor"], b["inv_level_sigma2"], 5.99)
+    assert np.array_equal(bi, z["ps_idx"]) and np.array_equal(bd, z["ps_dist"]) and np.array_equal(pr, z["ps_proj"])
+    n, m = oracle.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], z["sim3_matched_in"], b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 8,
+                                            1.0, b["scale_factors"], b["log_scale_factor"])
+    assert n == int(z["sim3_n"]) and np.array_equal(m, z["sim3_m"])
+    n, mp, rep = oracle.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 4.0,
+                                  b["scale_factors"], b["log_scale_factor"])
+    assert n == int(z["fuse_n"]) and np.array_equal(mp, z["fuse_mp"]) and np.array_equal(rep, z["fuse_rep"])
+    si = _sub(z, "i_")
+    n, m, pm = oracle.search_for_initialization(si["k1"], si["d1"], si["k2"], si["d2"], si["bounds"], si["prev_matched"], 100, 0.9, True)
+    assert n == int(z["init_n"]) and np.array_equal(m, z["init_m"]) and np.array_equal(pm, z["init_pm"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_kf_matcher_functions(capi):
+    z = np.load(os.path.join(G, "kf_matcher_functions.npz"))
+    a, b = _kf_from_golden(z, "a"), _kf_from_golden(z, "b")
+    pts = _sub(z, "pt_")
+    a["mp"] = a["mp"].copy(); b["mp"] = b["mp"].copy()
+    va, vb = capi.keyframe_view(a), capi.keyframe_view(b)
+    n, m, _ = capi.search_by_bow_kf_kf(va, vb, 0.8, True)
+    assert n == int(z["bowkk_n"]) and np.array_equal(m, z["bowkk_m"])
+    F = capi.frame_view(b["kps"], b["desc"], b["bounds"], b["scale_factors"])
+    n, m, _ = capi.search_by_bow_kf_frame(va, F, b["fv"], 0.7, True)
+    assert n == int(z["bowkf_n"]) and np.array_equal(m, z["bowkf_m"])
+    geo = capi.triangulation_geometry(va, vb)
+    assert np.array_equal(geo[3], z["tri_F12"]) and np.array_equal(geo[2], z["tri_ep"])
+    n, pairs = capi.search_for_triangulation(va, vb, False, True)
+    assert n == int(z["tri_n"]) and np.array_equal(pairs, z["tri_pairs"])
+    P = capi.map_points_view(pts)
+    n, bi = capi.fuse(vb, capi.map_points_view({k: v for k, v in pts.items() if k != "bad"}), None, 3.0)
+    assert np.array_equal(bi, np.where((z["ps_idx"] >= 0) & (z["ps_dist"] <= 50), z["ps_idx"], -1))
+    # unit-scale similarity == the keyframe pose
+    n, m, _ = capi.search_by_projection_sim3(vb, b["Rcw"], b["tcw"], 1.0, P, z["sim3_matched_in"], 8, 1.0)
+    assert n == int(z["sim3_n"]) and np.array_equal(m, z["sim3_m"])
+    n, rep = capi.fuse_sim3(vb, b["Rcw"], b["tcw"], 1.0, P, 4.0)
+    assert n == int(z["fuse_n"]) and np.array_equal(b["mp"], z["fuse_mp"]) and np.array_equal(rep, z["fuse_rep"])
+    si = _sub(z, "i_")
+    F1 = capi.frame_view(si["k1"], si["d1"], si["bounds"], si["scale_factors"])
+    F2 = capi.frame_view(si["k2"], si["d2"], si["bounds"], si["scale_factors"])
+    n, m, pm = capi.search_for_initialization(F1, F2, si["prev_matched"], 100, 0.9, True)
+    assert n == int(z["init_n"]) and np.array_equal(m, z["init_m"]) and np.array_equal(pm, z["init_pm"])

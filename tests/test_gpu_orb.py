@@ -92,10 +92,22 @@ def test_chunked_pipeline_equals_single(capi, oracle, frames):
         del os.environ["DVM_CHUNKS"]
 
 
-def _chunked(capi, oracle, frames):
+@pytest.mark.parametrize("groups", ["1,3", "0,2", "2,8"])
+def test_level_group_pipelining_equals_single(capi, oracle, frames, groups):
+    """DVM_GROUPS=a,b launches FAST per level group and the octree of a group on a second stream under the next
+    group's FAST cells (orb_pipeline.cpp, off by default): results must not change."""
+    import os
+    os.environ["DVM_GROUPS"] = groups
+    try:
+        _chunked(capi, oracle, frames, sizes=(64,))
+    finally:
+        del os.environ["DVM_GROUPS"]
+
+
+def _chunked(capi, oracle, frames, sizes=(64, 97, 256)):
     orc = oracle.OrbOracle()
     ref = [orc.extract(f) for f in frames]
-    for B in (64, 97, 256):
+    for B in sizes:
         batch = np.stack([frames[i % len(frames)] for i in range(B)])
         e = capi.OrbExtractor(max_batch=B)
         for rep in range(2):
