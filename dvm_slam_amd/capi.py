@@ -797,21 +797,36 @@ def fuse_sim3(KF, R, t, s, P, th, device=0):
     return n, rep[:P[0].n]
 
 
-def search_by_projection_sim3(KF, R, t, s, P, matched, th, ratio_hamming=1.0, device=0):
-    """SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) (:395-496).  Returns (nmatches, vpMatched, #re-queries)."""
+def search_by_projection_sim3(KF, R, t, s, P, matched, th, ratio_hamming=1.0, device=0, point_kf=None, matched_kf=None):
+    """SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) (:395-496); with point_kf / matched_kf the overload
+    that also fills vpMatchedKF (:498-603).  Returns (nmatches, vpMatched, #re-queries[, vpMatchedKF])."""
     S = _sim3_view(R, t, s)
     m = np.array(matched, np.int32, copy=True); rq = C.c_int32(0)
+    pk = None if point_kf is None else np.ascontiguousarray(point_kf, np.int32)
+    mk = None if matched_kf is None else np.array(matched_kf, np.int32, copy=True)
     n = _hcall("dvmh_search_by_projection_sim3", C.c_int32, C.c_int32(device), C.byref(KF[0]), C.byref(S), C.byref(P[0]),
-               C.c_void_p(m.ctypes.data), C.c_int32(int(th)), C.c_float(ratio_hamming), C.byref(rq))
+               None if pk is None else C.c_void_p(pk.ctypes.data), C.c_void_p(m.ctypes.data),
+               None if mk is None else C.c_void_p(mk.ctypes.data), C.c_int32(int(th)), C.c_float(ratio_hamming), C.byref(rq))
     check(min(n, 0))
-    return n, m, rq.value
+    return (n, m, rq.value) if mk is None else (n, m, rq.value, mk)
+
+
+def search_by_sim3(KF1, KF2, P1, P2, matches12, idx_in_kf2, s12, R12, t12, th, device=0):
+    """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1347-1551).  Returns (nFound, vpMatches12 updated)."""
+    S = _sim3_view(R12, t12, s12)
+    m = np.array(matches12, np.int32, copy=True)
+    ix = None if idx_in_kf2 is None else np.ascontiguousarray(idx_in_kf2, np.int32)
+    n = _hcall("dvmh_search_by_sim3", C.c_int32, C.c_int32(device), C.byref(KF1[0]), C.byref(KF2[0]), C.byref(P1[0]), C.byref(P2[0]),
+               C.c_void_p(m.ctypes.data), None if ix is None else C.c_void_p(ix.ctypes.data), C.byref(S), C.c_float(th))
+    check(min(n, 0))
+    return n, m
 
 
 def project_search(grid, cam, pts, th, scale_factors, skip=None, gate_inv_sigma2=None, gate=5.99, valid=None):
     """dvm_project_search on a FrameGrid slot 0.  cam: dict(Rcw, tcw, Ow, K, bounds, log_scale_factor).  Returns (matches, proj)."""
     class _Cam(C.Structure):
         _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("K", C.c_float * 4), ("b", C.c_float * 4),
-                    ("lsf", C.c_float), ("nl", C.c_int32)]
+                    ("lsf", C.c_float), ("nl", C.c_int32), ("sim3_pair", C.c_int32), ("sR2", C.c_float * 9), ("t2", C.c_float * 3)]
     sf = np.ascontiguousarray(scale_factors, np.float32)
     c = _Cam()
     c.Rcw = (C.c_float * 9)(*np.asarray(cam["Rcw"], np.float32).reshape(-1)); c.tcw = (C.c_float * 3)(*np.asarray(cam["tcw"], np.float32))

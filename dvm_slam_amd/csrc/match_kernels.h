@@ -61,6 +61,8 @@ struct TrackPoint {  // == dvm_track_point
 struct ProjectCam {  // == dvm_kf_camera (+ th)
   float R[9], t[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
   int32_t n_levels;
+  int32_t sim3_pair;      // != 0: SearchBySim3 form, p' = sR2 * (R p + t) + t2, distance = |p'|, no viewing-angle test
+  float sR2[9], t2[3];
   float th;
 };
 struct Projection {  // == dvm_projection

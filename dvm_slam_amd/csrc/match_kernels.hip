@@ -286,25 +286,38 @@ __global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, 
   pr.u = -1.f; pr.v = -1.f; pr.radius = 0.f; pr.level = -1;
   bool ok = valid == nullptr || valid[i] != 0;
   const float p0 = P[3 * i], p1 = P[3 * i + 1], p2 = P[3 * i + 2];
-  const float X = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(C.R[0], p0), __fmul_rn(C.R[1], p1)), __fmul_rn(C.R[2], p2)), C.t[0]);
-  const float Y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(C.R[3], p0), __fmul_rn(C.R[4], p1)), __fmul_rn(C.R[5], p2)), C.t[1]);
-  const float Z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(C.R[6], p0), __fmul_rn(C.R[7], p1)), __fmul_rn(C.R[8], p2)), C.t[2]);
+  float X = (C.R[0] * p0 + C.R[1] * p1 + C.R[2] * p2) + C.t[0];
+  float Y = (C.R[3] * p0 + C.R[4] * p1 + C.R[5] * p2) + C.t[1];
+  float Z = (C.R[6] * p0 + C.R[7] * p1 + C.R[8] * p2) + C.t[2];
+  float u, v;
+  if (C.sim3_pair) {   // SearchBySim3 (:1395-1411): p3Dc2 = S21 * (T1w * p3Dw); u = fx * (X * invz) + cx with invz = 1.0 / Z
+    const float X2 = (C.sR2[0] * X + C.sR2[1] * Y + C.sR2[2] * Z) + C.t2[0];
+    const float Y2 = (C.sR2[3] * X + C.sR2[4] * Y + C.sR2[5] * Z) + C.t2[1];
+    const float Z2 = (C.sR2[6] * X + C.sR2[7] * Y + C.sR2[8] * Z) + C.t2[2];
+    X = X2; Y = Y2; Z = Z2;
+    const float invz = (float)(1.0 / (double)Z);
+    u = C.fx * (X * invz) + C.cx;
+    v = C.fy * (Y * invz) + C.cy;
+  } else {
+    u = C.fx * X / Z + C.cx;
+    v = C.fy * Y / Z + C.cy;
+  }
   ok = ok && !(Z < 0.0f);
-  const float u = __fadd_rn(__fdiv_rn(__fmul_rn(C.fx, X), Z), C.cx), v = __fadd_rn(__fdiv_rn(__fmul_rn(C.fy, Y), Z), C.cy);
   ok = ok && (u >= C.min_x && u < C.max_x && v >= C.min_y && v < C.max_y);
   if (ok) {
-    const float maxDistance = __fmul_rn(1.2f, max_dist[i]), minDistance = __fmul_rn(0.8f, min_dist[i]);
-    const float q0 = __fsub_rn(p0, C.Ow[0]), q1 = __fsub_rn(p1, C.Ow[1]), q2 = __fsub_rn(p2, C.Ow[2]);
-    const float dist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(q0, q0), __fmul_rn(q1, q1)), __fmul_rn(q2, q2)));
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    float q0 = p0 - C.Ow[0], q1 = p1 - C.Ow[1], q2 = p2 - C.Ow[2];
+    if (C.sim3_pair) { q0 = X; q1 = Y; q2 = Z; }
+    const float dist = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
     ok = !(dist < minDistance || dist > maxDistance);
     if (ok) {
-      const float dot = __fadd_rn(__fadd_rn(__fmul_rn(q0, normal[3 * i]), __fmul_rn(q1, normal[3 * i + 1])), __fmul_rn(q2, normal[3 * i + 2]));
-      ok = !((double)dot < 0.5 * (double)dist);
+      const float dot = (q0 * normal[3 * i] + q1 * normal[3 * i + 1]) + q2 * normal[3 * i + 2];
+      ok = C.sim3_pair || !((double)dot < 0.5 * (double)dist);
       if (ok) {
-        const float ratio = __fdiv_rn(max_dist[i], dist);
-        int nScale = (int)ceilf(__fdiv_rn(logf(ratio), C.log_scale_factor));
+        const float ratio = max_dist[i] / dist;
+        int nScale = (int)ceilf(logf(ratio) / C.log_scale_factor);
         nScale = nScale < 0 ? 0 : (nScale >= C.n_levels ? C.n_levels - 1 : nScale);
-        pr.u = u; pr.v = v; pr.level = nScale; pr.radius = __fmul_rn(C.th, scale_factors[nScale]);
+        pr.u = u; pr.v = v; pr.level = nScale; pr.radius = C.th * scale_factors[nScale];
       }
     }
   }

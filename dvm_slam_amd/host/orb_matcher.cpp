@@ -564,6 +564,7 @@ int ORBmatcher::project_search(const KeyFrameView& KF, const float* Rcw, const f
   int rc = ensure_grid(KF);
   if (rc != DVM_OK) return rc;
   dvm_kf_camera cam;
+  std::memset(&cam, 0, sizeof(cam));
   std::memcpy(cam.Rcw, Rcw, 36); std::memcpy(cam.tcw, tcw, 12); std::memcpy(cam.Ow, Ow, 12);
   cam.fx = KF.fx; cam.fy = KF.fy; cam.cx = KF.cx; cam.cy = KF.cy;
   cam.min_x = KF.mnMinX; cam.max_x = KF.mnMaxX; cam.min_y = KF.mnMinY; cam.max_y = KF.mnMaxY;
@@ -633,6 +634,11 @@ int ORBmatcher::Fuse(KeyFrameView& KF, const Sim3View& Scw, const MapPointsView&
 
 int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& P, int32_t* vpMatched, int th,
                                    float ratioHamming) {
+  return SearchByProjection(KF, Scw, P, nullptr, vpMatched, nullptr, th, ratioHamming);
+}
+
+int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& P, const int32_t* vpPointsKFs,
+                                   int32_t* vpMatched, int32_t* vpMatchedKF, int th, float ratioHamming) {
   if (P.n == 0) return 0;
   last_requeried = 0;
   float tcw[3], Ow[3];
@@ -665,9 +671,61 @@ int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, 
         if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
       }
     }
-    if (bestIdx >= 0 && bestDist <= TH_LOW * ratioHamming) { vpMatched[bestIdx] = P.id[i]; nmatches++; }
+    if (bestIdx >= 0 && bestDist <= TH_LOW * ratioHamming) {
+      vpMatched[bestIdx] = P.id[i];
+      if (vpMatchedKF && vpPointsKFs) vpMatchedKF[bestIdx] = vpPointsKFs[i];
+      nmatches++;
+    }
   }
   return nmatches;
+}
+
+int ORBmatcher::SearchBySim3(const KeyFrameView& KF1, const KeyFrameView& KF2, const MapPointsView& MPs1, const MapPointsView& MPs2,
+                             int32_t* vpMatches12, const int32_t* vnIdxInKF2, const Sim3View& S12, float th) {
+  const int N1 = KF1.N, N2 = KF2.N;
+  float sR12[9], sR21[9], t21[3];   // S21 = S12.inverse(); a Sim3 acts as (s R) p + t
+  const float s21 = 1.0f / S12.s;
+  for (int k = 0; k < 9; k++) sR12[k] = S12.s * S12.R[k];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) sR21[3 * r + c] = s21 * S12.R[3 * c + r];
+  for (int r = 0; r < 3; r++) t21[r] = -((sR21[3 * r] * S12.t[0] + sR21[3 * r + 1] * S12.t[1]) + sR21[3 * r + 2] * S12.t[2]);
+  std::vector<uint8_t> valid1(N1, 0), valid2(N2, 0), am2(N2, 0);
+  for (int i = 0; i < N1; i++) {
+    if (vpMatches12[i] >= 0) {
+      const int idx2 = vnIdxInKF2 ? vnIdxInKF2[i] : -1;
+      if (idx2 >= 0 && idx2 < N2) am2[idx2] = 1;
+    } else if (KF1.mvpMapPoints[i] >= 0 && !(KF1.mpBad && KF1.mpBad[i])) valid1[i] = 1;
+  }
+  for (int i = 0; i < N2; i++)
+    if (KF2.mvpMapPoints[i] >= 0 && !am2[i] && !(KF2.mpBad && KF2.mpBad[i])) valid2[i] = 1;
+  auto direction = [&](const KeyFrameView& from, const KeyFrameView& into, const MapPointsView& P, const std::vector<uint8_t>& valid,
+                       const float* sR, const float* t, std::vector<dvm_match>& res) -> int {
+    int rc = ensure_grid(into);
+    if (rc != DVM_OK) return rc;
+    dvm_kf_camera cam;
+    std::memset(&cam, 0, sizeof(cam));
+    std::memcpy(cam.Rcw, from.Rcw, 36); std::memcpy(cam.tcw, from.tcw, 12);
+    cam.fx = KF1.fx; cam.fy = KF1.fy; cam.cx = KF1.cx; cam.cy = KF1.cy;   // the reference uses pKF1's calibration in both directions
+    cam.min_x = into.mnMinX; cam.max_x = into.mnMaxX; cam.min_y = into.mnMinY; cam.max_y = into.mnMaxY;
+    cam.log_scale_factor = into.mfLogScaleFactor; cam.n_levels = into.nLevels;
+    cam.sim3_pair = 1;
+    std::memcpy(cam.sR2, sR, 36); std::memcpy(cam.t2, t, 12);
+    res.resize(P.n);
+    return dvm_project_search(grid_, 0, nullptr, &cam, P.pos, P.normal ? P.normal : P.pos, P.min_dist, P.max_dist, P.desc, valid.data(), P.n,
+                              th, into.mvScaleFactors, nullptr, 0.0, res.data(), nullptr, 0, nullptr);
+  };
+  std::vector<dvm_match> r1, r2;
+  int rc = direction(KF1, KF2, MPs1, valid1, sR21, t21, r1);
+  if (rc != DVM_OK) return rc;
+  rc = direction(KF2, KF1, MPs2, valid2, sR12, S12.t, r2);
+  if (rc != DVM_OK) return rc;
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    if (!valid1[i1] || r1[i1].best_idx < 0 || r1[i1].best_dist > TH_HIGH) continue;
+    const int idx2 = r1[i1].best_idx;
+    if (valid2[idx2] && r2[idx2].best_dist <= TH_HIGH && r2[idx2].best_idx == i1) { vpMatches12[i1] = KF2.mvpMapPoints[idx2]; nFound++; }
+  }
+  return nFound;
 }
 
 }  // namespace dvm_host
@@ -747,10 +805,15 @@ int dvmh_fuse_sim3(int device, KeyFrameView* KF, const Sim3View* Scw, const MapP
   dvm_host::ORBmatcher m(0.6f, true, device);
   return m.Fuse(*KF, *Scw, *P, th, replace);
 }
-int dvmh_search_by_projection_sim3(int device, const KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, int32_t* matched,
-                                   int th, float ratio_hamming, int* requeried) {
+int dvmh_search_by_sim3(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, const MapPointsView* P1, const MapPointsView* P2,
+                        int32_t* matches12, const int32_t* idx_in_kf2, const Sim3View* S12, float th) {
   dvm_host::ORBmatcher m(0.6f, true, device);
-  const int n = m.SearchByProjection(*KF, *Scw, *P, matched, th, ratio_hamming);
+  return m.SearchBySim3(*KF1, *KF2, *P1, *P2, matches12, idx_in_kf2, *S12, th);
+}
+int dvmh_search_by_projection_sim3(int device, const KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, const int32_t* point_kf,
+                                   int32_t* matched, int32_t* matched_kf, int th, float ratio_hamming, int* requeried) {
+  dvm_host::ORBmatcher m(0.6f, true, device);
+  const int n = m.SearchByProjection(*KF, *Scw, *P, point_kf, matched, matched_kf, th, ratio_hamming);
   if (requeried) *requeried = m.last_requeried;
   return n;
 }

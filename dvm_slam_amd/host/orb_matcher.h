@@ -144,6 +144,15 @@ class ORBmatcher {
   //                        int th, float ratioHamming)   (:395-496), whole function.  vpMatched: KF.N ids (in/out).
   int SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& vpPoints, int32_t* vpMatched, int th,
                          float ratioHamming = 1.f);
+  // ... and the overload that also records which keyframe each point came from (:498-603): vpPointsKFs[i] -> vpMatchedKF[idx]
+  int SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& vpPoints, const int32_t* vpPointsKFs,
+                         int32_t* vpMatched, int32_t* vpMatchedKF, int th, float ratioHamming = 1.f);
+  // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th)
+  // (:1347-1551), whole function.  MPsN: the map point of every keypoint of KFN (entry i is read only where
+  // KFN.mvpMapPoints[i] >= 0); vnIdxInKF2[i] = get<0>(vpMatches12[i]->GetIndexInKeyFrame(pKF2)) for the entries set at entry
+  // (may be null).  Both directions are one dvm_project_search call each (cam.sim3_pair); the mutual check is host code.
+  int SearchBySim3(const KeyFrameView& KF1, const KeyFrameView& KF2, const MapPointsView& MPs1, const MapPointsView& MPs2,
+                   int32_t* vpMatches12, const int32_t* vnIdxInKF2, const Sim3View& S12, float th);
 
   int last_requeried = 0;  // queries re-issued on the host because an earlier match claimed their keypoint
 

@@ -179,15 +179,23 @@ int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, 
 
 /* Projection of n map points into a keyframe + windowed best-descriptor search -- the common body of
  * ORBmatcher::Fuse(KF, vpMapPoints, th) (ORBmatcher.cc:1060-1234, gate_inv_sigma2 = KF.mvInvLevelSigma2, gate = 5.99),
- * Fuse(KF, Scw, ...) (:1236-1345), SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) x2 (:395-603)
- * (gate_inv_sigma2 = NULL).  Per point (skipped when valid[i] == 0; valid may be NULL): p3Dc = Rcw*p + tcw (for the
+ * Fuse(KF, Scw, ...) (:1236-1345), SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) x2 (:395-603),
+ * both directions of SearchBySim3 (:1347-1551; cam->sim3_pair) (gate_inv_sigma2 = NULL).  Per point (skipped when valid[i] == 0; valid may be NULL): p3Dc = Rcw*p + tcw (for the
  * Sim3 variants Rcw = Scw.rotationMatrix(), tcw = Scw.translation()/Scw.scale()), depth >= 0, KeyFrame::IsInImage,
  * dist in [0.8*min_dist, 1.2*max_dist], PO.Pn >= 0.5*dist, level = MapPoint::PredictScale, radius = th *
  * scale_factors[level], candidates = KeyFrame::GetFeaturesInArea(u, v, radius) with octave in [level-1, level], minus
  * skip[idx] != 0 (skip may be NULL; `cap` bytes of the train frame).  out[i] = best / second best (strict '<', first
  * wins); proj[i] (may be NULL) = projection, radius and predicted level (-1: rejected before the search).
  * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
-typedef struct { float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor; int32_t n_levels; } dvm_kf_camera;
+typedef struct {
+  float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
+  int32_t n_levels;
+  /* sim3_pair != 0 selects the ORBmatcher::SearchBySim3 form (ORBmatcher.cc:1380-1437): p' = sR2 * (Rcw p + tcw) + t2
+   * (the other keyframe's pose, then S21 resp. S12 with sR2 = scale * rotation), u = fx * (X * invz) + cx with
+   * invz = 1.0 / Z, distance = |p'|, no viewing-angle test; Ow is not used. */
+  int32_t sim3_pair;
+  float sR2[9], t2[3];
+} dvm_kf_camera;
 typedef struct { float u, v, radius; int32_t level; } dvm_projection;
 int dvm_project_search(const dvm_frame* train, int slot, const uint8_t* skip, const dvm_kf_camera* cam, const float* P,
                        const float* normal, const float* min_dist, const float* max_dist, const uint8_t* desc,

@@ -24,6 +24,7 @@
 //                                whole function, :395-496 SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming)
 //                                whole function; KeyFrame.cc:750-794 GetFeaturesInArea / IsInImage; MapPoint.cc:573-587
 //                                PredictScale              -> orc_project_search(), orc_fuse_sim3(), orc_search_by_projection_sim3()
+//   src/ORBmatcher.cc:1347-1551  SearchBySim3, whole function      -> orc_search_by_sim3()
 //   src/MapPoint.cc:384-453      MapPoint::ComputeDistinctiveDescriptors -> orc_distinctive_descriptors()
 //   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1025-1138 transform (TF_IDF, L1), BowVector.cpp:32-72,
 //   FeatureVector.cpp:27-38, ScoringObject.cpp:23-63 L1Scoring::score, FORB.cpp:80-97 -> orc_vocab_transform(), orc_bow_score()
@@ -765,6 +766,82 @@ int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t*
     if (bi >= 0 && bd <= kThLow * ratioHamming) { matched[bi] = point_id[i]; nmatches++; }
   }
   return nmatches;
+}
+
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1347-1551).  Per-keypoint map point data: mpN[i] id (-1 NULL),
+// badN[i], PN (3 per keypoint), minN / maxN (mfMin/MaxDistance), mdescN (32 per keypoint).  idx_in_kf2[i] =
+// get<0>(vpMatches12[i]->GetIndexInKeyFrame(pKF2)) for the entries of matches12 that are set at entry.  S12 = (s, R, t);
+// S21 = S12.inverse() = (1/s, R^T, -(1/s) R^T t); a Sim3 acts as (s R) p + t with the matrix s R formed first.
+namespace {
+void sim3_direction(int Na, const int32_t* mpa, const uint8_t* bada, const uint8_t* already_a, const float* Pa, const float* mina,
+                    const float* maxa, const uint8_t* mdesca, const float* Raw, const float* taw, const float* sR, const float* t,
+                    int Nb, const orc_keypoint* kpsb, const uint8_t* descb, const float* bounds, const float* K, float th,
+                    const float* scale_factors, float log_scale_factor, int n_levels, std::vector<int>& vnMatch) {
+  orc_grid* g = orc_grid_create(kpsb, Nb, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> vIndices;
+  vnMatch.assign(Na, -1);
+  for (int i = 0; i < Na; i++) {
+    if (mpa[i] < 0 || already_a[i]) continue;
+    if (bada && bada[i]) continue;
+    const float* p = Pa + 3 * i;
+    float c1[3], c2[3];
+    for (int r = 0; r < 3; r++) c1[r] = ((Raw[3 * r] * p[0] + Raw[3 * r + 1] * p[1]) + Raw[3 * r + 2] * p[2]) + taw[r];
+    for (int r = 0; r < 3; r++) c2[r] = ((sR[3 * r] * c1[0] + sR[3 * r + 1] * c1[1]) + sR[3 * r + 2] * c1[2]) + t[r];
+    if (c2[2] < 0.0) continue;
+    const float invz = 1.0 / c2[2];
+    const float x = c2[0] * invz, y = c2[1] * invz;
+    const float u = K[0] * x + K[2], v = K[1] * y + K[3];
+    if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) continue;
+    const float maxDistance = 1.2f * maxa[i], minDistance = 0.8f * mina[i];
+    const float dist3D = std::sqrt((c2[0] * c2[0] + c2[1] * c2[1]) + c2[2] * c2[2]);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float ratio = maxa[i] / dist3D;
+    int nScale = (int)std::ceil(std::log(ratio) / log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+    const float radius = th * scale_factors[nScale];
+    features_in_area(g, u, v, radius, -1, -1, vIndices);
+    int bestDist = INT32_MAX, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (kpsb[idx].octave < nScale - 1 || kpsb[idx].octave > nScale) continue;
+      const int dist = descriptor_distance(mdesca + 32 * (size_t)i, descb + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= 100) vnMatch[i] = bestIdx;   // TH_HIGH
+  }
+  orc_grid_destroy(g);
+}
+}  // namespace
+
+int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const uint8_t* bad1, const float* P1,
+                       const float* min1, const float* max1, const uint8_t* mdesc1, const float* R1w, const float* t1w, int N2,
+                       const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2, const float* P2,
+                       const float* min2, const float* max2, const uint8_t* mdesc2, const float* R2w, const float* t2w,
+                       const float* bounds, const float* K, float s12, const float* R12, const float* t12, float th,
+                       const float* scale_factors, float log_scale_factor, int n_levels, int32_t* matches12, const int32_t* idx_in_kf2) {
+  float sR12[9], sR21[9], t21[3];
+  const float s21 = 1.0f / s12;
+  for (int k = 0; k < 9; k++) sR12[k] = s12 * R12[k];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) sR21[3 * r + c] = s21 * R12[3 * c + r];
+  for (int r = 0; r < 3; r++) t21[r] = -((sR21[3 * r] * t12[0] + sR21[3 * r + 1] * t12[1]) + sR21[3 * r + 2] * t12[2]);
+  std::vector<uint8_t> am1(N1, 0), am2(N2, 0);
+  for (int i = 0; i < N1; i++)
+    if (matches12[i] >= 0) {
+      am1[i] = 1;
+      const int idx2 = idx_in_kf2 ? idx_in_kf2[i] : -1;
+      if (idx2 >= 0 && idx2 < N2) am2[idx2] = 1;
+    }
+  std::vector<int> vnMatch1, vnMatch2;
+  sim3_direction(N1, mp1, bad1, am1.data(), P1, min1, max1, mdesc1, R1w, t1w, sR21, t21, N2, kps2, desc2, bounds, K, th, scale_factors,
+                 log_scale_factor, n_levels, vnMatch1);
+  sim3_direction(N2, mp2, bad2, am2.data(), P2, min2, max2, mdesc2, R2w, t2w, sR12, t12, N1, kps1, desc1, bounds, K, th, scale_factors,
+                 log_scale_factor, n_levels, vnMatch2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = mp2[idx2]; nFound++; }
+  }
+  return nFound;
 }
 
 }  // extern "C"

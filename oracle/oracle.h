@@ -152,6 +152,13 @@ int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t*
                                   const float* max_dist, const uint8_t* pdesc, int th, float ratioHamming, const float* scale_factors,
                                   float log_scale_factor, int n_levels);
 
+int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const uint8_t* bad1, const float* P1,
+                       const float* min1, const float* max1, const uint8_t* mdesc1, const float* R1w, const float* t1w, int N2,
+                       const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2, const float* P2,
+                       const float* min2, const float* max2, const uint8_t* mdesc2, const float* R2w, const float* t2w,
+                       const float* bounds, const float* K, float s12, const float* R12, const float* t12, float th,
+                       const float* scale_factors, float log_scale_factor, int n_levels, int32_t* matches12, const int32_t* idx_in_kf2);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
 

@@ -539,6 +539,21 @@ def search_by_projection_sim3(kps, desc, bounds, matched, Rcw, tcw, Ow, K, pts, 
     return nm, m
 
 
+def search_by_sim3(kf1, mps1, kf2, mps2, s12, R12, t12, th, matches12, idx_in_kf2):
+    """ORBmatcher::SearchBySim3.  kfN: keyframe dicts (kps, desc, mp, bad, Rcw, tcw, bounds, K, scale_factors, log_scale_factor);
+    mpsN: per-keypoint map point data dict(pos, min_dist, max_dist, desc).  Returns (nFound, vpMatches12 updated)."""
+    k1, d1 = _kd(kf1["kps"], kf1["desc"]); k2, d2 = _kd(kf2["kps"], kf2["desc"])
+    m = np.array(matches12, np.int32, copy=True)
+    sf = _f32(kf1["scale_factors"])
+    n = _call(lib().orc_search_by_sim3, C.c_int32, len(k1), k1, d1, np.ascontiguousarray(kf1["mp"], np.int32), _u8(kf1.get("bad")),
+              _f32(mps1["pos"]), _f32(mps1["min_dist"]), _f32(mps1["max_dist"]), _u8(mps1["desc"]), _f32(kf1["Rcw"]).reshape(-1), _f32(kf1["tcw"]),
+              len(k2), k2, d2, np.ascontiguousarray(kf2["mp"], np.int32), _u8(kf2.get("bad")), _f32(mps2["pos"]), _f32(mps2["min_dist"]),
+              _f32(mps2["max_dist"]), _u8(mps2["desc"]), _f32(kf2["Rcw"]).reshape(-1), _f32(kf2["tcw"]), _f32(kf1["bounds"]), _f32(kf1["K"]),
+              F32(s12), _f32(R12).reshape(-1), _f32(t12), F32(th), sf, F32(kf1["log_scale_factor"]), len(sf), m,
+              None if idx_in_kf2 is None else np.ascontiguousarray(idx_in_kf2, np.int32))
+    return n, m
+
+
 def distinctive_descriptors(desc, off):
     """MapPoint::ComputeDistinctiveDescriptors for a batch.  Returns (best_idx, best_median)."""
     L = lib()

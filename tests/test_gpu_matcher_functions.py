@@ -166,3 +166,46 @@ def test_fuse_and_sim3_searches(capi, oracle, seed):
         assert nm_g == nm_o and np.array_equal(m_g, m_o)
         if th == 8:
             assert nm_o > 50 and req > 0, "scene must exercise the claimed-keypoint re-query"
+
+
+def _per_keypoint_points(kf, pts):
+    """Map point data per keypoint (the point a keypoint observes; arbitrary where mvpMapPoints < 0)."""
+    idx = np.where(kf["pt_of_kp"] >= 0, kf["pt_of_kp"], 0).astype(np.int64)
+    return dict(pos=pts["pos"][idx], normal=pts["normal"][idx], min_dist=pts["min_dist"][idx], max_dist=pts["max_dist"][idx], desc=pts["desc"][idx])
+
+
+@pytest.mark.parametrize("seed,s12,th", [(0, 1.0, 7.5), (1, 1.03, 7.5), (2, 0.97, 3.0)])
+def test_search_by_sim3(capi, oracle, seed, s12, th):
+    sc = make_kf_pair_scene(oracle, seed, mapped_frac=0.8)
+    a, b = sc["kf"]
+    geo = oracle.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    R12, t12 = geo[0], geo[1]
+    p1, p2 = _per_keypoint_points(a, sc["pts"]), _per_keypoint_points(b, sc["pts"])
+    rng = np.random.default_rng(seed)
+    # a few matches known at entry (their KF2 index marks vbAlreadyMatched2)
+    m_in = np.full(len(a["kps"]), -1, np.int32); idx2 = np.full(len(a["kps"]), -1, np.int32)
+    for i in rng.choice(len(a["kps"]), 40, replace=False):
+        j = np.nonzero((b["pt_of_kp"] == a["pt_of_kp"][i]) & (a["pt_of_kp"][i] >= 0))[0]
+        if len(j) and a["mp"][i] >= 0:
+            m_in[i] = a["mp"][i]; idx2[i] = j[0]
+    n_o, m_o = oracle.search_by_sim3(a, p1, b, p2, s12, R12, t12, th, m_in, idx2)
+    va = capi.keyframe_view(dict(a, mp=a["mp"].copy())); vb = capi.keyframe_view(dict(b, mp=b["mp"].copy()))
+    n_g, m_g = capi.search_by_sim3(va, vb, capi.map_points_view(p1), capi.map_points_view(p2), m_in, idx2, s12, R12, t12, th)
+    assert n_g == n_o and np.array_equal(m_g, m_o)
+    if th > 5:
+        assert n_o > 150
+
+
+def test_search_by_projection_sim3_records_keyframes(capi, oracle):
+    sc = make_kf_pair_scene(oracle, 4, dup_frac=0.25)
+    kf, pts = sc["kf"][1], sc["pts"]
+    matched = np.full(len(kf["kps"]), -1, np.int32)
+    point_kf = (np.arange(len(pts["pos"])) % 17 + 500).astype(np.int32)
+    nm_o, m_o = oracle.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], pts, 8, 1.0,
+                                                 kf["scale_factors"], kf["log_scale_factor"])
+    v = capi.keyframe_view(dict(kf, mp=kf["mp"].copy()))
+    nm_g, m_g, _, mk = capi.search_by_projection_sim3(v, kf["Rcw"], kf["tcw"], 1.0, capi.map_points_view(pts), matched, 8, 1.0, point_kf=point_kf,
+                                                      matched_kf=np.full(len(kf["kps"]), -1, np.int32))
+    assert nm_g == nm_o and np.array_equal(m_g, m_o)
+    hit = m_g >= 0
+    assert np.array_equal(mk[hit], point_kf[m_g[hit] - 1000]) and np.all(mk[~hit] == -1)
