@@ -846,3 +846,100 @@ def project_search(grid, cam, pts, th, scale_factors, skip=None, gate_inv_sigma2
     check(fn(grid.h, C.c_int32(0), vp(sk), C.byref(c), C.c_void_p(P.pos), C.c_void_p(P.normal), C.c_void_p(P.min_dist), C.c_void_p(P.max_dist),
              C.c_void_p(P.desc), vp(va), C.c_int32(n), C.c_float(th), vp(sf), vp(gi), C.c_double(gate), vp(out), vp(proj), C.c_int32(0), None))
     return out[:n], proj[:n]
+
+
+def bowdb_query_raw(bows, q_ids, q_vals, erase=(), device=0):
+    """dvm_bowdb_* directly: store `bows` (list of (ids, vals)), erase some slots, query.  Returns (common, first_word, score)."""
+    L = lib()
+    h = C.c_void_p()
+    L.dvm_bowdb_create.restype = C.c_int32; L.dvm_bowdb_create.argtypes = [C.c_int32, C.c_void_p]
+    check(L.dvm_bowdb_create(device, C.byref(h)))
+    try:
+        for ids, vals in bows:
+            i = np.ascontiguousarray(ids, np.int32); v = np.ascontiguousarray(vals, np.float64)
+            slot = C.c_int32(-1)
+            L.dvm_bowdb_add.restype = C.c_int32; L.dvm_bowdb_add.argtypes = None
+            check(L.dvm_bowdb_add(h, C.c_void_p(i.ctypes.data) if len(i) else None, C.c_void_p(v.ctypes.data) if len(v) else None,
+                                  C.c_int32(len(i)), C.byref(slot)))
+        for s in erase:
+            L.dvm_bowdb_erase.restype = C.c_int32; L.dvm_bowdb_erase.argtypes = None
+            check(L.dvm_bowdb_erase(h, C.c_int32(int(s))))
+        n = len(bows)
+        qi = np.ascontiguousarray(q_ids, np.int32); qv = np.ascontiguousarray(q_vals, np.float64)
+        common = np.zeros(n, np.int32); first = np.zeros(n, np.int32); score = np.zeros(n, np.float32)
+        L.dvm_bowdb_query.restype = C.c_int32; L.dvm_bowdb_query.argtypes = None
+        check(L.dvm_bowdb_query(h, C.c_void_p(qi.ctypes.data) if len(qi) else None, C.c_void_p(qv.ctypes.data) if len(qv) else None,
+                                C.c_int32(len(qi)), C.c_void_p(common.ctypes.data), C.c_void_p(first.ctypes.data), C.c_void_p(score.ctypes.data)))
+        return common, first, score
+    finally:
+        L.dvm_bowdb_destroy.restype = None; L.dvm_bowdb_destroy.argtypes = [C.c_void_p]
+        L.dvm_bowdb_destroy(h)
+
+
+class HostKeyFrameDatabase:
+    """dvm_host::KeyFrameDatabase (host/keyframe_database.cpp over dvm_bowdb_*): add / erase / CalculateMergeScore /
+    DetectMergePossibility / DetectNBestCandidates on keyframe slots (reference KeyFrameDatabase.cc:43-70,555-808)."""
+    PREFIX = "dvmh_kfdb_"
+
+    def _lib(self):
+        return host_lib()
+
+    def __init__(self, device=0):
+        f = host_lib().dvmh_kfdb_create; f.restype = C.c_void_p; f.argtypes = [C.c_int32]
+        self.h = C.c_void_p(f(device))
+        if not self.h.value:
+            raise DvmError(-5, lib().dvm_last_error().decode(errors="replace"))
+
+    def _f(self, name, restype=None):
+        f = getattr(self._lib(), self.PREFIX + name); f.restype = restype; f.argtypes = None
+        return f
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self._f("destroy")(self.h); self.h = C.c_void_p()
+
+    __del__ = close
+
+    @staticmethod
+    def _bow(ids, vals):
+        return np.ascontiguousarray(ids, np.int32), np.ascontiguousarray(vals, np.float64)
+
+    def add(self, ids, vals, map_id, uuid, mn_id):
+        i, v = self._bow(ids, vals)
+        return self._f("add", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_int32(map_id), C.c_uint64(uuid), C.c_int64(mn_id))
+
+    def erase(self, slot): self._f("erase")(self.h, C.c_int32(slot))
+    def set_bad(self, slot, bad): self._f("set_bad")(self.h, C.c_int32(slot), C.c_int32(int(bad)))
+    def set_map_bad(self, map_id, bad): self._f("set_map_bad")(self.h, C.c_int32(map_id), C.c_int32(int(bad)))
+
+    def set_neighbours(self, slot, neigh):
+        a = np.ascontiguousarray(neigh, np.int32)
+        self._f("set_neighbours")(self.h, C.c_int32(slot), _p(a) if len(a) else None, C.c_int32(len(a)))
+
+    def set_connected(self, slot, conn):
+        a = np.ascontiguousarray(conn, np.int32)
+        self._f("set_connected")(self.h, C.c_int32(slot), _p(a) if len(a) else None, C.c_int32(len(a)))
+
+    def state(self, slot):
+        q = C.c_uint64(0); w = C.c_int32(0); s = C.c_float(0)
+        self._f("get_state")(self.h, C.c_int32(slot), C.byref(q), C.byref(w), C.byref(s))
+        return q.value, w.value, s.value
+
+    def merge_score(self, ids, vals, key_frame_id, map_id, score=0.0):
+        i, v = self._bow(ids, vals)
+        sc = C.c_float(score); best = C.c_int32(-1)
+        self._f("merge_score", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_uint64(key_frame_id), C.c_int32(map_id), C.byref(sc), C.byref(best))
+        return sc.value, best.value
+
+    def detect_merge_possibility(self, ids, vals, uuid, map_id):
+        i, v = self._bow(ids, vals)
+        best = C.c_int32(-1); sc = C.c_float(0); base = C.c_float(0)
+        r = self._f("detect_merge_possibility", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_uint64(uuid), C.c_int32(map_id), C.byref(best),
+                                                           C.byref(sc), C.byref(base))
+        return r, best.value, sc.value, base.value
+
+    def detect_n_best(self, slot, n_num):
+        lo = np.zeros(max(n_num, 1), np.int32); me = np.zeros(max(n_num, 1), np.int32)
+        nl = C.c_int32(0); nm = C.c_int32(0)
+        self._f("detect_n_best", C.c_int32)(self.h, C.c_int32(slot), C.c_int32(n_num), _p(lo), C.byref(nl), _p(me), C.byref(nm))
+        return lo[:nl.value].copy(), me[:nm.value].copy()

@@ -578,6 +578,111 @@ int dvm_match_triangulation(const uint8_t* desc1, const dvm_keypoint* kps1, int 
   return rc == DVM_OK ? st.download() : rc;
 }
 
+struct dvm_bowdb {
+  int device = 0;
+  std::vector<int32_t> off, len;          // per slot (len < 0: erased)
+  size_t used = 0, cap = 0;               // words stored / capacity of d_ids, d_vals
+  int32_t* d_ids = nullptr;
+  double* d_vals = nullptr;
+  int32_t *d_off = nullptr, *d_len = nullptr, *d_common = nullptr, *d_first = nullptr;
+  float* d_score = nullptr;
+  size_t slot_cap = 0;
+  bool meta_dirty = true;
+};
+
+void dvm_bowdb_destroy(dvm_bowdb* db) {
+  if (!db) return;
+  hipSetDevice(db->device);
+  for (void* p : {(void*)db->d_ids, (void*)db->d_vals, (void*)db->d_off, (void*)db->d_len, (void*)db->d_common, (void*)db->d_first, (void*)db->d_score})
+    if (p) hipFree(p);
+  delete db;
+}
+
+int dvm_bowdb_create(int device, dvm_bowdb** out) {
+  if (!out) return DVM_ERR_INVALID;
+  *out = nullptr;
+  int rc = need_device(device);
+  if (rc != DVM_OK) return rc;
+  dvm_bowdb* db = new dvm_bowdb;
+  db->device = device;
+  *out = db;
+  return DVM_OK;
+}
+
+int dvm_bowdb_size(const dvm_bowdb* db) { return db ? (int)db->off.size() : 0; }
+
+int dvm_bowdb_add(dvm_bowdb* db, const int32_t* word_ids, const double* values, int n, int32_t* slot) {
+  if (!db || n < 0 || (n > 0 && (!word_ids || !values))) return DVM_ERR_INVALID;
+  for (int i = 1; i < n; i++)
+    if (word_ids[i] <= word_ids[i - 1]) { set_error("bowdb: word ids must be strictly ascending"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(db->device));
+  if (db->used + (size_t)n > db->cap) {   // grow the word arrays (doubling), keeping what is stored
+    const size_t ncap = std::max<size_t>(std::max<size_t>(db->cap * 2, db->used + (size_t)n), 1 << 16);
+    int32_t* ni = nullptr; double* nv = nullptr;
+    DVM_HIP(hipMalloc(&ni, ncap * 4));
+    if (hipMalloc(&nv, ncap * 8) != hipSuccess) { hipFree(ni); set_error("hipMalloc(bowdb)"); return DVM_ERR_HIP; }
+    if (db->used) {
+      DVM_HIP(hipMemcpy(ni, db->d_ids, db->used * 4, hipMemcpyDeviceToDevice));
+      DVM_HIP(hipMemcpy(nv, db->d_vals, db->used * 8, hipMemcpyDeviceToDevice));
+    }
+    if (db->d_ids) hipFree(db->d_ids);
+    if (db->d_vals) hipFree(db->d_vals);
+    db->d_ids = ni; db->d_vals = nv; db->cap = ncap;
+  }
+  if (n) {
+    DVM_HIP(hipMemcpy(db->d_ids + db->used, word_ids, (size_t)n * 4, hipMemcpyHostToDevice));
+    DVM_HIP(hipMemcpy(db->d_vals + db->used, values, (size_t)n * 8, hipMemcpyHostToDevice));
+  }
+  if (slot) *slot = (int32_t)db->off.size();
+  db->off.push_back((int32_t)db->used);
+  db->len.push_back(n);
+  db->used += (size_t)n;
+  db->meta_dirty = true;
+  return DVM_OK;
+}
+
+int dvm_bowdb_erase(dvm_bowdb* db, int32_t slot) {
+  if (!db || slot < 0 || slot >= (int32_t)db->off.size()) return DVM_ERR_INVALID;
+  db->len[slot] = -1;
+  db->meta_dirty = true;
+  return DVM_OK;
+}
+
+int dvm_bowdb_query(dvm_bowdb* db, const int32_t* word_ids, const double* values, int n, int32_t* common, int32_t* first_word,
+                    float* score) {
+  if (!db || n < 0 || (n > 0 && (!word_ids || !values)) || !common || !first_word || !score) return DVM_ERR_INVALID;
+  const int N = (int)db->off.size();
+  if (N == 0) return DVM_OK;
+  DVM_HIP(hipSetDevice(db->device));
+  if ((size_t)N > db->slot_cap) {
+    for (void* p : {(void*)db->d_off, (void*)db->d_len, (void*)db->d_common, (void*)db->d_first, (void*)db->d_score})
+      if (p) hipFree(p);
+    db->d_off = db->d_len = db->d_common = db->d_first = nullptr; db->d_score = nullptr;
+    db->slot_cap = std::max<size_t>((size_t)N * 2, 1024);
+    DVM_HIP(hipMalloc(&db->d_off, db->slot_cap * 4)); DVM_HIP(hipMalloc(&db->d_len, db->slot_cap * 4));
+    DVM_HIP(hipMalloc(&db->d_common, db->slot_cap * 4)); DVM_HIP(hipMalloc(&db->d_first, db->slot_cap * 4));
+    DVM_HIP(hipMalloc(&db->d_score, db->slot_cap * 4));
+    db->meta_dirty = true;
+  }
+  if (db->meta_dirty) {
+    DVM_HIP(hipMemcpy(db->d_off, db->off.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    DVM_HIP(hipMemcpy(db->d_len, db->len.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    db->meta_dirty = false;
+  }
+  Stage st;
+  const int iq = st.in(word_ids, (size_t)n * 4), iv = st.in(values, (size_t)n * 8);
+  int rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_bowdb_query(nullptr, db->d_off, db->d_len, db->d_ids, db->d_vals, N, st.ptr<int32_t>(iq), st.ptr<double>(iv), n, db->d_common,
+                     db->d_first, db->d_score);
+  rc = hip_check(hipGetLastError(), "bowdb_query launch");
+  if (rc != DVM_OK) return rc;
+  DVM_HIP(hipMemcpy(common, db->d_common, (size_t)N * 4, hipMemcpyDeviceToHost));
+  DVM_HIP(hipMemcpy(first_word, db->d_first, (size_t)N * 4, hipMemcpyDeviceToHost));
+  DVM_HIP(hipMemcpy(score, db->d_score, (size_t)N * 4, hipMemcpyDeviceToHost));
+  return DVM_OK;
+}
+
 int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median,
                                 int on_device, void* stream) {
   if (n_points < 0) return DVM_ERR_INVALID;

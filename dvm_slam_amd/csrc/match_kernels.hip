@@ -396,6 +396,59 @@ __global__ void __launch_bounds__(256) k_match_triangulation(const uint8_t* __re
   }
 }
 
+// KeyFrameDatabase place-recognition queries (reference src/KeyFrameDatabase.cc:224-808: DetectCandidates,
+// DetectNBestCandidates, CalculateMergeScore) walk an inverted file word -> keyframes to count, per keyframe, the words it
+// shares with the query BowVector, then score the survivors with L1Scoring::score (DBoW2/ScoringObject.cpp:23-63).
+// A keyframe is in the inverted list of a word iff its BowVector holds the word, so the count is |ids(query) n ids(kf)| and
+// the position of a keyframe in lKFsSharingWords is ordered by (first shared word, insertion order): one wave per stored
+// keyframe intersects its sorted word list with the query's (binary search per word) and produces count, first shared
+// word and the score for ALL keyframes at once -- no inverted file on the device.  The double sum of the score is taken
+// in ascending word order (the reference's merge walk) by walking the hit mask of each 64-word chunk.
+__global__ void __launch_bounds__(256) k_bowdb_query(const int32_t* __restrict__ kf_off, const int32_t* __restrict__ kf_len,
+                                                     const int32_t* __restrict__ ids, const double* __restrict__ vals, int n_kf,
+                                                     const int32_t* __restrict__ qids, const double* __restrict__ qvals, int nq,
+                                                     int32_t* __restrict__ common, int32_t* __restrict__ first_word,
+                                                     float* __restrict__ score) {
+  const int lane = threadIdx.x & 63;
+  const int kf = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (kf >= n_kf) return;
+  const int off = kf_off[kf], len = kf_len[kf];   // len < 0: erased slot
+  int n_common = 0, first = -1;
+  double acc = 0.0;
+  for (int base = 0; base < len; base += 64) {
+    const int p = base + lane;
+    bool hit = false;
+    double term = 0.0;
+    if (p < len) {
+      const int id = ids[off + p];
+      int lo = 0, hi = nq;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (qids[mid] < id) lo = mid + 1; else hi = mid;
+      }
+      if (lo < nq && qids[lo] == id) {
+        hit = true;
+        const double vi = qvals[lo], wi = vals[off + p];   // score(v1 = query, v2 = keyframe)
+        term = fabs(vi - wi) - fabs(vi) - fabs(wi);
+      }
+    }
+    unsigned long long mask = __ballot(hit);
+    if (mask != 0ull && first < 0) first = ids[off + base + (int)__builtin_ctzll(mask)];
+    n_common += __builtin_popcountll(mask);
+    while (mask) {
+      const int l = (int)__builtin_ctzll(mask);
+      const int lo32 = __builtin_amdgcn_readlane(__double2loint(term), l), hi32 = __builtin_amdgcn_readlane(__double2hiint(term), l);
+      acc += __hiloint2double(hi32, lo32);
+      mask &= mask - 1;
+    }
+  }
+  if (lane == 0) {
+    common[kf] = len < 0 ? -1 : n_common;
+    first_word[kf] = first;
+    score[kf] = (float)(-acc / 2.0);
+  }
+}
+
 // Frame::isInFrustum, mono branch (reference src/Frame.cc:575-636) + MapPoint::PredictScale
 // (src/MapPoint.cc:573-587): thread per map point, float arithmetic in the reference's order.
 __global__ void __launch_bounds__(256) k_is_in_frustum(FrustumFrame F, const float* __restrict__ P, const float* __restrict__ normal,
@@ -483,6 +536,12 @@ void launch_match_triangulation(hipStream_t s, const uint8_t* desc1, const dvm_k
                                 int32_t* best_dist) {
   hipLaunchKernelGGL(k_match_triangulation, dim3((nq + 15) / 16), dim3(256), 0, s, desc1, kps1, qidx, nq, desc2, kps2, off, cand, G,
                      scale_factors2, level_sigma2_2, best_idx, best_dist);
+}
+void launch_bowdb_query(hipStream_t s, const int32_t* kf_off, const int32_t* kf_len, const int32_t* ids, const double* vals, int n_kf,
+                        const int32_t* qids, const double* qvals, int nq, int32_t* common, int32_t* first_word, float* score) {
+  if (n_kf > 0)
+    hipLaunchKernelGGL(k_bowdb_query, dim3((n_kf + 3) / 4), dim3(256), 0, s, kf_off, kf_len, ids, vals, n_kf, qids, qvals, nq, common,
+                       first_word, score);
 }
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D) {
   hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 63) / 64, (nA + 3) / 4), dim3(256), 0, s, A, nA, B, nB, D);

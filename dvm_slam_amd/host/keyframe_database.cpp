@@ -1,0 +1,203 @@
+// dvm_slam_amd/host/keyframe_database.cpp -- see keyframe_database.h.
+#include "keyframe_database.h"
+
+#include <algorithm>
+#include <list>
+
+namespace dvm_host {
+
+KeyFrameDatabase::KeyFrameDatabase(int device) {
+  if (dvm_bowdb_create(device, &db_) != DVM_OK) db_ = nullptr;
+}
+KeyFrameDatabase::~KeyFrameDatabase() { if (db_) dvm_bowdb_destroy(db_); }
+
+int KeyFrameDatabase::add(const BowVector& bow, int32_t map_id, uint64_t uuid, int64_t mnId) {
+  std::vector<int32_t> ids;
+  std::vector<double> vals;
+  for (const auto& wv : bow) { ids.push_back((int32_t)wv.first); vals.push_back(wv.second); }
+  int32_t slot = -1;
+  const int rc = dvm_bowdb_add(db_, ids.data(), vals.data(), (int)ids.size(), &slot);
+  if (rc != DVM_OK) return rc;
+  KF k;
+  k.bow = bow; k.map_id = map_id; k.uuid = uuid; k.mnId = mnId; k.seq = (uint64_t)slot;
+  kfs_.push_back(k);
+  return slot;
+}
+
+void KeyFrameDatabase::erase(int slot) {
+  kfs_[slot].erased = true;
+  dvm_bowdb_erase(db_, slot);
+}
+
+int KeyFrameDatabase::query_device(const BowVector& bow) {
+  std::vector<int32_t> ids;
+  std::vector<double> vals;
+  for (const auto& wv : bow) { ids.push_back((int32_t)wv.first); vals.push_back(wv.second); }
+  const int N = dvm_bowdb_size(db_);
+  common_.assign(N, 0); first_.assign(N, -1); score_.assign(N, 0.f);
+  return dvm_bowdb_query(db_, ids.data(), vals.data(), (int)ids.size(), common_.data(), first_.data(), score_.data());
+}
+
+std::vector<int32_t> KeyFrameDatabase::walk_order() const {
+  std::vector<int32_t> order;
+  for (int s = 0; s < (int)kfs_.size(); s++)
+    if (common_[s] > 0) order.push_back(s);
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    return first_[a] != first_[b] ? first_[a] < first_[b] : kfs_[a].seq < kfs_[b].seq;
+  });
+  return order;
+}
+
+int KeyFrameDatabase::CalculateMergeScore(const BowVector& bowVector, uint64_t keyFrameId, int32_t map_id, float& score,
+                                          int32_t& bestKeyFrame) {
+  for (KF& k : kfs_)   // ResetPlaceRecognitionQuery(map)
+    if (k.map_id == map_id && !k.erased) { k.query = 0; k.words = 0; k.score = 0; }
+  const int rc = query_device(bowVector);
+  if (rc != DVM_OK) return rc;
+  std::vector<int32_t> lKFsSharingWords;
+  for (int32_t s : walk_order()) {
+    KF& k = kfs_[s];
+    if (!(k.map_id == map_id && !k.bad && k.uuid != keyFrameId)) continue;
+    if (k.query != keyFrameId) { k.words = 0; k.score = 0; k.query = keyFrameId; lKFsSharingWords.push_back(s); }
+    k.words += common_[s];
+  }
+  if (lKFsSharingWords.empty()) return DVM_OK;
+  int maxCommonWords = 0;
+  for (int32_t s : lKFsSharingWords) maxCommonWords = std::max(maxCommonWords, kfs_[s].words);
+  const int minCommonWords = maxCommonWords * 0.8f;
+  std::vector<std::pair<float, int32_t>> lScoreAndMatch;
+  for (int32_t s : lKFsSharingWords)
+    if (kfs_[s].words > minCommonWords) { kfs_[s].score = score_[s]; lScoreAndMatch.push_back({score_[s], s}); }
+  for (const auto& sm : lScoreAndMatch) {
+    float bestScore = sm.first, accScore = bestScore;
+    int32_t pBestKF = sm.second;
+    for (int32_t s2 : kfs_[sm.second].neigh) {
+      const KF& k2 = kfs_[s2];
+      if (k2.query != keyFrameId) continue;
+      accScore += k2.score;
+      if (k2.score > bestScore) { pBestKF = s2; bestScore = k2.score; }
+    }
+    if (accScore > score) { score = accScore; bestKeyFrame = pBestKF; }
+  }
+  return DVM_OK;
+}
+
+int KeyFrameDatabase::DetectMergePossibility(const BowVector& bowVector, uint64_t uuid, int32_t map_id, int32_t& bestKeyFrame,
+                                             float* score_out, float* baseline_out) {
+  float score = 0;
+  bestKeyFrame = -1;
+  int rc = CalculateMergeScore(bowVector, uuid, map_id, score, bestKeyFrame);
+  if (rc != DVM_OK) return rc;
+  if (score_out) *score_out = score;
+  if (baseline_out) *baseline_out = 0;
+  if (score == 0) return 0;
+  float baselineScore = 0;
+  int32_t baselineBest = -1;
+  const KF b = kfs_[bestKeyFrame];
+  rc = CalculateMergeScore(b.bow, b.uuid, b.map_id, baselineScore, baselineBest);
+  if (rc != DVM_OK) return rc;
+  if (baseline_out) *baseline_out = baselineScore;
+  return score > baselineScore * 0.9 ? 1 : 0;
+}
+
+int KeyFrameDatabase::DetectNBestCandidates(int slot, std::vector<int32_t>& vpLoopCand, std::vector<int32_t>& vpMergeCand, int nNumCandidates) {
+  vpLoopCand.clear(); vpMergeCand.clear();
+  const KF pKF = kfs_[slot];
+  const uint64_t qid = (uint64_t)pKF.mnId;
+  const int rc = query_device(pKF.bow);
+  if (rc != DVM_OK) return rc;
+  std::vector<int32_t> lKFsSharingWords;
+  for (int32_t s : walk_order()) {   // s shares common_[s] >= 1 words: it is touched common_[s] times by the walk (:563-575)
+    KF& k = kfs_[s];
+    if (k.query != qid) {
+      if (!pKF.connected.count(s) && k.mnId != pKF.mnId) {
+        k.query = qid; lKFsSharingWords.push_back(s);
+        k.words = common_[s];          // reset at the first touch, then one increment per shared word
+      } else {
+        k.words = 1;                   // reset at EVERY touch (the query id is never set), then incremented once
+      }
+    } else {
+      k.words += common_[s];           // same query id as last time: the counter keeps counting
+    }
+  }
+  if (lKFsSharingWords.empty()) return DVM_OK;
+  int maxCommonWords = 0;
+  for (int32_t s : lKFsSharingWords) maxCommonWords = std::max(maxCommonWords, kfs_[s].words);
+  const int minCommonWords = maxCommonWords * 0.8f;
+  std::vector<std::pair<float, int32_t>> lScoreAndMatch;
+  for (int32_t s : lKFsSharingWords)
+    if (kfs_[s].words > minCommonWords) { kfs_[s].score = score_[s]; lScoreAndMatch.push_back({score_[s], s}); }
+  if (lScoreAndMatch.empty()) return DVM_OK;
+  std::list<std::pair<float, int32_t>> lAccScoreAndMatch;
+  for (const auto& sm : lScoreAndMatch) {
+    float bestScore = sm.first, accScore = bestScore;
+    int32_t pBestKF = sm.second;
+    for (int32_t s2 : kfs_[sm.second].neigh) {
+      const KF& k2 = kfs_[s2];
+      if (k2.query != qid) continue;
+      accScore += k2.score;
+      if (k2.score > bestScore) { pBestKF = s2; bestScore = k2.score; }
+    }
+    lAccScoreAndMatch.push_back({accScore, pBestKF});
+  }
+  lAccScoreAndMatch.sort([](const std::pair<float, int32_t>& a, const std::pair<float, int32_t>& b) { return a.first > b.first; });
+  std::set<int32_t> spAlreadyAddedKF;
+  for (const auto& am : lAccScoreAndMatch) {
+    if (!((int)vpLoopCand.size() < nNumCandidates || (int)vpMergeCand.size() < nNumCandidates)) break;
+    const int32_t s = am.second;
+    const KF& k = kfs_[s];
+    if (k.bad) continue;   // the reference never advances past a bad keyframe here (:651-652); they do not reach this list
+    if (!spAlreadyAddedKF.count(s)) {
+      if (pKF.map_id == k.map_id && (int)vpLoopCand.size() < nNumCandidates) vpLoopCand.push_back(s);
+      else if (pKF.map_id != k.map_id && (int)vpMergeCand.size() < nNumCandidates && !bad_maps_.count(k.map_id)) vpMergeCand.push_back(s);
+      spAlreadyAddedKF.insert(s);
+    }
+  }
+  return DVM_OK;
+}
+
+}  // namespace dvm_host
+
+// ---- C entry points for the Python harness
+using dvm_host::BowVector;
+using dvm_host::KeyFrameDatabase;
+static BowVector to_bow(const int32_t* ids, const double* vals, int n) {
+  BowVector b;
+  for (int i = 0; i < n; i++) b[(unsigned)ids[i]] = vals[i];
+  return b;
+}
+extern "C" {
+KeyFrameDatabase* dvmh_kfdb_create(int device) {
+  KeyFrameDatabase* db = new KeyFrameDatabase(device);
+  if (!db->ok()) { delete db; return nullptr; }
+  return db;
+}
+void dvmh_kfdb_destroy(KeyFrameDatabase* db) { delete db; }
+int dvmh_kfdb_add(KeyFrameDatabase* db, const int32_t* ids, const double* vals, int n, int32_t map_id, uint64_t uuid, int64_t mnId) {
+  return db->add(to_bow(ids, vals, n), map_id, uuid, mnId);
+}
+void dvmh_kfdb_erase(KeyFrameDatabase* db, int slot) { db->erase(slot); }
+void dvmh_kfdb_set_bad(KeyFrameDatabase* db, int slot, int bad) { db->SetBadFlag(slot, bad != 0); }
+void dvmh_kfdb_set_map_bad(KeyFrameDatabase* db, int32_t map_id, int bad) { db->SetMapBad(map_id, bad != 0); }
+void dvmh_kfdb_set_neighbours(KeyFrameDatabase* db, int slot, const int32_t* neigh, int n) { db->SetBestCovisibilityKeyFrames(slot, neigh, n); }
+void dvmh_kfdb_set_connected(KeyFrameDatabase* db, int slot, const int32_t* conn, int n) { db->SetConnectedKeyFrames(slot, conn, n); }
+void dvmh_kfdb_get_state(KeyFrameDatabase* db, int slot, uint64_t* query, int32_t* words, float* score) {
+  const KeyFrameDatabase::State s = db->GetState(slot);
+  *query = s.query; *words = s.words; *score = s.score;
+}
+int dvmh_kfdb_merge_score(KeyFrameDatabase* db, const int32_t* qids, const double* qvals, int nq, uint64_t keyFrameId, int32_t map_id,
+                          float* score, int32_t* bestKeyFrame) {
+  return db->CalculateMergeScore(to_bow(qids, qvals, nq), keyFrameId, map_id, *score, *bestKeyFrame);
+}
+int dvmh_kfdb_detect_merge_possibility(KeyFrameDatabase* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
+                                       int32_t* bestKeyFrame, float* score, float* baseline) {
+  return db->DetectMergePossibility(to_bow(qids, qvals, nq), uuid, map_id, *bestKeyFrame, score, baseline);
+}
+int dvmh_kfdb_detect_n_best(KeyFrameDatabase* db, int slot, int nNum, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge) {
+  std::vector<int32_t> l, m;
+  const int rc = db->DetectNBestCandidates(slot, l, m, nNum);
+  *n_loop = (int32_t)l.size(); *n_merge = (int32_t)m.size();
+  std::copy(l.begin(), l.end(), loop); std::copy(m.begin(), m.end(), merge);
+  return rc;
+}
+}

@@ -1,0 +1,70 @@
+// dvm_slam_amd/host/keyframe_database.h -- host-side mirror of ORB_SLAM3::KeyFrameDatabase's place-recognition queries
+// as DVM-SLAM uses them to decide map merges (reference src/KeyFrameDatabase.cc:43-70 add / erase, :555-669
+// DetectNBestCandidates, :688-786 CalculateMergeScore, :789-808 DetectMergePossibility).
+//
+// Keyframes are slots (the index add() returns) with the few attributes the queries read: BowVector, map, uuid, mnId, isBad,
+// GetBestCovisibilityKeyFrames(10), GetConnectedKeyFrames().  The per-keyframe word intersection and the L1 scores of ALL
+// stored keyframes come from one device call per query (dvm_bowdb_query); the reference's inverted-file walk is replaced by
+// ordering the sharing keyframes by (first shared word, position in that word's inverted list = insertion order), which is
+// the order in which the walk meets them.  The per-keyframe query state (mnPlaceRecognitionQuery / Words / Score, stale
+// values included), the covisibility accumulation and the candidate selection are replayed on the host.
+#pragma once
+#include <cstdint>
+#include <set>
+#include <vector>
+
+#include "dvmslam_hip.h"
+#include "orb_vocabulary.h"
+
+namespace dvm_host {
+
+class KeyFrameDatabase {
+ public:
+  explicit KeyFrameDatabase(int device = 0);
+  ~KeyFrameDatabase();
+  KeyFrameDatabase(const KeyFrameDatabase&) = delete;
+  bool ok() const { return db_ != nullptr; }
+
+  // void add(KeyFrame* pKF): returns the slot
+  int add(const BowVector& bow, int32_t map_id, uint64_t uuid, int64_t mnId);
+  void erase(int slot);
+  void SetBadFlag(int slot, bool bad) { kfs_[slot].bad = bad; }
+  void SetMapBad(int32_t map_id, bool bad) { if (bad) bad_maps_.insert(map_id); else bad_maps_.erase(map_id); }
+  void SetBestCovisibilityKeyFrames(int slot, const int32_t* neigh, int n) { kfs_[slot].neigh.assign(neigh, neigh + n); }
+  void SetConnectedKeyFrames(int slot, const int32_t* conn, int n) { kfs_[slot].connected = std::set<int32_t>(conn, conn + n); }
+
+  // void CalculateMergeScore(DBoW2::BowVector bowVector, uuid, Map* map, float& score, KeyFrame*& bestKeyFrame)
+  int CalculateMergeScore(const BowVector& bowVector, uint64_t uuid, int32_t map_id, float& score, int32_t& bestKeyFrame);
+  // pair<bool, uuid> DetectMergePossibility(DBoW2::BowVector bowVector, uuid, Map* map): returns 1 / 0 (or < 0: dvm_status)
+  int DetectMergePossibility(const BowVector& bowVector, uint64_t uuid, int32_t map_id, int32_t& bestKeyFrame, float* score = nullptr,
+                             float* baseline = nullptr);
+  // void DetectNBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand, int nNumCandidates)
+  int DetectNBestCandidates(int slot, std::vector<int32_t>& vpLoopCand, std::vector<int32_t>& vpMergeCand, int nNumCandidates);
+
+  struct State { uint64_t query; int32_t words; float score; };
+  State GetState(int slot) const { return {kfs_[slot].query, kfs_[slot].words, kfs_[slot].score}; }
+
+ private:
+  struct KF {
+    BowVector bow;
+    int32_t map_id = 0;
+    int64_t mnId = 0;
+    uint64_t uuid = 0;
+    bool bad = false, erased = false;
+    uint64_t seq = 0;                 // position key inside every inverted list it is in (push_back order)
+    std::vector<int32_t> neigh;
+    std::set<int32_t> connected;
+    uint64_t query = 0;
+    int words = 0;
+    float score = 0;
+  };
+  int query_device(const BowVector& bow);   // fills common_ / first_ / score_
+  std::vector<int32_t> walk_order() const;   // slots sharing a word, in inverted-file walk order
+  dvm_bowdb* db_ = nullptr;
+  std::vector<KF> kfs_;
+  std::set<int32_t> bad_maps_;
+  std::vector<int32_t> common_, first_;
+  std::vector<float> score_;
+};
+
+}  // namespace dvm_host

@@ -237,6 +237,25 @@ void dvm_vocab_destroy(dvm_vocab* v);
 int dvm_vocab_transform(const dvm_vocab* v, const uint8_t* features, int n, int levelsup, int32_t* word_id, int32_t* node_id,
                         double* weight, int on_device, void* stream);
 
+/* BowVectors of the keyframes of a KeyFrameDatabase on the device + the per-query work of its place-recognition searches
+ * (reference src/KeyFrameDatabase.cc:43-70 add / erase, :224-808 DetectCandidates / DetectNBestCandidates /
+ * CalculateMergeScore): for every stored keyframe at once, the number of words it shares with the query BowVector
+ * (= mnPlaceRecognitionWords after the inverted-file walk), the first shared word (with the insertion order this gives the
+ * keyframe's position in lKFsSharingWords) and mpVoc->score(query, keyframe) (L1Scoring, cast to float as the reference
+ * stores it).  Word ids ascending (std::map order).  The covisibility accumulation and candidate selection on top are
+ * host code (dvm_slam_amd/host/keyframe_database.cpp). */
+typedef struct dvm_bowdb dvm_bowdb;
+int dvm_bowdb_create(int device, dvm_bowdb** out);
+void dvm_bowdb_destroy(dvm_bowdb* db);
+/* append a keyframe's BowVector; *slot receives its index (slots are never reused) */
+int dvm_bowdb_add(dvm_bowdb* db, const int32_t* word_ids, const double* values, int n, int32_t* slot);
+int dvm_bowdb_erase(dvm_bowdb* db, int32_t slot);
+int dvm_bowdb_size(const dvm_bowdb* db);   /* slots handed out so far */
+/* common[s] = shared words (-1: erased slot), first_word[s] = smallest shared word id (-1 none), score[s]; arrays of
+ * dvm_bowdb_size() entries, host pointers, synchronous. */
+int dvm_bowdb_query(dvm_bowdb* db, const int32_t* word_ids, const double* values, int n, int32_t* common, int32_t* first_word,
+                    float* score);
+
 /* TrackWithMotionModel-style frame-to-frame search over a batch (ORBmatcher.cc:1596-1611, mono):
  * pair i (0 <= i < count) searches train slot first_slot+i for every keypoint of frame i-1 of the
  * device arrays (d_kps + (i-1)*kps_stride, ...); pair 0 takes its queries from the carry frame

@@ -169,6 +169,23 @@ void orc_vocab_transform(int n_nodes, const int32_t* child_off, const int32_t* c
                          int32_t* n_bow, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int32_t* n_fv);
 double orc_bow_score(const int32_t* ids1, const double* vals1, int n1, const int32_t* ids2, const double* vals2, int n2);
 
+/* ---- KeyFrameDatabase place recognition (KeyFrameDatabase.cc:43-70,555-808; see kfdb_oracle.cpp).  Keyframes are slots. ---- */
+typedef struct orc_kfdb orc_kfdb;
+orc_kfdb* orc_kfdb_create(void);
+void orc_kfdb_destroy(orc_kfdb* db);
+int orc_kfdb_add(orc_kfdb* db, const int32_t* ids, const double* vals, int n, int32_t map_id, uint64_t uuid, int64_t mnId);
+void orc_kfdb_erase(orc_kfdb* db, int slot);
+void orc_kfdb_set_bad(orc_kfdb* db, int slot, int bad);
+void orc_kfdb_set_map_bad(orc_kfdb* db, int32_t map_id, int bad);
+void orc_kfdb_set_neighbours(orc_kfdb* db, int slot, const int32_t* neigh, int n);
+void orc_kfdb_set_connected(orc_kfdb* db, int slot, const int32_t* conn, int n);
+void orc_kfdb_get_state(const orc_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score);
+void orc_kfdb_merge_score(orc_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t keyFrameId, int32_t map_id,
+                          float* score, int32_t* bestKeyFrame);
+int orc_kfdb_detect_merge_possibility(orc_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
+                                      int32_t* bestKeyFrame, float* score_out, float* baseline_out);
+void orc_kfdb_detect_n_best(orc_kfdb* db, int slot, int nNumCandidates, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge);
+
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel */ } orc_ba_camera;

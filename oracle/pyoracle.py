@@ -630,3 +630,73 @@ def pose_graph_optimize(S, fixed, edges_v, edges_meas, fix_scale=False, iteratio
     st = np.zeros(70)
     L.orc_pose_graph_optimize(_p(So), _p(fx), len(So), _p(ev), _p(em), len(ev), int(fix_scale), int(iterations), _p(st))
     return So, st
+
+
+class KeyFrameDatabase:
+    """KeyFrameDatabase place-recognition queries (kfdb_oracle.cpp) on keyframe slots."""
+    PREFIX = "orc_kfdb_"
+
+    def _lib(self):
+        return lib()
+
+    def _create(self):
+        f = getattr(self._lib(), self.PREFIX + "create"); f.restype = C.c_void_p; f.argtypes = []
+        return C.c_void_p(f())
+
+    def __init__(self):
+        self.h = self._create()
+        assert self.h.value
+
+    def _f(self, name, restype=None):
+        f = getattr(self._lib(), self.PREFIX + name); f.restype = restype; f.argtypes = None
+        return f
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self._f("destroy")(self.h); self.h = C.c_void_p()
+
+    __del__ = close
+
+    @staticmethod
+    def _bow(ids, vals):
+        return np.ascontiguousarray(ids, np.int32), np.ascontiguousarray(vals, np.float64)
+
+    def add(self, ids, vals, map_id, uuid, mn_id):
+        i, v = self._bow(ids, vals)
+        return self._f("add", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_int32(map_id), C.c_uint64(uuid), C.c_int64(mn_id))
+
+    def erase(self, slot): self._f("erase")(self.h, C.c_int32(slot))
+    def set_bad(self, slot, bad): self._f("set_bad")(self.h, C.c_int32(slot), C.c_int32(int(bad)))
+    def set_map_bad(self, map_id, bad): self._f("set_map_bad")(self.h, C.c_int32(map_id), C.c_int32(int(bad)))
+
+    def set_neighbours(self, slot, neigh):
+        a = np.ascontiguousarray(neigh, np.int32)
+        self._f("set_neighbours")(self.h, C.c_int32(slot), _p(a) if len(a) else None, C.c_int32(len(a)))
+
+    def set_connected(self, slot, conn):
+        a = np.ascontiguousarray(conn, np.int32)
+        self._f("set_connected")(self.h, C.c_int32(slot), _p(a) if len(a) else None, C.c_int32(len(a)))
+
+    def state(self, slot):
+        q = C.c_uint64(0); w = C.c_int32(0); s = C.c_float(0)
+        self._f("get_state")(self.h, C.c_int32(slot), C.byref(q), C.byref(w), C.byref(s))
+        return q.value, w.value, s.value
+
+    def merge_score(self, ids, vals, key_frame_id, map_id, score=0.0):
+        i, v = self._bow(ids, vals)
+        sc = C.c_float(score); best = C.c_int32(-1)
+        self._f("merge_score", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_uint64(key_frame_id), C.c_int32(map_id), C.byref(sc), C.byref(best))
+        return sc.value, best.value
+
+    def detect_merge_possibility(self, ids, vals, uuid, map_id):
+        i, v = self._bow(ids, vals)
+        best = C.c_int32(-1); sc = C.c_float(0); base = C.c_float(0)
+        r = self._f("detect_merge_possibility", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_uint64(uuid), C.c_int32(map_id), C.byref(best),
+                                                           C.byref(sc), C.byref(base))
+        return r, best.value, sc.value, base.value
+
+    def detect_n_best(self, slot, n_num):
+        lo = np.zeros(max(n_num, 1), np.int32); me = np.zeros(max(n_num, 1), np.int32)
+        nl = C.c_int32(0); nm = C.c_int32(0)
+        self._f("detect_n_best", C.c_int32)(self.h, C.c_int32(slot), C.c_int32(n_num), _p(lo), C.byref(nl), _p(me), C.byref(nm))
+        return lo[:nl.value].copy(), me[:nm.value].copy()

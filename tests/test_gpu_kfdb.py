@@ -1,0 +1,78 @@
+"""GPU parity of the KeyFrameDatabase place-recognition path (second half): dvm_bowdb_query against the
+brute-force definition, and the host mirror dvm_host::KeyFrameDatabase (device word intersection + scores, host replay of
+the reference's bookkeeping) against the inverted-file oracle through long mixed operation sequences.  Exact."""
+import numpy as np
+import pytest
+
+from kfdb_scene import fill, make_db_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bowdb_query_raw(capi, oracle):
+    kfs = make_db_scene(3, n_maps=2, kf_per_map=70)
+    kfs.append(dict(ids=np.zeros(0, np.int32), vals=np.zeros(0, np.float64)))           # empty BowVector
+    kfs.append(dict(ids=np.arange(0, 3000, 2, dtype=np.int32), vals=np.full(1500, 1 / 1500.0)))  # > 64 words per chunk, many hits
+    q = kfs[7]
+    common, first, score = capi.bowdb_query_raw([(k["ids"], k["vals"]) for k in kfs], q["ids"], q["vals"], erase=(3, 20))
+    for j, k in enumerate(kfs):
+        if j in (3, 20):
+            assert common[j] == -1
+            continue
+        inter = np.intersect1d(q["ids"], k["ids"])
+        assert common[j] == len(inter)
+        assert first[j] == (inter[0] if len(inter) else -1)
+        assert score[j] == np.float32(oracle.bow_score(q["ids"], q["vals"], k["ids"], k["vals"]))
+    # empty query
+    common, first, score = capi.bowdb_query_raw([(k["ids"], k["vals"]) for k in kfs[:5]], np.zeros(0, np.int32), np.zeros(0))
+    assert np.all(common == 0) and np.all(first == -1) and np.all(score == 0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_keyframe_database_sequences(capi, oracle, seed):
+    kfs = make_db_scene(seed + 10)
+    dbo = oracle.KeyFrameDatabase()
+    dbg = capi.HostKeyFrameDatabase()
+    fill(dbo, kfs); fill(dbg, kfs)
+    rng = np.random.default_rng(seed)
+    n = len(kfs)
+    alive = set(range(n))
+    hits = 0
+    for step in range(120):
+        op = rng.random()
+        j = int(rng.choice(sorted(alive)))
+        q = kfs[j]
+        if op < 0.35:
+            m = int(rng.integers(0, 3))
+            r_o = dbo.detect_merge_possibility(q["ids"], q["vals"], q["uuid"], m)
+            r_g = dbg.detect_merge_possibility(q["ids"], q["vals"], q["uuid"], m)
+            assert r_o == r_g, (step, r_o, r_g)
+            hits += r_o[1] >= 0
+        elif op < 0.55:
+            m = int(rng.integers(0, 3))
+            s0 = float(rng.choice([0.0, 0.5]))
+            assert dbo.merge_score(q["ids"], q["vals"], q["uuid"], m, s0) == dbg.merge_score(q["ids"], q["vals"], q["uuid"], m, s0)
+        elif op < 0.85:
+            lo, mo = dbo.detect_n_best(j, 3)
+            lg, mg = dbg.detect_n_best(j, 3)
+            assert np.array_equal(lo, lg) and np.array_equal(mo, mg), (step, lo, lg, mo, mg)
+            hits += len(lo) + len(mo) > 0
+        elif op < 0.92 and len(alive) > 30:
+            dbo.erase(j); dbg.erase(j); alive.discard(j)
+        elif op < 0.96:
+            b = bool(rng.integers(0, 2))
+            dbo.set_bad(j, b); dbg.set_bad(j, b)
+        else:   # a new keyframe arrives
+            k = dict(kfs[j]); k["uuid"] = int(rng.integers(1, 2**62)); k["mn_id"] = len(kfs) + 1
+            so = dbo.add(k["ids"], k["vals"], k["map_id"], k["uuid"], k["mn_id"]); sg = dbg.add(k["ids"], k["vals"], k["map_id"], k["uuid"], k["mn_id"])
+            assert so == sg == len(kfs)
+            for db in (dbo, dbg):
+                db.set_neighbours(so, kfs[j]["neigh"]); db.set_connected(so, kfs[j]["connected"])
+            k["neigh"], k["connected"] = kfs[j]["neigh"], kfs[j]["connected"]
+            kfs.append(k); alive.add(so)
+        if step % 20 == 0:
+            for s in range(len(kfs)):
+                assert dbo.state(s) == dbg.state(s), (step, s)
+    assert hits > 20
+    for s in range(len(kfs)):
+        assert dbo.state(s) == dbg.state(s)
