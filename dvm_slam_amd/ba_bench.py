@@ -45,14 +45,14 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
         "ms_graph_build_excluded": st["ms_structure"], "chi2_initial": st["chi2_initial"], "chi2_final": st["chi2_final"],
         "dtype": "f64", "huber_delta": delta,
         "gpu_state": "hot (timed right after GPU work; an idle MI355X stays at its 584 MHz idle clock under this host-"
-                     "synchronised LM loop: ~315 it/s cold vs ~1050 it/s hot)",
+                     "synchronised LM loop: ~315 it/s cold vs ~1250 it/s hot)",
         "roofline": {"bound": "mfma", "kernel": "k_chol_diag/k_chol_trsm/k_chol_update: reduced-camera Cholesky on v_mfma_f64_16x16x4",
                      "achieved": FLOPS_DENSE_CHOLESKY * st["total_trials"] / dt / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": FLOPS_DENSE_CHOLESKY * st["total_trials"] / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                      "note": "dense-equivalent rate: n^3/3 FLOP of a dense n=2994 factorisation per trial over the WHOLE "
                              "iteration time (edge pass, Schur, solve, update); the solver itself skips structurally zero "
                              "64x64 tiles (symbolic tile fill), so executed FLOPs are lower -- the solve is a dependency chain of "
-                             "elimination-tree levels (12 at this size after nested dissection; 47 tile columns before), "
+                             "elimination-tree levels (9 at this size after nested dissection, 8 launched; 47 tile columns before), "
                              "each level = 3 launches, not MFMA-throughput bound (DESIGN.md section 3)"},
     }
     if cpu_seconds > 0:
