@@ -74,3 +74,20 @@ def max_over_ranks(seconds: float, device=None) -> float:
 def agent_stream_segment(rank: int, frames_per_agent: int) -> int:
     """First frame index of the camera path segment an agent (rank) processes: agents are independent."""
     return rank * frames_per_agent
+
+
+def all_gather_varlen(block: torch.Tensor) -> list[torch.Tensor]:
+    """C2 with ragged payloads (DVMW blocks, dvm_slam_amd/wire.py): sizes first (one int64 all_gather), then one all_gather of
+    blocks padded to the largest; returns every agent's block trimmed to its own size.  Tensors stay on their device."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [block]
+    world = dist.get_world_size()
+    n = torch.tensor([block.numel()], dtype=torch.int64, device=block.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = int(max(int(s.item()) for s in sizes))
+    padded = torch.zeros(mx, dtype=torch.uint8, device=block.device)
+    padded[:block.numel()] = block
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded)
+    return [o[:int(s.item())] for o, s in zip(out, sizes)]

@@ -45,6 +45,20 @@ def _worker(rank, world, port, q):
     peer = exchange.unpack_keyframe(got[1 - rank], cap, po.KP_DTYPE)
     D = po.hamming_matrix(desc, peer[4])
     ok &= D.shape == (n, 40 + (1 - rank) * 7)
+    # DVMW map deltas of different sizes: every agent receives and decodes every agent's block
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from dvm_slam_amd import capi, wire
+    from wire_scene import assert_equal_delta, make_delta
+    kfs, mps = make_delta(wire, capi, 50 + rank, n_kf=2 + rank, n_mp=10 + 20 * rank, agent=rank)
+    mine = torch.from_numpy(wire.build(kfs, mps, sender_agent=rank))
+    blocks = exchange.all_gather_varlen(mine)
+    ok &= len(blocks) == world and len({b.numel() for b in blocks}) == world
+    for r, b in enumerate(blocks):
+        ek, em = make_delta(wire, capi, 50 + r, n_kf=2 + r, n_mp=10 + 20 * r, agent=r)
+        parsed = wire.parse(b.numpy())
+        ok &= int(parsed[0]["sender_agent"]) == r
+        assert_equal_delta(wire, ek, em, parsed)
     sim3 = torch.arange(8, dtype=torch.float64) * (1.0 if rank == 1 else 0.0)
     exchange.broadcast_sim3(sim3, src=1)
     ok &= bool((sim3 == torch.arange(8, dtype=torch.float64)).all())
