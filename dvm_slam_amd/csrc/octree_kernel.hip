@@ -21,7 +21,7 @@
 
 namespace dvm {
 
-constexpr int kOctMaxNodes = 1536;
+constexpr int kOctMaxNodes = 3584;   // 44 B of dynamic LDS per node slot: 154 KB of the 160 KB a gfx950 workgroup may own
 struct ONodeRec {
   int16_t x0, y0, x1, y1;
   int32_t cnt;

@@ -455,8 +455,14 @@ int OrbPipeline::configure(int rows, int cols) {
       set_error("image too narrow for DistributeOctTree: round((cols-32)/(rows-32)) = 0 at some pyramid level");
       return DVM_ERR_INVALID;
     }
-  // quotas beyond the device octree's node capacity (e.g. 3000 features on 2 levels): same algorithm on the host
-  host_octree = host_octree_forced || !octree_fits_device(PD);
+  // A level quota beyond the device octree's node capacity (3 576 keypoints on one level, i.e. ~16 000 features at the
+  // usual 1.2 / 8 levels) is refused: there is no silent CPU path.  DVM_HOST_OCTREE=1 (debug / A-B switch) runs the same
+  // algorithm on the host for any configuration.
+  host_octree = host_octree_forced;
+  if (!host_octree && !octree_fits_device(PD)) {
+    set_error("a pyramid level's keypoint quota exceeds the device octree capacity (3576 nodes); lower nFeatures");
+    return DVM_ERR_CAPACITY;
+  }
   tiny_levels = false;
   for (int l = 0; l < PD.nlevels; l++) tiny_levels |= (PD.lv[l].w < 40 || PD.lv[l].h < 20);
   PD.ncells = (int)cells.size();
