@@ -207,6 +207,20 @@ class OrbExtractor:
         check(self.L.dvm_orb_extract_batch_device(self.h, C.c_void_p(d_ptr), batch, rows, cols, stride, frame_stride,
                                                   lap[0], lap[1]))
 
+    def staging(self, batch, rows, cols) -> np.ndarray:
+        """The handle's pinned input buffer as a (batch, rows, cols) uint8 array (dvm_orb_staging); waits for the previous copy."""
+        p = C.c_void_p()
+        f = self.L.dvm_orb_staging
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, C.c_int32(batch), C.c_int32(rows), C.c_int32(cols), C.byref(p)))
+        buf = (C.c_uint8 * (batch * rows * cols)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(batch, rows, cols)
+
+    def extract_staged(self, batch, rows, cols, lap=(0, 1000)):
+        f = self.L.dvm_orb_extract_staged
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, C.c_int32(batch), C.c_int32(rows), C.c_int32(cols), C.c_int32(lap[0]), C.c_int32(lap[1])))
+
     def sync(self):
         check(self.L.dvm_orb_sync(self.h))
 

@@ -141,6 +141,14 @@ int dvm_orb_extract_batch_host(dvm_orb* h, const uint8_t* imgs, int batch, int r
   if (!h) return DVM_ERR_INVALID;
   return h->p->extract_host(imgs, batch, rows, cols, stride, frame_stride, lap0, lap1);
 }
+int dvm_orb_staging(dvm_orb* h, int batch, int rows, int cols, uint8_t** host_ptr) {
+  if (!h) return DVM_ERR_INVALID;
+  return h->p->staging(batch, rows, cols, host_ptr);
+}
+int dvm_orb_extract_staged(dvm_orb* h, int batch, int rows, int cols, int lap0, int lap1) {
+  if (!h) return DVM_ERR_INVALID;
+  return h->p->extract_staged(batch, rows, cols, lap0, lap1);
+}
 int dvm_orb_sync(dvm_orb* h) { return h ? h->p->sync() : DVM_ERR_INVALID; }
 int dvm_orb_result_device(dvm_orb* h, int frame, const dvm_keypoint** d_kps, const uint8_t** d_desc,
                           const int32_t** d_n, int* capacity) {

@@ -51,6 +51,12 @@ class OrbPipeline {
                      int lap1);
   int extract_host(const uint8_t* imgs, int batch, int rows, int cols, int stride, int64_t frame_stride, int lap0,
                    int lap1);
+  int ensure_stage(size_t need);
+  hipStream_t copy_stream = nullptr;            // H2D of the staged ingest (dvm_orb_extract_staged)
+  hipEvent_t ev_copied = nullptr, ev_stage_free = nullptr;
+  bool copy_pending = false, stage_free_valid = false;
+  int staging(int batch, int rows, int cols, uint8_t** host_ptr);
+  int extract_staged(int batch, int rows, int cols, int lap0, int lap1);
   int sync();
   int download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono);
 

@@ -85,6 +85,12 @@ int dvm_orb_extract_batch_device(dvm_orb* h, const uint8_t* d_imgs, int batch, i
 int dvm_orb_extract_batch_host(dvm_orb* h, const uint8_t* imgs, int batch, int rows, int cols, int stride,
                                int64_t frame_stride, int lap0, int lap1);
 /* blocks until the handle's stream is idle */
+/* Pinned-staging ingest: dvm_orb_staging returns the handle's page-locked input buffer (batch x rows x cols bytes, rows
+ * tight) for the caller -- camera driver, decoder -- to write frames into; dvm_orb_extract_staged queues the PCIe copy and
+ * the extraction on the handle's stream and returns without waiting.  dvm_orb_staging waits for the previous copy out of
+ * the buffer.  Two handles used alternately overlap one batch's transfer with the other's kernels. */
+int dvm_orb_staging(dvm_orb* h, int batch, int rows, int cols, uint8_t** host_ptr);
+int dvm_orb_extract_staged(dvm_orb* h, int batch, int rows, int cols, int lap0, int lap1);
 int dvm_orb_sync(dvm_orb* h);
 /* device views of frame f's results (valid until the next extract on this handle).  kps are in
  * the reference's output order; d_n points at the int32 keypoint count of the frame. */

@@ -121,6 +121,42 @@ def _chunked(capi, oracle, frames, sizes=(64, 97, 256)):
         e.close()
 
 
+def test_staged_ingest_pipeline(capi, oracle, frames):
+    """dvm_orb_staging / dvm_orb_extract_staged: frames written into the handle's pinned buffer, H2D on the copy stream; the
+    buffer is refilled with DIFFERENT frames while the previous batch is still computing (no sync in between), two handles
+    alternate as in bench.py's PCIe-inclusive leg.  Every batch must still be exact."""
+    from dvm_slam_amd import synth
+    orc = oracle.OrbOracle()
+    B = 8
+    sets = [np.stack([synth.small_image(50 * k + j, 480, 640) for j in range(B)]) for k in range(4)]
+    ref = [[orc.extract(img) for img in st] for st in sets]
+    exts = [capi.OrbExtractor(max_batch=B), capi.OrbExtractor(max_batch=B)]
+    pending = [None, None]
+
+    def check(k, e):
+        for f in (0, 3, B - 1):
+            n_g, k_g, d_g, m_g = e.download(f)
+            n_o, k_o, d_o, m_o = ref[k][f]
+            assert (n_g, m_g) == (n_o, m_o), (k, f)
+            _same_kps(k_g, k_o)
+            assert np.array_equal(d_g, d_o)
+
+    for rep in range(2):
+        for k in range(4):
+            e = exts[k & 1]
+            if pending[k & 1] is not None:
+                check(pending[k & 1], e)
+            buf = e.staging(B, 480, 640)
+            buf[:] = sets[k]
+            e.extract_staged(B, 480, 640)
+            buf2 = e.staging(B, 480, 640)      # returns as soon as the copy has left the pinned buffer ...
+            buf2[:] = 0                        # ... so scribbling over it must not disturb the batch in flight
+            pending[k & 1] = k
+    for i, e in enumerate(exts):
+        check(pending[i], e)
+        e.close()
+
+
 def test_edge_cases(capi, oracle):
     e = capi.OrbExtractor(max_batch=1)
     orc = oracle.OrbOracle()
