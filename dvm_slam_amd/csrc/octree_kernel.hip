@@ -21,7 +21,7 @@
 
 namespace dvm {
 
-constexpr int kOctMaxNodes = 3584;   // 44 B of dynamic LDS per node slot: 154 KB of the 160 KB a gfx950 workgroup may own
+constexpr int kOctMaxNodes = 2688;   // 58 B of dynamic LDS per node slot: 152 KB of the 160 KB a gfx950 workgroup may own (+ ~3 KB static)
 struct ONodeRec {
   int16_t x0, y0, x1, y1;
   int32_t cnt;
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ can
                                                 int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
                                                 int level_first) {
   // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64):
-  // 44 B per slot, so the BASELINE config (cap 256) keeps ~11 KB and 8 workgroups fit a CU
+  // 58 B per slot, so the BASELINE config (cap 256) keeps ~15 KB and 8 workgroups fit a CU
   extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
   ONodeRec* listA = reinterpret_cast<ONodeRec*>(oct_smem);
   ONodeRec* listB = listA + cap;
@@ -424,18 +424,25 @@ int octree_required_nodes(const PipelineDesc& PD) {
 }
 bool octree_fits_device(const PipelineDesc& PD) { return octree_required_nodes(PD) <= kOctMaxNodes; }
 
+static size_t octree_lds_bytes(int cap) { return (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2); }
+
+// Called once per configuration (OrbPipeline::configure), on the handle's device: beyond the default 48 KB of dynamic
+// LDS the limit has to be raised per device, and a configuration the hardware cannot hold must be refused BEFORE anything
+// is launched (a failed k_octree launch would leave the selection arrays of the following kernels undefined).
+bool octree_prepare_device(const PipelineDesc& PD) {
+  if (!octree_fits_device(PD)) return false;
+  const size_t bytes = octree_lds_bytes(octree_required_nodes(PD));
+  if (bytes <= 48 * 1024) return true;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
                    int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err,
                    int batch, int level_first, int level_num) {
   if (level_num <= 0) return;
-  int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
-  const size_t bytes = (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2);
-  // beyond the default 48 KB of dynamic LDS the limit has to be raised on the CURRENT device (the attribute is per
-  // device and the library serves one handle per GPU), so no process-wide "done once" flag
-  if (bytes > 48 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  hipLaunchKernelGGL(k_octree, dim3(level_num, batch), dim3(256), bytes, s, d_cand, d_cell_count, d_cells, d_dense, d_lvl_count,
-                     PD, d_nid, d_sel, d_nsel, d_err, cap, level_first);
+  const int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
+  hipLaunchKernelGGL(k_octree, dim3(level_num, batch), dim3(256), octree_lds_bytes(cap), s, d_cand, d_cell_count, d_cells, d_dense,
+                     d_lvl_count, PD, d_nid, d_sel, d_nsel, d_err, cap, level_first);
 }
 
 }  // namespace dvm

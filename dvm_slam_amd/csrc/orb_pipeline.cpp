@@ -461,12 +461,12 @@ int OrbPipeline::configure(int rows, int cols) {
       set_error("image too narrow for DistributeOctTree: round((cols-32)/(rows-32)) = 0 at some pyramid level");
       return DVM_ERR_INVALID;
     }
-  // A level quota beyond the device octree's node capacity (3 576 keypoints on one level, i.e. ~16 000 features at the
+  // A level quota beyond the device octree's node capacity (2 680 keypoints on one level, i.e. ~12 300 features at the
   // usual 1.2 / 8 levels) is refused: there is no silent CPU path.  DVM_HOST_OCTREE=1 (debug / A-B switch) runs the same
   // algorithm on the host for any configuration.
   host_octree = host_octree_forced;
-  if (!host_octree && !octree_fits_device(PD)) {
-    set_error("a pyramid level's keypoint quota exceeds the device octree capacity (3576 nodes); lower nFeatures");
+  if (!host_octree && !octree_prepare_device(PD)) {
+    set_error("a pyramid level's keypoint quota exceeds the device octree capacity (2680 nodes); lower nFeatures");
     return DVM_ERR_CAPACITY;
   }
   tiny_levels = false;

@@ -209,12 +209,13 @@ def test_other_parameters(capi, oracle):
 def test_soak_regressions(capi, oracle):
     """Cases found by tools/soak_parity.py: (a) small quotas on wide images -- the first octree sweep splits all
     nIni = round(W / H) root nodes before the node count is compared with the quota, so a level may keep up to 4 * nIni
-    keypoints (> quota + 2); (b) level quotas above 1 528 (up to 3 576: the whole 160 KB of LDS for one workgroup) still run
+    keypoints (> quota + 2); (b) level quotas above 1 528 (up to 2 680: the whole 160 KB of LDS for one workgroup) still run
     on the device, larger ones are refused (no silent CPU path);
     (c) portrait sizes with nIni = 0 (the reference divides by zero) are rejected."""
     from dvm_slam_amd import synth
     for (h, w, nf, sf, nl, it, mt) in [(326, 895, 100, 1.3, 8, 31, 19), (200, 664, 100, 1.2, 8, 36, 3), (126, 1192, 100, 1.3, 4, 20, 20),
-                                       (410, 766, 3000, 1.3, 2, 33, 24), (480, 640, 3000, 1.3, 2, 19, 17), (600, 800, 12000, 1.2, 8, 12, 5)]:
+                                       (410, 766, 3000, 1.3, 2, 33, 24), (480, 640, 3000, 1.3, 2, 19, 17), (600, 800, 12000, 1.2, 8, 12, 5),
+                                       (546, 670, 2680, 1.2, 1, 33, 15)]:
         img = synth.small_image(h + w, h, w)
         e = capi.OrbExtractor(nf, sf, nl, it, mt, max_batch=1)
         orc = oracle.OrbOracle(nf, sf, nl, it, mt)
@@ -228,10 +229,11 @@ def test_soak_regressions(capi, oracle):
     with pytest.raises(capi.DvmError, match="too narrow"):
         e.extract(synth.small_image(3, 900, 300))
     e.close()
-    e = capi.OrbExtractor(20000, 1.2, 8, 20, 7, max_batch=1)
-    with pytest.raises(capi.DvmError, match="octree capacity"):
-        e.extract(synth.small_image(4, 480, 640))
-    e.close()
+    for nf, nl in ((20000, 8), (3000, 1), (2681, 1)):
+        e = capi.OrbExtractor(nf, 1.2, nl, 20, 7, max_batch=1)
+        with pytest.raises(capi.DvmError, match="octree capacity"):
+            e.extract(synth.small_image(4, 480, 640))
+        e.close()
 
 
 def test_reconfigure_same_handle(capi, oracle):
