@@ -175,7 +175,7 @@ def main():
         lanes.append(dict(ext=ext, grid=grid, st=ext.stream(), ts=torch.cuda.ExternalStream(ext.stream()), res=(k_ptr, d_ptr, n_ptr),
                           carry=(torch.zeros((cap, 7), dtype=torch.int32, device="cuda"), torch.zeros((cap, 32), dtype=torch.uint8, device="cuda"),
                                  torch.zeros(1, dtype=torch.int32, device="cuda")),
-                          carry_ready=torch.cuda.Event(), matches=torch.zeros((B, cap, 4), dtype=torch.int32, device="cuda"),
+                          carry_ready=torch.cuda.Event(), match_done=torch.cuda.Event(), matches=torch.zeros((B, cap, 4), dtype=torch.int32, device="cuda"),
                           nq=torch.zeros(B, dtype=torch.int32, device="cuda"), scale=ext.scale_factors_device()))
     nbatches = nstream // B
 
@@ -189,6 +189,9 @@ def main():
             ln["ts"].wait_event(prev["carry_ready"])                 # the previous batch's last frame has been copied out
         grid.match_frames_batch(0, B, k_ptr, cap, d_ptr, cap * 32, n_ptr, tuple(t.data_ptr() for t in prev["carry"]), cap, 15.0,
                                 ln["scale"], 8, ln["matches"].data_ptr(), cap, ln["nq"].data_ptr(), stream=ln["st"])
+        ln["match_done"].record(ln["ts"])
+        if nl > 1 and i > 1:
+            ln["ts"].wait_event(prev["match_done"])                  # the reader of this lane's previous carry has finished
         ext.copy_result(B - 1, *(t.data_ptr() for t in ln["carry"]))
         ln["carry_ready"].record(ln["ts"])
 
