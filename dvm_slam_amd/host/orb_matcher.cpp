@@ -369,6 +369,7 @@ int ORBmatcher::SearchByBoW(const KeyFrameView& KF, const FrameView& F, const Fe
   });
   const int nq = (int)qkf.size();
   if (nq == 0) return 0;
+  if (cand.empty()) cand.push_back(-1);   // every common node is empty on the other side: nothing to scan, not an error
   std::vector<dvm_match> res(nq);
   int rc = dvm_match_lists(F.mDescriptors, F.N, qdesc.data(), nq, off.data(), cand.data(), res.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
@@ -433,6 +434,7 @@ int ORBmatcher::SearchByBoW(const KeyFrameView& KF1, const KeyFrameView& KF2, in
   });
   const int nq = (int)q1.size();
   if (nq == 0) return 0;
+  if (cand.empty()) cand.push_back(-1);
   std::vector<dvm_match> res(nq);
   int rc = dvm_match_lists(KF2.mDescriptors, KF2.N, qdesc.data(), nq, off.data(), cand.data(), res.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
@@ -522,6 +524,7 @@ int ORBmatcher::SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameVi
   });
   const int nq = (int)qidx.size();
   if (nq == 0) return 0;
+  if (cand.empty()) cand.push_back(-1);
   std::vector<int32_t> bi(nq), bd(nq);
   int rc = dvm_match_triangulation(KF1.mDescriptors, KF1.mvKeysUn, KF1.N, qidx.data(), nq, KF2.mDescriptors, KF2.mvKeysUn, KF2.N,
                                    off.data(), cand.data(), F12, ep, bCoarse ? 1 : 0, KF2.mvScaleFactors, KF2.mvLevelSigma2, KF2.nLevels,

@@ -1,0 +1,71 @@
+"""BASELINE.json config 3 on one GPU: the 2-agent inter-map merge chain (BoW candidate -> SearchByBoW -> Sim3 RANSAC
+hypotheses -> OptimizeSim3 -> SearchBySim3) composed by dvm_slam_amd/merge.py, once over the HIP library and once over the
+CPU oracle, step by step identical (integers) / within the stated float tolerances, and against the ground truth."""
+import numpy as np
+import pytest
+
+from merge_scene import make_two_agent_scene
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleOps:
+    def __init__(self, po, voc):
+        self.po, self.voc = po, voc
+
+    def transform(self, desc, levelsup):
+        return self.po.vocab_transform(self.voc, desc, levelsup)
+
+    def new_database(self):
+        return self.po.KeyFrameDatabase()
+
+    def search_by_bow(self, a, b, nnratio):
+        return self.po.search_by_bow_kf_kf(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["mp"], b["bad"], b["fv"], nnratio, True)
+
+    def sim3_hypotheses(self, P1c, P2c, e1, e2, K1, K2, triples):
+        return self.po.sim3_hypotheses(P1c, P2c, e1, e2, K1, K2, triples, False)
+
+    def optimize_sim3(self, S12, P1c, P2c, o1, o2, w1, w2, K1, K2, th2):
+        return self.po.optimize_sim3(S12, False, P1c, P2c, o1, o2, w1, w2, K1, K2, th2)
+
+    def search_by_sim3(self, a, pa, b, pb, m12, idx2, s, R, t, th):
+        return self.po.search_by_sim3(a, pa, b, pb, s, R, t, th, m12, idx2)
+
+
+@pytest.mark.parametrize("seed,s_w", [(0, 1.6), (1, 0.7), (2, 1.0)])
+def test_two_agent_merge_chain(capi, oracle, seed, s_w):
+    from dvm_slam_amd import merge, synth
+    voc = synth.vocabulary(k=10, L=4, seed=5)
+    sc = make_two_agent_scene(oracle, seed, s_w=s_w)
+    triples = np.random.default_rng(seed).integers(0, 1 << 30, (200, 3)).astype(np.int64)
+    triples[:, 1] += (triples[:, 1] == triples[:, 0]); triples[:, 2] += 2 * ((triples[:, 2] == triples[:, 0]) | (triples[:, 2] == triples[:, 1]))
+    res = {}
+    for name, ops in (("gpu", merge.GpuOps(voc)), ("cpu", OracleOps(oracle, voc))):
+        peers = [dict(p) for p in sc["peers"]]
+        db = merge.fill_database(ops, peers, levelsup=2)
+        res[name] = merge.merge_with_peer(ops, sc["a"], sc["pa"], peers, sc["peer_pts"], db, 2, triples)
+    g, c = res["gpu"], res["cpu"]
+    # 1. the peer keyframe of the same place is found, identically
+    assert g["candidate"] == c["candidate"] == sc["true_idx"] and g["merge_possible"] == c["merge_possible"]
+    assert g["score"] == c["score"] and g["baseline"] == c["baseline"]
+    # 2. SearchByBoW: identical correspondences
+    assert g["n_bow_matches"] == c["n_bow_matches"] > 100 and np.array_equal(g["bow_matches"], c["bow_matches"])
+    # 3. RANSAC hypotheses: s, R, t to 1e-5; the same hypothesis wins
+    assert np.allclose(g["hyp_T"], c["hyp_T"], rtol=1e-5, atol=1e-5)
+    assert np.all(np.abs(g["hyp_inliers"] - c["hyp_inliers"]) <= 2)
+    assert g["best_hyp"] == c["best_hyp"] and 0.6 * g["n_bow_matches"] < g["hyp_inliers"][g["best_hyp"]] < g["n_bow_matches"]
+    assert g["hyp_inliers"].min() < 0.5 * g["hyp_inliers"].max()        # hypotheses built on an outlier lose
+    # 4. OptimizeSim3 (fed with each side's own hypothesis): same inlier set, Sim3 to 1e-5, and the ground truth is recovered
+    assert g["n_sim3_inliers"] == c["n_sim3_inliers"] > 80 and np.array_equal(g["sim3_inliers"], c["sim3_inliers"])
+    assert np.abs(g["S12"] - c["S12"]).max() < 1e-5
+    from scipy.spatial.transform import Rotation
+    gt = sc["gt"]
+    assert abs(g["S12"][7] / gt["s"] - 1) < 0.02
+    assert np.linalg.norm(Rotation.from_quat(g["S12"][:4]).as_matrix() - gt["R"]) < 0.02
+    assert np.linalg.norm(g["S12"][4:7] - gt["t"]) < 0.05 * max(1.0, np.linalg.norm(gt["t"]))
+    # 5. SearchBySim3: more correspondences, all but a few identical (the two refined similarities differ by ~1e-6)
+    assert g["n_sim3_new"] >= 3 and abs(g["n_sim3_new"] - c["n_sim3_new"]) <= 3
+    assert np.mean(g["matches"] == c["matches"]) > 0.995
+    # ... and they are right: a matched B map point is the B copy of A's own map point
+    hit = g["matches"] >= 0
+    assert np.mean(g["matches"][hit] - 100000 == sc["a"]["mp"][hit]) > 0.9      # (the scene holds near-duplicate points)
