@@ -825,6 +825,17 @@ def search_by_projection_sim3(KF, R, t, s, P, matched, th, ratio_hamming=1.0, de
     return (n, m, rq.value) if mk is None else (n, m, rq.value, mk)
 
 
+def search_by_projection_reloc(Cur, KF, P, already, th, orb_dist, check_ori=True, device=0):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1750-1860).  Cur = frame_view(...) built with its mp
+    array (updated in place) and pose set on the struct.  Returns (nmatches, #host re-queries)."""
+    al = np.sort(np.ascontiguousarray(already, np.int32)); rq = C.c_int32(0)
+    n = _hcall("dvmh_search_by_projection_reloc", C.c_int32, C.c_int32(device), C.byref(Cur[0]), C.byref(KF[0]), C.byref(P[0]),
+               C.c_void_p(al.ctypes.data) if len(al) else None, C.c_int32(len(al)), C.c_float(th), C.c_int32(int(orb_dist)),
+               C.c_int32(int(check_ori)), C.byref(rq))
+    check(min(n, 0))
+    return n, rq.value
+
+
 def search_by_sim3(KF1, KF2, P1, P2, matches12, idx_in_kf2, s12, R12, t12, th, device=0):
     """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1347-1551).  Returns (nFound, vpMatches12 updated)."""
     S = _sim3_view(R12, t12, s12)

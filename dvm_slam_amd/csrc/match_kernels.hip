@@ -282,15 +282,15 @@ __global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, 
   const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (i >= n) return;
   const FrameView F = FB.slot(slot);
-  Projection pr;
-  pr.u = -1.f; pr.v = -1.f; pr.radius = 0.f; pr.level = -1;
+  float out_u = -1.f, out_v = -1.f, out_r = 0.f;
+  int out_level = -1;
   bool ok = valid == nullptr || valid[i] != 0;
   const float p0 = P[3 * i], p1 = P[3 * i + 1], p2 = P[3 * i + 2];
   float X = (C.R[0] * p0 + C.R[1] * p1 + C.R[2] * p2) + C.t[0];
   float Y = (C.R[3] * p0 + C.R[4] * p1 + C.R[5] * p2) + C.t[1];
   float Z = (C.R[6] * p0 + C.R[7] * p1 + C.R[8] * p2) + C.t[2];
   float u, v;
-  if (C.sim3_pair) {   // SearchBySim3 (:1395-1411): p3Dc2 = S21 * (T1w * p3Dw); u = fx * (X * invz) + cx with invz = 1.0 / Z
+  if (C.sim3_pair == 1) {   // SearchBySim3 (:1395-1411): p3Dc2 = S21 * (T1w * p3Dw); u = fx * (X * invz) + cx with invz = 1.0 / Z
     const float X2 = (C.sR2[0] * X + C.sR2[1] * Y + C.sR2[2] * Z) + C.t2[0];
     const float Y2 = (C.sR2[3] * X + C.sR2[4] * Y + C.sR2[5] * Z) + C.t2[1];
     const float Z2 = (C.sR2[6] * X + C.sR2[7] * Y + C.sR2[8] * Z) + C.t2[2];
@@ -302,28 +302,33 @@ __global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, 
     u = C.fx * X / Z + C.cx;
     v = C.fy * Y / Z + C.cy;
   }
-  ok = ok && !(Z < 0.0f);
-  ok = ok && (u >= C.min_x && u < C.max_x && v >= C.min_y && v < C.max_y);
+  // sim3_pair == 2: SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1750-1860) -- no depth test, bounds
+  // inclusive at both ends
+  const bool reloc = C.sim3_pair == 2;
+  const bool in_strict = u >= C.min_x && u < C.max_x && v >= C.min_y && v < C.max_y;
+  const bool in_loose = !(u < C.min_x || u > C.max_x) && !(v < C.min_y || v > C.max_y);
+  const bool front = !(Z < 0.0f);
+  ok = ok && (reloc ? in_loose : (front && in_strict));
   if (ok) {
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
     float q0 = p0 - C.Ow[0], q1 = p1 - C.Ow[1], q2 = p2 - C.Ow[2];
-    if (C.sim3_pair) { q0 = X; q1 = Y; q2 = Z; }
+    if (C.sim3_pair == 1) { q0 = X; q1 = Y; q2 = Z; }
     const float dist = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
     ok = !(dist < minDistance || dist > maxDistance);
     if (ok) {
       const float dot = (q0 * normal[3 * i] + q1 * normal[3 * i + 1]) + q2 * normal[3 * i + 2];
-      ok = C.sim3_pair || !((double)dot < 0.5 * (double)dist);
+      ok = C.sim3_pair != 0 || !((double)dot < 0.5 * (double)dist);
       if (ok) {
         const float ratio = max_dist[i] / dist;
         int nScale = (int)ceilf(logf(ratio) / C.log_scale_factor);
         nScale = nScale < 0 ? 0 : (nScale >= C.n_levels ? C.n_levels - 1 : nScale);
-        pr.u = u; pr.v = v; pr.level = nScale; pr.radius = C.th * scale_factors[nScale];
+        out_u = u; out_v = v; out_level = nScale; out_r = C.th * scale_factors[nScale];
       }
     }
   }
   uint32_t k1 = (256u << 16) | 0xFFFFu, k2 = k1;
-  if (pr.level >= 0)   // uniform inside the row: all 16 lanes computed the same projection
-    window_top2(F, pr.u, pr.v, pr.radius, pr.level - 1, pr.level, desc + (size_t)i * 32, skip, gate_inv_sigma2, gate, lane, k1, k2);
+  if (out_level >= 0)   // uniform inside the row: all 16 lanes computed the same projection
+    window_top2(F, out_u, out_v, out_r, out_level - 1, reloc ? out_level + 1 : out_level, desc + (size_t)i * 32, skip, gate_inv_sigma2, gate, lane, k1, k2);
   if (lane == 0) {
     dvm_match_pod m;
     const int p1i = (int)(k1 & 0xFFFFu), p2i = (int)(k2 & 0xFFFFu);
@@ -333,7 +338,11 @@ __global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, 
     m.best_level = (m.best_dist < 256) ? (int16_t)__float_as_int(F.skp[p1i].z) : (int16_t)-1;
     m.second_level = (m.second_dist < 256) ? (int16_t)__float_as_int(F.skp[p2i].z) : (int16_t)-1;
     out[i] = m;
-    if (proj) proj[i] = pr;
+    if (proj) {
+      Projection pr;
+      pr.u = out_u; pr.v = out_v; pr.radius = out_r; pr.level = out_level;
+      proj[i] = pr;
+    }
   }
 }
 

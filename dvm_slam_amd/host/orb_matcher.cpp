@@ -731,6 +731,71 @@ int ORBmatcher::SearchBySim3(const KeyFrameView& KF1, const KeyFrameView& KF2, c
   return nFound;
 }
 
+int ORBmatcher::SearchByProjection(FrameView& Cur, const KeyFrameView& KF, const MapPointsView& P, const int32_t* sAlreadyFound,
+                                   int nAlreadyFound, float th, int ORBdist) {
+  if (KF.N == 0) return 0;
+  last_requeried = 0;
+  float Ow[3];   // Tcw.inverse().translation()
+  for (int r = 0; r < 3; r++) Ow[r] = -((Cur.Rcw[r] * Cur.tcw[0] + Cur.Rcw[3 + r] * Cur.tcw[1]) + Cur.Rcw[6 + r] * Cur.tcw[2]);
+  std::vector<uint8_t> valid(KF.N, 0), skip;
+  for (int i = 0; i < KF.N; i++) {
+    const int id = KF.mvpMapPoints[i];
+    if (id < 0 || (KF.mpBad && KF.mpBad[i])) continue;
+    if (std::binary_search(sAlreadyFound, sAlreadyFound + nAlreadyFound, id)) continue;
+    valid[i] = 1;
+  }
+  int rc = ensure_grid(Cur);
+  if (rc != DVM_OK) return rc;
+  skip.assign(grid_cap_, 0);
+  for (int j = 0; j < Cur.N; j++) skip[j] = Cur.mvpMapPoints[j] >= 0;
+  dvm_kf_camera cam;
+  std::memset(&cam, 0, sizeof(cam));
+  std::memcpy(cam.Rcw, Cur.Rcw, 36); std::memcpy(cam.tcw, Cur.tcw, 12); std::memcpy(cam.Ow, Ow, 12);
+  cam.fx = Cur.fx; cam.fy = Cur.fy; cam.cx = Cur.cx; cam.cy = Cur.cy;
+  cam.min_x = Cur.mnMinX; cam.max_x = Cur.mnMaxX; cam.min_y = Cur.mnMinY; cam.max_y = Cur.mnMaxY;
+  cam.log_scale_factor = KF.mfLogScaleFactor; cam.n_levels = Cur.nLevels;
+  cam.sim3_pair = 2;
+  std::vector<dvm_match> res(KF.N);
+  std::vector<dvm_projection> proj(KF.N);
+  rc = dvm_project_search(grid_, 0, skip.data(), &cam, P.pos, P.normal ? P.normal : P.pos, P.min_dist, P.max_dist, P.desc, valid.data(), KF.N, th,
+                          Cur.mvScaleFactors, nullptr, 0.0, res.data(), proj.data(), 0, nullptr);
+  if (rc != DVM_OK) return rc;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (auto& h : rotHist) h.reserve(500);
+  HostGrid hg;
+  bool hg_built = false;
+  std::vector<int> cand;
+  for (int i = 0; i < KF.N; i++) {
+    if (!valid[i] || proj[i].level < 0) continue;
+    int bestIdx2 = res[i].best_idx, bestDist = res[i].best_dist;
+    if (bestIdx2 >= 0 && Cur.mvpMapPoints[bestIdx2] >= 0) {   // claimed by an earlier point of this call
+      if (!hg_built) { hg.build(Cur); hg_built = true; }
+      last_requeried++;
+      hg.query(proj[i].u, proj[i].v, proj[i].radius, proj[i].level - 1, proj[i].level + 1, cand);
+      bestDist = 256; bestIdx2 = -1;
+      for (int i2 : cand) {
+        if (Cur.mvpMapPoints[i2] >= 0) continue;
+        const int dist = DescriptorDistance(P.desc + 32 * (size_t)i, Cur.mDescriptors + 32 * (size_t)i2);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+      }
+    }
+    if (bestIdx2 >= 0 && bestDist <= ORBdist) {
+      Cur.mvpMapPoints[bestIdx2] = KF.mvpMapPoints[i];
+      nmatches++;
+      if (mbCheckOrientation) rotHist[RotBin(KF.mvKeysUn[i].angle, Cur.mvKeysUn[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) { Cur.mvpMapPoints[idx] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
 }  // namespace dvm_host
 
 // ---- C entry point for the Python harness (tests only; a C++ caller uses the class directly)
@@ -807,6 +872,13 @@ int dvmh_fuse(int device, const KeyFrameView* KF, const MapPointsView* P, const 
 int dvmh_fuse_sim3(int device, KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, float th, int32_t* replace) {
   dvm_host::ORBmatcher m(0.6f, true, device);
   return m.Fuse(*KF, *Scw, *P, th, replace);
+}
+int dvmh_search_by_projection_reloc(int device, FrameView* Cur, const KeyFrameView* KF, const MapPointsView* P, const int32_t* already,
+                                    int n_already, float th, int orb_dist, int check_ori, int* requeried) {
+  dvm_host::ORBmatcher m(0.9f, check_ori != 0, device);
+  const int n = m.SearchByProjection(*Cur, *KF, *P, already, n_already, th, orb_dist);
+  if (requeried) *requeried = m.last_requeried;
+  return n;
 }
 int dvmh_search_by_sim3(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, const MapPointsView* P1, const MapPointsView* P2,
                         int32_t* matches12, const int32_t* idx_in_kf2, const Sim3View* S12, float th) {

@@ -147,6 +147,11 @@ class ORBmatcher {
   // ... and the overload that also records which keyframe each point came from (:498-603): vpPointsKFs[i] -> vpMatchedKF[idx]
   int SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& vpPoints, const int32_t* vpPointsKFs,
                          int32_t* vpMatched, int32_t* vpMatchedKF, int th, float ratioHamming = 1.f);
+  // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, const float th,
+  //                        const int ORBdist)   (:1750-1860, relocalisation), whole function.  MPs: the map point of every
+  // keypoint of pKF; sAlreadyFound: ascending ids; CurrentFrame.mvpMapPoints receives ids.
+  int SearchByProjection(FrameView& CurrentFrame, const KeyFrameView& KF, const MapPointsView& MPs, const int32_t* sAlreadyFound,
+                         int nAlreadyFound, float th, int ORBdist);
   // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th)
   // (:1347-1551), whole function.  MPsN: the map point of every keypoint of KFN (entry i is read only where
   // KFN.mvpMapPoints[i] >= 0); vnIdxInKF2[i] = get<0>(vpMatches12[i]->GetIndexInKeyFrame(pKF2)) for the entries set at entry

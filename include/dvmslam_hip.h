@@ -198,7 +198,9 @@ typedef struct {
   int32_t n_levels;
   /* sim3_pair != 0 selects the ORBmatcher::SearchBySim3 form (ORBmatcher.cc:1380-1437): p' = sR2 * (Rcw p + tcw) + t2
    * (the other keyframe's pose, then S21 resp. S12 with sR2 = scale * rotation), u = fx * (X * invz) + cx with
-   * invz = 1.0 / Z, distance = |p'|, no viewing-angle test; Ow is not used. */
+   * invz = 1.0 / Z, distance = |p'|, no viewing-angle test; Ow is not used.
+   * sim3_pair == 2 selects the relocalisation form, ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th,
+   * ORBdist) (:1750-1860): no depth test, bounds inclusive at both ends, no viewing-angle test, octaves [level-1, level+1]. */
   int32_t sim3_pair;
   float sR2[9], t2[3];
 } dvm_kf_camera;

@@ -25,6 +25,7 @@
 //                                whole function; KeyFrame.cc:750-794 GetFeaturesInArea / IsInImage; MapPoint.cc:573-587
 //                                PredictScale              -> orc_project_search(), orc_fuse_sim3(), orc_search_by_projection_sim3()
 //   src/ORBmatcher.cc:1347-1551  SearchBySim3, whole function      -> orc_search_by_sim3()
+//   src/ORBmatcher.cc:1750-1860  SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) -> orc_search_by_projection_reloc()
 //   src/MapPoint.cc:384-453      MapPoint::ComputeDistinctiveDescriptors -> orc_distinctive_descriptors()
 //   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1025-1138 transform (TF_IDF, L1), BowVector.cpp:32-72,
 //   FeatureVector.cpp:27-38, ScoringObject.cpp:23-63 L1Scoring::score, FORB.cpp:80-97 -> orc_vocab_transform(), orc_bow_score()
@@ -842,6 +843,60 @@ int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, c
     if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = mp2[idx2]; nFound++; }
   }
   return nFound;
+}
+
+// ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1750-1860, relocalisation): the map
+// points of pKF (per keypoint: id -1 = NULL, bad flag, position, distances, descriptor) are projected with the current
+// frame's pose; already (sorted ids) = sAlreadyFound; mp_c (in/out) = CurrentFrame.mvpMapPoints as ids.
+int orc_search_by_projection_reloc(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* bounds,
+                                   const float* Rcw, const float* tcw, const float* Ow, const float* K, int Nk, const orc_keypoint* kps_k,
+                                   const int32_t* mp_k, const uint8_t* bad_k, const float* P, const float* min_dist, const float* max_dist,
+                                   const uint8_t* pdesc, const int32_t* already, int n_already, float th, int ORBdist,
+                                   const float* scale_factors, float log_scale_factor, int n_levels, int check_ori) {
+  int nmatches = 0;
+  std::vector<int> rotHist[kHisto];
+  orc_grid* g = orc_grid_create(kps_c, Nc, bounds[0], bounds[1], bounds[2], bounds[3]);
+  std::vector<int> vIndices2;
+  for (int i = 0; i < Nk; i++) {
+    if (mp_k[i] < 0) continue;
+    if ((bad_k && bad_k[i]) || std::binary_search(already, already + n_already, mp_k[i])) continue;
+    const float* p = P + 3 * i;
+    float c[3];
+    for (int r = 0; r < 3; r++) c[r] = ((Rcw[3 * r] * p[0] + Rcw[3 * r + 1] * p[1]) + Rcw[3 * r + 2] * p[2]) + tcw[r];
+    const float u = K[0] * c[0] / c[2] + K[2], v = K[1] * c[1] / c[2] + K[3];
+    if (u < bounds[0] || u > bounds[1]) continue;
+    if (v < bounds[2] || v > bounds[3]) continue;
+    const float PO[3] = {p[0] - Ow[0], p[1] - Ow[1], p[2] - Ow[2]};
+    const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float ratio = max_dist[i] / dist3D;
+    int nPredictedLevel = (int)std::ceil(std::log(ratio) / log_scale_factor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0; else if (nPredictedLevel >= n_levels) nPredictedLevel = n_levels - 1;
+    const float radius = th * scale_factors[nPredictedLevel];
+    features_in_area(g, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+    if (vIndices2.empty()) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (mp_c[i2] >= 0) continue;
+      const int dist = descriptor_distance(pdesc + 32 * (size_t)i, desc_c + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= ORBdist) {
+      mp_c[bestIdx2] = mp_k[i];
+      nmatches++;
+      if (check_ori) rotHist[rot_bin(kps_k[i].angle, kps_c[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+    for (int i = 0; i < kHisto; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) { mp_c[idx] = -1; nmatches--; }
+  }
+  orc_grid_destroy(g);
+  return nmatches;
 }
 
 }  // extern "C"

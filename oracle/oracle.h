@@ -159,6 +159,12 @@ int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, c
                        const float* bounds, const float* K, float s12, const float* R12, const float* t12, float th,
                        const float* scale_factors, float log_scale_factor, int n_levels, int32_t* matches12, const int32_t* idx_in_kf2);
 
+int orc_search_by_projection_reloc(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* bounds,
+                                   const float* Rcw, const float* tcw, const float* Ow, const float* K, int Nk, const orc_keypoint* kps_k,
+                                   const int32_t* mp_k, const uint8_t* bad_k, const float* P, const float* min_dist, const float* max_dist,
+                                   const uint8_t* pdesc, const int32_t* already, int n_already, float th, int ORBdist,
+                                   const float* scale_factors, float log_scale_factor, int n_levels, int check_ori);
+
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);
 

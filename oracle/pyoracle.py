@@ -554,6 +554,19 @@ def search_by_sim3(kf1, mps1, kf2, mps2, s12, R12, t12, th, matches12, idx_in_kf
     return n, m
 
 
+def search_by_projection_reloc(cur_kps, cur_desc, cur_mp, bounds, Rcw, tcw, Ow, K, kf, kf_pts, already, th, orb_dist, scale_factors,
+                               log_scale_factor, check_ori=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist).  Returns (nmatches, mvpMapPoints updated)."""
+    kc, dc = _kd(cur_kps, cur_desc); kk, _ = _kd(kf["kps"], kf["desc"])
+    m = np.array(cur_mp, np.int32, copy=True)
+    al = np.sort(np.ascontiguousarray(already, np.int32))
+    sf = _f32(scale_factors)
+    n = _call(lib().orc_search_by_projection_reloc, C.c_int32, len(kc), kc, dc, m, _f32(bounds), _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow), _f32(K),
+              len(kk), kk, np.ascontiguousarray(kf["mp"], np.int32), _u8(kf.get("bad")), _f32(kf_pts["pos"]), _f32(kf_pts["min_dist"]),
+              _f32(kf_pts["max_dist"]), _u8(kf_pts["desc"]), al, len(al), F32(th), int(orb_dist), sf, F32(log_scale_factor), len(sf), int(check_ori))
+    return n, m
+
+
 def distinctive_descriptors(desc, off):
     """MapPoint::ComputeDistinctiveDescriptors for a batch.  Returns (best_idx, best_median)."""
     L = lib()

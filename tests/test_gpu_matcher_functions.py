@@ -209,3 +209,24 @@ def test_search_by_projection_sim3_records_keyframes(capi, oracle):
     assert nm_g == nm_o and np.array_equal(m_g, m_o)
     hit = m_g >= 0
     assert np.array_equal(mk[hit], point_kf[m_g[hit] - 1000]) and np.all(mk[~hit] == -1)
+
+
+@pytest.mark.parametrize("seed,th,orb_dist,ori", [(0, 10.0, 100, True), (1, 3.0, 64, True), (2, 10.0, 100, False)])
+def test_search_by_projection_relocalisation(capi, oracle, seed, th, orb_dist, ori):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): keyframe a's map points into frame b."""
+    import ctypes as C
+    sc = make_kf_pair_scene(oracle, seed, mapped_frac=0.8, dup_frac=0.25)
+    a, b = sc["kf"]
+    pa = _per_keypoint_points(a, sc["pts"])
+    rng = np.random.default_rng(seed)
+    cur_mp = np.where(rng.random(len(b["kps"])) < 0.2, b["mp"], -1).astype(np.int32)      # some keypoints already matched
+    already = np.unique(cur_mp[cur_mp >= 0])
+    n_o, m_o = oracle.search_by_projection_reloc(b["kps"], b["desc"], cur_mp, b["bounds"], b["Rcw"], b["tcw"], b["Ow"], b["K"], a, pa, already, th,
+                                                 orb_dist, b["scale_factors"], b["log_scale_factor"], ori)
+    m_g = cur_mp.copy()
+    F = capi.frame_view(b["kps"], b["desc"], b["bounds"], b["scale_factors"], mp=m_g, K=b["K"])
+    F[0].Rcw = (C.c_float * 9)(*b["Rcw"]); F[0].tcw = (C.c_float * 3)(*b["tcw"])
+    n_g, req = capi.search_by_projection_reloc(F, capi.keyframe_view(dict(a, mp=a["mp"].copy())), capi.map_points_view(pa), already, th, orb_dist, ori)
+    assert n_g == n_o and np.array_equal(m_g, m_o)
+    if th >= 10:
+        assert n_o > 150 and req > 0
