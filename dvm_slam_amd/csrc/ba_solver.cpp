@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -37,6 +38,7 @@ struct dvm_ba {
   BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
   double tile_fill = 1.0;                             // non-zero tiles / all lower tiles of the factor
   hipGraphExec_t trial_graph = nullptr;  // one LM trial (push, Schur, Cholesky solve, update, chi2) as a hipGraph
+  bool use_graph = false;                // DVM_BA_GRAPH=1 replays the trial as a hipGraph (see dvm_ba_optimize: not thread-friendly)
 
   template <typename T>
   int dalloc(T** p, size_t n) {
@@ -72,6 +74,7 @@ int dvm_ba_create(int device, dvm_ba** out) {
   DVM_HIP(hipSetDevice(device));
   dvm_ba* h = new dvm_ba;
   h->device = device;
+  if (const char* e = getenv("DVM_BA_GRAPH")) h->use_graph = (e[0] == '1');
   int rc = hip_check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "stream");
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_scalars, 8 * sizeof(double)), "malloc");
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_fail, sizeof(int)), "malloc");
@@ -269,9 +272,12 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       // launches, replayed as ONE hipGraph (the host would otherwise be the bottleneck)
       h->h_scalars[7] = lambda;
       DVM_HIP(hipMemcpyAsync(h->d_scalars + 7, h->h_scalars + 7, sizeof(double), hipMemcpyHostToDevice, s));
-      if (!h->trial_graph) {
-        hipGraph_t g = nullptr;
-        DVM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      // The trial as a plain launch sequence (~45 asynchronous launches, each 5-60 us of GPU work: the host stays ahead).
+      // DVM_BA_GRAPH=1 records it once into a hipGraph instead -- measured equal (1261 vs 1275 it/s) and OFF by default:
+      // while a thread captures, this runtime rejects legacy-stream calls (a synchronous hipMemcpy) made by ANY other host
+      // thread, in every capture mode, and the capture itself is poisoned -- the reference calls its optimizers
+      // concurrently from Tracking, LocalMapping and LoopClosing (tests/test_gpu_threads.py).
+      auto enqueue_trial = [&]() {
         hipMemcpyAsync(h->d_poses_bak, V.poses, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(h->d_points_bak, V.points, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s);
         hipMemsetAsync(h->d_fail, 0, sizeof(int), s);
@@ -279,11 +285,20 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         ba_launch_cholesky_solve(s, V, h->d_fail);
         ba_launch_backsub_update(s, V, h->d_scalars, S_SCALE);
         ba_launch_edge_eval(s, V, false, h->d_scalars, S_TMPCHI);
-        DVM_HIP(hipStreamEndCapture(s, &g));
-        DVM_HIP(hipGraphInstantiate(&h->trial_graph, g, nullptr, nullptr, 0));
-        hipGraphDestroy(g);
+      };
+      if (!h->trial_graph && h->use_graph) {
+        hipGraph_t g = nullptr;
+        bool captured = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (captured) {
+          enqueue_trial();
+          captured = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr;
+        }
+        if (captured && hipGraphInstantiate(&h->trial_graph, g, nullptr, nullptr, 0) != hipSuccess) h->trial_graph = nullptr;
+        if (g) hipGraphDestroy(g);
+        (void)hipGetLastError();   // a failed capture must not surface as the error of the next call
       }
-      DVM_HIP(hipGraphLaunch(h->trial_graph, s));
+      if (h->trial_graph) DVM_HIP(hipGraphLaunch(h->trial_graph, s));
+      else enqueue_trial();
       rc = read_scalars(h);
       if (rc != DVM_OK) return rc;
       const bool ok2 = (*h->h_fail == 0);

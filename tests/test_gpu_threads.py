@@ -1,0 +1,72 @@
+"""The boundary's threading contract: one extractor instance per tracking thread, the static Optimizer
+functions called concurrently from Tracking (PoseOptimization), LocalMapping (local BA) and LoopClosing (OptimizeSim3).
+Four host threads hammer the C ABI at once (ctypes drops the GIL during the calls); every result must equal the one the
+same call gives when it runs alone."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_callers(capi, oracle, frames):
+    from dvm_slam_amd import synth
+    orc = oracle.OrbOracle()
+    ref_ext = [orc.extract(f) for f in frames]
+    pr = synth.ba_problem(n_kf=14, n_pts=400, seed=5)
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(5.991))
+
+    def run_ba():
+        ba = capi.BundleAdjuster()
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        st = ba.optimize(6)
+        p, x = ba.result()
+        ba.close()
+        return st["trials"], p, x
+
+    ba_ref = run_ba()
+    rng = np.random.default_rng(0)
+    Xw = rng.uniform(-3, 3, (300, 3)) + [0, 0, 8]
+    K = np.array([500.0, 500.0, 320.0, 240.0])
+    obs = np.stack([K[0] * Xw[:, 0] / Xw[:, 2] + K[2], K[1] * Xw[:, 1] / Xw[:, 2] + K[3]], 1) + rng.normal(0, 0.5, (300, 2))
+    pose0 = np.array([0.05, -0.03, 0.1, 0.0, 0.0, 0.0, 1.0])
+    po_ref = capi.pose_optimize(pose0[None], Xw[None], obs[None], np.ones((1, 300)), [300], K)
+    errors = []
+
+    def guard(fn):
+        def w():
+            try:
+                fn()
+            except Exception as ex:   # noqa: BLE001
+                errors.append(repr(ex))
+        return w
+
+    def t_extract(k):
+        def f():
+            ext = capi.OrbExtractor(max_batch=1)
+            for it in range(12):
+                i = (it + k) % len(frames)
+                n, kp, d, m = ext.extract(frames[i])
+                n_o, k_o, d_o, m_o = ref_ext[i]
+                assert (n, m) == (n_o, m_o) and np.array_equal(d, d_o) and np.array_equal(kp["x"], k_o["x"]) and np.array_equal(kp["angle"], k_o["angle"])
+            ext.close()
+        return f
+
+    def t_ba():
+        for _ in range(4):
+            tr, p, x = run_ba()
+            assert tr == ba_ref[0] and np.array_equal(p, ba_ref[1]) and np.array_equal(x, ba_ref[2])
+
+    def t_pose():
+        for _ in range(40):
+            p, o, n = capi.pose_optimize(pose0[None], Xw[None], obs[None], np.ones((1, 300)), [300], K)
+            assert np.array_equal(p, po_ref[0]) and np.array_equal(o, po_ref[1]) and n[0] == po_ref[2][0]
+
+    threads = [threading.Thread(target=guard(f)) for f in (t_extract(0), t_extract(1), t_ba, t_pose)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
