@@ -433,7 +433,7 @@ bool octree_prepare_device(const PipelineDesc& PD) {
   if (!octree_fits_device(PD)) return false;
   const size_t bytes = octree_lds_bytes(octree_required_nodes(PD));
   if (bytes <= 48 * 1024) return true;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+  return raise_dynamic_lds(reinterpret_cast<const void*>(k_octree), (int)bytes);
 }
 
 void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,

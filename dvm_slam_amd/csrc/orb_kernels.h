@@ -21,6 +21,9 @@ void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, i
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num);
 int octree_root_nodes(const LevelDesc& L);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-(device, kernel) cap shared by every handle and host thread: only ever
+// RAISE it, so that a handle with a smaller configuration cannot pull the cap under a launch another thread is about to make.
+bool raise_dynamic_lds(const void* fn, int bytes);
 bool octree_fits_device(const PipelineDesc& PD);
 bool octree_prepare_device(const PipelineDesc& PD);   // raises the LDS limit for this configuration; false: cannot run it   // else: DistributeOctTree runs on the host for this configuration
 void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,

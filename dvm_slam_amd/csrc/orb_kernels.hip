@@ -12,6 +12,10 @@
 // IEEE rounding, the same sequence the CPU oracle performs.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -984,6 +988,19 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
 // ------------------------------------------------------------------------------------- launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+bool raise_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mtx;
+  static std::map<std::pair<int, const void*>, int> cap;   // (device, kernel) -> bytes granted so far
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mtx);
+  int& have = cap[{dev, fn}];
+  if (bytes <= have) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  have = bytes;
+  return true;
+}
+
 void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gauss7) {
   uint2 w[256];
   for (int i = 0; i < 256; i++) w[i] = make_uint2(0u, 0u);
@@ -1032,8 +1049,7 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
 #define DVM_FAST_LAUNCH(P, W)                                                                                              \
   do {                                                                                                                     \
     if (lay.total() > 48 * 1024)                                                                                           \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cells<P, W>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                          lay.total());                                                                                    \
+      raise_dynamic_lds(reinterpret_cast<const void*>(k_fast_cells<P, W>), lay.total());                                   \
     hipLaunchKernelGGL((k_fast_cells<P, W>), grid, dim3(64 * W), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells, PD,   \
                        d_cand, d_cell_count, max_rw, max_rh, batch, cell_first, cell_num);                                 \
   } while (0)

@@ -1,6 +1,6 @@
 """The boundary's threading contract: one extractor instance per tracking thread, the static Optimizer
 functions called concurrently from Tracking (PoseOptimization), LocalMapping (local BA) and LoopClosing (OptimizeSim3).
-Four host threads hammer the C ABI at once (ctypes drops the GIL during the calls); every result must equal the one the
+Five host threads hammer the C ABI at once (ctypes drops the GIL during the calls); every result must equal the one the
 same call gives when it runs alone."""
 import threading
 
@@ -54,6 +54,16 @@ def test_concurrent_callers(capi, oracle, frames):
             ext.close()
         return f
 
+    big_img = synth.small_image(77, 600, 800)
+    big_ref = oracle.OrbOracle(8000, 1.2, 8, 12, 5).extract(big_img, cap=4 * 8000 + 256)
+
+    def t_extract_big():     # a configuration whose octree needs > 48 KB of LDS, next to the default one (shared per-kernel LDS cap)
+        ext = capi.OrbExtractor(8000, 1.2, 8, 12, 5, max_batch=1)
+        for _ in range(6):
+            n, kp, d, m = ext.extract(big_img)
+            assert (n, m) == (big_ref[0], big_ref[3]) and np.array_equal(d, big_ref[2])
+        ext.close()
+
     def t_ba():
         for _ in range(4):
             tr, p, x = run_ba()
@@ -64,7 +74,7 @@ def test_concurrent_callers(capi, oracle, frames):
             p, o, n = capi.pose_optimize(pose0[None], Xw[None], obs[None], np.ones((1, 300)), [300], K)
             assert np.array_equal(p, po_ref[0]) and np.array_equal(o, po_ref[1]) and n[0] == po_ref[2][0]
 
-    threads = [threading.Thread(target=guard(f)) for f in (t_extract(0), t_extract(1), t_ba, t_pose)]
+    threads = [threading.Thread(target=guard(f)) for f in (t_extract(0), t_extract(1), t_extract_big, t_ba, t_pose)]
     for t in threads:
         t.start()
     for t in threads:
