@@ -133,8 +133,50 @@ def kf_functions():
     print("kf functions", n1, n2, n3, int((bi >= 0).sum()), n4, n5, n6)
 
 
+def db_wire():
+    """Fourth set: KeyFrameDatabase queries, the relocalisation search and one DVMW block (byte-exact format pin)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from kfdb_scene import fill, make_db_scene
+    from matcher_scene import make_kf_pair_scene
+    from wire_scene import make_delta
+    from dvm_slam_amd import capi, wire
+    kfs = make_db_scene(31, n_maps=2, kf_per_map=14, n_words=1500, words_per_kf=90)
+    db = po.KeyFrameDatabase()
+    fill(db, kfs)
+    out = dict(db_n=len(kfs))
+    for i, k in enumerate(kfs):
+        out[f"db_ids_{i}"], out[f"db_vals_{i}"] = k["ids"], k["vals"]
+        out[f"db_neigh_{i}"], out[f"db_conn_{i}"] = k["neigh"], k["connected"]
+    out["db_meta"] = np.array([[k["map_id"], k["mn_id"]] for k in kfs], np.int64)
+    out["db_uuid"] = np.array([k["uuid"] for k in kfs], np.uint64)
+    q = [3, 9, 20]
+    out["db_queries"] = np.array(q)
+    out["db_merge"] = np.array([db.detect_merge_possibility(kfs[i]["ids"], kfs[i]["vals"], kfs[i]["uuid"], 1 - kfs[i]["map_id"]) for i in q], np.float64)
+    nb = [db.detect_n_best(i, 3) for i in (5, 17)]
+    for j, (lo, me) in enumerate(nb):
+        out[f"db_loop_{j}"], out[f"db_mergecand_{j}"] = lo, me
+    sc = make_kf_pair_scene(po, 33, n_pts=300, n_clutter=60, mapped_frac=0.8, dup_frac=0.2)
+    a, b = sc["kf"]
+    idx = np.where(a["pt_of_kp"] >= 0, a["pt_of_kp"], 0).astype(np.int64)
+    pa = dict(pos=sc["pts"]["pos"][idx], min_dist=sc["pts"]["min_dist"][idx], max_dist=sc["pts"]["max_dist"][idx], desc=sc["pts"]["desc"][idx])
+    cur_mp = np.where(np.random.default_rng(3).random(len(b["kps"])) < 0.2, b["mp"], -1).astype(np.int32)
+    already = np.unique(cur_mp[cur_mp >= 0])
+    n, m = po.search_by_projection_reloc(b["kps"], b["desc"], cur_mp, b["bounds"], b["Rcw"], b["tcw"], b["Ow"], b["K"], a, pa, already, 10.0, 100,
+                                         b["scale_factors"], b["log_scale_factor"], True)
+    for tag, kf in (("ra", a), ("rb", b)):
+        for k in ("kps", "desc", "mp", "bad", "Rcw", "tcw", "Ow", "K", "bounds", "scale_factors"):
+            out[f"{tag}_{k}"] = kf[k]
+    out.update({"rp_" + k: v for k, v in pa.items()}, r_cur_mp=cur_mp, r_already=already, r_n=n, r_m=m, r_lsf=np.float32(b["log_scale_factor"]))
+    dk, dm = make_delta(wire, capi, 7, 2, 10)
+    out["wire_block"] = wire.build(dk, dm, sender_agent=3)
+    np.savez_compressed(os.path.join(HERE, "db_wire.npz"), **out)
+    print("db/wire", out["db_merge"][:, 0], n, out["wire_block"].size)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "more":
+    if len(sys.argv) > 1 and sys.argv[1] == "db":
+        db_wire()
+    elif len(sys.argv) > 1 and sys.argv[1] == "more":
         more()
     elif len(sys.argv) > 1 and sys.argv[1] == "kf":
         kf_functions()
@@ -142,3 +184,4 @@ if __name__ == "__main__":
         main()
         more()
         kf_functions()
+        db_wire()

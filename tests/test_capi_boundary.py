@@ -69,6 +69,25 @@ def test_fails_loudly_without_gpu(capi):
         capi.BundleAdjuster()
     with pytest.raises(capi.DvmError):
         capi.FrameGrid()
+    # the newer entry points behave the same: no device -> an error, never a computed result
+    z32 = np.zeros((2, 32), np.uint8)
+    with pytest.raises(capi.DvmError):
+        capi.match_lists(z32, z32, np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32))
+    with pytest.raises(capi.DvmError):
+        capi.distinctive_descriptors(z32, np.array([0, 2], np.int32))
+    with pytest.raises(capi.DvmError):
+        capi.bowdb_query_raw([(np.array([1, 2], np.int32), np.array([0.5, 0.5]))], np.array([1], np.int32), np.array([1.0]))
+    with pytest.raises(capi.DvmError):
+        capi.sim3_hypotheses(np.ones((4, 3), np.float32), np.ones((4, 3), np.float32), np.ones(4, np.float32), np.ones(4, np.float32),
+                             np.ones(4, np.float32), np.ones(4, np.float32), np.array([[0, 1, 2]], np.int32))
+    with pytest.raises(capi.DvmError):
+        capi.pose_optimize(np.array([[0, 0, 0, 0, 0, 0, 1.0]]), np.ones((1, 4, 3)), np.ones((1, 4, 2)), np.ones((1, 4)), [4], [500, 500, 320, 240])
+    from dvm_slam_amd import wire
+    with pytest.raises(capi.DvmError):
+        wire.gather_keypoints_device(64, 0, 1, 64, 1, 64, 32)     # never dereferenced: refused before any launch
+    # the host mirrors sit on top of the same library: they fail with it
+    with pytest.raises((capi.DvmError, AssertionError)):
+        capi.HostKeyFrameDatabase()
 
 
 def test_graft_entry_symbols():

@@ -201,3 +201,57 @@ def test_hip_reproduces_kf_matcher_functions(capi):
     F2 = capi.frame_view(si["k2"], si["d2"], si["bounds"], si["scale_factors"])
     n, m, pm = capi.search_for_initialization(F1, F2, si["prev_matched"], 100, 0.9, True)
     assert n == int(z["init_n"]) and np.array_equal(m, z["init_m"]) and np.array_equal(pm, z["init_pm"])
+
+
+def _db_from_golden(z, db):
+    n = int(z["db_n"])
+    for i in range(n):
+        s = db.add(z[f"db_ids_{i}"], z[f"db_vals_{i}"], int(z["db_meta"][i, 0]), int(z["db_uuid"][i]), int(z["db_meta"][i, 1]))
+        assert s == i
+    for i in range(n):
+        db.set_neighbours(i, z[f"db_neigh_{i}"]); db.set_connected(i, z[f"db_conn_{i}"])
+    return n
+
+
+def _check_db(z, db):
+    _db_from_golden(z, db)
+    for row, i in zip(z["db_merge"], z["db_queries"]):
+        i = int(i)
+        r = db.detect_merge_possibility(z[f"db_ids_{i}"], z[f"db_vals_{i}"], int(z["db_uuid"][i]), 1 - int(z["db_meta"][i, 0]))
+        assert np.array_equal(np.array(r, np.float64), row), (i, r, row)
+    for j, i in enumerate((5, 17)):
+        lo, me = db.detect_n_best(i, 3)
+        assert np.array_equal(lo, z[f"db_loop_{j}"]) and np.array_equal(me, z[f"db_mergecand_{j}"])
+
+
+def test_oracle_reproduces_db_wire_set(oracle, capi):
+    from dvm_slam_amd import wire
+    from wire_scene import make_delta
+    z = np.load(os.path.join(G, "db_wire.npz"))
+    _check_db(z, oracle.KeyFrameDatabase())
+    a = {k: z[f"ra_{k}"] for k in ("kps", "desc", "mp", "bad")}
+    n, m = oracle.search_by_projection_reloc(z["rb_kps"], z["rb_desc"], z["r_cur_mp"], z["rb_bounds"], z["rb_Rcw"], z["rb_tcw"], z["rb_Ow"], z["rb_K"], a,
+                                             _sub(z, "rp_"), z["r_already"], 10.0, 100, z["rb_scale_factors"], float(z["r_lsf"]), True)
+    assert n == int(z["r_n"]) and np.array_equal(m, z["r_m"])
+    # the DVMW block is a format pin: the builder must reproduce it byte for byte, and it must parse
+    dk, dm = make_delta(wire, capi, 7, 2, 10)
+    blk = wire.build(dk, dm, sender_agent=3)
+    assert np.array_equal(blk, z["wire_block"])
+    h, kfs, mps = wire.parse(z["wire_block"])
+    assert int(h["n_keyframes"]) == 2 and int(h["n_mappoints"]) == 10 and int(h["sender_agent"]) == 3
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_db_wire_set(capi):
+    import ctypes as C
+    z = np.load(os.path.join(G, "db_wire.npz"))
+    _check_db(z, capi.HostKeyFrameDatabase())
+    a = {k: z[f"ra_{k}"] for k in ("kps", "desc", "mp", "bad")}
+    a.update(bounds=z["ra_bounds"], scale_factors=z["ra_scale_factors"], log_scale_factor=float(z["r_lsf"]))
+    a["mp"] = a["mp"].copy()
+    m = z["r_cur_mp"].copy()
+    F = capi.frame_view(z["rb_kps"], z["rb_desc"], z["rb_bounds"], z["rb_scale_factors"], mp=m, K=z["rb_K"])
+    F[0].Rcw = (C.c_float * 9)(*z["rb_Rcw"]); F[0].tcw = (C.c_float * 3)(*z["rb_tcw"])
+    pts = _sub(z, "rp_"); pts["normal"] = pts["pos"]
+    n, _ = capi.search_by_projection_reloc(F, capi.keyframe_view(a), capi.map_points_view(pts), z["r_already"], 10.0, 100, True)
+    assert n == int(z["r_n"]) and np.array_equal(m, z["r_m"])
