@@ -277,6 +277,18 @@ def main():
                     traffic = pmc["kernels"]["dvm::k_fast_cells"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
+            valu = None
+            try:  # VALU issue time of the whole step from the committed SQ_INSTS_VALU pass (same kernels, same batch)
+                if pmc["batch"] == frames_per_launch:
+                    per_step = {"dvm::k_pyr_level0": 1, "dvm::k_pyr_resize": 7, "dvm::k_fast_cells": 1, "dvm::k_blur7": 1, "dvm::k_octree": 1,
+                                "dvm::k_assemble": 1, "dvm::k_orient_desc": 1, "dvm::k_frame_build": 1, "dvm::k_match_window": 1}
+                    ms = sum(pmc["kernels"][k]["valu_issue_ms"] * n for k, n in per_step.items())
+                    valu = {"issue_ms_per_step": ms, "frac_of_step": ms / (dt / a.steps * 1e3),
+                            "k_fast_cells_issue_ms": pmc["kernels"]["dvm::k_fast_cells"]["valu_issue_ms"],
+                            "note": "sum over the step's kernels of SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), from profiles/"
+                                    "r01_pmc_traffic.json: the path is VALU-issue bound, not HBM bound (DESIGN.md section 3)"}
+            except Exception:
+                valu = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "bytes_per_launch": BYTES_PER_FRAME_FAST * frames_per_launch, "avg_launch_ms": fast_ms / fast_n,
@@ -285,6 +297,7 @@ def main():
                     "pipeline_achieved": BYTES_PER_FRAME_TOTAL * total_frames / world / dt / 1e9,   # whole step, GB/s per GPU
                     "pipeline_frac": BYTES_PER_FRAME_TOTAL * total_frames / world / dt / 1e9 / HBM_PEAK_GBS,
                     "gpu_kernel_ms_per_step": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()},
+                    "valu_issue": valu,
                     "note": f"{nl} pipeline lanes: k_fast_cells launches of one batch overlap the tail kernels of the previous batch, so the "
                             "per-launch duration above includes that contention" if nl > 1 else None}
             if excl and excl[1]:
