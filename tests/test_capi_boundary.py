@@ -93,3 +93,26 @@ def test_fails_loudly_without_gpu(capi):
 def test_graft_entry_symbols():
     import __graft_entry__ as g
     assert g.exported_symbols() == _declared()
+
+
+def test_headers_are_plain_c_and_link(tmp_path):
+    """include/*.h are the boundary: they must compile as C99 and as C++11, and a C program must link against the library
+    (the reference-side binding is C++ shim classes over exactly these declarations)."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "dvmslam_hip.h"\n#include "dvmslam_wire.h"\n'
+                   'int main(void) {\n  dvm_wire_header h = {0};\n  dvm_wire_layout_t L;\n  h.n_keyframes = 2; h.n_keypoints = 5;\n'
+                   '  if (dvm_wire_layout(&h, &L) != DVM_OK) return 2;\n  printf("%s %llu\\n", dvm_version(), (unsigned long long)L.total_bytes);\n'
+                   '  return sizeof(dvm_keypoint) == 28 && sizeof(dvm_wire_keyframe) == 192 ? 0 : 3;\n}\n')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "dvm_slam_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{inc}", "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", f"-I{inc}", "-fsyntax-only", "-x", "c++", str(src)])
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", f"-I{inc}", str(src), "-o", str(exe), f"-L{libdir}", "-ldvmslam_hip", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("dvmslam-hip") and out.stdout.split()[-1] == "960", (out.stdout, out.stderr)
+    # the host C++ mirrors' headers stand on their own too
+    host = os.path.join(ROOT, "dvm_slam_amd", "host")
+    hdr = tmp_path / "host.cpp"
+    hdr.write_text('#include "orb_matcher.h"\n#include "orb_vocabulary.h"\n#include "keyframe_database.h"\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", f"-I{inc}", f"-I{host}", "-fsyntax-only", str(hdr)])
