@@ -4,6 +4,8 @@
 // changes: Frame.cc:411,508-511 keeps calling (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors, vLapping).
 #pragma once
 #include <opencv2/core/core.hpp>
+#include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "dvmslam_hip.h"
@@ -39,6 +41,15 @@ class ORBextractor {
     int n = 0, mono = 0;
     int rc = dvm_orb_extract(h_, image.data, image.rows, image.cols, (int)image.step, vLappingArea[0], vLappingArea[1],
                              kps_.data(), desc.data, cap_, &n, &mono);
+    if (rc == DVM_ERR_CAPACITY && n > cap_) {
+      // a level may keep max(quota + 2, 4 * round(W / H)) keypoints -- the first DistributeOctTree sweep splits every root
+      // node before the count is compared with the quota (ORBextractor.cc:423-470) -- so wide images with small quotas can
+      // return more than nfeatures + 5 * nlevels: *n holds the size needed, the results are still on the device
+      cap_ = n + 8;
+      kps_.resize(cap_);
+      desc.create(cap_, 32, CV_8U);
+      rc = dvm_orb_download(h_, 0, kps_.data(), desc.data, cap_, &n, &mono);
+    }
     if (rc != DVM_OK) throw std::runtime_error(dvm_last_error());
     _keypoints.resize(n);
     std::memcpy(static_cast<void*>(_keypoints.data()), kps_.data(), sizeof(dvm_keypoint) * n);
