@@ -76,7 +76,14 @@ def merge_with_peer(ops, kf, kf_points, peer_kfs, peer_points, peer_db, levelsup
     out.update(merge_possible=ok, candidate=best, score=score, baseline=base)
     if best < 0:
         return out
-    pk, pp = peer_kfs[best], peer_points[best]
+    out.update(solve_against_candidate(ops, kf, kf_points, peer_kfs[best], peer_points[best], triples, nnratio, th_sim3))
+    return out
+
+
+def solve_against_candidate(ops, kf, kf_points, pk, pp, triples, nnratio=0.75, th_sim3=7.5):
+    """Steps 2-5 for one candidate keyframe `pk` (with per-keypoint map point data `pp`) of the peer; `kf` carries its feature
+    vector.  Returns the intermediate results (see merge_with_peer)."""
+    out = {}
     n12, m12 = ops.search_by_bow(kf, pk, nnratio)
     out.update(n_bow_matches=n12, bow_matches=m12)
     sel = np.flatnonzero(m12 >= 0)

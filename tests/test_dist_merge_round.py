@@ -1,0 +1,84 @@
+"""BASELINE.json config 4 on CPU: two agents (world_size 2, gloo) run one decentralised merge round (dvm_slam_amd/agents.py):
+BoW vectors all-gathered, each agent tests the peer's vector against its own keyframe database, the recognising agent ships
+the candidate keyframe + map points as a DVMW block, the other solves the similarity and announces it.  The numerical steps
+run on the CPU oracle here (the GPU counterpart of every step has its own parity test); what is under test is the protocol:
+ragged collectives, block contents surviving the wire, the right agent solving, every agent receiving the result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvm_slam_amd import agents, merge, synth
+    from merge_scene import make_two_agent_scene
+    from oracle import pyoracle as po
+    from test_gpu_merge_pipeline import OracleOps
+    voc = synth.vocabulary(k=10, L=4, seed=5)
+    ops = OracleOps(po, voc)
+    sc = make_two_agent_scene(po, 1, s_w=0.7)
+    rng = np.random.default_rng(9)
+    triples = rng.integers(0, 1 << 30, (200, 3)).astype(np.int64)
+    if rank == 0:     # agent A: its current keyframe is the one B has seen; its own map holds unrelated keyframes
+        own = []
+        for k in range(5):
+            n = 700
+            own.append(dict(sc["a"], desc=rng.integers(0, 256, (n, 32), dtype=np.uint8), kps=sc["a"]["kps"][:n].copy(), mp=np.full(n, -1, np.int32),
+                            bad=np.zeros(n, np.uint8), uuid=900 + k, mn_id=10 + k, neigh=np.zeros(0, np.int32)))
+        own_pts = [dict(pos=np.zeros((700, 3), np.float32), normal=np.zeros((700, 3), np.float32), min_dist=np.ones(700, np.float32),
+                        max_dist=np.ones(700, np.float32), desc=o["desc"]) for o in own]
+        me = dict(kf=sc["a"], kf_points=sc["pa"], peers=own, peer_pts=own_pts)
+    else:             # agent B: the database that contains the keyframe of the same place; its current keyframe is somewhere else
+        peers = [dict(p) for p in sc["peers"]]
+        cur = next(i for i in range(len(peers)) if i != sc["true_idx"])
+        me = dict(kf=dict(peers[cur], uuid=4242), kf_points=sc["peer_pts"][cur], peers=peers, peer_pts=sc["peer_pts"])
+    me["db"] = merge.fill_database(ops, me["peers"], 2)
+    res = agents.merge_round(ops, me, 2, triples)
+    ok = True
+    dbg = dict(seen=res["seen"], solved=list(res["solved"].keys()), sim3={k: (v[0], float(v[1][7])) for k, v in res["sim3"].items()}, true=sc["true_idx"], gt=sc["gt"]["s"])
+    if rank == 1:
+        ok &= res["seen"].get(0, (None,))[0] == sc["true_idx"]
+        # a BoW look-alike may be offered by agent 0 too: the geometric verification throws it out (no announcement from rank 1)
+        ok &= all(r_.get("n_sim3_inliers", 0) < 20 for r_ in res["solved"].values())
+    else:
+        ok &= list(res["solved"].keys()) == [1]
+        r = res["solved"][1]
+        ok &= r["n_bow_matches"] > 100 and r["n_sim3_inliers"] > 80 and r["S12"] is not None
+        # the same chain without any wire in between gives the same numbers
+        ref = merge.solve_against_candidate(ops, dict(sc["a"], fv={k: ops.transform(sc["a"]["desc"], 2)[k] for k in ("fv_nodes", "fv_off", "fv_feat")}),
+                                            sc["pa"], dict(sc["peers"][sc["true_idx"]], fv=ops.transform(sc["peers"][sc["true_idx"]]["desc"], 2)),
+                                            sc["peer_pts"][sc["true_idx"]], triples)
+        ok &= np.array_equal(r["bow_matches"], ref["bow_matches"]) and np.abs(r["S12"] - ref["S12"]).max() < 1e-4
+        ok &= abs(r["S12"][7] / sc["gt"]["s"] - 1) < 0.02
+    # every agent has heard the announcement of agent 0
+    ok &= list(res["sim3"].keys()) == [0] and res["sim3"][0][0] == 1 and abs(res["sim3"][0][1][7] / sc["gt"]["s"] - 1) < 0.02
+    q.put((rank, bool(ok), dbg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_agent_merge_round_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
