@@ -36,3 +36,21 @@ def test_bench_contract_and_lane_equivalence():
     d1 = _run("--cpu-seconds", "0", "--lanes", "1", "--no-pcie")
     assert d1["config"]["pipeline_lanes"] == 1
     assert d1["sanity_matches_le_TH_HIGH_last_step"] == d2["sanity_matches_le_TH_HIGH_last_step"] > 1000
+
+
+def test_bench_two_ranks_control_flow():
+    """The N > 1 path of bench.py (rendezvous, barriers, max-over-ranks timing, rank-0-only reporting) with two ranks that
+    share the one GPU of the test box over gloo (DVM_BENCH_SHARE_GPU / DVM_BENCH_BACKEND are test hooks; the driver launches
+    the same file with one rank per GPU over RCCL)."""
+    env = dict(os.environ, DVM_BENCH_SHARE_GPU="1", DVM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--stream-frames", "32", "--no-ba",
+           "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "agents2"
+    assert abs(d["value"] - 2 * 3 * 32 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]      # whole-job frames over the max-over-ranks time
+    assert "pcie_inclusive" not in d                     # N = 1 only
