@@ -37,8 +37,8 @@ def pack_candidate(kf, pts, agent):
     kpmp = np.zeros((n, 16), np.uint8)
     for j in np.flatnonzero(has):
         kpmp[j] = _id_to_uuid(kf["mp"][j])
-    q = _quat_pose(kf["Rcw"])
-    rec = dict(uuid=_id_to_uuid(kf["uuid"]), mn_id=kf["mn_id"], tcw=kf["tcw"], qcw=q, fx=kf["K"][0], fy=kf["K"][1], cx=kf["K"][2], cy=kf["K"][3],
+    T = np.asarray(kf["Tcw"], np.float32).reshape(7)   # Sophus::SE3f as stored: the wire record carries exactly these 7 floats
+    rec = dict(uuid=_id_to_uuid(kf["uuid"]), mn_id=kf["mn_id"], tcw=T[4:], qcw=T[:4], fx=kf["K"][0], fy=kf["K"][1], cx=kf["K"][2], cy=kf["K"][3],
                min_x=kf["bounds"][0], max_x=kf["bounds"][1], min_y=kf["bounds"][2], max_y=kf["bounds"][3], scale_factor=1.2,
                log_scale_factor=kf["log_scale_factor"], n_levels=len(kf["scale_factors"]), creator_agent=agent, origin_map_id=kf["map_id"],
                kps=kf["kps"], desc=kf["desc"], kp_mappoint=kpmp, fv=kf["fv"], bow_ids=kf["bow"][0], bow_vals=kf["bow"][1])
@@ -54,7 +54,6 @@ def pack_candidate(kf, pts, agent):
 def unpack_candidate(block, template):
     """DVMW block -> (keyframe dict, per-keypoint map point data) in the form merge.py works on; `template` supplies the scale
     tables (every agent runs the same extractor configuration)."""
-    from scipy.spatial.transform import Rotation
     h, kfs, mps = wire.parse(block)
     k = kfs[0]
     rec = k["rec"]
@@ -63,24 +62,21 @@ def unpack_candidate(block, template):
     pts = dict(pos=np.zeros((n, 3), np.float32), normal=np.zeros((n, 3), np.float32), min_dist=np.ones(n, np.float32),
                max_dist=np.ones(n, np.float32), desc=np.zeros((n, 32), np.uint8))
     for m in mps:
+        if len(m["obs"]) < 1:
+            raise ValueError("DVMW candidate block: map point without an observation")
         j = int(m["obs"][0]["index"])
+        if not 0 <= j < n:
+            raise ValueError(f"DVMW candidate block: observation index {j} outside the keyframe's {n} keypoints")
         mp[j] = _uuid_to_id(m["rec"]["uuid"]); bad[j] = int(m["rec"]["flags"]) & 1
         pts["pos"][j], pts["normal"][j] = m["rec"]["pos"], m["rec"]["normal"]
         pts["min_dist"][j], pts["max_dist"][j], pts["desc"][j] = m["rec"]["min_distance"], m["rec"]["max_distance"], m["rec"]["descriptor"]
-    R = Rotation.from_quat(rec["qcw"].astype(np.float64)).as_matrix().astype(np.float32)
     kf = dict(kps=np.array(k["kps"]), desc=np.array(k["desc"]), mp=mp, bad=bad, fv={a: np.array(b) for a, b in k["fv"].items()},
-              Rcw=R.reshape(-1), tcw=np.array(rec["tcw"], np.float32), Ow=(-(R.T @ rec["tcw"])).astype(np.float32),
+              Tcw=np.concatenate([np.asarray(rec["qcw"], np.float32), np.asarray(rec["tcw"], np.float32)]),
               K=np.array([rec["fx"], rec["fy"], rec["cx"], rec["cy"]], np.float32),
               bounds=np.array([rec["min_x"], rec["max_x"], rec["min_y"], rec["max_y"]], np.float32), scale_factors=template["scale_factors"],
               level_sigma2=template["level_sigma2"], inv_level_sigma2=template["inv_level_sigma2"], log_scale_factor=float(rec["log_scale_factor"]),
               uuid=_uuid_to_id(rec["uuid"]), map_id=int(rec["origin_map_id"]), mn_id=int(rec["mn_id"]))
     return kf, pts, int(h["sender_agent"])
-
-
-def _quat_pose(Rcw):
-    from scipy.spatial.transform import Rotation
-    q = Rotation.from_matrix(np.asarray(Rcw, np.float64).reshape(3, 3)).as_quat()
-    return (-q if q[3] < 0 else q).astype(np.float32)
 
 
 def _gather_arrays(arrs, device):

@@ -472,26 +472,27 @@ def host_lib():
         _HOST = C.CDLL(HOST_LIB_PATH)
         vp = C.c_void_p
         _HOST.dvmh_search_by_projection_frames.restype = C.c_int32
-        _HOST.dvmh_search_by_projection_frames.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32,
+        _HOST.dvmh_search_by_projection_frames.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32,
                                                            C.c_int32, vp, vp, vp, vp, C.c_float, C.c_int32, vp]
     return _HOST
 
 
-def search_by_projection_frames(kps_c, desc_c, mp_c, Rcw, tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
+def search_by_projection_frames(kps_c, desc_c, mp_c, Tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
                                 check_ori=True, device=0):
     """dvm_host::ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono=true) -- reference
-    ORBmatcher.cc:1553-1748.  Returns (nmatches, updated mvpMapPoints of the current frame, #host re-queries)."""
+    ORBmatcher.cc:1553-1748.  Tcw: CurrentFrame.GetPose() as 7 floats (qx, qy, qz, qw, t).  Returns (nmatches, updated mvpMapPoints of the current frame, #host re-queries)."""
     H = host_lib()
     kps_c = np.ascontiguousarray(kps_c, KP_DTYPE); kps_l = np.ascontiguousarray(kps_l, KP_DTYPE)
     desc_c = np.ascontiguousarray(desc_c, np.uint8)
     mp = np.array(mp_c, np.int32, copy=True)
     mp_l = np.ascontiguousarray(mp_l, np.int32)
     outl = None if outlier_l is None else np.ascontiguousarray(outlier_l, np.uint8)
-    f = [np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, K, bounds, scale_factors)]
+    f = [np.ascontiguousarray(a, np.float32) for a in (Tcw, K, bounds, scale_factors)]
+    assert f[0].shape == (7,)
     mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
     req = C.c_int32(0)
     n = H.dvmh_search_by_projection_frames(device, len(kps_c), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f],
-                                           len(f[4]), len(kps_l), _p(kps_l), _p(mp_l), None if outl is None else _p(outl),
+                                           len(f[3]), len(kps_l), _p(kps_l), _p(mp_l), None if outl is None else _p(outl),
                                            _p(mps), float(th), int(check_ori), C.byref(req))
     if n < 0:
         check(n)
@@ -645,15 +646,15 @@ class _FeatureVectorView(C.Structure):
 
 class _FrameView(C.Structure):
     _fields_ = [("N", C.c_int32), ("mvKeysUn", C.c_void_p), ("mDescriptors", C.c_void_p), ("mvpMapPoints", C.c_void_p),
-                ("mvbOutlier", C.c_void_p), ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("mvbOutlier", C.c_void_p), ("Tcw", C.c_float * 7), ("fx", C.c_float), ("fy", C.c_float),
                 ("cx", C.c_float), ("cy", C.c_float), ("mnMinX", C.c_float), ("mnMaxX", C.c_float), ("mnMinY", C.c_float),
                 ("mnMaxY", C.c_float), ("mvScaleFactors", C.c_void_p), ("nLevels", C.c_int32)]
 
 
 class _KeyFrameView(C.Structure):
     _fields_ = [("N", C.c_int32), ("mvKeysUn", C.c_void_p), ("mDescriptors", C.c_void_p), ("mvpMapPoints", C.c_void_p),
-                ("mpBad", C.c_void_p), ("mFeatVec", _FeatureVectorView), ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3),
-                ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("mpBad", C.c_void_p), ("mFeatVec", _FeatureVectorView), ("Tcw", C.c_float * 7), ("Twc", C.c_float * 7),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("mnMinX", C.c_float), ("mnMaxX", C.c_float), ("mnMinY", C.c_float), ("mnMaxY", C.c_float),
                 ("mvScaleFactors", C.c_void_p), ("mvLevelSigma2", C.c_void_p), ("mvInvLevelSigma2", C.c_void_p),
                 ("mfLogScaleFactor", C.c_float), ("nLevels", C.c_int32)]
@@ -664,8 +665,8 @@ class _MapPointsView(C.Structure):
                 ("min_dist", C.c_void_p), ("max_dist", C.c_void_p), ("desc", C.c_void_p)]
 
 
-class _Sim3View(C.Structure):
-    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("s", C.c_float)]
+class _Sim3View(C.Structure):   # dvm_sim3f: Sophus::Sim3f as stored (RxSO3 quaternion x, y, z, w with |q|^2 = scale; translation)
+    _fields_ = [("q", C.c_float * 4), ("t", C.c_float * 3)]
 
 
 def _ptr(a):
@@ -681,8 +682,8 @@ def _fv_view(fv, keep):
     return v
 
 
-def frame_view(kps, desc, bounds, scale_factors, mp=None, K=(0, 0, 0, 0)):
-    """FrameView for the matcher mirrors; returns (struct, keepalive list)."""
+def frame_view(kps, desc, bounds, scale_factors, mp=None, K=(0, 0, 0, 0), Tcw=None):
+    """FrameView for the matcher mirrors; returns (struct, keepalive list).  Tcw: 7-float SE3f (qx, qy, qz, qw, t)."""
     keep = [np.ascontiguousarray(kps, KP_DTYPE), np.ascontiguousarray(desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)]
     v = _FrameView()
     v.N, v.mvKeysUn, v.mDescriptors, v.mvScaleFactors, v.nLevels = len(keep[0]), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), len(keep[2])
@@ -691,12 +692,66 @@ def frame_view(kps, desc, bounds, scale_factors, mp=None, K=(0, 0, 0, 0)):
         v.mvpMapPoints = _ptr(mp)
     v.fx, v.fy, v.cx, v.cy = (float(x) for x in K)
     v.mnMinX, v.mnMaxX, v.mnMinY, v.mnMaxY = (float(x) for x in bounds)
+    if Tcw is not None:
+        v.Tcw = (C.c_float * 7)(*np.asarray(Tcw, np.float32).reshape(7))
     return v, keep
 
 
+def _pose_call(name, T, *outs):
+    a = np.ascontiguousarray(T, np.float32).reshape(7)
+    _hcall(name, None, C.c_void_p(a.ctypes.data), *(C.c_void_p(o.ctypes.data) for o in outs))
+
+
+def se3_inverse(T):
+    """Sophus::SE3f::inverse() in the product's float arithmetic (csrc/pose_f32.h); 7-float poses."""
+    out = np.zeros(7, np.float32)
+    _pose_call("dvmh_se3_inverse", T, out)
+    return out
+
+
+def pose_matrices(Tcw):
+    """Frame::UpdatePoseMatrices (Frame.cc:553-559): (mRcw[3,3], mtcw, mOw) of a 7-float SE3f."""
+    R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); Ow = np.zeros(3, np.float32)
+    _pose_call("dvmh_pose_matrices", Tcw, R, t, Ow)
+    return R.reshape(3, 3), t, Ow
+
+
+def sim3_to_se3(S):
+    """Tcw = SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale()), Ow = Tcw.inverse().translation() (ORBmatcher.cc:403-404)."""
+    T = np.zeros(7, np.float32); Ow = np.zeros(3, np.float32)
+    _pose_call("dvmh_sim3_to_se3", S, T, Ow)
+    return T, Ow
+
+
+def sim3_inverse(S):
+    out = np.zeros(7, np.float32)
+    _pose_call("dvmh_sim3_inverse", S, out)
+    return out
+
+
+def se3_act(T, P):
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3); out = np.zeros_like(P)
+    a = np.ascontiguousarray(T, np.float32).reshape(7)
+    _hcall("dvmh_se3_apply", None, C.c_void_p(a.ctypes.data), C.c_void_p(P.ctypes.data), C.c_int32(len(P)), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def sim3_act(S, P):
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3); out = np.zeros_like(P)
+    a = np.ascontiguousarray(S, np.float32).reshape(7)
+    _hcall("dvmh_sim3_apply", None, C.c_void_p(a.ctypes.data), C.c_void_p(P.ctypes.data), C.c_int32(len(P)), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def logf_shared(x):
+    """The shared logf of MapPoint::PredictScale (csrc/pose_f32.h), host build."""
+    return np.array([_hcall("dvmh_logf", C.c_float, C.c_float(float(v))) for v in np.asarray(x, np.float32).reshape(-1)], np.float32)
+
+
 def keyframe_view(kf):
-    """kf: dict(kps, desc, mp (int32, modified in place by Fuse), bad, fv, Rcw, tcw, Ow, K, bounds, scale_factors,
-    level_sigma2, inv_level_sigma2, log_scale_factor); missing optional keys are NULL.  Returns (struct, keepalive)."""
+    """kf: dict(kps, desc, mp (int32, modified in place by Fuse), bad, fv, Tcw (7-float SE3f; Twc is derived as KeyFrame::SetPose
+    does), K, bounds, scale_factors, level_sigma2, inv_level_sigma2, log_scale_factor); missing optional keys are NULL.
+    Returns (struct, keepalive)."""
     keep = [np.ascontiguousarray(kf["kps"], KP_DTYPE), np.ascontiguousarray(kf["desc"], np.uint8)]
     v = _KeyFrameView()
     v.N, v.mvKeysUn, v.mDescriptors = len(keep[0]), _ptr(keep[0]), _ptr(keep[1])
@@ -707,9 +762,9 @@ def keyframe_view(kf):
     if kf.get("bad") is not None:
         b = np.ascontiguousarray(kf["bad"], np.uint8); keep.append(b); v.mpBad = _ptr(b)
     v.mFeatVec = _fv_view(kf.get("fv"), keep)
-    for name, key, n in (("Rcw", "Rcw", 9), ("tcw", "tcw", 3), ("Ow", "Ow", 3)):
-        if kf.get(key) is not None:
-            setattr(v, name, (C.c_float * n)(*np.asarray(kf[key], np.float32).reshape(-1)))
+    if kf.get("Tcw") is not None:
+        v.Tcw = (C.c_float * 7)(*np.asarray(kf["Tcw"], np.float32).reshape(7))
+        v.Twc = (C.c_float * 7)(*se3_inverse(kf["Tcw"]))
     v.fx, v.fy, v.cx, v.cy = (float(x) for x in kf.get("K", (0, 0, 0, 0)))
     v.mnMinX, v.mnMaxX, v.mnMinY, v.mnMaxY = (float(x) for x in kf["bounds"])
     for name, key in (("mvScaleFactors", "scale_factors"), ("mvLevelSigma2", "level_sigma2"), ("mvInvLevelSigma2", "inv_level_sigma2")):
@@ -733,9 +788,10 @@ def map_points_view(pts):
     return v, keep
 
 
-def _sim3_view(R, t, s):
+def _sim3_view(S):
+    S = np.asarray(S, np.float32).reshape(7)
     v = _Sim3View()
-    v.R = (C.c_float * 9)(*np.asarray(R, np.float32).reshape(-1)); v.t = (C.c_float * 3)(*np.asarray(t, np.float32)); v.s = float(s)
+    v.q = (C.c_float * 4)(*S[:4]); v.t = (C.c_float * 3)(*S[4:])
     return v
 
 
@@ -802,19 +858,20 @@ def fuse(KF, P, in_kf, th, device=0):
     return n, bi[:P[0].n]
 
 
-def fuse_sim3(KF, R, t, s, P, th, device=0):
-    """Fuse(KF, Scw, vpPoints, th, vpReplacePoint) (:1236-1345); KF's mp array is updated in place.  Returns (nFused, replace)."""
-    S = _sim3_view(R, t, s)
+def fuse_sim3(KF, Scw, P, th, device=0):
+    """Fuse(KF, Scw, vpPoints, th, vpReplacePoint) (:1236-1345); Scw: 7-float Sim3f; KF's mp array is updated in place.
+    Returns (nFused, replace)."""
+    S = _sim3_view(Scw)
     rep = np.zeros(max(P[0].n, 1), np.int32)
     n = _hcall("dvmh_fuse_sim3", C.c_int32, C.c_int32(device), C.byref(KF[0]), C.byref(S), C.byref(P[0]), C.c_float(th), C.c_void_p(rep.ctypes.data))
     check(min(n, 0))
     return n, rep[:P[0].n]
 
 
-def search_by_projection_sim3(KF, R, t, s, P, matched, th, ratio_hamming=1.0, device=0, point_kf=None, matched_kf=None):
+def search_by_projection_sim3(KF, Scw, P, matched, th, ratio_hamming=1.0, device=0, point_kf=None, matched_kf=None):
     """SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) (:395-496); with point_kf / matched_kf the overload
-    that also fills vpMatchedKF (:498-603).  Returns (nmatches, vpMatched, #re-queries[, vpMatchedKF])."""
-    S = _sim3_view(R, t, s)
+    that also fills vpMatchedKF (:498-603).  Scw: 7-float Sim3f.  Returns (nmatches, vpMatched, #re-queries[, vpMatchedKF])."""
+    S = _sim3_view(Scw)
     m = np.array(matched, np.int32, copy=True); rq = C.c_int32(0)
     pk = None if point_kf is None else np.ascontiguousarray(point_kf, np.int32)
     mk = None if matched_kf is None else np.array(matched_kf, np.int32, copy=True)
@@ -836,9 +893,9 @@ def search_by_projection_reloc(Cur, KF, P, already, th, orb_dist, check_ori=True
     return n, rq.value
 
 
-def search_by_sim3(KF1, KF2, P1, P2, matches12, idx_in_kf2, s12, R12, t12, th, device=0):
-    """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1347-1551).  Returns (nFound, vpMatches12 updated)."""
-    S = _sim3_view(R12, t12, s12)
+def search_by_sim3(KF1, KF2, P1, P2, matches12, idx_in_kf2, S12, th, device=0):
+    """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1347-1551).  S12: 7-float Sim3f.  Returns (nFound, vpMatches12 updated)."""
+    S = _sim3_view(S12)
     m = np.array(matches12, np.int32, copy=True)
     ix = None if idx_in_kf2 is None else np.ascontiguousarray(idx_in_kf2, np.int32)
     n = _hcall("dvmh_search_by_sim3", C.c_int32, C.c_int32(device), C.byref(KF1[0]), C.byref(KF2[0]), C.byref(P1[0]), C.byref(P2[0]),
@@ -848,13 +905,17 @@ def search_by_sim3(KF1, KF2, P1, P2, matches12, idx_in_kf2, s12, R12, t12, th, d
 
 
 def project_search(grid, cam, pts, th, scale_factors, skip=None, gate_inv_sigma2=None, gate=5.99, valid=None):
-    """dvm_project_search on a FrameGrid slot 0.  cam: dict(Rcw, tcw, Ow, K, bounds, log_scale_factor).  Returns (matches, proj)."""
+    """dvm_project_search on a FrameGrid slot 0.  cam: dict(Tcw (7-float SE3f), Ow, K, bounds, log_scale_factor[, sim3_pair, S2]).
+    Returns (matches, proj)."""
     class _Cam(C.Structure):
-        _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("K", C.c_float * 4), ("b", C.c_float * 4),
-                    ("lsf", C.c_float), ("nl", C.c_int32), ("sim3_pair", C.c_int32), ("sR2", C.c_float * 9), ("t2", C.c_float * 3)]
+        _fields_ = [("Tcw", C.c_float * 7), ("Ow", C.c_float * 3), ("K", C.c_float * 4), ("b", C.c_float * 4),
+                    ("lsf", C.c_float), ("nl", C.c_int32), ("sim3_pair", C.c_int32), ("S2", C.c_float * 7)]
     sf = np.ascontiguousarray(scale_factors, np.float32)
     c = _Cam()
-    c.Rcw = (C.c_float * 9)(*np.asarray(cam["Rcw"], np.float32).reshape(-1)); c.tcw = (C.c_float * 3)(*np.asarray(cam["tcw"], np.float32))
+    c.Tcw = (C.c_float * 7)(*np.asarray(cam["Tcw"], np.float32).reshape(7))
+    c.sim3_pair = int(cam.get("sim3_pair", 0))
+    if cam.get("S2") is not None:
+        c.S2 = (C.c_float * 7)(*np.asarray(cam["S2"], np.float32).reshape(7))
     c.Ow = (C.c_float * 3)(*np.asarray(cam["Ow"], np.float32)); c.K = (C.c_float * 4)(*np.asarray(cam["K"], np.float32))
     c.b = (C.c_float * 4)(*np.asarray(cam["bounds"], np.float32)); c.lsf = float(cam["log_scale_factor"]); c.nl = len(sf)
     P, keep = map_points_view(pts)

@@ -59,10 +59,11 @@ struct TrackPoint {  // == dvm_track_point
   int32_t level, in_view;
 };
 struct ProjectCam {  // == dvm_kf_camera (+ th)
-  float R[9], t[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
+  float q[4], t[3];       // Tcw as Sophus::SE3f stores it: unit quaternion (x, y, z, w) + translation
+  float Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
   int32_t n_levels;
-  int32_t sim3_pair;      // != 0: SearchBySim3 form, p' = sR2 * (R p + t) + t2, distance = |p'|, no viewing-angle test
-  float sR2[9], t2[3];
+  int32_t sim3_pair;      // 1: SearchBySim3 form, p' = S2 * (Tcw * p), distance = |p'|, no viewing-angle test; 2: relocalisation form
+  float q2[4], t2[3];     // S2 as Sophus::Sim3f stores it: RxSO3 quaternion (scale = |q2|^2) + translation
   float th;
 };
 struct Projection {  // == dvm_projection

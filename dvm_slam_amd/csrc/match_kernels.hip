@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "match_kernels.h"
+#include "pose_f32.h"
 
 namespace dvm {
 
@@ -286,15 +287,16 @@ __global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, 
   int out_level = -1;
   bool ok = valid == nullptr || valid[i] != 0;
   const float p0 = P[3 * i], p1 = P[3 * i + 1], p2 = P[3 * i + 2];
-  float X = (C.R[0] * p0 + C.R[1] * p1 + C.R[2] * p2) + C.t[0];
-  float Y = (C.R[3] * p0 + C.R[4] * p1 + C.R[5] * p2) + C.t[1];
-  float Z = (C.R[6] * p0 + C.R[7] * p1 + C.R[8] * p2) + C.t[2];
+  // p3Dc = Tcw * p3Dw: Sophus' quaternion form (so3.hpp:356-367), never a rotation matrix
+  const float pw[3] = {p0, p1, p2};
+  float pc[3];
+  dvm_pose::se3_apply(C.q, C.t, pw, pc);
+  float X = pc[0], Y = pc[1], Z = pc[2];
   float u, v;
   if (C.sim3_pair == 1) {   // SearchBySim3 (:1395-1411): p3Dc2 = S21 * (T1w * p3Dw); u = fx * (X * invz) + cx with invz = 1.0 / Z
-    const float X2 = (C.sR2[0] * X + C.sR2[1] * Y + C.sR2[2] * Z) + C.t2[0];
-    const float Y2 = (C.sR2[3] * X + C.sR2[4] * Y + C.sR2[5] * Z) + C.t2[1];
-    const float Z2 = (C.sR2[6] * X + C.sR2[7] * Y + C.sR2[8] * Z) + C.t2[2];
-    X = X2; Y = Y2; Z = Z2;
+    float p2c[3];
+    dvm_pose::sim3_apply(C.q2, C.t2, pc, p2c);
+    X = p2c[0]; Y = p2c[1]; Z = p2c[2];
     const float invz = (float)(1.0 / (double)Z);
     u = C.fx * (X * invz) + C.cx;
     v = C.fy * (Y * invz) + C.cy;
@@ -313,15 +315,13 @@ __global__ void __launch_bounds__(256) k_project_search(FrameView FB, int slot, 
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
     float q0 = p0 - C.Ow[0], q1 = p1 - C.Ow[1], q2 = p2 - C.Ow[2];
     if (C.sim3_pair == 1) { q0 = X; q1 = Y; q2 = Z; }
-    const float dist = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
+    const float dist = sqrtf(dvm_pose::sum3(q0 * q0, q1 * q1, q2 * q2));   // Vector3f::norm(): a0 + (a1 + a2)
     ok = !(dist < minDistance || dist > maxDistance);
     if (ok) {
-      const float dot = (q0 * normal[3 * i] + q1 * normal[3 * i + 1]) + q2 * normal[3 * i + 2];
+      const float dot = dvm_pose::sum3(q0 * normal[3 * i], q1 * normal[3 * i + 1], q2 * normal[3 * i + 2]);
       ok = C.sim3_pair != 0 || !((double)dot < 0.5 * (double)dist);
       if (ok) {
-        const float ratio = max_dist[i] / dist;
-        int nScale = (int)ceilf(logf(ratio) / C.log_scale_factor);
-        nScale = nScale < 0 ? 0 : (nScale >= C.n_levels ? C.n_levels - 1 : nScale);
+        const int nScale = dvm_pose::predict_scale(max_dist[i], dist, C.log_scale_factor, C.n_levels);
         out_u = u; out_v = v; out_level = nScale; out_r = C.th * scale_factors[nScale];
       }
     }
@@ -468,10 +468,11 @@ __global__ void __launch_bounds__(256) k_is_in_frustum(FrustumFrame F, const flo
   TrackPoint o;
   o.in_view = 0; o.proj_x = -1; o.proj_y = -1; o.proj_xr = 0; o.depth = 0; o.level = -1; o.view_cos = 0;
   const float p0 = P[3 * i], p1 = P[3 * i + 1], p2 = P[3 * i + 2];
-  const float X = (F.Rcw[0] * p0 + F.Rcw[1] * p1 + F.Rcw[2] * p2) + F.tcw[0];
-  const float Y = (F.Rcw[3] * p0 + F.Rcw[4] * p1 + F.Rcw[5] * p2) + F.tcw[1];
-  const float Z = (F.Rcw[6] * p0 + F.Rcw[7] * p1 + F.Rcw[8] * p2) + F.tcw[2];
-  const float Pc_dist = sqrtf(X * X + Y * Y + Z * Z);
+  // Pc = mRcw * P + mtcw (Frame.cc:585): Eigen's 3x3 * 3x1 coefficient is a0 + (a1 + a2)
+  const float X = dvm_pose::sum3(F.Rcw[0] * p0, F.Rcw[1] * p1, F.Rcw[2] * p2) + F.tcw[0];
+  const float Y = dvm_pose::sum3(F.Rcw[3] * p0, F.Rcw[4] * p1, F.Rcw[5] * p2) + F.tcw[1];
+  const float Z = dvm_pose::sum3(F.Rcw[6] * p0, F.Rcw[7] * p1, F.Rcw[8] * p2) + F.tcw[2];
+  const float Pc_dist = sqrtf(dvm_pose::sum3(X * X, Y * Y, Z * Z));
   const float invz = 1.0f / Z;
   bool ok = !(Z < 0.0f);
   const float u = F.fx * X / Z + F.cx, v = F.fy * Y / Z + F.cy;
@@ -480,13 +481,11 @@ __global__ void __launch_bounds__(256) k_is_in_frustum(FrustumFrame F, const flo
     o.proj_x = u; o.proj_y = v;
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
     const float q0 = p0 - F.Ow[0], q1 = p1 - F.Ow[1], q2 = p2 - F.Ow[2];
-    const float dist = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    const float dist = sqrtf(dvm_pose::sum3(q0 * q0, q1 * q1, q2 * q2));
     if (!(dist < minDistance || dist > maxDistance)) {
-      const float viewCos = (q0 * normal[3 * i] + q1 * normal[3 * i + 1] + q2 * normal[3 * i + 2]) / dist;
+      const float viewCos = dvm_pose::sum3(q0 * normal[3 * i], q1 * normal[3 * i + 1], q2 * normal[3 * i + 2]) / dist;
       if (!(viewCos < cos_limit)) {
-        const float ratio = max_dist[i] / dist;
-        int nScale = (int)ceilf(logf(ratio) / F.log_scale_factor);
-        nScale = nScale < 0 ? 0 : (nScale >= F.n_levels ? F.n_levels - 1 : nScale);
+        const int nScale = dvm_pose::predict_scale(max_dist[i], dist, F.log_scale_factor, F.n_levels);
         o.in_view = 1; o.proj_xr = u - F.bf * invz; o.depth = Pc_dist; o.level = nScale; o.view_cos = viewCos;
       }
     }

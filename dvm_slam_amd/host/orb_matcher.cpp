@@ -1,6 +1,8 @@
 // dvm_slam_amd/host/orb_matcher.cpp -- see orb_matcher.h.  Host C++ (g++), links libdvmslam_hip.so.
 #include "orb_matcher.h"
 
+#include "../csrc/pose_f32.h"
+
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -97,9 +99,9 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
     if (mp < 0) continue;
     if (Last.mvbOutlier && Last.mvbOutlier[i]) continue;
     const float* X = MPs[mp].pos;
-    const float xc = (Cur.Rcw[0] * X[0] + Cur.Rcw[1] * X[1] + Cur.Rcw[2] * X[2]) + Cur.tcw[0];
-    const float yc = (Cur.Rcw[3] * X[0] + Cur.Rcw[4] * X[1] + Cur.Rcw[5] * X[2]) + Cur.tcw[1];
-    const float zc = (Cur.Rcw[6] * X[0] + Cur.Rcw[7] * X[1] + Cur.Rcw[8] * X[2]) + Cur.tcw[2];
+    float x3Dc[3];   // Tcw * x3Dw: Sophus' quaternion action (:1577, so3.hpp:356-367)
+    dvm_pose::se3_apply(Cur.Tcw.q, Cur.Tcw.t, X, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1], zc = x3Dc[2];
     const float invzc = (float)(1.0 / zc);
     if (invzc < 0) continue;
     const float u = Cur.fx * xc / zc + Cur.cx, v = Cur.fy * yc / zc + Cur.cy;
@@ -478,29 +480,25 @@ int ORBmatcher::SearchByBoW(const KeyFrameView& KF1, const KeyFrameView& KF2, in
 }
 
 void ORBmatcher::TriangulationGeometry(const KeyFrameView& KF1, const KeyFrameView& KF2, float* R12, float* t12, float* ep, float* F12) {
-  auto mul = [](const float* A, const float* B, float* C) {
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
-  };
-  const float *R1w = KF1.Rcw, *t1w = KF1.tcw, *R2w = KF2.Rcw, *t2w = KF2.tcw;
-  float Cw[3], C2[3];   // Cw = KF1 camera centre; C2 = T2w * Cw; ep = pKF2->mpCamera->project(C2)
-  for (int r = 0; r < 3; r++) Cw[r] = -((R1w[r] * t1w[0] + R1w[3 + r] * t1w[1]) + R1w[6 + r] * t1w[2]);
-  for (int r = 0; r < 3; r++) C2[r] = ((R2w[3 * r] * Cw[0] + R2w[3 * r + 1] * Cw[1]) + R2w[3 * r + 2] * Cw[2]) + t2w[r];
+  // Cw = pKF1->GetCameraCenter(); C2 = T2w * Cw; ep = pKF2->mpCamera->project(C2)   (:842-848)
+  float C2[3];
+  dvm_pose::se3_apply(KF2.Tcw.q, KF2.Tcw.t, KF1.Twc.t, C2);
   ep[0] = KF2.fx * C2[0] / C2[2] + KF2.cx;
   ep[1] = KF2.fy * C2[1] / C2[2] + KF2.cy;
-  float R2wT[9];   // T12 = T1w * Tw2
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) R2wT[3 * r + c] = R2w[3 * c + r];
-  mul(R1w, R2wT, R12);
-  for (int r = 0; r < 3; r++) t12[r] = t1w[r] - ((R12[3 * r] * t2w[0] + R12[3 * r + 1] * t2w[1]) + R12[3 * r + 2] * t2w[2]);
-  // F12 = K1^-T [t12]x R12 K2^-1 (Pinhole::epipolarConstrain), K^-1 in closed form
-  const float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
-  const float K1invT[9] = {1.f / KF1.fx, 0.f, 0.f, 0.f, 1.f / KF1.fy, 0.f, -KF1.cx / KF1.fx, -KF1.cy / KF1.fy, 1.f};
-  const float K2inv[9] = {1.f / KF2.fx, 0.f, -KF2.cx / KF2.fx, 0.f, 1.f / KF2.fy, -KF2.cy / KF2.fy, 0.f, 0.f, 1.f};
-  float A[9], B[9];
-  mul(K1invT, t12x, A);
-  mul(A, R12, B);
-  mul(B, K2inv, F12);
+  // T12 = T1w * Tw2; R12 = T12.rotationMatrix(); t12 = T12.translation()   (:856-859)
+  float q12[4];
+  dvm_pose::se3_compose(KF1.Tcw.q, KF1.Tcw.t, KF2.Twc.q, KF2.Twc.t, q12, t12);
+  dvm_pose::quat_matrix(q12, R12);
+  // F12 = K1.transpose().inverse() * t12x * R12 * K2.inverse()   (Pinhole.cpp:106-110; Eigen cofactor inverse, products left to right)
+  const float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};   // SO3f::hat
+  const float K1T[9] = {KF1.fx, 0.f, 0.f, 0.f, KF1.fy, 0.f, KF1.cx, KF1.cy, 1.f};
+  const float K2[9] = {KF2.fx, 0.f, KF2.cx, 0.f, KF2.fy, KF2.cy, 0.f, 0.f, 1.f};
+  float K1Tinv[9], K2inv[9], A[9], B[9];
+  dvm_pose::mat3_inverse(K1T, K1Tinv);
+  dvm_pose::mat3_inverse(K2, K2inv);
+  dvm_pose::mat3_mul(K1Tinv, t12x, A);
+  dvm_pose::mat3_mul(A, R12, B);
+  dvm_pose::mat3_mul(B, K2inv, F12);
 }
 
 int ORBmatcher::SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameView& KF2, int32_t* vMatchedPairs, bool bOnlyStereo,
@@ -561,14 +559,14 @@ int ORBmatcher::ensure_grid(const KeyFrameView& KF) {
   return ensure_grid(F);
 }
 
-int ORBmatcher::project_search(const KeyFrameView& KF, const float* Rcw, const float* tcw, const float* Ow, const MapPointsView& P,
+int ORBmatcher::project_search(const KeyFrameView& KF, const dvm_se3f& Tcw, const float* Ow, const MapPointsView& P,
                                const uint8_t* valid, const uint8_t* skip, float th, bool gate, std::vector<dvm_match>& res,
                                std::vector<dvm_projection>& proj) {
   int rc = ensure_grid(KF);
   if (rc != DVM_OK) return rc;
   dvm_kf_camera cam;
   std::memset(&cam, 0, sizeof(cam));
-  std::memcpy(cam.Rcw, Rcw, 36); std::memcpy(cam.tcw, tcw, 12); std::memcpy(cam.Ow, Ow, 12);
+  cam.Tcw = Tcw; std::memcpy(cam.Ow, Ow, 12);
   cam.fx = KF.fx; cam.fy = KF.fy; cam.cx = KF.cx; cam.cy = KF.cy;
   cam.min_x = KF.mnMinX; cam.max_x = KF.mnMaxX; cam.min_y = KF.mnMinY; cam.max_y = KF.mnMaxY;
   cam.log_scale_factor = KF.mfLogScaleFactor; cam.n_levels = KF.nLevels;
@@ -586,7 +584,7 @@ int ORBmatcher::Fuse(const KeyFrameView& KF, const MapPointsView& P, const uint8
     if ((P.id && P.id[i] < 0) || (P.bad && P.bad[i]) || (inKF && inKF[i])) valid[i] = 0;   // !pMP, isBad(), IsInKeyFrame(pKF)
   std::vector<dvm_match> res;
   std::vector<dvm_projection> proj;
-  int rc = project_search(KF, KF.Rcw, KF.tcw, KF.Ow, P, valid.data(), nullptr, th, true, res, proj);
+  int rc = project_search(KF, KF.Tcw, KF.Twc.t, P, valid.data(), nullptr, th, true, res, proj);
   if (rc != DVM_OK) return rc;
   int nFused = 0;
   for (int i = 0; i < P.n; i++) {
@@ -596,17 +594,25 @@ int ORBmatcher::Fuse(const KeyFrameView& KF, const MapPointsView& P, const uint8
   return nFused;
 }
 
-namespace {
-void DecomposeSim3(const Sim3View& S, float* tcw, float* Ow) {   // Tcw = SE3f(R, t / s); Ow = Tcw.inverse().translation()
-  for (int r = 0; r < 3; r++) tcw[r] = S.t[r] / S.s;
-  for (int r = 0; r < 3; r++) Ow[r] = -((S.R[r] * tcw[0] + S.R[3 + r] * tcw[1]) + S.R[6 + r] * tcw[2]);
+void KeyFrameView::SetPose(const dvm_se3f& T) { Tcw = T; Twc = InverseSE3(T); }
+dvm_se3f InverseSE3(const dvm_se3f& T) {
+  dvm_se3f r;
+  dvm_pose::se3_inverse(T.q, T.t, r.q, r.t);
+  return r;
 }
-}  // namespace
+void PoseMatrices(const dvm_se3f& Tcw, float* Rcw, float* tcw, float* Ow) {
+  const dvm_se3f Twc = InverseSE3(Tcw);
+  dvm_pose::quat_matrix(Tcw.q, Rcw);
+  std::memcpy(tcw, Tcw.t, 12);
+  std::memcpy(Ow, Twc.t, 12);
+}
+void Sim3ToSE3(const dvm_sim3f& Scw, dvm_se3f& Tcw, float* Ow) { dvm_pose::sim3_decompose(Scw.q, Scw.t, Tcw.q, Tcw.t, Ow); }
 
 int ORBmatcher::Fuse(KeyFrameView& KF, const Sim3View& Scw, const MapPointsView& P, float th, int32_t* vpReplacePoint) {
   if (P.n == 0) return 0;
-  float tcw[3], Ow[3];
-  DecomposeSim3(Scw, tcw, Ow);
+  dvm_se3f Tcw;
+  float Ow[3];
+  Sim3ToSE3(Scw, Tcw, Ow);
   std::vector<int32_t> already(KF.mvpMapPoints, KF.mvpMapPoints + KF.N);   // spAlreadyFound = pKF->GetMapPoints()
   std::sort(already.begin(), already.end());
   std::vector<uint8_t> valid(P.n, 1);
@@ -616,7 +622,7 @@ int ORBmatcher::Fuse(KeyFrameView& KF, const Sim3View& Scw, const MapPointsView&
   }
   std::vector<dvm_match> res;
   std::vector<dvm_projection> proj;
-  int rc = project_search(KF, Scw.R, tcw, Ow, P, valid.data(), nullptr, th, false, res, proj);
+  int rc = project_search(KF, Tcw, Ow, P, valid.data(), nullptr, th, false, res, proj);
   if (rc != DVM_OK) return rc;
   int nFused = 0;
   std::vector<uint8_t> fresh(KF.N, 0);
@@ -644,8 +650,9 @@ int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, 
                                    int32_t* vpMatched, int32_t* vpMatchedKF, int th, float ratioHamming) {
   if (P.n == 0) return 0;
   last_requeried = 0;
-  float tcw[3], Ow[3];
-  DecomposeSim3(Scw, tcw, Ow);
+  dvm_se3f Tcw;
+  float Ow[3];
+  Sim3ToSE3(Scw, Tcw, Ow);
   std::vector<int32_t> already(vpMatched, vpMatched + KF.N);   // spAlreadyFound (fixed at entry)
   std::sort(already.begin(), already.end());
   std::vector<uint8_t> valid(P.n, 1), skip(KF.N, 0);
@@ -654,7 +661,7 @@ int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, 
   for (int j = 0; j < KF.N; j++) skip[j] = vpMatched[j] >= 0;
   std::vector<dvm_match> res;
   std::vector<dvm_projection> proj;
-  int rc = project_search(KF, Scw.R, tcw, Ow, P, valid.data(), skip.data(), (float)th, false, res, proj);
+  int rc = project_search(KF, Tcw, Ow, P, valid.data(), skip.data(), (float)th, false, res, proj);
   if (rc != DVM_OK) return rc;
   int nmatches = 0;
   HostGrid hg;
@@ -686,12 +693,8 @@ int ORBmatcher::SearchByProjection(const KeyFrameView& KF, const Sim3View& Scw, 
 int ORBmatcher::SearchBySim3(const KeyFrameView& KF1, const KeyFrameView& KF2, const MapPointsView& MPs1, const MapPointsView& MPs2,
                              int32_t* vpMatches12, const int32_t* vnIdxInKF2, const Sim3View& S12, float th) {
   const int N1 = KF1.N, N2 = KF2.N;
-  float sR12[9], sR21[9], t21[3];   // S21 = S12.inverse(); a Sim3 acts as (s R) p + t
-  const float s21 = 1.0f / S12.s;
-  for (int k = 0; k < 9; k++) sR12[k] = S12.s * S12.R[k];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) sR21[3 * r + c] = s21 * S12.R[3 * c + r];
-  for (int r = 0; r < 3; r++) t21[r] = -((sR21[3 * r] * S12.t[0] + sR21[3 * r + 1] * S12.t[1]) + sR21[3 * r + 2] * S12.t[2]);
+  dvm_sim3f S21;   // S21 = S12.inverse()   (:1359, sim3.hpp:129-132)
+  dvm_pose::sim3_inverse(S12.q, S12.t, S21.q, S21.t);
   std::vector<uint8_t> valid1(N1, 0), valid2(N2, 0), am2(N2, 0);
   for (int i = 0; i < N1; i++) {
     if (vpMatches12[i] >= 0) {
@@ -702,25 +705,25 @@ int ORBmatcher::SearchBySim3(const KeyFrameView& KF1, const KeyFrameView& KF2, c
   for (int i = 0; i < N2; i++)
     if (KF2.mvpMapPoints[i] >= 0 && !am2[i] && !(KF2.mpBad && KF2.mpBad[i])) valid2[i] = 1;
   auto direction = [&](const KeyFrameView& from, const KeyFrameView& into, const MapPointsView& P, const std::vector<uint8_t>& valid,
-                       const float* sR, const float* t, std::vector<dvm_match>& res) -> int {
+                       const dvm_sim3f& S2, std::vector<dvm_match>& res) -> int {
     int rc = ensure_grid(into);
     if (rc != DVM_OK) return rc;
     dvm_kf_camera cam;
     std::memset(&cam, 0, sizeof(cam));
-    std::memcpy(cam.Rcw, from.Rcw, 36); std::memcpy(cam.tcw, from.tcw, 12);
+    cam.Tcw = from.Tcw;
     cam.fx = KF1.fx; cam.fy = KF1.fy; cam.cx = KF1.cx; cam.cy = KF1.cy;   // the reference uses pKF1's calibration in both directions
     cam.min_x = into.mnMinX; cam.max_x = into.mnMaxX; cam.min_y = into.mnMinY; cam.max_y = into.mnMaxY;
     cam.log_scale_factor = into.mfLogScaleFactor; cam.n_levels = into.nLevels;
     cam.sim3_pair = 1;
-    std::memcpy(cam.sR2, sR, 36); std::memcpy(cam.t2, t, 12);
+    cam.S2 = S2;
     res.resize(P.n);
     return dvm_project_search(grid_, 0, nullptr, &cam, P.pos, P.normal ? P.normal : P.pos, P.min_dist, P.max_dist, P.desc, valid.data(), P.n,
                               th, into.mvScaleFactors, nullptr, 0.0, res.data(), nullptr, 0, nullptr);
   };
   std::vector<dvm_match> r1, r2;
-  int rc = direction(KF1, KF2, MPs1, valid1, sR21, t21, r1);
+  int rc = direction(KF1, KF2, MPs1, valid1, S21, r1);
   if (rc != DVM_OK) return rc;
-  rc = direction(KF2, KF1, MPs2, valid2, sR12, S12.t, r2);
+  rc = direction(KF2, KF1, MPs2, valid2, S12, r2);
   if (rc != DVM_OK) return rc;
   int nFound = 0;
   for (int i1 = 0; i1 < N1; i1++) {
@@ -735,8 +738,8 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const KeyFrameView& KF, const
                                    int nAlreadyFound, float th, int ORBdist) {
   if (KF.N == 0) return 0;
   last_requeried = 0;
-  float Ow[3];   // Tcw.inverse().translation()
-  for (int r = 0; r < 3; r++) Ow[r] = -((Cur.Rcw[r] * Cur.tcw[0] + Cur.Rcw[3 + r] * Cur.tcw[1]) + Cur.Rcw[6 + r] * Cur.tcw[2]);
+  const dvm_se3f Twc = InverseSE3(Cur.Tcw);   // Ow = Tcw.inverse().translation()   (:1755)
+  const float* Ow = Twc.t;
   std::vector<uint8_t> valid(KF.N, 0), skip;
   for (int i = 0; i < KF.N; i++) {
     const int id = KF.mvpMapPoints[i];
@@ -750,7 +753,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const KeyFrameView& KF, const
   for (int j = 0; j < Cur.N; j++) skip[j] = Cur.mvpMapPoints[j] >= 0;
   dvm_kf_camera cam;
   std::memset(&cam, 0, sizeof(cam));
-  std::memcpy(cam.Rcw, Cur.Rcw, 36); std::memcpy(cam.tcw, Cur.tcw, 12); std::memcpy(cam.Ow, Ow, 12);
+  cam.Tcw = Cur.Tcw; std::memcpy(cam.Ow, Ow, 12);
   cam.fx = Cur.fx; cam.fy = Cur.fy; cam.cx = Cur.cx; cam.cy = Cur.cy;
   cam.min_x = Cur.mnMinX; cam.max_x = Cur.mnMaxX; cam.min_y = Cur.mnMinY; cam.max_y = Cur.mnMaxY;
   cam.log_scale_factor = KF.mfLogScaleFactor; cam.n_levels = Cur.nLevels;
@@ -800,13 +803,13 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const KeyFrameView& KF, const
 
 // ---- C entry point for the Python harness (tests only; a C++ caller uses the class directly)
 extern "C" int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c,
-                                                int32_t* mp_c, const float* Rcw, const float* tcw, const float* K,
+                                                int32_t* mp_c, const dvm_se3f* Tcw, const float* K,
                                                 const float* bounds, const float* scale_factors, int nlevels, int Nl,
                                                 const dvm_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
                                                 const dvm_host::MapPointPOD* mps, float th, int check_ori, int* requeried) {
   dvm_host::FrameView C, L;
   C.N = Nc; C.mvKeysUn = kps_c; C.mDescriptors = desc_c; C.mvpMapPoints = mp_c;
-  std::memcpy(C.Rcw, Rcw, 36); std::memcpy(C.tcw, tcw, 12);
+  C.Tcw = *Tcw;
   C.fx = K[0]; C.fy = K[1]; C.cx = K[2]; C.cy = K[3];
   C.mnMinX = bounds[0]; C.mnMaxX = bounds[1]; C.mnMinY = bounds[2]; C.mnMaxY = bounds[3];
   C.mvScaleFactors = scale_factors; C.nLevels = nlevels;
@@ -858,6 +861,17 @@ int dvmh_search_by_bow_kf_kf(int device, const KeyFrameView* KF1, const KeyFrame
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
+void dvmh_pose_matrices(const dvm_se3f* Tcw, float* Rcw, float* tcw, float* Ow) { dvm_host::PoseMatrices(*Tcw, Rcw, tcw, Ow); }
+void dvmh_se3_inverse(const dvm_se3f* T, dvm_se3f* out) { *out = dvm_host::InverseSE3(*T); }
+void dvmh_sim3_to_se3(const dvm_sim3f* S, dvm_se3f* Tcw, float* Ow) { dvm_host::Sim3ToSE3(*S, *Tcw, Ow); }
+void dvmh_se3_apply(const dvm_se3f* T, const float* p, int n, float* out) {
+  for (int i = 0; i < n; i++) dvm_pose::se3_apply(T->q, T->t, p + 3 * i, out + 3 * i);
+}
+void dvmh_sim3_apply(const dvm_sim3f* S, const float* p, int n, float* out) {
+  for (int i = 0; i < n; i++) dvm_pose::sim3_apply(S->q, S->t, p + 3 * i, out + 3 * i);
+}
+void dvmh_sim3_inverse(const dvm_sim3f* S, dvm_sim3f* out) { dvm_pose::sim3_inverse(S->q, S->t, out->q, out->t); }
+float dvmh_logf(float x) { return dvm_pose::logf_shared(x); }
 void dvmh_triangulation_geometry(const KeyFrameView* KF1, const KeyFrameView* KF2, float* R12, float* t12, float* ep, float* F12) {
   dvm_host::ORBmatcher::TriangulationGeometry(*KF1, *KF2, R12, t12, ep, F12);
 }

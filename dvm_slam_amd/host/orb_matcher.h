@@ -37,7 +37,7 @@ struct FrameView {
   const uint8_t* mDescriptors = nullptr;    // N x 32
   int32_t* mvpMapPoints = nullptr;          // index into the map-point array, -1 = NULL
   const uint8_t* mvbOutlier = nullptr;      // may be null (no outliers)
-  float Rcw[9], tcw[3];                     // GetPose()
+  dvm_se3f Tcw;                             // GetPose(): Sophus::SE3f as stored (unit quaternion x,y,z,w + translation)
   float fx, fy, cx, cy;                     // pinhole mpCamera
   float mnMinX, mnMaxX, mnMinY, mnMaxY;
   const float* mvScaleFactors = nullptr;
@@ -61,7 +61,8 @@ struct KeyFrameView {
   int32_t* mvpMapPoints = nullptr;       // GetMapPointMatches(): map point id per keypoint, -1 = NULL
   const uint8_t* mpBad = nullptr;        // isBad() of that map point (may be null: none is bad)
   FeatureVectorView mFeatVec;
-  float Rcw[9], tcw[3], Ow[3];           // GetPose() as rotation matrix + translation, GetCameraCenter()
+  dvm_se3f Tcw, Twc;                     // GetPose(), GetPoseInverse(); GetCameraCenter() = Twc.t (KeyFrame.cc:224-257)
+  void SetPose(const dvm_se3f& T);       // KeyFrame::SetPose: mTcw = T; mTwc = mTcw.inverse()
   float fx, fy, cx, cy;
   float mnMinX, mnMaxX, mnMinY, mnMaxY;
   const float* mvScaleFactors = nullptr;
@@ -84,7 +85,14 @@ struct MapPointsView {
   const uint8_t* desc = nullptr;         // 32n
 };
 
-struct Sim3View { float R[9], t[3], s; };   // Sophus::Sim3f: rotationMatrix(), translation(), scale()
+typedef dvm_sim3f Sim3View;   // Sophus::Sim3f as stored: RxSO3 quaternion (x,y,z,w; scale = |q|^2) + translation
+
+// Pose helpers in the reference's own float arithmetic (csrc/pose_f32.h restates Sophus / Eigen):
+// Frame::UpdatePoseMatrices (Frame.cc:553-559): mRcw = mTcw.rotationMatrix(), mtcw, mOw = mTcw.inverse().translation()
+void PoseMatrices(const dvm_se3f& Tcw, float* Rcw, float* tcw, float* Ow);
+// Tcw = SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale()), Ow = Tcw.inverse().translation() (ORBmatcher.cc:403-404)
+void Sim3ToSE3(const dvm_sim3f& Scw, dvm_se3f& Tcw, float* Ow);
+dvm_se3f InverseSE3(const dvm_se3f& T);
 
 class ORBmatcher {
  public:
@@ -128,7 +136,8 @@ class ORBmatcher {
   // vMatchedPairs: up to KF1.N (idx1, idx2) pairs ordered by idx1.  Whole search on the device (dvm_match_triangulation).
   int SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameView& KF2, int32_t* vMatchedPairs, bool bOnlyStereo = false,
                              bool bCoarse = false);
-  // the geometry it derives from the two poses (:841-862, Pinhole.cpp:106-110): R12, t12, epipole in image 2, F12
+  // the geometry it derives from the two poses (:841-862, Pinhole.cpp:106-110) through Sophus' SE3 products and Eigen's
+  // 3x3 inverse / products: R12, t12, epipole in image 2, F12
   static void TriangulationGeometry(const KeyFrameView& KF1, const KeyFrameView& KF2, float* R12, float* t12, float* ep, float* F12);
 
   // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th, const bool bRight = false)   (:1060-1234),
@@ -170,7 +179,7 @@ class ORBmatcher {
   int grid_cap_ = 0;
   int ensure_grid(const FrameView& F);
   int ensure_grid(const KeyFrameView& KF);
-  int project_search(const KeyFrameView& KF, const float* Rcw, const float* tcw, const float* Ow, const MapPointsView& P,
+  int project_search(const KeyFrameView& KF, const dvm_se3f& Tcw, const float* Ow, const MapPointsView& P,
                      const uint8_t* valid, const uint8_t* skip, float th, bool gate, std::vector<dvm_match>& res,
                      std::vector<dvm_projection>& proj);
 };

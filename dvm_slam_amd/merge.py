@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import synth
+
 
 class GpuOps:
     """The accelerated implementation of every step (dvm_slam_amd.capi: host mirrors + C ABI)."""
@@ -40,9 +42,9 @@ class GpuOps:
     def optimize_sim3(self, S12, P1c, P2c, o1, o2, w1, w2, K1, K2, th2):
         return self.capi.optimize_sim3(S12, False, P1c, P2c, o1, o2, w1, w2, K1, K2, th2, self.device)
 
-    def search_by_sim3(self, a, pa, b, pb, m12, idx2, s, R, t, th):
+    def search_by_sim3(self, a, pa, b, pb, m12, idx2, S12, th):
         c = self.capi
-        return c.search_by_sim3(c.keyframe_view(dict(a)), c.keyframe_view(dict(b)), c.map_points_view(pa), c.map_points_view(pb), m12, idx2, s, R, t, th,
+        return c.search_by_sim3(c.keyframe_view(dict(a)), c.keyframe_view(dict(b)), c.map_points_view(pa), c.map_points_view(pb), m12, idx2, S12, th,
                                 self.device)
 
 
@@ -66,7 +68,7 @@ def _quat_from_R(R):
 
 
 def merge_with_peer(ops, kf, kf_points, peer_kfs, peer_points, peer_db, levelsup, triples, nnratio=0.75, th_sim3=7.5):
-    """kf: the current keyframe of this agent (keyframe dict: kps, desc, mp, bad, Rcw, tcw, K, bounds, scale tables, uuid,
+    """kf: the current keyframe of this agent (keyframe dict: kps, desc, mp, bad, Tcw (7-float SE3f), K, bounds, scale tables, uuid,
     map_id ...); kf_points / peer_points[j]: map point data PER KEYPOINT (pos in the owner's world frame, min / max
     distance, descriptor).  Returns a dict with every intermediate result (None fields when the merge is rejected)."""
     out = dict(candidate=-1)
@@ -91,10 +93,11 @@ def solve_against_candidate(ops, kf, kf_points, pk, pp, triples, nnratio=0.75, t
         return out
     idx2_of_id = {int(v): j for j, v in enumerate(pk["mp"]) if v >= 0}
     i2 = np.array([idx2_of_id[int(v)] for v in m12[sel]])
-    R1, t1 = np.asarray(kf["Rcw"], np.float32).reshape(3, 3), np.asarray(kf["tcw"], np.float32)
-    R2, t2 = np.asarray(pk["Rcw"], np.float32).reshape(3, 3), np.asarray(pk["tcw"], np.float32)
-    P1c = (kf_points["pos"][sel] @ R1.T + t1).astype(np.float32)
-    P2c = (pp["pos"][i2] @ R2.T + t2).astype(np.float32)
+    # Sim3Solver.cc:66-90: mvX3Dc = Rcw * X3Dw + tcw with the keyframes' rotation matrices
+    R1, t1 = synth.Rt_from_se3(kf["Tcw"])
+    R2, t2 = synth.Rt_from_se3(pk["Tcw"])
+    P1c = (kf_points["pos"][sel].astype(np.float64) @ R1.T + t1).astype(np.float32)
+    P2c = (pp["pos"][i2].astype(np.float64) @ R2.T + t2).astype(np.float32)
     e1 = np.floor(9.210 * kf["level_sigma2"][kf["kps"]["octave"][sel]]).astype(np.float32)     # Sim3Solver.cc:106-107
     e2 = np.floor(9.210 * pk["level_sigma2"][pk["kps"]["octave"][i2]]).astype(np.float32)
     T, nin, mask = ops.sim3_hypotheses(P1c, P2c, e1, e2, kf["K"], pk["K"], triples % len(sel))
@@ -118,6 +121,7 @@ def solve_against_candidate(ops, kf, kf_points, pk, pp, triples, nnratio=0.75, t
     m_in = np.full(len(kf["kps"]), -1, np.int32); idx2 = np.full(len(kf["kps"]), -1, np.int32)
     keep = sel[inl.astype(bool)]
     m_in[keep] = m12[keep]; idx2[keep] = i2[inl.astype(bool)]
-    nf, m_all = ops.search_by_sim3(kf, kf_points, pk, pp, m_in, idx2, np.float32(S[7]), Rr, S[4:7].astype(np.float32), th_sim3)
+    S12f = synth.sim3_from_sRt(S[7], Rr, S[4:7])     # the Sophus::Sim3f handed to SearchBySim3 (LoopClosing.cc: gScm -> Sim3f)
+    nf, m_all = ops.search_by_sim3(kf, kf_points, pk, pp, m_in, idx2, S12f, th_sim3)
     out.update(n_sim3_new=nf, matches=m_all)
     return out

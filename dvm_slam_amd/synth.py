@@ -140,6 +140,28 @@ def _quat_from_rot(R: np.ndarray) -> np.ndarray:
     return q / np.linalg.norm(q)
 
 
+def se3_from_Rt(R, t) -> np.ndarray:
+    """A pose as the reference holds it (Sophus::SE3f): 7 float32 = unit quaternion coeffs (x, y, z, w), translation."""
+    q = _quat_from_rot(np.asarray(R, np.float64).reshape(3, 3))
+    return np.concatenate([q, np.asarray(t, np.float64).reshape(3)]).astype(np.float32)
+
+
+def Rt_from_se3(T):
+    """(R[3,3], t[3]) float64 of a 7-float pose (plain numpy; NOT the reference's float arithmetic -- test geometry only)."""
+    T = np.asarray(T, np.float64).reshape(7)
+    x, y, z, w = T[:4] / np.linalg.norm(T[:4])
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return R, T[4:].copy()
+
+
+def sim3_from_sRt(s, R, t) -> np.ndarray:
+    """Sophus::Sim3f as stored: RxSO3 quaternion (x, y, z, w) with |q|^2 = scale, translation; 7 float32."""
+    q = _quat_from_rot(np.asarray(R, np.float64).reshape(3, 3)) * np.sqrt(float(s))
+    return np.concatenate([q, np.asarray(t, np.float64).reshape(3)]).astype(np.float32)
+
+
 def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = SEED_BA, noise_px: float = 1.0,
                outlier_frac: float = 0.05, radius: float = 50.0):
     """Synthetic global-BA problem.  Returns a dict of numpy arrays:

@@ -16,14 +16,16 @@ from __future__ import annotations
 import numpy as np
 from scipy.spatial.transform import Rotation
 
+from . import synth
+
 
 class GpuOps:
     def __init__(self, device=0):
         from . import capi
         self.capi, self.device = capi, device
 
-    def search_by_projection(self, cur, last, mps, Rcw, tcw, K, bounds, scale, th):
-        n, mp, _ = self.capi.search_by_projection_frames(cur["kps"], cur["desc"], cur["mp"], Rcw, tcw, K, bounds, scale, last["kps"], last["mp"],
+    def search_by_projection(self, cur, last, mps, Tcw, K, bounds, scale, th):
+        n, mp, _ = self.capi.search_by_projection_frames(cur["kps"], cur["desc"], cur["mp"], Tcw, K, bounds, scale, last["kps"], last["mp"],
                                                          last.get("outlier"), mps, th, True, self.device)
         return n, mp
 
@@ -33,6 +35,9 @@ class GpuOps:
 
     def frustum_frame(self):
         return self.capi.FrustumFrame()
+
+    def pose_matrices(self, Tcw):
+        return self.capi.pose_matrices(Tcw)
 
     def is_in_frustum(self, F, P, normal, dmin, dmax):
         return self.capi.is_in_frustum(F, P, normal, dmin, dmax, 0.5)
@@ -86,9 +91,10 @@ def track(ops, frames, map_points, mp_dtype, K, bounds, scale, inv_sigma2, pose0
         mps["pos"], mps["desc"], mps["n_obs"] = X.astype(np.float32), map_points["desc"], map_points["n_obs"]
         cur = dict(frames[t], mp=np.full(len(frames[t]["kps"]), -1, np.int32))
         last = dict(frames[t - 1], mp=assign[-1])
-        n, mp = ops.search_by_projection(cur, last, mps, Rc.astype(np.float32).reshape(-1), tc.astype(np.float32), K, bounds, scale, th)
+        Tcw = synth.se3_from_Rt(Rc, tc)   # mCurrentFrame.SetPose(mVelocity * mLastFrame.GetPose()): a Sophus::SE3f
+        n, mp = ops.search_by_projection(cur, last, mps, Tcw, K, bounds, scale, th)
         if n < 20:   # Tracking.cc: retry with a wider window
-            n, mp = ops.search_by_projection(cur, last, mps, Rc.astype(np.float32).reshape(-1), tc.astype(np.float32), K, bounds, scale, 2 * th)
+            n, mp = ops.search_by_projection(cur, last, mps, Tcw, K, bounds, scale, 2 * th)
         sel = np.flatnonzero(mp >= 0)
         kp = frames[t]["kps"]
         obs = np.stack([kp["x"][sel], kp["y"][sel]], 1).astype(np.float64)
@@ -98,8 +104,8 @@ def track(ops, frames, map_points, mp_dtype, K, bounds, scale, inv_sigma2, pose0
         # ---- TrackLocalMap (Tracking.cc SearchLocalPoints + TrackLocalMap): project the map, match what is not matched yet
         Rn, tn = rt_of(pose)
         F = ops.frustum_frame()
-        F.Rcw[:] = Rn.astype(np.float32).reshape(-1).tolist(); F.tcw[:] = tn.astype(np.float32).tolist()
-        F.Ow[:] = (-(Rn.T @ tn)).astype(np.float32).tolist()
+        mRcw, mtcw, mOw = ops.pose_matrices(synth.se3_from_Rt(Rn, tn))   # Frame::SetPose -> UpdatePoseMatrices
+        F.Rcw[:] = mRcw.reshape(-1).tolist(); F.tcw[:] = mtcw.tolist(); F.Ow[:] = mOw.tolist()
         F.fx, F.fy, F.cx, F.cy = (float(v) for v in K)
         F.min_x, F.max_x, F.min_y, F.max_y = (float(v) for v in bounds)
         F.bf, F.log_scale_factor, F.n_levels = 0.0, float(np.log(np.float32(1.2))), len(scale)

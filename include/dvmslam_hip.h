@@ -167,7 +167,8 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
                      const int32_t* d_nq, dvm_match* out, int on_device, void* stream);
 
 /* Frame::isInFrustum (Frame.cc:575-636, mono branch) for n map points at once: projection with the frame's
- * Rcw/tcw (float), image bounds, distance inside [0.8*mfMinDistance, 1.2*mfMaxDistance], viewing cosine,
+ * Rcw/tcw (float; mRcw = mTcw.rotationMatrix(), Frame.cc:553-559 -- this function does use the matrix form, :585),
+ * image bounds, distance inside [0.8*mfMinDistance, 1.2*mfMaxDistance], viewing cosine,
  * MapPoint::PredictScale.  Outputs the mbTrackInView / mTrackProj* / mnTrackScaleLevel / mTrackViewCos fields the
  * reference stores on the MapPoint.  Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
 typedef struct { float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, bf, log_scale_factor; int32_t n_levels; } dvm_frustum_frame;
@@ -186,23 +187,30 @@ int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, 
 /* Projection of n map points into a keyframe + windowed best-descriptor search -- the common body of
  * ORBmatcher::Fuse(KF, vpMapPoints, th) (ORBmatcher.cc:1060-1234, gate_inv_sigma2 = KF.mvInvLevelSigma2, gate = 5.99),
  * Fuse(KF, Scw, ...) (:1236-1345), SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) x2 (:395-603),
- * both directions of SearchBySim3 (:1347-1551; cam->sim3_pair) (gate_inv_sigma2 = NULL).  Per point (skipped when valid[i] == 0; valid may be NULL): p3Dc = Rcw*p + tcw (for the
- * Sim3 variants Rcw = Scw.rotationMatrix(), tcw = Scw.translation()/Scw.scale()), depth >= 0, KeyFrame::IsInImage,
+ * both directions of SearchBySim3 (:1347-1551; cam->sim3_pair) (gate_inv_sigma2 = NULL).  Per point (skipped when valid[i] == 0; valid may be NULL):
+ * p3Dc = Tcw * p in Sophus' QUATERNION form (Thirdparty/Sophus/sophus/so3.hpp:356-367, se3.hpp:319-324 -- the reference never
+ * goes through a rotation matrix here, and the two forms differ in the last float ulp), depth >= 0, KeyFrame::IsInImage,
  * dist in [0.8*min_dist, 1.2*max_dist], PO.Pn >= 0.5*dist, level = MapPoint::PredictScale, radius = th *
  * scale_factors[level], candidates = KeyFrame::GetFeaturesInArea(u, v, radius) with octave in [level-1, level], minus
  * skip[idx] != 0 (skip may be NULL; `cap` bytes of the train frame).  out[i] = best / second best (strict '<', first
  * wins); proj[i] (may be NULL) = projection, radius and predicted level (-1: rejected before the search).
  * Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
+typedef struct { float q[4], t[3]; } dvm_se3f;   /* Sophus::SE3f: unit_quaternion().coeffs() = (x, y, z, w), translation() */
+typedef struct { float q[4], t[3]; } dvm_sim3f;  /* Sophus::Sim3f: rxso3().quaternion().coeffs() (scale = |q|^2), translation() */
 typedef struct {
-  float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
+  /* Tcw: KeyFrame::GetPose() / Frame::GetPose(); for the Sim3 variants SE3f(Scw.rotationMatrix(), Scw.translation() /
+   * Scw.scale()) (ORBmatcher.cc:403,505,1245 -- dvm_host::Sim3ToSE3 derives it in the reference's order).
+   * Ow: GetCameraCenter() resp. Tcw.inverse().translation(). */
+  dvm_se3f Tcw;
+  float Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
   int32_t n_levels;
-  /* sim3_pair != 0 selects the ORBmatcher::SearchBySim3 form (ORBmatcher.cc:1380-1437): p' = sR2 * (Rcw p + tcw) + t2
-   * (the other keyframe's pose, then S21 resp. S12 with sR2 = scale * rotation), u = fx * (X * invz) + cx with
-   * invz = 1.0 / Z, distance = |p'|, no viewing-angle test; Ow is not used.
+  /* sim3_pair == 1 selects the ORBmatcher::SearchBySim3 form (ORBmatcher.cc:1380-1437): p' = S2 * (Tcw * p) with Tcw the
+   * OTHER keyframe's pose and S2 = S21 resp. S12 (Sim3f action rxso3.hpp:265-273, sim3.hpp:226-229),
+   * u = fx * (X * invz) + cx with invz = 1.0 / Z, distance = |p'|, no viewing-angle test; Ow is not used.
    * sim3_pair == 2 selects the relocalisation form, ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th,
    * ORBdist) (:1750-1860): no depth test, bounds inclusive at both ends, no viewing-angle test, octaves [level-1, level+1]. */
   int32_t sim3_pair;
-  float sR2[9], t2[3];
+  dvm_sim3f S2;
 } dvm_kf_camera;
 typedef struct { float u, v, radius; int32_t level; } dvm_projection;
 int dvm_project_search(const dvm_frame* train, int slot, const uint8_t* skip, const dvm_kf_camera* cam, const float* P,

@@ -30,6 +30,7 @@
 //   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1025-1138 transform (TF_IDF, L1), BowVector.cpp:32-72,
 //   FeatureVector.cpp:27-38, ScoringObject.cpp:23-63 L1Scoring::score, FORB.cpp:80-97 -> orc_vocab_transform(), orc_bow_score()
 #include "oracle.h"
+#include "sophus_oracle.h"
 
 #include <algorithm>
 #include <cmath>
@@ -38,7 +39,18 @@
 #include <vector>
 
 namespace {
+namespace so = sophus_oracle;
 const int kGridCols = 64, kGridRows = 48;  // Frame.h:44-45
+// poses cross the oracle's C interface as 7 floats: quaternion coeffs (x, y, z, w) as Sophus stores them, then translation
+so::SE3 load_se3(const float* T) { return so::SE3{so::Quat{T[0], T[1], T[2], T[3]}, {T[4], T[5], T[6]}}; }
+so::Sim3 load_sim3(const float* S) { return so::Sim3{so::Quat{S[0], S[1], S[2], S[3]}, {S[4], S[5], S[6]}}; }
+// MapPoint::PredictScale (MapPoint.cc:573-587); log(float) is the shared logf spec (sophus_oracle.h)
+int predict_scale(float max_dist, float dist, float log_scale_factor, int n_levels) {
+  const float ratio = max_dist / dist;
+  int nScale = (int)std::ceil(so::logf_spec(ratio) / log_scale_factor);
+  if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+  return nScale;
+}
 
 int descriptor_distance(const uint8_t* a, const uint8_t* b) {
   int dist = 0;
@@ -159,8 +171,9 @@ void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* 
     o.in_view = 0; o.proj_x = -1; o.proj_y = -1; o.proj_xr = 0; o.depth = 0; o.level = -1; o.view_cos = 0;
     const float* p = P + 3 * i;
     float Pc[3];
-    for (int r = 0; r < 3; r++) Pc[r] = (F->Rcw[3 * r] * p[0] + F->Rcw[3 * r + 1] * p[1] + F->Rcw[3 * r + 2] * p[2]) + F->tcw[r];
-    const float Pc_dist = std::sqrt(Pc[0] * Pc[0] + Pc[1] * Pc[1] + Pc[2] * Pc[2]);
+    so::mat3_vec(F->Rcw, p, Pc);                                 // mRcw * P + mtcw (:585): matrix form, Eigen's sum order
+    for (int r = 0; r < 3; r++) Pc[r] = Pc[r] + F->tcw[r];
+    const float Pc_dist = so::norm3(Pc);
     const float PcZ = Pc[2];
     const float invz = 1.0f / PcZ;
     if (PcZ < 0.0f) continue;
@@ -170,14 +183,12 @@ void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* 
     o.proj_x = u; o.proj_y = v;
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
     const float PO[3] = {p[0] - F->Ow[0], p[1] - F->Ow[1], p[2] - F->Ow[2]};
-    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    const float dist = so::norm3(PO);
     if (dist < minDistance || dist > maxDistance) continue;
     const float* Pn = normal + 3 * i;
-    const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+    const float viewCos = so::dot3(PO, Pn) / dist;
     if (viewCos < viewing_cos_limit) continue;
-    const float ratio = max_dist[i] / dist;
-    int nScale = (int)std::ceil(std::log(ratio) / F->log_scale_factor);
-    if (nScale < 0) nScale = 0; else if (nScale >= F->n_levels) nScale = F->n_levels - 1;
+    const int nScale = predict_scale(max_dist[i], dist, F->log_scale_factor, F->n_levels);
     o.in_view = 1; o.proj_xr = u - F->bf * invz; o.depth = Pc_dist; o.level = nScale; o.view_cos = viewCos;
   }
 }
@@ -185,8 +196,8 @@ void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* 
 // ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- ORBmatcher.cc:1553-1748,
 // monocular (bForward = bBackward = false, no right image, no Nleft).  Plain sequential restatement: the claim check
 // `CurrentFrame.mvpMapPoints[i2]->Observations() > 0` is evaluated against the state left by earlier iterations.
-int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* Rcw,
-                                    const float* tcw, const float* K, const float* bounds, const float* scale_factors,
+int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* Tcw7,
+                                    const float* K, const float* bounds, const float* scale_factors,
                                     int Nl, const orc_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
                                     const orc_map_point* mps, float th, int check_ori) {
   const int HISTO_LENGTH = 30, TH_HIGH = 100;
@@ -195,13 +206,14 @@ int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uin
   const float factor = 1.0f / HISTO_LENGTH;
   orc_grid* g = orc_grid_create(kps_c, Nc, bounds[0], bounds[1], bounds[2], bounds[3]);
   std::vector<int> vIndices2;
+  const so::SE3 Tcw = load_se3(Tcw7);   // CurrentFrame.GetPose() (:1562)
   for (int i = 0; i < Nl; i++) {
     const int pMP = mp_l[i];
     if (pMP < 0) continue;
     if (outlier_l && outlier_l[i]) continue;
     const float* X = mps[pMP].pos;
     float x3Dc[3];
-    for (int r = 0; r < 3; r++) x3Dc[r] = (Rcw[3 * r] * X[0] + Rcw[3 * r + 1] * X[1] + Rcw[3 * r + 2] * X[2]) + tcw[r];
+    so::se3_act(Tcw, X, x3Dc);           // Tcw * x3Dw (:1577): Sophus' quaternion action
     const float invzc = 1.0 / x3Dc[2];
     if (invzc < 0) continue;
     const float u = K[0] * x3Dc[0] / x3Dc[2] + K[2], v = K[1] * x3Dc[1] / x3Dc[2] + K[3];  // Pinhole::project
@@ -570,33 +582,29 @@ int orc_search_by_bow_kf_kf(int N1, const orc_keypoint* kps1, const uint8_t* des
 }
 
 // Geometry of SearchForTriangulation (ORBmatcher.cc:841-862) + Pinhole::epipolarConstrain's fundamental matrix
-// (Pinhole.cpp:106-110), float, products evaluated left to right with plain sum-of-products rows; K^-1 in closed form.
-// (The reference goes through Sophus quaternions and Eigen's 3x3 inverse: same values up to float rounding -- unpinned.)
-void orc_triangulation_geometry(const float* R1w, const float* t1w, const float* R2w, const float* t2w, const float* K1,
-                                const float* K2, float* R12, float* t12, float* ep, float* F12) {
-  auto mul = [](const float* A, const float* B, float* C) {
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
-  };
-  // Cw = -R1w^T t1w (camera centre of KF1); C2 = R2w Cw + t2w; ep = project(C2)
-  float Cw[3], C2[3];
-  for (int r = 0; r < 3; r++) Cw[r] = -((R1w[r] * t1w[0] + R1w[3 + r] * t1w[1]) + R1w[6 + r] * t1w[2]);
-  for (int r = 0; r < 3; r++) C2[r] = ((R2w[3 * r] * Cw[0] + R2w[3 * r + 1] * Cw[1]) + R2w[3 * r + 2] * Cw[2]) + t2w[r];
+// (Pinhole.cpp:106-110): Cw = pKF1->GetCameraCenter() = T1w.inverse().translation() (KeyFrame.cc:224-257), C2 = T2w * Cw,
+// T12 = T1w * Tw2 (Sophus SE3 product: normalised quaternion product), R12 = T12.rotationMatrix(), F12 =
+// K1.transpose().inverse() * hat(t12) * R12 * K2.inverse() with Eigen's cofactor inverse and left-to-right 3x3 products.
+void orc_triangulation_geometry(const float* T1w7, const float* T2w7, const float* K1, const float* K2, float* R12, float* t12,
+                                float* ep, float* F12) {
+  const so::SE3 T1w = load_se3(T1w7), T2w = load_se3(T2w7);
+  const so::SE3 Tw1 = so::se3_inverse(T1w), Tw2 = so::se3_inverse(T2w);
+  float C2[3];
+  so::se3_act(T2w, Tw1.t, C2);
   ep[0] = K2[0] * C2[0] / C2[2] + K2[2];
   ep[1] = K2[1] * C2[1] / C2[2] + K2[3];
-  // T12 = T1w * Tw2: R12 = R1w R2w^T, t12 = t1w - R12 t2w
-  float R2wT[9];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) R2wT[3 * r + c] = R2w[3 * c + r];
-  mul(R1w, R2wT, R12);
-  for (int r = 0; r < 3; r++) t12[r] = t1w[r] - ((R12[3 * r] * t2w[0] + R12[3 * r + 1] * t2w[1]) + R12[3 * r + 2] * t2w[2]);
-  const float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};
-  const float K1invT[9] = {1.f / K1[0], 0.f, 0.f, 0.f, 1.f / K1[1], 0.f, -K1[2] / K1[0], -K1[3] / K1[1], 1.f};
-  const float K2inv[9] = {1.f / K2[0], 0.f, -K2[2] / K2[0], 0.f, 1.f / K2[1], -K2[3] / K2[1], 0.f, 0.f, 1.f};
-  float A[9], B[9];
-  mul(K1invT, t12x, A);
-  mul(A, R12, B);
-  mul(B, K2inv, F12);
+  const so::SE3 T12 = so::se3_mul(T1w, Tw2);
+  so::quat_to_matrix(T12.q, R12);
+  for (int r = 0; r < 3; r++) t12[r] = T12.t[r];
+  const float t12x[9] = {0.f, -t12[2], t12[1], t12[2], 0.f, -t12[0], -t12[1], t12[0], 0.f};   // SO3f::hat
+  const float K1T[9] = {K1[0], 0.f, 0.f, 0.f, K1[1], 0.f, K1[2], K1[3], 1.f};
+  const float K2m[9] = {K2[0], 0.f, K2[2], 0.f, K2[1], K2[3], 0.f, 0.f, 1.f};
+  float K1Tinv[9], K2inv[9], A[9], B[9];
+  so::mat3_inverse(K1T, K1Tinv);
+  so::mat3_inverse(K2m, K2inv);
+  so::mat3_mul(K1Tinv, t12x, A);
+  so::mat3_mul(A, R12, B);
+  so::mat3_mul(B, K2inv, F12);
 }
 
 int orc_search_for_triangulation(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const int32_t* fv_nodes1,
@@ -666,13 +674,14 @@ int orc_search_for_triangulation(int N1, const orc_keypoint* kps1, const uint8_t
 // Projection gates + window search shared by Fuse x2 and SearchByProjection(KF, Scw, ...) (see the file header).
 // best_idx / best_dist per point (-1 / 256: nothing found or rejected by a gate); proj = (u, v, radius, level) with
 // level -1 when a gate rejected the point.  skip[idx] != 0 removes a keyframe keypoint from every window.
-void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, const uint8_t* skip, const float* Rcw,
-                        const float* tcw, const float* Ow, const float* K, int n, const float* P, const float* normal,
+void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, const uint8_t* skip, const float* Tcw7,
+                        const float* Ow, const float* K, int n, const float* P, const float* normal,
                         const float* min_dist, const float* max_dist, const uint8_t* pdesc, const uint8_t* valid, float th,
                         const float* scale_factors, float log_scale_factor, int n_levels, const float* gate_inv_sigma2, double gate,
                         int32_t* best_idx, int32_t* best_dist, float* proj) {
   orc_grid* g = orc_grid_create(kps, N, bounds[0], bounds[1], bounds[2], bounds[3]);
   std::vector<int> vIndices;
+  const so::SE3 Tcw = load_se3(Tcw7);
   for (int i = 0; i < n; i++) {
     best_idx[i] = -1; best_dist[i] = 256;
     float* pr = proj ? proj + 4 * i : nullptr;
@@ -680,19 +689,17 @@ void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, con
     if (valid && !valid[i]) continue;
     const float* p = P + 3 * i;
     float c[3];
-    for (int r = 0; r < 3; r++) c[r] = ((Rcw[3 * r] * p[0] + Rcw[3 * r + 1] * p[1]) + Rcw[3 * r + 2] * p[2]) + tcw[r];
+    so::se3_act(Tcw, p, c);   // p3Dc = Tcw * p3Dw (:424,527,1107,1267)
     if (c[2] < 0.0f) continue;
     const float u = K[0] * c[0] / c[2] + K[2], v = K[1] * c[1] / c[2] + K[3];
     if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) continue;   // KeyFrame::IsInImage
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
     const float PO[3] = {p[0] - Ow[0], p[1] - Ow[1], p[2] - Ow[2]};
-    const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+    const float dist3D = so::norm3(PO);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
-    const float dot = (PO[0] * normal[3 * i] + PO[1] * normal[3 * i + 1]) + PO[2] * normal[3 * i + 2];
+    const float dot = so::dot3(PO, normal + 3 * i);
     if (dot < 0.5 * dist3D) continue;
-    const float ratio = max_dist[i] / dist3D;                                  // MapPoint::PredictScale
-    int nScale = (int)std::ceil(std::log(ratio) / log_scale_factor);
-    if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+    const int nScale = predict_scale(max_dist[i], dist3D, log_scale_factor, n_levels);
     const float radius = th * scale_factors[nScale];
     if (pr) { pr[0] = u; pr[1] = v; pr[2] = radius; pr[3] = (float)nScale; }
     features_in_area(g, u, v, radius, -1, -1, vIndices);                       // KeyFrame::GetFeaturesInArea: no level filter
@@ -717,9 +724,13 @@ void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, con
 // ORBmatcher::Fuse(KF, Scw, vpPoints, th, vpReplacePoint): kf_mp (in/out) = KF map point ids per keypoint, kf_mp_bad = their
 // isBad(); point i has id point_id[i]; replace[i] receives the id of the KF map point to be replaced (-1 none).
 int orc_fuse_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* kf_mp, const uint8_t* kf_mp_bad,
-                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                  const float* Scw7, const float* K, int n, const int32_t* point_id,
                   const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist, const float* max_dist,
                   const uint8_t* pdesc, float th, const float* scale_factors, float log_scale_factor, int n_levels, int32_t* replace) {
+  so::SE3 Tcw;   // Tcw = SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale()); Ow = Tcw.inverse().translation() (:1245-1246)
+  float Ow[3];
+  so::sim3_to_se3(load_sim3(Scw7), Tcw, Ow);
+  const float Tcw7[7] = {Tcw.q.x, Tcw.q.y, Tcw.q.z, Tcw.q.w, Tcw.t[0], Tcw.t[1], Tcw.t[2]};
   std::vector<uint8_t> valid(n, 1);
   std::vector<int32_t> already(kf_mp, kf_mp + N);   // spAlreadyFound = pKF->GetMapPoints() at entry
   std::sort(already.begin(), already.end());
@@ -728,7 +739,7 @@ int orc_fuse_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const flo
     if ((point_bad && point_bad[i]) || std::binary_search(already.begin(), already.end(), point_id[i])) valid[i] = 0;
   }
   std::vector<int32_t> bi(n), bd(n);
-  orc_project_search(N, kps, desc, bounds, nullptr, Rcw, tcw, Ow, K, n, P, normal, min_dist, max_dist, pdesc, valid.data(), th,
+  orc_project_search(N, kps, desc, bounds, nullptr, Tcw7, Ow, K, n, P, normal, min_dist, max_dist, pdesc, valid.data(), th,
                      scale_factors, log_scale_factor, n_levels, nullptr, 0.0, bi.data(), bd.data(), nullptr);
   int nFused = 0;
   std::vector<uint8_t> fresh(N, 0);   // keypoints that received a point in this call (never bad)
@@ -749,10 +760,14 @@ int orc_fuse_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const flo
 // ORBmatcher::SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming) (:395-496): matched (in/out) = point id
 // per KF keypoint (-1 = NULL); a keypoint matched earlier (at entry or in this call) is skipped by later points.
 int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* matched,
-                                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                                  const float* Scw7, const float* K, int n, const int32_t* point_id,
                                   const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist,
                                   const float* max_dist, const uint8_t* pdesc, int th, float ratioHamming, const float* scale_factors,
                                   float log_scale_factor, int n_levels) {
+  so::SE3 Tcw;   // (:403-404)
+  float Ow[3];
+  so::sim3_to_se3(load_sim3(Scw7), Tcw, Ow);
+  const float Tcw7[7] = {Tcw.q.x, Tcw.q.y, Tcw.q.z, Tcw.q.w, Tcw.t[0], Tcw.t[1], Tcw.t[2]};
   std::vector<int32_t> already(matched, matched + N);
   std::sort(already.begin(), already.end());
   int nmatches = 0;
@@ -761,7 +776,7 @@ int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t*
     if ((point_bad && point_bad[i]) || (point_id[i] >= 0 && std::binary_search(already.begin(), already.end(), point_id[i]))) continue;
     for (int j = 0; j < N; j++) skip[j] = matched[j] >= 0;
     int32_t bi, bd;
-    orc_project_search(N, kps, desc, bounds, skip.data(), Rcw, tcw, Ow, K, 1, P + 3 * i, normal + 3 * i, min_dist + i, max_dist + i,
+    orc_project_search(N, kps, desc, bounds, skip.data(), Tcw7, Ow, K, 1, P + 3 * i, normal + 3 * i, min_dist + i, max_dist + i,
                        pdesc + 32 * (size_t)i, one.data(), (float)th, scale_factors, log_scale_factor, n_levels, nullptr, 0.0, &bi, &bd,
                        nullptr);
     if (bi >= 0 && bd <= kThLow * ratioHamming) { matched[bi] = point_id[i]; nmatches++; }
@@ -771,11 +786,12 @@ int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t*
 
 // ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1347-1551).  Per-keypoint map point data: mpN[i] id (-1 NULL),
 // badN[i], PN (3 per keypoint), minN / maxN (mfMin/MaxDistance), mdescN (32 per keypoint).  idx_in_kf2[i] =
-// get<0>(vpMatches12[i]->GetIndexInKeyFrame(pKF2)) for the entries of matches12 that are set at entry.  S12 = (s, R, t);
-// S21 = S12.inverse() = (1/s, R^T, -(1/s) R^T t); a Sim3 acts as (s R) p + t with the matrix s R formed first.
+// get<0>(vpMatches12[i]->GetIndexInKeyFrame(pKF2)) for the entries of matches12 that are set at entry.  Poses and S12 are
+// Sophus objects (7 floats each); S21 = S12.inverse() (sim3.hpp:129-132); p3Dc2 = S21 * (T1w * p3Dw) with the quaternion
+// actions of se3.hpp:319-324 / rxso3.hpp:265-273.
 namespace {
 void sim3_direction(int Na, const int32_t* mpa, const uint8_t* bada, const uint8_t* already_a, const float* Pa, const float* mina,
-                    const float* maxa, const uint8_t* mdesca, const float* Raw, const float* taw, const float* sR, const float* t,
+                    const float* maxa, const uint8_t* mdesca, const so::SE3& Taw, const so::Sim3& Sba,
                     int Nb, const orc_keypoint* kpsb, const uint8_t* descb, const float* bounds, const float* K, float th,
                     const float* scale_factors, float log_scale_factor, int n_levels, std::vector<int>& vnMatch) {
   orc_grid* g = orc_grid_create(kpsb, Nb, bounds[0], bounds[1], bounds[2], bounds[3]);
@@ -786,19 +802,17 @@ void sim3_direction(int Na, const int32_t* mpa, const uint8_t* bada, const uint8
     if (bada && bada[i]) continue;
     const float* p = Pa + 3 * i;
     float c1[3], c2[3];
-    for (int r = 0; r < 3; r++) c1[r] = ((Raw[3 * r] * p[0] + Raw[3 * r + 1] * p[1]) + Raw[3 * r + 2] * p[2]) + taw[r];
-    for (int r = 0; r < 3; r++) c2[r] = ((sR[3 * r] * c1[0] + sR[3 * r + 1] * c1[1]) + sR[3 * r + 2] * c1[2]) + t[r];
+    so::se3_act(Taw, p, c1);      // p3Dc1 = T1w * p3Dw   (:1394)
+    so::sim3_act(Sba, c1, c2);    // p3Dc2 = S21 * p3Dc1  (:1395)
     if (c2[2] < 0.0) continue;
     const float invz = 1.0 / c2[2];
     const float x = c2[0] * invz, y = c2[1] * invz;
     const float u = K[0] * x + K[2], v = K[1] * y + K[3];
     if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) continue;
     const float maxDistance = 1.2f * maxa[i], minDistance = 0.8f * mina[i];
-    const float dist3D = std::sqrt((c2[0] * c2[0] + c2[1] * c2[1]) + c2[2] * c2[2]);
+    const float dist3D = so::norm3(c2);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
-    const float ratio = maxa[i] / dist3D;
-    int nScale = (int)std::ceil(std::log(ratio) / log_scale_factor);
-    if (nScale < 0) nScale = 0; else if (nScale >= n_levels) nScale = n_levels - 1;
+    const int nScale = predict_scale(maxa[i], dist3D, log_scale_factor, n_levels);
     const float radius = th * scale_factors[nScale];
     features_in_area(g, u, v, radius, -1, -1, vIndices);
     int bestDist = INT32_MAX, bestIdx = -1;
@@ -814,17 +828,13 @@ void sim3_direction(int Na, const int32_t* mpa, const uint8_t* bada, const uint8
 }  // namespace
 
 int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const uint8_t* bad1, const float* P1,
-                       const float* min1, const float* max1, const uint8_t* mdesc1, const float* R1w, const float* t1w, int N2,
+                       const float* min1, const float* max1, const uint8_t* mdesc1, const float* T1w7, int N2,
                        const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2, const float* P2,
-                       const float* min2, const float* max2, const uint8_t* mdesc2, const float* R2w, const float* t2w,
-                       const float* bounds, const float* K, float s12, const float* R12, const float* t12, float th,
+                       const float* min2, const float* max2, const uint8_t* mdesc2, const float* T2w7,
+                       const float* bounds, const float* K, const float* S12_7, float th,
                        const float* scale_factors, float log_scale_factor, int n_levels, int32_t* matches12, const int32_t* idx_in_kf2) {
-  float sR12[9], sR21[9], t21[3];
-  const float s21 = 1.0f / s12;
-  for (int k = 0; k < 9; k++) sR12[k] = s12 * R12[k];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) sR21[3 * r + c] = s21 * R12[3 * c + r];
-  for (int r = 0; r < 3; r++) t21[r] = -((sR21[3 * r] * t12[0] + sR21[3 * r + 1] * t12[1]) + sR21[3 * r + 2] * t12[2]);
+  const so::SE3 T1w = load_se3(T1w7), T2w = load_se3(T2w7);
+  const so::Sim3 S12 = load_sim3(S12_7), S21 = so::sim3_inverse(S12);
   std::vector<uint8_t> am1(N1, 0), am2(N2, 0);
   for (int i = 0; i < N1; i++)
     if (matches12[i] >= 0) {
@@ -833,9 +843,9 @@ int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, c
       if (idx2 >= 0 && idx2 < N2) am2[idx2] = 1;
     }
   std::vector<int> vnMatch1, vnMatch2;
-  sim3_direction(N1, mp1, bad1, am1.data(), P1, min1, max1, mdesc1, R1w, t1w, sR21, t21, N2, kps2, desc2, bounds, K, th, scale_factors,
+  sim3_direction(N1, mp1, bad1, am1.data(), P1, min1, max1, mdesc1, T1w, S21, N2, kps2, desc2, bounds, K, th, scale_factors,
                  log_scale_factor, n_levels, vnMatch1);
-  sim3_direction(N2, mp2, bad2, am2.data(), P2, min2, max2, mdesc2, R2w, t2w, sR12, t12, N1, kps1, desc1, bounds, K, th, scale_factors,
+  sim3_direction(N2, mp2, bad2, am2.data(), P2, min2, max2, mdesc2, T2w, S12, N1, kps1, desc1, bounds, K, th, scale_factors,
                  log_scale_factor, n_levels, vnMatch2);
   int nFound = 0;
   for (int i1 = 0; i1 < N1; i1++) {
@@ -849,7 +859,7 @@ int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, c
 // points of pKF (per keypoint: id -1 = NULL, bad flag, position, distances, descriptor) are projected with the current
 // frame's pose; already (sorted ids) = sAlreadyFound; mp_c (in/out) = CurrentFrame.mvpMapPoints as ids.
 int orc_search_by_projection_reloc(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* bounds,
-                                   const float* Rcw, const float* tcw, const float* Ow, const float* K, int Nk, const orc_keypoint* kps_k,
+                                   const float* Tcw7, const float* K, int Nk, const orc_keypoint* kps_k,
                                    const int32_t* mp_k, const uint8_t* bad_k, const float* P, const float* min_dist, const float* max_dist,
                                    const uint8_t* pdesc, const int32_t* already, int n_already, float th, int ORBdist,
                                    const float* scale_factors, float log_scale_factor, int n_levels, int check_ori) {
@@ -857,22 +867,22 @@ int orc_search_by_projection_reloc(int Nc, const orc_keypoint* kps_c, const uint
   std::vector<int> rotHist[kHisto];
   orc_grid* g = orc_grid_create(kps_c, Nc, bounds[0], bounds[1], bounds[2], bounds[3]);
   std::vector<int> vIndices2;
+  const so::SE3 Tcw = load_se3(Tcw7), Twc = so::se3_inverse(Tcw);   // Ow = Tcw.inverse().translation() (:1754-1755)
+  const float* Ow = Twc.t;
   for (int i = 0; i < Nk; i++) {
     if (mp_k[i] < 0) continue;
     if ((bad_k && bad_k[i]) || std::binary_search(already, already + n_already, mp_k[i])) continue;
     const float* p = P + 3 * i;
     float c[3];
-    for (int r = 0; r < 3; r++) c[r] = ((Rcw[3 * r] * p[0] + Rcw[3 * r + 1] * p[1]) + Rcw[3 * r + 2] * p[2]) + tcw[r];
+    so::se3_act(Tcw, p, c);   // x3Dc = Tcw * x3Dw (:1772)
     const float u = K[0] * c[0] / c[2] + K[2], v = K[1] * c[1] / c[2] + K[3];
     if (u < bounds[0] || u > bounds[1]) continue;
     if (v < bounds[2] || v > bounds[3]) continue;
     const float PO[3] = {p[0] - Ow[0], p[1] - Ow[1], p[2] - Ow[2]};
-    const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+    const float dist3D = so::norm3(PO);
     const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
     if (dist3D < minDistance || dist3D > maxDistance) continue;
-    const float ratio = max_dist[i] / dist3D;
-    int nPredictedLevel = (int)std::ceil(std::log(ratio) / log_scale_factor);
-    if (nPredictedLevel < 0) nPredictedLevel = 0; else if (nPredictedLevel >= n_levels) nPredictedLevel = n_levels - 1;
+    const int nPredictedLevel = predict_scale(max_dist[i], dist3D, log_scale_factor, n_levels);
     const float radius = th * scale_factors[nPredictedLevel];
     features_in_area(g, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
     if (vIndices2.empty()) continue;
@@ -898,5 +908,34 @@ int orc_search_by_projection_reloc(int Nc, const orc_keypoint* kps_c, const uint
   orc_grid_destroy(g);
   return nmatches;
 }
+
+// Pose helpers for the tests (the reference's own derivations, sophus_oracle.h): all 7-float poses
+void orc_se3_inverse(const float* T7, float* out7) {
+  const so::SE3 r = so::se3_inverse(load_se3(T7));
+  out7[0] = r.q.x; out7[1] = r.q.y; out7[2] = r.q.z; out7[3] = r.q.w; out7[4] = r.t[0]; out7[5] = r.t[1]; out7[6] = r.t[2];
+}
+void orc_pose_matrices(const float* Tcw7, float* Rcw, float* tcw, float* Ow) {   // Frame::UpdatePoseMatrices, Frame.cc:553-559
+  const so::SE3 T = load_se3(Tcw7), Twc = so::se3_inverse(T);
+  so::quat_to_matrix(T.q, Rcw);
+  for (int r = 0; r < 3; r++) { tcw[r] = T.t[r]; Ow[r] = Twc.t[r]; }
+}
+void orc_sim3_to_se3(const float* S7, float* Tcw7, float* Ow) {
+  so::SE3 T;
+  so::sim3_to_se3(load_sim3(S7), T, Ow);
+  Tcw7[0] = T.q.x; Tcw7[1] = T.q.y; Tcw7[2] = T.q.z; Tcw7[3] = T.q.w; Tcw7[4] = T.t[0]; Tcw7[5] = T.t[1]; Tcw7[6] = T.t[2];
+}
+void orc_sim3_inverse(const float* S7, float* out7) {
+  const so::Sim3 r = so::sim3_inverse(load_sim3(S7));
+  out7[0] = r.q.x; out7[1] = r.q.y; out7[2] = r.q.z; out7[3] = r.q.w; out7[4] = r.t[0]; out7[5] = r.t[1]; out7[6] = r.t[2];
+}
+void orc_se3_act(const float* T7, const float* p, int n, float* out) {
+  const so::SE3 T = load_se3(T7);
+  for (int i = 0; i < n; i++) so::se3_act(T, p + 3 * i, out + 3 * i);
+}
+void orc_sim3_act(const float* S7, const float* p, int n, float* out) {
+  const so::Sim3 S = load_sim3(S7);
+  for (int i = 0; i < n; i++) so::sim3_act(S, p + 3 * i, out + 3 * i);
+}
+float orc_logf(float x) { return so::logf_spec(x); }
 
 }  // extern "C"

@@ -105,8 +105,8 @@ void orc_is_in_frustum(const orc_frustum_frame* F, const float* P, const float* 
 /* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono=true), whole function (ORBmatcher.cc:1553-1748):
    mp_c / mp_l hold map-point indices (-1 = NULL); mp_c is updated in place; returns nmatches. */
 typedef struct { float pos[3]; uint8_t desc[32]; int32_t n_obs; } orc_map_point;
-int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* Rcw,
-                                    const float* tcw, const float* K, const float* bounds, const float* scale_factors,
+int orc_search_by_projection_frames(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* Tcw7,
+                                    const float* K, const float* bounds, const float* scale_factors,
                                     int Nl, const orc_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
                                     const orc_map_point* mps, float th, int check_ori);
 
@@ -130,40 +130,51 @@ int orc_search_by_bow_kf_kf(int N1, const orc_keypoint* kps1, const uint8_t* des
                             const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2,
                             const int32_t* fv_nodes2, const int32_t* fv_off2, const int32_t* fv_feat2, int nn2, float nnratio,
                             int check_ori, int32_t* matches12);
-void orc_triangulation_geometry(const float* R1w, const float* t1w, const float* R2w, const float* t2w, const float* K1,
-                                const float* K2, float* R12, float* t12, float* ep, float* F12);
+void orc_triangulation_geometry(const float* T1w7, const float* T2w7, const float* K1, const float* K2, float* R12, float* t12,
+                                float* ep, float* F12);
 int orc_search_for_triangulation(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const int32_t* fv_nodes1,
                                  const int32_t* fv_off1, const int32_t* fv_feat1, int nn1, int N2, const orc_keypoint* kps2,
                                  const uint8_t* desc2, const int32_t* mp2, const int32_t* fv_nodes2, const int32_t* fv_off2,
                                  const int32_t* fv_feat2, int nn2, const float* F12, const float* ep, const float* scale_factors2,
                                  const float* level_sigma2_2, int coarse, int check_ori, int32_t* pairs);
-void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, const uint8_t* skip, const float* Rcw,
-                        const float* tcw, const float* Ow, const float* K, int n, const float* P, const float* normal,
+void orc_project_search(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, const uint8_t* skip, const float* Tcw7,
+                        const float* Ow, const float* K, int n, const float* P, const float* normal,
                         const float* min_dist, const float* max_dist, const uint8_t* pdesc, const uint8_t* valid, float th,
                         const float* scale_factors, float log_scale_factor, int n_levels, const float* gate_inv_sigma2, double gate,
                         int32_t* best_idx, int32_t* best_dist, float* proj);
 int orc_fuse_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* kf_mp, const uint8_t* kf_mp_bad,
-                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                  const float* Scw7, const float* K, int n, const int32_t* point_id,
                   const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist, const float* max_dist,
                   const uint8_t* pdesc, float th, const float* scale_factors, float log_scale_factor, int n_levels, int32_t* replace);
 int orc_search_by_projection_sim3(int N, const orc_keypoint* kps, const uint8_t* desc, const float* bounds, int32_t* matched,
-                                  const float* Rcw, const float* tcw, const float* Ow, const float* K, int n, const int32_t* point_id,
+                                  const float* Scw7, const float* K, int n, const int32_t* point_id,
                                   const uint8_t* point_bad, const float* P, const float* normal, const float* min_dist,
                                   const float* max_dist, const uint8_t* pdesc, int th, float ratioHamming, const float* scale_factors,
                                   float log_scale_factor, int n_levels);
 
 int orc_search_by_sim3(int N1, const orc_keypoint* kps1, const uint8_t* desc1, const int32_t* mp1, const uint8_t* bad1, const float* P1,
-                       const float* min1, const float* max1, const uint8_t* mdesc1, const float* R1w, const float* t1w, int N2,
+                       const float* min1, const float* max1, const uint8_t* mdesc1, const float* T1w7, int N2,
                        const orc_keypoint* kps2, const uint8_t* desc2, const int32_t* mp2, const uint8_t* bad2, const float* P2,
-                       const float* min2, const float* max2, const uint8_t* mdesc2, const float* R2w, const float* t2w,
-                       const float* bounds, const float* K, float s12, const float* R12, const float* t12, float th,
+                       const float* min2, const float* max2, const uint8_t* mdesc2, const float* T2w7,
+                       const float* bounds, const float* K, const float* S12_7, float th,
                        const float* scale_factors, float log_scale_factor, int n_levels, int32_t* matches12, const int32_t* idx_in_kf2);
 
 int orc_search_by_projection_reloc(int Nc, const orc_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const float* bounds,
-                                   const float* Rcw, const float* tcw, const float* Ow, const float* K, int Nk, const orc_keypoint* kps_k,
+                                   const float* Tcw7, const float* K, int Nk, const orc_keypoint* kps_k,
                                    const int32_t* mp_k, const uint8_t* bad_k, const float* P, const float* min_dist, const float* max_dist,
                                    const uint8_t* pdesc, const int32_t* already, int n_already, float th, int ORBdist,
                                    const float* scale_factors, float log_scale_factor, int n_levels, int check_ori);
+
+/* Pose arithmetic of the reference (oracle/sophus_oracle.h: Sophus so3/se3/rxso3/sim3.hpp + Eigen 3.4.0 restated in f32).
+ * A pose is 7 floats: quaternion coeffs (x, y, z, w) as Sophus stores them (unit for SE3f, |q|^2 = scale for Sim3f), then
+ * translation.  orc_pose_matrices = Frame::UpdatePoseMatrices (Frame.cc:553-559). */
+void orc_se3_inverse(const float* T7, float* out7);
+void orc_pose_matrices(const float* Tcw7, float* Rcw, float* tcw, float* Ow);
+void orc_sim3_to_se3(const float* S7, float* Tcw7, float* Ow);
+void orc_sim3_inverse(const float* S7, float* out7);
+void orc_se3_act(const float* T7, const float* p, int n, float* out);
+void orc_sim3_act(const float* S7, const float* p, int n, float* out);
+float orc_logf(float x);
 
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);

@@ -323,10 +323,54 @@ TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4")
                         ("level", "<i4"), ("in_view", "<i4")])
 
 
-def make_frustum_frame(Rcw, tcw, K, bounds=(0.0, 640.0, 0.0, 480.0), bf=0.0, scale_factor=1.2, n_levels=8, cls=FrustumFrame):
-    Rcw = np.asarray(Rcw, np.float32).reshape(3, 3)
-    tcw = np.asarray(tcw, np.float32)
-    Ow = (-(Rcw.T @ tcw)).astype(np.float32)
+def pose_matrices(Tcw):
+    """Frame::UpdatePoseMatrices (Frame.cc:553-559) on a 7-float SE3f (qx, qy, qz, qw, t): (mRcw[3,3], mtcw, mOw) float32."""
+    Rcw = np.zeros(9, np.float32); tcw = np.zeros(3, np.float32); Ow = np.zeros(3, np.float32)
+    _call(lib().orc_pose_matrices, None, _f32(Tcw), Rcw, tcw, Ow)
+    return Rcw.reshape(3, 3), tcw, Ow
+
+
+def se3_inverse(T):
+    out = np.zeros(7, np.float32)
+    _call(lib().orc_se3_inverse, None, _f32(T), out)
+    return out
+
+
+def sim3_inverse(S):
+    out = np.zeros(7, np.float32)
+    _call(lib().orc_sim3_inverse, None, _f32(S), out)
+    return out
+
+
+def sim3_to_se3(S):
+    """(Tcw7, Ow) = SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale()), Tcw.inverse().translation()."""
+    T = np.zeros(7, np.float32); Ow = np.zeros(3, np.float32)
+    _call(lib().orc_sim3_to_se3, None, _f32(S), T, Ow)
+    return T, Ow
+
+
+def se3_act(T, P):
+    P = _f32(P).reshape(-1, 3); out = np.zeros_like(P)
+    _call(lib().orc_se3_act, None, _f32(T), P, len(P), out)
+    return out
+
+
+def sim3_act(S, P):
+    P = _f32(P).reshape(-1, 3); out = np.zeros_like(P)
+    _call(lib().orc_sim3_act, None, _f32(S), P, len(P), out)
+    return out
+
+
+def logf(x):
+    L = lib()
+    L.orc_logf.restype = C.c_float; L.orc_logf.argtypes = [C.c_float]
+    return np.array([L.orc_logf(float(v)) for v in np.asarray(x, np.float32).reshape(-1)], np.float32)
+
+
+def make_frustum_frame(Tcw, K, bounds=(0.0, 640.0, 0.0, 480.0), bf=0.0, scale_factor=1.2, n_levels=8, cls=FrustumFrame, matrices=None):
+    """Tcw: 7-float SE3f; mRcw / mtcw / mOw are derived as Frame::UpdatePoseMatrices does (`matrices` = a function doing that:
+    the HIP tests pass the product's own, capi.pose_matrices)."""
+    Rcw, tcw, Ow = (matrices or pose_matrices)(Tcw)
     F = cls()
     F.Rcw[:] = list(Rcw.reshape(-1)); F.tcw[:] = list(tcw); F.Ow[:] = list(Ow)
     F.fx, F.fy, F.cx, F.cy = [float(np.float32(v)) for v in K]
@@ -360,20 +404,20 @@ def optimize_sim3(S12, fix_scale, P1c, P2c, obs1, obs2, w1, w2, K1, K2, th2):
 MAP_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
 
 
-def search_by_projection_frames(kps_c, desc_c, mp_c, Rcw, tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
+def search_by_projection_frames(kps_c, desc_c, mp_c, Tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
                                 check_ori=True):
     """Whole ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (mono).  Returns (nmatches, mp_c updated copy)."""
     L = lib()
     vp = C.c_void_p
     L.orc_search_by_projection_frames.restype = C.c_int32
-    L.orc_search_by_projection_frames.argtypes = [C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp,
+    L.orc_search_by_projection_frames.argtypes = [C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp,
                                                   C.c_float, C.c_int32]
     kps_c = np.ascontiguousarray(kps_c, KP_DTYPE); kps_l = np.ascontiguousarray(kps_l, KP_DTYPE)
     desc_c = np.ascontiguousarray(desc_c, np.uint8)
     mp = np.array(mp_c, np.int32, copy=True)
     mp_l = np.ascontiguousarray(mp_l, np.int32)
     outl = None if outlier_l is None else np.ascontiguousarray(outlier_l, np.uint8)
-    f = [np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, K, bounds, scale_factors)]
+    f = [np.ascontiguousarray(a, np.float32) for a in (Tcw, K, bounds, scale_factors)]
     mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
     n = L.orc_search_by_projection_frames(len(kps_c), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f], len(kps_l), _p(kps_l),
                                           _p(mp_l), None if outl is None else _p(outl), _p(mps), float(th), int(check_ori))
@@ -480,10 +524,10 @@ def search_by_bow_kf_kf(kps1, desc1, mp1, bad1, fv1, kps2, desc2, mp2, bad2, fv2
     return n, m
 
 
-def triangulation_geometry(R1w, t1w, R2w, t2w, K1, K2):
+def triangulation_geometry(T1w, T2w, K1, K2):
     """R12, t12, epipole in image 2 and F12 (float32) as SearchForTriangulation / epipolarConstrain build them."""
     R12 = np.zeros(9, np.float32); t12 = np.zeros(3, np.float32); ep = np.zeros(2, np.float32); F12 = np.zeros(9, np.float32)
-    _call(lib().orc_triangulation_geometry, None, _f32(R1w).reshape(-1), _f32(t1w), _f32(R2w).reshape(-1), _f32(t2w), _f32(K1), _f32(K2),
+    _call(lib().orc_triangulation_geometry, None, _f32(T1w), _f32(T2w), _f32(K1), _f32(K2),
           R12, t12, ep, F12)
     return R12, t12, ep, F12
 
@@ -500,7 +544,7 @@ def search_for_triangulation(kps1, desc1, mp1, fv1, kps2, desc2, mp2, fv2, F12, 
     return n, pairs[:n]
 
 
-def project_search(kps, desc, bounds, skip, Rcw, tcw, Ow, K, pts, th, scale_factors, log_scale_factor, gate_inv_sigma2=None,
+def project_search(kps, desc, bounds, skip, Tcw, Ow, K, pts, th, scale_factors, log_scale_factor, gate_inv_sigma2=None,
                    gate=0.0):
     """Projection gates + window search of Fuse / SearchByProjection(KF, Scw, ...).  pts: dict(pos, normal, min_dist, max_dist,
     desc, valid).  Returns (best_idx, best_dist, proj[n, 4] = u, v, radius, level)."""
@@ -508,60 +552,60 @@ def project_search(kps, desc, bounds, skip, Rcw, tcw, Ow, K, pts, th, scale_fact
     n = len(pts["pos"])
     bi = np.zeros(n, np.int32); bd = np.zeros(n, np.int32); pr = np.zeros((n, 4), np.float32)
     sf = _f32(scale_factors)
-    _call(lib().orc_project_search, None, len(k), k, d, _f32(bounds), _u8(skip), _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow), _f32(K), n,
+    _call(lib().orc_project_search, None, len(k), k, d, _f32(bounds), _u8(skip), _f32(Tcw), _f32(Ow), _f32(K), n,
           _f32(pts["pos"]), _f32(pts["normal"]), _f32(pts["min_dist"]), _f32(pts["max_dist"]), _u8(pts["desc"]), _u8(pts.get("valid")),
           F32(th), sf, F32(log_scale_factor), len(sf), _f32(gate_inv_sigma2), F64(gate), bi, bd, pr)
     return bi, bd, pr
 
 
-def fuse_sim3(kps, desc, bounds, kf_mp, kf_mp_bad, Rcw, tcw, Ow, K, pts, th, scale_factors, log_scale_factor):
+def fuse_sim3(kps, desc, bounds, kf_mp, kf_mp_bad, Scw, K, pts, th, scale_factors, log_scale_factor):
     """ORBmatcher::Fuse(KF, Scw, vpPoints, th, vpReplacePoint).  pts adds id, bad.  Returns (nFused, kf_mp updated, replace)."""
     k, d = _kd(kps, desc)
     n = len(pts["pos"])
     mp = np.array(kf_mp, np.int32, copy=True); rep = np.zeros(n, np.int32)
     sf = _f32(scale_factors)
-    nf = _call(lib().orc_fuse_sim3, C.c_int32, len(k), k, d, _f32(bounds), mp, _u8(kf_mp_bad), _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow),
+    nf = _call(lib().orc_fuse_sim3, C.c_int32, len(k), k, d, _f32(bounds), mp, _u8(kf_mp_bad), _f32(Scw),
                _f32(K), n, np.ascontiguousarray(pts["id"], np.int32), _u8(pts.get("bad")), _f32(pts["pos"]), _f32(pts["normal"]),
                _f32(pts["min_dist"]), _f32(pts["max_dist"]), _u8(pts["desc"]), F32(th), sf, F32(log_scale_factor), len(sf), rep)
     return nf, mp, rep
 
 
-def search_by_projection_sim3(kps, desc, bounds, matched, Rcw, tcw, Ow, K, pts, th, ratio_hamming, scale_factors, log_scale_factor):
+def search_by_projection_sim3(kps, desc, bounds, matched, Scw, K, pts, th, ratio_hamming, scale_factors, log_scale_factor):
     """ORBmatcher::SearchByProjection(KF, Scw, vpPoints, vpMatched, th, ratioHamming).  Returns (nmatches, vpMatched updated)."""
     k, d = _kd(kps, desc)
     n = len(pts["pos"])
     m = np.array(matched, np.int32, copy=True)
     sf = _f32(scale_factors)
-    nm = _call(lib().orc_search_by_projection_sim3, C.c_int32, len(k), k, d, _f32(bounds), m, _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow),
+    nm = _call(lib().orc_search_by_projection_sim3, C.c_int32, len(k), k, d, _f32(bounds), m, _f32(Scw),
                _f32(K), n, np.ascontiguousarray(pts["id"], np.int32), _u8(pts.get("bad")), _f32(pts["pos"]), _f32(pts["normal"]),
                _f32(pts["min_dist"]), _f32(pts["max_dist"]), _u8(pts["desc"]), int(th), F32(ratio_hamming), sf, F32(log_scale_factor),
                len(sf))
     return nm, m
 
 
-def search_by_sim3(kf1, mps1, kf2, mps2, s12, R12, t12, th, matches12, idx_in_kf2):
-    """ORBmatcher::SearchBySim3.  kfN: keyframe dicts (kps, desc, mp, bad, Rcw, tcw, bounds, K, scale_factors, log_scale_factor);
+def search_by_sim3(kf1, mps1, kf2, mps2, S12, th, matches12, idx_in_kf2):
+    """ORBmatcher::SearchBySim3.  S12: 7-float Sim3f.  kfN: keyframe dicts (kps, desc, mp, bad, Tcw, bounds, K, scale_factors, log_scale_factor);
     mpsN: per-keypoint map point data dict(pos, min_dist, max_dist, desc).  Returns (nFound, vpMatches12 updated)."""
     k1, d1 = _kd(kf1["kps"], kf1["desc"]); k2, d2 = _kd(kf2["kps"], kf2["desc"])
     m = np.array(matches12, np.int32, copy=True)
     sf = _f32(kf1["scale_factors"])
     n = _call(lib().orc_search_by_sim3, C.c_int32, len(k1), k1, d1, np.ascontiguousarray(kf1["mp"], np.int32), _u8(kf1.get("bad")),
-              _f32(mps1["pos"]), _f32(mps1["min_dist"]), _f32(mps1["max_dist"]), _u8(mps1["desc"]), _f32(kf1["Rcw"]).reshape(-1), _f32(kf1["tcw"]),
+              _f32(mps1["pos"]), _f32(mps1["min_dist"]), _f32(mps1["max_dist"]), _u8(mps1["desc"]), _f32(kf1["Tcw"]),
               len(k2), k2, d2, np.ascontiguousarray(kf2["mp"], np.int32), _u8(kf2.get("bad")), _f32(mps2["pos"]), _f32(mps2["min_dist"]),
-              _f32(mps2["max_dist"]), _u8(mps2["desc"]), _f32(kf2["Rcw"]).reshape(-1), _f32(kf2["tcw"]), _f32(kf1["bounds"]), _f32(kf1["K"]),
-              F32(s12), _f32(R12).reshape(-1), _f32(t12), F32(th), sf, F32(kf1["log_scale_factor"]), len(sf), m,
+              _f32(mps2["max_dist"]), _u8(mps2["desc"]), _f32(kf2["Tcw"]), _f32(kf1["bounds"]), _f32(kf1["K"]),
+              _f32(S12), F32(th), sf, F32(kf1["log_scale_factor"]), len(sf), m,
               None if idx_in_kf2 is None else np.ascontiguousarray(idx_in_kf2, np.int32))
     return n, m
 
 
-def search_by_projection_reloc(cur_kps, cur_desc, cur_mp, bounds, Rcw, tcw, Ow, K, kf, kf_pts, already, th, orb_dist, scale_factors,
+def search_by_projection_reloc(cur_kps, cur_desc, cur_mp, bounds, Tcw, K, kf, kf_pts, already, th, orb_dist, scale_factors,
                                log_scale_factor, check_ori=True):
     """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist).  Returns (nmatches, mvpMapPoints updated)."""
     kc, dc = _kd(cur_kps, cur_desc); kk, _ = _kd(kf["kps"], kf["desc"])
     m = np.array(cur_mp, np.int32, copy=True)
     al = np.sort(np.ascontiguousarray(already, np.int32))
     sf = _f32(scale_factors)
-    n = _call(lib().orc_search_by_projection_reloc, C.c_int32, len(kc), kc, dc, m, _f32(bounds), _f32(Rcw).reshape(-1), _f32(tcw), _f32(Ow), _f32(K),
+    n = _call(lib().orc_search_by_projection_reloc, C.c_int32, len(kc), kc, dc, m, _f32(bounds), _f32(Tcw), _f32(K),
               len(kk), kk, np.ascontiguousarray(kf["mp"], np.int32), _u8(kf.get("bad")), _f32(kf_pts["pos"]), _f32(kf_pts["min_dist"]),
               _f32(kf_pts["max_dist"]), _u8(kf_pts["desc"]), al, len(al), F32(th), int(orb_dist), sf, F32(log_scale_factor), len(sf), int(check_ori))
     return n, m

@@ -103,7 +103,7 @@ def kf_functions():
     pts = sc["pts"]
     out = {}
     for tag, kf in (("a", a), ("b", b)):
-        for k in ("kps", "desc", "mp", "bad", "Rcw", "tcw", "Ow"):
+        for k in ("kps", "desc", "mp", "bad", "Tcw"):
             out[f"{tag}_{k}"] = kf[k]
         for k, v in kf["fv"].items():
             out[f"{tag}_{k}"] = v
@@ -114,15 +114,18 @@ def kf_functions():
         out["pt_" + k] = v
     n1, m1 = po.search_by_bow_kf_kf(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["mp"], b["bad"], b["fv"], 0.8, True)
     n2, m2 = po.search_by_bow_kf_frame(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["fv"], 0.7, True)
-    geo = po.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    geo = po.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
     n3, pairs = po.search_for_triangulation(a["kps"], a["desc"], a["mp"], a["fv"], b["kps"], b["desc"], b["mp"], b["fv"], geo[3], geo[2],
                                             b["scale_factors"], b["level_sigma2"], False, True)
-    bi, bd, pr = po.project_search(b["kps"], b["desc"], b["bounds"], None, b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 3.0, b["scale_factors"],
+    bi, bd, pr = po.project_search(b["kps"], b["desc"], b["bounds"], None, b["Tcw"], po.se3_inverse(b["Tcw"])[4:], b["K"], pts, 3.0, b["scale_factors"],
                                    b["log_scale_factor"], b["inv_level_sigma2"], 5.99)
     matched = np.where(np.random.default_rng(2).random(len(b["kps"])) < 0.3, b["mp"], -1).astype(np.int32)
-    n4, m4 = po.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], matched, b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 8, 1.0,
+    # a genuine similarity (scale 1.3) whose SE3 part is keyframe b's pose: both Sim3 consumers decompose it themselves
+    Scw = synth.sim3_from_sRt(1.3, b["Rcw"].reshape(3, 3), b["tcw"] * np.float32(1.3))
+    out["b_Scw"] = Scw
+    n4, m4 = po.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], matched, Scw, b["K"], pts, 8, 1.0,
                                           b["scale_factors"], b["log_scale_factor"])
-    n5, mp5, rep5 = po.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 4.0,
+    n5, mp5, rep5 = po.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], Scw, b["K"], pts, 4.0,
                                  b["scale_factors"], b["log_scale_factor"])
     si = make_init_scene(po, 22, n=400)
     n6, m6, pm6 = po.search_for_initialization(si["k1"], si["d1"], si["k2"], si["d2"], si["bounds"], si["prev_matched"], 100, 0.9, True)
@@ -161,10 +164,10 @@ def db_wire():
     pa = dict(pos=sc["pts"]["pos"][idx], min_dist=sc["pts"]["min_dist"][idx], max_dist=sc["pts"]["max_dist"][idx], desc=sc["pts"]["desc"][idx])
     cur_mp = np.where(np.random.default_rng(3).random(len(b["kps"])) < 0.2, b["mp"], -1).astype(np.int32)
     already = np.unique(cur_mp[cur_mp >= 0])
-    n, m = po.search_by_projection_reloc(b["kps"], b["desc"], cur_mp, b["bounds"], b["Rcw"], b["tcw"], b["Ow"], b["K"], a, pa, already, 10.0, 100,
+    n, m = po.search_by_projection_reloc(b["kps"], b["desc"], cur_mp, b["bounds"], b["Tcw"], b["K"], a, pa, already, 10.0, 100,
                                          b["scale_factors"], b["log_scale_factor"], True)
     for tag, kf in (("ra", a), ("rb", b)):
-        for k in ("kps", "desc", "mp", "bad", "Rcw", "tcw", "Ow", "K", "bounds", "scale_factors"):
+        for k in ("kps", "desc", "mp", "bad", "Tcw", "K", "bounds", "scale_factors"):
             out[f"{tag}_{k}"] = kf[k]
     out.update({"rp_" + k: v for k, v in pa.items()}, r_cur_mp=cur_mp, r_already=already, r_n=n, r_m=m, r_lsf=np.float32(b["log_scale_factor"]))
     dk, dm = make_delta(wire, capi, 7, 2, 10)

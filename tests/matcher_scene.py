@@ -1,6 +1,8 @@
 """Synthetic two-frame tracking scene for the whole-function SearchByProjection(CurrentFrame, LastFrame) tests."""
 import numpy as np
 
+from dvm_slam_amd import synth
+
 
 def make_scene(oracle, seed=0, n_last=1000, n_cur=1100, dup_frac=0.15, zero_obs_frac=0.1, flip_bits=20):
     """LastFrame keypoints carry map points; CurrentFrame keypoints are noisy re-projections (plus clutter) so that
@@ -65,7 +67,8 @@ def make_scene(oracle, seed=0, n_last=1000, n_cur=1100, dup_frac=0.15, zero_obs_
     mp_c = np.full(n_cur, -1, np.int32)
     pre = rng.choice(n_cur, 40, replace=False)          # already-associated keypoints (some with 0 observations)
     mp_c[pre] = rng.integers(0, n_last, 40)
-    return dict(kps_c=kc, desc_c=dc, mp_c=mp_c, Rcw=Rcw.reshape(-1), tcw=tcw, K=K, bounds=bounds, scale_factors=scale,
+    # Tcw: the pose as the reference holds it (Sophus::SE3f, 7 floats: unit quaternion x, y, z, w + translation)
+    return dict(kps_c=kc, desc_c=dc, mp_c=mp_c, Tcw=synth.se3_from_Rt(Rcw, tcw), K=K, bounds=bounds, scale_factors=scale,
                 kps_l=kl, mp_l=mp_l, outlier_l=outl, mps=mps)
 
 
@@ -75,8 +78,8 @@ def make_local_map_scene(oracle, seed=0, **kw):
     sc = make_scene(oracle, seed, **kw)
     rng = np.random.default_rng(seed + 100)
     mps, K = sc["mps"], sc["K"]
-    R = sc["Rcw"].reshape(3, 3)
-    Xc = mps["pos"] @ R.T + sc["tcw"]
+    R, t = synth.Rt_from_se3(sc["Tcw"])
+    Xc = (mps["pos"] @ R.T + t).astype(np.float32)
     n = len(mps)
     pts = np.zeros(n, oracle.TRACKED_POINT_DTYPE)
     pts["proj_x"] = K[0] * Xc[:, 0] / Xc[:, 2] + K[2]
@@ -176,7 +179,7 @@ def make_kf_pair_scene(oracle, seed=0, n_pts=900, n_clutter=250, n_nodes=120, ma
         fv = dict(fv_nodes=nodes.astype(np.int32), fv_off=np.concatenate([[0], np.cumsum(counts)]).astype(np.int32),
                   fv_feat=order.astype(np.int32))
         Ow = (-(R.T @ t)).astype(np.float32)
-        kfs.append(dict(kps=kps, desc=desc, mp=mp, bad=bad, fv=fv, Rcw=R.reshape(-1).copy(), tcw=t, Ow=Ow, K=K, bounds=bounds,
+        kfs.append(dict(kps=kps, desc=desc, mp=mp, bad=bad, fv=fv, Tcw=synth.se3_from_Rt(R, t), Rcw=R.reshape(-1).copy(), tcw=t, Ow=Ow, K=K, bounds=bounds,
                         scale_factors=scale, level_sigma2=sigma2, inv_level_sigma2=inv_sigma2,
                         log_scale_factor=float(np.log(np.float32(1.2))), pt_of_kp=np.concatenate([idx, np.full(n_clutter, -1)])))
     # map points for the projection searches: the 3-D points + normals / scale ranges as MapPoint::UpdateNormalAndDepth leaves them

@@ -2,6 +2,7 @@
 config-3 merge pipeline test."""
 import numpy as np
 
+from dvm_slam_amd import synth
 from matcher_scene import make_kf_pair_scene
 
 
@@ -24,7 +25,7 @@ def make_two_agent_scene(oracle, seed=0, n_distract=12, s_w=1.6):
         return dict(pos=pos[idx], normal=pts["normal"][idx], min_dist=(pts["min_dist"][idx] * scale).astype(np.float32),
                     max_dist=(pts["max_dist"][idx] * scale).astype(np.float32), desc=pts["desc"][idx])
     a = dict(a, uuid=111, map_id=0, mn_id=1)
-    b = dict(b, Rcw=R2p.reshape(-1), tcw=t2p, Ow=(-(R2p.T @ t2p)).astype(np.float32), uuid=222, map_id=1, mn_id=1,
+    b = dict(b, Tcw=synth.se3_from_Rt(R2p, t2p), Rcw=R2p.reshape(-1), tcw=t2p, Ow=(-(R2p.T @ t2p)).astype(np.float32), uuid=222, map_id=1, mn_id=1,
              mp=np.where(b["mp"] >= 0, b["mp"] + 100000, -1).astype(np.int32))     # B's own map point ids
     pa, pb = per_kp(a, pts["pos"], 1.0), per_kp(b, XB, s_w)
     wrong = rng.random(len(pb["pos"])) < 0.15          # badly triangulated points in B's map: geometric outliers for RANSAC

@@ -137,7 +137,7 @@ def test_hip_reproduces_second_set(capi):
 
 
 def _kf_from_golden(z, tag):
-    kf = {k: z[f"{tag}_{k}"] for k in ("kps", "desc", "mp", "bad", "Rcw", "tcw", "Ow")}
+    kf = {k: z[f"{tag}_{k}"] for k in ("kps", "desc", "mp", "bad", "Tcw")}
     kf["fv"] = {k: z[f"{tag}_{k}"] for k in ("fv_nodes", "fv_off", "fv_feat")}
     for k in ("K", "bounds", "scale_factors", "level_sigma2", "inv_level_sigma2"):
         kf[k] = z[k]
@@ -153,18 +153,18 @@ def test_oracle_reproduces_kf_matcher_functions(oracle):
     assert n == int(z["bowkk_n"]) and np.array_equal(m, z["bowkk_m"])
     n, m = oracle.search_by_bow_kf_frame(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["fv"], 0.7, True)
     assert n == int(z["bowkf_n"]) and np.array_equal(m, z["bowkf_m"])
-    geo = oracle.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    geo = oracle.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
     assert np.array_equal(geo[3], z["tri_F12"]) and np.array_equal(geo[2], z["tri_ep"])
     n, pairs = oracle.search_for_triangulation(a["kps"], a["desc"], a["mp"], a["fv"], b["kps"], b["desc"], b["mp"], b["fv"], geo[3], geo[2],
                                                b["scale_factors"], b["level_sigma2"], False, True)
     assert n == int(z["tri_n"]) and np.array_equal(pairs, z["tri_pairs"])
-    bi, bd, pr = oracle.project_search(b["kps"], b["desc"], b["bounds"], None, b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 3.0, b["scale_factors"],
+    bi, bd, pr = oracle.project_search(b["kps"], b["desc"], b["bounds"], None, b["Tcw"], oracle.se3_inverse(b["Tcw"])[4:], b["K"], pts, 3.0, b["scale_factors"],
                                        b["log_scale_factor"], b["inv_level_sigma2"], 5.99)
     assert np.array_equal(bi, z["ps_idx"]) and np.array_equal(bd, z["ps_dist"]) and np.array_equal(pr, z["ps_proj"])
-    n, m = oracle.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], z["sim3_matched_in"], b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 8,
+    n, m = oracle.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], z["sim3_matched_in"], z["b_Scw"], b["K"], pts, 8,
                                             1.0, b["scale_factors"], b["log_scale_factor"])
     assert n == int(z["sim3_n"]) and np.array_equal(m, z["sim3_m"])
-    n, mp, rep = oracle.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], b["Rcw"], b["tcw"], b["Ow"], b["K"], pts, 4.0,
+    n, mp, rep = oracle.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], z["b_Scw"], b["K"], pts, 4.0,
                                   b["scale_factors"], b["log_scale_factor"])
     assert n == int(z["fuse_n"]) and np.array_equal(mp, z["fuse_mp"]) and np.array_equal(rep, z["fuse_rep"])
     si = _sub(z, "i_")
@@ -191,10 +191,9 @@ def test_hip_reproduces_kf_matcher_functions(capi):
     P = capi.map_points_view(pts)
     n, bi = capi.fuse(vb, capi.map_points_view({k: v for k, v in pts.items() if k != "bad"}), None, 3.0)
     assert np.array_equal(bi, np.where((z["ps_idx"] >= 0) & (z["ps_dist"] <= 50), z["ps_idx"], -1))
-    # unit-scale similarity == the keyframe pose
-    n, m, _ = capi.search_by_projection_sim3(vb, b["Rcw"], b["tcw"], 1.0, P, z["sim3_matched_in"], 8, 1.0)
+    n, m, _ = capi.search_by_projection_sim3(vb, z["b_Scw"], P, z["sim3_matched_in"], 8, 1.0)
     assert n == int(z["sim3_n"]) and np.array_equal(m, z["sim3_m"])
-    n, rep = capi.fuse_sim3(vb, b["Rcw"], b["tcw"], 1.0, P, 4.0)
+    n, rep = capi.fuse_sim3(vb, z["b_Scw"], P, 4.0)
     assert n == int(z["fuse_n"]) and np.array_equal(b["mp"], z["fuse_mp"]) and np.array_equal(rep, z["fuse_rep"])
     si = _sub(z, "i_")
     F1 = capi.frame_view(si["k1"], si["d1"], si["bounds"], si["scale_factors"])
@@ -230,7 +229,7 @@ def test_oracle_reproduces_db_wire_set(oracle, capi):
     z = np.load(os.path.join(G, "db_wire.npz"))
     _check_db(z, oracle.KeyFrameDatabase())
     a = {k: z[f"ra_{k}"] for k in ("kps", "desc", "mp", "bad")}
-    n, m = oracle.search_by_projection_reloc(z["rb_kps"], z["rb_desc"], z["r_cur_mp"], z["rb_bounds"], z["rb_Rcw"], z["rb_tcw"], z["rb_Ow"], z["rb_K"], a,
+    n, m = oracle.search_by_projection_reloc(z["rb_kps"], z["rb_desc"], z["r_cur_mp"], z["rb_bounds"], z["rb_Tcw"], z["rb_K"], a,
                                              _sub(z, "rp_"), z["r_already"], 10.0, 100, z["rb_scale_factors"], float(z["r_lsf"]), True)
     assert n == int(z["r_n"]) and np.array_equal(m, z["r_m"])
     # the DVMW block is a format pin: the builder must reproduce it byte for byte, and it must parse
@@ -243,15 +242,13 @@ def test_oracle_reproduces_db_wire_set(oracle, capi):
 
 @pytest.mark.gpu
 def test_hip_reproduces_db_wire_set(capi):
-    import ctypes as C
     z = np.load(os.path.join(G, "db_wire.npz"))
     _check_db(z, capi.HostKeyFrameDatabase())
     a = {k: z[f"ra_{k}"] for k in ("kps", "desc", "mp", "bad")}
     a.update(bounds=z["ra_bounds"], scale_factors=z["ra_scale_factors"], log_scale_factor=float(z["r_lsf"]))
     a["mp"] = a["mp"].copy()
     m = z["r_cur_mp"].copy()
-    F = capi.frame_view(z["rb_kps"], z["rb_desc"], z["rb_bounds"], z["rb_scale_factors"], mp=m, K=z["rb_K"])
-    F[0].Rcw = (C.c_float * 9)(*z["rb_Rcw"]); F[0].tcw = (C.c_float * 3)(*z["rb_tcw"])
+    F = capi.frame_view(z["rb_kps"], z["rb_desc"], z["rb_bounds"], z["rb_scale_factors"], mp=m, K=z["rb_K"], Tcw=z["rb_Tcw"])
     pts = _sub(z, "rp_"); pts["normal"] = pts["pos"]
     n, _ = capi.search_by_projection_reloc(F, capi.keyframe_view(a), capi.map_points_view(pts), z["r_already"], 10.0, 100, True)
     assert n == int(z["r_n"]) and np.array_equal(m, z["r_m"])

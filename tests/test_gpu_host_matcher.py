@@ -48,8 +48,8 @@ def test_search_by_projection_real_frames(capi, oracle, frames):
     mps["pos"][:, 2] = z
     mps["desc"] = d0
     mps["n_obs"] = rng.integers(0, 4, len(k0))
-    args = dict(kps_c=k1, desc_c=d1, mp_c=np.full(len(k1), -1, np.int32), Rcw=np.eye(3, dtype=np.float32).reshape(-1),
-                tcw=np.zeros(3, np.float32), K=K, bounds=np.array([0, 640, 0, 480], np.float32),
+    args = dict(kps_c=k1, desc_c=d1, mp_c=np.full(len(k1), -1, np.int32),
+                Tcw=np.array([0, 0, 0, 1, 0, 0, 0], np.float32), K=K, bounds=np.array([0, 640, 0, 480], np.float32),
                 scale_factors=orc.tables()["scale"], kps_l=k0, mp_l=np.arange(len(k0), dtype=np.int32), outlier_l=None, mps=mps)
     n_o, mp_o = oracle.search_by_projection_frames(th=15.0, **args)
     n_g, mp_g, _ = capi.search_by_projection_frames(th=15.0, **args)

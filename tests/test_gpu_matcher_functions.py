@@ -5,6 +5,7 @@ Exact: match counts and every output entry."""
 import numpy as np
 import pytest
 
+from dvm_slam_amd import synth
 from matcher_scene import make_init_scene, make_kf_pair_scene
 
 pytestmark = pytest.mark.gpu
@@ -79,7 +80,7 @@ def test_search_for_triangulation(capi, oracle, seed, coarse, ori):
     sc = make_kf_pair_scene(oracle, seed, mapped_frac=0.4, dup_frac=0.2)
     a, b = sc["kf"]
     (va, _), (vb, _) = _kfviews(capi, sc)
-    geo_o = oracle.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    geo_o = oracle.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
     geo_g = capi.triangulation_geometry(va, vb)
     for x, y in zip(geo_o, geo_g):
         assert np.array_equal(x, y)
@@ -93,10 +94,9 @@ def test_search_for_triangulation_epipole_inside(capi, oracle):
     """Camera 2 moved along the optical axis: the epipole lies inside the image and the exclusion disc removes candidates."""
     sc = make_kf_pair_scene(oracle, 11, mapped_frac=0.3)
     a, b = sc["kf"]
-    b = dict(b); b["Rcw"] = np.eye(3, dtype=np.float32).reshape(-1); b["tcw"] = np.array([0.02, -0.01, -1.5], np.float32)
-    b["Ow"] = -b["tcw"]
+    b = dict(b); b["Tcw"] = synth.se3_from_Rt(np.eye(3), [0.02, -0.01, -1.5])
     va = capi.keyframe_view(dict(a)); vb = capi.keyframe_view(b)
-    geo = oracle.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    geo = oracle.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
     assert 0 < geo[2][0] < 640 and 0 < geo[2][1] < 480
     for coarse in (True, False):
         n_o, p_o = oracle.search_for_triangulation(a["kps"], a["desc"], a["mp"], a["fv"], b["kps"], b["desc"], b["mp"], b["fv"], geo[3], geo[2],
@@ -115,11 +115,11 @@ def test_project_search_device(capi, oracle, seed, th, gate):
     valid = (rng.random(len(pts["pos"])) < 0.9).astype(np.uint8)
     p2 = dict(pts); p2["valid"] = valid
     gi = kf["inv_level_sigma2"] if gate else None
-    bi_o, bd_o, pr_o = oracle.project_search(kf["kps"], kf["desc"], kf["bounds"], skip, kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], p2, th,
+    bi_o, bd_o, pr_o = oracle.project_search(kf["kps"], kf["desc"], kf["bounds"], skip, kf["Tcw"], oracle.se3_inverse(kf["Tcw"])[4:], kf["K"], p2, th,
                                              kf["scale_factors"], kf["log_scale_factor"], gi, 5.99)
     g = capi.FrameGrid(2048)
     g.build(kf["kps"], kf["desc"], tuple(float(x) for x in kf["bounds"]))
-    cam = dict(Rcw=kf["Rcw"], tcw=kf["tcw"], Ow=kf["Ow"], K=kf["K"], bounds=kf["bounds"], log_scale_factor=kf["log_scale_factor"])
+    cam = dict(Tcw=kf["Tcw"], Ow=capi.se3_inverse(kf["Tcw"])[4:], K=kf["K"], bounds=kf["bounds"], log_scale_factor=kf["log_scale_factor"])
     m, pr = capi.project_search(g, cam, pts, th, kf["scale_factors"], skip=skip, gate_inv_sigma2=gi, gate=5.99, valid=valid)
     g.close()
     assert np.array_equal(pr["level"], pr_o[:, 3].astype(np.int32))
@@ -138,31 +138,26 @@ def test_fuse_and_sim3_searches(capi, oracle, seed):
     in_kf = np.isin(pts["id"], kf["mp"][kf["mp"] >= 0]).astype(np.uint8)
     valid = ((pts["bad"] == 0) & (in_kf == 0)).astype(np.uint8)
     p2 = dict(pts); p2["valid"] = valid
-    bi_o, bd_o, _ = oracle.project_search(kf["kps"], kf["desc"], kf["bounds"], None, kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], p2, 3.0,
+    bi_o, bd_o, _ = oracle.project_search(kf["kps"], kf["desc"], kf["bounds"], None, kf["Tcw"], oracle.se3_inverse(kf["Tcw"])[4:], kf["K"], p2, 3.0,
                                           kf["scale_factors"], kf["log_scale_factor"], kf["inv_level_sigma2"], 5.99)
     want = np.where((bi_o >= 0) & (bd_o <= 50), bi_o, -1)
     d = dict(kf); d["mp"] = kf["mp"].copy()
     n_g, bi_g = capi.fuse(capi.keyframe_view(d), P, in_kf, 3.0)
     assert np.array_equal(bi_g, want) and n_g == int((want >= 0).sum()) > 100
-    # Sim3 variants with a genuine similarity: Scw = (R, s*t_cw.., s)
-    s = np.float32(1.7)
-    R, tcw = kf["Rcw"], kf["tcw"]
-    t_sim = (tcw * s).astype(np.float32)
-    tcw2 = (t_sim / s).astype(np.float32)
-    R3 = R.reshape(3, 3)
-    Ow2 = np.array([-np.float32(np.float32(np.float32(R3[0, r] * tcw2[0]) + np.float32(R3[1, r] * tcw2[1])) + np.float32(R3[2, r] * tcw2[2]))
-                    for r in range(3)], np.float32)
-    nf_o, mp_o, rep_o = oracle.fuse_sim3(kf["kps"], kf["desc"], kf["bounds"], kf["mp"], kf["bad"], R, tcw2, Ow2, kf["K"], pts, 4.0,
+    # Sim3 variants with a genuine similarity: Scw = (s, R, s * tcw) as a Sophus::Sim3f; both sides decompose it themselves
+    s = 1.7
+    Scw = synth.sim3_from_sRt(s, kf["Rcw"].reshape(3, 3), kf["tcw"] * s)
+    nf_o, mp_o, rep_o = oracle.fuse_sim3(kf["kps"], kf["desc"], kf["bounds"], kf["mp"], kf["bad"], Scw, kf["K"], pts, 4.0,
                                          kf["scale_factors"], kf["log_scale_factor"])
     d = dict(kf); d["mp"] = kf["mp"].copy()
-    nf_g, rep_g = capi.fuse_sim3(capi.keyframe_view(d), R, t_sim, s, P, 4.0)
+    nf_g, rep_g = capi.fuse_sim3(capi.keyframe_view(d), Scw, P, 4.0)
     assert nf_g == nf_o > 100 and np.array_equal(rep_g, rep_o) and np.array_equal(d["mp"], mp_o)
     matched = np.where(np.random.default_rng(seed).random(len(kf["kps"])) < 0.3, kf["mp"], -1).astype(np.int32)
     for th, ratio in ((8, 1.0), (3, 0.8)):
-        nm_o, m_o = oracle.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, R, tcw2, Ow2, kf["K"], pts, th, ratio,
+        nm_o, m_o = oracle.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, Scw, kf["K"], pts, th, ratio,
                                                      kf["scale_factors"], kf["log_scale_factor"])
         d = dict(kf); d["mp"] = kf["mp"].copy()
-        nm_g, m_g, req = capi.search_by_projection_sim3(capi.keyframe_view(d), R, t_sim, s, P, matched, th, ratio)
+        nm_g, m_g, req = capi.search_by_projection_sim3(capi.keyframe_view(d), Scw, P, matched, th, ratio)
         assert nm_g == nm_o and np.array_equal(m_g, m_o)
         if th == 8:
             assert nm_o > 50 and req > 0, "scene must exercise the claimed-keypoint re-query"
@@ -178,8 +173,8 @@ def _per_keypoint_points(kf, pts):
 def test_search_by_sim3(capi, oracle, seed, s12, th):
     sc = make_kf_pair_scene(oracle, seed, mapped_frac=0.8)
     a, b = sc["kf"]
-    geo = oracle.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
-    R12, t12 = geo[0], geo[1]
+    geo = oracle.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
+    S12 = synth.sim3_from_sRt(s12, geo[0].reshape(3, 3), geo[1])
     p1, p2 = _per_keypoint_points(a, sc["pts"]), _per_keypoint_points(b, sc["pts"])
     rng = np.random.default_rng(seed)
     # a few matches known at entry (their KF2 index marks vbAlreadyMatched2)
@@ -188,9 +183,9 @@ def test_search_by_sim3(capi, oracle, seed, s12, th):
         j = np.nonzero((b["pt_of_kp"] == a["pt_of_kp"][i]) & (a["pt_of_kp"][i] >= 0))[0]
         if len(j) and a["mp"][i] >= 0:
             m_in[i] = a["mp"][i]; idx2[i] = j[0]
-    n_o, m_o = oracle.search_by_sim3(a, p1, b, p2, s12, R12, t12, th, m_in, idx2)
+    n_o, m_o = oracle.search_by_sim3(a, p1, b, p2, S12, th, m_in, idx2)
     va = capi.keyframe_view(dict(a, mp=a["mp"].copy())); vb = capi.keyframe_view(dict(b, mp=b["mp"].copy()))
-    n_g, m_g = capi.search_by_sim3(va, vb, capi.map_points_view(p1), capi.map_points_view(p2), m_in, idx2, s12, R12, t12, th)
+    n_g, m_g = capi.search_by_sim3(va, vb, capi.map_points_view(p1), capi.map_points_view(p2), m_in, idx2, S12, th)
     assert n_g == n_o and np.array_equal(m_g, m_o)
     if th > 5:
         assert n_o > 150
@@ -201,10 +196,11 @@ def test_search_by_projection_sim3_records_keyframes(capi, oracle):
     kf, pts = sc["kf"][1], sc["pts"]
     matched = np.full(len(kf["kps"]), -1, np.int32)
     point_kf = (np.arange(len(pts["pos"])) % 17 + 500).astype(np.int32)
-    nm_o, m_o = oracle.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], pts, 8, 1.0,
+    Scw = synth.sim3_from_sRt(1.0, kf["Rcw"].reshape(3, 3), kf["tcw"])
+    nm_o, m_o = oracle.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, Scw, kf["K"], pts, 8, 1.0,
                                                  kf["scale_factors"], kf["log_scale_factor"])
     v = capi.keyframe_view(dict(kf, mp=kf["mp"].copy()))
-    nm_g, m_g, _, mk = capi.search_by_projection_sim3(v, kf["Rcw"], kf["tcw"], 1.0, capi.map_points_view(pts), matched, 8, 1.0, point_kf=point_kf,
+    nm_g, m_g, _, mk = capi.search_by_projection_sim3(v, Scw, capi.map_points_view(pts), matched, 8, 1.0, point_kf=point_kf,
                                                       matched_kf=np.full(len(kf["kps"]), -1, np.int32))
     assert nm_g == nm_o and np.array_equal(m_g, m_o)
     hit = m_g >= 0
@@ -214,18 +210,16 @@ def test_search_by_projection_sim3_records_keyframes(capi, oracle):
 @pytest.mark.parametrize("seed,th,orb_dist,ori", [(0, 10.0, 100, True), (1, 3.0, 64, True), (2, 10.0, 100, False)])
 def test_search_by_projection_relocalisation(capi, oracle, seed, th, orb_dist, ori):
     """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): keyframe a's map points into frame b."""
-    import ctypes as C
     sc = make_kf_pair_scene(oracle, seed, mapped_frac=0.8, dup_frac=0.25)
     a, b = sc["kf"]
     pa = _per_keypoint_points(a, sc["pts"])
     rng = np.random.default_rng(seed)
     cur_mp = np.where(rng.random(len(b["kps"])) < 0.2, b["mp"], -1).astype(np.int32)      # some keypoints already matched
     already = np.unique(cur_mp[cur_mp >= 0])
-    n_o, m_o = oracle.search_by_projection_reloc(b["kps"], b["desc"], cur_mp, b["bounds"], b["Rcw"], b["tcw"], b["Ow"], b["K"], a, pa, already, th,
+    n_o, m_o = oracle.search_by_projection_reloc(b["kps"], b["desc"], cur_mp, b["bounds"], b["Tcw"], b["K"], a, pa, already, th,
                                                  orb_dist, b["scale_factors"], b["log_scale_factor"], ori)
     m_g = cur_mp.copy()
-    F = capi.frame_view(b["kps"], b["desc"], b["bounds"], b["scale_factors"], mp=m_g, K=b["K"])
-    F[0].Rcw = (C.c_float * 9)(*b["Rcw"]); F[0].tcw = (C.c_float * 3)(*b["tcw"])
+    F = capi.frame_view(b["kps"], b["desc"], b["bounds"], b["scale_factors"], mp=m_g, K=b["K"], Tcw=b["Tcw"])
     n_g, req = capi.search_by_projection_reloc(F, capi.keyframe_view(dict(a, mp=a["mp"].copy())), capi.map_points_view(pa), already, th, orb_dist, ori)
     assert n_g == n_o and np.array_equal(m_g, m_o)
     if th >= 10:

@@ -28,8 +28,8 @@ class OracleOps:
     def optimize_sim3(self, S12, P1c, P2c, o1, o2, w1, w2, K1, K2, th2):
         return self.po.optimize_sim3(S12, False, P1c, P2c, o1, o2, w1, w2, K1, K2, th2)
 
-    def search_by_sim3(self, a, pa, b, pb, m12, idx2, s, R, t, th):
-        return self.po.search_by_sim3(a, pa, b, pb, s, R, t, th, m12, idx2)
+    def search_by_sim3(self, a, pa, b, pb, m12, idx2, S12, th):
+        return self.po.search_by_sim3(a, pa, b, pb, S12, th, m12, idx2)
 
 
 @pytest.mark.parametrize("seed,s_w", [(0, 1.6), (1, 0.7), (2, 1.0)])

@@ -13,8 +13,8 @@ class OracleOps:
     def __init__(self, po):
         self.po = po
 
-    def search_by_projection(self, cur, last, mps, Rcw, tcw, K, bounds, scale, th):
-        return self.po.search_by_projection_frames(cur["kps"], cur["desc"], cur["mp"], Rcw, tcw, K, bounds, scale, last["kps"], last["mp"],
+    def search_by_projection(self, cur, last, mps, Tcw, K, bounds, scale, th):
+        return self.po.search_by_projection_frames(cur["kps"], cur["desc"], cur["mp"], Tcw, K, bounds, scale, last["kps"], last["mp"],
                                                    last.get("outlier"), mps, th, True)
 
     def pose_optimize(self, pose, Xw, obs, w, K):
@@ -22,6 +22,9 @@ class OracleOps:
 
     def frustum_frame(self):
         return self.po.FrustumFrame()
+
+    def pose_matrices(self, Tcw):
+        return self.po.pose_matrices(Tcw)
 
     def is_in_frustum(self, F, P, normal, dmin, dmax):
         return self.po.is_in_frustum(F, P, normal, dmin, dmax, 0.5)

@@ -2,6 +2,8 @@
 independent brute-force numpy definitions of what each function must return on scenes WITHOUT sequential conflicts, and
 for internal consistency (claims, mutual best) on scenes with them."""
 import numpy as np
+
+from dvm_slam_amd import synth
 import pytest
 
 from matcher_scene import make_init_scene, make_kf_pair_scene
@@ -81,7 +83,7 @@ def test_search_by_bow_with_conflicts_is_consistent():
 def test_search_for_triangulation_definition():
     sc = make_kf_pair_scene(po, seed=7)
     a, b = sc["kf"]
-    R12, t12, ep, F12 = po.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    R12, t12, ep, F12 = po.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
     # F12 against the double-precision definition
     R1, R2 = a["Rcw"].reshape(3, 3).astype(np.float64), b["Rcw"].reshape(3, 3).astype(np.float64)
     Rd = R1 @ R2.T; td = a["tcw"].astype(np.float64) - Rd @ b["tcw"].astype(np.float64)
@@ -110,7 +112,7 @@ def test_search_for_triangulation_definition():
 def test_project_search_and_fuse():
     sc = make_kf_pair_scene(po, seed=8)
     kf, pts = sc["kf"][1], sc["pts"]
-    bi, bd, pr = po.project_search(kf["kps"], kf["desc"], kf["bounds"], None, kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], pts, 3.0,
+    bi, bd, pr = po.project_search(kf["kps"], kf["desc"], kf["bounds"], None, kf["Tcw"], po.se3_inverse(kf["Tcw"])[4:], kf["K"], pts, 3.0,
                                    kf["scale_factors"], kf["log_scale_factor"], gate_inv_sigma2=kf["inv_level_sigma2"], gate=5.99)
     hit = bi >= 0
     assert hit.sum() > 300
@@ -133,11 +135,12 @@ def test_project_search_and_fuse():
         if best[1] >= 0:
             assert _ham(pts["desc"][i], kf["desc"][bi[i]]) == best[0]
     # the Sim3 variants: scale 1 similarity == the SE3 pose
-    nf, mp_new, rep = po.fuse_sim3(kf["kps"], kf["desc"], kf["bounds"], kf["mp"], kf["bad"], kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], pts, 4.0,
+    Scw = synth.sim3_from_sRt(1.0, kf["Rcw"].reshape(3, 3), kf["tcw"])
+    nf, mp_new, rep = po.fuse_sim3(kf["kps"], kf["desc"], kf["bounds"], kf["mp"], kf["bad"], Scw, kf["K"], pts, 4.0,
                                    kf["scale_factors"], kf["log_scale_factor"])
     assert nf > 100 and nf == int((rep >= 0).sum()) + int((mp_new != kf["mp"]).sum())
     matched = np.where(np.random.default_rng(1).random(len(kf["kps"])) < 0.3, kf["mp"], -1).astype(np.int32)
-    nm, m2 = po.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, kf["Rcw"], kf["tcw"], kf["Ow"], kf["K"], pts, 8, 1.0,
+    nm, m2 = po.search_by_projection_sim3(kf["kps"], kf["desc"], kf["bounds"], matched, Scw, kf["K"], pts, 8, 1.0,
                                           kf["scale_factors"], kf["log_scale_factor"])
     assert nm == int((m2 != matched).sum()) > 50
     new_ids = m2[m2 != matched]

@@ -197,14 +197,15 @@ def test_search_by_projection_frames_oracle_semantics(oracle):
     n, mp = po.search_by_projection_frames(th=15.0, check_ori=False, **sc)
     # brute force: for every valid last-frame map point, best current keypoint in the window, in order, with claims
     kc, dc, kl, mps = sc["kps_c"], sc["desc_c"], sc["kps_l"], sc["mps"]
-    R = sc["Rcw"].reshape(3, 3); t = sc["tcw"]; K = sc["K"]
+    K = sc["K"]
+    Xc_all = po.se3_act(sc["Tcw"], mps["pos"])     # the projection arithmetic itself is pinned in test_pose_arithmetic.py
     grid = po.Grid(kc)
     ref = np.full(len(kc), -1, np.int32); cnt = 0
     for i in range(len(kl)):
         if sc["mp_l"][i] < 0 or sc["outlier_l"][i]:
             continue
         X = mps["pos"][i]
-        xc = [np.float32(np.float32(np.float32(R[r, 0] * X[0]) + np.float32(R[r, 1] * X[1])) + np.float32(R[r, 2] * X[2])) + t[r] for r in range(3)]
+        xc = Xc_all[i]
         if xc[2] < 0:
             continue
         u = np.float32(np.float32(K[0] * xc[0]) / xc[2]) + K[2]; v = np.float32(np.float32(K[1] * xc[1]) / xc[2]) + K[3]

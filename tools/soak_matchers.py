@@ -34,7 +34,7 @@ def one_case(rng):
     F = capi.frame_view(b["kps"], b["desc"], b["bounds"], b["scale_factors"])
     n_g, m_g, _ = capi.search_by_bow_kf_frame(va, F, b["fv"], ratio, ori)
     if n_o != n_g or not np.array_equal(m_o, m_g): bad.append("bow_kf_frame")
-    geo = po.triangulation_geometry(a["Rcw"], a["tcw"], b["Rcw"], b["tcw"], a["K"], b["K"])
+    geo = po.triangulation_geometry(a["Tcw"], b["Tcw"], a["K"], b["K"])
     coarse = bool(rng.integers(0, 2))
     n_o, p_o = po.search_for_triangulation(a["kps"], a["desc"], a["mp"], a["fv"], b["kps"], b["desc"], b["mp"], b["fv"], geo[3], geo[2],
                                            b["scale_factors"], b["level_sigma2"], coarse, ori)
@@ -44,33 +44,31 @@ def one_case(rng):
     P = capi.map_points_view(pts)
     in_kf = np.isin(pts["id"], b["mp"][b["mp"] >= 0]).astype(np.uint8)
     p2 = dict(pts); p2["valid"] = ((pts["bad"] == 0) & (in_kf == 0)).astype(np.uint8)
-    bi_o, bd_o, _ = po.project_search(b["kps"], b["desc"], b["bounds"], None, b["Rcw"], b["tcw"], b["Ow"], b["K"], p2, th, b["scale_factors"],
+    bi_o, bd_o, _ = po.project_search(b["kps"], b["desc"], b["bounds"], None, b["Tcw"], po.se3_inverse(b["Tcw"])[4:], b["K"], p2, th, b["scale_factors"],
                                       b["log_scale_factor"], b["inv_level_sigma2"], 5.99)
     n_g, bi_g = capi.fuse(vb, P, in_kf, th)
     if not np.array_equal(bi_g, np.where((bi_o >= 0) & (bd_o <= 50), bi_o, -1)): bad.append("fuse")
-    s = np.float32(rng.uniform(0.5, 2.0))
-    t_sim = (b["tcw"] * s).astype(np.float32); tcw2 = (t_sim / s).astype(np.float32)
-    R3 = b["Rcw"].reshape(3, 3)
-    Ow2 = np.array([-np.float32(np.float32(np.float32(R3[0, r] * tcw2[0]) + np.float32(R3[1, r] * tcw2[1])) + np.float32(R3[2, r] * tcw2[2]))
-                    for r in range(3)], np.float32)
-    nf_o, mp_o, rep_o = po.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], b["Rcw"], tcw2, Ow2, b["K"], pts, th, b["scale_factors"],
+    s = float(rng.uniform(0.5, 2.0))
+    Scw = synth.sim3_from_sRt(s, b["Rcw"].reshape(3, 3), b["tcw"] * np.float32(s))   # a Sophus::Sim3f; both sides decompose it
+    nf_o, mp_o, rep_o = po.fuse_sim3(b["kps"], b["desc"], b["bounds"], b["mp"], b["bad"], Scw, b["K"], pts, th, b["scale_factors"],
                                      b["log_scale_factor"])
     d = dict(b, mp=b["mp"].copy())
-    nf_g, rep_g = capi.fuse_sim3(capi.keyframe_view(d), b["Rcw"], t_sim, s, P, th)
+    nf_g, rep_g = capi.fuse_sim3(capi.keyframe_view(d), Scw, P, th)
     if nf_o != nf_g or not np.array_equal(rep_o, rep_g) or not np.array_equal(mp_o, d["mp"]): bad.append("fuse_sim3")
     matched = np.where(rng.random(len(b["kps"])) < rng.uniform(0, 0.6), b["mp"], -1).astype(np.int32)
     rh = float(rng.choice([0.8, 1.0, 1.5]))
-    nm_o, mm_o = po.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], matched, b["Rcw"], tcw2, Ow2, b["K"], pts, int(th), rh,
+    nm_o, mm_o = po.search_by_projection_sim3(b["kps"], b["desc"], b["bounds"], matched, Scw, b["K"], pts, int(th), rh,
                                               b["scale_factors"], b["log_scale_factor"])
-    nm_g, mm_g, _ = capi.search_by_projection_sim3(vb, b["Rcw"], t_sim, s, P, matched, int(th), rh)
+    nm_g, mm_g, _ = capi.search_by_projection_sim3(vb, Scw, P, matched, int(th), rh)
     if nm_o != nm_g or not np.array_equal(mm_o, mm_g): bad.append("search_by_projection_sim3")
     idx = lambda kf: np.where(kf["pt_of_kp"] >= 0, kf["pt_of_kp"], 0).astype(np.int64)
     pk = lambda kf: dict(pos=pts["pos"][idx(kf)], normal=pts["normal"][idx(kf)], min_dist=pts["min_dist"][idx(kf)], max_dist=pts["max_dist"][idx(kf)],
                          desc=pts["desc"][idx(kf)])
     s12 = float(rng.uniform(0.8, 1.25))
     m_in = np.full(len(a["kps"]), -1, np.int32)
-    ns_o, ms_o = po.search_by_sim3(a, pk(a), b, pk(b), s12, geo[0], geo[1], th, m_in, None)
-    ns_g, ms_g = capi.search_by_sim3(va, vb, capi.map_points_view(pk(a)), capi.map_points_view(pk(b)), m_in, None, s12, geo[0], geo[1], th)
+    S12 = synth.sim3_from_sRt(s12, geo[0].reshape(3, 3), geo[1])
+    ns_o, ms_o = po.search_by_sim3(a, pk(a), b, pk(b), S12, th, m_in, None)
+    ns_g, ms_g = capi.search_by_sim3(va, vb, capi.map_points_view(pk(a)), capi.map_points_view(pk(b)), m_in, None, S12, th)
     if ns_o != ns_g or not np.array_equal(ms_o, ms_g): bad.append("search_by_sim3")
     si = make_init_scene(po, seed, n=int(rng.integers(50, 3000)), shift=float(rng.uniform(0, 30)), flip_bits=int(rng.integers(0, 40)))
     win = int(rng.choice([10, 30, 100]))
