@@ -332,7 +332,7 @@ def main():
         # (measured: 315 it/s cold vs 1050 it/s hot); the CPU baseline below leaves the GPU idle for ~12 s.
         if not a.no_ba:
             try:
-                from dvm_slam_amd import ba_bench
+                import ba_bench
                 out["ba"] = ba_bench.run(local, a.ba_iters, cpu_seconds=6.0 if a.cpu_seconds > 0 else 0.0)
             except ImportError:
                 out["ba"] = None

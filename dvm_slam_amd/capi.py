@@ -1022,6 +1022,8 @@ class HostKeyFrameDatabase:
         best = C.c_int32(-1); sc = C.c_float(0); base = C.c_float(0)
         r = self._f("detect_merge_possibility", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_uint64(uuid), C.c_int32(map_id), C.byref(best),
                                                            C.byref(sc), C.byref(base))
+        if r < 0:
+            check(r)
         return r, best.value, sc.value, base.value
 
     def detect_n_best(self, slot, n_num):

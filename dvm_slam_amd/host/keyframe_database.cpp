@@ -12,6 +12,8 @@ KeyFrameDatabase::KeyFrameDatabase(int device) {
 KeyFrameDatabase::~KeyFrameDatabase() { if (db_) dvm_bowdb_destroy(db_); }
 
 int KeyFrameDatabase::add(const BowVector& bow, int32_t map_id, uint64_t uuid, int64_t mnId) {
+  if (uuid == 0) return DVM_ERR_INVALID;
+  Lock l(mMutex_);
   std::vector<int32_t> ids;
   std::vector<double> vals;
   for (const auto& wv : bow) { ids.push_back((int32_t)wv.first); vals.push_back(wv.second); }
@@ -25,6 +27,7 @@ int KeyFrameDatabase::add(const BowVector& bow, int32_t map_id, uint64_t uuid, i
 }
 
 void KeyFrameDatabase::erase(int slot) {
+  Lock l(mMutex_);
   kfs_[slot].erased = true;
   dvm_bowdb_erase(db_, slot);
 }
@@ -50,6 +53,8 @@ std::vector<int32_t> KeyFrameDatabase::walk_order() const {
 
 int KeyFrameDatabase::CalculateMergeScore(const BowVector& bowVector, uint64_t keyFrameId, int32_t map_id, float& score,
                                           int32_t& bestKeyFrame) {
+  if (keyFrameId == 0) return DVM_ERR_INVALID;
+  Lock l(mMutex_);
   for (KF& k : kfs_)   // ResetPlaceRecognitionQuery(map)
     if (k.map_id == map_id && !k.erased) { k.query = 0; k.words = 0; k.score = 0; }
   const int rc = query_device(bowVector);
@@ -84,6 +89,7 @@ int KeyFrameDatabase::CalculateMergeScore(const BowVector& bowVector, uint64_t k
 
 int KeyFrameDatabase::DetectMergePossibility(const BowVector& bowVector, uint64_t uuid, int32_t map_id, int32_t& bestKeyFrame,
                                              float* score_out, float* baseline_out) {
+  Lock l(mMutex_);
   float score = 0;
   bestKeyFrame = -1;
   int rc = CalculateMergeScore(bowVector, uuid, map_id, score, bestKeyFrame);
@@ -102,6 +108,7 @@ int KeyFrameDatabase::DetectMergePossibility(const BowVector& bowVector, uint64_
 
 int KeyFrameDatabase::DetectNBestCandidates(int slot, std::vector<int32_t>& vpLoopCand, std::vector<int32_t>& vpMergeCand, int nNumCandidates) {
   vpLoopCand.clear(); vpMergeCand.clear();
+  Lock l(mMutex_);
   const KF pKF = kfs_[slot];
   const uint64_t qid = (uint64_t)pKF.mnId;
   const int rc = query_device(pKF.bow);

@@ -8,8 +8,16 @@
 // ordering the sharing keyframes by (first shared word, position in that word's inverted list = insertion order), which is
 // the order in which the walk meets them.  The per-keyframe query state (mnPlaceRecognitionQuery / Words / Score, stale
 // values included), the covisibility accumulation and the candidate selection are replayed on the host.
+//
+// Threading contract (same as the reference, which serialises add / erase / Detect* / CalculateMergeScore under mMutex because
+// LocalMapping, KeyFrame::SetBadFlag, LoopClosing and the wrapper's merge callback reach the database from different threads):
+// every public method takes the database's mutex for its whole duration, the device call included, so the device-side CSR
+// (re)allocation in add() can never run under a query kernel.  The dvm_bowdb handle must not be used behind the class's back.
+// uuid 0 is reserved: 0 is the reset value of mnPlaceRecognitionQuery (KeyFrame.cc:62), a query with id 0 would never enter
+// lKFsSharingWords -- add() and the queries return DVM_ERR_INVALID for it.
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -28,10 +36,10 @@ class KeyFrameDatabase {
   // void add(KeyFrame* pKF): returns the slot
   int add(const BowVector& bow, int32_t map_id, uint64_t uuid, int64_t mnId);
   void erase(int slot);
-  void SetBadFlag(int slot, bool bad) { kfs_[slot].bad = bad; }
-  void SetMapBad(int32_t map_id, bool bad) { if (bad) bad_maps_.insert(map_id); else bad_maps_.erase(map_id); }
-  void SetBestCovisibilityKeyFrames(int slot, const int32_t* neigh, int n) { kfs_[slot].neigh.assign(neigh, neigh + n); }
-  void SetConnectedKeyFrames(int slot, const int32_t* conn, int n) { kfs_[slot].connected = std::set<int32_t>(conn, conn + n); }
+  void SetBadFlag(int slot, bool bad) { Lock l(mMutex_); kfs_[slot].bad = bad; }
+  void SetMapBad(int32_t map_id, bool bad) { Lock l(mMutex_); if (bad) bad_maps_.insert(map_id); else bad_maps_.erase(map_id); }
+  void SetBestCovisibilityKeyFrames(int slot, const int32_t* neigh, int n) { Lock l(mMutex_); kfs_[slot].neigh.assign(neigh, neigh + n); }
+  void SetConnectedKeyFrames(int slot, const int32_t* conn, int n) { Lock l(mMutex_); kfs_[slot].connected = std::set<int32_t>(conn, conn + n); }
 
   // void CalculateMergeScore(DBoW2::BowVector bowVector, uuid, Map* map, float& score, KeyFrame*& bestKeyFrame)
   int CalculateMergeScore(const BowVector& bowVector, uint64_t uuid, int32_t map_id, float& score, int32_t& bestKeyFrame);
@@ -42,9 +50,11 @@ class KeyFrameDatabase {
   int DetectNBestCandidates(int slot, std::vector<int32_t>& vpLoopCand, std::vector<int32_t>& vpMergeCand, int nNumCandidates);
 
   struct State { uint64_t query; int32_t words; float score; };
-  State GetState(int slot) const { return {kfs_[slot].query, kfs_[slot].words, kfs_[slot].score}; }
+  State GetState(int slot) const { Lock l(mMutex_); return {kfs_[slot].query, kfs_[slot].words, kfs_[slot].score}; }
 
  private:
+  typedef std::lock_guard<std::recursive_mutex> Lock;   // recursive: DetectMergePossibility runs CalculateMergeScore twice
+  mutable std::recursive_mutex mMutex_;
   struct KF {
     BowVector bow;
     int32_t map_id = 0;

@@ -80,3 +80,56 @@ def test_concurrent_callers(capi, oracle, frames):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors
+
+
+def test_keyframe_database_concurrent_add_and_query(capi):
+    """dvm_host::KeyFrameDatabase under the reference's threading (LocalMapping adds / erases keyframes while LoopClosing and
+    the merge callback query): three threads on ONE database.  Queries against map 0 -- which nobody modifies -- must give the
+    same answer as on a quiet database, whatever map 1 is going through (reallocation of the device CSR included)."""
+    from kfdb_scene import fill, make_db_scene
+    kfs = make_db_scene(5, n_maps=2, kf_per_map=30, n_words=3000, words_per_kf=120)
+    quiet = capi.HostKeyFrameDatabase()
+    fill(quiet, kfs)
+    qs = [k for k in kfs if k["map_id"] == 1][:6]     # queries from map 1's keyframes against map 0
+    want = [quiet.detect_merge_possibility(q["ids"], q["vals"], q["uuid"], 0) for q in qs]
+    quiet.close()
+    db = capi.HostKeyFrameDatabase()
+    fill(db, kfs)
+    errors, stop = [], threading.Event()
+
+    def adder():
+        try:
+            rng = np.random.default_rng(1)
+            for it in range(400):
+                ids = np.unique(rng.integers(0, 3000, 400)).astype(np.int32)      # big vectors: force the CSR to grow
+                s = db.add(ids, rng.random(len(ids)), 1, int(rng.integers(1, 2 ** 62)), 1000 + it)
+                assert s >= 0
+                if it % 3 == 0:
+                    db.erase(s)
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+        finally:
+            stop.set()
+
+    def querier():
+        try:
+            while not stop.is_set():
+                for q, w in zip(qs, want):
+                    assert db.detect_merge_possibility(q["ids"], q["vals"], q["uuid"], 0) == w
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+            stop.set()
+
+    threads = [threading.Thread(target=adder), threading.Thread(target=querier), threading.Thread(target=querier)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    db.close()
+    assert not errors, errors
+    with pytest.raises(capi.DvmError):     # uuid 0 is the reset value of mnPlaceRecognitionQuery: rejected, not silently blind
+        db2 = capi.HostKeyFrameDatabase()
+        try:
+            db2.detect_merge_possibility(qs[0]["ids"], qs[0]["vals"], 0, 0)
+        finally:
+            db2.close()
