@@ -845,6 +845,14 @@ int orc_pose_graph_optimize(double* Sio, const uint8_t* fixed, int n, const int3
   int nBad = 0, it_done = 0, trials = 0, stop = 0;
   double chi_last = 0, chi_init = 0;
   std::vector<double> H((size_t)dim * dim), Hl, b(dim), x(dim);
+  std::vector<int> first(dim);   // envelope of the lower triangle
+  for (int r = 0; r < dim; r++) first[r] = r - r % 7;
+  for (int k = 0; k < E; k++) {
+    const int a = idx[ev[2 * k]], c = idx[ev[2 * k + 1]];
+    if (a < 0 || c < 0) continue;
+    const int hi = std::max(a, c), lo = std::min(a, c);
+    for (int r = 7 * hi; r < 7 * hi + 7; r++) first[r] = std::min(first[r], 7 * lo);
+  }
   for (int it = 0; it < iterations; it++) {
     double currentChi = chi_all(), tempChi = currentChi;
     const double iniChi = currentChi;
@@ -885,22 +893,25 @@ int orc_pose_graph_optimize(double* Sio, const uint8_t* fixed, int n, const int3
       std::vector<Sim3d> bak = S;   // push()
       Hl = H;
       for (int r = 0; r < dim; r++) Hl[(size_t)r * dim + r] += lambda;
-      bool ok = true;   // dense Cholesky + solve
-      for (int j = 0; j < dim && ok; j++) {
-        double dj = Hl[(size_t)j * dim + j];
-        for (int k = 0; k < j; k++) dj -= Hl[(size_t)j * dim + k] * Hl[(size_t)j * dim + k];
-        if (!(dj > 0)) { ok = false; break; }
-        dj = std::sqrt(dj);
-        Hl[(size_t)j * dim + j] = dj;
-        for (int r = j + 1; r < dim; r++) {
-          double v = Hl[(size_t)r * dim + j];
-          for (int k = 0; k < j; k++) v -= Hl[(size_t)r * dim + k] * Hl[(size_t)j * dim + k];
-          Hl[(size_t)r * dim + j] = v / dj;
+      // Cholesky + solve on the ENVELOPE of H (row r starts at its first structurally non-zero column): the skipped
+      // products are exact zeros of the dense factorisation, every kept sum runs over ascending k as before -> same bits
+      bool ok = true;
+      for (int r = 0; r < dim && ok; r++) {
+        double* Lr = &Hl[(size_t)r * dim];
+        for (int j = first[r]; j < r; j++) {
+          const double* Lj = &Hl[(size_t)j * dim];
+          double v = Lr[j];
+          for (int k = std::max(first[r], first[j]); k < j; k++) v -= Lr[k] * Lj[k];
+          Lr[j] = v / Lj[j];
         }
+        double dj = Lr[r];
+        for (int k = first[r]; k < r; k++) dj -= Lr[k] * Lr[k];
+        if (!(dj > 0)) { ok = false; break; }
+        Lr[r] = std::sqrt(dj);
       }
       if (ok) {
-        for (int r = 0; r < dim; r++) { double v = b[r]; for (int k = 0; k < r; k++) v -= Hl[(size_t)r * dim + k] * x[k]; x[r] = v / Hl[(size_t)r * dim + r]; }
-        for (int r = dim - 1; r >= 0; r--) { double v = x[r]; for (int k = r + 1; k < dim; k++) v -= Hl[(size_t)k * dim + r] * x[k]; x[r] = v / Hl[(size_t)r * dim + r]; }
+        for (int r = 0; r < dim; r++) { double v = b[r]; for (int k = first[r]; k < r; k++) v -= Hl[(size_t)r * dim + k] * x[k]; x[r] = v / Hl[(size_t)r * dim + r]; }
+        for (int r = dim - 1; r >= 0; r--) { double v = x[r]; for (int k = r + 1; k < dim; k++) if (first[k] <= r) v -= Hl[(size_t)k * dim + r] * x[k]; x[r] = v / Hl[(size_t)r * dim + r]; }
         for (int v = 0; v < n; v++) if (!fixed[v]) oplus(S[v], &x[7 * idx[v]]);
       }
       tempChi = ok ? chi_all() : std::numeric_limits<double>::max();
