@@ -495,8 +495,16 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   if (tid == 0) s_cnt_ini = 0;
   __syncthreads();
 
-  const int tlow = min(PD.ini_th, PD.min_th);
   const uint8_t* T = tile + sh;
+  // Two thresholds, like the reference: FAST(iniThFAST) first, the whole cell again at minThFAST only if that found nothing.
+  // Pass 0 runs the pre-test and the strength network at t = iniTh: a strict local maximum p with S(p) >= iniTh beats every
+  // neighbour whose score is below iniTh whether that score is known or counted as 0, so the maxima found among the
+  // S >= iniTh pixels are exactly cv::FAST(iniTh, nms) -- and far fewer pixels survive the pre-test than at t = minTh
+  // (the strength network, ~150 instructions per survivor, is where this kernel's time goes).  Pass 1 (rare: flat cells,
+  // where few pixels survive anyway) repeats A-C at t = minTh; the scores already in the map stay valid (same values).
+  int tlow = PD.ini_th;
+  int total = 0;
+  for (int pass = 0; pass < 2; pass++) {
   // ---- A. compass pre-test.  One item = one LDS dword column of one row = 4 pixels: north / south / centre
   // dwords plus west / east dwords give all five bytes of each pixel; v_perm_b32 zero-extends byte pairs to
   // packed u16, the test itself is 9 packed min/max per pixel pair:
@@ -604,7 +612,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
       const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
       const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
                          max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
-      if (sv > mx) fl = (sv >= PD.ini_th ? 1 : 0) | (sv >= PD.min_th ? 2 : 0);
+      if (sv > mx) fl = 1;    // every corner of this pass has sv >= tlow + 0: score = max(A,B) - 1 >= tlow
     }
     cnt_ini += fl & 1;
     if (r < 16) flags_lo |= (uint32_t)fl << (2 * r);
@@ -612,7 +620,15 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   }
   if (cnt_ini) atomicAdd(&s_cnt_ini, cnt_ini);
   __syncthreads();
-  const int bit = (s_cnt_ini > 0) ? 1 : 2;  // first call non-empty -> keep it, else the retry's result
+  if (s_cnt_ini == 0) {   // workgroup-uniform: nothing at this threshold
+    if (pass == 0 && PD.min_th < PD.ini_th) {
+      tlow = PD.min_th;
+      __syncthreads();      // everyone has read s_cnt_ini / the lists before they are rebuilt
+      continue;
+    }
+    break;
+  }
+  const int bit = 1;
   // ordered compaction: wave lists in wave order, inside a list in list order = row-major
   int kept = 0;
   for (int r = 0; r < rounds; r++) {
@@ -621,7 +637,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   }
   if (lane == 0) s_tot[wave] = kept;
   __syncthreads();
-  int base = 0, total = 0;
+  int base = 0;
 #pragma unroll
   for (int w = 0; w < NW; w++) { if (w < wave) base += s_tot[w]; total += s_tot[w]; }
   uint32_t* out = cand + (int64_t)f * PD.cand_frame_slots + c.cand_base;
@@ -637,6 +653,8 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
       out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), myscore[k]);
     }
     base += __popcll(m);
+  }
+    break;
   }
   if (tid == 0) *my_count = min(total, c.cand_cap);
 }
