@@ -57,7 +57,27 @@ struct BaView {
   const int32_t* colstrips;     // per column: its strip rows
   const int32_t *h_level_off, *h_strip_off, *h_tgt_off;  // HOST arrays [nlevels+1]
   int32_t nlevels;
-  const double* lambda;     // device scalar: current LM damping (so the per-trial launch sequence is a replayable graph)
+  const double* lambda;     // device scalar with the current LM damping (pose graph), or null: use lambda_v
+  double lambda_v;          // LM damping by value (bundle adjustment: no H2D copy per trial)
+  double *poses_new, *points_new;   // trial state: k_update writes exp(dx) * poses -> poses_new, points + dx -> points_new; an
+                                    // accepted trial swaps the pointers on the host, a rejected one leaves (poses, points) alone
+                                    // -- g2o's push() / pop() / discardTop() without copies
+};
+
+// How a phase-ending kernel hands its scalar to the host without a D2H copy + stream synchronisation: the LAST workgroup to
+// finish (arrival counter) sums the per-workgroup partials in the fixed order of k_reduce_sum and stores the result into
+// page-locked host memory mapped into the device; with `publish` it then copies the Cholesky failure flag and releases
+// `seq` (system scope), which the host is spinning on.
+struct BaPublish {
+  double* dev_vals;               // device memory [8]: every phase result lands here first (visible to later kernels)
+  double* host_vals;              // mapped host memory [8]: the publishing workgroup copies dev_vals[0..5] + the failure flag
+                                  // here itself, right before releasing `seq` -- one writer, one ordered stream of stores
+  unsigned long long* host_seq;   // mapped host memory
+  unsigned long long seq;
+  unsigned int* counter;          // device arrival counter (reset by the last workgroup)
+  const int* d_fail;              // device: Cholesky failure flag of this trial (copied to host_vals[6] on publish), may be null
+  int slot;
+  int publish;
 };
 
 // Sim3 pose graph (Optimizer::OptimizeEssentialGraph numerics): vertex states + EdgeSim3 list + block structure.
@@ -81,11 +101,13 @@ void pg_launch_edge_eval(hipStream_t s, const PgView& G, bool jac, double* d_sca
 void pg_launch_build(hipStream_t s, const PgView& G, const BaView& T);
 void pg_launch_update(hipStream_t s, const PgView& G, const BaView& T, double* d_scalars, int slot_scale);
 
-void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, double* d_scalars, int slot);
-void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot_maxdiag);
-void ba_launch_schur(hipStream_t s, const BaView& V);
+// jac: linearise at (poses, points); !jac: chi2 only, at the trial state (poses_new, points_new)
+void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPublish& pub);
+void ba_launch_accum(hipStream_t s, const BaView& V);
+void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub);
+void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail);
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail);
-void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale);
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub);
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
 void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const double* P1c, const double* P2c,
                              const double* obs1, const double* obs2, const double* w1, const double* w2, int N,

@@ -105,18 +105,69 @@ __device__ __forceinline__ void robustify(double e, double delta, double& rho0, 
   else { const double s = sqrt(e); rho0 = 2 * s * delta - delta * delta; rho1 = delta / s; }
 }
 
+__device__ __forceinline__ double ba_lambda(const BaView& V) { return V.lambda ? *V.lambda : V.lambda_v; }
+
+// Block sum of `v` -> partial[blockIdx.x]; the last workgroup to arrive then reduces all partials exactly like
+// k_reduce_sum (thread-strided sums, then the same tree: identical bits) and hands the result to the host (BaPublish).
+template <bool MAX>
+__device__ __forceinline__ void block_reduce_publish(double v, double* __restrict__ partial, const BaPublish& pub) {
+  __shared__ double s_red[256];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, nb = gridDim.x;
+  s_red[tid] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) s_red[tid] = MAX ? fmax(s_red[tid], s_red[tid + off]) : s_red[tid] + s_red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    // 8-byte agent-scope (write-through) store of the partial, drained before the arrival is counted: whoever sees the
+    // count can read the partial with an agent-scope load.  No release fence: that would write back this XCD's whole L2
+    // (the edge pass has just dirtied megabytes) once per workgroup -- measured 23 -> 58 us on k_edge_eval.
+    __hip_atomic_store(partial + blockIdx.x, s_red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(pub.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nb - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double acc = 0;
+  for (int i = tid; i < nb; i += 256) {
+    const double p = __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = MAX ? fmax(acc, p) : acc + p;
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) s_red[tid] = MAX ? fmax(s_red[tid], s_red[tid + off]) : s_red[tid] + s_red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __hip_atomic_store(pub.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pub.dev_vals + pub.slot, s_red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pub.publish) {
+      // results of earlier kernels of this phase (other slots) are in dev_vals: kernel boundaries made them visible
+      for (int i = 0; i < 6; i++) {
+        const double v = (i == pub.slot) ? s_red[0] : __hip_atomic_load(pub.dev_vals + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pub.host_vals + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      const int f = pub.d_fail ? __hip_atomic_load(pub.d_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      __hip_atomic_store(pub.host_vals + 6, (double)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(pub.host_seq, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K8
 // JAC=false: residual / chi2 only (computeActiveErrors + activeRobustChi2 terms).
 // JAC=true : additionally Jacobians A (2x3, point), B (2x6, pose), weights and Hpl block W (6x3).
 template <bool JAC>
-__global__ void __launch_bounds__(256) k_edge_eval(BaView V) {
-  __shared__ double s_part[256];
+__global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   double rho0 = 0;
   if (k < V.E) {
     const int p = V.e_pose[k], l = V.e_point[k];
-    const double* T = V.poses + 7 * (size_t)p;
-    const double* X = V.points + 3 * (size_t)l;
+    const double* T = (JAC ? V.poses : V.poses_new) + 7 * (size_t)p;     // chi2-only evaluations look at the TRIAL state
+    const double* X = (JAC ? V.points : V.points_new) + 3 * (size_t)l;
     double R[9], Xc[3];
     quat_to_R(T + 3, R);
     mat3_vec(R, X, Xc);
@@ -157,14 +208,7 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V) {
         for (int b = 0; b < 3; b++) W[3 * a + b] = pose_free ? w * (B[a] * A[b] + B[6 + a] * A[3 + b]) : 0.0;
     }
   }
-  // fixed-order block reduction of rho0 -> partial[blockIdx.x]
-  s_part[threadIdx.x] = rho0;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) V.partial[blockIdx.x] = s_part[0];
+  block_reduce_publish<false>(rho0, V.partial, pub);   // fixed-order sum of rho0 over all edges -> host
 }
 
 // Sum `n` partials in a fixed order into out[slot]; single workgroup.
@@ -242,26 +286,18 @@ __global__ void __launch_bounds__(256) k_pose_accum(BaView V) {
   }
 }
 
-// max |diag| over Hpp and Hll -> out[slot] (computeLambdaInit); single workgroup.
-__global__ void __launch_bounds__(256) k_max_diag(BaView V, double* out, int slot) {
-  __shared__ double s[256];
+// max |diag| over Hpp and Hll (computeLambdaInit) -> host, grid-wide with the last workgroup finishing the reduction.
+__global__ void __launch_bounds__(256) k_max_diag(BaView V, BaPublish pub) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
   double m = 0;
-  for (int i = threadIdx.x; i < V.nfree * 6; i += 256) m = fmax(m, fabs(V.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
-  for (int i = threadIdx.x; i < V.L * 3; i += 256)
-    if (V.pt_start[i / 3 + 1] > V.pt_start[i / 3]) m = fmax(m, fabs(V.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
-  s[threadIdx.x] = m;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[slot] = s[0];
+  if (i < V.nfree * 6) m = fabs(V.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]);
+  if (i < V.L * 3 && V.pt_start[i / 3 + 1] > V.pt_start[i / 3]) m = fmax(m, fabs(V.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+  block_reduce_publish<true>(m, V.partial2, pub);
 }
 
 // ------------------------------------------------------------------------------------------ K9
-__global__ void __launch_bounds__(256) k_dinv(BaView V) {
-  const double lambda = *V.lambda;
-  const int l = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void dinv_landmark(const BaView& V, int l) {
+  const double lambda = ba_lambda(V);
   if (l >= V.L) return;
   if (V.pt_start[l + 1] == V.pt_start[l]) return;  // landmark without observation: not a vertex of the graph
   const double* H = V.Hll + 9 * (size_t)l;
@@ -278,12 +314,13 @@ __global__ void __launch_bounds__(256) k_dinv(BaView V) {
   db[1] = D[3] * bl[0] + D[4] * bl[1] + D[5] * bl[2];
   db[2] = D[6] * bl[0] + D[7] * bl[1] + D[8] * bl[2];
 }
+__global__ void __launch_bounds__(256) k_dinv(BaView V) { dinv_landmark(V, blockIdx.x * 256 + threadIdx.x); }
 
 // One wave per non-zero lower block (i1 >= i2) of the reduced camera matrix:
 //   S[i1,i2] = Hpp[i1] (+lambda I) if i1 == i2  -  sum over co-observed landmarks of W1 Dinv W2^T
 // `pairs` lists (edge of pose i1, edge of pose i2) per block (symbolic structure built once on host).
 __global__ void __launch_bounds__(256) k_schur_blocks(BaView V) {
-  const double lambda = *V.lambda;
+  const double lambda = ba_lambda(V);
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= V.nblk) return;
@@ -364,6 +401,29 @@ __global__ void __launch_bounds__(256) k_pad_identity(BaView V) {
   if (w >= V.per_tile * V.dof || (r >> 6) * V.per_tile + w / V.dof >= V.nfree) V.S[(size_t)r * V.ldS + r] = 1.0;
 }
 
+// Start of a BA trial in ONE launch: workgroups [0, nb_dinv) invert the damped landmark blocks (k_dinv), the others clear one
+// structurally non-zero tile each (k_zero_tiles) and put the identity on the padding rows of the diagonal tiles
+// (k_pad_identity); the Cholesky failure flag is reset on the way.
+__global__ void __launch_bounds__(256) k_trial_prologue(BaView V, int nb_dinv, int* __restrict__ fail) {
+  if ((int)blockIdx.x < nb_dinv) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fail = 0;
+    dinv_landmark(V, blockIdx.x * 256 + threadIdx.x);
+    return;
+  }
+  const int t = blockIdx.x - nb_dinv;
+  const int ti = V.nz_tiles[2 * t], tj = V.nz_tiles[2 * t + 1];
+  double* base = V.S + (size_t)ti * 64 * V.ldS + tj * 64;
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int r = i >> 5, c2 = i & 31;
+    reinterpret_cast<double2*>(base + (size_t)r * V.ldS)[c2] = make_double2(0.0, 0.0);
+  }
+  if (ti == tj && ti * 64 < V.n_pad) {
+    __syncthreads();
+    const int w = threadIdx.x;
+    if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = 1.0;
+  }
+}
+
 // ----------------------------------------------------------------------------------------- K10
 // Tile Cholesky of the lower triangle of S (row-major, leading dim ldS), NB = 64, over n1 = n_pad + 1 rows: the
 // extra row carries bschur^T, so after the factorisation row n_pad holds y^T with L y = bschur (forward
@@ -392,8 +452,15 @@ constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
 // then Linv by block forward substitution, Linv_ij = -Linv_ii * sum_k L_ik Linv_kj, again on MFMA: the
 // C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly its B-operand
 // layout for k-step = reg, so the running sum feeds the next product without touching LDS.
+#ifdef DVM_CHOL_DEBUG
+__device__ long long g_chol_dbg[32];
+#define DVM_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DVM_STAMP(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, const int32_t* __restrict__ cols,
                                                   int* __restrict__ fail, double* __restrict__ Linv_all) {
+  DVM_STAMP(0);
   const int kb = cols[blockIdx.x];
   __shared__ double Bm[NB * LP];
   __shared__ double Li[NB * LP];
@@ -401,84 +468,120 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = kb * NB;
   const int kw = min(NB, n1 - k0);
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    double v = (r == c) ? 1.0 : 0.0;  // rows / columns beyond the matrix: identity
-    if (r < kw && c <= r) v = S[(size_t)(k0 + r) * ldS + k0 + c];
-    Bm[r * LP + c] = v;
-    Li[r * LP + c] = 0.0;
+  {
+    // the whole tile with 8 independent 16-byte loads per thread, issued back to back (a load per loop iteration behind a
+    // branch serialised 16 global round trips: ~13 of the kernel's 27 us); rows beyond the matrix are clamped and replaced
+    double2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+      v[i] = *reinterpret_cast<const double2*>(S + (size_t)(k0 + min(r, kw - 1)) * ldS + k0 + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+      const bool in = r < kw;
+      Bm[r * LP + c] = (in && c <= r) ? v[i].x : (r == c ? 1.0 : 0.0);          // rows / columns beyond the matrix: identity
+      Bm[r * LP + c + 1] = (in && c + 1 <= r) ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
+      Li[r * LP + c] = 0.0;
+      Li[r * LP + c + 1] = 0.0;
+    }
   }
   __syncthreads();
+  DVM_STAMP(1);
   const int lr = lane & 15, lq = lane >> 4;
-  __shared__ double s_rinv[16];
+  __shared__ double s_rinv[4][16];
+  __shared__ double Pcol[16][NB];      // the panel's finished columns, one row per column: broadcast source for the updates
+  // inverse of the 16x16 diagonal sub-block bb (needed by the L^-1 assembly at the end), one wave: column `lane` of the
+  // inverse by forward substitution, L_it straight from LDS (uniform address = broadcast read)
+  auto invert_block = [&](int bb) {
+    const int ob = 16 * bb;
+    double y[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < i; t++) {
+        const double l = Bm[(ob + i) * LP + ob + t];
+        if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
+      }
+      y[i] = (s0 + s1) * s_rinv[bb][i];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const double v = (lane <= i) ? y[i] : 0.0;
+        Iv[bb][i][lane] = v;
+        Li[(ob + i) * LP + ob + lane] = v;
+      }
+    }
+  };
+  // finished block column bb of L (rows 16 bb .. 63) -> global, by two waves (128 threads)
+  auto store_panel = [&](int bb, int t, int nt) {
+    const int ob = 16 * bb;
+    for (int i = t; i < (NB - ob) * 16; i += nt) {
+      const int r = ob + (i >> 4), c = ob + (i & 15);
+      if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Bm[r * LP + c];
+    }
+  };
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
+    DVM_STAMP(2 + 3 * b);
     if (wave == 0) {
-      // ---- A: the whole 16-column PANEL (diagonal sub-block + every row below it) in registers, lane = panel row.
-      // Column j: s_r = a_rj - sum_{k<j} a_rk L_jk with L_jk broadcast from lane j by v_readlane; the rows below the
-      // diagonal sub-block ride along in the same instructions, so no separate triangular solve is needed.
+      // ---- A: the whole 16-column PANEL (diagonal sub-block + every row below it) in registers, lane = panel row;
+      // the rows below the diagonal sub-block ride along in the same instructions (no separate triangular solve).
+      // Right-looking: a finished column j updates every later column c of every row, a_c -= L_ij * L_cj.  The factor
+      // L_cj is the same for all lanes: column j is published to LDS once and read back with uniform-address (broadcast)
+      // reads -- except for c = j + 1, the next pivot column, which gets it by v_readlane.  Measured per 16-column panel
+      // (cycle stamps, 2.4 GHz): 7 400 cycles with every L_cj by v_readlane, 6 080 this way, 10 200 when the updates are
+      // pinned in program order (each then waits out the LDS round trip); the compiler schedules the updates of a column
+      // lazily, right before that column's pivot, which keeps LDS latency off the chain.
       double a[16];
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = (lane < nrows && (lane >= 16 || c <= lane)) ? Bm[(o + lane) * LP + o + c] : 0.0;
       bool bad = false;
+      double lprev = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
-        // L_jk, k < j - 1: finished columns were published to LDS (all lanes read one address: a broadcast read, and the
-        // reads pipeline); only the column finished in the previous step comes by v_readlane, so no step waits on LDS
-        double s0 = a[j], s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < j; k++) {
-          const double t = (k == j - 1) ? bcast_lane(a[k], j) : Bm[(o + j) * LP + o + k];
-          if (k & 1) s1 = __builtin_fma(-a[k], t, s1); else s0 = __builtin_fma(-a[k], t, s0);
-        }
-        const double s = s0 + s1;
-        const double d = bcast_lane(s, j);
+        const double d = bcast_lane(a[j], j);
         if (!(d > 0.0)) bad = true;
         const double dd = d > 0.0 ? d : 1.0;
         double y = __builtin_amdgcn_rsq(dd);     // 1 / L_jj: v_rsq_f64 + two Newton steps instead of sqrt and divisions
+        if (j >= 1) {                            // deferred updates of column j - 1 (columns j + 1 .. 15)
+#pragma unroll
+          for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lprev, Pcol[j - 1][c], a[c]);
+        }
         y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
         y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+        const double lj = lane > j ? a[j] * y : 0.0;
+        Pcol[j][lane] = lj;
+        if (j + 1 < 16) a[j + 1] = __builtin_fma(-lj, bcast_lane(lj, j + 1), a[j + 1]);
         double sq = dd * y;
         sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);   // sqrt(dd) to the last bit or one ulp
-        if (lane == 0) s_rinv[j] = y;
-        a[j] = (lane == j) ? sq : (lane > j ? s * y : 0.0);
-        if (lane < nrows) Bm[(o + lane) * LP + o + j] = a[j];          // publish column j
+        if (lane == 0) s_rinv[b][j] = y;
+        a[j] = (lane == j) ? sq : lj;
+        lprev = lj;
+      }
+      if (lane < nrows) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (lane < 16 && c > lane) ? 0.0 : a[c];
       }
       if (bad && lane == 0) *fail = 1;
-      if (lane < 16) {   // zero the strict upper part of the diagonal sub-block
-#pragma unroll
-        for (int c = 1; c < 16; c++) if (c > lane) Bm[(o + lane) * LP + o + c] = 0.0;
-      }
+    } else if (b >= 1) {
+      // the other waves are idle during the panel: one inverts the previous diagonal sub-block, two send the previous
+      // block column of L home
+      if (wave == 3) invert_block(b - 1);
+      else store_panel(b - 1, tid - 64, 128);
     }
+    DVM_STAMP(3 + 3 * b);
     __syncthreads();
-    if (wave == 3) {
-      // ---- inverse of the 16x16 diagonal sub-block (needed by the L^-1 assembly below, not by this loop): off the
-      // critical path, on the wave that has no trailing update to do
-      double y[16];   // column `lane` of the inverse; L_it comes straight from LDS (uniform address = broadcast read)
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-        for (int t = 0; t < i; t++) {
-          const double l = Bm[(o + i) * LP + o + t];
-          if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
-        }
-        y[i] = (s0 + s1) * s_rinv[i];
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const double v = (lane <= i) ? y[i] : 0.0;
-          Iv[b][i][lane] = v;
-          Li[(o + i) * LP + o + lane] = v;
-        }
-      }
-    } else {
-      // ---- C: trailing sub-blocks (i >= j > b), round-robin over waves 0..2
+    DVM_STAMP(4 + 3 * b);
+    if (b < 3) {
+      // ---- C: trailing sub-blocks (i >= j > b), round-robin over the four waves
       int pair = 0;
       for (int i = b + 1; i < 4; i++)
         for (int j = b + 1; j <= i; j++, pair++) {
-          if (pair % 3 != wave) continue;
+          if ((pair & 3) != wave) continue;
           const int oi = 16 * i, oj = 16 * j;
           double4_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -487,13 +590,13 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 #pragma unroll
           for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
         }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Bm[r * LP + c];
-  }
+  if (wave == 3) invert_block(3);
+  else store_panel(3, tid, 192);
+  __syncthreads();
+  DVM_STAMP(14);
   // ---- Linv: wave j builds block column j top-down
   if (wave < 3) {
     const int j = wave;
@@ -513,91 +616,84 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       __builtin_amdgcn_wave_barrier();
     }
   }
+  DVM_STAMP(15);
   __syncthreads();
+  DVM_STAMP(16);
   double* Lo = Linv_all + (size_t)kb * NB * NB;
   for (int i = tid; i < NB * NB; i += 256) Lo[i] = Li[(i >> 6) * LP + (i & 63)];
+  DVM_STAMP(17);
 }
+#ifdef DVM_CHOL_DEBUG
+extern "C" int dvm_debug_chol_stamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_dbg), sizeof(long long) * 32); }
+#endif
 
 
 // Panel solve of step kb: strip i (64 rows below the diagonal block) becomes X = A_ik * Linv_kk^T
-// (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM.
+// (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM.  One workgroup per 32x32 QUADRANT of
+// the strip (grid = 4 x strips), each wave one 16x16 block: an f64 MFMA occupies its SIMD for 64 cycles, so a whole tile on
+// one workgroup is 1.7 us of matrix pipe alone; spread over four CUs the product leaves the critical path of the level.
+constexpr int QP = 66;   // LDS pitch (doubles) of a 32x64 half strip: conflict-free for the MFMA operand reads
 __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1,
                                                    const double* __restrict__ Linv_all, const int32_t* __restrict__ strips) {
-  __shared__ double Ai[NB][NB + 1];
-  __shared__ double Li[NB][NB + 1];
+  __shared__ double Ai[32 * QP];
+  __shared__ double Li[32 * QP];
   const int tid = threadIdx.x;
-  const int kb = strips[2 * blockIdx.x + 1];
+  const int st = blockIdx.x >> 2, qi = (blockIdx.x & 2) * 16, qj = (blockIdx.x & 1) * 32;
+  const int kb = strips[2 * st + 1];
   const int k0 = kb * NB;
-  const int r0 = strips[2 * blockIdx.x] * NB;  // tile row of a structurally non-zero strip of column kb
+  const int r0 = strips[2 * st] * NB;  // tile row of a structurally non-zero strip of column kb
   const int rw = min(NB, n1 - r0);
   const double* Lk = Linv_all + (size_t)kb * NB * NB;
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i / NB, c = i % NB;
-    Ai[r][c] = (r < rw) ? S[(size_t)(r0 + r) * ldS + k0 + c] : 0.0;
-    Li[r][c] = Lk[i];
+  for (int i = tid; i < 32 * NB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    Ai[r * QP + c] = (qi + r < rw) ? S[(size_t)(r0 + qi + r) * ldS + k0 + c] : 0.0;
+    Li[r * QP + c] = Lk[(qj + r) * NB + c];
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
-  const int qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
-  double4_t acc[2][2];
-#pragma unroll
-  for (int x = 0; x < 2; x++)
-#pragma unroll
-    for (int y = 0; y < 2; y++) acc[x][y] = (double4_t){0, 0, 0, 0};
+  const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
   const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll 4
-  for (int k = 0; k < NB; k += 4) {
-    const double a0 = Ai[qi + lr][k + lk], a1 = Ai[qi + 16 + lr][k + lk];
-    const double b0 = Li[qj + lr][k + lk], b1 = Li[qj + 16 + lr][k + lk];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
+  double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < NB; k += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(wi + lr) * QP + k + lk], Li[(wj + lr) * QP + k + lk], acc, 0, 0, 0);
   const int kw = min(NB, n1 - k0);
 #pragma unroll
-  for (int x = 0; x < 2; x++)
-#pragma unroll
-    for (int y = 0; y < 2; y++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = qi + 16 * x + (lane >> 4) + 4 * r, col = qj + 16 * y + (lane & 15);
-        if (row < rw && col < kw) S[(size_t)(r0 + row) * ldS + k0 + col] = acc[x][y][r];
-      }
+  for (int r = 0; r < 4; r++) {
+    const int row = qi + wi + lk + 4 * r, col = qj + wj + lr;
+    if (row < rw && col < kw) S[(size_t)(r0 + row) * ldS + k0 + col] = acc[r];
+  }
 }
 
-// Trailing update A_ij -= sum_k A_ik A_jk^T for one 64x64 tile (ti >= tj) and the columns k of the current level
-// that reach it (contrib[c0..c1), ascending: fixed summation order).  4 waves, each owning a 32x32 quadrant = 2x2
-// MFMA tiles of v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
-// C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg).
+// Trailing update A_ij -= sum_k A_ik A_jk^T for one 32x32 QUADRANT of a 64x64 tile (ti >= tj) and the columns k of the
+// current level that reach it (contrib[c0..c1), ascending: fixed summation order).  grid = 4 x targets; 4 waves, each one
+// 16x16 block of the quadrant (v_mfma_f64_16x16x4_f64: A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
+// C/D: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg).  The half strips of contributor c+1 travel global ->
+// registers while contributor c is on the matrix pipe.
 __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int ldS, int n1,
                                                      const int32_t* __restrict__ targets, const int32_t* __restrict__ contrib) {
-  __shared__ double Ai[NB][NB + 1];
-  __shared__ double Aj[NB][NB + 1];
-  const int ti = targets[4 * blockIdx.x], tj = targets[4 * blockIdx.x + 1];
-  const int c0 = targets[4 * blockIdx.x + 2], c1 = targets[4 * blockIdx.x + 3];
-  const int i0 = ti * NB, j0 = tj * NB;
-  const int iw = min(NB, n1 - i0), jw = min(NB, n1 - j0);
+  __shared__ double Ai[32 * QP];
+  __shared__ double Aj[32 * QP];
+  const int tg = blockIdx.x >> 2, qi = (blockIdx.x & 2) * 16, qj = (blockIdx.x & 1) * 32;
+  const int ti = targets[4 * tg], tj = targets[4 * tg + 1];
+  const int c0 = targets[4 * tg + 2], c1 = targets[4 * tg + 3];
+  if (ti == tj && qj > qi) return;   // strictly upper quadrant of a diagonal tile
+  const int i0 = ti * NB + qi, j0 = tj * NB + qj;
+  const int iw = min(32, n1 - i0), jw = min(32, n1 - j0);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
-  const bool idle = (ti == tj && qj > qi);  // strictly upper quadrant of a diagonal tile
-  double4_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = (double4_t){0, 0, 0, 0};
+  const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+  double4_t acc = {0, 0, 0, 0};
   const int lr = lane & 15, lk = lane >> 4;
-  // software pipeline: the two strips of contributor c+1 travel global -> registers while contributor c is on the MFMAs
-  // thread t owns elements (row 4k + t / 64, column t % 64), k = 0..15: every load instruction covers 4 full rows
+  // thread t owns elements (row 4k + t / 64, column t % 64), k = 0..7: every load instruction covers 4 full rows
   const int pr = tid >> 6, pc = tid & 63;
-  double ra[16], rb[16];
+  double ra[8], rb[8];
   auto fetch = [&](int c) {
     const int k0 = contrib[c] * NB;
     const double* ga = S + (size_t)(i0 + pr) * ldS + k0 + pc;
     const double* gb = S + (size_t)(j0 + pr) * ldS + k0 + pc;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 8; k++) {
       ra[k] = (4 * k + pr < iw) ? ga[(size_t)4 * k * ldS] : 0.0;
       rb[k] = (4 * k + pr < jw) ? gb[(size_t)4 * k * ldS] : 0.0;
     }
@@ -606,30 +702,18 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
   for (int c = c0; c < c1; c++) {
     if (c > c0) __syncthreads();          // the previous contributor's MFMAs have read Ai / Aj
 #pragma unroll
-    for (int k = 0; k < 16; k++) { Ai[4 * k + pr][pc] = ra[k]; Aj[4 * k + pr][pc] = rb[k]; }
+    for (int k = 0; k < 8; k++) { Ai[(4 * k + pr) * QP + pc] = ra[k]; Aj[(4 * k + pr) * QP + pc] = rb[k]; }
     __syncthreads();
     if (c + 1 < c1) fetch(c + 1);
-    if (idle) continue;
-#pragma unroll 4
-    for (int k = 0; k < NB; k += 4) {
-      double a0 = Ai[qi + lr][k + lk], a1 = Ai[qi + 16 + lr][k + lk];
-      double b0 = Aj[qj + lr][k + lk], b1 = Aj[qj + 16 + lr][k + lk];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
+#pragma unroll
+    for (int k = 0; k < NB; k += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(wi + lr) * QP + k + lk], Aj[(wj + lr) * QP + k + lk], acc, 0, 0, 0);
   }
-  if (idle) return;
 #pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = qi + 16 * a + (lane >> 4) + 4 * r, col = qj + 16 * b + (lane & 15);
-        if (row < iw && col < jw && (i0 + row) >= (j0 + col)) S[(size_t)(i0 + row) * ldS + j0 + col] -= acc[a][b][r];
-      }
+  for (int r = 0; r < 4; r++) {
+    const int row = wi + lk + 4 * r, col = wj + lr;
+    if (row < iw && col < jw && (i0 + row) >= (j0 + col)) S[(size_t)(i0 + row) * ldS + j0 + col] -= acc[r];
+  }
 }
 
 // Backward substitution L^T x = y (y = row n_pad of S) in PULL form, one workgroup per tile column of a level,
@@ -682,11 +766,6 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) k_copy_rhs_row(const double* __restrict__ S, int ldS, int n, double* __restrict__ x) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) x[i] = S[(size_t)n * ldS + i];
-}
-
 // ----------------------------------------------------------------------------------------- K11
 // xl = Dinv (bl - sum_k W_k^T xp[pose(k)])   (block_solver.hpp:459-483); thread per landmark.
 __global__ void __launch_bounds__(256) k_point_backsub(BaView V) {
@@ -715,9 +794,8 @@ __global__ void __launch_bounds__(256) k_point_backsub(BaView V) {
 
 // oplus: cameras T <- exp(dx) T (se3quat.h:212-240, types_six_dof_expmap.h:71-74), landmarks X += dx;
 // also the per-thread terms of computeScale = sum x (lambda x + b), reduced like k_edge_eval.
-__global__ void __launch_bounds__(256) k_update(BaView V) {
-  const double lambda = *V.lambda;
-  __shared__ double s_part[256];
+__global__ void __launch_bounds__(256) k_update(BaView V, BaPublish pub) {
+  const double lambda = ba_lambda(V);
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = 6 * V.nfree;
   double sc = 0;
@@ -727,22 +805,22 @@ __global__ void __launch_bounds__(256) k_update(BaView V) {
     const double* b = V.bp + 6 * (size_t)i;
 #pragma unroll
     for (int a = 0; a < 6; a++) sc += u[a] * (lambda * u[a] + b[a]);
-    se3_oplus(V.poses + 7 * (size_t)p, u);
+    double T[7];
+#pragma unroll
+    for (int a = 0; a < 7; a++) T[a] = V.poses[7 * (size_t)p + a];
+    se3_oplus(T, u);
+#pragma unroll
+    for (int a = 0; a < 7; a++) V.poses_new[7 * (size_t)p + a] = T[a];
   }
   if (i < V.L && V.pt_start[i + 1] > V.pt_start[i]) {
     const double* u = V.x + n + 3 * (size_t)i;
     const double* b = V.bl + 3 * (size_t)i;
-    double* X = V.points + 3 * (size_t)i;
+    const double* X = V.points + 3 * (size_t)i;
+    double* Xn = V.points_new + 3 * (size_t)i;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { sc += u[a] * (lambda * u[a] + b[a]); X[a] += u[a]; }
+    for (int a = 0; a < 3; a++) { sc += u[a] * (lambda * u[a] + b[a]); Xn[a] = X[a] + u[a]; }
   }
-  s_part[threadIdx.x] = sc;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) V.partial2[blockIdx.x] = s_part[0];
+  block_reduce_publish<false>(sc, V.partial2, pub);
 }
 
 // per-edge depth sign at the current state (EdgeSE3ProjectXYZ::isDepthPositive)
@@ -1611,24 +1689,24 @@ __global__ void __launch_bounds__(256) k_pg_update(PgView G, BaView T) {
 // ------------------------------------------------------------------------------------- launchers
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, double* d_scalars, int slot) {
+void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPublish& pub) {
   const int nb = cdiv(V.E, 256);
-  if (jac) hipLaunchKernelGGL(k_edge_eval<true>, dim3(nb), dim3(256), 0, s, V);
-  else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V);
-  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, V.partial, nb, d_scalars, slot);
+  if (jac) hipLaunchKernelGGL(k_edge_eval<true>, dim3(nb), dim3(256), 0, s, V, pub);
+  else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V, pub);
 }
-void ba_launch_accum(hipStream_t s, const BaView& V, double* d_scalars, int slot_maxdiag) {
+void ba_launch_accum(hipStream_t s, const BaView& V) {
   hipLaunchKernelGGL(k_point_accum, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
   if (V.nfree > 0) hipLaunchKernelGGL(k_pose_accum, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
-  if (slot_maxdiag >= 0) hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, s, V, d_scalars, slot_maxdiag);
 }
-void ba_launch_schur(hipStream_t s, const BaView& V) {
-  hipLaunchKernelGGL(k_dinv, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
+void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
+  hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);
+}
+void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
+  const int nb_dinv = cdiv(V.L, 256);
+  hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_dinv, d_fail);
   if (V.nfree == 0) return;
-  hipLaunchKernelGGL(k_zero_tiles, dim3(V.n_nz), dim3(256), 0, s, V.S, V.ldS, V.nz_tiles);
   hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
-  hipLaunchKernelGGL(k_pad_identity, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V);
 }
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
   if (V.nfree == 0) return;
@@ -1640,19 +1718,17 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
     // used -- row n_pad already holds y = L^-1 b once the last camera level is done -- so that level is not launched
     if (h == V.nlevels - 1 && nc == 1 && ns == 0 && nt == 0) break;
     hipLaunchKernelGGL(k_chol_diag, dim3(nc), dim3(256), 0, s, V.S, V.ldS, n1, V.cols + V.h_level_off[h], d_fail, V.Linv);
-    if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
-    if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
+    if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
+    if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }
-  hipLaunchKernelGGL(k_copy_rhs_row, dim3(cdiv(V.n_pad, 256)), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.ytmp);
+  // y = L^-1 b is row n_pad of S (the augmented rhs row): the back substitution reads it in place
   for (int h = V.nlevels - 2; h >= 0; h--)   // (level nlevels - 1 is the rhs tile alone: not an unknown)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(V.h_level_off[h + 1] - V.h_level_off[h]), dim3(256), 0, s, V.S, V.ldS, V.n_pad,
-                       V.nfree, V.per_tile, V.dof, V.cols + V.h_level_off[h], V.ytmp, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
+                       V.nfree, V.per_tile, V.dof, V.cols + V.h_level_off[h], V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
 }
-void ba_launch_backsub_update(hipStream_t s, const BaView& V, double* d_scalars, int slot_scale) {
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
-  const int nb = cdiv(std::max(V.L, V.nfree), 256);
-  hipLaunchKernelGGL(k_update, dim3(nb), dim3(256), 0, s, V);
-  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, V.partial2, nb, d_scalars, slot_scale);
+  hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(V.L, V.nfree), 256)), dim3(256), 0, s, V, pub);
 }
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out) {
   hipLaunchKernelGGL(k_edge_depth, dim3(cdiv(V.E, 256)), dim3(256), 0, s, V, d_out);

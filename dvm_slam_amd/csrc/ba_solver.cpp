@@ -7,6 +7,7 @@
 // sparse_optimizer.cpp:349-412) runs here on the host, one scalar read-back per trial step; every
 // numerical step is a HIP kernel (ba_kernels.hip).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -27,18 +28,19 @@ struct dvm_ba {
   hipStream_t stream = nullptr;
   BaView V{};
   std::vector<void*> allocs;
-  double* d_scalars = nullptr;   // [8]
+  // Phase results travel to the host through page-locked memory mapped into the device (BaPublish): h_vals[0..7] scalars
+  // (chi2, trial chi2, scale, max diagonal, ..., [6] = Cholesky failure flag), h_seq the sequence number the host spins on.
+  double* h_vals = nullptr;                 // hipHostMalloc'ed [16]; [8] holds the sequence number
+  double* d_vals = nullptr;                 // the same memory as the device sees it
+  unsigned long long seq = 0;
+  unsigned int* d_counter = nullptr;        // arrival counters of the in-kernel reductions [4]
+  double* d_dev_vals = nullptr;             // device copy of the phase results [8]
   int* d_fail = nullptr;
-  double* h_scalars = nullptr;   // pinned [8]
-  int* h_fail = nullptr;         // pinned
-  double *d_poses_bak = nullptr, *d_points_bak = nullptr;
   uint8_t* d_depth = nullptr;
   bool have_problem = false;
   double ms_structure = 0;
   BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
   double tile_fill = 1.0;                             // non-zero tiles / all lower tiles of the factor
-  hipGraphExec_t trial_graph = nullptr;  // one LM trial (push, Schur, Cholesky solve, update, chi2) as a hipGraph
-  bool use_graph = false;                // DVM_BA_GRAPH=1 replays the trial as a hipGraph (see dvm_ba_optimize: not thread-friendly)
 
   template <typename T>
   int dalloc(T** p, size_t n) {
@@ -56,7 +58,6 @@ struct dvm_ba {
     return rc;
   }
   void free_problem() {
-    if (trial_graph) { hipGraphExecDestroy(trial_graph); trial_graph = nullptr; }
     for (void* p : allocs) hipFree(p);
     allocs.clear();
     have_problem = false;
@@ -74,13 +75,15 @@ int dvm_ba_create(int device, dvm_ba** out) {
   DVM_HIP(hipSetDevice(device));
   dvm_ba* h = new dvm_ba;
   h->device = device;
-  if (const char* e = getenv("DVM_BA_GRAPH")) h->use_graph = (e[0] == '1');
   int rc = hip_check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "stream");
-  if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_scalars, 8 * sizeof(double)), "malloc");
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_fail, sizeof(int)), "malloc");
-  if (rc == DVM_OK) rc = hip_check(hipHostMalloc(&h->h_scalars, 8 * sizeof(double)), "hostmalloc");
-  if (rc == DVM_OK) rc = hip_check(hipHostMalloc(&h->h_fail, sizeof(int)), "hostmalloc");
-  if (rc != DVM_OK) { delete h; return rc; }
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_counter, 4 * sizeof(unsigned int)), "malloc");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(h->d_counter, 0, 4 * sizeof(unsigned int)), "memset");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_dev_vals, 8 * sizeof(double)), "malloc");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(h->d_dev_vals, 0, 8 * sizeof(double)), "memset");
+  if (rc == DVM_OK) rc = hip_check(hipHostMalloc(&h->h_vals, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent), "hostmalloc");
+  if (rc == DVM_OK) { std::memset(h->h_vals, 0, 16 * sizeof(double)); rc = hip_check(hipHostGetDevicePointer((void**)&h->d_vals, h->h_vals, 0), "devptr"); }
+  if (rc != DVM_OK) { dvm_ba_destroy(h); return rc; }
   *out = h;
   return DVM_OK;
 }
@@ -90,10 +93,10 @@ void dvm_ba_destroy(dvm_ba* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   h->free_problem();
-  if (h->d_scalars) hipFree(h->d_scalars);
   if (h->d_fail) hipFree(h->d_fail);
-  if (h->h_scalars) hipHostFree(h->h_scalars);
-  if (h->h_fail) hipHostFree(h->h_fail);
+  if (h->d_counter) hipFree(h->d_counter);
+  if (h->d_dev_vals) hipFree(h->d_dev_vals);
+  if (h->h_vals) hipHostFree(h->h_vals);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -187,7 +190,7 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   int rc = DVM_OK;
   auto ok = [&](int r) { if (rc == DVM_OK) rc = r; };
   ok(h->dalloc(&V.poses, 7 * (size_t)P)); ok(h->dalloc(&V.points, 3 * (size_t)L));
-  ok(h->dalloc(&h->d_poses_bak, 7 * (size_t)P)); ok(h->dalloc(&h->d_points_bak, 3 * (size_t)L));
+  ok(h->dalloc(&V.poses_new, 7 * (size_t)P)); ok(h->dalloc(&V.points_new, 3 * (size_t)L));
   ok(h->upload(&V.pidx, pidx)); ok(h->upload(&V.free_pose, free_pose));
   ok(h->upload(&V.e_pose, e_pose)); ok(h->upload(&V.e_point, e_point));
   ok(h->upload(&V.e_obs, e_obs)); ok(h->upload(&V.e_info, e_info));
@@ -219,22 +222,42 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   }
   ok(hip_check(hipMemcpy(V.poses, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
   ok(hip_check(hipMemcpy(V.points, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
+  // the trial buffers start as copies: fixed cameras and unobserved landmarks are never rewritten
+  ok(hip_check(hipMemcpy(V.poses_new, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
+  ok(hip_check(hipMemcpy(V.points_new, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
   ok(hip_check(hipMemset(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double)), "memset"));
   ok(hip_check(hipMemset(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double)), "memset"));   // once: trials clear only the non-zero tiles
   ok(hip_check(hipMemset(V.e_chi2, 0, (size_t)E * sizeof(double)), "memset"));
   ok(hip_check(hipDeviceSynchronize(), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  V.lambda = h->d_scalars + 7;
+  V.lambda = nullptr;   // damping travels by value (BaView::lambda_v)
   h->have_problem = true;
   return DVM_OK;
 }
 
-static int read_scalars(dvm_ba* h) {
-  DVM_HIP(hipMemcpyAsync(h->h_scalars, h->d_scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  DVM_HIP(hipMemcpyAsync(h->h_fail, h->d_fail, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  DVM_HIP(hipStreamSynchronize(h->stream));
-  return DVM_OK;
+// Wait until the device has released sequence number `seq` into the mapped host memory (BaPublish).  Spinning on host
+// memory costs a few microseconds; hipStreamSynchronize + D2H copies cost ~60 us per LM iteration (r01 timeline).  The
+// stream's status is polled sparsely so that a failed launch / device fault surfaces instead of hanging the caller.
+static int wait_seq(dvm_ba* h, unsigned long long seq) {
+  volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(h->h_vals + 8);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; spin++) {
+    if (*p >= seq) { std::atomic_thread_fence(std::memory_order_acquire); return DVM_OK; }
+    if ((spin & 0xFFF) == 0xFFF) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return hip_check(q, "bundle adjustment stream");
+      if (q == hipSuccess && *p < seq) {           // everything ran, nothing was published: should be impossible
+        if (*p >= seq) continue;
+        set_error("bundle adjustment: phase result was not published");
+        return DVM_ERR_HIP;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+        set_error("bundle adjustment: timed out waiting for the device");
+        return DVM_ERR_HIP;
+      }
+    }
+  }
 }
 
 // optimizer.optimize(iterations) with OptimizationAlgorithmLevenberg.  stop_flag mirrors g2o's
@@ -244,67 +267,53 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   DVM_HIP(hipSetDevice(h->device));
   BaView& V = h->V;
   hipStream_t s = h->stream;
-  const int n = 6 * V.nfree;
   if (st) { std::memset(st, 0, sizeof(*st)); st->ms_structure = h->ms_structure; }
   const auto t0 = std::chrono::steady_clock::now();
-  enum { S_CHI = 0, S_TMPCHI = 1, S_SCALE = 2, S_MAXDIAG = 3 };
+  enum { S_CHI = 0, S_TMPCHI = 1, S_SCALE = 2, S_MAXDIAG = 3, S_FAIL = 6 };
+  auto pub = [&](int slot, int counter, bool publish, bool with_fail) {
+    BaPublish p;
+    p.dev_vals = h->d_dev_vals; p.host_vals = h->d_vals; p.host_seq = reinterpret_cast<unsigned long long*>(h->d_vals + 8);
+    p.seq = publish ? ++h->seq : 0; p.counter = h->d_counter + counter; p.d_fail = with_fail ? h->d_fail : nullptr;
+    p.slot = slot; p.publish = publish ? 1 : 0;
+    return p;
+  };
   double lambda = -1, ni = 2;
   int nBad = 0, it_done = 0, trials_total = 0, stop = 0;
   double chi_last = 0;
   auto terminate = [&]() { return stop_flag && *stop_flag; };
   for (int it = 0; it < iterations && !terminate(); it++) {
-    // computeActiveErrors + activeRobustChi2 + buildSystem (one fused edge pass at the current state)
-    ba_launch_edge_eval(s, V, true, h->d_scalars, S_CHI);
-    ba_launch_accum(s, V, h->d_scalars, it == 0 ? S_MAXDIAG : -1);
-    int rc = read_scalars(h);
+    // computeActiveErrors + activeRobustChi2 + buildSystem (one fused edge pass at the current state).  chi2 reaches the
+    // host from the edge pass itself, so the accumulation kernels below run while the host prepares the first trial.
+    ba_launch_edge_eval(s, V, true, pub(S_CHI, 0, it != 0, false));
+    ba_launch_accum(s, V);
+    if (it == 0) ba_launch_max_diag(s, V, pub(S_MAXDIAG, 1, true, false));
+    int rc = hip_check(hipGetLastError(), "bundle adjustment launch");
+    if (rc == DVM_OK) rc = wait_seq(h, h->seq);
     if (rc != DVM_OK) return rc;
-    double currentChi = h->h_scalars[S_CHI], tempChi = currentChi;
+    double currentChi = h->h_vals[S_CHI], tempChi = currentChi;
     const double iniChi = currentChi;
     if (it == 0) {
       if (st) st->chi2_initial = currentChi;
-      lambda = 1e-5 * h->h_scalars[S_MAXDIAG];  // computeLambdaInit, _tau = 1e-5
+      lambda = 1e-5 * h->h_vals[S_MAXDIAG];  // computeLambdaInit, _tau = 1e-5
       ni = 2; nBad = 0;
     }
     double rho = 0;
     int qmax = 0;
     do {
-      // one trial = push() + setLambda/Schur + reduced solve + landmarks/oplus + chi2: ~200 small
-      // launches, replayed as ONE hipGraph (the host would otherwise be the bottleneck)
-      h->h_scalars[7] = lambda;
-      DVM_HIP(hipMemcpyAsync(h->d_scalars + 7, h->h_scalars + 7, sizeof(double), hipMemcpyHostToDevice, s));
-      // The trial as a plain launch sequence (~45 asynchronous launches, each 5-60 us of GPU work: the host stays ahead).
-      // DVM_BA_GRAPH=1 records it once into a hipGraph instead -- measured equal (1261 vs 1275 it/s) and OFF by default:
-      // while a thread captures, this runtime rejects legacy-stream calls (a synchronous hipMemcpy) made by ANY other host
-      // thread, in every capture mode, and the capture itself is poisoned -- the reference calls its optimizers
-      // concurrently from Tracking, LocalMapping and LoopClosing (tests/test_gpu_threads.py).
-      auto enqueue_trial = [&]() {
-        hipMemcpyAsync(h->d_poses_bak, V.poses, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(h->d_points_bak, V.points, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s);
-        hipMemsetAsync(h->d_fail, 0, sizeof(int), s);
-        ba_launch_schur(s, V);
-        ba_launch_cholesky_solve(s, V, h->d_fail);
-        ba_launch_backsub_update(s, V, h->d_scalars, S_SCALE);
-        ba_launch_edge_eval(s, V, false, h->d_scalars, S_TMPCHI);
-      };
-      if (!h->trial_graph && h->use_graph) {
-        hipGraph_t g = nullptr;
-        bool captured = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (captured) {
-          enqueue_trial();
-          captured = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr;
-        }
-        if (captured && hipGraphInstantiate(&h->trial_graph, g, nullptr, nullptr, 0) != hipSuccess) h->trial_graph = nullptr;
-        if (g) hipGraphDestroy(g);
-        (void)hipGetLastError();   // a failed capture must not surface as the error of the next call
-      }
-      if (h->trial_graph) DVM_HIP(hipGraphLaunch(h->trial_graph, s));
-      else enqueue_trial();
-      rc = read_scalars(h);
+      // one trial = setLambda + Schur complement + reduced solve + landmarks + oplus into the TRIAL state + its chi2:
+      // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
+      V.lambda_v = lambda;
+      ba_launch_schur(s, V, h->d_fail);
+      ba_launch_cholesky_solve(s, V, h->d_fail);
+      ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
+      ba_launch_edge_eval(s, V, false, pub(S_TMPCHI, 0, true, true));
+      rc = hip_check(hipGetLastError(), "bundle adjustment launch");
+      if (rc == DVM_OK) rc = wait_seq(h, h->seq);
       if (rc != DVM_OK) return rc;
-      const bool ok2 = (*h->h_fail == 0);
-      tempChi = ok2 ? h->h_scalars[S_TMPCHI] : std::numeric_limits<double>::max();
+      const bool ok2 = (h->h_vals[S_FAIL] == 0.0);
+      tempChi = ok2 ? h->h_vals[S_TMPCHI] : std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
-      double scale = ok2 ? h->h_scalars[S_SCALE] : 0.0;
+      double scale = ok2 ? h->h_vals[S_SCALE] : 0.0;
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
@@ -313,11 +322,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         lambda *= std::max(1. / 3., alpha);
         ni = 2;
         currentChi = tempChi;
+        std::swap(V.poses, V.poses_new);       // discardTop(): the trial state becomes the estimate
+        std::swap(V.points, V.points_new);
       } else {
         lambda *= ni;
-        ni *= 2;
-        DVM_HIP(hipMemcpyAsync(V.poses, h->d_poses_bak, 7 * (size_t)V.P * sizeof(double), hipMemcpyDeviceToDevice, s));  // pop()
-        DVM_HIP(hipMemcpyAsync(V.points, h->d_points_bak, 3 * (size_t)V.L * sizeof(double), hipMemcpyDeviceToDevice, s));
+        ni *= 2;                               // pop(): (poses, points) were never touched
       }
       qmax++;
       trials_total++;
@@ -330,7 +339,6 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     if (nBad >= 3) { stop = 2; break; }
   }
   DVM_HIP(hipStreamSynchronize(s));
-  (void)n;
   if (st) {
     st->iterations = it_done; st->total_trials = trials_total; st->stop_reason = stop;
     st->chi2_final = chi_last; st->lambda_final = lambda;
