@@ -37,7 +37,8 @@ struct BaView {
   const int32_t *pair_k1, *pair_k2;            // per block: (edge of i1, edge of i2) sharing a landmark
   double* S;                // [ldS][ldS] dense lower triangle + augmented rhs row
   double* Linv;             // [ldS/64][64*64] inverses of the factored diagonal blocks
-  double* ytmp;             // [n_pad]
+  double* ytmp;             // [n_pad + 64] doubles, used as int32 words: [0] ticket, [1 + k] hand-off flag of tile column k
+                            // of the one-launch back substitution; must be zeroed once after allocation
   double* x;                // [6*nfree + 3*L]
   double *partial, *partial2;
   // Reduced camera system in TILE space (ba_ordering.h): camera i (elimination order) owns rows
@@ -106,7 +107,8 @@ void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPubli
 void ba_launch_accum(hipStream_t s, const BaView& V);
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub);
 void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail);
-void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail);
+// solve_seq: a number > 0 that differs from call to call on this BaView (the back substitution's hand-off flags compare against it)
+void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq);
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub);
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
 void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const double* P1c, const double* P2c,

@@ -629,38 +629,51 @@ extern "C" int dvm_debug_chol_stamps(long long* out) { return (int)hipMemcpyFrom
 
 
 // Panel solve of step kb: strip i (64 rows below the diagonal block) becomes X = A_ik * Linv_kk^T
-// (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM.  One workgroup per 32x32 QUADRANT of
-// the strip (grid = 4 x strips), each wave one 16x16 block: an f64 MFMA occupies its SIMD for 64 cycles, so a whole tile on
-// one workgroup is 1.7 us of matrix pipe alone; spread over four CUs the product leaves the critical path of the level.
-constexpr int QP = 66;   // LDS pitch (doubles) of a 32x64 half strip: conflict-free for the MFMA operand reads
+// (a 64x64x64 product on v_mfma_f64_16x16x4_f64) -- the triangular solve as a GEMM, IN PLACE.  One workgroup per 16-ROW
+// slice of the strip (grid = 4 x strips), each wave one 16x16 block of it: an f64 MFMA occupies its SIMD for 64 cycles, so a
+// whole tile on one workgroup is 1.7 us of matrix pipe alone.  The split is by rows only: a workgroup reads and overwrites
+// nothing but its own rows (a split by columns would let one workgroup overwrite A entries another is still reading).
+constexpr int QP = 66;   // LDS pitch (doubles): conflict-free for the MFMA operand reads
 __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1,
                                                    const double* __restrict__ Linv_all, const int32_t* __restrict__ strips) {
-  __shared__ double Ai[32 * QP];
-  __shared__ double Li[32 * QP];
+  __shared__ double Ai[16 * QP];
+  __shared__ double Li[NB * QP];
   const int tid = threadIdx.x;
-  const int st = blockIdx.x >> 2, qi = (blockIdx.x & 2) * 16, qj = (blockIdx.x & 1) * 32;
+  const int st = blockIdx.x >> 2, qi = (blockIdx.x & 3) * 16;
   const int kb = strips[2 * st + 1];
   const int k0 = kb * NB;
   const int r0 = strips[2 * st] * NB;  // tile row of a structurally non-zero strip of column kb
   const int rw = min(NB, n1 - r0);
+  if (qi >= rw) return;
   const double* Lk = Linv_all + (size_t)kb * NB * NB;
-  for (int i = tid; i < 32 * NB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    Ai[r * QP + c] = (qi + r < rw) ? S[(size_t)(r0 + qi + r) * ldS + k0 + c] : 0.0;
-    Li[r * QP + c] = Lk[(qj + r) * NB + c];
+  {
+    double2 l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) l[i] = *reinterpret_cast<const double2*>(Lk + (8 * i + (tid >> 5)) * NB + 2 * (tid & 31));
+    const int r = tid >> 4, c = 4 * (tid & 15);
+    const double* src = S + (size_t)(r0 + min(qi + r, rw - 1)) * ldS + k0 + c;
+    const double2 a0 = *reinterpret_cast<const double2*>(src), a1 = *reinterpret_cast<const double2*>(src + 2);
+    const bool in = qi + r < rw;
+    Ai[r * QP + c] = in ? a0.x : 0.0; Ai[r * QP + c + 1] = in ? a0.y : 0.0;
+    Ai[r * QP + c + 2] = in ? a1.x : 0.0; Ai[r * QP + c + 3] = in ? a1.y : 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      Li[(8 * i + (tid >> 5)) * QP + 2 * (tid & 31)] = l[i].x;
+      Li[(8 * i + (tid >> 5)) * QP + 2 * (tid & 31) + 1] = l[i].y;
+    }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
-  const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+  const int wj = wave * 16;
   const int lr = lane & 15, lk = lane >> 4;
   double4_t acc = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < NB; k += 4)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(wi + lr) * QP + k + lk], Li[(wj + lr) * QP + k + lk], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[lr * QP + k + lk], Li[(wj + lr) * QP + k + lk], acc, 0, 0, 0);
   const int kw = min(NB, n1 - k0);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int row = qi + wi + lk + 4 * r, col = qj + wj + lr;
+    const int row = qi + lk + 4 * r, col = wj + lr;
     if (row < rw && col < kw) S[(size_t)(r0 + row) * ldS + k0 + col] = acc[r];
   }
 }
@@ -716,29 +729,49 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
   }
 }
 
-// Backward substitution L^T x = y (y = row n_pad of S) in PULL form, one workgroup per tile column of a level,
-// levels visited from the root down:  x_k = Linv_kk^T (y_k - sum_{i in struct(k)} L(i,k)^T x_i); the x_i belong to
-// ancestors of k and are final.  The result goes to row space (xrow, for the descendants) and, compacted to
-// 6 doubles per camera, to V.x for the update kernels.
+// Backward substitution L^T x = y (y = row n_pad of S) in PULL form, ALL tile columns in one launch:
+//   x_k = Linv_kk^T (y_k - sum_{i in struct(k)} L(i,k)^T x_i);  the x_i belong to ancestors of k in the elimination tree.
+// One workgroup per tile column.  A workgroup takes a ticket and processes the ticket-th column in root-first order, so
+// every column it has to wait for is held by a workgroup that is already running (no deadlock whatever the dispatch
+// order); x_i travels through `xrow` with 8-byte agent-scope (write-through) stores, drained before the column's flag is
+// raised to the solve's sequence number -- no fences, no flag reset (MI355X_MICROARCH.md, hand-off forms).  Eight
+// dependent launches of ~5 us each before (one per level) -> one launch with a ~2 us hop per level.
+// The result goes to row space (xrow, for the descendants) and, compacted to dof doubles per unknown, to x.
 __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n_pad, int nfree, int per_tile, int dof,
-                                                        const int32_t* __restrict__ cols, const double* __restrict__ y,
+                                                        const int32_t* __restrict__ cols, int ncols, const double* __restrict__ y,
                                                         double* __restrict__ xrow, double* __restrict__ x,
                                                         const double* __restrict__ Linv_all,
                                                         const int32_t* __restrict__ colstrip_off,
-                                                        const int32_t* __restrict__ colstrips) {
+                                                        const int32_t* __restrict__ colstrips, int32_t* __restrict__ sync, int gen,
+                                                        int* __restrict__ fail) {
   __shared__ double yk[NB];
   __shared__ double xi[NB];
   __shared__ double part[4][NB];
+  __shared__ int s_col;
   const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
-  const int kb = cols[blockIdx.x];
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == ncols - 1) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is taken
+    s_col = cols[ncols - 1 - t];     // `cols` lists leaves first
+  }
+  __syncthreads();
+  const int kb = s_col;
+  int32_t* flags = sync + 1;
   const int k0 = kb * NB;
-  if (k0 >= n_pad) return;                       // the rhs tile itself
+  if (k0 >= n_pad) return;                       // the rhs tile itself (never in the list; defensive)
   if (tid < NB) yk[tid] = y[k0 + tid];
   for (int s = colstrip_off[kb]; s < colstrip_off[kb + 1]; s++) {
-    const int i0 = colstrips[s] * NB;
+    const int it = colstrips[s], i0 = it * NB;
     if (i0 >= n_pad) continue;                   // the rhs row is not an unknown
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(flags + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 24)) { *fail = 2; break; }   // never hang the device: give up, the trial is rejected
+      }
+    }
     __syncthreads();
-    if (tid < NB) xi[tid] = xrow[i0 + tid];
+    if (tid < NB) xi[tid] = __hip_atomic_load(xrow + i0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     double u = 0;
 #pragma unroll
@@ -758,11 +791,13 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   for (int r = 0; r < 16; r++) s += Lk[(16 * q + r) * NB + c] * yk[16 * q + r];
   part[q][c] = s;
   __syncthreads();
-  if (tid < NB) {
+  if (tid < NB) {   // one wave
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    xrow[k0 + tid] = v;
+    __hip_atomic_store(xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int cam = kb * per_tile + tid / dof;
     if (tid < per_tile * dof && cam < nfree) x[dof * (size_t)cam + tid % dof] = v;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's x_k has reached the coherence point
+    if (tid == 0) __hip_atomic_store(flags + kb, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1708,7 +1743,7 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
 }
-void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
+void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
   const int n1 = V.n_pad + 1;
   for (int h = 0; h < V.nlevels; h++) {
@@ -1721,10 +1756,13 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail) {
     if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
     if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }
-  // y = L^-1 b is row n_pad of S (the augmented rhs row): the back substitution reads it in place
-  for (int h = V.nlevels - 2; h >= 0; h--)   // (level nlevels - 1 is the rhs tile alone: not an unknown)
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(V.h_level_off[h + 1] - V.h_level_off[h]), dim3(256), 0, s, V.S, V.ldS, V.n_pad,
-                       V.nfree, V.per_tile, V.dof, V.cols + V.h_level_off[h], V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips);
+  // y = L^-1 b is row n_pad of S (the augmented rhs row): the back substitution reads it in place; one launch for all
+  // camera tile columns (levels 0 .. nlevels - 2; level nlevels - 1 is the rhs tile alone: not an unknown)
+  const int ncols = V.h_level_off[V.nlevels - 1];
+  if (ncols > 0)
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(ncols), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.nfree, V.per_tile, V.dof, V.cols, ncols,
+                       V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips, reinterpret_cast<int32_t*>(V.ytmp),
+                       solve_seq, d_fail);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);

@@ -33,6 +33,7 @@ struct dvm_ba {
   double* h_vals = nullptr;                 // hipHostMalloc'ed [16]; [8] holds the sequence number
   double* d_vals = nullptr;                 // the same memory as the device sees it
   unsigned long long seq = 0;
+  int solve_seq = 0;
   unsigned int* d_counter = nullptr;        // arrival counters of the in-kernel reductions [4]
   double* d_dev_vals = nullptr;             // device copy of the phase results [8]
   int* d_fail = nullptr;
@@ -228,6 +229,8 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   ok(hip_check(hipMemset(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double)), "memset"));
   ok(hip_check(hipMemset(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double)), "memset"));   // once: trials clear only the non-zero tiles
   ok(hip_check(hipMemset(V.e_chi2, 0, (size_t)E * sizeof(double)), "memset"));
+  ok(hip_check(hipMemset(V.ytmp, 0, ((size_t)V.n_pad + 64) * sizeof(double)), "memset"));   // ticket + hand-off flags of the back substitution
+  h->solve_seq = 0;
   ok(hip_check(hipDeviceSynchronize(), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -304,7 +307,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
       V.lambda_v = lambda;
       ba_launch_schur(s, V, h->d_fail);
-      ba_launch_cholesky_solve(s, V, h->d_fail);
+      ba_launch_cholesky_solve(s, V, h->d_fail, ++h->solve_seq);
       ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
       ba_launch_edge_eval(s, V, false, pub(S_TMPCHI, 0, true, true));
       rc = hip_check(hipGetLastError(), "bundle adjustment launch");

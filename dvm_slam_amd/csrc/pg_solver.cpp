@@ -119,6 +119,8 @@ extern "C" int dvm_pose_graph_optimize(int device, double* S, const uint8_t* fix
   T.lambda = d_scalars + 7;
   if (D.rc != DVM_OK) return D.rc;
   DVM_HIP(hipMemset(T.S, 0, (size_t)T.ldS * T.ldS * sizeof(double)));   // once: trials clear only the non-zero tiles
+  DVM_HIP(hipMemset(T.ytmp, 0, ((size_t)T.n_pad + 64) * sizeof(double)));  // ticket + hand-off flags of the back substitution
+  int solve_seq = 0;
   // estimates: unit quaternions with w >= 0 like g2o::Sim3's constructor (sim3.h:56-60 normalises r)
   std::vector<double> Sn(S, S + 8 * (size_t)n);
   for (int v = 0; v < n; v++) {
@@ -157,7 +159,7 @@ extern "C" int dvm_pose_graph_optimize(int device, double* S, const uint8_t* fix
       DVM_HIP(hipMemcpyAsync(d_bak, G.S, 8 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));   // push()
       DVM_HIP(hipMemsetAsync(d_fail, 0, sizeof(int), s));
       pg_launch_build(s, G, T);
-      ba_launch_cholesky_solve(s, T, d_fail);
+      ba_launch_cholesky_solve(s, T, d_fail, ++solve_seq);
       pg_launch_update(s, G, T, d_scalars, S_SCALE);
       pg_launch_edge_eval(s, G, false, d_scalars, S_TMPCHI);
       rc = read();
