@@ -55,10 +55,23 @@ class ORBextractor {
     std::memcpy(static_cast<void*>(_keypoints.data()), kps_.data(), sizeof(dvm_keypoint) * n);
     if (n == 0) _descriptors.release();
     else desc.rowRange(0, n).copyTo(_descriptors);
-    // mvImagePyramid is only read by Frame::ComputeStereoMatches (stereo; Frame.cc:856,940-956): expose the
-    // device pyramid lazily through dvm_orb_pyramid() + hipMemcpy2D when a stereo caller needs it.
+    // mvImagePyramid is read only by Frame::ComputeStereoMatches (stereo; Frame.cc:856,940-956).  DVM-SLAM is monocular, so
+    // the pyramid normally stays on the device; a stereo caller sets mbExposePyramid and gets the levels copied out.
+    if (mbExposePyramid) FillImagePyramid();
     return mono;
   }
+
+  // mvImagePyramid[level] <- the device pyramid of the last frame (dvm_orb_debug_level: tight rows, no border), on demand
+  void FillImagePyramid() {
+    for (int l = 0; l < nlevels_; l++) {
+      const uint8_t* d = nullptr;
+      int rows = 0, cols = 0, stride = 0;
+      if (dvm_orb_pyramid(h_, 0, l, &d, &rows, &cols, &stride) != DVM_OK) throw std::runtime_error(dvm_last_error());
+      mvImagePyramid[l].create(rows, cols, CV_8U);
+      if (dvm_orb_debug_level(h_, 0, l, /*bordered=*/0, mvImagePyramid[l].data) != DVM_OK) throw std::runtime_error(dvm_last_error());
+    }
+  }
+  bool mbExposePyramid = false;
 
   int inline GetLevels() { return nlevels_; }
   float inline GetScaleFactor() { return scaleFactor_; }

@@ -1,0 +1,3 @@
+// test stub (tests/stubs/README.md)
+#pragma once
+#include "orbslam3_stub.h"

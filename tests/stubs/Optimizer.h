@@ -1,0 +1,18 @@
+// test stub (tests/stubs/README.md): the five statics of ORB_SLAM3::Optimizer (include/Optimizer.h:48-101) the shim defines
+#pragma once
+#include "orbslam3_stub.h"
+#include "Thirdparty/g2o/g2o/types/sim3.h"
+namespace ORB_SLAM3 {
+class Optimizer {
+ public:
+  void static BundleAdjustment(const std::vector<KeyFrame*>& vpKF, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
+                               bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
+  void static GlobalBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
+                                     const bool bRobust = true);
+  void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
+                                    int& num_edges);
+  int static PoseOptimization(Frame* pFrame);
+  static int OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches1, g2o::Sim3& g2oS12, const float th2,
+                          const bool bFixScale, Eigen::Matrix<double, 7, 7>& mAcumHessian, const bool bAllPoints = false);
+};
+}  // namespace ORB_SLAM3

@@ -1,0 +1,31 @@
+"""The drop-in shims of the four reference classes (dvm_slam_amd/host/*_shim.h) must keep compiling against the reference's
+signatures: `g++ -fsyntax-only` on each one with the minimal stand-in declarations under tests/stubs/ (OpenCV / Eigen /
+Sophus / g2o / DBoW2 / ORB_SLAM3 names only -- no reference code).  Inside the reference tree the same headers see the real
+ones."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dvm_slam_amd", "host")
+
+
+@pytest.mark.parametrize("shim", ["ORBextractor_shim.h", "ORBmatcher_shim.h", "Optimizer_shim.h", "Frame_grid_shim.h"])
+def test_shim_compiles_against_reference_signatures(shim):
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"),
+                        "-I", os.path.join(ROOT, "include"), "-I", HOST, "-x", "c++", "-"],
+                       input=f'#include "{shim}"\nint main() {{ return 0; }}\n', capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_shims_cover_the_reference_public_interface():
+    """Every public ORBmatcher method of include/ORBmatcher.h:37-95 and the five monocular Optimizer statics are defined."""
+    m = open(os.path.join(HOST, "ORBmatcher_shim.h")).read()
+    for name, count in (("int SearchByProjection(", 5), ("int SearchByBoW(", 2), ("int SearchForInitialization(", 1),
+                        ("int SearchForTriangulation(", 1), ("int SearchBySim3(", 1), ("int Fuse(", 2), ("static int DescriptorDistance(", 1)):
+        assert m.count(name) == count, name
+    o = open(os.path.join(HOST, "Optimizer_shim.h")).read()
+    for name in ("Optimizer::BundleAdjustment(", "Optimizer::GlobalBundleAdjustemnt(", "Optimizer::LocalBundleAdjustment(",
+                 "Optimizer::PoseOptimization(", "Optimizer::OptimizeSim3("):
+        assert "inline void " + name in o or "inline int " + name in o, name
