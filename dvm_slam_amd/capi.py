@@ -394,6 +394,52 @@ class BundleAdjuster:
         check(self.L.dvm_ba_set_problem(self.h, _p(poses), _p(fixed), self.P, _p(points), self.Lm, _p(edges), self.E,
                                         C.byref(cam)))
 
+    def set_problem_sharded(self, poses, fixed, points, edges, intrinsics, huber_delta, rank, world):
+        """BASELINE config 5: the whole problem on every rank, the observations of the landmarks `point % world == rank`
+        evaluated here (dvm_ba_set_problem_sharded).  Needs set_allreduce() before optimize()."""
+        poses = np.ascontiguousarray(poses, np.float64)
+        points = np.ascontiguousarray(points, np.float64)
+        fixed = np.ascontiguousarray(fixed, np.uint8)
+        edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+        cam = BaCamera(*[float(v) for v in intrinsics], float(huber_delta))
+        self.P, self.Lm = len(poses), len(points)
+        self.E = int((edges["point"] % world == rank).sum())
+        f = self.L.dvm_ba_set_problem_sharded
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, _p(poses), _p(fixed), C.c_int32(self.P), _p(points), C.c_int32(self.Lm), _p(edges), C.c_int32(len(edges)),
+                C.byref(cam), C.c_int32(rank), C.c_int32(world)))
+
+    def schedule_info(self):
+        out = (C.c_int64 * 12)()
+        f = self.L.dvm_ba_schedule_info
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, out))
+        keys = ("levels", "columns", "strips", "targets", "products", "products_on_diagonal_targets", "nz_tiles", "ldS", "free_cameras",
+                "nz_blocks", "edges", "tiles_per_side")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def profile(self, enable=-1):
+        ms = (C.c_double * 4)(); tr = C.c_int32(0); it = C.c_int32(0)
+        f = self.L.dvm_ba_profile
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, C.c_int32(enable), ms, C.byref(tr), C.byref(it)))
+        return dict(ms_linearise=ms[0], ms_schur=ms[1], ms_cholesky_solve=ms[2], ms_update_chi2=ms[3], trials=tr.value, iterations=it.value)
+
+    def allreduce_doubles(self):
+        f = self.L.dvm_ba_allreduce_doubles
+        f.restype = C.c_int64; f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
+    ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)
+
+    def set_allreduce(self, fn, d_buf, cap_doubles):
+        """fn(buf_address, n, on_host, op, stream) -> 0 on success: in-place all-reduce of n doubles (device buffer = d_buf, or a
+        host address); op 0 sum, 1 max."""
+        self._ar_cb = self.ALLREDUCE_FN(lambda ctx, buf, n, on_host, op, stream: int(fn(buf, n, on_host, op, stream)))
+        f = self.L.dvm_ba_set_allreduce
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, self._ar_cb, None, C.c_void_p(d_buf), C.c_int64(cap_doubles)))
+
     def optimize(self, iterations, stop_flag=None):
         st = BaStats()
         check(self.L.dvm_ba_optimize(self.h, iterations, _p(stop_flag) if stop_flag is not None else None, C.byref(st)))

@@ -60,6 +60,10 @@ struct BaView {
   int32_t nlevels;
   const double* lambda;     // device scalar with the current LM damping (pose graph), or null: use lambda_v
   double lambda_v;          // LM damping by value (bundle adjustment: no H2D copy per trial)
+  double damp_s;            // 1 normally.  Landmark-sharded BA (dvm_ba_set_problem_sharded): every rank builds a PARTIAL reduced
+                            // system that is summed over ranks, so what is not a sum over edges -- lambda on the camera
+                            // diagonal, the identity padding, the augmented corner, the cameras' lambda x^2 -- is contributed by
+                            // rank 0 only (damp_s = 0 elsewhere)
   double *poses_new, *points_new;   // trial state: k_update writes exp(dx) * poses -> poses_new, points + dx -> points_new; an
                                     // accepted trial swaps the pointers on the host, a rejected one leaves (poses, points) alone
                                     // -- g2o's push() / pop() / discardTop() without copies
@@ -111,6 +115,13 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail);
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq);
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub);
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
+// sharded BA: the structurally non-zero tiles of S (augmented rhs row included) <-> a contiguous buffer of n_nz * 4096 doubles
+void ba_launch_pack_tiles(hipStream_t s, const BaView& V, double* buf, bool unpack);
+// sharded BA: diag(Hpp) (6 per free camera) <-> buffer; and max(buffer[0..6 nfree), diag Hll of the local landmarks) -> host
+void ba_launch_hpp_diag(hipStream_t s, const BaView& V, double* buf);
+void ba_launch_max_diag_sharded(hipStream_t s, const BaView& V, const double* hpp_diag, const BaPublish& pub);
+// sharded BA: buf[3 l + k] = points[l] for owned landmarks (pt_start[l+1] > pt_start[l]), 0 elsewhere; and the inverse after the sum
+void ba_launch_points_exchange(hipStream_t s, const BaView& V, double* buf, bool scatter);
 void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const double* P1c, const double* P2c,
                              const double* obs1, const double* obs2, const double* w1, const double* w2, int N,
                              const double* K, double th2, uint8_t* inlier, int32_t* nin, double* chi_scratch, uint8_t* flag_scratch);

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) k_schur_blocks(BaView V) {
 #pragma unroll
     for (int i = 0; i < 36; i++) if (i == lane) v = acc[i];
     v = -v;
-    if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + lane] + (a == b ? lambda : 0.0);
+    if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + lane] + (a == b ? lambda * V.damp_s : 0.0);
     V.S[(size_t)(ba_row(i1) + a) * V.ldS + ba_row(i2) + b] = v;
   }
 }
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
     for (int a = 0; a < 6; a++) acc[a] += __shfl_xor(acc[a], off);
   if (lane == 0) {
     for (int a = 0; a < 6; a++) V.S[(size_t)V.n_pad * V.ldS + ba_row(fi) + a] = V.bp[6 * (size_t)fi + a] - acc[a];
-    if (fi == 0) V.S[(size_t)V.n_pad * V.ldS + V.n_pad] = 1e200;  // augmented corner: keeps the last pivot positive
+    if (fi == 0) V.S[(size_t)V.n_pad * V.ldS + V.n_pad] = 1e200 * V.damp_s;  // augmented corner: keeps the last pivot positive
   }
 }
 
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) k_trial_prologue(BaView V, int nb_dinv, i
   if (ti == tj && ti * 64 < V.n_pad) {
     __syncthreads();
     const int w = threadIdx.x;
-    if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = 1.0;
+    if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = V.damp_s;
   }
 }
 
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(256) k_update(BaView V, BaPublish pub) {
     const double* u = V.x + 6 * (size_t)i;
     const double* b = V.bp + 6 * (size_t)i;
 #pragma unroll
-    for (int a = 0; a < 6; a++) sc += u[a] * (lambda * u[a] + b[a]);
+    for (int a = 0; a < 6; a++) sc += u[a] * (lambda * V.damp_s * u[a] + b[a]);
     double T[7];
 #pragma unroll
     for (int a = 0; a < 7; a++) T[a] = V.poses[7 * (size_t)p + a];
@@ -1767,6 +1767,50 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
   hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(V.L, V.nfree), 256)), dim3(256), 0, s, V, pub);
+}
+__global__ void __launch_bounds__(256) k_pack_tiles(BaView V, double* __restrict__ buf, int unpack) {
+  const int ti = V.nz_tiles[2 * blockIdx.x], tj = V.nz_tiles[2 * blockIdx.x + 1];
+  double* base = V.S + (size_t)ti * 64 * V.ldS + tj * 64;
+  double* b = buf + (size_t)blockIdx.x * 4096;
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int r = i >> 5, c2 = i & 31;
+    double2* g = reinterpret_cast<double2*>(base + (size_t)r * V.ldS) + c2;
+    double2* p = reinterpret_cast<double2*>(b + r * 64) + c2;
+    if (unpack) *g = *p; else *p = *g;
+  }
+}
+__global__ void __launch_bounds__(256) k_hpp_diag(BaView V, double* __restrict__ buf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < V.nfree * 6) buf[i] = V.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)];
+}
+__global__ void __launch_bounds__(256) k_max_diag_sharded(BaView V, const double* __restrict__ hpp_diag, BaPublish pub) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double m = 0;
+  if (i < V.nfree * 6) m = fabs(hpp_diag[i]);
+  if (i < V.L * 3 && V.pt_start[i / 3 + 1] > V.pt_start[i / 3]) m = fmax(m, fabs(V.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+  block_reduce_publish<true>(m, V.partial2, pub);
+}
+__global__ void __launch_bounds__(256) k_points_exchange(BaView V, double* __restrict__ buf, int scatter) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= V.L) return;
+  const bool own = V.pt_start[l + 1] > V.pt_start[l];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (scatter) V.points[3 * (size_t)l + k] = buf[3 * (size_t)l + k];
+    else buf[3 * (size_t)l + k] = own ? V.points[3 * (size_t)l + k] : 0.0;
+  }
+}
+void ba_launch_pack_tiles(hipStream_t s, const BaView& V, double* buf, bool unpack) {
+  hipLaunchKernelGGL(k_pack_tiles, dim3(V.n_nz), dim3(256), 0, s, V, buf, unpack ? 1 : 0);
+}
+void ba_launch_hpp_diag(hipStream_t s, const BaView& V, double* buf) {
+  hipLaunchKernelGGL(k_hpp_diag, dim3(cdiv(6 * V.nfree, 256)), dim3(256), 0, s, V, buf);
+}
+void ba_launch_max_diag_sharded(hipStream_t s, const BaView& V, const double* hpp_diag, const BaPublish& pub) {
+  hipLaunchKernelGGL(k_max_diag_sharded, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, hpp_diag, pub);
+}
+void ba_launch_points_exchange(hipStream_t s, const BaView& V, double* buf, bool scatter) {
+  hipLaunchKernelGGL(k_points_exchange, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V, buf, scatter ? 1 : 0);
 }
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out) {
   hipLaunchKernelGGL(k_edge_depth, dim3(cdiv(V.E, 256)), dim3(256), 0, s, V, d_out);

@@ -34,6 +34,18 @@ struct dvm_ba {
   double* d_vals = nullptr;                 // the same memory as the device sees it
   unsigned long long seq = 0;
   int solve_seq = 0;
+  // landmark-sharded mode (dvm_ba_set_problem_sharded): rank r of `world` owns the landmarks l with l % world == r
+  int rank = 0, world = 1;
+  // optional HIP-event timing of the phases of a trial (dvm_ba_profile): [0] linearise, [1] Schur complement, [2] tile Cholesky +
+  // back substitution, [3] landmarks + update + chi2; milliseconds accumulated over prof_trials trials / prof_iters iterations
+  bool prof = false;
+  hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double prof_ms[4] = {0, 0, 0, 0};
+  int prof_trials = 0, prof_iters = 0;
+  dvm_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  double* ar_buf = nullptr;      // caller's device buffer the collectives run on
+  int64_t ar_cap = 0;
   unsigned int* d_counter = nullptr;        // arrival counters of the in-kernel reductions [4]
   double* d_dev_vals = nullptr;             // device copy of the phase results [8]
   int* d_fail = nullptr;
@@ -95,6 +107,7 @@ void dvm_ba_destroy(dvm_ba* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   h->free_problem();
   if (h->d_fail) hipFree(h->d_fail);
+  for (auto& e : h->pev) if (e) hipEventDestroy(e);
   if (h->d_counter) hipFree(h->d_counter);
   if (h->d_dev_vals) hipFree(h->d_dev_vals);
   if (h->h_vals) hipHostFree(h->h_vals);
@@ -104,9 +117,13 @@ void dvm_ba_destroy(dvm_ba* h) {
 
 // Graph construction ("buildStructure", block_solver.hpp:143-295): vertex ordering, CSR incidence
 // lists and the block pattern of the reduced camera matrix.  Done once per problem on the host.
-int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
-                       const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam) {
-  if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1) { set_error("dvm_ba_set_problem: bad arguments"); return DVM_ERR_INVALID; }
+static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
+                            const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
+  if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1 || world < 1 || rank < 0 || rank >= world) {
+    set_error("dvm_ba_set_problem: bad arguments");
+    return DVM_ERR_INVALID;
+  }
+  h->rank = rank; h->world = world;
   DVM_HIP(hipSetDevice(h->device));
   DVM_HIP(hipStreamSynchronize(h->stream));
   h->free_problem();
@@ -162,6 +179,38 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
         blocks[{i1, i2}].push_back({k1, k2});
       }
     }
+  // ---- landmark sharding: the STRUCTURE above (free cameras, ordering, block pattern, and below the tile schedule) comes from
+  // all edges and is identical on every rank; the edge arrays, the incidence lists and the (edge, edge) pairs keep only the
+  // edges of the landmarks this rank owns.  A landmark owned elsewhere has no local edge: for the kernels it is "not a vertex".
+  if (world > 1) {
+    std::vector<int32_t> loc_of(E, -1);
+    int El = 0;
+    for (int k = 0; k < E; k++) if (e_point[k] % world == rank) loc_of[k] = El++;
+    if (El == 0) { set_error("dvm_ba_set_problem_sharded: this rank owns no observed landmark"); return DVM_ERR_INVALID; }
+    std::vector<int32_t> ep(El), el(El);
+    std::vector<double> eo(2 * (size_t)El), ei(El);
+    for (int k = 0; k < E; k++) {
+      const int j = loc_of[k];
+      if (j < 0) continue;
+      ep[j] = e_pose[k]; el[j] = e_point[k]; eo[2 * (size_t)j] = e_obs[2 * (size_t)k]; eo[2 * (size_t)j + 1] = e_obs[2 * (size_t)k + 1]; ei[j] = e_info[k];
+    }
+    e_pose.swap(ep); e_point.swap(el); e_obs.swap(eo); e_info.swap(ei);
+    std::fill(pt_start.begin(), pt_start.end(), 0); std::fill(ps_start.begin(), ps_start.end(), 0);
+    for (int j = 0; j < El; j++) { pt_start[e_point[j] + 1]++; ps_start[e_pose[j] + 1]++; }
+    for (int l = 0; l < L; l++) pt_start[l + 1] += pt_start[l];
+    for (int p = 0; p < P; p++) ps_start[p + 1] += ps_start[p];
+    pt_edges.assign(El, 0); ps_edges.assign(El, 0);
+    std::vector<int32_t> pf(pt_start.begin(), pt_start.end() - 1), sf(ps_start.begin(), ps_start.end() - 1);
+    for (int j = 0; j < El; j++) { pt_edges[pf[e_point[j]]++] = j; ps_edges[sf[e_pose[j]]++] = j; }
+    for (auto& kv : blocks) {
+      std::vector<std::pair<int, int>> keep;
+      for (auto& pr : kv.second)
+        if (loc_of[pr.first] >= 0) keep.push_back({loc_of[pr.first], loc_of[pr.second]});   // same landmark: both local or neither
+      kv.second.swap(keep);
+    }
+    E = El;
+    V.E = El;
+  }
   std::vector<int32_t> blk_i1, blk_i2, blk_start{0}, pair_k1, pair_k2;
   for (auto& kv : blocks) {
     blk_i1.push_back(kv.first.first); blk_i2.push_back(kv.first.second);
@@ -235,8 +284,58 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   V.lambda = nullptr;   // damping travels by value (BaView::lambda_v)
+  V.damp_s = rank == 0 ? 1.0 : 0.0;
   h->have_problem = true;
   return DVM_OK;
+}
+
+int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
+                       const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam) {
+  return set_problem_impl(h, poses, fixed, P, points, L, edges, E, cam, 0, 1);
+}
+int dvm_ba_set_problem_sharded(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
+                               const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
+  return set_problem_impl(h, poses, fixed, P, points, L, edges, E, cam, rank, world);
+}
+int dvm_ba_set_allreduce(dvm_ba* h, dvm_allreduce_fn fn, void* ctx, void* d_buf, int64_t cap_doubles) {
+  if (!h) return DVM_ERR_INVALID;
+  h->allreduce = fn; h->allreduce_ctx = ctx; h->ar_buf = static_cast<double*>(d_buf); h->ar_cap = cap_doubles;
+  return DVM_OK;
+}
+int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out) {
+  if (!h || !h->have_problem || !out) return DVM_ERR_STATE;
+  const BaTileSchedule& SC = h->sched;
+  int64_t nlaunched = 0, ncols = 0, nstrips = 0, ntargets = 0, ncontrib = 0, ndiag_contrib = 0;
+  for (int lv = 0; lv < SC.nlevels; lv++) {
+    const int nc = SC.level_off[lv + 1] - SC.level_off[lv], ns = SC.strip_off[lv + 1] - SC.strip_off[lv], nt = SC.tgt_off[lv + 1] - SC.tgt_off[lv];
+    if (lv == SC.nlevels - 1 && nc == 1 && ns == 0 && nt == 0) break;   // the rhs tile alone: not launched
+    nlaunched++; ncols += nc; nstrips += ns; ntargets += nt;
+    for (int t = SC.tgt_off[lv]; t < SC.tgt_off[lv + 1]; t++) {
+      const int64_t n = SC.targets[4 * t + 3] - SC.targets[4 * t + 2];
+      ncontrib += n;
+      if (SC.targets[4 * t] == SC.targets[4 * t + 1]) ndiag_contrib += n;
+    }
+  }
+  out[0] = nlaunched; out[1] = ncols; out[2] = nstrips; out[3] = ntargets; out[4] = ncontrib; out[5] = ndiag_contrib;
+  out[6] = h->V.n_nz; out[7] = h->V.ldS; out[8] = h->V.nfree; out[9] = h->V.nblk; out[10] = h->V.E; out[11] = SC.ntiles;
+  return DVM_OK;
+}
+int dvm_ba_profile(dvm_ba* h, int enable, double* ms4, int32_t* trials, int32_t* iters) {
+  if (!h) return DVM_ERR_INVALID;
+  if (ms4) for (int k = 0; k < 4; k++) ms4[k] = h->prof_ms[k];
+  if (trials) *trials = h->prof_trials;
+  if (iters) *iters = h->prof_iters;
+  if (enable >= 0) {
+    h->prof = enable != 0;
+    if (h->prof && !h->pev[0]) for (auto& e : h->pev) if (hipEventCreate(&e) != hipSuccess) return DVM_ERR_HIP;
+    for (double& v : h->prof_ms) v = 0;
+    h->prof_trials = h->prof_iters = 0;
+  }
+  return DVM_OK;
+}
+int64_t dvm_ba_allreduce_doubles(const dvm_ba* h) {
+  if (!h || !h->have_problem) return 0;
+  return std::max<int64_t>({(int64_t)h->V.n_nz * 4096, 3 * (int64_t)h->V.L, 6 * (int64_t)h->V.nfree, 8});
 }
 
 // Wait until the device has released sequence number `seq` into the mapped host memory (BaPublish).  Spinning on host
@@ -280,6 +379,15 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     p.slot = slot; p.publish = publish ? 1 : 0;
     return p;
   };
+  const bool sharded = h->world > 1;
+  if (sharded && (!h->allreduce || !h->ar_buf || h->ar_cap < dvm_ba_allreduce_doubles(h))) {
+    set_error("dvm_ba_optimize: sharded problem without dvm_ba_set_allreduce (callback + device buffer of dvm_ba_allreduce_doubles())");
+    return DVM_ERR_STATE;
+  }
+  // collectives of the sharded mode: in-place over ranks, on the caller's device buffer (ordered on the BA stream) or on a
+  // few host doubles
+  auto ar_dev = [&](int64_t n, int op) { return h->allreduce(h->allreduce_ctx, h->ar_buf, n, 0, op, (void*)s) == 0 ? DVM_OK : DVM_ERR_HIP; };
+  auto ar_host = [&](double* v, int64_t n, int op) { return h->allreduce(h->allreduce_ctx, v, n, 1, op, (void*)s) == 0 ? DVM_OK : DVM_ERR_HIP; };
   double lambda = -1, ni = 2;
   int nBad = 0, it_done = 0, trials_total = 0, stop = 0;
   double chi_last = 0;
@@ -287,12 +395,28 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   for (int it = 0; it < iterations && !terminate(); it++) {
     // computeActiveErrors + activeRobustChi2 + buildSystem (one fused edge pass at the current state).  chi2 reaches the
     // host from the edge pass itself, so the accumulation kernels below run while the host prepares the first trial.
-    ba_launch_edge_eval(s, V, true, pub(S_CHI, 0, it != 0, false));
+    if (h->prof) hipEventRecord(h->pev[0], s);
+    ba_launch_edge_eval(s, V, true, pub(S_CHI, 0, it != 0 || sharded, false));
     ba_launch_accum(s, V);
-    if (it == 0) ba_launch_max_diag(s, V, pub(S_MAXDIAG, 1, true, false));
+    if (h->prof) hipEventRecord(h->pev[1], s);
+    if (it == 0 && !sharded) ba_launch_max_diag(s, V, pub(S_MAXDIAG, 1, true, false));
     int rc = hip_check(hipGetLastError(), "bundle adjustment launch");
     if (rc == DVM_OK) rc = wait_seq(h, h->seq);
     if (rc != DVM_OK) return rc;
+    if (sharded) {
+      double v = h->h_vals[S_CHI];                       // chi2 of the local edges (read before the next publication rewrites the slots)
+      if ((rc = ar_host(&v, 1, 0)) != DVM_OK) return rc;
+      if (it == 0) {   // computeLambdaInit needs max |diag| of the SUMMED Hpp and of every Hll
+        ba_launch_hpp_diag(s, V, h->ar_buf);
+        if ((rc = ar_dev(6 * (int64_t)V.nfree, 0)) != DVM_OK) return rc;
+        ba_launch_max_diag_sharded(s, V, h->ar_buf, pub(S_MAXDIAG, 1, true, false));
+        if ((rc = wait_seq(h, h->seq)) != DVM_OK) return rc;
+        double m = h->h_vals[S_MAXDIAG];
+        if ((rc = ar_host(&m, 1, 1)) != DVM_OK) return rc;
+        h->h_vals[S_MAXDIAG] = m;
+      }
+      h->h_vals[S_CHI] = v;
+    }
     double currentChi = h->h_vals[S_CHI], tempChi = currentChi;
     const double iniChi = currentChi;
     if (it == 0) {
@@ -306,13 +430,35 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       // one trial = setLambda + Schur complement + reduced solve + landmarks + oplus into the TRIAL state + its chi2:
       // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
       V.lambda_v = lambda;
+      if (h->prof) {
+        if (qmax == 0) { hipEventSynchronize(h->pev[1]); float ms = 0; hipEventElapsedTime(&ms, h->pev[0], h->pev[1]); h->prof_ms[0] += ms; h->prof_iters++; }
+        hipEventRecord(h->pev[0], s);
+      }
       ba_launch_schur(s, V, h->d_fail);
+      if (h->prof) hipEventRecord(h->pev[1], s);
+      if (sharded) {   // sum the partial reduced systems (non-zero tiles incl. the rhs row): ~6 MB at 500 keyframes
+        ba_launch_pack_tiles(s, V, h->ar_buf, false);
+        if ((rc = ar_dev((int64_t)V.n_nz * 4096, 0)) != DVM_OK) return rc;
+        ba_launch_pack_tiles(s, V, h->ar_buf, true);
+      }
       ba_launch_cholesky_solve(s, V, h->d_fail, ++h->solve_seq);
+      if (h->prof) hipEventRecord(h->pev[2], s);
       ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
       ba_launch_edge_eval(s, V, false, pub(S_TMPCHI, 0, true, true));
+      if (h->prof) hipEventRecord(h->pev[3], s);
       rc = hip_check(hipGetLastError(), "bundle adjustment launch");
       if (rc == DVM_OK) rc = wait_seq(h, h->seq);
       if (rc != DVM_OK) return rc;
+      if (h->prof) {
+        hipEventSynchronize(h->pev[3]);
+        for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, h->pev[k], h->pev[k + 1]); h->prof_ms[1 + k] += ms; }
+        h->prof_trials++;
+      }
+      if (sharded) {
+        double v[2] = {h->h_vals[S_TMPCHI], h->h_vals[S_SCALE]};
+        if ((rc = ar_host(v, 2, 0)) != DVM_OK) return rc;
+        h->h_vals[S_TMPCHI] = v[0]; h->h_vals[S_SCALE] = v[1];
+      }
       const bool ok2 = (h->h_vals[S_FAIL] == 0.0);
       tempChi = ok2 ? h->h_vals[S_TMPCHI] : std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
@@ -340,6 +486,12 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     if (qmax == 10 || rho == 0) { stop = 1; break; }
     if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
     if (nBad >= 3) { stop = 2; break; }
+  }
+  if (sharded) {   // every rank ends with every landmark: owners contribute theirs, the sum is scattered back
+    ba_launch_points_exchange(s, V, h->ar_buf, false);
+    const int rc = ar_dev(3 * (int64_t)V.L, 0);
+    if (rc != DVM_OK) return rc;
+    ba_launch_points_exchange(s, V, h->ar_buf, true);
   }
   DVM_HIP(hipStreamSynchronize(s));
   if (st) {

@@ -307,6 +307,32 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
  * iterations and trials, may be written by another thread (LocalMapping.cc:305,359) */
 int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
 int dvm_ba_get_result(dvm_ba* h, double* poses, double* points);
+/* BASELINE.json config 5 (global BA sharded over the GPUs of a node; the reference solves it on one CPU thread,
+ * Optimizer.cc:44-53 -> block_solver.hpp:381-439): rank r of `world` receives the WHOLE problem (so that the free-camera
+ * order, the block pattern and the tile schedule are identical everywhere) but evaluates only the observations of the
+ * landmarks it owns (point % world == rank): edge pass, Hll / Hpl, its share of Hpp / b and of the Schur complement.  Per LM
+ * trial the partial reduced camera systems -- the structurally non-zero 64x64 tiles, rhs row included -- are summed over the
+ * ranks through the caller's all-reduce (RCCL over xGMI), every rank factors the sum redundantly, back-substitutes its own
+ * landmarks and moves all cameras; chi2 / scale are two more host scalars.  dvm_ba_optimize ends with one exchange of the
+ * landmarks, so dvm_ba_get_result returns the full state on every rank.  dvm_ba_edge_chi2 then covers the LOCAL edges
+ * (those with point % world == rank, in input order).
+ * dvm_allreduce_fn: in-place reduction over all ranks of n doubles at `buf` -- device memory (on_host = 0; must be ordered
+ * after the work already queued on `stream` and before work queued later) or host memory (on_host = 1); op 0 = sum,
+ * 1 = max; returns 0 on success.  d_buf: device buffer of at least dvm_ba_allreduce_doubles() doubles owned by the caller
+ * (e.g. a torch tensor, so that torch.distributed can reduce it). */
+typedef int (*dvm_allreduce_fn)(void* ctx, void* buf, int64_t n, int on_host, int op, void* stream);
+int dvm_ba_set_problem_sharded(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
+                               const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world);
+int dvm_ba_set_allreduce(dvm_ba* h, dvm_allreduce_fn fn, void* ctx, void* d_buf, int64_t cap_doubles);
+int64_t dvm_ba_allreduce_doubles(const dvm_ba* h);
+/* Measurement aids (bench.py).  dvm_ba_schedule_info: the symbolic tile factorisation of the current problem,
+ * out[12] = {levels launched, tile columns, strips (trsm tiles), update targets, (target, contributor) products, of which on
+ * diagonal targets, non-zero tiles, ldS, free cameras, non-zero 6x6 blocks, local edges, tiles per side} -- what the executed
+ * FLOP count of one LM trial follows from.  dvm_ba_profile: enable (1) / disable (0) / read only (-1) HIP-event timing of the
+ * four phases of a trial; ms4 = {linearise, Schur complement, tile Cholesky + back substitution, landmarks + update + chi2}
+ * accumulated since the last enable, over *trials trials / *iters iterations. */
+int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out);
+int dvm_ba_profile(dvm_ba* h, int enable, double* ms4, int32_t* trials, int32_t* iters);
 /* per-edge chi2() as g2o reports it after optimize(), and isDepthPositive() (outlier tests of
  * Optimizer.cc:1317-1354); either output may be NULL */
 int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive);

@@ -1,0 +1,45 @@
+"""BASELINE.json config 5, the landmark-sharded global BA (dvm_ba_set_problem_sharded + the all-reduce of the reduced camera
+system's non-zero tiles): two / three ranks sharing the test box's one GPU over gloo must walk the same LM trial sequence
+as the single-GPU solver and end within 1e-6 of it (and of the CPU oracle), every rank holding the full result."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,n_kf,n_pts,delta,iters,port", [(2, 40, 1500, float(np.sqrt(5.991)), 8, 29611), (3, 100, 4000, 0.0, 5, 29612),
+                                                              (2, 500, 20000, float(np.sqrt(5.991)), 6, 29613)])
+def test_sharded_ba_matches_single_gpu(capi, oracle, world, n_kf, n_pts, delta, iters, port):
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=n_kf * 31 + n_pts)
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    s1 = ba.optimize(iters)
+    p1, x1 = ba.result()
+    ba.close()
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "res")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_ba_worker.py"), str(n_kf), str(n_pts), repr(delta), str(iters), out]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        res = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    for z in res:
+        assert list(z["trials"]) == s1["trials"], "LM accept / reject sequence differs from the single-GPU run"
+        assert abs(float(z["chi2_initial"]) - s1["chi2_initial"]) <= 1e-10 * s1["chi2_initial"]
+        assert np.allclose(z["chi2"], s1["chi2"], rtol=1e-9) and np.allclose(z["lam"], s1["lam"], rtol=1e-6)
+        assert np.abs(z["poses"] - p1).max() < 1e-6 and np.abs(z["points"] - x1).max() < 1e-6
+        # one tile all-reduce + two host scalars per trial, chi2 per iteration, lambda init, the final landmark exchange
+        assert int(z["calls"]) == 2 * sum(s1["trials"]) + len(s1["trials"]) + 2 + 1
+    for z in res[1:]:      # every rank ends with the same full state, bit for bit (identical sums on all ranks)
+        assert np.array_equal(z["poses"], res[0]["poses"]) and np.array_equal(z["points"], res[0]["points"])
+    po_, pto, so, _ = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, iters)
+    assert list(res[0]["trials"]) == so["trials"]
+    assert np.abs(res[0]["poses"] - po_).max() < 1e-6 and np.abs(res[0]["points"] - pto).max() < 1e-6
