@@ -6,9 +6,21 @@ import time
 
 import numpy as np
 
-# per single-trial iteration, dense reduced system n = 6*499 = 2994
+# per single-trial iteration, dense reduced system n = 6*499 = 2994 (the dense-equivalent figure, kept as a note)
 FLOPS_DENSE_CHOLESKY = 2994 ** 3 / 3.0
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (CDNA4), also the FP64 vector peak
+HBM_PEAK_GBS = 8000.0
+T3 = 64 ** 3
+
+
+def executed_flops_per_trial(info):
+    """FLOPs the tile solver actually executes per LM trial, from the symbolic factorisation (dvm_ba_schedule_info): per tile
+    column a 64x64 Cholesky + triangular inverse (2 * 64^3 / 3), per strip a 64^3 GEMM (trsm by the inverse), per
+    (target, contributor) product a 64^3 GEMM (three quadrants of four on diagonal targets), back substitution 2 * 64^2 per
+    strip and column."""
+    gemm = 2.0 * T3
+    return (info["columns"] * gemm / 3.0 + info["strips"] * gemm + (info["products"] - 0.25 * info["products_on_diagonal_targets"]) * gemm
+            + (info["strips"] + info["columns"]) * 2.0 * 64 * 64)
 
 
 def _prewarm(seconds: float):
@@ -23,7 +35,9 @@ def _prewarm(seconds: float):
         torch.cuda.synchronize()
 
 
-def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float = 0.0):
+def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float = 0.0, repeats: int = 20):
+    """The timed region is `repeats` optimisations of `iters` LM iterations each of the same problem (set_problem, i.e. the
+    reference's graph construction, outside it), so that it lasts long enough for clock sampling to see it."""
     from dvm_slam_amd import capi, synth
     if prewarm_s > 0:
         _prewarm(prewarm_s)
@@ -33,28 +47,53 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
     ba = capi.BundleAdjuster(device)
     ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
     ba.optimize(2)  # warm-up (kernel load)
-    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
-    t0 = time.perf_counter()
-    st = ba.optimize(iters)
-    dt = time.perf_counter() - t0
+    dt, its, trials = 0.0, 0, 0
+    for _ in range(max(1, repeats)):
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        t0 = time.perf_counter()
+        st = ba.optimize(iters)
+        dt += time.perf_counter() - t0
+        its += st["iterations"]; trials += st["total_trials"]
     poses_g, points_g = ba.result()
+    info = ba.schedule_info()
+    # second pass with HIP events around the phases of every trial (not part of `value`)
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    ba.profile(1)
+    ba.optimize(iters)
+    prof = ba.profile(0)
     ba.close()
+    fl = executed_flops_per_trial(info)
+    t_solve = prof["ms_cholesky_solve"] / max(prof["trials"], 1) * 1e-3
+    nblk_pairs = None
+    E, L, nfree = info["edges"], len(pr["points"]), info["free_cameras"]
+    hbm = {  # algorithmic bytes of the memory-bound phases per launch group / measured event time
+        "linearise": {"bytes": E * (256 + 192), "ms": prof["ms_linearise"] / max(prof["iterations"], 1)},
+        "landmarks_update_chi2": {"bytes": E * (18 * 8 + 64) + L * 9 * 8 * 2 + E * 64, "ms": prof["ms_update_chi2"] / max(prof["trials"], 1)},
+    }
+    for v in hbm.values():
+        v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None
+        v["frac_of_8TBps"] = v["GBps"] / HBM_PEAK_GBS if v["GBps"] else None
     out = {
         "metric": "BA iterations/sec, 500 KF / 20k landmarks / 160k observations (outer LM iterations)",
-        "value": st["iterations"] / dt, "unit": "iterations/s", "iterations": st["iterations"],
-        "trials": st["total_trials"], "ms_per_iteration": dt / max(st["iterations"], 1) * 1e3,
+        "value": its / dt, "unit": "iterations/s", "iterations": its, "trials": trials, "runs": max(1, repeats),
+        "ms_per_iteration": dt / max(its, 1) * 1e3,
         "ms_graph_build_excluded": st["ms_structure"], "chi2_initial": st["chi2_initial"], "chi2_final": st["chi2_final"],
         "dtype": "f64", "huber_delta": delta,
-        "gpu_state": "hot (timed right after GPU work; an idle MI355X stays at its 584 MHz idle clock under this host-"
-                     "synchronised LM loop: ~315 it/s cold vs ~1250 it/s hot)",
-        "roofline": {"bound": "mfma", "kernel": "k_chol_diag/k_chol_trsm/k_chol_update: reduced-camera Cholesky on v_mfma_f64_16x16x4",
-                     "achieved": FLOPS_DENSE_CHOLESKY * st["total_trials"] / dt / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": FLOPS_DENSE_CHOLESKY * st["total_trials"] / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
-                     "note": "dense-equivalent rate: n^3/3 FLOP of a dense n=2994 factorisation per trial over the WHOLE "
-                             "iteration time (edge pass, Schur, solve, update); the solver itself skips structurally zero "
-                             "64x64 tiles (symbolic tile fill), so executed FLOPs are lower -- the solve is a dependency chain of "
-                             "elimination-tree levels (9 at this size after nested dissection, 8 launched; 47 tile columns before), "
-                             "each level = 3 launches, not MFMA-throughput bound (DESIGN.md section 3)"},
+        "gpu_state": "hot (timed right after GPU work; the LM loop polls mapped host memory instead of synchronising the stream)",
+        "roofline": {"bound": "mfma", "kernel": "k_chol_diag / k_chol_trsm / k_chol_update (+ k_chol_backsolve): tile Cholesky of the reduced "
+                                               "camera system on v_mfma_f64_16x16x4",
+                     "achieved": fl / t_solve / 1e12 if t_solve > 0 else None, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fl / t_solve / 1e12 / FP64_MATRIX_PEAK_TFLOPS if t_solve > 0 else None,
+                     "executed_flop_per_trial": fl, "solve_ms_per_trial": t_solve * 1e3, "schedule": info,
+                     "traffic": None,
+                     "note": "EXECUTED FLOPs of the symbolic tile factorisation (dvm_ba_schedule_info) over the HIP-event time of the "
+                             "factorisation + back substitution launches of a trial.  The solve is a dependency chain of elimination-tree "
+                             "levels (diag -> trsm -> update per level), not matrix-pipe bound; dense-equivalent (n^3/3 per trial over the "
+                             f"whole iteration): {FLOPS_DENSE_CHOLESKY * trials / dt / 1e12:.2f} TFLOP/s"},
+        "phase_ms": {"linearise_per_iteration": prof["ms_linearise"] / max(prof["iterations"], 1),
+                     "schur_per_trial": prof["ms_schur"] / max(prof["trials"], 1), "cholesky_solve_per_trial": t_solve * 1e3,
+                     "landmarks_update_chi2_per_trial": prof["ms_update_chi2"] / max(prof["trials"], 1)},
+        "hbm": hbm,
     }
     if cpu_seconds > 0:
         out["cpu_baseline"], (poses_c, points_c, st_c) = cpu_baseline(pr, delta, cpu_seconds, iters)
@@ -66,6 +105,40 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
         if not (par["trials_equal"] and par["chi2_final_rel"] <= 1e-9 and par["max_abs_pose"] < 1e-6 and par["max_abs_landmark"] < 1e-6):
             raise RuntimeError(f"BA leg: GPU result differs from the CPU oracle on the benchmarked problem: {par}")
     return out
+
+
+def run_sharded(device: int, iters: int = 10, repeats: int = 5):
+    """Config 5: the same problem, landmark-sharded over all ranks of the job (every rank calls this).  Returns the record on
+    every rank; wall time is the max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from dvm_slam_amd import capi, sharded_ba, synth
+    pr = synth.ba_problem()
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(5.991))
+    sb = sharded_ba.ShardedBundleAdjuster(device)
+    sb.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    sb.optimize(2)
+    dt, its, trials = 0.0, 0, 0
+    for _ in range(repeats):
+        sb.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        sb.calls = sb.bytes_reduced = 0
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = sb.optimize(iters)
+        torch.cuda.synchronize()
+        dt += time.perf_counter() - t0
+        its += st["iterations"]; trials += st["total_trials"]
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if sb.on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    rec = {"metric": "BA iterations/sec, 500 KF / 20k landmarks, landmark-sharded over the ranks (config 5)", "value": its / dt,
+           "unit": "iterations/s", "ranks": sb.world, "iterations": its, "trials": trials, "ms_per_iteration": dt / max(its, 1) * 1e3,
+           "allreduce_calls_per_run": sb.calls, "allreduce_bytes_per_run": sb.bytes_reduced, "chi2_final": st["chi2_final"],
+           "backend": "nccl (RCCL)" if sb.on_gpu else "gloo (through the host: test configuration)"}
+    sb.close()
+    return rec
 
 
 def cpu_baseline(pr, delta, budget_s, iters):

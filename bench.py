@@ -3,10 +3,11 @@
 
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
 
-A "step" = one batch of `--batch` synthetic 640x480 frames through the whole front end on one GPU:
-ORB extract (8-level pyramid, per-cell FAST, octree, orientation, blur, rBRIEF, 1000 features) +
-frame-to-frame windowed Hamming matching against the previous frame (M3 rule, th=15).  Inputs are
-resident in HBM before the timed region.  One agent (= one frame stream) per GPU, no data-path
+A "step" = `--chunks-per-step` x `--batch` (default 80 x 256 = 20 480) synthetic 640x480 frames of the agent's stream through
+the whole front end on one GPU: ORB extract (8-level pyramid, per-cell FAST, octree, orientation, blur, rBRIEF, 1000 features)
++ frame-to-frame windowed Hamming matching against the previous frame (M3 rule, th=15), launched 256 frames at a time.
+1024 distinct frames (315 MB, more than the 256 MiB MALL) are resident in HBM before the timed region and cycled; the
+driver's 20 steps make a timed region of ~2 s.  One agent (= one frame stream) per GPU, no data-path
 collective: `value` = frames processed by all ranks / max-over-ranks wall time ("weak" scaling).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
@@ -37,10 +38,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s ach
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step (per GPU)")
-    ap.add_argument("--stream-frames", type=int, default=256, help="distinct synthetic frames resident in HBM")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per launch group (per GPU)")
+    ap.add_argument("--chunks-per-step", type=int, default=80, help="launch groups per step: a step is chunks x batch frames")
+    ap.add_argument("--stream-frames", type=int, default=1024, help="distinct synthetic frames resident in HBM (cycled)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--lanes", type=int, default=2, help="double-buffered pipeline instances the batches alternate over")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the one-lane k_fast_cells pass (clean rocprofv3 averages)")
@@ -213,7 +215,13 @@ def main():
                           nq=torch.zeros(B, dtype=torch.int32, device="cuda"), scale=ext.scale_factors_device()))
     nbatches = nstream // B
 
-    def step(i):
+    chunks = max(1, a.chunks_per_step)
+
+    def step(s_idx):
+        for j in range(chunks):
+            chunk(s_idx * chunks + j)
+
+    def chunk(i):
         ln, prev = lanes[i % nl], lanes[(i - 1) % nl]
         ext, grid, (k_ptr, d_ptr, n_ptr) = ln["ext"], ln["grid"], ln["res"]
         off = (i % nbatches) * B
@@ -256,7 +264,9 @@ def main():
     for k in ("pyramid", "fast", "octree", "assemble", "blur", "orient_desc"):
         parts = [ln["ext"].profile_get(k) for ln in lanes]
         prof[k] = (sum(p[0] for p in parts), sum(p[1] for p in parts))
-    nmatched = int((lanes[(a.warmup + a.steps - 1) % nl]["matches"][:, :, 1] <= 100).sum().item())  # TH_HIGH gate, sanity only
+    last = lanes[((a.warmup + a.steps) * chunks - 1) % nl]
+    valid = torch.arange(last["matches"].shape[1], device="cuda")[None, :] < last["nq"][:, None]     # rows beyond a pair's query count are stale
+    nmatched = int(((last["matches"][:, :, 1] <= 100) & valid).sum().item())  # TH_HIGH gate, sanity only
     ext, grid = lanes[0]["ext"], lanes[0]["grid"]
     # k_fast_cells alone on the chip (one lane, nothing overlapping it): the kernel-quality figure next to the one the
     # pipelined timed region yields; same live HIP-event measurement, 8 further steps, not part of `value`
@@ -269,31 +279,63 @@ def main():
         ext.profiling(False)
         excl = ext.profile_get("fast")
 
+    # BASELINE config 5: the 500-keyframe global BA landmark-sharded over all ranks (dvm_slam_amd/sharded_ba.py), reported beside
+    # the one-GPU number of the `ba` leg.  Every rank takes part; a watchdog bounds the damage if a collective wedges.
+    sharded_rec = None
+    if world > 1 and not a.no_ba:
+        import threading
+        box = {}
+
+        def _sharded():
+            try:
+                import ba_bench
+                box["rec"] = ba_bench.run_sharded(local, a.ba_iters)
+            except Exception as ex:   # noqa: BLE001
+                box["rec"] = {"error": repr(ex)}
+
+        th = threading.Thread(target=_sharded, daemon=True)
+        th.start()
+        th.join(timeout=180.0)
+        sharded_rec = box.get("rec", {"error": "timed out after 180 s"})
+        hard_exit = th.is_alive()
+    else:
+        hard_exit = False
     if rank == 0:
-        total_frames = world * a.steps * B
+        total_frames = world * a.steps * chunks * B
         fast_ms, fast_n = prof["fast"]
         roof = None
         if fast_n:
             per_launch_s = fast_ms / fast_n / 1e3
-            frames_per_launch = a.steps * B / fast_n          # = B (one k_fast_cells launch per batch)
+            frames_per_launch = a.steps * chunks * B / fast_n          # = B (one k_fast_cells launch per 256-frame chunk)
             ach = BYTES_PER_FRAME_FAST * frames_per_launch / per_launch_s / 1e9
             traffic = None
-            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same batch size only)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc, pmc_file = None, None
+            for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                    pmc_file = cand
+                    break
+                except Exception:
+                    pmc = None
+            try:  # HBM bytes per launch from the committed PMC passes (same launch-group size only)
                 if pmc["batch"] == frames_per_launch:
                     traffic = pmc["kernels"]["dvm::k_fast_cells"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
             valu = None
-            try:  # VALU issue time of the whole step from the committed SQ_INSTS_VALU pass (same kernels, same batch)
+            try:  # VALU issue time of one 256-frame launch group from the committed SQ_INSTS_VALU pass
                 if pmc["batch"] == frames_per_launch:
-                    per_step = {"dvm::k_pyr_level0": 1, "dvm::k_pyr_resize": 7, "dvm::k_fast_cells": 1, "dvm::k_blur7": 1, "dvm::k_octree": 1,
-                                "dvm::k_assemble": 1, "dvm::k_orient_desc": 1, "dvm::k_frame_build": 1, "dvm::k_match_window": 1}
-                    ms = sum(pmc["kernels"][k]["valu_issue_ms"] * n for k, n in per_step.items())
-                    valu = {"issue_ms_per_step": ms, "frac_of_step": ms / (dt / a.steps * 1e3),
-                            "k_fast_cells_issue_ms": pmc["kernels"]["dvm::k_fast_cells"]["valu_issue_ms"],
-                            "note": "sum over the step's kernels of SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), from profiles/"
-                                    "r01_pmc_traffic.json: the path is VALU-issue bound, not HBM bound (DESIGN.md section 3)"}
+                    per_chunk = {"dvm::k_pyr_level0": 1, "dvm::k_pyr_resize": 7, "dvm::k_fast_cells": 1, "dvm::k_blur7": 1, "dvm::k_octree": 1,
+                                 "dvm::k_assemble": 1, "dvm::k_orient_desc": 1, "dvm::k_frame_build": 1, "dvm::k_match_window": 1}
+                    wi = sum(pmc["kernels"][k]["valu_wave_instr_per_launch"] * n for k, n in per_chunk.items())
+                    chunk_ms = dt / (a.steps * chunks) * 1e3
+                    ms2, ms4 = wi * 2 / (1024 * 2.4e9) * 1e3, wi * 4 / (1024 * 2.4e9) * 1e3
+                    valu = {"wave_instr_per_launch_group": wi, "issue_ms_if_all_2_cycle": ms2, "issue_ms_if_all_4_cycle": ms4,
+                            "launch_group_ms": chunk_ms, "frac_low": ms2 / chunk_ms, "frac_high": ms4 / chunk_ms, "source": f"profiles/{pmc_file}",
+                            "note": "SQ_INSTS_VALU x cycles / (1024 SIMDs x 2.4 GHz).  Measured issue cost on gfx950 (tools/valu_issue.hip, "
+                                    "profiles/r02_valu_issue.jsonl): 2 cycles per wave-instruction for VOP2 (v_add_u32, v_min_u16, v_and_b32 ...), "
+                                    "4 for every VOP3 / VOP3P form (v_pk_min/max_u16, v_perm_b32, v_min3, v_dot4, v_sad, v_mad, v_readlane ...), "
+                                    "8 for v_min3_u16 / v_max3_u16; these kernels mix both classes, so the truth lies between the two bounds"}
             except Exception:
                 valu = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -303,7 +345,9 @@ def main():
                     "all_stage_bytes_per_frame": BYTES_PER_FRAME_TOTAL,
                     "pipeline_achieved": BYTES_PER_FRAME_TOTAL * total_frames / world / dt / 1e9,   # whole step, GB/s per GPU
                     "pipeline_frac": BYTES_PER_FRAME_TOTAL * total_frames / world / dt / 1e9 / HBM_PEAK_GBS,
-                    "gpu_kernel_ms_per_step": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()},
+                    "gpu_kernel_event_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()},
+                    "gpu_kernel_event_note": "HIP-event span of each stage's launches on its own stream; the two lanes and the low-priority "
+                                             "blur stream overlap, so these are NOT additive work figures (blur alone spans most of a launch group)",
                     "valu_issue": valu,
                     "note": f"{nl} pipeline lanes: k_fast_cells launches of one batch overlap the tail kernels of the previous batch, so the "
                             "per-launch duration above includes that contention" if nl > 1 else None}
@@ -318,7 +362,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "single agent tracking front end: 640x480 8-level ORB extract (1000 features) + "
                                    "frame-to-frame windowed Hamming match, one agent per GPU",
-                       "frames_per_step_per_gpu": B, "nfeatures": 1000, "nlevels": 8, "scale_factor": 1.2,
+                       "frames_per_step_per_gpu": chunks * B, "frames_per_launch_group": B, "launch_groups_per_step": chunks,
+                       "resident_stream_frames": nstream, "nfeatures": 1000, "nlevels": 8, "scale_factor": 1.2,
                        "ini_th_fast": 20, "min_th_fast": 7, "match": "SearchByProjection(Cur,Last) window th=15",
                        "parallelism": f"agents{world}", "pipeline_lanes": nl},
             "roofline": roof, "sanity_matches_le_TH_HIGH_last_step": nmatched,
@@ -326,7 +371,7 @@ def main():
         if world == 1 and not a.no_pcie:
             for ln in lanes:             # a handle owns two streams; more than four per process share hardware queues
                 ln["ext"].close(); ln["grid"].close()
-            out["pcie_inclusive"] = pcie_inclusive_leg(capi, frames, B, max(8, a.steps // 2), local)
+            out["pcie_inclusive"] = pcie_inclusive_leg(capi, frames, B, max(16, a.steps * chunks // 8), local)
         # BA leg first, while the GPU is still in its operating power state from the extract leg: the LM loop alone
         # (host-synchronised, mostly single-workgroup kernels) does not lift an idle MI355X off its 584 MHz idle clock
         # (measured: 315 it/s cold vs 1050 it/s hot); the CPU baseline below leaves the GPU idle for ~12 s.
@@ -336,9 +381,14 @@ def main():
                 out["ba"] = ba_bench.run(local, a.ba_iters, cpu_seconds=6.0 if a.cpu_seconds > 0 else 0.0)
             except ImportError:
                 out["ba"] = None
+        if sharded_rec is not None:
+            out["ba_sharded"] = sharded_rec
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if hard_exit:          # a wedged collective: the line is out, do not wait for the process group
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

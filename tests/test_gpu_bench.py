@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "64", "--stream-frames", "64",
-                          "--no-ba", *extra], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "64", "--stream-frames", "128",
+                          "--chunks-per-step", "3", "--no-ba", *extra], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -27,6 +27,7 @@ def test_bench_contract_and_lane_equivalence():
         assert k in d2, k
     assert d2["n_gpus"] == 1 and d2["steps"] == 4 and d2["warmup"] == 2 and d2["vs_baseline"] is None and d2["dtype"] == "u8"
     assert "workload" in d2["config"] and d2["config"]["pipeline_lanes"] == 2
+    assert d2["config"]["frames_per_step_per_gpu"] == 3 * 64 and abs(d2["value"] - 4 * 3 * 64 / (d2["ms_per_step"] * 4 / 1e3)) < 1e-6 * d2["value"]
     r = d2["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert r["exclusive"]["avg_launch_ms"] > 0
@@ -44,13 +45,19 @@ def test_bench_two_ranks_control_flow():
     the same file with one rank per GPU over RCCL)."""
     env = dict(os.environ, DVM_BENCH_SHARE_GPU="1", DVM_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--stream-frames", "32", "--no-ba",
-           "--cpu-seconds", "0"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--stream-frames", "64",
+           "--chunks-per-step", "2", "--ba-iters", "3", "--cpu-seconds", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]          # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "agents2"
-    assert abs(d["value"] - 2 * 3 * 32 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]      # whole-job frames over the max-over-ranks time
+    assert abs(d["value"] - 2 * 3 * 2 * 32 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]   # whole-job frames over the max-over-ranks time
     assert "pcie_inclusive" not in d                     # N = 1 only
+    # config 5 beside the one-GPU BA: the landmark-sharded solve over both ranks (gloo here, RCCL under the driver)
+    sh, one = d["ba_sharded"], d["ba"]
+    assert "error" not in sh, sh
+    assert sh["ranks"] == 2 and sh["value"] > 0 and sh["allreduce_bytes_per_run"] > 1e6
+    assert abs(sh["chi2_final"] - one["chi2_final"]) <= 1e-9 * one["chi2_final"]
+    assert one["roofline"]["frac"] > 0 and one["roofline"]["schedule"]["nz_tiles"] > 100
