@@ -434,6 +434,12 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
 // zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
 #define DVM_PERM2(a, b, i0, i1) __builtin_amdgcn_perm((a), (b), 0x0c000c00u | (uint32_t)(i0) | ((uint32_t)(i1) << 16))
 
+#ifdef DVM_FAST_DEBUG
+__device__ unsigned long long g_fast_dbg[8192 * 8];
+#define DVM_FSTAMP(i) do { if (threadIdx.x == 0) { const long long t_ = __builtin_readcyclecounter(); unsigned long long* g_ = g_fast_dbg + (blockIdx.x & 8191) * 8; if (i) g_[i] += (unsigned long long)(t_ - t_prev_); else g_[0] += 1ull; t_prev_ = t_; } } while (0)
+#else
+#define DVM_FSTAMP(i) do { } while (0)
+#endif
 constexpr int kFastFramesPerWG = 4;   // a workgroup walks the same cell of 4 frames: amortises dispatch + prologue (8: measured slower, 0.61 vs 0.57 ms -- longer tail)
 template <int PITCH, int NW>
 __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int pyr_frame_bytes, const CellDesc& c,
@@ -452,6 +458,9 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
 
   const LevelDesc& L = PD.lv[c.level];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DVM_FAST_DEBUG
+  long long t_prev_ = 0;
+#endif
   const int rw = c.rw, rh = c.rh;
   const int ew = rw - 6, eh = rh - 6;  // evaluated area (FAST skips a 3-px frame of the ROI)
   const int sp = (ew + 2 + 3) & ~3;    // score pitch (1-px zero ring), multiple of 4
@@ -460,6 +469,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     if (tid == 0) *my_count = 0;
     return;
   }
+  DVM_FSTAMP(0);
   // ---- 1. tile load: aligned dwords covering each ROI row; LDS column = global column - (x_start & ~3)
   const int64_t row0 = (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + c.y0) * L.stride;
   const int xg = kEdge + c.x0;           // first ROI column inside the bordered row
@@ -494,6 +504,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   for (int i = tid; i < (sp * (eh + 2)) >> 2; i += NT) s32[i] = 0;
   if (tid == 0) s_cnt_ini = 0;
   __syncthreads();
+  DVM_FSTAMP(1);
 
   const uint8_t* T = tile + sh;
   // Two thresholds, like the reference: FAST(iniThFAST) first, the whole cell again at minThFAST only if that found nothing.
@@ -576,6 +587,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
       if (cc >= ncol) { cc -= ncol; ey++; }
     }
   }
+  DVM_FSTAMP(2);
   // ---- B. per wave, no barrier: full strength of the wave's OWN survivors.  Corners (score > 0) are compacted in
   // place at the head of the wave's list -- the write position never passes the read position -- with their scores
   // at the same offsets of `pscore`; the four corner lists concatenated are still row-major.
@@ -599,7 +611,9 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     }
     ncorner += __popcll(bc);
   }
+  DVM_FSTAMP(3);
   __syncthreads();   // the score map is complete
+  DVM_FSTAMP(4);
   // ---- C. per wave: strict local maxima among its corners; bit0 = passes iniTh, bit1 = passes minTh
   const int rounds = (ncorner + 63) >> 6;   // <= 32: a wave owns at most 2048 pixels
   uint32_t flags_lo = 0, flags_hi = 0;      // 2 bits per round
@@ -619,6 +633,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     else flags_hi |= (uint32_t)fl << (2 * (r - 16));
   }
   if (cnt_ini) atomicAdd(&s_cnt_ini, cnt_ini);
+  DVM_FSTAMP(5);
   __syncthreads();
   if (s_cnt_ini == 0) {   // workgroup-uniform: nothing at this threshold
     if (pass == 0 && PD.min_th < PD.ini_th) {
@@ -656,6 +671,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   }
     break;
   }
+  DVM_FSTAMP(6);
   if (tid == 0) *my_count = min(total, c.cand_cap);
 }
 
@@ -679,6 +695,16 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   }
 }
 
+#ifdef DVM_FAST_DEBUG
+extern "C" int dvm_debug_fast_stamps(unsigned long long* out, int reset) {
+  static unsigned long long h[8192 * 8];
+  int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast_dbg), sizeof(h));
+  for (int i = 0; i < 16; i++) out[i] = 0;
+  for (int b = 0; b < 8192; b++) for (int i = 0; i < 8; i++) out[i] += h[b * 8 + i];
+  if (reset) { for (auto& v : h) v = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_dbg), h, sizeof(h)); }
+  return rc;
+}
+#endif
 // ------------------------------------------------------------------------------------ assemble
 // operator() output placement (reference ORBextractor.cc:898-951).  One workgroup per frame.
 // Walks the selected keypoints in (level, octree-list) order g = 0..N-1, scales pt by
