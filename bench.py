@@ -181,12 +181,32 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local)
-    if world > 1:
+    # DVM_BENCH_FORCE_DIST=1 (tests/test_gpu_rccl.py): initialise the process group even for one rank, so that the RCCL branch --
+    # communicator on this GPU, barriers, the max-over-ranks all-reduce, the sharded-BA collectives on the solver's stream --
+    # executes on a 1-GPU box exactly as it does for N > 1
+    use_dist = world > 1 or os.environ.get("DVM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29650")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        exchange.SHORTCUT_SINGLE_RANK = not (world == 1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    def flush_c_stdio():
+        # RCCL announces itself ("Librccl path : ...") through C stdio, which is block-buffered on a pipe and would otherwise
+        # land AFTER the JSON line when the process exits: push it out now, on every rank
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+
+    if use_dist:
+        dist.barrier()          # creates the communicator (and makes RCCL print) before anything is timed
+        flush_c_stdio()
     B = a.batch
     nstream = max(a.stream_frames, B)
     nstream = (nstream + B - 1) // B * B
@@ -241,7 +261,7 @@ def main():
         for ln in lanes:
             ln["ext"].sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -282,7 +302,7 @@ def main():
     # BASELINE config 5: the 500-keyframe global BA landmark-sharded over all ranks (dvm_slam_amd/sharded_ba.py), reported beside
     # the one-GPU number of the `ba` leg.  Every rank takes part; a watchdog bounds the damage if a collective wedges.
     sharded_rec = None
-    if world > 1 and not a.no_ba:
+    if use_dist and not a.no_ba:
         import threading
         box = {}
 
@@ -385,11 +405,12 @@ def main():
             out["ba_sharded"] = sharded_rec
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
     if hard_exit:          # a wedged collective: the line is out, do not wait for the process group
         sys.stdout.flush()
         os._exit(0)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -36,6 +36,7 @@ struct dvm_ba {
   int solve_seq = 0;
   // landmark-sharded mode (dvm_ba_set_problem_sharded): rank r of `world` owns the landmarks l with l % world == r
   int rank = 0, world = 1;
+  bool sharded_api = false;   // problem set through dvm_ba_set_problem_sharded: with a collective registered, even a single rank runs the sharded flow
   // optional HIP-event timing of the phases of a trial (dvm_ba_profile): [0] linearise, [1] Schur complement, [2] tile Cholesky +
   // back substitution, [3] landmarks + update + chi2; milliseconds accumulated over prof_trials trials / prof_iters iterations
   bool prof = false;
@@ -291,11 +292,15 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
 
 int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
                        const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam) {
-  return set_problem_impl(h, poses, fixed, P, points, L, edges, E, cam, 0, 1);
+  const int rc = set_problem_impl(h, poses, fixed, P, points, L, edges, E, cam, 0, 1);
+  if (rc == DVM_OK) h->sharded_api = false;
+  return rc;
 }
 int dvm_ba_set_problem_sharded(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
                                const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
-  return set_problem_impl(h, poses, fixed, P, points, L, edges, E, cam, rank, world);
+  const int rc = set_problem_impl(h, poses, fixed, P, points, L, edges, E, cam, rank, world);
+  if (rc == DVM_OK) h->sharded_api = true;
+  return rc;
 }
 int dvm_ba_set_allreduce(dvm_ba* h, dvm_allreduce_fn fn, void* ctx, void* d_buf, int64_t cap_doubles) {
   if (!h) return DVM_ERR_INVALID;
@@ -379,7 +384,9 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     p.slot = slot; p.publish = publish ? 1 : 0;
     return p;
   };
-  const bool sharded = h->world > 1;
+  // a one-rank job that registered a collective takes the sharded flow too (sum over one rank = identity): that is how the
+  // RCCL path is exercised on a single-GPU box (tests/test_gpu_rccl.py)
+  const bool sharded = h->world > 1 || (h->sharded_api && h->allreduce && h->ar_buf);
   if (sharded && (!h->allreduce || !h->ar_buf || h->ar_cap < dvm_ba_allreduce_doubles(h))) {
     set_error("dvm_ba_optimize: sharded problem without dvm_ba_set_allreduce (callback + device buffer of dvm_ba_allreduce_doubles())");
     return DVM_ERR_STATE;

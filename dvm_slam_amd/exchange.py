@@ -14,6 +14,15 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+# One rank has nobody to talk to: the collectives below return at once.  Tests on a 1-GPU box clear this to push a single
+# rank through RCCL all the same (tests/test_gpu_rccl.py).
+SHORTCUT_SINGLE_RANK = True
+
+
+def _alone() -> bool:
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and SHORTCUT_SINGLE_RANK)
+
+
 KP_BYTES = 28   # dvm_keypoint / cv::KeyPoint
 HEADER_BYTES = 64  # uuid[16] | n int32 | agent int32 | pose 7 x f32 | pad
 
@@ -49,7 +58,7 @@ def unpack_keyframe(block: torch.Tensor, cap: int, kp_dtype):
 
 def all_gather_blocks(block: torch.Tensor) -> list[torch.Tensor]:
     """C2: every agent receives every agent's block (same size on all ranks)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         return [block]
     out = [torch.empty_like(block) for _ in range(dist.get_world_size())]
     dist.all_gather(out, block)
@@ -58,13 +67,13 @@ def all_gather_blocks(block: torch.Tensor) -> list[torch.Tensor]:
 
 def broadcast_sim3(sim3: torch.Tensor, src: int) -> torch.Tensor:
     """C4: (s, qx,qy,qz,qw, tx,ty,tz) float64 from the merging agent to all."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _alone():
         dist.broadcast(sim3, src)
     return sim3
 
 
 def max_over_ranks(seconds: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -79,7 +88,7 @@ def agent_stream_segment(rank: int, frames_per_agent: int) -> int:
 def all_gather_varlen(block: torch.Tensor) -> list[torch.Tensor]:
     """C2 with ragged payloads (DVMW blocks, dvm_slam_amd/wire.py): sizes first (one int64 all_gather), then one all_gather of
     blocks padded to the largest; returns every agent's block trimmed to its own size.  Tensors stay on their device."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         return [block]
     world = dist.get_world_size()
     n = torch.tensor([block.numel()], dtype=torch.int64, device=block.device)
