@@ -344,8 +344,7 @@ __global__ void __launch_bounds__(256) k_pyr_borders(uint8_t* __restrict__ pyr, 
 //   A = max over the 16 nine-pixel arcs of min(v - p_i) = v - min_arcs max_i p_i
 //   B = max over arcs of min(p_i - v)                   = max_arcs min_i p_i - v
 // so the whole sliding-window network runs on the raw ring bytes: window-9 min and max over the circular
-// 16-vector by doubling (2,4,8,+1) on PACKED 16-bit lanes (v_pk_min_u16 / v_pk_max_u16: two ring
-// positions per instruction).  PITCH != 0: compile-time LDS pitch, ring offsets become ds_read immediates.
+// 16-vector on PACKED 16-bit lanes (v_pk_min_u16 / v_pk_max_u16: two ring positions per instruction).  PITCH != 0: compile-time LDS pitch, ring offsets become ds_read immediates.
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ushort2_t pk(int lo, int hi) {
   const uint32_t w = (uint32_t)lo | ((uint32_t)hi << 16);
@@ -360,29 +359,29 @@ __device__ __forceinline__ int fast_strength(const uint8_t* __restrict__ t, int 
   int p[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) p[k] = (int)t[cx[k] + cy[k] * pitch];
-  ushort2_t P[8], Q[8];   // P[j] = (p[2j], p[2j+1]),  Q[j] = (p[2j+1], p[2j+2])
+  // van Herk / Gil-Werman on the ring split into two blocks of 8, both blocks side by side in the halves of a packed
+  // register: X[i] = (p[i], p[8+i]).  The 9-arc starting at k < 8 is p[k..7] (a suffix of block 0) plus p[8..8+k] (a prefix of
+  // block 1); the arc starting at 8 + k is the suffix of block 1 plus the prefix of block 0.  So with packed prefix / suffix
+  // scans (7 + 7 operations) arc k and arc 8 + k come out of ONE packed operation on (suffix[k], prefix[k] with its halves
+  // swapped -- an op_sel modifier, no instruction): 29 packed operations per side instead of 40 for the doubling network.
+  ushort2_t X[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    P[j] = pk(p[2 * j], p[2 * j + 1]);
-    Q[j] = pk(p[2 * j + 1], p[(2 * j + 2) & 15]);
-  }
-  ushort2_t lo[8], hi[8];
+  for (int i = 0; i < 8; i++) X[i] = pk(p[i], p[i + 8]);
+  ushort2_t pmin[8], pmax[8], smin[8], smax[8];
+  pmin[0] = pmax[0] = X[0];
+  smin[7] = smax[7] = X[7];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {  // windows of 2: (w2[2j], w2[2j+1])
-    lo[j] = __builtin_elementwise_min(P[j], Q[j]);
-    hi[j] = __builtin_elementwise_max(P[j], Q[j]);
-  }
-  ushort2_t lo4[8], hi4[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) {  // windows of 4
-    lo4[j] = __builtin_elementwise_min(lo[j], lo[(j + 1) & 7]);
-    hi4[j] = __builtin_elementwise_max(hi[j], hi[(j + 1) & 7]);
+  for (int i = 1; i < 8; i++) {
+    pmin[i] = __builtin_elementwise_min(pmin[i - 1], X[i]);
+    pmax[i] = __builtin_elementwise_max(pmax[i - 1], X[i]);
+    smin[7 - i] = __builtin_elementwise_min(smin[8 - i], X[7 - i]);
+    smax[7 - i] = __builtin_elementwise_max(smax[8 - i], X[7 - i]);
   }
   ushort2_t maxmin = pk(0, 0), minmax = pk(255, 255);
 #pragma unroll
-  for (int j = 0; j < 8; j++) {  // windows of 8, then the ninth element p[k+8]
-    const ushort2_t lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[j], lo4[(j + 2) & 7]), P[(j + 4) & 7]);
-    const ushort2_t hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[j], hi4[(j + 2) & 7]), P[(j + 4) & 7]);
+  for (int k = 0; k < 8; k++) {
+    const ushort2_t lo9 = __builtin_elementwise_min(smin[k], __builtin_shufflevector(pmin[k], pmin[k], 1, 0));
+    const ushort2_t hi9 = __builtin_elementwise_max(smax[k], __builtin_shufflevector(pmax[k], pmax[k], 1, 0));
     maxmin = __builtin_elementwise_max(maxmin, lo9);
     minmax = __builtin_elementwise_min(minmax, hi9);
   }
@@ -550,12 +549,12 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
           // west neighbour (x-3) of pixel k = byte k+1 of {Cd:Wd}; east (x+3) = byte k+3 of {Ed:Cd}
           const ushort2_t W = __builtin_bit_cast(ushort2_t, DVM_PERM2(Cd, Wd, 2 * h + 1, 2 * h + 2));
           const ushort2_t E = __builtin_bit_cast(ushort2_t, DVM_PERM2(Ed, Cd, 2 * h + 3, 2 * h + 4));
-          const ushort2_t mx = __builtin_elementwise_min(
-              __builtin_elementwise_min(__builtin_elementwise_max(N, E), __builtin_elementwise_max(E, S)),
-              __builtin_elementwise_min(__builtin_elementwise_max(S, W), __builtin_elementwise_max(W, N)));
-          const ushort2_t mn = __builtin_elementwise_max(
-              __builtin_elementwise_max(__builtin_elementwise_min(N, E), __builtin_elementwise_min(E, S)),
-              __builtin_elementwise_max(__builtin_elementwise_min(S, W), __builtin_elementwise_min(W, N)));
+          // the four adjacent compass pairs (N,E) (E,S) (S,W) (W,N) are exactly {N,S} x {E,W}, so
+          //   min over pairs of max(x, y) = max(min(N,S), min(E,W)),  max over pairs of min(x, y) = min(max(N,S), max(E,W))
+          const ushort2_t nsl = __builtin_elementwise_min(N, S), nsh = __builtin_elementwise_max(N, S);
+          const ushort2_t ewl = __builtin_elementwise_min(E, W), ewh = __builtin_elementwise_max(E, W);
+          const ushort2_t mx = __builtin_elementwise_max(nsl, ewl);
+          const ushort2_t mn = __builtin_elementwise_min(nsh, ewh);
           typedef short short2s __attribute__((ext_vector_type(2)));
           const short2s dk = __builtin_bit_cast(short2s, C) - __builtin_bit_cast(short2s, mx);   // darker margin
           const short2s br = __builtin_bit_cast(short2s, mn) - __builtin_bit_cast(short2s, C);   // brighter margin
