@@ -433,6 +433,17 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
 // zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
 #define DVM_PERM2(a, b, i0, i1) __builtin_amdgcn_perm((a), (b), 0x0c000c00u | (uint32_t)(i0) | ((uint32_t)(i1) << 16))
 
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts, then the row carries)
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
 #ifdef DVM_FAST_DEBUG
 __device__ unsigned long long g_fast_dbg[8192 * 8];
 #define DVM_FSTAMP(i) do { if (threadIdx.x == 0) { const long long t_ = __builtin_readcyclecounter(); unsigned long long* g_ = g_fast_dbg + (blockIdx.x & 8191) * 8; if (i) g_[i] += (unsigned long long)(t_ - t_prev_); else g_[0] += 1ull; t_prev_ = t_; } } while (0)
@@ -533,9 +544,19 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     int ey = (int)(((float)it + 0.5f) * (1.0f / (float)ncol)), cc = it - ey * ncol;
     const int dy = 64 / ncol, dc = 64 - dy * ncol;
     const ushort2_t T2 = pk(tlow, tlow);
+    // valid pixels of the first / last dword column (evaluated x in [0, ew)), in the survivor-bit layout below
+    const int exb0 = 4 * c0 - sh - 3;                       // evaluated x of byte 0 of column c0 (may be < 0)
+    const int vlo = max(0, -exb0), vhi = min(4, ew - (exb0 + 4 * (ncol - 1)));
+    uint32_t mask_first = 0, mask_last = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t bit = (k & 1 ? 0x80000000u : 0x00008000u) >> (k >> 1);
+      if (k >= vlo) mask_first |= bit;
+      if (k < vhi) mask_last |= bit;
+    }
+    if (ncol == 1) mask_first &= mask_last;
     for (int r = 0; r < roundsA; r++) {
       uint32_t pm = 0;
-      int exb = 0;
       if (it < it_end) {
         const int c = c0 + cc;
         const uint32_t* row = t32 + (ey + 3) * pitch4 + c;
@@ -561,26 +582,22 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
           const short2s m = __builtin_elementwise_max(dk, br);
           q[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2s, T2) - m);  // sign bit of a half set <=> margin > t
         }
-        exb = 4 * c - sh - 3;                                   // evaluated x of byte 0 (may be < 0)
-        const int vlo = max(0, -exb), vhi = min(4, ew - exb);   // valid bytes [vlo, vhi)
-        const uint32_t vmask = (0xFu >> (4 - vhi)) & (0xFu << vlo);
-        pm = (((q[0] >> 15) & 1u) | ((q[0] >> 30) & 2u) | ((q[1] >> 13) & 4u) | ((q[1] >> 28) & 8u)) & vmask;
+        // survivor bits stay where the sign bits are: pixel 0 -> bit 15, 1 -> bit 31, 2 -> bit 14, 3 -> bit 30
+        const uint32_t vmask = cc == 0 ? mask_first : (cc == ncol - 1 ? mask_last : 0xC000C000u);
+        pm = ((q[0] & 0x80008000u) | ((q[1] >> 1) & 0x40004000u)) & vmask;
       }
-      unsigned long long bm[4];
-      int mine = 0, tot = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        bm[k] = __ballot((pm >> k) & 1u);
-        mine += __builtin_amdgcn_mbcnt_hi((uint32_t)(bm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[k], 0u));
-        tot += __popcll(bm[k]);
-      }
+      // ordered append: lane-major, pixel order inside a lane = exclusive prefix sum of the lanes' survivor counts
+      const int cnt = __popc(pm);
+      const int incl = wave_incl_scan(cnt);
       if (pm) {
-        int pos = wcount + mine;
-        const int e0 = (ey << 7) + exb;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if ((pm >> k) & 1u) mylist[pos++] = (uint16_t)(e0 + k);
+        int pos = wcount + incl - cnt;
+        const int e0 = (ey << 7) + 4 * cc + exb0;
+        if (pm & 0x00008000u) mylist[pos++] = (uint16_t)e0;
+        if (pm & 0x80000000u) mylist[pos++] = (uint16_t)(e0 + 1);
+        if (pm & 0x00004000u) mylist[pos++] = (uint16_t)(e0 + 2);
+        if (pm & 0x40000000u) mylist[pos] = (uint16_t)(e0 + 3);
       }
+      const int tot = __builtin_amdgcn_readlane(incl, 63);
       wcount += tot;
       it += 64; cc += dc; ey += dy;
       if (cc >= ncol) { cc -= ncol; ey++; }
