@@ -115,6 +115,8 @@ def lib():
     L.dvm_frame_build_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, f32, f32, f32, f32, vp]
     L.dvm_match_window.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     L.dvm_is_in_frustum.argtypes = [C.POINTER(FrustumFrame), vp, vp, vp, vp, i32, f32, vp, i32, vp]
+    L.dvm_undistort_keypoints.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.dvm_image_bounds.argtypes = [vp, i32, i32, vp]
     L.dvm_match_lists.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp]
     L.dvm_match_frames_batch.argtypes = [vp, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, f32, vp, i32, vp, i64,
                                          vp, vp]
@@ -488,6 +490,28 @@ def is_in_frustum(F: "FrustumFrame", P, normal, min_dist, max_dist, viewing_cos_
     out = np.zeros(len(P), TRACK_DTYPE)
     check(lib().dvm_is_in_frustum(C.byref(F), _p(P), _p(normal), _p(min_dist), _p(max_dist), len(P), float(viewing_cos_limit),
                                   _p(out), 0, None))
+    return out
+
+
+def undistort_keypoints(cam, kps, d_in=None, d_out=None, n=None, stream=None):
+    """Frame::UndistortKeyPoints: cam = (fx, fy, cx, cy, k1, k2, p1, p2, k3) float32; kps a KP_DTYPE array (returns the
+    undistorted copy), or device pointers d_in / d_out of n keypoints (asynchronous on `stream`)."""
+    cam = np.ascontiguousarray(cam, np.float32)
+    assert cam.shape == (9,)
+    if d_in is not None:
+        check(lib().dvm_undistort_keypoints(_p(cam), d_in, d_out, int(n), 1, stream))
+        return None
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros_like(kps)
+    check(lib().dvm_undistort_keypoints(_p(cam), _p(kps), _p(out), len(kps), 0, None))
+    return out
+
+
+def image_bounds(cam, cols, rows):
+    """Frame::ComputeImageBounds -> float32 (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    cam = np.ascontiguousarray(cam, np.float32)
+    out = np.zeros(4, np.float32)
+    check(lib().dvm_image_bounds(_p(cam), int(cols), int(rows), _p(out)))
     return out
 
 

@@ -485,6 +485,46 @@ int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const floa
   return rc;
 }
 
+int dvm_undistort_keypoints(const dvm_distortion* cam, const dvm_keypoint* kps_in, dvm_keypoint* kps_out, int n, int on_device, void* stream) {
+  static_assert(sizeof(dvm_distortion) == sizeof(dvm_undistort::Camera) && sizeof(dvm_keypoint) == 28, "layout");
+  if (!cam || n < 0) return DVM_ERR_INVALID;
+  if (n == 0) return DVM_OK;
+  if (!kps_in || !kps_out) return DVM_ERR_INVALID;
+  if (!(cam->fx != 0.0f) || !(cam->fy != 0.0f)) { set_error("dvm_undistort_keypoints: zero focal length"); return DVM_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  dvm_undistort::Camera C;
+  std::memcpy(&C, cam, sizeof(C));
+  if (on_device) {
+    launch_undistort_keypoints((hipStream_t)stream, C, reinterpret_cast<const float*>(kps_in), reinterpret_cast<float*>(kps_out), n);
+    return hip_check(hipGetLastError(), "undistort launch");
+  }
+  float* d = nullptr;
+  int rc = hip_check(hipMalloc(&d, (size_t)n * 28), "hipMalloc");
+  if (rc != DVM_OK) return rc;
+  rc = hip_check(hipMemcpy(d, kps_in, (size_t)n * 28, hipMemcpyHostToDevice), "memcpy");
+  if (rc == DVM_OK) { launch_undistort_keypoints(nullptr, C, d, d, n); rc = hip_check(hipGetLastError(), "undistort launch"); }
+  if (rc == DVM_OK) rc = hip_check(hipMemcpy(kps_out, d, (size_t)n * 28, hipMemcpyDeviceToHost), "memcpy");
+  hipFree(d);
+  return rc;
+}
+
+int dvm_image_bounds(const dvm_distortion* cam, int cols, int rows, float bounds[4]) {
+  if (!cam || !bounds || cols <= 0 || rows <= 0) return DVM_ERR_INVALID;
+  if (cam->k1 == 0.0f) {   // Frame.cc:843-847
+    bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+    return DVM_OK;
+  }
+  dvm_keypoint c[4];
+  std::memset(c, 0, sizeof(c));
+  c[0].x = 0.0f; c[0].y = 0.0f; c[1].x = (float)cols; c[1].y = 0.0f; c[2].x = 0.0f; c[2].y = (float)rows; c[3].x = (float)cols; c[3].y = (float)rows;
+  const int rc = dvm_undistort_keypoints(cam, c, c, 4, 0, nullptr);
+  if (rc != DVM_OK) return rc;
+  bounds[0] = std::min(c[0].x, c[2].x); bounds[1] = std::max(c[1].x, c[3].x);
+  bounds[2] = std::min(c[0].y, c[1].y); bounds[3] = std::max(c[2].y, c[3].y);
+  return DVM_OK;
+}
+
 int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, const int32_t* off, const int32_t* cand,
                     dvm_match* out, int on_device, void* stream) {
   if (nq < 0 || nt < 0) return DVM_ERR_INVALID;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "orb_kernels.h"
+#include "undistort_f64.h"
 
 namespace dvm {
 
@@ -82,6 +83,7 @@ void launch_match_triangulation(hipStream_t s, const uint8_t* desc1, const dvm_k
                                 const uint8_t* desc2, const dvm_keypoint_pod* kps2, const int32_t* off, const int32_t* cand,
                                 const TriGeom& G, const float* scale_factors2, const float* level_sigma2_2, int32_t* best_idx,
                                 int32_t* best_dist);
+void launch_undistort_keypoints(hipStream_t s, const dvm_undistort::Camera& cam, const float* in, float* out, int n);
 void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
                           const float* max_dist, int n, float cos_limit, TrackPoint* out);
 void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_stride, const uint8_t* desc,

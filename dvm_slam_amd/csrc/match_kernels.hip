@@ -12,6 +12,7 @@
 
 #include "match_kernels.h"
 #include "pose_f32.h"
+#include "undistort_f64.h"
 
 namespace dvm {
 
@@ -523,6 +524,21 @@ void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int 
   hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 15) / 16, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride);
 }
+// Frame::UndistortKeyPoints (Frame.cc:791-818): thread per keypoint, cv::undistortPoints in double (undistort_f64.h)
+__global__ void __launch_bounds__(256) k_undistort_keypoints(dvm_undistort::Camera cam, const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float kp[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) kp[k] = in[7 * (int64_t)i + k];
+  if (cam.k1 != 0.0f) dvm_undistort::undistort_point(cam, kp[0], kp[1], &kp[0], &kp[1]);
+#pragma unroll
+  for (int k = 0; k < 7; k++) out[7 * (int64_t)i + k] = kp[k];
+}
+void launch_undistort_keypoints(hipStream_t s, const dvm_undistort::Camera& cam, const float* in, float* out, int n) {
+  hipLaunchKernelGGL(k_undistort_keypoints, dim3((n + 255) / 256), dim3(256), 0, s, cam, in, out, n);
+}
+
 void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
                           const float* max_dist, int n, float cos_limit, TrackPoint* out) {
   hipLaunchKernelGGL(k_is_in_frustum, dim3((n + 255) / 256), dim3(256), 0, s, F, P, normal, min_dist, max_dist, n, cos_limit, out);

@@ -1,6 +1,10 @@
 // dvm_slam_amd/host/Frame_grid_shim.h -- the Frame members of the accelerated path (reference include/Frame.h:72-74,221-251,
 // src/Frame.cc:443-506,575-636,712-782) over the dvmslam_hip C ABI.
 //
+//   void Frame::UndistortKeyPoints()                                    same name / signature (Frame.cc:791-818): mvKeys -> mvKeysUn
+//   void Frame::ComputeImageBounds(const cv::Mat& imLeft)                same name / signature (Frame.cc:820-848)
+//        cv::undistortPoints(pts, K, mDistCoef, noArray(), mK) on the device (dvm_undistort_keypoints / dvm_image_bounds);
+//        both keep the reference's k1 == 0 shortcut
 //   bool Frame::isInFrustum(MapPoint* pMP, float viewingCosLimit)        same name / signature: one map point, device call
 //   int  Frame_isInFrustumBatch(Frame&, const std::vector<MapPoint*>&, float viewingCosLimit)
 //        what Tracking::SearchLocalPoints (Tracking.cc) should call instead of its per-point loop: every local map point in
@@ -58,6 +62,37 @@ inline int run(const dvm_frustum_frame& f, MapPoint* const* pts, int n, float vi
   return nin;
 }
 }  // namespace dvm_frame_detail
+
+namespace dvm_frame_detail {
+// K = Pinhole::toK() (== mK for the pinhole camera DVM-SLAM runs), D = mDistCoef: 4 x 1 (k1 k2 p1 p2) or 5 x 1 (+ k3), CV_32F
+inline dvm_distortion distortion(const Frame& F) {
+  dvm_distortion d;
+  d.fx = F.mK.at<float>(0, 0); d.fy = F.mK.at<float>(1, 1); d.cx = F.mK.at<float>(0, 2); d.cy = F.mK.at<float>(1, 2);
+  d.k1 = F.mDistCoef.at<float>(0); d.k2 = F.mDistCoef.at<float>(1); d.p1 = F.mDistCoef.at<float>(2); d.p2 = F.mDistCoef.at<float>(3);
+  d.k3 = F.mDistCoef.rows * F.mDistCoef.cols > 4 ? F.mDistCoef.at<float>(4) : 0.0f;
+  return d;
+}
+}  // namespace dvm_frame_detail
+
+inline void Frame::UndistortKeyPoints() {
+  if (mDistCoef.at<float>(0) == 0.0) {
+    mvKeysUn = mvKeys;
+    return;
+  }
+  static_assert(sizeof(cv::KeyPoint) == sizeof(dvm_keypoint), "cv::KeyPoint layout");
+  const dvm_distortion d = dvm_frame_detail::distortion(*this);
+  mvKeysUn.resize(N);
+  if (N == 0) return;
+  if (dvm_undistort_keypoints(&d, reinterpret_cast<const dvm_keypoint*>(mvKeys.data()), reinterpret_cast<dvm_keypoint*>(mvKeysUn.data()), N, 0, NULL) != DVM_OK)
+    throw std::runtime_error(dvm_last_error());
+}
+
+inline void Frame::ComputeImageBounds(const cv::Mat& imLeft) {
+  const dvm_distortion d = dvm_frame_detail::distortion(*this);
+  float b[4];
+  if (dvm_image_bounds(&d, imLeft.cols, imLeft.rows, b) != DVM_OK) throw std::runtime_error(dvm_last_error());
+  mnMinX = b[0]; mnMaxX = b[1]; mnMinY = b[2]; mnMaxY = b[3];
+}
 
 // bool Frame::isInFrustum(MapPoint* pMP, float viewingCosLimit), mono branch (Nleft == -1)
 inline bool Frame::isInFrustum(MapPoint* pMP, float viewingCosLimit) {

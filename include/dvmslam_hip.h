@@ -166,6 +166,15 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
                      const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
                      const int32_t* d_nq, dvm_match* out, int on_device, void* stream);
 
+/* Frame::UndistortKeyPoints (Frame.cc:791-818) and Frame::ComputeImageBounds (:820-848): cv::undistortPoints(pts, K, D,
+ * noArray(), K) -- OpenCV's 5-iteration fixed-point inversion of the (k1, k2, p1, p2, k3) model, in double from the float
+ * inputs.  kps_out[i] = kps_in[i] with the point replaced (in place allowed); k1 == 0 copies, as the reference's early return
+ * does.  dvm_image_bounds: {mnMinX, mnMaxX, mnMinY, mnMaxY} from the four undistorted image corners ({0, cols, 0, rows} for
+ * k1 == 0); the values dvm_frame_build and the matcher gates take.  Host pointers (synchronous) or device pointers. */
+typedef struct { float fx, fy, cx, cy, k1, k2, p1, p2, k3; } dvm_distortion;
+int dvm_undistort_keypoints(const dvm_distortion* cam, const dvm_keypoint* kps_in, dvm_keypoint* kps_out, int n, int on_device, void* stream);
+int dvm_image_bounds(const dvm_distortion* cam, int cols, int rows, float bounds[4]);
+
 /* Frame::isInFrustum (Frame.cc:575-636, mono branch) for n map points at once: projection with the frame's
  * Rcw/tcw (float; mRcw = mTcw.rotationMatrix(), Frame.cc:553-559 -- this function does use the matrix form, :585),
  * image bounds, distance inside [0.8*mfMinDistance, 1.2*mfMaxDistance], viewing cosine,

@@ -938,4 +938,65 @@ void orc_sim3_act(const float* S7, const float* p, int n, float* out) {
 }
 float orc_logf(float x) { return so::logf_spec(x); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cc:791-848).  cv::undistortPoints is OpenCV (not in /root/reference):
+// restated from OpenCV 4.x modules/calib3d/src/undistort.dispatch.cpp, cvUndistortPointsInternal, as the public
+// cv::undistortPoints(src, dst, K, D, R = noArray(), P) runs it -- TermCriteria(MAX_ITER, 5, 0.01): exactly five passes of
+//   r2 = x^2 + y^2;  icdist = (1 + ((k7 r2 + k6) r2 + k5) r2) / (1 + ((k4 r2 + k1) r2 + k0) r2);
+//   dX = 2 k2 x y + k3 (r2 + 2 x^2) + k8 r2 + k9 r2^2;  dY = k2 (r2 + 2 y^2) + 2 k3 x y + k10 r2 + k11 r2^2;
+//   x = (x0 - dX) icdist;  y = (y0 - dY) icdist
+// in double on k = (k1, k2, p1, p2, k3, 0 ...) converted from CV_32F, then (x, y, 1) through P * R (here K * I) and one
+// rounding to float.  PARITY UNPINNED: OpenCV is not available to run against.
+static void undistort_one(const float* cam, float uf, float vf, float* xo, float* yo) {
+  double A[3][3] = {{(double)cam[0], 0, (double)cam[2]}, {0, (double)cam[1], (double)cam[3]}, {0, 0, 1}};
+  double k[14] = {0};
+  for (int i = 0; i < 5; i++) k[i] = (double)cam[4 + i];
+  double RR[3][3];
+  for (int r = 0; r < 3; r++)          // cvMatMul(&_PP, &_RR, &_RR) with RR = I, PP = K
+    for (int c = 0; c < 3; c++) {
+      double acc = 0;
+      for (int m = 0; m < 3; m++) acc += A[r][m] * (m == c ? 1.0 : 0.0);
+      RR[r][c] = acc;
+    }
+  const double fx = A[0][0], fy = A[1][1], ifx = 1. / fx, ify = 1. / fy, cx = A[0][2], cy = A[1][2];
+  double x = uf, y = vf;
+  const double u = x, v = y;
+  x = (x - cx) * ifx;
+  y = (y - cy) * ify;
+  const double x0 = x, y0 = y;     // tilt model off: invMatTilt = I, invProj = 1
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+    if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+    const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+    const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+  const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+  const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+  *xo = (float)(xx * ww);
+  *yo = (float)(yy * ww);
+}
+// cam = {fx, fy, cx, cy, k1, k2, p1, p2, k3}; xy in / out: n x 2 floats.  k1 == 0: copy (Frame.cc:792-795)
+void orc_undistort_points(const float* cam, const float* xy_in, int n, float* xy_out) {
+  for (int i = 0; i < n; i++) {
+    if (cam[4] == 0.0f) { xy_out[2 * i] = xy_in[2 * i]; xy_out[2 * i + 1] = xy_in[2 * i + 1]; }
+    else undistort_one(cam, xy_in[2 * i], xy_in[2 * i + 1], &xy_out[2 * i], &xy_out[2 * i + 1]);
+  }
+}
+// Frame::ComputeImageBounds (Frame.cc:820-848): out = {mnMinX, mnMaxX, mnMinY, mnMaxY}
+void orc_image_bounds(const float* cam, int cols, int rows, float* out) {
+  if (cam[4] != 0.0f) {
+    const float in[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+    float m[8];
+    orc_undistort_points(cam, in, 4, m);
+    out[0] = std::min(m[0], m[4]); out[1] = std::max(m[2], m[6]);
+    out[2] = std::min(m[1], m[3]); out[3] = std::max(m[5], m[7]);
+  } else {
+    out[0] = 0.0f; out[1] = (float)cols; out[2] = 0.0f; out[3] = (float)rows;
+  }
+}
+
 }  // extern "C"

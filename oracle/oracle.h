@@ -175,6 +175,10 @@ void orc_sim3_inverse(const float* S7, float* out7);
 void orc_se3_act(const float* T7, const float* p, int n, float* out);
 void orc_sim3_act(const float* S7, const float* p, int n, float* out);
 float orc_logf(float x);
+/* Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cc:791-848; cv::undistortPoints restated, see match_oracle.cpp).
+   cam = {fx, fy, cx, cy, k1, k2, p1, p2, k3} */
+void orc_undistort_points(const float* cam, const float* xy_in, int n, float* xy_out);
+void orc_image_bounds(const float* cam, int cols, int rows, float* out4);
 
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:384-453), batched over map points (CSR offsets into desc) */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);

@@ -389,6 +389,27 @@ def is_in_frustum(F, P, normal, min_dist, max_dist, viewing_cos_limit=0.5):
     return out
 
 
+def undistort_points(cam, xy):
+    """Frame::UndistortKeyPoints' cv::undistortPoints(pts, K, D, noArray(), K); cam = (fx, fy, cx, cy, k1, k2, p1, p2, k3)."""
+    L = lib()
+    L.orc_undistort_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    cam = np.ascontiguousarray(cam, np.float32); xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    assert cam.shape == (9,)
+    out = np.zeros_like(xy)
+    L.orc_undistort_points(_p(cam), _p(xy), len(xy), _p(out))
+    return out
+
+
+def image_bounds(cam, cols, rows):
+    """Frame::ComputeImageBounds -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    L = lib()
+    L.orc_image_bounds.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    cam = np.ascontiguousarray(cam, np.float32)
+    out = np.zeros(4, np.float32)
+    L.orc_image_bounds(_p(cam), int(cols), int(rows), _p(out))
+    return out
+
+
 def optimize_sim3(S12, fix_scale, P1c, P2c, obs1, obs2, w1, w2, K1, K2, th2):
     """Optimizer::OptimizeSim3 numerics.  Returns (S12[8], inlier mask, nIn)."""
     L = lib()

@@ -20,6 +20,9 @@ class Mat {
   bool empty() const { return rows == 0; }
   Mat row(int) const { return *this; }
   Mat rowRange(int, int) const { return *this; }
+  template <class T> T& at(int i) { return reinterpret_cast<T*>(data)[i]; }
+  template <class T> const T& at(int i) const { return reinterpret_cast<const T*>(data)[i]; }
+  template <class T> const T& at(int r, int c) const { return reinterpret_cast<const T*>(data)[r * cols + c]; }
   template <class T> T* ptr(int = 0) { return reinterpret_cast<T*>(data); }
   template <class T> const T* ptr(int = 0) const { return reinterpret_cast<const T*>(data); }
   void create(int r, int c, int t) { rows = r; cols = c; type_ = t; }

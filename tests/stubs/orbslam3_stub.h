@@ -112,6 +112,9 @@ class Frame {
   Sophus::SE3f GetPose() const;
   void SetPose(const Sophus::SE3<float>& Tcw);
   bool isInFrustum(MapPoint* pMP, float viewingCosLimit);
+  void UndistortKeyPoints();                          // private in the reference (Frame.h): the shim is compiled into Frame.cc
+  void ComputeImageBounds(const cv::Mat& imLeft);
+  cv::Mat mK, mDistCoef;
   int N = 0;
   std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
   std::vector<float> mvuRight, mvDepth;

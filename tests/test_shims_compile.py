@@ -29,3 +29,6 @@ def test_shims_cover_the_reference_public_interface():
     for name in ("Optimizer::BundleAdjustment(", "Optimizer::GlobalBundleAdjustemnt(", "Optimizer::LocalBundleAdjustment(",
                  "Optimizer::PoseOptimization(", "Optimizer::OptimizeSim3("):
         assert "inline void " + name in o or "inline int " + name in o, name
+    f = open(os.path.join(HOST, "Frame_grid_shim.h")).read()
+    for name in ("inline bool Frame::isInFrustum(", "inline void Frame::UndistortKeyPoints(", "inline void Frame::ComputeImageBounds("):
+        assert name in f, name
