@@ -1032,6 +1032,52 @@ def bowdb_query_raw(bows, q_ids, q_vals, erase=(), device=0):
         L.dvm_bowdb_destroy(h)
 
 
+class BowDb:
+    """dvm_bowdb_* handle (tests): add / erase / query / stats on one store."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.L.dvm_bowdb_create.restype = C.c_int32; self.L.dvm_bowdb_create.argtypes = [C.c_int32, C.c_void_p]
+        check(self.L.dvm_bowdb_create(device, C.byref(self.h)))
+        self.n = 0
+
+    def add(self, ids, vals):
+        i = np.ascontiguousarray(ids, np.int32); v = np.ascontiguousarray(vals, np.float64)
+        slot = C.c_int32(-1)
+        self.L.dvm_bowdb_add.restype = C.c_int32; self.L.dvm_bowdb_add.argtypes = None
+        check(self.L.dvm_bowdb_add(self.h, C.c_void_p(i.ctypes.data) if len(i) else None, C.c_void_p(v.ctypes.data) if len(v) else None,
+                                   C.c_int32(len(i)), C.byref(slot)))
+        self.n += 1
+        return slot.value
+
+    def erase(self, slot):
+        self.L.dvm_bowdb_erase.restype = C.c_int32; self.L.dvm_bowdb_erase.argtypes = None
+        check(self.L.dvm_bowdb_erase(self.h, C.c_int32(int(slot))))
+
+    def query(self, q_ids, q_vals):
+        qi = np.ascontiguousarray(q_ids, np.int32); qv = np.ascontiguousarray(q_vals, np.float64)
+        common = np.zeros(self.n, np.int32); first = np.zeros(self.n, np.int32); score = np.zeros(self.n, np.float32)
+        self.L.dvm_bowdb_query.restype = C.c_int32; self.L.dvm_bowdb_query.argtypes = None
+        check(self.L.dvm_bowdb_query(self.h, C.c_void_p(qi.ctypes.data) if len(qi) else None, C.c_void_p(qv.ctypes.data) if len(qv) else None,
+                                     C.c_int32(len(qi)), C.c_void_p(common.ctypes.data), C.c_void_p(first.ctypes.data), C.c_void_p(score.ctypes.data)))
+        return common, first, score
+
+    def stats(self):
+        out = np.zeros(4, np.int64)
+        self.L.dvm_bowdb_stats.restype = C.c_int32; self.L.dvm_bowdb_stats.argtypes = [C.c_void_p, C.c_void_p]
+        check(self.L.dvm_bowdb_stats(self.h, _p(out)))
+        return dict(slots=int(out[0]), live=int(out[1]), words=int(out[2]), capacity=int(out[3]))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.dvm_bowdb_destroy.restype = None; self.L.dvm_bowdb_destroy.argtypes = [C.c_void_p]
+            self.L.dvm_bowdb_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+
 class HostKeyFrameDatabase:
     """dvm_host::KeyFrameDatabase (host/keyframe_database.cpp over dvm_bowdb_*): add / erase / CalculateMergeScore /
     DetectMergePossibility / DetectNBestCandidates on keyframe slots (reference KeyFrameDatabase.cc:43-70,555-808)."""

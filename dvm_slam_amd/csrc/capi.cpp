@@ -628,11 +628,14 @@ int dvm_match_triangulation(const uint8_t* desc1, const dvm_keypoint* kps1, int 
 
 struct dvm_bowdb {
   int device = 0;
-  std::vector<int32_t> off, len;          // per slot (len < 0: erased)
-  size_t used = 0, cap = 0;               // words stored / capacity of d_ids, d_vals
+  std::vector<int64_t> off;               // per slot: first word (64-bit: a long session stores more than 2^31 words)
+  std::vector<int32_t> len;               // per slot (len < 0: erased)
+  std::vector<int32_t> live;              // slots with len >= 0, ascending: what a query launches over
+  size_t used = 0, cap = 0, dead = 0;     // words stored (live + erased) / capacity of d_ids, d_vals / words of erased slots
   int32_t* d_ids = nullptr;
   double* d_vals = nullptr;
-  int32_t *d_off = nullptr, *d_len = nullptr, *d_common = nullptr, *d_first = nullptr;
+  int64_t* d_off = nullptr;
+  int32_t *d_len = nullptr, *d_live = nullptr, *d_common = nullptr, *d_first = nullptr;
   float* d_score = nullptr;
   size_t slot_cap = 0;
   bool meta_dirty = true;
@@ -641,7 +644,7 @@ struct dvm_bowdb {
 void dvm_bowdb_destroy(dvm_bowdb* db) {
   if (!db) return;
   hipSetDevice(db->device);
-  for (void* p : {(void*)db->d_ids, (void*)db->d_vals, (void*)db->d_off, (void*)db->d_len, (void*)db->d_common, (void*)db->d_first, (void*)db->d_score})
+  for (void* p : {(void*)db->d_ids, (void*)db->d_vals, (void*)db->d_off, (void*)db->d_len, (void*)db->d_live, (void*)db->d_common, (void*)db->d_first, (void*)db->d_score})
     if (p) hipFree(p);
   delete db;
 }
@@ -664,25 +667,45 @@ int dvm_bowdb_add(dvm_bowdb* db, const int32_t* word_ids, const double* values, 
   for (int i = 1; i < n; i++)
     if (word_ids[i] <= word_ids[i - 1]) { set_error("bowdb: word ids must be strictly ascending"); return DVM_ERR_INVALID; }
   DVM_HIP(hipSetDevice(db->device));
-  if (db->used + (size_t)n > db->cap) {   // grow the word arrays (doubling), keeping what is stored
-    const size_t ncap = std::max<size_t>(std::max<size_t>(db->cap * 2, db->used + (size_t)n), 1 << 16);
+  // Erased keyframes leave their words behind (the reference culls keyframes all the time): once the dead words outnumber
+  // the live ones, repack the live slots' ranges into fresh arrays, in slot order.  Slot numbers never change.
+  const bool repack = db->dead >= ((size_t)1 << 16) && db->dead > db->used - db->dead;
+  if (repack || db->used + (size_t)n > db->cap) {   // grow (doubling) and / or repack, keeping what is stored
+    const size_t live_words = db->used - db->dead;
+    const size_t keep = repack ? live_words : db->used;
+    const size_t ncap = std::max<size_t>(std::max<size_t>(repack ? keep * 2 : db->cap * 2, keep + (size_t)n), 1 << 16);
     int32_t* ni = nullptr; double* nv = nullptr;
     DVM_HIP(hipMalloc(&ni, ncap * 4));
     if (hipMalloc(&nv, ncap * 8) != hipSuccess) { hipFree(ni); set_error("hipMalloc(bowdb)"); return DVM_ERR_HIP; }
-    if (db->used) {
-      DVM_HIP(hipMemcpy(ni, db->d_ids, db->used * 4, hipMemcpyDeviceToDevice));
-      DVM_HIP(hipMemcpy(nv, db->d_vals, db->used * 8, hipMemcpyDeviceToDevice));
+    hipError_t e = hipSuccess;
+    if (repack) {
+      size_t w = 0;
+      for (size_t k = 0; k < db->off.size() && e == hipSuccess; k++) {
+        if (db->len[k] <= 0) { if (db->len[k] == 0) db->off[k] = (int64_t)w; continue; }
+        const size_t L = (size_t)db->len[k];
+        e = hipMemcpyAsync(ni + w, db->d_ids + db->off[k], L * 4, hipMemcpyDeviceToDevice, nullptr);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv + w, db->d_vals + db->off[k], L * 8, hipMemcpyDeviceToDevice, nullptr);
+        db->off[k] = (int64_t)w;
+        w += L;
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      if (e == hipSuccess) { db->used = w; db->dead = 0; }
+    } else if (db->used) {
+      e = hipMemcpy(ni, db->d_ids, db->used * 4, hipMemcpyDeviceToDevice);
+      if (e == hipSuccess) e = hipMemcpy(nv, db->d_vals, db->used * 8, hipMemcpyDeviceToDevice);
     }
+    if (e != hipSuccess) { hipFree(ni); hipFree(nv); set_error(std::string("bowdb grow / repack: ") + hipGetErrorString(e)); return DVM_ERR_HIP; }
     if (db->d_ids) hipFree(db->d_ids);
     if (db->d_vals) hipFree(db->d_vals);
     db->d_ids = ni; db->d_vals = nv; db->cap = ncap;
+    db->meta_dirty = true;
   }
   if (n) {
     DVM_HIP(hipMemcpy(db->d_ids + db->used, word_ids, (size_t)n * 4, hipMemcpyHostToDevice));
     DVM_HIP(hipMemcpy(db->d_vals + db->used, values, (size_t)n * 8, hipMemcpyHostToDevice));
   }
   if (slot) *slot = (int32_t)db->off.size();
-  db->off.push_back((int32_t)db->used);
+  db->off.push_back((int64_t)db->used);
   db->len.push_back(n);
   db->used += (size_t)n;
   db->meta_dirty = true;
@@ -691,6 +714,7 @@ int dvm_bowdb_add(dvm_bowdb* db, const int32_t* word_ids, const double* values, 
 
 int dvm_bowdb_erase(dvm_bowdb* db, int32_t slot) {
   if (!db || slot < 0 || slot >= (int32_t)db->off.size()) return DVM_ERR_INVALID;
+  if (db->len[slot] > 0) db->dead += (size_t)db->len[slot];
   db->len[slot] = -1;
   db->meta_dirty = true;
   return DVM_OK;
@@ -699,35 +723,53 @@ int dvm_bowdb_erase(dvm_bowdb* db, int32_t slot) {
 int dvm_bowdb_query(dvm_bowdb* db, const int32_t* word_ids, const double* values, int n, int32_t* common, int32_t* first_word,
                     float* score) {
   if (!db || n < 0 || (n > 0 && (!word_ids || !values)) || !common || !first_word || !score) return DVM_ERR_INVALID;
+  for (int i = 1; i < n; i++)   // the kernel binary-searches the query ids
+    if (word_ids[i] <= word_ids[i - 1]) { set_error("bowdb: query word ids must be strictly ascending"); return DVM_ERR_INVALID; }
   const int N = (int)db->off.size();
   if (N == 0) return DVM_OK;
   DVM_HIP(hipSetDevice(db->device));
   if ((size_t)N > db->slot_cap) {
-    for (void* p : {(void*)db->d_off, (void*)db->d_len, (void*)db->d_common, (void*)db->d_first, (void*)db->d_score})
+    for (void* p : {(void*)db->d_off, (void*)db->d_len, (void*)db->d_live, (void*)db->d_common, (void*)db->d_first, (void*)db->d_score})
       if (p) hipFree(p);
-    db->d_off = db->d_len = db->d_common = db->d_first = nullptr; db->d_score = nullptr;
+    db->d_off = nullptr; db->d_len = db->d_live = db->d_common = db->d_first = nullptr; db->d_score = nullptr;
     db->slot_cap = std::max<size_t>((size_t)N * 2, 1024);
-    DVM_HIP(hipMalloc(&db->d_off, db->slot_cap * 4)); DVM_HIP(hipMalloc(&db->d_len, db->slot_cap * 4));
+    DVM_HIP(hipMalloc(&db->d_off, db->slot_cap * 8)); DVM_HIP(hipMalloc(&db->d_len, db->slot_cap * 4));
+    DVM_HIP(hipMalloc(&db->d_live, db->slot_cap * 4));
     DVM_HIP(hipMalloc(&db->d_common, db->slot_cap * 4)); DVM_HIP(hipMalloc(&db->d_first, db->slot_cap * 4));
     DVM_HIP(hipMalloc(&db->d_score, db->slot_cap * 4));
     db->meta_dirty = true;
   }
   if (db->meta_dirty) {
-    DVM_HIP(hipMemcpy(db->d_off, db->off.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    db->live.clear();
+    for (int k = 0; k < N; k++) if (db->len[k] >= 0) db->live.push_back(k);
+    DVM_HIP(hipMemcpy(db->d_off, db->off.data(), (size_t)N * 8, hipMemcpyHostToDevice));
     DVM_HIP(hipMemcpy(db->d_len, db->len.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    if (!db->live.empty()) DVM_HIP(hipMemcpy(db->d_live, db->live.data(), db->live.size() * 4, hipMemcpyHostToDevice));
     db->meta_dirty = false;
   }
   Stage st;
   const int iq = st.in(word_ids, (size_t)n * 4), iv = st.in(values, (size_t)n * 8);
   int rc = st.upload();
   if (rc != DVM_OK) return rc;
-  launch_bowdb_query(nullptr, db->d_off, db->d_len, db->d_ids, db->d_vals, N, st.ptr<int32_t>(iq), st.ptr<double>(iv), n, db->d_common,
-                     db->d_first, db->d_score);
+  // erased slots answer (common -1, first word -1, score 0) without costing a wavefront: the launch covers the live slots only
+  DVM_HIP(hipMemsetAsync(db->d_common, 0xFF, (size_t)N * 4, nullptr));
+  DVM_HIP(hipMemsetAsync(db->d_first, 0xFF, (size_t)N * 4, nullptr));
+  DVM_HIP(hipMemsetAsync(db->d_score, 0, (size_t)N * 4, nullptr));
+  launch_bowdb_query(nullptr, db->d_off, db->d_len, db->d_live, (int)db->live.size(), db->d_ids, db->d_vals, st.ptr<int32_t>(iq), st.ptr<double>(iv), n,
+                     db->d_common, db->d_first, db->d_score);
   rc = hip_check(hipGetLastError(), "bowdb_query launch");
   if (rc != DVM_OK) return rc;
   DVM_HIP(hipMemcpy(common, db->d_common, (size_t)N * 4, hipMemcpyDeviceToHost));
   DVM_HIP(hipMemcpy(first_word, db->d_first, (size_t)N * 4, hipMemcpyDeviceToHost));
   DVM_HIP(hipMemcpy(score, db->d_score, (size_t)N * 4, hipMemcpyDeviceToHost));
+  return DVM_OK;
+}
+
+int dvm_bowdb_stats(const dvm_bowdb* db, int64_t out[4]) {
+  if (!db || !out) return DVM_ERR_INVALID;
+  int64_t nlive = 0;
+  for (int32_t l : db->len) nlive += l >= 0;
+  out[0] = (int64_t)db->off.size(); out[1] = nlive; out[2] = (int64_t)db->used; out[3] = (int64_t)db->cap;
   return DVM_OK;
 }
 

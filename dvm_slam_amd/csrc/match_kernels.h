@@ -95,8 +95,8 @@ void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int 
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride);
 void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,
                         int nq, dvm_match_pod* out);
-void launch_bowdb_query(hipStream_t s, const int32_t* kf_off, const int32_t* kf_len, const int32_t* ids, const double* vals, int n_kf,
-                        const int32_t* qids, const double* qvals, int nq, int32_t* common, int32_t* first_word, float* score);
+void launch_bowdb_query(hipStream_t s, const int64_t* kf_off, const int32_t* kf_len, const int32_t* live, int n_live, const int32_t* ids,
+                        const double* vals, const int32_t* qids, const double* qvals, int nq, int32_t* common, int32_t* first_word, float* score);
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D);
 
 void launch_distinctive(hipStream_t s, const uint8_t* desc, const int32_t* off, int npts, int32_t* best_idx, int32_t* best_median);

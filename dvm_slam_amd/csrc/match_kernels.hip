@@ -414,15 +414,20 @@ __global__ void __launch_bounds__(256) k_match_triangulation(const uint8_t* __re
 // keyframe intersects its sorted word list with the query's (binary search per word) and produces count, first shared
 // word and the score for ALL keyframes at once -- no inverted file on the device.  The double sum of the score is taken
 // in ascending word order (the reference's merge walk) by walking the hit mask of each 64-word chunk.
-__global__ void __launch_bounds__(256) k_bowdb_query(const int32_t* __restrict__ kf_off, const int32_t* __restrict__ kf_len,
-                                                     const int32_t* __restrict__ ids, const double* __restrict__ vals, int n_kf,
+__global__ void __launch_bounds__(256) k_bowdb_query(const int64_t* __restrict__ kf_off, const int32_t* __restrict__ kf_len,
+                                                     const int32_t* __restrict__ live, int n_live,
+                                                     const int32_t* __restrict__ ids_base, const double* __restrict__ vals_base,
                                                      const int32_t* __restrict__ qids, const double* __restrict__ qvals, int nq,
                                                      int32_t* __restrict__ common, int32_t* __restrict__ first_word,
                                                      float* __restrict__ score) {
   const int lane = threadIdx.x & 63;
-  const int kf = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (kf >= n_kf) return;
-  const int off = kf_off[kf], len = kf_len[kf];   // len < 0: erased slot
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (li >= n_live) return;
+  const int kf = live[li];                         // erased slots are not launched (their results are preset by the host)
+  const int len = kf_len[kf];
+  const int32_t* __restrict__ ids = ids_base + kf_off[kf];
+  const double* __restrict__ vals = vals_base + kf_off[kf];
+  constexpr int off = 0;
   int n_common = 0, first = -1;
   double acc = 0.0;
   for (int base = 0; base < len; base += 64) {
@@ -561,11 +566,11 @@ void launch_match_triangulation(hipStream_t s, const uint8_t* desc1, const dvm_k
   hipLaunchKernelGGL(k_match_triangulation, dim3((nq + 15) / 16), dim3(256), 0, s, desc1, kps1, qidx, nq, desc2, kps2, off, cand, G,
                      scale_factors2, level_sigma2_2, best_idx, best_dist);
 }
-void launch_bowdb_query(hipStream_t s, const int32_t* kf_off, const int32_t* kf_len, const int32_t* ids, const double* vals, int n_kf,
-                        const int32_t* qids, const double* qvals, int nq, int32_t* common, int32_t* first_word, float* score) {
-  if (n_kf > 0)
-    hipLaunchKernelGGL(k_bowdb_query, dim3((n_kf + 3) / 4), dim3(256), 0, s, kf_off, kf_len, ids, vals, n_kf, qids, qvals, nq, common,
-                       first_word, score);
+void launch_bowdb_query(hipStream_t s, const int64_t* kf_off, const int32_t* kf_len, const int32_t* live, int n_live, const int32_t* ids,
+                        const double* vals, const int32_t* qids, const double* qvals, int nq, int32_t* common, int32_t* first_word, float* score) {
+  if (n_live > 0)
+    hipLaunchKernelGGL(k_bowdb_query, dim3((n_live + 3) / 4), dim3(256), 0, s, kf_off, kf_len, live, n_live, ids, vals, qids, qvals, nq,
+                       common, first_word, score);
 }
 void launch_hamming_matrix(hipStream_t s, const uint8_t* A, int nA, const uint8_t* B, int nB, uint16_t* D) {
   hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 63) / 64, (nA + 3) / 4), dim3(256), 0, s, A, nA, B, nB, D);

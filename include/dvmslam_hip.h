@@ -280,6 +280,9 @@ int dvm_bowdb_size(const dvm_bowdb* db);   /* slots handed out so far */
  * dvm_bowdb_size() entries, host pointers, synchronous. */
 int dvm_bowdb_query(dvm_bowdb* db, const int32_t* word_ids, const double* values, int n, int32_t* common, int32_t* first_word,
                     float* score);
+/* out[4] = {slots ever added, live slots, words stored (live + erased, shrinks when the store is repacked), word capacity}.
+ * Erased slots keep their number; their words are reclaimed by a repack once they outnumber the live words. */
+int dvm_bowdb_stats(const dvm_bowdb* db, int64_t out[4]);
 
 /* TrackWithMotionModel-style frame-to-frame search over a batch (ORBmatcher.cc:1596-1611, mono):
  * pair i (0 <= i < count) searches train slot first_slot+i for every keypoint of frame i-1 of the

@@ -28,6 +28,42 @@ def test_bowdb_query_raw(capi, oracle):
     assert np.all(common == 0) and np.all(first == -1) and np.all(score == 0)
 
 
+def test_bowdb_culling_reclaims_words_and_keeps_answers(capi, oracle):
+    """Keyframe culling: erased slots keep their numbers but stop costing query work, their words are reclaimed by
+    a repack once they outnumber the live ones, and every answer stays what a store holding only the live keyframes gives."""
+    rng = np.random.default_rng(5)
+    db = capi.BowDb()
+    bows = []
+    for k in range(600):
+        ids = np.sort(rng.choice(20000, 400, replace=False)).astype(np.int32)
+        vals = rng.random(400); vals /= vals.sum()
+        bows.append((ids, vals))
+        assert db.add(ids, vals) == k
+    q = bows[17]
+    before = db.query(*q)
+    assert db.stats() == dict(slots=600, live=600, words=240000, capacity=db.stats()["capacity"])
+    dead = [k for k in range(600) if k % 4 != 1]
+    for k in dead:
+        db.erase(k)
+    mid = db.query(*q)
+    assert db.stats()["words"] == 240000 and db.stats()["live"] == 150          # erase alone reclaims nothing
+    ids = np.sort(rng.choice(20000, 400, replace=False)).astype(np.int32); vals = np.full(400, 1 / 400.0)
+    assert db.add(ids, vals) == 600                                               # ... the next add repacks
+    st = db.stats()
+    assert st["slots"] == 601 and st["live"] == 151 and st["words"] == 151 * 400 and st["capacity"] < 240000
+    after = db.query(*q)
+    live = np.array([k for k in range(600) if k % 4 == 1])
+    for res in (mid, after):
+        assert np.all(res[0][dead] == -1) and np.all(res[1][dead] == -1) and np.all(res[2][dead] == 0)
+        for a, b in zip(res, before):
+            assert np.array_equal(a[live], b[live])
+    inter = np.intersect1d(q[0], ids)
+    assert after[0][600] == len(inter) and after[2][600] == np.float32(oracle.bow_score(q[0], q[1], ids, vals))
+    with pytest.raises(RuntimeError):
+        db.query(q[0][::-1], q[1])                                                 # query ids must ascend (binary search)
+    db.close()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_keyframe_database_sequences(capi, oracle, seed):
     kfs = make_db_scene(seed + 10)
