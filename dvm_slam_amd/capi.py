@@ -335,6 +335,13 @@ class FrameGrid:
         desc = np.ascontiguousarray(desc, np.uint8)
         check(self.L.dvm_frame_build(self.h, slot, _p(kps), _p(desc), len(kps), None, *bounds, 0, None))
 
+    def overflows(self):
+        """Sticky count of device-side keypoint counts that exceeded the capacity (raises DvmError if non-zero)."""
+        n = C.c_int32(0)
+        self.L.dvm_frame_overflows.restype = C.c_int32; self.L.dvm_frame_overflows.argtypes = [C.c_void_p, C.c_void_p]
+        check(self.L.dvm_frame_overflows(self.h, C.byref(n)))
+        return n.value
+
     def build_batch_device(self, first_slot, count, d_kps, kps_stride, d_desc, desc_stride, d_n, bounds, stream=None):
         check(self.L.dvm_frame_build_batch(self.h, first_slot, count, C.c_void_p(d_kps), kps_stride, C.c_void_p(d_desc),
                                            desc_stride, C.c_void_p(d_n), *bounds, C.c_void_p(stream or 0)))

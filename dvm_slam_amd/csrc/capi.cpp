@@ -341,6 +341,8 @@ int dvm_frame_create(int device, int capacity, int slots, dvm_frame** out) {
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.cellx_start, S * 80 * 4), "hipMalloc");
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.n_sorted, S * 4), "hipMalloc");
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.n_total, S * 4), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&V.n_overflow, 4), "hipMalloc");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(V.n_overflow, 0, 4), "memset");
   if (rc == DVM_OK) rc = hip_check(hipMemset(V.cellx_start, 0, S * 80 * 4), "memset");
   if (rc == DVM_OK) rc = hip_check(hipMemset(V.n_sorted, 0, S * 4), "memset");
   if (rc == DVM_OK) rc = hip_check(hipMemset(V.n_total, 0, S * 4), "memset");
@@ -360,6 +362,7 @@ void dvm_frame_destroy(dvm_frame* f) {
   if (V.cellx_start) hipFree(V.cellx_start);
   if (V.n_sorted) hipFree(V.n_sorted);
   if (V.n_total) hipFree(V.n_total);
+  if (V.n_overflow) hipFree(V.n_overflow);
   if (f->d_scratch) hipFree(f->d_scratch);
   delete f;
 }
@@ -407,6 +410,16 @@ int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8
   if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "sync");
   return rc;
 }
+int dvm_frame_overflows(dvm_frame* f, int32_t* count) {
+  if (!f || !count) return DVM_ERR_INVALID;
+  int rc = hip_check(hipSetDevice(f->device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  rc = hip_check(hipMemcpy(count, f->view.n_overflow, 4, hipMemcpyDeviceToHost), "memcpy");   // synchronises with the null stream only
+  if (rc != DVM_OK) return rc;
+  if (*count) { set_error("frame grid: a device-side keypoint count exceeded the handle's capacity and was truncated"); return DVM_ERR_CAPACITY; }
+  return DVM_OK;
+}
+
 int dvm_frame_build_batch(dvm_frame* f, int first_slot, int count, const dvm_keypoint* d_kps, int64_t kps_stride,
                           const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n, float minX, float maxX,
                           float minY, float maxY, void* stream) {

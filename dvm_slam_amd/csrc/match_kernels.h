@@ -23,6 +23,7 @@ struct FrameView {
   int32_t* cellx_start;  // [65] first sorted position with grid column >= c
   int32_t* n_sorted;     // keypoints inside the grid
   int32_t* n_total;      // keypoints given
+  int32_t* n_overflow;   // one per handle: device-side counts (d_n) that exceeded cap and were clamped (sticky; dvm_frame_overflows)
   int32_t cap;
   float minX, minY, wInv, hInv;
   __host__ __device__ FrameView slot(int s) const {

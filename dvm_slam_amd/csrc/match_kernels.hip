@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(1024) k_frame_build(const dvm_keypoint_pod* __
   const dvm_keypoint_pod* kps = kps_base + (int64_t)blockIdx.x * kps_stride;
   const uint8_t* desc = desc_base + (int64_t)blockIdx.x * desc_stride;
   int n = d_n ? d_n[blockIdx.x] : n_host;
+  if (tid == 0 && n > F.cap) atomicAdd(F.n_overflow, 1);   // a truncated frame is reported, not hidden (dvm_frame_overflows)
   n = min(max(n, 0), F.cap);
   int P = 64;
   while (P < n) P <<= 1;
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
       qdesc = PQ.desc + (int64_t)(pair - 1) * PQ.desc_stride;
       nq = PQ.n[pair - 1];
     }
+    if (q == 0 && lane == 0 && nq > PQ.cap) atomicAdd(F.n_overflow, 1);
     nq = min(nq, PQ.cap);
     if (q == 0 && lane == 0 && PQ.n_out) PQ.n_out[pair] = nq;
     out += (int64_t)pair * out_stride;

@@ -754,6 +754,13 @@ int OrbPipeline::sync() {
   DVM_HIP(hipSetDevice(device));
   DVM_HIP(hipStreamSynchronize(stream));
   prof.resolve();
+  // the device octree's overflow flag: checked at every synchronisation point, so the device-resident consumers
+  // (dvm_orb_result_device, dvm_orb_copy_result, the wire gather) cannot read a silently truncated level either
+  if (d_err) {
+    int32_t oct_err = 0;
+    DVM_HIP(hipMemcpy(&oct_err, d_err, 4, hipMemcpyDeviceToHost));
+    if (oct_err) { set_error("device octree: node capacity exceeded (internal: configure() refuses such quotas)"); return DVM_ERR_CAPACITY; }
+  }
   return DVM_OK;
 }
 
@@ -764,9 +771,6 @@ int OrbPipeline::download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, 
   DVM_HIP(hipMemcpyAsync(h_mono, d_mono, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
   int rc = sync();
   if (rc != DVM_OK) return rc;
-  int32_t oct_err = 0;
-  DVM_HIP(hipMemcpy(&oct_err, d_err, 4, hipMemcpyDeviceToHost));
-  if (oct_err) { set_error("device octree: node capacity exceeded (internal: configure() should have chosen the host path)"); return DVM_ERR_CAPACITY; }
   const int N = h_n[frame];
   if (n) *n = N;
   if (mono) *mono = h_mono[frame];

@@ -1,5 +1,6 @@
 // dvm_slam_amd/csrc/wire.cpp -- DVMW map wire format: layout, host-side assembly and validation (include/dvmslam_wire.h).
 #include <cstring>
+#include <map>
 #include <string>
 
 #include "../../include/dvmslam_wire.h"
@@ -102,6 +103,19 @@ int dvm_wire_validate(const void* block, uint64_t bytes) {
     const int32_t* ff = reinterpret_cast<const int32_t*>(b + L.offset[9]) + kfs[i].fv_feat_off;
     for (uint64_t k = 0; k < nf; k++)
       if (ff[k] < 0 || (uint32_t)ff[k] >= kfs[i].n_kp) { dvm::set_error("wire: feature index beyond the keyframe's keypoints"); return DVM_ERR_INVALID; }
+  }
+  // observations: a keypoint index is never negative (index_right may be -1: monocular), and where the observing keyframe
+  // travels in the same block the index must address one of ITS keypoints -- consumers index with it (agents.unpack_candidate)
+  if (h.n_obs) {
+    std::map<std::pair<uint64_t, uint64_t>, uint32_t> n_kp_of;
+    auto key = [](const dvm_uuid& u) { uint64_t a, c; std::memcpy(&a, u.b, 8); std::memcpy(&c, u.b + 8, 8); return std::make_pair(a, c); };
+    for (uint32_t i = 0; i < h.n_keyframes; i++) n_kp_of[key(kfs[i].uuid)] = kfs[i].n_kp;
+    const dvm_wire_obs* obs = reinterpret_cast<const dvm_wire_obs*>(b + L.offset[11]);
+    for (uint32_t k = 0; k < h.n_obs; k++) {
+      if (obs[k].index < 0 || obs[k].index_right < -1) { dvm::set_error("wire: observation " + std::to_string(k) + " has a negative keypoint index"); return DVM_ERR_INVALID; }
+      const auto it = n_kp_of.find(key(obs[k].kf_uuid));
+      if (it != n_kp_of.end() && (uint32_t)obs[k].index >= it->second) { dvm::set_error("wire: observation " + std::to_string(k) + " indexes past its keyframe's keypoints"); return DVM_ERR_INVALID; }
+    }
   }
   return DVM_OK;
 }

@@ -148,6 +148,10 @@ int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8
 int dvm_frame_build_batch(dvm_frame* f, int first_slot, int count, const dvm_keypoint* d_kps, int64_t kps_stride,
                           const uint8_t* d_desc, int64_t desc_stride, const int32_t* d_n, float minX, float maxX,
                           float minY, float maxY, void* stream);
+/* Device-side counts (d_n of dvm_frame_build[_batch], the per-frame counts of dvm_match_frames_batch) larger than the handle's
+ * capacity are clamped by the kernels; every such event is counted.  Call after synchronising the stream(s) the launches
+ * went to: *count = events so far (sticky), returns DVM_ERR_CAPACITY if non-zero. */
+int dvm_frame_overflows(dvm_frame* f, int32_t* count);
 
 typedef struct {
   int32_t best_idx;     /* index into the slot's ORIGINAL keypoint order, -1 if no candidate */

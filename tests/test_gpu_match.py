@@ -247,3 +247,27 @@ def test_vocab_transform(capi, oracle, k, L):
     a = capi.vocab_transform_host(voc, feats[:800], 4); b = capi.vocab_transform_host(voc, feats[600:], 4)
     assert capi.bow_score_host(a["bow_ids"], a["bow_vals"], b["bow_ids"], b["bow_vals"]) == \
         oracle.bow_score(a["bow_ids"], a["bow_vals"], b["bow_ids"], b["bow_vals"])
+
+
+def test_frame_grid_reports_truncated_device_counts(capi):
+    """a device-side count above the handle's capacity is clamped by k_frame_build -- and counted, so the caller of
+    the device-resident path learns about it (dvm_frame_overflows) instead of silently matching against a truncated frame."""
+    import torch
+    rng = np.random.default_rng(3)
+    cap = 512
+    g = capi.FrameGrid(capacity=cap, slots=2)
+    k = np.zeros(2 * 600, capi.KP_DTYPE)
+    k["x"] = rng.uniform(0, 640, len(k)); k["y"] = rng.uniform(0, 480, len(k))
+    d_k = torch.from_numpy(k.view(np.uint8).copy()).cuda()
+    d_d = torch.from_numpy(rng.integers(0, 256, (len(k), 32), dtype=np.uint8)).cuda()
+    d_n = torch.tensor([500, 400], dtype=torch.int32).cuda()
+    g.build_batch_device(0, 2, d_k.data_ptr(), 600, d_d.data_ptr(), 600 * 32, d_n.data_ptr(), (0.0, 640.0, 0.0, 480.0))
+    torch.cuda.synchronize()
+    assert g.overflows() == 0
+    d_n = torch.tensor([500, 600], dtype=torch.int32).cuda()          # second frame: 600 keypoints into 512 slots
+    g.build_batch_device(0, 2, d_k.data_ptr(), 600, d_d.data_ptr(), 600 * 32, d_n.data_ptr(), (0.0, 640.0, 0.0, 480.0))
+    torch.cuda.synchronize()
+    with pytest.raises(capi.DvmError) as e:
+        g.overflows()
+    assert "truncated" in str(e.value)
+    g.close()

@@ -78,6 +78,20 @@ def test_damaged_blocks_are_rejected(wire, capi):
     wire.sections(b)[9][int(S[1][kf]["fv_feat_off"])] = 10 ** 6                   # feature index beyond the keypoints
     with pytest.raises(capi.DvmError):
         wire.validate(b)
+    # observations index the observing keyframe's keypoints: negative, or past the end of a keyframe travelling in the block
+    obs = wire.sections(blk)[11]
+    assert len(obs) > 0
+    uu = {bytes(S[1][k]["uuid"].tobytes()): int(S[1][k]["n_kp"]) for k in range(len(kfs))}
+    j = [i for i in range(len(obs)) if bytes(obs[i]["kf_uuid"].tobytes()) in uu][0]
+    for val in (-1, uu[bytes(obs[j]["kf_uuid"].tobytes())], 10 ** 6):
+        b = blk.copy()
+        wire.sections(b)[11][j]["index"] = val
+        with pytest.raises(capi.DvmError):
+            wire.validate(b)
+    b = blk.copy()
+    wire.sections(b)[11][j]["index_right"] = -2
+    with pytest.raises(capi.DvmError):
+        wire.validate(b)
     # builder-side checks
     bad = [dict(k) for k in kfs]; bad[0]["bow_ids"] = bad[0]["bow_ids"][::-1].copy() if len(bad[0]["bow_ids"]) > 1 else np.array([5, 3], np.int32)
     bad[0]["bow_vals"] = np.zeros(len(bad[0]["bow_ids"]))

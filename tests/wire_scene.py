@@ -37,7 +37,8 @@ def make_delta(wire, capi, seed=0, n_kf=3, n_mp=40, agent=1):
     for i in range(n_mp):
         obs = np.zeros(int(rng.integers(0, 5)) if n_kf else 0, wire.OBS)
         for o in obs:
-            o["kf_uuid"] = kf_uuids[int(rng.integers(0, n_kf))]; o["index"] = rng.integers(0, 50); o["index_right"] = -1
+            k = int(rng.integers(0, n_kf))
+            o["kf_uuid"] = kf_uuids[k]; o["index"] = rng.integers(0, len(kfs[k]["kps"])); o["index_right"] = -1
         mps.append(dict(uuid=mp_uuids[i], ref_kf_uuid=kf_uuids[int(rng.integers(0, n_kf))] if n_kf else uu(), replaced_uuid=np.zeros(16, np.uint8), mn_id=5000 + i,
                         first_kf_id=100, pos=rng.normal(size=3).astype(np.float32), normal=rng.normal(size=3).astype(np.float32),
                         min_distance=float(rng.uniform(0.5, 2)), max_distance=float(rng.uniform(4, 20)),
