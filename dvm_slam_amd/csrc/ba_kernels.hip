@@ -226,8 +226,8 @@ __global__ void __launch_bounds__(256) k_reduce_sum(const double* __restrict__ p
 }
 
 // Hll (3x3) and bl per landmark: thread per landmark, edges in input order.
-__global__ void __launch_bounds__(256) k_point_accum(BaView V) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void point_accum_body(const BaView& V, int block) {
+  const int l = block * 256 + threadIdx.x;
   if (l >= V.L) return;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   for (int i = V.pt_start[l]; i < V.pt_start[l + 1]; i++) {
@@ -248,9 +248,9 @@ __global__ void __launch_bounds__(256) k_point_accum(BaView V) {
 
 // Hpp (6x6) and bp per free camera: one wave per camera, lanes stride over the camera's edges, then a
 // fixed-order xor-butterfly reduction (identical on every run).
-__global__ void __launch_bounds__(256) k_pose_accum(BaView V) {
+__device__ __forceinline__ void pose_accum_body(const BaView& V, int block) {
   const int lane = threadIdx.x & 63;
-  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int fi = block * 4 + (threadIdx.x >> 6);
   if (fi >= V.nfree) return;
   const int p = V.free_pose[fi];
   double H[21], b[6];
@@ -286,6 +286,13 @@ __global__ void __launch_bounds__(256) k_pose_accum(BaView V) {
   }
 }
 
+// Both accumulations in ONE launch (they are independent of each other): workgroups [0, nb_pose) take the cameras -- the
+// longer job, so it starts first --, the rest the landmarks.  Two dependent 14 us launches before.
+__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose) {
+  if ((int)blockIdx.x < nb_pose) pose_accum_body(V, blockIdx.x);
+  else point_accum_body(V, blockIdx.x - nb_pose);
+}
+
 // max |diag| over Hpp and Hll (computeLambdaInit) -> host, grid-wide with the last workgroup finishing the reduction.
 __global__ void __launch_bounds__(256) k_max_diag(BaView V, BaPublish pub) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -319,10 +326,10 @@ __global__ void __launch_bounds__(256) k_dinv(BaView V) { dinv_landmark(V, block
 // One wave per non-zero lower block (i1 >= i2) of the reduced camera matrix:
 //   S[i1,i2] = Hpp[i1] (+lambda I) if i1 == i2  -  sum over co-observed landmarks of W1 Dinv W2^T
 // `pairs` lists (edge of pose i1, edge of pose i2) per block (symbolic structure built once on host).
-__global__ void __launch_bounds__(256) k_schur_blocks(BaView V) {
+__device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
   const double lambda = ba_lambda(V);
   const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int blk = block * 4 + (threadIdx.x >> 6);
   if (blk >= V.nblk) return;
   const int i1 = V.blk_i1[blk], i2 = V.blk_i2[blk];
   double acc[36];
@@ -359,9 +366,9 @@ __global__ void __launch_bounds__(256) k_schur_blocks(BaView V) {
 }
 
 // bschur[i] = bp[i] - sum_{edges k of camera i} W_k (Dinv bl)_{point(k)}  -> augmented row n of S.
-__global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
+__device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
   const int lane = threadIdx.x & 63;
-  const int fi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int fi = block * 4 + (threadIdx.x >> 6);
   if (fi >= V.nfree) return;
   const int p = V.free_pose[fi];
   double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -380,6 +387,13 @@ __global__ void __launch_bounds__(256) k_schur_rhs(BaView V) {
     for (int a = 0; a < 6; a++) V.S[(size_t)V.n_pad * V.ldS + ba_row(fi) + a] = V.bp[6 * (size_t)fi + a] - acc[a];
     if (fi == 0) V.S[(size_t)V.n_pad * V.ldS + V.n_pad] = 1e200 * V.damp_s;  // augmented corner: keeps the last pivot positive
   }
+}
+
+// The reduced system and its right-hand side in ONE launch (independent of each other; both only need Dinv / db of the
+// prologue): workgroups [0, nb_blk) build the 6x6 blocks, the rest the rhs row.
+__global__ void __launch_bounds__(256) k_schur(BaView V, int nb_blk) {
+  if ((int)blockIdx.x < nb_blk) schur_blocks_body(V, blockIdx.x);
+  else schur_rhs_body(V, blockIdx.x - nb_blk);
 }
 
 // clears the structurally non-zero tiles of S (a trial rebuilds them); everything else is never touched and stays zero
@@ -1730,8 +1744,8 @@ void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPubli
   else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V, pub);
 }
 void ba_launch_accum(hipStream_t s, const BaView& V) {
-  hipLaunchKernelGGL(k_point_accum, dim3(cdiv(V.L, 256)), dim3(256), 0, s, V);
-  if (V.nfree > 0) hipLaunchKernelGGL(k_pose_accum, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
+  const int nb_pose = V.nfree > 0 ? cdiv(V.nfree, 4) : 0;
+  hipLaunchKernelGGL(k_accum, dim3(nb_pose + cdiv(V.L, 256)), dim3(256), 0, s, V, nb_pose);
 }
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);
@@ -1740,8 +1754,8 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_dinv = cdiv(V.L, 256);
   hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_dinv, d_fail);
   if (V.nfree == 0) return;
-  hipLaunchKernelGGL(k_schur_blocks, dim3(cdiv(V.nblk, 4)), dim3(256), 0, s, V);
-  hipLaunchKernelGGL(k_schur_rhs, dim3(cdiv(V.nfree, 4)), dim3(256), 0, s, V);
+  const int nb_blk = cdiv(V.nblk, 4);
+  hipLaunchKernelGGL(k_schur, dim3(nb_blk + cdiv(V.nfree, 4)), dim3(256), 0, s, V, nb_blk);
 }
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
