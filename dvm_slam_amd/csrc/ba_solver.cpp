@@ -36,6 +36,9 @@ struct dvm_ba {
   int solve_seq = 0;
   // landmark-sharded mode (dvm_ba_set_problem_sharded): rank r of `world` owns the landmarks l with l % world == r
   int rank = 0, world = 1;
+  // second set of linearisation buffers: a trial evaluates its state WITH Jacobians and accumulates Hpp / Hll into these, so
+  // that an accepted trial's state is already linearised when the next iteration starts (swapped in with the state)
+  double *alt_lin = nullptr, *alt_W = nullptr, *alt_Hpp = nullptr, *alt_bp = nullptr, *alt_Hll = nullptr, *alt_bl = nullptr;
   bool sharded_api = false;   // problem set through dvm_ba_set_problem_sharded: with a collective registered, even a single rank runs the sharded flow
   // optional HIP-event timing of the phases of a trial (dvm_ba_profile): [0] linearise, [1] Schur complement, [2] tile Cholesky +
   // back substitution, [3] landmarks + update + chi2; milliseconds accumulated over prof_trials trials / prof_iters iterations
@@ -253,6 +256,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->dalloc(&V.Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&V.bp, (size_t)n));
   ok(h->dalloc(&V.Hll, 9 * (size_t)L)); ok(h->dalloc(&V.bl, 3 * (size_t)L));
   ok(h->dalloc(&V.Dinv, 9 * (size_t)L)); ok(h->dalloc(&V.db, 3 * (size_t)L));
+  ok(h->dalloc(&h->alt_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&h->alt_W, (size_t)E * 18));
+  ok(h->dalloc(&h->alt_Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&h->alt_bp, (size_t)n));
+  ok(h->dalloc(&h->alt_Hll, 9 * (size_t)L)); ok(h->dalloc(&h->alt_bl, 3 * (size_t)L));
   ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)V.n_pad + 64));
   ok(h->dalloc(&V.xrow, (size_t)V.n_pad + 64));
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
@@ -399,7 +405,16 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   int nBad = 0, it_done = 0, trials_total = 0, stop = 0;
   double chi_last = 0;
   auto terminate = [&]() { return stop_flag && *stop_flag; };
+  // Speculative linearisation: every trial evaluates its state with the Jacobian kernel (chi2 is the same sum either way)
+  // into the alternate buffers and accumulates Hpp / Hll there while the host waits for chi2 and decides.  Trials are
+  // accepted far more often than not; an accepted trial hands the next iteration its state AND that state's linearisation
+  // by swapping pointers, so the iteration starts at the Schur complement (computeActiveErrors + buildSystem already done,
+  // on the same values g2o would compute them on); a rejected trial's buffers are simply overwritten by the next one.
+  bool lin_ready = false;
+  double spec_chi = 0;
   for (int it = 0; it < iterations && !terminate(); it++) {
+    int rc = DVM_OK;
+    if (!lin_ready) {
     // computeActiveErrors + activeRobustChi2 + buildSystem (one fused edge pass at the current state).  chi2 reaches the
     // host from the edge pass itself, so the accumulation kernels below run while the host prepares the first trial.
     if (h->prof) hipEventRecord(h->pev[0], s);
@@ -407,9 +422,10 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     ba_launch_accum(s, V);
     if (h->prof) hipEventRecord(h->pev[1], s);
     if (it == 0 && !sharded) ba_launch_max_diag(s, V, pub(S_MAXDIAG, 1, true, false));
-    int rc = hip_check(hipGetLastError(), "bundle adjustment launch");
+    rc = hip_check(hipGetLastError(), "bundle adjustment launch");
     if (rc == DVM_OK) rc = wait_seq(h, h->seq);
     if (rc != DVM_OK) return rc;
+    if (h->prof) { hipEventSynchronize(h->pev[1]); float ms = 0; hipEventElapsedTime(&ms, h->pev[0], h->pev[1]); h->prof_ms[0] += ms; }
     if (sharded) {
       double v = h->h_vals[S_CHI];                       // chi2 of the local edges (read before the next publication rewrites the slots)
       if ((rc = ar_host(&v, 1, 0)) != DVM_OK) return rc;
@@ -424,6 +440,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       }
       h->h_vals[S_CHI] = v;
     }
+    } else {
+      h->h_vals[S_CHI] = spec_chi;     // the accepted trial's chi2: the same kernel on the same state
+      lin_ready = false;
+    }
+    if (h->prof) h->prof_iters++;
     double currentChi = h->h_vals[S_CHI], tempChi = currentChi;
     const double iniChi = currentChi;
     if (it == 0) {
@@ -437,10 +458,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       // one trial = setLambda + Schur complement + reduced solve + landmarks + oplus into the TRIAL state + its chi2:
       // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
       V.lambda_v = lambda;
-      if (h->prof) {
-        if (qmax == 0) { hipEventSynchronize(h->pev[1]); float ms = 0; hipEventElapsedTime(&ms, h->pev[0], h->pev[1]); h->prof_ms[0] += ms; h->prof_iters++; }
-        hipEventRecord(h->pev[0], s);
-      }
+      if (h->prof) hipEventRecord(h->pev[0], s);
       ba_launch_schur(s, V, h->d_fail);
       if (h->prof) hipEventRecord(h->pev[1], s);
       if (sharded) {   // sum the partial reduced systems (non-zero tiles incl. the rhs row): ~6 MB at 500 keyframes
@@ -451,8 +469,14 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       ba_launch_cholesky_solve(s, V, h->d_fail, ++h->solve_seq);
       if (h->prof) hipEventRecord(h->pev[2], s);
       ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
-      ba_launch_edge_eval(s, V, false, pub(S_TMPCHI, 0, true, true));
-      if (h->prof) hipEventRecord(h->pev[3], s);
+      {
+        BaView VT = V;                                   // the trial state, linearised into the alternate buffers
+        VT.poses = V.poses_new; VT.points = V.points_new;
+        VT.e_lin = h->alt_lin; VT.e_W = h->alt_W; VT.Hpp = h->alt_Hpp; VT.bp = h->alt_bp; VT.Hll = h->alt_Hll; VT.bl = h->alt_bl;
+        ba_launch_edge_eval(s, VT, true, pub(S_TMPCHI, 0, true, true));
+        ba_launch_accum(s, VT);                          // runs while the host waits for chi2 and decides
+        if (h->prof) hipEventRecord(h->pev[3], s);
+      }
       rc = hip_check(hipGetLastError(), "bundle adjustment launch");
       if (rc == DVM_OK) rc = wait_seq(h, h->seq);
       if (rc != DVM_OK) return rc;
@@ -480,6 +504,9 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         currentChi = tempChi;
         std::swap(V.poses, V.poses_new);       // discardTop(): the trial state becomes the estimate
         std::swap(V.points, V.points_new);
+        std::swap(V.e_lin, h->alt_lin); std::swap(V.e_W, h->alt_W); std::swap(V.Hpp, h->alt_Hpp); std::swap(V.bp, h->alt_bp);
+        std::swap(V.Hll, h->alt_Hll); std::swap(V.bl, h->alt_bl);
+        lin_ready = true; spec_chi = tempChi;
       } else {
         lambda *= ni;
         ni *= 2;                               // pop(): (poses, points) were never touched

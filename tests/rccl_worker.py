@@ -52,7 +52,7 @@ def main():
     rec["ba_bits_equal"] = bool(np.array_equal(p1, p2) and np.array_equal(x1, x2))
     rec["ba_calls"] = sb.calls
     rec["ba_bytes"] = sb.bytes_reduced
-    rec["ba_expected_calls"] = 2 * sum(s1["trials"]) + len(s1["trials"]) + 2 + 1
+    rec["ba_expected_calls"] = 2 * sum(s1["trials"]) + 1 + 2 + 1
     sb.close()
     dist.barrier()
     dist.destroy_process_group()

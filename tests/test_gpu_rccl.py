@@ -32,7 +32,7 @@ def test_exchange_and_sharded_ba_over_rccl():
     assert rec["backend"] == "nccl"
     assert rec["max_over_ranks"] == 1.5 and rec["varlen_ok"] and rec["blocks_ok"] and rec["sim3_ok"]
     # one rank's "sum over ranks" is the identity: the sharded solver must reproduce the unsharded one bit for bit, having
-    # gone through RCCL once per LM trial (+ chi2 per iteration, lambda init, the final landmark exchange)
+    # gone through RCCL once per LM trial (+ the start state's chi2, lambda init, the final landmark exchange)
     assert rec["ba_trials_equal"] and rec["ba_bits_equal"]
     assert rec["ba_calls"] == rec["ba_expected_calls"] and rec["ba_bytes"] > 0
 
