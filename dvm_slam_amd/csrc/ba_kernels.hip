@@ -326,42 +326,111 @@ __global__ void __launch_bounds__(256) k_dinv(BaView V) { dinv_landmark(V, block
 // One wave per non-zero lower block (i1 >= i2) of the reduced camera matrix:
 //   S[i1,i2] = Hpp[i1] (+lambda I) if i1 == i2  -  sum over co-observed landmarks of W1 Dinv W2^T
 // `pairs` lists (edge of pose i1, edge of pose i2) per block (symbolic structure built once on host).
+// Gather form: the pairs of a block reference W rows (144 B) and Dinv blocks (72 B) scattered over tens of MB.  Read
+// lane-per-pair, every load instruction touches 64 different cache lines and the kernel runs at the texture addresser's
+// line rate (measured 75 us, whatever the occupancy).  So a wave stages 32 pairs at a time through LDS with CHUNK-PARALLEL
+// loads -- consecutive lanes read consecutive 16-byte chunks of the same row: ~7 rows per instruction instead of 64 -- and
+// then computes from LDS, two lanes per pair (lane half hf owns rows 3 hf .. 3 hf + 2 of the 6x6 product).  Summation order:
+// pair slots p, p + 32, ... per lane, then the xor-butterfly over the 32 slots -- fixed, identical on every run.
+constexpr int kSchurStagePairs = 32, kSchurRow = 45;   // doubles per staged pair: W1 (18) | W2 (18) | Dinv (9); odd dword-pair stride: conflict-free
 __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
+  __shared__ double s_stage[4][kSchurStagePairs * kSchurRow];
+  __shared__ int32_t s_idx[4][3][kSchurStagePairs];
   const double lambda = ba_lambda(V);
-  const int lane = threadIdx.x & 63;
-  const int blk = block * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = block * 4 + wave;
   if (blk >= V.nblk) return;
   const int i1 = V.blk_i1[blk], i2 = V.blk_i2[blk];
-  double acc[36];
+  const int hf = lane & 1, slot = lane >> 1;
+  double* stage = s_stage[wave];
+  int32_t (*idx)[kSchurStagePairs] = s_idx[wave];
+  double acc[18];
 #pragma unroll
-  for (int i = 0; i < 36; i++) acc[i] = 0;
-  for (int t = V.blk_start[blk] + lane; t < V.blk_start[blk + 1]; t += 64) {
-    const int k1 = V.pair_k1[t], k2 = V.pair_k2[t];
-    const double* W1 = V.e_W + (size_t)k1 * 18;
-    const double* W2 = V.e_W + (size_t)k2 * 18;
-    const double* D = V.Dinv + 9 * (size_t)V.e_point[k1];
-    double WD[18];
+  for (int i = 0; i < 18; i++) acc[i] = 0;
+  // Software pipeline over the stages of the block (a wave walks its stages serially, so every dependent global round trip
+  // inside a stage is paid n_stages times: measured 2.1 us per stage, 12 stages for the largest blocks): the (edge, edge, point)
+  // indices are fetched two stages ahead, the rows one stage ahead into registers; a stage then costs max(compute, one load
+  // latency) instead of three latencies plus the compute.
+  constexpr int kIt = (kSchurStagePairs * 9 + 63) / 64;
+  const int t_beg = V.blk_start[blk], t_end = V.blk_start[blk + 1];
+  const int nst = (t_end - t_beg + kSchurStagePairs - 1) / kSchurStagePairs;
+  auto load_idx = [&](int st, int& k1, int& k2, int& pt) {
+    const int t = t_beg + st * kSchurStagePairs + lane;
+    k1 = k2 = pt = 0;
+    if (st < nst && lane < kSchurStagePairs && t < t_end) { k1 = V.pair_k1[t]; k2 = V.pair_k2[t]; pt = V.pair_pt[t]; }
+  };
+  double2 rw1[kIt], rw2[kIt];
+  double rd[kIt];
+  auto load_rows = [&](int st) {     // reads the indices of stage `st` from LDS
+    const int np = min(kSchurStagePairs, t_end - (t_beg + st * kSchurStagePairs));
 #pragma unroll
-    for (int a = 0; a < 6; a++)
+    for (int i = 0; i < kIt; i++) {
+      const int c = i * 64 + lane;
+      const int pr = (c * 57) >> 9, part = c - 9 * pr;     // c / 9 for c < 512
+      if (pr < np) {
+        rw1[i] = *reinterpret_cast<const double2*>(V.e_W + (size_t)idx[0][pr] * 18 + 2 * part);
+        rw2[i] = *reinterpret_cast<const double2*>(V.e_W + (size_t)idx[1][pr] * 18 + 2 * part);
+        rd[i] = V.Dinv[9 * (size_t)idx[2][pr] + part];
+      }
+    }
+  };
+  int a1, a2, a3, b1, b2, b3;
+  load_idx(0, a1, a2, a3);
+  load_idx(1, b1, b2, b3);
+  if (lane < kSchurStagePairs) { idx[0][lane] = a1; idx[1][lane] = a2; idx[2][lane] = a3; }
+  __builtin_amdgcn_wave_barrier();
+  load_rows(0);
+  for (int st = 0; st < nst; st++) {
+    const int np = min(kSchurStagePairs, t_end - (t_beg + st * kSchurStagePairs));
+    __builtin_amdgcn_wave_barrier();                       // stage st - 1 has been consumed (DS operations of a wave execute in order)
 #pragma unroll
-      for (int b = 0; b < 3; b++) WD[3 * a + b] = W1[3 * a] * D[b] + W1[3 * a + 1] * D[3 + b] + W1[3 * a + 2] * D[6 + b];
+    for (int i = 0; i < kIt; i++) {
+      const int c = i * 64 + lane;
+      const int pr = (c * 57) >> 9, part = c - 9 * pr;
+      if (pr < np) {
+        double* row = stage + pr * kSchurRow;
+        row[2 * part] = rw1[i].x; row[2 * part + 1] = rw1[i].y;
+        row[18 + 2 * part] = rw2[i].x; row[18 + 2 * part + 1] = rw2[i].y;
+        row[36 + part] = rd[i];
+      }
+    }
+    if (st + 1 < nst) {
+      if (lane < kSchurStagePairs) { idx[0][lane] = b1; idx[1][lane] = b2; idx[2][lane] = b3; }
+      __builtin_amdgcn_wave_barrier();
+      load_rows(st + 1);                                   // in flight while stage st is computed
+      load_idx(st + 2, b1, b2, b3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (slot < np) {
+      const double* row = stage + slot * kSchurRow;
+      const double* W1 = row + 9 * hf;                     // rows 3 hf .. 3 hf + 2 of W1 (6 x 3, row-major)
+      const double* W2 = row + 18;
+      const double* D = row + 36;
+      double WD[9];
 #pragma unroll
-    for (int a = 0; a < 6; a++)
+      for (int a = 0; a < 3; a++)
 #pragma unroll
-      for (int b = 0; b < 6; b++) acc[6 * a + b] += WD[3 * a] * W2[3 * b] + WD[3 * a + 1] * W2[3 * b + 1] + WD[3 * a + 2] * W2[3 * b + 2];
+        for (int b = 0; b < 3; b++) WD[3 * a + b] = W1[3 * a] * D[b] + W1[3 * a + 1] * D[3 + b] + W1[3 * a + 2] * D[6 + b];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) acc[6 * a + b] += WD[3 * a] * W2[3 * b] + WD[3 * a + 1] * W2[3 * b + 1] + WD[3 * a + 2] * W2[3 * b + 2];
+    }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
+  for (int off = 32; off > 1; off >>= 1)
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], off);
-  if (lane < 36) {
-    const int a = lane / 6, b = lane % 6;
-    double v = 0;
+    for (int i = 0; i < 18; i++) acc[i] += __shfl_xor(acc[i], off);
+  if (lane < 2) {
 #pragma unroll
-    for (int i = 0; i < 36; i++) if (i == lane) v = acc[i];
-    v = -v;
-    if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + lane] + (a == b ? lambda * V.damp_s : 0.0);
-    V.S[(size_t)(ba_row(i1) + a) * V.ldS + ba_row(i2) + b] = v;
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        const int ra = 3 * hf + a;
+        double v = -acc[6 * a + b];
+        if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + 6 * ra + b] + (ra == b ? lambda * V.damp_s : 0.0);
+        V.S[(size_t)(ba_row(i1) + ra) * V.ldS + ba_row(i2) + b] = v;
+      }
   }
 }
 
@@ -391,9 +460,16 @@ __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
 
 // The reduced system and its right-hand side in ONE launch (independent of each other; both only need Dinv / db of the
 // prologue): workgroups [0, nb_blk) build the 6x6 blocks, the rest the rhs row.
-__global__ void __launch_bounds__(256) k_schur(BaView V, int nb_blk) {
-  if ((int)blockIdx.x < nb_blk) schur_blocks_body(V, blockIdx.x);
-  else schur_rhs_body(V, blockIdx.x - nb_blk);
+__global__ void __launch_bounds__(256) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs) {
+  // The rhs workgroups come FIRST: a camera's rhs is one wave walking ~320 edges (17 us on its own); dispatched behind a
+  // thousand block workgroups it would start late and set the kernel's tail.
+  if ((int)blockIdx.x < nb_rhs) { schur_rhs_body(V, blockIdx.x); return; }
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MB L2.  Workgroup b takes block
+  // group (b % 8) * nb_chunk + b / 8, so an XCD works through a CONTIGUOUS run of the (camera-sorted) block list: the W rows
+  // of its ~60 cameras (46 KB each) stay in that L2.
+  const int b = (int)blockIdx.x - nb_rhs;
+  const int g = (b & 7) * nb_chunk + (b >> 3);
+  if (g < nb_blk) schur_blocks_body(V, g);
 }
 
 // clears the structurally non-zero tiles of S (a trial rebuilds them); everything else is never touched and stays zero
@@ -1754,8 +1830,9 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_dinv = cdiv(V.L, 256);
   hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_dinv, d_fail);
   if (V.nfree == 0) return;
-  const int nb_blk = cdiv(V.nblk, 4);
-  hipLaunchKernelGGL(k_schur, dim3(nb_blk + cdiv(V.nfree, 4)), dim3(256), 0, s, V, nb_blk);
+  const int nb_blk = cdiv(V.nblk, 4), nb_chunk = cdiv(nb_blk, 8);
+  const int nb_rhs = (cdiv(V.nfree, 4) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
+  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(256), 0, s, V, nb_blk, nb_chunk, nb_rhs);
 }
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;

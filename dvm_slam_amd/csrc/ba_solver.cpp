@@ -252,6 +252,11 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.ps_start, ps_start)); ok(h->upload(&V.ps_edges, ps_edges));
   ok(h->upload(&V.blk_i1, blk_i1)); ok(h->upload(&V.blk_i2, blk_i2)); ok(h->upload(&V.blk_start, blk_start));
   ok(h->upload(&V.pair_k1, pair_k1)); ok(h->upload(&V.pair_k2, pair_k2));
+  {
+    std::vector<int32_t> pair_pt(pair_k1.size());
+    for (size_t t = 0; t < pair_k1.size(); t++) pair_pt[t] = e_point[pair_k1[t]];
+    ok(h->upload(&V.pair_pt, pair_pt));
+  }
   ok(h->dalloc(&V.e_chi2, (size_t)E)); ok(h->dalloc(&V.e_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&V.e_W, (size_t)E * 18));
   ok(h->dalloc(&V.Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&V.bp, (size_t)n));
   ok(h->dalloc(&V.Hll, 9 * (size_t)L)); ok(h->dalloc(&V.bl, 3 * (size_t)L));

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from dvm_slam_amd import capi            # noqa: E402
+from dvm_slam_amd import capi, synth     # noqa: E402
 from oracle import pyoracle as po        # noqa: E402
 from matcher_scene import make_init_scene, make_kf_pair_scene   # noqa: E402
 
