@@ -338,8 +338,7 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
   __shared__ int32_t s_idx[4][3][kSchurStagePairs];
   const double lambda = ba_lambda(V);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int blk = block * 4 + wave;
-  if (blk >= V.nblk) return;
+  const int blk = block;                                   // one block per WORKGROUP: its stages are dealt over the four waves
   const int i1 = V.blk_i1[blk], i2 = V.blk_i2[blk];
   const int hf = lane & 1, slot = lane >> 1;
   double* stage = s_stage[wave];
@@ -375,12 +374,12 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
     }
   };
   int a1, a2, a3, b1, b2, b3;
-  load_idx(0, a1, a2, a3);
-  load_idx(1, b1, b2, b3);
+  load_idx(wave, a1, a2, a3);
+  load_idx(wave + 4, b1, b2, b3);
   if (lane < kSchurStagePairs) { idx[0][lane] = a1; idx[1][lane] = a2; idx[2][lane] = a3; }
   __builtin_amdgcn_wave_barrier();
-  load_rows(0);
-  for (int st = 0; st < nst; st++) {
+  if (wave < nst) load_rows(wave);
+  for (int st = wave; st < nst; st += 4) {
     const int np = min(kSchurStagePairs, t_end - (t_beg + st * kSchurStagePairs));
     __builtin_amdgcn_wave_barrier();                       // stage st - 1 has been consumed (DS operations of a wave execute in order)
 #pragma unroll
@@ -394,11 +393,11 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
         row[36 + part] = rd[i];
       }
     }
-    if (st + 1 < nst) {
+    if (st + 4 < nst) {
       if (lane < kSchurStagePairs) { idx[0][lane] = b1; idx[1][lane] = b2; idx[2][lane] = b3; }
       __builtin_amdgcn_wave_barrier();
-      load_rows(st + 1);                                   // in flight while stage st is computed
-      load_idx(st + 2, b1, b2, b3);
+      load_rows(st + 4);                                   // in flight while stage st is computed
+      load_idx(st + 8, b1, b2, b3);
     }
     __builtin_amdgcn_wave_barrier();
     if (slot < np) {
@@ -417,20 +416,29 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
         for (int b = 0; b < 6; b++) acc[6 * a + b] += WD[3 * a] * W2[3 * b] + WD[3 * a + 1] * W2[3 * b + 1] + WD[3 * a + 2] * W2[3 * b + 2];
     }
   }
+  // Sum over the 32 pair slots THROUGH LDS: every lane parks its 18 partial sums in the (now idle) stage buffer, then lane
+  // (hf, a, b) adds the 32 slots of its output in slot order.  ds_bpermute_b32 -- what __shfl_xor compiles to -- occupies the
+  // CU's LDS unit for 24 cycles per instruction (tools/valu_issue2.hip): the 180 of them a double-precision butterfly over
+  // 18 values needs were ~30 us of this kernel; 18 ds_write_b64 + 32 ds_read_b64 are ~200 cycles.
+  __builtin_amdgcn_wave_barrier();
+  {
+    double* red = stage + (size_t)lane * 19;                // 19-double pitch: odd dword-pair stride, conflict-free both ways
 #pragma unroll
-  for (int off = 32; off > 1; off >>= 1)
-#pragma unroll
-    for (int i = 0; i < 18; i++) acc[i] += __shfl_xor(acc[i], off);
-  if (lane < 2) {
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 6; b++) {
-        const int ra = 3 * hf + a;
-        double v = -acc[6 * a + b];
-        if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + 6 * ra + b] + (ra == b ? lambda * V.damp_s : 0.0);
-        V.S[(size_t)(ba_row(i1) + ra) * V.ldS + ba_row(i2) + b] = v;
-      }
+    for (int i = 0; i < 18; i++) red[i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int ohf = lane / 18, oi = lane - 18 * ohf;        // output (row 3 ohf + oi / 6, column oi % 6)
+    double v = 0;
+    for (int w = 0; w < 4; w++) {                           // waves in order, slots in order: a fixed summation order
+      const double* st_w = s_stage[w];
+#pragma unroll 8
+      for (int sl = 0; sl < 32; sl++) v += st_w[(size_t)(2 * sl + ohf) * 19 + oi];
+    }
+    const int ra = 3 * ohf + oi / 6, cb = oi % 6;
+    v = -v;
+    if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + 6 * ra + cb] + (ra == cb ? lambda * V.damp_s : 0.0);
+    V.S[(size_t)(ba_row(i1) + ra) * V.ldS + ba_row(i2) + cb] = v;
   }
 }
 
@@ -1830,7 +1838,7 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_dinv = cdiv(V.L, 256);
   hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_dinv, d_fail);
   if (V.nfree == 0) return;
-  const int nb_blk = cdiv(V.nblk, 4), nb_chunk = cdiv(nb_blk, 8);
+  const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
   const int nb_rhs = (cdiv(V.nfree, 4) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
   hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(256), 0, s, V, nb_blk, nb_chunk, nb_rhs);
 }
