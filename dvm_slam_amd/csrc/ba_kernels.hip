@@ -157,6 +157,48 @@ __device__ __forceinline__ void block_reduce_publish(double v, double* __restric
   }
 }
 
+// Sums of N per-thread doubles over a 256-thread workgroup, THROUGH LDS: every thread parks its values (pitch N + 1), thread
+// (q, i) adds the 64 threads of wave q for value i in thread order, then the four wave sums are added -- a fixed order.  The
+// alternative, xor-butterflies of __shfl_xor, is ds_bpermute_b32 twice per double and step: 24 cycles of the CU's LDS unit
+// each (tools/valu_issue2.hip), 336 of them for 28 values -- 13 us per reduction with four waves sharing the unit.
+// park: 256 * (N + 1) doubles, part: 4 * N doubles, out: N doubles (all in LDS; out is valid for every thread on return).
+template <int N>
+__device__ __forceinline__ void block_sum_lds(const double* v, double* park, double* part, double* out) {
+  const int tid = threadIdx.x;
+  double* mine = park + (size_t)tid * (N + 1);
+#pragma unroll
+  for (int i = 0; i < N; i++) mine[i] = v[i];
+  __syncthreads();
+  if (tid < 4 * N) {
+    const int q = tid / N, i = tid - q * N;
+    const double* col = park + (size_t)(64 * q) * (N + 1) + i;
+    double s = 0;
+#pragma unroll 16
+    for (int l = 0; l < 64; l++) s += col[(size_t)l * (N + 1)];
+    part[q * N + i] = s;
+  }
+  __syncthreads();
+  if (tid < N) out[tid] = (part[tid] + part[N + tid]) + (part[2 * N + tid] + part[3 * N + tid]);
+  __syncthreads();
+}
+// the same for one wave (64 lanes), no workgroup barrier: lane i < N returns the sum of value i over the lanes, in lane order
+template <int N>
+__device__ __forceinline__ double wave_sum_lds(const double* v, double* park /* 64 * (N + 1) doubles of this wave */) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  double* mine = park + (size_t)lane * (N + 1);
+#pragma unroll
+  for (int i = 0; i < N; i++) mine[i] = v[i];
+  __builtin_amdgcn_wave_barrier();
+  double s = 0;
+  if (lane < N) {
+#pragma unroll 16
+    for (int l = 0; l < 64; l++) s += park[(size_t)l * (N + 1) + lane];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------ K8
 // JAC=false: residual / chi2 only (computeActiveErrors + activeRobustChi2 terms).
 // JAC=true : additionally Jacobians A (2x3, point), B (2x6, pose), weights and Hpl block W (6x3).
@@ -270,19 +312,22 @@ __device__ __forceinline__ void pose_accum_body(const BaView& V, int block) {
       for (int c = 0; c <= a; c++) H[t++] += w * (B[a] * B[c] + B[6 + a] * B[6 + c]);
     }
   }
+  // lane t < 21 ends with H[t], lanes 21..26 with b (sum over the lanes through LDS, lane order: see wave_sum_lds)
+  __shared__ double s_park[4][64 * 28];
+  double v27[27];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int i = 0; i < 21; i++) v27[i] = H[i];
 #pragma unroll
-    for (int i = 0; i < 21; i++) H[i] += __shfl_xor(H[i], off);
-#pragma unroll
-    for (int i = 0; i < 6; i++) b[i] += __shfl_xor(b[i], off);
-  }
-  if (lane == 0) {
+  for (int i = 0; i < 6; i++) v27[21 + i] = b[i];
+  const double tot = wave_sum_lds<27>(v27, s_park[threadIdx.x >> 6]);
+  if (lane < 21) {
+    const int a = lane >= 15 ? 5 : lane >= 10 ? 4 : lane >= 6 ? 3 : lane >= 3 ? 2 : lane >= 1 ? 1 : 0;
+    const int c = lane - a * (a + 1) / 2;
     double* out = V.Hpp + 36 * (size_t)fi;
-    int t = 0;
-    for (int a = 0; a < 6; a++)
-      for (int c = 0; c <= a; c++) { out[6 * a + c] = H[t]; out[6 * c + a] = H[t]; t++; }
-    for (int a = 0; a < 6; a++) V.bp[6 * (size_t)fi + a] = b[a];
+    out[6 * a + c] = tot;
+    out[6 * c + a] = tot;
+  } else if (lane < 27) {
+    V.bp[6 * (size_t)fi + (lane - 21)] = tot;
   }
 }
 
@@ -975,18 +1020,9 @@ __global__ void __launch_bounds__(256) k_edge_depth(BaView V, uint8_t* __restric
 // round (chi2 > 5.991 as float), Huber removed after round 2.  ONE workgroup runs the whole thing for
 // one frame -- about 40 LM iterations with no host round trip; frames are batched over the grid.
 struct PoseAccum { double v[28]; };  // 21 upper-H + 6 b + 1 chi
-__device__ __forceinline__ void pose_block_reduce(PoseAccum& a, double (*s_red)[28], double* out28) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int i = 0; i < 28; i++) a.v[i] += __shfl_xor(a.v[i], off);
-  if (lane == 0)
-#pragma unroll
-    for (int i = 0; i < 28; i++) s_red[wave][i] = a.v[i];
-  __syncthreads();
-  if (threadIdx.x < 28) out28[threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
-  __syncthreads();
+__device__ __forceinline__ void pose_block_reduce(PoseAccum& a, double* park, double* part, double* out28) {
+  block_sum_lds<14>(a.v, park, part, out28);            // two halves keep the parking area at 30 KB
+  block_sum_lds<14>(a.v + 14, park, part, out28 + 14);
 }
 
 __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict__ pose_in, const double* __restrict__ Xw,
@@ -995,7 +1031,8 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
                                                        double fy, double cx, double cy, double* __restrict__ pose_out,
                                                        uint8_t* __restrict__ outlier, int32_t* __restrict__ n_inliers,
                                                        double* __restrict__ chi_scratch) {
-  __shared__ double s_red[4][28];
+  __shared__ double s_park[256 * 15];
+  __shared__ double s_part[4 * 14];
   __shared__ double s_sum[28];
   __shared__ double s_T[7], s_Tbak[7], s_T0[7];
   __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
@@ -1060,7 +1097,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
         }
       }
     }
-    pose_block_reduce(a, s_red, s_sum);
+    pose_block_reduce(a, s_park, s_part, s_sum);
   };
 
   bool robust_on = true;
@@ -1276,14 +1313,15 @@ __global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12i
                                                        const double* __restrict__ w2, int N, const double* __restrict__ Kio,
                                                        double th2, uint8_t* __restrict__ inlier, int32_t* __restrict__ nin_out,
                                                        double* __restrict__ chi_scratch, uint8_t* __restrict__ flag_scratch) {
-  __shared__ double s_red[4][36];
+  __shared__ double s_park[256 * 19];
+  __shared__ double s_part[4 * 18];
   __shared__ double s_sum[36];
   __shared__ Sim3d s_S, s_bak;
   __shared__ Sim3M s_M[30];   // [0] S, [1] S^-1, [2+2d] S+d, [3+2d] (S+d)^-1, [16+2d] S-d, [17+2d] (S-d)^-1
   __shared__ double s_K[8];
   __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
   __shared__ int s_ctl, s_qmax, s_nbad, s_cnt;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   double* chi12 = chi_scratch;
   double* chi21 = chi_scratch + N;
   uint8_t* alive = flag_scratch;
@@ -1362,16 +1400,8 @@ __global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12i
         }
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int i = 0; i < 36; i++) acc[i] += __shfl_xor(acc[i], off);
-    if (lane == 0)
-#pragma unroll
-      for (int i = 0; i < 36; i++) s_red[wave][i] = acc[i];
-    __syncthreads();
-    if (tid < 36) s_sum[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-    __syncthreads();
+    block_sum_lds<18>(acc, s_park, s_part, s_sum);
+    block_sum_lds<18>(acc + 18, s_park, s_part, s_sum + 18);
   };
   auto optimize = [&](int iters) {
     for (int it = 0; it < iters; it++) {
