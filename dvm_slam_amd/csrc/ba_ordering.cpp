@@ -200,6 +200,10 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
       for (size_t a = 0; a < col[k].size(); a++)
         for (size_t b = 0; b <= a; b++) {
           const int ti = col[k][a], tj = col[k][b];
+          // the corner tile (rhs, rhs) holds one scalar, the last pivot, which nothing reads (the solve takes y = L^-1 b from
+          // the rhs ROW and never factors the root): EVERY column contributes to it, so updating it put an 18-long serial
+          // chain of products on the leaf level's critical path (22 us of a level that otherwise needs ~8)
+          if (ti == nt - 1 && tj == nt - 1) continue;
           if (upd[ti].empty()) upd[ti].resize(nt);
           if (upd[ti][tj].empty()) touched.push_back({ti, tj});
           upd[ti][tj].push_back(k);

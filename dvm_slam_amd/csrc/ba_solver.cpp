@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -273,6 +274,14 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
+  if (std::getenv("DVM_BA_DEBUG_SCHEDULE")) {
+    for (size_t l = 0; l + 1 < SC.tgt_off.size(); l++) {
+      int mx = 0; long sum = 0;
+      for (int t = SC.tgt_off[l]; t < SC.tgt_off[l + 1]; t++) { const int n = SC.targets[4 * t + 3] - SC.targets[4 * t + 2]; mx = std::max(mx, n); sum += n; }
+      std::fprintf(stderr, "level %zu: cols %d strips %d targets %d contributors sum %ld max %d\n", l, SC.level_off[l + 1] - SC.level_off[l],
+                   SC.strip_off[l + 1] - SC.strip_off[l], SC.tgt_off[l + 1] - SC.tgt_off[l], sum, mx);
+    }
+  }
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   // poses: normalise quaternions like SE3Quat's constructor (se3quat.h:261-266)
   std::vector<double> pn(poses, poses + 7 * (size_t)P);
