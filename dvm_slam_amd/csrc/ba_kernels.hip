@@ -913,13 +913,29 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   const int k0 = kb * NB;
   if (k0 >= n_pad) return;                       // the rhs tile itself (never in the list; defensive)
   if (tid < NB) yk[tid] = y[k0 + tid];
-  for (int s = colstrip_off[kb]; s < colstrip_off[kb + 1]; s++) {
+  // Everything that does not depend on an ancestor's x is fetched BEFORE waiting for it: this column's Linv tile and the
+  // strip tile of the first dependency (then always the next strip's tile while the current one is waited for / applied);
+  // the hop per level shrinks from flag + three dependent tile loads to flag + 64 doubles of x.
+  const double* Lk = Linv_all + (size_t)kb * NB * NB;
+  double lk[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) lk[r] = Lk[(16 * q + r) * NB + c];
+  const int s_beg = colstrip_off[kb], s_end = colstrip_off[kb + 1];
+  double tl[16];
+  auto fetch_tile = [&](int s) {
+    const int i0 = colstrips[s] * NB;
+    if (i0 >= n_pad) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) tl[r] = S[(size_t)(i0 + 16 * q + r) * ldS + k0 + c];
+  };
+  if (s_beg < s_end) fetch_tile(s_beg);
+  for (int s = s_beg; s < s_end; s++) {
     const int it = colstrips[s], i0 = it * NB;
-    if (i0 >= n_pad) continue;                   // the rhs row is not an unknown
+    if (i0 >= n_pad) { if (s + 1 < s_end) fetch_tile(s + 1); continue; }   // the rhs row is not an unknown
     if (tid == 0) {
       int spins = 0;
       while (__hip_atomic_load(flags + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 24)) { *fail = 2; break; }   // never hang the device: give up, the trial is rejected
       }
     }
@@ -928,20 +944,17 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
     __syncthreads();
     double u = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int rr = 16 * q + r;
-      u += S[(size_t)(i0 + rr) * ldS + k0 + c] * xi[rr];
-    }
+    for (int r = 0; r < 16; r++) u += tl[r] * xi[16 * q + r];
+    if (s + 1 < s_end) fetch_tile(s + 1);
     part[q][c] = u;
     __syncthreads();
     if (tid < NB) yk[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
   }
   __syncthreads();
-  const double* Lk = Linv_all + (size_t)kb * NB * NB;
   // (Linv^T y)[c] = sum_r Linv[r][c] y[r]  (Linv is zero above the diagonal); 4 row-quarters per column
   double s = 0;
 #pragma unroll
-  for (int r = 0; r < 16; r++) s += Lk[(16 * q + r) * NB + c] * yk[16 * q + r];
+  for (int r = 0; r < 16; r++) s += lk[r] * yk[16 * q + r];
   part[q][c] = s;
   __syncthreads();
   if (tid < NB) {   // one wave
