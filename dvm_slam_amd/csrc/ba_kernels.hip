@@ -689,9 +689,10 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       for (int c = 0; c < 16; c++) a[c] = (lane < nrows && (lane >= 16 || c <= lane)) ? Bm[(o + lane) * LP + o + c] : 0.0;
       bool bad = false;
       double lprev = 0.0;
+      double d_next = bcast_lane(a[0], 0);
 #pragma unroll
       for (int j = 0; j < 16; j++) {
-        const double d = bcast_lane(a[j], j);
+        const double d = d_next;                 // pivot a_jj, wave-uniform (see below)
         if (!(d > 0.0)) bad = true;
         const double dd = d > 0.0 ? d : 1.0;
         double y = __builtin_amdgcn_rsq(dd);     // 1 / L_jj: v_rsq_f64 + two Newton steps instead of sqrt and divisions
@@ -701,9 +702,18 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
         }
         y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
         y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+        // the NEXT pivot in wave-uniform form: its pre-update value is broadcast off the critical path (it only waits for the
+        // deferred update above), so the chain holds ONE cross-lane broadcast per column (l_{j+1,j}) instead of two -- the
+        // VGPR -> SGPR -> VGPR round trip costs 28 cycles (tools/valu_issue2.hip).  Same operands, same bits as updating
+        // a[j + 1] on lane j + 1 and broadcasting the result.
+        const double anext = (j + 1 < 16) ? bcast_lane(a[j + 1], j + 1) : 0.0;
         const double lj = lane > j ? a[j] * y : 0.0;
         Pcol[j][lane] = lj;
-        if (j + 1 < 16) a[j + 1] = __builtin_fma(-lj, bcast_lane(lj, j + 1), a[j + 1]);
+        if (j + 1 < 16) {
+          const double ln = bcast_lane(lj, j + 1);
+          a[j + 1] = __builtin_fma(-lj, ln, a[j + 1]);
+          d_next = __builtin_fma(-ln, ln, anext);
+        }
         double sq = dd * y;
         sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);   // sqrt(dd) to the last bit or one ulp
         if (lane == 0) s_rinv[b][j] = y;

@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find last k_edge_eval<true> and print the timeline of the following trial
 idx = [i for i, r in enumerate(rows) if "k_edge_eval<true>" in r["Kernel_Name"]]
-s = idx[-3]; e = idx[-2]
+s = idx[-4]; e = idx[-3]
 t0 = int(rows[s]["Start_Timestamp"])
 prev_end = t0
 for r in rows[s:e]:
