@@ -383,9 +383,10 @@ __global__ void __launch_bounds__(256) k_dinv(BaView V) { dinv_landmark(V, block
 // then computes from LDS, two lanes per pair (lane half hf owns rows 3 hf .. 3 hf + 2 of the 6x6 product).  Summation order:
 // pair slots p, p + 32, ... per lane, then the xor-butterfly over the 32 slots -- fixed, identical on every run.
 constexpr int kSchurStagePairs = 32, kSchurRow = 45;   // doubles per staged pair: W1 (18) | W2 (18) | Dinv (9); odd dword-pair stride: conflict-free
+template <int NW>   // waves of the workgroup = waves sharing one block
 __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
-  __shared__ double s_stage[4][kSchurStagePairs * kSchurRow];
-  __shared__ int32_t s_idx[4][3][kSchurStagePairs];
+  __shared__ double s_stage[NW][kSchurStagePairs * kSchurRow];
+  __shared__ int32_t s_idx[NW][3][kSchurStagePairs];
   const double lambda = ba_lambda(V);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = block;                                   // one block per WORKGROUP: its stages are dealt over the four waves
@@ -425,11 +426,11 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
   };
   int a1, a2, a3, b1, b2, b3;
   load_idx(wave, a1, a2, a3);
-  load_idx(wave + 4, b1, b2, b3);
+  load_idx(wave + NW, b1, b2, b3);
   if (lane < kSchurStagePairs) { idx[0][lane] = a1; idx[1][lane] = a2; idx[2][lane] = a3; }
   __builtin_amdgcn_wave_barrier();
   if (wave < nst) load_rows(wave);
-  for (int st = wave; st < nst; st += 4) {
+  for (int st = wave; st < nst; st += NW) {
     const int np = min(kSchurStagePairs, t_end - (t_beg + st * kSchurStagePairs));
     __builtin_amdgcn_wave_barrier();                       // stage st - 1 has been consumed (DS operations of a wave execute in order)
 #pragma unroll
@@ -443,11 +444,11 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
         row[36 + part] = rd[i];
       }
     }
-    if (st + 4 < nst) {
+    if (st + NW < nst) {
       if (lane < kSchurStagePairs) { idx[0][lane] = b1; idx[1][lane] = b2; idx[2][lane] = b3; }
       __builtin_amdgcn_wave_barrier();
-      load_rows(st + 4);                                   // in flight while stage st is computed
-      load_idx(st + 8, b1, b2, b3);
+      load_rows(st + NW);                                  // in flight while stage st is computed
+      load_idx(st + 2 * NW, b1, b2, b3);
     }
     __builtin_amdgcn_wave_barrier();
     if (slot < np) {
@@ -476,11 +477,11 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
 #pragma unroll
     for (int i = 0; i < 18; i++) red[i] = acc[i];
   }
-  __syncthreads();
+  if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   if (threadIdx.x < 36) {
     const int ohf = lane / 18, oi = lane - 18 * ohf;        // output (row 3 ohf + oi / 6, column oi % 6)
     double v = 0;
-    for (int w = 0; w < 4; w++) {                           // waves in order, slots in order: a fixed summation order
+    for (int w = 0; w < NW; w++) {                          // waves in order, slots in order: a fixed summation order
       const double* st_w = s_stage[w];
 #pragma unroll 8
       for (int sl = 0; sl < 32; sl++) v += st_w[(size_t)(2 * sl + ohf) * 19 + oi];
@@ -493,9 +494,10 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
 }
 
 // bschur[i] = bp[i] - sum_{edges k of camera i} W_k (Dinv bl)_{point(k)}  -> augmented row n of S.
+template <int NW>
 __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
   const int lane = threadIdx.x & 63;
-  const int fi = block * 4 + (threadIdx.x >> 6);
+  const int fi = block * NW + (threadIdx.x >> 6);
   if (fi >= V.nfree) return;
   const int p = V.free_pose[fi];
   double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -518,16 +520,17 @@ __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
 
 // The reduced system and its right-hand side in ONE launch (independent of each other; both only need Dinv / db of the
 // prologue): workgroups [0, nb_blk) build the 6x6 blocks, the rest the rhs row.
-__global__ void __launch_bounds__(256) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs) {
-  // The rhs workgroups come FIRST: a camera's rhs is one wave walking ~320 edges (17 us on its own); dispatched behind a
-  // thousand block workgroups it would start late and set the kernel's tail.
-  if ((int)blockIdx.x < nb_rhs) { schur_rhs_body(V, blockIdx.x); return; }
+constexpr int kSchurWaves = 2;   // one wave per workgroup: 12 KB of LDS each, every block resident at once, no lock-step between blocks
+__global__ void __launch_bounds__(64 * kSchurWaves) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs) {
+  // The rhs workgroups come FIRST: a camera's rhs is one wave walking ~320 edges (17 us on its own); dispatched behind
+  // thousands of block workgroups it would start late and set the kernel's tail.
+  if ((int)blockIdx.x < nb_rhs) { schur_rhs_body<kSchurWaves>(V, blockIdx.x); return; }
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MB L2.  Workgroup b takes block
   // group (b % 8) * nb_chunk + b / 8, so an XCD works through a CONTIGUOUS run of the (camera-sorted) block list: the W rows
   // of its ~60 cameras (46 KB each) stay in that L2.
   const int b = (int)blockIdx.x - nb_rhs;
   const int g = (b & 7) * nb_chunk + (b >> 3);
-  if (g < nb_blk) schur_blocks_body(V, g);
+  if (g < nb_blk) schur_blocks_body<kSchurWaves>(V, g);
 }
 
 // clears the structurally non-zero tiles of S (a trial rebuilds them); everything else is never touched and stays zero
@@ -1928,8 +1931,8 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_dinv, d_fail);
   if (V.nfree == 0) return;
   const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
-  const int nb_rhs = (cdiv(V.nfree, 4) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
-  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(256), 0, s, V, nb_blk, nb_chunk, nb_rhs);
+  const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
+  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs);
 }
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
