@@ -118,6 +118,7 @@ def run_sharded(device: int, iters: int = 10, repeats: int = 5):
     import torch
     import torch.distributed as dist
     from dvm_slam_amd import capi, sharded_ba, synth
+    torch.cuda.set_device(device)   # the current device is per THREAD: bench.py calls this from a watchdog thread
     pr = synth.ba_problem()
     e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
     delta = float(np.sqrt(5.991))
@@ -135,7 +136,7 @@ def run_sharded(device: int, iters: int = 10, repeats: int = 5):
         torch.cuda.synchronize()
         dt += time.perf_counter() - t0
         its += st["iterations"]; trials += st["total_trials"]
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if sb.on_gpu else "cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}" if sb.on_gpu else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     rec = {"metric": "BA iterations/sec, 500 KF / 20k landmarks, landmark-sharded over the ranks (config 5)", "value": its / dt,

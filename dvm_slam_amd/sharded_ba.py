@@ -54,7 +54,7 @@ class ShardedBundleAdjuster:
             assert buf == self.buf.data_ptr()
             t = self.buf[:n]
             if self.on_gpu:   # RCCL, ordered on the solver's stream: after its queued kernels, before the ones queued next
-                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                with torch.cuda.device(self.device), torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
                     dist.all_reduce(t, op=rop)
             else:             # gloo (tests: several ranks sharing one GPU): through the host
                 torch.cuda.synchronize()
