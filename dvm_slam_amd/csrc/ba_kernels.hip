@@ -473,9 +473,12 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
   // 18 values needs were ~30 us of this kernel; 18 ds_write_b64 + 32 ds_read_b64 are ~200 cycles.
   __builtin_amdgcn_wave_barrier();
   {
+    static_assert(2 * kSchurStagePairs * 19 <= kSchurStagePairs * kSchurRow, "the parking area reuses the stage buffer");
     double* red = stage + (size_t)lane * 19;                // 19-double pitch: odd dword-pair stride, conflict-free both ways
+    if (lane < 2 * kSchurStagePairs) {
 #pragma unroll
-    for (int i = 0; i < 18; i++) red[i] = acc[i];
+      for (int i = 0; i < 18; i++) red[i] = acc[i];
+    }
   }
   if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   if (threadIdx.x < 36) {
@@ -484,7 +487,7 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
     for (int w = 0; w < NW; w++) {                          // waves in order, slots in order: a fixed summation order
       const double* st_w = s_stage[w];
 #pragma unroll 8
-      for (int sl = 0; sl < 32; sl++) v += st_w[(size_t)(2 * sl + ohf) * 19 + oi];
+      for (int sl = 0; sl < kSchurStagePairs; sl++) v += st_w[(size_t)(2 * sl + ohf) * 19 + oi];
     }
     const int ra = 3 * ohf + oi / 6, cb = oi % 6;
     v = -v;
