@@ -56,6 +56,15 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
         its += st["iterations"]; trials += st["total_trials"]
     poses_g, points_g = ba.result()
     info = ba.schedule_info()
+    # also the GBA form, bRobust = false (LoopClosing.cc:2282) -- same problem, no Huber kernel
+    dt0, its0, tr0 = 0.0, 0, 0
+    for _ in range(max(1, repeats // 4)):
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], 0.0)
+        t0 = time.perf_counter()
+        st0 = ba.optimize(iters)
+        dt0 += time.perf_counter() - t0
+        its0 += st0["iterations"]; tr0 += st0["total_trials"]
+    huber_off = {"value": its0 / dt0, "unit": "iterations/s", "iterations": its0, "trials": tr0, "chi2_final": st0["chi2_final"]}
     # second pass with HIP events around the phases of every trial (not part of `value`)
     ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
     ba.profile(1)
@@ -81,7 +90,7 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
         "value": its / dt, "unit": "iterations/s", "iterations": its, "trials": trials, "runs": max(1, repeats),
         "ms_per_iteration": dt / max(its, 1) * 1e3,
         "ms_graph_build_excluded": st["ms_structure"], "chi2_initial": st["chi2_initial"], "chi2_final": st["chi2_final"],
-        "dtype": "f64", "huber_delta": delta,
+        "dtype": "f64", "huber_delta": delta, "huber_off": huber_off,
         "gpu_state": "hot (timed right after GPU work; the LM loop polls mapped host memory instead of synchronising the stream)",
         "roofline": {"bound": "mfma", "kernel": "k_chol_diag / k_chol_trsm / k_chol_update (+ k_chol_backsolve): tile Cholesky of the reduced "
                                                "camera system on v_mfma_f64_16x16x4",
@@ -145,6 +154,29 @@ def run_sharded(device: int, iters: int = 10, repeats: int = 5):
            "backend": "nccl (RCCL)" if sb.on_gpu else "gloo (through the host: test configuration)"}
     sb.close()
     return rec
+
+
+def run_replica(device: int, iters: int = 10, repeats: int = 5):
+    """SURVEY 8(e) "replicas": every rank solves its own copy of the 500-keyframe problem at the same time; returns this rank's
+    iterations/s (bench.py adds them up)."""
+    import torch
+    from dvm_slam_amd import capi, synth
+    torch.cuda.set_device(device)
+    pr = synth.ba_problem()
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(5.991))
+    ba = capi.BundleAdjuster(device)
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    ba.optimize(2)
+    dt, its = 0.0, 0
+    for _ in range(repeats):
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        t0 = time.perf_counter()
+        st = ba.optimize(iters)
+        dt += time.perf_counter() - t0
+        its += st["iterations"]
+    ba.close()
+    return its / dt
 
 
 def cpu_baseline(pr, delta, budget_s, iters):

@@ -310,6 +310,13 @@ def main():
             try:
                 import ba_bench
                 box["rec"] = ba_bench.run_sharded(local, a.ba_iters)
+                # "replicas": all ranks solve their own copy at once; the sum is what N independent global BAs deliver
+                dist.barrier()
+                mine = ba_bench.run_replica(local, a.ba_iters)
+                t = torch.tensor([mine], dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
+                dist.all_reduce(t)
+                box["rec"]["replicas"] = {"value": float(t.item()), "unit": "iterations/s (sum over ranks)", "ranks": world,
+                                          "this_rank": mine}
             except Exception as ex:   # noqa: BLE001
                 box["rec"] = {"error": repr(ex)}
 

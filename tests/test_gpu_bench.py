@@ -61,3 +61,7 @@ def test_bench_two_ranks_control_flow():
     assert sh["ranks"] == 2 and sh["value"] > 0 and sh["allreduce_bytes_per_run"] > 1e6
     assert abs(sh["chi2_final"] - one["chi2_final"]) <= 1e-9 * one["chi2_final"]
     assert one["roofline"]["frac"] > 0 and one["roofline"]["schedule"]["nz_tiles"] > 100
+    # "replicas" (SURVEY 8e): both ranks solve their own copy at once; the GBA form (no Huber kernel) beside the robust one
+    rep = sh["replicas"]
+    assert rep["ranks"] == 2 and rep["value"] >= rep["this_rank"] > 0
+    assert one["huber_off"]["value"] > 0 and one["huber_off"]["iterations"] > 0
