@@ -1000,68 +1000,70 @@ __device__ __forceinline__ double dpp_xor_add(double v, int ctrl_is) {
   else { lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); }                  // row_half_mirror
   return v + __hiloint2double(hi, lo);
 }
-__global__ void __launch_bounds__(256) k_point_backsub(BaView V) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  const int l = g >> 3, j = g & 7;
-  const bool live = l < V.L;
-  double t[3] = {0, 0, 0};
-  int i0 = 0, i1 = 0;
-  if (live) { i0 = V.pt_start[l]; i1 = V.pt_start[l + 1]; }
-  for (int i = i0 + j; i < i1; i += 8) {
-    const int k = V.pt_edges[i];
-    const int fi = V.pidx[V.e_pose[k]];
-    if (fi < 0) continue;
-    const double* W = V.e_W + (size_t)k * 18;
-    const double* xp = V.x + 6 * (size_t)fi;
-#pragma unroll
-    for (int b = 0; b < 3; b++)
-#pragma unroll
-      for (int a = 0; a < 6; a++) t[b] += W[3 * a + b] * xp[a];
-  }
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    t[b] = dpp_xor_add(t[b], 0);
-    t[b] = dpp_xor_add(t[b], 1);
-    t[b] = dpp_xor_add(t[b], 2);
-  }
-  if (!live || j != 0) return;
-  const int n = 6 * V.nfree;
-  double* xl = V.x + n + 3 * (size_t)l;
-  if (i1 == i0) { xl[0] = xl[1] = xl[2] = 0; return; }
-  const double c[3] = {V.bl[3 * (size_t)l] - t[0], V.bl[3 * (size_t)l + 1] - t[1], V.bl[3 * (size_t)l + 2] - t[2]};
-  const double* D = V.Dinv + 9 * (size_t)l;
-  xl[0] = D[0] * c[0] + D[1] * c[1] + D[2] * c[2];
-  xl[1] = D[3] * c[0] + D[4] * c[1] + D[5] * c[2];
-  xl[2] = D[6] * c[0] + D[7] * c[1] + D[8] * c[2];
-}
-
-// oplus: cameras T <- exp(dx) T (se3quat.h:212-240, types_six_dof_expmap.h:71-74), landmarks X += dx;
-// also the per-thread terms of computeScale = sum x (lambda x + b), reduced like k_edge_eval.
-__global__ void __launch_bounds__(256) k_update(BaView V, BaPublish pub) {
+// Landmark back substitution, oplus of cameras and landmarks into the TRIAL state and the terms of computeScale =
+// sum x (lambda x + b) in ONE launch (oplus: se3quat.h:212-240, types_six_dof_expmap.h:71-74): workgroups [0, nb_pose)
+// update the cameras (thread per camera), the rest the landmarks; every workgroup feeds the grid-wide reduction.
+__global__ void __launch_bounds__(256) k_point_backsub(BaView V, BaPublish pub, int nb_pose) {
   const double lambda = ba_lambda(V);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int n = 6 * V.nfree;
   double sc = 0;
-  if (i < V.nfree) {
-    const int p = V.free_pose[i];
-    const double* u = V.x + 6 * (size_t)i;
-    const double* b = V.bp + 6 * (size_t)i;
+  if ((int)blockIdx.x < nb_pose) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < V.nfree) {
+      const int p = V.free_pose[i];
+      const double* u = V.x + 6 * (size_t)i;
+      const double* b = V.bp + 6 * (size_t)i;
 #pragma unroll
-    for (int a = 0; a < 6; a++) sc += u[a] * (lambda * V.damp_s * u[a] + b[a]);
-    double T[7];
+      for (int a = 0; a < 6; a++) sc += u[a] * (lambda * V.damp_s * u[a] + b[a]);
+      double T[7];
 #pragma unroll
-    for (int a = 0; a < 7; a++) T[a] = V.poses[7 * (size_t)p + a];
-    se3_oplus(T, u);
+      for (int a = 0; a < 7; a++) T[a] = V.poses[7 * (size_t)p + a];
+      se3_oplus(T, u);
 #pragma unroll
-    for (int a = 0; a < 7; a++) V.poses_new[7 * (size_t)p + a] = T[a];
-  }
-  if (i < V.L && V.pt_start[i + 1] > V.pt_start[i]) {
-    const double* u = V.x + n + 3 * (size_t)i;
-    const double* b = V.bl + 3 * (size_t)i;
-    const double* X = V.points + 3 * (size_t)i;
-    double* Xn = V.points_new + 3 * (size_t)i;
+      for (int a = 0; a < 7; a++) V.poses_new[7 * (size_t)p + a] = T[a];
+    }
+  } else {
+    const int g = ((int)blockIdx.x - nb_pose) * 256 + threadIdx.x;
+    const int l = g >> 3, j = g & 7;
+    const bool live = l < V.L;
+    double t[3] = {0, 0, 0};
+    int i0 = 0, i1 = 0;
+    if (live) { i0 = V.pt_start[l]; i1 = V.pt_start[l + 1]; }
+    for (int i = i0 + j; i < i1; i += 8) {
+      const int k = V.pt_edges[i];
+      const int fi = V.pidx[V.e_pose[k]];
+      if (fi < 0) continue;
+      const double* W = V.e_W + (size_t)k * 18;
+      const double* xp = V.x + 6 * (size_t)fi;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { sc += u[a] * (lambda * u[a] + b[a]); Xn[a] = X[a] + u[a]; }
+      for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int a = 0; a < 6; a++) t[b] += W[3 * a + b] * xp[a];
+    }
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      t[b] = dpp_xor_add(t[b], 0);
+      t[b] = dpp_xor_add(t[b], 1);
+      t[b] = dpp_xor_add(t[b], 2);
+    }
+    if (live && j == 0) {
+      const int n = 6 * V.nfree;
+      double* xl = V.x + n + 3 * (size_t)l;
+      if (i1 == i0) {
+        xl[0] = xl[1] = xl[2] = 0;
+      } else {
+        const double* bl = V.bl + 3 * (size_t)l;
+        const double c[3] = {bl[0] - t[0], bl[1] - t[1], bl[2] - t[2]};
+        const double* D = V.Dinv + 9 * (size_t)l;
+        double u[3];
+        u[0] = D[0] * c[0] + D[1] * c[1] + D[2] * c[2];
+        u[1] = D[3] * c[0] + D[4] * c[1] + D[5] * c[2];
+        u[2] = D[6] * c[0] + D[7] * c[1] + D[8] * c[2];
+        const double* X = V.points + 3 * (size_t)l;
+        double* Xn = V.points_new + 3 * (size_t)l;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { xl[a] = u[a]; sc += u[a] * (lambda * u[a] + bl[a]); Xn[a] = X[a] + u[a]; }
+      }
+    }
   }
   block_reduce_publish<false>(sc, V.partial2, pub);
 }
@@ -1959,8 +1961,8 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
                        solve_seq, d_fail);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub) {
-  hipLaunchKernelGGL(k_point_backsub, dim3(cdiv(8 * V.L, 256)), dim3(256), 0, s, V);
-  hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(V.L, V.nfree), 256)), dim3(256), 0, s, V, pub);
+  const int nb_pose = cdiv(std::max(V.nfree, 1), 256);
+  hipLaunchKernelGGL(k_point_backsub, dim3(nb_pose + cdiv(8 * V.L, 256)), dim3(256), 0, s, V, pub, nb_pose);
 }
 __global__ void __launch_bounds__(256) k_pack_tiles(BaView V, double* __restrict__ buf, int unpack) {
   const int ti = V.nz_tiles[2 * blockIdx.x], tj = V.nz_tiles[2 * blockIdx.x + 1];
