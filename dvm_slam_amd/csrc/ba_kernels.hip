@@ -237,9 +237,6 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
       const double w = rho1 * info;
       const double wr0 = -info * e0 * rho1, wr1 = -info * e1 * rho1;
       double* out = V.e_lin + (size_t)k * kEdgeLinStride;
-#ifdef EDGE_NOSTORE
-      if (chi2 == 12345.678)
-#endif
       {
 #pragma unroll
       for (int i = 0; i < 6; i++) out[i] = A[i];
