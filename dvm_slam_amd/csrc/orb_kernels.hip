@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
 __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
                                                     LevelDesc L, const int32_t* __restrict__ tabs, int lds_pitch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rz_smem[];
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int tid = threadIdx.x, tx = tid & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the row tables / weights / LDS row bases below go to SGPRs
   const int f = blockIdx.z;
   const int w = L.w, bw = L.w + 2 * kEdge;
   const int X0 = blockIdx.x * kRzTW;               // first bordered column of the tile (dword aligned)
