@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
                                                     int64_t frame_stride, uint8_t* __restrict__ pyr,
                                                     int pyr_frame_bytes, LevelDesc L) {
   const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
-  const int yb = blockIdx.y * 16 + (threadIdx.x >> 6);
+  const int yb = blockIdx.y * 16 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addresses / mirror rows in SGPRs
   const int f = blockIdx.z;
   if (X >= cols + 2 * kEdge) return;
   const uint8_t* S = src + (int64_t)f * frame_stride;
