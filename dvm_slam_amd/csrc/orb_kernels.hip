@@ -75,7 +75,7 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 //                  the blur, which needs 3 px)
 // Destination dwords are aligned in BORDERED coordinates (the image starts at byte 19 of a row), so a
 // dword at a row end may mix interior and border bytes: those are stored byte-wise.
-constexpr int kRzTW = 256, kRzTH = 16;   // destination tile (bordered columns x interior rows)
+constexpr int kRzTW = 256, kRzTH = 64;   // destination tile (bordered columns x interior rows)
 
 __device__ __forceinline__ void store_px4(uint8_t* D, int X4, int w, uint32_t v) {
   const int d0 = X4 - kEdge;             // interior x of byte 0
