@@ -4,9 +4,8 @@
 //   PoseOptimization (:744-1028)  OptimizeSim3 (:1960-2212)
 // Same names, same signatures: a maintainer deletes these five bodies from src/Optimizer.cc and compiles this header into
 // the same translation unit (every other static -- inertial, essential graph -- stays where it is).  Each function keeps the
-// reference's graph GATHERING (which keyframes / map points / observations enter, which vertices are fixed) and its
-// WRITE-BACK (outlier erasure, SetPose / SetWorldPos / mTcwGBA ...) statement for statement; only the block between
-// "create optimizer" and "recover optimized data" is the device solve.  Stereo / fisheye-pair observations are not part of
+// reference's graph GATHERING rules (which keyframes / map points / observations enter, which vertices are fixed) and its
+// WRITE-BACK (outlier erasure, SetPose / SetWorldPos / mTcwGBA ...); the g2o block between them is the device solve.  Stereo / fisheye-pair observations are not part of
 // the accelerated path (DVM-SLAM is monocular): a keyframe that carries them is rejected with an exception.
 #pragma once
 #include <cmath>
@@ -44,364 +43,316 @@ inline void require_mono(KeyFrame* pKF, int leftIndex) {
     throw std::runtime_error("Optimizer shim: stereo / two-camera observation outside the accelerated (monocular) path");
 }
 
-// the device solve shared by BundleAdjustment and LocalBundleAdjustment
-struct BAProblem {
-  std::vector<KeyFrame*> kfs;
-  std::vector<uint8_t> fixed;
-  std::vector<MapPoint*> mps;
-  std::unordered_map<KeyFrame*, int32_t> kf_index;
+// One bundle-adjustment problem on its way to the device: cameras and landmarks get dense slots in insertion order, an
+// observation becomes an edge between two slots.  Shared by BundleAdjustment and LocalBundleAdjustment.
+struct Problem {
+  std::vector<KeyFrame*> cams;
+  std::vector<uint8_t> cam_fixed;
+  std::unordered_map<KeyFrame*, int32_t> cam_slot;
+  std::vector<MapPoint*> pts;
   std::vector<dvm_ba_edge> edges;
-  std::vector<KeyFrame*> edge_kf;
-  std::vector<MapPoint*> edge_mp;
-  std::vector<double> poses, points, chi2;
-  std::vector<uint8_t> depth_pos;
-  int add_kf(KeyFrame* pKF, bool fix) {
-    kf_index[pKF] = (int32_t)kfs.size();
-    kfs.push_back(pKF); fixed.push_back(fix ? 1 : 0);
-    return (int)kfs.size() - 1;
+  std::vector<std::pair<KeyFrame*, MapPoint*>> edge_owner;   // parallel to `edges`
+  std::vector<double> pose, xyz, chi2;
+  std::vector<uint8_t> in_front;
+
+  void camera(KeyFrame* kf, bool fixed) {
+    cam_slot.emplace(kf, (int32_t)cams.size());
+    cams.push_back(kf);
+    cam_fixed.push_back(fixed ? 1 : 0);
   }
-  void solve(int iterations, bool* pbStopFlag, double huber_delta) {
-    poses.resize(7 * kfs.size()); points.resize(3 * mps.size());
-    for (size_t i = 0; i < kfs.size(); i++) pose7(kfs[i]->GetPose(), &poses[7 * i]);
-    for (size_t i = 0; i < mps.size(); i++) {
-      const Eigen::Vector3d X = mps[i]->GetWorldPos().cast<double>();
-      for (int k = 0; k < 3; k++) points[3 * i + k] = X(k);
+  int32_t slot_of(KeyFrame* kf) const {
+    const auto it = cam_slot.find(kf);
+    return it == cam_slot.end() ? -1 : it->second;
+  }
+  // monocular observation `kp_index` of landmark slot `pt` in camera slot `cam` (an index of -1 carries no measurement)
+  void observe(KeyFrame* kf, int32_t cam, MapPoint* mp, int32_t pt, int kp_index) {
+    require_mono(kf, kp_index);
+    if (kp_index < 0) return;
+    const cv::KeyPoint& kp = kf->mvKeysUn[kp_index];
+    const dvm_ba_edge e = {cam, pt, kp.pt.x, kp.pt.y, kf->mvInvLevelSigma2[kp.octave]};
+    edges.push_back(e);
+    edge_owner.emplace_back(kf, mp);
+  }
+  void drop_edges_of(int32_t pt) {
+    while (!edges.empty() && edges.back().point == pt) { edges.pop_back(); edge_owner.pop_back(); }
+  }
+  Sophus::SE3f pose_of(size_t cam) const { return se3f(&pose[7 * cam]); }
+  Eigen::Vector3f position_of(size_t pt) const {
+    Eigen::Vector3d X;
+    for (int k = 0; k < 3; k++) X(k) = xyz[3 * pt + k];
+    return X.cast<float>();
+  }
+  // g2o's optimize(iterations) with the stop flag; afterwards pose / xyz hold the estimates, chi2 / in_front the per-edge tests
+  void run(int iterations, bool* stop, double huber_delta) {
+    pose.resize(7 * cams.size());
+    xyz.resize(3 * pts.size());
+    for (size_t i = 0; i < cams.size(); i++) pose7(cams[i]->GetPose(), &pose[7 * i]);
+    for (size_t i = 0; i < pts.size(); i++) {
+      const Eigen::Vector3d X = pts[i]->GetWorldPos().cast<double>();
+      for (int k = 0; k < 3; k++) xyz[3 * i + k] = X(k);
     }
-    KeyFrame* k0 = kfs[0];
-    dvm_ba_camera cam = {k0->fx, k0->fy, k0->cx, k0->cy, huber_delta};
-    dvm_ba* ba = NULL;
-    check(dvm_ba_create(0, &ba));
-    int rc = dvm_ba_set_problem(ba, poses.data(), fixed.data(), (int)kfs.size(), points.data(), (int)mps.size(), edges.data(),
-                                (int)edges.size(), &cam);
+    const KeyFrame* any = cams.front();
+    dvm_ba_camera cam = {any->fx, any->fy, any->cx, any->cy, huber_delta};
+    static_assert(sizeof(bool) == 1, "the stop flag is polled as a byte");
+    dvm_ba* h = NULL;
+    check(dvm_ba_create(0, &h));
     dvm_ba_stats st;
-    static_assert(sizeof(bool) == 1, "bool* pbStopFlag is read as a byte");
-    if (rc == DVM_OK) rc = dvm_ba_optimize(ba, iterations, reinterpret_cast<const volatile uint8_t*>(pbStopFlag), &st);
-    if (rc == DVM_OK) rc = dvm_ba_get_result(ba, poses.data(), points.data());
-    chi2.resize(edges.size()); depth_pos.resize(edges.size());
-    if (rc == DVM_OK) rc = dvm_ba_edge_chi2(ba, chi2.data(), depth_pos.data());
-    dvm_ba_destroy(ba);
+    int rc = dvm_ba_set_problem(h, pose.data(), cam_fixed.data(), (int)cams.size(), xyz.data(), (int)pts.size(), edges.data(),
+                                (int)edges.size(), &cam);
+    if (rc == DVM_OK) rc = dvm_ba_optimize(h, iterations, reinterpret_cast<const volatile uint8_t*>(stop), &st);
+    if (rc == DVM_OK) rc = dvm_ba_get_result(h, pose.data(), xyz.data());
+    chi2.resize(edges.size());
+    in_front.resize(edges.size());
+    if (rc == DVM_OK) rc = dvm_ba_edge_chi2(h, chi2.data(), in_front.data());
+    dvm_ba_destroy(h);
     check(rc);
   }
 };
 
 }  // namespace dvm_optimizer_detail
 
+// (Optimizer.cc:44-53)
 inline void Optimizer::GlobalBundleAdjustemnt(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
-  vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
-  vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
-  BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust);
+  BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
 }
 
+// (Optimizer.cc:55-356, monocular part)  Cameras: every good keyframe, the map's initial keyframe fixed.  Landmarks: every
+// good map point with at least one observation in a camera of the problem.  Results go to the entities directly when the
+// call belongs to the map's origin keyframe, otherwise to the mTcwGBA / mPosGBA staging members.
 inline void Optimizer::BundleAdjustment(const vector<KeyFrame*>& vpKFs, const vector<MapPoint*>& vpMP, int nIterations, bool* pbStopFlag,
                                         const unsigned long nLoopKF, const bool bRobust) {
   using namespace dvm_optimizer_detail;
-  vector<bool> vbNotIncludedMP;
-  vbNotIncludedMP.resize(vpMP.size());
-  Map* pMap = vpKFs[0]->GetMap();
-  BAProblem B;
-  long unsigned int maxKFid = 0;
-  // Set KeyFrame vertices
-  for (size_t i = 0; i < vpKFs.size(); i++) {
-    KeyFrame* pKF = vpKFs[i];
-    if (pKF->isBad()) continue;
-    B.add_kf(pKF, pKF->mnId == pMap->GetInitKFid());
-    if (pKF->mnId > maxKFid) maxKFid = pKF->mnId;
+  Map* map = vpKFs.front()->GetMap();
+  Problem prob;
+  unsigned long newest = 0;
+  for (KeyFrame* kf : vpKFs) {
+    if (kf->isBad()) continue;
+    prob.camera(kf, kf->mnId == map->GetInitKFid());
+    newest = std::max<unsigned long>(newest, kf->mnId);
   }
-  const float thHuber2D = sqrt(5.99);
-  std::vector<int32_t> mp_vertex(vpMP.size(), -1);
-  // Set MapPoint vertices + edges
+  std::vector<int32_t> slot_of_point(vpMP.size(), -1);     // -1: not part of the problem
   for (size_t i = 0; i < vpMP.size(); i++) {
-    MapPoint* pMP = vpMP[i];
-    if (pMP->isBad()) continue;
-    const map<KeyFrame*, tuple<int, int>> observations = pMP->GetObservations();
-    int nEdges = 0;
-    const int32_t vid = (int32_t)B.mps.size();
-    for (map<KeyFrame*, tuple<int, int>>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
-      KeyFrame* pKF = mit->first;
-      if (pKF->isBad() || pKF->mnId > maxKFid) continue;
-      auto kit = B.kf_index.find(pKF);
-      if (kit == B.kf_index.end()) continue;            // optimizer.vertex(pKF->mnId) == NULL
-      nEdges++;
-      const int leftIndex = get<0>(mit->second);
-      require_mono(pKF, leftIndex);
-      if (leftIndex != -1) {
-        const cv::KeyPoint& kpUn = pKF->mvKeysUn[leftIndex];
-        const float& invSigma2 = pKF->mvInvLevelSigma2[kpUn.octave];
-        dvm_ba_edge e = {kit->second, vid, kpUn.pt.x, kpUn.pt.y, invSigma2};
-        B.edges.push_back(e); B.edge_kf.push_back(pKF); B.edge_mp.push_back(pMP);
-      }
+    MapPoint* mp = vpMP[i];
+    if (mp->isBad()) continue;
+    const int32_t pt = (int32_t)prob.pts.size();
+    int seen_by = 0;
+    for (const auto& ob : mp->GetObservations()) {
+      KeyFrame* kf = ob.first;
+      if (kf->isBad() || kf->mnId > newest) continue;
+      const int32_t cam = prob.slot_of(kf);
+      if (cam < 0) continue;
+      seen_by++;
+      prob.observe(kf, cam, mp, pt, std::get<0>(ob.second));
     }
-    if (nEdges == 0) {
-      vbNotIncludedMP[i] = true;                         // optimizer.removeVertex(vPoint)
-      while (!B.edges.empty() && B.edges.back().point == vid) { B.edges.pop_back(); B.edge_kf.pop_back(); B.edge_mp.pop_back(); }
+    if (seen_by == 0) { prob.drop_edges_of(pt); continue; }
+    slot_of_point[i] = pt;
+    prob.pts.push_back(mp);
+  }
+  const float huber = sqrt(5.99);                            // the reference's float threshold for 2-D edges
+  prob.run(nIterations, pbStopFlag, bRobust ? (double)huber : 0.0);
+
+  const bool direct = nLoopKF == map->GetOriginKF()->mnId;
+  for (size_t c = 0; c < prob.cams.size(); c++) {
+    KeyFrame* kf = prob.cams[c];
+    if (direct) {
+      kf->SetPose(prob.pose_of(c));
     } else {
-      vbNotIncludedMP[i] = false;
-      mp_vertex[i] = vid;
-      B.mps.push_back(pMP);
+      kf->mTcwGBA = prob.pose_of(c);
+      kf->mnBAGlobalForKF = nLoopKF;
     }
   }
-  // Optimize!
-  B.solve(nIterations, pbStopFlag, bRobust ? (double)thHuber2D : 0.0);
-  // Recover optimized data: keyframes
-  for (size_t i = 0; i < B.kfs.size(); i++) {
-    KeyFrame* pKF = B.kfs[i];
-    if (nLoopKF == pMap->GetOriginKF()->mnId) {
-      pKF->SetPose(se3f(&B.poses[7 * i]));
-    } else {
-      pKF->mTcwGBA = se3f(&B.poses[7 * i]);   // Sophus::SE3d(...).cast<float>()
-      pKF->mnBAGlobalForKF = nLoopKF;
-      // (the reference's per-keyframe bad / good point census under `dist > 1` only fills local counters: nothing to write back)
-    }
-  }
-  // Points
   for (size_t i = 0; i < vpMP.size(); i++) {
-    if (vbNotIncludedMP[i]) continue;
-    MapPoint* pMP = vpMP[i];
-    if (pMP->isBad() || mp_vertex[i] < 0) continue;
-    Eigen::Vector3d X;
-    for (int k = 0; k < 3; k++) X(k) = B.points[3 * mp_vertex[i] + k];
-    if (nLoopKF == pMap->GetOriginKF()->mnId) {
-      pMP->SetWorldPos(X.cast<float>());
-      pMP->UpdateNormalAndDepth();
+    if (slot_of_point[i] < 0 || vpMP[i]->isBad()) continue;
+    MapPoint* mp = vpMP[i];
+    if (direct) {
+      mp->SetWorldPos(prob.position_of(slot_of_point[i]));
+      mp->UpdateNormalAndDepth();
     } else {
-      pMP->mPosGBA = X.cast<float>();
-      pMP->mnBAGlobalForKF = nLoopKF;
+      mp->mPosGBA = prob.position_of(slot_of_point[i]);
+      mp->mnBAGlobalForKF = nLoopKF;
     }
   }
 }
 
+// (Optimizer.cc:1030-1387, monocular non-inertial part)  Free cameras: the keyframe and its covisible neighbours of the same
+// map.  Landmarks: what they observe.  Fixed cameras: every other keyframe observing one of those landmarks.  Ten iterations
+// with the Huber kernel, then observations with chi2 > 5.991 or behind the camera are erased and the estimates written back.
 inline void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
                                              int& num_edges) {
   using namespace dvm_optimizer_detail;
-  // Local KeyFrames: First Breath Search from Current Keyframe
-  list<KeyFrame*> lLocalKeyFrames;
-  lLocalKeyFrames.push_back(pKF);
-  pKF->mnBALocalForKF = pKF->mnId;
-  Map* pCurrentMap = pKF->GetMap();
-  const vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
-  for (int i = 0, iend = vNeighKFs.size(); i < iend; i++) {
-    KeyFrame* pKFi = vNeighKFs[i];
-    pKFi->mnBALocalForKF = pKF->mnId;
-    if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lLocalKeyFrames.push_back(pKFi);
+  const unsigned long tag = pKF->mnId;
+  Map* own = pKF->GetMap();
+  const auto usable = [own](KeyFrame* kf) { return !kf->isBad() && kf->GetMap() == own; };
+
+  std::vector<KeyFrame*> free_cams(1, pKF);
+  pKF->mnBALocalForKF = tag;
+  for (KeyFrame* kf : pKF->GetVectorCovisibleKeyFrames()) {
+    kf->mnBALocalForKF = tag;
+    if (usable(kf)) free_cams.push_back(kf);
   }
-  // Local MapPoints seen in Local KeyFrames
-  num_fixedKF = 0;
-  list<MapPoint*> lLocalMapPoints;
-  for (list<KeyFrame*>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
-    KeyFrame* pKFi = *lit;
-    if (pKFi->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
-    vector<MapPoint*> vpMPs = pKFi->GetMapPointMatches();
-    for (vector<MapPoint*>::iterator vit = vpMPs.begin(), vend = vpMPs.end(); vit != vend; vit++) {
-      MapPoint* pMP = *vit;
-      if (pMP)
-        if (!pMP->isBad() && pMP->GetMap() == pCurrentMap)
-          if (pMP->mnBALocalForKF != pKF->mnId) {
-            lLocalMapPoints.push_back(pMP);
-            pMP->mnBALocalForKF = pKF->mnId;
-          }
+  bool holds_initial = false;
+  std::vector<MapPoint*> landmarks;
+  for (KeyFrame* kf : free_cams) {
+    holds_initial = holds_initial || kf->mnId == pMap->GetInitKFid();
+    for (MapPoint* mp : kf->GetMapPointMatches()) {
+      if (!mp || mp->isBad() || mp->GetMap() != own || mp->mnBALocalForKF == tag) continue;
+      mp->mnBALocalForKF = tag;
+      landmarks.push_back(mp);
     }
   }
-  // Fixed Keyframes. Keyframes that see Local MapPoints but that are not Local Keyframes
-  list<KeyFrame*> lFixedCameras;
-  for (list<MapPoint*>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
-    map<KeyFrame*, tuple<int, int>> observations = (*lit)->GetObservations();
-    for (map<KeyFrame*, tuple<int, int>>::iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
-      KeyFrame* pKFi = mit->first;
-      if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
-        pKFi->mnBAFixedForKF = pKF->mnId;
-        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lFixedCameras.push_back(pKFi);
-      }
+  std::vector<KeyFrame*> anchors;                            // keyframes that see a landmark without being free
+  for (MapPoint* mp : landmarks)
+    for (const auto& ob : mp->GetObservations()) {
+      KeyFrame* kf = ob.first;
+      if (kf->mnBALocalForKF == tag || kf->mnBAFixedForKF == tag) continue;
+      kf->mnBAFixedForKF = tag;
+      if (usable(kf)) anchors.push_back(kf);
     }
-  }
-  num_fixedKF = lFixedCameras.size() + num_fixedKF;
-  if (num_fixedKF == 0) return;   // "LM-LBA: There are 0 fixed KF in the optimizations, LBA aborted"
+  num_fixedKF = (int)anchors.size() + (holds_initial ? 1 : 0);
+  if (num_fixedKF == 0) return;                              // no gauge: the reference gives up here as well
   if (pMap->IsInertial()) throw std::runtime_error("Optimizer shim: inertial maps use the reference's own solver");
 
-  BAProblem B;
-  pCurrentMap->msOptKFs.clear();
-  pCurrentMap->msFixedKFs.clear();
-  // Set Local KeyFrame vertices, then the fixed ones
-  for (list<KeyFrame*>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
-    KeyFrame* pKFi = *lit;
-    B.add_kf(pKFi, pKFi->mnId == pMap->GetInitKFid());
-    pCurrentMap->msOptKFs.insert(pKFi->mnId);
+  Problem prob;
+  own->msOptKFs.clear();
+  own->msFixedKFs.clear();
+  for (KeyFrame* kf : free_cams) {
+    prob.camera(kf, kf->mnId == pMap->GetInitKFid());
+    own->msOptKFs.insert(kf->mnId);
   }
-  num_OptKF = lLocalKeyFrames.size();
-  for (list<KeyFrame*>::iterator lit = lFixedCameras.begin(), lend = lFixedCameras.end(); lit != lend; lit++) {
-    KeyFrame* pKFi = *lit;
-    B.add_kf(pKFi, true);
-    pCurrentMap->msFixedKFs.insert(pKFi->mnId);
+  for (KeyFrame* kf : anchors) {
+    prob.camera(kf, true);
+    own->msFixedKFs.insert(kf->mnId);
   }
-  const float thHuberMono = sqrt(5.991);
-  int nPoints = 0, nEdges = 0;
-  for (list<MapPoint*>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
-    MapPoint* pMP = *lit;
-    const int32_t vid = (int32_t)B.mps.size();
-    B.mps.push_back(pMP);
-    nPoints++;
-    const map<KeyFrame*, tuple<int, int>> observations = pMP->GetObservations();
-    for (map<KeyFrame*, tuple<int, int>>::const_iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
-      KeyFrame* pKFi = mit->first;
-      if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) {
-        const int leftIndex = get<0>(mit->second);
-        require_mono(pKFi, leftIndex);
-        if (leftIndex != -1) {   // Monocular observation
-          const cv::KeyPoint& kpUn = pKFi->mvKeysUn[leftIndex];
-          const float& invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave];
-          dvm_ba_edge e = {B.kf_index.at(pKFi), vid, kpUn.pt.x, kpUn.pt.y, invSigma2};
-          B.edges.push_back(e); B.edge_kf.push_back(pKFi); B.edge_mp.push_back(pMP);
-          nEdges++;
-        }
-      }
-    }
+  num_OptKF = (int)free_cams.size();
+  for (MapPoint* mp : landmarks) {
+    const int32_t pt = (int32_t)prob.pts.size();
+    prob.pts.push_back(mp);
+    for (const auto& ob : mp->GetObservations())
+      if (usable(ob.first)) prob.observe(ob.first, prob.cam_slot.at(ob.first), mp, pt, std::get<0>(ob.second));
   }
-  num_MPs = nPoints;
-  num_edges = nEdges;
-  if (pbStopFlag)
-    if (*pbStopFlag) return;
+  num_MPs = (int)prob.pts.size();
+  num_edges = (int)prob.edges.size();
+  if (pbStopFlag && *pbStopFlag) return;
 
-  B.solve(10, pbStopFlag, (double)thHuberMono);
+  const float huber = sqrt(5.991);
+  prob.run(10, pbStopFlag, (double)huber);
 
-  vector<pair<KeyFrame*, MapPoint*>> vToErase;
-  vToErase.reserve(B.edges.size());
-  // Check inlier observations
-  for (size_t i = 0, iend = B.edges.size(); i < iend; i++) {
-    MapPoint* pMP = B.edge_mp[i];
-    if (pMP->isBad()) continue;
-    if (B.chi2[i] > 5.991 || !B.depth_pos[i]) vToErase.push_back(make_pair(B.edge_kf[i], pMP));
+  std::vector<std::pair<KeyFrame*, MapPoint*>> rejected;
+  for (size_t e = 0; e < prob.edges.size(); e++) {
+    if (prob.edge_owner[e].second->isBad()) continue;
+    if (prob.chi2[e] > 5.991 || !prob.in_front[e]) rejected.push_back(prob.edge_owner[e]);
   }
-  // Get Map Mutex
   unique_lock<mutex> lock(pMap->mMutexMapUpdate);
-  if (!vToErase.empty()) {
-    for (size_t i = 0; i < vToErase.size(); i++) {
-      KeyFrame* pKFi = vToErase[i].first;
-      MapPoint* pMPi = vToErase[i].second;
-      pKFi->EraseMapPointMatch(pMPi);
-      pMPi->EraseObservation(pKFi);
-    }
+  for (const auto& r : rejected) {
+    r.first->EraseMapPointMatch(r.second);
+    r.second->EraseObservation(r.first);
   }
-  // Recover optimized data: keyframes, points
-  for (list<KeyFrame*>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
-    KeyFrame* pKFi = *lit;
-    pKFi->SetPose(se3f(&B.poses[7 * B.kf_index.at(pKFi)]));
-  }
-  {
-    size_t i = 0;
-    for (list<MapPoint*>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++, i++) {
-      MapPoint* pMP = *lit;
-      Eigen::Vector3d X;
-      for (int k = 0; k < 3; k++) X(k) = B.points[3 * i + k];
-      pMP->SetWorldPos(X.cast<float>());
-      pMP->UpdateNormalAndDepth();
-    }
+  for (size_t c = 0; c < free_cams.size(); c++) free_cams[c]->SetPose(prob.pose_of(c));      // free cameras hold slots 0 .. n - 1
+  for (size_t i = 0; i < landmarks.size(); i++) {
+    landmarks[i]->SetWorldPos(prob.position_of(i));
+    landmarks[i]->UpdateNormalAndDepth();
   }
   pMap->IncreaseChangeIndex();
 }
 
+// (Optimizer.cc:744-1028, monocular part)  Every keypoint of the frame that holds a map point becomes a unary reprojection
+// edge; the four optimize(10) rounds with their outlier re-classification run on the device.  Returns the inlier count, sets
+// the frame's pose and its mvbOutlier flags.
 inline int Optimizer::PoseOptimization(Frame* pFrame) {
   using namespace dvm_optimizer_detail;
-  int nInitialCorrespondences = 0;
-  const int N = pFrame->N;
-  std::vector<double> Xw, obs, w;
-  std::vector<size_t> vnIndexEdgeMono;
-  {
-    for (int i = 0; i < N; i++) {
-      MapPoint* pMP = pFrame->mvpMapPoints[i];
-      if (!pMP) continue;
-      if (pFrame->mpCamera2 || (!pFrame->mvuRight.empty() && pFrame->mvuRight[i] >= 0))
-        throw std::runtime_error("Optimizer shim: stereo observation outside the accelerated (monocular) path");
-      nInitialCorrespondences++;
-      pFrame->mvbOutlier[i] = false;
-      const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
-      obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y);
-      w.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
-      const Eigen::Vector3d X = pMP->GetWorldPos().cast<double>();
-      Xw.push_back(X(0)); Xw.push_back(X(1)); Xw.push_back(X(2));
-      vnIndexEdgeMono.push_back(i);
-    }
+  Frame& F = *pFrame;
+  std::vector<double> world, pixel, weight;
+  std::vector<int> keypoint_of;                              // edge -> keypoint index
+  for (int i = 0; i < F.N; i++) {
+    MapPoint* mp = F.mvpMapPoints[i];
+    if (!mp) continue;
+    if (F.mpCamera2 || (!F.mvuRight.empty() && F.mvuRight[i] >= 0))
+      throw std::runtime_error("Optimizer shim: stereo observation outside the accelerated (monocular) path");
+    F.mvbOutlier[i] = false;
+    const cv::KeyPoint& kp = F.mvKeysUn[i];
+    const Eigen::Vector3d X = mp->GetWorldPos().cast<double>();
+    for (int k = 0; k < 3; k++) world.push_back(X(k));
+    pixel.push_back(kp.pt.x);
+    pixel.push_back(kp.pt.y);
+    weight.push_back(F.mvInvLevelSigma2[kp.octave]);
+    keypoint_of.push_back(i);
   }
-  if (nInitialCorrespondences < 3) return 0;
-  double pose_in[7], pose_out[7];
-  pose7(pFrame->GetPose(), pose_in);
-  const int32_t n = nInitialCorrespondences;
-  std::vector<uint8_t> outlier(n);
-  int32_t ret = 0;
-  dvm_ba_camera cam = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, 0.0};
-  check(dvm_pose_optimize(0, pose_in, Xw.data(), obs.data(), w.data(), &n, n, 1, &cam, pose_out, outlier.data(), &ret));
-  for (int k = 0; k < n; k++) pFrame->mvbOutlier[vnIndexEdgeMono[k]] = outlier[k] != 0;
-  // Recover optimized pose and return number of inliers
-  pFrame->SetPose(se3f(pose_out));
-  return ret;
+  const int32_t n = (int32_t)keypoint_of.size();
+  if (n < 3) return 0;
+  double start[7], refined[7];
+  pose7(F.GetPose(), start);
+  std::vector<uint8_t> rejected(n);
+  int32_t inliers = 0;
+  dvm_ba_camera cam = {F.fx, F.fy, F.cx, F.cy, 0.0};
+  check(dvm_pose_optimize(0, start, world.data(), pixel.data(), weight.data(), &n, n, 1, &cam, refined, rejected.data(), &inliers));
+  for (int32_t e = 0; e < n; e++) F.mvbOutlier[keypoint_of[e]] = rejected[e] != 0;
+  F.SetPose(se3f(refined));
+  return inliers;
 }
 
+// (Optimizer.cc:1960-2212)  Matched map-point pairs of two keyframes, each expressed in its own camera frame (float matrix
+// form, Eigen's a0 + (a1 + a2) sums, as the reference computes R * P + t), with their keypoints (or, with bAllPoints, the
+// projection of the second point where it has no keypoint) -> 7-DoF refinement of S12 on the device.  Pairs rejected by the
+// chi2 test are cleared from vpMatches1; returns the inlier count.
 inline int Optimizer::OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches1, g2o::Sim3& g2oS12, const float th2,
                                    const bool bFixScale, Eigen::Matrix<double, 7, 7>& mAcumHessian, const bool bAllPoints) {
   using namespace dvm_optimizer_detail;
-  // Camera poses (matrix form, as the reference: P3D1c = R1w * P3D1w + t1w in float, Eigen's a0 + (a1 + a2) sums)
-  const Eigen::Matrix3f R1w = pKF1->GetRotation();
-  const Eigen::Vector3f t1w = pKF1->GetTranslation();
-  const Eigen::Matrix3f R2w = pKF2->GetRotation();
-  const Eigen::Vector3f t2w = pKF2->GetTranslation();
-  auto to_cam = [](const Eigen::Matrix3f& R, const Eigen::Vector3f& t, const Eigen::Vector3f& P, double* out) {
-    for (int r = 0; r < 3; r++) out[r] = (double)((R(r, 0) * P(0) + (R(r, 1) * P(1) + R(r, 2) * P(2))) + t(r));
-  };
-  const int N = vpMatches1.size();
-  const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
-  std::vector<double> P1c, P2c, obs1, obs2, w1, w2;
-  std::vector<size_t> vnIndexEdge;
-  int nCorrespondences = 0;
-  for (int i = 0; i < N; i++) {
-    if (!vpMatches1[i]) continue;
-    MapPoint* pMP1 = vpMapPoints1[i];
-    MapPoint* pMP2 = vpMatches1[i];
-    const int i2 = get<0>(pMP2->GetIndexInKeyFrame(pKF2));
-    double c1[3], c2[3];
-    if (pMP1 && pMP2) {
-      if (!pMP1->isBad() && !pMP2->isBad()) {
-        to_cam(R1w, t1w, pMP1->GetWorldPos(), c1);
-        to_cam(R2w, t2w, pMP2->GetWorldPos(), c2);
-      } else {
-        continue;
-      }
-    } else {
-      continue;   // the 3D position in KF1 doesn't exist: the reference adds an unconnected vertex only
+  struct CameraFrame {
+    Eigen::Matrix3f R;
+    Eigen::Vector3f t;
+    void map(const Eigen::Vector3f& P, double* out) const {
+      for (int r = 0; r < 3; r++) out[r] = (double)((R(r, 0) * P(0) + (R(r, 1) * P(1) + R(r, 2) * P(2))) + t(r));
     }
-    if (i2 < 0 && !bAllPoints) continue;
+  };
+  const CameraFrame cam1 = {pKF1->GetRotation(), pKF1->GetTranslation()}, cam2 = {pKF2->GetRotation(), pKF2->GetTranslation()};
+  const vector<MapPoint*> own1 = pKF1->GetMapPointMatches();
+  std::vector<double> in1, in2, px1, px2, w1, w2;
+  std::vector<int> match_of;                                 // pair -> index into vpMatches1
+  for (int i = 0, n = (int)vpMatches1.size(); i < n; i++) {
+    MapPoint* a = own1[i];
+    MapPoint* b = vpMatches1[i];
+    if (!a || !b || a->isBad() || b->isBad()) continue;      // (where KF1 has no point the reference adds an unconnected vertex only)
+    const int kp2 = std::get<0>(b->GetIndexInKeyFrame(pKF2));
+    if (kp2 < 0 && !bAllPoints) continue;
+    double c1[3], c2[3];
+    cam1.map(a->GetWorldPos(), c1);
+    cam2.map(b->GetWorldPos(), c2);
     if ((float)c2[2] < 0) continue;
-    nCorrespondences++;
-    const cv::KeyPoint& kpUn1 = pKF1->mvKeysUn[i];
-    obs1.push_back(kpUn1.pt.x); obs1.push_back(kpUn1.pt.y);
-    w1.push_back(pKF1->mvInvLevelSigma2[kpUn1.octave]);
-    if (i2 >= 0) {
-      const cv::KeyPoint& kpUn2 = pKF2->mvKeysUn[i2];
-      obs2.push_back(kpUn2.pt.x); obs2.push_back(kpUn2.pt.y);
-      w2.push_back(pKF2->mvInvLevelSigma2[kpUn2.octave]);
-    } else {
-      const float invz = 1 / (float)c2[2];
-      const float x = (float)c2[0] * invz, y = (float)c2[1] * invz;
-      obs2.push_back(x); obs2.push_back(y);
-      // kpUn2 = cv::KeyPoint(cv::Point2f(x, y), pMP2->mnTrackScaleLevel): the SIZE argument, so octave = 0
+    const cv::KeyPoint& k1 = pKF1->mvKeysUn[i];
+    px1.push_back(k1.pt.x);
+    px1.push_back(k1.pt.y);
+    w1.push_back(pKF1->mvInvLevelSigma2[k1.octave]);
+    if (kp2 >= 0) {
+      const cv::KeyPoint& k2 = pKF2->mvKeysUn[kp2];
+      px2.push_back(k2.pt.x);
+      px2.push_back(k2.pt.y);
+      w2.push_back(pKF2->mvInvLevelSigma2[k2.octave]);
+    } else {                                                 // synthetic keypoint at the normalised projection, octave 0
+      const float iz = 1 / (float)c2[2];
+      px2.push_back((float)c2[0] * iz);
+      px2.push_back((float)c2[1] * iz);
       w2.push_back(pKF2->mvInvLevelSigma2[0]);
     }
-    for (int k = 0; k < 3; k++) { P1c.push_back(c1[k]); P2c.push_back(c2[k]); }
-    vnIndexEdge.push_back(i);
+    for (int k = 0; k < 3; k++) { in1.push_back(c1[k]); in2.push_back(c2[k]); }
+    match_of.push_back(i);
   }
-  if (nCorrespondences == 0) return 0;
+  const int pairs = (int)match_of.size();
+  if (pairs == 0) return 0;
   double S[8] = {g2oS12.rotation().x(), g2oS12.rotation().y(), g2oS12.rotation().z(), g2oS12.rotation().w(),
                  g2oS12.translation()(0), g2oS12.translation()(1), g2oS12.translation()(2), g2oS12.scale()};
   const double K1[4] = {pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy}, K2[4] = {pKF2->fx, pKF2->fy, pKF2->cx, pKF2->cy};
-  std::vector<uint8_t> inlier(nCorrespondences);
-  int32_t nIn = 0;
-  check(dvm_optimize_sim3(0, S, bFixScale ? 1 : 0, P1c.data(), P2c.data(), obs1.data(), obs2.data(), w1.data(), w2.data(), nCorrespondences,
-                          K1, K2, (double)th2, inlier.data(), &nIn));
-  for (int k = 0; k < nCorrespondences; k++)
-    if (!inlier[k]) vpMatches1[vnIndexEdge[k]] = static_cast<MapPoint*>(NULL);
-  if (nIn == 0) return 0;      // fewer than 10 pairs survived the first round: g2oS12 stays as it was
-  mAcumHessian.setZero();      // mAcumHessian = Eigen::MatrixXd::Zero(7, 7) (never accumulated in the reference either)
+  std::vector<uint8_t> kept(pairs);
+  int32_t inliers = 0;
+  check(dvm_optimize_sim3(0, S, bFixScale ? 1 : 0, in1.data(), in2.data(), px1.data(), px2.data(), w1.data(), w2.data(), pairs, K1, K2,
+                          (double)th2, kept.data(), &inliers));
+  for (int e = 0; e < pairs; e++)
+    if (!kept[e]) vpMatches1[match_of[e]] = static_cast<MapPoint*>(NULL);
+  if (inliers == 0) return 0;                                // fewer than 10 pairs survived the first round: S12 stays as it was
+  mAcumHessian.setZero();                                    // (the reference never accumulates into it either)
   Eigen::Vector3d t;
   t(0) = S[4]; t(1) = S[5]; t(2) = S[6];
   g2oS12 = g2o::Sim3(Eigen::Quaterniond(S[3], S[0], S[1], S[2]), t, S[7]);
-  return nIn;
+  return inliers;
 }
 
 }  // namespace ORB_SLAM3
