@@ -675,6 +675,22 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Bm[r * LP + c];
     }
   };
+  // L^-1 block (i, j), i > j:  -Iv_i * sum_{k = j .. i - 1} L_ik Linv_kj  (blocks (k, j), k < i, must be in Li already), one wave;
+  // the C/D register layout of the f64 MFMA is its B-operand layout for k-step = reg, so the running sum feeds the product
+  // with Iv_i without touching LDS
+  auto linv_block = [&](int i, int j) {
+    double4_t t = {0, 0, 0, 0};
+    for (int k = j; k < i; k++) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4)
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(16 * i + lr) * LP + 16 * k + kk + lq], Li[(16 * k + kk + lq) * LP + 16 * j + lr], t, 0, 0, 0);
+    }
+    double4_t r4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int st = 0; st < 4; st++) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[i][lr][4 * st + lq], t[st], r4, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) Li[(16 * i + lq + 4 * r) * LP + 16 * j + lr] = -r4[r];
+  };
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
     DVM_STAMP(2 + 3 * b);
@@ -729,10 +745,13 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       }
       if (bad && lane == 0) *fail = 1;
     } else if (b >= 1) {
-      // the other waves are idle during the panel: one inverts the previous diagonal sub-block, two send the previous
-      // block column of L home
+      // the other waves are idle during the panel: one inverts the previous diagonal sub-block, the others send the previous
+      // block column of L home -- and, during the last panel, one already assembles L^-1 block (1, 0), whose inputs (Iv_0,
+      // Iv_1, L_10) are final by then
       if (wave == 3) invert_block(b - 1);
-      else store_panel(b - 1, tid - 64, 128);
+      else if (b < 3) store_panel(b - 1, tid - 64, 128);
+      else if (wave == 1) store_panel(b - 1, tid - 64, 64);
+      else linv_block(1, 0);
     }
     DVM_STAMP(3 + 3 * b);
     __syncthreads();
@@ -754,29 +773,13 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       __syncthreads();
     }
   }
+  // tail: L^-1 block row 2 needs Iv_2 (inverted during the last panel), block row 3 needs Iv_3 (inverted now)
   if (wave == 3) invert_block(3);
-  else store_panel(3, tid, 192);
+  else if (wave == 2) store_panel(3, tid - 128, 64);
+  else linv_block(2, wave);                  // (2, 0) on wave 0 -- reads (1, 0) from the last panel's idle time --, (2, 1) on wave 1
   __syncthreads();
   DVM_STAMP(14);
-  // ---- Linv: wave j builds block column j top-down
-  if (wave < 3) {
-    const int j = wave;
-    for (int i = j + 1; i < 4; i++) {
-      double4_t t = {0, 0, 0, 0};
-      for (int k = j; k < i; k++) {
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 4)
-          t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(16 * i + lr) * LP + 16 * k + kk + lq], Li[(16 * k + kk + lq) * LP + 16 * j + lr], t, 0, 0, 0);
-      }
-      double4_t r4 = {0, 0, 0, 0};
-#pragma unroll
-      for (int st = 0; st < 4; st++) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[i][lr][4 * st + lq], t[st], r4, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; r++) Li[(16 * i + lq + 4 * r) * LP + 16 * j + lr] = -r4[r];
-      __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes feed its next block row
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  if (wave < 3) linv_block(3, wave);
   DVM_STAMP(15);
   __syncthreads();
   DVM_STAMP(16);
