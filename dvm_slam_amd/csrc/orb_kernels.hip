@@ -975,74 +975,109 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 //   rBRIEF:   the 37 x 37 blurred patch (pattern radius 18.4) is staged in LDS as 37 rows x 10 dwords (6 instructions);
 //             the 512 rotated samples are LDS byte reads; 256 tests = 4 ballots of 64 lanes
 constexpr int kDescR = 18, kDescPitch = 40, kDescRows = 2 * kDescR + 1;
+constexpr int kDescPerWave = 4;   // keypoints a wave handles one after the other (16 per workgroup)
+// A wave walks kDescPerWave keypoints: all their loads go out first (blurred patches -> LDS, IC rows -> registers), then the
+// four pairs of moments are reduced, then LANES 0..3 run fastAtan2 + the double-precision sincos for the four keypoints AT ONCE
+// -- that part is ~100 instructions of wave-uniform floating point per keypoint when every keypoint has its own wave --, then
+// the four descriptors.  The pattern points (as floats) and the disc weights stay in registers across the keypoints.
 __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
                                                      const uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                      PipelineDesc PD, const KpAux* __restrict__ aux,
                                                      const int32_t* __restrict__ n_kp, dvm_keypoint_pod* __restrict__ kps,
                                                      uint8_t* __restrict__ desc, int batch) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescRows * kDescPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescPerWave][kDescRows * kDescPitch];
   int blk, f;
-  if (!xcd_frame_map((PD.kp_cap + 3) / 4, batch, blk, f)) return;
+  if (!xcd_frame_map((PD.kp_cap + 4 * kDescPerWave - 1) / (4 * kDescPerWave), batch, blk, f)) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blk * 4 + wave;
-  if (g >= n_kp[f]) return;
-  const KpAux a = aux[(int64_t)f * PD.kp_cap + g];
-  const LevelDesc& L = PD.lv[a.level];
-  // ---- blurred patch -> LDS (flat addressing of the blurred level, exactly what the byte gathers used to read;
-  // addresses are clamped to the level so the unused corner bytes of edge keypoints never leave the buffer)
-  const uint8_t* bl = blur + (int64_t)f * blur_frame_bytes + L.blur_off;
-  const int st = L.blur_stride;
-  const int bmax = st * L.h - 4;
-  uint8_t* P = s_patch[wave];
+  const int g0 = (blk * 4 + wave) * kDescPerWave;
+  const int nk = min(kDescPerWave, n_kp[f] - g0);          // wave-uniform
+  if (nk <= 0) return;
+  KpAux a[kDescPerWave];
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    const int item = lane + 64 * i;
-    const int r = (item * 205) >> 11, c = item - 10 * r;   // item / 10 for item < 1024
-    if (item < kDescRows * 10) {
-      const int off = min(max((a.cy - kDescR + r) * st + a.cx - kDescR + 4 * c, 0), bmax);
-      uint32_t v;
-      __builtin_memcpy(&v, bl + off, 4);
-      *reinterpret_cast<uint32_t*>(P + r * kDescPitch + 4 * c) = v;
+  for (int q = 0; q < kDescPerWave; q++) a[q] = aux[(int64_t)f * PD.kp_cap + g0 + min(q, nk - 1)];
+  // ---- blurred patches -> LDS (flat addressing of the blurred level; addresses are clamped to the level so the unused
+  // corner bytes of edge keypoints never leave the buffer)
+#pragma unroll
+  for (int q = 0; q < kDescPerWave; q++) {
+    const LevelDesc& L = PD.lv[a[q].level];
+    const uint8_t* bl = blur + (int64_t)f * blur_frame_bytes + L.blur_off;
+    const int st = L.blur_stride;
+    const int bmax = st * L.h - 4;
+    uint8_t* P = s_patch[wave][q];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int item = lane + 64 * i;
+      const int r = (item * 205) >> 11, c = item - 10 * r;   // item / 10 for item < 1024
+      if (item < kDescRows * 10) {
+        const int off = min(max((a[q].cy - kDescR + r) * st + a[q].cx - kDescR + 4 * c, 0), bmax);
+        uint32_t v;
+        __builtin_memcpy(&v, bl + off, 4);
+        *reinterpret_cast<uint32_t*>(P + r * kDescPitch + 4 * c) = v;
+      }
     }
   }
-  // ---- IC_Angle
-  const uint8_t* c0 = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + a.cy) * L.stride + kEdge + a.cx;
-  int m10 = 0, m01 = 0;
+  // ---- IC_Angle: the 31 x 31 patch as 31 rows x 8 unaligned dwords; moments = v_dot4_u32_u8 against the disc weights
+  uint2 w[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int item = lane + 64 * i;            // rows 0..30 (item 248..255: weights are zero, row clamped)
-    const int r = min(item >> 3, 30), c = item & 7;
-    uint32_t v;
-    __builtin_memcpy(&v, c0 + (r - kHalfPatch) * L.stride + 4 * c - kHalfPatch, 4);
-    const uint2 w = c_disc_w[item];
-    const int s1 = (int)__builtin_amdgcn_udot4(v, w.y, 0u, false);
-    const int su = (int)__builtin_amdgcn_udot4(v, w.x, 0u, false);
-    m10 += su - 16 * s1;
-    m01 += (r - kHalfPatch) * s1;
+  for (int i = 0; i < 4; i++) w[i] = c_disc_w[lane + 64 * i];
+  int m10[kDescPerWave], m01[kDescPerWave];
+#pragma unroll
+  for (int q = 0; q < kDescPerWave; q++) {
+    const LevelDesc& L = PD.lv[a[q].level];
+    const uint8_t* c0 = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + a[q].cy) * L.stride + kEdge + a[q].cx;
+    int s10 = 0, s01 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int item = lane + 64 * i;            // rows 0..30 (item 248..255: weights are zero, row clamped)
+      const int r = min(item >> 3, 30), c = item & 7;
+      uint32_t v;
+      __builtin_memcpy(&v, c0 + (r - kHalfPatch) * L.stride + 4 * c - kHalfPatch, 4);
+      const int s1 = (int)__builtin_amdgcn_udot4(v, w[i].y, 0u, false);
+      const int su = (int)__builtin_amdgcn_udot4(v, w[i].x, 0u, false);
+      s10 += su - 16 * s1;
+      s01 += (r - kHalfPatch) * s1;
+    }
+    m10[q] = wave_sum_i32(s10);
+    m01[q] = wave_sum_i32(s01);
   }
-  m10 = wave_sum_i32(m10);
-  m01 = wave_sum_i32(m01);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  float ca, sb;
-  sincos_deg(angle, ca, sb);
+  // ---- angle and rotation of the four keypoints on lanes 0..3, then handed to every lane by v_readlane
+  int my10 = 0, my01 = 0;
+#pragma unroll
+  for (int q = 0; q < kDescPerWave; q++) { if (lane == q) { my10 = m10[q]; my01 = m01[q]; } }
+  float ang_l = 0.f, ca_l = 1.f, sb_l = 0.f;
+  if (lane < kDescPerWave) {
+    ang_l = fast_atan2_deg((float)my01, (float)my10);
+    sincos_deg(ang_l, ca_l, sb_l);
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const uint8_t* c1 = P + kDescR * kDescPitch + kDescR;
-  unsigned long long words[4];
+  float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int* pt = &c_pattern[(64 * i + lane) * 4];
-    float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-    int t0 = c1[__float2int_rn(x0 * sb + y0 * ca) * kDescPitch + __float2int_rn(x0 * ca - y0 * sb)];
-    int t1 = c1[__float2int_rn(x1 * sb + y1 * ca) * kDescPitch + __float2int_rn(x1 * ca - y1 * sb)];
-    words[i] = __ballot(t0 < t1);
+    px0[i] = (float)pt[0]; py0[i] = (float)pt[1]; px1[i] = (float)pt[2]; py1[i] = (float)pt[3];
   }
-  if (lane == 0) {
-    kps[(int64_t)f * PD.kp_cap + a.out_pos].angle = angle;
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((int64_t)f * PD.kp_cap + a.out_pos) * 32);
-    d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+#pragma unroll
+  for (int q = 0; q < kDescPerWave; q++) {
+    if (q >= nk) break;
+    const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_l), q));
+    const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_l), q));
+    const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sb_l), q));
+    const uint8_t* c1 = s_patch[wave][q] + kDescR * kDescPitch + kDescR;
+    unsigned long long words[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int t0 = c1[__float2int_rn(px0[i] * sb + py0[i] * ca) * kDescPitch + __float2int_rn(px0[i] * ca - py0[i] * sb)];
+      const int t1 = c1[__float2int_rn(px1[i] * sb + py1[i] * ca) * kDescPitch + __float2int_rn(px1[i] * ca - py1[i] * sb)];
+      words[i] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+      kps[(int64_t)f * PD.kp_cap + a[q].out_pos].angle = angle;
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((int64_t)f * PD.kp_cap + a[q].out_pos) * 32);
+      d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+    }
   }
 }
 
@@ -1130,7 +1165,7 @@ void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const Til
 }
 void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
                         const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch) {
-  hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(cdiv(PD.kp_cap, 4), batch)), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes,
+  hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(cdiv(PD.kp_cap, 4 * kDescPerWave), batch)), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes,
                      d_blur, PD.blur_frame_bytes, PD, d_aux, d_n, d_kps, d_desc, batch);
 }
 
