@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ can
   const int W = (LV.w - kEdge + 3) - (kEdge - 3), H = (LV.h - kEdge + 3) - (kEdge - 3);  // maxX-minX, maxY-minY
   const int nIni = (int)roundf((float)W / (float)H);
   if (nIni <= 0 || 4 * nIni > cap || N + 8 > cap) {
-    if (tid == 0) { *out_n = 0; atomicExch(err_flag, 1); }
+    if (tid == 0) { *out_n = 0; __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // mapped host memory
     return;
   }
   const float hX = (float)W / (float)nIni;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ can
     block_scan_excl(a_scan, m, s_tmp, &s_keep);
     const int newSize = totalC + s_keep;
     if (newSize > cap) {
-      if (tid == 0) { *out_n = 0; atomicExch(err_flag, 2); }
+      if (tid == 0) { *out_n = 0; __hip_atomic_store(err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       return;
     }
     // ---- build the new list

@@ -339,13 +339,13 @@ int OrbPipeline::init() {
 
 void OrbPipeline::free_all() {
   void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_count, d_sel, d_nsel,
-                   d_kps, d_desc, d_aux, d_n, d_mono, d_nid, d_err};
+                   d_kps, d_desc, d_aux, d_n, d_mono, d_nid};
   for (void* p : dptrs) if (p) hipFree(p);
-  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono};
+  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono, (void*)h_err};
   for (void* p : hptrs) if (p) hipHostFree(p);
   d_pyr = d_blur = d_desc = nullptr; d_tabs = nullptr; d_cells = nullptr; d_tiles = nullptr;
   d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_count = d_nsel = d_n = d_mono = nullptr;
-  d_kps = nullptr; d_aux = nullptr; d_nid = nullptr; d_err = nullptr;
+  d_kps = nullptr; d_aux = nullptr; d_nid = nullptr; d_err = nullptr; h_err = nullptr;
   h_cell_count = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
   configured = false;  // (the host-image staging buffers d_stage/h_stage live until the destructor)
 }
@@ -496,8 +496,11 @@ int OrbPipeline::configure(int rows, int cols) {
   DVM_HIP(hipMalloc(&d_n, B * 4));
   DVM_HIP(hipMalloc(&d_mono, B * 4));
   DVM_HIP(hipMalloc(&d_nid, B * PD.cand_frame_slots * 4));
-  DVM_HIP(hipMalloc(&d_err, 4));
-  DVM_HIP(hipMemset(d_err, 0, 4));
+  // the octree's overflow flag lives in mapped host memory: the kernel stores to it (system scope), sync() reads it after
+  // the stream has drained -- no copy, no launch
+  DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_err), 4, hipHostMallocMapped));
+  *h_err = 0;
+  DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_err), h_err, 0));
   DVM_HIP(hipHostMalloc(&h_cell_count, B * std::max(PD.ncells, 1) * 4));
   DVM_HIP(hipHostMalloc(&h_dense, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipHostMalloc(&h_sel, B * PD.sel_frame_slots * 4));
@@ -756,10 +759,9 @@ int OrbPipeline::sync() {
   prof.resolve();
   // the device octree's overflow flag: checked at every synchronisation point, so the device-resident consumers
   // (dvm_orb_result_device, dvm_orb_copy_result, the wire gather) cannot read a silently truncated level either
-  if (d_err) {
-    int32_t oct_err = 0;
-    DVM_HIP(hipMemcpy(&oct_err, d_err, 4, hipMemcpyDeviceToHost));
-    if (oct_err) { set_error("device octree: node capacity exceeded (internal: configure() refuses such quotas)"); return DVM_ERR_CAPACITY; }
+  if (h_err && *reinterpret_cast<volatile int32_t*>(h_err)) {
+    set_error("device octree: node capacity exceeded (internal: configure() refuses such quotas)");
+    return DVM_ERR_CAPACITY;
   }
   return DVM_OK;
 }

@@ -110,7 +110,8 @@ class OrbPipeline {
   int32_t* d_n = nullptr;            // [batch]
   int32_t* d_mono = nullptr;
   int32_t* d_nid = nullptr;          // [batch][cand_frame_slots] octree scratch: node id per candidate
-  int32_t* d_err = nullptr;          // device error flag (octree capacity)
+  int32_t* d_err = nullptr;          // octree capacity flag: device address of ...
+  int32_t* h_err = nullptr;          // ... this word of mapped host memory
   bool host_octree = false;          // DistributeOctTree on the host instead of k_octree: forced (debug) or because a
   bool host_octree_forced = false;   // level quota exceeds the device kernel's node capacity
   uint8_t* d_stage = nullptr;        // staging for host images
