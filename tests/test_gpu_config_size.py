@@ -33,6 +33,27 @@ def test_global_ba_500kf_matches_oracle(capi, oracle, delta, iters):
     assert np.array_equal(pg[0], po_[0]) and depth.all()
 
 
+def test_global_ba_four_times_the_baseline_size(capi, oracle):
+    """2 000 keyframes / 80 000 landmarks / 640 000 observations (4x BASELINE config 5; S is a 12 864^2 tile matrix, 798 non-zero
+    tiles, ten elimination-tree levels): same LM trial sequence as the oracle, poses / landmarks far inside 1e-6."""
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=2000, n_pts=80000, seed=7)
+    assert len(pr["obs"]) == 640000
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(5.991))
+    po_, pto, so, _ = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, 6)
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    sg = ba.optimize(6)
+    pg, ptg = ba.result()
+    info = ba.schedule_info()
+    ba.close()
+    assert sg["trials"] == so["trials"] and sg["iterations"] == so["iterations"]
+    assert np.allclose(sg["chi2"], so["chi2"], rtol=1e-9)
+    assert np.abs(pg - po_).max() < 1e-6 and np.abs(ptg - pto).max() < 1e-6
+    assert info["free_cameras"] == 1999 and info["nz_tiles"] > 500
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_vocabulary_reference_shape_k10_L6(capi, oracle, ragged):
     """transform() through a 6-level, fan-out-10 tree (1 111 111 nodes when full) and the keyframe-database query on the
