@@ -29,7 +29,6 @@ struct dvm_ba {
   int device = 0;
   hipStream_t stream = nullptr;
   BaView V{};
-  std::vector<void*> allocs;
   // Phase results travel to the host through page-locked memory mapped into the device (BaPublish): h_vals[0..7] scalars
   // (chi2, trial chi2, scale, max diagonal, ..., [6] = Cholesky failure flag), h_seq the sequence number the host spins on.
   double* h_vals = nullptr;                 // hipHostMalloc'ed [16]; [8] holds the sequence number
@@ -61,12 +60,31 @@ struct dvm_ba {
   BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
   double tile_fill = 1.0;                             // non-zero tiles / all lower tiles of the factor
 
+  // Device memory of a problem comes from an arena the handle keeps across dvm_ba_set_problem calls: chunks are carved by a
+  // bump pointer and only RESET when the problem is replaced.  A fresh hipMalloc of this size class is mapped lazily -- the
+  // first optimize() after set_problem paid 18 ms of first-touch at 2 000 keyframes (0.5 GB of linearisation buffers) on
+  // top of 9 ms of iterations, every time, because allocations that large are not recycled by the runtime.
+  struct Chunk { uint8_t* base; size_t cap, used; };
+  std::vector<Chunk> chunks;
   template <typename T>
   int dalloc(T** p, size_t n) {
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    for (Chunk& c : chunks)
+      if (c.cap - c.used >= bytes) { *p = reinterpret_cast<T*>(c.base + c.used); c.used += bytes; return DVM_OK; }
+    size_t total = 0;
+    for (const Chunk& c : chunks) total += c.cap;
+    const size_t cap = std::max<size_t>({bytes, total, (size_t)8 << 20});
     void* q = nullptr;
-    int rc = hip_check(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc(ba)");
-    if (rc == DVM_OK) { allocs.push_back(q); *p = static_cast<T*>(q); }
-    return rc;
+    int rc = hip_check(hipMalloc(&q, cap), "hipMalloc(ba arena)");
+    if (rc != DVM_OK) {   // memory pressure: fall back to an exact-size chunk
+      rc = hip_check(hipMalloc(&q, bytes), "hipMalloc(ba)");
+      if (rc != DVM_OK) return rc;
+      chunks.push_back({static_cast<uint8_t*>(q), bytes, bytes});
+    } else {
+      chunks.push_back({static_cast<uint8_t*>(q), cap, bytes});
+    }
+    *p = reinterpret_cast<T*>(q);
+    return DVM_OK;
   }
   template <typename T>
   int upload(const T** dst, const std::vector<T>& v) {
@@ -76,10 +94,13 @@ struct dvm_ba {
     *dst = p;
     return rc;
   }
-  void free_problem() {
-    for (void* p : allocs) hipFree(p);
-    allocs.clear();
+  void free_problem() {           // the arena stays: the next problem reuses it
+    for (Chunk& c : chunks) c.used = 0;
     have_problem = false;
+  }
+  void release_arena() {
+    for (Chunk& c : chunks) hipFree(c.base);
+    chunks.clear();
   }
 };
 
@@ -112,6 +133,7 @@ void dvm_ba_destroy(dvm_ba* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   h->free_problem();
+  h->release_arena();
   if (h->d_fail) hipFree(h->d_fail);
   for (auto& e : h->pev) if (e) hipEventDestroy(e);
   if (h->d_counter) hipFree(h->d_counter);
@@ -231,30 +253,32 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   // the (edge of i1, edge of i2) pairs of every block, in landmark order: count, then fill (the order inside a block is the
   // one a map of vectors filled by the same loops had)
   std::vector<int32_t> blk_start(nblk + 1, 0);
-  auto for_each_pair = [&](auto&& fn) {
-    for (int l = 0; l < L; l++) {
-      if (world > 1 && l % world != rank) continue;
-      for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
-        const int k1 = pt_edges[a], c1 = e_cam[k1];
-        if (c1 < 0) continue;
-        const int i1 = cam_pos[c1];
-        for (int b = pt_start[l]; b < pt_start[l + 1]; b++) {
-          const int k2 = pt_edges[b], c2 = e_cam[k2];
-          if (c2 < 0) continue;
-          if (cam_pos[c2] > i1) continue;
-          fn(rank_of[pair_slot(std::max(c1, c2), std::min(c1, c2))], k1, k2);
-        }
+  struct PairRec { int32_t blk, k1, k2; };
+  std::vector<PairRec> recs;                       // one table lookup per pair: the count pass records what the fill pass needs
+  recs.reserve((size_t)E * 4);
+  for (int l = 0; l < L; l++) {
+    if (world > 1 && l % world != rank) continue;
+    for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
+      const int k1 = pt_edges[a], c1 = e_cam[k1];
+      if (c1 < 0) continue;
+      const int i1 = cam_pos[c1];
+      for (int b = pt_start[l]; b < pt_start[l + 1]; b++) {
+        const int k2 = pt_edges[b], c2 = e_cam[k2];
+        if (c2 < 0) continue;
+        if (cam_pos[c2] > i1) continue;
+        const int32_t blk = rank_of[pair_slot(std::max(c1, c2), std::min(c1, c2))];
+        blk_start[blk + 1]++;
+        recs.push_back({blk, k1, k2});
       }
     }
-  };
-  for_each_pair([&](int blk, int, int) { blk_start[blk + 1]++; });
+  }
   for (int r = 0; r < nblk; r++) blk_start[r + 1] += blk_start[r];
-  std::vector<int32_t> pair_k1(blk_start[nblk]), pair_k2(blk_start[nblk]), fill(blk_start.begin(), blk_start.end() - 1);
-  for_each_pair([&](int blk, int k1, int k2) {
-    const int t = fill[blk]++;
-    pair_k1[t] = world > 1 ? loc_of[k1] : k1;
-    pair_k2[t] = world > 1 ? loc_of[k2] : k2;
-  });
+  std::vector<int32_t> pair_k1(recs.size()), pair_k2(recs.size()), fill(blk_start.begin(), blk_start.end() - 1);
+  for (const PairRec& r : recs) {
+    const int t = fill[r.blk]++;
+    pair_k1[t] = world > 1 ? loc_of[r.k1] : r.k1;
+    pair_k2[t] = world > 1 ? loc_of[r.k2] : r.k2;
+  }
   mark("block pairs");
   if (world > 1) {
     std::vector<int32_t> ep(El), el(El);
@@ -353,7 +377,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(hip_check(hipMemcpy(V.poses_new, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
   ok(hip_check(hipMemcpy(V.points_new, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
   ok(hip_check(hipMemset(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double)), "memset"));
-  ok(hip_check(hipMemset(V.S, 0, (size_t)V.ldS * V.ldS * sizeof(double)), "memset"));   // once: trials clear only the non-zero tiles
+  // (S is NOT cleared as a whole: every kernel touches structurally non-zero tiles only, and a trial's prologue clears exactly
+  //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes --, and clearing it here cost up to 20 ms that surfaced
+  //  in the first optimize() after every set_problem.)
   ok(hip_check(hipMemset(V.e_chi2, 0, (size_t)E * sizeof(double)), "memset"));
   ok(hip_check(hipMemset(V.ytmp, 0, ((size_t)V.n_pad + 64) * sizeof(double)), "memset"));   // ticket + hand-off flags of the back substitution
   h->solve_seq = 0;
@@ -453,6 +479,10 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   hipStream_t s = h->stream;
   if (st) { std::memset(st, 0, sizeof(*st)); st->ms_structure = h->ms_structure; }
   const auto t0 = std::chrono::steady_clock::now();
+  const bool dbg_time = std::getenv("DVM_BA_DEBUG_SCHEDULE") != nullptr;
+  auto mark = [&](const char* what, int a) {
+    if (dbg_time) std::fprintf(stderr, "optimize: %-18s %d %9.3f ms\n", what, a, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
   enum { S_CHI = 0, S_TMPCHI = 1, S_SCALE = 2, S_MAXDIAG = 3, S_FAIL = 6 };
   auto pub = [&](int slot, int counter, bool publish, bool with_fail) {
     BaPublish p;
@@ -496,6 +526,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     rc = hip_check(hipGetLastError(), "bundle adjustment launch");
     if (rc == DVM_OK) rc = wait_seq(h, h->seq);
     if (rc != DVM_OK) return rc;
+    mark("linearised", it);
     if (h->prof) { hipEventSynchronize(h->pev[1]); float ms = 0; hipEventElapsedTime(&ms, h->pev[0], h->pev[1]); h->prof_ms[0] += ms; }
     if (sharded) {
       double v = h->h_vals[S_CHI];                       // chi2 of the local edges (read before the next publication rewrites the slots)
@@ -549,8 +580,10 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         if (h->prof) hipEventRecord(h->pev[3], s);
       }
       rc = hip_check(hipGetLastError(), "bundle adjustment launch");
+      mark("trial launched", it);
       if (rc == DVM_OK) rc = wait_seq(h, h->seq);
       if (rc != DVM_OK) return rc;
+      mark("trial published", it);
       if (h->prof) {
         hipEventSynchronize(h->pev[3]);
         for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, h->pev[k], h->pev[k + 1]); h->prof_ms[1 + k] += ms; }
@@ -599,6 +632,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     ba_launch_points_exchange(s, V, h->ar_buf, true);
   }
   DVM_HIP(hipStreamSynchronize(s));
+  mark("stream drained", it_done);
   if (st) {
     st->iterations = it_done; st->total_trials = trials_total; st->stop_reason = stop;
     st->chi2_final = chi_last; st->lambda_final = lambda;

@@ -94,8 +94,10 @@ struct Problem {
     const KeyFrame* any = cams.front();
     dvm_ba_camera cam = {any->fx, any->fy, any->cx, any->cy, huber_delta};
     static_assert(sizeof(bool) == 1, "the stop flag is polled as a byte");
-    dvm_ba* h = NULL;
-    check(dvm_ba_create(0, &h));
+    // one solver handle per calling thread, kept for the life of the thread: the handle recycles its device memory from one
+    // problem to the next (LocalMapping calls this every keyframe, LoopClosing's GBA thread occasionally)
+    static thread_local dvm_ba* h = NULL;
+    if (!h) check(dvm_ba_create(0, &h));
     dvm_ba_stats st;
     int rc = dvm_ba_set_problem(h, pose.data(), cam_fixed.data(), (int)cams.size(), xyz.data(), (int)pts.size(), edges.data(),
                                 (int)edges.size(), &cam);
@@ -104,7 +106,6 @@ struct Problem {
     chi2.resize(edges.size());
     in_front.resize(edges.size());
     if (rc == DVM_OK) rc = dvm_ba_edge_chi2(h, chi2.data(), in_front.data());
-    dvm_ba_destroy(h);
     check(rc);
   }
 };

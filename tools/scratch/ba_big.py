@@ -17,3 +17,7 @@ if len(sys.argv) > 3:
     eo = po.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
     t0 = time.perf_counter(); p_o, x_o, so, _ = po.ba_optimize(pr["poses"], pr["fixed"], pr["points"], eo, pr["intrinsics"], delta, 10); t1 = time.perf_counter()
     print("oracle s", t1 - t0, "trials equal", so["trials"] == st["trials"], "dP", np.abs(pg - p_o).max(), "dX", np.abs(xg - x_o).max())
+ba = capi.BundleAdjuster()
+ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+ba.profile(1); ba.optimize(10); prof = ba.profile(0); ba.close()
+print({k: (v / max(prof["trials"], 1) if k.startswith("ms") else v) for k, v in prof.items()})
