@@ -86,21 +86,48 @@ struct dvm_ba {
     *p = reinterpret_cast<T*>(q);
     return DVM_OK;
   }
+  // Uploads go through page-locked staging chunks (kept like the device arena) as asynchronous copies on the handle's
+  // stream: a synchronous hipMemcpy from pageable memory pins, copies and unpins per call, and the runtime was still busy
+  // with that when the first kernels of the following optimize() were launched (8-15 ms of launch delay at 2 000 keyframes).
+  struct HostChunk { uint8_t* base; size_t cap, used; };
+  std::vector<HostChunk> stage;
+  uint8_t* stage_alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    for (HostChunk& c : stage)
+      if (c.cap - c.used >= bytes) { uint8_t* p = c.base + c.used; c.used += bytes; return p; }
+    size_t total = 0;
+    for (const HostChunk& c : stage) total += c.cap;
+    const size_t cap = std::max<size_t>({bytes, total, (size_t)4 << 20});
+    void* q = nullptr;
+    if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    stage.push_back({static_cast<uint8_t*>(q), cap, bytes});
+    return static_cast<uint8_t*>(q);
+  }
+  int copy_in(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return DVM_OK;
+    uint8_t* st = stage_alloc(bytes);
+    if (!st) return hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");   // no pinned memory left: plain copy
+    std::memcpy(st, src, bytes);
+    return hip_check(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, stream), "upload");
+  }
   template <typename T>
   int upload(const T** dst, const std::vector<T>& v) {
     T* p = nullptr;
     int rc = dalloc(&p, v.size());
-    if (rc == DVM_OK && !v.empty()) rc = hip_check(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "upload");
+    if (rc == DVM_OK) rc = copy_in(p, v.data(), v.size() * sizeof(T));
     *dst = p;
     return rc;
   }
-  void free_problem() {           // the arena stays: the next problem reuses it
+  void free_problem() {           // the arenas stay: the next problem reuses them (callers have synchronised the stream)
     for (Chunk& c : chunks) c.used = 0;
+    for (HostChunk& c : stage) c.used = 0;
     have_problem = false;
   }
   void release_arena() {
     for (Chunk& c : chunks) hipFree(c.base);
     chunks.clear();
+    for (HostChunk& c : stage) hipHostFree(c.base);
+    stage.clear();
   }
 };
 
@@ -371,19 +398,18 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     for (int i = 0; i < 4; i++) q[i] /= nn;
   }
-  ok(hip_check(hipMemcpy(V.poses, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
-  ok(hip_check(hipMemcpy(V.points, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
+  ok(h->copy_in(V.poses, pn.data(), pn.size() * sizeof(double)));
+  ok(h->copy_in(V.points, points, 3 * (size_t)L * sizeof(double)));
   // the trial buffers start as copies: fixed cameras and unobserved landmarks are never rewritten
-  ok(hip_check(hipMemcpy(V.poses_new, pn.data(), pn.size() * sizeof(double), hipMemcpyHostToDevice), "upload poses"));
-  ok(hip_check(hipMemcpy(V.points_new, points, 3 * (size_t)L * sizeof(double), hipMemcpyHostToDevice), "upload points"));
-  ok(hip_check(hipMemset(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double)), "memset"));
+  ok(h->copy_in(V.poses_new, pn.data(), pn.size() * sizeof(double)));
+  ok(h->copy_in(V.points_new, points, 3 * (size_t)L * sizeof(double)));
+  ok(hip_check(hipMemsetAsync(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double), h->stream), "memset"));
   // (S is NOT cleared as a whole: every kernel touches structurally non-zero tiles only, and a trial's prologue clears exactly
-  //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes --, and clearing it here cost up to 20 ms that surfaced
-  //  in the first optimize() after every set_problem.)
-  ok(hip_check(hipMemset(V.e_chi2, 0, (size_t)E * sizeof(double)), "memset"));
-  ok(hip_check(hipMemset(V.ytmp, 0, ((size_t)V.n_pad + 64) * sizeof(double)), "memset"));   // ticket + hand-off flags of the back substitution
+  //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes.)
+  ok(hip_check(hipMemsetAsync(V.e_chi2, 0, (size_t)E * sizeof(double), h->stream), "memset"));
+  ok(hip_check(hipMemsetAsync(V.ytmp, 0, ((size_t)V.n_pad + 64) * sizeof(double), h->stream), "memset"));   // ticket + hand-off flags of the back substitution
   h->solve_seq = 0;
-  ok(hip_check(hipDeviceSynchronize(), "sync"));
+  ok(hip_check(hipStreamSynchronize(h->stream), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   mark("state + memsets + sync");
   h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
