@@ -43,34 +43,96 @@ static int need_device(int device) {
   return hip_check(hipSetDevice(device), "hipSetDevice");
 }
 
-// Host-pointer convenience paths: one device allocation holding every staged input and output of a call.
+// Host-pointer convenience paths.  Every calling thread keeps ONE staging context per device: a page-locked host buffer, a
+// device buffer (both grow-only) and a stream.  A call packs its inputs into the pinned buffer, sends them with one
+// asynchronous copy, launches its kernels on the legacy default stream -- the context's stream is a BLOCKING stream, so the
+// default stream orders itself behind the upload and the download behind the kernels --, fetches all outputs with one copy
+// and synchronises once.  (hipMalloc + a pageable hipMemcpy per array + hipDeviceSynchronize + hipFree per call made
+// ORBmatcher::SearchByProjection over 1 100 keypoints a 1.8 ms call next to a 0.44 ms CPU run of the same function.)
 namespace {
+struct StageCtx {
+  int device = -1;
+  hipStream_t s = nullptr;
+  uint8_t *h = nullptr, *d = nullptr;
+  size_t hcap = 0, dcap = 0;
+  void release() {
+    if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
+    if (h) hipHostFree(h);
+    if (d) hipFree(d);
+    s = nullptr; h = d = nullptr; hcap = dcap = 0;
+  }
+  int ensure(size_t bytes) {
+    int dev = 0;
+    int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (rc != DVM_OK) return rc;
+    if (dev != device) { release(); device = dev; }
+    if (!s) { rc = hip_check(hipStreamCreateWithFlags(&s, hipStreamDefault), "stream"); if (rc != DVM_OK) return rc; }
+    rc = hip_check(hipStreamSynchronize(s), "sync");   // the previous call's asynchronous traffic has left the buffers
+    if (rc != DVM_OK) return rc;
+    if (bytes > hcap) {
+      if (h) hipHostFree(h);
+      h = nullptr; hcap = 0;
+      const size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+      rc = hip_check(hipHostMalloc(reinterpret_cast<void**>(&h), cap, hipHostMallocDefault), "hipHostMalloc");
+      if (rc != DVM_OK) return rc;
+      hcap = cap;
+    }
+    if (bytes > dcap) {
+      if (d) hipFree(d);
+      d = nullptr; dcap = 0;
+      const size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+      rc = hip_check(hipMalloc(reinterpret_cast<void**>(&d), cap), "hipMalloc");
+      if (rc != DVM_OK) return rc;
+      dcap = cap;
+    }
+    return DVM_OK;
+  }
+  ~StageCtx() { release(); }
+};
+StageCtx& stage_ctx() {
+  thread_local StageCtx c;
+  return c;
+}
+
 struct Stage {
   struct Item { const void* src; void* dst; size_t bytes, off; };
   std::vector<Item> items;
-  size_t total = 0;
+  size_t total = 0, in_bytes = 0;
   uint8_t* d = nullptr;
+  StageCtx* ctx = nullptr;
   int add(const void* src, void* dst, size_t bytes) {
-    items.push_back({src, dst, bytes, total});
-    total += (std::max<size_t>(bytes, 16) + 15) & ~(size_t)15;
+    items.push_back({src, dst, bytes, 0});
     return (int)items.size() - 1;
   }
   int in(const void* src, size_t bytes) { return add(src, nullptr, src ? bytes : 0); }
   int out(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0); }
+  int scratch(size_t bytes) { return add(nullptr, nullptr, bytes); }   // device-only working memory
+  static size_t pad(size_t b) { return (std::max<size_t>(b, 16) + 255) & ~(size_t)255; }
+  // inputs first (one contiguous span to send), then outputs and scratch; ptr() is valid from here on
   int upload() {
-    int rc = hip_check(hipMalloc(&d, std::max<size_t>(total, 16)), "hipMalloc");
-    for (const Item& it : items)
-      if (rc == DVM_OK && it.src && it.bytes) rc = hip_check(hipMemcpy(d + it.off, it.src, it.bytes, hipMemcpyHostToDevice), "memcpy");
+    size_t off = 0;
+    for (Item& it : items) if (it.src) { it.off = off; off += pad(it.bytes); }
+    in_bytes = off;
+    for (Item& it : items) if (!it.src) { it.off = off; off += pad(it.bytes); }
+    total = off;
+    ctx = &stage_ctx();
+    int rc = ctx->ensure(total);
+    if (rc != DVM_OK) return rc;
+    d = ctx->d;
+    for (const Item& it : items) if (it.src && it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes);
+    if (in_bytes) rc = hip_check(hipMemcpyAsync(d, ctx->h, in_bytes, hipMemcpyHostToDevice, ctx->s), "upload");
     return rc;
   }
   template <class T> T* ptr(int i) const { return items[i].bytes ? reinterpret_cast<T*>(d + items[i].off) : nullptr; }
   int download() {
-    int rc = hip_check(hipDeviceSynchronize(), "sync");
-    for (const Item& it : items)
-      if (rc == DVM_OK && it.dst && it.bytes) rc = hip_check(hipMemcpy(it.dst, d + it.off, it.bytes, hipMemcpyDeviceToHost), "memcpy");
+    size_t lo = total, hi = 0;
+    for (const Item& it : items) if (it.dst && it.bytes) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.bytes); }
+    int rc = DVM_OK;
+    if (hi > lo) rc = hip_check(hipMemcpyAsync(ctx->h + lo, d + lo, hi - lo, hipMemcpyDeviceToHost, ctx->s), "download");
+    if (rc == DVM_OK) rc = hip_check(hipStreamSynchronize(ctx->s), "sync");
+    for (const Item& it : items) if (rc == DVM_OK && it.dst && it.bytes) std::memcpy(it.dst, ctx->h + it.off, it.bytes);
     return rc;
   }
-  ~Stage() { if (d) hipFree(d); }
 };
 }  // namespace
 
@@ -377,14 +439,6 @@ static int frame_bounds(dvm_frame* f, float minX, float maxX, float minY, float 
   V.hInv = static_cast<float>(48) / static_cast<float>(maxY - minY);
   return DVM_OK;
 }
-static int frame_scratch(dvm_frame* f, size_t bytes) {
-  if (bytes <= f->scratch_bytes) return DVM_OK;
-  if (f->d_scratch) hipFree(f->d_scratch);
-  f->d_scratch = nullptr; f->scratch_bytes = 0;
-  int rc = hip_check(hipMalloc(&f->d_scratch, bytes), "hipMalloc");
-  if (rc == DVM_OK) f->scratch_bytes = bytes;
-  return rc;
-}
 int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, const int32_t* d_n,
                     float minX, float maxX, float minY, float maxY, int on_device, void* stream) {
   if (!f || slot < 0 || slot >= f->slots || n < 0 || n > f->cap || (n && (!kps || !desc))) return DVM_ERR_INVALID;
@@ -396,19 +450,14 @@ int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8
     launch_frame_build((hipStream_t)stream, reinterpret_cast<const dvm_keypoint_pod*>(kps), 0, desc, 0, n, d_n, f->view, slot, 1);
     return hip_check(hipGetLastError(), "frame_build launch");
   }
-  const size_t kb = (size_t)std::max(n, 1) * sizeof(dvm_keypoint), db = (size_t)std::max(n, 1) * 32;
-  rc = frame_scratch(f, kb + db);
+  // the keypoints / descriptors travel through the calling thread's staging context (asynchronous copy on its blocking
+  // stream); the kernel follows on the default stream; nothing waits: whatever uses the grid next is ordered behind it
+  Stage st;
+  const int iK = st.in(kps, (size_t)n * sizeof(dvm_keypoint)), iD = st.in(desc, (size_t)n * 32);
+  rc = st.upload();
   if (rc != DVM_OK) return rc;
-  uint8_t* base = static_cast<uint8_t*>(f->d_scratch);
-  if (n) {
-    rc = hip_check(hipMemcpy(base, kps, (size_t)n * sizeof(dvm_keypoint), hipMemcpyHostToDevice), "memcpy");
-    if (rc == DVM_OK) rc = hip_check(hipMemcpy(base + kb, desc, (size_t)n * 32, hipMemcpyHostToDevice), "memcpy");
-    if (rc != DVM_OK) return rc;
-  }
-  launch_frame_build(nullptr, reinterpret_cast<const dvm_keypoint_pod*>(base), 0, base + kb, 0, n, nullptr, f->view, slot, 1);
-  rc = hip_check(hipGetLastError(), "frame_build launch");
-  if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "sync");
-  return rc;
+  launch_frame_build(nullptr, st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iD), 0, n, nullptr, f->view, slot, 1);
+  return hip_check(hipGetLastError(), "frame_build launch");
 }
 int dvm_frame_overflows(dvm_frame* f, int32_t* count) {
   if (!f || !count) return DVM_ERR_INVALID;
@@ -446,28 +495,15 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
   }
   // host convenience path: stage queries, run, copy back
   const size_t qb = (size_t)nq;
-  const size_t off_desc = 0, off_x = off_desc + qb * 32, off_y = off_x + qb * 4, off_r = off_y + qb * 4,
-               off_min = off_r + qb * 4, off_max = off_min + qb * 4, off_out = off_max + qb * 4,
-               off_skip = off_out + qb * sizeof(dvm_match), total = off_skip + (size_t)train->cap;
-  uint8_t* d = nullptr;
-  rc = hip_check(hipMalloc(&d, total), "hipMalloc");
+  Stage st;
+  const int iD = st.in(qdesc, qb * 32), iX = st.in(qx, qb * 4), iY = st.in(qy, qb * 4), iR = st.in(qr, qb * 4), iMin = st.in(qmin, qb * 4),
+            iMax = st.in(qmax, qb * 4), iS = st.in(skip, (size_t)train->cap), oM = st.out(out, qb * sizeof(dvm_match));
+  rc = st.upload();
   if (rc != DVM_OK) return rc;
-  auto up = [&](size_t off, const void* src, size_t bytes) {
-    if (rc == DVM_OK) rc = hip_check(hipMemcpy(d + off, src, bytes, hipMemcpyHostToDevice), "memcpy");
-  };
-  up(off_desc, qdesc, qb * 32); up(off_x, qx, qb * 4); up(off_y, qy, qb * 4); up(off_r, qr, qb * 4);
-  up(off_min, qmin, qb * 4); up(off_max, qmax, qb * 4);
-  if (skip) up(off_skip, skip, (size_t)train->cap);
-  if (rc == DVM_OK) {
-    launch_match_window(nullptr, train->view, slot, skip ? d + off_skip : nullptr, d + off_desc,
-                        reinterpret_cast<float*>(d + off_x), reinterpret_cast<float*>(d + off_y),
-                        reinterpret_cast<float*>(d + off_r), reinterpret_cast<int32_t*>(d + off_min),
-                        reinterpret_cast<int32_t*>(d + off_max), nq, nullptr, nq, reinterpret_cast<dvm_match_pod*>(d + off_out));
-    rc = hip_check(hipGetLastError(), "match launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, d + off_out, qb * sizeof(dvm_match), hipMemcpyDeviceToHost), "memcpy");
-  hipFree(d);
-  return rc;
+  launch_match_window(nullptr, train->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
+                      st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, nullptr, nq, st.ptr<dvm_match_pod>(oM));
+  rc = hip_check(hipGetLastError(), "match launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const float* normal, const float* min_dist,
@@ -484,18 +520,16 @@ int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const floa
     launch_is_in_frustum((hipStream_t)stream, F, P, normal, min_dist, max_dist, n, viewing_cos_limit, reinterpret_cast<TrackPoint*>(out));
     return hip_check(hipGetLastError(), "is_in_frustum launch");
   }
-  const size_t N = (size_t)n, total = N * (3 + 3 + 1 + 1) * 4 + N * sizeof(TrackPoint);
-  uint8_t* d = nullptr;
-  int rc = hip_check(hipMalloc(&d, total), "hipMalloc");
+  const size_t N = (size_t)n;
+  Stage st;
+  const int iP = st.in(P, N * 12), iN = st.in(normal, N * 12), imin = st.in(min_dist, N * 4), imax = st.in(max_dist, N * 4),
+            oT = st.out(out, N * sizeof(TrackPoint));
+  int rc = st.upload();
   if (rc != DVM_OK) return rc;
-  float* dP = reinterpret_cast<float*>(d); float* dN = dP + 3 * N; float* dmin = dN + 3 * N; float* dmax = dmin + N;
-  TrackPoint* dout = reinterpret_cast<TrackPoint*>(dmax + N);
-  auto up = [&](void* dst, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "memcpy"); };
-  up(dP, P, N * 12); up(dN, normal, N * 12); up(dmin, min_dist, N * 4); up(dmax, max_dist, N * 4);
-  if (rc == DVM_OK) { launch_is_in_frustum(nullptr, F, dP, dN, dmin, dmax, n, viewing_cos_limit, dout); rc = hip_check(hipGetLastError(), "launch"); }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, dout, N * sizeof(TrackPoint), hipMemcpyDeviceToHost), "memcpy");
-  hipFree(d);
-  return rc;
+  launch_is_in_frustum(nullptr, F, st.ptr<float>(iP), st.ptr<float>(iN), st.ptr<float>(imin), st.ptr<float>(imax), n, viewing_cos_limit,
+                       st.ptr<TrackPoint>(oT));
+  rc = hip_check(hipGetLastError(), "launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_undistort_keypoints(const dvm_distortion* cam, const dvm_keypoint* kps_in, dvm_keypoint* kps_out, int n, int on_device, void* stream) {
@@ -512,14 +546,13 @@ int dvm_undistort_keypoints(const dvm_distortion* cam, const dvm_keypoint* kps_i
     launch_undistort_keypoints((hipStream_t)stream, C, reinterpret_cast<const float*>(kps_in), reinterpret_cast<float*>(kps_out), n);
     return hip_check(hipGetLastError(), "undistort launch");
   }
-  float* d = nullptr;
-  int rc = hip_check(hipMalloc(&d, (size_t)n * 28), "hipMalloc");
+  Stage st;
+  const int iK = st.in(kps_in, (size_t)n * 28), oK = st.out(kps_out, (size_t)n * 28);
+  int rc = st.upload();
   if (rc != DVM_OK) return rc;
-  rc = hip_check(hipMemcpy(d, kps_in, (size_t)n * 28, hipMemcpyHostToDevice), "memcpy");
-  if (rc == DVM_OK) { launch_undistort_keypoints(nullptr, C, d, d, n); rc = hip_check(hipGetLastError(), "undistort launch"); }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(kps_out, d, (size_t)n * 28, hipMemcpyDeviceToHost), "memcpy");
-  hipFree(d);
-  return rc;
+  launch_undistort_keypoints(nullptr, C, st.ptr<float>(iK), st.ptr<float>(oK), n);
+  rc = hip_check(hipGetLastError(), "undistort launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_image_bounds(const dvm_distortion* cam, int cols, int rows, float bounds[4]) {
@@ -551,22 +584,14 @@ int dvm_match_lists(const uint8_t* tdesc, int nt, const uint8_t* qdesc, int nq, 
   }
   const int ncand = off[nq];
   if (ncand < 0) return DVM_ERR_INVALID;
-  const size_t b_t = (size_t)std::max(nt, 1) * 32, b_q = (size_t)nq * 32, b_off = (size_t)(nq + 1) * 4, b_c = (size_t)std::max(ncand, 1) * 4,
-               b_out = (size_t)nq * sizeof(dvm_match);
-  const size_t o_t = 0, o_q = o_t + b_t, o_off = o_q + b_q, o_c = o_off + b_off, o_out = (o_c + b_c + 15) & ~(size_t)15, total = o_out + b_out;
-  uint8_t* d = nullptr;
-  int rc = hip_check(hipMalloc(&d, total), "hipMalloc");
+  Stage st;
+  const int iT = st.in(tdesc, (size_t)nt * 32), iQ = st.in(qdesc, (size_t)nq * 32), iO = st.in(off, (size_t)(nq + 1) * 4),
+            iC = st.in(cand, (size_t)ncand * 4), oM = st.out(out, (size_t)nq * sizeof(dvm_match));
+  int rc = st.upload();
   if (rc != DVM_OK) return rc;
-  auto up = [&](size_t o, const void* src, size_t bytes) { if (rc == DVM_OK && bytes) rc = hip_check(hipMemcpy(d + o, src, bytes, hipMemcpyHostToDevice), "memcpy"); };
-  up(o_t, tdesc, (size_t)nt * 32); up(o_q, qdesc, b_q); up(o_off, off, b_off); up(o_c, cand, (size_t)ncand * 4);
-  if (rc == DVM_OK) {
-    launch_match_lists(nullptr, d + o_t, d + o_q, reinterpret_cast<int32_t*>(d + o_off), reinterpret_cast<int32_t*>(d + o_c), nq,
-                       reinterpret_cast<dvm_match_pod*>(d + o_out));
-    rc = hip_check(hipGetLastError(), "match_lists launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(out, d + o_out, b_out, hipMemcpyDeviceToHost), "memcpy");
-  hipFree(d);
-  return rc;
+  launch_match_lists(nullptr, st.ptr<uint8_t>(iT), st.ptr<uint8_t>(iQ), st.ptr<int32_t>(iO), st.ptr<int32_t>(iC), nq, st.ptr<dvm_match_pod>(oM));
+  rc = hip_check(hipGetLastError(), "match_lists launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_project_search(const dvm_frame* train, int slot, const uint8_t* skip, const dvm_kf_camera* cam, const float* P,

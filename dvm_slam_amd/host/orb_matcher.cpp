@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace dvm_host {
@@ -56,7 +59,21 @@ struct HostGrid {
 }  // namespace
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri, int device) : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
-ORBmatcher::~ORBmatcher() { if (grid_) dvm_frame_destroy(grid_); }
+// The device grid belongs to the calling THREAD, not to the matcher object: ORB-SLAM3 constructs an ORBmatcher as a local in
+// most of its callers (one per tracked frame), and creating / destroying a frame handle is a dozen device allocations.
+namespace {
+struct GridCache {
+  dvm_frame* g = nullptr;
+  int cap = 0, device = -1;
+  ~GridCache() { if (g) dvm_frame_destroy(g); }
+};
+GridCache& grid_cache() {
+  thread_local GridCache c;
+  return c;
+}
+}  // namespace
+
+ORBmatcher::~ORBmatcher() {}
 
 int ORBmatcher::DescriptorDistance(const uint8_t* a, const uint8_t* b) {
   int dist = 0;
@@ -82,6 +99,9 @@ void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, int L, int& ind1, i
 }
 
 int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const MapPointPOD* MPs, float th, bool bMono) {
+  const auto T0 = std::chrono::steady_clock::now();
+  const bool dbg = std::getenv("DVM_HOST_DEBUG_TIMING") != nullptr;
+  auto mark = [&](const char* w) { if (dbg) std::fprintf(stderr, "SBP %-14s %8.3f ms\n", w, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); };
   (void)bMono;  // DVM-SLAM is monocular (src/slam_system/src/ros_mono.cpp:19): bForward = bBackward = false
   int nmatches = 0;
   last_requeried = 0;
@@ -117,8 +137,10 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   if (nq == 0) return 0;
 
   // ---- one batched device search against CurrentFrame's grid (claims known at entry are masked)
+  mark("queries");
   int rc = ensure_grid(Cur);
   if (rc != DVM_OK) return rc;
+  mark("grid");
   std::vector<uint8_t> claimed(grid_cap_, 0);
   for (int j = 0; j < Cur.N; j++)
     if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) claimed[j] = 1;
@@ -126,6 +148,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   rc = dvm_match_window(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
                         nullptr, res.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
+  mark("match");
 
   // ---- sequential epilogue in query order (:1613-1664): a keypoint claimed by an earlier match of THIS call is
   // skipped by later queries, so a result whose best candidate has been claimed meanwhile is recomputed
@@ -168,17 +191,22 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
       if (i != ind1 && i != ind2 && i != ind3)
         for (int idx : rotHist[i]) { Cur.mvpMapPoints[idx] = -1; nmatches--; }
   }
+  mark("epilogue");
   return nmatches;
 }
 
 int ORBmatcher::ensure_grid(const FrameView& F) {
-  if (!grid_ || grid_cap_ < F.N) {
-    if (grid_) dvm_frame_destroy(grid_);
-    grid_ = nullptr;
-    grid_cap_ = std::max(2048, F.N);
-    int rc = dvm_frame_create(device_, grid_cap_, 1, &grid_);
-    if (rc != DVM_OK) return rc;
+  GridCache& c = grid_cache();
+  if (!c.g || c.cap < F.N || c.device != device_) {
+    if (c.g) dvm_frame_destroy(c.g);
+    c.g = nullptr;
+    c.cap = std::max(2048, F.N);
+    c.device = device_;
+    int rc = dvm_frame_create(device_, c.cap, 1, &c.g);
+    if (rc != DVM_OK) { c.cap = 0; return rc; }
   }
+  grid_ = c.g;
+  grid_cap_ = c.cap;
   return dvm_frame_build(grid_, 0, F.mvKeysUn, F.mDescriptors, F.N, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY, 0, nullptr);
 }
 
