@@ -21,6 +21,7 @@
 #include "../../include/dvmslam_hip.h"
 #include "ba_kernels.h"
 #include "ba_ordering.h"
+#include "host_stage.h"
 #include "orb_pipeline.h"  // set_error / hip_check / DVM_HIP
 
 using namespace dvm;
@@ -703,27 +704,17 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
   for (int f = 0; f < batch; f++) if (n[f] < 0 || n[f] > stride) { set_error("n[f] out of range"); return DVM_ERR_INVALID; }
   DVM_HIP(hipSetDevice(device));
   const size_t B = (size_t)batch, S = (size_t)stride;
-  const size_t b_pose = B * 7 * 8, b_x = B * S * 3 * 8, b_o = B * S * 2 * 8, b_w = B * S * 8, b_n = B * 4, b_out = B * S, b_chi = B * S * 8;
-  const size_t off_pose = 0, off_x = off_pose + b_pose, off_o = off_x + b_x, off_w = off_o + b_o, off_pout = off_w + b_w,
-               off_chi = off_pout + b_pose, off_n = off_chi + b_chi, off_nin = off_n + b_n, off_outl = off_nin + b_n,
-               total = off_outl + b_out;
-  uint8_t* d = nullptr;
-  DVM_HIP(hipMalloc(&d, total));
-  int rc = DVM_OK;
-  auto up = [&](size_t off, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(d + off, src, bytes, hipMemcpyHostToDevice), "upload"); };
-  up(off_pose, pose_in, b_pose); up(off_x, Xw, b_x); up(off_o, obs, b_o); up(off_w, inv_sigma2, b_w); up(off_n, n, b_n);
-  if (rc == DVM_OK) {
-    ba_launch_pose_optimize(nullptr, (const double*)(d + off_pose), (const double*)(d + off_x), (const double*)(d + off_o),
-                            (const double*)(d + off_w), (const int32_t*)(d + off_n), stride, batch, cam->fx, cam->fy, cam->cx,
-                            cam->cy, (double*)(d + off_pout), d + off_outl, (int32_t*)(d + off_nin), (double*)(d + off_chi));
-    rc = hip_check(hipGetLastError(), "pose_optimize launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "pose_optimize sync");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(pose_out, d + off_pout, b_pose, hipMemcpyDeviceToHost), "download");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(outlier, d + off_outl, b_out, hipMemcpyDeviceToHost), "download");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(n_inliers, d + off_nin, b_n, hipMemcpyDeviceToHost), "download");
-  hipFree(d);
-  return rc;
+  Stage st;   // the calling thread's staging context: one upload, one download, one synchronisation (host_stage.h)
+  const int iP = st.in(pose_in, B * 7 * 8), iX = st.in(Xw, B * S * 3 * 8), iO = st.in(obs, B * S * 2 * 8), iW = st.in(inv_sigma2, B * S * 8),
+            iN = st.in(n, B * 4), oP = st.out(pose_out, B * 7 * 8), oL = st.out(outlier, B * S), oI = st.out(n_inliers, B * 4),
+            sC = st.scratch(B * S * 8);
+  int rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  ba_launch_pose_optimize(nullptr, st.ptr<double>(iP), st.ptr<double>(iX), st.ptr<double>(iO), st.ptr<double>(iW), st.ptr<int32_t>(iN), stride,
+                          batch, cam->fx, cam->fy, cam->cx, cam->cy, st.ptr<double>(oP), st.ptr<uint8_t>(oL), st.ptr<int32_t>(oI),
+                          st.ptr<double>(sC));
+  rc = hip_check(hipGetLastError(), "pose_optimize launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c, const double* P2c, const double* obs1,

@@ -43,98 +43,7 @@ static int need_device(int device) {
   return hip_check(hipSetDevice(device), "hipSetDevice");
 }
 
-// Host-pointer convenience paths.  Every calling thread keeps ONE staging context per device: a page-locked host buffer, a
-// device buffer (both grow-only) and a stream.  A call packs its inputs into the pinned buffer, sends them with one
-// asynchronous copy, launches its kernels on the legacy default stream -- the context's stream is a BLOCKING stream, so the
-// default stream orders itself behind the upload and the download behind the kernels --, fetches all outputs with one copy
-// and synchronises once.  (hipMalloc + a pageable hipMemcpy per array + hipDeviceSynchronize + hipFree per call made
-// ORBmatcher::SearchByProjection over 1 100 keypoints a 1.8 ms call next to a 0.44 ms CPU run of the same function.)
-namespace {
-struct StageCtx {
-  int device = -1;
-  hipStream_t s = nullptr;
-  uint8_t *h = nullptr, *d = nullptr;
-  size_t hcap = 0, dcap = 0;
-  void release() {
-    if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
-    if (h) hipHostFree(h);
-    if (d) hipFree(d);
-    s = nullptr; h = d = nullptr; hcap = dcap = 0;
-  }
-  int ensure(size_t bytes) {
-    int dev = 0;
-    int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
-    if (rc != DVM_OK) return rc;
-    if (dev != device) { release(); device = dev; }
-    if (!s) { rc = hip_check(hipStreamCreateWithFlags(&s, hipStreamDefault), "stream"); if (rc != DVM_OK) return rc; }
-    rc = hip_check(hipStreamSynchronize(s), "sync");   // the previous call's asynchronous traffic has left the buffers
-    if (rc != DVM_OK) return rc;
-    if (bytes > hcap) {
-      if (h) hipHostFree(h);
-      h = nullptr; hcap = 0;
-      const size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
-      rc = hip_check(hipHostMalloc(reinterpret_cast<void**>(&h), cap, hipHostMallocDefault), "hipHostMalloc");
-      if (rc != DVM_OK) return rc;
-      hcap = cap;
-    }
-    if (bytes > dcap) {
-      if (d) hipFree(d);
-      d = nullptr; dcap = 0;
-      const size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
-      rc = hip_check(hipMalloc(reinterpret_cast<void**>(&d), cap), "hipMalloc");
-      if (rc != DVM_OK) return rc;
-      dcap = cap;
-    }
-    return DVM_OK;
-  }
-  ~StageCtx() { release(); }
-};
-StageCtx& stage_ctx() {
-  thread_local StageCtx c;
-  return c;
-}
-
-struct Stage {
-  struct Item { const void* src; void* dst; size_t bytes, off; };
-  std::vector<Item> items;
-  size_t total = 0, in_bytes = 0;
-  uint8_t* d = nullptr;
-  StageCtx* ctx = nullptr;
-  int add(const void* src, void* dst, size_t bytes) {
-    items.push_back({src, dst, bytes, 0});
-    return (int)items.size() - 1;
-  }
-  int in(const void* src, size_t bytes) { return add(src, nullptr, src ? bytes : 0); }
-  int out(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0); }
-  int scratch(size_t bytes) { return add(nullptr, nullptr, bytes); }   // device-only working memory
-  static size_t pad(size_t b) { return (std::max<size_t>(b, 16) + 255) & ~(size_t)255; }
-  // inputs first (one contiguous span to send), then outputs and scratch; ptr() is valid from here on
-  int upload() {
-    size_t off = 0;
-    for (Item& it : items) if (it.src) { it.off = off; off += pad(it.bytes); }
-    in_bytes = off;
-    for (Item& it : items) if (!it.src) { it.off = off; off += pad(it.bytes); }
-    total = off;
-    ctx = &stage_ctx();
-    int rc = ctx->ensure(total);
-    if (rc != DVM_OK) return rc;
-    d = ctx->d;
-    for (const Item& it : items) if (it.src && it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes);
-    if (in_bytes) rc = hip_check(hipMemcpyAsync(d, ctx->h, in_bytes, hipMemcpyHostToDevice, ctx->s), "upload");
-    return rc;
-  }
-  template <class T> T* ptr(int i) const { return items[i].bytes ? reinterpret_cast<T*>(d + items[i].off) : nullptr; }
-  int download() {
-    size_t lo = total, hi = 0;
-    for (const Item& it : items) if (it.dst && it.bytes) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.bytes); }
-    int rc = DVM_OK;
-    if (hi > lo) rc = hip_check(hipMemcpyAsync(ctx->h + lo, d + lo, hi - lo, hipMemcpyDeviceToHost, ctx->s), "download");
-    if (rc == DVM_OK) rc = hip_check(hipStreamSynchronize(ctx->s), "sync");
-    for (const Item& it : items) if (rc == DVM_OK && it.dst && it.bytes) std::memcpy(it.dst, ctx->h + it.off, it.bytes);
-    return rc;
-  }
-};
-}  // namespace
+#include "host_stage.h"
 
 extern "C" {
 
