@@ -275,22 +275,13 @@ int dvm_hamming_matrix(const uint8_t* A, int nA, const uint8_t* B, int nB, uint1
     return hip_check(hipGetLastError(), "hamming launch");
   }
   if (rc != DVM_OK) return rc;
-  uint8_t *dA = nullptr, *dB = nullptr;
-  uint16_t* dD = nullptr;
-  rc = hip_check(hipMalloc(&dA, (size_t)nA * 32), "hipMalloc");
-  if (rc == DVM_OK) rc = hip_check(hipMalloc(&dB, (size_t)nB * 32), "hipMalloc");
-  if (rc == DVM_OK) rc = hip_check(hipMalloc(&dD, (size_t)nA * nB * 2), "hipMalloc");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(dA, A, (size_t)nA * 32, hipMemcpyHostToDevice), "memcpy");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(dB, B, (size_t)nB * 32, hipMemcpyHostToDevice), "memcpy");
-  if (rc == DVM_OK) {
-    launch_hamming_matrix(nullptr, dA, nA, dB, nB, dD);
-    rc = hip_check(hipGetLastError(), "hamming launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(D, dD, (size_t)nA * nB * 2, hipMemcpyDeviceToHost), "memcpy");
-  if (dA) hipFree(dA);
-  if (dB) hipFree(dB);
-  if (dD) hipFree(dD);
-  return rc;
+  Stage st;
+  const int iA = st.in(A, (size_t)nA * 32), iB = st.in(B, (size_t)nB * 32), oD = st.out(D, (size_t)nA * nB * 2);
+  rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_hamming_matrix(nullptr, st.ptr<uint8_t>(iA), nA, st.ptr<uint8_t>(iB), nB, st.ptr<uint16_t>(oD));
+  rc = hip_check(hipGetLastError(), "hamming launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 int dvm_frame_create(int device, int capacity, int slots, dvm_frame** out) {
@@ -733,22 +724,14 @@ int dvm_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int n_p
   }
   const int total = off[n_points];
   if (total < 0) return DVM_ERR_INVALID;
-  const size_t b_d = (size_t)std::max(total, 1) * 32, b_off = (size_t)(n_points + 1) * 4, b_o = (size_t)n_points * 4;
-  const size_t o_d = 0, o_off = o_d + b_d, o_i = o_off + ((b_off + 15) & ~(size_t)15), o_m = o_i + ((b_o + 15) & ~(size_t)15), tot = o_m + b_o;
-  uint8_t* d = nullptr;
-  int rc = hip_check(hipMalloc(&d, tot), "hipMalloc");
+  Stage st;
+  const int iD = st.in(desc, (size_t)total * 32), iO = st.in(off, (size_t)(n_points + 1) * 4), oI = st.out(best_idx, (size_t)n_points * 4),
+            oM = st.out(best_median, (size_t)n_points * 4);
+  int rc = st.upload();
   if (rc != DVM_OK) return rc;
-  if (total > 0) rc = hip_check(hipMemcpy(d + o_d, desc, (size_t)total * 32, hipMemcpyHostToDevice), "memcpy");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(d + o_off, off, b_off, hipMemcpyHostToDevice), "memcpy");
-  if (rc == DVM_OK) {
-    launch_distinctive(nullptr, d + o_d, reinterpret_cast<int32_t*>(d + o_off), n_points, reinterpret_cast<int32_t*>(d + o_i),
-                       reinterpret_cast<int32_t*>(d + o_m));
-    rc = hip_check(hipGetLastError(), "distinctive launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(best_idx, d + o_i, b_o, hipMemcpyDeviceToHost), "memcpy");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(best_median, d + o_m, b_o, hipMemcpyDeviceToHost), "memcpy");
-  hipFree(d);
-  return rc;
+  launch_distinctive(nullptr, st.ptr<uint8_t>(iD), st.ptr<int32_t>(iO), n_points, st.ptr<int32_t>(oI), st.ptr<int32_t>(oM));
+  rc = hip_check(hipGetLastError(), "distinctive launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 struct dvm_vocab {
