@@ -729,32 +729,20 @@ int dvm_optimize_sim3(int device, double* S12, int fix_scale, const double* P1c,
   if (device < 0 || device >= ndev) return DVM_ERR_INVALID;
   DVM_HIP(hipSetDevice(device));
   const size_t n = (size_t)N;
-  // doubles: S12[8] K[8] P1c[3n] P2c[3n] obs1[2n] obs2[2n] w1[n] w2[n] chi[2n]; then int32 nin; bytes inlier[n] flags[2n]
-  const size_t nd = 16 + 14 * n;
-  const size_t total = nd * 8 + 8 + 3 * n;
-  uint8_t* d = nullptr;
-  DVM_HIP(hipMalloc(&d, total));
-  double* dd = reinterpret_cast<double*>(d);
-  double *dS = dd, *dK = dd + 8, *dP1 = dd + 16, *dP2 = dP1 + 3 * n, *dO1 = dP2 + 3 * n, *dO2 = dO1 + 2 * n, *dW1 = dO2 + 2 * n,
-         *dW2 = dW1 + n, *dChi = dW2 + n;
-  int32_t* dNin = reinterpret_cast<int32_t*>(dd + nd);
-  uint8_t* dInl = reinterpret_cast<uint8_t*>(dNin) + 8;
-  uint8_t* dFlags = dInl + n;
-  int rc = DVM_OK;
-  auto up = [&](void* dst, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload"); };
-  double K[8];
+  double K[8], S_out[8];
   std::memcpy(K, K1, 32); std::memcpy(K + 4, K2, 32);
-  up(dS, S12, 64); up(dK, K, 64); up(dP1, P1c, 24 * n); up(dP2, P2c, 24 * n); up(dO1, obs1, 16 * n); up(dO2, obs2, 16 * n);
-  up(dW1, w1, 8 * n); up(dW2, w2, 8 * n);
-  if (rc == DVM_OK) {
-    ba_launch_optimize_sim3(nullptr, dS, fix_scale, dP1, dP2, dO1, dO2, dW1, dW2, N, dK, th2, dInl, dNin, dChi, dFlags);
-    rc = hip_check(hipGetLastError(), "optimize_sim3 launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipDeviceSynchronize(), "optimize_sim3 sync");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(n_inliers, dNin, 4, hipMemcpyDeviceToHost), "download");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(inlier, dInl, n, hipMemcpyDeviceToHost), "download");
-  if (rc == DVM_OK && *n_inliers > 0) rc = hip_check(hipMemcpy(S12, dS, 64, hipMemcpyDeviceToHost), "download");
-  hipFree(d);
+  Stage st;   // S12 is refined in place on the device: staged in, fetched into S_out, handed over only if the solve succeeded
+  const int ioS = st.add(S12, S_out, 64), iK = st.in(K, 64), iP1 = st.in(P1c, 24 * n), iP2 = st.in(P2c, 24 * n), iO1 = st.in(obs1, 16 * n),
+            iO2 = st.in(obs2, 16 * n), iW1 = st.in(w1, 8 * n), iW2 = st.in(w2, 8 * n), oN = st.out(n_inliers, 4), oI = st.out(inlier, n),
+            sChi = st.scratch(16 * n), sFl = st.scratch(2 * n);
+  int rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  ba_launch_optimize_sim3(nullptr, st.ptr<double>(ioS), fix_scale, st.ptr<double>(iP1), st.ptr<double>(iP2), st.ptr<double>(iO1), st.ptr<double>(iO2),
+                          st.ptr<double>(iW1), st.ptr<double>(iW2), N, st.ptr<double>(iK), th2, st.ptr<uint8_t>(oI), st.ptr<int32_t>(oN),
+                          st.ptr<double>(sChi), st.ptr<uint8_t>(sFl));
+  rc = hip_check(hipGetLastError(), "optimize_sim3 launch");
+  if (rc == DVM_OK) rc = st.download();
+  if (rc == DVM_OK && *n_inliers > 0) std::memcpy(S12, S_out, 64);
   return rc;
 }
 
@@ -771,29 +759,17 @@ int dvm_sim3_hypotheses(int device, const float* P1c, const float* P2c, const fl
   if (device < 0 || device >= ndev) return DVM_ERR_INVALID;
   DVM_HIP(hipSetDevice(device));
   const size_t n = (size_t)N, hh = (size_t)H;
-  // floats: P1c[3n] P2c[3n] e1[n] e2[n] K[8] T12[13h]; int32: triples[3h] nin[h]; bytes: mask[h*n]
-  const size_t nf = 8 * n + 8 + 13 * hh, ni = 4 * hh;
-  uint8_t* d = nullptr;
-  DVM_HIP(hipMalloc(&d, nf * 4 + ni * 4 + hh * n + 16));
-  float* df = reinterpret_cast<float*>(d);
-  float *dP1 = df, *dP2 = df + 3 * n, *dE1 = df + 6 * n, *dE2 = df + 7 * n, *dK = df + 8 * n, *dT = dK + 8;
-  int32_t* dTri = reinterpret_cast<int32_t*>(df + nf);
-  int32_t* dNin = dTri + 3 * hh;
-  uint8_t* dMask = reinterpret_cast<uint8_t*>(dNin + hh);
-  int rc = DVM_OK;
-  auto up = [&](void* dst, const void* src, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload"); };
   float K[8];
   std::memcpy(K, K1, 16); std::memcpy(K + 4, K2, 16);
-  up(dP1, P1c, 12 * n); up(dP2, P2c, 12 * n); up(dE1, max_err1, 4 * n); up(dE2, max_err2, 4 * n); up(dK, K, 32); up(dTri, triples, 12 * hh);
-  if (rc == DVM_OK) {
-    ba_launch_sim3_hypotheses(nullptr, dP1, dP2, dE1, dE2, N, dK, dTri, H, fix_scale, dT, dNin, dMask);
-    rc = hip_check(hipGetLastError(), "sim3_hypotheses launch");
-  }
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(T12, dT, 52 * hh, hipMemcpyDeviceToHost), "download");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(n_inliers, dNin, 4 * hh, hipMemcpyDeviceToHost), "download");
-  if (rc == DVM_OK) rc = hip_check(hipMemcpy(inlier_mask, dMask, hh * n, hipMemcpyDeviceToHost), "download");
-  hipFree(d);
-  return rc;
+  Stage st;
+  const int iP1 = st.in(P1c, 12 * n), iP2 = st.in(P2c, 12 * n), iE1 = st.in(max_err1, 4 * n), iE2 = st.in(max_err2, 4 * n), iK = st.in(K, 32),
+            iT = st.in(triples, 12 * hh), oT = st.out(T12, 52 * hh), oN = st.out(n_inliers, 4 * hh), oM = st.out(inlier_mask, hh * n);
+  int rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  ba_launch_sim3_hypotheses(nullptr, st.ptr<float>(iP1), st.ptr<float>(iP2), st.ptr<float>(iE1), st.ptr<float>(iE2), N, st.ptr<float>(iK),
+                            st.ptr<int32_t>(iT), H, fix_scale, st.ptr<float>(oT), st.ptr<int32_t>(oN), st.ptr<uint8_t>(oM));
+  rc = hip_check(hipGetLastError(), "sim3_hypotheses launch");
+  return rc == DVM_OK ? st.download() : rc;
 }
 
 }  // extern "C"
