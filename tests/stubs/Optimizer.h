@@ -2,6 +2,7 @@
 #pragma once
 #include "orbslam3_stub.h"
 #include "Thirdparty/g2o/g2o/types/sim3.h"
+#include "LoopClosing.h"
 namespace ORB_SLAM3 {
 class Optimizer {
  public:
@@ -14,5 +15,8 @@ class Optimizer {
   int static PoseOptimization(Frame* pFrame);
   static int OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches1, g2o::Sim3& g2oS12, const float th2,
                           const bool bFixScale, Eigen::Matrix<double, 7, 7>& mAcumHessian, const bool bAllPoints = false);
+  void static OptimizeEssentialGraph(Map* pMap, KeyFrame* pLoopKF, KeyFrame* pCurKF, const LoopClosing::KeyFrameAndPose& NonCorrectedSim3,
+                                     const LoopClosing::KeyFrameAndPose& CorrectedSim3,
+                                     const std::map<KeyFrame*, std::set<KeyFrame*>>& LoopConnections, const bool& bFixScale);
 };
 }  // namespace ORB_SLAM3

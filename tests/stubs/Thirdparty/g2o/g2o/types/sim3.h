@@ -9,5 +9,8 @@ struct Sim3 {
   const Eigen::Quaterniond& rotation() const { return r; }
   const Eigen::Vector3d& translation() const { return t; }
   const double& scale() const { return s; }
+  Sim3 inverse() const;
+  Sim3 operator*(const Sim3& other) const;
+  Eigen::Vector3d map(const Eigen::Vector3d& xyz) const;
 };
 }  // namespace g2o

@@ -51,6 +51,8 @@ class MapPoint {
   float GetMinDistance();   // (+) returns mfMinDistance (MapPoint::PredictScale reads the raw value, MapPoint.cc:573-587)
   float GetMaxDistance();   // (+) returns mfMaxDistance
   Map* GetMap();
+  KeyFrame* GetReferenceKeyFrame();
+  long unsigned int mnCorrectedByKF, mnCorrectedReference;
   long unsigned int mnId;
   float mTrackProjX, mTrackProjY, mTrackDepth, mTrackDepthR, mTrackProjXR, mTrackProjYR;
   bool mbTrackInView, mbTrackInViewR;
@@ -75,6 +77,13 @@ class KeyFrame {
   void EraseMapPointMatch(MapPoint* pMP);
   void AddMapPoint(MapPoint* pMP, const size_t& idx);
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames();
+  std::vector<KeyFrame*> GetCovisiblesByWeight(const int& w);
+  int GetWeight(KeyFrame* pKF);
+  KeyFrame* GetParent();
+  bool hasChild(KeyFrame* pKF);
+  std::set<KeyFrame*> GetLoopEdges();
+  bool bImu = false;
+  KeyFrame* mPrevKF = nullptr;
   bool isBad();
   Map* GetMap();
   long unsigned int mnId;

@@ -27,7 +27,7 @@ def test_shims_cover_the_reference_public_interface():
         assert m.count(name) == count, name
     o = open(os.path.join(HOST, "Optimizer_shim.h")).read()
     for name in ("Optimizer::BundleAdjustment(", "Optimizer::GlobalBundleAdjustemnt(", "Optimizer::LocalBundleAdjustment(",
-                 "Optimizer::PoseOptimization(", "Optimizer::OptimizeSim3("):
+                 "Optimizer::PoseOptimization(", "Optimizer::OptimizeSim3(", "Optimizer::OptimizeEssentialGraph("):
         assert "inline void " + name in o or "inline int " + name in o, name
     f = open(os.path.join(HOST, "Frame_grid_shim.h")).read()
     for name in ("inline bool Frame::isInFrustum(", "inline void Frame::UndistortKeyPoints(", "inline void Frame::ComputeImageBounds("):
