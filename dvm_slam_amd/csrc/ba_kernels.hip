@@ -603,6 +603,11 @@ constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
 // then Linv by block forward substitution, Linv_ij = -Linv_ii * sum_k L_ik Linv_kj, again on MFMA: the
 // C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly its B-operand
 // layout for k-step = reg, so the running sum feeds the next product without touching LDS.
+// Beside the LAST panel the three idle waves finish everything that does not need its result: wave 3 inverts sub-block 2 and
+// assembles L^-1 block (2, 0), wave 1 blocks (1, 0) and (2, 1) -- two LDS flags order them --, both then form the sums of
+// block row 3; wave 2 inverts sub-block 3 row by row BEHIND wave 0 (it reads the columns wave 0 publishes for its own
+// deferred updates).  The tail after the panel is four MFMAs per block of row 3 and the 16-byte store of L^-1
+// (7 000 -> 3 000 cycles of a 40 000-cycle kernel, same bits).
 #ifdef DVM_CHOL_DEBUG
 __device__ long long g_chol_dbg[32];
 #define DVM_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_dbg[i] = __builtin_readcyclecounter(); } while (0)
@@ -613,9 +618,17 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
                                                   int* __restrict__ fail, double* __restrict__ Linv_all) {
   DVM_STAMP(0);
   const int kb = cols[blockIdx.x];
-  __shared__ double Bm[NB * LP];
-  __shared__ double Li[NB * LP];
-  __shared__ double Iv[4][16][17];
+  // One LDS block, laid out by hand: everything that is read with CONSTANT (wave-uniform) addresses sits in the first 64 KB,
+  // where a ds instruction's 16-bit offset field reaches it -- left to the compiler, Li / Iv / Pcol landed above 64 KB and every
+  // such address became a v_mov of a literal parked in an AGPR (hundreds of them in the kernel's prologue).
+  typedef __attribute__((address_space(3))) double lds_f64;
+  __shared__ double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 2 * NB * LP];
+  lds_f64* const lds = (lds_f64*)smem;
+  lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
+  lds_f64 (*const s_rinv)[16] = (lds_f64 (*)[16])(lds + 16 * NB);
+  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB + 4 * 16);
+  lds_f64* const Bm = lds + 16 * NB + 4 * 16 + 4 * 16 * 17;
+  lds_f64* const Li = Bm + NB * LP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = kb * NB;
   const int kw = min(NB, n1 - k0);
@@ -641,8 +654,17 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   __syncthreads();
   DVM_STAMP(1);
   const int lr = lane & 15, lq = lane >> 4;
-  __shared__ double s_rinv[4][16];
-  __shared__ double Pcol[16][NB];      // the panel's finished columns, one row per column: broadcast source for the updates
+  __shared__ int s_flag[2];            // last panel: [0] Iv_2 is in LDS (wave 3), [1] L^-1 block (1, 0) is in LDS (wave 1)
+  if (tid < 2) s_flag[tid] = 0;        // (ordered before their first use by the barriers of the first three panels)
+  auto signal = [&](int f) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&s_flag[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_for = [&](int f) {
+    for (int spins = 0; __hip_atomic_load(&s_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && spins < (1 << 16); spins++)
+      __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
   // inverse of the 16x16 diagonal sub-block bb (needed by the L^-1 assembly at the end), one wave: column `lane` of the
   // inverse by forward substitution, L_it straight from LDS (uniform address = broadcast read)
   auto invert_block = [&](int bb) {
@@ -667,6 +689,47 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       }
     }
   };
+  // The LAST diagonal sub-block is inverted WHILE wave 0 still factorises it: row i of the inverse needs L_it (t < i) and
+  // 1 / L_ii, which wave 0 publishes column by column (Pcol, s_rinv) anyway.  The slots are filled with a tag before the panel
+  // (kTag: a NaN payload no arithmetic produces) and the reader waits for the tag to go: wave 0's instruction stream is
+  // untouched (a select that put 1 / L_jj into Pcol[j][j] cost 300-700 cycles per panel).  Same operands in the same order
+  // as invert_block(3) after the panel: same bits.  (1.2 us of the kernel's tail were this inversion.)
+  constexpr unsigned long long kTag = 0x7FF8DEADBEEF0001ull;
+  auto invert_last_block_behind_panel = [&]() {
+    // Row i = (e_i - sum_{t<i} L_it y_t) / L_ii: the sum only needs columns < i, which the wait of row i - 1 has already seen
+    // (wave 0 stores Pcol[j][.] and then s_rinv[.][j], and a wave's LDS operations complete in order), so it is formed BEFORE
+    // waiting for column i; behind the wait there is one multiplication.  The store order is the compiler's (checked in the
+    // ISA): the newest word of every sum is compared with the tag, off the waiting path, and a hit marks the column failed
+    // instead of passing a tag on as data.
+    const int ob = 48;
+    double y[16];
+    bool late = false;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < i; t++) {
+        const double l = __hip_atomic_load(&Pcol[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t == i - 1) late = late || (unsigned long long)__double_as_longlong(l) == kTag;
+        if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
+      }
+      const double sum = s0 + s1;
+      double ri = 0.0;
+      for (int spins = 0;; spins++) {
+        ri = __hip_atomic_load(&s_rinv[3][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((unsigned long long)__double_as_longlong(ri) != kTag) break;
+        if (spins > (1 << 14)) { late = true; break; }      // never hang: the column is flagged as failed instead
+        __builtin_amdgcn_s_sleep(1);
+      }
+      y[i] = sum * ri;
+      if (lane < 16) {
+        const double v = (lane <= i) ? y[i] : 0.0;
+        Iv[3][i][lane] = v;
+        Li[(ob + i) * LP + ob + lane] = v;
+      }
+    }
+    if (late && lane == 0) *fail = 1;
+  };
   // finished block column bb of L (rows 16 bb .. 63) -> global, by two waves (128 threads)
   auto store_panel = [&](int bb, int t, int nt) {
     const int ob = 16 * bb;
@@ -678,19 +741,26 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   // L^-1 block (i, j), i > j:  -Iv_i * sum_{k = j .. i - 1} L_ik Linv_kj  (blocks (k, j), k < i, must be in Li already), one wave;
   // the C/D register layout of the f64 MFMA is its B-operand layout for k-step = reg, so the running sum feeds the product
   // with Iv_i without touching LDS
-  auto linv_block = [&](int i, int j) {
+  auto linv_sum = [&](int i, int j) {
     double4_t t = {0, 0, 0, 0};
     for (int k = j; k < i; k++) {
 #pragma unroll
       for (int kk = 0; kk < 16; kk += 4)
         t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(16 * i + lr) * LP + 16 * k + kk + lq], Li[(16 * k + kk + lq) * LP + 16 * j + lr], t, 0, 0, 0);
     }
+    return t;
+  };
+  auto linv_finish = [&](int i, int j, double4_t t) {
     double4_t r4 = {0, 0, 0, 0};
 #pragma unroll
     for (int st = 0; st < 4; st++) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[i][lr][4 * st + lq], t[st], r4, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; r++) Li[(16 * i + lq + 4 * r) * LP + 16 * j + lr] = -r4[r];
   };
+  auto linv_block = [&](int i, int j) { linv_finish(i, j, linv_sum(i, j)); };
+  // block row 3 of L^-1: the sums over block rows 0..2 are formed beside the last panel (waves 3 and 1), only the product with
+  // Iv_3 -- four MFMAs -- is left for the tail
+  double4_t t3a = {0, 0, 0, 0}, t3b = {0, 0, 0, 0};
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
     DVM_STAMP(2 + 3 * b);
@@ -748,15 +818,28 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       // the other waves are idle during the panel: one inverts the previous diagonal sub-block, the others send the previous
       // block column of L home -- and, during the last panel, one already assembles L^-1 block (1, 0), whose inputs (Iv_0,
       // Iv_1, L_10) are final by then
-      if (wave == 3) invert_block(b - 1);
-      else if (b < 3) store_panel(b - 1, tid - 64, 128);
-      else if (wave == 1) store_panel(b - 1, tid - 64, 64);
-      else linv_block(1, 0);
+      if (wave == 3) {
+        invert_block(b - 1);
+        if (b == 3) { signal(0); wait_for(1); linv_block(2, 0); t3a = linv_sum(3, 0); }
+      } else if (b < 3) {
+        store_panel(b - 1, tid - 64, 128);
+      } else if (wave == 1) {
+        store_panel(2, tid - 64, 64);
+        linv_block(1, 0); signal(1);
+        wait_for(0); linv_block(2, 1); t3a = linv_sum(3, 1); t3b = linv_sum(3, 2);
+      } else {
+       
+        invert_last_block_behind_panel();
+      }
     }
     DVM_STAMP(3 + 3 * b);
     __syncthreads();
     DVM_STAMP(4 + 3 * b);
     if (b < 3) {
+      if (b == 2 && wave == 1) {   // panel 2's columns are dead: tag the slots the last panel publishes (one pair below: wave 0's)
+        for (int i = lane; i < 16 * 16; i += 64) Pcol[i >> 4][i & 15] = __longlong_as_double((long long)kTag);
+        if (lane < 16) s_rinv[3][lane] = __longlong_as_double((long long)kTag);
+      }
       // ---- C: trailing sub-blocks (i >= j > b), round-robin over the four waves
       int pair = 0;
       for (int i = b + 1; i < 4; i++)
@@ -773,18 +856,20 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       __syncthreads();
     }
   }
-  // tail: L^-1 block row 2 needs Iv_2 (inverted during the last panel), block row 3 needs Iv_3 (inverted now)
-  if (wave == 3) invert_block(3);
-  else if (wave == 2) store_panel(3, tid - 128, 64);
-  else linv_block(2, wave);                  // (2, 0) on wave 0 -- reads (1, 0) from the last panel's idle time --, (2, 1) on wave 1
-  __syncthreads();
+  // tail: only L^-1 block row 3 is left (Iv_3 and block rows 0..2 were finished beside the last panel)
   DVM_STAMP(14);
-  if (wave < 3) linv_block(3, wave);
+  if (wave == 3) linv_finish(3, 0, t3a);
+  else if (wave == 1) { linv_finish(3, 1, t3a); linv_finish(3, 2, t3b); }
+  else if (wave == 0) store_panel(3, tid, 64);
   DVM_STAMP(15);
   __syncthreads();
   DVM_STAMP(16);
   double* Lo = Linv_all + (size_t)kb * NB * NB;
-  for (int i = tid; i < NB * NB; i += 256) Lo[i] = Li[(i >> 6) * LP + (i & 63)];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {            // 16-byte stores: a wave writes 1 KB per instruction
+    const int r = 8 * k + (tid >> 5), c = 2 * (tid & 31);
+    *reinterpret_cast<double2*>(Lo + r * NB + c) = make_double2(Li[r * LP + c], Li[r * LP + c + 1]);
+  }
   DVM_STAMP(17);
 }
 #ifdef DVM_CHOL_DEBUG
