@@ -53,6 +53,9 @@ struct BaView {
   const int32_t* strips;    // (row tile, column) pairs by level                 (h_strip_off)
   const int32_t* targets;   // (ti, tj, c0, c1) trailing tiles by level          (h_tgt_off)
   const int32_t* contrib;   // contributing columns of each target, ascending
+  const int32_t* contrib_strip;  // per contribution: indices (into strips) of the two strips it multiplies
+  int32_t* strip_flags;     // [4 * strips]: hand-off flag of every 16-row slice of a strip (k_chol_trsm_update); zeroed once after
+                            // allocation, compared with the solve's sequence number like the back substitution's flags
   const int32_t* nz_tiles;  // (i, j) pairs of the structurally non-zero tiles (n_nz of them): cleared before every trial
   int32_t n_nz;
   const int32_t* colstrip_off;  // [ntiles+1] device

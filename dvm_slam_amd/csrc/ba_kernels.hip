@@ -14,6 +14,8 @@
 // All accumulations are gathers with a fixed order: results are run-to-run deterministic.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ba_kernels.h"
 
 namespace dvm {
@@ -949,6 +951,14 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
   const int lr = lane & 15, lk = lane >> 4;
   // thread t owns elements (row 4k + t / 64, column t % 64), k = 0..7: every load instruction covers 4 full rows
   const int pr = tid >> 6, pc = tid & 63;
+  // the target's own entries are fetched first: they are only needed at the very end, where the load used to be one more
+  // dependent round trip behind the last product
+  double tgt[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = wi + lk + 4 * r, col = wj + lr;
+    tgt[r] = (row < iw && col < jw && (i0 + row) >= (j0 + col)) ? S[(size_t)(i0 + row) * ldS + j0 + col] : 0.0;
+  }
   // Three contributors in flight: a contributor's half strips travel global -> registers while the two before it are
   // staged / on the matrix pipe.  With one in flight every contributor cost a full L2 round trip (~2.2 us against 0.43 us of
   // MFMA): the leaf level, where a separator tile collects up to ten columns, took 22 us.
@@ -984,7 +994,135 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = wi + lk + 4 * r, col = wj + lr;
-    if (row < iw && col < jw && (i0 + row) >= (j0 + col)) S[(size_t)(i0 + row) * ldS + j0 + col] -= acc[r];
+    if (row < iw && col < jw && (i0 + row) >= (j0 + col)) S[(size_t)(i0 + row) * ldS + j0 + col] = tgt[r] - acc[r];
+  }
+}
+
+// k_chol_trsm and k_chol_update of one level in ONE launch.  Workgroups [0, n_trsm) are the panel solve's 16-row slices,
+// the others the update's 32x32 quadrants; a quadrant waits for the slices of the strips it multiplies instead of a kernel
+// boundary (4.8 + 5.5 us per level as two launches, each mostly boundary + load latency: ~1.7 us of boundary and one round
+// trip less per level).  Hand-off (MI355X_MICROARCH.md, valid forms): the slice is written with 8-byte agent-scope
+// (write-through) stores, drained (s_waitcnt vmcnt(0)) before its flag is raised to the solve's sequence number; the reader
+// polls the flags with relaxed agent-scope loads on a few lanes and reads the strips with agent-scope loads (no L1, and the
+// XCD's L2 cannot hold these lines yet: nothing in this launch reads a strip before its flag).  No deadlock: the launcher
+// only uses this kernel when the whole grid is resident at once; a wait is bounded anyway and flags the trial as failed.
+__global__ void __launch_bounds__(256) k_chol_trsm_update(double* __restrict__ S, int ldS, int n1, const double* __restrict__ Linv_all,
+                                                          const int32_t* __restrict__ strips, int strip_base, int n_trsm,
+                                                          const int32_t* __restrict__ targets, const int32_t* __restrict__ contrib,
+                                                          const int32_t* __restrict__ contrib_strip, int32_t* __restrict__ flags,
+                                                          int gen, int gen_pub, int* __restrict__ fail) {
+  __shared__ double smem[16 * QP + NB * QP];     // trsm: Ai (16 rows) + Li (64 rows); update: Ai + Aj (32 rows each)
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < n_trsm) {
+    double* Ai = smem;
+    double* Li = smem + 16 * QP;
+    const int st = blockIdx.x >> 2, sl = blockIdx.x & 3, qi = sl * 16;
+    const int kb = strips[2 * st + 1];
+    const int k0 = kb * NB;
+    const int r0 = strips[2 * st] * NB;
+    const int rw = min(NB, n1 - r0);
+    if (qi < rw) {
+      const double* Lk = Linv_all + (size_t)kb * NB * NB;
+      {
+        double2 l[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = *reinterpret_cast<const double2*>(Lk + (8 * i + (tid >> 5)) * NB + 2 * (tid & 31));
+        const int r = tid >> 4, c = 4 * (tid & 15);
+        const double* src = S + (size_t)(r0 + min(qi + r, rw - 1)) * ldS + k0 + c;
+        const double2 a0 = *reinterpret_cast<const double2*>(src), a1 = *reinterpret_cast<const double2*>(src + 2);
+        const bool in = qi + r < rw;
+        Ai[r * QP + c] = in ? a0.x : 0.0; Ai[r * QP + c + 1] = in ? a0.y : 0.0;
+        Ai[r * QP + c + 2] = in ? a1.x : 0.0; Ai[r * QP + c + 3] = in ? a1.y : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          Li[(8 * i + (tid >> 5)) * QP + 2 * (tid & 31)] = l[i].x;
+          Li[(8 * i + (tid >> 5)) * QP + 2 * (tid & 31) + 1] = l[i].y;
+        }
+      }
+      __syncthreads();
+      const int wave = tid >> 6, lane = tid & 63;
+      const int wj = wave * 16;
+      const int lr = lane & 15, lk = lane >> 4;
+      double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NB; k += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[lr * QP + k + lk], Li[(wj + lr) * QP + k + lk], acc, 0, 0, 0);
+      const int kw = min(NB, n1 - k0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = qi + lk + 4 * r, col = wj + lr;
+        if (row < rw && col < kw) __hip_atomic_store(S + (size_t)(r0 + row) * ldS + k0 + col, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's part of the slice has reached the coherence point
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + 4 * (strip_base + st) + sl, gen_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // gen_pub == gen (debug switch: see the launcher)
+    return;
+  }
+  double* Ai = smem;
+  double* Aj = smem + 32 * QP;
+  const int bx = blockIdx.x - n_trsm;
+  const int tg = bx >> 2, qi = (bx & 2) * 16, qj = (bx & 1) * 32;
+  const int ti = targets[4 * tg], tj = targets[4 * tg + 1];
+  const int c0 = targets[4 * tg + 2], c1 = targets[4 * tg + 3];
+  if (ti == tj && qj > qi) return;   // strictly upper quadrant of a diagonal tile
+  const int i0 = ti * NB + qi, j0 = tj * NB + qj;
+  const int iw = min(32, n1 - i0), jw = min(32, n1 - j0);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+  double4_t acc = {0, 0, 0, 0};
+  const int lr = lane & 15, lk = lane >> 4;
+  const int pr = tid >> 6, pc = tid & 63;
+  double tgt[4];                       // the target's own entries: nothing in this launch writes them, fetched before the wait
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = wi + lk + 4 * r, col = wj + lr;
+    tgt[r] = (row < iw && col < jw && (i0 + row) >= (j0 + col)) ? S[(size_t)(i0 + row) * ldS + j0 + col] : 0.0;
+  }
+  // the slices this quadrant multiplies: rows [qi, qi + 32) of strip (ti, k) and rows [qj, qj + 32) of strip (tj, k) for every
+  // contributing column k -- four flags per contributor, one lane each
+  for (int f = tid; f < 4 * (c1 - c0); f += 256) {
+    const int c = c0 + (f >> 2), side = (f >> 1) & 1, half = f & 1;
+    const int32_t* flag = flags + 4 * contrib_strip[2 * c + side] + ((side ? qj : qi) >> 4) + half;
+    for (int spins = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen; spins++) {
+      __builtin_amdgcn_s_sleep(2);
+      if (spins > (1 << 18)) { *fail = 2; break; }          // never hang the device: give up, the trial is rejected
+    }
+  }
+  __syncthreads();
+  double ra0[8], rb0[8], ra1[8], rb1[8], ra2[8], rb2[8];
+  auto fetch = [&](int c, double* ra, double* rb) {
+    const int k0 = contrib[c] * NB;
+    const double* ga = S + (size_t)(i0 + pr) * ldS + k0 + pc;
+    const double* gb = S + (size_t)(j0 + pr) * ldS + k0 + pc;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      ra[k] = (4 * k + pr < iw) ? __hip_atomic_load(ga + (size_t)4 * k * ldS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      rb[k] = (4 * k + pr < jw) ? __hip_atomic_load(gb + (size_t)4 * k * ldS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+  };
+  auto step = [&](int c, double* ra, double* rb) {
+    if (c > c0) __syncthreads();          // the previous contributor's MFMAs have read Ai / Aj
+#pragma unroll
+    for (int k = 0; k < 8; k++) { Ai[(4 * k + pr) * QP + pc] = ra[k]; Aj[(4 * k + pr) * QP + pc] = rb[k]; }
+    __syncthreads();
+    if (c + 3 < c1) fetch(c + 3, ra, rb);
+#pragma unroll
+    for (int k = 0; k < NB; k += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(wi + lr) * QP + k + lk], Aj[(wj + lr) * QP + k + lk], acc, 0, 0, 0);
+  };
+  fetch(c0, ra0, rb0);
+  if (c0 + 1 < c1) fetch(c0 + 1, ra1, rb1);
+  if (c0 + 2 < c1) fetch(c0 + 2, ra2, rb2);
+  for (int c = c0; c < c1; c += 3) {
+    step(c, ra0, rb0);
+    if (c + 1 < c1) step(c + 1, ra1, rb1);
+    if (c + 2 < c1) step(c + 2, ra2, rb2);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = wi + lk + 4 * r, col = wj + lr;
+    if (row < iw && col < jw && (i0 + row) >= (j0 + col)) S[(size_t)(i0 + row) * ldS + j0 + col] = tgt[r] - acc[r];
   }
 }
 
@@ -2024,9 +2162,13 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
   hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs);
 }
+constexpr int kFusedLevelMaxWGs = 512;   // 2 workgroups per CU on 256 CUs (3 fit: 41 KB of LDS each); the leaf level of the BASELINE problem (536) measured the same fused or not
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
   const int n1 = V.n_pad + 1;
+  // test switch: the slices publish a sequence number nobody waits for, so every wait times out and the caller's retry path
+  // (one launch per phase) has to produce the result (tests/test_gpu_ba.py)
+  static const bool break_handoff = std::getenv("DVM_BA_DEBUG_BREAK_HANDOFF") != nullptr;
   for (int h = 0; h < V.nlevels; h++) {
     const int nc = V.h_level_off[h + 1] - V.h_level_off[h], ns = V.h_strip_off[h + 1] - V.h_strip_off[h];
     const int nt = V.h_tgt_off[h + 1] - V.h_tgt_off[h];
@@ -2034,6 +2176,14 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
     // used -- row n_pad already holds y = L^-1 b once the last camera level is done -- so that level is not launched
     if (h == V.nlevels - 1 && nc == 1 && ns == 0 && nt == 0) break;
     hipLaunchKernelGGL(k_chol_diag, dim3(nc), dim3(256), 0, s, V.S, V.ldS, n1, V.cols + V.h_level_off[h], d_fail, V.Linv);
+    // solve + update of the level as ONE launch when every workgroup of it is resident at once (a quadrant then never waits
+    // for a slice that has no compute unit to run on): 41 KB of LDS per workgroup = 3 per CU
+    if (ns > 0 && nt > 0 && 4 * (ns + nt) <= kFusedLevelMaxWGs && V.contrib_strip && V.strip_flags) {
+      hipLaunchKernelGGL(k_chol_trsm_update, dim3(4 * (ns + nt)), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h],
+                         V.h_strip_off[h], 4 * ns, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib, V.contrib_strip, V.strip_flags, solve_seq,
+                         break_handoff ? -1 : solve_seq, d_fail);
+      continue;
+    }
     if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
     if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }

@@ -190,13 +190,18 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
   for (int k = 0; k < nt; k++) nl = std::max(nl, height[k] + 1);
   S.nlevels = nl;
   S.level_off.assign(1, 0); S.strip_off.assign(1, 0); S.tgt_off.assign(1, 0);
+  std::vector<std::vector<int32_t>> strip_id(nt);   // strip_id[i][k] = index of strip (i, k) in S.strips
   for (int h = 0; h < nl; h++) {
     std::vector<std::vector<std::vector<int>>> upd(nt);   // upd[ti][tj] -> contributing columns (dense map is fine: nt is small)
     std::vector<std::pair<int, int>> touched;
     for (int k = 0; k < nt; k++) {
       if (height[k] != h) continue;
       S.cols.push_back(k);
-      for (int i : col[k]) { S.strips.push_back(i); S.strips.push_back(k); }
+      for (int i : col[k]) {
+        if (strip_id[i].empty()) strip_id[i].assign(nt, -1);
+        strip_id[i][k] = (int32_t)(S.strips.size() / 2);
+        S.strips.push_back(i); S.strips.push_back(k);
+      }
       for (size_t a = 0; a < col[k].size(); a++)
         for (size_t b = 0; b <= a; b++) {
           const int ti = col[k][a], tj = col[k][b];
@@ -213,7 +218,10 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
     for (auto& t : touched) {
       S.targets.push_back(t.first); S.targets.push_back(t.second);
       S.targets.push_back((int32_t)S.contrib.size());
-      for (int k : upd[t.first][t.second]) S.contrib.push_back(k);
+      for (int k : upd[t.first][t.second]) {
+        S.contrib.push_back(k);
+        S.contrib_strip.push_back(strip_id[t.first][k]); S.contrib_strip.push_back(strip_id[t.second][k]);
+      }
       S.targets.push_back((int32_t)S.contrib.size());
     }
     S.level_off.push_back((int32_t)S.cols.size());

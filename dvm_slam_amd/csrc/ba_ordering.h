@@ -34,6 +34,7 @@ struct BaTileSchedule {
   std::vector<int32_t> tgt_off;        // [nlevels+1] -> targets (quads)
   std::vector<int32_t> targets;        // (ti, tj, c0, c1): trailing tile ti >= tj updated by contrib[c0..c1)
   std::vector<int32_t> contrib;        // column k of each contribution, ascending within a target (deterministic sum)
+  std::vector<int32_t> contrib_strip;  // per contribution: indices (into strips) of the strips (ti, k) and (tj, k) it multiplies
   std::vector<int32_t> colstrip_off;   // [ntiles+1] -> colstrips
   std::vector<int32_t> colstrips;      // per column k: row tiles i > k with L(i,k) != 0 (back substitution)
   std::vector<int32_t> nz_tiles;       // (i, j), i >= j: every structurally non-zero tile of the factor (what a trial must clear)

@@ -36,6 +36,7 @@ struct dvm_ba {
   double* d_vals = nullptr;                 // the same memory as the device sees it
   unsigned long long seq = 0;
   int solve_seq = 0;
+  bool fuse_levels = true;   // k_chol_trsm_update (solve + update of a level in one launch) until one of its waits times out
   // landmark-sharded mode (dvm_ba_set_problem_sharded): rank r of `world` owns the landmarks l with l % world == r
   int rank = 0, world = 1;
   // second set of linearisation buffers: a trial evaluates its state WITH Jacobians and accumulates Hpp / Hll into these, so
@@ -372,7 +373,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->dalloc(&h->alt_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&h->alt_W, (size_t)E * 18));
   ok(h->dalloc(&h->alt_Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&h->alt_bp, (size_t)n));
   ok(h->dalloc(&h->alt_Hll, 9 * (size_t)L)); ok(h->dalloc(&h->alt_bl, 3 * (size_t)L));
-  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)V.n_pad + 64));
+  ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)V.n_pad + 64 + 2 * (SC.strips.size() / 2) + 2));
   ok(h->dalloc(&V.xrow, (size_t)V.n_pad + 64));
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(8 * (size_t)L + 255) / 256 + (size_t)(V.nfree + 255) / 256 + 2));   // block partials of k_point_backsub / k_max_diag
@@ -380,6 +381,8 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.nz_tiles, SC.nz_tiles)); V.n_nz = (int)(SC.nz_tiles.size() / 2);
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
+  ok(h->upload(&V.contrib_strip, SC.contrib_strip));
+  V.strip_flags = reinterpret_cast<int32_t*>(V.ytmp + (size_t)V.n_pad + 64);   // behind the back substitution's words, cleared with them
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
   if (std::getenv("DVM_BA_DEBUG_SCHEDULE")) {
     for (size_t l = 0; l + 1 < SC.tgt_off.size(); l++) {
@@ -408,8 +411,8 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   // (S is NOT cleared as a whole: every kernel touches structurally non-zero tiles only, and a trial's prologue clears exactly
   //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes.)
   ok(hip_check(hipMemsetAsync(V.e_chi2, 0, (size_t)E * sizeof(double), h->stream), "memset"));
-  ok(hip_check(hipMemsetAsync(V.ytmp, 0, ((size_t)V.n_pad + 64) * sizeof(double), h->stream), "memset"));   // ticket + hand-off flags of the back substitution
-  h->solve_seq = 0;
+  ok(hip_check(hipMemsetAsync(V.ytmp, 0, ((size_t)V.n_pad + 64 + 2 * (SC.strips.size() / 2) + 2) * sizeof(double), h->stream), "memset"));   // ticket + hand-off flags of the back substitution
+  h->solve_seq = 0; h->fuse_levels = true;
   ok(hip_check(hipStreamSynchronize(h->stream), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
   mark("state + memsets + sync");
@@ -587,6 +590,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       // one trial = setLambda + Schur complement + reduced solve + landmarks + oplus into the TRIAL state + its chi2:
       // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
       V.lambda_v = lambda;
+      for (int attempt = 0;; attempt++) {
       if (h->prof) hipEventRecord(h->pev[0], s);
       ba_launch_schur(s, V, h->d_fail);
       if (h->prof) hipEventRecord(h->pev[1], s);
@@ -595,7 +599,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         if ((rc = ar_dev((int64_t)V.n_nz * 4096, 0)) != DVM_OK) return rc;
         ba_launch_pack_tiles(s, V, h->ar_buf, true);
       }
-      ba_launch_cholesky_solve(s, V, h->d_fail, ++h->solve_seq);
+      {
+        BaView VS = V;                                   // in-launch hand-offs (k_chol_trsm_update) only while they have never timed out
+        if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
+        ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
+      }
       if (h->prof) hipEventRecord(h->pev[2], s);
       ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
       {
@@ -611,6 +619,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       if (rc == DVM_OK) rc = wait_seq(h, h->seq);
       if (rc != DVM_OK) return rc;
       mark("trial published", it);
+      // a wait inside the solve gave up (other work held the compute units its producer needed): nothing was decided on this
+      // result -- the same trial runs again, with one launch per phase from now on
+      if (h->h_vals[S_FAIL] == 2.0 && h->fuse_levels && !sharded && attempt == 0) { h->fuse_levels = false; continue; }
+      break;
+      }
       if (h->prof) {
         hipEventSynchronize(h->pev[3]);
         for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, h->pev[k], h->pev[k + 1]); h->prof_ms[1 + k] += ms; }

@@ -112,6 +112,7 @@ extern "C" int dvm_pose_graph_optimize(int device, double* S, const uint8_t* fix
   T.ytmp = D.alloc<double>((size_t)T.n_pad + 64); T.xrow = D.alloc<double>((size_t)T.n_pad + 64); T.x = D.alloc<double>(7 * (size_t)nfree + 8);
   T.nz_tiles = D.upload(SC.nz_tiles); T.n_nz = (int)(SC.nz_tiles.size() / 2);
   T.cols = D.upload(SC.cols); T.strips = D.upload(SC.strips); T.targets = D.upload(SC.targets); T.contrib = D.upload(SC.contrib);
+  T.contrib_strip = nullptr; T.strip_flags = nullptr;   // the pose graph keeps one launch per phase (k_chol_trsm_update needs the caller's retry path)
   T.colstrip_off = D.upload(SC.colstrip_off); T.colstrips = D.upload(SC.colstrips);
   T.h_level_off = SC.level_off.data(); T.h_strip_off = SC.strip_off.data(); T.h_tgt_off = SC.tgt_off.data();
   double* d_scalars = D.alloc<double>(8);

@@ -105,6 +105,40 @@ def test_ba_full_size_properties(capi):
     ba.close()
 
 
+_HANDOFF_WORKER = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dvm_slam_amd import capi, synth
+pr = synth.ba_problem(n_kf=100, n_pts=4000, seed=7)
+e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+ba = capi.BundleAdjuster()
+ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], float(np.sqrt(5.991)))
+st = ba.optimize(4)
+p, pts = ba.result()
+np.savez(sys.argv[1], p=p, pts=pts, trials=np.array(st["trials"]), chi2=np.array(st["chi2"]))
+"""
+
+
+def test_ba_level_handoff_timeout_falls_back_to_one_launch_per_phase(tmp_path):
+    """k_chol_trsm_update hands a level's solved strips to its update workgroups inside one launch.  With the slices
+    publishing a sequence number nobody waits for (DVM_BA_DEBUG_BREAK_HANDOFF) every such wait gives up: the solver must
+    notice, repeat the trial with one launch per phase, and end with exactly the bits of an undisturbed run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("plain", {}), ("broken", {"DVM_BA_DEBUG_BREAK_HANDOFF": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _HANDOFF_WORKER % root, out], env={**os.environ, **extra},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["trials"], b["trials"]) and np.array_equal(a["chi2"], b["chi2"])
+    assert np.array_equal(a["p"], b["p"]) and np.array_equal(a["pts"], b["pts"])
+
+
 def _pose_case(seed, n_pts=400, out_frac=0.1):
     from dvm_slam_amd import synth
     rng = np.random.default_rng(seed)
