@@ -204,9 +204,18 @@ __device__ __forceinline__ double wave_sum_lds(const double* v, double* park /* 
 // ------------------------------------------------------------------------------------------ K8
 // JAC=false: residual / chi2 only (computeActiveErrors + activeRobustChi2 terms).
 // JAC=true : additionally Jacobians A (2x3, point), B (2x6, pose), weights and Hpl block W (6x3).
+// The Jacobian rows leave through LDS: a thread's row is 192 B (e_lin) + 144 B (W), and 21 per-thread row stores touch 64
+// different cache lines per instruction (1 344 line writes per wave for 172 lines of data: ~10 of the kernel's 28 us).  A wave's
+// 64 rows are one contiguous 12 KB / 9 KB image in global memory: every lane parks its row in LDS (row pitch 26 / 18 doubles:
+// 16-byte writes without bank conflicts) and the wave copies the image out with 16-byte stores, 1 KB per instruction.
+constexpr int kLinPitch = 26;
 template <bool JAC>
 __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
   const int k = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double2 s_rows[JAC ? 4 * 64 * kLinPitch / 2 : 1];
+  double* park = reinterpret_cast<double*>(s_rows) + (size_t)(threadIdx.x >> 6) * 64 * kLinPitch;   // this wave's rows
+  const int lane = threadIdx.x & 63;
+  double Wv[18];
   double rho0 = 0;
   if (k < V.E) {
     const int p = V.e_pose[k], l = V.e_point[k];
@@ -238,20 +247,40 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
         for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
       const double w = rho1 * info;
       const double wr0 = -info * e0 * rho1, wr1 = -info * e1 * rho1;
-      double* out = V.e_lin + (size_t)k * kEdgeLinStride;
-      {
+      double2* mine = reinterpret_cast<double2*>(park + (size_t)lane * kLinPitch);
+      mine[0] = make_double2(A[0], A[1]); mine[1] = make_double2(A[2], A[3]); mine[2] = make_double2(A[4], A[5]);
 #pragma unroll
-      for (int i = 0; i < 6; i++) out[i] = A[i];
-#pragma unroll
-      for (int i = 0; i < 12; i++) out[6 + i] = B[i];
-      out[18] = w; out[19] = wr0; out[20] = wr1;
-      double* W = V.e_W + (size_t)k * 18;
+      for (int i = 0; i < 6; i++) mine[3 + i] = make_double2(B[2 * i], B[2 * i + 1]);
+      mine[9] = make_double2(w, wr0); mine[10] = make_double2(wr1, 0.0); mine[11] = make_double2(0.0, 0.0);
       const bool pose_free = V.pidx[p] >= 0;
 #pragma unroll
       for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int b = 0; b < 3; b++) W[3 * a + b] = pose_free ? w * (B[a] * A[b] + B[6 + a] * A[3 + b]) : 0.0;
-      }
+        for (int b = 0; b < 3; b++) Wv[3 * a + b] = pose_free ? w * (B[a] * A[b] + B[6 + a] * A[3 + b]) : 0.0;
+    }
+  }
+  if (JAC) {
+    const int first = blockIdx.x * 256 + (threadIdx.x & ~63);      // the wave's first edge
+    const int nrow = min(64, V.E - first);                          // (<= 0 for a wave beyond the last edge)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double2* img = reinterpret_cast<double2*>(V.e_lin + (size_t)first * kEdgeLinStride);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      const int g = 64 * i + lane, row = g / 12, c = g - 12 * row;      // 16-byte chunk g of the image = chunk c of row `row`
+      if (row < nrow) img[g] = *reinterpret_cast<const double2*>(park + (size_t)row * kLinPitch + 2 * c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (k < V.E) {
+      double2* mine = reinterpret_cast<double2*>(park + (size_t)lane * 18);
+#pragma unroll
+      for (int i = 0; i < 9; i++) mine[i] = make_double2(Wv[2 * i], Wv[2 * i + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double2* imgw = reinterpret_cast<double2*>(V.e_W + (size_t)first * 18);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int g = 64 * i + lane, row = g / 9;
+      if (row < nrow) imgw[g] = *reinterpret_cast<const double2*>(park + 2 * (size_t)g);      // pitch 18 = the image itself
     }
   }
   block_reduce_publish<false>(rho0, V.partial, pub);   // fixed-order sum of rho0 over all edges -> host
