@@ -914,11 +914,19 @@ extern "C" int dvm_debug_chol_stamps(long long* out) { return (int)hipMemcpyFrom
 // whole tile on one workgroup is 1.7 us of matrix pipe alone.  The split is by rows only: a workgroup reads and overwrites
 // nothing but its own rows (a split by columns would let one workgroup overwrite A entries another is still reading).
 constexpr int QP = 66;   // LDS pitch (doubles): conflict-free for the MFMA operand reads
+// (xrow_tag != null on the first solve launch of a factorisation: workgroup 0 also fills the back substitution's hand-off
+// slots with kXTag -- see k_chol_backsolve)
+constexpr unsigned long long kXTag = 0x7FF8DEADBEEF0002ull;   // a NaN payload no arithmetic produces
+__device__ __forceinline__ void tag_xrow(double* __restrict__ xrow, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) xrow[i] = __longlong_as_double((long long)kXTag);
+}
 __global__ void __launch_bounds__(256) k_chol_trsm(double* __restrict__ S, int ldS, int n1,
-                                                   const double* __restrict__ Linv_all, const int32_t* __restrict__ strips) {
+                                                   const double* __restrict__ Linv_all, const int32_t* __restrict__ strips,
+                                                   double* __restrict__ xrow_tag, int n_tag) {
   __shared__ double Ai[16 * QP];
   __shared__ double Li[NB * QP];
   const int tid = threadIdx.x;
+  if (xrow_tag && blockIdx.x == 0) tag_xrow(xrow_tag, n_tag);
   const int st = blockIdx.x >> 2, qi = (blockIdx.x & 3) * 16;
   const int kb = strips[2 * st + 1];
   const int k0 = kb * NB;
@@ -1039,9 +1047,10 @@ __global__ void __launch_bounds__(256) k_chol_trsm_update(double* __restrict__ S
                                                           const int32_t* __restrict__ strips, int strip_base, int n_trsm,
                                                           const int32_t* __restrict__ targets, const int32_t* __restrict__ contrib,
                                                           const int32_t* __restrict__ contrib_strip, int32_t* __restrict__ flags,
-                                                          int gen, int gen_pub, int* __restrict__ fail) {
+                                                          int gen, int gen_pub, int* __restrict__ fail, double* __restrict__ xrow_tag, int n_tag) {
   __shared__ double smem[16 * QP + NB * QP];     // trsm: Ai (16 rows) + Li (64 rows); update: Ai + Aj (32 rows each)
   const int tid = threadIdx.x;
+  if (xrow_tag && blockIdx.x == 0) tag_xrow(xrow_tag, n_tag);
   if ((int)blockIdx.x < n_trsm) {
     double* Ai = smem;
     double* Li = smem + 16 * QP;
@@ -1159,9 +1168,10 @@ __global__ void __launch_bounds__(256) k_chol_trsm_update(double* __restrict__ S
 //   x_k = Linv_kk^T (y_k - sum_{i in struct(k)} L(i,k)^T x_i);  the x_i belong to ancestors of k in the elimination tree.
 // One workgroup per tile column.  A workgroup takes a ticket and processes the ticket-th column in root-first order, so
 // every column it has to wait for is held by a workgroup that is already running (no deadlock whatever the dispatch
-// order); x_i travels through `xrow` with 8-byte agent-scope (write-through) stores, drained before the column's flag is
-// raised to the solve's sequence number -- no fences, no flag reset (MI355X_MICROARCH.md, hand-off forms).  Eight
-// dependent launches of ~5 us each before (one per level) -> one launch with a ~2 us hop per level.
+// order); x_i travels through `xrow` as 64 data-tagged words: the slots are filled with kXTag by the first solve launch of the
+// factorisation, the producer overwrites them with 8-byte agent-scope (write-through) stores and every consumer lane waits
+// for ITS word to change -- no flag, no drain in front of a flag (the back substitution of the BASELINE problem: 25.8 -> 20.7 us).
+// Eight dependent launches of ~5 us each before (one per level) -> one launch with a ~2 us hop per level.
 // The result goes to row space (xrow, for the descendants) and, compacted to dof doubles per unknown, to x.
 __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict__ S, int ldS, int n_pad, int nfree, int per_tile, int dof,
                                                         const int32_t* __restrict__ cols, int ncols, const double* __restrict__ y,
@@ -1182,7 +1192,6 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   }
   __syncthreads();
   const int kb = s_col;
-  int32_t* flags = sync + 1;
   const int k0 = kb * NB;
   if (k0 >= n_pad) return;                       // the rhs tile itself (never in the list; defensive)
   if (tid < NB) yk[tid] = y[k0 + tid];
@@ -1205,15 +1214,15 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   for (int s = s_beg; s < s_end; s++) {
     const int it = colstrips[s], i0 = it * NB;
     if (i0 >= n_pad) { if (s + 1 < s_end) fetch_tile(s + 1); continue; }   // the rhs row is not an unknown
-    if (tid == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(flags + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+    if (tid < NB) {   // every lane waits for its own word of x_i: the data is its own flag
+      double v = __hip_atomic_load(xrow + i0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spins = 0; (unsigned long long)__double_as_longlong(v) == kXTag; spins++) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 24)) { *fail = 2; break; }   // never hang the device: give up, the trial is rejected
+        if (spins > (1 << 22)) { *fail = 2; break; }     // never hang the device: give up, the trial is rejected
+        v = __hip_atomic_load(xrow + i0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      xi[tid] = v;
     }
-    __syncthreads();
-    if (tid < NB) xi[tid] = __hip_atomic_load(xrow + i0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     double u = 0;
 #pragma unroll
@@ -1232,11 +1241,9 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   __syncthreads();
   if (tid < NB) {   // one wave
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    __hip_atomic_store(xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // replaces the tag: the word is the hand-off
     const int cam = kb * per_tile + tid / dof;
     if (tid < per_tile * dof && cam < nfree) x[dof * (size_t)cam + tid % dof] = v;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's x_k has reached the coherence point
-    if (tid == 0) __hip_atomic_store(flags + kb, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -2198,6 +2205,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   // test switch: the slices publish a sequence number nobody waits for, so every wait times out and the caller's retry path
   // (one launch per phase) has to produce the result (tests/test_gpu_ba.py)
   static const bool break_handoff = std::getenv("DVM_BA_DEBUG_BREAK_HANDOFF") != nullptr;
+  double* tag = V.xrow;   // the first launch that solves strips also re-arms the back substitution's hand-off slots (no strips: no waits)
   for (int h = 0; h < V.nlevels; h++) {
     const int nc = V.h_level_off[h + 1] - V.h_level_off[h], ns = V.h_strip_off[h + 1] - V.h_strip_off[h];
     const int nt = V.h_tgt_off[h + 1] - V.h_tgt_off[h];
@@ -2210,10 +2218,11 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
     if (ns > 0 && nt > 0 && 4 * (ns + nt) <= kFusedLevelMaxWGs && V.contrib_strip && V.strip_flags) {
       hipLaunchKernelGGL(k_chol_trsm_update, dim3(4 * (ns + nt)), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h],
                          V.h_strip_off[h], 4 * ns, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib, V.contrib_strip, V.strip_flags, solve_seq,
-                         break_handoff ? -1 : solve_seq, d_fail);
+                         break_handoff ? -1 : solve_seq, d_fail, tag, V.n_pad);
+      tag = nullptr;
       continue;
     }
-    if (ns > 0) hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h]);
+    if (ns > 0) { hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h], tag, V.n_pad); tag = nullptr; }
     if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }
   // y = L^-1 b is row n_pad of S (the augmented rhs row): the back substitution reads it in place; one launch for all
