@@ -364,11 +364,30 @@ __device__ __forceinline__ void pose_accum_body(const BaView& V, int block) {
   }
 }
 
+// one structurally non-zero tile of the reduced system back to "empty": zeros, identity on the padding rows of a diagonal tile
+__device__ __forceinline__ void clear_tile(const BaView& V, int t) {
+  const int ti = V.nz_tiles[2 * t], tj = V.nz_tiles[2 * t + 1];
+  double* base = V.S + (size_t)ti * 64 * V.ldS + tj * 64;
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int r = i >> 5, c2 = i & 31;
+    reinterpret_cast<double2*>(base + (size_t)r * V.ldS)[c2] = make_double2(0.0, 0.0);
+  }
+  if (ti == tj && ti * 64 < V.n_pad) {
+    __syncthreads();
+    const int w = threadIdx.x;
+    if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = V.damp_s;
+  }
+}
+
 // Both accumulations in ONE launch (they are independent of each other): workgroups [0, nb_pose) take the cameras -- the
-// longer job, so it starts first --, the rest the landmarks.  Two dependent 14 us launches before.
-__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose) {
+// longer job, so it starts first --, the next nb_point the landmarks (two dependent 14 us launches before), and the rest
+// empty the reduced system for the trial that follows: every trial is preceded by a linearisation, the factor of the last
+// trial is dead by then, and this launch runs while the host decides -- the trial's own first launch shrinks to the 79
+// landmark workgroups.
+__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose, int nb_point) {
   if ((int)blockIdx.x < nb_pose) pose_accum_body(V, blockIdx.x);
-  else point_accum_body(V, blockIdx.x - nb_pose);
+  else if ((int)blockIdx.x < nb_pose + nb_point) point_accum_body(V, blockIdx.x - nb_pose);
+  else clear_tile(V, blockIdx.x - nb_pose - nb_point);
 }
 
 // max |diag| over Hpp and Hll (computeLambdaInit) -> host, grid-wide with the last workgroup finishing the reduction.
@@ -583,27 +602,11 @@ __global__ void __launch_bounds__(256) k_pad_identity(BaView V) {
   if (w >= V.per_tile * V.dof || (r >> 6) * V.per_tile + w / V.dof >= V.nfree) V.S[(size_t)r * V.ldS + r] = 1.0;
 }
 
-// Start of a BA trial in ONE launch: workgroups [0, nb_dinv) invert the damped landmark blocks (k_dinv), the others clear one
-// structurally non-zero tile each (k_zero_tiles) and put the identity on the padding rows of the diagonal tiles
-// (k_pad_identity); the Cholesky failure flag is reset on the way.
-__global__ void __launch_bounds__(256) k_trial_prologue(BaView V, int nb_dinv, int* __restrict__ fail) {
-  if ((int)blockIdx.x < nb_dinv) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *fail = 0;
-    dinv_landmark(V, blockIdx.x * 256 + threadIdx.x);
-    return;
-  }
-  const int t = blockIdx.x - nb_dinv;
-  const int ti = V.nz_tiles[2 * t], tj = V.nz_tiles[2 * t + 1];
-  double* base = V.S + (size_t)ti * 64 * V.ldS + tj * 64;
-  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
-    const int r = i >> 5, c2 = i & 31;
-    reinterpret_cast<double2*>(base + (size_t)r * V.ldS)[c2] = make_double2(0.0, 0.0);
-  }
-  if (ti == tj && ti * 64 < V.n_pad) {
-    __syncthreads();
-    const int w = threadIdx.x;
-    if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = V.damp_s;
-  }
+// Start of a BA trial: the damped landmark blocks are inverted (k_dinv); the Cholesky failure flag is reset on the way.  (The
+// reduced system was emptied by the linearisation's launch, k_accum.)
+__global__ void __launch_bounds__(256) k_trial_prologue(BaView V, int* __restrict__ fail) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *fail = 0;
+  dinv_landmark(V, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ----------------------------------------------------------------------------------------- K10
@@ -2185,14 +2188,15 @@ void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPubli
 }
 void ba_launch_accum(hipStream_t s, const BaView& V) {
   const int nb_pose = V.nfree > 0 ? cdiv(V.nfree, 4) : 0;
-  hipLaunchKernelGGL(k_accum, dim3(nb_pose + cdiv(V.L, 256)), dim3(256), 0, s, V, nb_pose);
+  const int nb_point = cdiv(V.L, 256);
+  hipLaunchKernelGGL(k_accum, dim3(nb_pose + nb_point + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_pose, nb_point);
 }
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);
 }
 void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_dinv = cdiv(V.L, 256);
-  hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_dinv, d_fail);
+  hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv), dim3(256), 0, s, V, d_fail);
   if (V.nfree == 0) return;
   const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
   const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
