@@ -48,7 +48,8 @@ class BaStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("stop_reason", C.c_int32), ("pad", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("trials_per_iter", C.c_int32 * 64), ("chi2_per_iter", C.c_double * 64),
-                ("lambda_per_iter", C.c_double * 64), ("ms_structure", C.c_double), ("ms_optimize", C.c_double)]
+                ("lambda_per_iter", C.c_double * 64), ("ms_structure", C.c_double), ("ms_optimize", C.c_double),
+                ("spec_trials", C.c_int32), ("spec_kept", C.c_int32)]
 
 
 class FrustumFrame(C.Structure):
@@ -456,7 +457,7 @@ class BundleAdjuster:
         return dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason,
                     chi2_initial=st.chi2_initial, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
                     trials=list(st.trials_per_iter[:n]), chi2=list(st.chi2_per_iter[:n]), lam=list(st.lambda_per_iter[:n]),
-                    ms_structure=st.ms_structure, ms_optimize=st.ms_optimize)
+                    ms_structure=st.ms_structure, ms_optimize=st.ms_optimize, spec_trials=st.spec_trials, spec_kept=st.spec_kept)
 
     def result(self):
         poses = np.zeros((self.P, 7), np.float64)

@@ -87,6 +87,14 @@ struct BaPublish {
   const int* d_fail;              // device: Cholesky failure flag of this trial (copied to host_vals[6] on publish), may be null
   int slot;
   int publish;
+  // Speculation on the trial being ACCEPTED (ba_solver.cpp): the workgroup that publishes the trial's chi2 also takes g2o's
+  // decision -- rho from chi2 / the gain-ratio denominator (dev_vals[2]) / the failure flag, and the damping an accepted trial
+  // hands to the next iteration -- into spec[0] (the next lambda, or -1: rejected) and host_vals[7]; the launches that follow
+  // on the stream (k_accum's landmark inverses, the next trial's k_schur) read it instead of waiting for the host.
+  double* spec;                   // device [2], or null: no decision on the device
+  double cur_chi, lambda;         // the iteration's accepted chi2 and the trial's damping
+  int n_bad;                      // iterations in a row without a 0.1 % improvement so far (the stopping rule of dvm_ba_optimize): an accepted
+                                  // trial that completes the third one ends the optimisation -- nothing is enqueued behind it (spec[0] = -2)
 };
 
 // Sim3 pose graph (Optimizer::OptimizeEssentialGraph numerics): vertex states + EdgeSim3 list + block structure.
@@ -112,7 +120,13 @@ void pg_launch_update(hipStream_t s, const PgView& G, const BaView& T, double* d
 
 // jac: linearise at (poses, points); !jac: chi2 only, at the trial state (poses_new, points_new)
 void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPublish& pub);
-void ba_launch_accum(hipStream_t s, const BaView& V);
+// spec (device, BaPublish::spec) != null: landmarks also get Dinv / db for the damping an accepted trial continues with
+void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec = nullptr);
+// the structurally non-zero tiles of S back to empty (what ba_launch_accum does on its way)
+void ba_launch_clear_tiles(hipStream_t s, const BaView& V);
+// the Schur complement alone, for a trial whose damping is decided on the device: V.lambda points at BaPublish::spec (a negative
+// value there = the trial before was rejected: the launch does nothing); resets the Cholesky failure flag like the prologue
+void ba_launch_schur_speculative(hipStream_t s, const BaView& V, int* d_fail);
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub);
 void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail);
 // solve_seq: a number > 0 that differs from call to call on this BaView (the back substitution's hand-off flags compare against it)

@@ -154,6 +154,28 @@ __device__ __forceinline__ void block_reduce_publish(double v, double* __restric
       }
       const int f = pub.d_fail ? __hip_atomic_load(pub.d_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       __hip_atomic_store(pub.host_vals + 6, (double)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (pub.spec) {
+        // OptimizationAlgorithmLevenberg::solve's accept / reject and lambda update (optimization_algorithm_levenberg.cpp:
+        // 113-131) exactly as dvm_ba_optimize takes them on the host, which checks the result bit for bit before it relies on
+        // anything derived from it.  pow(t, 3) is formed with the rounding errors of both products carried along (the
+        // correctly rounded cube, which is what libm returns for almost every t).
+        const double tmp = f == 0 ? s_red[0] : 1.7976931348623157e308;
+        const double scale = (f == 0 ? __hip_atomic_load(pub.dev_vals + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0) + 1e-3;
+        const double rho = (pub.cur_chi - tmp) / scale;
+        double next = -1.0;
+        if (rho > 0 && isfinite(tmp)) {
+          const double t = 2 * rho - 1;
+          const double t2 = t * t, e2 = __builtin_fma(t, t, -t2);
+          const double t3 = t2 * t, e3 = __builtin_fma(t2, t, -t3);
+          const double cube = t3 + (e3 + e2 * t);
+          double alpha = 1. - cube;
+          alpha = fmin(alpha, 2. / 3.);
+          next = pub.lambda * fmax(1. / 3., alpha);
+          if ((pub.cur_chi - tmp) * 1e3 < pub.cur_chi && pub.n_bad + 1 >= 3) next = -2.0;   // accepted, and the optimisation stops here
+        }
+        __hip_atomic_store(pub.spec, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pub.host_vals + 7, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       __hip_atomic_store(pub.host_seq, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -300,8 +322,24 @@ __global__ void __launch_bounds__(256) k_reduce_sum(const double* __restrict__ p
   if (threadIdx.x == 0) out[slot] = s[0];
 }
 
+// (Hll + lambda I)^-1 and its product with bl for one landmark
+__device__ __forceinline__ void dinv_apply(const double* H, const double* bl, double lambda, double* __restrict__ D, double* __restrict__ db) {
+  const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3], e = H[4] + lambda, f = H[5], g = H[6], h = H[7], i = H[8] + lambda;
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  const double id = 1.0 / det;
+  double o[9];
+  o[0] = (e * i - f * h) * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+  o[3] = (f * g - d * i) * id; o[4] = (a * i - c * g) * id; o[5] = (c * d - a * f) * id;
+  o[6] = (d * h - e * g) * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
+#pragma unroll
+  for (int k = 0; k < 9; k++) D[k] = o[k];
+  db[0] = o[0] * bl[0] + o[1] * bl[1] + o[2] * bl[2];
+  db[1] = o[3] * bl[0] + o[4] * bl[1] + o[5] * bl[2];
+  db[2] = o[6] * bl[0] + o[7] * bl[1] + o[8] * bl[2];
+}
+
 // Hll (3x3) and bl per landmark: thread per landmark, edges in input order.
-__device__ __forceinline__ void point_accum_body(const BaView& V, int block) {
+__device__ __forceinline__ void point_accum_body(const BaView& V, int block, const double* __restrict__ spec) {
   const int l = block * 256 + threadIdx.x;
   if (l >= V.L) return;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -319,6 +357,12 @@ __device__ __forceinline__ void point_accum_body(const BaView& V, int block) {
   for (int i = 0; i < 9; i++) V.Hll[9 * (size_t)l + i] = H[i];
 #pragma unroll
   for (int i = 0; i < 3; i++) V.bl[3 * (size_t)l + i] = b[i];
+  // the trial this state belongs to was accepted on the device (spec[0] = the next damping): the next trial's prologue work --
+  // (Hll + lambda I)^-1 and Dinv bl, dinv_landmark's arithmetic on the same values -- is done here, from registers
+  if (spec) {
+    const double lambda = *spec;
+    if (lambda >= 0 && V.pt_start[l + 1] != V.pt_start[l]) dinv_apply(H, b, lambda, V.Dinv + 9 * (size_t)l, V.db + 3 * (size_t)l);
+  }
 }
 
 // Hpp (6x6) and bp per free camera: one wave per camera, lanes stride over the camera's edges, then a
@@ -384,9 +428,9 @@ __device__ __forceinline__ void clear_tile(const BaView& V, int t) {
 // empty the reduced system for the trial that follows: every trial is preceded by a linearisation, the factor of the last
 // trial is dead by then, and this launch runs while the host decides -- the trial's own first launch shrinks to the 79
 // landmark workgroups.
-__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose, int nb_point) {
+__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose, int nb_point, const double* __restrict__ spec) {
   if ((int)blockIdx.x < nb_pose) pose_accum_body(V, blockIdx.x);
-  else if ((int)blockIdx.x < nb_pose + nb_point) point_accum_body(V, blockIdx.x - nb_pose);
+  else if ((int)blockIdx.x < nb_pose + nb_point) point_accum_body(V, blockIdx.x - nb_pose, spec);
   else clear_tile(V, blockIdx.x - nb_pose - nb_point);
 }
 
@@ -404,19 +448,7 @@ __device__ __forceinline__ void dinv_landmark(const BaView& V, int l) {
   const double lambda = ba_lambda(V);
   if (l >= V.L) return;
   if (V.pt_start[l + 1] == V.pt_start[l]) return;  // landmark without observation: not a vertex of the graph
-  const double* H = V.Hll + 9 * (size_t)l;
-  const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3], e = H[4] + lambda, f = H[5], g = H[6], h = H[7], i = H[8] + lambda;
-  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-  const double id = 1.0 / det;
-  double* D = V.Dinv + 9 * (size_t)l;
-  D[0] = (e * i - f * h) * id; D[1] = (c * h - b * i) * id; D[2] = (b * f - c * e) * id;
-  D[3] = (f * g - d * i) * id; D[4] = (a * i - c * g) * id; D[5] = (c * d - a * f) * id;
-  D[6] = (d * h - e * g) * id; D[7] = (b * g - a * h) * id; D[8] = (a * e - b * d) * id;
-  const double* bl = V.bl + 3 * (size_t)l;
-  double* db = V.db + 3 * (size_t)l;
-  db[0] = D[0] * bl[0] + D[1] * bl[1] + D[2] * bl[2];
-  db[1] = D[3] * bl[0] + D[4] * bl[1] + D[5] * bl[2];
-  db[2] = D[6] * bl[0] + D[7] * bl[1] + D[8] * bl[2];
+  dinv_apply(V.Hll + 9 * (size_t)l, V.bl + 3 * (size_t)l, lambda, V.Dinv + 9 * (size_t)l, V.db + 3 * (size_t)l);
 }
 __global__ void __launch_bounds__(256) k_dinv(BaView V) { dinv_landmark(V, blockIdx.x * 256 + threadIdx.x); }
 
@@ -571,7 +603,14 @@ __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
 // The reduced system and its right-hand side in ONE launch (independent of each other; both only need Dinv / db of the
 // prologue): workgroups [0, nb_blk) build the 6x6 blocks, the rest the rhs row.
 constexpr int kSchurWaves = 2;   // one wave per workgroup: 12 KB of LDS each, every block resident at once, no lock-step between blocks
-__global__ void __launch_bounds__(64 * kSchurWaves) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs) {
+__global__ void __launch_bounds__(64 * kSchurWaves) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs, int* __restrict__ fail_reset) {
+  // speculative launch (ba_launch_schur_speculative): the damping comes from the device-side decision; a negative value = the
+  // trial before this one was rejected, the host will start the next one itself.  There is no prologue launch in front of a
+  // speculative one: the Cholesky failure flag is reset here.
+  if (fail_reset) {
+    if (*V.lambda < 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fail_reset = 0;
+  }
   // The rhs workgroups come FIRST: a camera's rhs is one wave walking ~320 edges (17 us on its own); dispatched behind
   // thousands of block workgroups it would start late and set the kernel's tail.
   if ((int)blockIdx.x < nb_rhs) { schur_rhs_body<kSchurWaves>(V, blockIdx.x); return; }
@@ -2186,10 +2225,10 @@ void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPubli
   if (jac) hipLaunchKernelGGL(k_edge_eval<true>, dim3(nb), dim3(256), 0, s, V, pub);
   else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V, pub);
 }
-void ba_launch_accum(hipStream_t s, const BaView& V) {
+void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec) {
   const int nb_pose = V.nfree > 0 ? cdiv(V.nfree, 4) : 0;
   const int nb_point = cdiv(V.L, 256);
-  hipLaunchKernelGGL(k_accum, dim3(nb_pose + nb_point + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_pose, nb_point);
+  hipLaunchKernelGGL(k_accum, dim3(nb_pose + nb_point + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_pose, nb_point, spec);
 }
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);
@@ -2200,7 +2239,17 @@ void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   if (V.nfree == 0) return;
   const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
   const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
-  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs);
+  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, (int*)nullptr);
+}
+void ba_launch_schur_speculative(hipStream_t s, const BaView& V, int* d_fail) {
+  if (V.nfree == 0 || !V.lambda) return;
+  const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);
+  const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;
+  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, d_fail);
+}
+__global__ void __launch_bounds__(256) k_clear_tiles(BaView V) { clear_tile(V, blockIdx.x); }
+void ba_launch_clear_tiles(hipStream_t s, const BaView& V) {
+  if (V.nfree > 0 && V.n_nz > 0) hipLaunchKernelGGL(k_clear_tiles, dim3(V.n_nz), dim3(256), 0, s, V);
 }
 constexpr int kFusedLevelMaxWGs = 512;   // 2 workgroups per CU on 256 CUs (3 fit: 41 KB of LDS each); the leaf level of the BASELINE problem (536) measured the same fused or not
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {

@@ -36,6 +36,8 @@ struct dvm_ba {
   double* d_vals = nullptr;                 // the same memory as the device sees it
   unsigned long long seq = 0;
   int solve_seq = 0;
+  bool speculate = true;     // device-side accept / reject + the next trial's Schur complement enqueued ahead (DVM_BA_NO_SPECULATION=1: off)
+  double* d_spec = nullptr;  // device [2]: BaPublish::spec
   bool fuse_levels = true;   // k_chol_trsm_update (solve + update of a level in one launch) until one of its waits times out
   // landmark-sharded mode (dvm_ba_set_problem_sharded): rank r of `world` owns the landmarks l with l % world == r
   int rank = 0, world = 1;
@@ -150,6 +152,9 @@ int dvm_ba_create(int device, dvm_ba** out) {
   if (rc == DVM_OK) rc = hip_check(hipMemset(h->d_counter, 0, 4 * sizeof(unsigned int)), "memset");
   if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_dev_vals, 8 * sizeof(double)), "malloc");
   if (rc == DVM_OK) rc = hip_check(hipMemset(h->d_dev_vals, 0, 8 * sizeof(double)), "memset");
+  if (rc == DVM_OK) rc = hip_check(hipMalloc(&h->d_spec, 2 * sizeof(double)), "malloc");
+  if (rc == DVM_OK) rc = hip_check(hipMemset(h->d_spec, 0, 2 * sizeof(double)), "memset");
+  h->speculate = std::getenv("DVM_BA_NO_SPECULATION") == nullptr;
   if (rc == DVM_OK) rc = hip_check(hipHostMalloc(&h->h_vals, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent), "hostmalloc");
   if (rc == DVM_OK) { std::memset(h->h_vals, 0, 16 * sizeof(double)); rc = hip_check(hipHostGetDevicePointer((void**)&h->d_vals, h->h_vals, 0), "devptr"); }
   if (rc != DVM_OK) { dvm_ba_destroy(h); return rc; }
@@ -167,6 +172,7 @@ void dvm_ba_destroy(dvm_ba* h) {
   for (auto& e : h->pev) if (e) hipEventDestroy(e);
   if (h->d_counter) hipFree(h->d_counter);
   if (h->d_dev_vals) hipFree(h->d_dev_vals);
+  if (h->d_spec) hipFree(h->d_spec);
   if (h->h_vals) hipHostFree(h->h_vals);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -482,9 +488,15 @@ int64_t dvm_ba_allreduce_doubles(const dvm_ba* h) {
 static int wait_seq(dvm_ba* h, unsigned long long seq) {
   volatile unsigned long long* p = reinterpret_cast<volatile unsigned long long*>(h->h_vals + 8);
   const auto t0 = std::chrono::steady_clock::now();
+  double next_query = 5e-3;   // seconds.  NOT earlier: hipStreamQuery puts a marker packet on the queue when work is pending, and a
+                              // marker between two kernels of a trial (the next trial's k_schur is enqueued before this wait)
+                              // costs the device ~6 us -- a healthy trial publishes within a millisecond
   for (unsigned spin = 0;; spin++) {
     if (*p >= seq) { std::atomic_thread_fence(std::memory_order_acquire); return DVM_OK; }
     if ((spin & 0xFFF) == 0xFFF) {
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited < next_query) continue;
+      next_query = waited + 5e-3;
       const hipError_t q = hipStreamQuery(h->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return hip_check(q, "bundle adjustment stream");
       if (q == hipSuccess && *p < seq) {           // everything ran, nothing was published: should be impossible
@@ -492,7 +504,7 @@ static int wait_seq(dvm_ba* h, unsigned long long seq) {
         set_error("bundle adjustment: phase result was not published");
         return DVM_ERR_HIP;
       }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+      if (waited > 30.0) {
         set_error("bundle adjustment: timed out waiting for the device");
         return DVM_ERR_HIP;
       }
@@ -519,6 +531,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     p.dev_vals = h->d_dev_vals; p.host_vals = h->d_vals; p.host_seq = reinterpret_cast<unsigned long long*>(h->d_vals + 8);
     p.seq = publish ? ++h->seq : 0; p.counter = h->d_counter + counter; p.d_fail = with_fail ? h->d_fail : nullptr;
     p.slot = slot; p.publish = publish ? 1 : 0;
+    p.spec = nullptr; p.cur_chi = 0; p.lambda = 0; p.n_bad = 0;
     return p;
   };
   // a one-rank job that registered a collective takes the sharded flow too (sum over one rank = identity): that is how the
@@ -543,6 +556,15 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   // on the same values g2o would compute them on); a rejected trial's buffers are simply overwritten by the next one.
   bool lin_ready = false;
   double spec_chi = 0;
+  // Speculation on acceptance, one step further: the workgroup that publishes a trial's chi2 takes the accept / reject
+  // decision and the next damping itself (BaPublish::spec), the linearisation's launch derives the landmark inverses of the
+  // NEXT trial from it, and that trial's Schur complement is enqueued right behind -- all before the host has seen chi2, so an
+  // accepted trial (the normal case) costs the device neither the host's decision latency nor a prologue launch.  The host
+  // takes the same decision on the same numbers and only keeps what was enqueued if the device's damping equals its own bit
+  // for bit; otherwise (a rejected trial: the speculative launch has done nothing; a damping that differs in the last bit: it
+  // has filled S) the next trial starts the ordinary way, after emptying S if need be.
+  const bool speculate = !sharded && h->speculate;
+  bool schur_enqueued = false;      // the NEXT trial's k_schur is already on the stream, for (V after the swap, lambda)
   for (int it = 0; it < iterations && !terminate(); it++) {
     int rc = DVM_OK;
     if (!lin_ready) {
@@ -586,13 +608,18 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     }
     double rho = 0;
     int qmax = 0;
+    bool spec_now = false;
     do {
       // one trial = setLambda + Schur complement + reduced solve + landmarks + oplus into the TRIAL state + its chi2:
       // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
       V.lambda_v = lambda;
       for (int attempt = 0;; attempt++) {
       if (h->prof) hipEventRecord(h->pev[0], s);
-      ba_launch_schur(s, V, h->d_fail);
+      if (schur_enqueued && attempt == 0) schur_enqueued = false;        // this trial's Schur complement is on the stream already
+      else {
+        if (attempt > 0) ba_launch_clear_tiles(s, V);                      // the failed attempt's solve has consumed S
+        ba_launch_schur(s, V, h->d_fail);
+      }
       if (h->prof) hipEventRecord(h->pev[1], s);
       if (sharded) {   // sum the partial reduced systems (non-zero tiles incl. the rhs row): ~6 MB at 500 keyframes
         ba_launch_pack_tiles(s, V, h->ar_buf, false);
@@ -610,9 +637,19 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         BaView VT = V;                                   // the trial state, linearised into the alternate buffers
         VT.poses = V.poses_new; VT.points = V.points_new;
         VT.e_lin = h->alt_lin; VT.e_W = h->alt_W; VT.Hpp = h->alt_Hpp; VT.bp = h->alt_bp; VT.Hll = h->alt_Hll; VT.bl = h->alt_bl;
-        ba_launch_edge_eval(s, VT, true, pub(S_TMPCHI, 0, true, true));
-        ba_launch_accum(s, VT);                          // runs while the host waits for chi2 and decides
+        // (no speculation into an iteration that will not run, nor on a repeated attempt)
+        spec_now = speculate && attempt == 0 && it + 1 < iterations;
+        BaPublish pe = pub(S_TMPCHI, 0, true, true);
+        if (spec_now) { pe.spec = h->d_spec; pe.cur_chi = currentChi; pe.lambda = lambda; pe.n_bad = nBad; }
+        ba_launch_edge_eval(s, VT, true, pe);
+        ba_launch_accum(s, VT, spec_now ? h->d_spec : nullptr);   // runs while the host waits for chi2 and decides
         if (h->prof) hipEventRecord(h->pev[3], s);
+        if (spec_now) {
+          BaView VA = VT;                                // the next trial as it looks if this one is accepted
+          VA.poses_new = V.poses; VA.points_new = V.points;
+          VA.lambda = h->d_spec;
+          ba_launch_schur_speculative(s, VA, h->d_fail);
+        }
       }
       rc = hip_check(hipGetLastError(), "bundle adjustment launch");
       mark("trial launched", it);
@@ -621,9 +658,17 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       mark("trial published", it);
       // a wait inside the solve gave up (other work held the compute units its producer needed): nothing was decided on this
       // result -- the same trial runs again, with one launch per phase from now on
-      if (h->h_vals[S_FAIL] == 2.0 && h->fuse_levels && !sharded && attempt == 0) { h->fuse_levels = false; continue; }
+      if (h->h_vals[S_FAIL] == 2.0 && h->fuse_levels && !sharded && attempt == 0) {
+        h->fuse_levels = false;
+        if (spec_now) {                                  // whatever was enqueued behind the failed attempt is void
+          DVM_HIP(hipStreamSynchronize(s));
+          spec_now = false;
+        }
+        continue;
+      }
       break;
       }
+      const double dev_next = spec_now ? h->h_vals[7] : -1.0;   // the device's decision: next damping, or -1 (rejected)
       if (h->prof) {
         hipEventSynchronize(h->pev[3]);
         for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, h->pev[k], h->pev[k + 1]); h->prof_ms[1 + k] += ms; }
@@ -651,9 +696,16 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         std::swap(V.e_lin, h->alt_lin); std::swap(V.e_W, h->alt_W); std::swap(V.Hpp, h->alt_Hpp); std::swap(V.bp, h->alt_bp);
         std::swap(V.Hll, h->alt_Hll); std::swap(V.bl, h->alt_bl);
         lin_ready = true; spec_chi = tempChi;
+        if (spec_now) {
+          if (std::memcmp(&dev_next, &lambda, sizeof(double)) == 0) schur_enqueued = true;   // same decision, same damping: keep it
+          else if (dev_next >= 0) ba_launch_clear_tiles(s, V);                                // it ran on another damping
+          if (st) { st->spec_trials++; st->spec_kept += schur_enqueued ? 1 : 0; }
+        }
       } else {
         lambda *= ni;
         ni *= 2;                               // pop(): (poses, points) were never touched
+        if (spec_now && dev_next >= 0) ba_launch_clear_tiles(s, V);   // (the device accepted what the host rejects: never seen)
+        if (st && spec_now) st->spec_trials++;
       }
       qmax++;
       trials_total++;

@@ -312,6 +312,8 @@ typedef struct {
   int32_t trials_per_iter[64];
   double chi2_per_iter[64], lambda_per_iter[64];
   double ms_structure, ms_optimize;                   /* host wall time: graph build / optimize() */
+  int32_t spec_trials, spec_kept;                     /* trials whose successor was enqueued on the device's own accept decision,
+                                                         and how many of those the host's decision confirmed bit for bit */
 } dvm_ba_stats;
 typedef struct dvm_ba dvm_ba;
 int dvm_ba_create(int device, dvm_ba** out);
