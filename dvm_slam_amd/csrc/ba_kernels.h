@@ -93,6 +93,7 @@ struct BaPublish {
   // on the stream (k_accum's landmark inverses, the next trial's k_schur) read it instead of waiting for the host.
   double* spec;                   // device [2], or null: no decision on the device
   double cur_chi, lambda;         // the iteration's accepted chi2 and the trial's damping
+  int spec_mode;                  // 0: the LM decision described above; 1: spec[0] = 1e-5 * (the reduced max |diag|), computeLambdaInit
   int n_bad;                      // iterations in a row without a 0.1 % improvement so far (the stopping rule of dvm_ba_optimize): an accepted
                                   // trial that completes the third one ends the optimisation -- nothing is enqueued behind it (spec[0] = -2)
 };
@@ -121,7 +122,8 @@ void pg_launch_update(hipStream_t s, const PgView& G, const BaView& T, double* d
 // jac: linearise at (poses, points); !jac: chi2 only, at the trial state (poses_new, points_new)
 void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPublish& pub);
 // spec (device, BaPublish::spec) != null: landmarks also get Dinv / db for the damping an accepted trial continues with
-void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec = nullptr);
+// max_pub != null: the launch also reduces max |diag(Hpp), diag(Hll)| and publishes it (computeLambdaInit's input)
+void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec = nullptr, const BaPublish* max_pub = nullptr);
 // the structurally non-zero tiles of S back to empty (what ba_launch_accum does on its way)
 void ba_launch_clear_tiles(hipStream_t s, const BaView& V);
 // the Schur complement alone, for a trial whose damping is decided on the device: V.lambda points at BaPublish::spec (a negative

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "ba_kernels.h"
 
@@ -112,10 +113,10 @@ __device__ __forceinline__ double ba_lambda(const BaView& V) { return V.lambda ?
 // Block sum of `v` -> partial[blockIdx.x]; the last workgroup to arrive then reduces all partials exactly like
 // k_reduce_sum (thread-strided sums, then the same tree: identical bits) and hands the result to the host (BaPublish).
 template <bool MAX>
-__device__ __forceinline__ void block_reduce_publish(double v, double* __restrict__ partial, const BaPublish& pub) {
+__device__ __forceinline__ void block_reduce_publish(double v, double* __restrict__ partial, const BaPublish& pub, int nb_part = 0) {
   __shared__ double s_red[256];
   __shared__ int s_last;
-  const int tid = threadIdx.x, nb = gridDim.x;
+  const int tid = threadIdx.x, nb = nb_part ? nb_part : (int)gridDim.x;   // workgroups [0, nb) take part
   s_red[tid] = v;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
@@ -163,7 +164,8 @@ __device__ __forceinline__ void block_reduce_publish(double v, double* __restric
         const double scale = (f == 0 ? __hip_atomic_load(pub.dev_vals + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0) + 1e-3;
         const double rho = (pub.cur_chi - tmp) / scale;
         double next = -1.0;
-        if (rho > 0 && isfinite(tmp)) {
+        if (pub.spec_mode == 1) next = 1e-5 * s_red[0];   // computeLambdaInit (_tau = 1e-5) on the max |diag| this workgroup has just reduced
+        else if (rho > 0 && isfinite(tmp)) {
           const double t = 2 * rho - 1;
           const double t2 = t * t, e2 = __builtin_fma(t, t, -t2);
           const double t3 = t2 * t, e3 = __builtin_fma(t2, t, -t3);
@@ -339,9 +341,9 @@ __device__ __forceinline__ void dinv_apply(const double* H, const double* bl, do
 }
 
 // Hll (3x3) and bl per landmark: thread per landmark, edges in input order.
-__device__ __forceinline__ void point_accum_body(const BaView& V, int block, const double* __restrict__ spec) {
+__device__ __forceinline__ double point_accum_body(const BaView& V, int block, const double* __restrict__ spec) {   // returns max |Hll diagonal|
   const int l = block * 256 + threadIdx.x;
-  if (l >= V.L) return;
+  if (l >= V.L) return 0.0;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   for (int i = V.pt_start[l]; i < V.pt_start[l + 1]; i++) {
     const double* lin = V.e_lin + (size_t)V.pt_edges[i] * kEdgeLinStride;
@@ -363,14 +365,15 @@ __device__ __forceinline__ void point_accum_body(const BaView& V, int block, con
     const double lambda = *spec;
     if (lambda >= 0 && V.pt_start[l + 1] != V.pt_start[l]) dinv_apply(H, b, lambda, V.Dinv + 9 * (size_t)l, V.db + 3 * (size_t)l);
   }
+  return V.pt_start[l + 1] > V.pt_start[l] ? fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8]))) : 0.0;   // (a landmark nobody observes is no vertex)
 }
 
 // Hpp (6x6) and bp per free camera: one wave per camera, lanes stride over the camera's edges, then a
 // fixed-order xor-butterfly reduction (identical on every run).
-__device__ __forceinline__ void pose_accum_body(const BaView& V, int block) {
+__device__ __forceinline__ double pose_accum_body(const BaView& V, int block) {   // returns this thread's |Hpp diagonal entry| (or 0)
   const int lane = threadIdx.x & 63;
   const int fi = block * 4 + (threadIdx.x >> 6);
-  if (fi >= V.nfree) return;
+  if (fi >= V.nfree) return 0.0;
   const int p = V.free_pose[fi];
   double H[21], b[6];
 #pragma unroll
@@ -403,9 +406,11 @@ __device__ __forceinline__ void pose_accum_body(const BaView& V, int block) {
     double* out = V.Hpp + 36 * (size_t)fi;
     out[6 * a + c] = tot;
     out[6 * c + a] = tot;
+    return a == c ? fabs(tot) : 0.0;
   } else if (lane < 27) {
     V.bp[6 * (size_t)fi + (lane - 21)] = tot;
   }
+  return 0.0;
 }
 
 // one structurally non-zero tile of the reduced system back to "empty": zeros, identity on the padding rows of a diagonal tile
@@ -428,10 +433,14 @@ __device__ __forceinline__ void clear_tile(const BaView& V, int t) {
 // empty the reduced system for the trial that follows: every trial is preceded by a linearisation, the factor of the last
 // trial is dead by then, and this launch runs while the host decides -- the trial's own first launch shrinks to the 79
 // landmark workgroups.
-__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose, int nb_point, const double* __restrict__ spec) {
-  if ((int)blockIdx.x < nb_pose) pose_accum_body(V, blockIdx.x);
-  else if ((int)blockIdx.x < nb_pose + nb_point) point_accum_body(V, blockIdx.x - nb_pose, spec);
-  else clear_tile(V, blockIdx.x - nb_pose - nb_point);
+// with_max: the launch also delivers max |diag| over Hpp and Hll (computeLambdaInit; k_max_diag as a launch of its own before).
+__global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose, int nb_point, const double* __restrict__ spec, BaPublish pub, int with_max) {
+  if (spec && *spec == -2.0) return;   // the device-side decision: accepted, and the optimisation ends with it -- nobody reads this linearisation
+  double m;
+  if ((int)blockIdx.x < nb_pose) m = pose_accum_body(V, blockIdx.x);
+  else if ((int)blockIdx.x < nb_pose + nb_point) m = point_accum_body(V, blockIdx.x - nb_pose, spec);
+  else { clear_tile(V, blockIdx.x - nb_pose - nb_point); return; }
+  if (with_max) block_reduce_publish<true>(m, V.partial2, pub, nb_pose + nb_point);
 }
 
 // max |diag| over Hpp and Hll (computeLambdaInit) -> host, grid-wide with the last workgroup finishing the reduction.
@@ -2225,10 +2234,13 @@ void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPubli
   if (jac) hipLaunchKernelGGL(k_edge_eval<true>, dim3(nb), dim3(256), 0, s, V, pub);
   else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V, pub);
 }
-void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec) {
+void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec, const BaPublish* max_pub) {
   const int nb_pose = V.nfree > 0 ? cdiv(V.nfree, 4) : 0;
   const int nb_point = cdiv(V.L, 256);
-  hipLaunchKernelGGL(k_accum, dim3(nb_pose + nb_point + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_pose, nb_point, spec);
+  BaPublish none;
+  std::memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(k_accum, dim3(nb_pose + nb_point + (V.nfree > 0 ? V.n_nz : 0)), dim3(256), 0, s, V, nb_pose, nb_point, spec,
+                     max_pub ? *max_pub : none, max_pub ? 1 : 0);
 }
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);

@@ -382,7 +382,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)V.n_pad + 64 + 2 * (SC.strips.size() / 2) + 2));
   ok(h->dalloc(&V.xrow, (size_t)V.n_pad + 64));
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
-  ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(8 * (size_t)L + 255) / 256 + (size_t)(V.nfree + 255) / 256 + 2));   // block partials of k_point_backsub / k_max_diag
+  ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(8 * (size_t)L + 255) / 256 + (size_t)(V.nfree + 255) / 256 + (size_t)(V.nfree + 3) / 4 + 2));   // block partials of k_point_backsub / k_max_diag
   ok(h->dalloc(&h->d_depth, (size_t)E));
   ok(h->upload(&V.nz_tiles, SC.nz_tiles)); V.n_nz = (int)(SC.nz_tiles.size() / 2);
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
@@ -531,7 +531,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     p.dev_vals = h->d_dev_vals; p.host_vals = h->d_vals; p.host_seq = reinterpret_cast<unsigned long long*>(h->d_vals + 8);
     p.seq = publish ? ++h->seq : 0; p.counter = h->d_counter + counter; p.d_fail = with_fail ? h->d_fail : nullptr;
     p.slot = slot; p.publish = publish ? 1 : 0;
-    p.spec = nullptr; p.cur_chi = 0; p.lambda = 0; p.n_bad = 0;
+    p.spec = nullptr; p.cur_chi = 0; p.lambda = 0; p.n_bad = 0; p.spec_mode = 0;
     return p;
   };
   // a one-rank job that registered a collective takes the sharded flow too (sum over one rank = identity): that is how the
@@ -565,16 +565,34 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   // has filled S) the next trial starts the ordinary way, after emptying S if need be.
   const bool speculate = !sharded && h->speculate;
   bool schur_enqueued = false;      // the NEXT trial's k_schur is already on the stream, for (V after the swap, lambda)
+  bool tiles_clear = false;         // the structurally non-zero tiles of S are empty: k_accum's launch was the last to touch S
   for (int it = 0; it < iterations && !terminate(); it++) {
     int rc = DVM_OK;
+    bool first_spec = false;
     if (!lin_ready) {
     // computeActiveErrors + activeRobustChi2 + buildSystem (one fused edge pass at the current state).  chi2 reaches the
     // host from the edge pass itself, so the accumulation kernels below run while the host prepares the first trial.
     if (h->prof) hipEventRecord(h->pev[0], s);
     ba_launch_edge_eval(s, V, true, pub(S_CHI, 0, it != 0 || sharded, false));
-    ba_launch_accum(s, V);
+    if (it == 0 && !sharded) {
+      // computeLambdaInit's max |diag| comes out of the accumulation launch itself; with speculation on, the first trial's
+      // prologue and Schur complement follow at once on the damping the device derives from it (checked below)
+      BaPublish pm = pub(S_MAXDIAG, 1, true, false);
+      first_spec = speculate && iterations > 0;
+      if (first_spec) { pm.spec = h->d_spec; pm.spec_mode = 1; }
+      ba_launch_accum(s, V, nullptr, &pm);
+      tiles_clear = true;
+      if (first_spec) {
+        BaView VA = V;
+        VA.lambda = h->d_spec;
+        ba_launch_schur(s, VA, h->d_fail);
+        tiles_clear = false;
+      }
+    } else {
+      ba_launch_accum(s, V);
+      tiles_clear = true;
+    }
     if (h->prof) hipEventRecord(h->pev[1], s);
-    if (it == 0 && !sharded) ba_launch_max_diag(s, V, pub(S_MAXDIAG, 1, true, false));
     rc = hip_check(hipGetLastError(), "bundle adjustment launch");
     if (rc == DVM_OK) rc = wait_seq(h, h->seq);
     if (rc != DVM_OK) return rc;
@@ -605,6 +623,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       if (st) st->chi2_initial = currentChi;
       lambda = 1e-5 * h->h_vals[S_MAXDIAG];  // computeLambdaInit, _tau = 1e-5
       ni = 2; nBad = 0;
+      if (first_spec) {
+        const double dev_l = h->h_vals[7];
+        if (std::memcmp(&dev_l, &lambda, sizeof(double)) == 0) schur_enqueued = true;   // (else: it ran on another damping, S is cleared below)
+        if (st) { st->spec_trials++; st->spec_kept += schur_enqueued ? 1 : 0; }
+      }
     }
     double rho = 0;
     int qmax = 0;
@@ -617,9 +640,12 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       if (h->prof) hipEventRecord(h->pev[0], s);
       if (schur_enqueued && attempt == 0) schur_enqueued = false;        // this trial's Schur complement is on the stream already
       else {
-        if (attempt > 0) ba_launch_clear_tiles(s, V);                      // the failed attempt's solve has consumed S
+        // S must be empty where the Schur complement does not write: normally the linearisation's launch has seen to it; not
+        // after a failed attempt (its solve has consumed S), a speculative launch on another damping, or a chi2-only evaluation
+        if (!tiles_clear) ba_launch_clear_tiles(s, V);
         ba_launch_schur(s, V, h->d_fail);
       }
+      tiles_clear = false;
       if (h->prof) hipEventRecord(h->pev[1], s);
       if (sharded) {   // sum the partial reduced systems (non-zero tiles incl. the rhs row): ~6 MB at 500 keyframes
         ba_launch_pack_tiles(s, V, h->ar_buf, false);
@@ -641,14 +667,20 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         spec_now = speculate && attempt == 0 && it + 1 < iterations;
         BaPublish pe = pub(S_TMPCHI, 0, true, true);
         if (spec_now) { pe.spec = h->d_spec; pe.cur_chi = currentChi; pe.lambda = lambda; pe.n_bad = nBad; }
-        ba_launch_edge_eval(s, VT, true, pe);
-        ba_launch_accum(s, VT, spec_now ? h->d_spec : nullptr);   // runs while the host waits for chi2 and decides
+        if (it + 1 >= iterations && !sharded) {
+          ba_launch_edge_eval(s, V, false, pe);          // the budget's last iteration: nobody will use a linearisation, chi2 alone (same sum)
+        } else {
+          ba_launch_edge_eval(s, VT, true, pe);
+          ba_launch_accum(s, VT, spec_now ? h->d_spec : nullptr);   // runs while the host waits for chi2 and decides
+          tiles_clear = true;
+        }
         if (h->prof) hipEventRecord(h->pev[3], s);
         if (spec_now) {
           BaView VA = VT;                                // the next trial as it looks if this one is accepted
           VA.poses_new = V.poses; VA.points_new = V.points;
           VA.lambda = h->d_spec;
           ba_launch_schur_speculative(s, VA, h->d_fail);
+          tiles_clear = false;                           // (true again below if the device rejected the trial: that launch does nothing)
         }
       }
       rc = hip_check(hipGetLastError(), "bundle adjustment launch");
@@ -669,6 +701,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       break;
       }
       const double dev_next = spec_now ? h->h_vals[7] : -1.0;   // the device's decision: next damping, or -1 (rejected)
+      if (spec_now && dev_next < 0) tiles_clear = true;
       if (h->prof) {
         hipEventSynchronize(h->pev[3]);
         for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, h->pev[k], h->pev[k + 1]); h->prof_ms[1 + k] += ms; }
@@ -698,13 +731,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         lin_ready = true; spec_chi = tempChi;
         if (spec_now) {
           if (std::memcmp(&dev_next, &lambda, sizeof(double)) == 0) schur_enqueued = true;   // same decision, same damping: keep it
-          else if (dev_next >= 0) ba_launch_clear_tiles(s, V);                                // it ran on another damping
           if (st) { st->spec_trials++; st->spec_kept += schur_enqueued ? 1 : 0; }
         }
       } else {
         lambda *= ni;
         ni *= 2;                               // pop(): (poses, points) were never touched
-        if (spec_now && dev_next >= 0) ba_launch_clear_tiles(s, V);   // (the device accepted what the host rejects: never seen)
         if (st && spec_now) st->spec_trials++;
       }
       qmax++;
@@ -723,8 +754,12 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     if (rc != DVM_OK) return rc;
     ba_launch_points_exchange(s, V, h->ar_buf, true);
   }
-  DVM_HIP(hipStreamSynchronize(s));
-  mark("stream drained", it_done);
+  // The answer is complete: the last trial's publication is behind every launch that writes the state.  What may still be on
+  // the stream is the speculative linearisation behind that trial (it leaves at once when the device saw the optimisation end);
+  // every entry point that reads device memory synchronises the stream itself, so the blocking wait here -- 50-80 us of
+  // interrupt latency on an almost idle stream, per call -- is only paid where a collective has to be finished.
+  if (sharded) DVM_HIP(hipStreamSynchronize(s));
+  mark("returning", it_done);
   if (st) {
     st->iterations = it_done; st->total_trials = trials_total; st->stop_reason = stop;
     st->chi2_final = chi_last; st->lambda_final = lambda;
