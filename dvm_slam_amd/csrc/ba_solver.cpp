@@ -563,7 +563,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   // takes the same decision on the same numbers and only keeps what was enqueued if the device's damping equals its own bit
   // for bit; otherwise (a rejected trial: the speculative launch has done nothing; a damping that differs in the last bit: it
   // has filled S) the next trial starts the ordinary way, after emptying S if need be.
-  const bool speculate = !sharded && h->speculate;
+  const bool speculate = !sharded && h->speculate && !h->prof;   // (the profiling pass times every phase of a trial on its own)
   bool schur_enqueued = false;      // the NEXT trial's k_schur is already on the stream, for (V after the swap, lambda)
   bool tiles_clear = false;         // the structurally non-zero tiles of S are empty: k_accum's launch was the last to touch S
   for (int it = 0; it < iterations && !terminate(); it++) {
