@@ -58,9 +58,16 @@ int main(int argc, char** argv) {
     for (int t = S.tgt_off[h]; t < S.tgt_off[h + 1]; t++) {
       const int ti = S.targets[4 * t], tj = S.targets[4 * t + 1];
       if (level_of[ti] <= h || level_of[tj] <= h) return fail("update target already factored");
-      for (int c = S.targets[4 * t + 2]; c < S.targets[4 * t + 3]; c++)
+      for (int c = S.targets[4 * t + 2]; c < S.targets[4 * t + 3]; c++) {
         if (level_of[S.contrib[c]] != h) return fail("contribution from another level");
+        // k_chol_trsm_update waits on the slices of exactly these two strips: (ti, k) and (tj, k), both solved by THIS level's launch
+        const int ti = S.targets[4 * t], tj = S.targets[4 * t + 1], k = S.contrib[c];
+        const int si = S.contrib_strip[2 * c], sj = S.contrib_strip[2 * c + 1];
+        if (si < S.strip_off[h] || si >= S.strip_off[h + 1] || sj < S.strip_off[h] || sj >= S.strip_off[h + 1]) return fail("contrib_strip outside the level");
+        if (S.strips[2 * si] != ti || S.strips[2 * si + 1] != k || S.strips[2 * sj] != tj || S.strips[2 * sj + 1] != k) return fail("contrib_strip names another strip");
+      }
     }
+    if (S.contrib_strip.size() != 2 * S.contrib.size()) return fail("contrib_strip size");
   }
   std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
               S.targets.size() / 4);
