@@ -157,7 +157,9 @@ __device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, in
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
+// (80 SGPRs: a 256-thread workgroup is admitted per CU up to 800 / (ceil(sgpr / 16) * 16 + 16) times -- 6 at the 101 the compiler
+// takes on its own, 8 at <= 80, which is also what the 17.5 KB of LDS allow: all 2 048 workgroups of a 256-frame batch resident at once)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
                                                 const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
                                                 int32_t* __restrict__ lvl_count, PipelineDesc PD,
                                                 int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
