@@ -62,6 +62,8 @@ struct BaView {
   const int32_t* colstrips;     // per column: its strip rows
   const int32_t *h_level_off, *h_strip_off, *h_tgt_off;  // HOST arrays [nlevels+1]
   int32_t nlevels;
+  int32_t n_root_raw;       // columns of the last launched level whose only strip is the rhs row: their panel solve (one 64x64
+                            // matrix-vector product each) is done by the back substitution itself, no k_chol_trsm launch (0: launch it)
   const double* lambda;     // device scalar with the current LM damping (pose graph), or null: use lambda_v
   double lambda_v;          // LM damping by value (bundle adjustment: no H2D copy per trial)
   double damp_s;            // 1 normally.  Landmark-sharded BA (dvm_ba_set_problem_sharded): every rank builds a PARTIAL reduced

@@ -1230,16 +1230,17 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
                                                         const double* __restrict__ Linv_all,
                                                         const int32_t* __restrict__ colstrip_off,
                                                         const int32_t* __restrict__ colstrips, int32_t* __restrict__ sync, int gen,
-                                                        int* __restrict__ fail) {
+                                                        int* __restrict__ fail, int n_raw) {
   __shared__ double yk[NB];
   __shared__ double xi[NB];
   __shared__ double part[4][NB];
-  __shared__ int s_col;
+  __shared__ int s_col, s_ticket;
   const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
   if (tid == 0) {
     const int t = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == ncols - 1) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is taken
     s_col = cols[ncols - 1 - t];     // `cols` lists leaves first
+    s_ticket = t;
   }
   __syncthreads();
   const int kb = s_col;
@@ -1253,6 +1254,22 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   double lk[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) lk[r] = Lk[(16 * q + r) * NB + c];
+  if (s_ticket < n_raw) {
+    // a column of the last level: nothing but the rhs row hangs below it, and the factorisation left that row unsolved (the
+    // launcher skipped the level's k_chol_trsm: 5 us for one 64 x 64 matrix-vector product per column) -- y_k = Linv_kk r here
+    __shared__ double Pm[NB][NB + 1];
+    __syncthreads();                               // yk (= r) is in LDS
+#pragma unroll
+    for (int r = 0; r < 16; r++) Pm[16 * q + r][c] = lk[r] * yk[c];
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) s += Pm[c][16 * q + j];
+    part[q][c] = s;
+    __syncthreads();
+    if (tid < NB) yk[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+  }
   const int s_beg = colstrip_off[kb], s_end = colstrip_off[kb + 1];
   double tl[16];
   auto fetch_tile = [&](int s) {
@@ -2271,6 +2288,9 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   // (one launch per phase) has to produce the result (tests/test_gpu_ba.py)
   static const bool break_handoff = std::getenv("DVM_BA_DEBUG_BREAK_HANDOFF") != nullptr;
   double* tag = V.xrow;   // the first launch that solves strips also re-arms the back substitution's hand-off slots (no strips: no waits)
+  int root_level = V.nlevels - 1;          // the last level that is launched (see the break below), where n_root_raw applies
+  if (root_level >= 1 && V.h_level_off[root_level + 1] - V.h_level_off[root_level] == 1 && V.h_strip_off[root_level + 1] == V.h_strip_off[root_level] &&
+      V.h_tgt_off[root_level + 1] == V.h_tgt_off[root_level]) root_level--;
   for (int h = 0; h < V.nlevels; h++) {
     const int nc = V.h_level_off[h + 1] - V.h_level_off[h], ns = V.h_strip_off[h + 1] - V.h_strip_off[h];
     const int nt = V.h_tgt_off[h + 1] - V.h_tgt_off[h];
@@ -2287,6 +2307,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
       tag = nullptr;
       continue;
     }
+    if (ns > 0 && nt == 0 && V.n_root_raw > 0 && h == root_level) continue;   // the back substitution solves these rhs strips itself
     if (ns > 0) { hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h], tag, V.n_pad); tag = nullptr; }
     if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }
@@ -2296,7 +2317,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   if (ncols > 0)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(ncols), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.nfree, V.per_tile, V.dof, V.cols, ncols,
                        V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips, reinterpret_cast<int32_t*>(V.ytmp),
-                       solve_seq, d_fail);
+                       solve_seq, d_fail, V.n_root_raw);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub) {
   const int nb_pose = cdiv(std::max(V.nfree, 1), 256);
