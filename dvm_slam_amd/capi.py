@@ -456,7 +456,7 @@ class BundleAdjuster:
         n = min(st.iterations, 64)
         return dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason,
                     chi2_initial=st.chi2_initial, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
-                    trials=list(st.trials_per_iter[:n]), chi2=list(st.chi2_per_iter[:n]), lam=list(st.lambda_per_iter[:n]),
+                    trials=st.trials_per_iter[:n], chi2=st.chi2_per_iter[:n], lam=st.lambda_per_iter[:n],   # (a ctypes array slice is a list)
                     ms_structure=st.ms_structure, ms_optimize=st.ms_optimize, spec_trials=st.spec_trials, spec_kept=st.spec_kept)
 
     def result(self):
