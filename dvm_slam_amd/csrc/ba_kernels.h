@@ -7,7 +7,9 @@
 
 namespace dvm {
 
-constexpr int kEdgeLinStride = 24;  // doubles per edge: A[6] B[12] w wr0 wr1 + pad
+constexpr int kEdgeLinStride = 16;  // doubles per edge and array (one 128-byte line each): e_lin = B[12] w wr0 wr1 + pad (what the camera
+                                    // accumulation reads), e_linA = A[6] w wr0 wr1 + pad (what the landmark accumulation reads).  As ONE 192-byte row both
+                                    // gathers dragged 2-3 lines per edge through the memory system: ~100 MB for 30 MB of operands
 // first row of camera i (elimination order) in the tiled reduced system: 10 whole cameras per 64-row tile
 __host__ __device__ inline int ba_row(int i) { return (i / 10) * 64 + (i % 10) * 6; }
 
@@ -24,7 +26,8 @@ struct BaView {
   const double* e_obs;      // [E][2]
   const double* e_info;     // [E]
   double* e_chi2;           // [E] chi2 at the last evaluation (what g2o's e->chi2() reports)
-  double* e_lin;            // [E][kEdgeLinStride]
+  double* e_lin;            // [E][kEdgeLinStride]  pose half of the linearisation
+  double* e_linA;           // [E][kEdgeLinStride]  landmark half
   double* e_W;              // [E][18]  Hpl block (pose 6 x point 3)
   const int32_t* pt_start;  // [L+1] CSR landmark -> edges (input order)
   const int32_t* pt_edges;  // [E]

@@ -232,14 +232,14 @@ __device__ __forceinline__ double wave_sum_lds(const double* v, double* park /* 
 // different cache lines per instruction (1 344 line writes per wave for 172 lines of data: ~10 of the kernel's 28 us).  A wave's
 // 64 rows are one contiguous 12 KB / 9 KB image in global memory: every lane parks its row in LDS (row pitch 26 / 18 doubles:
 // 16-byte writes without bank conflicts) and the wave copies the image out with 16-byte stores, 1 KB per instruction.
-constexpr int kLinPitch = 26;
+constexpr int kLinPitch = 18;
 template <bool JAC>
 __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   __shared__ double2 s_rows[JAC ? 4 * 64 * kLinPitch / 2 : 1];
   double* park = reinterpret_cast<double*>(s_rows) + (size_t)(threadIdx.x >> 6) * 64 * kLinPitch;   // this wave's rows
   const int lane = threadIdx.x & 63;
-  double Wv[18];
+  double Wv[18], Av[9];
   double rho0 = 0;
   if (k < V.E) {
     const int p = V.e_pose[k], l = V.e_point[k];
@@ -272,10 +272,12 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
       const double w = rho1 * info;
       const double wr0 = -info * e0 * rho1, wr1 = -info * e1 * rho1;
       double2* mine = reinterpret_cast<double2*>(park + (size_t)lane * kLinPitch);
-      mine[0] = make_double2(A[0], A[1]); mine[1] = make_double2(A[2], A[3]); mine[2] = make_double2(A[4], A[5]);
 #pragma unroll
-      for (int i = 0; i < 6; i++) mine[3 + i] = make_double2(B[2 * i], B[2 * i + 1]);
-      mine[9] = make_double2(w, wr0); mine[10] = make_double2(wr1, 0.0); mine[11] = make_double2(0.0, 0.0);
+      for (int i = 0; i < 6; i++) mine[i] = make_double2(B[2 * i], B[2 * i + 1]);
+      mine[6] = make_double2(w, wr0); mine[7] = make_double2(wr1, 0.0);
+#pragma unroll
+      for (int i = 0; i < 6; i++) Av[i] = A[i];
+      Av[6] = w; Av[7] = wr0; Av[8] = wr1;
       const bool pose_free = V.pidx[p] >= 0;
 #pragma unroll
       for (int a = 0; a < 6; a++)
@@ -289,9 +291,23 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double2* img = reinterpret_cast<double2*>(V.e_lin + (size_t)first * kEdgeLinStride);
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-      const int g = 64 * i + lane, row = g / 12, c = g - 12 * row;      // 16-byte chunk g of the image = chunk c of row `row`
+    for (int i = 0; i < 8; i++) {
+      const int g = 64 * i + lane, row = g >> 3, c = g & 7;      // 16-byte chunk g of the image = chunk c of row `row`
       if (row < nrow) img[g] = *reinterpret_cast<const double2*>(park + (size_t)row * kLinPitch + 2 * c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (k < V.E) {                                   // the landmark half the same way
+      double2* mine = reinterpret_cast<double2*>(park + (size_t)lane * kLinPitch);
+#pragma unroll
+      for (int i = 0; i < 4; i++) mine[i] = make_double2(Av[2 * i], Av[2 * i + 1]);
+      mine[4] = make_double2(Av[8], 0.0); mine[5] = make_double2(0.0, 0.0); mine[6] = make_double2(0.0, 0.0); mine[7] = make_double2(0.0, 0.0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double2* imga = reinterpret_cast<double2*>(V.e_linA + (size_t)first * kEdgeLinStride);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int g = 64 * i + lane, row = g >> 3, c = g & 7;
+      if (row < nrow) imga[g] = *reinterpret_cast<const double2*>(park + (size_t)row * kLinPitch + 2 * c);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (k < V.E) {
@@ -345,14 +361,30 @@ __device__ __forceinline__ double point_accum_body(const BaView& V, int block, c
   const int l = block * 256 + threadIdx.x;
   if (l >= V.L) return 0.0;
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-  for (int i = V.pt_start[l]; i < V.pt_start[l + 1]; i++) {
-    const double* lin = V.e_lin + (size_t)V.pt_edges[i] * kEdgeLinStride;
-    const double w = lin[18], wr0 = lin[19], wr1 = lin[20];
+  const int e_end = V.pt_start[l + 1];
+  for (int i0 = V.pt_start[l]; i0 < e_end; i0 += 4) {      // four edges in flight (index -> row: two dependent round trips each)
+    int k[4];
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      b[a] += lin[a] * wr0 + lin[3 + a] * wr1;
+    for (int u = 0; u < 4; u++) k[u] = (i0 + u < e_end) ? V.pt_edges[i0 + u] : -1;
+    double Av[4][6], wv[4][3];
 #pragma unroll
-      for (int c = 0; c < 3; c++) H[3 * a + c] += w * (lin[a] * lin[c] + lin[3 + a] * lin[3 + c]);
+    for (int u = 0; u < 4; u++) {
+      const double* lin = V.e_linA + (size_t)max(k[u], 0) * kEdgeLinStride;
+#pragma unroll
+      for (int j = 0; j < 6; j++) Av[u][j] = lin[j];
+      wv[u][0] = lin[6]; wv[u][1] = lin[7]; wv[u][2] = lin[8];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k[u] < 0) continue;
+      const double* lin = Av[u];
+      const double w = wv[u][0], wr0 = wv[u][1], wr1 = wv[u][2];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        b[a] += lin[a] * wr0 + lin[3 + a] * wr1;
+#pragma unroll
+        for (int c = 0; c < 3; c++) H[3 * a + c] += w * (lin[a] * lin[c] + lin[3 + a] * lin[3 + c]);
+      }
     }
   }
 #pragma unroll
@@ -380,16 +412,33 @@ __device__ __forceinline__ double pose_accum_body(const BaView& V, int block) { 
   for (int i = 0; i < 21; i++) H[i] = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) b[i] = 0;
-  for (int i = V.ps_start[p] + lane; i < V.ps_start[p + 1]; i += 64) {
-    const double* lin = V.e_lin + (size_t)V.ps_edges[i] * kEdgeLinStride;
-    const double* B = lin + 6;
-    const double w = lin[18], wr0 = lin[19], wr1 = lin[20];
-    int t = 0;
+  // four edges per lane in flight: index -> row is a dependent pair of global round trips, and a camera of the BASELINE problem
+  // gives a lane five edges -- one after the other that was ten round trips (the kernel's whole 15 us); same summation order
+  const int e_end = V.ps_start[p + 1];
+  for (int i0 = V.ps_start[p] + lane; i0 < e_end; i0 += 4 * 64) {
+    int k[4];
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
-      b[a] += B[a] * wr0 + B[6 + a] * wr1;
+    for (int u = 0; u < 4; u++) k[u] = (i0 + 64 * u < e_end) ? V.ps_edges[i0 + 64 * u] : -1;
+    double Bv[4][12], wv[4][3];
 #pragma unroll
-      for (int c = 0; c <= a; c++) H[t++] += w * (B[a] * B[c] + B[6 + a] * B[6 + c]);
+    for (int u = 0; u < 4; u++) {
+      const double* lin = V.e_lin + (size_t)max(k[u], 0) * kEdgeLinStride;
+#pragma unroll
+      for (int j = 0; j < 12; j++) Bv[u][j] = lin[j];
+      wv[u][0] = lin[12]; wv[u][1] = lin[13]; wv[u][2] = lin[14];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k[u] < 0) continue;
+      const double* B = Bv[u];
+      const double w = wv[u][0], wr0 = wv[u][1], wr1 = wv[u][2];
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        b[a] += B[a] * wr0 + B[6 + a] * wr1;
+#pragma unroll
+        for (int c = 0; c <= a; c++) H[t++] += w * (B[a] * B[c] + B[6 + a] * B[6 + c]);
+      }
     }
   }
   // lane t < 21 ends with H[t], lanes 21..26 with b (sum over the lanes through LDS, lane order: see wave_sum_lds)

@@ -43,7 +43,7 @@ struct dvm_ba {
   int rank = 0, world = 1;
   // second set of linearisation buffers: a trial evaluates its state WITH Jacobians and accumulates Hpp / Hll into these, so
   // that an accepted trial's state is already linearised when the next iteration starts (swapped in with the state)
-  double *alt_lin = nullptr, *alt_W = nullptr, *alt_Hpp = nullptr, *alt_bp = nullptr, *alt_Hll = nullptr, *alt_bl = nullptr;
+  double *alt_lin = nullptr, *alt_linA = nullptr, *alt_W = nullptr, *alt_Hpp = nullptr, *alt_bp = nullptr, *alt_Hll = nullptr, *alt_bl = nullptr;
   bool sharded_api = false;   // problem set through dvm_ba_set_problem_sharded: with a collective registered, even a single rank runs the sharded flow
   // optional HIP-event timing of the phases of a trial (dvm_ba_profile): [0] linearise, [1] Schur complement, [2] tile Cholesky +
   // back substitution, [3] landmarks + update + chi2; milliseconds accumulated over prof_trials trials / prof_iters iterations
@@ -384,11 +384,11 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     for (size_t t = 0; t < pair_k1.size(); t++) pair_pt[t] = e_point[pair_k1[t]];
     ok(h->upload(&V.pair_pt, pair_pt));
   }
-  ok(h->dalloc(&V.e_chi2, (size_t)E)); ok(h->dalloc(&V.e_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&V.e_W, (size_t)E * 18));
+  ok(h->dalloc(&V.e_chi2, (size_t)E)); ok(h->dalloc(&V.e_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&V.e_linA, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&V.e_W, (size_t)E * 18));
   ok(h->dalloc(&V.Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&V.bp, (size_t)n));
   ok(h->dalloc(&V.Hll, 9 * (size_t)L)); ok(h->dalloc(&V.bl, 3 * (size_t)L));
   ok(h->dalloc(&V.Dinv, 9 * (size_t)L)); ok(h->dalloc(&V.db, 3 * (size_t)L));
-  ok(h->dalloc(&h->alt_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&h->alt_W, (size_t)E * 18));
+  ok(h->dalloc(&h->alt_lin, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&h->alt_linA, (size_t)E * kEdgeLinStride)); ok(h->dalloc(&h->alt_W, (size_t)E * 18));
   ok(h->dalloc(&h->alt_Hpp, 36 * (size_t)V.nfree)); ok(h->dalloc(&h->alt_bp, (size_t)n));
   ok(h->dalloc(&h->alt_Hll, 9 * (size_t)L)); ok(h->dalloc(&h->alt_bl, 3 * (size_t)L));
   ok(h->dalloc(&V.S, (size_t)V.ldS * V.ldS)); ok(h->dalloc(&V.Linv, (size_t)(V.ldS / 64) * 64 * 64)); ok(h->dalloc(&V.ytmp, (size_t)V.n_pad + 64 + 2 * (SC.strips.size() / 2) + 2));
@@ -674,7 +674,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       {
         BaView VT = V;                                   // the trial state, linearised into the alternate buffers
         VT.poses = V.poses_new; VT.points = V.points_new;
-        VT.e_lin = h->alt_lin; VT.e_W = h->alt_W; VT.Hpp = h->alt_Hpp; VT.bp = h->alt_bp; VT.Hll = h->alt_Hll; VT.bl = h->alt_bl;
+        VT.e_lin = h->alt_lin; VT.e_linA = h->alt_linA; VT.e_W = h->alt_W; VT.Hpp = h->alt_Hpp; VT.bp = h->alt_bp; VT.Hll = h->alt_Hll; VT.bl = h->alt_bl;
         // (no speculation into an iteration that will not run, nor on a repeated attempt)
         spec_now = speculate && attempt == 0 && it + 1 < iterations;
         BaPublish pe = pub(S_TMPCHI, 0, true, true);
@@ -738,7 +738,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         currentChi = tempChi;
         std::swap(V.poses, V.poses_new);       // discardTop(): the trial state becomes the estimate
         std::swap(V.points, V.points_new);
-        std::swap(V.e_lin, h->alt_lin); std::swap(V.e_W, h->alt_W); std::swap(V.Hpp, h->alt_Hpp); std::swap(V.bp, h->alt_bp);
+        std::swap(V.e_lin, h->alt_lin); std::swap(V.e_linA, h->alt_linA); std::swap(V.e_W, h->alt_W); std::swap(V.Hpp, h->alt_Hpp); std::swap(V.bp, h->alt_bp);
         std::swap(V.Hll, h->alt_Hll); std::swap(V.bl, h->alt_bl);
         lin_ready = true; spec_chi = tempChi;
         if (spec_now) {
