@@ -148,12 +148,17 @@ __device__ __forceinline__ void block_reduce_publish(double v, double* __restric
     __hip_atomic_store(pub.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(pub.dev_vals + pub.slot, s_red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (pub.publish) {
-      // results of earlier kernels of this phase (other slots) are in dev_vals: kernel boundaries made them visible
-      for (int i = 0; i < 6; i++) {
-        const double v = (i == pub.slot) ? s_red[0] : __hip_atomic_load(pub.dev_vals + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pub.host_vals + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      const int f = pub.d_fail ? __hip_atomic_load(pub.d_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      // results of earlier kernels of this phase (other slots) are in dev_vals: kernel boundaries made them visible.  ALL of them
+      // (and the failure flag) are fetched before the first store: alternating agent-scope loads and system-scope stores was six
+      // dependent round trips on one thread -- 4-5 us at the very end of the kernel that publishes chi2 in every trial
+      double dv[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) dv[i] = pub.dev_vals[i];
+      const int f = pub.d_fail ? *pub.d_fail : 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) dv[i] = (i == pub.slot) ? s_red[0] : dv[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) __hip_atomic_store(pub.host_vals + i, dv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(pub.host_vals + 6, (double)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (pub.spec) {
         // OptimizationAlgorithmLevenberg::solve's accept / reject and lambda update (optimization_algorithm_levenberg.cpp:
@@ -161,7 +166,7 @@ __device__ __forceinline__ void block_reduce_publish(double v, double* __restric
         // anything derived from it.  pow(t, 3) is formed with the rounding errors of both products carried along (the
         // correctly rounded cube, which is what libm returns for almost every t).
         const double tmp = f == 0 ? s_red[0] : 1.7976931348623157e308;
-        const double scale = (f == 0 ? __hip_atomic_load(pub.dev_vals + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0) + 1e-3;
+        const double scale = (f == 0 ? dv[2] : 0.0) + 1e-3;
         const double rho = (pub.cur_chi - tmp) / scale;
         double next = -1.0;
         if (pub.spec_mode == 1) next = 1e-5 * s_red[0];   // computeLambdaInit (_tau = 1e-5) on the max |diag| this workgroup has just reduced
