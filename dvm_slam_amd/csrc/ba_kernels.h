@@ -31,6 +31,7 @@ struct BaView {
   double* e_W;              // [E][18]  Hpl block (pose 6 x point 3)
   const int32_t* pt_start;  // [L+1] CSR landmark -> edges (input order)
   const int32_t* pt_edges;  // [E]
+  const int32_t* pt_fi;     // [E] free index (or -1) of the camera of edge pt_edges[i]: spares the landmark back substitution two dependent loads
   const int32_t* ps_start;  // [P+1] CSR camera -> edges
   const int32_t* ps_edges;  // [E]
   double *Hpp, *bp;         // [nfree][36], [nfree*6]

@@ -1411,7 +1411,7 @@ __global__ void __launch_bounds__(256) k_point_backsub(BaView V, BaPublish pub, 
     if (live) { i0 = V.pt_start[l]; i1 = V.pt_start[l + 1]; }
     for (int i = i0 + j; i < i1; i += 8) {
       const int k = V.pt_edges[i];
-      const int fi = V.pidx[V.e_pose[k]];
+      const int fi = V.pt_fi[i];
       if (fi < 0) continue;
       const double* W = V.e_W + (size_t)k * 18;
       const double* xp = V.x + 6 * (size_t)fi;

@@ -376,6 +376,11 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.e_pose, e_pose)); ok(h->upload(&V.e_point, e_point));
   ok(h->upload(&V.e_obs, e_obs)); ok(h->upload(&V.e_info, e_info));
   ok(h->upload(&V.pt_start, pt_start)); ok(h->upload(&V.pt_edges, pt_edges));
+  {
+    std::vector<int32_t> pt_fi(pt_edges.size());
+    for (size_t i = 0; i < pt_edges.size(); i++) pt_fi[i] = pidx[e_pose[pt_edges[i]]];
+    ok(h->upload(&V.pt_fi, pt_fi));
+  }
   ok(h->upload(&V.ps_start, ps_start)); ok(h->upload(&V.ps_edges, ps_edges));
   ok(h->upload(&V.blk_i1, blk_i1)); ok(h->upload(&V.blk_i2, blk_i2)); ok(h->upload(&V.blk_start, blk_start));
   ok(h->upload(&V.pair_k1, pair_k1)); ok(h->upload(&V.pair_k2, pair_k2));
