@@ -119,6 +119,46 @@ np.savez(sys.argv[1], p=p, pts=pts, trials=np.array(st["trials"]), chi2=np.array
 """
 
 
+_SPEC_WORKER = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dvm_slam_amd import capi, synth
+pr = synth.ba_problem(n_kf=40, n_pts=300, k_obs=3, seed=22, noise_px=3.0, outlier_frac=0.2)   # trials 1,1,1,1,1,1,3,1,3,1: rejections on the way
+e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+ba = capi.BundleAdjuster()
+ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], 0.0)
+st = ba.optimize(10)
+p, pts = ba.result()
+np.savez(sys.argv[1], p=p, pts=pts, trials=np.array(st["trials"]), chi2=np.array(st["chi2"]), lam=np.array(st["lam"]),
+         spec=np.array([st["spec_trials"], st["spec_kept"]]))
+"""
+
+
+def test_ba_device_side_decision_changes_nothing_but_the_timeline(tmp_path):
+    """The accept / reject decision taken on the device only decides what is enqueued AHEAD of the host's own decision
+    (DESIGN.md section 3): with it switched off (DVM_BA_NO_SPECULATION) the LM sequence, every damping value and the final state
+    must be the same bits -- on a problem that has rejected trials -- and with it on nearly every accepted trial's successor
+    must have been kept."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("spec", {}), ("plain", {"DVM_BA_NO_SPECULATION": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _SPEC_WORKER % root, out], env={**os.environ, **extra},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["trials"], b["trials"]) and np.array_equal(a["chi2"], b["chi2"]) and np.array_equal(a["lam"], b["lam"])
+    assert np.array_equal(a["p"], b["p"]) and np.array_equal(a["pts"], b["pts"])
+    assert b["spec"][0] == 0
+    assert a["trials"].max() > 1, "the problem is meant to have rejected trials"
+    accepted = len(a["trials"])
+    assert a["spec"][0] >= accepted and a["spec"][1] >= accepted - 2, (a["spec"], a["trials"])
+
+
 def test_ba_level_handoff_timeout_falls_back_to_one_launch_per_phase(tmp_path):
     """k_chol_trsm_update hands a level's solved strips to its update workgroups inside one launch.  With the slices
     publishing a sequence number nobody waits for (DVM_BA_DEBUG_BREAK_HANDOFF) every such wait gives up: the solver must
