@@ -281,6 +281,8 @@ class OrbExtractor:
         return k[:n.value].copy()
 
     def profiling(self, on=True):
+        """True / 1: HIP events around every stage; 2: around the dominant kernel (k_fast_cells) only -- an event record is a marker
+        packet between two kernels of the batch, a few microseconds of idle device each; False / 0: none."""
         check(self.L.dvm_orb_profiling(self.h, int(on)))
 
     def profile_reset(self):

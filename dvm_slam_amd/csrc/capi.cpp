@@ -247,6 +247,7 @@ int dvm_orb_debug_level_keypoints(dvm_orb* h, int frame, int level, dvm_keypoint
 int dvm_orb_profiling(dvm_orb* h, int enable) {
   if (!h) return DVM_ERR_INVALID;
   h->p->prof.enabled = enable != 0;
+  h->p->prof.only_fast = enable == 2;
   return DVM_OK;
 }
 int dvm_orb_profile_get(dvm_orb* h, const char* name, double* total_ms, int64_t* launches) {

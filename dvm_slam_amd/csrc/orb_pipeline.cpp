@@ -42,15 +42,16 @@ hipEvent_t Profiler::get_event() {
 }
 void Profiler::begin(hipStream_t s, const char* name) {
   if (!enabled) return;
-  Pending p{name, get_event(), get_event(), s, false};
-  hipEventRecord(p.a, s);
+  const bool live = !only_fast || std::strcmp(name, "fast") == 0;
+  Pending p{name, live ? get_event() : nullptr, live ? get_event() : nullptr, s, false, live};
+  if (live) hipEventRecord(p.a, s);
   pending_.push_back(p);
 }
 void Profiler::end(hipStream_t s) {   // closes the most recent open bracket of stream `s` (brackets of different streams nest)
   if (!enabled) return;
   for (auto it = pending_.rbegin(); it != pending_.rend(); ++it)
     if (!it->closed && it->stream == s) {
-      hipEventRecord(it->b, s);
+      if (it->live) hipEventRecord(it->b, s);
       it->closed = true;
       return;
     }
@@ -58,6 +59,7 @@ void Profiler::end(hipStream_t s) {   // closes the most recent open bracket of 
 void Profiler::resolve() {
   for (auto& p : pending_) {
     float ms = 0;
+    if (!p.live) continue;
     if (p.closed && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
       auto& t = totals_[p.name];
       t.first += ms;

@@ -24,6 +24,8 @@ int hip_check(hipError_t e, const char* what);
 class Profiler {
  public:
   bool enabled = false;
+  bool only_fast = false;   // dvm_orb_profiling(h, 2): HIP events around the dominant kernel's bracket only -- every event record is a marker
+                            // packet between two kernels of the batch (a few microseconds of idle device each; twelve per batch otherwise)
   void begin(hipStream_t s, const char* name);
   void end(hipStream_t s);
   void resolve();  // after a stream sync: fold finished pairs into the totals
@@ -32,7 +34,7 @@ class Profiler {
   ~Profiler();
 
  private:
-  struct Pending { std::string name; hipEvent_t a, b; hipStream_t stream; bool closed; };
+  struct Pending { std::string name; hipEvent_t a, b; hipStream_t stream; bool closed; bool live; };
   std::vector<Pending> pending_;
   std::vector<hipEvent_t> pool_;
   std::map<std::string, std::pair<double, int64_t>> totals_;
