@@ -233,10 +233,11 @@ __device__ __forceinline__ double wave_sum_lds(const double* v, double* park /* 
 // ------------------------------------------------------------------------------------------ K8
 // JAC=false: residual / chi2 only (computeActiveErrors + activeRobustChi2 terms).
 // JAC=true : additionally Jacobians A (2x3, point), B (2x6, pose), weights and Hpl block W (6x3).
-// The Jacobian rows leave through LDS: a thread's row is 192 B (e_lin) + 144 B (W), and 21 per-thread row stores touch 64
-// different cache lines per instruction (1 344 line writes per wave for 172 lines of data: ~10 of the kernel's 28 us).  A wave's
-// 64 rows are one contiguous 12 KB / 9 KB image in global memory: every lane parks its row in LDS (row pitch 26 / 18 doubles:
-// 16-byte writes without bank conflicts) and the wave copies the image out with 16-byte stores, 1 KB per instruction.
+// The Jacobian rows leave through LDS: a thread's rows are 128 B (e_lin: camera half) + 128 B (e_linA: landmark half) + 144 B (W),
+// and per-thread row stores touch 64 different cache lines per instruction (1 344 line writes per wave for 172 lines of data when
+// the halves still shared a 192-byte row: ~10 of the kernel's 28 us).  A wave's 64 rows are one contiguous 8 KB / 8 KB / 9 KB image
+// in global memory: every lane parks its row in LDS (row pitch 18 doubles: 16-byte writes without bank conflicts), three times in
+// turn, and the wave copies the image out with 16-byte stores, 1 KB per instruction.
 constexpr int kLinPitch = 18;
 template <bool JAC>
 __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
