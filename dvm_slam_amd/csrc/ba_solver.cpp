@@ -654,68 +654,68 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       // ~40 asynchronous launches, no copy, no host synchronisation inside (push / pop are a pointer swap)
       V.lambda_v = lambda;
       for (int attempt = 0;; attempt++) {
-      if (h->prof) hipEventRecord(h->pev[0], s);
-      if (schur_enqueued && attempt == 0) schur_enqueued = false;        // this trial's Schur complement is on the stream already
-      else {
-        // S must be empty where the Schur complement does not write: normally the linearisation's launch has seen to it; not
-        // after a failed attempt (its solve has consumed S), a speculative launch on another damping, or a chi2-only evaluation
-        if (!tiles_clear) ba_launch_clear_tiles(s, V);
-        ba_launch_schur(s, V, h->d_fail);
-      }
-      tiles_clear = false;
-      if (h->prof) hipEventRecord(h->pev[1], s);
-      if (sharded) {   // sum the partial reduced systems (non-zero tiles incl. the rhs row): ~6 MB at 500 keyframes
-        ba_launch_pack_tiles(s, V, h->ar_buf, false);
-        if ((rc = ar_dev((int64_t)V.n_nz * 4096, 0)) != DVM_OK) return rc;
-        ba_launch_pack_tiles(s, V, h->ar_buf, true);
-      }
-      {
-        BaView VS = V;                                   // in-launch hand-offs (k_chol_trsm_update) only while they have never timed out
-        if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
-        ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
-      }
-      if (h->prof) hipEventRecord(h->pev[2], s);
-      ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
-      {
-        BaView VT = V;                                   // the trial state, linearised into the alternate buffers
-        VT.poses = V.poses_new; VT.points = V.points_new;
-        VT.e_lin = h->alt_lin; VT.e_linA = h->alt_linA; VT.e_W = h->alt_W; VT.Hpp = h->alt_Hpp; VT.bp = h->alt_bp; VT.Hll = h->alt_Hll; VT.bl = h->alt_bl;
-        // (no speculation into an iteration that will not run, nor on a repeated attempt)
-        spec_now = speculate && attempt == 0 && it + 1 < iterations;
-        BaPublish pe = pub(S_TMPCHI, 0, true, true);
-        if (spec_now) { pe.spec = h->d_spec; pe.cur_chi = currentChi; pe.lambda = lambda; pe.n_bad = nBad; }
-        if (it + 1 >= iterations && !sharded) {
-          ba_launch_edge_eval(s, V, false, pe);          // the budget's last iteration: nobody will use a linearisation, chi2 alone (same sum)
-        } else {
-          ba_launch_edge_eval(s, VT, true, pe);
-          ba_launch_accum(s, VT, spec_now ? h->d_spec : nullptr);   // runs while the host waits for chi2 and decides
-          tiles_clear = true;
+        if (h->prof) hipEventRecord(h->pev[0], s);
+        if (schur_enqueued && attempt == 0) schur_enqueued = false;        // this trial's Schur complement is on the stream already
+        else {
+          // S must be empty where the Schur complement does not write: normally the linearisation's launch has seen to it; not
+          // after a failed attempt (its solve has consumed S), a speculative launch on another damping, or a chi2-only evaluation
+          if (!tiles_clear) ba_launch_clear_tiles(s, V);
+          ba_launch_schur(s, V, h->d_fail);
         }
-        if (h->prof) hipEventRecord(h->pev[3], s);
-        if (spec_now) {
-          BaView VA = VT;                                // the next trial as it looks if this one is accepted
-          VA.poses_new = V.poses; VA.points_new = V.points;
-          VA.lambda = h->d_spec;
-          ba_launch_schur_speculative(s, VA, h->d_fail);
-          tiles_clear = false;                           // (true again below if the device rejected the trial: that launch does nothing)
+        tiles_clear = false;
+        if (h->prof) hipEventRecord(h->pev[1], s);
+        if (sharded) {   // sum the partial reduced systems (non-zero tiles incl. the rhs row): ~6 MB at 500 keyframes
+          ba_launch_pack_tiles(s, V, h->ar_buf, false);
+          if ((rc = ar_dev((int64_t)V.n_nz * 4096, 0)) != DVM_OK) return rc;
+          ba_launch_pack_tiles(s, V, h->ar_buf, true);
         }
-      }
-      rc = hip_check(hipGetLastError(), "bundle adjustment launch");
-      mark("trial launched", it);
-      if (rc == DVM_OK) rc = wait_seq(h, h->seq);
-      if (rc != DVM_OK) return rc;
-      mark("trial published", it);
-      // a wait inside the solve gave up (other work held the compute units its producer needed): nothing was decided on this
-      // result -- the same trial runs again, with one launch per phase from now on
-      if (h->h_vals[S_FAIL] == 2.0 && h->fuse_levels && !sharded && attempt == 0) {
-        h->fuse_levels = false;
-        if (spec_now) {                                  // whatever was enqueued behind the failed attempt is void
-          DVM_HIP(hipStreamSynchronize(s));
-          spec_now = false;
+        {
+          BaView VS = V;                                   // in-launch hand-offs (k_chol_trsm_update) only while they have never timed out
+          if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
+          ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
         }
-        continue;
-      }
-      break;
+        if (h->prof) hipEventRecord(h->pev[2], s);
+        ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
+        {
+          BaView VT = V;                                   // the trial state, linearised into the alternate buffers
+          VT.poses = V.poses_new; VT.points = V.points_new;
+          VT.e_lin = h->alt_lin; VT.e_linA = h->alt_linA; VT.e_W = h->alt_W; VT.Hpp = h->alt_Hpp; VT.bp = h->alt_bp; VT.Hll = h->alt_Hll; VT.bl = h->alt_bl;
+          // (no speculation into an iteration that will not run, nor on a repeated attempt)
+          spec_now = speculate && attempt == 0 && it + 1 < iterations;
+          BaPublish pe = pub(S_TMPCHI, 0, true, true);
+          if (spec_now) { pe.spec = h->d_spec; pe.cur_chi = currentChi; pe.lambda = lambda; pe.n_bad = nBad; }
+          if (it + 1 >= iterations && !sharded) {
+            ba_launch_edge_eval(s, V, false, pe);          // the budget's last iteration: nobody will use a linearisation, chi2 alone (same sum)
+          } else {
+            ba_launch_edge_eval(s, VT, true, pe);
+            ba_launch_accum(s, VT, spec_now ? h->d_spec : nullptr);   // runs while the host waits for chi2 and decides
+            tiles_clear = true;
+          }
+          if (h->prof) hipEventRecord(h->pev[3], s);
+          if (spec_now) {
+            BaView VA = VT;                                // the next trial as it looks if this one is accepted
+            VA.poses_new = V.poses; VA.points_new = V.points;
+            VA.lambda = h->d_spec;
+            ba_launch_schur_speculative(s, VA, h->d_fail);
+            tiles_clear = false;                           // (true again below if the device rejected the trial: that launch does nothing)
+          }
+        }
+        rc = hip_check(hipGetLastError(), "bundle adjustment launch");
+        mark("trial launched", it);
+        if (rc == DVM_OK) rc = wait_seq(h, h->seq);
+        if (rc != DVM_OK) return rc;
+        mark("trial published", it);
+        // a wait inside the solve gave up (other work held the compute units its producer needed): nothing was decided on this
+        // result -- the same trial runs again, with one launch per phase from now on
+        if (h->h_vals[S_FAIL] == 2.0 && h->fuse_levels && !sharded && attempt == 0) {
+          h->fuse_levels = false;
+          if (spec_now) {                                  // whatever was enqueued behind the failed attempt is void
+            DVM_HIP(hipStreamSynchronize(s));
+            spec_now = false;
+          }
+          continue;
+        }
+        break;
       }
       const double dev_next = spec_now ? h->h_vals[7] : -1.0;   // the device's decision: next damping, or -1 (rejected)
       if (spec_now && dev_next < 0) tiles_clear = true;
