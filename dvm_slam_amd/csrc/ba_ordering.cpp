@@ -228,6 +228,17 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
     S.strip_off.push_back((int32_t)(S.strips.size() / 2));
     S.tgt_off.push_back((int32_t)(S.targets.size() / 4));
   }
+  {
+    int hl = S.nlevels - 1;
+    if (hl >= 1 && S.level_off[hl + 1] - S.level_off[hl] == 1 && S.strip_off[hl + 1] == S.strip_off[hl] && S.tgt_off[hl + 1] == S.tgt_off[hl]) hl--;
+    S.root_level = hl;
+    S.n_root_raw = 0;
+    if (hl >= 0 && S.tgt_off[hl + 1] == S.tgt_off[hl]) {
+      bool only_rhs = true;
+      for (int st = S.strip_off[hl]; st < S.strip_off[hl + 1]; st++) only_rhs = only_rhs && S.strips[2 * st] == nt - 1;
+      if (only_rhs) S.n_root_raw = S.level_off[hl + 1] - S.level_off[hl];
+    }
+  }
   S.colstrip_off.assign(1, 0);
   for (int k = 0; k < nt; k++) {
     for (int i : col[k]) S.colstrips.push_back(i);

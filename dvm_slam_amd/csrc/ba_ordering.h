@@ -38,6 +38,9 @@ struct BaTileSchedule {
   std::vector<int32_t> colstrip_off;   // [ntiles+1] -> colstrips
   std::vector<int32_t> colstrips;      // per column k: row tiles i > k with L(i,k) != 0 (back substitution)
   std::vector<int32_t> nz_tiles;       // (i, j), i >= j: every structurally non-zero tile of the factor (what a trial must clear)
+  int root_level = -1;                 // the last level that gets launches (the level of the rhs tile alone behind it is skipped)
+  int n_root_raw = 0;                  // its columns, if nothing but the rhs row hangs below them and they update nothing: their panel
+                                       // solve is one matrix-vector product each, done by the back substitution (0: launched as usual)
   double fill = 1.0;                   // non-zero tiles / all lower tiles
 };
 // T[i][j] (i >= j) = structurally non-zero tile of the matrix in elimination order; the last tile row (rhs) is dense.

@@ -355,18 +355,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   const BaTileSchedule& SC = h->sched;
   h->tile_fill = SC.fill;
   V.nlevels = SC.nlevels;
-  {
-    // the last level that is launched (the level after it is the rhs tile alone): if nothing but the rhs row hangs below its
-    // columns and it updates nothing, its panel solve is a matrix-vector product per column -- left to k_chol_backsolve
-    V.n_root_raw = 0;
-    int hl = SC.nlevels - 1;
-    if (hl >= 1 && SC.level_off[hl + 1] - SC.level_off[hl] == 1 && SC.strip_off[hl + 1] == SC.strip_off[hl] && SC.tgt_off[hl + 1] == SC.tgt_off[hl]) hl--;
-    if (hl >= 0 && SC.tgt_off[hl + 1] == SC.tgt_off[hl]) {
-      bool only_rhs = true;
-      for (int st = SC.strip_off[hl]; st < SC.strip_off[hl + 1]; st++) only_rhs = only_rhs && SC.strips[2 * st] == SC.ntiles - 1;
-      if (only_rhs) V.n_root_raw = SC.level_off[hl + 1] - SC.level_off[hl];
-    }
-  }
+  V.n_root_raw = SC.n_root_raw;   // (ba_ordering.h: the last launched level's panel solve left to the back substitution)
 
   int rc = DVM_OK;
   auto ok = [&](int r) { if (rc == DVM_OK) rc = r; };

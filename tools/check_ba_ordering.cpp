@@ -69,6 +69,16 @@ int main(int argc, char** argv) {
     }
     if (S.contrib_strip.size() != 2 * S.contrib.size()) return fail("contrib_strip size");
   }
+  // the level whose panel solve is left to the back substitution: only rhs strips below its columns, no update, and every later
+  // level is the rhs tile alone
+  if (S.root_level < 0 || S.root_level >= S.nlevels) return fail("root_level out of range");
+  for (int h = S.root_level + 1; h < S.nlevels; h++)
+    if (S.level_off[h + 1] - S.level_off[h] != 1 || S.cols[S.level_off[h]] != nt - 1) return fail("a camera level behind root_level");
+  if (S.n_root_raw) {
+    const int h = S.root_level;
+    if (S.n_root_raw != S.level_off[h + 1] - S.level_off[h] || S.tgt_off[h + 1] != S.tgt_off[h]) return fail("n_root_raw on a level that updates");
+    for (int s2 = S.strip_off[h]; s2 < S.strip_off[h + 1]; s2++) if (S.strips[2 * s2] != nt - 1) return fail("n_root_raw with a strip above the rhs row");
+  }
   std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
               S.targets.size() / 4);
   if (loop && n >= 300 && S.nlevels > nt / 2) return fail("nested dissection did not shorten the dependency chain");
