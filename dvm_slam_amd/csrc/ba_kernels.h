@@ -25,6 +25,8 @@ struct BaView {
   const int32_t* e_point;   // [E]
   const double* e_obs;      // [E][2]
   const double* e_info;     // [E]
+  const uint8_t* e_flags;   // [E] or null (= every edge active and robust).  bit 0: the edge is at level 0 (g2o: part of the active set; a level-1 edge
+                            // contributes nothing and keeps the chi2 of its last evaluation), bit 1: it keeps its robust kernel (else delta = 0)
   double* e_chi2;           // [E] chi2 at the last evaluation (what g2o's e->chi2() reports)
   double* e_lin;            // [E][kEdgeLinStride]  pose half of the linearisation
   double* e_linA;           // [E][kEdgeLinStride]  landmark half

@@ -260,9 +260,12 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
     const double e0 = V.e_obs[2 * (size_t)k] - (V.fx * x / z + V.cx);
     const double e1 = V.e_obs[2 * (size_t)k + 1] - (V.fy * y / z + V.cy);
     const double chi2 = e0 * info * e0 + e1 * info * e1;
-    V.e_chi2[k] = chi2;
+    const unsigned fl = V.e_flags ? V.e_flags[k] : 3u;
+    const bool active = (fl & 1u) != 0;                 // g2o: level 0.  A level-1 edge is outside the active set: no error evaluation
+    if (active) V.e_chi2[k] = chi2;                     // (its chi2() stays what it was), nothing in chi2 / H / b
     double rho1;
-    robustify(chi2, V.delta, rho0, rho1);
+    robustify(chi2, (fl & 2u) ? V.delta : 0.0, rho0, rho1);
+    if (!active) { rho0 = 0; rho1 = 0; }
     if (JAC) {
       const double J[6] = {-(V.fx / z), 0, V.fx * x / (z * z), 0, -(V.fy / z), V.fy * y / (z * z)};
       double A[6], B[12];
@@ -275,8 +278,14 @@ __global__ void __launch_bounds__(256) k_edge_eval(BaView V, BaPublish pub) {
       for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
-      const double w = rho1 * info;
-      const double wr0 = -info * e0 * rho1, wr1 = -info * e1 * rho1;
+      if (!active) {                                    // exact zeros whatever the geometry (a point on the camera plane: inf / NaN rows)
+#pragma unroll
+        for (int i = 0; i < 6; i++) A[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) B[i] = 0.0;
+      }
+      const double w = active ? rho1 * info : 0.0;
+      const double wr0 = active ? -info * e0 * rho1 : 0.0, wr1 = active ? -info * e1 * rho1 : 0.0;
       double2* mine = reinterpret_cast<double2*>(park + (size_t)lane * kLinPitch);
 #pragma unroll
       for (int i = 0; i < 6; i++) mine[i] = make_double2(B[2 * i], B[2 * i + 1]);

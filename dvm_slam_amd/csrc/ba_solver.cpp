@@ -59,6 +59,7 @@ struct dvm_ba {
   double* d_dev_vals = nullptr;             // device copy of the phase results [8]
   int* d_fail = nullptr;
   uint8_t* d_depth = nullptr;
+  uint8_t* d_flags = nullptr;               // per-edge level / robust-kernel flags (dvm_ba_set_edge_flags); V.e_flags points here once set
   bool have_problem = false;
   double ms_structure = 0;
   BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
@@ -390,6 +391,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->dalloc(&V.x, (size_t)n + 3 * (size_t)L));
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(8 * (size_t)L + 255) / 256 + (size_t)(V.nfree + 255) / 256 + (size_t)(V.nfree + 3) / 4 + 2));   // block partials of k_point_backsub / k_max_diag
   ok(h->dalloc(&h->d_depth, (size_t)E));
+  ok(h->dalloc(&h->d_flags, (size_t)E));
   ok(h->upload(&V.nz_tiles, SC.nz_tiles)); V.n_nz = (int)(SC.nz_tiles.size() / 2);
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
@@ -451,6 +453,18 @@ int dvm_ba_set_allreduce(dvm_ba* h, dvm_allreduce_fn fn, void* ctx, void* d_buf,
   if (!h) return DVM_ERR_INVALID;
   h->allreduce = fn; h->allreduce_ctx = ctx; h->ar_buf = static_cast<double*>(d_buf); h->ar_cap = cap_doubles;
   return DVM_OK;
+}
+// g2o's e->setLevel(1) / e->setRobustKernel(0) between two optimize() calls on the same graph (the two-round solves of
+// Optimizer.cc:3474-3519 and :161-...): the flags take effect with the next dvm_ba_optimize; the state, the structure and
+// the factorisation schedule stay as they are (a level-1 edge contributes exact zeros).
+int dvm_ba_set_edge_flags(dvm_ba* h, const uint8_t* flags) {
+  if (!h || !h->have_problem) { set_error("dvm_ba_set_edge_flags: no problem set"); return DVM_ERR_STATE; }
+  if (h->world > 1) { set_error("dvm_ba_set_edge_flags: not available on a landmark-sharded problem"); return DVM_ERR_STATE; }
+  DVM_HIP(hipSetDevice(h->device));
+  if (!flags) { h->V.e_flags = nullptr; return DVM_OK; }
+  const int rc = h->copy_in(h->d_flags, flags, (size_t)h->V.E);
+  if (rc == DVM_OK) h->V.e_flags = h->d_flags;
+  return rc;
 }
 int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out) {
   if (!h || !h->have_problem || !out) return DVM_ERR_STATE;

@@ -1,9 +1,12 @@
 // dvm_slam_amd/host/Optimizer_shim.h -- the monocular, non-inertial statics of ORB_SLAM3::Optimizer (reference
 // include/Optimizer.h:48-101, src/Optimizer.cc) over the dvmslam_hip C ABI:
 //   BundleAdjustment (:55-356)  GlobalBundleAdjustemnt (:44-53)  LocalBundleAdjustment (:1030-1387)
-//   PoseOptimization (:744-1028)  OptimizeSim3 (:1960-2212)  OptimizeEssentialGraph (:1389-1652, the loop-closure overload)
-// Same names, same signatures: a maintainer deletes these six bodies from src/Optimizer.cc and compiles this header into
-// the same translation unit (every other static -- inertial, essential graph -- stays where it is).  Each function keeps the
+//   LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) (:3257-3675, the welding BA of a map merge)
+//   PoseOptimization (:744-1028)  OptimizeSim3 (:1960-2212)
+//   OptimizeEssentialGraph (:1389-1652, loop closure) and (:1653-1958, map merge)
+// i.e. every monocular, non-inertial static of include/Optimizer.h:48-92.
+// Same names, same signatures: a maintainer deletes these eight bodies from src/Optimizer.cc and compiles this header into
+// the same translation unit (the inertial statics stay where they are).  Each function keeps the
 // reference's graph GATHERING rules (which keyframes / map points / observations enter, which vertices are fixed) and its
 // WRITE-BACK (outlier erasure, SetPose / SetWorldPos / mTcwGBA ...); the g2o block between them is the device solve.  Stereo / fisheye-pair observations are not part of
 // the accelerated path (DVM-SLAM is monocular): a keyframe that carries them is rejected with an exception.
@@ -27,6 +30,8 @@ namespace ORB_SLAM3 {
 namespace dvm_optimizer_detail {
 
 inline void check(int rc) { if (rc != DVM_OK) throw std::runtime_error(dvm_last_error()); }
+// the HIP device of this agent's optimiser calls (one agent per GPU: set once at start-up, e.g. from LOCAL_RANK)
+inline int& device() { static int d = 0; return d; }
 // (t, q_xyzw) as doubles <- g2o::SE3Quat(Tcw.unit_quaternion().cast<double>(), Tcw.translation().cast<double>())
 inline void pose7(const Sophus::SE3f& T, double* p) {
   for (int i = 0; i < 3; i++) p[i] = (double)T.translation()(i);
@@ -83,8 +88,10 @@ struct Problem {
     for (int k = 0; k < 3; k++) X(k) = xyz[3 * pt + k];
     return X.cast<float>();
   }
-  // g2o's optimize(iterations) with the stop flag; afterwards pose / xyz hold the estimates, chi2 / in_front the per-edge tests
-  void run(int iterations, bool* stop, double huber_delta) {
+  // --- the g2o block: upload() = the graph as it stands when optimize() is first called; optimize() = optimizer.optimize(n) with
+  // the stop flag; set_flags() = e->setLevel / e->setRobustKernel between two rounds; collect() = estimates, e->chi2(),
+  // e->isDepthPositive().  run() is the one-round form.
+  void upload(double huber_delta) {
     pose.resize(7 * cams.size());
     xyz.resize(3 * pts.size());
     for (size_t i = 0; i < cams.size(); i++) pose7(cams[i]->GetPose(), &pose[7 * i]);
@@ -94,20 +101,37 @@ struct Problem {
     }
     const KeyFrame* any = cams.front();
     dvm_ba_camera cam = {any->fx, any->fy, any->cx, any->cy, huber_delta};
+    check(dvm_ba_set_problem(solver(), pose.data(), cam_fixed.data(), (int)cams.size(), xyz.data(), (int)pts.size(), edges.data(),
+                             (int)edges.size(), &cam));
+  }
+  void optimize(int iterations, bool* stop) {
     static_assert(sizeof(bool) == 1, "the stop flag is polled as a byte");
-    // one solver handle per calling thread, kept for the life of the thread: the handle recycles its device memory from one
-    // problem to the next (LocalMapping calls this every keyframe, LoopClosing's GBA thread occasionally)
-    static thread_local dvm_ba* h = NULL;
-    if (!h) check(dvm_ba_create(0, &h));
     dvm_ba_stats st;
-    int rc = dvm_ba_set_problem(h, pose.data(), cam_fixed.data(), (int)cams.size(), xyz.data(), (int)pts.size(), edges.data(),
-                                (int)edges.size(), &cam);
-    if (rc == DVM_OK) rc = dvm_ba_optimize(h, iterations, reinterpret_cast<const volatile uint8_t*>(stop), &st);
-    if (rc == DVM_OK) rc = dvm_ba_get_result(h, pose.data(), xyz.data());
+    check(dvm_ba_optimize(solver(), iterations, reinterpret_cast<const volatile uint8_t*>(stop), &st));
+  }
+  void set_flags(const std::vector<uint8_t>& flags) { check(dvm_ba_set_edge_flags(solver(), flags.data())); }
+  void collect() {
     chi2.resize(edges.size());
     in_front.resize(edges.size());
-    if (rc == DVM_OK) rc = dvm_ba_edge_chi2(h, chi2.data(), in_front.data());
-    check(rc);
+    check(dvm_ba_get_result(solver(), pose.data(), xyz.data()));
+    check(dvm_ba_edge_chi2(solver(), chi2.data(), in_front.data()));
+  }
+  void run(int iterations, bool* stop, double huber_delta) {
+    upload(huber_delta);
+    optimize(iterations, stop);
+    collect();
+  }
+  // One solver handle per calling thread, released when the thread ends: the handle recycles its device memory from one problem
+  // to the next (LocalMapping calls LocalBundleAdjustment every keyframe), and the reference starts a fresh std::thread for
+  // every global BA (LoopClosing.cc:1253,1799) -- a handle that outlived its thread would strand a GBA-sized arena each time.
+  struct SolverOfThread {
+    dvm_ba* h = NULL;
+    ~SolverOfThread() { if (h) dvm_ba_destroy(h); }
+  };
+  static dvm_ba* solver() {
+    static thread_local SolverOfThread mine;
+    if (!mine.h) check(dvm_ba_create(device(), &mine.h));
+    return mine.h;
   }
 };
 
@@ -230,7 +254,10 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Ma
     const int32_t pt = (int32_t)prob.pts.size();
     prob.pts.push_back(mp);
     for (const auto& ob : mp->GetObservations())
-      if (usable(ob.first)) prob.observe(ob.first, prob.cam_slot.at(ob.first), mp, pt, std::get<0>(ob.second));
+      if (usable(ob.first)) {
+        const int32_t cam = prob.slot_of(ob.first);            // (always a vertex: every usable observer is free or an anchor)
+        if (cam >= 0) prob.observe(ob.first, cam, mp, pt, std::get<0>(ob.second));
+      }
   }
   num_MPs = (int)prob.pts.size();
   num_edges = (int)prob.edges.size();
@@ -286,7 +313,7 @@ inline int Optimizer::PoseOptimization(Frame* pFrame) {
   std::vector<uint8_t> rejected(n);
   int32_t inliers = 0;
   dvm_ba_camera cam = {F.fx, F.fy, F.cx, F.cy, 0.0};
-  check(dvm_pose_optimize(0, start, world.data(), pixel.data(), weight.data(), &n, n, 1, &cam, refined, rejected.data(), &inliers));
+  check(dvm_pose_optimize(device(), start, world.data(), pixel.data(), weight.data(), &n, n, 1, &cam, refined, rejected.data(), &inliers));
   for (int32_t e = 0; e < n; e++) F.mvbOutlier[keypoint_of[e]] = rejected[e] != 0;
   F.SetPose(se3f(refined));
   return inliers;
@@ -345,7 +372,7 @@ inline int Optimizer::OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoi
   const double K1[4] = {pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy}, K2[4] = {pKF2->fx, pKF2->fy, pKF2->cx, pKF2->cy};
   std::vector<uint8_t> kept(pairs);
   int32_t inliers = 0;
-  check(dvm_optimize_sim3(0, S, bFixScale ? 1 : 0, in1.data(), in2.data(), px1.data(), px2.data(), w1.data(), w2.data(), pairs, K1, K2,
+  check(dvm_optimize_sim3(device(), S, bFixScale ? 1 : 0, in1.data(), in2.data(), px1.data(), px2.data(), w1.data(), w2.data(), pairs, K1, K2,
                           (double)th2, kept.data(), &inliers));
   for (int e = 0; e < pairs; e++)
     if (!kept[e]) vpMatches1[match_of[e]] = static_cast<MapPoint*>(NULL);
@@ -441,7 +468,7 @@ inline void Optimizer::OptimizeEssentialGraph(Map* pMap, KeyFrame* pLoopKF, KeyF
     o[7] = s0.scale();
   }
   dvm_pg_stats st;
-  check(dvm_pose_graph_optimize(0, S.data(), fixed.data(), n, edges.data(), (int)edges.size(), bFixScale ? 1 : 0, 20, &st));
+  check(dvm_pose_graph_optimize(device(), S.data(), fixed.data(), n, edges.data(), (int)edges.size(), bFixScale ? 1 : 0, 20, &st));
 
   unique_lock<mutex> lock(pMap->mMutexMapUpdate);
   std::vector<g2o::Sim3> corrected_wc(n);                    // inverse of the optimised S_cw
@@ -472,6 +499,223 @@ inline void Optimizer::OptimizeEssentialGraph(Map* pMap, KeyFrame* pLoopKF, KeyF
     mp->UpdateNormalAndDepth();
   }
   pMap->IncreaseChangeIndex();
+}
+
+// (Optimizer.cc:3257-3675, monocular part)  The welding bundle adjustment of a map merge (LoopClosing::MergeLocal,
+// LoopClosing.cc:1657): cameras are the two lists the caller hands over -- vpFixedKF fixed, vpAdjustKF free --, landmarks
+// what they observe; only observations made from those cameras enter.  Two rounds on one graph: optimize(5) with the Huber
+// kernel (delta = sqrt(5.99)), then observations with chi2 > 5.991 or behind the camera drop to level 1, every edge loses its
+// kernel, optimize(10); whatever fails the same test afterwards is erased and the estimates are written back.
+inline void Optimizer::LocalBundleAdjustment(KeyFrame* pMainKF, vector<KeyFrame*> vpAdjustKF, vector<KeyFrame*> vpFixedKF, bool* pbStopFlag) {
+  using namespace dvm_optimizer_detail;
+  const unsigned long tag = pMainKF->mnId;
+  Map* own = pMainKF->GetMap();
+  Problem prob;
+  std::vector<MapPoint*> landmarks;
+  unsigned long newest = 0;
+  const auto enter = [&](KeyFrame* kf, bool fixed) {
+    if (kf->isBad() || kf->GetMap() != own) return;
+    kf->mnBALocalForMerge = tag;
+    if (prob.slot_of(kf) < 0) prob.camera(kf, fixed);        // (a keyframe named twice keeps its first vertex, as g2o's addVertex does)
+    newest = std::max<unsigned long>(newest, kf->mnId);
+    for (MapPoint* mp : kf->GetMapPoints()) {
+      if (!mp || mp->isBad() || mp->GetMap() != own || mp->mnBALocalForMerge == tag) continue;
+      mp->mnBALocalForMerge = tag;
+      landmarks.push_back(mp);
+    }
+  };
+  for (KeyFrame* kf : vpFixedKF) enter(kf, true);
+  for (KeyFrame* kf : vpAdjustKF) enter(kf, false);
+  if (prob.cams.empty() || landmarks.empty()) return;
+
+  for (MapPoint* mp : landmarks) {
+    const int32_t pt = (int32_t)prob.pts.size();
+    prob.pts.push_back(mp);
+    for (const auto& ob : mp->GetObservations()) {
+      KeyFrame* kf = ob.first;
+      const int idx = std::get<0>(ob.second);
+      if (kf->isBad() || kf->mnId > newest || idx < 0 || !kf->GetMapPoint(idx)) continue;
+      const int32_t cam = prob.slot_of(kf);                  // only the cameras of the two lists
+      if (cam >= 0) prob.observe(kf, cam, mp, pt, idx);
+    }
+  }
+  if (prob.edges.empty()) return;
+  if (pbStopFlag && *pbStopFlag) return;
+
+  const float huber = sqrt(5.99);
+  prob.upload((double)huber);
+  prob.optimize(5, pbStopFlag);
+  const auto fails = [&prob](size_t e) { return prob.chi2[e] > 5.991 || !prob.in_front[e]; };
+  if (!(pbStopFlag && *pbStopFlag)) {
+    prob.collect();
+    std::vector<uint8_t> flags(prob.edges.size());
+    for (size_t e = 0; e < prob.edges.size(); e++) {
+      if (prob.edge_owner[e].second->isBad()) flags[e] = DVM_BA_EDGE_ACTIVE | DVM_BA_EDGE_ROBUST;   // untouched by the reference's loop
+      else flags[e] = fails(e) ? 0 : DVM_BA_EDGE_ACTIVE;
+    }
+    prob.set_flags(flags);
+    prob.optimize(10, pbStopFlag);
+  }
+  prob.collect();
+
+  std::vector<std::pair<KeyFrame*, MapPoint*>> rejected;
+  for (size_t e = 0; e < prob.edges.size(); e++)
+    if (!prob.edge_owner[e].second->isBad() && fails(e)) rejected.push_back(prob.edge_owner[e]);
+  unique_lock<mutex> lock(own->mMutexMapUpdate);
+  for (const auto& r : rejected) {
+    r.first->EraseMapPointMatch(r.second);
+    r.second->EraseObservation(r.first);
+  }
+  for (KeyFrame* kf : vpAdjustKF) {
+    if (kf->isBad()) continue;
+    const int32_t cam = prob.slot_of(kf);
+    if (cam >= 0) kf->SetPose(prob.pose_of(cam));
+  }
+  for (size_t i = 0; i < landmarks.size(); i++) {
+    if (landmarks[i]->isBad()) continue;
+    landmarks[i]->SetWorldPos(prob.position_of(i));
+    landmarks[i]->UpdateNormalAndDepth();
+  }
+}
+
+// (Optimizer.cc:1653-1958)  Essential-graph optimisation after a map merge (LoopClosing::MergeLocal, LoopClosing.cc:1747).
+// Vertices, all with scale 1: vpFixedKFs (the welding window of the merged map: fixed, "corrected" pose only),
+// vpFixedCorrectedKFs (the window of the old map: fixed, corrected pose + the pose before the merge, mTcwBefMerge) and
+// vpNonFixedKFs (the rest of the old map: free, uncorrected pose only).  An edge i -> j of the spanning tree, the loop edges or
+// the covisibility graph (weight >= 100) enters when both ends have a corrected pose or both have an uncorrected one; its
+// measurement is S_jw * S_wi with S_jw from the corrected poses in the first case, from the uncorrected ones in the second, and
+// S_wi always the inverse of i's UNcorrected pose (identity for a vertex that has none) -- exactly the reference's
+// expressions, edges between two fixed vertices included (they only move chi2, which the stopping rule looks at).  Twenty LM
+// iterations with free scale; then the free keyframes get [R | t / s] and remember their previous pose, and the map points
+// that were not corrected are carried over through their reference keyframe.
+inline void Optimizer::OptimizeEssentialGraph(KeyFrame* pCurKF, vector<KeyFrame*>& vpFixedKFs, vector<KeyFrame*>& vpFixedCorrectedKFs,
+                                              vector<KeyFrame*>& vpNonFixedKFs, vector<MapPoint*>& vpNonCorrectedMPs) {
+  using namespace dvm_optimizer_detail;
+  Map* pMap = pCurKF->GetMap();
+  const int kMinWeight = 100;
+  struct Vertex {
+    g2o::Sim3 estimate, uncorrected_cw, corrected_wc;          // VSim3->estimate(), vScw, vCorrectedSwc
+    bool has_corrected = false, has_uncorrected = false, fixed = false;   // vpGoodPose, vpBadPose
+  };
+  std::vector<Vertex> V;
+  std::unordered_map<unsigned long, int32_t> slot;             // mnId -> vertex
+  const auto unit = [](KeyFrame* kf) {
+    const Sophus::SE3d T = kf->GetPose().cast<double>();
+    return g2o::Sim3(T.unit_quaternion(), T.translation(), 1.0);
+  };
+  // g2o keeps the first vertex registered under an id; the per-id tables (poses, flags) take the values of the last list
+  const auto vertex_of = [&](KeyFrame* kf, bool fixed) -> Vertex& {
+    const auto it = slot.find(kf->mnId);
+    if (it != slot.end()) return V[it->second];
+    slot.emplace(kf->mnId, (int32_t)V.size());
+    V.emplace_back();
+    V.back().estimate = unit(kf);
+    V.back().fixed = fixed;
+    return V.back();
+  };
+  for (KeyFrame* kf : vpFixedKFs) {
+    if (kf->isBad()) continue;
+    Vertex& v = vertex_of(kf, true);
+    v.corrected_wc = unit(kf).inverse();
+    v.has_corrected = true; v.has_uncorrected = false;
+  }
+  std::set<unsigned long> entered;                             // sIdKF
+  for (KeyFrame* kf : vpFixedCorrectedKFs) {
+    if (kf->isBad()) continue;
+    Vertex& v = vertex_of(kf, true);
+    v.corrected_wc = unit(kf).inverse();
+    const Sophus::SE3d before = kf->mTcwBefMerge.cast<double>();
+    v.uncorrected_cw = g2o::Sim3(before.unit_quaternion(), before.translation(), 1.0);
+    v.has_corrected = true; v.has_uncorrected = true;
+    entered.insert(kf->mnId);
+  }
+  for (KeyFrame* kf : vpNonFixedKFs) {
+    if (kf->isBad() || entered.count(kf->mnId)) continue;
+    Vertex& v = vertex_of(kf, false);
+    v.uncorrected_cw = unit(kf);
+    v.has_corrected = false; v.has_uncorrected = true;
+    entered.insert(kf->mnId);
+  }
+  if (V.empty()) return;
+
+  std::vector<KeyFrame*> all;
+  all.insert(all.end(), vpFixedKFs.begin(), vpFixedKFs.end());
+  all.insert(all.end(), vpFixedCorrectedKFs.begin(), vpFixedCorrectedKFs.end());
+  all.insert(all.end(), vpNonFixedKFs.begin(), vpNonFixedKFs.end());
+  const std::set<KeyFrame*> members(all.begin(), all.end());
+  std::vector<dvm_pg_edge> edges;
+  for (KeyFrame* kf : all) {
+    const auto si = slot.find(kf->mnId);
+    if (si == slot.end()) continue;                            // (a bad keyframe: no pose of either kind, no relation)
+    const Vertex& vi = V[si->second];
+    const g2o::Sim3 Swi = vi.has_uncorrected ? vi.uncorrected_cw.inverse() : g2o::Sim3();
+    const auto link = [&](KeyFrame* to) {
+      const auto sj = slot.find(to->mnId);
+      if (sj == slot.end()) return;
+      const Vertex& vj = V[sj->second];
+      g2o::Sim3 Sjw;
+      if (vi.has_corrected && vj.has_corrected) Sjw = vj.corrected_wc.inverse();
+      else if (vi.has_uncorrected && vj.has_uncorrected) Sjw = vj.uncorrected_cw;
+      else return;
+      const g2o::Sim3 Sji = Sjw * Swi;
+      dvm_pg_edge e;
+      e.vi = si->second; e.vj = sj->second;
+      e.Sji[0] = Sji.rotation().x(); e.Sji[1] = Sji.rotation().y(); e.Sji[2] = Sji.rotation().z(); e.Sji[3] = Sji.rotation().w();
+      for (int k = 0; k < 3; k++) e.Sji[4 + k] = Sji.translation()(k);
+      e.Sji[7] = Sji.scale();
+      edges.push_back(e);
+    };
+    KeyFrame* parent = kf->GetParent();
+    if (parent && members.count(parent)) link(parent);
+    const std::set<KeyFrame*> loops = kf->GetLoopEdges();
+    for (KeyFrame* l : loops)
+      if (members.count(l) && l->mnId < kf->mnId) link(l);
+    for (KeyFrame* nb : kf->GetCovisiblesByWeight(kMinWeight)) {
+      if (!nb || nb == parent || kf->hasChild(nb) || loops.count(nb) || !members.count(nb)) continue;
+      if (!nb->isBad() && nb->mnId < kf->mnId) link(nb);
+    }
+  }
+  const int n = (int)V.size();
+  std::vector<double> S(8 * (size_t)n);
+  std::vector<uint8_t> fixed(n);
+  for (int v = 0; v < n; v++) {
+    const g2o::Sim3& s0 = V[v].estimate;
+    double* o = &S[8 * (size_t)v];
+    o[0] = s0.rotation().x(); o[1] = s0.rotation().y(); o[2] = s0.rotation().z(); o[3] = s0.rotation().w();
+    for (int k = 0; k < 3; k++) o[4 + k] = s0.translation()(k);
+    o[7] = s0.scale();
+    fixed[v] = V[v].fixed ? 1 : 0;
+  }
+  if (!edges.empty()) {
+    dvm_pg_stats st;
+    check(dvm_pose_graph_optimize(device(), S.data(), fixed.data(), n, edges.data(), (int)edges.size(), /*fix_scale=*/0, 20, &st));
+  }
+
+  unique_lock<mutex> lock(pMap->mMutexMapUpdate);
+  for (KeyFrame* kf : vpNonFixedKFs) {
+    if (kf->isBad()) continue;
+    const double* o = &S[8 * (size_t)slot.at(kf->mnId)];
+    Eigen::Vector3d t;
+    for (int k = 0; k < 3; k++) t(k) = o[4 + k] / o[7];       // Sim3 [sR t] -> SE3 [R t / s]
+    const Sophus::SE3d Tiw(Eigen::Quaterniond(o[3], o[0], o[1], o[2]), t);
+    kf->mTcwBefMerge = kf->GetPose();
+    kf->mTwcBefMerge = kf->GetPoseInverse();
+    kf->SetPose(Tiw.cast<float>());
+  }
+  for (MapPoint* mp : vpNonCorrectedMPs) {
+    if (mp->isBad()) continue;
+    KeyFrame* ref = mp->GetReferenceKeyFrame();
+    while (ref && ref->isBad()) {
+      mp->EraseObservation(ref);
+      ref = mp->GetReferenceKeyFrame();
+    }
+    if (!ref) continue;
+    const auto sr = slot.find(ref->mnId);
+    if (sr == slot.end() || !V[sr->second].has_uncorrected) continue;   // a reference keyframe from another map: left alone
+    const Sophus::SE3f before_wr = ref->mTwcBefMerge, Twr = ref->GetPoseInverse();
+    mp->SetWorldPos(Twr * before_wr.inverse() * mp->GetWorldPos());
+    mp->UpdateNormalAndDepth();
+  }
 }
 
 }  // namespace ORB_SLAM3

@@ -325,6 +325,16 @@ int dvm_ba_set_problem(dvm_ba* h, const double* poses, const uint8_t* fixed, int
  * iterations and trials, may be written by another thread (LocalMapping.cc:305,359) */
 int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
 int dvm_ba_get_result(dvm_ba* h, double* poses, double* points);
+/* Two-round solves on one graph -- the welding bundle adjustment of a map merge (Optimizer.cc:3474-3519: optimize(5), then
+ * e->setLevel(1) on the outliers, e->setRobustKernel(0) on every edge, initializeOptimization(0), optimize(10)) -- without a
+ * second dvm_ba_set_problem: flags[e] bit 0 = the edge stays at level 0 (a level-1 edge is outside the active set: it
+ * contributes nothing and dvm_ba_edge_chi2 keeps reporting the chi2 of its last evaluation, as g2o's e->chi2() does), bit 1 =
+ * the edge keeps its robust kernel (huber_delta of the problem).  Takes effect with the next dvm_ba_optimize, which starts
+ * from the estimates the previous one left (iteration 0 again: fresh computeLambdaInit).  NULL: every edge active and
+ * robust again.  Not available on a landmark-sharded problem. */
+#define DVM_BA_EDGE_ACTIVE 1
+#define DVM_BA_EDGE_ROBUST 2
+int dvm_ba_set_edge_flags(dvm_ba* h, const uint8_t* flags);
 /* BASELINE.json config 5 (global BA sharded over the GPUs of a node; the reference solves it on one CPU thread,
  * Optimizer.cc:44-53 -> block_solver.hpp:381-439): rank r of `world` receives the WHOLE problem (so that the free-camera
  * order, the block pattern and the tile schedule are identical everywhere) but evaluates only the observations of the

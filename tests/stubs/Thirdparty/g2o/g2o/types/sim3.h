@@ -1,4 +1,6 @@
-// test stub: g2o::Sim3 as Optimizer::OptimizeSim3 passes it (see tests/stubs/README.md)
+// test mock: g2o::Sim3 (rotation, translation, scale in double) with the three operations the Optimizer shim uses
+// (see tests/stubs/README.md).  Semantics of the reference's Thirdparty/g2o/g2o/types/sim3.h: inverse = (r*, r* (-t / s), 1 / s),
+// product = (r r', s (r t') + t, s s'), map(x) = s (r x) + t.
 #pragma once
 #include <Eigen/Core>
 namespace g2o {
@@ -9,8 +11,8 @@ struct Sim3 {
   const Eigen::Quaterniond& rotation() const { return r; }
   const Eigen::Vector3d& translation() const { return t; }
   const double& scale() const { return s; }
-  Sim3 inverse() const;
-  Sim3 operator*(const Sim3& other) const;
-  Eigen::Vector3d map(const Eigen::Vector3d& xyz) const;
+  Sim3 inverse() const { return Sim3(r.conjugate(), r.conjugate() * ((-1. / s) * t), 1. / s); }
+  Sim3 operator*(const Sim3& o) const { return Sim3(r * o.r, s * (r * o.t) + t, s * o.s); }
+  Eigen::Vector3d map(const Eigen::Vector3d& xyz) const { return s * (r * xyz) + t; }
 };
 }  // namespace g2o
