@@ -492,9 +492,10 @@ inline void Optimizer::OptimizeEssentialGraph(Map* pMap, KeyFrame* pLoopKF, KeyF
       const auto it = slot.find(mp->GetReferenceKeyFrame());
       if (it != slot.end()) ref = it->second;
     }
-    if (ref < 0) continue;
+    // (a reference keyframe that is not a vertex -- a bad one -- has identity entries in the reference's per-id tables: the point
+    //  is written back where it was)
     const Eigen::Vector3d P = mp->GetWorldPos().cast<double>();
-    const Eigen::Vector3d moved = corrected_wc[ref].map(before[ref].map(P));
+    const Eigen::Vector3d moved = ref < 0 ? P : corrected_wc[ref].map(before[ref].map(P));
     mp->SetWorldPos(moved.cast<float>());
     mp->UpdateNormalAndDepth();
   }

@@ -254,3 +254,84 @@ def mirror_erase(W, kf, mp, min_obs=3):
             for k2, i2 in P["obs"].items():
                 W.kf[k2]["matches"][i2] = -1
             P["obs"] = {}
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# Frames (Tracking's per-image object)
+def _add_frame(W, pose_tq, K, kps, desc=None, bounds=(0.0, 640.0, 0.0, 480.0)):
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    s, g, ig = W.tables
+    K = np.ascontiguousarray(K, np.float32)
+    b = np.ascontiguousarray(bounds, np.float32)
+    d = np.ascontiguousarray(desc, np.uint8) if desc is not None else None
+    f = W.L.sw_add_frame(W.h, _p(qt(pose_tq)), _p(K), len(kps), _p(kps), _p(d), _p(s), _p(g), _p(ig), len(s), C.c_float(float(np.log(np.float32(1.2)))), _p(b))
+    W.frame_n = getattr(W, "frame_n", {})
+    W.frame_n[f] = len(kps)
+    return f
+
+
+def _frame_set_matches(W, f, mp, outlier=None):
+    o = np.ascontiguousarray(outlier, np.uint8) if outlier is not None else None
+    W.L.sw_frame_set_matches(W.h, f, _p(_i32(mp)), _p(o))
+
+
+def _get_frame(W, f):
+    n = W.frame_n[f]
+    pose = np.zeros(7, np.float32); mp = np.zeros(max(n, 1), np.int32); out = np.zeros(max(n, 1), np.uint8)
+    calls = W.L.sw_get_frame(W.h, f, _p(pose), _p(mp), _p(out))
+    return dict(pose=np.concatenate([pose[4:7], pose[0:4]]), mp=mp[:n], outlier=out[:n], set_pose=calls)
+
+
+def _pose_optimization(W, f):
+    return W._chk(W.L.sw_pose_optimization(W.h, f))
+
+
+World.add_frame = _add_frame
+World.frame_set_matches = _frame_set_matches
+World.get_frame = _get_frame
+World.pose_optimization = _pose_optimization
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# g2o::Sim3 in plain Python floats with the operation order of tests/stubs (Eigen's quaternion product and point action):
+# the measurements a test derives are then bit-identical to the ones the shim derives from the same poses.
+def _cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+def q_rot(q, p):
+    v = q[:3]; w = q[3]
+    uv = _cross(v, p); uv = [u + u for u in uv]
+    c = _cross(v, uv)
+    return [(p[i] + w * uv[i]) + c[i] for i in range(3)]
+
+
+def q_mul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return [aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx,
+            aw * bw - ax * bx - ay * by - az * bz]
+
+
+def s_inv(S):
+    q, t, s = list(S[:4]), list(S[4:7]), S[7]
+    qc = [-q[0], -q[1], -q[2], q[3]]
+    k = -1. / s
+    return qc + q_rot(qc, [t[i] * k for i in range(3)]) + [1. / s]
+
+
+def s_mul(A, B):
+    r = q_rot(list(A[:4]), list(B[4:7]))
+    return q_mul(list(A[:4]), list(B[:4])) + [r[i] * A[7] + A[4 + i] for i in range(3)] + [A[7] * B[7]]
+
+
+def s_map(S, x):
+    r = q_rot(list(S[:4]), list(x))
+    return [r[i] * S[7] + S[4 + i] for i in range(3)]
+
+
+def sim3_of_pose(pose_tq_f32):
+    """g2o::Sim3(Tcw.unit_quaternion().cast<double>(), Tcw.translation().cast<double>(), 1.0) of a float (t, q) pose."""
+    p = np.asarray(pose_tq_f32, np.float32).astype(np.float64)
+    x, y, z, w = [float(v) for v in p[3:7]]
+    n = ((x * x + z * z) + (y * y + w * w)) ** 0.5        # Sophus: SE3f::cast<double>() re-normalises the quaternion (SO3's constructor)
+    return [x / n, y / n, z / n, w / n] + [float(v) for v in p[0:3]] + [1.0]

@@ -12,7 +12,8 @@ template <class T> class SE3 {
   const Eigen::Quaternion<T>& unit_quaternion() const { return q_; }
   const Eigen::Matrix<T, 3, 1>& translation() const { return t_; }
   Eigen::Matrix<T, 3, 3> rotationMatrix() const { return q_.toRotationMatrix(); }
-  template <class U> SE3<U> cast() const { return SE3<U>::raw(q_.template cast<U>(), t_.template cast<U>()); }
+  // (Sophus: SE3<U>(so3().cast<U>(), ...), and SO3<U>(quaternion) normalises -- a float pose cast to double has a unit quaternion to 1e-16)
+  template <class U> SE3<U> cast() const { return SE3<U>(q_.template cast<U>(), t_.template cast<U>()); }
   SE3 inverse() const {
     const Eigen::Quaternion<T> qi = q_.conjugate().normalized();
     return raw(qi, qi * (t_ * T(-1)));
