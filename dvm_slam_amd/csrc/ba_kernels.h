@@ -76,6 +76,7 @@ struct BaView {
                             // system that is summed over ranks, so what is not a sum over edges -- lambda on the camera
                             // diagonal, the identity padding, the augmented corner, the cameras' lambda x^2 -- is contributed by
                             // rank 0 only (damp_s = 0 elsewhere)
+  int32_t shard_rank, shard_world;  // landmark-sharded BA: this rank evaluates the landmarks l with l % shard_world == shard_rank (1 rank: all)
   double *poses_new, *points_new;   // trial state: k_update writes exp(dx) * poses -> poses_new, points + dx -> points_new; an
                                     // accepted trial swaps the pointers on the host, a rejected one leaves (poses, points) alone
                                     // -- g2o's push() / pop() / discardTop() without copies
@@ -141,14 +142,16 @@ void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub);
 void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail);
 // solve_seq: a number > 0 that differs from call to call on this BaView (the back substitution's hand-off flags compare against it)
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq);
-void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub);
+// d_fail: the Cholesky failure flag of this trial -- after a failed solve x keeps the last good solution (g2o's _x), which is applied all the same
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub, const int* d_fail);
 void ba_launch_edge_depth(hipStream_t s, const BaView& V, uint8_t* d_out);
 // sharded BA: the structurally non-zero tiles of S (augmented rhs row included) <-> a contiguous buffer of n_nz * 4096 doubles
 void ba_launch_pack_tiles(hipStream_t s, const BaView& V, double* buf, bool unpack);
 // sharded BA: diag(Hpp) (6 per free camera) <-> buffer; and max(buffer[0..6 nfree), diag Hll of the local landmarks) -> host
 void ba_launch_hpp_diag(hipStream_t s, const BaView& V, double* buf);
 void ba_launch_max_diag_sharded(hipStream_t s, const BaView& V, const double* hpp_diag, const BaPublish& pub);
-// sharded BA: buf[3 l + k] = points[l] for owned landmarks (pt_start[l+1] > pt_start[l]), 0 elsewhere; and the inverse after the sum
+// sharded BA: buf[3 l + k] = points[l] for the landmarks this rank owns (l % world == rank -- observed or not: an unobserved landmark
+// travels unchanged), 0 elsewhere; and the inverse after the sum
 void ba_launch_points_exchange(hipStream_t s, const BaView& V, double* buf, bool scatter);
 void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const double* P1c, const double* P2c,
                              const double* obs1, const double* obs2, const double* w1, const double* w2, int N,

@@ -166,7 +166,7 @@ __device__ __forceinline__ void block_reduce_publish(double v, double* __restric
         // anything derived from it.  pow(t, 3) is formed with the rounding errors of both products carried along (the
         // correctly rounded cube, which is what libm returns for almost every t).
         const double tmp = f == 0 ? s_red[0] : 1.7976931348623157e308;
-        const double scale = (f == 0 ? dv[2] : 0.0) + 1e-3;
+        const double scale = dv[2] + 1e-3;                     // computeScale() runs on whatever x holds, failed solve or not
         const double rho = (pub.cur_chi - tmp) / scale;
         double next = -1.0;
         if (pub.spec_mode == 1) next = 1e-5 * s_red[0];   // computeLambdaInit (_tau = 1e-5) on the max |diag| this workgroup has just reduced
@@ -1375,7 +1375,9 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     __hip_atomic_store(xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // replaces the tag: the word is the hand-off
     const int cam = kb * per_tile + tid / dof;
-    if (tid < per_tile * dof && cam < nfree) x[dof * (size_t)cam + tid % dof] = v;
+    // g2o's linear solver leaves _x untouched when the factorisation fails (linear_solver_eigen.h:89-112): x keeps the last
+    // successful solve's values, which the LM loop then applies all the same (optimization_algorithm_levenberg.cpp:111-127)
+    if (tid < per_tile * dof && cam < nfree && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) x[dof * (size_t)cam + tid % dof] = v;
   }
 }
 
@@ -1394,9 +1396,10 @@ __device__ __forceinline__ double dpp_xor_add(double v, int ctrl_is) {
 // Landmark back substitution, oplus of cameras and landmarks into the TRIAL state and the terms of computeScale =
 // sum x (lambda x + b) in ONE launch (oplus: se3quat.h:212-240, types_six_dof_expmap.h:71-74): workgroups [0, nb_pose)
 // update the cameras (thread per camera), the rest the landmarks; every workgroup feeds the grid-wide reduction.
-__global__ void __launch_bounds__(256) k_point_backsub(BaView V, BaPublish pub, int nb_pose) {
+__global__ void __launch_bounds__(256) k_point_backsub(BaView V, BaPublish pub, int nb_pose, const int* __restrict__ fail) {
   const double lambda = ba_lambda(V);
   double sc = 0;
+  const bool failed = fail && *fail != 0;   // the reduced solve failed: x (cameras: untouched by the back substitution) and xl keep the last good values
   if ((int)blockIdx.x < nb_pose) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < V.nfree) {
@@ -1449,6 +1452,7 @@ __global__ void __launch_bounds__(256) k_point_backsub(BaView V, BaPublish pub, 
         u[0] = D[0] * c[0] + D[1] * c[1] + D[2] * c[2];
         u[1] = D[3] * c[0] + D[4] * c[1] + D[5] * c[2];
         u[2] = D[6] * c[0] + D[7] * c[1] + D[8] * c[2];
+        if (failed) { u[0] = xl[0]; u[1] = xl[1]; u[2] = xl[2]; }     // (block_solver.hpp:445-446 returns before the landmark part)
         const double* X = V.points + 3 * (size_t)l;
         double* Xn = V.points_new + 3 * (size_t)l;
 #pragma unroll
@@ -2383,9 +2387,9 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
                        V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips, reinterpret_cast<int32_t*>(V.ytmp),
                        solve_seq, d_fail, V.n_root_raw);
 }
-void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub) {
+void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub, const int* d_fail) {
   const int nb_pose = cdiv(std::max(V.nfree, 1), 256);
-  hipLaunchKernelGGL(k_point_backsub, dim3(nb_pose + cdiv(8 * V.L, 256)), dim3(256), 0, s, V, pub, nb_pose);
+  hipLaunchKernelGGL(k_point_backsub, dim3(nb_pose + cdiv(8 * V.L, 256)), dim3(256), 0, s, V, pub, nb_pose, d_fail);
 }
 __global__ void __launch_bounds__(256) k_pack_tiles(BaView V, double* __restrict__ buf, int unpack) {
   const int ti = V.nz_tiles[2 * blockIdx.x], tj = V.nz_tiles[2 * blockIdx.x + 1];
@@ -2412,7 +2416,7 @@ __global__ void __launch_bounds__(256) k_max_diag_sharded(BaView V, const double
 __global__ void __launch_bounds__(256) k_points_exchange(BaView V, double* __restrict__ buf, int scatter) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= V.L) return;
-  const bool own = V.pt_start[l + 1] > V.pt_start[l];
+  const bool own = l % V.shard_world == V.shard_rank;   // by index, not by "has local edges": a landmark nobody observes keeps its value
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     if (scatter) V.points[3 * (size_t)l + k] = buf[3 * (size_t)l + k];

@@ -433,6 +433,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   h->ms_structure = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   V.lambda = nullptr;   // damping travels by value (BaView::lambda_v)
   V.damp_s = rank == 0 ? 1.0 : 0.0;
+  V.shard_rank = rank; V.shard_world = world;
   h->have_problem = true;
   return DVM_OK;
 }
@@ -584,6 +585,8 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   // for bit; otherwise (a rejected trial: the speculative launch has done nothing; a damping that differs in the last bit: it
   // has filled S) the next trial starts the ordinary way, after emptying S if need be.
   const bool speculate = !sharded && h->speculate && !h->prof;   // (the profiling pass times every phase of a trial on its own)
+  // g2o's buildStructure (iteration 0 of every optimize()) reallocates _x: "the last successful solve" starts empty
+  DVM_HIP(hipMemsetAsync(V.x, 0, ((size_t)6 * V.nfree + 3 * (size_t)V.L) * sizeof(double), s));
   bool schur_enqueued = false;      // the NEXT trial's k_schur is already on the stream, for (V after the swap, lambda)
   bool tiles_clear = false;         // the structurally non-zero tiles of S are empty: k_accum's launch was the last to touch S
   for (int it = 0; it < iterations && !terminate(); it++) {
@@ -678,7 +681,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
           ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
         }
         if (h->prof) hipEventRecord(h->pev[2], s);
-        ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false));
+        ba_launch_backsub_update(s, V, pub(S_SCALE, 2, false, false), h->d_fail);
         {
           BaView VT = V;                                   // the trial state, linearised into the alternate buffers
           VT.poses = V.poses_new; VT.points = V.points_new;
@@ -728,14 +731,21 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         h->prof_trials++;
       }
       if (sharded) {
-        double v[2] = {h->h_vals[S_TMPCHI], h->h_vals[S_SCALE]};
-        if ((rc = ar_host(v, 2, 0)) != DVM_OK) return rc;
-        h->h_vals[S_TMPCHI] = v[0]; h->h_vals[S_SCALE] = v[1];
+        // chi2 and the gain-ratio denominator are sums over ranks; the failure flag rides along (a sum of non-negative flags =
+        // "any rank failed"): every rank must take the SAME accept / reject decision, or the LM state and the collectives of
+        // the following trials diverge
+        double v[3] = {h->h_vals[S_TMPCHI], h->h_vals[S_SCALE], h->h_vals[S_FAIL] != 0.0 ? 1.0 : 0.0};
+        if ((rc = ar_host(v, 3, 0)) != DVM_OK) return rc;
+        h->h_vals[S_TMPCHI] = v[0]; h->h_vals[S_SCALE] = v[1]; h->h_vals[S_FAIL] = v[2] != 0.0 ? 1.0 : 0.0;
       }
+      // A failed linear solve (optimization_algorithm_levenberg.cpp:107-127): g2o still applies update(x) -- x being whatever the
+      // last successful solve left (zeros before the first) --, evaluates the errors there, then overrides tempChi with max()
+      // and divides by computeScale() of that x.  The kernels did the same (k_chol_backsolve / k_point_backsub keep x on a
+      // failure); max() is finite, so a negative scale would even accept the step, exactly as in the reference.
       const bool ok2 = (h->h_vals[S_FAIL] == 0.0);
       tempChi = ok2 ? h->h_vals[S_TMPCHI] : std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
-      double scale = ok2 ? h->h_vals[S_SCALE] : 0.0;
+      double scale = h->h_vals[S_SCALE];
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {

@@ -352,13 +352,16 @@ int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8
     return hip_check(hipGetLastError(), "frame_build launch");
   }
   // the keypoints / descriptors travel through the calling thread's staging context (asynchronous copy on its blocking
-  // stream); the kernel follows on the default stream; nothing waits: whatever uses the grid next is ordered behind it
+  // stream); the kernel follows on the legacy default stream.  The call returns once the grid is built: a consumer on a
+  // NON-BLOCKING stream (the ORB pipeline's and the BA's streams are, and on_device = 1 callers pass any stream) is not
+  // ordered behind the default stream and could otherwise read a half-built grid (~10 us for a 1000-keypoint frame)
   Stage st;
   const int iK = st.in(kps, (size_t)n * sizeof(dvm_keypoint)), iD = st.in(desc, (size_t)n * 32);
   rc = st.upload();
   if (rc != DVM_OK) return rc;
   launch_frame_build(nullptr, st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iD), 0, n, nullptr, f->view, slot, 1);
-  return hip_check(hipGetLastError(), "frame_build launch");
+  rc = hip_check(hipGetLastError(), "frame_build launch");
+  return rc == DVM_OK ? hip_check(hipStreamSynchronize(nullptr), "frame_build") : rc;
 }
 int dvm_frame_overflows(dvm_frame* f, int32_t* count) {
   if (!f || !count) return DVM_ERR_INVALID;
@@ -618,17 +621,20 @@ int dvm_bowdb_add(dvm_bowdb* db, const int32_t* word_ids, const double* values, 
     if (hipMalloc(&nv, ncap * 8) != hipSuccess) { hipFree(ni); set_error("hipMalloc(bowdb)"); return DVM_ERR_HIP; }
     hipError_t e = hipSuccess;
     if (repack) {
+      // the compacted offsets go to a scratch vector and replace db->off only once every copy has landed: a failure midway
+      // leaves the database exactly as it was (old arrays, old offsets)
+      std::vector<int64_t> noff(db->off);
       size_t w = 0;
       for (size_t k = 0; k < db->off.size() && e == hipSuccess; k++) {
-        if (db->len[k] <= 0) { if (db->len[k] == 0) db->off[k] = (int64_t)w; continue; }
+        if (db->len[k] <= 0) { if (db->len[k] == 0) noff[k] = (int64_t)w; continue; }
         const size_t L = (size_t)db->len[k];
         e = hipMemcpyAsync(ni + w, db->d_ids + db->off[k], L * 4, hipMemcpyDeviceToDevice, nullptr);
         if (e == hipSuccess) e = hipMemcpyAsync(nv + w, db->d_vals + db->off[k], L * 8, hipMemcpyDeviceToDevice, nullptr);
-        db->off[k] = (int64_t)w;
+        noff[k] = (int64_t)w;
         w += L;
       }
       if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-      if (e == hipSuccess) { db->used = w; db->dead = 0; }
+      if (e == hipSuccess) { db->off.swap(noff); db->used = w; db->dead = 0; }
     } else if (db->used) {
       e = hipMemcpy(ni, db->d_ids, db->used * 4, hipMemcpyDeviceToDevice);
       if (e == hipSuccess) e = hipMemcpy(nv, db->d_vals, db->used * 8, hipMemcpyDeviceToDevice);

@@ -3,11 +3,9 @@
 // Mirrors ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:47-91, src/ORBextractor.cc):
 //   constructor tables      ORBextractor.cc:282-339 -> OrbPipeline::OrbPipeline
 //   ComputePyramid          :957-976                -> launch_pyr_level0 / launch_pyr_resize
-//   ComputeKeyPointsOctTree :612-715                -> launch_fast + launch_octree (host fallback: octree_select)
+//   ComputeKeyPointsOctTree :612-715                -> launch_fast + launch_octree
 //   operator()              :876-955                -> extract_device (stage order, output placement)
-// Everything that touches pixels runs in HIP kernels (orb_kernels.hip).  DistributeOctTree is
-// sequential list surgery over <= ~10^4 candidates per level and stays on the host in this round
-// (SURVEY.md section 2.2 row K3); it is the only host compute on the path.
+// Everything runs in HIP kernels (orb_kernels.hip, octree_kernel.hip); the host only sequences launches.
 #include "orb_pipeline.h"
 
 #include <algorithm>
@@ -93,6 +91,7 @@ Profiler::~Profiler() {
 // because every child is push_front'ed (n1..n4 order) and the parent erased in place.  Phase 1
 // processes all splittable nodes in list order; phase 2 processes them in the order given by
 // std::sort(compareNodes) walked from the back, stopping as soon as the list reaches N nodes.
+#ifdef DVM_DEBUG   // the host restatement of DistributeOctTree: debug / A-B builds only (make DEBUG=1); a release library has no host compute path
 namespace {
 struct ONode {
   int x0, y0, x1, y1;
@@ -213,6 +212,8 @@ void octree_select(const uint32_t* cand, int n, int minX, int maxX, int minY, in
     out.push_back(cand[best]);
   }
 }
+#endif  // DVM_DEBUG
+
 
 // -------------------------------------------------------------------------------- OrbPipeline
 static inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
@@ -308,7 +309,9 @@ int OrbPipeline::init() {
     DVM_HIP(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
   }
   if (const char* e = getenv("DVM_SERIAL")) overlap_blur = (e[0] != '1');      // debug / A-B switch only
-  if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree_forced = (e[0] == '1');  // debug / A-B switch only
+#ifdef DVM_DEBUG
+  if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree_forced = (e[0] == '1');  // debug / A-B switch, debug builds only
+#endif
   host_octree = host_octree_forced;
   // orientation disc offsets (any order: the moments are exact integer sums)
   int8_t du[kDiscPixels], dv[kDiscPixels];
@@ -464,8 +467,8 @@ int OrbPipeline::configure(int rows, int cols) {
       return DVM_ERR_INVALID;
     }
   // A level quota beyond the device octree's node capacity (2 680 keypoints on one level, i.e. ~12 300 features at the
-  // usual 1.2 / 8 levels) is refused: there is no silent CPU path.  DVM_HOST_OCTREE=1 (debug / A-B switch) runs the same
-  // algorithm on the host for any configuration.
+  // usual 1.2 / 8 levels) is refused: there is no CPU path.  (A -DDVM_DEBUG build has DVM_HOST_OCTREE=1, the same algorithm on
+  // the host, as an A-B switch.)
   host_octree = host_octree_forced;
   if (!host_octree && !octree_prepare_device(PD)) {
     set_error("a pyramid level's keypoint quota exceeds the device octree capacity (2680 nodes); lower nFeatures");
@@ -681,7 +684,9 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
         DVM_HIP(hipStreamWaitEvent(st, ev_group[3], 0));
       }
       prof.end(st);
-    } else {
+    }
+#ifdef DVM_DEBUG
+    else {
     // ---- DistributeOctTree on the host (K3): per-cell candidate lists -> vToDistributeKeys per level -> octree_select
       DVM_HIP(hipMemcpyAsync(h_cell_count, d_cell_count, (size_t)batch * PD.ncells * 4, hipMemcpyDeviceToHost, st));
       DVM_HIP(hipMemcpyAsync(h_dense, d_cand, (size_t)batch * PD.cand_frame_slots * 4, hipMemcpyDeviceToHost, st));
@@ -715,6 +720,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       DVM_HIP(hipMemcpyAsync(d_nsel, h_nsel, (size_t)batch * L * 4, hipMemcpyHostToDevice, st));
       DVM_HIP(hipMemcpyAsync(d_sel, h_sel, (size_t)batch * PD.sel_frame_slots * 4, hipMemcpyHostToDevice, st));
     }
+#endif
 
     prof.begin(st, "assemble");
     launch_assemble(st, (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), PD, lap0, lap1, (d_kps + (size_t)f0 * PD.kp_cap), (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_mono + f0), nb);

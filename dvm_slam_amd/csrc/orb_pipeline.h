@@ -42,7 +42,9 @@ class Profiler {
 };
 
 // DistributeOctTree (reference ORBextractor.cc:419-610) on the host: array formulation, see .cpp
+#ifdef DVM_DEBUG
 void octree_select(const uint32_t* cand, int n, int minX, int maxX, int minY, int maxY, int N, std::vector<uint32_t>& out);
+#endif
 
 class OrbPipeline {
  public:
@@ -114,8 +116,8 @@ class OrbPipeline {
   int32_t* d_nid = nullptr;          // [batch][cand_frame_slots] octree scratch: node id per candidate
   int32_t* d_err = nullptr;          // octree capacity flag: device address of ...
   int32_t* h_err = nullptr;          // ... this word of mapped host memory
-  bool host_octree = false;          // DistributeOctTree on the host instead of k_octree: forced (debug) or because a
-  bool host_octree_forced = false;   // level quota exceeds the device kernel's node capacity
+  bool host_octree = false;          // -DDVM_DEBUG builds only: DistributeOctTree on the host instead of k_octree (DVM_HOST_OCTREE=1);
+  bool host_octree_forced = false;   // always false in a release library
   uint8_t* d_stage = nullptr;        // staging for host images
   size_t stage_bytes = 0;
   // pinned host mirrors

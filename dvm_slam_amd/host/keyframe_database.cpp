@@ -1,5 +1,6 @@
 // dvm_slam_amd/host/keyframe_database.cpp -- see keyframe_database.h.
 #include "keyframe_database.h"
+#include "dvmslam_host.h"
 
 #include <algorithm>
 #include <list>
@@ -173,34 +174,37 @@ static BowVector to_bow(const int32_t* ids, const double* vals, int n) {
   for (int i = 0; i < n; i++) b[(unsigned)ids[i]] = vals[i];
   return b;
 }
+struct dvmh_kfdb : KeyFrameDatabase {          // the opaque handle of include/dvmslam_host.h
+  explicit dvmh_kfdb(int device) : KeyFrameDatabase(device) {}
+};
 extern "C" {
-KeyFrameDatabase* dvmh_kfdb_create(int device) {
-  KeyFrameDatabase* db = new KeyFrameDatabase(device);
+dvmh_kfdb* dvmh_kfdb_create(int device) {
+  dvmh_kfdb* db = new dvmh_kfdb(device);
   if (!db->ok()) { delete db; return nullptr; }
   return db;
 }
-void dvmh_kfdb_destroy(KeyFrameDatabase* db) { delete db; }
-int dvmh_kfdb_add(KeyFrameDatabase* db, const int32_t* ids, const double* vals, int n, int32_t map_id, uint64_t uuid, int64_t mnId) {
+void dvmh_kfdb_destroy(dvmh_kfdb* db) { delete db; }
+int dvmh_kfdb_add(dvmh_kfdb* db, const int32_t* ids, const double* vals, int n, int32_t map_id, uint64_t uuid, int64_t mnId) {
   return db->add(to_bow(ids, vals, n), map_id, uuid, mnId);
 }
-void dvmh_kfdb_erase(KeyFrameDatabase* db, int slot) { db->erase(slot); }
-void dvmh_kfdb_set_bad(KeyFrameDatabase* db, int slot, int bad) { db->SetBadFlag(slot, bad != 0); }
-void dvmh_kfdb_set_map_bad(KeyFrameDatabase* db, int32_t map_id, int bad) { db->SetMapBad(map_id, bad != 0); }
-void dvmh_kfdb_set_neighbours(KeyFrameDatabase* db, int slot, const int32_t* neigh, int n) { db->SetBestCovisibilityKeyFrames(slot, neigh, n); }
-void dvmh_kfdb_set_connected(KeyFrameDatabase* db, int slot, const int32_t* conn, int n) { db->SetConnectedKeyFrames(slot, conn, n); }
-void dvmh_kfdb_get_state(KeyFrameDatabase* db, int slot, uint64_t* query, int32_t* words, float* score) {
+void dvmh_kfdb_erase(dvmh_kfdb* db, int slot) { db->erase(slot); }
+void dvmh_kfdb_set_bad(dvmh_kfdb* db, int slot, int bad) { db->SetBadFlag(slot, bad != 0); }
+void dvmh_kfdb_set_map_bad(dvmh_kfdb* db, int32_t map_id, int bad) { db->SetMapBad(map_id, bad != 0); }
+void dvmh_kfdb_set_neighbours(dvmh_kfdb* db, int slot, const int32_t* neigh, int n) { db->SetBestCovisibilityKeyFrames(slot, neigh, n); }
+void dvmh_kfdb_set_connected(dvmh_kfdb* db, int slot, const int32_t* conn, int n) { db->SetConnectedKeyFrames(slot, conn, n); }
+void dvmh_kfdb_get_state(dvmh_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score) {
   const KeyFrameDatabase::State s = db->GetState(slot);
   *query = s.query; *words = s.words; *score = s.score;
 }
-int dvmh_kfdb_merge_score(KeyFrameDatabase* db, const int32_t* qids, const double* qvals, int nq, uint64_t keyFrameId, int32_t map_id,
+int dvmh_kfdb_merge_score(dvmh_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t keyFrameId, int32_t map_id,
                           float* score, int32_t* bestKeyFrame) {
   return db->CalculateMergeScore(to_bow(qids, qvals, nq), keyFrameId, map_id, *score, *bestKeyFrame);
 }
-int dvmh_kfdb_detect_merge_possibility(KeyFrameDatabase* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
+int dvmh_kfdb_detect_merge_possibility(dvmh_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
                                        int32_t* bestKeyFrame, float* score, float* baseline) {
   return db->DetectMergePossibility(to_bow(qids, qvals, nq), uuid, map_id, *bestKeyFrame, score, baseline);
 }
-int dvmh_kfdb_detect_n_best(KeyFrameDatabase* db, int slot, int nNum, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge) {
+int dvmh_kfdb_detect_n_best(dvmh_kfdb* db, int slot, int nNum, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge) {
   std::vector<int32_t> l, m;
   const int rc = db->DetectNBestCandidates(slot, l, m, nNum);
   *n_loop = (int32_t)l.size(); *n_merge = (int32_t)m.size();

@@ -829,13 +829,17 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const KeyFrameView& KF, const
 
 }  // namespace dvm_host
 
-// ---- C entry point for the Python harness (tests only; a C++ caller uses the class directly)
-extern "C" int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c,
-                                                int32_t* mp_c, const dvm_se3f* Tcw, const float* K,
-                                                const float* bounds, const float* scale_factors, int nlevels, int Nl,
-                                                const dvm_keypoint* kps_l, const int32_t* mp_l, const uint8_t* outlier_l,
-                                                const dvm_host::MapPointPOD* mps, float th, int check_ori, int* requeried) {
-  dvm_host::FrameView C, L;
+// ---- C entry points (include/dvmslam_host.h): the same functions for callers without the C++ classes -- the Python harness of
+// tests/ and bench.py, a C or FFI binding.  A C++ caller uses the class directly.
+using dvm_host::FeatureVectorView;
+using dvm_host::FrameView;
+using dvm_host::KeyFrameView;
+using dvm_host::MapPointsView;
+extern "C" {
+int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,
+                                     const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
+                                     const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried) {
+  FrameView C, L;
   C.N = Nc; C.mvKeysUn = kps_c; C.mDescriptors = desc_c; C.mvpMapPoints = mp_c;
   C.Tcw = *Tcw;
   C.fx = K[0]; C.fy = K[1]; C.cx = K[2]; C.cy = K[3];
@@ -848,12 +852,10 @@ extern "C" int dvmh_search_by_projection_frames(int device, int Nc, const dvm_ke
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
-
-extern "C" int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp,
-                                                const uint8_t* claimed_obs, const float* bounds, const float* scale_factors,
-                                                int nlevels, const dvm_host::TrackedPointPOD* pts, int npts, float th,
-                                                float nnratio, int far_points, float th_far, int* requeried) {
-  dvm_host::FrameView F;
+int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
+                                     const float* bounds, const float* scale_factors, int nlevels, const dvmh_tracked_point* pts, int npts, float th,
+                                     float nnratio, int far_points, float th_far, int* requeried) {
+  FrameView F;
   F.N = N; F.mvKeysUn = kps; F.mDescriptors = desc; F.mvpMapPoints = mp;
   F.mnMinX = bounds[0]; F.mnMaxX = bounds[1]; F.mnMinY = bounds[2]; F.mnMaxY = bounds[3];
   F.mvScaleFactors = scale_factors; F.nLevels = nlevels;
@@ -862,30 +864,22 @@ extern "C" int dvmh_search_by_projection_points(int device, int N, const dvm_key
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
-
-// ---- C entry points for the M4-M7 mirrors (Python harness: the view structs are passed as ctypes.Structure)
-using dvm_host::FeatureVectorView;
-using dvm_host::FrameView;
-using dvm_host::KeyFrameView;
-using dvm_host::MapPointsView;
-using dvm_host::Sim3View;
-extern "C" {
-int dvmh_search_for_initialization(int device, const FrameView* F1, const FrameView* F2, float* prev_matched, int32_t* matches12,
-                                   int window, float nnratio, int check_ori) {
+int dvmh_search_for_initialization(int device, const dvmh_frame_view* F1, const dvmh_frame_view* F2, float* prev_matched, int32_t* matches12, int window,
+                                   float nnratio, int check_ori) {
   dvm_host::ORBmatcher m(nnratio, check_ori != 0, device);
-  return m.SearchForInitialization(*F1, *F2, prev_matched, matches12, window);
+  return m.SearchForInitialization(FrameView(*F1), FrameView(*F2), prev_matched, matches12, window);
 }
-int dvmh_search_by_bow_kf_frame(int device, const KeyFrameView* KF, const FrameView* F, const FeatureVectorView* Ffv, float nnratio,
+int dvmh_search_by_bow_kf_frame(int device, const dvmh_keyframe_view* KF, const dvmh_frame_view* F, const dvmh_feature_vector_view* Ffv, float nnratio,
                                 int check_ori, int32_t* matches, int* requeried) {
   dvm_host::ORBmatcher m(nnratio, check_ori != 0, device);
-  const int n = m.SearchByBoW(*KF, *F, *Ffv, matches);
+  const int n = m.SearchByBoW(KeyFrameView(*KF), FrameView(*F), FeatureVectorView(*Ffv), matches);
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
-int dvmh_search_by_bow_kf_kf(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, float nnratio, int check_ori,
-                             int32_t* matches12, int* requeried) {
+int dvmh_search_by_bow_kf_kf(int device, const dvmh_keyframe_view* KF1, const dvmh_keyframe_view* KF2, float nnratio, int check_ori, int32_t* matches12,
+                             int* requeried) {
   dvm_host::ORBmatcher m(nnratio, check_ori != 0, device);
-  const int n = m.SearchByBoW(*KF1, *KF2, matches12);
+  const int n = m.SearchByBoW(KeyFrameView(*KF1), KeyFrameView(*KF2), matches12);
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
@@ -900,37 +894,39 @@ void dvmh_sim3_apply(const dvm_sim3f* S, const float* p, int n, float* out) {
 }
 void dvmh_sim3_inverse(const dvm_sim3f* S, dvm_sim3f* out) { dvm_pose::sim3_inverse(S->q, S->t, out->q, out->t); }
 float dvmh_logf(float x) { return dvm_pose::logf_shared(x); }
-void dvmh_triangulation_geometry(const KeyFrameView* KF1, const KeyFrameView* KF2, float* R12, float* t12, float* ep, float* F12) {
-  dvm_host::ORBmatcher::TriangulationGeometry(*KF1, *KF2, R12, t12, ep, F12);
+void dvmh_triangulation_geometry(const dvmh_keyframe_view* KF1, const dvmh_keyframe_view* KF2, float* R12, float* t12, float* ep, float* F12) {
+  dvm_host::ORBmatcher::TriangulationGeometry(KeyFrameView(*KF1), KeyFrameView(*KF2), R12, t12, ep, F12);
 }
-int dvmh_search_for_triangulation(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, int coarse, int check_ori, int32_t* pairs) {
+int dvmh_search_for_triangulation(int device, const dvmh_keyframe_view* KF1, const dvmh_keyframe_view* KF2, int coarse, int check_ori, int32_t* pairs) {
   dvm_host::ORBmatcher m(0.6f, check_ori != 0, device);
-  return m.SearchForTriangulation(*KF1, *KF2, pairs, false, coarse != 0);
+  return m.SearchForTriangulation(KeyFrameView(*KF1), KeyFrameView(*KF2), pairs, false, coarse != 0);
 }
-int dvmh_fuse(int device, const KeyFrameView* KF, const MapPointsView* P, const uint8_t* inKF, float th, int32_t* best_idx) {
+int dvmh_fuse(int device, const dvmh_keyframe_view* KF, const dvmh_map_points_view* P, const uint8_t* inKF, float th, int32_t* best_idx) {
   dvm_host::ORBmatcher m(0.6f, true, device);
-  return m.Fuse(*KF, *P, inKF, th, best_idx);
+  return m.Fuse(KeyFrameView(*KF), MapPointsView(*P), inKF, th, best_idx);
 }
-int dvmh_fuse_sim3(int device, KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, float th, int32_t* replace) {
+int dvmh_fuse_sim3(int device, dvmh_keyframe_view* KF, const dvm_sim3f* Scw, const dvmh_map_points_view* P, float th, int32_t* replace) {
   dvm_host::ORBmatcher m(0.6f, true, device);
-  return m.Fuse(*KF, *Scw, *P, th, replace);
+  KeyFrameView K(*KF);                    // (the function writes through K.mvpMapPoints, the caller's array)
+  return m.Fuse(K, *Scw, MapPointsView(*P), th, replace);
 }
-int dvmh_search_by_projection_reloc(int device, FrameView* Cur, const KeyFrameView* KF, const MapPointsView* P, const int32_t* already,
+int dvmh_search_by_projection_reloc(int device, dvmh_frame_view* Cur, const dvmh_keyframe_view* KF, const dvmh_map_points_view* P, const int32_t* already,
                                     int n_already, float th, int orb_dist, int check_ori, int* requeried) {
   dvm_host::ORBmatcher m(0.9f, check_ori != 0, device);
-  const int n = m.SearchByProjection(*Cur, *KF, *P, already, n_already, th, orb_dist);
+  FrameView C(*Cur);
+  const int n = m.SearchByProjection(C, KeyFrameView(*KF), MapPointsView(*P), already, n_already, th, orb_dist);
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
-int dvmh_search_by_sim3(int device, const KeyFrameView* KF1, const KeyFrameView* KF2, const MapPointsView* P1, const MapPointsView* P2,
-                        int32_t* matches12, const int32_t* idx_in_kf2, const Sim3View* S12, float th) {
+int dvmh_search_by_sim3(int device, const dvmh_keyframe_view* KF1, const dvmh_keyframe_view* KF2, const dvmh_map_points_view* P1,
+                        const dvmh_map_points_view* P2, int32_t* matches12, const int32_t* idx_in_kf2, const dvm_sim3f* S12, float th) {
   dvm_host::ORBmatcher m(0.6f, true, device);
-  return m.SearchBySim3(*KF1, *KF2, *P1, *P2, matches12, idx_in_kf2, *S12, th);
+  return m.SearchBySim3(KeyFrameView(*KF1), KeyFrameView(*KF2), MapPointsView(*P1), MapPointsView(*P2), matches12, idx_in_kf2, *S12, th);
 }
-int dvmh_search_by_projection_sim3(int device, const KeyFrameView* KF, const Sim3View* Scw, const MapPointsView* P, const int32_t* point_kf,
+int dvmh_search_by_projection_sim3(int device, const dvmh_keyframe_view* KF, const dvm_sim3f* Scw, const dvmh_map_points_view* P, const int32_t* point_kf,
                                    int32_t* matched, int32_t* matched_kf, int th, float ratio_hamming, int* requeried) {
   dvm_host::ORBmatcher m(0.6f, true, device);
-  const int n = m.SearchByProjection(*KF, *Scw, *P, point_kf, matched, matched_kf, th, ratio_hamming);
+  const int n = m.SearchByProjection(KeyFrameView(*KF), *Scw, MapPointsView(*P), point_kf, matched, matched_kf, th, ratio_hamming);
   if (requeried) *requeried = m.last_requeried;
   return n;
 }

@@ -11,78 +11,38 @@
 #include <vector>
 
 #include "dvmslam_hip.h"
+#include "dvmslam_host.h"
 
 namespace dvm_host {
 
-struct MapPointPOD {
-  float pos[3];        // MapPoint::GetWorldPos()
-  uint8_t desc[32];    // MapPoint::GetDescriptor()
-  int32_t n_obs;       // MapPoint::Observations()
-};
-
-// A local map point as Tracking::SearchLocalPoints leaves it for the matcher: the mTrack* fields written by
-// Frame::isInFrustum (dvm_is_in_frustum fills the same values), isBad(), descriptor, Observations().
-struct TrackedPointPOD {
-  float mTrackProjX, mTrackProjY, mTrackDepth, mTrackViewCos;
-  int32_t mnTrackScaleLevel;
-  uint8_t mbTrackInView, bad, pad_[2];
-  uint8_t desc[32];
-  int32_t n_obs;
-};
+// The POD views live in the public C header (include/dvmslam_host.h, where the C entry points of this library are declared);
+// here they get constructors that zero them and the reference's defaults.
+typedef dvmh_map_point MapPointPOD;          // MapPoint::GetWorldPos(), GetDescriptor(), Observations()
+typedef dvmh_tracked_point TrackedPointPOD;  // a local map point as Tracking::SearchLocalPoints leaves it for the matcher (mTrack* fields, isBad, ...)
 
 // The members of ORB_SLAM3::Frame the matcher touches (mono).
-struct FrameView {
-  int N = 0;
-  const dvm_keypoint* mvKeysUn = nullptr;   // undistorted keypoints
-  const uint8_t* mDescriptors = nullptr;    // N x 32
-  int32_t* mvpMapPoints = nullptr;          // index into the map-point array, -1 = NULL
-  const uint8_t* mvbOutlier = nullptr;      // may be null (no outliers)
-  dvm_se3f Tcw;                             // GetPose(): Sophus::SE3f as stored (unit quaternion x,y,z,w + translation)
-  float fx, fy, cx, cy;                     // pinhole mpCamera
-  float mnMinX, mnMaxX, mnMinY, mnMaxY;
-  const float* mvScaleFactors = nullptr;
-  int nLevels = 8;
+struct FrameView : dvmh_frame_view {
+  FrameView() : dvmh_frame_view() { nLevels = 8; }
+  FrameView(const dvmh_frame_view& v) : dvmh_frame_view(v) {}
 };
-
 // DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened: node ids ascending, the features of node k are
 // feat[off[k] .. off[k+1]) in insertion order (dvm_host::ORBVocabulary::transform produces exactly this).
-struct FeatureVectorView {
-  int n = 0;
-  const int32_t* node = nullptr;
-  const int32_t* off = nullptr;
-  const int32_t* feat = nullptr;
+struct FeatureVectorView : dvmh_feature_vector_view {
+  FeatureVectorView() : dvmh_feature_vector_view() {}
+  FeatureVectorView(const dvmh_feature_vector_view& v) : dvmh_feature_vector_view(v) {}
 };
-
 // The members of ORB_SLAM3::KeyFrame the matcher touches (mono: NLeft == -1, no mpCamera2, mvuRight < 0).
-struct KeyFrameView {
-  int N = 0;
-  const dvm_keypoint* mvKeysUn = nullptr;
-  const uint8_t* mDescriptors = nullptr;
-  int32_t* mvpMapPoints = nullptr;       // GetMapPointMatches(): map point id per keypoint, -1 = NULL
-  const uint8_t* mpBad = nullptr;        // isBad() of that map point (may be null: none is bad)
-  FeatureVectorView mFeatVec;
-  dvm_se3f Tcw, Twc;                     // GetPose(), GetPoseInverse(); GetCameraCenter() = Twc.t (KeyFrame.cc:224-257)
+// GetCameraCenter() = Twc.t (KeyFrame.cc:224-257)
+struct KeyFrameView : dvmh_keyframe_view {
+  KeyFrameView() : dvmh_keyframe_view() { nLevels = 8; }
+  KeyFrameView(const dvmh_keyframe_view& v) : dvmh_keyframe_view(v) {}
   void SetPose(const dvm_se3f& T);       // KeyFrame::SetPose: mTcw = T; mTwc = mTcw.inverse()
-  float fx, fy, cx, cy;
-  float mnMinX, mnMaxX, mnMinY, mnMaxY;
-  const float* mvScaleFactors = nullptr;
-  const float* mvLevelSigma2 = nullptr;
-  const float* mvInvLevelSigma2 = nullptr;
-  float mfLogScaleFactor = 0.f;
-  int nLevels = 8;
 };
-
 // A list of map points as the projection searches read them (SoA): GetWorldPos, GetNormal, mfMinDistance / mfMaxDistance
 // (GetMin/MaxDistanceInvariance = 0.8 / 1.2 times these), GetDescriptor, isBad, and an id standing for the pointer.
-struct MapPointsView {
-  int n = 0;
-  const int32_t* id = nullptr;
-  const uint8_t* bad = nullptr;          // may be null
-  const float* pos = nullptr;            // 3n
-  const float* normal = nullptr;         // 3n
-  const float* min_dist = nullptr;
-  const float* max_dist = nullptr;
-  const uint8_t* desc = nullptr;         // 32n
+struct MapPointsView : dvmh_map_points_view {
+  MapPointsView() : dvmh_map_points_view() {}
+  MapPointsView(const dvmh_map_points_view& v) : dvmh_map_points_view(v) {}
 };
 
 typedef dvm_sim3f Sim3View;   // Sophus::Sim3f as stored: RxSO3 quaternion (x,y,z,w; scale = |q|^2) + translation

@@ -1,5 +1,6 @@
 // dvm_slam_amd/host/orb_vocabulary.cpp -- see orb_vocabulary.h.
 #include "orb_vocabulary.h"
+#include "dvmslam_host.h"
 
 #include <cmath>
 #include <cstring>

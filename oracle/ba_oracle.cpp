@@ -394,15 +394,19 @@ int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, 
     do {
       std::vector<Pose> poses_bak = ba.poses;
       std::vector<double> pts_bak = ba.pts;
+      // optimization_algorithm_levenberg.cpp:107-127, line by line: the update is applied and the errors are evaluated WHETHER OR
+      // NOT the linear solve succeeded -- after a failure _solver->x() still holds the last successful solve (the linear solver
+      // returns before writing it, linear_solver_eigen.h:89-112; zeros here before the first success, where g2o's freshly
+      // allocated _x is undefined) --, then tempChi is overridden with max() and divided by computeScale() of that x.  max() is
+      // finite: with a negative scale the step would be accepted.
       const bool ok = ba.solve(lambda);
-      if (ok) ba.apply_update();
-      tempChi = ok ? ba.robust_chi2() : std::numeric_limits<double>::max();
+      ba.apply_update();
+      tempChi = ba.robust_chi2();
+      if (!ok) tempChi = std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
       double scale = 0;
-      if (ok) {
-        for (int j = 0; j < n; j++) scale += ba.x[j] * (lambda * ba.x[j] + ba.bp[j]);
-        for (int j = 0; j < 3 * ba.nact; j++) scale += ba.x[n + j] * (lambda * ba.x[n + j] + ba.bl[j]);
-      }
+      for (int j = 0; j < n; j++) scale += ba.x[j] * (lambda * ba.x[j] + ba.bp[j]);
+      for (int j = 0; j < 3 * ba.nact; j++) scale += ba.x[n + j] * (lambda * ba.x[n + j] + ba.bl[j]);
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {

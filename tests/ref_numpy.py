@@ -314,6 +314,8 @@ def ba_lm_dense(Rs, ts, fixed, pts, edge_pose, edge_point, obs, info, K, delta, 
 
     lam, ni, nbad = -1.0, 2.0, 0
     hist = []
+    dx = np.zeros(n + m)
+    n_fail = 0
     for it in range(iterations):
         cur = chi(Rs, ts, pts)
         ini = cur
@@ -341,12 +343,23 @@ def ba_lm_dense(Rs, ts, fixed, pts, edge_pose, edge_point, obs, info, K, delta, 
         rho_ = 0.0; q = 0
         while True:
             bak = ([R.copy() for R in Rs], [t.copy() for t in ts], pts.copy())
-            dx = np.linalg.solve(H + lam * np.eye(n + m), b)
+            Hd = H + lam * np.eye(n + m)
+            # g2o's linear solver works on the reduced camera system and FAILS when that is not positive definite; the LM loop then
+            # applies whatever x still holds -- the last successful solve, zeros before the first -- and overrides tempChi with max()
+            # (optimization_algorithm_levenberg.cpp:107-127)
+            ok = True
+            try:
+                np.linalg.cholesky(Hd[:n, :n] - Hd[:n, n:] @ np.linalg.solve(Hd[n:, n:], Hd[n:, :n]))
+            except np.linalg.LinAlgError:
+                ok = False
+            if ok:
+                dx = np.linalg.solve(Hd, b)
+            n_fail += 0 if ok else 1
             for p in free:
                 dR, dt = se3_exp(dx[6 * pi[p]:6 * pi[p] + 6])
                 Rs[p] = dR @ Rs[p]; ts[p] = dR @ ts[p] + dt
             pts = pts + dx[n:].reshape(-1, 3)
-            tmp = chi(Rs, ts, pts)
+            tmp = chi(Rs, ts, pts) if ok else np.finfo(np.float64).max
             scale = dx @ (lam * dx + b) + 1e-3
             rho_ = (cur - tmp) / scale
             if rho_ > 0 and np.isfinite(tmp):
@@ -357,7 +370,7 @@ def ba_lm_dense(Rs, ts, fixed, pts, edge_pose, edge_point, obs, info, K, delta, 
             q += 1
             if not (rho_ < 0 and q < 10):
                 break
-        hist.append((q, cur, lam))
+        hist.append((q, cur, lam, n_fail))
         if q == 10 or rho_ == 0:
             break
         nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0

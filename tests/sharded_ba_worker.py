@@ -17,6 +17,8 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     pr = synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=n_kf * 31 + n_pts)
+    if len(sys.argv) > 6 and sys.argv[6] == "unobserved":       # three landmarks nobody observes (one per residue class mod 3): "not a vertex", they
+        pr["points"] = np.concatenate([pr["points"], [[1.5, -2.5, 3.5], [4.0, 5.0, 6.0], [-7.0, 8.0, 9.0]]])   # must come back exactly as they went in
     e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
     sb = sharded_ba.ShardedBundleAdjuster(0)
     sb.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)

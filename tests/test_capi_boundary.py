@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/dvmslam_hip.h declares; without a GPU
+"""The C-ABI libraries load and export every symbol include/dvmslam_hip.h / dvmslam_wire.h / dvmslam_host.h declare; without a GPU
 every compute entry point fails loudly (DVM_ERR_NO_DEVICE) -- there is no CPU fallback in the product."""
 import ctypes
 import os
@@ -30,6 +30,33 @@ def test_library_exports_every_declared_symbol(capi):
     exported = set(re.findall(r" T (dvm_[a-z0-9_]+)", out))
     assert set(names) <= exported
     assert lib.dvm_version().decode().startswith("dvmslam-hip")
+
+
+def _declared_host():
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dvmslam_host.h")).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(dvmh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_host_library_exports_every_declared_symbol(capi):
+    """include/dvmslam_host.h is the C interface of libdvmslam_host.so: every declared dvmh_* entry point is exported, and nothing
+    dvmh_* is exported that the header does not declare."""
+    names = _declared_host()
+    assert len(names) >= 30 and "dvmh_search_by_sim3" in names and "dvmh_kfdb_detect_merge_possibility" in names
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (dvmh_[a-z0-9_]+)", out))
+    assert set(names) == exported, (set(names) ^ exported)
+    # the ctypes mirrors of the view structs in capi.py have the header's sizes (checked by compiling a C probe)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "dvmslam_host.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dvmh_frame_view), '
+                             'sizeof(dvmh_keyframe_view), sizeof(dvmh_map_points_view), sizeof(dvmh_feature_vector_view), sizeof(dvmh_map_point), '
+                             'sizeof(dvmh_tracked_point)); return 0; }\n')
+        exe = os.path.join(td, "sz")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(capi._FrameView), ctypes.sizeof(capi._KeyFrameView), ctypes.sizeof(capi._MapPointsView),
+                     ctypes.sizeof(capi._FeatureVectorView), capi.MAP_POINT_DTYPE.itemsize, capi.TRACKED_POINT_DTYPE.itemsize], sizes
 
 
 def test_struct_layouts(capi):

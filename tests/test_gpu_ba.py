@@ -308,3 +308,21 @@ def test_pose_graph_optimize(capi, oracle, n, noise, fix):
     if fix:
         assert np.allclose(Sg[:, 7], pg["S0"][:, 7], atol=1e-12)
     assert np.array_equal(Sg[0], pg["S0"][0])            # the fixed vertex never moves
+
+
+@pytest.mark.parametrize("n_kf,n_pts,k_obs,radius,cam,factor", [(6, 40, 4, 20.0, 3, -0.02), (30, 900, 8, 50.0, 11, -0.05)])
+def test_ba_failed_linear_solve_follows_g2o(capi, oracle, n_kf, n_pts, k_obs, radius, cam, factor):
+    """Observations of one camera carry NEGATIVE information: the reduced camera system stays indefinite until the damping has grown
+    past the negative block, so the tile Cholesky FAILS -- first with an empty x, later (lambda has shrunk again) with the previous
+    solution still in x.  g2o applies update(x) and computeScale() all the same (optimization_algorithm_levenberg.cpp:107-127); device
+    and oracle must walk the same trial sequence and end in the same place, and report the same per-edge chi2 (the last evaluation)."""
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=n_kf, n_pts=n_pts, k_obs=k_obs, seed=3, radius=radius)
+    pr["inv_sigma2"] = pr["inv_sigma2"].copy()
+    pr["inv_sigma2"][pr["edge_pose"] == cam] *= factor
+    (po_, pto, so, chio), (pg, ptg, sg, chig, depth) = _run_both(capi, oracle, pr, 0.0, 8)
+    assert so["trials"][0] >= 3, "the first iteration must burn trials on failed solves"
+    assert sg["trials"] == so["trials"] and sg["iterations"] == so["iterations"] and sg["stop_reason"] == so["stop_reason"]
+    assert np.allclose(sg["chi2"], so["chi2"], rtol=1e-8) and np.allclose(sg["lam"], so["lam"], rtol=1e-6)
+    assert np.abs(pg - po_).max() < 1e-5 and np.abs(ptg - pto).max() < 1e-5
+    assert np.allclose(chig, chio, rtol=1e-5, atol=1e-7)

@@ -44,3 +44,29 @@ def test_sharded_ba_matches_single_gpu(capi, oracle, world, n_kf, n_pts, delta, 
     po_, pto, so, _ = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, iters)
     assert list(res[0]["trials"]) == so["trials"]
     assert np.abs(res[0]["poses"] - po_).max() < 1e-6 and np.abs(res[0]["points"] - pto).max() < 1e-6
+
+
+def test_sharded_ba_leaves_unobserved_landmarks_alone(capi):
+    """A landmark without any observation is not a vertex: the single-GPU solver never touches it, and the sharded flow -- whose final
+    exchange sums every rank's landmarks -- must hand it back unchanged on every rank (ownership by index, not by "has local edges")."""
+    from dvm_slam_amd import synth
+    n_kf, n_pts, delta, iters = 30, 900, float(np.sqrt(5.991)), 4
+    extra = np.array([[1.5, -2.5, 3.5], [4.0, 5.0, 6.0], [-7.0, 8.0, 9.0]])
+    pr = synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=n_kf * 31 + n_pts)
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"], np.concatenate([pr["points"], extra]), e, pr["intrinsics"], delta)
+    ba.optimize(iters)
+    p1, x1 = ba.result()
+    ba.close()
+    assert np.array_equal(x1[-3:], extra)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "res")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29617",
+               os.path.join(ROOT, "tests", "sharded_ba_worker.py"), str(n_kf), str(n_pts), repr(delta), str(iters), out, "unobserved"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        for k in range(3):
+            z = np.load(f"{out}.rank{k}.npz")
+            assert np.array_equal(z["points"][-3:], extra), k
+            assert np.abs(z["points"] - x1).max() < 1e-6 and np.abs(z["poses"] - p1).max() < 1e-6

@@ -33,6 +33,34 @@ def test_ba_oracle_matches_dense_lm(oracle, seed, delta):
     assert np.allclose(chi, chi_now, rtol=1e-9) and depth.all()
 
 
+def _indefinite_problem(seed=3):
+    """Observations of one camera carry NEGATIVE information: the reduced camera system is indefinite until the damping has grown
+    past the negative block, so linear solves FAIL -- at the start (x still empty) and again after lambda has shrunk (x stale)."""
+    pr = _tiny_problem(seed, 0.0)
+    info = pr["inv_sigma2"].copy()
+    info[pr["edge_pose"] == 3] *= -0.02
+    return pr, info
+
+
+def test_ba_oracle_failed_linear_solve_follows_g2o(oracle):
+    """optimization_algorithm_levenberg.cpp:107-127: after a failed solve the update is still applied with the solver's stale x, the
+    errors are evaluated there, tempChi becomes max() and rho is divided by computeScale() of the stale x."""
+    pr, info = _indefinite_problem()
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], info)
+    poses, pts, st, chi = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], 0.0, 8)
+    Rs = [ref.quat_to_R(p[3:]) for p in pr["poses"]]
+    ts = [p[:3].copy() for p in pr["poses"]]
+    Rn, tn, ptn, hist = ref.ba_lm_dense(Rs, ts, pr["fixed"], pr["points"], pr["edge_pose"], pr["edge_point"], pr["obs"], info, pr["intrinsics"], 0.0, 8)
+    assert hist[0][3] >= 2, "the first iteration must start with failed solves"
+    assert hist[-1][3] > hist[0][3], "a later iteration must fail again (stale x in play)"
+    assert st["trials"] == [h[0] for h in hist]
+    assert np.allclose(st["chi2"], [h[1] for h in hist], rtol=1e-7)
+    assert np.allclose(st["lam"], [h[2] for h in hist], rtol=1e-6)
+    for p in range(len(Rs)):
+        assert np.allclose(ref.quat_to_R(poses[p, 3:]), Rn[p], atol=1e-7) and np.allclose(poses[p, :3], tn[p], atol=1e-7)
+    assert np.allclose(pts, ptn, atol=1e-7)
+
+
 def test_ba_oracle_reduces_error_and_respects_gauge(oracle):
     from dvm_slam_amd import synth
     pr = synth.ba_problem(n_kf=30, n_pts=800, seed=7, outlier_frac=0.0)
