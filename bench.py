@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      -- dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration
   cpu_baseline  -- the CPU oracle (port of the reference path) timed single-threaded on this host
   ba            -- bundle-adjustment iterations/s (second half of BASELINE.json's metric) when built
+  latency / lba / merge / ba_cold -- per-call costs of configs 2 and 3 through the drop-in boundary (bench_legs.py)
 """
 from __future__ import annotations
 
@@ -49,6 +50,7 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident-input leg (N=1 only)")
     ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--no-legs", action="store_true", help="skip the per-call legs (latency, lba, ba_cold, merge; N=1 only)")
     return ap.parse_args()
 
 
@@ -422,6 +424,18 @@ def main():
                 out["ba"] = None
         if sharded_rec is not None:
             out["ba_sharded"] = sharded_rec
+        if world == 1 and not a.no_legs:
+            # what BASELINE configs 2 and 3 cost per call through the drop-in boundary (bench_legs.py), CPU oracle beside each
+            import bench_legs
+            cpu = a.cpu_seconds > 0
+            for name, fn in (("latency", lambda: bench_legs.latency(capi, frames[:64], local, cpu_calls=24 if cpu else 0)),
+                             ("lba", lambda: bench_legs.lba(local, cpu_seconds=4.0 if cpu else 0.0)),
+                             ("merge", lambda: bench_legs.merge(local, cpu_reps=3 if cpu else 0)),
+                             ("ba_cold", lambda: bench_legs.ba_cold(local))):
+                try:
+                    out[name] = fn()
+                except Exception as ex:   # noqa: BLE001 -- a leg that fails must not take the contract line with it
+                    out[name] = {"error": repr(ex)}
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
         flush_c_stdio()

@@ -1,0 +1,286 @@
+"""Further legs of bench.py's JSON line (rank 0, N = 1): what BASELINE.json's configs 2 and 3 cost per CALL, as the reference's
+threads would see it through the drop-in boundary -- host pointers in, host pointers out, one frame / one window at a time --
+each with the CPU oracle timed beside it in the same run (`cpu_baseline`, kind "port", 1 thread).
+
+  latency   one-frame dvm_orb_extract, SearchByProjection(Cur, Last) through libdvmslam_host, dvm_pose_optimize with batch 1:
+            median / p95 over 500 calls            (reference: Tracking.cc:1423-1426, :2610, :2632; Frame.cc:408-417 timers)
+  lba       LocalBundleAdjustment-sized window (30 keyframes of which 10 fixed, 3 000 landmarks, ~15 k observations): LM
+            iterations/s and the end-to-end call (set_problem + optimize(10) + get_result + edge_chi2)   (Optimizer.cc:1030-1387)
+  ba_cold   the 500-keyframe global BA started on a GPU that has been idle for 2 s (the reference runs it from an otherwise
+            idle LoopClosing / GBA thread)
+  merge     BASELINE config 3, stage by stage: vocabulary transform -> DetectMergePossibility over a 500-keyframe database ->
+            SearchByBoW -> 200 Sim3 hypotheses -> OptimizeSim3 -> SearchBySim3   (LoopClosing.cc:644-953)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0
+FP64_MATRIX_PEAK_TFLOPS = 78.6
+
+
+def _stats(ts):
+    a = np.sort(np.asarray(ts)) * 1e3
+    return {"median_ms": float(a[len(a) // 2]), "p95_ms": float(a[int(0.95 * (len(a) - 1))]), "mean_ms": float(a.mean()), "calls": len(a)}
+
+
+def _time_calls(fn, n, warm=5):
+    for i in range(warm):
+        fn(i)
+    ts = []
+    for i in range(n):
+        t0 = time.perf_counter()
+        fn(i)
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def _pose_case(seed, n_pts=300, out_frac=0.1):
+    from dvm_slam_amd import synth
+    rng = np.random.default_rng(seed)
+    pr = synth.ba_problem(n_kf=4, n_pts=n_pts, k_obs=4, seed=seed, noise_px=0.5, outlier_frac=0.0, radius=20.0)
+    kf = 1 + seed % 3
+    sel = pr["edge_pose"] == kf
+    Xw = pr["points_gt"][pr["edge_point"][sel]]
+    obs = pr["obs"][sel].copy()
+    bad = rng.random(len(obs)) < out_frac
+    obs[bad] += rng.choice([-1.0, 1.0], size=(int(bad.sum()), 2)) * 35.0
+    return pr["poses"][kf], Xw, obs, pr["inv_sigma2"][sel], pr["intrinsics"]
+
+
+def latency(capi, frames, device, calls=500, cpu_calls=24):
+    """Per-call latency of the three calls Tracking makes per frame, through the drop-in boundary (host arrays in and out)."""
+    ext = capi.OrbExtractor(max_batch=1, device=device)
+    scale = ext.tables()["scale"]
+    nfr = len(frames)
+    t_ext = _time_calls(lambda i: ext.extract(frames[i % nfr]), calls)
+    # SearchByProjection(Cur, Last): consecutive frames of the stream, last frame's keypoints carry map points at 3..9 m
+    rng = np.random.default_rng(9)
+    K = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    pairs = []
+    prev = ext.extract(frames[0])
+    for t in range(1, 9):
+        cur = ext.extract(frames[t])
+        _, k0, d0, _ = prev
+        _, k1, d1, _ = cur
+        z = rng.uniform(3, 9, len(k0)).astype(np.float32)
+        mps = np.zeros(len(k0), capi.MAP_POINT_DTYPE)
+        mps["pos"][:, 0] = (k0["x"] - K[2]) / K[0] * z; mps["pos"][:, 1] = (k0["y"] - K[3]) / K[1] * z; mps["pos"][:, 2] = z
+        mps["desc"] = d0; mps["n_obs"] = 1
+        pairs.append(dict(kps_c=k1, desc_c=d1, mp_c=np.full(len(k1), -1, np.int32), Tcw=np.array([0, 0, 0, 1, 0, 0, 0], np.float32), K=K,
+                          bounds=np.array([0, 640, 0, 480], np.float32), scale_factors=scale, kps_l=k0, mp_l=np.arange(len(k0), dtype=np.int32),
+                          outlier_l=None, mps=mps))
+        prev = cur
+    nm = []
+    t_sbp = _time_calls(lambda i: nm.append(capi.search_by_projection_frames(th=15.0, device=device, **pairs[i % len(pairs)])[0]), calls)
+    cases = [_pose_case(100 + i) for i in range(8)]
+
+    def pose(i):
+        c = cases[i % 8]
+        capi.pose_optimize(c[0][None], c[1][None], c[2][None], c[3][None], np.array([len(c[1])], np.int32), c[4], device)
+    t_pose = _time_calls(pose, calls)
+    ext.close()
+    out = {"unit": "ms per call, host arrays in -> host arrays out (Python / ctypes harness around the C ABI)",
+           "orb_extract_one_frame": _stats(t_ext), "search_by_projection_cur_last": dict(_stats(t_sbp), matches_per_call=float(np.mean(nm))),
+           "pose_optimization_one_frame": dict(_stats(t_pose), matches=int(np.mean([len(c[1]) for c in cases]))),
+           "reference": "Tracking.cc:1423-1426 (Frame ctor -> ORBextractor::operator()), :2610 (SearchByProjection), :2632 (PoseOptimization)"}
+    if cpu_calls > 0:
+        from oracle import pyoracle as po   # cpu_baseline leg: the checker timed as the baseline
+        orc = po.OrbOracle()
+        c_ext = _time_calls(lambda i: orc.extract(frames[i % nfr]), cpu_calls, warm=1)
+        c_sbp = _time_calls(lambda i: po.search_by_projection_frames(th=15.0, **pairs[i % len(pairs)]), cpu_calls, warm=1)
+        c_pose = _time_calls(lambda i: po.pose_optimize(*cases[i % 8]), cpu_calls, warm=1)
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": f"{cpu_calls} calls each of the same inputs, CPU oracle",
+                               "orb_extract_one_frame": _stats(c_ext), "search_by_projection_cur_last": _stats(c_sbp),
+                               "pose_optimization_one_frame": _stats(c_pose)}
+    return out
+
+
+def lba(device, iters=10, repeats=40, cpu_seconds=4.0):
+    """LocalBundleAdjustment as LocalMapping calls it per keyframe: a covisibility window with anchors."""
+    import ba_bench
+    from dvm_slam_amd import capi, synth
+    pr = synth.ba_problem(n_kf=30, n_pts=3000, k_obs=5, seed=0x1BA, radius=12.0)
+    pr["fixed"][:10] = 1                                         # lFixedCameras: keyframes that see the window's points from outside it
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(np.float32(5.991)))
+    ba = capi.BundleAdjuster(device)
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    ba.optimize(2)
+    t_call, t_opt, its, trials = [], 0.0, 0, 0
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        st = ba.optimize(iters)
+        pg, xg = ba.result()
+        chi, front = ba.edge_chi2()
+        t_call.append(time.perf_counter() - t0)
+        t_opt += st["ms_optimize"] * 1e-3; its += st["iterations"]; trials += st["total_trials"]
+    info = ba.schedule_info()
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    ba.profile(1)
+    ba.optimize(iters)
+    prof = ba.profile(0)
+    ba.close()
+    E, L = len(e), len(pr["points"])
+    fl = ba_bench.executed_flops_per_trial(info)
+    t_solve = prof["ms_cholesky_solve"] / max(prof["trials"], 1) * 1e-3
+    t_edge = prof["ms_update_chi2"] / max(prof["trials"], 1) * 1e-3
+    edge_bytes = E * (18 * 8 + 64) + L * 9 * 8 * 2 + E * (256 + 192)
+    out = {"problem": {"keyframes": 30, "fixed_keyframes": 10, "landmarks": L, "observations": E, "huber_delta": delta, "iterations_per_call": iters},
+           "value": its / t_opt, "unit": "LM iterations/s (inside dvm_ba_optimize)", "ms_per_iteration": t_opt / its * 1e3, "iterations": its, "trials": trials,
+           "end_to_end_call": dict(_stats(t_call), includes="dvm_ba_set_problem + dvm_ba_optimize(10) + dvm_ba_get_result + dvm_ba_edge_chi2, host arrays"),
+           "ms_graph_build": st["ms_structure"], "schedule": info,
+           "roofline": {"solve": {"bound": "mfma", "achieved": fl / t_solve / 1e12 if t_solve > 0 else None, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fl / t_solve / 1e12 / FP64_MATRIX_PEAK_TFLOPS if t_solve > 0 else None, "ms_per_trial": t_solve * 1e3,
+                                  "executed_flop_per_trial": fl},
+                        "landmarks_update_linearise": {"bound": "hbm", "achieved": edge_bytes / t_edge / 1e9 if t_edge > 0 else None, "peak": HBM_PEAK_GBS,
+                                                       "unit": "GB/s", "frac": edge_bytes / t_edge / 1e9 / HBM_PEAK_GBS if t_edge > 0 else None,
+                                                       "ms_per_trial": t_edge * 1e3, "bytes_per_trial": edge_bytes},
+                        "note": "at this size every kernel is a handful of workgroups: the call is launch- and dependency-latency bound, the fractions say so"},
+           "phase_ms_per_trial": {"schur": prof["ms_schur"] / max(prof["trials"], 1), "cholesky_solve": t_solve * 1e3, "landmarks_update_linearise": t_edge * 1e3},
+           "reference": "Optimizer.cc:1030-1387 (LocalMapping.cc:172)"}
+    if cpu_seconds > 0:
+        from oracle import pyoracle as po   # cpu_baseline leg
+        eo = po.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+        done, runs, t0 = 0, 0, time.perf_counter()
+        tc = []
+        while True:
+            t1 = time.perf_counter()
+            p, x, so, chio = po.ba_optimize(pr["poses"], pr["fixed"], pr["points"], eo, pr["intrinsics"], delta, iters)
+            po.ba_edge_chi2(p, x, eo, pr["intrinsics"])
+            tc.append(time.perf_counter() - t1)
+            done += so["iterations"]; runs += 1
+            if time.perf_counter() - t0 >= cpu_seconds or runs >= 200:
+                break
+        out["cpu_baseline"] = {"value": done / sum(tc), "unit": "LM iterations/s", "cores": 1, "kind": "port", "end_to_end_call": _stats(tc),
+                               "sample": f"{runs} runs of optimize({iters}) + edge chi2 on the same window, CPU oracle, {sum(tc):.1f} s"}
+        out["parity_vs_cpu"] = {"trials_equal": bool(st["trials"] == so["trials"]), "max_abs_pose": float(np.abs(pg - p).max()),
+                                "max_abs_landmark": float(np.abs(xg - x).max())}
+        if not (out["parity_vs_cpu"]["trials_equal"] and out["parity_vs_cpu"]["max_abs_pose"] < 1e-6 and out["parity_vs_cpu"]["max_abs_landmark"] < 1e-6):
+            raise RuntimeError(f"lba leg: GPU result differs from the CPU oracle: {out['parity_vs_cpu']}")
+    return out
+
+
+def ba_cold(device, iters=10, runs=5, idle_s=2.0):
+    """The 500-keyframe global BA on a GPU that has been idle: the clocks have dropped, the first kernels pay the ramp."""
+    from dvm_slam_amd import capi, synth
+    pr = synth.ba_problem()
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(5.991))
+    ba = capi.BundleAdjuster(device)
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    ba.optimize(2)
+    vals, calls = [], []
+    for _ in range(runs):
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        ba.result()                                              # (drains the stream)
+        time.sleep(idle_s)
+        t0 = time.perf_counter()
+        st = ba.optimize(iters)
+        calls.append(time.perf_counter() - t0)
+        vals.append(st["iterations"] / (st["ms_optimize"] * 1e-3))
+    ba.close()
+    return {"value": float(np.median(vals)), "unit": "iterations/s", "runs": runs, "idle_seconds_before_each_run": idle_s, "iterations_per_run": iters,
+            "all_runs": [float(v) for v in vals], "optimize_call": _stats(calls),
+            "note": "same problem and call as `ba`, but every optimize(10) starts after the GPU has sat idle (nothing else queued, power state dropped)"}
+
+
+class _Timed:
+    """Proxy around an ops object (merge.GpuOps or the oracle operators): accumulates wall time per stage."""
+
+    def __init__(self, ops):
+        self.ops, self.t, self.n = ops, {}, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self.ops, name)
+        if not callable(fn):
+            return fn
+
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            self.t[name] = self.t.get(name, 0.0) + time.perf_counter() - t0
+            self.n[name] = self.n.get(name, 0) + 1
+            return r
+        return w
+
+
+class _TimedDb:
+    def __init__(self, db, acc):
+        self.db, self.acc = db, acc
+
+    def __getattr__(self, name):
+        fn = getattr(self.db, name)
+        if name != "detect_merge_possibility":
+            return fn
+
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            self.acc.t["detect_merge_possibility"] = self.acc.t.get("detect_merge_possibility", 0.0) + time.perf_counter() - t0
+            self.acc.n["detect_merge_possibility"] = self.acc.n.get("detect_merge_possibility", 0) + 1
+            return r
+        return w
+
+
+def merge(device, reps=20, cpu_reps=3, db_keyframes=500):
+    """Config 3 as one chain per new keyframe, ms per stage (host arrays in / out per stage, as LoopClosing would call them)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dvm_slam_amd import capi, synth
+    from dvm_slam_amd import merge as mg
+    from merge_scene import make_two_agent_scene
+    voc = synth.vocabulary(k=10, L=4, seed=5)
+    sc = make_two_agent_scene(capi, 1, n_distract=db_keyframes - 1, s_w=0.7)     # (capi supplies the record dtypes the scene builder needs)
+    triples = np.random.default_rng(1).integers(0, 1 << 30, (200, 3)).astype(np.int64)
+    stages = ("transform", "detect_merge_possibility", "search_by_bow", "sim3_hypotheses", "optimize_sim3", "search_by_sim3")
+
+    def chain(ops, reps_):
+        T = _Timed(ops)
+        t0 = time.perf_counter()
+        peers = [dict(p) for p in sc["peers"]]                       # fill_database attaches each keyframe's BoW / feature vector
+        db = mg.fill_database(ops, peers, 2)
+        t_fill = time.perf_counter() - t0
+        tdb = _TimedDb(db, T)
+        res = None
+        tot = []
+        for _ in range(reps_):
+            t1 = time.perf_counter()
+            res = mg.merge_with_peer(T, sc["a"], sc["pa"], peers, sc["peer_pts"], tdb, 2, triples)
+            tot.append(time.perf_counter() - t1)
+        per = {s: T.t.get(s, 0.0) / max(T.n.get(s, 1), 1) * 1e3 for s in stages}
+        return res, per, tot, t_fill
+
+    gops = mg.GpuOps(voc, device)
+    chain(gops, 2)                                                # warm-up (kernel load, handle creation)
+    res, per, tot, t_fill = chain(gops, reps)
+    ok = res["candidate"] == sc["true_idx"] and res.get("n_sim3_inliers", 0) > 80 and abs(res["S12"][7] / sc["gt"]["s"] - 1) < 0.02
+    out = {"unit": "ms per stage call (host arrays in / out)", "database_keyframes": db_keyframes, "stage_ms": per, "chain": _stats(tot),
+           "database_fill_ms_per_keyframe": t_fill / db_keyframes * 1e3,
+           "result": {"candidate_found": bool(res["candidate"] == sc["true_idx"]), "bow_matches": int(res.get("n_bow_matches", 0)),
+                      "sim3_inliers": int(res.get("n_sim3_inliers", 0)), "scale_error": float(abs(res["S12"][7] / sc["gt"]["s"] - 1)) if res.get("S12") is not None else None,
+                      "matches_after_search_by_sim3": int((res["matches"] >= 0).sum()) if res.get("matches") is not None else None},
+           "reference": "orb_slam3_wrapper.cpp:457-618 -> KeyFrameDatabase.cc:789-808; LoopClosing.cc:644-953 (SearchByBoW, Sim3Solver, OptimizeSim3, SearchBySim3)"}
+    if not ok:
+        raise RuntimeError(f"merge leg: the chain did not recover the planted similarity: {out['result']}")
+    if cpu_reps > 0:
+        from oracle import pyoracle as po   # cpu_baseline leg
+
+        class OracleOps:
+            def transform(self, desc, levelsup): return po.vocab_transform(voc, desc, levelsup)
+            def new_database(self): return po.KeyFrameDatabase()
+            def search_by_bow(self, a, b, nnratio): return po.search_by_bow_kf_kf(a["kps"], a["desc"], a["mp"], a["bad"], a["fv"], b["kps"], b["desc"], b["mp"], b["bad"], b["fv"], nnratio, True)
+            def sim3_hypotheses(self, P1c, P2c, e1, e2, K1, K2, tr): return po.sim3_hypotheses(P1c, P2c, e1, e2, K1, K2, tr, False)
+            def optimize_sim3(self, S12, P1c, P2c, o1, o2, w1, w2, K1, K2, th2): return po.optimize_sim3(S12, False, P1c, P2c, o1, o2, w1, w2, K1, K2, th2)
+            def search_by_sim3(self, a, pa, b, pb, m12, idx2, S12, th): return po.search_by_sim3(a, pa, b, pb, S12, th, m12, idx2)
+        res_c, per_c, tot_c, fill_c = chain(OracleOps(), cpu_reps)
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "stage_ms": per_c, "chain": _stats(tot_c), "database_fill_ms_per_keyframe": fill_c / db_keyframes * 1e3,
+                               "sample": f"{cpu_reps} chains on the same scene and database, CPU oracle"}
+        out["parity_vs_cpu"] = {"candidate_equal": bool(res_c["candidate"] == res["candidate"]), "bow_matches_equal": bool(np.array_equal(res_c["bow_matches"], res["bow_matches"])),
+                                "sim3_max_abs_diff": float(np.abs(res_c["S12"] - res["S12"]).max())}
+    return out
