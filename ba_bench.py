@@ -74,6 +74,18 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
     ba.close()
     fl = executed_flops_per_trial(info)
     t_solve = prof["ms_cholesky_solve"] / max(prof["trials"], 1) * 1e-3
+    # HBM-side traffic per launch from the committed PMC passes (tools/run_profiles_r03.sh: --pmc FETCH_SIZE / WRITE_SIZE, read side
+    # calibrated x2 on known byte counts): the solve's kernels per trial, and the streaming kernels of a trial
+    traffic, pmc_k = None, {}
+    try:
+        import json
+        import os
+        pmc_k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")))["kernels"]
+        b = lambda k: pmc_k["dvm::" + k]["hbm_bytes_per_launch"]
+        lv = info["levels"]
+        traffic = lv * b("k_chol_diag") + max(lv - 2, 0) * b("k_chol_trsm_update") + b("k_chol_trsm") + b("k_chol_update") + b("k_chol_backsolve")
+    except Exception:   # noqa: BLE001
+        traffic = None
     nblk_pairs = None
     E, L, nfree = info["edges"], len(pr["points"]), info["free_cameras"]
     # algorithmic bytes of the memory-bound phase of a trial / measured event time: landmark back
@@ -86,6 +98,15 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
     for v in hbm.values():
         v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None
         v["frac_of_8TBps"] = v["GBps"] / HBM_PEAK_GBS if v["GBps"] else None
+    if pmc_k:
+        try:
+            hbm["landmarks_update_linearise"]["traffic"] = sum(pmc_k["dvm::" + k]["hbm_bytes_per_launch"] for k in ("k_point_backsub", "k_edge_eval", "k_accum"))
+            hbm["schur"] = {"bytes": None, "ms": prof["ms_schur"] / max(prof["trials"], 1), "traffic": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"],
+                            "traffic_GBps": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"] / (prof["ms_schur"] / max(prof["trials"], 1) * 1e-3) / 1e9,
+                            "note": "gathers of W rows: the measured fabric traffic over the event time of the launch"}
+            hbm["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2.0 + WRITE_SIZE, per launch)"
+        except Exception:   # noqa: BLE001
+            pass
     out = {
         "metric": "BA iterations/sec, 500 KF / 20k landmarks / 160k observations (outer LM iterations)",
         "value": its / dt, "unit": "iterations/s", "iterations": its, "trials": trials, "runs": max(1, repeats),
@@ -99,7 +120,7 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
                      "achieved": fl / t_solve / 1e12 if t_solve > 0 else None, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl / t_solve / 1e12 / FP64_MATRIX_PEAK_TFLOPS if t_solve > 0 else None,
                      "executed_flop_per_trial": fl, "solve_ms_per_trial": t_solve * 1e3, "schedule": info,
-                     "traffic": None,
+                     "traffic": traffic,
                      "note": "EXECUTED FLOPs of the symbolic tile factorisation (dvm_ba_schedule_info) over the HIP-event time of the "
                              "factorisation + back substitution launches of a trial.  The solve is a dependency chain of elimination-tree "
                              "levels (diag -> trsm -> update per level), not matrix-pipe bound; dense-equivalent (n^3/3 per trial over the "

@@ -350,7 +350,7 @@ def main():
             ach = BYTES_PER_FRAME_FAST * frames_per_launch / per_launch_s / 1e9
             traffic = None
             pmc, pmc_file = None, None
-            for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
+            for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                     pmc_file = cand
@@ -369,13 +369,22 @@ def main():
                                  "dvm::k_assemble": 1, "dvm::k_orient_desc": 1, "dvm::k_frame_build": 1, "dvm::k_match_window": 1}
                     wi = sum(pmc["kernels"][k]["valu_wave_instr_per_launch"] * n for k, n in per_chunk.items())
                     chunk_ms = dt / (a.steps * chunks) * 1e3
-                    ms2, ms4 = wi * 2 / (1024 * 2.4e9) * 1e3, wi * 4 / (1024 * 2.4e9) * 1e3
-                    valu = {"wave_instr_per_launch_group": wi, "issue_ms_if_all_2_cycle": ms2, "issue_ms_if_all_4_cycle": ms4,
-                            "launch_group_ms": chunk_ms, "frac_low": ms2 / chunk_ms, "frac_high": ms4 / chunk_ms, "source": f"profiles/{pmc_file}",
-                            "note": "SQ_INSTS_VALU x cycles / (1024 SIMDs x 2.4 GHz).  Measured issue cost on gfx950 (tools/valu_issue.hip, "
-                                    "profiles/r02_valu_issue.jsonl): 2 cycles per wave-instruction for VOP2 (v_add_u32, v_min_u16, v_and_b32 ...), "
-                                    "4 for every VOP3 / VOP3P form (v_pk_min/max_u16, v_perm_b32, v_min3, v_dot4, v_sad, v_mad, v_readlane ...), "
-                                    "8 for v_min3_u16 / v_max3_u16; these kernels mix both classes, so the truth lies between the two bounds"}
+                    # ONE number: every kernel's dynamic wave-instruction count (SQ_INSTS_VALU) x the mean issue cost of ITS static
+                    # instruction mix by measured cost class (tools/valu_mix.py: 2.25 / 4.15 / 4.6 / 8.2 / 16.3 cycles)
+                    cyc = sum(pmc["kernels"][k]["valu_wave_instr_per_launch"] * pmc["kernels"][k].get("mean_issue_cycles_per_valu_instr", 4.15) * n
+                              for k, n in per_chunk.items())
+                    issue_ms = cyc / (1024 * 2.4e9) * 1e3
+                    ms2, ms4 = wi * 2.25 / (1024 * 2.4e9) * 1e3, wi * 4.15 / (1024 * 2.4e9) * 1e3
+                    valu = {"frac": issue_ms / chunk_ms, "issue_ms_per_launch_group": issue_ms, "launch_group_ms": chunk_ms,
+                            "wave_instr_per_launch_group": wi, "mean_issue_cycles_per_wave_instr": cyc / wi,
+                            "per_kernel_issue_ms": {k.replace("dvm::", ""): pmc["kernels"][k]["valu_wave_instr_per_launch"] * pmc["kernels"][k].get("mean_issue_cycles_per_valu_instr", 4.15) * n
+                                                    / (1024 * 2.4e9) * 1e3 for k, n in per_chunk.items()},
+                            "bounds_if_all_full_rate_or_all_half_rate": [ms2 / chunk_ms, ms4 / chunk_ms], "source": f"profiles/{pmc_file} + profiles/r03_valu_mix.json",
+                            "note": "VALU issue time of one 256-frame launch group / its wall time.  Issue time = sum over kernels of SQ_INSTS_VALU (dynamic, "
+                                    "rocprofv3 --pmc) x the mean cycles per wave-instruction of the kernel's static instruction mix, each mnemonic priced by the "
+                                    "issue cost measured on this GPU at 8 waves per SIMD (profiles/r02_valu_issue*.jsonl: 2.25 full-rate integer / f32 add-mul, 4.15 "
+                                    "half-rate VOP3 / packed / dot / mad / conversions, 8.2 min3 / max3_u16), over 1024 SIMDs x 2.4 GHz.  Static mix, dynamic "
+                                    "count: loop bodies are not weighted."}
             except Exception:
                 valu = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
