@@ -1482,19 +1482,33 @@ __global__ void __launch_bounds__(256) k_edge_depth(BaView V, uint8_t* __restric
 // round (chi2 > 5.991 as float), Huber removed after round 2.  ONE workgroup runs the whole thing for
 // one frame -- about 40 LM iterations with no host round trip; frames are batched over the grid.
 struct PoseAccum { double v[28]; };  // 21 upper-H + 6 b + 1 chi
-__device__ __forceinline__ void pose_block_reduce(PoseAccum& a, double* park, double* part, double* out28) {
-  block_sum_lds<14>(a.v, park, part, out28);            // two halves keep the parking area at 30 KB
-  block_sum_lds<14>(a.v + 14, park, part, out28 + 14);
+// One value over the workgroup in a fixed order: xor-butterfly inside each wave, then the four wave sums in wave order.
+// (What the chi2-only evaluation of a trial needs: running the 28-value reduction for it cost 2 us per LM trial.)
+__device__ __forceinline__ double block_sum_one(double v, double* part4) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) part4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = (part4[0] + part4[1]) + (part4[2] + part4[3]);
+  __syncthreads();
+  return r;
 }
-
+// The kernel is a LATENCY path -- Tracking calls PoseOptimization two or three times per frame, one frame at a time, and a
+// workgroup runs ~40 dependent LM iterations -- so everything that repeats per iteration is kept off the memory system and off
+// the serial thread: a thread's correspondences (up to kPoseEdgesPerThread x 256 per frame; more fall back to global reads) live
+// in registers across all iterations together with their level flag and last chi2; the Jacobian pass reduces its 28 sums in one
+// pass through LDS; a trial's chi2-only pass reduces ONE value; the 6x6 solve forms 1 / L_ii once per row (v_rsq_f64 + two
+// Newton steps, as the tile Cholesky does) instead of 27 double-precision divisions and 6 square roots on a single lane.
+// (Measured, one frame of 300 matches: 363 us per call before, of which ~2.8 us per LM trial were the divisions.)
+constexpr int kPoseEdgesPerThread = 5;
 __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict__ pose_in, const double* __restrict__ Xw,
                                                        const double* __restrict__ obs, const double* __restrict__ info,
                                                        const int32_t* __restrict__ n_per_frame, int stride, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ pose_out,
                                                        uint8_t* __restrict__ outlier, int32_t* __restrict__ n_inliers,
                                                        double* __restrict__ chi_scratch) {
-  __shared__ double s_park[256 * 15];
-  __shared__ double s_part[4 * 14];
+  __shared__ double s_park[256 * 29];
+  __shared__ double s_part[4 * 28];
   __shared__ double s_sum[28];
   __shared__ double s_T[7], s_Tbak[7], s_T0[7];
   __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
@@ -1505,61 +1519,88 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
   const double* O = obs + (size_t)f * stride * 2;
   const double* W = info + (size_t)f * stride;
   uint8_t* outl = outlier + (size_t)f * stride;
-  double* last_chi = chi_scratch + (size_t)f * stride;  // e->chi2() as g2o reports it (last evaluation)
-  uint8_t* level = outl;  // level(1) == outlier flag in the reference's bookkeeping
+  double* last_chi = chi_scratch + (size_t)f * stride;  // e->chi2() as g2o reports it (last evaluation): edges beyond the register-resident ones
   const double delta = (double)sqrtf(5.991f);
   const float chi2Mono = 5.991f;
+  constexpr int EPT = kPoseEdgesPerThread;
   if (tid < 7) {
     double v = pose_in[7 * (size_t)f + tid];
     s_T0[tid] = v;
   }
   __syncthreads();
   if (tid == 0) quat_normalize(&s_T0[3]);
-  for (int i = tid; i < N; i += 256) { outl[i] = 0; last_chi[i] = 0; }
+  // this thread's correspondences: registers for the first EPT, global memory beyond
+  double eX[EPT][3], eO[EPT][2], eW[EPT], eChi[EPT];
+  bool eOut[EPT];       // level(1) == outlier flag in the reference's bookkeeping
+#pragma unroll
+  for (int e = 0; e < EPT; e++) {
+    const int i = tid + 256 * e;
+    const bool in = i < N;
+    const int ii = in ? i : 0;
+    eX[e][0] = X[3 * ii]; eX[e][1] = X[3 * ii + 1]; eX[e][2] = X[3 * ii + 2];
+    eO[e][0] = O[2 * ii]; eO[e][1] = O[2 * ii + 1];
+    eW[e] = W[ii];
+    eChi[e] = 0; eOut[e] = false;
+  }
+  for (int i = tid + 256 * EPT; i < N; i += 256) { outl[i] = 0; last_chi[i] = 0; }
   __syncthreads();
   if (N < 3) {  // nInitialCorrespondences < 3: return 0, pose untouched (Optimizer.cc:904-905)
     if (tid < 7) pose_out[7 * (size_t)f + tid] = pose_in[7 * (size_t)f + tid];
+    for (int i = tid; i < N; i += 256) outl[i] = 0;
     if (tid == 0) n_inliers[f] = 0;
     return;
   }
-  // evaluates the active edges at pose T: chi (always), H/b (jac) ; updates last_chi
+  // one active edge at pose (R, T): chi2 (always; returned), H / b terms (jac)
+  auto edge = [&](const double* R, const double* T, const double* Xp, double o0, double o1, double w0, bool jac, bool robust_on, PoseAccum& a) -> double {
+    double Xc[3];
+    mat3_vec(R, Xp, Xc);
+    Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
+    const double x = Xc[0], y = Xc[1], z = Xc[2];
+    const double e0 = o0 - (fx * x / z + cx), e1 = o1 - (fy * y / z + cy);
+    const double chi2 = e0 * w0 * e0 + e1 * w0 * e1;
+    double r0, r1;
+    robustify(chi2, robust_on ? delta : 0.0, r0, r1);
+    a.v[27] += r0;
+    if (jac) {
+      const double J[6] = {-(fx / z), 0, fx * x / (z * z), 0, -(fy / z), fy * y / (z * z)};
+      const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+      double B[12];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
+      const double w = r1 * w0, wr0 = -w0 * e0 * r1, wr1 = -w0 * e1 * r1;
+      int t = 0;
+#pragma unroll
+      for (int p = 0; p < 6; p++) {
+        a.v[21 + p] += B[p] * wr0 + B[6 + p] * wr1;
+#pragma unroll
+        for (int q = 0; q <= p; q++) a.v[t++] += w * (B[p] * B[q] + B[6 + p] * B[6 + q]);
+      }
+    }
+    return chi2;
+  };
+  // evaluates the active edges at pose T: chi (always), H / b (jac); updates the edges' last chi2.  Result in s_sum ([27] = chi2).
   auto eval = [&](const double* T, bool jac, bool robust_on) {
     PoseAccum a;
 #pragma unroll
     for (int i = 0; i < 28; i++) a.v[i] = 0;
     double R[9];
     quat_to_R(T + 3, R);
-    for (int i = tid; i < N; i += 256) {
-      if (level[i]) continue;
-      double Xc[3];
-      mat3_vec(R, X + 3 * i, Xc);
-      Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
-      const double x = Xc[0], y = Xc[1], z = Xc[2], w0 = W[i];
-      const double e0 = O[2 * i] - (fx * x / z + cx), e1 = O[2 * i + 1] - (fy * y / z + cy);
-      const double chi2 = e0 * w0 * e0 + e1 * w0 * e1;
-      last_chi[i] = chi2;
-      double r0, r1;
-      robustify(chi2, robust_on ? delta : 0.0, r0, r1);
-      a.v[27] += r0;
-      if (jac) {
-        const double J[6] = {-(fx / z), 0, fx * x / (z * z), 0, -(fy / z), fy * y / (z * z)};
-        const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
-        double B[12];
 #pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-          for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
-        const double w = r1 * w0, wr0 = -w0 * e0 * r1, wr1 = -w0 * e1 * r1;
-        int t = 0;
-#pragma unroll
-        for (int p = 0; p < 6; p++) {
-          a.v[21 + p] += B[p] * wr0 + B[6 + p] * wr1;
-#pragma unroll
-          for (int q = 0; q <= p; q++) a.v[t++] += w * (B[p] * B[q] + B[6 + p] * B[6 + q]);
-        }
-      }
+    for (int e = 0; e < EPT; e++) {
+      if (tid + 256 * e < N && !eOut[e]) eChi[e] = edge(R, T, eX[e], eO[e][0], eO[e][1], eW[e], jac, robust_on, a);
     }
-    pose_block_reduce(a, s_park, s_part, s_sum);
+    for (int i = tid + 256 * EPT; i < N; i += 256) {
+      if (outl[i]) continue;
+      last_chi[i] = edge(R, T, X + 3 * i, O[2 * i], O[2 * i + 1], W[i], jac, robust_on, a);
+    }
+    if (jac) block_sum_lds<28>(a.v, s_park, s_part, s_sum);
+    else {
+      const double c = block_sum_one(a.v[27], s_part);
+      if (tid == 0) s_sum[27] = c;
+      __syncthreads();
+    }
   };
 
   bool robust_on = true;
@@ -1568,7 +1609,9 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
     if (tid == 0) { s_nact = 0; s_ctl = 0; s_nbad = 0; }
     __syncthreads();
     int my = 0;
-    for (int i = tid; i < N; i += 256) my += level[i] ? 0 : 1;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) my += (tid + 256 * e < N && !eOut[e]) ? 1 : 0;
+    for (int i = tid + 256 * EPT; i < N; i += 256) my += outl[i] ? 0 : 1;
     if (my) atomicAdd(&s_nact, my);
     __syncthreads();
     const int nact = s_nact;
@@ -1597,18 +1640,41 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
         bool ok = true;
         if (tid == 0) {
           for (int i = 0; i < 7; i++) s_Tbak[i] = s_T[i];
-          // dense 6x6 Cholesky of (H + lambda I), lower-packed Hs[p(p+1)/2 + q]
-          double Lm[21];
-          for (int i = 0; i < 6 && ok; i++)
+          // dense 6x6 Cholesky of (H + lambda I), lower-packed Hs[p(p+1)/2 + q]; ri[j] = 1 / L_jj
+          double Lm[21], ri[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+#pragma unroll
             for (int j = 0; j <= i; j++) {
               double sacc = Hs[i * (i + 1) / 2 + j] + (i == j ? s_lambda : 0.0);
+#pragma unroll
               for (int k = 0; k < j; k++) sacc -= Lm[i * (i + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
-              if (i == j) { if (!(sacc > 0)) { ok = false; break; } Lm[i * (i + 1) / 2 + i] = sqrt(sacc); }
-              else Lm[i * (i + 1) / 2 + j] = sacc / Lm[j * (j + 1) / 2 + j];
+              if (i == j) {
+                if (!(sacc > 0)) ok = false;
+                const double dd = sacc > 0 ? sacc : 1.0;
+                double y = __builtin_amdgcn_rsq(dd);
+                y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+                y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+                double sq = dd * y;
+                sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);
+                Lm[i * (i + 1) / 2 + i] = sq; ri[i] = y;
+              } else Lm[i * (i + 1) / 2 + j] = sacc * ri[j];
             }
           if (ok) {
-            for (int i = 0; i < 6; i++) { double sacc = bs[i]; for (int k = 0; k < i; k++) sacc -= Lm[i * (i + 1) / 2 + k] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
-            for (int i = 5; i >= 0; i--) { double sacc = xs[i]; for (int k = i + 1; k < 6; k++) sacc -= Lm[k * (k + 1) / 2 + i] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              double sacc = bs[i];
+#pragma unroll
+              for (int k = 0; k < i; k++) sacc -= Lm[i * (i + 1) / 2 + k] * xs[k];
+              xs[i] = sacc * ri[i];
+            }
+#pragma unroll
+            for (int i = 5; i >= 0; i--) {
+              double sacc = xs[i];
+#pragma unroll
+              for (int k = i + 1; k < 6; k++) sacc -= Lm[k * (k + 1) / 2 + i] * xs[k];
+              xs[i] = sacc * ri[i];
+            }
             se3_oplus(s_T, xs);
           }
           s_ctl = ok ? 1 : 0;
@@ -1659,16 +1725,23 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
     {
       double R[9];
       quat_to_R(s_T + 3, R);
-      for (int i = tid; i < N; i += 256) {
-        if (outl[i]) {
-          double Xc[3];
-          mat3_vec(R, X + 3 * i, Xc);
-          Xc[0] += s_T[0]; Xc[1] += s_T[1]; Xc[2] += s_T[2];
-          const double e0 = O[2 * i] - (fx * Xc[0] / Xc[2] + cx), e1 = O[2 * i + 1] - (fy * Xc[1] / Xc[2] + cy);
-          last_chi[i] = e0 * W[i] * e0 + e1 * W[i] * e1;
+      auto fresh = [&](const double* Xp, double o0, double o1, double w0) {
+        double Xc[3];
+        mat3_vec(R, Xp, Xc);
+        Xc[0] += s_T[0]; Xc[1] += s_T[1]; Xc[2] += s_T[2];
+        const double e0 = o0 - (fx * Xc[0] / Xc[2] + cx), e1 = o1 - (fy * Xc[1] / Xc[2] + cy);
+        return e0 * w0 * e0 + e1 * w0 * e1;
+      };
+#pragma unroll
+      for (int e = 0; e < EPT; e++) {
+        if (tid + 256 * e < N) {
+          if (eOut[e]) eChi[e] = fresh(eX[e], eO[e][0], eO[e][1], eW[e]);
+          eOut[e] = (float)eChi[e] > chi2Mono;
         }
-        const float chi2 = (float)last_chi[i];
-        outl[i] = chi2 > chi2Mono ? 1 : 0;
+      }
+      for (int i = tid + 256 * EPT; i < N; i += 256) {
+        if (outl[i]) last_chi[i] = fresh(X + 3 * i, O[2 * i], O[2 * i + 1], W[i]);
+        outl[i] = (float)last_chi[i] > chi2Mono ? 1 : 0;
       }
     }
     if (round == 2) robust_on = false;
@@ -1678,7 +1751,12 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
   if (tid == 0) s_nact = 0;
   __syncthreads();
   int bad = 0;
-  for (int i = tid; i < N; i += 256) bad += outl[i];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) {
+    const int i = tid + 256 * e;
+    if (i < N) { outl[i] = eOut[e] ? 1 : 0; bad += eOut[e] ? 1 : 0; }
+  }
+  for (int i = tid + 256 * EPT; i < N; i += 256) bad += outl[i];
   if (bad) atomicAdd(&s_nact, bad);
   __syncthreads();
   if (tid < 7) pose_out[7 * (size_t)f + tid] = s_T[tid];
@@ -1775,8 +1853,8 @@ __global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12i
                                                        const double* __restrict__ w2, int N, const double* __restrict__ Kio,
                                                        double th2, uint8_t* __restrict__ inlier, int32_t* __restrict__ nin_out,
                                                        double* __restrict__ chi_scratch, uint8_t* __restrict__ flag_scratch) {
-  __shared__ double s_park[256 * 19];
-  __shared__ double s_part[4 * 18];
+  __shared__ double s_park[256 * 37];   // the 36 sums of a Jacobian pass in ONE pass through LDS
+  __shared__ double s_part[4 * 36];
   __shared__ double s_sum[36];
   __shared__ Sim3d s_S, s_bak;
   __shared__ Sim3M s_M[30];   // [0] S, [1] S^-1, [2+2d] S+d, [3+2d] (S+d)^-1, [16+2d] S-d, [17+2d] (S-d)^-1
@@ -1862,8 +1940,12 @@ __global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12i
         }
       }
     }
-    block_sum_lds<18>(acc, s_park, s_part, s_sum);
-    block_sum_lds<18>(acc + 18, s_park, s_part, s_sum + 18);
+    if (jac) block_sum_lds<36>(acc, s_park, s_part, s_sum);
+    else {          // a trial's chi2: one value (the full reduction here cost ~2 us per LM trial)
+      const double c = block_sum_one(acc[35], s_part);
+      if (tid == 0) s_sum[35] = c;
+      __syncthreads();
+    }
   };
   auto optimize = [&](int iters) {
     for (int it = 0; it < iters; it++) {
@@ -1884,18 +1966,43 @@ __global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12i
       while (true) {
         if (tid == 0) {
           s_bak = s_S;
-          double Lm[28];
+          // dense 7x7 Cholesky; ri[j] = 1 / L_jj by v_rsq_f64 + two Newton steps: no double-precision division or square root on
+          // this single lane (35 of them before: ~3 us per LM trial)
+          double Lm[28], ri[7];
           bool ok = true;
-          for (int i = 0; i < 7 && ok; i++)
+#pragma unroll
+          for (int i = 0; i < 7; i++)
+#pragma unroll
             for (int j = 0; j <= i; j++) {
               double sacc = Hs[i * (i + 1) / 2 + j] + (i == j ? s_lambda : 0.0);
+#pragma unroll
               for (int k = 0; k < j; k++) sacc -= Lm[i * (i + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
-              if (i == j) { if (!(sacc > 0)) { ok = false; break; } Lm[i * (i + 1) / 2 + i] = sqrt(sacc); }
-              else Lm[i * (i + 1) / 2 + j] = sacc / Lm[j * (j + 1) / 2 + j];
+              if (i == j) {
+                if (!(sacc > 0)) ok = false;
+                const double dd = sacc > 0 ? sacc : 1.0;
+                double y = __builtin_amdgcn_rsq(dd);
+                y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+                y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
+                double sq = dd * y;
+                sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);
+                Lm[i * (i + 1) / 2 + i] = sq; ri[i] = y;
+              } else Lm[i * (i + 1) / 2 + j] = sacc * ri[j];
             }
           if (ok) {
-            for (int i = 0; i < 7; i++) { double sacc = bs[i]; for (int k = 0; k < i; k++) sacc -= Lm[i * (i + 1) / 2 + k] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
-            for (int i = 6; i >= 0; i--) { double sacc = xs[i]; for (int k = i + 1; k < 7; k++) sacc -= Lm[k * (k + 1) / 2 + i] * xs[k]; xs[i] = sacc / Lm[i * (i + 1) / 2 + i]; }
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+              double sacc = bs[i];
+#pragma unroll
+              for (int k = 0; k < i; k++) sacc -= Lm[i * (i + 1) / 2 + k] * xs[k];
+              xs[i] = sacc * ri[i];
+            }
+#pragma unroll
+            for (int i = 6; i >= 0; i--) {
+              double sacc = xs[i];
+#pragma unroll
+              for (int k = i + 1; k < 7; k++) sacc -= Lm[k * (k + 1) / 2 + i] * xs[k];
+              xs[i] = sacc * ri[i];
+            }
             double u[7];
             for (int i = 0; i < 7; i++) u[i] = xs[i];
             if (fix_scale) u[6] = 0;
