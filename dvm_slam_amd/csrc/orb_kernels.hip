@@ -75,7 +75,7 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 //                  the blur, which needs 3 px)
 // Destination dwords are aligned in BORDERED coordinates (the image starts at byte 19 of a row), so a
 // dword at a row end may mix interior and border bytes: those are stored byte-wise.
-constexpr int kRzTW = 256, kRzTH = 64;   // destination tile (bordered columns x interior rows)
+constexpr int kRzTW = 256, kRzTH = 64;   // destination tile (bordered columns x interior rows); 16 rows for tiny batches (latency path)
 
 __device__ __forceinline__ void store_px4(uint8_t* D, int X4, int w, uint32_t v) {
   const int d0 = X4 - kEdge;             // interior x of byte 0
@@ -170,6 +170,10 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
 // level l = cv::resize(level l-1, INTER_LINEAR) WITH its REFLECT_101 frame.  A workgroup owns a 256 x 16 tile of
 // BORDERED columns x interior rows; a frame column computes the pixel it mirrors (its source lies in the same LDS
 // rectangle, at most 19 destination pixels further in), rows 1..19 / h-20..h-2 are stored twice (strip rows).
+// TH = rows per tile: 64 for throughput (the column set-up and the tile load are amortised over 16 rows per thread), 16 when a
+// handful of frames is all there is (one frame through the drop-in boundary: 21 workgroups of 16 serial rows each made every level
+// a 13 us launch; four times as many workgroups of 4 rows are back in ~6 us).  Same arithmetic, same bytes.
+template <int TH>
 __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
                                                     LevelDesc L, const int32_t* __restrict__ tabs, int lds_pitch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rz_smem[];
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   const int f = blockIdx.z;
   const int w = L.w, bw = L.w + 2 * kEdge;
   const int X0 = blockIdx.x * kRzTW;               // first bordered column of the tile (dword aligned)
-  const int y0 = blockIdx.y * kRzTH;               // first interior row
+  const int y0 = blockIdx.y * TH;               // first interior row
   if (X0 >= bw) return;
   // interior columns whose sources the tile needs: its own, plus the ones its frame columns mirror
   const int lo = X0 - kEdge, hi = min(X0 + kRzTW - 1, bw - 1) - kEdge;
@@ -189,7 +193,7 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   const int32_t* xal = xofs + L.w;   // (a0 | a1 << 16)
   const int32_t* yofs = xal + L.w;
   const int32_t* ybe = yofs + L.h;   // (b0 | b1 << 16)
-  const int yb = min(y0 + kRzTH - 1, L.h - 1);
+  const int yb = min(y0 + TH - 1, L.h - 1);
   const int sya = min(max(yofs[y0], 0), P.h - 1), syb = min(max(yofs[yb] + 1, 0), P.h - 1);
   const int sxa = xofs[dxa], sxb = xofs[dxb] + 1;  // sx+1 may be the first border column of level l-1 (weight 0)
   const int ga = (kEdge + sxa) & ~3;               // bordered source column of LDS column 0
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   }
   uint8_t* Dl = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off;
 #pragma unroll
-  for (int rr = 0; rr < kRzTH / 4; rr++) {
+  for (int rr = 0; rr < TH / 4; rr++) {
     const int dy = y0 + ty + 4 * rr;
     if (dy >= L.h) break;
     const int sy = yofs[dy];
@@ -1123,9 +1127,15 @@ void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, in
   // LDS for the source rectangle of a 256 x 16 destination tile (scale = P/L, +margins)
   const double sxs = (double)P.w / L.w, sys = (double)P.h / L.h;
   const int pitch = (((int)(kRzTW * sxs) + 16) + 3) & ~3;
+  if (batch <= 8) {   // latency path: short tiles
+    const int nrows = (int)(16 * sys) + 4;
+    dim3 grid(cdiv(L.w + 2 * kEdge, kRzTW), cdiv(L.h, 16), batch);
+    hipLaunchKernelGGL(k_pyr_resize<16>, grid, dim3(256), (size_t)pitch * nrows, s, d_pyr, PD.pyr_frame_bytes, P, L, d_tabs, pitch);
+    return;
+  }
   const int nrows = (int)(kRzTH * sys) + 4;
   dim3 grid(cdiv(L.w + 2 * kEdge, kRzTW), cdiv(L.h, kRzTH), batch);
-  hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)pitch * nrows, s, d_pyr, PD.pyr_frame_bytes, P, L, d_tabs, pitch);
+  hipLaunchKernelGGL(k_pyr_resize<kRzTH>, grid, dim3(256), (size_t)pitch * nrows, s, d_pyr, PD.pyr_frame_bytes, P, L, d_tabs, pitch);
 }
 void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch) {
   int rows = 0, maxw = 0;
