@@ -942,7 +942,11 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
         // VGPR -> SGPR -> VGPR round trip costs 28 cycles (tools/valu_issue2.hip).  Same operands, same bits as updating
         // a[j + 1] on lane j + 1 and broadcasting the result.
         const double anext = (j + 1 < 16) ? bcast_lane(a[j + 1], j + 1) : 0.0;
-        const double lj = lane > j ? a[j] * y : 0.0;
+        // (no "lane > j" select: a finished row's a[j] is its zero upper-triangle slot, and row j itself publishes d * y ~ L_jj into
+        //  Pcol[j][j], which nothing reads -- the updates take Pcol[j][c] for c > j, the trailing inverse Pcol[t][i] for t < i; what
+        //  the garbage does to the upper-triangle registers of the diagonal sub-block is wiped by the store below.  Three
+        //  instructions less on the one wave whose instruction count is the panel's time.)
+        const double lj = a[j] * y;
         Pcol[j][lane] = lj;
         if (j + 1 < 16) {
           const double ln = bcast_lane(lj, j + 1);
