@@ -737,6 +737,8 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {  // src_l
 }
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2f64 lds_v2f64;
 constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
 
 // Diagonal step kb: Cholesky factor L of the 64x64 block AND its inverse, one workgroup (4 waves).
@@ -768,7 +770,7 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   // where a ds instruction's 16-bit offset field reaches it -- left to the compiler, Li / Iv / Pcol landed above 64 KB and every
   // such address became a v_mov of a literal parked in an AGPR (hundreds of them in the kernel's prologue).
   typedef __attribute__((address_space(3))) double lds_f64;
-  __shared__ double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 2 * NB * LP];
+  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 2 * NB * LP];
   lds_f64* const lds = (lds_f64*)smem;
   lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
   lds_f64 (*const s_rinv)[16] = (lds_f64 (*)[16])(lds + 16 * NB);
@@ -915,50 +917,20 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       // the rows below the diagonal sub-block ride along in the same instructions (no separate triangular solve).
       // Right-looking: a finished column j updates every later column c of every row, a_c -= L_ij * L_cj.  The factor
       // L_cj is the same for all lanes: column j is published to LDS once and read back with uniform-address (broadcast)
-      // reads -- except for c = j + 1, the next pivot column, which gets it by v_readlane.  Measured per 16-column panel
-      // (cycle stamps, 2.4 GHz): 7 400 cycles with every L_cj by v_readlane, 6 080 this way, 10 200 when the updates are
-      // pinned in program order (each then waits out the LDS round trip); the compiler schedules the updates of a column
-      // lazily, right before that column's pivot, which keeps LDS latency off the chain.
+      // reads -- except for c = j + 1, the next pivot column, which gets it by v_readlane.  The 16 columns are ONE
+      // straight-line stream written by tools/gen_chol_panel.py (chol_panel.inc): this wave owns its SIMD and issues in order,
+      // nothing overlaps, so the panel costs the sum of its instructions' issue times (5.3 cycles an FP64 operation, 8.3
+      // when it needs the previous one, ~20 the rsq, ~30 a store behind an exec-mask round trip) -- the stream carries
+      // nothing the factorisation does not need (no sqrt for L_jj, which nobody reads; one positivity test per panel; the
+      // 1 / L_jj store from every lane) and a filler between any two dependent chain steps.  Cycle stamps per panel,
+      // 2.4 GHz: 7 400 with every L_cj by v_readlane, 5 850 as the rolled loop the compiler scheduled (366 / column),
+      // 3 850-4 150 now (250 / column); chain alone (no updates, no LDS) 2 600.
       double a[16];
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = (lane < nrows && (lane >= 16 || c <= lane)) ? Bm[(o + lane) * LP + o + c] : 0.0;
       bool bad = false;
-      double lprev = 0.0;
-      double d_next = bcast_lane(a[0], 0);
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const double d = d_next;                 // pivot a_jj, wave-uniform (see below)
-        if (!(d > 0.0)) bad = true;
-        const double dd = d > 0.0 ? d : 1.0;
-        double y = __builtin_amdgcn_rsq(dd);     // 1 / L_jj: v_rsq_f64 + two Newton steps instead of sqrt and divisions
-        if (j >= 1) {                            // deferred updates of column j - 1 (columns j + 1 .. 15)
-#pragma unroll
-          for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lprev, Pcol[j - 1][c], a[c]);
-        }
-        y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
-        y = __builtin_fma(0.5 * y, __builtin_fma(-dd * y, y, 1.0), y);
-        // the NEXT pivot in wave-uniform form: its pre-update value is broadcast off the critical path (it only waits for the
-        // deferred update above), so the chain holds ONE cross-lane broadcast per column (l_{j+1,j}) instead of two -- the
-        // VGPR -> SGPR -> VGPR round trip costs 28 cycles (tools/valu_issue2.hip).  Same operands, same bits as updating
-        // a[j + 1] on lane j + 1 and broadcasting the result.
-        const double anext = (j + 1 < 16) ? bcast_lane(a[j + 1], j + 1) : 0.0;
-        // (no "lane > j" select: a finished row's a[j] is its zero upper-triangle slot, and row j itself publishes d * y ~ L_jj into
-        //  Pcol[j][j], which nothing reads -- the updates take Pcol[j][c] for c > j, the trailing inverse Pcol[t][i] for t < i; what
-        //  the garbage does to the upper-triangle registers of the diagonal sub-block is wiped by the store below.  Three
-        //  instructions less on the one wave whose instruction count is the panel's time.)
-        const double lj = a[j] * y;
-        Pcol[j][lane] = lj;
-        if (j + 1 < 16) {
-          const double ln = bcast_lane(lj, j + 1);
-          a[j + 1] = __builtin_fma(-lj, ln, a[j + 1]);
-          d_next = __builtin_fma(-ln, ln, anext);
-        }
-        double sq = dd * y;
-        sq = __builtin_fma(0.5 * y, __builtin_fma(-sq, sq, dd), sq);   // sqrt(dd) to the last bit or one ulp
-        if (lane == 0) s_rinv[b][j] = y;
-        a[j] = (lane == j) ? sq : lj;
-        lprev = lj;
-      }
+      double d0 = bcast_lane(a[0], 0);          // pivot a_00, wave-uniform
+#include "chol_panel.inc"
       if (lane < nrows) {
 #pragma unroll
         for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (lane < 16 && c > lane) ? 0.0 : a[c];
