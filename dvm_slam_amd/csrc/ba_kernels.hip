@@ -745,22 +745,24 @@ constexpr int LP = NB + 1;  // LDS pitch (doubles) of a 64x64 block
 // The block is processed as four 16-column panels:
 //   A. wave 0: the panel (diagonal 16x16 sub-block and all rows below it) row-per-lane in registers, column
 //      broadcasts by v_readlane -- the only strictly sequential part (4 x 16 columns instead of 64); the rows below
-//      the diagonal are solved by the same instruction stream
+//      the diagonal are solved by the same instruction stream, and so is the sub-block's INVERSE: the lanes that have
+//      no row left (16 / 32 / 48 of them in panels 1 / 2 / 3) carry the rows of the identity, which the panel turns
+//      into the columns of the inverse
 //   C. trailing sub-blocks:      A_ij -= X_i * X_j^T               (v_mfma_f64_16x16x4_f64, waves 0..2)
-//      while wave 3 inverts the diagonal sub-block (16x16, registers) for the L^-1 assembly
 // then Linv by block forward substitution, Linv_ij = -Linv_ii * sum_k L_ik Linv_kj, again on MFMA: the
 // C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly its B-operand
 // layout for k-step = reg, so the running sum feeds the next product without touching LDS.
-// Beside the LAST panel the three idle waves finish everything that does not need its result: wave 3 inverts sub-block 2 and
-// assembles L^-1 block (2, 0), wave 1 blocks (1, 0) and (2, 1) -- two LDS flags order them --, both then form the sums of
-// block row 3; wave 2 inverts sub-block 3 row by row BEHIND wave 0 (it reads the columns wave 0 publishes for its own
-// deferred updates).  The tail after the panel is four MFMAs per block of row 3 and the 16-byte store of L^-1
-// (7 000 -> 3 000 cycles of a 40 000-cycle kernel, same bits).
+// The assembly runs beside the panels on the other waves, ordered by the panels' barriers alone: sub-block 0 (the one panel
+// without idle lanes) is inverted by wave 3 beside panel 1, block (1, 0) follows beside panel 2, blocks (2, 0), (2, 1) and the
+// three sums of block row 3 beside panel 3.  The tail after the last panel is four MFMAs per block of row 3, one block per
+// wave, and the 16-byte store of L^-1.
 #ifdef DVM_CHOL_DEBUG
 __device__ long long g_chol_dbg[32];
 #define DVM_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chol_dbg[i] = __builtin_readcyclecounter(); } while (0)
+#define DVM_STAMPW(i, w) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_chol_dbg[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DVM_STAMP(i) do { } while (0)
+#define DVM_STAMPW(i, w) do { } while (0)
 #endif
 __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, const int32_t* __restrict__ cols,
                                                   int* __restrict__ fail, double* __restrict__ Linv_all) {
@@ -770,12 +772,13 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   // where a ds instruction's 16-bit offset field reaches it -- left to the compiler, Li / Iv / Pcol landed above 64 KB and every
   // such address became a v_mov of a literal parked in an AGPR (hundreds of them in the kernel's prologue).
   typedef __attribute__((address_space(3))) double lds_f64;
-  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 2 * NB * LP];
+  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
   lds_f64* const lds = (lds_f64*)smem;
   lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
   lds_f64 (*const s_rinv)[16] = (lds_f64 (*)[16])(lds + 16 * NB);
-  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB + 4 * 16);
-  lds_f64* const Bm = lds + 16 * NB + 4 * 16 + 4 * 16 * 17;
+  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB + 4 * 16);                // inverses of the diagonal sub-blocks, TRANSPOSED: Iv[b][column][row]
+  lds_f64* const Id = lds + 16 * NB + 4 * 16 + 4 * 16 * 17;                            // 16x16 identity: the rows the idle lanes of a panel carry
+  lds_f64* const Bm = Id + 16 * 16;
   lds_f64* const Li = Bm + NB * LP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k0 = kb * NB;
@@ -795,26 +798,15 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       const bool in = r < kw;
       Bm[r * LP + c] = (in && c <= r) ? v[i].x : (r == c ? 1.0 : 0.0);          // rows / columns beyond the matrix: identity
       Bm[r * LP + c + 1] = (in && c + 1 <= r) ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
-      Li[r * LP + c] = 0.0;
-      Li[r * LP + c + 1] = 0.0;
     }
   }
+  Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
   __syncthreads();
   DVM_STAMP(1);
   const int lr = lane & 15, lq = lane >> 4;
-  __shared__ int s_flag[2];            // last panel: [0] Iv_2 is in LDS (wave 3), [1] L^-1 block (1, 0) is in LDS (wave 1)
-  if (tid < 2) s_flag[tid] = 0;        // (ordered before their first use by the barriers of the first three panels)
-  auto signal = [&](int f) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&s_flag[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  auto wait_for = [&](int f) {
-    for (int spins = 0; __hip_atomic_load(&s_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && spins < (1 << 16); spins++)
-      __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
-  // inverse of the 16x16 diagonal sub-block bb (needed by the L^-1 assembly at the end), one wave: column `lane` of the
-  // inverse by forward substitution, L_it straight from LDS (uniform address = broadcast read)
+  // inverse of the 16x16 diagonal sub-block bb by one wave: column `lane` of the inverse by forward substitution, L_it straight
+  // from LDS (uniform address = broadcast read).  Only sub-block 0 needs it (beside panel 1): the inverses of sub-blocks 1..3
+  // fall out of wave 0's own panel, see "identity rows" below.
   auto invert_block = [&](int bb) {
     const int ob = 16 * bb;
     double y[16];
@@ -832,60 +824,13 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const double v = (lane <= i) ? y[i] : 0.0;
-        Iv[bb][i][lane] = v;
+        Iv[bb][lane][i] = v;
         Li[(ob + i) * LP + ob + lane] = v;
       }
     }
   };
-  // The LAST diagonal sub-block is inverted WHILE wave 0 still factorises it: row i of the inverse needs L_it (t < i) and
-  // 1 / L_ii, which wave 0 publishes column by column (Pcol, s_rinv) anyway.  The slots are filled with a tag before the panel
-  // (kTag: a NaN payload no arithmetic produces) and the reader waits for the tag to go: wave 0's instruction stream is
-  // untouched (a select that put 1 / L_jj into Pcol[j][j] cost 300-700 cycles per panel).  Same operands in the same order
-  // as invert_block(3) after the panel: same bits.  (1.2 us of the kernel's tail were this inversion.)
-  constexpr unsigned long long kTag = 0x7FF8DEADBEEF0001ull;
-  auto invert_last_block_behind_panel = [&]() {
-    // Row i = (e_i - sum_{t<i} L_it y_t) / L_ii: the sum only needs columns < i, which the wait of row i - 1 has already seen
-    // (wave 0 stores Pcol[j][.] and then s_rinv[.][j], and a wave's LDS operations complete in order), so it is formed BEFORE
-    // waiting for column i; behind the wait there is one multiplication.  The store order is the compiler's (checked in the
-    // ISA): the newest word of every sum is compared with the tag, off the waiting path, and a hit marks the column failed
-    // instead of passing a tag on as data.
-    const int ob = 48;
-    double y[16];
-    bool late = false;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      double s0 = (lane == i) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-      for (int t = 0; t < i; t++) {
-        const double l = __hip_atomic_load(&Pcol[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (t == i - 1) late = late || (unsigned long long)__double_as_longlong(l) == kTag;
-        if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
-      }
-      const double sum = s0 + s1;
-      double ri = 0.0;
-      for (int spins = 0;; spins++) {
-        ri = __hip_atomic_load(&s_rinv[3][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((unsigned long long)__double_as_longlong(ri) != kTag) break;
-        if (spins > (1 << 14)) { late = true; break; }      // never hang: the column is flagged as failed instead
-        __builtin_amdgcn_s_sleep(1);
-      }
-      y[i] = sum * ri;
-      if (lane < 16) {
-        const double v = (lane <= i) ? y[i] : 0.0;
-        Iv[3][i][lane] = v;
-        Li[(ob + i) * LP + ob + lane] = v;
-      }
-    }
-    if (late && lane == 0) *fail = 1;
-  };
-  // finished block column bb of L (rows 16 bb .. 63) -> global, by two waves (128 threads)
-  auto store_panel = [&](int bb, int t, int nt) {
-    const int ob = 16 * bb;
-    for (int i = t; i < (NB - ob) * 16; i += nt) {
-      const int r = ob + (i >> 4), c = ob + (i & 15);
-      if (r < kw && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = Bm[r * LP + c];
-    }
-  };
+  // (The factor of the diagonal tile itself is NOT written back: nothing reads it -- the strips below are solved with L^-1, the
+  //  back substitution uses L^-1 and the strips.  S keeps the tile as the Schur complement left it.)
   // L^-1 block (i, j), i > j:  -Iv_i * sum_{k = j .. i - 1} L_ik Linv_kj  (blocks (k, j), k < i, must be in Li already), one wave;
   // the C/D register layout of the f64 MFMA is its B-operand layout for k-step = reg, so the running sum feeds the product
   // with Iv_i without touching LDS
@@ -894,21 +839,27 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
     for (int k = j; k < i; k++) {
 #pragma unroll
       for (int kk = 0; kk < 16; kk += 4)
-        t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(16 * i + lr) * LP + 16 * k + kk + lq], Li[(16 * k + kk + lq) * LP + 16 * j + lr], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(16 * i + lr) * LP + 16 * k + kk + lq],
+                                                 k == j ? Iv[j][lr][kk + lq] : Li[(16 * k + kk + lq) * LP + 16 * j + lr], t, 0, 0, 0);
     }
     return t;
   };
   auto linv_finish = [&](int i, int j, double4_t t) {
     double4_t r4 = {0, 0, 0, 0};
 #pragma unroll
-    for (int st = 0; st < 4; st++) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[i][lr][4 * st + lq], t[st], r4, 0, 0, 0);
+    for (int st = 0; st < 4; st++) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[i][4 * st + lq][lr], t[st], r4, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; r++) Li[(16 * i + lq + 4 * r) * LP + 16 * j + lr] = -r4[r];
   };
   auto linv_block = [&](int i, int j) { linv_finish(i, j, linv_sum(i, j)); };
+  // the inverse of diagonal sub-block bb, which wave 0's panel left in Iv, into its place in Li (for the final store), one wave
+  auto copy_inverse = [&](int bb) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) Li[(16 * bb + lq + 4 * q) * LP + 16 * bb + lr] = Iv[bb][lr][lq + 4 * q];
+  };
   // block row 3 of L^-1: the sums over block rows 0..2 are formed beside the last panel (waves 3 and 1), only the product with
   // Iv_3 -- four MFMAs -- is left for the tail
-  double4_t t3a = {0, 0, 0, 0}, t3b = {0, 0, 0, 0};
+  double4_t t3a = {0, 0, 0, 0};
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
     DVM_STAMP(2 + 3 * b);
@@ -926,42 +877,45 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       // 2.4 GHz: 7 400 with every L_cj by v_readlane, 5 850 as the rolled loop the compiler scheduled (366 / column),
       // 3 850-4 150 now (250 / column); chain alone (no updates, no LDS) 2 600.
       double a[16];
+      // IDENTITY ROWS: panels 1..3 have 16, 32, 48 lanes without a row.  Sixteen of them carry the rows of the identity: the
+      // panel turns a row a_i below the diagonal sub-block into a_i L^-T, so the row e_i comes out as row i of L^-T = column i of
+      // the sub-block's inverse -- by the very instructions that factorise the panel, none added: the lane's source and
+      // destination pointers differ, that is all.  (Before: a second wave inverted the sub-block from LDS, 2 800 cycles beside
+      // the next panel or, for the last one, 1 300 cycles behind this wave.)
+      const int idl = lane - nrows;                          // 0..15 in panels 1..3: this lane carries e_idl
+      const bool has_row = lane < nrows, is_id = b >= 1 && idl >= 0 && idl < 16;
+      const lds_f64* const src = has_row ? Bm + (o + lane) * LP + o : Id + 16 * (idl & 15);
 #pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = (lane < nrows && (lane >= 16 || c <= lane)) ? Bm[(o + lane) * LP + o + c] : 0.0;
+      for (int c = 0; c < 16; c++) a[c] = ((has_row || is_id) && (lane >= 16 || c <= lane)) ? src[c] : 0.0;
       bool bad = false;
       double d0 = bcast_lane(a[0], 0);          // pivot a_00, wave-uniform
 #include "chol_panel.inc"
-      if (lane < nrows) {
+      // rows of L back to Bm; identity lanes: Iv_b[column idl][row c] = (L^-1)_{c, idl} (exact zeros above the diagonal, c < idl)
+      lds_f64* const dst = has_row ? Bm + (o + lane) * LP + o : &Iv[b][idl & 15][0];
+      if (has_row || is_id) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) Bm[(o + lane) * LP + o + c] = (lane < 16 && c > lane) ? 0.0 : a[c];
+        for (int c = 0; c < 16; c++) dst[c] = (lane < 16 && c > lane) ? 0.0 : a[c];
       }
       if (bad && lane == 0) *fail = 1;
     } else if (b >= 1) {
-      // the other waves are idle during the panel: one inverts the previous diagonal sub-block, the others send the previous
-      // block column of L home -- and, during the last panel, one already assembles L^-1 block (1, 0), whose inputs (Iv_0,
-      // Iv_1, L_10) are final by then
-      if (wave == 3) {
-        invert_block(b - 1);
-        if (b == 3) { signal(0); wait_for(1); linv_block(2, 0); t3a = linv_sum(3, 0); }
-      } else if (b < 3) {
-        store_panel(b - 1, tid - 64, 128);
-      } else if (wave == 1) {
-        store_panel(2, tid - 64, 64);
-        linv_block(1, 0); signal(1);
-        wait_for(0); linv_block(2, 1); t3a = linv_sum(3, 1); t3b = linv_sum(3, 2);
+      // beside the panel, no flags (everything is ordered by the panels' barriers): panel 1 -- wave 3 inverts sub-block 0;
+      // panel 2 -- wave 1 assembles L^-1 block (1, 0); panel 3 -- block (2, 0), (2, 1) and the sums of block row 3, one per wave
+      if (b == 1) {
+        if (wave == 3) invert_block(0);
+      } else if (b == 2) {
+        if (wave == 1) linv_block(1, 0);
+        else if (wave == 2) copy_inverse(1);
       } else {
-       
-        invert_last_block_behind_panel();
+        if (wave == 3) { linv_block(2, 0); t3a = linv_sum(3, 0); }
+        else if (wave == 1) { linv_block(2, 1); t3a = linv_sum(3, 1); }
+        else { t3a = linv_sum(3, 2); copy_inverse(2); }
       }
     }
     DVM_STAMP(3 + 3 * b);
+    if (b == 3) { DVM_STAMPW(18, 1); DVM_STAMPW(19, 2); DVM_STAMPW(20, 3); }
     __syncthreads();
     DVM_STAMP(4 + 3 * b);
     if (b < 3) {
-      if (b == 2 && wave == 1) {   // panel 2's columns are dead: tag the slots the last panel publishes (one pair below: wave 0's)
-        for (int i = lane; i < 16 * 16; i += 64) Pcol[i >> 4][i & 15] = __longlong_as_double((long long)kTag);
-        if (lane < 16) s_rinv[3][lane] = __longlong_as_double((long long)kTag);
-      }
       // ---- C: trailing sub-blocks (i >= j > b), round-robin over the four waves
       int pair = 0;
       for (int i = b + 1; i < 4; i++)
@@ -980,9 +934,8 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   }
   // tail: only L^-1 block row 3 is left (Iv_3 and block rows 0..2 were finished beside the last panel)
   DVM_STAMP(14);
-  if (wave == 3) linv_finish(3, 0, t3a);
-  else if (wave == 1) { linv_finish(3, 1, t3a); linv_finish(3, 2, t3b); }
-  else if (wave == 0) store_panel(3, tid, 64);
+  if (wave >= 1) linv_finish(3, wave == 3 ? 0 : wave, t3a);
+  else copy_inverse(3);
   DVM_STAMP(15);
   __syncthreads();
   DVM_STAMP(16);
@@ -990,7 +943,9 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 #pragma unroll
   for (int k = 0; k < 8; k++) {            // 16-byte stores: a wave writes 1 KB per instruction
     const int r = 8 * k + (tid >> 5), c = 2 * (tid & 31);
-    *reinterpret_cast<double2*>(Lo + r * NB + c) = make_double2(Li[r * LP + c], Li[r * LP + c + 1]);
+    const bool lower = (c >> 4) <= (r >> 4);     // the 16x16 blocks above the diagonal were never written in LDS: zeros from here
+    const double2 v = lower ? make_double2(Li[r * LP + c], Li[r * LP + c + 1]) : make_double2(0.0, 0.0);
+    *reinterpret_cast<double2*>(Lo + r * NB + c) = v;
   }
   DVM_STAMP(17);
 }

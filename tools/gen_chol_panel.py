@@ -13,7 +13,7 @@ factorisation does not need:
     L^-1 assembly the entries below the diagonal); the diagonal slot keeps d * rsqrt(d), L_jj to an ulp or two;
   * no per-column positivity test: a pivot <= 0 turns 1 / L_jj into inf / NaN, which every later pivot inherits (each one
     subtracts the square of an entry scaled by it) -- the LAST column's 1 / L_jj is tested once;
-  * one multiplication less in the two Newton steps behind v_rsq_f64 (see column_block).
+  * 1 / sqrt(d) by v_rsq_f64 and one cubic correction instead of two Newton steps (see column_block).
 
 Pinning is done with empty `asm volatile` statements: the asm behind statement i names what statement i produced and an input
 of statement i + 2 as "+v" / "+s" operands (the value passes "through" the asm); volatile asms keep their order and the data
@@ -51,19 +51,16 @@ def S(v):
 
 def column_block(j, spread):
     """Statements of column j in issue order: the chain steps, fillers in the slots behind them."""
-    d, y, t, c, l, n, x = f"d{j}", f"y{j}", f"t{j}", f"c{j}", f"a[{j}]", f"n{j}", f"x{j}"   # l: the finished column lives on in a[j]
-    # 1 / sqrt(d): v_rsq_f64 (2^-24) and two Newton steps (1.24 ulp at most, tools/dev/rsq_acc.hip) in the form t = (-d/2) y,
-    # u = fma(t, y, 1/2), y += y u: the same bits as y += (y/2) fma(-d y, y, 1) (scaling by 1/2 commutes with rounding), one
-    # multiplication per column instead of two.  (One cubic step, y += y r (1/2 + 3/8 r), reaches the same 1.24 ulp two
-    # instructions sooner -- but with other roundings, and the 500-keyframe pose graph, conditioned 1e9, is decided by them.)
+    d, y, t, z, q, l, n, x = f"d{j}", f"y{j}", f"t{j}", f"z{j}", f"q{j}", f"a[{j}]", f"n{j}", f"x{j}"   # l: the finished column lives on in a[j]
+    # 1 / sqrt(d): v_rsq_f64 (2^-24) and ONE cubic step, y += y r (1/2 + 3/8 r), r = 1 - d y^2: 1.24 ulp at most, exactly what two
+    # Newton steps reach (tools/rsq_acc.hip, 4 M arguments over 26 decades), in five instructions four deep instead of
+    # seven six deep
     ch = [
         ("rsq", Stmt(f"double {y} = __builtin_amdgcn_rsq({d});", [V(y)], [V(d)])),
-        ("t", Stmt(f"double {t} = {c} * {y};", [V(t)], [V(y), V(c)])),
-        ("r", Stmt(f"{t} = __builtin_fma({t}, {y}, 0.5);", [V(t)], [V(t), V(y)])),
-        ("y1", Stmt(f"{y} = __builtin_fma({y}, {t}, {y});", [V(y)], [V(t), V(y)])),
-        ("t2", Stmt(f"{t} = {c} * {y};", [V(t)], [V(y), V(c)])),
-        ("r2", Stmt(f"{t} = __builtin_fma({t}, {y}, 0.5);", [V(t)], [V(t), V(y)])),
-        ("y", Stmt(f"{y} = __builtin_fma({y}, {t}, {y});", [V(y)], [V(t), V(y)])),
+        ("t", Stmt(f"double {t} = (-{d}) * {y};", [V(t)], [V(y), V(d)])),
+        ("r", Stmt(f"{t} = __builtin_fma({t}, {y}, 1.0);", [V(t)], [V(t), V(y)])),
+        ("z", Stmt(f"double {z} = {y} * {t};", [V(z)], [V(t), V(y)])),
+        ("y", Stmt(f"{y} = __builtin_fma({z}, {q}, {y});", [V(y)], [V(z), V(q), V(y)])),
         ("l", Stmt(f"{l} = {l} * {y};", [V(l)], [V(y), V(l)])),
     ]
     if j + 1 < N:
@@ -71,12 +68,12 @@ def column_block(j, spread):
         ch.append(("d", Stmt(f"double d{j + 1} = __builtin_fma(-{n}, {n}, {x});", [V(f"d{j + 1}")], [S(n), S(x)])))
     slots = {name: [] for name, _ in ch}
     last = ch[-1][0]
-    slots["rsq"].append(Stmt(f"double {c} = -0.5 * {d};", [V(c)], [V(d)]))
+    slots["z"].append(Stmt(f"double {q} = __builtin_fma(0.375, {t}, 0.5);", [V(q)], [V(t)]))
 
     # Deferred updates, a[c] -= L_.p * L_cp.  Column p's broadcasts are read from LDS behind its store (slot "n" of block p), so
-    # its updates start behind step "y1" of block p + 1 -- the next pivot column c = p + 2 first: its broadcast for the pivot is
+    # its updates start behind step "r" of block p + 1 -- the next pivot column c = p + 2 first: its broadcast for the pivot is
     # taken behind step "y" -- and run on through the first slots of block p + 2 (a[c], c >= p + 3, is not needed earlier, and
-    # the updates of one a[c] stay in column order: block p + 2 applies column p + 1 from slot "y1" on).  Where exactly a filler
+    # the updates of one a[c] stay in column order: block p + 2 applies column p + 1 from slot "r" on).  Where exactly a filler
     # sits matters little: this wave issues in order and nothing overlaps, a filler between two dependent chain steps saves the
     # ~3 cycles of the dependent issue (8.3 instead of 5.3), that is all.
     def upd(p, c):
@@ -84,13 +81,13 @@ def column_block(j, spread):
         return Stmt(f"a[{c}] = __builtin_fma(-a[{p}], {pv}, a[{c}]);", [V(f"a[{c}]")], [V(f"a[{c}]"), V(f"a[{p}]")])
 
     def placement(p):
-        one = [(p + 1, "y1"), (p + 1, "t2"), (p + 1, "r2"), (p + 1, "l"), (p + 2, "rsq"), (p + 2, "rsq"), (p + 2, "t"), (p + 2, "r")]
+        one = [(p + 1, "r"), (p + 1, "y"), (p + 1, "l"), (p + 1, "n"), (p + 2, "rsq"), (p + 2, "rsq"), (p + 2, "t")]
         pos = one + one[1:] + one[1:]
         out = []
         for i, c in enumerate(range(p + 2, N)):
             b_, s_ = pos[i]
             if b_ >= N:                       # no block p + 2 for the last columns: everything in block p + 1
-                b_, s_ = p + 1, ["y1", "t2", "r2", "l"][i % 4]
+                b_, s_ = p + 1, ["r", "y", "l", "n"][i % 4]
             out.append((b_, s_, c))
         return out
     for p in (j - 1, j - 2):
