@@ -859,6 +859,16 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   };
   // block row 3 of L^-1: the sums over block rows 0..2 are formed beside the last panel (waves 3 and 1), only the product with
   // Iv_3 -- four MFMAs -- is left for the tail
+  // trailing update of sub-block (i, j) with the columns of panel bs:  A_ij -= X_i X_j^T, one wave
+  auto trail = [&](int bs, int i, int j) {
+    const int oi = 16 * i, oj = 16 * j, os = 16 * bs;
+    double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + os + k + lq], Bm[(oj + lr) * LP + os + k + lq], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
+  };
   double4_t t3a = {0, 0, 0, 0};
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
@@ -898,13 +908,17 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       }
       if (bad && lane == 0) *fail = 1;
     } else if (b >= 1) {
-      // beside the panel, no flags (everything is ordered by the panels' barriers): panel 1 -- wave 3 inverts sub-block 0;
-      // panel 2 -- wave 1 assembles L^-1 block (1, 0); panel 3 -- block (2, 0), (2, 1) and the sums of block row 3, one per wave
+      // beside the panel, no flags (everything is ordered by the panels' barriers): first the trailing updates of the PREVIOUS
+      // panel that the current one does not need (sub-blocks right of its block column, see C below), then the pieces of L^-1
+      // whose inputs are final: panel 1 -- wave 3 inverts sub-block 0; panel 2 -- wave 1 assembles block (1, 0); panel 3 --
+      // blocks (2, 0), (2, 1) and the sums of block row 3, one per wave
       if (b == 1) {
+        if (wave == 1) trail(0, 2, 2); else if (wave == 2) trail(0, 3, 2); else trail(0, 3, 3);
         if (wave == 3) invert_block(0);
       } else if (b == 2) {
         if (wave == 1) linv_block(1, 0);
         else if (wave == 2) copy_inverse(1);
+        else trail(1, 3, 3);
       } else {
         if (wave == 3) { linv_block(2, 0); t3a = linv_sum(3, 0); }
         else if (wave == 1) { linv_block(2, 1); t3a = linv_sum(3, 1); }
@@ -916,19 +930,10 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
     __syncthreads();
     DVM_STAMP(4 + 3 * b);
     if (b < 3) {
-      // ---- C: trailing sub-blocks (i >= j > b), round-robin over the four waves
-      int pair = 0;
-      for (int i = b + 1; i < 4; i++)
-        for (int j = b + 1; j <= i; j++, pair++) {
-          if ((pair & 3) != wave) continue;
-          const int oi = 16 * i, oj = 16 * j;
-          double4_t acc = {0, 0, 0, 0};
-#pragma unroll
-          for (int k = 0; k < 16; k += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bm[(oi + lr) * LP + o + k + lq], Bm[(oj + lr) * LP + o + k + lq], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
-        }
+      // ---- C: trailing sub-blocks.  Only the next panel's block column (i, b + 1), i > b, is on the critical path: one wave
+      // each, one round; the sub-blocks right of it are updated beside the next panel (A above) -- same operands, same order per
+      // sub-block (panel b's contribution lands before panel b + 1's, a barrier in between), same bits.
+      if (wave >= 1 && b + wave < 4) trail(b, b + wave, b + 1);
       __syncthreads();
     }
   }
