@@ -35,9 +35,9 @@ def _prewarm(seconds: float):
         torch.cuda.synchronize()
 
 
-def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float = 0.0, repeats: int = 350):
+def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float = 0.0, repeats: int = 420):
     """The timed region is `repeats` optimisations of `iters` LM iterations each of the same problem (set_problem, i.e. the
-    reference's graph construction, outside it): 350 x 9 iterations = ~1 s of dvm_ba_optimize, long enough for clock sampling to
+    reference's graph construction, outside it): 420 x 9 iterations = ~1.06 s of dvm_ba_optimize, long enough for clock sampling to
     see it (each run is preceded by ~8 ms of set_problem on the host, during which the GPU idles)."""
     from dvm_slam_amd import capi, synth
     if prewarm_s > 0:
