@@ -1,6 +1,7 @@
 """Host-side logic of the product that can be checked without a GPU."""
 import os
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -28,3 +29,28 @@ def test_ba_ordering_and_level_schedule(tmp_path):
     out = subprocess.run([str(exe), "499", "7", "1"], capture_output=True, text=True)
     levels = int(out.stdout.split("levels=")[1].split()[0])
     assert levels <= 16, out.stdout   # 51 tile columns, one after the other, before the reordering
+
+
+def test_generated_cholesky_panel_is_in_sync(tmp_path):
+    """csrc/chol_panel.inc (the straight-line 16-column panel of k_chol_diag) is generated: the committed file must be what
+    tools/gen_chol_panel.py writes, and the stream must hold the whole factorisation -- 16 reciprocal square roots, the 15
+    immediate and 105 deferred rank-1 updates (a[c] -= L_.p L_cp for every p < c < 16), every column published once."""
+    import re
+    out = tmp_path / "panel.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_chol_panel.py"), "--out", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    assert text == open(os.path.join(ROOT, "dvm_slam_amd", "csrc", "chol_panel.inc")).read()
+    assert text.count("__builtin_amdgcn_rsq(") == 16
+    upd = re.findall(r"a\[(\d+)\] = __builtin_fma\(-a\[(\d+)\], (n\d+|p\d+_\d+(?:\.[xy])?), a\[\1\]\);", text)
+    assert len(upd) == 120 and sorted((int(c), int(p)) for c, p, _ in upd) == sorted((c, p) for c in range(16) for p in range(c))
+    for c, p, src in upd:                                   # the broadcast an update reads is the one of ITS column pair
+        if src.startswith("p"):
+            m = re.match(r"p(\d+)_(\d+)(?:\.([xy]))?", src)
+            assert int(m.group(1)) == int(p) and int(m.group(2)) + (1 if m.group(3) == "y" else 0) == int(c)
+        else:
+            assert src == f"n{p}" and int(c) == int(p) + 1
+    # per target column the updates appear in source-column order (the rolled loop's summation order)
+    for c in range(16):
+        ps = [int(p) for cc, p, _ in upd if int(cc) == c]
+        assert ps == sorted(ps)
+    assert len(re.findall(r"Pcol\[\d+\]\[lane\] = a\[\d+\];", text)) == 16 and len(re.findall(r"s_rinv\[b\]\[\d+\] = y\d+;", text)) == 16

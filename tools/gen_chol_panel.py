@@ -145,7 +145,12 @@ def emit(seq, lag=3):
 
 
 def main():
-    spread = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    out_path = OUT
+    argv = sys.argv[1:]
+    if "--out" in argv:                       # tests/test_host_logic.py regenerates into a temporary file and compares
+        out_path = argv[argv.index("--out") + 1]
+        del argv[argv.index("--out"):argv.index("--out") + 2]
+    spread = int(argv[0]) if argv else 2
     seq = []
     for j in range(N):
         seq.extend(column_block(j, spread))
@@ -158,9 +163,9 @@ def main():
     out += emit(seq, int(os.environ.get('PANEL_LAG', '4')))
     out.append(f"  bad = !(y{N - 1} > 0.0 && y{N - 1} < __builtin_inf());   // a pivot <= 0 anywhere in the panel ends here as inf / NaN")
     out.append("}")
-    with open(OUT, "w") as f:
+    with open(out_path, "w") as f:
         f.write("\n".join(out) + "\n")
-    print(f"{OUT}: {len(seq)} statements")
+    print(f"{out_path}: {len(seq)} statements")
 
 
 if __name__ == "__main__":
