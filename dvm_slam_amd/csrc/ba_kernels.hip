@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(256) k_chol_trsm_update(double* __restrict__ S
     const int c = c0 + (f >> 2), side = (f >> 1) & 1, half = f & 1;
     const int32_t* flag = flags + 4 * contrib_strip[2 * c + side] + ((side ? qj : qi) >> 4) + half;
     for (int spins = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen; spins++) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (spins > (1 << 18)) { *fail = 2; break; }          // never hang the device: give up, the trial is rejected
     }
   }
