@@ -775,7 +775,6 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
   lds_f64* const lds = (lds_f64*)smem;
   lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
-  lds_f64 (*const s_rinv)[16] = (lds_f64 (*)[16])(lds + 16 * NB);
   lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB + 4 * 16);                // inverses of the diagonal sub-blocks, TRANSPOSED: Iv[b][column][row]
   lds_f64* const Id = lds + 16 * NB + 4 * 16 + 4 * 16 * 17;                            // 16x16 identity: the rows the idle lanes of a panel carry
   lds_f64* const Bm = Id + 16 * 16;
@@ -809,6 +808,8 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   // fall out of wave 0's own panel, see "identity rows" below.
   auto invert_block = [&](int bb) {
     const int ob = 16 * bb;
+    // 1 / L_ii from the L_ii the panel left in the tile (d * rsqrt(d)): one division, lane i's, instead of a store per column there
+    const double rl = 1.0 / Bm[(ob + (lane & 15)) * LP + ob + (lane & 15)];
     double y[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -818,7 +819,7 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
         const double l = Bm[(ob + i) * LP + ob + t];
         if (t & 1) s1 = __builtin_fma(-l, y[t], s1); else s0 = __builtin_fma(-l, y[t], s0);
       }
-      y[i] = (s0 + s1) * s_rinv[bb][i];
+      y[i] = (s0 + s1) * bcast_lane(rl, i);
     }
     if (lane < 16) {
 #pragma unroll
@@ -913,8 +914,7 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
       // whose inputs are final: panel 1 -- wave 3 inverts sub-block 0; panel 2 -- wave 1 assembles block (1, 0); panel 3 --
       // blocks (2, 0), (2, 1) and the sums of block row 3, one per wave
       if (b == 1) {
-        if (wave == 1) trail(0, 2, 2); else if (wave == 2) trail(0, 3, 2); else trail(0, 3, 3);
-        if (wave == 3) invert_block(0);
+        if (wave == 1) trail(0, 2, 2); else if (wave == 2) { trail(0, 3, 2); trail(0, 3, 3); } else invert_block(0);
       } else if (b == 2) {
         if (wave == 1) linv_block(1, 0);
         else if (wave == 2) copy_inverse(1);

@@ -95,8 +95,8 @@ def test_essential_graph_500_keyframes_first_step(capi, oracle):
     from the second LM iteration on the trajectory is decided by that noise (measured: |dt| 0.15 after iteration 2, both sides
     equally far from the ground truth; the reference is in the same regime).  What IS comparable, and compared here with stated
     tolerances: the first LM iteration -- a 4.8-unit correction of the drifted estimates -- agrees to chi2 rel. 5e-6,
-    translations 1e-4 (2e-5 of the step), quaternions 5e-6, scales 1e-5; and the 20-iteration run ends several times closer to the
-    ground truth than it started, chi2 down by two orders of magnitude.  How far down is decided by rounding, on both sides
+    translations 1e-4 (2e-5 of the step), quaternions 5e-6, scales 1e-5; and the 20-iteration run brings chi2 down by two orders of
+    magnitude and, on the noisy graph, ends several times closer to the ground truth than it started.  How far down is decided by rounding, on both sides
     (tools/pg_noise.py, chi2_final / chi2_initial after 20 iterations): the ORACLE ends at 1.2e-3 on the noise-free graph and
     at 1.4e-4 .. 2.1e-4 on the noisy ones; the device anywhere in 7e-5 .. 9e-3, depending on which (equally accurate, 1.24 ulp)
     reciprocal square root and which summation order the tile Cholesky's inverse uses."""
@@ -116,5 +116,6 @@ def test_essential_graph_500_keyframes_first_step(capi, oracle):
         assert np.array_equal(Sg[0], pg["S0"][0])
         Sg, stg = capi.pose_graph_optimize(pg["S0"], pg["fixed"], pg["edges_v"], pg["edges_meas"], iterations=20)
         e0 = np.abs(pg["S0"][:, 4:7] - pg["S_gt"][:, 4:7]).max()
-        assert np.abs(Sg[:, 4:7] - pg["S_gt"][:, 4:7]).max() < 0.15 * e0      # noise-driven tail (docstring): a loose bound
+        if noise > 0:      # (the noise-free graph's optimum is a zero-residual valley: steps along its near-null directions do not show
+            assert np.abs(Sg[:, 4:7] - pg["S_gt"][:, 4:7]).max() < 0.15 * e0      # in chi2 -- the ORACLE ends 0.75 e0 from the ground truth there)
         assert stg["chi2_final"] < 2e-2 * stg["chi2_initial"]               # docstring: the oracle itself is at 1.2e-3 here

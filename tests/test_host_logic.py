@@ -53,4 +53,4 @@ def test_generated_cholesky_panel_is_in_sync(tmp_path):
     for c in range(16):
         ps = [int(p) for cc, p, _ in upd if int(cc) == c]
         assert ps == sorted(ps)
-    assert len(re.findall(r"Pcol\[\d+\]\[lane\] = a\[\d+\];", text)) == 16 and len(re.findall(r"s_rinv\[b\]\[\d+\] = y\d+;", text)) == 16
+    assert len(re.findall(r"Pcol\[\d+\]\[lane\] = a\[\d+\];", text)) == 16

@@ -63,6 +63,9 @@ def column_block(j, spread):
         ("y", Stmt(f"{y} = __builtin_fma({z}, {q}, {y});", [V(y)], [V(z), V(q), V(y)])),
         ("l", Stmt(f"{l} = {l} * {y};", [V(l)], [V(y), V(l)])),
     ]
+    # (the next pivot from its PRE-update value, broadcast off the chain, and the square of l_{j+1,j}: broadcasting the updated
+    #  a[j+1] instead saves two instructions per column but puts a second cross-lane hop on the chain -- 100-200 cycles per
+    #  panel slower)
     if j + 1 < N:
         ch.append(("n", Stmt(f"double {n} = bcast_lane({l}, {j + 1});", [S(n)], [V(l)])))
         ch.append(("d", Stmt(f"double d{j + 1} = __builtin_fma(-{n}, {n}, {x});", [V(f"d{j + 1}")], [S(n), S(x)])))
@@ -99,14 +102,12 @@ def column_block(j, spread):
     # the next pivot's pre-update value, broadcast off the chain
     if j + 1 < N:
         slots["y"].append(Stmt(f"double {x} = bcast_lane(a[{j + 1}], {j + 1});", [S(x)], [V(f"a[{j + 1}]")]))
-    # behind the broadcast of l_{j+1,j}: publish the column -- L_.j, then 1 / L_jj: the wave that inverts the last diagonal
-    # sub-block behind this one relies on that order (a wave's LDS operations complete in order) --, fetch its broadcasts for the
-    # next blocks' updates, then the immediate update of the next pivot column
+    # behind the broadcast of l_{j+1,j}: publish the column, fetch its broadcasts for the next blocks' updates, then the
+    # immediate update of the next pivot column.  (1 / L_jj is not published: the one consumer left, the inversion of sub-block 0
+    # beside panel 1, divides by the L_jj it finds in the tile -- sixteen divisions on an idle wave against a store per column
+    # here.)
     pub = "n" if j + 1 < N else last
     slots[pub].append(Stmt(f"Pcol[{j}][lane] = {l};", [], [V(l)]))
-    slots[pub].append(Stmt('asm volatile("" ::: "memory");'))
-    # (every lane, same address, same value: one ds_write; a lane-0 store costs 30 cycles of exec-mask round trip)
-    slots[pub].append(Stmt(f"s_rinv[b][{j}] = {y};", [], [V(y)]))
     # (the first broadcast alone when it would be the upper half of a pair: a pair whose lower half is dead invites the register
     #  allocator to reuse that half while the read is in flight, and the chain then waits for the LDS)
     if (j + 2) & 1 and j + 2 < N:
@@ -156,8 +157,8 @@ def main():
         seq.extend(column_block(j, spread))
     out = [
         "// GENERATED by tools/gen_chol_panel.py -- do not edit; the generator's header explains the schedule.",
-        "// In: double a[16] (the panel row of this lane), d0 (pivot a_00, wave-uniform), lane, b, Pcol, s_rinv.",
-        "// Out: a[] = the row of L (diagonal slot: d * rsqrt(d)), Pcol / s_rinv published column by column, bad.",
+        "// In: double a[16] (the panel row of this lane), d0 (pivot a_00, wave-uniform), lane, Pcol.",
+        "// Out: a[] = the row of L (diagonal slot: d * rsqrt(d)), Pcol published column by column, bad.",
         "{",
     ]
     out += emit(seq, int(os.environ.get('PANEL_LAG', '4')))
