@@ -795,8 +795,10 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
     for (int i = 0; i < 8; i++) {
       const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
       const bool in = r < kw;
-      Bm[r * LP + c] = (in && c <= r) ? v[i].x : (r == c ? 1.0 : 0.0);          // rows / columns beyond the matrix: identity
-      Bm[r * LP + c + 1] = (in && c + 1 <= r) ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
+      // rows beyond the matrix: identity.  (What lands ABOVE the diagonal is never read: the panel masks the upper triangle of
+      // its diagonal sub-block, everything else works on blocks at or below the diagonal.)
+      Bm[r * LP + c] = in ? v[i].x : (r == c ? 1.0 : 0.0);
+      Bm[r * LP + c + 1] = in ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
     }
   }
   Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
