@@ -42,6 +42,7 @@ struct BaView {
   const int32_t *blk_i1, *blk_i2, *blk_start;  // non-zero lower blocks of the reduced camera matrix
   const int32_t *pair_k1, *pair_k2;            // per block: (edge of i1, edge of i2) sharing a landmark
   const int32_t* pair_pt;    // [npairs] landmark of the pair (= e_point[pair_k1]): spares the gather kernel a dependent load
+  int32_t schur_wide;        // 1: few blocks with long pair lists (a local-BA window) -- k_schur with 8 waves per block instead of 2
   double* S;                // [ldS][ldS] dense lower triangle + augmented rhs row
   double* Linv;             // [ldS/64][64*64] inverses of the factored diagonal blocks
   double* ytmp;             // [n_pad + 64] doubles, used as int32 words: [0] ticket, [1 + k] hand-off flag of tile column k

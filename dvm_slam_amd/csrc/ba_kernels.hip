@@ -417,9 +417,12 @@ __device__ __forceinline__ double point_accum_body(const BaView& V, int block, c
 
 // Hpp (6x6) and bp per free camera: one wave per camera, lanes stride over the camera's edges, then a
 // fixed-order xor-butterfly reduction (identical on every run).
+// SPLIT (BaView::schur_wide, a local-BA window: a few cameras with hundreds of edges each on an otherwise empty chip): ONE
+// camera per workgroup, its edges dealt over the four waves, the waves' sums added in wave order.
+template <bool SPLIT>
 __device__ __forceinline__ double pose_accum_body(const BaView& V, int block) {   // returns this thread's |Hpp diagonal entry| (or 0)
-  const int lane = threadIdx.x & 63;
-  const int fi = block * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = SPLIT ? block : block * 4 + wave;
   if (fi >= V.nfree) return 0.0;
   const int p = V.free_pose[fi];
   double H[21], b[6];
@@ -430,10 +433,11 @@ __device__ __forceinline__ double pose_accum_body(const BaView& V, int block) { 
   // four edges per lane in flight: index -> row is a dependent pair of global round trips, and a camera of the BASELINE problem
   // gives a lane five edges -- one after the other that was ten round trips (the kernel's whole 15 us); same summation order
   const int e_end = V.ps_start[p + 1];
-  for (int i0 = V.ps_start[p] + lane; i0 < e_end; i0 += 4 * 64) {
+  const int step = SPLIT ? 256 : 64;
+  for (int i0 = V.ps_start[p] + lane + (SPLIT ? 64 * wave : 0); i0 < e_end; i0 += 4 * step) {
     int k[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) k[u] = (i0 + 64 * u < e_end) ? V.ps_edges[i0 + 64 * u] : -1;
+    for (int u = 0; u < 4; u++) k[u] = (i0 + step * u < e_end) ? V.ps_edges[i0 + step * u] : -1;
     double Bv[4][12], wv[4][3];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -463,7 +467,14 @@ __device__ __forceinline__ double pose_accum_body(const BaView& V, int block) { 
   for (int i = 0; i < 21; i++) v27[i] = H[i];
 #pragma unroll
   for (int i = 0; i < 6; i++) v27[21 + i] = b[i];
-  const double tot = wave_sum_lds<27>(v27, s_park[threadIdx.x >> 6]);
+  double tot = wave_sum_lds<27>(v27, s_park[wave]);
+  if (SPLIT) {
+    __shared__ double s_w[4][27];
+    if (lane < 27) s_w[wave][lane] = tot;
+    __syncthreads();
+    if (wave != 0) return 0.0;
+    if (lane < 27) tot = ((s_w[0][lane] + s_w[1][lane]) + s_w[2][lane]) + s_w[3][lane];
+  }
   if (lane < 21) {
     const int a = lane >= 15 ? 5 : lane >= 10 ? 4 : lane >= 6 ? 3 : lane >= 3 ? 2 : lane >= 1 ? 1 : 0;
     const int c = lane - a * (a + 1) / 2;
@@ -501,7 +512,7 @@ __device__ __forceinline__ void clear_tile(const BaView& V, int t) {
 __global__ void __launch_bounds__(256) k_accum(BaView V, int nb_pose, int nb_point, const double* __restrict__ spec, BaPublish pub, int with_max) {
   if (spec && *spec == -2.0) return;   // the device-side decision: accepted, and the optimisation ends with it -- nobody reads this linearisation
   double m;
-  if ((int)blockIdx.x < nb_pose) m = pose_accum_body(V, blockIdx.x);
+  if ((int)blockIdx.x < nb_pose) m = V.schur_wide ? pose_accum_body<true>(V, blockIdx.x) : pose_accum_body<false>(V, blockIdx.x);
   else if ((int)blockIdx.x < nb_pose + nb_point) m = point_accum_body(V, blockIdx.x - nb_pose, spec);
   else { clear_tile(V, blockIdx.x - nb_pose - nb_point); return; }
   if (with_max) block_reduce_publish<true>(m, V.partial2, pub, nb_pose + nb_point);
@@ -649,24 +660,63 @@ __device__ __forceinline__ void schur_blocks_body(const BaView& V, int block) {
 }
 
 // bschur[i] = bp[i] - sum_{edges k of camera i} W_k (Dinv bl)_{point(k)}  -> augmented row n of S.
-template <int NW>
+// SPLIT = false: one wave per camera (NW cameras per workgroup) -- the global problem has hundreds of cameras, and the rhs hides
+// under the block workgroups.  SPLIT = true (BaView::schur_wide, a local-BA window): ONE camera per workgroup, its edges dealt
+// over the NW waves (wave w takes edges w*64 + lane, then + 64 NW, ...): twenty cameras of 500 edges each were twenty waves
+// walking three dependent global round trips per 256 edges, 27 us -- longer than the blocks.  Fixed summation order either way:
+// per lane in edge order, xor butterfly over the lanes, then (SPLIT) the waves in order.
+template <int NW, bool SPLIT>
 __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
-  const int lane = threadIdx.x & 63;
-  const int fi = block * NW + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = SPLIT ? block : block * NW + wave;
   if (fi >= V.nfree) return;
   const int p = V.free_pose[fi];
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = V.ps_start[p] + lane; i < V.ps_start[p + 1]; i += 64) {
-    const int k = V.ps_edges[i];
-    const double* W = V.e_W + (size_t)k * 18;
-    const double* db = V.db + 3 * (size_t)V.e_point[k];
+  // four edges per lane in flight: edge index -> (W row, landmark index -> Dinv bl) is a chain of three global round trips; same
+  // summation order as one after the other
+  const int e_end = V.ps_start[p + 1];
+  const int first = V.ps_start[p] + lane + (SPLIT ? 64 * wave : 0), step = SPLIT ? 64 * NW : 64;
+  for (int i0 = first; i0 < e_end; i0 += 4 * step) {
+    int k[4], pt[4];
 #pragma unroll
-    for (int a = 0; a < 6; a++) acc[a] += W[3 * a] * db[0] + W[3 * a + 1] * db[1] + W[3 * a + 2] * db[2];
+    for (int u = 0; u < 4; u++) k[u] = (i0 + step * u < e_end) ? V.ps_edges[i0 + step * u] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; u++) pt[u] = V.e_point[max(k[u], 0)];
+    double Wv[4][18], dv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const double* W = V.e_W + (size_t)max(k[u], 0) * 18;
+      const double* db = V.db + 3 * (size_t)pt[u];
+#pragma unroll
+      for (int j = 0; j < 18; j++) Wv[u][j] = W[j];
+      dv[u][0] = db[0]; dv[u][1] = db[1]; dv[u][2] = db[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k[u] < 0) continue;
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[a] += Wv[u][3 * a] * dv[u][0] + Wv[u][3 * a + 1] * dv[u][1] + Wv[u][3 * a + 2] * dv[u][2];
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
     for (int a = 0; a < 6; a++) acc[a] += __shfl_xor(acc[a], off);
+  if (SPLIT) {
+    __shared__ double s_w[NW][6];
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) s_w[wave][a] = acc[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double t = 0;
+      for (int w = 0; w < NW; w++) t += s_w[w][threadIdx.x];
+      V.S[(size_t)V.n_pad * V.ldS + ba_row(fi) + threadIdx.x] = V.bp[6 * (size_t)fi + threadIdx.x] - t;
+    }
+    if (fi == 0 && threadIdx.x == 0) V.S[(size_t)V.n_pad * V.ldS + V.n_pad] = 1e200 * V.damp_s;  // augmented corner: keeps the last pivot positive
+    return;
+  }
   if (lane == 0) {
     for (int a = 0; a < 6; a++) V.S[(size_t)V.n_pad * V.ldS + ba_row(fi) + a] = V.bp[6 * (size_t)fi + a] - acc[a];
     if (fi == 0) V.S[(size_t)V.n_pad * V.ldS + V.n_pad] = 1e200 * V.damp_s;  // augmented corner: keeps the last pivot positive
@@ -675,8 +725,14 @@ __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
 
 // The reduced system and its right-hand side in ONE launch (independent of each other; both only need Dinv / db of the
 // prologue): workgroups [0, nb_blk) build the 6x6 blocks, the rest the rhs row.
-constexpr int kSchurWaves = 2;   // one wave per workgroup: 12 KB of LDS each, every block resident at once, no lock-step between blocks
-__global__ void __launch_bounds__(64 * kSchurWaves) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs, int* __restrict__ fail_reset) {
+// Waves per block: 2 for the global problem (thousands of blocks of ~180 pairs: 12 KB of LDS per wave, every block resident at
+// once), 8 for a local-BA window (BaView::schur_wide: ~100 blocks of ~500 pairs -- with two waves a block was eight dependent
+// stages of gathers per wave on a chip that is otherwise empty: 28 us for 45 000 pairs).  The stages of a block are dealt
+// round-robin over its waves and the waves' partial sums are added in wave order: deterministic for either width.
+constexpr int kSchurWaves = 2, kSchurWavesWide = 8;
+template <int kNW>
+__global__ void __launch_bounds__(64 * kNW) k_schur(BaView V, int nb_blk, int nb_chunk, int nb_rhs, int* __restrict__ fail_reset) {
+  constexpr int kSchurWaves = kNW;
   // speculative launch (ba_launch_schur_speculative): the damping comes from the device-side decision; a negative value = the
   // trial before this one was rejected, the host will start the next one itself.  There is no prologue launch in front of a
   // speculative one: the Cholesky failure flag is reset here.
@@ -686,7 +742,7 @@ __global__ void __launch_bounds__(64 * kSchurWaves) k_schur(BaView V, int nb_blk
   }
   // The rhs workgroups come FIRST: a camera's rhs is one wave walking ~320 edges (17 us on its own); dispatched behind
   // thousands of block workgroups it would start late and set the kernel's tail.
-  if ((int)blockIdx.x < nb_rhs) { schur_rhs_body<kSchurWaves>(V, blockIdx.x); return; }
+  if ((int)blockIdx.x < nb_rhs) { schur_rhs_body<kSchurWaves, kNW == kSchurWavesWide>(V, blockIdx.x); return; }
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MB L2.  Workgroup b takes block
   // group (b % 8) * nb_chunk + b / 8, so an XCD works through a CONTIGUOUS run of the (camera-sorted) block list: the W rows
   // of its ~60 cameras (46 KB each) stay in that L2.
@@ -772,11 +828,11 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   // where a ds instruction's 16-bit offset field reaches it -- left to the compiler, Li / Iv / Pcol landed above 64 KB and every
   // such address became a v_mov of a literal parked in an AGPR (hundreds of them in the kernel's prologue).
   typedef __attribute__((address_space(3))) double lds_f64;
-  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
+  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
   lds_f64* const lds = (lds_f64*)smem;
   lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
-  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB + 4 * 16);                // inverses of the diagonal sub-blocks, TRANSPOSED: Iv[b][column][row]
-  lds_f64* const Id = lds + 16 * NB + 4 * 16 + 4 * 16 * 17;                            // 16x16 identity: the rows the idle lanes of a panel carry
+  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);                // inverses of the diagonal sub-blocks, TRANSPOSED: Iv[b][column][row]
+  lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;                            // 16x16 identity: the rows the idle lanes of a panel carry
   lds_f64* const Bm = Id + 16 * 16;
   lds_f64* const Li = Bm + NB * LP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2365,7 +2421,7 @@ void ba_launch_edge_eval(hipStream_t s, const BaView& V, bool jac, const BaPubli
   else hipLaunchKernelGGL(k_edge_eval<false>, dim3(nb), dim3(256), 0, s, V, pub);
 }
 void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec, const BaPublish* max_pub) {
-  const int nb_pose = V.nfree > 0 ? cdiv(V.nfree, 4) : 0;
+  const int nb_pose = V.nfree > 0 ? (V.schur_wide ? V.nfree : cdiv(V.nfree, 4)) : 0;   // (wide: a workgroup per camera)
   const int nb_point = cdiv(V.L, 256);
   BaPublish none;
   std::memset(&none, 0, sizeof(none));
@@ -2375,19 +2431,22 @@ void ba_launch_accum(hipStream_t s, const BaView& V, const double* spec, const B
 void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);
 }
+static void launch_schur_kernel(hipStream_t s, const BaView& V, int* fail_reset) {
+  const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
+  const int nw = V.schur_wide ? kSchurWavesWide : kSchurWaves;
+  const int nb_rhs = ((V.schur_wide ? V.nfree : cdiv(V.nfree, nw)) + 7) & ~7;   // (wide: a workgroup per camera) a multiple of 8 keeps the XCD phase of the block workgroups
+  if (V.schur_wide) hipLaunchKernelGGL(k_schur<kSchurWavesWide>, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWavesWide), 0, s, V, nb_blk, nb_chunk, nb_rhs, fail_reset);
+  else hipLaunchKernelGGL(k_schur<kSchurWaves>, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, fail_reset);
+}
 void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_dinv = cdiv(V.L, 256);
   hipLaunchKernelGGL(k_trial_prologue, dim3(nb_dinv), dim3(256), 0, s, V, d_fail);
   if (V.nfree == 0) return;
-  const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
-  const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;   // a multiple of 8 keeps the XCD phase of the block workgroups
-  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, (int*)nullptr);
+  launch_schur_kernel(s, V, nullptr);
 }
 void ba_launch_schur_speculative(hipStream_t s, const BaView& V, int* d_fail) {
   if (V.nfree == 0 || !V.lambda) return;
-  const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);
-  const int nb_rhs = (cdiv(V.nfree, kSchurWaves) + 7) & ~7;
-  hipLaunchKernelGGL(k_schur, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, d_fail);
+  launch_schur_kernel(s, V, d_fail);
 }
 __global__ void __launch_bounds__(256) k_clear_tiles(BaView V) { clear_tile(V, blockIdx.x); }
 void ba_launch_clear_tiles(hipStream_t s, const BaView& V) {

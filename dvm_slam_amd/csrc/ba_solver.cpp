@@ -374,6 +374,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.ps_start, ps_start)); ok(h->upload(&V.ps_edges, ps_edges));
   ok(h->upload(&V.blk_i1, blk_i1)); ok(h->upload(&V.blk_i2, blk_i2)); ok(h->upload(&V.blk_start, blk_start));
   ok(h->upload(&V.pair_k1, pair_k1)); ok(h->upload(&V.pair_k2, pair_k2));
+  V.schur_wide = (V.nblk > 0 && V.nblk <= 512 && pair_k1.size() / (size_t)V.nblk >= 192) ? 1 : 0;   // few blocks, long pair lists: see k_schur
   {
     std::vector<int32_t> pair_pt(pair_k1.size());
     for (size_t t = 0; t < pair_k1.size(); t++) pair_pt[t] = e_point[pair_k1[t]];
