@@ -50,6 +50,31 @@ def test_ba_matches_oracle(capi, oracle, n_kf, n_pts, delta, iters):
     assert depth.all()
 
 
+def test_ba_local_window_wide_kernels(capi, oracle):
+    """A local-BA window as LocalMapping builds it -- few cameras, hundreds of observations each, a third of them fixed -- takes the
+    "wide" forms of k_schur / k_accum (BaView::schur_wide: one workgroup per camera, eight waves per 6x6 block): same LM
+    sequence and optimum as the oracle, and bit-identical from run to run (fixed summation order)."""
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=30, n_pts=3000, k_obs=5, seed=0x1BA, radius=12.0)
+    pr["fixed"][:10] = 1
+    delta = np.sqrt(5.991)
+    # the rule of dvm_ba_set_problem: <= 512 non-zero blocks with >= 192 (edge, edge) pairs each on average
+    free_obs = np.bincount(pr["edge_point"][pr["fixed"][pr["edge_pose"]] == 0], minlength=len(pr["points"]))
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"]),
+                   pr["intrinsics"], delta)
+    nblk = ba.schedule_info()["nz_blocks"]
+    ba.close()
+    assert nblk <= 512 and int((free_obs * (free_obs + 1) // 2).sum()) // nblk >= 192
+    (po_, pto, so, chio), (pg, ptg, sg, chig, depth) = _run_both(capi, oracle, pr, delta, 10)
+    assert sg["trials"] == so["trials"] and sg["iterations"] == so["iterations"]
+    assert np.allclose(sg["chi2"], so["chi2"], rtol=1e-9)
+    assert np.abs(pg - po_).max() < POSE_TOL and np.abs(ptg - pto).max() < POSE_TOL
+    assert np.array_equal(pg[:10], po_[:10])
+    (_, _, _, _), (pg2, ptg2, sg2, _, _) = _run_both(capi, oracle, pr, delta, 10)
+    assert np.array_equal(pg, pg2) and np.array_equal(ptg, ptg2) and sg2["chi2"] == sg["chi2"]
+
+
 def test_ba_fixed_cameras_and_unobserved(capi, oracle):
     """LBA shape: several fixed cameras observing the window's landmarks, a camera and a landmark without edges."""
     from dvm_slam_amd import synth
