@@ -916,8 +916,6 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 #pragma unroll
     for (int q = 0; q < 4; q++) Li[(16 * bb + lq + 4 * q) * LP + 16 * bb + lr] = Iv[bb][lr][lq + 4 * q];
   };
-  // block row 3 of L^-1: the sums over block rows 0..2 are formed beside the last panel (waves 3 and 1), only the product with
-  // Iv_3 -- four MFMAs -- is left for the tail
   // trailing update of sub-block (i, j) with the columns of panel bs:  A_ij -= X_i X_j^T, one wave
   auto trail = [&](int bs, int i, int j) {
     const int oi = 16 * i, oj = 16 * j, os = 16 * bs;
@@ -928,6 +926,8 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 #pragma unroll
     for (int r = 0; r < 4; r++) Bm[(oi + lq + 4 * r) * LP + oj + lr] -= acc[r];
   };
+  // block row 3 of L^-1: its three sums are formed beside the last panel (one per wave 1..3), only the product with Iv_3 -- four
+  // MFMAs -- is left for the tail
   double4_t t3a = {0, 0, 0, 0};
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
