@@ -1152,6 +1152,18 @@ class HostKeyFrameDatabase:
             check(r)
         return r, best.value, sc.value, base.value
 
+    def detect_reloc(self, ids, vals, frame_id, map_id, cap=4096):
+        """DetectRelocalizationCandidates(F, pMap): candidate slots in the reference's order."""
+        i, v = self._bow(ids, vals)
+        out = np.zeros(cap, np.int32); n = C.c_int32(0)
+        self._f("detect_reloc", C.c_int32)(self.h, _p(i), _p(v), C.c_int32(len(i)), C.c_uint64(frame_id), C.c_int32(map_id), _p(out), C.byref(n))
+        return out[:n.value].copy()
+
+    def reloc_state(self, slot):
+        q = C.c_uint64(0); w = C.c_int32(0); sc = C.c_float(0)
+        self._f("get_reloc_state")(self.h, C.c_int32(slot), C.byref(q), C.byref(w), C.byref(sc))
+        return q.value, w.value, sc.value
+
     def detect_n_best(self, slot, n_num):
         lo = np.zeros(max(n_num, 1), np.int32); me = np.zeros(max(n_num, 1), np.int32)
         nl = C.c_int32(0); nm = C.c_int32(0)

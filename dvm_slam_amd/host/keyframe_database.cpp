@@ -164,6 +164,55 @@ int KeyFrameDatabase::DetectNBestCandidates(int slot, std::vector<int32_t>& vpLo
   return DVM_OK;
 }
 
+// KeyFrameDatabase.cc:810-909.  The walk of the inverted file meets a keyframe once per shared word: the first touch of a
+// keyframe whose mnRelocQuery is not this frame's id resets its counter and enters it into the list, every touch increments --
+// so a keyframe that already carries the id (the same frame asked twice; id 0 against the reset value 0) keeps counting and
+// is NOT listed, exactly as in the reference.  No map / bad filter until the very end.
+int KeyFrameDatabase::DetectRelocalizationCandidates(const BowVector& bowVector, uint64_t frameId, int32_t map_id,
+                                                     std::vector<int32_t>& vpRelocCandidates) {
+  vpRelocCandidates.clear();
+  Lock l(mMutex_);
+  const int rc = query_device(bowVector);
+  if (rc != DVM_OK) return rc;
+  std::vector<int32_t> lKFsSharingWords;
+  for (int32_t s : walk_order()) {
+    KF& k = kfs_[s];
+    if (k.reloc_query != frameId) { k.reloc_words = 0; k.reloc_query = frameId; lKFsSharingWords.push_back(s); }
+    k.reloc_words += common_[s];
+  }
+  if (lKFsSharingWords.empty()) return DVM_OK;
+  int maxCommonWords = 0;
+  for (int32_t s : lKFsSharingWords) maxCommonWords = std::max(maxCommonWords, kfs_[s].reloc_words);
+  const int minCommonWords = maxCommonWords * 0.8f;
+  std::vector<std::pair<float, int32_t>> lScoreAndMatch;
+  for (int32_t s : lKFsSharingWords)
+    if (kfs_[s].reloc_words > minCommonWords) { kfs_[s].reloc_score = score_[s]; lScoreAndMatch.push_back({score_[s], s}); }
+  if (lScoreAndMatch.empty()) return DVM_OK;
+  std::vector<std::pair<float, int32_t>> lAccScoreAndMatch;
+  float bestAccScore = 0;
+  for (const auto& sm : lScoreAndMatch) {
+    float bestScore = sm.first, accScore = bestScore;
+    int32_t pBestKF = sm.second;
+    for (int32_t s2 : kfs_[sm.second].neigh) {
+      const KF& k2 = kfs_[s2];
+      if (k2.reloc_query != frameId) continue;
+      accScore += k2.reloc_score;
+      if (k2.reloc_score > bestScore) { pBestKF = s2; bestScore = k2.reloc_score; }
+    }
+    lAccScoreAndMatch.push_back({accScore, pBestKF});
+    if (accScore > bestAccScore) bestAccScore = accScore;
+  }
+  const float minScoreToRetain = 0.75f * bestAccScore;
+  std::set<int32_t> spAlreadyAddedKF;
+  for (const auto& am : lAccScoreAndMatch) {
+    if (!(am.first > minScoreToRetain)) continue;
+    const int32_t s = am.second;
+    if (kfs_[s].map_id != map_id) continue;
+    if (!spAlreadyAddedKF.count(s)) { vpRelocCandidates.push_back(s); spAlreadyAddedKF.insert(s); }
+  }
+  return DVM_OK;
+}
+
 }  // namespace dvm_host
 
 // ---- C entry points for the Python harness
@@ -203,6 +252,18 @@ int dvmh_kfdb_merge_score(dvmh_kfdb* db, const int32_t* qids, const double* qval
 int dvmh_kfdb_detect_merge_possibility(dvmh_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
                                        int32_t* bestKeyFrame, float* score, float* baseline) {
   return db->DetectMergePossibility(to_bow(qids, qvals, nq), uuid, map_id, *bestKeyFrame, score, baseline);
+}
+int dvmh_kfdb_detect_reloc(dvmh_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t frame_id, int32_t map_id,
+                           int32_t* out, int32_t* n_out) {
+  std::vector<int32_t> c;
+  const int rc = db->DetectRelocalizationCandidates(to_bow(qids, qvals, nq), frame_id, map_id, c);
+  *n_out = (int32_t)c.size();
+  std::copy(c.begin(), c.end(), out);
+  return rc;
+}
+void dvmh_kfdb_get_reloc_state(dvmh_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score) {
+  const KeyFrameDatabase::State s = db->GetRelocState(slot);
+  *query = s.query; *words = s.words; *score = s.score;
 }
 int dvmh_kfdb_detect_n_best(dvmh_kfdb* db, int slot, int nNum, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge) {
   std::vector<int32_t> l, m;

@@ -1,6 +1,7 @@
 // dvm_slam_amd/host/keyframe_database.h -- host-side mirror of ORB_SLAM3::KeyFrameDatabase's place-recognition queries
 // as DVM-SLAM uses them to decide map merges (reference src/KeyFrameDatabase.cc:43-70 add / erase, :555-669
-// DetectNBestCandidates, :688-786 CalculateMergeScore, :789-808 DetectMergePossibility).
+// DetectNBestCandidates, :688-786 CalculateMergeScore, :789-808 DetectMergePossibility) and for relocalisation (:810-909
+// DetectRelocalizationCandidates).
 //
 // Keyframes are slots (the index add() returns) with the few attributes the queries read: BowVector, map, uuid, mnId, isBad,
 // GetBestCovisibilityKeyFrames(10), GetConnectedKeyFrames().  The per-keyframe word intersection and the L1 scores of ALL
@@ -49,7 +50,11 @@ class KeyFrameDatabase {
   // void DetectNBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand, int nNumCandidates)
   int DetectNBestCandidates(int slot, std::vector<int32_t>& vpLoopCand, std::vector<int32_t>& vpMergeCand, int nNumCandidates);
 
+  // vector<KeyFrame*> DetectRelocalizationCandidates(Frame* F, Map* pMap): the frame is (mBowVec, mnId)
+  int DetectRelocalizationCandidates(const BowVector& bowVector, uint64_t frameId, int32_t map_id, std::vector<int32_t>& vpRelocCandidates);
+
   struct State { uint64_t query; int32_t words; float score; };
+  State GetRelocState(int slot) const { Lock l(mMutex_); return {kfs_[slot].reloc_query, kfs_[slot].reloc_words, kfs_[slot].reloc_score}; }
   State GetState(int slot) const { Lock l(mMutex_); return {kfs_[slot].query, kfs_[slot].words, kfs_[slot].score}; }
 
  private:
@@ -67,6 +72,9 @@ class KeyFrameDatabase {
     uint64_t query = 0;
     int words = 0;
     float score = 0;
+    uint64_t reloc_query = 0;         // mnRelocQuery / mnRelocWords / mRelocScore: a state of their own (KeyFrame.h)
+    int reloc_words = 0;
+    float reloc_score = 0;
   };
   int query_device(const BowVector& bow);   // fills common_ / first_ / score_
   std::vector<int32_t> walk_order() const;   // slots sharing a word, in inverted-file walk order

@@ -134,7 +134,13 @@ int dvmh_kfdb_merge_score(dvmh_kfdb* db, const int32_t* qids, const double* qval
                           int32_t* bestKeyFrame);                                           /* CalculateMergeScore, :688-786 */
 int dvmh_kfdb_detect_merge_possibility(dvmh_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
                                        int32_t* bestKeyFrame, float* score, float* baseline); /* DetectMergePossibility, :789-808 */
-int dvmh_kfdb_detect_n_best(dvmh_kfdb* db, int slot, int nNum, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge);   /* :555-669 */
+int dvmh_kfdb_detect_n_best(dvmh_kfdb* db, int slot, int nNum, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge);
+/* vector<KeyFrame*> KeyFrameDatabase::DetectRelocalizationCandidates(Frame* F, Map* pMap) (KeyFrameDatabase.cc:810-909): the frame is
+ * its BowVector and mnId; `out` needs room for one entry per stored keyframe.  dvmh_kfdb_get_reloc_state: mnRelocQuery /
+ * mnRelocWords / mRelocScore of a slot (the state the query leaves on the keyframes). */
+int dvmh_kfdb_detect_reloc(dvmh_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t frame_id, int32_t map_id,
+                           int32_t* out, int32_t* n_out);
+void dvmh_kfdb_get_reloc_state(dvmh_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score);   /* :555-669 */
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
 //   src/KeyFrameDatabase.cc:671-678   ResetPlaceRecognitionQuery
 //   src/KeyFrameDatabase.cc:688-786   CalculateMergeScore (DVM-SLAM)   -> orc_kfdb_merge_score()
 //   src/KeyFrameDatabase.cc:789-808   DetectMergePossibility (DVM-SLAM)-> orc_kfdb_detect_merge_possibility()
+//   src/KeyFrameDatabase.cc:810-909   DetectRelocalizationCandidates   -> orc_kfdb_detect_reloc()
 //   Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-63  L1Scoring::score   -> orc_bow_score()
 // The keyframe state the queries read and write (mnPlaceRecognitionQuery / Words / Score) lives in the database object,
 // stale values included, exactly as it lives on the KeyFrame objects in the reference.
@@ -33,6 +34,9 @@ struct orc_kfdb {
     uint64_t query = 0;           // mnPlaceRecognitionQuery
     int words = 0;                // mnPlaceRecognitionWords
     float score = 0;              // mPlaceRecognitionScore
+    uint64_t reloc_query = 0;     // mnRelocQuery (KeyFrame.cc:60: 0)
+    int reloc_words = 0;          // mnRelocWords
+    float reloc_score = 0;        // mRelocScore (stale values live on, as on the KeyFrame objects)
   };
   std::vector<KF> kfs;
   std::map<int32_t, std::list<int32_t>> inverted;   // mvInvertedFile
@@ -184,4 +188,64 @@ void orc_kfdb_detect_n_best(orc_kfdb* db, int slot, int nNumCandidates, int32_t*
   }
 }
 
+/* KeyFrameDatabase::DetectRelocalizationCandidates(Frame* F, Map* pMap) (:810-909): the frame is (BowVector, mnId).  Note what the
+ * reference does and this keeps: the walk is over ALL keyframes of the inverted file (any map, bad or not); the map filter
+ * comes last; a neighbour whose mnRelocQuery equals the frame id contributes its mRelocScore even when THIS query did not
+ * score it (too few common words: the value of an earlier query, or 0); a frame id equal to a keyframe's mnRelocQuery (0 for
+ * the very first frame) never enters that keyframe into the list. */
+void orc_kfdb_detect_reloc(orc_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t frame_id, int32_t map_id,
+                           int32_t* out, int32_t* n_out) {
+  *n_out = 0;
+  std::list<int32_t> lKFsSharingWords;
+  for (int w = 0; w < nq; w++) {
+    auto it = db->inverted.find(qids[w]);
+    if (it == db->inverted.end()) continue;
+    for (int32_t s : it->second) {
+      orc_kfdb::KF& k = db->kfs[s];
+      if (k.reloc_query != frame_id) { k.reloc_words = 0; k.reloc_query = frame_id; lKFsSharingWords.push_back(s); }
+      k.reloc_words++;
+    }
+  }
+  if (lKFsSharingWords.empty()) return;
+  int maxCommonWords = 0;
+  for (int32_t s : lKFsSharingWords) maxCommonWords = std::max(maxCommonWords, db->kfs[s].reloc_words);
+  const int minCommonWords = maxCommonWords * 0.8f;
+  std::list<std::pair<float, int32_t>> lScoreAndMatch;
+  for (int32_t s : lKFsSharingWords) {
+    orc_kfdb::KF& k = db->kfs[s];
+    if (k.reloc_words > minCommonWords) {
+      const float si = (float)orc_bow_score(qids, qvals, nq, k.ids.data(), k.vals.data(), (int)k.ids.size());
+      k.reloc_score = si;
+      lScoreAndMatch.push_back({si, s});
+    }
+  }
+  if (lScoreAndMatch.empty()) return;
+  std::list<std::pair<float, int32_t>> lAccScoreAndMatch;
+  float bestAccScore = 0;
+  for (const auto& sm : lScoreAndMatch) {
+    float bestScore = sm.first, accScore = bestScore;
+    int32_t pBestKF = sm.second;
+    for (int32_t s2 : db->kfs[sm.second].neigh) {
+      const orc_kfdb::KF& k2 = db->kfs[s2];
+      if (k2.reloc_query != frame_id) continue;
+      accScore += k2.reloc_score;
+      if (k2.reloc_score > bestScore) { pBestKF = s2; bestScore = k2.reloc_score; }
+    }
+    lAccScoreAndMatch.push_back({accScore, pBestKF});
+    if (accScore > bestAccScore) bestAccScore = accScore;
+  }
+  const float minScoreToRetain = 0.75f * bestAccScore;
+  std::set<int32_t> spAlreadyAddedKF;
+  for (const auto& am : lAccScoreAndMatch) {
+    if (am.first > minScoreToRetain) {
+      const int32_t s = am.second;
+      if (db->kfs[s].map_id != map_id) continue;
+      if (!spAlreadyAddedKF.count(s)) { out[(*n_out)++] = s; spAlreadyAddedKF.insert(s); }
+    }
+  }
+}
+void orc_kfdb_get_reloc_state(const orc_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score) {
+  const orc_kfdb::KF& k = db->kfs[slot];
+  *query = k.reloc_query; *words = k.reloc_words; *score = k.reloc_score;
+}
 }  // extern "C"

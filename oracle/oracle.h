@@ -206,6 +206,10 @@ void orc_kfdb_merge_score(orc_kfdb* db, const int32_t* qids, const double* qvals
 int orc_kfdb_detect_merge_possibility(orc_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t uuid, int32_t map_id,
                                       int32_t* bestKeyFrame, float* score_out, float* baseline_out);
 void orc_kfdb_detect_n_best(orc_kfdb* db, int slot, int nNumCandidates, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge);
+/* DetectRelocalizationCandidates(Frame*, Map*) (KeyFrameDatabase.cc:810-909): out holds at most one entry per stored keyframe */
+void orc_kfdb_detect_reloc(orc_kfdb* db, const int32_t* qids, const double* qvals, int nq, uint64_t frame_id, int32_t map_id,
+                           int32_t* out, int32_t* n_out);
+void orc_kfdb_get_reloc_state(const orc_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score);
 
 /* ---- bundle adjustment (reference Optimizer.cc + vendored g2o; see ba_oracle.cpp) ---- */
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } orc_ba_edge;

@@ -73,8 +73,8 @@ def test_keyframe_database_sequences(capi, oracle, seed):
     rng = np.random.default_rng(seed)
     n = len(kfs)
     alive = set(range(n))
-    hits = 0
-    for step in range(120):
+    hits = reloc_hits = 0
+    for step in range(160):
         op = rng.random()
         j = int(rng.choice(sorted(alive)))
         q = kfs[j]
@@ -88,6 +88,13 @@ def test_keyframe_database_sequences(capi, oracle, seed):
             m = int(rng.integers(0, 3))
             s0 = float(rng.choice([0.0, 0.5]))
             assert dbo.merge_score(q["ids"], q["vals"], q["uuid"], m, s0) == dbg.merge_score(q["ids"], q["vals"], q["uuid"], m, s0)
+        elif op < 0.42 + 0.35:      # Tracking::Relocalization's query: a frame (any BoW vector, small id range -> repeated and zero ids occur)
+            m = int(rng.integers(0, 3))
+            fid = int(rng.integers(0, 12))
+            co = dbo.detect_reloc(q["ids"], q["vals"], fid, m)
+            cg = dbg.detect_reloc(q["ids"], q["vals"], fid, m)
+            assert np.array_equal(co, cg), (step, fid, co, cg)
+            reloc_hits += len(co) > 0
         elif op < 0.85:
             lo, mo = dbo.detect_n_best(j, 3)
             lg, mg = dbg.detect_n_best(j, 3)
@@ -109,6 +116,7 @@ def test_keyframe_database_sequences(capi, oracle, seed):
         if step % 20 == 0:
             for s in range(len(kfs)):
                 assert dbo.state(s) == dbg.state(s), (step, s)
-    assert hits > 20
+                assert dbo.reloc_state(s) == dbg.reloc_state(s), (step, s)
+    assert hits > 20 and reloc_hits > 5
     for s in range(len(kfs)):
-        assert dbo.state(s) == dbg.state(s)
+        assert dbo.state(s) == dbg.state(s) and dbo.reloc_state(s) == dbg.reloc_state(s)
