@@ -820,45 +820,25 @@ __device__ long long g_chol_dbg[32];
 #define DVM_STAMP(i) do { } while (0)
 #define DVM_STAMPW(i, w) do { } while (0)
 #endif
-__global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, const int32_t* __restrict__ cols,
-                                                  int* __restrict__ fail, double* __restrict__ Linv_all) {
-  DVM_STAMP(0);
-  const int kb = cols[blockIdx.x];
-  // One LDS block, laid out by hand: everything that is read with CONSTANT (wave-uniform) addresses sits in the first 64 KB,
-  // where a ds instruction's 16-bit offset field reaches it -- left to the compiler, Li / Iv / Pcol landed above 64 KB and every
-  // such address became a v_mov of a literal parked in an AGPR (hundreds of them in the kernel's prologue).
-  typedef __attribute__((address_space(3))) double lds_f64;
-  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
-  lds_f64* const lds = (lds_f64*)smem;
-  lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
-  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);                // inverses of the diagonal sub-blocks, TRANSPOSED: Iv[b][column][row]
-  lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;                            // 16x16 identity: the rows the idle lanes of a panel carry
-  lds_f64* const Bm = Id + 16 * 16;
-  lds_f64* const Li = Bm + NB * LP;
+typedef __attribute__((address_space(3))) double lds_f64;
+// LDS of one tile factorisation (laid out by the caller, see k_chol_diag): Bm = the tile (rows beyond the matrix: identity), Li = where
+// L^-1 goes; Pcol / Iv / Id are scratch (Id must hold the 16x16 identity).
+struct DiagLds {
+  lds_f64 (*Pcol)[NB];
+  lds_f64 (*Iv)[16][17];
+  lds_f64* Id;
+  lds_f64* Bm;
+  lds_f64* Li;
+};
+// One 64x64 tile in LDS: on return (all threads, behind a barrier) Li holds L^-1 -- every 16x16 block at or below the diagonal;
+// the blocks above it are NOT written -- and Bm the blocks of L below the diagonal blocks.  256 threads.
+__device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict__ fail) {
+  lds_f64 (*const Pcol)[NB] = D.Pcol;
+  lds_f64 (*const Iv)[16][17] = D.Iv;
+  lds_f64* const Id = D.Id;
+  lds_f64* const Bm = D.Bm;
+  lds_f64* const Li = D.Li;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = kb * NB;
-  const int kw = min(NB, n1 - k0);
-  {
-    // the whole tile with 8 independent 16-byte loads per thread, issued back to back (a load per loop iteration behind a
-    // branch serialised 16 global round trips: ~13 of the kernel's 27 us); rows beyond the matrix are clamped and replaced
-    double2 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
-      v[i] = *reinterpret_cast<const double2*>(S + (size_t)(k0 + min(r, kw - 1)) * ldS + k0 + c);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
-      const bool in = r < kw;
-      // rows beyond the matrix: identity.  (What lands ABOVE the diagonal is never read: the panel masks the upper triangle of
-      // its diagonal sub-block, everything else works on blocks at or below the diagonal.)
-      Bm[r * LP + c] = in ? v[i].x : (r == c ? 1.0 : 0.0);
-      Bm[r * LP + c + 1] = in ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
-    }
-  }
-  Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
-  __syncthreads();
   DVM_STAMP(1);
   const int lr = lane & 15, lq = lane >> 4;
   // inverse of the 16x16 diagonal sub-block bb by one wave: column `lane` of the inverse by forward substitution, L_it straight
@@ -1001,6 +981,48 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   else copy_inverse(3);
   DVM_STAMP(15);
   __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, const int32_t* __restrict__ cols,
+                                                  int* __restrict__ fail, double* __restrict__ Linv_all) {
+  DVM_STAMP(0);
+  const int kb = cols[blockIdx.x];
+  // One LDS block, laid out by hand: everything that is read with CONSTANT (wave-uniform) addresses sits in the first 64 KB,
+  // where a ds instruction's 16-bit offset field reaches it -- left to the compiler, Li / Iv / Pcol landed above 64 KB and every
+  // such address became a v_mov of a literal parked in an AGPR (hundreds of them in the kernel's prologue).
+  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
+  lds_f64* const lds = (lds_f64*)smem;
+  lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;                                   // the panel's finished columns, one row per column: broadcast source for the updates
+  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);                // inverses of the diagonal sub-blocks, TRANSPOSED: Iv[b][column][row]
+  lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;                            // 16x16 identity: the rows the idle lanes of a panel carry
+  lds_f64* const Bm = Id + 16 * 16;
+  lds_f64* const Li = Bm + NB * LP;
+  const int tid = threadIdx.x;
+  const int k0 = kb * NB;
+  const int kw = min(NB, n1 - k0);
+  {
+    // the whole tile with 8 independent 16-byte loads per thread, issued back to back (a load per loop iteration behind a
+    // branch serialised 16 global round trips: ~13 of the kernel's 27 us); rows beyond the matrix are clamped and replaced
+    double2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+      v[i] = *reinterpret_cast<const double2*>(S + (size_t)(k0 + min(r, kw - 1)) * ldS + k0 + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+      const bool in = r < kw;
+      // rows beyond the matrix: identity.  (What lands ABOVE the diagonal is never read: the panel masks the upper triangle of
+      // its diagonal sub-block, everything else works on blocks at or below the diagonal.)
+      Bm[r * LP + c] = in ? v[i].x : (r == c ? 1.0 : 0.0);
+      Bm[r * LP + c + 1] = in ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
+    }
+  }
+  Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+  __syncthreads();
+  const DiagLds D = {Pcol, Iv, Id, Bm, Li};
+  chol_diag_tile(D, fail);
   DVM_STAMP(16);
   double* Lo = Linv_all + (size_t)kb * NB * NB;
 #pragma unroll
