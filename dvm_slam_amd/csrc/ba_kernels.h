@@ -69,6 +69,8 @@ struct BaView {
   const int32_t* colstrips;     // per column: its strip rows
   const int32_t *h_level_off, *h_strip_off, *h_tgt_off;  // HOST arrays [nlevels+1]
   int32_t nlevels;
+  int32_t pair_a, pair_b;   // tile columns of the top pair (ba_ordering.h: BaTileSchedule::pair_a / pair_b) and pair_ok = 1, or pair_ok = 0
+  int32_t pair_ok;
   int32_t n_root_raw;       // columns of the last launched level whose only strip is the rhs row: their panel solve (one 64x64
                             // matrix-vector product each) is done by the back substitution itself, no k_chol_trsm launch (0: launch it)
   const double* lambda;     // device scalar with the current LM damping (pose graph), or null: use lambda_v

@@ -1034,6 +1034,138 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   }
   DVM_STAMP(17);
 }
+// The TOP PAIR of the elimination order in one workgroup (BaTileSchedule::pair_a / pair_b): column A, whose only tiles below
+// the diagonal are (B, A) and the rhs row, and the root column B.  As separate launches this is diag(A) -> panel solve + update
+// -> diag(B) -> two hops of the back substitution: five dependent kernels whose tiles travel through memory between them
+// (~34 us of an iteration's solve at 500 keyframes, and the WHOLE solve of a local-BA window of <= 20 free keyframes).  Here
+// the three tiles and the two rhs pieces are loaded once, everything else happens in LDS:
+//   L_A, L_A^-1 (chol_diag_tile) ; X = (B,A) L_A^-T (MFMA, only the k-blocks L_A^-1 has) ; (B,B) -= X X^T (MFMA, lower blocks) ;
+//   L_B, L_B^-1 ; y_A = L_A^-1 r_A, y_B = L_B^-1 (r_B - X y_A), x_B = L_B^-T y_B, x_A = L_A^-T (y_A - X^T x_B).
+// Four tile buffers (BmA -> X, raw (B,A) -> L_B^-1, BmB, L_A^-1) = 133 KB of the CU's 160 KB.  Nothing but x leaves: no one
+// else reads these columns' factor (their descendants need x_A / x_B, which go to xrow like any other column's).
+__global__ void __launch_bounds__(256) k_chol_pair(const double* __restrict__ S, int ldS, int n_pad, int kbA, int kbB, int nfree, int per_tile,
+                                                  int dof, double* __restrict__ xrow, double* __restrict__ x, int* __restrict__ fail) {
+  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 4 * NB * LP + 10 * NB];
+  lds_f64* const lds = (lds_f64*)smem;
+  lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;
+  lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);
+  lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;
+  lds_f64* const T1 = Id + 16 * 16;          // tile (A,A): L_A; then X = L(B,A)
+  lds_f64* const T2 = T1 + NB * LP;          // tile (B,A) as the Schur complement left it; then L_B^-1
+  lds_f64* const T3 = T2 + NB * LP;          // tile (B,B)
+  lds_f64* const T4 = T3 + NB * LP;          // L_A^-1
+  lds_f64* const vr0 = T4 + NB * LP;         // r_A -> y_A -> (y_A - X^T x_B)
+  lds_f64* const vr1 = vr0 + NB;             // r_B -> y_B
+  lds_f64* const vx0 = vr1 + NB;
+  lds_f64* const vx1 = vx0 + NB;
+  lds_f64* const vt = vx1 + NB;              // a product's result before it is combined
+  lds_f64* const part = vt + NB;             // [4][NB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int a0 = kbA * NB, b0 = kbB * NB;
+  {
+    double2 va[8], vb[8], vc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+      va[i] = *reinterpret_cast<const double2*>(S + (size_t)(a0 + r) * ldS + a0 + c);
+      vb[i] = *reinterpret_cast<const double2*>(S + (size_t)(b0 + r) * ldS + a0 + c);
+      vc[i] = *reinterpret_cast<const double2*>(S + (size_t)(b0 + r) * ldS + b0 + c);
+    }
+    double rv = 0;
+    if (tid < 2 * NB) rv = S[(size_t)n_pad * ldS + (tid < NB ? a0 + tid : b0 + tid - NB)];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+      T1[r * LP + c] = va[i].x; T1[r * LP + c + 1] = va[i].y;
+      T2[r * LP + c] = vb[i].x; T2[r * LP + c + 1] = vb[i].y;
+      T3[r * LP + c] = vc[i].x; T3[r * LP + c + 1] = vc[i].y;
+    }
+    if (tid < NB) vr0[tid] = rv; else if (tid < 2 * NB) vr1[tid - NB] = rv;
+  }
+  Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+  __syncthreads();
+  // the 16x16 blocks above the diagonal of an inverse are never written by chol_diag_tile: zeroed, so that what follows can
+  // treat it as a full matrix
+  auto zero_upper = [&](lds_f64* M) {
+    for (int i = tid; i < 6 * 256; i += 256) {
+      const int blk = i >> 8, e = i & 255;
+      const int bi = blk < 3 ? 0 : blk < 5 ? 1 : 2, bj = blk < 3 ? blk + 1 : blk < 5 ? blk - 1 : 3;
+      M[(16 * bi + (e >> 4)) * LP + 16 * bj + (e & 15)] = 0.0;
+    }
+  };
+  // out[c] = sum_k M[c][k] v[k]   (TR: sum_k M[k][c] v[k]), in a fixed order: 16 terms per thread, then the four quarters
+  auto matvec = [&](const lds_f64* M, bool TR, const lds_f64* v, lds_f64* out) {
+    const int c = tid & 63, q = tid >> 6;
+    double sacc = 0;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      const int k = 16 * q + kk;
+      sacc += (TR ? M[k * LP + c] : M[c * LP + k]) * v[k];
+    }
+    part[q * NB + c] = sacc;
+    __syncthreads();
+    if (tid < NB) out[tid] = (part[tid] + part[NB + tid]) + (part[2 * NB + tid] + part[3 * NB + tid]);
+    __syncthreads();
+  };
+  const DiagLds DA = {Pcol, Iv, Id, T1, T4};
+  chol_diag_tile(DA, fail);
+  zero_upper(T4);
+  __syncthreads();
+  // X = (B,A) L_A^-T: wave w takes block row w; column block bj only needs the k-blocks 0..bj (L_A^-1 is lower triangular)
+  {
+    double4_t xb[4];
+#pragma unroll
+    for (int bj = 0; bj < 4; bj++) {
+      double4_t acc = {0, 0, 0, 0};
+      for (int k = 0; k < 16 * (bj + 1); k += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[(16 * wave + lr) * LP + k + lq], T4[(16 * bj + lr) * LP + k + lq], acc, 0, 0, 0);
+      xb[bj] = acc;
+    }
+#pragma unroll
+    for (int bj = 0; bj < 4; bj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) T1[(16 * wave + lq + 4 * r) * LP + 16 * bj + lr] = xb[bj][r];
+  }
+  __syncthreads();
+  matvec(T4, false, vr0, vr0);                 // y_A = L_A^-1 r_A   (in place: every thread has read v before the first barrier)
+  matvec(T1, false, vr0, vt);                  // X y_A
+  if (tid < NB) vr1[tid] -= vt[tid];
+  // (B,B) -= X X^T, the ten blocks at or below the diagonal dealt over the waves
+  {
+    const int bis[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, bjs[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+    for (int t = wave; t < 10; t += 4) {
+      const int bi = bis[t], bj = bjs[t];
+      double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NB; k += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T1[(16 * bi + lr) * LP + k + lq], T1[(16 * bj + lr) * LP + k + lq], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) T3[(16 * bi + lq + 4 * r) * LP + 16 * bj + lr] -= acc[r];
+    }
+  }
+  __syncthreads();
+  const DiagLds DB = {Pcol, Iv, Id, T3, T2};
+  chol_diag_tile(DB, fail);
+  zero_upper(T2);
+  __syncthreads();
+  matvec(T2, false, vr1, vr1);                 // y_B
+  matvec(T2, true, vr1, vx1);                  // x_B = L_B^-T y_B
+  matvec(T1, true, vx1, vt);                   // X^T x_B
+  if (tid < NB) vr0[tid] -= vt[tid];
+  __syncthreads();
+  matvec(T4, true, vr0, vx0);                  // x_A = L_A^-T (y_A - X^T x_B)
+  // g2o's linear solver leaves _x untouched when the factorisation fails (see k_chol_backsolve)
+  const bool good = __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+  if (tid < 2 * NB) {
+    const int t = tid & 63, kb = tid < NB ? kbA : kbB;
+    const double v = tid < NB ? vx0[t] : vx1[t];
+    __hip_atomic_store(xrow + kb * NB + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int cam = kb * per_tile + t / dof;
+    if (t < per_tile * dof && cam < nfree && good) x[dof * (size_t)cam + t % dof] = v;
+  }
+}
+
 #ifdef DVM_CHOL_DEBUG
 extern "C" int dvm_debug_chol_stamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_dbg), sizeof(long long) * 32); }
 #endif
@@ -2485,7 +2617,10 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   int root_level = V.nlevels - 1;          // the last level that is launched (see the break below), where n_root_raw applies
   if (root_level >= 1 && V.h_level_off[root_level + 1] - V.h_level_off[root_level] == 1 && V.h_strip_off[root_level + 1] == V.h_strip_off[root_level] &&
       V.h_tgt_off[root_level + 1] == V.h_tgt_off[root_level]) root_level--;
+  // the top pair of the elimination order (two single-column levels: root_level - 1 and root_level) goes to k_chol_pair
+  const bool pair = V.pair_ok && root_level >= 1;
   for (int h = 0; h < V.nlevels; h++) {
+    if (pair && h == root_level - 1) break;
     const int nc = V.h_level_off[h + 1] - V.h_level_off[h], ns = V.h_strip_off[h + 1] - V.h_strip_off[h];
     const int nt = V.h_tgt_off[h + 1] - V.h_tgt_off[h];
     // the root of the elimination tree is the tile of the augmented rhs row: its "factorisation" (one scalar) is never
@@ -2507,11 +2642,18 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   }
   // y = L^-1 b is row n_pad of S (the augmented rhs row): the back substitution reads it in place; one launch for all
   // camera tile columns (levels 0 .. nlevels - 2; level nlevels - 1 is the rhs tile alone: not an unknown)
-  const int ncols = V.h_level_off[V.nlevels - 1];
+  int ncols = V.h_level_off[V.nlevels - 1];
+  int n_raw = V.n_root_raw;
+  if (pair) {
+    // (the slots of xrow that the remaining columns wait on were tagged by the first strip launch above; these two are written for good)
+    hipLaunchKernelGGL(k_chol_pair, dim3(1), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.pair_a, V.pair_b, V.nfree, V.per_tile, V.dof, V.xrow, V.x, d_fail);
+    ncols -= 2;          // `cols` lists the levels in order: the pair's columns are its last two entries
+    n_raw = 0;
+  }
   if (ncols > 0)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(ncols), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.nfree, V.per_tile, V.dof, V.cols, ncols,
                        V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips, reinterpret_cast<int32_t*>(V.ytmp),
-                       solve_seq, d_fail, V.n_root_raw);
+                       solve_seq, d_fail, n_raw);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub, const int* d_fail) {
   const int nb_pose = cdiv(std::max(V.nfree, 1), 256);

@@ -239,6 +239,24 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
       if (only_rhs) S.n_root_raw = S.level_off[hl + 1] - S.level_off[hl];
     }
   }
+  // the top pair (ba_ordering.h): root level = one column b with only its rhs strip; the level before = one column a whose strips are
+  // (b, a) and (rhs, a) -- its targets are then (b, b) and (rhs, b), nothing else
+  if (S.n_root_raw == 1 && S.root_level >= 1) {
+    const int hb = S.root_level, ha = hb - 1;
+    if (S.level_off[ha + 1] - S.level_off[ha] == 1) {
+      const int a = S.cols[S.level_off[ha]], b = S.cols[S.level_off[hb]];
+      bool ok = true, has_ba = false;
+      for (int st = S.strip_off[ha]; st < S.strip_off[ha + 1]; st++) {
+        const int i = S.strips[2 * st];
+        if (i == b) has_ba = true; else if (i != nt - 1) ok = false;
+      }
+      for (int t = S.tgt_off[ha]; t < S.tgt_off[ha + 1]; t++) {
+        const int ti = S.targets[4 * t], tj = S.targets[4 * t + 1];
+        if (!((ti == b && tj == b) || (ti == nt - 1 && tj == b))) ok = false;
+      }
+      if (ok && has_ba) { S.pair_a = a; S.pair_b = b; }
+    }
+  }
   S.colstrip_off.assign(1, 0);
   for (int k = 0; k < nt; k++) {
     for (int i : col[k]) S.colstrips.push_back(i);

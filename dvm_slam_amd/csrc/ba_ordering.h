@@ -41,6 +41,9 @@ struct BaTileSchedule {
   int root_level = -1;                 // the last level that gets launches (the level of the rhs tile alone behind it is skipped)
   int n_root_raw = 0;                  // its columns, if nothing but the rhs row hangs below them and they update nothing: their panel
                                        // solve is one matrix-vector product each, done by the back substitution (0: launched as usual)
+  int pair_a = -1, pair_b = -1;        // the last two camera tile columns when they form a chain of their own: the root column b (only the rhs
+                                       // row below it) and column a alone on the level before it with nothing but (b, a) and the rhs row below --
+                                       // one workgroup factorises both and solves for their unknowns (k_chol_pair); -1: no such pair
   double fill = 1.0;                   // non-zero tiles / all lower tiles
 };
 // T[i][j] (i >= j) = structurally non-zero tile of the matrix in elimination order; the last tile row (rhs) is dense.

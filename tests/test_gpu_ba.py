@@ -75,6 +75,29 @@ def test_ba_local_window_wide_kernels(capi, oracle):
     assert np.array_equal(pg, pg2) and np.array_equal(ptg, ptg2) and sg2["chi2"] == sg["chi2"]
 
 
+@pytest.mark.parametrize("n_kf,n_pts", [(16, 400), (120, 4000)])
+def test_ba_top_pair_kernel_matches_level_launches(capi, oracle, n_kf, n_pts, monkeypatch):
+    """The last two tile columns of the elimination order are factorised and solved by ONE workgroup (k_chol_pair) when the schedule
+    ends in such a chain -- a window of <= 20 free keyframes is nothing else.  Same LM sequence and, to rounding, the same result as
+    the level-by-level launches (DVM_BA_NO_PAIR=1), which stay the path for every other shape."""
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=n_kf + n_pts)
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    out = []
+    for no_pair in (False, True):
+        if no_pair:
+            monkeypatch.setenv("DVM_BA_NO_PAIR", "1")
+        ba = capi.BundleAdjuster()
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], float(np.sqrt(5.991)))
+        st = ba.optimize(8)
+        out.append((st, *ba.result()))
+        ba.close()
+    (sa, pa, xa), (sb, pb, xb) = out
+    assert sa["trials"] == sb["trials"] and sa["iterations"] == sb["iterations"]
+    assert np.allclose(sa["chi2"], sb["chi2"], rtol=1e-10)
+    assert np.abs(pa - pb).max() < 1e-8 and np.abs(xa - xb).max() < 1e-8
+
+
 def test_ba_fixed_cameras_and_unobserved(capi, oracle):
     """LBA shape: several fixed cameras observing the window's landmarks, a camera and a landmark without edges."""
     from dvm_slam_amd import synth

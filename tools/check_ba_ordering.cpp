@@ -79,8 +79,26 @@ int main(int argc, char** argv) {
     if (S.n_root_raw != S.level_off[h + 1] - S.level_off[h] || S.tgt_off[h + 1] != S.tgt_off[h]) return fail("n_root_raw on a level that updates");
     for (int s2 = S.strip_off[h]; s2 < S.strip_off[h + 1]; s2++) if (S.strips[2 * s2] != nt - 1) return fail("n_root_raw with a strip above the rhs row");
   }
-  std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
-              S.targets.size() / 4);
+  // the top pair (k_chol_pair): the last two columns of `cols`, each alone on its level; a's tiles below the diagonal are (b, a) and the
+  // rhs row, b's the rhs row; what a updates is (b, b) and (rhs, b)
+  if ((S.pair_a >= 0) != (S.pair_b >= 0)) return fail("half a pair");
+  if (S.pair_a >= 0) {
+    const int hb = S.root_level, ha = hb - 1;
+    if (ha < 0 || S.n_root_raw != 1) return fail("pair without a single raw root column");
+    if (S.level_off[ha + 1] - S.level_off[ha] != 1 || S.level_off[hb + 1] - S.level_off[hb] != 1) return fail("pair levels hold other columns");
+    if (S.cols[S.level_off[ha]] != S.pair_a || S.cols[S.level_off[hb]] != S.pair_b) return fail("pair columns are not the levels' columns");
+    if (S.level_off[hb + 1] != S.level_off[S.nlevels - 1] && S.level_off[hb + 1] != (int)S.cols.size() - 1 && S.level_off[hb + 1] != (int)S.cols.size())
+      return fail("pair is not at the end of the column list");
+    bool ba = false;
+    for (int i : std::vector<int>(S.colstrips.begin() + S.colstrip_off[S.pair_a], S.colstrips.begin() + S.colstrip_off[S.pair_a + 1])) {
+      if (i == S.pair_b) ba = true; else if (i != nt - 1) return fail("pair column a has another tile below it");
+    }
+    if (!ba) return fail("pair without the tile (b, a)");
+    for (int i : std::vector<int>(S.colstrips.begin() + S.colstrip_off[S.pair_b], S.colstrips.begin() + S.colstrip_off[S.pair_b + 1]))
+      if (i != nt - 1) return fail("pair column b has a tile below it");
+  }
+  std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu pair=%d,%d\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
+              S.targets.size() / 4, S.pair_a, S.pair_b);
   if (loop && n >= 300 && S.nlevels > nt / 2) return fail("nested dissection did not shorten the dependency chain");
   return 0;
 }
