@@ -14,6 +14,7 @@
 #include "ORBextractor_shim.h"
 #include "ORBmatcher_shim.h"
 #include "Optimizer_shim.h"
+#include "Sim3Solver_shim.h"
 #include "Frame_grid_shim.h"
 
 using namespace ORB_SLAM3;
@@ -98,6 +99,7 @@ int sw_add_keyframe(World* w, int map, unsigned long id, const float* pose7, con
   if (pose7_inv) kf->mock_pose(se3_of(pose7), se3_of(pose7_inv));
   else { kf->SetPose(se3_of(pose7)); kf->mock_set_pose = 0; }
   kf->mbBad = bad != 0;
+  for (int i = 0; i < 4; i++) w->cam.p_[i] = K4[i];      // Pinhole::mvParameters = (fx, fy, cx, cy)
   kf->mpCamera = &w->cam;
   m->mock_kfs.push_back(kf);
   m->mock_max_kf_id = std::max(m->mock_max_kf_id, id);
@@ -239,6 +241,36 @@ int sw_optimize_sim3(World* w, int kf1, int kf2, int32_t* matches1, double* S12,
   });
 }
 
+// Sim3Solver (LoopClosing.cc: `Sim3Solver solver(pKF, pKFi, vpMatches, fixScale, vpMatchedKF); solver.SetRansacParameters(0.99, min, max);
+// while (!converged && !noMore) T = solver.iterate(nPerCall, noMore, inliers, nInliers, converged);`) after srand(seed).
+// matches12: per keypoint of kf1 the matched map point (index, -1 none).  out16: the returned T12 (row-major 4x4); est: the getters
+// {R (9), t (3), s}; info: {calls, converged, noMore, nInliers, N}
+int sw_sim3_solver(World* w, int kf1, int kf2, const int32_t* matches12, int fix_scale, int min_inliers, int max_its, int per_call, unsigned seed,
+                   float* out16, float* est13, uint8_t* inliers, int32_t* info) {
+  return guarded(w, [&] {
+    KeyFrame* k1 = w->kfs[kf1].get();
+    KeyFrame* k2 = w->kfs[kf2].get();
+    std::vector<MapPoint*> m = mp_list(w, matches12, k1->N);
+    srand(seed);
+    Sim3Solver solver(k1, k2, m, fix_scale != 0);
+    solver.SetRansacParameters(0.99, min_inliers, max_its);
+    bool noMore = false, conv = false;
+    std::vector<bool> vin;
+    int nin = 0, calls = 0;
+    Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+    while (!conv && !noMore) { T = solver.iterate(per_call, noMore, vin, nin, conv); calls++; }
+    for (int i = 0; i < 16; i++) out16[i] = T(i / 4, i % 4);
+    const Eigen::Matrix3f R = solver.GetEstimatedRotation();
+    const Eigen::Vector3f t = solver.GetEstimatedTranslation();
+    for (int i = 0; i < 9; i++) est13[i] = R(i / 3, i % 3);
+    for (int i = 0; i < 3; i++) est13[9 + i] = t(i);
+    est13[12] = solver.GetEstimatedScale();
+    for (int i = 0; i < k1->N; i++) inliers[i] = i < (int)vin.size() && vin[i];
+    info[0] = calls; info[1] = conv; info[2] = noMore; info[3] = nin;
+    return 0;
+  });
+}
+
 // ---- frames
 int sw_add_frame(World* w, const float* pose7, const float* K4, int N, const dvm_keypoint* kps, const uint8_t* desc, const float* scale, const float* sigma2,
                  const float* inv_sigma2, int nlevels, float log_scale, const float* bounds /* minX maxX minY maxY */) {
@@ -259,6 +291,7 @@ int sw_add_frame(World* w, const float* pose7, const float* K4, int N, const dvm
   F.mvInvScaleFactors.resize(nlevels);
   for (int l = 0; l < nlevels; l++) F.mvInvScaleFactors[l] = 1.0f / scale[l];
   if (bounds) { Frame::mnMinX = bounds[0]; Frame::mnMaxX = bounds[1]; Frame::mnMinY = bounds[2]; Frame::mnMaxY = bounds[3]; }
+  for (int i = 0; i < 4; i++) w->cam.p_[i] = K4[i];
   F.mpCamera = &w->cam;
   F.SetPose(se3_of(pose7));
   F.mock_set_pose = 0;

@@ -187,6 +187,12 @@ class World:
         cp = _i32(connections).reshape(-1, 2)
         self._chk(self.L.sw_essential_graph_loop(self.h, m, loop_kf, cur_kf, _p(nk), _p(ns), len(nk), _p(ck), _p(cs), len(ck), _p(cp), len(cp), int(fix_scale)))
 
+    def sim3_solver(self, kf1, kf2, matches12, fix_scale, min_inliers, max_its, per_call, seed, n1):
+        m = _i32(matches12)
+        T = np.zeros(16, np.float32); est = np.zeros(13, np.float32); inl = np.zeros(n1, np.uint8); info = np.zeros(4, np.int32)
+        self._chk(self.L.sw_sim3_solver(self.h, kf1, kf2, _p(m), int(fix_scale), min_inliers, max_its, per_call, C.c_uint(seed), _p(T), _p(est), _p(inl), _p(info)))
+        return T.reshape(4, 4), est, inl.astype(bool), dict(calls=int(info[0]), converged=bool(info[1]), no_more=bool(info[2]), n_inliers=int(info[3]))
+
     def optimize_sim3(self, kf1, kf2, matches1, S12, th2, fix_scale, all_points=False):
         m = _i32(matches1).copy(); S = np.ascontiguousarray(S12, np.float64).copy()
         n = self._chk(self.L.sw_optimize_sim3(self.h, kf1, kf2, _p(m), _p(S), C.c_float(th2), int(fix_scale), int(all_points)))

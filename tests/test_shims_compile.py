@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "dvm_slam_amd", "host")
 
 
-@pytest.mark.parametrize("shim", ["ORBextractor_shim.h", "ORBmatcher_shim.h", "Optimizer_shim.h", "Frame_grid_shim.h"])
+@pytest.mark.parametrize("shim", ["ORBextractor_shim.h", "ORBmatcher_shim.h", "Optimizer_shim.h", "Frame_grid_shim.h", "Sim3Solver_shim.h"])
 def test_shim_compiles_against_reference_signatures(shim):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"),
                         "-I", os.path.join(ROOT, "include"), "-I", HOST, "-x", "c++", "-"],
@@ -30,6 +30,12 @@ def test_shims_cover_the_reference_public_interface():
     for name, count in (("Optimizer::BundleAdjustment(", 1), ("Optimizer::GlobalBundleAdjustemnt(", 1), ("Optimizer::LocalBundleAdjustment(", 2),
                         ("Optimizer::PoseOptimization(", 1), ("Optimizer::OptimizeSim3(", 1), ("Optimizer::OptimizeEssentialGraph(", 2)):
         assert o.count("inline void " + name) + o.count("inline int " + name) == count, name   # every mono non-inertial static of Optimizer.h:48-92
+    v = open(os.path.join(HOST, "Sim3Solver_shim.h")).read()
+    for name, count in (("inline Sim3Solver::Sim3Solver(", 1), ("inline void Sim3Solver::SetRansacParameters(", 1), ("inline Eigen::Matrix4f Sim3Solver::iterate(", 2),
+                        ("inline Eigen::Matrix4f Sim3Solver::find(", 1), ("inline Eigen::Matrix4f Sim3Solver::GetEstimatedTransformation(", 1),
+                        ("inline Eigen::Matrix3f Sim3Solver::GetEstimatedRotation(", 1), ("inline Eigen::Vector3f Sim3Solver::GetEstimatedTranslation(", 1),
+                        ("inline float Sim3Solver::GetEstimatedScale(", 1)):
+        assert v.count(name) == count, name                  # the public interface of include/Sim3Solver.h:34-47
     f = open(os.path.join(HOST, "Frame_grid_shim.h")).read()
     for name in ("inline bool Frame::isInFrustum(", "inline void Frame::UndistortKeyPoints(", "inline void Frame::ComputeImageBounds("):
         assert name in f, name
