@@ -663,6 +663,38 @@ def vocab_transform_host(voc, features, levelsup, device=0):
                 fv_feat=ff[:fo[nf.value]])
 
 
+class HostVocabulary:
+    """dvm_host::ORBVocabulary loaded from DBoW2's text format (loadFromTextFile, TemplatedVocabulary.h:1211-1286) and kept on the device."""
+
+    def __init__(self, filename, device=0):
+        H = host_lib()
+        H.dvmh_vocab_load_text.restype = C.c_void_p
+        H.dvmh_vocab_load_text.argtypes = [C.c_int32, C.c_char_p, C.c_void_p]
+        info = np.zeros(4, np.int32)
+        self.h = C.c_void_p(H.dvmh_vocab_load_text(device, os.fsencode(filename), _p(info)))
+        if not self.h.value:
+            raise DvmError(-1, f"{filename}: not a DBoW2 text vocabulary (or the device refused it)")
+        self.k, self.L, self.nodes, self.words = (int(x) for x in info)
+
+    def transform(self, features, levelsup):
+        H = host_lib()
+        H.dvmh_vocab_transform_loaded.restype = C.c_int32; H.dvmh_vocab_transform_loaded.argtypes = None
+        f = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+        n = len(f)
+        bi = np.zeros(n + 1, np.int32); bv = np.zeros(n + 1, np.float64); fn = np.zeros(n + 1, np.int32)
+        fo = np.zeros(n + 2, np.int32); ff = np.zeros(n + 1, np.int32)
+        nb = C.c_int32(0); nf = C.c_int32(0)
+        check(H.dvmh_vocab_transform_loaded(self.h, _p(f), C.c_int32(n), C.c_int32(levelsup), _p(bi), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf)))
+        return dict(bow_ids=bi[:nb.value], bow_vals=bv[:nb.value], fv_nodes=fn[:nf.value], fv_off=fo[:nf.value + 1], fv_feat=ff[:fo[nf.value]])
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            f = host_lib().dvmh_vocab_destroy; f.restype = None; f.argtypes = [C.c_void_p]
+            f(self.h); self.h = C.c_void_p()
+
+    __del__ = close
+
+
 def bow_score_host(ids1, vals1, ids2, vals2):
     H = host_lib()
     H.dvmh_bow_score.restype = C.c_double

@@ -4,6 +4,9 @@
 
 #include <cmath>
 #include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
 
 namespace dvm_host {
 
@@ -12,6 +15,49 @@ ORBVocabulary::ORBVocabulary(int device, int n_nodes, const int32_t* child_off, 
   if (dvm_vocab_create(device, n_nodes, child_off, children, desc, weight, word_id, L, &v_) != DVM_OK) v_ = nullptr;
 }
 ORBVocabulary::~ORBVocabulary() { if (v_) dvm_vocab_destroy(v_); }
+
+ORBVocabulary* ORBVocabulary::loadFromTextFile(int device, const char* filename) {
+  std::ifstream f(filename);
+  if (!f.is_open()) return nullptr;
+  std::string line;
+  if (!std::getline(f, line)) return nullptr;
+  int k = -1, L = -1, n1 = -1, n2 = -1;
+  { std::stringstream ss(line); ss >> k >> L >> n1 >> n2; }
+  if (k < 2 || k > 20 || L < 1 || L > 10 || n1 != 0 || n2 != 0) return nullptr;     // (:1231) + L1_NORM / TF_IDF only
+  std::vector<int32_t> parent(1, -1), word_id(1, -1);
+  std::vector<uint8_t> desc(32, 0);
+  std::vector<double> weight(1, 0.0);
+  int n_words = 0;
+  while (std::getline(f, line)) {
+    if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+    std::stringstream ss(line);
+    int pid = -1, leaf = 0;
+    ss >> pid >> leaf;
+    const int nid = (int)parent.size();
+    if (ss.fail() || pid < 0 || pid >= nid) return nullptr;
+    uint8_t d[32];
+    for (int i = 0; i < 32; i++) { int v = 0; ss >> v; if (ss.fail() || v < 0 || v > 255) return nullptr; d[i] = (uint8_t)v; }
+    double w = 0;
+    ss >> w;
+    if (ss.fail()) return nullptr;
+    parent.push_back(pid);
+    desc.insert(desc.end(), d, d + 32);
+    weight.push_back(w);
+    word_id.push_back(leaf > 0 ? n_words++ : -1);
+  }
+  const int n = (int)parent.size();
+  if (n < 2 || n_words == 0) return nullptr;
+  // children lists in node order (m_nodes[pid].children.push_back(nid) with ascending nid)
+  std::vector<int32_t> child_off(n + 1, 0), children(n - 1);
+  for (int i = 1; i < n; i++) child_off[parent[i] + 1]++;
+  for (int i = 0; i < n; i++) child_off[i + 1] += child_off[i];
+  std::vector<int32_t> fill(child_off.begin(), child_off.end() - 1);
+  for (int i = 1; i < n; i++) children[fill[parent[i]]++] = i;
+  ORBVocabulary* voc = new ORBVocabulary(device, n, child_off.data(), children.data(), desc.data(), weight.data(), word_id.data(), L);
+  if (!voc->ok()) { delete voc; return nullptr; }
+  voc->k_ = k; voc->L_ = L; voc->n_nodes_ = n; voc->n_words_ = n_words;
+  return voc;
+}
 
 int ORBVocabulary::transform(const uint8_t* features, int n, BowVector& v, FeatureVector& fv, int levelsup) const {
   v.clear();
@@ -82,6 +128,38 @@ extern "C" int dvmh_vocab_transform(int device, int n_nodes, const int32_t* chil
   }
   *n_fv = m;
   return DVM_OK;
+}
+
+static int export_maps(const dvm_host::BowVector& v, const dvm_host::FeatureVector& fv, int32_t* bow_ids, double* bow_vals, int* n_bow,
+                       int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int* n_fv) {
+  int k = 0;
+  for (auto& e : v) { bow_ids[k] = (int32_t)e.first; bow_vals[k] = e.second; k++; }
+  *n_bow = k;
+  int m = 0, t = 0;
+  fv_off[0] = 0;
+  for (auto& e : fv) {
+    fv_nodes[m] = (int32_t)e.first;
+    for (unsigned i : e.second) fv_feat[t++] = (int32_t)i;
+    fv_off[++m] = t;
+  }
+  *n_fv = m;
+  return DVM_OK;
+}
+struct dvmh_vocab : dvm_host::ORBVocabulary {};     // the opaque handle of include/dvmslam_host.h
+extern "C" dvmh_vocab* dvmh_vocab_load_text(int device, const char* filename, int32_t* info4) {
+  dvm_host::ORBVocabulary* v = dvm_host::ORBVocabulary::loadFromTextFile(device, filename);
+  if (v && info4) { info4[0] = v->k(); info4[1] = v->L(); info4[2] = v->nodes(); info4[3] = v->size(); }
+  return static_cast<dvmh_vocab*>(v);
+}
+extern "C" void dvmh_vocab_destroy(dvmh_vocab* v) { delete static_cast<dvm_host::ORBVocabulary*>(v); }
+extern "C" int dvmh_vocab_transform_loaded(dvmh_vocab* voc, const uint8_t* features, int n, int levelsup, int32_t* bow_ids, double* bow_vals,
+                                           int* n_bow, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int* n_fv) {
+  if (!voc) return DVM_ERR_INVALID;
+  dvm_host::BowVector v;
+  dvm_host::FeatureVector fv;
+  const int rc = voc->transform(features, n, v, fv, levelsup);
+  if (rc != DVM_OK) return rc;
+  return export_maps(v, fv, bow_ids, bow_vals, n_bow, fv_nodes, fv_off, fv_feat, n_fv);
 }
 
 extern "C" double dvmh_bow_score(const int32_t* ids1, const double* vals1, int n1, const int32_t* ids2, const double* vals2, int n2) {

@@ -20,6 +20,17 @@ class ORBVocabulary {
   // tree as in dvm_vocab_create (CSR children lists); the arrays are copied to the device
   ORBVocabulary(int device, int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* desc,
                 const double* weight, const int32_t* word_id, int L);
+  // bool loadFromTextFile(const std::string& filename) (TemplatedVocabulary.h:1211-1286): the text form ORBvoc.txt ships in --
+  // "k L scoring weighting", then one line per node: "parent isLeaf d0 .. d31 weight", node ids in file order from 1 (0 = root),
+  // word ids in leaf order.  Returns nullptr when the file does not parse (wrong header, a parent that does not precede its
+  // child, no leaf) or the device refuses the tree.  Only L1_NORM scoring / TF_IDF weighting (scoring 0, weighting 0: what
+  // ORB-SLAM3's vocabulary uses) are accepted.  A trailing empty line is skipped (the reference's eof loop turns it into a
+  // node with an uninitialised parent).
+  static ORBVocabulary* loadFromTextFile(int device, const char* filename);
+  int k() const { return k_; }
+  int L() const { return L_; }
+  int nodes() const { return n_nodes_; }
+  int size() const { return n_words_; }      // unsigned int size() const: number of words
   ~ORBVocabulary();
   ORBVocabulary(const ORBVocabulary&) = delete;
   bool ok() const { return v_ != nullptr; }
@@ -31,6 +42,7 @@ class ORBVocabulary {
 
  private:
   dvm_vocab* v_ = nullptr;
+  int k_ = 0, L_ = 0, n_nodes_ = 0, n_words_ = 0;
 };
 
 }  // namespace dvm_host

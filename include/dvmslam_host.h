@@ -117,6 +117,13 @@ float dvmh_logf(float x);                                                       
 int dvmh_vocab_transform(int device, int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* desc, const double* weight,
                          const int32_t* word_id, int L, const uint8_t* features, int n, int levelsup, int32_t* bow_ids, double* bow_vals, int* n_bow,
                          int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int* n_fv);
+/* bool TemplatedVocabulary::loadFromTextFile(filename) (TemplatedVocabulary.h:1211-1286; ORBvoc.txt's format) into a vocabulary that lives
+ * on the device; info4 = {k, L, nodes, words}.  NULL: the file does not parse.  dvmh_vocab_transform_loaded = transform() on it. */
+typedef struct dvmh_vocab dvmh_vocab;
+dvmh_vocab* dvmh_vocab_load_text(int device, const char* filename, int32_t* info4);
+void dvmh_vocab_destroy(dvmh_vocab* v);
+int dvmh_vocab_transform_loaded(dvmh_vocab* voc, const uint8_t* features, int n, int levelsup, int32_t* bow_ids, double* bow_vals, int* n_bow,
+                                int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int* n_fv);
 double dvmh_bow_score(const int32_t* ids1, const double* vals1, int n1, const int32_t* ids2, const double* vals2, int n2);   /* L1 score, ScoringObject.cpp:23-63 */
 
 /* ---- KeyFrameDatabase (src/KeyFrameDatabase.cc:43-70, 555-808); keyframes are slots, uuid 0 is reserved */

@@ -249,6 +249,49 @@ def test_vocab_transform(capi, oracle, k, L):
         oracle.bow_score(a["bow_ids"], a["bow_vals"], b["bow_ids"], b["bow_vals"])
 
 
+def _write_dbow2_text(voc, path, k):
+    """The vocabulary in DBoW2's text form (saveToTextFile, TemplatedVocabulary.h:1290-1315): "k L scoring weighting", then one line per
+    node in id order: parent, isLeaf, 32 descriptor bytes, weight.  synth.vocabulary numbers its nodes breadth-first, children after
+    parents, as a file read by loadFromTextFile does."""
+    parent = np.zeros(voc["n_nodes"], np.int64)
+    for n in range(voc["n_nodes"]):
+        parent[voc["children"][voc["child_off"][n]:voc["child_off"][n + 1]]] = n
+    with open(path, "w") as f:
+        f.write(f"{k} {voc['L']}  0 0\n")
+        for n in range(1, voc["n_nodes"]):
+            leaf = int(voc["word_id"][n] >= 0)
+            f.write(f"{parent[n]} {leaf} " + " ".join(str(int(b)) for b in voc["desc"][n]) + f" {float(voc['weight'][n])!r}\n")
+        f.write("\n")                                  # ORBvoc.txt ends in a newline; the loader must not turn it into a node
+
+
+def test_vocabulary_from_text_file(capi, oracle, tmp_path):
+    """ORBVocabulary::loadFromTextFile: the tree read from DBoW2's text format gives the transform of the tree built from the arrays
+    (word ids in leaf order, children in node order), a damaged file is refused."""
+    from dvm_slam_amd import synth
+    voc = synth.vocabulary(k=9, L=3, seed=77)
+    path = tmp_path / "voc.txt"
+    _write_dbow2_text(voc, path, 9)
+    hv = capi.HostVocabulary(str(path))
+    assert (hv.k, hv.L, hv.nodes, hv.words) == (9, 3, voc["n_nodes"], int((voc["word_id"] >= 0).sum()))
+    rng = np.random.default_rng(8)
+    feats = voc["desc"][rng.integers(1, voc["n_nodes"], 900)].copy()
+    feats[rng.random(feats.shape) < 0.04] ^= 0x42
+    for levelsup in (0, 2, 4):
+        h = hv.transform(feats, levelsup)
+        r = oracle.vocab_transform(voc, feats, levelsup)
+        for key in ("bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+            assert np.array_equal(h[key], r[key]), key
+    hv.close()
+    text = path.read_text().splitlines()
+    bad = tmp_path / "bad.txt"
+    bad.write_text("\n".join([text[0]] + [text[1].replace(text[1].split()[0], "5", 1)] + text[2:]))      # a parent that does not exist yet
+    with pytest.raises(RuntimeError):
+        capi.HostVocabulary(str(bad))
+    bad.write_text("30 3 0 0\n" + "\n".join(text[1:]))                                                   # k out of range
+    with pytest.raises(RuntimeError):
+        capi.HostVocabulary(str(bad))
+
+
 def test_frame_grid_reports_truncated_device_counts(capi):
     """a device-side count above the handle's capacity is clamped by k_frame_build -- and counted, so the caller of
     the device-resident path learns about it (dvm_frame_overflows) instead of silently matching against a truncated frame."""
