@@ -15,6 +15,7 @@
 #include "ORBmatcher_shim.h"
 #include "Optimizer_shim.h"
 #include "Sim3Solver_shim.h"
+#include "ORBVocabulary_shim.h"
 #include "Frame_grid_shim.h"
 
 using namespace ORB_SLAM3;
@@ -267,6 +268,34 @@ int sw_sim3_solver(World* w, int kf1, int kf2, const int32_t* matches12, int fix
     est13[12] = solver.GetEstimatedScale();
     for (int i = 0; i < k1->N; i++) inliers[i] = i < (int)vin.size() && vin[i];
     info[0] = calls; info[1] = conv; info[2] = noMore; info[3] = nin;
+    return 0;
+  });
+}
+
+// ORBVocabulary: loadFromTextFile, then what Frame::ComputeBoW / KeyFrame::ComputeBoW do (Frame.cc:783-789): the descriptor rows as a
+// vector<cv::Mat>, transform(.., 4) -> the two maps flattened for the caller; score of the vector against itself's half
+int sw_vocab_compute_bow(World* w, const char* path, const uint8_t* desc, int n, int levelsup, int32_t* bow_ids, double* bow_vals, int32_t* n_bow,
+                         int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_feat, int32_t* n_fv, int32_t* voc_size, double* self_score) {
+  return guarded(w, [&] {
+    ORBVocabulary voc;
+    if (!voc.loadFromTextFile(path)) return -2;
+    *voc_size = (int32_t)voc.size();
+    cv::Mat D;
+    D.create(std::max(n, 1), 32, CV_8U);
+    if (n) std::memcpy(D.data, desc, 32 * (size_t)n);
+    std::vector<cv::Mat> vCurrentDesc;
+    for (int i = 0; i < n; i++) vCurrentDesc.push_back(D.row(i));
+    DBoW2::BowVector bv;
+    DBoW2::FeatureVector fv;
+    voc.transform(vCurrentDesc, bv, fv, levelsup);
+    int k = 0;
+    for (const auto& e : bv) { bow_ids[k] = (int32_t)e.first; bow_vals[k] = e.second; k++; }
+    *n_bow = k;
+    int m = 0, t = 0;
+    fv_off[0] = 0;
+    for (const auto& e : fv) { fv_nodes[m] = (int32_t)e.first; for (unsigned i : e.second) fv_feat[t++] = (int32_t)i; fv_off[++m] = t; }
+    *n_fv = m;
+    *self_score = voc.score(bv, bv);
     return 0;
   });
 }

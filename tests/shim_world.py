@@ -187,6 +187,16 @@ class World:
         cp = _i32(connections).reshape(-1, 2)
         self._chk(self.L.sw_essential_graph_loop(self.h, m, loop_kf, cur_kf, _p(nk), _p(ns), len(nk), _p(ck), _p(cs), len(ck), _p(cp), len(cp), int(fix_scale)))
 
+    def vocab_compute_bow(self, path, desc, levelsup):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        bi = np.zeros(n + 1, np.int32); bv = np.zeros(n + 1, np.float64); fn = np.zeros(n + 1, np.int32); fo = np.zeros(n + 2, np.int32); ff = np.zeros(n + 1, np.int32)
+        nb = C.c_int32(0); nf = C.c_int32(0); vs = C.c_int32(0); sc = C.c_double(0)
+        self._chk(self.L.sw_vocab_compute_bow(self.h, os.fsencode(path), _p(d), n, levelsup, _p(bi), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf),
+                                              C.byref(vs), C.byref(sc)))
+        return dict(bow_ids=bi[:nb.value], bow_vals=bv[:nb.value], fv_nodes=fn[:nf.value], fv_off=fo[:nf.value + 1], fv_feat=ff[:fo[nf.value]],
+                    size=vs.value, self_score=sc.value)
+
     def sim3_solver(self, kf1, kf2, matches12, fix_scale, min_inliers, max_its, per_call, seed, n1):
         m = _i32(matches12)
         T = np.zeros(16, np.float32); est = np.zeros(13, np.float32); inl = np.zeros(n1, np.uint8); info = np.zeros(4, np.int32)

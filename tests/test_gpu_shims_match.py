@@ -331,3 +331,23 @@ def test_orb_extractor_call_operator(capi, oracle, frames):
     mono = W._chk(W.L.sw_extract(W.h, sw._p(padded), rows, cols, cols + 24, 1000, f32(1.2), 8, 20, 7, 0, 100, sw._p(kps), sw._p(desc), cap, sw._p(n), 0, None, None, None))
     assert (mono, int(n[0])) == (mono2, n2) and 0 < mono2 < n2 and np.array_equal(kps["x"][:n2], k2["x"]) and np.array_equal(desc[:n2], d2)
     assert W._chk(W.L.sw_extract(W.h, None, 0, 0, 0, 1000, f32(1.2), 8, 20, 7, 0, 1000, sw._p(kps), sw._p(desc), cap, sw._p(n), 0, None, None, None)) == -1
+
+
+def test_orb_vocabulary_class(oracle, tmp_path):
+    """ORB_SLAM3::ORBVocabulary as Frame::ComputeBoW / KeyFrame::ComputeBoW use it: loadFromTextFile, transform(vector<cv::Mat>, BowVector&,
+    FeatureVector&, 4), score(), size() -- BoW vector (ids, normalised weights) and feature vector identical to the oracle's."""
+    from dvm_slam_amd import synth
+    from test_gpu_match import _write_dbow2_text
+    voc = synth.vocabulary(k=8, L=4, seed=21)
+    path = tmp_path / "voc.txt"
+    _write_dbow2_text(voc, path, 8)
+    rng = np.random.default_rng(4)
+    desc = voc["desc"][rng.integers(1, voc["n_nodes"], 700)].copy()
+    desc[rng.random(desc.shape) < 0.03] ^= 0x18
+    W = sw.World()
+    g = W.vocab_compute_bow(str(path), desc, 4)
+    r = oracle.vocab_transform(voc, desc, 4)
+    for key in ("bow_ids", "bow_vals", "fv_nodes", "fv_off", "fv_feat"):
+        assert np.array_equal(g[key], r[key]), key
+    assert g["size"] == int((voc["word_id"] >= 0).sum())
+    assert g["self_score"] == oracle.bow_score(r["bow_ids"], r["bow_vals"], r["bow_ids"], r["bow_vals"]) and abs(g["self_score"] - 1.0) < 1e-12
