@@ -16,6 +16,7 @@
 #include "Optimizer_shim.h"
 #include "Sim3Solver_shim.h"
 #include "ORBVocabulary_shim.h"
+#include "KeyFrameDatabase_shim.h"
 #include "Frame_grid_shim.h"
 
 using namespace ORB_SLAM3;
@@ -31,6 +32,7 @@ struct World {
   std::vector<std::unique_ptr<MapPoint>> mps;
   std::vector<std::unique_ptr<Frame>> frames;
   GeometricCamera cam;
+  std::unique_ptr<KeyFrameDatabase> kfdb;
   std::string error;
   int kf_index(KeyFrame* k) const { for (size_t i = 0; i < kfs.size(); i++) if (kfs[i].get() == k) return (int)i; return -1; }
   int mp_index(MapPoint* p) const { if (!p) return -1; for (size_t i = 0; i < mps.size(); i++) if (mps[i].get() == p) return (int)i; return -2; }
@@ -296,6 +298,69 @@ int sw_vocab_compute_bow(World* w, const char* path, const uint8_t* desc, int n,
     for (const auto& e : fv) { fv_nodes[m] = (int32_t)e.first; for (unsigned i : e.second) fv_feat[t++] = (int32_t)i; fv_off[++m] = t; }
     *n_fv = m;
     *self_score = voc.score(bv, bv);
+    return 0;
+  });
+}
+
+// ---- KeyFrameDatabase (the class, on KeyFrame* / Map* / Frame*)
+void sw_kf_set_bow(World* w, int kf, const int32_t* ids, const double* vals, int n) {
+  DBoW2::BowVector& b = w->kfs[kf]->mBowVec;
+  b.clear();
+  for (int i = 0; i < n; i++) b[(DBoW2::WordId)ids[i]] = vals[i];
+}
+void sw_kf_set_uuid(World* w, int kf, const uint8_t* u16) { std::memcpy(w->kfs[kf]->uuid.data, u16, 16); }
+void sw_kf_set_connected(World* w, int kf, const int32_t* others, int n) {
+  w->kfs[kf]->mock_connected.clear();
+  for (int i = 0; i < n; i++) w->kfs[kf]->mock_connected.insert(w->kfs[others[i]].get());
+}
+void sw_kf_set_bad(World* w, int kf, int bad) { w->kfs[kf]->mbBad = bad != 0; }
+void sw_map_set_bad(World* w, int map, int bad) { w->maps[map]->mock_bad = bad != 0; }
+int sw_kfdb_create(World* w) { return guarded(w, [&] { w->kfdb.reset(new KeyFrameDatabase()); return 0; }); }
+int sw_kfdb_add(World* w, int kf) { return guarded(w, [&] { w->kfdb->add(w->kfs[kf].get()); return 0; }); }
+int sw_kfdb_erase(World* w, int kf) { return guarded(w, [&] { w->kfdb->erase(w->kfs[kf].get()); return 0; }); }
+int sw_kfdb_clear_map(World* w, int map) { return guarded(w, [&] { w->kfdb->clearMap(w->maps[map].get()); return 0; }); }
+// returns found (0 / 1); best_kf = index of the keyframe whose uuid comes back (-1: nil uuid)
+int sw_kfdb_detect_merge_possibility(World* w, const int32_t* ids, const double* vals, int n, const uint8_t* u16, int map, int32_t* best_kf) {
+  return guarded(w, [&] {
+    DBoW2::BowVector b;
+    for (int i = 0; i < n; i++) b[(DBoW2::WordId)ids[i]] = vals[i];
+    boost::uuids::uuid u;
+    std::memcpy(u.data, u16, 16);
+    const std::pair<bool, boost::uuids::uuid> r = w->kfdb->DetectMergePossibility(b, u, w->maps[map].get());
+    *best_kf = w->kf_index(w->kfdb->ConvertUuidToKeyFrame(r.second));
+    return r.first ? 1 : 0;
+  });
+}
+int sw_kfdb_merge_score(World* w, const int32_t* ids, const double* vals, int n, const uint8_t* u16, int map, float* score, int32_t* best_kf) {
+  return guarded(w, [&] {
+    DBoW2::BowVector b;
+    for (int i = 0; i < n; i++) b[(DBoW2::WordId)ids[i]] = vals[i];
+    boost::uuids::uuid u;
+    std::memcpy(u.data, u16, 16);
+    KeyFrame* best = nullptr;
+    w->kfdb->CalculateMergeScore(b, u, w->maps[map].get(), *score, best);
+    *best_kf = w->kf_index(best);
+    return 0;
+  });
+}
+int sw_kfdb_detect_n_best(World* w, int kf, int n_num, int32_t* loop, int32_t* n_loop, int32_t* merge, int32_t* n_merge) {
+  return guarded(w, [&] {
+    std::vector<KeyFrame*> l, m;
+    w->kfdb->DetectNBestCandidates(w->kfs[kf].get(), l, m, n_num);
+    *n_loop = (int32_t)l.size(); *n_merge = (int32_t)m.size();
+    for (size_t i = 0; i < l.size(); i++) loop[i] = w->kf_index(l[i]);
+    for (size_t i = 0; i < m.size(); i++) merge[i] = w->kf_index(m[i]);
+    return 0;
+  });
+}
+int sw_kfdb_detect_reloc(World* w, const int32_t* ids, const double* vals, int n, unsigned long frame_id, int map, int32_t* out, int32_t* n_out) {
+  return guarded(w, [&] {
+    Frame F;
+    for (int i = 0; i < n; i++) F.mBowVec[(DBoW2::WordId)ids[i]] = vals[i];
+    F.mnId = frame_id;
+    const std::vector<KeyFrame*> c = w->kfdb->DetectRelocalizationCandidates(&F, w->maps[map].get());
+    *n_out = (int32_t)c.size();
+    for (size_t i = 0; i < c.size(); i++) out[i] = w->kf_index(c[i]);
     return 0;
   });
 }

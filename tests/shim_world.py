@@ -187,6 +187,46 @@ class World:
         cp = _i32(connections).reshape(-1, 2)
         self._chk(self.L.sw_essential_graph_loop(self.h, m, loop_kf, cur_kf, _p(nk), _p(ns), len(nk), _p(ck), _p(cs), len(ck), _p(cp), len(cp), int(fix_scale)))
 
+    # ---- KeyFrameDatabase (the class)
+    @staticmethod
+    def _uuid16(u):
+        return np.frombuffer(int(u).to_bytes(16, "little"), np.uint8).copy()
+
+    def kf_set_bow(self, kf, ids, vals):
+        i = _i32(ids); v = np.ascontiguousarray(vals, np.float64)
+        self.L.sw_kf_set_bow(self.h, kf, _p(i), _p(v), len(i))
+
+    def kf_set_uuid(self, kf, u): self.L.sw_kf_set_uuid(self.h, kf, _p(self._uuid16(u)))
+
+    def kf_set_connected(self, kf, others):
+        o = _i32(others); self.L.sw_kf_set_connected(self.h, kf, _p(o) if len(o) else None, len(o))
+
+    def kf_set_bad(self, kf, bad): self.L.sw_kf_set_bad(self.h, kf, int(bad))
+    def map_set_bad(self, m, bad): self.L.sw_map_set_bad(self.h, m, int(bad))
+    def kfdb_create(self): self._chk(self.L.sw_kfdb_create(self.h))
+    def kfdb_add(self, kf): self._chk(self.L.sw_kfdb_add(self.h, kf))
+    def kfdb_erase(self, kf): self._chk(self.L.sw_kfdb_erase(self.h, kf))
+
+    def kfdb_detect_merge_possibility(self, ids, vals, uuid, m):
+        i = _i32(ids); v = np.ascontiguousarray(vals, np.float64); best = C.c_int32(-1)
+        r = self._chk(self.L.sw_kfdb_detect_merge_possibility(self.h, _p(i), _p(v), len(i), _p(self._uuid16(uuid)), m, C.byref(best)))
+        return r, best.value
+
+    def kfdb_merge_score(self, ids, vals, uuid, m, score=0.0):
+        i = _i32(ids); v = np.ascontiguousarray(vals, np.float64); best = C.c_int32(-1); sc = C.c_float(score)
+        self._chk(self.L.sw_kfdb_merge_score(self.h, _p(i), _p(v), len(i), _p(self._uuid16(uuid)), m, C.byref(sc), C.byref(best)))
+        return sc.value, best.value
+
+    def kfdb_detect_n_best(self, kf, n_num):
+        lo = np.zeros(max(n_num, 1), np.int32); me = np.zeros(max(n_num, 1), np.int32); nl = C.c_int32(0); nm = C.c_int32(0)
+        self._chk(self.L.sw_kfdb_detect_n_best(self.h, kf, n_num, _p(lo), C.byref(nl), _p(me), C.byref(nm)))
+        return lo[:nl.value].copy(), me[:nm.value].copy()
+
+    def kfdb_detect_reloc(self, ids, vals, frame_id, m, cap=4096):
+        i = _i32(ids); v = np.ascontiguousarray(vals, np.float64); out = np.zeros(cap, np.int32); n = C.c_int32(0)
+        self._chk(self.L.sw_kfdb_detect_reloc(self.h, _p(i), _p(v), len(i), C.c_ulong(frame_id), m, _p(out), C.byref(n)))
+        return out[:n.value].copy()
+
     def vocab_compute_bow(self, path, desc, levelsup):
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
         n = len(d)

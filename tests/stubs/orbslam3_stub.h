@@ -19,6 +19,7 @@
 #include <sophus/sim3.hpp>
 
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#include <boost/uuid/uuid.hpp>
 
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
@@ -45,6 +46,8 @@ class Map {
   KeyFrame* GetOriginKF() { return mock_origin; }
   void IncreaseChangeIndex() { mock_change_index++; }
   bool IsInertial() { return false; }
+  bool IsBad() { return mock_bad; }
+  bool mock_bad = false;
   void EraseMapPoint(MapPoint* p) { mock_mps.erase(std::remove(mock_mps.begin(), mock_mps.end(), p), mock_mps.end()); }
   std::mutex mMutexMapUpdate;
   std::set<long unsigned int> msOptKFs, msFixedKFs;
@@ -148,6 +151,13 @@ class KeyFrame {
   void ReplaceMapPointMatch(const int& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }
   void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
+  std::vector<KeyFrame*> GetBestCovisibilityKeyFrames(const int& N) {   // (KeyFrame.cc: the first N of the ordered list)
+    if ((int)mvpOrderedConnectedKeyFrames.size() < N) return mvpOrderedConnectedKeyFrames;
+    return std::vector<KeyFrame*>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + N);
+  }
+  std::set<KeyFrame*> GetConnectedKeyFrames() { return mock_connected; }   // (KeyFrame.cc: the keys of mConnectedKeyFrameWeights)
+  boost::uuids::uuid uuid = boost::uuids::nil_uuid();
+  std::set<KeyFrame*> mock_connected;
   std::vector<KeyFrame*> GetCovisiblesByWeight(const int& w) {          // (KeyFrame.cc: the ordered list down to weight w)
     std::vector<KeyFrame*> out;
     for (size_t i = 0; i < mvpOrderedConnectedKeyFrames.size(); i++) if (mvOrderedWeights[i] >= w) out.push_back(mvpOrderedConnectedKeyFrames[i]);

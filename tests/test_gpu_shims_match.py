@@ -351,3 +351,64 @@ def test_orb_vocabulary_class(oracle, tmp_path):
         assert np.array_equal(g[key], r[key]), key
     assert g["size"] == int((voc["word_id"] >= 0).sum())
     assert g["self_score"] == oracle.bow_score(r["bow_ids"], r["bow_vals"], r["bow_ids"], r["bow_vals"]) and abs(g["self_score"] - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_keyframe_database_class(oracle, seed):
+    """ORB_SLAM3::KeyFrameDatabase on KeyFrame* / Map* / Frame* (host/KeyFrameDatabase_shim.h): add / erase, DetectMergePossibility and
+    CalculateMergeScore on a peer's BoW vector + uuid, DetectNBestCandidates of a stored keyframe, DetectRelocalizationCandidates of
+    a frame -- a mixed sequence against the oracle's database.  Bad flags and covisibility are changed ON THE OBJECTS between the
+    queries: the class reads them live, as the reference does."""
+    from kfdb_scene import fill, make_db_scene
+    kfs = make_db_scene(seed + 20, kf_per_map=30)
+    dbo = oracle.KeyFrameDatabase()
+    fill(dbo, kfs)
+    W = sw.World()
+    for m in range(3):
+        W.add_map(0)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
+    K = np.array([149.0, 149.0, 320.0, 240.0])
+    nokp = np.zeros(0, sw.KEYPOINT_DTYPE)
+    for j, k in enumerate(kfs):
+        i = W.add_keyframe(k["map_id"], k["mn_id"], ident, K, nokp)
+        assert i == j
+        W.kf_set_bow(i, k["ids"], k["vals"]); W.kf_set_uuid(i, k["uuid"])
+    for j, k in enumerate(kfs):
+        W.set_covisible(j, list(k["neigh"]), [100 - t for t in range(len(k["neigh"]))])
+        W.kf_set_connected(j, list(k["connected"]))
+    W.kfdb_create()
+    for j in range(len(kfs)):
+        W.kfdb_add(j)
+    rng = np.random.default_rng(seed)
+    alive = set(range(len(kfs)))
+    hits = 0
+    for step in range(90):
+        op = rng.random()
+        j = int(rng.choice(sorted(alive)))
+        q = kfs[j]
+        if op < 0.3:
+            m = int(rng.integers(0, 3))
+            ro = dbo.detect_merge_possibility(q["ids"], q["vals"], q["uuid"], m)
+            rg = W.kfdb_detect_merge_possibility(q["ids"], q["vals"], q["uuid"], m)
+            assert (ro[0], ro[1]) == rg, (step, ro, rg)
+            hits += ro[1] >= 0
+        elif op < 0.4:
+            m = int(rng.integers(0, 3))
+            assert dbo.merge_score(q["ids"], q["vals"], q["uuid"], m, 0.0) == W.kfdb_merge_score(q["ids"], q["vals"], q["uuid"], m, 0.0)
+        elif op < 0.65:
+            lo, mo = dbo.detect_n_best(j, 3)
+            lg, mg = W.kfdb_detect_n_best(j, 3)
+            assert np.array_equal(lo, lg) and np.array_equal(mo, mg), (step, lo, lg, mo, mg)
+            hits += len(lo) + len(mo) > 0
+        elif op < 0.85:
+            m = int(rng.integers(0, 3)); fid = int(rng.integers(1, 40))
+            co = dbo.detect_reloc(q["ids"], q["vals"], fid, m)
+            cg = W.kfdb_detect_reloc(q["ids"], q["vals"], fid, m)
+            assert np.array_equal(co, cg), (step, co, cg)
+            hits += len(co) > 0
+        elif op < 0.92 and len(alive) > 20:
+            dbo.erase(j); W.kfdb_erase(j); alive.discard(j)
+        else:
+            b = bool(rng.integers(0, 2))
+            dbo.set_bad(j, b); W.kf_set_bad(j, b)
+    assert hits > 15
