@@ -17,6 +17,7 @@
 #include "Sim3Solver_shim.h"
 #include "ORBVocabulary_shim.h"
 #include "KeyFrameDatabase_shim.h"
+#include "MapPoint_shim.h"
 #include "Frame_grid_shim.h"
 
 using namespace ORB_SLAM3;
@@ -298,6 +299,17 @@ int sw_vocab_compute_bow(World* w, const char* path, const uint8_t* desc, int n,
     for (const auto& e : fv) { fv_nodes[m] = (int32_t)e.first; for (unsigned i : e.second) fv_feat[t++] = (int32_t)i; fv_off[++m] = t; }
     *n_fv = m;
     *self_score = voc.score(bv, bv);
+    return 0;
+  });
+}
+
+// MapPoint::ComputeDistinctiveDescriptors: one by one (the member) or all of `mps` in one call (the batched form); out = 32 B per point
+int sw_compute_distinctive(World* w, const int32_t* mps, int n, int batched, uint8_t* out) {
+  return guarded(w, [&] {
+    std::vector<MapPoint*> v = mp_list(w, mps, n);
+    if (batched) MapPoint_ComputeDistinctiveDescriptorsBatch(v);
+    else for (MapPoint* p : v) p->ComputeDistinctiveDescriptors();
+    for (int i = 0; i < n; i++) { const cv::Mat d = v[i]->GetDescriptor(); std::memcpy(out + 32 * (size_t)i, d.data, 32); }
     return 0;
   });
 }

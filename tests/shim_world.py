@@ -227,6 +227,11 @@ class World:
         self._chk(self.L.sw_kfdb_detect_reloc(self.h, _p(i), _p(v), len(i), C.c_ulong(frame_id), m, _p(out), C.byref(n)))
         return out[:n.value].copy()
 
+    def compute_distinctive(self, mps, batched):
+        m = _i32(mps); out = np.zeros((len(m), 32), np.uint8)
+        self._chk(self.L.sw_compute_distinctive(self.h, _p(m), len(m), int(batched), _p(out)))
+        return out
+
     def vocab_compute_bow(self, path, desc, levelsup):
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
         n = len(d)

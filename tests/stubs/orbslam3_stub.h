@@ -74,6 +74,8 @@ class MapPoint {
   inline void AddObservation(KeyFrame* pKF, int idx);
   inline void SetBadFlag();
   inline void Replace(MapPoint* pMP);
+  void ComputeDistinctiveDescriptors();          // defined by host/MapPoint_shim.h
+  std::mutex mMutexFeatures;
   std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF) {       // (MapPoint.cc: (-1, -1) when the keyframe does not observe the point)
     const auto it = mObservations.find(pKF);
     return it == mObservations.end() ? std::tuple<int, int>(-1, -1) : it->second;

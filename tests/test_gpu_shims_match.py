@@ -412,3 +412,45 @@ def test_keyframe_database_class(oracle, seed):
             b = bool(rng.integers(0, 2))
             dbo.set_bad(j, b); W.kf_set_bad(j, b)
     assert hits > 15
+
+
+def test_mappoint_compute_distinctive_descriptors(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors, the member and the batched form: rows gathered from the observing keyframes in the
+    point's own observation order (bad keyframes skipped), the least-median row cloned into mDescriptor; bad points, points
+    without (good) observations keep what they had."""
+    rng = np.random.default_rng(12)
+    W = sw.World(); W.add_map(0)
+    K = np.array([149.0, 149.0, 320.0, 240.0]); ident = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
+    nkf, nkp = 14, 40
+    descs = []
+    base = rng.integers(0, 256, (nkp, 32), dtype=np.uint8)
+    for k in range(nkf):
+        d = base.copy()
+        flip = rng.random(d.shape) < 0.06
+        d[flip] ^= rng.integers(1, 256, int(flip.sum()), dtype=np.uint8)
+        descs.append(d)
+        kps = np.zeros(nkp, sw.KEYPOINT_DTYPE)
+        W.add_keyframe(0, k + 1, ident, K, kps, desc=d, bad=(k == 5))
+    mps = []
+    for i in range(nkp):
+        mps.append(W.add_mappoint(0, i, np.zeros(3, np.float32), bad=(i == 3)))
+        if i == 7:
+            continue                                    # no observation at all
+        seen = rng.choice(nkf, size=int(rng.integers(1, 13)), replace=False) if i != 9 else np.array([5])   # point 9: only the bad keyframe
+        for k in seen:
+            W.observe(int(k), mps[-1], i)
+    before = np.stack([np.zeros(32, np.uint8)] * nkp)
+    want = before.copy()
+    for i in range(nkp):
+        if i in (3, 7):
+            continue
+        rows = [descs[k][j] for k, j in W.mp_observations(mps[i]).items() if k != 5]      # the point's own std::map order
+        if not rows:
+            continue
+        r = np.stack(rows)
+        bi, _ = oracle.distinctive_descriptors(r.reshape(-1, 32), np.array([0, len(r)], np.int32))
+        want[i] = r[int(bi[0])]
+    got = W.compute_distinctive(mps, batched=False)
+    assert np.array_equal(got, want)
+    W2_got = W.compute_distinctive(mps, batched=True)
+    assert np.array_equal(W2_got, want)
