@@ -108,12 +108,33 @@ struct dvm_ba {
     stage.push_back({static_cast<uint8_t*>(q), cap, bytes});
     return static_cast<uint8_t*>(q);
   }
+  // The copies are queued and issued by flush_copies(): a problem set-up is two dozen small arrays, and neighbours in the device
+  // arena are neighbours in the staging chunk too (both sides advance in 256-byte steps), so runs of them leave as ONE
+  // hipMemcpyAsync -- each call costs the host ~5 us, a third of a local-BA window's whole set-up.
+  struct Pending { uint8_t* dst; const uint8_t* src; size_t bytes; };
+  std::vector<Pending> pending;
   int copy_in(void* dst, const void* src, size_t bytes) {
     if (!bytes) return DVM_OK;
-    uint8_t* st = stage_alloc(bytes);
-    if (!st) return hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");   // no pinned memory left: plain copy
+    uint8_t* st = stage_alloc((bytes + 255) & ~(size_t)255);
+    if (!st) {                                                            // no pinned memory left: plain copy, in order
+      const int rc = flush_copies();
+      return rc != DVM_OK ? rc : hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");
+    }
     std::memcpy(st, src, bytes);
-    return hip_check(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, stream), "upload");
+    if (!pending.empty()) {
+      Pending& l = pending.back();
+      const size_t lp = (l.bytes + 255) & ~(size_t)255;
+      if (l.dst + lp == static_cast<uint8_t*>(dst) && l.src + lp == st) { l.bytes = lp + bytes; return DVM_OK; }   // (the slack of the previous array travels along)
+    }
+    pending.push_back({static_cast<uint8_t*>(dst), st, bytes});
+    return DVM_OK;
+  }
+  int flush_copies() {
+    int rc = DVM_OK;
+    for (const Pending& c : pending)
+      if (rc == DVM_OK) rc = hip_check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, stream), "upload");
+    pending.clear();
+    return rc;
   }
   template <typename T>
   int upload(const T** dst, const std::vector<T>& v) {
@@ -126,6 +147,7 @@ struct dvm_ba {
   void free_problem() {           // the arenas stay: the next problem reuses them (callers have synchronised the stream)
     for (Chunk& c : chunks) c.used = 0;
     for (HostChunk& c : stage) c.used = 0;
+    pending.clear();
     have_problem = false;
   }
   void release_arena() {
@@ -423,6 +445,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   // the trial buffers start as copies: fixed cameras and unobserved landmarks are never rewritten
   ok(h->copy_in(V.poses_new, pn.data(), pn.size() * sizeof(double)));
   ok(h->copy_in(V.points_new, points, 3 * (size_t)L * sizeof(double)));
+  ok(h->flush_copies());                       // every array of the problem, merged into a few copies (copy_in)
   ok(hip_check(hipMemsetAsync(V.x, 0, ((size_t)n + 3 * (size_t)L) * sizeof(double), h->stream), "memset"));
   // (S is NOT cleared as a whole: every kernel touches structurally non-zero tiles only, and a trial's prologue clears exactly
   //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes.)
@@ -465,7 +488,8 @@ int dvm_ba_set_edge_flags(dvm_ba* h, const uint8_t* flags) {
   if (h->world > 1) { set_error("dvm_ba_set_edge_flags: not available on a landmark-sharded problem"); return DVM_ERR_STATE; }
   DVM_HIP(hipSetDevice(h->device));
   if (!flags) { h->V.e_flags = nullptr; return DVM_OK; }
-  const int rc = h->copy_in(h->d_flags, flags, (size_t)h->V.E);
+  int rc = h->copy_in(h->d_flags, flags, (size_t)h->V.E);
+  if (rc == DVM_OK) rc = h->flush_copies();
   if (rc == DVM_OK) h->V.e_flags = h->d_flags;
   return rc;
 }
