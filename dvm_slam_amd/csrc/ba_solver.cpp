@@ -121,19 +121,30 @@ struct dvm_ba {
       return rc != DVM_OK ? rc : hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload");
     }
     std::memcpy(st, src, bytes);
+    if (bytes > ((size_t)512 << 10)) {       // a large array goes out at once: its DMA runs under the staging of the next one
+      const int rc = flush_copies();
+      return rc != DVM_OK ? rc : hip_check(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, stream), "upload");
+    }
     if (!pending.empty()) {
       Pending& l = pending.back();
       const size_t lp = (l.bytes + 255) & ~(size_t)255;
-      if (l.dst + lp == static_cast<uint8_t*>(dst) && l.src + lp == st) { l.bytes = lp + bytes; return DVM_OK; }   // (the slack of the previous array travels along)
+      if (l.dst + lp == static_cast<uint8_t*>(dst) && l.src + lp == st) { l.bytes = lp + bytes; return queued(bytes); }   // (the slack of the previous array travels along)
     }
     pending.push_back({static_cast<uint8_t*>(dst), st, bytes});
-    return DVM_OK;
+    return queued(bytes);
+  }
+  // a large problem's arrays are megabytes: they go out while the host is still staging the next ones
+  size_t pending_bytes = 0;
+  int queued(size_t bytes) {
+    pending_bytes += bytes;
+    return pending_bytes > ((size_t)2 << 20) ? flush_copies() : DVM_OK;
   }
   int flush_copies() {
     int rc = DVM_OK;
     for (const Pending& c : pending)
       if (rc == DVM_OK) rc = hip_check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, stream), "upload");
     pending.clear();
+    pending_bytes = 0;
     return rc;
   }
   template <typename T>
@@ -148,6 +159,7 @@ struct dvm_ba {
     for (Chunk& c : chunks) c.used = 0;
     for (HostChunk& c : stage) c.used = 0;
     pending.clear();
+    pending_bytes = 0;
     have_problem = false;
   }
   void release_arena() {
