@@ -12,6 +12,8 @@
  * here from the published OpenCV 4.x algorithms; everything else follows
  * the reference file:line cited at each function.  The oracle is pinned only against independent
  * brute-force numpy restatements (tests/test_oracle_*.py) and the committed tests/golden vectors.
+ * (oracle/_ref -- `make _ref` -- holds the one piece of the reference that compiles from its own
+ * files, DUtils::Random; it pins the RANSAC draws of the Sim3Solver tests and nothing else.)
  */
 #ifndef DVM_ORACLE_H
 #define DVM_ORACLE_H

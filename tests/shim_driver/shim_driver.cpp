@@ -245,6 +245,15 @@ int sw_optimize_sim3(World* w, int kf1, int kf2, int32_t* matches1, double* S12,
   });
 }
 
+// 1 = DUtils::Random comes from oracle/_ref/libdutils_ref.so (the reference's Random.cpp), 0 = from the stub header
+int sw_dutils_is_reference() {
+#ifdef DVM_REF_DUTILS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 // Sim3Solver (LoopClosing.cc: `Sim3Solver solver(pKF, pKFi, vpMatches, fixScale, vpMatchedKF); solver.SetRansacParameters(0.99, min, max);
 // while (!converged && !noMore) T = solver.iterate(nPerCall, noMore, inliers, nInliers, converged);`) after srand(seed).
 // matches12: per keypoint of kf1 the matched map point (index, -1 none).  out16: the returned T12 (row-major 4x4); est: the getters

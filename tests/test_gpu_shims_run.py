@@ -8,6 +8,7 @@ LocalBundleAdjustment), :744-1028 (PoseOptimization), :1960-2212 (OptimizeSim3),
 import numpy as np
 import pytest
 
+import ref_dutils
 import shim_world as sw
 from dvm_slam_amd import synth
 
@@ -603,11 +604,19 @@ def test_sim3_solver_class(oracle, fix_scale):
     eps = np.float32(min_inl) / np.float32(n)
     its = int(np.ceil(np.log(1 - 0.99) / np.log(1 - float(eps) ** 3)))
     max_its_eff = max(1, min(its, max_its))
+    # the expectation draws with the reference's own DUtils::Random when oracle/_ref holds it (and then the driver is linked
+    # against the same object code: sw_dutils_is_reference), with the restatement tests/test_ref_dutils.py pins otherwise
+    ref_rng = ref_dutils.load_reference()
     libc = ctypes.CDLL("libc.so.6")
-    libc.srand(seed)
+    if ref_rng is not None:
+        assert W.L.sw_dutils_is_reference() == 1, "oracle/_ref/libdutils_ref.so is there but the shim driver was built without it"
+        ref_rng.seed(seed)
+        rand_int = ref_rng.random_int
+    else:
+        libc.srand(seed)
 
-    def rand_int(lo, hi):
-        return int((libc.rand() / (2147483647 + 1.0)) * (hi - lo + 1)) + lo
+        def rand_int(lo, hi):
+            return ref_dutils.python_random_int(libc, lo, hi)
     done, exp = 0, None
     best_n = 0
     calls = 0
