@@ -59,7 +59,9 @@ int pseudo_peripheral(const Graph& g, const std::vector<char>& in, int start) {
 }
 
 // nested dissection of the sub-graph `nodes`: returns the elimination order (separators last)
-void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vector<int>& out) {
+// (root_sep: how many entries at the END of `out` form the last piece's top separator -- their mutual order is free)
+void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vector<int>& out, int* root_sep = nullptr) {
+  if (root_sep) *root_sep = (int)std::min<size_t>(nodes.size(), 1);
   if (nodes.size() <= 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
   std::vector<char> in(g.size(), 0);
   for (int v : nodes) in[v] = 1;
@@ -73,6 +75,7 @@ void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vecto
     for (auto& l : lv) { cnt += l.size(); for (int v : l) done[v] = 1; }
     if (lv.size() < 3) {   // no interior level to cut at: a clique-like piece, eliminate as is
       for (auto& l : lv) out.insert(out.end(), l.begin(), l.end());
+      if (root_sep) *root_sep = 1;
       continue;
     }
     // separator = the level that best balances the two sides
@@ -91,37 +94,50 @@ void nested_dissection(const Graph& g, const std::vector<int>& nodes, std::vecto
     nested_dissection(g, A, out);
     nested_dissection(g, B, out);
     out.insert(out.end(), lv[mid].begin(), lv[mid].end());
+    if (root_sep) *root_sep = (int)lv[mid].size();
   }
 }
 }  // namespace
 
 namespace {
 // camera sequence `seq` (a banded order) -> tiles of 10 consecutive cameras -> nested dissection of the tile graph
-// -> final position of every camera
-std::vector<int> order_from_sequence(const Graph& g, const std::vector<int>& seq, int kCamsPerTile) {
+// -> final position of every camera.  When n is not a multiple of 10 one tile is short, and the row mapping
+// i -> (i / 10) * 64 + (i % 10) * 6 only allows it as the LAST tile of the elimination order: `short_at` says which group of
+// the sequence is the short one (the groups before and behind it are full); the dissection reports the tiles of its
+// top separator (`root_tiles`: their mutual order is free, so a short tile among them moves to the end at no cost).  A short
+// tile from further down is shifted to the end of the order too -- which costs a level of the dependency chain (the shifted
+// tile hangs below the root separator) -- so the caller re-tiles with the short group at one of `root_tiles`.
+std::vector<int> order_from_sequence(const Graph& g, const std::vector<int>& seq, int kCamsPerTile, int short_at, std::vector<int>* root_tiles) {
   const int n = (int)seq.size();
   const int nt = (n + kCamsPerTile - 1) / kCamsPerTile;
-  std::vector<int> tile_of(n);
-  for (int i = 0; i < n; i++) tile_of[seq[i]] = i / kCamsPerTile;
+  const int rem = n % kCamsPerTile;
+  if (rem == 0 || short_at < 0 || short_at >= nt) short_at = nt - 1;
+  const int s0 = short_at * kCamsPerTile, s1 = s0 + (rem ? rem : kCamsPerTile);   // sequence range of the short group
+  std::vector<int> tile_of(n), first(nt + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const int t = i < s0 ? i / kCamsPerTile : (i < s1 ? short_at : short_at + 1 + (i - s1) / kCamsPerTile);
+    tile_of[seq[i]] = t;
+    first[t + 1] = i + 1;
+  }
   Graph tg(nt);
   for (int a = 0; a < n; a++)
     for (int b : g[a]) if (tile_of[a] != tile_of[b]) tg[tile_of[a]].push_back(tile_of[b]);
   tg = clean(tg);
   std::vector<int> all_tiles(nt), torder;
   for (int t = 0; t < nt; t++) all_tiles[t] = t;
-  nested_dissection(tg, all_tiles, torder);
-  // a partially filled tile may only be the LAST one (row mapping i -> (i / 10) * 64 + (i % 10) * 6): if the short
-  // tile was moved forward by the dissection, shift it to the end of the order
-  if (n % kCamsPerTile != 0 && nt > 0 && torder.back() != nt - 1) {
+  int root_sep = 1;
+  nested_dissection(tg, all_tiles, torder, &root_sep);
+  if (root_tiles) root_tiles->assign(torder.end() - std::min<int>(root_sep, nt), torder.end());
+  if (rem != 0 && nt > 0 && torder.back() != short_at) {   // (inside the root separator the move is free: its tiles are a chain anyway)
     std::vector<int> t2;
-    for (int t : torder) if (t != nt - 1) t2.push_back(t);
-    t2.push_back(nt - 1);
+    for (int t : torder) if (t != short_at) t2.push_back(t);
+    t2.push_back(short_at);
     torder.swap(t2);
   }
   std::vector<int> pos(n, -1);
   int p = 0;
   for (int t : torder)
-    for (int i = t * kCamsPerTile; i < std::min(n, (t + 1) * kCamsPerTile); i++) pos[seq[i]] = p++;
+    for (int i = first[t]; i < first[t + 1]; i++) pos[seq[i]] = p++;
   return pos;
 }
 
@@ -159,9 +175,26 @@ std::vector<int> ba_order_cameras(const std::vector<std::vector<int>>& adj_in, i
         for (int v : l) { cm.push_back(v); placed[v] = 1; }
     }
   }
-  const std::vector<int> p1 = order_from_sequence(g, natural, per_tile), p2 = order_from_sequence(g, cm, per_tile);
-  const auto e1 = evaluate(g, p1, per_tile), e2 = evaluate(g, p2, per_tile);
-  return (e1 < e2 || e1 == e2) ? p1 : p2;   // shortest dependency chain, then least fill
+  // per candidate sequence: the short tile at the end of the sequence first, then where the dissection wants its last tile
+  std::vector<int> best;
+  std::pair<int, double> best_e{1 << 30, 0.0};
+  const int nt = (n + per_tile - 1) / per_tile;
+  for (const std::vector<int>* seq : {&natural, &cm}) {
+    std::vector<int> todo{nt - 1}, tried;
+    for (int attempt = 0; attempt < 6 && !todo.empty(); attempt++) {
+      const int short_at = todo.back();
+      todo.pop_back();
+      tried.push_back(short_at);
+      std::vector<int> root;
+      const std::vector<int> p = order_from_sequence(g, *seq, per_tile, short_at, &root);
+      const auto e = evaluate(g, p, per_tile);
+      if (e < best_e) { best_e = e; best = p; }   // shortest dependency chain, then least fill; ties keep the earlier candidate
+      if (n % per_tile == 0 || std::find(root.begin(), root.end(), short_at) != root.end()) break;
+      for (int t : root)
+        if (std::find(tried.begin(), tried.end(), t) == tried.end() && std::find(todo.begin(), todo.end(), t) == todo.end()) todo.push_back(t);
+    }
+  }
+  return best;
 }
 
 BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {

@@ -451,6 +451,7 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
 
 #ifdef DVM_FAST_DEBUG
 __device__ unsigned long long g_fast_dbg[8192 * 8];
+__device__ unsigned int g_fast_hist[96];   // [0,32): survivors per wave / 8; [32,64): corners per wave / 4; [64,96): survivors per cell / 8
 #define DVM_FSTAMP(i) do { if (threadIdx.x == 0) { const long long t_ = __builtin_readcyclecounter(); unsigned long long* g_ = g_fast_dbg + (blockIdx.x & 8191) * 8; if (i) g_[i] += (unsigned long long)(t_ - t_prev_); else g_[0] += 1ull; t_prev_ = t_; } } while (0)
 #else
 #define DVM_FSTAMP(i) do { } while (0)
@@ -609,6 +610,9 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     }
   }
   DVM_FSTAMP(2);
+#ifdef DVM_FAST_DEBUG
+  if (lane == 0 && pass == 0) atomicAdd(&g_fast_hist[min(wcount >> 3, 31)], 1u);
+#endif
   // ---- B. per wave, no barrier: full strength of the wave's OWN survivors.  Corners (score > 0) are compacted in
   // place at the head of the wave's list -- the write position never passes the read position -- with their scores
   // at the same offsets of `pscore`; the four corner lists concatenated are still row-major.
@@ -633,6 +637,9 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     ncorner += __popcll(bc);
   }
   DVM_FSTAMP(3);
+#ifdef DVM_FAST_DEBUG
+  if (lane == 0 && pass == 0) atomicAdd(&g_fast_hist[32 + min(ncorner >> 2, 31)], 1u);
+#endif
   __syncthreads();   // the score map is complete
   DVM_FSTAMP(4);
   // ---- C. per wave: strict local maxima among its corners; bit0 = passes iniTh, bit1 = passes minTh
@@ -721,6 +728,12 @@ extern "C" int dvm_debug_fast_stamps(unsigned long long* out, int reset) {
   static unsigned long long h[8192 * 8];
   int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast_dbg), sizeof(h));
   for (int i = 0; i < 16; i++) out[i] = 0;
+  {
+    unsigned int hh[96];
+    rc |= (int)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_fast_hist), sizeof(hh));
+    for (int i = 0; i < 96; i++) out[16 + i] = hh[i];
+    if (reset) { for (auto& v : hh) v = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_hist), hh, sizeof(hh)); }
+  }
   for (int b = 0; b < 8192; b++) for (int i = 0; i < 8; i++) out[i] += h[b * 8 + i];
   if (reset) { for (auto& v : h) v = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_dbg), h, sizeof(h)); }
   return rc;

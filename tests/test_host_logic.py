@@ -26,9 +26,21 @@ def test_ba_ordering_and_level_schedule(tmp_path):
                  ["10", "9", "0"], ["11", "2", "1"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True)
         assert out.returncode == 0, (args, out.stdout + out.stderr)
-    out = subprocess.run([str(exe), "499", "7", "1"], capture_output=True, text=True)
-    levels = int(out.stdout.split("levels=")[1].split()[0])
-    assert levels <= 16, out.stdout   # 51 tile columns, one after the other, before the reordering
+    def levels(n, loop):
+        out = subprocess.run([str(exe), str(n), "7", loop], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return int(out.stdout.split("levels=")[1].split()[0])
+    # a ring of 50 tiles: 7 levels of tile columns (two paths of 24 -> 5, the two-tile root separator -> 2) + the rhs tile;
+    # 51 tile columns one after the other before the reordering
+    assert levels(500, "1") == 8
+    # a partially filled tile may only be the LAST of the elimination order: the tiling is chosen so that the short tile lies in
+    # the dissection's root separator -- it must not cost a level (it did: 9 at 499 cameras, the bench problem).  A short tile
+    # of fewer cameras than the co-visibility span cannot separate its neighbours, there the extra level stays.
+    for n in (497, 499, 507):
+        assert levels(n, "1") == 8, n
+        assert levels(n, "0") == 7, n
+    for n in (491, 495, 501):
+        assert levels(n, "1") <= 9, n
 
 
 def test_generated_cholesky_panel_is_in_sync(tmp_path):
