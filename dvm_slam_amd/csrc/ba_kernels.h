@@ -71,6 +71,7 @@ struct BaView {
   int32_t nlevels;
   int32_t pair_a, pair_b;   // tile columns of the top pair (ba_ordering.h: BaTileSchedule::pair_a / pair_b) and pair_ok = 1, or pair_ok = 0
   int32_t pair_ok;
+  int32_t diag_in_level;    // levels of <= 256 slice workgroups factor their diagonal tiles inside k_chol_trsm_update<true> (0: DVM_BA_NO_DIAG_IN_LEVEL)
   int32_t n_root_raw;       // columns of the last launched level whose only strip is the rhs row: their panel solve (one 64x64
                             // matrix-vector product each) is done by the back substitution itself, no k_chol_trsm launch (0: launch it)
   const double* lambda;     // device scalar with the current LM damping (pose graph), or null: use lambda_v

@@ -1306,14 +1306,99 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
 // polls the flags with relaxed agent-scope loads on a few lanes and reads the strips with agent-scope loads (no L1, and the
 // XCD's L2 cannot hold these lines yet: nothing in this launch reads a strip before its flag).  No deadlock: the launcher
 // only uses this kernel when the whole grid is resident at once; a wait is bounded anyway and flags the trial as failed.
-__global__ void __launch_bounds__(256) k_chol_trsm_update(double* __restrict__ S, int ldS, int n1, const double* __restrict__ Linv_all,
+//
+// kDiag: the level's k_chol_diag launch is folded in as well.  Every slice workgroup factors its column's diagonal tile ITSELF
+// (chol_diag_tile in its own LDS: the 12 workgroups of a column with three strips do the same work and get the same bits) while
+// its 16 strip rows are already on their way from memory, and multiplies by the L^-1 it finds in LDS: the level loses a kernel
+// boundary and the L^-1 store -> load round trip (~2.5 us of ~19); the column's first slice workgroup stores L^-1 for the back
+// substitution afterwards, off the critical path.  86 KB of LDS: one workgroup per CU, so the launcher uses it for levels of
+// <= 256 workgroups (slices + quadrants, or the slices alone with the update as a second launch).
+template <bool kDiag>
+__global__ void __launch_bounds__(256) k_chol_trsm_update(double* __restrict__ S, int ldS, int n1, double* __restrict__ Linv_all,
                                                           const int32_t* __restrict__ strips, int strip_base, int n_trsm,
                                                           const int32_t* __restrict__ targets, const int32_t* __restrict__ contrib,
                                                           const int32_t* __restrict__ contrib_strip, int32_t* __restrict__ flags,
                                                           int gen, int gen_pub, int* __restrict__ fail, double* __restrict__ xrow_tag, int n_tag) {
-  __shared__ double smem[16 * QP + NB * QP];     // trsm: Ai (16 rows) + Li (64 rows); update: Ai + Aj (32 rows each)
+  // trsm: Ai (16 rows) + Li (64 rows); update: Ai + Aj (32 rows each); kDiag: the layout of k_chol_diag (Ai over Pcol / Iv)
+  __shared__ __attribute__((aligned(16))) double smem[kDiag ? 16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP : 16 * QP + NB * QP];
   const int tid = threadIdx.x;
   if (xrow_tag && blockIdx.x == 0) tag_xrow(xrow_tag, n_tag);
+  if (kDiag && (int)blockIdx.x < n_trsm) {
+    const int st = blockIdx.x >> 2, sl = blockIdx.x & 3, qi = sl * 16;
+    const int kb = strips[2 * st + 1];
+    const int k0 = kb * NB;
+    const int r0 = strips[2 * st] * NB;
+    const int rw = min(NB, n1 - r0);
+    if (qi < rw) {
+      lds_f64* const lds = (lds_f64*)smem;
+      lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;
+      lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);
+      lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;
+      lds_f64* const Bm = Id + 16 * 16;
+      lds_f64* const Li = Bm + NB * LP;
+      const int kw = min(NB, n1 - k0);
+      // this slice's 16 strip rows: in flight during the whole factorisation
+      const int sr = tid >> 4, sc = 4 * (tid & 15);
+      const double* src = S + (size_t)(r0 + min(qi + sr, rw - 1)) * ldS + k0 + sc;
+      const double2 a0 = *reinterpret_cast<const double2*>(src), a1 = *reinterpret_cast<const double2*>(src + 2);
+      {
+        double2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+          v[i] = *reinterpret_cast<const double2*>(S + (size_t)(k0 + min(r, kw - 1)) * ldS + k0 + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int r = 8 * i + (tid >> 5), c = 2 * (tid & 31);
+          const bool in = r < kw;
+          Bm[r * LP + c] = in ? v[i].x : (r == c ? 1.0 : 0.0);
+          Bm[r * LP + c + 1] = in ? v[i].y : (r == c + 1 ? 1.0 : 0.0);
+        }
+      }
+      Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+      __syncthreads();
+      const DiagLds D = {Pcol, Iv, Id, Bm, Li};
+      chol_diag_tile(D, fail);                    // (ends behind a barrier: Pcol / Iv are free)
+      lds_f64* const Ai = lds;
+      {
+        const bool in = qi + sr < rw;
+        Ai[sr * QP + sc] = in ? a0.x : 0.0; Ai[sr * QP + sc + 1] = in ? a0.y : 0.0;
+        Ai[sr * QP + sc + 2] = in ? a1.x : 0.0; Ai[sr * QP + sc + 3] = in ? a1.y : 0.0;
+      }
+      __syncthreads();
+      const int wave = tid >> 6, lane = tid & 63;
+      const int wj = wave * 16;
+      const int lr = lane & 15, lk = lane >> 4;
+      double4_t acc = {0, 0, 0, 0};
+      // X = A L^-T: column block `wave` of X needs the k-blocks 0..wave of L^-1 (the blocks above its diagonal were never written in
+      // LDS; in the stored L^-1 they are zeros, so the products left out here are the exact zeros the two-launch form adds)
+      for (int k = 0; k < 16 * (wave + 1); k += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[lr * QP + k + lk], Li[(wj + lr) * LP + k + lk], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = qi + lk + 4 * r, col = wj + lr;
+        if (row < rw && col < kw) __hip_atomic_store(S + (size_t)(r0 + row) * ldS + k0 + col, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + 4 * (strip_base + st) + sl, gen_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // L^-1 for the back substitution: the first slice of the column's first strip (a level lists a column's strips together)
+      if (sl == 0 && (st == 0 || strips[2 * (st - 1) + 1] != kb)) {
+        double* Lo = Linv_all + (size_t)kb * NB * NB;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int r = 8 * k + (tid >> 5), c = 2 * (tid & 31);
+          const bool lower = (c >> 4) <= (r >> 4);
+          const double2 v = lower ? make_double2(Li[r * LP + c], Li[r * LP + c + 1]) : make_double2(0.0, 0.0);
+          *reinterpret_cast<double2*>(Lo + r * NB + c) = v;
+        }
+      }
+      return;
+    }
+    if (tid == 0) __hip_atomic_store(flags + 4 * (strip_base + st) + sl, gen_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if ((int)blockIdx.x < n_trsm) {
     double* Ai = smem;
     double* Li = smem + 16 * QP;
@@ -2606,6 +2691,7 @@ __global__ void __launch_bounds__(256) k_clear_tiles(BaView V) { clear_tile(V, b
 void ba_launch_clear_tiles(hipStream_t s, const BaView& V) {
   if (V.nfree > 0 && V.n_nz > 0) hipLaunchKernelGGL(k_clear_tiles, dim3(V.n_nz), dim3(256), 0, s, V);
 }
+constexpr int kDiagLevelMaxWGs = 256;    // k_chol_trsm_update<true>: 86 KB of LDS, one workgroup per CU
 constexpr int kFusedLevelMaxWGs = 512;   // 2 workgroups per CU on 256 CUs (3 fit: 41 KB of LDS each); the leaf level of the BASELINE problem (536) measured the same fused or not
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
@@ -2613,6 +2699,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   // test switch: the slices publish a sequence number nobody waits for, so every wait times out and the caller's retry path
   // (one launch per phase) has to produce the result (tests/test_gpu_ba.py)
   static const bool break_handoff = std::getenv("DVM_BA_DEBUG_BREAK_HANDOFF") != nullptr;
+  const bool diag_in_level = V.diag_in_level != 0;   // (A/B switch DVM_BA_NO_DIAG_IN_LEVEL, read by dvm_ba_set_problem)
   double* tag = V.xrow;   // the first launch that solves strips also re-arms the back substitution's hand-off slots (no strips: no waits)
   int root_level = V.nlevels - 1;          // the last level that is launched (see the break below), where n_root_raw applies
   if (root_level >= 1 && V.h_level_off[root_level + 1] - V.h_level_off[root_level] == 1 && V.h_strip_off[root_level + 1] == V.h_strip_off[root_level] &&
@@ -2626,17 +2713,29 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
     // the root of the elimination tree is the tile of the augmented rhs row: its "factorisation" (one scalar) is never
     // used -- row n_pad already holds y = L^-1 b once the last camera level is done -- so that level is not launched
     if (h == V.nlevels - 1 && nc == 1 && ns == 0 && nt == 0) break;
+    const bool raw_root = ns > 0 && nt == 0 && V.n_root_raw > 0 && h == root_level;   // the back substitution solves these rhs strips itself
+    // the whole level -- factorisation of the diagonal tiles included -- as one launch (k_chol_trsm_update<true>): one workgroup
+    // per CU, so only while slices + quadrants fit the chip at once; else the slices alone that way and the update behind them
+    const bool all = nt > 0 && 4 * (ns + nt) <= kDiagLevelMaxWGs;
+    if (diag_in_level && !raw_root && ns > 0 && V.contrib_strip && V.strip_flags && 4 * ns <= kDiagLevelMaxWGs) {
+      hipLaunchKernelGGL(k_chol_trsm_update<true>, dim3(4 * (ns + (all ? nt : 0))), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv,
+                         V.strips + 2 * (size_t)V.h_strip_off[h], V.h_strip_off[h], 4 * ns, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib,
+                         V.contrib_strip, V.strip_flags, solve_seq, break_handoff ? -1 : solve_seq, d_fail, tag, V.n_pad);
+      tag = nullptr;
+      if (nt > 0 && !all) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
+      continue;
+    }
     hipLaunchKernelGGL(k_chol_diag, dim3(nc), dim3(256), 0, s, V.S, V.ldS, n1, V.cols + V.h_level_off[h], d_fail, V.Linv);
     // solve + update of the level as ONE launch when every workgroup of it is resident at once (a quadrant then never waits
     // for a slice that has no compute unit to run on): 41 KB of LDS per workgroup = 3 per CU
     if (ns > 0 && nt > 0 && 4 * (ns + nt) <= kFusedLevelMaxWGs && V.contrib_strip && V.strip_flags) {
-      hipLaunchKernelGGL(k_chol_trsm_update, dim3(4 * (ns + nt)), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h],
+      hipLaunchKernelGGL(k_chol_trsm_update<false>, dim3(4 * (ns + nt)), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h],
                          V.h_strip_off[h], 4 * ns, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib, V.contrib_strip, V.strip_flags, solve_seq,
                          break_handoff ? -1 : solve_seq, d_fail, tag, V.n_pad);
       tag = nullptr;
       continue;
     }
-    if (ns > 0 && nt == 0 && V.n_root_raw > 0 && h == root_level) continue;   // the back substitution solves these rhs strips itself
+    if (raw_root) continue;
     if (ns > 0) { hipLaunchKernelGGL(k_chol_trsm, dim3(4 * ns), dim3(256), 0, s, V.S, V.ldS, n1, V.Linv, V.strips + 2 * (size_t)V.h_strip_off[h], tag, V.n_pad); tag = nullptr; }
     if (nt > 0) hipLaunchKernelGGL(k_chol_update, dim3(4 * nt), dim3(256), 0, s, V.S, V.ldS, n1, V.targets + 4 * (size_t)V.h_tgt_off[h], V.contrib);
   }

@@ -391,6 +391,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   h->tile_fill = SC.fill;
   V.nlevels = SC.nlevels;
   V.pair_ok = SC.pair_a >= 0 && std::getenv("DVM_BA_NO_PAIR") == nullptr; V.pair_a = SC.pair_a; V.pair_b = SC.pair_b;   // (DVM_BA_NO_PAIR: A/B switch)
+  V.diag_in_level = std::getenv("DVM_BA_NO_DIAG_IN_LEVEL") == nullptr;
   V.n_root_raw = SC.n_root_raw;   // (ba_ordering.h: the last launched level's panel solve left to the back substitution)
 
   int rc = DVM_OK;

@@ -98,6 +98,29 @@ def test_ba_top_pair_kernel_matches_level_launches(capi, oracle, n_kf, n_pts, mo
     assert np.abs(pa - pb).max() < 1e-8 and np.abs(xa - xb).max() < 1e-8
 
 
+@pytest.mark.parametrize("n_kf,n_pts", [(60, 2000), (240, 8000)])
+def test_ba_diag_in_level_kernel_is_bit_identical(capi, oracle, n_kf, n_pts, monkeypatch):
+    """Levels of <= 256 slice workgroups factor their diagonal tiles inside the level's own launch (k_chol_trsm_update<true>: every
+    slice workgroup factors its column's tile in its LDS instead of reading L^-1 from a k_chol_diag launch).  Same operations in the
+    same order -- the products it leaves out are the zeros above L^-1's diagonal blocks -- so the results equal those of the separate
+    launches (DVM_BA_NO_DIAG_IN_LEVEL=1) bit for bit."""
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(n_kf=n_kf, n_pts=n_pts, seed=3 * n_kf)
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    out = []
+    for separate in (False, True):
+        if separate:
+            monkeypatch.setenv("DVM_BA_NO_DIAG_IN_LEVEL", "1")
+        ba = capi.BundleAdjuster()
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], float(np.sqrt(5.991)))
+        st = ba.optimize(6)
+        out.append((st, *ba.result()))
+        ba.close()
+    (sa, pa, xa), (sb, pb, xb) = out
+    assert sa["trials"] == sb["trials"] and sa["iterations"] == sb["iterations"] and sa["chi2"] == sb["chi2"]
+    assert np.array_equal(pa, pb) and np.array_equal(xa, xb)
+
+
 def test_ba_fixed_cameras_and_unobserved(capi, oracle):
     """LBA shape: several fixed cameras observing the window's landmarks, a camera and a landmark without edges."""
     from dvm_slam_amd import synth

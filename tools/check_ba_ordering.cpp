@@ -99,6 +99,10 @@ int main(int argc, char** argv) {
   }
   std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu pair=%d,%d\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
               S.targets.size() / 4, S.pair_a, S.pair_b);
+  if (std::getenv("DVM_ORDER_VERBOSE"))
+    for (int h = 0; h < S.nlevels; h++)
+      std::printf("  level %d: %d columns, %d strips, %d targets\n", h, S.level_off[h + 1] - S.level_off[h], S.strip_off[h + 1] - S.strip_off[h],
+                  S.tgt_off[h + 1] - S.tgt_off[h]);
   if (loop && n >= 300 && S.nlevels > nt / 2) return fail("nested dissection did not shorten the dependency chain");
   return 0;
 }
