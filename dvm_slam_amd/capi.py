@@ -58,6 +58,12 @@ class FrustumFrame(C.Structure):
                 ("max_y", C.c_float), ("bf", C.c_float), ("log_scale_factor", C.c_float), ("n_levels", C.c_int32)]
 
 
+class TriPair(C.Structure):   # == dvm_tri_pair
+    _fields_ = [("cos_parallax_max", C.c_double), ("K1", C.c_float * 4), ("K2", C.c_float * 4), ("T1w", C.c_float * 12), ("T2w", C.c_float * 12),
+                ("Ow1", C.c_float * 3), ("Ow2", C.c_float * 3), ("ratio_factor", C.c_float), ("th_far", C.c_float), ("far_points", C.c_int32),
+                ("n_levels", C.c_int32)]
+
+
 TRACK_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"),
                         ("level", "<i4"), ("in_view", "<i4")])
 
@@ -501,6 +507,27 @@ def is_in_frustum(F: "FrustumFrame", P, normal, min_dist, max_dist, viewing_cos_
     check(lib().dvm_is_in_frustum(C.byref(F), _p(P), _p(normal), _p(min_dist), _p(max_dist), len(P), float(viewing_cos_limit),
                                   _p(out), 0, None))
     return out
+
+
+def triangulate_matches(K1, K2, T1w, T2w, Ow1, Ow2, kps1, kps2, pairs, sigma2_1, sigma2_2, sf1, sf2, ratio_factor,
+                        cos_parallax_max=0.9998, far_points=False, th_far=0.0):
+    """LocalMapping::CreateNewMapPoints' per-match geometry for one neighbour keyframe (dvm_triangulate_matches).
+    Returns (x3D[n,3] float32, status[n] int32)."""
+    P = TriPair()
+    P.cos_parallax_max = float(cos_parallax_max)
+    for name, v, k in (("K1", K1, 4), ("K2", K2, 4), ("T1w", T1w, 12), ("T2w", T2w, 12), ("Ow1", Ow1, 3), ("Ow2", Ow2, 3)):
+        setattr(P, name, (C.c_float * k)(*np.asarray(v, np.float32).reshape(-1)))
+    f = [np.ascontiguousarray(x, np.float32) for x in (sigma2_1, sigma2_2, sf1, sf2)]
+    P.ratio_factor = float(ratio_factor); P.th_far = float(th_far); P.far_points = int(far_points); P.n_levels = len(f[0])
+    k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+    pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    n = len(pr)
+    X = np.zeros((n, 3), np.float32); st = np.zeros(n, np.int32)
+    L = lib()
+    L.dvm_triangulate_matches.restype = C.c_int
+    L.dvm_triangulate_matches.argtypes = [C.POINTER(TriPair), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    check(L.dvm_triangulate_matches(C.byref(P), _p(k1), len(k1), _p(k2), len(k2), _p(pr), n, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(X), _p(st), 0, None))
+    return X, st
 
 
 def undistort_keypoints(cam, kps, d_in=None, d_out=None, n=None, stream=None):

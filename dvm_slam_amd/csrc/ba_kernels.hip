@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "ba_kernels.h"
+#include "jacobi4.h"
 
 namespace dvm {
 
@@ -2344,29 +2345,7 @@ void ba_launch_optimize_sim3(hipStream_t s, double* S12io, int fix_scale, const 
 // communication), the N correspondences are strided over the lanes, inliers counted by ballots.  The minimal sets are
 // input (the reference draws them with DUtils::Random).  float / double split as in the reference except the 4x4
 // eigen-decomposition: cyclic Jacobi in double ("Horn spec", same as the oracle) instead of Eigen::EigenSolver<float>.
-__device__ __forceinline__ void jacobi4_dev(double A[4][4], double V[4][4]) {
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 16; sweep++) {
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-      for (int q = p + 1; q < 4; q++) {
-        if (A[p][q] == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
-      }
-  }
-}
+// (jacobi4_dev: jacobi4.h)
 
 __global__ void __launch_bounds__(64) k_sim3_hypotheses(const float* __restrict__ P1c, const float* __restrict__ P2c,
                                                         const float* __restrict__ max_err1, const float* __restrict__ max_err2,

@@ -436,6 +436,45 @@ int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const floa
   return rc == DVM_OK ? st.download() : rc;
 }
 
+int dvm_triangulate_matches(const dvm_tri_pair* pair, const dvm_keypoint* kps1, int n1, const dvm_keypoint* kps2, int n2,
+                            const int32_t* pairs, int n, const float* sigma2_1, const float* sigma2_2, const float* scale_factors_1,
+                            const float* scale_factors_2, float* x3D, int32_t* status, int on_device, void* stream) {
+  static_assert(sizeof(dvm_tri_pair) == sizeof(TriPair) && sizeof(dvm_keypoint) == sizeof(dvm_keypoint_pod), "layout");
+  if (!pair || n < 0 || n1 < 0 || n2 < 0) return DVM_ERR_INVALID;
+  if (n == 0) return DVM_OK;
+  if (!kps1 || !kps2 || !pairs || !sigma2_1 || !sigma2_2 || !scale_factors_1 || !scale_factors_2 || !x3D || !status) return DVM_ERR_INVALID;
+  if (pair->n_levels <= 0 || pair->n_levels > 64) { set_error("dvm_triangulate_matches: n_levels out of range"); return DVM_ERR_INVALID; }
+  if (!(pair->K1[0] != 0.0f) || !(pair->K1[1] != 0.0f) || !(pair->K2[0] != 0.0f) || !(pair->K2[1] != 0.0f)) {
+    set_error("dvm_triangulate_matches: zero focal length");
+    return DVM_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  TriPair P;
+  std::memcpy(&P, pair, sizeof(P));
+  if (on_device) {
+    launch_triangulate_matches((hipStream_t)stream, P, reinterpret_cast<const dvm_keypoint_pod*>(kps1), n1, reinterpret_cast<const dvm_keypoint_pod*>(kps2), n2,
+                               pairs, n, sigma2_1, sigma2_2, scale_factors_1, scale_factors_2, x3D, status);
+    return hip_check(hipGetLastError(), "triangulate_matches launch");
+  }
+  for (int m = 0; m < n; m++)
+    if (pairs[2 * m] < 0 || pairs[2 * m] >= n1 || pairs[2 * m + 1] < 0 || pairs[2 * m + 1] >= n2) {
+      set_error("dvm_triangulate_matches: match index out of range");
+      return DVM_ERR_INVALID;
+    }
+  const size_t N = (size_t)n, L = (size_t)P.n_levels;
+  Stage st;
+  const int iK1 = st.in(kps1, (size_t)n1 * sizeof(dvm_keypoint)), iK2 = st.in(kps2, (size_t)n2 * sizeof(dvm_keypoint)), iP = st.in(pairs, N * 8),
+            iS1 = st.in(sigma2_1, L * 4), iS2 = st.in(sigma2_2, L * 4), iF1 = st.in(scale_factors_1, L * 4), iF2 = st.in(scale_factors_2, L * 4),
+            oX = st.out(x3D, N * 12), oS = st.out(status, N * 4);
+  int rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_triangulate_matches(nullptr, P, st.ptr<dvm_keypoint_pod>(iK1), n1, st.ptr<dvm_keypoint_pod>(iK2), n2, st.ptr<int32_t>(iP), n, st.ptr<float>(iS1),
+                             st.ptr<float>(iS2), st.ptr<float>(iF1), st.ptr<float>(iF2), st.ptr<float>(oX), st.ptr<int32_t>(oS));
+  rc = hip_check(hipGetLastError(), "launch");
+  return rc == DVM_OK ? st.download() : rc;
+}
+
 int dvm_undistort_keypoints(const dvm_distortion* cam, const dvm_keypoint* kps_in, dvm_keypoint* kps_out, int n, int on_device, void* stream) {
   static_assert(sizeof(dvm_distortion) == sizeof(dvm_undistort::Camera) && sizeof(dvm_keypoint) == 28, "layout");
   if (!cam || n < 0) return DVM_ERR_INVALID;

@@ -60,6 +60,12 @@ struct TrackPoint {  // == dvm_track_point
   float proj_x, proj_y, proj_xr, depth, view_cos;
   int32_t level, in_view;
 };
+struct TriPair {  // == dvm_tri_pair
+  double cos_parallax_max;
+  float K1[4], K2[4], T1w[12], T2w[12], Ow1[3], Ow2[3];
+  float ratio_factor, th_far;
+  int32_t far_points, n_levels;
+};
 struct ProjectCam {  // == dvm_kf_camera (+ th)
   float q[4], t[3];       // Tcw as Sophus::SE3f stores it: unit quaternion (x, y, z, w) + translation
   float Ow[3], fx, fy, cx, cy, min_x, max_x, min_y, max_y, log_scale_factor;
@@ -85,6 +91,9 @@ void launch_match_triangulation(hipStream_t s, const uint8_t* desc1, const dvm_k
                                 const TriGeom& G, const float* scale_factors2, const float* level_sigma2_2, int32_t* best_idx,
                                 int32_t* best_dist);
 void launch_undistort_keypoints(hipStream_t s, const dvm_undistort::Camera& cam, const float* in, float* out, int n);
+void launch_triangulate_matches(hipStream_t s, const TriPair& P, const dvm_keypoint_pod* kps1, int n1, const dvm_keypoint_pod* kps2, int n2,
+                                const int32_t* pairs, int n, const float* sigma2_1, const float* sigma2_2, const float* sf1,
+                                const float* sf2, float* x3D, int32_t* status);
 void launch_is_in_frustum(hipStream_t s, const FrustumFrame& F, const float* P, const float* normal, const float* min_dist,
                           const float* max_dist, int n, float cos_limit, TrackPoint* out);
 void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_stride, const uint8_t* desc,

@@ -13,6 +13,7 @@
 #include "match_kernels.h"
 #include "pose_f32.h"
 #include "undistort_f64.h"
+#include "jacobi4.h"
 
 namespace dvm {
 
@@ -499,6 +500,102 @@ __global__ void __launch_bounds__(256) k_is_in_frustum(FrustumFrame F, const flo
     }
   }
   out[i] = o;
+}
+
+// LocalMapping::CreateNewMapPoints, the geometry of one neighbour keyframe's matches (reference src/LocalMapping.cc:598-741, monocular
+// pinhole branch; GeometricTools::Triangulate src/GeometricTools.cc:48-67): thread per match.  Parallax of the two rays, the
+// homogeneous point (null vector of the 4x4 system: eigenvector of the smallest eigenvalue of A^T A by cyclic Jacobi in double --
+// the reference runs Eigen::JacobiSVD<Matrix4f>, tolerance parity), depth, reprojection error and scale-consistency tests in float
+// in Eigen's evaluation order, comparisons with double literals in double.  status: include/dvmslam_hip.h.
+__global__ void __launch_bounds__(128) k_triangulate_matches(TriPair P, const dvm_keypoint_pod* __restrict__ kps1, int n1,
+                                                             const dvm_keypoint_pod* __restrict__ kps2, int n2,
+                                                             const int32_t* __restrict__ pairs, int n, const float* __restrict__ sigma2_1,
+                                                             const float* __restrict__ sigma2_2, const float* __restrict__ sf1,
+                                                             const float* __restrict__ sf2, float* __restrict__ x3D_out,
+                                                             int32_t* __restrict__ status) {
+  const int m = blockIdx.x * 128 + threadIdx.x;
+  if (m >= n) return;
+  using dvm_pose::sum3;
+  float* X = x3D_out + 3 * (int64_t)m;
+  X[0] = X[1] = X[2] = 0.0f;
+  const int i1 = pairs[2 * m], i2 = pairs[2 * m + 1];
+  if (i1 < 0 || i1 >= n1 || i2 < 0 || i2 >= n2) { status[m] = -1; return; }
+  const dvm_keypoint_pod kp1 = kps1[i1], kp2 = kps2[i2];
+  if (kp1.octave < 0 || kp1.octave >= P.n_levels || kp2.octave < 0 || kp2.octave >= P.n_levels) { status[m] = -1; return; }
+  const float* T1w = P.T1w;
+  const float* T2w = P.T2w;
+  const float xn1[3] = {(kp1.x - P.K1[2]) / P.K1[0], (kp1.y - P.K1[3]) / P.K1[1], 1.0f};
+  const float xn2[3] = {(kp2.x - P.K2[2]) / P.K2[0], (kp2.y - P.K2[3]) / P.K2[1], 1.0f};
+  float r1[3], r2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    r1[i] = sum3(T1w[i] * xn1[0], T1w[4 + i] * xn1[1], T1w[8 + i] * xn1[2]);
+    r2[i] = sum3(T2w[i] * xn2[0], T2w[4 + i] * xn2[1], T2w[8 + i] * xn2[2]);
+  }
+  const float nr1 = sqrtf(sum3(r1[0] * r1[0], r1[1] * r1[1], r1[2] * r1[2])), nr2 = sqrtf(sum3(r2[0] * r2[0], r2[1] * r2[1], r2[2] * r2[2]));
+  const float cosParallaxRays = sum3(r1[0] * r2[0], r1[1] * r2[1], r1[2] * r2[2]) / (nr1 * nr2);
+  const float cosParallaxStereo = cosParallaxRays + 1;
+  if (!(cosParallaxRays < cosParallaxStereo && cosParallaxRays > 0 && (double)cosParallaxRays < P.cos_parallax_max)) { status[m] = 1; return; }
+  float A[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    A[0][k] = xn1[0] * T1w[8 + k] - T1w[k];
+    A[1][k] = xn1[1] * T1w[8 + k] - T1w[4 + k];
+    A[2][k] = xn2[0] * T2w[8 + k] - T2w[k];
+    A[3][k] = xn2[1] * T2w[8 + k] - T2w[4 + k];
+  }
+  double B[4][4], V[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc += (double)A[k][i] * (double)A[k][j];
+      B[i][j] = acc;
+    }
+  jacobi4_dev(B, V);
+  int mi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++) if (B[k][k] < B[mi][mi]) mi = k;
+  float vh[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) vh[k] = (float)(mi == 0 ? V[k][0] : mi == 1 ? V[k][1] : mi == 2 ? V[k][2] : V[k][3]);
+  if (vh[3] == 0) { status[m] = 2; return; }
+  const float x3D[3] = {vh[0] / vh[3], vh[1] / vh[3], vh[2] / vh[3]};
+  X[0] = x3D[0]; X[1] = x3D[1]; X[2] = x3D[2];
+  const float z1 = sum3(T1w[8] * x3D[0], T1w[9] * x3D[1], T1w[10] * x3D[2]) + T1w[11];
+  if (z1 <= 0) { status[m] = 3; return; }
+  const float z2 = sum3(T2w[8] * x3D[0], T2w[9] * x3D[1], T2w[10] * x3D[2]) + T2w[11];
+  if (z2 <= 0) { status[m] = 4; return; }
+  {
+    const float x1 = sum3(T1w[0] * x3D[0], T1w[1] * x3D[1], T1w[2] * x3D[2]) + T1w[3];
+    const float y1 = sum3(T1w[4] * x3D[0], T1w[5] * x3D[1], T1w[6] * x3D[2]) + T1w[7];
+    const float u = P.K1[0] * x1 / z1 + P.K1[2], v = P.K1[1] * y1 / z1 + P.K1[3];
+    const float ex = u - kp1.x, ey = v - kp1.y;
+    if ((double)(ex * ex + ey * ey) > 5.991 * (double)sigma2_1[kp1.octave]) { status[m] = 5; return; }
+  }
+  {
+    const float x2 = sum3(T2w[0] * x3D[0], T2w[1] * x3D[1], T2w[2] * x3D[2]) + T2w[3];
+    const float y2 = sum3(T2w[4] * x3D[0], T2w[5] * x3D[1], T2w[6] * x3D[2]) + T2w[7];
+    const float u = P.K2[0] * x2 / z2 + P.K2[2], v = P.K2[1] * y2 / z2 + P.K2[3];
+    const float ex = u - kp2.x, ey = v - kp2.y;
+    if ((double)(ex * ex + ey * ey) > 5.991 * (double)sigma2_2[kp2.octave]) { status[m] = 6; return; }
+  }
+  const float d1[3] = {x3D[0] - P.Ow1[0], x3D[1] - P.Ow1[1], x3D[2] - P.Ow1[2]}, d2[3] = {x3D[0] - P.Ow2[0], x3D[1] - P.Ow2[1], x3D[2] - P.Ow2[2]};
+  const float dist1 = sqrtf(sum3(d1[0] * d1[0], d1[1] * d1[1], d1[2] * d1[2])), dist2 = sqrtf(sum3(d2[0] * d2[0], d2[1] * d2[1], d2[2] * d2[2]));
+  if (dist1 == 0 || dist2 == 0) { status[m] = 7; return; }
+  if (P.far_points && (dist1 >= P.th_far || dist2 >= P.th_far)) { status[m] = 8; return; }
+  const float ratioDist = dist2 / dist1;
+  const float ratioOctave = sf1[kp1.octave] / sf2[kp2.octave];
+  if (ratioDist * P.ratio_factor < ratioOctave || ratioDist > ratioOctave * P.ratio_factor) { status[m] = 9; return; }
+  status[m] = 0;
+}
+void launch_triangulate_matches(hipStream_t s, const TriPair& P, const dvm_keypoint_pod* kps1, int n1, const dvm_keypoint_pod* kps2, int n2,
+                                const int32_t* pairs, int n, const float* sigma2_1, const float* sigma2_2, const float* sf1,
+                                const float* sf2, float* x3D, int32_t* status) {
+  hipLaunchKernelGGL(k_triangulate_matches, dim3((n + 127) / 128), dim3(128), 0, s, P, kps1, n1, kps2, n2, pairs, n, sigma2_1, sigma2_2, sf1, sf2,
+                     x3D, status);
 }
 
 // D[i][j] = Hamming(A[i], B[j]); one thread per pair, 64 columns x 4 rows per workgroup.

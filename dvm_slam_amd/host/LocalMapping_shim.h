@@ -1,0 +1,74 @@
+// dvm_slam_amd/host/LocalMapping_shim.h -- the geometry of ORB_SLAM3::LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:446-745)
+// on the HIP library.  CreateNewMapPoints stays the reference's function: neighbour selection, the baseline / median-depth test,
+// ORBmatcher::SearchForTriangulation (host/ORBmatcher_shim.h) and the creation of the MapPoints are unchanged.  What moves to the
+// device is the body of its per-match loop for one neighbour keyframe (:534-741, monocular pinhole branch): parallax of the two
+// rays, GeometricTools::Triangulate, the depth / reprojection / distance / scale-consistency tests -- all matches of the
+// neighbour in one launch (dvm_triangulate_matches).  The loop then reads
+//
+//   std::vector<Eigen::Vector3f> vX3D; std::vector<int> vStatus;
+//   TriangulateMatches(mpCurrentKeyFrame, pKF2, vMatchedIndices, mbInertial, mbFarPoints, mThFarPoints, vX3D, vStatus);
+//   for (int ikp = 0; ikp < nmatches; ikp++) {
+//     if (vStatus[ikp] != 0) continue;                       // one of the reference's `continue`s (status = which one)
+//     MapPoint* pMP = new MapPoint(vX3D[ikp], mpCurrentKeyFrame, mpAtlas->GetCurrentMap(), mpAtlas->GetAgentId());
+//     ... AddObservation x2, AddMapPoint x2, ComputeDistinctiveDescriptors, UpdateNormalAndDepth, mpAtlas->AddMapPoint: as before
+//   }
+//
+// Not covered: the stereo / two-camera-rig branches (bStereo1 / bStereo2, mpCamera2) -- DVM-SLAM's agents are monocular.
+// Parity: float arithmetic in Eigen's evaluation order; the homogeneous point comes from a double Jacobi diagonalisation of
+// A^T A where the reference runs Eigen::JacobiSVD<Matrix4f> -- the same vector up to float SVD error (tolerance parity, as for
+// Sim3Solver's eigen-decomposition; decisions equal away from the thresholds).
+#pragma once
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "KeyFrame.h"
+#include "dvmslam_hip.h"
+
+namespace ORB_SLAM3 {
+
+inline void TriangulateMatches(KeyFrame* pKF1, KeyFrame* pKF2, const std::vector<std::pair<size_t, size_t>>& vMatchedIndices, bool bInertial,
+                               bool bFarPoints, float thFarPoints, std::vector<Eigen::Vector3f>& vX3D, std::vector<int>& vStatus) {
+  static_assert(sizeof(cv::KeyPoint) == sizeof(dvm_keypoint), "cv::KeyPoint is passed as dvm_keypoint");
+  const int n = (int)vMatchedIndices.size();
+  vX3D.assign(n, Eigen::Vector3f());
+  vStatus.assign(n, 0);
+  if (n == 0) return;
+  dvm_tri_pair P;
+  P.cos_parallax_max = bInertial ? 0.9996 : 0.9998;                     // (:655-656)
+  auto fill = [](KeyFrame* kf, float* K, float* T, float* Ow) {
+    for (int i = 0; i < 4; i++) K[i] = kf->mpCamera->getParameter(i);
+    const Sophus::SE3f Tcw = kf->GetPose();                            // eigTcw = sophTcw.matrix3x4() (:470, :519)
+    const Eigen::Matrix3f R = Tcw.rotationMatrix();
+    const Eigen::Vector3f t = Tcw.translation(), O = kf->GetCameraCenter();
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) T[4 * r + c] = R(r, c);
+      T[4 * r + 3] = t(r);
+      Ow[r] = O(r);
+    }
+  };
+  fill(pKF1, P.K1, P.T1w, P.Ow1);
+  fill(pKF2, P.K2, P.T2w, P.Ow2);
+  P.ratio_factor = 1.5f * pKF1->mfScaleFactor;                          // (:483)
+  P.th_far = thFarPoints;
+  P.far_points = bFarPoints ? 1 : 0;
+  P.n_levels = (int)pKF1->mvLevelSigma2.size();
+  if (pKF2->mvLevelSigma2.size() != pKF1->mvLevelSigma2.size() || pKF1->mvScaleFactors.size() != pKF1->mvLevelSigma2.size() ||
+      pKF2->mvScaleFactors.size() != pKF1->mvLevelSigma2.size())
+    throw std::invalid_argument("TriangulateMatches: the two keyframes' pyramid tables differ in length");
+  std::vector<int32_t> pairs(2 * (size_t)n);
+  for (int i = 0; i < n; i++) { pairs[2 * i] = (int32_t)vMatchedIndices[i].first; pairs[2 * i + 1] = (int32_t)vMatchedIndices[i].second; }
+  std::vector<float> X(3 * (size_t)n);
+  std::vector<int32_t> st(n);
+  if (dvm_triangulate_matches(&P, reinterpret_cast<const dvm_keypoint*>(pKF1->mvKeysUn.data()), (int)pKF1->mvKeysUn.size(),
+                              reinterpret_cast<const dvm_keypoint*>(pKF2->mvKeysUn.data()), (int)pKF2->mvKeysUn.size(), pairs.data(), n,
+                              pKF1->mvLevelSigma2.data(), pKF2->mvLevelSigma2.data(), pKF1->mvScaleFactors.data(), pKF2->mvScaleFactors.data(),
+                              X.data(), st.data(), 0, nullptr) != DVM_OK)
+    throw std::runtime_error(dvm_last_error());
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) vX3D[i](k) = X[3 * i + k];
+    vStatus[i] = st[i];
+  }
+}
+
+}  // namespace ORB_SLAM3

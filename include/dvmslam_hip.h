@@ -189,6 +189,29 @@ typedef struct { float proj_x, proj_y, proj_xr, depth, view_cos; int32_t level; 
 int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const float* normal, const float* min_dist,
                       const float* max_dist, int n, float viewing_cos_limit, dvm_track_point* out, int on_device, void* stream);
 
+/* LocalMapping::CreateNewMapPoints, the geometry of ONE neighbour keyframe (LocalMapping.cc:598-741, monocular pinhole branch) for
+ * the index pairs ORBmatcher::SearchForTriangulation returned: unprojectEig, parallax of the two rays (cos > 0 and, in double,
+ * < cos_parallax_max: 0.9998, 0.9996 inertial), GeometricTools::Triangulate (GeometricTools.cc:48-67), z > 0 in both cameras,
+ * reprojection error <= 5.991 * mvLevelSigma2[octave] in both, zero / far distance, the distance-ratio vs octave-ratio test with
+ * ratio_factor = 1.5f * mfScaleFactor.  pairs[2 m], pairs[2 m + 1] = index into kps1 (the current keyframe's mvKeysUn) / kps2.
+ * x3D[3 m ..] = the triangulated point (zeros when no triangulation was attempted), status[m]: 0 accepted -- the caller creates the
+ * MapPoint --, 1 parallax, 2 homogeneous w == 0, 3 z1 <= 0, 4 z2 <= 0, 5 / 6 reprojection error in keyframe 1 / 2, 7 zero distance,
+ * 8 far point, 9 scale consistency, -1 index or octave out of range.  float arithmetic in Eigen's evaluation order; the null
+ * vector of the 4x4 system comes from a double Jacobi diagonalisation of A^T A instead of Eigen::JacobiSVD<Matrix4f> (tolerance
+ * parity on x3D).  Host pointers (synchronous) or device pointers (asynchronous on `stream`). */
+typedef struct {
+  double cos_parallax_max;
+  float K1[4], K2[4];       /* fx, fy, cx, cy */
+  float T1w[12], T2w[12];   /* KeyFrame::GetPose().matrix3x4(), row-major */
+  float Ow1[3], Ow2[3];     /* KeyFrame::GetCameraCenter() */
+  float ratio_factor, th_far;
+  int32_t far_points;       /* mbFarPoints */
+  int32_t n_levels;         /* length of the sigma2 / scale-factor tables */
+} dvm_tri_pair;
+int dvm_triangulate_matches(const dvm_tri_pair* pair, const dvm_keypoint* kps1, int n1, const dvm_keypoint* kps2, int n2,
+                            const int32_t* pairs, int n, const float* sigma2_1, const float* sigma2_2, const float* scale_factors_1,
+                            const float* scale_factors_2, float* x3D, int32_t* status, int on_device, void* stream);
+
 /* Best / second best over an explicit candidate list per query -- the inner loop of the
  * vocabulary-node restricted searches (SearchByBoW ORBmatcher.cc:262-300,760-800; SearchForTriangulation
  * :905-960; SearchBySim3; Fuse): query q scans train descriptors cand[off[q] .. off[q+1]) in that order

@@ -1046,4 +1046,94 @@ void orc_sim3_hypotheses(const float* P1c, const float* P2c, const float* max_er
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LocalMapping::CreateNewMapPoints, the geometry of ONE neighbour keyframe (reference src/LocalMapping.cc:598-741, monocular
+// pinhole branch) for the matches SearchForTriangulation returned: parallax of the two rays, GeometricTools::Triangulate
+// (src/GeometricTools.cc:48-67), positive depth in both cameras, reprojection error against 5.991 * sigma2 in both, the
+// distance-ratio / octave-ratio consistency test.  float arithmetic in Eigen's evaluation order (3-term sums a0 + (a1 + a2),
+// v / s as divisions, Pinhole::project as (fx * x) / z + cx); comparisons against double literals in double, as C++ promotes
+// them.  The one step that differs in METHOD: the reference takes the right singular vector of the smallest singular value of
+// the 4x4 float matrix A from Eigen::JacobiSVD<Matrix4f>; here (and on the device) it is the eigenvector of the smallest
+// eigenvalue of A^T A, formed and diagonalised in double by cyclic Jacobi rotations and rounded to float -- tolerance parity on
+// x3D (the same vector up to float SVD error), identical decisions away from the thresholds.
+// status: 0 accepted; 1 parallax (cos <= 0 or >= cos_parallax_max: "no stereo and very low parallax"); 2 homogeneous w == 0;
+// 3 z1 <= 0; 4 z2 <= 0; 5 reprojection error in keyframe 1; 6 in keyframe 2; 7 zero distance; 8 far point; 9 scale consistency.
+void orc_triangulate_matches(const float* K1, const float* K2, const float* T1w /*3x4 row-major: KeyFrame::GetPose().matrix3x4()*/,
+                             const float* T2w, const float* Ow1, const float* Ow2, const orc_keypoint* kps1, const orc_keypoint* kps2,
+                             const int32_t* pairs /*[n][2]*/, int n, const float* sigma2_1, const float* sigma2_2, const float* sf1,
+                             const float* sf2, float ratio_factor, double cos_parallax_max, int far_points, float th_far,
+                             float* x3D_out /*[n][3]*/, int32_t* status) {
+  auto sum3 = [](float a, float b, float c) { return a + (b + c); };
+  for (int m = 0; m < n; m++) {
+    const orc_keypoint& kp1 = kps1[pairs[2 * m]];
+    const orc_keypoint& kp2 = kps2[pairs[2 * m + 1]];
+    float* X = x3D_out + 3 * (size_t)m;
+    X[0] = X[1] = X[2] = 0.0f;
+    // unprojectEig (Pinhole.cpp:61-63)
+    const float xn1[3] = {(kp1.x - K1[2]) / K1[0], (kp1.y - K1[3]) / K1[1], 1.0f};
+    const float xn2[3] = {(kp2.x - K2[2]) / K2[0], (kp2.y - K2[3]) / K2[1], 1.0f};
+    // ray = Rwc * xn, Rwc = Rcw^T (:632-633)
+    float r1[3], r2[3];
+    for (int i = 0; i < 3; i++) {
+      r1[i] = sum3(T1w[0 * 4 + i] * xn1[0], T1w[1 * 4 + i] * xn1[1], T1w[2 * 4 + i] * xn1[2]);
+      r2[i] = sum3(T2w[0 * 4 + i] * xn2[0], T2w[1 * 4 + i] * xn2[1], T2w[2 * 4 + i] * xn2[2]);
+    }
+    const float n1 = std::sqrt(sum3(r1[0] * r1[0], r1[1] * r1[1], r1[2] * r1[2])), n2 = std::sqrt(sum3(r2[0] * r2[0], r2[1] * r2[1], r2[2] * r2[2]));
+    const float cosParallaxRays = sum3(r1[0] * r2[0], r1[1] * r2[1], r1[2] * r2[2]) / (n1 * n2);
+    // mono: cosParallaxStereo = cosParallaxRays + 1 (:636-646), no stereo alternative (:663-675)
+    const float cosParallaxStereo = cosParallaxRays + 1;
+    if (!(cosParallaxRays < cosParallaxStereo && cosParallaxRays > 0 && (double)cosParallaxRays < cos_parallax_max)) { status[m] = 1; continue; }
+    // GeometricTools::Triangulate
+    float A[4][4];
+    for (int k = 0; k < 4; k++) {
+      A[0][k] = xn1[0] * T1w[8 + k] - T1w[0 + k];
+      A[1][k] = xn1[1] * T1w[8 + k] - T1w[4 + k];
+      A[2][k] = xn2[0] * T2w[8 + k] - T2w[0 + k];
+      A[3][k] = xn2[1] * T2w[8 + k] - T2w[4 + k];
+    }
+    double B[4][4], V[4][4];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double acc = 0.0;
+        for (int k = 0; k < 4; k++) acc += (double)A[k][i] * (double)A[k][j];
+        B[i][j] = acc;
+      }
+    jacobi4(B, V);
+    int mi = 0;
+    for (int k = 1; k < 4; k++) if (B[k][k] < B[mi][mi]) mi = k;
+    const float vh[4] = {(float)V[0][mi], (float)V[1][mi], (float)V[2][mi], (float)V[3][mi]};
+    if (vh[3] == 0) { status[m] = 2; continue; }
+    const float x3D[3] = {vh[0] / vh[3], vh[1] / vh[3], vh[2] / vh[3]};
+    X[0] = x3D[0]; X[1] = x3D[1]; X[2] = x3D[2];
+    const float z1 = sum3(T1w[8] * x3D[0], T1w[9] * x3D[1], T1w[10] * x3D[2]) + T1w[11];
+    if (z1 <= 0) { status[m] = 3; continue; }
+    const float z2 = sum3(T2w[8] * x3D[0], T2w[9] * x3D[1], T2w[10] * x3D[2]) + T2w[11];
+    if (z2 <= 0) { status[m] = 4; continue; }
+    const float sigmaSquare1 = sigma2_1[kp1.octave];
+    const float x1 = sum3(T1w[0] * x3D[0], T1w[1] * x3D[1], T1w[2] * x3D[2]) + T1w[3];
+    const float y1 = sum3(T1w[4] * x3D[0], T1w[5] * x3D[1], T1w[6] * x3D[2]) + T1w[7];
+    {
+      const float u = K1[0] * x1 / z1 + K1[2], v = K1[1] * y1 / z1 + K1[3];
+      const float errX1 = u - kp1.x, errY1 = v - kp1.y;
+      if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaSquare1) { status[m] = 5; continue; }
+    }
+    const float sigmaSquare2 = sigma2_2[kp2.octave];
+    const float x2 = sum3(T2w[0] * x3D[0], T2w[1] * x3D[1], T2w[2] * x3D[2]) + T2w[3];
+    const float y2 = sum3(T2w[4] * x3D[0], T2w[5] * x3D[1], T2w[6] * x3D[2]) + T2w[7];
+    {
+      const float u = K2[0] * x2 / z2 + K2[2], v = K2[1] * y2 / z2 + K2[3];
+      const float errX2 = u - kp2.x, errY2 = v - kp2.y;
+      if ((errX2 * errX2 + errY2 * errY2) > 5.991 * sigmaSquare2) { status[m] = 6; continue; }
+    }
+    const float d1[3] = {x3D[0] - Ow1[0], x3D[1] - Ow1[1], x3D[2] - Ow1[2]}, d2[3] = {x3D[0] - Ow2[0], x3D[1] - Ow2[1], x3D[2] - Ow2[2]};
+    const float dist1 = std::sqrt(sum3(d1[0] * d1[0], d1[1] * d1[1], d1[2] * d1[2])), dist2 = std::sqrt(sum3(d2[0] * d2[0], d2[1] * d2[1], d2[2] * d2[2]));
+    if (dist1 == 0 || dist2 == 0) { status[m] = 7; continue; }
+    if (far_points && (dist1 >= th_far || dist2 >= th_far)) { status[m] = 8; continue; }
+    const float ratioDist = dist2 / dist1;
+    const float ratioOctave = sf1[kp1.octave] / sf2[kp2.octave];
+    if (ratioDist * ratio_factor < ratioOctave || ratioDist > ratioOctave * ratio_factor) { status[m] = 9; continue; }
+    status[m] = 0;
+  }
+}
+
 }  // extern "C"

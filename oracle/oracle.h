@@ -249,6 +249,14 @@ void orc_sim3_hypotheses(const float* P1c, const float* P2c, const float* max_er
                          const float* K2, const int32_t* triples, int H, int fix_scale, float* T12, int32_t* n_inliers,
                          uint8_t* inlier_mask);
 
+/* LocalMapping::CreateNewMapPoints, per-match geometry for one neighbour keyframe (LocalMapping.cc:598-741 mono pinhole branch,
+ * GeometricTools.cc:48-67): parallax, triangulation, depth / reprojection / scale-consistency tests.  T*w: 3x4 row-major
+ * (GetPose().matrix3x4()); pairs [n][2] = (index in keyframe 1, index in keyframe 2); status 0 = accepted (see ba_oracle.cpp). */
+void orc_triangulate_matches(const float* K1, const float* K2, const float* T1w, const float* T2w, const float* Ow1, const float* Ow2,
+                             const orc_keypoint* kps1, const orc_keypoint* kps2, const int32_t* pairs, int n, const float* sigma2_1,
+                             const float* sigma2_2, const float* sf1, const float* sf2, float ratio_factor, double cos_parallax_max,
+                             int far_points, float th_far, float* x3D_out, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

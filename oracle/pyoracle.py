@@ -688,6 +688,25 @@ def sim3_hypotheses(P1c, P2c, max_err1, max_err2, K1, K2, triples, fix_scale=Fal
     return T, nin, mask
 
 
+def triangulate_matches(K1, K2, T1w, T2w, Ow1, Ow2, kps1, kps2, pairs, sigma2_1, sigma2_2, sf1, sf2, ratio_factor,
+                        cos_parallax_max=0.9998, far_points=False, th_far=0.0):
+    """LocalMapping::CreateNewMapPoints' per-match geometry (mono pinhole).  kps*: structured keypoint arrays (KP_DTYPE) or
+    [N,7] float32 in cv::KeyPoint layout.  Returns (x3D[n,3] float32, status[n] int32)."""
+    L = lib()
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    L.orc_triangulate_matches.restype = None
+    L.orc_triangulate_matches.argtypes = [vp] * 9 + [i32] + [vp] * 4 + [f32, C.c_double, i32, f32, vp, vp]
+    f = [np.ascontiguousarray(x, np.float32) for x in (K1, K2, T1w, T2w, Ow1, Ow2, sigma2_1, sigma2_2, sf1, sf2)]
+    k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+    assert k1.dtype.itemsize * (k1.shape[1] if k1.ndim == 2 else 1) == 28 and k2.dtype.itemsize * (k2.shape[1] if k2.ndim == 2 else 1) == 28
+    pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    n = len(pr)
+    X = np.zeros((n, 3), np.float32); st = np.zeros(n, np.int32)
+    L.orc_triangulate_matches(_p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(f[4]), _p(f[5]), _p(k1), _p(k2), _p(pr), n, _p(f[6]), _p(f[7]),
+                              _p(f[8]), _p(f[9]), float(ratio_factor), float(cos_parallax_max), int(far_points), float(th_far), _p(X), _p(st))
+    return X, st
+
+
 def sim3_exp_log(u):
     L = lib()
     L.orc_sim3_exp_log.restype = None

@@ -176,8 +176,21 @@ def db_wire():
     print("db/wire", out["db_merge"][:, 0], n, out["wire_block"].size)
 
 
+def triangulation():
+    """LocalMapping::CreateNewMapPoints' per-match geometry (oracle.triangulate_matches) on a tests/tri_scene.py scene."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import tri_scene
+    S = tri_scene.scene(seed=77, n=240, baseline=0.45)
+    X, st = po.triangulate_matches(S["K1"], S["K2"], S["T1w"], S["T2w"], S["Ow1"], S["Ow2"], S["kps1"], S["kps2"], S["pairs"], S["sigma2_1"],
+                                   S["sigma2_2"], S["sf1"], S["sf2"], S["ratio_factor"], far_points=True, th_far=9.0)
+    np.savez_compressed(os.path.join(HERE, "triangulation.npz"), x3D=X, status=st, th_far=np.float32(9.0), **S)
+    print("triangulation", np.bincount(st, minlength=10))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "db":
+    if len(sys.argv) > 1 and sys.argv[1] == "tri":
+        triangulation()
+    elif len(sys.argv) > 1 and sys.argv[1] == "db":
         db_wire()
     elif len(sys.argv) > 1 and sys.argv[1] == "more":
         more()
@@ -188,3 +201,4 @@ if __name__ == "__main__":
         more()
         kf_functions()
         db_wire()
+        triangulation()

@@ -18,6 +18,7 @@
 #include "ORBVocabulary_shim.h"
 #include "KeyFrameDatabase_shim.h"
 #include "MapPoint_shim.h"
+#include "LocalMapping_shim.h"
 #include "Frame_grid_shim.h"
 
 using namespace ORB_SLAM3;
@@ -490,6 +491,32 @@ int sw_search_for_triangulation(World* w, int kf1, int kf2, int32_t* pairs, int 
     const int n = m.SearchForTriangulation(w->kfs[kf1].get(), w->kfs[kf2].get(), v, false, coarse != 0);
     for (size_t i = 0; i < v.size() && (int)i < cap; i++) { pairs[2 * i] = (int32_t)v[i].first; pairs[2 * i + 1] = (int32_t)v[i].second; }
     return n;
+  });
+}
+// LocalMapping::CreateNewMapPoints' per-match geometry for one neighbour (host/LocalMapping_shim.h); also returns what the mock
+// keyframes hand to it (3x4 poses, camera centres), so that the test can give the oracle the same inputs
+int sw_triangulate_matches(World* w, int kf1, int kf2, const int32_t* pairs, int n, int inertial, int far_points, float th_far, float* x3d,
+                           int32_t* status, float* T1w, float* T2w, float* Ow1, float* Ow2) {
+  return guarded(w, [&] {
+    std::vector<std::pair<size_t, size_t>> v(n);
+    for (int i = 0; i < n; i++) v[i] = {(size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]};
+    std::vector<Eigen::Vector3f> X;
+    std::vector<int> st;
+    TriangulateMatches(w->kfs[kf1].get(), w->kfs[kf2].get(), v, inertial != 0, far_points != 0, th_far, X, st);
+    for (int i = 0; i < n; i++) { for (int k = 0; k < 3; k++) x3d[3 * i + k] = X[i](k); status[i] = st[i]; }
+    KeyFrame* kf[2] = {w->kfs[kf1].get(), w->kfs[kf2].get()};
+    float* T[2] = {T1w, T2w};
+    float* O[2] = {Ow1, Ow2};
+    for (int a = 0; a < 2; a++) {
+      const Sophus::SE3f Tcw = kf[a]->GetPose();
+      const Eigen::Matrix3f R = Tcw.rotationMatrix();
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T[a][4 * r + c] = R(r, c);
+        T[a][4 * r + 3] = Tcw.translation()(r);
+        O[a][r] = kf[a]->GetCameraCenter()(r);
+      }
+    }
+    return 0;
   });
 }
 // ORBmatcher::Fuse(pKF, vpMapPoints, th): the search on the device, Replace / AddObservation on the mock map

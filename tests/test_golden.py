@@ -252,3 +252,22 @@ def test_hip_reproduces_db_wire_set(capi):
     pts = _sub(z, "rp_"); pts["normal"] = pts["pos"]
     n, _ = capi.search_by_projection_reloc(F, capi.keyframe_view(a), capi.map_points_view(pts), z["r_already"], 10.0, 100, True)
     assert n == int(z["r_n"]) and np.array_equal(m, z["r_m"])
+
+
+def _tri_args(z):
+    return (z["K1"], z["K2"], z["T1w"], z["T2w"], z["Ow1"], z["Ow2"], z["kps1"], z["kps2"], z["pairs"], z["sigma2_1"], z["sigma2_2"], z["sf1"],
+            z["sf2"], float(z["ratio_factor"]))
+
+
+def test_oracle_reproduces_triangulation_set(oracle):
+    z = np.load(os.path.join(G, "triangulation.npz"))
+    X, st = oracle.triangulate_matches(*_tri_args(z), far_points=True, th_far=float(z["th_far"]))
+    assert np.array_equal(st, z["status"]) and np.array_equal(X.view(np.uint32), z["x3D"].view(np.uint32))
+    assert {0, 1, 3, 5, 8, 9} <= set(np.unique(st).tolist())
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_triangulation_set(capi):
+    z = np.load(os.path.join(G, "triangulation.npz"))
+    X, st = capi.triangulate_matches(*_tri_args(z), far_points=True, th_far=float(z["th_far"]))
+    assert np.array_equal(st, z["status"]) and np.array_equal(X.view(np.uint32), z["x3D"].view(np.uint32))

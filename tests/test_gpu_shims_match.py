@@ -197,6 +197,35 @@ def test_search_for_triangulation(capi, oracle, seed, coarse):
     assert n == n_o > 100 and np.array_equal(pairs[:n], np.asarray(p_o).reshape(-1, 2)[:n])
 
 
+@pytest.mark.parametrize("seed,far", [(0, False), (2, True)])
+def test_create_new_map_points_geometry(capi, oracle, seed, far):
+    """LocalMapping::CreateNewMapPoints for one neighbour, as the shims run it: ORBmatcher::SearchForTriangulation, then
+    TriangulateMatches (host/LocalMapping_shim.h) on the pairs it returned.  Compared with the oracle given the same keyframes."""
+    sc = _consistent_pair(oracle, seed, mapped_frac=0.4, dup_frac=0.2)
+    a, b = sc["kf"]
+    W = _pair_world(capi, sc, observe=())
+    pairs = np.zeros((len(a["kps"]), 2), np.int32)
+    n = W._chk(W.L.sw_search_for_triangulation(W.h, 0, 1, sw._p(pairs), len(pairs), 0, 1))
+    assert n > 100
+    pairs = np.ascontiguousarray(pairs[:n])
+    X = np.zeros((n, 3), np.float32); st = np.full(n, -7, np.int32)
+    T1 = np.zeros(12, np.float32); T2 = np.zeros(12, np.float32); O1 = np.zeros(3, np.float32); O2 = np.zeros(3, np.float32)
+    args = lambda f, t: (W.h, 0, 1, sw._p(pairs), n, 0, int(f), f32(t), sw._p(X), sw._p(st), sw._p(T1), sw._p(T2), sw._p(O1), sw._p(O2))
+    W._chk(W.L.sw_triangulate_matches(*args(False, 0.0)))
+    assert (st == 0).sum() > 30
+    th_far = float(np.median(np.linalg.norm(X[st == 0] - O1, axis=1)))      # mThFarPoints in the middle of the accepted points
+    W._chk(W.L.sw_triangulate_matches(*args(far, th_far)))
+    Xo, so = oracle.triangulate_matches(a["K"], b["K"], T1, T2, O1, O2, a["kps"], b["kps"], pairs, a["level_sigma2"], b["level_sigma2"],
+                                        a["scale_factors"], b["scale_factors"], np.float32(1.5) * np.float32(a["scale_factors"][1]),
+                                        far_points=far, th_far=th_far)
+    assert np.array_equal(st, so) and np.array_equal(X.view(np.uint32), Xo.view(np.uint32))
+    assert (so == 0).sum() > 10 and ((so == 8).sum() > 10) == far
+    # the poses the mock keyframes handed over are the scene's (rotation matrix of the unit quaternion | translation)
+    Rt = np.asarray(oracle.se3_matrix(a["Tcw"]), np.float32).reshape(3, 4) if hasattr(oracle, "se3_matrix") else None
+    if Rt is not None:
+        assert np.allclose(T1.reshape(3, 4), Rt, atol=1e-6)
+
+
 @pytest.mark.parametrize("seed", [0, 2])
 def test_fuse_replays_replace_and_add_observation(capi, oracle, seed):
     """ORBmatcher::Fuse(pKF, vpMapPoints, th) (LocalMapping::SearchInNeighbors): the search is one device call, the graph edits

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "dvm_slam_amd", "host")
 
 
-@pytest.mark.parametrize("shim", ["ORBextractor_shim.h", "ORBmatcher_shim.h", "Optimizer_shim.h", "Frame_grid_shim.h", "Sim3Solver_shim.h", "ORBVocabulary_shim.h", "KeyFrameDatabase_shim.h", "MapPoint_shim.h"])
+@pytest.mark.parametrize("shim", ["ORBextractor_shim.h", "ORBmatcher_shim.h", "Optimizer_shim.h", "Frame_grid_shim.h", "Sim3Solver_shim.h", "ORBVocabulary_shim.h", "KeyFrameDatabase_shim.h", "MapPoint_shim.h", "LocalMapping_shim.h"])
 def test_shim_compiles_against_reference_signatures(shim):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"),
                         "-I", os.path.join(ROOT, "include"), "-I", HOST, "-x", "c++", "-"],
