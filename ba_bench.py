@@ -35,9 +35,9 @@ def _prewarm(seconds: float):
         torch.cuda.synchronize()
 
 
-def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float = 0.0, repeats: int = 420):
+def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float = 0.0, repeats: int = 470):
     """The timed region is `repeats` optimisations of `iters` LM iterations each of the same problem (set_problem, i.e. the
-    reference's graph construction, outside it): 420 x 9 iterations = ~1.06 s of dvm_ba_optimize, long enough for clock sampling to
+    reference's graph construction, outside it): 470 x 9 iterations = ~1.07 s of dvm_ba_optimize, long enough for clock sampling to
     see it (each run is preceded by ~8 ms of set_problem on the host, during which the GPU idles)."""
     from dvm_slam_amd import capi, synth
     if prewarm_s > 0:
@@ -115,7 +115,7 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
         "ms_graph_build_excluded": st["ms_structure"], "chi2_initial": st["chi2_initial"], "chi2_final": st["chi2_final"],
         "dtype": "f64", "huber_delta": delta, "huber_off": huber_off,
         "gpu_state": "hot (timed right after GPU work; the LM loop polls mapped host memory instead of synchronising the stream)",
-        "roofline": {"bound": "mfma", "kernel": "k_chol_diag / k_chol_trsm / k_chol_update (+ k_chol_backsolve): tile Cholesky of the reduced "
+        "roofline": {"bound": "mfma", "kernel": "k_chol_trsm_update<true> (a level: diagonal tiles + strips + update) / k_chol_update / k_chol_pair (+ k_chol_backsolve): tile Cholesky of the reduced "
                                                "camera system on v_mfma_f64_16x16x4",
                      "achieved": fl / t_solve / 1e12 if t_solve > 0 else None, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl / t_solve / 1e12 / FP64_MATRIX_PEAK_TFLOPS if t_solve > 0 else None,
@@ -123,7 +123,7 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
                      "traffic": traffic,
                      "note": "EXECUTED FLOPs of the symbolic tile factorisation (dvm_ba_schedule_info) over the HIP-event time of the "
                              "factorisation + back substitution launches of a trial.  The solve is a dependency chain of elimination-tree "
-                             "levels (diag -> trsm -> update per level), not matrix-pipe bound; dense-equivalent (n^3/3 per trial over the "
+                             "levels (diagonal tiles -> strips -> update per level), not matrix-pipe bound; dense-equivalent (n^3/3 per trial over the "
                              f"whole iteration): {FLOPS_DENSE_CHOLESKY * trials / dt / 1e12:.2f} TFLOP/s"},
         "phase_ms": {"first_linearisation_per_run": prof["ms_linearise"],
                      "schur_per_trial": prof["ms_schur"] / max(prof["trials"], 1), "cholesky_solve_per_trial": t_solve * 1e3,
