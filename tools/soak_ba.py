@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dvm_slam_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as po     # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tri_scene                      # noqa: E402
 
 
 def main():
@@ -19,9 +21,11 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    cases = bad = 0
+    cases = bad = tri_cases = 0
     while time.time() - t0 < budget:
         n_kf = int(rng.integers(3, 90)); n_pts = int(rng.integers(30, 1500)); k = int(rng.integers(2, min(8, n_kf) + 1))
+        if rng.random() < 0.12:       # many tile columns: the nested-dissection schedule, short tiles of every fill, the level kernels
+            n_kf = int(rng.integers(90, 420)); n_pts = int(rng.integers(20, 30) * n_kf); k = int(rng.integers(4, 9))
         delta = float(np.sqrt(5.991)) if rng.random() < 0.6 else 0.0
         iters = int(rng.integers(1, 12))
         pr = synth.ba_problem(n_kf, n_pts, k, seed=int(rng.integers(1 << 30)), noise_px=float(rng.choice([0.0, 0.5, 1.0, 3.0])),
@@ -55,6 +59,23 @@ def main():
             bad += 1
             print(f"BA EXCEPTION case {cases}: {tag}: {ex!r}", flush=True)
         cases += 1
+        # LocalMapping::CreateNewMapPoints' geometry: kernel == oracle bit for bit on a random two-view scene
+        try:
+            S = tri_scene.scene(seed=int(rng.integers(1 << 30)), n=int(rng.integers(1, 4000)), baseline=float(rng.uniform(0.02, 2.0)),
+                                noise_px=float(rng.choice([0.0, 0.5, 2.0])), wrong_frac=float(rng.choice([0.0, 0.2])))
+            a = (S["K1"], S["K2"], S["T1w"], S["T2w"], S["Ow1"], S["Ow2"], S["kps1"], S["kps2"], S["pairs"], S["sigma2_1"], S["sigma2_2"],
+                 S["sf1"], S["sf2"], S["ratio_factor"])
+            kw = dict(far_points=bool(rng.random() < 0.5), th_far=float(rng.uniform(2, 40)), cos_parallax_max=float(rng.choice([0.9998, 0.9996])))
+            Xo, so_ = po.triangulate_matches(*a, **kw)
+            Xg, sg_ = capi.triangulate_matches(*a, **kw)
+            tri_cases += 1
+            if not (np.array_equal(so_, sg_) and np.array_equal(Xo.view(np.uint32), Xg.view(np.uint32))):
+                bad += 1
+                print(f"TRIANGULATION MISMATCH case {cases}: n={len(S['pairs'])} status diff {(so_ != sg_).sum()}", flush=True)
+        except Exception as ex:
+            bad += 1
+            print(f"TRIANGULATION EXCEPTION case {cases}: {ex!r}", flush=True)
+    print(f"soak_ba: {tri_cases} triangulation scenes;", end=" ")
     print(f"soak_ba: {cases} cases, {bad} mismatches, {time.time() - t0:.0f} s, seed {seed}")
     sys.exit(1 if bad else 0)
 
