@@ -18,7 +18,10 @@ const int kCols = 64, kRows = 48;  // FRAME_GRID_COLS / ROWS, Frame.h:44-45
 
 // Frame::GetFeaturesInArea on the host, used only for the rare re-queries (Frame.cc:712-770)
 struct HostGrid {
-  std::vector<int> cell[kCols][kRows];
+  // the grid of Frame::AssignFeaturesToGrid as two flat arrays (counting sort: a cell's indices stay in insertion order, the
+  // order GetFeaturesInArea walks them in).  64 x 48 std::vectors, as the reference keeps it, cost ~0.1 ms to fill and free per
+  // call -- as much as the device search this grid only backs up
+  std::vector<int32_t> start, idx;     // start[ix * kRows + iy] .. start[ix * kRows + iy + 1] into idx
   float minX, minY, wInv, hInv;
   const dvm_keypoint* kps;
   void build(const FrameView& F) { build(F.mvKeysUn, F.N, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY); }
@@ -27,11 +30,19 @@ struct HostGrid {
     minX = mnMinX; minY = mnMinY;
     wInv = static_cast<float>(kCols) / static_cast<float>(mnMaxX - mnMinX);
     hInv = static_cast<float>(kRows) / static_cast<float>(mnMaxY - mnMinY);
+    start.assign(kCols * kRows + 1, 0);
+    std::vector<int32_t> cell_of(N);
     for (int i = 0; i < N; i++) {
       const int px = (int)std::round((kps[i].x - minX) * wInv), py = (int)std::round((kps[i].y - minY) * hInv);
-      if (px < 0 || px >= kCols || py < 0 || py >= kRows) continue;
-      cell[px][py].push_back(i);
+      const bool in = !(px < 0 || px >= kCols || py < 0 || py >= kRows);
+      cell_of[i] = in ? px * kRows + py : -1;
+      if (in) start[cell_of[i] + 1]++;
     }
+    for (int c = 0; c < kCols * kRows; c++) start[c + 1] += start[c];
+    idx.resize(start[kCols * kRows]);
+    std::vector<int32_t> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < N; i++)
+      if (cell_of[i] >= 0) idx[fill[cell_of[i]]++] = i;
   }
   void query(float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const {
     out.clear();
@@ -46,13 +57,14 @@ struct HostGrid {
     const bool check = (minLevel > 0) || (maxLevel >= 0);
     for (int ix = c0; ix <= c1; ix++)
       for (int iy = r0; iy <= r1; iy++)
-        for (int idx : cell[ix][iy]) {
-          const dvm_keypoint& kp = kps[idx];
+        for (int32_t p = start[ix * kRows + iy]; p < start[ix * kRows + iy + 1]; p++) {
+          const int id = idx[p];
+          const dvm_keypoint& kp = kps[id];
           if (check) {
             if (kp.octave < minLevel) continue;
             if (maxLevel >= 0 && kp.octave > maxLevel) continue;
           }
-          if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) out.push_back(idx);
+          if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) out.push_back(id);
         }
   }
 };
@@ -192,6 +204,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
         for (int idx : rotHist[i]) { Cur.mvpMapPoints[idx] = -1; nmatches--; }
   }
   mark("epilogue");
+  if (dbg) std::fprintf(stderr, "SBP queries %d matches %d re-queried %d\n", nq, nmatches, last_requeried);
   return nmatches;
 }
 
