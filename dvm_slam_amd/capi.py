@@ -355,7 +355,7 @@ class FrameGrid:
         check(self.L.dvm_frame_build_batch(self.h, first_slot, count, C.c_void_p(d_kps), kps_stride, C.c_void_p(d_desc),
                                            desc_stride, C.c_void_p(d_n), *bounds, C.c_void_p(stream or 0)))
 
-    def match_window(self, qdesc, qx, qy, qr, qmin, qmax, skip=None, slot=0):
+    def match_window(self, qdesc, qx, qy, qr, qmin, qmax, skip=None, slot=0, top2=False):
         qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
         nq = len(qdesc)
         qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
@@ -365,9 +365,16 @@ class FrameGrid:
         if skip is not None:
             sk = np.zeros(self.capacity, np.uint8)
             sk[:len(skip)] = skip
-        check(self.L.dvm_match_window(self.h, slot, _p(sk), _p(qdesc), _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), nq,
-                                      None, _p(out), 0, None))
-        return out
+        if not top2:
+            check(self.L.dvm_match_window(self.h, slot, _p(sk), _p(qdesc), _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), nq,
+                                          None, _p(out), 0, None))
+            return out
+        second = np.full(nq, -7, np.int32)
+        self.L.dvm_match_window_top2.restype = C.c_int
+        self.L.dvm_match_window_top2.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p]
+        check(self.L.dvm_match_window_top2(self.h, slot, _p(sk), _p(qdesc), _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), nq,
+                                           None, _p(out), _p(second), 0, None))
+        return out, second
 
     def match_frames_batch(self, first_slot, count, d_kps, kps_stride, d_desc, desc_stride, d_n, carry, cap, th,
                            d_scale, nlevels, d_out, out_stride, d_nq_out=None, stream=None):

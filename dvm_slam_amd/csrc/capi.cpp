@@ -384,9 +384,9 @@ int dvm_frame_build_batch(dvm_frame* f, int first_slot, int count, const dvm_key
   return hip_check(hipGetLastError(), "frame_build launch");
 }
 
-int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
-                     const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
-                     const int32_t* d_nq, dvm_match* out, int on_device, void* stream) {
+int dvm_match_window_top2(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                          const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
+                          const int32_t* d_nq, dvm_match* out, int32_t* second_idx, int on_device, void* stream) {
   if (!train || slot < 0 || slot >= train->slots || nq < 0) return DVM_ERR_INVALID;
   if (nq == 0) return DVM_OK;
   if (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !out) return DVM_ERR_INVALID;
@@ -394,20 +394,27 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
   if (rc != DVM_OK) return rc;
   if (on_device) {
     launch_match_window((hipStream_t)stream, train->view, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, d_nq, nq,
-                        reinterpret_cast<dvm_match_pod*>(out));
+                        reinterpret_cast<dvm_match_pod*>(out), second_idx);
     return hip_check(hipGetLastError(), "match launch");
   }
   // host convenience path: stage queries, run, copy back
   const size_t qb = (size_t)nq;
   Stage st;
   const int iD = st.in(qdesc, qb * 32), iX = st.in(qx, qb * 4), iY = st.in(qy, qb * 4), iR = st.in(qr, qb * 4), iMin = st.in(qmin, qb * 4),
-            iMax = st.in(qmax, qb * 4), iS = st.in(skip, (size_t)train->cap), oM = st.out(out, qb * sizeof(dvm_match));
+            iMax = st.in(qmax, qb * 4), iS = st.in(skip, (size_t)train->cap), oM = st.out(out, qb * sizeof(dvm_match)),
+            oS = second_idx ? st.out(second_idx, qb * 4) : -1;
   rc = st.upload();
   if (rc != DVM_OK) return rc;
   launch_match_window(nullptr, train->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
-                      st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, nullptr, nq, st.ptr<dvm_match_pod>(oM));
+                      st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, nullptr, nq, st.ptr<dvm_match_pod>(oM),
+                      second_idx ? st.ptr<int32_t>(oS) : nullptr);
   rc = hip_check(hipGetLastError(), "match launch");
   return rc == DVM_OK ? st.download() : rc;
+}
+int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                     const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
+                     const int32_t* d_nq, dvm_match* out, int on_device, void* stream) {
+  return dvm_match_window_top2(train, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, d_nq, out, nullptr, on_device, stream);
 }
 
 int dvm_is_in_frustum(const dvm_frustum_frame* frame, const float* P, const float* normal, const float* min_dist,

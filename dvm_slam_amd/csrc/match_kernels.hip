@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
                                                       const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax,
                                                       int nq_host, const int32_t* __restrict__ d_nq, PairQueries PQ,
                                                       float th, const float* __restrict__ scale_factors, int nlevels,
-                                                      dvm_match_pod* __restrict__ out, int64_t out_stride) {
+                                                      dvm_match_pod* __restrict__ out, int64_t out_stride,
+                                                      int32_t* __restrict__ second_idx) {
   const int lane = threadIdx.x & 15;               // lane within the query's row
   const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int pair = blockIdx.y;
@@ -224,6 +225,8 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
     m.best_level = (m.best_dist < 256) ? (int16_t)__float_as_int(F.skp[p1].z) : (int16_t)-1;
     m.second_level = (m.second_dist < 256) ? (int16_t)__float_as_int(F.skp[p2].z) : (int16_t)-1;
     out[q] = m;
+    // the runner-up's index: what the reference's scan finds when the best candidate is excluded (a caller replaying claims)
+    if (!QUERIES_FROM_KPS && second_idx) second_idx[q] = (m.second_dist < 256) ? F.sidx[p2] : -1;
   }
 }
 
@@ -618,15 +621,15 @@ void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_
 }
 void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc,
                          const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
-                         int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out) {
+                         int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out, int32_t* second_idx) {
   PairQueries pq{};
   hipLaunchKernelGGL(k_match_window<false>, dim3((grid_q + 15) / 16, 1), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr,
-                     qmin, qmax, nq, d_nq, pq, 0.f, nullptr, 0, out, 0);
+                     qmin, qmax, nq, d_nq, pq, 0.f, nullptr, 0, out, 0, second_idx);
 }
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {
   hipLaunchKernelGGL(k_match_window<true>, dim3((pq.cap + 15) / 16, count), dim3(256), 0, s, F, first_slot, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride);
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, pq, th, scale_factors, nlevels, out, out_stride, nullptr);
 }
 // Frame::UndistortKeyPoints (Frame.cc:791-818): thread per keypoint, cv::undistortPoints in double (undistort_f64.h)
 __global__ void __launch_bounds__(256) k_undistort_keypoints(dvm_undistort::Camera cam, const float* __restrict__ in, float* __restrict__ out, int n) {

@@ -157,8 +157,9 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   for (int j = 0; j < Cur.N; j++)
     if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) claimed[j] = 1;
   std::vector<dvm_match> res(nq);
-  rc = dvm_match_window(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
-                        nullptr, res.data(), 0, nullptr);
+  std::vector<int32_t> runner_up(nq);
+  rc = dvm_match_window_top2(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
+                             nullptr, res.data(), runner_up.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
   mark("match");
 
@@ -170,7 +171,10 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   std::vector<int> cand;
   for (int q = 0; q < nq; q++) {
     int bestIdx2 = res[q].best_idx, bestDist = res[q].best_dist;
-    if (bestIdx2 >= 0 && claimed_now[bestIdx2] && !claimed[bestIdx2]) {
+    if (bestIdx2 >= 0 && claimed_now[bestIdx2] && !claimed[bestIdx2] && runner_up[q] >= 0 && !claimed_now[runner_up[q]]) {
+      // the scan skips the claimed best and ends on the runner-up (strict '<', first wins: the second smallest (distance, position))
+      bestIdx2 = runner_up[q]; bestDist = res[q].second_dist;
+    } else if (bestIdx2 >= 0 && claimed_now[bestIdx2] && !claimed[bestIdx2]) {
       if (!hg_built) { hg.build(Cur); hg_built = true; }
       last_requeried++;
       hg.query(qx[q], qy[q], qr[q], qmin[q], qmax[q], cand);

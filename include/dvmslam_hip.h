@@ -169,6 +169,12 @@ typedef struct {
 int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                      const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
                      const int32_t* d_nq, dvm_match* out, int on_device, void* stream);
+/* The same search, also returning the runner-up's train index (second_idx[q], -1 if none; may be NULL): what the reference's
+ * scan returns when the best candidate is excluded -- a caller replaying ORBmatcher.cc:1613-1664's claims in query order takes
+ * it when the best candidate was claimed by an earlier query of the same call, instead of searching again. */
+int dvm_match_window_top2(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                          const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
+                          const int32_t* d_nq, dvm_match* out, int32_t* second_idx, int on_device, void* stream);
 
 /* Frame::UndistortKeyPoints (Frame.cc:791-818) and Frame::ComputeImageBounds (:820-848): cv::undistortPoints(pts, K, D,
  * noArray(), K) -- OpenCV's 5-iteration fixed-point inversion of the (k1, k2, p1, p2, k3) model, in double from the float

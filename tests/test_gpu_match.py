@@ -58,6 +58,17 @@ def test_match_window_vs_oracle(capi, oracle, frames):
     skip = (rng.random(len(k1)) < 0.3).astype(np.uint8)
     _check_matches(grid_g.match_window(qd, qx, qy, qr, qmin, qmax, skip=skip),
                    grid_o.match_window(d1, qd, qx, qy, qr, qmin, qmax, skip=skip))
+    # the runner-up's index (dvm_match_window_top2): what the scan returns when the best candidate is masked as well
+    g2, second = grid_g.match_window(qd, qx, qy, qr, qmin, qmax, skip=skip, top2=True)
+    _check_matches(g2, grid_o.match_window(d1, qd, qx, qy, qr, qmin, qmax, skip=skip))
+    assert np.all((second >= 0) == (g2["second_dist"] < 256))
+    checked = 0
+    for q in np.flatnonzero(g2["best_idx"] >= 0)[:200]:
+        sk2 = skip.copy(); sk2[g2["best_idx"][q]] = 1
+        o = grid_o.match_window(d1, qd[q:q + 1], qx[q:q + 1], qy[q:q + 1], qr[q:q + 1], qmin[q:q + 1], qmax[q:q + 1], skip=sk2)
+        assert int(o["best_idx"][0]) == int(second[q]) and (second[q] < 0 or int(o["best_dist"][0]) == int(g2["second_dist"][q]))
+        checked += second[q] >= 0
+    assert checked > 50
     grid_g.close()
 
 
