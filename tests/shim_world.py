@@ -31,7 +31,13 @@ def lib():
         path = os.path.join(DRV_DIR, "libshimdriver.so")
         if not os.path.exists(path):
             build()
-        _lib = C.CDLL(path)
+        try:
+            _lib = C.CDLL(path)
+        except OSError:
+            # a prebuilt driver whose oracle/_ref/libdutils_ref.so did not travel with it: rebuild (its Makefile links the
+            # reference's DUtils::Random only when that file is there, the stub's inline form otherwise)
+            subprocess.check_call(["make", "-B", "-C", DRV_DIR], stdout=subprocess.DEVNULL)
+            _lib = C.CDLL(path)
         _lib.sw_create.restype = C.c_void_p
         _lib.sw_error.restype = C.c_char_p
     return _lib
