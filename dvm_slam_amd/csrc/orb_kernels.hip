@@ -202,12 +202,25 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   uint32_t* lds32 = reinterpret_cast<uint32_t*>(rz_smem);
   const int nrow = syb - sya + 1;
   {
-    int r = (int)(((float)tid + 0.5f) * (1.0f / (float)ndw)), c = tid - r * ndw;   // exact for these small ints
-    const int dr = 256 / ndw, dc = 256 - dr * ndw;
-    while (r < nrow) {
-      lds32[r * (lds_pitch >> 2) + c] = reinterpret_cast<const uint32_t*>(Sg + (int64_t)r * P.stride)[c];
-      c += dc; r += dr;
-      if (c >= ndw) { c -= ndw; r++; }
+    // EIGHT loads in flight per thread: written as one load + one LDS store per loop iteration, the compiler put an
+    // s_waitcnt vmcnt(0) between them and a workgroup paid ~25 global round trips in a row for its ~6 400 source dwords
+    // (a 256 x 64 tile's launch was 30 us of waiting: the seven resize launches of a 256-frame batch 241 us for 102 us of issue)
+    const int total = nrow * ndw, pitch4 = lds_pitch >> 2, sstride4 = P.stride >> 2;
+    const float inv = 1.0f / (float)ndw;
+    const uint32_t* S32 = reinterpret_cast<const uint32_t*>(Sg);   // (ga and the row pitch are multiples of 4)
+    for (int base = tid; base < total; base += 256 * 8) {
+      uint32_t v[8];
+      int at[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int i = min(base + 256 * k, total - 1);
+        const int r = (int)(((float)i + 0.5f) * inv), c = i - r * ndw;     // exact for these small ints
+        v[k] = S32[r * sstride4 + c];
+        at[k] = r * pitch4 + c;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (base + 256 * k < total) lds32[at[k]] = v[k];
     }
   }
   __syncthreads();
@@ -1165,11 +1178,12 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
   // two waves per cell while 32 survivor rounds of 128 cover the largest cell, else four
   const bool small = (max_rw - 6) * (max_rh - 6) <= 32 * 128;
   // (beyond the default 48 KB of dynamic LDS the limit is raised on the current device: per device, so per launch)
+  static const int lds_pad = std::getenv("DVM_FAST_LDS_PAD") ? atoi(std::getenv("DVM_FAST_LDS_PAD")) : 0;   /* experiment */
 #define DVM_FAST_LAUNCH(P, W)                                                                                              \
   do {                                                                                                                     \
     if (lay.total() > 48 * 1024)                                                                                           \
       raise_dynamic_lds(reinterpret_cast<const void*>(k_fast_cells<P, W>), lay.total());                                   \
-    hipLaunchKernelGGL((k_fast_cells<P, W>), grid, dim3(64 * W), lay.total(), s, d_pyr, PD.pyr_frame_bytes, d_cells, PD,   \
+    hipLaunchKernelGGL((k_fast_cells<P, W>), grid, dim3(64 * W), lay.total() + lds_pad, s, d_pyr, PD.pyr_frame_bytes, d_cells, PD,   \
                        d_cand, d_cell_count, max_rw, max_rh, batch, cell_first, cell_num);                                 \
   } while (0)
   // (one wave per cell was measured too: occupancy-bound, 0.76 ms vs 0.68 ms for two)
