@@ -445,7 +445,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int max_rw, int max_rh) {
   const int ew = max_rw - 6 > 0 ? max_rw - 6 : 1, eh = max_rh - 6 > 0 ? max_rh - 6 : 1;
   l.score_bytes = ((((ew + 2 + 3) & ~3) * (eh + 2)) + 15) & ~15;
   l.plist_bytes = (((ew + 9) * eh + 16) * 2 + 15) & ~15;   // 4 wave regions of ceil(items/4)*4 entries
-  l.pscore_bytes = (((ew + 9) * eh + 16) + 15) & ~15;      // corner scores, same offsets as the lists
+  l.pscore_bytes = 0;      // (corner scores are read back from the score map)
   return l;
 }
 // zero-extend two bytes of the 8-byte pool {a: bytes 4..7, b: bytes 0..3} into the halves of a dword
@@ -480,7 +480,6 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   uint8_t* tile = fast_smem;
   uint8_t* score = tile + lay.tile_bytes;
   uint16_t* plist = reinterpret_cast<uint16_t*>(score + lay.score_bytes);
-  uint8_t* pscore = reinterpret_cast<uint8_t*>(plist) + lay.plist_bytes;
   __shared__ int s_cnt_ini;
   constexpr int NT = 64 * NW;   // NW = 2 for small cells: fewer half-empty rounds and half the per-wave fixed cost
   __shared__ int s_tot[NW];
@@ -627,9 +626,8 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   if (lane == 0 && pass == 0) atomicAdd(&g_fast_hist[min(wcount >> 3, 31)], 1u);
 #endif
   // ---- B. per wave, no barrier: full strength of the wave's OWN survivors.  Corners (score > 0) are compacted in
-  // place at the head of the wave's list -- the write position never passes the read position -- with their scores
-  // at the same offsets of `pscore`; the four corner lists concatenated are still row-major.
-  uint8_t* myscore = pscore + wave * Q * 4;
+  // place at the head of the wave's list -- the write position never passes the read position --; their scores live in
+  // the score map; the four corner lists concatenated are still row-major.
   int ncorner = 0;   // wave-uniform
   for (int base = 0; base < wcount; base += 64) {
     const int k = base + lane;
@@ -645,7 +643,6 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     if (sc > 0) {
       const int pos = ncorner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u));
       mylist[pos] = (uint16_t)pe;
-      myscore[pos] = (uint8_t)sc;
     }
     ncorner += __popcll(bc);
   }
@@ -663,8 +660,9 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     const int k = r * 64 + lane;
     int fl = 0;
     if (k < ncorner) {
-      const int sv = myscore[k], pe = mylist[k];
+      const int pe = mylist[k];
       const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
+      const int sv = s[0];
       const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
                          max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
       if (sv > mx) fl = 1;    // every corner of this pass has sv >= tlow + 0: score = max(A,B) - 1 >= tlow
@@ -706,7 +704,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
       const int k = r * 64 + lane;
       const int pe = mylist[k];
       // border-relative level coordinates: (roi origin + 3 + e) - 16
-      out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), myscore[k]);
+      out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), score[((pe >> 7) + 1) * sp + (pe & 127) + 1]);
     }
     base += __popcll(m);
   }
