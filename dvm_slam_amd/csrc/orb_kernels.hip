@@ -1003,9 +1003,11 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 //   rBRIEF:   the 37 x 37 blurred patch (pattern radius 18.4) is staged in LDS as 37 rows x 10 dwords (6 instructions);
 //             the 512 rotated samples are LDS byte reads; 256 tests = 4 ballots of 64 lanes
 constexpr int kDescR = 18, kDescPitch = 40, kDescRows = 2 * kDescR + 1;
-constexpr int kDescPerWave = 4;   // keypoints a wave handles one after the other (16 per workgroup)
+constexpr int kDescPerWave = 2;   // keypoints a wave handles one after the other (8 per workgroup).  4 made this kernel itself 12 % faster
+                                  // (more loads in flight) but held 24 KB of LDS per workgroup, which the stages of the other pipeline lane
+                                  // could not use: the 256-frame stream ran 222.7 k frames/s with 4, 227-228 k with 2, 222.4 k with 1
 // A wave walks kDescPerWave keypoints: all their loads go out first (blurred patches -> LDS, IC rows -> registers), then the
-// four pairs of moments are reduced, then LANES 0..3 run fastAtan2 + the double-precision sincos for the four keypoints AT ONCE
+// pairs of moments are reduced, then LANES 0..kDescPerWave-1 run fastAtan2 + the double-precision sincos for the wave's keypoints AT ONCE
 // -- that part is ~100 instructions of wave-uniform floating point per keypoint when every keypoint has its own wave --, then
 // the four descriptors.  The pattern points (as floats) and the disc weights stay in registers across the keypoints.
 __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
