@@ -869,12 +869,20 @@ __global__ void __launch_bounds__(256) k_blur7(const uint8_t* __restrict__ pyr, 
                                                           (int64_t)(kEdge + t.y0 - 3) * L.stride + colb);
   uint32_t* r32 = reinterpret_cast<uint32_t*>(raw);
   {
-    int y = tid / 18, x = tid - 18 * y;           // 256 = 14 * 18 + 4
-    while (y < th + 6) {
-      r32[y * 18 + x] = (x < ndw) ? g32[(int64_t)y * (L.stride >> 2) + x] : 0u;
-      x += 4; y += 14;
-      if (x >= 18) { x -= 18; y++; }
+    // (kBlurTH + 6) * 18 = 1260 dwords = 5 per thread: all loads go out before the first LDS store (one load + s_waitcnt
+    // vmcnt(0) + store per loop iteration was five global round trips in a row)
+    constexpr int kIt = ((kBlurTH + 6) * 18 + 255) / 256;
+    uint32_t v[kIt];
+    const int total = (th + 6) * 18;
+#pragma unroll
+    for (int k = 0; k < kIt; k++) {
+      const int i = min(tid + 256 * k, total - 1);
+      const int y = i / 18, x = i - 18 * y;
+      v[k] = (x < ndw) ? g32[(int64_t)y * (L.stride >> 2) + x] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < kIt; k++)
+      if (tid + 256 * k < total) r32[tid + 256 * k] = v[k];
   }
   __syncthreads();
   const uint32_t g0 = c_gauss7[0], g1 = c_gauss7[1], g2 = c_gauss7[2], g3 = c_gauss7[3];
