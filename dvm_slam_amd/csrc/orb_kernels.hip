@@ -237,13 +237,23 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
     al[k] = (uint32_t)xal[dxc];
   }
   uint8_t* Dl = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off;
+  // the row tables of this wave's TH / 4 rows, all fetched before the first row is computed (read inside the loop, every row
+  // began with two scalar loads and an s_waitcnt lgkmcnt(0))
+  int sy_[TH / 4];
+  uint32_t bb_[TH / 4];
+#pragma unroll
+  for (int rr = 0; rr < TH / 4; rr++) {
+    const int dyc = min(y0 + ty + 4 * rr, L.h - 1);
+    sy_[rr] = yofs[dyc];
+    bb_[rr] = (uint32_t)ybe[dyc];
+  }
 #pragma unroll
   for (int rr = 0; rr < TH / 4; rr++) {
     const int dy = y0 + ty + 4 * rr;
     if (dy >= L.h) break;
-    const int sy = yofs[dy];
+    const int sy = sy_[rr];
     const int r0 = min(max(sy, 0), P.h - 1) - sya, r1 = min(max(sy + 1, 0), P.h - 1) - sya;
-    const uint32_t bb = (uint32_t)ybe[dy];
+    const uint32_t bb = bb_[rr];
     const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
     const uint8_t* S0 = rz_smem + r0 * lds_pitch;
     const uint8_t* S1 = rz_smem + r1 * lds_pitch;
@@ -1036,23 +1046,30 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
   for (int q = 0; q < kDescPerWave; q++) a[q] = aux[(int64_t)f * PD.kp_cap + g0 + min(q, nk - 1)];
   // ---- blurred patches -> LDS (flat addressing of the blurred level; addresses are clamped to the level so the unused
   // corner bytes of edge keypoints never leave the buffer)
+  // (registers first, LDS afterwards: with the store inside the load loop the second keypoint's loads waited for the first one's)
+  uint32_t pv[kDescPerWave][6];
 #pragma unroll
   for (int q = 0; q < kDescPerWave; q++) {
     const LevelDesc& L = PD.lv[a[q].level];
     const uint8_t* bl = blur + (int64_t)f * blur_frame_bytes + L.blur_off;
     const int st = L.blur_stride;
     const int bmax = st * L.h - 4;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int item = min(lane + 64 * i, kDescRows * 10 - 1);
+      const int r = (item * 205) >> 11, c = item - 10 * r;   // item / 10 for item < 1024
+      const int off = min(max((a[q].cy - kDescR + r) * st + a[q].cx - kDescR + 4 * c, 0), bmax);
+      __builtin_memcpy(&pv[q][i], bl + off, 4);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kDescPerWave; q++) {
     uint8_t* P = s_patch[wave][q];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       const int item = lane + 64 * i;
-      const int r = (item * 205) >> 11, c = item - 10 * r;   // item / 10 for item < 1024
-      if (item < kDescRows * 10) {
-        const int off = min(max((a[q].cy - kDescR + r) * st + a[q].cx - kDescR + 4 * c, 0), bmax);
-        uint32_t v;
-        __builtin_memcpy(&v, bl + off, 4);
-        *reinterpret_cast<uint32_t*>(P + r * kDescPitch + 4 * c) = v;
-      }
+      const int r = (item * 205) >> 11, c = item - 10 * r;
+      if (item < kDescRows * 10) *reinterpret_cast<uint32_t*>(P + r * kDescPitch + 4 * c) = pv[q][i];
     }
   }
   // ---- IC_Angle: the 31 x 31 patch as 31 rows x 8 unaligned dwords; moments = v_dot4_u32_u8 against the disc weights
