@@ -1039,11 +1039,12 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g0 = (blk * 4 + wave) * kDescPerWave;
-  const int nk = min(kDescPerWave, n_kp[f] - g0);          // wave-uniform
-  if (nk <= 0) return;
-  KpAux a[kDescPerWave];
+  const int nkf = n_kp[f];
+  if (nkf - blk * 4 * kDescPerWave <= 0) return;           // the whole workgroup is past the frame's keypoints
+  const int nk = max(min(kDescPerWave, nkf - g0), 0);      // wave-uniform; a wave without keypoints stays for the barriers below
+  KpAux a[kDescPerWave];                                   // (and walks keypoint 0 of the workgroup: valid data, nothing stored)
 #pragma unroll
-  for (int q = 0; q < kDescPerWave; q++) a[q] = aux[(int64_t)f * PD.kp_cap + g0 + min(q, nk - 1)];
+  for (int q = 0; q < kDescPerWave; q++) a[q] = aux[(int64_t)f * PD.kp_cap + (nk > 0 ? g0 + min(q, nk - 1) : blk * 4 * kDescPerWave)];
   // ---- blurred patches -> LDS (flat addressing of the blurred level; addresses are clamped to the level so the unused
   // corner bytes of edge keypoints never leave the buffer)
   // (registers first, LDS afterwards: with the store inside the load loop the second keypoint's loads waited for the first one's)
@@ -1096,18 +1097,22 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
     m10[q] = wave_sum_i32(s10);
     m01[q] = wave_sum_i32(s01);
   }
-  // ---- angle and rotation of the four keypoints on lanes 0..3, then handed to every lane by v_readlane
-  int my10 = 0, my01 = 0;
+  // ---- angle and rotation: fastAtan2 + the double-precision sincos are ~150 instructions of one-lane floating point per
+  // keypoint; every wave running them for its own two keypoints spent a third of the kernel's issue slots on two lanes.  The
+  // moments of the workgroup's 4 x kDescPerWave keypoints meet in LDS and ONE wave computes all the angles, a lane each.
+  __shared__ int s_mom[4 * kDescPerWave][2];
+  __shared__ float s_rot[4 * kDescPerWave][3];
 #pragma unroll
-  for (int q = 0; q < kDescPerWave; q++) { if (lane == q) { my10 = m10[q]; my01 = m01[q]; } }
-  float ang_l = 0.f, ca_l = 1.f, sb_l = 0.f;
-  if (lane < kDescPerWave) {
-    ang_l = fast_atan2_deg((float)my01, (float)my10);
-    sincos_deg(ang_l, ca_l, sb_l);
+  for (int q = 0; q < kDescPerWave; q++)
+    if (lane == q) { s_mom[wave * kDescPerWave + q][0] = m10[q]; s_mom[wave * kDescPerWave + q][1] = m01[q]; }
+  __syncthreads();
+  if (threadIdx.x < 4 * kDescPerWave) {
+    float ang, ca_, sb_;
+    ang = fast_atan2_deg((float)s_mom[threadIdx.x][1], (float)s_mom[threadIdx.x][0]);
+    sincos_deg(ang, ca_, sb_);
+    s_rot[threadIdx.x][0] = ang; s_rot[threadIdx.x][1] = ca_; s_rot[threadIdx.x][2] = sb_;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __syncthreads();
   float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -1117,9 +1122,7 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
 #pragma unroll
   for (int q = 0; q < kDescPerWave; q++) {
     if (q >= nk) break;
-    const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_l), q));
-    const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_l), q));
-    const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sb_l), q));
+    const float angle = s_rot[wave * kDescPerWave + q][0], ca = s_rot[wave * kDescPerWave + q][1], sb = s_rot[wave * kDescPerWave + q][2];
     const uint8_t* c1 = s_patch[wave][q] + kDescR * kDescPitch + kDescR;
     unsigned long long words[4];
 #pragma unroll
