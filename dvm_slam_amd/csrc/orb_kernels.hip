@@ -490,7 +490,6 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   uint8_t* tile = fast_smem;
   uint8_t* score = tile + lay.tile_bytes;
   uint16_t* plist = reinterpret_cast<uint16_t*>(score + lay.score_bytes);
-  __shared__ int s_cnt_ini;
   constexpr int NT = 64 * NW;   // NW = 2 for small cells: fewer half-empty rounds and half the per-wave fixed cost
   __shared__ int s_tot[NW];
 
@@ -540,7 +539,6 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   }
   uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
   for (int i = tid; i < (sp * (eh + 2)) >> 2; i += NT) s32[i] = 0;
-  if (tid == 0) s_cnt_ini = 0;
   __syncthreads();
   DVM_FSTAMP(1);
 
@@ -665,7 +663,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
   // ---- C. per wave: strict local maxima among its corners; bit0 = passes iniTh, bit1 = passes minTh
   const int rounds = (ncorner + 63) >> 6;   // <= 32: a wave owns at most 2048 pixels
   uint32_t flags_lo = 0, flags_hi = 0;      // 2 bits per round
-  int cnt_ini = 0;
+  int kept = 0;                             // wave-uniform: strict maxima of this wave (ballots; was an LDS atomic per lane + a barrier of its own)
   for (int r = 0; r < rounds; r++) {
     const int k = r * 64 + lane;
     int fl = 0;
@@ -677,30 +675,26 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
                          max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
       if (sv > mx) fl = 1;    // every corner of this pass has sv >= tlow + 0: score = max(A,B) - 1 >= tlow
     }
-    cnt_ini += fl & 1;
+    kept += __popcll(__ballot(fl != 0));
     if (r < 16) flags_lo |= (uint32_t)fl << (2 * r);
     else flags_hi |= (uint32_t)fl << (2 * (r - 16));
   }
-  if (cnt_ini) atomicAdd(&s_cnt_ini, cnt_ini);
+  if (lane == 0) s_tot[wave] = kept;
   DVM_FSTAMP(5);
   __syncthreads();
-  if (s_cnt_ini == 0) {   // workgroup-uniform: nothing at this threshold
+  int wg_kept = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) wg_kept += s_tot[w];
+  if (wg_kept == 0) {   // workgroup-uniform: nothing at this threshold
     if (pass == 0 && PD.min_th < PD.ini_th) {
       tlow = PD.min_th;
-      __syncthreads();      // everyone has read s_cnt_ini / the lists before they are rebuilt
+      __syncthreads();      // everyone has read s_tot / the lists before they are rebuilt
       continue;
     }
     break;
   }
   const int bit = 1;
   // ordered compaction: wave lists in wave order, inside a list in list order = row-major
-  int kept = 0;
-  for (int r = 0; r < rounds; r++) {
-    const int fl = (r < 16) ? (flags_lo >> (2 * r)) : (flags_hi >> (2 * (r - 16)));
-    kept += __popcll(__ballot((fl & bit) != 0));
-  }
-  if (lane == 0) s_tot[wave] = kept;
-  __syncthreads();
   int base = 0;
 #pragma unroll
   for (int w = 0; w < NW; w++) { if (w < wave) base += s_tot[w]; total += s_tot[w]; }
