@@ -630,7 +630,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     }
   }
   DVM_FSTAMP(2);
-#ifdef DVM_FAST_DEBUG
+#ifdef DVM_FAST_HIST
   if (lane == 0 && pass == 0) atomicAdd(&g_fast_hist[min(wcount >> 3, 31)], 1u);
 #endif
   // ---- B. per wave, no barrier: full strength of the wave's OWN survivors.  Corners (score > 0) are compacted in
@@ -655,7 +655,7 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
     ncorner += __popcll(bc);
   }
   DVM_FSTAMP(3);
-#ifdef DVM_FAST_DEBUG
+#ifdef DVM_FAST_HIST
   if (lane == 0 && pass == 0) atomicAdd(&g_fast_hist[32 + min(ncorner >> 2, 31)], 1u);
 #endif
   __syncthreads();   // the score map is complete
