@@ -537,8 +537,8 @@ __device__ __forceinline__ void fast_cell(const uint8_t* __restrict__ pyr, int p
       if (x >= dwr) { x -= dwr; y++; }
     }
   }
-  uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
-  for (int i = tid; i < (sp * (eh + 2)) >> 2; i += NT) s32[i] = 0;
+  uint4* s128 = reinterpret_cast<uint4*>(score);           // (score starts 16-byte aligned and its allocation is rounded up to 16)
+  for (int i = tid; i < (sp * (eh + 2) + 15) >> 4; i += NT) s128[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   DVM_FSTAMP(1);
 
