@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s ach
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE of the launcher, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per launch group (per GPU)")
@@ -166,11 +166,35 @@ def pcie_inclusive_leg(capi, frames, B, steps, device):
             "note": "input in pinned host memory (dvm_orb_staging), 2 handles ping-pong: H2D of one batch under the kernels of the other"}
 
 
+def relaunch_distributed(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): become the launcher -- the same
+    command under `torch.distributed.run --nproc-per-node N`, one rank per GPU over RCCL, rendezvous on 127.0.0.1."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DVM_BENCH_RELAUNCHED"] = "1"
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus is None:
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_distributed(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks (one rank per GPU: they must agree)")
     # test hooks (tests/test_gpu_bench.py): several ranks sharing GPU 0 over gloo exercise the N > 1 control flow on a 1-GPU box
     backend = os.environ.get("DVM_BENCH_BACKEND", "nccl")
     if os.environ.get("DVM_BENCH_SHARE_GPU") == "1":
@@ -282,6 +306,13 @@ def main():
     for ln in lanes:
         ln["ext"].profiling(False)
     dt = exchange.max_over_ranks(dt, device="cuda" if backend == "nccl" else "cpu")
+    # which GPU every rank ran on, gathered over the same process group the timing used (the line reports what was launched, not what was asked for)
+    rank_devices = [local]
+    if use_dist:
+        mine = torch.tensor([rank, local, torch.cuda.current_device()], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        rank_devices = [int(g[2].item()) for g in sorted(got, key=lambda g: int(g[0].item()))]
     prof = {}
     parts = [ln["ext"].profile_get("fast") for ln in lanes]
     prof["fast"] = (sum(p[0] for p in parts), sum(p[1] for p in parts))
@@ -415,7 +446,10 @@ def main():
                        "frames_per_step_per_gpu": chunks * B, "frames_per_launch_group": B, "launch_groups_per_step": chunks,
                        "resident_stream_frames": nstream, "nfeatures": 1000, "nlevels": 8, "scale_factor": 1.2,
                        "ini_th_fast": 20, "min_th_fast": 7, "match": "SearchByProjection(Cur,Last) window th=15",
-                       "parallelism": f"agents{world}", "pipeline_lanes": nl},
+                       "parallelism": f"agents{world}", "pipeline_lanes": nl,
+                       "ranks": {"count": world, "backend": ("rccl" if backend == "nccl" else backend) if use_dist else "none (single process)",
+                                 "cuda_device_of_rank": rank_devices, "launched_by": "bench.py itself (--gpus N without a launcher)"
+                                 if os.environ.get("DVM_BENCH_RELAUNCHED") == "1" else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python")}},
             "roofline": roof, "sanity_matches_le_TH_HIGH_last_step": nmatched,
         }
         if world == 1 and not a.no_pcie:

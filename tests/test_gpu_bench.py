@@ -65,3 +65,24 @@ def test_bench_two_ranks_control_flow():
     rep = sh["replicas"]
     assert rep["ranks"] == 2 and rep["value"] >= rep["this_rank"] > 0
     assert one["huber_off"]["value"] > 0 and one["huber_off"]["iterations"] > 0
+
+
+def test_bench_plain_command_honours_gpus():
+    """The driver's command shape without a launcher: `python bench.py --gpus 2` must itself start two ranks (here both on the
+    one GPU of the box, over gloo) and report n_gpus = 2 -- not one rank on GPU 0 under the label it was asked for."""
+    env = dict(os.environ, DVM_BENCH_SHARE_GPU="1", DVM_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--stream-frames", "64",
+           "--chunks-per-step", "2", "--no-ba", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"]["count"] == 2 and len(d["config"]["ranks"]["cuda_device_of_rank"]) == 2
+    assert d["config"]["ranks"]["launched_by"].startswith("bench.py itself")
+    # a launcher whose rank count disagrees with --gpus is refused, not mislabelled
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)
