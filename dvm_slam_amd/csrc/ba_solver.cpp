@@ -60,6 +60,7 @@ struct dvm_ba {
   int* d_fail = nullptr;
   uint8_t* d_depth = nullptr;
   uint8_t* d_flags = nullptr;               // per-edge level / robust-kernel flags (dvm_ba_set_edge_flags); V.e_flags points here once set
+  uint8_t* h_flags = nullptr;               // ONE page-locked staging slot of E bytes for them, reserved with the problem and reused by every call
   bool have_problem = false;
   double ms_structure = 0;
   BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
@@ -429,6 +430,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->dalloc(&V.partial, (size_t)(E + 255) / 256)); ok(h->dalloc(&V.partial2, (size_t)(8 * (size_t)L + 255) / 256 + (size_t)(V.nfree + 255) / 256 + (size_t)(V.nfree + 3) / 4 + 2));   // block partials of k_point_backsub / k_max_diag
   ok(h->dalloc(&h->d_depth, (size_t)E));
   ok(h->dalloc(&h->d_flags, (size_t)E));
+  h->h_flags = h->stage_alloc((size_t)std::max(E, 1));      // (nullptr when pinned memory is exhausted: set_edge_flags then copies synchronously)
   ok(h->upload(&V.nz_tiles, SC.nz_tiles)); V.n_nz = (int)(SC.nz_tiles.size() / 2);
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
@@ -501,8 +503,17 @@ int dvm_ba_set_edge_flags(dvm_ba* h, const uint8_t* flags) {
   if (h->world > 1) { set_error("dvm_ba_set_edge_flags: not available on a landmark-sharded problem"); return DVM_ERR_STATE; }
   DVM_HIP(hipSetDevice(h->device));
   if (!flags) { h->V.e_flags = nullptr; return DVM_OK; }
-  int rc = h->copy_in(h->d_flags, flags, (size_t)h->V.E);
-  if (rc == DVM_OK) rc = h->flush_copies();
+  // the flags change between the rounds of one problem (the welding BA's setLevel(1) round): they travel through the slot
+  // reserved by set_problem -- staging them with copy_in() would take E more bytes of the pinned arena per call, which is only
+  // rewound when the problem is replaced.  The slot may still be the source of the previous call's copy: wait for the stream.
+  int rc = hip_check(hipStreamSynchronize(h->stream), "dvm_ba_set_edge_flags: sync");
+  if (rc != DVM_OK) return rc;
+  if (h->h_flags) {
+    std::memcpy(h->h_flags, flags, (size_t)h->V.E);
+    rc = hip_check(hipMemcpyAsync(h->d_flags, h->h_flags, (size_t)h->V.E, hipMemcpyHostToDevice, h->stream), "upload(flags)");
+  } else {
+    rc = hip_check(hipMemcpy(h->d_flags, flags, (size_t)h->V.E, hipMemcpyHostToDevice), "upload(flags)");   // the stream is idle: ordered
+  }
   if (rc == DVM_OK) h->V.e_flags = h->d_flags;
   return rc;
 }

@@ -54,6 +54,7 @@ int dvm_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+int dvm_set_device(int device) { return need_device(device); }
 
 // ------------------------------------------------------------------------------------------ ORB
 int dvm_orb_create(const dvm_orb_params* p, int device, int max_batch, dvm_orb** out) {

@@ -23,6 +23,7 @@
 
 #include "Frame.h"
 #include "MapPoint.h"
+#include "dvm_device.h"
 #include "dvmslam_hip.h"
 
 namespace ORB_SLAM3 {
@@ -46,6 +47,7 @@ inline int run(const dvm_frustum_frame& f, MapPoint* const* pts, int n, float vi
     mind[i] = pts[i]->GetMinDistance(); maxd[i] = pts[i]->GetMaxDistance();   // raw mfMin/MaxDistance (see ORBmatcher_shim.h)
   }
   std::vector<dvm_track_point> out(n);
+  dvm_host::use_device();
   if (dvm_is_in_frustum(&f, P.data(), Nn.data(), mind.data(), maxd.data(), n, viewingCosLimit, out.data(), 0, NULL) != DVM_OK)
     throw std::runtime_error(dvm_last_error());
   int nin = 0;
@@ -83,6 +85,7 @@ inline void Frame::UndistortKeyPoints() {
   const dvm_distortion d = dvm_frame_detail::distortion(*this);
   mvKeysUn.resize(N);
   if (N == 0) return;
+  dvm_host::use_device();
   if (dvm_undistort_keypoints(&d, reinterpret_cast<const dvm_keypoint*>(mvKeys.data()), reinterpret_cast<dvm_keypoint*>(mvKeysUn.data()), N, 0, NULL) != DVM_OK)
     throw std::runtime_error(dvm_last_error());
 }

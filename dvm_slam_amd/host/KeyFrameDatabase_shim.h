@@ -32,14 +32,16 @@
 #include "KeyFrame.h"
 #include "Map.h"
 #include "ORBVocabulary.h"
+#include "dvm_device.h"
 #include "keyframe_database.h"
 
 namespace ORB_SLAM3 {
 
 class KeyFrameDatabase {
  public:
-  KeyFrameDatabase() : db_(new dvm_host::KeyFrameDatabase(0)) {}
-  explicit KeyFrameDatabase(const ORBVocabulary& voc, int device = 0) : mpVoc(&voc), db_(new dvm_host::KeyFrameDatabase(device)) {}
+  KeyFrameDatabase() : db_(new dvm_host::KeyFrameDatabase(dvm_host::device())), live_(this) { db_->SetLiveView(&live_); }
+  explicit KeyFrameDatabase(const ORBVocabulary& voc, int device = dvm_host::device())
+      : mpVoc(&voc), db_(new dvm_host::KeyFrameDatabase(device)), live_(this) { db_->SetLiveView(&live_); }
   ~KeyFrameDatabase() { delete db_; }
   KeyFrameDatabase(const KeyFrameDatabase&) = delete;
 
@@ -144,34 +146,39 @@ class KeyFrameDatabase {
     uids_[u] = id;
     return id;
   }
-  // what the reference reads from the objects during a query
-  void refresh(KeyFrame* pQuery) {
+  // What the reference reads from the objects DURING a query -- pKFi->GetMap() (LoopClosing::MergeLocal moves keyframes between
+  // maps with UpdateMap, LoopClosing.cc:1558,1767), isBad(), GetBestCovisibilityKeyFrames(10), GetConnectedKeyFrames() -- is read
+  // from them during the query here too: the mirror asks this view for the slots it reaches (the handful above the common-word
+  // bar), not for every stored keyframe.  Map bad flags: a few maps, pushed per query.
+  struct Live : dvm_host::LiveKeyFrameView {
+    KeyFrameDatabase* o;
+    explicit Live(KeyFrameDatabase* o_) : o(o_) {}
+    bool isBad(int slot) override { return o->kf_of_[slot]->isBad(); }
+    int32_t map_id(int slot) override { return o->map_id(o->kf_of_[slot]->GetMap()); }
+    void best_covisibles(int slot, std::vector<int32_t>& out) override {
+      out.clear();
+      for (KeyFrame* n : o->kf_of_[slot]->GetBestCovisibilityKeyFrames(10)) {
+        const auto it = o->slot_of_.find(n);
+        if (it != o->slot_of_.end()) out.push_back(it->second);      // (a neighbour outside the database carries no query id: the walk skips it)
+      }
+    }
+    void connected(int slot, std::set<int32_t>& out) override {
+      out.clear();
+      for (KeyFrame* n : o->kf_of_[slot]->GetConnectedKeyFrames()) {
+        const auto it = o->slot_of_.find(n);
+        if (it != o->slot_of_.end()) out.insert(it->second);
+      }
+    }
+  };
+  void refresh(KeyFrame*) {
     for (const auto& ms : map_ids_) db_->SetMapBad(ms.second, ms.first->IsBad());
-    std::vector<int32_t> idx;
-    for (const auto& ks : slot_of_) {
-      KeyFrame* k = ks.first;
-      db_->SetBadFlag(ks.second, k->isBad());
-      idx.clear();
-      for (KeyFrame* n : k->GetBestCovisibilityKeyFrames(10)) {
-        const auto it = slot_of_.find(n);
-        if (it != slot_of_.end()) idx.push_back(it->second);     // (a neighbour outside the database carries no query id: the walk skips it)
-      }
-      db_->SetBestCovisibilityKeyFrames(ks.second, idx.data(), (int)idx.size());
-    }
-    if (pQuery) {
-      idx.clear();
-      for (KeyFrame* n : pQuery->GetConnectedKeyFrames()) {
-        const auto it = slot_of_.find(n);
-        if (it != slot_of_.end()) idx.push_back(it->second);
-      }
-      db_->SetConnectedKeyFrames(slot_of_[pQuery], idx.data(), (int)idx.size());
-    }
   }
 
   const ORBVocabulary* mpVoc = nullptr;
   std::map<boost::uuids::uuid, KeyFrame*> uuidToKeyFrame;
   std::mutex mMutex;
   dvm_host::KeyFrameDatabase* db_;
+  Live live_;
   std::map<KeyFrame*, int> slot_of_;
   std::vector<KeyFrame*> kf_of_;
   std::map<Map*, int32_t> map_ids_;

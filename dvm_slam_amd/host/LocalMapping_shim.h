@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "KeyFrame.h"
+#include "dvm_device.h"
 #include "dvmslam_hip.h"
 
 namespace ORB_SLAM3 {
@@ -60,6 +61,7 @@ inline void TriangulateMatches(KeyFrame* pKF1, KeyFrame* pKF2, const std::vector
   for (int i = 0; i < n; i++) { pairs[2 * i] = (int32_t)vMatchedIndices[i].first; pairs[2 * i + 1] = (int32_t)vMatchedIndices[i].second; }
   std::vector<float> X(3 * (size_t)n);
   std::vector<int32_t> st(n);
+  dvm_host::use_device();
   if (dvm_triangulate_matches(&P, reinterpret_cast<const dvm_keypoint*>(pKF1->mvKeysUn.data()), (int)pKF1->mvKeysUn.size(),
                               reinterpret_cast<const dvm_keypoint*>(pKF2->mvKeysUn.data()), (int)pKF2->mvKeysUn.size(), pairs.data(), n,
                               pKF1->mvLevelSigma2.data(), pKF2->mvLevelSigma2.data(), pKF1->mvScaleFactors.data(), pKF2->mvScaleFactors.data(),

@@ -5,7 +5,7 @@
 // sorted[0.5 * (N - 1)], the first strictly smaller median wins).  Here the rows of ALL the points of a call travel to the device in
 // one block and come back as one index per point (dvm_distinctive_descriptors: a wave per point, N x N distances row by row,
 // the median by a ballot binary search) -- LocalMapping::ProcessNewKeyFrame / CreateNewMapPoints / SearchInNeighbors call the
-// member once per map point, hundreds of times per keyframe: MapPoint_ComputeDistinctiveDescriptorsBatch(points) does them together.
+// member once per map point, hundreds of times per keyframe: MapPoint::ComputeDistinctiveDescriptorsBatch(points) does them together.
 #pragma once
 #include <map>
 #include <mutex>
@@ -15,11 +15,14 @@
 
 #include "KeyFrame.h"
 #include "MapPoint.h"
+#include "dvm_device.h"
 #include "dvmslam_hip.h"
 
 namespace ORB_SLAM3 {
 
-inline void MapPoint_ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoint*>& points) {
+// static member: it reads mbBad / mObservations and writes mDescriptor under mMutexFeatures, all protected (include/MapPoint.h:210-248).
+// The reference's header gains its declaration: `static void ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoint*>&);`
+inline void MapPoint::ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoint*>& points) {
   std::vector<uint8_t> rows;
   std::vector<int32_t> off(1, 0);
   std::vector<MapPoint*> who;
@@ -28,9 +31,10 @@ inline void MapPoint_ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoi
     if (!p) continue;
     std::map<KeyFrame*, std::tuple<int, int>> observations;
     {
+      // the members themselves, as :391-395 reads them: isBad() and GetObservations() take this same non-recursive mutex
       std::unique_lock<std::mutex> lock1(p->mMutexFeatures);
-      if (p->isBad()) continue;                           // (:391-393; isBad() reads mbBad)
-      observations = p->GetObservations();
+      if (p->mbBad) continue;
+      observations = p->mObservations;
     }
     if (observations.empty()) continue;
     std::vector<cv::Mat> v;
@@ -50,6 +54,7 @@ inline void MapPoint_ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoi
   }
   if (who.empty()) return;
   std::vector<int32_t> best(who.size()), median(who.size());
+  dvm_host::use_device();
   if (dvm_distinctive_descriptors(rows.data(), off.data(), (int)who.size(), best.data(), median.data(), 0, nullptr) != DVM_OK)
     throw std::runtime_error(dvm_last_error());
   for (size_t i = 0; i < who.size(); i++) {
@@ -58,6 +63,6 @@ inline void MapPoint_ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoi
   }
 }
 
-inline void MapPoint::ComputeDistinctiveDescriptors() { MapPoint_ComputeDistinctiveDescriptorsBatch(std::vector<MapPoint*>(1, this)); }
+inline void MapPoint::ComputeDistinctiveDescriptors() { ComputeDistinctiveDescriptorsBatch(std::vector<MapPoint*>(1, this)); }
 
 }  // namespace ORB_SLAM3

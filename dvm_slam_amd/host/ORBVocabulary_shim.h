@@ -17,13 +17,14 @@
 
 #include "Thirdparty/DBoW2/DBoW2/BowVector.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#include "dvm_device.h"
 #include "orb_vocabulary.h"
 
 namespace ORB_SLAM3 {
 
 class ORBVocabulary {
  public:
-  explicit ORBVocabulary(int device = 0) : device_(device) {}
+  explicit ORBVocabulary(int device = dvm_host::device()) : device_(device) {}
   bool loadFromTextFile(const std::string& filename) {
     voc_.reset(dvm_host::ORBVocabulary::loadFromTextFile(device_, filename.c_str()));
     return voc_ != nullptr;

@@ -8,6 +8,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include "dvm_device.h"
 #include "dvmslam_hip.h"
 
 namespace ORB_SLAM3 {
@@ -19,7 +20,7 @@ class ORBextractor {
   ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
       : nlevels_(nlevels), scaleFactor_(scaleFactor) {
     dvm_orb_params p{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
-    if (dvm_orb_create(&p, /*device=*/0, /*max_batch=*/1, &h_) != DVM_OK) throw std::runtime_error(dvm_last_error());
+    if (dvm_orb_create(&p, dvm_host::device(), /*max_batch=*/1, &h_) != DVM_OK) throw std::runtime_error(dvm_last_error());
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     dvm_orb_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr);

@@ -23,13 +23,14 @@
 #include "Frame.h"
 #include "KeyFrame.h"
 #include "MapPoint.h"
+#include "dvm_device.h"
 #include "orb_matcher.h"
 
 namespace ORB_SLAM3 {
 
 class ORBmatcher {
  public:
-  ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri), m_(nnratio, checkOri, 0) {}
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri), m_(nnratio, checkOri, dvm_host::device()) {}
 
   // Computes the Hamming distance between two ORB descriptors
   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {

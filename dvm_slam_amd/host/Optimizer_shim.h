@@ -24,14 +24,15 @@
 #include "Map.h"
 #include "MapPoint.h"
 #include "Optimizer.h"
+#include "dvm_device.h"
 #include "dvmslam_hip.h"
 
 namespace ORB_SLAM3 {
 namespace dvm_optimizer_detail {
 
 inline void check(int rc) { if (rc != DVM_OK) throw std::runtime_error(dvm_last_error()); }
-// the HIP device of this agent's optimiser calls (one agent per GPU: set once at start-up, e.g. from LOCAL_RANK)
-inline int& device() { static int d = 0; return d; }
+// the HIP device of this agent (one agent per GPU: dvm_host::set_device(k) once at start-up, e.g. from LOCAL_RANK -- dvm_device.h)
+inline int device() { return dvm_host::device(); }
 // (t, q_xyzw) as doubles <- g2o::SE3Quat(Tcw.unit_quaternion().cast<double>(), Tcw.translation().cast<double>())
 inline void pose7(const Sophus::SE3f& T, double* p) {
   for (int i = 0; i < 3; i++) p[i] = (double)T.translation()(i);

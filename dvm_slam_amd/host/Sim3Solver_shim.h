@@ -1,20 +1,20 @@
-// dvm_slam_amd/host/Sim3Solver_shim.h -- ORB_SLAM3::Sim3Solver (include/Sim3Solver.h:31-140, src/Sim3Solver.cc) on the HIP library:
-// the member function bodies.  Same class, same signatures, same members: a maintainer deletes the bodies of the constructor,
-// SetRansacParameters, both iterate() overloads, find() and the four getters from src/Sim3Solver.cc and compiles this header
-// into the same translation unit (ComputeCentroid / ComputeSim3 / CheckInliers / Project / FromCameraToImage are no longer
-// called: their arithmetic -- Horn's closed form on three correspondences and the reprojection test of all N in both images,
-// :294-408 -- runs on the device, one wave per hypothesis, dvm_sim3_hypotheses).
+// dvm_slam_amd/host/Sim3Solver_shim.h -- the RANSAC loop of ORB_SLAM3::Sim3Solver (src/Sim3Solver.cc:154-216: both iterate()
+// overloads and find()) on the HIP library.  NOTHING ELSE of the class moves: the constructor, SetRansacParameters and the
+// getters stay where they are in src/Sim3Solver.cc (they are host bookkeeping on KeyFrame* / MapPoint*); a maintainer deletes
+// the bodies of iterate() x2 and find() there and includes this header.  ComputeCentroid / ComputeSim3 /
+// CheckInliers / Project are then no longer called: Horn's closed form on three correspondences and the reprojection test of all
+// N points in both images (:294-408) run on the device, one wave per hypothesis (dvm_sim3_hypotheses).
 //
-// What iterate() does differently from the reference, and why it does not matter: the reference draws ONE minimal set per
-// RANSAC iteration and stops drawing at the first hypothesis with more than mRansacMinInliers inliers; here the sets of the
-// whole call (nIterations of them, or what is left of mRansacMaxIts) are drawn first, with the same DUtils::Random::RandomInt
-// procedure, evaluated in one launch, and the reference's sequential rule (:186-203: ">= best" replaces, "> min inliers"
-// returns) is applied to the results in order -- so the returned hypothesis, its inliers, mnIterations and the best-so-far
-// state are the reference's for those draws; only libc's rand() has been advanced by the sets behind the accepted one, and that
-// stream is shared by every thread of the reference anyway (Tracking's and LoopClosing's RANSACs interleave in it).
+// What a call does differently from the reference, and why the caller cannot tell: the reference draws ONE minimal set per
+// RANSAC iteration and stops drawing at the first hypothesis with more than mRansacMinInliers inliers.  Here all sets a call may
+// need (nIterations, or what mRansacMaxIts leaves) are drawn up front with the reference's own DUtils::Random::RandomInt
+// procedure (:166-181), all hypotheses are evaluated by one launch, and the outcome is read off the per-hypothesis inlier
+// counts: the running best is taken over by every hypothesis that ties or beats it, the first such hypothesis above the
+// acceptance bar ends the call -- the rule of :186-203.  Returned transform, inlier flags, mnIterations and the best-so-far
+// members are therefore the reference's for those draws; only libc's rand() stream has advanced past the sets behind the
+// accepted one (a stream all threads of the reference share and interleave in anyway).
 #pragma once
 #include <algorithm>
-#include <cmath>
 #include <stdexcept>
 #include <vector>
 
@@ -22,161 +22,142 @@
 #include "MapPoint.h"
 #include "Sim3Solver.h"
 #include "Thirdparty/DBoW2/DUtils/Random.h"
+#include "dvm_device.h"
 #include "dvmslam_hip.h"
 
 namespace ORB_SLAM3 {
 namespace dvm_sim3solver_detail {
-inline int& device() { static int d = 0; return d; }     // one agent per GPU: set once at start-up
+
+// the hypotheses of one call as the device returns them: per hypothesis s, R (row-major), t, the inlier count and one flag per point
+struct Batch {
+  int H = 0, N = 0;
+  std::vector<float> T12;          // 13 floats per hypothesis
+  std::vector<int32_t> inliers;
+  std::vector<uint8_t> mask;       // H x N
+  float scale(int h) const { return T12[13 * (size_t)h]; }
+  Eigen::Matrix3f rotation(int h) const {
+    Eigen::Matrix3f R;
+    for (int k = 0; k < 9; k++) R(k / 3, k % 3) = T12[13 * (size_t)h + 1 + k];
+    return R;
+  }
+  Eigen::Vector3f translation(int h) const {
+    Eigen::Vector3f t;
+    for (int k = 0; k < 3; k++) t(k) = T12[13 * (size_t)h + 10 + k];
+    return t;
+  }
+  Eigen::Matrix4f matrix(int h) const {                       // [sR | t; 0 0 0 1]
+    Eigen::Matrix4f M = Eigen::Matrix4f::Identity();
+    const Eigen::Matrix3f R = rotation(h);
+    const Eigen::Vector3f t = translation(h);
+    const float s = scale(h);
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) M(r, c) = s * R(r, c);
+      M(r, 3) = t(r);
+    }
+    return M;
+  }
+  std::vector<bool> flags(int h) const {
+    std::vector<bool> f(N);
+    for (int i = 0; i < N; i++) f[i] = mask[(size_t)h * N + i] != 0;
+    return f;
+  }
+};
+
 }  // namespace dvm_sim3solver_detail
 
-inline Sim3Solver::Sim3Solver(KeyFrame* pKF1, KeyFrame* pKF2, const vector<MapPoint*>& vpMatched12, const bool bFixScale,
-                              vector<KeyFrame*> vpKeyFrameMatchedMP)
-    : mnIterations(0), mnBestInliers(0), mbFixScale(bFixScale), pCamera1(pKF1->mpCamera), pCamera2(pKF2->mpCamera) {
-  bool bDifferentKFs = false;
-  if (vpKeyFrameMatchedMP.empty()) {
-    bDifferentKFs = true;
-    vpKeyFrameMatchedMP = vector<KeyFrame*>(vpMatched12.size(), pKF2);
-  }
-  mpKF1 = pKF1;
-  mpKF2 = pKF2;
-  vector<MapPoint*> vpKeyFrameMP1 = pKF1->GetMapPointMatches();
-  mN1 = vpMatched12.size();
-  mvpMatches12 = vpMatched12;
-  const Eigen::Matrix3f Rcw1 = pKF1->GetRotation(), Rcw2 = pKF2->GetRotation();
-  const Eigen::Vector3f tcw1 = pKF1->GetTranslation(), tcw2 = pKF2->GetTranslation();
-  size_t idx = 0;
-  KeyFrame* pKFm = pKF2;
-  for (int i1 = 0; i1 < mN1; i1++) {
-    if (!vpMatched12[i1]) continue;
-    MapPoint* pMP1 = vpKeyFrameMP1[i1];
-    MapPoint* pMP2 = vpMatched12[i1];
-    if (!pMP1) continue;
-    if (pMP1->isBad() || pMP2->isBad()) continue;
-    if (bDifferentKFs) pKFm = vpKeyFrameMatchedMP[i1];
-    const int indexKF1 = std::get<0>(pMP1->GetIndexInKeyFrame(pKF1));
-    const int indexKF2 = std::get<0>(pMP2->GetIndexInKeyFrame(pKFm));
-    if (indexKF1 < 0 || indexKF2 < 0) continue;
-    const cv::KeyPoint& kp1 = pKF1->mvKeysUn[indexKF1];
-    const cv::KeyPoint& kp2 = pKFm->mvKeysUn[indexKF2];
-    const float sigmaSquare1 = pKF1->mvLevelSigma2[kp1.octave];
-    const float sigmaSquare2 = pKFm->mvLevelSigma2[kp2.octave];
-    mvnMaxError1.push_back(9.210 * sigmaSquare1);          // vector<size_t>: truncated, as in the reference (:99-100)
-    mvnMaxError2.push_back(9.210 * sigmaSquare2);
-    mvpMapPoints1.push_back(pMP1);
-    mvpMapPoints2.push_back(pMP2);
-    mvnIndices1.push_back(i1);
-    mvX3Dc1.push_back(Rcw1 * pMP1->GetWorldPos() + tcw1);
-    mvX3Dc2.push_back(Rcw2 * pMP2->GetWorldPos() + tcw2);
-    mvAllIndices.push_back(idx);
-    idx++;
-  }
-  // (mvP1im1 / mvP2im2, the points' own projections, are formed by the kernel from mvX3Dc1 / mvX3Dc2 and the calibration)
-  SetRansacParameters();
-}
-
-inline void Sim3Solver::SetRansacParameters(double probability, int minInliers, int maxIterations) {
-  mRansacProb = probability;
-  mRansacMinInliers = minInliers;
-  mRansacMaxIts = maxIterations;
-  N = mvpMapPoints1.size();
-  mvbInliersi.resize(N);
-  float epsilon = (float)mRansacMinInliers / N;
-  int nIterations;
-  if (mRansacMinInliers == N) nIterations = 1;
-  else nIterations = ceil(log(1 - mRansacProb) / log(1 - pow(epsilon, 3)));
-  mRansacMaxIts = std::max(1, std::min(nIterations, mRansacMaxIts));
-  mnIterations = 0;
-}
-
 inline Eigen::Matrix4f Sim3Solver::iterate(int nIterations, bool& bNoMore, vector<bool>& vbInliers, int& nInliers, bool& bConverge) {
-  bNoMore = false;
-  bConverge = false;
-  vbInliers = vector<bool>(mN1, false);
+  using dvm_sim3solver_detail::Batch;
+  bNoMore = bConverge = false;
   nInliers = 0;
+  vbInliers.assign(mN1, false);
   if (N < mRansacMinInliers) {
     bNoMore = true;
     return Eigen::Matrix4f::Identity();
   }
-  // the minimal sets of this call, drawn as :166-181 draws them
-  const int H = std::max(0, std::min(nIterations, mRansacMaxIts - mnIterations));
-  std::vector<int32_t> triples(3 * (size_t)H);
-  vector<size_t> vAvailableIndices;
-  for (int h = 0; h < H; h++) {
-    vAvailableIndices = mvAllIndices;
-    for (short i = 0; i < 3; ++i) {
-      const int randi = DUtils::Random::RandomInt(0, vAvailableIndices.size() - 1);
-      triples[3 * h + i] = (int32_t)vAvailableIndices[randi];
-      vAvailableIndices[randi] = vAvailableIndices.back();
-      vAvailableIndices.pop_back();
+  Batch b;
+  b.N = N;
+  b.H = std::max(0, std::min(nIterations, mRansacMaxIts - mnIterations));
+  Eigen::Matrix4f result = Eigen::Matrix4f::Identity();      // (the reference returns an uninitialised matrix when nothing ties the best)
+  if (b.H > 0) {
+    // minimal sets: three distinct correspondence indices each, RandomInt over the shrinking pool (:166-181)
+    std::vector<int32_t> sets(3 * (size_t)b.H);
+    std::vector<size_t> pool;
+    for (int32_t* s = sets.data(); s != sets.data() + sets.size(); s += 3) {
+      pool = mvAllIndices;
+      for (int k = 0; k < 3; k++) {
+        const int pick = DUtils::Random::RandomInt(0, pool.size() - 1);
+        s[k] = (int32_t)pool[pick];
+        pool[pick] = pool.back();
+        pool.pop_back();
+      }
     }
-  }
-  Eigen::Matrix4f bestSim3 = Eigen::Matrix4f::Identity();    // (the reference leaves it uninitialised when no hypothesis of the call ties the best)
-  if (H > 0) {
-    std::vector<float> P1(3 * (size_t)N), P2(3 * (size_t)N), e1(N), e2(N);
+    // camera-frame points and per-point error bounds as flat arrays; the kernel projects them itself
+    std::vector<float> P1(3 * (size_t)N), P2(3 * (size_t)N), bound1(N), bound2(N);
     for (int i = 0; i < N; i++) {
-      for (int k = 0; k < 3; k++) { P1[3 * i + k] = mvX3Dc1[i](k); P2[3 * i + k] = mvX3Dc2[i](k); }
-      e1[i] = (float)mvnMaxError1[i]; e2[i] = (float)mvnMaxError2[i];
+      for (int k = 0; k < 3; k++) {
+        P1[3 * (size_t)i + k] = mvX3Dc1[i](k);
+        P2[3 * (size_t)i + k] = mvX3Dc2[i](k);
+      }
+      bound1[i] = (float)mvnMaxError1[i];
+      bound2[i] = (float)mvnMaxError2[i];
     }
-    const float K1[4] = {pCamera1->getParameter(0), pCamera1->getParameter(1), pCamera1->getParameter(2), pCamera1->getParameter(3)};
-    const float K2[4] = {pCamera2->getParameter(0), pCamera2->getParameter(1), pCamera2->getParameter(2), pCamera2->getParameter(3)};
-    std::vector<float> T12(13 * (size_t)H);
-    std::vector<int32_t> nin(H);
-    std::vector<uint8_t> masks((size_t)H * N);
-    if (dvm_sim3_hypotheses(dvm_sim3solver_detail::device(), P1.data(), P2.data(), e1.data(), e2.data(), N, K1, K2, triples.data(), H,
-                            mbFixScale ? 1 : 0, T12.data(), nin.data(), masks.data()) != DVM_OK)
+    float K1[4], K2[4];
+    for (int k = 0; k < 4; k++) { K1[k] = pCamera1->getParameter(k); K2[k] = pCamera2->getParameter(k); }
+    b.T12.resize(13 * (size_t)b.H);
+    b.inliers.resize(b.H);
+    b.mask.resize((size_t)b.H * N);
+    if (dvm_sim3_hypotheses(dvm_host::device(), P1.data(), P2.data(), bound1.data(), bound2.data(), N, K1, K2, sets.data(), b.H,
+                            mbFixScale ? 1 : 0, b.T12.data(), b.inliers.data(), b.mask.data()) != DVM_OK)
       throw std::runtime_error(dvm_last_error());
-    for (int h = 0; h < H; h++) {
-      mnIterations++;
-      const float* t = &T12[13 * (size_t)h];
-      ms12i = t[0];
-      for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) mR12i(r, c) = t[1 + 3 * r + c];
-        mt12i(r) = t[10 + r];
-      }
-      mT12i = Eigen::Matrix4f::Identity();
-      for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) mT12i(r, c) = ms12i * mR12i(r, c);
-        mT12i(r, 3) = mt12i(r);
-      }
-      mnInliersi = nin[h];
-      for (int i = 0; i < N; i++) mvbInliersi[i] = masks[(size_t)h * N + i] != 0;
-      if (mnInliersi >= mnBestInliers) {
-        mvbBestInliers = mvbInliersi;
-        mnBestInliers = mnInliersi;
-        mBestT12 = mT12i;
-        mBestRotation = mR12i;
-        mBestTranslation = mt12i;
-        mBestScale = ms12i;
-        if (mnInliersi > mRansacMinInliers) {
-          nInliers = mnInliersi;
-          for (int i = 0; i < N; i++)
-            if (mvbInliersi[i]) vbInliers[mvnIndices1[i]] = true;
-          bConverge = true;
-          return mBestT12;
-        }
-        bestSim3 = mBestT12;
-      }
+    // read the outcome off the counts: `champion` = last hypothesis that tied or beat the running best, `accepted` = the first
+    // of those above the bar (the call ends there and the hypotheses behind it were never "iterated")
+    int champion = -1, accepted = -1, best = mnBestInliers;
+    for (int h = 0; h < b.H && accepted < 0; h++) {
+      if (b.inliers[h] < best) continue;
+      best = b.inliers[h];
+      champion = h;
+      if (best > mRansacMinInliers) accepted = h;
+    }
+    const int last = accepted >= 0 ? accepted : b.H - 1;       // the hypothesis the per-iteration members describe on return
+    mnIterations += last + 1;
+    ms12i = b.scale(last);
+    mR12i = b.rotation(last);
+    mt12i = b.translation(last);
+    mT12i = b.matrix(last);
+    mnInliersi = b.inliers[last];
+    mvbInliersi = b.flags(last);
+    if (champion >= 0) {
+      mnBestInliers = best;
+      mvbBestInliers = b.flags(champion);
+      mBestScale = b.scale(champion);
+      mBestRotation = b.rotation(champion);
+      mBestTranslation = b.translation(champion);
+      mBestT12 = b.matrix(champion);
+      result = mBestT12;
+    }
+    if (accepted >= 0) {
+      nInliers = mnBestInliers;
+      for (int i = 0; i < N; i++)
+        if (mvbBestInliers[i]) vbInliers[mvnIndices1[i]] = true;
+      bConverge = true;
+      return result;
     }
   }
-  if (mnIterations >= mRansacMaxIts) bNoMore = true;
-  return bestSim3;
+  bNoMore = mnIterations >= mRansacMaxIts;
+  return result;
 }
 
-// (:154-207: the four-argument form returns the identity unless a hypothesis passes)
+// the four-argument form hands out the identity unless a hypothesis passed (:154-207)
 inline Eigen::Matrix4f Sim3Solver::iterate(int nIterations, bool& bNoMore, vector<bool>& vbInliers, int& nInliers) {
-  bool bConverge = false;
-  const Eigen::Matrix4f T = iterate(nIterations, bNoMore, vbInliers, nInliers, bConverge);
-  return bConverge ? T : Eigen::Matrix4f::Identity();
+  bool converged = false;
+  const Eigen::Matrix4f T = iterate(nIterations, bNoMore, vbInliers, nInliers, converged);
+  if (!converged) return Eigen::Matrix4f::Identity();
+  return T;
 }
 
 inline Eigen::Matrix4f Sim3Solver::find(vector<bool>& vbInliers12, int& nInliers) {
-  bool bFlag;
-  return iterate(mRansacMaxIts, bFlag, vbInliers12, nInliers);
+  bool exhausted = false;
+  return iterate(mRansacMaxIts, exhausted, vbInliers12, nInliers);
 }
-
-inline Eigen::Matrix4f Sim3Solver::GetEstimatedTransformation() { return mBestT12; }
-inline Eigen::Matrix3f Sim3Solver::GetEstimatedRotation() { return mBestRotation; }
-inline Eigen::Vector3f Sim3Solver::GetEstimatedTranslation() { return mBestTranslation; }
-inline float Sim3Solver::GetEstimatedScale() { return mBestScale; }
 
 }  // namespace ORB_SLAM3

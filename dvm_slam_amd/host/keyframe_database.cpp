@@ -56,14 +56,16 @@ int KeyFrameDatabase::CalculateMergeScore(const BowVector& bowVector, uint64_t k
                                           int32_t& bestKeyFrame) {
   if (keyFrameId == 0) return DVM_ERR_INVALID;
   Lock l(mMutex_);
-  for (KF& k : kfs_)   // ResetPlaceRecognitionQuery(map)
-    if (k.map_id == map_id && !k.erased) { k.query = 0; k.words = 0; k.score = 0; }
+  for (int s = 0; s < (int)kfs_.size(); s++) {   // ResetPlaceRecognitionQuery(map): the keyframes that are in that map NOW
+    KF& k = kfs_[s];
+    if (!k.erased && map_of(s) == map_id) { k.query = 0; k.words = 0; k.score = 0; }
+  }
   const int rc = query_device(bowVector);
   if (rc != DVM_OK) return rc;
   std::vector<int32_t> lKFsSharingWords;
   for (int32_t s : walk_order()) {
     KF& k = kfs_[s];
-    if (!(k.map_id == map_id && !k.bad && k.uuid != keyFrameId)) continue;
+    if (!(map_of(s) == map_id && !bad_of(s) && k.uuid != keyFrameId)) continue;
     if (k.query != keyFrameId) { k.words = 0; k.score = 0; k.query = keyFrameId; lKFsSharingWords.push_back(s); }
     k.words += common_[s];
   }
@@ -77,7 +79,7 @@ int KeyFrameDatabase::CalculateMergeScore(const BowVector& bowVector, uint64_t k
   for (const auto& sm : lScoreAndMatch) {
     float bestScore = sm.first, accScore = bestScore;
     int32_t pBestKF = sm.second;
-    for (int32_t s2 : kfs_[sm.second].neigh) {
+    for (int32_t s2 : neigh_of(sm.second)) {
       const KF& k2 = kfs_[s2];
       if (k2.query != keyFrameId) continue;
       accScore += k2.score;
@@ -101,7 +103,7 @@ int KeyFrameDatabase::DetectMergePossibility(const BowVector& bowVector, uint64_
   float baselineScore = 0;
   int32_t baselineBest = -1;
   const KF b = kfs_[bestKeyFrame];
-  rc = CalculateMergeScore(b.bow, b.uuid, b.map_id, baselineScore, baselineBest);
+  rc = CalculateMergeScore(b.bow, b.uuid, map_of(bestKeyFrame), baselineScore, baselineBest);
   if (rc != DVM_OK) return rc;
   if (baseline_out) *baseline_out = baselineScore;
   return score > baselineScore * 0.9 ? 1 : 0;
@@ -110,6 +112,7 @@ int KeyFrameDatabase::DetectMergePossibility(const BowVector& bowVector, uint64_
 int KeyFrameDatabase::DetectNBestCandidates(int slot, std::vector<int32_t>& vpLoopCand, std::vector<int32_t>& vpMergeCand, int nNumCandidates) {
   vpLoopCand.clear(); vpMergeCand.clear();
   Lock l(mMutex_);
+  if (live_) { live_->connected(slot, kfs_[slot].connected); map_of(slot); }
   const KF pKF = kfs_[slot];
   const uint64_t qid = (uint64_t)pKF.mnId;
   const int rc = query_device(pKF.bow);
@@ -140,7 +143,7 @@ int KeyFrameDatabase::DetectNBestCandidates(int slot, std::vector<int32_t>& vpLo
   for (const auto& sm : lScoreAndMatch) {
     float bestScore = sm.first, accScore = bestScore;
     int32_t pBestKF = sm.second;
-    for (int32_t s2 : kfs_[sm.second].neigh) {
+    for (int32_t s2 : neigh_of(sm.second)) {
       const KF& k2 = kfs_[s2];
       if (k2.query != qid) continue;
       accScore += k2.score;
@@ -153,11 +156,11 @@ int KeyFrameDatabase::DetectNBestCandidates(int slot, std::vector<int32_t>& vpLo
   for (const auto& am : lAccScoreAndMatch) {
     if (!((int)vpLoopCand.size() < nNumCandidates || (int)vpMergeCand.size() < nNumCandidates)) break;
     const int32_t s = am.second;
-    const KF& k = kfs_[s];
-    if (k.bad) continue;   // the reference never advances past a bad keyframe here (:651-652); they do not reach this list
+    if (bad_of(s)) continue;   // the reference never advances past a bad keyframe here (:651-652); they do not reach this list
     if (!spAlreadyAddedKF.count(s)) {
-      if (pKF.map_id == k.map_id && (int)vpLoopCand.size() < nNumCandidates) vpLoopCand.push_back(s);
-      else if (pKF.map_id != k.map_id && (int)vpMergeCand.size() < nNumCandidates && !bad_maps_.count(k.map_id)) vpMergeCand.push_back(s);
+      const int32_t ms = map_of(s);
+      if (pKF.map_id == ms && (int)vpLoopCand.size() < nNumCandidates) vpLoopCand.push_back(s);
+      else if (pKF.map_id != ms && (int)vpMergeCand.size() < nNumCandidates && !bad_maps_.count(ms)) vpMergeCand.push_back(s);
       spAlreadyAddedKF.insert(s);
     }
   }
@@ -193,7 +196,7 @@ int KeyFrameDatabase::DetectRelocalizationCandidates(const BowVector& bowVector,
   for (const auto& sm : lScoreAndMatch) {
     float bestScore = sm.first, accScore = bestScore;
     int32_t pBestKF = sm.second;
-    for (int32_t s2 : kfs_[sm.second].neigh) {
+    for (int32_t s2 : neigh_of(sm.second)) {
       const KF& k2 = kfs_[s2];
       if (k2.reloc_query != frameId) continue;
       accScore += k2.reloc_score;
@@ -207,7 +210,7 @@ int KeyFrameDatabase::DetectRelocalizationCandidates(const BowVector& bowVector,
   for (const auto& am : lAccScoreAndMatch) {
     if (!(am.first > minScoreToRetain)) continue;
     const int32_t s = am.second;
-    if (kfs_[s].map_id != map_id) continue;
+    if (map_of(s) != map_id) continue;
     if (!spAlreadyAddedKF.count(s)) { vpRelocCandidates.push_back(s); spAlreadyAddedKF.insert(s); }
   }
   return DVM_OK;
@@ -239,6 +242,7 @@ int dvmh_kfdb_add(dvmh_kfdb* db, const int32_t* ids, const double* vals, int n, 
 void dvmh_kfdb_erase(dvmh_kfdb* db, int slot) { db->erase(slot); }
 void dvmh_kfdb_set_bad(dvmh_kfdb* db, int slot, int bad) { db->SetBadFlag(slot, bad != 0); }
 void dvmh_kfdb_set_map_bad(dvmh_kfdb* db, int32_t map_id, int bad) { db->SetMapBad(map_id, bad != 0); }
+void dvmh_kfdb_set_map(dvmh_kfdb* db, int slot, int32_t map_id) { db->SetMap(slot, map_id); }
 void dvmh_kfdb_set_neighbours(dvmh_kfdb* db, int slot, const int32_t* neigh, int n) { db->SetBestCovisibilityKeyFrames(slot, neigh, n); }
 void dvmh_kfdb_set_connected(dvmh_kfdb* db, int slot, const int32_t* conn, int n) { db->SetConnectedKeyFrames(slot, conn, n); }
 void dvmh_kfdb_get_state(dvmh_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score) {

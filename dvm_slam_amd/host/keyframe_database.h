@@ -27,9 +27,23 @@
 
 namespace dvm_host {
 
+// What the reference reads from the KeyFrame / Map OBJECTS while a query runs (pKFi->GetMap(), isBad(), GetBestCovisibilityKeyFrames(10),
+// GetConnectedKeyFrames(); KeyFrameDatabase.cc:585-660, 706-790, 850-905): a caller that owns live objects (host/KeyFrameDatabase_shim.h)
+// installs this view and the mirror asks it -- only for the slots a query actually reaches, as the reference does -- instead of
+// relying on values pushed with the Set* calls (which remain for callers without objects: the C harness, the tests).
+struct LiveKeyFrameView {
+  virtual ~LiveKeyFrameView() {}
+  virtual bool isBad(int slot) = 0;
+  virtual int32_t map_id(int slot) = 0;
+  virtual void best_covisibles(int slot, std::vector<int32_t>& out) = 0;   // slots of GetBestCovisibilityKeyFrames(10) that are in the database
+  virtual void connected(int slot, std::set<int32_t>& out) = 0;            // slots of GetConnectedKeyFrames()
+};
+
 class KeyFrameDatabase {
  public:
   explicit KeyFrameDatabase(int device = 0);
+  void SetLiveView(LiveKeyFrameView* v) { Lock l(mMutex_); live_ = v; }
+  void SetMap(int slot, int32_t map_id) { Lock l(mMutex_); kfs_[slot].map_id = map_id; }   // KeyFrame::UpdateMap (LoopClosing::MergeLocal moves keyframes)
   ~KeyFrameDatabase();
   KeyFrameDatabase(const KeyFrameDatabase&) = delete;
   bool ok() const { return db_ != nullptr; }
@@ -76,6 +90,11 @@ class KeyFrameDatabase {
     int reloc_words = 0;
     float reloc_score = 0;
   };
+  // attribute reads of a query: the live view when one is installed (the value is also kept, so that the state getters see it)
+  int32_t map_of(int s) { if (live_) kfs_[s].map_id = live_->map_id(s); return kfs_[s].map_id; }
+  bool bad_of(int s) { if (live_) kfs_[s].bad = live_->isBad(s); return kfs_[s].bad; }
+  const std::vector<int32_t>& neigh_of(int s) { if (live_) live_->best_covisibles(s, kfs_[s].neigh); return kfs_[s].neigh; }
+  LiveKeyFrameView* live_ = nullptr;
   int query_device(const BowVector& bow);   // fills common_ / first_ / score_
   std::vector<int32_t> walk_order() const;   // slots sharing a word, in inverted-file walk order
   dvm_bowdb* db_ = nullptr;

@@ -349,6 +349,7 @@ int ORBmatcher::SearchForInitialization(const FrameView& F1, const FrameView& F2
     if (F2.mvKeysUn[j].octave == 0) { col_of[j] = ncol++; d2.insert(d2.end(), F2.mDescriptors + 32 * (size_t)j, F2.mDescriptors + 32 * (size_t)j + 32); }
   if (rows.empty() || ncol == 0) return 0;
   std::vector<uint16_t> D((size_t)rows.size() * ncol);
+  if (int rcd = dvm_set_device(device_)) return rcd;   // stateless entry point: runs on the calling thread's current device
   int rc = dvm_hamming_matrix(d1.data(), (int)rows.size(), d2.data(), ncol, D.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
 
@@ -418,6 +419,7 @@ int ORBmatcher::SearchByBoW(const KeyFrameView& KF, const FrameView& F, const Fe
   if (nq == 0) return 0;
   if (cand.empty()) cand.push_back(-1);   // every common node is empty on the other side: nothing to scan, not an error
   std::vector<dvm_match> res(nq);
+  if (int rcd = dvm_set_device(device_)) return rcd;   // stateless entry point: runs on the calling thread's current device
   int rc = dvm_match_lists(F.mDescriptors, F.N, qdesc.data(), nq, off.data(), cand.data(), res.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
   int nmatches = 0;
@@ -483,6 +485,7 @@ int ORBmatcher::SearchByBoW(const KeyFrameView& KF1, const KeyFrameView& KF2, in
   if (nq == 0) return 0;
   if (cand.empty()) cand.push_back(-1);
   std::vector<dvm_match> res(nq);
+  if (int rcd = dvm_set_device(device_)) return rcd;   // stateless entry point: runs on the calling thread's current device
   int rc = dvm_match_lists(KF2.mDescriptors, KF2.N, qdesc.data(), nq, off.data(), cand.data(), res.data(), 0, nullptr);
   if (rc != DVM_OK) return rc;
   int nmatches = 0;
@@ -569,6 +572,7 @@ int ORBmatcher::SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameVi
   if (nq == 0) return 0;
   if (cand.empty()) cand.push_back(-1);
   std::vector<int32_t> bi(nq), bd(nq);
+  if (int rcd = dvm_set_device(device_)) return rcd;   // stateless entry point: runs on the calling thread's current device
   int rc = dvm_match_triangulation(KF1.mDescriptors, KF1.mvKeysUn, KF1.N, qidx.data(), nq, KF2.mDescriptors, KF2.mvKeysUn, KF2.N,
                                    off.data(), cand.data(), F12, ep, bCoarse ? 1 : 0, KF2.mvScaleFactors, KF2.mvLevelSigma2, KF2.nLevels,
                                    bi.data(), bd.data(), 0, nullptr);

@@ -45,6 +45,12 @@ const char* dvm_last_error(void);
 const char* dvm_version(void);
 /* number of visible HIP devices (0 when none); never fails */
 int dvm_device_count(void);
+/* makes `device` the calling THREAD's current HIP device.  Entry points that take a handle or a device argument select their GPU
+ * themselves; the stateless ones without either (dvm_hamming_matrix, dvm_is_in_frustum, dvm_triangulate_matches,
+ * dvm_undistort_keypoints, dvm_match_lists, dvm_match_triangulation, dvm_distinctive_descriptors, dvm_pose_optimize's host form ...)
+ * run on the calling thread's current device -- 0 on a fresh thread.  An agent pinned to GPU k calls this once per thread (the shims
+ * of dvm_slam_amd/host do it through dvm_host::use_device()).  DVM_ERR_NO_DEVICE / DVM_ERR_INVALID as for the handle constructors. */
+int dvm_set_device(int device);
 
 /* layout-identical to cv::KeyPoint (7 x 4 B): pt.x, pt.y, size, angle, response, octave, class_id */
 typedef struct {

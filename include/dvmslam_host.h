@@ -134,6 +134,7 @@ int dvmh_kfdb_add(dvmh_kfdb* db, const int32_t* ids, const double* vals, int n, 
 void dvmh_kfdb_erase(dvmh_kfdb* db, int slot);
 void dvmh_kfdb_set_bad(dvmh_kfdb* db, int slot, int bad);
 void dvmh_kfdb_set_map_bad(dvmh_kfdb* db, int32_t map_id, int bad);
+void dvmh_kfdb_set_map(dvmh_kfdb* db, int slot, int32_t map_id);                              /* KeyFrame::UpdateMap: LoopClosing::MergeLocal moves keyframes to the merged map (LoopClosing.cc:1558,1767) */
 void dvmh_kfdb_set_neighbours(dvmh_kfdb* db, int slot, const int32_t* neigh, int n);        /* GetBestCovisibilityKeyFrames(10) */
 void dvmh_kfdb_set_connected(dvmh_kfdb* db, int slot, const int32_t* conn, int n);          /* GetConnectedKeyFrames() */
 void dvmh_kfdb_get_state(dvmh_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score);

@@ -63,6 +63,8 @@ void orc_kfdb_erase(orc_kfdb* db, int slot) {   // :52-70
   k.erased = true;
 }
 void orc_kfdb_set_bad(orc_kfdb* db, int slot, int bad) { db->kfs[slot].bad = bad != 0; }
+// KeyFrame::UpdateMap: the keyframe now belongs to another map (LoopClosing::MergeLocal, LoopClosing.cc:1558,1767); every query reads pKFi->GetMap() live
+void orc_kfdb_set_map(orc_kfdb* db, int slot, int32_t map_id) { db->kfs[slot].map_id = map_id; }
 void orc_kfdb_set_map_bad(orc_kfdb* db, int32_t map_id, int bad) { if (bad) db->bad_maps.insert(map_id); else db->bad_maps.erase(map_id); }
 void orc_kfdb_set_neighbours(orc_kfdb* db, int slot, const int32_t* neigh, int n) { db->kfs[slot].neigh.assign(neigh, neigh + n); }
 void orc_kfdb_set_connected(orc_kfdb* db, int slot, const int32_t* conn, int n) { db->kfs[slot].connected = std::set<int32_t>(conn, conn + n); }

@@ -200,6 +200,7 @@ int orc_kfdb_add(orc_kfdb* db, const int32_t* ids, const double* vals, int n, in
 void orc_kfdb_erase(orc_kfdb* db, int slot);
 void orc_kfdb_set_bad(orc_kfdb* db, int slot, int bad);
 void orc_kfdb_set_map_bad(orc_kfdb* db, int32_t map_id, int bad);
+void orc_kfdb_set_map(orc_kfdb* db, int slot, int32_t map_id);
 void orc_kfdb_set_neighbours(orc_kfdb* db, int slot, const int32_t* neigh, int n);
 void orc_kfdb_set_connected(orc_kfdb* db, int slot, const int32_t* conn, int n);
 void orc_kfdb_get_state(const orc_kfdb* db, int slot, uint64_t* query, int32_t* words, float* score);

@@ -764,6 +764,7 @@ class KeyFrameDatabase:
 
     def erase(self, slot): self._f("erase")(self.h, C.c_int32(slot))
     def set_bad(self, slot, bad): self._f("set_bad")(self.h, C.c_int32(slot), C.c_int32(int(bad)))
+    def set_map(self, slot, map_id): self._f("set_map")(self.h, C.c_int32(slot), C.c_int32(map_id))
     def set_map_bad(self, map_id, bad): self._f("set_map_bad")(self.h, C.c_int32(map_id), C.c_int32(int(bad)))
 
     def set_neighbours(self, slot, neigh):

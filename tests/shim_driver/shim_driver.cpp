@@ -67,7 +67,7 @@ extern "C" {
 World* sw_create() { return new World; }
 void sw_destroy(World* w) { delete w; }
 const char* sw_error(World* w) { return w->error.c_str(); }
-void sw_set_device(int d) { dvm_optimizer_detail::device() = d; }
+void sw_set_device(int d) { dvm_host::set_device(d); }
 
 int sw_add_map(World* w, unsigned long init_kf_id) {
   w->maps.emplace_back(new Map);
@@ -125,8 +125,8 @@ int sw_add_mappoint(World* w, int map, unsigned long id, const float* xyz, const
   MapPoint* p = w->mps.back().get();
   if (normal) for (int k = 0; k < 3; k++) p->mNormalVector(k) = normal[k];
   p->mfMinDistance = min_dist; p->mfMaxDistance = max_dist;
-  if (desc) std::memcpy(p->mDescriptor.data, desc, 32);
-  p->mbBad = bad != 0;
+  if (desc) std::memcpy(MapPoint::MockAccess::descriptor(p).data, desc, 32);
+  MapPoint::MockAccess::bad(p) = bad != 0;
   w->maps[map]->mock_mps.push_back(p);
   return (int)w->mps.size() - 1;
 }
@@ -166,7 +166,7 @@ void sw_get_mp(World* w, int mp, float* xyz, float* gba_xyz, int32_t* info /* ba
   MapPoint* p = w->mps[mp].get();
   if (xyz) for (int k = 0; k < 3; k++) xyz[k] = p->mWorldPos(k);
   if (gba_xyz) for (int k = 0; k < 3; k++) gba_xyz[k] = p->mPosGBA(k);
-  if (info) { info[0] = p->mbBad; info[1] = p->mock_set_pos; info[2] = p->mock_update_normal; info[3] = p->nObs; info[4] = (int32_t)p->mnBAGlobalForKF; info[5] = w->mp_index(p->mpReplaced); }
+  if (info) { info[0] = MapPoint::MockAccess::bad(p); info[1] = p->mock_set_pos; info[2] = p->mock_update_normal; info[3] = p->nObs; info[4] = (int32_t)p->mnBAGlobalForKF; info[5] = w->mp_index(p->mpReplaced); }
 }
 int sw_get_kf_matches(World* w, int kf, int32_t* out) {
   KeyFrame* k = w->kfs[kf].get();
@@ -175,7 +175,7 @@ int sw_get_kf_matches(World* w, int kf, int32_t* out) {
 }
 int sw_get_mp_observations(World* w, int mp, int32_t* kf_out, int32_t* idx_out, int cap) {
   int n = 0;
-  for (const auto& o : w->mps[mp]->mObservations) {
+  for (const auto& o : MapPoint::MockAccess::observations(w->mps[mp].get())) {
     if (n < cap) { kf_out[n] = w->kf_index(o.first); idx_out[n] = std::get<0>(o.second); }
     n++;
   }
@@ -317,7 +317,7 @@ int sw_vocab_compute_bow(World* w, const char* path, const uint8_t* desc, int n,
 int sw_compute_distinctive(World* w, const int32_t* mps, int n, int batched, uint8_t* out) {
   return guarded(w, [&] {
     std::vector<MapPoint*> v = mp_list(w, mps, n);
-    if (batched) MapPoint_ComputeDistinctiveDescriptorsBatch(v);
+    if (batched) MapPoint::ComputeDistinctiveDescriptorsBatch(v);
     else for (MapPoint* p : v) p->ComputeDistinctiveDescriptors();
     for (int i = 0; i < n; i++) { const cv::Mat d = v[i]->GetDescriptor(); std::memcpy(out + 32 * (size_t)i, d.data, 32); }
     return 0;
@@ -336,6 +336,7 @@ void sw_kf_set_connected(World* w, int kf, const int32_t* others, int n) {
   for (int i = 0; i < n; i++) w->kfs[kf]->mock_connected.insert(w->kfs[others[i]].get());
 }
 void sw_kf_set_bad(World* w, int kf, int bad) { w->kfs[kf]->mbBad = bad != 0; }
+void sw_kf_update_map(World* w, int kf, int map) { w->kfs[kf]->UpdateMap(w->maps[map].get()); }    // KeyFrame::UpdateMap, as LoopClosing::MergeLocal calls it
 void sw_map_set_bad(World* w, int map, int bad) { w->maps[map]->mock_bad = bad != 0; }
 int sw_kfdb_create(World* w) { return guarded(w, [&] { w->kfdb.reset(new KeyFrameDatabase()); return 0; }); }
 int sw_kfdb_add(World* w, int kf) { return guarded(w, [&] { w->kfdb->add(w->kfs[kf].get()); return 0; }); }

@@ -207,6 +207,7 @@ class World:
     def kf_set_connected(self, kf, others):
         o = _i32(others); self.L.sw_kf_set_connected(self.h, kf, _p(o) if len(o) else None, len(o))
 
+    def kf_update_map(self, kf, m): self.L.sw_kf_update_map(self.h, kf, int(m))
     def kf_set_bad(self, kf, bad): self.L.sw_kf_set_bad(self.h, kf, int(bad))
     def map_set_bad(self, m, bad): self.L.sw_map_set_bad(self.h, m, int(bad))
     def kfdb_create(self): self._chk(self.L.sw_kfdb_create(self.h))

@@ -6,6 +6,8 @@
 // The two accessors marked (+) are the ONLY additions a maintainer makes to the reference.
 #pragma once
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <list>
 #include <map>
 #include <mutex>
@@ -68,21 +70,23 @@ class MapPoint {
   Eigen::Vector3f GetWorldPos() { return mWorldPos; }
   void SetWorldPos(const Eigen::Vector3f& Pos) { mWorldPos = Pos; mock_set_pos++; }
   Eigen::Vector3f GetNormal() { return mNormalVector; }
-  std::map<KeyFrame*, std::tuple<int, int>> GetObservations() { return mObservations; }
+  // (MapPoint.cc:272-275, 361-367: both take mMutexFeatures, a NON-recursive mutex -- the mock does too, and a caller that already
+  //  holds it is reported instead of left to hang)
+  std::map<KeyFrame*, std::tuple<int, int>> GetObservations() { MockFeatureLock l(this, "GetObservations"); return mObservations; }
   int Observations() { return nObs; }
   inline void EraseObservation(KeyFrame* pKF, int minObservationsBeforeDeletion = 3);
   inline void AddObservation(KeyFrame* pKF, int idx);
   inline void SetBadFlag();
   inline void Replace(MapPoint* pMP);
   void ComputeDistinctiveDescriptors();          // defined by host/MapPoint_shim.h
-  std::mutex mMutexFeatures;
+  static void ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoint*>& points);   // (+) declared for host/MapPoint_shim.h
   std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF) {       // (MapPoint.cc: (-1, -1) when the keyframe does not observe the point)
     const auto it = mObservations.find(pKF);
     return it == mObservations.end() ? std::tuple<int, int>(-1, -1) : it->second;
   }
   bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
-  bool isBad() { return mbBad; }
-  cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+  bool isBad() { MockFeatureLock l(this, "isBad"); return mbBad; }
+  cv::Mat GetDescriptor() { MockFeatureLock l(this, "GetDescriptor"); return mDescriptor.clone(); }
   void UpdateNormalAndDepth() { mock_update_normal++; }
   float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
   float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
@@ -100,17 +104,39 @@ class MapPoint {
   long unsigned int mnBALocalForKF = ~0ul, mnBALocalForMerge = ~0ul;
   Eigen::Vector3f mPosGBA;
   long unsigned int mnBAGlobalForKF = 0;
-  // mock state (the reference keeps these protected)
+  // mock state (the reference keeps these protected; the mock leaves the ones no shim may touch public for the test driver)
   Eigen::Vector3f mWorldPos, mNormalVector;
-  std::map<KeyFrame*, std::tuple<int, int>> mObservations;
   int nObs = 0;
-  bool mbBad = false;
   MapPoint* mpReplaced = nullptr;
-  cv::Mat mDescriptor;
   float mfMinDistance = 0, mfMaxDistance = 0;
+  struct MockAccess;          // test driver only (tests/shim_driver/): reads / writes the protected members below
+
+ protected:                   // as in include/MapPoint.h:210-248: a free function that touches these does not compile
+  std::map<KeyFrame*, std::tuple<int, int>> mObservations;
+  bool mbBad = false;
+  cv::Mat mDescriptor;
+  std::mutex mMutexFeatures;
+  struct MockFeatureLock {    // std::mutex cannot name its owner: in the single-threaded shim tests a failed try_lock IS a self-deadlock
+    MapPoint* p;
+    MockFeatureLock(MapPoint* p_, const char* who) : p(p_) {
+      if (!p->mMutexFeatures.try_lock()) {
+        std::fprintf(stderr, "mock MapPoint::%s(): mMutexFeatures is already held by the caller -- against the reference this deadlocks\n", who);
+        std::abort();
+      }
+    }
+    ~MockFeatureLock() { p->mMutexFeatures.unlock(); }
+  };
+
+ public:
   Map* mpMap;
   KeyFrame* mpRefKF = nullptr;
   int mock_set_pos = 0, mock_update_normal = 0;
+};
+
+struct MapPoint::MockAccess {
+  static bool& bad(MapPoint* p) { return p->mbBad; }
+  static cv::Mat& descriptor(MapPoint* p) { return p->mDescriptor; }
+  static std::map<KeyFrame*, std::tuple<int, int>>& observations(MapPoint* p) { return p->mObservations; }
 };
 
 struct KeyFrameInit {   // mock only: what the reference's KeyFrame(Frame&, Map*, KeyFrameDatabase*) copies out of the frame
@@ -176,6 +202,7 @@ class KeyFrame {
   KeyFrame* mPrevKF = nullptr;
   bool isBad() { return mbBad; }
   Map* GetMap() { return mpMap; }
+  void UpdateMap(Map* pMap) { mpMap = pMap; }      // (KeyFrame.cc: under mMutexMap)
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul, mnBAGlobalForKF = 0, mnBALocalForMerge = ~0ul;
   Sophus::SE3f mTcwGBA, mTcwBefMerge, mTwcBefMerge;

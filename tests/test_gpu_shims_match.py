@@ -410,8 +410,8 @@ def test_keyframe_database_class(oracle, seed):
         W.kfdb_add(j)
     rng = np.random.default_rng(seed)
     alive = set(range(len(kfs)))
-    hits = 0
-    for step in range(90):
+    hits = moved = 0
+    for step in range(140):
         op = rng.random()
         j = int(rng.choice(sorted(alive)))
         q = kfs[j]
@@ -437,10 +437,17 @@ def test_keyframe_database_class(oracle, seed):
             hits += len(co) > 0
         elif op < 0.92 and len(alive) > 20:
             dbo.erase(j); W.kfdb_erase(j); alive.discard(j)
-        else:
+        elif op < 0.96:
             b = bool(rng.integers(0, 2))
             dbo.set_bad(j, b); W.kf_set_bad(j, b)
-    assert hits > 15
+        else:
+            # LoopClosing::MergeLocal moves keyframes into the merged map with KeyFrame::UpdateMap (LoopClosing.cc:1558,1767) AFTER they
+            # were added: every later query must see them in their new map (loop vs merge candidates, the relocalisation filter, the
+            # map whose query state CalculateMergeScore resets)
+            m_new = int(rng.integers(0, 3))
+            dbo.set_map(j, m_new); W.kf_update_map(j, m_new)
+            moved += 1
+    assert hits > 15 and moved > 0
 
 
 def test_mappoint_compute_distinctive_descriptors(oracle):
