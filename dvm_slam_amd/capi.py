@@ -487,6 +487,55 @@ class BundleAdjuster:
         return chi, dp
 
 
+class BaWindow(C.Structure):
+    """dvm_ba_window (include/dvmslam_hip.h)"""
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("iterations", C.c_int32),
+                ("poses", C.c_void_p), ("fixed", C.c_void_p), ("points", C.c_void_p), ("edges", C.c_void_p), ("cam", BaCamera),
+                ("poses_out", C.c_void_p), ("points_out", C.c_void_p), ("edge_chi2_out", C.c_void_p), ("depth_positive_out", C.c_void_p)]
+
+
+def ba_optimize_windows(problems, device=0, stop_flag=None):
+    """dvm_ba_optimize_windows: K independent bundle adjustments in one launch.  problems: dicts with poses [P,7], fixed [P], points [L,3],
+    edges (BA_EDGE_DTYPE), intrinsics (fx, fy, cx, cy), huber_delta, iterations.  Returns one dict per window: poses, points, edge_chi2,
+    depth_positive, stats (the keys of BundleAdjuster.optimize)."""
+    K = len(problems)
+    wins = (BaWindow * max(K, 1))()
+    stats = (BaStats * max(K, 1))()
+    keep, outs = [], []
+    for k, pr in enumerate(problems):
+        poses = np.ascontiguousarray(pr["poses"], np.float64); points = np.ascontiguousarray(pr["points"], np.float64)
+        fixed = np.ascontiguousarray(pr["fixed"], np.uint8); edges = np.ascontiguousarray(pr["edges"], BA_EDGE_DTYPE)
+        o = dict(poses=np.zeros_like(poses), points=np.zeros_like(points), edge_chi2=np.zeros(len(edges), np.float64),
+                 depth_positive=np.zeros(len(edges), np.uint8))
+        keep.append((poses, points, fixed, edges)); outs.append(o)
+        w = wins[k]
+        w.n_poses, w.n_points, w.n_edges, w.iterations = len(poses), len(points), len(edges), int(pr["iterations"])
+        w.poses, w.fixed, w.points, w.edges = poses.ctypes.data, fixed.ctypes.data, points.ctypes.data, edges.ctypes.data
+        w.cam = BaCamera(*[float(v) for v in pr["intrinsics"]], float(pr["huber_delta"]))
+        w.poses_out, w.points_out, w.edge_chi2_out, w.depth_positive_out = (o["poses"].ctypes.data, o["points"].ctypes.data, o["edge_chi2"].ctypes.data,
+                                                                            o["depth_positive"].ctypes.data)
+    f = lib().dvm_ba_optimize_windows
+    f.restype = C.c_int32; f.argtypes = None
+    check(f(C.c_int32(device), wins, C.c_int32(K), _p(stop_flag) if stop_flag is not None else None, stats))
+    for k, o in enumerate(outs):
+        st = stats[k]
+        n = min(st.iterations, 64)
+        o["stats"] = dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason, chi2_initial=st.chi2_initial,
+                          chi2_final=st.chi2_final, lambda_final=st.lambda_final, trials=st.trials_per_iter[:n], chi2=st.chi2_per_iter[:n],
+                          lam=st.lambda_per_iter[:n], ms_structure=st.ms_structure, ms_optimize=st.ms_optimize)
+    return outs
+
+
+def f64_spec_eval(x, device=0):
+    """csrc/f64_spec.h on the device: returns (sin, cos, cube) of the doubles in x."""
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(3 * len(x), np.float64)
+    f = lib().dvm_f64_spec_eval
+    f.restype = C.c_int32; f.argtypes = None
+    check(f(C.c_int32(device), _p(x), C.c_int32(len(x)), _p(out)))
+    return out[:len(x)], out[len(x):2 * len(x)], out[2 * len(x):]
+
+
 def pose_optimize(poses, Xw, obs, inv_sigma2, n, intrinsics, device=0):
     """Optimizer::PoseOptimization for a batch of frames.  poses [B,7]; Xw [B,S,3]; obs [B,S,2]; inv_sigma2 [B,S];
     n [B].  Returns (poses [B,7], outlier [B,S] uint8, n_inliers [B])."""

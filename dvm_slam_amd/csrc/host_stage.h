@@ -74,8 +74,9 @@ struct Stage {
   int out(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0); }
   int scratch(size_t bytes) { return add(nullptr, nullptr, bytes); }   // device-only working memory
   static size_t pad(size_t b) { return (std::max<size_t>(b, 16) + 255) & ~(size_t)255; }
-  // inputs first (one contiguous span to send), then outputs and scratch; ptr() is valid from here on
-  int upload() {
+  // inputs first (one contiguous span to send), then outputs and scratch; ptr() is valid from here on.  A caller whose INPUTS hold
+  // device addresses of other items (a table of views) calls layout() first, fills them in, then upload().
+  int layout() {
     size_t off = 0;
     for (Item& it : items) if (it.src) { it.off = off; off += pad(it.bytes); }
     in_bytes = off;
@@ -85,6 +86,11 @@ struct Stage {
     int rc = ctx->ensure(total);
     if (rc != DVM_OK) return rc;
     d = ctx->d;
+    return DVM_OK;
+  }
+  int upload() {
+    int rc = d ? DVM_OK : layout();
+    if (rc != DVM_OK) return rc;
     for (const Item& it : items) if (it.src && it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes);
     if (in_bytes) rc = hip_check(hipMemcpyAsync(d, ctx->h, in_bytes, hipMemcpyHostToDevice, ctx->s), "upload");
     return rc;

@@ -139,12 +139,14 @@ class KeyFrameDatabase {
     map_ids_[m] = id;
     return id;
   }
-  uint64_t uid(const boost::uuids::uuid& u) {        // 0 is reserved by the mirror (the reset value of the query ids)
-    const auto it = uids_.find(u);
-    if (it != uids_.end()) return it->second;
-    const uint64_t id = uids_.size() + 1;
-    uids_[u] = id;
-    return id;
+  // The reference turns a uuid into its query id with boost::hash_range over the 16 bytes (KeyFrameDatabase.cc:693): a 64-bit hash that
+  // cannot meet the small mnId values DetectNBestCandidates writes into the same mnPlaceRecognitionQuery member.  Same here: FNV-1a over
+  // the bytes (small consecutive ids DID collide with mnIds: a keyframe last touched by DetectNBestCandidates of keyframe 8 looked
+  // "already visited" to the merge query with id 8).  0 is the mirror's reset value: never handed out.
+  static uint64_t uid(const boost::uuids::uuid& u) {
+    uint64_t h = 1469598103934665603ull;
+    for (const auto* p = u.data; p != u.data + 16; ++p) { h ^= (uint64_t)(uint8_t)*p; h *= 1099511628211ull; }
+    return h ? h : 1;
   }
   // What the reference reads from the objects DURING a query -- pKFi->GetMap() (LoopClosing::MergeLocal moves keyframes between
   // maps with UpdateMap, LoopClosing.cc:1558,1767), isBad(), GetBestCovisibilityKeyFrames(10), GetConnectedKeyFrames() -- is read
@@ -182,7 +184,6 @@ class KeyFrameDatabase {
   std::map<KeyFrame*, int> slot_of_;
   std::vector<KeyFrame*> kf_of_;
   std::map<Map*, int32_t> map_ids_;
-  std::map<boost::uuids::uuid, uint64_t> uids_;
 };
 
 }  // namespace ORB_SLAM3

@@ -252,6 +252,65 @@ def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = 
                 edge_point=edge_point, obs=obs, inv_sigma2=inv_sigma2, intrinsics=np.array([FX, FY, CX, CY]))
 
 
+def small_window_problem(n_kf: int = 2, n_pts: int = 150, seed: int = 1, noise_px: float = 1.0, outlier_frac: float = 0.05, baseline: float = 0.15,
+                         min_obs: int = 2):
+    """The shape of the bundle adjustments ORB-SLAM3 runs on a FRESH monocular map: n_kf = 2 is Tracking::CreateInitialMapMonocular's
+    GlobalBundleAdjustemnt(map, 20) (Tracking.cc:2330) -- keyframe 0 fixed at the identity, keyframe 1 a small baseline away, the
+    points triangulated from the two views at a median depth of ~1 (the map is rescaled so) --; n_kf = 3..6 are the local windows of the
+    keyframes inserted right after (Optimizer.cc:1030-1387).  Cameras look down +z from a line along x; every point is observed by a
+    random subset of >= min_obs cameras.  Same keys as ba_problem()."""
+    rng = np.random.default_rng(seed)
+    centres = np.stack([baseline * np.arange(n_kf) + rng.normal(0, 0.02 * baseline, n_kf), rng.normal(0, 0.1 * baseline, n_kf),
+                        rng.normal(0, 0.1 * baseline, n_kf)], axis=1)
+    centres[0] = 0
+    Rcw, tcw = [], []
+    for i in range(n_kf):
+        R = np.eye(3) if i == 0 else _rot_from_axis_angle(rng.normal(0, np.deg2rad(2.0), 3))
+        Rcw.append(R); tcw.append(-R @ centres[i])
+    pts, edge_pose, edge_point, obs = [], [], [], []
+    tries = 0
+    while len(pts) < n_pts:
+        tries += 1
+        if tries > 400 * n_pts:
+            raise RuntimeError("could not place landmarks")
+        depth = rng.uniform(0.5, 2.0)
+        pw = np.array([(rng.uniform(40, WIDTH - 40) - CX) / FX * depth, (rng.uniform(40, HEIGHT - 40) - CY) / FY * depth, depth])
+        seen = []
+        for i in range(n_kf):
+            q = Rcw[i] @ pw + tcw[i]
+            if q[2] > 0.1:
+                u, v = FX * q[0] / q[2] + CX, FY * q[1] / q[2] + CY
+                if 0 <= u < WIDTH and 0 <= v < HEIGHT:
+                    seen.append((i, u, v))
+        if len(seen) < min_obs:
+            continue
+        k = int(rng.integers(min_obs, len(seen) + 1))
+        pick = sorted(rng.choice(len(seen), size=k, replace=False))
+        for j in pick:
+            edge_pose.append(seen[j][0]); edge_point.append(len(pts)); obs.append(seen[j][1:])
+        pts.append(pw)
+    pts = np.asarray(pts)
+    edge_pose = np.asarray(edge_pose, np.int32); edge_point = np.asarray(edge_point, np.int32)
+    obs = np.asarray(obs, np.float64)
+    E = len(edge_pose)
+    obs += rng.normal(0, noise_px, obs.shape)
+    out = rng.random(E) < outlier_frac
+    obs[out] += rng.choice([-1.0, 1.0], size=(int(out.sum()), 2)) * 30.0
+    inv_sigma2 = (1.2 ** (-2.0 * rng.integers(0, 8, size=E))).astype(np.float64)
+    poses_gt = np.zeros((n_kf, 7)); poses = np.zeros((n_kf, 7))
+    for i in range(n_kf):
+        poses_gt[i, :3] = tcw[i]; poses_gt[i, 3:] = _quat_from_rot(Rcw[i])
+        if i == 0:
+            poses[i] = poses_gt[i]
+            continue
+        dR = _rot_from_axis_angle(rng.normal(0, np.deg2rad(0.3), 3))
+        poses[i, :3] = dR @ tcw[i] + rng.normal(0, 0.03 * baseline, 3); poses[i, 3:] = _quat_from_rot(dR @ Rcw[i])
+    points = pts * (1.0 + rng.normal(0, 0.03, (len(pts), 1)))        # triangulation error is mostly along the ray
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
+    return dict(poses=poses, poses_gt=poses_gt, fixed=fixed, points=points, points_gt=pts, edge_pose=edge_pose, edge_point=edge_point, obs=obs,
+                inv_sigma2=inv_sigma2, intrinsics=np.array([FX, FY, CX, CY]))
+
+
 def vocabulary(k: int = 10, L: int = 3, seed: int = 0x0B0C, ragged: bool = True, stop_frac: float = 0.02):
     """Synthetic DBoW2 vocabulary tree (ORBvoc.txt is not shipped with the reference: .MISSING_LARGE_BLOBS).
     Breadth-first node ids, root = 0, depth L, fan-out k (6..k when `ragged`), random 256-bit node descriptors,

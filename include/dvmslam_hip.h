@@ -401,6 +401,36 @@ int dvm_ba_profile(dvm_ba* h, int enable, double* ms4, int32_t* trials, int32_t*
 int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive);
 void* dvm_ba_stream(dvm_ba* h);
 
+/* K INDEPENDENT bundle adjustments in one launch: the LocalBundleAdjustment windows (Optimizer.cc:1030-1387) of several agents that
+ * share this GPU (BASELINE.json config 4 with more agents than GPUs), or the GlobalBundleAdjustemnt of a freshly initialised
+ * two-keyframe map (Tracking.cc:2330, Optimizer.cc:55-356).  Every window is what one dvm_ba_set_problem + dvm_ba_optimize(iterations)
+ * + dvm_ba_get_result + dvm_ba_edge_chi2 sequence would be given and return; one workgroup per window runs the whole
+ * optimizer.optimize(iterations) on the device.
+ * Summation order: every sum of a window runs in the order of g2o's single-threaded code (edges in input order per Hessian block
+ * and in chi2, landmarks in index order in the Schur complement, columns in order in the Cholesky factorisation) and sin / cos /
+ * pow(x, 3) are the fixed double-precision sequences of csrc/f64_spec.h, so the result is BIT-IDENTICAL to the CPU restatement of
+ * g2o's recipe -- which matters for windows with a weak gauge (one or two free cameras), whose result moves by 1e-3 and more when
+ * only the order of the floating-point sums changes.
+ * Limits: at most 30 free cameras per window (DVM_ERR_CAPACITY above; dvm_ba_optimize has no limit).  Host pointers, synchronous.
+ * stop_flag (may be NULL) is polled by the kernel between iterations and trials, for all windows.  stats: K entries or NULL;
+ * ms_optimize = wall time of the whole call (upload, launch, download), ms_structure = this window's share of the host set-up. */
+typedef struct {
+  int32_t n_poses, n_points, n_edges, iterations;
+  const double* poses;         /* [n_poses][7]  (tx,ty,tz,qx,qy,qz,qw), world -> camera */
+  const uint8_t* fixed;        /* [n_poses] */
+  const double* points;        /* [n_points][3] */
+  const dvm_ba_edge* edges;    /* [n_edges], pose / point are indices into THIS window's arrays */
+  dvm_ba_camera cam;
+  double* poses_out;           /* [n_poses][7] or NULL */
+  double* points_out;          /* [n_points][3] or NULL */
+  double* edge_chi2_out;       /* [n_edges] or NULL: e->chi2() after the last computeActiveErrors */
+  uint8_t* depth_positive_out; /* [n_edges] or NULL: isDepthPositive() at the result */
+} dvm_ba_window;
+int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
+/* csrc/f64_spec.h evaluated on the device for n arguments: out = [sin(x) | cos(x) | x^3], 3 n doubles.  A test aid: the host build of
+ * the spec, the device build and the oracle's restatement must agree bit for bit (tests/test_f64_spec.py, tests/test_gpu_ba_window.py). */
+int dvm_f64_spec_eval(int device, const double* x, int n, double* out);
+
 /* Optimizer::PoseOptimization (Optimizer.cc:744-1028, monocular edges): `batch` independent frames.
  * Frame f: pose (tx,ty,tz,qx,qy,qz,qw) at pose_in + 7f; n[f] 2D-3D matches stored with a common
  * `stride` (Xw [batch][stride][3], obs [batch][stride][2] = undistorted keypoint, inv_sigma2

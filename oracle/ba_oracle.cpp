@@ -27,6 +27,8 @@
 #include <limits>
 #include <vector>
 
+#include "f64_spec.h"
+
 namespace {
 
 struct Pose { double t[3]; double q[4]; };  // q = (x,y,z,w)
@@ -88,8 +90,10 @@ void pose_oplus(Pose& T, const double u[6]) {
     for (int i = 0; i < 9; i++) R[i] = I[i] + O[i] + O2[i];
     std::memcpy(V, R, sizeof(R));
   } else {
-    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta),
-                 c = (theta - std::sin(theta)) / std::pow(theta, 3);
+    // se3quat.h:229-234 calls libm's sin / cos / pow(theta, 3); no two libms agree on those bits, so the oracle evaluates the shared
+    // double-precision spec instead (oracle/f64_spec.h: fdlibm kernels, correctly rounded cube; within 1 ulp of glibc)
+    const double sn = orc_spec::sin(theta), cs = orc_spec::cos(theta);
+    const double a = sn / theta, b = (1 - cs) / (theta * theta), c = (theta - sn) / orc_spec::cube(theta);
     for (int i = 0; i < 9; i++) {
       R[i] = I[i] + a * O[i] + b * O2[i];
       V[i] = I[i] + b * O[i] + c * O2[i];
@@ -410,7 +414,7 @@ int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, 
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        double alpha = 1. - orc_spec::cube(2 * rho - 1);   // pow(2 rho - 1, 3), optimization_algorithm_levenberg.cpp:131 (f64_spec.h: the correctly rounded cube)
         alpha = std::min(alpha, 2. / 3.);
         lambda *= std::max(1. / 3., alpha);
         ni = 2;
@@ -442,6 +446,11 @@ int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, 
     st->stop_reason = stop;
   }
   return it_done;
+}
+
+// the double-precision spec, for tests/test_f64_spec.py: out[0..n) = sin, out[n..2n) = cos, out[2n..3n) = cube
+void orc_f64_spec(const double* x, int n, double* out) {
+  for (int i = 0; i < n; i++) { out[i] = orc_spec::sin(x[i]); out[n + i] = orc_spec::cos(x[i]); out[2 * n + i] = orc_spec::cube(x[i]); }
 }
 
 // per-edge raw chi2 and depth sign at the given state (Optimizer.cc:1317-1354 outlier tests)

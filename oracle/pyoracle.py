@@ -285,6 +285,16 @@ def ba_optimize(poses, fixed, points, edges, intrinsics, huber_delta, iterations
     return poses, points, stats, chi
 
 
+def f64_spec(x):
+    """oracle/f64_spec.h: (sin, cos, cube) of the doubles in x."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(3 * len(x), np.float64)
+    L.orc_f64_spec.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.orc_f64_spec(_p(x), len(x), _p(out))
+    return out[:len(x)], out[len(x):2 * len(x)], out[2 * len(x):]
+
+
 def ba_edge_chi2(poses, points, edges, intrinsics):
     L = lib()
     L.orc_ba_edge_chi2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(BaCamera), C.c_void_p, C.c_void_p]

@@ -1,0 +1,152 @@
+"""dvm_ba_optimize_windows (csrc/ba_window.hip): K independent bundle adjustments in one launch, every sum in g2o's sequential order ->
+BIT-IDENTICAL to the CPU oracle: poses, points, per-edge chi2, the LM trial sequence, chi2 and lambda of every iteration.  The cases
+are the ones the 1e-6 tolerance cannot cover: the two-keyframe GlobalBundleAdjustemnt(map, 20) of a monocular
+initialisation (Tracking.cc:2330), local windows of 3..5 keyframes (Optimizer.cc:1030), weak-gauge toys whose result moves by 1e-3 and
+more under a mere re-ordering of the edges (tools/ba_sensitivity.py)."""
+import numpy as np
+import pytest
+
+from dvm_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+DELTA = float(np.sqrt(5.991))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.int64)
+
+
+def _window(pr, delta, iters, fixed=None):
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    return dict(poses=pr["poses"], fixed=pr["fixed"] if fixed is None else fixed, points=pr["points"], edges=e, intrinsics=pr["intrinsics"],
+                huber_delta=delta, iterations=iters)
+
+
+def _oracle(oracle, w):
+    P, X, st, chi = oracle.ba_optimize(w["poses"], w["fixed"], w["points"], w["edges"], w["intrinsics"], w["huber_delta"], w["iterations"])
+    _, depth = oracle.ba_edge_chi2(P, X, w["edges"], w["intrinsics"])
+    return P, X, st, chi, depth
+
+
+def _assert_identical(g, o, tag=""):
+    P, X, st, chi, depth = o
+    s = g["stats"]
+    assert s["iterations"] == st["iterations"] and s["total_trials"] == st["total_trials"] and s["stop_reason"] == st["stop_reason"], (tag, s, st)
+    assert list(s["trials"]) == list(st["trials"]), tag
+    assert np.array_equal(_bits(s["chi2"]), _bits(st["chi2"])), (tag, s["chi2"], st["chi2"])
+    assert np.array_equal(_bits(s["lam"]), _bits(st["lam"])), tag
+    assert _bits([s["chi2_initial"], s["chi2_final"], s["lambda_final"]]).tolist() == _bits([st["chi2_initial"], st["chi2_final"], st["lambda_final"]]).tolist(), tag
+    assert np.array_equal(_bits(g["poses"]), _bits(P)), (tag, np.abs(g["poses"] - P).max())
+    assert np.array_equal(_bits(g["points"]), _bits(X)), (tag, np.abs(g["points"] - X).max())
+    assert np.array_equal(_bits(g["edge_chi2"]), _bits(chi)), tag
+    assert np.array_equal(g["depth_positive"], depth), tag
+
+
+def test_f64_spec_device_equals_oracle(oracle):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-np.pi / 4, np.pi / 4, 200_000), rng.uniform(-1e-3, 1e-3, 50_000), rng.uniform(-50, 50, 50_000),
+                        np.array([0.0, -0.0, 2.0 ** -27, 2.0 ** -28, 0.3, 0.78125, np.pi / 4, 1.0, -3.0, 1e5])])
+    sg, cg, qg = capi.f64_spec_eval(x)
+    so, co, qo = oracle.f64_spec(x)
+    for name, a, b in (("sin", sg, so), ("cos", cg, co), ("cube", qg, qo)):
+        assert np.array_equal(_bits(a), _bits(b)), name
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mono_initialisation_global_ba_is_bit_identical(oracle, seed):
+    """Tracking::CreateInitialMapMonocular: GlobalBundleAdjustemnt(mpAtlas->GetCurrentMap(), 20) on two keyframes (the first fixed) and the
+    points triangulated from them, robust kernel on (Optimizer.h: bRobust = true)."""
+    pr = synth.small_window_problem(2, 100 + 40 * seed, seed=100 + seed, noise_px=[0.5, 1.0, 2.0][seed % 3], outlier_frac=[0.0, 0.05][seed % 2])
+    w = _window(pr, DELTA, 20)
+    g = capi.ba_optimize_windows([w])[0]
+    _assert_identical(g, _oracle(oracle, w), f"seed {seed}")
+
+
+@pytest.mark.parametrize("n_kf,seed", [(3, 0), (3, 1), (4, 2), (4, 3), (5, 4), (5, 5), (6, 6)])
+def test_small_local_windows_are_bit_identical(oracle, n_kf, seed):
+    """LocalBundleAdjustment right after initialisation: 3..6 keyframes, optimize(10) (and the 5 + 10 pattern as two windows of a batch:
+    the second starts from the first one's result, as Optimizer.cc:1306-1311 continues on the same graph)."""
+    pr = synth.small_window_problem(n_kf, 120 + 30 * seed, seed=200 + seed)
+    fixed = pr["fixed"].copy()
+    if seed % 2:
+        fixed[1] = 1                                     # a second fixed keyframe (the window's covisible-but-not-local ones)
+    w = _window(pr, DELTA, 10, fixed)
+    g = capi.ba_optimize_windows([w])[0]
+    o = _oracle(oracle, w)
+    _assert_identical(g, o, f"kf {n_kf} seed {seed}")
+    w5 = dict(w, iterations=5)
+    g5 = capi.ba_optimize_windows([w5])[0]
+    o5 = _oracle(oracle, w5)
+    _assert_identical(g5, o5, "first round")
+    w10 = dict(w, poses=g5["poses"], points=g5["points"], iterations=10)
+    _assert_identical(capi.ba_optimize_windows([w10])[0], _oracle(oracle, dict(w, poses=o5[0], points=o5[1], iterations=10)), "second round")
+
+
+def test_weak_gauge_problems_that_no_tolerance_covers(oracle):
+    """The class the soak kept reporting: ring-scene toys with one free camera and two-view landmarks.  The oracle
+    run on the SAME problem with its edges in another order lands up to 1e-1 away from itself -- and the window kernel lands on the
+    oracle's bits."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    done = 0
+    while done < 24:
+        n_kf = int(rng.integers(2, 5)); k = int(rng.integers(2, n_kf + 1))
+        try:
+            pr = synth.ba_problem(n_kf, int(rng.integers(60, 400)), k, seed=int(rng.integers(1 << 30)), noise_px=float(rng.choice([0.5, 1.0, 3.0])),
+                                  outlier_frac=float(rng.choice([0.0, 0.2])))
+        except RuntimeError:
+            continue
+        done += 1
+        delta = DELTA if done % 3 else 0.0
+        w = _window(pr, delta, 20)
+        o = _oracle(oracle, w)
+        _assert_identical(capi.ba_optimize_windows([w])[0], o, f"case {done}")
+        perm = rng.permutation(len(w["edges"]))
+        P2, X2, _, _ = oracle.ba_optimize(w["poses"], w["fixed"], w["points"], w["edges"][perm], w["intrinsics"], delta, 20)
+        worst = max(worst, float(np.abs(P2 - o[0]).max()), float(np.abs(X2 - o[1]).max()))
+    assert worst > 1e-6, worst       # the premise: re-ordering alone moves these problems beyond the tolerance (typically 1e-3 .. 1e-1)
+
+
+def test_batch_of_mixed_windows_one_launch(oracle):
+    """K windows of different shapes in ONE call -- 2..30 free cameras, Huber on / off, different iteration counts, a window without
+    edges, a window whose cameras are all fixed -- each identical to its own oracle run (no cross-talk between workgroups)."""
+    rng = np.random.default_rng(3)
+    wins = []
+    for k in range(14):
+        n_kf = [2, 3, 5, 8, 12, 20, 31][k % 7]
+        if n_kf <= 6:
+            pr = synth.small_window_problem(n_kf, int(rng.integers(60, 300)), seed=300 + k)
+        else:
+            pr = synth.ba_problem(n_kf, int(rng.integers(200, 900)), int(rng.integers(3, 7)), seed=300 + k)
+        wins.append(_window(pr, DELTA if k % 2 else 0.0, int(rng.integers(3, 12))))
+    empty = synth.small_window_problem(3, 40, seed=9)
+    wins.append(dict(_window(empty, DELTA, 5), edges=np.zeros(0, capi.BA_EDGE_DTYPE)))
+    wins.append(_window(empty, DELTA, 5, fixed=np.ones(3, np.uint8)))                   # landmarks only
+    out = capi.ba_optimize_windows(wins)
+    assert len(out) == len(wins)
+    for k, (g, w) in enumerate(zip(out, wins)):
+        _assert_identical(g, _oracle(oracle, w), f"window {k}")
+    assert max(int((1 - np.asarray(w["fixed"])).sum()) for w in wins) == 30             # the LDS limit itself is exercised
+
+
+def test_failed_linear_solve_follows_g2o(oracle):
+    """A window whose reduced system is not positive definite at the first damping (landmarks behind a camera: negative curvature is
+    impossible with J^T J, so the failure is provoked with NaN-free but huge residual weights on a degenerate two-point problem) takes g2o's
+    failed-solve branch: stale x applied, chi2 = max, the trial rejected -- as the oracle does."""
+    pr = synth.small_window_problem(2, 6, seed=5, noise_px=0.0, outlier_frac=0.0)
+    pr["inv_sigma2"][:] = 1e300                           # H overflows to inf -> the pivot test !(s > 0) fails on NaN / inf - inf
+    w = _window(pr, 0.0, 3)
+    _assert_identical(capi.ba_optimize_windows([w])[0], _oracle(oracle, w), "overflow")
+
+
+def test_limits_and_stop_flag(oracle):
+    pr = synth.ba_problem(40, 600, 5, seed=8)
+    w = _window(pr, DELTA, 5)
+    with pytest.raises(capi.DvmError) as ei:
+        capi.ba_optimize_windows([w])
+    assert ei.value.code == -3          # DVM_ERR_CAPACITY
+    small = _window(synth.small_window_problem(3, 80, seed=1), DELTA, 10)
+    stop = np.ones(1, np.uint8)                           # already raised: g2o's terminate() before the first iteration
+    g = capi.ba_optimize_windows([small], stop_flag=stop)[0]
+    assert g["stats"]["iterations"] == 0 and np.array_equal(_bits(g["points"]), _bits(small["points"]))
+    assert capi.ba_optimize_windows([]) == []
