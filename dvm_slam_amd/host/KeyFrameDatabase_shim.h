@@ -52,6 +52,7 @@ class KeyFrameDatabase {
     if ((int)kf_of_.size() <= slot) kf_of_.resize(slot + 1, nullptr);
     kf_of_[slot] = pKF;
     slot_of_[pKF] = slot;
+    ever_slot_[pKF] = slot;
     uuidToKeyFrame[pKF->uuid] = pKF;
   }
   void erase(KeyFrame* pKF) {
@@ -59,14 +60,14 @@ class KeyFrameDatabase {
     const auto it = slot_of_.find(pKF);
     if (it == slot_of_.end()) return;
     db_->erase(it->second);
-    kf_of_[it->second] = nullptr;
-    slot_of_.erase(it);
-    uuidToKeyFrame.erase(pKF->uuid);
+    slot_of_.erase(it);                    // kf_of_ / ever_slot_ keep the slot: the keyframe object lives on (ORB-SLAM3 never deletes
+    uuidToKeyFrame.erase(pKF->uuid);       // keyframes) and other keyframes' covisibility lists may still name it (see Live::best_covisibles)
   }
   void clear() {
     std::unique_lock<std::mutex> lock(mMutex);
     for (const auto& ks : slot_of_) db_->erase(ks.second);
     slot_of_.clear();
+    ever_slot_.clear();
     std::fill(kf_of_.begin(), kf_of_.end(), nullptr);
     uuidToKeyFrame.clear();
   }
@@ -76,6 +77,7 @@ class KeyFrameDatabase {
       if (it->first->GetMap() == pMap) {
         db_->erase(it->second);
         kf_of_[it->second] = nullptr;
+        ever_slot_.erase(it->first);
         uuidToKeyFrame.erase(it->first->uuid);
         it = slot_of_.erase(it);
       } else {
@@ -159,9 +161,12 @@ class KeyFrameDatabase {
     int32_t map_id(int slot) override { return o->map_id(o->kf_of_[slot]->GetMap()); }
     void best_covisibles(int slot, std::vector<int32_t>& out) override {
       out.clear();
+      // a neighbour that has LEFT the database still carries the query id / score of the last query that touched it (the reference
+      // reads pKF2->mnPlaceRecognitionQuery of the object, in the inverted file or not): its slot outlives erase().  One that was
+      // never added has never been touched: no query can match its id.
       for (KeyFrame* n : o->kf_of_[slot]->GetBestCovisibilityKeyFrames(10)) {
-        const auto it = o->slot_of_.find(n);
-        if (it != o->slot_of_.end()) out.push_back(it->second);      // (a neighbour outside the database carries no query id: the walk skips it)
+        const auto it = o->ever_slot_.find(n);
+        if (it != o->ever_slot_.end()) out.push_back(it->second);
       }
     }
     void connected(int slot, std::set<int32_t>& out) override {
@@ -182,6 +187,7 @@ class KeyFrameDatabase {
   dvm_host::KeyFrameDatabase* db_;
   Live live_;
   std::map<KeyFrame*, int> slot_of_;
+  std::map<KeyFrame*, int> ever_slot_;      // last slot of every keyframe that has ever been in the database (its query state lives there)
   std::vector<KeyFrame*> kf_of_;
   std::map<Map*, int32_t> map_ids_;
 };

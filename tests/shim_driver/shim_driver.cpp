@@ -338,7 +338,21 @@ void sw_kf_set_connected(World* w, int kf, const int32_t* others, int n) {
 void sw_kf_set_bad(World* w, int kf, int bad) { w->kfs[kf]->mbBad = bad != 0; }
 void sw_kf_update_map(World* w, int kf, int map) { w->kfs[kf]->UpdateMap(w->maps[map].get()); }    // KeyFrame::UpdateMap, as LoopClosing::MergeLocal calls it
 void sw_map_set_bad(World* w, int map, int bad) { w->maps[map]->mock_bad = bad != 0; }
-int sw_kfdb_create(World* w) { return guarded(w, [&] { w->kfdb.reset(new KeyFrameDatabase()); return 0; }); }
+// test probe: the class keeps its mirror protected; the per-keyframe query state (mnPlaceRecognitionQuery / Words / Score and the relocalisation
+// triple, which the reference keeps in public KeyFrame members) is read through a derived class
+struct KfdbProbe : KeyFrameDatabase {
+  bool state(KeyFrame* k, int reloc, uint64_t* q, int32_t* wd, float* sc) {
+    const auto it = slot_of_.find(k);
+    if (it == slot_of_.end()) return false;
+    const dvm_host::KeyFrameDatabase::State s = reloc ? db_->GetRelocState(it->second) : db_->GetState(it->second);
+    *q = s.query; *wd = s.words; *sc = s.score;
+    return true;
+  }
+};
+int sw_kfdb_create(World* w) { return guarded(w, [&] { w->kfdb.reset(new KfdbProbe()); return 0; }); }
+int sw_kfdb_get_state(World* w, int kf, int reloc, uint64_t* query, int32_t* words, float* score) {
+  return static_cast<KfdbProbe*>(w->kfdb.get())->state(w->kfs[kf].get(), reloc, query, words, score) ? 1 : 0;
+}
 int sw_kfdb_add(World* w, int kf) { return guarded(w, [&] { w->kfdb->add(w->kfs[kf].get()); return 0; }); }
 int sw_kfdb_erase(World* w, int kf) { return guarded(w, [&] { w->kfdb->erase(w->kfs[kf].get()); return 0; }); }
 int sw_kfdb_clear_map(World* w, int map) { return guarded(w, [&] { w->kfdb->clearMap(w->maps[map].get()); return 0; }); }

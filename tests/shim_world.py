@@ -211,6 +211,12 @@ class World:
     def kf_set_bad(self, kf, bad): self.L.sw_kf_set_bad(self.h, kf, int(bad))
     def map_set_bad(self, m, bad): self.L.sw_map_set_bad(self.h, m, int(bad))
     def kfdb_create(self): self._chk(self.L.sw_kfdb_create(self.h))
+    def kfdb_get_state(self, kf, reloc=False):
+        q = C.c_uint64(0); w = C.c_int32(0); s = C.c_float(0)
+        if not self.L.sw_kfdb_get_state(self.h, kf, int(reloc), C.byref(q), C.byref(w), C.byref(s)):
+            return None
+        return q.value, w.value, s.value
+
     def kfdb_add(self, kf): self._chk(self.L.sw_kfdb_add(self.h, kf))
     def kfdb_erase(self, kf): self._chk(self.L.sw_kfdb_erase(self.h, kf))
 

@@ -387,7 +387,9 @@ def test_keyframe_database_class(oracle, seed):
     """ORB_SLAM3::KeyFrameDatabase on KeyFrame* / Map* / Frame* (host/KeyFrameDatabase_shim.h): add / erase, DetectMergePossibility and
     CalculateMergeScore on a peer's BoW vector + uuid, DetectNBestCandidates of a stored keyframe, DetectRelocalizationCandidates of
     a frame -- a mixed sequence against the oracle's database.  Bad flags and covisibility are changed ON THE OBJECTS between the
-    queries: the class reads them live, as the reference does."""
+    queries: the class reads them live, as the reference does.  Keyframes ERASED from the database stay in their neighbours' covisibility
+    lists with the query state they last had -- the reference reads the object's members, inverted file or not (a 140-step sequence found
+    the class skipping them)."""
     from kfdb_scene import fill, make_db_scene
     kfs = make_db_scene(seed + 20, kf_per_map=30)
     dbo = oracle.KeyFrameDatabase()
@@ -411,6 +413,7 @@ def test_keyframe_database_class(oracle, seed):
     rng = np.random.default_rng(seed)
     alive = set(range(len(kfs)))
     hits = moved = 0
+    qmap = {}
     for step in range(140):
         op = rng.random()
         j = int(rng.choice(sorted(alive)))
@@ -447,6 +450,11 @@ def test_keyframe_database_class(oracle, seed):
             m_new = int(rng.integers(0, 3))
             dbo.set_map(j, m_new); W.kf_update_map(j, m_new)
             moved += 1
+        # the per-keyframe query state (mnPlaceRecognitionQuery / Words / Score) after every step; query ids through a bijection (the oracle is
+        # handed the uuid integers, the class hashes the uuid bytes as the reference does)
+        for jj in sorted(alive):
+            so, sg = dbo.state(jj), W.kfdb_get_state(jj)
+            assert so[1:] == sg[1:] and qmap.setdefault(sg[0], so[0]) == so[0], (step, jj, so, sg)
     assert hits > 15 and moved > 0
 
 
