@@ -393,6 +393,9 @@ def make_edges(edge_pose, edge_point, obs, inv_sigma2) -> np.ndarray:
     return e
 
 
+BA_EDGE_ACTIVE, BA_EDGE_ROBUST = 1, 2     # DVM_BA_EDGE_ACTIVE / DVM_BA_EDGE_ROBUST
+
+
 class BundleAdjuster:
     """Optimizer::BundleAdjustment / LocalBundleAdjustment numerics (reference Optimizer.cc:55-356,1030-1387)."""
 
@@ -473,6 +476,17 @@ class BundleAdjuster:
                     chi2_initial=st.chi2_initial, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
                     trials=st.trials_per_iter[:n], chi2=st.chi2_per_iter[:n], lam=st.lambda_per_iter[:n],   # (a ctypes array slice is a list)
                     ms_structure=st.ms_structure, ms_optimize=st.ms_optimize, spec_trials=st.spec_trials, spec_kept=st.spec_kept)
+
+    def set_edge_flags(self, flags):
+        """dvm_ba_set_edge_flags: per edge BA_EDGE_ACTIVE | BA_EDGE_ROBUST (None: every edge active and robust again)."""
+        f = self.L.dvm_ba_set_edge_flags
+        f.restype = C.c_int32; f.argtypes = None
+        if flags is None:
+            check(f(self.h, None))
+        else:
+            fl = np.ascontiguousarray(flags, np.uint8)
+            assert len(fl) == self.E
+            check(f(self.h, _p(fl)))
 
     def result(self):
         poses = np.zeros((self.P, 7), np.float64)

@@ -63,6 +63,16 @@ struct dvm_ba {
   uint8_t* h_flags = nullptr;               // ONE page-locked staging slot of E bytes for them, reserved with the problem and reused by every call
   bool have_problem = false;
   double ms_structure = 0;
+  // Window mode (csrc/ba_window.hip): a problem with a handful of free cameras -- the two-keyframe global BA of a monocular
+  // initialisation, the first local windows -- is solved by the sequential-order kernel, whose result is bit-identical to g2o's
+  // summation order: with one or two free cameras the gauge is held by the damping alone and any other order lands 1e-3 and more
+  // away.  The state then lives in these host copies between calls; the tile solver's device arrays are
+  // brought up to date only when a call needs them (edge flags set: the welding BA's second round).
+  bool win_mode = false, win_device_stale = false;
+  std::vector<double> ws_poses, ws_points, ws_chi2;
+  std::vector<uint8_t> ws_fixed, ws_depth;
+  std::vector<dvm_ba_edge> ws_edges;
+  dvm_ba_camera ws_cam{};
   BaTileSchedule sched;                               // level schedule of the tile Cholesky (host copy: launch sizes)
   double tile_fill = 1.0;                             // non-zero tiles / all lower tiles of the factor
 
@@ -475,6 +485,16 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   V.damp_s = rank == 0 ? 1.0 : 0.0;
   V.shard_rank = rank; V.shard_world = world;
   h->have_problem = true;
+  {
+    static const int max_free = [] { const char* e = std::getenv("DVM_BA_WINDOW_MAX_FREE"); return e ? std::atoi(e) : 6; }();
+    h->win_mode = world == 1 && V.nfree <= std::min(max_free, 30) && !std::getenv("DVM_BA_NO_WINDOW");
+    h->win_device_stale = false;
+    if (h->win_mode) {
+      h->ws_poses = pn; h->ws_points.assign(points, points + 3 * (size_t)L); h->ws_fixed.assign(fixed, fixed + P);
+      h->ws_edges.assign(edges, edges + E); h->ws_cam = *cam;
+      h->ws_chi2.assign(E, 0.0); h->ws_depth.assign(E, 0);
+    }
+  }
   return DVM_OK;
 }
 
@@ -590,6 +610,31 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   DVM_HIP(hipSetDevice(h->device));
   BaView& V = h->V;
   hipStream_t s = h->stream;
+  if (h->win_mode && !V.e_flags && !h->prof) {
+    // the whole optimize() as one launch of the sequential-order kernel; the state continues from the previous call without a
+    // second normalisation (g2o keeps the graph between optimize() calls)
+    dvm_ba_window w{};
+    w.n_poses = V.P; w.n_points = V.L; w.n_edges = V.E; w.iterations = iterations;
+    w.poses = h->ws_poses.data(); w.fixed = h->ws_fixed.data(); w.points = h->ws_points.data(); w.edges = h->ws_edges.data(); w.cam = h->ws_cam;
+    std::vector<double> po(h->ws_poses.size()), xo(h->ws_points.size());
+    w.poses_out = po.data(); w.points_out = xo.data(); w.edge_chi2_out = h->ws_chi2.data(); w.depth_positive_out = h->ws_depth.data();
+    dvm_ba_stats ws;
+    const int rc = dvm_ba_optimize_windows_impl(h->device, &w, 1, stop_flag, &ws, /*normalize_input=*/false);
+    if (rc != DVM_OK) return rc;
+    h->ws_poses.swap(po); h->ws_points.swap(xo);
+    h->win_device_stale = true;
+    if (st) { *st = ws; st->ms_structure = h->ms_structure; }
+    return DVM_OK;
+  }
+  if (h->win_mode && h->win_device_stale) {      // the tile solver takes over (edge flags, profiling): it continues from the window kernel's state
+    DVM_HIP(hipStreamSynchronize(s));
+    DVM_HIP(hipMemcpy(V.poses, h->ws_poses.data(), h->ws_poses.size() * sizeof(double), hipMemcpyHostToDevice));
+    DVM_HIP(hipMemcpy(V.points, h->ws_points.data(), h->ws_points.size() * sizeof(double), hipMemcpyHostToDevice));
+    DVM_HIP(hipMemcpy(V.poses_new, h->ws_poses.data(), h->ws_poses.size() * sizeof(double), hipMemcpyHostToDevice));
+    DVM_HIP(hipMemcpy(V.points_new, h->ws_points.data(), h->ws_points.size() * sizeof(double), hipMemcpyHostToDevice));
+    DVM_HIP(hipMemcpy(V.e_chi2, h->ws_chi2.data(), h->ws_chi2.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->win_device_stale = false;
+  }
   if (st) { std::memset(st, 0, sizeof(*st)); st->ms_structure = h->ms_structure; }
   const auto t0 = std::chrono::steady_clock::now();
   const bool dbg_time = std::getenv("DVM_BA_DEBUG_SCHEDULE") != nullptr;
@@ -839,6 +884,12 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
   // every entry point that reads device memory synchronises the stream itself, so the blocking wait here -- 50-80 us of
   // interrupt latency on an almost idle stream, per call -- is only paid where a collective has to be finished.
   if (sharded) DVM_HIP(hipStreamSynchronize(s));
+  if (h->win_mode) {     // a window-mode problem that took the tile solver for this call: the host copies follow the device state
+    DVM_HIP(hipStreamSynchronize(s));
+    DVM_HIP(hipMemcpy(h->ws_poses.data(), V.poses, h->ws_poses.size() * sizeof(double), hipMemcpyDeviceToHost));
+    DVM_HIP(hipMemcpy(h->ws_points.data(), V.points, h->ws_points.size() * sizeof(double), hipMemcpyDeviceToHost));
+    DVM_HIP(hipMemcpy(h->ws_chi2.data(), V.e_chi2, h->ws_chi2.size() * sizeof(double), hipMemcpyDeviceToHost));
+  }
   mark("returning", it_done);
   if (st) {
     st->iterations = it_done; st->total_trials = trials_total; st->stop_reason = stop;
@@ -851,6 +902,11 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
 int dvm_ba_get_result(dvm_ba* h, double* poses, double* points) {
   if (!h || !h->have_problem) return DVM_ERR_STATE;
   DVM_HIP(hipSetDevice(h->device));
+  if (h->win_mode && h->win_device_stale) {       // the state of the window kernel's last run
+    if (poses) std::memcpy(poses, h->ws_poses.data(), h->ws_poses.size() * sizeof(double));
+    if (points) std::memcpy(points, h->ws_points.data(), h->ws_points.size() * sizeof(double));
+    return DVM_OK;
+  }
   DVM_HIP(hipStreamSynchronize(h->stream));
   if (poses) DVM_HIP(hipMemcpy(poses, h->V.poses, 7 * (size_t)h->V.P * sizeof(double), hipMemcpyDeviceToHost));
   if (points) DVM_HIP(hipMemcpy(points, h->V.points, 3 * (size_t)h->V.L * sizeof(double), hipMemcpyDeviceToHost));
@@ -862,6 +918,11 @@ int dvm_ba_get_result(dvm_ba* h, double* poses, double* points) {
 int dvm_ba_edge_chi2(dvm_ba* h, double* chi2, uint8_t* depth_positive) {
   if (!h || !h->have_problem) return DVM_ERR_STATE;
   DVM_HIP(hipSetDevice(h->device));
+  if (h->win_mode && h->win_device_stale) {
+    if (chi2) std::memcpy(chi2, h->ws_chi2.data(), h->ws_chi2.size() * sizeof(double));
+    if (depth_positive) std::memcpy(depth_positive, h->ws_depth.data(), h->ws_depth.size());
+    return DVM_OK;
+  }
   if (depth_positive) ba_launch_edge_depth(h->stream, h->V, h->d_depth);
   DVM_HIP(hipStreamSynchronize(h->stream));
   if (chi2) DVM_HIP(hipMemcpy(chi2, h->V.e_chi2, (size_t)h->V.E * sizeof(double), hipMemcpyDeviceToHost));

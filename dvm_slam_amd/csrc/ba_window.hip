@@ -36,6 +36,7 @@
 
 #include "../../include/dvmslam_hip.h"
 #include "f64_spec.h"
+#include "ba_kernels.h"
 #include "host_stage.h"
 #include "orb_pipeline.h"   // set_error / hip_check / DVM_HIP
 
@@ -552,12 +553,12 @@ struct WinBuild {
   std::vector<double> e_obs, e_info;
 };
 
-int build_window(const dvm_ba_window& w, WinBuild& b) {
+int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize) {
   const int P = w.n_poses, L = w.n_points, E = w.n_edges;
   if (P < 0 || L < 0 || E < 0 || (P && (!w.poses || !w.fixed)) || (L && !w.points) || (E && !w.edges)) { set_error("dvm_ba_optimize_windows: null array"); return DVM_ERR_INVALID; }
   b.P = P; b.L = L; b.E = E;
   b.poses.assign(w.poses, w.poses + 7 * (size_t)P);
-  for (int p = 0; p < P; p++) {              // quat_normalize as the oracle / g2o::SE3Quat(q, t) does it: sign, then divide by the norm
+  for (int p = 0; normalize && p < P; p++) {   // quat_normalize as the oracle / g2o::SE3Quat(q, t) does it: sign, then divide by the norm
     double* q = &b.poses[7 * (size_t)p + 3];
     if (q[3] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
     const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -638,16 +639,14 @@ struct StopWord {                      // a word of page-locked host memory the 
 
 }  // namespace
 
-extern "C" {
-
-int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
+int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input) {
   if (K < 0 || (K && !windows)) { set_error("dvm_ba_optimize_windows: null windows"); return DVM_ERR_INVALID; }
   if (K == 0) return DVM_OK;
   int rc = dvm_set_device(device);
   if (rc != DVM_OK) return rc;
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<WinBuild> B(K);
-  for (int k = 0; k < K; k++) if ((rc = build_window(windows[k], B[k])) != DVM_OK) return rc;
+  for (int k = 0; k < K; k++) if ((rc = build_window(windows[k], B[k], normalize_input)) != DVM_OK) return rc;
   const auto t1 = std::chrono::steady_clock::now();
   thread_local StopWord sw;
   if ((rc = sw.ensure()) != DVM_OK) return rc;
@@ -742,6 +741,12 @@ int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, con
     }
   }
   return DVM_OK;
+}
+
+extern "C" {
+
+int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
+  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true);
 }
 
 int dvm_f64_spec_eval(int device, const double* x, int n, double* out) {

@@ -331,15 +331,27 @@ struct BA {
 
 extern "C" {
 
+static int ba_optimize_impl(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
+                            const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2, bool normalize_input);
 int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
                     const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2) {
+  return ba_optimize_impl(poses, fixed, P, points, L, edges, E, cam, iterations, st, edge_chi2, true);
+}
+// a further optimizer.optimize(n) on the SAME graph (Optimizer.cc:1306-1311, :3474-3519: g2o keeps the vertices between the
+// calls): the estimates are taken as the previous call left them, without SE3Quat's constructor normalising them again
+int orc_ba_optimize_continue(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
+                             const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2) {
+  return ba_optimize_impl(poses, fixed, P, points, L, edges, E, cam, iterations, st, edge_chi2, false);
+}
+static int ba_optimize_impl(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
+                            const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2, bool normalize_input) {
   BA ba;
   ba.P = P; ba.L = L; ba.E = E;
   ba.poses.resize(P);
   for (int p = 0; p < P; p++) {
     std::memcpy(ba.poses[p].t, poses + 7 * p, 3 * sizeof(double));
     std::memcpy(ba.poses[p].q, poses + 7 * p + 3, 4 * sizeof(double));
-    quat_normalize(ba.poses[p].q);
+    if (normalize_input) quat_normalize(ba.poses[p].q);
   }
   ba.fixed.assign(fixed, fixed + P);
   ba.pts.assign(points, points + 3 * (size_t)L);

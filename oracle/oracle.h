@@ -228,6 +228,9 @@ typedef struct {
  * edge's chi2() as g2o would report it after optimize().  Returns iterations performed. */
 int orc_ba_optimize(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
                     const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2);
+/* a further optimize(n) on the same graph: estimates taken as they are (no normalisation of the input quaternions) */
+int orc_ba_optimize_continue(double* poses, const uint8_t* fixed, int P, double* points, int L, const orc_ba_edge* edges, int E,
+                             const orc_ba_camera* cam, int iterations, orc_ba_stats* st, double* edge_chi2);
 /* oracle/f64_spec.h evaluated on n arguments: out = [sin | cos | cube] */
 void orc_f64_spec(const double* x, int n, double* out);
 void orc_ba_edge_chi2(const double* poses, const double* points, const orc_ba_edge* edges, int E,

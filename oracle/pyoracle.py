@@ -264,11 +264,13 @@ def make_edges(edge_pose, edge_point, obs, inv_sigma2) -> np.ndarray:
     return e
 
 
-def ba_optimize(poses, fixed, points, edges, intrinsics, huber_delta, iterations, libpath=None):
-    """Returns (poses, points, stats dict, edge_chi2)."""
+def ba_optimize(poses, fixed, points, edges, intrinsics, huber_delta, iterations, libpath=None, continue_graph=False):
+    """Returns (poses, points, stats dict, edge_chi2).  continue_graph: a further optimize() on the same graph -- the estimates are
+    taken as the previous call left them (no normalisation of the input quaternions)."""
     L = lib(libpath) if libpath else lib()
-    L.orc_ba_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
-                                  C.POINTER(BaCamera), C.c_int32, C.POINTER(BaStats), C.c_void_p]
+    fn = L.orc_ba_optimize_continue if continue_graph else L.orc_ba_optimize
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                   C.POINTER(BaCamera), C.c_int32, C.POINTER(BaStats), C.c_void_p]
     poses = np.array(poses, np.float64, copy=True, order="C")
     points = np.array(points, np.float64, copy=True, order="C")
     fixed = np.ascontiguousarray(fixed, np.uint8)
@@ -276,8 +278,8 @@ def ba_optimize(poses, fixed, points, edges, intrinsics, huber_delta, iterations
     cam = BaCamera(*[float(v) for v in intrinsics], float(huber_delta))
     st = BaStats()
     chi = np.zeros(len(edges), np.float64)
-    it = L.orc_ba_optimize(_p(poses), _p(fixed), len(poses), _p(points), len(points), _p(edges), len(edges),
-                           C.byref(cam), iterations, C.byref(st), _p(chi))
+    it = fn(_p(poses), _p(fixed), len(poses), _p(points), len(points), _p(edges), len(edges),
+            C.byref(cam), iterations, C.byref(st), _p(chi))
     n = st.iterations
     stats = dict(iterations=it, total_trials=st.total_trials, stop_reason=st.stop_reason, chi2_initial=st.chi2_initial,
                  chi2_final=st.chi2_final, lambda_final=st.lambda_final, trials=list(st.trials_per_iter[:n]),

@@ -150,3 +150,68 @@ def test_limits_and_stop_flag(oracle):
     g = capi.ba_optimize_windows([small], stop_flag=stop)[0]
     assert g["stats"]["iterations"] == 0 and np.array_equal(_bits(g["points"]), _bits(small["points"]))
     assert capi.ba_optimize_windows([]) == []
+
+
+# ---------------------------------------------------------------------------------------------- the handle API on small problems
+def _handle_run(pr, delta, rounds, fixed=None, flags_before_round=None):
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"] if fixed is None else fixed, pr["points"], e, pr["intrinsics"], delta)
+    out = []
+    for r, it in enumerate(rounds):
+        st = ba.optimize(it)
+        P, X = ba.result()
+        chi, depth = ba.edge_chi2()
+        out.append((P, X, st, chi, depth))
+    ba.close()
+    return e, out
+
+
+@pytest.mark.parametrize("n_kf,seed", [(2, 0), (2, 1), (3, 2), (4, 3), (6, 4), (7, 5)])
+def test_ba_handle_on_small_problems_is_bit_identical(oracle, n_kf, seed):
+    """dvm_ba_set_problem / dvm_ba_optimize / dvm_ba_get_result / dvm_ba_edge_chi2 -- the entry points Optimizer_shim.h calls -- on
+    problems with <= 6 free cameras run the sequential-order kernel: GlobalBundleAdjustemnt(map, 20) of a two-keyframe map and
+    LocalBundleAdjustment's optimize(5) + optimize(10) on the same graph (Optimizer.cc:1306-1311) come out with the oracle's bits,
+    the second round continuing from the first WITHOUT re-normalising the quaternions, as g2o's persistent graph does."""
+    pr = synth.small_window_problem(n_kf, 140, seed=400 + seed)
+    rounds = [20] if n_kf == 2 else [5, 10]
+    e, got = _handle_run(pr, DELTA, rounds)
+    P, X = pr["poses"], pr["points"]
+    for r, it in enumerate(rounds):
+        P, X, st, chi = oracle.ba_optimize(P, pr["fixed"], X, e, pr["intrinsics"], DELTA, it, continue_graph=r > 0)
+        _, depth = oracle.ba_edge_chi2(P, X, e, pr["intrinsics"])
+        Pg, Xg, sg, chig, depthg = got[r]
+        assert sg["trials"] == st["trials"] and np.array_equal(_bits(sg["chi2"]), _bits(st["chi2"])) and np.array_equal(_bits(sg["lam"]), _bits(st["lam"])), (r, sg, st)
+        assert np.array_equal(_bits(Pg), _bits(P)) and np.array_equal(_bits(Xg), _bits(X)), (r, np.abs(Pg - P).max(), np.abs(Xg - X).max())
+        assert np.array_equal(_bits(chig), _bits(chi)) and np.array_equal(depthg, depth), r
+
+
+def test_ba_handle_window_mode_hands_over_to_the_tile_solver(oracle):
+    """Edge flags (the welding BA's second round, Optimizer.cc:3474-3519) are the tile solver's: a small problem that has run the
+    window kernel continues there from the window kernel's state, and back."""
+    pr = synth.small_window_problem(4, 160, seed=77, outlier_frac=0.1)
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], DELTA)
+    ba.optimize(5)                                       # window kernel
+    P1, X1 = ba.result()
+    chi1, _ = ba.edge_chi2()
+    Po, Xo, _, chio = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], DELTA, 5)
+    assert np.array_equal(_bits(P1), _bits(Po)) and np.array_equal(_bits(chi1), _bits(chio))
+    flags = np.where(chi1 > 5.991, 0, capi.BA_EDGE_ACTIVE).astype(np.uint8)     # outliers to level 1, robust kernel off everywhere
+    ba.set_edge_flags(flags)
+    st2 = ba.optimize(10)                                # tile solver, from the window kernel's state
+    P2, X2 = ba.result()
+    chi2, _ = ba.edge_chi2()
+    assert np.array_equal(_bits(chi2[flags == 0]), _bits(chi1[flags == 0]))       # level-1 edges keep the chi2 of their last evaluation
+    keep = flags != 0
+    ek = e[keep]
+    Pr, Xr, str_, _ = oracle.ba_optimize(Po, pr["fixed"], Xo, ek, pr["intrinsics"], 0.0, 10, continue_graph=True)
+    assert st2["trials"] == str_["trials"]
+    assert np.abs(P2 - Pr).max() < 1e-6 and np.abs(X2 - Xr).max() < 1e-6          # the tile solver's own summation order: tolerance parity
+    ba.set_edge_flags(None)
+    ba.optimize(3)                                       # window kernel again, from the tile solver's state
+    P3, X3 = ba.result()
+    Pc, Xc, _, _ = oracle.ba_optimize(P2, pr["fixed"], X2, e, pr["intrinsics"], DELTA, 3, continue_graph=True)
+    assert np.array_equal(_bits(P3), _bits(Pc)) and np.array_equal(_bits(X3), _bits(Xc))
+    ba.close()
