@@ -167,6 +167,68 @@ def lba(device, iters=10, repeats=40, cpu_seconds=4.0):
     return out
 
 
+def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
+    """BASELINE config 4 with more agents than GPUs: the LocalBundleAdjustment windows of K agents solved side by side by ONE launch of the
+    sequential-order kernel (dvm_ba_optimize_windows; a workgroup per window, g2o's summation order -> bit-identical to the oracle), next to
+    the same K windows solved one after the other through the tile solver's handle (the `lba` leg's call).  K different windows: every
+    agent has its own map (different seeds), 30 keyframes / 20 free / 3 000 landmarks / ~15 000 observations each."""
+    from dvm_slam_amd import capi, synth
+    delta = float(np.sqrt(np.float32(5.991)))
+    kmax = max(Ks)
+    wins = []
+    for a in range(kmax):
+        pr = synth.ba_problem(n_kf=30, n_pts=3000, k_obs=5, seed=0x1BA + a, radius=12.0)
+        pr["fixed"][:10] = 1
+        wins.append(dict(poses=pr["poses"], fixed=pr["fixed"], points=pr["points"], edges=capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"]),
+                         intrinsics=pr["intrinsics"], huber_delta=delta, iterations=iters))
+    capi.ba_optimize_windows(wins[:1], device)         # kernel load
+    out = {"problem": {"keyframes": 30, "fixed_keyframes": 10, "landmarks": 3000, "observations_window_0": len(wins[0]["edges"]), "iterations_per_call": iters,
+                       "huber_delta": delta}, "unit": "LM iterations/s, summed over the K windows of a call (host arrays in, results out)", "by_K": {},
+           "reference": "Optimizer.cc:1030-1387 per window; one window per agent (orb_slam3_wrapper.cpp runs one System per agent)"}
+    res = None
+    for K in Ks:
+        ts, its = [], 0
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            res = capi.ba_optimize_windows(wins[:K], device)
+            ts.append(time.perf_counter() - t0)
+            its = sum(r["stats"]["iterations"] for r in res)
+        best = float(np.median(ts))
+        out["by_K"][str(K)] = {"value": its / best, "ms_per_call": best * 1e3, "ms_per_window": best * 1e3 / K, "iterations": its,
+                               "host_setup_ms_per_window": res[0]["stats"]["ms_structure"]}
+    # the same K windows through the tile solver, one handle, one after the other (what K agents queueing on one GPU get today)
+    ba = capi.BundleAdjuster(device)
+    t_seq, its_seq = [], 0
+    for a in range(min(kmax, 8)):
+        w = wins[a]
+        t0 = time.perf_counter()
+        ba.set_problem(w["poses"], w["fixed"], w["points"], w["edges"], w["intrinsics"], delta)
+        st = ba.optimize(iters)
+        ba.result(); ba.edge_chi2()
+        t_seq.append(time.perf_counter() - t0); its_seq += st["iterations"]
+    ba.close()
+    out["tile_solver_sequential"] = {"value": its_seq / sum(t_seq), "ms_per_window": float(np.median(t_seq)) * 1e3, "windows": len(t_seq),
+                                     "note": "dvm_ba_set_problem + dvm_ba_optimize + get_result + edge_chi2 per window, one after the other"}
+    if cpu_windows > 0:
+        from oracle import pyoracle as po   # cpu_baseline leg + parity of THIS run
+        tc, itc = [], 0
+        ident = True
+        for a in range(min(cpu_windows, kmax)):
+            w = wins[a]
+            t0 = time.perf_counter()
+            p, x, so, chio = po.ba_optimize(w["poses"], w["fixed"], w["points"], w["edges"], w["intrinsics"], delta, iters)
+            tc.append(time.perf_counter() - t0); itc += so["iterations"]
+            g = res[a]
+            ident = ident and bool(np.array_equal(g["poses"].view(np.int64), p.view(np.int64)) and np.array_equal(g["points"].view(np.int64), x.view(np.int64)) and
+                                   np.array_equal(g["edge_chi2"].view(np.int64), chio.view(np.int64)) and list(g["stats"]["trials"]) == list(so["trials"]))
+        out["cpu_baseline"] = {"value": itc / sum(tc), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"{len(tc)} of the windows, optimize({iters}) each, CPU oracle, {sum(tc):.1f} s"}
+        out["parity_vs_cpu"] = {"windows_checked": len(tc), "bit_identical": ident}
+        if not ident:
+            raise RuntimeError("lba_batch leg: a window's result is not bit-identical to the CPU oracle")
+    return out
+
+
 def ba_cold(device, iters=10, runs=5, idle_s=2.0):
     """The 500-keyframe global BA on a GPU that has been idle: the clocks have dropped, the first kernels pay the ramp."""
     from dvm_slam_amd import capi, synth

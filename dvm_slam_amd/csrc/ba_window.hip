@@ -31,6 +31,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -44,11 +46,19 @@ namespace dvm {
 
 constexpr int kWinThreads = 512;
 constexpr int kWinMaxFree = 30;          // 6 * 30 = 180 rows: packed lower triangle 130 320 B of LDS
-constexpr int kWinLdsMisc = 2 * 180 + 64 + 8 * 128;   // doubles besides S: rhs / diag, control words, the waves' sequential-sum buffers
+constexpr int kRowB = 16, kRowA = 12, kRowW = 18, kRowD = 24, kRowH = 12;   // doubles per row of the per-edge / per-landmark arrays below
+constexpr int kWinIntCap = 6 * kWinThreads;   // ints of one chunk's index block (six per thread in flight)
 
-// device view of one window: pointers into the call's staging block
+// device view of one window: pointers into the call's staging block.
+// Per-edge rows live in the order their consumer walks them, so that a chunk of consecutive rows is one coalesced copy into LDS:
+//   rowB [E][16]  edge order            B (2x6), w, wr0, wr1         -> Hpp / bp chains of the cameras (edge order)
+//   rowA [E][12]  landmark-major (lpos) A (2x3), w, wr0, wr1         -> Hll / bl of a landmark: its rows are contiguous
+//   rowW [F][18]  landmark-major over the F edges of FREE cameras (fpos): W = w B^T A
+// (W Dinv and W Dinv bl of a trial never reach global memory: the Schur pass forms them in LDS from the staged W rows.)
 struct BaWin {
-  int32_t P, L, E, nfree, nact, nblk, iterations, pad0;
+  int32_t P, L, E, F, nfree, nact, nblk, iterations;
+  int32_t C, C2, n_sc, n_hc;          // rows per Schur chunk / per Hessian chunk, number of chunks
+  int32_t stage_doubles, pad0;        // LDS doubles of the staging area this window needs
   double fx, fy, cx, cy, delta;
   double *poses, *poses_t;            // [P][7] accepted / trial state
   double *pts, *pts_t;                // [L][3]
@@ -57,15 +67,23 @@ struct BaWin {
   const int32_t *free_pose, *act_pt;  // [nfree], [nact]
   const int32_t *e_pose, *e_point;    // [E]
   const double *e_obs, *e_info;       // [E][2], [E]
-  double *e_A, *e_B, *e_w, *e_W, *e_WD, *e_Wdb;   // [E][6], [E][12], [E][4] (w, wr0, wr1, -), [E][18], [E][18], [E][6]
-  double *e_chi2, *e_rho;             // [E] chi2 / rho(chi2) of the last evaluation
+  const int32_t *lpos, *fpos;         // [E] row of the edge in landmark-major order over all edges / over free-camera edges (-1)
+  const int32_t *pt_start, *f_start;  // [nact + 1] a landmark's rows in rowA / in rowW
+  const int32_t *f_cam;               // [F] free camera index of the row
+  double *rowB, *rowA, *rowW;
+  double *e_chi2, *e_rho;             // [E] chi2 / rho(chi2) of the last evaluation, edge order
   uint8_t* e_depth;                   // [E] isDepthPositive() at the final state
-  const int32_t *cam_start, *cam_edges;     // free camera -> its edges, ascending edge index            [nfree + 1], [..]
-  const int32_t *camp_edges;                // the same lists ordered by (landmark, edge): the Schur loop's order
-  const int32_t *pt_start, *pt_edges;       // active landmark -> its edges, ascending                   [nact + 1], [..]
-  const int32_t *blk_i1, *blk_i2, *blk_start, *pair_k1, *pair_k2;   // non-zero lower blocks of the reduced system and their pair lists
-  double *Hpp, *bp, *Hll, *bl, *Dinv, *db, *x, *terms;   // [nfree][36], [6 nfree], [nact][9], [3 nact], [nact][9], [3 nact], [6 nfree + 3 nact] x 2
+  // Hessian chunks (edge order, C2 rows each), one fixed-size int block per chunk:
+  // [per camera the range of its rows in the list (nfree + 1) | the chunk's free-camera row slots, camera-major (C2)]
+  const int32_t *hc_ints;             // [n_hc][nfree + 1 + C2]
+  // Schur chunks (whole landmarks, <= C free rows, <= C landmarks): descriptor {first row, rows, int offset, int length, runs, pairs, first
+  // landmark, landmarks}; int block = [per camera the range of its rows (nfree + 1) | row slots camera-major (rows) | landmark of every row,
+  // relative (rows) | runs: i1 | i2 << 8 | first pair << 16, + sentinel | pairs: slot1 | slot2 << 16, sorted by block]
+  const int32_t *sc_desc, *sc_ints;   // [n_sc][8]
+  const int32_t *blk_ij;              // [nblk] i1 | i2 << 8
+  double *Hpp, *bp, *HB, *DD, *x, *terms;   // [nfree][36], [6 nfree], [nact][12] = Hll (9) bl (3), [nact][12] = Dinv (9) Dinv bl (3), [6 nfree + 3 nact] x 2
   dvm_ba_stats* stats;
+  unsigned long long* prof;           // [16] shader-clock cycles per phase, accumulated by thread 0 (DVM_BA_WINDOW_PROF=1), or null
 };
 
 // ------------------------------------------------------------------------------------------------ small algebra (the oracle's sequences)
@@ -175,15 +193,30 @@ __device__ double wave_sequential_sum(const double* __restrict__ v, int n, doubl
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // 16 values at a time into registers, the next 16 requested before the current 16 are added: left to itself the compiler waits
+    // for every ds_read right in front of its add (~26 cycles per value instead of the add's own 8)
+    double t[2][16];
 #pragma unroll
-    for (int j = 0; j < 64; j++) s += b[j];
+    for (int j = 0; j < 16; j++) t[0][j] = b[j];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g < 3) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) t[(g + 1) & 1][j] = b[16 * (g + 1) + j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; j++) s += t[g & 1][j];
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   return s;
 }
 
 // ------------------------------------------------------------------------------------------------ edge pass
 // JAC = false: computeActiveErrors -- chi2 and rho of every edge at the state (poses, pts).  JAC = true: additionally linearizeOplus +
-// the edge's part of constructQuadraticForm: A (2x3), B (2x6), w = rho' Omega, wr = -Omega e rho', W = w B^T A.
+// the edge's part of constructQuadraticForm: A (2x3), B (2x6), w = rho' Omega, wr = -Omega e rho', W = w B^T A, each into the row its
+// consumer will stream.
 template <bool JAC>
 __device__ void win_edge_pass(const BaWin& W, const double* __restrict__ poses, const double* __restrict__ pts) {
   for (int k = threadIdx.x; k < W.E; k += kWinThreads) {
@@ -217,62 +250,140 @@ __device__ void win_edge_pass(const BaWin& W, const double* __restrict__ poses, 
       for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
     const double w = r1 * info;
     const double wr0 = -info * e0 * r1, wr1 = -info * e1 * r1;
-    double* oA = W.e_A + 6 * (size_t)k;
-    double* oB = W.e_B + 12 * (size_t)k;
-    double* oW = W.e_W + 18 * (size_t)k;
-#pragma unroll
-    for (int i = 0; i < 6; i++) oA[i] = A[i];
+    double* oB = W.rowB + kRowB * (size_t)k;
+    double* oA = W.rowA + kRowA * (size_t)W.lpos[k];
 #pragma unroll
     for (int i = 0; i < 12; i++) oB[i] = B[i];
-    W.e_w[4 * (size_t)k] = w; W.e_w[4 * (size_t)k + 1] = wr0; W.e_w[4 * (size_t)k + 2] = wr1;
-    if (W.pidx[p] >= 0) {
+    oB[12] = w; oB[13] = wr0; oB[14] = wr1; oB[15] = 1.0;       // (slot 15: the "weight" of a bp chain step, see win_accumulate_cameras)
+#pragma unroll
+    for (int i = 0; i < 6; i++) oA[i] = A[i];
+    oA[6] = w; oA[7] = wr0; oA[8] = wr1;
+    const int fp = W.fpos[k];
+    if (fp >= 0) {
+      double* oW = W.rowW + kRowW * (size_t)fp;
 #pragma unroll
       for (int a = 0; a < 6; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) oW[3 * a + b] = w * (B[a] * A[b] + B[6 + a] * A[3 + b]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 18; i++) oW[i] = 0.0;
     }
   }
 }
 
-// Hpp / bp of the free cameras and Hll / bl of the active landmarks: every entry is one lane's chain over the vertex's edges in
-// edge order.  Camera entries: 21 lower (a, b) pairs + 6 of bp = 27 lanes per camera; landmark: one thread does its 6 + 3 chains.
-__device__ void win_accumulate(const BaWin& W) {
-  const int ncam_lanes = 27 * W.nfree;
-  for (int t = threadIdx.x; t < ncam_lanes; t += kWinThreads) {
-    const int i = t / 27, e = t - 27 * i;
+// A chunk of a streamed pass travels global memory -> registers -> LDS: every thread fetches its share of the NEXT chunk (fixed
+// stride, a handful of values) before the current one is consumed, so the round trip to L2 runs under the chain steps instead of in
+// front of them (a copy loop per chunk cost ~6 us of dependent latencies: descriptor -> rows -> LDS -> barrier).
+// barrier for data exchanged through LDS only: __syncthreads() also waits for every global access in flight (s_waitcnt vmcnt(0)), i.e.
+// for the NEXT chunk's rows that have just been requested -- which is the round trip the register pipeline exists to hide
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int ND, int NI>
+struct ChunkRegs {
+  double d[ND];
+  int32_t i[NI];
+  __device__ __forceinline__ void load_d(int slot0, const double* __restrict__ src, int n) {     // values slot0, slot0 + 1, ... of this thread
+#pragma unroll
+    for (int u = 0; u < ND; u++) if (u >= slot0) { const int idx = threadIdx.x + (u - slot0) * kWinThreads; d[u] = idx < n ? src[idx] : 0.0; }
+  }
+  __device__ __forceinline__ void load_i(const int32_t* __restrict__ src, int n) {
+#pragma unroll
+    for (int u = 0; u < NI; u++) { const int idx = threadIdx.x + u * kWinThreads; i[u] = idx < n ? src[idx] : 0; }
+  }
+};
+template <int N0, int N1, int ND, int NI>
+__device__ __forceinline__ void store_d(const ChunkRegs<ND, NI>& r, double* __restrict__ dst, int n) {   // registers N0 .. N1 - 1 -> dst
+#pragma unroll
+  for (int u = N0; u < N1; u++) { const int idx = threadIdx.x + (u - N0) * kWinThreads; if (idx < n) dst[idx] = r.d[u]; }
+}
+template <int ND, int NI>
+__device__ __forceinline__ void store_i(const ChunkRegs<ND, NI>& r, int32_t* __restrict__ dst, int n) {
+#pragma unroll
+  for (int u = 0; u < NI; u++) { const int idx = threadIdx.x + u * kWinThreads; if (idx < n) dst[idx] = r.i[u]; }
+}
+
+// Hpp / bp of the free cameras: every entry is ONE lane's chain over the camera's edges in edge order (BaseBinaryEdge::
+// constructQuadraticForm is called edge by edge).  The B rows stream through LDS C2 edges at a time, the chunk's rows listed per
+// camera (host tables), so that a chain step is a few LDS reads.  21 lower (a, b) entries + 6 of bp = 27 lanes per camera, at most two
+// (camera, entry) pairs per thread (27 * 30 <= 2 * 512).
+__device__ void win_accumulate_cameras(const BaWin& W, double* stage) {
+  const int tid = threadIdx.x, nlanes = 27 * W.nfree;
+  double* rows = stage;                                               // [C2][16]
+  int32_t* ints = reinterpret_cast<int32_t*>(rows + (size_t)W.C2 * kRowB);   // [nfree + 1] ranges | [<= C2] row slots, camera-major
+  double acc[2] = {0.0, 0.0};
+  int cam[2], ea[2], eb[2];
+  // one form for both kinds of chain: acc += row[ow] * (row[o1] * row[o2] + row[o3] * row[o4]) -- an Hpp entry (a, b): w * (B_a B_b + B_6+a B_6+b);
+  // a bp entry a: 1.0 * (B_a wr0 + B_6+a wr1), and 1.0 * x is x
+  int o1[2], o2[2], o3[2], o4[2], ow[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int t = tid + u * kWinThreads;
+    cam[u] = t < nlanes ? t / 27 : -1;
+    const int e = t - 27 * (t / 27);
     int a, b;
     if (e < 21) { a = 0; int r = e; while (r > a) { r -= a + 1; a++; } b = r; }   // e = a (a + 1) / 2 + b, b <= a
-    else { a = e - 21; b = 0; }
-    const int s0 = W.cam_start[i], s1 = W.cam_start[i + 1];
-    double acc = 0.0;
-    if (e < 21) {
-      for (int q = s0; q < s1; q++) {
-        const int k = W.cam_edges[q];
-        const double* B = W.e_B + 12 * (size_t)k;
-        const double w = W.e_w[4 * (size_t)k];
-        acc += w * (B[a] * B[b] + B[6 + a] * B[6 + b]);
-      }
-      W.Hpp[36 * (size_t)i + 6 * a + b] = acc;
-      W.Hpp[36 * (size_t)i + 6 * b + a] = acc;       // (a product commutes: the mirrored entry has the same bits)
-    } else {
-      for (int q = s0; q < s1; q++) {
-        const int k = W.cam_edges[q];
-        const double* B = W.e_B + 12 * (size_t)k;
-        const double wr0 = W.e_w[4 * (size_t)k + 1], wr1 = W.e_w[4 * (size_t)k + 2];
-        acc += B[a] * wr0 + B[6 + a] * wr1;
-      }
-      W.bp[6 * (size_t)i + a] = acc;
-    }
+    else { a = e - 21; b = -1; }                                                   // bp(a)
+    ea[u] = a; eb[u] = b;
+    o1[u] = a; o3[u] = 6 + a;
+    if (b >= 0) { o2[u] = b; o4[u] = 6 + b; ow[u] = 12; } else { o2[u] = 13; o4[u] = 14; ow[u] = 15; }
   }
+  if (W.n_hc > 0) {
+    // chunk c = edges [c C2, c C2 + C2) and the int block at c * (nfree + 1 + C2): nothing to look up before its loads can go out
+    const int istride = W.nfree + 1 + W.C2;
+    ChunkRegs<8, 1> pre;
+    pre.load_d(0, W.rowB, min(W.C2, W.E) * kRowB);
+    pre.load_i(W.hc_ints, istride);
+    for (int c = 0; c < W.n_hc; c++) {
+      const int nr = min(W.C2, W.E - c * W.C2);
+      lds_barrier();                                                  // the previous chunk has been consumed
+      store_d<0, 8>(pre, rows, nr * kRowB);
+      store_i(pre, ints, istride);
+      if (c + 1 < W.n_hc) {
+        const int k1 = (c + 1) * W.C2;
+        pre.load_d(0, W.rowB + kRowB * (size_t)k1, min(W.C2, W.E - k1) * kRowB);
+        pre.load_i(W.hc_ints + (size_t)(c + 1) * istride, istride);
+      }
+      lds_barrier();
+      const int32_t* range = ints;
+      const int32_t* list = ints + W.nfree + 1;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (cam[u] < 0) continue;
+        double sacc = acc[u];
+        const int q1 = range[cam[u] + 1];
+        // four steps at a time: their operands are fetched together, then the four dependent additions; a step beyond the camera's
+        // range adds +0.0, which changes nothing (the accumulator is never -0.0)
+        for (int q = range[cam[u]]; q < q1; q += 4) {
+          double term[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const bool in = q + j < q1;
+            const double* B = rows + kRowB * (in ? list[q + j] : 0);
+            const double v = B[ow[u]] * (B[o1[u]] * B[o2[u]] + B[o3[u]] * B[o4[u]]);
+            term[j] = in ? v : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) sacc += term[j];
+        }
+        acc[u] = sacc;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    if (cam[u] < 0) continue;
+    const int i = cam[u], a = ea[u], b = eb[u];
+    if (b >= 0) { W.Hpp[36 * (size_t)i + 6 * a + b] = acc[u]; W.Hpp[36 * (size_t)i + 6 * b + a] = acc[u]; }   // (a product commutes: the mirrored entry has the same bits)
+    else W.bp[6 * (size_t)i + a] = acc[u];
+  }
+}
+
+// Hll / bl of the active landmarks: a thread per landmark, its rows (edge order) are contiguous in rowA
+__device__ void win_accumulate_landmarks(const BaWin& W) {
   for (int li = threadIdx.x; li < W.nact; li += kWinThreads) {
     double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
-      const int k = W.pt_edges[q];
-      const double* A = W.e_A + 6 * (size_t)k;
-      const double w = W.e_w[4 * (size_t)k], wr0 = W.e_w[4 * (size_t)k + 1], wr1 = W.e_w[4 * (size_t)k + 2];
+      const double* A = W.rowA + kRowA * (size_t)q;
+      const double w = A[6], wr0 = A[7], wr1 = A[8];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         g[a] += A[a] * wr0 + A[3 + a] * wr1;
@@ -280,15 +391,174 @@ __device__ void win_accumulate(const BaWin& W) {
         for (int b = 0; b < 3; b++) h[3 * a + b] += w * (A[a] * A[b] + A[3 + a] * A[3 + b]);
       }
     }
+    double* o = W.HB + kRowH * (size_t)li;
 #pragma unroll
-    for (int i = 0; i < 9; i++) W.Hll[9 * (size_t)li + i] = h[i];
+    for (int i = 0; i < 9; i++) o[i] = h[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) W.bl[3 * (size_t)li + i] = g[i];
+    for (int i = 0; i < 3; i++) o[9 + i] = g[i];
   }
 }
 
 // packed lower triangle: row i starts at i (i + 1) / 2
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// solve(lambda), first half (block_solver.hpp:381-439): Dinv = (Hll + lambda I)^-1 per landmark, then landmark by landmark, per landmark
+// every (edge, edge) pair of free cameras: Hschur(i1, i2) -= (W1 Dinv) W2^T, bschur(i1) -= W1 Dinv bl.  S and rhs live in LDS and start
+// as Hpp + lambda I / bp.  The landmarks stream through LDS in chunks of whole landmarks: their Hll | bl and their W rows arrive by the
+// register pipeline above, Dinv / Dinv bl are formed in place (and stored for the back substitution), W Dinv / W Dinv bl are formed
+// in LDS -- they never exist in global memory --, and the chunk's pairs, listed by block, are applied: the 36 entries of a block's run
+// are 36 work items; a block appears in ONE run per chunk and the chunks follow each other behind barriers, so every entry of S
+// receives its subtractions in landmark order -- the order of g2o's loop.  rhs(6 i + a) likewise walks camera i's rows of the chunk.
+__device__ void win_schur(const BaWin& W, double* S, double* rhs, double* stage, double lambda) {
+  const int tid = threadIdx.x, n = 6 * W.nfree;
+  double* __restrict__ Wb = stage;                                    // [C][18]
+  double* __restrict__ Db = Wb + (size_t)W.C * kRowW;                 // [C][24]
+  double* __restrict__ Hl = Db + (size_t)W.C * kRowD;                 // [C][12]  Hll | bl  ->  Dinv | Dinv bl
+  int32_t* ints = reinterpret_cast<int32_t*>(Hl + (size_t)W.C * kRowH);
+  for (int i = tid; i < n * (n + 1) / 2; i += kWinThreads) S[i] = 0.0;
+  __syncthreads();
+  for (int t = tid; t < 21 * W.nfree; t += kWinThreads) {
+    const int i = t / 21, e = t - 21 * i;
+    int a = 0, r = e; while (r > a) { r -= a + 1; a++; }
+    const int b = r;
+    S[tri(6 * i + a, 6 * i + b)] = W.Hpp[36 * (size_t)i + 6 * a + b] + (a == b ? lambda : 0.0);
+  }
+  for (int t = tid; t < n; t += kWinThreads) rhs[t] = W.bp[t];
+  if (W.n_sc == 0) { __syncthreads(); return; }
+  struct Desc { int r0, nr, ioff, ni, nu, np, la, nlm; };
+  const Desc* descs = reinterpret_cast<const Desc*>(W.sc_desc);
+  ChunkRegs<8, 6> pre;               // W rows: C * 18 <= 5 per thread; Hll | bl: C * 12 <= 3 per thread; ints <= 6 per thread
+  Desc dsc = descs[0], nxt = descs[W.n_sc > 1 ? 1 : 0];      // the descriptor of chunk c + 1 is in registers a chunk before its loads go out
+  pre.load_d(0, W.rowW + kRowW * (size_t)dsc.r0, dsc.nr * kRowW);
+  pre.load_d(5, W.HB + kRowH * (size_t)dsc.la, dsc.nlm * kRowH);
+  pre.load_i(W.sc_ints + dsc.ioff, dsc.ni);
+  unsigned long long tp = __builtin_amdgcn_s_memtime();
+  auto lap2 = [&](int slot) { if (W.prof && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); W.prof[slot] += t - tp; tp = t; } };
+  for (int c = 0; c < W.n_sc; c++) {
+    const Desc cur = dsc;
+    lds_barrier();
+    lap2(11);
+    store_d<0, 5>(pre, Wb, cur.nr * kRowW);
+    store_d<5, 8>(pre, Hl, cur.nlm * kRowH);
+    store_i(pre, ints, cur.ni);
+    if (c + 1 < W.n_sc) {
+      dsc = nxt;
+      pre.load_d(0, W.rowW + kRowW * (size_t)dsc.r0, dsc.nr * kRowW);
+      pre.load_d(5, W.HB + kRowH * (size_t)dsc.la, dsc.nlm * kRowH);
+      pre.load_i(W.sc_ints + dsc.ioff, dsc.ni);
+      if (c + 2 < W.n_sc) nxt = descs[c + 2];
+    }
+    lds_barrier();
+    lap2(12);
+    const int32_t* crange = ints;
+    const int32_t* crows = crange + W.nfree + 1;
+    const int32_t* rowlm = crows + cur.nr;
+    const int32_t* runs = rowlm + cur.nr;
+    const int32_t* pairs = runs + cur.nu;
+    if (tid < cur.nlm) {             // Dinv, Dinv bl of the chunk's landmarks, in place
+      double* h = Hl + kRowH * tid;
+      double D[9], Di[9], d3[3];
+#pragma unroll
+      for (int i = 0; i < 9; i++) D[i] = h[i];
+      const double g[3] = {h[9], h[10], h[11]};
+      D[0] += lambda; D[4] += lambda; D[8] += lambda;
+      w_inv3(D, Di);
+      w_mat3_vec(Di, g, d3);
+      double* o = W.DD + kRowH * (size_t)(cur.la + tid);
+#pragma unroll
+      for (int i = 0; i < 9; i++) { h[i] = Di[i]; o[i] = Di[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; i++) { h[9 + i] = d3[i]; o[9 + i] = d3[i]; }
+    }
+    lds_barrier();
+    lap2(13);
+    // W Dinv (18) and W Dinv bl (6) of every row: three entries of a thread at a time, operands first (each alone is two dependent LDS
+    // round trips for five flops)
+    for (int e0 = tid; e0 < cur.nr * kRowD; e0 += 3 * kWinThreads) {
+      double w0[3], w1[3], w2[3], h0[3], h1[3], h2[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int e = min(e0 + u * kWinThreads, cur.nr * kRowD - 1);
+        const int row = e / kRowD, j = e - kRowD * row;
+        const double* h = Hl + kRowH * rowlm[row];
+        const int a = j < 18 ? j / 3 : j - 18;
+        const double* W1 = Wb + kRowW * row + 3 * a;
+        w0[u] = W1[0]; w1[u] = W1[1]; w2[u] = W1[2];
+        if (j < 18) { const int b = j - 3 * a; h0[u] = h[b]; h1[u] = h[3 + b]; h2[u] = h[6 + b]; }
+        else { h0[u] = h[9]; h1[u] = h[10]; h2[u] = h[11]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int e = e0 + u * kWinThreads;
+        if (e < cur.nr * kRowD) Db[e] = w0[u] * h0[u] + w1[u] * h1[u] + w2[u] * h2[u];
+      }
+    }
+    lds_barrier();
+    lap2(14);
+    for (int t = tid; t < n; t += kWinThreads) {
+      const int i = t / 6, a = t - 6 * i;
+      double sacc = rhs[t];
+      const int q1 = crange[i + 1];
+      for (int q = crange[i]; q < q1; q += 4) {                       // (four steps' operands together; a step beyond the range subtracts +0.0)
+        double term[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const bool in = q + j < q1; const double v = Db[kRowD * (in ? crows[q + j] : 0) + 18 + a]; term[j] = in ? v : 0.0; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) sacc -= term[j];
+      }
+      rhs[t] = sacc;
+    }
+    lap2(3);
+    if (6 * (cur.nu - 1) >= kWinThreads / 2) {
+      // many short runs (a window of many cameras): a work item = row a of a block's run -- its three W Dinv values meet all six
+      // columns of W2 (b <= a on a diagonal block)
+      for (int t = tid; t < 6 * (cur.nu - 1); t += kWinThreads) {
+        const int ru = t / 6, a = t - 6 * ru;
+        const int rw = runs[ru], i1 = rw & 255, i2 = (rw >> 8) & 255, q0 = rw >> 16, q1 = runs[ru + 1] >> 16;
+        const int nb = i1 == i2 ? a + 1 : 6;
+        double* Srow = S + tri(6 * i1 + a, 6 * i2);
+        double sv[6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) sv[b] = b < nb ? Srow[b] : 0.0;
+        for (int q = q0; q < q1; q++) {
+          const int pr = pairs[q];
+          const double* WD = Db + kRowD * (pr & 0xffff) + 3 * a;
+          const double* W2 = Wb + kRowW * (pr >> 16);
+          const double d0 = WD[0], d1 = WD[1], d2 = WD[2];
+#pragma unroll
+          for (int b = 0; b < 6; b++) sv[b] -= d0 * W2[3 * b] + d1 * W2[3 * b + 1] + d2 * W2[3 * b + 2];
+        }
+#pragma unroll
+        for (int b = 0; b < 6; b++) if (b < nb) Srow[b] = sv[b];
+      }
+    } else {
+      // few long runs (two or three cameras): a work item = one entry (a, b) of a block's run, its pairs two at a time
+      for (int t = tid; t < 36 * (cur.nu - 1); t += kWinThreads) {
+        const int ru = t / 36, ab = t - 36 * ru, a = ab / 6, b = ab - 6 * a;
+        const int rw = runs[ru], i1 = rw & 255, i2 = (rw >> 8) & 255, q0 = rw >> 16, q1 = runs[ru + 1] >> 16;
+        if (i1 == i2 && b > a) continue;
+        const int idx = tri(6 * i1 + a, 6 * i2 + b);
+        double sacc = S[idx];
+        for (int q = q0; q < q1; q += 2) {
+          double term[2];
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const bool in = q + j < q1;
+            const int pr = in ? pairs[q + j] : 0;
+            const double* WD = Db + kRowD * (pr & 0xffff) + 3 * a;
+            const double* W2 = Wb + kRowW * (pr >> 16) + 3 * b;
+            const double v = WD[0] * W2[0] + WD[1] * W2[1] + WD[2] * W2[2];
+            term[j] = in ? v : 0.0;
+          }
+          sacc -= term[0];
+          sacc -= term[1];
+        }
+        S[idx] = sacc;
+      }
+    }
+  }
+  __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------------ the kernel
 __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop) {
@@ -300,7 +570,8 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
   double* rhs = S + (size_t)n * (n + 1) / 2;        // bschur -> x_p                                          [n]
   double* diag = rhs + n;                           // L_kk                                                   [n]
   double* ctl = diag + n;                           // control words shared by the workgroup                  [64]
-  double* seqbuf = ctl + 64 + 128 * wave;           // this wave's buffer of wave_sequential_sum              [128]
+  double* seqbuf = ctl + 64 + 128 * (wave & 1);     // wave_sequential_sum's buffer (waves 0 and 1 use it)    [2][128]
+  double* stage = ctl + 64 + 256;                   // streaming area of the chunked passes                   [stage_doubles]
   dvm_ba_stats* const st = W.stats;                 // written by thread 0 only
   if (tid == 0) {
     st->iterations = st->total_trials = st->stop_reason = st->pad = 0;
@@ -318,26 +589,36 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
 
   double lambda = -1, ni = 2, currentChi = 0, chi_last = 0;
   int nBad = 0, it_done = 0, trials_total = 0, stop_reason = 0;
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+  auto lap = [&](int slot) {        // phase timing: thread 0 between barriers
+    if (W.prof && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); W.prof[slot] += t - tprev; tprev = t; }
+  };
   for (int it = 0; it < W.iterations; it++) {
     if (tid == 0) ctl[0] = (stop && *stop) ? 1.0 : 0.0;
     __syncthreads();
     if (ctl[0] != 0.0) break;
     // computeActiveErrors + robust chi2 + buildSystem at the accepted state.  (From the second iteration on g2o recomputes the chi2
     // of the state the last accepted trial has just evaluated: same state, same sums, same bits -- only the Jacobians are new.)
+    lap(15);
     win_edge_pass<true>(W, poses, pts);
     __syncthreads();
+    lap(0);
     if (it == 0) {
       if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
     }
-    win_accumulate(W);
+    win_accumulate_landmarks(W);
     __syncthreads();
+    lap(1);
+    win_accumulate_cameras(W, stage);
+    __syncthreads();
+    lap(2);
     if (it == 0) {
       currentChi = ctl[1];
       if (tid == 0) st->chi2_initial = currentChi;
       // computeLambdaInit: tau * max |diagonal| over all active vertices (a maximum has no order)
       double mx = 0;
       for (int i = tid; i < n; i += kWinThreads) mx = fmax(mx, fabs(W.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
-      for (int i = tid; i < nl; i += kWinThreads) mx = fmax(mx, fabs(W.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+      for (int i = tid; i < nl; i += kWinThreads) mx = fmax(mx, fabs(W.HB[kRowH * (size_t)(i / 3) + 4 * (i % 3)]));
       for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
       __syncthreads();
       if ((tid & 63) == 0) ctl[8 + wave] = mx;
@@ -352,58 +633,10 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
     int qmax = 0;
     bool stopped = false;
     do {
-      // ---- solve(lambda): damped landmark inverses, W Dinv, W Dinv bl per edge
-      for (int li = tid; li < W.nact; li += kWinThreads) {
-        double D[9], Di[9], d3[3];
-#pragma unroll
-        for (int i = 0; i < 9; i++) D[i] = W.Hll[9 * (size_t)li + i];
-        D[0] += lambda; D[4] += lambda; D[8] += lambda;
-        w_inv3(D, Di);
-        w_mat3_vec(Di, W.bl + 3 * (size_t)li, d3);
-#pragma unroll
-        for (int i = 0; i < 9; i++) W.Dinv[9 * (size_t)li + i] = Di[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) W.db[3 * (size_t)li + i] = d3[i];
-      }
-      for (int i = tid; i < n * (n + 1) / 2; i += kWinThreads) S[i] = 0.0;
-      __syncthreads();
-      for (int k = tid; k < W.E; k += kWinThreads) {
-        if (W.pidx[W.e_pose[k]] < 0) continue;
-        const int li = W.lidx[W.e_point[k]];
-        const double* W1 = W.e_W + 18 * (size_t)k;
-        const double* Di = W.Dinv + 9 * (size_t)li;
-        const double* d3 = W.db + 3 * (size_t)li;
-        double* WD = W.e_WD + 18 * (size_t)k;
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-          for (int b = 0; b < 3; b++) WD[3 * a + b] = W1[3 * a] * Di[b] + W1[3 * a + 1] * Di[3 + b] + W1[3 * a + 2] * Di[6 + b];
-          W.e_Wdb[6 * (size_t)k + a] = W1[3 * a] * d3[0] + W1[3 * a + 1] * d3[1] + W1[3 * a + 2] * d3[2];
-        }
-      }
-      __syncthreads();
-      // bschur(i) = bp(i) - sum over the camera's edges in (landmark, edge) order of W Dinv bl
-      for (int t = tid; t < n; t += kWinThreads) {
-        const int i = t / 6, a = t - 6 * i;
-        double acc = W.bp[t];
-        for (int q = W.cam_start[i]; q < W.cam_start[i + 1]; q++) acc -= W.e_Wdb[6 * (size_t)W.camp_edges[q] + a];
-        rhs[t] = acc;
-      }
-      // Hschur(i1, i2) = [Hpp + lambda I] - sum over the block's pairs in landmark order of (W1 Dinv) W2^T
-      for (int t = tid; t < 36 * W.nblk; t += kWinThreads) {
-        const int blk = t / 36, ab = t - 36 * blk, a = ab / 6, b = ab - 6 * a;
-        const int i1 = W.blk_i1[blk], i2 = W.blk_i2[blk];
-        if (i1 == i2 && b > a) continue;
-        double acc = 0.0;
-        if (i1 == i2) acc = W.Hpp[36 * (size_t)i1 + 6 * a + b] + (a == b ? lambda : 0.0);
-        for (int q = W.blk_start[blk]; q < W.blk_start[blk + 1]; q++) {
-          const double* WD = W.e_WD + 18 * (size_t)W.pair_k1[q] + 3 * a;
-          const double* W2 = W.e_W + 18 * (size_t)W.pair_k2[q] + 3 * b;
-          acc -= WD[0] * W2[0] + WD[1] * W2[1] + WD[2] * W2[2];
-        }
-        S[tri(6 * i1 + a, 6 * i2 + b)] = acc;
-      }
-      __syncthreads();
+      // ---- solve(lambda): Dinv, Schur complement, reduced right-hand side (one streamed pass)
+      lap(3);
+      win_schur(W, S, rhs, stage, lambda);
+      lap(4);
       // ---- Cholesky: entry (i, j) receives its subtractions L(i, k) L(j, k) in ascending k, as the row-wise dot products of the
       // envelope factorisation apply them; L(i, j) = s / L(j, j) by IEEE division, L(j, j) = sqrt(s)
       bool ok = true;
@@ -421,6 +654,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
         }
         __syncthreads();
       }
+      lap(5);
       if (ok) {
         // forward substitution: y(i) = (b(i) - sum_{j < i} L(i, j) y(j)) / L(i, i), the subtractions in ascending j; then backward:
         // x(i) /= L(i, i); x(j) -= L(i, j) x(i) for j < i, i descending.  One wave, its lanes own rows lane, lane + 64, lane + 128.
@@ -442,15 +676,15 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
           }
         }
         __syncthreads();
+        lap(6);
         for (int i = tid; i < n; i += kWinThreads) W.x[i] = rhs[i];
-        // xl = Dinv (bl - W^T xp): per landmark, its edges in order, per edge the six camera components in order
+        // xl = Dinv (bl - W^T xp): per landmark, its free-camera rows in order, per row the six camera components in order
         for (int li = tid; li < W.nact; li += kWinThreads) {
-          double c0 = W.bl[3 * (size_t)li], c1 = W.bl[3 * (size_t)li + 1], c2 = W.bl[3 * (size_t)li + 2];
-          for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
-            const int k = W.pt_edges[q];
-            const int i = W.pidx[W.e_pose[k]];
-            if (i < 0) continue;
-            const double* Wk = W.e_W + 18 * (size_t)k;
+          const double* hb = W.HB + kRowH * (size_t)li;
+          double c0 = hb[9], c1 = hb[10], c2 = hb[11];
+          for (int q = W.f_start[li]; q < W.f_start[li + 1]; q++) {
+            const int i = W.f_cam[q];
+            const double* Wk = W.rowW + kRowW * (size_t)q;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
               const double xa = rhs[6 * i + a];
@@ -459,11 +693,12 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
           }
           const double c[3] = {c0, c1, c2};
           double xl[3];
-          w_mat3_vec(W.Dinv + 9 * (size_t)li, c, xl);
+          w_mat3_vec(W.DD + kRowH * (size_t)li, c, xl);
           W.x[n + 3 * (size_t)li] = xl[0]; W.x[n + 3 * (size_t)li + 1] = xl[1]; W.x[n + 3 * (size_t)li + 2] = xl[2];
         }
       }
       __syncthreads();
+      lap(7);
       // ---- the update is applied and the errors evaluated whether or not the solve succeeded (g2o: x then still holds the last
       // successful solve, optimization_algorithm_levenberg.cpp:107-127); computeScale's terms x_j (lambda x_j + b_j)
       for (int i = tid; i < W.nfree; i += kWinThreads) {
@@ -475,13 +710,16 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
         pts_t[3 * (size_t)l + t % 3] = pts[3 * (size_t)l + t % 3] + W.x[n + t];
       }
       for (int j = tid; j < n; j += kWinThreads) { const double xj = W.x[j]; W.terms[j] = xj * (lambda * xj + W.bp[j]); }
-      for (int j = tid; j < nl; j += kWinThreads) { const double xj = W.x[n + j]; W.terms[n + j] = xj * (lambda * xj + W.bl[j]); }
+      for (int j = tid; j < nl; j += kWinThreads) { const double xj = W.x[n + j]; W.terms[n + j] = xj * (lambda * xj + W.HB[kRowH * (size_t)(j / 3) + 9 + j % 3]); }
       __syncthreads();
+      lap(8);
       win_edge_pass<false>(W, poses_t, pts_t);
       __syncthreads();
+      lap(9);
       if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
       if (wave == 1) { const double c = wave_sequential_sum(W.terms, n + nl, seqbuf); if (tid == 64) ctl[2] = c; }
       __syncthreads();
+      lap(10);
       // ---- the decision, taken by every thread on the same words (optimization_algorithm_levenberg.cpp:113-147)
       tempChi = ok ? ctl[1] : 1.7976931348623157e308;
       rho = currentChi - tempChi;
@@ -545,11 +783,12 @@ using namespace dvm;
 namespace {
 
 // host-side structure of one window: g2o's vertex ordering and incidence lists (sparse_optimizer.cpp:161-185, block_solver.hpp:143-295)
+// and the chunk tables the kernel streams by
 struct WinBuild {
-  int P = 0, L = 0, E = 0, nfree = 0, nact = 0, nblk = 0;
+  int P = 0, L = 0, E = 0, F = 0, nfree = 0, nact = 0, nblk = 0, C = 128, C2 = 256, n_sc = 0, n_hc = 0, stage_doubles = 0;
   std::vector<double> poses;                 // normalised quaternions (SE3Quat's constructor)
-  std::vector<int32_t> pidx, lidx, free_pose, act_pt, e_pose, e_point, cam_start, cam_edges, camp_edges, pt_start, pt_edges;
-  std::vector<int32_t> blk_i1, blk_i2, blk_start, pair_k1, pair_k2;
+  std::vector<int32_t> pidx, lidx, free_pose, act_pt, e_pose, e_point, lpos, fpos, pt_start, f_start, f_cam;
+  std::vector<int32_t> hc_ints, sc_desc, sc_ints, blk_ij;
   std::vector<double> e_obs, e_info;
 };
 
@@ -576,53 +815,99 @@ int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize) {
   for (int p = 0; p < P; p++) if (!w.fixed[p] && pose_used[p]) { b.pidx[p] = b.nfree++; b.free_pose.push_back(p); }
   for (int l = 0; l < L; l++) if (pt_used[l]) { b.lidx[l] = b.nact++; b.act_pt.push_back(l); }
   if (b.nfree > kWinMaxFree) { set_error("dvm_ba_optimize_windows: more than 30 free cameras in one window (use dvm_ba_optimize)"); return DVM_ERR_CAPACITY; }
-  // incidence lists in edge order
-  b.cam_start.assign(b.nfree + 1, 0); b.pt_start.assign(b.nact + 1, 0);
-  for (int k = 0; k < E; k++) {
-    if (b.pidx[b.e_pose[k]] >= 0) b.cam_start[b.pidx[b.e_pose[k]] + 1]++;
-    b.pt_start[b.lidx[b.e_point[k]] + 1]++;
-  }
-  for (int i = 0; i < b.nfree; i++) b.cam_start[i + 1] += b.cam_start[i];
+  if (b.nfree > 24) { b.C = 32; b.C2 = 64; }              // the packed reduced system takes up to 130 KB of the 160: smaller streaming chunks (else 128 / 256)
+  const int nf = b.nfree;
+  // landmark-major order of the edges (a landmark's edges in input order): rowA's order; its free-camera subsequence: rowW's order
+  b.pt_start.assign(b.nact + 1, 0);
+  for (int k = 0; k < E; k++) b.pt_start[b.lidx[b.e_point[k]] + 1]++;
   for (int i = 0; i < b.nact; i++) b.pt_start[i + 1] += b.pt_start[i];
-  b.cam_edges.resize(b.cam_start[b.nfree]); b.pt_edges.resize(b.pt_start[b.nact]);
+  std::vector<int32_t> pt_edges(E);
+  b.lpos.resize(E);
   {
-    std::vector<int32_t> cc(b.cam_start.begin(), b.cam_start.end() - 1), pc(b.pt_start.begin(), b.pt_start.end() - 1);
-    for (int k = 0; k < E; k++) {
-      const int i = b.pidx[b.e_pose[k]];
-      if (i >= 0) b.cam_edges[cc[i]++] = k;
-      b.pt_edges[pc[b.lidx[b.e_point[k]]]++] = k;
-    }
+    std::vector<int32_t> pc(b.pt_start.begin(), b.pt_start.end() - 1);
+    for (int k = 0; k < E; k++) { const int q = pc[b.lidx[b.e_point[k]]]++; pt_edges[q] = k; b.lpos[k] = q; }
   }
-  // the Schur loop's order (block_solver.hpp:381-439): landmark by landmark, a landmark's edges in order, per edge the edges again.
-  // camp_edges: a camera's edges as that loop meets them; pairs: per non-zero lower block (i1 >= i2) its (k1, k2) in that order.
-  b.camp_edges.resize(b.cam_edges.size());
-  std::vector<int32_t> blk_of((size_t)b.nfree * b.nfree, -1);
-  std::vector<std::vector<int32_t>> pairs;
-  {
-    std::vector<int32_t> cc(b.cam_start.begin(), b.cam_start.end() - 1);
-    for (int li = 0; li < b.nact; li++) {
-      for (int q1 = b.pt_start[li]; q1 < b.pt_start[li + 1]; q1++) {
-        const int k1 = b.pt_edges[q1], i1 = b.pidx[b.e_pose[k1]];
-        if (i1 < 0) continue;
-        b.camp_edges[cc[i1]++] = k1;
-        for (int q2 = b.pt_start[li]; q2 < b.pt_start[li + 1]; q2++) {
-          const int k2 = b.pt_edges[q2], i2 = b.pidx[b.e_pose[k2]];
-          if (i2 < 0 || i2 > i1) continue;
-          if (i2 == i1 && k2 != k1) continue;
-          int32_t& id = blk_of[(size_t)i1 * b.nfree + i2];
-          if (id < 0) { id = (int32_t)pairs.size(); pairs.emplace_back(); b.blk_i1.push_back(i1); b.blk_i2.push_back(i2); }
-          pairs[id].push_back(k1); pairs[id].push_back(k2);
+  b.fpos.assign(E, -1); b.f_start.assign(b.nact + 1, 0);
+  std::vector<int32_t> f_edge;
+  int maxdeg = 0;
+  for (int li = 0; li < b.nact; li++) {
+    for (int q = b.pt_start[li]; q < b.pt_start[li + 1]; q++) {
+      const int k = pt_edges[q], i = b.pidx[b.e_pose[k]];
+      if (i < 0) continue;
+      b.fpos[k] = (int32_t)f_edge.size(); f_edge.push_back(k); b.f_cam.push_back(i);
+    }
+    b.f_start[li + 1] = (int32_t)f_edge.size();
+    maxdeg = std::max(maxdeg, b.f_start[li + 1] - b.f_start[li]);
+  }
+  b.F = (int)f_edge.size();
+  if (maxdeg > b.C) { set_error("dvm_ba_optimize_windows: a landmark with more free-camera observations than a streaming chunk holds (duplicate observations?)"); return DVM_ERR_CAPACITY; }
+  // Hessian chunks: C2 consecutive edges; the free-camera ones among them listed per camera (ascending edge = the camera's own order)
+  b.n_hc = nf ? (E + b.C2 - 1) / b.C2 : 0;
+  b.hc_ints.assign((size_t)b.n_hc * (nf + 1 + b.C2), 0);
+  for (int c = 0; c < b.n_hc; c++) {
+    const int k0 = c * b.C2, k1 = std::min(E, k0 + b.C2);
+    int32_t* rg = &b.hc_ints[(size_t)c * (nf + 1 + b.C2)];       // [range (nf + 1) | row slots, camera-major (<= C2)]
+    for (int k = k0; k < k1; k++) { const int i = b.pidx[b.e_pose[k]]; if (i >= 0) rg[i + 1]++; }
+    for (int i = 0; i < nf; i++) rg[i + 1] += rg[i];
+    std::vector<int32_t> fill(rg, rg + nf);
+    for (int k = k0; k < k1; k++) { const int i = b.pidx[b.e_pose[k]]; if (i >= 0) rg[nf + 1 + fill[i]++] = k - k0; }
+  }
+  // Schur chunks: whole landmarks -- at most C of them, at most C free rows, an int block of at most kWinIntCap --; per chunk the rows by
+  // camera, the landmark of every row, and the (edge, edge) pairs of block_solver.hpp:381-439 -- landmark by landmark, per landmark edge k1
+  // (outer) x edge k2 (inner), lower blocks only, (k1, k1) on the diagonal -- sorted by block (stable: a block's pairs stay in landmark order)
+  std::vector<int32_t> blk_of((size_t)nf * nf, -1);
+  int max_ints = 0;
+  for (int li = 0; li < b.nact;) {
+    const int r0 = b.f_start[li];
+    int lj = li, npairs = 0;
+    while (lj < b.nact && lj - li < b.C && b.f_start[lj + 1] - r0 <= b.C) {
+      const int deg = b.f_start[lj + 1] - b.f_start[lj];
+      const int np_new = npairs + deg * (deg + 1) / 2 + deg * (deg - 1) / 2 * 0;    // lower blocks incl. the diagonal: one pair per (k1, k2) with i2 <= i1
+      const int rows_new = b.f_start[lj + 1] - r0;
+      if (lj > li && nf + 1 + 2 * rows_new + 2 * (np_new + deg * deg) + 1 > kWinIntCap) break;   // (generous: duplicates of a camera add pairs)
+      npairs = np_new; lj++;
+    }
+    if (lj == li) { set_error("dvm_ba_optimize_windows: a landmark does not fit a streaming chunk"); return DVM_ERR_CAPACITY; }
+    const int r1 = b.f_start[lj], nr = r1 - r0;
+    const int32_t ioff = (int32_t)b.sc_ints.size();
+    b.sc_ints.resize(ioff + nf + 1 + 2 * nr, 0);
+    int32_t* rg = &b.sc_ints[ioff];
+    for (int r = r0; r < r1; r++) rg[b.f_cam[r] + 1]++;
+    for (int i = 0; i < nf; i++) rg[i + 1] += rg[i];
+    {
+      std::vector<int32_t> fill(rg, rg + nf);
+      for (int r = r0; r < r1; r++) b.sc_ints[ioff + nf + 1 + fill[b.f_cam[r]]++] = r - r0;
+    }
+    for (int l2 = li; l2 < lj; l2++)
+      for (int r = b.f_start[l2]; r < b.f_start[l2 + 1]; r++) b.sc_ints[ioff + nf + 1 + nr + (r - r0)] = l2 - li;
+    std::vector<std::pair<int32_t, int32_t>> pr;       // (block, slot1 | slot2 << 16)
+    for (int l2 = li; l2 < lj; l2++)
+      for (int q1 = b.f_start[l2]; q1 < b.f_start[l2 + 1]; q1++)
+        for (int q2 = b.f_start[l2]; q2 < b.f_start[l2 + 1]; q2++) {
+          const int i1 = b.f_cam[q1], i2 = b.f_cam[q2];
+          if (i2 > i1 || (i2 == i1 && q2 != q1)) continue;
+          int32_t& id = blk_of[(size_t)i1 * nf + i2];
+          if (id < 0) { id = (int32_t)b.blk_ij.size(); b.blk_ij.push_back(i1 | (i2 << 8)); }
+          pr.push_back({id, (q1 - r0) | ((q2 - r0) << 16)});
         }
-      }
-    }
+    std::stable_sort(pr.begin(), pr.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
+    int nruns = 0;
+    for (size_t j = 0; j < pr.size(); j++)
+      if (j == 0 || pr[j].first != pr[j - 1].first) { b.sc_ints.push_back(b.blk_ij[pr[j].first] | ((int32_t)j << 16)); nruns++; }   // (i1 | i2 << 8 | first pair << 16)
+    b.sc_ints.push_back((int32_t)pr.size() << 16);       // sentinel: where the last run ends
+    for (const auto& q : pr) b.sc_ints.push_back(q.second);
+    const int ni = (int)b.sc_ints.size() - ioff;
+    if (ni > kWinIntCap || pr.size() >= 65536) { set_error("dvm_ba_optimize_windows: the index block of a chunk exceeds its capacity"); return DVM_ERR_CAPACITY; }
+    max_ints = std::max(max_ints, ni);
+    const int32_t d[8] = {r0, nr, ioff, ni, nruns + 1, (int32_t)pr.size(), li, lj - li};
+    b.sc_desc.insert(b.sc_desc.end(), d, d + 8);
+    li = lj;
   }
-  // every free camera has a diagonal block even without a landmark of its own among the free ones (it always has: it is "used")
-  b.nblk = (int)pairs.size();
-  b.blk_start.assign(b.nblk + 1, 0);
-  for (int i = 0; i < b.nblk; i++) b.blk_start[i + 1] = b.blk_start[i] + (int32_t)pairs[i].size() / 2;
-  b.pair_k1.resize(b.blk_start[b.nblk]); b.pair_k2.resize(b.blk_start[b.nblk]);
-  for (int i = 0; i < b.nblk; i++)
-    for (size_t j = 0; j < pairs[i].size() / 2; j++) { b.pair_k1[b.blk_start[i] + j] = pairs[i][2 * j]; b.pair_k2[b.blk_start[i] + j] = pairs[i][2 * j + 1]; }
+  b.n_sc = (int)b.sc_desc.size() / 8;
+  b.nblk = (int)b.blk_ij.size();
+  const size_t hess = (size_t)b.C2 * kRowB + ((size_t)b.C2 + nf + 1 + 1) / 2;
+  const size_t schur = (size_t)b.C * (kRowW + kRowD + kRowH) + ((size_t)max_ints + 1) / 2;
+  b.stage_doubles = (int)std::max(hess, schur) + 2;
   return DVM_OK;
 }
 
@@ -653,10 +938,12 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   *sw.h = (stop_flag && *stop_flag) ? 1 : 0;
 
   Stage st;
-  struct Slots { int poses, pts, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, cam_start, cam_edges, camp_edges, pt_start, pt_edges,
-                     blk_i1, blk_i2, blk_start, pair_k1, pair_k2, out_poses, out_pts, echi, edepth, stats, poses_t, pts_t, eA, eB, ew, eW, eWD, eWdb, erho, Hpp, bp, Hll,
-                     bl, Dinv, db, x, terms; };
+  struct Slots { int poses, pts, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, lpos, fpos, pt_start, f_start, f_cam, hc_ints, sc_desc, sc_ints,
+                     blk_ij, out_poses, out_pts, echi, edepth, stats, poses_t, pts_t, rowB, rowA, rowW, erho, Hpp, bp, HB, DD, x, terms, prof; };
   std::vector<Slots> sl(K);
+  static const bool want_prof = std::getenv("DVM_BA_WINDOW_PROF") != nullptr;
+  std::vector<std::vector<unsigned long long>> prof_out(K, std::vector<unsigned long long>(16, 0));
+  std::vector<unsigned long long> prof_zero(16, 0);
   auto I32 = [&](const std::vector<int32_t>& v) { return st.in(v.empty() ? nullptr : v.data(), v.size() * 4); };
   auto F64 = [&](const std::vector<double>& v) { return st.in(v.empty() ? nullptr : v.data(), v.size() * 8); };
   for (int k = 0; k < K; k++) {                     // inputs: the state and g2o's graph structure as index arrays
@@ -665,8 +952,8 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     s.pts = st.in(b.L ? windows[k].points : nullptr, 24 * (size_t)b.L);
     s.pidx = I32(b.pidx); s.lidx = I32(b.lidx); s.free_pose = I32(b.free_pose); s.act_pt = I32(b.act_pt); s.e_pose = I32(b.e_pose); s.e_point = I32(b.e_point);
     s.e_obs = F64(b.e_obs); s.e_info = F64(b.e_info);
-    s.cam_start = I32(b.cam_start); s.cam_edges = I32(b.cam_edges); s.camp_edges = I32(b.camp_edges); s.pt_start = I32(b.pt_start); s.pt_edges = I32(b.pt_edges);
-    s.blk_i1 = I32(b.blk_i1); s.blk_i2 = I32(b.blk_i2); s.blk_start = I32(b.blk_start); s.pair_k1 = I32(b.pair_k1); s.pair_k2 = I32(b.pair_k2);
+    s.lpos = I32(b.lpos); s.fpos = I32(b.fpos); s.pt_start = I32(b.pt_start); s.f_start = I32(b.f_start); s.f_cam = I32(b.f_cam);
+    s.hc_ints = I32(b.hc_ints); s.sc_desc = I32(b.sc_desc); s.sc_ints = I32(b.sc_ints); s.blk_ij = I32(b.blk_ij);
   }
   std::vector<BaWin> views(K);
   const int views_slot = st.in(views.data(), sizeof(BaWin) * (size_t)K);   // filled in below, once layout() has placed everything
@@ -680,43 +967,47 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     s.echi = st.out(o.chi2.data(), 8 * (size_t)b.E);
     s.edepth = st.out(o.depth.data(), (size_t)b.E);
     s.stats = st.out(&o.st, sizeof(dvm_ba_stats));
+    s.prof = want_prof ? st.add(prof_zero.data(), prof_out[k].data(), 128) : -1;
   }
   for (int k = 0; k < K; k++) {                     // working memory
     const WinBuild& b = B[k]; Slots& s = sl[k];
-    const size_t E = b.E, n = 6 * (size_t)b.nfree, nl = 3 * (size_t)b.nact;
+    const size_t E = b.E, F = b.F, n = 6 * (size_t)b.nfree, nl = 3 * (size_t)b.nact;
     s.poses_t = st.scratch(56 * (size_t)b.P); s.pts_t = st.scratch(24 * (size_t)b.L);
-    s.eA = st.scratch(48 * E); s.eB = st.scratch(96 * E); s.ew = st.scratch(32 * E); s.eW = st.scratch(144 * E); s.eWD = st.scratch(144 * E); s.eWdb = st.scratch(48 * E);
+    s.rowB = st.scratch(8 * kRowB * E); s.rowA = st.scratch(8 * kRowA * E); s.rowW = st.scratch(8 * kRowW * F);
     s.erho = st.scratch(8 * E);
-    s.Hpp = st.scratch(288 * (size_t)b.nfree); s.bp = st.scratch(8 * n); s.Hll = st.scratch(72 * (size_t)b.nact); s.bl = st.scratch(8 * nl);
-    s.Dinv = st.scratch(72 * (size_t)b.nact); s.db = st.scratch(8 * nl); s.x = st.scratch(8 * (n + nl)); s.terms = st.scratch(8 * (n + nl));
+    s.Hpp = st.scratch(288 * (size_t)b.nfree); s.bp = st.scratch(8 * n); s.HB = st.scratch(8 * kRowH * (size_t)b.nact); s.DD = st.scratch(8 * kRowH * (size_t)b.nact);
+    s.x = st.scratch(8 * (n + nl)); s.terms = st.scratch(8 * (n + nl));
   }
   if ((rc = st.layout()) != DVM_OK) return rc;
+  size_t lds_doubles = 0;
   for (int k = 0; k < K; k++) {
     const WinBuild& b = B[k]; const Slots& s = sl[k]; BaWin& v = views[k];
     std::memset(&v, 0, sizeof(v));
-    v.P = b.P; v.L = b.L; v.E = b.E; v.nfree = b.nfree; v.nact = b.nact; v.nblk = b.nblk; v.iterations = windows[k].iterations;
+    v.P = b.P; v.L = b.L; v.E = b.E; v.F = b.F; v.nfree = b.nfree; v.nact = b.nact; v.nblk = b.nblk; v.iterations = windows[k].iterations;
+    v.C = b.C; v.C2 = b.C2; v.n_sc = b.n_sc; v.n_hc = b.n_hc; v.stage_doubles = b.stage_doubles;
     v.fx = windows[k].cam.fx; v.fy = windows[k].cam.fy; v.cx = windows[k].cam.cx; v.cy = windows[k].cam.cy; v.delta = windows[k].cam.huber_delta;
     v.poses = st.ptr<double>(s.poses); v.pts = st.ptr<double>(s.pts); v.poses_t = st.ptr<double>(s.poses_t); v.pts_t = st.ptr<double>(s.pts_t);
     v.out_poses = st.ptr<double>(s.out_poses); v.out_pts = st.ptr<double>(s.out_pts);
     v.pidx = st.ptr<int32_t>(s.pidx); v.lidx = st.ptr<int32_t>(s.lidx); v.free_pose = st.ptr<int32_t>(s.free_pose); v.act_pt = st.ptr<int32_t>(s.act_pt);
     v.e_pose = st.ptr<int32_t>(s.e_pose); v.e_point = st.ptr<int32_t>(s.e_point); v.e_obs = st.ptr<double>(s.e_obs); v.e_info = st.ptr<double>(s.e_info);
-    v.e_A = st.ptr<double>(s.eA); v.e_B = st.ptr<double>(s.eB); v.e_w = st.ptr<double>(s.ew); v.e_W = st.ptr<double>(s.eW); v.e_WD = st.ptr<double>(s.eWD);
-    v.e_Wdb = st.ptr<double>(s.eWdb); v.e_chi2 = st.ptr<double>(s.echi); v.e_rho = st.ptr<double>(s.erho); v.e_depth = st.ptr<uint8_t>(s.edepth);
-    v.cam_start = st.ptr<int32_t>(s.cam_start); v.cam_edges = st.ptr<int32_t>(s.cam_edges); v.camp_edges = st.ptr<int32_t>(s.camp_edges);
-    v.pt_start = st.ptr<int32_t>(s.pt_start); v.pt_edges = st.ptr<int32_t>(s.pt_edges);
-    v.blk_i1 = st.ptr<int32_t>(s.blk_i1); v.blk_i2 = st.ptr<int32_t>(s.blk_i2); v.blk_start = st.ptr<int32_t>(s.blk_start);
-    v.pair_k1 = st.ptr<int32_t>(s.pair_k1); v.pair_k2 = st.ptr<int32_t>(s.pair_k2);
-    v.Hpp = st.ptr<double>(s.Hpp); v.bp = st.ptr<double>(s.bp); v.Hll = st.ptr<double>(s.Hll); v.bl = st.ptr<double>(s.bl); v.Dinv = st.ptr<double>(s.Dinv);
-    v.db = st.ptr<double>(s.db); v.x = st.ptr<double>(s.x); v.terms = st.ptr<double>(s.terms);
+    v.lpos = st.ptr<int32_t>(s.lpos); v.fpos = st.ptr<int32_t>(s.fpos); v.pt_start = st.ptr<int32_t>(s.pt_start); v.f_start = st.ptr<int32_t>(s.f_start);
+    v.f_cam = st.ptr<int32_t>(s.f_cam);
+    v.rowB = st.ptr<double>(s.rowB); v.rowA = st.ptr<double>(s.rowA); v.rowW = st.ptr<double>(s.rowW);
+    v.e_chi2 = st.ptr<double>(s.echi); v.e_rho = st.ptr<double>(s.erho); v.e_depth = st.ptr<uint8_t>(s.edepth);
+    v.hc_ints = st.ptr<int32_t>(s.hc_ints); v.sc_desc = st.ptr<int32_t>(s.sc_desc); v.sc_ints = st.ptr<int32_t>(s.sc_ints);
+    v.blk_ij = st.ptr<int32_t>(s.blk_ij);
+    v.Hpp = st.ptr<double>(s.Hpp); v.bp = st.ptr<double>(s.bp); v.HB = st.ptr<double>(s.HB); v.DD = st.ptr<double>(s.DD);
+    v.x = st.ptr<double>(s.x); v.terms = st.ptr<double>(s.terms);
     v.stats = st.ptr<dvm_ba_stats>(s.stats);
+    v.prof = s.prof >= 0 ? st.ptr<unsigned long long>(s.prof) : nullptr;
+    const size_t n = 6 * (size_t)b.nfree;
+    lds_doubles = std::max(lds_doubles, n * (n + 1) / 2 + 2 * n + 64 + 256 + (size_t)b.stage_doubles);
   }
   if ((rc = st.upload()) != DVM_OK) return rc;
-  // dynamic LDS: the packed reduced system of the largest window + the fixed part; the attribute is raised to the kernel's maximum once per call
-  int max_n = 0;
-  for (int k = 0; k < K; k++) max_n = std::max(max_n, 6 * B[k].nfree);
-  const size_t lds_bytes = sizeof(double) * ((size_t)max_n * (max_n + 1) / 2 + kWinLdsMisc);
-  DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double) * ((size_t)(6 * kWinMaxFree) * (6 * kWinMaxFree + 1) / 2 + kWinLdsMisc))));
+  // dynamic LDS: the packed reduced system of the largest window, rhs / diagonal, control words and the streaming area
+  const size_t lds_bytes = sizeof(double) * lds_doubles;
+  if (lds_bytes > 160 * 1024) { set_error("dvm_ba_optimize_windows: a window needs more than 160 KB of LDS"); return DVM_ERR_CAPACITY; }
+  DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, 0, st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
   if (stop_flag) {                     // g2o's forceStopFlag: written by another thread while the optimisation runs (LocalMapping.cc:305,359)
@@ -728,6 +1019,11 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   }
   if ((rc = st.download()) != DVM_OK) return rc;
   const auto t2 = std::chrono::steady_clock::now();
+  if (want_prof) {
+    static const char* names[16] = {"edge pass + Jacobians", "Hll / bl", "Hpp / bp (streamed)", "schur: rhs chain", "Schur (streamed)", "Cholesky", "forward / backward", "landmark back-sub",
+                                    "oplus + scale terms", "edge pass chi2", "sequential sums", "schur: runs + wait", "schur: store + prefetch", "schur: Dinv", "schur: W Dinv", "decision + rest"};
+    for (int i = 0; i < 16; i++) if (prof_out[0][i]) std::fprintf(stderr, "window 0: %-24s %10.1f us\n", names[i], prof_out[0][i] / 2400.0);   // s_memtime ticks at the shader clock (MI355X_MICROARCH.md): us at 2.4 GHz
+  }
   for (int k = 0; k < K; k++) {
     const dvm_ba_window& w = windows[k];
     if (w.poses_out && B[k].P) std::memcpy(w.poses_out, outs[k].poses.data(), 56 * (size_t)B[k].P);
