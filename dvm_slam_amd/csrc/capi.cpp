@@ -6,6 +6,8 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/dvmslam_hip.h"
@@ -20,7 +22,19 @@ using namespace dvm;
 struct dvm_orb {
   OrbPipeline* p;
   float* d_scale = nullptr;
+  uint64_t id = 0, serial = 0;      // dvm_device_frame: which handle, which extraction
+  int last_n = 0;
 };
+// handle id -> serial of its current result (dvm_device_frame_valid); ids are never reused
+static std::mutex g_orb_live_mu;
+static std::unordered_map<uint64_t, uint64_t> g_orb_live;
+static uint64_t g_orb_next_id = 1;
+static void orb_result_changed(dvm_orb* h, int n) {
+  std::lock_guard<std::mutex> l(g_orb_live_mu);
+  if (!h->id) h->id = g_orb_next_id++;
+  g_orb_live[h->id] = ++h->serial;
+  h->last_n = n;
+}
 
 struct dvm_frame {
   int device, cap, slots;
@@ -78,6 +92,7 @@ int dvm_orb_create(const dvm_orb_params* p, int device, int max_batch, dvm_orb**
 }
 void dvm_orb_destroy(dvm_orb* h) {
   if (!h) return;
+  if (h->id) { std::lock_guard<std::mutex> l(g_orb_live_mu); g_orb_live.erase(h->id); }
   if (h->d_scale) hipFree(h->d_scale);
   delete h->p;
   delete h;
@@ -99,18 +114,39 @@ int dvm_orb_extract(dvm_orb* h, const uint8_t* img, int rows, int cols, int stri
   if (!h) return DVM_ERR_INVALID;
   if (n) *n = 0;
   if (mono_index) *mono_index = -1;
+  orb_result_changed(h, -1);                 // whatever a dvm_device_frame of this handle named is being overwritten
   int rc = h->p->extract_host(img, 1, rows, cols, stride, (int64_t)rows * stride, lap0, lap1);
   if (rc != DVM_OK) return rc;
-  return h->p->download(0, kps, desc, cap, n, mono_index);
+  int nn = 0;
+  rc = h->p->download(0, kps, desc, cap, &nn, mono_index);
+  if (n) *n = nn;
+  if (rc == DVM_OK) h->last_n = nn;
+  return rc;
+}
+int dvm_orb_last_result(dvm_orb* h, dvm_device_frame* out) {
+  if (!h || !out) return DVM_ERR_INVALID;
+  if (!h->p->configured || h->last_n < 0 || !h->id) { set_error("dvm_orb_last_result: no single-frame result on this handle"); return DVM_ERR_STATE; }
+  OrbPipeline& P = *h->p;
+  out->d_kps = reinterpret_cast<const dvm_keypoint*>(P.d_kps); out->d_desc = P.d_desc;
+  out->n = h->last_n; out->device = P.device; out->handle_id = h->id; out->serial = h->serial;
+  return DVM_OK;
+}
+int dvm_device_frame_valid(const dvm_device_frame* ref) {
+  if (!ref || !ref->handle_id || !ref->d_kps) return 0;
+  std::lock_guard<std::mutex> l(g_orb_live_mu);
+  const auto it = g_orb_live.find(ref->handle_id);
+  return it != g_orb_live.end() && it->second == ref->serial ? 1 : 0;
 }
 int dvm_orb_extract_batch_device(dvm_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int stride,
                                  int64_t frame_stride, int lap0, int lap1) {
   if (!h) return DVM_ERR_INVALID;
+  orb_result_changed(h, -1);
   return h->p->extract_device(d_imgs, batch, rows, cols, stride, frame_stride, lap0, lap1);
 }
 int dvm_orb_extract_batch_host(dvm_orb* h, const uint8_t* imgs, int batch, int rows, int cols, int stride,
                                int64_t frame_stride, int lap0, int lap1) {
   if (!h) return DVM_ERR_INVALID;
+  orb_result_changed(h, -1);
   return h->p->extract_host(imgs, batch, rows, cols, stride, frame_stride, lap0, lap1);
 }
 int dvm_orb_staging(dvm_orb* h, int batch, int rows, int cols, uint8_t** host_ptr) {
@@ -119,6 +155,7 @@ int dvm_orb_staging(dvm_orb* h, int batch, int rows, int cols, uint8_t** host_pt
 }
 int dvm_orb_extract_staged(dvm_orb* h, int batch, int rows, int cols, int lap0, int lap1) {
   if (!h) return DVM_ERR_INVALID;
+  orb_result_changed(h, -1);
   return h->p->extract_staged(batch, rows, cols, lap0, lap1);
 }
 int dvm_orb_sync(dvm_orb* h) { return h ? h->p->sync() : DVM_ERR_INVALID; }

@@ -28,6 +28,10 @@ class ORBextractor {
     cap_ = nfeatures + 5 * nlevels + 8;
     kps_.resize(cap_);
   }
+  // The result of the last operator() call as it still sits in HBM.  Frame's constructor stores it beside mvKeys / mDescriptors
+  // (one added member + one line after ExtractORB); ORBmatcher then builds the frame's feature grid from it
+  // instead of uploading the same 60 KB again.  Stale references (the extractor has moved on) are recognised and ignored.
+  const dvm_device_frame& LastDeviceResult() const { return last_; }
   ~ORBextractor() { dvm_orb_destroy(h_); }
   ORBextractor(const ORBextractor&) = delete;
 
@@ -52,6 +56,7 @@ class ORBextractor {
       rc = dvm_orb_download(h_, 0, kps_.data(), desc.data, cap_, &n, &mono);
     }
     if (rc != DVM_OK) throw std::runtime_error(dvm_last_error());
+    if (dvm_orb_last_result(h_, &last_) != DVM_OK) last_ = dvm_device_frame{};
     _keypoints.resize(n);
     std::memcpy(static_cast<void*>(_keypoints.data()), kps_.data(), sizeof(dvm_keypoint) * n);
     if (n == 0) _descriptors.release();
@@ -84,6 +89,7 @@ class ORBextractor {
   std::vector<cv::Mat> mvImagePyramid;
 
  protected:
+  dvm_device_frame last_{};
   dvm_orb* h_ = nullptr;
   int nlevels_, cap_;
   float scaleFactor_;

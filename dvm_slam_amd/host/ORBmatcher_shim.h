@@ -33,6 +33,7 @@ class ORBmatcher {
   ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri), m_(nnratio, checkOri, dvm_host::device()) {}
 
   // Computes the Hamming distance between two ORB descriptors
+  bool dvmLastGridFromDevice() const { return m_.last_grid_from_device; }   // (diagnostic: the last search built its grid from Frame::mDvmDevice)
   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
     return dvm_host::ORBmatcher::DescriptorDistance(a.ptr<uint8_t>(), b.ptr<uint8_t>());
   }
@@ -289,6 +290,8 @@ class ORBmatcher {
     V.fx = F.fx; V.fy = F.fy; V.cx = F.cx; V.cy = F.cy;
     V.mnMinX = F.mnMinX; V.mnMaxX = F.mnMaxX; V.mnMinY = F.mnMinY; V.mnMaxY = F.mnMaxY;
     V.mvScaleFactors = F.mvScaleFactors.data(); V.nLevels = F.mnScaleLevels;
+    // the extractor's result is still in HBM and these are its keypoints unchanged (no distortion: mvKeysUn == mvKeys, Frame.cc:792-795)
+    V.dev = (F.mDvmDevice.handle_id && (F.mDistCoef.empty() || F.mDistCoef.at<float>(0) == 0.0f)) ? &F.mDvmDevice : nullptr;
     return V;
   }
 

@@ -224,6 +224,13 @@ int ORBmatcher::ensure_grid(const FrameView& F) {
   }
   grid_ = c.g;
   grid_cap_ = c.cap;
+  // the frame's keypoints + descriptors are still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> ORBmatcher.cc:1553
+  // without a round trip through the host): the grid is built from there, on the default stream the searches follow on
+  if (F.dev && F.dev->n == F.N && F.dev->device == device_ && dvm_device_frame_valid(F.dev)) {
+    last_grid_from_device = true;
+    return dvm_frame_build(grid_, 0, F.dev->d_kps, F.dev->d_desc, F.N, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY, 1, nullptr);
+  }
+  last_grid_from_device = false;
   return dvm_frame_build(grid_, 0, F.mvKeysUn, F.mDescriptors, F.N, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY, 0, nullptr);
 }
 

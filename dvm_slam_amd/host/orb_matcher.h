@@ -135,6 +135,9 @@ class ORBmatcher {
   float mfNNratio;
   bool mbCheckOrientation;
   int device_;
+ public:
+  bool last_grid_from_device = false;     // the last call built its grid from a dvm_device_frame (no upload)
+ private:
   dvm_frame* grid_ = nullptr;
   int grid_cap_ = 0;
   int ensure_grid(const FrameView& F);

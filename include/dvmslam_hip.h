@@ -102,6 +102,19 @@ int dvm_orb_sync(dvm_orb* h);
  * the reference's output order; d_n points at the int32 keypoint count of the frame. */
 int dvm_orb_result_device(dvm_orb* h, int frame, const dvm_keypoint** d_kps, const uint8_t** d_desc,
                           const int32_t** d_n, int* capacity);
+/* A reference to the keypoints + descriptors a single-frame dvm_orb_extract has just produced, still in HBM: a plain value the
+ * caller keeps beside the host copies (the Frame that owns mvKeys / mDescriptors -- Frame.cc:411 -- and every copy of that Frame) and
+ * hands to the consumers of the same data (dvm_frame_build through dvmh_frame_view::dev: the grid of SearchByProjection is then
+ * built from the device arrays, no second upload).  The arrays live until the handle extracts again or is destroyed;
+ * dvm_device_frame_valid tells (0 / 1) whether a reference still names the handle's current result. */
+typedef struct {
+  const dvm_keypoint* d_kps;
+  const uint8_t* d_desc;
+  int32_t n, device;
+  uint64_t handle_id, serial;
+} dvm_device_frame;
+int dvm_orb_last_result(dvm_orb* h, dvm_device_frame* out);
+int dvm_device_frame_valid(const dvm_device_frame* ref);
 /* asynchronous device-to-device copy (on the handle's stream) of frame f's keypoints, descriptors
  * and count into caller-owned device buffers (capacity as reported by dvm_orb_result_device) --
  * used to carry the last frame of a batch over to the next batch's frame-to-frame search */

@@ -28,6 +28,9 @@ typedef struct dvmh_frame_view {
   float mnMinX, mnMaxX, mnMinY, mnMaxY;
   const float* mvScaleFactors;
   int32_t nLevels;
+  const dvm_device_frame* dev;           /* may be NULL.  The extractor's reference to these very keypoints + descriptors in HBM
+                                            (dvm_orb_last_result): valid only while mvKeysUn == mvKeys (no distortion) -- the feature
+                                            grid is then built from the device arrays instead of uploading them again */
 } dvmh_frame_view;
 /* the members of ORB_SLAM3::KeyFrame the matcher touches (monocular; include/KeyFrame.h) */
 typedef struct dvmh_keyframe_view {

@@ -35,6 +35,8 @@ struct World {
   std::vector<std::unique_ptr<Frame>> frames;
   GeometricCamera cam;
   std::unique_ptr<KeyFrameDatabase> kfdb;
+  std::unique_ptr<ORBextractor> extractor;           // Tracking's mpORBextractorLeft: one instance, used frame after frame
+  bool last_grid_from_device = false;
   std::string error;
   int kf_index(KeyFrame* k) const { for (size_t i = 0; i < kfs.size(); i++) if (kfs[i].get() == k) return (int)i; return -1; }
   int mp_index(MapPoint* p) const { if (!p) return -1; for (size_t i = 0; i < mps.size(); i++) if (mps[i].get() == p) return (int)i; return -2; }
@@ -476,7 +478,40 @@ void sw_mp_set_track(World* w, int mp, float px, float py, float depth, float vi
 
 // ---- ORBmatcher
 int sw_search_by_projection_last(World* w, int cur, int last, float th, float nnratio, int check_ori) {
-  return guarded(w, [&] { ORBmatcher m(nnratio, check_ori != 0); return m.SearchByProjection(*w->frames[cur], *w->frames[last], th, true); });
+  return guarded(w, [&] {
+    ORBmatcher m(nnratio, check_ori != 0);
+    const int n = m.SearchByProjection(*w->frames[cur], *w->frames[last], th, true);
+    w->last_grid_from_device = m.dvmLastGridFromDevice();
+    return n;
+  });
+}
+int sw_last_grid_from_device(World* w) { return w->last_grid_from_device ? 1 : 0; }
+// Frame::ExtractORB (Frame.cc:411) on the World's persistent extractor: (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors, vLapping), then
+// what the constructor derives from it (N, mvKeysUn = mvKeys for an undistorted camera, the per-keypoint vectors) and -- keep_device --
+// the optional added line `mDvmDevice = mpORBextractorLeft->LastDeviceResult()`
+int sw_frame_extract(World* w, int f, const uint8_t* img, int rows, int cols, int stride, int keep_device) {
+  return guarded(w, [&] {
+    if (!w->extractor) w->extractor.reset(new ORBextractor(1000, 1.2f, 8, 20, 7));
+    Frame& F = *w->frames[f];
+    cv::Mat image(rows, cols, CV_8UC1, const_cast<uint8_t*>(img), (size_t)stride);
+    std::vector<int> lap = {0, 1000};
+    cv::_InputArray in(image), mask;
+    cv::_OutputArray out(F.mDescriptors);
+    (*w->extractor)(in, mask, F.mvKeys, out, lap);
+    F.N = (int)F.mvKeys.size();
+    F.mvKeysUn = F.mvKeys;
+    F.mvuRight.assign(F.N, -1.0f); F.mvDepth.assign(F.N, -1.0f);
+    F.mvpMapPoints.assign(F.N, static_cast<MapPoint*>(nullptr));
+    F.mvbOutlier.assign(F.N, false);
+    F.mDvmDevice = keep_device ? w->extractor->LastDeviceResult() : dvm_device_frame{};
+    return F.N;
+  });
+}
+int sw_frame_keypoints(World* w, int f, dvm_keypoint* kps, uint8_t* desc) {
+  Frame& F = *w->frames[f];
+  if (F.N) std::memcpy(kps, static_cast<const void*>(F.mvKeysUn.data()), sizeof(dvm_keypoint) * (size_t)F.N);
+  for (int r = 0; r < F.N; r++) std::memcpy(desc + 32 * (size_t)r, F.mDescriptors.ptr<uint8_t>(r), 32);
+  return F.N;
 }
 int sw_search_by_projection_points(World* w, int f, const int32_t* mps, int n, float th, int far_points, float th_far, float nnratio) {
   return guarded(w, [&] { ORBmatcher m(nnratio, true); return m.SearchByProjection(*w->frames[f], mp_list(w, mps, n), th, far_points != 0, th_far); });

@@ -22,6 +22,7 @@
 
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 #include <boost/uuid/uuid.hpp>
+#include "dvmslam_hip.h"      // dvm_device_frame (the optional Frame member)
 
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
@@ -295,6 +296,7 @@ class Frame {
   void UndistortKeyPoints();                          // private in the reference (Frame.h): the shim is compiled into Frame.cc
   void ComputeImageBounds(const cv::Mat& imLeft);
   cv::Mat mK, mDistCoef;
+  dvm_device_frame mDvmDevice{};     // (+) optional: `mDvmDevice = mpORBextractorLeft->LastDeviceResult();` after ExtractORB (Frame.cc:411), INTEGRATION.md section 0
   int N = 0;
   std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
   std::vector<float> mvuRight, mvDepth;

@@ -498,3 +498,44 @@ def test_mappoint_compute_distinctive_descriptors(oracle):
     assert np.array_equal(got, want)
     W2_got = W.compute_distinctive(mps, batched=True)
     assert np.array_equal(W2_got, want)
+
+
+def test_frame_hand_off_stays_on_the_device(capi, oracle):
+    """The reference's flow Frame.cc:411 (ExtractORB) -> Frame.cc:481 (grid) -> ORBmatcher.cc:1553 (SearchByProjection(CurrentFrame, LastFrame))
+    through the shims with the optional `Frame::mDvmDevice = mpORBextractorLeft->LastDeviceResult()` line: the current frame's feature grid is
+    built from the keypoints + descriptors the extractor left in HBM -- no second upload -- and the search returns exactly what it returns
+    from the host copies.  A reference that has gone stale (the extractor has produced another frame since) is recognised and ignored."""
+    from dvm_slam_amd import synth
+    frames = synth.frame_stream(3)
+    H, Wd = frames.shape[1:]
+    K = (149.0, 149.0, 320.0, 240.0)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
+    scale = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    results = {}
+    for mode in ("host", "device", "stale"):
+        W = sw.World(); W.add_map(0); _tables(W, scale)
+        nokp = np.zeros(0, sw.KEYPOINT_DTYPE)
+        last = W.add_frame(ident, K, nokp, None, bounds=(0, Wd, 0, H))
+        cur = W.add_frame(ident, K, nokp, None, bounds=(0, Wd, 0, H))
+        img = lambda i: (sw._p(np.ascontiguousarray(frames[i])), H, Wd, Wd)
+        nl = W._chk(W.L.sw_frame_extract(W.h, last, *img(0), 0))
+        nc = W._chk(W.L.sw_frame_extract(W.h, cur, *img(1), 0 if mode == "host" else 1))
+        if mode == "stale":
+            extra = W.add_frame(ident, K, nokp, None, bounds=(0, Wd, 0, H))
+            W._chk(W.L.sw_frame_extract(W.h, extra, *img(2), 1))          # the extractor moves on: cur's reference no longer names its result
+        assert nl > 900 and nc > 900
+        kl = np.zeros(nl, sw.KEYPOINT_DTYPE); dl = np.zeros((nl, 32), np.uint8)
+        W.L.sw_frame_keypoints(W.h, last, sw._p(kl), sw._p(dl))
+        # the last frame's map points: its keypoints back-projected to depth 4 (the identity pose), carrying its descriptors
+        mp_l = np.full(nl, -1, np.int32)
+        for j in range(0, nl, 2):
+            z = 4.0
+            X = [(kl["x"][j] - K[2]) / K[0] * z, (kl["y"][j] - K[3]) / K[1] * z, z]
+            mp_l[j] = W.add_mappoint(0, j, X, desc=dl[j])
+            W.L.sw_mp_set_obs_count(W.h, int(mp_l[j]), 2)
+        W.frame_set_matches(last, mp_l)
+        n = W._chk(W.L.sw_search_by_projection_last(W.h, cur, last, f32(15.0), f32(0.9), 1))
+        results[mode] = (n, W.get_frame(cur)["mp"].copy(), bool(W.L.sw_last_grid_from_device(W.h)))
+    assert results["host"][2] is False and results["device"][2] is True and results["stale"][2] is False
+    assert results["host"][0] == results["device"][0] == results["stale"][0] > 200
+    assert np.array_equal(results["host"][1], results["device"][1]) and np.array_equal(results["host"][1], results["stale"][1])
