@@ -360,7 +360,24 @@ def _pose_optimization(W, f):
     return W._chk(W.L.sw_pose_optimization(W.h, f))
 
 
+def _frame_extract(W, f, img, keep_device):
+    """Frame::ExtractORB on the world's persistent extractor (+ the optional mDvmDevice line): returns N."""
+    img = np.ascontiguousarray(img, np.uint8)
+    n = W._chk(W.L.sw_frame_extract(W.h, f, _p(img), img.shape[0], img.shape[1], img.shape[1], int(keep_device)))
+    W.frame_n[f] = n
+    return n
+
+
+def _frame_keypoints(W, f):
+    n = W.frame_n[f]
+    k = np.zeros(max(n, 1), KEYPOINT_DTYPE); d = np.zeros((max(n, 1), 32), np.uint8)
+    W.L.sw_frame_keypoints(W.h, f, _p(k), _p(d))
+    return k[:n], d[:n]
+
+
 World.add_frame = _add_frame
+World.frame_extract = _frame_extract
+World.frame_keypoints = _frame_keypoints
 World.frame_set_matches = _frame_set_matches
 World.get_frame = _get_frame
 World.pose_optimization = _pose_optimization

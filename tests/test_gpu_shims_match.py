@@ -517,15 +517,13 @@ def test_frame_hand_off_stays_on_the_device(capi, oracle):
         nokp = np.zeros(0, sw.KEYPOINT_DTYPE)
         last = W.add_frame(ident, K, nokp, None, bounds=(0, Wd, 0, H))
         cur = W.add_frame(ident, K, nokp, None, bounds=(0, Wd, 0, H))
-        img = lambda i: (sw._p(np.ascontiguousarray(frames[i])), H, Wd, Wd)
-        nl = W._chk(W.L.sw_frame_extract(W.h, last, *img(0), 0))
-        nc = W._chk(W.L.sw_frame_extract(W.h, cur, *img(1), 0 if mode == "host" else 1))
+        nl = W.frame_extract(last, frames[0], False)
+        nc = W.frame_extract(cur, frames[1], mode != "host")
         if mode == "stale":
             extra = W.add_frame(ident, K, nokp, None, bounds=(0, Wd, 0, H))
-            W._chk(W.L.sw_frame_extract(W.h, extra, *img(2), 1))          # the extractor moves on: cur's reference no longer names its result
+            W.frame_extract(extra, frames[2], True)                       # the extractor moves on: cur's reference no longer names its result
         assert nl > 900 and nc > 900
-        kl = np.zeros(nl, sw.KEYPOINT_DTYPE); dl = np.zeros((nl, 32), np.uint8)
-        W.L.sw_frame_keypoints(W.h, last, sw._p(kl), sw._p(dl))
+        kl, dl = W.frame_keypoints(last)
         # the last frame's map points: its keypoints back-projected to depth 4 (the identity pose), carrying its descriptors
         mp_l = np.full(nl, -1, np.int32)
         for j in range(0, nl, 2):
