@@ -471,7 +471,8 @@ def main():
             # what BASELINE configs 2 and 3 cost per call through the drop-in boundary (bench_legs.py), CPU oracle beside each
             import bench_legs
             cpu = a.cpu_seconds > 0
-            for name, fn in (("latency", lambda: bench_legs.latency(capi, frames[:64], local, cpu_calls=24 if cpu else 0)),
+            for name, fn in (("batch_sweep", lambda: bench_legs.batch_sweep()),
+                             ("latency", lambda: bench_legs.latency(capi, frames[:64], local, cpu_calls=24 if cpu else 0)),
                              ("lba", lambda: bench_legs.lba(local, cpu_seconds=4.0 if cpu else 0.0)),
                              ("lba_batch", lambda: bench_legs.lba_batch(local, cpu_windows=4 if cpu else 0)),
                              ("merge", lambda: bench_legs.merge(local, cpu_reps=3 if cpu else 0)),

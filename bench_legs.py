@@ -78,6 +78,20 @@ def latency(capi, frames, device, calls=500, cpu_calls=24):
         prev = cur
     nm = []
     t_sbp = _time_calls(lambda i: nm.append(capi.search_by_projection_frames(th=15.0, device=device, **pairs[i % len(pairs)])[0]), calls)
+    # the same search when the current frame's keypoints + descriptors are still in HBM where the extractor left them (dvm_orb_last_result ->
+    # dvmh_frame_view::dev; the shims' Frame::mDvmDevice): extraction of frame t is outside the timed call, as it is in Tracking
+    used = []
+    def sbp_dev(i):
+        t = 1 + i % 8
+        ext.extract(frames[t])
+        ref = ext.last_result()
+        t0 = time.perf_counter()
+        r = capi.search_by_projection_frames(th=15.0, device=device, dev_c=ref, **pairs[t - 1])
+        used.append(r[3])
+        return time.perf_counter() - t0
+    for i in range(5):
+        sbp_dev(i)
+    t_sbp_dev = [sbp_dev(i) for i in range(calls)]
     cases = [_pose_case(100 + i) for i in range(8)]
 
     def pose(i):
@@ -87,6 +101,8 @@ def latency(capi, frames, device, calls=500, cpu_calls=24):
     ext.close()
     out = {"unit": "ms per call, host arrays in -> host arrays out (Python / ctypes harness around the C ABI)",
            "orb_extract_one_frame": _stats(t_ext), "search_by_projection_cur_last": dict(_stats(t_sbp), matches_per_call=float(np.mean(nm))),
+           "search_by_projection_cur_last_device_resident": dict(_stats(t_sbp_dev), grid_built_from_hbm_fraction=float(np.mean(used)),
+                                                                 note="Frame.cc:411 -> ORBmatcher.cc:1553 without re-uploading the frame: dvm_orb_last_result + dvmh_frame_view::dev"),
            "pose_optimization_one_frame": dict(_stats(t_pose), matches=int(np.mean([len(c[1]) for c in cases]))),
            "reference": "Tracking.cc:1423-1426 (Frame ctor -> ORBextractor::operator()), :2610 (SearchByProjection), :2632 (PoseOptimization)"}
     if cpu_calls > 0:
@@ -98,6 +114,30 @@ def latency(capi, frames, device, calls=500, cpu_calls=24):
         out["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": f"{cpu_calls} calls each of the same inputs, CPU oracle",
                                "orb_extract_one_frame": _stats(c_ext), "search_by_projection_cur_last": _stats(c_sbp),
                                "pose_optimization_one_frame": _stats(c_pose)}
+    return out
+
+
+def batch_sweep(batches=(1, 8, 32), steps=3, frames_per_step=4096):
+    """The headline metric at the launch-group sizes an ONLINE system sees -- 1 frame (one agent), 8 / 32 (that many agents' simultaneous frames on
+    one GPU) -- next to the 256 of the main line: bench.py itself with --batch B (same stream, same two-lane pipeline, frames resident in HBM,
+    extract + grid + match per launch group), one subprocess per size."""
+    import json
+    import subprocess
+    out = {"unit": "frames/s (device-resident frames, two pipeline lanes)", "by_batch": {},
+           "note": "bench.py --batch B --no-ba --no-legs --no-pcie --no-exclusive --cpu-seconds 0; launch-group latency = ms_per_launch_group"}
+    for B in batches:
+        chunks = max(2, min(frames_per_step // B, 1024))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", str(B), "--chunks-per-step", str(chunks), "--steps", str(steps), "--warmup", "1",
+               "--stream-frames", str(max(256, 4 * B)), "--no-ba", "--no-legs", "--no-pcie", "--no-exclusive", "--cpu-seconds", "0"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            out["by_batch"][str(B)] = {"value": d["value"], "ms_per_launch_group": d["ms_per_step"] / chunks, "launch_groups": steps * chunks,
+                                       "k_fast_cells_ms_per_launch": d["roofline"]["avg_launch_ms"] if d.get("roofline") else None}
+        except Exception as ex:   # noqa: BLE001
+            out["by_batch"][str(B)] = {"error": repr(ex)}
     return out
 
 

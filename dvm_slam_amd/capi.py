@@ -187,6 +187,14 @@ class OrbExtractor:
     def cap(self):
         return self.nfeatures + 5 * self.nlevels + 8
 
+    def last_result(self):
+        """dvm_orb_last_result: a DeviceFrame naming the keypoints + descriptors of the last extract(), still in HBM."""
+        r = DeviceFrame()
+        f = self.L.dvm_orb_last_result
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.h, C.byref(r)))
+        return r
+
     def extract(self, img: np.ndarray, lap=(0, 1000)):
         """operator(): returns (n, keypoints, descriptors, monoIndex); n == -1 for an empty image."""
         if img is None or img.size == 0:
@@ -654,8 +662,13 @@ def host_lib():
     return _HOST
 
 
+class DeviceFrame(C.Structure):
+    """dvm_device_frame (include/dvmslam_hip.h): the extractor's last single-frame result, still in HBM"""
+    _fields_ = [("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("n", C.c_int32), ("device", C.c_int32), ("handle_id", C.c_uint64), ("serial", C.c_uint64)]
+
+
 def search_by_projection_frames(kps_c, desc_c, mp_c, Tcw, K, bounds, scale_factors, kps_l, mp_l, outlier_l, mps, th,
-                                check_ori=True, device=0):
+                                check_ori=True, device=0, dev_c=None):
     """dvm_host::ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono=true) -- reference
     ORBmatcher.cc:1553-1748.  Tcw: CurrentFrame.GetPose() as 7 floats (qx, qy, qz, qw, t).  Returns (nmatches, updated mvpMapPoints of the current frame, #host re-queries)."""
     H = host_lib()
@@ -668,6 +681,15 @@ def search_by_projection_frames(kps_c, desc_c, mp_c, Tcw, K, bounds, scale_facto
     assert f[0].shape == (7,)
     mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
     req = C.c_int32(0)
+    if dev_c is not None:       # the current frame's data is still in HBM (OrbExtractor.last_result()): returns a 4th value, 1 if the grid was built from it
+        fn = H.dvmh_search_by_projection_frames_dev
+        fn.restype = C.c_int32; fn.argtypes = None
+        used = C.c_int32(0)
+        n = fn(C.c_int32(device), C.c_int32(len(kps_c)), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f], C.c_int32(len(f[3])), C.c_int32(len(kps_l)), _p(kps_l),
+               _p(mp_l), None if outl is None else _p(outl), _p(mps), C.c_float(float(th)), C.c_int32(int(check_ori)), C.byref(req), C.byref(dev_c), C.byref(used))
+        if n < 0:
+            check(n)
+        return n, mp, req.value, used.value
     n = H.dvmh_search_by_projection_frames(device, len(kps_c), _p(kps_c), _p(desc_c), _p(mp), *[_p(a) for a in f],
                                            len(f[3]), len(kps_l), _p(kps_l), _p(mp_l), None if outl is None else _p(outl),
                                            _p(mps), float(th), int(check_ori), C.byref(req))
@@ -857,7 +879,7 @@ class _FrameView(C.Structure):
     _fields_ = [("N", C.c_int32), ("mvKeysUn", C.c_void_p), ("mDescriptors", C.c_void_p), ("mvpMapPoints", C.c_void_p),
                 ("mvbOutlier", C.c_void_p), ("Tcw", C.c_float * 7), ("fx", C.c_float), ("fy", C.c_float),
                 ("cx", C.c_float), ("cy", C.c_float), ("mnMinX", C.c_float), ("mnMaxX", C.c_float), ("mnMinY", C.c_float),
-                ("mnMaxY", C.c_float), ("mvScaleFactors", C.c_void_p), ("nLevels", C.c_int32)]
+                ("mnMaxY", C.c_float), ("mvScaleFactors", C.c_void_p), ("nLevels", C.c_int32), ("dev", C.c_void_p)]
 
 
 class _KeyFrameView(C.Structure):

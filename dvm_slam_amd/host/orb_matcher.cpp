@@ -880,6 +880,25 @@ int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps
   if (requeried) *requeried = m.last_requeried;
   return n;
 }
+int dvmh_search_by_projection_frames_dev(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,
+                                         const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
+                                         const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried,
+                                         const dvm_device_frame* dev_c, int* grid_from_device) {
+  FrameView C, L;
+  C.N = Nc; C.mvKeysUn = kps_c; C.mDescriptors = desc_c; C.mvpMapPoints = mp_c;
+  C.Tcw = *Tcw;
+  C.fx = K[0]; C.fy = K[1]; C.cx = K[2]; C.cy = K[3];
+  C.mnMinX = bounds[0]; C.mnMaxX = bounds[1]; C.mnMinY = bounds[2]; C.mnMaxY = bounds[3];
+  C.mvScaleFactors = scale_factors; C.nLevels = nlevels;
+  L = C;
+  C.dev = dev_c;
+  L.N = Nl; L.mvKeysUn = kps_l; L.mDescriptors = nullptr; L.mvpMapPoints = const_cast<int32_t*>(mp_l); L.mvbOutlier = outlier_l;
+  dvm_host::ORBmatcher m(0.9f, check_ori != 0, device);
+  const int n = m.SearchByProjection(C, L, mps, th, true);
+  if (requeried) *requeried = m.last_requeried;
+  if (grid_from_device) *grid_from_device = m.last_grid_from_device ? 1 : 0;
+  return n;
+}
 int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
                                      const float* bounds, const float* scale_factors, int nlevels, const dvmh_tracked_point* pts, int npts, float th,
                                      float nnratio, int far_points, float th_far, int* requeried) {

@@ -76,6 +76,12 @@ typedef struct dvmh_tracked_point {
 int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,
                                      const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
                                      const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried);
+/* the same with the current frame's keypoints + descriptors still in HBM where the extractor left them (dvm_orb_last_result): the grid is
+ * built from there when the reference is valid (*grid_from_device = 1), from the host arrays otherwise */
+int dvmh_search_by_projection_frames_dev(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,
+                                         const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
+                                         const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried,
+                                         const dvm_device_frame* dev_c, int* grid_from_device);
 /* SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), :44-205.  claimed_obs[j] != 0 <=> F.mvpMapPoints[j]->Observations() > 0 */
 int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
                                      const float* bounds, const float* scale_factors, int nlevels, const dvmh_tracked_point* pts, int npts, float th,
