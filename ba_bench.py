@@ -144,6 +144,48 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
     return out
 
 
+def run_loop_closed(device: int, iters: int = 10, repeats: int = 20, cpu_iters: int = 2):
+    """Second workload of the BA metric: 500 keyframes / 20 000 landmarks again, but a map AFTER loop closures -- the camera has gone round the loop
+    twice (keyframe i and i + 250 see the same landmarks: bands far off the diagonal of the reduced camera matrix) and 0.2 % of the landmarks carry
+    three long-range observations from anywhere on the loop: 38 % of the 50 x 50 tile pairs are coupled before factorisation (the headline
+    problem: a ring, 7.6 % of the tiles non-zero, 7 elimination levels).  Parity: the first `cpu_iters` iterations against the CPU oracle (its
+    envelope Cholesky is close to dense here: seconds per trial)."""
+    from dvm_slam_amd import capi, synth
+    pr = synth.ba_problem(laps=2, long_range_frac=0.002, long_range_obs=3)
+    e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    delta = float(np.sqrt(5.991))
+    ba = capi.BundleAdjuster(device)
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    ba.optimize(2)
+    dt, its, trials = 0.0, 0, 0
+    for _ in range(repeats):
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        st = ba.optimize(iters)
+        dt += st["ms_optimize"] * 1e-3; its += st["iterations"]; trials += st["total_trials"]
+    info = ba.schedule_info()
+    fl = executed_flops_per_trial(info)
+    out = {"problem": "500 KF / 20 000 landmarks, two laps of the loop + 0.2 % landmarks with 3 long-range observations (synth.ba_problem(laps=2, long_range_frac=0.002))",
+           "observations": len(e), "value": its / dt, "unit": "iterations/s", "iterations": its, "trials": trials, "ms_per_iteration": dt / max(its, 1) * 1e3,
+           "ms_graph_build_excluded": st["ms_structure"], "schedule": info, "tile_fill_of_factor": info["nz_tiles"] / (info["tiles_per_side"] * (info["tiles_per_side"] + 1) / 2),
+           "executed_flop_per_trial": fl, "chi2_initial": st["chi2_initial"], "chi2_final": st["chi2_final"]}
+    if cpu_iters > 0:
+        from oracle import pyoracle as po   # checker + cpu_baseline of this problem
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        sg = ba.optimize(cpu_iters)
+        pg, xg = ba.result()
+        t0 = time.perf_counter()
+        pc, xc, sc, _ = po.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, cpu_iters)
+        tc = time.perf_counter() - t0
+        par = {"iterations_compared": cpu_iters, "trials_equal": bool(sg["trials"] == sc["trials"]), "chi2_rel": abs(sg["chi2_final"] - sc["chi2_final"]) / sc["chi2_final"],
+               "max_abs_pose": float(np.abs(pg - pc).max()), "max_abs_landmark": float(np.abs(xg - xc).max())}
+        out["parity_vs_cpu"] = par
+        out["cpu_baseline"] = {"value": sc["iterations"] / tc, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": f"{sc['iterations']} iterations ({sc['total_trials']} trials), {tc:.1f} s"}
+        if not (par["trials_equal"] and par["chi2_rel"] <= 1e-9 and par["max_abs_pose"] < 1e-6 and par["max_abs_landmark"] < 1e-6):
+            raise RuntimeError(f"loop-closed BA leg: GPU result differs from the CPU oracle: {par}")
+    ba.close()
+    return out
+
+
 def run_sharded(device: int, iters: int = 10, repeats: int = 5):
     """Config 5: the same problem, landmark-sharded over all ranks of the job (every rank calls this).  Returns the record on
     every rank; wall time is the max over ranks."""

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident-input leg (N=1 only)")
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--no-legs", action="store_true", help="skip the per-call legs (latency, lba, ba_cold, merge; N=1 only)")
+    ap.add_argument("--texture", choices=("rich", "low"), default="rich", help="synthetic stream: the BASELINE corner-rich one, or the weakly textured second workload")
     return ap.parse_args()
 
 
@@ -237,7 +238,7 @@ def main():
     nstream = max(a.stream_frames, B)
     nstream = (nstream + B - 1) // B * B
     # every rank is its own agent: a different segment of the camera path
-    frames = synth.frame_stream(nstream, start=exchange.agent_stream_segment(rank, nstream))
+    frames = synth.frame_stream(nstream, start=exchange.agent_stream_segment(rank, nstream), texture=a.texture)
     d_frames = torch.from_numpy(frames).cuda()
     H, W = frames.shape[1:]
 
@@ -446,7 +447,7 @@ def main():
                        "frames_per_step_per_gpu": chunks * B, "frames_per_launch_group": B, "launch_groups_per_step": chunks,
                        "resident_stream_frames": nstream, "nfeatures": 1000, "nlevels": 8, "scale_factor": 1.2,
                        "ini_th_fast": 20, "min_th_fast": 7, "match": "SearchByProjection(Cur,Last) window th=15",
-                       "parallelism": f"agents{world}", "pipeline_lanes": nl,
+                       "parallelism": f"agents{world}", "pipeline_lanes": nl, "stream_texture": a.texture,
                        "ranks": {"count": world, "backend": ("rccl" if backend == "nccl" else backend) if use_dist else "none (single process)",
                                  "cuda_device_of_rank": rank_devices, "launched_by": "bench.py itself (--gpus N without a launcher)"
                                  if os.environ.get("DVM_BENCH_RELAUNCHED") == "1" else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python")}},
@@ -463,6 +464,11 @@ def main():
             try:
                 import ba_bench
                 out["ba"] = ba_bench.run(local, a.ba_iters, cpu_seconds=6.0 if a.cpu_seconds > 0 else 0.0)
+                if world == 1 and not a.no_legs:
+                    try:       # second workload of the BA metric: the same size with loop-closure bands and long-range observations
+                        out["ba"]["loop_closed"] = ba_bench.run_loop_closed(local, a.ba_iters, cpu_iters=2 if a.cpu_seconds > 0 else 0)
+                    except Exception as ex:   # noqa: BLE001
+                        out["ba"]["loop_closed"] = {"error": repr(ex)}
             except ImportError:
                 out["ba"] = None
         if sharded_rec is not None:
@@ -472,6 +478,7 @@ def main():
             import bench_legs
             cpu = a.cpu_seconds > 0
             for name, fn in (("batch_sweep", lambda: bench_legs.batch_sweep()),
+                             ("low_texture", lambda: bench_legs.low_texture(capi, local, cpu=cpu)),
                              ("latency", lambda: bench_legs.latency(capi, frames[:64], local, cpu_calls=24 if cpu else 0)),
                              ("lba", lambda: bench_legs.lba(local, cpu_seconds=4.0 if cpu else 0.0)),
                              ("lba_batch", lambda: bench_legs.lba_batch(local, cpu_windows=4 if cpu else 0)),

@@ -141,6 +141,42 @@ def batch_sweep(batches=(1, 8, 32), steps=3, frames_per_step=4096):
     return out
 
 
+def low_texture(capi, device, cpu=True, steps=3):
+    """Second workload of the extract + match metric (the headline stream is corner-rich: ~8 % of its pixels are FAST corners at iniThFAST, every
+    level fills its keypoint quota): a weakly textured scene (synth.low_texture) -- ~1 % corners, many cells re-run at minThFAST
+    (ORBextractor.cc:664-670), levels short of their quota.  Same pipeline, same batch; parity with the oracle asserted on frames of THIS stream."""
+    import json
+    import subprocess
+    from dvm_slam_amd import synth
+    out = {"unit": "frames/s", "stream": "synth.low_texture through the same camera path; bench.py --texture low (256-frame launch groups, two lanes, frames resident in HBM)"}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--texture", "low", "--steps", str(steps), "--warmup", "1", "--stream-frames", "512", "--no-ba", "--no-legs",
+           "--no-pcie", "--cpu-seconds", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out.update(value=d["value"], ms_per_launch_group=d["ms_per_step"] / d["config"]["launch_groups_per_step"],
+               k_fast_cells={"avg_launch_ms": d["roofline"]["avg_launch_ms"], "achieved_GBps": d["roofline"]["achieved"], "frac_of_hbm_peak": d["roofline"]["frac"],
+                             "exclusive": d["roofline"].get("exclusive")})
+    frames = synth.frame_stream(3, texture="low")
+    ext = capi.OrbExtractor(max_batch=1, device=device)
+    got = [ext.extract(f) for f in frames]
+    ext.close()
+    out["keypoints_per_frame"] = [int(g[0]) for g in got]
+    if cpu:
+        from oracle import pyoracle as po   # checker + cpu_baseline of this stream
+        orc = po.OrbOracle()
+        t0 = time.perf_counter()
+        ref = [orc.extract(f) for f in frames]
+        dt = time.perf_counter() - t0
+        ok = all(g[0] == o[0] and all(np.array_equal(g[1][k], o[1][k]) for k in ("x", "y", "size", "angle", "response", "octave")) and np.array_equal(g[2], o[2])
+                 for g, o in zip(got, ref))
+        out["parity_vs_cpu"] = {"frames": len(frames), "bit_identical": bool(ok)}
+        out["cpu_baseline"] = {"value": len(frames) / dt, "unit": "frames/s (extract only)", "cores": 1, "kind": "port", "sample": f"{len(frames)} frames of this stream"}
+        if not ok:
+            raise RuntimeError("low_texture leg: extraction differs from the CPU oracle")
+    return out
+
+
 def lba(device, iters=10, repeats=40, cpu_seconds=4.0):
     """LocalBundleAdjustment as LocalMapping calls it per keyframe: a covisibility window with anchors."""
     import ba_bench

@@ -93,9 +93,36 @@ def frame_homography(t: int) -> np.ndarray:
     return T1 @ R @ P @ T0
 
 
-def frame_stream(n: int = 256, seed: int = SEED_FRAMES, h: int = HEIGHT, w: int = WIDTH, start: int = 0) -> np.ndarray:
-    """Returns uint8 [n, h, w]."""
-    tex = base_texture(seed)
+def low_texture(seed: int = SEED_FRAMES, h: int = 960, w: int = 1280, nrect: int = 220) -> np.ndarray:
+    """The other end of the data dependence of the extractor: a weakly textured scene (walls, floor, a few objects) -- smooth shading, faint
+    surface noise, a couple of hundred low-contrast patches and only a few strong ones.  Few pixels are FAST corners at iniThFAST = 20 (~1 %
+    against ~8 % of base_texture), many cells have none and are re-run at minThFAST = 7 (ORBextractor.cc:664-670), levels fall short of
+    their keypoint quota."""
+    rng = np.random.default_rng(seed + 77)
+    tex = 90.0 + 70.0 * (0.7 * _value_noise(rng, h, w, 256) + 0.3 * _value_noise(rng, h, w, 64)) + 6.0 * _value_noise(rng, h, w, 3)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for j in range(nrect):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        hw, hh = rng.uniform(8, 90), rng.uniform(8, 90)
+        ang = rng.uniform(0, np.pi) if rng.random() < 0.5 else 0.0
+        strong = j % 9 == 0
+        r = int(np.ceil(np.hypot(hw, hh))) + 1
+        x0, x1 = max(int(cx) - r, 0), min(int(cx) + r + 1, w)
+        y0, y1 = max(int(cy) - r, 0), min(int(cy) + r + 1, h)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        dx = xx[y0:y1, x0:x1] - cx
+        dy = yy[y0:y1, x0:x1] - cy
+        u = dx * np.cos(ang) + dy * np.sin(ang)
+        v = -dx * np.sin(ang) + dy * np.cos(ang)
+        m = (np.abs(u) <= hw) & (np.abs(v) <= hh)
+        tex[y0:y1, x0:x1][m] += rng.uniform(-60, 60) if strong else rng.uniform(-14, 14)
+    return np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+
+
+def frame_stream(n: int = 256, seed: int = SEED_FRAMES, h: int = HEIGHT, w: int = WIDTH, start: int = 0, texture: str = "rich") -> np.ndarray:
+    """Returns uint8 [n, h, w].  texture: "rich" (the BASELINE stream: corner-rich) or "low" (low_texture: few corners, minThFAST cells)."""
+    tex = base_texture(seed) if texture == "rich" else low_texture(seed)
     return np.stack([_warp(tex, frame_homography(start + t), h, w) for t in range(n)])
 
 
@@ -163,16 +190,20 @@ def sim3_from_sRt(s, R, t) -> np.ndarray:
 
 
 def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = SEED_BA, noise_px: float = 1.0,
-               outlier_frac: float = 0.05, radius: float = 50.0):
+               outlier_frac: float = 0.05, radius: float = 50.0, laps: int = 1, long_range_frac: float = 0.0, long_range_obs: int = 3):
     """Synthetic global-BA problem.  Returns a dict of numpy arrays:
 
     poses  [P,7] f64  (tx,ty,tz, qx,qy,qz,qw) world->camera (Tcw), perturbed initial estimate
     poses_gt [P,7], fixed [P] u8 (KF 0 fixed), points [L,3] f64 perturbed, points_gt [L,3],
     edge_pose [E] i32, edge_point [E] i32, obs [E,2] f64, inv_sigma2 [E] f64, intrinsics (fx,fy,cx,cy).
     Every landmark is observed by k_obs consecutive keyframes that see it in-frame.
+    laps > 1: the camera goes round the loop `laps` times (keyframe i and i + n_kf / laps stand at the same place) and a landmark is seen by
+    k_obs / laps consecutive keyframes of EVERY lap -- the co-visibility of a map after loop closures: bands far off the diagonal.
+    long_range_frac: that share of the landmarks is also observed by long_range_obs keyframes anywhere on the loop that have it in view (the
+    wide lens sees across the ring): scattered long-range couplings, as a merged map has them.
     """
     rng = np.random.default_rng(seed)
-    ang = 2 * np.pi * np.arange(n_kf) / n_kf
+    ang = 2 * np.pi * laps * np.arange(n_kf) / n_kf
     centres = np.stack([radius * np.cos(ang), radius * np.sin(ang), np.zeros(n_kf)], axis=1)
     Rcw = np.zeros((n_kf, 3, 3))
     tcw = np.zeros((n_kf, 3))
@@ -201,8 +232,14 @@ def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = 
         v = rng.uniform(60, HEIGHT - 60)
         pc = np.array([(u - CX) / FX * depth, (v - CY) / FY * depth, depth])
         pw = Rcw[a].T @ (pc - tcw[a])
-        first = a - k_obs // 2
-        kfs = [(first + j) % n_kf for j in range(k_obs)]
+        if laps == 1:
+            first = a - k_obs // 2
+            kfs = [(first + j) % n_kf for j in range(k_obs)]
+        else:
+            per = max(1, k_obs // laps)
+            lap_len = n_kf // laps
+            first = a % lap_len - per // 2
+            kfs = [((first + j) % lap_len + lp * lap_len) % n_kf for lp in range(laps) for j in range(per)]
         uv = []
         ok = True
         for kf in kfs:
@@ -215,7 +252,7 @@ def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = 
                 ok = False
                 break
             uv.append((uu, vv))
-        if not ok or len(set(kfs)) != k_obs:
+        if not ok or len(set(kfs)) != len(kfs):
             continue
         pts[l] = pw
         for kf, o in zip(kfs, uv):
@@ -223,6 +260,26 @@ def ba_problem(n_kf: int = 500, n_pts: int = 20000, k_obs: int = 8, seed: int = 
             edge_point.append(l)
             obs.append(o)
         l += 1
+    if long_range_frac > 0:       # (its own generator: the default problem's random stream is untouched)
+        rng2 = np.random.default_rng(seed + 0x10C)
+        have = {}
+        for kf, l2 in zip(edge_pose, edge_point):
+            have.setdefault(l2, set()).add(kf)
+        for l2 in np.flatnonzero(rng2.random(n_pts) < long_range_frac):
+            added = 0
+            for kf in rng2.permutation(n_kf):
+                if added >= long_range_obs:
+                    break
+                if kf in have[l2]:
+                    continue
+                q = Rcw[kf] @ pts[l2] + tcw[kf]
+                if q[2] <= 0.5:
+                    continue
+                uu, vv = FX * q[0] / q[2] + CX, FY * q[1] / q[2] + CY
+                if 0 <= uu < WIDTH and 0 <= vv < HEIGHT:
+                    edge_pose.append(int(kf)); edge_point.append(int(l2)); obs.append((uu, vv)); have[l2].add(int(kf)); added += 1
+        order = np.lexsort((np.asarray(edge_pose), np.asarray(edge_point)))      # landmark-major, as the base problem
+        edge_pose = list(np.asarray(edge_pose)[order]); edge_point = list(np.asarray(edge_point)[order]); obs = list(np.asarray(obs)[order])
     edge_pose = np.asarray(edge_pose, np.int32)
     edge_point = np.asarray(edge_point, np.int32)
     obs = np.asarray(obs, np.float64)
