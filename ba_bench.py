@@ -76,14 +76,28 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
     t_solve = prof["ms_cholesky_solve"] / max(prof["trials"], 1) * 1e-3
     # HBM-side traffic per launch from the committed PMC passes (tools/run_profiles_r03.sh: --pmc FETCH_SIZE / WRITE_SIZE, read side
     # calibrated x2 on known byte counts): the solve's kernels per trial, and the streaming kernels of a trial
-    traffic, pmc_k = None, {}
+    traffic, pmc_k, pmc_src = None, {}, None
     try:
         import json
         import os
-        pmc_k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")))["kernels"]
-        b = lambda k: pmc_k["dvm::" + k]["hbm_bytes_per_launch"]
-        lv = info["levels"]
-        traffic = lv * b("k_chol_diag") + max(lv - 2, 0) * b("k_chol_trsm_update") + b("k_chol_trsm") + b("k_chol_update") + b("k_chol_backsolve")
+        import sys
+        root = os.path.dirname(os.path.abspath(__file__))
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+            try:
+                fold = json.load(open(os.path.join(root, "profiles", cand)))
+                break
+            except Exception:   # noqa: BLE001
+                fold = None
+        pmc_k = fold["kernels"]
+        sys.path.insert(0, os.path.join(root, "tools"))
+        from kernels_sha import kernels_sha
+        sha_now = kernels_sha()
+        pmc_src = {"file": f"profiles/{cand}", "kernels_sha_of_fold": fold.get("kernels_sha"), "kernels_sha_running": sha_now,
+                   "stale": None if not fold.get("kernels_sha") else bool(fold["kernels_sha"] != sha_now)}
+        # the solve = whichever k_chol_* kernels the schedule of THIS build launches: their HBM bytes per LM trial (per-launch bytes x the
+        # dispatches of the profiled run / its trials); folds older than round 4 carry no per-trial figure
+        solve = {k: v["hbm_bytes_per_ba_trial"] for k, v in pmc_k.items() if k.startswith("dvm::k_chol_") and "hbm_bytes_per_ba_trial" in v}
+        traffic = sum(solve.values()) if solve else None
     except Exception:   # noqa: BLE001
         traffic = None
     nblk_pairs = None
@@ -101,10 +115,16 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
     if pmc_k:
         try:
             hbm["landmarks_update_linearise"]["traffic"] = sum(pmc_k["dvm::" + k]["hbm_bytes_per_launch"] for k in ("k_point_backsub", "k_edge_eval", "k_accum"))
-            hbm["schur"] = {"bytes": None, "ms": prof["ms_schur"] / max(prof["trials"], 1), "traffic": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"],
-                            "traffic_GBps": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"] / (prof["ms_schur"] / max(prof["trials"], 1) * 1e-3) / 1e9,
-                            "note": "gathers of W rows: the measured fabric traffic over the event time of the launch"}
-            hbm["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2.0 + WRITE_SIZE, per launch)"
+            # k_schur as a roofline object of its own: algorithmic bytes = every Hpl block W (144 B) read once + the landmark's Dinv (72 B per
+            # landmark) + the non-zero 6x6 blocks written once ("re-reads Hpl 144 B x E = 23 MB")
+            sch_bytes = E * 144 + L * 72 + info["nz_blocks"] * 288
+            sch_ms = prof["ms_schur"] / max(prof["trials"], 1)
+            hbm["schur"] = {"bound": "hbm", "kernel": "k_schur", "bytes": sch_bytes, "ms": sch_ms, "achieved": sch_bytes / (sch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": sch_bytes / (sch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"],
+                            "traffic_over_algorithmic": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"] / sch_bytes,
+                            "traffic_GBps": pmc_k["dvm::k_schur"]["hbm_bytes_per_launch"] / (sch_ms * 1e-3) / 1e9,
+                            "note": "W rows gathered per (edge, edge) pair: the counter traffic above the algorithmic bytes is re-reads of W"}
+            hbm["traffic_source"] = pmc_src
         except Exception:   # noqa: BLE001
             pass
     out = {
@@ -120,7 +140,7 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
                      "achieved": fl / t_solve / 1e12 if t_solve > 0 else None, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl / t_solve / 1e12 / FP64_MATRIX_PEAK_TFLOPS if t_solve > 0 else None,
                      "executed_flop_per_trial": fl, "solve_ms_per_trial": t_solve * 1e3, "schedule": info,
-                     "traffic": traffic,
+                     "traffic": traffic, "traffic_source": pmc_src,
                      "note": "EXECUTED FLOPs of the symbolic tile factorisation (dvm_ba_schedule_info) over the HIP-event time of the "
                              "factorisation + back substitution launches of a trial.  The solve is a dependency chain of elimination-tree "
                              "levels (diagonal tiles -> strips -> update per level), not matrix-pipe bound; dense-equivalent (n^3/3 per trial over the "

@@ -382,7 +382,7 @@ def main():
             ach = BYTES_PER_FRAME_FAST * frames_per_launch / per_launch_s / 1e9
             traffic = None
             pmc, pmc_file = None, None
-            for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
+            for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                     pmc_file = cand
@@ -394,6 +394,16 @@ def main():
                     traffic = pmc["kernels"]["dvm::k_fast_cells"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
+            # which build the quoted counters were taken on (tools/kernels_sha.py, stamped into the fold when it is collected) against the build
+            # that is running: `stale` says the fold describes OTHER kernels than the ones just timed
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from kernels_sha import kernels_sha
+                sha_now = kernels_sha()
+            except Exception:   # noqa: BLE001
+                sha_now = None
+            pmc_src = {"file": f"profiles/{pmc_file}" if pmc_file else None, "kernels_sha_of_fold": (pmc or {}).get("kernels_sha"), "kernels_sha_running": sha_now,
+                       "stale": None if not pmc or not (pmc or {}).get("kernels_sha") or not sha_now else bool(pmc["kernels_sha"] != sha_now)}
             valu = None
             try:  # VALU issue time of one 256-frame launch group from the committed SQ_INSTS_VALU pass
                 if pmc["batch"] == frames_per_launch:
@@ -407,11 +417,23 @@ def main():
                               for k, n in per_chunk.items())
                     issue_ms = cyc / (1024 * 2.4e9) * 1e3
                     ms2, ms4 = wi * 2.25 / (1024 * 2.4e9) * 1e3, wi * 4.15 / (1024 * 2.4e9) * 1e3
-                    valu = {"frac": issue_ms / chunk_ms, "issue_ms_per_launch_group": issue_ms, "launch_group_ms": chunk_ms,
+                    # the COUNTER: SQ_ACTIVE_INST_VALU (quad-cycles of VALU execution, chip-wide) x 4 / (1024 SIMDs x the launch's cycles), per kernel of the
+                    # profiled pass, weighted by the kernels' launches in a launch group
+                    busy = None
+                    try:
+                        num = sum(pmc["kernels"][k]["valu_busy_frac_counter"] * pmc["kernels"][k]["profiled_duration_us"] * n for k, n in per_chunk.items())
+                        den = sum(pmc["kernels"][k]["profiled_duration_us"] * n for k, n in per_chunk.items())
+                        busy = {"frac_of_kernel_time": num / den, "k_fast_cells": pmc["kernels"]["dvm::k_fast_cells"]["valu_busy_frac_counter"],
+                                "per_kernel": {k.replace("dvm::", ""): pmc["kernels"][k]["valu_busy_frac_counter"] for k in per_chunk},
+                                "note": "counter-based: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch cycles) of the profiled pass (kernel-trace duration x the clock GRBM_GUI_ACTIVE gives)"}
+                    except Exception:   # noqa: BLE001
+                        busy = None
+                    valu = {"kind": "model (static instruction mix x dynamic SQ_INSTS_VALU)", "counter_valu_busy": busy,
+                            "frac": issue_ms / chunk_ms, "issue_ms_per_launch_group": issue_ms, "launch_group_ms": chunk_ms,
                             "wave_instr_per_launch_group": wi, "mean_issue_cycles_per_wave_instr": cyc / wi,
                             "per_kernel_issue_ms": {k.replace("dvm::", ""): pmc["kernels"][k]["valu_wave_instr_per_launch"] * pmc["kernels"][k].get("mean_issue_cycles_per_valu_instr", 4.15) * n
                                                     / (1024 * 2.4e9) * 1e3 for k, n in per_chunk.items()},
-                            "bounds_if_all_full_rate_or_all_half_rate": [ms2 / chunk_ms, ms4 / chunk_ms], "source": f"profiles/{pmc_file} + profiles/r03_valu_mix.json",
+                            "bounds_if_all_full_rate_or_all_half_rate": [ms2 / chunk_ms, ms4 / chunk_ms], "source": f"profiles/{pmc_file} + its valu_mix",
                             "note": "VALU issue time of one 256-frame launch group / its wall time.  Issue time = sum over kernels of SQ_INSTS_VALU (dynamic, "
                                     "rocprofv3 --pmc) x the mean cycles per wave-instruction of the kernel's static instruction mix, each mnemonic priced by the "
                                     "issue cost measured on this GPU at 8 waves per SIMD (profiles/r02_valu_issue*.jsonl: 2.25 full-rate integer / f32 add-mul, 4.15 "
@@ -420,7 +442,7 @@ def main():
             except Exception:
                 valu = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
                     "bytes_per_launch": BYTES_PER_FRAME_FAST * frames_per_launch, "avg_launch_ms": fast_ms / fast_n,
                     "frames_per_launch": frames_per_launch,
                     "all_stage_bytes_per_frame": BYTES_PER_FRAME_TOTAL,

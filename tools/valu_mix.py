@@ -88,7 +88,7 @@ def kernels_of(src):
 
 def main():
     out = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "cost_cycles": COST, "kernels": {}}
-    for src in ("orb_kernels.hip", "octree_kernel.hip", "match_kernels.hip", "ba_kernels.hip"):
+    for src in ("orb_kernels.hip", "octree_kernel.hip", "match_kernels.hip", "ba_kernels.hip", "ba_window.hip"):
         out["kernels"].update(kernels_of(src))
     js = json.dumps(out, indent=1)
     if len(sys.argv) > 1:
