@@ -7,6 +7,7 @@
 
 namespace dvm {
 
+constexpr int kSchurLmLandmarks = 32, kSchurLmRows = 256, kSchurLmPairs = 1536, kSchurLmRuns = 512;   // a chunk of k_schur_lm: W rows 37 KB + Dinv + its index lists = 50 KB of LDS, three workgroups per CU (750 workgroups for the 500-keyframe problem: one round)
 constexpr int kEdgeLinStride = 16;  // doubles per edge and array (one 128-byte line each): e_lin = B[12] w wr0 wr1 + pad (what the camera
                                     // accumulation reads), e_linA = A[6] w wr0 wr1 + pad (what the landmark accumulation reads).  As ONE 192-byte row both
                                     // gathers dragged 2-3 lines per edge through the memory system: ~100 MB for 30 MB of operands
@@ -43,6 +44,17 @@ struct BaView {
   const int32_t *pair_k1, *pair_k2;            // per block: (edge of i1, edge of i2) sharing a landmark
   const int32_t* pair_pt;    // [npairs] landmark of the pair (= e_point[pair_k1]): spares the gather kernel a dependent load
   int32_t schur_wide;        // 1: few blocks with long pair lists (a local-BA window) -- k_schur with 8 waves per block instead of 2
+  // Landmark-chunk form of the Schur complement (k_schur_lm + k_schur_reduce; an experiment, built and used only under DVM_BA_SCHUR_LM=1):
+  // the landmarks, sorted by their first camera, in chunks of <= kSchurLmLandmarks landmarks / <= kSchurLmRows free-camera rows.
+  int32_t n_slc, n_slrun;    // chunks; runs (= partial 6x6 blocks) over all chunks
+  const int32_t* sl_desc;    // [n_slc][8]: row offset, rows, landmark offset, landmarks, pair offset, pairs, run offset, runs
+  const int32_t* sl_row_edge;   // per chunk row: the (local) edge whose W row it is
+  const int32_t* sl_row_lm;     // per chunk row: its landmark's slot in the chunk
+  const int32_t* sl_lm;         // per chunk landmark slot: the landmark
+  const int32_t* sl_pairs;      // per chunk, sorted by block: row1 | row2 << 9 | landmark slot << 18
+  const int32_t* sl_runs;       // per run: block, first pair (index inside the chunk); one sentinel per chunk
+  double* sl_part;              // [n_slrun][36] partial blocks, summed per block in chunk order by k_schur_reduce
+  const int32_t *bp_start, *bp_slots;   // per block: its runs (global run indices), ascending chunk
   double* S;                // [ldS][ldS] dense lower triangle + augmented rhs row
   double* Linv;             // [ldS/64][64*64] inverses of the factored diagonal blocks
   double* ytmp;             // [n_pad + 64] doubles, used as int32 words: [0] ticket, [1 + k] hand-off flag of tile column k

@@ -752,6 +752,110 @@ __global__ void __launch_bounds__(64 * kNW) k_schur(BaView V, int nb_blk, int nb
   if (g < nb_blk) schur_blocks_body<kSchurWaves>(V, g);
 }
 
+// ---- the landmark-chunk form (BaView::sl_*).  Workgroup = one chunk of landmarks (<= 64 landmarks, <= 512 free-camera rows): its W rows go
+// to LDS once -- a row is then used by every pair it is in, where the per-block form fetched it once per pair --, each landmark's Dinv too; the
+// chunk's (edge, edge) pairs are listed by block, and a work item is row a of one block's run: W1 Dinv (three values per pair, formed on the
+// fly) against the six rows of W2, summed over the run's pairs in landmark order into one partial 6x6 block.  k_schur_reduce adds a block's
+// partials in chunk order, negates, adds Hpp + lambda I on the diagonal and writes the block into tile space.  Both orders are fixed.
+__global__ void __launch_bounds__(256) k_schur_lm(BaView V, int nb_rhs, int* __restrict__ fail_reset) {
+  if (fail_reset) {
+    if (*V.lambda < 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fail_reset = 0;
+  }
+  if ((int)blockIdx.x < nb_rhs) {      // (a local-BA window: one camera per workgroup, its ~500 edges dealt over the four waves)
+    if (V.schur_wide) schur_rhs_body<4, true>(V, blockIdx.x); else schur_rhs_body<4, false>(V, blockIdx.x);
+    return;
+  }
+  extern __shared__ double sl_lds[];
+  const int c = (int)blockIdx.x - nb_rhs, tid = threadIdx.x;
+  const int32_t* d = V.sl_desc + 8 * (size_t)c;
+  const int row_off = d[0], nrows = d[1], lm_off = d[2], nlm = d[3], pair_off = d[4], run_off = d[6], nruns = d[7];
+  const int npairs = d[5];
+  double* Wb = sl_lds;                                  // [nrows][18]
+  double* Di = Wb + (size_t)kSchurLmRows * 18;          // [nlm][9]
+  int32_t* pairs = reinterpret_cast<int32_t*>(Di + kSchurLmLandmarks * 9);   // [npairs]  (in LDS: a pair step must not be a round trip to L2)
+  int32_t* runs = pairs + kSchurLmPairs;                // [nruns + 1][2]
+  // W rows: nine 16-byte pieces per row, consecutive lanes take consecutive pieces.  All of a thread's loads go out before the first LDS
+  // store: a copy loop (index load -> row load -> ds_write per iteration) paid two round trips to L2 fourteen times over, 26 of the 65 us
+  // this kernel took
+  {
+    constexpr int kIt = (kSchurLmRows * 9 + 255) / 256;
+    int32_t ek[kIt];
+#pragma unroll
+    for (int u = 0; u < kIt; u++) { const int i = tid + 256 * u; ek[u] = i < nrows * 9 ? V.sl_row_edge[row_off + i / 9] : -1; }
+    double2 wv[kIt];
+#pragma unroll
+    for (int u = 0; u < kIt; u++) {
+      const int i = tid + 256 * u;
+      if (ek[u] >= 0) wv[u] = *reinterpret_cast<const double2*>(V.e_W + (size_t)ek[u] * 18 + 2 * (i % 9));
+    }
+    constexpr int kPt = (kSchurLmPairs + 255) / 256, kLt = (kSchurLmLandmarks * 9 + 255) / 256, kUt = (2 * (kSchurLmRuns + 1) + 255) / 256;
+    int32_t pv[kPt], lv[kLt], uv[kUt];
+#pragma unroll
+    for (int u = 0; u < kPt; u++) { const int i = tid + 256 * u; pv[u] = i < npairs ? V.sl_pairs[pair_off + i] : 0; }
+#pragma unroll
+    for (int u = 0; u < kLt; u++) { const int i = tid + 256 * u; lv[u] = i < nlm * 9 ? V.sl_lm[lm_off + i / 9] : -1; }
+#pragma unroll
+    for (int u = 0; u < kUt; u++) { const int i = tid + 256 * u; uv[u] = i < 2 * (nruns + 1) ? V.sl_runs[2 * (size_t)run_off + i] : 0; }
+    double dv[kLt];
+#pragma unroll
+    for (int u = 0; u < kLt; u++) { const int i = tid + 256 * u; if (lv[u] >= 0) dv[u] = V.Dinv[9 * (size_t)lv[u] + i % 9]; }
+#pragma unroll
+    for (int u = 0; u < kIt; u++) {
+      const int i = tid + 256 * u;
+      if (ek[u] >= 0) { const int r = i / 9, part = i - 9 * r; Wb[18 * r + 2 * part] = wv[u].x; Wb[18 * r + 2 * part + 1] = wv[u].y; }
+    }
+#pragma unroll
+    for (int u = 0; u < kPt; u++) { const int i = tid + 256 * u; if (i < npairs) pairs[i] = pv[u]; }
+#pragma unroll
+    for (int u = 0; u < kLt; u++) { const int i = tid + 256 * u; if (lv[u] >= 0) Di[i] = dv[u]; }
+#pragma unroll
+    for (int u = 0; u < kUt; u++) { const int i = tid + 256 * u; if (i < 2 * (nruns + 1)) runs[i] = uv[u]; }
+  }
+  __syncthreads();
+  double* part0 = V.sl_part + 36 * (size_t)(run_off - c);          // (run_off counts one sentinel per earlier chunk)
+  for (int t = tid; t < 6 * nruns; t += 256) {
+    const int ru = t / 6, a = t - 6 * ru;
+    const int q0 = runs[2 * ru + 1], q1 = runs[2 * ru + 3];
+    double sv[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = q0; q < q1; q++) {
+      const int pr = pairs[q], r1 = pr & 511, r2 = (pr >> 9) & 511;
+      const double* W1 = Wb + 18 * r1 + 3 * a;
+      const double* D = Di + 9 * (pr >> 18);
+      const double* W2 = Wb + 18 * r2;
+      const double w0 = W1[0], w1 = W1[1], w2 = W1[2];
+      const double d0 = w0 * D[0] + w1 * D[3] + w2 * D[6], d1 = w0 * D[1] + w1 * D[4] + w2 * D[7], d2 = w0 * D[2] + w1 * D[5] + w2 * D[8];
+#pragma unroll
+      for (int b = 0; b < 6; b++) sv[b] += d0 * W2[3 * b] + d1 * W2[3 * b + 1] + d2 * W2[3 * b + 2];
+    }
+    double* o = part0 + 36 * (size_t)ru + 6 * a;
+#pragma unroll
+    for (int b = 0; b < 6; b++) o[b] = sv[b];
+  }
+}
+__global__ void __launch_bounds__(256) k_schur_reduce(BaView V) {
+  if (V.lambda && *V.lambda < 0) return;                // (speculative launch behind a rejected trial)
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 36 * V.nblk) return;
+  const int blk = t / 36, e = t - 36 * blk, ra = e / 6, cb = e - 6 * ra;
+  double v = 0;
+  const int q0 = V.bp_start[blk], q1 = V.bp_start[blk + 1];
+  for (int q = q0; q < q1; q += 8) {                    // eight partials at a time: their slots, then their values, then the eight additions in order
+    int32_t sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) sl[j] = q + j < q1 ? V.bp_slots[q + j] : -1;
+    double pv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) pv[j] = sl[j] >= 0 ? V.sl_part[36 * (size_t)sl[j] + e] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v += pv[j];             // (+0.0 beyond the list: exact)
+  }
+  v = -v;
+  const int i1 = V.blk_i1[blk], i2 = V.blk_i2[blk];
+  if (i1 == i2) v += V.Hpp[36 * (size_t)i1 + e] + (ra == cb ? ba_lambda(V) * V.damp_s : 0.0);
+  V.S[(size_t)(ba_row(i1) + ra) * V.ldS + ba_row(i2) + cb] = v;
+}
+
 // clears the structurally non-zero tiles of S (a trial rebuilds them); everything else is never touched and stays zero
 // from the allocation-time memset: 197 of 1 326 tiles = 6 MB instead of 85 MB at 500 keyframes
 __global__ void __launch_bounds__(256) k_zero_tiles(double* __restrict__ S, int ldS, const int32_t* __restrict__ nz) {
@@ -2650,6 +2754,15 @@ void ba_launch_max_diag(hipStream_t s, const BaView& V, const BaPublish& pub) {
   hipLaunchKernelGGL(k_max_diag, dim3(cdiv(std::max(3 * V.L, 6 * V.nfree), 256)), dim3(256), 0, s, V, pub);
 }
 static void launch_schur_kernel(hipStream_t s, const BaView& V, int* fail_reset) {
+  if (V.n_slc > 0) {     // the landmark-chunk form (built by dvm_ba_set_problem only under DVM_BA_SCHUR_LM=1: measured slower)
+    const int nb_rhs = V.schur_wide ? V.nfree : cdiv(V.nfree, 4);
+    const size_t lds = sizeof(double) * ((size_t)kSchurLmRows * 18 + kSchurLmLandmarks * 9) + sizeof(int32_t) * (kSchurLmPairs + 2 * (kSchurLmRuns + 1));
+    static bool raised = false;
+    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+    hipLaunchKernelGGL(k_schur_lm, dim3(nb_rhs + V.n_slc), dim3(256), lds, s, V, nb_rhs, fail_reset);
+    hipLaunchKernelGGL(k_schur_reduce, dim3(cdiv(36 * V.nblk, 256)), dim3(256), 0, s, V);
+    return;
+  }
   const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
   const int nw = V.schur_wide ? kSchurWavesWide : kSchurWaves;
   const int nb_rhs = ((V.schur_wide ? V.nfree : cdiv(V.nfree, nw)) + 7) & ~7;   // (wide: a workgroup per camera) a multiple of 8 keeps the XCD phase of the block workgroups

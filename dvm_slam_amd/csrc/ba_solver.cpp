@@ -382,6 +382,83 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   }
   V.nblk = (int)blk_i1.size();
   const int n = 6 * V.nfree;
+  // ---- landmark-chunk form of the Schur complement.  The per-block form gathers W1 | W2 | Dinv per (edge, edge) pair: 360 B for a pair,
+  // 260 MB for the 720 k pairs of the 500-keyframe problem, of which 77 MB come from HBM -- every W row is fetched once per pair it
+  // is in.  Here a workgroup takes a chunk of landmarks, loads their W rows ONCE (23 MB in all) and forms every pair product of those
+  // landmarks from LDS; what a chunk contributes to a block is one partial 6x6 block (a "run"), and a second small launch adds a
+  // block's runs in chunk order (a fixed order: no atomics).  Landmarks are sorted by their first camera, so a chunk touches the few
+  // blocks of neighbouring cameras and a block collects from few chunks.
+  std::vector<int32_t> sl_desc, sl_row_edge, sl_row_lm, sl_lm, sl_pairs, sl_runs, bp_start(V.nblk + 1, 0), bp_slots;
+  V.n_slc = V.n_slrun = 0;
+  if (std::getenv("DVM_BA_SCHUR_LM")) {        // experiment switch: 54 + 7 us against the per-block form's 53 us on the 500-keyframe problem
+    std::unordered_map<uint64_t, int32_t> blk_of;
+    blk_of.reserve((size_t)V.nblk * 2);
+    for (int b = 0; b < V.nblk; b++) blk_of[((uint64_t)blk_i1[b] << 32) | (uint32_t)blk_i2[b]] = b;
+    std::vector<std::pair<int32_t, int32_t>> lms;       // (first camera position, landmark) of every landmark with a free-camera edge here
+    for (int l = 0; l < L; l++) {
+      int first = 1 << 30;
+      for (int a = pt_start[l]; a < pt_start[l + 1]; a++) { const int fi = pidx[e_pose[pt_edges[a]]]; if (fi >= 0) first = std::min(first, fi); }
+      if (first < (1 << 30)) lms.push_back({first, l});
+    }
+    std::sort(lms.begin(), lms.end());
+    std::vector<std::pair<int32_t, int32_t>> run_of_blk;   // (block, global run index), for the per-block lists
+    size_t i = 0;
+    bool chunks_ok = true;
+    while (i < lms.size() && chunks_ok) {
+      const int32_t row_off = (int32_t)sl_row_edge.size(), lm_off = (int32_t)sl_lm.size(), pair_off = (int32_t)sl_pairs.size(), run_off = (int32_t)sl_runs.size() / 2;
+      int nrows = 0, nlm = 0, nrun_bound = 0;
+      std::vector<std::pair<int32_t, int32_t>> pr;      // (block, row1 | row2 << 9 | landmark slot << 18)
+      std::vector<int32_t> seen_blk;
+      while (i < lms.size() && nlm < kSchurLmLandmarks) {
+        const int l = lms[i].second;
+        int deg = 0;
+        for (int a = pt_start[l]; a < pt_start[l + 1]; a++) deg += pidx[e_pose[pt_edges[a]]] >= 0;
+        if (deg > kSchurLmRows || deg * (deg + 1) / 2 > std::min(kSchurLmPairs, kSchurLmRuns)) { chunks_ok = false; break; }   // a landmark seen by > 44 free cameras: the per-block form takes the problem
+        // the chunk's limits: rows and pairs (LDS), and blocks -- a landmark of degree d can open d (d + 1) / 2 new runs at most
+        if (nrows + deg > kSchurLmRows || (int)pr.size() + deg * (deg + 1) / 2 > kSchurLmPairs || nrun_bound + deg * (deg + 1) / 2 > kSchurLmRuns) { if (nlm > 0) break; }
+        const int r0 = nrows;
+        for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
+          const int k = pt_edges[a];
+          if (pidx[e_pose[k]] < 0) continue;
+          sl_row_edge.push_back(k); sl_row_lm.push_back(nlm); nrows++;
+        }
+        // block_solver.hpp:381-439: edge k1 (outer) x edge k2 (inner) of the landmark, lower blocks only
+        for (int q1 = r0; q1 < nrows; q1++)
+          for (int q2 = r0; q2 < nrows; q2++) {
+            const int i1 = pidx[e_pose[sl_row_edge[row_off + q1]]], i2 = pidx[e_pose[sl_row_edge[row_off + q2]]];
+            if (i2 > i1) continue;
+            const int32_t bid = blk_of[((uint64_t)i1 << 32) | (uint32_t)i2];
+            pr.push_back({bid, q1 | (q2 << 9) | (nlm << 18)});
+            seen_blk.push_back(bid);
+          }
+        std::sort(seen_blk.begin(), seen_blk.end());
+        seen_blk.erase(std::unique(seen_blk.begin(), seen_blk.end()), seen_blk.end());
+        nrun_bound = (int)seen_blk.size();
+        sl_lm.push_back(l); nlm++; i++;
+      }
+      std::stable_sort(pr.begin(), pr.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
+      int nruns = 0;
+      for (size_t j = 0; j < pr.size(); j++) {
+        if (j == 0 || pr[j].first != pr[j - 1].first) {
+          run_of_blk.push_back({pr[j].first, (int32_t)sl_runs.size() / 2 - (int32_t)(sl_desc.size() / 8)});   // global run index = position minus the sentinels before it
+          sl_runs.push_back(pr[j].first); sl_runs.push_back((int32_t)j); nruns++;
+        }
+        sl_pairs.push_back(pr[j].second);
+      }
+      sl_runs.push_back(-1); sl_runs.push_back((int32_t)pr.size());      // sentinel: where the chunk's last run ends
+      const int32_t d[8] = {row_off, nrows, lm_off, nlm, pair_off, (int32_t)pr.size(), run_off, nruns};
+      sl_desc.insert(sl_desc.end(), d, d + 8);
+    }
+    if (!chunks_ok) { sl_desc.clear(); sl_row_edge.clear(); sl_row_lm.clear(); sl_lm.clear(); sl_pairs.clear(); sl_runs.clear(); run_of_blk.clear(); }
+    V.n_slc = (int)sl_desc.size() / 8;
+    V.n_slrun = (int)run_of_blk.size();
+    for (const auto& rb : run_of_blk) bp_start[rb.first + 1]++;
+    for (int b = 0; b < V.nblk; b++) bp_start[b + 1] += bp_start[b];
+    bp_slots.resize(run_of_blk.size());
+    std::vector<int32_t> fillp(bp_start.begin(), bp_start.end() - 1);
+    for (const auto& rb : run_of_blk) bp_slots[fillp[rb.first]++] = rb.second;     // run_of_blk is in chunk order: so is every block's list
+  }
+  mark("landmark chunks");
   // ---- tile space: 10 whole cameras per 64-row tile, one extra tile for the augmented rhs row
   const int ncamt = (V.nfree + kCamsPerTile - 1) / kCamsPerTile, nkb = ncamt + 1;
   V.n_pad = 64 * ncamt;
@@ -419,6 +496,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     ok(h->upload(&V.pt_fi, pt_fi));
   }
   ok(h->upload(&V.ps_start, ps_start)); ok(h->upload(&V.ps_edges, ps_edges));
+  ok(h->upload(&V.sl_desc, sl_desc)); ok(h->upload(&V.sl_row_edge, sl_row_edge)); ok(h->upload(&V.sl_row_lm, sl_row_lm)); ok(h->upload(&V.sl_lm, sl_lm));
+  ok(h->upload(&V.sl_pairs, sl_pairs)); ok(h->upload(&V.sl_runs, sl_runs)); ok(h->upload(&V.bp_start, bp_start)); ok(h->upload(&V.bp_slots, bp_slots));
+  ok(h->dalloc(&V.sl_part, 36 * (size_t)std::max(V.n_slrun, 1)));
   ok(h->upload(&V.blk_i1, blk_i1)); ok(h->upload(&V.blk_i2, blk_i2)); ok(h->upload(&V.blk_start, blk_start));
   ok(h->upload(&V.pair_k1, pair_k1)); ok(h->upload(&V.pair_k2, pair_k2));
   V.schur_wide = (V.nblk > 0 && V.nblk <= 512 && pair_k1.size() / (size_t)V.nblk >= 192) ? 1 : 0;   // few blocks, long pair lists: see k_schur
