@@ -36,7 +36,7 @@ done
 rm -rf /tmp/p4 && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p4 -- $SHORT > $O/pmc_SQ.log 2>&1
 python -c "$FOLD" "$(find /tmp/p4 -name '*counter_collection.csv' | head -1)" $O/r04_pmc_sq_counters.csv
 cp "$(find /tmp/p4 -name '*kernel_trace.csv' | head -1)" $O/r04_pmc_sq_kernel_trace.csv 2>/dev/null
-TR=$(tail -1 $O/pmc_ba_FETCH_SIZE.log | awk '{print $2}')
+TR=$(grep "^trials" $O/pmc_ba_FETCH_SIZE.log | tail -1 | awk "{print \$2}")
 python $R/tools/valu_mix.py $O/r04_valu_mix.json > $O/valu_mix.log 2>&1 || cp $R/profiles/r03_valu_mix.json $O/r04_valu_mix.json
 python $R/tools/pmc_traffic.py --fetch $O/r04_pmc_FETCH_SIZE.csv $O/r04_pmc_ba_FETCH_SIZE.csv --write $O/r04_pmc_WRITE_SIZE.csv $O/r04_pmc_ba_WRITE_SIZE.csv \
    --sq $O/r04_pmc_sq_counters.csv --sq-trace $O/r04_pmc_sq_kernel_trace.csv --calib-fetch $O/r04_pmc_calib_FETCH_SIZE.csv --calib-write $O/r04_pmc_calib_WRITE_SIZE.csv \
