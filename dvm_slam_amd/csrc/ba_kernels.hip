@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "ba_kernels.h"
+#include "f64_spec.h"
 #include "jacobi4.h"
 
 namespace dvm {
@@ -79,7 +80,9 @@ __device__ __forceinline__ void se3_oplus(double* T, const double* u) {
 #pragma unroll
     for (int k = 0; k < 9; k++) { R[k] = ((k % 4 == 0) ? 1.0 : 0.0) + O[k] + O2[k]; Vm[k] = R[k]; }
   } else {
-    const double a = sin(theta) / theta, bb = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+    // sin / cos / pow(theta, 3) of SE3Quat::exp: the double-precision spec the oracle evaluates too (csrc/f64_spec.h), not the device libm
+    const double sn = f64_sin(theta), cs = f64_cos(theta);
+    const double a = sn / theta, bb = (1 - cs) / (theta * theta), c = (theta - sn) / f64_cube(theta);
 #pragma unroll
     for (int k = 0; k < 9; k++) {
       const double I = (k % 4 == 0) ? 1.0 : 0.0;

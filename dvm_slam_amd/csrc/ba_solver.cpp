@@ -20,6 +20,7 @@
 
 #include "../../include/dvmslam_hip.h"
 #include "ba_kernels.h"
+#include "f64_spec.h"
 #include "ba_ordering.h"
 #include "host_stage.h"
 #include "orb_pipeline.h"  // set_error / hip_check / DVM_HIP
@@ -924,7 +925,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        double alpha = 1. - dvm::f64_cube(2 * rho - 1);   // pow(2 rho - 1, 3) as the spec both sides share (csrc/f64_spec.h: the correctly rounded cube)
         alpha = std::min(alpha, 2. / 3.);
         lambda *= std::max(1. / 3., alpha);
         ni = 2;
