@@ -393,13 +393,14 @@ int dvm_frame_build(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8
   // stream); the kernel follows on the legacy default stream.  The call returns once the grid is built: a consumer on a
   // NON-BLOCKING stream (the ORB pipeline's and the BA's streams are, and on_device = 1 callers pass any stream) is not
   // ordered behind the default stream and could otherwise read a half-built grid (~10 us for a 1000-keypoint frame)
+  // (keypoints and descriptors are read once each by k_frame_build: mapped, no copy in front of the kernel)
   Stage st;
-  const int iK = st.in(kps, (size_t)n * sizeof(dvm_keypoint)), iD = st.in(desc, (size_t)n * 32);
+  const int iK = st.in_mapped(kps, (size_t)n * sizeof(dvm_keypoint)), iD = st.in_mapped(desc, (size_t)n * 32);
   rc = st.upload();
   if (rc != DVM_OK) return rc;
-  launch_frame_build(nullptr, st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iD), 0, n, nullptr, f->view, slot, 1);
+  launch_frame_build(st.stream(), st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iD), 0, n, nullptr, f->view, slot, 1);
   rc = hip_check(hipGetLastError(), "frame_build launch");
-  return rc == DVM_OK ? hip_check(hipStreamSynchronize(nullptr), "frame_build") : rc;
+  return rc == DVM_OK ? hip_check(hipStreamSynchronize(st.stream()), "frame_build") : rc;
 }
 int dvm_frame_overflows(dvm_frame* f, int32_t* count) {
   if (!f || !count) return DVM_ERR_INVALID;
@@ -438,16 +439,48 @@ int dvm_match_window_top2(const dvm_frame* train, int slot, const uint8_t* skip,
   // host convenience path: stage queries, run, copy back
   const size_t qb = (size_t)nq;
   Stage st;
-  const int iD = st.in(qdesc, qb * 32), iX = st.in(qx, qb * 4), iY = st.in(qy, qb * 4), iR = st.in(qr, qb * 4), iMin = st.in(qmin, qb * 4),
-            iMax = st.in(qmax, qb * 4), iS = st.in(skip, (size_t)train->cap), oM = st.out(out, qb * sizeof(dvm_match)),
-            oS = second_idx ? st.out(second_idx, qb * 4) : -1;
+  // the query arrays are read once and the results written once: mapped; the skip flags are looked up per candidate: copied
+  const int iD = st.in_mapped(qdesc, qb * 32), iX = st.in_mapped(qx, qb * 4), iY = st.in_mapped(qy, qb * 4), iR = st.in_mapped(qr, qb * 4),
+            iMin = st.in_mapped(qmin, qb * 4), iMax = st.in_mapped(qmax, qb * 4), iS = st.in(skip, (size_t)train->cap),
+            oM = st.out_mapped(out, qb * sizeof(dvm_match)), oS = second_idx ? st.out_mapped(second_idx, qb * 4) : -1;
   rc = st.upload();
   if (rc != DVM_OK) return rc;
-  launch_match_window(nullptr, train->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
+  launch_match_window(st.stream(), train->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
                       st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, nullptr, nq, st.ptr<dvm_match_pod>(oM),
                       second_idx ? st.ptr<int32_t>(oS) : nullptr);
   rc = hip_check(hipGetLastError(), "match launch");
   return rc == DVM_OK ? st.download() : rc;
+}
+int dvm_frame_build_match_window_top2(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
+                                      float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
+                                      const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                      const int32_t* qmax, int nq, dvm_match* out, int32_t* second_idx) {
+  if (!f || slot < 0 || slot >= f->slots || n < 0 || n > f->cap || (n && (!kps || !desc)) || nq < 0) return DVM_ERR_INVALID;
+  if (nq && (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !out)) return DVM_ERR_INVALID;
+  int rc = frame_bounds(f, minX, maxX, minY, maxY);
+  if (rc != DVM_OK) return rc;
+  rc = hip_check(hipSetDevice(f->device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  const size_t qb = (size_t)nq;
+  Stage st;
+  const int iK = st.in_mapped(kps, (size_t)n * sizeof(dvm_keypoint)), iDs = st.in_mapped(desc, (size_t)n * 32);
+  const int iD = st.in_mapped(qdesc, qb * 32), iX = st.in_mapped(qx, qb * 4), iY = st.in_mapped(qy, qb * 4), iR = st.in_mapped(qr, qb * 4),
+            iMin = st.in_mapped(qmin, qb * 4), iMax = st.in_mapped(qmax, qb * 4), iS = st.in(skip, (size_t)f->cap),
+            oM = st.out_mapped(out, qb * sizeof(dvm_match)), oS = second_idx ? st.out_mapped(second_idx, qb * 4) : -1;
+  rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_frame_build(st.stream(), st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iDs), 0, n, nullptr, f->view, slot, 1);
+  if (nq)
+    launch_match_window(st.stream(), f->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
+                        st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, nullptr, nq, st.ptr<dvm_match_pod>(oM),
+                        second_idx ? st.ptr<int32_t>(oS) : nullptr);
+  rc = hip_check(hipGetLastError(), "frame_build + match launch");
+  return rc == DVM_OK ? st.download() : rc;   // (download() synchronises the stream: the grid is complete for any later consumer)
+}
+void* dvm_thread_stream(int device) {
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  StageCtx& c = stage_ctx();
+  return c.ensure(16) == DVM_OK ? (void*)c.s : nullptr;
 }
 int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                      const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,

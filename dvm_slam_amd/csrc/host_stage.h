@@ -21,11 +21,26 @@ struct StageCtx {
   hipStream_t s = nullptr;
   uint8_t *h = nullptr, *d = nullptr;
   size_t hcap = 0, dcap = 0;
+  uint8_t *hm = nullptr, *hm_dev = nullptr;   // mapped pinned buffer (items the kernels read / write in place over PCIe) and its device address
+  size_t hmcap = 0;
   void release() {
     if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); }
     if (h) hipHostFree(h);
+    if (hm) hipHostFree(hm);
     if (d) hipFree(d);
-    s = nullptr; h = d = nullptr; hcap = dcap = 0;
+    s = nullptr; h = d = hm = hm_dev = nullptr; hcap = dcap = hmcap = 0;
+  }
+  int ensure_mapped(size_t bytes) {
+    if (bytes <= hmcap) return DVM_OK;
+    if (hm) hipHostFree(hm);
+    hm = hm_dev = nullptr; hmcap = 0;
+    const size_t cap = std::max<size_t>(bytes * 2, (size_t)1 << 20);
+    int rc = hip_check(hipHostMalloc(reinterpret_cast<void**>(&hm), cap, hipHostMallocMapped), "hipHostMalloc");
+    if (rc != DVM_OK) return rc;
+    rc = hip_check(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm_dev), hm, 0), "hipHostGetDevicePointer");
+    if (rc != DVM_OK) return rc;
+    hmcap = cap;
+    return DVM_OK;
   }
   int ensure(size_t bytes) {
     int dev = 0;
@@ -60,16 +75,25 @@ inline StageCtx& stage_ctx() {
   return c;
 }
 
+// Items come in two kinds.  COPIED (in / out / scratch): packed into the pinned buffer, one asynchronous H2D copy, kernels, one D2H
+// copy -- for anything a kernel reads more than once or updates in place.  MAPPED (in_mapped / out_mapped): the kernel reads the
+// input from / writes the output to page-locked host memory directly -- for arrays touched ONCE per call (a query list, a result
+// list), where the copy command in front of / behind the kernel costs more than the kernel: a per-frame call with ~50 KB in and
+// ~16 KB out is a chain of latencies, not a bandwidth problem.  A call whose items are all mapped queues no copy at all.
+// Kernels of the convenience paths are launched on stream() -- one in-order chain per calling thread.
 struct Stage {
-  struct Item { const void* src; void* dst; size_t bytes, off; };
+  struct Item { const void* src; void* dst; size_t bytes, off; bool mapped; };
   std::vector<Item> items;
-  size_t total = 0, in_bytes = 0;
+  size_t total = 0, in_bytes = 0, mapped_total = 0;
   uint8_t* d = nullptr;
   StageCtx* ctx = nullptr;
-  int add(const void* src, void* dst, size_t bytes) {
-    items.push_back({src, dst, bytes, 0});
+  int add(const void* src, void* dst, size_t bytes, bool mapped = false) {
+    items.push_back({src, dst, bytes, 0, mapped});
     return (int)items.size() - 1;
   }
+  int in_mapped(const void* src, size_t bytes) { return add(src, nullptr, src ? bytes : 0, true); }
+  int out_mapped(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0, true); }
+  hipStream_t stream() const { return ctx ? ctx->s : nullptr; }
   int in(const void* src, size_t bytes) { return add(src, nullptr, src ? bytes : 0); }
   int out(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0); }
   int scratch(size_t bytes) { return add(nullptr, nullptr, bytes); }   // device-only working memory
@@ -77,13 +101,16 @@ struct Stage {
   // inputs first (one contiguous span to send), then outputs and scratch; ptr() is valid from here on.  A caller whose INPUTS hold
   // device addresses of other items (a table of views) calls layout() first, fills them in, then upload().
   int layout() {
-    size_t off = 0;
-    for (Item& it : items) if (it.src) { it.off = off; off += pad(it.bytes); }
+    size_t off = 0, moff = 0;
+    for (Item& it : items) if (it.src && !it.mapped) { it.off = off; off += pad(it.bytes); }
     in_bytes = off;
-    for (Item& it : items) if (!it.src) { it.off = off; off += pad(it.bytes); }
+    for (Item& it : items) if (!it.src && !it.mapped) { it.off = off; off += pad(it.bytes); }
     total = off;
+    for (Item& it : items) if (it.mapped) { it.off = moff; moff += pad(it.bytes); }
+    mapped_total = moff;
     ctx = &stage_ctx();
-    int rc = ctx->ensure(total);
+    int rc = ctx->ensure(std::max<size_t>(total, 16));
+    if (rc == DVM_OK && mapped_total) rc = ctx->ensure_mapped(mapped_total);
     if (rc != DVM_OK) return rc;
     d = ctx->d;
     return DVM_OK;
@@ -91,18 +118,20 @@ struct Stage {
   int upload() {
     int rc = d ? DVM_OK : layout();
     if (rc != DVM_OK) return rc;
-    for (const Item& it : items) if (it.src && it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes);
+    for (const Item& it : items) if (it.src && it.bytes) std::memcpy((it.mapped ? ctx->hm : ctx->h) + it.off, it.src, it.bytes);
     if (in_bytes) rc = hip_check(hipMemcpyAsync(d, ctx->h, in_bytes, hipMemcpyHostToDevice, ctx->s), "upload");
     return rc;
   }
-  template <class T> T* ptr(int i) const { return items[i].bytes ? reinterpret_cast<T*>(d + items[i].off) : nullptr; }
+  template <class T> T* ptr(int i) const {
+    return items[i].bytes ? reinterpret_cast<T*>((items[i].mapped ? ctx->hm_dev : d) + items[i].off) : nullptr;
+  }
   int download() {
     size_t lo = total, hi = 0;
-    for (const Item& it : items) if (it.dst && it.bytes) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.bytes); }
+    for (const Item& it : items) if (it.dst && it.bytes && !it.mapped) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.bytes); }
     int rc = DVM_OK;
     if (hi > lo) rc = hip_check(hipMemcpyAsync(ctx->h + lo, d + lo, hi - lo, hipMemcpyDeviceToHost, ctx->s), "download");
     if (rc == DVM_OK) rc = hip_check(hipStreamSynchronize(ctx->s), "sync");
-    for (const Item& it : items) if (rc == DVM_OK && it.dst && it.bytes) std::memcpy(it.dst, ctx->h + it.off, it.bytes);
+    for (const Item& it : items) if (rc == DVM_OK && it.dst && it.bytes) std::memcpy(it.dst, (it.mapped ? ctx->hm : ctx->h) + it.off, it.bytes);
     return rc;
   }
 };

@@ -48,6 +48,9 @@ __global__ void __launch_bounds__(1024) k_frame_build(const dvm_keypoint_pod* __
     keys[i] = key;
   }
   __syncthreads();
+  // A wave owns the 64-aligned blocks of its lanes (i = tid + 1024 t), so a stage with partner distance j < 64 only touches keys
+  // the same wave wrote: between two such stages the wave's own LDS order is enough.  The workgroup barrier (16 waves, ~0.25 us,
+  // and the sort is 55 stages for 1 024 keys) stays where a stage reads or has written across waves: 14 of the 55.
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < P; i += 1024) {
@@ -58,7 +61,13 @@ __global__ void __launch_bounds__(1024) k_frame_build(const dvm_keypoint_pod* __
           if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
         }
       }
-      __syncthreads();
+      const int jn = j > 1 ? (j >> 1) : k;   // partner distance of the next stage (stage k << 1 opens with j = k)
+      if (j >= 64 || jn >= 64) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
   // number of indexed keypoints = first invalid key (binary search by thread 0 is fine: log2(8192))

@@ -159,12 +159,19 @@ __device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, in
 
 // (80 SGPRs: a 256-thread workgroup is admitted per CU up to 800 / (ceil(sgpr / 16) * 16 + 16) times -- 6 at the 101 the compiler
 // takes on its own, 8 at <= 80, which is also what the 17.5 KB of LDS allow: all 2 048 workgroups of a 256-frame batch resident at once)
+#ifdef DVM_OCT_PROF
+__device__ unsigned long long g_oct_prof[32];
+#define OCT_T(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned long long now_ = wall_clock64(); g_oct_prof[k] += now_ - oct_last_; oct_last_ = now_; } } while (0)
+#else
+#define OCT_T(k) do {} while (0)
+#endif
+template <bool LAT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
                                                 const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
                                                 int32_t* __restrict__ lvl_count, PipelineDesc PD,
                                                 int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
                                                 int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
-                                                int level_first) {
+                                                int level_first, int cap_n) {
   // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64):
   // 58 B per slot, so the BASELINE config (cap 256) keeps ~15 KB and 8 workgroups fit a CU
   extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
@@ -177,11 +184,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
   int16_t* proc = reinterpret_cast<int16_t*>(skey + cap);    // processing order: list indices
   int16_t* prank = proc + cap;                               // list index -> rank in processing order or -1
   uint16_t* sval = reinterpret_cast<uint16_t*>(prank + cap); // sort payload / expandable set (creation order)
+  // latency variant (a handful of frames per launch, LDS is not what limits residency): cap_n keys + node ids after the node slots
+  lds_u32* cand_l = (lds_u32*)(oct_smem + ((cap * 58 + 15) & ~15));   // (58 B per node slot above: octree_lds_bytes)
+  lds_i32* nid_l = reinterpret_cast<lds_i32*>(cand_l + cap_n);
   __shared__ int s_tmp[256];
   __shared__ int s_stack[144];
   __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
 
   const int level = level_first + blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+#ifdef DVM_OCT_PROF
+  unsigned long long oct_last_ = wall_clock64();
+#endif
   const LevelDesc& LV = PD.lv[level];
   // ---- vToDistributeKeys of this level: the per-cell candidate lists (k_fast_cells) concatenated in the reference's
   // cell loop order, into the level's own range of `dense` (this used to be a separate per-frame kernel; doing it here
@@ -202,7 +215,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
       const int start = s_carry + s_cnt[tid];
       if (cn > 0) {
         const uint32_t* sp = src + cells[ci].cand_base;
-        for (int k = 0; k < cn; k++) cand_w[start + k] = sp[k];
+        for (int k = 0; k < cn; k++) {
+          const uint32_t v = sp[k];
+          cand_w[start + k] = v;
+          if constexpr (LAT) { if (start + k < cap_n) cand_l[start + k] = v; }
+        }
       }
       __syncthreads();
       if (tid == 0) s_carry += s_total;
@@ -214,8 +231,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
     __syncthreads();
   }
   const int n = s_carry;
-  const uint32_t* cand = cand_w;
-  int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + LV.cand_off;
+  OCT_T(0);
   uint32_t* out = sel + (int64_t)f * PD.sel_frame_slots + LV.sel_off;
   int32_t* out_n = nsel + f * PD.nlevels + level;
   const int N = LV.quota;
@@ -223,193 +239,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
     if (tid == 0) *out_n = 0;
     return;
   }
-  const int W = (LV.w - kEdge + 3) - (kEdge - 3), H = (LV.h - kEdge + 3) - (kEdge - 3);  // maxX-minX, maxY-minY
-  const int nIni = (int)roundf((float)W / (float)H);
-  if (nIni <= 0 || 4 * nIni > cap || N + 8 > cap) {
-    if (tid == 0) { *out_n = 0; __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // mapped host memory
-    return;
-  }
-  const float hX = (float)W / (float)nIni;
-  ONodeRec* L = listA;
-  ONodeRec* Lnew = listB;
-  // ---- roots (:424-458)
-  for (int i = tid; i < nIni; i += 256) {
-    ONodeRec r;
-    r.x0 = (int16_t)(int)(hX * (float)i);
-    r.x1 = (int16_t)(int)(hX * (float)(i + 1));
-    r.y0 = 0; r.y1 = (int16_t)H; r.cnt = 0;
-    Lnew[i] = r;
-    a_scan[i] = 0;
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    int x = (int)(cand[i] & 0xFFFu);
-    int r = (int)((float)x / hX);
-    nid[i] = r;
-    atomicAdd(&Lnew[r].cnt, 1);
-  }
-  __syncthreads();
-  for (int i = tid; i < nIni; i += 256) a_scan[i] = Lnew[i].cnt > 0 ? 1 : 0;
-  __syncthreads();
-  block_scan_excl(a_scan, nIni, s_tmp, &s_total);
-  for (int i = tid; i < nIni; i += 256)
-    if (Lnew[i].cnt > 0) L[a_scan[i]] = Lnew[i];
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) nid[i] = a_scan[nid[i]];
-  if (tid == 0) { s_m = s_total; s_phase = 1; s_finish = 0; s_ne = 0; }
-  __syncthreads();
-
-  while (true) {
-    const int m = s_m;
-    const int phase = s_phase;
-    // ---- processing order
-    if (phase == 1) {
-      for (int j = tid; j < m; j += 256) a_scan[j] = L[j].cnt > 1 ? 1 : 0;
-      __syncthreads();
-      block_scan_excl(a_scan, m, s_tmp, &s_np);
-      for (int j = tid; j < m; j += 256)
-        if (L[j].cnt > 1) proc[a_scan[j]] = (int16_t)j;
-      __syncthreads();
-    } else {
-      const int ne = s_ne;
-      for (int k = tid; k < ne; k += 256) {
-        const int j = sval[k];
-        skey[k] = ((uint32_t)L[j].cnt << 12) | (uint32_t)(uint16_t)L[j].x0;
-      }
-      __syncthreads();
-      // std::sort = __introsort_loop (the only part that is not a stable sort) on one wavefront in rank form,
-      // then __final_insertion_sort == stable ordering of that output, computed in parallel by rank
-      if (tid < 64) wave_introsort_loop((lds_u32*)skey, (lds_u16*)sval, ne, (lds_i32*)s_stack, (lds_i32*)a_scan, (lds_i32*)b_scan);
-      __syncthreads();
-      for (int k = tid; k < ne; k += 256) {
-        const uint32_t kk = skey[k];
-        int rank = 0;
-        for (int j = 0; j < ne; j++) {
-          const uint32_t kj = skey[j];
-          rank += (kj < kk || (kj == kk && j < k)) ? 1 : 0;
-        }
-        proc[ne - 1 - rank] = (int16_t)sval[k];  // processed from the back of the sorted vector (:551)
-      }
-      if (tid == 0) s_np = ne;
-      __syncthreads();
-    }
-    int np = s_np;
-    // ---- child sizes of every node in the processing order
-    for (int t = tid; t < np; t += 256) { const int j = proc[t]; cc[j][0] = cc[j][1] = cc[j][2] = cc[j][3] = 0; }
-    for (int j = tid; j < m; j += 256) prank[j] = -1;
-    __syncthreads();
-    for (int t = tid; t < np; t += 256) prank[proc[t]] = (int16_t)t;
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-      const int j = nid[i];
-      if (prank[j] >= 0) {
-        const ONodeRec r = L[j];
-        const int xm = r.x0 + (r.x1 - r.x0 + 1) / 2, ym = r.y0 + (r.y1 - r.y0 + 1) / 2;  // ceil(float(d)/2)
-        const uint32_t c = cand[i];
-        const int x = (int)(c & 0xFFFu), y = (int)((c >> 12) & 0xFFFu);
-        const int q = (x < xm ? 0 : 1) + (y < ym ? 0 : 2);
-        atomicAdd(&cc[j][q], 1);
-      }
-    }
-    __syncthreads();
-    // ---- children per processed node (processing order); phase 2: cut where the list reaches N
-    for (int t = tid; t < np; t += 256) {
-      const int j = proc[t];
-      b_scan[t] = (cc[j][0] > 0) + (cc[j][1] > 0) + (cc[j][2] > 0) + (cc[j][3] > 0);
-    }
-    __syncthreads();
-    if (phase == 2) {
-      // inclusive gain scan: size after processing t = m + sum_{t'<=t} (nchild - 1)
-      for (int t = tid; t < np; t += 256) a_scan[t] = b_scan[t] - 1;
-      if (tid == 0) s_cut = np;
-      __syncthreads();
-      block_scan_excl(a_scan, np, s_tmp, &s_total);
-      for (int t = tid; t < np; t += 256)
-        if (m + a_scan[t] + (b_scan[t] - 1) >= N) atomicMin(&s_cut, t + 1);
-      __syncthreads();
-      np = s_cut;
-      for (int t = np + tid; t < s_np; t += 256) prank[proc[t]] = -1;  // not reached: stay in the list
-      __syncthreads();
-    }
-    block_scan_excl(b_scan, np, s_tmp, &s_total);
-    const int totalC = s_total;
-    for (int j = tid; j < m; j += 256) a_scan[j] = prank[j] < 0 ? 1 : 0;
-    __syncthreads();
-    block_scan_excl(a_scan, m, s_tmp, &s_keep);
-    const int newSize = totalC + s_keep;
-    if (newSize > cap) {
-      if (tid == 0) { *out_n = 0; __hip_atomic_store(err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  if constexpr (LAT) {
+    if (n <= cap_n) {   // the level's keys and their node ids stay in LDS: the two passes over them per round are the critical path
+      const lds_u32* cand = cand_l;
+      lds_i32* nid = nid_l;
+#include "octree_rounds.inc"
       return;
     }
-    // ---- build the new list
-    for (int j = tid; j < m; j += 256)
-      if (prank[j] < 0) { Lnew[totalC + a_scan[j]] = L[j]; a_scan[j] = totalC + a_scan[j]; }
-    for (int t = tid; t < np; t += 256) {
-      const int j = proc[t];
-      const ONodeRec r = L[j];
-      const int xm = r.x0 + (r.x1 - r.x0 + 1) / 2, ym = r.y0 + (r.y1 - r.y0 + 1) / 2;
-      int posC = b_scan[t];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = cc[j][q];
-        if (c > 0) {
-          ONodeRec ch;
-          ch.x0 = (q & 1) ? (int16_t)xm : r.x0;
-          ch.x1 = (q & 1) ? r.x1 : (int16_t)xm;
-          ch.y0 = (q & 2) ? (int16_t)ym : r.y0;
-          ch.y1 = (q & 2) ? r.y1 : (int16_t)ym;
-          ch.cnt = c;
-          const int ni = totalC - 1 - posC;
-          Lnew[ni] = ch;
-          cc[j][q] = ni;
-          posC++;
-        }
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-      const int j = nid[i];
-      if (prank[j] >= 0) {
-        const ONodeRec r = L[j];
-        const int xm = r.x0 + (r.x1 - r.x0 + 1) / 2, ym = r.y0 + (r.y1 - r.y0 + 1) / 2;
-        const uint32_t c = cand[i];
-        const int x = (int)(c & 0xFFFu), y = (int)((c >> 12) & 0xFFFu);
-        nid[i] = cc[j][(x < xm ? 0 : 1) + (y < ym ? 0 : 2)];
-      } else {
-        nid[i] = a_scan[j];
-      }
-    }
-    __syncthreads();
-    // ---- nodes created this round with > 1 key, in creation order (posC ascending = index descending)
-    for (int p = tid; p < totalC; p += 256) b_scan[p] = Lnew[totalC - 1 - p].cnt > 1 ? 1 : 0;
-    __syncthreads();
-    block_scan_excl(b_scan, totalC, s_tmp, &s_ne);
-    for (int p = tid; p < totalC; p += 256)
-      if (Lnew[totalC - 1 - p].cnt > 1) sval[b_scan[p]] = (uint16_t)(totalC - 1 - p);
-    __syncthreads();
-    if (tid == 0) {
-      const int nToExpand = s_ne;
-      if (newSize >= N || newSize == m) s_finish = 1;
-      else if (phase == 1 && newSize + nToExpand * 3 > N) s_phase = 2;
-      s_m = newSize;
-    }
-    ONodeRec* tsw = L; L = Lnew; Lnew = tsw;
-    __syncthreads();
-    if (s_finish) break;
   }
-
-  // ---- keep the best key of every node (:594-607)
-  const int m = s_m;
-  for (int j = tid; j < m; j += 256) a_scan[j] = 0;
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    const uint32_t key = ((cand[i] >> 24) << 20) | (0xFFFFFu - (uint32_t)i);
-    atomicMax(reinterpret_cast<unsigned int*>(&a_scan[nid[i]]), key);
+  {
+    const uint32_t* cand = cand_w;
+    int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + LV.cand_off;
+#include "octree_rounds.inc"
   }
-  __syncthreads();
-  const int mo = min(m, LV.sel_cap);
-  for (int j = tid; j < mo; j += 256) out[j] = cand[0xFFFFFu - ((uint32_t)a_scan[j] & 0xFFFFFu)];
-  if (tid == 0) *out_n = mo;
 }
 
 // root nodes of a level: nIni = round((maxX - minX) / (maxY - minY)) (ORBextractor.cc:423)
@@ -427,6 +269,15 @@ int octree_required_nodes(const PipelineDesc& PD) {
 bool octree_fits_device(const PipelineDesc& PD) { return octree_required_nodes(PD) <= kOctMaxNodes; }
 
 static size_t octree_lds_bytes(int cap) { return (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2); }
+static_assert(2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2 == 58, "k_octree places the latency variant's key arrays after 58 B per node slot");
+// latency variant: keys + node ids of a level in LDS as well, as many as fit next to the node slots (8 B per key)
+constexpr int kOctLatKeys = 8192;
+static int octree_lat_keys(int cap) {
+  const size_t base = (octree_lds_bytes(cap) + 15) & ~(size_t)15;
+  const size_t room = base < 156 * 1024 ? 156 * 1024 - base : 0;
+  return (int)std::min<size_t>(kOctLatKeys, room / 8);
+}
+static size_t octree_lat_lds_bytes(int cap) { return ((octree_lds_bytes(cap) + 15) & ~(size_t)15) + (size_t)octree_lat_keys(cap) * 8; }
 
 // Called once per configuration (OrbPipeline::configure), on the handle's device: beyond the default 48 KB of dynamic
 // LDS the limit has to be raised per device, and a configuration the hardware cannot hold must be refused BEFORE anything
@@ -434,17 +285,32 @@ static size_t octree_lds_bytes(int cap) { return (size_t)cap * (2 * sizeof(ONode
 bool octree_prepare_device(const PipelineDesc& PD) {
   if (!octree_fits_device(PD)) return false;
   const size_t bytes = octree_lds_bytes(octree_required_nodes(PD));
+  if (!raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<true>), (int)octree_lat_lds_bytes(octree_required_nodes(PD)))) return false;
   if (bytes <= 48 * 1024) return true;
-  return raise_dynamic_lds(reinterpret_cast<const void*>(k_octree), (int)bytes);
+  return raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), (int)bytes);
 }
 
 void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
                    int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err,
-                   int batch, int level_first, int level_num) {
+                   int batch, int level_first, int level_num, bool latency) {
   if (level_num <= 0) return;
   const int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
-  hipLaunchKernelGGL(k_octree, dim3(level_num, batch), dim3(256), octree_lds_bytes(cap), s, d_cand, d_cell_count, d_cells, d_dense,
-                     d_lvl_count, PD, d_nid, d_sel, d_nsel, d_err, cap, level_first);
+  if (latency) {
+    hipLaunchKernelGGL(k_octree<true>, dim3(level_num, batch), dim3(256), octree_lat_lds_bytes(cap), s, d_cand, d_cell_count, d_cells, d_dense,
+                       d_lvl_count, PD, d_nid, d_sel, d_nsel, d_err, cap, level_first, octree_lat_keys(cap));
+    return;
+  }
+  hipLaunchKernelGGL(k_octree<false>, dim3(level_num, batch), dim3(256), octree_lds_bytes(cap), s, d_cand, d_cell_count, d_cells, d_dense,
+                     d_lvl_count, PD, d_nid, d_sel, d_nsel, d_err, cap, level_first, 0);
 }
 
+#ifdef DVM_OCT_PROF
+extern "C" int dvm_debug_oct_prof(unsigned long long* out, int reset) {
+  unsigned long long h[32];
+  int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_oct_prof), sizeof(h));
+  for (int i = 0; i < 32; i++) out[i] = h[i];
+  if (reset) { for (auto& v : h) v = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), h, sizeof(h)); }
+  return rc;
+}
+#endif
 }  // namespace dvm

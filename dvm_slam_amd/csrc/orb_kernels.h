@@ -13,6 +13,15 @@ struct dvm_keypoint_pod {
   int32_t octave, class_id;
 };
 
+// Latency path (a handful of frames per call): the caller's copies of the results in mapped pinned host memory, written by the
+// kernels that produce them (posted PCIe writes) instead of by D2H copies queued behind them.  All null: HBM only.
+struct HostMirror {
+  dvm_keypoint_pod* kps = nullptr;
+  uint8_t* desc = nullptr;
+  int32_t* n = nullptr;
+  int32_t* mono = nullptr;
+};
+
 void upload_constants(const int8_t* disc_u, const int8_t* disc_v, const int* gauss7);
 void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, int sstride, int64_t frame_stride,
                        uint8_t* d_pyr, const PipelineDesc& PD, int batch);
@@ -28,12 +37,14 @@ bool octree_fits_device(const PipelineDesc& PD);
 bool octree_prepare_device(const PipelineDesc& PD);   // raises the LDS limit for this configuration; false: cannot run it   // else: DistributeOctTree runs on the host for this configuration
 void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
                    int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err,
-                   int batch, int level_first, int level_num);
+                   int batch, int level_first, int level_num, bool latency = false);
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
-                     int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch);
+                     int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch,
+                     HostMirror hm = HostMirror());
 void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
                  const int32_t* d_lvl_start, int batch);
 void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
-                        const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch);
+                        const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch,
+                        HostMirror hm = HostMirror());
 
 }  // namespace dvm

@@ -121,15 +121,11 @@ __device__ __forceinline__ void mirror_rows(int y, int h, int& top, int& bot) {
 // also builds the byte-reversed run of the pixels it mirrors and merges the two per byte, so every cache line of
 // the bordered row is written once, in full.  Rows 1..19 and h-20..h-2 are stored a second time into the top /
 // bottom strip row that mirrors them.
-__global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ src, int rows, int cols, int sstride,
-                                                    int64_t frame_stride, uint8_t* __restrict__ pyr,
-                                                    int pyr_frame_bytes, LevelDesc L) {
-  const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
-  const int yb = blockIdx.y * 16 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addresses / mirror rows in SGPRs
-  const int f = blockIdx.z;
+__device__ __forceinline__ void pyr_level0_tile(const uint8_t* __restrict__ S, int rows, int cols, int sstride,
+                                                uint8_t* __restrict__ D, const LevelDesc& L, int bx, int by) {
+  const int X = (bx * 64 + (threadIdx.x & 63)) * 16;
+  const int yb = by * 16 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row addresses / mirror rows in SGPRs
   if (X >= cols + 2 * kEdge) return;
-  const uint8_t* S = src + (int64_t)f * frame_stride;
-  uint8_t* D = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off;
   const bool left = X < kEdge, right = X + 16 > cols + kEdge;
   // mirrored run: left frame  x' = 19 - X - k  -> reversed window starting at 4 - X
   //               right frame x' = 2w + 17 - X - k -> reversed window starting at 2w + 2 - X
@@ -167,22 +163,28 @@ __global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(256) k_pyr_level0(const uint8_t* __restrict__ src, int rows, int cols, int sstride,
+                                                    int64_t frame_stride, uint8_t* __restrict__ pyr,
+                                                    int pyr_frame_bytes, LevelDesc L) {
+  const int f = blockIdx.z;
+  pyr_level0_tile(src + (int64_t)f * frame_stride, rows, cols, sstride, pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off, L, blockIdx.x, blockIdx.y);
+}
+
 // level l = cv::resize(level l-1, INTER_LINEAR) WITH its REFLECT_101 frame.  A workgroup owns a 256 x 16 tile of
 // BORDERED columns x interior rows; a frame column computes the pixel it mirrors (its source lies in the same LDS
 // rectangle, at most 19 destination pixels further in), rows 1..19 / h-20..h-2 are stored twice (strip rows).
 // TH = rows per tile: 64 for throughput (the column set-up and the tile load are amortised over 16 rows per thread), 16 when a
 // handful of frames is all there is (one frame through the drop-in boundary: 21 workgroups of 16 serial rows each made every level
 // a 13 us launch; four times as many workgroups of 4 rows are back in ~6 us).  Same arithmetic, same bytes.
+extern __shared__ __attribute__((aligned(16))) uint8_t rz_smem[];
 template <int TH>
-__global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
-                                                    LevelDesc L, const int32_t* __restrict__ tabs, int lds_pitch) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t rz_smem[];
+__device__ __forceinline__ void pyr_resize_tile(uint8_t* __restrict__ pyr, int pyr_frame_bytes, const LevelDesc& P, const LevelDesc& L,
+                                                const int32_t* __restrict__ tabs, int lds_pitch, int f, int bx, int by) {
   const int tid = threadIdx.x, tx = tid & 63;
   const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the row tables / weights / LDS row bases below go to SGPRs
-  const int f = blockIdx.z;
   const int w = L.w, bw = L.w + 2 * kEdge;
-  const int X0 = blockIdx.x * kRzTW;               // first bordered column of the tile (dword aligned)
-  const int y0 = blockIdx.y * TH;               // first interior row
+  const int X0 = bx * kRzTW;               // first bordered column of the tile (dword aligned)
+  const int y0 = by * TH;               // first interior row
   if (X0 >= bw) return;
   // interior columns whose sources the tile needs: its own, plus the ones its frame columns mirror
   const int lo = X0 - kEdge, hi = min(X0 + kRzTW - 1, bw - 1) - kEdge;
@@ -199,6 +201,29 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
   const int ga = (kEdge + sxa) & ~3;               // bordered source column of LDS column 0
   const int ndw = ((kEdge + sxb - ga) >> 2) + 1;
   const uint8_t* Sg = pyr + (int64_t)f * pyr_frame_bytes + P.pyr_off + (int64_t)(kEdge + sya) * P.stride + ga;
+  // this thread's column tables and this wave's row tables go out BEFORE the tile is fetched: they depend on the tables only,
+  // and behind the barrier they were one more memory round trip on a kernel that is nothing but a chain of them at small batch
+  const int X4 = X0 + 4 * tx;
+  int sx[4];
+  uint32_t al[4];   // (a0 | a1 << 16): the two 11-bit horizontal weights, ready for v_dot2_u32_u16
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int x = X4 + k - kEdge;
+    const int xm = x < 0 ? -x : (x >= w ? 2 * (w - 1) - x : x);   // REFLECT_101 (one bounce: w >= 20)
+    const int dxc = min(max(min(max(xm, dxa), dxb), 0), w - 1);   // pad bytes beyond the frame: any in-tile column
+    sx[k] = kEdge + xofs[dxc] - ga;
+    al[k] = (uint32_t)xal[dxc];
+  }
+  // the row tables of this wave's TH / 4 rows, all fetched before the first row is computed (read inside the loop, every row
+  // began with two scalar loads and an s_waitcnt lgkmcnt(0))
+  int sy_[TH / 4];
+  uint32_t bb_[TH / 4];
+#pragma unroll
+  for (int rr = 0; rr < TH / 4; rr++) {
+    const int dyc = min(y0 + ty + 4 * rr, L.h - 1);
+    sy_[rr] = yofs[dyc];
+    bb_[rr] = (uint32_t)ybe[dyc];
+  }
   uint32_t* lds32 = reinterpret_cast<uint32_t*>(rz_smem);
   const int nrow = syb - sya + 1;
   {
@@ -224,29 +249,8 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
     }
   }
   __syncthreads();
-  const int X4 = X0 + 4 * tx;
   if (X4 >= bw) return;
-  int sx[4];
-  uint32_t al[4];   // (a0 | a1 << 16): the two 11-bit horizontal weights, ready for v_dot2_u32_u16
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int x = X4 + k - kEdge;
-    const int xm = x < 0 ? -x : (x >= w ? 2 * (w - 1) - x : x);   // REFLECT_101 (one bounce: w >= 20)
-    const int dxc = min(max(min(max(xm, dxa), dxb), 0), w - 1);   // pad bytes beyond the frame: any in-tile column
-    sx[k] = kEdge + xofs[dxc] - ga;
-    al[k] = (uint32_t)xal[dxc];
-  }
   uint8_t* Dl = pyr + (int64_t)f * pyr_frame_bytes + L.pyr_off;
-  // the row tables of this wave's TH / 4 rows, all fetched before the first row is computed (read inside the loop, every row
-  // began with two scalar loads and an s_waitcnt lgkmcnt(0))
-  int sy_[TH / 4];
-  uint32_t bb_[TH / 4];
-#pragma unroll
-  for (int rr = 0; rr < TH / 4; rr++) {
-    const int dyc = min(y0 + ty + 4 * rr, L.h - 1);
-    sy_[rr] = yofs[dyc];
-    bb_[rr] = (uint32_t)ybe[dyc];
-  }
 #pragma unroll
   for (int rr = 0; rr < TH / 4; rr++) {
     const int dy = y0 + ty + 4 * rr;
@@ -275,6 +279,12 @@ __global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, i
     if (top >= 0) *reinterpret_cast<uint32_t*>(Dl + (int64_t)top * L.stride + X4) = v;
     if (bot >= 0) *reinterpret_cast<uint32_t*>(Dl + (int64_t)bot * L.stride + X4) = v;
   }
+}
+
+template <int TH>
+__global__ void __launch_bounds__(256) k_pyr_resize(uint8_t* __restrict__ pyr, int pyr_frame_bytes, LevelDesc P,
+                                                    LevelDesc L, const int32_t* __restrict__ tabs, int lds_pitch) {
+  pyr_resize_tile<TH>(pyr, pyr_frame_bytes, P, L, tabs, lds_pitch, blockIdx.z, blockIdx.x, blockIdx.y);
 }
 
 // FALLBACK for tiny levels (w < 40 or h < 20, where the mirror bounces more than once): the level kernels above
@@ -762,11 +772,11 @@ extern "C" int dvm_debug_fast_stamps(unsigned long long* out, int reset) {
 __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel,
                                                   PipelineDesc PD, int lap0, int lap1, dvm_keypoint_pod* __restrict__ kps,
                                                   KpAux* __restrict__ aux, int32_t* __restrict__ n_out,
-                                                  int32_t* __restrict__ mono_out) {
+                                                  int32_t* __restrict__ mono_out, HostMirror hm) {
   __shared__ int s_lvl_start[kMaxLevels + 1];
-  __shared__ int s_scan[256];
-  __shared__ int s_carry;
+  __shared__ int s_wave[2][4];   // lapping keypoints per wave, double-buffered over the 256-keypoint steps: one barrier per step
   const int f = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
   if (tid == 0) {
     int acc = 0;
     for (int l = 0; l < PD.nlevels; l++) {
@@ -774,14 +784,14 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ s
       acc += min(nsel[f * PD.nlevels + l], PD.lv[l].sel_cap);
     }
     s_lvl_start[PD.nlevels] = min(acc, PD.kp_cap);
-    s_carry = 0;
   }
   __syncthreads();
   const int N = s_lvl_start[PD.nlevels];
   const uint32_t* S = sel + (int64_t)f * PD.sel_frame_slots;
   dvm_keypoint_pod* K = kps + (int64_t)f * PD.kp_cap;
   KpAux* A = aux + (int64_t)f * PD.kp_cap;
-  for (int g0 = 0; g0 < N; g0 += 256) {
+  int carry = 0;   // lapping keypoints before this step (every thread keeps the same count)
+  for (int g0 = 0, it = 0; g0 < N; g0 += 256, it++) {
     int g = g0 + tid;
     int lvl = 0, inlap = 0;
     float px = 0, py = 0, resp = 0;
@@ -801,16 +811,19 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ s
       resp = (float)s;
       inlap = (px >= (float)lap0 && px <= (float)lap1) ? 1 : 0;
     }
-    s_scan[tid] = inlap;
+    // lapping keypoints among g' < g: ballot within the wave, the four wave totals through LDS
+    const unsigned long long b = __ballot(inlap);
+    if (lane == 0) s_wave[it & 1][wv] = __popcll(b);
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      int v = (tid >= off) ? s_scan[tid - off] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
+    int before = __popcll(b & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const int c = s_wave[it & 1][w];
+      before += w < wv ? c : 0;
+      total += c;
     }
     if (g < N) {
-      int lap_before = s_carry + s_scan[tid] - inlap;  // lapping keypoints among g' < g
+      int lap_before = carry + before;
       int pos = inlap ? (N - 1 - lap_before) : (g - lap_before);
       dvm_keypoint_pod kp;
       kp.x = px; kp.y = py;
@@ -820,17 +833,17 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ s
       kp.octave = lvl;
       kp.class_id = -1;
       K[pos] = kp;
+      if (hm.kps) hm.kps[(int64_t)f * PD.kp_cap + pos] = kp;   // latency path: the caller's copy, written over PCIe as it is produced
       KpAux a;
       a.level = (int16_t)lvl; a.pad = 0; a.cx = (int16_t)cx; a.cy = (int16_t)cy; a.out_pos = pos;
       A[g] = a;
     }
-    __syncthreads();
-    if (tid == 255) s_carry += s_scan[255];
-    __syncthreads();
+    carry += total;
   }
   if (tid == 0) {
     n_out[f] = N;
-    mono_out[f] = N - s_carry;
+    mono_out[f] = N - carry;
+    if (hm.n) { hm.n[f] = N; hm.mono[f] = N - carry; }
   }
 }
 
@@ -1026,7 +1039,7 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
                                                      const uint8_t* __restrict__ blur, int blur_frame_bytes,
                                                      PipelineDesc PD, const KpAux* __restrict__ aux,
                                                      const int32_t* __restrict__ n_kp, dvm_keypoint_pod* __restrict__ kps,
-                                                     uint8_t* __restrict__ desc, int batch) {
+                                                     uint8_t* __restrict__ desc, int batch, HostMirror hm) {
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescPerWave][kDescRows * kDescPitch];
   int blk, f;
   if (!xcd_frame_map((PD.kp_cap + 4 * kDescPerWave - 1) / (4 * kDescPerWave), batch, blk, f)) return;
@@ -1129,6 +1142,11 @@ __global__ void __launch_bounds__(256) k_orient_desc(const uint8_t* __restrict__
       kps[(int64_t)f * PD.kp_cap + a[q].out_pos].angle = angle;
       unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((int64_t)f * PD.kp_cap + a[q].out_pos) * 32);
       d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+      if (hm.kps) {
+        hm.kps[(int64_t)f * PD.kp_cap + a[q].out_pos].angle = angle;
+        unsigned long long* h = reinterpret_cast<unsigned long long*>(hm.desc + ((int64_t)f * PD.kp_cap + a[q].out_pos) * 32);
+        h[0] = words[0]; h[1] = words[1]; h[2] = words[2]; h[3] = words[3];
+      }
     }
   }
 }
@@ -1214,8 +1232,8 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
 #undef DVM_FAST_LAUNCH
 }
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
-                     int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch) {
-  hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(256), 0, s, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono);
+                     int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch, HostMirror hm) {
+  hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(256), 0, s, d_sel, d_nsel, PD, lap0, lap1, d_kps, d_aux, d_n, d_mono, hm);
 }
 void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const PipelineDesc& PD,
                  const int32_t* d_lvl_start, int batch) {
@@ -1223,9 +1241,9 @@ void launch_blur(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, const Til
                      PD.blur_frame_bytes, d_tiles, PD, d_lvl_start, batch);
 }
 void launch_orient_desc(hipStream_t s, const uint8_t* d_pyr, const uint8_t* d_blur, const PipelineDesc& PD,
-                        const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch) {
+                        const KpAux* d_aux, const int32_t* d_n, dvm_keypoint_pod* d_kps, uint8_t* d_desc, int batch, HostMirror hm) {
   hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(cdiv(PD.kp_cap, 4 * kDescPerWave), batch)), dim3(256), 0, s, d_pyr, PD.pyr_frame_bytes,
-                     d_blur, PD.blur_frame_bytes, PD, d_aux, d_n, d_kps, d_desc, batch);
+                     d_blur, PD.blur_frame_bytes, PD, d_aux, d_n, d_kps, d_desc, batch, hm);
 }
 
 }  // namespace dvm

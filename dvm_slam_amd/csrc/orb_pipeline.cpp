@@ -260,7 +260,7 @@ OrbPipeline::~OrbPipeline() {
   if (ev_stage_free) hipEventDestroy(ev_stage_free);
   if (d_stage) hipFree(d_stage);
   if (h_stage) hipHostFree(h_stage);
-  for (hipStream_t st : {lane_main[1], lane_side[0], lane_side[1]})
+  for (hipStream_t st : {lane_main[1], lane_side[0], lane_side[1], lat_aux})
     if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   for (int c = 0; c < kMaxChunks; c++)
     for (hipEvent_t e : {ev_compact[c], ev_fork[c], ev_join[c]})
@@ -308,6 +308,9 @@ int OrbPipeline::init() {
     DVM_HIP(hipEventCreateWithFlags(&ev_fork[c], hipEventDisableTiming));
     DVM_HIP(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
   }
+  if (const char* e = getenv("DVM_LATENCY_PATH")) latency_path = (e[0] != '0');
+  if (const char* e = getenv("DVM_LAT_SPLIT")) lat_split = (e[0] != '0');
+  if (const char* e = getenv("DVM_ZERO_COPY_IN")) zero_copy_in = (e[0] != '0');
   if (const char* e = getenv("DVM_SERIAL")) overlap_blur = (e[0] != '1');      // debug / A-B switch only
 #ifdef DVM_DEBUG
   if (const char* e = getenv("DVM_HOST_OCTREE")) host_octree_forced = (e[0] == '1');  // debug / A-B switch, debug builds only
@@ -346,12 +349,13 @@ void OrbPipeline::free_all() {
   void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_count, d_sel, d_nsel,
                    d_kps, d_desc, d_aux, d_n, d_mono, d_nid};
   for (void* p : dptrs) if (p) hipFree(p);
-  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono, (void*)h_err};
+  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono, (void*)h_err, h_kps_m, h_desc_m};
   for (void* p : hptrs) if (p) hipHostFree(p);
   d_pyr = d_blur = d_desc = nullptr; d_tabs = nullptr; d_cells = nullptr; d_tiles = nullptr;
   d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_count = d_nsel = d_n = d_mono = nullptr;
   d_kps = nullptr; d_aux = nullptr; d_nid = nullptr; d_err = nullptr; h_err = nullptr;
   h_cell_count = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
+  h_kps_m = nullptr; h_desc_m = nullptr; last_mirrored = false;
   configured = false;  // (the host-image staging buffers d_stage/h_stage live until the destructor)
 }
 
@@ -510,8 +514,13 @@ int OrbPipeline::configure(int rows, int cols) {
   DVM_HIP(hipHostMalloc(&h_dense, B * PD.cand_frame_slots * 4));
   DVM_HIP(hipHostMalloc(&h_sel, B * PD.sel_frame_slots * 4));
   DVM_HIP(hipHostMalloc(&h_nsel, B * L * 4));
-  DVM_HIP(hipHostMalloc(&h_n, B * 4));
-  DVM_HIP(hipHostMalloc(&h_mono, B * 4));
+  DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_n), B * 4, hipHostMallocMapped));
+  DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_mono), B * 4, hipHostMallocMapped));
+  {
+    const size_t mb = std::min<size_t>(B, kLatencyBatch);
+    DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_kps_m), mb * PD.kp_cap * sizeof(dvm_keypoint_pod), hipHostMallocMapped));
+    DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_desc_m), mb * PD.kp_cap * 32, hipHostMallocMapped));
+  }
   if (!tabs.empty()) DVM_HIP(hipMemcpy(d_tabs, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice));
   if (!cells.empty()) DVM_HIP(hipMemcpy(d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
   if (!tiles.empty()) DVM_HIP(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
@@ -553,6 +562,11 @@ int OrbPipeline::extract_host(const uint8_t* imgs, int batch, int rows, int cols
   for (int f = 0; f < batch; f++)
     for (int y = 0; y < rows; y++)
       std::memcpy(h_stage + ((size_t)f * rows + y) * cols, imgs + (size_t)f * frame_stride + (size_t)y * stride, cols);
+  if (latency_path && zero_copy_in && batch <= kLatencyBatch) {   // level 0 reads the pinned buffer itself (see orb_pipeline.h)
+    uint8_t* d_view = nullptr;
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_view), h_stage, 0));
+    return extract_device(d_view, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
+  }
   DVM_HIP(hipMemcpyAsync(d_stage, h_stage, need, hipMemcpyHostToDevice, stream));
   return extract_device(d_stage, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
 }
@@ -607,11 +621,24 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   if (rc != DVM_OK) return rc;
   const int L = PD.nlevels;
   last_batch = batch;
+  const bool small = latency_path && batch <= kLatencyBatch;
+  HostMirror hm;
+  last_mirrored = small;
+  if (small) {
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.kps), h_kps_m, 0));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.desc), h_desc_m, 0));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.n), h_n, 0));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.mono), h_mono, 0));
+  }
+  const bool blur_first = blur_early && !small;
+  const bool split0 = small && lat_split && overlap_blur && !host_octree && !tiny_levels && L > 1 && chunks == 1 && group_split[0] >= L;
+  if (split0 && !lat_aux) DVM_HIP(hipStreamCreateWithFlags(&lat_aux, hipStreamNonBlocking));
 
   // Per chunk: one in-order chain, except the blur: it depends only on the pyramid and on the per-level candidate
   // counts, so it runs on the lane's side stream concurrently with the latency-bound k_octree (one workgroup per
   // level whose critical path is a single-lane std::sort emulation) and joins before the descriptors.
   // DVM_SERIAL=1 keeps the blur on the main chain, DVM_CHUNKS=1 disables the chunk pipeline.
+  int nck = host_octree ? 1 : std::min(chunks, std::max(1, batch / 32));   // chunks of >= 32 frames
   auto run_half = [&](hipStream_t st, hipStream_t side, int ck, int f0, int nb) -> int {
     uint8_t* pyr_f0 = d_pyr + (size_t)f0 * PD.pyr_frame_bytes;
     uint32_t* cand_f0 = d_cand + (size_t)f0 * PD.cand_frame_slots;
@@ -621,6 +648,18 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     // at the price of two k_fast_cells launches per batch; not kept.  launch_fast still takes a cell range.)
     prof.begin(st, "pyramid");
     launch_pyr_level0(st, d_imgs + (int64_t)f0 * frame_stride, rows, cols, stride, frame_stride, pyr_f0, PD, nb);
+    uint32_t* dense_f0 = d_dense + (size_t)f0 * PD.cand_frame_slots;
+    int32_t* lcnt_f0 = d_lvl_count + (size_t)f0 * kMaxLevels;
+    int32_t* nid_f0 = d_nid + (size_t)f0 * PD.cand_frame_slots;
+    uint32_t* sel_f0 = d_sel + (size_t)f0 * PD.sel_frame_slots;
+    int32_t* nsel_f0 = d_nsel + (size_t)f0 * L;
+    if (split0) {   // level 0: FAST cells + octree on the second stream, beside everything below up to k_assemble
+      DVM_HIP(hipEventRecord(ev_group[0], st));
+      DVM_HIP(hipStreamWaitEvent(lat_aux, ev_group[0], 0));
+      launch_fast(lat_aux, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, PD.lv[0].cell_first, PD.lv[0].cell_count);
+      launch_octree(lat_aux, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, 0, 1, true);
+      DVM_HIP(hipEventRecord(ev_group[3], lat_aux));
+    }
     if (d_imgs == d_stage && ev_stage_free && f0 + nb >= batch) {   // the staged input has been consumed: the next batch's
       DVM_HIP(hipEventRecord(ev_stage_free, st));                   // H2D copy may overwrite it while this one computes
       stage_free_valid = true;
@@ -628,8 +667,8 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     for (int l = 1; l < L; l++) launch_pyr_resize(st, pyr_f0, PD, l, d_tabs, nb);
     if (tiny_levels) launch_pyr_borders(st, pyr_f0, PD, nb);   // else: fused into the level kernels
     prof.end(st);
-    const bool blur_forked = overlap_blur && !host_octree && side != nullptr;
-    if (blur_forked && blur_early) {   // blur needs the pyramid only: low-priority side stream, fills the idle slots of
+    const bool blur_forked = overlap_blur && !host_octree && side != nullptr && !small;   // latency path: one chain, no events (below)
+    if (blur_forked && blur_first) {   // blur needs the pyramid only: low-priority side stream, fills the idle slots of
       DVM_HIP(hipEventRecord(ev_fork[ck], st));               // FAST's tail, the small scan kernels and the octree
       DVM_HIP(hipStreamWaitEvent(side, ev_fork[ck], 0));
       prof.begin(side, "blur");
@@ -645,13 +684,8 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     hipStream_t aux = lane_main[st == lane_main[0] ? 1 : 0];
     const bool grouped = overlap_blur && !host_octree && chunks == 1 && aux != nullptr && group_split[0] < L;
     const int g_a = std::min(std::max(group_split[0], 0), L), g_b = std::min(std::max(group_split[1], g_a), L);
-    const int gl[4] = {0, grouped ? g_a : L, grouped ? g_b : L, L};   // level groups [gl[i], gl[i+1])
-    uint32_t* dense_f0 = d_dense + (size_t)f0 * PD.cand_frame_slots;
-    int32_t* lcnt_f0 = d_lvl_count + (size_t)f0 * kMaxLevels;
-    int32_t* nid_f0 = d_nid + (size_t)f0 * PD.cand_frame_slots;
-    uint32_t* sel_f0 = d_sel + (size_t)f0 * PD.sel_frame_slots;
-    int32_t* nsel_f0 = d_nsel + (size_t)f0 * L;
-    int oct_main_first = 0;   // levels below this one have their octree on the auxiliary stream
+    const int gl[4] = {split0 ? 1 : 0, grouped ? g_a : L, grouped ? g_b : L, L};   // level groups [gl[i], gl[i+1])
+    int oct_main_first = split0 ? 1 : 0;   // levels below this one have their octree on the auxiliary stream
     prof.begin(st, "fast");   // one bracket over the (up to three) k_fast_cells launches of the batch
     for (int gi = 0; gi < 3; gi++) {
       const int la = gl[gi], lb = gl[gi + 1];
@@ -661,25 +695,35 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       if (grouped && lb < L) {
         DVM_HIP(hipEventRecord(ev_group[gi], st));
         DVM_HIP(hipStreamWaitEvent(aux, ev_group[gi], 0));
-        launch_octree(aux, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, lb - la);
+        launch_octree(aux, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, lb - la, small);
         oct_main_first = lb;
       }
     }
     prof.end(st);
-    DVM_HIP(hipEventRecord(ev_compact[ck], st));   // this chunk has left the throughput-bound stages
-    if (blur_forked && !blur_early) {
-      DVM_HIP(hipEventRecord(ev_fork[ck], st));
+    if (nck > 1) DVM_HIP(hipEventRecord(ev_compact[ck], st));   // this chunk has left the throughput-bound stages
+    // blur after FAST: only the event goes between FAST and the octree; the side stream's calls come after the octree's launch, so
+    // the host is not still talking to the side stream while the main chain waits for its next kernel (latency path)
+    auto fork_blur = [&]() -> int {
       DVM_HIP(hipStreamWaitEvent(side, ev_fork[ck], 0));
       prof.begin(side, "blur");
       launch_blur(side, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, nullptr, nb);
       prof.end(side);
       DVM_HIP(hipEventRecord(ev_join[ck], side));
+      return DVM_OK;
+    };
+    const bool blur_late = blur_forked && !blur_first;
+    if (blur_late) {
+      DVM_HIP(hipEventRecord(ev_fork[ck], st));
+      if (host_octree) { const int rcb = fork_blur(); if (rcb != DVM_OK) return rcb; }
     }
     if (!host_octree) {
       prof.begin(st, "octree");   // the part of the octree work that is NOT hidden behind FAST
       const int la = oct_main_first;
-      launch_octree(st, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, L - la);
-      if (oct_main_first > 0) {
+      launch_octree(st, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, L - la, small);
+      if (blur_late) { const int rcb = fork_blur(); if (rcb != DVM_OK) return rcb; }
+      if (split0) {
+        DVM_HIP(hipStreamWaitEvent(st, ev_group[3], 0));
+      } else if (oct_main_first > 0) {
         DVM_HIP(hipEventRecord(ev_group[3], aux));
         DVM_HIP(hipStreamWaitEvent(st, ev_group[3], 0));
       }
@@ -723,7 +767,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
 #endif
 
     prof.begin(st, "assemble");
-    launch_assemble(st, (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), PD, lap0, lap1, (d_kps + (size_t)f0 * PD.kp_cap), (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_mono + f0), nb);
+    launch_assemble(st, (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), PD, lap0, lap1, (d_kps + (size_t)f0 * PD.kp_cap), (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_mono + f0), nb, hm);
     prof.end(st);
     if (!blur_forked) {
       prof.begin(st, "blur");
@@ -733,12 +777,11 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       DVM_HIP(hipStreamWaitEvent(st, ev_join[ck], 0));
     }
     prof.begin(st, "orient_desc");
-    launch_orient_desc(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), PD, (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_kps + (size_t)f0 * PD.kp_cap), (d_desc + (size_t)f0 * PD.kp_cap * 32), nb);
+    launch_orient_desc(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), PD, (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_kps + (size_t)f0 * PD.kp_cap), (d_desc + (size_t)f0 * PD.kp_cap * 32), nb, hm);
     prof.end(st);
 
     return DVM_OK;
   };
-  int nck = host_octree ? 1 : std::min(chunks, std::max(1, batch / 32));   // chunks of >= 32 frames
   if (nck == 1) {
     rc = run_half(stream, lane_side[0], 0, 0, batch);
     if (rc != DVM_OK) return rc;
@@ -777,6 +820,19 @@ int OrbPipeline::sync() {
 int OrbPipeline::download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono) {
   if (!configured || frame < 0 || frame >= last_batch) { set_error("no results for that frame"); return DVM_ERR_STATE; }
   DVM_HIP(hipSetDevice(device));
+  if (last_mirrored) {   // latency path: the kernels stored the results here as they produced them
+    int rc = sync();
+    if (rc != DVM_OK) return rc;
+    const int N = h_n[frame];
+    if (n) *n = N;
+    if (mono) *mono = h_mono[frame];
+    if (N > cap) { set_error("keypoint buffer too small"); return DVM_ERR_CAPACITY; }
+    if (N > 0) {
+      if (kps) std::memcpy(kps, h_kps_m + (size_t)frame * PD.kp_cap, (size_t)N * sizeof(dvm_keypoint));
+      if (desc) std::memcpy(desc, h_desc_m + (size_t)frame * PD.kp_cap * 32, (size_t)N * 32);
+    }
+    return DVM_OK;
+  }
   DVM_HIP(hipMemcpyAsync(h_n, d_n, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
   DVM_HIP(hipMemcpyAsync(h_mono, d_mono, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
   int rc = sync();

@@ -128,6 +128,25 @@ class OrbPipeline {
   int32_t* h_n = nullptr;
   int32_t* h_mono = nullptr;
   uint8_t* h_stage = nullptr;
+  // Latency path -- a call of at most kLatencyBatch frames (Tracking hands over ONE): nothing is bandwidth-bound at that size, the
+  // call is a chain of ~13 dependent launches plus the copies around it (0.217 ms host to host before, 0.176 ms now).  So
+  // (1) level 0 reads the image from the pinned staging buffer over PCIe (no H2D copy in front of the chain);
+  // (2) the blur stays on the main chain: the fork / join events around a side stream cost more than the 9 us the blur takes;
+  // (3) k_assemble / k_orient_desc also store counts, keypoints and descriptors into mapped host memory, so download() is a
+  //     stream synchronisation and a memcpy;
+  // (4) k_octree keeps a level's keys and node ids in LDS (template variant).
+  // DVM_LATENCY_PATH=0 / DVM_ZERO_COPY_IN=0: A-B switches.  Tried and not kept: the pyramid in one launch with inter-workgroup
+  // flags (write-through stores + per-row-tile counters: 56 us against 45 us for the eight launches -- a cross-XCD hand-off costs
+  // more than a kernel boundary); the whole call as a captured hipGraph (0.183 ms: replay is no cheaper than 17 eager calls);
+  // level 0's FAST + octree on a second stream behind k_pyr_level0 (DVM_LAT_SPLIT=1, 0.187 ms: the host issues the second
+  // chain's launches in front of the first one's, and in a graph the branches serialised: 0.34 ms).
+  static constexpr int kLatencyBatch = 4;
+  bool latency_path = true, zero_copy_in = true;
+  bool lat_split = false;            // opt-in, see above
+  hipStream_t lat_aux = nullptr;     // created by the first small call: a handle that only ever sees large batches keeps its two streams
+  bool last_mirrored = false;        // the last batch's results are in h_kps_m / h_desc_m / h_n / h_mono
+  dvm_keypoint_pod* h_kps_m = nullptr;   // [kLatencyBatch][kp_cap], mapped
+  uint8_t* h_desc_m = nullptr;           // [kLatencyBatch][kp_cap][32], mapped
 
  private:
   int configure(int rows, int cols);

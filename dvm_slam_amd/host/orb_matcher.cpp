@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 namespace dvm_host {
 
@@ -98,6 +99,17 @@ int ORBmatcher::DescriptorDistance(const uint8_t* a, const uint8_t* b) {
   return dist;
 }
 
+void ORBmatcher::ComputeThreeMaxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = sizes[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
 void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
   int max1 = 0, max2 = 0, max3 = 0;
   for (int i = 0; i < L; i++) {
@@ -117,8 +129,10 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   (void)bMono;  // DVM-SLAM is monocular (src/slam_system/src/ros_mono.cpp:19): bForward = bBackward = false
   int nmatches = 0;
   last_requeried = 0;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  for (auto& h : rotHist) h.reserve(500);
+  // rotHist[bin] of :1566-1568 as (keypoint, bin) pairs + counts: the 30 vectors only ever feed ComputeThreeMaxima's sizes and the
+  // final sweep over the losing bins
+  std::vector<std::pair<int, int>> rotPairs;
+  int rotCount[HISTO_LENGTH] = {0};
   const float factor = 1.0f / HISTO_LENGTH;
 
   // ---- queries, exactly the loop header of :1573-1611
@@ -126,6 +140,8 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   std::vector<float> qx, qy, qr;
   std::vector<int32_t> qmin, qmax;
   std::vector<uint8_t> qdesc;
+  qi.reserve(Last.N); qx.reserve(Last.N); qy.reserve(Last.N); qr.reserve(Last.N); qmin.reserve(Last.N); qmax.reserve(Last.N);
+  qdesc.reserve((size_t)Last.N * 32);
   for (int i = 0; i < Last.N; i++) {
     const int mp = Last.mvpMapPoints[i];
     if (mp < 0) continue;
@@ -150,16 +166,29 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
 
   // ---- one batched device search against CurrentFrame's grid (claims known at entry are masked)
   mark("queries");
-  int rc = ensure_grid(Cur);
+  // the grid of CurrentFrame and the search over it are ONE chain on the calling thread's stream (this is the per-frame call of
+  // Tracking: two staged calls with a synchronisation each cost more than the two kernels)
+  int rc = ensure_handle(Cur.N);
   if (rc != DVM_OK) return rc;
-  mark("grid");
   std::vector<uint8_t> claimed(grid_cap_, 0);
   for (int j = 0; j < Cur.N; j++)
     if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) claimed[j] = 1;
   std::vector<dvm_match> res(nq);
   std::vector<int32_t> runner_up(nq);
-  rc = dvm_match_window_top2(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
-                             nullptr, res.data(), runner_up.data(), 0, nullptr);
+  if (resident(Cur)) {   // keypoints + descriptors still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> here)
+    last_grid_from_device = true;
+    void* ts = dvm_thread_stream(device_);
+    rc = dvm_frame_build(grid_, 0, Cur.dev->d_kps, Cur.dev->d_desc, Cur.N, nullptr, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, 1, ts);
+    if (rc != DVM_OK) return rc;
+    mark("grid");
+    rc = dvm_match_window_top2(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
+                               nullptr, res.data(), runner_up.data(), 0, nullptr);
+  } else {
+    last_grid_from_device = false;
+    rc = dvm_frame_build_match_window_top2(grid_, 0, Cur.mvKeysUn, Cur.mDescriptors, Cur.N, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY,
+                                           claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
+                                           res.data(), runner_up.data());
+  }
   if (rc != DVM_OK) return rc;
   mark("match");
 
@@ -167,6 +196,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   // skipped by later queries, so a result whose best candidate has been claimed meanwhile is recomputed
   HostGrid hg;
   bool hg_built = false;
+  double requery_ms = 0;
   std::vector<uint8_t> claimed_now = claimed;
   std::vector<int> cand;
   for (int q = 0; q < nq; q++) {
@@ -175,6 +205,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
       // the scan skips the claimed best and ends on the runner-up (strict '<', first wins: the second smallest (distance, position))
       bestIdx2 = runner_up[q]; bestDist = res[q].second_dist;
     } else if (bestIdx2 >= 0 && claimed_now[bestIdx2] && !claimed[bestIdx2]) {
+      const auto tq0 = dbg ? std::chrono::steady_clock::now() : T0;
       if (!hg_built) { hg.build(Cur); hg_built = true; }
       last_requeried++;
       hg.query(qx[q], qy[q], qr[q], qmin[q], qmax[q], cand);
@@ -184,6 +215,7 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
         const int dist = DescriptorDistance(&qdesc[32 * (size_t)q], Cur.mDescriptors + 32 * (size_t)i2);
         if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
       }
+      if (dbg) requery_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
     }
     if (bestDist <= TH_HIGH) {
       const int i = qi[q];
@@ -196,37 +228,46 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
         if (rot < 0.0) rot += 360.0f;
         int bin = (int)std::round(rot * factor);
         if (bin == HISTO_LENGTH) bin = 0;
-        rotHist[bin].push_back(bestIdx2);
+        rotPairs.emplace_back(bestIdx2, bin);
+        rotCount[bin]++;
       }
     }
   }
   if (mbCheckOrientation) {
     int ind1 = -1, ind2 = -1, ind3 = -1;
-    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++)
-      if (i != ind1 && i != ind2 && i != ind3)
-        for (int idx : rotHist[i]) { Cur.mvpMapPoints[idx] = -1; nmatches--; }
+    ComputeThreeMaxima(rotCount, HISTO_LENGTH, ind1, ind2, ind3);
+    for (const auto& pr : rotPairs)
+      if (pr.second != ind1 && pr.second != ind2 && pr.second != ind3) { Cur.mvpMapPoints[pr.first] = -1; nmatches--; }
   }
   mark("epilogue");
-  if (dbg) std::fprintf(stderr, "SBP queries %d matches %d re-queried %d\n", nq, nmatches, last_requeried);
+  if (dbg) std::fprintf(stderr, "SBP queries %d matches %d re-queried %d (%.3f ms in the host re-queries)\n", nq, nmatches, last_requeried, requery_ms);
   return nmatches;
 }
 
-int ORBmatcher::ensure_grid(const FrameView& F) {
+int ORBmatcher::ensure_handle(int N) {
   GridCache& c = grid_cache();
-  if (!c.g || c.cap < F.N || c.device != device_) {
+  if (!c.g || c.cap < N || c.device != device_) {
     if (c.g) dvm_frame_destroy(c.g);
     c.g = nullptr;
-    c.cap = std::max(2048, F.N);
+    c.cap = std::max(2048, N);
     c.device = device_;
     int rc = dvm_frame_create(device_, c.cap, 1, &c.g);
     if (rc != DVM_OK) { c.cap = 0; return rc; }
   }
   grid_ = c.g;
   grid_cap_ = c.cap;
+  return DVM_OK;
+}
+bool ORBmatcher::resident(const FrameView& F) const {
+  return F.dev && F.dev->n == F.N && F.dev->device == device_ && dvm_device_frame_valid(F.dev);
+}
+
+int ORBmatcher::ensure_grid(const FrameView& F) {
+  int rc0 = ensure_handle(F.N);
+  if (rc0 != DVM_OK) return rc0;
   // the frame's keypoints + descriptors are still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> ORBmatcher.cc:1553
   // without a round trip through the host): the grid is built from there, on the default stream the searches follow on
-  if (F.dev && F.dev->n == F.N && F.dev->device == device_ && dvm_device_frame_valid(F.dev)) {
+  if (resident(F)) {
     last_grid_from_device = true;
     return dvm_frame_build(grid_, 0, F.dev->d_kps, F.dev->d_desc, F.N, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY, 1, nullptr);
   }

@@ -132,6 +132,7 @@ class ORBmatcher {
 
  private:
   void ComputeThreeMaxima(std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3);  // :1862-1896
+  void ComputeThreeMaxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3);   // the same on the bins' sizes
   float mfNNratio;
   bool mbCheckOrientation;
   int device_;
@@ -140,6 +141,8 @@ class ORBmatcher {
  private:
   dvm_frame* grid_ = nullptr;
   int grid_cap_ = 0;
+  int ensure_handle(int N);                 // the calling thread's cached grid handle, at least N keypoints
+  bool resident(const FrameView& F) const;  // F's keypoints + descriptors are still in HBM on this matcher's device
   int ensure_grid(const FrameView& F);
   int ensure_grid(const KeyFrameView& KF);
   int project_search(const KeyFrameView& KF, const dvm_se3f& Tcw, const float* Ow, const MapPointsView& P,

@@ -194,6 +194,18 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
 int dvm_match_window_top2(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                           const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
                           const int32_t* d_nq, dvm_match* out, int32_t* second_idx, int on_device, void* stream);
+/* Host-pointer convenience, latency path of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1553-1748):
+ * dvm_frame_build(f, slot, kps, desc, n, ..., on_device = 0) followed by dvm_match_window_top2(f, slot, ..., on_device = 0) as ONE
+ * staged call -- one upload, the two kernels back to back on the calling thread's stream, one synchronisation.  Same results as
+ * the two calls. */
+int dvm_frame_build_match_window_top2(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
+                                      float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
+                                      const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                      const int32_t* qmax, int nq, dvm_match* out, int32_t* second_idx);
+/* The stream the host-pointer convenience calls of the CALLING THREAD run on (device `device`; created on first use).  A caller
+ * that builds a grid with on_device = 1 and then searches it through a host-pointer call passes it as `stream`, so that the two are
+ * one in-order chain (no synchronisation in between). */
+void* dvm_thread_stream(int device);
 
 /* Frame::UndistortKeyPoints (Frame.cc:791-818) and Frame::ComputeImageBounds (:820-848): cv::undistortPoints(pts, K, D,
  * noArray(), K) -- OpenCV's 5-iteration fixed-point inversion of the (k1, k2, p1, p2, k3) model, in double from the float
