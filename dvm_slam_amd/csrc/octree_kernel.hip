@@ -26,6 +26,11 @@ struct ONodeRec {
   int16_t x0, y0, x1, y1;
   int32_t cnt;
 };
+struct OSplitRec {   // a node that has been split, in the slot of its ONodeRec: split point and the list indices of its children (-1: none)
+  int16_t xm, ym;
+  int16_t child[4];
+};
+static_assert(sizeof(OSplitRec) == sizeof(ONodeRec), "a split record replaces the node's record in place");
 // LDS-typed accessor for introsort_emul.h: with plain (generic) pointers the serial sort compiles to
 // flat_load/flat_store, several times the latency of ds_read/ds_write -- and that latency IS the
 // critical path of this kernel.
@@ -133,6 +138,19 @@ __device__ void wave_introsort_loop(lds_u32* key, lds_u16* val, int n, lds_i32* 
   }
 }
 
+// exclusive prefix of v over the 64 lanes; total = the wave's sum (uniform)
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int& total) {
+  const int lane = threadIdx.x & 63;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  total = __shfl(x, 63, 64);
+  return x - v;
+}
+
 // exclusive scan of data[0..m) in place, 256 threads (4 waves): per-thread serial chunk, wave scan by
 // DPP-free shuffles, 4 wave totals through LDS.  *total (shared) receives the sum.  3 barriers.
 __device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, int* total) {
@@ -165,6 +183,8 @@ __device__ unsigned long long g_oct_prof[32];
 #else
 #define OCT_T(k) do {} while (0)
 #endif
+// (1 024 threads for the latency variant: measured slower, 41 us against 37 -- a pass over the keys is bound by the CU's LDS
+// throughput under random access, ~11 LDS operations per key, not by the latency of one key's chain)
 template <bool LAT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
                                                 const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
@@ -172,21 +192,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
                                                 int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
                                                 int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
                                                 int level_first, int cap_n) {
-  // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64):
-  // 58 B per slot, so the BASELINE config (cap 256) keeps ~15 KB and 8 workgroups fit a CU
+  // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64): 58 B per slot in the throughput
+  // form (the BASELINE config, cap 256, keeps ~15 KB and 8 workgroups fit a CU), 56 B per slot + the keys in the latency form
   extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
   ONodeRec* listA = reinterpret_cast<ONodeRec*>(oct_smem);
   ONodeRec* listB = listA + cap;
-  int(*cc)[4] = reinterpret_cast<int(*)[4]>(listB + cap);   // child key counts, later child new-index
-  int* a_scan = reinterpret_cast<int*>(cc + cap);            // scan workspace 1 (keep index / flags)
-  int* b_scan = a_scan + cap;                                // scan workspace 2 (children per processed node)
-  uint32_t* skey = reinterpret_cast<uint32_t*>(b_scan + cap);  // sort keys
-  int16_t* proc = reinterpret_cast<int16_t*>(skey + cap);    // processing order: list indices
-  int16_t* prank = proc + cap;                               // list index -> rank in processing order or -1
-  uint16_t* sval = reinterpret_cast<uint16_t*>(prank + cap); // sort payload / expandable set (creation order)
-  // latency variant (a handful of frames per launch, LDS is not what limits residency): cap_n keys + node ids after the node slots
-  lds_u32* cand_l = (lds_u32*)(oct_smem + ((cap * 58 + 15) & ~15));   // (58 B per node slot above: octree_lds_bytes)
-  lds_i32* nid_l = reinterpret_cast<lds_i32*>(cand_l + cap_n);
+  int(*cc)[4] = reinterpret_cast<int(*)[4]>(listB + cap);   // child key counts of the processed nodes
+  int* a_scan = reinterpret_cast<int*>(cc + cap);            // kept node -> index in the new list / scan workspace
+  // throughput form (octree_rounds.inc)
+  int* b_scan = nullptr;              // scan workspace 2 (children per processed node)
+  int16_t* prank = nullptr;           // list index -> rank in processing order or -1
+  // latency form (octree_rounds_wave.inc)
+  int16_t *prankA = nullptr, *prankB = nullptr;   // the same for two rounds in flight
+  lds_u32* cand_l = nullptr;          // cap_n keys + node ids behind the node slots
+  lds_i32* nid_l = nullptr;
+  uint32_t* skey;                     // sort keys (wave form also: first child slot per processed node, best key per node)
+  int16_t* proc;                      // processing order: list indices
+  uint16_t* sval;                     // sort payload / expandable set (creation order)
+  if constexpr (LAT) {
+    skey = reinterpret_cast<uint32_t*>(a_scan + cap);
+    proc = reinterpret_cast<int16_t*>(skey + cap);
+    prankA = proc + cap;
+    prankB = prankA + cap;
+    sval = reinterpret_cast<uint16_t*>(prankB + cap);
+    cand_l = (lds_u32*)(oct_smem + ((cap * 56 + 15) & ~15));   // (56 B per node slot above: octree_lat_lds_bytes)
+    nid_l = reinterpret_cast<lds_i32*>(cand_l + cap_n);
+  } else {
+    b_scan = a_scan + cap;
+    skey = reinterpret_cast<uint32_t*>(b_scan + cap);
+    proc = reinterpret_cast<int16_t*>(skey + cap);
+    prank = proc + cap;
+    sval = reinterpret_cast<uint16_t*>(prank + cap);
+  }
+  constexpr int NT = 256;
   __shared__ int s_tmp[256];
   __shared__ int s_stack[144];
   __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
@@ -240,14 +278,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
     return;
   }
   if constexpr (LAT) {
-    if (n <= cap_n) {   // the level's keys and their node ids stay in LDS: the two passes over them per round are the critical path
+    if (n <= cap_n) {   // the level's keys and their node ids stay in LDS
       const lds_u32* cand = cand_l;
       lds_i32* nid = nid_l;
-#include "octree_rounds.inc"
-      return;
+#include "octree_rounds_wave.inc"
+    } else {
+      const uint32_t* cand = cand_w;
+      int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + LV.cand_off;
+#include "octree_rounds_wave.inc"
     }
-  }
-  {
+  } else {
     const uint32_t* cand = cand_w;
     int32_t* nid = nid_scratch + (int64_t)f * PD.cand_frame_slots + LV.cand_off;
 #include "octree_rounds.inc"
@@ -268,16 +308,16 @@ int octree_required_nodes(const PipelineDesc& PD) {
 }
 bool octree_fits_device(const PipelineDesc& PD) { return octree_required_nodes(PD) <= kOctMaxNodes; }
 
-static size_t octree_lds_bytes(int cap) { return (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2); }
-static_assert(2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2 == 58, "k_octree places the latency variant's key arrays after 58 B per node slot");
+static size_t octree_lds_bytes(int cap) { return (size_t)cap * (2 * sizeof(ONodeRec) + 16 + 4 + 4 + 4 + 2 + 2 + 2); }   // throughput form: 58 B / slot
+static_assert(2 * sizeof(ONodeRec) + 16 + 4 + 4 + 2 + 2 + 2 + 2 == 56, "k_octree<true> places its key arrays after 56 B per node slot");
 // latency variant: keys + node ids of a level in LDS as well, as many as fit next to the node slots (8 B per key)
 constexpr int kOctLatKeys = 8192;
 static int octree_lat_keys(int cap) {
-  const size_t base = (octree_lds_bytes(cap) + 15) & ~(size_t)15;
+  const size_t base = ((size_t)cap * 56 + 15) & ~(size_t)15;
   const size_t room = base < 156 * 1024 ? 156 * 1024 - base : 0;
   return (int)std::min<size_t>(kOctLatKeys, room / 8);
 }
-static size_t octree_lat_lds_bytes(int cap) { return ((octree_lds_bytes(cap) + 15) & ~(size_t)15) + (size_t)octree_lat_keys(cap) * 8; }
+static size_t octree_lat_lds_bytes(int cap) { return (((size_t)cap * 56 + 15) & ~(size_t)15) + (size_t)octree_lat_keys(cap) * 8; }
 
 // Called once per configuration (OrbPipeline::configure), on the handle's device: beyond the default 48 KB of dynamic
 // LDS the limit has to be raised per device, and a configuration the hardware cannot hold must be refused BEFORE anything
