@@ -246,7 +246,8 @@ def lba(device, iters=10, repeats=40, cpu_seconds=4.0):
 def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
     """BASELINE config 4 with more agents than GPUs: the LocalBundleAdjustment windows of K agents solved side by side by ONE launch of the
     sequential-order kernel (dvm_ba_optimize_windows; a workgroup per window, g2o's summation order -> bit-identical to the oracle), next to
-    the same K windows solved one after the other through the tile solver's handle (the `lba` leg's call).  K different windows: every
+    the same K windows solved one after the other through the tile solver's handle (the `lba` leg's call) and solved concurrently by
+    dvm_ba_optimize_batch (pooled handles, host threads of the call).  K different windows: every
     agent has its own map (different seeds), 30 keyframes / 20 free / 3 000 landmarks / ~15 000 observations each."""
     from dvm_slam_amd import capi, synth
     delta = float(np.sqrt(np.float32(5.991)))
@@ -285,15 +286,45 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
     ba.close()
     out["tile_solver_sequential"] = {"value": its_seq / sum(t_seq), "ms_per_window": float(np.median(t_seq)) * 1e3, "windows": len(t_seq),
                                      "note": "dvm_ba_set_problem + dvm_ba_optimize + get_result + edge_chi2 per window, one after the other"}
+    # ... and solved concurrently: dvm_ba_optimize_batch, host threads of the call each driving a pooled handle (what K agents' LocalMapping
+    # threads sharing the GPU get).  Results must be the sequential ones bit for bit: the same solver runs each window.
+    seq_ref = []
+    ba = capi.BundleAdjuster(device)
+    for a in range(min(kmax, 4)):
+        w = wins[a]
+        ba.set_problem(w["poses"], w["fixed"], w["points"], w["edges"], w["intrinsics"], delta)
+        ba.optimize(iters)
+        seq_ref.append(ba.result())
+    ba.close()
+    capi.ba_optimize_batch(wins[:kmax], device)   # the pool's handles exist from here on
+    conc = {"call": "dvm_ba_optimize_batch (threads = library default)", "by_K": {}}
+    resb = None
+    for K in Ks:
+        ts, its = [], 0
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            resb = capi.ba_optimize_batch(wins[:K], device)
+            ts.append(time.perf_counter() - t0)
+            its = sum(r["stats"]["iterations"] for r in resb)
+        best = float(np.median(ts))
+        conc["by_K"][str(K)] = {"value": its / best, "ms_per_call": best * 1e3, "ms_per_window": best * 1e3 / K, "iterations": its}
+    same = all(np.array_equal(resb[a]["poses"].view(np.int64), seq_ref[a][0].view(np.int64)) and
+               np.array_equal(resb[a]["points"].view(np.int64), seq_ref[a][1].view(np.int64)) for a in range(min(len(seq_ref), len(resb))))
+    conc["identical_to_sequential_handle"] = bool(same)
+    if not same:
+        raise RuntimeError("lba_batch leg: dvm_ba_optimize_batch differs from the same windows solved one after the other")
+    out["concurrent_tile_solver"] = conc
     if cpu_windows > 0:
         from oracle import pyoracle as po   # cpu_baseline leg + parity of THIS run
         tc, itc = [], 0
         ident = True
+        cpu_ref = []
         for a in range(min(cpu_windows, kmax)):
             w = wins[a]
             t0 = time.perf_counter()
             p, x, so, chio = po.ba_optimize(w["poses"], w["fixed"], w["points"], w["edges"], w["intrinsics"], delta, iters)
             tc.append(time.perf_counter() - t0); itc += so["iterations"]
+            cpu_ref.append((p, x))
             g = res[a]
             ident = ident and bool(np.array_equal(g["poses"].view(np.int64), p.view(np.int64)) and np.array_equal(g["points"].view(np.int64), x.view(np.int64)) and
                                    np.array_equal(g["edge_chi2"].view(np.int64), chio.view(np.int64)) and list(g["stats"]["trials"]) == list(so["trials"]))
@@ -302,6 +333,12 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
         out["parity_vs_cpu"] = {"windows_checked": len(tc), "bit_identical": ident}
         if not ident:
             raise RuntimeError("lba_batch leg: a window's result is not bit-identical to the CPU oracle")
+        if cpu_ref:   # the concurrent call against the same oracle runs, at the general solver's tolerance
+            dp = max(float(np.abs(resb[a]["poses"] - cpu_ref[a][0]).max()) for a in range(min(len(cpu_ref), len(resb))))
+            dx = max(float(np.abs(resb[a]["points"] - cpu_ref[a][1]).max()) for a in range(min(len(cpu_ref), len(resb))))
+            out["concurrent_tile_solver"]["parity_vs_cpu"] = {"max_abs_pose": dp, "max_abs_landmark": dx, "tolerance": 1e-6}
+            if not (dp < 1e-6 and dx < 1e-6):
+                raise RuntimeError(f"lba_batch leg: dvm_ba_optimize_batch differs from the CPU oracle: {dp} {dx}")
     return out
 
 

@@ -516,7 +516,13 @@ class BaWindow(C.Structure):
                 ("poses_out", C.c_void_p), ("points_out", C.c_void_p), ("edge_chi2_out", C.c_void_p), ("depth_positive_out", C.c_void_p)]
 
 
-def ba_optimize_windows(problems, device=0, stop_flag=None):
+def ba_optimize_batch(problems, device=0, threads=0, stop_flag=None):
+    """dvm_ba_optimize_batch: the same K problems, each on the general solver, up to `threads` of them concurrently (0: the library's default).
+    Same arguments and return value as ba_optimize_windows."""
+    return ba_optimize_windows(problems, device, stop_flag, _threads=int(threads), _batch=True)
+
+
+def ba_optimize_windows(problems, device=0, stop_flag=None, _threads=0, _batch=False):
     """dvm_ba_optimize_windows: K independent bundle adjustments in one launch.  problems: dicts with poses [P,7], fixed [P], points [L,3],
     edges (BA_EDGE_DTYPE), intrinsics (fx, fy, cx, cy), huber_delta, iterations.  Returns one dict per window: poses, points, edge_chi2,
     depth_positive, stats (the keys of BundleAdjuster.optimize)."""
@@ -536,9 +542,14 @@ def ba_optimize_windows(problems, device=0, stop_flag=None):
         w.cam = BaCamera(*[float(v) for v in pr["intrinsics"]], float(pr["huber_delta"]))
         w.poses_out, w.points_out, w.edge_chi2_out, w.depth_positive_out = (o["poses"].ctypes.data, o["points"].ctypes.data, o["edge_chi2"].ctypes.data,
                                                                             o["depth_positive"].ctypes.data)
-    f = lib().dvm_ba_optimize_windows
-    f.restype = C.c_int32; f.argtypes = None
-    check(f(C.c_int32(device), wins, C.c_int32(K), _p(stop_flag) if stop_flag is not None else None, stats))
+    if _batch:
+        f = lib().dvm_ba_optimize_batch
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(C.c_int32(device), wins, C.c_int32(K), C.c_int32(_threads), _p(stop_flag) if stop_flag is not None else None, stats))
+    else:
+        f = lib().dvm_ba_optimize_windows
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(C.c_int32(device), wins, C.c_int32(K), _p(stop_flag) if stop_flag is not None else None, stats))
     for k, o in enumerate(outs):
         st = stats[k]
         n = min(st.iterations, 64)

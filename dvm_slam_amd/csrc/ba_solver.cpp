@@ -15,6 +15,9 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1095,3 +1098,104 @@ int dvm_sim3_hypotheses(int device, const float* P1c, const float* P2c, const fl
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- batch of independent problems
+// K independent bundle adjustments solved CONCURRENTLY: the LocalBundleAdjustment windows of several agents that share this GPU
+// (BASELINE.json config 4 with more agents than GPUs; in the reference every agent's LocalMapping thread runs its own
+// Optimizer::LocalBundleAdjustment, Optimizer.cc:1030-1387).  One window on the tile solver is a chain of ~400 small launches with
+// the host's LM decisions in between: 1.2 ms during which the GPU is mostly idle.  Up to `threads` host threads each take a solver
+// handle from a process-wide pool (a handle keeps its buffers, streams and pinned words: creating one costs milliseconds) and pull
+// windows from a shared counter, so the chains of different windows interleave on the device.  Every window gives exactly what
+// dvm_ba_set_problem + dvm_ba_optimize(iterations) + dvm_ba_get_result + dvm_ba_edge_chi2 on its own handle give -- the routing of
+// small problems to the sequential-order kernel included.
+namespace {
+struct BaPool {
+  std::mutex m;
+  std::vector<std::pair<int, dvm_ba*>> idle;   // (device, handle)
+  dvm_ba* take(int device, int* rc) {
+    {
+      std::lock_guard<std::mutex> lock(m);
+      for (size_t i = 0; i < idle.size(); i++)
+        if (idle[i].first == device) { dvm_ba* h = idle[i].second; idle.erase(idle.begin() + (long)i); return h; }
+    }
+    dvm_ba* h = nullptr;
+    *rc = dvm_ba_create(device, &h);
+    return *rc == DVM_OK ? h : nullptr;
+  }
+  void give(int device, dvm_ba* h) {
+    std::lock_guard<std::mutex> lock(m);
+    if (idle.size() < 64) { idle.emplace_back(device, h); return; }
+    dvm_ba_destroy(h);
+  }
+};
+BaPool& ba_pool() {
+  static BaPool* p = new BaPool();   // never destroyed: its handles own HIP objects, and the runtime may be gone at static destruction
+  return *p;
+}
+int solve_one_window(dvm_ba* h, const dvm_ba_window& w, const volatile uint8_t* stop_flag, dvm_ba_stats* st) {
+  int rc = dvm_ba_set_problem(h, w.poses, w.fixed, w.n_poses, w.points, w.n_points, w.edges, w.n_edges, &w.cam);
+  if (rc != DVM_OK) return rc;
+  rc = dvm_ba_optimize(h, w.iterations, stop_flag, st);
+  if (rc != DVM_OK) return rc;
+  if (w.poses_out || w.points_out) {
+    // dvm_ba_get_result wants both arrays: a window that asks for one of them gets the other into scratch
+    std::vector<double> tp, tq;
+    double* po = w.poses_out;
+    double* qo = w.points_out;
+    if (!po) { tp.resize((size_t)w.n_poses * 7); po = tp.data(); }
+    if (!qo) { tq.resize((size_t)std::max(w.n_points, 1) * 3); qo = tq.data(); }
+    rc = dvm_ba_get_result(h, po, qo);
+    if (rc != DVM_OK) return rc;
+  }
+  if (w.edge_chi2_out || w.depth_positive_out) rc = dvm_ba_edge_chi2(h, w.edge_chi2_out, w.depth_positive_out);
+  return rc;
+}
+}  // namespace
+
+extern "C" int dvm_ba_optimize_batch(int device, const dvm_ba_window* windows, int K, int threads, const volatile uint8_t* stop_flag,
+                                     dvm_ba_stats* stats) {
+  if (K < 0 || (K && !windows)) return DVM_ERR_INVALID;
+  if (K == 0) return DVM_OK;
+  for (int k = 0; k < K; k++) {
+    const dvm_ba_window& w = windows[k];
+    if (w.n_poses < 1 || w.n_points < 0 || w.n_edges < 0 || w.iterations < 0 || !w.poses || !w.fixed || (w.n_points && !w.points) ||
+        (w.n_edges && !w.edges)) {
+      set_error("dvm_ba_optimize_batch: window " + std::to_string(k) + " is incomplete");
+      return DVM_ERR_INVALID;
+    }
+  }
+  // default 4: the runtime multiplexes a process's streams onto 4 hardware queues (GPU_MAX_HW_QUEUES); measured on 32 LBA windows:
+  // 1 thread 8.5 k it/s, 2: 15.5 k, 4: 22-23 k, 8: 19-27 k (25-27 k with 8 or 16 hardware queues), 32: 17-30 k
+  int T = threads > 0 ? threads : 4;
+  if (const char* e = getenv("DVM_BA_BATCH_THREADS")) T = std::max(1, atoi(e));
+  T = std::max(1, std::min(T, K));
+  std::atomic<int> next{0};
+  std::vector<int> rcs((size_t)K, DVM_OK);
+  std::vector<std::string> errs((size_t)T);
+  std::vector<int> trc((size_t)T, DVM_OK);
+  auto work = [&](int t) {
+    if (hipSetDevice(device) != hipSuccess) { trc[t] = DVM_ERR_HIP; errs[t] = "hipSetDevice failed"; return; }
+    int rc = DVM_OK;
+    dvm_ba* h = ba_pool().take(device, &rc);
+    if (!h) { trc[t] = rc; errs[t] = last_error_cstr(); return; }
+    for (;;) {
+      const int k = next.fetch_add(1);
+      if (k >= K) break;
+      rcs[k] = solve_one_window(h, windows[k], stop_flag, stats ? &stats[k] : nullptr);
+      if (rcs[k] != DVM_OK && errs[t].empty()) errs[t] = "window " + std::to_string(k) + ": " + last_error_cstr();
+    }
+    ba_pool().give(device, h);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  for (int t = 0; t < T; t++)
+    if (trc[t] != DVM_OK) { set_error("dvm_ba_optimize_batch: " + errs[t]); return trc[t]; }
+  for (int k = 0; k < K; k++)
+    if (rcs[k] != DVM_OK) {
+      for (int t = 0; t < T; t++) if (!errs[t].empty()) { set_error("dvm_ba_optimize_batch: " + errs[t]); break; }
+      return rcs[k];
+    }
+  return DVM_OK;
+}

@@ -13,6 +13,7 @@
 namespace dvm {
 
 void set_error(const std::string& msg);
+const char* last_error_cstr();   // the calling thread's last error text
 int hip_check(hipError_t e, const char* what);
 #define DVM_HIP(call)                                  \
   do {                                                 \

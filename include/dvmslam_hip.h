@@ -452,6 +452,15 @@ typedef struct {
   uint8_t* depth_positive_out; /* [n_edges] or NULL: isDepthPositive() at the result */
 } dvm_ba_window;
 int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
+/* The same K independent problems solved CONCURRENTLY on the general solver: up to `threads` (<= 0: 4) host threads of this call each
+ * drive one solver handle from a process-wide pool and pull windows from a shared counter, so that the launch chains of different
+ * windows interleave on the device (one window alone leaves it mostly idle).  Window k gets exactly what dvm_ba_set_problem +
+ * dvm_ba_optimize(iterations) + dvm_ba_get_result + dvm_ba_edge_chi2 on a handle of its own give -- no limit on the number of free
+ * cameras, parity with the CPU recipe as for dvm_ba_optimize (windows of at most 6 free cameras take the sequential-order kernel
+ * there and are bit-identical).  This is the call for several agents' LocalBundleAdjustment windows per GPU
+ * (Optimizer.cc:1030-1387, one LocalMapping thread per agent in the reference).  stats: K entries or NULL. */
+int dvm_ba_optimize_batch(int device, const dvm_ba_window* windows, int K, int threads, const volatile uint8_t* stop_flag,
+                          dvm_ba_stats* stats);
 /* csrc/f64_spec.h evaluated on the device for n arguments: out = [sin(x) | cos(x) | x^3], 3 n doubles.  A test aid: the host build of
  * the spec, the device build and the oracle's restatement must agree bit for bit (tests/test_f64_spec.py, tests/test_gpu_ba_window.py). */
 int dvm_f64_spec_eval(int device, const double* x, int n, double* out);

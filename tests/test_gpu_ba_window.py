@@ -215,3 +215,43 @@ def test_ba_handle_window_mode_hands_over_to_the_tile_solver(oracle):
     Pc, Xc, _, _ = oracle.ba_optimize(P2, pr["fixed"], X2, e, pr["intrinsics"], DELTA, 3, continue_graph=True)
     assert np.array_equal(_bits(P3), _bits(Pc)) and np.array_equal(_bits(X3), _bits(Xc))
     ba.close()
+
+
+def test_concurrent_batch_equals_one_handle_per_window(oracle):
+    """dvm_ba_optimize_batch: K windows of very different sizes (two-keyframe initialisation maps, small local windows, 30-keyframe
+    LocalBundleAdjustment windows) solved concurrently by pooled handles give, window by window, the bits of the same window solved alone
+    through dvm_ba_set_problem + dvm_ba_optimize + dvm_ba_get_result + dvm_ba_edge_chi2; the small ones (sequential-order kernel) are the
+    oracle's bits, the large ones agree with it to the general solver's tolerance."""
+    wins = []
+    for k in range(3):
+        wins.append(_window(synth.small_window_problem(2 + 2 * k, 90 + 30 * k, seed=600 + k), DELTA, 10))
+    for k in range(4):
+        pr = synth.ba_problem(n_kf=30, n_pts=800, k_obs=5, seed=0x2BA + k, radius=12.0)
+        pr["fixed"][:10] = 1
+        wins.append(_window(pr, DELTA, 10))
+    wins.append(_window(synth.small_window_problem(3, 70, seed=610), DELTA, 5))
+    alone = []
+    ba = capi.BundleAdjuster(0)
+    for w in wins:
+        ba.set_problem(w["poses"], w["fixed"], w["points"], w["edges"], w["intrinsics"], w["huber_delta"])
+        st = ba.optimize(w["iterations"])
+        p, x = ba.result()
+        chi, depth = ba.edge_chi2()
+        alone.append((p.copy(), x.copy(), chi.copy(), depth.copy(), st))
+    ba.close()
+    for threads in (0, 1, 3, 8):
+        res = capi.ba_optimize_batch(wins, threads=threads)
+        for k, (g, a) in enumerate(zip(res, alone)):
+            assert np.array_equal(_bits(g["poses"]), _bits(a[0])) and np.array_equal(_bits(g["points"]), _bits(a[1])), (threads, k)
+            assert np.array_equal(_bits(g["edge_chi2"]), _bits(a[2])) and np.array_equal(g["depth_positive"], a[3]), (threads, k)
+            assert g["stats"]["iterations"] == a[4]["iterations"] and list(g["stats"]["trials"]) == list(a[4]["trials"]), (threads, k)
+    for k in (0, 1, 2, 7):
+        _assert_identical(res[k], _oracle(oracle, wins[k]), f"window {k}")
+    for k in (3, 4):
+        P, X, st, chi, depth = _oracle(oracle, wins[k])
+        assert list(res[k]["stats"]["trials"]) == list(st["trials"])
+        assert np.abs(res[k]["poses"] - P).max() < 1e-6 and np.abs(res[k]["points"] - X).max() < 1e-6   # tolerance of the general solver (north_star: 1e-6)
+    # an incomplete window is refused before anything runs
+    bad = dict(wins[0]); bad["edges"] = wins[0]["edges"][:0]; bad["poses"] = wins[0]["poses"][:0]
+    with pytest.raises(capi.DvmError):
+        capi.ba_optimize_batch([wins[0], bad])
