@@ -384,6 +384,25 @@ class FrameGrid:
                                            None, _p(out), _p(second), 0, None))
         return out, second
 
+    def match_window_ranked(self, qdesc, qx, qy, qr, qmin, qmax, skip=None, slot=0):
+        """dvm_match_window_ranked: the four best candidates per query, best first.  Returns (idx [nq,4] int32, -1 past the end; dist [nq,4])."""
+        qdesc = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        nq = len(qdesc)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        ranked = np.zeros((nq, 4), np.uint32)
+        sk = None
+        if skip is not None:
+            sk = np.zeros(self.capacity, np.uint8)
+            sk[:len(skip)] = skip
+        f = self.L.dvm_match_window_ranked
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        check(f(self.h, slot, _p(sk), _p(qdesc), _p(qx), _p(qy), _p(qr), _p(qmin), _p(qmax), nq, _p(ranked), 0, None))
+        dist = (ranked >> 16).astype(np.int32)
+        idx = np.where(dist < 256, (ranked & 0xFFFF).astype(np.int32), -1)
+        return idx, dist
+
     def match_frames_batch(self, first_slot, count, d_kps, kps_stride, d_desc, desc_stride, d_n, carry, cap, th,
                            d_scale, nlevels, d_out, out_stride, d_nq_out=None, stream=None):
         ck, cd, cn = carry if carry else (0, 0, 0)

@@ -451,12 +451,35 @@ int dvm_match_window_top2(const dvm_frame* train, int slot, const uint8_t* skip,
   rc = hip_check(hipGetLastError(), "match launch");
   return rc == DVM_OK ? st.download() : rc;
 }
-int dvm_frame_build_match_window_top2(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
-                                      float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
-                                      const float* qx, const float* qy, const float* qr, const int32_t* qmin,
-                                      const int32_t* qmax, int nq, dvm_match* out, int32_t* second_idx) {
+int dvm_match_window_ranked(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx, const float* qy,
+                            const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked, int on_device, void* stream) {
+  if (!train || slot < 0 || slot >= train->slots || nq < 0) return DVM_ERR_INVALID;
+  if (nq == 0) return DVM_OK;
+  if (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !ranked) return DVM_ERR_INVALID;
+  int rc = hip_check(hipSetDevice(train->device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  if (on_device) {
+    launch_match_window_ranked((hipStream_t)stream, train->view, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, ranked);
+    return hip_check(hipGetLastError(), "match launch");
+  }
+  const size_t qb = (size_t)nq;
+  Stage st;   // the query arrays are read once and the results written once: mapped; the skip flags are looked up per candidate: copied
+  const int iD = st.in_mapped(qdesc, qb * 32), iX = st.in_mapped(qx, qb * 4), iY = st.in_mapped(qy, qb * 4), iR = st.in_mapped(qr, qb * 4),
+            iMin = st.in_mapped(qmin, qb * 4), iMax = st.in_mapped(qmax, qb * 4), iS = st.in(skip, (size_t)train->cap),
+            oR = st.out_mapped(ranked, qb * 16);
+  rc = st.upload();
+  if (rc != DVM_OK) return rc;
+  launch_match_window_ranked(st.stream(), train->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
+                             st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, st.ptr<uint32_t>(oR));
+  rc = hip_check(hipGetLastError(), "match launch");
+  return rc == DVM_OK ? st.download() : rc;
+}
+int dvm_frame_build_match_window_ranked(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
+                                        float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
+                                        const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                        const int32_t* qmax, int nq, uint32_t* ranked) {
   if (!f || slot < 0 || slot >= f->slots || n < 0 || n > f->cap || (n && (!kps || !desc)) || nq < 0) return DVM_ERR_INVALID;
-  if (nq && (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !out)) return DVM_ERR_INVALID;
+  if (nq && (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !ranked)) return DVM_ERR_INVALID;
   int rc = frame_bounds(f, minX, maxX, minY, maxY);
   if (rc != DVM_OK) return rc;
   rc = hip_check(hipSetDevice(f->device), "hipSetDevice");
@@ -466,14 +489,13 @@ int dvm_frame_build_match_window_top2(dvm_frame* f, int slot, const dvm_keypoint
   const int iK = st.in_mapped(kps, (size_t)n * sizeof(dvm_keypoint)), iDs = st.in_mapped(desc, (size_t)n * 32);
   const int iD = st.in_mapped(qdesc, qb * 32), iX = st.in_mapped(qx, qb * 4), iY = st.in_mapped(qy, qb * 4), iR = st.in_mapped(qr, qb * 4),
             iMin = st.in_mapped(qmin, qb * 4), iMax = st.in_mapped(qmax, qb * 4), iS = st.in(skip, (size_t)f->cap),
-            oM = st.out_mapped(out, qb * sizeof(dvm_match)), oS = second_idx ? st.out_mapped(second_idx, qb * 4) : -1;
+            oR = st.out_mapped(ranked, qb * 16);
   rc = st.upload();
   if (rc != DVM_OK) return rc;
   launch_frame_build(st.stream(), st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iDs), 0, n, nullptr, f->view, slot, 1);
   if (nq)
-    launch_match_window(st.stream(), f->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
-                        st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, nullptr, nq, st.ptr<dvm_match_pod>(oM),
-                        second_idx ? st.ptr<int32_t>(oS) : nullptr);
+    launch_match_window_ranked(st.stream(), f->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
+                               st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, st.ptr<uint32_t>(oR));
   rc = hip_check(hipGetLastError(), "frame_build + match launch");
   return rc == DVM_OK ? st.download() : rc;   // (download() synchronises the stream: the grid is complete for any later consumer)
 }

@@ -101,6 +101,8 @@ void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_
 void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc,
                          const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
                          int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out, int32_t* second_idx = nullptr);
+void launch_match_window_ranked(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                                const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked);
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride);
 void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,

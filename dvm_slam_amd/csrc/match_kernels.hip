@@ -239,6 +239,83 @@ __global__ void __launch_bounds__(256) k_match_window(FrameView FB, int first_sl
   }
 }
 
+// The same scan returning the FOUR best candidates in the reference's order of preference (distance, then scan position: strict '<',
+// first wins).  A caller that replays ORBmatcher.cc:1613-1664's claims in query order walks the list to the first keypoint no earlier
+// query of the call has taken -- with the best two only (k_match_window), 15 % of a frame's queries had to be searched again on the host.
+// ranked[q][c] = dist << 16 | train index, dist = 256 from the end of the list on (fewer than four candidates: the list is complete).
+__device__ __forceinline__ void sort4(uint32_t (&k)[4]) {
+  uint32_t t;
+#define DVM_CE(a, b) t = min(k[a], k[b]); k[b] = max(k[a], k[b]); k[a] = t;
+  DVM_CE(0, 1) DVM_CE(2, 3) DVM_CE(0, 2) DVM_CE(1, 3) DVM_CE(1, 2)
+#undef DVM_CE
+}
+__global__ void __launch_bounds__(256) k_match_window_ranked(FrameView FB, int slot, const uint8_t* __restrict__ skip,
+                                                             const uint8_t* __restrict__ qdesc, const float* __restrict__ qx,
+                                                             const float* __restrict__ qy, const float* __restrict__ qr,
+                                                             const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax, int nq,
+                                                             uint32_t* __restrict__ ranked) {
+  const int lane = threadIdx.x & 15;               // lane within the query's DPP row
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (q >= nq) return;
+  const FrameView F = FB.slot(slot);
+  const float x = qx[q], y = qy[q], r = qr[q];
+  const int minLevel = qmin[q], maxLevel = qmax[q];
+  const uint32_t none = (256u << 16) | 0xFFFFu;
+  uint32_t k[4] = {none, none, none, none};
+  const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+  const int nMaxCellX = min(kGridCols - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+  const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+  const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+  const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
+  if (!empty && nMinCellX <= nMaxCellX) {
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(qdesc + (size_t)q * 32);
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = qd[i];
+    const int beg = F.cellx_start[nMinCellX], end = F.cellx_start[nMaxCellX + 1];
+    for (int p = beg + lane; p < end; p += 16) {
+      const float4 kp = F.skp[p];
+      const int oct = __float_as_int(kp.z);
+      const int iy = __float_as_int(kp.w) % kGridRows;
+      if (iy < nMinCellY || iy > nMaxCellY) continue;
+      if (checkLevels) {
+        if (oct < minLevel) continue;
+        if (maxLevel >= 0 && oct > maxLevel) continue;
+      }
+      const float dx = kp.x - x, dy = kp.y - y;
+      if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+      if (skip && skip[F.sidx[p]]) continue;
+      const uint4* td = reinterpret_cast<const uint4*>(F.sdesc + (size_t)p * 32);
+      const uint4 a = td[0], b = td[1];
+      const int d = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
+                    __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
+      const uint32_t key = ((uint32_t)d << 16) | (uint32_t)p;
+      if (key < k[3]) { k[3] = key; sort4(k); }
+    }
+  }
+  // the four smallest of two ascending 4-lists: min(a[i], b[3 - i]) (a bitonic half-cleaner), sorted again; the sets are disjoint
+#define DVM_TOP4_STEP(CTRL)                                                                                     \
+  {                                                                                                             \
+    uint32_t o[4];                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) o[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k[i], CTRL, 0xF, 0xF, false); \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) k[i] = min(k[i], o[3 - i]);                                   \
+    sort4(k);                                                                                                   \
+  }
+  DVM_TOP4_STEP(0xB1)    // quad_perm [1,0,3,2]
+  DVM_TOP4_STEP(0x4E)    // quad_perm [2,3,0,1]
+  DVM_TOP4_STEP(0x141)   // row_half_mirror
+  DVM_TOP4_STEP(0x140)   // row_mirror
+#undef DVM_TOP4_STEP
+  if (lane < 4) {
+    uint32_t mine = k[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) mine = lane == i ? k[i] : mine;
+    const uint32_t d = mine >> 16;
+    ranked[(size_t)q * 4 + lane] = d < 256 ? ((d << 16) | (uint32_t)F.sidx[mine & 0xFFFFu]) : (256u << 16);
+  }
+}
+
 // Best / second-best over an EXPLICIT candidate list per query (CSR: cand[off[q] .. off[q+1]) in the
 // reference's scan order).  This is the inner loop of the vocabulary-node restricted searches --
 // ORBmatcher::SearchByBoW (reference src/ORBmatcher.cc:262-300,:760-800), SearchForTriangulation
@@ -634,6 +711,10 @@ void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint
   PairQueries pq{};
   hipLaunchKernelGGL(k_match_window<false>, dim3((grid_q + 15) / 16, 1), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr,
                      qmin, qmax, nq, d_nq, pq, 0.f, nullptr, 0, out, 0, second_idx);
+}
+void launch_match_window_ranked(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
+                                const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked) {
+  hipLaunchKernelGGL(k_match_window_ranked, dim3((nq + 15) / 16), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, ranked);
 }
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {

@@ -173,21 +173,20 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   std::vector<uint8_t> claimed(grid_cap_, 0);
   for (int j = 0; j < Cur.N; j++)
     if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) claimed[j] = 1;
-  std::vector<dvm_match> res(nq);
-  std::vector<int32_t> runner_up(nq);
+  std::vector<uint32_t> ranked((size_t)nq * 4);   // the four best candidates per query: dist << 16 | index, best first
   if (resident(Cur)) {   // keypoints + descriptors still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> here)
     last_grid_from_device = true;
     void* ts = dvm_thread_stream(device_);
     rc = dvm_frame_build(grid_, 0, Cur.dev->d_kps, Cur.dev->d_desc, Cur.N, nullptr, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, 1, ts);
     if (rc != DVM_OK) return rc;
     mark("grid");
-    rc = dvm_match_window_top2(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
-                               nullptr, res.data(), runner_up.data(), 0, nullptr);
+    rc = dvm_match_window_ranked(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
+                                 ranked.data(), 0, nullptr);
   } else {
     last_grid_from_device = false;
-    rc = dvm_frame_build_match_window_top2(grid_, 0, Cur.mvKeysUn, Cur.mDescriptors, Cur.N, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY,
-                                           claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
-                                           res.data(), runner_up.data());
+    rc = dvm_frame_build_match_window_ranked(grid_, 0, Cur.mvKeysUn, Cur.mDescriptors, Cur.N, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY,
+                                             claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
+                                             ranked.data());
   }
   if (rc != DVM_OK) return rc;
   mark("match");
@@ -200,11 +199,19 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   std::vector<uint8_t> claimed_now = claimed;
   std::vector<int> cand;
   for (int q = 0; q < nq; q++) {
-    int bestIdx2 = res[q].best_idx, bestDist = res[q].best_dist;
-    if (bestIdx2 >= 0 && claimed_now[bestIdx2] && !claimed[bestIdx2] && runner_up[q] >= 0 && !claimed_now[runner_up[q]]) {
-      // the scan skips the claimed best and ends on the runner-up (strict '<', first wins: the second smallest (distance, position))
-      bestIdx2 = runner_up[q]; bestDist = res[q].second_dist;
-    } else if (bestIdx2 >= 0 && claimed_now[bestIdx2] && !claimed[bestIdx2]) {
+    // the scan of :1613-1650 skips keypoints an earlier query of this call has taken and keeps the smallest (distance, position) of
+    // the rest: the first entry of the ranked list that is still free.  Only when all four are taken (and the list may go on) is the
+    // window searched again here.
+    int bestIdx2 = -1, bestDist = 256;
+    bool exhausted = true;
+    for (int c = 0; c < 4; c++) {
+      const uint32_t key = ranked[(size_t)q * 4 + c];
+      const int dist = (int)(key >> 16);
+      if (dist >= 256) { exhausted = false; break; }   // end of the list: nothing else in the window
+      const int idx = (int)(key & 0xFFFFu);
+      if (!claimed_now[idx]) { bestIdx2 = idx; bestDist = dist; exhausted = false; break; }
+    }
+    if (exhausted) {
       const auto tq0 = dbg ? std::chrono::steady_clock::now() : T0;
       if (!hg_built) { hg.build(Cur); hg_built = true; }
       last_requeried++;

@@ -194,14 +194,20 @@ int dvm_match_window(const dvm_frame* train, int slot, const uint8_t* skip, cons
 int dvm_match_window_top2(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                           const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq,
                           const int32_t* d_nq, dvm_match* out, int32_t* second_idx, int on_device, void* stream);
+/* The same scan returning the FOUR best candidates of every query in the reference's order of preference (distance, then scan
+ * position): ranked[4 q + c] = dist << 16 | train index, dist = 256 from the end of the list on (fewer than four candidates: the list
+ * is complete).  For a caller replaying ORBmatcher.cc:1613-1664's claims in query order: it walks the list to the first keypoint no
+ * earlier query of the call has taken, and searches again itself only when all four are gone. */
+int dvm_match_window_ranked(const dvm_frame* train, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx, const float* qy,
+                            const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked, int on_device, void* stream);
 /* Host-pointer convenience, latency path of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1553-1748):
- * dvm_frame_build(f, slot, kps, desc, n, ..., on_device = 0) followed by dvm_match_window_top2(f, slot, ..., on_device = 0) as ONE
+ * dvm_frame_build(f, slot, kps, desc, n, ..., on_device = 0) followed by dvm_match_window_ranked(f, slot, ..., on_device = 0) as ONE
  * staged call -- one upload, the two kernels back to back on the calling thread's stream, one synchronisation.  Same results as
  * the two calls. */
-int dvm_frame_build_match_window_top2(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
-                                      float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
-                                      const float* qx, const float* qy, const float* qr, const int32_t* qmin,
-                                      const int32_t* qmax, int nq, dvm_match* out, int32_t* second_idx);
+int dvm_frame_build_match_window_ranked(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
+                                        float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
+                                        const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                        const int32_t* qmax, int nq, uint32_t* ranked);
 /* The stream the host-pointer convenience calls of the CALLING THREAD run on (device `device`; created on first use).  A caller
  * that builds a grid with on_device = 1 and then searches it through a host-pointer call passes it as `stream`, so that the two are
  * one in-order chain (no synchronisation in between). */

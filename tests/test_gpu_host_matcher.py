@@ -17,8 +17,20 @@ def test_search_by_projection_frames(capi, oracle, seed, th, ori):
     assert n_g == n_o
     assert np.array_equal(mp_g, mp_o)
     assert n_o > 300
-    if seed == 0:
-        assert req > 0, "scene must exercise the claimed-keypoint re-query path"
+
+
+def test_search_by_projection_frames_crowded(capi, oracle):
+    """Several times more projected map points than keypoints and wide windows: the four best candidates the device returns per query
+    are often all taken by earlier queries of the call, so the host's fallback search (the full window again, claims applied) runs -- and
+    the result is still the sequential oracle's."""
+    total = 0
+    for seed, n_cur, th in ((7, 160, 60.0), (8, 220, 40.0), (9, 300, 80.0)):
+        sc = make_scene(oracle, seed, n_last=1000, n_cur=n_cur)
+        n_o, mp_o = oracle.search_by_projection_frames(th=th, check_ori=True, **sc)
+        n_g, mp_g, req = capi.search_by_projection_frames(th=th, check_ori=True, **sc)
+        assert n_g == n_o and np.array_equal(mp_g, mp_o), (seed, n_cur)
+        total += req
+    assert total > 20, "the scenes must exercise the fallback search"
 
 
 def test_search_by_projection_frames_degenerate(capi, oracle):

@@ -69,6 +69,23 @@ def test_match_window_vs_oracle(capi, oracle, frames):
         assert int(o["best_idx"][0]) == int(second[q]) and (second[q] < 0 or int(o["best_dist"][0]) == int(g2["second_dist"][q]))
         checked += second[q] >= 0
     assert checked > 50
+    # the ranked list (dvm_match_window_ranked): entry c is what the scan returns when entries 0..c-1 are masked as well
+    ridx, rdist = grid_g.match_window_ranked(qd, qx, qy, qr, qmin, qmax, skip=skip)
+    assert np.array_equal(ridx[:, 0], g2["best_idx"]) and np.array_equal(rdist[:, 0][ridx[:, 0] >= 0], g2["best_dist"][ridx[:, 0] >= 0])
+    assert np.array_equal(ridx[:, 1], second)
+    deep = 0
+    for q in np.flatnonzero(ridx[:, 1] >= 0)[:150]:
+        sk2 = skip.copy()
+        for c in range(4):
+            o = grid_o.match_window(d1, qd[q:q + 1], qx[q:q + 1], qy[q:q + 1], qr[q:q + 1], qmin[q:q + 1], qmax[q:q + 1], skip=sk2)
+            assert int(o["best_idx"][0]) == int(ridx[q, c]), (q, c)
+            if ridx[q, c] < 0:
+                assert np.all(ridx[q, c:] < 0) and np.all(rdist[q, c:] == 256)
+                break
+            assert int(o["best_dist"][0]) == int(rdist[q, c])
+            sk2[ridx[q, c]] = 1
+            deep += c == 3
+    assert deep > 20
     grid_g.close()
 
 
