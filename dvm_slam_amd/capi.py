@@ -203,15 +203,15 @@ class OrbExtractor:
             return -1, None, None, -1
         if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
             img = np.ascontiguousarray(img, np.uint8)  # row-strided views (stride > cols) pass through as they are
-        kps = np.zeros(self.cap, KP_DTYPE)
-        desc = np.zeros((self.cap, 32), np.uint8)
+        kps = np.empty(self.cap, KP_DTYPE)          # (the call fills [0, n); the rest is never looked at)
+        desc = np.empty((self.cap, 32), np.uint8)
         n, mono = C.c_int(0), C.c_int(0)
         rc = self.L.dvm_orb_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], lap[0], lap[1],
                                     _p(kps), _p(desc), self.cap, C.byref(n), C.byref(mono))
         if rc == -3 and n.value > self.cap:   # DVM_ERR_CAPACITY: *n holds the size needed (small quotas on wide images)
             return self.download(0, cap=n.value)
         check(rc)
-        return n.value, kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+        return n.value, kps[:n.value], desc[:n.value], mono.value
 
     def extract_batch_host(self, imgs: np.ndarray, lap=(0, 1000)):
         imgs = np.ascontiguousarray(imgs, np.uint8)

@@ -135,10 +135,11 @@ class OrbPipeline {
   // (2) the blur stays on the main chain: the fork / join events around a side stream cost more than the 9 us the blur takes;
   // (3) k_assemble / k_orient_desc also store counts, keypoints and descriptors into mapped host memory, so download() is a
   //     stream synchronisation and a memcpy;
-  // (4) k_octree keeps a level's keys and node ids in LDS (template variant).
+  // (4) k_octree<true>: wave-synchronous rounds, the level's keys and node ids in LDS (octree_rounds_wave.inc).
   // DVM_LATENCY_PATH=0 / DVM_ZERO_COPY_IN=0: A-B switches.  Tried and not kept: the pyramid in one launch with inter-workgroup
   // flags (write-through stores + per-row-tile counters: 56 us against 45 us for the eight launches -- a cross-XCD hand-off costs
-  // more than a kernel boundary); the whole call as a captured hipGraph (0.183 ms: replay is no cheaper than 17 eager calls);
+  // more than a kernel boundary); three pyramid levels per launch, a tile recomputing the rectangles of the levels between its
+  // group's base and itself in LDS (bit-identical, 15 us per three-level group against 3 x 5 us: no gain at 256 or 1 024 threads); the whole call as a captured hipGraph (0.183 ms: replay is no cheaper than 17 eager calls);
   // level 0's FAST + octree on a second stream behind k_pyr_level0 (DVM_LAT_SPLIT=1, 0.187 ms: the host issues the second
   // chain's launches in front of the first one's, and in a graph the branches serialised: 0.34 ms).
   static constexpr int kLatencyBatch = 4;
