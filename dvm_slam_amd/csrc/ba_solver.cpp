@@ -1030,12 +1030,24 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
   DVM_HIP(hipSetDevice(device));
   const size_t B = (size_t)batch, S = (size_t)stride;
   Stage st;   // the calling thread's staging context: one upload, one download, one synchronisation (host_stage.h)
-  const int iP = st.in(pose_in, B * 7 * 8), iX = st.in(Xw, B * S * 3 * 8), iO = st.in(obs, B * S * 2 * 8), iW = st.in(inv_sigma2, B * S * 8),
-            iN = st.in(n, B * 4), oP = st.out(pose_out, B * 7 * 8), oL = st.out(outlier, B * S), oI = st.out(n_inliers, B * 4),
-            sC = st.scratch(B * S * 8);
+  // A frame or a few (Tracking's per-frame call): k_pose_optimize reads every correspondence ONCE, into registers, and writes the
+  // results once at the end, so the arrays stay in mapped host memory and no copy command brackets the kernel.  Beyond
+  // kPoseEdgesPerThread x 256 correspondences per frame the kernel re-reads them every iteration: copied, as large batches are.
+  const bool direct = S <= 1280 && B * S <= 8192;
+  int iP, iX, iO, iW, iN, oP, oL, oI;
+  if (direct) {
+    iP = st.in_mapped(pose_in, B * 7 * 8); iX = st.in_mapped(Xw, B * S * 3 * 8); iO = st.in_mapped(obs, B * S * 2 * 8);
+    iW = st.in_mapped(inv_sigma2, B * S * 8); iN = st.in_mapped(n, B * 4);
+    oP = st.out_mapped(pose_out, B * 7 * 8); oL = st.out_mapped(outlier, B * S); oI = st.out_mapped(n_inliers, B * 4);
+  } else {
+    iP = st.in(pose_in, B * 7 * 8); iX = st.in(Xw, B * S * 3 * 8); iO = st.in(obs, B * S * 2 * 8); iW = st.in(inv_sigma2, B * S * 8);
+    iN = st.in(n, B * 4);
+    oP = st.out(pose_out, B * 7 * 8); oL = st.out(outlier, B * S); oI = st.out(n_inliers, B * 4);
+  }
+  const int sC = st.scratch(B * S * 8);
   int rc = st.upload();
   if (rc != DVM_OK) return rc;
-  ba_launch_pose_optimize(nullptr, st.ptr<double>(iP), st.ptr<double>(iX), st.ptr<double>(iO), st.ptr<double>(iW), st.ptr<int32_t>(iN), stride,
+  ba_launch_pose_optimize(st.stream(), st.ptr<double>(iP), st.ptr<double>(iX), st.ptr<double>(iO), st.ptr<double>(iW), st.ptr<int32_t>(iN), stride,
                           batch, cam->fx, cam->fy, cam->cx, cam->cy, st.ptr<double>(oP), st.ptr<uint8_t>(oL), st.ptr<int32_t>(oI),
                           st.ptr<double>(sC));
   rc = hip_check(hipGetLastError(), "pose_optimize launch");

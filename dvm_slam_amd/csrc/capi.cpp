@@ -477,7 +477,7 @@ int dvm_match_window_ranked(const dvm_frame* train, int slot, const uint8_t* ski
 int dvm_frame_build_match_window_ranked(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
                                         float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
                                         const float* qx, const float* qy, const float* qr, const int32_t* qmin,
-                                        const int32_t* qmax, int nq, uint32_t* ranked) {
+                                        const int32_t* qmax, int nq, uint32_t* ranked, int kps_on_device) {
   if (!f || slot < 0 || slot >= f->slots || n < 0 || n > f->cap || (n && (!kps || !desc)) || nq < 0) return DVM_ERR_INVALID;
   if (nq && (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !ranked)) return DVM_ERR_INVALID;
   int rc = frame_bounds(f, minX, maxX, minY, maxY);
@@ -486,13 +486,15 @@ int dvm_frame_build_match_window_ranked(dvm_frame* f, int slot, const dvm_keypoi
   if (rc != DVM_OK) return rc;
   const size_t qb = (size_t)nq;
   Stage st;
-  const int iK = st.in_mapped(kps, (size_t)n * sizeof(dvm_keypoint)), iDs = st.in_mapped(desc, (size_t)n * 32);
+  // (kps_on_device: the frame's keypoints + descriptors are device arrays already -- where the extractor left them)
+  const int iK = kps_on_device ? -1 : st.in_mapped(kps, (size_t)n * sizeof(dvm_keypoint)), iDs = kps_on_device ? -1 : st.in_mapped(desc, (size_t)n * 32);
   const int iD = st.in_mapped(qdesc, qb * 32), iX = st.in_mapped(qx, qb * 4), iY = st.in_mapped(qy, qb * 4), iR = st.in_mapped(qr, qb * 4),
             iMin = st.in_mapped(qmin, qb * 4), iMax = st.in_mapped(qmax, qb * 4), iS = st.in(skip, (size_t)f->cap),
             oR = st.out_mapped(ranked, qb * 16);
   rc = st.upload();
   if (rc != DVM_OK) return rc;
-  launch_frame_build(st.stream(), st.ptr<dvm_keypoint_pod>(iK), 0, st.ptr<uint8_t>(iDs), 0, n, nullptr, f->view, slot, 1);
+  launch_frame_build(st.stream(), kps_on_device ? reinterpret_cast<const dvm_keypoint_pod*>(kps) : st.ptr<dvm_keypoint_pod>(iK), 0,
+                     kps_on_device ? desc : st.ptr<uint8_t>(iDs), 0, n, nullptr, f->view, slot, 1);
   if (nq)
     launch_match_window_ranked(st.stream(), f->view, slot, st.ptr<uint8_t>(iS), st.ptr<uint8_t>(iD), st.ptr<float>(iX), st.ptr<float>(iY),
                                st.ptr<float>(iR), st.ptr<int32_t>(iMin), st.ptr<int32_t>(iMax), nq, st.ptr<uint32_t>(oR));

@@ -174,20 +174,12 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   for (int j = 0; j < Cur.N; j++)
     if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) claimed[j] = 1;
   std::vector<uint32_t> ranked((size_t)nq * 4);   // the four best candidates per query: dist << 16 | index, best first
-  if (resident(Cur)) {   // keypoints + descriptors still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> here)
-    last_grid_from_device = true;
-    void* ts = dvm_thread_stream(device_);
-    rc = dvm_frame_build(grid_, 0, Cur.dev->d_kps, Cur.dev->d_desc, Cur.N, nullptr, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, 1, ts);
-    if (rc != DVM_OK) return rc;
-    mark("grid");
-    rc = dvm_match_window_ranked(grid_, 0, claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
-                                 ranked.data(), 0, nullptr);
-  } else {
-    last_grid_from_device = false;
-    rc = dvm_frame_build_match_window_ranked(grid_, 0, Cur.mvKeysUn, Cur.mDescriptors, Cur.N, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY,
-                                             claimed.data(), qdesc.data(), qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq,
-                                             ranked.data());
-  }
+  // keypoints + descriptors still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> here): the grid is built from there
+  const bool res = resident(Cur);
+  last_grid_from_device = res;
+  rc = dvm_frame_build_match_window_ranked(grid_, 0, res ? Cur.dev->d_kps : Cur.mvKeysUn, res ? Cur.dev->d_desc : Cur.mDescriptors, Cur.N,
+                                           Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, claimed.data(), qdesc.data(), qx.data(), qy.data(),
+                                           qr.data(), qmin.data(), qmax.data(), nq, ranked.data(), res ? 1 : 0);
   if (rc != DVM_OK) return rc;
   mark("match");
 

@@ -203,11 +203,12 @@ int dvm_match_window_ranked(const dvm_frame* train, int slot, const uint8_t* ski
 /* Host-pointer convenience, latency path of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1553-1748):
  * dvm_frame_build(f, slot, kps, desc, n, ..., on_device = 0) followed by dvm_match_window_ranked(f, slot, ..., on_device = 0) as ONE
  * staged call -- one upload, the two kernels back to back on the calling thread's stream, one synchronisation.  Same results as
- * the two calls. */
+ * the two calls.  kps_on_device != 0: kps / desc are DEVICE arrays (dvm_orb_last_result: the frame as the extractor left it in HBM);
+ * everything else stays a host pointer. */
 int dvm_frame_build_match_window_ranked(dvm_frame* f, int slot, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX,
                                         float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
                                         const float* qx, const float* qy, const float* qr, const int32_t* qmin,
-                                        const int32_t* qmax, int nq, uint32_t* ranked);
+                                        const int32_t* qmax, int nq, uint32_t* ranked, int kps_on_device);
 /* The stream the host-pointer convenience calls of the CALLING THREAD run on (device `device`; created on first use).  A caller
  * that builds a grid with on_device = 1 and then searches it through a host-pointer call passes it as `stream`, so that the two are
  * one in-order chain (no synchronisation in between). */
