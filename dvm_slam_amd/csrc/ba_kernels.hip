@@ -1842,6 +1842,12 @@ __device__ __forceinline__ double block_sum_one(double v, double* part4) {
 // Newton steps, as the tile Cholesky does) instead of 27 double-precision divisions and 6 square roots on a single lane.
 // (Measured, one frame of 300 matches: 363 us per call before, of which ~2.8 us per LM trial were the divisions.)
 constexpr int kPoseEdgesPerThread = 5;
+#ifdef DVM_POSE_PROF   // make EXTRA=-DDVM_POSE_PROF: per-phase clocks of workgroup 0 (dvm_debug_pose_prof), measurement builds only
+__device__ unsigned long long g_pose_prof[16];
+#define POSE_T(k) do { if (tid == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_pose_prof[k] += now_ - pose_last_; pose_last_ = now_; } } while (0)
+#else
+#define POSE_T(k) do {} while (0)
+#endif
 __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict__ pose_in, const double* __restrict__ Xw,
                                                        const double* __restrict__ obs, const double* __restrict__ info,
                                                        const int32_t* __restrict__ n_per_frame, int stride, double fx,
@@ -1855,6 +1861,9 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
   __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
   __shared__ int s_ctl, s_qmax, s_nbad, s_nact;
   const int f = blockIdx.x, tid = threadIdx.x;
+#ifdef DVM_POSE_PROF
+  unsigned long long pose_last_ = wall_clock64();
+#endif
   const int N = n_per_frame[f];
   const double* X = Xw + (size_t)f * stride * 3;
   const double* O = obs + (size_t)f * stride * 2;
@@ -1956,8 +1965,10 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
     if (my) atomicAdd(&s_nact, my);
     __syncthreads();
     const int nact = s_nact;
+    POSE_T(0);
     for (int it = 0; it < 10 && nact > 0; it++) {
       eval(s_T, true, robust_on);
+      POSE_T(1);
       if (tid == 0) {
         s_cur = s_sum[27]; s_ini = s_sum[27];
         if (it == 0) {
@@ -1976,6 +1987,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
 #pragma unroll
         for (int i = 0; i < 6; i++) bs[i] = s_sum[21 + i];
       }
+      POSE_T(2);
       while (true) {
         double xs[6];
         bool ok = true;
@@ -2021,8 +2033,10 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
           s_ctl = ok ? 1 : 0;
         }
         __syncthreads();
+        POSE_T(3);
         const bool okb = s_ctl != 0;
         if (okb) eval(s_T, false, robust_on);
+        POSE_T(4);
         if (tid == 0) {
           const double tempChi = okb ? s_sum[27] : 1.7976931348623157e308;
           double rho = s_cur - tempChi;
@@ -2031,7 +2045,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
           scale += 1e-3;
           rho /= scale;
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow(2 * rho - 1, 3);
+            double alpha = 1. - f64_cube(2 * rho - 1);   // pow(2 rho - 1, 3) as the shared double-precision spec forms it (f64_spec.h)
             alpha = fmin(alpha, 2. / 3.);
             s_lambda *= fmax(1. / 3., alpha);
             s_ni = 2;
@@ -2045,6 +2059,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
           s_ctl = (rho < 0 && s_qmax < 10) ? 1 : 0;  // continue the trial loop?
         }
         __syncthreads();
+        POSE_T(5);
         if (!s_ctl) break;
         __syncthreads();
       }
@@ -2060,6 +2075,10 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
       __syncthreads();
       const int stop = s_ctl;
       __syncthreads();
+      POSE_T(6);
+#ifdef DVM_POSE_PROF
+      if (tid == 0 && blockIdx.x == 0) g_pose_prof[15]++;
+#endif
       if (stop) break;
     }
     // classification (Optimizer.cc:923-948): outliers recompute their error, inliers report the last evaluation
@@ -2087,6 +2106,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
     }
     if (round == 2) robust_on = false;
     __syncthreads();
+    POSE_T(7);
     if (N < 10) break;  // optimizer.edges().size() < 10
   }
   if (tid == 0) s_nact = 0;
@@ -2104,6 +2124,15 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
   if (tid == 0) n_inliers[f] = N - s_nact;
 }
 
+#ifdef DVM_POSE_PROF
+extern "C" int dvm_debug_pose_prof(unsigned long long* out, int reset) {
+  unsigned long long h[16];
+  int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pose_prof), sizeof(h));
+  for (int i = 0; i < 16; i++) out[i] = h[i];
+  if (reset) { for (auto& v : h) v = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pose_prof), h, sizeof(h)); }
+  return rc;
+}
+#endif
 void ba_launch_pose_optimize(hipStream_t s, const double* pose_in, const double* Xw, const double* obs, const double* info,
                              const int32_t* n_per_frame, int stride, int batch, double fx, double fy, double cx, double cy,
                              double* pose_out, uint8_t* outlier, int32_t* n_inliers, double* chi_scratch) {
@@ -2365,7 +2394,7 @@ __global__ void __launch_bounds__(256) k_optimize_sim3(double* __restrict__ S12i
           scale += 1e-3;
           rho /= scale;
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow(2 * rho - 1, 3);
+            double alpha = 1. - f64_cube(2 * rho - 1);   // pow(2 rho - 1, 3) as the shared double-precision spec forms it (f64_spec.h)
             alpha = fmin(alpha, 2. / 3.);
             s_lambda *= fmax(1. / 3., alpha);
             s_ni = 2;

@@ -570,7 +570,7 @@ int orc_pose_optimize(double* pose, const double* Xw, const double* obs, const d
         scale += 1e-3;
         rho /= scale;
         if (rho > 0 && std::isfinite(tempChi)) {
-          double alpha = 1. - std::pow(2 * rho - 1, 3);
+          double alpha = 1. - orc_spec::cube(2 * rho - 1);
           alpha = std::min(alpha, 2. / 3.);
           lambda *= std::max(1. / 3., alpha);
           ni = 2;
@@ -748,7 +748,7 @@ int orc_optimize_sim3(double* S12io, int fix_scale, const double* P1c, const dou
         rho = currentChi - tempChi;
         double scale = 0; if (ok) for (int j = 0; j < 7; j++) scale += x[j] * (lambda * x[j] + b[j]);
         scale += 1e-3; rho /= scale;
-        if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - std::pow(2 * rho - 1, 3); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
+        if (rho > 0 && std::isfinite(tempChi)) { double alpha = 1. - orc_spec::cube(2 * rho - 1); alpha = std::min(alpha, 2. / 3.); lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; }
         else { lambda *= ni; ni *= 2; S = bak; }
         qmax++;
       } while (rho < 0 && qmax < 10);
@@ -946,7 +946,7 @@ int orc_pose_graph_optimize(double* Sio, const uint8_t* fixed, int n, const int3
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        double alpha = 1. - orc_spec::cube(2 * rho - 1);
         alpha = std::min(alpha, 2. / 3.);
         lambda *= std::max(1. / 3., alpha);
         ni = 2;
