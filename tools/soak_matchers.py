@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from dvm_slam_amd import capi, synth     # noqa: E402
 from oracle import pyoracle as po        # noqa: E402
-from matcher_scene import make_init_scene, make_kf_pair_scene   # noqa: E402
+from matcher_scene import make_init_scene, make_kf_pair_scene, make_scene   # noqa: E402
 
 
 def one_case(rng):
@@ -76,6 +76,15 @@ def one_case(rng):
     F1 = capi.frame_view(si["k1"], si["d1"], si["bounds"], si["scale_factors"]); F2 = capi.frame_view(si["k2"], si["d2"], si["bounds"], si["scale_factors"])
     n_g, m_g, pm_g = capi.search_for_initialization(F1, F2, si["prev_matched"], win, 0.9, ori)
     if n_o != n_g or not np.array_equal(m_o, m_g) or not np.array_equal(pm_o, pm_g): bad.append("init")
+    # SearchByProjection(CurrentFrame, LastFrame): from sparse to crowded frames (the device's ranked four candidates per query, the
+    # host's claim replay and -- when all four are taken -- its fallback search)
+    n_cur = int(rng.choice([120, 200, 400, 800, 1100, 2000]))
+    sf = make_scene(po, seed, n_last=int(rng.integers(100, 1500)), n_cur=n_cur, dup_frac=float(rng.uniform(0, 0.4)),
+                    zero_obs_frac=float(rng.uniform(0, 0.3)), flip_bits=int(rng.integers(0, 40)))
+    thf = float(rng.choice([7.0, 15.0, 30.0, 60.0]))
+    n_o, mp_o = po.search_by_projection_frames(th=thf, check_ori=ori, **sf)
+    n_g, mp_g, _ = capi.search_by_projection_frames(th=thf, check_ori=ori, **sf)
+    if n_o != n_g or not np.array_equal(mp_o, mp_g): bad.append("search_by_projection_frames")
     return seed, bad
 
 
@@ -90,7 +99,7 @@ def main():
         if bad:
             nbad += 1
             print("MISMATCH seed", seed, bad, flush=True)
-    print(f"soak_matchers: {cases} scenes x 9 functions, {nbad} scenes with mismatches, {time.time() - t0:.0f} s")
+    print(f"soak_matchers: {cases} scenes x 10 functions, {nbad} scenes with mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if nbad else 0)
 
 
