@@ -11,11 +11,13 @@
 
 namespace dvm {
 // Host-pointer convenience paths.  Every calling thread keeps ONE staging context per device: a page-locked host buffer, a
-// device buffer (both grow-only) and a stream.  A call packs its inputs into the pinned buffer, sends them with one
-// asynchronous copy, launches its kernels on the legacy default stream -- the context's stream is a BLOCKING stream, so the
-// default stream orders itself behind the upload and the download behind the kernels --, fetches all outputs with one copy
-// and synchronises once.  (hipMalloc + a pageable hipMemcpy per array + hipDeviceSynchronize + hipFree per call made
-// ORBmatcher::SearchByProjection over 1 100 keypoints a 1.8 ms call next to a 0.44 ms CPU run of the same function.)
+// device buffer, a MAPPED page-locked buffer (all grow-only) and a stream.  A call packs its copied inputs into the pinned buffer
+// and sends them with one asynchronous copy, writes its mapped inputs where the kernels read them in place, launches its kernels,
+// fetches the copied outputs with one copy and synchronises once.  The context's stream is a BLOCKING stream: entry points that
+// still launch on the legacy default stream are ordered behind the upload and in front of the download by the runtime; the per-frame
+// entry points (grid build, window searches, PoseOptimization) launch on stream() itself -- one in-order chain, no cross-stream
+// hand-off.  (hipMalloc + a pageable hipMemcpy per array + hipDeviceSynchronize + hipFree per call made
+// ORBmatcher::SearchByProjection over 1 100 keypoints a 1.8 ms call next to a 0.44 ms CPU run of the same function; it is 0.10 ms now.)
 struct StageCtx {
   int device = -1;
   hipStream_t s = nullptr;
