@@ -520,6 +520,10 @@ int OrbPipeline::configure(int rows, int cols) {
     const size_t mb = std::min<size_t>(B, kLatencyBatch);
     DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_kps_m), mb * PD.kp_cap * sizeof(dvm_keypoint_pod), hipHostMallocMapped));
     DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_desc_m), mb * PD.kp_cap * 32, hipHostMallocMapped));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&mirror_dev.kps), h_kps_m, 0));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&mirror_dev.desc), h_desc_m, 0));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&mirror_dev.n), h_n, 0));
+    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&mirror_dev.mono), h_mono, 0));
   }
   if (!tabs.empty()) DVM_HIP(hipMemcpy(d_tabs, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice));
   if (!cells.empty()) DVM_HIP(hipMemcpy(d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
@@ -540,7 +544,7 @@ int OrbPipeline::ensure_stage(size_t need) {
     copy_pending = false; stage_free_valid = false;
     if (d_stage) hipFree(d_stage);
     if (h_stage) hipHostFree(h_stage);
-    d_stage = nullptr; h_stage = nullptr; stage_bytes = 0;
+    d_stage = nullptr; h_stage = nullptr; stage_bytes = 0; stage_view = nullptr;
     DVM_HIP(hipMalloc(&d_stage, need));
     DVM_HIP(hipHostMalloc(&h_stage, need));
     stage_bytes = need;
@@ -563,9 +567,8 @@ int OrbPipeline::extract_host(const uint8_t* imgs, int batch, int rows, int cols
     for (int y = 0; y < rows; y++)
       std::memcpy(h_stage + ((size_t)f * rows + y) * cols, imgs + (size_t)f * frame_stride + (size_t)y * stride, cols);
   if (latency_path && zero_copy_in && batch <= kLatencyBatch) {   // level 0 reads the pinned buffer itself (see orb_pipeline.h)
-    uint8_t* d_view = nullptr;
-    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_view), h_stage, 0));
-    return extract_device(d_view, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
+    if (!stage_view) DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&stage_view), h_stage, 0));
+    return extract_device(stage_view, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
   }
   DVM_HIP(hipMemcpyAsync(d_stage, h_stage, need, hipMemcpyHostToDevice, stream));
   return extract_device(d_stage, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
@@ -625,10 +628,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
   HostMirror hm;
   last_mirrored = small;
   if (small) {
-    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.kps), h_kps_m, 0));
-    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.desc), h_desc_m, 0));
-    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.n), h_n, 0));
-    DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hm.mono), h_mono, 0));
+    hm = mirror_dev;   // (device addresses of the mapped result buffers, looked up once per configuration)
   }
   const bool blur_first = blur_early && !small;
   const bool split0 = small && lat_split && overlap_blur && !host_octree && !tiny_levels && L > 1 && chunks == 1 && group_split[0] >= L;

@@ -149,6 +149,8 @@ class OrbPipeline {
   bool last_mirrored = false;        // the last batch's results are in h_kps_m / h_desc_m / h_n / h_mono
   dvm_keypoint_pod* h_kps_m = nullptr;   // [kLatencyBatch][kp_cap], mapped
   uint8_t* h_desc_m = nullptr;           // [kLatencyBatch][kp_cap][32], mapped
+  HostMirror mirror_dev;                 // their device addresses (and those of h_n / h_mono)
+  uint8_t* stage_view = nullptr;         // device address of h_stage
 
  private:
   int configure(int rows, int cols);
