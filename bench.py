@@ -14,7 +14,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      -- dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration
   cpu_baseline  -- the CPU oracle (port of the reference path) timed single-threaded on this host
   ba            -- bundle-adjustment iterations/s (second half of BASELINE.json's metric) when built
-  latency / lba / merge / ba_cold -- per-call costs of configs 2 and 3 through the drop-in boundary (bench_legs.py)
+  latency / online_agents / lba / lba_batch / merge / ba_cold -- per-call costs of configs 2, 3 and 4 through the drop-in boundary (bench_legs.py)
 """
 from __future__ import annotations
 
@@ -502,6 +502,7 @@ def main():
             for name, fn in (("batch_sweep", lambda: bench_legs.batch_sweep()),
                              ("low_texture", lambda: bench_legs.low_texture(capi, local, cpu=cpu)),
                              ("latency", lambda: bench_legs.latency(capi, frames[:64], local, cpu_calls=24 if cpu else 0)),
+                             ("online_agents", lambda: bench_legs.online_agents(capi, frames[:16], local)),
                              ("lba", lambda: bench_legs.lba(local, cpu_seconds=4.0 if cpu else 0.0)),
                              ("lba_batch", lambda: bench_legs.lba_batch(local, cpu_windows=4 if cpu else 0)),
                              ("merge", lambda: bench_legs.merge(local, cpu_reps=3 if cpu else 0)),

@@ -177,6 +177,77 @@ def low_texture(capi, device, cpu=True, steps=3):
     return out
 
 
+def online_agents(capi, frames, device, Ks=(1, 2, 4, 8), frames_per_agent=150):
+    """K agents tracking on ONE GPU through the drop-in boundary, a host thread and an extractor handle each (the online shape of BASELINE
+    config 4 with more agents than GPUs): per frame ORBextractor::operator() -> SearchByProjection(Cur, Last) -> PoseOptimization, host
+    arrays in and out, every call synchronous as Tracking makes them.  Whole-job frames/s over the K threads; results of every thread are
+    checked against the single-thread run of the same frames (same calls, same bits)."""
+    import threading
+    scale = None
+    K4 = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    rng = np.random.default_rng(9)
+    ext0 = capi.OrbExtractor(max_batch=1, device=device)
+    scale = ext0.tables()["scale"]
+    cyc = 8
+    exts = [ext0.extract(frames[t]) for t in range(cyc + 1)]
+    pairs = []
+    for t in range(1, cyc + 1):
+        _, k0, d0, _ = exts[t - 1]
+        _, k1, d1, _ = exts[t]
+        z = rng.uniform(3, 9, len(k0)).astype(np.float32)
+        mps = np.zeros(len(k0), capi.MAP_POINT_DTYPE)
+        mps["pos"][:, 0] = (k0["x"] - K4[2]) / K4[0] * z; mps["pos"][:, 1] = (k0["y"] - K4[3]) / K4[1] * z; mps["pos"][:, 2] = z
+        mps["desc"] = d0; mps["n_obs"] = 1
+        pairs.append(dict(kps_c=k1, desc_c=d1, mp_c=np.full(len(k1), -1, np.int32), Tcw=np.array([0, 0, 0, 1, 0, 0, 0], np.float32), K=K4,
+                          bounds=np.array([0, 640, 0, 480], np.float32), scale_factors=scale, kps_l=k0, mp_l=np.arange(len(k0), dtype=np.int32),
+                          outlier_l=None, mps=mps))
+    cases = [_pose_case(100 + i) for i in range(cyc)]
+    ext0.close()
+
+    def agent(nframes, out, gate=None):
+        ext = capi.OrbExtractor(max_batch=1, device=device)
+        ext.extract(frames[0])      # buffers sized, kernels loaded: outside the timed region
+        if gate is not None:
+            gate.wait()             # all agents ready
+            gate.wait()             # clock started
+        acc = []
+        for i in range(nframes):
+            t = 1 + i % cyc
+            n, k, d, _ = ext.extract(frames[t])
+            nm = capi.search_by_projection_frames(th=15.0, device=device, **pairs[t - 1])[0]
+            c = cases[t - 1]
+            po = capi.pose_optimize(c[0][None], c[1][None], c[2][None], c[3][None], np.array([len(c[1])], np.int32), c[4], device)
+            if i < cyc:
+                acc.append((n, int(d[:n].astype(np.int64).sum()), int(nm), po[0].tobytes(), int(po[2][0])))
+        ext.close()
+        out.append(acc)
+
+    ref = []
+    agent(2 * cyc, ref)        # warm-up + the single-thread reference
+    out = {"unit": "frames/s over all agents (extract + SearchByProjection + PoseOptimization per frame, host arrays in -> out, one thread per agent)",
+           "note": "Python threads around the C ABI: the calls release the GIL, the argument marshalling between them does not -- a C++ host would sit above these numbers",
+           "by_agents": {}, "reference": "Tracking.cc:1423-1426, :2610, :2632 per frame; one System per agent (orb_slam3_wrapper.cpp)"}
+    same = True
+    for K in Ks:
+        res, ths = [], []
+        gate = threading.Barrier(K + 1)
+        for _ in range(K):
+            th = threading.Thread(target=agent, args=(frames_per_agent, res, gate))
+            th.start(); ths.append(th)
+        gate.wait()
+        t0 = time.perf_counter()
+        gate.wait()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        same = same and len(res) == K and all(r == ref[0] for r in res)
+        out["by_agents"][str(K)] = {"value": K * frames_per_agent / dt, "ms_per_frame_per_agent": dt / frames_per_agent * 1e3}
+    out["identical_to_single_thread"] = bool(same)
+    if not same:
+        raise RuntimeError("online_agents leg: a thread's results differ from the single-thread run")
+    return out
+
+
 def lba(device, iters=10, repeats=40, cpu_seconds=4.0):
     """LocalBundleAdjustment as LocalMapping calls it per keyframe: a covisibility window with anchors."""
     import ba_bench
