@@ -18,6 +18,7 @@
 #include "introsort_emul.h"
 #include "orb_device.h"
 #include "orb_kernels.h"
+#include "blur_tile.h"
 
 namespace dvm {
 
@@ -175,26 +176,24 @@ __device__ __forceinline__ void block_scan_excl(int* data, int m, int* s_tmp, in
   __syncthreads();
 }
 
-// (80 SGPRs: a 256-thread workgroup is admitted per CU up to 800 / (ceil(sgpr / 16) * 16 + 16) times -- 6 at the 101 the compiler
-// takes on its own, 8 at <= 80, which is also what the 17.5 KB of LDS allow: all 2 048 workgroups of a 256-frame batch resident at once)
 #ifdef DVM_OCT_PROF
 __device__ unsigned long long g_oct_prof[32];
-#define OCT_T(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned long long now_ = wall_clock64(); g_oct_prof[k] += now_ - oct_last_; oct_last_ = now_; } } while (0)
+#define OCT_T(k) do { if (tid == 0 && level == 0 && f == 0) { const unsigned long long now_ = wall_clock64(); g_oct_prof[k] += now_ - oct_last_; oct_last_ = now_; } } while (0)
 #else
 #define OCT_T(k) do {} while (0)
 #endif
 // (1 024 threads for the latency variant: measured slower, 41 us against 37 -- a pass over the keys is bound by the CU's LDS
 // throughput under random access, ~11 LDS operations per key, not by the latency of one key's chain)
+extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
 template <bool LAT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
-                                                const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
-                                                int32_t* __restrict__ lvl_count, PipelineDesc PD,
-                                                int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
-                                                int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
-                                                int level_first, int cap_n) {
+__device__ __forceinline__ void octree_level(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
+                                             const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
+                                             int32_t* __restrict__ lvl_count, const PipelineDesc& PD,
+                                             int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
+                                             int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
+                                             int level, int f, int cap_n) {
   // dynamic LDS, `cap` node slots (host: max level quota + 8, >= 4 * root nodes, multiple of 64): 58 B per slot in the throughput
   // form (the BASELINE config, cap 256, keeps ~15 KB and 8 workgroups fit a CU), 56 B per slot + the keys in the latency form
-  extern __shared__ __attribute__((aligned(16))) unsigned char oct_smem[];
   ONodeRec* listA = reinterpret_cast<ONodeRec*>(oct_smem);
   ONodeRec* listB = listA + cap;
   int(*cc)[4] = reinterpret_cast<int(*)[4]>(listB + cap);   // child key counts of the processed nodes
@@ -229,7 +228,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
   __shared__ int s_stack[144];
   __shared__ int s_m, s_np, s_ne, s_total, s_keep, s_phase, s_finish, s_cut;
 
-  const int level = level_first + blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
 #ifdef DVM_OCT_PROF
   unsigned long long oct_last_ = wall_clock64();
 #endif
@@ -294,6 +293,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
   }
 }
 
+// (80 SGPRs: a 256-thread workgroup is admitted per CU up to 800 / (ceil(sgpr / 16) * 16 + 16) times -- 6 at the 101 the compiler
+// takes on its own, 8 at <= 80, which is also what the 17.5 KB of LDS allow: all 2 048 workgroups of a 256-frame batch resident at once)
+template <bool LAT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
+                                                const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
+                                                int32_t* __restrict__ lvl_count, PipelineDesc PD,
+                                                int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
+                                                int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap,
+                                                int level_first, int cap_n) {
+  octree_level<LAT>(cand_slots, cell_count, cells, dense, lvl_count, PD, nid_scratch, sel, nsel, err_flag, cap, level_first + (int)blockIdx.x,
+                    (int)blockIdx.y, cap_n);
+}
+// One-frame path: the octree of every level AND the 7x7 blur of the whole pyramid in one launch.  The blur depends on the pyramid only;
+// as a launch of its own it was 9 us on the chain (or a side stream whose fork / join events cost more than that).  Here its tiles are
+// the workgroups behind the octree's `n_oct` (one per level and frame, dispatched first): they fill the chip the octree's handful of
+// latency-bound workgroups leave idle and are done long before those are.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree_blur(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
+                                                const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
+                                                int32_t* __restrict__ lvl_count, PipelineDesc PD,
+                                                int32_t* __restrict__ nid_scratch, uint32_t* __restrict__ sel,
+                                                int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap, int cap_n,
+                                                const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, const TileDesc* __restrict__ tiles,
+                                                uint4 gauss) {
+  const int n_oct = PD.nlevels * (int)gridDim.y;
+  const int b = (int)blockIdx.x, f = (int)blockIdx.y;
+  if (b < PD.nlevels) {
+    octree_level<true>(cand_slots, cell_count, cells, dense, lvl_count, PD, nid_scratch, sel, nsel, err_flag, cap, b, f, cap_n);
+  } else {
+    __shared__ __attribute__((aligned(16))) uint8_t raw[(kBlurTH + 6) * kRawPitch];
+    __shared__ __attribute__((aligned(16))) uint32_t hpt[kBlurTW * kHtPitch];
+    (void)n_oct;
+    blur_tile(pyr, PD.pyr_frame_bytes, blur, PD.blur_frame_bytes, tiles[b - PD.nlevels], PD, f, gauss.x, gauss.y, gauss.z, gauss.w, raw, hpt);
+  }
+}
+
 // root nodes of a level: nIni = round((maxX - minX) / (maxY - minY)) (ORBextractor.cc:423)
 int octree_root_nodes(const LevelDesc& L) {
   const int W = L.w - 2 * (kEdge - 3), H = L.h - 2 * (kEdge - 3);
@@ -312,6 +346,7 @@ static size_t octree_lds_bytes(int cap) { return (size_t)cap * (2 * sizeof(ONode
 static_assert(2 * sizeof(ONodeRec) + 16 + 4 + 4 + 2 + 2 + 2 + 2 == 56, "k_octree<true> places its key arrays after 56 B per node slot");
 // latency variant: keys + node ids of a level in LDS as well, as many as fit next to the node slots (8 B per key)
 constexpr int kOctLatKeys = 8192;
+constexpr int kOctBlurKeys = 4096;   // k_octree_blur: its blur workgroups reserve the launch's LDS too -- 32 KB of keys keeps two of them on a CU
 static int octree_lat_keys(int cap) {
   const size_t base = ((size_t)cap * 56 + 15) & ~(size_t)15;
   const size_t room = base < 156 * 1024 ? 156 * 1024 - base : 0;
@@ -326,6 +361,7 @@ bool octree_prepare_device(const PipelineDesc& PD) {
   if (!octree_fits_device(PD)) return false;
   const size_t bytes = octree_lds_bytes(octree_required_nodes(PD));
   if (!raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<true>), (int)octree_lat_lds_bytes(octree_required_nodes(PD)))) return false;
+  if (octree_blur_fits(PD) && !raise_dynamic_lds(reinterpret_cast<const void*>(k_octree_blur), 64 * 1024)) return false;
   if (bytes <= 48 * 1024) return true;
   return raise_dynamic_lds(reinterpret_cast<const void*>(k_octree<false>), (int)bytes);
 }
@@ -353,4 +389,24 @@ extern "C" int dvm_debug_oct_prof(unsigned long long* out, int reset) {
   return rc;
 }
 #endif
+// k_octree_blur reserves, per workgroup, the octree's dynamic LDS plus the blur's and the octree's static arrays: taken only while two
+// workgroups still fit a CU (small node capacities -- the usual configurations); otherwise the two launches stay separate
+bool octree_blur_fits(const PipelineDesc& PD) {
+  const int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
+  const int keys = std::min(octree_lat_keys(cap), kOctBlurKeys);
+  const size_t lds = (((size_t)cap * 56 + 15) & ~(size_t)15) + (size_t)keys * 8 + 20 * 1024;
+  return keys >= 1024 && lds <= 76 * 1024;
+}
+// the one-frame path's launch: octrees of all levels + the blur of all levels (k_octree_blur); gauss7: the 8.8 kernel of the blur
+void launch_octree_blur(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
+                        int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch,
+                        const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const int* gauss7) {
+  const int cap = std::min(octree_required_nodes(PD), kOctMaxNodes);
+  const int keys = std::min(octree_lat_keys(cap), kOctBlurKeys);
+  const size_t lds = (((size_t)cap * 56 + 15) & ~(size_t)15) + (size_t)keys * 8;
+  hipLaunchKernelGGL(k_octree_blur, dim3(PD.nlevels + PD.ntiles, batch), dim3(256), lds, s, d_cand, d_cell_count, d_cells, d_dense, d_lvl_count, PD,
+                     d_nid, d_sel, d_nsel, d_err, cap, keys, d_pyr, d_blur, d_tiles,
+                     make_uint4((uint32_t)gauss7[0], (uint32_t)gauss7[1], (uint32_t)gauss7[2], (uint32_t)gauss7[3]));
+}
+
 }  // namespace dvm

@@ -38,6 +38,10 @@ bool octree_prepare_device(const PipelineDesc& PD);   // raises the LDS limit fo
 void launch_octree(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
                    int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err,
                    int batch, int level_first, int level_num, bool latency = false);
+bool octree_blur_fits(const PipelineDesc& PD);
+void launch_octree_blur(hipStream_t s, const uint32_t* d_cand, const int32_t* d_cell_count, const CellDesc* d_cells, uint32_t* d_dense,
+                        int32_t* d_lvl_count, const PipelineDesc& PD, int32_t* d_nid, uint32_t* d_sel, int32_t* d_nsel, int32_t* d_err, int batch,
+                        const uint8_t* d_pyr, uint8_t* d_blur, const TileDesc* d_tiles, const int* gauss7);
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
                      int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch,
                      HostMirror hm = HostMirror());

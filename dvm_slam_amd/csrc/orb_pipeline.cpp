@@ -309,6 +309,7 @@ int OrbPipeline::init() {
     DVM_HIP(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
   }
   if (const char* e = getenv("DVM_LATENCY_PATH")) latency_path = (e[0] != '0');
+  if (const char* e = getenv("DVM_OCT_BLUR")) oct_blur = (e[0] != '0');
   if (const char* e = getenv("DVM_LAT_SPLIT")) lat_split = (e[0] != '0');
   if (const char* e = getenv("DVM_ZERO_COPY_IN")) zero_copy_in = (e[0] != '0');
   if (const char* e = getenv("DVM_SERIAL")) overlap_blur = (e[0] != '1');      // debug / A-B switch only
@@ -339,6 +340,7 @@ int OrbPipeline::init() {
     }
     g7[3] = (int)(256 - 2 * acc);
   }
+  for (int i = 0; i < 7; i++) gauss7[i] = g7[i];
   upload_constants(du, dv, g7);
   DVM_HIP(hipGetLastError());
   DVM_HIP(hipDeviceSynchronize());
@@ -686,6 +688,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     const int g_a = std::min(std::max(group_split[0], 0), L), g_b = std::min(std::max(group_split[1], g_a), L);
     const int gl[4] = {split0 ? 1 : 0, grouped ? g_a : L, grouped ? g_b : L, L};   // level groups [gl[i], gl[i+1])
     int oct_main_first = split0 ? 1 : 0;   // levels below this one have their octree on the auxiliary stream
+    bool blur_done = false;
     prof.begin(st, "fast");   // one bracket over the (up to three) k_fast_cells launches of the batch
     for (int gi = 0; gi < 3; gi++) {
       const int la = gl[gi], lb = gl[gi + 1];
@@ -719,7 +722,13 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     if (!host_octree) {
       prof.begin(st, "octree");   // the part of the octree work that is NOT hidden behind FAST
       const int la = oct_main_first;
-      launch_octree(st, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, L - la, small);
+      if (small && oct_blur && la == 0 && !blur_forked && octree_blur_fits(PD)) {   // one-frame path: octrees + blur tiles in one launch
+        launch_octree_blur(st, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, pyr_f0,
+                           d_blur + (size_t)f0 * PD.blur_frame_bytes, d_tiles, gauss7);
+        blur_done = true;
+      } else {
+        launch_octree(st, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, la, L - la, small);
+      }
       if (blur_late) { const int rcb = fork_blur(); if (rcb != DVM_OK) return rcb; }
       if (split0) {
         DVM_HIP(hipStreamWaitEvent(st, ev_group[3], 0));
@@ -769,7 +778,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     prof.begin(st, "assemble");
     launch_assemble(st, (d_sel + (size_t)f0 * PD.sel_frame_slots), (d_nsel + (size_t)f0 * L), PD, lap0, lap1, (d_kps + (size_t)f0 * PD.kp_cap), (d_aux + (size_t)f0 * PD.kp_cap), (d_n + f0), (d_mono + f0), nb, hm);
     prof.end(st);
-    if (!blur_forked) {
+    if (!blur_forked && !blur_done) {
       prof.begin(st, "blur");
       launch_blur(st, (d_pyr + (size_t)f0 * PD.pyr_frame_bytes), (d_blur + (size_t)f0 * PD.blur_frame_bytes), d_tiles, PD, nullptr, nb);
       prof.end(st);

@@ -132,10 +132,12 @@ class OrbPipeline {
   // Latency path -- a call of at most kLatencyBatch frames (Tracking hands over ONE): nothing is bandwidth-bound at that size, the
   // call is a chain of ~13 dependent launches plus the copies around it (0.217 ms host to host before, 0.176 ms now).  So
   // (1) level 0 reads the image from the pinned staging buffer over PCIe (no H2D copy in front of the chain);
-  // (2) the blur stays on the main chain: the fork / join events around a side stream cost more than the 9 us the blur takes;
+  // (2) no side stream: the fork / join events around it cost more than the 9 us the blur takes (see (5));
   // (3) k_assemble / k_orient_desc also store counts, keypoints and descriptors into mapped host memory, so download() is a
   //     stream synchronisation and a memcpy;
-  // (4) k_octree<true>: wave-synchronous rounds, the level's keys and node ids in LDS (octree_rounds_wave.inc).
+  // (4) k_octree<true>: wave-synchronous rounds, the level's keys and node ids in LDS (octree_rounds_wave.inc);
+  // (5) the blur's tiles ride in the octree's launch (k_octree_blur): they need the pyramid only and fill the chip the octree's eight
+  //     latency-bound workgroups leave idle -- off the chain without a second stream.
   // DVM_LATENCY_PATH=0 / DVM_ZERO_COPY_IN=0: A-B switches.  Tried and not kept: the pyramid in one launch with inter-workgroup
   // flags (write-through stores + per-row-tile counters: 56 us against 45 us for the eight launches -- a cross-XCD hand-off costs
   // more than a kernel boundary); three pyramid levels per launch, a tile recomputing the rectangles of the levels between its
@@ -145,6 +147,8 @@ class OrbPipeline {
   static constexpr int kLatencyBatch = 4;
   bool latency_path = true, zero_copy_in = true;
   bool lat_split = false;            // opt-in, see above
+  bool oct_blur = true;              // (5) the blur as extra workgroups of the octree launch (k_octree_blur); DVM_OCT_BLUR=0: A-B switch
+  int gauss7[7] = {};                // the blur's 8.8 fixed-point kernel (also in constant memory for k_blur7)
   hipStream_t lat_aux = nullptr;     // created by the first small call: a handle that only ever sees large batches keeps its two streams
   bool last_mirrored = false;        // the last batch's results are in h_kps_m / h_desc_m / h_n / h_mono
   dvm_keypoint_pod* h_kps_m = nullptr;   // [kLatencyBatch][kp_cap], mapped
