@@ -293,7 +293,8 @@ int OrbPipeline::init() {
     // for the opt-in chunk / level-group pipelines (a fifth stream in the process made every stage ~2x slower).
     int least = 0, greatest = 0;
     DVM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    DVM_HIP(hipStreamCreateWithPriority(&lane_side[0], hipStreamNonBlocking, least));
+    side_priority = least;   // lane_side[0] is created by the first call that forks the blur (batches of more than kLatencyBatch frames):
+                             // a handle that only ever sees single frames keeps ONE stream -- K agents on a GPU are K + K staging streams, not 3 K
     if (chunks > 1 || group_split[0] < kMaxLevels) {
       DVM_HIP(hipStreamCreateWithPriority(&lane_side[1], hipStreamNonBlocking, least));
       DVM_HIP(hipStreamCreateWithFlags(&lane_main[1], hipStreamNonBlocking));
@@ -791,6 +792,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
 
     return DVM_OK;
   };
+  if (!small && !lane_side[0] && overlap_blur) DVM_HIP(hipStreamCreateWithPriority(&lane_side[0], hipStreamNonBlocking, side_priority));
   if (nck == 1) {
     rc = run_half(stream, lane_side[0], 0, 0, batch);
     if (rc != DVM_OK) return rc;

@@ -84,6 +84,7 @@ class OrbPipeline {
                              // step (concurrent queues do not recover the k_octree idle time), so the default is off
   bool blur_early = true;    // launch the blur right after the pyramid (all levels) instead of after the candidate counts
   bool overlap_blur = true;  // DVM_SERIAL=1 puts the blur back on `stream`
+  int side_priority = 0;     // lowest stream priority of the device (the blur's side stream)
   Profiler prof;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> nfeat;
