@@ -245,7 +245,50 @@ def online_agents(capi, frames, device, Ks=(1, 2, 4, 8), frames_per_agent=150):
     out["identical_to_single_thread"] = bool(same)
     if not same:
         raise RuntimeError("online_agents leg: a thread's results differ from the single-thread run")
+    # the same from a C++ host (tools/online_agents.cpp: std::threads on the C ABI, no interpreter lock between the calls)
+    try:
+        out["cpp_host"] = _online_agents_cpp(frames, cyc, scale, pairs, cases, device, Ks, frames_per_agent)
+    except Exception as e:   # the tool is an extra: a missing compiler must not take the leg down
+        out["cpp_host"] = {"skipped": f"{type(e).__name__}: {e}"}
     return out
+
+
+def _online_agents_cpp(frames, cyc, scale, pairs, cases, device, Ks, frames_per_agent):
+    import json
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(root, "tools", "bin", "online_agents")
+    src = os.path.join(root, "tools", "online_agents.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-I" + os.path.join(root, "include"), "-L" + os.path.join(root, "dvm_slam_amd", "lib"),
+                               "-ldvmslam_host", "-ldvmslam_hip", "-lpthread", "-Wl,-rpath," + os.path.join(root, "dvm_slam_amd", "lib"), "-o", exe])
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        path = f.name
+        fr = np.ascontiguousarray(frames[:cyc + 1], np.uint8)
+        f.write(np.array([cyc, fr.shape[1], fr.shape[2]], np.int32).tobytes())
+        f.write(fr.tobytes())
+        f.write(np.ascontiguousarray(scale[:8], np.float32).tobytes())
+        for p in pairs:
+            f.write(np.array([len(p["kps_c"]), len(p["kps_l"])], np.int32).tobytes())
+            f.write(np.ascontiguousarray(p["kps_c"]).tobytes()); f.write(np.ascontiguousarray(p["desc_c"], np.uint8).tobytes())
+            f.write(np.ascontiguousarray(p["kps_l"]).tobytes()); f.write(np.ascontiguousarray(p["mps"]).tobytes())
+        for c in cases:
+            f.write(np.array([len(c[1])], np.int32).tobytes())
+            f.write(np.ascontiguousarray(c[0], np.float64).tobytes()); f.write(np.ascontiguousarray(c[1], np.float64).tobytes())
+            f.write(np.ascontiguousarray(c[2], np.float64).tobytes()); f.write(np.ascontiguousarray(c[3], np.float64).tobytes())
+            f.write(np.ascontiguousarray(c[4][:4], np.float64).tobytes())
+    try:
+        r = subprocess.run([exe, path, str(device), str(frames_per_agent)] + [str(k) for k in Ks], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    if r.returncode != 0:
+        raise RuntimeError(f"online_agents (C++ host) failed: {r.stderr.strip()[-300:]}")
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    if not res.get("identical_results_across_agents", False):
+        raise RuntimeError("online_agents (C++ host): agents disagree")
+    return res
 
 
 def lba(device, iters=10, repeats=40, cpu_seconds=4.0):

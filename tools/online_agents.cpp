@@ -1,0 +1,166 @@
+// tools/online_agents.cpp -- K agents tracking on ONE GPU through the drop-in C ABI, one host thread and one extractor handle each:
+// per frame dvm_orb_extract (ORBextractor::operator()) -> dvmh_search_by_projection_frames (SearchByProjection(Cur, Last)) ->
+// dvm_pose_optimize (PoseOptimization), host arrays in and out, every call synchronous as Tracking makes them (Tracking.cc:1423-1426,
+// :2610, :2632).  The Python leg of the same name measures the same thing through ctypes and is bound by the interpreter lock above
+// ~5 k frames/s; this is the C++ host the reference is.  Inputs come from a file bench_legs.online_agents writes (frames, the search
+// inputs of every frame pair, the pose cases); every thread's results are reduced to a checksum and must equal thread 0's.
+//   usage: online_agents <inputs.bin> <device> <frames_per_agent> K [K ...]     -> one JSON object on stdout
+// Build: g++ -O2 -std=c++17 tools/online_agents.cpp -Iinclude -Ldvm_slam_amd/lib -ldvmslam_host -ldvmslam_hip -lpthread
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "dvmslam_hip.h"
+#include "dvmslam_host.h"
+
+namespace {
+struct Pair {
+  int Nc = 0, Nl = 0;
+  std::vector<dvm_keypoint> kc, kl;
+  std::vector<uint8_t> dc;
+  std::vector<dvmh_map_point> mps;
+};
+struct PoseCase {
+  int n = 0;
+  double pose[7];
+  std::vector<double> X, obs, w;
+  dvm_ba_camera cam;
+};
+struct Inputs {
+  int cyc = 0, rows = 0, cols = 0;
+  std::vector<uint8_t> frames;   // (cyc + 1) x rows x cols
+  float scale[8];
+  std::vector<Pair> pairs;       // cyc
+  std::vector<PoseCase> poses;   // cyc
+};
+template <class T> bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+bool load(const char* path, Inputs& in) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  int32_t h[3];
+  bool ok = rd(f, h, 3);
+  in.cyc = h[0]; in.rows = h[1]; in.cols = h[2];
+  in.frames.resize((size_t)(in.cyc + 1) * in.rows * in.cols);
+  ok = ok && rd(f, in.frames.data(), in.frames.size()) && rd(f, in.scale, 8);
+  for (int t = 0; ok && t < in.cyc; t++) {
+    Pair p;
+    int32_t n2[2];
+    ok = rd(f, n2, 2);
+    p.Nc = n2[0]; p.Nl = n2[1];
+    p.kc.resize(p.Nc); p.dc.resize((size_t)p.Nc * 32); p.kl.resize(p.Nl); p.mps.resize(p.Nl);
+    ok = ok && rd(f, p.kc.data(), p.Nc) && rd(f, p.dc.data(), p.dc.size()) && rd(f, p.kl.data(), p.Nl) && rd(f, p.mps.data(), p.Nl);
+    in.pairs.push_back(std::move(p));
+  }
+  for (int t = 0; ok && t < in.cyc; t++) {
+    PoseCase c;
+    int32_t n;
+    ok = rd(f, &n, 1);
+    c.n = n;
+    c.X.resize((size_t)n * 3); c.obs.resize((size_t)n * 2); c.w.resize(n);
+    double k4[4];
+    ok = ok && rd(f, c.pose, 7) && rd(f, c.X.data(), c.X.size()) && rd(f, c.obs.data(), c.obs.size()) && rd(f, c.w.data(), c.w.size()) && rd(f, k4, 4);
+    c.cam = dvm_ba_camera{k4[0], k4[1], k4[2], k4[3], 0.0};
+    in.poses.push_back(std::move(c));
+  }
+  fclose(f);
+  return ok;
+}
+uint64_t mix(uint64_t h, const void* p, size_t n) {   // FNV-1a
+  const uint8_t* b = static_cast<const uint8_t*>(p);
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+struct Gate {
+  std::mutex m; std::condition_variable cv; int waiting = 0, gen = 0, parties = 0;
+  void wait() {
+    std::unique_lock<std::mutex> l(m);
+    const int g = gen;
+    if (++waiting == parties) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(l, [&] { return gen != g; });
+  }
+};
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 5) { std::fprintf(stderr, "usage: online_agents <inputs.bin> <device> <frames_per_agent> K [K ...]\n"); return 2; }
+  Inputs in;
+  if (!load(argv[1], in)) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+  const int device = std::atoi(argv[2]), nframes = std::atoi(argv[3]);
+  const float K4[4] = {500.f, 500.f, 320.f, 240.f}, bounds[4] = {0.f, 640.f, 0.f, 480.f};
+  const dvm_se3f Tcw{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}};
+  std::string out = "{\"unit\": \"frames/s over all agents (extract + SearchByProjection + PoseOptimization per frame, host arrays in -> out, one C++ thread per agent)\", \"by_agents\": {";
+  uint64_t ref_sum = 0;
+  bool same = true, first_k = true;
+  for (int a = 4; a < argc; a++) {
+    const int K = std::atoi(argv[a]);
+    Gate gate; gate.parties = K + 1;
+    std::vector<uint64_t> sums(K, 0);
+    std::vector<int> rcs(K, 0);
+    auto agent = [&](int id) {
+      dvm_set_device(device);
+      dvm_orb_params P{1000, 1.2f, 8, 20, 7};
+      dvm_orb* h = nullptr;
+      int rc = dvm_orb_create(&P, device, 1, &h);
+      const int cap = 4096;
+      std::vector<dvm_keypoint> kps(cap);
+      std::vector<uint8_t> desc((size_t)cap * 32);
+      int n = 0, mono = 0;
+      const size_t fb = (size_t)in.rows * in.cols;
+      if (rc == 0) rc = dvm_orb_extract(h, in.frames.data(), in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);   // sizes buffers
+      gate.wait();   // all agents ready
+      gate.wait();   // clock started
+      uint64_t sum = 1469598103934665603ull;
+      std::vector<int32_t> mp_c, mp_l;
+      for (int i = 0; i < nframes && rc == 0; i++) {
+        const int t = 1 + i % in.cyc;
+        rc = dvm_orb_extract(h, in.frames.data() + (size_t)t * fb, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
+        if (rc) break;
+        const Pair& p = in.pairs[t - 1];
+        mp_c.assign(p.Nc, -1);
+        mp_l.resize(p.Nl);
+        for (int j = 0; j < p.Nl; j++) mp_l[j] = j;
+        const int nm = dvmh_search_by_projection_frames(device, p.Nc, p.kc.data(), p.dc.data(), mp_c.data(), &Tcw, K4, bounds, in.scale, 8, p.Nl,
+                                                        p.kl.data(), mp_l.data(), nullptr, p.mps.data(), 15.0f, 1, nullptr);
+        if (nm < 0) { rc = nm; break; }
+        const PoseCase& c = in.poses[t - 1];
+        double pose_out[7];
+        std::vector<uint8_t> outl(c.n);
+        int32_t ninl = 0, nn = c.n;
+        rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, pose_out, outl.data(), &ninl);
+        if (rc) break;
+        if (i < in.cyc) {   // one cycle of results -> checksum
+          sum = mix(sum, &n, 4); sum = mix(sum, kps.data(), (size_t)n * sizeof(dvm_keypoint)); sum = mix(sum, desc.data(), (size_t)n * 32);
+          sum = mix(sum, &nm, 4); sum = mix(sum, mp_c.data(), mp_c.size() * 4); sum = mix(sum, pose_out, sizeof(pose_out)); sum = mix(sum, outl.data(), outl.size());
+        }
+      }
+      sums[id] = sum; rcs[id] = rc;
+      if (h) dvm_orb_destroy(h);
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < K; k++) th.emplace_back(agent, k);
+    gate.wait();
+    const auto t0 = std::chrono::steady_clock::now();
+    gate.wait();
+    for (auto& t : th) t.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int k = 0; k < K; k++) {
+      if (rcs[k]) { std::fprintf(stderr, "agent %d of %d failed: rc %d (%s)\n", k, K, rcs[k], dvm_last_error()); return 1; }
+      if (a == 4 && k == 0) ref_sum = sums[0];
+      same = same && sums[k] == ref_sum;
+    }
+    char buf[160];
+    std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_frame_per_agent\": %.4f}", first_k ? "" : ", ", K, K * (double)nframes / dt, dt / nframes * 1e3);
+    out += buf;
+    first_k = false;
+  }
+  out += std::string("}, \"identical_results_across_agents\": ") + (same ? "true" : "false") + "}";
+  std::puts(out.c_str());
+  return same ? 0 : 1;
+}
