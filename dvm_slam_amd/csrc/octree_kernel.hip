@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
 }
 // One-frame path: the octree of every level AND the 7x7 blur of the whole pyramid in one launch.  The blur depends on the pyramid only;
 // as a launch of its own it was 9 us on the chain (or a side stream whose fork / join events cost more than that).  Here its tiles are
-// the workgroups behind the octree's `n_oct` (one per level and frame, dispatched first): they fill the chip the octree's handful of
+// the workgroups behind the octree's (one per level, dispatched first): they fill the chip the octree's handful of
 // latency-bound workgroups leave idle and are done long before those are.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_octree_blur(const uint32_t* __restrict__ cand_slots, const int32_t* __restrict__ cell_count,
                                                 const CellDesc* __restrict__ cells, uint32_t* __restrict__ dense,
@@ -316,14 +316,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) k_oc
                                                 int32_t* __restrict__ nsel, int32_t* __restrict__ err_flag, int cap, int cap_n,
                                                 const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, const TileDesc* __restrict__ tiles,
                                                 uint4 gauss) {
-  const int n_oct = PD.nlevels * (int)gridDim.y;
-  const int b = (int)blockIdx.x, f = (int)blockIdx.y;
+  const int b = (int)blockIdx.x, f = (int)blockIdx.y;   // x: the frame's levels, then its blur tiles
   if (b < PD.nlevels) {
     octree_level<true>(cand_slots, cell_count, cells, dense, lvl_count, PD, nid_scratch, sel, nsel, err_flag, cap, b, f, cap_n);
   } else {
     __shared__ __attribute__((aligned(16))) uint8_t raw[(kBlurTH + 6) * kRawPitch];
     __shared__ __attribute__((aligned(16))) uint32_t hpt[kBlurTW * kHtPitch];
-    (void)n_oct;
     blur_tile(pyr, PD.pyr_frame_bytes, blur, PD.blur_frame_bytes, tiles[b - PD.nlevels], PD, f, gauss.x, gauss.y, gauss.z, gauss.w, raw, hpt);
   }
 }

@@ -131,7 +131,7 @@ class OrbPipeline {
   int32_t* h_mono = nullptr;
   uint8_t* h_stage = nullptr;
   // Latency path -- a call of at most kLatencyBatch frames (Tracking hands over ONE): nothing is bandwidth-bound at that size, the
-  // call is a chain of ~13 dependent launches plus the copies around it (0.217 ms host to host before, 0.176 ms now).  So
+  // call is a chain of ~13 dependent launches plus the copies around it (0.229 ms host to host before, 0.157 ms now).  So
   // (1) level 0 reads the image from the pinned staging buffer over PCIe (no H2D copy in front of the chain);
   // (2) no side stream: the fork / join events around it cost more than the 9 us the blur takes (see (5));
   // (3) k_assemble / k_orient_desc also store counts, keypoints and descriptors into mapped host memory, so download() is a
@@ -142,7 +142,8 @@ class OrbPipeline {
   // DVM_LATENCY_PATH=0 / DVM_ZERO_COPY_IN=0: A-B switches.  Tried and not kept: the pyramid in one launch with inter-workgroup
   // flags (write-through stores + per-row-tile counters: 56 us against 45 us for the eight launches -- a cross-XCD hand-off costs
   // more than a kernel boundary); three pyramid levels per launch, a tile recomputing the rectangles of the levels between its
-  // group's base and itself in LDS (bit-identical, 15 us per three-level group against 3 x 5 us: no gain at 256 or 1 024 threads); the whole call as a captured hipGraph (0.183 ms: replay is no cheaper than 17 eager calls);
+  // group's base and itself in LDS (bit-identical, 15 us per three-level group against 3 x 5 us: no gain at 256 or 1 024 threads);
+  // the whole call as a captured hipGraph (0.183 ms against 0.180: replay is no cheaper than 17 eager calls);
   // level 0's FAST + octree on a second stream behind k_pyr_level0 (DVM_LAT_SPLIT=1, 0.187 ms: the host issues the second
   // chain's launches in front of the first one's, and in a graph the branches serialised: 0.34 ms).
   static constexpr int kLatencyBatch = 4;
@@ -150,7 +151,7 @@ class OrbPipeline {
   bool lat_split = false;            // opt-in, see above
   bool oct_blur = true;              // (5) the blur as extra workgroups of the octree launch (k_octree_blur); DVM_OCT_BLUR=0: A-B switch
   int gauss7[7] = {};                // the blur's 8.8 fixed-point kernel (also in constant memory for k_blur7)
-  hipStream_t lat_aux = nullptr;     // created by the first small call: a handle that only ever sees large batches keeps its two streams
+  hipStream_t lat_aux = nullptr;     // DVM_LAT_SPLIT=1 only: created by the first small call
   bool last_mirrored = false;        // the last batch's results are in h_kps_m / h_desc_m / h_n / h_mono
   dvm_keypoint_pod* h_kps_m = nullptr;   // [kLatencyBatch][kp_cap], mapped
   uint8_t* h_desc_m = nullptr;           // [kLatencyBatch][kp_cap][32], mapped
