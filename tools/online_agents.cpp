@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
     const int K = std::atoi(argv[a]);
     Gate gate; gate.parties = K + 1;
     std::vector<uint64_t> sums(K, 0);
+    double call_ms[3] = {0, 0, 0};   // agent 0: time inside each of the three calls
     std::vector<int> rcs(K, 0);
     auto agent = [&](int id) {
       dvm_set_device(device);
@@ -120,8 +121,10 @@ int main(int argc, char** argv) {
       std::vector<int32_t> mp_c, mp_l;
       for (int i = 0; i < nframes && rc == 0; i++) {
         const int t = 1 + i % in.cyc;
+        const auto c0 = std::chrono::steady_clock::now();
         rc = dvm_orb_extract(h, in.frames.data() + (size_t)t * fb, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
         if (rc) break;
+        const auto c1 = std::chrono::steady_clock::now();
         const Pair& p = in.pairs[t - 1];
         mp_c.assign(p.Nc, -1);
         mp_l.resize(p.Nl);
@@ -129,12 +132,19 @@ int main(int argc, char** argv) {
         const int nm = dvmh_search_by_projection_frames(device, p.Nc, p.kc.data(), p.dc.data(), mp_c.data(), &Tcw, K4, bounds, in.scale, 8, p.Nl,
                                                         p.kl.data(), mp_l.data(), nullptr, p.mps.data(), 15.0f, 1, nullptr);
         if (nm < 0) { rc = nm; break; }
+        const auto c2 = std::chrono::steady_clock::now();
         const PoseCase& c = in.poses[t - 1];
         double pose_out[7];
         std::vector<uint8_t> outl(c.n);
         int32_t ninl = 0, nn = c.n;
         rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, pose_out, outl.data(), &ninl);
         if (rc) break;
+        if (id == 0) {
+          const auto c3 = std::chrono::steady_clock::now();
+          call_ms[0] += std::chrono::duration<double, std::milli>(c1 - c0).count();
+          call_ms[1] += std::chrono::duration<double, std::milli>(c2 - c1).count();
+          call_ms[2] += std::chrono::duration<double, std::milli>(c3 - c2).count();
+        }
         if (i < in.cyc) {   // one cycle of results -> checksum
           sum = mix(sum, &n, 4); sum = mix(sum, kps.data(), (size_t)n * sizeof(dvm_keypoint)); sum = mix(sum, desc.data(), (size_t)n * 32);
           sum = mix(sum, &nm, 4); sum = mix(sum, mp_c.data(), mp_c.size() * 4); sum = mix(sum, pose_out, sizeof(pose_out)); sum = mix(sum, outl.data(), outl.size());
@@ -155,8 +165,9 @@ int main(int argc, char** argv) {
       if (a == 4 && k == 0) ref_sum = sums[0];
       same = same && sums[k] == ref_sum;
     }
-    char buf[160];
-    std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_frame_per_agent\": %.4f}", first_k ? "" : ", ", K, K * (double)nframes / dt, dt / nframes * 1e3);
+    char buf[320];
+    std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_frame_per_agent\": %.4f, \"agent0_ms_in_extract_search_pose\": [%.4f, %.4f, %.4f]}", first_k ? "" : ", ", K,
+                  K * (double)nframes / dt, dt / nframes * 1e3, call_ms[0] / nframes, call_ms[1] / nframes, call_ms[2] / nframes);
     out += buf;
     first_k = false;
   }
