@@ -171,14 +171,18 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   int rc = ensure_handle(Cur.N);
   if (rc != DVM_OK) return rc;
   std::vector<uint8_t> claimed(grid_cap_, 0);
+  bool any_claimed = false;
   for (int j = 0; j < Cur.N; j++)
-    if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) claimed[j] = 1;
+    if (Cur.mvpMapPoints[j] >= 0 && MPs[Cur.mvpMapPoints[j]].n_obs > 0) { claimed[j] = 1; any_claimed = true; }
+  // (TrackWithMotionModel clears CurrentFrame.mvpMapPoints before it searches, Tracking.cc:2606: nothing is claimed at entry, and the
+  // call then queues no copy at all -- every other array is read in place)
+  const uint8_t* skip = any_claimed ? claimed.data() : nullptr;
   std::vector<uint32_t> ranked((size_t)nq * 4);   // the four best candidates per query: dist << 16 | index, best first
   // keypoints + descriptors still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> here): the grid is built from there
   const bool res = resident(Cur);
   last_grid_from_device = res;
   rc = dvm_frame_build_match_window_ranked(grid_, 0, res ? Cur.dev->d_kps : Cur.mvKeysUn, res ? Cur.dev->d_desc : Cur.mDescriptors, Cur.N,
-                                           Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, claimed.data(), qdesc.data(), qx.data(), qy.data(),
+                                           Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, skip, qdesc.data(), qx.data(), qy.data(),
                                            qr.data(), qmin.data(), qmax.data(), nq, ranked.data(), res ? 1 : 0);
   if (rc != DVM_OK) return rc;
   mark("match");
