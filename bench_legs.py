@@ -206,7 +206,10 @@ def online_agents(capi, frames, device, Ks=(1, 2, 4, 8), frames_per_agent=150):
 
     def agent(nframes, out, gate=None):
         ext = capi.OrbExtractor(max_batch=1, device=device)
-        ext.extract(frames[0])      # buffers sized, kernels loaded: outside the timed region
+        ext.extract(frames[0])      # buffers sized, kernels loaded, and this thread's grid handle / staging context created: outside the timed region
+        capi.search_by_projection_frames(th=15.0, device=device, **pairs[0])
+        c0 = cases[0]
+        capi.pose_optimize(c0[0][None], c0[1][None], c0[2][None], c0[3][None], np.array([len(c0[1])], np.int32), c0[4], device)
         if gate is not None:
             gate.wait()             # all agents ready
             gate.wait()             # clock started
