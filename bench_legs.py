@@ -283,7 +283,7 @@ def _online_agents_cpp(frames, cyc, scale, pairs, cases, device, Ks, frames_per_
             f.write(np.ascontiguousarray(c[2], np.float64).tobytes()); f.write(np.ascontiguousarray(c[3], np.float64).tobytes())
             f.write(np.ascontiguousarray(c[4][:4], np.float64).tobytes())
     try:
-        r = subprocess.run([exe, path, str(device), str(frames_per_agent)] + [str(k) for k in Ks], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "--pool=32", path, str(device), str(frames_per_agent)] + [str(k) for k in Ks], capture_output=True, text=True, timeout=300)
     finally:
         os.unlink(path)
     if r.returncode != 0:

@@ -331,6 +331,45 @@ def match_lists(tdesc: np.ndarray, qdesc: np.ndarray, offsets: np.ndarray, cand:
     return out
 
 
+class OrbPool:
+    """dvm_orb_pool_*: one extractor shared by several agents' threads; frames arriving together are extracted as one batch."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, max_batch=32, window_us=-1, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        p = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        f = self.L.dvm_orb_pool_create
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(C.byref(p), C.c_int32(device), C.c_int32(max_batch), C.c_int32(window_us), C.byref(self.h)))
+        self.cap = 4 * max(nfeatures, 1) + 256   # (small quotas on wide images keep up to 4 * nIni keypoints per level)
+        self._x = self.L.dvm_orb_pool_extract
+        self._x.restype = C.c_int32; self._x.argtypes = None
+
+    def extract(self, img, lap=(0, 1000)):
+        """One frame (blocking, from any thread): (n, keypoints, descriptors, monoIndex, frames in the batch this call ran in)."""
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            img = np.ascontiguousarray(img, np.uint8)
+        kps = np.empty(self.cap, KP_DTYPE)
+        desc = np.empty((self.cap, 32), np.uint8)
+        n, mono, bs = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self._x(self.h, _p(img), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]), C.c_int32(img.strides[0]), C.c_int32(lap[0]), C.c_int32(lap[1]),
+                      _p(kps), _p(desc), C.c_int32(self.cap), C.byref(n), C.byref(mono), C.byref(bs)))
+        return n.value, kps[:n.value], desc[:n.value], mono.value, bs.value
+
+    def close(self):
+        if self.h:
+            f = self.L.dvm_orb_pool_destroy
+            f.restype = None; f.argtypes = None
+            f(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrameGrid:
     """Frame's feature grid + windowed search (reference Frame.cc:443-506,712-782; ORBmatcher.cc:70-115)."""
 

@@ -83,6 +83,20 @@ int dvm_orb_tables(const dvm_orb* h, float* scale, float* inv_scale, float* sigm
 int dvm_orb_extract(dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
                     dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
 
+/* A SHARED extractor for several agents' frames.  The reference runs one ORBextractor per agent, each called once per frame from that
+ * agent's tracking thread (Tracking.cc:1423-1426; orb_slam3_wrapper.cpp runs one System per agent).  K such threads on one GPU issue K
+ * chains of small launches that serialise in the runtime; dvm_orb_pool_extract is the same blocking call -- one image in, that
+ * frame's keypoints and descriptors out, the same bytes as dvm_orb_extract -- but frames that arrive within `window_us` of each other
+ * (and share size and lapping area) are extracted as ONE batch of up to max_batch frames: the caller that opened the batch waits for
+ * the arrivals to pause, runs it, and every caller copies its own frame's results out.  Two batches are in flight (one collecting while
+ * one runs).  Callable from any number of threads at once; a lone caller pays the window (default 20 us when window_us < 0).
+ * batch_size (may be NULL): how many frames the call's batch held. */
+typedef struct dvm_orb_pool dvm_orb_pool;
+int dvm_orb_pool_create(const dvm_orb_params* p, int device, int max_batch, int window_us, dvm_orb_pool** out);
+void dvm_orb_pool_destroy(dvm_orb_pool* pool);
+int dvm_orb_pool_extract(dvm_orb_pool* pool, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1, dvm_keypoint* kps,
+                         uint8_t* desc, int cap, int* n, int* mono_index, int* batch_size);
+
 /* Batched, device-resident form: `batch` frames of rows x cols at d_imgs + f*frame_stride (bytes),
  * row pitch `stride`.  Asynchronous on the handle's stream; results stay in HBM until fetched. */
 int dvm_orb_extract_batch_device(dvm_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int stride,

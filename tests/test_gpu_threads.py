@@ -133,3 +133,50 @@ def test_keyframe_database_concurrent_add_and_query(capi):
             db2.detect_merge_possibility(qs[0]["ids"], qs[0]["vals"], 0, 0)
         finally:
             db2.close()
+
+
+def test_pooled_extractor_equals_one_extractor_per_frame(capi):
+    """dvm_orb_pool_*: K threads hand their frames to ONE shared extractor, which runs frames that arrive together as one batch; every
+    caller must get exactly what dvm_orb_extract gives for its frame -- whatever batch it happened to ride in (mixed image sizes included:
+    a frame of another shape waits for the next batch)."""
+    import threading
+    from dvm_slam_amd import synth
+    frames = synth.frame_stream(12)
+    small = [synth.small_image(50 + i, 240, 320) for i in range(4)]
+    ref_ext = capi.OrbExtractor(max_batch=1)
+    ref = [ref_ext.extract(f) for f in frames]
+    ref_small = [ref_ext.extract(f) for f in small]
+    ref_ext.close()
+    pool = capi.OrbPool(max_batch=8, window_us=200)
+    K, per = 8, 24
+    errors, sizes = [], []
+
+    def agent(k):
+        try:
+            for i in range(per):
+                if k == 7 and i % 3 == 0:            # one agent with another camera now and then
+                    j = (i // 3) % 4
+                    n, kp, d, m, bs = pool.extract(small[j])
+                    r = ref_small[j]
+                else:
+                    j = (k + i) % 12
+                    n, kp, d, m, bs = pool.extract(frames[j])
+                    r = ref[j]
+                sizes.append(bs)
+                if n != r[0] or m != r[3] or kp.tobytes() != r[1].tobytes() or not np.array_equal(d, r[2]):
+                    errors.append((k, i, n, r[0]))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ths = [threading.Thread(target=agent, args=(k,)) for k in range(K)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths), "a pooled call did not return"
+    assert not errors, errors[:3]
+    assert max(sizes) > 1, "the frames never shared a batch"
+    # a lone caller still works (pays the window)
+    n, kp, d, m, bs = pool.extract(frames[3])
+    assert bs == 1 and n == ref[3][0] and kp.tobytes() == ref[3][1].tobytes()
+    pool.close()

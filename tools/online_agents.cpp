@@ -89,110 +89,140 @@ struct Gate {
 };
 }  // namespace
 
+// one measurement: K agent threads, `nframes` frames each; pool != nullptr: extraction through the shared extractor (dvm_orb_pool_extract)
+struct Result { double fps = 0, ms_per_frame = 0, mean[3] = {0, 0, 0}, med[3] = {0, 0, 0}, mean_batch = 0; int rc = 0; uint64_t sum0 = 0; bool same = true; };
+
+static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_pool* pool) {
+  const float K4[4] = {500.f, 500.f, 320.f, 240.f}, bounds[4] = {0.f, 640.f, 0.f, 480.f};
+  const dvm_se3f Tcw{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}};
+  Gate gate; gate.parties = K + 1;
+  std::vector<uint64_t> sums(K, 0);
+  std::vector<int> rcs(K, 0);
+  double call_ms[3] = {0, 0, 0};   // agent 0: time inside each of the three calls (mean), and their medians
+  std::vector<double> call_all[3];
+  std::atomic<long> batch_frames{0}, batch_calls{0};
+  auto agent = [&](int id) {
+    dvm_set_device(device);
+    dvm_orb_params P{1000, 1.2f, 8, 20, 7};
+    dvm_orb* h = nullptr;
+    int rc = pool ? 0 : dvm_orb_create(&P, device, 1, &h);
+    const int cap = 4096;
+    std::vector<dvm_keypoint> kps(cap);
+    std::vector<uint8_t> desc((size_t)cap * 32);
+    int n = 0, mono = 0, bs = 0;
+    const size_t fb = (size_t)in.rows * in.cols;
+    auto extract = [&](const uint8_t* img) {
+      return pool ? dvm_orb_pool_extract(pool, img, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono, &bs)
+                  : dvm_orb_extract(h, img, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
+    };
+    std::vector<int32_t> mp_c, mp_l;
+    {  // one untimed frame: the extractor's buffers, this thread's grid handle and staging context (pinned allocations, a stream) exist
+      if (rc == 0) rc = extract(in.frames.data());
+      const Pair& p = in.pairs[0];
+      mp_c.assign(p.Nc, -1); mp_l.resize(p.Nl);
+      for (int j = 0; j < p.Nl; j++) mp_l[j] = j;
+      if (rc == 0) {
+        const int nm = dvmh_search_by_projection_frames(device, p.Nc, p.kc.data(), p.dc.data(), mp_c.data(), &Tcw, K4, bounds, in.scale, 8, p.Nl, p.kl.data(),
+                                                        mp_l.data(), nullptr, p.mps.data(), 15.0f, 1, nullptr);
+        if (nm < 0) rc = nm;
+      }
+      const PoseCase& c = in.poses[0];
+      double po[7]; std::vector<uint8_t> ol(c.n); int32_t ni = 0, nn = c.n;
+      if (rc == 0) rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, po, ol.data(), &ni);
+    }
+    gate.wait();   // all agents ready
+    gate.wait();   // clock started
+    uint64_t sum = 1469598103934665603ull;
+    for (int i = 0; i < nframes && rc == 0; i++) {
+      const int t = 1 + i % in.cyc;
+      const auto c0 = std::chrono::steady_clock::now();
+      rc = extract(in.frames.data() + (size_t)t * fb);
+      if (rc) break;
+      if (pool) { batch_frames += bs; batch_calls += 1; }
+      const auto c1 = std::chrono::steady_clock::now();
+      const Pair& p = in.pairs[t - 1];
+      mp_c.assign(p.Nc, -1);
+      mp_l.resize(p.Nl);
+      for (int j = 0; j < p.Nl; j++) mp_l[j] = j;
+      const int nm = dvmh_search_by_projection_frames(device, p.Nc, p.kc.data(), p.dc.data(), mp_c.data(), &Tcw, K4, bounds, in.scale, 8, p.Nl,
+                                                      p.kl.data(), mp_l.data(), nullptr, p.mps.data(), 15.0f, 1, nullptr);
+      if (nm < 0) { rc = nm; break; }
+      const auto c2 = std::chrono::steady_clock::now();
+      const PoseCase& c = in.poses[t - 1];
+      double pose_out[7];
+      std::vector<uint8_t> outl(c.n);
+      int32_t ninl = 0, nn = c.n;
+      rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, pose_out, outl.data(), &ninl);
+      if (rc) break;
+      if (id == 0) {
+        const auto c3 = std::chrono::steady_clock::now();
+        const double d[3] = {std::chrono::duration<double, std::milli>(c1 - c0).count(), std::chrono::duration<double, std::milli>(c2 - c1).count(),
+                             std::chrono::duration<double, std::milli>(c3 - c2).count()};
+        for (int q = 0; q < 3; q++) { call_ms[q] += d[q]; call_all[q].push_back(d[q]); }
+      }
+      if (i < in.cyc) {   // one cycle of results -> checksum
+        sum = mix(sum, &n, 4); sum = mix(sum, kps.data(), (size_t)n * sizeof(dvm_keypoint)); sum = mix(sum, desc.data(), (size_t)n * 32);
+        sum = mix(sum, &nm, 4); sum = mix(sum, mp_c.data(), mp_c.size() * 4); sum = mix(sum, pose_out, sizeof(pose_out)); sum = mix(sum, outl.data(), outl.size());
+      }
+    }
+    sums[id] = sum; rcs[id] = rc;
+    if (h) dvm_orb_destroy(h);
+  };
+  std::vector<std::thread> th;
+  for (int k = 0; k < K; k++) th.emplace_back(agent, k);
+  gate.wait();
+  const auto t0 = std::chrono::steady_clock::now();
+  gate.wait();
+  for (auto& t : th) t.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  Result R;
+  for (int k = 0; k < K; k++) {
+    if (rcs[k]) { std::fprintf(stderr, "agent %d of %d failed: rc %d (%s)\n", k, K, rcs[k], dvm_last_error()); R.rc = rcs[k]; }
+    R.same = R.same && sums[k] == sums[0];
+  }
+  R.sum0 = sums[0];
+  R.fps = K * (double)nframes / dt; R.ms_per_frame = dt / nframes * 1e3;
+  for (int q = 0; q < 3; q++) {
+    R.mean[q] = call_ms[q] / nframes;
+    if (!call_all[q].empty()) { std::sort(call_all[q].begin(), call_all[q].end()); R.med[q] = call_all[q][call_all[q].size() / 2]; }
+  }
+  R.mean_batch = batch_calls ? (double)batch_frames / (double)batch_calls : 0;
+  return R;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 5) { std::fprintf(stderr, "usage: online_agents <inputs.bin> <device> <frames_per_agent> K [K ...]\n"); return 2; }
+  int pool_batch = 0;
+  if (argc > 1 && std::strncmp(argv[1], "--pool=", 7) == 0) { pool_batch = std::atoi(argv[1] + 7); argv++; argc--; }
+  if (argc < 5) { std::fprintf(stderr, "usage: online_agents [--pool=<max_batch>] <inputs.bin> <device> <frames_per_agent> K [K ...]\n"); return 2; }
   Inputs in;
   if (!load(argv[1], in)) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
   const int device = std::atoi(argv[2]), nframes = std::atoi(argv[3]);
-  const float K4[4] = {500.f, 500.f, 320.f, 240.f}, bounds[4] = {0.f, 640.f, 0.f, 480.f};
-  const dvm_se3f Tcw{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}};
-  std::string out = "{\"unit\": \"frames/s over all agents (extract + SearchByProjection + PoseOptimization per frame, host arrays in -> out, one C++ thread per agent)\", \"by_agents\": {";
-  uint64_t ref_sum = 0;
-  bool same = true, first_k = true;
-  for (int a = 4; a < argc; a++) {
-    const int K = std::atoi(argv[a]);
-    Gate gate; gate.parties = K + 1;
-    std::vector<uint64_t> sums(K, 0);
-    double call_ms[3] = {0, 0, 0};   // agent 0: time inside each of the three calls (mean), and their medians
-    std::vector<double> call_all[3];
-    std::vector<int> rcs(K, 0);
-    auto agent = [&](int id) {
-      dvm_set_device(device);
-      dvm_orb_params P{1000, 1.2f, 8, 20, 7};
-      dvm_orb* h = nullptr;
-      int rc = dvm_orb_create(&P, device, 1, &h);
-      const int cap = 4096;
-      std::vector<dvm_keypoint> kps(cap);
-      std::vector<uint8_t> desc((size_t)cap * 32);
-      int n = 0, mono = 0;
-      const size_t fb = (size_t)in.rows * in.cols;
-      std::vector<int32_t> mp_c, mp_l;
-      {  // one untimed frame: the extractor's buffers, this thread's grid handle and staging context (pinned allocations, a stream) exist
-        if (rc == 0) rc = dvm_orb_extract(h, in.frames.data(), in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
-        const Pair& p = in.pairs[0];
-        mp_c.assign(p.Nc, -1); mp_l.resize(p.Nl);
-        for (int j = 0; j < p.Nl; j++) mp_l[j] = j;
-        if (rc == 0) {
-          const int nm = dvmh_search_by_projection_frames(device, p.Nc, p.kc.data(), p.dc.data(), mp_c.data(), &Tcw, K4, bounds, in.scale, 8, p.Nl, p.kl.data(),
-                                                          mp_l.data(), nullptr, p.mps.data(), 15.0f, 1, nullptr);
-          if (nm < 0) rc = nm;
-        }
-        const PoseCase& c = in.poses[0];
-        double po[7]; std::vector<uint8_t> ol(c.n); int32_t ni = 0, nn = c.n;
-        if (rc == 0) rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, po, ol.data(), &ni);
-      }
-      gate.wait();   // all agents ready
-      gate.wait();   // clock started
-      uint64_t sum = 1469598103934665603ull;
-      for (int i = 0; i < nframes && rc == 0; i++) {
-        const int t = 1 + i % in.cyc;
-        const auto c0 = std::chrono::steady_clock::now();
-        rc = dvm_orb_extract(h, in.frames.data() + (size_t)t * fb, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
-        if (rc) break;
-        const auto c1 = std::chrono::steady_clock::now();
-        const Pair& p = in.pairs[t - 1];
-        mp_c.assign(p.Nc, -1);
-        mp_l.resize(p.Nl);
-        for (int j = 0; j < p.Nl; j++) mp_l[j] = j;
-        const int nm = dvmh_search_by_projection_frames(device, p.Nc, p.kc.data(), p.dc.data(), mp_c.data(), &Tcw, K4, bounds, in.scale, 8, p.Nl,
-                                                        p.kl.data(), mp_l.data(), nullptr, p.mps.data(), 15.0f, 1, nullptr);
-        if (nm < 0) { rc = nm; break; }
-        const auto c2 = std::chrono::steady_clock::now();
-        const PoseCase& c = in.poses[t - 1];
-        double pose_out[7];
-        std::vector<uint8_t> outl(c.n);
-        int32_t ninl = 0, nn = c.n;
-        rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, pose_out, outl.data(), &ninl);
-        if (rc) break;
-        if (id == 0) {
-          const auto c3 = std::chrono::steady_clock::now();
-          call_ms[0] += std::chrono::duration<double, std::milli>(c1 - c0).count();
-          call_ms[1] += std::chrono::duration<double, std::milli>(c2 - c1).count();
-          call_ms[2] += std::chrono::duration<double, std::milli>(c3 - c2).count();
-          call_all[0].push_back(std::chrono::duration<double, std::milli>(c1 - c0).count());
-          call_all[1].push_back(std::chrono::duration<double, std::milli>(c2 - c1).count());
-          call_all[2].push_back(std::chrono::duration<double, std::milli>(c3 - c2).count());
-        }
-        if (i < in.cyc) {   // one cycle of results -> checksum
-          sum = mix(sum, &n, 4); sum = mix(sum, kps.data(), (size_t)n * sizeof(dvm_keypoint)); sum = mix(sum, desc.data(), (size_t)n * 32);
-          sum = mix(sum, &nm, 4); sum = mix(sum, mp_c.data(), mp_c.size() * 4); sum = mix(sum, pose_out, sizeof(pose_out)); sum = mix(sum, outl.data(), outl.size());
-        }
-      }
-      sums[id] = sum; rcs[id] = rc;
-      if (h) dvm_orb_destroy(h);
-    };
-    std::vector<std::thread> th;
-    for (int k = 0; k < K; k++) th.emplace_back(agent, k);
-    gate.wait();
-    const auto t0 = std::chrono::steady_clock::now();
-    gate.wait();
-    for (auto& t : th) t.join();
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (int k = 0; k < K; k++) {
-      if (rcs[k]) { std::fprintf(stderr, "agent %d of %d failed: rc %d (%s)\n", k, K, rcs[k], dvm_last_error()); return 1; }
-      if (a == 4 && k == 0) ref_sum = sums[0];
-      same = same && sums[k] == ref_sum;
-    }
-    char buf[480];
-    double med[3] = {0, 0, 0};
-    for (int q = 0; q < 3; q++)
-      if (!call_all[q].empty()) { std::sort(call_all[q].begin(), call_all[q].end()); med[q] = call_all[q][call_all[q].size() / 2]; }
-    std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_frame_per_agent\": %.4f, \"agent0_ms_in_extract_search_pose\": {\"mean\": [%.4f, %.4f, %.4f], \"median\": [%.4f, %.4f, %.4f]}}",
-                  first_k ? "" : ", ", K, K * (double)nframes / dt, dt / nframes * 1e3, call_ms[0] / nframes, call_ms[1] / nframes, call_ms[2] / nframes, med[0], med[1], med[2]);
-    out += buf;
-    first_k = false;
+  dvm_orb_pool* pool = nullptr;
+  if (pool_batch > 0) {
+    dvm_orb_params P{1000, 1.2f, 8, 20, 7};
+    if (dvm_orb_pool_create(&P, device, pool_batch, -1, &pool) != 0) { std::fprintf(stderr, "pool: %s\n", dvm_last_error()); return 1; }
   }
-  out += std::string("}, \"identical_results_across_agents\": ") + (same ? "true" : "false") + "}";
+  std::string out = "{\"unit\": \"frames/s over all agents (extract + SearchByProjection + PoseOptimization per frame, host arrays in -> out, one C++ thread per agent)\"";
+  bool same = true;
+  uint64_t ref = 0;
+  for (int mode = 0; mode < (pool ? 2 : 1); mode++) {
+    out += mode == 0 ? ", \"by_agents\": {" : ", \"by_agents_pooled_extraction\": {";
+    for (int a = 4; a < argc; a++) {
+      const int K = std::atoi(argv[a]);
+      const Result R = measure(in, device, nframes, K, mode ? pool : nullptr);
+      if (R.rc) return 1;
+      if (mode == 0 && a == 4) ref = R.sum0;
+      same = same && R.same && R.sum0 == ref;
+      char buf[640];
+      std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_frame_per_agent\": %.4f, \"agent0_ms_in_extract_search_pose\": {\"mean\": [%.4f, %.4f, %.4f], \"median\": [%.4f, %.4f, %.4f]}%s",
+                    a == 4 ? "" : ", ", K, R.fps, R.ms_per_frame, R.mean[0], R.mean[1], R.mean[2], R.med[0], R.med[1], R.med[2], mode ? "" : "}");
+      out += buf;
+      if (mode) { std::snprintf(buf, sizeof(buf), ", \"mean_frames_per_batch\": %.2f}", R.mean_batch); out += buf; }
+    }
+    out += "}";
+  }
+  if (pool) dvm_orb_pool_destroy(pool);
+  out += std::string(", \"identical_results_across_agents\": ") + (same ? "true" : "false") + "}";
   std::puts(out.c_str());
   return same ? 0 : 1;
 }
