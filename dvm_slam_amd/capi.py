@@ -370,6 +370,45 @@ class OrbPool:
             pass
 
 
+class PosePool:
+    """dvm_pose_pool_*: PoseOptimization of one frame per call, from any thread; calls arriving together run as one launch."""
+
+    def __init__(self, max_batch=32, window_us=-1, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        f = self.L.dvm_pose_pool_create
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(C.c_int32(device), C.c_int32(max_batch), C.c_int32(window_us), C.byref(self.h)))
+        self._x = self.L.dvm_pose_pool_optimize
+        self._x.restype = C.c_int32; self._x.argtypes = None
+
+    def optimize(self, pose, Xw, obs, inv_sigma2, intrinsics):
+        """One frame: pose [7], Xw [n,3], obs [n,2], inv_sigma2 [n].  Returns (pose [7], outlier [n] uint8, n_inliers, frames in the launch)."""
+        pose = np.ascontiguousarray(pose, np.float64).reshape(7)
+        Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+        n = len(Xw)
+        obs = np.ascontiguousarray(obs, np.float64).reshape(n, 2)
+        w = np.ascontiguousarray(inv_sigma2, np.float64).reshape(n)
+        cam = BaCamera(*[float(v) for v in intrinsics], 0.0)
+        out = np.zeros(7, np.float64); outl = np.zeros(max(n, 1), np.uint8)
+        ninl, bs = C.c_int32(0), C.c_int(0)
+        check(self._x(self.h, _p(pose), _p(Xw), _p(obs), _p(w), C.c_int32(n), C.byref(cam), _p(out), _p(outl), C.byref(ninl), C.byref(bs)))
+        return out, outl[:n], ninl.value, bs.value
+
+    def close(self):
+        if self.h:
+            f = self.L.dvm_pose_pool_destroy
+            f.restype = None; f.argtypes = None
+            f(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrameGrid:
     """Frame's feature grid + windowed search (reference Frame.cc:443-506,712-782; ORBmatcher.cc:70-115)."""
 

@@ -1,0 +1,107 @@
+// dvm_slam_amd/csrc/group_commit.h -- "group commit" for blocking per-agent calls (dvm_orb_pool_*, dvm_pose_pool_*).
+//
+// K agents that share a GPU make the reference's per-frame calls from K tracking threads.  Issued one by one those are K chains of small
+// launches that serialise in the runtime; the same work as ONE batched launch costs little more than a single call.  The protocol that
+// turns the one into the other without changing what a caller sees:
+//   join()    a caller takes the next slot of the COLLECTING lane (opening a free lane if none collects); calls whose shape key differs
+//             from the collecting batch's, or that find it full, wait for the next one;
+//   (the caller writes its inputs into its slot -- outside the lock, all callers at once)
+//   arrive()  the caller that took slot 0 LEADS the batch: it waits until the batch is full or nobody has joined for `window_us`, closes
+//             it (the other lane starts collecting), waits until every joined caller has written its inputs, and returns true -- the
+//             leader then runs the batch and publish()es; every other caller blocks in arrive() until that has happened;
+//   result()  status and size of the batch; the caller reads its slot's outputs (no lock);
+//   finish()  the last reader frees the lane.
+// Two lanes: while one batch runs, the next one collects.
+#pragma once
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+namespace dvm {
+
+struct GroupCommit {
+  using clock = std::chrono::steady_clock;
+  struct Lane {
+    enum State { FREE, COLLECT, RUN, DONE } state = FREE;
+    int count = 0, copied = 0, readers = 0, rc = 0;
+    int64_t key[4] = {0, 0, 0, 0};
+    clock::time_point last_join;
+    std::string err;
+  };
+  std::mutex m;
+  std::condition_variable cv;
+  Lane lane[2];
+  int cur = 0;          // the lane new calls join
+  int max_batch = 1, window_us = 20;
+
+  // open(li): called under the lock when a free lane is opened for `key` (allocate / size the lane's buffers); non-zero = error, returned
+  template <class Open>
+  int join(const int64_t key[4], Open&& open, int& li, int& slot) {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      Lane& C = lane[cur];
+      if (C.state == Lane::FREE) {
+        const int rc = open(cur);
+        if (rc != 0) return rc;
+        C.state = Lane::COLLECT; C.count = 0; C.copied = 0; C.readers = 0; C.rc = 0; C.err.clear();
+        std::memcpy(C.key, key, sizeof(C.key));
+      }
+      if (C.state == Lane::COLLECT && C.count < max_batch && std::memcmp(C.key, key, sizeof(C.key)) == 0) {
+        li = cur; slot = C.count++; C.last_join = clock::now();
+        return 0;
+      }
+      cv.wait(lk);   // the collecting batch is full / of another shape, or both lanes are busy: the next state change wakes us
+    }
+  }
+  bool arrive(int li, int slot) {
+    std::unique_lock<std::mutex> lk(m);
+    Lane& L = lane[li];
+    L.copied++;
+    if (slot != 0) {
+      cv.notify_all();                               // (the leader may be waiting for this input, or for this arrival)
+      while (L.state != Lane::DONE) cv.wait(lk);
+      return false;
+    }
+    const auto window = std::chrono::microseconds(window_us);
+    while (L.count < max_batch) {
+      const auto deadline = L.last_join + window;
+      if (clock::now() >= deadline) break;
+      cv.wait_until(lk, deadline);
+    }
+    L.state = Lane::RUN;                             // closed: nobody joins any more
+    if (lane[li ^ 1].state == Lane::FREE || lane[li ^ 1].state == Lane::COLLECT) cur = li ^ 1;
+    cv.notify_all();                                 // waiting callers may open the other lane
+    while (L.copied < L.count) cv.wait(lk);          // every joined caller has written its inputs
+    return true;
+  }
+  int batch_count(int li) {
+    std::lock_guard<std::mutex> lk(m);
+    return lane[li].count;
+  }
+  void publish(int li, int rc, const std::string& err) {
+    std::lock_guard<std::mutex> lk(m);
+    Lane& L = lane[li];
+    L.rc = rc; L.err = err; L.readers = L.count; L.state = Lane::DONE;
+    cv.notify_all();
+  }
+  int result(int li, std::string* err, int* count) {
+    std::lock_guard<std::mutex> lk(m);
+    if (err) *err = lane[li].err;
+    if (count) *count = lane[li].count;
+    return lane[li].rc;
+  }
+  void finish(int li) {
+    std::lock_guard<std::mutex> lk(m);
+    Lane& L = lane[li];
+    if (--L.readers == 0) {
+      L.state = Lane::FREE;
+      if (lane[cur].state != Lane::COLLECT) cur = li;   // nothing is collecting: the freed lane is the next to open
+      cv.notify_all();
+    }
+  }
+};
+
+}  // namespace dvm

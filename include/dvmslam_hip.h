@@ -496,6 +496,16 @@ int dvm_pose_optimize(int device, const double* pose_in, const double* Xw, const
                       const int32_t* n, int stride, int batch, const dvm_ba_camera* cam, double* pose_out,
                       uint8_t* outlier, int32_t* n_inliers);
 
+/* The shared form for several agents on one GPU (as dvm_orb_pool for the extractor): dvm_pose_pool_optimize is dvm_pose_optimize for ONE
+ * frame -- same arguments, same results bit for bit --, callable from any number of threads; calls that arrive within `window_us` of each
+ * other and share the camera run as ONE launch of the batched kernel (a workgroup per frame).  A frame with more than 1 280
+ * correspondences is handed to dvm_pose_optimize directly.  batch_size (may be NULL): how many frames the call's launch held. */
+typedef struct dvm_pose_pool dvm_pose_pool;
+int dvm_pose_pool_create(int device, int max_batch, int window_us, dvm_pose_pool** out);
+void dvm_pose_pool_destroy(dvm_pose_pool* pool);
+int dvm_pose_pool_optimize(dvm_pose_pool* pool, const double* pose_in, const double* Xw, const double* obs, const double* inv_sigma2, int n,
+                           const dvm_ba_camera* cam, double* pose_out, uint8_t* outlier, int32_t* n_inliers, int* batch_size);
+
 /* Optimizer::OptimizeSim3 (Optimizer.cc:1960-2212), numerics for N correspondences gathered by the caller:
  * P1c / P2c = the matched map points in their own key frame's camera frame (R1w*P+t1w, R2w*P+t2w), obs1 / obs2 =
  * undistorted keypoints in KF1 / KF2, w1 / w2 = mvInvLevelSigma2[octave], K1 / K2 = (fx,fy,cx,cy) of both pinhole

@@ -180,3 +180,48 @@ def test_pooled_extractor_equals_one_extractor_per_frame(capi):
     n, kp, d, m, bs = pool.extract(frames[3])
     assert bs == 1 and n == ref[3][0] and kp.tobytes() == ref[3][1].tobytes()
     pool.close()
+
+
+def test_pooled_pose_optimization_equals_single_calls(capi):
+    """dvm_pose_pool_*: K threads' PoseOptimization calls run as one launch when they arrive together; every caller gets the bits
+    dvm_pose_optimize gives for its frame alone (frames of different sizes and, for one agent, another camera)."""
+    import threading
+    import bench_legs
+    cases = [bench_legs._pose_case(300 + i, n_pts=int(n)) for i, n in enumerate((300, 120, 700, 40, 300, 900, 9, 250))]
+    ref = []
+    for c in cases:
+        p, o, ni = capi.pose_optimize(c[0][None], c[1][None], c[2][None], c[3][None], np.array([len(c[1])], np.int32), c[4], 0)
+        ref.append((p[0].copy(), o[0][:len(c[1])].copy(), int(ni[0])))
+    other_cam = np.array(cases[0][4], np.float64).copy(); other_cam[0] *= 1.01
+    c0 = cases[0]
+    p, o, ni = capi.pose_optimize(c0[0][None], c0[1][None], c0[2][None], c0[3][None], np.array([len(c0[1])], np.int32), other_cam, 0)
+    ref_other = (p[0].copy(), o[0][:len(c0[1])].copy(), int(ni[0]))
+    pool = capi.PosePool(max_batch=8, window_us=200)
+    errors, sizes = [], []
+
+    def agent(k):
+        try:
+            for i in range(20):
+                if k == 5 and i % 4 == 0:
+                    po, ol, ni, bs = pool.optimize(c0[0], c0[1], c0[2], c0[3], other_cam)
+                    r = ref_other
+                else:
+                    j = (k + i) % len(cases)
+                    c = cases[j]
+                    po, ol, ni, bs = pool.optimize(c[0], c[1], c[2], c[3], c[4])
+                    r = ref[j]
+                sizes.append(bs)
+                if po.tobytes() != r[0].tobytes() or not np.array_equal(ol, r[1]) or ni != r[2]:
+                    errors.append((k, i))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ths = [threading.Thread(target=agent, args=(k,)) for k in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths), "a pooled call did not return"
+    assert not errors, errors[:3]
+    assert max(sizes) > 1, "the calls never shared a launch"
+    pool.close()

@@ -92,7 +92,7 @@ struct Gate {
 // one measurement: K agent threads, `nframes` frames each; pool != nullptr: extraction through the shared extractor (dvm_orb_pool_extract)
 struct Result { double fps = 0, ms_per_frame = 0, mean[3] = {0, 0, 0}, med[3] = {0, 0, 0}, mean_batch = 0; int rc = 0; uint64_t sum0 = 0; bool same = true; };
 
-static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_pool* pool) {
+static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_pool* pool, dvm_pose_pool* ppool) {
   const float K4[4] = {500.f, 500.f, 320.f, 240.f}, bounds[4] = {0.f, 640.f, 0.f, 480.f};
   const dvm_se3f Tcw{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}};
   Gate gate; gate.parties = K + 1;
@@ -115,6 +115,11 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
       return pool ? dvm_orb_pool_extract(pool, img, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono, &bs)
                   : dvm_orb_extract(h, img, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
     };
+    auto pose_opt = [&](const PoseCase& c, double* po, uint8_t* ol, int32_t* ni) {
+      int32_t nn = c.n;
+      return ppool ? dvm_pose_pool_optimize(ppool, c.pose, c.X.data(), c.obs.data(), c.w.data(), c.n, &c.cam, po, ol, ni, nullptr)
+                   : dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, po, ol, ni);
+    };
     std::vector<int32_t> mp_c, mp_l;
     {  // one untimed frame: the extractor's buffers, this thread's grid handle and staging context (pinned allocations, a stream) exist
       if (rc == 0) rc = extract(in.frames.data());
@@ -127,8 +132,8 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
         if (nm < 0) rc = nm;
       }
       const PoseCase& c = in.poses[0];
-      double po[7]; std::vector<uint8_t> ol(c.n); int32_t ni = 0, nn = c.n;
-      if (rc == 0) rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, po, ol.data(), &ni);
+      double po[7]; std::vector<uint8_t> ol(c.n); int32_t ni = 0;
+      if (rc == 0) rc = pose_opt(c, po, ol.data(), &ni);
     }
     gate.wait();   // all agents ready
     gate.wait();   // clock started
@@ -151,8 +156,8 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
       const PoseCase& c = in.poses[t - 1];
       double pose_out[7];
       std::vector<uint8_t> outl(c.n);
-      int32_t ninl = 0, nn = c.n;
-      rc = dvm_pose_optimize(device, c.pose, c.X.data(), c.obs.data(), c.w.data(), &nn, c.n, 1, &c.cam, pose_out, outl.data(), &ninl);
+      int32_t ninl = 0;
+      rc = pose_opt(c, pose_out, outl.data(), &ninl);
       if (rc) break;
       if (id == 0) {
         const auto c3 = std::chrono::steady_clock::now();
@@ -198,18 +203,22 @@ int main(int argc, char** argv) {
   if (!load(argv[1], in)) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
   const int device = std::atoi(argv[2]), nframes = std::atoi(argv[3]);
   dvm_orb_pool* pool = nullptr;
+  dvm_pose_pool* ppool = nullptr;
   if (pool_batch > 0) {
     dvm_orb_params P{1000, 1.2f, 8, 20, 7};
-    if (dvm_orb_pool_create(&P, device, pool_batch, -1, &pool) != 0) { std::fprintf(stderr, "pool: %s\n", dvm_last_error()); return 1; }
+    if (dvm_orb_pool_create(&P, device, pool_batch, -1, &pool) != 0 || dvm_pose_pool_create(device, pool_batch, -1, &ppool) != 0) {
+      std::fprintf(stderr, "pool: %s\n", dvm_last_error());
+      return 1;
+    }
   }
   std::string out = "{\"unit\": \"frames/s over all agents (extract + SearchByProjection + PoseOptimization per frame, host arrays in -> out, one C++ thread per agent)\"";
   bool same = true;
   uint64_t ref = 0;
   for (int mode = 0; mode < (pool ? 2 : 1); mode++) {
-    out += mode == 0 ? ", \"by_agents\": {" : ", \"by_agents_pooled_extraction\": {";
+    out += mode == 0 ? ", \"by_agents\": {" : ", \"by_agents_pooled\": {";   // pooled: extraction and PoseOptimization through the shared services
     for (int a = 4; a < argc; a++) {
       const int K = std::atoi(argv[a]);
-      const Result R = measure(in, device, nframes, K, mode ? pool : nullptr);
+      const Result R = measure(in, device, nframes, K, mode ? pool : nullptr, mode ? ppool : nullptr);
       if (R.rc) return 1;
       if (mode == 0 && a == 4) ref = R.sum0;
       same = same && R.same && R.sum0 == ref;
@@ -222,6 +231,7 @@ int main(int argc, char** argv) {
     out += "}";
   }
   if (pool) dvm_orb_pool_destroy(pool);
+  if (ppool) dvm_pose_pool_destroy(ppool);
   out += std::string(", \"identical_results_across_agents\": ") + (same ? "true" : "false") + "}";
   std::puts(out.c_str());
   return same ? 0 : 1;
