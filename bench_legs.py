@@ -177,7 +177,7 @@ def low_texture(capi, device, cpu=True, steps=3):
     return out
 
 
-def online_agents(capi, frames, device, Ks=(1, 2, 4, 8), frames_per_agent=150):
+def online_agents(capi, frames, device, Ks=(1, 4, 8, 16, 32), frames_per_agent=150):
     """K agents tracking on ONE GPU through the drop-in boundary, a host thread and an extractor handle each (the online shape of BASELINE
     config 4 with more agents than GPUs): per frame ORBextractor::operator() -> SearchByProjection(Cur, Last) -> PoseOptimization, host
     arrays in and out, every call synchronous as Tracking makes them.  Whole-job frames/s over the K threads; results of every thread are
