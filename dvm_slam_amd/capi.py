@@ -409,6 +409,42 @@ class PosePool:
             pass
 
 
+class MatchPool:
+    """dvm_match_pool_*: the grid build + ranked window search of SearchByProjection(Cur, Last) for several threads at once.
+    use(): route this process's search_by_projection_frames calls through it (dvmh_set_match_pool); release() / close() undo that."""
+
+    def __init__(self, max_batch=32, kp_cap=2048, q_cap=2048, window_us=-1, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        f = self.L.dvm_match_pool_create
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(C.c_int32(device), C.c_int32(max_batch), C.c_int32(kp_cap), C.c_int32(q_cap), C.c_int32(window_us), C.byref(self.h)))
+
+    def use(self):
+        f = host_lib().dvmh_set_match_pool
+        f.restype = None; f.argtypes = [C.c_void_p]
+        f(self.h)
+
+    def release(self):
+        f = host_lib().dvmh_set_match_pool
+        f.restype = None; f.argtypes = [C.c_void_p]
+        f(None)
+
+    def close(self):
+        if self.h:
+            self.release()
+            f = self.L.dvm_match_pool_destroy
+            f.restype = None; f.argtypes = None
+            f(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrameGrid:
     """Frame's feature grid + windowed search (reference Frame.cc:443-506,712-782; ORBmatcher.cc:70-115)."""
 

@@ -57,6 +57,7 @@ static int need_device(int device) {
   return hip_check(hipSetDevice(device), "hipSetDevice");
 }
 
+#include "group_commit.h"
 #include "host_stage.h"
 
 extern "C" {
@@ -978,4 +979,150 @@ int dvm_match_frames_batch(const dvm_frame* train, int first_slot, int count, co
   return hip_check(hipGetLastError(), "match_frames launch");
 }
 
+
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ shared search service
+// The grid build + ranked window search of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) (dvm_frame_build_match_window_ranked) for
+// several agents' tracking threads at once: calls that arrive together run as ONE launch pair (k_frame_build over the batch's grid slots,
+// k_match_window_ranked with a frame per blockIdx.y) -- the third of the shared per-GPU services, see orb_pool.cpp / group_commit.h.
+// A lane keeps every slot's arrays in MAPPED host memory (each is read or written once per call); the skip flags, which the search looks up
+// per candidate, travel through a device buffer and only when some frame of the batch has any.
+
+namespace {
+struct MatchLane {
+  dvm_frame* grid = nullptr;                 // max_batch slots
+  dvm_keypoint* kps = nullptr; uint8_t* desc = nullptr; int32_t* n = nullptr;                      // [B][kp_cap], mapped
+  uint8_t* qdesc = nullptr; float *qx = nullptr, *qy = nullptr, *qr = nullptr; int32_t *qmin = nullptr, *qmax = nullptr, *nq = nullptr;   // [B][q_cap]
+  uint32_t* ranked = nullptr;                // [B][q_cap][4]
+  int32_t* skip_on = nullptr;                // [B]
+  uint8_t *h_skip = nullptr, *d_skip = nullptr;   // [B][kp_cap]: pinned / device
+  hipStream_t stream = nullptr;
+  float bounds[4] = {0, 0, 0, 0};
+};
+}  // namespace
+
+struct dvm_match_pool {
+  int device = 0, kp_cap = 0, q_cap = 0;
+  GroupCommit gc;
+  MatchLane lane[2];
+};
+
+static void match_lane_free(MatchLane& L) {
+  for (void* p : {(void*)L.kps, (void*)L.desc, (void*)L.n, (void*)L.qdesc, (void*)L.qx, (void*)L.qy, (void*)L.qr, (void*)L.qmin, (void*)L.qmax, (void*)L.nq,
+                  (void*)L.ranked, (void*)L.skip_on, (void*)L.h_skip})
+    if (p) hipHostFree(p);
+  if (L.d_skip) hipFree(L.d_skip);
+  if (L.grid) dvm_frame_destroy(L.grid);
+  if (L.stream) hipStreamDestroy(L.stream);
+  L = MatchLane{};
+}
+
+extern "C" int dvm_match_pool_create(int device, int max_batch, int kp_cap, int q_cap, int window_us, dvm_match_pool** out) {
+  if (!out || max_batch < 1 || max_batch > 256 || kp_cap < 1 || kp_cap > kFrameCap || q_cap < 1 || q_cap > 65536) {
+    set_error("dvm_match_pool_create: bad parameters");
+    return DVM_ERR_INVALID;
+  }
+  *out = nullptr;
+  int rc = need_device(device);
+  if (rc != DVM_OK) return rc;
+  rc = hip_check(hipSetDevice(device), "hipSetDevice");
+  if (rc != DVM_OK) return rc;
+  dvm_match_pool* pool = new (std::nothrow) dvm_match_pool();
+  if (!pool) return DVM_ERR_INVALID;
+  pool->device = device; pool->kp_cap = kp_cap; pool->q_cap = (q_cap + 15) & ~15;
+  pool->gc.max_batch = max_batch; pool->gc.window_us = window_us < 0 ? 20 : window_us;
+  const size_t B = (size_t)max_batch, K = (size_t)kp_cap, Q = (size_t)pool->q_cap;
+  for (MatchLane& L : pool->lane) {
+    auto mapped = [&](void** p, size_t bytes) { if (rc == DVM_OK) rc = hip_check(hipHostMalloc(p, bytes, hipHostMallocMapped), "hipHostMalloc"); };
+    if (rc == DVM_OK) rc = dvm_frame_create(device, kp_cap, max_batch, &L.grid);
+    mapped(reinterpret_cast<void**>(&L.kps), B * K * sizeof(dvm_keypoint)); mapped(reinterpret_cast<void**>(&L.desc), B * K * 32);
+    mapped(reinterpret_cast<void**>(&L.n), B * 4); mapped(reinterpret_cast<void**>(&L.qdesc), B * Q * 32);
+    mapped(reinterpret_cast<void**>(&L.qx), B * Q * 4); mapped(reinterpret_cast<void**>(&L.qy), B * Q * 4); mapped(reinterpret_cast<void**>(&L.qr), B * Q * 4);
+    mapped(reinterpret_cast<void**>(&L.qmin), B * Q * 4); mapped(reinterpret_cast<void**>(&L.qmax), B * Q * 4); mapped(reinterpret_cast<void**>(&L.nq), B * 4);
+    mapped(reinterpret_cast<void**>(&L.ranked), B * Q * 16); mapped(reinterpret_cast<void**>(&L.skip_on), B * 4);
+    if (rc == DVM_OK) rc = hip_check(hipHostMalloc(reinterpret_cast<void**>(&L.h_skip), B * K), "hipHostMalloc");
+    if (rc == DVM_OK) rc = hip_check(hipMalloc(reinterpret_cast<void**>(&L.d_skip), B * K), "hipMalloc");
+    if (rc == DVM_OK) rc = hip_check(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking), "stream");
+  }
+  if (rc != DVM_OK) {
+    for (MatchLane& L : pool->lane) match_lane_free(L);
+    delete pool;
+    return rc;
+  }
+  *out = pool;
+  return DVM_OK;
+}
+extern "C" void dvm_match_pool_destroy(dvm_match_pool* pool) {
+  if (!pool) return;
+  hipSetDevice(pool->device);
+  for (MatchLane& L : pool->lane) { if (L.stream) hipStreamSynchronize(L.stream); match_lane_free(L); }
+  delete pool;
+}
+extern "C" int dvm_match_pool_capacity(const dvm_match_pool* pool, int* kp_cap, int* q_cap) {
+  if (!pool) return DVM_ERR_INVALID;
+  if (kp_cap) *kp_cap = pool->kp_cap;
+  if (q_cap) *q_cap = pool->q_cap;
+  return DVM_OK;
+}
+extern "C" int dvm_match_pool_build_match_ranked(dvm_match_pool* pool, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX, float maxX, float minY,
+                                      float maxY, const uint8_t* skip, const uint8_t* qdesc, const float* qx, const float* qy, const float* qr,
+                                      const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked, int* batch_size) {
+  if (!pool || n < 0 || nq < 0 || (n && (!kps || !desc)) || (nq && (!qdesc || !qx || !qy || !qr || !qmin || !qmax || !ranked))) return DVM_ERR_INVALID;
+  if (n > pool->kp_cap || nq > pool->q_cap) { set_error("dvm_match_pool: frame larger than the pool's capacity"); return DVM_ERR_CAPACITY; }
+  if (!(maxX > minX) || !(maxY > minY)) { set_error("frame bounds empty"); return DVM_ERR_INVALID; }
+  if (batch_size) *batch_size = 0;
+  int64_t key[4] = {0, 0, 0, 0};   // the frames of a batch share the image bounds (one grid geometry per launch)
+  std::memcpy(&key[0], &minX, 4); std::memcpy(&key[1], &maxX, 4); std::memcpy(&key[2], &minY, 4); std::memcpy(&key[3], &maxY, 4);
+  int li = 0, slot = 0;
+  int rc = pool->gc.join(key, [&](int l) {
+    MatchLane& O = pool->lane[l];
+    O.bounds[0] = minX; O.bounds[1] = maxX; O.bounds[2] = minY; O.bounds[3] = maxY;
+    return 0;
+  }, li, slot);
+  if (rc != DVM_OK) return rc;
+  MatchLane& L = pool->lane[li];
+  const size_t K = (size_t)pool->kp_cap, Q = (size_t)pool->q_cap, s = (size_t)slot;
+  if (n) { std::memcpy(L.kps + s * K, kps, (size_t)n * sizeof(dvm_keypoint)); std::memcpy(L.desc + s * K * 32, desc, (size_t)n * 32); }
+  L.n[slot] = n; L.nq[slot] = nq;
+  if (nq) {
+    std::memcpy(L.qdesc + s * Q * 32, qdesc, (size_t)nq * 32);
+    std::memcpy(L.qx + s * Q, qx, (size_t)nq * 4); std::memcpy(L.qy + s * Q, qy, (size_t)nq * 4); std::memcpy(L.qr + s * Q, qr, (size_t)nq * 4);
+    std::memcpy(L.qmin + s * Q, qmin, (size_t)nq * 4); std::memcpy(L.qmax + s * Q, qmax, (size_t)nq * 4);
+  }
+  L.skip_on[slot] = skip ? 1 : 0;
+  if (skip) std::memcpy(L.h_skip + s * K, skip, (size_t)n);
+  if (pool->gc.arrive(li, slot)) {
+    const int count = pool->gc.batch_count(li);
+    int r = hip_check(hipSetDevice(pool->device), "hipSetDevice");
+    if (r == DVM_OK) r = frame_bounds(L.grid, L.bounds[0], L.bounds[1], L.bounds[2], L.bounds[3]);
+    if (r == DVM_OK) {
+      bool any_skip = false;
+      for (int b = 0; b < count; b++) any_skip = any_skip || L.skip_on[b];
+      if (any_skip) r = hip_check(hipMemcpyAsync(L.d_skip, L.h_skip, (size_t)count * K, hipMemcpyHostToDevice, L.stream), "skip upload");
+    }
+    if (r == DVM_OK) {
+      auto dev = [](void* h) { void* d = nullptr; hipHostGetDevicePointer(&d, h, 0); return d; };
+      launch_frame_build(L.stream, static_cast<const dvm_keypoint_pod*>(dev(L.kps)), (int64_t)K, static_cast<const uint8_t*>(dev(L.desc)), (int64_t)K * 32, 0,
+                         static_cast<const int32_t*>(dev(L.n)), L.grid->view, 0, count);
+      launch_match_window_ranked_batch(L.stream, L.grid->view, 0, count, L.d_skip, static_cast<const int32_t*>(dev(L.skip_on)), (int)K,
+                                       static_cast<const uint8_t*>(dev(L.qdesc)), static_cast<const float*>(dev(L.qx)), static_cast<const float*>(dev(L.qy)),
+                                       static_cast<const float*>(dev(L.qr)), static_cast<const int32_t*>(dev(L.qmin)), static_cast<const int32_t*>(dev(L.qmax)),
+                                       static_cast<const int32_t*>(dev(L.nq)), (int)Q, static_cast<uint32_t*>(dev(L.ranked)));
+      r = hip_check(hipGetLastError(), "frame_build + match launch");
+      if (r == DVM_OK) r = hip_check(hipStreamSynchronize(L.stream), "search");
+    }
+    pool->gc.publish(li, r, r == DVM_OK ? std::string() : std::string(last_error_cstr()));
+  }
+  std::string err;
+  int count = 0;
+  rc = pool->gc.result(li, &err, &count);
+  if (rc == DVM_OK) {
+    if (nq) std::memcpy(ranked, L.ranked + s * Q * 4, (size_t)nq * 16);
+    if (batch_size) *batch_size = count;
+  } else {
+    set_error("dvm_match_pool: " + err);
+  }
+  pool->gc.finish(li);
+  return rc;
+}

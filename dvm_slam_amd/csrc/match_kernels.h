@@ -103,6 +103,9 @@ void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint
                          int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out, int32_t* second_idx = nullptr);
 void launch_match_window_ranked(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                                 const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked);
+void launch_match_window_ranked_batch(hipStream_t s, const FrameView& F, int first_slot, int count, const uint8_t* skip, const int32_t* skip_on,
+                                      int skip_stride, const uint8_t* qdesc, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                      const int32_t* qmax, const int32_t* nq_arr, int qstride, uint32_t* ranked);
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride);
 void launch_match_lists(hipStream_t s, const uint8_t* tdesc, const uint8_t* qdesc, const int32_t* off, const int32_t* cand,

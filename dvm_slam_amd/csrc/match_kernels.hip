@@ -249,15 +249,26 @@ __device__ __forceinline__ void sort4(uint32_t (&k)[4]) {
   DVM_CE(0, 1) DVM_CE(2, 3) DVM_CE(0, 2) DVM_CE(1, 3) DVM_CE(1, 2)
 #undef DVM_CE
 }
+// blockIdx.y = frame of a batch (the shared search service, dvm_match_pool_*): frame b searches grid slot `slot + b` with its own query
+// arrays at b * qstride elements, nq_arr[b] queries and -- where skip_on[b] is set -- the skip flags at b * skip_stride bytes.
+// A single search is the batch of one (qstride = 0, nq_arr = skip_on = NULL).
 __global__ void __launch_bounds__(256) k_match_window_ranked(FrameView FB, int slot, const uint8_t* __restrict__ skip,
                                                              const uint8_t* __restrict__ qdesc, const float* __restrict__ qx,
                                                              const float* __restrict__ qy, const float* __restrict__ qr,
                                                              const int32_t* __restrict__ qmin, const int32_t* __restrict__ qmax, int nq,
-                                                             uint32_t* __restrict__ ranked) {
+                                                             uint32_t* __restrict__ ranked, int qstride, const int32_t* __restrict__ nq_arr,
+                                                             const int32_t* __restrict__ skip_on, int skip_stride) {
   const int lane = threadIdx.x & 15;               // lane within the query's DPP row
   const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int b = blockIdx.y;
+  if (nq_arr) nq = nq_arr[b];
   if (q >= nq) return;
-  const FrameView F = FB.slot(slot);
+  const FrameView F = FB.slot(slot + b);
+  {
+    const size_t o = (size_t)b * qstride;
+    qdesc += o * 32; qx += o; qy += o; qr += o; qmin += o; qmax += o; ranked += o * 4;
+    if (skip_on) skip = skip_on[b] ? skip + (size_t)b * skip_stride : nullptr;
+  }
   const float x = qx[q], y = qy[q], r = qr[q];
   const int minLevel = qmin[q], maxLevel = qmax[q];
   const uint32_t none = (256u << 16) | 0xFFFFu;
@@ -714,7 +725,14 @@ void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint
 }
 void launch_match_window_ranked(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                                 const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked) {
-  hipLaunchKernelGGL(k_match_window_ranked, dim3((nq + 15) / 16), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, ranked);
+  hipLaunchKernelGGL(k_match_window_ranked, dim3((nq + 15) / 16), dim3(256), 0, s, F, slot, skip, qdesc, qx, qy, qr, qmin, qmax, nq, ranked, 0,
+                     nullptr, nullptr, 0);
+}
+void launch_match_window_ranked_batch(hipStream_t s, const FrameView& F, int first_slot, int count, const uint8_t* skip, const int32_t* skip_on,
+                                      int skip_stride, const uint8_t* qdesc, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                                      const int32_t* qmax, const int32_t* nq_arr, int qstride, uint32_t* ranked) {
+  hipLaunchKernelGGL(k_match_window_ranked, dim3((qstride + 15) / 16, count), dim3(256), 0, s, F, first_slot, skip, qdesc, qx, qy, qr, qmin, qmax, 0,
+                     ranked, qstride, nq_arr, skip_on, skip_stride);
 }
 void launch_match_frames(hipStream_t s, const FrameView& F, int first_slot, int count, const PairQueries& pq, float th,
                          const float* scale_factors, int nlevels, dvm_match_pod* out, int64_t out_stride) {

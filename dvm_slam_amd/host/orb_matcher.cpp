@@ -4,6 +4,7 @@
 #include "../csrc/pose_f32.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <chrono>
@@ -70,6 +71,9 @@ struct HostGrid {
   }
 };
 }  // namespace
+
+static std::atomic<dvm_match_pool*> g_match_pool{nullptr};   // dvmh_set_match_pool
+void set_match_pool(dvm_match_pool* pool) { g_match_pool.store(pool, std::memory_order_release); }
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri, int device) : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
 // The device grid belongs to the calling THREAD, not to the matcher object: ORB-SLAM3 constructs an ORBmatcher as a local in
@@ -181,9 +185,16 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
   // keypoints + descriptors still in HBM where ORBextractor::operator() left them (Frame.cc:411 -> here): the grid is built from there
   const bool res = resident(Cur);
   last_grid_from_device = res;
-  rc = dvm_frame_build_match_window_ranked(grid_, 0, res ? Cur.dev->d_kps : Cur.mvKeysUn, res ? Cur.dev->d_desc : Cur.mDescriptors, Cur.N,
-                                           Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, skip, qdesc.data(), qx.data(), qy.data(),
-                                           qr.data(), qmin.data(), qmax.data(), nq, ranked.data(), res ? 1 : 0);
+  dvm_match_pool* pool = g_match_pool.load(std::memory_order_acquire);
+  int pool_kp = 0, pool_q = 0;
+  if (pool && !res) dvm_match_pool_capacity(pool, &pool_kp, &pool_q);
+  if (pool && !res && Cur.N <= pool_kp && nq <= pool_q)   // several agents on this GPU: the search rides in the shared service's batch
+    rc = dvm_match_pool_build_match_ranked(pool, Cur.mvKeysUn, Cur.mDescriptors, Cur.N, Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, skip, qdesc.data(),
+                                           qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), nq, ranked.data(), nullptr);
+  else
+    rc = dvm_frame_build_match_window_ranked(grid_, 0, res ? Cur.dev->d_kps : Cur.mvKeysUn, res ? Cur.dev->d_desc : Cur.mDescriptors, Cur.N,
+                                             Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY, skip, qdesc.data(), qx.data(), qy.data(),
+                                             qr.data(), qmin.data(), qmax.data(), nq, ranked.data(), res ? 1 : 0);
   if (rc != DVM_OK) return rc;
   mark("match");
 
@@ -908,6 +919,7 @@ using dvm_host::FrameView;
 using dvm_host::KeyFrameView;
 using dvm_host::MapPointsView;
 extern "C" {
+void dvmh_set_match_pool(dvm_match_pool* pool) { dvm_host::set_match_pool(pool); }
 int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,
                                      const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
                                      const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried) {

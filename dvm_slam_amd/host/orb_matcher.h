@@ -54,6 +54,9 @@ void PoseMatrices(const dvm_se3f& Tcw, float* Rcw, float* tcw, float* Ow);
 void Sim3ToSE3(const dvm_sim3f& Scw, dvm_se3f& Tcw, float* Ow);
 dvm_se3f InverseSE3(const dvm_se3f& T);
 
+// process-wide: route SearchByProjection(Cur, Last)'s grid build + window search through a shared search service (NULL: per-thread calls)
+void set_match_pool(dvm_match_pool* pool);
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // ORBmatcher.cc:36-38

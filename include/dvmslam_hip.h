@@ -223,6 +223,17 @@ int dvm_frame_build_match_window_ranked(dvm_frame* f, int slot, const dvm_keypoi
                                         float maxX, float minY, float maxY, const uint8_t* skip, const uint8_t* qdesc,
                                         const float* qx, const float* qy, const float* qr, const int32_t* qmin,
                                         const int32_t* qmax, int nq, uint32_t* ranked, int kps_on_device);
+/* The shared form of the call above for several agents on one GPU (as dvm_orb_pool for the extractor): the same arguments (host pointers), the
+ * same ranked lists, callable from any number of threads; calls that arrive within `window_us` of each other and share the image bounds run
+ * as ONE launch pair over the batch's grid slots.  kp_cap / q_cap: keypoints / queries per frame the pool holds (a larger frame is refused
+ * with DVM_ERR_CAPACITY: the caller takes dvm_frame_build_match_window_ranked).  batch_size (may be NULL): frames in the call's launch. */
+typedef struct dvm_match_pool dvm_match_pool;
+int dvm_match_pool_create(int device, int max_batch, int kp_cap, int q_cap, int window_us, dvm_match_pool** out);
+void dvm_match_pool_destroy(dvm_match_pool* pool);
+int dvm_match_pool_capacity(const dvm_match_pool* pool, int* kp_cap, int* q_cap);
+int dvm_match_pool_build_match_ranked(dvm_match_pool* pool, const dvm_keypoint* kps, const uint8_t* desc, int n, float minX, float maxX, float minY,
+                                      float maxY, const uint8_t* skip, const uint8_t* qdesc, const float* qx, const float* qy, const float* qr,
+                                      const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked, int* batch_size);
 /* The stream the host-pointer convenience calls of the CALLING THREAD run on (device `device`; created on first use).  A caller
  * that builds a grid with on_device = 1 and then searches it through a host-pointer call passes it as `stream`, so that the two are
  * one in-order chain (no synchronisation in between). */

@@ -76,6 +76,10 @@ typedef struct dvmh_tracked_point {
 int dvmh_search_by_projection_frames(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,
                                      const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
                                      const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried);
+/* Several agents on one GPU: route the grid build + window search of every SearchByProjection(CurrentFrame, LastFrame) of this process
+ * through a shared search service (dvm_match_pool_create, include/dvmslam_hip.h); NULL: back to one staged call per thread.  Frames beyond
+ * the pool's capacity, and frames still in HBM, keep the per-thread call.  The pool must outlive the calls. */
+void dvmh_set_match_pool(dvm_match_pool* pool);
 /* the same with the current frame's keypoints + descriptors still in HBM where the extractor left them (dvm_orb_last_result): the grid is
  * built from there when the reference is valid (*grid_from_device = 1), from the host arrays otherwise */
 int dvmh_search_by_projection_frames_dev(int device, int Nc, const dvm_keypoint* kps_c, const uint8_t* desc_c, int32_t* mp_c, const dvm_se3f* Tcw,

@@ -225,3 +225,44 @@ def test_pooled_pose_optimization_equals_single_calls(capi):
     assert not errors, errors[:3]
     assert max(sizes) > 1, "the calls never shared a launch"
     pool.close()
+
+
+def test_pooled_search_by_projection_equals_single_calls(capi, oracle):
+    """dvm_match_pool_* behind dvmh_set_match_pool: K threads' SearchByProjection(Cur, Last) calls share launches; every call returns what
+    the per-thread call returns (which the oracle confirms), sparse and crowded frames, with and without keypoints claimed at entry."""
+    import threading
+    from matcher_scene import make_scene
+    scenes = [make_scene(oracle, 20 + i, n_last=int(nl), n_cur=int(nc)) for i, (nl, nc) in enumerate(((1000, 1100), (400, 500), (1000, 300), (1500, 1800)))]
+    ths_ = (15.0, 7.0, 40.0, 15.0)
+    for sc in scenes[:2]:
+        sc["mp_c"] = np.full_like(sc["mp_c"], -1)     # nothing claimed at entry (the TrackWithMotionModel case): no skip array travels
+    ref = [capi.search_by_projection_frames(th=t, **sc)[:2] for sc, t in zip(scenes, ths_)]
+    for (n_g, mp_g), sc, t in zip(ref, scenes, ths_):
+        n_o, mp_o = oracle.search_by_projection_frames(th=t, **sc)
+        assert n_g == n_o and np.array_equal(mp_g, mp_o)
+    pool = capi.MatchPool(max_batch=8, kp_cap=2048, q_cap=2048, window_us=200)
+    pool.use()
+    errors = []
+
+    def agent(k):
+        try:
+            for i in range(16):
+                j = (k + i) % len(scenes)
+                n, mp, _ = capi.search_by_projection_frames(th=ths_[j], **scenes[j])
+                if n != ref[j][0] or not np.array_equal(mp, ref[j][1]):
+                    errors.append((k, i, j))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    try:
+        ths = [threading.Thread(target=agent, args=(k,)) for k in range(8)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ths), "a pooled call did not return"
+        assert not errors, errors[:3]
+    finally:
+        pool.close()
+    n, mp, _ = capi.search_by_projection_frames(th=ths_[0], **scenes[0])   # back on the per-thread call
+    assert n == ref[0][0] and np.array_equal(mp, ref[0][1])

@@ -204,9 +204,11 @@ int main(int argc, char** argv) {
   const int device = std::atoi(argv[2]), nframes = std::atoi(argv[3]);
   dvm_orb_pool* pool = nullptr;
   dvm_pose_pool* ppool = nullptr;
+  dvm_match_pool* mpool = nullptr;
   if (pool_batch > 0) {
     dvm_orb_params P{1000, 1.2f, 8, 20, 7};
-    if (dvm_orb_pool_create(&P, device, pool_batch, -1, &pool) != 0 || dvm_pose_pool_create(device, pool_batch, -1, &ppool) != 0) {
+    if (dvm_orb_pool_create(&P, device, pool_batch, -1, &pool) != 0 || dvm_pose_pool_create(device, pool_batch, -1, &ppool) != 0 ||
+        dvm_match_pool_create(device, pool_batch, 2048, 2048, -1, &mpool) != 0) {
       std::fprintf(stderr, "pool: %s\n", dvm_last_error());
       return 1;
     }
@@ -215,9 +217,10 @@ int main(int argc, char** argv) {
   bool same = true;
   uint64_t ref = 0;
   for (int mode = 0; mode < (pool ? 2 : 1); mode++) {
-    out += mode == 0 ? ", \"by_agents\": {" : ", \"by_agents_pooled\": {";   // pooled: extraction and PoseOptimization through the shared services
+    out += mode == 0 ? ", \"by_agents\": {" : ", \"by_agents_pooled\": {";   // pooled: all three calls through the shared services
     for (int a = 4; a < argc; a++) {
       const int K = std::atoi(argv[a]);
+      dvmh_set_match_pool(mode ? mpool : nullptr);   // the search of SearchByProjection(Cur, Last) through the shared service (pooled mode)
       const Result R = measure(in, device, nframes, K, mode ? pool : nullptr, mode ? ppool : nullptr);
       if (R.rc) return 1;
       if (mode == 0 && a == 4) ref = R.sum0;
@@ -232,6 +235,8 @@ int main(int argc, char** argv) {
   }
   if (pool) dvm_orb_pool_destroy(pool);
   if (ppool) dvm_pose_pool_destroy(ppool);
+  dvmh_set_match_pool(nullptr);
+  if (mpool) dvm_match_pool_destroy(mpool);
   out += std::string(", \"identical_results_across_agents\": ") + (same ? "true" : "false") + "}";
   std::puts(out.c_str());
   return same ? 0 : 1;
