@@ -90,7 +90,8 @@ int dvm_orb_extract(dvm_orb* h, const uint8_t* img, int rows, int cols, int stri
  * (and share size and lapping area) are extracted as ONE batch of up to max_batch frames: the caller that opened the batch waits for
  * the arrivals to pause, runs it, and every caller copies its own frame's results out.  Two batches are in flight (one collecting while
  * one runs).  Callable from any number of threads at once; a lone caller pays the window (default 20 us when window_us < 0).
- * batch_size (may be NULL): how many frames the call's batch held. */
+ * batch_size (may be NULL): how many frames the call's batch held.  Destroy a pool only when no call on it is in flight (this holds for
+ * dvm_pose_pool and dvm_match_pool too). */
 typedef struct dvm_orb_pool dvm_orb_pool;
 int dvm_orb_pool_create(const dvm_orb_params* p, int device, int max_batch, int window_us, dvm_orb_pool** out);
 void dvm_orb_pool_destroy(dvm_orb_pool* pool);
