@@ -1,4 +1,4 @@
-// dvm_slam_amd/csrc/group_commit.h -- "group commit" for blocking per-agent calls (dvm_orb_pool_*, dvm_pose_pool_*).
+// dvm_slam_amd/csrc/group_commit.h -- "group commit" for blocking per-agent calls (dvm_orb_pool_*, dvm_match_pool_*, dvm_pose_pool_*).
 //
 // K agents that share a GPU make the reference's per-frame calls from K tracking threads.  Issued one by one those are K chains of small
 // launches that serialise in the runtime; the same work as ONE batched launch costs little more than a single call.  The protocol that
@@ -36,6 +36,7 @@ struct GroupCommit {
   Lane lane[2];
   int cur = 0;          // the lane new calls join
   int max_batch = 1, window_us = 20;
+  int solo_streak = 0;  // consecutive batches of one call
 
   // open(li): called under the lock when a free lane is opened for `key` (allocate / size the lane's buffers); non-zero = error, returned
   template <class Open>
@@ -65,13 +66,16 @@ struct GroupCommit {
       while (L.state != Lane::DONE) cv.wait(lk);
       return false;
     }
-    const auto window = std::chrono::microseconds(window_us);
+    // a caller that has been alone for a while does not wait for company (it would pay the window on every call); the first shared
+    // batch brings the window back
+    const auto window = std::chrono::microseconds(solo_streak >= 8 ? 0 : window_us);
     while (L.count < max_batch) {
       const auto deadline = L.last_join + window;
       if (clock::now() >= deadline) break;
       cv.wait_until(lk, deadline);
     }
     L.state = Lane::RUN;                             // closed: nobody joins any more
+    solo_streak = L.count == 1 ? solo_streak + 1 : 0;
     if (lane[li ^ 1].state == Lane::FREE || lane[li ^ 1].state == Lane::COLLECT) cur = li ^ 1;
     cv.notify_all();                                 // waiting callers may open the other lane
     while (L.copied < L.count) cv.wait(lk);          // every joined caller has written its inputs

@@ -618,6 +618,17 @@ int OrbPipeline::extract_staged(int batch, int rows, int cols, int lap0, int lap
   return extract_device(d_stage, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
 }
 
+// The frames in the pinned buffer of staging(), read IN PLACE when they are few (the latency path's zero-copy ingest: no H2D copy queued);
+// otherwise extract_staged().  For callers that synchronise before they touch the buffer again (the shared extractor of orb_pool.cpp).
+int OrbPipeline::extract_staged_sync_owner(int batch, int rows, int cols, int lap0, int lap1) {
+  if (!(latency_path && zero_copy_in && batch <= kLatencyBatch)) return extract_staged(batch, rows, cols, lap0, lap1);
+  if (batch < 1 || rows <= 0 || cols <= 0) return DVM_ERR_INVALID;
+  if (!h_stage || (size_t)batch * rows * cols > stage_bytes) { set_error("extract_staged: call dvm_orb_staging for this size first"); return DVM_ERR_STATE; }
+  DVM_HIP(hipSetDevice(device));
+  if (!stage_view) DVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&stage_view), h_stage, 0));
+  return extract_device(stage_view, batch, rows, cols, cols, (int64_t)rows * cols, lap0, lap1);
+}
+
 int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int cols, int stride, int64_t frame_stride,
                                 int lap0, int lap1) {
   if (!d_imgs || rows <= 0 || cols <= 0) return DVM_ERR_EMPTY;

@@ -62,6 +62,7 @@ class OrbPipeline {
   bool copy_pending = false, stage_free_valid = false;
   int staging(int batch, int rows, int cols, uint8_t** host_ptr);
   int extract_staged(int batch, int rows, int cols, int lap0, int lap1);
+  int extract_staged_sync_owner(int batch, int rows, int cols, int lap0, int lap1);   // few frames: read in place (no H2D copy)
   int sync();
   int download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono);
 

@@ -6,6 +6,7 @@
 // threads issue K chains of small launches that the runtime serialises: eight threads reach 6.5 k frames/s together through the
 // per-frame calls, where ONE launch group of eight frames extracts at 58 k frames/s.  The pools turn the former into the latter without
 // changing what a caller sees: the same blocking call, the same bytes back, but calls that arrive within a short window run as ONE batch.
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -80,7 +81,7 @@ extern "C" void dvm_orb_pool_destroy(dvm_orb_pool* pool) {
 static int orb_run_batch(dvm_orb_pool* pool, OrbLane& L, int count, int rows, int cols, int lap0, int lap1) {
   OrbPipeline& P = *L.p;
   int rc = hip_check(hipSetDevice(pool->device), "hipSetDevice");
-  if (rc == DVM_OK) rc = P.extract_staged(count, rows, cols, lap0, lap1);
+  if (rc == DVM_OK) rc = P.extract_staged_sync_owner(count, rows, cols, lap0, lap1);   // (a batch of up to four frames takes the one-frame path)
   if (rc != DVM_OK) return rc;
   const size_t cap = (size_t)P.PD.kp_cap, need = (size_t)pool->gc.max_batch * cap;
   if (need > L.res_cap || (int)cap != L.kp_cap) {
@@ -92,6 +93,17 @@ static int orb_run_batch(dvm_orb_pool* pool, OrbLane& L, int count, int rows, in
     L.res_cap = need; L.kp_cap = (int)cap;
   }
   const size_t B = (size_t)count;
+  if (P.last_mirrored) {   // the kernels stored the results into mapped host memory as they produced them: no copy commands
+    rc = P.sync();
+    if (rc != DVM_OK) return rc;
+    std::memcpy(L.h_n, P.h_n, B * 4); std::memcpy(L.h_mono, P.h_mono, B * 4);
+    for (size_t b = 0; b < B; b++) {
+      const size_t nb = (size_t)std::max(P.h_n[b], 0);
+      std::memcpy(L.h_kps + b * cap, P.h_kps_m + b * cap, nb * sizeof(dvm_keypoint));
+      std::memcpy(L.h_desc + b * cap * 32, P.h_desc_m + b * cap * 32, nb * 32);
+    }
+    return DVM_OK;
+  }
   DVM_HIP(hipMemcpyAsync(L.h_n, P.d_n, B * 4, hipMemcpyDeviceToHost, P.stream));
   DVM_HIP(hipMemcpyAsync(L.h_mono, P.d_mono, B * 4, hipMemcpyDeviceToHost, P.stream));
   DVM_HIP(hipMemcpyAsync(L.h_kps, P.d_kps, B * cap * sizeof(dvm_keypoint), hipMemcpyDeviceToHost, P.stream));
