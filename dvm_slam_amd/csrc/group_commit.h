@@ -37,16 +37,18 @@ struct GroupCommit {
   int cur = 0;          // the lane new calls join
   int max_batch = 1, window_us = 20;
   int solo_streak = 0;  // consecutive batches of one call
+  int inside = 0;       // calls between join() and finish()
 
   // open(li): called under the lock when a free lane is opened for `key` (allocate / size the lane's buffers); non-zero = error, returned
   template <class Open>
   int join(const int64_t key[4], Open&& open, int& li, int& slot) {
     std::unique_lock<std::mutex> lk(m);
+    inside++;
     for (;;) {
       Lane& C = lane[cur];
       if (C.state == Lane::FREE) {
         const int rc = open(cur);
-        if (rc != 0) return rc;
+        if (rc != 0) { inside--; return rc; }
         C.state = Lane::COLLECT; C.count = 0; C.copied = 0; C.readers = 0; C.rc = 0; C.err.clear();
         std::memcpy(C.key, key, sizeof(C.key));
       }
@@ -66,9 +68,11 @@ struct GroupCommit {
       while (L.state != Lane::DONE) cv.wait(lk);
       return false;
     }
-    // a caller that has been alone for a while does not wait for company (it would pay the window on every call); the first shared
-    // batch brings the window back
-    const auto window = std::chrono::microseconds(solo_streak >= 8 ? 0 : window_us);
+    // a caller that has been alone for a while does not wait for company (it would pay the window on every call) -- unless another
+    // call is inside the service right now, and every eighth solitary batch waits anyway, so that company is noticed when it comes;
+    // the first shared batch brings the window back
+    const bool alone = solo_streak >= 8 && inside <= 1 && (solo_streak & 7) != 0;
+    const auto window = std::chrono::microseconds(alone ? 0 : window_us);
     while (L.count < max_batch) {
       const auto deadline = L.last_join + window;
       if (clock::now() >= deadline) break;
@@ -100,6 +104,7 @@ struct GroupCommit {
   void finish(int li) {
     std::lock_guard<std::mutex> lk(m);
     Lane& L = lane[li];
+    inside--;
     if (--L.readers == 0) {
       L.state = Lane::FREE;
       if (lane[cur].state != Lane::COLLECT) cur = li;   // nothing is collecting: the freed lane is the next to open
