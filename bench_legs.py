@@ -177,7 +177,7 @@ def low_texture(capi, device, cpu=True, steps=3):
     return out
 
 
-def online_agents(capi, frames, device, Ks=(1, 4, 8, 16, 32), frames_per_agent=150):
+def online_agents(capi, frames, device, Ks=(1, 4, 8, 16, 32, 64), frames_per_agent=150):
     """K agents tracking on ONE GPU through the drop-in boundary, a host thread and an extractor handle each (the online shape of BASELINE
     config 4 with more agents than GPUs): per frame ORBextractor::operator() -> SearchByProjection(Cur, Last) -> PoseOptimization, host
     arrays in and out, every call synchronous as Tracking makes them.  Whole-job frames/s over the K threads; results of every thread are
@@ -283,7 +283,7 @@ def _online_agents_cpp(frames, cyc, scale, pairs, cases, device, Ks, frames_per_
             f.write(np.ascontiguousarray(c[2], np.float64).tobytes()); f.write(np.ascontiguousarray(c[3], np.float64).tobytes())
             f.write(np.ascontiguousarray(c[4][:4], np.float64).tobytes())
     try:
-        r = subprocess.run([exe, "--pool=32", path, str(device), str(frames_per_agent)] + [str(k) for k in Ks], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, "--pool=8", path, str(device), str(frames_per_agent)] + [str(k) for k in Ks], capture_output=True, text=True, timeout=300)
     finally:
         os.unlink(path)
     if r.returncode != 0:

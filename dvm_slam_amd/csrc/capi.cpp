@@ -1005,7 +1005,7 @@ struct MatchLane {
 struct dvm_match_pool {
   int device = 0, kp_cap = 0, q_cap = 0;
   GroupCommit gc;
-  MatchLane lane[2];
+  MatchLane lane[GroupCommit::kLanes];
 };
 
 static void match_lane_free(MatchLane& L) {

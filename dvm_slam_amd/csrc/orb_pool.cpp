@@ -44,7 +44,7 @@ struct dvm_orb_pool {
   dvm_orb_params P;
   int device = 0;
   GroupCommit gc;
-  OrbLane lane[2];
+  OrbLane lane[GroupCommit::kLanes];
 };
 
 extern "C" int dvm_orb_pool_create(const dvm_orb_params* p, int device, int max_batch, int window_us, dvm_orb_pool** out) {
@@ -174,7 +174,7 @@ struct PoseLane {
 struct dvm_pose_pool {
   int device = 0;
   GroupCommit gc;
-  PoseLane lane[2];
+  PoseLane lane[GroupCommit::kLanes];
 };
 
 static void pose_lane_free(PoseLane& L) {

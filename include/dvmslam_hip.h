@@ -88,8 +88,8 @@ int dvm_orb_extract(dvm_orb* h, const uint8_t* img, int rows, int cols, int stri
  * chains of small launches that serialise in the runtime; dvm_orb_pool_extract is the same blocking call -- one image in, that
  * frame's keypoints and descriptors out, the same bytes as dvm_orb_extract -- but frames that arrive within `window_us` of each other
  * (and share size and lapping area) are extracted as ONE batch of up to max_batch frames: the caller that opened the batch waits for
- * the arrivals to pause, runs it, and every caller copies its own frame's results out.  Two batches are in flight (one collecting while
- * one runs).  Callable from any number of threads at once; window_us < 0: 20 us; a caller that has been alone for eight calls stops waiting.
+ * the arrivals to pause, runs it, and every caller copies its own frame's results out.  Four batches are in flight (one collecting while
+ * others run; max_batch 8 measured best: small overlapping batches beat large ones that keep the agents in lockstep).  Callable from any number of threads at once; window_us < 0: 20 us; a caller that has been alone for eight calls stops waiting.
  * batch_size (may be NULL): how many frames the call's batch held.  Destroy a pool only when no call on it is in flight (this holds for
  * dvm_pose_pool and dvm_match_pool too). */
 typedef struct dvm_orb_pool dvm_orb_pool;

@@ -17,9 +17,10 @@ int main(int argc, char** argv) {
   const int W = argc > 4 ? std::atoi(argv[4]) : 50;
   dvm::GroupCommit gc;
   gc.max_batch = B; gc.window_us = W;
-  std::vector<long> in[2], out[2];
-  std::vector<int64_t> lane_key(2, -1);
-  for (int l = 0; l < 2; l++) { in[l].assign(B, 0); out[l].assign(B, 0); }
+  constexpr int NL = dvm::GroupCommit::kLanes;
+  std::vector<long> in[NL], out[NL];
+  std::vector<int64_t> lane_key(NL, -1);
+  for (int l = 0; l < NL; l++) { in[l].assign(B, 0); out[l].assign(B, 0); }
   std::atomic<long> runs{0}, jobs_run{0}, max_count{0}, wrong{0}, mixed{0}, open_fail_seen{0};
   std::atomic<int> fail_next_open{0};
   auto call = [&](int64_t shape, long x, long* y, int* batch) -> int {
