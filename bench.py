@@ -10,11 +10,13 @@ the whole front end on one GPU: ORB extract (8-level pyramid, per-cell FAST, oct
 driver's 20 steps make a timed region of ~2 s.  One agent (= one frame stream) per GPU, no data-path
 collective: `value` = frames processed by all ranks / max-over-ranks wall time ("weak" scaling).
 
-Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+Rank 0 prints, as the LAST stdout line, ONE compact JSON object (a few KB: compact()).  Besides the contract keys it carries
   roofline      -- dominant kernel (FAST cells): algorithmic bytes per launch / HIP-event duration
   cpu_baseline  -- the CPU oracle (port of the reference path) timed single-threaded on this host
-  ba            -- bundle-adjustment iterations/s (second half of BASELINE.json's metric) when built
-  latency / online_agents / lba / lba_batch / merge / ba_cold -- per-call costs of configs 2, 3 and 4 through the drop-in boundary (bench_legs.py)
+  ba            -- bundle-adjustment iterations/s (second half of BASELINE.json's metric): ring map + loop-closed map, summary only
+The complete record (per-stage event spans, VALU issue model, schedules ...) is written to gpurun_out/bench_full.json (--full-json).
+With --legs (N = 1) the per-call costs of configs 2, 3 and 4 through the drop-in boundary (bench_legs.py: batch_sweep, low_texture,
+latency, online_agents, lba, lba_batch, merge, ba_cold) run too; each prints its own `{"leg": ...}` stdout line BEFORE the contract line.
 """
 from __future__ import annotations
 
@@ -50,7 +52,10 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident-input leg (N=1 only)")
     ap.add_argument("--ba-iters", type=int, default=10)
-    ap.add_argument("--no-legs", action="store_true", help="skip the per-call legs (latency, lba, ba_cold, merge; N=1 only)")
+    ap.add_argument("--legs", action="store_true", help="also run the per-call legs (batch sweep, latency, online agents, lba, merge, ba_cold; N=1 only): "
+                                                         "each prints its own stdout line BEFORE the contract line")
+    ap.add_argument("--no-legs", action="store_true", help="(default since round 5; accepted for old command lines)")
+    ap.add_argument("--full-json", default=None, help="where the complete (uncompacted) record goes; default gpurun_out/bench_full.json")
     ap.add_argument("--texture", choices=("rich", "low"), default="rich", help="synthetic stream: the BASELINE corner-rich one, or the weakly textured second workload")
     return ap.parse_args()
 
@@ -165,6 +170,94 @@ def pcie_inclusive_leg(capi, frames, B, steps, device):
     return {"value": steps * B / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "h2d_gbps": steps * B * H * W / dt / 1e9,
             "note": "input in pinned host memory (dvm_orb_staging), 2 handles ping-pong: H2D of one batch under the kernels of the other"}
+
+
+LEG_KEYS = ("batch_sweep", "low_texture", "latency", "online_agents", "lba", "lba_batch", "merge", "ba_cold")
+
+
+def pick(d, *keys):
+    """Sub-dict of the keys that exist (None-safe)."""
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact(out):
+    """The contract line: the keys the driver parses + roofline + cpu_baseline + a BA summary, a few KB.  Everything else
+    of the record (per-kernel event spans, the VALU issue model, the legs) is in the full record (emit())."""
+    c = pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data")
+    cfg = dict(out["config"])
+    cfg["ranks"] = pick(cfg.get("ranks", {}), "count", "backend", "cuda_device_of_rank", "launched_by")
+    c["config"] = cfg
+    r = out.get("roofline")
+    if r:
+        cr = pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "frames_per_launch",
+                  "pipeline_achieved", "pipeline_frac", "all_stage_bytes_per_frame", "pipeline_traffic_over_algorithmic")
+        cr["traffic_source"] = pick(r.get("traffic_source") or {}, "file", "stale")
+        if r.get("exclusive"):
+            cr["exclusive"] = pick(r["exclusive"], "avg_launch_ms", "achieved", "frac")
+        try:
+            cr["valu_busy"] = r["valu_issue"]["counter_valu_busy"]["k_fast_cells"]
+        except Exception:   # noqa: BLE001
+            cr["valu_busy"] = None
+        c["roofline"] = cr
+    else:
+        c["roofline"] = None
+    cb = out.get("cpu_baseline")
+    if cb:
+        ccb = pick(cb, "value", "unit", "cores", "kind", "sample")
+        if isinstance(cb.get("one_agent_per_core"), dict):
+            ccb["one_agent_per_core"] = pick(cb["one_agent_per_core"], "value", "cores", "error")
+        c["cpu_baseline"] = ccb
+    ba = out.get("ba")
+    if isinstance(ba, dict):
+        cba = pick(ba, "metric", "value", "unit", "ms_per_iteration", "dtype", "iterations", "trials")
+        if isinstance(ba.get("roofline"), dict):
+            cba["roofline"] = pick(ba["roofline"], "bound", "achieved", "peak", "unit", "frac", "solve_ms_per_trial", "executed_flop_per_trial", "traffic")
+        try:
+            cba["hbm_schur"] = pick(ba["hbm"]["schur"], "achieved", "frac", "traffic", "traffic_over_algorithmic")
+        except Exception:   # noqa: BLE001
+            pass
+        if isinstance(ba.get("cpu_baseline"), dict):
+            cba["cpu_baseline"] = pick(ba["cpu_baseline"], "value", "unit", "cores", "kind")
+        if isinstance(ba.get("parity_vs_cpu"), dict):
+            cba["parity_vs_cpu"] = ba["parity_vs_cpu"]
+        lc = ba.get("loop_closed")
+        if isinstance(lc, dict):
+            clc = pick(lc, "value", "unit", "ms_per_iteration", "solver", "tile_fill_of_factor", "executed_flop_per_trial", "error")
+            if isinstance(lc.get("roofline"), dict):
+                clc["roofline"] = pick(lc["roofline"], "bound", "kernel", "achieved", "peak", "unit", "frac")
+            if isinstance(lc.get("cpu_baseline"), dict):
+                clc["cpu_baseline"] = pick(lc["cpu_baseline"], "value", "cores")
+            if isinstance(lc.get("parity_vs_cpu"), dict):
+                clc["parity_vs_cpu"] = lc["parity_vs_cpu"]
+            cba["loop_closed"] = clc
+        c["ba"] = cba
+    if isinstance(out.get("ba_sharded"), dict):
+        sh = out["ba_sharded"]
+        c["ba_sharded"] = pick(sh, "value", "unit", "ranks", "ms_per_iteration", "error")
+        if isinstance(sh.get("replicas"), dict):
+            c["ba_sharded"]["replicas"] = pick(sh["replicas"], "value", "ranks")
+    if isinstance(out.get("pcie_inclusive"), dict):
+        c["pcie_inclusive"] = pick(out["pcie_inclusive"], "value", "unit", "h2d_gbps")
+    c["sanity_matches_le_TH_HIGH_last_step"] = out.get("sanity_matches_le_TH_HIGH_last_step")
+    return c
+
+
+def emit(out, a):
+    """stdout: one line per leg (when --legs ran them), then -- LAST -- the compact contract line.  The complete record goes to a
+    file (gpurun_out/bench_full.json travels back from the GPU box) so that nothing the old one-line form carried is lost."""
+    path = a.full_json or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f)
+    except OSError as ex:
+        print(f"bench.py: full record not written ({ex})", file=sys.stderr)
+    for k in LEG_KEYS:
+        if k in out:
+            print(json.dumps({"leg": k, "record": out[k]}), flush=True)
+    line = json.dumps(compact(out))
+    print(line, flush=True)
 
 
 def relaunch_distributed(a):
@@ -486,7 +579,7 @@ def main():
             try:
                 import ba_bench
                 out["ba"] = ba_bench.run(local, a.ba_iters, cpu_seconds=6.0 if a.cpu_seconds > 0 else 0.0)
-                if world == 1 and not a.no_legs:
+                if world == 1:
                     try:       # second workload of the BA metric: the same size with loop-closure bands and long-range observations
                         out["ba"]["loop_closed"] = ba_bench.run_loop_closed(local, a.ba_iters, cpu_iters=2 if a.cpu_seconds > 0 else 0)
                     except Exception as ex:   # noqa: BLE001
@@ -495,7 +588,7 @@ def main():
                 out["ba"] = None
         if sharded_rec is not None:
             out["ba_sharded"] = sharded_rec
-        if world == 1 and not a.no_legs:
+        if world == 1 and a.legs and not a.no_legs:
             # what BASELINE configs 2 and 3 cost per call through the drop-in boundary (bench_legs.py), CPU oracle beside each
             import bench_legs
             cpu = a.cpu_seconds > 0
@@ -514,7 +607,7 @@ def main():
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)
         flush_c_stdio()
-        print(json.dumps(out), flush=True)
+        emit(out, a)
     if hard_exit:          # a wedged collective: the line is out, do not wait for the process group
         sys.stdout.flush()
         os._exit(0)

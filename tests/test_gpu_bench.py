@@ -11,17 +11,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
+def _contract_line(stdout):
+    """The driver's view: the LAST stdout line is the contract object, compact enough to survive an 8 KB tail."""
+    lines = stdout.rstrip("\n").splitlines()
+    assert lines and lines[-1].startswith("{"), stdout[-2000:]
+    assert len(lines[-1]) < 6000, len(lines[-1])
+    d = json.loads(lines[-1])
+    assert "leg" not in d
+    return d, [json.loads(l) for l in lines[:-1] if l.startswith("{")]
+
+
+def _run(*extra, tmp):
+    full = os.path.join(str(tmp), "full.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "64", "--stream-frames", "128",
-                          "--chunks-per-step", "3", "--no-ba", *extra], capture_output=True, text=True, timeout=600)
+                          "--chunks-per-step", "3", "--full-json", full, *extra], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    d, before = _contract_line(out.stdout)
+    assert before == [], out.stdout[-2000:]          # no --legs: the contract line is the only JSON on stdout
+    return d, json.load(open(full))
 
 
-def test_bench_contract_and_lane_equivalence():
-    d2 = _run("--cpu-seconds", "2")
+def test_bench_contract_and_lane_equivalence(tmp_path):
+    d2, full = _run("--cpu-seconds", "2", "--ba-iters", "3", tmp=tmp_path)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d2, k
@@ -33,25 +44,34 @@ def test_bench_contract_and_lane_equivalence():
     assert r["exclusive"]["avg_launch_ms"] > 0
     c = d2["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["one_agent_per_core"]["value"] > 0
     assert d2["pcie_inclusive"]["value"] > 0
-    d1 = _run("--cpu-seconds", "0", "--lanes", "1", "--no-pcie")
+    # the BA half of the metric rides on the same line as a summary: ring map and loop-closed map, roofline of the reduced solve
+    ba = d2["ba"]
+    assert ba["value"] > 0 and ba["dtype"] == "f64" and 0 < ba["roofline"]["frac"] < 1 and ba["cpu_baseline"]["value"] > 0
+    assert ba["parity_vs_cpu"]["trials_equal"] and ba["parity_vs_cpu"]["max_abs_pose"] < 1e-6
+    assert ba["loop_closed"]["value"] > 0, ba["loop_closed"]
+    # the complete record keeps what the line drops
+    assert full["value"] == d2["value"] and "gpu_kernel_event_ms_per_launch" in full["roofline"] and "schedule" in full["ba"]["roofline"]
+    d1, _ = _run("--cpu-seconds", "0", "--lanes", "1", "--no-pcie", "--no-ba", tmp=tmp_path)
     assert d1["config"]["pipeline_lanes"] == 1
     assert d1["sanity_matches_le_TH_HIGH_last_step"] == d2["sanity_matches_le_TH_HIGH_last_step"] > 1000
 
 
-def test_bench_two_ranks_control_flow():
+def test_bench_two_ranks_control_flow(tmp_path):
     """The N > 1 path of bench.py (rendezvous, barriers, max-over-ranks timing, rank-0-only reporting) with two ranks that
     share the one GPU of the test box over gloo (DVM_BENCH_SHARE_GPU / DVM_BENCH_BACKEND are test hooks; the driver launches
     the same file with one rank per GPU over RCCL)."""
     env = dict(os.environ, DVM_BENCH_SHARE_GPU="1", DVM_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--stream-frames", "64",
-           "--chunks-per-step", "2", "--ba-iters", "3", "--cpu-seconds", "0"]
+           "--chunks-per-step", "2", "--ba-iters", "3", "--cpu-seconds", "0", "--full-json", str(tmp_path / "full.json")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 only
-    d = json.loads(lines[0])
+    d, before = _contract_line(out.stdout)
+    assert before == [], out.stdout[-2000:]              # rank 0 only, one line
+    assert d["ba_sharded"]["ranks"] == 2 and d["ba_sharded"]["value"] > 0 and d["ba_sharded"]["replicas"]["ranks"] == 2
+    d = json.load(open(tmp_path / "full.json"))
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "agents2"
     assert abs(d["value"] - 2 * 3 * 2 * 32 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]   # whole-job frames over the max-over-ranks time
     assert "pcie_inclusive" not in d                     # N = 1 only
@@ -77,9 +97,8 @@ def test_bench_plain_command_honours_gpus():
            "--chunks-per-step", "2", "--no-ba", "--cpu-seconds", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d, before = _contract_line(out.stdout)
+    assert before == [], out.stdout[-2000:]
     assert d["n_gpus"] == 2 and d["config"]["ranks"]["count"] == 2 and len(d["config"]["ranks"]["cuda_device_of_rank"]) == 2
     assert d["config"]["ranks"]["launched_by"].startswith("bench.py itself")
     # a launcher whose rank count disagrees with --gpus is refused, not mislabelled
