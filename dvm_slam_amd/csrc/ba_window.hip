@@ -753,6 +753,15 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
     if (nBad >= 3) { stop_reason = 2; break; }
   }
   __syncthreads();
+  // No iteration ran (iterations == 0, or the stop word was already up at the first poll): no edge pass has written e_chi2 / e_rho, and the
+  // caller downloads them (Optimizer_shim's LocalBundleAdjustment erases observations on chi2 > 5.991).  Evaluate the edges at the
+  // unchanged input state, so that what leaves is the chi2 OF the state that leaves -- never the previous tenant of the buffer.
+  if (it_done == 0) {
+    win_edge_pass<false>(W, poses, pts);
+    __syncthreads();
+    if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) { st->chi2_initial = c; chi_last = c; } }
+    __syncthreads();
+  }
   // results: the accepted state (the buffers may have been swapped any number of times), depth signs at that state
   for (int i = tid; i < 7 * W.P; i += kWinThreads) W.out_poses[i] = poses[i];
   for (int i = tid; i < 3 * W.L; i += kWinThreads) W.out_pts[i] = pts[i];

@@ -150,6 +150,27 @@ def test_limits_and_stop_flag(oracle):
     g = capi.ba_optimize_windows([small], stop_flag=stop)[0]
     assert g["stats"]["iterations"] == 0 and np.array_equal(_bits(g["points"]), _bits(small["points"]))
     assert capi.ba_optimize_windows([]) == []
+    # no iteration ran: the per-edge chi2 that leaves is the chi2 OF the (unchanged) state that leaves, not whatever the reused
+    # device buffer held (the shim erases observations on chi2 > 5.991) -- with the stop word up, and with iterations = 0
+    big = _window(synth.small_window_problem(4, 300, seed=2), DELTA, 10)
+    capi.ba_optimize_windows([big])                      # leaves its own chi2 values in the thread's staging buffers
+    for case in (dict(stop_flag=stop), dict()):
+        w = small if case else dict(small, iterations=0)
+        g = capi.ba_optimize_windows([w], **case)[0]
+        chi, depth = oracle.ba_edge_chi2(g["poses"], g["points"], small["edges"], small["intrinsics"])
+        assert g["stats"]["iterations"] == 0 and g["stats"]["total_trials"] == 0
+        assert np.array_equal(_bits(g["edge_chi2"]), _bits(chi)) and np.array_equal(g["depth_positive"], depth), case
+        assert chi.max() > 0 and g["stats"]["chi2_initial"] > 0 and g["stats"]["chi2_final"] == g["stats"]["chi2_initial"]
+    # the handle API (what Optimizer_shim calls) with the stop flag already raised
+    pr = synth.small_window_problem(3, 80, seed=1)
+    ba = capi.BundleAdjuster()
+    ba.set_problem(pr["poses"], pr["fixed"], pr["points"], small["edges"], pr["intrinsics"], DELTA)
+    st = ba.optimize(10, stop_flag=stop)
+    P, X = ba.result()
+    chi_g, _ = ba.edge_chi2()
+    chi, _ = oracle.ba_edge_chi2(P, X, small["edges"], pr["intrinsics"])
+    ba.close()
+    assert st["iterations"] == 0 and np.array_equal(_bits(chi_g), _bits(chi))
 
 
 # ---------------------------------------------------------------------------------------------- the handle API on small problems
