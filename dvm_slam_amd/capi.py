@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdvmslam_hip.so")
+LIB_PATH = os.environ.get("DVM_HIP_LIB") or os.path.join(_HERE, "lib", "libdvmslam_hip.so")   # (DVM_HIP_LIB: a measurement build, tools/build_flow_stamps.sh)
 
 DVM_OK = 0
 ERRORS = {-1: "DVM_ERR_INVALID", -2: "DVM_ERR_EMPTY", -3: "DVM_ERR_CAPACITY", -4: "DVM_ERR_HIP",

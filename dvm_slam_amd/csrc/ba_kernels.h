@@ -79,6 +79,15 @@ struct BaView {
   int32_t n_nz;
   const int32_t* colstrip_off;  // [ntiles+1] device
   const int32_t* colstrips;     // per column: its strip rows
+  // FLOW form of the solve (k_chol_flow, ba_ordering.h): tile tasks taken through a ticket, factorisation + back substitution in ONE launch
+  const int32_t* flow_tasks;    // [n_flow_tasks][8]
+  const int32_t* flow_contrib;  // [..][4] flattened contributor lists (ba_ordering.h)
+  const int32_t* colstrip_id;   // per colstrips entry: index of that strip
+  int32_t* flow_flags;          // [2 x strips] a 32-row half of X published | [tiles] L^-1 of a column | [tiles] T' of a diagonal tile (PRE) | xrow tagged |
+                                // ticket; compared with the solve's sequence number, zeroed once after allocation
+  int32_t n_flow_tasks, n_strips_total, n_tiles_total;
+  int32_t flow;                 // 1: ba_launch_cholesky_solve uses k_chol_flow (set by dvm_ba_set_problem; 0 after one of its waits timed out)
+  int32_t flow_wgs;             // persistent workgroups to launch (compute units of the device)
   const int32_t *h_level_off, *h_strip_off, *h_tgt_off;  // HOST arrays [nlevels+1]
   int32_t nlevels;
   int32_t pair_a, pair_b;   // tile columns of the top pair (ba_ordering.h: BaTileSchedule::pair_a / pair_b) and pair_ok = 1, or pair_ok = 0

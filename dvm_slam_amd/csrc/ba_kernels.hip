@@ -1683,10 +1683,12 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
 #pragma unroll
     for (int r = 0; r < 16; r++) tl[r] = S[(size_t)(i0 + 16 * q + r) * ldS + k0 + c];
   };
-  if (s_beg < s_end) fetch_tile(s_beg);
-  for (int s = s_beg; s < s_end; s++) {
+  // (round 5: the ancestors nearest the ROOT first -- their x is the first to arrive; in ascending order the column's parent, whose x
+  //  arrives last, blocked every other product behind it: ~16 us a hop on a column with 40 strips.  A changed summation order.)
+  if (s_beg < s_end) fetch_tile(s_end - 1);
+  for (int s = s_end - 1; s >= s_beg; s--) {
     const int it = colstrips[s], i0 = it * NB;
-    if (i0 >= n_pad) { if (s + 1 < s_end) fetch_tile(s + 1); continue; }   // the rhs row is not an unknown
+    if (i0 >= n_pad) { if (s > s_beg) fetch_tile(s - 1); continue; }   // the rhs row is not an unknown
     if (tid < NB) {   // every lane waits for its own word of x_i: the data is its own flag
       double v = __hip_atomic_load(xrow + i0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int spins = 0; (unsigned long long)__double_as_longlong(v) == kXTag; spins++) {
@@ -1700,7 +1702,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
     double u = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) u += tl[r] * xi[16 * q + r];
-    if (s + 1 < s_end) fetch_tile(s + 1);
+    if (s > s_beg) fetch_tile(s - 1);
     part[q][c] = u;
     __syncthreads();
     if (tid < NB) yk[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
@@ -1719,6 +1721,440 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
     // g2o's linear solver leaves _x untouched when the factorisation fails (linear_solver_eigen.h:89-112): x keeps the last
     // successful solve's values, which the LM loop then applies all the same (optimization_algorithm_levenberg.cpp:111-127)
     if (tid < per_tile * dof && cam < nfree && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) x[dof * (size_t)cam + tid % dof] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------- flow
+// The WHOLE reduced solve -- tile factorisation and back substitution -- as ONE persistent launch (round 5).  The level launches above pay a
+// kernel boundary (or two) per elimination-tree level and run a level's trailing update to completion before the next diagonal tile
+// starts; on a reduced system whose tree is a long chain (a loop-closed map: 37 levels at 500 keyframes) that is 43 us a level.  Here
+// every structurally non-zero tile of a camera column is a TASK (BaTileSchedule::flow_tasks), taken by the workgroups through a ticket:
+//   diagonal tile (k, k): gathers its updates LEFT-LOOKING -- tgt = S(k,k), then per level that updates it acc = sum over that level's
+//     columns m of X(k,m) X(k,m)^T and tgt -= acc, the order and association of the level launches: same bits --, factorises
+//     (chol_diag_tile) and publishes L_k^-1;
+//   strip tile (i, k): gathers its updates the same way, waits for L_k^-1 and publishes X(i,k) = T L_k^-T in place;
+//   then one task per camera column of the back substitution (k_chol_backsolve's body, root first).
+// A task waits only for tasks BEFORE it in the list (a tile's contributors are columns of lower levels, its own diagonal tile is listed
+// first, the back substitution comes last), so the workgroups that hold tickets always make progress: no residency assumption, no
+// deadlock whatever else runs on the chip.  Hand-off: the payload is stored write-through (sc1: 16-byte buffer stores, or 8-byte
+// agent-scope stores straight from the MFMA accumulators), drained by every storing wave, then ONE lane raises the tile's flag to the
+// solve's sequence number; the consumer polls that word relaxed and reads the payload with sc1 loads (MI355X_MICROARCH.md, valid forms).
+// What this buys: no kernel boundaries, and the trailing update of a column overlaps the factorisation of the next diagonal tile --
+// the chain per level is [last contribution -> factorise -> L^-1 -> first strip], not [everything of the level].
+#ifdef DVM_FLOW_DEBUG
+// per task: [0] start, [1] gather done, [2] L^-1 there (strip) / tile in LDS (diagonal), [3] computed, [4] published, [5] wall-clock ticks
+// thread 0 spent in flow_wait, [6] workgroup, [7] XCC id.  wall_clock64: 100 MHz.
+__device__ long long g_flow_dbg[4096 * 8];
+#define DVM_FSTMP(t, i) do { if (threadIdx.x == 0 && (t) < 4096) g_flow_dbg[(t) * 8 + (i)] = (long long)wall_clock64(); } while (0)
+extern "C" int dvm_debug_flow_stamps(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flow_dbg), sizeof(long long) * (size_t)n); }
+#else
+#define DVM_FSTMP(t, i) do { } while (0)
+#endif
+struct FlowArgs {
+  double* S; int ldS, n1, n_pad;
+  double* Linv_all;
+  const int32_t *tasks, *fc;
+  int n_factor, n_back;
+  int32_t* flags; int nstrips, ntiles;
+  int gen; int* fail;
+  const int32_t* cols; double* xrow; double* x;
+  const int32_t *colstrip_off, *colstrips, *colstrip_id;
+  int nfree, per_tile, dof;
+};
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+// bounded wait of ONE lane for a word to reach the solve's sequence number; a timeout marks the trial (fail = 2: the host repeats it with
+// the level launches) and lets everybody run out: once the mark is up nobody waits any more
+__device__ __forceinline__ void flow_wait_raw(const int32_t* flag, int gen, int* __restrict__ fail) {
+  for (int spins = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen; spins++) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 255) == 255 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) return;
+    if (spins > (1 << 19)) { __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  }
+}
+#ifdef DVM_FLOW_DEBUG
+__device__ __forceinline__ void flow_wait_dbg(const int32_t* flag, int gen, int* __restrict__ fail, long long* wacc) {
+  const long long w0 = (long long)wall_clock64();
+  flow_wait_raw(flag, gen, fail);
+  *wacc += (long long)wall_clock64() - w0;
+}
+#define flow_wait(f, g, x) flow_wait_dbg(f, g, x, &s_wacc)
+#else
+#define flow_wait(f, g, x) flow_wait_raw(f, g, x)
+#endif
+__device__ __forceinline__ double2 u4_to_d2(v4u32 v) {
+  return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
+__device__ __forceinline__ v4u32 d2_to_u4(double a, double b) {
+  return v4u32{(unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
+}
+// One contributor's products for the NS blocks a wave owns: acc[s] += A_s B_s^T over the 64 columns of the strips in LDS.  Branch-free and
+// unrolled by 16 columns with the operands of a chunk read before its MFMAs, so that the LDS latency of chunk n + 1 sits under the matrix
+// pipe of chunk n (with a test per slot inside the loop the compiler read, waited and multiplied one block at a time: ~2.5x the pipe time).
+template <int NS, bool SHARE_B>
+__device__ __forceinline__ void flow_mma(const double* __restrict__ Ai, const double* __restrict__ Bp, const int (&arow)[3], const int (&brow)[3], int lr, int lk,
+                                         double4_t (&acc)[3]) {
+  const double* pa[NS];
+  const double* pb[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) { pa[s] = Ai + (arow[s] + lr) * QP + lk; pb[s] = Bp + (brow[s] + lr) * QP + lk; }
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 16) {
+    double a[NS][4], b[NS][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        a[s][j] = pa[s][kk + 4 * j];
+        if (!SHARE_B || s == 0) b[s][j] = pb[s][kk + 4 * j];
+      }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][j], b[SHARE_B ? 0 : s][j], acc[s], 0, 0, 0);
+  }
+}
+__global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
+  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
+  __shared__ int s_ticket, s_ready[2];
+#ifdef DVM_FLOW_DEBUG
+  __shared__ long long s_wacc;
+#endif
+  static_assert(2 * NB * QP <= 16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP, "the gather buffers live inside the factorisation's LDS block");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ldS = A.ldS;
+  const int F_L = 2 * A.nstrips, F_P = F_L + A.ntiles;
+  int32_t* const tagged = A.flags + F_P + A.ntiles;
+  int32_t* const ticket = tagged + 1;
+  const int ntotal = A.n_factor + A.n_back;
+  // buffer descriptors (wave-uniform inputs only): S and the L^-1 tiles, for the 16-byte sc1 loads / stores
+  const auto rS = __builtin_amdgcn_make_buffer_rsrc(A.S, 0, (int)min((size_t)ldS * ldS * sizeof(double), (size_t)0x7FFFFFF0), 0x00020000);
+  const auto rL = __builtin_amdgcn_make_buffer_rsrc(A.Linv_all, 0, (int)((size_t)A.ntiles * NB * NB * sizeof(double)), 0x00020000);
+  double* const Ai = smem;
+  double* const Aj = smem + NB * QP;
+  const int crow = tid >> 5, ccol = 2 * (tid & 31);      // 16-byte chunk of a 64-double row: instruction i covers rows 8 i + crow
+  for (;;) {
+    __syncthreads();                       // the previous task is through with the LDS block and s_ticket
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == ntotal + (int)gridDim.x - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last draw of the launch: every workgroup draws one ticket beyond the list
+      s_ticket = t;
+    }
+    __syncthreads();
+    const int t = s_ticket;
+    if (t >= ntotal) return;
+#ifdef DVM_FLOW_DEBUG
+    if (tid == 0) s_wacc = 0;
+    if (tid == 0 && t < 4096) g_flow_dbg[t * 8 + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;   // (XCC_ID register: best effort)
+#endif
+    DVM_FSTMP(t, 0);
+    if (t == 0) {
+      // the back substitution's hand-off slots: tags (write-through), published before anybody may poll them
+      for (int i = tid; i < A.n_pad; i += 256) __hip_atomic_store(reinterpret_cast<unsigned long long*>(A.xrow) + i, kXTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(tagged, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < A.n_factor) {
+      // ------------------------------------------------------------------------------------------ a tile (or half tile) of the factor
+      const int32_t* T = A.tasks + 8 * (size_t)t;
+      const int kind = T[0], ti = T[1], tj = T[2], half = T[3], c0 = T[4], c1 = T[5], self = T[6], pre = T[7];
+      const bool slice = kind == 1;
+      const int i0 = ti * NB + (slice ? 32 * half : 0), j0 = tj * NB;
+      const int rw = min(slice ? 32 : NB, A.n1 - i0);      // rows of the region that exist (the rhs row: one)
+#ifdef DVM_FLOW_DEBUG
+      if (tid == 0 && t < 4096) g_flow_dbg[t * 8 + 6] = (long long)blockIdx.x | ((long long)kind << 12) | ((long long)ti << 16) | ((long long)tj << 32) | ((long long)(c1 - c0) << 48);
+#endif
+      // the 16x16 blocks this wave owns (slot s): a slice -- column block `wave` of its two block rows; a diagonal tile -- its ten lower
+      // blocks dealt 3 3 2 2.  arow / brow: first row of the block's A / B operand in the LDS buffers (= the block's position in the region)
+      int arow[3], brow[3];
+      bool son[3];
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        if (slice) { arow[s] = 16 * s; brow[s] = 16 * wave; son[s] = s < 2 && 16 * s < rw; }
+        else {
+          const int b = wave < 2 ? 3 * wave + s : 6 + 2 * (wave - 2) + s;          // index into the row-major list of lower blocks
+          son[s] = wave < 2 || s < 2;
+          const int bi = b < 1 ? 0 : b < 3 ? 1 : b < 6 ? 2 : 3;
+          arow[s] = 16 * bi; brow[s] = 16 * (b - bi * (bi + 1) / 2);
+        }
+      }
+      double4_t tgt[3], acc[3];
+      if (kind == 0 && pre) {                // the sum of the earlier levels, left in place by the tile's PRE task
+        if (tid == 0) flow_wait(A.flags + F_P + tj, A.gen, A.fail);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        acc[s] = double4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = arow[s] + lk + 4 * r, col = brow[s] + lr;
+          const double* p = A.S + (size_t)(i0 + min(row, rw - 1)) * ldS + j0 + col;
+          const double v = (kind == 0 && pre) ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+          tgt[s][r] = (son[s] && row < rw) ? v : 0.0;
+        }
+      }
+      // ---- gather: three contributors in flight (global -> registers), one in LDS under the matrix pipe.  A contributor's three flags
+      // (its A half, both halves of B) are looked at by three lanes at once, and the look for contributor c + 3 is issued before step
+      // c's products and read behind them: a poll is a ~1 us trip to the coherence point, which three in a row on one lane in front of
+      // a barrier put on every step (4.4 us a contributor measured, 1.3 us of it matrix pipe).
+      v4u32 g0[12], g1[12], g2[12];
+      bool l0 = false, l1 = false, l2 = false;
+      int rc = 0;
+      auto flag_of = [&](int c, int f) -> const int32_t* {      // f = 0: the A operand's half; 1, 2: the halves of B
+        const int32_t* e = A.fc + 4 * (size_t)c;
+        return f == 0 ? A.flags + 2 * e[1] + (slice ? half : 0) : A.flags + 2 * e[2] + (f - 1);
+      };
+      auto wait_block = [&](int c) {
+        if (tid < 3) flow_wait(flag_of(c, tid), A.gen, A.fail);
+        __syncthreads();
+      };
+      auto fetch = [&](int c, v4u32 (&g)[12]) {
+        const int m0 = A.fc[4 * (size_t)c] * NB;
+        if (slice) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) g[i] = __builtin_amdgcn_raw_buffer_load_b128(rS, (int)(((size_t)(i0 + min(8 * i + crow, rw - 1)) * ldS + m0 + ccol) * 8), 0, 16);
+#pragma unroll
+          for (int i = 0; i < 8; i++) g[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(rS, (int)(((size_t)(j0 + 8 * i + crow) * ldS + m0 + ccol) * 8), 0, 16);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) g[i] = __builtin_amdgcn_raw_buffer_load_b128(rS, (int)(((size_t)(i0 + 8 * i + crow) * ldS + m0 + ccol) * 8), 0, 16);
+        }
+      };
+      // chk: the step before this one looked at the flags of contributor c + 2 (result in s_ready): its loads go into that step's registers (gp)
+      auto step = [&](int c, v4u32 (&g)[12], bool& l, v4u32 (&gp)[12], bool& lp, bool chk) {
+        if (!l) { wait_block(c); fetch(c, g); }
+        __syncthreads();                   // the product before this one has read Ai / Aj (and s_ready is written)
+        if (chk) { lp = s_ready[(rc - 1) & 1] != 0; if (lp) fetch(c + 2, gp); }
+        if (slice) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) *reinterpret_cast<double2*>(Ai + (8 * i + crow) * QP + ccol) = 8 * i + crow < rw ? u4_to_d2(g[i]) : make_double2(0.0, 0.0);
+#pragma unroll
+          for (int i = 0; i < 8; i++) *reinterpret_cast<double2*>(Aj + (8 * i + crow) * QP + ccol) = u4_to_d2(g[4 + i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) *reinterpret_cast<double2*>(Ai + (8 * i + crow) * QP + ccol) = u4_to_d2(g[i]);
+        }
+        const bool look = c + 3 < c1;
+        int fv = A.gen;
+        if (look && tid < 3) fv = __hip_atomic_load(flag_of(c + 3, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // (wave-uniform choice of the straight-line form: a slice owns two blocks with one B operand -- the rhs row: one --, a diagonal
+        //  tile three or two blocks a wave)
+        if (slice) { if (son[1]) flow_mma<2, true>(Ai, Aj, arow, brow, lr, lk, acc); else flow_mma<1, true>(Ai, Aj, arow, brow, lr, lk, acc); }
+        else if (son[2]) flow_mma<3, false>(Ai, Ai, arow, brow, lr, lk, acc);
+        else flow_mma<2, false>(Ai, Ai, arow, brow, lr, lk, acc);
+        if (look) {
+          if (wave == 0) { const bool ok = __all(fv == A.gen); if (tid == 0) s_ready[rc & 1] = ok ? 1 : 0; }
+          rc++;
+        }
+        if (A.fc[4 * (size_t)c + 3]) {     // the level's last contributor: the level launch subtracts its sum here
+#pragma unroll
+          for (int s = 0; s < 3; s++) { tgt[s] -= acc[s]; acc[s] = double4_t{0, 0, 0, 0}; }
+        }
+      };
+      {
+        // the first three contributors: nine flags, nine lanes, one look
+        int fv = A.gen;
+        if (tid < 9 && c0 + tid / 3 < c1) fv = __hip_atomic_load(flag_of(c0 + tid / 3, tid % 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) {
+          const unsigned long long bad = __ballot(fv != A.gen);
+          if (tid == 0) { s_ready[0] = (int)(bad & 0x1FF); }
+        }
+        __syncthreads();
+        const int bad = s_ready[0];
+        __syncthreads();
+        l0 = c0 < c1 && (bad & 7) == 0; l1 = c0 + 1 < c1 && (bad & 0x38) == 0; l2 = c0 + 2 < c1 && (bad & 0x1C0) == 0;
+        if (l0) fetch(c0, g0);
+        if (l1) fetch(c0 + 1, g1);
+        if (l2) fetch(c0 + 2, g2);
+      }
+      {
+        bool chk = false;
+        for (int c = c0; c < c1; c += 3) {
+          step(c, g0, l0, g2, l2, chk); chk = c + 3 < c1;
+          if (c + 1 < c1) { step(c + 1, g1, l1, g0, l0, chk); chk = c + 4 < c1; }
+          if (c + 2 < c1) { step(c + 2, g2, l2, g1, l1, chk); chk = c + 5 < c1; }
+        }
+      }
+      if (c0 < c1) __syncthreads();        // everybody is through with Ai / Aj
+      DVM_FSTMP(t, 1);
+      if (slice) {
+        // ---- X = T L^-T (block (bi, bj) needs the k-blocks 0..bj of L^-1: it is lower triangular), published in place, flag
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+          if (son[s]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ai[(arow[s] + lk + 4 * r) * QP + brow[s] + lr] = tgt[s][r];
+          }
+        if (tid == 0) flow_wait(A.flags + F_L + tj, A.gen, A.fail);
+        __syncthreads();
+        DVM_FSTMP(t, 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) g0[i] = __builtin_amdgcn_raw_buffer_load_b128(rL, (int)(((size_t)tj * NB * NB + (8 * i + crow) * NB + ccol) * 8), 0, 16);
+#pragma unroll
+        for (int i = 0; i < 8; i++) *reinterpret_cast<double2*>(Aj + (8 * i + crow) * QP + ccol) = u4_to_d2(g0[i]);
+        __syncthreads();
+        // the eight blocks cost 4 (bj + 1) MFMAs each: dealt so that every wave issues 20 -- waves 0, 1: column blocks 3 and 0 of block
+        // row `wave`; waves 2, 3: column blocks 2 and 1 of block row `wave - 2`
+        const int xbi = wave & 1, xbj0 = wave < 2 ? 3 : 2, xbj1 = wave < 2 ? 0 : 1;
+        double4_t x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+        if (16 * xbi < rw) {
+          for (int kk = 0; kk < 16 * (xbj0 + 1); kk += 4)
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(16 * xbi + lr) * QP + kk + lk], Aj[(16 * xbj0 + lr) * QP + kk + lk], x0, 0, 0, 0);
+          for (int kk = 0; kk < 16 * (xbj1 + 1); kk += 4)
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(16 * xbi + lr) * QP + kk + lk], Aj[(16 * xbj1 + lr) * QP + kk + lk], x1, 0, 0, 0);
+        }
+        __syncthreads();                   // T has been read: X takes its place (staging for the 16-byte stores)
+        if (16 * xbi < rw) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            Ai[(16 * xbi + lk + 4 * r) * QP + 16 * xbj0 + lr] = x0[r];
+            Ai[(16 * xbi + lk + 4 * r) * QP + 16 * xbj1 + lr] = x1[r];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int r = 8 * i + crow;
+          if (r < rw) __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(Ai[r * QP + ccol], Ai[r * QP + ccol + 1]), rS, (int)(((size_t)(i0 + r) * ldS + j0 + ccol) * 8), 0, 16);
+        }
+        DVM_FSTMP(t, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the flag
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(A.flags + 2 * self + half, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (kind == 2) {
+        // ---- PRE: the partial sum back in place (lower blocks), flag
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+          if (son[s]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ai[(arow[s] + lk + 4 * r) * QP + brow[s] + lr] = tgt[s][r];
+          }
+        __syncthreads();
+        DVM_FSTMP(t, 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int r = 8 * i + crow;
+          if ((ccol >> 4) <= (r >> 4)) __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(Ai[r * QP + ccol], Ai[r * QP + ccol + 1]), rS, (int)(((size_t)(i0 + r) * ldS + j0 + ccol) * 8), 0, 16);
+        }
+        DVM_FSTMP(t, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(A.flags + F_P + tj, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        // ---- DIAG: T -> the factorisation's LDS block, L^-1 out (16-byte sc1 stores), flag.  (The factor of the tile itself is not
+        // written back, as in k_chol_diag: nothing reads it.)
+        lds_f64* const lds = (lds_f64*)smem;
+        lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;
+        lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);
+        lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;
+        lds_f64* const Bm = Id + 16 * 16;
+        lds_f64* const Li = Bm + NB * LP;
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+          if (son[s]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Bm[(arow[s] + lk + 4 * r) * LP + brow[s] + lr] = tgt[s][r];
+          }
+        Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+        __syncthreads();
+        DVM_FSTMP(t, 2);
+        const DiagLds D = {Pcol, Iv, Id, Bm, Li};
+        chol_diag_tile(D, A.fail);
+        DVM_FSTMP(t, 3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int r = 8 * k + crow;
+          const bool lower = (ccol >> 4) <= (r >> 4);      // the blocks above the diagonal were never written in LDS: zeros from here
+          __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(lower ? Li[r * LP + ccol] : 0.0, lower ? Li[r * LP + ccol + 1] : 0.0), rL, (int)(((size_t)tj * NB * NB + r * NB + ccol) * 8), 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(A.flags + F_L + tj, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      DVM_FSTMP(t, 4);
+#ifdef DVM_FLOW_DEBUG
+      if (tid == 0 && t < 4096) g_flow_dbg[t * 8 + 5] = s_wacc;
+#endif
+      continue;
+    }
+    // -------------------------------------------------------------------------------------------- back substitution of one column
+    {
+      double* const yk = smem;                 // [NB]
+      double* const xi = smem + NB;            // [NB]
+      double (*const part)[NB] = (double (*)[NB])(smem + 2 * NB);   // [4][NB]
+      const int c = tid & 63, q = tid >> 6;
+      const int kb = A.cols[A.n_back - 1 - (t - A.n_factor)];      // `cols` lists leaves first
+      const int k0 = kb * NB;
+      const int s_beg = A.colstrip_off[kb], s_end = A.colstrip_off[kb + 1];
+#ifdef DVM_FLOW_DEBUG
+      if (tid == 0 && t < 4096) g_flow_dbg[t * 8 + 6] = (long long)blockIdx.x | (3ll << 12) | ((long long)kb << 16);
+#endif
+      // one lane per flag: the column's L^-1, the tags, and both halves of each of its strips (the rhs row: one half)
+      if (tid == 0) flow_wait(tagged, A.gen, A.fail);
+      if (tid == 1) flow_wait(A.flags + F_L + kb, A.gen, A.fail);
+      for (int f = tid; f < 2 * (s_end - s_beg); f += 256) {
+        const int s = s_beg + (f >> 1);
+        if ((f & 1) == 0 || A.colstrips[s] * NB < A.n_pad) flow_wait(A.flags + 2 * A.colstrip_id[s] + (f & 1), A.gen, A.fail);
+      }
+      __syncthreads();
+      DVM_FSTMP(t, 1);
+      auto ld = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      if (tid < NB) yk[tid] = ld(A.S + (size_t)A.n_pad * ldS + k0 + tid);
+      const double* Lk = A.Linv_all + (size_t)kb * NB * NB;
+      double lkk[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) lkk[r] = ld(Lk + (16 * q + r) * NB + c);
+      double tl[16];
+      auto fetch_tile = [&](int s) {
+        const int r0 = A.colstrips[s] * NB;
+        if (r0 >= A.n_pad) return;
+#pragma unroll
+        for (int r = 0; r < 16; r++) tl[r] = ld(A.S + (size_t)(r0 + 16 * q + r) * ldS + k0 + c);
+      };
+      // ancestors nearest the root first: their x is the first to arrive, the parent's the last (see k_chol_backsolve)
+      if (s_beg < s_end) fetch_tile(s_end - 1);
+      for (int s = s_end - 1; s >= s_beg; s--) {
+        const int r0 = A.colstrips[s] * NB;
+        if (r0 >= A.n_pad) { if (s > s_beg) fetch_tile(s - 1); continue; }   // the rhs row is not an unknown
+        if (tid < NB) {   // every lane waits for its own word of x_i: the data is its own flag
+          double v = ld(A.xrow + r0 + tid);
+          for (int spins = 0; (unsigned long long)__double_as_longlong(v) == kXTag; spins++) {
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1 << 19) || ((spins & 255) == 255 && __hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2)) {
+              __hip_atomic_store(A.fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+            v = ld(A.xrow + r0 + tid);
+          }
+          xi[tid] = v;
+        }
+        __syncthreads();
+        double u = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) u += tl[r] * xi[16 * q + r];
+        if (s > s_beg) fetch_tile(s - 1);
+        part[q][c] = u;
+        __syncthreads();
+        if (tid < NB) yk[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      }
+      __syncthreads();
+      double sum = 0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) sum += lkk[r] * yk[16 * q + r];
+      part[q][c] = sum;
+      __syncthreads();
+      if (tid < NB) {
+        const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        __hip_atomic_store(A.xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // replaces the tag: the word is the hand-off
+        const int cam = kb * A.per_tile + tid / A.dof;
+        // (g2o's linear solver leaves _x untouched when the factorisation fails: see k_chol_backsolve)
+        if (tid < A.per_tile * A.dof && cam < A.nfree && __hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) A.x[A.dof * (size_t)cam + tid % A.dof] = v;
+      }
+      DVM_FSTMP(t, 4);
+    }
   }
 }
 
@@ -2820,6 +3256,19 @@ constexpr int kFusedLevelMaxWGs = 512;   // 2 workgroups per CU on 256 CUs (3 fi
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
   const int n1 = V.n_pad + 1;
+  if (V.flow && V.flow_tasks && V.flow_flags && V.strip_flags) {     // the whole solve as one persistent launch of tile tasks (k_chol_flow)
+    FlowArgs A;
+    A.S = V.S; A.ldS = V.ldS; A.n1 = n1; A.n_pad = V.n_pad; A.Linv_all = V.Linv;
+    A.tasks = V.flow_tasks; A.fc = V.flow_contrib;
+    A.n_factor = V.n_flow_tasks; A.n_back = V.h_level_off[V.nlevels - 1];
+    A.flags = V.flow_flags; A.nstrips = V.n_strips_total; A.ntiles = V.n_tiles_total;
+    A.gen = solve_seq; A.fail = d_fail;
+    A.cols = V.cols; A.xrow = V.xrow; A.x = V.x; A.colstrip_off = V.colstrip_off; A.colstrips = V.colstrips; A.colstrip_id = V.colstrip_id;
+    A.nfree = V.nfree; A.per_tile = V.per_tile; A.dof = V.dof;
+    const int wgs = std::max(1, std::min(A.n_factor + A.n_back, V.flow_wgs > 0 ? V.flow_wgs : 256));
+    hipLaunchKernelGGL(k_chol_flow, dim3(wgs), dim3(256), 0, s, A);
+    return;
+  }
   // test switch: the slices publish a sequence number nobody waits for, so every wait times out and the caller's retry path
   // (one launch per phase) has to produce the result (tests/test_gpu_ba.py)
   static const bool break_handoff = std::getenv("DVM_BA_DEBUG_BREAK_HANDOFF") != nullptr;

@@ -292,8 +292,63 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
   }
   S.colstrip_off.assign(1, 0);
   for (int k = 0; k < nt; k++) {
-    for (int i : col[k]) S.colstrips.push_back(i);
+    for (int i : col[k]) { S.colstrips.push_back(i); S.colstrip_id.push_back(strip_id[i][k]); }
     S.colstrip_off.push_back((int32_t)S.colstrips.size());
+  }
+  // ---- flow form (ba_ordering.h): per tile the contributors of every level that updates it, flattened in the order the level launches
+  // apply them, with an end-of-level mark; then the task list, level by level: PRE and DIAG of the level's columns, then its slices
+  {
+    std::vector<std::vector<int32_t>> segs((size_t)nt * nt);
+    for (int h = 0; h < nl; h++)
+      for (int t = S.tgt_off[h]; t < S.tgt_off[h + 1]; t++) {
+        auto& v = segs[(size_t)S.targets[4 * t] * nt + S.targets[4 * t + 1]];
+        v.push_back(S.targets[4 * t + 2]); v.push_back(S.targets[4 * t + 3]);
+      }
+    // contributors of the level ranges [sg0, sg1) of a tile -> flow_contrib entries (column, strip of the A operand, strip of the B operand, last of its level)
+    auto add_contrib = [&](const std::vector<int32_t>& v, size_t sg0, size_t sg1) {
+      for (size_t sg = sg0; sg < sg1; sg++)
+        for (int c = v[2 * sg]; c < v[2 * sg + 1]; c++) {
+          const int32_t e[4] = {S.contrib[c], S.contrib_strip[2 * c], S.contrib_strip[2 * c + 1], c == v[2 * sg + 1] - 1 ? 1 : 0};
+          S.flow_contrib.insert(S.flow_contrib.end(), e, e + 4);
+        }
+    };
+    auto add_task = [&](int kind, int ti, int tj, int half, int32_t c0, int self, int pre) {
+      const int32_t t[8] = {kind, ti, tj, half, c0, (int32_t)(S.flow_contrib.size() / 4), self, pre};
+      S.flow_tasks.insert(S.flow_tasks.end(), t, t + 8);
+    };
+    for (int h = 0; h < nl; h++) {
+      // diagonal tiles of the level: all levels but the last one that updates the tile are summed by a PRE task (off the critical
+      // path); the DIAG task takes that sum, adds the last level -- the tile's children in the elimination tree --, factorises
+      for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) {
+        const int k = S.cols[c];
+        if (k == nt - 1) continue;
+        const auto& v = segs[(size_t)k * nt + k];
+        if (v.size() / 2 >= 2) {
+          const int32_t c0 = (int32_t)(S.flow_contrib.size() / 4);
+          add_contrib(v, 0, v.size() / 2 - 1);
+          add_task(2, k, k, 0, c0, -1, 0);
+        }
+      }
+      for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) {
+        const int k = S.cols[c];
+        if (k == nt - 1) continue;
+        const auto& v = segs[(size_t)k * nt + k];
+        const size_t ns = v.size() / 2;
+        const int32_t c0 = (int32_t)(S.flow_contrib.size() / 4);
+        add_contrib(v, ns >= 2 ? ns - 1 : 0, ns);
+        add_task(0, k, k, 0, c0, -1, ns >= 2 ? 1 : 0);
+      }
+      // strips: one task per 32-row half (the rhs row: its one row is in half 0)
+      for (int st = S.strip_off[h]; st < S.strip_off[h + 1]; st++) {
+        const int ti = S.strips[2 * st], tj = S.strips[2 * st + 1];
+        const auto& v = segs[(size_t)ti * nt + tj];
+        for (int half = 0; half < (ti == nt - 1 ? 1 : 2); half++) {
+          const int32_t c0 = (int32_t)(S.flow_contrib.size() / 4);
+          add_contrib(v, 0, v.size() / 2);
+          add_task(1, ti, tj, half, c0, st, 0);
+        }
+      }
+    }
   }
   return S;
 }

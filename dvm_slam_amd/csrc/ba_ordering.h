@@ -45,6 +45,17 @@ struct BaTileSchedule {
                                        // row below it) and column a alone on the level before it with nothing but (b, a) and the rhs row below --
                                        // one workgroup factorises both and solves for their unknowns (k_chol_pair); -1: no such pair
   double fill = 1.0;                   // non-zero tiles / all lower tiles
+  // FLOW form (k_chol_flow): factorisation + back substitution as ONE persistent launch of tile tasks taken through a ticket.
+  //   SLICE (kind 1): a 32-row half of a strip tile (i, k) gathers its updates LEFT-LOOKING -- tgt = S, then per level that updates the
+  //     tile acc = sum over that level's columns m of X(i,m) X(k,m)^T and tgt -= acc: the order and association of the level launches,
+  //     same bits --, waits for L_k^-1 and publishes X = T L_k^-T in place;
+  //   PRE (kind 2): a diagonal tile (k, k) with updates from more than one level -- every level but the last, T' in place;
+  //   DIAG (kind 0): the diagonal tile's last level (its children in the elimination tree), factorisation, L_k^-1 published.
+  // A task only ever waits for tasks BEFORE it in the list (contributors are columns of lower levels; PRE and DIAG of a level are
+  // listed before its slices), so whatever holds tickets makes progress: no residency assumption.
+  std::vector<int32_t> flow_tasks;     // 8 ints per task: kind, ti, tj, half, c0, c1 (flow_contrib entries), own strip index or -1, DIAG: 1 = a PRE task precedes
+  std::vector<int32_t> flow_contrib;   // 4 ints per entry: column m, strip (ti, m), strip (tj, m), 1 = last contributor of its level (tgt -= acc behind it)
+  std::vector<int32_t> colstrip_id;    // per `colstrips` entry: that strip's index in `strips`
 };
 // T[i][j] (i >= j) = structurally non-zero tile of the matrix in elimination order; the last tile row (rhs) is dense.
 BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T);

@@ -230,6 +230,11 @@ void dvm_ba_destroy(dvm_ba* h) {
 
 // Graph construction ("buildStructure", block_solver.hpp:143-295): vertex ordering, CSR incidence
 // lists and the block pattern of the reduced camera matrix.  Done once per problem on the host.
+// the default choice between the level launches and the flow form of the reduced solve (k_chol_flow); DVM_BA_FLOW overrides it
+static bool kFlowDefault(const BaTileSchedule& SC) {
+  (void)SC;
+  return false;
+}
 static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
                             const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
   if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1 || world < 1 || rank < 0 || rank >= world) {
@@ -484,7 +489,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   V.nlevels = SC.nlevels;
   V.pair_ok = SC.pair_a >= 0 && std::getenv("DVM_BA_NO_PAIR") == nullptr; V.pair_a = SC.pair_a; V.pair_b = SC.pair_b;   // (DVM_BA_NO_PAIR: A/B switch)
   V.diag_in_level = std::getenv("DVM_BA_NO_DIAG_IN_LEVEL") == nullptr;
-  V.n_root_raw = SC.n_root_raw;   // (ba_ordering.h: the last launched level's panel solve left to the back substitution)
+  V.n_root_raw = std::getenv("DVM_BA_NO_ROOT_RAW") ? 0 : SC.n_root_raw;   // (ba_ordering.h: the last launched level's panel solve left to the back substitution; the switch: A/B and tests)
 
   int rc = DVM_OK;
   auto ok = [&](int r) { if (rc == DVM_OK) rc = r; };
@@ -529,6 +534,20 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
   ok(h->upload(&V.contrib_strip, SC.contrib_strip));
+  // the flow form of the solve (k_chol_flow): task list, per-tile level ranges, flags (zeroed once: they are compared with the solve's sequence number)
+  ok(h->upload(&V.flow_tasks, SC.flow_tasks)); ok(h->upload(&V.flow_contrib, SC.flow_contrib)); ok(h->upload(&V.colstrip_id, SC.colstrip_id));
+  V.n_flow_tasks = (int)(SC.flow_tasks.size() / 8); V.n_strips_total = (int)(SC.strips.size() / 2); V.n_tiles_total = nkb;
+  ok(h->dalloc(&V.flow_flags, 2 * (size_t)V.n_strips_total + 2 * (size_t)nkb + 4));
+  {
+    // which form: the level launches pay ~17 us a level when a level is a handful of tiles and ~43 us when its trailing update is large; the flow
+    // form pays one launch and a ~19 us chain per level whatever the level's size.  DVM_BA_FLOW=0 / 1 forces the choice (A/B switch).
+    const char* e = std::getenv("DVM_BA_FLOW");
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    V.flow_wgs = cus;
+    const bool fits = (size_t)V.ldS * V.ldS * sizeof(double) < (size_t)0x7FFFFFF0;      // 32-bit buffer offsets into S
+    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC)) && fits && world == 1 ? 1 : 0;
+  }
   V.strip_flags = reinterpret_cast<int32_t*>(V.ytmp + (size_t)V.n_pad + 64);   // behind the back substitution's words, cleared with them
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
   if (std::getenv("DVM_BA_DEBUG_SCHEDULE")) {
@@ -560,6 +579,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes.)
   ok(hip_check(hipMemsetAsync(V.e_chi2, 0, (size_t)E * sizeof(double), h->stream), "memset"));
   ok(hip_check(hipMemsetAsync(V.ytmp, 0, ((size_t)V.n_pad + 64 + 2 * (SC.strips.size() / 2) + 2) * sizeof(double), h->stream), "memset"));   // ticket + hand-off flags of the back substitution
+  ok(hip_check(hipMemsetAsync(V.flow_flags, 0, (2 * (size_t)V.n_strips_total + 2 * (size_t)nkb + 4) * sizeof(int32_t), h->stream), "memset"));
   h->solve_seq = 0; h->fuse_levels = true;
   ok(hip_check(hipStreamSynchronize(h->stream), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
@@ -856,7 +876,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         }
         {
           BaView VS = V;                                   // in-launch hand-offs (k_chol_trsm_update) only while they have never timed out
-          if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
+          if (sharded || !h->fuse_levels) { VS.strip_flags = nullptr; VS.flow = 0; }
           ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
         }
         if (h->prof) hipEventRecord(h->pev[2], s);
