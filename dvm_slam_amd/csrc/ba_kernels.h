@@ -82,9 +82,10 @@ struct BaView {
   // FLOW form of the solve (k_chol_flow, ba_ordering.h): tile tasks taken through a ticket, factorisation + back substitution in ONE launch
   const int32_t* flow_tasks;    // [n_flow_tasks][8]
   const int32_t* flow_contrib;  // [..][4] flattened contributor lists (ba_ordering.h)
+  const int32_t* flow_col;      // [tiles][8] chain links and diagonal-tile modes (ba_ordering.h)
   const int32_t* colstrip_id;   // per colstrips entry: index of that strip
-  int32_t* flow_flags;          // [2 x strips] a 32-row half of X published | [tiles] L^-1 of a column | [tiles] T' of a diagonal tile (PRE) | xrow tagged |
-                                // ticket; compared with the solve's sequence number, zeroed once after allocation
+  int32_t* flow_flags;          // [2 x strips] a 32-row half of X published | [tiles] L^-1 of a column | [tiles] T' of a diagonal tile (PRE) | [2 x strips] a
+                                // half of a chain strip gathered | xrow tagged | ticket; compared with the solve's sequence number, zeroed once after allocation
   int32_t n_flow_tasks, n_strips_total, n_tiles_total;
   int32_t flow;                 // 1: ba_launch_cholesky_solve uses k_chol_flow (set by dvm_ba_set_problem; 0 after one of its waits timed out)
   int32_t flow_wgs;             // persistent workgroups to launch (compute units of the device)

@@ -940,7 +940,11 @@ struct DiagLds {
 };
 // One 64x64 tile in LDS: on return (all threads, behind a barrier) Li holds L^-1 -- every 16x16 block at or below the diagonal;
 // the blocks above it are NOT written -- and Bm the blocks of L below the diagonal blocks.  256 threads.
-__device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict__ fail) {
+// Hook: what waves 1..3 do for the CALLER beside the last panel, while wave 0 is in the column chain (k_chol_flow: the chain strip of the
+// NEXT step travels global -> LDS under the factorisation): hook.begin() before, hook.end() behind their own work there.  NoDiagHook: no code.
+struct NoDiagHook { static constexpr bool on = false; __device__ void begin() {} __device__ void end() {} };
+template <class Hook>
+__device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict__ fail, Hook& hook) {
   lds_f64 (*const Pcol)[NB] = D.Pcol;
   lds_f64 (*const Iv)[16][17] = D.Iv;
   lds_f64* const Id = D.Id;
@@ -1020,6 +1024,7 @@ __device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict
   for (int b = 0; b < 4; b++) {
     const int o = 16 * b, nrows = NB - o;
     DVM_STAMP(2 + 3 * b);
+    if (Hook::on && b == 3 && wave != 0) hook.begin();
     if (wave == 0) {
       // ---- A: the whole 16-column PANEL (diagonal sub-block + every row below it) in registers, lane = panel row;
       // the rows below the diagonal sub-block ride along in the same instructions (no separate triangular solve).
@@ -1071,6 +1076,7 @@ __device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict
         else { t3a = linv_sum(3, 2); copy_inverse(2); }
       }
     }
+    if (Hook::on && b == 3 && wave != 0) hook.end();
     DVM_STAMP(3 + 3 * b);
     if (b == 3) { DVM_STAMPW(18, 1); DVM_STAMPW(19, 2); DVM_STAMPW(20, 3); }
     __syncthreads();
@@ -1090,6 +1096,8 @@ __device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict
   DVM_STAMP(15);
   __syncthreads();
 }
+
+__device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict__ fail) { NoDiagHook h; chol_diag_tile(D, fail, h); }
 
 __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int ldS, int n1, const int32_t* __restrict__ cols,
                                                   int* __restrict__ fail, double* __restrict__ Linv_all) {
@@ -1750,10 +1758,54 @@ extern "C" int dvm_debug_flow_stamps(long long* out, int n) { return (int)hipMem
 #else
 #define DVM_FSTMP(t, i) do { } while (0)
 #endif
+// k_chol_flow's hook into the factorisation (chol_diag_tile): the gathered chain strip T(p, k) into LDS under the last panel
+struct FlowTHook {
+  static constexpr bool on = true;
+  const int32_t* flags;        // the two "half gathered" words of the chain strip (null: no chain parent)
+  int gen;
+  __amdgpu_buffer_rsrc_t rS;
+  int toff, ldS;               // byte offset of the tile in S
+  double* Xb;                  // LDS, pitch QP
+  int* s_flag;                 // LDS word: 1 = the tile is (being) loaded
+  int* fv;                     // the look's register (per thread)
+  typedef unsigned int v4u32_ __attribute__((ext_vector_type(4)));
+  // begin (waves 1..3, top of the last panel): wave 3 issues the loads of the strip's two flags
+  __device__ __forceinline__ void begin() {
+    *fv = gen;
+    if (flags && threadIdx.x >= 192 && threadIdx.x < 194) *fv = __hip_atomic_load(flags + (threadIdx.x - 192), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // end (behind their own work there): wave 3 says whether both halves are gathered (LDS word: 2 = not decided yet, 0 / 1); the three
+  // waves then move the tile, 2048 chunks of 16 bytes over 192 threads, global -> registers -> LDS
+  __device__ __forceinline__ void end() {
+    if (threadIdx.x >= 192) {
+      const bool ok = __all(*fv == gen) && flags != nullptr;
+      if (threadIdx.x == 192) *reinterpret_cast<volatile int*>(s_flag) = ok ? 1 : 0;
+    }
+    int f;
+    while ((f = *reinterpret_cast<volatile int*>(s_flag)) == 2) __builtin_amdgcn_s_sleep(1);
+    if (f == 0) return;
+    const int q0 = (int)threadIdx.x - 64;
+    v4u32_ v[11];
+#pragma unroll
+    for (int j = 0; j < 11; j++) {
+      const int q = min(q0 + 192 * j, 2047);
+      v[j] = __builtin_amdgcn_raw_buffer_load_b128(rS, toff + (int)(((size_t)(q >> 5) * ldS + 2 * (q & 31)) * 8), 0, 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 11; j++) {
+      const int q = q0 + 192 * j;
+      if (q < 2048) {
+        double2 d;
+        d.x = __hiloint2double((int)v[j].y, (int)v[j].x); d.y = __hiloint2double((int)v[j].w, (int)v[j].z);
+        *reinterpret_cast<double2*>(Xb + (q >> 5) * 66 + 2 * (q & 31)) = d;
+      }
+    }
+  }
+};
 struct FlowArgs {
   double* S; int ldS, n1, n_pad;
   double* Linv_all;
-  const int32_t *tasks, *fc;
+  const int32_t *tasks, *fc, *colinfo;
   int n_factor, n_back;
   int32_t* flags; int nstrips, ntiles;
   int gen; int* fail;
@@ -1814,7 +1866,8 @@ __device__ __forceinline__ void flow_mma(const double* __restrict__ Ai, const do
   }
 }
 __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
-  __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP];
+  constexpr int kCholLds = 16 * NB + 4 * 16 * 17 + 16 * 16 + 2 * NB * LP;      // the factorisation's block (also the gather buffers Ai / Aj)
+  __shared__ __attribute__((aligned(16))) double smem[kCholLds + NB * QP];     // + the chain strip T -> X (119 KB: one workgroup per CU either way)
   __shared__ int s_ticket, s_ready[2];
 #ifdef DVM_FLOW_DEBUG
   __shared__ long long s_wacc;
@@ -1823,8 +1876,8 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int ldS = A.ldS;
-  const int F_L = 2 * A.nstrips, F_P = F_L + A.ntiles;
-  int32_t* const tagged = A.flags + F_P + A.ntiles;
+  const int F_L = 2 * A.nstrips, F_P = F_L + A.ntiles, F_T = F_P + A.ntiles;      // flag spaces: X halves | L^-1 | PRE | gathered halves of chain strips
+  int32_t* const tagged = A.flags + F_T + 2 * A.nstrips;
   int32_t* const ticket = tagged + 1;
   const int ntotal = A.n_factor + A.n_back;
   // buffer descriptors (wave-uniform inputs only): S and the L^-1 tiles, for the 16-byte sc1 loads / stores
@@ -1859,7 +1912,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
       // ------------------------------------------------------------------------------------------ a tile (or half tile) of the factor
       const int32_t* T = A.tasks + 8 * (size_t)t;
       const int kind = T[0], ti = T[1], tj = T[2], half = T[3], c0 = T[4], c1 = T[5], self = T[6], pre = T[7];
-      const bool slice = kind == 1;
+      const bool slice = kind == 1 || kind == 4;
       const int i0 = ti * NB + (slice ? 32 * half : 0), j0 = tj * NB;
       const int rw = min(slice ? 32 : NB, A.n1 - i0);      // rows of the region that exist (the rhs row: one)
 #ifdef DVM_FLOW_DEBUG
@@ -1880,10 +1933,6 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
         }
       }
       double4_t tgt[3], acc[3];
-      if (kind == 0 && pre) {                // the sum of the earlier levels, left in place by the tile's PRE task
-        if (tid == 0) flow_wait(A.flags + F_P + tj, A.gen, A.fail);
-        __syncthreads();
-      }
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         acc[s] = double4_t{0, 0, 0, 0};
@@ -1891,8 +1940,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
         for (int r = 0; r < 4; r++) {
           const int row = arow[s] + lk + 4 * r, col = brow[s] + lr;
           const double* p = A.S + (size_t)(i0 + min(row, rw - 1)) * ldS + j0 + col;
-          const double v = (kind == 0 && pre) ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-          tgt[s][r] = (son[s] && row < rw) ? v : 0.0;
+          tgt[s][r] = (son[s] && row < rw) ? *p : 0.0;
         }
       }
       // ---- gather: three contributors in flight (global -> registers), one in LDS under the matrix pipe.  A contributor's three flags
@@ -1980,7 +2028,26 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
       }
       if (c0 < c1) __syncthreads();        // everybody is through with Ai / Aj
       DVM_FSTMP(t, 1);
-      if (slice) {
+      if (kind == 4) {
+        // ---- a half of a chain strip: T in place (the chain's workgroup solves it), flag
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+          if (son[s]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Ai[(arow[s] + lk + 4 * r) * QP + brow[s] + lr] = tgt[s][r];
+          }
+        __syncthreads();
+        DVM_FSTMP(t, 2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int r = 8 * i + crow;
+          if (r < rw) __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(Ai[r * QP + ccol], Ai[r * QP + ccol + 1]), rS, (int)(((size_t)(i0 + r) * ldS + j0 + ccol) * 8), 0, 16);
+        }
+        DVM_FSTMP(t, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(A.flags + F_T + 2 * self + half, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (slice) {
         // ---- X = T L^-T (block (bi, bj) needs the k-blocks 0..bj of L^-1: it is lower triangular), published in place, flag
 #pragma unroll
         for (int s = 0; s < 2; s++)
@@ -2025,7 +2092,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
         __syncthreads();
         if (tid == 0) __hip_atomic_store(A.flags + 2 * self + half, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (kind == 2) {
-        // ---- PRE: the partial sum back in place (lower blocks), flag
+        // ---- PRE: the sum of the levels before the last one back in place (lower blocks), flag
 #pragma unroll
         for (int s = 0; s < 3; s++)
           if (son[s]) {
@@ -2044,35 +2111,127 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
         __syncthreads();
         if (tid == 0) __hip_atomic_store(A.flags + F_P + tj, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        // ---- DIAG: T -> the factorisation's LDS block, L^-1 out (16-byte sc1 stores), flag.  (The factor of the tile itself is not
-        // written back, as in k_chol_diag: nothing reads it.)
+        // ---- DIAG: a leaf's diagonal tile (no contributor: tgt = S), and then UP THE TREE along the chain: factorise k; solve the chain
+        // strip (p, k) with the L_k^-1 that is in LDS; publish L_k^-1 and X(p, k); take what PRE left of (p, p), add X X^T -- the last
+        // contributor of p's last level --, subtract; k = p.  (The factor of a diagonal tile itself is not written back, as in k_chol_diag.)
         lds_f64* const lds = (lds_f64*)smem;
         lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;
         lds_f64 (*const Iv)[16][17] = (lds_f64 (*)[16][17])(lds + 16 * NB);
         lds_f64* const Id = lds + 16 * NB + 4 * 16 * 17;
         lds_f64* const Bm = Id + 16 * 16;
         lds_f64* const Li = Bm + NB * LP;
+        double* const Xb = smem + kCholLds;   // T -> X of the chain strip, pitch QP
+        int k = tj;
+        for (;;) {
+          const int p = A.colinfo[8 * k], cstrip = A.colinfo[8 * k + 1];
 #pragma unroll
-        for (int s = 0; s < 3; s++)
-          if (son[s]) {
+          for (int s = 0; s < 3; s++)
+            if (son[s]) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) Bm[(arow[s] + lk + 4 * r) * LP + brow[s] + lr] = tgt[s][r];
+              for (int r = 0; r < 4; r++) Bm[(arow[s] + lk + 4 * r) * LP + brow[s] + lr] = tgt[s][r];
+            }
+          Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+          if (tid == 0) s_ready[0] = 2;     // (the hook's word: not decided yet)
+          __syncthreads();
+          v4u32 tq[8];
+          const int toff = p >= 0 ? (int)(((size_t)p * NB * ldS + (size_t)k * NB) * 8) : 0;
+          DVM_FSTMP(3500 + k, 0);
+          // the chain strip T(p, k): its two halves are looked at from INSIDE the factorisation (wave 3, beside the last panel), and if
+          // they are there the tile travels into Xb under that panel and the tail
+          int hook_fv = 0;
+          FlowTHook hook;
+          hook.flags = p >= 0 ? A.flags + F_T + 2 * cstrip : nullptr; hook.gen = A.gen; hook.rS = rS; hook.toff = toff; hook.ldS = ldS;
+          hook.Xb = Xb; hook.s_flag = &s_ready[0]; hook.fv = &hook_fv;
+          const DiagLds D = {Pcol, Iv, Id, Bm, Li};
+          chol_diag_tile(D, A.fail, hook);
+          const bool tpre = s_ready[0] == 1;
+#ifdef DVM_FLOW_DEBUG
+          if (tid == 0) g_flow_dbg[(3500 + k) * 8 + 6] = tpre ? 1 : 0;
+#endif
+          DVM_FSTMP(3500 + k, 1);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int r = 8 * q + crow;
+            const bool lower = (ccol >> 4) <= (r >> 4);      // the blocks above the diagonal were never written in LDS: zeros from here
+            __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(lower ? Li[r * LP + ccol] : 0.0, lower ? Li[r * LP + ccol + 1] : 0.0), rL, (int)(((size_t)k * NB * NB + r * NB + ccol) * 8), 0, 16);
           }
-        Id[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
-        __syncthreads();
-        DVM_FSTMP(t, 2);
-        const DiagLds D = {Pcol, Iv, Id, Bm, Li};
-        chol_diag_tile(D, A.fail);
-        DVM_FSTMP(t, 3);
+          // L_k^-1 is what this column's other strips wait for: out at once (drain, flag), whatever the chain waits for next
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(A.flags + F_L + k, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p < 0) break;                // the chain ends here (the root, or a column that is not its parent's last contributor)
+          if (!tpre) {
+            if (tid < 2) flow_wait(A.flags + F_T + 2 * cstrip + tid, A.gen, A.fail);
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int r = 8 * k + crow;
-          const bool lower = (ccol >> 4) <= (r >> 4);      // the blocks above the diagonal were never written in LDS: zeros from here
-          __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(lower ? Li[r * LP + ccol] : 0.0, lower ? Li[r * LP + ccol + 1] : 0.0), rL, (int)(((size_t)tj * NB * NB + r * NB + ccol) * 8), 0, 16);
+            for (int i = 0; i < 8; i++) tq[i] = __builtin_amdgcn_raw_buffer_load_b128(rS, toff + (int)(((size_t)(8 * i + crow) * ldS + ccol) * 8), 0, 16);
+#pragma unroll
+            for (int i = 0; i < 8; i++) *reinterpret_cast<double2*>(Xb + (8 * i + crow) * QP + ccol) = u4_to_d2(tq[i]);
+          }
+          const int pmode = A.colinfo[8 * p + 2], lc0 = A.colinfo[8 * p + 3], lc1 = A.colinfo[8 * p + 4];
+          if (pmode >= 2 && tid == 0) flow_wait(A.flags + F_P + p, A.gen, A.fail);      // (long there: PRE runs levels ahead)
+          __syncthreads();
+          // what PRE left of (p, p): on its way while the strip is solved
+          const int pi0 = p * NB;
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int row = arow[s] + lk + 4 * r, col = brow[s] + lr;
+              const double* q = A.S + (size_t)(pi0 + row) * ldS + pi0 + col;
+              tgt[s][r] = !son[s] ? 0.0 : pmode >= 2 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+              acc[s][r] = 0.0;
+            }
+          }
+          DVM_FSTMP(3500 + k, 2);
+          // X = T L_k^-T: wave w takes block row w (4 + 8 + 12 + 16 MFMAs: L^-1 is lower triangular)
+          double4_t xr[4];
+#pragma unroll
+          for (int bj = 0; bj < 4; bj++) {
+            double4_t x4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 16 * (bj + 1); kk += 4)
+              x4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xb[(16 * wave + lr) * QP + kk + lk], Li[(16 * bj + lr) * LP + kk + lk], x4, 0, 0, 0);
+            xr[bj] = x4;
+          }
+          __syncthreads();                 // T has been read: X takes its place
+#pragma unroll
+          for (int bj = 0; bj < 4; bj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Xb[(16 * wave + lk + 4 * r) * QP + 16 * bj + lr] = xr[bj][r];
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int r = 8 * i + crow;
+            __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(Xb[r * QP + ccol], Xb[r * QP + ccol + 1]), rS, toff + (int)(((size_t)r * ldS + ccol) * 8), 0, 16);
+          }
+          DVM_FSTMP(3500 + k, 3);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // X has left (every storing wave): its flags go up before anything else --
+          __syncthreads();                                     // the next chain strip's gather is waiting for them
+          if (tid < 2) __hip_atomic_store(A.flags + 2 * cstrip + tid, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // p's other children (the contributors of its last level before the chain child, ascending): their strips (p, m) come from
+          // memory like any gathered contributor, one at a time -- there are one or two
+          for (int c = lc0; c < lc1; c++) {
+            const int32_t* e = A.fc + 4 * (size_t)c;
+            if (tid < 2) flow_wait(A.flags + 2 * e[1] + tid, A.gen, A.fail);
+            __syncthreads();               // (also: the product before this one has read Ai)
+#pragma unroll
+            for (int i = 0; i < 8; i++) tq[i] = __builtin_amdgcn_raw_buffer_load_b128(rS, (int)(((size_t)(pi0 + 8 * i + crow) * ldS + (size_t)e[0] * NB + ccol) * 8), 0, 16);
+#pragma unroll
+            for (int i = 0; i < 8; i++) *reinterpret_cast<double2*>(Ai + (8 * i + crow) * QP + ccol) = u4_to_d2(tq[i]);
+            __syncthreads();
+            if (son[2]) flow_mma<3, false>(Ai, Ai, arow, brow, lr, lk, acc);
+            else flow_mma<2, false>(Ai, Ai, arow, brow, lr, lk, acc);
+          }
+          // the chain child's product, the last of p's last level: acc += X X^T, tgt -= acc
+          if (son[2]) flow_mma<3, false>(Xb, Xb, arow, brow, lr, lk, acc);
+          else flow_mma<2, false>(Xb, Xb, arow, brow, lr, lk, acc);
+#pragma unroll
+          for (int s = 0; s < 3; s++) { tgt[s] -= acc[s]; acc[s] = double4_t{0, 0, 0, 0}; }
+          __syncthreads();                 // Xb / Ai have been read: Bm may be written
+          DVM_FSTMP(3500 + k, 4);
+          k = p;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(A.flags + F_L + tj, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       DVM_FSTMP(t, 4);
 #ifdef DVM_FLOW_DEBUG
@@ -3259,7 +3418,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   if (V.flow && V.flow_tasks && V.flow_flags && V.strip_flags) {     // the whole solve as one persistent launch of tile tasks (k_chol_flow)
     FlowArgs A;
     A.S = V.S; A.ldS = V.ldS; A.n1 = n1; A.n_pad = V.n_pad; A.Linv_all = V.Linv;
-    A.tasks = V.flow_tasks; A.fc = V.flow_contrib;
+    A.tasks = V.flow_tasks; A.fc = V.flow_contrib; A.colinfo = V.flow_col;
     A.n_factor = V.n_flow_tasks; A.n_back = V.h_level_off[V.nlevels - 1];
     A.flags = V.flow_flags; A.nstrips = V.n_strips_total; A.ntiles = V.n_tiles_total;
     A.gen = solve_seq; A.fail = d_fail;

@@ -316,36 +316,53 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
       const int32_t t[8] = {kind, ti, tj, half, c0, (int32_t)(S.flow_contrib.size() / 4), self, pre};
       S.flow_tasks.insert(S.flow_tasks.end(), t, t + 8);
     };
+    // diagonal tiles: the LAST contributor of tile (p, p) -- the largest column of the highest level that updates it -- is a child k of p
+    // in the elimination tree whose first strip is (p, k): p's CHAIN CHILD.  The workgroup that factorises k goes on to p itself (solves
+    // the strip (p, k) with the L^-1 it holds in LDS, multiplies, factorises p): no hand-off on the chain.  The levels before the last
+    // one are summed by a PRE task off the critical path; the other contributors of the last level (p's other children) by the chain's
+    // workgroup itself, in order, before its own product.  flow_col[k] = {p if k is p's chain child else -1, strip (p, k), mode of k's
+    // own tile: 0 no contributor (a ticketed leaf), 1 the last level only (tgt = S), 2 PRE leaves tgt'; the last level's other
+    // contributors as a range of flow_contrib; 0 0 0}
+    S.flow_col.assign((size_t)8 * nt, 0);
+    std::vector<char> chain_strip(S.strips.size() / 2, 0);
+    std::vector<int32_t> nseg(nt, 0);
+    for (int k = 0; k < nt; k++) S.flow_col[8 * k] = S.flow_col[8 * k + 1] = -1;
+    for (int k = 0; k + 1 < nt; k++) {
+      const auto& v = segs[(size_t)k * nt + k];
+      nseg[k] = (int)(v.size() / 2);
+      if (v.empty()) { S.flow_leaves++; continue; }
+      const int clast = v[v.size() - 1] - 1;                    // last contributor: entry clast of `contrib`
+      const int child = S.contrib[clast], st = S.contrib_strip[2 * clast];
+      S.flow_col[8 * child] = k; S.flow_col[8 * child + 1] = st;
+      chain_strip[st] = 1;
+      S.flow_col[8 * k + 2] = nseg[k] >= 2 ? 2 : 1;
+      S.flow_col[8 * k + 3] = (int32_t)(S.flow_contrib.size() / 4);
+      add_contrib(v, v.size() / 2 - 1, v.size() / 2);
+      S.flow_contrib.resize(S.flow_contrib.size() - 4);         // (the chain child's product comes from LDS)
+      S.flow_col[8 * k + 4] = (int32_t)(S.flow_contrib.size() / 4);
+    }
     for (int h = 0; h < nl; h++) {
-      // diagonal tiles of the level: all levels but the last one that updates the tile are summed by a PRE task (off the critical
-      // path); the DIAG task takes that sum, adds the last level -- the tile's children in the elimination tree --, factorises
       for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) {
         const int k = S.cols[c];
-        if (k == nt - 1) continue;
+        if (k == nt - 1 || nseg[k] < 2) continue;
         const auto& v = segs[(size_t)k * nt + k];
-        if (v.size() / 2 >= 2) {
-          const int32_t c0 = (int32_t)(S.flow_contrib.size() / 4);
-          add_contrib(v, 0, v.size() / 2 - 1);
-          add_task(2, k, k, 0, c0, -1, 0);
-        }
-      }
-      for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) {
-        const int k = S.cols[c];
-        if (k == nt - 1) continue;
-        const auto& v = segs[(size_t)k * nt + k];
-        const size_t ns = v.size() / 2;
         const int32_t c0 = (int32_t)(S.flow_contrib.size() / 4);
-        add_contrib(v, ns >= 2 ? ns - 1 : 0, ns);
-        add_task(0, k, k, 0, c0, -1, ns >= 2 ? 1 : 0);
+        add_contrib(v, 0, v.size() / 2 - 1);
+        add_task(2, k, k, 0, c0, -1, 2);
       }
-      // strips: one task per 32-row half (the rhs row: its one row is in half 0)
+      for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) {
+        const int k = S.cols[c];
+        if (k == nt - 1 || nseg[k] != 0) continue;
+        add_task(0, k, k, 0, (int32_t)(S.flow_contrib.size() / 4), -1, 0);
+      }
+      // strips: one task per 32-row half (the rhs row: its one row is in half 0); a chain strip is gathered only (kind 4: T in place)
       for (int st = S.strip_off[h]; st < S.strip_off[h + 1]; st++) {
         const int ti = S.strips[2 * st], tj = S.strips[2 * st + 1];
         const auto& v = segs[(size_t)ti * nt + tj];
         for (int half = 0; half < (ti == nt - 1 ? 1 : 2); half++) {
           const int32_t c0 = (int32_t)(S.flow_contrib.size() / 4);
           add_contrib(v, 0, v.size() / 2);
-          add_task(1, ti, tj, half, c0, st, 0);
+          add_task(chain_strip[st] ? 4 : 1, ti, tj, half, c0, st, 0);
         }
       }
     }

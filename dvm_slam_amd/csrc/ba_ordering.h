@@ -48,13 +48,17 @@ struct BaTileSchedule {
   // FLOW form (k_chol_flow): factorisation + back substitution as ONE persistent launch of tile tasks taken through a ticket.
   //   SLICE (kind 1): a 32-row half of a strip tile (i, k) gathers its updates LEFT-LOOKING -- tgt = S, then per level that updates the
   //     tile acc = sum over that level's columns m of X(i,m) X(k,m)^T and tgt -= acc: the order and association of the level launches,
-  //     same bits --, waits for L_k^-1 and publishes X = T L_k^-T in place;
-  //   PRE (kind 2): a diagonal tile (k, k) with updates from more than one level -- every level but the last, T' in place;
-  //   DIAG (kind 0): the diagonal tile's last level (its children in the elimination tree), factorisation, L_k^-1 published.
-  // A task only ever waits for tasks BEFORE it in the list (contributors are columns of lower levels; PRE and DIAG of a level are
-  // listed before its slices), so whatever holds tickets makes progress: no residency assumption.
-  std::vector<int32_t> flow_tasks;     // 8 ints per task: kind, ti, tj, half, c0, c1 (flow_contrib entries), own strip index or -1, DIAG: 1 = a PRE task precedes
+  //     same bits --, waits for L_k^-1 and publishes X = T L_k^-T in place;  TSLICE (kind 4): the same for a CHAIN strip, gather only;
+  //   PRE (kind 2): a diagonal tile (p, p) updated by more than one level -- all levels but the last one, T' in place;
+  //   DIAG (kind 0): a leaf's diagonal tile: factorisation, L^-1 published -- and then UP THE TREE along the chain (flow_col): the
+  //     workgroup solves the chain strip (p, k) with the L_k^-1 it holds, publishes X(p,k), gathers p's other children, adds X X^T, factorises p ...
+  // A ticketed task only waits for tasks BEFORE it in the list, except the chain, which waits for the TSLICE / PRE tasks of the columns
+  // it climbs to: those are drawn by the other workgroups (the launcher keeps the chains -- one per leaf -- far below the workgroup count).
+  std::vector<int32_t> flow_tasks;     // 8 ints per task: kind, ti, tj, half, c0, c1 (flow_contrib entries), own strip index or -1, PRE: the tile's mode
   std::vector<int32_t> flow_contrib;   // 4 ints per entry: column m, strip (ti, m), strip (tj, m), 1 = last contributor of its level (tgt -= acc behind it)
+  std::vector<int32_t> flow_col;       // 8 ints per tile column: chain parent or -1, chain strip, mode of the column's own diagonal tile, the other
+                                       // contributors of its last level as a range of flow_contrib, 0 0 0 (see ba_ordering.cpp)
+  int flow_leaves = 0;                 // columns without contributors = ticketed DIAG tasks = chains
   std::vector<int32_t> colstrip_id;    // per `colstrips` entry: that strip's index in `strips`
 };
 // T[i][j] (i >= j) = structurally non-zero tile of the matrix in elimination order; the last tile row (rhs) is dense.

@@ -231,10 +231,11 @@ void dvm_ba_destroy(dvm_ba* h) {
 // Graph construction ("buildStructure", block_solver.hpp:143-295): vertex ordering, CSR incidence
 // lists and the block pattern of the reduced camera matrix.  Done once per problem on the host.
 // the default choice between the level launches and the flow form of the reduced solve (k_chol_flow); DVM_BA_FLOW overrides it
-static bool kFlowDefault(const BaTileSchedule& SC) {
-  (void)SC;
-  return false;
-}
+// Measured (DESIGN.md section 10, 500 keyframes): the flow form costs ~15.5 us per level of a chain (the factorisation's own 7.7 us + the
+// chain strip and its product in the same workgroup) and ~20 us per level with two children; the level launches ~17 us per level when a
+// level is a handful of tiles and ~20 us when its trailing update is large.  A bushy tree of few levels (a ring: 7) is level-launch
+// territory, a tree that is mostly a chain (a loop-closed map: 37 levels) the flow form's: 980 -> 1 270 it/s.
+static bool kFlowDefault(const BaTileSchedule& SC) { return SC.nlevels >= 12; }
 static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
                             const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
   if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1 || world < 1 || rank < 0 || rank >= world) {
@@ -535,9 +536,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
   ok(h->upload(&V.contrib_strip, SC.contrib_strip));
   // the flow form of the solve (k_chol_flow): task list, per-tile level ranges, flags (zeroed once: they are compared with the solve's sequence number)
-  ok(h->upload(&V.flow_tasks, SC.flow_tasks)); ok(h->upload(&V.flow_contrib, SC.flow_contrib)); ok(h->upload(&V.colstrip_id, SC.colstrip_id));
+  ok(h->upload(&V.flow_tasks, SC.flow_tasks)); ok(h->upload(&V.flow_contrib, SC.flow_contrib)); ok(h->upload(&V.flow_col, SC.flow_col)); ok(h->upload(&V.colstrip_id, SC.colstrip_id));
   V.n_flow_tasks = (int)(SC.flow_tasks.size() / 8); V.n_strips_total = (int)(SC.strips.size() / 2); V.n_tiles_total = nkb;
-  ok(h->dalloc(&V.flow_flags, 2 * (size_t)V.n_strips_total + 2 * (size_t)nkb + 4));
+  ok(h->dalloc(&V.flow_flags, 4 * (size_t)V.n_strips_total + 2 * (size_t)nkb + 4));
   {
     // which form: the level launches pay ~17 us a level when a level is a handful of tiles and ~43 us when its trailing update is large; the flow
     // form pays one launch and a ~19 us chain per level whatever the level's size.  DVM_BA_FLOW=0 / 1 forces the choice (A/B switch).
@@ -546,7 +547,8 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     V.flow_wgs = cus;
     const bool fits = (size_t)V.ldS * V.ldS * sizeof(double) < (size_t)0x7FFFFFF0;      // 32-bit buffer offsets into S
-    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC)) && fits && world == 1 ? 1 : 0;
+    // (the chains -- one per leaf of the elimination tree -- wait for tasks the OTHER workgroups draw: they must stay a minority)
+    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC)) && fits && world == 1 && 4 * SC.flow_leaves <= cus ? 1 : 0;
   }
   V.strip_flags = reinterpret_cast<int32_t*>(V.ytmp + (size_t)V.n_pad + 64);   // behind the back substitution's words, cleared with them
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
@@ -579,7 +581,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   //  those.  The matrix is ldS^2 doubles -- 1.3 GB at 2 000 keyframes.)
   ok(hip_check(hipMemsetAsync(V.e_chi2, 0, (size_t)E * sizeof(double), h->stream), "memset"));
   ok(hip_check(hipMemsetAsync(V.ytmp, 0, ((size_t)V.n_pad + 64 + 2 * (SC.strips.size() / 2) + 2) * sizeof(double), h->stream), "memset"));   // ticket + hand-off flags of the back substitution
-  ok(hip_check(hipMemsetAsync(V.flow_flags, 0, (2 * (size_t)V.n_strips_total + 2 * (size_t)nkb + 4) * sizeof(int32_t), h->stream), "memset"));
+  ok(hip_check(hipMemsetAsync(V.flow_flags, 0, (4 * (size_t)V.n_strips_total + 2 * (size_t)nkb + 4) * sizeof(int32_t), h->stream), "memset"));
   h->solve_seq = 0; h->fuse_levels = true;
   ok(hip_check(hipStreamSynchronize(h->stream), "sync"));
   if (rc != DVM_OK) { h->free_problem(); return rc; }
@@ -657,6 +659,11 @@ int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out) {
   }
   out[0] = nlaunched; out[1] = ncols; out[2] = nstrips; out[3] = ntargets; out[4] = ncontrib; out[5] = ndiag_contrib;
   out[6] = h->V.n_nz; out[7] = h->V.ldS; out[8] = h->V.nfree; out[9] = h->V.nblk; out[10] = h->V.E; out[11] = SC.ntiles;
+  return DVM_OK;
+}
+int dvm_ba_solve_info(const dvm_ba* h, int64_t* out) {
+  if (!h || !h->have_problem || !out) return DVM_ERR_STATE;
+  out[0] = h->V.flow && h->fuse_levels ? 1 : 0; out[1] = h->V.n_flow_tasks; out[2] = h->sched.flow_leaves; out[3] = h->V.flow_wgs;
   return DVM_OK;
 }
 int dvm_ba_profile(dvm_ba* h, int enable, double* ms4, int32_t* trials, int32_t* iters) {

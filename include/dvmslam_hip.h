@@ -453,6 +453,13 @@ int64_t dvm_ba_allreduce_doubles(const dvm_ba* h);
  * four phases of a trial; ms4 = {linearise, Schur complement, tile Cholesky + back substitution, landmarks + update + chi2}
  * accumulated since the last enable, over *trials trials / *iters iterations. */
 int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out);
+/* dvm_ba_solve_info: which form of the reduced solve (the replacement of g2o's LinearSolverEigen::solve,
+ * Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:89-112, under BlockSolver::solve, g2o/core/block_solver.hpp:354-486) the current
+ * problem runs: out[4] = {form: 0 = one launch (or two) per elimination-tree level, 1 = the flow form -- the whole factorisation + back
+ * substitution as ONE persistent launch of tile tasks, chosen when the elimination tree is mostly a chain (a loop-closed map) --,
+ * tile tasks of the flow form, chains (= leaves of the elimination tree), workgroups launched}.  Same numbers either way: the two forms
+ * sum in the same order. */
+int dvm_ba_solve_info(const dvm_ba* h, int64_t* out);
 int dvm_ba_profile(dvm_ba* h, int enable, double* ms4, int32_t* trials, int32_t* iters);
 /* per-edge chi2() as g2o reports it after optimize(), and isDepthPositive() (outlier tests of
  * Optimizer.cc:1317-1354); either output may be NULL */

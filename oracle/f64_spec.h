@@ -15,7 +15,15 @@ inline uint32_t hi_word(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (
 inline double with_hi_word(uint32_t hi) { const uint64_t u = (uint64_t)hi << 32; double x; std::memcpy(&x, &u, 8); return x; }
 
 // correctly rounded x^3: products' rounding errors via fma, one final rounding
+#ifdef ORC_LIBM
+}  // namespace orc_spec
+#include <cmath>
+namespace orc_spec {
+inline double cube(double t) { return std::pow(t, 3); }
+inline double cube_spec(double t) {
+#else
 inline double cube(double t) {
+#endif
   const double sq = t * t, sq_err = __builtin_fma(t, t, -sq);
   const double cu = sq * t, cu_err = __builtin_fma(sq, t, -cu);
   return cu + (cu_err + sq_err * t);
@@ -53,7 +61,23 @@ inline int reduce(double x, double& y0, double& y1) {
   return x < 0 ? -n : n;
 }
 inline bool small(double x) { return (hi_word(x) & 0x7fffffffu) <= 0x3fe921fbu; }
-inline double sin(double x) {
+#ifdef ORC_LIBM
+// `make libm` (oracle/Makefile): the oracle as a glibc-linked g2o would compute -- std::sin / std::cos / std::pow(x, 3) exactly where
+// the reference calls them -- for tests/test_oracle_libm.py, which measures how far "bit-identical to the spec oracle" can sit from that
+}  // namespace orc_spec
+#include <cmath>
+namespace orc_spec {
+inline double sin_spec(double x);
+inline double cos_spec(double x);
+inline double sin(double x) { return std::sin(x); }
+inline double cos(double x) { return std::cos(x); }
+#define ORC_SPEC_SIN sin_spec
+#define ORC_SPEC_COS cos_spec
+#else
+#define ORC_SPEC_SIN sin
+#define ORC_SPEC_COS cos
+#endif
+inline double ORC_SPEC_SIN(double x) {
   if (small(x)) return ksin(x, 0.0, false);
   double y0, y1;
   switch (reduce(x, y0, y1) & 3) {
@@ -63,7 +87,7 @@ inline double sin(double x) {
     default: return -kcos(y0, y1);
   }
 }
-inline double cos(double x) {
+inline double ORC_SPEC_COS(double x) {
   if (small(x)) return kcos(x, 0.0);
   double y0, y1;
   switch (reduce(x, y0, y1) & 3) {

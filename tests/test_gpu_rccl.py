@@ -37,9 +37,9 @@ def test_exchange_and_sharded_ba_over_rccl():
     assert rec["ba_calls"] == rec["ba_expected_calls"] and rec["ba_bytes"] > 0
 
 
-def test_bench_distributed_control_flow_over_rccl():
+def test_bench_distributed_control_flow_over_rccl(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--chunks-per-step", "2",
-           "--stream-frames", "256", "--cpu-seconds", "0", "--no-pcie", "--no-exclusive", "--ba-iters", "3"]
+           "--stream-frames", "256", "--cpu-seconds", "0", "--no-pcie", "--no-exclusive", "--ba-iters", "3", "--full-json", str(tmp_path / "full.json")]
     env = _env(29656)
     env["DVM_BENCH_FORCE_DIST"] = "1"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -47,7 +47,8 @@ def test_bench_distributed_control_flow_over_rccl():
     lines = r.stdout.strip().splitlines()
     assert lines[-1].startswith("{"), "the JSON line must be the last thing on stdout (RCCL's banner flushed before it)"
     line = json.loads(lines[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["ba_sharded"]["value"] > 0 and len(lines[-1]) < 6000
+    line = json.load(open(tmp_path / "full.json"))          # the complete record (the contract line carries a summary)
     sh = line["ba_sharded"]
     assert "error" not in sh, sh
     assert sh["backend"].startswith("nccl") and sh["ranks"] == 1 and sh["value"] > 0

@@ -25,8 +25,11 @@ N = 4096
 out = (C.c_longlong * (N * 8))()
 print("rc", capi.lib().dvm_debug_flow_stamps(out, N * 8), "levels", info["levels"], "tiles", info["nz_tiles"])
 v = np.array(out[:], dtype=np.int64).reshape(N, 8)
+np.save(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"flow_stamps_{which}.npy"), v)
 meta = v[:, 6]
 kind = (meta >> 12) & 15; ti = (meta >> 16) & 0xFFFF; tj = (meta >> 32) & 0xFFFF; ncon = (meta >> 48) & 0xFFFF; wg = meta & 0xFFF
+chain = v[3500:3500 + 200].copy()
+v[3500:] = 0
 used = v[:, 0] > 0
 n = int(used.sum())
 t0 = v[used, 0].min()
@@ -38,16 +41,21 @@ d.sort(key=lambda i: v[i, 4])
 print("diagonal tiles by completion: col ncontrib | start  gather_done  in_lds  factored  published | waited(us)  wg xcc")
 for i in d:
     print(f"  col {ti[i]:3d} nc {ncon[i]:3d} | {us(v[i,0]):7.1f} {us(v[i,1]):7.1f} {us(v[i,2]):7.1f} {us(v[i,3]):7.1f} {us(v[i,4]):7.1f} | wait {v[i,5]/100.0:6.1f}  wg {wg[i]} xcc {v[i,7]}")
+print("chain (per column, by factor start): col | factor_start factored  L^-1+T in LDS  X in LDS+stores issued  iteration done | T prefetched")
+cc = [i for i in range(200) if chain[i, 0] > 0]
+cc.sort(key=lambda i: chain[i, 0])
+for i in cc:
+    print(f"  col {i:3d} | {us(chain[i,0]):7.1f} {us(chain[i,1]):7.1f} {us(chain[i,2]) if chain[i,2] else 0:7.1f} {us(chain[i,3]) if chain[i,3] else 0:7.1f} {us(chain[i,4]) if chain[i,4] else 0:7.1f} | {chain[i,6]}")
 pp = [i for i in range(n) if kind[i] == 2]
 pp.sort(key=lambda i: v[i, 4])
 print("PRE tasks by completion: col nc | start gather_done staged stored published | waited")
 for i in pp:
     print(f"  col {ti[i]:3d} nc {ncon[i]:3d} | {us(v[i,0]):7.1f} {us(v[i,1]):7.1f} {us(v[i,2]):7.1f} {us(v[i,3]):7.1f} {us(v[i,4]):7.1f} | wait {v[i,5]/100.0:6.1f}")
-s = [i for i in range(n) if kind[i] == 1]
+s = [i for i in range(n) if kind[i] in (1, 4)]
 print("slices (first / last 40 by completion): (i,k) nc | start gather_done linv_there computed published | waited")
 s.sort(key=lambda i: v[i, 4])
-for i in s[:40] + s[-40:]:
-    print(f"  ({ti[i]:3d},{tj[i]:3d}) nc {ncon[i]:3d} | {us(v[i,0]):7.1f} {us(v[i,1]):7.1f} {us(v[i,2]):7.1f} {us(v[i,3]):7.1f} {us(v[i,4]):7.1f} | wait {v[i,5]/100.0:6.1f}")
+for i in s:
+    print(f"  k{kind[i]} ({ti[i]:3d},{tj[i]:3d}) nc {ncon[i]:3d} | {us(v[i,0]):7.1f} {us(v[i,1]):7.1f} {us(v[i,2]):7.1f} {us(v[i,3]):7.1f} {us(v[i,4]):7.1f} | wait {v[i,5]/100.0:6.1f}")
 b = [i for i in range(n) if kind[i] == 3]
 b.sort(key=lambda i: v[i, 4])
 print("back substitution: col | start flags_there done")
