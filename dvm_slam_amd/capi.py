@@ -588,11 +588,12 @@ class BundleAdjuster:
         return dict(zip(keys, [int(v) for v in out]))
 
     def solve_info(self):
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 6)()
         f = self.L.dvm_ba_solve_info
         f.restype = C.c_int32; f.argtypes = None
         check(f(self.h, out))
-        return dict(form="flow" if out[0] else "levels", flow_tasks=int(out[1]), chains=int(out[2]), workgroups=int(out[3]))
+        return dict(form="flow" if out[0] else "levels", flow_tasks=int(out[1]), chains=int(out[2]), workgroups=int(out[3]), kept_landmarks=int(out[4]),
+                    camera_tiles=int(out[5]))
 
     def profile(self, enable=-1):
         ms = (C.c_double * 4)(); tr = C.c_int32(0); it = C.c_int32(0)

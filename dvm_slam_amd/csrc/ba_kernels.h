@@ -79,6 +79,17 @@ struct BaView {
   int32_t n_nz;
   const int32_t* colstrip_off;  // [ntiles+1] device
   const int32_t* colstrips;     // per column: its strip rows
+  // KEPT LANDMARKS ("border", round 5).  A map whose reduced camera system is ruined by a handful of landmarks -- a few dozen points seen from
+  // places far apart on the trajectory couple camera tiles that nothing else couples: 0.2 % of the landmarks turn the 7-level elimination
+  // tree of a 500-keyframe loop into a 37-level chain -- keeps those landmarks OUT of the Schur complement: they stay unknowns of the
+  // reduced system, 21 to a 64-row tile (3 x 21 rows + one of padding) behind the camera tiles and in front of the rhs row,
+  //     [ S_E  W_K ] [xp  ]   [bp - sum_E W Dinv bl]        S_E: Schur complement over the ELIMINATED landmarks only,
+  //     [ W_K' H_K ] [xl_K] = [bl_K                ]        H_K = Hll + lambda I of the kept ones, W_K their Hpl blocks
+  // -- the same linear system as g2o's (block_solver.hpp:381-486 eliminates every landmark), another elimination order.  kept_slot[l] =
+  // position of landmark l among the kept ones or -1; kept_list the inverse; ncamt = camera tiles (the kept tiles follow).
+  const int32_t* kept_slot;     // [L] or null (nkept = 0)
+  const int32_t* kept_list;     // [nkept]
+  int32_t nkept, ncamt;
   // FLOW form of the solve (k_chol_flow, ba_ordering.h): tile tasks taken through a ticket, factorisation + back substitution in ONE launch
   const int32_t* flow_tasks;    // [n_flow_tasks][8]
   const int32_t* flow_contrib;  // [..][4] flattened contributor lists (ba_ordering.h)

@@ -375,6 +375,12 @@ __device__ __forceinline__ void dinv_apply(const double* H, const double* bl, do
   db[2] = o[6] * bl[0] + o[7] * bl[1] + o[8] * bl[2];
 }
 
+// a KEPT landmark (BaView::kept_slot) is not eliminated: it contributes nothing to the Schur complement or its right-hand side
+__device__ __forceinline__ void dinv_kept(const BaView& V, int l) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) V.Dinv[9 * (size_t)l + k] = 0.0;
+  V.db[3 * (size_t)l] = V.db[3 * (size_t)l + 1] = V.db[3 * (size_t)l + 2] = 0.0;
+}
 // Hll (3x3) and bl per landmark: thread per landmark, edges in input order.
 __device__ __forceinline__ double point_accum_body(const BaView& V, int block, const double* __restrict__ spec) {   // returns max |Hll diagonal|
   const int l = block * 256 + threadIdx.x;
@@ -414,7 +420,10 @@ __device__ __forceinline__ double point_accum_body(const BaView& V, int block, c
   // (Hll + lambda I)^-1 and Dinv bl, dinv_landmark's arithmetic on the same values -- is done here, from registers
   if (spec) {
     const double lambda = *spec;
-    if (lambda >= 0 && V.pt_start[l + 1] != V.pt_start[l]) dinv_apply(H, b, lambda, V.Dinv + 9 * (size_t)l, V.db + 3 * (size_t)l);
+    if (lambda >= 0 && V.pt_start[l + 1] != V.pt_start[l]) {
+      if (V.nkept && V.kept_slot[l] >= 0) dinv_kept(V, l);
+      else dinv_apply(H, b, lambda, V.Dinv + 9 * (size_t)l, V.db + 3 * (size_t)l);
+    }
   }
   return V.pt_start[l + 1] > V.pt_start[l] ? fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8]))) : 0.0;   // (a landmark nobody observes is no vertex)
 }
@@ -503,7 +512,9 @@ __device__ __forceinline__ void clear_tile(const BaView& V, int t) {
   if (ti == tj && ti * 64 < V.n_pad) {
     __syncthreads();
     const int w = threadIdx.x;
-    if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = V.damp_s;
+    if (V.nkept && ti >= V.ncamt) {      // a tile of kept landmarks: 3 rows each, 21 to the tile
+      if (w < 64 && (w >= 63 || (ti - V.ncamt) * 21 + w / 3 >= V.nkept)) base[(size_t)w * V.ldS + w] = V.damp_s;
+    } else if (w < 64 && (w >= V.per_tile * V.dof || ti * V.per_tile + w / V.dof >= V.nfree)) base[(size_t)w * V.ldS + w] = V.damp_s;
   }
 }
 
@@ -536,6 +547,7 @@ __device__ __forceinline__ void dinv_landmark(const BaView& V, int l) {
   const double lambda = ba_lambda(V);
   if (l >= V.L) return;
   if (V.pt_start[l + 1] == V.pt_start[l]) return;  // landmark without observation: not a vertex of the graph
+  if (V.nkept && V.kept_slot[l] >= 0) { dinv_kept(V, l); return; }
   dinv_apply(V.Hll + 9 * (size_t)l, V.bl + 3 * (size_t)l, lambda, V.Dinv + 9 * (size_t)l, V.db + 3 * (size_t)l);
 }
 __global__ void __launch_bounds__(256) k_dinv(BaView V) { dinv_landmark(V, blockIdx.x * 256 + threadIdx.x); }
@@ -727,6 +739,34 @@ __device__ __forceinline__ void schur_rhs_body(const BaView& V, int block) {
   }
 }
 
+// The three rows of kept landmark j (BaView::kept_*): Hll + lambda I on the diagonal, the transposed Hpl block of every observation
+// by a free camera left of it (dvm_ba_set_problem keeps no landmark with two observations from one camera: every block is written
+// once), bl in the rhs row.  The tiles were emptied for this trial like every other non-zero tile.
+__device__ __forceinline__ void schur_kept_body(const BaView& V, int j) {
+  if (j >= V.nkept) return;
+  const int l = V.kept_list[j];
+  const int row0 = 64 * (V.ncamt + j / 21) + 3 * (j % 21);
+  const double lambda = ba_lambda(V);
+  double* const Sr = V.S + (size_t)row0 * V.ldS;
+  const int i0 = V.pt_start[l], i1 = V.pt_start[l + 1];
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += (int)blockDim.x) {
+    const int fi = V.pt_fi[i];
+    if (fi < 0) continue;
+    const double* W = V.e_W + (size_t)V.pt_edges[i] * 18;       // 6 (camera) x 3 (landmark)
+    const int c0 = ba_row(fi);
+#pragma unroll
+    for (int bb = 0; bb < 3; bb++)
+#pragma unroll
+      for (int a = 0; a < 6; a++) Sr[(size_t)bb * V.ldS + c0 + a] = W[3 * a + bb];
+  }
+  if (threadIdx.x < 9) {
+    const int a = threadIdx.x / 3, c = threadIdx.x % 3;
+    if (c <= a) Sr[(size_t)a * V.ldS + row0 + c] = V.Hll[9 * (size_t)l + 3 * a + c] + (a == c ? lambda * V.damp_s : 0.0);
+  } else if (threadIdx.x < 12) {
+    V.S[(size_t)V.n_pad * V.ldS + row0 + (threadIdx.x - 9)] = V.bl[3 * (size_t)l + (threadIdx.x - 9)];
+  }
+}
+
 // The reduced system and its right-hand side in ONE launch (independent of each other; both only need Dinv / db of the
 // prologue): workgroups [0, nb_blk) build the 6x6 blocks, the rest the rhs row.
 // Waves per block: 2 for the global problem (thousands of blocks of ~180 pairs: 12 KB of LDS per wave, every block resident at
@@ -751,6 +791,7 @@ __global__ void __launch_bounds__(64 * kNW) k_schur(BaView V, int nb_blk, int nb
   // group (b % 8) * nb_chunk + b / 8, so an XCD works through a CONTIGUOUS run of the (camera-sorted) block list: the W rows
   // of its ~60 cameras (46 KB each) stay in that L2.
   const int b = (int)blockIdx.x - nb_rhs;
+  if (b >= 8 * nb_chunk) { schur_kept_body(V, b - 8 * nb_chunk); return; }      // the rows of a kept landmark (behind the block workgroups)
   const int g = (b & 7) * nb_chunk + (b >> 3);
   if (g < nb_blk) schur_blocks_body<kSchurWaves>(V, g);
 }
@@ -1058,7 +1099,9 @@ __device__ __forceinline__ void chol_diag_tile(const DiagLds& D, int* __restrict
 #pragma unroll
         for (int c = 0; c < 16; c++) dst[c] = (lane < 16 && c > lane) ? 0.0 : a[c];
       }
-      if (bad && lane == 0) *fail = 1;
+      // (write-through: inside k_chol_flow other workgroups -- other XCDs -- read the flag before the launch ends: a plain store stayed in this
+      //  XCD's L2 and the back substitution wrote x of a failed solve, now and then)
+      if (bad && lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (b >= 1) {
       // beside the panel, no flags (everything is ordered by the panels' barriers): first the trailing updates of the PREVIOUS
       // panel that the current one does not need (sub-blocks right of its block column, see C below), then the pieces of L^-1
@@ -1150,6 +1193,18 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
   }
   DVM_STAMP(17);
 }
+// x of tile column kb, row t (value v) into the compact solution vector: a camera tile holds per_tile unknowns of dof rows; a tile of kept
+// landmarks (kb >= ncamt, BaView::kept_*) 21 landmarks of 3 rows, whose x lives behind the cameras' at 3 * landmark
+__device__ __forceinline__ void write_x(double* __restrict__ x, int kb, int t, double v, int nfree, int per_tile, int dof, int ncamt, int nkept,
+                                        const int32_t* __restrict__ kept_list) {
+  if (nkept > 0 && kb >= ncamt) {
+    const int j = (kb - ncamt) * 21 + t / 3;
+    if (t < 63 && j < nkept) x[dof * (size_t)nfree + 3 * (size_t)kept_list[j] + t % 3] = v;
+    return;
+  }
+  const int cam = kb * per_tile + t / dof;
+  if (t < per_tile * dof && cam < nfree) x[dof * (size_t)cam + t % dof] = v;
+}
 // The TOP PAIR of the elimination order in one workgroup (BaTileSchedule::pair_a / pair_b): column A, whose only tiles below
 // the diagonal are (B, A) and the rhs row, and the root column B.  As separate launches this is diag(A) -> panel solve + update
 // -> diag(B) -> two hops of the back substitution: five dependent kernels whose tiles travel through memory between them
@@ -1160,7 +1215,8 @@ __global__ void __launch_bounds__(256) k_chol_diag(double* __restrict__ S, int l
 // Four tile buffers (BmA -> X, raw (B,A) -> L_B^-1, BmB, L_A^-1) = 133 KB of the CU's 160 KB.  Nothing but x leaves: no one
 // else reads these columns' factor (their descendants need x_A / x_B, which go to xrow like any other column's).
 __global__ void __launch_bounds__(256) k_chol_pair(const double* __restrict__ S, int ldS, int n_pad, int kbA, int kbB, int nfree, int per_tile,
-                                                  int dof, double* __restrict__ xrow, double* __restrict__ x, int* __restrict__ fail) {
+                                                  int dof, double* __restrict__ xrow, double* __restrict__ x, int* __restrict__ fail,
+                                                  int ncamt, int nkept, const int32_t* __restrict__ kept_list) {
   __shared__ __attribute__((aligned(16))) double smem[16 * NB + 4 * 16 * 17 + 16 * 16 + 4 * NB * LP + 10 * NB];
   lds_f64* const lds = (lds_f64*)smem;
   lds_f64 (*const Pcol)[NB] = (lds_f64 (*)[NB])lds;
@@ -1277,8 +1333,7 @@ __global__ void __launch_bounds__(256) k_chol_pair(const double* __restrict__ S,
     const int t = tid & 63, kb = tid < NB ? kbA : kbB;
     const double v = tid < NB ? vx0[t] : vx1[t];
     __hip_atomic_store(xrow + kb * NB + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int cam = kb * per_tile + t / dof;
-    if (t < per_tile * dof && cam < nfree && good) x[dof * (size_t)cam + t % dof] = v;
+    if (good) write_x(x, kb, t, v, nfree, per_tile, dof, ncamt, nkept, kept_list);
   }
 }
 
@@ -1643,7 +1698,7 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
                                                         const double* __restrict__ Linv_all,
                                                         const int32_t* __restrict__ colstrip_off,
                                                         const int32_t* __restrict__ colstrips, int32_t* __restrict__ sync, int gen,
-                                                        int* __restrict__ fail, int n_raw) {
+                                                        int* __restrict__ fail, int n_raw, int ncamt, int nkept, const int32_t* __restrict__ kept_list) {
   __shared__ double yk[NB];
   __shared__ double xi[NB];
   __shared__ double part[4][NB];
@@ -1725,10 +1780,9 @@ __global__ void __launch_bounds__(256) k_chol_backsolve(const double* __restrict
   if (tid < NB) {   // one wave
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     __hip_atomic_store(xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // replaces the tag: the word is the hand-off
-    const int cam = kb * per_tile + tid / dof;
     // g2o's linear solver leaves _x untouched when the factorisation fails (linear_solver_eigen.h:89-112): x keeps the last
     // successful solve's values, which the LM loop then applies all the same (optimization_algorithm_levenberg.cpp:111-127)
-    if (tid < per_tile * dof && cam < nfree && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) x[dof * (size_t)cam + tid % dof] = v;
+    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) write_x(x, kb, tid, v, nfree, per_tile, dof, ncamt, nkept, kept_list);
   }
 }
 
@@ -1812,6 +1866,7 @@ struct FlowArgs {
   const int32_t* cols; double* xrow; double* x;
   const int32_t *colstrip_off, *colstrips, *colstrip_id;
   int nfree, per_tile, dof;
+  int ncamt, nkept; const int32_t* kept_list;
 };
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 // bounded wait of ONE lane for a word to reach the solve's sequence number; a timeout marks the trial (fail = 2: the host repeats it with
@@ -1911,7 +1966,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
     if (t < A.n_factor) {
       // ------------------------------------------------------------------------------------------ a tile (or half tile) of the factor
       const int32_t* T = A.tasks + 8 * (size_t)t;
-      const int kind = T[0], ti = T[1], tj = T[2], half = T[3], c0 = T[4], c1 = T[5], self = T[6], pre = T[7];
+      const int kind = T[0], ti = T[1], tj = T[2], half = T[3], c0 = T[4], c1 = T[5], self = T[6];
       const bool slice = kind == 1 || kind == 4;
       const int i0 = ti * NB + (slice ? 32 * half : 0), j0 = tj * NB;
       const int rw = min(slice ? 32 : NB, A.n1 - i0);      // rows of the region that exist (the rhs row: one)
@@ -2308,9 +2363,8 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
       if (tid < NB) {
         const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         __hip_atomic_store(A.xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // replaces the tag: the word is the hand-off
-        const int cam = kb * A.per_tile + tid / A.dof;
         // (g2o's linear solver leaves _x untouched when the factorisation fails: see k_chol_backsolve)
-        if (tid < A.per_tile * A.dof && cam < A.nfree && __hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) A.x[A.dof * (size_t)cam + tid % A.dof] = v;
+        if (__hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) write_x(A.x, kb, tid, v, A.nfree, A.per_tile, A.dof, A.ncamt, A.nkept, A.kept_list);
       }
       DVM_FSTMP(t, 4);
     }
@@ -2388,7 +2442,9 @@ __global__ void __launch_bounds__(256) k_point_backsub(BaView V, BaPublish pub, 
         u[0] = D[0] * c[0] + D[1] * c[1] + D[2] * c[2];
         u[1] = D[3] * c[0] + D[4] * c[1] + D[5] * c[2];
         u[2] = D[6] * c[0] + D[7] * c[1] + D[8] * c[2];
-        if (failed) { u[0] = xl[0]; u[1] = xl[1]; u[2] = xl[2]; }     // (block_solver.hpp:445-446 returns before the landmark part)
+        // (block_solver.hpp:445-446 returns before the landmark part); a kept landmark is an unknown of the reduced system: the back
+        // substitution has written its x already
+        if (failed || (V.nkept && V.kept_slot[l] >= 0)) { u[0] = xl[0]; u[1] = xl[1]; u[2] = xl[2]; }
         const double* X = V.points + 3 * (size_t)l;
         double* Xn = V.points_new + 3 * (size_t)l;
 #pragma unroll
@@ -3393,8 +3449,8 @@ static void launch_schur_kernel(hipStream_t s, const BaView& V, int* fail_reset)
   const int nb_blk = V.nblk, nb_chunk = cdiv(nb_blk, 8);   // one workgroup per 6x6 block
   const int nw = V.schur_wide ? kSchurWavesWide : kSchurWaves;
   const int nb_rhs = ((V.schur_wide ? V.nfree : cdiv(V.nfree, nw)) + 7) & ~7;   // (wide: a workgroup per camera) a multiple of 8 keeps the XCD phase of the block workgroups
-  if (V.schur_wide) hipLaunchKernelGGL(k_schur<kSchurWavesWide>, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWavesWide), 0, s, V, nb_blk, nb_chunk, nb_rhs, fail_reset);
-  else hipLaunchKernelGGL(k_schur<kSchurWaves>, dim3(nb_rhs + 8 * nb_chunk), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, fail_reset);
+  if (V.schur_wide) hipLaunchKernelGGL(k_schur<kSchurWavesWide>, dim3(nb_rhs + 8 * nb_chunk + V.nkept), dim3(64 * kSchurWavesWide), 0, s, V, nb_blk, nb_chunk, nb_rhs, fail_reset);
+  else hipLaunchKernelGGL(k_schur<kSchurWaves>, dim3(nb_rhs + 8 * nb_chunk + V.nkept), dim3(64 * kSchurWaves), 0, s, V, nb_blk, nb_chunk, nb_rhs, fail_reset);
 }
 void ba_launch_schur(hipStream_t s, const BaView& V, int* d_fail) {
   const int nb_dinv = cdiv(V.L, 256);
@@ -3423,7 +3479,7 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
     A.flags = V.flow_flags; A.nstrips = V.n_strips_total; A.ntiles = V.n_tiles_total;
     A.gen = solve_seq; A.fail = d_fail;
     A.cols = V.cols; A.xrow = V.xrow; A.x = V.x; A.colstrip_off = V.colstrip_off; A.colstrips = V.colstrips; A.colstrip_id = V.colstrip_id;
-    A.nfree = V.nfree; A.per_tile = V.per_tile; A.dof = V.dof;
+    A.nfree = V.nfree; A.per_tile = V.per_tile; A.dof = V.dof; A.ncamt = V.ncamt; A.nkept = V.nkept; A.kept_list = V.kept_list;
     const int wgs = std::max(1, std::min(A.n_factor + A.n_back, V.flow_wgs > 0 ? V.flow_wgs : 256));
     hipLaunchKernelGGL(k_chol_flow, dim3(wgs), dim3(256), 0, s, A);
     return;
@@ -3477,14 +3533,14 @@ void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int s
   int n_raw = V.n_root_raw;
   if (pair) {
     // (the slots of xrow that the remaining columns wait on were tagged by the first strip launch above; these two are written for good)
-    hipLaunchKernelGGL(k_chol_pair, dim3(1), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.pair_a, V.pair_b, V.nfree, V.per_tile, V.dof, V.xrow, V.x, d_fail);
+    hipLaunchKernelGGL(k_chol_pair, dim3(1), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.pair_a, V.pair_b, V.nfree, V.per_tile, V.dof, V.xrow, V.x, d_fail, V.ncamt, V.nkept, V.kept_list);
     ncols -= 2;          // `cols` lists the levels in order: the pair's columns are its last two entries
     n_raw = 0;
   }
   if (ncols > 0)
     hipLaunchKernelGGL(k_chol_backsolve, dim3(ncols), dim3(256), 0, s, V.S, V.ldS, V.n_pad, V.nfree, V.per_tile, V.dof, V.cols, ncols,
                        V.S + (size_t)V.n_pad * V.ldS, V.xrow, V.x, V.Linv, V.colstrip_off, V.colstrips, reinterpret_cast<int32_t*>(V.ytmp),
-                       solve_seq, d_fail, n_raw);
+                       solve_seq, d_fail, n_raw, V.ncamt, V.nkept, V.kept_list);
 }
 void ba_launch_backsub_update(hipStream_t s, const BaView& V, const BaPublish& pub, const int* d_fail) {
   const int nb_pose = cdiv(std::max(V.nfree, 1), 256);

@@ -284,7 +284,6 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   std::vector<int32_t> dense_id;
   std::unordered_map<uint64_t, int32_t> sparse_id;
   const bool dense = (size_t)nf * nf <= ((size_t)1 << 24);
-  if (dense) dense_id.assign((size_t)nf * nf, -1);
   std::vector<std::pair<int32_t, int32_t>> pair_cams;          // id -> (hi, lo) natural indices, in first-seen order
   auto pair_slot = [&](int hi, int lo) -> int32_t& {
     if (dense) return dense_id[(size_t)hi * nf + lo];
@@ -292,28 +291,91 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     if (it == sparse_id.end()) it = sparse_id.emplace(((uint64_t)hi << 32) | (uint32_t)lo, -1).first;
     return it->second;
   };
-  auto touch = [&](int x, int y) {
+  auto touch = [&](int x, int y) -> int32_t {
     int32_t& id = pair_slot(std::max(x, y), std::min(x, y));
     if (id < 0) { id = (int32_t)pair_cams.size(); pair_cams.push_back({std::max(x, y), std::min(x, y)}); }
+    return id;
   };
-  for (int i = 0; i < nf; i++) touch(i, i);
   std::vector<int32_t> e_cam(E);
   for (int k = 0; k < E; k++) e_cam[k] = nat_of[e_pose[k]];
-  for (int l = 0; l < L; l++)
-    for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
-      const int ca = e_cam[pt_edges[a]];
-      if (ca < 0) continue;
-      for (int b = pt_start[l]; b < a; b++) {
-        const int cb = e_cam[pt_edges[b]];
-        if (cb >= 0) touch(ca, cb);
+  // KEPT LANDMARKS (ba_kernels.h, BaView::kept_*): when the elimination tree of the tile factorisation comes out deep (>= 12 levels: a
+  // chain, not a bush) and a few landmarks are to blame -- landmarks that couple camera pairs hardly anything else couples (<= 2
+  // co-observed landmarks) --, those landmarks (at most 63: three tiles) are left out of the Schur complement and stay unknowns of the
+  // reduced system; the structure is then built again without their couplings.  DVM_BA_BORDER=0 switches it off (A/B, tests).
+  std::vector<int32_t> kept_slot(L, -1), kept_list;
+  const bool try_border = world == 1 && nf > 60 && !(std::getenv("DVM_BA_BORDER") && std::atoi(std::getenv("DVM_BA_BORDER")) == 0);
+  std::vector<int> cam_pos;
+  int levels_all = 0;
+  for (int pass = 0;; pass++) {
+    if (dense) dense_id.assign((size_t)nf * nf, -1); else sparse_id.clear();
+    pair_cams.clear();
+    std::vector<int32_t> pair_cnt;                               // per pair: landmarks that see both cameras
+    for (int i = 0; i < nf; i++) touch(i, i);
+    for (int l = 0; l < L; l++) {
+      if (kept_slot[l] >= 0) continue;
+      for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
+        const int ca = e_cam[pt_edges[a]];
+        if (ca < 0) continue;
+        for (int b = pt_start[l]; b < a; b++) {
+          const int cb = e_cam[pt_edges[b]];
+          if (cb < 0) continue;
+          const int32_t id = touch(ca, cb);
+          if (pass == 0 && try_border) { if ((size_t)id >= pair_cnt.size()) pair_cnt.resize(pair_cams.size(), 0); pair_cnt[id]++; }
+        }
       }
     }
-  std::vector<std::vector<int>> cam_adj(nf);
-  for (const auto& pc : pair_cams)
-    if (pc.first != pc.second) { cam_adj[pc.first].push_back(pc.second); cam_adj[pc.second].push_back(pc.first); }
-  mark("incidence + adjacency");
-  const std::vector<int> cam_pos = ba_order_cameras(cam_adj);
-  mark("camera order");
+    std::vector<std::vector<int>> cam_adj(nf);
+    for (const auto& pc : pair_cams)
+      if (pc.first != pc.second) { cam_adj[pc.first].push_back(pc.second); cam_adj[pc.second].push_back(pc.first); }
+    if (pass == 0) mark("incidence + adjacency");
+    cam_pos = ba_order_cameras(cam_adj);
+    if (pass == 0) mark("camera order");
+    if (!try_border || pass == 2) break;
+    // how deep does the tree of this structure come out?
+    const int nct = (nf + kCamsPerTile - 1) / kCamsPerTile, nbt0 = ((int)kept_list.size() + 20) / 21;
+    std::vector<std::vector<char>> T0(nct + nbt0 + 1, std::vector<char>(nct + nbt0 + 1, 0));
+    for (const auto& pc : pair_cams) {
+      const int t1 = cam_pos[pc.first] / kCamsPerTile, t2 = cam_pos[pc.second] / kCamsPerTile;
+      T0[std::max(t1, t2)][std::min(t1, t2)] = 1;
+    }
+    for (size_t j = 0; j < kept_list.size(); j++) {
+      const int l = kept_list[j], tb = nct + (int)j / 21;
+      T0[tb][tb] = 1;
+      for (int a = pt_start[l]; a < pt_start[l + 1]; a++) if (e_cam[pt_edges[a]] >= 0) T0[tb][cam_pos[e_cam[pt_edges[a]]] / kCamsPerTile] = 1;
+    }
+    const int levels = ba_tile_schedule(T0).nlevels;
+    if (pass == 1) {
+      if (4 * levels <= 3 * levels_all) break;                   // the tree is at least a quarter shorter: keep them
+      std::fill(kept_slot.begin(), kept_slot.end(), -1); kept_list.clear();      // no gain: the plain structure, once more
+      pass = 1;                                                   // (-> pass 2: build and leave)
+      continue;
+    }
+    levels_all = levels;
+    if (levels < 12) break;
+    // the landmarks to blame, by the number of weak camera pairs each one is the (near) only reason for
+    std::vector<std::pair<int32_t, int32_t>> cand;               // (score, landmark)
+    for (int l = 0; l < L; l++) {
+      int score = 0;
+      bool dup = false;
+      for (int a = pt_start[l]; a < pt_start[l + 1] && !dup; a++) {
+        const int ca = e_cam[pt_edges[a]];
+        if (ca < 0) continue;
+        for (int b = pt_start[l]; b < a; b++) {
+          const int cb = e_cam[pt_edges[b]];
+          if (cb < 0) continue;
+          if (cb == ca) { dup = true; break; }                  // two observations from one camera: its border block would be written twice
+          if (pair_cnt[pair_slot(std::max(ca, cb), std::min(ca, cb))] <= 2) score++;
+        }
+      }
+      if (score > 0 && !dup) cand.push_back({score, l});
+    }
+    if (cand.empty()) break;
+    std::sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+    if (cand.size() > 63) cand.resize(63);
+    std::sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.second < y.second; });
+    for (const auto& c : cand) { kept_slot[c.second] = (int32_t)kept_list.size(); kept_list.push_back(c.second); }
+    mark("kept landmarks chosen");
+  }
   std::vector<int32_t> pidx(P, -1), free_pose(nf);
   for (int a = 0; a < nf; a++) { pidx[nat_pose[a]] = cam_pos[a]; free_pose[cam_pos[a]] = nat_pose[a]; }
   // non-zero lower blocks (i1 >= i2) in ascending (i1, i2) order -- k_schur deals contiguous runs of this list to the XCDs
@@ -349,6 +411,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   recs.reserve((size_t)E * 4);
   for (int l = 0; l < L; l++) {
     if (world > 1 && l % world != rank) continue;
+    if (kept_slot[l] >= 0) continue;                 // not eliminated: no term in the Schur complement
     for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
       const int k1 = pt_edges[a], c1 = e_cam[k1];
       if (c1 < 0) continue;
@@ -470,8 +533,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   }
   mark("landmark chunks");
   // ---- tile space: 10 whole cameras per 64-row tile, one extra tile for the augmented rhs row
-  const int ncamt = (V.nfree + kCamsPerTile - 1) / kCamsPerTile, nkb = ncamt + 1;
-  V.n_pad = 64 * ncamt;
+  const int ncamt = (V.nfree + kCamsPerTile - 1) / kCamsPerTile, nkeptt = ((int)kept_list.size() + 20) / 21, nkb = ncamt + nkeptt + 1;
+  V.ncamt = ncamt; V.nkept = (int)kept_list.size();
+  V.n_pad = 64 * (ncamt + nkeptt);
   V.per_tile = kCamsPerTile; V.dof = 6;
   V.ldS = 64 * nkb;
   // ---- symbolic tile Cholesky + level schedule.  SLAM reduced camera matrices are banded along the trajectory plus
@@ -481,6 +545,14 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   for (size_t b = 0; b < blk_i1.size(); b++) {
     const int tr = blk_i1[b] / kCamsPerTile, tc = blk_i2[b] / kCamsPerTile;
     T[std::max(tr, tc)][std::min(tr, tc)] = 1;
+  }
+  for (size_t j = 0; j < kept_list.size(); j++) {     // the tiles of the kept landmarks: coupled to the tiles of the cameras that see them
+    const int l = kept_list[j], tb = ncamt + (int)j / 21;
+    T[tb][tb] = 1;
+    for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
+      const int c = e_cam[pt_edges[a]];
+      if (c >= 0) T[tb][cam_pos[c] / kCamsPerTile] = 1;
+    }
   }
   mark("block arrays");
   h->sched = ba_tile_schedule(T);
@@ -535,6 +607,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   ok(h->upload(&V.cols, SC.cols)); ok(h->upload(&V.strips, SC.strips)); ok(h->upload(&V.targets, SC.targets));
   ok(h->upload(&V.contrib, SC.contrib)); ok(h->upload(&V.colstrip_off, SC.colstrip_off)); ok(h->upload(&V.colstrips, SC.colstrips));
   ok(h->upload(&V.contrib_strip, SC.contrib_strip));
+  if (V.nkept) { ok(h->upload(&V.kept_slot, kept_slot)); ok(h->upload(&V.kept_list, kept_list)); }
   // the flow form of the solve (k_chol_flow): task list, per-tile level ranges, flags (zeroed once: they are compared with the solve's sequence number)
   ok(h->upload(&V.flow_tasks, SC.flow_tasks)); ok(h->upload(&V.flow_contrib, SC.flow_contrib)); ok(h->upload(&V.flow_col, SC.flow_col)); ok(h->upload(&V.colstrip_id, SC.colstrip_id));
   V.n_flow_tasks = (int)(SC.flow_tasks.size() / 8); V.n_strips_total = (int)(SC.strips.size() / 2); V.n_tiles_total = nkb;
@@ -663,7 +736,7 @@ int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out) {
 }
 int dvm_ba_solve_info(const dvm_ba* h, int64_t* out) {
   if (!h || !h->have_problem || !out) return DVM_ERR_STATE;
-  out[0] = h->V.flow && h->fuse_levels ? 1 : 0; out[1] = h->V.n_flow_tasks; out[2] = h->sched.flow_leaves; out[3] = h->V.flow_wgs;
+  out[0] = h->V.flow && h->fuse_levels ? 1 : 0; out[1] = h->V.n_flow_tasks; out[2] = h->sched.flow_leaves; out[3] = h->V.flow_wgs; out[4] = h->V.nkept; out[5] = h->V.ncamt;
   return DVM_OK;
 }
 int dvm_ba_profile(dvm_ba* h, int enable, double* ms4, int32_t* trials, int32_t* iters) {

@@ -69,12 +69,13 @@ PROBLEMS = {
 def test_flow_equals_level_launches_bit_for_bit(name):
     pr = synth.ba_problem(**PROBLEMS[name])
     iters = 6 if len(pr["poses"]) >= 500 else 8
-    lvl, info_l = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "0", "DVM_BA_NO_PAIR": "1", "DVM_BA_NO_ROOT_RAW": "1", "DVM_BA_NO_WINDOW": "1"}, rounds=2)
-    flo, info_f = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "1", "DVM_BA_NO_WINDOW": "1"}, rounds=2)
+    # (DVM_BA_BORDER=0: the deep trees are what this file is about)
+    lvl, info_l = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "0", "DVM_BA_NO_PAIR": "1", "DVM_BA_NO_ROOT_RAW": "1", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"}, rounds=2)
+    flo, info_f = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "1", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"}, rounds=2)
     assert info_l["levels"] == info_f["levels"] and info_l["nz_tiles"] == info_f["nz_tiles"]
     _same_bits(lvl, flo, name)
     # the default level launches (top pair in one workgroup: another summation order in its 2-column solve): same trial sequence, 1e-9
-    dfl, _ = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "0", "DVM_BA_NO_WINDOW": "1"}, rounds=2)
+    dfl, _ = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "0", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"}, rounds=2)
     for (Pa, Xa, sa, _), (Pb, Xb, sb, _) in zip(dfl, flo):
         assert sa["trials"] == sb["trials"]
         assert np.abs(Pa - Pb).max() < 1e-9 and np.abs(Xa - Xb).max() < 1e-9
@@ -86,7 +87,7 @@ def test_flow_matches_oracle(oracle, name, delta):
     iters = 3 if len(pr["poses"]) >= 500 else 8
     e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
     Po, Xo, so, chio = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, iters)
-    (Pg, Xg, sg, chig), = _run(pr, delta, iters, {"DVM_BA_FLOW": "1", "DVM_BA_NO_WINDOW": "1"})[0]
+    (Pg, Xg, sg, chig), = _run(pr, delta, iters, {"DVM_BA_FLOW": "1", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"})[0]
     assert sg["iterations"] == so["iterations"] and sg["trials"] == so["trials"] and sg["stop_reason"] == so["stop_reason"]
     assert np.allclose(sg["chi2"], so["chi2"], rtol=1e-9)
     assert np.abs(Pg - Po).max() < 1e-6 and np.abs(Xg - Xo).max() < 1e-6, (np.abs(Pg - Po).max(), np.abs(Xg - Xo).max())
@@ -139,3 +140,48 @@ def test_flow_concurrent_handles_make_progress():
     finally:
         os.environ.pop("DVM_BA_FLOW", None)
         os.environ.pop("DVM_BA_NO_WINDOW", None)
+
+
+# ---------------------------------------------------------------------------------------------- kept landmarks ("border")
+@pytest.mark.parametrize("name,delta", [("loop500", DELTA), ("loop500", 0.0), ("web120", DELTA)])
+def test_kept_landmarks_same_solution_shorter_tree(oracle, name, delta):
+    """A few landmarks seen from far apart make the elimination tree a chain (loop500: 40 of 20 000 landmarks, 37 levels).  Left out of
+    the Schur complement and kept as unknowns of the reduced system (BaView::kept_*), the tree is a bush again -- and the solution is the
+    same: against the run with DVM_BA_BORDER=0 and against the oracle within the accuracy contract, identical LM trial sequences."""
+    pr = synth.ba_problem(**PROBLEMS[name])
+    iters = 4 if len(pr["poses"]) >= 500 else 8
+    (Pk, Xk, sk, chik), = _run(pr, delta, iters, {"DVM_BA_NO_WINDOW": "1"})[0]
+    info_k = _info(pr, delta, {})
+    (Pn, Xn, sn, chin), = _run(pr, delta, iters, {"DVM_BA_BORDER": "0", "DVM_BA_NO_WINDOW": "1"})[0]
+    info_n = _info(pr, delta, {"DVM_BA_BORDER": "0"})
+    assert info_k[1]["kept_landmarks"] > 0 and info_n[1]["kept_landmarks"] == 0
+    assert info_k[0]["levels"] <= 0.75 * info_n[0]["levels"], (info_k, info_n)
+    assert sk["trials"] == sn["trials"] and sk["iterations"] == sn["iterations"]
+    assert np.abs(Pk - Pn).max() < 1e-7 and np.abs(Xk - Xn).max() < 1e-7, (np.abs(Pk - Pn).max(), np.abs(Xk - Xn).max())
+    assert np.allclose(sk["chi2"], sn["chi2"], rtol=1e-10) and np.allclose(chik, chin, rtol=1e-6, atol=1e-9)
+    e = oracle.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+    Po, Xo, so, _ = oracle.ba_optimize(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta, iters)
+    assert sk["trials"] == so["trials"] and np.abs(Pk - Po).max() < 1e-6 and np.abs(Xk - Xo).max() < 1e-6
+
+
+def _info(pr, delta, env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+        ba = capi.BundleAdjuster()
+        ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+        out = (ba.schedule_info(), ba.solve_info())
+        ba.close()
+        return out
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_ring_keeps_no_landmark():
+    pr = synth.ba_problem()
+    assert _info(pr, DELTA, {})[1]["kept_landmarks"] == 0
