@@ -82,7 +82,7 @@ def run(device: int, iters: int = 10, cpu_seconds: float = 6.0, prewarm_s: float
         import os
         import sys
         root = os.path.dirname(os.path.abspath(__file__))
-        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
             try:
                 fold = json.load(open(os.path.join(root, "profiles", cand)))
                 break

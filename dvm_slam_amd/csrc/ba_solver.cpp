@@ -804,11 +804,17 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     w.poses_out = po.data(); w.points_out = xo.data(); w.edge_chi2_out = h->ws_chi2.data(); w.depth_positive_out = h->ws_depth.data();
     dvm_ba_stats ws;
     const int rc = dvm_ba_optimize_windows_impl(h->device, &w, 1, stop_flag, &ws, /*normalize_input=*/false);
-    if (rc != DVM_OK) return rc;
-    h->ws_poses.swap(po); h->ws_points.swap(xo);
-    h->win_device_stale = true;
-    if (st) { *st = ws; st->ms_structure = h->ms_structure; }
-    return DVM_OK;
+    if (rc == DVM_ERR_CAPACITY && !h->win_device_stale) {
+      // what the sequential-order kernel cannot hold (a landmark with more rows than a chunk: duplicate observations; an index block
+      // beyond its staging area) the tile solver can: this problem is its from now on (round-4 advice)
+      h->win_mode = false;
+    } else {
+      if (rc != DVM_OK) return rc;
+      h->ws_poses.swap(po); h->ws_points.swap(xo);
+      h->win_device_stale = true;
+      if (st) { *st = ws; st->ms_structure = h->ms_structure; }
+      return DVM_OK;
+    }
   }
   if (h->win_mode && h->win_device_stale) {      // the tile solver takes over (edge flags, profiling): it continues from the window kernel's state
     DVM_HIP(hipStreamSynchronize(s));
@@ -1236,7 +1242,10 @@ struct BaPool {
   }
   void give(int device, dvm_ba* h) {
     std::lock_guard<std::mutex> lock(m);
-    if (idle.size() < 64) { idle.emplace_back(device, h); return; }
+    // at most 8 idle handles a device (each still holds its last problem's device and pinned buffers: 64 of them were the process's for good)
+    int same = 0;
+    for (const auto& e : idle) same += e.first == device;
+    if (same < 8) { idle.emplace_back(device, h); return; }
     dvm_ba_destroy(h);
   }
 };
@@ -1283,6 +1292,7 @@ extern "C" int dvm_ba_optimize_batch(int device, const dvm_ba_window* windows, i
   T = std::max(1, std::min(T, K));
   std::atomic<int> next{0};
   std::vector<int> rcs((size_t)K, DVM_OK);
+  std::vector<char> done((size_t)K, 0);
   std::vector<std::string> errs((size_t)T);
   std::vector<int> trc((size_t)T, DVM_OK);
   auto work = [&](int t) {
@@ -1294,6 +1304,7 @@ extern "C" int dvm_ba_optimize_batch(int device, const dvm_ba_window* windows, i
       const int k = next.fetch_add(1);
       if (k >= K) break;
       rcs[k] = solve_one_window(h, windows[k], stop_flag, stats ? &stats[k] : nullptr);
+      done[k] = 1;
       if (rcs[k] != DVM_OK && errs[t].empty()) errs[t] = "window " + std::to_string(k) + ": " + last_error_cstr();
     }
     ba_pool().give(device, h);
@@ -1302,8 +1313,10 @@ extern "C" int dvm_ba_optimize_batch(int device, const dvm_ba_window* windows, i
   for (int t = 1; t < T; t++) pool.emplace_back(work, t);
   work(0);
   for (auto& th : pool) th.join();
-  for (int t = 0; t < T; t++)
-    if (trc[t] != DVM_OK) { set_error("dvm_ba_optimize_batch: " + errs[t]); return trc[t]; }
+  // a worker that could not start (no handle, no device) is an error only if windows were left unsolved: the other workers drain the list
+  if (!std::all_of(done.begin(), done.end(), [](char d) { return d != 0; }))
+    for (int t = 0; t < T; t++)
+      if (trc[t] != DVM_OK) { set_error("dvm_ba_optimize_batch: " + errs[t]); return trc[t]; }
   for (int k = 0; k < K; k++)
     if (rcs[k] != DVM_OK) {
       for (int t = 0; t < T; t++) if (!errs[t].empty()) { set_error("dvm_ba_optimize_batch: " + errs[t]); break; }

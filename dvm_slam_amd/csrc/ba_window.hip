@@ -1017,12 +1017,14 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   const size_t lds_bytes = sizeof(double) * lds_doubles;
   if (lds_bytes > 160 * 1024) { set_error("dvm_ba_optimize_windows: a window needs more than 160 KB of LDS"); return DVM_ERR_CAPACITY; }
   DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, 0, st.ptr<BaWin>(views_slot), sw.d);
+  // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
+  // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
+  hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
   if (stop_flag) {                     // g2o's forceStopFlag: written by another thread while the optimisation runs (LocalMapping.cc:305,359)
     hipEvent_t ev;
     DVM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    DVM_HIP(hipEventRecord(ev, 0));
+    DVM_HIP(hipEventRecord(ev, st.stream()));
     while (hipEventQuery(ev) == hipErrorNotReady) *sw.h = *stop_flag ? 1 : 0;
     hipEventDestroy(ev);
   }
@@ -1062,7 +1064,7 @@ int dvm_f64_spec_eval(int device, const double* x, int n, double* out) {
   Stage st;
   const int ix = st.in(x, 8 * (size_t)n), io = st.out(out, 24 * (size_t)n);
   if ((rc = st.upload()) != DVM_OK) return rc;
-  hipLaunchKernelGGL(k_f64_spec, dim3((n + 255) / 256), dim3(256), 0, 0, st.ptr<double>(ix), n, st.ptr<double>(io));
+  hipLaunchKernelGGL(k_f64_spec, dim3((n + 255) / 256), dim3(256), 0, st.stream(), st.ptr<double>(ix), n, st.ptr<double>(io));
   DVM_HIP(hipGetLastError());
   return st.download();
 }

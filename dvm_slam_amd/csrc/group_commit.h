@@ -3,8 +3,8 @@
 // K agents that share a GPU make the reference's per-frame calls from K tracking threads.  Issued one by one those are K chains of small
 // launches that serialise in the runtime; the same work as ONE batched launch costs little more than a single call.  The protocol that
 // turns the one into the other without changing what a caller sees:
-//   join()    a caller takes the next slot of the COLLECTING lane (opening a free lane if none collects); calls whose shape key differs
-//             from the collecting batch's, or that find it full, wait for the next one;
+//   join()    a caller takes the next slot of the lane that COLLECTS calls of its shape key (opening a free lane if none does: one collecting
+//             lane per shape); a call that finds its lane full and no lane free waits for the next state change;
 //   (the caller writes its inputs into its slot -- outside the lock, all callers at once)
 //   arrive()  the caller that took slot 0 LEADS the batch: it waits until the batch is full or nobody has joined for `window_us`, closes
 //             it (the other lane starts collecting), waits until every joined caller has written its inputs, and returns true -- the
@@ -48,22 +48,34 @@ struct GroupCommit {
     std::unique_lock<std::mutex> lk(m);
     inside++;
     for (;;) {
-      if (lane[cur].state == Lane::RUN || lane[cur].state == Lane::DONE)   // the lane we were sent to is busy: any free one will do
-        for (int l = 0; l < kLanes; l++)
-          if (lane[l].state == Lane::FREE) { cur = l; break; }
-      Lane& C = lane[cur];
-      if (C.state == Lane::FREE) {
-        const int rc = open(cur);
-        if (rc != 0) { inside--; return rc; }
-        C.state = Lane::COLLECT; C.count = 0; C.copied = 0; C.readers = 0; C.rc = 0; C.err.clear();
-        std::memcpy(C.key, key, sizeof(C.key));
+      // a collecting lane of THIS shape with room (the current one first); else any free lane is opened for it -- one collecting lane per
+      // shape, so that agents with different image sizes / cameras / bounds batch side by side instead of queueing behind each other's
+      // batches (round-4 advice: a minority shape could starve while free lanes stood by)
+      int pick = -1;
+      for (int d = 0; d < kLanes && pick < 0; d++) {
+        const int l = (cur + d) % kLanes;
+        if (lane[l].state == Lane::COLLECT && lane[l].count < max_batch && std::memcmp(lane[l].key, key, sizeof(lane[l].key)) == 0) pick = l;
       }
-      if (C.state == Lane::COLLECT && C.count < max_batch && std::memcmp(C.key, key, sizeof(C.key)) == 0) {
-        li = cur; slot = C.count++; C.last_join = clock::now();
+      if (pick < 0)
+        for (int d = 0; d < kLanes; d++) {
+          const int l = (cur + d) % kLanes;
+          if (lane[l].state != Lane::FREE) continue;
+          const int rc = open(l);
+          if (rc != 0) { inside--; return rc; }
+          Lane& C = lane[l];
+          C.state = Lane::COLLECT; C.count = 0; C.copied = 0; C.readers = 0; C.rc = 0; C.err.clear();
+          std::memcpy(C.key, key, sizeof(C.key));
+          if (lane[cur].state != Lane::COLLECT) cur = l;
+          pick = l;
+          break;
+        }
+      if (pick >= 0) {
+        Lane& C = lane[pick];
+        li = pick; slot = C.count++; C.last_join = clock::now();
         if (C.count == max_batch) C.cv.notify_all();   // full: the leader need not sit out its window
         return 0;
       }
-      cv_join.wait(lk);   // the collecting batch is full / of another shape and no lane is free: the next state change wakes us
+      cv_join.wait(lk);   // every lane is busy or collects another shape at capacity: the next state change wakes us
     }
   }
   bool arrive(int li, int slot) {

@@ -22,7 +22,7 @@ def _declared():
 
 def test_library_exports_every_declared_symbol(capi):
     lib = capi.lib()
-    names = _declared()
+    names = [n for n in _declared() if not n.startswith("dvm_exchange_")]      # (include/dvmslam_rccl.h: its own library, below)
     assert len(names) >= 55 and "dvm_wire_validate" in names and "dvm_bowdb_query" in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol(capi):
     exported = set(re.findall(r" T (dvm_[a-z0-9_]+)", out))
     assert set(names) <= exported
     assert lib.dvm_version().decode().startswith("dvmslam-hip")
+
+
+def test_rccl_library_exports_every_declared_symbol():
+    """include/dvmslam_rccl.h is the C interface of libdvmslam_rccl.so (the inter-agent exchange for a C++ agent node): every declared
+    dvm_exchange_* is exported and nothing else; the header is plain C; and libdvmslam_hip.so does NOT depend on librccl."""
+    names = sorted(n for n in _declared() if n.startswith("dvm_exchange_"))
+    assert len(names) >= 14 and "dvm_exchange_allreduce" in names and "dvm_exchange_allgather_varlen" in names
+    so = os.path.join(ROOT, "dvm_slam_amd", "lib", "libdvmslam_rccl.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    assert set(names) == set(re.findall(r" T (dvm_[a-z0-9_]+)", out))
+    need = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "librccl" in need
+    need = subprocess.run(["readelf", "-d", os.path.join(ROOT, "dvm_slam_amd", "lib", "libdvmslam_hip.so")], capture_output=True, text=True).stdout
+    assert "librccl" not in need
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "dvmslam_rccl.h")])
 
 
 def _declared_host():
