@@ -2204,11 +2204,46 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
           if (tid == 0) g_flow_dbg[(3500 + k) * 8 + 6] = tpre ? 1 : 0;
 #endif
           DVM_FSTMP(3500 + k, 1);
+          const bool fold_root = p < 0 && A.colinfo[8 * k + 5] != 0;
+          if (!fold_root) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int r = 8 * q + crow;
-            const bool lower = (ccol >> 4) <= (r >> 4);      // the blocks above the diagonal were never written in LDS: zeros from here
-            __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(lower ? Li[r * LP + ccol] : 0.0, lower ? Li[r * LP + ccol + 1] : 0.0), rL, (int)(((size_t)k * NB * NB + r * NB + ccol) * 8), 0, 16);
+            for (int q = 0; q < 8; q++) {
+              const int r = 8 * q + crow;
+              const bool lower = (ccol >> 4) <= (r >> 4);      // the blocks above the diagonal were never written in LDS: zeros from here
+              __builtin_amdgcn_raw_buffer_store_b128(d2_to_u4(lower ? Li[r * LP + ccol] : 0.0, lower ? Li[r * LP + ccol + 1] : 0.0), rL, (int)(((size_t)k * NB * NB + r * NB + ccol) * 8), 0, 16);
+            }
+          }
+          if (fold_root) {
+            // a ROOT column (only the rhs row hangs below it): nobody else needs its factor.  y = L^-1 r and x = L^-T y right here, from
+            // the L^-1 in LDS -- the sums of k_chol_backsolve's n_raw branch and of its last step, term for term (the blocks of L^-1 above
+            // the diagonal, never written in LDS, are the zeros the stored tile has)
+            double* const yk = Xb;
+            double* const part = Xb + NB;
+            if (tid == 0) flow_wait(A.flags + F_T + 2 * cstrip, A.gen, A.fail);
+            __syncthreads();
+            const int c = tid & 63, q = tid >> 6, k0 = k * NB;
+            if (tid < NB) yk[tid] = __hip_atomic_load(A.S + (size_t)A.n_pad * ldS + k0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            double sy = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) sy += (q <= (c >> 4) ? Li[c * LP + 16 * q + j] : 0.0) * yk[16 * q + j];
+            part[q * NB + c] = sy;
+            __syncthreads();
+            if (tid < NB) yk[tid] = (part[tid] + part[NB + tid]) + (part[2 * NB + tid] + part[3 * NB + tid]);
+            __syncthreads();
+            double sx = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sx += ((c >> 4) <= q ? Li[(16 * q + r) * LP + c] : 0.0) * yk[16 * q + r];
+            __syncthreads();
+            part[q * NB + c] = sx;
+            __syncthreads();
+            if (tid < NB) {
+              const double v = (part[tid] + part[NB + tid]) + (part[2 * NB + tid] + part[3 * NB + tid]);
+              __hip_atomic_store(A.xrow + k0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) write_x(A.x, k, tid, v, A.nfree, A.per_tile, A.dof, A.ncamt, A.nkept, A.kept_list);
+            }
+            DVM_FSTMP(3500 + k, 4);
+            break;
           }
           // L_k^-1 is what this column's other strips wait for: out at once (drain, flag), whatever the chain waits for next
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2223,8 +2258,9 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
 #pragma unroll
             for (int i = 0; i < 8; i++) *reinterpret_cast<double2*>(Xb + (8 * i + crow) * QP + ccol) = u4_to_d2(tq[i]);
           }
+          const bool cont = A.colinfo[8 * k + 6] != 0;          // k is p's chain child: this workgroup goes on to p
           const int pmode = A.colinfo[8 * p + 2], lc0 = A.colinfo[8 * p + 3], lc1 = A.colinfo[8 * p + 4];
-          if (pmode >= 2 && tid == 0) flow_wait(A.flags + F_P + p, A.gen, A.fail);      // (long there: PRE runs levels ahead)
+          if (cont && pmode >= 2 && tid == 0) flow_wait(A.flags + F_P + p, A.gen, A.fail);      // (long there: PRE runs levels ahead)
           __syncthreads();
           // what PRE left of (p, p): on its way while the strip is solved
           const int pi0 = p * NB;
@@ -2234,7 +2270,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
             for (int r = 0; r < 4; r++) {
               const int row = arow[s] + lk + 4 * r, col = brow[s] + lr;
               const double* q = A.S + (size_t)(pi0 + row) * ldS + pi0 + col;
-              tgt[s][r] = !son[s] ? 0.0 : pmode >= 2 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+              tgt[s][r] = (!son[s] || !cont) ? 0.0 : pmode >= 2 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
               acc[s][r] = 0.0;
             }
           }
@@ -2264,6 +2300,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // X has left (every storing wave): its flags go up before anything else --
           __syncthreads();                                     // the next chain strip's gather is waiting for them
           if (tid < 2) __hip_atomic_store(A.flags + 2 * cstrip + tid, A.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!cont) break;     // not the parent's chain child: the parent belongs to a sibling's workgroup, which gathers this strip
           // p's other children (the contributors of its last level before the chain child, ascending): their strips (p, m) come from
           // memory like any gathered contributor, one at a time -- there are one or two
           for (int c = lc0; c < lc1; c++) {
@@ -2302,6 +2339,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs A) {
       const int c = tid & 63, q = tid >> 6;
       const int kb = A.cols[A.n_back - 1 - (t - A.n_factor)];      // `cols` lists leaves first
       const int k0 = kb * NB;
+      if (A.colinfo[8 * kb + 5]) continue;      // a root column: solved by the chain's workgroup the moment it was factored
       const int s_beg = A.colstrip_off[kb], s_end = A.colstrip_off[kb + 1];
 #ifdef DVM_FLOW_DEBUG
       if (tid == 0 && t < 4096) g_flow_dbg[t * 8 + 6] = (long long)blockIdx.x | (3ll << 12) | ((long long)kb << 16);

@@ -320,27 +320,45 @@ BaTileSchedule ba_tile_schedule(std::vector<std::vector<char>> T) {
     // in the elimination tree whose first strip is (p, k): p's CHAIN CHILD.  The workgroup that factorises k goes on to p itself (solves
     // the strip (p, k) with the L^-1 it holds in LDS, multiplies, factorises p): no hand-off on the chain.  The levels before the last
     // one are summed by a PRE task off the critical path; the other contributors of the last level (p's other children) by the chain's
-    // workgroup itself, in order, before its own product.  flow_col[k] = {p if k is p's chain child else -1, strip (p, k), mode of k's
-    // own tile: 0 no contributor (a ticketed leaf), 1 the last level only (tgt = S), 2 PRE leaves tgt'; the last level's other
-    // contributors as a range of flow_contrib; 0 0 0}
+    // workgroup itself, in order, before its own product.  flow_col[k] = {parent p (the row of k's first strip) or -1, strip (p, k), mode
+    // of k's own tile: 0 no contributor (a ticketed leaf), 1 the last level only (tgt = S), 2 PRE leaves tgt'; the last level's other
+    // contributors as a range of flow_contrib; 1 = a root column solved in place; 1 = k is p's chain child; 0}
     S.flow_col.assign((size_t)8 * nt, 0);
     std::vector<char> chain_strip(S.strips.size() / 2, 0);
     std::vector<int32_t> nseg(nt, 0);
     for (int k = 0; k < nt; k++) S.flow_col[8 * k] = S.flow_col[8 * k + 1] = -1;
+    // EVERY column's workgroup solves the strip to the column's parent (its first strip) itself, with the L^-1 it holds in LDS -- the
+    // chain child's and the other children's alike: the parent waits for all of them, and a child's strip is ready ~4 us earlier than
+    // through an L^-1 hand-off to a slice task.  [0] = parent, [1] = that strip (gathered only), [6] = 1: go on to the parent
+    for (int k = 0; k + 1 < nt; k++)
+      if (!col[k].empty() && col[k][0] != nt - 1) {
+        S.flow_col[8 * k] = col[k][0]; S.flow_col[8 * k + 1] = strip_id[col[k][0]][k];
+        chain_strip[strip_id[col[k][0]][k]] = 1;
+      }
     for (int k = 0; k + 1 < nt; k++) {
       const auto& v = segs[(size_t)k * nt + k];
       nseg[k] = (int)(v.size() / 2);
       if (v.empty()) { S.flow_leaves++; continue; }
       const int clast = v[v.size() - 1] - 1;                    // last contributor: entry clast of `contrib`
-      const int child = S.contrib[clast], st = S.contrib_strip[2 * clast];
-      S.flow_col[8 * child] = k; S.flow_col[8 * child + 1] = st;
-      chain_strip[st] = 1;
+      const int child = S.contrib[clast];
+      S.flow_col[8 * child + 6] = 1;                           // k's chain child: its workgroup goes on to k
       S.flow_col[8 * k + 2] = nseg[k] >= 2 ? 2 : 1;
       S.flow_col[8 * k + 3] = (int32_t)(S.flow_contrib.size() / 4);
       add_contrib(v, v.size() / 2 - 1, v.size() / 2);
       S.flow_contrib.resize(S.flow_contrib.size() - 4);         // (the chain child's product comes from LDS)
       S.flow_col[8 * k + 4] = (int32_t)(S.flow_contrib.size() / 4);
     }
+    // the ROOT columns (the last launched level, when nothing but the rhs row hangs below them: n_root_raw): the level launches leave
+    // their panel solve -- one matrix-vector product -- to the back substitution; in the flow form the chain's workgroup does both
+    // itself, with the L^-1 it holds in LDS, the moment the column is factored: y = L^-1 r, x = L^-T y (same sums).  flow_col[k][5] = 1,
+    // [1] = the rhs strip, which is then gathered only
+    if (S.n_root_raw > 0 && S.root_level >= 0)
+      for (int c = S.level_off[S.root_level]; c < S.level_off[S.root_level + 1]; c++) {
+        const int k = S.cols[c];
+        if (k == nt - 1 || col[k].size() != 1 || col[k][0] != nt - 1) continue;
+        S.flow_col[8 * k + 5] = 1; S.flow_col[8 * k + 1] = strip_id[nt - 1][k];
+        chain_strip[strip_id[nt - 1][k]] = 1;
+      }
     for (int h = 0; h < nl; h++) {
       for (int c = S.level_off[h]; c < S.level_off[h + 1]; c++) {
         const int k = S.cols[c];

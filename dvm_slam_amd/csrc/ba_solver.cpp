@@ -232,10 +232,11 @@ void dvm_ba_destroy(dvm_ba* h) {
 // lists and the block pattern of the reduced camera matrix.  Done once per problem on the host.
 // the default choice between the level launches and the flow form of the reduced solve (k_chol_flow); DVM_BA_FLOW overrides it
 // Measured (DESIGN.md section 10, 500 keyframes): the flow form costs ~15.5 us per level of a chain (the factorisation's own 7.7 us + the
-// chain strip and its product in the same workgroup) and ~20 us per level with two children; the level launches ~17 us per level when a
-// level is a handful of tiles and ~20 us when its trailing update is large.  A bushy tree of few levels (a ring: 7) is level-launch
-// territory, a tree that is mostly a chain (a loop-closed map: 37 levels) the flow form's: 980 -> 1 270 it/s.
-static bool kFlowDefault(const BaTileSchedule& SC) { return SC.nlevels >= 12; }
+// parent strip and its product in the same workgroup) and ~18 us per level with two children; the level launches ~17 us per level when a
+// level is a handful of tiles and ~20 us when its trailing update is large, and they own the small problems (the top-pair kernel solves
+// a local-BA window's whole reduced system in one workgroup).  From 8 levels on (the 500-keyframe ring: 4 036 -> 4 092 it/s; the same map
+// with loop closures, 14 levels after the kept landmarks: 2 404 -> 2 509) the flow form is the default.
+static bool kFlowDefault(const BaTileSchedule& SC) { return SC.nlevels >= 8; }
 static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
                             const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
   if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1 || world < 1 || rank < 0 || rank >= world) {

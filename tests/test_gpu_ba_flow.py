@@ -2,8 +2,8 @@
 csrc/ba_kernels.hip) against the level launches it replaces and against the CPU oracle.
 
 The flow form gathers a tile's updates level by level in the order the level launches apply them and runs the same tile factorisation,
-panel solve and back substitution arithmetic: with the top pair kernel and the root level's matrix-vector panel solve switched off (DVM_BA_NO_PAIR,
-DVM_BA_NO_ROOT_RAW: both sum in another order) the two forms must agree BIT FOR BIT -- poses, landmarks, chi2, lambda, the LM trial sequence.  Against the default level
+panel solve and back substitution arithmetic: with the top pair kernel switched off (DVM_BA_NO_PAIR: its in-LDS solve of the last two
+columns sums in another order) the two forms must agree BIT FOR BIT -- poses, landmarks, chi2, lambda, the LM trial sequence.  Against the default level
 launches (pair on) and the oracle the bound is the north star's 1e-6 with identical trial sequences.  Reference recipe:
 G2O/core/block_solver.hpp:354-486, G2O/solvers/linear_solver_eigen.h:89-112."""
 import os
@@ -70,7 +70,7 @@ def test_flow_equals_level_launches_bit_for_bit(name):
     pr = synth.ba_problem(**PROBLEMS[name])
     iters = 6 if len(pr["poses"]) >= 500 else 8
     # (DVM_BA_BORDER=0: the deep trees are what this file is about)
-    lvl, info_l = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "0", "DVM_BA_NO_PAIR": "1", "DVM_BA_NO_ROOT_RAW": "1", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"}, rounds=2)
+    lvl, info_l = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "0", "DVM_BA_NO_PAIR": "1", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"}, rounds=2)
     flo, info_f = _run(pr, DELTA, iters, {"DVM_BA_FLOW": "1", "DVM_BA_NO_WINDOW": "1", "DVM_BA_BORDER": "0"}, rounds=2)
     assert info_l["levels"] == info_f["levels"] and info_l["nz_tiles"] == info_f["nz_tiles"]
     _same_bits(lvl, flo, name)
@@ -100,7 +100,7 @@ def test_flow_failed_factorisation_follows_g2o(oracle):
     pr = synth.ba_problem(n_kf=40, n_pts=1200, seed=15)
     pr["inv_sigma2"] = pr["inv_sigma2"].copy()
     pr["inv_sigma2"][::7] = 1e300
-    lvl, _ = _run(pr, 0.0, 3, {"DVM_BA_FLOW": "0", "DVM_BA_NO_PAIR": "1", "DVM_BA_NO_ROOT_RAW": "1", "DVM_BA_NO_WINDOW": "1"})
+    lvl, _ = _run(pr, 0.0, 3, {"DVM_BA_FLOW": "0", "DVM_BA_NO_PAIR": "1", "DVM_BA_NO_WINDOW": "1"})
     flo, _ = _run(pr, 0.0, 3, {"DVM_BA_FLOW": "1", "DVM_BA_NO_WINDOW": "1"})
     assert lvl[0][2]["trials"] == flo[0][2]["trials"]
     assert np.array_equal(_bits(lvl[0][0]), _bits(flo[0][0])) and np.array_equal(_bits(lvl[0][1]), _bits(flo[0][1]))
