@@ -185,3 +185,73 @@ def _info(pr, delta, env):
 def test_ring_keeps_no_landmark():
     pr = synth.ba_problem()
     assert _info(pr, DELTA, {})[1]["kept_landmarks"] == 0
+
+
+_BREAK_WORKER = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from dvm_slam_amd import capi, synth
+pr = synth.ba_problem(n_kf=230, n_pts=6000, k_obs=4, seed=12)
+e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+ba = capi.BundleAdjuster()
+ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], float(np.sqrt(5.991)))
+form0 = ba.solve_info()["form"]
+st = ba.optimize(4)
+p, pts = ba.result()
+np.savez(sys.argv[1], p=p, pts=pts, trials=np.array(st["trials"]), chi2=np.array(st["chi2"]), form=np.array([form0 == "flow", ba.solve_info()["form"] == "flow"]))
+"""
+
+
+def test_flow_wait_timeout_falls_back_to_the_level_launches(tmp_path):
+    """Every wait inside k_chol_flow is bounded.  With the strips publishing a sequence number nobody waits for
+    (DVM_BA_DEBUG_BREAK_FLOW) the waits give up, the trial is marked, and dvm_ba_optimize repeats it with one launch per phase -- for
+    good: the run ends on exactly the bits of the per-phase form (the level launches with THEIR hand-offs broken)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("levels", {"DVM_BA_FLOW": "0", "DVM_BA_DEBUG_BREAK_HANDOFF": "1"}), ("flow_broken", {"DVM_BA_FLOW": "1", "DVM_BA_DEBUG_BREAK_FLOW": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _BREAK_WORKER % root, out], env={**os.environ, **extra}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert list(b["form"]) == [True, False] and list(a["form"]) == [False, False]       # the flow form was chosen, and given up
+    assert np.array_equal(a["trials"], b["trials"]) and np.array_equal(a["chi2"], b["chi2"])
+    assert np.array_equal(a["p"], b["p"]) and np.array_equal(a["pts"], b["pts"])
+
+
+def test_kept_landmarks_with_edge_flags(oracle):
+    """dvm_ba_set_edge_flags (level-1 edges leave the active set, others lose their robust kernel: Optimizer.cc:1317-1354) on a problem
+    that keeps landmarks: an inactive edge's Hpl block is exact zeros in the border tiles too; kept and not kept agree."""
+    pr = synth.ba_problem(**PROBLEMS["loop500"])
+    rng = np.random.default_rng(3)
+    E = len(pr["edge_pose"])
+    flags = np.full(E, 3, np.uint8)
+    flags[rng.random(E) < 0.05] = 0            # inactive
+    flags[rng.random(E) < 0.10] &= 1           # active, not robust
+    res = []
+    for env in ({}, {"DVM_BA_BORDER": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
+            ba = capi.BundleAdjuster()
+            ba.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], DELTA)
+            kept = ba.solve_info()["kept_landmarks"]
+            ba.optimize(2)
+            ba.set_edge_flags(flags)
+            st = ba.optimize(3)
+            P, X = ba.result()
+            chi, _ = ba.edge_chi2()
+            ba.close()
+            res.append((kept, st, P, X, chi))
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    (ka, sa, Pa, Xa, ca), (kb, sb, Pb, Xb, cb) = res
+    assert ka > 0 and kb == 0 and sa["trials"] == sb["trials"]
+    assert np.abs(Pa - Pb).max() < 1e-7 and np.abs(Xa - Xb).max() < 1e-7 and np.allclose(ca, cb, rtol=1e-6, atol=1e-9)
