@@ -26,18 +26,21 @@ def main():
     cases = bad = tri_cases = window_cases = order_sensitive = 0
     while time.time() - t0 < budget:
         n_kf = int(rng.integers(2, 90)); n_pts = int(rng.integers(30, 1500)); k = int(rng.integers(2, min(8, n_kf) + 1))
-        if rng.random() < 0.12:       # many tile columns: the nested-dissection schedule, short tiles of every fill, the level kernels
+        if rng.random() < float(os.environ.get("SOAK_BIG_FRAC", "0.12")):       # many tile columns: the nested-dissection schedule, short tiles of every fill, the level kernels
             n_kf = int(rng.integers(90, 420)); n_pts = int(rng.integers(20, 30) * n_kf); k = int(rng.integers(4, 9))
         delta = float(np.sqrt(5.991)) if rng.random() < 0.6 else 0.0
         iters = int(rng.integers(1, 12))
+        extra_kw = {}
+        if n_kf >= 90 and rng.random() < 0.5:      # maps after loop closures / with landmarks seen from far apart: deep elimination trees, kept landmarks, the flow form
+            extra_kw = dict(laps=int(rng.integers(1, 3)), long_range_frac=float(rng.choice([0.001, 0.003, 0.01])), long_range_obs=int(rng.integers(2, 5)))
         pr = synth.ba_problem(n_kf, n_pts, k, seed=int(rng.integers(1 << 30)), noise_px=float(rng.choice([0.0, 0.5, 1.0, 3.0])),
-                              outlier_frac=float(rng.choice([0.0, 0.05, 0.2])))
+                              outlier_frac=float(rng.choice([0.0, 0.05, 0.2])), **extra_kw)
         fixed = pr["fixed"].copy()
         extra = rng.random(n_kf) < rng.choice([0.0, 0.1, 0.5])
         fixed[extra] = 1
         if fixed.all():
             fixed[-1] = 0
-        tag = f"kf={n_kf} pts={n_pts} k={k} delta={delta:.2f} it={iters} fixed={int(fixed.sum())} E={len(pr['edge_pose'])}"
+        tag = f"kf={n_kf} pts={n_pts} k={k} delta={delta:.2f} it={iters} fixed={int(fixed.sum())} E={len(pr['edge_pose'])} {extra_kw if extra_kw else ''}"
         try:
             e = po.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"])
             Po, Xo, so, chio = po.ba_optimize(pr["poses"], fixed, pr["points"], e, pr["intrinsics"], delta, iters)
