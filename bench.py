@@ -534,7 +534,20 @@ def main():
                                     "count: loop bodies are not weighted."}
             except Exception:
                 valu = None
+            # the whole launch group's counter traffic against its algorithmic bytes (SURVEY 8d's numerator: pyramid build + FAST read + blur
+            # read / write; the per-keypoint patch gathers of orientation / descriptors and level 0's bordered copy are NOT in it, they are
+            # what the ratio shows: the blurred and the raw pyramid are read once more by k_orient_desc, whose patches cover every level)
+            pipe_ratio = None
+            try:
+                if pmc["batch"] == frames_per_launch:
+                    per_chunk_all = {"dvm::k_pyr_level0": 1, "dvm::k_pyr_resize": 7, "dvm::k_fast_cells": 1, "dvm::k_blur7": 1, "dvm::k_octree": 1,
+                                     "dvm::k_assemble": 1, "dvm::k_orient_desc": 1, "dvm::k_frame_build": 1, "dvm::k_match_window": 1}
+                    tot = sum(pmc["kernels"][k]["hbm_bytes_per_launch"] * n for k, n in per_chunk_all.items())
+                    pipe_ratio = tot / (BYTES_PER_FRAME_TOTAL * frames_per_launch)
+            except Exception:   # noqa: BLE001
+                pipe_ratio = None
             roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "pipeline_traffic_over_algorithmic": pipe_ratio,
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
                     "bytes_per_launch": BYTES_PER_FRAME_FAST * frames_per_launch, "avg_launch_ms": fast_ms / fast_n,
                     "frames_per_launch": frames_per_launch,
