@@ -26,6 +26,25 @@ def test_ba_ordering_and_level_schedule(tmp_path):
                  ["10", "9", "0"], ["11", "2", "1"]):
         out = subprocess.run([str(exe)] + args, capture_output=True, text=True)
         assert out.returncode == 0, (args, out.stdout + out.stderr)
+    # a deep tree (the loop-closed map of bench.py's second BA workload: 0.2 % of the landmarks seen from far apart): the flow form's
+    # task list and chains are executed symbolically by the tool -- no circular wait, every tile produced once, contributor lists = the
+    # level schedule's
+    import itertools
+    import numpy as np
+    from dvm_slam_amd import synth
+    pr = synth.ba_problem(laps=2, long_range_frac=0.002)
+    free = {int(p): i for i, p in enumerate(np.nonzero(pr["fixed"] == 0)[0])}
+    cams = [[] for _ in range(len(pr["points"]))]
+    for p_, l_ in zip(pr["edge_pose"], pr["edge_point"]):
+        if int(p_) in free:
+            cams[int(l_)].append(free[int(p_)])
+    pairs = set()
+    for c in cams:
+        pairs.update(itertools.combinations(sorted(set(c)), 2))
+    adj = tmp_path / "adj.txt"
+    adj.write_text(f"{len(free)}\n" + "".join(f"{a} {b}\n" for a, b in sorted(pairs)))
+    out = subprocess.run([str(exe), "0", "0", "0", str(adj)], capture_output=True, text=True)
+    assert out.returncode == 0 and "levels=3" in out.stdout, out.stdout + out.stderr          # 37 or 38 levels
     def levels(n, loop):
         out = subprocess.run([str(exe), str(n), "7", loop], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr

@@ -97,6 +97,150 @@ int main(int argc, char** argv) {
     for (int i : std::vector<int>(S.colstrips.begin() + S.colstrip_off[S.pair_b], S.colstrips.begin() + S.colstrip_off[S.pair_b + 1]))
       if (i != nt - 1) return fail("pair column b has a tile below it");
   }
+  // ---- the FLOW form (k_chol_flow): executed symbolically.  Flags as the kernel has them: X of a strip half, L^-1 of a column, PRE of a
+  // column, T of a chain-strip half.  Ticketed tasks run when their inputs are there; a DIAG task climbs its chain.  Everything must get
+  // done (no circular wait), every strip half and every column must be produced exactly once, a ticketed task may only wait for flags
+  // that EARLIER tickets produce (chains wait for later tickets by design: TSLICE / PRE of the columns they climb to), and every tile's
+  // contributor list must be the level launches' (same columns, same order, the end-of-level marks where the levels end).
+  {
+    const int ns = (int)(S.strips.size() / 2), ntask = (int)(S.flow_tasks.size() / 8);
+    if ((int)S.flow_col.size() != 8 * nt) return fail("flow_col size");
+    std::vector<char> X(2 * ns, 0), L(nt, 0), P(nt, 0), Tf(2 * ns, 0), xdone(nt, 0), done(ntask, 0);
+    std::vector<int> producer_ticket_X(2 * ns, -1), producer_ticket_L(nt, -1), producer_ticket_P(nt, -1);   // ticket of the (chain root) task that produces the flag
+    // chain state per leaf task: current column, stage
+    struct Chain { int task, k; bool active; };
+    std::vector<Chain> chains;
+    auto contrib_ready = [&](int c, int half, bool slice) {
+      const int32_t* e = &S.flow_contrib[4 * (size_t)c];
+      return X[2 * e[1] + (slice ? half : 0)] && (slice || X[2 * e[1] + 1]) && X[2 * e[2]] && X[2 * e[2] + 1];
+    };
+    // reference contributor lists per tile from the level schedule
+    auto level_list = [&](int ti, int tj) {
+      std::vector<std::pair<int, int>> v;     // (column, last-of-level)
+      for (int h = 0; h < S.nlevels; h++)
+        for (int t = S.tgt_off[h]; t < S.tgt_off[h + 1]; t++)
+          if (S.targets[4 * t] == ti && S.targets[4 * t + 1] == tj)
+            for (int c = S.targets[4 * t + 2]; c < S.targets[4 * t + 3]; c++) v.push_back({S.contrib[c], c == S.targets[4 * t + 3] - 1});
+      return v;
+    };
+    int leaves = 0;
+    for (int t = 0; t < ntask; t++) {
+      const int32_t* T = &S.flow_tasks[8 * (size_t)t];
+      const int kind = T[0], ti = T[1], tj = T[2], c0 = T[4], c1 = T[5];
+      if (kind == 0) leaves++;
+      if (kind == 1 || kind == 4) {
+        const auto ref = level_list(ti, tj);
+        if ((int)ref.size() != c1 - c0) return fail("flow: a slice's contributor count differs from the level schedule");
+        for (int c = c0; c < c1; c++)
+          if (S.flow_contrib[4 * c] != ref[c - c0].first || S.flow_contrib[4 * c + 3] != (ref[c - c0].second ? 1 : 0)) return fail("flow: a slice's contributor list differs");
+        if (S.strips[2 * T[6]] != ti || S.strips[2 * T[6] + 1] != tj) return fail("flow: a slice names another strip");
+      }
+      if (kind == 2 || kind == 0) if (ti != tj) return fail("flow: PRE / DIAG off the diagonal");
+    }
+    if (leaves != S.flow_leaves) return fail("flow_leaves");
+    // diagonal tiles: PRE list + the chain's own list + the chain child = the level schedule's list
+    for (int k = 0; k + 1 < nt; k++) {
+      const auto ref = level_list(k, k);
+      std::vector<int> got;
+      for (int t = 0; t < ntask; t++) {
+        const int32_t* T = &S.flow_tasks[8 * (size_t)t];
+        if (T[0] == 2 && T[1] == k) for (int c = T[4]; c < T[5]; c++) got.push_back(S.flow_contrib[4 * c]);
+      }
+      for (int c = S.flow_col[8 * k + 3]; c < S.flow_col[8 * k + 4]; c++) got.push_back(S.flow_contrib[4 * c]);
+      int child = -1;
+      for (int m = 0; m + 1 < nt; m++) if (S.flow_col[8 * m] == k && S.flow_col[8 * m + 6]) { if (child >= 0) return fail("flow: two chain children"); child = m; }
+      if (child >= 0) got.push_back(child);
+      if (got.size() != ref.size()) return fail("flow: a diagonal tile's contributors are not the level schedule's");
+      for (size_t i = 0; i < ref.size(); i++) if (got[i] != ref[i].first) return fail("flow: a diagonal tile's contributor order differs");
+      if (ref.empty() != (S.flow_col[8 * k + 2] == 0)) return fail("flow: mode 0 <-> no contributor");
+    }
+    bool progress = true;
+    int rounds = 0;
+    while (progress) {
+      progress = false;
+      if (++rounds > 10 * (ntask + nt) + 10) return fail("flow: symbolic execution does not terminate");
+      for (int t = 0; t < ntask; t++) {
+        if (done[t]) continue;
+        const int32_t* T = &S.flow_tasks[8 * (size_t)t];
+        const int kind = T[0], ti = T[1], tj = T[2], half = T[3], c0 = T[4], c1 = T[5], self = T[6];
+        bool ok = true;
+        for (int c = c0; c < c1 && ok; c++) {
+          ok = contrib_ready(c, half, kind == 1 || kind == 4);
+          // a ticketed task waits only for flags whose producing ticket is EARLIER
+          const int32_t* e = &S.flow_contrib[4 * (size_t)c];
+          if (ok) for (int f : {2 * e[1] + ((kind == 1 || kind == 4) ? half : 0), 2 * e[2], 2 * e[2] + 1})
+            if (producer_ticket_X[f] > t) return fail("flow: a ticketed task waits for a later ticket");
+        }
+        if (!ok) continue;
+        if (kind == 1) {
+          if (!L[tj]) continue;
+          if (producer_ticket_L[tj] > t) return fail("flow: a slice waits for an L^-1 of a later ticket");
+          if (X[2 * self + half]) return fail("flow: a strip half produced twice");
+          X[2 * self + half] = 1; producer_ticket_X[2 * self + half] = t;
+        } else if (kind == 4) {
+          if (Tf[2 * self + half]) return fail("flow: a chain strip half gathered twice");
+          Tf[2 * self + half] = 1;
+        } else if (kind == 2) {
+          if (P[tj]) return fail("flow: PRE twice");
+          P[tj] = 1; producer_ticket_P[tj] = t;
+        } else {
+          if (S.flow_col[8 * ti + 2] != 0) return fail("flow: a ticketed DIAG task with contributors");
+          chains.push_back({t, ti, true});
+        }
+        if (kind != 0) { done[t] = 1; progress = true; }
+        else { done[t] = 1; progress = true; }
+        (void)ti;
+      }
+      // the chains: one step each per round
+      for (auto& ch : chains) {
+        while (ch.active) {
+          const int k = ch.k, p = S.flow_col[8 * k], cs = S.flow_col[8 * k + 1];
+          if (L[k] == 2) {                                 // published, waiting for the parent's other children
+            bool sib = true;
+            for (int c = S.flow_col[8 * p + 3]; c < S.flow_col[8 * p + 4]; c++) sib = sib && X[2 * S.flow_contrib[4 * c + 1]] && X[2 * S.flow_contrib[4 * c + 1] + 1];
+            if (!sib) break;
+            L[k] = 1; ch.k = p; progress = true;
+            continue;
+          }
+          if (L[k]) return fail("flow: a column factorised twice");
+          // (the column's own tile is complete here: checked on the way up)
+          if (p < 0 && S.flow_col[8 * k + 5]) {            // a root solved in place: needs the gathered rhs strip
+            if (!Tf[2 * cs]) break;
+            L[k] = 1; xdone[k] = 1; producer_ticket_L[k] = ch.task; ch.active = false; progress = true;
+            break;
+          }
+          if (p < 0) { L[k] = 1; producer_ticket_L[k] = ch.task; ch.active = false; progress = true; break; }
+          if (!(Tf[2 * cs] && Tf[2 * cs + 1])) break;      // waits for the two TSLICE halves
+          const bool cont = S.flow_col[8 * k + 6] != 0;
+          if (cont) {
+            const int mode = S.flow_col[8 * p + 2];
+            if (mode >= 2 && !P[p]) break;
+            bool sib = true;
+            for (int c = S.flow_col[8 * p + 3]; c < S.flow_col[8 * p + 4]; c++) sib = sib && X[2 * S.flow_contrib[4 * c + 1]] && X[2 * S.flow_contrib[4 * c + 1] + 1];
+            // (the kernel publishes L_k^-1 and X(p,k) BEFORE it waits for the siblings: model that order, or two chains that are each
+            //  other's... cannot be: siblings never wait for each other, only the chain child waits)
+            if (!L[k]) { L[k] = 1; producer_ticket_L[k] = ch.task; X[2 * cs] = X[2 * cs + 1] = 1; producer_ticket_X[2 * cs] = producer_ticket_X[2 * cs + 1] = ch.task; progress = true; }
+            if (!sib) { L[k] = 2; break; }
+            L[k] = 1;
+            ch.k = p; progress = true;
+            continue;
+          }
+          L[k] = 1; producer_ticket_L[k] = ch.task;
+          if (X[2 * cs] || X[2 * cs + 1]) return fail("flow: a chain strip solved twice");
+          X[2 * cs] = X[2 * cs + 1] = 1; producer_ticket_X[2 * cs] = producer_ticket_X[2 * cs + 1] = ch.task;
+          ch.active = false; progress = true;
+        }
+      }
+    }
+    for (int t = 0; t < ntask; t++) if (!done[t]) return fail("flow: a task never becomes runnable (circular wait)");
+    for (auto& ch : chains) if (ch.active) return fail("flow: a chain never ends");
+    for (int k = 0; k + 1 < nt; k++) if (L[k] != 1) return fail("flow: a column is never factorised");
+    for (int st = 0; st < ns; st++) {
+      const bool rhs = S.strips[2 * st] == nt - 1;
+      const bool folded = rhs && S.flow_col[8 * S.strips[2 * st + 1] + 5];
+      if (!folded && (!X[2 * st] || (!rhs && !X[2 * st + 1]))) return fail("flow: a strip half is never published");
+    }
+  }
   std::printf("ok n=%d tiles=%d levels=%d fill=%.3f strips=%zu targets=%zu pair=%d,%d\n", n, nt, S.nlevels, S.fill, S.strips.size() / 2,
               S.targets.size() / 4, S.pair_a, S.pair_b);
   if (std::getenv("DVM_ORDER_VERBOSE"))
