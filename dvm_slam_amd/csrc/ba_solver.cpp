@@ -231,12 +231,14 @@ void dvm_ba_destroy(dvm_ba* h) {
 // Graph construction ("buildStructure", block_solver.hpp:143-295): vertex ordering, CSR incidence
 // lists and the block pattern of the reduced camera matrix.  Done once per problem on the host.
 // the default choice between the level launches and the flow form of the reduced solve (k_chol_flow); DVM_BA_FLOW overrides it
-// Measured (DESIGN.md section 10, 500 keyframes): the flow form costs ~15.5 us per level of a chain (the factorisation's own 7.7 us + the
-// parent strip and its product in the same workgroup) and ~18 us per level with two children; the level launches ~17 us per level when a
-// level is a handful of tiles and ~20 us when its trailing update is large, and they own the small problems (the top-pair kernel solves
-// a local-BA window's whole reduced system in one workgroup).  From 8 levels on (the 500-keyframe ring: 4 036 -> 4 092 it/s; the same map
-// with loop closures, 14 levels after the kept landmarks: 2 404 -> 2 509) the flow form is the default.
-static bool kFlowDefault(const BaTileSchedule& SC) { return SC.nlevels >= 8; }
+// Measured: the flow form costs ~15.5 us per level of a chain (the factorisation's own 7.7 us + the parent strip and
+// its product in the same workgroup) and ~18 us per level with two children; the level launches ~17 us per level when a level is a handful of
+// tiles and ~20 us when its trailing update is large, and they own the small problems (the top-pair kernel solves a local-BA window's whole
+// reduced system in one workgroup).  From 5 levels on the flow form wins -- 100 keyframes 6 927 -> 7 114 it/s, 200: 5 536 -> 5 739, the
+// 500-keyframe ring 4 036 -> 4 092, the same map with loop closures (13 levels after the kept landmarks) 2 404 -> 2 509 -- as long as its
+// tasks are a few per workgroup: a task holds its workgroup while it waits, and at 1 000 keyframes with loop closures (1 848 tasks on 256
+// workgroups) the level launches are ahead again (1 401 vs 1 313 it/s).
+static bool kFlowDefault(const BaTileSchedule& SC, int workgroups) { return SC.nlevels >= 5 && (int)(SC.flow_tasks.size() / 8) <= 4 * workgroups; }
 static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed, int P, const double* points, int L,
                             const dvm_ba_edge* edges, int E, const dvm_ba_camera* cam, int rank, int world) {
   if (!h || !poses || !fixed || !points || !edges || !cam || P < 1 || L < 1 || E < 1 || world < 1 || rank < 0 || rank >= world) {
@@ -301,8 +303,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   for (int k = 0; k < E; k++) e_cam[k] = nat_of[e_pose[k]];
   // KEPT LANDMARKS (ba_kernels.h, BaView::kept_*): when the elimination tree of the tile factorisation comes out deep (>= 12 levels: a
   // chain, not a bush) and a few landmarks are to blame -- landmarks that couple camera pairs hardly anything else couples (<= 2
-  // co-observed landmarks) --, those landmarks (at most 63: three tiles) are left out of the Schur complement and stay unknowns of the
+  // co-observed landmarks) --, those landmarks (at most 210: ten tiles) are left out of the Schur complement and stay unknowns of the
   // reduced system; the structure is then built again without their couplings.  DVM_BA_BORDER=0 switches it off (A/B, tests).
+  constexpr size_t kMaxKept = 210;                               // ten tiles of 21
   std::vector<int32_t> kept_slot(L, -1), kept_list;
   const bool try_border = world == 1 && nf > 60 && !(std::getenv("DVM_BA_BORDER") && std::atoi(std::getenv("DVM_BA_BORDER")) == 0);
   std::vector<int> cam_pos;
@@ -372,7 +375,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     }
     if (cand.empty()) break;
     std::sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-    if (cand.size() > 63) cand.resize(63);
+    if (cand.size() > kMaxKept) cand.resize(kMaxKept);
     std::sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.second < y.second; });
     for (const auto& c : cand) { kept_slot[c.second] = (int32_t)kept_list.size(); kept_list.push_back(c.second); }
     mark("kept landmarks chosen");
@@ -622,7 +625,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     V.flow_wgs = cus;
     const bool fits = (size_t)V.ldS * V.ldS * sizeof(double) < (size_t)0x7FFFFFF0;      // 32-bit buffer offsets into S
     // (the chains -- one per leaf of the elimination tree -- wait for tasks the OTHER workgroups draw: they must stay a minority)
-    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC)) && fits && world == 1 && 4 * SC.flow_leaves <= cus ? 1 : 0;
+    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC, cus)) && fits && world == 1 && 4 * SC.flow_leaves <= cus ? 1 : 0;
   }
   V.strip_flags = reinterpret_cast<int32_t*>(V.ytmp + (size_t)V.n_pad + 64);   // behind the back substitution's words, cleared with them
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();

@@ -465,10 +465,10 @@ int dvm_ba_schedule_info(const dvm_ba* h, int64_t* out);
 /* dvm_ba_solve_info: which form of the reduced solve (the replacement of g2o's LinearSolverEigen::solve,
  * Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:89-112, under BlockSolver::solve, g2o/core/block_solver.hpp:354-486) the current
  * problem runs: out[6] = {form: 0 = one launch (or two) per elimination-tree level, 1 = the flow form -- the whole factorisation + back
- * substitution as ONE persistent launch of tile tasks, chosen when the elimination tree is mostly a chain --, tile tasks of the flow
+ * substitution as ONE persistent launch of tile tasks, chosen from 5 elimination levels on while the tasks are few per workgroup --, tile tasks of the flow
  * form, chains (= leaves of the elimination tree), workgroups launched, KEPT landmarks, camera tiles}.  The two forms sum in the same order
  * (same numbers).  Kept landmarks: when a few landmarks seen from places far apart on the trajectory are what makes the elimination tree
- * deep (>= 12 levels), up to 63 of them are not eliminated into the Schur complement but stay unknowns of the reduced system, in tiles of
+ * deep (>= 12 levels), up to 210 of them are not eliminated into the Schur complement but stay unknowns of the reduced system, in tiles of
  * their own behind the camera tiles -- the same linear system as g2o's, eliminated in another order (results agree within the 1e-6 of
  * the accuracy contract, not bit for bit).  DVM_BA_BORDER=0 in the environment switches that off. */
 int dvm_ba_solve_info(const dvm_ba* h, int64_t* out);

@@ -239,7 +239,8 @@ def test_ba_level_handoff_timeout_falls_back_to_one_launch_per_phase(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tag, extra in (("plain", {}), ("broken", {"DVM_BA_DEBUG_BREAK_HANDOFF": "1"})):
+    # (DVM_BA_FLOW=0: the level launches are what this test is about; the flow form's own fallback: tests/test_gpu_ba_flow.py)
+    for tag, extra in (("plain", {"DVM_BA_FLOW": "0"}), ("broken", {"DVM_BA_FLOW": "0", "DVM_BA_DEBUG_BREAK_HANDOFF": "1"})):
         out = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, "-c", _HANDOFF_WORKER % root, out], env={**os.environ, **extra},
                            capture_output=True, text=True, timeout=600)
