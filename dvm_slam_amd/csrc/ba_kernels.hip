@@ -3509,7 +3509,7 @@ constexpr int kFusedLevelMaxWGs = 512;   // 2 workgroups per CU on 256 CUs (3 fi
 void ba_launch_cholesky_solve(hipStream_t s, const BaView& V, int* d_fail, int solve_seq) {
   if (V.nfree == 0) return;
   const int n1 = V.n_pad + 1;
-  if (V.flow && V.flow_tasks && V.flow_flags && V.strip_flags) {     // the whole solve as one persistent launch of tile tasks (k_chol_flow)
+  if (V.flow && V.flow_tasks && V.flow_flags) {     // the whole solve as one persistent launch of tile tasks (k_chol_flow)
     FlowArgs A;
     A.S = V.S; A.ldS = V.ldS; A.n1 = n1; A.n_pad = V.n_pad; A.Linv_all = V.Linv;
     A.tasks = V.flow_tasks; A.fc = V.flow_contrib; A.colinfo = V.flow_col;

@@ -625,7 +625,7 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     V.flow_wgs = cus;
     const bool fits = (size_t)V.ldS * V.ldS * sizeof(double) < (size_t)0x7FFFFFF0;      // 32-bit buffer offsets into S
     // (the chains -- one per leaf of the elimination tree -- wait for tasks the OTHER workgroups draw: they must stay a minority)
-    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC, cus)) && fits && world == 1 && 4 * SC.flow_leaves <= cus ? 1 : 0;
+    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC, cus)) && fits && 4 * SC.flow_leaves <= cus ? 1 : 0;
   }
   V.strip_flags = reinterpret_cast<int32_t*>(V.ytmp + (size_t)V.n_pad + 64);   // behind the back substitution's words, cleared with them
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
@@ -966,7 +966,10 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         }
         {
           BaView VS = V;                                   // in-launch hand-offs (k_chol_trsm_update) only while they have never timed out
-          if (sharded || !h->fuse_levels) { VS.strip_flags = nullptr; VS.flow = 0; }
+          // (the fused level launches assume their whole grid resident: not with several ranks on one GPU, nor after a timeout; the flow
+          //  form assumes nothing of the kind and stays for a sharded solve -- every rank solves the summed system redundantly)
+          if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
+          if (!h->fuse_levels) VS.flow = 0;
           ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
         }
         if (h->prof) hipEventRecord(h->pev[2], s);
