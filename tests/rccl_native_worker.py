@@ -76,6 +76,15 @@ def main():
     rec["ba_allreduce_doubles"] = int(n)
     R.dvm_exchange_destroy(ex)
     R.dvm_exchange_comm_destroy(comm)
+    # the same through dvm_slam_amd.sharded_ba.ShardedBundleAdjuster(native=True): what bench.py's sharded leg runs under DVM_SHARDED_NATIVE=1
+    from dvm_slam_amd import sharded_ba
+    sn = sharded_ba.ShardedBundleAdjuster(0, native=True)
+    sn.set_problem(pr["poses"], pr["fixed"], pr["points"], e, pr["intrinsics"], delta)
+    s3 = sn.optimize(8)
+    p3, x3 = sn.result()
+    sn.close()
+    rec["class_native_bits_equal"] = bool(s1["trials"] == s3["trials"] and np.array_equal(p1, p3) and np.array_equal(x1, x3))
+    rec["class_python_calls"] = int(sn.calls)          # the Python callback must not have run
     json.dump(rec, open(out, "w"))
 
 

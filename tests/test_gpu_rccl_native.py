@@ -26,3 +26,4 @@ def test_native_exchange_and_sharded_ba_allreduce():
     assert rec["blocks_ok"] and rec["varlen_ok"] and rec["sim3_ok"] and rec["max_over_ranks"] == 1.5
     assert rec["varlen_too_small"] == -3
     assert rec["ba_trials_equal"] and rec["ba_bits_equal"] and rec["ba_allreduce_doubles"] > 1000
+    assert rec["class_native_bits_equal"] and rec["class_python_calls"] == 0
