@@ -315,18 +315,16 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     pair_cams.clear();
     std::vector<int32_t> pair_cnt;                               // per pair: landmarks that see both cameras
     for (int i = 0; i < nf; i++) touch(i, i);
+    std::vector<int32_t> lc;                                     // the free cameras of one landmark, in edge order
     for (int l = 0; l < L; l++) {
       if (kept_slot[l] >= 0) continue;
-      for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
-        const int ca = e_cam[pt_edges[a]];
-        if (ca < 0) continue;
-        for (int b = pt_start[l]; b < a; b++) {
-          const int cb = e_cam[pt_edges[b]];
-          if (cb < 0) continue;
-          const int32_t id = touch(ca, cb);
+      lc.clear();
+      for (int a = pt_start[l]; a < pt_start[l + 1]; a++) { const int ca = e_cam[pt_edges[a]]; if (ca >= 0) lc.push_back(ca); }
+      for (size_t a = 1; a < lc.size(); a++)
+        for (size_t b = 0; b < a; b++) {
+          const int32_t id = touch(lc[a], lc[b]);
           if (pass == 0 && try_border) { if ((size_t)id >= pair_cnt.size()) pair_cnt.resize(pair_cams.size(), 0); pair_cnt[id]++; }
         }
-      }
     }
     std::vector<std::vector<int>> cam_adj(nf);
     for (const auto& pc : pair_cams)
@@ -412,23 +410,28 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   std::vector<int32_t> blk_start(nblk + 1, 0);
   struct PairRec { int32_t blk, k1, k2; };
   std::vector<PairRec> recs;                       // one table lookup per pair: the count pass records what the fill pass needs
-  recs.reserve((size_t)E * 4);
+  {
+    size_t npairs = 0;                               // (an exact reserve: the vector used to grow -- and copy itself -- once or twice on the way)
+    for (int l = 0; l < L; l++) { const size_t d = (size_t)(pt_start[l + 1] - pt_start[l]); npairs += d * (d + 1) / 2; }
+    recs.reserve(npairs);
+  }
+  struct LmEdge { int32_t k, c, pos; };
+  std::vector<LmEdge> le;                          // the free-camera edges of one landmark (edge, natural camera, position), in edge order
   for (int l = 0; l < L; l++) {
     if (world > 1 && l % world != rank) continue;
     if (kept_slot[l] >= 0) continue;                 // not eliminated: no term in the Schur complement
+    le.clear();
     for (int a = pt_start[l]; a < pt_start[l + 1]; a++) {
-      const int k1 = pt_edges[a], c1 = e_cam[k1];
-      if (c1 < 0) continue;
-      const int i1 = cam_pos[c1];
-      for (int b = pt_start[l]; b < pt_start[l + 1]; b++) {
-        const int k2 = pt_edges[b], c2 = e_cam[k2];
-        if (c2 < 0) continue;
-        if (cam_pos[c2] > i1) continue;
-        const int32_t blk = rank_of[pair_slot(std::max(c1, c2), std::min(c1, c2))];
-        blk_start[blk + 1]++;
-        recs.push_back({blk, k1, k2});
-      }
+      const int k = pt_edges[a], c = e_cam[k];
+      if (c >= 0) le.push_back({k, c, cam_pos[c]});
     }
+    for (const LmEdge& x : le)
+      for (const LmEdge& y : le) {
+        if (y.pos > x.pos) continue;
+        const int32_t blk = rank_of[pair_slot(std::max(x.c, y.c), std::min(x.c, y.c))];
+        blk_start[blk + 1]++;
+        recs.push_back({blk, x.k, y.k});
+      }
   }
   for (int r = 0; r < nblk; r++) blk_start[r + 1] += blk_start[r];
   std::vector<int32_t> pair_k1(recs.size()), pair_k2(recs.size()), fill(blk_start.begin(), blk_start.end() - 1);
