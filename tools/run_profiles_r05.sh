@@ -2,6 +2,7 @@
 #   1. --kernel-trace --stats of the timed region of bench.py (extract + match only)        -> r05_a_extract_kernel_stats.csv
 #   2. --kernel-trace --stats of the BA leg alone (tools/ba_only.py)                         -> r05_b_ba_kernel_stats.csv
 #   2b. the same of the loop-closed workload (tools/ba_loop_only.py), default and with DVM_BA_BORDER=0 -> r05_b2_* / r05_b3_*
+#   2c. the densely coupled 2 000-keyframe map (tools/ba_dense_regime.py)                    -> r05_b4_*
 #   3. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters incl. SQ_ACTIVE_INST_VALU) of a short extract run -> r05_pmc_*.csv
 #   4. separate --pmc passes (FETCH_SIZE | WRITE_SIZE) of the BA leg (tools/ba_short.py prints its trial count)       -> r05_pmc_ba_*.csv
 #   5. the same two counters on known-byte-count kernels of every access width (tools/pmc_calib.hip)                  -> r05_pmc_calib_*.csv
@@ -30,6 +31,9 @@ rm -rf /tmp/p2b && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 cp $(find /tmp/p2b -name "*kernel_stats.csv" | head -1) $O/r05_b2_ba_loop_closed_kernel_stats.csv
 rm -rf /tmp/p2c && DVM_BA_BORDER=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2c -- python $R/tools/ba_loop_only.py > $O/b3_ba_loop.log 2>&1
 cp $(find /tmp/p2c -name "*kernel_stats.csv" | head -1) $O/r05_b3_ba_loop_closed_noborder_flow_kernel_stats.csv
+rm -rf /tmp/p2d && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2d -- python $R/tools/ba_dense_regime.py > $O/b4_ba_dense.log 2>&1
+cp $(find /tmp/p2d -name "*kernel_stats.csv" | head -1) $O/r05_b4_ba_dense_2000kf_kernel_stats.csv
+grep '^{"keyframes"' $O/b4_ba_dense.log > $O/r05_b4_ba_dense_2000kf.json
 SHORT="python $R/bench.py --steps 1 --warmup 1 --chunks-per-step 2 --no-ba --no-pcie --no-exclusive --no-legs --cpu-seconds 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p3 && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p3 -- $SHORT > $O/pmc_$C.log 2>&1
