@@ -307,7 +307,9 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
   // reduced system; the structure is then built again without their couplings.  DVM_BA_BORDER=0 switches it off (A/B, tests).
   constexpr size_t kMaxKept = 210;                               // ten tiles of 21
   std::vector<int32_t> kept_slot(L, -1), kept_list;
-  const bool try_border = world == 1 && nf > 60 && !(std::getenv("DVM_BA_BORDER") && std::atoi(std::getenv("DVM_BA_BORDER")) == 0);
+  // (the landmark-chunk form of the Schur complement, DVM_BA_SCHUR_LM, has no workgroups for the kept landmarks' rows: the two do not combine)
+  const bool try_border = world == 1 && nf > 60 && !std::getenv("DVM_BA_SCHUR_LM") &&
+                          !(std::getenv("DVM_BA_BORDER") && std::atoi(std::getenv("DVM_BA_BORDER")) == 0);
   std::vector<int> cam_pos;
   int levels_all = 0;
   for (int pass = 0;; pass++) {
@@ -628,7 +630,11 @@ static int set_problem_impl(dvm_ba* h, const double* poses, const uint8_t* fixed
     V.flow_wgs = cus;
     const bool fits = (size_t)V.ldS * V.ldS * sizeof(double) < (size_t)0x7FFFFFF0;      // 32-bit buffer offsets into S
     // (the chains -- one per leaf of the elimination tree -- wait for tasks the OTHER workgroups draw: they must stay a minority)
-    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC, cus)) && fits && 4 * SC.flow_leaves <= cus ? 1 : 0;
+    // several roots (a disconnected reduced camera graph): one tree's back substitution could write x before a diagonal tile of another
+    // tree fails, and g2o's linear solver leaves x untouched when the factorisation fails -- such graphs keep the level launches
+    int roots = 0;
+    for (size_t k = 0; k + 1 < SC.flow_col.size() / 8; k++) roots += SC.flow_col[8 * k] < 0;
+    V.flow = (e ? std::atoi(e) != 0 : kFlowDefault(SC, cus)) && fits && 4 * SC.flow_leaves <= cus && roots <= 1 ? 1 : 0;
   }
   V.strip_flags = reinterpret_cast<int32_t*>(V.ytmp + (size_t)V.n_pad + 64);   // behind the back substitution's words, cleared with them
   V.h_level_off = SC.level_off.data(); V.h_strip_off = SC.strip_off.data(); V.h_tgt_off = SC.tgt_off.data();
@@ -969,10 +975,12 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         }
         {
           BaView VS = V;                                   // in-launch hand-offs (k_chol_trsm_update) only while they have never timed out
-          // (the fused level launches assume their whole grid resident: not with several ranks on one GPU, nor after a timeout; the flow
-          //  form assumes nothing of the kind and stays for a sharded solve -- every rank solves the summed system redundantly)
+          // (the fused level launches assume their whole grid resident: not with several ranks on one GPU, nor after a timeout;
+          //  every rank of a sharded solve solves the summed system redundantly)
           if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
-          if (!h->fuse_levels) VS.flow = 0;
+          // a sharded solve keeps the level launches: a wait that gives up inside k_chol_flow has no collective retry (S_FAIL is
+          // all-reduced as "factorisation failed"), and before the flow form sharded solves had no in-launch waits at all
+          if (!h->fuse_levels || sharded) VS.flow = 0;
           ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
         }
         if (h->prof) hipEventRecord(h->pev[2], s);

@@ -84,19 +84,25 @@ int dvm_exchange_allgather_blocks(dvm_exchange* ex, const void* d_block, int64_t
 
 int dvm_exchange_allgather_varlen(dvm_exchange* ex, const void* d_block, int64_t bytes, void* d_recv, int64_t cap, int64_t* sizes_out) {
   if (!ex || bytes < 0 || cap < 0 || !sizes_out || (bytes && !d_block) || (cap && !d_recv)) return fail("dvm_exchange_allgather_varlen: bad arguments");
-  // sizes first: one int64 per rank through the scratch buffer
-  EX_TRY(ex->reserve(sizeof(int64_t) * (size_t)(ex->world + 1) + (size_t)cap));
+  // (size, cap) first: two int64 per rank through the scratch buffer.  The slot capacity must be the same on every rank (the second
+  // all-gather's count); gathering it with the sizes lets every rank see a mismatch and fail together instead of hanging in RCCL
+  const int W = ex->world;
+  EX_TRY(ex->reserve(sizeof(int64_t) * (size_t)(2 * W + 2) + (size_t)cap));
   int64_t* d_sizes = static_cast<int64_t*>(ex->scratch);
-  EX_TRY(hipc(hipMemcpyAsync(d_sizes + ex->world, &bytes, sizeof(int64_t), hipMemcpyHostToDevice, ex->stream), "copy size"));
-  EX_TRY(nc(ncclAllGather(d_sizes + ex->world, d_sizes, 1, ncclInt64, ex->comm, ex->stream), "ncclAllGather(sizes)"));
-  EX_TRY(hipc(hipMemcpyAsync(sizes_out, d_sizes, sizeof(int64_t) * (size_t)ex->world, hipMemcpyDeviceToHost, ex->stream), "copy sizes"));
+  const int64_t mine[2] = {bytes, cap};
+  std::vector<int64_t> all((size_t)2 * W);
+  EX_TRY(hipc(hipMemcpyAsync(d_sizes + 2 * W, mine, 2 * sizeof(int64_t), hipMemcpyHostToDevice, ex->stream), "copy size"));
+  EX_TRY(nc(ncclAllGather(d_sizes + 2 * W, d_sizes, 2, ncclInt64, ex->comm, ex->stream), "ncclAllGather(sizes)"));
+  EX_TRY(hipc(hipMemcpyAsync(all.data(), d_sizes, sizeof(int64_t) * (size_t)(2 * W), hipMemcpyDeviceToHost, ex->stream), "copy sizes"));
   EX_TRY(hipc(hipStreamSynchronize(ex->stream), "sync"));
   int64_t mx = 0;
-  for (int r = 0; r < ex->world; r++) mx = std::max(mx, sizes_out[r]);
+  bool caps_agree = true;
+  for (int r = 0; r < W; r++) { sizes_out[r] = all[2 * r]; mx = std::max(mx, sizes_out[r]); caps_agree = caps_agree && all[2 * r + 1] == cap; }
+  if (!caps_agree) { g_err = "dvm_exchange_allgather_varlen: the ranks passed different slot capacities"; return -3; }
   if (mx > cap) { g_err = "dvm_exchange_allgather_varlen: a block of " + std::to_string(mx) + " bytes exceeds the slot capacity"; return -3; }
   if (cap == 0) return 0;
   // every rank contributes a full slot (its block, zero padded): staged behind the sizes in the scratch buffer
-  uint8_t* d_pad = reinterpret_cast<uint8_t*>(d_sizes + ex->world + 1);
+  uint8_t* d_pad = reinterpret_cast<uint8_t*>(d_sizes + 2 * W + 2);
   EX_TRY(hipc(hipMemsetAsync(d_pad, 0, (size_t)cap, ex->stream), "pad"));
   if (bytes) EX_TRY(hipc(hipMemcpyAsync(d_pad, d_block, (size_t)bytes, hipMemcpyDeviceToDevice, ex->stream), "stage block"));
   return nc(ncclAllGather(d_pad, d_recv, (size_t)cap, ncclUint8, ex->comm, ex->stream), "ncclAllGather(ragged blocks)");

@@ -37,7 +37,8 @@ int dvm_exchange_world(const dvm_exchange* ex);
 /* every agent's block of `bytes` bytes into d_recv[world * bytes], rank order */
 int dvm_exchange_allgather_blocks(dvm_exchange* ex, const void* d_block, int64_t bytes, void* d_recv);
 /* ragged blocks: d_recv has world slots of cap bytes; sizes_out[world] (host) = every agent's size.  Fails with -3 if a block exceeds cap
- * (sizes_out is filled all the same, so that the caller can size the buffer and repeat). */
+ * (sizes_out is filled all the same, so that the caller can size the buffer and repeat).  cap must be the same on every rank (it is the
+ * count of the collective): the capacities are gathered with the sizes and every rank returns -3 together when they differ. */
 int dvm_exchange_allgather_varlen(dvm_exchange* ex, const void* d_block, int64_t bytes, void* d_recv, int64_t cap, int64_t* sizes_out);
 int dvm_exchange_send_block(dvm_exchange* ex, const void* d_block, int64_t bytes, int peer);
 int dvm_exchange_recv_block(dvm_exchange* ex, void* d_block, int64_t bytes, int peer);

@@ -1,5 +1,6 @@
 """Host-side logic of the product that can be checked without a GPU."""
 import os
+import re
 import subprocess
 import sys
 
@@ -44,7 +45,7 @@ def test_ba_ordering_and_level_schedule(tmp_path):
     adj = tmp_path / "adj.txt"
     adj.write_text(f"{len(free)}\n" + "".join(f"{a} {b}\n" for a, b in sorted(pairs)))
     out = subprocess.run([str(exe), "0", "0", "0", str(adj)], capture_output=True, text=True)
-    assert out.returncode == 0 and "levels=3" in out.stdout, out.stdout + out.stderr          # 37 or 38 levels
+    assert out.returncode == 0 and re.search(r"levels=3[0-9]\b", out.stdout), out.stdout + out.stderr          # 37 or 38 levels
     def levels(n, loop):
         out = subprocess.run([str(exe), str(n), "7", loop], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
