@@ -28,7 +28,7 @@ void launch_pyr_level0(hipStream_t s, const uint8_t* d_src, int rows, int cols, 
 void launch_pyr_resize(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int level, const int32_t* d_tabs, int batch);
 void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, int batch);
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
-                 int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num);
+                 int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num, const CellDesc* h_cells);
 int octree_root_nodes(const LevelDesc& L);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-(device, kernel) cap shared by every handle and host thread: only ever
 // RAISE it, so that a handle with a smaller configuration cannot pull the cap under a launch another thread is about to make.

@@ -743,6 +743,243 @@ __global__ void __launch_bounds__(64 * NW) k_fast_cells(const uint8_t* __restric
   }
 }
 
+// ---- ONE WAVE PER CELL (k_fast_cells1): the same stages for cells whose ROI fits a 48-byte LDS pitch.  A single wave owns the
+// whole cell, so nothing is split per wave: no list regions, no per-wave round quantisation of the survivor lists, no barriers between
+// the stages, no prefix over waves in the output.  To keep eight of these waves on a SIMD the workgroup's LDS stays under 5 KB:
+//   * the survivor list holds ONE pre-test round (<= 256 entries): stage B consumes it right behind the round, in FULL rounds of 64 --
+//     what does not fill a round stays in a register (one entry per lane) and goes first in the next one, so the strength network only
+//     ever runs a partial round once per cell and pass;
+//   * the corner list is capped (kFast1Corners).  A cell with more corners than that (noise) drops the list for this pass and stage C
+//     walks the score map pixel by pixel instead: same set, same order, slower.
+constexpr int kFast1List = 256, kFast1Corners = 384;
+struct FastLds1 {
+  int tile_bytes, score_bytes;
+  __host__ __device__ int total() const { return tile_bytes + score_bytes + 2 * (kFast1List + kFast1Corners); }
+};
+__host__ __device__ inline FastLds1 fast1_lds_layout(int pitch, int max_rw, int max_rh) {
+  FastLds1 l;
+  l.tile_bytes = (pitch * max_rh + 15) & ~15;
+  const int ew = max_rw - 6 > 0 ? max_rw - 6 : 1, eh = max_rh - 6 > 0 ? max_rh - 6 : 1;
+  l.score_bytes = ((((ew + 2 + 3) & ~3) * (eh + 2)) + 15) & ~15;
+  return l;
+}
+// pitch 48 holds a row of sh + rw <= 3 + rw bytes (sh = the ROI's misalignment in the pyramid row); wider cells take pitch 64
+__host__ __device__ inline int fast1_pick_pitch(int max_rw) { return max_rw + 3 <= 48 ? 48 : (max_rw + 3 <= 64 ? 64 : 0); }
+
+template <int PITCH>
+__device__ __forceinline__ void fast_cell1(const uint8_t* __restrict__ pyr, int pyr_frame_bytes, const CellDesc& c,
+                                           const PipelineDesc& PD, uint32_t* __restrict__ cand,
+                                           int32_t* __restrict__ cell_count, int max_rw, int max_rh, int cell_id, int f) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+  const FastLds1 lay = fast1_lds_layout(PITCH, max_rw, max_rh);
+  uint8_t* tile = fast_smem;
+  uint8_t* score = tile + lay.tile_bytes;
+  uint16_t* list = reinterpret_cast<uint16_t*>(score + lay.score_bytes);
+  uint16_t* clist = list + kFast1List;
+
+  const LevelDesc& L = PD.lv[c.level];
+  const int lane = threadIdx.x;
+  const int rw = c.rw, rh = c.rh;
+  const int ew = rw - 6, eh = rh - 6;
+  const int sp = (ew + 2 + 3) & ~3;
+  int32_t* my_count = cell_count + (int64_t)f * PD.ncells + cell_id;
+  if (ew <= 0 || eh <= 0) {
+    if (lane == 0) *my_count = 0;
+    return;
+  }
+  // ---- 1. tile load (as fast_cell: 16 bytes per lane and item, rows of PITCH / 16 items)
+  const int64_t row0 = (int64_t)f * pyr_frame_bytes + L.pyr_off + (int64_t)(kEdge + c.y0) * L.stride;
+  const int xg = kEdge + c.x0;
+  const int sh = xg & 3;
+  const int dwr = (sh + rw + 3) >> 2;
+  const uint32_t* g32 = reinterpret_cast<const uint32_t*>(pyr + row0 + (xg - sh));
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
+  constexpr int pitch4 = PITCH >> 2;
+  {
+    const int q = (dwr + 3) >> 2;
+    int y = (int)(((float)lane + 0.5f) * (1.0f / (float)q)), x = lane - y * q;
+    const int dy = 64 / q, dx = 64 - dy * q;
+    while (y < rh) {
+      uint4 v;
+      __builtin_memcpy(&v, g32 + (int64_t)y * (L.stride >> 2) + 4 * x, 16);
+      *reinterpret_cast<uint4*>(t32 + y * pitch4 + 4 * x) = v;
+      x += dx; y += dy;
+      if (x >= q) { x -= q; y++; }
+    }
+  }
+  uint4* s128 = reinterpret_cast<uint4*>(score);
+  for (int i = lane; i < (sp * (eh + 2) + 15) >> 4; i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+
+  const uint8_t* T = tile + sh;
+  uint32_t* out = cand + (int64_t)f * PD.cand_frame_slots + c.cand_base;
+  int tlow = PD.ini_th;
+  int total = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int c0 = (sh + 3) >> 2, c1 = (sh + 3 + ew - 1) >> 2, ncol = c1 - c0 + 1;
+    const int nitems = eh * ncol;
+    const int roundsA = (nitems + 63) >> 6;
+    int nc = 0;              // corners in clist (wave-uniform)
+    bool overflow = false;   // wave-uniform: clist dropped for this pass
+    int npend = 0, pend = 0; // survivors waiting for a full round: lane i < npend holds one
+    // stage B on 64 (or, at the end, npend) survivors, one per lane
+    auto strength_round = [&](int pe, bool valid) {
+      int sc = 0;
+      if (valid) {
+        const int ey = pe >> 7, ex = pe & 127;
+        const int m = fast_strength<PITCH>(&T[(ey + 3) * PITCH + ex + 3], PITCH);
+        sc = m > tlow ? m - 1 : 0;
+        if (sc) score[(ey + 1) * sp + ex + 1] = (uint8_t)sc;
+      }
+      const unsigned long long bc = __ballot(sc > 0);
+      const int n = __popcll(bc);
+      if (nc + n > kFast1Corners) overflow = true;
+      if (!overflow) {
+        if (sc > 0) clist[nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u))] = (uint16_t)pe;
+        nc += n;
+      }
+    };
+    {
+      int it = lane;
+      int ey = (int)(((float)it + 0.5f) * (1.0f / (float)ncol)), cc = it - ey * ncol;
+      const int dy = 64 / ncol, dc = 64 - dy * ncol;
+      const ushort2_t T2 = pk(tlow, tlow);
+      const int exb0 = 4 * c0 - sh - 3;
+      const int vlo = max(0, -exb0), vhi = min(4, ew - (exb0 + 4 * (ncol - 1)));
+      uint32_t mask_first = 0, mask_last = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t bit = (k & 1 ? 0x80000000u : 0x00008000u) >> (k >> 1);
+        if (k >= vlo) mask_first |= bit;
+        if (k < vhi) mask_last |= bit;
+      }
+      if (ncol == 1) mask_first &= mask_last;
+      for (int r = 0; r < roundsA; r++) {
+        uint32_t pm = 0;
+        if (it < nitems) {
+          const int cix = c0 + cc;
+          const uint32_t* row = t32 + (ey + 3) * pitch4 + cix;
+          const uint32_t Cd = row[0], Wd = row[-1], Ed = row[1], Nd = row[3 * pitch4], Sd = row[-3 * pitch4];
+          uint32_t q[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const ushort2_t C = __builtin_bit_cast(ushort2_t, DVM_PERM2(0u, Cd, 2 * h, 2 * h + 1));
+            const ushort2_t N = __builtin_bit_cast(ushort2_t, DVM_PERM2(0u, Nd, 2 * h, 2 * h + 1));
+            const ushort2_t S = __builtin_bit_cast(ushort2_t, DVM_PERM2(0u, Sd, 2 * h, 2 * h + 1));
+            const ushort2_t W = __builtin_bit_cast(ushort2_t, DVM_PERM2(Cd, Wd, 2 * h + 1, 2 * h + 2));
+            const ushort2_t E = __builtin_bit_cast(ushort2_t, DVM_PERM2(Ed, Cd, 2 * h + 3, 2 * h + 4));
+            const ushort2_t nsl = __builtin_elementwise_min(N, S), nsh = __builtin_elementwise_max(N, S);
+            const ushort2_t ewl = __builtin_elementwise_min(E, W), ewh = __builtin_elementwise_max(E, W);
+            const ushort2_t mx = __builtin_elementwise_max(nsl, ewl);
+            const ushort2_t mn = __builtin_elementwise_min(nsh, ewh);
+            typedef short short2s __attribute__((ext_vector_type(2)));
+            const short2s dk = __builtin_bit_cast(short2s, C) - __builtin_bit_cast(short2s, mx);
+            const short2s br = __builtin_bit_cast(short2s, mn) - __builtin_bit_cast(short2s, C);
+            const short2s m = __builtin_elementwise_max(dk, br);
+            q[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2s, T2) - m);
+          }
+          const uint32_t vmask = cc == 0 ? mask_first : (cc == ncol - 1 ? mask_last : 0xC000C000u);
+          pm = ((q[0] & 0x80008000u) | ((q[1] >> 1) & 0x40004000u)) & vmask;
+        }
+        const int cnt = __popc(pm);
+        const int incl = wave_incl_scan(cnt);
+        if (pm) {
+          int pos = incl - cnt;
+          const int e0 = (ey << 7) + 4 * cc + exb0;
+          if (pm & 0x00008000u) list[pos++] = (uint16_t)e0;
+          if (pm & 0x80000000u) list[pos++] = (uint16_t)(e0 + 1);
+          if (pm & 0x00004000u) list[pos++] = (uint16_t)(e0 + 2);
+          if (pm & 0x40000000u) list[pos] = (uint16_t)(e0 + 3);
+        }
+        int avail = __builtin_amdgcn_readlane(incl, 63), base = 0;
+        // ---- B, full rounds only: the waiting entries first (they come before this round's in row-major order)
+        while (npend + avail >= 64) {
+          const int pe = lane < npend ? pend : (int)list[base + lane - npend];
+          strength_round(pe, true);
+          base += 64 - npend; avail -= 64 - npend; npend = 0;
+        }
+        if (avail) {
+          if (lane >= npend && lane < npend + avail) pend = list[base + lane - npend];
+          npend += avail;
+        }
+        it += 64; cc += dc; ey += dy;
+        if (cc >= ncol) { cc -= ncol; ey++; }
+      }
+    }
+    if (npend) strength_round(pend, lane < npend);
+    __syncthreads();   // (one wave: orders the score-map stores before stage C's loads)
+    // ---- C. strict local maxima, written straight to the cell's slots in list order = row-major
+    int kept = 0;
+    if (!overflow) {
+      for (int r = 0; r < nc; r += 64) {
+        const int k = r + lane;
+        bool keep = false;
+        int pe = 0, sv = 0;
+        if (k < nc) {
+          pe = clist[k];
+          const uint8_t* s = &score[((pe >> 7) + 1) * sp + (pe & 127) + 1];
+          sv = s[0];
+          const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
+                             max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
+          keep = sv > mx;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = kept + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep && pos < c.cand_cap)
+          out[pos] = pack_cand(c.x0 + 3 + (pe & 127) - (kEdge - 3), c.y0 + 3 + (pe >> 7) - (kEdge - 3), sv);
+        kept += __popcll(m);
+      }
+    } else {
+      // the score map pixel by pixel (every non-zero score is a corner of this pass: see the pass comment in fast_cell)
+      int ey = (int)(((float)lane + 0.5f) * (1.0f / (float)ew)), ex = lane - ey * ew;
+      const int dy = 64 / ew, dx = 64 - dy * ew;
+      for (int k = 0; k < ew * eh; k += 64) {
+        bool keep = false;
+        int sv = 0;
+        if (ey < eh) {
+          const uint8_t* s = &score[(ey + 1) * sp + ex + 1];
+          sv = s[0];
+          const int mx = max(max(max(s[-sp - 1], s[-sp]), max(s[-sp + 1], s[-1])),
+                             max(max(s[1], s[sp - 1]), max(s[sp], s[sp + 1])));
+          keep = sv > 0 && sv > mx;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = kept + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep && pos < c.cand_cap) out[pos] = pack_cand(c.x0 + 3 + ex - (kEdge - 3), c.y0 + 3 + ey - (kEdge - 3), sv);
+        kept += __popcll(m);
+        ex += dx; ey += dy;
+        if (ex >= ew) { ex -= ew; ey++; }
+      }
+    }
+    total = kept;
+    if (kept == 0 && pass == 0 && PD.min_th < PD.ini_th) {
+      tlow = PD.min_th;
+      __syncthreads();
+      continue;
+    }
+    break;
+  }
+  if (lane == 0) *my_count = min(total, c.cand_cap);
+}
+
+// same launch geometry as k_fast_cells (workgroup = one wave)
+template <int PITCH>
+__global__ void __launch_bounds__(64, 8) __attribute__((amdgpu_num_sgpr(80))) k_fast_cells1(const uint8_t* __restrict__ pyr, int pyr_frame_bytes,
+                                                    const CellDesc* __restrict__ cells, PipelineDesc PD,
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ cell_count,
+                                                    int max_rw, int max_rh, int batch, int cell_first, int cell_num) {
+  const int b = blockIdx.x, i = b >> 3;
+  const int cell_id = cell_first + i % cell_num;
+  const int fbase = (i / cell_num) * (8 * kFastFramesPerWG) + (b & 7);
+  const CellDesc c = cells[cell_id];
+  for (int j = 0; j < kFastFramesPerWG; j++) {
+    const int f = fbase + 8 * j;
+    if (f >= batch) break;
+    if (j) __syncthreads();
+    fast_cell1<PITCH>(pyr, pyr_frame_bytes, c, PD, cand, cell_count, max_rw, max_rh, cell_id, f);
+  }
+}
+
 #ifdef DVM_FAST_DEBUG
 extern "C" int dvm_debug_fast_stamps(unsigned long long* out, int reset) {
   static unsigned long long h[8192 * 8];
@@ -1119,9 +1356,9 @@ void launch_pyr_borders(hipStream_t s, uint8_t* d_pyr, const PipelineDesc& PD, i
   dim3 grid(std::max(1, cdiv(cdiv(maxw, 16), 64)), strip_blocks + cdiv(rows, 128), batch);
   hipLaunchKernelGGL(k_pyr_borders, grid, dim3(256), 0, s, d_pyr, PD, strip_blocks);
 }
-void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
-                 int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num) {
-  if (cell_num <= 0) return;
+// the two-wave (four-wave) form, one launch over a cell range
+static void launch_fast_wide(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
+                             int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num) {
   const FastLds lay = fast_lds_layout(max_rw, max_rh);
   const dim3 grid(cell_num * 8 * ((batch + 8 * kFastFramesPerWG - 1) / (8 * kFastFramesPerWG)));
   // two waves per cell while 32 survivor rounds of 128 cover the largest cell, else four
@@ -1139,6 +1376,49 @@ void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, c
   if (lay.tile_pitch == 64) { if (small) DVM_FAST_LAUNCH(64, 2); else DVM_FAST_LAUNCH(64, 4); }
   else DVM_FAST_LAUNCH(0, 4);
 #undef DVM_FAST_LAUNCH
+}
+// Levels whose cells fit k_fast_cells1's small LDS layout (one wave per cell, eight waves per SIMD) take that kernel; the others (the
+// coarse levels' taller cells at 640 x 480, any level of a large-cell configuration) the two-wave form.  Consecutive levels of one kind
+// share a launch.  h_cells = host copy of the cell table (nullptr: the wide form for everything).
+void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
+                 int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num, const CellDesc* h_cells) {
+  if (cell_num <= 0) return;
+  static const int lds1_max = std::getenv("DVM_FAST1_LDS") ? atoi(std::getenv("DVM_FAST1_LDS")) : 5120;   // 0: the wide form only (A/B)
+  static const int lds1_max64 = std::getenv("DVM_FAST1_LDS64") ? atoi(std::getenv("DVM_FAST1_LDS64")) : 0;
+  if (!h_cells || lds1_max <= 0) { launch_fast_wide(s, d_pyr, d_cells, PD, d_cand, d_cell_count, batch, max_rw, max_rh, cell_first, cell_num); return; }
+  const int end = cell_first + cell_num;
+  int run_first = cell_first, run_kind = -1, run_rw = 0, run_rh = 0;
+  auto flush = [&](int upto) {
+    if (upto <= run_first || run_kind < 0) return;
+    const int n = upto - run_first;
+    if (run_kind == 0) { launch_fast_wide(s, d_pyr, d_cells, PD, d_cand, d_cell_count, batch, run_rw, run_rh, run_first, n); return; }
+    const int pitch = run_kind;
+    const int lds = fast1_lds_layout(pitch, run_rw, run_rh).total();
+    const dim3 grid(n * 8 * ((batch + 8 * kFastFramesPerWG - 1) / (8 * kFastFramesPerWG)));
+    if (pitch == 48)
+      hipLaunchKernelGGL((k_fast_cells1<48>), grid, dim3(64), lds, s, d_pyr, PD.pyr_frame_bytes, d_cells, PD, d_cand, d_cell_count, run_rw, run_rh, batch, run_first, n);
+    else
+      hipLaunchKernelGGL((k_fast_cells1<64>), grid, dim3(64), lds, s, d_pyr, PD.pyr_frame_bytes, d_cells, PD, d_cand, d_cell_count, run_rw, run_rh, batch, run_first, n);
+  };
+  int c = cell_first;
+  while (c < end) {
+    const int lvl = h_cells[c].level;
+    int e = c, rw = 8, rh = 8;
+    for (; e < end && h_cells[e].level == lvl; e++) { rw = std::max<int>(rw, h_cells[e].rw); rh = std::max<int>(rh, h_cells[e].rh); }
+    const int pitch = fast1_pick_pitch(rw);
+    // (a list entry packs the evaluated x into 7 bits and y above it: the same limits as the wide form's)
+    // kind: 0 = the wide form, else the one-wave form's LDS pitch (levels of different pitch do not share a launch: the narrow
+    // layout is what keeps eight waves on a SIMD)
+    const int kind = pitch != 0 && fast1_lds_layout(pitch, rw, rh).total() <= (pitch == 48 ? lds1_max : lds1_max64) ? pitch : 0;
+    if (kind != 0 && kind == run_kind) {   // joining the run must not push the run's own layout over the limit
+      const int jrw = std::max(run_rw, rw), jrh = std::max(run_rh, rh);
+      if (fast1_lds_layout(kind, jrw, jrh).total() > (kind == 48 ? lds1_max : lds1_max64)) { flush(c); run_first = c; run_kind = -1; }
+    }
+    if (kind != run_kind) { flush(c); run_first = c; run_kind = kind; run_rw = rw; run_rh = rh; }
+    else { run_rw = std::max(run_rw, rw); run_rh = std::max(run_rh, rh); }
+    c = e;
+  }
+  flush(end);
 }
 void launch_assemble(hipStream_t s, const uint32_t* d_sel, const int32_t* d_nsel, const PipelineDesc& PD, int lap0,
                      int lap1, dvm_keypoint_pod* d_kps, KpAux* d_aux, int32_t* d_n, int32_t* d_mono, int batch, HostMirror hm) {

@@ -670,7 +670,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
     if (split0) {   // level 0: FAST cells + octree on the second stream, beside everything below up to k_assemble
       DVM_HIP(hipEventRecord(ev_group[0], st));
       DVM_HIP(hipStreamWaitEvent(lat_aux, ev_group[0], 0));
-      launch_fast(lat_aux, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, PD.lv[0].cell_first, PD.lv[0].cell_count);
+      launch_fast(lat_aux, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, PD.lv[0].cell_first, PD.lv[0].cell_count, cells.data());
       launch_octree(lat_aux, cand_f0, cnt_f0, d_cells, dense_f0, lcnt_f0, PD, nid_f0, sel_f0, nsel_f0, d_err, nb, 0, 1, true);
       DVM_HIP(hipEventRecord(ev_group[3], lat_aux));
     }
@@ -706,7 +706,7 @@ int OrbPipeline::extract_device(const uint8_t* d_imgs, int batch, int rows, int 
       const int la = gl[gi], lb = gl[gi + 1];
       if (la >= lb) continue;
       const int c_first = PD.lv[la].cell_first, c_end = PD.lv[lb - 1].cell_first + PD.lv[lb - 1].cell_count;
-      launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, c_first, c_end - c_first);
+      launch_fast(st, pyr_f0, d_cells, PD, cand_f0, cnt_f0, nb, max_cell_rw, max_cell_rh, c_first, c_end - c_first, cells.data());
       if (grouped && lb < L) {
         DVM_HIP(hipEventRecord(ev_group[gi], st));
         DVM_HIP(hipStreamWaitEvent(aux, ev_group[gi], 0));
