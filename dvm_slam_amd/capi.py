@@ -850,6 +850,67 @@ def search_by_projection_frames(kps_c, desc_c, mp_c, Tcw, K, bounds, scale_facto
     return n, mp, req.value
 
 
+class TrackResult(C.Structure):
+    """dvmh_track_result (include/dvmslam_host.h)"""
+    _fields_ = [("n", C.c_int32), ("mono_index", C.c_int32), ("nmatches", C.c_int32), ("nmatches_search", C.c_int32), ("nmatches_map", C.c_int32),
+                ("n_inliers", C.c_int32), ("wide_window", C.c_int32), ("replayed_on_host", C.c_int32), ("tracked", C.c_int32),
+                ("Tcw", C.c_float * 7), ("pose", C.c_double * 7)]
+
+
+class Distortion(C.Structure):
+    """dvm_distortion (include/dvmslam_hip.h)"""
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
+class Tracker:
+    """dvm_tracker + dvmh_track_with_motion_model: Frame::Frame -> ExtractORB and Tracking::TrackWithMotionModel of one frame as ONE
+    device chain behind one synchronisation (reference src/Frame.cc:371-411, src/Tracking.cc:2584-2667)."""
+
+    def __init__(self, ext: "OrbExtractor", device=0, max_queries=None):
+        self.L, self.H, self.ext, self.device = lib(), host_lib(), ext, device
+        self.t = C.c_void_p()
+        f = self.L.dvm_tracker_create
+        f.restype = C.c_int32; f.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        check(f(device, ext.cap, max_queries or ext.cap, C.byref(self.t)))
+
+    def close(self):
+        if getattr(self, "t", None) and self.t.value:
+            f = self.L.dvm_tracker_destroy
+            f.restype = None; f.argtypes = [C.c_void_p]
+            f(self.t)
+            self.t = C.c_void_p()
+
+    __del__ = close
+
+    def track(self, img, Tcw_pred, K, bounds, scale_factors, inv_sigma2, kps_l, mp_l, outlier_l, mps, th=15.0, check_ori=True, dist=None,
+              lap=(0, 1000)):
+        """Tcw_pred: 7 floats (qx, qy, qz, qw, t).  Returns a dict: n, kps, desc, kps_un, mp (mvpMapPoints after the outlier drop), dropped,
+        pose (7 doubles: t, q), and the counters of dvmh_track_result."""
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = self.ext.cap
+        kps = np.empty(cap, KP_DTYPE); kun = np.empty(cap, KP_DTYPE); desc = np.empty((cap, 32), np.uint8)
+        mp = np.empty(cap, np.int32); dropped = np.empty(cap, np.int32)
+        kps_l = np.ascontiguousarray(kps_l, KP_DTYPE); mp_l = np.ascontiguousarray(mp_l, np.int32)
+        outl = None if outlier_l is None else np.ascontiguousarray(outlier_l, np.uint8)
+        f4 = [np.ascontiguousarray(a, np.float32) for a in (Tcw_pred, K, bounds, scale_factors, inv_sigma2)]
+        mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
+        res = TrackResult()
+        fn = self.H.dvmh_track_with_motion_model
+        fn.restype = C.c_int32; fn.argtypes = None
+        vp = C.c_void_p
+        rc = fn(self.t, self.ext.h, C.c_int32(self.device), vp(img.ctypes.data), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]), C.c_int32(img.strides[0]),
+                C.c_int32(lap[0]), C.c_int32(lap[1]), _p(f4[0]), _p(f4[1]), _p(f4[2]), None if dist is None else C.byref(dist), _p(f4[3]), _p(f4[4]),
+                C.c_int32(len(f4[3])), C.c_int32(len(kps_l)), _p(kps_l), _p(mp_l), None if outl is None else _p(outl), _p(mps), C.c_float(float(th)),
+                C.c_int32(int(check_ori)), _p(kps), _p(desc), C.c_int32(cap), _p(kun), _p(mp), _p(dropped), C.byref(res))
+        check(rc)
+        n = res.n
+        out = {k: getattr(res, k) for k in ("n", "mono_index", "nmatches", "nmatches_search", "nmatches_map", "n_inliers", "wide_window",
+                                            "replayed_on_host", "tracked")}
+        out.update(kps=kps[:n], kps_un=kun[:n], desc=desc[:n], mp=mp[:n], dropped=dropped[:n], pose=np.array(res.pose[:], np.float64),
+                   Tcw=np.array(res.Tcw[:], np.float32))
+        return out
+
+
 TRACKED_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
                                 ("in_view", "u1"), ("bad", "u1"), ("pad", "u1", (2,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
 

@@ -978,9 +978,9 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
           // (the fused level launches assume their whole grid resident: not with several ranks on one GPU, nor after a timeout;
           //  every rank of a sharded solve solves the summed system redundantly)
           if (sharded || !h->fuse_levels) VS.strip_flags = nullptr;
-          // a sharded solve keeps the level launches: a wait that gives up inside k_chol_flow has no collective retry (S_FAIL is
-          // all-reduced as "factorisation failed"), and before the flow form sharded solves had no in-launch waits at all
-          if (!h->fuse_levels || sharded) VS.flow = 0;
+          // (a sharded solve keeps the flow form -- every rank solves the summed system redundantly, on its own GPU; a wait that
+          //  gives up on ANY rank is all-reduced below and every rank repeats the trial with the level launches)
+          if (!h->fuse_levels) VS.flow = 0;
           ba_launch_cholesky_solve(s, VS, h->d_fail, ++h->solve_seq);
         }
         if (h->prof) hipEventRecord(h->pev[2], s);
@@ -1014,9 +1014,19 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         if (rc == DVM_OK) rc = wait_seq(h, h->seq);
         if (rc != DVM_OK) return rc;
         mark("trial published", it);
+        bool timed_out = h->h_vals[S_FAIL] == 2.0;
+        if (sharded) {
+          // chi2 and the gain-ratio denominator are sums over ranks; the failure flag rides along (a sum of non-negative flags =
+          // "any rank failed"; 1e6 = "a wait inside some rank's solve gave up"): every rank must take the SAME accept / reject /
+          // repeat decision, or the LM state and the collectives of the following trials diverge
+          double v[3] = {h->h_vals[S_TMPCHI], h->h_vals[S_SCALE], timed_out ? 1e6 : (h->h_vals[S_FAIL] != 0.0 ? 1.0 : 0.0)};
+          if ((rc = ar_host(v, 3, 0)) != DVM_OK) return rc;
+          timed_out = v[2] >= 1e6;
+          h->h_vals[S_TMPCHI] = v[0]; h->h_vals[S_SCALE] = v[1]; h->h_vals[S_FAIL] = timed_out ? 2.0 : (v[2] != 0.0 ? 1.0 : 0.0);
+        }
         // a wait inside the solve gave up (other work held the compute units its producer needed): nothing was decided on this
-        // result -- the same trial runs again, with one launch per phase from now on
-        if (h->h_vals[S_FAIL] == 2.0 && h->fuse_levels && !sharded && attempt == 0) {
+        // result -- the same trial runs again (on every rank of a sharded solve), with one launch per phase from now on
+        if (timed_out && h->fuse_levels && attempt == 0) {
           h->fuse_levels = false;
           if (spec_now) {                                  // whatever was enqueued behind the failed attempt is void
             DVM_HIP(hipStreamSynchronize(s));
@@ -1032,14 +1042,6 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
         hipEventSynchronize(h->pev[3]);
         for (int k = 0; k < 3; k++) { float ms = 0; hipEventElapsedTime(&ms, h->pev[k], h->pev[k + 1]); h->prof_ms[1 + k] += ms; }
         h->prof_trials++;
-      }
-      if (sharded) {
-        // chi2 and the gain-ratio denominator are sums over ranks; the failure flag rides along (a sum of non-negative flags =
-        // "any rank failed"): every rank must take the SAME accept / reject decision, or the LM state and the collectives of
-        // the following trials diverge
-        double v[3] = {h->h_vals[S_TMPCHI], h->h_vals[S_SCALE], h->h_vals[S_FAIL] != 0.0 ? 1.0 : 0.0};
-        if ((rc = ar_host(v, 3, 0)) != DVM_OK) return rc;
-        h->h_vals[S_TMPCHI] = v[0]; h->h_vals[S_SCALE] = v[1]; h->h_vals[S_FAIL] = v[2] != 0.0 ? 1.0 : 0.0;
       }
       // A failed linear solve (optimization_algorithm_levenberg.cpp:107-127): g2o still applies update(x) -- x being whatever the
       // last successful solve left (zeros before the first) --, evaluates the errors there, then overrides tempChi with max()

@@ -1395,7 +1395,11 @@ static void launch_fast_wide(hipStream_t s, const uint8_t* d_pyr, const CellDesc
 void launch_fast(hipStream_t s, const uint8_t* d_pyr, const CellDesc* d_cells, const PipelineDesc& PD, uint32_t* d_cand,
                  int32_t* d_cell_count, int batch, int max_rw, int max_rh, int cell_first, int cell_num, const CellDesc* h_cells) {
   if (cell_num <= 0) return;
-  static const int lds1_max = std::getenv("DVM_FAST1_LDS") ? atoi(std::getenv("DVM_FAST1_LDS")) : 5120;   // 0: the wide form only (A/B)
+  // LDS is granted in steps of 1 280 bytes: <= 5 120 keeps 32 one-wave workgroups on a CU.  (Measured and not adopted: a second tier
+  // <= 6 400 bytes, or a 64-byte pitch, for the taller cells of the coarse levels -- two more launches with short grids, 0.51 ms
+  // against 0.39; and one polarity per list entry with half the strength network -- the wider expansion eats what stage B saves.)
+  // DVM_FAST1_LDS=0: the wide form only (A/B)
+  static const int lds1_max = std::getenv("DVM_FAST1_LDS") ? atoi(std::getenv("DVM_FAST1_LDS")) : 5120;
   static const int lds1_max64 = std::getenv("DVM_FAST1_LDS64") ? atoi(std::getenv("DVM_FAST1_LDS64")) : 0;
   if (!h_cells || lds1_max <= 0) { launch_fast_wide(s, d_pyr, d_cells, PD, d_cand, d_cell_count, batch, max_rw, max_rh, cell_first, cell_num); return; }
   const int end = cell_first + cell_num;

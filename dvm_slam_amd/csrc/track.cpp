@@ -1,0 +1,187 @@
+// dvm_slam_amd/csrc/track.cpp -- dvm_tracker: ONE enqueue per tracked frame (include/dvmslam_hip.h, "tracking step").
+//
+// The reference's per-frame hot loop is Frame::Frame -> ExtractORB (src/Frame.cc:371-411) followed by
+// Tracking::TrackWithMotionModel (src/Tracking.cc:2584-2667): SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1553-1748)
+// -> Optimizer::PoseOptimization (src/Optimizer.cc:744-1028) -> outlier matches dropped.  Through the three separate calls of this
+// library that is three blocking host <-> device round trips with the claim replay, the rotation histogram and the edge gathering on
+// the host in between.  Here the whole step is one chain on the extractor's stream:
+//   dvm_track_begin    queues the extraction of the frame and returns (the host builds the projection queries meanwhile: they need
+//                      LastFrame's map points and the predicted pose, nothing of the new frame)
+//   dvm_track_finish   queues [undistortion] -> grid (k_frame_build) -> ranked window search -> k_track_claims -> k_track_gather ->
+//                      k_pose_optimize -> k_track_finish behind it, synchronises ONCE and hands everything back
+// Results are those of the separate calls bit for bit (tests/test_gpu_track_frame.py).  Two cases are handed back to the caller
+// unfinished, flagged in dvm_track_result::status: fewer than min_matches matches (the reference searches again with a doubled window,
+// Tracking.cc:2616-2624: call dvm_track_finish again with the wider queries -- no new extraction), and a query whose four ranked
+// candidates were all taken by earlier queries (the list may go on: the caller replays the epilogue from the ranked lists on the host).
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "../../include/dvmslam_hip.h"
+#include "ba_kernels.h"
+#include "match_kernels.h"
+#include "orb_pipeline.h"
+#include "track_kernels.h"
+
+using namespace dvm;
+
+struct dvm_tracker {
+  int device = 0, kp_cap = 0, q_cap = 0;
+  dvm_frame* grid = nullptr;
+  uint8_t* d_buf = nullptr;        // device working set (one allocation)
+  uint8_t *hm = nullptr, *hm_dev = nullptr;   // mapped page-locked buffer: queries in, results out
+  size_t hm_bytes = 0;
+  // device
+  uint32_t* d_ranked; int32_t* d_assign; int32_t* d_res; double *d_Xw, *d_obs, *d_info, *d_chi; int32_t *d_edge_kp, *d_nedges;
+  uint8_t* d_edge_out; dvm_keypoint_pod* d_kps_un;
+  // mapped (host address; device address = hm_dev + (p - hm))
+  struct Mapped {
+    uint8_t* qdesc; float *qx, *qy, *qr; int32_t *qmin, *qmax; uint8_t* q_claims; float *q_angle, *q_pos; double* pose_in;
+    int32_t* assign; uint8_t* outlier; int32_t* res; int32_t* fin; int32_t* nedges; double* pose_out; int32_t* n_inl; float* inv_sigma2;
+    dvm_keypoint_pod* kps_un;
+  } m;
+  template <class T> T* dev(T* host_ptr) const { return reinterpret_cast<T*>(hm_dev + (reinterpret_cast<uint8_t*>(host_ptr) - hm)); }
+  bool begun = false;
+  int rows = 0, cols = 0;
+};
+
+namespace {
+size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+template <class T> T* carve(uint8_t*& p, size_t count) { T* r = reinterpret_cast<T*>(p); p += pad256(count * sizeof(T)); return r; }
+}  // namespace
+
+extern "C" {
+
+int dvm_tracker_create(int device, int max_keypoints, int max_queries, dvm_tracker** out) {
+  if (!out || max_keypoints < 1 || max_queries < 1) return DVM_ERR_INVALID;
+  *out = nullptr;
+  if (max_keypoints > kFrameCap || max_queries > kFrameCap || track_claims_lds(max_keypoints, max_queries) > 60 * 1024) {
+    set_error("dvm_tracker_create: capacity beyond what the claim replay keeps in LDS (9 B per keypoint + 4 B per query <= 60 KB)");
+    return DVM_ERR_CAPACITY;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible (libdvmslam_hip has no CPU path)"); return DVM_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { set_error("device index out of range"); return DVM_ERR_INVALID; }
+  DVM_HIP(hipSetDevice(device));
+  dvm_tracker* t = new (std::nothrow) dvm_tracker();
+  if (!t) return DVM_ERR_INVALID;
+  t->device = device; t->kp_cap = max_keypoints; t->q_cap = max_queries;
+  int rc = dvm_frame_create(device, max_keypoints, 1, &t->grid);
+  if (rc != DVM_OK) { delete t; return rc; }
+  const size_t K = (size_t)max_keypoints, Q = (size_t)max_queries;
+  // device working set
+  size_t dbytes = pad256(Q * 16) + pad256(K * 4) + pad256(16) + pad256(K * 24) + pad256(K * 16) + 2 * pad256(K * 8) + pad256(K * 4) + pad256(16) +
+                  pad256(K) + pad256(K * sizeof(dvm_keypoint_pod));
+  if (hipMalloc(reinterpret_cast<void**>(&t->d_buf), dbytes) != hipSuccess) { dvm_tracker_destroy(t); set_error("dvm_tracker_create: hipMalloc"); return DVM_ERR_HIP; }
+  uint8_t* p = t->d_buf;
+  t->d_ranked = carve<uint32_t>(p, Q * 4); t->d_assign = carve<int32_t>(p, K); t->d_res = carve<int32_t>(p, 4);
+  t->d_Xw = carve<double>(p, K * 3); t->d_obs = carve<double>(p, K * 2); t->d_info = carve<double>(p, K); t->d_chi = carve<double>(p, K);
+  t->d_edge_kp = carve<int32_t>(p, K); t->d_nedges = carve<int32_t>(p, 4); t->d_edge_out = carve<uint8_t>(p, K);
+  t->d_kps_un = carve<dvm_keypoint_pod>(p, K);
+  // mapped buffer
+  size_t mbytes = pad256(Q * 32) + 3 * pad256(Q * 4) + 2 * pad256(Q * 4) + pad256(Q) + pad256(Q * 4) + pad256(Q * 12) + pad256(56) + pad256(K * 4) +
+                  pad256(K) + 3 * pad256(16) + pad256(56) + pad256(4) + pad256(64 * 4) + pad256(K * sizeof(dvm_keypoint_pod));
+  if (hipHostMalloc(reinterpret_cast<void**>(&t->hm), mbytes, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&t->hm_dev), t->hm, 0) != hipSuccess) {
+    dvm_tracker_destroy(t); set_error("dvm_tracker_create: mapped host memory"); return DVM_ERR_HIP;
+  }
+  t->hm_bytes = mbytes;
+  std::memset(t->hm, 0, mbytes);
+  p = t->hm;
+  auto& m = t->m;
+  m.qdesc = carve<uint8_t>(p, Q * 32); m.qx = carve<float>(p, Q); m.qy = carve<float>(p, Q); m.qr = carve<float>(p, Q);
+  m.qmin = carve<int32_t>(p, Q); m.qmax = carve<int32_t>(p, Q); m.q_claims = carve<uint8_t>(p, Q); m.q_angle = carve<float>(p, Q);
+  m.q_pos = carve<float>(p, Q * 3); m.pose_in = carve<double>(p, 7); m.assign = carve<int32_t>(p, K); m.outlier = carve<uint8_t>(p, K);
+  m.res = carve<int32_t>(p, 4); m.fin = carve<int32_t>(p, 4); m.nedges = carve<int32_t>(p, 4); m.pose_out = carve<double>(p, 7);
+  m.n_inl = carve<int32_t>(p, 1); m.inv_sigma2 = carve<float>(p, 64); m.kps_un = carve<dvm_keypoint_pod>(p, K);
+  *out = t;
+  return DVM_OK;
+}
+
+void dvm_tracker_destroy(dvm_tracker* t) {
+  if (!t) return;
+  hipSetDevice(t->device);
+  if (t->grid) dvm_frame_destroy(t->grid);
+  if (t->d_buf) hipFree(t->d_buf);
+  if (t->hm) hipHostFree(t->hm);
+  delete t;
+}
+
+int dvm_track_begin(dvm_tracker* t, dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1) {
+  if (!t || !h) return DVM_ERR_INVALID;
+  t->begun = false;
+  const int rc = dvm_orb_extract_batch_host(h, img, 1, rows, cols, stride, (int64_t)rows * stride, lap0, lap1);
+  if (rc != DVM_OK) return rc;
+  t->begun = true; t->rows = rows; t->cols = cols;
+  return DVM_OK;
+}
+
+int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm_keypoint* kps, uint8_t* desc, int cap, dvm_keypoint* kps_un,
+                     int32_t* assign, uint8_t* outlier, uint32_t* ranked, dvm_track_result* res) {
+  if (!t || !h || !q || !res || !kps || !desc || !assign || !outlier) return DVM_ERR_INVALID;
+  if (!t->begun) { set_error("dvm_track_finish: no dvm_track_begin on this tracker"); return DVM_ERR_STATE; }
+  if (q->nq < 0 || q->nq > t->q_cap || q->nlevels < 1 || q->nlevels > 64 || !q->inv_level_sigma2) { set_error("dvm_track_finish: bad query set"); return DVM_ERR_INVALID; }
+  if (q->nq && (!q->qdesc || !q->qx || !q->qy || !q->qr || !q->qmin || !q->qmax || !q->q_claims || !q->q_angle || !q->q_pos)) return DVM_ERR_INVALID;
+  std::memset(res, 0, sizeof(*res));
+  DVM_HIP(hipSetDevice(t->device));
+  hipStream_t s = (hipStream_t)dvm_orb_stream(h);
+  const dvm_keypoint* d_kps = nullptr; const uint8_t* d_desc = nullptr; const int32_t* d_n = nullptr; int ocap = 0;
+  int rc = dvm_orb_result_device(h, 0, &d_kps, &d_desc, &d_n, &ocap);
+  if (rc != DVM_OK) return rc;
+  if (ocap > t->kp_cap) { set_error("dvm_track_finish: the extractor's keypoint capacity exceeds the tracker's"); return DVM_ERR_CAPACITY; }
+  const int nq = q->nq;
+  auto& m = t->m;
+  // queries -> mapped memory (read in place by the kernels, once each)
+  std::memcpy(m.qdesc, q->qdesc, (size_t)nq * 32); std::memcpy(m.qx, q->qx, (size_t)nq * 4); std::memcpy(m.qy, q->qy, (size_t)nq * 4);
+  std::memcpy(m.qr, q->qr, (size_t)nq * 4); std::memcpy(m.qmin, q->qmin, (size_t)nq * 4); std::memcpy(m.qmax, q->qmax, (size_t)nq * 4);
+  std::memcpy(m.q_claims, q->q_claims, (size_t)nq); std::memcpy(m.q_angle, q->q_angle, (size_t)nq * 4); std::memcpy(m.q_pos, q->q_pos, (size_t)nq * 12);
+  std::memcpy(m.pose_in, q->pose_in, 56); std::memcpy(m.inv_sigma2, q->inv_level_sigma2, (size_t)q->nlevels * 4);
+  // mvKeysUn: the extractor's keypoints themselves without distortion (Frame.cc:791-797), else undistorted on the device (:799-818)
+  const bool undist = q->dist && q->dist->k1 != 0.0f;
+  const dvm_keypoint* d_un = d_kps;
+  if (undist) {
+    rc = dvm_undistort_keypoints(q->dist, d_kps, reinterpret_cast<dvm_keypoint*>(t->d_kps_un), ocap, 1, s);
+    if (rc != DVM_OK) return rc;
+    d_un = reinterpret_cast<const dvm_keypoint*>(t->d_kps_un);
+    if (kps_un) DVM_HIP(hipMemcpyAsync(m.kps_un, t->d_kps_un, (size_t)ocap * sizeof(dvm_keypoint_pod), hipMemcpyDeviceToHost, s));
+  }
+  rc = dvm_frame_build(t->grid, 0, d_un, d_desc, 0, d_n, q->bounds[0], q->bounds[1], q->bounds[2], q->bounds[3], 1, s);
+  if (rc != DVM_OK) return rc;
+  if (nq) {
+    rc = dvm_match_window_ranked(t->grid, 0, nullptr, t->dev(m.qdesc), t->dev(m.qx), t->dev(m.qy), t->dev(m.qr), t->dev(m.qmin), t->dev(m.qmax), nq,
+                                 t->d_ranked, 1, s);
+    if (rc != DVM_OK) return rc;
+  }
+  launch_track_claims(s, t->d_ranked, t->dev(m.q_claims), t->dev(m.q_angle), nq, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, q->th_high,
+                      q->check_ori, t->d_assign, t->d_res, t->dev(m.assign), t->dev(m.res));
+  launch_track_gather(s, t->d_assign, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, t->dev(m.q_pos), t->dev(m.inv_sigma2), q->nlevels, t->d_Xw,
+                      t->d_obs, t->d_info, t->d_edge_kp, t->d_nedges, t->d_res, q->min_matches, t->dev(m.nedges));
+  ba_launch_pose_optimize(s, t->dev(m.pose_in), t->d_Xw, t->d_obs, t->d_info, t->d_nedges, ocap, 1, q->cam.fx, q->cam.fy, q->cam.cx, q->cam.cy,
+                          t->dev(m.pose_out), t->d_edge_out, t->dev(m.n_inl), t->d_chi);
+  launch_track_finish(s, t->d_assign, d_n, ocap, t->d_edge_kp, t->d_nedges, t->d_edge_out, t->dev(m.q_claims), t->dev(m.outlier), t->dev(m.fin));
+  // (what the host wants back is written to mapped memory by the kernels themselves: no copy command behind the chain)
+  rc = hip_check(hipGetLastError(), "tracking chain launch");
+  if (rc != DVM_OK) return rc;
+  int n = 0, mono = -1;
+  rc = dvm_orb_download(h, 0, kps, desc, cap, &n, &mono);   // synchronises the stream: the whole chain is through
+  if (rc != DVM_OK) return rc;
+  res->n = n; res->mono_index = mono;
+  if (kps_un) std::memcpy(kps_un, undist ? reinterpret_cast<const dvm_keypoint*>(m.kps_un) : kps, (size_t)n * sizeof(dvm_keypoint));
+  std::memcpy(assign, m.assign, (size_t)n * 4);
+  res->nmatches = m.res[0];
+  res->nmatches_before_rotation = m.res[2];
+  if (m.res[1]) {                       // a query ran out of ranked candidates: the caller replays the epilogue from the lists
+    res->status = DVM_TRACK_REPLAY_ON_HOST;
+    if (ranked && nq) DVM_HIP(hipMemcpy(ranked, t->d_ranked, (size_t)nq * 16, hipMemcpyDeviceToHost));
+    std::memset(outlier, 0, (size_t)n);
+    return DVM_OK;
+  }
+  if (res->nmatches < q->min_matches) { res->status = DVM_TRACK_FEW_MATCHES; std::memset(outlier, 0, (size_t)n); return DVM_OK; }
+  res->status = DVM_TRACK_COMPLETE;
+  std::memcpy(outlier, m.outlier, (size_t)n);
+  res->n_edges = m.nedges[0]; res->n_inliers = m.n_inl[0]; res->nmatches_map = m.fin[0]; res->nmatches_after = m.fin[1];
+  std::memcpy(res->pose, m.pose_out, 56);
+  return DVM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,17 @@
+// dvm_slam_amd/csrc/track_kernels.h -- launchers of track_kernels.hip (the device chain of dvm_track_finish).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_kernels.h"   // dvm_keypoint_pod
+
+namespace dvm {
+size_t track_claims_lds(int kp_cap, int nq);
+void launch_track_claims(hipStream_t s, const uint32_t* ranked, const uint8_t* q_claims, const float* q_angle, int nq, const dvm_keypoint_pod* kps,
+                         const int32_t* d_n, int kp_cap, int th_high, int check_ori, int32_t* assign, int32_t* res, int32_t* assign_host, int32_t* res_host);
+void launch_track_gather(hipStream_t s, const int32_t* assign, const dvm_keypoint_pod* kps_un, const int32_t* d_n, int kp_cap, const float* q_pos,
+                         const float* inv_sigma2, int nlevels, double* Xw, double* obs, double* info, int32_t* edge_kp, int32_t* n_edges,
+                         const int32_t* res, int min_matches, int32_t* n_edges_host);
+void launch_track_finish(hipStream_t s, int32_t* assign, const int32_t* d_n, int kp_cap, const int32_t* edge_kp, const int32_t* n_edges,
+                         const uint8_t* edge_outlier, const uint8_t* q_claims, uint8_t* outlier, int32_t* out);
+}  // namespace dvm

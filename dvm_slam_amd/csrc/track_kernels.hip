@@ -1,0 +1,221 @@
+// dvm_slam_amd/csrc/track_kernels.hip -- the device side of dvm_track_begin / dvm_track_finish (include/dvmslam_hip.h): what the
+// reference's Tracking::TrackWithMotionModel does between the window search and the pose it ends on, as kernels of ONE stream chain
+// behind the extraction of the frame (no host step in between):
+//   k_track_claims   ORBmatcher::SearchByProjection(CurrentFrame, LastFrame): the sequential epilogue of src/ORBmatcher.cc:1613-1664
+//                    (a keypoint taken by an earlier query is skipped by the later ones) and the rotation histogram :1652-1663,
+//                    :1730-1745, replayed from the ranked candidate lists of k_match_window_ranked
+//   k_track_gather   Optimizer::PoseOptimization's edge list (src/Optimizer.cc:768-838): the matched keypoints in keypoint order
+//   k_track_finish   the outlier flags back in keypoint order, Tracking.cc:2636-2660 (outlier matches dropped, nmatchesMap)
+// The pose itself is k_pose_optimize (ba_kernels.hip), launched between the last two.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "track_kernels.h"
+
+namespace dvm {
+
+namespace {
+constexpr int kHisto = 30;   // HISTO_LENGTH, ORBmatcher.cc:38
+}
+
+// One wave.  Queries are decided in blocks of 64, one per lane.  Inside a block a lane's choice depends on what the lanes before it
+// take: every round each undecided lane proposes its first candidate that is still free; a lane whose proposal is also proposed by
+// an EARLIER undecided lane that will take it (owner[] = smallest such lane) is blocked; the lanes in front of the first blocked lane
+// are final and commit, the rest propose again.  The first undecided lane is never blocked, so every round commits at least one.
+//   ranked[q][0..3]  dist << 16 | keypoint, best first, dist >= 256 = end of the list (k_match_window_ranked)
+//   q_claims[q]      the query's map point has Observations() > 0: its match takes the keypoint (:1620-1622)
+//   q_angle[q]       LastFrame.mvKeysUn[i].angle
+// Outputs: assign[j] = the query matched to keypoint j at the end of the call or -1; res[0] = nmatches, res[1] = 1 if some query
+// found all four ranked candidates taken while its list may go on (the caller then repeats the epilogue on the host: rare),
+// res[2] = matches before the rotation check.
+__global__ void __launch_bounds__(64) k_track_claims(const uint32_t* __restrict__ ranked, const uint8_t* __restrict__ q_claims,
+                                                     const float* __restrict__ q_angle, int nq, const dvm_keypoint_pod* __restrict__ kps,
+                                                     const int32_t* __restrict__ d_n, int kp_cap, int th_high, int check_ori,
+                                                     int32_t* __restrict__ assign, int32_t* __restrict__ res, int32_t* __restrict__ assign_host,
+                                                     int32_t* __restrict__ res_host) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t track_smem[];
+  const int lane = threadIdx.x;
+  const int N = min(*d_n, kp_cap);
+  int32_t* s_assign = reinterpret_cast<int32_t*>(track_smem);             // [kp_cap]
+  uint32_t* s_owner = reinterpret_cast<uint32_t*>(s_assign + kp_cap);      // [kp_cap]
+  uint32_t* s_qres = s_owner + kp_cap;                                     // [nq]: keypoint | bin << 16, or 0xFFFFFFFF
+  uint8_t* s_claimed = reinterpret_cast<uint8_t*>(s_qres + nq);            // [kp_cap]
+  __shared__ int s_rot[kHisto];
+  __shared__ int s_ind[3];
+  for (int j = lane; j < kp_cap; j += 64) { s_assign[j] = -1; s_owner[j] = 0xFFFFFFFFu; s_claimed[j] = 0; }
+  for (int q = lane; q < nq; q += 64) s_qres[q] = 0xFFFFFFFFu;
+  if (lane < kHisto) s_rot[lane] = 0;
+  __syncthreads();
+  int exhausted_any = 0;
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int q = q0 + lane;
+    uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    bool decided = q >= nq;
+    bool claims = false;
+    if (!decided) {
+      const uint4 k4 = *reinterpret_cast<const uint4*>(ranked + 4 * (size_t)q);
+      key[0] = k4.x; key[1] = k4.y; key[2] = k4.z; key[3] = k4.w;
+      claims = q_claims[q] != 0;
+    }
+    int c = 0;
+    while (__ballot(!decided)) {
+      int prop = -1, pdist = 256;
+      bool exhausted = false;
+      if (!decided) {
+        for (; c < 4; c++) {
+          const int dist = (int)(key[c] >> 16);
+          if (dist >= 256) break;                      // end of the list: nothing else in the window
+          const int idx = (int)(key[c] & 0xFFFFu);
+          if (idx < N && !s_claimed[idx]) { prop = idx; pdist = dist; break; }
+        }
+        exhausted = c == 4;                            // all four taken, the list may go on
+      }
+      const bool matched = prop >= 0 && pdist <= th_high;
+      const bool takes = matched && claims;
+      if (!decided && takes) atomicMin(&s_owner[prop], (uint32_t)lane);
+      __syncthreads();
+      const bool blocked = !decided && prop >= 0 && s_owner[prop] < (uint32_t)lane;
+      const unsigned long long bm = __ballot(blocked);
+      const int first_blocked = bm ? (int)__builtin_ctzll(bm) : 64;
+      __syncthreads();
+      if (!decided && takes) s_owner[prop] = 0xFFFFFFFFu;
+      if (!decided && lane < first_blocked) {
+        decided = true;
+        if (exhausted) exhausted_any = 1;
+        if (matched) {
+          atomicMax(&s_assign[prop], q);              // the last writer in query order stays (:1651: CurrentFrame.mvpMapPoints[bestIdx2] = pMP)
+          if (takes) s_claimed[prop] = 1;
+          int bin = 0;
+          if (check_ori) {
+            float rot = q_angle[q] - kps[prop].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            bin = (int)roundf(rot * (1.0f / (float)kHisto));
+            if (bin == kHisto) bin = 0;
+            atomicAdd(&s_rot[bin], 1);
+          }
+          s_qres[q] = (uint32_t)prop | ((uint32_t)bin << 16);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // ComputeThreeMaxima (ORBmatcher.cc:1750-1802) on one lane, then the matches of the other bins are taken back (:1730-1745)
+  if (lane == 0) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < kHisto; i++) {
+      const int s = s_rot[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+    s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+  }
+  __syncthreads();
+  int nmatched = 0, ndropped = 0;
+  for (int q = lane; q < ((nq + 63) & ~63); q += 64) {
+    const uint32_t r = q < nq ? s_qres[q] : 0xFFFFFFFFu;
+    const bool m = r != 0xFFFFFFFFu;
+    bool drop = false;
+    if (m && check_ori) {
+      const int bin = (int)(r >> 16);
+      drop = bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2];
+      if (drop) s_assign[r & 0xFFFFu] = -1;
+    }
+    nmatched += __popcll(__ballot(m));
+    ndropped += __popcll(__ballot(drop));
+  }
+  __syncthreads();
+  // (both copies: the device one feeds k_track_gather, the mapped one is what the host reads after the chain's one synchronisation)
+  for (int j = lane; j < kp_cap; j += 64) { const int a = j < N ? s_assign[j] : -1; assign[j] = a; assign_host[j] = a; }
+  const int any_exhausted = __ballot(exhausted_any != 0) != 0ull;
+  if (lane == 0) {
+    res[0] = nmatched - ndropped; res[1] = any_exhausted; res[2] = nmatched;
+    res_host[0] = nmatched - ndropped; res_host[1] = any_exhausted; res_host[2] = nmatched;
+  }
+}
+
+// PoseOptimization's edges (Optimizer.cc:768-838): keypoints with a map point, in keypoint order.  One workgroup, block scan.
+//   Xw[e] = (double)pos of the query's map point, obs[e] = (double)mvKeysUn[i].pt, info[e] = (double)mvInvLevelSigma2[octave]
+// edge_kp[e] = i.  n_edges[0] = count (0 if the frame has fewer than min_matches matches: the caller's retry / lost path).
+__global__ void __launch_bounds__(256) k_track_gather(const int32_t* __restrict__ assign, const dvm_keypoint_pod* __restrict__ kps_un,
+                                                      const int32_t* __restrict__ d_n, int kp_cap, const float* __restrict__ q_pos,
+                                                      const float* __restrict__ inv_sigma2, int nlevels, double* __restrict__ Xw,
+                                                      double* __restrict__ obs, double* __restrict__ info, int32_t* __restrict__ edge_kp,
+                                                      int32_t* __restrict__ n_edges, const int32_t* __restrict__ res, int min_matches,
+                                                      int32_t* __restrict__ n_edges_host) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int N = min(*d_n, kp_cap);
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const bool go = res[0] >= min_matches && res[1] == 0;
+  for (int i0 = 0; i0 < N && go; i0 += 256) {
+    const int i = i0 + tid;
+    const int q = i < N ? assign[i] : -1;
+    const unsigned long long m = __ballot(q >= 0);
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    int pos = s_base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    for (int w = 0; w < wv; w++) pos += s_wave[w];
+    if (q >= 0) {
+      const dvm_keypoint_pod kp = kps_un[i];
+      Xw[3 * pos] = (double)q_pos[3 * q]; Xw[3 * pos + 1] = (double)q_pos[3 * q + 1]; Xw[3 * pos + 2] = (double)q_pos[3 * q + 2];
+      obs[2 * pos] = (double)kp.x; obs[2 * pos + 1] = (double)kp.y;
+      info[pos] = (double)inv_sigma2[min(max(kp.octave, 0), nlevels - 1)];
+      edge_kp[pos] = i;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (tid == 0) { n_edges[0] = s_base; n_edges_host[0] = s_base; }
+}
+
+// mvbOutlier in keypoint order; Tracking.cc:2636-2660: a match PoseOptimization marked an outlier loses its map point, the others
+// with Observations() > 0 count into nmatchesMap.  out[0] = nmatchesMap, out[1] = matches left.
+__global__ void __launch_bounds__(256) k_track_finish(int32_t* __restrict__ assign, const int32_t* __restrict__ d_n, int kp_cap,
+                                                      const int32_t* __restrict__ edge_kp, const int32_t* __restrict__ n_edges,
+                                                      const uint8_t* __restrict__ edge_outlier, const uint8_t* __restrict__ q_claims,
+                                                      uint8_t* __restrict__ outlier, int32_t* __restrict__ out) {
+  __shared__ int s_cnt[2];
+  const int tid = threadIdx.x;
+  const int N = min(*d_n, kp_cap), E = n_edges[0];
+  if (tid < 2) s_cnt[tid] = 0;
+  for (int j = tid; j < kp_cap; j += 256) outlier[j] = 0;
+  __syncthreads();
+  int map = 0, left = 0;
+  for (int e = tid; e < E; e += 256) {
+    const int i = edge_kp[e];
+    if (i < 0 || i >= N) continue;
+    if (edge_outlier[e]) { outlier[i] = 1; }
+    else { left++; if (q_claims[assign[i]]) map++; }
+  }
+  atomicAdd(&s_cnt[0], map);
+  atomicAdd(&s_cnt[1], left);
+  __syncthreads();
+  if (tid < 2) out[tid] = s_cnt[tid];
+}
+
+size_t track_claims_lds(int kp_cap, int nq) { return (size_t)kp_cap * 9 + (size_t)nq * 4 + 16; }
+
+void launch_track_claims(hipStream_t s, const uint32_t* ranked, const uint8_t* q_claims, const float* q_angle, int nq, const dvm_keypoint_pod* kps,
+                         const int32_t* d_n, int kp_cap, int th_high, int check_ori, int32_t* assign, int32_t* res, int32_t* assign_host, int32_t* res_host) {
+  hipLaunchKernelGGL(k_track_claims, dim3(1), dim3(64), track_claims_lds(kp_cap, nq), s, ranked, q_claims, q_angle, nq, kps, d_n, kp_cap, th_high,
+                     check_ori, assign, res, assign_host, res_host);
+}
+void launch_track_gather(hipStream_t s, const int32_t* assign, const dvm_keypoint_pod* kps_un, const int32_t* d_n, int kp_cap, const float* q_pos,
+                         const float* inv_sigma2, int nlevels, double* Xw, double* obs, double* info, int32_t* edge_kp, int32_t* n_edges,
+                         const int32_t* res, int min_matches, int32_t* n_edges_host) {
+  hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(256), 0, s, assign, kps_un, d_n, kp_cap, q_pos, inv_sigma2, nlevels, Xw, obs, info, edge_kp, n_edges,
+                     res, min_matches, n_edges_host);
+}
+void launch_track_finish(hipStream_t s, int32_t* assign, const int32_t* d_n, int kp_cap, const int32_t* edge_kp, const int32_t* n_edges,
+                         const uint8_t* edge_outlier, const uint8_t* q_claims, uint8_t* outlier, int32_t* out) {
+  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(256), 0, s, assign, d_n, kp_cap, edge_kp, n_edges, edge_outlier, q_claims, outlier, out);
+}
+
+}  // namespace dvm

@@ -126,24 +126,14 @@ void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, int L, int& ind1, i
   else if (max3 < 0.1f * (float)max1) ind3 = -1;
 }
 
-int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const MapPointPOD* MPs, float th, bool bMono) {
-  const auto T0 = std::chrono::steady_clock::now();
-  const bool dbg = std::getenv("DVM_HOST_DEBUG_TIMING") != nullptr;
-  auto mark = [&](const char* w) { if (dbg) std::fprintf(stderr, "SBP %-14s %8.3f ms\n", w, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); };
-  (void)bMono;  // DVM-SLAM is monocular (src/slam_system/src/ros_mono.cpp:19): bForward = bBackward = false
-  int nmatches = 0;
-  last_requeried = 0;
-  // rotHist[bin] of :1566-1568 as (keypoint, bin) pairs + counts: the 30 vectors only ever feed ComputeThreeMaxima's sizes and the
-  // final sweep over the losing bins
-  std::vector<std::pair<int, int>> rotPairs;
-  int rotCount[HISTO_LENGTH] = {0};
-  const float factor = 1.0f / HISTO_LENGTH;
-
-  // ---- queries, exactly the loop header of :1573-1611
-  std::vector<int> qi;                 // index in LastFrame
-  std::vector<float> qx, qy, qr;
-  std::vector<int32_t> qmin, qmax;
-  std::vector<uint8_t> qdesc;
+// The loop header of SearchByProjection(CurrentFrame, LastFrame) (:1573-1611): LastFrame's map points projected with CurrentFrame's
+// pose, the ones in front of the camera and inside the image bounds become window queries.
+void BuildFrameQueries(const FrameView& Cur, const FrameView& Last, const MapPointPOD* MPs, float th, FrameQueries& Q) {
+  std::vector<int>& qi = Q.qi;
+  std::vector<float>&qx = Q.qx, &qy = Q.qy, &qr = Q.qr;
+  std::vector<int32_t>&qmin = Q.qmin, &qmax = Q.qmax;
+  std::vector<uint8_t>& qdesc = Q.qdesc;
+  qi.clear(); qx.clear(); qy.clear(); qr.clear(); qmin.clear(); qmax.clear(); qdesc.clear();
   qi.reserve(Last.N); qx.reserve(Last.N); qy.reserve(Last.N); qr.reserve(Last.N); qmin.reserve(Last.N); qmax.reserve(Last.N);
   qdesc.reserve((size_t)Last.N * 32);
   for (int i = 0; i < Last.N; i++) {
@@ -165,6 +155,28 @@ int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const 
     qmin.push_back(nLastOctave - 1); qmax.push_back(nLastOctave + 1);
     qdesc.insert(qdesc.end(), MPs[mp].desc, MPs[mp].desc + 32);
   }
+}
+
+int ORBmatcher::SearchByProjection(FrameView& Cur, const FrameView& Last, const MapPointPOD* MPs, float th, bool bMono) {
+  const auto T0 = std::chrono::steady_clock::now();
+  const bool dbg = std::getenv("DVM_HOST_DEBUG_TIMING") != nullptr;
+  auto mark = [&](const char* w) { if (dbg) std::fprintf(stderr, "SBP %-14s %8.3f ms\n", w, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); };
+  (void)bMono;  // DVM-SLAM is monocular (src/slam_system/src/ros_mono.cpp:19): bForward = bBackward = false
+  int nmatches = 0;
+  last_requeried = 0;
+  // rotHist[bin] of :1566-1568 as (keypoint, bin) pairs + counts: the 30 vectors only ever feed ComputeThreeMaxima's sizes and the
+  // final sweep over the losing bins
+  std::vector<std::pair<int, int>> rotPairs;
+  int rotCount[HISTO_LENGTH] = {0};
+  const float factor = 1.0f / HISTO_LENGTH;
+
+  // ---- queries, exactly the loop header of :1573-1611
+  FrameQueries Q;
+  BuildFrameQueries(Cur, Last, MPs, th, Q);
+  std::vector<int>& qi = Q.qi;
+  std::vector<float>&qx = Q.qx, &qy = Q.qy, &qr = Q.qr;
+  std::vector<int32_t>&qmin = Q.qmin, &qmax = Q.qmax;
+  std::vector<uint8_t>& qdesc = Q.qdesc;
   const int nq = (int)qi.size();
   if (nq == 0) return 0;
 

@@ -57,6 +57,16 @@ dvm_se3f InverseSE3(const dvm_se3f& T);
 // process-wide: route SearchByProjection(Cur, Last)'s grid build + window search through a shared search service (NULL: per-thread calls)
 void set_match_pool(dvm_match_pool* pool);
 
+// the window queries of SearchByProjection(CurrentFrame, LastFrame): qi = index in LastFrame, (qx, qy, qr) = projection and radius,
+// [qmin, qmax] = octave range, qdesc = the map points' descriptors
+struct FrameQueries {
+  std::vector<int> qi;
+  std::vector<float> qx, qy, qr;
+  std::vector<int32_t> qmin, qmax;
+  std::vector<uint8_t> qdesc;
+};
+void BuildFrameQueries(const FrameView& Cur, const FrameView& Last, const MapPointPOD* MPs, float th, FrameQueries& Q);
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // ORBmatcher.cc:36-38

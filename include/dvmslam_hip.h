@@ -537,6 +537,55 @@ void dvm_pose_pool_destroy(dvm_pose_pool* pool);
 int dvm_pose_pool_optimize(dvm_pose_pool* pool, const double* pose_in, const double* Xw, const double* obs, const double* inv_sigma2, int n,
                            const dvm_ba_camera* cam, double* pose_out, uint8_t* outlier, int32_t* n_inliers, int* batch_size);
 
+/* ---- The tracking step of one frame as ONE device chain (csrc/track.cpp): Frame::Frame -> ExtractORB (src/Frame.cc:371-411), then
+ * Tracking::TrackWithMotionModel (src/Tracking.cc:2584-2667) = SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1553-1748)
+ * -> Optimizer::PoseOptimization (src/Optimizer.cc:744-1028) -> outlier matches dropped (:2636-2660).
+ *   dvm_track_begin   queues the extraction of the frame on the extractor's stream and returns;
+ *   dvm_track_finish  queues [Frame::UndistortKeyPoints] -> AssignFeaturesToGrid -> the ranked window search of the caller's projection
+ *                     queries -> claim replay + rotation histogram -> PoseOptimization -> outlier flags behind it, synchronises once and
+ *                     returns the frame's keypoints / descriptors (what dvm_orb_extract returns) together with the tracking results.
+ * The queries are what the loop header of ORBmatcher.cc:1573-1611 produces from LastFrame's map points and the predicted pose (the
+ * host library's dvmh_track_with_motion_model builds them while the extraction runs).  CurrentFrame.mvpMapPoints is taken as cleared
+ * (Tracking.cc:2603).  Results equal dvm_orb_extract + dvmh_search_by_projection_frames + dvm_pose_optimize bit for bit. */
+typedef struct dvm_tracker dvm_tracker;
+typedef struct {
+  int32_t nq;
+  const uint8_t* qdesc;            /* [nq][32] the map points' descriptors */
+  const float *qx, *qy, *qr;       /* projection (u, v) and window radius th * mvScaleFactors[nLastOctave] */
+  const int32_t *qmin, *qmax;      /* nLastOctave - 1, nLastOctave + 1 */
+  const uint8_t* q_claims;         /* [nq] the map point has Observations() > 0 */
+  const float* q_angle;            /* [nq] LastFrame.mvKeysUn[i].angle */
+  const float* q_pos;              /* [nq][3] GetWorldPos() */
+  float bounds[4];                 /* mnMinX mnMaxX mnMinY mnMaxY */
+  const dvm_distortion* dist;      /* NULL or k1 == 0: mvKeysUn = mvKeys */
+  const float* inv_level_sigma2;   /* mvInvLevelSigma2, nlevels entries */
+  int32_t nlevels;
+  dvm_ba_camera cam;               /* fx fy cx cy of PoseOptimization's edges */
+  double pose_in[7];               /* the predicted Tcw (tx ty tz qx qy qz qw): mVelocity * mLastFrame.GetPose() */
+  int32_t th_high, check_ori;      /* ORBmatcher::TH_HIGH (100), mbCheckOrientation */
+  int32_t min_matches;             /* 20 (Tracking.cc:2616) */
+} dvm_track_queries;
+enum { DVM_TRACK_COMPLETE = 0, DVM_TRACK_FEW_MATCHES = 1, DVM_TRACK_REPLAY_ON_HOST = 2 };
+typedef struct {
+  int32_t n, mono_index;           /* the extraction's keypoint count and monoIndex */
+  int32_t status;                  /* DVM_TRACK_COMPLETE; FEW_MATCHES: nmatches < min_matches, no pose (search again with the doubled window:
+                                      dvm_track_finish with the wider queries); REPLAY_ON_HOST: a query found all four ranked candidates taken
+                                      while its list may go on -- `ranked` holds the lists, assign / nmatches are not final */
+  int32_t nmatches;                /* SearchByProjection's return value */
+  int32_t nmatches_before_rotation;
+  int32_t n_edges, n_inliers;      /* PoseOptimization: nInitialCorrespondences and its return value */
+  int32_t nmatches_map, nmatches_after;   /* Tracking.cc:2636-2660: nmatchesMap and nmatches after the outliers were dropped */
+  double pose[7];                  /* the optimised Tcw */
+} dvm_track_result;
+int dvm_tracker_create(int device, int max_keypoints, int max_queries, dvm_tracker** out);
+void dvm_tracker_destroy(dvm_tracker* t);
+int dvm_track_begin(dvm_tracker* t, dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1);
+/* kps / desc [cap]: the extraction; kps_un (may be NULL): mvKeysUn; assign [cap]: per keypoint the index of the query matched to it or -1
+ * (BEFORE the outlier drop); outlier [cap]: mvbOutlier as PoseOptimization leaves it (the matches Tracking then drops); ranked (may be
+ * NULL): [nq][4] candidate lists, filled for REPLAY_ON_HOST only.  May be called again after one dvm_track_begin (wider window). */
+int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm_keypoint* kps, uint8_t* desc, int cap, dvm_keypoint* kps_un,
+                     int32_t* assign, uint8_t* outlier, uint32_t* ranked, dvm_track_result* res);
+
 /* Optimizer::OptimizeSim3 (Optimizer.cc:1960-2212), numerics for N correspondences gathered by the caller:
  * P1c / P2c = the matched map points in their own key frame's camera frame (R1w*P+t1w, R2w*P+t2w), obs1 / obs2 =
  * undistorted keypoints in KF1 / KF2, w1 / w2 = mvInvLevelSigma2[octave], K1 / K2 = (fx,fy,cx,cy) of both pinhole

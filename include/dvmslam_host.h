@@ -86,6 +86,35 @@ int dvmh_search_by_projection_frames_dev(int device, int Nc, const dvm_keypoint*
                                          const float* K, const float* bounds, const float* scale_factors, int nlevels, int Nl, const dvm_keypoint* kps_l,
                                          const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori, int* requeried,
                                          const dvm_device_frame* dev_c, int* grid_from_device);
+/* ---- One tracked frame as one device chain: Frame::Frame -> ExtractORB (src/Frame.cc:371-411) + Tracking::TrackWithMotionModel
+ * (src/Tracking.cc:2584-2667) over dvm_track_begin / dvm_track_finish (include/dvmslam_hip.h).  The extraction is queued first; the
+ * projection queries of LastFrame's map points are built on the host while it runs; grid, window search, claim replay, rotation check,
+ * PoseOptimization and the outlier flags follow on the same stream; ONE synchronisation.  The doubled window of Tracking.cc:2616-2624
+ * (fewer than 20 matches) and the rare host replay of the claims are handled here.  Results equal dvm_orb_extract +
+ * dvmh_search_by_projection_frames + dvm_pose_optimize + the outlier drop, bit for bit.
+ *   Tcw_pred = mVelocity * mLastFrame.GetPose() (what TrackWithMotionModel sets on CurrentFrame); K = fx fy cx cy; dist may be NULL
+ *   out: kps / desc [cap] (mvKeys, mDescriptors), kps_un [cap] (mvKeysUn; may be NULL), mp_c [cap] = CurrentFrame.mvpMapPoints after the
+ *   outlier drop (index into mps or -1), dropped [cap] = the map point whose match PoseOptimization rejected or -1 (the caller's
+ *   pMP->mbTrackInView = false / mnLastFrameSeen bookkeeping, Tracking.cc:2645-2652) */
+typedef struct {
+  int32_t n, mono_index;       /* extraction */
+  int32_t nmatches;            /* after the outlier drop (Tracking.cc:2653) */
+  int32_t nmatches_search;     /* SearchByProjection's return value (of the doubled window if that ran) */
+  int32_t nmatches_map;        /* nmatchesMap */
+  int32_t n_inliers;           /* PoseOptimization's return value */
+  int32_t wide_window;         /* 1: the doubled window was searched */
+  int32_t replayed_on_host;    /* 1: the claims were replayed on the host (a query ran out of ranked candidates) */
+  int32_t tracked;             /* 0: fewer than 20 matches even with the doubled window (TrackWithMotionModel returns false; pose untouched) */
+  dvm_se3f Tcw;                /* the optimised pose as CurrentFrame.SetPose receives it */
+  double pose[7];              /* the same as PoseOptimization's doubles (tx ty tz qx qy qz qw) */
+} dvmh_track_result;
+int dvmh_track_with_motion_model(dvm_tracker* t, dvm_orb* h, int device, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
+                                 const dvm_se3f* Tcw_pred, const float* K, const float* bounds, const dvm_distortion* dist,
+                                 const float* scale_factors, const float* inv_level_sigma2, int nlevels, int Nl, const dvm_keypoint* kps_l,
+                                 const int32_t* mp_l, const uint8_t* outlier_l, const dvmh_map_point* mps, float th, int check_ori,
+                                 dvm_keypoint* kps, uint8_t* desc, int cap, dvm_keypoint* kps_un, int32_t* mp_c, int32_t* dropped,
+                                 dvmh_track_result* out);
+
 /* SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), :44-205.  claimed_obs[j] != 0 <=> F.mvpMapPoints[j]->Observations() > 0 */
 int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
                                      const float* bounds, const float* scale_factors, int nlevels, const dvmh_tracked_point* pts, int npts, float th,
