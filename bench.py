@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--legs", action="store_true", help="also run the per-call legs (batch sweep, latency, online agents, lba, merge, ba_cold; N=1 only): "
                                                          "each prints its own stdout line BEFORE the contract line")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short config-2 / config-3 per-call legs of the default run")
     ap.add_argument("--no-legs", action="store_true", help="(default since round 5; accepted for old command lines)")
     ap.add_argument("--full-json", default=None, help="where the complete (uncompacted) record goes; default gpurun_out/bench_full.json")
     ap.add_argument("--texture", choices=("rich", "low"), default="rich", help="synthetic stream: the BASELINE corner-rich one, or the weakly textured second workload")
@@ -240,6 +241,26 @@ def compact(out):
     if isinstance(out.get("pcie_inclusive"), dict):
         c["pcie_inclusive"] = pick(out["pcie_inclusive"], "value", "unit", "h2d_gbps")
     c["sanity_matches_le_TH_HIGH_last_step"] = out.get("sanity_matches_le_TH_HIGH_last_step")
+    cl = {}
+    try:
+        lat = out["latency"]
+        cl["unit"] = "ms per call (median), host arrays in -> host arrays out"
+        for k_out, k_in in (("extract", "orb_extract_one_frame"), ("search_by_projection", "search_by_projection_cur_last"),
+                            ("pose_optimization", "pose_optimization_one_frame"), ("track_frame_one_chain", "track_with_motion_model_one_frame")):
+            cl[k_out] = round(lat[k_in]["median_ms"], 4)
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        cl["lba_window_call"] = round(out["lba"]["end_to_end_call"]["median_ms"], 4)
+        cl["lba_window_iterations_per_s"] = round(out["lba"]["value"], 1)
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        cl["merge_chain"] = round(out["merge"]["chain"]["median_ms"], 4)
+    except Exception:   # noqa: BLE001
+        pass
+    if cl:
+        c["config_legs"] = cl
     return c
 
 
@@ -616,6 +637,19 @@ def main():
                 try:
                     out[name] = fn()
                 except Exception as ex:   # noqa: BLE001 -- a leg that fails must not take the contract line with it
+                    out[name] = {"error": repr(ex)}
+        if world == 1 and not a.no_config_legs:
+            # configs 2 / 3 in every default run (short forms of the --legs records, no CPU legs): per-call latencies of the tracked frame,
+            # the local-BA window call and the merge chain through the drop-in boundary -> `config_legs` of the contract line
+            import bench_legs
+            for name, fn in (("latency", lambda: bench_legs.latency(capi, frames[:64], local, calls=200, cpu_calls=0)),
+                             ("lba", lambda: bench_legs.lba(local, repeats=12, cpu_seconds=0.0)),
+                             ("merge", lambda: bench_legs.merge(local, reps=8, cpu_reps=0))):
+                if name in out and "error" not in out[name]:
+                    continue
+                try:
+                    out[name] = fn()
+                except Exception as ex:   # noqa: BLE001
                     out[name] = {"error": repr(ex)}
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, a.cpu_seconds)

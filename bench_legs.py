@@ -2,8 +2,8 @@
 threads would see it through the drop-in boundary -- host pointers in, host pointers out, one frame / one window at a time --
 each with the CPU oracle timed beside it in the same run (`cpu_baseline`, kind "port", 1 thread).
 
-  latency   one-frame dvm_orb_extract, SearchByProjection(Cur, Last) through libdvmslam_host, dvm_pose_optimize with batch 1:
-            median / p95 over 500 calls            (reference: Tracking.cc:1423-1426, :2610, :2632; Frame.cc:408-417 timers)
+  latency   one-frame dvm_orb_extract, SearchByProjection(Cur, Last) through libdvmslam_host, dvm_pose_optimize with batch 1, and the three
+            as ONE device chain (dvmh_track_with_motion_model): median / p95 over 500 calls            (reference: Tracking.cc:1423-1426, :2610, :2632; Frame.cc:408-417 timers)
   lba       LocalBundleAdjustment-sized window (30 keyframes of which 10 fixed, 3 000 landmarks, ~15 k observations): LM
             iterations/s and the end-to-end call (set_problem + optimize(10) + get_result + edge_chi2)   (Optimizer.cc:1030-1387)
   ba_cold   the 500-keyframe global BA started on a GPU that has been idle for 2 s (the reference runs it from an otherwise
@@ -98,12 +98,30 @@ def latency(capi, frames, device, calls=500, cpu_calls=24):
         c = cases[i % 8]
         capi.pose_optimize(c[0][None], c[1][None], c[2][None], c[3][None], np.array([len(c[1])], np.int32), c[4], device)
     t_pose = _time_calls(pose, calls)
+    # the whole tracked frame as ONE device chain behind one synchronisation (dvm_track_begin / dvm_track_finish through
+    # dvmh_track_with_motion_model): pixels in -> keypoints, descriptors, mvpMapPoints after the outlier drop and the optimised pose out
+    inv_s2 = ext.tables()["inv_sigma2"]
+    trk = capi.Tracker(ext, device=device)
+    tinfo = []
+
+    def track(i):
+        t = 1 + i % 8
+        p = pairs[t - 1]
+        r = trk.track(frames[t], p["Tcw"], K, p["bounds"], scale, inv_s2, p["kps_l"], p["mp_l"], None, p["mps"], th=15.0)
+        tinfo.append((r["nmatches_search"], r["n_inliers"], r["tracked"], r["replayed_on_host"], r["wide_window"]))
+    t_track = _time_calls(track, calls)
+    trk.close()
     ext.close()
     out = {"unit": "ms per call, host arrays in -> host arrays out (Python / ctypes harness around the C ABI)",
            "orb_extract_one_frame": _stats(t_ext), "search_by_projection_cur_last": dict(_stats(t_sbp), matches_per_call=float(np.mean(nm))),
            "search_by_projection_cur_last_device_resident": dict(_stats(t_sbp_dev), grid_built_from_hbm_fraction=float(np.mean(used)),
                                                                  note="Frame.cc:411 -> ORBmatcher.cc:1553 without re-uploading the frame: dvm_orb_last_result + dvmh_frame_view::dev"),
            "pose_optimization_one_frame": dict(_stats(t_pose), matches=int(np.mean([len(c[1]) for c in cases]))),
+           "track_with_motion_model_one_frame": dict(_stats(t_track), matches_per_call=float(np.mean([a[0] for a in tinfo])), inliers_per_call=float(np.mean([a[1] for a in tinfo])),
+                                                     tracked_fraction=float(np.mean([a[2] for a in tinfo])), replayed_on_host_fraction=float(np.mean([a[3] for a in tinfo])),
+                                                     wide_window_fraction=float(np.mean([a[4] for a in tinfo])),
+                                                     note="Frame::Frame -> ExtractORB + TrackWithMotionModel (SearchByProjection(Cur, Last) -> PoseOptimization -> outlier drop) as one "
+                                                          "enqueue: dvmh_track_with_motion_model, host image in -> host results out"),
            "reference": "Tracking.cc:1423-1426 (Frame ctor -> ORBextractor::operator()), :2610 (SearchByProjection), :2632 (PoseOptimization)"}
     if cpu_calls > 0:
         from oracle import pyoracle as po   # cpu_baseline leg: the checker timed as the baseline

@@ -92,7 +92,7 @@ struct Gate {
 // one measurement: K agent threads, `nframes` frames each; pool != nullptr: extraction through the shared extractor (dvm_orb_pool_extract)
 struct Result { double fps = 0, ms_per_frame = 0, mean[3] = {0, 0, 0}, med[3] = {0, 0, 0}, mean_batch = 0; int rc = 0; uint64_t sum0 = 0; bool same = true; };
 
-static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_pool* pool, dvm_pose_pool* ppool) {
+static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_pool* pool, dvm_pose_pool* ppool, bool one_chain = false) {
   const float K4[4] = {500.f, 500.f, 320.f, 240.f}, bounds[4] = {0.f, 640.f, 0.f, 480.f};
   const dvm_se3f Tcw{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}};
   Gate gate; gate.parties = K + 1;
@@ -111,6 +111,18 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
     std::vector<uint8_t> desc((size_t)cap * 32);
     int n = 0, mono = 0, bs = 0;
     const size_t fb = (size_t)in.rows * in.cols;
+    float inv_s2[8];
+    for (int l = 0; l < 8; l++) inv_s2[l] = 1.0f / (in.scale[l] * in.scale[l]);
+    dvm_tracker* trk = nullptr;
+    if (one_chain && rc == 0) rc = dvm_tracker_create(device, cap, cap, &trk);
+    std::vector<dvm_keypoint> kun(cap);
+    std::vector<int32_t> mp_t(cap), dropped(cap);
+    dvmh_track_result tr{};
+    auto track = [&](const uint8_t* img, const Pair& p, const int32_t* mpl) {   // the whole tracked frame as one device chain
+      return dvmh_track_with_motion_model(trk, h, device, img, in.rows, in.cols, in.cols, 0, 1000, &Tcw, K4, bounds, nullptr, in.scale, inv_s2, 8, p.Nl,
+                                          p.kl.data(), mpl, nullptr, p.mps.data(), 15.0f, 1, kps.data(), desc.data(), cap, kun.data(), mp_t.data(),
+                                          dropped.data(), &tr);
+    };
     auto extract = [&](const uint8_t* img) {
       return pool ? dvm_orb_pool_extract(pool, img, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono, &bs)
                   : dvm_orb_extract(h, img, in.rows, in.cols, in.cols, 0, 1000, kps.data(), desc.data(), cap, &n, &mono);
@@ -134,6 +146,7 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
       const PoseCase& c = in.poses[0];
       double po[7]; std::vector<uint8_t> ol(c.n); int32_t ni = 0;
       if (rc == 0) rc = pose_opt(c, po, ol.data(), &ni);
+      if (rc == 0 && one_chain) rc = track(in.frames.data() + fb, p, mp_l.data());
     }
     gate.wait();   // all agents ready
     gate.wait();   // clock started
@@ -141,6 +154,22 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
     for (int i = 0; i < nframes && rc == 0; i++) {
       const int t = 1 + i % in.cyc;
       const auto c0 = std::chrono::steady_clock::now();
+      if (one_chain) {
+        const Pair& p = in.pairs[t - 1];
+        mp_l.resize(p.Nl);
+        for (int j = 0; j < p.Nl; j++) mp_l[j] = j;
+        rc = track(in.frames.data() + (size_t)t * fb, p, mp_l.data());
+        if (rc) break;
+        if (id == 0) {
+          const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+          call_ms[0] += d; call_all[0].push_back(d);
+        }
+        if (i < in.cyc) {
+          sum = mix(sum, &tr.n, 4); sum = mix(sum, kps.data(), (size_t)tr.n * sizeof(dvm_keypoint)); sum = mix(sum, desc.data(), (size_t)tr.n * 32);
+          sum = mix(sum, &tr.nmatches, 4); sum = mix(sum, mp_t.data(), (size_t)tr.n * 4); sum = mix(sum, tr.pose, sizeof(tr.pose));
+        }
+        continue;
+      }
       rc = extract(in.frames.data() + (size_t)t * fb);
       if (rc) break;
       if (pool) { batch_frames += bs; batch_calls += 1; }
@@ -171,6 +200,7 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
       }
     }
     sums[id] = sum; rcs[id] = rc;
+    if (trk) dvm_tracker_destroy(trk);
     if (h) dvm_orb_destroy(h);
   };
   std::vector<std::thread> th;
@@ -216,20 +246,24 @@ int main(int argc, char** argv) {
   std::string out = "{\"unit\": \"frames/s over all agents (extract + SearchByProjection + PoseOptimization per frame, host arrays in -> out, one C++ thread per agent)\"";
   bool same = true;
   uint64_t ref = 0;
-  for (int mode = 0; mode < (pool ? 2 : 1); mode++) {
-    out += mode == 0 ? ", \"by_agents\": {" : ", \"by_agents_pooled\": {";   // pooled: all three calls through the shared services
+  uint64_t ref_chain = 0;
+  for (int mode = 0; mode < 3; mode++) {
+    if (mode == 1 && !pool) continue;
+    // pooled: all three calls through the shared services; one_chain: dvmh_track_with_motion_model (one enqueue + one synchronisation per frame)
+    out += mode == 0 ? ", \"by_agents\": {" : mode == 1 ? ", \"by_agents_pooled\": {" : ", \"by_agents_one_chain\": {";
     for (int a = 4; a < argc; a++) {
       const int K = std::atoi(argv[a]);
-      dvmh_set_match_pool(mode ? mpool : nullptr);   // the search of SearchByProjection(Cur, Last) through the shared service (pooled mode)
-      const Result R = measure(in, device, nframes, K, mode ? pool : nullptr, mode ? ppool : nullptr);
+      dvmh_set_match_pool(mode == 1 ? mpool : nullptr);   // the search of SearchByProjection(Cur, Last) through the shared service (pooled mode)
+      const Result R = measure(in, device, nframes, K, mode == 1 ? pool : nullptr, mode == 1 ? ppool : nullptr, mode == 2);
       if (R.rc) return 1;
       if (mode == 0 && a == 4) ref = R.sum0;
-      same = same && R.same && R.sum0 == ref;
+      if (mode == 2 && a == 4) ref_chain = R.sum0;
+      same = same && R.same && R.sum0 == (mode == 2 ? ref_chain : ref);
       char buf[640];
       std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_frame_per_agent\": %.4f, \"agent0_ms_in_extract_search_pose\": {\"mean\": [%.4f, %.4f, %.4f], \"median\": [%.4f, %.4f, %.4f]}%s",
-                    a == 4 ? "" : ", ", K, R.fps, R.ms_per_frame, R.mean[0], R.mean[1], R.mean[2], R.med[0], R.med[1], R.med[2], mode ? "" : "}");
+                    a == 4 ? "" : ", ", K, R.fps, R.ms_per_frame, R.mean[0], R.mean[1], R.mean[2], R.med[0], R.med[1], R.med[2], mode == 1 ? "" : "}");
       out += buf;
-      if (mode) { std::snprintf(buf, sizeof(buf), ", \"mean_frames_per_batch\": %.2f}", R.mean_batch); out += buf; }
+      if (mode == 1) { std::snprintf(buf, sizeof(buf), ", \"mean_frames_per_batch\": %.2f}", R.mean_batch); out += buf; }
     }
     out += "}";
   }
