@@ -108,7 +108,7 @@ def latency(capi, frames, device, calls=500, cpu_calls=24):
         t = 1 + i % 8
         p = pairs[t - 1]
         r = trk.track(frames[t], p["Tcw"], K, p["bounds"], scale, inv_s2, p["kps_l"], p["mp_l"], None, p["mps"], th=15.0)
-        tinfo.append((r["nmatches_search"], r["n_inliers"], r["tracked"], r["replayed_on_host"], r["wide_window"]))
+        tinfo.append((r["nmatches_search"], r["n_inliers"], r["tracked"], r["replayed_on_host"], r["wide_window"], r["n_requeried"]))
     t_track = _time_calls(track, calls)
     trk.close()
     ext.close()
@@ -119,7 +119,7 @@ def latency(capi, frames, device, calls=500, cpu_calls=24):
            "pose_optimization_one_frame": dict(_stats(t_pose), matches=int(np.mean([len(c[1]) for c in cases]))),
            "track_with_motion_model_one_frame": dict(_stats(t_track), matches_per_call=float(np.mean([a[0] for a in tinfo])), inliers_per_call=float(np.mean([a[1] for a in tinfo])),
                                                      tracked_fraction=float(np.mean([a[2] for a in tinfo])), replayed_on_host_fraction=float(np.mean([a[3] for a in tinfo])),
-                                                     wide_window_fraction=float(np.mean([a[4] for a in tinfo])),
+                                                     wide_window_fraction=float(np.mean([a[4] for a in tinfo])), windows_searched_again_per_call=float(np.mean([a[5] for a in tinfo])),
                                                      note="Frame::Frame -> ExtractORB + TrackWithMotionModel (SearchByProjection(Cur, Last) -> PoseOptimization -> outlier drop) as one "
                                                           "enqueue: dvmh_track_with_motion_model, host image in -> host results out"),
            "reference": "Tracking.cc:1423-1426 (Frame ctor -> ORBextractor::operator()), :2610 (SearchByProjection), :2632 (PoseOptimization)"}

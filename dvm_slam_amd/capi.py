@@ -854,7 +854,7 @@ class TrackResult(C.Structure):
     """dvmh_track_result (include/dvmslam_host.h)"""
     _fields_ = [("n", C.c_int32), ("mono_index", C.c_int32), ("nmatches", C.c_int32), ("nmatches_search", C.c_int32), ("nmatches_map", C.c_int32),
                 ("n_inliers", C.c_int32), ("wide_window", C.c_int32), ("replayed_on_host", C.c_int32), ("tracked", C.c_int32),
-                ("Tcw", C.c_float * 7), ("pose", C.c_double * 7)]
+                ("Tcw", C.c_float * 7), ("pose", C.c_double * 7), ("n_requeried", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Distortion(C.Structure):
@@ -905,7 +905,7 @@ class Tracker:
         check(rc)
         n = res.n
         out = {k: getattr(res, k) for k in ("n", "mono_index", "nmatches", "nmatches_search", "nmatches_map", "n_inliers", "wide_window",
-                                            "replayed_on_host", "tracked")}
+                                            "replayed_on_host", "tracked", "n_requeried")}
         out.update(kps=kps[:n], kps_un=kun[:n], desc=desc[:n], mp=mp[:n], dropped=dropped[:n], pose=np.array(res.pose[:], np.float64),
                    Tcw=np.array(res.Tcw[:], np.float32))
         return out

@@ -44,6 +44,8 @@ struct dvm_frame {
   size_t scratch_bytes = 0;
 };
 
+namespace dvm { FrameView frame_view_of(const ::dvm_frame* f) { return f->view; } }
+
 static int need_device(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

@@ -6,6 +6,8 @@
 #include "orb_kernels.h"
 #include "undistort_f64.h"
 
+struct dvm_frame;
+
 namespace dvm {
 
 constexpr int kFrameCap = 8192;  // keypoints per frame slot (13-bit index inside the sort key)
@@ -16,6 +18,8 @@ struct dvm_match_pod {  // == dvm_match
 };
 
 // Device view of a set of frame slots, each `cap` keypoints, sorted in GetFeaturesInArea order.
+constexpr int kGridCols = 64, kGridRows = 48;  // Frame.h:44-45 (FRAME_GRID_COLS / FRAME_GRID_ROWS)
+
 struct FrameView {
   float4* skp;           // (x, y, octave bits, cell bits) per sorted position
   int32_t* sidx;         // original keypoint index
@@ -101,6 +105,8 @@ void launch_frame_build(hipStream_t s, const dvm_keypoint_pod* kps, int64_t kps_
 void launch_match_window(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc,
                          const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax,
                          int nq, const int32_t* d_nq, int grid_q, dvm_match_pod* out, int32_t* second_idx = nullptr);
+// the device view of a grid handle (capi.cpp; for the kernels of other translation units that search the same grid: track.cpp)
+FrameView frame_view_of(const struct ::dvm_frame* f);
 void launch_match_window_ranked(hipStream_t s, const FrameView& F, int slot, const uint8_t* skip, const uint8_t* qdesc, const float* qx,
                                 const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int nq, uint32_t* ranked);
 void launch_match_window_ranked_batch(hipStream_t s, const FrameView& F, int first_slot, int count, const uint8_t* skip, const int32_t* skip_on,

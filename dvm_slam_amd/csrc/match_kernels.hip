@@ -17,7 +17,6 @@
 
 namespace dvm {
 
-constexpr int kGridCols = 64, kGridRows = 48;  // Frame.h:44-45
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 
 // One workgroup (1024 threads) per frame slot.  Bitonic sort of (cell << 13 | idx) keys in LDS, then

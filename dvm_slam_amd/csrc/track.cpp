@@ -152,7 +152,10 @@ int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm
                                  t->d_ranked, 1, s);
     if (rc != DVM_OK) return rc;
   }
-  launch_track_claims(s, t->d_ranked, t->dev(m.q_claims), t->dev(m.q_angle), nq, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, q->th_high,
+  TrackRequery rq{};
+  rq.F = frame_view_of(t->grid).slot(0);    // (bounds of the dvm_frame_build above)
+  rq.qdesc = t->dev(m.qdesc); rq.qx = t->dev(m.qx); rq.qy = t->dev(m.qy); rq.qr = t->dev(m.qr); rq.qmin = t->dev(m.qmin); rq.qmax = t->dev(m.qmax);
+  launch_track_claims(s, t->d_ranked, t->dev(m.q_claims), t->dev(m.q_angle), nq, rq, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, q->th_high,
                       q->check_ori, t->d_assign, t->d_res, t->dev(m.assign), t->dev(m.res));
   launch_track_gather(s, t->d_assign, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, t->dev(m.q_pos), t->dev(m.inv_sigma2), q->nlevels, t->d_Xw,
                       t->d_obs, t->d_info, t->d_edge_kp, t->d_nedges, t->d_res, q->min_matches, t->dev(m.nedges));
@@ -170,6 +173,7 @@ int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm
   std::memcpy(assign, m.assign, (size_t)n * 4);
   res->nmatches = m.res[0];
   res->nmatches_before_rotation = m.res[2];
+  res->n_requeried = m.res[3];
   if (m.res[1]) {                       // a query ran out of ranked candidates: the caller replays the epilogue from the lists
     res->status = DVM_TRACK_REPLAY_ON_HOST;
     if (ranked && nq) DVM_HIP(hipMemcpy(ranked, t->d_ranked, (size_t)nq * 16, hipMemcpyDeviceToHost));

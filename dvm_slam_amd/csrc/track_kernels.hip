@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "match_kernels.h"
 #include "track_kernels.h"
 
 namespace dvm {
@@ -25,11 +26,14 @@ constexpr int kHisto = 30;   // HISTO_LENGTH, ORBmatcher.cc:38
 //   ranked[q][0..3]  dist << 16 | keypoint, best first, dist >= 256 = end of the list (k_match_window_ranked)
 //   q_claims[q]      the query's map point has Observations() > 0: its match takes the keypoint (:1620-1622)
 //   q_angle[q]       LastFrame.mvKeysUn[i].angle
-// Outputs: assign[j] = the query matched to keypoint j at the end of the call or -1; res[0] = nmatches, res[1] = 1 if some query
-// found all four ranked candidates taken while its list may go on (the caller then repeats the epilogue on the host: rare),
-// res[2] = matches before the rotation check.
+//   RQ               the grid the lists were ranked on and the query arrays: a query that finds all four ranked candidates taken while
+//                    its list may go on has its window scanned again by the whole wave at its turn (on the dense bench stream
+//                    about one query in 60: every frame has some)
+// Outputs: assign[j] = the query matched to keypoint j at the end of the call or -1; res[0] = nmatches, res[1] = 1 if such a query could
+// not be searched again here (RQ.F.skp == nullptr: the caller then repeats the epilogue on the host), res[2] = matches before the
+// rotation check, res[3] = queries searched again.
 __global__ void __launch_bounds__(64) k_track_claims(const uint32_t* __restrict__ ranked, const uint8_t* __restrict__ q_claims,
-                                                     const float* __restrict__ q_angle, int nq, const dvm_keypoint_pod* __restrict__ kps,
+                                                     const float* __restrict__ q_angle, int nq, TrackRequery RQ, const dvm_keypoint_pod* __restrict__ kps,
                                                      const int32_t* __restrict__ d_n, int kp_cap, int th_high, int check_ori,
                                                      int32_t* __restrict__ assign, int32_t* __restrict__ res, int32_t* __restrict__ assign_host,
                                                      int32_t* __restrict__ res_host) {
@@ -46,7 +50,7 @@ __global__ void __launch_bounds__(64) k_track_claims(const uint32_t* __restrict_
   for (int q = lane; q < nq; q += 64) s_qres[q] = 0xFFFFFFFFu;
   if (lane < kHisto) s_rot[lane] = 0;
   __syncthreads();
-  int exhausted_any = 0;
+  int exhausted_any = 0, n_requeried = 0;
   for (int q0 = 0; q0 < nq; q0 += 64) {
     const int q = q0 + lane;
     uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -70,11 +74,64 @@ __global__ void __launch_bounds__(64) k_track_claims(const uint32_t* __restrict_
         }
         exhausted = c == 4;                            // all four taken, the list may go on
       }
+      // A query whose four ranked candidates are all taken (the list may go on) waits until every query in front of it is final --
+      // it blocks the lanes behind it meanwhile --, then the whole wave scans its window again, skipping what is taken by now:
+      // the reference's loop of ORBmatcher.cc:1613-1650 at that query's turn (smallest (distance, scan position) among the free ones)
+      const unsigned long long und = __ballot(!decided);
+      const int first_und = (int)__builtin_ctzll(und);
+      const bool requery = ((__ballot(!decided && exhausted) >> first_und) & 1ull) != 0ull;
+      if (requery && RQ.F.skp) {
+        const int qf = q0 + first_und;
+        const float x = RQ.qx[qf], y = RQ.qy[qf], r = RQ.qr[qf];
+        const int minLevel = RQ.qmin[qf], maxLevel = RQ.qmax[qf];
+        const FrameView& F = RQ.F;
+        uint32_t best = (256u << 16) | 0xFFFFu;
+        const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+        const int nMaxCellX = min(kGridCols - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+        const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+        const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+        const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
+        if (!empty && nMinCellX <= nMaxCellX) {
+          const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+          const uint32_t* qd = reinterpret_cast<const uint32_t*>(RQ.qdesc + (size_t)qf * 32);
+          uint32_t w[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) w[i] = qd[i];
+          const int beg = F.cellx_start[nMinCellX], end = F.cellx_start[nMaxCellX + 1];
+          for (int p = beg + lane; p < end; p += 64) {
+            const float4 kp = F.skp[p];
+            const int oct = __float_as_int(kp.z);
+            const int iy = __float_as_int(kp.w) % kGridRows;
+            if (iy < nMinCellY || iy > nMaxCellY) continue;
+            if (checkLevels) {
+              if (oct < minLevel) continue;
+              if (maxLevel >= 0 && oct > maxLevel) continue;
+            }
+            const float dx = kp.x - x, dy = kp.y - y;
+            if (!(fabsf(dx) < r && fabsf(dy) < r)) continue;
+            const int idx = F.sidx[p];
+            if (idx >= N || s_claimed[idx]) continue;
+            const uint4* td = reinterpret_cast<const uint4*>(F.sdesc + (size_t)p * 32);
+            const uint4 a = td[0], b = td[1];
+            const int d = __popc(a.x ^ w[0]) + __popc(a.y ^ w[1]) + __popc(a.z ^ w[2]) + __popc(a.w ^ w[3]) +
+                          __popc(b.x ^ w[4]) + __popc(b.y ^ w[5]) + __popc(b.z ^ w[6]) + __popc(b.w ^ w[7]);
+            best = min(best, ((uint32_t)d << 16) | (uint32_t)p);
+          }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+        if (lane == first_und) {
+          exhausted = false;
+          pdist = (int)(best >> 16);
+          prop = pdist < 256 ? F.sidx[best & 0xFFFFu] : -1;
+          n_requeried++;
+        }
+      }
       const bool matched = prop >= 0 && pdist <= th_high;
       const bool takes = matched && claims;
       if (!decided && takes) atomicMin(&s_owner[prop], (uint32_t)lane);
       __syncthreads();
-      const bool blocked = !decided && prop >= 0 && s_owner[prop] < (uint32_t)lane;
+      const bool blocked = !decided && ((prop >= 0 && s_owner[prop] < (uint32_t)lane) || (exhausted && RQ.F.skp != nullptr));
       const unsigned long long bm = __ballot(blocked);
       const int first_blocked = bm ? (int)__builtin_ctzll(bm) : 64;
       __syncthreads();
@@ -131,9 +188,12 @@ __global__ void __launch_bounds__(64) k_track_claims(const uint32_t* __restrict_
   // (both copies: the device one feeds k_track_gather, the mapped one is what the host reads after the chain's one synchronisation)
   for (int j = lane; j < kp_cap; j += 64) { const int a = j < N ? s_assign[j] : -1; assign[j] = a; assign_host[j] = a; }
   const int any_exhausted = __ballot(exhausted_any != 0) != 0ull;
+  int nrq = n_requeried;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nrq += __shfl_xor(nrq, o);
   if (lane == 0) {
-    res[0] = nmatched - ndropped; res[1] = any_exhausted; res[2] = nmatched;
-    res_host[0] = nmatched - ndropped; res_host[1] = any_exhausted; res_host[2] = nmatched;
+    res[0] = nmatched - ndropped; res[1] = any_exhausted; res[2] = nmatched; res[3] = nrq;
+    res_host[0] = nmatched - ndropped; res_host[1] = any_exhausted; res_host[2] = nmatched; res_host[3] = nrq;
   }
 }
 
@@ -202,9 +262,10 @@ __global__ void __launch_bounds__(256) k_track_finish(int32_t* __restrict__ assi
 
 size_t track_claims_lds(int kp_cap, int nq) { return (size_t)kp_cap * 9 + (size_t)nq * 4 + 16; }
 
-void launch_track_claims(hipStream_t s, const uint32_t* ranked, const uint8_t* q_claims, const float* q_angle, int nq, const dvm_keypoint_pod* kps,
-                         const int32_t* d_n, int kp_cap, int th_high, int check_ori, int32_t* assign, int32_t* res, int32_t* assign_host, int32_t* res_host) {
-  hipLaunchKernelGGL(k_track_claims, dim3(1), dim3(64), track_claims_lds(kp_cap, nq), s, ranked, q_claims, q_angle, nq, kps, d_n, kp_cap, th_high,
+void launch_track_claims(hipStream_t s, const uint32_t* ranked, const uint8_t* q_claims, const float* q_angle, int nq, const TrackRequery& rq,
+                         const dvm_keypoint_pod* kps, const int32_t* d_n, int kp_cap, int th_high, int check_ori, int32_t* assign, int32_t* res,
+                         int32_t* assign_host, int32_t* res_host) {
+  hipLaunchKernelGGL(k_track_claims, dim3(1), dim3(64), track_claims_lds(kp_cap, nq), s, ranked, q_claims, q_angle, nq, rq, kps, d_n, kp_cap, th_high,
                      check_ori, assign, res, assign_host, res_host);
 }
 void launch_track_gather(hipStream_t s, const int32_t* assign, const dvm_keypoint_pod* kps_un, const int32_t* d_n, int kp_cap, const float* q_pos,

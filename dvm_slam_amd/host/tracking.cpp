@@ -68,7 +68,7 @@ extern "C" int dvmh_track_with_motion_model(dvm_tracker* t, dvm_orb* h, int devi
     tq.th_high = TH_HIGH; tq.check_ori = check_ori; tq.min_matches = 20;
     rc = dvm_track_finish(t, h, &tq, kps, desc, cap, kps_un, assign.data(), outl.data(), ranked.data(), &tr);
     if (rc != DVM_OK) return rc;
-    out->n = tr.n; out->mono_index = tr.mono_index;
+    out->n = tr.n; out->mono_index = tr.mono_index; out->n_requeried = tr.n_requeried;
     if (tr.status != DVM_TRACK_FEW_MATCHES || attempt == 1) break;
     th_now = 2 * th;                       // Tracking.cc:2616-2624: "Not enough matches, wider window search"
     out->wide_window = 1;

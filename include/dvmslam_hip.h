@@ -569,12 +569,14 @@ enum { DVM_TRACK_COMPLETE = 0, DVM_TRACK_FEW_MATCHES = 1, DVM_TRACK_REPLAY_ON_HO
 typedef struct {
   int32_t n, mono_index;           /* the extraction's keypoint count and monoIndex */
   int32_t status;                  /* DVM_TRACK_COMPLETE; FEW_MATCHES: nmatches < min_matches, no pose (search again with the doubled window:
-                                      dvm_track_finish with the wider queries); REPLAY_ON_HOST: a query found all four ranked candidates taken
-                                      while its list may go on -- `ranked` holds the lists, assign / nmatches are not final */
+                                      dvm_track_finish with the wider queries); REPLAY_ON_HOST: kept for callers of older builds -- the device now
+                                      searches such a query's window again itself (n_requeried), the status is no longer produced */
   int32_t nmatches;                /* SearchByProjection's return value */
   int32_t nmatches_before_rotation;
   int32_t n_edges, n_inliers;      /* PoseOptimization: nInitialCorrespondences and its return value */
   int32_t nmatches_map, nmatches_after;   /* Tracking.cc:2636-2660: nmatchesMap and nmatches after the outliers were dropped */
+  int32_t n_requeried;             /* queries whose four ranked candidates were all taken by earlier queries: their windows were searched
+                                      again on the device at their turn (ORBmatcher.cc:1613-1650 skips taken keypoints) */
   double pose[7];                  /* the optimised Tcw */
 } dvm_track_result;
 int dvm_tracker_create(int device, int max_keypoints, int max_queries, dvm_tracker** out);

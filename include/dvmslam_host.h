@@ -103,10 +103,12 @@ typedef struct {
   int32_t nmatches_map;        /* nmatchesMap */
   int32_t n_inliers;           /* PoseOptimization's return value */
   int32_t wide_window;         /* 1: the doubled window was searched */
-  int32_t replayed_on_host;    /* 1: the claims were replayed on the host (a query ran out of ranked candidates) */
+  int32_t replayed_on_host;    /* 1: the claims were replayed on the host (not produced any more: see n_requeried) */
   int32_t tracked;             /* 0: fewer than 20 matches even with the doubled window (TrackWithMotionModel returns false; pose untouched) */
   dvm_se3f Tcw;                /* the optimised pose as CurrentFrame.SetPose receives it */
   double pose[7];              /* the same as PoseOptimization's doubles (tx ty tz qx qy qz qw) */
+  int32_t n_requeried;         /* queries whose window the device searched again at their turn (all four ranked candidates taken) */
+  int32_t pad_;
 } dvmh_track_result;
 int dvmh_track_with_motion_model(dvm_tracker* t, dvm_orb* h, int device, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1,
                                  const dvm_se3f* Tcw_pred, const float* K, const float* bounds, const dvm_distortion* dist,

@@ -104,3 +104,43 @@ def test_track_frame_equals_separate_calls_and_oracle(scene, p_obs0, th):
             gt = ps.pose7(*poses[t])
             assert np.abs(fused["pose"][:3] - gt[:3]).max() < 0.05   # and it finds the camera (map noise 1 cm, pixel noise of ORB)
     trk.close(); ext.close()
+
+
+def test_track_frame_dense_stream_requeries_on_device():
+    """The bench stream is dense enough that some query of every frame finds all four ranked candidates taken by earlier queries: the
+    device searches those windows again at the query's turn (k_track_claims), nothing is replayed on the host, and the results are
+    those of the separate calls (whose host epilogue re-queries the same windows) and of the oracle chain."""
+    from dvm_slam_amd import capi, synth
+    from oracle import pyoracle as po
+    frames = synth.frame_stream(4)
+    ext = capi.OrbExtractor(max_batch=1)
+    tab = ext.tables()
+    scale, inv_s2 = tab["scale"], tab["inv_sigma2"]
+    trk = capi.Tracker(ext)
+    orc = po.OrbOracle()
+    rng = np.random.default_rng(9)
+    Kc = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    Tcw = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    total_rq = 0
+    for t in (1, 2, 3):
+        n0, k0, d0, _ = ext.extract(frames[t - 1])
+        z = rng.uniform(3, 9, n0).astype(np.float32)
+        mps = np.zeros(n0, capi.MAP_POINT_DTYPE)
+        mps["pos"][:, 0] = (k0["x"] - Kc[2]) / Kc[0] * z; mps["pos"][:, 1] = (k0["y"] - Kc[3]) / Kc[1] * z; mps["pos"][:, 2] = z
+        mps["desc"] = d0; mps["n_obs"] = 1
+        mp_l = np.arange(n0, dtype=np.int32)
+        fused = trk.track(frames[t], Tcw, Kc, BOUNDS, scale, inv_s2, k0, mp_l, None, mps, th=15.0)
+        assert fused["replayed_on_host"] == 0
+        total_rq += fused["n_requeried"]
+        sep = _separate_calls(lambda im: ext.extract(im),
+                              lambda k, d, m, T, kl, ml, mp_, th_: capi.search_by_projection_frames(k, d, m, T, Kc, BOUNDS, scale, kl, ml, None, mp_, th_)[:2],
+                              lambda p, X, o, w: [r[0] for r in capi.pose_optimize(p[None], X[None], o[None], w[None], [len(X)], Kc)],
+                              frames[t], Tcw, scale, inv_s2, k0, mp_l, mps, 15.0)
+        _check(fused, sep, exact_pose=True)
+        orc_out = _separate_calls(lambda im: orc.extract(im),
+                                  lambda k, d, m, T, kl, ml, mp_, th_: po.search_by_projection_frames(k, d, m, T, Kc, BOUNDS, scale, kl, ml, None, mp_, th_)[:2],
+                                  lambda p, X, o, w: po.pose_optimize(p, X, o, w, Kc),
+                                  frames[t], Tcw, scale, inv_s2, k0, mp_l, mps, 15.0)
+        _check(fused, orc_out, exact_pose=False)
+    assert total_rq > 0       # the case this test is for did occur
+    trk.close(); ext.close()
