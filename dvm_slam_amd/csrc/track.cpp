@@ -14,6 +14,8 @@
 // Tracking.cc:2616-2624: call dvm_track_finish again with the wider queries -- no new extraction), and a query whose four ranked
 // candidates were all taken by earlier queries (the list may go on: the caller replays the epilogue from the ranked lists on the host).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -41,6 +43,11 @@ struct dvm_tracker {
     dvm_keypoint_pod* kps_un;
   } m;
   template <class T> T* dev(T* host_ptr) const { return reinterpret_cast<T*>(hm_dev + (reinterpret_cast<uint8_t*>(host_ptr) - hm)); }
+  // the query block: built in the mapped buffer (page-locked), copied to the device by ONE asynchronous copy on a side stream while the
+  // extraction runs; the kernels read the device copy (the one-wave claim replay walks it serially: a PCIe read per step would be its chain)
+  uint8_t* d_q = nullptr; size_t q_bytes = 0;
+  hipStream_t cstream = nullptr; hipEvent_t cev = nullptr;
+  template <class T> T* qdev(T* host_ptr) const { return reinterpret_cast<T*>(d_q + (reinterpret_cast<uint8_t*>(host_ptr) - hm)); }
   bool begun = false;
   int rows = 0, cols = 0;
 };
@@ -55,8 +62,8 @@ extern "C" {
 int dvm_tracker_create(int device, int max_keypoints, int max_queries, dvm_tracker** out) {
   if (!out || max_keypoints < 1 || max_queries < 1) return DVM_ERR_INVALID;
   *out = nullptr;
-  if (max_keypoints > kFrameCap || max_queries > kFrameCap || track_claims_lds(max_keypoints, max_queries) > 60 * 1024) {
-    set_error("dvm_tracker_create: capacity beyond what the claim replay keeps in LDS (9 B per keypoint + 4 B per query <= 60 KB)");
+  if (max_keypoints > kFrameCap || max_queries > kFrameCap || track_claims_lds(max_keypoints, max_queries) > 150 * 1024) {
+    set_error("dvm_tracker_create: capacity beyond what the claim replay keeps in LDS (9 B per keypoint + 21 B per query <= 150 KB)");
     return DVM_ERR_CAPACITY;
   }
   int ndev = 0;
@@ -89,11 +96,16 @@ int dvm_tracker_create(int device, int max_keypoints, int max_queries, dvm_track
   std::memset(t->hm, 0, mbytes);
   p = t->hm;
   auto& m = t->m;
-  m.qdesc = carve<uint8_t>(p, Q * 32); m.qx = carve<float>(p, Q); m.qy = carve<float>(p, Q); m.qr = carve<float>(p, Q);
-  m.qmin = carve<int32_t>(p, Q); m.qmax = carve<int32_t>(p, Q); m.q_claims = carve<uint8_t>(p, Q); m.q_angle = carve<float>(p, Q);
-  m.q_pos = carve<float>(p, Q * 3); m.pose_in = carve<double>(p, 7); m.assign = carve<int32_t>(p, K); m.outlier = carve<uint8_t>(p, K);
-  m.res = carve<int32_t>(p, 4); m.fin = carve<int32_t>(p, 4); m.nedges = carve<int32_t>(p, 4); m.pose_out = carve<double>(p, 7);
-  m.n_inl = carve<int32_t>(p, 1); m.inv_sigma2 = carve<float>(p, 64); m.kps_un = carve<dvm_keypoint_pod>(p, K);
+  // [query block: sized per call, see dvm_track_finish] [results]
+  t->q_bytes = pad256(Q * 32) + 3 * pad256(Q * 4) + 2 * pad256(Q * 4) + pad256(Q) + pad256(Q * 4) + pad256(Q * 12) + pad256(56) + pad256(64 * 4);
+  p += t->q_bytes;
+  m.assign = carve<int32_t>(p, K); m.outlier = carve<uint8_t>(p, K);
+  m.res = carve<int32_t>(p, 8); m.fin = carve<int32_t>(p, 4); m.nedges = carve<int32_t>(p, 4); m.pose_out = carve<double>(p, 7);
+  m.n_inl = carve<int32_t>(p, 1); m.kps_un = carve<dvm_keypoint_pod>(p, K);
+  if (hipMalloc(reinterpret_cast<void**>(&t->d_q), t->q_bytes) != hipSuccess || hipStreamCreateWithFlags(&t->cstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&t->cev, hipEventDisableTiming) != hipSuccess) {
+    dvm_tracker_destroy(t); set_error("dvm_tracker_create: query block"); return DVM_ERR_HIP;
+  }
   *out = t;
   return DVM_OK;
 }
@@ -103,6 +115,9 @@ void dvm_tracker_destroy(dvm_tracker* t) {
   hipSetDevice(t->device);
   if (t->grid) dvm_frame_destroy(t->grid);
   if (t->d_buf) hipFree(t->d_buf);
+  if (t->d_q) hipFree(t->d_q);
+  if (t->cev) hipEventDestroy(t->cev);
+  if (t->cstream) hipStreamDestroy(t->cstream);
   if (t->hm) hipHostFree(t->hm);
   delete t;
 }
@@ -131,11 +146,23 @@ int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm
   if (ocap > t->kp_cap) { set_error("dvm_track_finish: the extractor's keypoint capacity exceeds the tracker's"); return DVM_ERR_CAPACITY; }
   const int nq = q->nq;
   auto& m = t->m;
-  // queries -> mapped memory (read in place by the kernels, once each)
+  {   // the query block of THIS call, packed (nq entries per array): one copy of ~75 KB for 1 000 queries
+    uint8_t* p = t->hm;
+    const size_t Qn = (size_t)nq;
+    m.qdesc = carve<uint8_t>(p, Qn * 32); m.qx = carve<float>(p, Qn); m.qy = carve<float>(p, Qn); m.qr = carve<float>(p, Qn);
+    m.qmin = carve<int32_t>(p, Qn); m.qmax = carve<int32_t>(p, Qn); m.q_claims = carve<uint8_t>(p, Qn); m.q_angle = carve<float>(p, Qn);
+    m.q_pos = carve<float>(p, Qn * 3); m.pose_in = carve<double>(p, 7); m.inv_sigma2 = carve<float>(p, 64);
+  }
   std::memcpy(m.qdesc, q->qdesc, (size_t)nq * 32); std::memcpy(m.qx, q->qx, (size_t)nq * 4); std::memcpy(m.qy, q->qy, (size_t)nq * 4);
   std::memcpy(m.qr, q->qr, (size_t)nq * 4); std::memcpy(m.qmin, q->qmin, (size_t)nq * 4); std::memcpy(m.qmax, q->qmax, (size_t)nq * 4);
   std::memcpy(m.q_claims, q->q_claims, (size_t)nq); std::memcpy(m.q_angle, q->q_angle, (size_t)nq * 4); std::memcpy(m.q_pos, q->q_pos, (size_t)nq * 12);
   std::memcpy(m.pose_in, q->pose_in, 56); std::memcpy(m.inv_sigma2, q->inv_level_sigma2, (size_t)q->nlevels * 4);
+  {
+    const size_t used = (size_t)(reinterpret_cast<uint8_t*>(m.inv_sigma2) - t->hm) + pad256(64 * 4);
+    DVM_HIP(hipMemcpyAsync(t->d_q, t->hm, used, hipMemcpyHostToDevice, t->cstream));   // beside the extraction, not behind it
+    DVM_HIP(hipEventRecord(t->cev, t->cstream));
+    DVM_HIP(hipStreamWaitEvent(s, t->cev, 0));
+  }
   // mvKeysUn: the extractor's keypoints themselves without distortion (Frame.cc:791-797), else undistorted on the device (:799-818)
   const bool undist = q->dist && q->dist->k1 != 0.0f;
   const dvm_keypoint* d_un = d_kps;
@@ -148,20 +175,21 @@ int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm
   rc = dvm_frame_build(t->grid, 0, d_un, d_desc, 0, d_n, q->bounds[0], q->bounds[1], q->bounds[2], q->bounds[3], 1, s);
   if (rc != DVM_OK) return rc;
   if (nq) {
-    rc = dvm_match_window_ranked(t->grid, 0, nullptr, t->dev(m.qdesc), t->dev(m.qx), t->dev(m.qy), t->dev(m.qr), t->dev(m.qmin), t->dev(m.qmax), nq,
+    rc = dvm_match_window_ranked(t->grid, 0, nullptr, t->qdev(m.qdesc), t->qdev(m.qx), t->qdev(m.qy), t->qdev(m.qr), t->qdev(m.qmin), t->qdev(m.qmax), nq,
                                  t->d_ranked, 1, s);
     if (rc != DVM_OK) return rc;
   }
   TrackRequery rq{};
   rq.F = frame_view_of(t->grid).slot(0);    // (bounds of the dvm_frame_build above)
-  rq.qdesc = t->dev(m.qdesc); rq.qx = t->dev(m.qx); rq.qy = t->dev(m.qy); rq.qr = t->dev(m.qr); rq.qmin = t->dev(m.qmin); rq.qmax = t->dev(m.qmax);
-  launch_track_claims(s, t->d_ranked, t->dev(m.q_claims), t->dev(m.q_angle), nq, rq, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, q->th_high,
+  { static const bool no_rq = std::getenv("DVM_TRACK_NO_REQUERY") != nullptr; if (no_rq) rq.F.skp = nullptr; }   /* timing experiment only */
+  rq.qdesc = t->qdev(m.qdesc); rq.qx = t->qdev(m.qx); rq.qy = t->qdev(m.qy); rq.qr = t->qdev(m.qr); rq.qmin = t->qdev(m.qmin); rq.qmax = t->qdev(m.qmax);
+  launch_track_claims(s, t->d_ranked, t->qdev(m.q_claims), t->qdev(m.q_angle), nq, rq, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, q->th_high,
                       q->check_ori, t->d_assign, t->d_res, t->dev(m.assign), t->dev(m.res));
-  launch_track_gather(s, t->d_assign, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, t->dev(m.q_pos), t->dev(m.inv_sigma2), q->nlevels, t->d_Xw,
+  launch_track_gather(s, t->d_assign, reinterpret_cast<const dvm_keypoint_pod*>(d_un), d_n, ocap, t->qdev(m.q_pos), t->qdev(m.inv_sigma2), q->nlevels, t->d_Xw,
                       t->d_obs, t->d_info, t->d_edge_kp, t->d_nedges, t->d_res, q->min_matches, t->dev(m.nedges));
-  ba_launch_pose_optimize(s, t->dev(m.pose_in), t->d_Xw, t->d_obs, t->d_info, t->d_nedges, ocap, 1, q->cam.fx, q->cam.fy, q->cam.cx, q->cam.cy,
+  ba_launch_pose_optimize(s, t->qdev(m.pose_in), t->d_Xw, t->d_obs, t->d_info, t->d_nedges, ocap, 1, q->cam.fx, q->cam.fy, q->cam.cx, q->cam.cy,
                           t->dev(m.pose_out), t->d_edge_out, t->dev(m.n_inl), t->d_chi);
-  launch_track_finish(s, t->d_assign, d_n, ocap, t->d_edge_kp, t->d_nedges, t->d_edge_out, t->dev(m.q_claims), t->dev(m.outlier), t->dev(m.fin));
+  launch_track_finish(s, t->d_assign, d_n, ocap, t->d_edge_kp, t->d_nedges, t->d_edge_out, t->qdev(m.q_claims), t->dev(m.outlier), t->dev(m.fin), t->d_res);
   // (what the host wants back is written to mapped memory by the kernels themselves: no copy command behind the chain)
   rc = hip_check(hipGetLastError(), "tracking chain launch");
   if (rc != DVM_OK) return rc;
@@ -174,6 +202,7 @@ int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm
   res->nmatches = m.res[0];
   res->nmatches_before_rotation = m.res[2];
   res->n_requeried = m.res[3];
+  if (std::getenv("DVM_TRACK_DEBUG")) std::fprintf(stderr, "track: nq %d rounds %d requeried %d\n", nq, m.res[4], m.res[3]);
   if (m.res[1]) {                       // a query ran out of ranked candidates: the caller replays the epilogue from the lists
     res->status = DVM_TRACK_REPLAY_ON_HOST;
     if (ranked && nq) DVM_HIP(hipMemcpy(ranked, t->d_ranked, (size_t)nq * 16, hipMemcpyDeviceToHost));

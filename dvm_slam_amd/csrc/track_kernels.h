@@ -20,5 +20,5 @@ void launch_track_gather(hipStream_t s, const int32_t* assign, const dvm_keypoin
                          const float* inv_sigma2, int nlevels, double* Xw, double* obs, double* info, int32_t* edge_kp, int32_t* n_edges,
                          const int32_t* res, int min_matches, int32_t* n_edges_host);
 void launch_track_finish(hipStream_t s, int32_t* assign, const int32_t* d_n, int kp_cap, const int32_t* edge_kp, const int32_t* n_edges,
-                         const uint8_t* edge_outlier, const uint8_t* q_claims, uint8_t* outlier, int32_t* out);
+                         const uint8_t* edge_outlier, const uint8_t* q_claims, uint8_t* outlier, int32_t* out, const int32_t* res);
 }  // namespace dvm
