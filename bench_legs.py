@@ -408,6 +408,30 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
         best = float(np.median(ts))
         out["by_K"][str(K)] = {"value": its / best, "ms_per_call": best * 1e3, "ms_per_window": best * 1e3 / K, "iterations": its,
                                "host_setup_ms_per_window": res[0]["stats"]["ms_structure"]}
+    # the same K windows by ONE launch of the FAST form (dvm_ba_optimize_windows_fast: LM control on the device, tree sums in a fixed order;
+    # the general solver's tolerance contract instead of bit identity).  K = 128: four times the 32 windows (the launch fills 128 CUs)
+    capi.ba_optimize_windows(wins[:1], device, fast=True)
+    fast = {"call": "dvm_ba_optimize_windows_fast (one launch, a workgroup per window)", "by_K": {}}
+    resf = None
+    for K in tuple(Ks) + (4 * kmax,):
+        wk = [wins[a % kmax] for a in range(K)]
+        ts, its = [], 0
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            resf = capi.ba_optimize_windows(wk, device, fast=True)
+            ts.append(time.perf_counter() - t0)
+            its = sum(r["stats"]["iterations"] for r in resf)
+        best = float(np.median(ts))
+        fast["by_K"][str(K)] = {"value": its / best, "ms_per_call": best * 1e3, "ms_per_window": best * 1e3 / K, "iterations": its,
+                                "host_setup_ms_per_window": resf[0]["stats"]["ms_structure"], "ms_upload_launch_download": resf[0]["stats"]["ms_optimize"]}
+    dpo = max(float(np.abs(resf[a]["poses"] - res[a]["poses"]).max()) for a in range(min(len(res), kmax)))
+    dxo = max(float(np.abs(resf[a]["points"] - res[a]["points"]).max()) for a in range(min(len(res), kmax)))
+    same_trials = all(list(resf[a]["stats"]["trials"]) == list(res[a]["stats"]["trials"]) for a in range(min(len(res), kmax)))
+    fast["vs_sequential_order_kernel"] = {"max_abs_pose": dpo, "max_abs_landmark": dxo, "same_trial_sequence": bool(same_trials), "tolerance": 1e-6,
+                                          "note": "the sequential-order kernel's results are the CPU oracle's bit for bit (parity_vs_cpu below)"}
+    if not (dpo < 1e-6 and dxo < 1e-6 and same_trials):
+        raise RuntimeError(f"lba_batch leg: the fast form differs from the sequential-order kernel beyond the contract: {dpo} {dxo} {same_trials}")
+    out["fast_windows"] = fast
     # the same K windows through the tile solver, one handle, one after the other (what K agents queueing on one GPU get today)
     ba = capi.BundleAdjuster(device)
     t_seq, its_seq = [], 0

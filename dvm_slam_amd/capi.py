@@ -663,10 +663,10 @@ def ba_optimize_batch(problems, device=0, threads=0, stop_flag=None):
     return ba_optimize_windows(problems, device, stop_flag, _threads=int(threads), _batch=True)
 
 
-def ba_optimize_windows(problems, device=0, stop_flag=None, _threads=0, _batch=False):
+def ba_optimize_windows(problems, device=0, stop_flag=None, _threads=0, _batch=False, fast=False):
     """dvm_ba_optimize_windows: K independent bundle adjustments in one launch.  problems: dicts with poses [P,7], fixed [P], points [L,3],
     edges (BA_EDGE_DTYPE), intrinsics (fx, fy, cx, cy), huber_delta, iterations.  Returns one dict per window: poses, points, edge_chi2,
-    depth_positive, stats (the keys of BundleAdjuster.optimize)."""
+    depth_positive, stats (the keys of BundleAdjuster.optimize).  fast=True: dvm_ba_optimize_windows_fast (tree sums in a fixed order)."""
     K = len(problems)
     wins = (BaWindow * max(K, 1))()
     stats = (BaStats * max(K, 1))()
@@ -688,7 +688,7 @@ def ba_optimize_windows(problems, device=0, stop_flag=None, _threads=0, _batch=F
         f.restype = C.c_int32; f.argtypes = None
         check(f(C.c_int32(device), wins, C.c_int32(K), C.c_int32(_threads), _p(stop_flag) if stop_flag is not None else None, stats))
     else:
-        f = lib().dvm_ba_optimize_windows
+        f = lib().dvm_ba_optimize_windows_fast if fast else lib().dvm_ba_optimize_windows
         f.restype = C.c_int32; f.argtypes = None
         check(f(C.c_int32(device), wins, C.c_int32(K), _p(stop_flag) if stop_flag is not None else None, stats))
     for k, o in enumerate(outs):

@@ -34,6 +34,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dvmslam_hip.h"
@@ -84,6 +87,13 @@ struct BaWin {
   double *Hpp, *bp, *HB, *DD, *x, *terms;   // [nfree][36], [6 nfree], [nact][12] = Hll (9) bl (3), [nact][12] = Dinv (9) Dinv bl (3), [6 nfree + 3 nact] x 2
   dvm_ba_stats* stats;
   unsigned long long* prof;           // [16] shader-clock cycles per phase, accumulated by thread 0 (DVM_BA_WINDOW_PROF=1), or null
+  // ---- the FAST form only (k_ba_window<true>: tree sums in a fixed order instead of g2o's sequential ones, nothing streamed through LDS)
+  const int32_t *cam_start, *cam_edges;   // [nfree + 1], [edges of free cameras]: a camera's edges in edge order (rows of rowB)
+  const int32_t *cw_start, *cw_rows;      // [nfree + 1], [F]: a camera's rows of rowW / rowT, ascending
+  const int32_t *f_lm;                    // [F] active landmark of the row
+  const int32_t *bp_start;                // [nblk + 1] a block's (row of camera i1, row of camera i2) pairs, landmark order
+  const int2* bp_pairs;
+  double* rowT;                           // [F][24] W Dinv (18) | W Dinv bl (6) of the trial
 };
 
 // ------------------------------------------------------------------------------------------------ small algebra (the oracle's sequences)
@@ -560,7 +570,173 @@ __device__ void win_schur(const BaWin& W, double* S, double* rhs, double* stage,
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------ the FAST form
+// The same optimizer with every sum as a tree in a FIXED order (deterministic, but not g2o's sequential order: results agree with the
+// oracle to the general solver's tolerance instead of bit for bit).  What the sequential order costs is not its additions but the
+// machinery that feeds one lane's chain: 80 Schur chunks and 60 Hessian chunks per trial, each a handful of barrier-separated phases.
+// Here a wave owns a camera (Hpp / bp, the reduced right-hand side) or a block of the reduced system, its lanes stride the camera's
+// edges / the block's pairs straight from L2, and 27 / 6 / 36 partial sums per lane meet in four DPP steps and one LDS hop.
+template <int CTRL>
+__device__ __forceinline__ double w_dpp_add(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+// the sum over a DPP row (16 lanes), in all of its lanes: quad swaps, half-row mirror, row mirror
+__device__ __forceinline__ double w_row_sum(double v) {
+  v = w_dpp_add<0xB1>(v); v = w_dpp_add<0x4E>(v); v = w_dpp_add<0x141>(v); v = w_dpp_add<0x140>(v);
+  return v;
+}
+// acc[0..N) of the 64 lanes -> lane i < N returns the wave's sum of acc[i] ((row0 + row1) + (row2 + row3)); wbuf: 4 * N doubles of LDS, this wave's
+template <int N>
+__device__ __forceinline__ double w_wave_reduce(double (&acc)[N], double* __restrict__ wbuf) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < N; i++) acc[i] = w_row_sum(acc[i]);
+  __builtin_amdgcn_wave_barrier();      // (the previous use of wbuf has been read)
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i++) wbuf[(lane >> 4) * N + i] = acc[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double r = 0.0;
+  if (lane < N) r = (wbuf[lane] + wbuf[N + lane]) + (wbuf[2 * N + lane] + wbuf[3 * N + lane]);
+  return r;
+}
+// sum of v[0..n) over the workgroup, the same value in every thread: strided partial sums, row sums, then the 32 row sums in index order
+__device__ double win_block_sum(const double* __restrict__ v, int n, double* __restrict__ red /* 32 doubles of LDS */) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kWinThreads) s += v[i];
+  s = w_row_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4] = s;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < kWinThreads / 16; i++) t += red[i];
+  return t;
+}
+// Hpp / bp: a wave per free camera, its lanes stride the camera's edges (rows of rowB in edge order)
+__device__ void win_accumulate_cameras_fast(const BaWin& W, double* wred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* wbuf = wred + wave * 4 * 36;
+  for (int i = wave; i < W.nfree; i += kWinThreads / 64) {
+    double acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) acc[t] = 0.0;
+    const int q1 = W.cam_start[i + 1];
+    for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
+      const double* Bp = W.rowB + kRowB * (size_t)W.cam_edges[q];
+      double B[15];
+#pragma unroll
+      for (int j = 0; j < 15; j++) B[j] = Bp[j];
+      const double w = B[12], wr0 = B[13], wr1 = B[14];
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b = 0; b <= a; b++) acc[t++] += w * (B[a] * B[b] + B[6 + a] * B[6 + b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[21 + a] += B[a] * wr0 + B[6 + a] * wr1;
+    }
+    const double tot = w_wave_reduce<27>(acc, wbuf);
+    if (lane < 21) {
+      int a = 0, r = lane; while (r > a) { r -= a + 1; a++; }
+      const int b = r;
+      W.Hpp[36 * (size_t)i + 6 * a + b] = tot; W.Hpp[36 * (size_t)i + 6 * b + a] = tot;
+    } else if (lane < 27) W.bp[6 * (size_t)i + (lane - 21)] = tot;
+  }
+}
+// solve(lambda), first half, FAST form: S = Hpp + lambda I - sum_l W Dinv W^T, rhs = bp - sum_l W Dinv bl (block_solver.hpp:381-439)
+__device__ void win_schur_fast(const BaWin& W, double* S, double* rhs, double* wred, double lambda) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = 6 * W.nfree;
+  for (int i = tid; i < n * (n + 1) / 2; i += kWinThreads) S[i] = 0.0;
+  // Dinv, Dinv bl per landmark
+  for (int li = tid; li < W.nact; li += kWinThreads) {
+    const double* h = W.HB + kRowH * (size_t)li;
+    double D[9], Di[9], d3[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) D[i] = h[i];
+    const double g[3] = {h[9], h[10], h[11]};
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    w_inv3(D, Di);
+    w_mat3_vec(Di, g, d3);
+    double* o = W.DD + kRowH * (size_t)li;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[i] = Di[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[9 + i] = d3[i];
+  }
+  __syncthreads();
+  for (int t = tid; t < 21 * W.nfree; t += kWinThreads) {
+    const int i = t / 21, e = t - 21 * i;
+    int a = 0, r = e; while (r > a) { r -= a + 1; a++; }
+    const int b = r;
+    S[tri(6 * i + a, 6 * i + b)] = W.Hpp[36 * (size_t)i + 6 * a + b] + (a == b ? lambda : 0.0);
+  }
+  // W Dinv, W Dinv bl per free row
+  for (int r = tid; r < W.F; r += kWinThreads) {
+    const double* Wr = W.rowW + kRowW * (size_t)r;
+    const double* h = W.DD + kRowH * (size_t)W.f_lm[r];
+    double w[18], d[12];
+#pragma unroll
+    for (int j = 0; j < 18; j++) w[j] = Wr[j];
+#pragma unroll
+    for (int j = 0; j < 12; j++) d[j] = h[j];
+    double* o = W.rowT + kRowD * (size_t)r;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) o[3 * a + b] = w[3 * a] * d[b] + w[3 * a + 1] * d[3 + b] + w[3 * a + 2] * d[6 + b];
+      o[18 + a] = w[3 * a] * d[9] + w[3 * a + 1] * d[10] + w[3 * a + 2] * d[11];
+    }
+  }
+  __syncthreads();
+  double* wbuf = wred + wave * 4 * 36;
+  // the reduced right-hand side: a wave per camera over the camera's rows
+  for (int i = wave; i < W.nfree; i += kWinThreads / 64) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int q1 = W.cw_start[i + 1];
+    for (int q = W.cw_start[i] + lane; q < q1; q += 64) {
+      const double* T = W.rowT + kRowD * (size_t)W.cw_rows[q] + 18;
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[a] += T[a];
+    }
+    const double tot = w_wave_reduce<6>(acc, wbuf);
+    if (lane < 6) rhs[6 * i + lane] = W.bp[6 * (size_t)i + lane] - tot;
+  }
+  // the blocks: a wave per block over the block's pairs
+  for (int bk = wave; bk < W.nblk; bk += kWinThreads / 64) {
+    double acc[36];
+#pragma unroll
+    for (int t = 0; t < 36; t++) acc[t] = 0.0;
+    const int q1 = W.bp_start[bk + 1];
+    for (int q = W.bp_start[bk] + lane; q < q1; q += 64) {
+      const int2 pr = W.bp_pairs[q];
+      const double* T1 = W.rowT + kRowD * (size_t)pr.x;
+      const double* W2 = W.rowW + kRowW * (size_t)pr.y;
+      double t1[18], w2[18];
+#pragma unroll
+      for (int j = 0; j < 18; j++) { t1[j] = T1[j]; w2[j] = W2[j]; }
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) acc[6 * a + b] += t1[3 * a] * w2[3 * b] + t1[3 * a + 1] * w2[3 * b + 1] + t1[3 * a + 2] * w2[3 * b + 2];
+    }
+    const double tot = w_wave_reduce<36>(acc, wbuf);
+    const int ij = W.blk_ij[bk], i1 = ij & 255, i2 = (ij >> 8) & 255;
+    if (lane < 36) {
+      const int a = lane / 6, b = lane - 6 * a;
+      if (i1 != i2 || b <= a) { const int idx = tri(6 * i1 + a, 6 * i2 + b); S[idx] = S[idx] - tot; }
+    }
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
+template <bool FAST>
 __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop) {
   extern __shared__ double lds[];
   const BaWin& W = wins[blockIdx.x];
@@ -604,12 +780,13 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
     __syncthreads();
     lap(0);
     if (it == 0) {
-      if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
+      if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 16); if (tid == 0) ctl[1] = c; }
+      else if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
     }
     win_accumulate_landmarks(W);
     __syncthreads();
     lap(1);
-    win_accumulate_cameras(W, stage);
+    if constexpr (FAST) win_accumulate_cameras_fast(W, stage); else win_accumulate_cameras(W, stage);
     __syncthreads();
     lap(2);
     if (it == 0) {
@@ -635,7 +812,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
     do {
       // ---- solve(lambda): Dinv, Schur complement, reduced right-hand side (one streamed pass)
       lap(3);
-      win_schur(W, S, rhs, stage, lambda);
+      if constexpr (FAST) win_schur_fast(W, S, rhs, stage, lambda); else win_schur(W, S, rhs, stage, lambda);
       lap(4);
       // ---- Cholesky: entry (i, j) receives its subtractions L(i, k) L(j, k) in ascending k, as the row-wise dot products of the
       // envelope factorisation apply them; L(i, j) = s / L(j, j) by IEEE division, L(j, j) = sqrt(s)
@@ -716,8 +893,14 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
       win_edge_pass<false>(W, poses_t, pts_t);
       __syncthreads();
       lap(9);
-      if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
-      if (wave == 1) { const double c = wave_sequential_sum(W.terms, n + nl, seqbuf); if (tid == 64) ctl[2] = c; }
+      if constexpr (FAST) {
+        const double c = win_block_sum(W.e_rho, W.E, ctl + 16);
+        const double c2 = win_block_sum(W.terms, n + nl, ctl + 16);
+        if (tid == 0) { ctl[1] = c; ctl[2] = c2; }
+      } else {
+        if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
+        if (wave == 1) { const double c = wave_sequential_sum(W.terms, n + nl, seqbuf); if (tid == 64) ctl[2] = c; }
+      }
       __syncthreads();
       lap(10);
       // ---- the decision, taken by every thread on the same words (optimization_algorithm_levenberg.cpp:113-147)
@@ -759,7 +942,8 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
   if (it_done == 0) {
     win_edge_pass<false>(W, poses, pts);
     __syncthreads();
-    if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) { st->chi2_initial = c; chi_last = c; } }
+    if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 16); chi_last = c; if (tid == 0) st->chi2_initial = c; }   // (every thread holds c)
+    else if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) { st->chi2_initial = c; chi_last = c; } }
     __syncthreads();
   }
   // results: the accepted state (the buffers may have been swapped any number of times), depth signs at that state
@@ -799,9 +983,11 @@ struct WinBuild {
   std::vector<int32_t> pidx, lidx, free_pose, act_pt, e_pose, e_point, lpos, fpos, pt_start, f_start, f_cam;
   std::vector<int32_t> hc_ints, sc_desc, sc_ints, blk_ij;
   std::vector<double> e_obs, e_info;
+  // the FAST form's tables
+  std::vector<int32_t> cam_start, cam_edges, cw_start, cw_rows, f_lm, bp_start, bp_pairs;   // bp_pairs: (row1, row2) interleaved
 };
 
-int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize) {
+int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize, bool fast = false) {
   const int P = w.n_poses, L = w.n_points, E = w.n_edges;
   if (P < 0 || L < 0 || E < 0 || (P && (!w.poses || !w.fixed)) || (L && !w.points) || (E && !w.edges)) { set_error("dvm_ba_optimize_windows: null array"); return DVM_ERR_INVALID; }
   b.P = P; b.L = L; b.E = E;
@@ -849,6 +1035,46 @@ int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize) {
     maxdeg = std::max(maxdeg, b.f_start[li + 1] - b.f_start[li]);
   }
   b.F = (int)f_edge.size();
+  if (fast) {
+    // nothing is streamed in chunks: per camera its edges (edge order) and its rows of rowW, per row its landmark, per block of the
+    // reduced system its (row, row) pairs in landmark order (block_solver.hpp:381-439: edge k1 (outer) x edge k2 (inner), lower blocks)
+    b.cam_start.assign(nf + 1, 0); b.cw_start.assign(nf + 1, 0);
+    for (int k = 0; k < E; k++) { const int i = b.pidx[b.e_pose[k]]; if (i >= 0) b.cam_start[i + 1]++; }
+    for (int i = 0; i < nf; i++) b.cam_start[i + 1] += b.cam_start[i];
+    b.cam_edges.resize(b.cam_start[nf]);
+    { std::vector<int32_t> fill(b.cam_start.begin(), b.cam_start.end() - 1);
+      for (int k = 0; k < E; k++) { const int i = b.pidx[b.e_pose[k]]; if (i >= 0) b.cam_edges[fill[i]++] = k; } }
+    for (int r = 0; r < b.F; r++) b.cw_start[b.f_cam[r] + 1]++;
+    for (int i = 0; i < nf; i++) b.cw_start[i + 1] += b.cw_start[i];
+    b.cw_rows.resize(b.F); b.f_lm.resize(b.F);
+    { std::vector<int32_t> fill(b.cw_start.begin(), b.cw_start.end() - 1);
+      for (int r = 0; r < b.F; r++) b.cw_rows[fill[b.f_cam[r]]++] = r; }
+    for (int li = 0; li < b.nact; li++) for (int r = b.f_start[li]; r < b.f_start[li + 1]; r++) b.f_lm[r] = li;
+    std::vector<int32_t> blk_of((size_t)nf * nf, -1), cnt;
+    auto each_pair = [&](auto&& fn) {
+      for (int li = 0; li < b.nact; li++)
+        for (int q1 = b.f_start[li]; q1 < b.f_start[li + 1]; q1++)
+          for (int q2 = b.f_start[li]; q2 < b.f_start[li + 1]; q2++) {
+            const int i1 = b.f_cam[q1], i2 = b.f_cam[q2];
+            if (i2 > i1 || (i2 == i1 && q2 != q1)) continue;
+            fn(i1, i2, q1, q2);
+          }
+    };
+    each_pair([&](int i1, int i2, int, int) {
+      int32_t& id = blk_of[(size_t)i1 * nf + i2];
+      if (id < 0) { id = (int32_t)b.blk_ij.size(); b.blk_ij.push_back(i1 | (i2 << 8)); cnt.push_back(0); }
+      cnt[id]++;
+    });
+    b.nblk = (int)b.blk_ij.size();
+    b.bp_start.assign(b.nblk + 1, 0);
+    for (int j = 0; j < b.nblk; j++) b.bp_start[j + 1] = b.bp_start[j] + cnt[j];
+    b.bp_pairs.resize(2 * (size_t)b.bp_start[b.nblk]);
+    { std::vector<int32_t> fill(b.bp_start.begin(), b.bp_start.end() - 1);
+      each_pair([&](int i1, int i2, int q1, int q2) { const int at = fill[blk_of[(size_t)i1 * nf + i2]]++; b.bp_pairs[2 * (size_t)at] = q1; b.bp_pairs[2 * (size_t)at + 1] = q2; }); }
+    b.n_hc = b.n_sc = 0;
+    b.stage_doubles = (kWinThreads / 64) * 4 * 36;       // the waves' reduction buffers
+    return DVM_OK;
+  }
   if (maxdeg > b.C) { set_error("dvm_ba_optimize_windows: a landmark with more free-camera observations than a streaming chunk holds (duplicate observations?)"); return DVM_ERR_CAPACITY; }
   // Hessian chunks: C2 consecutive edges; the free-camera ones among them listed per camera (ascending edge = the camera's own order)
   b.n_hc = nf ? (E + b.C2 - 1) / b.C2 : 0;
@@ -933,14 +1159,29 @@ struct StopWord {                      // a word of page-locked host memory the 
 
 }  // namespace
 
-int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input) {
+int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input, bool fast) {
   if (K < 0 || (K && !windows)) { set_error("dvm_ba_optimize_windows: null windows"); return DVM_ERR_INVALID; }
   if (K == 0) return DVM_OK;
   int rc = dvm_set_device(device);
   if (rc != DVM_OK) return rc;
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<WinBuild> B(K);
-  for (int k = 0; k < K; k++) if ((rc = build_window(windows[k], B[k], normalize_input)) != DVM_OK) return rc;
+  if (fast && K > 1) {
+    // the windows' index tables are independent: built by up to 16 host threads (0.2 ms each; 32 of them one after the other would cost
+    // more than the launch that solves them)
+    const int T = std::min(K, 16);
+    std::vector<int> rcs(K, DVM_OK);
+    std::vector<std::string> errs(K);
+    std::atomic<int> next{0};
+    auto work = [&] { for (;;) { const int k = next.fetch_add(1); if (k >= K) break; rcs[k] = build_window(windows[k], B[k], normalize_input, true); if (rcs[k] != DVM_OK) errs[k] = last_error_cstr(); } };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    for (int k = 0; k < K; k++) if (rcs[k] != DVM_OK) { set_error(errs[k]); return rcs[k]; }
+  } else {
+    for (int k = 0; k < K; k++) if ((rc = build_window(windows[k], B[k], normalize_input, fast)) != DVM_OK) return rc;
+  }
   const auto t1 = std::chrono::steady_clock::now();
   thread_local StopWord sw;
   if ((rc = sw.ensure()) != DVM_OK) return rc;
@@ -948,7 +1189,8 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
 
   Stage st;
   struct Slots { int poses, pts, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, lpos, fpos, pt_start, f_start, f_cam, hc_ints, sc_desc, sc_ints,
-                     blk_ij, out_poses, out_pts, echi, edepth, stats, poses_t, pts_t, rowB, rowA, rowW, erho, Hpp, bp, HB, DD, x, terms, prof; };
+                     blk_ij, out_poses, out_pts, echi, edepth, stats, poses_t, pts_t, rowB, rowA, rowW, erho, Hpp, bp, HB, DD, x, terms, prof,
+                     cam_start, cam_edges, cw_start, cw_rows, f_lm, bp_start, bp_pairs, rowT; };
   std::vector<Slots> sl(K);
   static const bool want_prof = std::getenv("DVM_BA_WINDOW_PROF") != nullptr;
   std::vector<std::vector<unsigned long long>> prof_out(K, std::vector<unsigned long long>(16, 0));
@@ -963,6 +1205,8 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     s.e_obs = F64(b.e_obs); s.e_info = F64(b.e_info);
     s.lpos = I32(b.lpos); s.fpos = I32(b.fpos); s.pt_start = I32(b.pt_start); s.f_start = I32(b.f_start); s.f_cam = I32(b.f_cam);
     s.hc_ints = I32(b.hc_ints); s.sc_desc = I32(b.sc_desc); s.sc_ints = I32(b.sc_ints); s.blk_ij = I32(b.blk_ij);
+    s.cam_start = I32(b.cam_start); s.cam_edges = I32(b.cam_edges); s.cw_start = I32(b.cw_start); s.cw_rows = I32(b.cw_rows); s.f_lm = I32(b.f_lm);
+    s.bp_start = I32(b.bp_start); s.bp_pairs = I32(b.bp_pairs);
   }
   std::vector<BaWin> views(K);
   const int views_slot = st.in(views.data(), sizeof(BaWin) * (size_t)K);   // filled in below, once layout() has placed everything
@@ -986,6 +1230,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     s.erho = st.scratch(8 * E);
     s.Hpp = st.scratch(288 * (size_t)b.nfree); s.bp = st.scratch(8 * n); s.HB = st.scratch(8 * kRowH * (size_t)b.nact); s.DD = st.scratch(8 * kRowH * (size_t)b.nact);
     s.x = st.scratch(8 * (n + nl)); s.terms = st.scratch(8 * (n + nl));
+    s.rowT = fast ? st.scratch(8 * kRowD * F) : -1;
   }
   if ((rc = st.layout()) != DVM_OK) return rc;
   size_t lds_doubles = 0;
@@ -1005,6 +1250,11 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     v.e_chi2 = st.ptr<double>(s.echi); v.e_rho = st.ptr<double>(s.erho); v.e_depth = st.ptr<uint8_t>(s.edepth);
     v.hc_ints = st.ptr<int32_t>(s.hc_ints); v.sc_desc = st.ptr<int32_t>(s.sc_desc); v.sc_ints = st.ptr<int32_t>(s.sc_ints);
     v.blk_ij = st.ptr<int32_t>(s.blk_ij);
+    if (fast) {
+      v.cam_start = st.ptr<int32_t>(s.cam_start); v.cam_edges = st.ptr<int32_t>(s.cam_edges); v.cw_start = st.ptr<int32_t>(s.cw_start);
+      v.cw_rows = st.ptr<int32_t>(s.cw_rows); v.f_lm = st.ptr<int32_t>(s.f_lm); v.bp_start = st.ptr<int32_t>(s.bp_start);
+      v.bp_pairs = reinterpret_cast<const int2*>(st.ptr<int32_t>(s.bp_pairs)); v.rowT = st.ptr<double>(s.rowT);
+    }
     v.Hpp = st.ptr<double>(s.Hpp); v.bp = st.ptr<double>(s.bp); v.HB = st.ptr<double>(s.HB); v.DD = st.ptr<double>(s.DD);
     v.x = st.ptr<double>(s.x); v.terms = st.ptr<double>(s.terms);
     v.stats = st.ptr<dvm_ba_stats>(s.stats);
@@ -1016,10 +1266,11 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   // dynamic LDS: the packed reduced system of the largest window, rhs / diagonal, control words and the streaming area
   const size_t lds_bytes = sizeof(double) * lds_doubles;
   if (lds_bytes > 160 * 1024) { set_error("dvm_ba_optimize_windows: a window needs more than 160 KB of LDS"); return DVM_ERR_CAPACITY; }
-  DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fast ? k_ba_window<true> : k_ba_window<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
   // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
-  hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
+  if (fast) hipLaunchKernelGGL(k_ba_window<true>, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
+  else hipLaunchKernelGGL(k_ba_window<false>, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
   if (stop_flag) {                     // g2o's forceStopFlag: written by another thread while the optimisation runs (LocalMapping.cc:305,359)
     hipEvent_t ev;
@@ -1053,7 +1304,10 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
 extern "C" {
 
 int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
-  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true);
+  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, false);
+}
+int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
+  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, true);
 }
 
 int dvm_f64_spec_eval(int device, const double* x, int n, double* out) {
