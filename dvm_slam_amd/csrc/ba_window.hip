@@ -48,6 +48,7 @@
 namespace dvm {
 
 constexpr int kWinThreads = 512;
+constexpr int kFastThreads = 512;        // (measured: 1 024 threads / 128 VGPRs is no faster -- the phases are bound by the CU's one 64 B/clk memory pipe, not by latency)
 constexpr int kWinMaxFree = 30;          // 6 * 30 = 180 rows: packed lower triangle 130 320 B of LDS
 constexpr int kRowB = 16, kRowA = 12, kRowW = 18, kRowD = 24, kRowH = 12;   // doubles per row of the per-edge / per-landmark arrays below
 constexpr int kWinIntCap = 6 * kWinThreads;   // ints of one chunk's index block (six per thread in flight)
@@ -87,13 +88,19 @@ struct BaWin {
   double *Hpp, *bp, *HB, *DD, *x, *terms;   // [nfree][36], [6 nfree], [nact][12] = Hll (9) bl (3), [nact][12] = Dinv (9) Dinv bl (3), [6 nfree + 3 nact] x 2
   dvm_ba_stats* stats;
   unsigned long long* prof;           // [16] shader-clock cycles per phase, accumulated by thread 0 (DVM_BA_WINDOW_PROF=1), or null
-  // ---- the FAST form only (k_ba_window<true>: tree sums in a fixed order instead of g2o's sequential ones, nothing streamed through LDS)
-  const int32_t *cam_start, *cam_edges;   // [nfree + 1], [edges of free cameras]: a camera's edges in edge order (rows of rowB)
-  const int32_t *cw_start, *cw_rows;      // [nfree + 1], [F]: a camera's rows of rowW / rowT, ascending
-  const int32_t *f_lm;                    // [F] active landmark of the row
+  // ---- the FAST form only (k_ba_window<true>: tree sums in a fixed order instead of g2o's sequential ones, nothing streamed through LDS).
+  // Its edges are SORTED camera-major on the host -- free cameras first, a camera's edges by landmark, the fixed cameras' edges behind
+  // them -- and the per-edge rows are structure-of-arrays with pitch Fp / Ep, so that a lane per edge reads and writes consecutive words.
+  // e_pose / e_point / e_obs / e_info above are in that order; the first F edges are the free cameras' (the rows of W / T / B).
+  int32_t Fp, Ep;                         // pitches: F and E rounded up to 64
+  const int32_t *e_orig;                  // [E] the edge's index in the caller's list (chi2 / depth go back there)
+  const int32_t *e_lm;                    // [E] active landmark of the edge
+  const int32_t *cam_start;               // [nfree + 1] a free camera's edges
+  const int32_t *pt_edges;                // [E] a landmark's edges (sorted indices, ascending: its free-camera rows come first), ranges pt_start
   const int32_t *bp_start;                // [nblk + 1] a block's (row of camera i1, row of camera i2) pairs, landmark order
   const int2* bp_pairs;
-  double* rowT;                           // [F][24] W Dinv (18) | W Dinv bl (6) of the trial
+  double *Bs, *Ws, *Ts, *Cs;              // [15][Fp] B (12) w wr0 wr1 | [18][Fp] W | [24][Fp] W Dinv (18), W Dinv bl (6) | [3][Fp] W^T x_p
+  double *chi_s;                          // [E] chi2 of the last evaluation, sorted order
 };
 
 // ------------------------------------------------------------------------------------------------ small algebra (the oracle's sequences)
@@ -605,32 +612,104 @@ __device__ __forceinline__ double w_wave_reduce(double (&acc)[N], double* __rest
   return r;
 }
 // sum of v[0..n) over the workgroup, the same value in every thread: strided partial sums, row sums, then the 32 row sums in index order
-__device__ double win_block_sum(const double* __restrict__ v, int n, double* __restrict__ red /* 32 doubles of LDS */) {
+__device__ double win_block_sum(const double* __restrict__ v, int n, double* __restrict__ red /* kFastThreads / 16 doubles of LDS */) {
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += kWinThreads) s += v[i];
+  for (int i = threadIdx.x; i < n; i += kFastThreads) s += v[i];
   s = w_row_sum(s);
   __syncthreads();
   if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4] = s;
   __syncthreads();
   double t = 0.0;
 #pragma unroll
-  for (int i = 0; i < kWinThreads / 16; i++) t += red[i];
+  for (int i = 0; i < kFastThreads / 16; i++) t += red[i];
   return t;
 }
-// Hpp / bp: a wave per free camera, its lanes stride the camera's edges (rows of rowB in edge order)
+// edge pass of the FAST form: a thread per edge of the camera-major order; every per-edge store is to consecutive words
+template <bool JAC>
+__device__ void win_edge_pass_fast(const BaWin& W, const double* __restrict__ poses, const double* __restrict__ pts) {
+  const size_t Fp = (size_t)W.Fp;
+  for (int k = threadIdx.x; k < W.E; k += kFastThreads) {
+    const int p = W.e_pose[k], l = W.e_point[k];
+    const double* T = poses + 7 * (size_t)p;
+    const double* X = pts + 3 * (size_t)l;
+    double R[9], Xc[3];
+    w_quat_to_R(T + 3, R);
+    w_mat3_vec(R, X, Xc);
+    Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
+    const double x = Xc[0], y = Xc[1], z = Xc[2];
+    const double info = W.e_info[k];
+    const double e0 = W.e_obs[2 * k] - (W.fx * x / z + W.cx);
+    const double e1 = W.e_obs[2 * k + 1] - (W.fy * y / z + W.cy);
+    const double chi2 = e0 * info * e0 + e1 * info * e1;
+    double r0, r1;
+    w_robustify(chi2, W.delta, r0, r1);
+    W.chi_s[k] = chi2;
+    W.e_rho[k] = r0;
+    if (!JAC) continue;
+    const double J[6] = {-(W.fx / z), 0, W.fx * x / (z * z), 0, -(W.fy / z), W.fy * y / (z * z)};
+    double A[6], B[12];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) A[3 * r + c] = J[3 * r] * R[c] + J[3 * r + 1] * R[3 + c] + J[3 * r + 2] * R[6 + c];
+    const double w = r1 * info;
+    const double wr0 = -info * e0 * r1, wr1 = -info * e1 * r1;
+    double2* oA = reinterpret_cast<double2*>(W.rowA + kRowA * (size_t)k);      // (96-byte rows, 16-byte stores)
+    oA[0] = make_double2(A[0], A[1]); oA[1] = make_double2(A[2], A[3]); oA[2] = make_double2(A[4], A[5]);
+    oA[3] = make_double2(w, wr0); oA[4] = make_double2(wr1, 0.0);
+    if (k < W.F) {
+      const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
+#pragma unroll
+      for (int i = 0; i < 12; i++) W.Bs[i * Fp + k] = B[i];
+      W.Bs[12 * Fp + k] = w; W.Bs[13 * Fp + k] = wr0; W.Bs[14 * Fp + k] = wr1;
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) W.Ws[(3 * a + b) * Fp + k] = w * (B[a] * A[b] + B[6 + a] * A[3 + b]);
+    }
+  }
+}
+// Hll / bl: a thread per landmark gathers its edges' A rows (sorted indices ascending: the order of the sums is fixed)
+__device__ void win_accumulate_landmarks_fast(const BaWin& W) {
+  for (int li = threadIdx.x; li < W.nact; li += kFastThreads) {
+    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
+      const double2* Ap = reinterpret_cast<const double2*>(W.rowA + kRowA * (size_t)W.pt_edges[q]);
+      const double2 a01 = Ap[0], a23 = Ap[1], a45 = Ap[2], ww = Ap[3], w1 = Ap[4];
+      const double A[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
+      const double w = ww.x, wr0 = ww.y, wr1 = w1.x;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        g[a] += A[a] * wr0 + A[3 + a] * wr1;
+#pragma unroll
+        for (int b = 0; b < 3; b++) h[3 * a + b] += w * (A[a] * A[b] + A[3 + a] * A[3 + b]);
+      }
+    }
+    double* o = W.HB + kRowH * (size_t)li;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[i] = h[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[9 + i] = g[i];
+  }
+}
+// Hpp / bp: a wave per free camera, its lanes stride the camera's edges (a contiguous range of the sorted order)
 __device__ void win_accumulate_cameras_fast(const BaWin& W, double* wred) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t Fp = (size_t)W.Fp;
   double* wbuf = wred + wave * 4 * 36;
-  for (int i = wave; i < W.nfree; i += kWinThreads / 64) {
+  for (int i = wave; i < W.nfree; i += kFastThreads / 64) {
     double acc[27];
 #pragma unroll
     for (int t = 0; t < 27; t++) acc[t] = 0.0;
     const int q1 = W.cam_start[i + 1];
     for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
-      const double* Bp = W.rowB + kRowB * (size_t)W.cam_edges[q];
       double B[15];
 #pragma unroll
-      for (int j = 0; j < 15; j++) B[j] = Bp[j];
+      for (int j = 0; j < 15; j++) B[j] = W.Bs[j * Fp + q];
       const double w = B[12], wr0 = B[13], wr1 = B[14];
       int t = 0;
 #pragma unroll
@@ -652,9 +731,12 @@ __device__ void win_accumulate_cameras_fast(const BaWin& W, double* wred) {
 // solve(lambda), first half, FAST form: S = Hpp + lambda I - sum_l W Dinv W^T, rhs = bp - sum_l W Dinv bl (block_solver.hpp:381-439)
 __device__ void win_schur_fast(const BaWin& W, double* S, double* rhs, double* wred, double lambda) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = 6 * W.nfree;
-  for (int i = tid; i < n * (n + 1) / 2; i += kWinThreads) S[i] = 0.0;
+  const size_t Fp = (size_t)W.Fp;
+  unsigned long long tp = __builtin_amdgcn_s_memtime();
+  auto lap2 = [&](int slot) { if (W.prof && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); W.prof[slot] += t - tp; tp = t; } };
+  for (int i = tid; i < n * (n + 1) / 2; i += kFastThreads) S[i] = 0.0;
   // Dinv, Dinv bl per landmark
-  for (int li = tid; li < W.nact; li += kWinThreads) {
+  for (int li = tid; li < W.nact; li += kFastThreads) {
     const double* h = W.HB + kRowH * (size_t)li;
     double D[9], Di[9], d3[3];
 #pragma unroll
@@ -670,56 +752,54 @@ __device__ void win_schur_fast(const BaWin& W, double* S, double* rhs, double* w
     for (int i = 0; i < 3; i++) o[9 + i] = d3[i];
   }
   __syncthreads();
-  for (int t = tid; t < 21 * W.nfree; t += kWinThreads) {
+  lap2(13);
+  for (int t = tid; t < 21 * W.nfree; t += kFastThreads) {
     const int i = t / 21, e = t - 21 * i;
     int a = 0, r = e; while (r > a) { r -= a + 1; a++; }
     const int b = r;
     S[tri(6 * i + a, 6 * i + b)] = W.Hpp[36 * (size_t)i + 6 * a + b] + (a == b ? lambda : 0.0);
   }
-  // W Dinv, W Dinv bl per free row
-  for (int r = tid; r < W.F; r += kWinThreads) {
-    const double* Wr = W.rowW + kRowW * (size_t)r;
-    const double* h = W.DD + kRowH * (size_t)W.f_lm[r];
+  // W Dinv, W Dinv bl: a lane per free row (consecutive words of W in, of T out; the landmark's 96 bytes gathered)
+  for (int r = tid; r < W.F; r += kFastThreads) {
+    const double2* hp = reinterpret_cast<const double2*>(W.DD + kRowH * (size_t)W.e_lm[r]);
     double w[18], d[12];
 #pragma unroll
-    for (int j = 0; j < 18; j++) w[j] = Wr[j];
+    for (int j = 0; j < 6; j++) { const double2 v = hp[j]; d[2 * j] = v.x; d[2 * j + 1] = v.y; }
 #pragma unroll
-    for (int j = 0; j < 12; j++) d[j] = h[j];
-    double* o = W.rowT + kRowD * (size_t)r;
+    for (int j = 0; j < 18; j++) w[j] = W.Ws[j * Fp + r];
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-      for (int b = 0; b < 3; b++) o[3 * a + b] = w[3 * a] * d[b] + w[3 * a + 1] * d[3 + b] + w[3 * a + 2] * d[6 + b];
-      o[18 + a] = w[3 * a] * d[9] + w[3 * a + 1] * d[10] + w[3 * a + 2] * d[11];
+      for (int b = 0; b < 3; b++) W.Ts[(3 * a + b) * Fp + r] = w[3 * a] * d[b] + w[3 * a + 1] * d[3 + b] + w[3 * a + 2] * d[6 + b];
+      W.Ts[(18 + a) * Fp + r] = w[3 * a] * d[9] + w[3 * a + 1] * d[10] + w[3 * a + 2] * d[11];
     }
   }
   __syncthreads();
+  lap2(14);
   double* wbuf = wred + wave * 4 * 36;
-  // the reduced right-hand side: a wave per camera over the camera's rows
-  for (int i = wave; i < W.nfree; i += kWinThreads / 64) {
+  // the reduced right-hand side: a wave per camera over the camera's rows (contiguous)
+  for (int i = wave; i < W.nfree; i += kFastThreads / 64) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    const int q1 = W.cw_start[i + 1];
-    for (int q = W.cw_start[i] + lane; q < q1; q += 64) {
-      const double* T = W.rowT + kRowD * (size_t)W.cw_rows[q] + 18;
+    const int q1 = W.cam_start[i + 1];
+    for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
 #pragma unroll
-      for (int a = 0; a < 6; a++) acc[a] += T[a];
+      for (int a = 0; a < 6; a++) acc[a] += W.Ts[(18 + a) * Fp + q];
     }
     const double tot = w_wave_reduce<6>(acc, wbuf);
     if (lane < 6) rhs[6 * i + lane] = W.bp[6 * (size_t)i + lane] - tot;
   }
-  // the blocks: a wave per block over the block's pairs
-  for (int bk = wave; bk < W.nblk; bk += kWinThreads / 64) {
+  lap2(3);
+  // the blocks: a wave per block, a lane per pair (rows of camera i1 / of camera i2: ascending inside the cameras' ranges)
+  for (int bk = wave; bk < W.nblk; bk += kFastThreads / 64) {
     double acc[36];
 #pragma unroll
     for (int t = 0; t < 36; t++) acc[t] = 0.0;
     const int q1 = W.bp_start[bk + 1];
     for (int q = W.bp_start[bk] + lane; q < q1; q += 64) {
       const int2 pr = W.bp_pairs[q];
-      const double* T1 = W.rowT + kRowD * (size_t)pr.x;
-      const double* W2 = W.rowW + kRowW * (size_t)pr.y;
       double t1[18], w2[18];
 #pragma unroll
-      for (int j = 0; j < 18; j++) { t1[j] = T1[j]; w2[j] = W2[j]; }
+      for (int j = 0; j < 18; j++) { t1[j] = W.Ts[j * Fp + pr.x]; w2[j] = W.Ws[j * Fp + pr.y]; }
 #pragma unroll
       for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -733,12 +813,42 @@ __device__ void win_schur_fast(const BaWin& W, double* S, double* rhs, double* w
     }
   }
   __syncthreads();
+  lap2(11);
+}
+// xl = Dinv (bl - W^T xp): a lane per free row forms W^T x_p of its camera (consecutive words), a thread per landmark adds its rows'
+__device__ void win_landmark_backsub_fast(const BaWin& W, const double* __restrict__ rhs /* x_p, LDS */, int n) {
+  const size_t Fp = (size_t)W.Fp;
+  for (int r = threadIdx.x; r < W.F; r += kFastThreads) {
+    const double* xp = rhs + 6 * W.f_cam[r];
+    double c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      const double xa = xp[a];
+      c0 += W.Ws[(3 * a) * Fp + r] * xa; c1 += W.Ws[(3 * a + 1) * Fp + r] * xa; c2 += W.Ws[(3 * a + 2) * Fp + r] * xa;
+    }
+    W.Cs[r] = c0; W.Cs[Fp + r] = c1; W.Cs[2 * Fp + r] = c2;
+  }
+  __syncthreads();
+  for (int li = threadIdx.x; li < W.nact; li += kFastThreads) {
+    const double* hb = W.HB + kRowH * (size_t)li;
+    double c0 = hb[9], c1 = hb[10], c2 = hb[11];
+    for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
+      const int r = W.pt_edges[q];
+      if (r >= W.F) break;                                   // (ascending: the fixed cameras' edges follow)
+      c0 -= W.Cs[r]; c1 -= W.Cs[Fp + r]; c2 -= W.Cs[2 * Fp + r];
+    }
+    const double c[3] = {c0, c1, c2};
+    double xl[3];
+    w_mat3_vec(W.DD + kRowH * (size_t)li, c, xl);
+    W.x[n + 3 * (size_t)li] = xl[0]; W.x[n + 3 * (size_t)li + 1] = xl[1]; W.x[n + 3 * (size_t)li + 2] = xl[2];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
 template <bool FAST>
-__global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop) {
+__global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop) {
   extern __shared__ double lds[];
+  constexpr int NT = FAST ? kFastThreads : kWinThreads;
   const BaWin& W = wins[blockIdx.x];
   const int tid = threadIdx.x, wave = tid >> 6;
   const int n = 6 * W.nfree, nl = 3 * W.nact;
@@ -756,10 +866,10 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
     st->ms_structure = st->ms_optimize = 0; st->spec_trials = st->spec_kept = 0;
   }
   // g2o's buildStructure reallocates _x: "the last successful solve" starts as zeros
-  for (int i = tid; i < n + nl; i += kWinThreads) W.x[i] = 0.0;
+  for (int i = tid; i < n + nl; i += NT) W.x[i] = 0.0;
   // the trial state starts as a copy (fixed cameras and unobserved landmarks never change)
-  for (int i = tid; i < 7 * W.P; i += kWinThreads) W.poses_t[i] = W.poses[i];
-  for (int i = tid; i < 3 * W.L; i += kWinThreads) W.pts_t[i] = W.pts[i];
+  for (int i = tid; i < 7 * W.P; i += NT) W.poses_t[i] = W.poses[i];
+  for (int i = tid; i < 3 * W.L; i += NT) W.pts_t[i] = W.pts[i];
   double* poses = W.poses; double* poses_t = W.poses_t; double* pts = W.pts; double* pts_t = W.pts_t;
   __syncthreads();
 
@@ -776,14 +886,14 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
     // computeActiveErrors + robust chi2 + buildSystem at the accepted state.  (From the second iteration on g2o recomputes the chi2
     // of the state the last accepted trial has just evaluated: same state, same sums, same bits -- only the Jacobians are new.)
     lap(15);
-    win_edge_pass<true>(W, poses, pts);
+    if constexpr (FAST) win_edge_pass_fast<true>(W, poses, pts); else win_edge_pass<true>(W, poses, pts);
     __syncthreads();
     lap(0);
     if (it == 0) {
-      if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 16); if (tid == 0) ctl[1] = c; }
+      if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 64); if (tid == 0) ctl[1] = c; }
       else if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
     }
-    win_accumulate_landmarks(W);
+    if constexpr (FAST) win_accumulate_landmarks_fast(W); else win_accumulate_landmarks(W);
     __syncthreads();
     lap(1);
     if constexpr (FAST) win_accumulate_cameras_fast(W, stage); else win_accumulate_cameras(W, stage);
@@ -794,14 +904,14 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
       if (tid == 0) st->chi2_initial = currentChi;
       // computeLambdaInit: tau * max |diagonal| over all active vertices (a maximum has no order)
       double mx = 0;
-      for (int i = tid; i < n; i += kWinThreads) mx = fmax(mx, fabs(W.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
-      for (int i = tid; i < nl; i += kWinThreads) mx = fmax(mx, fabs(W.HB[kRowH * (size_t)(i / 3) + 4 * (i % 3)]));
+      for (int i = tid; i < n; i += NT) mx = fmax(mx, fabs(W.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+      for (int i = tid; i < nl; i += NT) mx = fmax(mx, fabs(W.HB[kRowH * (size_t)(i / 3) + 4 * (i % 3)]));
       for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
       __syncthreads();
       if ((tid & 63) == 0) ctl[8 + wave] = mx;
       __syncthreads();
       mx = ctl[8];
-      for (int w2 = 1; w2 < kWinThreads / 64; w2++) mx = fmax(mx, ctl[8 + w2]);
+      for (int w2 = 1; w2 < NT / 64; w2++) mx = fmax(mx, ctl[8 + w2]);
       lambda = 1e-5 * mx;
       ni = 2; nBad = 0;
     }
@@ -816,47 +926,118 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
       lap(4);
       // ---- Cholesky: entry (i, j) receives its subtractions L(i, k) L(j, k) in ascending k, as the row-wise dot products of the
       // envelope factorisation apply them; L(i, j) = s / L(j, j) by IEEE division, L(j, j) = sqrt(s)
+      // Six columns (one camera) at a time -- two barriers per camera instead of two per column: every thread factorises the 6 x 6
+      // diagonal block for itself (the same 21 words, the same operations: the same bits in every thread), then its rows' six
+      // entries of the panel, column by column; the trailing entries then take the six columns' subtractions in ascending k.  Every
+      // entry sees the operations of the column-by-column form in the same order: identical bits.
       bool ok = true;
-      for (int k = 0; k < n; k++) {
-        const double d = S[tri(k, k)];
-        if (!(d > 0)) { ok = false; break; }             // uniform: every thread reads the same word
-        const double lkk = sqrt(d);
-        for (int i = k + 1 + tid; i < n; i += kWinThreads) S[tri(i, k)] = S[tri(i, k)] / lkk;
-        if (tid == 0) diag[k] = lkk;
+      for (int k0 = 0; k0 < n && ok; k0 += 6) {
+        double Ld[21], dg[6];            // the diagonal block's factor (lower, packed) and its L_kk
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+          for (int c = 0; c <= a; c++) {
+            double v = S[tri(k0 + a, k0 + c)];
+#pragma unroll
+            for (int k = 0; k < c; k++) v -= Ld[a * (a + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
+            if (a == c) {
+              if (!(v > 0)) ok = false;              // uniform: every thread computes the same word
+              dg[a] = sqrt(v);
+              Ld[a * (a + 1) / 2 + a] = v;
+            } else Ld[a * (a + 1) / 2 + c] = v / dg[c];
+          }
+        }
+        if (!ok) break;
+        __syncthreads();                 // (everybody has read the block before its owner overwrites it)
+        if (tid == 0) {
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            diag[k0 + a] = dg[a];
+#pragma unroll
+            for (int c = 0; c < a; c++) S[tri(k0 + a, k0 + c)] = Ld[a * (a + 1) / 2 + c];
+          }
+        }
+        for (int i = k0 + 6 + tid; i < n; i += NT) {
+          double* row = S + tri(i, k0);
+          double l[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            double v = row[c];
+#pragma unroll
+            for (int k = 0; k < c; k++) v -= l[k] * Ld[c * (c + 1) / 2 + k];
+            l[c] = v / dg[c];
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) row[c] = l[c];
+        }
         __syncthreads();
         const int tx = tid & 15, ty = tid >> 4;
-        for (int i = k + 1 + ty; i < n; i += kWinThreads / 16) {
-          const double lik = S[tri(i, k)];
-          for (int j = k + 1 + tx; j <= i; j += 16) S[tri(i, j)] -= lik * S[tri(j, k)];
+        for (int i = k0 + 6 + ty; i < n; i += NT / 16) {
+          const double* ri = S + tri(i, k0);
+          const double li0 = ri[0], li1 = ri[1], li2 = ri[2], li3 = ri[3], li4 = ri[4], li5 = ri[5];
+          for (int j = k0 + 6 + tx; j <= i; j += 16) {
+            const double* rj = S + tri(j, k0);
+            double v = S[tri(i, j)];
+            v -= li0 * rj[0]; v -= li1 * rj[1]; v -= li2 * rj[2]; v -= li3 * rj[3]; v -= li4 * rj[4]; v -= li5 * rj[5];
+            S[tri(i, j)] = v;
+          }
         }
         __syncthreads();
       }
       lap(5);
       if (ok) {
         // forward substitution: y(i) = (b(i) - sum_{j < i} L(i, j) y(j)) / L(i, i), the subtractions in ascending j; then backward:
-        // x(i) /= L(i, i); x(j) -= L(i, j) x(i) for j < i, i descending.  One wave, its lanes own rows lane, lane + 64, lane + 128.
+        // x(i) /= L(i, i); x(j) -= L(i, j) x(i) for j < i, i descending.  One wave, a camera's six unknowns per step: every lane forms the
+        // six values for itself, then applies them to its rows in the order of the one-at-a-time form.
         if (wave == 0) {
           const int lane = tid;
-          for (int i = 0; i < n; i++) {
+          for (int k0 = 0; k0 < n; k0 += 6) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double yi = rhs[i] / diag[i];
+            double y[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+              double v = rhs[k0 + a];
+#pragma unroll
+              for (int c = 0; c < a; c++) v -= S[tri(k0 + a, k0 + c)] * y[c];
+              y[a] = v / diag[k0 + a];
+            }
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) rhs[i] = yi;
-            for (int r = i + 1 + lane; r < n; r += 64) rhs[r] -= S[tri(r, i)] * yi;
+            if (lane < 6) { double yv = y[0]; yv = lane == 1 ? y[1] : yv; yv = lane == 2 ? y[2] : yv; yv = lane == 3 ? y[3] : yv; yv = lane == 4 ? y[4] : yv; yv = lane == 5 ? y[5] : yv; rhs[k0 + lane] = yv; }
+            for (int r = k0 + 6 + lane; r < n; r += 64) {
+              const double* rr = S + tri(r, k0);
+              double v = rhs[r];
+#pragma unroll
+              for (int a = 0; a < 6; a++) v -= rr[a] * y[a];
+              rhs[r] = v;
+            }
           }
-          for (int i = n - 1; i >= 0; i--) {
+          for (int k0 = n - 6; k0 >= 0; k0 -= 6) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double xi = rhs[i] / diag[i];
+            double x6[6];
+#pragma unroll
+            for (int a = 5; a >= 0; a--) {
+              double v = rhs[k0 + a];
+#pragma unroll
+              for (int c = 5; c > a; c--) v -= S[tri(k0 + c, k0 + a)] * x6[c];
+              x6[a] = v / diag[k0 + a];
+            }
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) rhs[i] = xi;
-            for (int j = lane; j < i; j += 64) rhs[j] -= S[tri(i, j)] * xi;
+            if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
+            for (int j = lane; j < k0; j += 64) {
+              double v = rhs[j];
+#pragma unroll
+              for (int a = 5; a >= 0; a--) v -= S[tri(k0 + a, j)] * x6[a];
+              rhs[j] = v;
+            }
           }
         }
         __syncthreads();
         lap(6);
-        for (int i = tid; i < n; i += kWinThreads) W.x[i] = rhs[i];
+        for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];
         // xl = Dinv (bl - W^T xp): per landmark, its free-camera rows in order, per row the six camera components in order
-        for (int li = tid; li < W.nact; li += kWinThreads) {
+        if constexpr (FAST) win_landmark_backsub_fast(W, rhs, n);
+        else
+        for (int li = tid; li < W.nact; li += NT) {
           const double* hb = W.HB + kRowH * (size_t)li;
           double c0 = hb[9], c1 = hb[10], c2 = hb[11];
           for (int q = W.f_start[li]; q < W.f_start[li + 1]; q++) {
@@ -878,24 +1059,24 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
       lap(7);
       // ---- the update is applied and the errors evaluated whether or not the solve succeeded (g2o: x then still holds the last
       // successful solve, optimization_algorithm_levenberg.cpp:107-127); computeScale's terms x_j (lambda x_j + b_j)
-      for (int i = tid; i < W.nfree; i += kWinThreads) {
+      for (int i = tid; i < W.nfree; i += NT) {
         const int p = W.free_pose[i];
         w_se3_oplus(poses + 7 * (size_t)p, W.x + 6 * (size_t)i, poses_t + 7 * (size_t)p);
       }
-      for (int t = tid; t < nl; t += kWinThreads) {
+      for (int t = tid; t < nl; t += NT) {
         const int l = W.act_pt[t / 3];
         pts_t[3 * (size_t)l + t % 3] = pts[3 * (size_t)l + t % 3] + W.x[n + t];
       }
-      for (int j = tid; j < n; j += kWinThreads) { const double xj = W.x[j]; W.terms[j] = xj * (lambda * xj + W.bp[j]); }
-      for (int j = tid; j < nl; j += kWinThreads) { const double xj = W.x[n + j]; W.terms[n + j] = xj * (lambda * xj + W.HB[kRowH * (size_t)(j / 3) + 9 + j % 3]); }
+      for (int j = tid; j < n; j += NT) { const double xj = W.x[j]; W.terms[j] = xj * (lambda * xj + W.bp[j]); }
+      for (int j = tid; j < nl; j += NT) { const double xj = W.x[n + j]; W.terms[n + j] = xj * (lambda * xj + W.HB[kRowH * (size_t)(j / 3) + 9 + j % 3]); }
       __syncthreads();
       lap(8);
-      win_edge_pass<false>(W, poses_t, pts_t);
+      if constexpr (FAST) win_edge_pass_fast<false>(W, poses_t, pts_t); else win_edge_pass<false>(W, poses_t, pts_t);
       __syncthreads();
       lap(9);
       if constexpr (FAST) {
-        const double c = win_block_sum(W.e_rho, W.E, ctl + 16);
-        const double c2 = win_block_sum(W.terms, n + nl, ctl + 16);
+        const double c = win_block_sum(W.e_rho, W.E, ctl + 64);
+        const double c2 = win_block_sum(W.terms, n + nl, ctl + 64);
         if (tid == 0) { ctl[1] = c; ctl[2] = c2; }
       } else {
         if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
@@ -940,22 +1121,26 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
   // caller downloads them (Optimizer_shim's LocalBundleAdjustment erases observations on chi2 > 5.991).  Evaluate the edges at the
   // unchanged input state, so that what leaves is the chi2 OF the state that leaves -- never the previous tenant of the buffer.
   if (it_done == 0) {
-    win_edge_pass<false>(W, poses, pts);
+    if constexpr (FAST) win_edge_pass_fast<false>(W, poses, pts); else win_edge_pass<false>(W, poses, pts);
     __syncthreads();
-    if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 16); chi_last = c; if (tid == 0) st->chi2_initial = c; }   // (every thread holds c)
+    if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 64); chi_last = c; if (tid == 0) st->chi2_initial = c; }   // (every thread holds c)
     else if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) { st->chi2_initial = c; chi_last = c; } }
     __syncthreads();
   }
   // results: the accepted state (the buffers may have been swapped any number of times), depth signs at that state
-  for (int i = tid; i < 7 * W.P; i += kWinThreads) W.out_poses[i] = poses[i];
-  for (int i = tid; i < 3 * W.L; i += kWinThreads) W.out_pts[i] = pts[i];
-  for (int k = tid; k < W.E; k += kWinThreads) {
+  for (int i = tid; i < 7 * W.P; i += NT) W.out_poses[i] = poses[i];
+  for (int i = tid; i < 3 * W.L; i += NT) W.out_pts[i] = pts[i];
+  for (int k = tid; k < W.E; k += NT) {
     const double* T = poses + 7 * (size_t)W.e_pose[k];
     const double* X = pts + 3 * (size_t)W.e_point[k];
     double R[9], Xc[3];
     w_quat_to_R(T + 3, R);
     w_mat3_vec(R, X, Xc);
-    W.e_depth[k] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
+    if constexpr (FAST) {     // back to the caller's edge order
+      const int ko = W.e_orig[k];
+      W.e_depth[ko] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
+      W.e_chi2[ko] = W.chi_s[k];
+    } else W.e_depth[k] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
   }
   if (tid == 0) {
     st->iterations = it_done; st->total_trials = trials_total; st->chi2_final = chi_last; st->lambda_final = lambda; st->stop_reason = stop_reason;
@@ -983,9 +1168,81 @@ struct WinBuild {
   std::vector<int32_t> pidx, lidx, free_pose, act_pt, e_pose, e_point, lpos, fpos, pt_start, f_start, f_cam;
   std::vector<int32_t> hc_ints, sc_desc, sc_ints, blk_ij;
   std::vector<double> e_obs, e_info;
-  // the FAST form's tables
-  std::vector<int32_t> cam_start, cam_edges, cw_start, cw_rows, f_lm, bp_start, bp_pairs;   // bp_pairs: (row1, row2) interleaved
+  // the FAST form's tables (the e_* arrays above are then in the camera-major order)
+  int Fp = 0, Ep = 0;
+  std::vector<int32_t> e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs;   // bp_pairs: (row1, row2) interleaved
 };
+
+// The FAST form's structure: edges sorted camera-major (free cameras in free-index order, a camera's edges by landmark, then the fixed
+// cameras' edges), per landmark its edges in that order, per block of the reduced system its (row, row) pairs in landmark order
+// (block_solver.hpp:381-439: edge k1 (outer) x edge k2 (inner), lower blocks; (k1, k1) on the diagonal).
+int build_window_fast(WinBuild& b) {
+  const int E = b.E, nf = b.nfree, P = b.P;
+  // rank of an edge's camera: free index, or nf + pose for a fixed camera; two stable counting sorts: by landmark, then by rank
+  std::vector<int32_t> by_lm(E), order(E);
+  {
+    std::vector<int32_t> cnt(b.nact + 1, 0);
+    for (int k = 0; k < E; k++) cnt[b.lidx[b.e_point[k]] + 1]++;
+    for (int i = 0; i < b.nact; i++) cnt[i + 1] += cnt[i];
+    for (int k = 0; k < E; k++) by_lm[cnt[b.lidx[b.e_point[k]]]++] = k;
+    std::vector<int32_t> cr(nf + P + 1, 0);
+    auto rank = [&](int k) { const int i = b.pidx[b.e_pose[k]]; return i >= 0 ? i : nf + b.e_pose[k]; };
+    for (int k = 0; k < E; k++) cr[rank(k) + 1]++;
+    for (int i = 0; i < nf + P; i++) cr[i + 1] += cr[i];
+    b.cam_start.assign(cr.begin(), cr.begin() + nf + 1);
+    for (int j = 0; j < E; j++) { const int k = by_lm[j]; order[cr[rank(k)]++] = k; }
+  }
+  b.F = nf ? b.cam_start[nf] : 0;
+  b.Fp = (b.F + 63) & ~63; b.Ep = (E + 63) & ~63;
+  std::vector<int32_t> ep(E), ept(E);
+  std::vector<double> eo(2 * (size_t)E), ei(E);
+  b.e_orig = order; b.e_lm.resize(E);
+  for (int j = 0; j < E; j++) {
+    const int k = order[j];
+    ep[j] = b.e_pose[k]; ept[j] = b.e_point[k]; eo[2 * (size_t)j] = b.e_obs[2 * (size_t)k]; eo[2 * (size_t)j + 1] = b.e_obs[2 * (size_t)k + 1]; ei[j] = b.e_info[k];
+    b.e_lm[j] = b.lidx[ept[j]];
+  }
+  b.e_pose.swap(ep); b.e_point.swap(ept); b.e_obs.swap(eo); b.e_info.swap(ei);
+  b.f_cam.resize(b.F);
+  for (int i = 0; i < nf; i++) for (int j = b.cam_start[i]; j < b.cam_start[i + 1]; j++) b.f_cam[j] = i;
+  // a landmark's edges, ascending sorted index (its free rows first)
+  b.pt_start.assign(b.nact + 1, 0);
+  for (int j = 0; j < E; j++) b.pt_start[b.e_lm[j] + 1]++;
+  for (int i = 0; i < b.nact; i++) b.pt_start[i + 1] += b.pt_start[i];
+  b.pt_edges.resize(E);
+  { std::vector<int32_t> fill(b.pt_start.begin(), b.pt_start.end() - 1);
+    for (int j = 0; j < E; j++) b.pt_edges[fill[b.e_lm[j]]++] = j; }
+  // blocks and their pairs.  Within a landmark the free rows ascend with the camera: (q1, q2) with camera(q2) <= camera(q1) is q2 <= q1,
+  // minus the off-diagonal pairs of two observations by the SAME camera (as the sequential-order form leaves them out)
+  std::vector<int32_t> blk_of((size_t)nf * nf, -1), cnt;
+  auto each_pair = [&](auto&& fn) {
+    for (int li = 0; li < b.nact; li++) {
+      const int q0 = b.pt_start[li];
+      int qe = q0;
+      while (qe < b.pt_start[li + 1] && b.pt_edges[qe] < b.F) qe++;
+      for (int a1 = q0; a1 < qe; a1++)
+        for (int a2 = q0; a2 <= a1; a2++) {
+          const int r1 = b.pt_edges[a1], r2 = b.pt_edges[a2], i1 = b.f_cam[r1], i2 = b.f_cam[r2];
+          if (i1 == i2 && r1 != r2) continue;
+          fn(i1, i2, r1, r2);
+        }
+    }
+  };
+  each_pair([&](int i1, int i2, int, int) {
+    int32_t& id = blk_of[(size_t)i1 * nf + i2];
+    if (id < 0) { id = (int32_t)b.blk_ij.size(); b.blk_ij.push_back(i1 | (i2 << 8)); cnt.push_back(0); }
+    cnt[id]++;
+  });
+  b.nblk = (int)b.blk_ij.size();
+  b.bp_start.assign(b.nblk + 1, 0);
+  for (int j = 0; j < b.nblk; j++) b.bp_start[j + 1] = b.bp_start[j] + cnt[j];
+  b.bp_pairs.resize(2 * (size_t)b.bp_start[b.nblk]);
+  { std::vector<int32_t> fill(b.bp_start.begin(), b.bp_start.end() - 1);
+    each_pair([&](int i1, int i2, int r1, int r2) { const int at = fill[blk_of[(size_t)i1 * nf + i2]]++; b.bp_pairs[2 * (size_t)at] = r1; b.bp_pairs[2 * (size_t)at + 1] = r2; }); }
+  b.n_hc = b.n_sc = 0;
+  b.stage_doubles = (kFastThreads / 64) * 4 * 36;      // the waves' reduction buffers
+  return DVM_OK;
+}
 
 int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize, bool fast = false) {
   const int P = w.n_poses, L = w.n_points, E = w.n_edges;
@@ -1011,6 +1268,7 @@ int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize, bool fast 
   for (int l = 0; l < L; l++) if (pt_used[l]) { b.lidx[l] = b.nact++; b.act_pt.push_back(l); }
   if (b.nfree > kWinMaxFree) { set_error("dvm_ba_optimize_windows: more than 30 free cameras in one window (use dvm_ba_optimize)"); return DVM_ERR_CAPACITY; }
   if (b.nfree > 24) { b.C = 32; b.C2 = 64; }              // the packed reduced system takes up to 130 KB of the 160: smaller streaming chunks (else 128 / 256)
+  if (fast) return build_window_fast(b);
   const int nf = b.nfree;
   // landmark-major order of the edges (a landmark's edges in input order): rowA's order; its free-camera subsequence: rowW's order
   b.pt_start.assign(b.nact + 1, 0);
@@ -1035,46 +1293,6 @@ int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize, bool fast 
     maxdeg = std::max(maxdeg, b.f_start[li + 1] - b.f_start[li]);
   }
   b.F = (int)f_edge.size();
-  if (fast) {
-    // nothing is streamed in chunks: per camera its edges (edge order) and its rows of rowW, per row its landmark, per block of the
-    // reduced system its (row, row) pairs in landmark order (block_solver.hpp:381-439: edge k1 (outer) x edge k2 (inner), lower blocks)
-    b.cam_start.assign(nf + 1, 0); b.cw_start.assign(nf + 1, 0);
-    for (int k = 0; k < E; k++) { const int i = b.pidx[b.e_pose[k]]; if (i >= 0) b.cam_start[i + 1]++; }
-    for (int i = 0; i < nf; i++) b.cam_start[i + 1] += b.cam_start[i];
-    b.cam_edges.resize(b.cam_start[nf]);
-    { std::vector<int32_t> fill(b.cam_start.begin(), b.cam_start.end() - 1);
-      for (int k = 0; k < E; k++) { const int i = b.pidx[b.e_pose[k]]; if (i >= 0) b.cam_edges[fill[i]++] = k; } }
-    for (int r = 0; r < b.F; r++) b.cw_start[b.f_cam[r] + 1]++;
-    for (int i = 0; i < nf; i++) b.cw_start[i + 1] += b.cw_start[i];
-    b.cw_rows.resize(b.F); b.f_lm.resize(b.F);
-    { std::vector<int32_t> fill(b.cw_start.begin(), b.cw_start.end() - 1);
-      for (int r = 0; r < b.F; r++) b.cw_rows[fill[b.f_cam[r]]++] = r; }
-    for (int li = 0; li < b.nact; li++) for (int r = b.f_start[li]; r < b.f_start[li + 1]; r++) b.f_lm[r] = li;
-    std::vector<int32_t> blk_of((size_t)nf * nf, -1), cnt;
-    auto each_pair = [&](auto&& fn) {
-      for (int li = 0; li < b.nact; li++)
-        for (int q1 = b.f_start[li]; q1 < b.f_start[li + 1]; q1++)
-          for (int q2 = b.f_start[li]; q2 < b.f_start[li + 1]; q2++) {
-            const int i1 = b.f_cam[q1], i2 = b.f_cam[q2];
-            if (i2 > i1 || (i2 == i1 && q2 != q1)) continue;
-            fn(i1, i2, q1, q2);
-          }
-    };
-    each_pair([&](int i1, int i2, int, int) {
-      int32_t& id = blk_of[(size_t)i1 * nf + i2];
-      if (id < 0) { id = (int32_t)b.blk_ij.size(); b.blk_ij.push_back(i1 | (i2 << 8)); cnt.push_back(0); }
-      cnt[id]++;
-    });
-    b.nblk = (int)b.blk_ij.size();
-    b.bp_start.assign(b.nblk + 1, 0);
-    for (int j = 0; j < b.nblk; j++) b.bp_start[j + 1] = b.bp_start[j] + cnt[j];
-    b.bp_pairs.resize(2 * (size_t)b.bp_start[b.nblk]);
-    { std::vector<int32_t> fill(b.bp_start.begin(), b.bp_start.end() - 1);
-      each_pair([&](int i1, int i2, int q1, int q2) { const int at = fill[blk_of[(size_t)i1 * nf + i2]]++; b.bp_pairs[2 * (size_t)at] = q1; b.bp_pairs[2 * (size_t)at + 1] = q2; }); }
-    b.n_hc = b.n_sc = 0;
-    b.stage_doubles = (kWinThreads / 64) * 4 * 36;       // the waves' reduction buffers
-    return DVM_OK;
-  }
   if (maxdeg > b.C) { set_error("dvm_ba_optimize_windows: a landmark with more free-camera observations than a streaming chunk holds (duplicate observations?)"); return DVM_ERR_CAPACITY; }
   // Hessian chunks: C2 consecutive edges; the free-camera ones among them listed per camera (ascending edge = the camera's own order)
   b.n_hc = nf ? (E + b.C2 - 1) / b.C2 : 0;
@@ -1190,7 +1408,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   Stage st;
   struct Slots { int poses, pts, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, lpos, fpos, pt_start, f_start, f_cam, hc_ints, sc_desc, sc_ints,
                      blk_ij, out_poses, out_pts, echi, edepth, stats, poses_t, pts_t, rowB, rowA, rowW, erho, Hpp, bp, HB, DD, x, terms, prof,
-                     cam_start, cam_edges, cw_start, cw_rows, f_lm, bp_start, bp_pairs, rowT; };
+                     e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs, Bs, Ws, Ts, Cs, chi_s; };
   std::vector<Slots> sl(K);
   static const bool want_prof = std::getenv("DVM_BA_WINDOW_PROF") != nullptr;
   std::vector<std::vector<unsigned long long>> prof_out(K, std::vector<unsigned long long>(16, 0));
@@ -1205,7 +1423,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     s.e_obs = F64(b.e_obs); s.e_info = F64(b.e_info);
     s.lpos = I32(b.lpos); s.fpos = I32(b.fpos); s.pt_start = I32(b.pt_start); s.f_start = I32(b.f_start); s.f_cam = I32(b.f_cam);
     s.hc_ints = I32(b.hc_ints); s.sc_desc = I32(b.sc_desc); s.sc_ints = I32(b.sc_ints); s.blk_ij = I32(b.blk_ij);
-    s.cam_start = I32(b.cam_start); s.cam_edges = I32(b.cam_edges); s.cw_start = I32(b.cw_start); s.cw_rows = I32(b.cw_rows); s.f_lm = I32(b.f_lm);
+    s.e_orig = I32(b.e_orig); s.e_lm = I32(b.e_lm); s.cam_start = I32(b.cam_start); s.pt_edges = I32(b.pt_edges);
     s.bp_start = I32(b.bp_start); s.bp_pairs = I32(b.bp_pairs);
   }
   std::vector<BaWin> views(K);
@@ -1226,11 +1444,14 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     const WinBuild& b = B[k]; Slots& s = sl[k];
     const size_t E = b.E, F = b.F, n = 6 * (size_t)b.nfree, nl = 3 * (size_t)b.nact;
     s.poses_t = st.scratch(56 * (size_t)b.P); s.pts_t = st.scratch(24 * (size_t)b.L);
-    s.rowB = st.scratch(8 * kRowB * E); s.rowA = st.scratch(8 * kRowA * E); s.rowW = st.scratch(8 * kRowW * F);
+    s.rowB = fast ? -1 : st.scratch(8 * kRowB * E); s.rowA = st.scratch(8 * kRowA * E); s.rowW = fast ? -1 : st.scratch(8 * kRowW * F);
     s.erho = st.scratch(8 * E);
     s.Hpp = st.scratch(288 * (size_t)b.nfree); s.bp = st.scratch(8 * n); s.HB = st.scratch(8 * kRowH * (size_t)b.nact); s.DD = st.scratch(8 * kRowH * (size_t)b.nact);
     s.x = st.scratch(8 * (n + nl)); s.terms = st.scratch(8 * (n + nl));
-    s.rowT = fast ? st.scratch(8 * kRowD * F) : -1;
+    if (fast) {
+      const size_t Fp = (size_t)b.Fp;
+      s.Bs = st.scratch(8 * 15 * Fp); s.Ws = st.scratch(8 * 18 * Fp); s.Ts = st.scratch(8 * 24 * Fp); s.Cs = st.scratch(8 * 3 * Fp); s.chi_s = st.scratch(8 * E);
+    }
   }
   if ((rc = st.layout()) != DVM_OK) return rc;
   size_t lds_doubles = 0;
@@ -1246,14 +1467,15 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     v.e_pose = st.ptr<int32_t>(s.e_pose); v.e_point = st.ptr<int32_t>(s.e_point); v.e_obs = st.ptr<double>(s.e_obs); v.e_info = st.ptr<double>(s.e_info);
     v.lpos = st.ptr<int32_t>(s.lpos); v.fpos = st.ptr<int32_t>(s.fpos); v.pt_start = st.ptr<int32_t>(s.pt_start); v.f_start = st.ptr<int32_t>(s.f_start);
     v.f_cam = st.ptr<int32_t>(s.f_cam);
-    v.rowB = st.ptr<double>(s.rowB); v.rowA = st.ptr<double>(s.rowA); v.rowW = st.ptr<double>(s.rowW);
+    v.rowB = fast ? nullptr : st.ptr<double>(s.rowB); v.rowA = st.ptr<double>(s.rowA); v.rowW = fast ? nullptr : st.ptr<double>(s.rowW);
     v.e_chi2 = st.ptr<double>(s.echi); v.e_rho = st.ptr<double>(s.erho); v.e_depth = st.ptr<uint8_t>(s.edepth);
     v.hc_ints = st.ptr<int32_t>(s.hc_ints); v.sc_desc = st.ptr<int32_t>(s.sc_desc); v.sc_ints = st.ptr<int32_t>(s.sc_ints);
     v.blk_ij = st.ptr<int32_t>(s.blk_ij);
     if (fast) {
-      v.cam_start = st.ptr<int32_t>(s.cam_start); v.cam_edges = st.ptr<int32_t>(s.cam_edges); v.cw_start = st.ptr<int32_t>(s.cw_start);
-      v.cw_rows = st.ptr<int32_t>(s.cw_rows); v.f_lm = st.ptr<int32_t>(s.f_lm); v.bp_start = st.ptr<int32_t>(s.bp_start);
-      v.bp_pairs = reinterpret_cast<const int2*>(st.ptr<int32_t>(s.bp_pairs)); v.rowT = st.ptr<double>(s.rowT);
+      v.Fp = b.Fp; v.Ep = b.Ep;
+      v.e_orig = st.ptr<int32_t>(s.e_orig); v.e_lm = st.ptr<int32_t>(s.e_lm); v.cam_start = st.ptr<int32_t>(s.cam_start); v.pt_edges = st.ptr<int32_t>(s.pt_edges);
+      v.bp_start = st.ptr<int32_t>(s.bp_start); v.bp_pairs = reinterpret_cast<const int2*>(st.ptr<int32_t>(s.bp_pairs));
+      v.Bs = st.ptr<double>(s.Bs); v.Ws = st.ptr<double>(s.Ws); v.Ts = st.ptr<double>(s.Ts); v.Cs = st.ptr<double>(s.Cs); v.chi_s = st.ptr<double>(s.chi_s);
     }
     v.Hpp = st.ptr<double>(s.Hpp); v.bp = st.ptr<double>(s.bp); v.HB = st.ptr<double>(s.HB); v.DD = st.ptr<double>(s.DD);
     v.x = st.ptr<double>(s.x); v.terms = st.ptr<double>(s.terms);
@@ -1269,7 +1491,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fast ? k_ba_window<true> : k_ba_window<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
   // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
-  if (fast) hipLaunchKernelGGL(k_ba_window<true>, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
+  if (fast) hipLaunchKernelGGL(k_ba_window<true>, dim3(K), dim3(kFastThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   else hipLaunchKernelGGL(k_ba_window<false>, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
   if (stop_flag) {                     // g2o's forceStopFlag: written by another thread while the optimisation runs (LocalMapping.cc:305,359)
