@@ -173,7 +173,7 @@ def pcie_inclusive_leg(capi, frames, B, steps, device):
             "note": "input in pinned host memory (dvm_orb_staging), 2 handles ping-pong: H2D of one batch under the kernels of the other"}
 
 
-LEG_KEYS = ("batch_sweep", "low_texture", "latency", "online_agents", "lba", "lba_batch", "merge", "ba_cold")
+LEG_KEYS = ("batch_sweep", "low_texture", "latency", "online_agents", "lba", "lba_batch", "lba_fast", "merge", "ba_cold")
 
 
 def pick(d, *keys):
@@ -253,6 +253,10 @@ def compact(out):
     try:
         cl["lba_window_call"] = round(out["lba"]["end_to_end_call"]["median_ms"], 4)
         cl["lba_window_iterations_per_s"] = round(out["lba"]["value"], 1)
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        cl["lba_32_windows_one_launch_iterations_per_s"] = round(out["lba_fast"]["value"], 1)
     except Exception:   # noqa: BLE001
         pass
     try:
@@ -644,7 +648,8 @@ def main():
             import bench_legs
             for name, fn in (("latency", lambda: bench_legs.latency(capi, frames[:64], local, calls=200, cpu_calls=0)),
                              ("lba", lambda: bench_legs.lba(local, repeats=12, cpu_seconds=0.0)),
-                             ("merge", lambda: bench_legs.merge(local, reps=8, cpu_reps=0))):
+                             ("merge", lambda: bench_legs.merge(local, reps=8, cpu_reps=0)),
+                             ("lba_fast", lambda: bench_legs.lba_fast(local))):
                 if name in out and "error" not in out[name]:
                     continue
                 try:

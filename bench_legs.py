@@ -501,6 +501,30 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
     return out
 
 
+def lba_fast(device, K=32, iters=10, repeats=4):
+    """K LocalBundleAdjustment windows (30 keyframes / 20 free / 3 000 landmarks / ~15 000 observations each, different maps) by ONE launch of
+    dvm_ba_optimize_windows_fast (LM control on the device, a workgroup per window): the short form of lba_batch's `fast_windows` for the
+    default run's contract line.  Reference: Optimizer.cc:1030-1387 per window, LocalMapping.cc:172."""
+    from dvm_slam_amd import capi, synth
+    delta = float(np.sqrt(np.float32(5.991)))
+    wins = []
+    for a in range(K):
+        pr = synth.ba_problem(n_kf=30, n_pts=3000, k_obs=5, seed=0x1BA + a, radius=12.0)
+        pr["fixed"][:10] = 1
+        wins.append(dict(poses=pr["poses"], fixed=pr["fixed"], points=pr["points"], edges=capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"]),
+                         intrinsics=pr["intrinsics"], huber_delta=delta, iterations=iters))
+    capi.ba_optimize_windows(wins, device, fast=True)
+    ts, its, res = [], 0, None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        res = capi.ba_optimize_windows(wins, device, fast=True)
+        ts.append(time.perf_counter() - t0)
+        its = sum(r["stats"]["iterations"] for r in res)
+    best = float(np.median(ts))
+    return {"value": its / best, "unit": "LM iterations/s summed over the K windows of a call (host arrays in, results out)", "K": K, "ms_per_call": best * 1e3,
+            "iterations": its, "call": "dvm_ba_optimize_windows_fast", "ms_upload_launch_download": res[0]["stats"]["ms_optimize"]}
+
+
 def ba_cold(device, iters=10, runs=5, idle_s=2.0):
     """The 500-keyframe global BA on a GPU that has been idle: the clocks have dropped, the first kernels pay the ramp."""
     from dvm_slam_amd import capi, synth
