@@ -279,7 +279,7 @@ def emit(out, a):
     except OSError as ex:
         print(f"bench.py: full record not written ({ex})", file=sys.stderr)
     for k in LEG_KEYS:
-        if k in out:
+        if k in out and a.legs:       # (the default run's short config legs live in the full record and in `config_legs` of the line)
             print(json.dumps({"leg": k, "record": out[k]}), flush=True)
     line = json.dumps(compact(out))
     print(line, flush=True)

@@ -51,9 +51,13 @@ def test_bench_contract_and_lane_equivalence(tmp_path):
     assert ba["value"] > 0 and ba["dtype"] == "f64" and 0 < ba["roofline"]["frac"] < 1 and ba["cpu_baseline"]["value"] > 0
     assert ba["parity_vs_cpu"]["trials_equal"] and ba["parity_vs_cpu"]["max_abs_pose"] < 1e-6
     assert ba["loop_closed"]["value"] > 0, ba["loop_closed"]
+    # configs 2 / 3 ride along as per-call figures (the short legs of the default run)
+    cl = d2["config_legs"]
+    for k in ("extract", "search_by_projection", "pose_optimization", "track_frame_one_chain", "lba_window_call", "lba_32_windows_one_launch_iterations_per_s", "merge_chain"):
+        assert cl[k] > 0, (k, cl)
     # the complete record keeps what the line drops
     assert full["value"] == d2["value"] and "gpu_kernel_event_ms_per_launch" in full["roofline"] and "schedule" in full["ba"]["roofline"]
-    d1, _ = _run("--cpu-seconds", "0", "--lanes", "1", "--no-pcie", "--no-ba", tmp=tmp_path)
+    d1, _ = _run("--cpu-seconds", "0", "--lanes", "1", "--no-pcie", "--no-ba", "--no-config-legs", tmp=tmp_path)
     assert d1["config"]["pipeline_lanes"] == 1
     assert d1["sanity_matches_le_TH_HIGH_last_step"] == d2["sanity_matches_le_TH_HIGH_last_step"] > 1000
 
