@@ -21,7 +21,7 @@ keep = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Siz
 keep = [k for k in keep if rows and k in rows[0]]
 w = csv.DictWriter(open(sys.argv[2], "w"), keep); w.writeheader()
 for r in rows: w.writerow({k: r[k] for k in keep})'
-BENCH="python $R/bench.py --steps 3 --warmup 1 --chunks-per-step 8 --no-ba --no-pcie --no-exclusive --no-legs --cpu-seconds 0"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --chunks-per-step 8 --no-ba --no-pcie --no-exclusive --no-legs --no-config-legs --cpu-seconds 0"
 rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- $BENCH > $O/a_bench.log 2>&1
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/r06_a_extract_kernel_stats.csv
 rm -rf /tmp/p2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python $R/tools/ba_only.py > $O/b_ba.log 2>&1
@@ -34,7 +34,7 @@ cp $(find /tmp/p2c -name "*kernel_stats.csv" | head -1) $O/r06_b3_ba_loop_closed
 rm -rf /tmp/p2d && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2d -- python $R/tools/ba_dense_regime.py > $O/b4_ba_dense.log 2>&1
 cp $(find /tmp/p2d -name "*kernel_stats.csv" | head -1) $O/r06_b4_ba_dense_2000kf_kernel_stats.csv
 grep '^{"keyframes"' $O/b4_ba_dense.log > $O/r06_b4_ba_dense_2000kf.json
-SHORT="python $R/bench.py --steps 1 --warmup 1 --chunks-per-step 2 --no-ba --no-pcie --no-exclusive --no-legs --cpu-seconds 0"
+SHORT="python $R/bench.py --steps 1 --warmup 1 --chunks-per-step 2 --no-ba --no-pcie --no-exclusive --no-legs --no-config-legs --cpu-seconds 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p3 && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p3 -- $SHORT > $O/pmc_$C.log 2>&1
   python -c "$FOLD" "$(find /tmp/p3 -name '*counter_collection.csv' | head -1)" $O/r06_pmc_$C.csv
