@@ -500,13 +500,26 @@ def main():
             ach = BYTES_PER_FRAME_FAST * frames_per_launch / per_launch_s / 1e9
             traffic = None
             pmc, pmc_file = None, None
-            for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
+            for cand in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # the newest committed rocprofv3 PMC fold
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                     pmc_file = cand
                     break
                 except Exception:
                     pmc = None
+            try:   # FAST is two launches per launch group since round 6 (k_fast_cells1: one wave per cell; k_fast_cells: the taller cells): one entry
+                k1, k0 = pmc["kernels"].get("dvm::k_fast_cells1"), pmc["kernels"].get("dvm::k_fast_cells")
+                if k1 and k0:
+                    m = dict(k0)
+                    for f in ("hbm_bytes_per_launch", "hbm_bytes_per_launch_raw", "valu_wave_instr_per_launch", "profiled_duration_us"):
+                        if f in k0 and f in k1:
+                            m[f] = k0[f] + k1[f]
+                    for f, w in (("valu_busy_frac_counter", "profiled_duration_us"), ("mean_issue_cycles_per_valu_instr", "valu_wave_instr_per_launch")):
+                        if f in k0 and f in k1 and w in k0 and w in k1:
+                            m[f] = (k0[f] * k0[w] + k1[f] * k1[w]) / (k0[w] + k1[w])
+                    pmc["kernels"]["dvm::k_fast_cells"] = m
+            except Exception:   # noqa: BLE001
+                pass
             try:  # HBM bytes per launch from the committed PMC passes (same launch-group size only)
                 if pmc["batch"] == frames_per_launch:
                     traffic = pmc["kernels"]["dvm::k_fast_cells"]["hbm_bytes_per_launch"]
@@ -571,7 +584,7 @@ def main():
                     pipe_ratio = tot / (BYTES_PER_FRAME_TOTAL * frames_per_launch)
             except Exception:   # noqa: BLE001
                 pipe_ratio = None
-            roof = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "k_fast_cells1 + k_fast_cells (FAST of one launch group: two launches)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "pipeline_traffic_over_algorithmic": pipe_ratio,
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
                     "bytes_per_launch": BYTES_PER_FRAME_FAST * frames_per_launch, "avg_launch_ms": fast_ms / fast_n,
