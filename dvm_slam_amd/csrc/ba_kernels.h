@@ -204,4 +204,4 @@ void ba_launch_pose_optimize(hipStream_t s, const double* pose_in, const double*
 // csrc/ba_window.hip: dvm_ba_optimize_windows with the choice of normalising the input quaternions (a fresh graph: SE3Quat's
 // constructor does) or taking them as they are (the state a previous optimize() of the same graph left)
 #include "../../include/dvmslam_hip.h"
-int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input, bool fast);
+int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input, bool fast, int cluster);

@@ -816,7 +816,7 @@ int dvm_ba_optimize(dvm_ba* h, int iterations, const volatile uint8_t* stop_flag
     std::vector<double> po(h->ws_poses.size()), xo(h->ws_points.size());
     w.poses_out = po.data(); w.points_out = xo.data(); w.edge_chi2_out = h->ws_chi2.data(); w.depth_positive_out = h->ws_depth.data();
     dvm_ba_stats ws;
-    const int rc = dvm_ba_optimize_windows_impl(h->device, &w, 1, stop_flag, &ws, /*normalize_input=*/false, /*fast=*/false);
+    const int rc = dvm_ba_optimize_windows_impl(h->device, &w, 1, stop_flag, &ws, /*normalize_input=*/false, /*fast=*/false, /*cluster=*/0);
     if (rc == DVM_ERR_CAPACITY && !h->win_device_stale) {
       // what the sequential-order kernel cannot hold (a landmark with more rows than a chunk: duplicate observations; an index block
       // beyond its staging area) the tile solver can: this problem is its from now on (round-4 advice)

@@ -101,6 +101,11 @@ struct BaWin {
   const int2* bp_pairs;
   double *Bs, *Ws, *Ts, *Cs;              // [15][Fp] B (12) w wr0 wr1 | [18][Fp] W | [24][Fp] W Dinv (18), W Dinv bl (6) | [3][Fp] W^T x_p
   double *chi_s;                          // [E] chi2 of the last evaluation, sorted order
+  // ---- the CLUSTER form (k_ba_window_cluster: G workgroups per window): what the workgroups hand each other through global memory
+  unsigned int *cl_ctr, *cl_tmo;          // arrival counter of the window's barriers, time-out word (both zeroed before every launch)
+  double *Sblk, *rhsg;                    // [nblk][36] the blocks of the reduced system as their owner waves leave them, [6 nfree]
+  double *cl_part;                        // [4][8] partial sums of the eight fixed parts: chi2, scale terms, max |diag|
+  double *cl_ctl;                         // [4] 0: the solve succeeded, 1: the stop word as the leader saw it
 };
 
 // ------------------------------------------------------------------------------------------------ small algebra (the oracle's sequences)
@@ -1147,6 +1152,578 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
   }
 }
 
+// ------------------------------------------------------------------------------------------------ the CLUSTER form
+// The FAST form on G workgroups per window (G = 1, 2, 4, 8).  One CU streams a window's ~23 MB per iteration through ONE 64 B/clk
+// memory pipe with eight waves' worth of requests in flight (~40 GB/s): with K <= 32 windows on 256 CUs the other seven eighths of the
+// chip idle.  Here every data-parallel phase is split over the cluster -- element ranges in EIGHT fixed parts (part p belongs to
+// workgroup p % G: the partial sums and therefore the results do not depend on G), cameras / blocks round-robin over the cluster's
+// waves -- and the phases are separated by cluster barriers (Guideline 16, counter form: every wave drains, lane 0 releases at agent
+// scope, arrives on the window's counter, polls it relaxed, acquires).  The reduced system is solved by workgroup 0 (S in its LDS);
+// every workgroup takes the LM decisions redundantly on the same words.  Correctness does not depend on where the workgroups run;
+// the block -> window map only tries to keep a window's workgroups on one XCD (observed: block b runs on XCD b % 8).  Every spin is
+// bounded: a barrier that times out (a workgroup of the cluster is not resident) raises cl_tmo and the whole cluster leaves; the
+// host then solves the batch with G = 1, which needs no co-residency.
+constexpr int kParts = 8;
+struct ClusterCtx { int g, G; unsigned int epoch; bool dead; };
+
+__device__ __forceinline__ bool cluster_barrier(const BaWin& W, ClusterCtx& C, int* s_flag) {
+  if (C.G == 1) { __syncthreads(); return true; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its stores have left
+  __syncthreads();
+  C.epoch++;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (restated: the compiler may drop the wait behind buffer_wbl2)
+    __hip_atomic_fetch_add(W.cl_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int target = C.epoch * (unsigned int)C.G;
+    int ok = 1;
+    for (unsigned int spins = 0; __hip_atomic_load(W.cl_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((spins & 63u) == 63u && __hip_atomic_load(W.cl_tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (spins > (1u << 20)) { __hip_atomic_store(W.cl_tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  __syncthreads();
+  if (!ok) C.dead = true;
+  return ok;
+}
+// the elements [lo, hi) of part p of n (fixed eight parts, multiples of 64)
+__device__ __forceinline__ void part_range(int n, int p, int& lo, int& hi) {
+  const int chunk = (((n + kParts - 1) / kParts) + 63) & ~63;
+  lo = min(n, p * chunk); hi = min(n, lo + chunk);
+}
+// the partial sums of this workgroup's parts of v[0..n) -> W.cl_part[slot * 8 + part]
+__device__ void cluster_partial_sums(const BaWin& W, const ClusterCtx& C, const double* __restrict__ v, int n, int slot, double* red) {
+  __syncthreads();                    // (v's entries of this workgroup's parts were written by its own threads just before)
+  for (int p = C.g; p < kParts; p += C.G) {
+    int lo, hi;
+    part_range(n, p, lo, hi);
+    double s = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += kWinThreads) s += v[i];
+    s = w_row_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < kWinThreads / 16; i++) t += red[i];
+      W.cl_part[slot * kParts + p] = t;
+    }
+  }
+}
+__device__ __forceinline__ double cluster_total(const BaWin& W, int slot) {
+  double t = 0.0;
+#pragma unroll
+  for (int p = 0; p < kParts; p++) t += W.cl_part[slot * kParts + p];
+  return t;
+}
+// Dinv and Dinv bl of a landmark from Hll | bl and the damping: formed where they are needed (the T rows, the back substitution) --
+// the same operations on the same words give the same bits, and a phase (and its barrier) less
+__device__ __forceinline__ void w_dinv(const double* __restrict__ h, double lambda, double* Di, double* d3) {
+  double D[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) D[i] = h[i];
+  const double g3[3] = {h[9], h[10], h[11]};
+  D[0] += lambda; D[4] += lambda; D[8] += lambda;
+  w_inv3(D, Di);
+  w_mat3_vec(Di, g3, d3);
+}
+
+template <bool JAC>
+__device__ void cl_edge_pass(const BaWin& W, const ClusterCtx& C, const double* __restrict__ poses, const double* __restrict__ pts) {
+  const size_t Fp = (size_t)W.Fp;
+  for (int p = C.g; p < kParts; p += C.G) {
+    int lo, hi;
+    part_range(W.E, p, lo, hi);
+    for (int k = lo + threadIdx.x; k < hi; k += kWinThreads) {
+      const int pi = W.e_pose[k], l = W.e_point[k];
+      const double* T = poses + 7 * (size_t)pi;
+      const double* X = pts + 3 * (size_t)l;
+      double R[9], Xc[3];
+      w_quat_to_R(T + 3, R);
+      w_mat3_vec(R, X, Xc);
+      Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
+      const double x = Xc[0], y = Xc[1], z = Xc[2];
+      const double info = W.e_info[k];
+      const double e0 = W.e_obs[2 * k] - (W.fx * x / z + W.cx);
+      const double e1 = W.e_obs[2 * k + 1] - (W.fy * y / z + W.cy);
+      const double chi2 = e0 * info * e0 + e1 * info * e1;
+      double r0, r1;
+      w_robustify(chi2, W.delta, r0, r1);
+      W.chi_s[k] = chi2;
+      W.e_rho[k] = r0;
+      if (!JAC) continue;
+      const double J[6] = {-(W.fx / z), 0, W.fx * x / (z * z), 0, -(W.fy / z), W.fy * y / (z * z)};
+      double A[6], B[12];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[3 * r + c] = J[3 * r] * R[c] + J[3 * r + 1] * R[3 + c] + J[3 * r + 2] * R[6 + c];
+      const double w = r1 * info;
+      const double wr0 = -info * e0 * r1, wr1 = -info * e1 * r1;
+      double2* oA = reinterpret_cast<double2*>(W.rowA + kRowA * (size_t)k);
+      oA[0] = make_double2(A[0], A[1]); oA[1] = make_double2(A[2], A[3]); oA[2] = make_double2(A[4], A[5]);
+      oA[3] = make_double2(w, wr0); oA[4] = make_double2(wr1, 0.0);
+      if (k < W.F) {
+        const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
+#pragma unroll
+        for (int i = 0; i < 12; i++) W.Bs[i * Fp + k] = B[i];
+        W.Bs[12 * Fp + k] = w; W.Bs[13 * Fp + k] = wr0; W.Bs[14 * Fp + k] = wr1;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; b2++) W.Ws[(3 * a + b2) * Fp + k] = w * (B[a] * A[b2] + B[6 + a] * A[3 + b2]);
+      }
+    }
+  }
+}
+// Hll / bl of this workgroup's landmarks, Hpp / bp of its waves' cameras; mx = max |diagonal| over what it formed
+__device__ double cl_accumulate(const BaWin& W, const ClusterCtx& C, double* wred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t Fp = (size_t)W.Fp;
+  double mx = 0.0;
+  for (int p = C.g; p < kParts; p += C.G) {
+    int lo, hi;
+    part_range(W.nact, p, lo, hi);
+    for (int li = lo + threadIdx.x; li < hi; li += kWinThreads) {
+      double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g3[3] = {0, 0, 0};
+      for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
+        const double2* Ap = reinterpret_cast<const double2*>(W.rowA + kRowA * (size_t)W.pt_edges[q]);
+        const double2 a01 = Ap[0], a23 = Ap[1], a45 = Ap[2], ww = Ap[3], w1 = Ap[4];
+        const double A[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
+        const double w = ww.x, wr0 = ww.y, wr1 = w1.x;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          g3[a] += A[a] * wr0 + A[3 + a] * wr1;
+#pragma unroll
+          for (int b2 = 0; b2 < 3; b2++) h[3 * a + b2] += w * (A[a] * A[b2] + A[3 + a] * A[3 + b2]);
+        }
+      }
+      double* o = W.HB + kRowH * (size_t)li;
+#pragma unroll
+      for (int i = 0; i < 9; i++) o[i] = h[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) o[9 + i] = g3[i];
+      mx = fmax(mx, fmax(fabs(h[0]), fmax(fabs(h[4]), fabs(h[8]))));
+    }
+  }
+  double* wbuf = wred + wave * 4 * 36;
+  for (int i = C.g * (kWinThreads / 64) + wave; i < W.nfree; i += C.G * (kWinThreads / 64)) {
+    double acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) acc[t] = 0.0;
+    const int q1 = W.cam_start[i + 1];
+    for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
+      double B[15];
+#pragma unroll
+      for (int j = 0; j < 15; j++) B[j] = W.Bs[j * Fp + q];
+      const double w = B[12], wr0 = B[13], wr1 = B[14];
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b2 = 0; b2 <= a; b2++) acc[t++] += w * (B[a] * B[b2] + B[6 + a] * B[6 + b2]);
+      }
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[21 + a] += B[a] * wr0 + B[6 + a] * wr1;
+    }
+    const double tot = w_wave_reduce<27>(acc, wbuf);
+    if (lane < 21) {
+      int a = 0, r = lane; while (r > a) { r -= a + 1; a++; }
+      const int b2 = r;
+      W.Hpp[36 * (size_t)i + 6 * a + b2] = tot; W.Hpp[36 * (size_t)i + 6 * b2 + a] = tot;
+      if (a == b2) mx = fmax(mx, fabs(tot));
+    } else if (lane < 27) W.bp[6 * (size_t)i + (lane - 21)] = tot;
+  }
+  return mx;
+}
+// W Dinv | W Dinv bl of this workgroup's rows
+__device__ void cl_t_rows(const BaWin& W, const ClusterCtx& C, double lambda) {
+  const size_t Fp = (size_t)W.Fp;
+  for (int p = C.g; p < kParts; p += C.G) {
+    int lo, hi;
+    part_range(W.F, p, lo, hi);
+    for (int r = lo + threadIdx.x; r < hi; r += kWinThreads) {
+      const double2* hp = reinterpret_cast<const double2*>(W.HB + kRowH * (size_t)W.e_lm[r]);
+      double w[18], h[12], Di[9], d3[3];
+#pragma unroll
+      for (int j = 0; j < 6; j++) { const double2 v = hp[j]; h[2 * j] = v.x; h[2 * j + 1] = v.y; }
+#pragma unroll
+      for (int j = 0; j < 18; j++) w[j] = W.Ws[j * Fp + r];
+      w_dinv(h, lambda, Di, d3);
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++) W.Ts[(3 * a + b2) * Fp + r] = w[3 * a] * Di[b2] + w[3 * a + 1] * Di[3 + b2] + w[3 * a + 2] * Di[6 + b2];
+        W.Ts[(18 + a) * Fp + r] = w[3 * a] * d3[0] + w[3 * a + 1] * d3[1] + w[3 * a + 2] * d3[2];
+      }
+    }
+  }
+}
+// the reduced right-hand side and the blocks of the reduced system, each formed completely by ONE wave of the cluster
+__device__ void cl_schur(const BaWin& W, const ClusterCtx& C, double* wred, double lambda) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t Fp = (size_t)W.Fp;
+  double* wbuf = wred + wave * 4 * 36;
+  const int gw = C.g * (kWinThreads / 64) + wave, GW = C.G * (kWinThreads / 64);
+  for (int i = gw; i < W.nfree; i += GW) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int q1 = W.cam_start[i + 1];
+    for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[a] += W.Ts[(18 + a) * Fp + q];
+    }
+    const double tot = w_wave_reduce<6>(acc, wbuf);
+    if (lane < 6) W.rhsg[6 * i + lane] = W.bp[6 * (size_t)i + lane] - tot;
+  }
+  for (int bk = gw; bk < W.nblk; bk += GW) {
+    double acc[36];
+#pragma unroll
+    for (int t = 0; t < 36; t++) acc[t] = 0.0;
+    const int q1 = W.bp_start[bk + 1];
+    for (int q = W.bp_start[bk] + lane; q < q1; q += 64) {
+      const int2 pr = W.bp_pairs[q];
+      double t1[18], w2[18];
+#pragma unroll
+      for (int j = 0; j < 18; j++) { t1[j] = W.Ts[j * Fp + pr.x]; w2[j] = W.Ws[j * Fp + pr.y]; }
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 6; b2++) acc[6 * a + b2] += t1[3 * a] * w2[3 * b2] + t1[3 * a + 1] * w2[3 * b2 + 1] + t1[3 * a + 2] * w2[3 * b2 + 2];
+    }
+    const double tot = w_wave_reduce<36>(acc, wbuf);
+    const int ij = W.blk_ij[bk], i1 = ij & 255, i2 = (ij >> 8) & 255;
+    if (lane < 36) {
+      const int a = lane / 6, b2 = lane - 6 * a;
+      const double base = i1 == i2 ? W.Hpp[36 * (size_t)i1 + 6 * a + b2] + (a == b2 ? lambda : 0.0) : 0.0;
+      W.Sblk[36 * (size_t)bk + lane] = base - tot;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop, int K, int G) {
+  extern __shared__ double lds[];
+  constexpr int NT = kWinThreads;
+  __shared__ int s_flag;
+  const int bid = blockIdx.x, slot = bid >> 3;
+  const int wi = (slot / G) * 8 + (bid & 7);
+  if (wi >= K) return;
+  const BaWin& W = wins[wi];
+  ClusterCtx C{slot % G, G, 0u, false};
+  const bool leader = C.g == 0;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int n = 6 * W.nfree, nl = 3 * W.nact;
+  double* S = lds;                                  // (workgroup 0 of the cluster only) packed lower triangle, n (n + 1) / 2
+  double* rhs = S + (size_t)n * (n + 1) / 2;
+  double* diag = rhs + n;
+  double* ctl = diag + n;                           // [64]
+  double* red = ctl + 64;                           // [256] partial sums of the tree reductions
+  double* wred = ctl + 64 + 256;                    // the waves' reduction buffers
+  dvm_ba_stats* const st = W.stats;
+  if (leader && tid == 0) {
+    st->iterations = st->total_trials = st->stop_reason = st->pad = 0;
+    st->chi2_initial = st->chi2_final = st->lambda_final = 0;
+    for (int i = 0; i < 64; i++) { st->trials_per_iter[i] = 0; st->chi2_per_iter[i] = 0; st->lambda_per_iter[i] = 0; }
+    st->ms_structure = st->ms_optimize = 0; st->spec_trials = st->spec_kept = 0;
+    W.cl_ctl[1] = (stop && *stop) ? 1.0 : 0.0;
+  }
+  for (int p = C.g; p < kParts; p += G) {
+    int lo, hi;
+    part_range(n + nl, p, lo, hi);
+    for (int i = lo + tid; i < hi; i += NT) W.x[i] = 0.0;
+    part_range(7 * W.P, p, lo, hi);
+    for (int i = lo + tid; i < hi; i += NT) W.poses_t[i] = W.poses[i];
+    part_range(3 * W.L, p, lo, hi);
+    for (int i = lo + tid; i < hi; i += NT) W.pts_t[i] = W.pts[i];
+  }
+  double* poses = W.poses; double* poses_t = W.poses_t; double* pts = W.pts; double* pts_t = W.pts_t;
+  if (!cluster_barrier(W, C, &s_flag)) return;
+
+  double lambda = -1, ni = 2, currentChi = 0, chi_last = 0;
+  int nBad = 0, it_done = 0, trials_total = 0, stop_reason = 0;
+  bool stopped = W.cl_ctl[1] != 0.0;
+  for (int it = 0; it < W.iterations && !stopped; it++) {
+    cl_edge_pass<true>(W, C, poses, pts);
+    if (it == 0) cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
+    if (!cluster_barrier(W, C, &s_flag)) return;
+    {
+      double mx = cl_accumulate(W, C, wred);
+      if (it == 0) {      // computeLambdaInit's max |diagonal|: this workgroup's share -> its parts' slots (a maximum has no order)
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        __syncthreads();
+        if ((tid & 63) == 0) red[wave] = mx;
+        __syncthreads();
+        if (tid == 0) {
+          double m = red[0];
+          for (int w2 = 1; w2 < NT / 64; w2++) m = fmax(m, red[w2]);
+          for (int p = 0; p < kParts; p++) if (p % G == C.g) W.cl_part[2 * kParts + p] = m;
+        }
+      }
+    }
+    if (!cluster_barrier(W, C, &s_flag)) return;
+    if (it == 0) {
+      currentChi = cluster_total(W, 0);
+      if (leader && tid == 0) st->chi2_initial = currentChi;
+      double mx = 0;
+      for (int p = 0; p < kParts; p++) mx = fmax(mx, W.cl_part[2 * kParts + p]);
+      lambda = 1e-5 * mx;
+      ni = 2; nBad = 0;
+    }
+    const double iniChi = currentChi;
+    double tempChi = currentChi, rho = 0;
+    int qmax = 0;
+    do {
+      cl_t_rows(W, C, lambda);
+      if (!cluster_barrier(W, C, &s_flag)) return;
+      cl_schur(W, C, wred, lambda);
+      if (!cluster_barrier(W, C, &s_flag)) return;
+      if (leader) {
+        for (int i = tid; i < n * (n + 1) / 2; i += NT) S[i] = 0.0;
+        __syncthreads();
+        for (int t = tid; t < 36 * W.nblk; t += NT) {
+          const int bk = t / 36, e = t - 36 * bk, a = e / 6, b2 = e - 6 * a;
+          const int ij = W.blk_ij[bk], i1 = ij & 255, i2 = (ij >> 8) & 255;
+          if (i1 != i2 || b2 <= a) S[tri(6 * i1 + a, 6 * i2 + b2)] = W.Sblk[t];
+        }
+        for (int t = tid; t < n; t += NT) rhs[t] = W.rhsg[t];
+        __syncthreads();
+        bool ok = true;
+        for (int k0 = 0; k0 < n && ok; k0 += 6) {
+          double Ld[21], dg[6];
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int c = 0; c <= a; c++) {
+              double v = S[tri(k0 + a, k0 + c)];
+#pragma unroll
+              for (int k = 0; k < c; k++) v -= Ld[a * (a + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
+              if (a == c) {
+                if (!(v > 0)) ok = false;
+                dg[a] = sqrt(v);
+                Ld[a * (a + 1) / 2 + a] = v;
+              } else Ld[a * (a + 1) / 2 + c] = v / dg[c];
+            }
+          }
+          if (!ok) break;
+          __syncthreads();
+          if (tid == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+              diag[k0 + a] = dg[a];
+#pragma unroll
+              for (int c = 0; c < a; c++) S[tri(k0 + a, k0 + c)] = Ld[a * (a + 1) / 2 + c];
+            }
+          }
+          for (int i = k0 + 6 + tid; i < n; i += NT) {
+            double* row = S + tri(i, k0);
+            double l[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              double v = row[c];
+#pragma unroll
+              for (int k = 0; k < c; k++) v -= l[k] * Ld[c * (c + 1) / 2 + k];
+              l[c] = v / dg[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) row[c] = l[c];
+          }
+          __syncthreads();
+          const int tx = tid & 15, ty = tid >> 4;
+          for (int i = k0 + 6 + ty; i < n; i += NT / 16) {
+            const double* ri = S + tri(i, k0);
+            const double li0 = ri[0], li1 = ri[1], li2 = ri[2], li3 = ri[3], li4 = ri[4], li5 = ri[5];
+            for (int j = k0 + 6 + tx; j <= i; j += 16) {
+              const double* rj = S + tri(j, k0);
+              double v = S[tri(i, j)];
+              v -= li0 * rj[0]; v -= li1 * rj[1]; v -= li2 * rj[2]; v -= li3 * rj[3]; v -= li4 * rj[4]; v -= li5 * rj[5];
+              S[tri(i, j)] = v;
+            }
+          }
+          __syncthreads();
+        }
+        if (ok) {
+          if (wave == 0) {
+            const int lane = tid;
+            for (int k0 = 0; k0 < n; k0 += 6) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              double y[6];
+#pragma unroll
+              for (int a = 0; a < 6; a++) {
+                double v = rhs[k0 + a];
+#pragma unroll
+                for (int c = 0; c < a; c++) v -= S[tri(k0 + a, k0 + c)] * y[c];
+                y[a] = v / diag[k0 + a];
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (lane < 6) { double yv = y[0]; yv = lane == 1 ? y[1] : yv; yv = lane == 2 ? y[2] : yv; yv = lane == 3 ? y[3] : yv; yv = lane == 4 ? y[4] : yv; yv = lane == 5 ? y[5] : yv; rhs[k0 + lane] = yv; }
+              for (int r = k0 + 6 + lane; r < n; r += 64) {
+                const double* rr = S + tri(r, k0);
+                double v = rhs[r];
+#pragma unroll
+                for (int a = 0; a < 6; a++) v -= rr[a] * y[a];
+                rhs[r] = v;
+              }
+            }
+            for (int k0 = n - 6; k0 >= 0; k0 -= 6) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              double x6[6];
+#pragma unroll
+              for (int a = 5; a >= 0; a--) {
+                double v = rhs[k0 + a];
+#pragma unroll
+                for (int c = 5; c > a; c--) v -= S[tri(k0 + c, k0 + a)] * x6[c];
+                x6[a] = v / diag[k0 + a];
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
+              for (int j = lane; j < k0; j += 64) {
+                double v = rhs[j];
+#pragma unroll
+                for (int a = 5; a >= 0; a--) v -= S[tri(k0 + a, j)] * x6[a];
+                rhs[j] = v;
+              }
+            }
+          }
+          __syncthreads();
+          for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];
+        }
+        if (tid == 0) { W.cl_ctl[0] = ok ? 1.0 : 0.0; W.cl_ctl[1] = (stop && *stop) ? 1.0 : 0.0; }
+      }
+      if (!cluster_barrier(W, C, &s_flag)) return;
+      const bool ok = W.cl_ctl[0] != 0.0;
+      const size_t Fp = (size_t)W.Fp;
+      if (ok) {      // W^T x_p of this workgroup's rows
+        for (int p = C.g; p < kParts; p += G) {
+          int lo, hi;
+          part_range(W.F, p, lo, hi);
+          for (int r = lo + tid; r < hi; r += NT) {
+            const double* xp = W.x + 6 * W.f_cam[r];
+            double c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+              const double xa = xp[a];
+              c0 += W.Ws[(3 * a) * Fp + r] * xa; c1 += W.Ws[(3 * a + 1) * Fp + r] * xa; c2 += W.Ws[(3 * a + 2) * Fp + r] * xa;
+            }
+            W.Cs[r] = c0; W.Cs[Fp + r] = c1; W.Cs[2 * Fp + r] = c2;
+          }
+        }
+      }
+      if (!cluster_barrier(W, C, &s_flag)) return;
+      // landmarks of this workgroup: xl = Dinv (bl - sum of their rows' W^T x_p), the trial point, the scale terms; its cameras: oplus
+      for (int p = C.g; p < kParts; p += G) {
+        int lo, hi;
+        part_range(W.nact, p, lo, hi);
+        for (int li = lo + tid; li < hi; li += NT) {
+          const double* hb = W.HB + kRowH * (size_t)li;
+          double xl[3];
+          if (ok) {
+            double h[12], Di[9], d3[3];
+#pragma unroll
+            for (int j = 0; j < 12; j++) h[j] = hb[j];
+            w_dinv(h, lambda, Di, d3);
+            double c0 = h[9], c1 = h[10], c2 = h[11];
+            for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
+              const int r = W.pt_edges[q];
+              if (r >= W.F) break;
+              c0 -= W.Cs[r]; c1 -= W.Cs[Fp + r]; c2 -= W.Cs[2 * Fp + r];
+            }
+            const double c[3] = {c0, c1, c2};
+            w_mat3_vec(Di, c, xl);
+#pragma unroll
+            for (int a = 0; a < 3; a++) W.x[n + 3 * (size_t)li + a] = xl[a];
+          } else {
+#pragma unroll
+            for (int a = 0; a < 3; a++) xl[a] = W.x[n + 3 * (size_t)li + a];     // (a failed solve: the last successful one's x)
+          }
+          const int l = W.act_pt[li];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            pts_t[3 * (size_t)l + a] = pts[3 * (size_t)l + a] + xl[a];
+            W.terms[n + 3 * li + a] = xl[a] * (lambda * xl[a] + hb[9 + a]);
+          }
+        }
+        part_range(W.nfree, p, lo, hi);
+        for (int i = lo + tid; i < hi; i += NT) {
+          const int pp = W.free_pose[i];
+          w_se3_oplus(poses + 7 * (size_t)pp, W.x + 6 * (size_t)i, poses_t + 7 * (size_t)pp);
+#pragma unroll
+          for (int a = 0; a < 6; a++) { const double xj = W.x[6 * i + a]; W.terms[6 * i + a] = xj * (lambda * xj + W.bp[6 * i + a]); }
+        }
+      }
+      if (!cluster_barrier(W, C, &s_flag)) return;
+      cl_edge_pass<false>(W, C, poses_t, pts_t);
+      cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
+      cluster_partial_sums(W, C, W.terms, n + nl, 1, red);
+      if (!cluster_barrier(W, C, &s_flag)) return;
+      // ---- the decision, taken by every thread of every workgroup on the same words (optimization_algorithm_levenberg.cpp:113-147)
+      tempChi = ok ? cluster_total(W, 0) : 1.7976931348623157e308;
+      rho = currentChi - tempChi;
+      const double scale = cluster_total(W, 1) + 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - f64_cube(2 * rho - 1);
+        alpha = (2. / 3. < alpha) ? 2. / 3. : alpha;
+        lambda *= (1. / 3. < alpha) ? alpha : 1. / 3.;
+        ni = 2;
+        currentChi = tempChi;
+        double* sw = poses; poses = poses_t; poses_t = sw;
+        sw = pts; pts = pts_t; pts_t = sw;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+      }
+      qmax++;
+      trials_total++;
+      stopped = W.cl_ctl[1] != 0.0;
+    } while (rho < 0 && qmax < 10 && !stopped);
+    it_done++;
+    chi_last = currentChi;
+    if (leader && tid == 0 && it < 64) { st->trials_per_iter[it] = qmax; st->chi2_per_iter[it] = currentChi; st->lambda_per_iter[it] = lambda; }
+    if (qmax == 10 || rho == 0) { stop_reason = 1; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { stop_reason = 2; break; }
+  }
+  if (it_done == 0) {     // no iteration ran: the edges are evaluated at the unchanged input state (see k_ba_window)
+    cl_edge_pass<false>(W, C, poses, pts);
+    cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
+    if (!cluster_barrier(W, C, &s_flag)) return;
+    chi_last = cluster_total(W, 0);
+    if (leader && tid == 0) st->chi2_initial = chi_last;
+  }
+  // results: the accepted state, chi2 / depth signs back in the caller's edge order (every workgroup its parts; all inputs are final:
+  // the last barrier is behind every write of the state and of chi_s)
+  for (int p = C.g; p < kParts; p += G) {
+    int lo, hi;
+    part_range(7 * W.P, p, lo, hi);
+    for (int i = lo + tid; i < hi; i += NT) W.out_poses[i] = poses[i];
+    part_range(3 * W.L, p, lo, hi);
+    for (int i = lo + tid; i < hi; i += NT) W.out_pts[i] = pts[i];
+    part_range(W.E, p, lo, hi);
+    for (int k = lo + tid; k < hi; k += NT) {
+      const double* T = poses + 7 * (size_t)W.e_pose[k];
+      const double* X = pts + 3 * (size_t)W.e_point[k];
+      double R[9], Xc[3];
+      w_quat_to_R(T + 3, R);
+      w_mat3_vec(R, X, Xc);
+      const int ko = W.e_orig[k];
+      W.e_depth[ko] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
+      W.e_chi2[ko] = W.chi_s[k];
+    }
+  }
+  if (leader && tid == 0) {
+    st->iterations = it_done; st->total_trials = trials_total; st->chi2_final = chi_last; st->lambda_final = lambda; st->stop_reason = stop_reason;
+  }
+}
+
 // evaluates csrc/f64_spec.h on the device (tests: the device build against the host build and the oracle's restatement)
 __global__ void k_f64_spec(const double* __restrict__ x, int n, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1377,7 +1954,7 @@ struct StopWord {                      // a word of page-locked host memory the 
 
 }  // namespace
 
-int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input, bool fast) {
+int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats, bool normalize_input, bool fast, int cluster) {
   if (K < 0 || (K && !windows)) { set_error("dvm_ba_optimize_windows: null windows"); return DVM_ERR_INVALID; }
   if (K == 0) return DVM_OK;
   int rc = dvm_set_device(device);
@@ -1408,7 +1985,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   Stage st;
   struct Slots { int poses, pts, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, lpos, fpos, pt_start, f_start, f_cam, hc_ints, sc_desc, sc_ints,
                      blk_ij, out_poses, out_pts, echi, edepth, stats, poses_t, pts_t, rowB, rowA, rowW, erho, Hpp, bp, HB, DD, x, terms, prof,
-                     e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs, Bs, Ws, Ts, Cs, chi_s; };
+                     e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs, Bs, Ws, Ts, Cs, chi_s, cl_sync, Sblk, rhsg, cl_part, cl_ctl; };
   std::vector<Slots> sl(K);
   static const bool want_prof = std::getenv("DVM_BA_WINDOW_PROF") != nullptr;
   std::vector<std::vector<unsigned long long>> prof_out(K, std::vector<unsigned long long>(16, 0));
@@ -1426,6 +2003,9 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     s.e_orig = I32(b.e_orig); s.e_lm = I32(b.e_lm); s.cam_start = I32(b.cam_start); s.pt_edges = I32(b.pt_edges);
     s.bp_start = I32(b.bp_start); s.bp_pairs = I32(b.bp_pairs);
   }
+  std::vector<uint32_t> sync_zero(16, 0u);        // the cluster form's arrival counter [0] and time-out word [8], zero at every launch
+  std::vector<std::vector<uint32_t>> sync_back(K, std::vector<uint32_t>(16, 0u));
+  if (fast) for (int k = 0; k < K; k++) sl[k].cl_sync = st.add(sync_zero.data(), sync_back[k].data(), 64);
   std::vector<BaWin> views(K);
   const int views_slot = st.in(views.data(), sizeof(BaWin) * (size_t)K);   // filled in below, once layout() has placed everything
   struct Outs { std::vector<double> poses, pts, chi2; std::vector<uint8_t> depth; dvm_ba_stats st; };
@@ -1451,6 +2031,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     if (fast) {
       const size_t Fp = (size_t)b.Fp;
       s.Bs = st.scratch(8 * 15 * Fp); s.Ws = st.scratch(8 * 18 * Fp); s.Ts = st.scratch(8 * 24 * Fp); s.Cs = st.scratch(8 * 3 * Fp); s.chi_s = st.scratch(8 * E);
+      s.Sblk = st.scratch(8 * 36 * (size_t)std::max(b.nblk, 1)); s.rhsg = st.scratch(8 * std::max<size_t>(n, 1)); s.cl_part = st.scratch(8 * 4 * 8); s.cl_ctl = st.scratch(8 * 4);
     }
   }
   if ((rc = st.layout()) != DVM_OK) return rc;
@@ -1476,6 +2057,8 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
       v.e_orig = st.ptr<int32_t>(s.e_orig); v.e_lm = st.ptr<int32_t>(s.e_lm); v.cam_start = st.ptr<int32_t>(s.cam_start); v.pt_edges = st.ptr<int32_t>(s.pt_edges);
       v.bp_start = st.ptr<int32_t>(s.bp_start); v.bp_pairs = reinterpret_cast<const int2*>(st.ptr<int32_t>(s.bp_pairs));
       v.Bs = st.ptr<double>(s.Bs); v.Ws = st.ptr<double>(s.Ws); v.Ts = st.ptr<double>(s.Ts); v.Cs = st.ptr<double>(s.Cs); v.chi_s = st.ptr<double>(s.chi_s);
+      v.cl_ctr = st.ptr<unsigned int>(s.cl_sync); v.cl_tmo = v.cl_ctr + 8;
+      v.Sblk = st.ptr<double>(s.Sblk); v.rhsg = st.ptr<double>(s.rhsg); v.cl_part = st.ptr<double>(s.cl_part); v.cl_ctl = st.ptr<double>(s.cl_ctl);
     }
     v.Hpp = st.ptr<double>(s.Hpp); v.bp = st.ptr<double>(s.bp); v.HB = st.ptr<double>(s.HB); v.DD = st.ptr<double>(s.DD);
     v.x = st.ptr<double>(s.x); v.terms = st.ptr<double>(s.terms);
@@ -1488,10 +2071,23 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   // dynamic LDS: the packed reduced system of the largest window, rhs / diagonal, control words and the streaming area
   const size_t lds_bytes = sizeof(double) * lds_doubles;
   if (lds_bytes > 160 * 1024) { set_error("dvm_ba_optimize_windows: a window needs more than 160 KB of LDS"); return DVM_ERR_CAPACITY; }
-  DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fast ? k_ba_window<true> : k_ba_window<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (!fast) DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
   // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
-  if (fast) hipLaunchKernelGGL(k_ba_window<true>, dim3(K), dim3(kFastThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
+  int G = 1;
+  if (fast) {
+    // the cluster size: the largest of 8 / 4 / 2 / 1 workgroups per window whose grid (8 * ceil(K / 8) * G workgroups, one per CU: the
+    // reduced system's LDS) is resident at once; forced by `cluster` (the G = 1 repeat after a barrier time-out) or DVM_BA_CLUSTER
+    int cus = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const char* env_c = std::getenv("DVM_BA_CLUSTER");      // (read at every call: the tests walk the cluster sizes)
+    const int env_g = env_c ? atoi(env_c) : 0;
+    const int want = cluster > 0 ? cluster : env_g;
+    const int groups = 8 * ((K + 7) / 8);
+    for (int g = 8; g >= 1; g >>= 1) if ((want > 0 && g == want) || (want <= 0 && groups * g <= cus)) { G = g; break; }
+    DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_ba_window_cluster, dim3(groups * G), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d, K, G);
+  }
   else hipLaunchKernelGGL(k_ba_window<false>, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
   if (stop_flag) {                     // g2o's forceStopFlag: written by another thread while the optimisation runs (LocalMapping.cc:305,359)
@@ -1502,6 +2098,12 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     hipEventDestroy(ev);
   }
   if ((rc = st.download()) != DVM_OK) return rc;
+  if (fast && G > 1) {
+    bool timed_out = false;
+    for (int k = 0; k < K; k++) timed_out = timed_out || sync_back[k][8] != 0u;
+    if (timed_out)     // a cluster's workgroups were not all resident (other work held compute units): solve the batch again, one workgroup per window
+      return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, normalize_input, true, 1);
+  }
   const auto t2 = std::chrono::steady_clock::now();
   if (want_prof) {
     static const char* names[16] = {"edge pass + Jacobians", "Hll / bl", "Hpp / bp (streamed)", "schur: rhs chain", "Schur (streamed)", "Cholesky", "forward / backward", "landmark back-sub",
@@ -1526,10 +2128,10 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
 extern "C" {
 
 int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
-  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, false);
+  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, false, 0);
 }
 int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
-  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, true);
+  return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, true, 0);
 }
 
 int dvm_f64_spec_eval(int device, const double* x, int n, double* out) {

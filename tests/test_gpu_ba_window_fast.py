@@ -93,3 +93,19 @@ def test_fast_windows_capacity():
     pr = synth.ba_problem(n_kf=40, n_pts=600, k_obs=6, seed=0x3E0, radius=12.0)
     with pytest.raises(capi.DvmError):
         capi.ba_optimize_windows([_window(pr, 3, n_fixed=2)], fast=True)     # 38 free cameras
+
+
+def test_fast_windows_do_not_depend_on_the_cluster_size(windows, monkeypatch):
+    """k_ba_window_cluster: G = 1, 2, 4, 8 workgroups per window -- element ranges are split in eight FIXED parts and every camera / block
+    of the reduced system is summed by one wave, so the bits do not depend on G (nor, therefore, on how many windows share the launch)."""
+    ref = None
+    for G in (1, 2, 4, 8):
+        monkeypatch.setenv("DVM_BA_CLUSTER", str(G))
+        res = capi.ba_optimize_windows(windows[:5], fast=True)
+        if ref is None:
+            ref = res
+            continue
+        for k, (a, b) in enumerate(zip(ref, res)):
+            assert np.array_equal(_bits(a["poses"]), _bits(b["poses"])) and np.array_equal(_bits(a["points"]), _bits(b["points"])), (G, k)
+            assert np.array_equal(_bits(a["edge_chi2"]), _bits(b["edge_chi2"])) and list(a["stats"]["trials"]) == list(b["stats"]["trials"]), (G, k)
+            assert np.array_equal(_bits(a["stats"]["chi2"]), _bits(b["stats"]["chi2"])), (G, k)
