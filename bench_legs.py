@@ -411,7 +411,7 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
     # the same K windows by ONE launch of the FAST form (dvm_ba_optimize_windows_fast: LM control on the device, tree sums in a fixed order;
     # the general solver's tolerance contract instead of bit identity).  K = 128: four times the 32 windows (the launch fills 128 CUs)
     capi.ba_optimize_windows(wins[:1], device, fast=True)
-    fast = {"call": "dvm_ba_optimize_windows_fast (one launch, a workgroup per window)", "by_K": {}}
+    fast = {"call": "dvm_ba_optimize_windows_fast (one launch, a cluster of up to 8 workgroups per window: k_ba_window_cluster)", "by_K": {}}
     resf = None
     for K in tuple(Ks) + (4 * kmax,):
         wk = [wins[a % kmax] for a in range(K)]
@@ -503,7 +503,7 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
 
 def lba_fast(device, K=32, iters=10, repeats=4):
     """K LocalBundleAdjustment windows (30 keyframes / 20 free / 3 000 landmarks / ~15 000 observations each, different maps) by ONE launch of
-    dvm_ba_optimize_windows_fast (LM control on the device, a workgroup per window): the short form of lba_batch's `fast_windows` for the
+    dvm_ba_optimize_windows_fast (LM control on the device, a cluster of workgroups per window): the short form of lba_batch's `fast_windows` for the
     default run's contract line.  Reference: Optimizer.cc:1030-1387 per window, LocalMapping.cc:172."""
     from dvm_slam_amd import capi, synth
     delta = float(np.sqrt(np.float32(5.991)))

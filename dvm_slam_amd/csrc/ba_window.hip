@@ -27,6 +27,12 @@
 //
 // The price is speed per window -- the sequential sums are one lane's dependent FP64 additions (8 cycles each) -- which K windows side
 // by side buy back; one large window is the tile solver's job (dvm_ba_optimize).
+//
+// dvm_ba_optimize_windows_fast (k_ba_window_cluster, second half of this file) is the same optimizer for MANY LocalBundleAdjustment
+// windows per call (Optimizer.cc:1030-1387, one per agent): tree sums in a fixed order instead of the sequential ones, edges sorted
+// camera-major with structure-of-arrays rows, a cluster of G = 1 / 2 / 4 / 8 workgroups per window separated by agent-scope phase
+// barriers, the reduced system solved in workgroup 0's LDS.  Deterministic, independent of G; equal to the oracle to the general
+// solver's contract (same LM trial sequence, 1e-6), not bit for bit (tests/test_gpu_ba_window_fast.py, tools/soak_r06.py).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -48,7 +54,6 @@
 namespace dvm {
 
 constexpr int kWinThreads = 512;
-constexpr int kFastThreads = 512;        // (measured: 1 024 threads / 128 VGPRs is no faster -- the phases are bound by the CU's one 64 B/clk memory pipe, not by latency)
 constexpr int kWinMaxFree = 30;          // 6 * 30 = 180 rows: packed lower triangle 130 320 B of LDS
 constexpr int kRowB = 16, kRowA = 12, kRowW = 18, kRowD = 24, kRowH = 12;   // doubles per row of the per-edge / per-landmark arrays below
 constexpr int kWinIntCap = 6 * kWinThreads;   // ints of one chunk's index block (six per thread in flight)
@@ -88,7 +93,7 @@ struct BaWin {
   double *Hpp, *bp, *HB, *DD, *x, *terms;   // [nfree][36], [6 nfree], [nact][12] = Hll (9) bl (3), [nact][12] = Dinv (9) Dinv bl (3), [6 nfree + 3 nact] x 2
   dvm_ba_stats* stats;
   unsigned long long* prof;           // [16] shader-clock cycles per phase, accumulated by thread 0 (DVM_BA_WINDOW_PROF=1), or null
-  // ---- the FAST form only (k_ba_window<true>: tree sums in a fixed order instead of g2o's sequential ones, nothing streamed through LDS).
+  // ---- the fast (cluster) form only (k_ba_window_cluster: tree sums in a fixed order instead of g2o's sequential ones, nothing streamed through LDS).
   // Its edges are SORTED camera-major on the host -- free cameras first, a camera's edges by landmark, the fixed cameras' edges behind
   // them -- and the per-edge rows are structure-of-arrays with pitch Fp / Ep, so that a lane per edge reads and writes consecutive words.
   // e_pose / e_point / e_obs / e_info above are in that order; the first F edges are the free cameras' (the rows of W / T / B).
@@ -582,12 +587,9 @@ __device__ void win_schur(const BaWin& W, double* S, double* rhs, double* stage,
   __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------ the FAST form
-// The same optimizer with every sum as a tree in a FIXED order (deterministic, but not g2o's sequential order: results agree with the
-// oracle to the general solver's tolerance instead of bit for bit).  What the sequential order costs is not its additions but the
-// machinery that feeds one lane's chain: 80 Schur chunks and 60 Hessian chunks per trial, each a handful of barrier-separated phases.
-// Here a wave owns a camera (Hpp / bp, the reduced right-hand side) or a block of the reduced system, its lanes stride the camera's
-// edges / the block's pairs straight from L2, and 27 / 6 / 36 partial sums per lane meet in four DPP steps and one LDS hop.
+// ------------------------------------------------------------------------------------------------ tree reductions (cluster form)
+// Sums as trees in a FIXED order (deterministic, but not g2o's sequential order): partial sums per lane meet in four DPP steps and one
+// LDS hop.  Used by the cluster form below (k_ba_window_cluster); the sequential-order kernel (k_ba_window) does not use them.
 template <int CTRL>
 __device__ __forceinline__ double w_dpp_add(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -616,244 +618,10 @@ __device__ __forceinline__ double w_wave_reduce(double (&acc)[N], double* __rest
   if (lane < N) r = (wbuf[lane] + wbuf[N + lane]) + (wbuf[2 * N + lane] + wbuf[3 * N + lane]);
   return r;
 }
-// sum of v[0..n) over the workgroup, the same value in every thread: strided partial sums, row sums, then the 32 row sums in index order
-__device__ double win_block_sum(const double* __restrict__ v, int n, double* __restrict__ red /* kFastThreads / 16 doubles of LDS */) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += kFastThreads) s += v[i];
-  s = w_row_sum(s);
-  __syncthreads();
-  if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4] = s;
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int i = 0; i < kFastThreads / 16; i++) t += red[i];
-  return t;
-}
-// edge pass of the FAST form: a thread per edge of the camera-major order; every per-edge store is to consecutive words
-template <bool JAC>
-__device__ void win_edge_pass_fast(const BaWin& W, const double* __restrict__ poses, const double* __restrict__ pts) {
-  const size_t Fp = (size_t)W.Fp;
-  for (int k = threadIdx.x; k < W.E; k += kFastThreads) {
-    const int p = W.e_pose[k], l = W.e_point[k];
-    const double* T = poses + 7 * (size_t)p;
-    const double* X = pts + 3 * (size_t)l;
-    double R[9], Xc[3];
-    w_quat_to_R(T + 3, R);
-    w_mat3_vec(R, X, Xc);
-    Xc[0] += T[0]; Xc[1] += T[1]; Xc[2] += T[2];
-    const double x = Xc[0], y = Xc[1], z = Xc[2];
-    const double info = W.e_info[k];
-    const double e0 = W.e_obs[2 * k] - (W.fx * x / z + W.cx);
-    const double e1 = W.e_obs[2 * k + 1] - (W.fy * y / z + W.cy);
-    const double chi2 = e0 * info * e0 + e1 * info * e1;
-    double r0, r1;
-    w_robustify(chi2, W.delta, r0, r1);
-    W.chi_s[k] = chi2;
-    W.e_rho[k] = r0;
-    if (!JAC) continue;
-    const double J[6] = {-(W.fx / z), 0, W.fx * x / (z * z), 0, -(W.fy / z), W.fy * y / (z * z)};
-    double A[6], B[12];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) A[3 * r + c] = J[3 * r] * R[c] + J[3 * r + 1] * R[3 + c] + J[3 * r + 2] * R[6 + c];
-    const double w = r1 * info;
-    const double wr0 = -info * e0 * r1, wr1 = -info * e1 * r1;
-    double2* oA = reinterpret_cast<double2*>(W.rowA + kRowA * (size_t)k);      // (96-byte rows, 16-byte stores)
-    oA[0] = make_double2(A[0], A[1]); oA[1] = make_double2(A[2], A[3]); oA[2] = make_double2(A[4], A[5]);
-    oA[3] = make_double2(w, wr0); oA[4] = make_double2(wr1, 0.0);
-    if (k < W.F) {
-      const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
-#pragma unroll
-      for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) B[6 * r + c] = J[3 * r] * S[c] + J[3 * r + 1] * S[6 + c] + J[3 * r + 2] * S[12 + c];
-#pragma unroll
-      for (int i = 0; i < 12; i++) W.Bs[i * Fp + k] = B[i];
-      W.Bs[12 * Fp + k] = w; W.Bs[13 * Fp + k] = wr0; W.Bs[14 * Fp + k] = wr1;
-#pragma unroll
-      for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) W.Ws[(3 * a + b) * Fp + k] = w * (B[a] * A[b] + B[6 + a] * A[3 + b]);
-    }
-  }
-}
-// Hll / bl: a thread per landmark gathers its edges' A rows (sorted indices ascending: the order of the sums is fixed)
-__device__ void win_accumulate_landmarks_fast(const BaWin& W) {
-  for (int li = threadIdx.x; li < W.nact; li += kFastThreads) {
-    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
-      const double2* Ap = reinterpret_cast<const double2*>(W.rowA + kRowA * (size_t)W.pt_edges[q]);
-      const double2 a01 = Ap[0], a23 = Ap[1], a45 = Ap[2], ww = Ap[3], w1 = Ap[4];
-      const double A[6] = {a01.x, a01.y, a23.x, a23.y, a45.x, a45.y};
-      const double w = ww.x, wr0 = ww.y, wr1 = w1.x;
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        g[a] += A[a] * wr0 + A[3 + a] * wr1;
-#pragma unroll
-        for (int b = 0; b < 3; b++) h[3 * a + b] += w * (A[a] * A[b] + A[3 + a] * A[3 + b]);
-      }
-    }
-    double* o = W.HB + kRowH * (size_t)li;
-#pragma unroll
-    for (int i = 0; i < 9; i++) o[i] = h[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) o[9 + i] = g[i];
-  }
-}
-// Hpp / bp: a wave per free camera, its lanes stride the camera's edges (a contiguous range of the sorted order)
-__device__ void win_accumulate_cameras_fast(const BaWin& W, double* wred) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t Fp = (size_t)W.Fp;
-  double* wbuf = wred + wave * 4 * 36;
-  for (int i = wave; i < W.nfree; i += kFastThreads / 64) {
-    double acc[27];
-#pragma unroll
-    for (int t = 0; t < 27; t++) acc[t] = 0.0;
-    const int q1 = W.cam_start[i + 1];
-    for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
-      double B[15];
-#pragma unroll
-      for (int j = 0; j < 15; j++) B[j] = W.Bs[j * Fp + q];
-      const double w = B[12], wr0 = B[13], wr1 = B[14];
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 6; a++) {
-#pragma unroll
-        for (int b = 0; b <= a; b++) acc[t++] += w * (B[a] * B[b] + B[6 + a] * B[6 + b]);
-      }
-#pragma unroll
-      for (int a = 0; a < 6; a++) acc[21 + a] += B[a] * wr0 + B[6 + a] * wr1;
-    }
-    const double tot = w_wave_reduce<27>(acc, wbuf);
-    if (lane < 21) {
-      int a = 0, r = lane; while (r > a) { r -= a + 1; a++; }
-      const int b = r;
-      W.Hpp[36 * (size_t)i + 6 * a + b] = tot; W.Hpp[36 * (size_t)i + 6 * b + a] = tot;
-    } else if (lane < 27) W.bp[6 * (size_t)i + (lane - 21)] = tot;
-  }
-}
-// solve(lambda), first half, FAST form: S = Hpp + lambda I - sum_l W Dinv W^T, rhs = bp - sum_l W Dinv bl (block_solver.hpp:381-439)
-__device__ void win_schur_fast(const BaWin& W, double* S, double* rhs, double* wred, double lambda) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = 6 * W.nfree;
-  const size_t Fp = (size_t)W.Fp;
-  unsigned long long tp = __builtin_amdgcn_s_memtime();
-  auto lap2 = [&](int slot) { if (W.prof && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); W.prof[slot] += t - tp; tp = t; } };
-  for (int i = tid; i < n * (n + 1) / 2; i += kFastThreads) S[i] = 0.0;
-  // Dinv, Dinv bl per landmark
-  for (int li = tid; li < W.nact; li += kFastThreads) {
-    const double* h = W.HB + kRowH * (size_t)li;
-    double D[9], Di[9], d3[3];
-#pragma unroll
-    for (int i = 0; i < 9; i++) D[i] = h[i];
-    const double g[3] = {h[9], h[10], h[11]};
-    D[0] += lambda; D[4] += lambda; D[8] += lambda;
-    w_inv3(D, Di);
-    w_mat3_vec(Di, g, d3);
-    double* o = W.DD + kRowH * (size_t)li;
-#pragma unroll
-    for (int i = 0; i < 9; i++) o[i] = Di[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) o[9 + i] = d3[i];
-  }
-  __syncthreads();
-  lap2(13);
-  for (int t = tid; t < 21 * W.nfree; t += kFastThreads) {
-    const int i = t / 21, e = t - 21 * i;
-    int a = 0, r = e; while (r > a) { r -= a + 1; a++; }
-    const int b = r;
-    S[tri(6 * i + a, 6 * i + b)] = W.Hpp[36 * (size_t)i + 6 * a + b] + (a == b ? lambda : 0.0);
-  }
-  // W Dinv, W Dinv bl: a lane per free row (consecutive words of W in, of T out; the landmark's 96 bytes gathered)
-  for (int r = tid; r < W.F; r += kFastThreads) {
-    const double2* hp = reinterpret_cast<const double2*>(W.DD + kRowH * (size_t)W.e_lm[r]);
-    double w[18], d[12];
-#pragma unroll
-    for (int j = 0; j < 6; j++) { const double2 v = hp[j]; d[2 * j] = v.x; d[2 * j + 1] = v.y; }
-#pragma unroll
-    for (int j = 0; j < 18; j++) w[j] = W.Ws[j * Fp + r];
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-#pragma unroll
-      for (int b = 0; b < 3; b++) W.Ts[(3 * a + b) * Fp + r] = w[3 * a] * d[b] + w[3 * a + 1] * d[3 + b] + w[3 * a + 2] * d[6 + b];
-      W.Ts[(18 + a) * Fp + r] = w[3 * a] * d[9] + w[3 * a + 1] * d[10] + w[3 * a + 2] * d[11];
-    }
-  }
-  __syncthreads();
-  lap2(14);
-  double* wbuf = wred + wave * 4 * 36;
-  // the reduced right-hand side: a wave per camera over the camera's rows (contiguous)
-  for (int i = wave; i < W.nfree; i += kFastThreads / 64) {
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const int q1 = W.cam_start[i + 1];
-    for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
-#pragma unroll
-      for (int a = 0; a < 6; a++) acc[a] += W.Ts[(18 + a) * Fp + q];
-    }
-    const double tot = w_wave_reduce<6>(acc, wbuf);
-    if (lane < 6) rhs[6 * i + lane] = W.bp[6 * (size_t)i + lane] - tot;
-  }
-  lap2(3);
-  // the blocks: a wave per block, a lane per pair (rows of camera i1 / of camera i2: ascending inside the cameras' ranges)
-  for (int bk = wave; bk < W.nblk; bk += kFastThreads / 64) {
-    double acc[36];
-#pragma unroll
-    for (int t = 0; t < 36; t++) acc[t] = 0.0;
-    const int q1 = W.bp_start[bk + 1];
-    for (int q = W.bp_start[bk] + lane; q < q1; q += 64) {
-      const int2 pr = W.bp_pairs[q];
-      double t1[18], w2[18];
-#pragma unroll
-      for (int j = 0; j < 18; j++) { t1[j] = W.Ts[j * Fp + pr.x]; w2[j] = W.Ws[j * Fp + pr.y]; }
-#pragma unroll
-      for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int b = 0; b < 6; b++) acc[6 * a + b] += t1[3 * a] * w2[3 * b] + t1[3 * a + 1] * w2[3 * b + 1] + t1[3 * a + 2] * w2[3 * b + 2];
-    }
-    const double tot = w_wave_reduce<36>(acc, wbuf);
-    const int ij = W.blk_ij[bk], i1 = ij & 255, i2 = (ij >> 8) & 255;
-    if (lane < 36) {
-      const int a = lane / 6, b = lane - 6 * a;
-      if (i1 != i2 || b <= a) { const int idx = tri(6 * i1 + a, 6 * i2 + b); S[idx] = S[idx] - tot; }
-    }
-  }
-  __syncthreads();
-  lap2(11);
-}
-// xl = Dinv (bl - W^T xp): a lane per free row forms W^T x_p of its camera (consecutive words), a thread per landmark adds its rows'
-__device__ void win_landmark_backsub_fast(const BaWin& W, const double* __restrict__ rhs /* x_p, LDS */, int n) {
-  const size_t Fp = (size_t)W.Fp;
-  for (int r = threadIdx.x; r < W.F; r += kFastThreads) {
-    const double* xp = rhs + 6 * W.f_cam[r];
-    double c0 = 0, c1 = 0, c2 = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-      const double xa = xp[a];
-      c0 += W.Ws[(3 * a) * Fp + r] * xa; c1 += W.Ws[(3 * a + 1) * Fp + r] * xa; c2 += W.Ws[(3 * a + 2) * Fp + r] * xa;
-    }
-    W.Cs[r] = c0; W.Cs[Fp + r] = c1; W.Cs[2 * Fp + r] = c2;
-  }
-  __syncthreads();
-  for (int li = threadIdx.x; li < W.nact; li += kFastThreads) {
-    const double* hb = W.HB + kRowH * (size_t)li;
-    double c0 = hb[9], c1 = hb[10], c2 = hb[11];
-    for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
-      const int r = W.pt_edges[q];
-      if (r >= W.F) break;                                   // (ascending: the fixed cameras' edges follow)
-      c0 -= W.Cs[r]; c1 -= W.Cs[Fp + r]; c2 -= W.Cs[2 * Fp + r];
-    }
-    const double c[3] = {c0, c1, c2};
-    double xl[3];
-    w_mat3_vec(W.DD + kRowH * (size_t)li, c, xl);
-    W.x[n + 3 * (size_t)li] = xl[0]; W.x[n + 3 * (size_t)li + 1] = xl[1]; W.x[n + 3 * (size_t)li + 2] = xl[2];
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ the kernel
-template <bool FAST>
-__global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop) {
+__global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop) {
   extern __shared__ double lds[];
-  constexpr int NT = FAST ? kFastThreads : kWinThreads;
+  constexpr int NT = kWinThreads;
   const BaWin& W = wins[blockIdx.x];
   const int tid = threadIdx.x, wave = tid >> 6;
   const int n = 6 * W.nfree, nl = 3 * W.nact;
@@ -891,17 +659,16 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
     // computeActiveErrors + robust chi2 + buildSystem at the accepted state.  (From the second iteration on g2o recomputes the chi2
     // of the state the last accepted trial has just evaluated: same state, same sums, same bits -- only the Jacobians are new.)
     lap(15);
-    if constexpr (FAST) win_edge_pass_fast<true>(W, poses, pts); else win_edge_pass<true>(W, poses, pts);
+    win_edge_pass<true>(W, poses, pts);
     __syncthreads();
     lap(0);
     if (it == 0) {
-      if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 64); if (tid == 0) ctl[1] = c; }
-      else if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
+      if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
     }
-    if constexpr (FAST) win_accumulate_landmarks_fast(W); else win_accumulate_landmarks(W);
+    win_accumulate_landmarks(W);
     __syncthreads();
     lap(1);
-    if constexpr (FAST) win_accumulate_cameras_fast(W, stage); else win_accumulate_cameras(W, stage);
+    win_accumulate_cameras(W, stage);
     __syncthreads();
     lap(2);
     if (it == 0) {
@@ -927,7 +694,7 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
     do {
       // ---- solve(lambda): Dinv, Schur complement, reduced right-hand side (one streamed pass)
       lap(3);
-      if constexpr (FAST) win_schur_fast(W, S, rhs, stage, lambda); else win_schur(W, S, rhs, stage, lambda);
+      win_schur(W, S, rhs, stage, lambda);
       lap(4);
       // ---- Cholesky: entry (i, j) receives its subtractions L(i, k) L(j, k) in ascending k, as the row-wise dot products of the
       // envelope factorisation apply them; L(i, j) = s / L(j, j) by IEEE division, L(j, j) = sqrt(s)
@@ -1040,8 +807,6 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
         lap(6);
         for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];
         // xl = Dinv (bl - W^T xp): per landmark, its free-camera rows in order, per row the six camera components in order
-        if constexpr (FAST) win_landmark_backsub_fast(W, rhs, n);
-        else
         for (int li = tid; li < W.nact; li += NT) {
           const double* hb = W.HB + kRowH * (size_t)li;
           double c0 = hb[9], c1 = hb[10], c2 = hb[11];
@@ -1076,17 +841,11 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
       for (int j = tid; j < nl; j += NT) { const double xj = W.x[n + j]; W.terms[n + j] = xj * (lambda * xj + W.HB[kRowH * (size_t)(j / 3) + 9 + j % 3]); }
       __syncthreads();
       lap(8);
-      if constexpr (FAST) win_edge_pass_fast<false>(W, poses_t, pts_t); else win_edge_pass<false>(W, poses_t, pts_t);
+      win_edge_pass<false>(W, poses_t, pts_t);
       __syncthreads();
       lap(9);
-      if constexpr (FAST) {
-        const double c = win_block_sum(W.e_rho, W.E, ctl + 64);
-        const double c2 = win_block_sum(W.terms, n + nl, ctl + 64);
-        if (tid == 0) { ctl[1] = c; ctl[2] = c2; }
-      } else {
-        if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
-        if (wave == 1) { const double c = wave_sequential_sum(W.terms, n + nl, seqbuf); if (tid == 64) ctl[2] = c; }
-      }
+      if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) ctl[1] = c; }
+      if (wave == 1) { const double c = wave_sequential_sum(W.terms, n + nl, seqbuf); if (tid == 64) ctl[2] = c; }
       __syncthreads();
       lap(10);
       // ---- the decision, taken by every thread on the same words (optimization_algorithm_levenberg.cpp:113-147)
@@ -1126,10 +885,9 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
   // caller downloads them (Optimizer_shim's LocalBundleAdjustment erases observations on chi2 > 5.991).  Evaluate the edges at the
   // unchanged input state, so that what leaves is the chi2 OF the state that leaves -- never the previous tenant of the buffer.
   if (it_done == 0) {
-    if constexpr (FAST) win_edge_pass_fast<false>(W, poses, pts); else win_edge_pass<false>(W, poses, pts);
+    win_edge_pass<false>(W, poses, pts);
     __syncthreads();
-    if constexpr (FAST) { const double c = win_block_sum(W.e_rho, W.E, ctl + 64); chi_last = c; if (tid == 0) st->chi2_initial = c; }   // (every thread holds c)
-    else if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) { st->chi2_initial = c; chi_last = c; } }
+    if (wave == 0) { const double c = wave_sequential_sum(W.e_rho, W.E, seqbuf); if (tid == 0) { st->chi2_initial = c; chi_last = c; } }
     __syncthreads();
   }
   // results: the accepted state (the buffers may have been swapped any number of times), depth signs at that state
@@ -1141,11 +899,7 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
     double R[9], Xc[3];
     w_quat_to_R(T + 3, R);
     w_mat3_vec(R, X, Xc);
-    if constexpr (FAST) {     // back to the caller's edge order
-      const int ko = W.e_orig[k];
-      W.e_depth[ko] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
-      W.e_chi2[ko] = W.chi_s[k];
-    } else W.e_depth[k] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
+    W.e_depth[k] = (Xc[2] + T[2]) > 0.0 ? 1 : 0;
   }
   if (tid == 0) {
     st->iterations = it_done; st->total_trials = trials_total; st->chi2_final = chi_last; st->lambda_final = lambda; st->stop_reason = stop_reason;
@@ -1153,7 +907,7 @@ __global__ void __launch_bounds__(FAST ? kFastThreads : kWinThreads) k_ba_window
 }
 
 // ------------------------------------------------------------------------------------------------ the CLUSTER form
-// The FAST form on G workgroups per window (G = 1, 2, 4, 8).  One CU streams a window's ~23 MB per iteration through ONE 64 B/clk
+// dvm_ba_optimize_windows_fast: the optimizer with tree sums in a fixed order, on G workgroups per window (G = 1, 2, 4, 8).  One CU streams a window's ~23 MB per iteration through ONE 64 B/clk
 // memory pipe with eight waves' worth of requests in flight (~40 GB/s): with K <= 32 windows on 256 CUs the other seven eighths of the
 // chip idle.  Here every data-parallel phase is split over the cluster -- element ranges in EIGHT fixed parts (part p belongs to
 // workgroup p % G: the partial sums and therefore the results do not depend on G), cameras / blocks round-robin over the cluster's
@@ -1413,7 +1167,6 @@ __device__ void cl_schur(const BaWin& W, const ClusterCtx& C, double* wred, doub
 __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop, int K, int G) {
   extern __shared__ double lds[];
   constexpr int NT = kWinThreads;
-  __shared__ int s_flag;
   const int bid = blockIdx.x, slot = bid >> 3;
   const int wi = (slot / G) * 8 + (bid & 7);
   if (wi >= K) return;
@@ -1428,6 +1181,8 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
   double* ctl = diag + n;                           // [64]
   double* red = ctl + 64;                           // [256] partial sums of the tree reductions
   double* wred = ctl + 64 + 256;                    // the waves' reduction buffers
+  int* const s_flag_p = reinterpret_cast<int*>(ctl + 60);   // the barrier's verdict (no static LDS beside the 160 KB dynamic block)
+#define s_flag (*s_flag_p)
   dvm_ba_stats* const st = W.stats;
   if (leader && tid == 0) {
     st->iterations = st->total_trials = st->stop_reason = st->pad = 0;
@@ -1722,6 +1477,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
   if (leader && tid == 0) {
     st->iterations = it_done; st->total_trials = trials_total; st->chi2_final = chi_last; st->lambda_final = lambda; st->stop_reason = stop_reason;
   }
+#undef s_flag
 }
 
 // evaluates csrc/f64_spec.h on the device (tests: the device build against the host build and the oracle's restatement)
@@ -1745,24 +1501,37 @@ struct WinBuild {
   std::vector<int32_t> pidx, lidx, free_pose, act_pt, e_pose, e_point, lpos, fpos, pt_start, f_start, f_cam;
   std::vector<int32_t> hc_ints, sc_desc, sc_ints, blk_ij;
   std::vector<double> e_obs, e_info;
-  // the FAST form's tables (the e_* arrays above are then in the camera-major order)
+  // the fast form's tables (the e_* arrays above are then in the camera-major order)
   int Fp = 0, Ep = 0;
   std::vector<int32_t> e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs;   // bp_pairs: (row1, row2) interleaved
+  // scratch of build_window_fast, kept with the object: a pooled WinBuild touches no fresh pages from its second use on (32 windows
+  // built by 16 threads spent 2.3 ms of a 9 ms call in the page faults of their ~2 MB of vectors each)
+  std::vector<int32_t> t_by_lm, t_ep, t_ept, t_cnt, t_blk_of, t_cr, t_fill;
+  std::vector<double> t_eo, t_ei;
+  void reset() {
+    P = L = E = F = nfree = nact = nblk = 0; C = 128; C2 = 256; n_sc = n_hc = stage_doubles = 0; Fp = Ep = 0;
+    for (auto* v : {&pidx, &lidx, &free_pose, &act_pt, &e_pose, &e_point, &lpos, &fpos, &pt_start, &f_start, &f_cam, &hc_ints, &sc_desc, &sc_ints, &blk_ij,
+                    &e_orig, &e_lm, &cam_start, &pt_edges, &bp_start, &bp_pairs}) v->clear();
+    poses.clear(); e_obs.clear(); e_info.clear();
+  }
 };
 
-// The FAST form's structure: edges sorted camera-major (free cameras in free-index order, a camera's edges by landmark, then the fixed
+// The fast form's structure: edges sorted camera-major (free cameras in free-index order, a camera's edges by landmark, then the fixed
 // cameras' edges), per landmark its edges in that order, per block of the reduced system its (row, row) pairs in landmark order
 // (block_solver.hpp:381-439: edge k1 (outer) x edge k2 (inner), lower blocks; (k1, k1) on the diagonal).
 int build_window_fast(WinBuild& b) {
   const int E = b.E, nf = b.nfree, P = b.P;
   // rank of an edge's camera: free index, or nf + pose for a fixed camera; two stable counting sorts: by landmark, then by rank
-  std::vector<int32_t> by_lm(E), order(E);
+  std::vector<int32_t>& by_lm = b.t_by_lm; std::vector<int32_t>& order = b.e_orig;
+  by_lm.resize(E); order.resize(E);
   {
-    std::vector<int32_t> cnt(b.nact + 1, 0);
+    std::vector<int32_t>& cnt = b.t_cnt;
+    cnt.assign(b.nact + 1, 0);
     for (int k = 0; k < E; k++) cnt[b.lidx[b.e_point[k]] + 1]++;
     for (int i = 0; i < b.nact; i++) cnt[i + 1] += cnt[i];
     for (int k = 0; k < E; k++) by_lm[cnt[b.lidx[b.e_point[k]]]++] = k;
-    std::vector<int32_t> cr(nf + P + 1, 0);
+    std::vector<int32_t>& cr = b.t_cr;
+    cr.assign(nf + P + 1, 0);
     auto rank = [&](int k) { const int i = b.pidx[b.e_pose[k]]; return i >= 0 ? i : nf + b.e_pose[k]; };
     for (int k = 0; k < E; k++) cr[rank(k) + 1]++;
     for (int i = 0; i < nf + P; i++) cr[i + 1] += cr[i];
@@ -1771,9 +1540,10 @@ int build_window_fast(WinBuild& b) {
   }
   b.F = nf ? b.cam_start[nf] : 0;
   b.Fp = (b.F + 63) & ~63; b.Ep = (E + 63) & ~63;
-  std::vector<int32_t> ep(E), ept(E);
-  std::vector<double> eo(2 * (size_t)E), ei(E);
-  b.e_orig = order; b.e_lm.resize(E);
+  std::vector<int32_t>& ep = b.t_ep; std::vector<int32_t>& ept = b.t_ept;
+  std::vector<double>& eo = b.t_eo; std::vector<double>& ei = b.t_ei;
+  ep.resize(E); ept.resize(E); eo.resize(2 * (size_t)E); ei.resize(E);
+  b.e_lm.resize(E);
   for (int j = 0; j < E; j++) {
     const int k = order[j];
     ep[j] = b.e_pose[k]; ept[j] = b.e_point[k]; eo[2 * (size_t)j] = b.e_obs[2 * (size_t)k]; eo[2 * (size_t)j + 1] = b.e_obs[2 * (size_t)k + 1]; ei[j] = b.e_info[k];
@@ -1787,11 +1557,13 @@ int build_window_fast(WinBuild& b) {
   for (int j = 0; j < E; j++) b.pt_start[b.e_lm[j] + 1]++;
   for (int i = 0; i < b.nact; i++) b.pt_start[i + 1] += b.pt_start[i];
   b.pt_edges.resize(E);
-  { std::vector<int32_t> fill(b.pt_start.begin(), b.pt_start.end() - 1);
+  { std::vector<int32_t>& fill = b.t_fill;
+    fill.assign(b.pt_start.begin(), b.pt_start.end() - 1);
     for (int j = 0; j < E; j++) b.pt_edges[fill[b.e_lm[j]]++] = j; }
   // blocks and their pairs.  Within a landmark the free rows ascend with the camera: (q1, q2) with camera(q2) <= camera(q1) is q2 <= q1,
   // minus the off-diagonal pairs of two observations by the SAME camera (as the sequential-order form leaves them out)
-  std::vector<int32_t> blk_of((size_t)nf * nf, -1), cnt;
+  std::vector<int32_t>& blk_of = b.t_blk_of; std::vector<int32_t>& cnt = b.t_cnt;
+  blk_of.assign((size_t)nf * nf, -1); cnt.clear();
   auto each_pair = [&](auto&& fn) {
     for (int li = 0; li < b.nact; li++) {
       const int q0 = b.pt_start[li];
@@ -1814,16 +1586,18 @@ int build_window_fast(WinBuild& b) {
   b.bp_start.assign(b.nblk + 1, 0);
   for (int j = 0; j < b.nblk; j++) b.bp_start[j + 1] = b.bp_start[j] + cnt[j];
   b.bp_pairs.resize(2 * (size_t)b.bp_start[b.nblk]);
-  { std::vector<int32_t> fill(b.bp_start.begin(), b.bp_start.end() - 1);
+  { std::vector<int32_t>& fill = b.t_fill;
+    fill.assign(b.bp_start.begin(), b.bp_start.end() - 1);
     each_pair([&](int i1, int i2, int r1, int r2) { const int at = fill[blk_of[(size_t)i1 * nf + i2]]++; b.bp_pairs[2 * (size_t)at] = r1; b.bp_pairs[2 * (size_t)at + 1] = r2; }); }
   b.n_hc = b.n_sc = 0;
-  b.stage_doubles = (kFastThreads / 64) * 4 * 36;      // the waves' reduction buffers
+  b.stage_doubles = (kWinThreads / 64) * 4 * 36;       // the waves' reduction buffers
   return DVM_OK;
 }
 
 int build_window(const dvm_ba_window& w, WinBuild& b, bool normalize, bool fast = false) {
   const int P = w.n_poses, L = w.n_points, E = w.n_edges;
   if (P < 0 || L < 0 || E < 0 || (P && (!w.poses || !w.fixed)) || (L && !w.points) || (E && !w.edges)) { set_error("dvm_ba_optimize_windows: null array"); return DVM_ERR_INVALID; }
+  b.reset();
   b.P = P; b.L = L; b.E = E;
   b.poses.assign(w.poses, w.poses + 7 * (size_t)P);
   for (int p = 0; normalize && p < P; p++) {   // quat_normalize as the oracle / g2o::SE3Quat(q, t) does it: sign, then divide by the norm
@@ -1960,7 +1734,11 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   int rc = dvm_set_device(device);
   if (rc != DVM_OK) return rc;
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<WinBuild> B(K);
+  // (the fast form keeps its windows' host tables in a per-thread pool: see WinBuild's scratch members)
+  static thread_local std::vector<WinBuild> build_pool;
+  std::vector<WinBuild> local_builds;
+  if (fast) { if ((int)build_pool.size() < K) build_pool.resize(K); } else local_builds.resize(K);
+  std::vector<WinBuild>& B = fast ? build_pool : local_builds;
   if (fast && K > 1) {
     // the windows' index tables are independent: built by up to 16 host threads (0.2 ms each; 32 of them one after the other would cost
     // more than the launch that solves them)
@@ -2034,7 +1812,9 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
       s.Sblk = st.scratch(8 * 36 * (size_t)std::max(b.nblk, 1)); s.rhsg = st.scratch(8 * std::max<size_t>(n, 1)); s.cl_part = st.scratch(8 * 4 * 8); s.cl_ctl = st.scratch(8 * 4);
     }
   }
+  const auto t1a = std::chrono::steady_clock::now();
   if ((rc = st.layout()) != DVM_OK) return rc;
+  const auto t1b = std::chrono::steady_clock::now();
   size_t lds_doubles = 0;
   for (int k = 0; k < K; k++) {
     const WinBuild& b = B[k]; const Slots& s = sl[k]; BaWin& v = views[k];
@@ -2067,11 +1847,13 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     const size_t n = 6 * (size_t)b.nfree;
     lds_doubles = std::max(lds_doubles, n * (n + 1) / 2 + 2 * n + 64 + 256 + (size_t)b.stage_doubles);
   }
+  const auto t1c = std::chrono::steady_clock::now();
   if ((rc = st.upload()) != DVM_OK) return rc;
+  const auto t1d = std::chrono::steady_clock::now();
   // dynamic LDS: the packed reduced system of the largest window, rhs / diagonal, control words and the streaming area
   const size_t lds_bytes = sizeof(double) * lds_doubles;
   if (lds_bytes > 160 * 1024) { set_error("dvm_ba_optimize_windows: a window needs more than 160 KB of LDS"); return DVM_ERR_CAPACITY; }
-  if (!fast) DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (!fast) DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
   // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
   int G = 1;
@@ -2088,7 +1870,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k_ba_window_cluster, dim3(groups * G), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d, K, G);
   }
-  else hipLaunchKernelGGL(k_ba_window<false>, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
+  else hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
   if (stop_flag) {                     // g2o's forceStopFlag: written by another thread while the optimisation runs (LocalMapping.cc:305,359)
     hipEvent_t ev;
@@ -2097,7 +1879,13 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     while (hipEventQuery(ev) == hipErrorNotReady) *sw.h = *stop_flag ? 1 : 0;
     hipEventDestroy(ev);
   }
+  const auto t1e = std::chrono::steady_clock::now();
   if ((rc = st.download()) != DVM_OK) return rc;
+  if (std::getenv("DVM_BA_WINDOW_TIMING")) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "windows K=%d G=%d: build %.2f  register %.2f  layout %.2f  views %.2f  upload(memcpy + enqueue) %.2f  launch %.2f  wait + download %.2f ms\n", K, G,
+                 ms(t0, t1), ms(t1, t1a), ms(t1a, t1b), ms(t1b, t1c), ms(t1c, t1d), ms(t1d, t1e), ms(t1e, std::chrono::steady_clock::now()));
+  }
   if (fast && G > 1) {
     bool timed_out = false;
     for (int k = 0; k < K; k++) timed_out = timed_out || sync_back[k][8] != 0u;

@@ -504,12 +504,17 @@ typedef struct {
   uint8_t* depth_positive_out; /* [n_edges] or NULL: isDepthPositive() at the result */
 } dvm_ba_window;
 int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
-/* The same K windows, ONE launch, a workgroup per window, the whole Levenberg-Marquardt control on the device -- with every sum as a tree
- * in a FIXED order instead of g2o's sequential one (a wave per camera / per block of the reduced system, its lanes striding the edges /
- * pairs; nothing streamed through LDS in chunks): 3-4 x faster per window than dvm_ba_optimize_windows.  Deterministic (same bits run to
- * run); equal to the CPU recipe to the general solver's contract -- same LM trial sequence, poses / landmarks within 1e-6 on
- * well-posed windows -- not bit for bit.  Up to 30 free cameras per window (DVM_ERR_CAPACITY beyond: dvm_ba_optimize_batch).  This is the
- * call for the LocalBundleAdjustment windows of several agents sharing a GPU (Optimizer.cc:1030-1387, LocalMapping.cc:172). */
+/* The same K windows, ONE launch, the whole Levenberg-Marquardt control on the device -- with every sum as a tree in a FIXED order instead of
+ * g2o's sequential one, and a CLUSTER of G workgroups per window (G = the largest of 8 / 4 / 2 / 1 for which the launch's
+ * 8 * ceil(K / 8) * G workgroups are resident at once; DVM_BA_CLUSTER forces it): the data-parallel phases are split over the cluster and
+ * separated by agent-scope barriers, workgroup 0 solves the reduced system in its LDS.  One window: 2.7 ms (tile solver 1.1 ms, the
+ * sequential-order kernel 15 ms); 32 windows: 3.5 ms of kernel, 7.8 ms per call from host arrays = 41 k LM iterations/s.  Deterministic and
+ * independent of G and of the other windows of the call; equal to the CPU recipe to the general solver's contract -- same LM trial
+ * sequence, poses / landmarks within 1e-6 on well-posed windows -- not bit for bit.  Up to 30 free cameras per window (DVM_ERR_CAPACITY
+ * beyond: dvm_ba_optimize_batch).  A barrier that times out (a workgroup of a cluster not resident: other work holds compute units) makes the
+ * call repeat the batch with G = 1, which needs no co-residency.  The calling thread keeps its windows' host tables for the next call
+ * (~2 MB per window).  This is the call for the LocalBundleAdjustment windows of several agents sharing a GPU (Optimizer.cc:1030-1387,
+ * LocalMapping.cc:172). */
 int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
 /* The same K independent problems solved CONCURRENTLY on the general solver: up to `threads` (<= 0: 4) host threads of this call each
  * drive one solver handle from a process-wide pool and pull windows from a shared counter, so that the launch chains of different
