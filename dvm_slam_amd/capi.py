@@ -663,41 +663,58 @@ def ba_optimize_batch(problems, device=0, threads=0, stop_flag=None):
     return ba_optimize_windows(problems, device, stop_flag, _threads=int(threads), _batch=True)
 
 
+class BaWindowBatch:
+    """K bundle-adjustment windows marshalled ONCE into the dvm_ba_window array of the C ABI (input arrays referenced, output arrays allocated):
+    what a C++ agent node holds anyway.  run() is then the bare library call -- the per-call Python work of ba_optimize_windows (~35 us per
+    window) stays out of a timed loop."""
+
+    def __init__(self, problems):
+        K = len(problems)
+        self.K = K
+        self.wins = (BaWindow * max(K, 1))()
+        self.stats = (BaStats * max(K, 1))()
+        self.keep, self.outs = [], []
+        for k, pr in enumerate(problems):
+            poses = np.ascontiguousarray(pr["poses"], np.float64); points = np.ascontiguousarray(pr["points"], np.float64)
+            fixed = np.ascontiguousarray(pr["fixed"], np.uint8); edges = np.ascontiguousarray(pr["edges"], BA_EDGE_DTYPE)
+            o = dict(poses=np.zeros_like(poses), points=np.zeros_like(points), edge_chi2=np.zeros(len(edges), np.float64),
+                     depth_positive=np.zeros(len(edges), np.uint8))
+            self.keep.append((poses, points, fixed, edges)); self.outs.append(o)
+            w = self.wins[k]
+            w.n_poses, w.n_points, w.n_edges, w.iterations = len(poses), len(points), len(edges), int(pr["iterations"])
+            w.poses, w.fixed, w.points, w.edges = poses.ctypes.data, fixed.ctypes.data, points.ctypes.data, edges.ctypes.data
+            w.cam = BaCamera(*[float(v) for v in pr["intrinsics"]], float(pr["huber_delta"]))
+            w.poses_out, w.points_out, w.edge_chi2_out, w.depth_positive_out = (o["poses"].ctypes.data, o["points"].ctypes.data, o["edge_chi2"].ctypes.data,
+                                                                                o["depth_positive"].ctypes.data)
+
+    def run(self, device=0, stop_flag=None, fast=False, _threads=0, _batch=False):
+        """One library call over the K windows; returns the per-window dicts (the output arrays are this object's: copy what must outlive the next run)."""
+        sf = _p(stop_flag) if stop_flag is not None else None
+        if _batch:
+            f = lib().dvm_ba_optimize_batch
+            f.restype = C.c_int32; f.argtypes = None
+            check(f(C.c_int32(device), self.wins, C.c_int32(self.K), C.c_int32(_threads), sf, self.stats))
+        else:
+            f = lib().dvm_ba_optimize_windows_fast if fast else lib().dvm_ba_optimize_windows
+            f.restype = C.c_int32; f.argtypes = None
+            check(f(C.c_int32(device), self.wins, C.c_int32(self.K), sf, self.stats))
+        return self.results()
+
+    def results(self):
+        for k, o in enumerate(self.outs):
+            st = self.stats[k]
+            n = min(st.iterations, 64)
+            o["stats"] = dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason, chi2_initial=st.chi2_initial,
+                              chi2_final=st.chi2_final, lambda_final=st.lambda_final, trials=st.trials_per_iter[:n], chi2=st.chi2_per_iter[:n],
+                              lam=st.lambda_per_iter[:n], ms_structure=st.ms_structure, ms_optimize=st.ms_optimize)
+        return self.outs
+
+
 def ba_optimize_windows(problems, device=0, stop_flag=None, _threads=0, _batch=False, fast=False):
     """dvm_ba_optimize_windows: K independent bundle adjustments in one launch.  problems: dicts with poses [P,7], fixed [P], points [L,3],
     edges (BA_EDGE_DTYPE), intrinsics (fx, fy, cx, cy), huber_delta, iterations.  Returns one dict per window: poses, points, edge_chi2,
     depth_positive, stats (the keys of BundleAdjuster.optimize).  fast=True: dvm_ba_optimize_windows_fast (tree sums in a fixed order)."""
-    K = len(problems)
-    wins = (BaWindow * max(K, 1))()
-    stats = (BaStats * max(K, 1))()
-    keep, outs = [], []
-    for k, pr in enumerate(problems):
-        poses = np.ascontiguousarray(pr["poses"], np.float64); points = np.ascontiguousarray(pr["points"], np.float64)
-        fixed = np.ascontiguousarray(pr["fixed"], np.uint8); edges = np.ascontiguousarray(pr["edges"], BA_EDGE_DTYPE)
-        o = dict(poses=np.zeros_like(poses), points=np.zeros_like(points), edge_chi2=np.zeros(len(edges), np.float64),
-                 depth_positive=np.zeros(len(edges), np.uint8))
-        keep.append((poses, points, fixed, edges)); outs.append(o)
-        w = wins[k]
-        w.n_poses, w.n_points, w.n_edges, w.iterations = len(poses), len(points), len(edges), int(pr["iterations"])
-        w.poses, w.fixed, w.points, w.edges = poses.ctypes.data, fixed.ctypes.data, points.ctypes.data, edges.ctypes.data
-        w.cam = BaCamera(*[float(v) for v in pr["intrinsics"]], float(pr["huber_delta"]))
-        w.poses_out, w.points_out, w.edge_chi2_out, w.depth_positive_out = (o["poses"].ctypes.data, o["points"].ctypes.data, o["edge_chi2"].ctypes.data,
-                                                                            o["depth_positive"].ctypes.data)
-    if _batch:
-        f = lib().dvm_ba_optimize_batch
-        f.restype = C.c_int32; f.argtypes = None
-        check(f(C.c_int32(device), wins, C.c_int32(K), C.c_int32(_threads), _p(stop_flag) if stop_flag is not None else None, stats))
-    else:
-        f = lib().dvm_ba_optimize_windows_fast if fast else lib().dvm_ba_optimize_windows
-        f.restype = C.c_int32; f.argtypes = None
-        check(f(C.c_int32(device), wins, C.c_int32(K), _p(stop_flag) if stop_flag is not None else None, stats))
-    for k, o in enumerate(outs):
-        st = stats[k]
-        n = min(st.iterations, 64)
-        o["stats"] = dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason, chi2_initial=st.chi2_initial,
-                          chi2_final=st.chi2_final, lambda_final=st.lambda_final, trials=st.trials_per_iter[:n], chi2=st.chi2_per_iter[:n],
-                          lam=st.lambda_per_iter[:n], ms_structure=st.ms_structure, ms_optimize=st.ms_optimize)
-    return outs
+    return BaWindowBatch(problems).run(device, stop_flag, fast, _threads, _batch)
 
 
 def f64_spec_eval(x, device=0):

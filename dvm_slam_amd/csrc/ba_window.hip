@@ -1740,17 +1740,14 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   if (fast) { if ((int)build_pool.size() < K) build_pool.resize(K); } else local_builds.resize(K);
   std::vector<WinBuild>& B = fast ? build_pool : local_builds;
   if (fast && K > 1) {
-    // the windows' index tables are independent: built by up to 16 host threads (0.2 ms each; 32 of them one after the other would cost
+    // the windows' index tables are independent: built by up to 16 pooled host threads (0.2 ms each; 32 of them one after the other would cost
     // more than the launch that solves them)
-    const int T = std::min(K, 16);
     std::vector<int> rcs(K, DVM_OK);
     std::vector<std::string> errs(K);
-    std::atomic<int> next{0};
-    auto work = [&] { for (;;) { const int k = next.fetch_add(1); if (k >= K) break; rcs[k] = build_window(windows[k], B[k], normalize_input, true); if (rcs[k] != DVM_OK) errs[k] = last_error_cstr(); } };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    HostPool::get().run((size_t)K, 32, [&](size_t k) {
+      rcs[k] = build_window(windows[k], B[k], normalize_input, true);
+      if (rcs[k] != DVM_OK) errs[k] = last_error_cstr();
+    });
     for (int k = 0; k < K; k++) if (rcs[k] != DVM_OK) { set_error(errs[k]); return rcs[k]; }
   } else {
     for (int k = 0; k < K; k++) if ((rc = build_window(windows[k], B[k], normalize_input, fast)) != DVM_OK) return rc;

@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -79,6 +82,67 @@ inline StageCtx& stage_ctx() {
   return c;
 }
 
+// A few persistent host threads for the batch entry points (window tables, staging copies of tens of MB): run(n, fn) calls fn(i) for
+// i in [0, n) on the caller and up to `width` - 1 workers and returns when all are done.  Spawning std::threads per call cost 30-50 us
+// each -- as much as the work they were given.  One job at a time (callers serialise on a mutex); workers sleep between jobs.
+class HostPool {
+ public:
+  static HostPool& get() { static HostPool p; return p; }
+  template <class F> void run(size_t n, int width, F&& fn) {
+    if (n == 0) return;
+    if (width <= 1 || n == 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::lock_guard<std::mutex> job_lock(job_mtx_);
+    std::function<void(size_t)> f = fn;
+    {
+      std::lock_guard<std::mutex> l(mtx_);
+      ensure(std::min<int>(width - 1, kMax));
+      fn_ = &f; n_ = n; next_.store(0); active_ = std::min<int>(width - 1, (int)workers_.size()); pending_ = active_; gen_++;
+    }
+    cv_.notify_all();
+    for (;;) { const size_t i = next_.fetch_add(1); if (i >= n) break; f(i); }
+    std::unique_lock<std::mutex> l(mtx_);
+    done_cv_.wait(l, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  static constexpr int kMax = 32;
+  std::mutex job_mtx_, mtx_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0;
+  std::atomic<size_t> next_{0};
+  int active_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+  void ensure(int want) {
+    while ((int)workers_.size() < want) {
+      const int id = (int)workers_.size();
+      workers_.emplace_back([this, id] {
+        unsigned long seen = 0;
+        for (;;) {
+          std::unique_lock<std::mutex> l(mtx_);
+          cv_.wait(l, [&] { return stop_ || (gen_ != seen && id < active_); });
+          if (stop_) return;
+          seen = gen_;
+          const std::function<void(size_t)>* f = fn_;
+          const size_t n = n_;
+          l.unlock();
+          for (;;) { const size_t i = next_.fetch_add(1); if (i >= n) break; (*f)(i); }
+          l.lock();
+          if (--pending_ == 0) done_cv_.notify_one();
+        }
+      });
+    }
+  }
+  HostPool() = default;
+  ~HostPool() {
+    { std::lock_guard<std::mutex> l(mtx_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+};
+
 // Items come in two kinds.  COPIED (in / out / scratch): packed into the pinned buffer, one asynchronous H2D copy, kernels, one D2H
 // copy -- for anything a kernel reads more than once or updates in place.  MAPPED (in_mapped / out_mapped): the kernel reads the
 // input from / writes the output to page-locked host memory directly -- for arrays touched ONCE per call (a query list, a result
@@ -136,14 +200,8 @@ struct Stage {
       if (up) { if (it.src && it.bytes) std::memcpy(stage, it.src, it.bytes); }
       else if (it.dst && it.bytes) std::memcpy(it.dst, stage, it.bytes);
     };
-    const int T = bytes > ((size_t)4 << 20) ? 8 : 1;
-    if (T == 1) { for (const Item& it : items) one(it); return; }
-    std::atomic<size_t> next{0};
-    auto work = [&] { for (;;) { const size_t i = next.fetch_add(1); if (i >= items.size()) break; one(items[i]); } };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    if (bytes <= ((size_t)4 << 20)) { for (const Item& it : items) one(it); return; }
+    HostPool::get().run(items.size(), 8, [&](size_t i) { one(items[i]); });
   }
   template <class T> T* ptr(int i) const {
     return items[i].bytes ? reinterpret_cast<T*>((items[i].mapped ? ctx->hm_dev : d) + items[i].off) : nullptr;
