@@ -429,6 +429,136 @@ __device__ void win_accumulate_landmarks(const BaWin& W) {
 // packed lower triangle: row i starts at i (i + 1) / 2
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
+// Cholesky of the reduced system in LDS (packed lower triangle), in place; diag receives L_kk.  Entry (i, j) receives its subtractions
+// L(i, k) L(j, k) in ascending k, as the row-wise dot products of the envelope factorisation apply them; L(i, j) = s / L(j, j) by IEEE
+// division, L(j, j) = sqrt(s).  Six columns (one camera) at a time -- two barriers per camera instead of two per column: every thread
+// factorises the 6 x 6 diagonal block for itself (the same 21 words, the same operations: the same bits in every thread), then its
+// rows' six entries of the panel, column by column; the trailing entries then take the six columns' subtractions in ascending k.
+// Every entry sees the operations of the column-by-column form in the same order: identical bits.  The panel also goes to Lp
+// (n x 7 doubles: an odd pitch in 8-byte words keeps the sixteen rows a half-wave reads apart on different LDS banks; read out of the
+// packed triangle, whose rows start at i (i + 1) / 2, the trailing update spent most of its time in bank conflicts).
+// EXACT = false (the cluster form, whose contract is a tolerance): the pivots' reciprocal square roots (v_rsq_f64 + two Newton steps) and
+// multiplications replace the IEEE square roots and divisions -- the six-pivot chain of a camera's diagonal block is what a step waits
+// for (six dependent sqrt + div pairs, ~300 cycles each); 1 / L_kk is kept in column 6 of Lp for the substitution.
+__device__ __forceinline__ double w_rsqrt_refined(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-v * y, y, 1.0), y);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-v * y, y, 1.0), y);
+  return y;
+}
+template <bool EXACT>
+__device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, double* __restrict__ Lp, int n) {
+  const int tid = threadIdx.x;
+  constexpr int NT = kWinThreads;
+  bool ok = true;
+  for (int k0 = 0; k0 < n && ok; k0 += 6) {
+    double Ld[21], dg[6], rdg[6];    // the diagonal block's factor (lower, packed), its L_kk and (EXACT = false) 1 / L_kk
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int c = 0; c <= a; c++) {
+        double v = S[tri(k0 + a, k0 + c)];
+#pragma unroll
+        for (int k = 0; k < c; k++) v -= Ld[a * (a + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
+        if (a == c) {
+          if (!(v > 0)) ok = false;              // uniform: every thread computes the same word
+          if constexpr (EXACT) { dg[a] = sqrt(v); rdg[a] = 0.0; }
+          else { rdg[a] = w_rsqrt_refined(v > 0 ? v : 1.0); dg[a] = v * rdg[a]; }
+          Ld[a * (a + 1) / 2 + a] = v;
+        } else {
+          if constexpr (EXACT) Ld[a * (a + 1) / 2 + c] = v / dg[c]; else Ld[a * (a + 1) / 2 + c] = v * rdg[c];
+        }
+      }
+    }
+    if (!ok) break;
+    // (no barrier here: the panel reads rows below the block and writes them and Lp, which the previous step's update has finished with
+    //  behind its closing barrier; the block's own factor is written once everybody has read the block -- behind the panel's barrier)
+    for (int i = k0 + 6 + tid; i < n; i += NT) {
+      double* row = S + tri(i, k0);
+      double l[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = row[c];
+#pragma unroll
+        for (int k = 0; k < c; k++) v -= l[k] * Ld[c * (c + 1) / 2 + k];
+        if constexpr (EXACT) l[c] = v / dg[c]; else l[c] = v * rdg[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) { row[c] = l[c]; Lp[7 * i + c] = l[c]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        diag[k0 + a] = dg[a];
+        if constexpr (!EXACT) Lp[7 * (k0 + a) + 6] = rdg[a];
+#pragma unroll
+        for (int c = 0; c < a; c++) S[tri(k0 + a, k0 + c)] = Ld[a * (a + 1) / 2 + c];
+      }
+    }
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int i = k0 + 6 + ty; i < n; i += NT / 16) {
+      const double* ri = Lp + 7 * i;
+      const double li0 = ri[0], li1 = ri[1], li2 = ri[2], li3 = ri[3], li4 = ri[4], li5 = ri[5];
+      double* Si = S + tri(i, 0);
+      for (int j = k0 + 6 + tx; j <= i; j += 16) {
+        const double* rj = Lp + 7 * j;
+        double v = Si[j];
+        v -= li0 * rj[0]; v -= li1 * rj[1]; v -= li2 * rj[2]; v -= li3 * rj[3]; v -= li4 * rj[4]; v -= li5 * rj[5];
+        Si[j] = v;
+      }
+    }
+    __syncthreads();
+  }
+  return ok;
+}
+// forward substitution: y(i) = (b(i) - sum_{j < i} L(i, j) y(j)) / L(i, i), the subtractions in ascending j; then backward:
+// x(i) /= L(i, i); x(j) -= L(i, j) x(i) for j < i, i descending.  ONE wave (the caller's wave 0), a camera's six unknowns per step:
+// every lane forms the six values for itself, then applies them to its rows in the order of the one-at-a-time form.
+template <bool EXACT>
+__device__ void win_substitute(const double* __restrict__ S, const double* __restrict__ diag, const double* __restrict__ Lp, double* __restrict__ rhs, int n) {
+  const int lane = threadIdx.x & 63;
+  for (int k0 = 0; k0 < n; k0 += 6) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double y[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double v = rhs[k0 + a];
+#pragma unroll
+      for (int c = 0; c < a; c++) v -= S[tri(k0 + a, k0 + c)] * y[c];
+      if constexpr (EXACT) y[a] = v / diag[k0 + a]; else y[a] = v * Lp[7 * (k0 + a) + 6];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) { double yv = y[0]; yv = lane == 1 ? y[1] : yv; yv = lane == 2 ? y[2] : yv; yv = lane == 3 ? y[3] : yv; yv = lane == 4 ? y[4] : yv; yv = lane == 5 ? y[5] : yv; rhs[k0 + lane] = yv; }
+    for (int r = k0 + 6 + lane; r < n; r += 64) {
+      const double* rr = S + tri(r, k0);
+      double v = rhs[r];
+#pragma unroll
+      for (int a = 0; a < 6; a++) v -= rr[a] * y[a];
+      rhs[r] = v;
+    }
+  }
+  for (int k0 = n - 6; k0 >= 0; k0 -= 6) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double x6[6];
+#pragma unroll
+    for (int a = 5; a >= 0; a--) {
+      double v = rhs[k0 + a];
+#pragma unroll
+      for (int c = 5; c > a; c--) v -= S[tri(k0 + c, k0 + a)] * x6[c];
+      if constexpr (EXACT) x6[a] = v / diag[k0 + a]; else x6[a] = v * Lp[7 * (k0 + a) + 6];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
+    for (int j = lane; j < k0; j += 64) {
+      double v = rhs[j];
+#pragma unroll
+      for (int a = 5; a >= 0; a--) v -= S[tri(k0 + a, j)] * x6[a];
+      rhs[j] = v;
+    }
+  }
+}
+
 // solve(lambda), first half (block_solver.hpp:381-439): Dinv = (Hll + lambda I)^-1 per landmark, then landmark by landmark, per landmark
 // every (edge, edge) pair of free cameras: Hschur(i1, i2) -= (W1 Dinv) W2^T, bschur(i1) -= W1 Dinv bl.  S and rhs live in LDS and start
 // as Hpp + lambda I / bp.  The landmarks stream through LDS in chunks of whole landmarks: their Hll | bl and their W rows arrive by the
@@ -696,113 +826,11 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
       lap(3);
       win_schur(W, S, rhs, stage, lambda);
       lap(4);
-      // ---- Cholesky: entry (i, j) receives its subtractions L(i, k) L(j, k) in ascending k, as the row-wise dot products of the
-      // envelope factorisation apply them; L(i, j) = s / L(j, j) by IEEE division, L(j, j) = sqrt(s)
-      // Six columns (one camera) at a time -- two barriers per camera instead of two per column: every thread factorises the 6 x 6
-      // diagonal block for itself (the same 21 words, the same operations: the same bits in every thread), then its rows' six
-      // entries of the panel, column by column; the trailing entries then take the six columns' subtractions in ascending k.  Every
-      // entry sees the operations of the column-by-column form in the same order: identical bits.
-      bool ok = true;
-      for (int k0 = 0; k0 < n && ok; k0 += 6) {
-        double Ld[21], dg[6];            // the diagonal block's factor (lower, packed) and its L_kk
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-          for (int c = 0; c <= a; c++) {
-            double v = S[tri(k0 + a, k0 + c)];
-#pragma unroll
-            for (int k = 0; k < c; k++) v -= Ld[a * (a + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
-            if (a == c) {
-              if (!(v > 0)) ok = false;              // uniform: every thread computes the same word
-              dg[a] = sqrt(v);
-              Ld[a * (a + 1) / 2 + a] = v;
-            } else Ld[a * (a + 1) / 2 + c] = v / dg[c];
-          }
-        }
-        if (!ok) break;
-        __syncthreads();                 // (everybody has read the block before its owner overwrites it)
-        if (tid == 0) {
-#pragma unroll
-          for (int a = 0; a < 6; a++) {
-            diag[k0 + a] = dg[a];
-#pragma unroll
-            for (int c = 0; c < a; c++) S[tri(k0 + a, k0 + c)] = Ld[a * (a + 1) / 2 + c];
-          }
-        }
-        for (int i = k0 + 6 + tid; i < n; i += NT) {
-          double* row = S + tri(i, k0);
-          double l[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            double v = row[c];
-#pragma unroll
-            for (int k = 0; k < c; k++) v -= l[k] * Ld[c * (c + 1) / 2 + k];
-            l[c] = v / dg[c];
-          }
-#pragma unroll
-          for (int c = 0; c < 6; c++) row[c] = l[c];
-        }
-        __syncthreads();
-        const int tx = tid & 15, ty = tid >> 4;
-        for (int i = k0 + 6 + ty; i < n; i += NT / 16) {
-          const double* ri = S + tri(i, k0);
-          const double li0 = ri[0], li1 = ri[1], li2 = ri[2], li3 = ri[3], li4 = ri[4], li5 = ri[5];
-          for (int j = k0 + 6 + tx; j <= i; j += 16) {
-            const double* rj = S + tri(j, k0);
-            double v = S[tri(i, j)];
-            v -= li0 * rj[0]; v -= li1 * rj[1]; v -= li2 * rj[2]; v -= li3 * rj[3]; v -= li4 * rj[4]; v -= li5 * rj[5];
-            S[tri(i, j)] = v;
-          }
-        }
-        __syncthreads();
-      }
+      // ---- Cholesky + substitution of the reduced system (win_cholesky / win_substitute: the column-by-column operation order)
+      const bool ok = win_cholesky<true>(S, diag, ctl + 64, n);       // (Lp: the streaming area is idle during the solve)
       lap(5);
       if (ok) {
-        // forward substitution: y(i) = (b(i) - sum_{j < i} L(i, j) y(j)) / L(i, i), the subtractions in ascending j; then backward:
-        // x(i) /= L(i, i); x(j) -= L(i, j) x(i) for j < i, i descending.  One wave, a camera's six unknowns per step: every lane forms the
-        // six values for itself, then applies them to its rows in the order of the one-at-a-time form.
-        if (wave == 0) {
-          const int lane = tid;
-          for (int k0 = 0; k0 < n; k0 += 6) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double y[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-              double v = rhs[k0 + a];
-#pragma unroll
-              for (int c = 0; c < a; c++) v -= S[tri(k0 + a, k0 + c)] * y[c];
-              y[a] = v / diag[k0 + a];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 6) { double yv = y[0]; yv = lane == 1 ? y[1] : yv; yv = lane == 2 ? y[2] : yv; yv = lane == 3 ? y[3] : yv; yv = lane == 4 ? y[4] : yv; yv = lane == 5 ? y[5] : yv; rhs[k0 + lane] = yv; }
-            for (int r = k0 + 6 + lane; r < n; r += 64) {
-              const double* rr = S + tri(r, k0);
-              double v = rhs[r];
-#pragma unroll
-              for (int a = 0; a < 6; a++) v -= rr[a] * y[a];
-              rhs[r] = v;
-            }
-          }
-          for (int k0 = n - 6; k0 >= 0; k0 -= 6) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double x6[6];
-#pragma unroll
-            for (int a = 5; a >= 0; a--) {
-              double v = rhs[k0 + a];
-#pragma unroll
-              for (int c = 5; c > a; c--) v -= S[tri(k0 + c, k0 + a)] * x6[c];
-              x6[a] = v / diag[k0 + a];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
-            for (int j = lane; j < k0; j += 64) {
-              double v = rhs[j];
-#pragma unroll
-              for (int a = 5; a >= 0; a--) v -= S[tri(k0 + a, j)] * x6[a];
-              rhs[j] = v;
-            }
-          }
-        }
+        if (wave == 0) win_substitute<true>(S, diag, ctl + 64, rhs, n);
         __syncthreads();
         lap(6);
         for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];
@@ -1251,103 +1279,9 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
         }
         for (int t = tid; t < n; t += NT) rhs[t] = W.rhsg[t];
         __syncthreads();
-        bool ok = true;
-        for (int k0 = 0; k0 < n && ok; k0 += 6) {
-          double Ld[21], dg[6];
-#pragma unroll
-          for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int c = 0; c <= a; c++) {
-              double v = S[tri(k0 + a, k0 + c)];
-#pragma unroll
-              for (int k = 0; k < c; k++) v -= Ld[a * (a + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
-              if (a == c) {
-                if (!(v > 0)) ok = false;
-                dg[a] = sqrt(v);
-                Ld[a * (a + 1) / 2 + a] = v;
-              } else Ld[a * (a + 1) / 2 + c] = v / dg[c];
-            }
-          }
-          if (!ok) break;
-          __syncthreads();
-          if (tid == 0) {
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-              diag[k0 + a] = dg[a];
-#pragma unroll
-              for (int c = 0; c < a; c++) S[tri(k0 + a, k0 + c)] = Ld[a * (a + 1) / 2 + c];
-            }
-          }
-          for (int i = k0 + 6 + tid; i < n; i += NT) {
-            double* row = S + tri(i, k0);
-            double l[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-              double v = row[c];
-#pragma unroll
-              for (int k = 0; k < c; k++) v -= l[k] * Ld[c * (c + 1) / 2 + k];
-              l[c] = v / dg[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) row[c] = l[c];
-          }
-          __syncthreads();
-          const int tx = tid & 15, ty = tid >> 4;
-          for (int i = k0 + 6 + ty; i < n; i += NT / 16) {
-            const double* ri = S + tri(i, k0);
-            const double li0 = ri[0], li1 = ri[1], li2 = ri[2], li3 = ri[3], li4 = ri[4], li5 = ri[5];
-            for (int j = k0 + 6 + tx; j <= i; j += 16) {
-              const double* rj = S + tri(j, k0);
-              double v = S[tri(i, j)];
-              v -= li0 * rj[0]; v -= li1 * rj[1]; v -= li2 * rj[2]; v -= li3 * rj[3]; v -= li4 * rj[4]; v -= li5 * rj[5];
-              S[tri(i, j)] = v;
-            }
-          }
-          __syncthreads();
-        }
+        const bool ok = win_cholesky<false>(S, diag, ctl + 64, n);     // (Lp: the reduction buffers are idle during the solve)
         if (ok) {
-          if (wave == 0) {
-            const int lane = tid;
-            for (int k0 = 0; k0 < n; k0 += 6) {
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              double y[6];
-#pragma unroll
-              for (int a = 0; a < 6; a++) {
-                double v = rhs[k0 + a];
-#pragma unroll
-                for (int c = 0; c < a; c++) v -= S[tri(k0 + a, k0 + c)] * y[c];
-                y[a] = v / diag[k0 + a];
-              }
-              __builtin_amdgcn_wave_barrier();
-              if (lane < 6) { double yv = y[0]; yv = lane == 1 ? y[1] : yv; yv = lane == 2 ? y[2] : yv; yv = lane == 3 ? y[3] : yv; yv = lane == 4 ? y[4] : yv; yv = lane == 5 ? y[5] : yv; rhs[k0 + lane] = yv; }
-              for (int r = k0 + 6 + lane; r < n; r += 64) {
-                const double* rr = S + tri(r, k0);
-                double v = rhs[r];
-#pragma unroll
-                for (int a = 0; a < 6; a++) v -= rr[a] * y[a];
-                rhs[r] = v;
-              }
-            }
-            for (int k0 = n - 6; k0 >= 0; k0 -= 6) {
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              double x6[6];
-#pragma unroll
-              for (int a = 5; a >= 0; a--) {
-                double v = rhs[k0 + a];
-#pragma unroll
-                for (int c = 5; c > a; c--) v -= S[tri(k0 + c, k0 + a)] * x6[c];
-                x6[a] = v / diag[k0 + a];
-              }
-              __builtin_amdgcn_wave_barrier();
-              if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
-              for (int j = lane; j < k0; j += 64) {
-                double v = rhs[j];
-#pragma unroll
-                for (int a = 5; a >= 0; a--) v -= S[tri(k0 + a, j)] * x6[a];
-                rhs[j] = v;
-              }
-            }
-          }
+          if (wave == 0) win_substitute<false>(S, diag, ctl + 64, rhs, n);
           __syncthreads();
           for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];
         }
