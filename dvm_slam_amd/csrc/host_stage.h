@@ -186,6 +186,24 @@ struct Stage {
   int upload() {
     int rc = d ? DVM_OK : layout();
     if (rc != DVM_OK) return rc;
+    if (in_bytes > ((size_t)8 << 20)) {
+      // a large batch: the inputs go in four pieces, each piece's host copies (pooled threads) under the previous piece's DMA
+      std::vector<size_t> idx;
+      for (size_t i = 0; i < items.size(); i++) if (items[i].src && !items[i].mapped) idx.push_back(i);
+      for (size_t i = 0; i < items.size(); i++) if (items[i].src && items[i].mapped && items[i].bytes) std::memcpy(ctx->hm + items[i].off, items[i].src, items[i].bytes);
+      size_t first = 0;
+      for (int piece = 0; piece < 4 && first < idx.size(); piece++) {
+        const size_t lo = items[idx[first]].off, want = piece == 3 ? in_bytes : (in_bytes * (piece + 1)) / 4;
+        size_t last = first;
+        while (last < idx.size() && (piece == 3 || items[idx[last]].off + pad(items[idx[last]].bytes) <= want || last == first)) last++;
+        HostPool::get().run(last - first, 8, [&](size_t j) { const Item& it = items[idx[first + j]]; if (it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes); });
+        const size_t hi = last < idx.size() ? items[idx[last]].off : in_bytes;
+        rc = hip_check(hipMemcpyAsync(d + lo, ctx->h + lo, hi - lo, hipMemcpyHostToDevice, ctx->s), "upload");
+        if (rc != DVM_OK) return rc;
+        first = last;
+      }
+      return rc;
+    }
     copy_items(true);
     if (in_bytes) rc = hip_check(hipMemcpyAsync(d, ctx->h, in_bytes, hipMemcpyHostToDevice, ctx->s), "upload");
     return rc;
