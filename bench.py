@@ -257,6 +257,7 @@ def compact(out):
         pass
     try:
         cl["lba_32_windows_one_launch_iterations_per_s"] = round(out["lba_fast"]["value"], 1)
+        cl["lba_32_windows_roofline"] = pick(out["lba_fast"]["roofline"], "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms")
     except Exception:   # noqa: BLE001
         pass
     try:

@@ -522,8 +522,37 @@ def lba_fast(device, K=32, iters=10, repeats=4):
         ts.append(time.perf_counter() - t0)
         its = sum(r["stats"]["iterations"] for r in res)
     best = float(np.median(ts))
+    # roofline of k_ba_window_cluster: ALGORITHMIC bytes of its phases (what each phase has to read and write once, doubles and index words;
+    # DESIGN.md section 3) over the launch's HIP-event duration, against the HBM peak
+    alg = 0.0
+    for w, r in zip(wins, res):
+        e = w["edges"]
+        free = ~np.asarray(w["fixed"], bool)
+        ef = free[e["pose"]]
+        E, F, nact = len(e), int(ef.sum()), len(np.unique(e["point"]))
+        deg = np.bincount(e["point"][ef])
+        pairs = float((deg * (deg + 1) // 2).sum())
+        per_iteration = 152.0 * E + 264.0 * F + 80.0 * E + 120.0 * F + 96.0 * nact                 # edge pass with Jacobians; Hll / bl, Hpp / bp
+        per_trial = 432.0 * F + 48.0 * F + 288.0 * pairs + 168.0 * F + 24.0 * F + 196.0 * nact + 88.0 * E   # T rows; rhs + blocks; W^T x; landmarks; chi2 pass + sums
+        alg += per_iteration * r["stats"]["iterations"] + per_trial * sum(r["stats"]["trials"])
+    k_ms = res[0]["stats"]["kernel_us"] / 1e3
+    traffic = None
+    try:   # counter traffic of the same launch shape (K = 32: 256 workgroups) from the committed separate --pmc passes, calibrated as the main fold
+        import csv
+        import json
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))["calibration"]
+        tot = 0.0
+        for cn, fac in (("FETCH_SIZE", cal["read"]["8"]), ("WRITE_SIZE", cal["write"]["8"])):
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r06_pmc_lba_cluster_{cn}.csv"))) if int(r["Grid_Size"]) == 512 * 8 * 32]
+            tot += float(np.mean(v)) * 1024.0 * fac
+        traffic = tot if K == 32 else None
+    except Exception:   # noqa: BLE001
+        traffic = None
+    roof = {"bound": "hbm", "kernel": "k_ba_window_cluster", "achieved": alg / (k_ms / 1e3) / 1e9 if k_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None, "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms, "traffic": traffic,
+            "note": "algorithmic bytes of the data-parallel phases / the launch's HIP-event duration; counter traffic: profiles/r06_pmc_lba_cluster_*.csv"}
     return {"value": its / best, "unit": "LM iterations/s summed over the K windows of a call (host arrays in, results out)", "K": K, "ms_per_call": best * 1e3,
-            "iterations": its, "call": "dvm_ba_optimize_windows_fast", "ms_upload_launch_download": res[0]["stats"]["ms_optimize"]}
+            "iterations": its, "call": "dvm_ba_optimize_windows_fast", "ms_upload_launch_download": res[0]["stats"]["ms_optimize"], "roofline": roof}
 
 
 def ba_cold(device, iters=10, runs=5, idle_s=2.0):

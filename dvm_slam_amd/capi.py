@@ -45,7 +45,7 @@ class BaCamera(C.Structure):
 
 
 class BaStats(C.Structure):
-    _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("stop_reason", C.c_int32), ("pad", C.c_int32),
+    _fields_ = [("iterations", C.c_int32), ("total_trials", C.c_int32), ("stop_reason", C.c_int32), ("kernel_us", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
                 ("trials_per_iter", C.c_int32 * 64), ("chi2_per_iter", C.c_double * 64),
                 ("lambda_per_iter", C.c_double * 64), ("ms_structure", C.c_double), ("ms_optimize", C.c_double),
@@ -706,7 +706,7 @@ class BaWindowBatch:
             n = min(st.iterations, 64)
             o["stats"] = dict(iterations=st.iterations, total_trials=st.total_trials, stop_reason=st.stop_reason, chi2_initial=st.chi2_initial,
                               chi2_final=st.chi2_final, lambda_final=st.lambda_final, trials=st.trials_per_iter[:n], chi2=st.chi2_per_iter[:n],
-                              lam=st.lambda_per_iter[:n], ms_structure=st.ms_structure, ms_optimize=st.ms_optimize)
+                              lam=st.lambda_per_iter[:n], ms_structure=st.ms_structure, ms_optimize=st.ms_optimize, kernel_us=st.kernel_us)
         return self.outs
 
 

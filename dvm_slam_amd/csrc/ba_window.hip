@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
   double* stage = ctl + 64 + 256;                   // streaming area of the chunked passes                   [stage_doubles]
   dvm_ba_stats* const st = W.stats;                 // written by thread 0 only
   if (tid == 0) {
-    st->iterations = st->total_trials = st->stop_reason = st->pad = 0;
+    st->iterations = st->total_trials = st->stop_reason = st->kernel_us = 0;
     st->chi2_initial = st->chi2_final = st->lambda_final = 0;
     for (int i = 0; i < 64; i++) { st->trials_per_iter[i] = 0; st->chi2_per_iter[i] = 0; st->lambda_per_iter[i] = 0; }
     st->ms_structure = st->ms_optimize = 0; st->spec_trials = st->spec_kept = 0;
@@ -1213,7 +1213,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
 #define s_flag (*s_flag_p)
   dvm_ba_stats* const st = W.stats;
   if (leader && tid == 0) {
-    st->iterations = st->total_trials = st->stop_reason = st->pad = 0;
+    st->iterations = st->total_trials = st->stop_reason = st->kernel_us = 0;
     st->chi2_initial = st->chi2_final = st->lambda_final = 0;
     for (int i = 0; i < 64; i++) { st->trials_per_iter[i] = 0; st->chi2_per_iter[i] = 0; st->lambda_per_iter[i] = 0; }
     st->ms_structure = st->ms_optimize = 0; st->spec_trials = st->spec_kept = 0;
@@ -1788,6 +1788,8 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
   // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
   int G = 1;
+  struct KernelEvents { hipEvent_t a = nullptr, b = nullptr; ~KernelEvents() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } };
+  thread_local KernelEvents kev;     // the launch's duration -> dvm_ba_stats::kernel_us (the fast form's roofline figure in bench_legs.lba_fast)
   if (fast) {
     // the cluster size: the largest of 8 / 4 / 2 / 1 workgroups per window whose grid (8 * ceil(K / 8) * G workgroups, one per CU: the
     // reduced system's LDS) is resident at once; forced by `cluster` (the G = 1 repeat after a barrier time-out) or DVM_BA_CLUSTER
@@ -1799,7 +1801,10 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     const int groups = 8 * ((K + 7) / 8);
     for (int g = 8; g >= 1; g >>= 1) if ((want > 0 && g == want) || (want <= 0 && groups * g <= cus)) { G = g; break; }
     DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (!kev.a) { DVM_HIP(hipEventCreate(&kev.a)); DVM_HIP(hipEventCreate(&kev.b)); }
+    hipEventRecord(kev.a, st.stream());
     hipLaunchKernelGGL(k_ba_window_cluster, dim3(groups * G), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d, K, G);
+    hipEventRecord(kev.b, st.stream());
   }
   else hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);
   DVM_HIP(hipGetLastError());
@@ -1837,6 +1842,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     if (w.depth_positive_out && B[k].E) std::memcpy(w.depth_positive_out, outs[k].depth.data(), (size_t)B[k].E);
     if (stats) {
       stats[k] = outs[k].st;
+      if (fast && kev.a) { float ms = 0; if (hipEventElapsedTime(&ms, kev.a, kev.b) == hipSuccess) stats[k].kernel_us = (int32_t)(ms * 1e3f + 0.5f); }
       stats[k].ms_structure = std::chrono::duration<double, std::milli>(t1 - t0).count() / K;
       stats[k].ms_optimize = std::chrono::duration<double, std::milli>(t2 - t1).count();     // the whole batch: upload, the one launch, download
     }

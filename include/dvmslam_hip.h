@@ -400,7 +400,8 @@ int dvm_match_frames_batch(const dvm_frame* train, int first_slot, int count, co
 typedef struct { int32_t pose, point; double u, v, inv_sigma2; } dvm_ba_edge;
 typedef struct { double fx, fy, cx, cy, huber_delta; /* <= 0: no robust kernel (bRobust=false) */ } dvm_ba_camera;
 typedef struct {
-  int32_t iterations, total_trials, stop_reason, pad; /* stop: 0 iteration budget / stop flag, 1 LM terminate, 2 Mur-Artal criterion */
+  int32_t iterations, total_trials, stop_reason, kernel_us; /* stop: 0 iteration budget / stop flag, 1 LM terminate, 2 Mur-Artal criterion;
+                                                          kernel_us: dvm_ba_optimize_windows_fast only -- the launch's duration (HIP events), 0 elsewhere */
   double chi2_initial, chi2_final, lambda_final;
   int32_t trials_per_iter[64];
   double chi2_per_iter[64], lambda_per_iter[64];
