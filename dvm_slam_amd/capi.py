@@ -928,6 +928,82 @@ class Tracker:
         return out
 
 
+class TrackIn(C.Structure):
+    """dvmh_track_in (include/dvmslam_host.h)"""
+    _fields_ = [("Tcw_pred", C.c_void_p), ("Nl", C.c_int32), ("kps_l", C.c_void_p), ("mp_l", C.c_void_p), ("outlier_l", C.c_void_p), ("mps", C.c_void_p)]
+
+
+class TrackOut(C.Structure):
+    """dvmh_track_out (include/dvmslam_host.h)"""
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("cap", C.c_int32), ("kps_un", C.c_void_p), ("mp_c", C.c_void_p), ("dropped", C.c_void_p)]
+
+
+class TrackerBatch:
+    """dvm_tracker_create_batch + dvmh_track_with_motion_model_batch: the tracked frames of up to max_frames agents as ONE chain of batched
+    launches.  ext: an OrbExtractor with max_batch >= max_frames."""
+
+    def __init__(self, ext: "OrbExtractor", max_frames, device=0):
+        self.L, self.H, self.ext, self.device, self.max_frames = lib(), host_lib(), ext, device, int(max_frames)
+        self.t = C.c_void_p()
+        f = self.L.dvm_tracker_create_batch
+        f.restype = C.c_int32; f.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        check(f(device, self.max_frames, ext.cap, ext.cap, C.byref(self.t)))
+        cap, B = ext.cap, self.max_frames
+        self.kps = np.empty((B, cap), KP_DTYPE); self.kun = np.empty((B, cap), KP_DTYPE); self.desc = np.empty((B, cap, 32), np.uint8)
+        self.mp = np.empty((B, cap), np.int32); self.dropped = np.empty((B, cap), np.int32)
+        self.res = (TrackResult * B)()
+        self.outs = (TrackOut * B)()
+        for b in range(B):
+            o = self.outs[b]
+            o.kps, o.desc, o.cap, o.kps_un = self.kps[b].ctypes.data, self.desc[b].ctypes.data, cap, self.kun[b].ctypes.data
+            o.mp_c, o.dropped = self.mp[b].ctypes.data, self.dropped[b].ctypes.data
+
+    def close(self):
+        if getattr(self, "t", None) and self.t.value:
+            f = self.L.dvm_tracker_destroy
+            f.restype = None; f.argtypes = [C.c_void_p]
+            f(self.t)
+            self.t = C.c_void_p()
+
+    __del__ = close
+
+    def prepare(self, Tcw_preds, lasts):
+        """lasts: per agent (kps_l, mp_l, outlier_l or None, mps).  Returns the marshalled dvmh_track_in array (keep it alive with its arrays)."""
+        n = len(lasts)
+        ins = (TrackIn * n)()
+        keep = []
+        for b, (T, (kl, ml, ol, mps)) in enumerate(zip(Tcw_preds, lasts)):
+            T = np.ascontiguousarray(T, np.float32); kl = np.ascontiguousarray(kl, KP_DTYPE); ml = np.ascontiguousarray(ml, np.int32)
+            ol = None if ol is None else np.ascontiguousarray(ol, np.uint8); mps = np.ascontiguousarray(mps, MAP_POINT_DTYPE)
+            keep.append((T, kl, ml, ol, mps))
+            i = ins[b]
+            i.Tcw_pred, i.Nl, i.kps_l, i.mp_l, i.outlier_l, i.mps = T.ctypes.data, len(kl), kl.ctypes.data, ml.ctypes.data, None if ol is None else ol.ctypes.data, mps.ctypes.data
+        return ins, keep
+
+    def track(self, imgs, ins, K, bounds, scale_factors, inv_sigma2, th=15.0, check_ori=True, lap=(0, 1000)):
+        """imgs [count, rows, cols] u8; ins: prepare()'s array.  Returns one dict per frame (views into this object's arrays)."""
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        count = imgs.shape[0]
+        f4 = [np.ascontiguousarray(a, np.float32) for a in (K, bounds, scale_factors, inv_sigma2)]
+        fn = self.H.dvmh_track_with_motion_model_batch
+        fn.restype = C.c_int32; fn.argtypes = None
+        vp = C.c_void_p
+        rc = fn(self.t, self.ext.h, C.c_int32(self.device), C.c_int32(count), vp(imgs.ctypes.data), C.c_int32(imgs.shape[1]), C.c_int32(imgs.shape[2]),
+                C.c_int32(imgs.strides[1]), C.c_int64(imgs.strides[0]), C.c_int32(lap[0]), C.c_int32(lap[1]), _p(f4[0]), _p(f4[1]), _p(f4[2]), _p(f4[3]),
+                C.c_int32(len(f4[2])), C.c_float(float(th)), C.c_int32(int(check_ori)), ins[0] if isinstance(ins, tuple) else ins, self.outs, self.res)
+        check(rc)
+        out = []
+        for b in range(count):
+            r = self.res[b]
+            n = r.n
+            d = {k: getattr(r, k) for k in ("n", "mono_index", "nmatches", "nmatches_search", "nmatches_map", "n_inliers", "wide_window", "replayed_on_host",
+                                            "tracked", "n_requeried")}
+            d.update(kps=self.kps[b, :n], kps_un=self.kun[b, :n], desc=self.desc[b, :n], mp=self.mp[b, :n], dropped=self.dropped[b, :n],
+                     pose=np.array(r.pose[:], np.float64), Tcw=np.array(r.Tcw[:], np.float32))
+            out.append(d)
+        return out
+
+
 TRACKED_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("depth", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
                                 ("in_view", "u1"), ("bad", "u1"), ("pad", "u1", (2,)), ("desc", "u1", (32,)), ("n_obs", "<i4")])
 

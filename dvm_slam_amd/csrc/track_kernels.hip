@@ -32,12 +32,24 @@ constexpr int kHisto = 30;   // HISTO_LENGTH, ORBmatcher.cc:38
 // Outputs: assign[j] = the query matched to keypoint j at the end of the call or -1; res[0] = nmatches, res[1] = 1 if such a query could
 // not be searched again here (RQ.F.skp == nullptr: the caller then repeats the epilogue on the host), res[2] = matches before the
 // rotation check, res[3] = queries searched again.
+// blockIdx.x = frame of a batch (dvm_track_finish_batch: K agents' frames in one chain): frame b's per-query arrays lie at b * B.qstride
+// elements, its keypoints at b * B.kps_stride, its grid in slot b, its results at b * kp_cap / b * 8; a single frame is the batch of one.
 __global__ void __launch_bounds__(256) k_track_claims(const uint32_t* __restrict__ ranked, const uint8_t* __restrict__ q_claims,
                                                       const float* __restrict__ q_angle, int nq, TrackRequery RQ, const dvm_keypoint_pod* __restrict__ kps,
                                                       const int32_t* __restrict__ d_n, int kp_cap, int th_high, int check_ori,
                                                       int32_t* __restrict__ assign, int32_t* __restrict__ res, int32_t* __restrict__ assign_host,
-                                                      int32_t* __restrict__ res_host) {
+                                                      int32_t* __restrict__ res_host, TrackBatch B) {
   extern __shared__ __attribute__((aligned(16))) uint8_t track_smem[];
+  {
+    const int b = blockIdx.x;
+    if (B.nq_arr) nq = B.nq_arr[b];
+    const size_t qo = (size_t)b * B.qstride;
+    ranked += qo * 4; q_claims += qo; q_angle += qo;
+    RQ.qdesc += qo * 32; RQ.qx += qo; RQ.qy += qo; RQ.qr += qo; RQ.qmin += qo; RQ.qmax += qo;
+    if (RQ.F.skp) RQ.F = RQ.F.slot(b);
+    kps += (size_t)b * B.kps_stride; d_n += b;
+    assign += (size_t)b * kp_cap; assign_host += (size_t)b * kp_cap; res += 8 * b; res_host += 8 * b;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = min(*d_n, kp_cap);
   const int nq_pad = (nq + 63) & ~63;
@@ -227,9 +239,15 @@ __global__ void __launch_bounds__(256) k_track_gather(const int32_t* __restrict_
                                                       const float* __restrict__ inv_sigma2, int nlevels, double* __restrict__ Xw,
                                                       double* __restrict__ obs, double* __restrict__ info, int32_t* __restrict__ edge_kp,
                                                       int32_t* __restrict__ n_edges, const int32_t* __restrict__ res, int min_matches,
-                                                      int32_t* __restrict__ n_edges_host) {
+                                                      int32_t* __restrict__ n_edges_host, TrackBatch B) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
+  {
+    const int b = blockIdx.x;
+    assign += (size_t)b * kp_cap; kps_un += (size_t)b * B.kps_stride; d_n += b; q_pos += (size_t)b * B.qstride * 3;
+    Xw += (size_t)b * kp_cap * 3; obs += (size_t)b * kp_cap * 2; info += (size_t)b * kp_cap; edge_kp += (size_t)b * kp_cap;
+    n_edges += b; n_edges_host += b; res += 8 * b;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int N = min(*d_n, kp_cap);
   if (tid == 0) s_base = 0;
@@ -262,8 +280,13 @@ __global__ void __launch_bounds__(256) k_track_gather(const int32_t* __restrict_
 __global__ void __launch_bounds__(256) k_track_finish(int32_t* __restrict__ assign, const int32_t* __restrict__ d_n, int kp_cap,
                                                       const int32_t* __restrict__ edge_kp, const int32_t* __restrict__ n_edges,
                                                       const uint8_t* __restrict__ edge_outlier, const uint8_t* __restrict__ q_claims,
-                                                      uint8_t* __restrict__ outlier, int32_t* __restrict__ out, const int32_t* __restrict__ res) {
+                                                      uint8_t* __restrict__ outlier, int32_t* __restrict__ out, const int32_t* __restrict__ res, TrackBatch B) {
   __shared__ int s_cnt[2];
+  {
+    const int b = blockIdx.x;
+    assign += (size_t)b * kp_cap; d_n += b; edge_kp += (size_t)b * kp_cap; n_edges += b; edge_outlier += (size_t)b * kp_cap;
+    q_claims += (size_t)b * B.qstride; outlier += (size_t)b * kp_cap; out += 4 * b; res += 8 * b;
+  }
   const int tid = threadIdx.x;
   const int N = min(*d_n, kp_cap), E = n_edges[0];
   if (tid < 2) s_cnt[tid] = 0;
@@ -288,21 +311,21 @@ size_t track_claims_lds(int kp_cap, int nq) { const size_t qp = ((size_t)nq + 63
 
 void launch_track_claims(hipStream_t s, const uint32_t* ranked, const uint8_t* q_claims, const float* q_angle, int nq, const TrackRequery& rq,
                          const dvm_keypoint_pod* kps, const int32_t* d_n, int kp_cap, int th_high, int check_ori, int32_t* assign, int32_t* res,
-                         int32_t* assign_host, int32_t* res_host) {
-  const size_t lds = track_claims_lds(kp_cap, nq);
+                         int32_t* assign_host, int32_t* res_host, const TrackBatch& B) {
+  const size_t lds = track_claims_lds(kp_cap, B.count > 1 || B.nq_arr ? B.qstride : nq);
   if (lds > 48 * 1024) raise_dynamic_lds(reinterpret_cast<const void*>(k_track_claims), (int)lds);
-  hipLaunchKernelGGL(k_track_claims, dim3(1), dim3(256), lds, s, ranked, q_claims, q_angle, nq, rq, kps, d_n, kp_cap, th_high,
-                     check_ori, assign, res, assign_host, res_host);
+  hipLaunchKernelGGL(k_track_claims, dim3(B.count), dim3(256), lds, s, ranked, q_claims, q_angle, nq, rq, kps, d_n, kp_cap, th_high,
+                     check_ori, assign, res, assign_host, res_host, B);
 }
 void launch_track_gather(hipStream_t s, const int32_t* assign, const dvm_keypoint_pod* kps_un, const int32_t* d_n, int kp_cap, const float* q_pos,
                          const float* inv_sigma2, int nlevels, double* Xw, double* obs, double* info, int32_t* edge_kp, int32_t* n_edges,
-                         const int32_t* res, int min_matches, int32_t* n_edges_host) {
-  hipLaunchKernelGGL(k_track_gather, dim3(1), dim3(256), 0, s, assign, kps_un, d_n, kp_cap, q_pos, inv_sigma2, nlevels, Xw, obs, info, edge_kp, n_edges,
-                     res, min_matches, n_edges_host);
+                         const int32_t* res, int min_matches, int32_t* n_edges_host, const TrackBatch& B) {
+  hipLaunchKernelGGL(k_track_gather, dim3(B.count), dim3(256), 0, s, assign, kps_un, d_n, kp_cap, q_pos, inv_sigma2, nlevels, Xw, obs, info, edge_kp, n_edges,
+                     res, min_matches, n_edges_host, B);
 }
 void launch_track_finish(hipStream_t s, int32_t* assign, const int32_t* d_n, int kp_cap, const int32_t* edge_kp, const int32_t* n_edges,
-                         const uint8_t* edge_outlier, const uint8_t* q_claims, uint8_t* outlier, int32_t* out, const int32_t* res) {
-  hipLaunchKernelGGL(k_track_finish, dim3(1), dim3(256), 0, s, assign, d_n, kp_cap, edge_kp, n_edges, edge_outlier, q_claims, outlier, out, res);
+                         const uint8_t* edge_outlier, const uint8_t* q_claims, uint8_t* outlier, int32_t* out, const int32_t* res, const TrackBatch& B) {
+  hipLaunchKernelGGL(k_track_finish, dim3(B.count), dim3(256), 0, s, assign, d_n, kp_cap, edge_kp, n_edges, edge_outlier, q_claims, outlier, out, res, B);
 }
 
 }  // namespace dvm

@@ -134,3 +134,121 @@ extern "C" int dvmh_track_with_motion_model(dvm_tracker* t, dvm_orb* h, int devi
   for (int k = 0; k < 4; k++) out->Tcw.q[k] = (float)out->pose[3 + k];
   return DVM_OK;
 }
+
+
+// ---- K agents' frames at one camera tick: dvmh_track_with_motion_model for `count` frames through ONE chain of batched launches
+// (dvm_track_begin_batch / dvm_track_finish_batch).  Per frame exactly the steps of the single call; the queries of the frames are
+// built by a few host threads while the batch extraction runs.
+namespace {
+struct AgentQueries {
+  FrameQueries Q;
+  std::vector<uint8_t> q_claims;
+  std::vector<float> q_angle, q_pos;
+  FrameView C, L;
+  void build(const dvmh_track_in& in, const float* K, const float* bounds, const float* scale_factors, int nlevels, float th) {
+    C = FrameView();
+    C.N = 0; C.Tcw = *in.Tcw_pred;
+    C.fx = K[0]; C.fy = K[1]; C.cx = K[2]; C.cy = K[3];
+    C.mnMinX = bounds[0]; C.mnMaxX = bounds[1]; C.mnMinY = bounds[2]; C.mnMaxY = bounds[3];
+    C.mvScaleFactors = scale_factors; C.nLevels = nlevels;
+    L = C;
+    L.N = in.Nl; L.mvKeysUn = in.kps_l; L.mvpMapPoints = const_cast<int32_t*>(in.mp_l); L.mvbOutlier = in.outlier_l;
+    dvm_host::BuildFrameQueries(C, L, in.mps, th, Q);
+    const int nq = (int)Q.qi.size();
+    q_claims.resize((size_t)nq); q_angle.resize((size_t)nq); q_pos.resize((size_t)nq * 3);
+    for (int q = 0; q < nq; q++) {
+      const int i = Q.qi[q], mp = in.mp_l[i];
+      q_claims[q] = in.mps[mp].n_obs > 0;
+      q_angle[q] = in.kps_l[i].angle;
+      q_pos[3 * q] = in.mps[mp].pos[0]; q_pos[3 * q + 1] = in.mps[mp].pos[1]; q_pos[3 * q + 2] = in.mps[mp].pos[2];
+    }
+  }
+  void fill(dvm_track_queries& tq, const dvmh_track_in& in, const float* K, const float* bounds, const float* inv_level_sigma2, int nlevels, int check_ori) const {
+    std::memset(&tq, 0, sizeof(tq));
+    tq.nq = (int)Q.qi.size(); tq.qdesc = Q.qdesc.data(); tq.qx = Q.qx.data(); tq.qy = Q.qy.data(); tq.qr = Q.qr.data(); tq.qmin = Q.qmin.data(); tq.qmax = Q.qmax.data();
+    tq.q_claims = q_claims.data(); tq.q_angle = q_angle.data(); tq.q_pos = q_pos.data();
+    std::memcpy(tq.bounds, bounds, 16);
+    tq.dist = nullptr; tq.inv_level_sigma2 = inv_level_sigma2; tq.nlevels = nlevels;
+    tq.cam.fx = K[0]; tq.cam.fy = K[1]; tq.cam.cx = K[2]; tq.cam.cy = K[3]; tq.cam.huber_delta = 0.0;
+    for (int k = 0; k < 3; k++) tq.pose_in[k] = (double)in.Tcw_pred->t[k];
+    for (int k = 0; k < 4; k++) tq.pose_in[3 + k] = (double)in.Tcw_pred->q[k];
+    tq.th_high = TH_HIGH; tq.check_ori = check_ori; tq.min_matches = 20;
+  }
+};
+}  // namespace
+
+#include <thread>
+
+extern "C" int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, int device, int count, const uint8_t* imgs, int rows, int cols, int stride,
+                                                  int64_t frame_stride, int lap0, int lap1, const float* K, const float* bounds, const float* scale_factors,
+                                                  const float* inv_level_sigma2, int nlevels, float th, int check_ori, const dvmh_track_in* in,
+                                                  const dvmh_track_out* outs, dvmh_track_result* res) {
+  if (!t || !h || !imgs || !K || !bounds || !scale_factors || !inv_level_sigma2 || !in || !outs || !res || count < 1) return DVM_ERR_INVALID;
+  for (int b = 0; b < count; b++) {
+    if (!in[b].Tcw_pred || (in[b].Nl && (!in[b].kps_l || !in[b].mp_l || !in[b].mps)) || !outs[b].kps || !outs[b].desc || !outs[b].mp_c || !outs[b].dropped) return DVM_ERR_INVALID;
+    std::memset(&res[b], 0, sizeof(res[b]));
+  }
+  (void)device;
+  int rc = dvm_track_begin_batch(t, h, imgs, count, rows, cols, stride, frame_stride, lap0, lap1);
+  if (rc != DVM_OK) return rc;
+  std::vector<AgentQueries> AQ((size_t)count);
+  auto build_all = [&](float scale, const std::vector<uint8_t>* only) {
+    const int T = std::min(count, 8);
+    std::vector<std::thread> pool;
+    auto work = [&](int t0) { for (int b = t0; b < count; b += T) if (!only || (*only)[b]) AQ[b].build(in[b], K, bounds, scale_factors, nlevels, scale * th); };
+    for (int k = 1; k < T; k++) pool.emplace_back(work, k);
+    work(0);
+    for (auto& x : pool) x.join();
+  };
+  build_all(1.0f, nullptr);
+  std::vector<dvm_track_queries> tq((size_t)count);
+  std::vector<dvm_track_frame_out> fo((size_t)count);
+  std::vector<dvm_track_result> tr((size_t)count);
+  std::vector<std::vector<int32_t>> assign((size_t)count);
+  std::vector<std::vector<uint8_t>> outl((size_t)count);
+  std::vector<std::vector<dvm_keypoint>> un_local((size_t)count);
+  for (int b = 0; b < count; b++) {
+    const int cap = outs[b].cap;
+    assign[b].resize((size_t)cap); outl[b].resize((size_t)cap);
+    dvm_keypoint* un = outs[b].kps_un;
+    if (!un) { un_local[b].resize((size_t)cap); un = un_local[b].data(); }
+    fo[b] = dvm_track_frame_out{outs[b].kps, outs[b].desc, cap, un, assign[b].data(), outl[b].data(), nullptr};
+  }
+  std::vector<uint8_t> wide((size_t)count, 0);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    for (int b = 0; b < count; b++) AQ[b].fill(tq[b], in[b], K, bounds, inv_level_sigma2, nlevels, check_ori);
+    rc = dvm_track_finish_batch(t, h, count, tq.data(), fo.data(), tr.data());
+    if (rc != DVM_OK) return rc;
+    bool any = false;
+    if (attempt == 0)
+      for (int b = 0; b < count; b++) if (tr[b].status == DVM_TRACK_FEW_MATCHES) { wide[b] = 1; any = true; }
+    if (!any) break;
+    build_all(2.0f, &wide);          // Tracking.cc:2616-2624: "Not enough matches, wider window search" -- for the frames that need it
+  }
+  for (int b = 0; b < count; b++) {
+    dvmh_track_result* out = &res[b];
+    const dvm_track_result& r = tr[b];
+    const int N = r.n;
+    int32_t* mp_c = outs[b].mp_c; int32_t* dropped = outs[b].dropped;
+    out->n = r.n; out->mono_index = r.mono_index; out->n_requeried = r.n_requeried; out->wide_window = wide[b];
+    for (int j = 0; j < N; j++) { mp_c[j] = -1; dropped[j] = -1; }
+    out->nmatches_search = r.nmatches;
+    if (r.status != DVM_TRACK_COMPLETE) {     // not tracked: the matches of the (doubled) search stay as SearchByProjection left them
+      for (int j = 0; j < N; j++) if (assign[b][j] >= 0) mp_c[j] = in[b].mp_l[AQ[b].Q.qi[assign[b][j]]];
+      out->nmatches = r.nmatches; out->tracked = 0; out->Tcw = *in[b].Tcw_pred;
+      for (int k = 0; k < 3; k++) out->pose[k] = (double)in[b].Tcw_pred->t[k];
+      for (int k = 0; k < 4; k++) out->pose[3 + k] = (double)in[b].Tcw_pred->q[k];
+      continue;
+    }
+    for (int j = 0; j < N; j++) {
+      if (assign[b][j] < 0) continue;
+      const int mp = in[b].mp_l[AQ[b].Q.qi[assign[b][j]]];
+      if (outl[b][j]) dropped[j] = mp; else mp_c[j] = mp;
+    }
+    out->nmatches = r.nmatches_after; out->nmatches_map = r.nmatches_map; out->n_inliers = r.n_inliers; out->tracked = 1;
+    std::memcpy(out->pose, r.pose, 56);
+    for (int k = 0; k < 3; k++) out->Tcw.t[k] = (float)out->pose[k];
+    for (int k = 0; k < 4; k++) out->Tcw.q[k] = (float)out->pose[3 + k];
+  }
+  return DVM_OK;
+}

@@ -593,6 +593,19 @@ typedef struct {
   double pose[7];                  /* the optimised Tcw */
 } dvm_track_result;
 int dvm_tracker_create(int device, int max_keypoints, int max_queries, dvm_tracker** out);
+/* The same for up to max_frames frames per call -- the frames of several agents sharing the GPU at one camera tick: ONE chain of batched
+ * launches (extraction of the batch, max_frames grids, ranked searches, claim replays and PoseOptimizations side by side, a workgroup per
+ * frame) behind ONE synchronisation.  The extractor handle needs max_batch >= count.  The frames of a call share camera, image bounds,
+ * level table and matcher thresholds, and are not undistorted here (k1 != 0: the single-frame call).  Frame b's results equal
+ * dvm_track_begin / dvm_track_finish on that frame alone, bit for bit. */
+typedef struct {
+  dvm_keypoint* kps; uint8_t* desc; int32_t cap;   /* [cap] the extraction (as dvm_orb_extract) */
+  dvm_keypoint* kps_un;                            /* [cap] or NULL: mvKeysUn */
+  int32_t* assign; uint8_t* outlier;               /* [cap] as dvm_track_finish */
+  uint32_t* ranked;                                /* NULL, or [nq][4] (REPLAY_ON_HOST only) */
+} dvm_track_frame_out;
+int dvm_tracker_create_batch(int device, int max_frames, int max_keypoints, int max_queries, dvm_tracker** out);
+int dvm_track_begin_batch(dvm_tracker* t, dvm_orb* h, const uint8_t* imgs, int count, int rows, int cols, int stride, int64_t frame_stride, int lap0, int lap1);
 void dvm_tracker_destroy(dvm_tracker* t);
 int dvm_track_begin(dvm_tracker* t, dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1);
 /* kps / desc [cap]: the extraction; kps_un (may be NULL): mvKeysUn; assign [cap]: per keypoint the index of the query matched to it or -1
@@ -600,6 +613,9 @@ int dvm_track_begin(dvm_tracker* t, dvm_orb* h, const uint8_t* img, int rows, in
  * NULL): [nq][4] candidate lists, filled for REPLAY_ON_HOST only.  May be called again after one dvm_track_begin (wider window). */
 int dvm_track_finish(dvm_tracker* t, dvm_orb* h, const dvm_track_queries* q, dvm_keypoint* kps, uint8_t* desc, int cap, dvm_keypoint* kps_un,
                      int32_t* assign, uint8_t* outlier, uint32_t* ranked, dvm_track_result* res);
+/* qs / outs / res: `count` entries, frame b of the dvm_track_begin_batch call.  A frame with fewer than min_matches matches reports
+ * DVM_TRACK_FEW_MATCHES; the call may be repeated (all frames, the wider queries for those) after one begin. */
+int dvm_track_finish_batch(dvm_tracker* t, dvm_orb* h, int count, const dvm_track_queries* qs, const dvm_track_frame_out* outs, dvm_track_result* res);
 
 /* Optimizer::OptimizeSim3 (Optimizer.cc:1960-2212), numerics for N correspondences gathered by the caller:
  * P1c / P2c = the matched map points in their own key frame's camera frame (R1w*P+t1w, R2w*P+t2w), obs1 / obs2 =

@@ -117,6 +117,25 @@ int dvmh_track_with_motion_model(dvm_tracker* t, dvm_orb* h, int device, const u
                                  dvm_keypoint* kps, uint8_t* desc, int cap, dvm_keypoint* kps_un, int32_t* mp_c, int32_t* dropped,
                                  dvmh_track_result* out);
 
+/* The same for `count` frames at once -- the frames of several agents sharing the GPU at one camera tick (dvm_tracker_create_batch with
+ * max_frames >= count; an extractor handle with max_batch >= count): ONE chain of batched launches behind ONE synchronisation, the frames'
+ * queries built by a few host threads while the batch extraction runs.  imgs: frame b at imgs + b * frame_stride.  The frames share K,
+ * bounds, the level tables, th and check_ori (one camera model per call); distortion is not applied (k1 != 0: the single call).
+ * Frame b's outputs equal dvmh_track_with_motion_model on that frame alone, bit for bit. */
+typedef struct {
+  const dvm_se3f* Tcw_pred;                  /* mVelocity * mLastFrame.GetPose() of this agent */
+  int32_t Nl; const dvm_keypoint* kps_l; const int32_t* mp_l; const uint8_t* outlier_l;   /* its LastFrame */
+  const dvmh_map_point* mps;                 /* its map points */
+} dvmh_track_in;
+typedef struct {
+  dvm_keypoint* kps; uint8_t* desc; int32_t cap; dvm_keypoint* kps_un;   /* [cap]; kps_un may be NULL */
+  int32_t *mp_c, *dropped;                   /* [cap] as in the single call */
+} dvmh_track_out;
+int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, int device, int count, const uint8_t* imgs, int rows, int cols, int stride,
+                                       int64_t frame_stride, int lap0, int lap1, const float* K, const float* bounds, const float* scale_factors,
+                                       const float* inv_level_sigma2, int nlevels, float th, int check_ori, const dvmh_track_in* in,
+                                       const dvmh_track_out* outs, dvmh_track_result* res);
+
 /* SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints), :44-205.  claimed_obs[j] != 0 <=> F.mvpMapPoints[j]->Observations() > 0 */
 int dvmh_search_by_projection_points(int device, int N, const dvm_keypoint* kps, const uint8_t* desc, int32_t* mp, const uint8_t* claimed_obs,
                                      const float* bounds, const float* scale_factors, int nlevels, const dvmh_tracked_point* pts, int npts, float th,

@@ -144,3 +144,42 @@ def test_track_frame_dense_stream_requeries_on_device():
         _check(fused, orc_out, exact_pose=False)
     assert total_rq > 0       # the case this test is for did occur
     trk.close(); ext.close()
+
+
+def test_track_batch_equals_single_frames():
+    """dvmh_track_with_motion_model_batch: the frames of several agents (different streams, different maps, different numbers of queries, one
+    of them with too few matches -> the doubled window) through ONE chain of batched launches: every frame's outputs equal the single call's."""
+    from dvm_slam_amd import capi, synth
+    B = 6
+    ext1 = capi.OrbExtractor(max_batch=1)
+    extB = capi.OrbExtractor(max_batch=B)
+    tab = ext1.tables()
+    scale, inv_s2 = tab["scale"], tab["inv_sigma2"]
+    trk1 = capi.Tracker(ext1)
+    trkB = capi.TrackerBatch(extB, B)
+    dense = synth.frame_stream(8)
+    low = synth.frame_stream(4, texture="low")
+    rng = np.random.default_rng(21)
+    Kc = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    imgs, Ts, lasts, ths = [], [], [], []
+    for b in range(B):
+        stream, t = (low, 1 + b % 3) if b == 2 else (dense, 1 + b)
+        n0, k0, d0, _ = ext1.extract(stream[t - 1])
+        z = rng.uniform(3, 9, n0).astype(np.float32)
+        mps = np.zeros(n0, capi.MAP_POINT_DTYPE)
+        mps["pos"][:, 0] = (k0["x"] - Kc[2]) / Kc[0] * z; mps["pos"][:, 1] = (k0["y"] - Kc[3]) / Kc[1] * z; mps["pos"][:, 2] = z
+        mps["desc"] = d0; mps["n_obs"] = np.where(rng.random(n0) < 0.2, 0, 1)
+        mp_l = np.arange(n0, dtype=np.int32)
+        mp_l[rng.random(n0) < (0.992 if b == 4 else 0.1 * b)] = -1        # agent 4 carries very few map points: fewer than 20 matches, the wide window
+        imgs.append(stream[t]); Ts.append(np.array([0, 0, 0, 1, 0.002 * b, 0, 0], np.float32)); lasts.append((k0.copy(), mp_l, None, mps))
+    ins, keep = trkB.prepare(Ts, lasts)
+    got = trkB.track(np.stack(imgs), ins, Kc, BOUNDS, scale, inv_s2, th=15.0)
+    wide = 0
+    for b in range(B):
+        k0, mp_l, _, mps = lasts[b]
+        one = trk1.track(imgs[b], Ts[b], Kc, BOUNDS, scale, inv_s2, k0, mp_l, None, mps, th=15.0)
+        _check(got[b], one, exact_pose=True)
+        assert got[b]["n_requeried"] == one["n_requeried"] and got[b]["replayed_on_host"] == 0
+        wide += got[b]["wide_window"]
+    assert wide >= 1, [(g["nmatches_search"], g["wide_window"], g["tracked"]) for g in got]
+    trkB.close(); trk1.close(); extB.close(); ext1.close()
