@@ -186,6 +186,10 @@ int dvm_orb_download(dvm_orb* h, int frame, dvm_keypoint* kps, uint8_t* desc, in
   if (!h) return DVM_ERR_INVALID;
   return h->p->download(frame, kps, desc, cap, n, mono_index);
 }
+int dvm_orb_download_batch(dvm_orb* h, int count, dvm_keypoint* const* kps, uint8_t* const* desc, const int* caps, int* n, int* mono_index) {
+  if (!h || !caps) return DVM_ERR_INVALID;
+  return h->p->download_batch(count, kps, desc, caps, n, mono_index);
+}
 int dvm_orb_pyramid(dvm_orb* h, int frame, int level, const uint8_t** d_ptr, int* rows, int* cols, int* stride) {
   if (!h || !h->p->configured) return DVM_ERR_STATE;
   OrbPipeline& P = *h->p;

@@ -352,13 +352,14 @@ void OrbPipeline::free_all() {
   void* dptrs[] = {d_pyr, d_blur, d_tabs, d_cells, d_tiles, d_cand, d_dense, d_cell_count, d_lvl_count, d_sel, d_nsel,
                    d_kps, d_desc, d_aux, d_n, d_mono, d_nid};
   for (void* p : dptrs) if (p) hipFree(p);
-  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono, (void*)h_err, h_kps_m, h_desc_m};
+  void* hptrs[] = {h_cell_count, h_dense, h_sel, h_nsel, h_n, h_mono, (void*)h_err, h_kps_m, h_desc_m, h_kps_b, h_desc_b};
   for (void* p : hptrs) if (p) hipHostFree(p);
   d_pyr = d_blur = d_desc = nullptr; d_tabs = nullptr; d_cells = nullptr; d_tiles = nullptr;
   d_cand = d_dense = d_sel = nullptr; d_cell_count = d_lvl_count = d_nsel = d_n = d_mono = nullptr;
   d_kps = nullptr; d_aux = nullptr; d_nid = nullptr; d_err = nullptr; h_err = nullptr;
   h_cell_count = h_nsel = h_n = h_mono = nullptr; h_dense = h_sel = nullptr;
   h_kps_m = nullptr; h_desc_m = nullptr; last_mirrored = false;
+  h_kps_b = nullptr; h_desc_b = nullptr; h_batch_cap = 0;
   configured = false;  // (the host-image staging buffers d_stage/h_stage live until the destructor)
 }
 
@@ -866,6 +867,47 @@ int OrbPipeline::download(int frame, dvm_keypoint* kps, uint8_t* desc, int cap, 
   if (N > 0) {
     if (kps) DVM_HIP(hipMemcpy(kps, d_kps + (size_t)frame * PD.kp_cap, (size_t)N * sizeof(dvm_keypoint), hipMemcpyDeviceToHost));
     if (desc) DVM_HIP(hipMemcpy(desc, d_desc + (size_t)frame * PD.kp_cap * 32, (size_t)N * 32, hipMemcpyDeviceToHost));
+  }
+  return DVM_OK;
+}
+
+// the first `count` frames' results in one go: two copies of the whole [count][kp_cap] blocks into page-locked memory behind the handle's
+// stream, ONE synchronisation, then the frames' N entries each (download() frame by frame is two blocking copies to pageable memory per
+// frame: 32 frames of a batched tracking chain spent 1.3 ms there)
+int OrbPipeline::download_batch(int count, dvm_keypoint* const* kps, uint8_t* const* desc, const int* caps, int* n, int* mono) {
+  if (!configured || count < 1 || count > last_batch) { set_error("no results for those frames"); return DVM_ERR_STATE; }
+  if (last_mirrored || count == 1) {
+    for (int f = 0; f < count; f++) {
+      const int rc = download(f, kps ? kps[f] : nullptr, desc ? desc[f] : nullptr, caps[f], n ? n + f : nullptr, mono ? mono + f : nullptr);
+      if (rc != DVM_OK) return rc;
+    }
+    return DVM_OK;
+  }
+  DVM_HIP(hipSetDevice(device));
+  const size_t need = (size_t)count * PD.kp_cap;
+  if (need > h_batch_cap) {
+    if (h_kps_b) hipHostFree(h_kps_b);
+    if (h_desc_b) hipHostFree(h_desc_b);
+    h_kps_b = nullptr; h_desc_b = nullptr; h_batch_cap = 0;
+    DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_kps_b), need * sizeof(dvm_keypoint_pod)));
+    DVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_desc_b), need * 32));
+    h_batch_cap = need;
+  }
+  DVM_HIP(hipMemcpyAsync(h_n, d_n, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
+  DVM_HIP(hipMemcpyAsync(h_mono, d_mono, (size_t)last_batch * 4, hipMemcpyDeviceToHost, stream));
+  DVM_HIP(hipMemcpyAsync(h_kps_b, d_kps, need * sizeof(dvm_keypoint_pod), hipMemcpyDeviceToHost, stream));
+  DVM_HIP(hipMemcpyAsync(h_desc_b, d_desc, need * 32, hipMemcpyDeviceToHost, stream));
+  const int rc = sync();
+  if (rc != DVM_OK) return rc;
+  for (int f = 0; f < count; f++) {
+    const int N = h_n[f];
+    if (n) n[f] = N;
+    if (mono) mono[f] = h_mono[f];
+    if (N > caps[f]) { set_error("keypoint buffer too small"); return DVM_ERR_CAPACITY; }
+    if (N > 0) {
+      if (kps && kps[f]) std::memcpy(kps[f], h_kps_b + (size_t)f * PD.kp_cap, (size_t)N * sizeof(dvm_keypoint));
+      if (desc && desc[f]) std::memcpy(desc[f], h_desc_b + (size_t)f * PD.kp_cap * 32, (size_t)N * 32);
+    }
   }
   return DVM_OK;
 }

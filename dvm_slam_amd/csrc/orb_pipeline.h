@@ -154,6 +154,10 @@ class OrbPipeline {
   int gauss7[7] = {};                // the blur's 8.8 fixed-point kernel (also in constant memory for k_blur7)
   hipStream_t lat_aux = nullptr;     // DVM_LAT_SPLIT=1 only: created by the first small call
   bool last_mirrored = false;        // the last batch's results are in h_kps_m / h_desc_m / h_n / h_mono
+  dvm_keypoint_pod* h_kps_b = nullptr;   // download_batch: page-locked [frames][kp_cap] blocks, grown on demand
+  uint8_t* h_desc_b = nullptr;
+  size_t h_batch_cap = 0;
+  int download_batch(int count, dvm_keypoint* const* kps, uint8_t* const* desc, const int* caps, int* n, int* mono);
   dvm_keypoint_pod* h_kps_m = nullptr;   // [kLatencyBatch][kp_cap], mapped
   uint8_t* h_desc_m = nullptr;           // [kLatencyBatch][kp_cap][32], mapped
   HostMirror mirror_dev;                 // their device addresses (and those of h_n / h_mono)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/dvmslam_hip.h"
 #include "ba_kernels.h"
@@ -134,6 +135,15 @@ int dvm_track_begin_batch(dvm_tracker* t, dvm_orb* h, const uint8_t* imgs, int c
   t->begun = count; t->rows = rows; t->cols = cols;
   return DVM_OK;
 }
+int dvm_track_begin_staged(dvm_tracker* t, dvm_orb* h, int count, int rows, int cols, int lap0, int lap1) {
+  if (!t || !h || count < 1) return DVM_ERR_INVALID;
+  if (count > t->max_frames) { set_error("dvm_track_begin_staged: more frames than the tracker was created for"); return DVM_ERR_CAPACITY; }
+  t->begun = 0;
+  const int rc = dvm_orb_extract_staged(h, count, rows, cols, lap0, lap1);
+  if (rc != DVM_OK) return rc;
+  t->begun = count; t->rows = rows; t->cols = cols;
+  return DVM_OK;
+}
 int dvm_track_begin(dvm_tracker* t, dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1) {
   return dvm_track_begin_batch(t, h, img, 1, rows, cols, stride, (int64_t)rows * stride, lap0, lap1);
 }
@@ -225,14 +235,18 @@ int dvm_track_finish_batch(dvm_tracker* t, dvm_orb* h, int count, const dvm_trac
   // (what the host wants back is written to mapped memory by the kernels themselves: no copy command behind the chain)
   rc = hip_check(hipGetLastError(), "tracking chain launch");
   if (rc != DVM_OK) return rc;
+  {   // the extraction's results of all frames: one synchronisation (the whole chain is through), block copies
+    std::vector<dvm_keypoint*> kp(count); std::vector<uint8_t*> dp(count); std::vector<int> caps(count), ns(count), monos(count);
+    for (int b = 0; b < count; b++) { kp[b] = outs[b].kps; dp[b] = outs[b].desc; caps[b] = outs[b].cap; }
+    rc = dvm_orb_download_batch(h, count, kp.data(), dp.data(), caps.data(), ns.data(), monos.data());
+    if (rc != DVM_OK) return rc;
+    for (int b = 0; b < count; b++) { res[b].n = ns[b]; res[b].mono_index = monos[b]; }
+  }
   for (int b = 0; b < count; b++) {
     const dvm_track_queries& q = qs[b];
     const dvm_track_frame_out& o = outs[b];
     dvm_track_result& r = res[b];
-    int n = 0, mono = -1;
-    rc = dvm_orb_download(h, b, o.kps, o.desc, o.cap, &n, &mono);   // (the first one synchronises the stream: the whole chain is through)
-    if (rc != DVM_OK) return rc;
-    r.n = n; r.mono_index = mono;
+    const int n = r.n;
     if (o.kps_un) std::memcpy(o.kps_un, undist ? reinterpret_cast<const dvm_keypoint*>(m.kps_un) : o.kps, (size_t)n * sizeof(dvm_keypoint));
     const size_t ko = (size_t)b * ocap;
     std::memcpy(o.assign, m.assign + ko, (size_t)n * 4);

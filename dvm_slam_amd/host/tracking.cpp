@@ -183,13 +183,13 @@ extern "C" int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, in
                                                   int64_t frame_stride, int lap0, int lap1, const float* K, const float* bounds, const float* scale_factors,
                                                   const float* inv_level_sigma2, int nlevels, float th, int check_ori, const dvmh_track_in* in,
                                                   const dvmh_track_out* outs, dvmh_track_result* res) {
-  if (!t || !h || !imgs || !K || !bounds || !scale_factors || !inv_level_sigma2 || !in || !outs || !res || count < 1) return DVM_ERR_INVALID;
+  if (!t || !h || !K || !bounds || !scale_factors || !inv_level_sigma2 || !in || !outs || !res || count < 1) return DVM_ERR_INVALID;
   for (int b = 0; b < count; b++) {
     if (!in[b].Tcw_pred || (in[b].Nl && (!in[b].kps_l || !in[b].mp_l || !in[b].mps)) || !outs[b].kps || !outs[b].desc || !outs[b].mp_c || !outs[b].dropped) return DVM_ERR_INVALID;
     std::memset(&res[b], 0, sizeof(res[b]));
   }
   (void)device;
-  int rc = dvm_track_begin_batch(t, h, imgs, count, rows, cols, stride, frame_stride, lap0, lap1);
+  int rc = imgs ? dvm_track_begin_batch(t, h, imgs, count, rows, cols, stride, frame_stride, lap0, lap1) : dvm_track_begin_staged(t, h, count, rows, cols, lap0, lap1);
   if (rc != DVM_OK) return rc;
   std::vector<AgentQueries> AQ((size_t)count);
   auto build_all = [&](float scale, const std::vector<uint8_t>* only) {

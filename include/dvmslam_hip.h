@@ -138,6 +138,9 @@ int dvm_orb_copy_result(dvm_orb* h, int frame, dvm_keypoint* d_kps_dst, uint8_t*
 const float* dvm_orb_scale_factors_device(dvm_orb* h);
 /* synchronises, then copies frame f's results to the host */
 int dvm_orb_download(dvm_orb* h, int frame, dvm_keypoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+/* the first `count` frames of the last batch in one go (one synchronisation, two block copies through page-locked memory): kps[f] / desc[f]
+ * with caps[f] entries, n[f], mono_index[f] */
+int dvm_orb_download_batch(dvm_orb* h, int count, dvm_keypoint* const* kps, uint8_t* const* desc, const int* caps, int* n, int* mono_index);
 /* mvImagePyramid[level] of frame f: device pointer to pixel (0,0) of the level; the 19-px
  * REFLECT_101 border is addressable at negative offsets exactly like the reference's ROI Mats */
 int dvm_orb_pyramid(dvm_orb* h, int frame, int level, const uint8_t** d_ptr, int* rows, int* cols, int* stride);
@@ -606,6 +609,8 @@ typedef struct {
 } dvm_track_frame_out;
 int dvm_tracker_create_batch(int device, int max_frames, int max_keypoints, int max_queries, dvm_tracker** out);
 int dvm_track_begin_batch(dvm_tracker* t, dvm_orb* h, const uint8_t* imgs, int count, int rows, int cols, int stride, int64_t frame_stride, int lap0, int lap1);
+/* the same for `count` frames the caller has written into the extractor's page-locked input buffer (dvm_orb_staging): no host copy */
+int dvm_track_begin_staged(dvm_tracker* t, dvm_orb* h, int count, int rows, int cols, int lap0, int lap1);
 void dvm_tracker_destroy(dvm_tracker* t);
 int dvm_track_begin(dvm_tracker* t, dvm_orb* h, const uint8_t* img, int rows, int cols, int stride, int lap0, int lap1);
 /* kps / desc [cap]: the extraction; kps_un (may be NULL): mvKeysUn; assign [cap]: per keypoint the index of the query matched to it or -1

@@ -131,6 +131,7 @@ typedef struct {
   dvm_keypoint* kps; uint8_t* desc; int32_t cap; dvm_keypoint* kps_un;   /* [cap]; kps_un may be NULL */
   int32_t *mp_c, *dropped;                   /* [cap] as in the single call */
 } dvmh_track_out;
+/* imgs == NULL: the frames are already in the extractor's page-locked input buffer (dvm_orb_staging, tight rows) */
 int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, int device, int count, const uint8_t* imgs, int rows, int cols, int stride,
                                        int64_t frame_stride, int lap0, int lap1, const float* K, const float* bounds, const float* scale_factors,
                                        const float* inv_level_sigma2, int nlevels, float th, int check_ori, const dvmh_track_in* in,

@@ -225,6 +225,62 @@ static Result measure(const Inputs& in, int device, int nframes, int K, dvm_orb_
   return R;
 }
 
+// K agents' frames per camera tick through ONE batched chain (dvmh_track_with_motion_model_batch), one host thread
+static Result measure_batched(const Inputs& in, int device, int nframes, int K, uint64_t* sum_agent0) {
+  Result R;
+  const float K4[4] = {500.f, 500.f, 320.f, 240.f}, bounds[4] = {0.f, 640.f, 0.f, 480.f};
+  const dvm_se3f Tcw{{0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}};
+  dvm_set_device(device);
+  dvm_orb_params P{1000, 1.2f, 8, 20, 7};
+  dvm_orb* h = nullptr;
+  dvm_tracker* trk = nullptr;
+  const int cap = 4096;
+  int rc = dvm_orb_create(&P, device, K, &h);
+  if (rc == 0) rc = dvm_tracker_create_batch(device, K, cap, cap, &trk);
+  if (rc) { R.rc = rc; return R; }
+  float inv_s2[8];
+  for (int l = 0; l < 8; l++) inv_s2[l] = 1.0f / (in.scale[l] * in.scale[l]);
+  const size_t fb = (size_t)in.rows * in.cols;
+  std::vector<std::vector<dvm_keypoint>> kps(K, std::vector<dvm_keypoint>(cap)), kun(K, std::vector<dvm_keypoint>(cap));
+  std::vector<std::vector<uint8_t>> desc(K, std::vector<uint8_t>((size_t)cap * 32));
+  std::vector<std::vector<int32_t>> mp_t(K, std::vector<int32_t>(cap)), dropped(K, std::vector<int32_t>(cap)), mp_l(K);
+  std::vector<dvmh_track_in> tin(K);
+  std::vector<dvmh_track_out> tout(K);
+  std::vector<dvmh_track_result> tr(K);
+  for (int a = 0; a < K; a++) tout[a] = dvmh_track_out{kps[a].data(), desc[a].data(), cap, kun[a].data(), mp_t[a].data(), dropped[a].data()};
+  uint64_t sum = 1469598103934665603ull;
+  auto tick = [&](int i) {
+    uint8_t* staging = nullptr;        // the cameras' frames go straight into the extractor's page-locked input buffer
+    if (dvm_orb_staging(h, K, in.rows, in.cols, &staging) != 0) return -1;
+    for (int a = 0; a < K; a++) {      // agent a is `a` frames ahead in the cycle: different frames and maps in one batch
+      const int t = 1 + (i + a) % in.cyc;
+      std::memcpy(staging + (size_t)a * fb, in.frames.data() + (size_t)t * fb, fb);
+      const Pair& p = in.pairs[t - 1];
+      mp_l[a].resize(p.Nl);
+      for (int j = 0; j < p.Nl; j++) mp_l[a][j] = j;
+      tin[a] = dvmh_track_in{&Tcw, p.Nl, p.kl.data(), mp_l[a].data(), nullptr, p.mps.data()};
+    }
+    return dvmh_track_with_motion_model_batch(trk, h, device, K, nullptr, in.rows, in.cols, in.cols, (int64_t)fb, 0, 1000, K4, bounds, in.scale, inv_s2, 8, 15.0f, 1,
+                                              tin.data(), tout.data(), tr.data());
+  };
+  rc = tick(0);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < nframes && rc == 0; i++) {
+    rc = tick(i);
+    if (rc == 0 && i < in.cyc) {       // agent 0's results over one cycle -> the checksum the one-chain mode forms
+      sum = mix(sum, &tr[0].n, 4); sum = mix(sum, kps[0].data(), (size_t)tr[0].n * sizeof(dvm_keypoint)); sum = mix(sum, desc[0].data(), (size_t)tr[0].n * 32);
+      sum = mix(sum, &tr[0].nmatches, 4); sum = mix(sum, mp_t[0].data(), (size_t)tr[0].n * 4); sum = mix(sum, tr[0].pose, sizeof(tr[0].pose));
+    }
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc) std::fprintf(stderr, "batched chain failed: rc %d (%s)\n", rc, dvm_last_error());
+  R.rc = rc; R.fps = K * (double)nframes / dt; R.ms_per_frame = dt / nframes * 1e3;
+  *sum_agent0 = sum;
+  dvm_tracker_destroy(trk);
+  dvm_orb_destroy(h);
+  return R;
+}
+
 int main(int argc, char** argv) {
   int pool_batch = 0;
   if (argc > 1 && std::strncmp(argv[1], "--pool=", 7) == 0) { pool_batch = std::atoi(argv[1] + 7); argv++; argc--; }
@@ -264,6 +320,20 @@ int main(int argc, char** argv) {
                     a == 4 ? "" : ", ", K, R.fps, R.ms_per_frame, R.mean[0], R.mean[1], R.mean[2], R.med[0], R.med[1], R.med[2], mode == 1 ? "" : "}");
       out += buf;
       if (mode == 1) { std::snprintf(buf, sizeof(buf), ", \"mean_frames_per_batch\": %.2f}", R.mean_batch); out += buf; }
+    }
+    out += "}";
+  }
+  {   // the same K agents, their frames of a tick through ONE batched chain (one host thread)
+    out += ", \"by_agents_batched_chain\": {";
+    for (int a = 4; a < argc; a++) {
+      const int K = std::atoi(argv[a]);
+      uint64_t s0 = 0;
+      const Result R = measure_batched(in, device, std::max(nframes / 2, 20), K, &s0);
+      if (R.rc) return 1;
+      same = same && s0 == ref_chain;      // agent 0 sees the frames the one-chain mode's agents see: the same results
+      char buf[256];
+      std::snprintf(buf, sizeof(buf), "%s\"%d\": {\"value\": %.1f, \"ms_per_tick\": %.4f}", a == 4 ? "" : ", ", K, R.fps, R.ms_per_frame);
+      out += buf;
     }
     out += "}";
   }
