@@ -1856,6 +1856,38 @@ int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, con
   return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, false, 0);
 }
 int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
+  // A batch of 64 or more windows goes in two halves, the second on a persistent helper thread with its own staging buffers and stream: the
+  // host side of such a call (tables, 60+ MB of staging) is as long as its kernel, and two threads halve it; the two launches (G workgroups
+  // per window each) share the chip.  Every window's result is independent of its batch and of G, so the split changes nothing but the
+  // time (128 windows: 23 -> 18 ms = 72 k it/s; 32 windows gain nothing -- their halves' kernels just run side by side: measured 40 against 52 k).
+  static const bool no_split = std::getenv("DVM_BA_NO_SPLIT") != nullptr;
+  if (K >= 64 && !no_split) {
+    if (K < 0 || !windows) { set_error("dvm_ba_optimize_windows: null windows"); return DVM_ERR_INVALID; }
+    HelperThread& H = HelperThread::get();
+    std::unique_lock<std::mutex> user(H.use, std::try_to_lock);
+    if (user.owns_lock()) {
+      const int K0 = (K + 1) / 2, K1 = K - K0;
+      // the cluster size of BOTH launches from the whole batch: their workgroups must all be resident together (two half grids that each
+      // filled the chip would starve each other's barriers)
+      int cus = 0, G = 1;
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      const char* env_c = std::getenv("DVM_BA_CLUSTER");
+      const int want = env_c ? atoi(env_c) : 0;
+      const int groups = 8 * ((K0 + 7) / 8) + 8 * ((K1 + 7) / 8);
+      for (int g = 8; g >= 1; g >>= 1) if ((want > 0 && g == want) || (want <= 0 && groups * g <= cus)) { G = g; break; }
+      int rc1 = DVM_OK;
+      std::string err1;
+      H.submit([&, K0, K1, G] {
+        rc1 = dvm_ba_optimize_windows_impl(device, windows + K0, K1, stop_flag, stats ? stats + K0 : nullptr, true, true, G);
+        if (rc1 != DVM_OK) err1 = last_error_cstr();
+      });
+      const int rc0 = dvm_ba_optimize_windows_impl(device, windows, K0, stop_flag, stats, true, true, G);
+      H.wait();
+      if (rc0 != DVM_OK) return rc0;
+      if (rc1 != DVM_OK) { set_error(err1); return rc1; }
+      return DVM_OK;
+    }
+  }
   return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, true, 0);
 }
 

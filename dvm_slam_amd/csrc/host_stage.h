@@ -143,6 +143,38 @@ class HostPool {
   }
 };
 
+// ONE persistent helper thread: submit(fn) runs fn on it, wait() blocks until it is done.  For a call that splits its batch in two halves and
+// works on both at once (dvm_ba_optimize_windows_fast: the second half's tables and upload under the first half's kernel) -- the helper
+// keeps its thread-local staging buffers between calls, which a std::thread per call would allocate and free every time.
+class HelperThread {
+ public:
+  static HelperThread& get() { static HelperThread h; return h; }
+  std::mutex use;                    // one user at a time (held by the caller from submit to wait)
+  void submit(std::function<void()> fn) {
+    { std::lock_guard<std::mutex> l(m_); job_ = std::move(fn); has_ = true; done_ = false; }
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    cv_.notify_all();
+  }
+  void wait() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return done_; }); }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool has_ = false, done_ = true, stop_ = false;
+  std::thread th_;
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return has_ || stop_; }); if (stop_) return; f = std::move(job_); has_ = false; }
+      f();
+      { std::lock_guard<std::mutex> l(m_); done_ = true; }
+      cv_.notify_all();
+    }
+  }
+  HelperThread() = default;
+  ~HelperThread() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+};
+
 // Items come in two kinds.  COPIED (in / out / scratch): packed into the pinned buffer, one asynchronous H2D copy, kernels, one D2H
 // copy -- for anything a kernel reads more than once or updates in place.  MAPPED (in_mapped / out_mapped): the kernel reads the
 // input from / writes the output to page-locked host memory directly -- for arrays touched ONCE per call (a query list, a result

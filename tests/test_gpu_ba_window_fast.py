@@ -109,3 +109,20 @@ def test_fast_windows_do_not_depend_on_the_cluster_size(windows, monkeypatch):
             assert np.array_equal(_bits(a["poses"]), _bits(b["poses"])) and np.array_equal(_bits(a["points"]), _bits(b["points"])), (G, k)
             assert np.array_equal(_bits(a["edge_chi2"]), _bits(b["edge_chi2"])) and list(a["stats"]["trials"]) == list(b["stats"]["trials"]), (G, k)
             assert np.array_equal(_bits(a["stats"]["chi2"]), _bits(b["stats"]["chi2"])), (G, k)
+
+
+def test_fast_windows_large_batch_split_in_two_halves():
+    """64 windows and more go as two concurrent half-batches (a helper thread with its own staging buffers and stream, one cluster size for
+    both launches): window k's bits are those of the same window in a small batch."""
+    base = []
+    for k in range(6):
+        pr = synth.ba_problem(n_kf=10 + 2 * k, n_pts=250 + 60 * k, k_obs=4, seed=0x4A0 + k, radius=10.0)
+        base.append(_window(pr, 6, n_fixed=3))
+    ref = capi.ba_optimize_windows(base, fast=True)
+    wins = [base[k % 6] for k in range(70)]
+    for _ in range(2):
+        res = capi.ba_optimize_windows(wins, fast=True)
+        for k, g in enumerate(res):
+            r = ref[k % 6]
+            assert np.array_equal(_bits(g["poses"]), _bits(r["poses"])) and np.array_equal(_bits(g["points"]), _bits(r["points"])), k
+            assert np.array_equal(_bits(g["edge_chi2"]), _bits(r["edge_chi2"])) and list(g["stats"]["trials"]) == list(r["stats"]["trials"]), k
