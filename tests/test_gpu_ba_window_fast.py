@@ -126,3 +126,14 @@ def test_fast_windows_large_batch_split_in_two_halves():
             r = ref[k % 6]
             assert np.array_equal(_bits(g["poses"]), _bits(r["poses"])) and np.array_equal(_bits(g["points"]), _bits(r["points"])), k
             assert np.array_equal(_bits(g["edge_chi2"]), _bits(r["edge_chi2"])) and list(g["stats"]["trials"]) == list(r["stats"]["trials"]), k
+
+
+def test_fast_windows_repeat_with_one_workgroup_after_a_barrier_timeout(windows, monkeypatch):
+    """A cluster barrier that times out (a workgroup not resident: other work holds compute units) makes the call repeat the batch with
+    G = 1; DVM_BA_TEST_TIMEOUT takes that path without a real time-out.  Same bits (the results do not depend on G)."""
+    ref = capi.ba_optimize_windows(windows[:4], fast=True)
+    monkeypatch.setenv("DVM_BA_TEST_TIMEOUT", "1")
+    res = capi.ba_optimize_windows(windows[:4], fast=True)
+    for k, (a, b) in enumerate(zip(ref, res)):
+        assert np.array_equal(_bits(a["poses"]), _bits(b["poses"])) and np.array_equal(_bits(a["points"]), _bits(b["points"])), k
+        assert list(a["stats"]["trials"]) == list(b["stats"]["trials"]), k
