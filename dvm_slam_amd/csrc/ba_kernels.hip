@@ -2548,7 +2548,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
   __shared__ double s_sum[28];
   __shared__ double s_T[7], s_Tbak[7], s_T0[7];
   __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
-  __shared__ int s_ctl, s_qmax, s_nbad, s_nact;
+  __shared__ int s_ctl, s_qmax, s_nbad, s_nact, s_lin;
   const int f = blockIdx.x, tid = threadIdx.x;
 #ifdef DVM_POSE_PROF
   unsigned long long pose_last_ = wall_clock64();
@@ -2645,7 +2645,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
   bool robust_on = true;
   for (int round = 0; round < 4; round++) {
     if (tid < 7) s_T[tid] = s_T0[tid];  // vSE3->setEstimate(pFrame->GetPose()) every round
-    if (tid == 0) { s_nact = 0; s_ctl = 0; s_nbad = 0; }
+    if (tid == 0) { s_nact = 0; s_ctl = 0; s_nbad = 0; s_lin = 0; }
     __syncthreads();
     int my = 0;
 #pragma unroll
@@ -2656,7 +2656,13 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
     const int nact = s_nact;
     POSE_T(0);
     for (int it = 0; it < 10 && nact > 0; it++) {
-      eval(s_T, true, robust_on);
+      // Speculative linearisation (as the tile solver's LM loop does it): an accepted trial has evaluated its state WITH the Jacobians, so
+      // the iteration that follows finds H, b and chi2 of its state in s_sum already -- one pass per accepted trial instead of two
+      // (chi2 only, then the same edges again with Jacobians); a rejected trial's sums are simply overwritten.
+      const bool have_lin = s_lin != 0;
+      __syncthreads();
+      if (tid == 0) s_lin = 0;
+      if (!have_lin) eval(s_T, true, robust_on);
       POSE_T(1);
       if (tid == 0) {
         s_cur = s_sum[27]; s_ini = s_sum[27];
@@ -2724,7 +2730,8 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
         __syncthreads();
         POSE_T(3);
         const bool okb = s_ctl != 0;
-        if (okb) eval(s_T, false, robust_on);
+        const bool spec = it + 1 < 10;        // (the last iteration of a round: nobody would use the linearisation)
+        if (okb) eval(s_T, spec, robust_on);
         POSE_T(4);
         if (tid == 0) {
           const double tempChi = okb ? s_sum[27] : 1.7976931348623157e308;
@@ -2739,6 +2746,7 @@ __global__ void __launch_bounds__(256) k_pose_optimize(const double* __restrict_
             s_lambda *= fmax(1. / 3., alpha);
             s_ni = 2;
             s_cur = tempChi;
+            if (spec) s_lin = 1;                   // s_sum holds this state's linearisation
           } else {
             s_lambda *= s_ni; s_ni *= 2;
             for (int i = 0; i < 7; i++) s_T[i] = s_Tbak[i];
