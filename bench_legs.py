@@ -432,6 +432,30 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
     if not (dpo < 1e-6 and dxo < 1e-6 and same_trials):
         raise RuntimeError(f"lba_batch leg: the fast form differs from the sequential-order kernel beyond the contract: {dpo} {dxo} {same_trials}")
     out["fast_windows"] = fast
+    # ... and the same windows as BLOCKING one-window calls of K threads (one LocalMapping thread per agent) through dvm_ba_pool_*
+    try:
+        import threading
+        pool = capi.BaPool(device, max_batch=32)
+        by = {}
+        for K in (8, kmax):
+            batches = [capi.BaWindowBatch([wins[a]]) for a in range(K)]
+            sizes, calls = [], 4
+            def agent(a):
+                for _ in range(calls):
+                    sizes.append(pool.optimize(batches[a])[1])
+            for a in range(K):
+                pool.optimize(batches[a])
+            th = [threading.Thread(target=agent, args=(a,)) for a in range(K)]
+            t0 = time.perf_counter()
+            for x in th: x.start()
+            for x in th: x.join()
+            dt = time.perf_counter() - t0
+            its = sum(b.results()[0]["stats"]["iterations"] for b in batches) * calls
+            by[str(K)] = {"value": its / dt, "ms_per_call_per_agent": dt / calls * 1e3, "mean_windows_per_launch": float(np.mean(sizes))}
+        pool.close()
+        out["fast_windows_pool"] = {"call": "dvm_ba_pool_optimize from K Python threads (the calls release the interpreter lock)", "by_K": by}
+    except Exception as ex:   # noqa: BLE001
+        out["fast_windows_pool"] = {"error": repr(ex)}
     # the same K windows through the tile solver, one handle, one after the other (what K agents queueing on one GPU get today)
     ba = capi.BundleAdjuster(device)
     t_seq, its_seq = [], 0

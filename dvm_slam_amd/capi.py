@@ -710,6 +710,33 @@ class BaWindowBatch:
         return self.outs
 
 
+class BaPool:
+    """dvm_ba_pool_*: blocking one-window calls from any number of threads, batched behind the boundary into launches of the cluster form."""
+
+    def __init__(self, device=0, max_batch=32, window_us=-1):
+        self.p = C.c_void_p()
+        f = lib().dvm_ba_pool_create
+        f.restype = C.c_int32; f.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        check(f(device, max_batch, window_us, C.byref(self.p)))
+
+    def close(self):
+        if getattr(self, "p", None) and self.p.value:
+            f = lib().dvm_ba_pool_destroy
+            f.restype = None; f.argtypes = [C.c_void_p]
+            f(self.p)
+            self.p = C.c_void_p()
+
+    __del__ = close
+
+    def optimize(self, batch: "BaWindowBatch"):
+        """batch: a BaWindowBatch of ONE window (marshalled by the caller's thread).  Returns (result dict, windows in the launch)."""
+        n = C.c_int32(0)
+        f = lib().dvm_ba_pool_optimize
+        f.restype = C.c_int32; f.argtypes = None
+        check(f(self.p, batch.wins, batch.stats, C.byref(n)))
+        return batch.results()[0], n.value
+
+
 def ba_optimize_windows(problems, device=0, stop_flag=None, _threads=0, _batch=False, fast=False):
     """dvm_ba_optimize_windows: K independent bundle adjustments in one launch.  problems: dicts with poses [P,7], fixed [P], points [L,3],
     edges (BA_EDGE_DTYPE), intrinsics (fx, fy, cx, cy), huber_delta, iterations.  Returns one dict per window: poses, points, edge_chi2,

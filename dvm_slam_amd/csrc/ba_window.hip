@@ -41,6 +41,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,6 +49,7 @@
 #include "../../include/dvmslam_hip.h"
 #include "f64_spec.h"
 #include "ba_kernels.h"
+#include "group_commit.h"
 #include "host_stage.h"
 #include "orb_pipeline.h"   // set_error / hip_check / DVM_HIP
 
@@ -1889,6 +1891,71 @@ int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K
     }
   }
   return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, true, 0);
+}
+
+// ---- dvm_ba_pool_*: the LocalBundleAdjustment calls of several agents' LocalMapping threads (one per agent in the reference:
+// LocalMapping.cc:172 -> Optimizer.cc:1030-1387), each a BLOCKING call with its own window, batched behind the boundary into one launch
+// of the cluster form (group commit, as dvm_orb_pool / dvm_match_pool / dvm_pose_pool do it for the tracking threads' per-frame calls).
+// A window's result does not depend on the batch it rode in (k_ba_window_cluster): every caller gets the bits of a solo
+// dvm_ba_optimize_windows_fast call.
+struct dvm_ba_pool {
+  int device = 0;
+  GroupCommit gc;
+  std::vector<dvm_ba_window> win[GroupCommit::kLanes];
+  std::vector<dvm_ba_stats> st[GroupCommit::kLanes];
+};
+int dvm_ba_pool_create(int device, int max_batch, int window_us, dvm_ba_pool** out) {
+  if (!out || max_batch < 1 || max_batch > 256) return DVM_ERR_INVALID;
+  *out = nullptr;
+  int rc = dvm_set_device(device);
+  if (rc != DVM_OK) return rc;
+  dvm_ba_pool* p = new (std::nothrow) dvm_ba_pool();
+  if (!p) return DVM_ERR_INVALID;
+  p->device = device;
+  p->gc.max_batch = max_batch;
+  p->gc.window_us = window_us >= 0 ? window_us : 300;     // a LocalBundleAdjustment call takes milliseconds: 0.3 ms of collecting costs little
+  for (int l = 0; l < GroupCommit::kLanes; l++) { p->win[l].resize((size_t)max_batch); p->st[l].resize((size_t)max_batch); }
+  *out = p;
+  return DVM_OK;
+}
+void dvm_ba_pool_destroy(dvm_ba_pool* pool) { delete pool; }
+int dvm_ba_pool_optimize(dvm_ba_pool* pool, const dvm_ba_window* w, dvm_ba_stats* stats, int* batch_size) {
+  if (!pool || !w) return DVM_ERR_INVALID;
+  if (w->n_poses < 1 || w->n_points < 0 || w->n_edges < 0 || w->iterations < 0 || !w->poses || !w->fixed || (w->n_points && !w->points) || (w->n_edges && !w->edges)) {
+    set_error("dvm_ba_pool_optimize: the window is incomplete");
+    return DVM_ERR_INVALID;
+  }
+  const int64_t key[4] = {0, 0, 0, 0};
+  int li = 0, slot = 0;
+  int rc = pool->gc.join(key, [](int) { return 0; }, li, slot);
+  if (rc != 0) return rc;
+  pool->win[li][(size_t)slot] = *w;                       // (the arrays stay the caller's: it is blocked here until the batch is through)
+  if (pool->gc.arrive(li, slot)) {
+    const int count = pool->gc.batch_count(li);
+    // the batch runs on the library's helper thread, whichever caller leads it: ONE set of page-locked / device staging buffers and
+    // window tables for the service instead of one per agent thread (they are thread-local: ~5 MB per window of the largest batch)
+    int brc = DVM_OK;
+    std::string berr;
+    {
+      HelperThread& H = HelperThread::get();
+      std::lock_guard<std::mutex> user(H.use);
+      H.submit([&] {
+        brc = dvm_set_device(pool->device);
+        if (brc == DVM_OK) brc = dvm_ba_optimize_windows_fast(pool->device, pool->win[li].data(), count, nullptr, pool->st[li].data());
+        if (brc != DVM_OK) berr = last_error_cstr();
+      });
+      H.wait();
+    }
+    pool->gc.publish(li, brc, berr);
+  }
+  std::string err;
+  int count = 0;
+  rc = pool->gc.result(li, &err, &count);
+  if (rc == DVM_OK && stats) *stats = pool->st[li][(size_t)slot];
+  if (batch_size) *batch_size = count;
+  pool->gc.finish(li);
+  if (rc != DVM_OK) set_error("dvm_ba_pool_optimize: " + err);
+  return rc;
 }
 
 int dvm_f64_spec_eval(int device, const double* x, int n, double* out) {

@@ -521,6 +521,14 @@ int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, con
  * (~2 MB per window).  This is the call for the LocalBundleAdjustment windows of several agents sharing a GPU (Optimizer.cc:1030-1387,
  * LocalMapping.cc:172). */
 int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats);
+/* The shared form for several agents' LocalMapping threads (as dvm_orb_pool / dvm_pose_pool for the tracking threads): dvm_ba_pool_optimize
+ * is dvm_ba_optimize_windows_fast for ONE window -- a blocking call from any number of threads; calls that arrive within `window_us`
+ * (< 0: 300) of each other run as ONE launch.  The result of a window does not depend on the batch it rode in: every caller gets the bits
+ * of a solo dvm_ba_optimize_windows_fast call.  batch_size (may be NULL): how many windows the call's launch held.  No stop flag. */
+typedef struct dvm_ba_pool dvm_ba_pool;
+int dvm_ba_pool_create(int device, int max_batch, int window_us, dvm_ba_pool** out);
+void dvm_ba_pool_destroy(dvm_ba_pool* pool);
+int dvm_ba_pool_optimize(dvm_ba_pool* pool, const dvm_ba_window* w, dvm_ba_stats* stats, int* batch_size);
 /* The same K independent problems solved CONCURRENTLY on the general solver: up to `threads` (<= 0: 4) host threads of this call each
  * drive one solver handle from a process-wide pool and pull windows from a shared counter, so that the launch chains of different
  * windows interleave on the device (one window alone leaves it mostly idle).  Window k gets exactly what dvm_ba_set_problem +

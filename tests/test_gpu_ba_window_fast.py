@@ -137,3 +137,31 @@ def test_fast_windows_repeat_with_one_workgroup_after_a_barrier_timeout(windows,
     for k, (a, b) in enumerate(zip(ref, res)):
         assert np.array_equal(_bits(a["poses"]), _bits(b["poses"])) and np.array_equal(_bits(a["points"]), _bits(b["points"])), k
         assert list(a["stats"]["trials"]) == list(b["stats"]["trials"]), k
+
+
+def test_ba_pool_batches_blocking_calls_of_many_threads(windows):
+    """dvm_ba_pool_optimize: LocalMapping threads of several agents, each with a blocking one-window call; the service batches them into
+    launches of the cluster form; every caller gets the bits of a solo call (a window's result does not depend on its batch)."""
+    import threading
+    base = windows[:4]
+    ref = capi.ba_optimize_windows(base, fast=True)
+    pool = capi.BaPool(max_batch=8, window_us=2000)
+    T, rounds = 8, 3
+    out = [[None] * rounds for _ in range(T)]
+    sizes = []
+    def agent(t):
+        for r in range(rounds):
+            b = capi.BaWindowBatch([base[(t + r) % 4]])
+            res, n = pool.optimize(b)
+            out[t][r] = dict(poses=res["poses"].copy(), points=res["points"].copy(), trials=list(res["stats"]["trials"]))
+            sizes.append(n)
+    th = [threading.Thread(target=agent, args=(t,)) for t in range(T)]
+    for x in th: x.start()
+    for x in th: x.join()
+    for t in range(T):
+        for r in range(rounds):
+            g, a = out[t][r], ref[(t + r) % 4]
+            assert np.array_equal(_bits(g["poses"]), _bits(a["poses"])) and np.array_equal(_bits(g["points"]), _bits(a["points"])), (t, r)
+            assert g["trials"] == list(a["stats"]["trials"]), (t, r)
+    assert max(sizes) > 1, sizes          # calls did ride together
+    pool.close()
