@@ -1197,11 +1197,15 @@ __device__ void cl_schur(const BaWin& W, const ClusterCtx& C, double* wred, doub
 __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* __restrict__ wins, const volatile int* __restrict__ stop, int K, int G) {
   extern __shared__ double lds[];
   constexpr int NT = kWinThreads;
+  // K < 0: the placement test's map (tests/test_gpu_ba_window_fast.py) -- a window's workgroups are CONSECUTIVE blocks, i.e. spread over all
+  // eight XCDs; the results must not depend on it (they do not: the barriers release and acquire at agent scope)
+  const bool scatter = K < 0;
+  if (scatter) K = -K;
   const int bid = blockIdx.x, slot = bid >> 3;
-  const int wi = (slot / G) * 8 + (bid & 7);
+  const int wi = scatter ? bid / G : (slot / G) * 8 + (bid & 7);
   if (wi >= K) return;
   const BaWin& W = wins[wi];
-  ClusterCtx C{slot % G, G, 0u, false};
+  ClusterCtx C{scatter ? bid % G : slot % G, G, 0u, false};
   const bool leader = C.g == 0;
   const int tid = threadIdx.x, wave = tid >> 6;
   const int n = 6 * W.nfree, nl = 3 * W.nact;
@@ -1805,7 +1809,8 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!kev.a) { DVM_HIP(hipEventCreate(&kev.a)); DVM_HIP(hipEventCreate(&kev.b)); }
     hipEventRecord(kev.a, st.stream());
-    hipLaunchKernelGGL(k_ba_window_cluster, dim3(groups * G), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d, K, G);
+    const bool scatter = std::getenv("DVM_BA_CLUSTER_SCATTER") != nullptr;     // (placement test: see the kernel)
+    hipLaunchKernelGGL(k_ba_window_cluster, dim3(groups * G), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d, scatter ? -K : K, G);
     hipEventRecord(kev.b, st.stream());
   }
   else hipLaunchKernelGGL(k_ba_window, dim3(K), dim3(kWinThreads), lds_bytes, st.stream(), st.ptr<BaWin>(views_slot), sw.d);

@@ -87,7 +87,9 @@ inline StageCtx& stage_ctx() {
 // each -- as much as the work they were given.  One job at a time (callers serialise on a mutex); workers sleep between jobs.
 class HostPool {
  public:
-  static HostPool& get() { static HostPool p; return p; }
+  // (never destroyed: its sleeping workers end with the process -- a destructor that joins them would run in every forked child of a
+  //  process that had used the pool, where those threads do not exist)
+  static HostPool& get() { static HostPool* p = new HostPool; return *p; }
   template <class F> void run(size_t n, int width, F&& fn) {
     if (n == 0) return;
     if (width <= 1 || n == 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
@@ -148,7 +150,7 @@ class HostPool {
 // keeps its thread-local staging buffers between calls, which a std::thread per call would allocate and free every time.
 class HelperThread {
  public:
-  static HelperThread& get() { static HelperThread h; return h; }
+  static HelperThread& get() { static HelperThread* h = new HelperThread; return *h; }   // (never destroyed: see HostPool)
   std::mutex use;                    // one user at a time (held by the caller from submit to wait)
   void submit(std::function<void()> fn) {
     { std::lock_guard<std::mutex> l(m_); job_ = std::move(fn); has_ = true; done_ = false; }

@@ -165,3 +165,16 @@ def test_ba_pool_batches_blocking_calls_of_many_threads(windows):
             assert g["trials"] == list(a["stats"]["trials"]), (t, r)
     assert max(sizes) > 1, sizes          # calls did ride together
     pool.close()
+
+
+def test_fast_windows_do_not_depend_on_the_placement(windows, monkeypatch):
+    """The cluster's workgroups normally sit on one XCD (block b runs on XCD b % 8: speed only).  DVM_BA_CLUSTER_SCATTER maps a window's
+    eight workgroups to CONSECUTIVE blocks -- one per XCD, whose L2s are not coherent with each other --: the same bits, run after run
+    (the phase barriers release and acquire at agent scope; nothing relies on co-location)."""
+    ref = capi.ba_optimize_windows(windows[:6], fast=True)
+    monkeypatch.setenv("DVM_BA_CLUSTER_SCATTER", "1")
+    for rep in range(4):
+        res = capi.ba_optimize_windows(windows[:6], fast=True)
+        for k, (a, b) in enumerate(zip(ref, res)):
+            assert np.array_equal(_bits(a["poses"]), _bits(b["poses"])) and np.array_equal(_bits(a["points"]), _bits(b["points"])), (rep, k)
+            assert np.array_equal(_bits(a["edge_chi2"]), _bits(b["edge_chi2"])) and list(a["stats"]["trials"]) == list(b["stats"]["trials"]), (rep, k)
