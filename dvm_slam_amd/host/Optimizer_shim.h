@@ -50,6 +50,11 @@ inline void require_mono(KeyFrame* pKF, int leftIndex) {
     throw std::runtime_error("Optimizer shim: stereo / two-camera observation outside the accelerated (monocular) path");
 }
 
+// Several agents on one GPU: once a pool is registered (dvm_ba_pool_create -- one per process and GPU), LocalBundleAdjustment sends its
+// window through it; NULL: back to a solver handle per calling thread.  The pool must outlive the calls.
+inline dvm_ba_pool*& local_ba_pool_slot() { static dvm_ba_pool* p = NULL; return p; }
+inline void set_local_ba_pool(dvm_ba_pool* p) { local_ba_pool_slot() = p; }
+
 // One bundle-adjustment problem on its way to the device: cameras and landmarks get dense slots in insertion order, an
 // observation becomes an edge between two slots.  Shared by BundleAdjustment and LocalBundleAdjustment.
 struct Problem {
@@ -121,6 +126,33 @@ struct Problem {
     upload(huber_delta);
     optimize(iterations, stop);
     collect();
+  }
+  // The one-round form through a shared dvm_ba_pool (several agents' LocalMapping threads on one GPU: their windows ride in ONE launch,
+  // include/dvmslam_hip.h).  Returns false when the window is beyond that path's capacity (more than 30 free cameras): the caller takes
+  // run().  The stop flag is honoured before the call only (a launch shared with other agents is not interrupted for one of them).
+  bool run_pooled(dvm_ba_pool* pool, int iterations, double huber_delta) {
+    pose.resize(7 * cams.size());
+    xyz.resize(3 * pts.size());
+    for (size_t i = 0; i < cams.size(); i++) pose7(cams[i]->GetPose(), &pose[7 * i]);
+    for (size_t i = 0; i < pts.size(); i++) {
+      const Eigen::Vector3d X = pts[i]->GetWorldPos().cast<double>();
+      for (int k = 0; k < 3; k++) xyz[3 * i + k] = X(k);
+    }
+    chi2.resize(edges.size());
+    in_front.resize(edges.size());
+    const KeyFrame* any = cams.front();
+    dvm_ba_window w;
+    w.n_poses = (int32_t)cams.size(); w.n_points = (int32_t)pts.size(); w.n_edges = (int32_t)edges.size(); w.iterations = iterations;
+    w.poses = pose.data(); w.fixed = cam_fixed.data(); w.points = xyz.data(); w.edges = edges.data();
+    w.cam = dvm_ba_camera{any->fx, any->fy, any->cx, any->cy, huber_delta};
+    std::vector<double> pose_out(pose.size()), xyz_out(xyz.size());
+    w.poses_out = pose_out.data(); w.points_out = xyz_out.data(); w.edge_chi2_out = chi2.data(); w.depth_positive_out = in_front.data();
+    dvm_ba_stats st;
+    const int rc = dvm_ba_pool_optimize(pool, &w, &st, NULL);
+    if (rc == DVM_ERR_CAPACITY) return false;
+    check(rc);
+    pose.swap(pose_out); xyz.swap(xyz_out);
+    return true;
   }
   // One solver handle per calling thread, released when the thread ends: the handle recycles its device memory from one problem
   // to the next (LocalMapping calls LocalBundleAdjustment every keyframe), and the reference starts a fresh std::thread for
@@ -265,7 +297,8 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Ma
   if (pbStopFlag && *pbStopFlag) return;
 
   const float huber = sqrt(5.991);
-  prob.run(10, pbStopFlag, (double)huber);
+  dvm_ba_pool* pool = local_ba_pool_slot();
+  if (!pool || !prob.run_pooled(pool, 10, (double)huber)) prob.run(10, pbStopFlag, (double)huber);
 
   std::vector<std::pair<KeyFrame*, MapPoint*>> rejected;
   for (size_t e = 0; e < prob.edges.size(); e++) {

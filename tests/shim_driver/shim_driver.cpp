@@ -185,6 +185,13 @@ int sw_get_mp_observations(World* w, int mp, int32_t* kf_out, int32_t* idx_out, 
 }
 
 // ---- Optimizer
+// register / drop the shared dvm_ba_pool of LocalBundleAdjustment (several agents on one GPU: Optimizer_shim.h)
+int sw_set_local_ba_pool(int on) {
+  static dvm_ba_pool* pool = nullptr;
+  if (on && !pool && dvm_ba_pool_create(dvm_host::device(), 8, 100, &pool) != 0) return -1;
+  ORB_SLAM3::dvm_optimizer_detail::set_local_ba_pool(on ? pool : nullptr);
+  return 0;
+}
 int sw_local_ba(World* w, int kf, int map, uint8_t* stop, int32_t* counts4) {
   return guarded(w, [&] {
     int a = -1, b = -1, c = -1, d = -1;

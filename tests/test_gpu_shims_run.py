@@ -59,7 +59,10 @@ def _check_tables(W):
         assert W.get_mp(m)["bad"] == W.mp[m]["bad"], f"bad flag of map point {m}"
 
 
-def test_local_bundle_adjustment(oracle):
+@pytest.mark.parametrize("pooled", [False, True])
+def test_local_bundle_adjustment(oracle, pooled):
+    """pooled: the window goes through a registered dvm_ba_pool (the several-agents-on-one-GPU form, Optimizer_shim.h
+    set_local_ba_pool) -- same tables, same rejected observations, poses and points within the same tolerance."""
     pr = _problem()
     # keyframe 9 is bad, keyframes 13..15 belong to another map, map point 7 is bad: none of them may enter the window
     W = sw.world_from_problem(pr, kf_ids=[10 + 3 * k for k in range(16)], map_of_kf=[0] * 13 + [1] * 3, init_kf_id=10, bad_kf={9}, bad_mp={7})
@@ -89,7 +92,11 @@ def test_local_bundle_adjustment(oracle):
     po, xo, st, chi = oracle.ba_optimize(poses, fx, points, edges, pr["intrinsics"], huber, 10)
     _, front = oracle.ba_edge_chi2(po, xo, edges, pr["intrinsics"])
 
-    out = W.local_ba(main, own)
+    assert W.L.sw_set_local_ba_pool(int(pooled)) == 0
+    try:
+        out = W.local_ba(main, own)
+    finally:
+        W.L.sw_set_local_ba_pool(0)
     assert out == dict(num_fixedKF=len(anchors) + int(holds_initial), num_OptKF=len(free), num_MPs=len(landmarks), num_edges=len(edges))
     assert len(anchors) > 0 and len(free) > 4 and st["iterations"] >= 3
 
@@ -118,6 +125,48 @@ def test_local_bundle_adjustment(oracle):
     opt = np.zeros(64, np.uint64); fxd = np.zeros(64, np.uint64); nf = np.zeros(1, np.int32)
     n = W.L.sw_map_opt_fixed(W.h, own, sw._p(opt), sw._p(fxd), 64, sw._p(nf))
     assert sorted(opt[:n]) == sorted(W.kf[k]["id"] for k in free) and sorted(fxd[:nf[0]]) == sorted(W.kf[k]["id"] for k in anchors)
+
+
+def test_local_bundle_adjustment_pooled_from_several_threads():
+    """Four agents' LocalMapping threads calling LocalBundleAdjustment at once with a registered pool: every world ends with the
+    bits of its solo pooled call (the result of a window does not depend on the launch it rode in)."""
+    import threading
+    seeds = [3, 5, 8, 13]
+
+    def world(seed):
+        return sw.world_from_problem(_problem(seed=seed), init_kf_id=0)
+
+    def state(W):
+        return ([W.get_kf(k)["pose"].copy() for k in range(len(W.kf))], [W.get_mp(m)["pos"].copy() for m in range(len(W.mp))],
+                [W.mp_observations(m) for m in range(len(W.mp))])
+
+    probe = world(seeds[0])
+    assert probe.L.sw_set_local_ba_pool(1) == 0
+    try:
+        solo = []
+        for s in seeds:
+            W = world(s)
+            out = W.local_ba(5, 0)
+            assert out["num_edges"] > 0
+            solo.append((out, state(W)))
+        worlds = [world(s) for s in seeds]
+        outs = [None] * len(seeds)
+
+        def job(i):
+            outs[i] = worlds[i].local_ba(5, 0)
+        th = [threading.Thread(target=job, args=(i,)) for i in range(len(seeds))]
+        for t in th: t.start()
+        for t in th: t.join()
+    finally:
+        probe.L.sw_set_local_ba_pool(0)
+    for i in range(len(seeds)):
+        assert outs[i] == solo[i][0]
+        got = state(worlds[i])
+        for a, b in zip(got[0], solo[i][1][0]):
+            assert np.array_equal(a, b)
+        for a, b in zip(got[1], solo[i][1][1]):
+            assert np.array_equal(a, b)
+        assert got[2] == solo[i][1][2]
 
 
 def test_local_bundle_adjustment_without_gauge_or_with_stop_flag(oracle):
