@@ -449,10 +449,12 @@ __device__ __forceinline__ double w_rsqrt_refined(double v) {
   return y;
 }
 template <bool EXACT>
-__device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, double* __restrict__ Lp, int n) {
+__device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, double* __restrict__ Lp, int n, unsigned long long* prof = nullptr) {
   const int tid = threadIdx.x;
   constexpr int NT = kWinThreads;
   bool ok = true;
+  unsigned long long tp = (prof && tid == 0) ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto lapc = [&](int slot) { if (prof && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[slot] += t - tp; tp = t; } };
   for (int k0 = 0; k0 < n && ok; k0 += 6) {
     double Ld[21], dg[6], rdg[6];    // the diagonal block's factor (lower, packed), its L_kk and (EXACT = false) 1 / L_kk
 #pragma unroll
@@ -473,6 +475,7 @@ __device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, 
       }
     }
     if (!ok) break;
+    lapc(12);
     // (no barrier here: the panel reads rows below the block and writes them and Lp, which the previous step's update has finished with
     //  behind its closing barrier; the block's own factor is written once everybody has read the block -- behind the panel's barrier)
     for (int i = k0 + 6 + tid; i < n; i += NT) {
@@ -488,7 +491,9 @@ __device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, 
 #pragma unroll
       for (int c = 0; c < 6; c++) { row[c] = l[c]; Lp[7 * i + c] = l[c]; }
     }
+    lapc(13);
     __syncthreads();
+    lapc(14);
     if (tid == 0) {
 #pragma unroll
       for (int a = 0; a < 6; a++) {
@@ -510,7 +515,9 @@ __device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, 
         Si[j] = v;
       }
     }
+    lapc(15);
     __syncthreads();
+    lapc(14);
   }
   return ok;
 }
@@ -556,6 +563,163 @@ __device__ void win_substitute(const double* __restrict__ S, const double* __res
       double v = rhs[j];
 #pragma unroll
       for (int a = 5; a >= 0; a--) v -= S[tri(k0 + a, j)] * x6[a];
+      rhs[j] = v;
+    }
+  }
+}
+
+// The cluster form's solve (its contract is a tolerance, not the column-by-column bits): the same six-columns-a-step factorisation with
+//   * the right-hand side as row n of the matrix -- it sits behind the packed triangle, i.e. AT tri(n, 0): its panel entries ARE the forward
+//     substitution's y, its trailing entries take the same subtractions as any other row -- no separate forward pass (one wave, 20
+//     dependent steps: 16 us of a 310 us iteration);
+//   * the 6 x 6 diagonal block factorised only by the waves that own panel rows (every thread of a wave for itself, as before) and by wave 0
+//     -- eight waves doing it side by side shared four SIMDs: 1 800 cycles a step instead of 600 --, fused multiply-adds throughout;
+//   * the trailing update on the FP64 matrix cores: A(i, j) -= sum_k L(i, k) L(j, k), k = 6 padded to 8, as two v_mfma_f64_16x16x4 per
+//     16 x 16 tile of the lower triangle (rows from the step's first trailing row), tiles dealt round-robin to the eight waves.  The panel
+//     copy Lp (pitch 9 doubles, columns 6 and 7 zero) supplies both operands.  A tile strictly below the diagonal whose sixteen rows all
+//     exist takes the short path (one multiplication for its four row offsets, no masks); diagonal tiles and the last tile row the masked
+//     one.  One entry at a time (six dependent multiply-subtract pairs behind seven LDS reads) the update was 1.5 us a step -- 30 of the
+//     factorisation's 51 us.
+// rinv[k] = 1 / L_kk and the diagonal block's own factor (rows k0 .. k0 + 5 of Lp, dead since their panel step) are what the backward
+// substitution reads.  flag: an LDS word (the positivity verdict).
+typedef double win_d4 __attribute__((ext_vector_type(4)));
+constexpr int kLpPitch = 9;
+__device__ __forceinline__ double w_rsqrt_fma(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-v * y, y, 1.0), y);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-v * y, y, 1.0), y);
+  return y;
+}
+__device__ bool win_cholesky_rhs(double* __restrict__ S, double* __restrict__ rinv, double* __restrict__ Lp, int n, int* __restrict__ flag,
+                                 unsigned long long* prof) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform: the tile loop below branches on it)
+  constexpr int NW = kWinThreads / 64, LPP = kLpPitch;
+  // (phase clocks of thread 0, kept in registers and added to prof[12..15] at the end: a read-modify-write of global memory per lap would put
+  //  its latency into the phase that follows)
+  unsigned long long tp = (prof && tid == 0) ? __builtin_amdgcn_s_memtime() : 0ull, pacc[4] = {0, 0, 0, 0};
+  auto lapc = [&](int slot) { if (prof && tid == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); pacc[slot - 12] += t - tp; tp = t; } };
+  if (tid == 0) *flag = 1;
+  __syncthreads();
+  for (int k0 = 0; k0 < n; k0 += 6) {
+    const int base = k0 + 6, rows = n + 1 - base;              // trailing rows base .. n (row n = the right-hand side)
+    if (wave == 0 || 64 * wave < rows) {
+      double Ld[21], rdg[6];
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = 0; c <= a; c++) {
+          double v = S[tri(k0 + a, k0 + c)];
+#pragma unroll
+          for (int k = 0; k < c; k++) v = __builtin_fma(-Ld[a * (a + 1) / 2 + k], Ld[c * (c + 1) / 2 + k], v);
+          if (a == c) {
+            if (!(v > 0)) ok = false;
+            rdg[a] = w_rsqrt_fma(v > 0 ? v : 1.0);
+            Ld[a * (a + 1) / 2 + a] = v;
+          } else Ld[a * (a + 1) / 2 + c] = v * rdg[c];
+        }
+      }
+      lapc(12);
+      const int i = base + tid;
+      if (i <= n) {
+        double* row = S + tri(i, k0);
+        double l[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double v = row[c];
+#pragma unroll
+          for (int k = 0; k < c; k++) v = __builtin_fma(-l[k], Ld[c * (c + 1) / 2 + k], v);
+          l[c] = v * rdg[c];
+        }
+        double* lp = Lp + LPP * i;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { row[c] = l[c]; lp[c] = l[c]; }
+        lp[6] = 0.0; lp[7] = 0.0;
+      }
+      if (tid == 0) {
+        if (!ok) *flag = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          rinv[k0 + a] = rdg[a];
+#pragma unroll
+          for (int c = 0; c < a; c++) Lp[LPP * (k0 + a) + c] = Ld[a * (a + 1) / 2 + c];
+        }
+      }
+      lapc(13);
+    }
+    __syncthreads();
+    lapc(14);
+    if (*flag == 0) break;                       // (uniform: read behind the barrier; nobody writes it before the next one)
+    // ---- trailing update, 16 x 16 tiles of rows / columns base + 16 t; tile t = ti (ti + 1) / 2 + tj goes to wave t mod 8
+    const int T = (rows + 15) >> 4, ntiles = T * (T + 1) / 2;
+    const int lr = lane & 15, lq = lane >> 4;
+    int ti = 0, tj = wave;
+    while (tj > ti) { tj -= ti + 1; ti++; }
+    for (int t = wave; t < ntiles; t += NW) {
+      const int i0 = base + 16 * ti, j0 = base + 16 * tj;
+      const int j = j0 + lr, ifirst = i0 + lq;
+      if (ti > tj && i0 + 15 <= n) {
+        const double* ra = Lp + LPP * (i0 + lr) + lq;
+        const double* rb = Lp + LPP * (j0 + lr) + lq;
+        const double a0 = ra[0], b0 = rb[0], a1 = ra[4], b1 = rb[4];
+        double* e0 = S + tri(ifirst, j);                   // rows ifirst + 4 r: tri(i + 4, j) = tri(i, j) + 4 i + 10
+        double* e1 = e0 + 4 * ifirst + 10;
+        double* e2 = e1 + 4 * ifirst + 26;
+        double* e3 = e2 + 4 * ifirst + 42;
+        const double c0 = *e0, c1 = *e1, c2 = *e2, c3 = *e3;
+        win_d4 acc = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+        *e0 = c0 - acc[0]; *e1 = c1 - acc[1]; *e2 = c2 - acc[2]; *e3 = c3 - acc[3];
+      } else {
+        const double* ra = Lp + LPP * min(i0 + lr, n) + lq;
+        const double* rb = Lp + LPP * min(j0 + lr, n) + lq;
+        const double a0 = ra[0], b0 = rb[0], a1 = ra[4], b1 = rb[4];
+        double* e[4];
+        double cur[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = ifirst + 4 * r;
+          e[r] = (i > n || j > i || j >= n) ? nullptr : S + tri(i, j);
+          cur[r] = e[r] ? *e[r] : 0.0;
+        }
+        win_d4 acc = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (e[r]) *e[r] = cur[r] - acc[r];
+      }
+      tj += NW;
+      while (tj > ti) { tj -= ti + 1; ti++; }
+    }
+    lapc(15);
+    __syncthreads();
+    lapc(14);
+  }
+  if (prof && tid == 0) for (int i = 0; i < 4; i++) prof[12 + i] += pacc[i];
+  return *flag != 0;
+}
+// backward substitution behind win_cholesky_rhs (rhs = row n of S holds y): x(i) = y(i) / L(i, i); y(j) -= L(i, j) x(i) for j < i, i
+// descending, a camera's six unknowns per step.  ONE wave.
+__device__ void win_backsubstitute(const double* __restrict__ S, const double* __restrict__ rinv, const double* __restrict__ Lp, double* __restrict__ rhs, int n) {
+  const int lane = threadIdx.x & 63;
+  for (int k0 = n - 6; k0 >= 0; k0 -= 6) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double x6[6];
+#pragma unroll
+    for (int a = 5; a >= 0; a--) {
+      double v = rhs[k0 + a];
+#pragma unroll
+      for (int c = 5; c > a; c--) v = __builtin_fma(-Lp[kLpPitch * (k0 + c) + a], x6[c], v);        // (the block's own factor: win_cholesky_rhs left it in Lp)
+      x6[a] = v * rinv[k0 + a];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
+    for (int j = lane; j < k0; j += 64) {
+      double v = rhs[j];
+#pragma unroll
+      for (int a = 5; a >= 0; a--) v = __builtin_fma(-S[tri(k0 + a, j)], x6[a], v);
       rhs[j] = v;
     }
   }
@@ -1177,6 +1341,8 @@ __device__ void cl_schur(const BaWin& W, const ClusterCtx& C, double* wred, doub
     for (int q = W.bp_start[bk] + lane; q < q1; q += 64) {
       const int2 pr = W.bp_pairs[q];
       double t1[18], w2[18];
+      // (gathered out of the column-major arrays, 36 eight-byte loads per pair.  Row-major copies of W Dinv and W -- a pair's operands in three
+      //  cache lines each instead of eighteen -- were measured: the pass went from 54 to 70 us, the pass that writes the rows from 19 to 31)
 #pragma unroll
       for (int j = 0; j < 18; j++) { t1[j] = W.Ts[j * Fp + pr.x]; w2[j] = W.Ws[j * Fp + pr.y]; }
 #pragma unroll
@@ -1218,6 +1384,11 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
   int* const s_flag_p = reinterpret_cast<int*>(ctl + 60);   // the barrier's verdict (no static LDS beside the 160 KB dynamic block)
 #define s_flag (*s_flag_p)
   dvm_ba_stats* const st = W.stats;
+  // DVM_BA_WINDOW_PROF: shader-clock cycles per phase of the cluster's workgroup 0 (slot 10: waiting in the barriers), by its thread 0
+  unsigned long long tprev = (W.prof && leader && tid == 0) ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto lap = [&](int slot) { if (W.prof && leader && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); W.prof[slot] += t - tprev; tprev = t; } };
+#define CL_BARRIER() do { lap(ph); if (!cluster_barrier(W, C, &s_flag)) return; lap(10); } while (0)
+  int ph = 11;
   if (leader && tid == 0) {
     st->iterations = st->total_trials = st->stop_reason = st->kernel_us = 0;
     st->chi2_initial = st->chi2_final = st->lambda_final = 0;
@@ -1235,15 +1406,17 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
     for (int i = lo + tid; i < hi; i += NT) W.pts_t[i] = W.pts[i];
   }
   double* poses = W.poses; double* poses_t = W.poses_t; double* pts = W.pts; double* pts_t = W.pts_t;
-  if (!cluster_barrier(W, C, &s_flag)) return;
+  CL_BARRIER();
 
   double lambda = -1, ni = 2, currentChi = 0, chi_last = 0;
   int nBad = 0, it_done = 0, trials_total = 0, stop_reason = 0;
   bool stopped = W.cl_ctl[1] != 0.0;
   for (int it = 0; it < W.iterations && !stopped; it++) {
+    ph = 0;
     cl_edge_pass<true>(W, C, poses, pts);
     if (it == 0) cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
-    if (!cluster_barrier(W, C, &s_flag)) return;
+    CL_BARRIER();
+    ph = 1;
     {
       double mx = cl_accumulate(W, C, wred);
       if (it == 0) {      // computeLambdaInit's max |diagonal|: this workgroup's share -> its parts' slots (a maximum has no order)
@@ -1258,7 +1431,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
         }
       }
     }
-    if (!cluster_barrier(W, C, &s_flag)) return;
+    CL_BARRIER();
     if (it == 0) {
       currentChi = cluster_total(W, 0);
       if (leader && tid == 0) st->chi2_initial = currentChi;
@@ -1271,10 +1444,13 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
     double tempChi = currentChi, rho = 0;
     int qmax = 0;
     do {
+      ph = 2;
       cl_t_rows(W, C, lambda);
-      if (!cluster_barrier(W, C, &s_flag)) return;
+      CL_BARRIER();
+      ph = 3;
       cl_schur(W, C, wred, lambda);
-      if (!cluster_barrier(W, C, &s_flag)) return;
+      CL_BARRIER();
+      ph = 6;
       if (leader) {
         for (int i = tid; i < n * (n + 1) / 2; i += NT) S[i] = 0.0;
         __syncthreads();
@@ -1285,15 +1461,19 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
         }
         for (int t = tid; t < n; t += NT) rhs[t] = W.rhsg[t];
         __syncthreads();
-        const bool ok = win_cholesky<false>(S, diag, ctl + 64, n);     // (Lp: the reduction buffers are idle during the solve)
+        lap(4);
+        // (rhs IS row n of the packed triangle; diag: 1 / L_kk; Lp: the reduction buffers are idle during the solve)
+        const bool ok = win_cholesky_rhs(S, diag, ctl + 64, n, reinterpret_cast<int*>(ctl + 61), W.prof);
+        lap(5);
         if (ok) {
-          if (wave == 0) win_substitute<false>(S, diag, ctl + 64, rhs, n);
+          if (wave == 0) win_backsubstitute(S, diag, ctl + 64, rhs, n);
           __syncthreads();
           for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];
         }
         if (tid == 0) { W.cl_ctl[0] = ok ? 1.0 : 0.0; W.cl_ctl[1] = (stop && *stop) ? 1.0 : 0.0; }
       }
-      if (!cluster_barrier(W, C, &s_flag)) return;
+      CL_BARRIER();
+      ph = 7;
       const bool ok = W.cl_ctl[0] != 0.0;
       const size_t Fp = (size_t)W.Fp;
       if (ok) {      // W^T x_p of this workgroup's rows
@@ -1312,7 +1492,8 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
           }
         }
       }
-      if (!cluster_barrier(W, C, &s_flag)) return;
+      CL_BARRIER();
+      ph = 8;
       // landmarks of this workgroup: xl = Dinv (bl - sum of their rows' W^T x_p), the trial point, the scale terms; its cameras: oplus
       for (int p = C.g; p < kParts; p += G) {
         int lo, hi;
@@ -1326,6 +1507,8 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
             for (int j = 0; j < 12; j++) h[j] = hb[j];
             w_dinv(h, lambda, Di, d3);
             double c0 = h[9], c1 = h[10], c2 = h[11];
+            // (the rows' W^T x_p come from the phase above: formed here, by the landmark's thread -- one phase and one barrier less -- the
+            //  scattered W loads made this phase 46-54 us instead of 18 + 18)
             for (int q = W.pt_start[li]; q < W.pt_start[li + 1]; q++) {
               const int r = W.pt_edges[q];
               if (r >= W.F) break;
@@ -1354,11 +1537,13 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
           for (int a = 0; a < 6; a++) { const double xj = W.x[6 * i + a]; W.terms[6 * i + a] = xj * (lambda * xj + W.bp[6 * i + a]); }
         }
       }
-      if (!cluster_barrier(W, C, &s_flag)) return;
+      CL_BARRIER();
+      ph = 9;
       cl_edge_pass<false>(W, C, poses_t, pts_t);
       cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
       cluster_partial_sums(W, C, W.terms, n + nl, 1, red);
-      if (!cluster_barrier(W, C, &s_flag)) return;
+      CL_BARRIER();
+      ph = 11;
       // ---- the decision, taken by every thread of every workgroup on the same words (optimization_algorithm_levenberg.cpp:113-147)
       tempChi = ok ? cluster_total(W, 0) : 1.7976931348623157e308;
       rho = currentChi - tempChi;
@@ -1390,7 +1575,7 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
   if (it_done == 0) {     // no iteration ran: the edges are evaluated at the unchanged input state (see k_ba_window)
     cl_edge_pass<false>(W, C, poses, pts);
     cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
-    if (!cluster_barrier(W, C, &s_flag)) return;
+    CL_BARRIER();
     chi_last = cluster_total(W, 0);
     if (leader && tid == 0) st->chi2_initial = chi_last;
   }
@@ -1417,6 +1602,8 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
   if (leader && tid == 0) {
     st->iterations = it_done; st->total_trials = trials_total; st->chi2_final = chi_last; st->lambda_final = lambda; st->stop_reason = stop_reason;
   }
+  lap(11);
+#undef CL_BARRIER
 #undef s_flag
 }
 
@@ -1448,6 +1635,40 @@ struct WinBuild {
   // built by 16 threads spent 2.3 ms of a 9 ms call in the page faults of their ~2 MB of vectors each)
   std::vector<int32_t> t_by_lm, t_ep, t_ept, t_cnt, t_blk_of, t_cr, t_fill;
   std::vector<double> t_eo, t_ei;
+  // the fast form's tables packed into page-locked memory by the builder's own thread, while they are in its caches (pack_fast); the block
+  // is one input of the call's staging, sent from where it lies
+  PinnedArena arena;
+  struct ArenaOff { ptrdiff_t poses, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, pt_start, f_cam, blk_ij, e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs; } ao;
+  ptrdiff_t shared_off = -1;          // >= 0: the tables lie at this offset of the call's shared block, not in `arena`
+  size_t packed_bytes = 0;
+  int pack_fast(PinnedArena* shared) {
+    auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    auto b4 = [&](const std::vector<int32_t>& v) { return pad(v.size() * 4); };
+    auto b8 = [&](const std::vector<double>& v) { return pad(v.size() * 8); };
+    const size_t total = b8(poses) + b4(pidx) + b4(lidx) + b4(free_pose) + b4(act_pt) + b4(e_pose) + b4(e_point) + b8(e_obs) + b8(e_info) + b4(pt_start) + b4(f_cam) +
+                         b4(blk_ij) + b4(e_orig) + b4(e_lm) + b4(cam_start) + b4(pt_edges) + b4(bp_start) + b4(bp_pairs);
+    shared_off = shared ? shared->claim(total) : -1;
+    if (shared_off < 0) { const int rc = arena.reserve(total); if (rc != DVM_OK) return rc; }
+    else arena.used = 0;
+    // (a span of the shared block is filled through a view of it: base at the span, the same bump logic)
+    uint8_t* const base = shared_off >= 0 ? shared->base + shared_off : arena.base;
+    size_t used = 0;
+    auto put = [&](const void* src, size_t bytes) -> ptrdiff_t {
+      if (!bytes) return -1;
+      const size_t off = used;
+      std::memcpy(base + off, src, bytes);
+      used = off + pad(bytes);
+      return (ptrdiff_t)off;
+    };
+    auto p4 = [&](const std::vector<int32_t>& v) { return put(v.data(), v.size() * 4); };
+    auto p8 = [&](const std::vector<double>& v) { return put(v.data(), v.size() * 8); };
+    ao.poses = p8(poses); ao.pidx = p4(pidx); ao.lidx = p4(lidx); ao.free_pose = p4(free_pose); ao.act_pt = p4(act_pt); ao.e_pose = p4(e_pose); ao.e_point = p4(e_point);
+    ao.e_obs = p8(e_obs); ao.e_info = p8(e_info); ao.pt_start = p4(pt_start); ao.f_cam = p4(f_cam); ao.blk_ij = p4(blk_ij); ao.e_orig = p4(e_orig); ao.e_lm = p4(e_lm);
+    ao.cam_start = p4(cam_start); ao.pt_edges = p4(pt_edges); ao.bp_start = p4(bp_start); ao.bp_pairs = p4(bp_pairs);
+    if (shared_off < 0) arena.used = used;
+    packed_bytes = used;
+    return DVM_OK;
+  }
   void reset() {
     P = L = E = F = nfree = nact = nblk = 0; C = 128; C2 = 256; n_sc = n_hc = stage_doubles = 0; Fp = Ep = 0;
     for (auto* v : {&pidx, &lidx, &free_pose, &act_pt, &e_pose, &e_point, &lpos, &fpos, &pt_start, &f_start, &f_cam, &hc_ints, &sc_desc, &sc_ints, &blk_ij,
@@ -1530,7 +1751,9 @@ int build_window_fast(WinBuild& b) {
     fill.assign(b.bp_start.begin(), b.bp_start.end() - 1);
     each_pair([&](int i1, int i2, int r1, int r2) { const int at = fill[blk_of[(size_t)i1 * nf + i2]]++; b.bp_pairs[2 * (size_t)at] = r1; b.bp_pairs[2 * (size_t)at + 1] = r2; }); }
   b.n_hc = b.n_sc = 0;
-  b.stage_doubles = (kWinThreads / 64) * 4 * 36;       // the waves' reduction buffers
+  // the waves' reduction buffers; during the solve the same area (from ctl + 64 on: 256 doubles of tree partials first) holds the panel copy
+  // of win_cholesky_rhs, (n + 1) rows of kLpPitch doubles
+  b.stage_doubles = std::max((kWinThreads / 64) * 4 * 36, kLpPitch * (6 * nf + 1) - 256 + 8);
   return DVM_OK;
 }
 
@@ -1679,20 +1902,77 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   std::vector<WinBuild> local_builds;
   if (fast) { if ((int)build_pool.size() < K) build_pool.resize(K); } else local_builds.resize(K);
   std::vector<WinBuild>& B = fast ? build_pool : local_builds;
+  // the fast form's tables of ALL windows go into one page-locked block (one DMA): sized before the builds from a generous estimate --
+  // ~66 bytes per edge are typical --; a window that finds it full packs into a block of its own
+  static thread_local PinnedArena shared_tables_tls;
+  // ... and travel to a device block of the same size, every window's span the moment its builder has packed it (from the builder's thread,
+  // on one of four upload streams: the copies of the first windows run under the builds of the last, and side by side -- one 32 MB copy
+  // behind the builds took 1.4 ms, 23 GB/s); the launch's stream waits for the four streams' events
+  struct TableUpload {
+    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t* dev = nullptr; size_t dcap = 0; int device = -1;
+    void release() {
+      for (int i = 0; i < 4; i++) { if (s[i]) { hipStreamSynchronize(s[i]); hipStreamDestroy(s[i]); } if (e[i]) hipEventDestroy(e[i]); s[i] = nullptr; e[i] = nullptr; }
+      if (dev) hipFree(dev);
+      dev = nullptr; dcap = 0;
+    }
+    int ensure(int dev_id, size_t bytes) {
+      if (dev_id != device) { release(); device = dev_id; }
+      for (int i = 0; i < 4; i++) {
+        if (!s[i]) { int rc = hip_check(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking), "stream"); if (rc != DVM_OK) return rc; }
+        if (!e[i]) { int rc = hip_check(hipEventCreateWithFlags(&e[i], hipEventDisableTiming), "event"); if (rc != DVM_OK) return rc; }
+      }
+      if (bytes > dcap) {
+        if (dev) hipFree(dev);
+        dev = nullptr; dcap = 0;
+        int rc = hip_check(hipMalloc(reinterpret_cast<void**>(&dev), bytes), "hipMalloc(window tables)");
+        if (rc != DVM_OK) return rc;
+        dcap = bytes;
+      }
+      return DVM_OK;
+    }
+    ~TableUpload() { release(); }
+  };
+  static thread_local TableUpload tup_tls;
+  // (the builders' threads must see THIS thread's block and streams: a thread_local named inside their lambda would be their own)
+  PinnedArena& shared_tables = shared_tables_tls;
+  TableUpload& tup = tup_tls;
+  if (fast) {
+    size_t est = 0;
+    for (int k = 0; k < K; k++) est += 80 * (size_t)std::max(windows[k].n_poses, 0) + 16 * (size_t)std::max(windows[k].n_points, 0) + 96 * (size_t)std::max(windows[k].n_edges, 0) + (64 << 10);
+    if ((rc = shared_tables.reserve(est)) != DVM_OK) return rc;
+    if ((rc = tup.ensure(device, shared_tables.cap)) != DVM_OK) return rc;
+  }
+  auto send_tables = [&](int k) -> int {        // window k's span of the shared block -> the device block, asynchronously
+    const WinBuild& b = B[k];
+    if (b.shared_off < 0 || !b.packed_bytes) return (int)DVM_OK;
+    return hip_check(hipMemcpyAsync(tup.dev + b.shared_off, shared_tables.base + b.shared_off, b.packed_bytes, hipMemcpyHostToDevice, tup.s[k & 3]), "upload(window tables)");
+  };
   if (fast && K > 1) {
     // the windows' index tables are independent: built by up to 16 pooled host threads (0.2 ms each; 32 of them one after the other would cost
     // more than the launch that solves them)
     std::vector<int> rcs(K, DVM_OK);
     std::vector<std::string> errs(K);
-    HostPool::get().run((size_t)K, 32, [&](size_t k) {
+    static const int bt = std::getenv("DVM_BA_BUILD_THREADS") ? std::max(1, atoi(std::getenv("DVM_BA_BUILD_THREADS"))) : 32;
+    HostPool::get().run((size_t)K, bt, [&](size_t k) {
       rcs[k] = build_window(windows[k], B[k], normalize_input, true);
+      if (rcs[k] == DVM_OK) { hipSetDevice(device); rcs[k] = B[k].pack_fast(&shared_tables); }
+      if (rcs[k] == DVM_OK) rcs[k] = send_tables((int)k);     // (a pooled thread: the device of the call, for the arena's first allocation)
       if (rcs[k] != DVM_OK) errs[k] = last_error_cstr();
     });
     for (int k = 0; k < K; k++) if (rcs[k] != DVM_OK) { set_error(errs[k]); return rcs[k]; }
   } else {
-    for (int k = 0; k < K; k++) if ((rc = build_window(windows[k], B[k], normalize_input, fast)) != DVM_OK) return rc;
+    for (int k = 0; k < K; k++) {
+      if ((rc = build_window(windows[k], B[k], normalize_input, fast)) != DVM_OK) return rc;
+      if (fast && ((rc = B[k].pack_fast(&shared_tables)) != DVM_OK || (rc = send_tables(k)) != DVM_OK)) return rc;
+    }
   }
   const auto t1 = std::chrono::steady_clock::now();
+  if (fast && std::getenv("DVM_BA_WINDOW_TIMING")) {     // (measurement only: how long the tables' copies run on behind the builds)
+    for (int i = 0; i < 4; i++) hipStreamSynchronize(tup.s[i]);
+    std::fprintf(stderr, "tables: %.1f MB, copies done %.2f ms behind the builds\n", shared_tables.top() / 1048576.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  }
   thread_local StopWord sw;
   if ((rc = sw.ensure()) != DVM_OK) return rc;
   *sw.h = (stop_flag && *stop_flag) ? 1 : 0;
@@ -1707,8 +1987,15 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   std::vector<unsigned long long> prof_zero(16, 0);
   auto I32 = [&](const std::vector<int32_t>& v) { return st.in(v.empty() ? nullptr : v.data(), v.size() * 4); };
   auto F64 = [&](const std::vector<double>& v) { return st.in(v.empty() ? nullptr : v.data(), v.size() * 8); };
+  std::vector<int> arena_slot(K, -1);
+  if (fast) for (int i = 0; i < 4; i++) DVM_HIP(hipEventRecord(tup.e[i], tup.s[i]));
   for (int k = 0; k < K; k++) {                     // inputs: the state and g2o's graph structure as index arrays
     const WinBuild& b = B[k]; Slots& s = sl[k];
+    if (fast) {     // the window's tables: already page-locked (WinBuild::pack_fast); the landmarks from the caller's array
+      if (b.shared_off < 0) arena_slot[k] = st.in_pinned(b.arena.used ? b.arena.base : nullptr, b.arena.used);
+      s.pts = st.in(b.L ? windows[k].points : nullptr, 24 * (size_t)b.L);
+      continue;
+    }
     s.poses = F64(b.poses);
     s.pts = st.in(b.L ? windows[k].points : nullptr, 24 * (size_t)b.L);
     s.pidx = I32(b.pidx); s.lidx = I32(b.lidx); s.free_pose = I32(b.free_pose); s.act_pt = I32(b.act_pt); s.e_pose = I32(b.e_pose); s.e_point = I32(b.e_point);
@@ -1759,20 +2046,30 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     v.P = b.P; v.L = b.L; v.E = b.E; v.F = b.F; v.nfree = b.nfree; v.nact = b.nact; v.nblk = b.nblk; v.iterations = windows[k].iterations;
     v.C = b.C; v.C2 = b.C2; v.n_sc = b.n_sc; v.n_hc = b.n_hc; v.stage_doubles = b.stage_doubles;
     v.fx = windows[k].cam.fx; v.fy = windows[k].cam.fy; v.cx = windows[k].cam.cx; v.cy = windows[k].cam.cy; v.delta = windows[k].cam.huber_delta;
-    v.poses = st.ptr<double>(s.poses); v.pts = st.ptr<double>(s.pts); v.poses_t = st.ptr<double>(s.poses_t); v.pts_t = st.ptr<double>(s.pts_t);
+    v.pts = st.ptr<double>(s.pts); v.poses_t = st.ptr<double>(s.poses_t); v.pts_t = st.ptr<double>(s.pts_t);
     v.out_poses = st.ptr<double>(s.out_poses); v.out_pts = st.ptr<double>(s.out_pts);
+    uint8_t* const ab = !fast ? nullptr : b.shared_off >= 0 ? tup.dev + b.shared_off : st.ptr<uint8_t>(arena_slot[k]);   // the window's tables on the device
+    auto A4 = [&](ptrdiff_t off) { return off < 0 ? nullptr : reinterpret_cast<int32_t*>(ab + off); };
+    auto A8 = [&](ptrdiff_t off) { return off < 0 ? nullptr : reinterpret_cast<double*>(ab + off); };
+    if (fast) {
+      v.poses = A8(b.ao.poses); v.pidx = A4(b.ao.pidx); v.lidx = A4(b.ao.lidx); v.free_pose = A4(b.ao.free_pose); v.act_pt = A4(b.ao.act_pt);
+      v.e_pose = A4(b.ao.e_pose); v.e_point = A4(b.ao.e_point); v.e_obs = A8(b.ao.e_obs); v.e_info = A8(b.ao.e_info);
+      v.pt_start = A4(b.ao.pt_start); v.f_cam = A4(b.ao.f_cam);
+    } else {
+    v.poses = st.ptr<double>(s.poses);
     v.pidx = st.ptr<int32_t>(s.pidx); v.lidx = st.ptr<int32_t>(s.lidx); v.free_pose = st.ptr<int32_t>(s.free_pose); v.act_pt = st.ptr<int32_t>(s.act_pt);
     v.e_pose = st.ptr<int32_t>(s.e_pose); v.e_point = st.ptr<int32_t>(s.e_point); v.e_obs = st.ptr<double>(s.e_obs); v.e_info = st.ptr<double>(s.e_info);
     v.lpos = st.ptr<int32_t>(s.lpos); v.fpos = st.ptr<int32_t>(s.fpos); v.pt_start = st.ptr<int32_t>(s.pt_start); v.f_start = st.ptr<int32_t>(s.f_start);
     v.f_cam = st.ptr<int32_t>(s.f_cam);
+    }
     v.rowB = fast ? nullptr : st.ptr<double>(s.rowB); v.rowA = st.ptr<double>(s.rowA); v.rowW = fast ? nullptr : st.ptr<double>(s.rowW);
     v.e_chi2 = st.ptr<double>(s.echi); v.e_rho = st.ptr<double>(s.erho); v.e_depth = st.ptr<uint8_t>(s.edepth);
-    v.hc_ints = st.ptr<int32_t>(s.hc_ints); v.sc_desc = st.ptr<int32_t>(s.sc_desc); v.sc_ints = st.ptr<int32_t>(s.sc_ints);
-    v.blk_ij = st.ptr<int32_t>(s.blk_ij);
+    if (!fast) { v.hc_ints = st.ptr<int32_t>(s.hc_ints); v.sc_desc = st.ptr<int32_t>(s.sc_desc); v.sc_ints = st.ptr<int32_t>(s.sc_ints); v.blk_ij = st.ptr<int32_t>(s.blk_ij); }
     if (fast) {
       v.Fp = b.Fp; v.Ep = b.Ep;
-      v.e_orig = st.ptr<int32_t>(s.e_orig); v.e_lm = st.ptr<int32_t>(s.e_lm); v.cam_start = st.ptr<int32_t>(s.cam_start); v.pt_edges = st.ptr<int32_t>(s.pt_edges);
-      v.bp_start = st.ptr<int32_t>(s.bp_start); v.bp_pairs = reinterpret_cast<const int2*>(st.ptr<int32_t>(s.bp_pairs));
+      v.blk_ij = A4(b.ao.blk_ij);
+      v.e_orig = A4(b.ao.e_orig); v.e_lm = A4(b.ao.e_lm); v.cam_start = A4(b.ao.cam_start); v.pt_edges = A4(b.ao.pt_edges);
+      v.bp_start = A4(b.ao.bp_start); v.bp_pairs = reinterpret_cast<const int2*>(A4(b.ao.bp_pairs));
       v.Bs = st.ptr<double>(s.Bs); v.Ws = st.ptr<double>(s.Ws); v.Ts = st.ptr<double>(s.Ts); v.Cs = st.ptr<double>(s.Cs); v.chi_s = st.ptr<double>(s.chi_s);
       v.cl_ctr = st.ptr<unsigned int>(s.cl_sync); v.cl_tmo = v.cl_ctr + 8;
       v.Sblk = st.ptr<double>(s.Sblk); v.rhsg = st.ptr<double>(s.rhsg); v.cl_part = st.ptr<double>(s.cl_part); v.cl_ctl = st.ptr<double>(s.cl_ctl);
@@ -1786,6 +2083,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   }
   const auto t1c = std::chrono::steady_clock::now();
   if ((rc = st.upload()) != DVM_OK) return rc;
+  if (fast) for (int i = 0; i < 4; i++) DVM_HIP(hipStreamWaitEvent(st.stream(), tup.e[i], 0));     // the tables have arrived before the launch starts
   const auto t1d = std::chrono::steady_clock::now();
   // dynamic LDS: the packed reduced system of the largest window, rhs / diagonal, control words and the streaming area
   const size_t lds_bytes = sizeof(double) * lds_doubles;
@@ -1837,8 +2135,12 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   }
   const auto t2 = std::chrono::steady_clock::now();
   if (want_prof) {
-    static const char* names[16] = {"edge pass + Jacobians", "Hll / bl", "Hpp / bp (streamed)", "schur: rhs chain", "Schur (streamed)", "Cholesky", "forward / backward", "landmark back-sub",
+    static const char* names_seq[16] = {"edge pass + Jacobians", "Hll / bl", "Hpp / bp (streamed)", "schur: rhs chain", "Schur (streamed)", "Cholesky", "forward / backward", "landmark back-sub",
                                     "oplus + scale terms", "edge pass chi2", "sequential sums", "schur: runs + wait", "schur: store + prefetch", "schur: Dinv", "schur: W Dinv", "decision + rest"};
+    const char* const* names = names_seq;
+    static const char* cnames[16] = {"edge pass + Jacobians", "Hll / bl, Hpp / bp", "W Dinv rows", "Schur blocks + rhs", "assemble S in LDS", "Cholesky", "substitution + x", "W^T x rows",
+                                     "landmarks + oplus", "edge pass chi2 + sums", "IN BARRIERS (workgroup 0)", "decision + rest", "  chol: diagonal block", "  chol: panel", "  chol: barriers", "  chol: trailing update"};
+    if (fast) names = cnames;
     for (int i = 0; i < 16; i++) if (prof_out[0][i]) std::fprintf(stderr, "window 0: %-24s %10.1f us\n", names[i], prof_out[0][i] / 2400.0);   // s_memtime ticks at the shader clock (MI355X_MICROARCH.md): us at 2.4 GHz
   }
   for (int k = 0; k < K; k++) {

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -177,6 +178,47 @@ class HelperThread {
   ~HelperThread() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
 };
 
+// Page-locked host memory a builder packs its tables into (one block per bundle-adjustment window, kept with the pooled builder): the
+// block is sent to the device from where it is (Stage::in_pinned).  The staging copy of 30 MB of window tables -- a separate pass over
+// data that had left the builders' caches -- was 1.2 ms of a 5.5 ms call.
+struct PinnedArena {
+  uint8_t* base = nullptr;
+  size_t cap = 0, used = 0;
+  int reserve(size_t bytes) {
+    used = 0; claimed.store(0);
+    if (bytes <= cap) return DVM_OK;
+    if (base) hipHostFree(base);
+    base = nullptr; cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+    int rc = hip_check(hipHostMalloc(reinterpret_cast<void**>(&base), want, hipHostMallocPortable), "hipHostMalloc(window tables)");
+    if (rc != DVM_OK) { base = nullptr; return rc; }
+    cap = want;
+    return DVM_OK;
+  }
+  // appends `bytes` from src at the next 256-byte boundary; returns the offset (-1: nothing to send)
+  ptrdiff_t put(const void* src, size_t bytes) {
+    if (!bytes) return -1;
+    const size_t off = used;
+    std::memcpy(base + off, src, bytes);
+    used = off + ((bytes + 255) & ~(size_t)255);
+    return (ptrdiff_t)off;
+  }
+  // several builders, one block (one DMA for all of them: 32 separate 1 MB copies cost 40 us each): claim() hands out a span, -1 when the
+  // block is full (the builder then packs into an arena of its own); top() = what has been claimed
+  std::atomic<size_t> claimed{0};
+  ptrdiff_t claim(size_t bytes) {
+    const size_t off = claimed.fetch_add(bytes);
+    return off + bytes <= cap ? (ptrdiff_t)off : -1;
+  }
+  size_t top() const { return std::min(claimed.load(), cap); }
+  PinnedArena() = default;
+  PinnedArena(const PinnedArena&) = delete;
+  PinnedArena& operator=(const PinnedArena&) = delete;
+  PinnedArena(PinnedArena&& o) noexcept : base(o.base), cap(o.cap), used(o.used) { o.base = nullptr; o.cap = o.used = 0; }   // (claimed: a moved arena is not in use)
+  PinnedArena& operator=(PinnedArena&& o) noexcept { if (this != &o) { if (base) hipHostFree(base); base = o.base; cap = o.cap; used = o.used; o.base = nullptr; o.cap = o.used = 0; } return *this; }
+  ~PinnedArena() { if (base) hipHostFree(base); }
+};
+
 // Items come in two kinds.  COPIED (in / out / scratch): packed into the pinned buffer, one asynchronous H2D copy, kernels, one D2H
 // copy -- for anything a kernel reads more than once or updates in place.  MAPPED (in_mapped / out_mapped): the kernel reads the
 // input from / writes the output to page-locked host memory directly -- for arrays touched ONCE per call (a query list, a result
@@ -184,15 +226,17 @@ class HelperThread {
 // ~16 KB out is a chain of latencies, not a bandwidth problem.  A call whose items are all mapped queues no copy at all.
 // Kernels of the convenience paths are launched on stream() -- one in-order chain per calling thread.
 struct Stage {
-  struct Item { const void* src; void* dst; size_t bytes, off; bool mapped; };
+  struct Item { const void* src; void* dst; size_t bytes, off; bool mapped; bool direct = false; };
   std::vector<Item> items;
   size_t total = 0, in_bytes = 0, mapped_total = 0;
   uint8_t* d = nullptr;
   StageCtx* ctx = nullptr;
   int add(const void* src, void* dst, size_t bytes, bool mapped = false) {
-    items.push_back({src, dst, bytes, 0, mapped});
+    items.push_back({src, dst, bytes, 0, mapped, false});
     return (int)items.size() - 1;
   }
+  // an input that already lies in page-locked host memory (a PinnedArena): sent from where it is, no copy into the staging buffer
+  int in_pinned(const void* src, size_t bytes) { const int i = add(src, nullptr, src ? bytes : 0); items[i].direct = true; return i; }
   int in_mapped(const void* src, size_t bytes) { return add(src, nullptr, src ? bytes : 0, true); }
   int out_mapped(void* dst, size_t bytes) { return add(nullptr, dst, dst ? bytes : 0, true); }
   hipStream_t stream() const { return ctx ? ctx->s : nullptr; }
@@ -204,8 +248,9 @@ struct Stage {
   // device addresses of other items (a table of views) calls layout() first, fills them in, then upload().
   int layout() {
     size_t off = 0, moff = 0;
-    for (Item& it : items) if (it.src && !it.mapped) { it.off = off; off += pad(it.bytes); }
+    for (Item& it : items) if (it.src && !it.mapped && !it.direct) { it.off = off; off += pad(it.bytes); }
     in_bytes = off;
+    for (Item& it : items) if (it.src && !it.mapped && it.direct) { it.off = off; off += pad(it.bytes); }
     for (Item& it : items) if (!it.src && !it.mapped) { it.off = off; off += pad(it.bytes); }
     total = off;
     for (Item& it : items) if (it.mapped) { it.off = moff; moff += pad(it.bytes); }
@@ -220,17 +265,21 @@ struct Stage {
   int upload() {
     int rc = d ? DVM_OK : layout();
     if (rc != DVM_OK) return rc;
+    for (const Item& it : items)        // (first: their DMA runs under the host copies of the staged items below)
+      if (it.direct && it.bytes && (rc = hip_check(hipMemcpyAsync(d + it.off, it.src, it.bytes, hipMemcpyHostToDevice, ctx->s), "upload")) != DVM_OK) return rc;
     if (in_bytes > ((size_t)8 << 20)) {
       // a large batch: the inputs go in four pieces, each piece's host copies (pooled threads) under the previous piece's DMA
       std::vector<size_t> idx;
-      for (size_t i = 0; i < items.size(); i++) if (items[i].src && !items[i].mapped) idx.push_back(i);
+      for (size_t i = 0; i < items.size(); i++) if (items[i].src && !items[i].mapped && !items[i].direct) idx.push_back(i);
       for (size_t i = 0; i < items.size(); i++) if (items[i].src && items[i].mapped && items[i].bytes) std::memcpy(ctx->hm + items[i].off, items[i].src, items[i].bytes);
       size_t first = 0;
-      for (int piece = 0; piece < 4 && first < idx.size(); piece++) {
-        const size_t lo = items[idx[first]].off, want = piece == 3 ? in_bytes : (in_bytes * (piece + 1)) / 4;
+      static const int np = std::getenv("DVM_STAGE_PIECES") ? std::max(1, atoi(std::getenv("DVM_STAGE_PIECES"))) : 4;
+      static const int nt = std::getenv("DVM_STAGE_THREADS") ? std::max(1, atoi(std::getenv("DVM_STAGE_THREADS"))) : 8;
+      for (int piece = 0; piece < np && first < idx.size(); piece++) {
+        const size_t lo = items[idx[first]].off, want = piece == np - 1 ? in_bytes : (in_bytes * (piece + 1)) / np;
         size_t last = first;
-        while (last < idx.size() && (piece == 3 || items[idx[last]].off + pad(items[idx[last]].bytes) <= want || last == first)) last++;
-        HostPool::get().run(last - first, 8, [&](size_t j) { const Item& it = items[idx[first + j]]; if (it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes); });
+        while (last < idx.size() && (piece == np - 1 || items[idx[last]].off + pad(items[idx[last]].bytes) <= want || last == first)) last++;
+        HostPool::get().run(last - first, nt, [&](size_t j) { const Item& it = items[idx[first + j]]; if (it.bytes) std::memcpy(ctx->h + it.off, it.src, it.bytes); });
         const size_t hi = last < idx.size() ? items[idx[last]].off : in_bytes;
         rc = hip_check(hipMemcpyAsync(d + lo, ctx->h + lo, hi - lo, hipMemcpyHostToDevice, ctx->s), "upload");
         if (rc != DVM_OK) return rc;
@@ -246,10 +295,10 @@ struct Stage {
   // one thread moves ~10 GB/s, the DMA engine behind it 55
   void copy_items(bool up) {
     size_t bytes = 0;
-    for (const Item& it : items) if ((up ? (const void*)it.src : (const void*)it.dst) && it.bytes) bytes += it.bytes;
+    for (const Item& it : items) if ((up ? (const void*)it.src : (const void*)it.dst) && it.bytes && !(up && it.direct)) bytes += it.bytes;
     auto one = [&](const Item& it) {
       uint8_t* stage = (it.mapped ? ctx->hm : ctx->h) + it.off;
-      if (up) { if (it.src && it.bytes) std::memcpy(stage, it.src, it.bytes); }
+      if (up) { if (it.src && it.bytes && !it.direct) std::memcpy(stage, it.src, it.bytes); }
       else if (it.dst && it.bytes) std::memcpy(it.dst, stage, it.bytes);
     };
     if (bytes <= ((size_t)4 << 20)) { for (const Item& it : items) one(it); return; }
