@@ -1413,6 +1413,10 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window_cluster(const BaWin* 
   bool stopped = W.cl_ctl[1] != 0.0;
   for (int it = 0; it < W.iterations && !stopped; it++) {
     ph = 0;
+    // (Evaluating a trial WITH its Jacobians into a second set of rows, so that an accepted trial hands the next iteration its linearisation --
+    //  as the tile solver's loop and k_pose_optimize do -- was measured: 2.92 -> 3.27 ms for 32 windows.  The pass it saves is 15 us, but
+    //  two sets of rows are 260 MB for 32 windows and no longer stay in the 256 MB memory-side cache: the accumulation behind it went from
+    //  27 to 48 us, the W Dinv pass from 18 to 25.)
     cl_edge_pass<true>(W, C, poses, pts);
     if (it == 0) cluster_partial_sums(W, C, W.e_rho, W.E, 0, red);
     CL_BARRIER();
@@ -1944,6 +1948,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     if ((rc = shared_tables.reserve(est)) != DVM_OK) return rc;
     if ((rc = tup.ensure(device, shared_tables.cap)) != DVM_OK) return rc;
   }
+  const bool private_tables = fast && std::getenv("DVM_BA_TEST_PRIVATE_TABLES") != nullptr;   // (test hook: every second window packs into a block of its own, as one that finds the shared block full does)
   auto send_tables = [&](int k) -> int {        // window k's span of the shared block -> the device block, asynchronously
     const WinBuild& b = B[k];
     if (b.shared_off < 0 || !b.packed_bytes) return (int)DVM_OK;
@@ -1957,7 +1962,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     static const int bt = std::getenv("DVM_BA_BUILD_THREADS") ? std::max(1, atoi(std::getenv("DVM_BA_BUILD_THREADS"))) : 32;
     HostPool::get().run((size_t)K, bt, [&](size_t k) {
       rcs[k] = build_window(windows[k], B[k], normalize_input, true);
-      if (rcs[k] == DVM_OK) { hipSetDevice(device); rcs[k] = B[k].pack_fast(&shared_tables); }
+      if (rcs[k] == DVM_OK) { hipSetDevice(device); rcs[k] = B[k].pack_fast((private_tables && (k & 1)) ? nullptr : &shared_tables); }
       if (rcs[k] == DVM_OK) rcs[k] = send_tables((int)k);     // (a pooled thread: the device of the call, for the arena's first allocation)
       if (rcs[k] != DVM_OK) errs[k] = last_error_cstr();
     });
@@ -2010,15 +2015,15 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   if (fast) for (int k = 0; k < K; k++) sl[k].cl_sync = st.add(sync_zero.data(), sync_back[k].data(), 64);
   std::vector<BaWin> views(K);
   const int views_slot = st.in(views.data(), sizeof(BaWin) * (size_t)K);   // filled in below, once layout() has placed everything
-  struct Outs { std::vector<double> poses, pts, chi2; std::vector<uint8_t> depth; dvm_ba_stats st; };
+  struct Outs { dvm_ba_stats st; };
   std::vector<Outs> outs(K);
-  for (int k = 0; k < K; k++) {                     // outputs (one contiguous span to fetch)
+  for (int k = 0; k < K; k++) {                     // outputs (one contiguous span to fetch), straight into the caller's arrays where it gave any
     const WinBuild& b = B[k]; Slots& s = sl[k]; Outs& o = outs[k];
-    o.poses.resize(7 * (size_t)b.P); o.pts.resize(3 * (size_t)b.L); o.chi2.resize(b.E); o.depth.resize(b.E);
-    s.out_poses = st.out(o.poses.data(), 56 * (size_t)b.P);
-    s.out_pts = st.out(o.pts.data(), 24 * (size_t)b.L);
-    s.echi = st.out(o.chi2.data(), 8 * (size_t)b.E);
-    s.edepth = st.out(o.depth.data(), (size_t)b.E);
+    const dvm_ba_window& w = windows[k];
+    s.out_poses = (w.poses_out && b.P) ? st.out(w.poses_out, 56 * (size_t)b.P) : st.scratch(56 * (size_t)b.P);
+    s.out_pts = (w.points_out && b.L) ? st.out(w.points_out, 24 * (size_t)b.L) : st.scratch(24 * (size_t)b.L);
+    s.echi = (w.edge_chi2_out && b.E) ? st.out(w.edge_chi2_out, 8 * (size_t)b.E) : st.scratch(8 * (size_t)b.E);
+    s.edepth = (w.depth_positive_out && b.E) ? st.out(w.depth_positive_out, (size_t)b.E) : st.scratch((size_t)b.E);
     s.stats = st.out(&o.st, sizeof(dvm_ba_stats));
     s.prof = want_prof ? st.add(prof_zero.data(), prof_out[k].data(), 128) : -1;
   }
@@ -2144,11 +2149,6 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
     for (int i = 0; i < 16; i++) if (prof_out[0][i]) std::fprintf(stderr, "window 0: %-24s %10.1f us\n", names[i], prof_out[0][i] / 2400.0);   // s_memtime ticks at the shader clock (MI355X_MICROARCH.md): us at 2.4 GHz
   }
   for (int k = 0; k < K; k++) {
-    const dvm_ba_window& w = windows[k];
-    if (w.poses_out && B[k].P) std::memcpy(w.poses_out, outs[k].poses.data(), 56 * (size_t)B[k].P);
-    if (w.points_out && B[k].L) std::memcpy(w.points_out, outs[k].pts.data(), 24 * (size_t)B[k].L);
-    if (w.edge_chi2_out && B[k].E) std::memcpy(w.edge_chi2_out, outs[k].chi2.data(), 8 * (size_t)B[k].E);
-    if (w.depth_positive_out && B[k].E) std::memcpy(w.depth_positive_out, outs[k].depth.data(), (size_t)B[k].E);
     if (stats) {
       stats[k] = outs[k].st;
       if (fast && kev.a) { float ms = 0; if (hipEventElapsedTime(&ms, kev.a, kev.b) == hipSuccess) stats[k].kernel_us = (int32_t)(ms * 1e3f + 0.5f); }
@@ -2165,12 +2165,13 @@ int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, con
   return dvm_ba_optimize_windows_impl(device, windows, K, stop_flag, stats, true, false, 0);
 }
 int dvm_ba_optimize_windows_fast(int device, const dvm_ba_window* windows, int K, const volatile uint8_t* stop_flag, dvm_ba_stats* stats) {
-  // A batch of 64 or more windows goes in two halves, the second on a persistent helper thread with its own staging buffers and stream: the
-  // host side of such a call (tables, 60+ MB of staging) is as long as its kernel, and two threads halve it; the two launches (G workgroups
-  // per window each) share the chip.  Every window's result is independent of its batch and of G, so the split changes nothing but the
-  // time (128 windows: 23 -> 18 ms = 72 k it/s; 32 windows gain nothing -- their halves' kernels just run side by side: measured 40 against 52 k).
-  static const bool no_split = std::getenv("DVM_BA_NO_SPLIT") != nullptr;
-  if (K >= 64 && !no_split) {
+  // DVM_BA_SPLIT: a batch of 64 or more windows in two halves, the second on a persistent helper thread with its own staging buffers and
+  // stream; the two launches (G workgroups per window each) share the chip.  Every window's result is independent of its batch and of G, so
+  // the split changes nothing but the time.  It was the default while the host side of such a call (tables, 60+ MB through a staging copy)
+  // was as long as its kernel (128 windows: 23 -> 18 ms); with the tables sent from the builders' threads the one launch is the faster and
+  // the steadier form (128 windows: 17.0-17.2 ms against 15.5-19.5).
+  const bool split = std::getenv("DVM_BA_SPLIT") != nullptr;       // (read at every call: the tests take both paths)
+  if (K >= 64 && split) {
     if (K < 0 || !windows) { set_error("dvm_ba_optimize_windows: null windows"); return DVM_ERR_INVALID; }
     HelperThread& H = HelperThread::get();
     std::unique_lock<std::mutex> user(H.use, std::try_to_lock);

@@ -111,9 +111,12 @@ def test_fast_windows_do_not_depend_on_the_cluster_size(windows, monkeypatch):
             assert np.array_equal(_bits(a["stats"]["chi2"]), _bits(b["stats"]["chi2"])), (G, k)
 
 
-def test_fast_windows_large_batch_split_in_two_halves():
-    """64 windows and more go as two concurrent half-batches (a helper thread with its own staging buffers and stream, one cluster size for
-    both launches): window k's bits are those of the same window in a small batch."""
+@pytest.mark.parametrize("split", [False, True])
+def test_fast_windows_large_batch_in_one_launch_or_two_halves(split, monkeypatch):
+    """70 windows in one launch, or (DVM_BA_SPLIT) as two concurrent half-batches -- a helper thread with its own staging buffers and stream,
+    one cluster size for both launches: window k's bits are those of the same window in a small batch."""
+    if split:
+        monkeypatch.setenv("DVM_BA_SPLIT", "1")
     base = []
     for k in range(6):
         pr = synth.ba_problem(n_kf=10 + 2 * k, n_pts=250 + 60 * k, k_obs=4, seed=0x4A0 + k, radius=10.0)
@@ -178,3 +181,21 @@ def test_fast_windows_do_not_depend_on_the_placement(windows, monkeypatch):
         for k, (a, b) in enumerate(zip(ref, res)):
             assert np.array_equal(_bits(a["poses"]), _bits(b["poses"])) and np.array_equal(_bits(a["points"]), _bits(b["points"])), (rep, k)
             assert np.array_equal(_bits(a["edge_chi2"]), _bits(b["edge_chi2"])) and list(a["stats"]["trials"]) == list(b["stats"]["trials"]), (rep, k)
+
+
+def test_fast_windows_with_tables_in_blocks_of_their_own(oracle, windows, monkeypatch):
+    """The windows' tables travel in one page-locked block sized from the edge counts before they are built (csrc/ba_window.hip:
+    shared_tables); a window that finds it full -- its (edge, edge) pair list far beyond the estimate -- packs into a block of its own,
+    sent on its own.  DVM_BA_TEST_PRIVATE_TABLES makes every second window of a call take that path: the same bits as without it."""
+    pr = synth.ba_problem(n_kf=32, n_pts=260, k_obs=32, seed=0x3D1, radius=12.0)
+    dense = _window(pr, 6, n_fixed=2)          # every landmark seen by all 30 free cameras: 465 pairs a landmark
+    assert len(dense["edges"]) == 32 * 260
+    batch = [windows[0], dense, windows[5], windows[1]]
+    ref = capi.ba_optimize_windows(batch, fast=True)
+    _check_vs_oracle(oracle, dense, ref[1], "dense window")
+    monkeypatch.setenv("DVM_BA_TEST_PRIVATE_TABLES", "1")
+    res = capi.ba_optimize_windows(batch, fast=True)
+    for a, b in zip(ref, res):
+        for key in ("poses", "points", "edge_chi2"):
+            assert np.array_equal(_bits(a[key]), _bits(b[key])), key
+        assert np.array_equal(a["depth_positive"], b["depth_positive"])
