@@ -439,7 +439,7 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
         by = {}
         for K in (8, kmax):
             batches = [capi.BaWindowBatch([wins[a]]) for a in range(K)]
-            sizes, calls = [], 4
+            sizes, calls = [], 12
             def agent(a):
                 for _ in range(calls):
                     sizes.append(pool.optimize(batches[a])[1])
