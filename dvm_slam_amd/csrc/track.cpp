@@ -24,6 +24,7 @@
 #include "ba_kernels.h"
 #include "match_kernels.h"
 #include "orb_pipeline.h"
+#include "host_stage.h"   // HostPool
 #include "track_kernels.h"
 
 using namespace dvm;
@@ -190,15 +191,15 @@ int dvm_track_finish_batch(dvm_tracker* t, dvm_orb* h, int count, const dvm_trac
     m.qmin = carve<int32_t>(p, Qn); m.qmax = carve<int32_t>(p, Qn); m.q_claims = carve<uint8_t>(p, Qn); m.q_angle = carve<float>(p, Qn);
     m.q_pos = carve<float>(p, Qn * 3); m.pose_in = carve<double>(p, (size_t)count * 7); m.nq_arr = carve<int32_t>(p, count); m.inv_sigma2 = carve<float>(p, 64);
   }
-  for (int b = 0; b < count; b++) {
+  HostPool::get().run((size_t)count, count >= 4 ? 8 : 1, [&](size_t b) {       // (a batch's query blocks: 2.4 MB for 32 frames)
     const dvm_track_queries& q = qs[b];
-    const size_t o = (size_t)b * Qs, nq = (size_t)q.nq;
+    const size_t o = b * Qs, nq = (size_t)q.nq;
     std::memcpy(m.qdesc + o * 32, q.qdesc, nq * 32); std::memcpy(m.qx + o, q.qx, nq * 4); std::memcpy(m.qy + o, q.qy, nq * 4);
     std::memcpy(m.qr + o, q.qr, nq * 4); std::memcpy(m.qmin + o, q.qmin, nq * 4); std::memcpy(m.qmax + o, q.qmax, nq * 4);
     std::memcpy(m.q_claims + o, q.q_claims, nq); std::memcpy(m.q_angle + o, q.q_angle, nq * 4); std::memcpy(m.q_pos + o * 3, q.q_pos, nq * 12);
-    std::memcpy(m.pose_in + 7 * (size_t)b, q.pose_in, 56);
+    std::memcpy(m.pose_in + 7 * b, q.pose_in, 56);
     m.nq_arr[b] = q.nq;
-  }
+  });
   std::memcpy(m.inv_sigma2, q0.inv_level_sigma2, (size_t)q0.nlevels * 4);
   {
     const size_t used = (size_t)(reinterpret_cast<uint8_t*>(m.inv_sigma2) - t->hm) + pad256(64 * 4);

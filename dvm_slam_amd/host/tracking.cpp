@@ -1,5 +1,13 @@
 // dvm_slam_amd/host/tracking.cpp -- dvmh_track_with_motion_model (include/dvmslam_host.h): the host side of the one-chain tracking
 // step.  Reference: Frame::Frame -> ExtractORB (src/Frame.cc:371-411), Tracking::TrackWithMotionModel (src/Tracking.cc:2584-2667).
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -179,6 +187,59 @@ struct AgentQueries {
 
 #include <thread>
 
+namespace {
+// A few persistent host threads for the per-tick work of the batched chain (the agents' query lists are independent): run(n, width, fn) calls
+// fn(i) for i in [0, n) on the caller and up to width - 1 workers and returns when all are done.  One job at a time; never destroyed (its
+// sleeping workers end with the process -- a destructor that joined them would run in forked children, where they do not exist).
+class TickPool {
+ public:
+  static TickPool& get() { static TickPool* p = new TickPool; return *p; }
+  template <class F> void run(int n, int width, F&& fn) {
+    if (n <= 0) return;
+    if (width <= 1 || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::lock_guard<std::mutex> job(job_mtx_);
+    std::function<void(int)> f = fn;
+    {
+      std::lock_guard<std::mutex> l(mtx_);
+      const int want = std::min(std::min(width - 1, n - 1), 31);
+      while ((int)workers_.size() < want) spawn();
+      fn_ = &f; n_ = n; next_.store(0); active_ = want; pending_ = want; gen_++;
+    }
+    cv_.notify_all();
+    for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; f(i); }
+    std::unique_lock<std::mutex> l(mtx_);
+    done_.wait(l, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  std::mutex job_mtx_, mtx_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0, active_ = 0, pending_ = 0;
+  std::atomic<int> next_{0};
+  unsigned long gen_ = 0;
+  void spawn() {
+    const int id = (int)workers_.size();
+    workers_.emplace_back([this, id] {
+      unsigned long seen = 0;
+      for (;;) {
+        std::unique_lock<std::mutex> l(mtx_);
+        cv_.wait(l, [&] { return gen_ != seen && id < active_; });
+        seen = gen_;
+        const std::function<void(int)>* f = fn_;
+        const int n = n_;
+        l.unlock();
+        for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; (*f)(i); }
+        l.lock();
+        if (--pending_ == 0) done_.notify_one();
+      }
+    });
+    workers_.back().detach();
+  }
+};
+}  // namespace
+
 extern "C" int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, int device, int count, const uint8_t* imgs, int rows, int cols, int stride,
                                                   int64_t frame_stride, int lap0, int lap1, const float* K, const float* bounds, const float* scale_factors,
                                                   const float* inv_level_sigma2, int nlevels, float th, int check_ori, const dvmh_track_in* in,
@@ -189,18 +250,20 @@ extern "C" int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, in
     std::memset(&res[b], 0, sizeof(res[b]));
   }
   (void)device;
+  static const bool timing = std::getenv("DVM_TRACK_BATCH_TIMING") != nullptr;       // host-side phase times of a tick on stderr
+  using clk = std::chrono::steady_clock;
+  clk::time_point tp0 = clk::now(), tp1, tp2, tp3, tp4;
   int rc = imgs ? dvm_track_begin_batch(t, h, imgs, count, rows, cols, stride, frame_stride, lap0, lap1) : dvm_track_begin_staged(t, h, count, rows, cols, lap0, lap1);
   if (rc != DVM_OK) return rc;
+  tp1 = clk::now();
   std::vector<AgentQueries> AQ((size_t)count);
+  // (persistent workers: spawning eight threads per tick and giving each four agents' queries took 0.45 ms of a 1.6 ms tick of 32 frames --
+  //  longer than the extraction it was meant to run under)
   auto build_all = [&](float scale, const std::vector<uint8_t>* only) {
-    const int T = std::min(count, 8);
-    std::vector<std::thread> pool;
-    auto work = [&](int t0) { for (int b = t0; b < count; b += T) if (!only || (*only)[b]) AQ[b].build(in[b], K, bounds, scale_factors, nlevels, scale * th); };
-    for (int k = 1; k < T; k++) pool.emplace_back(work, k);
-    work(0);
-    for (auto& x : pool) x.join();
+    TickPool::get().run(count, 24, [&](int b) { if (!only || (*only)[b]) AQ[b].build(in[b], K, bounds, scale_factors, nlevels, scale * th); });
   };
   build_all(1.0f, nullptr);
+  tp2 = clk::now();
   std::vector<dvm_track_queries> tq((size_t)count);
   std::vector<dvm_track_frame_out> fo((size_t)count);
   std::vector<dvm_track_result> tr((size_t)count);
@@ -217,8 +280,10 @@ extern "C" int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, in
   std::vector<uint8_t> wide((size_t)count, 0);
   for (int attempt = 0; attempt < 2; attempt++) {
     for (int b = 0; b < count; b++) AQ[b].fill(tq[b], in[b], K, bounds, inv_level_sigma2, nlevels, check_ori);
+    if (attempt == 0) tp3 = clk::now();
     rc = dvm_track_finish_batch(t, h, count, tq.data(), fo.data(), tr.data());
     if (rc != DVM_OK) return rc;
+    if (attempt == 0) tp4 = clk::now();
     bool any = false;
     if (attempt == 0)
       for (int b = 0; b < count; b++) if (tr[b].status == DVM_TRACK_FEW_MATCHES) { wide[b] = 1; any = true; }
@@ -249,6 +314,11 @@ extern "C" int dvmh_track_with_motion_model_batch(dvm_tracker* t, dvm_orb* h, in
     std::memcpy(out->pose, r.pose, 56);
     for (int k = 0; k < 3; k++) out->Tcw.t[k] = (float)out->pose[k];
     for (int k = 0; k < 4; k++) out->Tcw.q[k] = (float)out->pose[3 + k];
+  }
+  if (timing) {
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "track batch of %d: begin (images in + enqueue) %.3f  queries %.3f  tables + fill %.3f  finish (wait + results out) %.3f  rest %.3f ms\n", count,
+                 ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, tp4), ms(tp4, clk::now()));
   }
   return DVM_OK;
 }
