@@ -106,6 +106,7 @@ struct BaWin {
   const int32_t *pt_edges;                // [E] a landmark's edges (sorted indices, ascending: its free-camera rows come first), ranges pt_start
   const int32_t *bp_start;                // [nblk + 1] a block's (row of camera i1, row of camera i2) pairs, landmark order
   const int2* bp_pairs;
+  const int32_t *sched_start, *sched_task;   // the Schur pass's tasks per wave of the cluster (8 G waves): task < nfree: rhs of that camera, else block task - nfree
   double *Bs, *Ws, *Ts, *Cs;              // [15][Fp] B (12) w wr0 wr1 | [18][Fp] W | [24][Fp] W Dinv (18), W Dinv bl (6) | [3][Fp] W^T x_p
   double *chi_s;                          // [E] chi2 of the last evaluation, sorted order
   // ---- the CLUSTER form (k_ba_window_cluster: G workgroups per window): what the workgroups hand each other through global memory
@@ -1322,8 +1323,14 @@ __device__ void cl_schur(const BaWin& W, const ClusterCtx& C, double* wred, doub
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t Fp = (size_t)W.Fp;
   double* wbuf = wred + wave * 4 * 36;
-  const int gw = C.g * (kWinThreads / 64) + wave, GW = C.G * (kWinThreads / 64);
-  for (int i = gw; i < W.nfree; i += GW) {
+  // Which wave forms what is the host's schedule (build_window_fast: longest task first onto the least loaded of the cluster's 8 G waves): a
+  // diagonal block has ~8 rounds of 64 pairs, an off-diagonal one 1-2, and dealt round-robin the waves' loads differed by a factor of two.
+  // Every right-hand side and every block is still formed completely by ONE wave, in its own pair order: the same bits whatever the schedule.
+  const int gw = C.g * (kWinThreads / 64) + wave;
+  for (int idx = W.sched_start[gw]; idx < W.sched_start[gw + 1]; idx++) {
+    const int task = W.sched_task[idx];
+    if (task >= W.nfree) continue;
+    const int i = task;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const int q1 = W.cam_start[i + 1];
     for (int q = W.cam_start[i] + lane; q < q1; q += 64) {
@@ -1333,7 +1340,9 @@ __device__ void cl_schur(const BaWin& W, const ClusterCtx& C, double* wred, doub
     const double tot = w_wave_reduce<6>(acc, wbuf);
     if (lane < 6) W.rhsg[6 * i + lane] = W.bp[6 * (size_t)i + lane] - tot;
   }
-  for (int bk = gw; bk < W.nblk; bk += GW) {
+  for (int idx = W.sched_start[gw]; idx < W.sched_start[gw + 1]; idx++) {
+    const int bk = W.sched_task[idx] - W.nfree;
+    if (bk < 0) continue;
     double acc[36];
 #pragma unroll
     for (int t = 0; t < 36; t++) acc[t] = 0.0;
@@ -1641,8 +1650,10 @@ struct WinBuild {
   std::vector<double> t_eo, t_ei;
   // the fast form's tables packed into page-locked memory by the builder's own thread, while they are in its caches (pack_fast); the block
   // is one input of the call's staging, sent from where it lies
+  int cluster_waves = 8;              // 8 G: set by the call before the build (the Schur pass's schedule is per wave of the cluster)
+  std::vector<int32_t> sched_start, sched_task;
   PinnedArena arena;
-  struct ArenaOff { ptrdiff_t poses, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, pt_start, f_cam, blk_ij, e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs; } ao;
+  struct ArenaOff { ptrdiff_t poses, pidx, lidx, free_pose, act_pt, e_pose, e_point, e_obs, e_info, pt_start, f_cam, blk_ij, e_orig, e_lm, cam_start, pt_edges, bp_start, bp_pairs, sched_start, sched_task; } ao;
   ptrdiff_t shared_off = -1;          // >= 0: the tables lie at this offset of the call's shared block, not in `arena`
   size_t packed_bytes = 0;
   int pack_fast(PinnedArena* shared) {
@@ -1650,7 +1661,7 @@ struct WinBuild {
     auto b4 = [&](const std::vector<int32_t>& v) { return pad(v.size() * 4); };
     auto b8 = [&](const std::vector<double>& v) { return pad(v.size() * 8); };
     const size_t total = b8(poses) + b4(pidx) + b4(lidx) + b4(free_pose) + b4(act_pt) + b4(e_pose) + b4(e_point) + b8(e_obs) + b8(e_info) + b4(pt_start) + b4(f_cam) +
-                         b4(blk_ij) + b4(e_orig) + b4(e_lm) + b4(cam_start) + b4(pt_edges) + b4(bp_start) + b4(bp_pairs);
+                         b4(blk_ij) + b4(e_orig) + b4(e_lm) + b4(cam_start) + b4(pt_edges) + b4(bp_start) + b4(bp_pairs) + b4(sched_start) + b4(sched_task);
     shared_off = shared ? shared->claim(total) : -1;
     if (shared_off < 0) { const int rc = arena.reserve(total); if (rc != DVM_OK) return rc; }
     else arena.used = 0;
@@ -1669,6 +1680,7 @@ struct WinBuild {
     ao.poses = p8(poses); ao.pidx = p4(pidx); ao.lidx = p4(lidx); ao.free_pose = p4(free_pose); ao.act_pt = p4(act_pt); ao.e_pose = p4(e_pose); ao.e_point = p4(e_point);
     ao.e_obs = p8(e_obs); ao.e_info = p8(e_info); ao.pt_start = p4(pt_start); ao.f_cam = p4(f_cam); ao.blk_ij = p4(blk_ij); ao.e_orig = p4(e_orig); ao.e_lm = p4(e_lm);
     ao.cam_start = p4(cam_start); ao.pt_edges = p4(pt_edges); ao.bp_start = p4(bp_start); ao.bp_pairs = p4(bp_pairs);
+    ao.sched_start = p4(sched_start); ao.sched_task = p4(sched_task);
     if (shared_off < 0) arena.used = used;
     packed_bytes = used;
     return DVM_OK;
@@ -1754,6 +1766,30 @@ int build_window_fast(WinBuild& b) {
   { std::vector<int32_t>& fill = b.t_fill;
     fill.assign(b.bp_start.begin(), b.bp_start.end() - 1);
     each_pair([&](int i1, int i2, int r1, int r2) { const int at = fill[blk_of[(size_t)i1 * nf + i2]]++; b.bp_pairs[2 * (size_t)at] = r1; b.bp_pairs[2 * (size_t)at + 1] = r2; }); }
+  // the Schur pass's schedule: tasks = the nf right-hand sides (a camera's rows, six sums) and the blocks (a block's pairs, 36 sums), each
+  // done by one wave; cost ~ its rounds of 64 rows / pairs times the loads of a round, plus the reduction; longest first onto the least
+  // loaded wave (ties: the lowest wave)
+  {
+    const int GW = std::max(b.cluster_waves, 1), nt = nf + b.nblk;
+    std::vector<std::pair<int32_t, int32_t>> task(nt);          // (cost, id)
+    // (weights per round 6 / 36 = the loads of a round, 25 / 100 for a task's fixed part: kernel 2.92 -> 2.78 ms for 32 windows; other
+    //  weights -- diagonal blocks' coalesced rounds at 12 ... 80, the fixed part at 50 ... 300 -- measured within +-0.05 ms of it or worse)
+    for (int i = 0; i < nf; i++) task[i] = {6 * ((b.cam_start[i + 1] - b.cam_start[i] + 63) / 64) + 25, i};
+    for (int j = 0; j < b.nblk; j++) task[nf + j] = {36 * ((b.bp_start[j + 1] - b.bp_start[j] + 63) / 64) + 100, nf + j};
+    std::stable_sort(task.begin(), task.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first > y.first; });
+    std::vector<int64_t> load(GW, 0);
+    std::vector<int32_t> owner(nt, 0), count(GW + 1, 0);
+    for (int t = 0; t < nt; t++) {
+      int w = 0;
+      for (int k = 1; k < GW; k++) if (load[k] < load[w]) w = k;
+      load[w] += task[t].first; owner[t] = w; count[w + 1]++;
+    }
+    for (int k = 0; k < GW; k++) count[k + 1] += count[k];
+    b.sched_start.assign(count.begin(), count.end());
+    b.sched_task.assign(std::max(nt, 1), 0);
+    std::vector<int32_t> fill(count.begin(), count.end() - 1);
+    for (int t = 0; t < nt; t++) b.sched_task[fill[owner[t]]++] = task[t].second;
+  }
   b.n_hc = b.n_sc = 0;
   // the waves' reduction buffers; during the solve the same area (from ctl + 64 on: 256 doubles of tree partials first) holds the panel copy
   // of win_cholesky_rhs, (n + 1) rows of kLpPitch doubles
@@ -1901,11 +1937,25 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   int rc = dvm_set_device(device);
   if (rc != DVM_OK) return rc;
   const auto t0 = std::chrono::steady_clock::now();
+  // the cluster size: the largest of 8 / 4 / 2 / 1 workgroups per window whose grid (8 * ceil(K / 8) * G workgroups, one per CU: the
+  // reduced system's LDS) is resident at once; forced by `cluster` (the G = 1 repeat after a barrier time-out) or DVM_BA_CLUSTER.  Chosen
+  // before the builds: the windows' Schur schedules are per wave of the cluster.
+  int G = 1;
+  if (fast) {
+    int cus = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const char* env_c = std::getenv("DVM_BA_CLUSTER");      // (read at every call: the tests walk the cluster sizes)
+    const int env_g = env_c ? atoi(env_c) : 0;
+    const int want = cluster > 0 ? cluster : env_g;
+    const int groups = 8 * ((K + 7) / 8);
+    for (int g = 8; g >= 1; g >>= 1) if ((want > 0 && g == want) || (want <= 0 && groups * g <= cus)) { G = g; break; }
+  }
   // (the fast form keeps its windows' host tables in a per-thread pool: see WinBuild's scratch members)
   static thread_local std::vector<WinBuild> build_pool;
   std::vector<WinBuild> local_builds;
   if (fast) { if ((int)build_pool.size() < K) build_pool.resize(K); } else local_builds.resize(K);
   std::vector<WinBuild>& B = fast ? build_pool : local_builds;
+  if (fast) for (int k = 0; k < K; k++) B[k].cluster_waves = (kWinThreads / 64) * G;
   // the fast form's tables of ALL windows go into one page-locked block (one DMA): sized before the builds from a generous estimate --
   // ~66 bytes per edge are typical --; a window that finds it full packs into a block of its own
   static thread_local PinnedArena shared_tables_tls;
@@ -2075,6 +2125,7 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
       v.blk_ij = A4(b.ao.blk_ij);
       v.e_orig = A4(b.ao.e_orig); v.e_lm = A4(b.ao.e_lm); v.cam_start = A4(b.ao.cam_start); v.pt_edges = A4(b.ao.pt_edges);
       v.bp_start = A4(b.ao.bp_start); v.bp_pairs = reinterpret_cast<const int2*>(A4(b.ao.bp_pairs));
+      v.sched_start = A4(b.ao.sched_start); v.sched_task = A4(b.ao.sched_task);
       v.Bs = st.ptr<double>(s.Bs); v.Ws = st.ptr<double>(s.Ws); v.Ts = st.ptr<double>(s.Ts); v.Cs = st.ptr<double>(s.Cs); v.chi_s = st.ptr<double>(s.chi_s);
       v.cl_ctr = st.ptr<unsigned int>(s.cl_sync); v.cl_tmo = v.cl_ctr + 8;
       v.Sblk = st.ptr<double>(s.Sblk); v.rhsg = st.ptr<double>(s.rhsg); v.cl_part = st.ptr<double>(s.cl_part); v.cl_ctl = st.ptr<double>(s.cl_ctl);
@@ -2096,19 +2147,10 @@ int dvm_ba_optimize_windows_impl(int device, const dvm_ba_window* windows, int K
   if (!fast) DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // on the staging stream of the calling thread (upload -> kernel -> download is one in-order chain there; the legacy NULL stream would
   // also order this launch against every other thread's staging stream: dvm_ba_optimize_batch's workers serialised on it)
-  int G = 1;
   struct KernelEvents { hipEvent_t a = nullptr, b = nullptr; ~KernelEvents() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } };
   thread_local KernelEvents kev;     // the launch's duration -> dvm_ba_stats::kernel_us (the fast form's roofline figure in bench_legs.lba_fast)
   if (fast) {
-    // the cluster size: the largest of 8 / 4 / 2 / 1 workgroups per window whose grid (8 * ceil(K / 8) * G workgroups, one per CU: the
-    // reduced system's LDS) is resident at once; forced by `cluster` (the G = 1 repeat after a barrier time-out) or DVM_BA_CLUSTER
-    int cus = 0;
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    const char* env_c = std::getenv("DVM_BA_CLUSTER");      // (read at every call: the tests walk the cluster sizes)
-    const int env_g = env_c ? atoi(env_c) : 0;
-    const int want = cluster > 0 ? cluster : env_g;
     const int groups = 8 * ((K + 7) / 8);
-    for (int g = 8; g >= 1; g >>= 1) if ((want > 0 && g == want) || (want <= 0 && groups * g <= cus)) { G = g; break; }
     DVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_window_cluster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!kev.a) { DVM_HIP(hipEventCreate(&kev.a)); DVM_HIP(hipEventCreate(&kev.b)); }
     hipEventRecord(kev.a, st.stream());
