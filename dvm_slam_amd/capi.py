@@ -687,8 +687,9 @@ class BaWindowBatch:
             w.poses_out, w.points_out, w.edge_chi2_out, w.depth_positive_out = (o["poses"].ctypes.data, o["points"].ctypes.data, o["edge_chi2"].ctypes.data,
                                                                                 o["depth_positive"].ctypes.data)
 
-    def run(self, device=0, stop_flag=None, fast=False, _threads=0, _batch=False):
-        """One library call over the K windows; returns the per-window dicts (the output arrays are this object's: copy what must outlive the next run)."""
+    def run(self, device=0, stop_flag=None, fast=False, _threads=0, _batch=False, collect=True):
+        """One library call over the K windows; returns the per-window dicts (the output arrays are this object's: copy what must outlive the next run).
+        collect=False: the bare call -- results() builds the dicts (ctypes slices of the statistics: ~5 us a window) when they are wanted."""
         sf = _p(stop_flag) if stop_flag is not None else None
         if _batch:
             f = lib().dvm_ba_optimize_batch
@@ -698,7 +699,7 @@ class BaWindowBatch:
             f = lib().dvm_ba_optimize_windows_fast if fast else lib().dvm_ba_optimize_windows
             f.restype = C.c_int32; f.argtypes = None
             check(f(C.c_int32(device), self.wins, C.c_int32(self.K), sf, self.stats))
-        return self.results()
+        return self.results() if collect else None
 
     def results(self):
         for k, o in enumerate(self.outs):

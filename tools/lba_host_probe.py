@@ -15,7 +15,7 @@ for a in range(K):
 batch = capi.BaWindowBatch(wins)
 ts = []
 for i in range(25):
-    t0 = time.perf_counter(); batch.run(0, None, True); ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); batch.run(0, None, True, collect=False); ts.append(time.perf_counter() - t0)
 ts = np.array(ts[5:]) * 1e3
 its = sum(r["stats"]["iterations"] for r in batch.results())
 print("K=%d median %.2f ms  min %.2f  -> %.1f k it/s  kernel %.2f ms  [%s]" % (K, np.median(ts), ts.min(), its / np.median(ts), batch.results()[0]["stats"]["kernel_us"] / 1e3,
