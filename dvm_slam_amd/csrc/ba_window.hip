@@ -440,24 +440,13 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // Every entry sees the operations of the column-by-column form in the same order: identical bits.  The panel also goes to Lp
 // (n x 7 doubles: an odd pitch in 8-byte words keeps the sixteen rows a half-wave reads apart on different LDS banks; read out of the
 // packed triangle, whose rows start at i (i + 1) / 2, the trailing update spent most of its time in bank conflicts).
-// EXACT = false (the cluster form, whose contract is a tolerance): the pivots' reciprocal square roots (v_rsq_f64 + two Newton steps) and
-// multiplications replace the IEEE square roots and divisions -- the six-pivot chain of a camera's diagonal block is what a step waits
-// for (six dependent sqrt + div pairs, ~300 cycles each); 1 / L_kk is kept in column 6 of Lp for the substitution.
-__device__ __forceinline__ double w_rsqrt_refined(double v) {
-  double y = __builtin_amdgcn_rsq(v);
-  y = __builtin_fma(0.5 * y, __builtin_fma(-v * y, y, 1.0), y);
-  y = __builtin_fma(0.5 * y, __builtin_fma(-v * y, y, 1.0), y);
-  return y;
-}
-template <bool EXACT>
-__device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, double* __restrict__ Lp, int n, unsigned long long* prof = nullptr) {
+// (The sequential-order kernel's solve.  The cluster form, whose contract is a tolerance, has its own: win_cholesky_rhs below.)
+__device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, double* __restrict__ Lp, int n) {
   const int tid = threadIdx.x;
   constexpr int NT = kWinThreads;
   bool ok = true;
-  unsigned long long tp = (prof && tid == 0) ? __builtin_amdgcn_s_memtime() : 0ull;
-  auto lapc = [&](int slot) { if (prof && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[slot] += t - tp; tp = t; } };
   for (int k0 = 0; k0 < n && ok; k0 += 6) {
-    double Ld[21], dg[6], rdg[6];    // the diagonal block's factor (lower, packed), its L_kk and (EXACT = false) 1 / L_kk
+    double Ld[21], dg[6];    // the diagonal block's factor (lower, packed) and its L_kk
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -467,16 +456,14 @@ __device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, 
         for (int k = 0; k < c; k++) v -= Ld[a * (a + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
         if (a == c) {
           if (!(v > 0)) ok = false;              // uniform: every thread computes the same word
-          if constexpr (EXACT) { dg[a] = sqrt(v); rdg[a] = 0.0; }
-          else { rdg[a] = w_rsqrt_refined(v > 0 ? v : 1.0); dg[a] = v * rdg[a]; }
+          dg[a] = sqrt(v);
           Ld[a * (a + 1) / 2 + a] = v;
         } else {
-          if constexpr (EXACT) Ld[a * (a + 1) / 2 + c] = v / dg[c]; else Ld[a * (a + 1) / 2 + c] = v * rdg[c];
+          Ld[a * (a + 1) / 2 + c] = v / dg[c];
         }
       }
     }
     if (!ok) break;
-    lapc(12);
     // (no barrier here: the panel reads rows below the block and writes them and Lp, which the previous step's update has finished with
     //  behind its closing barrier; the block's own factor is written once everybody has read the block -- behind the panel's barrier)
     for (int i = k0 + 6 + tid; i < n; i += NT) {
@@ -487,19 +474,16 @@ __device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, 
         double v = row[c];
 #pragma unroll
         for (int k = 0; k < c; k++) v -= l[k] * Ld[c * (c + 1) / 2 + k];
-        if constexpr (EXACT) l[c] = v / dg[c]; else l[c] = v * rdg[c];
+        l[c] = v / dg[c];
       }
 #pragma unroll
       for (int c = 0; c < 6; c++) { row[c] = l[c]; Lp[7 * i + c] = l[c]; }
     }
-    lapc(13);
     __syncthreads();
-    lapc(14);
     if (tid == 0) {
 #pragma unroll
       for (int a = 0; a < 6; a++) {
         diag[k0 + a] = dg[a];
-        if constexpr (!EXACT) Lp[7 * (k0 + a) + 6] = rdg[a];
 #pragma unroll
         for (int c = 0; c < a; c++) S[tri(k0 + a, k0 + c)] = Ld[a * (a + 1) / 2 + c];
       }
@@ -516,17 +500,14 @@ __device__ bool win_cholesky(double* __restrict__ S, double* __restrict__ diag, 
         Si[j] = v;
       }
     }
-    lapc(15);
     __syncthreads();
-    lapc(14);
   }
   return ok;
 }
 // forward substitution: y(i) = (b(i) - sum_{j < i} L(i, j) y(j)) / L(i, i), the subtractions in ascending j; then backward:
 // x(i) /= L(i, i); x(j) -= L(i, j) x(i) for j < i, i descending.  ONE wave (the caller's wave 0), a camera's six unknowns per step:
 // every lane forms the six values for itself, then applies them to its rows in the order of the one-at-a-time form.
-template <bool EXACT>
-__device__ void win_substitute(const double* __restrict__ S, const double* __restrict__ diag, const double* __restrict__ Lp, double* __restrict__ rhs, int n) {
+__device__ void win_substitute(const double* __restrict__ S, const double* __restrict__ diag, double* __restrict__ rhs, int n) {
   const int lane = threadIdx.x & 63;
   for (int k0 = 0; k0 < n; k0 += 6) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -536,7 +517,7 @@ __device__ void win_substitute(const double* __restrict__ S, const double* __res
       double v = rhs[k0 + a];
 #pragma unroll
       for (int c = 0; c < a; c++) v -= S[tri(k0 + a, k0 + c)] * y[c];
-      if constexpr (EXACT) y[a] = v / diag[k0 + a]; else y[a] = v * Lp[7 * (k0 + a) + 6];
+      y[a] = v / diag[k0 + a];
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < 6) { double yv = y[0]; yv = lane == 1 ? y[1] : yv; yv = lane == 2 ? y[2] : yv; yv = lane == 3 ? y[3] : yv; yv = lane == 4 ? y[4] : yv; yv = lane == 5 ? y[5] : yv; rhs[k0 + lane] = yv; }
@@ -556,7 +537,7 @@ __device__ void win_substitute(const double* __restrict__ S, const double* __res
       double v = rhs[k0 + a];
 #pragma unroll
       for (int c = 5; c > a; c--) v -= S[tri(k0 + c, k0 + a)] * x6[c];
-      if constexpr (EXACT) x6[a] = v / diag[k0 + a]; else x6[a] = v * Lp[7 * (k0 + a) + 6];
+      x6[a] = v / diag[k0 + a];
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < 6) { double xv = x6[0]; xv = lane == 1 ? x6[1] : xv; xv = lane == 2 ? x6[2] : xv; xv = lane == 3 ? x6[3] : xv; xv = lane == 4 ? x6[4] : xv; xv = lane == 5 ? x6[5] : xv; rhs[k0 + lane] = xv; }
@@ -994,10 +975,10 @@ __global__ void __launch_bounds__(kWinThreads) k_ba_window(const BaWin* __restri
       win_schur(W, S, rhs, stage, lambda);
       lap(4);
       // ---- Cholesky + substitution of the reduced system (win_cholesky / win_substitute: the column-by-column operation order)
-      const bool ok = win_cholesky<true>(S, diag, ctl + 64, n);       // (Lp: the streaming area is idle during the solve)
+      const bool ok = win_cholesky(S, diag, ctl + 64, n);       // (Lp: the streaming area is idle during the solve)
       lap(5);
       if (ok) {
-        if (wave == 0) win_substitute<true>(S, diag, ctl + 64, rhs, n);
+        if (wave == 0) win_substitute(S, diag, rhs, n);
         __syncthreads();
         lap(6);
         for (int i = tid; i < n; i += NT) W.x[i] = rhs[i];

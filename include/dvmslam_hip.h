@@ -512,7 +512,7 @@ int dvm_ba_optimize_windows(int device, const dvm_ba_window* windows, int K, con
  * g2o's sequential one, and a CLUSTER of G workgroups per window (G = the largest of 8 / 4 / 2 / 1 for which the launch's
  * 8 * ceil(K / 8) * G workgroups are resident at once; DVM_BA_CLUSTER forces it): the data-parallel phases are split over the cluster and
  * separated by agent-scope barriers, workgroup 0 solves the reduced system in its LDS.  One window: 2.5 ms (tile solver 1.1 ms, the
- * sequential-order kernel 15 ms); 32 windows: 2.8 ms of kernel, 4.2-4.5 ms per call from host arrays = 70-76 k LM iterations/s; 128 windows: 15-17 ms =
+ * sequential-order kernel 15 ms); 32 windows: 2.8 ms of kernel, 4.2-4.8 ms per call from host arrays = 67-76 k LM iterations/s; 128 windows: 15-17 ms =
  * 75-84 k.  Deterministic and
  * independent of G and of the other windows of the call; equal to the CPU recipe to the general solver's contract -- same LM trial
  * sequence, poses / landmarks within 1e-6 on well-posed windows -- not bit for bit.  Up to 30 free cameras per window (DVM_ERR_CAPACITY
